@@ -1,0 +1,238 @@
+"""Generate golden vectors by running the REFERENCE code (imported from /root/reference with
+import-time stubs, see _ref_import.py) on seeded synthetic inputs.
+
+Run in the build container only:   python tests/golden/make_golden.py
+Outputs small ``.npz`` fixtures next to this file.  Inputs and weights are NOT stored: they are
+regenerated from ``unseenobjectswithmeanshift_amd.synthetic`` by name/seed, so a fixture holds
+only the reference's outputs (plus tiny explicit inputs for the smallest cases).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import _ref_import as R  # noqa: E402
+from unseenobjectswithmeanshift_amd import synthetic as syn  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def packbits(b):
+    return np.packbits(b.detach().cpu().numpy().astype(np.uint8).reshape(-1))
+
+
+def sample_idx(numel, k=8192, seed=7):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, numel, (k,), generator=g)
+
+
+# ------------------------------------------------------------------------------------------
+def g_position_encoding():
+    PE = R.ref("modeling.transformer_decoder.position_encoding")
+    out = {}
+    for n, (h, w) in [(128, (15, 20)), (32, (30, 40)), (32, (3, 2)), (128, (4, 6))]:
+        pe = PE.PositionEmbeddingSine(n, normalize=True)
+        out[f"pe_{n}_{h}x{w}"] = pe(torch.zeros(2, 1, h, w))
+    save("position_encoding", **out)
+
+
+def g_hypersphere_attention():
+    AU = R.ref("modeling.transformer_decoder.attention_util")
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(16, 10, 32, generator=g)
+    k = torch.randn(16, 37, 32, generator=g)
+    v = torch.randn(16, 37, 32, generator=g)
+    m = torch.rand(16, 10, 37, generator=g) < 0.4
+    m[:, :, 0] = False                    # keep every row attendable
+    addm = torch.zeros(16, 10, 37)
+    addm[m] = float("-inf")
+    o, a = AU.hypersphere_attention(q, k, v, addm)
+    o2, a2 = AU.hypersphere_attention(q, k, v, None)
+    # module-level: cross attention with packed weights and a bool mask
+    E, H, L, S, N = 256, 8, 10, 37, 2
+    shapes = {"in_proj_weight": (3 * E, E), "in_proj_bias": (3 * E,),
+              "out_proj.weight": (E, E), "out_proj.bias": (E,)}
+    sd = syn.synth_state_dict(shapes, salt=5)
+    attn = AU.MeanShiftAttention(E, H).eval()
+    attn.load_state_dict(sd, strict=True)
+    query = torch.randn(L, N, E, generator=g)
+    key = torch.randn(S, N, E, generator=g)
+    value = torch.randn(S, N, E, generator=g)
+    bm = torch.rand(N * H, L, S, generator=g) < 0.5
+    bm[:, :, 3] = False
+    with torch.no_grad():
+        y = attn(query, key, value, attn_mask=bm)[0]
+        y_nomask = attn(query, key, value)[0]
+    save("hypersphere_attention", q=q, k=k, v=v, mask=m, out=o, attn=a, out_nomask=o2,
+         attn_nomask=a2, query=query, key=key, value=value, bool_mask=bm, mha_out=y,
+         mha_out_nomask=y_nomask)
+
+
+def build_ref_decoder(dec_layers=9, dim_ff=2048, num_queries=100, salt=0):
+    DEC = R.ref("modeling.transformer_decoder.meanshiftformer_transformer_decoder")
+    dec = DEC.MeanShiftTransformerDecoder(
+        in_channels=64, mask_classification=True, num_classes=2, hidden_dim=256,
+        num_queries=num_queries, nheads=8, dim_feedforward=dim_ff, dec_layers=dec_layers,
+        pre_norm=False, mask_dim=256, enforce_input_project=False,
+        use_meanshift_cross_attention=True, disable_attention_mask=False,
+        use_meanshift_self_attention=True, decoder_block_norm=True).eval()
+    shapes = syn.decoder_param_shapes(dec_layers=dec_layers, dim_feedforward=dim_ff,
+                                      num_queries=num_queries)
+    ref_shapes = {k: tuple(v.shape) for k, v in dec.state_dict().items()}
+    assert ref_shapes == {k: tuple(v) for k, v in shapes.items()}, "decoder state-dict layout drifted"
+    assert list(ref_shapes) == list(shapes)
+    dec.load_state_dict(syn.synth_state_dict(shapes, salt=salt), strict=True)
+    return dec
+
+
+def g_decoder():
+    # small: 64x96 image, B=2 -- everything stored
+    dec = build_ref_decoder()
+    x, mf = syn.synth_decoder_inputs(2, 64, 96, seed=1)
+    with torch.no_grad():
+        out = dec(x, mf)
+    arrs = {"pred_logits": out["pred_logits"], "pred_masks": out["pred_masks"]}
+    for i, a in enumerate(out["aux_outputs"]):
+        arrs[f"aux{i}_logits"] = a["pred_logits"]
+        arrs[f"aux{i}_masks"] = a["pred_masks"].half()
+    save("decoder_small", **arrs)
+
+    # full 480x640 shapes, B=1 -- logits + sampled mask values + packed sign bits
+    x, mf = syn.synth_decoder_inputs(1, 480, 640, seed=2)
+    with torch.no_grad():
+        out = dec(x, mf)
+    pm = out["pred_masks"]
+    idx = sample_idx(pm.numel())
+    arrs = {"pred_logits": out["pred_logits"], "mask_sample_idx": idx,
+            "mask_sample_val": pm.flatten()[idx], "mask_sign_bits": packbits(pm > 0),
+            "mask_absmax": pm.abs().max()}
+    for i, a in enumerate(out["aux_outputs"]):
+        arrs[f"aux{i}_logits"] = a["pred_logits"]
+        arrs[f"aux{i}_sign_bits"] = packbits(a["pred_masks"] > 0)
+        arrs[f"aux{i}_sample_val"] = a["pred_masks"].flatten()[idx]
+    save("decoder_480x640", **arrs)
+
+
+def g_msda():
+    F_ = R.ref("modeling.pixel_decoder.ops.functions.ms_deform_attn_func")
+    # (1) the reference's own known-answer harness (OPS/test.py:24-63): seed 3, value = rand*0.01
+    N, M, D = 1, 2, 2
+    Lq, L, P = 2, 2, 2
+    shapes = torch.as_tensor([(6, 4), (3, 2)], dtype=torch.long)
+    S = int((shapes[:, 0] * shapes[:, 1]).sum())
+    torch.manual_seed(3)
+    arrs = {}
+    for tag in ("double", "float"):
+        value = torch.rand(N, S, M, D) * 0.01
+        loc = torch.rand(N, Lq, M, L, P, 2)
+        aw = torch.rand(N, Lq, M, L, P) + 1e-5
+        aw /= aw.sum(-1, keepdim=True).sum(-2, keepdim=True)
+        if tag == "double":
+            o = F_.ms_deform_attn_core_pytorch(value.double(), shapes, loc.double(), aw.double())
+        else:
+            o = F_.ms_deform_attn_core_pytorch(value, shapes, loc, aw)
+        arrs.update({f"t_{tag}_value": value, f"t_{tag}_loc": loc, f"t_{tag}_aw": aw, f"t_{tag}_out": o})
+    # (2) realistic layout: 8 heads x 8 dims, 3 levels x 4 points, locations spilling over borders
+    g = torch.Generator().manual_seed(21)
+    shp = [(15, 20), (8, 10), (4, 5)]
+    S = sum(h * w for h, w in shp)
+    N, M, D, L, P = 2, 8, 8, 3, 4
+    value = torch.randn(N, S, M, D, generator=g)
+    loc = torch.rand(N, S, M, L, P, 2, generator=g) * 1.3 - 0.15
+    aw = torch.softmax(torch.randn(N, S, M, L * P, generator=g), -1).view(N, S, M, L, P)
+    o = F_.ms_deform_attn_core_pytorch(value, torch.as_tensor(shp), loc, aw)
+    arrs.update({"r_shapes": np.array(shp), "r_value": value, "r_loc": loc, "r_aw": aw, "r_out": o})
+    save("msda_core", **arrs)
+
+
+def build_ref_pixel_decoder(salt=0):
+    MSD = R.ref("modeling.pixel_decoder.msdeformattn")
+    SS = R._ShapeSpec
+    shape = {"res2": SS(channels=256, stride=4), "res3": SS(channels=512, stride=8),
+             "res4": SS(channels=1024, stride=16), "res5": SS(channels=2048, stride=32)}
+    pd = MSD.MSDeformAttnPixelDecoder(
+        shape, transformer_dropout=0.0, transformer_nheads=8, transformer_dim_feedforward=1024,
+        transformer_enc_layers=6, conv_dim=64, mask_dim=256, norm="GN",
+        transformer_in_features=["res3", "res4", "res5"], common_stride=4).eval()
+    shapes = syn.pixel_decoder_param_shapes()
+    ref_shapes = {k: tuple(v.shape) for k, v in pd.state_dict().items()}
+    assert ref_shapes == {k: tuple(v) for k, v in shapes.items()}, \
+        (set(ref_shapes) ^ set(shapes), [k for k in shapes if k in ref_shapes and ref_shapes[k] != tuple(shapes[k])])
+    pd.load_state_dict(syn.synth_state_dict(shapes, salt=salt), strict=True)
+    return pd
+
+
+def g_pixel_decoder():
+    pd = build_ref_pixel_decoder()
+    feats = syn.synth_backbone_features(2, 64, 96, seed=3)
+    with torch.no_grad():
+        mf, enc0, ms = pd.forward_features(feats)
+    save("pixel_decoder_small", mask_features=mf, ms0=ms[0], ms1=ms[1], ms2=ms[2])
+    feats = syn.synth_backbone_features(1, 480, 640, seed=4)
+    with torch.no_grad():
+        mf, enc0, ms = pd.forward_features(feats)
+    idx = sample_idx(mf.numel(), k=16384)
+    save("pixel_decoder_480x640", mf_sample_idx=idx, mf_sample_val=mf.flatten()[idx],
+         mf_mean=mf.mean(), mf_std=mf.std(), ms0=ms[0], ms1=ms[1].half(),
+         ms2_sample_val=ms[2].flatten()[idx % ms[2].numel()])
+
+
+def g_mean_shift():
+    MS = R.ref("modeling.transformer_decoder.mean_shift")
+    arrs = {}
+    # pieces on a small problem
+    X, _ = syn.synth_unit_embeddings(2000, 64, clusters=6, sigma=0.15, seed=1)
+    np.random.seed(3)
+    first = np.random.randint(0, X.shape[0])
+    np.random.seed(3)
+    seeds, sel = MS.select_smart_seeds(X, 20, return_selected_indices=True)
+    W = MS.ball_kernel(seeds, X, 20)
+    Z = MS.seed_hill_climbing_ball(X, seeds, 20, max_iters=10)
+    cc = MS.connected_components(Z, 0.04)
+    # connected_components on a hand-made chain that exercises the label-mode branch
+    chain = torch.nn.functional.normalize(
+        torch.tensor([[1, 0, 0], [1, 0.5, 0], [1, 0.25, 0], [0, 0, 1], [1, 0.75, 0], [0, 0.1, 1]],
+                     dtype=torch.float32), dim=1)
+    cc_chain = MS.connected_components(chain, 0.04)
+    arrs.update(s_first=first, s_sel=sel, s_seeds=seeds, s_kernel_sum=W.sum(1), s_kernel_row0=W[0, :256],
+                s_Z=Z, s_cc=cc, chain=chain, cc_chain=cc_chain)
+    # end to end (MS:192-229 with epsilon = 2*0.02) on planted clusters, two sizes
+    for tag, n, k, S in (("a", 4800, 8, 50), ("b", 19200, 12, 100)):
+        X, ids = syn.synth_unit_embeddings(n, 64, clusters=k, sigma=0.15, seed=10 + k)
+        np.random.seed(3)
+        first = np.random.randint(0, n)
+        np.random.seed(3)
+        labels, sel = MS.mean_shift_smart_init(X, kappa=20, num_seeds=S, max_iters=10)
+        arrs.update({f"{tag}_first": first, f"{tag}_labels": labels.to(torch.int16), f"{tag}_sel": sel})
+    # noisy variant: 2% background points (every seed tends to stay a singleton)
+    X, ids = syn.synth_unit_embeddings(4800, 64, clusters=8, sigma=0.15, seed=33, background_frac=0.02)
+    np.random.seed(3)
+    first = np.random.randint(0, 4800)
+    np.random.seed(3)
+    labels, sel = MS.mean_shift_smart_init(X, kappa=20, num_seeds=50, max_iters=10)
+    arrs.update(n_first=first, n_labels=labels.to(torch.int16), n_sel=sel)
+    save("mean_shift", **arrs)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["pe", "attn", "decoder", "msda", "pixel", "ms"]
+    fns = {"pe": g_position_encoding, "attn": g_hypersphere_attention, "decoder": g_decoder,
+           "msda": g_msda, "pixel": g_pixel_decoder, "ms": g_mean_shift}
+    for w in which:
+        fns[w]()

@@ -1,0 +1,202 @@
+"""Seeded synthetic weights and inputs (no datasets / checkpoints exist offline).
+
+Weights are a pure function of (parameter name, shape, salt): the golden generator loads them
+into the *reference* modules, tests load the same tensors into the oracle and the HIP-backed
+modules, and ``bench.py`` uses them as the random-init model.  Nothing here touches the
+reference tree.  Scales follow the reference initialisers only loosely (xavier-like for
+matrices, unit-ish LayerNorm) -- the point is non-degenerate activations, not training.
+"""
+import math
+import zlib
+
+import numpy as np
+import torch
+
+
+def _gen(name: str, salt: int) -> torch.Generator:
+    g = torch.Generator(device="cpu")
+    g.manual_seed((zlib.crc32(name.encode()) ^ (salt * 0x9E3779B1)) & 0x7FFFFFFF)
+    return g
+
+
+def synth_param(name: str, shape, salt: int = 0) -> torch.Tensor:
+    """Deterministic fp32 tensor for state-dict entry ``name``."""
+    shape = tuple(int(s) for s in shape)
+    g = _gen(name, salt)
+    leaf = name.rsplit(".", 1)[-1]
+    if "norm" in name and leaf == "weight" or (name.endswith(".1.weight") and len(shape) == 1):
+        # LayerNorm / GroupNorm gains
+        return 1.0 + 0.1 * torch.randn(shape, generator=g)
+    if leaf in ("bias", "in_proj_bias") or len(shape) == 1:
+        if "sampling_offsets" in name:
+            # keep the reference's ring-shaped offset prior (ms_deform_attn.py:63-70) in spirit:
+            # offsets of a few pixels so samples leave the centre cell and cross borders
+            return 2.0 * torch.randn(shape, generator=g)
+        return 0.05 * torch.randn(shape, generator=g)
+    if "level_embed" in name or "query_" in name:
+        return torch.randn(shape, generator=g)
+    fan_out = shape[0]
+    fan_in = int(np.prod(shape[1:]))
+    std = math.sqrt(2.0 / (fan_in + fan_out))
+    if "sampling_offsets" in name:
+        std *= 4.0
+    return std * torch.randn(shape, generator=g)
+
+
+def synth_state_dict(shapes: dict, salt: int = 0) -> dict:
+    """``shapes``: name -> shape.  Returns name -> tensor, in the same order."""
+    return {k: synth_param(k, s, salt) for k, s in shapes.items()}
+
+
+# ----------------------------------------------------------------------------------------------
+# shapes of the two hot-path modules in the reference state-dict layout
+# ----------------------------------------------------------------------------------------------
+def decoder_param_shapes(in_channels=64, hidden_dim=256, num_queries=100, nheads=8,
+                         dim_feedforward=2048, dec_layers=9, mask_dim=256, num_classes=2,
+                         enforce_input_project=False, num_feature_levels=3):
+    """Keys/shapes of MeanShiftTransformerDecoder.state_dict()
+    (meanshiftformer_transformer_decoder.py:408-507)."""
+    s = {}
+    E = hidden_dim
+    for i in range(dec_layers):
+        p = f"transformer_self_attention_layers.{i}."
+        s[p + "self_attn.in_proj_weight"] = (3 * E, E)
+        s[p + "self_attn.in_proj_bias"] = (3 * E,)
+        s[p + "self_attn.out_proj.weight"] = (E, E)
+        s[p + "self_attn.out_proj.bias"] = (E,)
+        s[p + "norm.weight"] = (E,)
+        s[p + "norm.bias"] = (E,)
+    for i in range(dec_layers):
+        p = f"transformer_cross_attention_layers.{i}."
+        s[p + "meanshift_attn.in_proj_weight"] = (3 * E, E)
+        s[p + "meanshift_attn.in_proj_bias"] = (3 * E,)
+        s[p + "meanshift_attn.out_proj.weight"] = (E, E)
+        s[p + "meanshift_attn.out_proj.bias"] = (E,)
+        s[p + "norm.weight"] = (E,)
+        s[p + "norm.bias"] = (E,)
+    for i in range(dec_layers):
+        p = f"transformer_ffn_layers.{i}."
+        s[p + "linear1.weight"] = (dim_feedforward, E)
+        s[p + "linear1.bias"] = (dim_feedforward,)
+        s[p + "linear2.weight"] = (E, dim_feedforward)
+        s[p + "linear2.bias"] = (E,)
+        s[p + "norm.weight"] = (E,)
+        s[p + "norm.bias"] = (E,)
+    s["decoder_norm.weight"] = (E,)
+    s["decoder_norm.bias"] = (E,)
+    s["query_feat.weight"] = (num_queries, E)
+    s["query_embed.weight"] = (num_queries, E)
+    s["level_embed.weight"] = (num_feature_levels, E)
+    if in_channels != hidden_dim or enforce_input_project:
+        for i in range(num_feature_levels):
+            s[f"input_proj.{i}.weight"] = (E, in_channels, 1, 1)
+            s[f"input_proj.{i}.bias"] = (E,)
+    s["class_embed.weight"] = (num_classes + 1, E)
+    s["class_embed.bias"] = (num_classes + 1,)
+    dims = [E, E, E, mask_dim]
+    for j in range(3):
+        s[f"mask_embed.layers.{j}.weight"] = (dims[j + 1], dims[j])
+        s[f"mask_embed.layers.{j}.bias"] = (dims[j + 1],)
+    return s
+
+
+def pixel_decoder_param_shapes(in_channels=(256, 512, 1024, 2048), conv_dim=64, mask_dim=256,
+                               enc_layers=6, nheads=8, n_levels=3, n_points=4, d_ffn=1024):
+    """Keys/shapes of MSDeformAttnPixelDecoder.state_dict() with res2..res5 inputs, transformer
+    on res3..res5 and one extra FPN level (msdeformattn.py:197-290)."""
+    s = {}
+    C = conv_dim
+    # input_proj is ordered low-res -> high-res (res5, res4, res3) (msdeformattn.py:209-216)
+    for i, cin in enumerate(list(in_channels[1:])[::-1]):
+        s[f"input_proj.{i}.0.weight"] = (C, cin, 1, 1)
+        s[f"input_proj.{i}.0.bias"] = (C,)
+        s[f"input_proj.{i}.1.weight"] = (C,)
+        s[f"input_proj.{i}.1.bias"] = (C,)
+    s["transformer.level_embed"] = (n_levels, C)
+    for l in range(enc_layers):
+        p = f"transformer.encoder.layers.{l}."
+        s[p + "self_attn.sampling_offsets.weight"] = (nheads * n_levels * n_points * 2, C)
+        s[p + "self_attn.sampling_offsets.bias"] = (nheads * n_levels * n_points * 2,)
+        s[p + "self_attn.attention_weights.weight"] = (nheads * n_levels * n_points, C)
+        s[p + "self_attn.attention_weights.bias"] = (nheads * n_levels * n_points,)
+        s[p + "self_attn.value_proj.weight"] = (C, C)
+        s[p + "self_attn.value_proj.bias"] = (C,)
+        s[p + "self_attn.output_proj.weight"] = (C, C)
+        s[p + "self_attn.output_proj.bias"] = (C,)
+        s[p + "norm1.weight"] = (C,)
+        s[p + "norm1.bias"] = (C,)
+        s[p + "linear1.weight"] = (d_ffn, C)
+        s[p + "linear1.bias"] = (d_ffn,)
+        s[p + "linear2.weight"] = (C, d_ffn)
+        s[p + "linear2.bias"] = (C,)
+        s[p + "norm2.weight"] = (C,)
+        s[p + "norm2.bias"] = (C,)
+    s["mask_features.weight"] = (mask_dim, C, 1, 1)
+    s["mask_features.bias"] = (mask_dim,)
+    # one FPN level on res2 (norm="GN" => conv bias absent, msdeformattn.py:264-279)
+    s["adapter_1.weight"] = (C, in_channels[0], 1, 1)
+    s["adapter_1.norm.weight"] = (C,)
+    s["adapter_1.norm.bias"] = (C,)
+    s["layer_1.weight"] = (C, C, 3, 3)
+    s["layer_1.norm.weight"] = (C,)
+    s["layer_1.norm.bias"] = (C,)
+    return s
+
+
+# ----------------------------------------------------------------------------------------------
+# inputs
+# ----------------------------------------------------------------------------------------------
+def synth_backbone_features(batch, height, width, in_channels=(256, 512, 1024, 2048), seed=0,
+                            planted_objects=12):
+    """Synthetic ResNet-50 feature pyramid res2..res5 for an ``height x width`` image
+    (strides 4/8/16/32).  Post-ReLU-like (non-negative) activations with ``planted_objects``
+    spatial blobs per image so that attention masks are neither all-set nor all-clear
+    (SURVEY.md section 8(d) "structured" input)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(1000 + seed)
+    feats = {}
+    # blob layout at stride 4, shared by all levels through area pooling
+    h4, w4 = height // 4, width // 4
+    yy, xx = torch.meshgrid(torch.arange(h4, dtype=torch.float32), torch.arange(w4, dtype=torch.float32),
+                            indexing="ij")
+    obj = torch.zeros(batch, planted_objects, h4, w4)
+    for b in range(batch):
+        for k in range(planted_objects):
+            cy = torch.rand(1, generator=g).item() * h4
+            cx = torch.rand(1, generator=g).item() * w4
+            r = (0.04 + 0.08 * torch.rand(1, generator=g).item()) * min(h4, w4)
+            obj[b, k] = ((yy - cy) ** 2 + (xx - cx) ** 2 <= r * r).float()
+    for name, c, stride in zip(("res2", "res3", "res4", "res5"), in_channels, (4, 8, 16, 32)):
+        h, w = height // stride, width // stride
+        proto = torch.randn(planted_objects, c, generator=g)
+        o = torch.nn.functional.adaptive_avg_pool2d(obj, (h, w))              # (B,K,h,w)
+        x = torch.einsum("bkhw,kc->bchw", o, proto) + 0.5 * torch.randn(batch, c, h, w, generator=g)
+        feats[name] = torch.relu(x).contiguous()
+    return feats
+
+
+def synth_decoder_inputs(batch, height, width, in_channels=64, mask_dim=256, seed=0):
+    """Inputs of MeanShiftTransformerDecoder.forward: three maps at strides 32/16/8 and
+    mask_features at stride 4 (meanshiftformer_transformer_decoder.py:540)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(2000 + seed)
+    x = [torch.randn(batch, in_channels, height // s, width // s, generator=g) for s in (32, 16, 8)]
+    mf = torch.randn(batch, mask_dim, height // 4, width // 4, generator=g) * 0.5
+    return x, mf
+
+
+def synth_unit_embeddings(n, d=64, clusters=12, sigma=0.15, seed=0, background_frac=0.0):
+    """Planted vMF-like clusters on the unit sphere: normalize(mu_k + sigma*N(0,I)/sqrt(d))
+    (SURVEY.md section 8(d) mean-shift recipe).  Returns (X (n,d) fp32 unit rows, ids (n,))."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(3000 + seed)
+    mu = torch.nn.functional.normalize(torch.randn(clusters, d, generator=g), dim=1)
+    ids = torch.randint(0, clusters, (n,), generator=g)
+    X = mu[ids] + sigma * torch.randn(n, d, generator=g) / math.sqrt(d)
+    if background_frac > 0:
+        nb = int(n * background_frac)
+        idx = torch.randperm(n, generator=g)[:nb]
+        X[idx] = torch.randn(nb, d, generator=g)
+        ids[idx] = -1
+    X = torch.nn.functional.normalize(X, dim=1)
+    return X.contiguous(), ids
