@@ -1,0 +1,193 @@
+/*
+ * msm_hip.h -- C ABI of libmsm_hip.so: the MI355X (gfx950) kernels behind the MSMFormer
+ * inference hot path.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - the caller allocates every output and the workspace; the library never allocates,
+ *     never synchronises, and launches on the `stream` it is given (a hipStream_t passed as
+ *     void* so that the header needs no HIP include);
+ *   - every function returns MSM_OK (0) or a negative MSM_E_* code; msm_last_error_string()
+ *     describes the last failure on the calling thread;
+ *   - all floating-point data is fp32 (the reference op dispatches float/double only,
+ *     ops/src/cuda/ms_deform_attn_cuda.cu:69); token tensors are batch-major [B][L][E].
+ *
+ * Reference interfaces replaced (paths relative to the reference root, "OPS" =
+ * MSMFormer/meanshiftformer/modeling/pixel_decoder/ops, "DEC" = .../transformer_decoder/
+ * meanshiftformer_transformer_decoder.py, "AU" = .../transformer_decoder/attention_util.py,
+ * "MS" = lib/utils/mean_shift.py):
+ *   msm_msdeform_attn_fwd        <- MSDA.ms_deform_attn_forward, OPS/src/vision.cpp:19,
+ *                                   OPS/src/ms_deform_attn.h:25-44, OPS/src/cuda/ms_deform_attn_cuda.cu:25-85
+ *   msm_msdeform_attn_enc_fwd    <- MSDeformAttn.forward lines OPS/modules/ms_deform_attn.py:101-118 fused
+ *   msm_mask_logits_fwd          <- forward_prediction_heads einsum + attention-mask, DEC:668-680
+ *   msm_hypersphere_attn_fwd     <- hypersphere_attention, AU:64-82 (+ head split/merge AU:364-375,424)
+ *   msm_gemm_f32 / msm_layernorm_f32 / msm_groupnorm_* / msm_pos_embed_sine
+ *                                <- the torch ops around them (F.linear, Conv2d 1x1/3x3, LayerNorm,
+ *                                   GroupNorm, F.interpolate, PositionEmbeddingSine)
+ *   msm_ms_*                     <- select_smart_seeds MS:128-189, seed_hill_climbing_ball MS:79-109,
+ *                                   the assignment/relabel tail of mean_shift_smart_init MS:206-229
+ *   msm_instance_postprocess     <- F.interpolate + instance_inference,
+ *                                   MSMFormer/meanshiftformer/pretrained_meanshiftformer_model.py:337-343,461-497
+ */
+#ifndef MSM_HIP_H
+#define MSM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSM_OK 0
+#define MSM_E_INVALID (-1)   /* bad argument / unsupported shape */
+#define MSM_E_LAUNCH (-2)    /* hip launch error */
+#define MSM_E_WORKSPACE (-3) /* workspace too small */
+
+const char* msm_last_error_string(void);
+int msm_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Generic fp32 MFMA GEMM:  C[b](m,n) = act( sum_k (A[b](m,k) + A2[b](m,k)) * W[b](n,k) + bias )
+ *   A element (m,k) at A + b*a_sb + m*a_sm + k*a_sk; exactly one of a_sm/a_sk is 1
+ *   (a_sk==1: row-major activations; a_sm==1: NCHW feature map read as [K][M]).
+ *   a_mode 0: strided as above.  a_mode 2: implicit 3x3 convolution over an NHWC token map:
+ *     A is [B][conv_h*conv_w][conv_c], M = conv_h*conv_w, K = 9*conv_c, k = tap*conv_c + c,
+ *     zero padding 1 (replaces Conv2d(k=3,p=1), msdeformattn.py:268-277).
+ *   A2 (nullable) uses the strides of A with its own batch stride a2_sb (0 = broadcast).
+ *   W is [N][K] row-major (torch Linear / 1x1-conv weight), batch stride w_sb (0 = shared).
+ *   C element (m,n) at C + b*c_sb + m*c_sm + n*c_sn (any strides).
+ *   bias_mode 0 none, 1 bias[n], 2 bias[m].   act 0 none, 1 relu.
+ *   split_k > 1: K is cut in split_k equal parts, part s writes raw sums (no bias/act) to
+ *   C + s*c_ss; the consumer (msm_layernorm_f32) adds the parts.
+ * ------------------------------------------------------------------------------------------- */
+int msm_gemm_f32(const float* A, const float* A2, const float* W, const float* bias, float* C,
+                 int M, int N, int K, int batch,
+                 int64_t a_sm, int64_t a_sk, int64_t a_sb, int64_t a2_sb, int64_t w_sb,
+                 int64_t c_sm, int64_t c_sn, int64_t c_sb, int64_t c_ss,
+                 int a_mode, int conv_h, int conv_w, int conv_c,
+                 int bias_mode, int act, int split_k, void* stream);
+
+/* y = LayerNorm(x + sum_s parts[s] + bias; g1,b1);  if l2norm: y /= max(||y||,1e-12);
+ * if g2: y2 = LayerNorm(y; g2,b2).  rows x E, E in {64,128,256,512}.  x/parts/bias/y2 nullable.
+ * parts: n_parts slabs [rows][E] spaced part_stride floats.  (DEC:255-257,178-179,300-304,637-638,661) */
+int msm_layernorm_f32(const float* x, const float* parts, int n_parts, int64_t part_stride,
+                      const float* bias, const float* g1, const float* b1, int l2norm,
+                      const float* g2, const float* b2, float* y, float* y2,
+                      int rows, int E, float eps, void* stream);
+
+/* GroupNorm over token maps x [B][HW][C] (NHWC), `groups` groups of C/groups channels.
+ * stats: double [B][C][2] (sum, sum of squares), zeroed by msm_groupnorm_stats_f32 itself. */
+int msm_groupnorm_stats_f32(const float* x, double* stats, int B, int HW, int C, void* stream);
+/* y = GN(x)*gamma+beta (+ bilinear_upsample(up [B][uh*uw][C]) when up != NULL, align_corners=False,
+ * msdeformattn.py:348) (relu when relu != 0).  x/y are [B][H*W][C]. */
+int msm_groupnorm_apply_f32(const float* x, const double* stats, const float* gamma, const float* beta,
+                            const float* up, int uh, int uw, float* y,
+                            int B, int H, int W, int C, int groups, float eps, int relu, void* stream);
+
+/* PositionEmbeddingSine(normalize=True) for one H x W map (position_encoding.py:29-52).
+ * out element (c, y, x) at out + c*s_c + (y*W+x)*s_p; add_c (nullable, [2*npf]) is added per channel
+ * (level embedding, msdeformattn.py:75). */
+int msm_pos_embed_sine(float* out, int H, int W, int npf, int64_t s_c, int64_t s_p,
+                       const float* add_c, float temperature, float scale, void* stream);
+
+/* batched 2-D transpose: out[b][c][r] = in[b][r][c] */
+int msm_transpose_f32(const float* in, float* out, int B, int R, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Query x pixel-embedding mask step with fused attention-mask derivation (DEC:668-680).
+ *   mask_embed [B][Q][C], mask_feat [B][C][H*W] (NCHW, as produced by the pixel decoder).
+ *   mask_out  (nullable) [B][Q][H*W] = einsum("bqc,bchw->bqhw").
+ *   attn_out  (nullable) uint8 [B][Q][th*tw]: 1 where sigmoid(bilinear(mask -> th x tw)) < 0.5,
+ *             i.e. the 2x2-tap average is negative; requires H/th == W/tw in {2,4,8}.
+ *   row_any   (nullable with attn_out) int32 [B][Q]: set to 1 iff some key of the row is
+ *             attendable (the reference resets all-masked rows, DEC:618); zeroed by this call.
+ *   sparse != 0: rows of the mask that feed neither mask_out nor a tap are skipped.
+ * ------------------------------------------------------------------------------------------- */
+int msm_mask_logits_fwd(const float* mask_embed, const float* mask_feat, float* mask_out,
+                        uint8_t* attn_out, int32_t* row_any,
+                        int B, int Q, int C, int H, int W, int th, int tw, int sparse, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-head hypersphere (vMF) attention core (AU:64-82) on already projected q/k/v:
+ *   q [B][Lq][E], k,v [B][S][E] with per-batch strides (elements) q_sb, k_sb, v_sb and row
+ *   stride ldq/ldk/ldv; head h uses columns [h*32, h*32+32); head_dim is fixed to 32.
+ *   masked (nullable) uint8 [B][Lq][S] (1 = may not attend; shared by all heads, DEC:678);
+ *   row_any (nullable) int32 [B][Lq]: rows with 0 ignore the mask (DEC:618).
+ *   out [B][Lq][E] = per head normalize(softmax(kappa*q^.k^ + mask) v), heads concatenated.
+ *   workspace: float, at least msm_hypersphere_attn_workspace(...) elements.
+ * ------------------------------------------------------------------------------------------- */
+int64_t msm_hypersphere_attn_workspace(int B, int Lq, int S, int heads);
+int msm_hypersphere_attn_fwd(const float* q, const float* k, const float* v,
+                             const uint8_t* masked, const int32_t* row_any, float* out,
+                             int B, int Lq, int S, int heads,
+                             int64_t ldq, int64_t q_sb, int64_t ldk, int64_t k_sb,
+                             int64_t ldv, int64_t v_sb, float kappa,
+                             float* workspace, int64_t workspace_elems, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-scale deformable attention forward, reference ABI (OPS/src/ms_deform_attn.h:25-44):
+ *   value [B][S][M][D], spatial_shapes int64 [L][2] = (H,W), level_start_index int64 [L],
+ *   sampling_loc [B][Lq][M][L][P][2] (x,y in [0,1]), attn_weight [B][Lq][M][L][P],
+ *   out [B][Lq][M*D].  D must be a multiple of 4 and <= 64.
+ * ------------------------------------------------------------------------------------------- */
+int msm_msdeform_attn_fwd(const float* value, const int64_t* spatial_shapes,
+                          const int64_t* level_start_index, const float* sampling_loc,
+                          const float* attn_weight, float* out,
+                          int B, int S, int M, int D, int L, int Lq, int P, void* stream);
+
+/* Encoder self-attention form with the sampling arithmetic fused in
+ * (OPS/modules/ms_deform_attn.py:101-109 + msdeformattn.py:141-153): query i is pixel i of the
+ * concatenated levels, its reference point is that pixel's centre; `proj` [B][S][M*L*P*3] holds
+ * the raw sampling_offsets (first M*L*P*2 columns, (M,L,P,2) order) and attention logits (last
+ * M*L*P columns, (M,L*P) order) of the two linears; softmax over L*P is done here. */
+int msm_msdeform_attn_enc_fwd(const float* value, const int64_t* spatial_shapes,
+                              const int64_t* level_start_index, const float* proj, float* out,
+                              int B, int S, int M, int D, int L, int P, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Classic vMF mean shift over unit embeddings X [n][d] (d == 64), cosine metric.
+ * ------------------------------------------------------------------------------------------- */
+/* Farthest-point seeding (MS:155-187): indices[0] = first_index, then S-1 x { nearest =
+ * min(nearest, 0.5*(1 - X.s)); next = first argmax }.  seeds_out [S][d], indices_out int64 [S].
+ * workspace floats >= msm_ms_seed_workspace(n). */
+int64_t msm_ms_seed_workspace(int n);
+int msm_ms_select_seeds(const float* X, int n, int d, int num_seeds, int64_t first_index,
+                        float* seeds_out, int64_t* indices_out,
+                        float* workspace, int64_t workspace_elems, void* stream);
+/* iters x { Z = normalize( exp(kappa * Z X^T) X ) } (MS:90-107); Z [S][d] updated in place. */
+int64_t msm_ms_hill_climb_workspace(int n, int S);
+int msm_ms_hill_climb(const float* X, int n, int d, float* Z, int S, float kappa, int iters,
+                      float* workspace, int64_t workspace_elems, void* stream);
+/* closest = first argmin_s 0.5*(1 - X.Z_s); labels_out[i] = seed_labels[closest] (int64);
+ * counts int64 [num_labels] histogram of labels_out (zeroed here) (MS:206-221). */
+int msm_ms_assign(const float* X, int n, int d, const float* Z, int S, const int64_t* seed_labels,
+                  int64_t* labels_out, int64_t* counts, int num_labels, void* stream);
+/* swap label 0 with the first-argmax label of counts (MS:222-227); labels int64 [n] in place. */
+int msm_ms_relabel_largest_zero(int64_t* labels, int n, const int64_t* counts, int num_labels,
+                                void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Instance post-processing for one batch (pretrained_meanshiftformer_model.py:337-343,461-497):
+ *   mask_logits [B][Q][h*w] (low-res), query_index int32 [B][T] (selected queries, top-k done by
+ *   the caller on the Q*K class scores).  For each selected mask: bilinear upsample to H x W
+ *   (align_corners=False), pred_masks [B][T][H*W] = (m > 0), mask_score [B][T] =
+ *   sum(sigmoid(m)*[m>0]) / (sum([m>0]) + 1e-6), boxes [B][T][4] = x0,y0,x1+1,y1+1 (zeros if empty).
+ *   workspace floats >= B*T*8, zeroed here.
+ * ------------------------------------------------------------------------------------------- */
+/* Canonical top-k over the Q*K object-class scores of every image (pretrained_meanshiftformer_model.py:
+ * 466-474): scores = softmax(pred_logits [B][Q][K+1])[:, :-1] flattened to Q*K entries (index =
+ * q*K + class); the reference's topk(sorted=False) order is implementation-defined, here the T
+ * winners are returned score-descending with ascending index on ties.
+ * scores_out [B][T] float, classes_out [B][T] int64, query_index_out [B][T] int32.  Q*K <= 4096. */
+int msm_topk_class_scores(const float* pred_logits, int B, int Q, int K1, int T,
+                          float* scores_out, int64_t* classes_out, int32_t* query_index_out, void* stream);
+
+int msm_instance_postprocess(const float* mask_logits, const int32_t* query_index,
+                             float* pred_masks, float* mask_score, float* boxes,
+                             int B, int Q, int T, int h, int w, int H, int W,
+                             float* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSM_HIP_H */

@@ -1,0 +1,278 @@
+"""Kernel-level parity: every C-ABI entry point against the CPU oracle / plain torch fp32 on the
+same seeded inputs.  Needs a real MI355X (pytest -m gpu)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import msm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def ops():
+    from unseenobjectswithmeanshift_amd import ops as _ops
+    return _ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(got, ref, rtol=1e-4, atol=1e-5):
+    torch.testing.assert_close(got.cpu(), ref, rtol=rtol, atol=atol)
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(800, 256, 256), (37, 3, 256), (800, 2048, 256), (50400 // 8, 288, 64),
+                                   (100, 512, 256), (130, 70, 36)])
+def test_gemm_linear(M, N, K):
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    ref = F.linear(a, w, b)
+    close(ops().gemm(a.to(DEV), w.to(DEV), b.to(DEV)), ref)
+    close(ops().gemm(a.to(DEV), w.to(DEV), b.to(DEV), act="relu"), F.relu(ref))
+    close(ops().gemm(a.to(DEV), w.to(DEV)), F.linear(a, w))
+
+
+def test_gemm_a2_broadcast_and_splitk():
+    B, L, K, N = 3, 100, 256, 256
+    a, a2, w, b = rnd(B, L, K, seed=1), rnd(L, K, seed=2), rnd(N, K, seed=3, scale=K ** -0.5), rnd(N, seed=4)
+    close(ops().gemm(a.to(DEV), w.to(DEV), b.to(DEV), a2=a2.to(DEV)), F.linear(a + a2, w, b))
+    a2f = rnd(B, L, K, seed=5)
+    close(ops().gemm(a.to(DEV), w.to(DEV), b.to(DEV), a2=a2f.to(DEV)), F.linear(a + a2f, w, b))
+    # split-K raw parts + layernorm consumer
+    K2 = 2048
+    h, w2, b2 = rnd(B, L, K2, seed=6), rnd(N, K2, seed=7, scale=K2 ** -0.5), rnd(N, seed=8)
+    parts = ops().gemm(h.to(DEV), w2.to(DEV), split_k=8)
+    assert parts.shape == (8, B, L, N)
+    close(parts.sum(0), F.linear(h, w2), rtol=1e-4, atol=1e-4)
+    x, g1, be1, g2, be2 = rnd(B, L, N, seed=9), 1 + 0.1 * rnd(N, seed=10), rnd(N, seed=11), 1 + 0.1 * rnd(N, seed=12), rnd(N, seed=13)
+    y, y2 = ops().layernorm(x.to(DEV), g1.to(DEV), be1.to(DEV), parts=parts, bias=b2.to(DEV), l2norm=True,
+                            g2=g2.to(DEV), b2=be2.to(DEV))
+    r = F.layer_norm(x + F.linear(h, w2, b2), (N,), g1, be1)
+    r = r / r.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    close(y, r, atol=2e-5)
+    close(y2, F.layer_norm(r, (N,), g2, be2), atol=1e-4)
+
+
+@pytest.mark.parametrize("E", [64, 256])
+def test_layernorm_plain(E):
+    x, t, g, b = rnd(1000, E, seed=1), rnd(1, 1000, E, seed=2), 1 + 0.1 * rnd(E, seed=3), rnd(E, seed=4)
+    y = ops().layernorm(x.to(DEV), g.to(DEV), b.to(DEV), parts=t.to(DEV))
+    close(y, F.layer_norm(x + t[0], (E,), g, b), atol=2e-5)
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout", [(2, 2048, 15, 20, 64), (2, 256, 16, 24, 64), (2, 512, 2, 3, 64), (1, 64, 60, 80, 256)])
+def test_conv1x1_layouts(B, Cin, H, W, Cout):
+    x, w, b = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, seed=2, scale=Cin ** -0.5), rnd(Cout, seed=3)
+    ref = F.conv2d(x, w[:, :, None, None], b)
+    tok = ops().conv1x1_nchw_to_tokens(x.to(DEV), w.to(DEV), b.to(DEV))
+    close(tok, ref.flatten(2).transpose(1, 2), atol=1e-4)
+    back = ops().conv1x1_tokens_to_nchw(tok, torch.eye(Cout, device=DEV).contiguous(), None)
+    close(back, ref.flatten(2), atol=1e-4)
+    close(ops().transpose_last2(tok), ref.flatten(2), atol=1e-4)
+
+
+def test_conv3x3_groupnorm_fpn_path():
+    B, C, H, W = 2, 64, 16, 24
+    x, w = rnd(B, C, H, W, seed=1), rnd(C, C, 3, 3, seed=2, scale=(9 * C) ** -0.5)
+    g, be = 1 + 0.1 * rnd(C, seed=3), rnd(C, seed=4)
+    up = rnd(B, C, H // 2, W // 2, seed=5)
+    tok = x.flatten(2).transpose(1, 2).contiguous().to(DEV)
+    uptok = up.flatten(2).transpose(1, 2).contiguous().to(DEV)
+    # lateral: GN(x) + bilinear up
+    y = ops().groupnorm_tokens(tok, g.to(DEV), be.to(DEV), H, W, up=uptok, up_hw=(H // 2, W // 2))
+    ref = F.group_norm(x, 32, g, be) + F.interpolate(up, size=(H, W), mode="bilinear", align_corners=False)
+    close(y, ref.flatten(2).transpose(1, 2), atol=2e-5)
+    # output conv: 3x3 + GN + relu
+    wt = w.permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous().to(DEV)
+    c = ops().conv3x3_tokens(tok, wt, H, W)
+    refc = F.conv2d(x, w, None, padding=1)
+    close(c, refc.flatten(2).transpose(1, 2), atol=1e-4)
+    y = ops().groupnorm_tokens(c, g.to(DEV), be.to(DEV), H, W, relu=True)
+    close(y, F.relu(F.group_norm(refc, 32, g, be)).flatten(2).transpose(1, 2), atol=1e-4)
+
+
+@pytest.mark.parametrize("npf,H,W", [(128, 15, 20), (32, 30, 40), (32, 3, 2)])
+def test_pos_embed(npf, H, W):
+    ref = O.position_embedding_sine(1, H, W, npf)[0]
+    close(ops().pos_embed_sine(H, W, npf, DEV), ref, atol=2e-6)
+    add = rnd(2 * npf, seed=1)
+    tok = ops().pos_embed_sine(H, W, npf, DEV, layout="tokens", add_c=add.to(DEV))
+    close(tok, ref.flatten(1).t() + add, atol=2e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+def ref_mask_step(e, f, tgt):
+    mask = torch.einsum("bqc,bchw->bqhw", e, f)
+    m = F.interpolate(mask, size=tgt, mode="bilinear", align_corners=False)
+    return mask, (m.sigmoid().flatten(2) < 0.5)
+
+
+@pytest.mark.parametrize("B,Q,H,W,pool", [(2, 100, 16, 24, 2), (2, 100, 16, 24, 4), (2, 100, 16, 24, 8),
+                                          (1, 100, 120, 160, 8), (1, 100, 120, 160, 4), (1, 100, 120, 160, 2),
+                                          (1, 300, 48, 64, 4), (2, 20, 8, 8, 2)])
+def test_mask_logits(B, Q, H, W, pool):
+    C = 256
+    e, f = rnd(B, Q, C, seed=1, scale=0.3), rnd(B, C, H, W, seed=2)
+    tgt = (H // pool, W // pool)
+    mask_ref, attn_ref = ref_mask_step(e, f, tgt)
+    for want_mask, sparse in ((True, False), (False, False), (False, True)):
+        mask, attn, row_any = ops().mask_logits(e.to(DEV), f.to(DEV), want_mask=want_mask, target_size=tgt, sparse=sparse)
+        if want_mask:
+            close(mask, mask_ref, rtol=1e-4, atol=1e-4)
+        # bits may differ only where the pooled logit is within rounding of zero
+        got = attn.cpu().bool()
+        diff = got != attn_ref
+        if diff.any():
+            m = F.interpolate(mask_ref, size=tgt, mode="bilinear", align_corners=False).flatten(2)
+            assert m[diff].abs().max() < 1e-4
+        assert diff.float().mean() < 1e-4
+        assert torch.equal(row_any.cpu().bool(), ~got.all(-1))
+    mask, attn, row_any = ops().mask_logits(e.to(DEV), f.to(DEV), want_mask=True, target_size=None)
+    close(mask, mask_ref, rtol=1e-4, atol=1e-4)
+    assert attn is None and row_any is None
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,Lq,S,masked", [(2, 100, 300, True), (2, 100, 100, False), (1, 100, 4800, True),
+                                           (2, 100, 6, True), (1, 300, 1200, True), (2, 20, 37, True)])
+def test_hypersphere_attention(B, Lq, S, masked):
+    H, E = 8, 256
+    q, k, v = rnd(B, Lq, E, seed=1), rnd(B, S, E, seed=2), rnd(B, S, E, seed=3)
+    m = None
+    row_any = None
+    add = None
+    if masked:
+        g = torch.Generator().manual_seed(4)
+        m = torch.rand(B, Lq, S, generator=g) < 0.6
+        m[0, 1] = True                      # an all-masked row: must attend everywhere (DEC:618)
+        row_any = (~m.all(-1)).to(torch.int32)
+        eff = m.clone()
+        eff[m.all(-1)] = False
+        add = torch.zeros(B, 1, Lq, S)
+        add[eff[:, None]] = float("-inf")
+        add = add.expand(B, H, Lq, S).reshape(B * H, Lq, S)
+    qh = q.view(B, Lq, H, 32).permute(0, 2, 1, 3).reshape(B * H, Lq, 32)
+    kh = k.view(B, S, H, 32).permute(0, 2, 1, 3).reshape(B * H, S, 32)
+    vh = v.view(B, S, H, 32).permute(0, 2, 1, 3).reshape(B * H, S, 32)
+    o, _ = O.hypersphere_attention(qh, kh, vh, add)
+    ref = o.view(B, H, Lq, 32).permute(0, 2, 1, 3).reshape(B, Lq, E)
+    got = ops().hypersphere_attention(q.to(DEV), k.to(DEV), v.to(DEV), H,
+                                      masked=None if m is None else m.to(torch.uint8).to(DEV),
+                                      row_any=None if row_any is None else row_any.to(DEV))
+    close(got, ref, rtol=1e-4, atol=2e-5)
+
+
+def test_hypersphere_attention_strided_views():
+    B, L, H, E = 2, 100, 8, 256
+    qk, v = rnd(B, L, 2 * E, seed=1).to(DEV), rnd(B, L, E, seed=2).to(DEV)
+    got = ops().hypersphere_attention(qk[..., :E], qk[..., E:], v, H)
+    ref = ops().hypersphere_attention(qk[..., :E].contiguous(), qk[..., E:].contiguous(), v, H)
+    assert torch.equal(got, ref)
+
+
+# ---------------------------------------------------------------------------------------------
+def test_msda_reference_known_answer(golden):
+    g = golden("msda_core")
+    shapes = torch.tensor([(6, 4), (3, 2)], dtype=torch.int64)
+    start = torch.tensor([0, 24], dtype=torch.int64)
+    T = lambda k: torch.from_numpy(g[k])
+    out = ops().ms_deform_attn(T("t_float_value").to(DEV), shapes.to(DEV), start.to(DEV), T("t_float_loc").to(DEV),
+                               T("t_float_aw").to(DEV))
+    assert torch.allclose(out.cpu(), T("t_float_out"), rtol=1e-2, atol=1e-3)   # ops/test.py:58 criterion
+    close(out, T("t_float_out"), rtol=1e-5, atol=1e-8)
+
+
+def test_msda_realistic_and_fused(golden):
+    g = golden("msda_core")
+    T = lambda k: torch.from_numpy(g[k])
+    shp = [tuple(int(v) for v in r) for r in g["r_shapes"]]
+    shapes = torch.tensor(shp, dtype=torch.int64)
+    start = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    out = ops().ms_deform_attn(T("r_value").to(DEV), shapes.to(DEV), start.to(DEV), T("r_loc").to(DEV), T("r_aw").to(DEV))
+    close(out, T("r_out"), rtol=1e-4, atol=1e-5)
+    # encoder form: raw offsets + logits, reference points = pixel centres
+    N, S, M, D = g["r_value"].shape
+    L, P = 3, 4
+    proj = rnd(N, S, M * L * P * 3, seed=5)
+    proj[..., :M * L * P * 2] *= 3.0
+    value = T("r_value").reshape(N, S, M * D)
+    off = proj[..., :M * L * P * 2].reshape(N, S, M, L, P, 2)
+    aw = torch.softmax(proj[..., M * L * P * 2:].reshape(N, S, M, L * P), -1).reshape(N, S, M, L, P)
+    ref_pts = O.encoder_reference_points(shp, N)
+    norm = torch.tensor([[w, h] for h, w in shp], dtype=torch.float32)
+    loc = ref_pts[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    ref = O.ms_deform_attn_core(T("r_value"), shp, loc, aw)
+    got = ops().ms_deform_attn_encoder(value.contiguous().to(DEV), shapes.to(DEV), start.to(DEV), proj.to(DEV), M, P)
+    close(got, ref, rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+def test_mean_shift_kernels(golden):
+    from unseenobjectswithmeanshift_amd import synthetic as syn
+    g = golden("mean_shift")
+    X, _ = syn.synth_unit_embeddings(2000, 64, clusters=6, sigma=0.15, seed=1)
+    Xd = X.to(DEV)
+    seeds, sel = ops().ms_select_seeds(Xd, 20, int(g["s_first"]))
+    assert torch.equal(sel.cpu(), torch.from_numpy(g["s_sel"]))
+    assert torch.equal(seeds.cpu(), torch.from_numpy(g["s_seeds"]))
+    Z = ops().ms_hill_climb(Xd, seeds, 20.0, 10)
+    close(Z, torch.from_numpy(g["s_Z"]), rtol=1e-4, atol=1e-5)
+    seed_labels = torch.from_numpy(g["s_cc"])
+    num = int(seed_labels.max()) + 1
+    labels, counts = ops().ms_assign(Xd, Z, seed_labels.to(DEV), num)
+    Zc = Z.cpu()
+    ref_lab = seed_labels[torch.argmin(0.5 * (1 - X @ Zc.t()), dim=1)]
+    assert (labels.cpu() != ref_lab).float().mean() < 1e-3
+    assert torch.equal(counts.cpu(), torch.bincount(labels.cpu(), minlength=num))
+    lab2 = ops().ms_relabel_largest_zero(labels.clone(), counts)
+    lmax = int(torch.argmax(counts.cpu()))
+    exp = labels.cpu().clone()
+    if lmax != 0:
+        exp[labels.cpu() == 0] = lmax
+        exp[labels.cpu() == lmax] = 0
+    assert torch.equal(lab2.cpu(), exp)
+
+
+def test_mean_shift_many_seeds():
+    from unseenobjectswithmeanshift_amd import synthetic as syn
+    X, _ = syn.synth_unit_embeddings(5000, 64, clusters=24, sigma=0.15, seed=2)
+    seeds, sel = O.select_smart_seeds(X, 300, 17)
+    s2, sel2 = ops().ms_select_seeds(X.to(DEV), 300, 17)
+    assert (sel2.cpu() == sel).float().mean() > 0.9
+    Zref = O.seed_hill_climbing_ball(X, seeds, 20.0, 3)
+    Z = ops().ms_hill_climb(X.to(DEV), seeds.to(DEV), 20.0, 3)
+    close(Z, Zref, rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+def test_topk_and_postprocess():
+    B, Q, h, w, Hh, Ww, T = 2, 100, 30, 40, 120, 160, 20
+    logits = rnd(B, Q, 3, seed=1)
+    masks = rnd(B, Q, h, w, seed=2, scale=2.0)
+    masks[0, 5] = -1.0                                  # an empty mask
+    scores, classes, qidx = ops().topk_class_scores(logits.to(DEV), T)
+    for b in range(B):
+        ref = O.instance_inference(logits[b], masks[b], (Hh, Ww), topk=T)
+        sc = torch.softmax(logits[b], -1)[:, :-1].flatten()
+        idx = O.canonical_topk(sc, T)
+        assert torch.equal(qidx[b].cpu().long(), idx // 2)
+        assert torch.equal(classes[b].cpu(), idx % 2)
+        close(scores[b], sc[idx], rtol=1e-5, atol=1e-7)
+    force = qidx.clone()
+    force[0, 0] = 5
+    pm, ms, boxes = ops().instance_postprocess(masks.to(DEV), force, (Hh, Ww))
+    for b in range(B):
+        up = F.interpolate(masks[b][None], size=(Hh, Ww), mode="bilinear", align_corners=False)[0][force[b].cpu().long()]
+        binm = (up > 0).float()
+        mism = (pm[b].cpu() != binm)
+        assert mism.float().mean() < 1e-5
+        ref_score = (up.sigmoid().flatten(1) * binm.flatten(1)).sum(1) / (binm.flatten(1).sum(1) + 1e-6)
+        close(ms[b], ref_score, rtol=1e-4, atol=1e-5)
+        if not mism.any():
+            close(boxes[b], O.mask_boxes(up > 0), rtol=0, atol=0)
+    assert float(ms[0, 0]) == 0.0 and torch.equal(boxes[0, 0].cpu(), torch.zeros(4))

@@ -1,0 +1,79 @@
+"""ctypes binding of libmsm_hip.so (C ABI declared in include/msm_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised (the reference silently falls back to a PyTorch path on ANY exception,
+ops/modules/ms_deform_attn.py:116-121 -- deliberately not reproduced).
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsm_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "msm_hip.h")
+
+_lib = None
+
+c_f = ctypes.c_void_p      # float* (device)
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_l = ctypes.c_int64
+c_fl = ctypes.c_float
+
+_SIGNATURES = {
+    "msm_abi_version": (c_i, []),
+    "msm_last_error_string": (ctypes.c_char_p, []),
+    "msm_gemm_f32": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i,
+                           c_l, c_l, c_l, c_l, c_l, c_l, c_l, c_l, c_l,
+                           c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "msm_layernorm_f32": (c_i, [c_f, c_f, c_i, c_l, c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_p]),
+    "msm_groupnorm_stats_f32": (c_i, [c_f, c_p, c_i, c_i, c_i, c_p]),
+    "msm_groupnorm_apply_f32": (c_i, [c_f, c_p, c_f, c_f, c_f, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_i, c_p]),
+    "msm_pos_embed_sine": (c_i, [c_f, c_i, c_i, c_i, c_l, c_l, c_f, c_fl, c_fl, c_p]),
+    "msm_transpose_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_p]),
+    "msm_mask_logits_fwd": (c_i, [c_f, c_f, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "msm_hypersphere_attn_workspace": (c_l, [c_i, c_i, c_i, c_i]),
+    "msm_hypersphere_attn_fwd": (c_i, [c_f, c_f, c_f, c_p, c_p, c_f, c_i, c_i, c_i, c_i,
+                                       c_l, c_l, c_l, c_l, c_l, c_l, c_fl, c_f, c_l, c_p]),
+    "msm_msdeform_attn_fwd": (c_i, [c_f, c_p, c_p, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "msm_msdeform_attn_enc_fwd": (c_i, [c_f, c_p, c_p, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "msm_ms_seed_workspace": (c_l, [c_i]),
+    "msm_ms_select_seeds": (c_i, [c_f, c_i, c_i, c_i, c_l, c_f, c_p, c_f, c_l, c_p]),
+    "msm_ms_hill_climb_workspace": (c_l, [c_i, c_i]),
+    "msm_ms_hill_climb": (c_i, [c_f, c_i, c_i, c_f, c_i, c_fl, c_i, c_f, c_l, c_p]),
+    "msm_ms_assign": (c_i, [c_f, c_i, c_i, c_f, c_i, c_p, c_p, c_p, c_i, c_p]),
+    "msm_ms_relabel_largest_zero": (c_i, [c_p, c_i, c_p, c_i, c_p]),
+    "msm_topk_class_scores": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),
+    "msm_instance_postprocess": (c_i, [c_f, c_p, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
+}
+
+
+def declared_symbols():
+    """Function names declared in include/msm_hip.h (used by the symbol-export test)."""
+    with open(HEADER_PATH) as f:
+        src = f.read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(msm_[a-z0-9_]+)\s*\(", src)))
+
+
+def lib():
+    """Load libmsm_hip.so once; raise loudly when it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the HIP hot path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().msm_last_error_string()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,236 @@
+// Multi-head hypersphere (von Mises-Fisher) attention core (see include/msm_hip.h).
+//
+// Reference: hypersphere_attention, attention_util.py:64-82 -- q^ = q/|q|, k^ = k/|k| per head,
+// A = softmax(kappa * q^ k^T + mask), out = normalize(A v); head split/merge attention_util.py:364-375,
+// 424; bool mask -> -inf conversion attention_util.py:411-414; the decoder's all-masked-row reset,
+// meanshiftformer_transformer_decoder.py:618.
+//
+// The reference materialises (B*h, Lq, S) score / float-mask / softmax tensors.  Here nothing of
+// size Lq x S touches memory except the 1-byte mask:
+//   * logits are bounded (|kappa q^.k^| <= kappa), so softmax needs no running max: p = exp(s - kappa)
+//     in [e^-2kappa, 1]; partial sums over key ranges combine by plain addition;
+//   * S^T = K^ Q^T is computed with v_mfma_f32_16x16x4_f32 so that the probabilities land in
+//     registers already in A-operand layout for P V (lane = (query l&15, key slot l>>4));
+//   * the head dimension (32) is walked in the permuted order d = 8*(l>>4) + t so that every lane
+//     reads its q/k fragment as two contiguous float4;
+//   * each wave keeps all <=112 queries of a chunk (Q^ as 56 VGPRs, O as 56) and streams its share
+//     of the 16-key blocks; 4 waves + key splits across workgroups are reduced through LDS and a
+//     small combine kernel that also applies 1/l and the output L2 normalisation.
+#include "common.h"
+
+namespace msm {
+
+constexpr int AQB = 7;             // 16-query blocks per chunk
+constexpr int AQCH = AQB * 16;     // 112
+constexpr int HD = 32;             // head dim
+constexpr int PSTRIDE = HD + 1;    // partial row: 32 outputs + softmax denominator
+
+static int attn_nsplit(int B, int qchunks, int heads, int S) {
+    const int base = B * qchunks * heads;
+    int ns = cdiv(512, base);
+    const int maxs = max(1, S / 128);  // >= 2 key blocks per wave
+    if (ns > maxs) ns = maxs;
+    if (ns < 1) ns = 1;
+    return ns;
+}
+
+__global__ __launch_bounds__(256) void hs_attn_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                      const float* __restrict__ v, const uint8_t* __restrict__ masked,
+                                                      const int32_t* __restrict__ row_any, float* __restrict__ part,
+                                                      int Lq, int S, int heads, int qchunks, int nsplit, int64_t ldq,
+                                                      int64_t q_sb, int64_t ldk, int64_t k_sb, int64_t ldv,
+                                                      int64_t v_sb, float kappa) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [4][AQCH][PSTRIDE]
+    const int split = blockIdx.x, h = blockIdx.y;
+    const int b = blockIdx.z / qchunks, qc = blockIdx.z - b * qchunks;
+    const int q0 = qc * AQCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lj = lane & 15, lq = lane >> 4;
+
+    // ---- Q^ fragments (B operand): lane (query lj of block m, dims lq*8 + t) ----
+    float qf[AQB][8];
+    const float* qb = q + (int64_t)b * q_sb + h * HD + lq * 8;
+#pragma unroll
+    for (int m = 0; m < AQB; ++m) {
+        const int qi = q0 + m * 16 + lj;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+        if (qi < Lq) {
+            const float* p = qb + (int64_t)qi * ldq;
+            a = *reinterpret_cast<const float4*>(p);
+            c = *reinterpret_cast<const float4*>(p + 4);
+        }
+        float ss = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        const float rn = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        qf[m][0] = a.x * rn; qf[m][1] = a.y * rn; qf[m][2] = a.z * rn; qf[m][3] = a.w * rn;
+        qf[m][4] = c.x * rn; qf[m][5] = c.y * rn; qf[m][6] = c.z * rn; qf[m][7] = c.w * rn;
+    }
+    // per-row mask enable: rows whose keys are all masked attend everywhere (DEC:618)
+    bool use_mask[AQB];
+#pragma unroll
+    for (int m = 0; m < AQB; ++m) {
+        const int qi = q0 + m * 16 + lj;
+        use_mask[m] = masked != nullptr && qi < Lq && (row_any == nullptr || row_any[(int64_t)b * Lq + qi] != 0);
+    }
+
+    f32x4 o[AQB][2];
+    float lsum[AQB];
+#pragma unroll
+    for (int m = 0; m < AQB; ++m) {
+        o[m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        o[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        lsum[m] = 0.f;
+    }
+
+    // key blocks of 16: contiguous range per split, round-robin over the 4 waves
+    const int nkb = (S + 15) / 16;
+    const int kb_per = (nkb + nsplit - 1) / nsplit;
+    const int kb_beg = split * kb_per, kb_end = min(nkb, kb_beg + kb_per);
+    const float* kbp = k + (int64_t)b * k_sb + h * HD + lq * 8;
+    const float* vbp = v + (int64_t)b * v_sb + h * HD + lj;
+    const bool mask_vec = (S % 4) == 0;
+
+    for (int kb = kb_beg + wave; kb < kb_end; kb += 4) {
+        // K^ fragment (A operand): lane (key lj, dims lq*8 + t)
+        const int key_a = min(kb * 16 + lj, S - 1);
+        const float* kp = kbp + (int64_t)key_a * ldk;
+        const float4 a = *reinterpret_cast<const float4*>(kp);
+        const float4 c = *reinterpret_cast<const float4*>(kp + 4);
+        float ss = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        const float rn = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        float kf[8] = {a.x * rn, a.y * rn, a.z * rn, a.w * rn, c.x * rn, c.y * rn, c.z * rn, c.w * rn};
+        // V fragments (B operand of P V): lane (key lq*4 + r, dim db*16 + lj)
+        const int key_c0 = kb * 16 + lq * 4;
+        float vf[4][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* vp = vbp + (int64_t)min(key_c0 + r, S - 1) * ldv;
+            vf[r][0] = vp[0];
+            vf[r][1] = vp[16];
+        }
+#pragma unroll
+        for (int m = 0; m < AQB; ++m) {
+            f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 8; ++t) s = mfma16(kf[t], qf[m][t], s);
+            // s[r]: key key_c0 + r, query q0 + m*16 + lj
+            uint32_t mw = 0;
+            if (use_mask[m]) {
+                const uint8_t* mp = masked + ((int64_t)b * Lq + (q0 + m * 16 + lj)) * S + key_c0;
+                if (mask_vec) {
+                    if (key_c0 < S) mw = *reinterpret_cast<const uint32_t*>(mp);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (key_c0 + r < S) mw |= (uint32_t)mp[r] << (8 * r);
+                }
+            }
+            float p[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool dead = (key_c0 + r >= S) || ((mw >> (8 * r)) & 0xffu);
+                p[r] = dead ? 0.f : expf(kappa * s[r] - kappa);
+            }
+            lsum[m] += (p[0] + p[1]) + (p[2] + p[3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o[m][0] = mfma16(p[r], vf[r][0], o[m][0]);
+                o[m][1] = mfma16(p[r], vf[r][1], o[m][1]);
+            }
+        }
+    }
+
+    // ---- reduce the 4 waves through LDS, then one partial per workgroup ----
+    float* mine = red + wave * (AQCH * PSTRIDE);
+#pragma unroll
+    for (int m = 0; m < AQB; ++m) {
+        float l = lsum[m];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        if (lq == 0) mine[(m * 16 + lj) * PSTRIDE + HD] = l;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m * 16 + lq * 4 + r;
+            mine[row * PSTRIDE + lj] = o[m][0][r];
+            mine[row * PSTRIDE + 16 + lj] = o[m][1][r];
+        }
+    }
+    __syncthreads();
+    float* dst = part + ((((int64_t)blockIdx.z * heads + h) * nsplit) + split) * (AQCH * PSTRIDE);
+    for (int i = tid; i < AQCH * PSTRIDE; i += 256) {
+        dst[i] = (red[i] + red[AQCH * PSTRIDE + i]) + (red[2 * AQCH * PSTRIDE + i] + red[3 * AQCH * PSTRIDE + i]);
+    }
+}
+
+// out[b][q][h*32 + d] = normalize( (sum_splits O) / (sum_splits l) )
+__global__ __launch_bounds__(128) void hs_attn_combine_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                              int Lq, int heads, int qchunks, int nsplit) {
+    const int h = blockIdx.x;
+    const int b = blockIdx.y / qchunks, qc = blockIdx.y - b * qchunks;
+    const int ql = threadIdx.x;
+    const int qi = qc * AQCH + ql;
+    if (ql >= AQCH || qi >= Lq) return;
+    const float* src = part + (((int64_t)blockIdx.y * heads + h) * nsplit) * (AQCH * PSTRIDE) + ql * PSTRIDE;
+    float acc[HD + 1];
+#pragma unroll
+    for (int d = 0; d <= HD; ++d) acc[d] = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+#pragma unroll
+        for (int d = 0; d <= HD; ++d) acc[d] += src[(int64_t)s * (AQCH * PSTRIDE) + d];
+    }
+    const float l = acc[HD];
+    float ss = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+        acc[d] = acc[d] / l;
+        ss += acc[d] * acc[d];
+    }
+    const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+    float* o = out + ((int64_t)b * Lq + qi) * (heads * HD) + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = acc[d] / nrm;
+}
+
+}  // namespace msm
+
+using namespace msm;
+
+extern "C" int64_t msm_hypersphere_attn_workspace(int B, int Lq, int S, int heads) {
+    const int qchunks = cdiv(Lq, AQCH);
+    const int ns = attn_nsplit(B, qchunks, heads, S);
+    return (int64_t)B * qchunks * heads * ns * AQCH * PSTRIDE;
+}
+
+extern "C" int msm_hypersphere_attn_fwd(const float* q, const float* k, const float* v, const uint8_t* masked,
+                                        const int32_t* row_any, float* out, int B, int Lq, int S, int heads,
+                                        int64_t ldq, int64_t q_sb, int64_t ldk, int64_t k_sb, int64_t ldv,
+                                        int64_t v_sb, float kappa, float* workspace, int64_t workspace_elems,
+                                        void* stream) {
+    MSM_REQUIRE(q && k && v && out && workspace, "msm_hypersphere_attn_fwd: null pointer");
+    MSM_REQUIRE(B > 0 && Lq > 0 && S > 0 && heads > 0, "msm_hypersphere_attn_fwd: bad sizes");
+    MSM_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && q_sb % 4 == 0 && k_sb % 4 == 0 && (((uintptr_t)q) & 15) == 0 &&
+                    (((uintptr_t)k) & 15) == 0,
+                "msm_hypersphere_attn_fwd: q/k must be 16-byte aligned with strides multiple of 4");
+    MSM_REQUIRE(!masked || (((uintptr_t)masked) & 3) == 0, "msm_hypersphere_attn_fwd: mask must be 4-byte aligned");
+    const int qchunks = cdiv(Lq, AQCH);
+    const int ns = attn_nsplit(B, qchunks, heads, S);
+    const int64_t need = (int64_t)B * qchunks * heads * ns * AQCH * PSTRIDE;
+    if (workspace_elems < need) {
+        set_error("msm_hypersphere_attn_fwd: workspace %lld < %lld floats", (long long)workspace_elems, (long long)need);
+        return MSM_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = sizeof(float) * 4 * AQCH * PSTRIDE;
+    MSM_CHECK_HIP(hipFuncSetAttribute((const void*)hs_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid(ns, heads, B * qchunks), block(256);
+    hipLaunchKernelGGL(hs_attn_kernel, grid, block, lds, st, q, k, v, masked, row_any, workspace, Lq, S, heads, qchunks,
+                       ns, ldq, q_sb, ldk, k_sb, ldv, v_sb, kappa);
+    MSM_CHECK_LAUNCH("msm_hypersphere_attn_fwd");
+    dim3 g2(heads, B * qchunks), b2(128);
+    hipLaunchKernelGGL(hs_attn_combine_kernel, g2, b2, 0, st, workspace, out, Lq, heads, qchunks, ns);
+    MSM_CHECK_LAUNCH("msm_hypersphere_attn_fwd(combine)");
+    return MSM_OK;
+}

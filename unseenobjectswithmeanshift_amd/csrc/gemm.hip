@@ -1,0 +1,300 @@
+// Generic fp32 MFMA GEMM with fused prologue/epilogue (see include/msm_hip.h: msm_gemm_f32).
+//
+// Replaces the torch ops around the hot kernels of the reference: F.linear (attention_util.py:134-140,
+// 425; meanshiftformer_transformer_decoder.py:301,336-340,663-664; ops/modules/ms_deform_attn.py:95-104,
+// 123), 1x1 Conv2d (meanshiftformer_transformer_decoder.py:499,575; msdeformattn.py:212-220,245-252,
+// 264-266) and the 3x3 output conv (msdeformattn.py:268-277, as an implicit GEMM over NHWC tokens).
+//
+// Structure: 256 threads = 4 waves (2x2), each wave owns a (16*MI)x(16*NI) block of C built from
+// v_mfma_f32_16x16x4_f32 tiles (exact fp32).  A/W tiles of BK=32 are staged through LDS with
+// register prefetch of the next tile.  LDS row strides are chosen so that the fragment reads
+// (lane = (row l&15, k-slot l>>4)) are bank-conflict free for ds_read_b32:
+//   K-contiguous tiles  [rows][34]   : bank = (2*row + k) mod 32, distinct over the two 32-lane halves
+//   M-contiguous tiles  [32][BM+16]  : bank = (16*k + row) mod 32, likewise.
+#include "common.h"
+
+namespace msm {
+
+struct GemmArgs {
+    const float* A;
+    const float* A2;
+    const float* W;
+    const float* bias;
+    float* C;
+    int M, N, K, batch;
+    int64_t a_sm, a_sk, a_sb, a2_sb, w_sb, c_sm, c_sn, c_sb, c_ss;
+    int conv_h, conv_w, conv_c;
+    int bias_mode, act, split_k, k_per_split;
+    int vec_a, vec_w;
+};
+
+constexpr int BK = 32;
+constexpr int SK = BK + 2;  // row stride of K-contiguous LDS tiles
+
+// AMODE 0: A rows K-contiguous; 1: A is M-contiguous ([K][M]); 2: implicit 3x3 conv over NHWC tokens
+template <int MI, int NI, int AMODE>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+    constexpr int BM = 32 * MI, BN = 32 * NI;
+    constexpr int SM = BM + 16;  // row stride of the M-contiguous A tile
+    constexpr int A_ELEMS = (AMODE == 1) ? BK * SM : BM * SK;
+    __shared__ __attribute__((aligned(16))) float As[A_ELEMS];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * SK];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lj = lane & 15, lq = lane >> 4;
+    const int wm = (wave >> 1) * (16 * MI), wn = (wave & 1) * (16 * NI);
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int bz = blockIdx.z;
+    const int b = bz / p.split_k, ks = bz - b * p.split_k;
+    const int kbeg = ks * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+
+    const float* __restrict__ Ab = p.A + (int64_t)b * p.a_sb;
+    const float* __restrict__ A2b = p.A2 ? p.A2 + (int64_t)b * p.a2_sb : nullptr;
+    const float* __restrict__ Wb = p.W + (int64_t)b * p.w_sb;
+
+    float4 ra[MI], rb[NI];
+
+    auto load_a = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int f = tid + 256 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (AMODE == 0) {
+                const int row = f >> 3, k = k0 + (f & 7) * 4;
+                const int m = m0 + row;
+                if (m < p.M && k < kend) {
+                    const int64_t off = (int64_t)m * p.a_sm + k;
+                    if (p.vec_a) {
+                        v = *reinterpret_cast<const float4*>(Ab + off);
+                        if (A2b) {
+                            const float4 w = *reinterpret_cast<const float4*>(A2b + off);
+                            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+                        }
+                    } else {
+                        float t[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            t[e] = 0.f;
+                            if (k + e < kend) {
+                                t[e] = Ab[off + e];
+                                if (A2b) t[e] += A2b[off + e];
+                            }
+                        }
+                        v = make_float4(t[0], t[1], t[2], t[3]);
+                    }
+                }
+            } else if constexpr (AMODE == 1) {
+                const int kk = f / (BM / 4), m = m0 + (f % (BM / 4)) * 4;
+                const int k = k0 + kk;
+                if (k < kend && m < p.M) {
+                    const int64_t off = (int64_t)k * p.a_sk + m;
+                    if (p.vec_a) {
+                        v = *reinterpret_cast<const float4*>(Ab + off);
+                        if (A2b) {
+                            const float4 w = *reinterpret_cast<const float4*>(A2b + off);
+                            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+                        }
+                    } else {
+                        float t[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            t[e] = 0.f;
+                            if (m + e < p.M) {
+                                t[e] = Ab[off + e];
+                                if (A2b) t[e] += A2b[off + e];
+                            }
+                        }
+                        v = make_float4(t[0], t[1], t[2], t[3]);
+                    }
+                }
+            } else {
+                // implicit im2col: k = tap*C + c, pixel (y,x) = (m / W, m % W), zero padding 1
+                const int row = f >> 3, k = k0 + (f & 7) * 4;
+                const int m = m0 + row;
+                if (m < p.M && k < kend) {
+                    const int tap = k / p.conv_c, c = k - tap * p.conv_c;
+                    const int y = m / p.conv_w, x = m - y * p.conv_w;
+                    const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                    if (yy >= 0 && yy < p.conv_h && xx >= 0 && xx < p.conv_w) {
+                        v = *reinterpret_cast<const float4*>(Ab + ((int64_t)yy * p.conv_w + xx) * p.conv_c + c);
+                    }
+                }
+            }
+            ra[i] = v;
+        }
+    };
+    auto load_w = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f >> 3, k = k0 + (f & 7) * 4;
+            const int n = n0 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < p.N && k < kend) {
+                const int64_t off = (int64_t)n * p.K + k;
+                if (p.vec_w) {
+                    v = *reinterpret_cast<const float4*>(Wb + off);
+                } else {
+                    float t[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = (k + e < kend) ? Wb[off + e] : 0.f;
+                    v = make_float4(t[0], t[1], t[2], t[3]);
+                }
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int f = tid + 256 * i;
+            if constexpr (AMODE == 1) {
+                const int kk = f / (BM / 4), mm = (f % (BM / 4)) * 4;
+                *reinterpret_cast<float4*>(&As[kk * SM + mm]) = ra[i];
+            } else {
+                const int row = f >> 3, c4 = (f & 7) * 4;
+                float2* d = reinterpret_cast<float2*>(&As[row * SK + c4]);
+                d[0] = make_float2(ra[i].x, ra[i].y);
+                d[1] = make_float2(ra[i].z, ra[i].w);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f >> 3, c4 = (f & 7) * 4;
+            float2* d = reinterpret_cast<float2*>(&Bs[row * SK + c4]);
+            d[0] = make_float2(rb[i].x, rb[i].y);
+            d[1] = make_float2(rb[i].z, rb[i].w);
+        }
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    load_a(kbeg);
+    load_w(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        store_tiles();
+        __syncthreads();
+        if (k0 + BK < kend) {
+            load_a(k0 + BK);
+            load_w(k0 + BK);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4) {
+            float a[MI], bb[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                if constexpr (AMODE == 1)
+                    a[i] = As[(kk + lq) * SM + wm + i * 16 + lj];
+                else
+                    a[i] = As[(wm + i * 16 + lj) * SK + kk + lq];
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) bb[j] = Bs[(wn + j * 16 + lj) * SK + kk + lq];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(a[i], bb[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane holds rows (lq*4 + r), column lj of each 16x16 tile
+    float* __restrict__ Cb = p.C + (int64_t)b * p.c_sb + (int64_t)ks * p.c_ss;
+    const bool raw = p.split_k > 1;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = n0 + wn + j * 16 + lj;
+            if (n >= p.N) continue;
+            float bn = 0.f;
+            if (!raw && p.bias_mode == 1) bn = p.bias[n];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm + i * 16 + lq * 4 + r;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r];
+                if (!raw) {
+                    if (p.bias_mode == 1) v += bn;
+                    else if (p.bias_mode == 2) v += p.bias[m];
+                    if (p.act == 1) v = fmaxf(v, 0.f);
+                }
+                Cb[(int64_t)m * p.c_sm + (int64_t)n * p.c_sn] = v;
+            }
+        }
+    }
+}
+
+template <int AMODE>
+static int launch_gemm(const GemmArgs& p, hipStream_t st) {
+    // pick the largest tile that still yields enough workgroups to cover the 256 CUs
+    const int cfgs[5][2] = {{4, 4}, {2, 4}, {2, 2}, {1, 2}, {1, 1}};
+    int pick = 4;
+    for (int c = 0; c < 5; ++c) {
+        const int64_t blocks = (int64_t)cdiv(p.M, 32 * cfgs[c][0]) * cdiv(p.N, 32 * cfgs[c][1]) * p.batch * p.split_k;
+        if (blocks >= 512) { pick = c; break; }
+    }
+    const int mi = cfgs[pick][0], ni = cfgs[pick][1];
+    dim3 grid(cdiv(p.N, 32 * ni), cdiv(p.M, 32 * mi), p.batch * p.split_k);
+    dim3 block(256);
+    switch (pick) {
+        case 0: hipLaunchKernelGGL((gemm_kernel<4, 4, AMODE>), grid, block, 0, st, p); break;
+        case 1: hipLaunchKernelGGL((gemm_kernel<2, 4, AMODE>), grid, block, 0, st, p); break;
+        case 2: hipLaunchKernelGGL((gemm_kernel<2, 2, AMODE>), grid, block, 0, st, p); break;
+        case 3: hipLaunchKernelGGL((gemm_kernel<1, 2, AMODE>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_kernel<1, 1, AMODE>), grid, block, 0, st, p); break;
+    }
+    MSM_CHECK_LAUNCH("msm_gemm_f32");
+    return MSM_OK;
+}
+
+}  // namespace msm
+
+using namespace msm;
+
+extern "C" int msm_gemm_f32(const float* A, const float* A2, const float* W, const float* bias, float* C,
+                            int M, int N, int K, int batch,
+                            int64_t a_sm, int64_t a_sk, int64_t a_sb, int64_t a2_sb, int64_t w_sb,
+                            int64_t c_sm, int64_t c_sn, int64_t c_sb, int64_t c_ss,
+                            int a_mode, int conv_h, int conv_w, int conv_c,
+                            int bias_mode, int act, int split_k, void* stream) {
+    MSM_REQUIRE(A && W && C, "msm_gemm_f32: null pointer");
+    MSM_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "msm_gemm_f32: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
+    MSM_REQUIRE(split_k >= 1, "msm_gemm_f32: split_k must be >= 1");
+    MSM_REQUIRE(bias_mode == 0 || bias != nullptr, "msm_gemm_f32: bias_mode set without bias");
+    GemmArgs p;
+    p.A = A; p.A2 = A2; p.W = W; p.bias = bias; p.C = C;
+    p.M = M; p.N = N; p.K = K; p.batch = batch;
+    p.a_sm = a_sm; p.a_sk = a_sk; p.a_sb = a_sb; p.a2_sb = a2_sb; p.w_sb = w_sb;
+    p.c_sm = c_sm; p.c_sn = c_sn; p.c_sb = c_sb; p.c_ss = c_ss;
+    p.conv_h = conv_h; p.conv_w = conv_w; p.conv_c = conv_c;
+    p.bias_mode = bias_mode; p.act = act; p.split_k = split_k;
+    int kps = cdiv(K, split_k);
+    kps = cdiv(kps, BK) * BK;  // whole LDS tiles per split
+    p.k_per_split = kps;
+    MSM_REQUIRE((int64_t)kps * (split_k - 1) < K, "msm_gemm_f32: split_k=%d too large for K=%d", split_k, K);
+    const bool a16 = (((uintptr_t)A) & 15) == 0 && (!A2 || (((uintptr_t)A2) & 15) == 0);
+    p.vec_w = (K % 4 == 0) && ((((uintptr_t)W) & 15) == 0) && (w_sb % 4 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (a_mode == 2) {
+        MSM_REQUIRE(conv_c % 4 == 0 && K == 9 * conv_c && M == conv_h * conv_w && a16 && a_sb % 4 == 0 && !A2,
+                    "msm_gemm_f32: bad implicit-conv arguments");
+        p.vec_a = 1;
+        return launch_gemm<2>(p, st);
+    }
+    MSM_REQUIRE(a_mode == 0, "msm_gemm_f32: a_mode must be 0 or 2");
+    if (a_sk == 1) {
+        p.vec_a = a16 && (K % 4 == 0) && (a_sm % 4 == 0) && (a_sb % 4 == 0) && (a2_sb % 4 == 0);
+        return launch_gemm<0>(p, st);
+    }
+    MSM_REQUIRE(a_sm == 1, "msm_gemm_f32: one of a_sm/a_sk must be 1");
+    p.vec_a = a16 && (M % 4 == 0) && (a_sk % 4 == 0) && (a_sb % 4 == 0) && (a2_sb % 4 == 0);
+    return launch_gemm<1>(p, st);
+}

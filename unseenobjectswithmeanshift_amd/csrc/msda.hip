@@ -1,0 +1,201 @@
+// Multi-scale deformable attention forward (see include/msm_hip.h).
+//
+// Reference: ms_deformable_im2col_gpu_kernel, ops/src/cuda/ms_deform_im2col_cuda.cuh:242-304 and its
+// bilinear helper :38-89 (one thread per output scalar, 48 dependent 4-byte gathers each); host
+// wrapper ops/src/cuda/ms_deform_attn_cuda.cu:25-85; module arithmetic ops/modules/ms_deform_attn.py:
+// 101-109 and the encoder's reference points, msdeformattn.py:141-153.
+//
+// gfx950 mapping: a gather kernel is bound by the number of vector-memory instructions and the L2
+// sectors they touch, not by FLOPs.  One lane owns 4 consecutive channels (1 when D % 4 != 0) of one (query, head), so
+// every bilinear tap is ONE 16-byte load and the D/4 lanes of a head fetch a contiguous 4*D-byte
+// segment of `value` ([B][S][M][D], channel-fastest).  The M*D/4 lanes of a query write one
+// contiguous 4*M*D-byte output row.  Level geometry is read once into registers (the reference
+// re-reads the int64 shapes inside the point loop).  In the encoder form the softmax over the L*P
+// logits and the sampling-location arithmetic are done in registers, so sampling_locations and
+// attention_weights (7.3 MB per layer-image at 640x480) never exist in memory.
+#include "common.h"
+
+namespace msm {
+
+constexpr int MAXL = 8;
+
+template <int V>
+struct Vec {
+    float e[V];
+};
+template <int V>
+__device__ __forceinline__ Vec<V> ldv(const float* p) {
+    Vec<V> r;
+    if constexpr (V == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        r.e[0] = t.x; r.e[1] = t.y; r.e[2] = t.z; r.e[3] = t.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) r.e[i] = p[i];
+    }
+    return r;
+}
+
+// one sampling point: same arithmetic as cuh:290-300 and cuh:43-88
+template <int V>
+__device__ __forceinline__ void sample_point(Vec<V>& acc, const float* __restrict__ vl /* level base for (b, m, d) */,
+                                             int H, int W, int64_t pix_stride, float loc_x, float loc_y, float wgt) {
+    const float h_im = loc_y * (float)H - 0.5f;
+    const float w_im = loc_x * (float)W - 0.5f;
+    if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) return;
+    const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+    const int h_high = h_low + 1, w_high = w_low + 1;
+    const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+    const float hh = 1.f - lh, hw = 1.f - lw;
+    Vec<V> v1, v2, v3, v4;
+#pragma unroll
+    for (int i = 0; i < V; ++i) v1.e[i] = v2.e[i] = v3.e[i] = v4.e[i] = 0.f;
+    if (h_low >= 0 && w_low >= 0) v1 = ldv<V>(vl + ((int64_t)h_low * W + w_low) * pix_stride);
+    if (h_low >= 0 && w_high <= W - 1) v2 = ldv<V>(vl + ((int64_t)h_low * W + w_high) * pix_stride);
+    if (h_high <= H - 1 && w_low >= 0) v3 = ldv<V>(vl + ((int64_t)h_high * W + w_low) * pix_stride);
+    if (h_high <= H - 1 && w_high <= W - 1) v4 = ldv<V>(vl + ((int64_t)h_high * W + w_high) * pix_stride);
+    const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc.e[i] += (w1 * v1.e[i] + w2 * v2.e[i] + w3 * v3.e[i] + w4 * v4.e[i]) * wgt;
+}
+
+template <bool ENC, int V>
+__global__ __launch_bounds__(256) void msda_kernel(const float* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                   const int64_t* __restrict__ lstart, const float* __restrict__ loc,
+                                                   const float* __restrict__ wgt, const float* __restrict__ proj,
+                                                   float* __restrict__ out, int B, int S, int M, int D, int L, int Lq,
+                                                   int P) {
+    const int D4 = D / V;
+    const int64_t total = (int64_t)B * Lq * M * D4;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int d4 = (int)(idx % D4);
+    int64_t t = idx / D4;
+    const int m = (int)(t % M);
+    t /= M;
+    const int qi = (int)(t % Lq);
+    const int b = (int)(t / Lq);
+
+    int Hs[MAXL], Ws[MAXL], st[MAXL];
+#pragma unroll
+    for (int l = 0; l < MAXL; ++l) {
+        if (l < L) {
+            Hs[l] = (int)shapes[2 * l];
+            Ws[l] = (int)shapes[2 * l + 1];
+            st[l] = (int)lstart[l];
+        } else {
+            Hs[l] = Ws[l] = 1;
+            st[l] = 0;
+        }
+    }
+    const int64_t pix_stride = (int64_t)M * D;
+    const float* vb = value + (int64_t)b * S * pix_stride + m * D + d4 * V;
+    Vec<V> acc;
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc.e[i] = 0.f;
+
+    if constexpr (ENC) {
+        const int LP = L * P;
+        const float* pr = proj + ((int64_t)b * S + qi) * (M * LP * 3);
+        const float* offp = pr + (int64_t)m * LP * 2;
+        const float* lgp = pr + (int64_t)M * LP * 2 + (int64_t)m * LP;
+        // reference point = centre of pixel qi in its own level, normalised (msdeformattn.py:141-153)
+        int ql = 0;
+#pragma unroll
+        for (int l = 1; l < MAXL; ++l)
+            if (l < L && qi >= st[l]) ql = l;
+        const int local = qi - st[ql];
+        const int ry = local / Ws[ql], rx = local - ry * Ws[ql];
+        const float ref_x = ((float)rx + 0.5f) / (float)Ws[ql];
+        const float ref_y = ((float)ry + 0.5f) / (float)Hs[ql];
+        // softmax over the L*P logits (ms_deform_attn.py:103)
+        float mx = -INFINITY;
+        for (int i = 0; i < LP; ++i) mx = fmaxf(mx, lgp[i]);
+        float den = 0.f;
+        for (int i = 0; i < LP; ++i) den += expf(lgp[i] - mx);
+#pragma unroll
+        for (int l = 0; l < MAXL; ++l) {
+            if (l >= L) break;
+            const float* vl = vb + (int64_t)st[l] * pix_stride;
+            for (int p = 0; p < P; ++p) {
+                const int i = l * P + p;
+                const float lx = ref_x + offp[2 * i] / (float)Ws[l];      // ms_deform_attn.py:107-109
+                const float ly = ref_y + offp[2 * i + 1] / (float)Hs[l];
+                const float w = expf(lgp[i] - mx);
+                sample_point(acc, vl, Hs[l], Ws[l], pix_stride, lx, ly, w / den);
+            }
+        }
+    } else {
+        const int64_t base = (((int64_t)b * Lq + qi) * M + m) * L * P;
+        const float* lp = loc + base * 2;
+        const float* wp = wgt + base;
+#pragma unroll
+        for (int l = 0; l < MAXL; ++l) {
+            if (l >= L) break;
+            const float* vl = vb + (int64_t)st[l] * pix_stride;
+            for (int p = 0; p < P; ++p) {
+                const int i = l * P + p;
+                sample_point(acc, vl, Hs[l], Ws[l], pix_stride, lp[2 * i], lp[2 * i + 1], wp[i]);
+            }
+        }
+    }
+    float* op = out + (((int64_t)b * Lq + qi) * M + m) * D + d4 * V;
+    if constexpr (V == 4) {
+        *reinterpret_cast<float4*>(op) = make_float4(acc.e[0], acc.e[1], acc.e[2], acc.e[3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) op[i] = acc.e[i];
+    }
+}
+
+static int msda_common_checks(const char* name, const void* value, const void* out, int B, int S, int M, int D, int L,
+                              int Lq, int P) {
+    MSM_REQUIRE(B > 0 && S > 0 && M > 0 && Lq > 0 && P > 0, "%s: bad sizes", name);
+    MSM_REQUIRE(D > 0 && D <= 64, "%s: D=%d must be in 1..64", name, D);
+    MSM_REQUIRE(L > 0 && L <= MAXL, "%s: L=%d must be <= %d", name, L, MAXL);
+    MSM_REQUIRE((((uintptr_t)value) & 15) == 0 && (((uintptr_t)out) & 15) == 0, "%s: value/out must be 16-byte aligned", name);
+    return MSM_OK;
+}
+
+}  // namespace msm
+
+using namespace msm;
+
+extern "C" int msm_msdeform_attn_fwd(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                     const float* sampling_loc, const float* attn_weight, float* out, int B, int S,
+                                     int M, int D, int L, int Lq, int P, void* stream) {
+    MSM_REQUIRE(value && spatial_shapes && level_start_index && sampling_loc && attn_weight && out,
+                "msm_msdeform_attn_fwd: null pointer");
+    int rc = msda_common_checks("msm_msdeform_attn_fwd", value, out, B, S, M, D, L, Lq, P);
+    if (rc != MSM_OK) return rc;
+    const int V = (D % 4 == 0) ? 4 : 1;
+    const int64_t total = (int64_t)B * Lq * M * (D / V);
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (V == 4)
+        hipLaunchKernelGGL((msda_kernel<false, 4>), grid, block, 0, (hipStream_t)stream, value, spatial_shapes,
+                           level_start_index, sampling_loc, attn_weight, (const float*)nullptr, out, B, S, M, D, L, Lq, P);
+    else
+        hipLaunchKernelGGL((msda_kernel<false, 1>), grid, block, 0, (hipStream_t)stream, value, spatial_shapes,
+                           level_start_index, sampling_loc, attn_weight, (const float*)nullptr, out, B, S, M, D, L, Lq, P);
+    MSM_CHECK_LAUNCH("msm_msdeform_attn_fwd");
+    return MSM_OK;
+}
+
+extern "C" int msm_msdeform_attn_enc_fwd(const float* value, const int64_t* spatial_shapes,
+                                         const int64_t* level_start_index, const float* proj, float* out, int B, int S,
+                                         int M, int D, int L, int P, void* stream) {
+    MSM_REQUIRE(value && spatial_shapes && level_start_index && proj && out, "msm_msdeform_attn_enc_fwd: null pointer");
+    int rc = msda_common_checks("msm_msdeform_attn_enc_fwd", value, out, B, S, M, D, L, S, P);
+    if (rc != MSM_OK) return rc;
+    const int V = (D % 4 == 0) ? 4 : 1;
+    const int64_t total = (int64_t)B * S * M * (D / V);
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (V == 4)
+        hipLaunchKernelGGL((msda_kernel<true, 4>), grid, block, 0, (hipStream_t)stream, value, spatial_shapes,
+                           level_start_index, (const float*)nullptr, (const float*)nullptr, proj, out, B, S, M, D, L, S, P);
+    else
+        hipLaunchKernelGGL((msda_kernel<true, 1>), grid, block, 0, (hipStream_t)stream, value, spatial_shapes,
+                           level_start_index, (const float*)nullptr, (const float*)nullptr, proj, out, B, S, M, D, L, S, P);
+    MSM_CHECK_LAUNCH("msm_msdeform_attn_enc_fwd");
+    return MSM_OK;
+}

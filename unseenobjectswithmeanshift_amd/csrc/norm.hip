@@ -1,0 +1,277 @@
+// Row / group normalisation kernels (see include/msm_hip.h).
+//
+//   msm_layernorm_f32      : residual + split-K parts + bias -> LayerNorm [-> L2 normalise] [-> LayerNorm]
+//                            (meanshiftformer_transformer_decoder.py:255-257,178-179,300-304,637-638,661;
+//                             msdeformattn.py:116-118,124-126)
+//   msm_groupnorm_stats/apply : GroupNorm(32, C) over NHWC token maps with the FPN top-down
+//                            bilinear add and ReLU fused in (msdeformattn.py:212-220,262-277,343-351)
+//   msm_pos_embed_sine, msm_transpose_f32 : position_encoding.py:29-52 and layout glue.
+//
+// All of these are HBM-bound streaming kernels: one wave per row (LayerNorm) or one lane per
+// channel (GroupNorm) so that every global access is a full coalesced 256 B segment.
+#include "common.h"
+
+namespace msm {
+
+template <int VPT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ parts,
+                                                        int n_parts, int64_t part_stride,
+                                                        const float* __restrict__ bias,
+                                                        const float* __restrict__ g1, const float* __restrict__ b1,
+                                                        int l2norm, const float* __restrict__ g2,
+                                                        const float* __restrict__ b2, float* __restrict__ y,
+                                                        float* __restrict__ y2, int rows, float eps) {
+    constexpr int E = VPT * 64;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t base = (int64_t)row * E;
+    float v[VPT];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int e = lane + 64 * i;
+        float t = x ? x[base + e] : 0.f;
+        for (int s = 0; s < n_parts; ++s) t += parts[(int64_t)s * part_stride + base + e];
+        if (bias) t += bias[e];
+        v[i] = t;
+    }
+    auto ln = [&](const float* __restrict__ g, const float* __restrict__ b) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) s += v[i];
+        const float mean = wave_sum(s) * (1.0f / E);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const float d = v[i] - mean;
+            q += d * d;
+        }
+        const float var = wave_sum(q) * (1.0f / E);
+        const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int e = lane + 64 * i;
+            v[i] = (v[i] - mean) * rstd * g[e] + b[e];
+        }
+    };
+    ln(g1, b1);
+    if (l2norm) {
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) q += v[i] * v[i];
+        const float nrm = fmaxf(sqrtf(wave_sum(q)), 1e-12f);
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) v[i] = v[i] / nrm;
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) y[base + lane + 64 * i] = v[i];
+    if (g2) {
+        ln(g2, b2);
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) y2[base + lane + 64 * i] = v[i];
+    }
+}
+
+// ---- GroupNorm --------------------------------------------------------------------------------
+// stats[b][c] = (sum, sumsq) in double: lane = channel, waves stride over pixels, one double
+// atomic per (block, channel).  Double accumulation keeps E[x^2]-E[x]^2 well conditioned and makes
+// the result insensitive to the (unordered) atomic arrival order at fp32 precision.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, double* __restrict__ stats,
+                                                       int HW, int C, int pix_per_block) {
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * pix_per_block;
+    const int p1 = min(HW, p0 + pix_per_block);
+    const int lanes_c = C;  // C <= 256 channels, thread t handles channel t % C, pixel stream t / C
+    const int streams = 256 / lanes_c;
+    const int c = threadIdx.x % lanes_c, s = threadIdx.x / lanes_c;
+    double sum = 0.0, sq = 0.0;
+    if (s < streams) {
+        const float* xb = x + ((int64_t)b * HW) * C + c;
+        for (int p = p0 + s; p < p1; p += streams) {
+            const float v = xb[(int64_t)p * C];
+            sum += (double)v;
+            sq += (double)v * (double)v;
+        }
+    }
+    __shared__ double red[2][256];
+    red[0][threadIdx.x] = sum;
+    red[1][threadIdx.x] = sq;
+    __syncthreads();
+    if (s == 0) {
+        for (int k = 1; k < streams; ++k) {
+            sum += red[0][k * lanes_c + c];
+            sq += red[1][k * lanes_c + c];
+        }
+        double* d = stats + ((int64_t)b * C + c) * 2;
+        atomicAdd(d, sum);
+        atomicAdd(d + 1, sq);
+    }
+}
+
+__device__ __forceinline__ void bilin_src(int dst, int in, int out, int& i0, int& i1, float& l1) {
+    // PyTorch area_pixel_compute_source_index, align_corners=False
+    const float scale = (float)in / (float)out;
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src;
+    i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+    l1 = src - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ up, int uh, int uw,
+                                                       float* __restrict__ y, int H, int W, int C, int groups,
+                                                       float eps, int relu) {
+    const int b = blockIdx.y;
+    const int HW = H * W;
+    const int cpg = C / groups;
+    const int64_t total = (int64_t)HW * C;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const int p = (int)(idx / C);
+        const int g0 = (c / cpg) * cpg;
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < cpg; ++k) {
+            s += stats[((int64_t)b * C + g0 + k) * 2];
+            q += stats[((int64_t)b * C + g0 + k) * 2 + 1];
+        }
+        const double cnt = (double)cpg * (double)HW;
+        const double mean = s / cnt;
+        double var = q / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        float v = (x[(int64_t)b * total + idx] - (float)mean) * rstd * gamma[c] + beta[c];
+        if (up) {
+            const int yy = p / W, xx = p - yy * W;
+            int y0, y1, x0, x1;
+            float ly, lx;
+            bilin_src(yy, uh, H, y0, y1, ly);
+            bilin_src(xx, uw, W, x0, x1, lx);
+            const float* ub = up + (int64_t)b * uh * uw * C + c;
+            const float v00 = ub[((int64_t)y0 * uw + x0) * C], v01 = ub[((int64_t)y0 * uw + x1) * C];
+            const float v10 = ub[((int64_t)y1 * uw + x0) * C], v11 = ub[((int64_t)y1 * uw + x1) * C];
+            const float hy = 1.f - ly, hx = 1.f - lx;
+            v += hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+        }
+        if (relu) v = fmaxf(v, 0.f);
+        y[(int64_t)b * total + idx] = v;
+    }
+}
+
+// ---- position encoding -------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pos_embed_kernel(float* __restrict__ out, int H, int W, int npf, int64_t s_c,
+                                                        int64_t s_p, const float* __restrict__ add_c,
+                                                        float temperature, float scale) {
+    const int64_t total = (int64_t)H * W * 2 * npf;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        // idx = p * (2*npf) + c  (channel fastest: coalesced for token-major outputs)
+        const int c = (int)(idx % (2 * npf));
+        const int p = (int)(idx / (2 * npf));
+        const int yy = p / W, xx = p - yy * W;
+        const bool is_y = c < npf;
+        const int i = is_y ? c : c - npf;
+        const float eps = 1e-6f;
+        const float e = is_y ? ((float)(yy + 1) / ((float)H + eps) * scale) : ((float)(xx + 1) / ((float)W + eps) * scale);
+        const float dim_t = powf(temperature, (float)(2 * (i / 2)) / (float)npf);
+        const float a = e / dim_t;
+        float v = (i & 1) ? cosf(a) : sinf(a);
+        if (add_c) v += add_c[c];
+        out[(int64_t)c * s_c + (int64_t)p * s_p] = v;
+    }
+}
+
+// ---- transpose ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const float* ib = in + (int64_t)b * R * C;
+    float* ob = out + (int64_t)b * R * C;
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        tile[k][tx] = (r < R && c < C) ? ib[(int64_t)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + tx;
+        if (r < R && c < C) ob[(int64_t)c * R + r] = tile[tx][k];
+    }
+}
+
+}  // namespace msm
+
+using namespace msm;
+
+extern "C" int msm_layernorm_f32(const float* x, const float* parts, int n_parts, int64_t part_stride,
+                                 const float* bias, const float* g1, const float* b1, int l2norm,
+                                 const float* g2, const float* b2, float* y, float* y2,
+                                 int rows, int E, float eps, void* stream) {
+    MSM_REQUIRE(g1 && b1 && y, "msm_layernorm_f32: null pointer");
+    MSM_REQUIRE(rows > 0, "msm_layernorm_f32: rows=%d", rows);
+    MSM_REQUIRE(n_parts == 0 || parts, "msm_layernorm_f32: parts missing");
+    MSM_REQUIRE(!g2 || (b2 && y2), "msm_layernorm_f32: second norm needs b2 and y2");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(cdiv(rows, 4)), block(256);
+#define LN_CASE(V)                                                                                             \
+    hipLaunchKernelGGL((layernorm_kernel<V>), grid, block, 0, st, x, parts, n_parts, part_stride, bias, g1, b1, \
+                       l2norm, g2, b2, y, y2, rows, eps)
+    switch (E) {
+        case 64: LN_CASE(1); break;
+        case 128: LN_CASE(2); break;
+        case 256: LN_CASE(4); break;
+        case 512: LN_CASE(8); break;
+        default: MSM_REQUIRE(false, "msm_layernorm_f32: unsupported E=%d", E);
+    }
+#undef LN_CASE
+    MSM_CHECK_LAUNCH("msm_layernorm_f32");
+    return MSM_OK;
+}
+
+extern "C" int msm_groupnorm_stats_f32(const float* x, double* stats, int B, int HW, int C, void* stream) {
+    MSM_REQUIRE(x && stats && B > 0 && HW > 0, "msm_groupnorm_stats_f32: bad arguments");
+    MSM_REQUIRE(C > 0 && C <= 256 && 256 % C == 0, "msm_groupnorm_stats_f32: C=%d must divide 256", C);
+    hipStream_t st = (hipStream_t)stream;
+    MSM_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * (size_t)B * C, st));
+    const int ppb = 512;
+    dim3 grid(cdiv(HW, ppb), B), block(256);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, block, 0, st, x, stats, HW, C, ppb);
+    MSM_CHECK_LAUNCH("msm_groupnorm_stats_f32");
+    return MSM_OK;
+}
+
+extern "C" int msm_groupnorm_apply_f32(const float* x, const double* stats, const float* gamma, const float* beta,
+                                       const float* up, int uh, int uw, float* y, int B, int H, int W, int C,
+                                       int groups, float eps, int relu, void* stream) {
+    MSM_REQUIRE(x && stats && gamma && beta && y, "msm_groupnorm_apply_f32: null pointer");
+    MSM_REQUIRE(groups > 0 && C % groups == 0, "msm_groupnorm_apply_f32: C=%d groups=%d", C, groups);
+    MSM_REQUIRE(!up || (uh > 0 && uw > 0), "msm_groupnorm_apply_f32: bad upsample source size");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = (int64_t)H * W * C;
+    dim3 grid((unsigned)min((int64_t)2048, (total + 255) / 256), B), block(256);
+    hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, st, x, stats, gamma, beta, up, uh, uw, y, H, W, C, groups, eps,
+                       relu);
+    MSM_CHECK_LAUNCH("msm_groupnorm_apply_f32");
+    return MSM_OK;
+}
+
+extern "C" int msm_pos_embed_sine(float* out, int H, int W, int npf, int64_t s_c, int64_t s_p, const float* add_c,
+                                  float temperature, float scale, void* stream) {
+    MSM_REQUIRE(out && H > 0 && W > 0 && npf > 0, "msm_pos_embed_sine: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = (int64_t)H * W * 2 * npf;
+    dim3 grid((unsigned)min((int64_t)2048, (total + 255) / 256)), block(256);
+    hipLaunchKernelGGL(pos_embed_kernel, grid, block, 0, st, out, H, W, npf, s_c, s_p, add_c, temperature, scale);
+    MSM_CHECK_LAUNCH("msm_pos_embed_sine");
+    return MSM_OK;
+}
+
+extern "C" int msm_transpose_f32(const float* in, float* out, int B, int R, int C, void* stream) {
+    MSM_REQUIRE(in && out && B > 0 && R > 0 && C > 0, "msm_transpose_f32: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(cdiv(C, 32), cdiv(R, 32), B), block(256);
+    hipLaunchKernelGGL(transpose_kernel, grid, block, 0, st, in, out, R, C);
+    MSM_CHECK_LAUNCH("msm_transpose_f32");
+    return MSM_OK;
+}

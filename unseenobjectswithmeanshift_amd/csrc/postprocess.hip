@@ -1,0 +1,165 @@
+// Instance post-processing (see include/msm_hip.h: msm_topk_class_scores, msm_instance_postprocess).
+//
+// Reference: MSMFormer/meanshiftformer/pretrained_meanshiftformer_model.py:337-343 upsamples ALL Q
+// low-resolution masks to image size (123 MB per 640x480 image), :355-376 post-processes them per
+// image and :461-497 (instance_inference) keeps top-k of them, thresholds at 0, scores each mask by
+// its mean sigmoid and takes boxes from the binary masks.  Here the top-k runs first on the tiny
+// class-score matrix and only the T selected masks are upsampled: one pass reads T low-res maps and
+// writes T binary maps (HBM-bound: 32 MB instead of >= 250 MB per image), with the score and box
+// reductions fused into it.
+#include "common.h"
+
+namespace msm {
+
+__global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ logits, int Q, int K1, int T,
+                                                   float* __restrict__ scores_out, int64_t* __restrict__ classes_out,
+                                                   int32_t* __restrict__ qidx_out) {
+    extern __shared__ float sc[];  // Q*K scores
+    const int b = blockIdx.x;
+    const int K = K1 - 1, n = Q * K;
+    const float* lg = logits + (int64_t)b * Q * K1;
+    for (int qi = threadIdx.x; qi < Q; qi += 256) {
+        float mx = -INFINITY;
+        for (int c = 0; c < K1; ++c) mx = fmaxf(mx, lg[qi * K1 + c]);
+        float den = 0.f;
+        for (int c = 0; c < K1; ++c) den += expf(lg[qi * K1 + c] - mx);
+        for (int c = 0; c < K; ++c) sc[qi * K + c] = expf(lg[qi * K1 + c] - mx) / den;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float s = sc[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const float o = sc[j];
+            rank += (o > s || (o == s && j < i)) ? 1 : 0;
+        }
+        if (rank < T) {
+            scores_out[(int64_t)b * T + rank] = s;
+            classes_out[(int64_t)b * T + rank] = (int64_t)(i % K);
+            qidx_out[(int64_t)b * T + rank] = i / K;
+        }
+    }
+}
+
+struct InstAcc {          // 32 bytes per (image, instance)
+    double sum_sig;
+    unsigned int cnt;
+    int xmin, ymin, xmax, ymax;
+    int pad;
+};
+
+__device__ __forceinline__ void src_index(int dst, float scale, int in, int& i0, int& i1, float& l1) {
+    float src = scale * ((float)dst + 0.5f) - 0.5f;   // align_corners=False
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src;
+    i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+    l1 = src - (float)i0;
+}
+
+// grid (tiles_x, rows/ROWS, B*T); each block upsamples a strip of the selected mask
+__global__ __launch_bounds__(256) void inst_upsample_kernel(const float* __restrict__ logits, const int32_t* __restrict__ qidx,
+                                                            float* __restrict__ masks, InstAcc* __restrict__ acc, int Q, int T,
+                                                            int h, int w, int H, int W, int rows_per_block) {
+    const int bt = blockIdx.z;
+    const int b = bt / T;
+    const int q = qidx[bt];
+    const float* src = logits + ((int64_t)b * Q + q) * h * w;
+    float* dst = masks + (int64_t)bt * H * W;
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    const int y0 = blockIdx.y * rows_per_block, y1 = min(H, y0 + rows_per_block);
+    double sum = 0.0;
+    unsigned int cnt = 0;
+    int xmin = 0x7fffffff, ymin = 0x7fffffff, xmax = -1, ymax = -1;
+    for (int y = y0; y < y1; ++y) {
+        int ya, yb;
+        float ly;
+        src_index(y, sy, h, ya, yb, ly);
+        const float hy = 1.f - ly;
+        for (int x = blockIdx.x * 256 + threadIdx.x; x < W; x += gridDim.x * 256) {
+            int xa, xb;
+            float lx;
+            src_index(x, sx, w, xa, xb, lx);
+            const float hx = 1.f - lx;
+            const float m = hy * (hx * src[ya * w + xa] + lx * src[ya * w + xb]) +
+                            ly * (hx * src[yb * w + xa] + lx * src[yb * w + xb]);
+            const bool on = m > 0.f;
+            dst[(int64_t)y * W + x] = on ? 1.f : 0.f;
+            if (on) {
+                sum += (double)(1.0f / (1.0f + expf(-m)));
+                cnt += 1;
+                xmin = min(xmin, x); xmax = max(xmax, x);
+                ymin = min(ymin, y); ymax = max(ymax, y);
+            }
+        }
+    }
+    // wave reduce, then one set of atomics per wave
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sum += __shfl_xor(sum, o, 64);
+        cnt += __shfl_xor(cnt, o, 64);
+        xmin = min(xmin, __shfl_xor(xmin, o, 64));
+        ymin = min(ymin, __shfl_xor(ymin, o, 64));
+        xmax = max(xmax, __shfl_xor(xmax, o, 64));
+        ymax = max(ymax, __shfl_xor(ymax, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && cnt > 0) {
+        InstAcc* a = acc + bt;
+        atomicAdd(&a->sum_sig, sum);
+        atomicAdd(&a->cnt, cnt);
+        atomicMin(&a->xmin, xmin);
+        atomicMin(&a->ymin, ymin);
+        atomicMax(&a->xmax, xmax);
+        atomicMax(&a->ymax, ymax);
+    }
+}
+
+__global__ void inst_init_kernel(InstAcc* __restrict__ acc, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) acc[i] = InstAcc{0.0, 0u, 0x7fffffff, 0x7fffffff, -1, -1, 0};
+}
+
+__global__ void inst_finish_kernel(const InstAcc* __restrict__ acc, float* __restrict__ score, float* __restrict__ boxes, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const InstAcc a = acc[i];
+    score[i] = (float)a.sum_sig / ((float)a.cnt + 1e-6f);
+    float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.cnt > 0) bx = make_float4((float)a.xmin, (float)a.ymin, (float)(a.xmax + 1), (float)(a.ymax + 1));
+    reinterpret_cast<float4*>(boxes)[i] = bx;
+}
+
+}  // namespace msm
+
+using namespace msm;
+
+extern "C" int msm_topk_class_scores(const float* pred_logits, int B, int Q, int K1, int T, float* scores_out,
+                                     int64_t* classes_out, int32_t* query_index_out, void* stream) {
+    MSM_REQUIRE(pred_logits && scores_out && classes_out && query_index_out, "msm_topk_class_scores: null pointer");
+    MSM_REQUIRE(B > 0 && Q > 0 && K1 >= 2, "msm_topk_class_scores: bad sizes");
+    const int n = Q * (K1 - 1);
+    MSM_REQUIRE(n <= 4096 && T > 0 && T <= n, "msm_topk_class_scores: need T <= Q*K <= 4096 (T=%d, Q*K=%d)", T, n);
+    hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(256), sizeof(float) * n, (hipStream_t)stream, pred_logits, Q, K1, T,
+                       scores_out, classes_out, query_index_out);
+    MSM_CHECK_LAUNCH("msm_topk_class_scores");
+    return MSM_OK;
+}
+
+extern "C" int msm_instance_postprocess(const float* mask_logits, const int32_t* query_index, float* pred_masks,
+                                        float* mask_score, float* boxes, int B, int Q, int T, int h, int w, int H, int W,
+                                        float* workspace, void* stream) {
+    MSM_REQUIRE(mask_logits && query_index && pred_masks && mask_score && boxes && workspace,
+                "msm_instance_postprocess: null pointer");
+    MSM_REQUIRE(B > 0 && Q > 0 && T > 0 && h > 0 && w > 0 && H > 0 && W > 0, "msm_instance_postprocess: bad sizes");
+    MSM_REQUIRE((((uintptr_t)workspace) & 7) == 0 && (((uintptr_t)boxes) & 15) == 0, "msm_instance_postprocess: misaligned pointer");
+    hipStream_t st = (hipStream_t)stream;
+    InstAcc* acc = reinterpret_cast<InstAcc*>(workspace);
+    const int n = B * T;
+    hipLaunchKernelGGL(inst_init_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, acc, n);
+    const int rows = 16;
+    dim3 grid(cdiv(W, 256), cdiv(H, rows), n);
+    hipLaunchKernelGGL(inst_upsample_kernel, grid, dim3(256), 0, st, mask_logits, query_index, pred_masks, acc, Q, T, h, w, H,
+                       W, rows);
+    hipLaunchKernelGGL(inst_finish_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, acc, mask_score, boxes, n);
+    MSM_CHECK_LAUNCH("msm_instance_postprocess");
+    return MSM_OK;
+}

@@ -1,0 +1,537 @@
+"""Host-side mirror of the reference's hot-path modules, running on the HIP kernels.
+
+Same class names, constructor keyword arguments, ``forward`` signatures, return structures and
+``state_dict()`` keys/shapes as the reference (so reference checkpoints load with strict=True):
+
+  PositionEmbeddingSine            <- transformer_decoder/position_encoding.py:12-52
+  MeanShiftAttention               <- transformer_decoder/attention_util.py:434-540
+  hypersphere_attention            <- transformer_decoder/attention_util.py:30-82
+  MeanShiftTransformerDecoder      <- transformer_decoder/meanshiftformer_transformer_decoder.py:343-695
+  MSDeformAttn                     <- pixel_decoder/ops/modules/ms_deform_attn.py:34-125
+  MSDeformAttnPixelDecoder         <- pixel_decoder/msdeformattn.py:164-358
+
+Inference only (no autograd through the kernels).  torch supplies parameters, device memory and
+streams; all arithmetic is in libmsm_hip.so.  Internally tokens are batch-major (B, L, E); the
+reference's (L, B, E) layout appears only at the MeanShiftAttention API boundary.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+
+KAPPA = 30  # attention_util.py:26
+
+
+class ShapeSpec:
+    """Stand-in for detectron2.layers.ShapeSpec (channels / stride of a backbone feature)."""
+
+    def __init__(self, channels=None, height=None, width=None, stride=None):
+        self.channels, self.height, self.width, self.stride = channels, height, width, stride
+
+
+# ----------------------------------------------------------------------------------------------
+class PositionEmbeddingSine(nn.Module):
+    def __init__(self, num_pos_feats=64, temperature=10000, normalize=False, scale=None):
+        super().__init__()
+        if scale is not None and normalize is False:
+            raise ValueError("normalize should be True if scale is passed")
+        if not normalize:
+            raise NotImplementedError("the hot path only uses normalize=True (DEC:415, MSD:241)")
+        self.num_pos_feats = num_pos_feats
+        self.temperature = temperature
+        self.normalize = normalize
+        self.scale = 2 * math.pi if scale is None else scale
+
+    def forward(self, x, mask=None):
+        if mask is not None:
+            raise NotImplementedError("padding masks are not used by the MSMFormer configs")
+        B, _, H, W = x.shape
+        pe = ops.pos_embed_sine(H, W, self.num_pos_feats, x.device, temperature=float(self.temperature),
+                                scale=float(self.scale))
+        return pe[None].expand(B, -1, -1, -1)
+
+
+# ----------------------------------------------------------------------------------------------
+def hypersphere_attention(q, k, v, attn_mask=None, dropout_p=0.0, kappa=KAPPA):
+    """Single-head form of attention_util.py:30-82 for (B, Nt, E=32*h) tensors is provided through
+    MeanShiftAttention; this functional entry point takes the reference's per-head layout
+    q (B*h, Nt, 32), k/v (B*h, Ns, 32) and a float mask with -inf entries, and returns the attended
+    values only (the (B*h, Nt, Ns) weights are never materialised)."""
+    if dropout_p > 0.0:
+        raise NotImplementedError("inference only")
+    Bh, Nt, E = q.shape
+    if E != 32:
+        raise RuntimeError("head_dim must be 32")
+    masked = row_any = None
+    if attn_mask is not None:
+        masked = (attn_mask == float("-inf")).to(torch.uint8).contiguous()
+        row_any = torch.ones((Bh, Nt), device=q.device, dtype=torch.int32)
+    return ops.hypersphere_attention(q.contiguous(), k.contiguous(), v.contiguous(), 1, masked=masked,
+                                     row_any=row_any, kappa=float(kappa))
+
+
+class MeanShiftAttention(nn.Module):
+    """Parameters laid out as nn.MultiheadAttention(embed_dim, num_heads) (attention_util.py:469-472):
+    in_proj_weight (3E,E), in_proj_bias (3E), out_proj.{weight,bias}."""
+
+    def __init__(self, embed_dim, num_heads=1, dropout=0., bias=True, add_bias_kv=False, add_zero_attn=False,
+                 kdim=None, vdim=None, batch_first=False, device=None, dtype=None):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.batch_first = False
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.constant_(self.out_proj.bias, 0.)
+
+    # batch-major core used by the decoder: everything (B, L, E)
+    def attend(self, tgt, memory_k, memory_v, *, query_pos=None, key_pos=None, masked=None, row_any=None,
+               kv=None):
+        E = self.embed_dim
+        w, b = self.in_proj_weight, self.in_proj_bias
+        q = ops.gemm(tgt, w[:E], b[:E], a2=query_pos)
+        if kv is None:
+            k = ops.gemm(memory_k, w[E:2 * E], b[E:2 * E], a2=key_pos)
+            v = ops.gemm(memory_v, w[2 * E:], b[2 * E:])
+        else:
+            k, v = kv
+        o = ops.hypersphere_attention(q, k, v, self.num_heads, masked=masked, row_any=row_any, kappa=float(KAPPA))
+        return ops.gemm(o, self.out_proj.weight, self.out_proj.bias)
+
+    def project_kv(self, memory, pos):
+        E = self.embed_dim
+        w, b = self.in_proj_weight, self.in_proj_bias
+        return ops.gemm(memory, w[E:2 * E], b[E:2 * E], a2=pos), ops.gemm(memory, w[2 * E:], b[2 * E:])
+
+    @torch.no_grad()
+    def forward(self, query, key, value, key_padding_mask=None, need_weights=True, attn_mask=None):
+        """Reference signature (attention_util.py:474-540): (L,N,E) / (S,N,E) inputs, bool attn_mask
+        (N*h, L, S) -- must be identical across the heads of one batch element, as the decoder
+        builds it (DEC:678).  Returns (attn_output (L,N,E), None): averaged weights are never built."""
+        if key_padding_mask is not None:
+            raise NotImplementedError("key_padding_mask is unused by the MSMFormer decoder (DEC:622)")
+        L, N, E = query.shape
+        S = key.shape[0]
+        q = query.transpose(0, 1).contiguous()
+        k = key.transpose(0, 1).contiguous()
+        v = value.transpose(0, 1).contiguous()
+        masked = row_any = None
+        if attn_mask is not None:
+            if attn_mask.dtype != torch.bool:
+                raise NotImplementedError("only bool attention masks")
+            m = attn_mask.view(N, self.num_heads, L, S)
+            masked = m[:, 0].to(torch.uint8).contiguous()
+            row_any = torch.ones((N, L), device=query.device, dtype=torch.int32)
+        out = self.attend(q, k, v, masked=masked, row_any=row_any)
+        return out.transpose(0, 1), None
+
+
+# ----------------------------------------------------------------------------------------------
+class MeanShiftCrossAttentionLayer(nn.Module):
+    def __init__(self, d_model, nhead=1, dropout=0.0, activation="relu", layer_normalize_before=False):
+        super().__init__()
+        if layer_normalize_before:
+            raise NotImplementedError("PRE_NORM=False in every MSMFormer config")
+        self.meanshift_attn = MeanShiftAttention(d_model, nhead)
+        self.norm = nn.LayerNorm(d_model)
+
+
+class MeanShiftSelfAttentionLayer(nn.Module):
+    def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False):
+        super().__init__()
+        if normalize_before:
+            raise NotImplementedError("PRE_NORM=False in every MSMFormer config")
+        self.self_attn = MeanShiftAttention(d_model, nhead)
+        self.norm = nn.LayerNorm(d_model)
+
+
+class FFNLayer(nn.Module):
+    def __init__(self, d_model, dim_feedforward=2048, dropout=0.0, activation="relu", normalize_before=False):
+        super().__init__()
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm = nn.LayerNorm(d_model)
+
+
+class MLP(nn.Module):
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        h = [hidden_dim] * (num_layers - 1)
+        self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = ops.gemm(x, layer.weight, layer.bias, act="relu" if i < self.num_layers - 1 else None)
+        return x
+
+
+class MeanShiftTransformerDecoder(nn.Module):
+    """meanshiftformer_transformer_decoder.py:343-695.  Only the configuration every MSMFormer yaml
+    selects is implemented (post-norm, mean-shift cross + self attention, attention masks on):
+    anything else raises at construction.
+
+    ``aux_outputs``: inference consumes only the last prediction (pretrained_meanshiftformer_model.py:
+    335-345), so by default the 9 intermediate (B,Q,H,W) masks are computed in registers for the
+    attention-mask bits but never written; set ``self.aux_outputs = True`` to get the reference's
+    full list.  ``self.sparse_taps = True`` additionally skips mask rows that feed no 2x2 tap."""
+
+    _version = 2
+
+    def __init__(self, in_channels, mask_classification=True, *, num_classes, hidden_dim, num_queries, nheads,
+                 dim_feedforward, dec_layers, pre_norm, mask_dim, enforce_input_project,
+                 use_meanshift_cross_attention=True, disable_attention_mask=False,
+                 use_meanshift_self_attention=True, decoder_block_norm=True):
+        super().__init__()
+        assert mask_classification, "Only support mask classification model"
+        if pre_norm or not use_meanshift_cross_attention or not use_meanshift_self_attention or disable_attention_mask:
+            raise NotImplementedError("only PRE_NORM=False with mean-shift cross/self attention and attention masks")
+        if hidden_dim % nheads or hidden_dim // nheads != 32:
+            raise NotImplementedError("head_dim must be 32 (HIDDEN_DIM 256 / NHEADS 8)")
+        self.mask_classification = mask_classification
+        self.num_heads = nheads
+        self.num_layers = dec_layers
+        self.num_queries = num_queries
+        self.decoder_block_norm = decoder_block_norm
+        self.num_feature_levels = 3
+        self.aux_outputs = False
+        self.sparse_taps = False
+        self.pe_layer = PositionEmbeddingSine(hidden_dim // 2, normalize=True)
+        self.transformer_self_attention_layers = nn.ModuleList(
+            MeanShiftSelfAttentionLayer(hidden_dim, nheads) for _ in range(dec_layers))
+        self.transformer_cross_attention_layers = nn.ModuleList(
+            MeanShiftCrossAttentionLayer(hidden_dim, nheads) for _ in range(dec_layers))
+        self.transformer_ffn_layers = nn.ModuleList(
+            FFNLayer(hidden_dim, dim_feedforward) for _ in range(dec_layers))
+        self.decoder_norm = nn.LayerNorm(hidden_dim)
+        self.query_feat = nn.Embedding(num_queries, hidden_dim)
+        self.query_embed = nn.Embedding(num_queries, hidden_dim)
+        self.level_embed = nn.Embedding(self.num_feature_levels, hidden_dim)
+        self.input_proj = nn.ModuleList()
+        for _ in range(self.num_feature_levels):
+            if in_channels != hidden_dim or enforce_input_project:
+                self.input_proj.append(nn.Conv2d(in_channels, hidden_dim, kernel_size=1))
+            else:
+                self.input_proj.append(nn.Sequential())
+        self.class_embed = nn.Linear(hidden_dim, num_classes + 1)
+        self.mask_embed = MLP(hidden_dim, hidden_dim, mask_dim, 3)
+        self._pos_cache = {}
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        # v1 -> v2 key migration, as the reference (DEC:348-369)
+        version = local_metadata.get("version", None)
+        if version is None or version < 2:
+            for k in list(state_dict.keys()):
+                if k.startswith(prefix) and "static_query" in k:
+                    state_dict[k.replace("static_query", "query_feat")] = state_dict.pop(k)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+
+    @classmethod
+    def from_config(cls, cfg, in_channels, mask_classification):
+        """cfg: any object with the reference's yacs attribute paths (DEC:510-538)."""
+        mf, sh = cfg.MODEL.MASK_FORMER, cfg.MODEL.SEM_SEG_HEAD
+        assert mf.DEC_LAYERS >= 1
+        return dict(in_channels=in_channels, mask_classification=mask_classification,
+                    num_classes=sh.NUM_CLASSES, hidden_dim=mf.HIDDEN_DIM, num_queries=mf.NUM_OBJECT_QUERIES,
+                    nheads=mf.NHEADS, dim_feedforward=mf.DIM_FEEDFORWARD, dec_layers=mf.DEC_LAYERS - 1,
+                    pre_norm=mf.PRE_NORM, enforce_input_project=mf.ENFORCE_INPUT_PROJ, mask_dim=sh.MASK_DIM,
+                    use_meanshift_cross_attention=mf.USE_MEANSHIFT_CROSS_ATTENTION,
+                    disable_attention_mask=mf.DISABLE_MEANSHIFT_ATTENTION_MASK,
+                    use_meanshift_self_attention=mf.USE_MEANSHIFT_SELF_ATTENTION,
+                    decoder_block_norm=mf.DECODER_BLOCK_NORM)
+
+    def _pos_tokens(self, h, w, device):
+        key = (h, w, str(device))
+        if key not in self._pos_cache:
+            self._pos_cache[key] = ops.pos_embed_sine(h, w, self.pe_layer.num_pos_feats, device, layout="tokens",
+                                                      temperature=float(self.pe_layer.temperature),
+                                                      scale=float(self.pe_layer.scale))
+        return self._pos_cache[key]
+
+    def _heads(self, d, mask_features, target_size, want_mask, want_cls):
+        cls = ops.gemm(d, self.class_embed.weight, self.class_embed.bias) if want_cls else None
+        e = self.mask_embed(d)
+        mask, attn, row_any = ops.mask_logits(e, mask_features, want_mask=want_mask, target_size=target_size,
+                                              sparse=self.sparse_taps)
+        return cls, mask, attn, row_any
+
+    @torch.no_grad()
+    def forward(self, x, mask_features, mask=None):
+        assert len(x) == self.num_feature_levels
+        del mask
+        B = x[0].shape[0]
+        dev = x[0].device
+        E = self.query_feat.weight.shape[1]
+        src, pos, sizes = [], [], []
+        for i in range(self.num_feature_levels):
+            h, w = x[i].shape[-2:]
+            sizes.append((int(h), int(w)))
+            pos.append(self._pos_tokens(int(h), int(w), dev))
+            xi = x[i].contiguous()
+            if isinstance(self.input_proj[i], nn.Conv2d):
+                wt = self.input_proj[i].weight.view(E, -1)
+                bias = self.input_proj[i].bias + self.level_embed.weight[i]          # DEC:575
+                src.append(ops.conv1x1_nchw_to_tokens(xi, wt, bias.contiguous()))
+            else:
+                t = ops.transpose_last2(xi.flatten(2))
+                src.append(t + self.level_embed.weight[i])
+        mask_features = mask_features.contiguous()
+        qpos = self.query_embed.weight
+        out = self.query_feat.weight[None].expand(B, -1, -1).contiguous()
+        full = self.aux_outputs
+        L = self.num_layers
+        pred_cls, pred_mask = [], []
+        d = ops.layernorm(out, self.decoder_norm.weight, self.decoder_norm.bias)
+        cls, m, attn, row_any = self._heads(d, mask_features, sizes[0], full or L == 0, full or L == 0)
+        pred_cls.append(cls)
+        pred_mask.append(m)
+        for i in range(L):
+            lvl = i % self.num_feature_levels                                     # DEC:608
+            ca = self.transformer_cross_attention_layers[i]
+            t2 = ca.meanshift_attn.attend(out, src[lvl], src[lvl], query_pos=qpos, key_pos=pos[lvl],
+                                          masked=attn, row_any=row_any)
+            out = ops.layernorm(out, ca.norm.weight, ca.norm.bias, parts=t2[None])
+            sa = self.transformer_self_attention_layers[i]
+            w, b = sa.self_attn.in_proj_weight, sa.self_attn.in_proj_bias
+            qk = ops.gemm(out, w[:2 * E], b[:2 * E], a2=qpos)                      # q and k share tgt + query_pos
+            v = ops.gemm(out, w[2 * E:], b[2 * E:])
+            o = ops.hypersphere_attention(qk[..., :E], qk[..., E:], v, self.num_heads, kappa=float(KAPPA))
+            t2 = ops.gemm(o, sa.self_attn.out_proj.weight, sa.self_attn.out_proj.bias)
+            out = ops.layernorm(out, sa.norm.weight, sa.norm.bias, parts=t2[None])
+            ff = self.transformer_ffn_layers[i]
+            hdn = ops.gemm(out, ff.linear1.weight, ff.linear1.bias, act="relu")
+            parts = ops.gemm(hdn, ff.linear2.weight, split_k=8 if ff.linear2.weight.shape[1] >= 1024 else 1)
+            if parts.dim() == 3:
+                parts = parts[None]
+            out, d = ops.layernorm(out, ff.norm.weight, ff.norm.bias, parts=parts, bias=ff.linear2.bias,
+                                   l2norm=self.decoder_block_norm, g2=self.decoder_norm.weight,
+                                   b2=self.decoder_norm.bias)
+            last = i == L - 1
+            tgt = None if (last and not full) else sizes[(i + 1) % self.num_feature_levels]
+            cls, m, attn, row_any = self._heads(d, mask_features, tgt, full or last, full or last)
+            pred_cls.append(cls)
+            pred_mask.append(m)
+        res = {"pred_logits": pred_cls[-1], "pred_masks": pred_mask[-1], "aux_outputs": []}
+        if full:
+            res["aux_outputs"] = [{"pred_logits": a, "pred_masks": b} for a, b in zip(pred_cls[:-1], pred_mask[:-1])]
+        return res
+
+
+# ----------------------------------------------------------------------------------------------
+class MSDeformAttn(nn.Module):
+    """ops/modules/ms_deform_attn.py:34-125 with the same parameters; forward takes the reference's
+    arguments.  The encoder calls ``forward_encoder`` (fused sampling arithmetic) instead."""
+
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError("d_model must be divisible by n_heads, but got {} and {}".format(d_model, n_heads))
+        self.im2col_step = 128
+        self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        nn.init.constant_(self.sampling_offsets.weight.data, 0.)
+        thetas = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
+        grid = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(self.n_heads, 1, 1, 2).repeat(
+            1, self.n_levels, self.n_points, 1)
+        for i in range(self.n_points):
+            grid[:, :, i, :] *= i + 1
+        with torch.no_grad():
+            self.sampling_offsets.bias = nn.Parameter(grid.view(-1))
+        nn.init.constant_(self.attention_weights.weight.data, 0.)
+        nn.init.constant_(self.attention_weights.bias.data, 0.)
+        nn.init.xavier_uniform_(self.value_proj.weight.data)
+        nn.init.constant_(self.value_proj.bias.data, 0.)
+        nn.init.xavier_uniform_(self.output_proj.weight.data)
+        nn.init.constant_(self.output_proj.bias.data, 0.)
+
+    def _proj_weights(self):
+        return (torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0).contiguous(),
+                torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0).contiguous())
+
+    def forward_encoder(self, src, lvl_pos, spatial_shapes, level_start_index):
+        """src (N,S,C); query = src + lvl_pos; reference points = pixel centres."""
+        value = ops.gemm(src, self.value_proj.weight, self.value_proj.bias)
+        w, b = self._proj_weights()
+        proj = ops.gemm(src, w, b, a2=lvl_pos)
+        out = ops.ms_deform_attn_encoder(value, spatial_shapes, level_start_index, proj, self.n_heads, self.n_points)
+        return ops.gemm(out, self.output_proj.weight, self.output_proj.bias)
+
+    @torch.no_grad()
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                input_padding_mask=None):
+        if input_padding_mask is not None:
+            raise NotImplementedError("padding masks are not used by the MSMFormer configs")
+        if reference_points.shape[-1] != 2:
+            raise NotImplementedError("only 2-d reference points")
+        N, Lq, _ = query.shape
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+        value = ops.gemm(input_flatten.contiguous(), self.value_proj.weight, self.value_proj.bias)
+        value = value.view(N, -1, M, self.d_model // M)
+        q = query.contiguous()
+        off = ops.gemm(q, self.sampling_offsets.weight, self.sampling_offsets.bias).view(N, Lq, M, L, P, 2)
+        aw = ops.gemm(q, self.attention_weights.weight, self.attention_weights.bias).view(N, Lq, M, L * P)
+        # the small location / softmax glue of the general (non-encoder) form stays in torch
+        aw = torch.softmax(aw, -1).view(N, Lq, M, L, P).contiguous()
+        normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1).to(off.dtype)
+        loc = (reference_points[:, :, None, :, None, :] + off / normalizer[None, None, None, :, None, :]).contiguous()
+        out = ops.ms_deform_attn(value, input_spatial_shapes, input_level_start_index, loc, aw)
+        return ops.gemm(out, self.output_proj.weight, self.output_proj.bias)
+
+
+class MSDeformAttnTransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    def forward_tokens(self, src, lvl_pos, spatial_shapes, level_start_index):
+        a = self.self_attn.forward_encoder(src, lvl_pos, spatial_shapes, level_start_index)
+        src = ops.layernorm(src, self.norm1.weight, self.norm1.bias, parts=a[None])          # MSD:124-126
+        h = ops.gemm(src, self.linear1.weight, self.linear1.bias, act="relu")
+        f = ops.gemm(h, self.linear2.weight, self.linear2.bias)
+        return ops.layernorm(src, self.norm2.weight, self.norm2.bias, parts=f[None])         # MSD:116-118
+
+
+class MSDeformAttnTransformerEncoder(nn.Module):
+    def __init__(self, layer_factory, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList(layer_factory() for _ in range(num_layers))
+        self.num_layers = num_layers
+
+
+class MSDeformAttnTransformerEncoderOnly(nn.Module):
+    def __init__(self, d_model=256, nhead=8, num_encoder_layers=6, dim_feedforward=1024, dropout=0.1,
+                 activation="relu", num_feature_levels=4, enc_n_points=4):
+        super().__init__()
+        self.d_model, self.nhead = d_model, nhead
+        self.encoder = MSDeformAttnTransformerEncoder(
+            lambda: MSDeformAttnTransformerEncoderLayer(d_model, dim_feedforward, dropout, activation,
+                                                        num_feature_levels, nhead, enc_n_points),
+            num_encoder_layers)
+        self.level_embed = nn.Parameter(torch.Tensor(num_feature_levels, d_model))
+        nn.init.normal_(self.level_embed)
+
+
+class _ConvNorm(nn.Conv2d):
+    """Parameter container with detectron2's Conv2d naming: .weight (+ .norm.{weight,bias})."""
+
+    def __init__(self, cin, cout, k, bias, norm_channels=None):
+        super().__init__(cin, cout, kernel_size=k, padding=k // 2, bias=bias)
+        self.norm = nn.GroupNorm(32, norm_channels) if norm_channels else None
+
+
+class MSDeformAttnPixelDecoder(nn.Module):
+    """pixel_decoder/msdeformattn.py:164-358 for norm == "GN"."""
+
+    def __init__(self, input_shape, *, transformer_dropout, transformer_nheads, transformer_dim_feedforward,
+                 transformer_enc_layers, conv_dim, mask_dim, norm=None, transformer_in_features, common_stride):
+        super().__init__()
+        if norm != "GN":
+            raise NotImplementedError('only SEM_SEG_HEAD.NORM == "GN"')
+        tis = {k: v for k, v in input_shape.items() if k in transformer_in_features}
+        input_shape = sorted(input_shape.items(), key=lambda x: x[1].stride)
+        self.in_features = [k for k, v in input_shape]
+        self.feature_strides = [v.stride for k, v in input_shape]
+        self.feature_channels = [v.channels for k, v in input_shape]
+        tis = sorted(tis.items(), key=lambda x: x[1].stride)
+        self.transformer_in_features = [k for k, v in tis]
+        t_channels = [v.channels for k, v in tis]
+        self.transformer_feature_strides = [v.stride for k, v in tis]
+        self.transformer_num_feature_levels = len(self.transformer_in_features)
+        self.input_proj = nn.ModuleList(
+            nn.Sequential(nn.Conv2d(c, conv_dim, kernel_size=1), nn.GroupNorm(32, conv_dim)) for c in t_channels[::-1])
+        for proj in self.input_proj:
+            nn.init.xavier_uniform_(proj[0].weight, gain=1)
+            nn.init.constant_(proj[0].bias, 0)
+        self.transformer = MSDeformAttnTransformerEncoderOnly(
+            d_model=conv_dim, dropout=transformer_dropout, nhead=transformer_nheads,
+            dim_feedforward=transformer_dim_feedforward, num_encoder_layers=transformer_enc_layers,
+            num_feature_levels=self.transformer_num_feature_levels)
+        self.pe_layer = PositionEmbeddingSine(conv_dim // 2, normalize=True)
+        self.mask_dim = mask_dim
+        self.conv_dim = conv_dim
+        self.mask_features = nn.Conv2d(conv_dim, mask_dim, kernel_size=1)
+        self.maskformer_num_feature_levels = 3
+        self.common_stride = common_stride
+        stride = min(self.transformer_feature_strides)
+        self.num_fpn_levels = int(math.log2(stride) - math.log2(self.common_stride))
+        if self.num_fpn_levels != 1:
+            raise NotImplementedError("exactly one extra FPN level (res2) is supported")
+        for idx, cin in enumerate(self.feature_channels[:self.num_fpn_levels]):
+            self.add_module("adapter_{}".format(idx + 1), _ConvNorm(cin, conv_dim, 1, False, conv_dim))
+            self.add_module("layer_{}".format(idx + 1), _ConvNorm(conv_dim, conv_dim, 3, False, conv_dim))
+        self._cache = {}
+
+    @classmethod
+    def from_config(cls, cfg, input_shape):
+        sh, mf = cfg.MODEL.SEM_SEG_HEAD, cfg.MODEL.MASK_FORMER
+        return dict(input_shape={k: v for k, v in input_shape.items() if k in sh.IN_FEATURES},
+                    conv_dim=sh.CONVS_DIM, mask_dim=sh.MASK_DIM, norm=sh.NORM, transformer_dropout=mf.DROPOUT,
+                    transformer_nheads=mf.NHEADS, transformer_dim_feedforward=1024,
+                    transformer_enc_layers=sh.TRANSFORMER_ENC_LAYERS,
+                    transformer_in_features=sh.DEFORMABLE_TRANSFORMER_ENCODER_IN_FEATURES,
+                    common_stride=sh.COMMON_STRIDE)
+
+    def _geometry(self, shapes, device):
+        key = (tuple(shapes), str(device))
+        if key not in self._cache:
+            ss = torch.tensor(shapes, dtype=torch.int64, device=device)
+            starts = torch.tensor([0] + list(torch.tensor([h * w for h, w in shapes]).cumsum(0)[:-1].tolist()),
+                                  dtype=torch.int64, device=device)
+            pos = [ops.pos_embed_sine(h, w, self.pe_layer.num_pos_feats, device, layout="tokens",
+                                      add_c=self.transformer.level_embed[l].contiguous())           # MSD:75
+                   for l, (h, w) in enumerate(shapes)]
+            self._cache[key] = (ss, starts, torch.cat(pos, 0).contiguous())
+        return self._cache[key]
+
+    @torch.no_grad()
+    def forward_features(self, features):
+        C = self.conv_dim
+        toks, shapes = [], []
+        for idx, f in enumerate(self.transformer_in_features[::-1]):            # res5, res4, res3
+            x = features[f].float().contiguous()
+            B, _, H, W = x.shape
+            conv, gn = self.input_proj[idx][0], self.input_proj[idx][1]
+            t = ops.conv1x1_nchw_to_tokens(x, conv.weight.view(C, -1), conv.bias)
+            toks.append(ops.groupnorm_tokens(t, gn.weight, gn.bias, H, W, groups=32, eps=gn.eps))
+            shapes.append((int(H), int(W)))
+        dev = toks[0].device
+        ss, starts, lvl_pos = self._geometry(shapes, dev)
+        src = torch.cat(toks, 1).contiguous()                                     # (B,S,C)
+        for layer in self.transformer.encoder.layers:
+            src = layer.forward_tokens(src, lvl_pos, ss, starts)
+        out_tok, out, o = [], [], 0
+        for (h, w) in shapes:
+            t = src[:, o:o + h * w].contiguous()
+            o += h * w
+            out_tok.append(t)
+            out.append(ops.transpose_last2(t).view(B, C, h, w))
+        # one FPN level on the highest-resolution backbone feature (MSD:343-351)
+        x = features[self.in_features[0]].float().contiguous()
+        H, W = int(x.shape[2]), int(x.shape[3])
+        lat = ops.conv1x1_nchw_to_tokens(x, self.adapter_1.weight.view(C, -1), None)
+        y = ops.groupnorm_tokens(lat, self.adapter_1.norm.weight, self.adapter_1.norm.bias, H, W, groups=32,
+                                 up=out_tok[-1], up_hw=shapes[-1], eps=self.adapter_1.norm.eps)
+        w3 = self.layer_1.weight.permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous()
+        y = ops.conv3x3_tokens(y, w3, H, W)
+        y = ops.groupnorm_tokens(y, self.layer_1.norm.weight, self.layer_1.norm.bias, H, W, groups=32, relu=True,
+                                 eps=self.layer_1.norm.eps)
+        mask_features = ops.conv1x1_tokens_to_nchw(y, self.mask_features.weight.view(self.mask_dim, C),
+                                                   self.mask_features.bias).view(B, self.mask_dim, H, W)
+        return mask_features, out[0], out[:self.maskformer_num_feature_levels]

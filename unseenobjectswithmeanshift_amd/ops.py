@@ -1,0 +1,320 @@
+"""Thin torch-tensor front end over the C ABI (include/msm_hip.h).
+
+torch is used for device memory and streams only: every function checks its arguments, allocates
+the outputs with torch.empty on the inputs' device and launches the HIP kernels of libmsm_hip.so
+on torch's current stream.  Tensors must be fp32 and live on a ROCm device; there is no CPU path.
+"""
+import ctypes
+
+import torch
+
+from ._lib import check, lib
+
+KAPPA = 30.0  # attention_util.py:26
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _chk(t, name, dtype=torch.float32):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be on the GPU (no CPU path in unseenobjectswithmeanshift_amd)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+
+
+def _c(t, name, dtype=torch.float32):
+    _chk(t, name, dtype)
+    if t is not None and not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    return t
+
+
+# ----------------------------------------------------------------------------------------------
+def gemm(a, w, bias=None, *, a2=None, act=None, out=None, split_k=1):
+    """out[..., n] = act((a + a2) @ w.T + bias) for row-major a (..., K) and w (N, K).
+    split_k > 1 returns raw partial sums of shape (split_k, ..., N) (bias/act must be None)."""
+    _c(a, "a"), _c(w, "w"), _c(bias, "bias"), _c(a2, "a2")
+    K = a.shape[-1]
+    N = w.shape[0]
+    M = a.numel() // K
+    a2_sb = 0
+    if a2 is not None:
+        if a2.shape == a.shape:
+            batch, Mb = 1, M
+        else:
+            # a2 broadcast over the leading batch dim of a: a (B, L, K), a2 (L, K)
+            if a.dim() != 3 or tuple(a2.shape) != tuple(a.shape[1:]):
+                raise RuntimeError("a2 must match a or a[0]")
+            batch, Mb = a.shape[0], a.shape[1]
+    else:
+        batch, Mb = 1, M
+    lead = a.shape[:-1]
+    if split_k > 1:
+        if bias is not None or act is not None:
+            raise RuntimeError("split_k output is raw: bias/act are applied by the consumer")
+        out = torch.empty((split_k,) + tuple(lead) + (N,), device=a.device, dtype=torch.float32)
+    elif out is None:
+        out = torch.empty(tuple(lead) + (N,), device=a.device, dtype=torch.float32)
+    rc = lib().msm_gemm_f32(_p(a), _p(a2), _p(w), _p(bias), _p(out), Mb, N, K, batch,
+                            K, 1, Mb * K, a2_sb, 0, N, 1, Mb * N, M * N,
+                            0, 0, 0, 0, 1 if bias is not None else 0, 1 if act == "relu" else 0,
+                            split_k, _stream())
+    check(rc, "msm_gemm_f32")
+    return out
+
+
+def conv1x1_nchw_to_tokens(x, w, bias=None):
+    """x (B, Cin, H, W) NCHW -> tokens (B, H*W, Cout) = x^T w^T + bias (a 1x1 Conv2d read through
+    the GEMM's M-contiguous A path; no transpose pass)."""
+    _c(x, "x"), _c(w, "w"), _c(bias, "bias")
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    HW = H * W
+    out = torch.empty((B, HW, Cout), device=x.device, dtype=torch.float32)
+    rc = lib().msm_gemm_f32(_p(x), None, _p(w), _p(bias), _p(out), HW, Cout, Cin, B,
+                            1, HW, Cin * HW, 0, 0, Cout, 1, HW * Cout, 0,
+                            0, 0, 0, 0, 1 if bias is not None else 0, 0, 1, _stream())
+    check(rc, "msm_gemm_f32(conv1x1 nchw)")
+    return out
+
+
+def conv1x1_tokens_to_nchw(t, w, bias=None):
+    """tokens (B, HW, Cin) -> (B, Cout, HW) with the weight as the MFMA A operand so that the
+    NCHW output rows are written contiguously (bias is per output row)."""
+    _c(t, "t"), _c(w, "w"), _c(bias, "bias")
+    B, HW, Cin = t.shape
+    Cout = w.shape[0]
+    out = torch.empty((B, Cout, HW), device=t.device, dtype=torch.float32)
+    # A = w (M=Cout, shared over batch), "W" = tokens of image b ([N=HW][K=Cin])
+    rc = lib().msm_gemm_f32(_p(w), None, _p(t), _p(bias), _p(out), Cout, HW, Cin, B,
+                            Cin, 1, 0, 0, HW * Cin, HW, 1, Cout * HW, 0,
+                            0, 0, 0, 0, 2 if bias is not None else 0, 0, 1, _stream())
+    check(rc, "msm_gemm_f32(conv1x1 to nchw)")
+    return out
+
+
+def conv3x3_tokens(t, w_tap_major, H, W):
+    """3x3 / pad 1 convolution over an NHWC token map t (B, H*W, Cin) with weights permuted to
+    (Cout, 9*Cin) tap-major; returns (B, H*W, Cout).  No bias (the reference layer has a norm)."""
+    _c(t, "t"), _c(w_tap_major, "w")
+    B, HW, Cin = t.shape
+    Cout = w_tap_major.shape[0]
+    out = torch.empty((B, HW, Cout), device=t.device, dtype=torch.float32)
+    rc = lib().msm_gemm_f32(_p(t), None, _p(w_tap_major), None, _p(out), HW, Cout, 9 * Cin, B,
+                            Cin, 1, HW * Cin, 0, 0, Cout, 1, HW * Cout, 0,
+                            2, H, W, Cin, 0, 0, 1, _stream())
+    check(rc, "msm_gemm_f32(conv3x3)")
+    return out
+
+
+def layernorm(x, g1, b1, *, parts=None, bias=None, l2norm=False, g2=None, b2=None, eps=1e-5):
+    """LayerNorm(x + sum(parts) + bias) [-> unit length] [-> second LayerNorm].  Returns y or (y, y2)."""
+    _c(x, "x"), _c(parts, "parts"), _c(bias, "bias"), _c(g1, "g1"), _c(b1, "b1"), _c(g2, "g2"), _c(b2, "b2")
+    ref = x if x is not None else parts[0]
+    E = ref.shape[-1]
+    rows = ref.numel() // E
+    y = torch.empty_like(ref)
+    y2 = torch.empty_like(ref) if g2 is not None else None
+    n_parts = 0 if parts is None else parts.shape[0]
+    rc = lib().msm_layernorm_f32(_p(x), _p(parts), n_parts, rows * E, _p(bias), _p(g1), _p(b1),
+                                 1 if l2norm else 0, _p(g2), _p(b2), _p(y), _p(y2), rows, E, eps, _stream())
+    check(rc, "msm_layernorm_f32")
+    return (y, y2) if g2 is not None else y
+
+
+def groupnorm_tokens(x, gamma, beta, H, W, groups=32, *, up=None, up_hw=None, relu=False, eps=1e-5):
+    """GroupNorm over an NHWC token map x (B, H*W, C); optionally adds the bilinear upsample of
+    `up` (B, uh*uw, C) and applies ReLU."""
+    _c(x, "x"), _c(gamma, "gamma"), _c(beta, "beta"), _c(up, "up")
+    B, HW, C = x.shape
+    stats = torch.empty((B, C, 2), device=x.device, dtype=torch.float64)
+    check(lib().msm_groupnorm_stats_f32(_p(x), _p(stats), B, HW, C, _stream()), "msm_groupnorm_stats_f32")
+    y = torch.empty_like(x)
+    uh, uw = (0, 0) if up is None else up_hw
+    rc = lib().msm_groupnorm_apply_f32(_p(x), _p(stats), _p(gamma), _p(beta), _p(up), uh, uw, _p(y),
+                                       B, H, W, C, groups, eps, 1 if relu else 0, _stream())
+    check(rc, "msm_groupnorm_apply_f32")
+    return y
+
+
+def pos_embed_sine(H, W, num_pos_feats, device, *, layout="nchw", add_c=None, temperature=10000.0,
+                   scale=6.283185307179586):
+    """PositionEmbeddingSine(normalize=True) for one map: (2N, H, W) for layout 'nchw',
+    (H*W, 2N) for 'tokens' (optionally with a per-channel vector added)."""
+    C = 2 * num_pos_feats
+    _c(add_c, "add_c")
+    if layout == "nchw":
+        out = torch.empty((C, H, W), device=device, dtype=torch.float32)
+        s_c, s_p = H * W, 1
+    else:
+        out = torch.empty((H * W, C), device=device, dtype=torch.float32)
+        s_c, s_p = 1, C
+    rc = lib().msm_pos_embed_sine(_p(out), H, W, num_pos_feats, s_c, s_p, _p(add_c), temperature, scale, _stream())
+    check(rc, "msm_pos_embed_sine")
+    return out
+
+
+def transpose_last2(x):
+    """(B, R, C) -> (B, C, R)"""
+    _c(x, "x")
+    B, R, C = x.shape
+    out = torch.empty((B, C, R), device=x.device, dtype=torch.float32)
+    check(lib().msm_transpose_f32(_p(x), _p(out), B, R, C, _stream()), "msm_transpose_f32")
+    return out
+
+
+def mask_logits(mask_embed, mask_features, *, want_mask=True, target_size=None, sparse=False):
+    """einsum('bqc,bchw->bqhw') with the next layer's attention mask fused.
+    Returns (mask (B,Q,H,W) or None, attn (B,Q,th*tw) uint8 or None, row_any (B,Q) int32 or None)."""
+    _c(mask_embed, "mask_embed"), _c(mask_features, "mask_features")
+    B, Q, C = mask_embed.shape
+    _, _, H, W = mask_features.shape
+    dev = mask_embed.device
+    mask = torch.empty((B, Q, H, W), device=dev, dtype=torch.float32) if want_mask else None
+    attn = row_any = None
+    th = tw = 0
+    if target_size is not None:
+        th, tw = int(target_size[0]), int(target_size[1])
+        attn = torch.empty((B, Q, th * tw), device=dev, dtype=torch.uint8)
+        row_any = torch.empty((B, Q), device=dev, dtype=torch.int32)
+    rc = lib().msm_mask_logits_fwd(_p(mask_embed), _p(mask_features), _p(mask), _p(attn), _p(row_any),
+                                   B, Q, C, H, W, th, tw, 1 if sparse else 0, _stream())
+    check(rc, "msm_mask_logits_fwd")
+    return mask, attn, row_any
+
+
+def hypersphere_attention(q, k, v, heads, *, masked=None, row_any=None, kappa=KAPPA):
+    """q (B,Lq,E), k/v (B,S,E) already projected (last dim contiguous, may be column slices of a
+    wider buffer); masked uint8 (B,Lq,S).  Returns (B,Lq,E)."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _chk(t, n)
+        if t.stride(-1) != 1:
+            raise RuntimeError(f"{n}: last dim must be contiguous")
+    _c(masked, "masked", torch.uint8), _c(row_any, "row_any", torch.int32)
+    B, Lq, E = q.shape
+    S = k.shape[1]
+    if E != heads * 32:
+        raise RuntimeError("head_dim must be 32")
+    out = torch.empty((B, Lq, E), device=q.device, dtype=torch.float32)
+    need = lib().msm_hypersphere_attn_workspace(B, Lq, S, heads)
+    ws = torch.empty((need,), device=q.device, dtype=torch.float32)
+    rc = lib().msm_hypersphere_attn_fwd(_p(q), _p(k), _p(v), _p(masked), _p(row_any), _p(out), B, Lq, S, heads,
+                                        q.stride(1), q.stride(0), k.stride(1), k.stride(0), v.stride(1), v.stride(0),
+                                        kappa, _p(ws), need, _stream())
+    check(rc, "msm_hypersphere_attn_fwd")
+    return out
+
+
+def ms_deform_attn(value, spatial_shapes, level_start_index, sampling_locations, attention_weights):
+    """Reference-ABI core op: value (N,S,M,D), shapes (L,2) int64, start (L,) int64,
+    loc (N,Lq,M,L,P,2), w (N,Lq,M,L,P) -> (N,Lq,M*D)."""
+    _c(value, "value"), _c(sampling_locations, "sampling_locations"), _c(attention_weights, "attention_weights")
+    _c(spatial_shapes, "spatial_shapes", torch.int64), _c(level_start_index, "level_start_index", torch.int64)
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = sampling_locations.shape
+    out = torch.empty((N, Lq, M * D), device=value.device, dtype=torch.float32)
+    rc = lib().msm_msdeform_attn_fwd(_p(value), _p(spatial_shapes), _p(level_start_index), _p(sampling_locations),
+                                     _p(attention_weights), _p(out), N, S, M, D, L, Lq, P, _stream())
+    check(rc, "msm_msdeform_attn_fwd")
+    return out
+
+
+def ms_deform_attn_encoder(value, spatial_shapes, level_start_index, proj, heads, n_points):
+    """Encoder self-attention form: value (N,S,C), proj (N,S,heads*L*P*3) raw offsets+logits."""
+    _c(value, "value"), _c(proj, "proj")
+    _c(spatial_shapes, "spatial_shapes", torch.int64), _c(level_start_index, "level_start_index", torch.int64)
+    N, S, C = value.shape
+    L = spatial_shapes.shape[0]
+    out = torch.empty((N, S, C), device=value.device, dtype=torch.float32)
+    rc = lib().msm_msdeform_attn_enc_fwd(_p(value), _p(spatial_shapes), _p(level_start_index), _p(proj), _p(out),
+                                         N, S, heads, C // heads, L, n_points, _stream())
+    check(rc, "msm_msdeform_attn_enc_fwd")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# mean shift (lib/utils/mean_shift.py)
+# ----------------------------------------------------------------------------------------------
+def ms_select_seeds(X, num_seeds, first_index):
+    """Farthest-point seeding.  X (n,64) unit rows.  Returns (seeds (S,64), indices int64 (S,))."""
+    _c(X, "X")
+    n, d = X.shape
+    seeds = torch.empty((num_seeds, d), device=X.device, dtype=torch.float32)
+    idx = torch.empty((num_seeds,), device=X.device, dtype=torch.int64)
+    need = lib().msm_ms_seed_workspace(n)
+    ws = torch.empty((need,), device=X.device, dtype=torch.float32)
+    rc = lib().msm_ms_select_seeds(_p(X), n, d, num_seeds, int(first_index), _p(seeds), _p(idx), _p(ws), need, _stream())
+    check(rc, "msm_ms_select_seeds")
+    return seeds, idx
+
+
+def ms_hill_climb(X, Z, kappa, iters):
+    """iters x { Z = normalize(exp(kappa Z X^T) X) }; returns the updated copy of Z."""
+    _c(X, "X"), _c(Z, "Z")
+    n, d = X.shape
+    S = Z.shape[0]
+    Z = Z.clone()
+    need = lib().msm_ms_hill_climb_workspace(n, S)
+    ws = torch.empty((need,), device=X.device, dtype=torch.float32)
+    rc = lib().msm_ms_hill_climb(_p(X), n, d, _p(Z), S, float(kappa), int(iters), _p(ws), need, _stream())
+    check(rc, "msm_ms_hill_climb")
+    return Z
+
+
+def ms_assign(X, Z, seed_labels, num_labels):
+    """labels[i] = seed_labels[first argmin_s 0.5(1 - X_i.Z_s)], counts = bincount(labels)."""
+    _c(X, "X"), _c(Z, "Z"), _c(seed_labels, "seed_labels", torch.int64)
+    n, d = X.shape
+    labels = torch.empty((n,), device=X.device, dtype=torch.int64)
+    counts = torch.empty((num_labels,), device=X.device, dtype=torch.int64)
+    rc = lib().msm_ms_assign(_p(X), n, d, _p(Z), Z.shape[0], _p(seed_labels), _p(labels), _p(counts), num_labels, _stream())
+    check(rc, "msm_ms_assign")
+    return labels, counts
+
+
+def ms_relabel_largest_zero(labels, counts):
+    _c(labels, "labels", torch.int64), _c(counts, "counts", torch.int64)
+    rc = lib().msm_ms_relabel_largest_zero(_p(labels), labels.numel(), _p(counts), counts.numel(), _stream())
+    check(rc, "msm_ms_relabel_largest_zero")
+    return labels
+
+
+# ----------------------------------------------------------------------------------------------
+# instance post-processing (pretrained_meanshiftformer_model.py:337-343, 461-497)
+# ----------------------------------------------------------------------------------------------
+def topk_class_scores(pred_logits, topk):
+    _c(pred_logits, "pred_logits")
+    B, Q, K1 = pred_logits.shape
+    dev = pred_logits.device
+    scores = torch.empty((B, topk), device=dev, dtype=torch.float32)
+    classes = torch.empty((B, topk), device=dev, dtype=torch.int64)
+    qidx = torch.empty((B, topk), device=dev, dtype=torch.int32)
+    rc = lib().msm_topk_class_scores(_p(pred_logits), B, Q, K1, topk, _p(scores), _p(classes), _p(qidx), _stream())
+    check(rc, "msm_topk_class_scores")
+    return scores, classes, qidx
+
+
+def instance_postprocess(mask_logits, query_index, image_size):
+    """mask_logits (B,Q,h,w), query_index int32 (B,T) -> (pred_masks (B,T,H,W) float 0/1,
+    mask_score (B,T), boxes (B,T,4))."""
+    _c(mask_logits, "mask_logits"), _c(query_index, "query_index", torch.int32)
+    B, Q, h, w = mask_logits.shape
+    T = query_index.shape[1]
+    H, W = int(image_size[0]), int(image_size[1])
+    dev = mask_logits.device
+    masks = torch.empty((B, T, H, W), device=dev, dtype=torch.float32)
+    score = torch.empty((B, T), device=dev, dtype=torch.float32)
+    boxes = torch.empty((B, T, 4), device=dev, dtype=torch.float32)
+    ws = torch.empty((B * T * 8,), device=dev, dtype=torch.float32)
+    rc = lib().msm_instance_postprocess(_p(mask_logits), _p(query_index), _p(masks), _p(score), _p(boxes),
+                                        B, Q, T, h, w, H, W, _p(ws), _stream())
+    check(rc, "msm_instance_postprocess")
+    return masks, score, boxes
