@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""Headline benchmark: MSMFormer inference hot path, images/sec at 640x480, 100 queries, 9 decoder
+layers (BASELINE.json).  One step = one pass of the hot path (MSDeformAttn pixel decoder ->
+hypersphere transformer decoder -> instance post-processing) over one batch of 8 synthetic frames'
+backbone features that are already resident in HBM.  Backbone excluded.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  Weak scaling: every rank processes its own batch of 8 images
+(independent units, no data-path collective); ranks exchange only a small metrics record.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
+H, W, Q, C_MASK, BATCH = 480, 640, 100, 256, 8
+
+
+def build_model(dev):
+    from unseenobjectswithmeanshift_amd import synthetic as syn
+    from unseenobjectswithmeanshift_amd.meta_arch import MeanShiftMaskFormer, build_resnet50_head
+    head = build_resnet50_head(num_queries=Q, dec_layers=9)
+    head.pixel_decoder.load_state_dict(syn.synth_state_dict(syn.pixel_decoder_param_shapes()), strict=True)
+    head.predictor.load_state_dict(syn.synth_state_dict(syn.decoder_param_shapes()), strict=True)
+    return MeanShiftMaskFormer(backbone=None, sem_seg_head=head.to(dev).eval(), num_queries=Q)
+
+
+def cpu_baseline(images=4):
+    """The oracle (CPU port of the reference algorithm, parity-pinned to reference goldens) on
+    the host cores of this box: same synthetic inputs/weights, one warm-up image then `images`
+    timed ones, processed one at a time like the reference predictor (batch 1, test_utils.py:165)."""
+    from oracle import msm_oracle as O
+    from unseenobjectswithmeanshift_amd import synthetic as syn
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    pd_sd = syn.synth_state_dict(syn.pixel_decoder_param_shapes())
+    dec_sd = syn.synth_state_dict(syn.decoder_param_shapes())
+
+    def one(seed):
+        feats = syn.synth_backbone_features(1, H, W, seed=seed)
+        t0 = time.perf_counter()
+        mf, _, ms = O.pixel_decoder_forward(pd_sd, feats)
+        out = O.decoder_forward(dec_sd, ms, mf)
+        O.instance_inference(out["pred_logits"][0], out["pred_masks"][0], (H, W), topk=20)
+        return time.perf_counter() - t0
+
+    one(100)
+    dt = sum(one(101 + i) for i in range(images))
+    return {"value": round(images / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{images} frames at 640x480 after 1 warm-up, batch 1, oracle pixel decoder + 9-layer decoder "
+                      f"+ instance post-processing in fp32 torch on {torch.get_num_threads()} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sparse-taps", action="store_true", help="skip mask rows that feed no attention-mask tap")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X: the hot path has no CPU implementation (oracle/ is test-only)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from unseenobjectswithmeanshift_amd import ops
+    from unseenobjectswithmeanshift_amd import synthetic as syn
+    from unseenobjectswithmeanshift_amd.distributed import gather_metrics, shard_range
+
+    model = build_model(dev)
+    model.sem_seg_head.predictor.sparse_taps = args.sparse_taps
+    # weak scaling: the global batch is world*8 images, rank r owns images [r*8, (r+1)*8)
+    lo, hi = shard_range(world * BATCH, world, rank)
+    feats = {k: v.to(dev) for k, v in syn.synth_backbone_features(hi - lo, H, W, seed=10 + rank).items()}
+
+    def step():
+        return model.inference(feats, (H, W))
+
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        out = None
+        for _ in range(max(1, args.warmup) if args.no_graph else 2):
+            out = step()
+        stream.synchronize()
+        graph = None
+        if not args.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                out = step()
+            for _ in range(args.warmup):
+                graph.replay()
+        stream.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            if graph is not None:
+                graph.replay()
+            else:
+                out = step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+
+        # dominant kernel (mask step, last-layer form writes the full mask): HIP events on this stream
+        ops.MASK_STEP_EVENTS = []
+        for _ in range(3):
+            step()
+        stream.synchronize()
+        per_call = [a.elapsed_time(b) for a, b in ops.MASK_STEP_EVENTS]
+        ops.MASK_STEP_EVENTS = None
+        # phase breakdown (eager, event-timed)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+        mf, _, msf = model.sem_seg_head.pixel_decoder.forward_features(feats)
+        ev[1].record()
+        pred = model.sem_seg_head.predictor(msf, mf)
+        ev[2].record()
+        sc, cl, qi = ops.topk_class_scores(pred["pred_logits"], 20)
+        ops.instance_postprocess(pred["pred_masks"], qi, (H, W), class_scores=sc)
+        ev[3].record()
+        stream.synchronize()
+        breakdown = {"pixel_decoder_ms": round(ev[0].elapsed_time(ev[1]), 3), "decoder_ms": round(ev[1].elapsed_time(ev[2]), 3),
+                     "postprocess_ms": round(ev[2].elapsed_time(ev[3]), 3), "launch": "eager"}
+
+    scores = out[0]
+    checksum = float(scores.double().sum().item())
+    rec = gather_metrics({"images": (hi - lo) * args.steps, "elapsed_s": elapsed, "checksum": checksum}, dist)
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    t_max = max(r["elapsed_s"] for r in rec)
+    total_images = sum(r["images"] for r in rec)
+    calls_per_step = len(per_call) // 3
+    mask_ms = sum(per_call) / len(per_call)
+    flops_per_launch = 2.0 * Q * C_MASK * (H // 4) * (W // 4) * (hi - lo)
+    achieved = flops_per_launch / (mask_ms * 1e-3) / 1e12
+    result = {
+        "metric": "images/sec @640x480 RGB-D, 100 queries, 9 decoder layers; % MFMA roofline",
+        "value": round(total_images / t_max, 2),
+        "unit": "images/sec",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * t_max / args.steps, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "configs[1]: batch=8 640x480 frames per GPU, synthetic ResNet-50 res2..res5 features "
+                               "-> MSDeformAttn pixel decoder (6 layers) -> 9-layer hypersphere decoder (100 queries) "
+                               "-> top-20 instance post-processing; backbone excluded",
+                   "global_batch": world * BATCH, "per_gpu_batch": BATCH, "launch": "eager" if graph is None else "hipgraph",
+                   "sparse_taps": bool(args.sparse_taps), "parallelism": f"dp{world}"},
+        "roofline": {"bound": "mfma", "kernel": "mask_logits_kernel (msm_mask_logits_fwd)",
+                     "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                     "launches_per_step": calls_per_step, "avg_launch_ms": round(mask_ms, 4),
+                     "flops_per_launch": flops_per_launch},
+        "breakdown": breakdown,
+    }
+    if not args.no_cpu_baseline and world == 1:
+        result["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

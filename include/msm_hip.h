@@ -171,7 +171,8 @@ int msm_ms_relabel_largest_zero(int64_t* labels, int n, const int64_t* counts, i
  *   mask_logits [B][Q][h*w] (low-res), query_index int32 [B][T] (selected queries, top-k done by
  *   the caller on the Q*K class scores).  For each selected mask: bilinear upsample to H x W
  *   (align_corners=False), pred_masks [B][T][H*W] = (m > 0), mask_score [B][T] =
- *   sum(sigmoid(m)*[m>0]) / (sum([m>0]) + 1e-6), boxes [B][T][4] = x0,y0,x1+1,y1+1 (zeros if empty).
+ *   sum(sigmoid(m)*[m>0]) / (sum([m>0]) + 1e-6), multiplied by class_scores [B][T] when that pointer
+ *   is not NULL (result.scores, :495); boxes [B][T][4] = x0,y0,x1+1,y1+1 (zeros if empty).
  *   workspace floats >= B*T*8, zeroed here.
  * ------------------------------------------------------------------------------------------- */
 /* Canonical top-k over the Q*K object-class scores of every image (pretrained_meanshiftformer_model.py:
@@ -183,7 +184,7 @@ int msm_topk_class_scores(const float* pred_logits, int B, int Q, int K1, int T,
                           float* scores_out, int64_t* classes_out, int32_t* query_index_out, void* stream);
 
 int msm_instance_postprocess(const float* mask_logits, const int32_t* query_index,
-                             float* pred_masks, float* mask_score, float* boxes,
+                             const float* class_scores, float* pred_masks, float* mask_score, float* boxes,
                              int B, int Q, int T, int h, int w, int H, int W,
                              float* workspace, void* stream);
 

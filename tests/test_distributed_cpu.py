@@ -1,0 +1,62 @@
+"""world_size-2 gloo test of the data-parallel plumbing used by bench.py (runs on CPU)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from unseenobjectswithmeanshift_amd.distributed import gather_metrics, shard_range
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 8, 64, 65):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_range(64, 8, 3) == (24, 32)            # BASELINE configs[2]: 64 frames over 8 GPUs
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(16, world, rank)
+    # each rank "processes" its shard: checksum = sum of its image ids
+    rec = {"images": hi - lo, "elapsed_s": 0.5 + rank, "checksum": float(sum(range(lo, hi)))}
+    dist.barrier()
+    allrec = gather_metrics(rec, dist)
+    q.put((rank, allrec))
+    dist.destroy_process_group()
+
+
+def test_gather_metrics_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        rec = got[rank]
+        assert [r["images"] for r in rec] == [8.0, 8.0]
+        assert max(r["elapsed_s"] for r in rec) == 1.5                  # bench takes the max over ranks
+        assert sum(r["checksum"] for r in rec) == float(sum(range(16)))  # every image processed exactly once
+
+
+def test_gather_metrics_single_process():
+    assert gather_metrics({"images": 8, "elapsed_s": 1.0, "checksum": 2.0}) == [{"images": 8, "elapsed_s": 1.0, "checksum": 2.0}]

@@ -1,0 +1,34 @@
+"""Drop-in for the reference's pybind module ``MultiScaleDeformableAttention``
+(ops/src/vision.cpp:18-21): same two function names and positional signatures, so the reference's
+``MSDeformAttnFunction`` (ops/functions/ms_deform_attn_func.py:32-49) works unmodified once this
+module is importable under that name:
+
+    import sys, unseenobjectswithmeanshift_amd.MultiScaleDeformableAttention as m
+    sys.modules["MultiScaleDeformableAttention"] = m
+"""
+import torch
+
+from . import ops
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    """ops/src/ms_deform_attn.h:25-44.  The batch-chunking argument only has to satisfy the
+    reference's divisibility check (ms_deform_attn_cuda.cu:55-57); one launch covers the batch."""
+    step = min(value.shape[0], int(im2col_step))
+    if value.shape[0] % step != 0:
+        raise RuntimeError("batch(%d) must divide im2col_step(%d)" % (value.shape[0], step))
+    for t, name in ((value, "value"), (spatial_shapes, "spatial_shapes"), (level_start_index, "level_start_index"),
+                    (sampling_loc, "sampling_loc"), (attn_weight, "attn_weight")):
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} tensor has to be contiguous")      # cu:33-37
+        if not t.is_cuda:
+            raise RuntimeError(f"{name} must be a CUDA tensor")             # cu:39-43
+    if value.dtype == torch.float64:
+        raise NotImplementedError("the gfx950 kernel is fp32; cast inputs with .float()")
+    return ops.ms_deform_attn(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
+
+
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
+                            im2col_step):
+    raise NotImplementedError("training (col2im backward, ms_deform_im2col_cuda.cuh:306-925) is out of scope "
+                              "for the inference hot path; see SURVEY.md section 8(f)")

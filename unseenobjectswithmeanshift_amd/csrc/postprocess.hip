@@ -118,11 +118,13 @@ __global__ void inst_init_kernel(InstAcc* __restrict__ acc, int n) {
     if (i < n) acc[i] = InstAcc{0.0, 0u, 0x7fffffff, 0x7fffffff, -1, -1, 0};
 }
 
-__global__ void inst_finish_kernel(const InstAcc* __restrict__ acc, float* __restrict__ score, float* __restrict__ boxes, int n) {
+__global__ void inst_finish_kernel(const InstAcc* __restrict__ acc, const float* __restrict__ class_scores,
+                                   float* __restrict__ score, float* __restrict__ boxes, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const InstAcc a = acc[i];
-    score[i] = (float)a.sum_sig / ((float)a.cnt + 1e-6f);
+    const float ms = (float)a.sum_sig / ((float)a.cnt + 1e-6f);
+    score[i] = class_scores ? class_scores[i] * ms : ms;
     float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.cnt > 0) bx = make_float4((float)a.xmin, (float)a.ymin, (float)(a.xmax + 1), (float)(a.ymax + 1));
     reinterpret_cast<float4*>(boxes)[i] = bx;
@@ -144,7 +146,8 @@ extern "C" int msm_topk_class_scores(const float* pred_logits, int B, int Q, int
     return MSM_OK;
 }
 
-extern "C" int msm_instance_postprocess(const float* mask_logits, const int32_t* query_index, float* pred_masks,
+extern "C" int msm_instance_postprocess(const float* mask_logits, const int32_t* query_index,
+                                        const float* class_scores, float* pred_masks,
                                         float* mask_score, float* boxes, int B, int Q, int T, int h, int w, int H, int W,
                                         float* workspace, void* stream) {
     MSM_REQUIRE(mask_logits && query_index && pred_masks && mask_score && boxes && workspace,
@@ -159,7 +162,7 @@ extern "C" int msm_instance_postprocess(const float* mask_logits, const int32_t*
     dim3 grid(cdiv(W, 256), cdiv(H, rows), n);
     hipLaunchKernelGGL(inst_upsample_kernel, grid, dim3(256), 0, st, mask_logits, query_index, pred_masks, acc, Q, T, h, w, H,
                        W, rows);
-    hipLaunchKernelGGL(inst_finish_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, acc, mask_score, boxes, n);
+    hipLaunchKernelGGL(inst_finish_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, acc, class_scores, mask_score, boxes, n);
     MSM_CHECK_LAUNCH("msm_instance_postprocess");
     return MSM_OK;
 }

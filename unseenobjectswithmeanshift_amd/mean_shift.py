@@ -1,0 +1,104 @@
+"""Classic UCN vMF mean-shift clustering on the HIP kernels.
+
+Mirrors lib/utils/mean_shift.py (and its copy under MSMFormer/.../transformer_decoder/mean_shift.py)
+and the driver lib/fcn/test_dataset.py:44-59: same function names, argument meaning and return
+values.  The O(n) passes (seeding, hill climbing, assignment, relabel) run on the GPU; the
+order-dependent merge of <= a few hundred seeds (connected_components, mean_shift.py:41-76) runs
+on the host exactly as the reference does, on a (S, 64) copy of the seeds.
+
+Only the cosine metric is implemented (cfg.TRAIN.EMBEDDING_METRIC == 'cosine' in every shipped
+experiment config); 'euclidean' raises.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+EMBEDDING_ALPHA = 0.02   # cfg.TRAIN.EMBEDDING_ALPHA, lib/fcn/config.py:255
+
+
+def _cosine_only(metric):
+    if metric != "cosine":
+        raise NotImplementedError("only metric='cosine' is implemented on the HIP path")
+
+
+def ball_kernel(Z, X, kappa, metric="cosine"):
+    """mean_shift.py:11-27.  Materialises the (S, n) kernel matrix -- provided for API parity and
+    small problems only; the clustering path below never builds it."""
+    _cosine_only(metric)
+    return torch.exp(kappa * ops.gemm(Z.contiguous(), X.contiguous()))
+
+
+def get_label_mode(array):
+    labels, counts = np.unique(array, return_counts=True)
+    return labels[np.argmax(counts)].item()
+
+
+def connected_components(Z, epsilon, metric="cosine"):
+    """mean_shift.py:41-76 on the host (sequential, order dependent)."""
+    _cosine_only(metric)
+    Zc = Z.detach().to("cpu", torch.float32)
+    n = Zc.shape[0]
+    K = 0
+    labels = torch.full((n,), -1, dtype=torch.long)
+    for i in range(n):
+        if labels[i] == -1:
+            comp = (0.5 * (1 - Zc @ Zc[i])) <= epsilon
+            seen = labels[comp]
+            if torch.unique(seen).shape[0] > 1:
+                t = seen.numpy()
+                label = get_label_mode(t[t != -1])
+            else:
+                label = K
+                K += 1
+            labels[comp] = label
+    return labels
+
+
+def seed_hill_climbing_ball(X, Z, kappa, max_iters=10, metric="cosine"):
+    _cosine_only(metric)
+    return ops.ms_hill_climb(X.contiguous(), Z.contiguous(), kappa, max_iters)
+
+
+def mean_shift_with_seeds(X, Z, kappa, max_iters=10, metric="cosine"):
+    Z = seed_hill_climbing_ball(X, Z, kappa, max_iters=max_iters, metric=metric)
+    return connected_components(Z, 2 * EMBEDDING_ALPHA, metric=metric), Z
+
+
+def select_smart_seeds(X, num_seeds, return_selected_indices=False, init_seeds=None, num_init_seeds=None,
+                       metric="cosine", first_index=None):
+    """mean_shift.py:128-189.  The first seed index comes from np.random.randint(0, n) like the
+    reference (mean_shift.py:155) unless ``first_index`` is given."""
+    _cosine_only(metric)
+    if init_seeds is not None:
+        raise NotImplementedError("init_seeds is unused by the inference path")
+    if first_index is None:
+        first_index = np.random.randint(0, X.shape[0])
+    seeds, idx = ops.ms_select_seeds(X.contiguous(), num_seeds, int(first_index))
+    return (seeds, idx) if return_selected_indices else (seeds,)
+
+
+def mean_shift_smart_init(X, kappa, num_seeds=100, max_iters=10, metric="cosine", first_index=None):
+    """mean_shift.py:192-229.  Returns (cluster_labels (n,) int64 on X.device, selected_indices (S,))."""
+    X = X.contiguous()
+    seeds, selected = select_smart_seeds(X, num_seeds, return_selected_indices=True, metric=metric,
+                                         first_index=first_index)
+    seed_labels, Z = mean_shift_with_seeds(X, seeds, kappa, max_iters=max_iters, metric=metric)
+    num = int(torch.unique(seed_labels).numel())
+    labels, counts = ops.ms_assign(X, Z, seed_labels.to(X.device), num)
+    ops.ms_relabel_largest_zero(labels, counts)
+    return labels, selected
+
+
+def clustering_features(features, num_seeds=100, metric="cosine"):
+    """lib/fcn/test_dataset.py:44-59: features (B,C,H,W) unit-norm along C -> (out_label (B,H,W) float,
+    selected_pixels list of (S,) index tensors).  kappa=20, 10 iterations."""
+    B, C, H, W = features.shape
+    out_label = torch.zeros((B, H, W), device=features.device)
+    selected_pixels = []
+    for j in range(B):
+        X = ops.transpose_last2(features[j].reshape(1, C, H * W).contiguous())[0]
+        labels, sel = mean_shift_smart_init(X, kappa=20, num_seeds=num_seeds, max_iters=10, metric=metric)
+        out_label[j] = labels.view(H, W).float()
+        selected_pixels.append(sel)
+    return out_label, selected_pixels

@@ -1,0 +1,209 @@
+"""Head, meta-architecture and predictor around the hot path.
+
+  MeanShiftMaskFormerHead   <- modeling/meta_arch/meanshift_former_head.py:18-143
+  MeanShiftMaskFormer       <- meanshiftformer_model.py / pretrained_meanshiftformer_model.py:244-378
+                               (eval branch) and instance_inference :461-497
+  Network_RGBD              <- lib/fcn/test_utils.py:150-166 (predictor __call__(sample) -> dict)
+  Instances                 <- the three detectron2 containers the harness reads, reduced to a
+                               field bag (pred_masks / pred_boxes / scores / pred_classes)
+
+detectron2 is not a dependency.  The backbone is out of scope: the
+meta-arch takes any ``backbone`` module mapping an image batch to {"res2".."res5"}; ``None`` means
+the caller already passes backbone features.  Inference only.
+"""
+import torch
+from torch import nn
+
+from . import ops
+
+
+class Instances:
+    """Minimal stand-in for detectron2.structures.Instances: attribute bag + boolean/index slicing
+    (what get_confident_instances / combine_masks use, lib/fcn/test_utils.py:35-112)."""
+
+    def __init__(self, image_size, **fields):
+        self.image_size = tuple(image_size)
+        self._fields = dict(fields)
+
+    def __getattr__(self, name):
+        f = self.__dict__.get("_fields", {})
+        if name in f:
+            return f[name]
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        if name in ("image_size", "_fields"):
+            super().__setattr__(name, value)
+        else:
+            self._fields[name] = value
+
+    def get(self, name):
+        return self._fields[name]
+
+    def has(self, name):
+        return name in self._fields
+
+    def get_fields(self):
+        return self._fields
+
+    def __len__(self):
+        for v in self._fields.values():
+            return len(v)
+        return 0
+
+    def __getitem__(self, item):
+        if isinstance(item, torch.Tensor) and item.dtype == torch.bool:
+            item = item.to(next(iter(self._fields.values())).device)
+        return Instances(self.image_size, **{k: v[item] for k, v in self._fields.items()})
+
+    def to(self, device):
+        return Instances(self.image_size, **{k: v.to(device) for k, v in self._fields.items()})
+
+
+class MeanShiftMaskFormerHead(nn.Module):
+    _version = 2
+
+    def __init__(self, input_shape, *, num_classes, pixel_decoder, loss_weight=1.0, ignore_value=-1,
+                 transformer_predictor, transformer_in_feature="multi_scale_pixel_decoder"):
+        super().__init__()
+        if transformer_in_feature != "multi_scale_pixel_decoder":
+            raise NotImplementedError("only TRANSFORMER_IN_FEATURE == 'multi_scale_pixel_decoder'")
+        input_shape = sorted(input_shape.items(), key=lambda x: x[1].stride)
+        self.in_features = [k for k, v in input_shape]
+        self.ignore_value = ignore_value
+        self.common_stride = 4
+        self.loss_weight = loss_weight
+        self.pixel_decoder = pixel_decoder
+        self.predictor = transformer_predictor
+        self.transformer_in_feature = transformer_in_feature
+        self.num_classes = num_classes
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        # head-prefix migration of old checkpoints (meanshift_former_head.py:23-45)
+        version = local_metadata.get("version", None)
+        if version is None or version < 2:
+            for k in list(state_dict.keys()):
+                if k.startswith(prefix) and "sem_seg_head" in k and not k.startswith(prefix + "predictor") \
+                        and not k.startswith(prefix + "pixel_decoder"):
+                    state_dict[k.replace(prefix, prefix + "pixel_decoder.")] = state_dict.pop(k)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+
+    def forward(self, features, image_height=None, image_width=None, mask=None):
+        return self.layers(features, image_height, image_width, mask)
+
+    def layers(self, features, image_height=None, image_width=None, mask=None):
+        """Returns (predictions, last_feature_map).  The reference also upsamples mask_features to
+        image size here (meanshift_former_head.py:121-126, 315 MB per 640x480 image) for the
+        training-only embedding loss; inference returns None for it."""
+        mask_features, _, multi_scale_features = self.pixel_decoder.forward_features(features)
+        predictions = self.predictor(multi_scale_features, mask_features, mask)
+        return predictions, None
+
+
+class MeanShiftMaskFormer(nn.Module):
+    """Inference branch of the meta-arch (pretrained_meanshiftformer_model.py:244-303,334-378)."""
+
+    def __init__(self, *, backbone, sem_seg_head, num_queries, test_topk_per_image=20, size_divisibility=32,
+                 instance_on=True):
+        super().__init__()
+        self.backbone = backbone
+        self.sem_seg_head = sem_seg_head
+        self.num_queries = num_queries
+        self.test_topk_per_image = test_topk_per_image
+        self.size_divisibility = size_divisibility
+        self.instance_on = instance_on
+
+    @torch.no_grad()
+    def inference(self, features, image_size):
+        """features: dict res2..res5 (B,C,h,w) on the GPU.  Returns the per-batch tensors
+        (scores (B,T), classes (B,T), masks (B,T,H,W), boxes (B,T,4), query_index (B,T))."""
+        outputs, _ = self.sem_seg_head(features, image_size[0], image_size[1])
+        cls_scores, classes, qidx = ops.topk_class_scores(outputs["pred_logits"], self.test_topk_per_image)
+        # scores = class prob * mean mask prob (PM:495), fused into the post-process kernel
+        masks, scores, boxes = ops.instance_postprocess(outputs["pred_masks"], qidx, image_size, class_scores=cls_scores)
+        return scores, classes, masks, boxes, qidx
+
+    @torch.no_grad()
+    def forward(self, batched_inputs):
+        """batched_inputs: list of dicts with "image" (3,H,W) -- or one dict holding a 4-D batch, as
+        the reference accepts (PM:270-273) -- plus, when ``backbone`` is None, "features"."""
+        first = batched_inputs[0]
+        if self.backbone is None:
+            feats = first["features"] if isinstance(first["features"], dict) and first["features"]["res2"].dim() == 4 \
+                else {k: torch.stack([x["features"][k] for x in batched_inputs]) for k in first["features"]}
+            H, W = first.get("height"), first.get("width")
+            if H is None:
+                H, W = 4 * feats["res2"].shape[-2], 4 * feats["res2"].shape[-1]
+        else:
+            images = first["image"] if first["image"].dim() == 4 else torch.stack([x["image"] for x in batched_inputs])
+            H, W = images.shape[-2:]
+            if H % self.size_divisibility or W % self.size_divisibility:
+                raise NotImplementedError("pad inputs to a multiple of %d (ImageList.from_tensors, PM:275)"
+                                          % self.size_divisibility)
+            feats = self.backbone(images)
+        scores, classes, masks, boxes, _ = self.inference(feats, (int(H), int(W)))
+        results = []
+        for b in range(scores.shape[0]):
+            inst = Instances((int(H), int(W)), pred_masks=masks[b], pred_boxes=boxes[b], scores=scores[b],
+                             pred_classes=classes[b])
+            results.append({"instances": inst})
+        return results
+
+
+class Network_RGBD:
+    """lib/fcn/test_utils.py:150-166: ``predictor(sample) -> {"instances": ...}`` for one sample."""
+
+    def __init__(self, model):
+        self.model = model.eval()
+
+    def __call__(self, sample):
+        with torch.no_grad():
+            return self.model([sample])[0]
+
+
+# ----------------------------------------------------------------------------------------------
+# harness helpers (host side), lib/fcn/test_utils.py:35-112
+# ----------------------------------------------------------------------------------------------
+def get_confident_instances(outputs, topk=False, score=0.7, num_class=2, low_threshold=0.4):
+    instances = outputs["instances"]
+    if topk:
+        if num_class >= 2:
+            instances = instances[instances.pred_classes == 1]
+            return instances[instances.scores > low_threshold]
+        return instances
+    return instances[instances.scores > score]
+
+
+def combine_masks(instances):
+    """(N,H,W) 0/1 masks -> (H,W) label image, labels 2..N+1, later instances overwrite earlier ones
+    (test_utils.py:93-112).  Returns a float64 numpy array like the reference."""
+    import numpy as np
+    mask = instances.get("pred_masks").to("cpu").numpy()
+    num, h, w = mask.shape if mask.ndim == 3 else (0, *instances.image_size)
+    out = np.zeros((h, w))
+    for m, lab in zip(mask, range(2, 2 + len(mask))):
+        out[np.nonzero(m)] = lab
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+def build_resnet50_head(num_queries=100, dec_layers=9, num_classes=2, hidden_dim=256, mask_dim=256, conv_dim=64,
+                        nheads=8, dim_feedforward=2048, enc_layers=6):
+    """The configuration of MSMFormer/configs/mixture_ResNet50.yaml:31-77 (hot path only)."""
+    from .modeling import MeanShiftTransformerDecoder, MSDeformAttnPixelDecoder, ShapeSpec
+    shape = {"res2": ShapeSpec(channels=256, stride=4), "res3": ShapeSpec(channels=512, stride=8),
+             "res4": ShapeSpec(channels=1024, stride=16), "res5": ShapeSpec(channels=2048, stride=32)}
+    pd = MSDeformAttnPixelDecoder(shape, transformer_dropout=0.0, transformer_nheads=nheads,
+                                  transformer_dim_feedforward=1024, transformer_enc_layers=enc_layers,
+                                  conv_dim=conv_dim, mask_dim=mask_dim, norm="GN",
+                                  transformer_in_features=["res3", "res4", "res5"], common_stride=4)
+    dec = MeanShiftTransformerDecoder(in_channels=conv_dim, mask_classification=True, num_classes=num_classes,
+                                      hidden_dim=hidden_dim, num_queries=num_queries, nheads=nheads,
+                                      dim_feedforward=dim_feedforward, dec_layers=dec_layers, pre_norm=False,
+                                      mask_dim=mask_dim, enforce_input_project=False,
+                                      use_meanshift_cross_attention=True, disable_attention_mask=False,
+                                      use_meanshift_self_attention=True, decoder_block_norm=True)
+    return MeanShiftMaskFormerHead(shape, num_classes=num_classes, pixel_decoder=pd, transformer_predictor=dec,
+                                   transformer_in_feature="multi_scale_pixel_decoder")

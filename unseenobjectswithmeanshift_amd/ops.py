@@ -12,6 +12,10 @@ from ._lib import check, lib
 
 KAPPA = 30.0  # attention_util.py:26
 
+# bench.py sets this to a list to collect (start, end) HIP event pairs around the dominant kernel
+# (msm_mask_logits_fwd) on the stream it is launched on; None = no instrumentation.
+MASK_STEP_EVENTS = None
+
 
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -185,9 +189,16 @@ def mask_logits(mask_embed, mask_features, *, want_mask=True, target_size=None, 
         th, tw = int(target_size[0]), int(target_size[1])
         attn = torch.empty((B, Q, th * tw), device=dev, dtype=torch.uint8)
         row_any = torch.empty((B, Q), device=dev, dtype=torch.int32)
+    ev = None
+    if MASK_STEP_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     rc = lib().msm_mask_logits_fwd(_p(mask_embed), _p(mask_features), _p(mask), _p(attn), _p(row_any),
                                    B, Q, C, H, W, th, tw, 1 if sparse else 0, _stream())
     check(rc, "msm_mask_logits_fwd")
+    if ev is not None:
+        ev[1].record()
+        MASK_STEP_EVENTS.append(ev)
     return mask, attn, row_any
 
 
@@ -302,10 +313,10 @@ def topk_class_scores(pred_logits, topk):
     return scores, classes, qidx
 
 
-def instance_postprocess(mask_logits, query_index, image_size):
+def instance_postprocess(mask_logits, query_index, image_size, class_scores=None):
     """mask_logits (B,Q,h,w), query_index int32 (B,T) -> (pred_masks (B,T,H,W) float 0/1,
-    mask_score (B,T), boxes (B,T,4))."""
-    _c(mask_logits, "mask_logits"), _c(query_index, "query_index", torch.int32)
+    score (B,T) = mean mask probability [* class_scores], boxes (B,T,4))."""
+    _c(mask_logits, "mask_logits"), _c(query_index, "query_index", torch.int32), _c(class_scores, "class_scores")
     B, Q, h, w = mask_logits.shape
     T = query_index.shape[1]
     H, W = int(image_size[0]), int(image_size[1])
@@ -314,7 +325,7 @@ def instance_postprocess(mask_logits, query_index, image_size):
     score = torch.empty((B, T), device=dev, dtype=torch.float32)
     boxes = torch.empty((B, T, 4), device=dev, dtype=torch.float32)
     ws = torch.empty((B * T * 8,), device=dev, dtype=torch.float32)
-    rc = lib().msm_instance_postprocess(_p(mask_logits), _p(query_index), _p(masks), _p(score), _p(boxes),
+    rc = lib().msm_instance_postprocess(_p(mask_logits), _p(query_index), _p(class_scores), _p(masks), _p(score), _p(boxes),
                                         B, Q, T, h, w, H, W, _p(ws), _stream())
     check(rc, "msm_instance_postprocess")
     return masks, score, boxes
