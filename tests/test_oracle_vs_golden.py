@@ -148,3 +148,33 @@ def test_mean_shift_end_to_end(golden):
     labels, sel, _, _ = O.mean_shift_smart_init(X, 20.0, 50, 10, int(g["n_first"]))
     assert torch.equal(sel, T(g["n_sel"]))
     assert torch.equal(labels, T(g["n_labels"]).long())
+
+
+def test_msda_c_restatement(golden):
+    """oracle/msda_ref.c (plain C loops after the CUDA kernel) against the reference's PyTorch op."""
+    import ctypes
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    subprocess.run(["make", "-s", "-C", here], check=True)
+    L = ctypes.CDLL(os.path.join(here, "libmsda_ref.so"))
+    g = golden("msda_core")
+
+    def run(fn, dtype, value, shapes, loc, aw):
+        value, loc, aw = (np.ascontiguousarray(a, dtype=dtype) for a in (value, loc, aw))
+        shp = np.ascontiguousarray(shapes, dtype=np.int64)
+        start = np.concatenate(([0], np.cumsum(shp[:, 0] * shp[:, 1])[:-1])).astype(np.int64)
+        B, S, M, D = value.shape
+        _, Lq, _, Lv, P, _ = loc.shape
+        out = np.zeros((B, Lq, M * D), dtype=dtype)
+        ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        fn(ptr(value), ptr(shp), ptr(start), ptr(loc), ptr(aw), ptr(out), B, S, M, D, Lv, Lq, P)
+        return torch.from_numpy(out)
+
+    t = [(6, 4), (3, 2)]
+    o = run(L.msda_ref_f64, np.float64, g["t_double_value"], t, g["t_double_loc"], g["t_double_aw"])
+    assert torch.allclose(o, T(g["t_double_out"]))
+    o = run(L.msda_ref_f32, np.float32, g["t_float_value"], t, g["t_float_loc"], g["t_float_aw"])
+    torch.testing.assert_close(o, T(g["t_float_out"]), rtol=1e-5, atol=1e-8)
+    o = run(L.msda_ref_f32, np.float32, g["r_value"], g["r_shapes"], g["r_loc"], g["r_aw"])
+    torch.testing.assert_close(o, T(g["r_out"]), rtol=1e-4, atol=1e-5)

@@ -224,7 +224,7 @@ extern "C" int msm_hypersphere_attn_fwd(const float* q, const float* k, const fl
     }
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = sizeof(float) * 4 * AQCH * PSTRIDE;
-    MSM_CHECK_HIP(hipFuncSetAttribute((const void*)hs_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)hs_attn_kernel, lds));
     dim3 grid(ns, heads, B * qchunks), block(256);
     hipLaunchKernelGGL(hs_attn_kernel, grid, block, lds, st, q, k, v, masked, row_any, workspace, Lq, S, heads, qchunks,
                        ns, ldq, q_sb, ldk, k_sb, ldv, v_sb, kappa);

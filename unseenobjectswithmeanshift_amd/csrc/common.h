@@ -10,6 +10,9 @@
 namespace msm {
 
 void set_error(const char* fmt, ...);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, size): cheap on the hot path and
+// keeps the call out of HIP-graph capture after warm-up.  Returns a hipError_t value.
+int ensure_dynamic_lds(const void* kernel, size_t bytes);
 
 #define MSM_REQUIRE(cond, ...)                 \
     do {                                       \

@@ -27,17 +27,28 @@ constexpr int QB = 7;           // 16-row MFMA blocks per query chunk
 constexpr int QCH = QB * 16;    // 112 queries per chunk
 constexpr int KU = 8;           // k-steps (of 4) per prefetch group
 
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float2 ld_f2(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+
 template <int POOL, bool WRITE>
 __global__ __launch_bounds__(256) void mask_logits_kernel(const float* __restrict__ emb, const float* __restrict__ feat,
                                                           float* __restrict__ mask_out, uint8_t* __restrict__ attn_out,
                                                           int32_t* __restrict__ row_any, int Q, int C, int H, int W,
                                                           int th, int tw, int ypar, int n_rowpairs, int rp_step,
-                                                          int rp_first) {
+                                                          int rp_first, int feat_bytes) {
     extern __shared__ __attribute__((aligned(16))) float Es[];
     const int SE = C + 2;
     const int b = blockIdx.z, qc = blockIdx.y;
     const int q0 = qc * QCH;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wave id is wave-uniform but not provably so to hipcc: readfirstlane keeps the tile loop, the
+    // row/column bookkeeping and the buffer descriptor in SGPRs (otherwise every buffer load is wrapped
+    // in a waterfall loop)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lj = lane & 15, lq = lane >> 4;
     const int HW = H * W;
 
@@ -56,6 +67,12 @@ __global__ __launch_bounds__(256) void mask_logits_kernel(const float* __restric
     const int ctiles = (W + 31) / 32;
     const int ntiles = n_rowpairs * ctiles;
     const float* fb = feat + (int64_t)b * C * HW;
+    // buffer descriptor over this image's feature map, held in SGPRs
+    const uint64_t fbu = (uint64_t)fb;   // readfirstlane makes the uniformity provable (no waterfall loops)
+    const uint64_t fbs = ((uint64_t)__builtin_amdgcn_readfirstlane((unsigned)(fbu >> 32)) << 32) |
+                         (uint64_t)__builtin_amdgcn_readfirstlane((unsigned)fbu);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)fbs, 0, feat_bytes, 0x00020000);   // feat_bytes = C*H*W*4 from the host: stays scalar
 
     for (int t = blockIdx.x * 4 + wave; t < ntiles; t += gridDim.x * 4) {
         const int rp = t / ctiles, ct = t - rp * ctiles;
@@ -64,8 +81,11 @@ __global__ __launch_bounds__(256) void mask_logits_kernel(const float* __restric
         const int c = ct * 32 + 2 * lj;
         const bool col_ok = c < W;  // W is even
         const int cl = col_ok ? c : 0;
-        const float* ptop = fb + (int64_t)max(ytop, 0) * W + cl;
-        const float* pbot = fb + (int64_t)min(ybot, H - 1) * W + cl;
+        // per-lane byte offsets of this lane's two pixels in k-row `lq`; the k-group part of the
+        // address is wave-uniform and travels in the buffer instruction's SGPR soffset, so the
+        // loads need no per-lane 64-bit address arithmetic at all
+        const unsigned voff_top = (unsigned)(((int64_t)lq * HW + (int64_t)max(ytop, 0) * W + cl) * 4);
+        const unsigned voff_bot = (unsigned)(((int64_t)lq * HW + (int64_t)min(ybot, H - 1) * W + cl) * 4);
 
         f32x4 acc[QB][4];
 #pragma unroll
@@ -73,44 +93,47 @@ __global__ __launch_bounds__(256) void mask_logits_kernel(const float* __restric
 #pragma unroll
             for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        float2 ft[KU], fbm[KU];
-#pragma unroll
-        for (int u = 0; u < KU; ++u) {
-            const int64_t ko = (int64_t)(u * 4 + lq) * HW;
-            ft[u] = *reinterpret_cast<const float2*>(ptop + ko);
-            fbm[u] = *reinterpret_cast<const float2*>(pbot + ko);
-        }
-        for (int k0 = 0; k0 < C; k0 += 4 * KU) {
-            float2 nt[KU], nb[KU];
-            const int kn = k0 + 4 * KU;
-            if (kn < C) {
-#pragma unroll
-                for (int u = 0; u < KU; ++u) {
-                    const int64_t ko = (int64_t)(kn + u * 4 + lq) * HW;
-                    nt[u] = *reinterpret_cast<const float2*>(ptop + ko);
-                    nb[u] = *reinterpret_cast<const float2*>(pbot + ko);
-                }
-            }
+        // K loop: groups of KU k-steps, two register buffers (A/B) in ping-pong.  The loads of the
+        // next group are issued BEFORE the MFMAs of the current one and pinned there with
+        // sched_barrier (left alone, hipcc sinks them behind the MFMAs and waits at once); no
+        // buffer copies, so the only vmcnt waits are the counted ones at each buffer's first use.
+        float2 tA[KU], bA[KU], tB[KU], bB[KU];
+        auto load_group = [&](float2(&t)[KU], float2(&bt)[KU], int kbase) {
 #pragma unroll
             for (int u = 0; u < KU; ++u) {
-                const float* er = &Es[lj * SE + k0 + u * 4 + lq];
+                const unsigned soff = (unsigned)(kbase + u * 4) * (unsigned)HW * 4u;
+                t[u] = ld_f2(rsrc, voff_top, soff);
+                bt[u] = ld_f2(rsrc, voff_bot, soff);
+            }
+        };
+        auto compute_group = [&](const float2(&t)[KU], const float2(&bt)[KU], int kbase) {
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                const float* er = &Es[lj * SE + kbase + u * 4 + lq];
 #pragma unroll
                 for (int m = 0; m < QB; ++m) {
                     const float a = er[m * 16 * SE];
-                    acc[m][0] = mfma16(a, ft[u].x, acc[m][0]);
-                    acc[m][1] = mfma16(a, ft[u].y, acc[m][1]);
-                    acc[m][2] = mfma16(a, fbm[u].x, acc[m][2]);
-                    acc[m][3] = mfma16(a, fbm[u].y, acc[m][3]);
+                    acc[m][0] = mfma16(a, t[u].x, acc[m][0]);
+                    acc[m][1] = mfma16(a, t[u].y, acc[m][1]);
+                    acc[m][2] = mfma16(a, bt[u].x, acc[m][2]);
+                    acc[m][3] = mfma16(a, bt[u].y, acc[m][3]);
                 }
             }
-            if (kn < C) {
-#pragma unroll
-                for (int u = 0; u < KU; ++u) {
-                    ft[u] = nt[u];
-                    fbm[u] = nb[u];
-                }
-            }
+        };
+        const int G = C / (4 * KU);
+        load_group(tA, bA, 0);
+        int g = 0;
+        for (; g + 1 < G; g += 2) {   // straight-line body: nothing for LLVM to sink the loads into
+            load_group(tB, bB, (g + 1) * (4 * KU));
+            __builtin_amdgcn_sched_barrier(0);
+            compute_group(tA, bA, g * (4 * KU));
+            __builtin_amdgcn_sched_barrier(0);
+            load_group(tA, bA, min(g + 2, G - 1) * (4 * KU));
+            __builtin_amdgcn_sched_barrier(0);
+            compute_group(tB, bB, (g + 1) * (4 * KU));
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (g < G) compute_group(tA, bA, g * (4 * KU));   // odd number of groups
 
         // ---- epilogue: lane holds queries q0 + m*16 + lq*4 + r, columns c (tiles 0,2) and c+1 (1,3)
         if constexpr (WRITE) {
@@ -182,6 +205,7 @@ extern "C" int msm_mask_logits_fwd(const float* mask_embed, const float* mask_fe
     MSM_REQUIRE(B > 0 && Q > 0 && H > 1 && W > 1, "msm_mask_logits_fwd: bad sizes");
     MSM_REQUIRE(C % 32 == 0 && C >= 32 && C <= 320, "msm_mask_logits_fwd: C=%d must be a multiple of 32 and <= 320", C);
     MSM_REQUIRE(W % 2 == 0 && H % 2 == 0, "msm_mask_logits_fwd: H=%d W=%d must be even", H, W);
+    MSM_REQUIRE((int64_t)C * H * W * 4 < (int64_t)1 << 31, "msm_mask_logits_fwd: one image of mask_feat must be < 2 GiB");
     MSM_REQUIRE((((uintptr_t)mask_embed) & 15) == 0 && (((uintptr_t)mask_feat) & 7) == 0 &&
                     (!mask_out || (((uintptr_t)mask_out) & 7) == 0),
                 "msm_mask_logits_fwd: misaligned pointer");
@@ -217,7 +241,7 @@ extern "C" int msm_mask_logits_fwd(const float* mask_embed, const float* mask_fe
     if (wg_per > target) wg_per = max(target, 1);
     dim3 grid(wg_per, qchunks, B), block(256);
     const size_t lds = sizeof(float) * (size_t)QCH * (C + 2);
-    void (*kern)(const float*, const float*, float*, uint8_t*, int32_t*, int, int, int, int, int, int, int, int, int, int);
+    void (*kern)(const float*, const float*, float*, uint8_t*, int32_t*, int, int, int, int, int, int, int, int, int, int, int);
     const bool wr = mask_out != nullptr;
     switch (pool) {
         case 0: kern = mask_logits_kernel<0, true>; break;
@@ -225,9 +249,9 @@ extern "C" int msm_mask_logits_fwd(const float* mask_embed, const float* mask_fe
         case 4: kern = wr ? mask_logits_kernel<4, true> : mask_logits_kernel<4, false>; break;
         default: kern = wr ? mask_logits_kernel<8, true> : mask_logits_kernel<8, false>; break;
     }
-    MSM_CHECK_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)kern, lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, mask_embed, mask_feat, mask_out, attn_out, row_any, Q, C, H, W, th, tw,
-                       ypar, n_rowpairs, rp_step, rp_first);
+                       ypar, n_rowpairs, rp_step, rp_first, (int)((int64_t)C * H * W * 4));
     MSM_CHECK_LAUNCH("msm_mask_logits_fwd");
     return MSM_OK;
 }

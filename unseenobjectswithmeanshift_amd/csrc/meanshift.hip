@@ -342,7 +342,7 @@ extern "C" int64_t msm_ms_hill_climb_workspace(int n, int S) {
 template <int NSB>
 static int hill_chunk_launch(const float* X, int n, const float* Zc, int Sc, float kappa, float* ws, int G, hipStream_t st) {
     const size_t lds = sizeof(float) * ((size_t)NSB * 16 * SZ + 4 * 16 * SZ);
-    MSM_CHECK_HIP(hipFuncSetAttribute((const void*)ms_hill_kernel<NSB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)ms_hill_kernel<NSB>, lds));
     hipLaunchKernelGGL((ms_hill_kernel<NSB>), dim3(G), dim3(256), lds, st, X, n, Zc, Sc, kappa, ws);
     return MSM_OK;
 }
@@ -403,7 +403,7 @@ extern "C" int msm_ms_assign(const float* X, int n, int d, const float* Z, int S
     const int nchunks = cdiv(cdiv(S, 16), MS_CH);
     const int G = hill_wgs(n);
     const size_t lds = sizeof(float) * ((size_t)nchunks * MS_CH * 16 * SZ + 4 * 16 * SZ) + sizeof(unsigned int) * (size_t)num_labels;
-    MSM_CHECK_HIP(hipFuncSetAttribute((const void*)ms_assign_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)ms_assign_kernel, lds));
     hipLaunchKernelGGL(ms_assign_kernel, dim3(G), dim3(256), lds, st, X, n, Z, S, nchunks, seed_labels, labels_out,
                        reinterpret_cast<unsigned long long*>(counts), num_labels);
     MSM_CHECK_LAUNCH("msm_ms_assign");
