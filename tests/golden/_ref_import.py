@@ -138,3 +138,19 @@ def ref(name):
     """Import a reference module, e.g. ref('modeling.transformer_decoder.attention_util')."""
     install_stubs()
     return importlib.import_module("refmsm." + name)
+
+
+def ref_functions(path, names, namespace):
+    """Execute ONLY the named top-level function definitions of a reference source file (in memory)
+    inside `namespace`.  Used for harness files whose module-level imports need cv2 / easydict /
+    detectron2 (lib/fcn/test_dataset.py, lib/fcn/test_utils.py, lib/utils/mask.py, lib/fcn/nms.py):
+    the functions themselves only use torch / numpy."""
+    import ast
+    with open(REF_ROOT + "/" + path) as f:
+        tree = ast.parse(f.read())
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    missing = set(names) - {n.name for n in keep}
+    assert not missing, missing
+    mod = ast.Module(body=keep, type_ignores=[])
+    exec(compile(mod, REF_ROOT + "/" + path, "exec"), namespace)
+    return namespace

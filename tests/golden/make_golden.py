@@ -230,9 +230,91 @@ def g_mean_shift():
     save("mean_shift", **arrs)
 
 
+
+
+# ------------------------------------------------------------------------------------------
+# two-stage harness (lib/fcn/test_utils.py, lib/fcn/test_dataset.py): torch/numpy-only functions
+# executed from the reference sources with a namespace standing in for their module globals
+# ------------------------------------------------------------------------------------------
+class _Inst:
+    """Just enough of detectron2.structures.Instances for get_confident_instances/combine_masks."""
+
+    def __init__(self, **f):
+        self.f = f
+
+    def __getattr__(self, k):
+        return self.__dict__["f"][k]
+
+    def get(self, k):
+        return self.f[k]
+
+    def __getitem__(self, idx):
+        return _Inst(**{k: v[idx] for k, v in self.f.items()})
+
+
+def harness_inputs(seed, H=96, W=128, n_inst=7):
+    """Synthetic instance predictions + depth for the harness: a few random rectangles/ellipses."""
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    masks = torch.zeros(n_inst, H, W)
+    for i in range(n_inst):
+        cy, cx = torch.rand(1, generator=g).item() * H, torch.rand(1, generator=g).item() * W
+        ry, rx = 6 + torch.rand(1, generator=g).item() * 18, 6 + torch.rand(1, generator=g).item() * 24
+        masks[i] = ((((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2) <= 1).float()
+    scores = torch.rand(n_inst, generator=g) * 0.6 + 0.35
+    classes = (torch.rand(n_inst, generator=g) < 0.8).long()
+    image = torch.rand(1, 3, H, W, generator=g)
+    z = 0.4 + 1.2 * torch.rand(1, 1, H, W, generator=g)
+    z[torch.rand(1, 1, H, W, generator=g) < 0.3] = 0
+    z[:, :, : H // 3, : W // 3] = 0                       # a region without depth
+    depth = torch.cat([torch.rand(1, 2, H, W, generator=g), z], 1)
+    return masks, scores, classes, image, depth
+
+
+def g_harness():
+    import torch.nn.functional as F_
+    ns_mask = R.ref_functions("lib/utils/mask.py", ["mask_to_tight_box_numpy", "mask_to_tight_box_pytorch", "mask_to_tight_box"],
+                              {"torch": torch, "np": np})
+    util = type("U", (), {"mask_to_tight_box": staticmethod(ns_mask["mask_to_tight_box"])})
+    cfg = type("C", (), {"device": "cpu", "TRAIN": type("T", (), {"SYN_CROP_SIZE": 224})})
+    td = R.ref_functions("lib/fcn/test_dataset.py", ["crop_rois", "match_label_crop", "filter_labels_depth"],
+                         {"torch": torch, "F": F_, "cfg": cfg, "util_": util, "np": np})
+    nms_ns = R.ref_functions("lib/fcn/nms.py", ["nms"], {"np": np})
+    tu = R.ref_functions("lib/fcn/test_utils.py", ["get_confident_instances", "combine_masks", "combine_masks_with_NMS"],
+                         {"torch": torch, "np": np, "nms": nms_ns["nms"]})
+    arrs = {}
+    for case, seed in enumerate((1, 2, 3)):
+        masks, scores, classes, image, depth = harness_inputs(seed)
+        inst = _Inst(pred_masks=masks, scores=scores, pred_classes=classes)
+        conf = tu["get_confident_instances"]({"instances": inst}, topk=False, score=0.6)
+        conf_topk = tu["get_confident_instances"]({"instances": inst}, topk=True, low_threshold=0.4)
+        label = tu["combine_masks"](conf)
+        label_topk = tu["combine_masks"](conf_topk)
+        bin_mask, score_mask, bbox = tu["combine_masks_with_NMS"](conf)
+        out_label = torch.as_tensor(label).unsqueeze(0)
+        filt = td["filter_labels_depth"](out_label, depth, 0.5)
+        rgb_crops, mask_crops, rois, depth_crops = td["crop_rois"](image, filt.clone(), depth)
+        # second stage stand-in: per crop a deterministic 2-instance labelling derived from the crop mask
+        labels_crop = torch.zeros(rgb_crops.shape[0], 224, 224)
+        for i in range(rgb_crops.shape[0]):
+            m = mask_crops[i]
+            labels_crop[i] = m * (2 + (torch.arange(224)[None, :] > 100).float())   # labels 2 / 3 inside the mask
+            labels_crop[i][:20, :20] = 5                                               # a spurious blob (mostly outside)
+        refined, labels_crop_out = td["match_label_crop"](filt, labels_crop.clone(), mask_crops, rois, depth_crops)
+        refined_nodepth, _ = td["match_label_crop"](filt, labels_crop.clone(), mask_crops, rois, None)
+        arrs.update({f"c{case}_label": label.astype(np.int16), f"c{case}_label_topk": label_topk.astype(np.int16),
+                     f"c{case}_nms_label": bin_mask.astype(np.int16), f"c{case}_nms_score": score_mask.astype(np.int16),
+                     f"c{case}_nms_bbox": bbox, f"c{case}_filt": filt.to(torch.int16),
+                     f"c{case}_rois": rois, f"c{case}_rgb_crops": rgb_crops[:, :, ::3, ::3], f"c{case}_mask_crops": packbits(mask_crops > 0),
+                     f"c{case}_depth_crops": depth_crops[:, :, ::3, ::3], f"c{case}_refined": refined.to(torch.int16),
+                     f"c{case}_refined_nodepth": refined_nodepth.to(torch.int16),
+                     f"c{case}_labels_crop_out": labels_crop_out[:, ::2, ::2].to(torch.int8)})
+    save("harness", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pe", "attn", "decoder", "msda", "pixel", "ms"]
+    which = sys.argv[1:] or ["pe", "attn", "decoder", "msda", "pixel", "ms", "harness"]
     fns = {"pe": g_position_encoding, "attn": g_hypersphere_attention, "decoder": g_decoder,
-           "msda": g_msda, "pixel": g_pixel_decoder, "ms": g_mean_shift}
+           "msda": g_msda, "pixel": g_pixel_decoder, "ms": g_mean_shift, "harness": g_harness}
     for w in which:
         fns[w]()

@@ -25,14 +25,18 @@ struct GemmArgs {
     int64_t a_sm, a_sk, a_sb, a2_sb, w_sb, c_sm, c_sn, c_sb, c_ss;
     int conv_h, conv_w, conv_c;
     int bias_mode, act, split_k, k_per_split;
-    int vec_a, vec_w;
+    int vec_a, vec_w, vec_c;
 };
 
 constexpr int BK = 32;
 constexpr int SK = BK + 2;  // row stride of K-contiguous LDS tiles
 
 // AMODE 0: A rows K-contiguous; 1: A is M-contiguous ([K][M]); 2: implicit 3x3 conv over NHWC tokens
-template <int MI, int NI, int AMODE>
+// SWAP: the MFMA operands are exchanged so that the accumulator holds C^T tiles (lane = row m, four
+// consecutive columns n in its registers): row-major outputs are then written with 16-byte stores.
+// Without SWAP a lane holds four consecutive rows m of one column: 16-byte stores for m-contiguous
+// (NCHW) outputs.
+template <int MI, int NI, int AMODE, bool SWAP>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     constexpr int BM = 32 * MI, BN = 32 * NI;
     constexpr int SM = BM + 16;  // row stride of the M-contiguous A tile
@@ -200,40 +204,50 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) acc[i][j] = mfma16(a[i], bb[j], acc[i][j]);
+                for (int j = 0; j < NI; ++j) acc[i][j] = SWAP ? mfma16(bb[j], a[i], acc[i][j]) : mfma16(a[i], bb[j], acc[i][j]);
         }
         __syncthreads();
     }
 
-    // epilogue: lane holds rows (lq*4 + r), column lj of each 16x16 tile
+    // epilogue.  !SWAP: lane holds rows m = .. + lq*4 + r, column n = .. + lj.
+    //            SWAP: lane holds row m = .. + lj, columns n = .. + lq*4 + r.
     float* __restrict__ Cb = p.C + (int64_t)b * p.c_sb + (int64_t)ks * p.c_ss;
     const bool raw = p.split_k > 1;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const int n = n0 + wn + j * 16 + lj;
-            if (n >= p.N) continue;
-            float bn = 0.f;
-            if (!raw && p.bias_mode == 1) bn = p.bias[n];
+            const int mb = m0 + wm + i * 16 + (SWAP ? lj : lq * 4);
+            const int nb = n0 + wn + j * 16 + (SWAP ? lq * 4 : lj);
+            if (mb >= p.M || nb >= p.N) continue;
+            float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm + i * 16 + lq * 4 + r;
-                if (m >= p.M) continue;
-                float v = acc[i][j][r];
-                if (!raw) {
-                    if (p.bias_mode == 1) v += bn;
-                    else if (p.bias_mode == 2) v += p.bias[m];
-                    if (p.act == 1) v = fmaxf(v, 0.f);
+                const int m = SWAP ? mb : mb + r, n = SWAP ? nb + r : nb;
+                float t = acc[i][j][r];
+                if (!raw && m < p.M && n < p.N) {
+                    if (p.bias_mode == 1) t += p.bias[n];
+                    else if (p.bias_mode == 2) t += p.bias[m];
+                    if (p.act == 1) t = fmaxf(t, 0.f);
                 }
-                Cb[(int64_t)m * p.c_sm + (int64_t)n * p.c_sn] = v;
+                v[r] = t;
+            }
+            float* dst = Cb + (int64_t)mb * p.c_sm + (int64_t)nb * p.c_sn;
+            const bool full = SWAP ? (nb + 3 < p.N) : (mb + 3 < p.M);
+            if (p.vec_c && full) {
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                const int64_t step = SWAP ? p.c_sn : p.c_sm;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (SWAP ? (nb + r < p.N) : (mb + r < p.M)) dst[r * step] = v[r];
             }
         }
     }
 }
 
-template <int AMODE>
-static int launch_gemm(const GemmArgs& p, hipStream_t st) {
+template <int AMODE, bool SWAP>
+static int launch_gemm_o(const GemmArgs& p, hipStream_t st) {
     // pick the largest tile that still yields enough workgroups to cover the 256 CUs
     const int cfgs[5][2] = {{4, 4}, {2, 4}, {2, 2}, {1, 2}, {1, 1}};
     int pick = 4;
@@ -245,14 +259,25 @@ static int launch_gemm(const GemmArgs& p, hipStream_t st) {
     dim3 grid(cdiv(p.N, 32 * ni), cdiv(p.M, 32 * mi), p.batch * p.split_k);
     dim3 block(256);
     switch (pick) {
-        case 0: hipLaunchKernelGGL((gemm_kernel<4, 4, AMODE>), grid, block, 0, st, p); break;
-        case 1: hipLaunchKernelGGL((gemm_kernel<2, 4, AMODE>), grid, block, 0, st, p); break;
-        case 2: hipLaunchKernelGGL((gemm_kernel<2, 2, AMODE>), grid, block, 0, st, p); break;
-        case 3: hipLaunchKernelGGL((gemm_kernel<1, 2, AMODE>), grid, block, 0, st, p); break;
-        default: hipLaunchKernelGGL((gemm_kernel<1, 1, AMODE>), grid, block, 0, st, p); break;
+        case 0: hipLaunchKernelGGL((gemm_kernel<4, 4, AMODE, SWAP>), grid, block, 0, st, p); break;
+        case 1: hipLaunchKernelGGL((gemm_kernel<2, 4, AMODE, SWAP>), grid, block, 0, st, p); break;
+        case 2: hipLaunchKernelGGL((gemm_kernel<2, 2, AMODE, SWAP>), grid, block, 0, st, p); break;
+        case 3: hipLaunchKernelGGL((gemm_kernel<1, 2, AMODE, SWAP>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_kernel<1, 1, AMODE, SWAP>), grid, block, 0, st, p); break;
     }
     MSM_CHECK_LAUNCH("msm_gemm_f32");
     return MSM_OK;
+}
+
+template <int AMODE>
+static int launch_gemm(GemmArgs& p, hipStream_t st) {
+    const bool c16 = (((uintptr_t)p.C) & 15) == 0 && p.c_sb % 4 == 0 && p.c_ss % 4 == 0;
+    if (p.c_sn == 1) {                     // row-major output: 4 consecutive n per lane
+        p.vec_c = c16 && p.c_sm % 4 == 0;
+        return launch_gemm_o<AMODE, true>(p, st);
+    }
+    p.vec_c = c16 && p.c_sm == 1 && p.c_sn % 4 == 0;   // m-contiguous (NCHW) output
+    return launch_gemm_o<AMODE, false>(p, st);
 }
 
 }  // namespace msm

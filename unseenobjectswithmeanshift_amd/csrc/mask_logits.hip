@@ -69,8 +69,9 @@ __global__ __launch_bounds__(256) void mask_logits_kernel(const float* __restric
     const float* fb = feat + (int64_t)b * C * HW;
     // buffer descriptor over this image's feature map, held in SGPRs
     const uint64_t fbu = (uint64_t)fb;   // readfirstlane makes the uniformity provable (no waterfall loops)
-    const uint64_t fbs = ((uint64_t)__builtin_amdgcn_readfirstlane((unsigned)(fbu >> 32)) << 32) |
-                         (uint64_t)__builtin_amdgcn_readfirstlane((unsigned)fbu);
+    // (readfirstlane returns int: go through unsigned, or a low half with bit 31 set sign-extends into the high half)
+    const uint64_t fbs = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(fbu >> 32)) << 32) |
+                         (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)fbu);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)fbs, 0, feat_bytes, 0x00020000);   // feat_bytes = C*H*W*4 from the host: stays scalar
 
