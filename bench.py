@@ -41,9 +41,7 @@ def cpu_baseline(images=6):
     timed ones, processed one at a time like the reference predictor (batch 1, test_utils.py:165)."""
     from oracle import msm_oracle as O
     from unseenobjectswithmeanshift_amd import synthetic as syn
-    # physical cores: SMT siblings only add contention to torch's CPU kernels
-    cores = max(1, (os.cpu_count() or 2) // 2)
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     pd_sd = syn.synth_state_dict(syn.pixel_decoder_param_shapes())
     dec_sd = syn.synth_state_dict(syn.decoder_param_shapes())
 
@@ -55,12 +53,22 @@ def cpu_baseline(images=6):
         O.instance_inference(out["pred_logits"][0], out["pred_masks"][0], (H, W), topk=20)
         return time.perf_counter() - t0
 
-    warm = one(100)
+    # pick the intra-op thread count that serves this workload best (all hardware threads is rarely it
+    # for torch's CPU kernels at these sizes); the choice is reported in `cores`
+    best = None
+    for nt in sorted({min(ncpu, c) for c in (16, 32, 64, max(1, ncpu // 2))}):
+        torch.set_num_threads(nt)
+        one(100)                       # warm-up at this thread count
+        t = one(100)
+        if best is None or t < best[0]:
+            best = (t, nt)
+    warm, nt = best
+    torch.set_num_threads(nt)
     # bounded sample: aim for <= ~20 s of CPU work whatever the host is
     images = max(1, min(images, int(20.0 / max(warm, 1e-3))))
     dt = sum(one(101 + i) for i in range(images))
     return {"value": round(images / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{images} frames at 640x480 after 1 warm-up, batch 1, oracle pixel decoder + 9-layer decoder "
+            "sample": f"{images} frames at 640x480 after warm-up and a thread-count sweep (16/32/64/half the CPUs, best kept), batch 1, oracle pixel decoder + 9-layer decoder "
                       f"+ instance post-processing in fp32 torch on {torch.get_num_threads()} threads"}
 
 

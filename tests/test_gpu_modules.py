@@ -123,8 +123,17 @@ def test_decoder_480x640_vs_reference(golden):
                       float(((m > 0).numpy() != ref_bits).mean())))
     for i, (dl, dm, fl) in enumerate(stats):
         print(f"prediction {i}: max|dlogits|={dl:.2e} max|dmask|={dm:.2e} sign-bit mismatch={fl:.2e}")
-    for dl, dm, fl in stats:
-        assert dl < 1e-3 and dm < 2e-3 and fl <= 1e-4
+    for dl, dm, fl in stats[:-1]:
+        assert dl < 1e-4 and dm < 2e-4 and fl <= 1e-5
+    # the last prediction sits behind nine discrete attention masks: one pooled logit within rounding of
+    # zero flips one (query, key) bit of the last cross-attention and moves its outputs by O(1e-3)
+    dl, dm, fl = stats[-1]
+    assert dl < 1e-3 and dm < 5e-3 and fl <= 1e-4
+    pm = out["pred_masks"].cpu() > 0
+    ref = torch.from_numpy(unpack(g["mask_sign_bits"], pm.shape))
+    inter = (pm & ref).flatten(2).sum(-1).float()
+    union = (pm | ref).flatten(2).sum(-1).float().clamp_min(1)
+    assert (inter / union)[union > 1].min() >= 0.99          # final instance-mask IoU
 
 
 def test_decoder_batch_consistency():

@@ -36,7 +36,11 @@ constexpr int SK = BK + 2;  // row stride of K-contiguous LDS tiles
 // consecutive columns n in its registers): row-major outputs are then written with 16-byte stores.
 // Without SWAP a lane holds four consecutive rows m of one column: 16-byte stores for m-contiguous
 // (NCHW) outputs.
-template <int MI, int NI, int AMODE, bool SWAP>
+// VEC: every tile load is one unconditional 16-byte load from a clamped address followed by a select
+// (no branches: hipcc otherwise puts each guarded load in its own basic block and the loads of a tile
+// are issued one latency after the other).  !VEC is the element-wise, fully guarded fallback for
+// unaligned / odd shapes.
+template <int MI, int NI, int AMODE, bool SWAP, bool VEC, bool HAS_A2>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     constexpr int BM = 32 * MI, BN = 32 * NI;
     constexpr int SM = BM + 16;  // row stride of the M-contiguous A tile
@@ -55,76 +59,82 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     const int kend = min(p.K, kbeg + p.k_per_split);
 
     const float* __restrict__ Ab = p.A + (int64_t)b * p.a_sb;
-    const float* __restrict__ A2b = p.A2 ? p.A2 + (int64_t)b * p.a2_sb : nullptr;
+    const float* __restrict__ A2b = HAS_A2 ? p.A2 + (int64_t)b * p.a2_sb : nullptr;
     const float* __restrict__ Wb = p.W + (int64_t)b * p.w_sb;
 
-    float4 ra[MI], rb[NI];
+    // Raw tile registers.  Loads are unconditional 16-byte loads from clamped addresses; the
+    // out-of-range select and the A2 add are applied when the tile is written to LDS (i.e. AFTER the
+    // MFMAs of the previous tile), so that the s_waitcnt for a prefetched tile sits behind the compute.
+    float4 ra[MI], ra2[HAS_A2 ? MI : 1], rb[NI];
+    // component-wise select (a float4 ?: is lowered through scratch memory by hipcc)
+    auto sel4 = [](bool ok, float4 v) { return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f); };
+    auto ld4 = [&](const float* ptr) { return *reinterpret_cast<const float4*>(ptr); };
+    auto ld4_guarded = [&](const float* base, const float* base2, int64_t off, int count) {
+        float t[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            t[e] = 0.f;
+            if (e < count) {
+                t[e] = base[off + e];
+                if (base2) t[e] += base2[off + e];
+            }
+        }
+        return make_float4(t[0], t[1], t[2], t[3]);
+    };
+    // validity of the float4 that thread `tid` loads for slot i of the tile starting at k0
+    auto a_ok = [&](int i, int k0) {
+        const int f = tid + 256 * i;
+        if constexpr (AMODE == 1) {
+            return (k0 + f / (BM / 4) < kend) && (m0 + (f % (BM / 4)) * 4 < p.M);
+        } else if constexpr (AMODE == 0) {
+            return (m0 + (f >> 3) < p.M) && (k0 + (f & 7) * 4 < kend);
+        } else {
+            const int k = k0 + (f & 7) * 4, m = m0 + (f >> 3);
+            const int tap = min(k, kend - 4) / p.conv_c;
+            const int mc = min(m, p.M - 1);
+            const int y = mc / p.conv_w, x = mc - y * p.conv_w;
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            return m < p.M && k < kend && yy >= 0 && yy < p.conv_h && xx >= 0 && xx < p.conv_w;
+        }
+    };
+    auto w_ok = [&](int i, int k0) {
+        const int f = tid + 256 * i;
+        return (n0 + (f >> 3) < p.N) && (k0 + (f & 7) * 4 < kend);
+    };
 
     auto load_a = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int f = tid + 256 * i;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v;
             if constexpr (AMODE == 0) {
                 const int row = f >> 3, k = k0 + (f & 7) * 4;
                 const int m = m0 + row;
-                if (m < p.M && k < kend) {
-                    const int64_t off = (int64_t)m * p.a_sm + k;
-                    if (p.vec_a) {
-                        v = *reinterpret_cast<const float4*>(Ab + off);
-                        if (A2b) {
-                            const float4 w = *reinterpret_cast<const float4*>(A2b + off);
-                            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-                        }
-                    } else {
-                        float t[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            t[e] = 0.f;
-                            if (k + e < kend) {
-                                t[e] = Ab[off + e];
-                                if (A2b) t[e] += A2b[off + e];
-                            }
-                        }
-                        v = make_float4(t[0], t[1], t[2], t[3]);
-                    }
+                if constexpr (VEC) {
+                    const int64_t off = (int64_t)min(m, p.M - 1) * p.a_sm + min(k, kend - 4);
+                    v = ld4(Ab + off);
+                    if constexpr (HAS_A2) ra2[i] = ld4(A2b + off);
+                } else {
+                    v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (m < p.M && k < kend) v = ld4_guarded(Ab, A2b, (int64_t)m * p.a_sm + k, kend - k);
                 }
             } else if constexpr (AMODE == 1) {
                 const int kk = f / (BM / 4), m = m0 + (f % (BM / 4)) * 4;
                 const int k = k0 + kk;
-                if (k < kend && m < p.M) {
-                    const int64_t off = (int64_t)k * p.a_sk + m;
-                    if (p.vec_a) {
-                        v = *reinterpret_cast<const float4*>(Ab + off);
-                        if (A2b) {
-                            const float4 w = *reinterpret_cast<const float4*>(A2b + off);
-                            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-                        }
-                    } else {
-                        float t[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            t[e] = 0.f;
-                            if (m + e < p.M) {
-                                t[e] = Ab[off + e];
-                                if (A2b) t[e] += A2b[off + e];
-                            }
-                        }
-                        v = make_float4(t[0], t[1], t[2], t[3]);
-                    }
+                if constexpr (VEC) {
+                    v = ld4(Ab + (int64_t)min(k, kend - 1) * p.a_sk + min(m, p.M - 4));
+                } else {
+                    v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (k < kend && m < p.M) v = ld4_guarded(Ab, nullptr, (int64_t)k * p.a_sk + m, p.M - m);
                 }
             } else {
                 // implicit im2col: k = tap*C + c, pixel (y,x) = (m / W, m % W), zero padding 1
-                const int row = f >> 3, k = k0 + (f & 7) * 4;
-                const int m = m0 + row;
-                if (m < p.M && k < kend) {
-                    const int tap = k / p.conv_c, c = k - tap * p.conv_c;
-                    const int y = m / p.conv_w, x = m - y * p.conv_w;
-                    const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-                    if (yy >= 0 && yy < p.conv_h && xx >= 0 && xx < p.conv_w) {
-                        v = *reinterpret_cast<const float4*>(Ab + ((int64_t)yy * p.conv_w + xx) * p.conv_c + c);
-                    }
-                }
+                const int k = min(k0 + (f & 7) * 4, kend - 4);
+                const int m = min(m0 + (f >> 3), p.M - 1);
+                const int tap = k / p.conv_c, c = k - tap * p.conv_c;
+                const int y = m / p.conv_w, x = m - y * p.conv_w;
+                const int yc = min(max(y + tap / 3 - 1, 0), p.conv_h - 1), xc = min(max(x + tap % 3 - 1, 0), p.conv_w - 1);
+                v = ld4(Ab + ((int64_t)yc * p.conv_w + xc) * p.conv_c + c);
             }
             ra[i] = v;
         }
@@ -135,42 +145,44 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
             const int f = tid + 256 * i;
             const int row = f >> 3, k = k0 + (f & 7) * 4;
             const int n = n0 + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < p.N && k < kend) {
-                const int64_t off = (int64_t)n * p.K + k;
-                if (p.vec_w) {
-                    v = *reinterpret_cast<const float4*>(Wb + off);
-                } else {
-                    float t[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) t[e] = (k + e < kend) ? Wb[off + e] : 0.f;
-                    v = make_float4(t[0], t[1], t[2], t[3]);
-                }
+            if constexpr (VEC) {
+                rb[i] = ld4(Wb + (int64_t)min(n, p.N - 1) * p.K + min(k, kend - 4));
+            } else {
+                rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (n < p.N && k < kend) rb[i] = ld4_guarded(Wb, nullptr, (int64_t)n * p.K + k, kend - k);
             }
-            rb[i] = v;
         }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int f = tid + 256 * i;
+            float4 v = ra[i];
+            if constexpr (VEC) {
+                if constexpr (HAS_A2) {
+                    v.x += ra2[i].x; v.y += ra2[i].y; v.z += ra2[i].z; v.w += ra2[i].w;
+                }
+                v = sel4(a_ok(i, k0), v);
+            }
             if constexpr (AMODE == 1) {
                 const int kk = f / (BM / 4), mm = (f % (BM / 4)) * 4;
-                *reinterpret_cast<float4*>(&As[kk * SM + mm]) = ra[i];
+                *reinterpret_cast<float4*>(&As[kk * SM + mm]) = v;
             } else {
                 const int row = f >> 3, c4 = (f & 7) * 4;
                 float2* d = reinterpret_cast<float2*>(&As[row * SK + c4]);
-                d[0] = make_float2(ra[i].x, ra[i].y);
-                d[1] = make_float2(ra[i].z, ra[i].w);
+                d[0] = make_float2(v.x, v.y);
+                d[1] = make_float2(v.z, v.w);
             }
         }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int f = tid + 256 * i;
             const int row = f >> 3, c4 = (f & 7) * 4;
+            float4 v = rb[i];
+            if constexpr (VEC) v = sel4(w_ok(i, k0), v);
             float2* d = reinterpret_cast<float2*>(&Bs[row * SK + c4]);
-            d[0] = make_float2(rb[i].x, rb[i].y);
-            d[1] = make_float2(rb[i].z, rb[i].w);
+            d[0] = make_float2(v.x, v.y);
+            d[1] = make_float2(v.z, v.w);
         }
     };
 
@@ -183,12 +195,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     load_a(kbeg);
     load_w(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        store_tiles();
+        store_tiles(k0);
         __syncthreads();
         if (k0 + BK < kend) {
             load_a(k0 + BK);
             load_w(k0 + BK);
         }
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above, the selects/LDS writes below the MFMAs
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
             float a[MI], bb[NI];
@@ -206,6 +219,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j) acc[i][j] = SWAP ? mfma16(bb[j], a[i], acc[i][j]) : mfma16(a[i], bb[j], acc[i][j]);
         }
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
     }
 
@@ -246,8 +260,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     }
 }
 
-template <int AMODE, bool SWAP>
+template <int AMODE, bool SWAP, bool HAS_A2>
 static int launch_gemm_o(const GemmArgs& p, hipStream_t st) {
+    dim3 block(256);
+    if (!(p.vec_a && p.vec_w)) {   // unaligned / odd shapes: guarded element-wise loads, smallest tile
+        dim3 grid(cdiv(p.N, 32), cdiv(p.M, 32), p.batch * p.split_k);
+        hipLaunchKernelGGL((gemm_kernel<1, 1, AMODE, SWAP, false, HAS_A2>), grid, block, 0, st, p);
+        MSM_CHECK_LAUNCH("msm_gemm_f32");
+        return MSM_OK;
+    }
     // pick the largest tile that still yields enough workgroups to cover the 256 CUs
     const int cfgs[5][2] = {{4, 4}, {2, 4}, {2, 2}, {1, 2}, {1, 1}};
     int pick = 4;
@@ -257,27 +278,26 @@ static int launch_gemm_o(const GemmArgs& p, hipStream_t st) {
     }
     const int mi = cfgs[pick][0], ni = cfgs[pick][1];
     dim3 grid(cdiv(p.N, 32 * ni), cdiv(p.M, 32 * mi), p.batch * p.split_k);
-    dim3 block(256);
     switch (pick) {
-        case 0: hipLaunchKernelGGL((gemm_kernel<4, 4, AMODE, SWAP>), grid, block, 0, st, p); break;
-        case 1: hipLaunchKernelGGL((gemm_kernel<2, 4, AMODE, SWAP>), grid, block, 0, st, p); break;
-        case 2: hipLaunchKernelGGL((gemm_kernel<2, 2, AMODE, SWAP>), grid, block, 0, st, p); break;
-        case 3: hipLaunchKernelGGL((gemm_kernel<1, 2, AMODE, SWAP>), grid, block, 0, st, p); break;
-        default: hipLaunchKernelGGL((gemm_kernel<1, 1, AMODE, SWAP>), grid, block, 0, st, p); break;
+        case 0: hipLaunchKernelGGL((gemm_kernel<4, 4, AMODE, SWAP, true, HAS_A2>), grid, block, 0, st, p); break;
+        case 1: hipLaunchKernelGGL((gemm_kernel<2, 4, AMODE, SWAP, true, HAS_A2>), grid, block, 0, st, p); break;
+        case 2: hipLaunchKernelGGL((gemm_kernel<2, 2, AMODE, SWAP, true, HAS_A2>), grid, block, 0, st, p); break;
+        case 3: hipLaunchKernelGGL((gemm_kernel<1, 2, AMODE, SWAP, true, HAS_A2>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_kernel<1, 1, AMODE, SWAP, true, HAS_A2>), grid, block, 0, st, p); break;
     }
     MSM_CHECK_LAUNCH("msm_gemm_f32");
     return MSM_OK;
 }
 
-template <int AMODE>
+template <int AMODE, bool HAS_A2>
 static int launch_gemm(GemmArgs& p, hipStream_t st) {
     const bool c16 = (((uintptr_t)p.C) & 15) == 0 && p.c_sb % 4 == 0 && p.c_ss % 4 == 0;
     if (p.c_sn == 1) {                     // row-major output: 4 consecutive n per lane
         p.vec_c = c16 && p.c_sm % 4 == 0;
-        return launch_gemm_o<AMODE, true>(p, st);
+        return launch_gemm_o<AMODE, true, HAS_A2>(p, st);
     }
     p.vec_c = c16 && p.c_sm == 1 && p.c_sn % 4 == 0;   // m-contiguous (NCHW) output
-    return launch_gemm_o<AMODE, false>(p, st);
+    return launch_gemm_o<AMODE, false, HAS_A2>(p, st);
 }
 
 }  // namespace msm
@@ -312,14 +332,16 @@ extern "C" int msm_gemm_f32(const float* A, const float* A2, const float* W, con
         MSM_REQUIRE(conv_c % 4 == 0 && K == 9 * conv_c && M == conv_h * conv_w && a16 && a_sb % 4 == 0 && !A2,
                     "msm_gemm_f32: bad implicit-conv arguments");
         p.vec_a = 1;
-        return launch_gemm<2>(p, st);
+        MSM_REQUIRE(p.vec_w, "msm_gemm_f32: implicit-conv weights must be 16-byte aligned");
+        return launch_gemm<2, false>(p, st);
     }
     MSM_REQUIRE(a_mode == 0, "msm_gemm_f32: a_mode must be 0 or 2");
     if (a_sk == 1) {
         p.vec_a = a16 && (K % 4 == 0) && (a_sm % 4 == 0) && (a_sb % 4 == 0) && (a2_sb % 4 == 0);
-        return launch_gemm<0>(p, st);
+        return A2 ? launch_gemm<0, true>(p, st) : launch_gemm<0, false>(p, st);
     }
     MSM_REQUIRE(a_sm == 1, "msm_gemm_f32: one of a_sm/a_sk must be 1");
-    p.vec_a = a16 && (M % 4 == 0) && (a_sk % 4 == 0) && (a_sb % 4 == 0) && (a2_sb % 4 == 0);
-    return launch_gemm<1>(p, st);
+    MSM_REQUIRE(!A2, "msm_gemm_f32: A2 is only supported for K-contiguous A");
+    p.vec_a = a16 && (M % 4 == 0) && (a_sk % 4 == 0) && (a_sb % 4 == 0);
+    return launch_gemm<1, false>(p, st);
 }
