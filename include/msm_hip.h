@@ -145,6 +145,22 @@ int msm_msdeform_attn_enc_fwd(const float* value, const int64_t* spatial_shapes,
                               int B, int S, int M, int D, int L, int P, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused token-wise block of one MSDeformAttn encoder layer (msdeformattn.py:122-131):
+ *   src_out = LN2(x + linear2(relu(linear1(x)))),  x = LN1(src + output_proj(attn))
+ * and, when value_out/proj_out are given, the NEXT layer's value_proj(src_out) and
+ * [sampling_offsets | attention_weights](src_out + pos) (ops/modules/ms_deform_attn.py:95-104).
+ *   attn, src, src_out, value_out: [M][64]; proj_out [M][proj_width]; pos [S][64], token t uses pos[t % S].
+ *   wstream: the layer's weights packed by the host into 32 KiB chunks of 4 KiB blocks in consumption
+ *   order (unseenobjectswithmeanshift_amd/modeling.py::pack_encoder_block documents the layout);
+ *   msm_encoder_block_stream_floats() gives its length.  small: bo,g1,be1 (64 each), b1 (d_ffn), b2,
+ *   g2,be2,bv (64 each), bp (proj_width).  d_model is fixed to 64.
+ * ------------------------------------------------------------------------------------------- */
+int64_t msm_encoder_block_stream_floats(int d_ffn, int proj_width);
+int msm_encoder_block_fwd(const float* attn, const float* src, const float* wstream, const float* small,
+                          const float* pos, float* src_out, float* value_out, float* proj_out,
+                          int M, int S, int d_ffn, int proj_width, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Classic vMF mean shift over unit embeddings X [n][d] (d == 64), cosine metric.
  * ------------------------------------------------------------------------------------------- */
 /* Farthest-point seeding (MS:155-187): indices[0] = first_index, then S-1 x { nearest =

@@ -276,3 +276,45 @@ def test_topk_and_postprocess():
         if not mism.any():
             close(boxes[b], O.mask_boxes(up > 0), rtol=0, atol=0)
     assert float(ms[0, 0]) == 0.0 and torch.equal(boxes[0, 0].cpu(), torch.zeros(4))
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,S,want_next", [(2, 394, True), (1, 50, False), (3, 130, True)])
+def test_encoder_block_fused(B, S, want_next):
+    """Fused encoder-layer tail vs the same chain in plain torch fp32 (msdeformattn.py:116-126)."""
+    C, DF, PW = 64, 1024, 288
+    attn, src, pos = rnd(B, S, C, seed=1), rnd(B, S, C, seed=2), rnd(S, C, seed=3)
+    wo, bo = rnd(C, C, seed=4, scale=C ** -0.5), rnd(C, seed=5, scale=0.1)
+    w1, b1 = rnd(DF, C, seed=6, scale=C ** -0.5), rnd(DF, seed=7, scale=0.1)
+    w2, b2 = rnd(C, DF, seed=8, scale=DF ** -0.5), rnd(C, seed=9, scale=0.1)
+    g1, be1, g2, be2 = 1 + 0.1 * rnd(C, seed=10), rnd(C, seed=11, scale=0.1), 1 + 0.1 * rnd(C, seed=12), rnd(C, seed=13, scale=0.1)
+    wv, bv = rnd(C, C, seed=14, scale=C ** -0.5), rnd(C, seed=15, scale=0.1)
+    wp, bp = rnd(PW, C, seed=16, scale=C ** -0.5), rnd(PW, seed=17)
+    x = F.layer_norm(src + F.linear(attn, wo, bo), (C,), g1, be1)
+    y = F.layer_norm(x + F.linear(F.relu(F.linear(x, w1, b1)), w2, b2), (C,), g2, be2)
+    d = lambda t: t.to(DEV).contiguous()
+    stream = ops().pack_encoder_block(d(wo), d(w1), d(w2), d(wv) if want_next else None, d(wp) if want_next else None)
+    small = torch.cat([bo, g1, be1, b1, b2, g2, be2, bv, bp]).to(DEV)
+    so, vo, po = ops().encoder_block(d(attn), d(src), stream, small, DF, PW, pos=d(pos), tokens_per_image=S, want_next=want_next)
+    close(so, y, rtol=1e-4, atol=2e-5)
+    if want_next:
+        close(vo, F.linear(y, wv, bv), rtol=1e-4, atol=2e-5)
+        close(po, F.linear(y + pos, wp, bp), rtol=1e-4, atol=5e-5)
+    else:
+        assert vo is None and po is None
+
+
+def test_pixel_decoder_fused_equals_unfused():
+    from unseenobjectswithmeanshift_amd import synthetic as syn
+    from unseenobjectswithmeanshift_amd.meta_arch import build_resnet50_head
+    head = build_resnet50_head()
+    head.pixel_decoder.load_state_dict(syn.synth_state_dict(syn.pixel_decoder_param_shapes()), strict=True)
+    pd = head.pixel_decoder.to(DEV).eval()
+    feats = {k: v.to(DEV) for k, v in syn.synth_backbone_features(2, 64, 96, seed=3).items()}
+    pd.fused_encoder = True
+    a = pd.forward_features(feats)
+    pd.fused_encoder = False
+    b = pd.forward_features(feats)
+    torch.testing.assert_close(a[0], b[0], rtol=1e-4, atol=5e-5)
+    for x, y in zip(a[2], b[2]):
+        torch.testing.assert_close(x, y, rtol=1e-4, atol=5e-5)

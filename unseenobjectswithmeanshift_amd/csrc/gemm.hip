@@ -11,6 +11,8 @@
 // (lane = (row l&15, k-slot l>>4)) are bank-conflict free for ds_read_b32:
 //   K-contiguous tiles  [rows][34]   : bank = (2*row + k) mod 32, distinct over the two 32-lane halves
 //   M-contiguous tiles  [32][BM+16]  : bank = (16*k + row) mod 32, likewise.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace msm {
@@ -26,6 +28,7 @@ struct GemmArgs {
     int conv_h, conv_w, conv_c;
     int bias_mode, act, split_k, k_per_split;
     int vec_a, vec_w, vec_c;
+    int dbg_nostore;   // tuning only (MSM_GEMM_NOSTORE=1): skip the epilogue stores
 };
 
 constexpr int BK = 32;
@@ -246,6 +249,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
                 }
                 v[r] = t;
             }
+            if (p.dbg_nostore && v[0] != 12345.678f) continue;
             float* dst = Cb + (int64_t)mb * p.c_sm + (int64_t)nb * p.c_sn;
             const bool full = SWAP ? (nb + 3 < p.N) : (mb + 3 < p.M);
             if (p.vec_c && full) {
@@ -269,13 +273,24 @@ static int launch_gemm_o(const GemmArgs& p, hipStream_t st) {
         MSM_CHECK_LAUNCH("msm_gemm_f32");
         return MSM_OK;
     }
-    // pick the largest tile that still yields enough workgroups to cover the 256 CUs
+    // tile choice (measured on MI355X, tools/microbench.py): 64x64 workgroup tiles beat 128x128 and 64x128
+    // on every shape of this model (more resident workgroups hide the LDS/barrier phases), so the order
+    // of preference is 64x64, 32x64, 32x32: the first that wastes < 20 % of its MFMA work on M/N padding
+    // and still yields >= 2 workgroups per CU; failing that, the low-waste tile with the most workgroups.
+    // 128x128 / 64x128 stay reachable through MSM_GEMM_TILE=0/1 for tuning.
     const int cfgs[5][2] = {{4, 4}, {2, 4}, {2, 2}, {1, 2}, {1, 1}};
-    int pick = 4;
-    for (int c = 0; c < 5; ++c) {
-        const int64_t blocks = (int64_t)cdiv(p.M, 32 * cfgs[c][0]) * cdiv(p.N, 32 * cfgs[c][1]) * p.batch * p.split_k;
+    int pick = -1, best_blocks = -1, fallback = 4;
+    for (int c = 2; c < 5; ++c) {
+        const int64_t bm = 32 * cfgs[c][0], bn = 32 * cfgs[c][1];
+        const int64_t gm = cdiv(p.M, bm), gn = cdiv(p.N, bn);
+        const double waste = 1.0 - (double)p.M * p.N / ((double)gm * bm * gn * bn);
+        const int64_t blocks = gm * gn * p.batch * p.split_k;
+        if (waste > 0.2 && c < 4) continue;
         if (blocks >= 512) { pick = c; break; }
+        if (blocks > best_blocks) { best_blocks = (int)blocks; fallback = c; }
     }
+    if (pick < 0) pick = fallback;
+    if (const char* e = getenv("MSM_GEMM_TILE")) pick = atoi(e);
     const int mi = cfgs[pick][0], ni = cfgs[pick][1];
     dim3 grid(cdiv(p.N, 32 * ni), cdiv(p.M, 32 * mi), p.batch * p.split_k);
     switch (pick) {
@@ -321,6 +336,7 @@ extern "C" int msm_gemm_f32(const float* A, const float* A2, const float* W, con
     p.c_sm = c_sm; p.c_sn = c_sn; p.c_sb = c_sb; p.c_ss = c_ss;
     p.conv_h = conv_h; p.conv_w = conv_w; p.conv_c = conv_c;
     p.bias_mode = bias_mode; p.act = act; p.split_k = split_k;
+    p.dbg_nostore = getenv("MSM_GEMM_NOSTORE") != nullptr;
     int kps = cdiv(K, split_k);
     kps = cdiv(kps, BK) * BK;  // whole LDS tiles per split
     p.k_per_split = kps;

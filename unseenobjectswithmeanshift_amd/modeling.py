@@ -477,6 +477,32 @@ class MSDeformAttnPixelDecoder(nn.Module):
             self.add_module("adapter_{}".format(idx + 1), _ConvNorm(cin, conv_dim, 1, False, conv_dim))
             self.add_module("layer_{}".format(idx + 1), _ConvNorm(conv_dim, conv_dim, 3, False, conv_dim))
         self._cache = {}
+        self._packed = None
+        self.fused_encoder = True      # False: one GEMM / LayerNorm launch per op (same results up to rounding)
+
+    def _packed_encoder(self, device):
+        """Weight streams of the fused encoder kernel, rebuilt only when a parameter changes."""
+        layers = self.transformer.encoder.layers
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.transformer.encoder.parameters())
+        if self._packed is None or self._packed[0] != key:
+            out = []
+            for l, layer in enumerate(layers):
+                nxt = layers[l + 1].self_attn if l + 1 < len(layers) else None
+                a = layer.self_attn
+                wv = wp = None
+                smalls = [a.output_proj.bias, layer.norm1.weight, layer.norm1.bias, layer.linear1.bias, layer.linear2.bias,
+                          layer.norm2.weight, layer.norm2.bias]
+                if nxt is not None:
+                    wv = nxt.value_proj.weight
+                    wp, bp = nxt._proj_weights()
+                    smalls += [nxt.value_proj.bias, bp]
+                else:
+                    smalls += [torch.zeros(64, device=device), torch.zeros(a.sampling_offsets.out_features + a.attention_weights.out_features, device=device)]
+                stream = ops.pack_encoder_block(a.output_proj.weight, layer.linear1.weight, layer.linear2.weight, wv, wp)
+                pw = a.sampling_offsets.out_features + a.attention_weights.out_features
+                out.append((stream, torch.cat([t.reshape(-1) for t in smalls]).contiguous(), layer.linear1.out_features, pw))
+            self._packed = (key, out)
+        return self._packed[1]
 
     @classmethod
     def from_config(cls, cfg, input_shape):
@@ -514,8 +540,24 @@ class MSDeformAttnPixelDecoder(nn.Module):
         dev = toks[0].device
         ss, starts, lvl_pos = self._geometry(shapes, dev)
         src = torch.cat(toks, 1).contiguous()                                     # (B,S,C)
-        for layer in self.transformer.encoder.layers:
-            src = layer.forward_tokens(src, lvl_pos, ss, starts)
+        layers = self.transformer.encoder.layers
+        if self.fused_encoder and C == 64:
+            # layer l = MSDeformAttn gather + ONE fused token-wise kernel that also emits layer l+1's
+            # value / sampling projections (the 1024-wide FFN activation never leaves registers)
+            packed = self._packed_encoder(dev)
+            a0 = layers[0].self_attn
+            value = ops.gemm(src, a0.value_proj.weight, a0.value_proj.bias)
+            w, b = a0._proj_weights()
+            proj = ops.gemm(src, w, b, a2=lvl_pos)
+            S_tok = src.shape[1]
+            for l, layer in enumerate(layers):
+                attn = ops.ms_deform_attn_encoder(value, ss, starts, proj, layer.self_attn.n_heads, layer.self_attn.n_points)
+                stream, small, d_ffn, pw = packed[l]
+                src, value, proj = ops.encoder_block(attn, src, stream, small, d_ffn, pw, pos=lvl_pos, tokens_per_image=S_tok,
+                                                     want_next=l + 1 < len(layers), eps=layer.norm1.eps)
+        else:
+            for layer in layers:
+                src = layer.forward_tokens(src, lvl_pos, ss, starts)
         out_tok, out, o = [], [], 0
         for (h, w) in shapes:
             t = src[:, o:o + h * w].contiguous()

@@ -329,3 +329,46 @@ def instance_postprocess(mask_logits, query_index, image_size, class_scores=None
                                         B, Q, T, h, w, H, W, _p(ws), _stream())
     check(rc, "msm_instance_postprocess")
     return masks, score, boxes
+
+
+# ----------------------------------------------------------------------------------------------
+# fused encoder block (msdeformattn.py:122-131)
+# ----------------------------------------------------------------------------------------------
+def pack_encoder_block(wo, w1, w2, wv=None, wp=None):
+    """Pack one encoder layer's matrices into the weight stream consumed by msm_encoder_block_fwd.
+
+    Stream = chunks of 8 blocks, one block = 1024 floats (4 KiB):
+      chunk 0            : output_proj  -- 4 row blocks [16 out rows][64 k] (+4 zero blocks)
+      chunks 1..d_ffn/64 : 4 x ( linear1 row block [16 hidden rows][64 k] , linear2 block [64 out rows][16 hidden] )
+      then (only with the next layer's wv/wp): value_proj 4 row blocks, then [offsets|weights] row blocks,
+      continuing into further chunks of 8.
+    A "row block" is 16 consecutive rows of a (N, 64) weight; the kernel applies the LDS swizzle itself."""
+    dev = wo.device
+    d_ffn = w1.shape[0]
+    blocks = [wo.reshape(4, 1024)] + [torch.zeros(4, 1024, device=dev)]
+    w1b = w1.reshape(d_ffn // 16, 1024)                                                # (hb, 16 rows * 64 k)
+    w2b = w2.reshape(64, d_ffn // 16, 16).permute(1, 0, 2).reshape(d_ffn // 16, 1024)    # (hb, 64 rows * 16 k)
+    blocks.append(torch.stack([w1b, w2b], 1).reshape(-1, 1024))                        # interleaved per hb
+    if wv is not None:
+        npb = wp.shape[0] // 16
+        tail = torch.cat([wv.reshape(4, 1024), wp.reshape(npb, 1024)], 0)
+        pad = (-tail.shape[0]) % 8
+        blocks += [tail, torch.zeros(pad, 1024, device=dev)]
+    return torch.cat(blocks, 0).reshape(-1).contiguous()
+
+
+def encoder_block(attn, src, wstream, small, d_ffn, proj_width, *, pos=None, tokens_per_image=None, want_next=True, eps=1e-5):
+    """One fused encoder-layer tail.  attn/src (B,S,64).  Returns (src_out, value_out, proj_out) with the
+    last two None when want_next is False."""
+    _c(attn, "attn"), _c(src, "src"), _c(wstream, "wstream"), _c(small, "small"), _c(pos, "pos")
+    B, S, C = src.shape
+    M = B * S
+    src_out = torch.empty_like(src)
+    value_out = proj_out = None
+    if want_next:
+        value_out = torch.empty_like(src)
+        proj_out = torch.empty((B, S, proj_width), device=src.device, dtype=torch.float32)
+    rc = lib().msm_encoder_block_fwd(_p(attn), _p(src), _p(wstream), _p(small), _p(pos), _p(src_out), _p(value_out),
+                                     _p(proj_out), M, tokens_per_image or S, d_ffn, proj_width, eps, _stream())
+    check(rc, "msm_encoder_block_fwd")
+    return src_out, value_out, proj_out
