@@ -56,7 +56,8 @@ int msm_abi_version(void);
  *   A2 (nullable) uses the strides of A with its own batch stride a2_sb (0 = broadcast).
  *   W is [N][K] row-major (torch Linear / 1x1-conv weight), batch stride w_sb (0 = shared).
  *   C element (m,n) at C + b*c_sb + m*c_sm + n*c_sn (any strides).
- *   bias_mode 0 none, 1 bias[n], 2 bias[m].   act 0 none, 1 relu.
+ *   bias_mode 0 none, 1 bias[n], 2 bias[m], 3 bias[m*N + n] (an [M][N] matrix shared by the batch).
+ *   act 0 none, 1 relu.
  *   split_k > 1: K is cut in split_k equal parts, part s writes raw sums (no bias/act) to
  *   C + s*c_ss; the consumer (msm_layernorm_f32) adds the parts.
  * ------------------------------------------------------------------------------------------- */

@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
                 if (!raw && m < p.M && n < p.N) {
                     if (p.bias_mode == 1) t += p.bias[n];
                     else if (p.bias_mode == 2) t += p.bias[m];
+                    else if (p.bias_mode == 3) t += p.bias[(int64_t)m * p.N + n];
                     if (p.act == 1) t = fmaxf(t, 0.f);
                 }
                 v[r] = t;

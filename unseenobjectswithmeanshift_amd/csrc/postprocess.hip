@@ -70,26 +70,38 @@ __global__ __launch_bounds__(256) void inst_upsample_kernel(const float* __restr
     double sum = 0.0;
     unsigned int cnt = 0;
     int xmin = 0x7fffffff, ymin = 0x7fffffff, xmax = -1, ymax = -1;
+    const bool vec = (W % 4) == 0;     // 4 pixels per thread, one 16-byte store
     for (int y = y0; y < y1; ++y) {
         int ya, yb;
         float ly;
         src_index(y, sy, h, ya, yb, ly);
         const float hy = 1.f - ly;
-        for (int x = blockIdx.x * 256 + threadIdx.x; x < W; x += gridDim.x * 256) {
-            int xa, xb;
-            float lx;
-            src_index(x, sx, w, xa, xb, lx);
-            const float hx = 1.f - lx;
-            const float m = hy * (hx * src[ya * w + xa] + lx * src[ya * w + xb]) +
-                            ly * (hx * src[yb * w + xa] + lx * src[yb * w + xb]);
-            const bool on = m > 0.f;
-            dst[(int64_t)y * W + x] = on ? 1.f : 0.f;
-            if (on) {
-                sum += (double)(1.0f / (1.0f + expf(-m)));
-                cnt += 1;
-                xmin = min(xmin, x); xmax = max(xmax, x);
-                ymin = min(ymin, y); ymax = max(ymax, y);
+        const float* ra = src + ya * w;
+        const float* rb = src + yb * w;
+        const int step = vec ? 4 : 1;
+        for (int x0 = (blockIdx.x * 256 + threadIdx.x) * step; x0 < W; x0 += gridDim.x * 256 * step) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = 0.f;
+                if (e < step) {
+                    const int x = x0 + e;
+                    int xa, xb;
+                    float lx;
+                    src_index(x, sx, w, xa, xb, lx);
+                    const float hx = 1.f - lx;
+                    const float m = hy * (hx * ra[xa] + lx * ra[xb]) + ly * (hx * rb[xa] + lx * rb[xb]);
+                    if (m > 0.f) {
+                        o[e] = 1.f;
+                        sum += (double)(1.0f / (1.0f + expf(-m)));
+                        cnt += 1;
+                        xmin = min(xmin, x); xmax = max(xmax, x);
+                        ymin = min(ymin, y); ymax = max(ymax, y);
+                    }
+                }
             }
+            if (vec) *reinterpret_cast<float4*>(dst + (int64_t)y * W + x0) = make_float4(o[0], o[1], o[2], o[3]);
+            else dst[(int64_t)y * W + x0] = o[0];
         }
     }
     // wave reduce, then one set of atomics per wave
@@ -153,13 +165,14 @@ extern "C" int msm_instance_postprocess(const float* mask_logits, const int32_t*
     MSM_REQUIRE(mask_logits && query_index && pred_masks && mask_score && boxes && workspace,
                 "msm_instance_postprocess: null pointer");
     MSM_REQUIRE(B > 0 && Q > 0 && T > 0 && h > 0 && w > 0 && H > 0 && W > 0, "msm_instance_postprocess: bad sizes");
-    MSM_REQUIRE((((uintptr_t)workspace) & 7) == 0 && (((uintptr_t)boxes) & 15) == 0, "msm_instance_postprocess: misaligned pointer");
+    MSM_REQUIRE((((uintptr_t)workspace) & 7) == 0 && (((uintptr_t)boxes) & 15) == 0 && (((uintptr_t)pred_masks) & 15) == 0,
+                "msm_instance_postprocess: misaligned pointer");
     hipStream_t st = (hipStream_t)stream;
     InstAcc* acc = reinterpret_cast<InstAcc*>(workspace);
     const int n = B * T;
     hipLaunchKernelGGL(inst_init_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, acc, n);
     const int rows = 16;
-    dim3 grid(cdiv(W, 256), cdiv(H, rows), n);
+    dim3 grid(cdiv((W % 4 == 0) ? W / 4 : W, 256), cdiv(H, rows), n);
     hipLaunchKernelGGL(inst_upsample_kernel, grid, dim3(256), 0, st, mask_logits, query_index, pred_masks, acc, Q, T, h, w, H,
                        W, rows);
     hipLaunchKernelGGL(inst_finish_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, acc, class_scores, mask_score, boxes, n);

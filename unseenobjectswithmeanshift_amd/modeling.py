@@ -220,6 +220,11 @@ class MeanShiftTransformerDecoder(nn.Module):
         self.class_embed = nn.Linear(hidden_dim, num_classes + 1)
         self.mask_embed = MLP(hidden_dim, hidden_dim, mask_dim, 3)
         self._pos_cache = {}
+        self._kv_cache = None
+        # K/V of every cross-attention layer come from ONE K=64 GEMM on the raw level features: input_proj,
+        # level embedding, position code and the in-projection are folded into per-layer constants
+        # (see _folded_kv).  False: materialise src = input_proj(x)+level_embed and project it (K=256).
+        self.fold_kv = True
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
                               error_msgs):
@@ -254,6 +259,39 @@ class MeanShiftTransformerDecoder(nn.Module):
                                                       scale=float(self.pe_layer.scale))
         return self._pos_cache[key]
 
+    def _folded_kv(self, sizes, device):
+        """Per layer i (level l = i % 3):  K_i = (input_proj_l(x) + level_embed_l + pos_l) Wk_i^T + bk_i
+                                        V_i = (input_proj_l(x) + level_embed_l)         Wv_i^T + bv_i
+        (DEC:575, AU:134-140) are affine in x, so they equal x [Wk_i Wp_l ; Wv_i Wp_l]^T + C_i with an
+        input-independent (H_l W_l, 2E) matrix C_i.  Folding cuts the projection FLOPs 4x (K = 64 instead
+        of 256) and removes the src tensors; the constants are evaluated in fp64 once per checkpoint/shape."""
+        E = self.query_feat.weight.shape[1]
+        params = [self.level_embed.weight] + [p for m in self.input_proj for p in m.parameters()] + \
+                 [p for l in self.transformer_cross_attention_layers for p in (l.meanshift_attn.in_proj_weight, l.meanshift_attn.in_proj_bias)]
+        key = (tuple(sizes), str(device)) + tuple((p.data_ptr(), p._version) for p in params)
+        if self._kv_cache is None or self._kv_cache[0] != key:
+            ws, cs = [], []
+            for i, layer in enumerate(self.transformer_cross_attention_layers):
+                l = i % self.num_feature_levels
+                h, w = sizes[l]
+                a = layer.meanshift_attn
+                wk, wv = a.in_proj_weight[E:2 * E].double(), a.in_proj_weight[2 * E:].double()
+                bk, bv = a.in_proj_bias[E:2 * E].double(), a.in_proj_bias[2 * E:].double()
+                lvl = self.level_embed.weight[l].double()
+                if isinstance(self.input_proj[l], nn.Conv2d):
+                    wp = self.input_proj[l].weight.view(E, -1).double()
+                    off = self.input_proj[l].bias.double() + lvl
+                else:
+                    wp = torch.eye(E, dtype=torch.float64, device=device)
+                    off = lvl
+                pos = self._pos_tokens(h, w, device).double()
+                kc = (pos + off) @ wk.t() + bk                               # (hw, E)
+                vc = (off @ wv.t() + bv).expand(h * w, -1)                   # (hw, E)
+                ws.append(torch.cat([wk @ wp, wv @ wp], 0).float().contiguous())
+                cs.append(torch.cat([kc, vc], 1).float().contiguous())
+            self._kv_cache = (key, ws, cs)
+        return self._kv_cache[1], self._kv_cache[2]
+
     def _heads(self, d, mask_features, target_size, want_mask, want_cls):
         cls = ops.gemm(d, self.class_embed.weight, self.class_embed.bias) if want_cls else None
         e = self.mask_embed(d)
@@ -268,19 +306,22 @@ class MeanShiftTransformerDecoder(nn.Module):
         B = x[0].shape[0]
         dev = x[0].device
         E = self.query_feat.weight.shape[1]
-        src, pos, sizes = [], [], []
+        src, pos, sizes, xs = [], [], [], []
         for i in range(self.num_feature_levels):
             h, w = x[i].shape[-2:]
             sizes.append((int(h), int(w)))
-            pos.append(self._pos_tokens(int(h), int(w), dev))
-            xi = x[i].contiguous()
-            if isinstance(self.input_proj[i], nn.Conv2d):
-                wt = self.input_proj[i].weight.view(E, -1)
-                bias = self.input_proj[i].bias + self.level_embed.weight[i]          # DEC:575
-                src.append(ops.conv1x1_nchw_to_tokens(xi, wt, bias.contiguous()))
-            else:
-                t = ops.transpose_last2(xi.flatten(2))
-                src.append(t + self.level_embed.weight[i])
+            xs.append(x[i].contiguous())
+        if self.fold_kv:
+            kv_w, kv_c = self._folded_kv(sizes, dev)
+        else:
+            for i in range(self.num_feature_levels):
+                pos.append(self._pos_tokens(*sizes[i], dev))
+                if isinstance(self.input_proj[i], nn.Conv2d):
+                    wt = self.input_proj[i].weight.view(E, -1)
+                    bias = self.input_proj[i].bias + self.level_embed.weight[i]          # DEC:575
+                    src.append(ops.conv1x1_nchw_to_tokens(xs[i], wt, bias.contiguous()))
+                else:
+                    src.append(ops.transpose_last2(xs[i].flatten(2)) + self.level_embed.weight[i])
         mask_features = mask_features.contiguous()
         qpos = self.query_embed.weight
         out = self.query_feat.weight[None].expand(B, -1, -1).contiguous()
@@ -294,8 +335,13 @@ class MeanShiftTransformerDecoder(nn.Module):
         for i in range(L):
             lvl = i % self.num_feature_levels                                     # DEC:608
             ca = self.transformer_cross_attention_layers[i]
-            t2 = ca.meanshift_attn.attend(out, src[lvl], src[lvl], query_pos=qpos, key_pos=pos[lvl],
-                                          masked=attn, row_any=row_any)
+            if self.fold_kv:
+                kv = ops.conv1x1_nchw_to_tokens(xs[lvl], kv_w[i], kv_c[i])            # (B, hw, 2E) = [K | V]
+                t2 = ca.meanshift_attn.attend(out, None, None, query_pos=qpos, masked=attn, row_any=row_any,
+                                              kv=(kv[..., :E], kv[..., E:]))
+            else:
+                t2 = ca.meanshift_attn.attend(out, src[lvl], src[lvl], query_pos=qpos, key_pos=pos[lvl],
+                                              masked=attn, row_any=row_any)
             out = ops.layernorm(out, ca.norm.weight, ca.norm.bias, parts=t2[None])
             sa = self.transformer_self_attention_layers[i]
             w, b = sa.self_attn.in_proj_weight, sa.self_attn.in_proj_bias

@@ -77,15 +77,19 @@ def gemm(a, w, bias=None, *, a2=None, act=None, out=None, split_k=1):
 
 def conv1x1_nchw_to_tokens(x, w, bias=None):
     """x (B, Cin, H, W) NCHW -> tokens (B, H*W, Cout) = x^T w^T + bias (a 1x1 Conv2d read through
-    the GEMM's M-contiguous A path; no transpose pass)."""
+    the GEMM's M-contiguous A path; no transpose pass).  bias: (Cout,) per channel, or (H*W, Cout) a
+    per-position matrix shared by the batch."""
     _c(x, "x"), _c(w, "w"), _c(bias, "bias")
     B, Cin, H, W = x.shape
     Cout = w.shape[0]
     HW = H * W
     out = torch.empty((B, HW, Cout), device=x.device, dtype=torch.float32)
+    mode = 0 if bias is None else (1 if bias.dim() == 1 else 3)
+    if mode == 3 and tuple(bias.shape) != (HW, Cout):
+        raise RuntimeError("matrix bias must be (H*W, Cout)")
     rc = lib().msm_gemm_f32(_p(x), None, _p(w), _p(bias), _p(out), HW, Cout, Cin, B,
                             1, HW, Cin * HW, 0, 0, Cout, 1, HW * Cout, 0,
-                            0, 0, 0, 0, 1 if bias is not None else 0, 0, 1, _stream())
+                            0, 0, 0, 0, mode, 0, 1, _stream())
     check(rc, "msm_gemm_f32(conv1x1 nchw)")
     return out
 
