@@ -136,6 +136,21 @@ def test_decoder_480x640_vs_reference(golden):
     assert (inter / union)[union > 1].min() >= 0.99          # final instance-mask IoU
 
 
+def test_decoder_execution_variants_agree():
+    """Folded vs explicit K/V projection and side-stream overlap on/off are the same computation."""
+    dec = make_decoder()
+    x, mf = syn.synth_decoder_inputs(2, 64, 96, seed=7)
+    xd, mfd = [t.to(DEV) for t in x], mf.to(DEV)
+    ref = dec(xd, mfd)
+    dec.overlap_kv = False
+    a = dec(xd, mfd)
+    assert torch.equal(a["pred_masks"], ref["pred_masks"]) and torch.equal(a["pred_logits"], ref["pred_logits"])
+    dec.fold_kv = False
+    b = dec(xd, mfd)
+    torch.testing.assert_close(b["pred_logits"], ref["pred_logits"], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(b["pred_masks"], ref["pred_masks"], rtol=1e-4, atol=3e-4)
+
+
 def test_decoder_batch_consistency():
     """Images are independent units: a batch of 4 equals four batches of 1 (data-parallel sharding)."""
     dec = make_decoder()

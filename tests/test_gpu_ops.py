@@ -112,10 +112,12 @@ def ref_mask_step(e, f, tgt):
     return mask, (m.sigmoid().flatten(2) < 0.5)
 
 
+@pytest.mark.parametrize("nc", ["2", "1"])
 @pytest.mark.parametrize("B,Q,H,W,pool", [(2, 100, 16, 24, 2), (2, 100, 16, 24, 4), (2, 100, 16, 24, 8),
                                           (1, 100, 120, 160, 8), (1, 100, 120, 160, 4), (1, 100, 120, 160, 2),
-                                          (1, 300, 48, 64, 4), (2, 20, 8, 8, 2)])
-def test_mask_logits(B, Q, H, W, pool):
+                                          (1, 300, 48, 64, 4), (2, 20, 8, 8, 2), (2, 100, 16, 24, 1), (1, 100, 60, 80, 1)])
+def test_mask_logits(B, Q, H, W, pool, nc, monkeypatch):
+    monkeypatch.setenv("MSM_MASK_NC", nc)          # wave tile 2x32 (8-byte loads) or 2x16 (4-byte loads)
     C = 256
     e, f = rnd(B, Q, C, seed=1, scale=0.3), rnd(B, C, H, W, seed=2)
     tgt = (H // pool, W // pool)
@@ -135,6 +137,15 @@ def test_mask_logits(B, Q, H, W, pool):
     mask, attn, row_any = ops().mask_logits(e.to(DEV), f.to(DEV), want_mask=True, target_size=None)
     close(mask, mask_ref, rtol=1e-4, atol=1e-4)
     assert attn is None and row_any is None
+
+
+def test_mask_logits_tile_choice_is_result_neutral(monkeypatch):
+    e, f = rnd(8, 100, 256, seed=3, scale=0.3).to(DEV), rnd(8, 256, 120, 160, seed=4).to(DEV)
+    outs = []
+    for nc in ("2", "1"):
+        monkeypatch.setenv("MSM_MASK_NC", nc)
+        outs.append(ops().mask_logits(e, f, want_mask=True, target_size=(30, 40)))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
 
 
 # ---------------------------------------------------------------------------------------------

@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""Turn rocprofv3 outputs under gpurun_out/ into the small tracked summaries under profiles/.
+   python tools/summarize_profile.py <prof_dir> <tag> [pmc_dir ...]"""
+import collections
+import csv
+import glob
+import os
+import shutil
+import sys
+
+prof, tag = sys.argv[1], sys.argv[2]
+os.makedirs("profiles", exist_ok=True)
+stats = glob.glob(os.path.join(prof, "*kernel_stats.csv"))[0]
+shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
+rows = list(csv.DictReader(open(stats)))
+with open(f"profiles/{tag}_kernel_stats.md", "w") as f:
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    f.write(f"# rocprofv3 --kernel-trace --stats summary ({tag})\n\n")
+    f.write("command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 2 --no-graph --no-cpu-baseline` "
+            "(16 passes of the hot path per run: 2 warm-up + 10 timed + 3 event-timed + 1 phase-timed)\n\n")
+    f.write("| kernel | calls | avg us | total ms | % |\n|---|---:|---:|---:|---:|\n")
+    for r in rows[:30]:
+        f.write(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['TotalDurationNs']) / 1e6:.2f} | "
+                f"{100 * float(r['TotalDurationNs']) / tot:.1f} |\n")
+    f.write(f"\ntotal GPU kernel time {tot / 1e6:.1f} ms over 16 passes = {tot / 16e6:.2f} ms per pass of 8 images\n")
+for pmc in sys.argv[3:]:
+    fs = glob.glob(os.path.join(pmc, "*counter_collection.csv"))
+    if not fs:
+        continue
+    agg = collections.defaultdict(list)
+    name = None
+    for r in csv.DictReader(open(fs[0])):
+        name = r["Counter_Name"]
+        agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    with open(f"profiles/{tag}_pmc_{name}.md", "w") as f:
+        f.write(f"# rocprofv3 --pmc {name} ({tag}), per-dispatch average, KB as reported (uncorrected)\n\n")
+        f.write("FETCH_SIZE on gfx950 reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section): "
+                "double it before comparing with a byte count; WRITE_SIZE matched known byte counts 1:1 here "
+                "(inst_upsample: 205 MB reported vs 197 MB written).\n\n| kernel | dispatches | avg KB |\n|---|---:|---:|\n")
+        for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:25]:
+            f.write(f"| `{k[:90]}` | {len(v)} | {sum(v) / len(v):.0f} |\n")
+print("ok")

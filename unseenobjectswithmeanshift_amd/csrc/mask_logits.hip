@@ -19,6 +19,8 @@
 //     wave are {top even cols, top odd cols, bottom even, bottom odd} and a 2x2 tap block is
 //     lane-local (s=2) or one lane away (s=4,8);
 //   * 7 x 4 accumulators (112 VGPRs), K-loop in register-prefetched groups of 8 k-steps.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace msm {
@@ -29,18 +31,38 @@ constexpr int KU = 8;           // k-steps (of 4) per prefetch group
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float2 ld_f2(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0);
-    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+// NC consecutive columns per lane: NC == 2 -> one 8-byte load per (k-row, image row), wave tile 2 x 32;
+// NC == 1 -> 4-byte loads, wave tile 2 x 16 (finer tiles: less quantisation loss when the tile count per
+// SIMD is small, e.g. 2.34 -> 3 rounds with 2 x 32 but 4.69 -> 5 half-rounds with 2 x 16 at B = 8).
+template <int NC>
+struct Cols {
+    float v[NC];
+};
+template <int NC>
+__device__ __forceinline__ Cols<NC> ld_cols(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    Cols<NC> c;
+    if constexpr (NC == 2) {
+        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0);
+        c.v[0] = __uint_as_float(t.x);
+        c.v[1] = __uint_as_float(t.y);
+    } else {
+        c.v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
+    }
+    return c;
 }
 
-template <int POOL, bool WRITE>
+// POOL: 0 = no attention mask; 1 = mask at the resolution of the logits (single-level decoder,
+// meanshiftformer_transformer_decoder.py:1012-1035 with target size == mask size: interpolate is the
+// identity); 2/4/8 = 2x2-tap average of a bilinear downsample by that factor.
+template <int POOL, bool WRITE, int NC>
 __global__ __launch_bounds__(256) void mask_logits_kernel(const float* __restrict__ emb, const float* __restrict__ feat,
                                                           float* __restrict__ mask_out, uint8_t* __restrict__ attn_out,
                                                           int32_t* __restrict__ row_any, int Q, int C, int H, int W,
                                                           int th, int tw, int ypar, int n_rowpairs, int rp_step,
                                                           int rp_first, int feat_bytes) {
     extern __shared__ __attribute__((aligned(16))) float Es[];
+    constexpr int TW = 16 * NC;      // tile width in columns
+    constexpr int NA = 2 * NC;       // accumulator column blocks: [row (top,bottom)][cc]
     const int SE = C + 2;
     const int b = blockIdx.z, qc = blockIdx.y;
     const int q0 = qc * QCH;
@@ -64,7 +86,7 @@ __global__ __launch_bounds__(256) void mask_logits_kernel(const float* __restric
     }
     __syncthreads();
 
-    const int ctiles = (W + 31) / 32;
+    const int ctiles = (W + TW - 1) / TW;
     const int ntiles = n_rowpairs * ctiles;
     const float* fb = feat + (int64_t)b * C * HW;
     // buffer descriptor over this image's feature map, held in SGPRs
@@ -79,45 +101,46 @@ __global__ __launch_bounds__(256) void mask_logits_kernel(const float* __restric
         const int rp = t / ctiles, ct = t - rp * ctiles;
         const int ytop = ypar + 2 * (rp_first + rp * rp_step);  // may be -1 (odd pairing): clamp loads
         const int ybot = ytop + 1;                               // may be H
-        const int c = ct * 32 + 2 * lj;
-        const bool col_ok = c < W;  // W is even
+        const int c = ct * TW + NC * lj;
+        const bool col_ok = c < W;  // W is a multiple of NC
         const int cl = col_ok ? c : 0;
-        // per-lane byte offsets of this lane's two pixels in k-row `lq`; the k-group part of the
+        // per-lane byte offsets of this lane's pixels in k-row `lq`; the k-group part of the
         // address is wave-uniform and travels in the buffer instruction's SGPR soffset, so the
         // loads need no per-lane 64-bit address arithmetic at all
         const unsigned voff_top = (unsigned)(((int64_t)lq * HW + (int64_t)max(ytop, 0) * W + cl) * 4);
         const unsigned voff_bot = (unsigned)(((int64_t)lq * HW + (int64_t)min(ybot, H - 1) * W + cl) * 4);
 
-        f32x4 acc[QB][4];
+        f32x4 acc[QB][NA];
 #pragma unroll
         for (int m = 0; m < QB; ++m)
 #pragma unroll
-            for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int n = 0; n < NA; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         // K loop: groups of KU k-steps, two register buffers (A/B) in ping-pong.  The loads of the
         // next group are issued BEFORE the MFMAs of the current one and pinned there with
         // sched_barrier (left alone, hipcc sinks them behind the MFMAs and waits at once); no
         // buffer copies, so the only vmcnt waits are the counted ones at each buffer's first use.
-        float2 tA[KU], bA[KU], tB[KU], bB[KU];
-        auto load_group = [&](float2(&t)[KU], float2(&bt)[KU], int kbase) {
+        Cols<NC> tA[KU], bA[KU], tB[KU], bB[KU];
+        auto load_group = [&](Cols<NC>(&t)[KU], Cols<NC>(&bt)[KU], int kbase) {
 #pragma unroll
             for (int u = 0; u < KU; ++u) {
                 const unsigned soff = (unsigned)(kbase + u * 4) * (unsigned)HW * 4u;
-                t[u] = ld_f2(rsrc, voff_top, soff);
-                bt[u] = ld_f2(rsrc, voff_bot, soff);
+                t[u] = ld_cols<NC>(rsrc, voff_top, soff);
+                bt[u] = ld_cols<NC>(rsrc, voff_bot, soff);
             }
         };
-        auto compute_group = [&](const float2(&t)[KU], const float2(&bt)[KU], int kbase) {
+        auto compute_group = [&](const Cols<NC>(&t)[KU], const Cols<NC>(&bt)[KU], int kbase) {
 #pragma unroll
             for (int u = 0; u < KU; ++u) {
                 const float* er = &Es[lj * SE + kbase + u * 4 + lq];
 #pragma unroll
                 for (int m = 0; m < QB; ++m) {
                     const float a = er[m * 16 * SE];
-                    acc[m][0] = mfma16(a, t[u].x, acc[m][0]);
-                    acc[m][1] = mfma16(a, t[u].y, acc[m][1]);
-                    acc[m][2] = mfma16(a, bt[u].x, acc[m][2]);
-                    acc[m][3] = mfma16(a, bt[u].y, acc[m][3]);
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) {
+                        acc[m][cc] = mfma16(a, t[u].v[cc], acc[m][cc]);
+                        acc[m][NC + cc] = mfma16(a, bt[u].v[cc], acc[m][NC + cc]);
+                    }
                 }
             }
         };
@@ -136,7 +159,8 @@ __global__ __launch_bounds__(256) void mask_logits_kernel(const float* __restric
         }
         if (g < G) compute_group(tA, bA, g * (4 * KU));   // odd number of groups
 
-        // ---- epilogue: lane holds queries q0 + m*16 + lq*4 + r, columns c (tiles 0,2) and c+1 (1,3)
+        // ---- epilogue: lane holds queries q0 + m*16 + lq*4 + r, columns c..c+NC-1 of rows ytop (acc[.][cc])
+        //      and ybot (acc[.][NC+cc])
         if constexpr (WRITE) {
             if (col_ok) {
 #pragma unroll
@@ -146,44 +170,63 @@ __global__ __launch_bounds__(256) void mask_logits_kernel(const float* __restric
                         const int q = q0 + m * 16 + lq * 4 + r;
                         if (q < Q) {
                             float* o = mask_out + ((int64_t)b * Q + q) * HW + c;
-                            if (ytop >= 0) *reinterpret_cast<float2*>(o + (int64_t)ytop * W) = make_float2(acc[m][0][r], acc[m][1][r]);
-                            if (ybot < H) *reinterpret_cast<float2*>(o + (int64_t)ybot * W) = make_float2(acc[m][2][r], acc[m][3][r]);
+                            if constexpr (NC == 2) {
+                                if (ytop >= 0) *reinterpret_cast<float2*>(o + (int64_t)ytop * W) = make_float2(acc[m][0][r], acc[m][1][r]);
+                                if (ybot < H) *reinterpret_cast<float2*>(o + (int64_t)ybot * W) = make_float2(acc[m][2][r], acc[m][3][r]);
+                            } else {
+                                if (ytop >= 0) o[(int64_t)ytop * W] = acc[m][0][r];
+                                if (ybot < H) o[(int64_t)ybot * W] = acc[m][1][r];
+                            }
                         }
                     }
                 }
             }
         }
-        if constexpr (POOL != 0) {
+        if constexpr (POOL == 1) {
+            // mask at full resolution: one bit per logit
+            if (col_ok) {
+#pragma unroll
+                for (int m = 0; m < QB; ++m) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int q = q0 + m * 16 + lq * 4 + r;
+                        if (q >= Q) continue;
+                        uint8_t* o = attn_out + ((int64_t)b * Q + q) * HW + c;
+                        bool any = false;
+#pragma unroll
+                        for (int cc = 0; cc < NC; ++cc) {
+                            if (ytop >= 0) { const bool mk = acc[m][cc][r] < 0.f; o[(int64_t)ytop * W + cc] = mk; any |= !mk; }
+                            if (ybot < H) { const bool mk = acc[m][NC + cc][r] < 0.f; o[(int64_t)ybot * W + cc] = mk; any |= !mk; }
+                        }
+                        if (any) row_any[(int64_t)b * Q + q] = 1;
+                    }
+                }
+            }
+        } else if constexpr (POOL != 0) {
             // tap rows are (POOL*i + POOL/2 - 1, +1): the pair (ytop, ybot) is a tap pair iff
             // ytop % POOL == POOL/2 - 1 (always true for POOL == 2 with even pairing)
-            const bool row_tap = (ytop >= 0) && (ybot < H) && ((ytop % POOL) == POOL / 2 - 1);
-            // column taps (POOL*i + POOL/2 - 1, +1): POOL 2 -> (c, c+1) in-lane;
-            // POOL 4/8 -> (c+1 of this lane, c of lane+1) when (c+1) % POOL == POOL/2 - 1
-            bool col_tap;
-            int tx;
-            if constexpr (POOL == 2) {
-                col_tap = col_ok;
-                tx = c >> 1;
-            } else {
-                col_tap = col_ok && (((c + 1) % POOL) == POOL / 2 - 1) && (c + 2 < W);
-                tx = (c + 1) / POOL;
-            }
+            const bool row_tap = (ytop >= 0) && (ybot < H) && ((ytop % POOL) == POOL / 2 - 1);   // wave-uniform
+            // tap columns are (POOL*i + POOL/2 - 1, +1).  NC == 2, POOL == 2: both in this lane.  Otherwise
+            // the left tap is this lane's LAST column and the right tap the next lane's first.
+            constexpr bool IN_LANE = (NC == 2 && POOL == 2);
+            const int cleft = IN_LANE ? c : c + NC - 1;
+            const bool col_tap = col_ok && ((cleft % POOL) == POOL / 2 - 1) && (cleft + 1 < W);
+            const int tx = cleft / POOL;
             const int ty = (ytop >= 0 ? ytop : 0) / POOL;
-            const bool wave_row_tap = row_tap;  // uniform per wave
 #pragma unroll
             for (int m = 0; m < QB; ++m) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float s;
-                    if constexpr (POOL == 2) {
+                    if constexpr (IN_LANE) {
                         s = (acc[m][0][r] + acc[m][1][r]) + (acc[m][2][r] + acc[m][3][r]);
                     } else {
                         const float n0 = __shfl_down(acc[m][0][r], 1, 64);
-                        const float n2 = __shfl_down(acc[m][2][r], 1, 64);
-                        s = (acc[m][1][r] + n0) + (acc[m][3][r] + n2);
+                        const float n2 = __shfl_down(acc[m][NC][r], 1, 64);
+                        s = (acc[m][NC - 1][r] + n0) + (acc[m][2 * NC - 1][r] + n2);
                     }
                     const int q = q0 + m * 16 + lq * 4 + r;
-                    if (wave_row_tap && col_tap && q < Q && tx < tw && ty < th) {
+                    if (row_tap && col_tap && q < Q && tx < tw && ty < th) {
                         const bool masked = s < 0.f;
                         attn_out[((int64_t)b * Q + q) * (th * tw) + ty * tw + tx] = masked ? 1 : 0;
                         if (!masked) row_any[(int64_t)b * Q + q] = 1;
@@ -216,7 +259,7 @@ extern "C" int msm_mask_logits_fwd(const float* mask_embed, const float* mask_fe
         MSM_REQUIRE(th > 0 && tw > 0 && H % th == 0 && W % tw == 0 && H / th == W / tw,
                     "msm_mask_logits_fwd: target %dx%d incompatible with %dx%d", th, tw, H, W);
         pool = H / th;
-        MSM_REQUIRE(pool == 2 || pool == 4 || pool == 8, "msm_mask_logits_fwd: pool factor %d not in {2,4,8}", pool);
+        MSM_REQUIRE(pool == 1 || pool == 2 || pool == 4 || pool == 8, "msm_mask_logits_fwd: pool factor %d not in {1,2,4,8}", pool);
     }
     hipStream_t st = (hipStream_t)stream;
     if (attn_out) MSM_CHECK_HIP(hipMemsetAsync(row_any, 0, sizeof(int32_t) * (size_t)B * Q, st));
@@ -233,23 +276,37 @@ extern "C" int msm_mask_logits_fwd(const float* mask_embed, const float* mask_fe
             n_rowpairs = H / pool;
         }
     }
-    const int ctiles = (W + 31) / 32;
-    const int ntiles = n_rowpairs * ctiles;
     const int qchunks = cdiv(Q, QCH);
+    // tile width: 2 x 32 (8-byte loads) or 2 x 16 (4-byte loads).  One tile keeps a SIMD busy for C/4*28 (or
+    // *14) MFMAs; with T tiles over the 1024 SIMDs the makespan is ceil(T/1024) tile times, so take the
+    // narrow tile when it shortens the makespan by more than the cost of the narrower loads.
+    const int64_t t32 = (int64_t)n_rowpairs * cdiv(W, 32) * B * qchunks;
+    const int64_t t16 = (int64_t)n_rowpairs * cdiv(W, 16) * B * qchunks;
+    const double cost32 = (double)cdiv(t32, 1024), cost16 = 0.5 * (double)cdiv(t16, 1024);
+    int nc = (cost16 * 1.04 < cost32) ? 1 : 2;
+    if (const char* e = getenv("MSM_MASK_NC")) nc = atoi(e) == 1 ? 1 : 2;
+    const int ctiles = cdiv(W, 16 * nc);
+    const int ntiles = n_rowpairs * ctiles;
     // persistent-ish grid: enough workgroups per (image, chunk) to cover the chip once
     int wg_per = cdiv(ntiles, 4);
     const int target = cdiv(256, B * qchunks);
     if (wg_per > target) wg_per = max(target, 1);
     dim3 grid(wg_per, qchunks, B), block(256);
     const size_t lds = sizeof(float) * (size_t)QCH * (C + 2);
-    void (*kern)(const float*, const float*, float*, uint8_t*, int32_t*, int, int, int, int, int, int, int, int, int, int, int);
+    typedef void (*kern_t)(const float*, const float*, float*, uint8_t*, int32_t*, int, int, int, int, int, int, int, int, int, int, int);
+    kern_t kern;
     const bool wr = mask_out != nullptr;
+#define MASK_PICK(P)                                                                                   \
+    (nc == 2 ? (wr ? (kern_t)mask_logits_kernel<P, true, 2> : (kern_t)mask_logits_kernel<P, false, 2>)   \
+             : (wr ? (kern_t)mask_logits_kernel<P, true, 1> : (kern_t)mask_logits_kernel<P, false, 1>))
     switch (pool) {
-        case 0: kern = mask_logits_kernel<0, true>; break;
-        case 2: kern = wr ? mask_logits_kernel<2, true> : mask_logits_kernel<2, false>; break;
-        case 4: kern = wr ? mask_logits_kernel<4, true> : mask_logits_kernel<4, false>; break;
-        default: kern = wr ? mask_logits_kernel<8, true> : mask_logits_kernel<8, false>; break;
+        case 0: kern = nc == 2 ? (kern_t)mask_logits_kernel<0, true, 2> : (kern_t)mask_logits_kernel<0, true, 1>; break;
+        case 1: kern = MASK_PICK(1); break;
+        case 2: kern = MASK_PICK(2); break;
+        case 4: kern = MASK_PICK(4); break;
+        default: kern = MASK_PICK(8); break;
     }
+#undef MASK_PICK
     MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)kern, lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, mask_embed, mask_feat, mask_out, attn_out, row_any, Q, C, H, W, th, tw,
                        ypar, n_rowpairs, rp_step, rp_first, (int)((int64_t)C * H * W * 4));

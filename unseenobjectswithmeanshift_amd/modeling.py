@@ -225,6 +225,11 @@ class MeanShiftTransformerDecoder(nn.Module):
         # level embedding, position code and the in-projection are folded into per-layer constants
         # (see _folded_kv).  False: materialise src = input_proj(x)+level_embed and project it (K=256).
         self.fold_kv = True
+        # the K/V projections depend only on the level features, not on the query chain: with overlap_kv they
+        # are issued on a side stream (fork/join events, also valid under HIP-graph capture) and run beside
+        # the latency-bound per-layer query kernels that leave most CUs idle
+        self.overlap_kv = True
+        self._side = None
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
                               error_msgs):
@@ -311,8 +316,21 @@ class MeanShiftTransformerDecoder(nn.Module):
             h, w = x[i].shape[-2:]
             sizes.append((int(h), int(w)))
             xs.append(x[i].contiguous())
+        kv_all, kv_ready = None, None
         if self.fold_kv:
             kv_w, kv_c = self._folded_kv(sizes, dev)
+            if self.overlap_kv:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=dev)
+                cur = torch.cuda.current_stream()
+                self._side.wait_stream(cur)                                   # fork
+                kv_all, kv_ready = [], []
+                with torch.cuda.stream(self._side):
+                    for i in range(self.num_layers):
+                        kv_all.append(ops.conv1x1_nchw_to_tokens(xs[i % self.num_feature_levels], kv_w[i], kv_c[i]))
+                        ev = torch.cuda.Event()
+                        ev.record(self._side)
+                        kv_ready.append(ev)
         else:
             for i in range(self.num_feature_levels):
                 pos.append(self._pos_tokens(*sizes[i], dev))
@@ -336,7 +354,11 @@ class MeanShiftTransformerDecoder(nn.Module):
             lvl = i % self.num_feature_levels                                     # DEC:608
             ca = self.transformer_cross_attention_layers[i]
             if self.fold_kv:
-                kv = ops.conv1x1_nchw_to_tokens(xs[lvl], kv_w[i], kv_c[i])            # (B, hw, 2E) = [K | V]
+                if kv_all is not None:
+                    torch.cuda.current_stream().wait_event(kv_ready[i])               # join for layer i only
+                    kv = kv_all[i]
+                else:
+                    kv = ops.conv1x1_nchw_to_tokens(xs[lvl], kv_w[i], kv_c[i])        # (B, hw, 2E) = [K | V]
                 t2 = ca.meanshift_attn.attend(out, None, None, query_pos=qpos, masked=attn, row_any=row_any,
                                               kv=(kv[..., :E], kv[..., E:]))
             else:
@@ -363,6 +385,8 @@ class MeanShiftTransformerDecoder(nn.Module):
             cls, m, attn, row_any = self._heads(d, mask_features, tgt, full or last, full or last)
             pred_cls.append(cls)
             pred_mask.append(m)
+        if kv_all is not None:
+            self._side.wait_stream(torch.cuda.current_stream())   # side-stream buffers are not recycled under us
         res = {"pred_logits": pred_cls[-1], "pred_masks": pred_mask[-1], "aux_outputs": []}
         if full:
             res["aux_outputs"] = [{"pred_logits": a, "pred_masks": b} for a, b in zip(pred_cls[:-1], pred_mask[:-1])]
