@@ -306,6 +306,15 @@ def pixel_decoder_forward(sd, features, nheads=8, enc_layers=6, n_points=4,
     return mask_features, out[0], out[:3]
 
 
+def simple_base_pixel_decoder_forward(sd, features, feature="res5"):
+    """SimpleBasePixelDecoder.forward_features (pixel_decoder/fpn.py:261-284): identity on the embedding,
+    mask_features = Conv3x3(64 -> mask_dim) with bias when mask_dim != 64."""
+    y = features[feature]
+    if "mask_features.weight" not in sd:
+        return y, None, [y]
+    return F.conv2d(y, sd["mask_features.weight"], sd["mask_features.bias"], padding=1), None, [y]
+
+
 # ----------------------------------------------------------------------------------------------
 # classic vMF mean shift (MS:11-229, TD:44-59) -- cosine metric only
 # ----------------------------------------------------------------------------------------------

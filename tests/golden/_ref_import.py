@@ -104,7 +104,7 @@ def install_stubs():
     _installed = True
     _mod("detectron2")
     _mod("detectron2.config", configurable=_configurable)
-    _mod("detectron2.layers", Conv2d=_Conv2d, ShapeSpec=_ShapeSpec, get_norm=_get_norm)
+    _mod("detectron2.layers", Conv2d=_Conv2d, ShapeSpec=_ShapeSpec, get_norm=_get_norm, DeformConv=None)
     _mod("detectron2.utils")
     _mod("detectron2.utils.registry", Registry=_Registry)
     _mod("detectron2.modeling", SEM_SEG_HEADS_REGISTRY=_Registry("SEM_SEG_HEADS"))

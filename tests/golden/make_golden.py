@@ -312,9 +312,39 @@ def g_harness():
     save("harness", **arrs)
 
 
+def g_ucn():
+    """UCN / RGB-D configuration: SimpleBasePixelDecoder + PretrainedMeanShiftTransformerDecoder (one
+    level, every pixel a key, attention mask at mask resolution), small full-resolution map."""
+    DEC = R.ref("modeling.transformer_decoder.meanshiftformer_transformer_decoder")
+    FPN = R.ref("modeling.pixel_decoder.fpn")
+    SS = R._ShapeSpec
+    pd = FPN.SimpleBasePixelDecoder({"res5": SS(channels=64, stride=1)}, conv_dim=64, mask_dim=256, norm="GN").eval()
+    pd_shapes = {"mask_features.weight": (256, 64, 3, 3), "mask_features.bias": (256,)}
+    assert {k: tuple(v.shape) for k, v in pd.state_dict().items()} == pd_shapes
+    pd.load_state_dict(syn.synth_state_dict(pd_shapes, salt=3), strict=True)
+    dec = DEC.PretrainedMeanShiftTransformerDecoder(
+        in_channels=64, mask_classification=True, num_classes=2, hidden_dim=256, num_queries=100, nheads=8,
+        dim_feedforward=2048, dec_layers=6, pre_norm=False, mask_dim=256, enforce_input_project=False,
+        use_meanshift_cross_attention=True, disable_attention_mask=False, use_meanshift_self_attention=True,
+        decoder_block_norm=True).eval()
+    shapes = syn.decoder_param_shapes(dec_layers=6, num_feature_levels=1)
+    assert {k: tuple(v.shape) for k, v in dec.state_dict().items()} == {k: tuple(v) for k, v in shapes.items()}
+    dec.load_state_dict(syn.synth_state_dict(shapes, salt=4), strict=True)
+    X, _ = syn.synth_unit_embeddings(2 * 32 * 48, 64, clusters=7, sigma=0.3, seed=21)
+    feat = X.view(2, 32 * 48, 64).transpose(1, 2).reshape(2, 64, 32, 48).contiguous()     # unit-norm along C (PM:299)
+    with torch.no_grad():
+        mf, _, ms = pd.forward_features({"res5": feat})
+        out = dec(ms, mf)
+    arrs = {"mask_features": mf.half(), "pred_logits": out["pred_logits"], "pred_masks": out["pred_masks"]}
+    for i, a in enumerate(out["aux_outputs"]):
+        arrs[f"aux{i}_logits"] = a["pred_logits"]
+        arrs[f"aux{i}_sign_bits"] = packbits(a["pred_masks"] > 0)
+    save("ucn_small", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pe", "attn", "decoder", "msda", "pixel", "ms", "harness"]
+    which = sys.argv[1:] or ["pe", "attn", "decoder", "msda", "pixel", "ms", "harness", "ucn"]
     fns = {"pe": g_position_encoding, "attn": g_hypersphere_attention, "decoder": g_decoder,
-           "msda": g_msda, "pixel": g_pixel_decoder, "ms": g_mean_shift, "harness": g_harness}
+           "msda": g_msda, "pixel": g_pixel_decoder, "ms": g_mean_shift, "harness": g_harness, "ucn": g_ucn}
     for w in which:
         fns[w]()

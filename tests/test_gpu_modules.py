@@ -151,6 +151,34 @@ def test_decoder_execution_variants_agree():
     torch.testing.assert_close(b["pred_masks"], ref["pred_masks"], rtol=1e-4, atol=3e-4)
 
 
+def test_ucn_path_vs_reference(golden):
+    """RGB-D / UCN configuration on the GPU: 3x3 mask-feature conv, 1536 full-resolution keys, attention
+    mask at mask resolution (POOL = 1)."""
+    from unseenobjectswithmeanshift_amd.meta_arch import build_ucn_head
+    g = golden("ucn_small")
+    head = build_ucn_head()
+    head.pixel_decoder.load_state_dict(syn.synth_state_dict({"mask_features.weight": (256, 64, 3, 3),
+                                                              "mask_features.bias": (256,)}, salt=3), strict=True)
+    head.predictor.load_state_dict(syn.synth_state_dict(syn.decoder_param_shapes(dec_layers=6, num_feature_levels=1),
+                                                        salt=4), strict=True)
+    head = head.to(DEV).eval()
+    head.predictor.aux_outputs = True
+    X, _ = syn.synth_unit_embeddings(2 * 32 * 48, 64, clusters=7, sigma=0.3, seed=21)
+    feat = X.view(2, 32 * 48, 64).transpose(1, 2).reshape(2, 64, 32, 48).contiguous()
+    mf, _, ms = head.pixel_decoder.forward_features({"res5": feat.to(DEV)})
+    torch.testing.assert_close(mf.cpu(), T(g["mask_features"]).float(), rtol=2e-3, atol=2e-3)
+    out, _ = head({"res5": feat.to(DEV)})
+    torch.testing.assert_close(out["pred_logits"].cpu(), T(g["pred_logits"]), rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(out["pred_masks"].cpu(), T(g["pred_masks"]), rtol=1e-3, atol=2e-3)
+    for i, a in enumerate(out["aux_outputs"]):
+        m = a["pred_masks"].cpu()
+        assert ((m > 0).numpy() != unpack(g[f"aux{i}_sign_bits"], m.shape)).mean() <= 1e-4
+    for variant in (False, True):
+        head.predictor.fold_kv = variant
+        again, _ = head({"res5": feat.to(DEV)})
+        torch.testing.assert_close(again["pred_masks"], out["pred_masks"], rtol=1e-3, atol=2e-3)
+
+
 def test_decoder_batch_consistency():
     """Images are independent units: a batch of 4 equals four batches of 1 (data-parallel sharding)."""
     dec = make_decoder()

@@ -80,6 +80,23 @@ def test_decoder_480x640(golden):
         assert ((a["pred_masks"] > 0).numpy() != bits).mean() <= 1e-5
 
 
+def test_ucn_path_small(golden):
+    """SimpleBasePixelDecoder + PretrainedMeanShiftTransformerDecoder (1 level, mask at key resolution)."""
+    g = golden("ucn_small")
+    pd_sd = syn.synth_state_dict({"mask_features.weight": (256, 64, 3, 3), "mask_features.bias": (256,)}, salt=3)
+    sd = syn.synth_state_dict(syn.decoder_param_shapes(dec_layers=6, num_feature_levels=1), salt=4)
+    X, _ = syn.synth_unit_embeddings(2 * 32 * 48, 64, clusters=7, sigma=0.3, seed=21)
+    feat = X.view(2, 32 * 48, 64).transpose(1, 2).reshape(2, 64, 32, 48).contiguous()
+    mf, _, ms = O.simple_base_pixel_decoder_forward(pd_sd, {"res5": feat})
+    torch.testing.assert_close(mf, T(g["mask_features"]).float(), rtol=2e-3, atol=2e-3)
+    out = O.decoder_forward(sd, ms, mf, dec_layers=6, num_feature_levels=1)
+    torch.testing.assert_close(out["pred_logits"], T(g["pred_logits"]), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(out["pred_masks"], T(g["pred_masks"]), rtol=1e-4, atol=2e-4)
+    for i, a in enumerate(out["aux_outputs"]):
+        bits = unpack(g[f"aux{i}_sign_bits"], a["pred_masks"].shape)
+        assert ((a["pred_masks"] > 0).numpy() != bits).mean() <= 1e-4
+
+
 def test_msda_reference_known_answer(golden):
     """Inputs of the reference's own harness (ops/test.py:24-63)."""
     g = golden("msda_core")

@@ -39,5 +39,60 @@ def gemm():
               f"tile={os.environ.get('MSM_GEMM_TILE', 'auto')} nostore={'MSM_GEMM_NOSTORE' in os.environ}", flush=True)
 
 
+def mask():
+    e = torch.randn(8, 100, 256, device=DEV) * 0.3
+    f = torch.randn(8, 256, 120, 160, device=DEV)
+    flops = 2.0 * 100 * 256 * 19200 * 8
+    for nc in ("2", "1"):
+        os.environ["MSM_MASK_NC"] = nc
+        for tgt, wm in (((15, 20), False), ((30, 40), False), ((60, 80), False), (None, True)):
+            t = timeit(lambda: ops.mask_logits(e, f, want_mask=wm, target_size=tgt), iters=50)
+            print(f"mask nc={nc} target={tgt} write={wm}: {t:7.1f} us  {flops / t / 1e6:6.1f} TFLOP/s", flush=True)
+
+
+def enc():
+    B, S = 8, 6300
+    attn, src, pos = torch.randn(B, S, 64, device=DEV), torch.randn(B, S, 64, device=DEV), torch.randn(S, 64, device=DEV)
+    wo, w1, w2 = torch.randn(64, 64, device=DEV) * .1, torch.randn(1024, 64, device=DEV) * .1, torch.randn(64, 1024, device=DEV) * .03
+    wv, wp = torch.randn(64, 64, device=DEV) * .1, torch.randn(288, 64, device=DEV) * .1
+    stream = ops.pack_encoder_block(wo, w1, w2, wv, wp)
+    small = torch.randn(64 * 7 + 1024 + 288, device=DEV) * .1
+    t = timeit(lambda: ops.encoder_block(attn, src, stream, small, 1024, 288, pos=pos, tokens_per_image=S), iters=30)
+    fl = B * S * 2.0 * (64 * 64 * 2 + 64 * 1024 * 2 + 64 * 288)
+    print(f"enc_block: {t:7.1f} us  {fl / t / 1e6:6.1f} TFLOP/s", flush=True)
+    value, proj = torch.randn(B, S, 64, device=DEV), torch.randn(B, S, 288, device=DEV)
+    ss = torch.tensor([(15, 20), (30, 40), (60, 80)], dtype=torch.int64, device=DEV)
+    st = torch.tensor([0, 300, 1500], dtype=torch.int64, device=DEV)
+    t = timeit(lambda: ops.ms_deform_attn_encoder(value, ss, st, proj, 8, 4), iters=30)
+    print(f"msda enc: {t:7.1f} us", flush=True)
+
+
+def attn():
+    B, E = 8, 256
+    for S in (300, 1200, 4800, 100):
+        q, k, v = torch.randn(B, 100, E, device=DEV), torch.randn(B, S, 2 * E, device=DEV), None
+        m = (torch.rand(B, 100, S, device=DEV) < 0.5).to(torch.uint8)
+        ra = torch.ones(B, 100, device=DEV, dtype=torch.int32)
+        t = timeit(lambda: ops.hypersphere_attention(q, k[..., :E], k[..., E:], 8, masked=m, row_any=ra), iters=30)
+        fl = 2.0 * 2 * B * 100 * S * E
+        print(f"hs_attn S={S}: {t:7.1f} us  {fl / t / 1e6:6.1f} TFLOP/s", flush=True)
+
+
+def ucn():
+    """RGB-D / UCN configuration at full size: 307 200 keys per image, 6 decoder layers."""
+    from unseenobjectswithmeanshift_amd import synthetic as syn
+    from unseenobjectswithmeanshift_amd.meta_arch import MeanShiftMaskFormer, build_ucn_head
+    B = int(os.environ.get("UCN_B", "2"))
+    head = build_ucn_head()
+    head.pixel_decoder.load_state_dict(syn.synth_state_dict({"mask_features.weight": (256, 64, 3, 3), "mask_features.bias": (256,)}, salt=3))
+    head.predictor.load_state_dict(syn.synth_state_dict(syn.decoder_param_shapes(dec_layers=6, num_feature_levels=1), salt=4))
+    head = head.to(DEV).eval()
+    model = MeanShiftMaskFormer(backbone=None, sem_seg_head=head, num_queries=100)
+    X, _ = syn.synth_unit_embeddings(B * 480 * 640, 64, clusters=12, sigma=0.3, seed=5)
+    feat = {"res5": X.view(B, 480 * 640, 64).transpose(1, 2).reshape(B, 64, 480, 640).contiguous().to(DEV)}
+    t = timeit(lambda: model.inference(feat, (480, 640)), iters=5, warm=2)
+    print(f"ucn B={B} 480x640: {t / 1e3:8.2f} ms per batch, {B / (t * 1e-6):7.1f} images/s, peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
+
+
 if __name__ == "__main__":
-    {"gemm": gemm}[sys.argv[1]]()
+    {"gemm": gemm, "mask": mask, "enc": enc, "attn": attn, "ucn": ucn}[sys.argv[1]]()

@@ -32,24 +32,36 @@ struct EncSmall {                      // offsets (floats) into the packed small
 
 __device__ __forceinline__ float4 lds4(const float4* base, int idx) { return base[idx]; }
 
-// one [16 rows][64 k] weight block (A operand) times the tile's activations (B operand, layout L)
-__device__ __forceinline__ f32x4 rowblock_mm(const float4* __restrict__ blk, int lj, int lq, const float (&act)[4][4]) {
-    f32x4 d0 = f32x4{0.f, 0.f, 0.f, 0.f}, d1 = d0;   // two accumulators: break the 40-cycle dependent-MFMA chain
+// A-operand fragments of one [16 rows][64 k] weight block: 4 x ds_read_b128 (conflict-free by the XOR swizzle)
+__device__ __forceinline__ void rowblock_read(const float4* __restrict__ blk, int lj, int lq, float4 (&w)[4]) {
 #pragma unroll
-    for (int fb = 0; fb < 4; ++fb) {
-        const float4 w = lds4(blk, lj * 16 + ((fb * 4 + lq) ^ lj));
-        if (fb & 1) {
-            d1 = mfma16(w.x, act[fb][0], d1);
-            d1 = mfma16(w.y, act[fb][1], d1);
-            d1 = mfma16(w.z, act[fb][2], d1);
-            d1 = mfma16(w.w, act[fb][3], d1);
-        } else {
-            d0 = mfma16(w.x, act[fb][0], d0);
-            d0 = mfma16(w.y, act[fb][1], d0);
-            d0 = mfma16(w.z, act[fb][2], d0);
-            d0 = mfma16(w.w, act[fb][3], d0);
-        }
-    }
+    for (int fb = 0; fb < 4; ++fb) w[fb] = lds4(blk, lj * 16 + ((fb * 4 + lq) ^ lj));
+}
+// 16 MFMAs: consecutive instructions alternate between two accumulators, so no MFMA waits for the 40-cycle
+// dependent-accumulator latency of its predecessor.  d0 + d1 is the block's output in layout L.
+__device__ __forceinline__ void rowblock_mma(const float4 (&w)[4], const float (&act)[4][4], f32x4& d0, f32x4& d1) {
+    d0 = mfma16(w[0].x, act[0][0], d0);
+    d1 = mfma16(w[1].x, act[1][0], d1);
+    d0 = mfma16(w[2].x, act[2][0], d0);
+    d1 = mfma16(w[3].x, act[3][0], d1);
+    d0 = mfma16(w[0].y, act[0][1], d0);
+    d1 = mfma16(w[1].y, act[1][1], d1);
+    d0 = mfma16(w[2].y, act[2][1], d0);
+    d1 = mfma16(w[3].y, act[3][1], d1);
+    d0 = mfma16(w[0].z, act[0][2], d0);
+    d1 = mfma16(w[1].z, act[1][2], d1);
+    d0 = mfma16(w[2].z, act[2][2], d0);
+    d1 = mfma16(w[3].z, act[3][2], d1);
+    d0 = mfma16(w[0].w, act[0][3], d0);
+    d1 = mfma16(w[1].w, act[1][3], d1);
+    d0 = mfma16(w[2].w, act[2][3], d0);
+    d1 = mfma16(w[3].w, act[3][3], d1);
+}
+__device__ __forceinline__ f32x4 rowblock_mm(const float4* __restrict__ blk, int lj, int lq, const float (&act)[4][4]) {
+    float4 w[4];
+    rowblock_read(blk, lj, lq, w);
+    f32x4 d0 = f32x4{0.f, 0.f, 0.f, 0.f}, d1 = d0;
+    rowblock_mma(w, act, d0, d1);
     return d0 + d1;
 }
 
@@ -90,8 +102,10 @@ __global__ __launch_bounds__(256) void enc_block_kernel(const float* __restrict_
                                                         EncSmall so, const float* __restrict__ pos,
                                                         float* __restrict__ src_out, float* __restrict__ value_out,
                                                         float* __restrict__ proj_out, int M, int S, int nffn, int nproj_blocks,
-                                                        int proj_ld, float eps) {
-    extern __shared__ __attribute__((aligned(16))) float4 wl[];   // [2][CHUNK_F4]
+                                                        int proj_ld, float eps, int n_small) {
+    extern __shared__ __attribute__((aligned(16))) float4 wl[];   // [2][CHUNK_F4] weight chunks, then the small parameters
+    float* sm = reinterpret_cast<float*>(wl + 2 * CHUNK_F4);
+    for (int i = threadIdx.x; i < n_small; i += 256) sm[i] = small[i];   // biases / LayerNorm vectors: read from LDS in the loop
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lj = lane & 15, lq = lane >> 4;
@@ -143,54 +157,69 @@ __global__ __launch_bounds__(256) void enc_block_kernel(const float* __restrict_
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) {
                 const f32x4 d = rowblock_mm(buf + ob * 256, lj, lq, act);
-                const float4 bo = *reinterpret_cast<const float4*>(small + so.bo + ob * 16 + lq * 4);
+                const float4 bo = *reinterpret_cast<const float4*>(sm + so.bo + ob * 16 + lq * 4);
                 x[ob][0] = d[0] + bo.x + res[ob][0];
                 x[ob][1] = d[1] + bo.y + res[ob][1];
                 x[ob][2] = d[2] + bo.z + res[ob][2];
                 x[ob][3] = d[3] + bo.w + res[ob][3];
             }
-            layer_norm_L(x, small + so.g1, small + so.be1, lq, eps);
+            layer_norm_L(x, sm + so.g1, sm + so.be1, lq, eps);
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) acc2[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
         } else if (c <= nffn) {
-            // ---- FFN: 4 hidden blocks of 16 per chunk; the hidden activation lives in 4 registers ----
+            // ---- FFN: 4 hidden blocks of 16 per chunk; the hidden activation lives in 4 registers.
+            // Software pipeline over the hidden blocks q: the 16 linear1 MFMAs of block q+1 are issued
+            // before block q's result is read back (bias + ReLU) and fed to its 16 linear2 MFMAs, and the
+            // LDS fragments are fetched one block ahead, so neither MFMA results nor ds_reads are waited on.
+            float4 w1[2][4], w2[4];
+            f32x4 dd[2][2];
+            rowblock_read(buf + 0 * 256, lj, lq, w1[0]);
+            rowblock_read(buf + 2 * 256, lj, lq, w1[1]);
+            dd[0][0] = dd[0][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            rowblock_mma(w1[0], x, dd[0][0], dd[0][1]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+                const int cur = q & 1, nxt = cur ^ 1;
                 const int hb = (c - 1) * 4 + q;
-                f32x4 h = rowblock_mm(buf + (2 * q) * 256, lj, lq, x);
-                const float4 b1 = *reinterpret_cast<const float4*>(small + so.b1 + hb * 16 + lq * 4);
+                // fragments: linear2 block q (used below), linear1 block q+2 (used next iteration)
+                const float4* w2p = buf + (2 * q + 1) * 256;
+#pragma unroll
+                for (int ob = 0; ob < 4; ++ob) {
+                    const int row = ob * 16 + lj;
+                    w2[ob] = lds4(w2p, row * 4 + (lq ^ ((row >> 2) & 3)));
+                }
+                if (q + 1 < 4) {
+                    dd[nxt][0] = dd[nxt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    rowblock_mma(w1[nxt], x, dd[nxt][0], dd[nxt][1]);          // linear1 of block q+1
+                    if (q + 2 < 4) rowblock_read(buf + (2 * (q + 2)) * 256, lj, lq, w1[cur]);
+                }
+                const float4 b1 = *reinterpret_cast<const float4*>(sm + so.b1 + hb * 16 + lq * 4);
+                f32x4 h = dd[cur][0] + dd[cur][1];
                 h[0] = fmaxf(h[0] + b1.x, 0.f);
                 h[1] = fmaxf(h[1] + b1.y, 0.f);
                 h[2] = fmaxf(h[2] + b1.z, 0.f);
                 h[3] = fmaxf(h[3] + b1.w, 0.f);
-                const float4* w2 = buf + (2 * q + 1) * 256;
-                float4 w[4];
+                // linear2 of block q, order (r, ob): consecutive MFMAs hit different accumulators
 #pragma unroll
-                for (int ob = 0; ob < 4; ++ob) {
-                    const int row = ob * 16 + lj;
-                    w[ob] = lds4(w2, row * 4 + (lq ^ ((row >> 2) & 3)));
-                }
-                // order (r, ob): consecutive MFMAs hit different accumulators
+                for (int ob = 0; ob < 4; ++ob) acc2[ob] = mfma16(w2[ob].x, h[0], acc2[ob]);
 #pragma unroll
-                for (int ob = 0; ob < 4; ++ob) acc2[ob] = mfma16(w[ob].x, h[0], acc2[ob]);
+                for (int ob = 0; ob < 4; ++ob) acc2[ob] = mfma16(w2[ob].y, h[1], acc2[ob]);
 #pragma unroll
-                for (int ob = 0; ob < 4; ++ob) acc2[ob] = mfma16(w[ob].y, h[1], acc2[ob]);
+                for (int ob = 0; ob < 4; ++ob) acc2[ob] = mfma16(w2[ob].z, h[2], acc2[ob]);
 #pragma unroll
-                for (int ob = 0; ob < 4; ++ob) acc2[ob] = mfma16(w[ob].z, h[2], acc2[ob]);
-#pragma unroll
-                for (int ob = 0; ob < 4; ++ob) acc2[ob] = mfma16(w[ob].w, h[3], acc2[ob]);
+                for (int ob = 0; ob < 4; ++ob) acc2[ob] = mfma16(w2[ob].w, h[3], acc2[ob]);
             }
             if (c == nffn) {
                 // ---- residual + LayerNorm2 (msdeformattn.py:116-118), write the layer output ----
 #pragma unroll
                 for (int ob = 0; ob < 4; ++ob) {
-                    const float4 b2 = *reinterpret_cast<const float4*>(small + so.b2 + ob * 16 + lq * 4);
+                    const float4 b2 = *reinterpret_cast<const float4*>(sm + so.b2 + ob * 16 + lq * 4);
                     x[ob][0] += acc2[ob][0] + b2.x;
                     x[ob][1] += acc2[ob][1] + b2.y;
                     x[ob][2] += acc2[ob][2] + b2.z;
                     x[ob][3] += acc2[ob][3] + b2.w;
                 }
-                layer_norm_L(x, small + so.g2, small + so.be2, lq, eps);
+                layer_norm_L(x, sm + so.g2, sm + so.be2, lq, eps);
                 if (tok_ok) {
 #pragma unroll
                     for (int ob = 0; ob < 4; ++ob)
@@ -206,7 +235,7 @@ __global__ __launch_bounds__(256) void enc_block_kernel(const float* __restrict_
 #pragma unroll
                 for (int ob = 0; ob < 4; ++ob) {
                     const f32x4 d = rowblock_mm(buf + ob * 256, lj, lq, x);
-                    const float4 bv = *reinterpret_cast<const float4*>(small + so.bv + ob * 16 + lq * 4);
+                    const float4 bv = *reinterpret_cast<const float4*>(sm + so.bv + ob * 16 + lq * 4);
                     if (tok_ok)
                         *reinterpret_cast<float4*>(value_out + (int64_t)tok * EC + ob * 16 + lq * 4) =
                             make_float4(d[0] + bv.x, d[1] + bv.y, d[2] + bv.z, d[3] + bv.w);
@@ -226,7 +255,7 @@ __global__ __launch_bounds__(256) void enc_block_kernel(const float* __restrict_
                 const int ob = ob_base + (j - blk0);
                 if (ob >= nproj_blocks) break;
                 const f32x4 d = rowblock_mm(buf + j * 256, lj, lq, x);
-                const float4 bp = *reinterpret_cast<const float4*>(small + so.bp + ob * 16 + lq * 4);
+                const float4 bp = *reinterpret_cast<const float4*>(sm + so.bp + ob * 16 + lq * 4);
                 if (tok_ok)
                     *reinterpret_cast<float4*>(proj_out + (int64_t)tok * proj_ld + ob * 16 + lq * 4) =
                         make_float4(d[0] + bp.x, d[1] + bp.y, d[2] + bp.z, d[3] + bp.w);
@@ -275,12 +304,13 @@ extern "C" int msm_encoder_block_fwd(const float* attn, const float* src, const 
     so.be2 = o; o += 64;
     so.bv = o; o += 64;
     so.bp = o;
-    const size_t lds = sizeof(float4) * 2 * CHUNK_F4;
+    const int n_small = so.bp + proj_width;
+    const size_t lds = sizeof(float4) * 2 * CHUNK_F4 + sizeof(float) * (size_t)((n_small + 3) / 4 * 4);
     MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)enc_block_kernel, lds));
     dim3 grid(cdiv(M, 64)), block(256);
     hipLaunchKernelGGL(enc_block_kernel, grid, block, lds, (hipStream_t)stream, attn, src,
                        reinterpret_cast<const float4*>(wstream), small, so, pos, src_out, value_out, proj_out, M, S, d_ffn / 64,
-                       proj_width / 16, proj_width, eps);
+                       proj_width / 16, proj_width, eps, n_small);
     MSM_CHECK_LAUNCH("msm_encoder_block_fwd");
     return MSM_OK;
 }

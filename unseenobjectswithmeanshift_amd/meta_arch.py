@@ -102,6 +102,11 @@ class MeanShiftMaskFormerHead(nn.Module):
         return predictions, None
 
 
+class PretrainedMeanShiftMaskFormerHead(MeanShiftMaskFormerHead):
+    """meanshift_former_head.py:145-275: identical glue for the UCN (RGB-D) configuration; the reference
+    calls exit() for any TRANSFORMER_IN_FEATURE other than "multi_scale_pixel_decoder" (:258-274)."""
+
+
 class MeanShiftMaskFormer(nn.Module):
     """Inference branch of the meta-arch (pretrained_meanshiftformer_model.py:244-303,334-378)."""
 
@@ -189,6 +194,21 @@ def combine_masks(instances):
 
 
 # ----------------------------------------------------------------------------------------------
+def build_ucn_head(num_queries=100, dec_layers=6, num_classes=2, hidden_dim=256, mask_dim=256, conv_dim=64, nheads=8,
+                   dim_feedforward=2048):
+    """The configuration of MSMFormer/configs/mixture_UCN.yaml:40-66 (RGB-D path): SimpleBasePixelDecoder +
+    PretrainedMeanShiftTransformerDecoder over the full-resolution 64-channel embedding ("res5")."""
+    from .modeling import PretrainedMeanShiftTransformerDecoder, ShapeSpec, SimpleBasePixelDecoder
+    shape = {"res5": ShapeSpec(channels=conv_dim, stride=1)}
+    pd = SimpleBasePixelDecoder(shape, conv_dim=conv_dim, mask_dim=mask_dim, norm="GN")
+    dec = PretrainedMeanShiftTransformerDecoder(in_channels=conv_dim, mask_classification=True, num_classes=num_classes,
+                                                hidden_dim=hidden_dim, num_queries=num_queries, nheads=nheads,
+                                                dim_feedforward=dim_feedforward, dec_layers=dec_layers, pre_norm=False,
+                                                mask_dim=mask_dim, enforce_input_project=False)
+    return PretrainedMeanShiftMaskFormerHead(shape, num_classes=num_classes, pixel_decoder=pd, transformer_predictor=dec,
+                                             transformer_in_feature="multi_scale_pixel_decoder")
+
+
 def build_resnet50_head(num_queries=100, dec_layers=9, num_classes=2, hidden_dim=256, mask_dim=256, conv_dim=64,
                         nheads=8, dim_feedforward=2048, enc_layers=6):
     """The configuration of MSMFormer/configs/mixture_ResNet50.yaml:31-77 (hot path only)."""

@@ -181,6 +181,7 @@ class MeanShiftTransformerDecoder(nn.Module):
     full list.  ``self.sparse_taps = True`` additionally skips mask rows that feed no 2x2 tap."""
 
     _version = 2
+    NUM_FEATURE_LEVELS = 3        # "we always use 3 scales" (DEC:494); the pretrained/UCN variant uses 1 (DEC:848)
 
     def __init__(self, in_channels, mask_classification=True, *, num_classes, hidden_dim, num_queries, nheads,
                  dim_feedforward, dec_layers, pre_norm, mask_dim, enforce_input_project,
@@ -197,7 +198,7 @@ class MeanShiftTransformerDecoder(nn.Module):
         self.num_layers = dec_layers
         self.num_queries = num_queries
         self.decoder_block_norm = decoder_block_norm
-        self.num_feature_levels = 3
+        self.num_feature_levels = self.NUM_FEATURE_LEVELS
         self.aux_outputs = False
         self.sparse_taps = False
         self.pe_layer = PositionEmbeddingSine(hidden_dim // 2, normalize=True)
@@ -228,7 +229,7 @@ class MeanShiftTransformerDecoder(nn.Module):
         # the K/V projections depend only on the level features, not on the query chain: with overlap_kv they
         # are issued on a side stream (fork/join events, also valid under HIP-graph capture) and run beside
         # the latency-bound per-layer query kernels that leave most CUs idle
-        self.overlap_kv = True
+        self.overlap_kv = False    # measured neutral at B=8 on MI355X (5.76 vs 5.69 ms/step): off by default
         self._side = None
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
@@ -391,6 +392,51 @@ class MeanShiftTransformerDecoder(nn.Module):
         if full:
             res["aux_outputs"] = [{"pred_logits": a, "pred_masks": b} for a, b in zip(pred_cls[:-1], pred_mask[:-1])]
         return res
+
+
+class PretrainedMeanShiftTransformerDecoder(MeanShiftTransformerDecoder):
+    """meanshiftformer_transformer_decoder.py:697-1048: the same decoder over ONE feature level -- every
+    pixel of the full-resolution 64-channel UCN embedding is a key, and the attention mask has the
+    resolution of the mask logits themselves (target size == mask size, so the bilinear resize is the
+    identity).  The kernels stream keys blockwise, so 307 200 keys need nothing new."""
+    NUM_FEATURE_LEVELS = 1
+
+
+class SimpleBasePixelDecoder(nn.Module):
+    """pixel_decoder/fpn.py:161-290: passes the backbone embedding through and, when mask_dim != 64,
+    derives mask_features with one 3x3 convolution (with bias, no norm)."""
+
+    def __init__(self, input_shape, *, conv_dim, mask_dim, norm=None):
+        super().__init__()
+        input_shape = sorted(input_shape.items(), key=lambda x: x[1].stride)
+        self.in_features = [k for k, v in input_shape]
+        self.mask_dim = mask_dim
+        self.conv_dim = conv_dim
+        if mask_dim != 64:
+            self.mask_features = nn.Conv2d(conv_dim, mask_dim, kernel_size=3, stride=1, padding=1)
+        self.maskformer_num_feature_levels = 1
+
+    @classmethod
+    def from_config(cls, cfg, input_shape):
+        sh = cfg.MODEL.SEM_SEG_HEAD
+        return dict(input_shape={k: v for k, v in input_shape.items() if k in sh.IN_FEATURES},
+                    conv_dim=sh.CONVS_DIM, mask_dim=sh.MASK_DIM, norm=sh.NORM)
+
+    @torch.no_grad()
+    def forward_features(self, features):
+        multi_scale_features = []
+        y = None
+        for f in self.in_features[::-1]:
+            y = features[f]
+            if len(multi_scale_features) < self.maskformer_num_feature_levels:
+                multi_scale_features.append(y)
+        if self.mask_dim == 64:
+            return y, None, multi_scale_features
+        B, C, H, W = y.shape
+        tok = ops.transpose_last2(y.contiguous().view(B, C, H * W))                       # NHWC tokens
+        w = self.mask_features.weight.permute(0, 2, 3, 1).reshape(self.mask_dim, 9 * C).contiguous()
+        mf = ops.conv3x3_tokens_to_nchw(tok, w, self.mask_features.bias, int(H), int(W))
+        return mf.view(B, self.mask_dim, H, W), None, multi_scale_features
 
 
 # ----------------------------------------------------------------------------------------------

@@ -123,6 +123,20 @@ def conv3x3_tokens(t, w_tap_major, H, W):
     return out
 
 
+def conv3x3_tokens_to_nchw(t, w_tap_major, bias, H, W):
+    """Same implicit GEMM, output written directly as NCHW (B, Cout, H*W) through the m-contiguous store
+    path (SimpleBasePixelDecoder.mask_features, fpn.py:237-246: Conv2d 3x3 with bias)."""
+    _c(t, "t"), _c(w_tap_major, "w"), _c(bias, "bias")
+    B, HW, Cin = t.shape
+    Cout = w_tap_major.shape[0]
+    out = torch.empty((B, Cout, HW), device=t.device, dtype=torch.float32)
+    rc = lib().msm_gemm_f32(_p(t), None, _p(w_tap_major), _p(bias), _p(out), HW, Cout, 9 * Cin, B,
+                            Cin, 1, HW * Cin, 0, 0, 1, HW, Cout * HW, 0,
+                            2, H, W, Cin, 1 if bias is not None else 0, 0, 1, _stream())
+    check(rc, "msm_gemm_f32(conv3x3 -> nchw)")
+    return out
+
+
 def layernorm(x, g1, b1, *, parts=None, bias=None, l2norm=False, g2=None, b2=None, eps=1e-5):
     """LayerNorm(x + sum(parts) + bias) [-> unit length] [-> second LayerNorm].  Returns y or (y, y2)."""
     _c(x, "x"), _c(parts, "parts"), _c(bias, "bias"), _c(g1, "g1"), _c(b1, "b1"), _c(g2, "g2"), _c(b2, "b2")
