@@ -258,6 +258,23 @@ def test_mean_shift_end_to_end_vs_reference(golden):
     assert torch.equal(labels.cpu(), T(g["a_labels"]).long())
 
 
+def test_mean_shift_full_size_matches_oracle():
+    """640x480 clustering (n = 307200, 100 seeds, 10 iterations, kappa 20) on planted clusters: seeds and
+    labels identical to the CPU oracle; also the size-independent properties (label 0 is the largest
+    cluster, labels are a function of the planted ids)."""
+    from unseenobjectswithmeanshift_amd import mean_shift as ms
+    X, ids = syn.synth_unit_embeddings(307200, 64, clusters=12, sigma=0.15, seed=3)
+    labels, sel = ms.mean_shift_smart_init(X.to(DEV), kappa=20, num_seeds=100, max_iters=10, first_index=11)
+    ref_labels, ref_sel, _, _ = O.mean_shift_smart_init(X, 20.0, 100, 10, 11)
+    assert torch.equal(sel.cpu(), ref_sel)
+    assert torch.equal(labels.cpu(), ref_labels)
+    lab = labels.cpu()
+    counts = torch.bincount(lab)
+    assert int(torch.argmax(counts)) == 0 and counts.numel() == 12
+    for c in range(12):
+        assert torch.unique(lab[ids == c]).numel() == 1
+
+
 def test_clustering_features_api():
     from unseenobjectswithmeanshift_amd import mean_shift as ms
     X, ids = syn.synth_unit_embeddings(2 * 40 * 60, 64, clusters=5, sigma=0.1, seed=4)
@@ -292,3 +309,65 @@ def test_meta_arch_inference_vs_oracle():
     conf = get_confident_instances(one, score=0.0)
     lab = combine_masks(conf)
     assert lab.shape == (64, 96)
+
+
+class _TinyBackbone(torch.nn.Module):
+    """Test-only stand-in for the (out-of-scope) ResNet-50: average-pool pyramid + fixed random 1x1 mixing,
+    plain torch ops.  Gives res2..res5 with the right channel counts for any H, W divisible by 32."""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(5)
+        self.mix = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(c, 6, generator=g) * 0.5) for c in (256, 512, 1024, 2048)])
+
+    def forward(self, images, depth=None):
+        x = images if depth is None else torch.cat([images, depth], 1)
+        if x.shape[1] == 3:
+            x = torch.cat([x, x], 1)
+        out = {}
+        for name, s, w in zip(("res2", "res3", "res4", "res5"), (4, 8, 16, 32), self.mix):
+            p = torch.nn.functional.avg_pool2d(x, s)
+            out[name] = torch.relu(torch.einsum("oc,bchw->bohw", w, p)).contiguous()
+        return out
+
+
+def test_two_stage_pipeline_on_gpu():
+    """BASELINE configs[3]: first stage on the full frame, depth filter, ROI crops resized to 224, a BATCHED
+    second stage over all crops, paste-back -- every tensor on the GPU, both stages on the HIP path."""
+    from unseenobjectswithmeanshift_amd import two_stage as ts
+    from unseenobjectswithmeanshift_amd.meta_arch import MeanShiftMaskFormer, Network_RGBD
+    head = make_pixel_decoder()
+    bb = _TinyBackbone().to(DEV).eval()
+
+    class RGBD(MeanShiftMaskFormer):
+        def forward(self, batched_inputs):
+            imgs = torch.stack([x["image"] for x in batched_inputs])
+            deps = torch.stack([x["depth"] for x in batched_inputs])
+            H, W = imgs.shape[-2:]
+            scores, classes, masks, boxes, _ = self.inference(self.backbone(imgs, deps), (int(H), int(W)))
+            from unseenobjectswithmeanshift_amd.meta_arch import Instances
+            return [{"instances": Instances((int(H), int(W)), pred_masks=masks[b], pred_boxes=boxes[b], scores=scores[b],
+                                            pred_classes=classes[b])} for b in range(len(batched_inputs))]
+
+    model = RGBD(backbone=bb, sem_seg_head=head, num_queries=100)
+
+    class Pred(Network_RGBD):
+        calls = 0
+
+        def batch_call(self, samples):
+            Pred.calls += 1
+            with torch.no_grad():
+                return self.model(samples)
+
+    first, second = Pred(model), Pred(model)
+    g = torch.Generator().manual_seed(3)
+    image = torch.rand(3, 96, 128, generator=g).to(DEV)
+    depth = torch.rand(3, 96, 128, generator=g).to(DEV)
+    out_label, refined, out_score, bbox = ts.test_sample_crop_nolabel({"image_color": image, "depth": depth}, first, second,
+                                                                      confident_score=0.0, topk=False)
+    assert out_label.shape == (1, 96, 128) and out_label.is_cuda
+    n_rois = int((torch.unique(out_label) != 0).sum())
+    if n_rois:
+        assert refined is not None and refined.shape == (1, 96, 128) and refined.is_cuda
+        assert Pred.calls == 1                      # one batched second-stage call for all crops
+        assert float(refined.max()) >= 1

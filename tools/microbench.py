@@ -94,5 +94,29 @@ def ucn():
     print(f"ucn B={B} 480x640: {t / 1e3:8.2f} ms per batch, {B / (t * 1e-6):7.1f} images/s, peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
 
 
+def meanshift():
+    """Classic UCN clustering at 640x480 (n = 307200, S = 100, 10 iterations) and the cfg-5 stress size."""
+    from unseenobjectswithmeanshift_amd import mean_shift as ms
+    from unseenobjectswithmeanshift_amd import synthetic as syn
+    for n, S, iters, k in ((307200, 100, 10, 12), (1228800, 300, 20, 24)):
+        X, _ = syn.synth_unit_embeddings(n, 64, clusters=k, sigma=0.15, seed=3)
+        Xd = X.to(DEV)
+        t_seed = timeit(lambda: ops.ms_select_seeds(Xd, S, 7), iters=3, warm=1)
+        seeds, _ = ops.ms_select_seeds(Xd, S, 7)
+        t_hill = timeit(lambda: ops.ms_hill_climb(Xd, seeds, 20.0, iters), iters=3, warm=1)
+        Z = ops.ms_hill_climb(Xd, seeds, 20.0, iters)
+        lab = torch.zeros(S, dtype=torch.int64, device=DEV)
+        t_asg = timeit(lambda: ops.ms_assign(Xd, Z, lab, 1), iters=3, warm=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            labels, sel = ms.mean_shift_smart_init(Xd, 20.0, S, iters, first_index=7)
+        torch.cuda.synchronize()
+        t_all = (time.perf_counter() - t0) / 3
+        print(f"mean-shift n={n} S={S} it={iters}: seeding {t_seed / 1e3:7.2f} ms ({S * n * 256 / t_seed / 1e6:6.2f} TB/s), "
+              f"hill-climb {t_hill / 1e3:7.2f} ms ({4.0 * S * n * 64 * iters / t_hill / 1e6:6.1f} TFLOP/s), assign {t_asg / 1e3:6.2f} ms, "
+              f"end-to-end {t_all * 1e3:7.2f} ms = {1 / t_all:6.1f} images/s, clusters={int(labels.max()) + 1}", flush=True)
+
+
 if __name__ == "__main__":
-    {"gemm": gemm, "mask": mask, "enc": enc, "attn": attn, "ucn": ucn}[sys.argv[1]]()
+    {"gemm": gemm, "mask": mask, "enc": enc, "attn": attn, "ucn": ucn, "meanshift": meanshift}[sys.argv[1]]()

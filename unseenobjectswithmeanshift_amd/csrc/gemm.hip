@@ -43,13 +43,18 @@ constexpr int SK = BK + 2;  // row stride of K-contiguous LDS tiles
 // (no branches: hipcc otherwise puts each guarded load in its own basic block and the loads of a tile
 // are issued one latency after the other).  !VEC is the element-wise, fully guarded fallback for
 // unaligned / odd shapes.
-template <int MI, int NI, int AMODE, bool SWAP, bool VEC, bool HAS_A2>
+// KT: LDS tile depth in units of 32 (BKX = 32*KT).  KT = 4 is used for the small, latency-bound GEMMs of
+// the decoder's per-query chain: K = 256 becomes two load phases with 16+ loads in flight per thread instead
+// of eight dependent ones.
+template <int MI, int NI, int AMODE, bool SWAP, bool VEC, bool HAS_A2, int KT>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     constexpr int BM = 32 * MI, BN = 32 * NI;
+    constexpr int BKX = BK * KT, SKX = BKX + 2, F4R = 8 * KT;   // tile depth, K-contiguous row stride, float4 per row
+    constexpr int LA = MI * KT, LW = NI * KT;                  // float4 loads per thread per tile
     constexpr int SM = BM + 16;  // row stride of the M-contiguous A tile
-    constexpr int A_ELEMS = (AMODE == 1) ? BK * SM : BM * SK;
+    constexpr int A_ELEMS = (AMODE == 1) ? BKX * SM : BM * SKX;
     __shared__ __attribute__((aligned(16))) float As[A_ELEMS];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * SK];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * SKX];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -68,7 +73,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     // Raw tile registers.  Loads are unconditional 16-byte loads from clamped addresses; the
     // out-of-range select and the A2 add are applied when the tile is written to LDS (i.e. AFTER the
     // MFMAs of the previous tile), so that the s_waitcnt for a prefetched tile sits behind the compute.
-    float4 ra[MI], ra2[HAS_A2 ? MI : 1], rb[NI];
+    float4 ra[LA], ra2[HAS_A2 ? LA : 1], rb[LW];
     // component-wise select (a float4 ?: is lowered through scratch memory by hipcc)
     auto sel4 = [](bool ok, float4 v) { return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f); };
     auto ld4 = [&](const float* ptr) { return *reinterpret_cast<const float4*>(ptr); };
@@ -90,9 +95,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
         if constexpr (AMODE == 1) {
             return (k0 + f / (BM / 4) < kend) && (m0 + (f % (BM / 4)) * 4 < p.M);
         } else if constexpr (AMODE == 0) {
-            return (m0 + (f >> 3) < p.M) && (k0 + (f & 7) * 4 < kend);
+            return (m0 + (f / F4R) < p.M) && (k0 + (f % F4R) * 4 < kend);
         } else {
-            const int k = k0 + (f & 7) * 4, m = m0 + (f >> 3);
+            const int k = k0 + (f % F4R) * 4, m = m0 + (f / F4R);
             const int tap = min(k, kend - 4) / p.conv_c;
             const int mc = min(m, p.M - 1);
             const int y = mc / p.conv_w, x = mc - y * p.conv_w;
@@ -102,16 +107,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     };
     auto w_ok = [&](int i, int k0) {
         const int f = tid + 256 * i;
-        return (n0 + (f >> 3) < p.N) && (k0 + (f & 7) * 4 < kend);
+        return (n0 + (f / F4R) < p.N) && (k0 + (f % F4R) * 4 < kend);
     };
 
     auto load_a = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
+        for (int i = 0; i < LA; ++i) {
             const int f = tid + 256 * i;
             float4 v;
             if constexpr (AMODE == 0) {
-                const int row = f >> 3, k = k0 + (f & 7) * 4;
+                const int row = f / F4R, k = k0 + (f % F4R) * 4;
                 const int m = m0 + row;
                 if constexpr (VEC) {
                     const int64_t off = (int64_t)min(m, p.M - 1) * p.a_sm + min(k, kend - 4);
@@ -132,8 +137,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
                 }
             } else {
                 // implicit im2col: k = tap*C + c, pixel (y,x) = (m / W, m % W), zero padding 1
-                const int k = min(k0 + (f & 7) * 4, kend - 4);
-                const int m = min(m0 + (f >> 3), p.M - 1);
+                const int k = min(k0 + (f % F4R) * 4, kend - 4);
+                const int m = min(m0 + (f / F4R), p.M - 1);
                 const int tap = k / p.conv_c, c = k - tap * p.conv_c;
                 const int y = m / p.conv_w, x = m - y * p.conv_w;
                 const int yc = min(max(y + tap / 3 - 1, 0), p.conv_h - 1), xc = min(max(x + tap % 3 - 1, 0), p.conv_w - 1);
@@ -144,9 +149,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     };
     auto load_w = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
+        for (int i = 0; i < LW; ++i) {
             const int f = tid + 256 * i;
-            const int row = f >> 3, k = k0 + (f & 7) * 4;
+            const int row = f / F4R, k = k0 + (f % F4R) * 4;
             const int n = n0 + row;
             if constexpr (VEC) {
                 rb[i] = ld4(Wb + (int64_t)min(n, p.N - 1) * p.K + min(k, kend - 4));
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     };
     auto store_tiles = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
+        for (int i = 0; i < LA; ++i) {
             const int f = tid + 256 * i;
             float4 v = ra[i];
             if constexpr (VEC) {
@@ -171,19 +176,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
                 const int kk = f / (BM / 4), mm = (f % (BM / 4)) * 4;
                 *reinterpret_cast<float4*>(&As[kk * SM + mm]) = v;
             } else {
-                const int row = f >> 3, c4 = (f & 7) * 4;
-                float2* d = reinterpret_cast<float2*>(&As[row * SK + c4]);
+                const int row = f / F4R, c4 = (f % F4R) * 4;
+                float2* d = reinterpret_cast<float2*>(&As[row * SKX + c4]);
                 d[0] = make_float2(v.x, v.y);
                 d[1] = make_float2(v.z, v.w);
             }
         }
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
+        for (int i = 0; i < LW; ++i) {
             const int f = tid + 256 * i;
-            const int row = f >> 3, c4 = (f & 7) * 4;
+            const int row = f / F4R, c4 = (f % F4R) * 4;
             float4 v = rb[i];
             if constexpr (VEC) v = sel4(w_ok(i, k0), v);
-            float2* d = reinterpret_cast<float2*>(&Bs[row * SK + c4]);
+            float2* d = reinterpret_cast<float2*>(&Bs[row * SKX + c4]);
             d[0] = make_float2(v.x, v.y);
             d[1] = make_float2(v.z, v.w);
         }
@@ -197,26 +202,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 
     load_a(kbeg);
     load_w(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    for (int k0 = kbeg; k0 < kend; k0 += BKX) {
         store_tiles(k0);
         __syncthreads();
-        if (k0 + BK < kend) {
-            load_a(k0 + BK);
-            load_w(k0 + BK);
+        if (k0 + BKX < kend) {
+            load_a(k0 + BKX);
+            load_w(k0 + BKX);
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above, the selects/LDS writes below the MFMAs
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 4) {
+        for (int kk = 0; kk < BKX; kk += 4) {
             float a[MI], bb[NI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 if constexpr (AMODE == 1)
                     a[i] = As[(kk + lq) * SM + wm + i * 16 + lj];
                 else
-                    a[i] = As[(wm + i * 16 + lj) * SK + kk + lq];
+                    a[i] = As[(wm + i * 16 + lj) * SKX + kk + lq];
             }
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bb[j] = Bs[(wn + j * 16 + lj) * SK + kk + lq];
+            for (int j = 0; j < NI; ++j) bb[j] = Bs[(wn + j * 16 + lj) * SKX + kk + lq];
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -270,7 +275,7 @@ static int launch_gemm_o(const GemmArgs& p, hipStream_t st) {
     dim3 block(256);
     if (!(p.vec_a && p.vec_w)) {   // unaligned / odd shapes: guarded element-wise loads, smallest tile
         dim3 grid(cdiv(p.N, 32), cdiv(p.M, 32), p.batch * p.split_k);
-        hipLaunchKernelGGL((gemm_kernel<1, 1, AMODE, SWAP, false, HAS_A2>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((gemm_kernel<1, 1, AMODE, SWAP, false, HAS_A2, 1>), grid, block, 0, st, p);
         MSM_CHECK_LAUNCH("msm_gemm_f32");
         return MSM_OK;
     }
@@ -294,12 +299,24 @@ static int launch_gemm_o(const GemmArgs& p, hipStream_t st) {
     if (const char* e = getenv("MSM_GEMM_TILE")) pick = atoi(e);
     const int mi = cfgs[pick][0], ni = cfgs[pick][1];
     dim3 grid(cdiv(p.N, 32 * ni), cdiv(p.M, 32 * mi), p.batch * p.split_k);
+    // deep LDS tiles for the small latency-bound shapes (row-major activations only)
+    const bool deep = AMODE == 0 && pick >= 3 && p.k_per_split >= 128 && getenv("MSM_GEMM_SHALLOW") == nullptr;
     switch (pick) {
-        case 0: hipLaunchKernelGGL((gemm_kernel<4, 4, AMODE, SWAP, true, HAS_A2>), grid, block, 0, st, p); break;
-        case 1: hipLaunchKernelGGL((gemm_kernel<2, 4, AMODE, SWAP, true, HAS_A2>), grid, block, 0, st, p); break;
-        case 2: hipLaunchKernelGGL((gemm_kernel<2, 2, AMODE, SWAP, true, HAS_A2>), grid, block, 0, st, p); break;
-        case 3: hipLaunchKernelGGL((gemm_kernel<1, 2, AMODE, SWAP, true, HAS_A2>), grid, block, 0, st, p); break;
-        default: hipLaunchKernelGGL((gemm_kernel<1, 1, AMODE, SWAP, true, HAS_A2>), grid, block, 0, st, p); break;
+        case 0: hipLaunchKernelGGL((gemm_kernel<4, 4, AMODE, SWAP, true, HAS_A2, 1>), grid, block, 0, st, p); break;
+        case 1: hipLaunchKernelGGL((gemm_kernel<2, 4, AMODE, SWAP, true, HAS_A2, 1>), grid, block, 0, st, p); break;
+        case 2: hipLaunchKernelGGL((gemm_kernel<2, 2, AMODE, SWAP, true, HAS_A2, 1>), grid, block, 0, st, p); break;
+        case 3:
+            if constexpr (AMODE == 0) {
+                if (deep) { hipLaunchKernelGGL((gemm_kernel<1, 2, 0, SWAP, true, HAS_A2, 4>), grid, block, 0, st, p); break; }
+            }
+            hipLaunchKernelGGL((gemm_kernel<1, 2, AMODE, SWAP, true, HAS_A2, 1>), grid, block, 0, st, p);
+            break;
+        default:
+            if constexpr (AMODE == 0) {
+                if (deep) { hipLaunchKernelGGL((gemm_kernel<1, 1, 0, SWAP, true, HAS_A2, 4>), grid, block, 0, st, p); break; }
+            }
+            hipLaunchKernelGGL((gemm_kernel<1, 1, AMODE, SWAP, true, HAS_A2, 1>), grid, block, 0, st, p);
+            break;
     }
     MSM_CHECK_LAUNCH("msm_gemm_f32");
     return MSM_OK;
@@ -339,7 +356,7 @@ extern "C" int msm_gemm_f32(const float* A, const float* A2, const float* W, con
     p.bias_mode = bias_mode; p.act = act; p.split_k = split_k;
     p.dbg_nostore = getenv("MSM_GEMM_NOSTORE") != nullptr;
     int kps = cdiv(K, split_k);
-    kps = cdiv(kps, BK) * BK;  // whole LDS tiles per split
+    kps = cdiv(kps, BK) * BK;  // whole 32-deep sub-tiles per split (deep tiles zero-fill their tail)
     p.k_per_split = kps;
     MSM_REQUIRE((int64_t)kps * (split_k - 1) < K, "msm_gemm_f32: split_k=%d too large for K=%d", split_k, K);
     const bool a16 = (((uintptr_t)A) & 15) == 0 && (!A2 || (((uintptr_t)A2) & 15) == 0);
