@@ -16,6 +16,8 @@
 //   * each wave keeps all <=112 queries of a chunk (Q^ as 56 VGPRs, O as 56) and streams its share
 //     of the 16-key blocks; 4 waves + key splits across workgroups are reduced through LDS and a
 //     small combine kernel that also applies 1/l and the output L2 normalisation.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace msm {
@@ -27,7 +29,8 @@ constexpr int PSTRIDE = HD + 1;    // partial row: 32 outputs + softmax denomina
 
 static int attn_nsplit(int B, int qchunks, int heads, int S) {
     const int base = B * qchunks * heads;
-    int ns = cdiv(512, base);
+    static const int target = getenv("MSM_ATTN_TARGET") ? atoi(getenv("MSM_ATTN_TARGET")) : 512;
+    int ns = cdiv(target, base);
     const int maxs = max(1, S / 128);  // >= 2 key blocks per wave
     if (ns > maxs) ns = maxs;
     if (ns < 1) ns = 1;
@@ -37,14 +40,15 @@ static int attn_nsplit(int B, int qchunks, int heads, int S) {
 __global__ __launch_bounds__(256) void hs_attn_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                       const float* __restrict__ v, const uint8_t* __restrict__ masked,
                                                       const int32_t* __restrict__ row_any, float* __restrict__ part,
-                                                      int Lq, int S, int heads, int qchunks, int nsplit, int64_t ldq,
+                                                      float* __restrict__ out, int Lq, int S, int heads, int qchunks, int nsplit, int64_t ldq,
                                                       int64_t q_sb, int64_t ldk, int64_t k_sb, int64_t ldv,
                                                       int64_t v_sb, float kappa) {
     extern __shared__ __attribute__((aligned(16))) float red[];  // [4][AQCH][PSTRIDE]
     const int split = blockIdx.x, h = blockIdx.y;
     const int b = blockIdx.z / qchunks, qc = blockIdx.z - b * qchunks;
     const int q0 = qc * AQCH;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably uniform: scalar key-block loop
     const int lj = lane & 15, lq = lane >> 4;
 
     // ---- Q^ fragments (B operand): lane (query lj of block m, dims lq*8 + t) ----
@@ -91,43 +95,56 @@ __global__ __launch_bounds__(256) void hs_attn_kernel(const float* __restrict__ 
     const float* vbp = v + (int64_t)b * v_sb + h * HD + lj;
     const bool mask_vec = (S % 4) == 0;
 
-    for (int kb = kb_beg + wave; kb < kb_end; kb += 4) {
-        // K^ fragment (A operand): lane (key lj, dims lq*8 + t)
+    // Software prefetch: the K / V fragments and the 7 mask words of key block kb+4 are fetched (from
+    // clamped, always-valid addresses) before the 112 MFMAs of block kb, pinned with sched_barrier.
+    struct Frag {
+        float4 ka, kc;
+        float v[4][2];
+        uint32_t mw[AQB];
+    };
+    auto fetch = [&](int kb, Frag& f) {
         const int key_a = min(kb * 16 + lj, S - 1);
         const float* kp = kbp + (int64_t)key_a * ldk;
-        const float4 a = *reinterpret_cast<const float4*>(kp);
-        const float4 c = *reinterpret_cast<const float4*>(kp + 4);
+        f.ka = *reinterpret_cast<const float4*>(kp);
+        f.kc = *reinterpret_cast<const float4*>(kp + 4);
+        const int key_c0 = kb * 16 + lq * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* vp = vbp + (int64_t)min(key_c0 + r, S - 1) * ldv;
+            f.v[r][0] = vp[0];
+            f.v[r][1] = vp[16];
+        }
+#pragma unroll
+        for (int m = 0; m < AQB; ++m) {
+            uint32_t w = 0;
+            if (masked != nullptr) {
+                const int qi = min(q0 + m * 16 + lj, Lq - 1);
+                const uint8_t* mp = masked + ((int64_t)b * Lq + qi) * S;
+                if (mask_vec) {
+                    w = *reinterpret_cast<const uint32_t*>(mp + min(key_c0, S - 4));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) w |= (uint32_t)mp[min(key_c0 + r, S - 1)] << (8 * r);
+                }
+            }
+            f.mw[m] = w;
+        }
+    };
+    auto consume = [&](int kb, const Frag& f) {
+        const float4 a = f.ka, c = f.kc;
         float ss = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
         ss += __shfl_xor(ss, 16, 64);
         ss += __shfl_xor(ss, 32, 64);
         const float rn = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-        float kf[8] = {a.x * rn, a.y * rn, a.z * rn, a.w * rn, c.x * rn, c.y * rn, c.z * rn, c.w * rn};
-        // V fragments (B operand of P V): lane (key lq*4 + r, dim db*16 + lj)
+        const float kf[8] = {a.x * rn, a.y * rn, a.z * rn, a.w * rn, c.x * rn, c.y * rn, c.z * rn, c.w * rn};
         const int key_c0 = kb * 16 + lq * 4;
-        float vf[4][2];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float* vp = vbp + (int64_t)min(key_c0 + r, S - 1) * ldv;
-            vf[r][0] = vp[0];
-            vf[r][1] = vp[16];
-        }
 #pragma unroll
         for (int m = 0; m < AQB; ++m) {
             f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 8; ++t) s = mfma16(kf[t], qf[m][t], s);
             // s[r]: key key_c0 + r, query q0 + m*16 + lj
-            uint32_t mw = 0;
-            if (use_mask[m]) {
-                const uint8_t* mp = masked + ((int64_t)b * Lq + (q0 + m * 16 + lj)) * S + key_c0;
-                if (mask_vec) {
-                    if (key_c0 < S) mw = *reinterpret_cast<const uint32_t*>(mp);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (key_c0 + r < S) mw |= (uint32_t)mp[r] << (8 * r);
-                }
-            }
+            const uint32_t mw = use_mask[m] ? f.mw[m] : 0u;
             float p[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -137,10 +154,26 @@ __global__ __launch_bounds__(256) void hs_attn_kernel(const float* __restrict__ 
             lsum[m] += (p[0] + p[1]) + (p[2] + p[3]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                o[m][0] = mfma16(p[r], vf[r][0], o[m][0]);
-                o[m][1] = mfma16(p[r], vf[r][1], o[m][1]);
+                o[m][0] = mfma16(p[r], f.v[r][0], o[m][0]);
+                o[m][1] = mfma16(p[r], f.v[r][1], o[m][1]);
             }
         }
+    };
+    {
+        Frag fa, fb;
+        int kb = kb_beg + wave;
+        if (kb < kb_end) fetch(kb, fa);
+        for (; kb + 4 < kb_end; kb += 8) {        // two blocks per trip: ping-pong without register copies
+            fetch(kb + 4, fb);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(kb, fa);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(min(kb + 8, nkb - 1), fa);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(kb + 4, fb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kb < kb_end) consume(kb, fa);
     }
 
     // ---- reduce the 4 waves through LDS, then one partial per workgroup ----
@@ -159,6 +192,30 @@ __global__ __launch_bounds__(256) void hs_attn_kernel(const float* __restrict__ 
         }
     }
     __syncthreads();
+    if (nsplit == 1) {
+        // single key range: finish here (1/l, output L2 normalisation, head merge) -- no partials, no 2nd launch
+        const int ql = tid;
+        const int qi = q0 + ql;
+        if (ql < AQCH && qi < Lq) {
+            float acc[HD + 1];
+#pragma unroll
+            for (int d = 0; d <= HD; ++d)
+                acc[d] = (red[ql * PSTRIDE + d] + red[AQCH * PSTRIDE + ql * PSTRIDE + d]) +
+                         (red[2 * AQCH * PSTRIDE + ql * PSTRIDE + d] + red[3 * AQCH * PSTRIDE + ql * PSTRIDE + d]);
+            const float l = acc[HD];
+            float ss = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                acc[d] = acc[d] / l;
+                ss += acc[d] * acc[d];
+            }
+            const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+            float* o_ = out + ((int64_t)b * Lq + qi) * (heads * HD) + h * HD;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) o_[d] = acc[d] / nrm;
+        }
+        return;
+    }
     float* dst = part + ((((int64_t)blockIdx.z * heads + h) * nsplit) + split) * (AQCH * PSTRIDE);
     for (int i = tid; i < AQCH * PSTRIDE; i += 256) {
         dst[i] = (red[i] + red[AQCH * PSTRIDE + i]) + (red[2 * AQCH * PSTRIDE + i] + red[3 * AQCH * PSTRIDE + i]);
@@ -226,9 +283,10 @@ extern "C" int msm_hypersphere_attn_fwd(const float* q, const float* k, const fl
     const size_t lds = sizeof(float) * 4 * AQCH * PSTRIDE;
     MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)hs_attn_kernel, lds));
     dim3 grid(ns, heads, B * qchunks), block(256);
-    hipLaunchKernelGGL(hs_attn_kernel, grid, block, lds, st, q, k, v, masked, row_any, workspace, Lq, S, heads, qchunks,
+    hipLaunchKernelGGL(hs_attn_kernel, grid, block, lds, st, q, k, v, masked, row_any, workspace, out, Lq, S, heads, qchunks,
                        ns, ldq, q_sb, ldk, k_sb, ldv, v_sb, kappa);
     MSM_CHECK_LAUNCH("msm_hypersphere_attn_fwd");
+    if (ns == 1) return MSM_OK;
     dim3 g2(heads, B * qchunks), b2(128);
     hipLaunchKernelGGL(hs_attn_combine_kernel, g2, b2, 0, st, workspace, out, Lq, heads, qchunks, ns);
     MSM_CHECK_LAUNCH("msm_hypersphere_attn_fwd(combine)");

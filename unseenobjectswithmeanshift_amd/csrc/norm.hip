@@ -73,34 +73,40 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // ---- GroupNorm --------------------------------------------------------------------------------
-// stats[b][c] = (sum, sumsq) in double: lane = channel, waves stride over pixels, one double
-// atomic per (block, channel).  Double accumulation keeps E[x^2]-E[x]^2 well conditioned and makes
-// the result insensitive to the (unordered) atomic arrival order at fp32 precision.
+// stats[b][c] = (sum, sumsq) in double.  Thread = (4 consecutive channels, pixel stream): 16-byte
+// loads, fp32 partial sums over a short run of pixels, then double for the cross-thread reduction and
+// one double atomic per (block, channel).  Double accumulation keeps E[x^2]-E[x]^2 well conditioned and
+// makes the result insensitive to the (unordered) atomic arrival order at fp32 precision.
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, double* __restrict__ stats,
                                                        int HW, int C, int pix_per_block) {
     const int b = blockIdx.y;
     const int p0 = blockIdx.x * pix_per_block;
     const int p1 = min(HW, p0 + pix_per_block);
-    const int lanes_c = C;  // C <= 256 channels, thread t handles channel t % C, pixel stream t / C
-    const int streams = 256 / lanes_c;
-    const int c = threadIdx.x % lanes_c, s = threadIdx.x / lanes_c;
-    double sum = 0.0, sq = 0.0;
-    if (s < streams) {
-        const float* xb = x + ((int64_t)b * HW) * C + c;
-        for (int p = p0 + s; p < p1; p += streams) {
-            const float v = xb[(int64_t)p * C];
-            sum += (double)v;
-            sq += (double)v * (double)v;
+    const int c4n = C >> 2;                    // float4 per pixel
+    const int streams = 256 / c4n;
+    const int c4 = threadIdx.x % c4n, st = threadIdx.x / c4n;
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    if (st < streams) {
+        const float* xb = x + ((int64_t)b * HW) * C + c4 * 4;
+        for (int p = p0 + st; p < p1; p += streams) {
+            const float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)p * C);
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+            q[0] += v.x * v.x; q[1] += v.y * v.y; q[2] += v.z * v.z; q[3] += v.w * v.w;
         }
     }
-    __shared__ double red[2][256];
-    red[0][threadIdx.x] = sum;
-    red[1][threadIdx.x] = sq;
+    __shared__ double red[2][4][256];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[0][e][threadIdx.x] = (double)s[e];
+        red[1][e][threadIdx.x] = (double)q[e];
+    }
     __syncthreads();
-    if (s == 0) {
-        for (int k = 1; k < streams; ++k) {
-            sum += red[0][k * lanes_c + c];
-            sq += red[1][k * lanes_c + c];
+    if (threadIdx.x < C) {
+        const int c = threadIdx.x, cc = c >> 2, e = c & 3;
+        double sum = 0.0, sq = 0.0;
+        for (int k = 0; k < streams; ++k) {
+            sum += red[0][e][k * c4n + cc];
+            sq += red[1][e][k * c4n + cc];
         }
         double* d = stats + ((int64_t)b * C + c) * 2;
         atomicAdd(d, sum);
@@ -118,19 +124,19 @@ __device__ __forceinline__ void bilin_src(int dst, int in, int out, int& i0, int
     l1 = src - (float)i0;
 }
 
+// y = (x - mean_g) * rstd_g * gamma + beta [+ bilinear(up)] [relu]; per-channel scale/shift are derived once
+// per block into LDS, the body is 16-byte loads/stores (thread = 4 channels of one pixel).
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ up, int uh, int uw,
                                                        float* __restrict__ y, int H, int W, int C, int groups,
                                                        float eps, int relu) {
+    __shared__ float sc[256], sh[256], mn[256];
     const int b = blockIdx.y;
     const int HW = H * W;
     const int cpg = C / groups;
-    const int64_t total = (int64_t)HW * C;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int c = (int)(idx % C);
-        const int p = (int)(idx / C);
-        const int g0 = (c / cpg) * cpg;
+    if (threadIdx.x < C) {
+        const int c = threadIdx.x, g0 = (c / cpg) * cpg;
         double s = 0.0, q = 0.0;
         for (int k = 0; k < cpg; ++k) {
             s += stats[((int64_t)b * C + g0 + k) * 2];
@@ -141,7 +147,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
         double var = q / cnt - mean * mean;
         if (var < 0.0) var = 0.0;
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        float v = (x[(int64_t)b * total + idx] - (float)mean) * rstd * gamma[c] + beta[c];
+        const float a = rstd * gamma[c];
+        sc[c] = a;
+        sh[c] = beta[c];
+        mn[c] = (float)mean;
+    }
+    __syncthreads();
+    const int c4n = C >> 2;
+    const int64_t total4 = (int64_t)HW * c4n;
+    const float* xb = x + (int64_t)b * HW * C;
+    float* yb = y + (int64_t)b * HW * C;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % c4n) * 4;
+        const int p = (int)(idx / c4n);
+        float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)p * C + c);
+        v.x = (v.x - mn[c]) * sc[c] + sh[c];
+        v.y = (v.y - mn[c + 1]) * sc[c + 1] + sh[c + 1];
+        v.z = (v.z - mn[c + 2]) * sc[c + 2] + sh[c + 2];
+        v.w = (v.w - mn[c + 3]) * sc[c + 3] + sh[c + 3];
         if (up) {
             const int yy = p / W, xx = p - yy * W;
             int y0, y1, x0, x1;
@@ -149,13 +172,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
             bilin_src(yy, uh, H, y0, y1, ly);
             bilin_src(xx, uw, W, x0, x1, lx);
             const float* ub = up + (int64_t)b * uh * uw * C + c;
-            const float v00 = ub[((int64_t)y0 * uw + x0) * C], v01 = ub[((int64_t)y0 * uw + x1) * C];
-            const float v10 = ub[((int64_t)y1 * uw + x0) * C], v11 = ub[((int64_t)y1 * uw + x1) * C];
+            const float4 v00 = *reinterpret_cast<const float4*>(ub + ((int64_t)y0 * uw + x0) * C);
+            const float4 v01 = *reinterpret_cast<const float4*>(ub + ((int64_t)y0 * uw + x1) * C);
+            const float4 v10 = *reinterpret_cast<const float4*>(ub + ((int64_t)y1 * uw + x0) * C);
+            const float4 v11 = *reinterpret_cast<const float4*>(ub + ((int64_t)y1 * uw + x1) * C);
             const float hy = 1.f - ly, hx = 1.f - lx;
-            v += hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+            v.x += hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+            v.y += hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+            v.z += hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+            v.w += hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
         }
-        if (relu) v = fmaxf(v, 0.f);
-        y[(int64_t)b * total + idx] = v;
+        if (relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(yb + (int64_t)p * C + c) = v;
     }
 }
 
@@ -231,10 +261,11 @@ extern "C" int msm_layernorm_f32(const float* x, const float* parts, int n_parts
 
 extern "C" int msm_groupnorm_stats_f32(const float* x, double* stats, int B, int HW, int C, void* stream) {
     MSM_REQUIRE(x && stats && B > 0 && HW > 0, "msm_groupnorm_stats_f32: bad arguments");
-    MSM_REQUIRE(C > 0 && C <= 256 && 256 % C == 0, "msm_groupnorm_stats_f32: C=%d must divide 256", C);
+    MSM_REQUIRE(C >= 4 && C <= 256 && C % 4 == 0 && 1024 % C == 0, "msm_groupnorm_stats_f32: C=%d must be a multiple of 4 dividing 1024", C);
+    MSM_REQUIRE((((uintptr_t)x) & 15) == 0, "msm_groupnorm_stats_f32: x must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     MSM_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * (size_t)B * C, st));
-    const int ppb = 512;
+    const int ppb = 256;
     dim3 grid(cdiv(HW, ppb), B), block(256);
     hipLaunchKernelGGL(gn_stats_kernel, grid, block, 0, st, x, stats, HW, C, ppb);
     MSM_CHECK_LAUNCH("msm_groupnorm_stats_f32");
@@ -245,11 +276,12 @@ extern "C" int msm_groupnorm_apply_f32(const float* x, const double* stats, cons
                                        const float* up, int uh, int uw, float* y, int B, int H, int W, int C,
                                        int groups, float eps, int relu, void* stream) {
     MSM_REQUIRE(x && stats && gamma && beta && y, "msm_groupnorm_apply_f32: null pointer");
-    MSM_REQUIRE(groups > 0 && C % groups == 0, "msm_groupnorm_apply_f32: C=%d groups=%d", C, groups);
+    MSM_REQUIRE(groups > 0 && C % groups == 0 && C % 4 == 0 && C <= 256, "msm_groupnorm_apply_f32: C=%d groups=%d", C, groups);
+    MSM_REQUIRE(((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)up)) & 15) == 0, "msm_groupnorm_apply_f32: pointers must be 16-byte aligned");
     MSM_REQUIRE(!up || (uh > 0 && uw > 0), "msm_groupnorm_apply_f32: bad upsample source size");
     hipStream_t st = (hipStream_t)stream;
-    const int64_t total = (int64_t)H * W * C;
-    dim3 grid((unsigned)min((int64_t)2048, (total + 255) / 256), B), block(256);
+    const int64_t total = (int64_t)H * W * (C / 4);
+    dim3 grid((unsigned)min((int64_t)1024, (total + 255) / 256), B), block(256);
     hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, st, x, stats, gamma, beta, up, uh, uw, y, H, W, C, groups, eps,
                        relu);
     MSM_CHECK_LAUNCH("msm_groupnorm_apply_f32");
