@@ -170,6 +170,14 @@ def main():
     mask_ms = sum(per_call) / len(per_call)
     flops_per_launch = 2.0 * Q * C_MASK * (H // 4) * (W // 4) * (hi - lo)
     achieved = flops_per_launch / (mask_ms * 1e-3) / 1e12
+    # HBM traffic of the same kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; the
+    # gfx950 x2 correction on FETCH_SIZE applied), summarised in profiles/ -- it cannot be measured in-process
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "mask_step_traffic.json")) as f:
+            traffic = json.load(f)["bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     result = {
         "metric": "images/sec @640x480 RGB-D, 100 queries, 9 decoder layers; % MFMA roofline",
         "value": round(total_images / t_max, 2),
@@ -190,7 +198,7 @@ def main():
                    "sparse_taps": bool(args.sparse_taps), "parallelism": f"dp{world}"},
         "roofline": {"bound": "mfma", "kernel": "mask_logits_kernel (msm_mask_logits_fwd)",
                      "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                      "launches_per_step": calls_per_step, "avg_launch_ms": round(mask_ms, 4),
                      "flops_per_launch": flops_per_launch},
         "breakdown": breakdown,
