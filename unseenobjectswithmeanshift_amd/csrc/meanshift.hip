@@ -16,98 +16,139 @@
 //               layout for the W X product;
 //   assignment: one more X pass, S^T tiles + an in-register first-min argmin.
 #include "common.h"
+#include <cstdlib>
 
 namespace msm {
 
 constexpr int MS_D = 64;
 constexpr int MS_SB = 19;              // up to 19 seed blocks of 16 -> S <= 304
 constexpr int MS_CH = 8;               // seed blocks handled per kernel instance (128 seeds)
-constexpr int SZ = MS_D + 1;           // LDS row stride (bank-conflict-free fragment reads)
+constexpr int SZ = MS_D + 4;           // LDS row stride in floats: 16-byte aligned rows, 17 slots apart -> b128 reads spread over the banks
 
 // ------------------------------------------------------------------------------------------------
 // seeding
 // ------------------------------------------------------------------------------------------------
-struct ArgMax {
-    float v;
-    int i;
-};
-__device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) {  // larger value, then smaller index
-    return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+// One farthest-point step = ONE launch, no inter-workgroup hand-off:
+//   nearest[i] = min(nearest[i], 0.5*(1 - X[i].X[winner(step-1)])), and the step's winner (first argmax) is
+//   folded into a single 64-bit atomicMax key  (order-preserving bits of the value) << 32 | (~index),
+//   so the larger value wins and, on ties, the smaller index -- exactly torch.argmax.  The NEXT launch
+//   decodes keys[step-1]; the kernel boundary is the only synchronisation.
+// Mapping: 16 lanes own 16 consecutive rows.  Each lane loads its 16-byte column chunk of all 16 rows
+// (16 independent loads in flight), and a 4-stage halving butterfly (15 shuffles) leaves lane j with the dot
+// product of row j, so the nearest[] update and the running argmax use every lane and 64-byte accesses.
+__device__ __forceinline__ unsigned int ordered_bits(float v) {
+    const unsigned int u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// nearest[i] = min(nearest[i], 0.5*(1 - X[i].X[cur]));  partial[blk] = first argmax over the block
-__global__ __launch_bounds__(256) void ms_seed_dist_kernel(const float* __restrict__ X, int n,
-                                                           const int64_t* __restrict__ sel, int step,
-                                                           float* __restrict__ nearest, ArgMax* __restrict__ partial) {
+template <bool SMALL>
+__global__ __launch_bounds__(256) void ms_seed_step_kernel(const float* __restrict__ X, int n,
+                                                           unsigned long long* __restrict__ keys, int step,
+                                                           float* __restrict__ nearest) {
     __shared__ float4 seed4[16];
-    __shared__ ArgMax red[4];
+    __shared__ unsigned long long red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t cur = sel[step - 1];
-    if (tid < 16) seed4[tid] = *reinterpret_cast<const float4*>(X + cur * MS_D + tid * 4);
-    __syncthreads();
-    const int sub = lane & 15;       // 16 lanes x float4 = one 256-byte row
-    const int rl = lane >> 4;        // 4 rows per wave instruction
-    const float4 s = seed4[sub];
-    ArgMax best{-INFINITY, 0x7fffffff};
-    // each block owns a contiguous range of rows so that indices grow with the scan
-    const int rows_per_block = (n + gridDim.x - 1) / gridDim.x;
+    const int j = lane & 15;         // column chunk while loading, row within the group after the butterfly
+    const int grp = lane >> 4;
+    const int rows_per_block = (((n + gridDim.x - 1) / gridDim.x) + 15) & ~15;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
-    for (int base = r0 + wave * 4; base < r1; base += 16) {
-        const int row = base + rl;
-        float dot = 0.f;
-        if (row < r1) {
-            const float4 x = *reinterpret_cast<const float4*>(X + (int64_t)row * MS_D + sub * 4);
-            dot = x.x * s.x + x.y * s.y + x.z * s.z + x.w * s.w;
-        }
-        dot += __shfl_xor(dot, 1, 64);
-        dot += __shfl_xor(dot, 2, 64);
-        dot += __shfl_xor(dot, 4, 64);
-        dot += __shfl_xor(dot, 8, 64);
-        if (row < r1 && sub == 0) {
-            float d = 0.5f * (1.0f - dot);
-            if (step > 1) d = fminf(nearest[row], d);
-            nearest[row] = d;
-            if (d > best.v) best = ArgMax{d, row};   // rows visited in increasing order per lane
-        }
-    }
+    int base = r0 + (wave * 4 + grp) * 16;
+    // The last group of the array is slid back to rows [n-16, n): re-processing a row is idempotent (same min,
+    // same key), so no per-row clamps and the 16 row loads share one address register + immediate offsets.
+    // (n < 16 keeps the rows clamped instead: SMALL.)
+    // program order = issue order: previous winner's key, this pass's 16 rows + nearest[], then the winner's row,
+    // so the two dependent latencies (key -> seed row) overlap the streaming loads
+    const unsigned long long prev = keys[step - 1];
+    float4 x[16];
+    int gb = SMALL ? base : min(base, n - 16);
+    {
+        const float* src = X + (int64_t)gb * MS_D + j * 4;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        ArgMax other{__shfl_xor(best.v, o, 64), __shfl_xor(best.i, o, 64)};
-        best = better(best, other);
+        for (int i = 0; i < 16; ++i)
+            x[i] = *reinterpret_cast<const float4*>(SMALL ? X + (int64_t)min(gb + i, n - 1) * MS_D + j * 4 : src + i * MS_D);
     }
-    if (lane == 0) red[wave] = best;
+    float near = (step > 1) ? nearest[min(gb + j, n - 1)] : INFINITY;
+    const unsigned int cur = 0xFFFFFFFFu - (unsigned int)(prev & 0xFFFFFFFFull);
+    if (tid < 16) seed4[tid] = *reinterpret_cast<const float4*>(X + (int64_t)cur * MS_D + tid * 4);
     __syncthreads();
-    if (tid == 0) partial[blockIdx.x] = better(better(red[0], red[1]), better(red[2], red[3]));
-}
-
-__global__ __launch_bounds__(256) void ms_seed_pick_kernel(const float* __restrict__ X, const ArgMax* __restrict__ partial,
-                                                           int nblk, int64_t* __restrict__ sel, int step,
-                                                           float* __restrict__ seeds) {
-    __shared__ ArgMax red[4];
-    __shared__ int chosen;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    ArgMax best{-INFINITY, 0x7fffffff};
-    for (int i = tid; i < nblk; i += 256) best = better(best, partial[i]);
+    const float4 s = seed4[j];
+    unsigned long long best = 0ull;
+    for (int pass = 0; base < r1; base += 256, ++pass) {
+        if (pass > 0) {   // multi-pass launches (n > 512 Ki rows); other resident waves cover this latency
+            gb = SMALL ? base : min(base, n - 16);
+            const float* src = X + (int64_t)gb * MS_D + j * 4;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                x[i] = *reinterpret_cast<const float4*>(SMALL ? X + (int64_t)min(gb + i, n - 1) * MS_D + j * 4 : src + i * MS_D);
+            if (step > 1) near = nearest[min(gb + j, n - 1)];
+        }
+        float p[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) p[i] = x[i].x * s.x + x[i].y * s.y + x[i].z * s.z + x[i].w * s.w;
+        const float near_now = near;
+        const int row = gb + j;
+        // halving butterfly: after the stage with mask m, lanes with (j & m) keep the upper half of the rows
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool hi = j & 8;
+            const float send = hi ? p[i] : p[i + 8];
+            const float keep = hi ? p[i + 8] : p[i];
+            p[i] = keep + __shfl_xor(send, 8, 64);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool hi = j & 4;
+            const float send = hi ? p[i] : p[i + 4];
+            const float keep = hi ? p[i + 4] : p[i];
+            p[i] = keep + __shfl_xor(send, 4, 64);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool hi = j & 2;
+            const float send = hi ? p[i] : p[i + 2];
+            const float keep = hi ? p[i + 2] : p[i];
+            p[i] = keep + __shfl_xor(send, 2, 64);
+        }
+        {
+            const bool hi = j & 1;
+            const float send = hi ? p[0] : p[1];
+            const float keep = hi ? p[1] : p[0];
+            p[0] = keep + __shfl_xor(send, 1, 64);
+        }
+        if (row < n) {
+            const float d = fminf(near_now, 0.5f * (1.0f - p[0]));
+            nearest[row] = d;
+            const unsigned long long key = ((unsigned long long)ordered_bits(d) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)row);
+            best = key > best ? key : best;
+        }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        ArgMax other{__shfl_xor(best.v, o, 64), __shfl_xor(best.i, o, 64)};
-        best = better(best, other);
+        const unsigned long long other = __shfl_xor(best, o, 64);
+        best = other > best ? other : best;
     }
     if (lane == 0) red[wave] = best;
     __syncthreads();
     if (tid == 0) {
-        const ArgMax b = better(better(red[0], red[1]), better(red[2], red[3]));
-        chosen = b.i;
-        sel[step] = (int64_t)b.i;
+        unsigned long long b = red[0];
+        b = red[1] > b ? red[1] : b;
+        b = red[2] > b ? red[2] : b;
+        b = red[3] > b ? red[3] : b;
+        if (b) atomicMax(&keys[step], b);
     }
-    __syncthreads();
-    if (tid < MS_D) seeds[(int64_t)step * MS_D + tid] = X[(int64_t)chosen * MS_D + tid];
 }
 
-__global__ void ms_seed_init_kernel(const float* __restrict__ X, int64_t first, int64_t* __restrict__ sel,
-                                    float* __restrict__ seeds) {
-    if (threadIdx.x == 0) sel[0] = first;
-    if (threadIdx.x < MS_D) seeds[threadIdx.x] = X[first * MS_D + threadIdx.x];
+__global__ void ms_seed_init_kernel(unsigned long long* __restrict__ keys, int num_seeds, int64_t first) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < num_seeds) keys[i] = i == 0 ? (0xFFFFFFFF00000000ull | (unsigned long long)(0xFFFFFFFFu - (unsigned int)first)) : 0ull;
+}
+
+__global__ void ms_seed_finish_kernel(const float* __restrict__ X, const unsigned long long* __restrict__ keys,
+                                      int64_t* __restrict__ sel, float* __restrict__ seeds) {
+    const int i = blockIdx.x;
+    const unsigned int idx = 0xFFFFFFFFu - (unsigned int)(keys[i] & 0xFFFFFFFFull);
+    if (threadIdx.x == 0) sel[i] = (int64_t)idx;
+    if (threadIdx.x < MS_D) seeds[(int64_t)i * MS_D + threadIdx.x] = X[(int64_t)idx * MS_D + threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -119,33 +160,37 @@ __global__ void ms_seed_init_kernel(const float* __restrict__ X, int64_t first, 
 template <int NSB>
 __device__ __forceinline__ void score_block(const float* __restrict__ xs, const float* __restrict__ zs, int lj, int lq,
                                             f32x4 (&st)[NSB]) {
-    float xa[16];
+    float4 xa[4];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) xa[t] = xs[lj * SZ + lq * 16 + t];
+    for (int u = 0; u < 4; ++u) xa[u] = *reinterpret_cast<const float4*>(xs + lj * SZ + lq * 16 + u * 4);
 #pragma unroll
     for (int sb = 0; sb < NSB; ++sb) {
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;      // two chains: no back-to-back dependent MFMAs
 #pragma unroll
-        for (int t = 0; t < 16; ++t) acc = mfma16(xa[t], zs[(sb * 16 + lj) * SZ + lq * 16 + t], acc);
-        st[sb] = acc;
+        for (int u = 0; u < 4; ++u) {
+            const float4 z = *reinterpret_cast<const float4*>(zs + (sb * 16 + lj) * SZ + lq * 16 + u * 4);
+            a0 = mfma16(xa[u].x, z.x, a0);
+            a1 = mfma16(xa[u].y, z.y, a1);
+            a0 = mfma16(xa[u].z, z.z, a0);
+            a1 = mfma16(xa[u].w, z.w, a1);
+        }
+        st[sb] = a0 + a1;
     }
 }
 
 __device__ __forceinline__ void stage_points(const float* __restrict__ X, int n, int p0, float* __restrict__ xs, int lane) {
-    // 16 rows x 64 floats: 4 coalesced 1 KiB wave loads
+    // 16 rows x 64 floats: 4 coalesced 1 KiB wave loads, 16-byte LDS stores
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = i * 4 + (lane >> 4), c4 = (lane & 15) * 4;
         const int src = min(p0 + row, n - 1);
-        const float4 v = *reinterpret_cast<const float4*>(X + (int64_t)src * MS_D + c4);
-        float* d = xs + row * SZ + c4;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        *reinterpret_cast<float4*>(xs + row * SZ + c4) = *reinterpret_cast<const float4*>(X + (int64_t)src * MS_D + c4);
     }
 }
 
 // ---- hill climbing: part[wg] = sum over the workgroup's points of exp(kappa s) x ----------------
 template <int NSB>
-__global__ __launch_bounds__(256) void ms_hill_kernel(const float* __restrict__ X, int n, const float* __restrict__ Z,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void ms_hill_kernel(const float* __restrict__ X, int n, const float* __restrict__ Z,
                                                       int S, float kappa, float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* zs = lds;                          // [NSB*16][SZ]
@@ -166,10 +211,24 @@ __global__ __launch_bounds__(256) void ms_hill_kernel(const float* __restrict__ 
 #pragma unroll
         for (int db = 0; db < 4; ++db) zn[sb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    const float kl2 = kappa * 1.4426950408889634f;
     const int nblocks = (n + 15) / 16;
+    // register-staged prefetch: the next 16 points are in flight while this slab's 32*NSB MFMAs run
+    const int srow = lane >> 4, scol = (lane & 15) * 4;
+#define MS_LOAD_SLAB(P0)                                                                                          \
+    nx0 = *reinterpret_cast<const float4*>(X + (int64_t)min((P0) + srow, n - 1) * MS_D + scol);                    \
+    nx1 = *reinterpret_cast<const float4*>(X + (int64_t)min((P0) + 4 + srow, n - 1) * MS_D + scol);                \
+    nx2 = *reinterpret_cast<const float4*>(X + (int64_t)min((P0) + 8 + srow, n - 1) * MS_D + scol);                \
+    nx3 = *reinterpret_cast<const float4*>(X + (int64_t)min((P0) + 12 + srow, n - 1) * MS_D + scol);
+    float4 nx0, nx1, nx2, nx3;
+    MS_LOAD_SLAB((blockIdx.x * 4 + wave) * 16)
     for (int pb = blockIdx.x * 4 + wave; pb < nblocks; pb += gridDim.x * 4) {
         const int p0 = pb * 16;
-        stage_points(X, n, p0, xs, lane);
+        *reinterpret_cast<float4*>(xs + srow * SZ + scol) = nx0;
+        *reinterpret_cast<float4*>(xs + (4 + srow) * SZ + scol) = nx1;
+        *reinterpret_cast<float4*>(xs + (8 + srow) * SZ + scol) = nx2;
+        *reinterpret_cast<float4*>(xs + (12 + srow) * SZ + scol) = nx3;
+        MS_LOAD_SLAB((pb + (int)gridDim.x * 4) * 16)
         // the slab is private to this wave; a wave-level fence orders the LDS writes before the reads
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -185,7 +244,8 @@ __global__ __launch_bounds__(256) void ms_hill_kernel(const float* __restrict__ 
         for (int sb = 0; sb < NSB; ++sb) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float w = (p0 + lq * 4 + r < n) ? expf(kappa * st[sb][r]) : 0.f;   // MS:26
+                // exp(kappa*s) through v_exp_f32: |kappa*s*log2e| <= 29 at kappa = 20, relative error ~2e-6
+                const float w = (p0 + lq * 4 + r < n) ? __builtin_amdgcn_exp2f(kl2 * st[sb][r]) : 0.f;   // MS:26
 #pragma unroll
                 for (int db = 0; db < 4; ++db) zn[sb][db] = mfma16(w, xb[r][db], zn[sb][db]);
             }
@@ -211,14 +271,34 @@ __global__ __launch_bounds__(256) void ms_hill_kernel(const float* __restrict__ 
     for (int i = tid; i < NSB * 16 * MS_D; i += 256) dst[i] = accum[i];
 }
 
-// Z[s] = normalize(sum_wg part[wg][s])  (MS:103 F.normalize)
-__global__ __launch_bounds__(64) void ms_hill_finish_kernel(const float* __restrict__ part, int nwg, int rows_padded,
-                                                            float* __restrict__ Z) {
-    const int s = blockIdx.x, d = threadIdx.x;
-    float acc = 0.f;
-    for (int g = 0; g < nwg; ++g) acc += part[((int64_t)g * rows_padded + s) * MS_D + d];
-    const float nrm = fmaxf(sqrtf(wave_sum(acc * acc)), 1e-12f);
-    Z[(int64_t)s * MS_D + d] = acc / nrm;
+#undef MS_LOAD_SLAB
+
+// Z[s] = normalize(sum_wg part[wg][s])  (MS:103 F.normalize).  16 waves per seed: wave w adds its fixed slice of
+// the workgroup partials (8 loads in flight), then the slices are added in wave order -- deterministic.
+__global__ __launch_bounds__(1024) void ms_hill_finish_kernel(const float* __restrict__ part, int nwg, int rows_padded,
+                                                              float* __restrict__ Z) {
+    __shared__ float slice[16][MS_D];
+    const int s = blockIdx.x, d = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int per = (nwg + 15) / 16;
+    const int g0 = w * per, g1 = min(nwg, g0 + per);
+    const float* src = part + (int64_t)s * MS_D + d;
+    const int64_t stride = (int64_t)rows_padded * MS_D;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int g = g0;
+    for (; g + 8 <= g1; g += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += src[(int64_t)(g + u) * stride];
+    }
+    for (; g < g1; ++g) a[0] += src[(int64_t)g * stride];
+    slice[w][d] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    __syncthreads();
+    if (w == 0) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc += slice[i][d];
+        const float nrm = fmaxf(sqrtf(wave_sum(acc * acc)), 1e-12f);
+        Z[(int64_t)s * MS_D + d] = acc / nrm;
+    }
 }
 
 // ---- assignment -----------------------------------------------------------------------------------
@@ -301,14 +381,27 @@ __global__ __launch_bounds__(256) void ms_relabel_kernel(int64_t* __restrict__ l
     }
 }
 
-static int seed_blocks(int n) { return max(1, min(1024, (n + 1023) / 1024)); }
+// whole 256-row passes per workgroup (every lane group busy), at most ~2048 atomics on the step's key
+static int seed_blocks(int n) {
+    const int passes = max(1, cdiv(n, 256 * 2048));
+    return max(1, cdiv(n, 256 * passes));
+}
+// seed blocks per hill-climb launch: equal chunks of at most `cap` blocks (env MSM_MS_CHUNK overrides the cap)
+static int hill_chunk(int nsb) {
+    static const int cap = [] {
+        const char* e = getenv("MSM_MS_CHUNK");
+        const int v = e ? atoi(e) : 0;
+        return (v >= 1 && v <= MS_CH) ? v : MS_CH;
+    }();
+    return cdiv(nsb, cdiv(nsb, cap));
+}
 static int hill_wgs(int n) { return max(1, min(512, ((n + 15) / 16 + 3) / 4)); }
 
 }  // namespace msm
 
 using namespace msm;
 
-extern "C" int64_t msm_ms_seed_workspace(int n) { return (int64_t)n + 2 * (int64_t)seed_blocks(n) + 16; }
+extern "C" int64_t msm_ms_seed_workspace(int n) { return (int64_t)n + 2 * (MS_SB * 16) + 16; }
 
 extern "C" int msm_ms_select_seeds(const float* X, int n, int d, int num_seeds, int64_t first_index, float* seeds_out,
                                    int64_t* indices_out, float* workspace, int64_t workspace_elems, void* stream) {
@@ -321,15 +414,15 @@ extern "C" int msm_ms_select_seeds(const float* X, int n, int d, int num_seeds, 
         return MSM_E_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
+    MSM_REQUIRE(num_seeds <= MS_SB * 16, "msm_ms_select_seeds: at most %d seeds", MS_SB * 16);
     const int nblk = seed_blocks(n);
-    ArgMax* partial = reinterpret_cast<ArgMax*>(workspace);
-    float* nearest = workspace + 2 * nblk;
-    hipLaunchKernelGGL(ms_seed_init_kernel, dim3(1), dim3(64), 0, st, X, first_index, indices_out, seeds_out);
-    MSM_CHECK_LAUNCH("msm_ms_select_seeds(init)");
-    for (int i = 1; i < num_seeds; ++i) {
-        hipLaunchKernelGGL(ms_seed_dist_kernel, dim3(nblk), dim3(256), 0, st, X, n, indices_out, i, nearest, partial);
-        hipLaunchKernelGGL(ms_seed_pick_kernel, dim3(1), dim3(256), 0, st, X, partial, nblk, indices_out, i, seeds_out);
-    }
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(workspace);       // [num_seeds]
+    float* nearest = workspace + 2 * (MS_SB * 16) + 8;
+    hipLaunchKernelGGL(ms_seed_init_kernel, dim3(cdiv(num_seeds, 64)), dim3(64), 0, st, keys, num_seeds, first_index);
+    for (int i = 1; i < num_seeds; ++i)
+        if (n >= 16) hipLaunchKernelGGL(ms_seed_step_kernel<false>, dim3(nblk), dim3(256), 0, st, X, n, keys, i, nearest);
+        else hipLaunchKernelGGL(ms_seed_step_kernel<true>, dim3(nblk), dim3(256), 0, st, X, n, keys, i, nearest);
+    hipLaunchKernelGGL(ms_seed_finish_kernel, dim3(num_seeds), dim3(64), 0, st, X, keys, indices_out, seeds_out);
     MSM_CHECK_LAUNCH("msm_ms_select_seeds");
     return MSM_OK;
 }
@@ -360,11 +453,12 @@ extern "C" int msm_ms_hill_climb(const float* X, int n, int d, float* Z, int S, 
     hipStream_t st = (hipStream_t)stream;
     const int G = hill_wgs(n);
     const int nsb = cdiv(S, 16);
+    const int CH = hill_chunk(nsb);
     for (int it = 0; it < iters; ++it) {
         // all chunks of one iteration read the same Z; the finish kernels run after every chunk
         float* ws = workspace;
-        for (int b0 = 0; b0 < nsb; b0 += MS_CH) {
-            const int nb = min(MS_CH, nsb - b0);
+        for (int b0 = 0; b0 < nsb; b0 += CH) {
+            const int nb = min(CH, nsb - b0);
             const float* Zc = Z + (int64_t)b0 * 16 * MS_D;
             const int Sc = min(S - b0 * 16, nb * 16);
             int rc = MSM_OK;
@@ -382,10 +476,10 @@ extern "C" int msm_ms_hill_climb(const float* X, int n, int d, float* Z, int S, 
             ws += (int64_t)G * nb * 16 * MS_D;
         }
         ws = workspace;
-        for (int b0 = 0; b0 < nsb; b0 += MS_CH) {
-            const int nb = min(MS_CH, nsb - b0);
+        for (int b0 = 0; b0 < nsb; b0 += CH) {
+            const int nb = min(CH, nsb - b0);
             const int Sc = min(S - b0 * 16, nb * 16);
-            hipLaunchKernelGGL(ms_hill_finish_kernel, dim3(Sc), dim3(64), 0, st, ws, G, nb * 16, Z + (int64_t)b0 * 16 * MS_D);
+            hipLaunchKernelGGL(ms_hill_finish_kernel, dim3(Sc), dim3(1024), 0, st, ws, G, nb * 16, Z + (int64_t)b0 * 16 * MS_D);
             ws += (int64_t)G * nb * 16 * MS_D;
         }
     }
