@@ -18,6 +18,8 @@
  * "MS" = lib/utils/mean_shift.py):
  *   msm_msdeform_attn_fwd        <- MSDA.ms_deform_attn_forward, OPS/src/vision.cpp:19,
  *                                   OPS/src/ms_deform_attn.h:25-44, OPS/src/cuda/ms_deform_attn_cuda.cu:25-85
+ *   msm_msdeform_attn_bwd        <- MSDA.ms_deform_attn_backward, OPS/src/vision.cpp:20,
+ *                                   OPS/src/ms_deform_attn.h:46-66, OPS/src/cuda/ms_deform_attn_cuda.cu:88-158
  *   msm_msdeform_attn_enc_fwd    <- MSDeformAttn.forward lines OPS/modules/ms_deform_attn.py:101-118 fused
  *   msm_mask_logits_fwd          <- forward_prediction_heads einsum + attention-mask, DEC:668-680
  *   msm_hypersphere_attn_fwd     <- hypersphere_attention, AU:64-82 (+ head split/merge AU:364-375,424)
@@ -134,6 +136,16 @@ int msm_hypersphere_attn_fwd(const float* q, const float* k, const float* v,
 int msm_msdeform_attn_fwd(const float* value, const int64_t* spatial_shapes,
                           const int64_t* level_start_index, const float* sampling_loc,
                           const float* attn_weight, float* out,
+                          int B, int S, int M, int D, int L, int Lq, int P, void* stream);
+
+/* Backward of the above, reference ABI ms_deform_attn_backward (OPS/src/ms_deform_attn.h:46-66,
+ * OPS/src/cuda/ms_deform_attn_cuda.cu:88-158, kernels ms_deform_im2col_cuda.cuh:306-925):
+ *   grad_output [B][Lq][M*D] -> grad_value [B][S][M][D] (zeroed here, accumulated with fp32 atomics as in
+ *   the reference), grad_sampling_loc [B][Lq][M][L][P][2], grad_attn_weight [B][Lq][M][L][P]. */
+int msm_msdeform_attn_bwd(const float* value, const int64_t* spatial_shapes,
+                          const int64_t* level_start_index, const float* sampling_loc,
+                          const float* attn_weight, const float* grad_output,
+                          float* grad_value, float* grad_sampling_loc, float* grad_attn_weight,
                           int B, int S, int M, int D, int L, int Lq, int P, void* stream);
 
 /* Encoder self-attention form with the sampling arithmetic fused in

@@ -235,6 +235,54 @@ def ms_deform_attn_core(value, spatial_shapes, sampling_locations, attention_wei
     return out.reshape(N, Lq, M * D)
 
 
+def ms_deform_attn_core_backward(value, spatial_shapes, sampling_locations, attention_weights, grad_output):
+    """Analytic backward of ms_deform_attn_core, restating the col2im kernels: bilinear helper
+    ms_deform_im2col_cuda.cuh:92-165 (grad_value scatter :128-160, grad_attn_weight = top_grad*val :164,
+    grad_sampling_loc = (W*grad_w_weight, H*grad_h_weight)*top_grad*attn :165-166), point test :352.
+    grad_output (N,Lq,M*D).  Returns (grad_value (N,S,M,D), grad_loc (N,Lq,M,L,P,2), grad_w (N,Lq,M,L,P))."""
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = sampling_locations.shape
+    go = grad_output.reshape(N, Lq, M, 1, D)
+    gvalue = torch.zeros_like(value)
+    gloc = torch.zeros_like(sampling_locations)
+    gw = torch.zeros_like(attention_weights)
+    n_idx = torch.arange(N)[:, None, None, None].expand(N, Lq, M, P)
+    m_idx = torch.arange(M)[None, None, :, None].expand(N, Lq, M, P)
+    start = 0
+    for lid, (H, W) in enumerate([(int(h), int(w)) for h, w in spatial_shapes]):
+        v = value[:, start:start + H * W]
+        loc = sampling_locations[:, :, :, lid]
+        aw = attention_weights[:, :, :, lid]                               # (N,Lq,M,P)
+        wim = loc[..., 0] * W - 0.5
+        him = loc[..., 1] * H - 0.5
+        inside = (him > -1) & (wim > -1) & (him < H) & (wim < W)
+        h0 = torch.floor(him)
+        w0 = torch.floor(wim)
+        lh, lw = him - h0, wim - w0
+        hh_, hw_ = 1 - lh, 1 - lw
+        h0, w0 = h0.long(), w0.long()
+        tg = go * aw[..., None]                                            # top_grad_value (N,Lq,M,P,D)
+        val = torch.zeros(N, Lq, M, P, D, dtype=value.dtype)
+        gx = torch.zeros(N, Lq, M, P, dtype=value.dtype)
+        gy = torch.zeros(N, Lq, M, P, dtype=value.dtype)
+        for dh, dw, wt, cx, cy in ((0, 0, hh_ * hw_, -hh_, -hw_), (0, 1, hh_ * lw, hh_, -lw),
+                                   (1, 0, lh * hw_, -lh, hw_), (1, 1, lh * lw, lh, lw)):
+            hh, ww = h0 + dh, w0 + dw
+            ok = inside & (hh >= 0) & (hh <= H - 1) & (ww >= 0) & (ww <= W - 1)
+            idx = hh.clamp(0, H - 1) * W + ww.clamp(0, W - 1)
+            g = v[n_idx, idx, m_idx] * ok[..., None]                       # corner values, zero outside
+            val = val + g * wt[..., None]
+            gx = gx + (g * tg).sum(-1) * cx
+            gy = gy + (g * tg).sum(-1) * cy
+            contrib = tg * (wt * ok)[..., None]
+            gvalue[:, start:start + H * W].index_put_((n_idx, idx, m_idx), contrib, accumulate=True)
+        gw[:, :, :, lid] = (go * val).sum(-1) * inside
+        gloc[:, :, :, lid, :, 0] = gx * W * inside
+        gloc[:, :, :, lid, :, 1] = gy * H * inside
+        start += H * W
+    return gvalue, gloc, gw
+
+
 def encoder_reference_points(spatial_shapes, batch):
     """MSD:141-153 with valid_ratios == 1: pixel centres / size, same for every level.
     Returns (batch, sum(HW), L, 2) in (x, y) order."""

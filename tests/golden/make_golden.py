@@ -161,6 +161,46 @@ def g_msda():
     save("msda_core", **arrs)
 
 
+def g_msda_bwd():
+    """Gradients of the reference's PyTorch op (functions/ms_deform_attn_func.py:52-72) by autograd in fp64 --
+    the ground truth the reference's own gradcheck (OPS/test.py:66-89) measures the CUDA backward against."""
+    F_ = R.ref("modeling.pixel_decoder.ops.functions.ms_deform_attn_func")
+    arrs = {}
+
+    def grads(tag, value, shapes, loc, aw, gout):
+        v, l, a = (t.double().clone().requires_grad_(True) for t in (value, loc, aw))
+        o = F_.ms_deform_attn_core_pytorch(v, torch.as_tensor(shapes), l, a)
+        o.backward(gout.double())
+        arrs.update({f"{tag}_shapes": np.array(shapes), f"{tag}_value": value, f"{tag}_loc": loc, f"{tag}_aw": aw,
+                     f"{tag}_gout": gout, f"{tag}_out": o.detach(), f"{tag}_gvalue": v.grad, f"{tag}_gloc": l.grad,
+                     f"{tag}_gaw": a.grad})
+
+    # (1) OPS/test.py:66-89 recipe: N=1, M=2, Lq=2, L=2, P=2, shapes (6,4),(3,2), value = rand*0.01, seed 3
+    torch.manual_seed(3)
+    shapes = [(6, 4), (3, 2)]
+    S = sum(h * w for h, w in shapes)
+    for ch in (30, 32, 64):
+        value = torch.rand(1, S, 2, ch, dtype=torch.float64) * 0.01
+        loc = torch.rand(1, 2, 2, 2, 2, 2, dtype=torch.float64)
+        aw = torch.rand(1, 2, 2, 2, 2, dtype=torch.float64) + 1e-5
+        aw /= aw.sum(-1, keepdim=True).sum(-2, keepdim=True)
+        gout = torch.rand(1, 2, 2 * ch, dtype=torch.float64)
+        grads(f"t{ch}", value, shapes, loc, aw, gout)
+    # (2) pixel-decoder layout: 8 heads x 8 dims, 3 levels x 4 points, locations spilling over the borders
+    g = torch.Generator().manual_seed(22)
+    shp = [(15, 20), (8, 10), (4, 5)]
+    S = sum(h * w for h, w in shp)
+    N, M, D, L, P, Lq = 2, 8, 8, 3, 4, 48
+    value = torch.randn(N, S, M, D, generator=g)
+    loc = torch.rand(N, Lq, M, L, P, 2, generator=g) * 1.3 - 0.15
+    aw = torch.softmax(torch.randn(N, Lq, M, L * P, generator=g), -1).view(N, Lq, M, L, P)
+    gout = torch.randn(N, Lq, M * D, generator=g)
+    grads("r", value, shp, loc, aw, gout)
+    for k in ("r_out", "r_gvalue", "r_gloc", "r_gaw"):      # fp64 autograd results, stored rounded to fp32
+        arrs[k] = arrs[k].float()
+    save("msda_backward", **arrs)
+
+
 def build_ref_pixel_decoder(salt=0):
     MSD = R.ref("modeling.pixel_decoder.msdeformattn")
     SS = R._ShapeSpec
@@ -343,8 +383,8 @@ def g_ucn():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pe", "attn", "decoder", "msda", "pixel", "ms", "harness", "ucn"]
+    which = sys.argv[1:] or ["pe", "attn", "decoder", "msda", "msda_bwd", "pixel", "ms", "harness", "ucn"]
     fns = {"pe": g_position_encoding, "attn": g_hypersphere_attention, "decoder": g_decoder,
-           "msda": g_msda, "pixel": g_pixel_decoder, "ms": g_mean_shift, "harness": g_harness, "ucn": g_ucn}
+           "msda": g_msda, "msda_bwd": g_msda_bwd, "pixel": g_pixel_decoder, "ms": g_mean_shift, "harness": g_harness, "ucn": g_ucn}
     for w in which:
         fns[w]()

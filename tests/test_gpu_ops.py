@@ -222,6 +222,56 @@ def test_msda_realistic_and_fused(golden):
     close(got, ref, rtol=1e-4, atol=1e-5)
 
 
+def _start(shapes):
+    return torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+
+
+@pytest.mark.parametrize("tag", ["t30", "t32", "t64", "r"])
+def test_msda_backward(golden, tag):
+    """msm_msdeform_attn_bwd vs fp64 autograd through the reference op (ops/test.py:66-89 recipe; the reference
+    accepts rel err 1e-2/abs 1e-3 there, this holds fp32 rounding).  t30: D/4 lanes not a power of two -> atomic path."""
+    g = golden("msda_backward")
+    G = lambda k: torch.from_numpy(g[f"{tag}_{k}"]).float()
+    shapes = torch.tensor(g[f"{tag}_shapes"], dtype=torch.int64)
+    gv, gl, gw = ops().ms_deform_attn_backward(G("value").to(DEV), shapes.to(DEV), _start(shapes).to(DEV), G("loc").to(DEV),
+                                               G("aw").to(DEV), G("gout").to(DEV))
+    scale = lambda t: float(t.abs().max())
+    close(gv, G("gvalue"), rtol=1e-4, atol=1e-5 * scale(G("gvalue")))
+    close(gl, G("gloc"), rtol=1e-4, atol=1e-5 * scale(G("gloc")))
+    close(gw, G("gaw"), rtol=1e-4, atol=1e-5 * scale(G("gaw")))
+
+
+def test_msda_module_shim_autograd(golden):
+    """The reference's MSDeformAttnFunction pattern (ms_deform_attn_func.py:32-49) over the drop-in module."""
+    from unseenobjectswithmeanshift_amd import MultiScaleDeformableAttention as MSDA
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, value, shapes, start, loc, aw, step):
+            ctx.step = step
+            ctx.save_for_backward(value, shapes, start, loc, aw)
+            return MSDA.ms_deform_attn_forward(value, shapes, start, loc, aw, step)
+
+        @staticmethod
+        def backward(ctx, go):
+            gv, gl, gw = MSDA.ms_deform_attn_backward(*ctx.saved_tensors, go.contiguous(), ctx.step)
+            return gv, None, None, gl, gw, None
+
+    g = golden("msda_backward")
+    G = lambda k: torch.from_numpy(g[f"r_{k}"]).float()
+    shapes = torch.tensor(g["r_shapes"], dtype=torch.int64)
+    v, l, a = (G(k).to(DEV).requires_grad_(True) for k in ("value", "loc", "aw"))
+    out = Fn.apply(v, shapes.to(DEV), _start(shapes).to(DEV), l, a, 64)
+    close(out, G("out"), rtol=1e-4, atol=1e-5)
+    out.backward(G("gout").to(DEV))
+    close(v.grad, G("gvalue"), rtol=1e-4, atol=1e-4)
+    close(l.grad, G("gloc"), rtol=1e-4, atol=1e-3)
+    close(a.grad, G("gaw"), rtol=1e-4, atol=1e-4)
+    with pytest.raises(RuntimeError):
+        MSDA.ms_deform_attn_backward(v.detach(), shapes.to(DEV), _start(shapes).to(DEV), l.detach(), a.detach(),
+                                     G("gout").to(DEV)[:, :, ::2], 64)
+
+
 # ---------------------------------------------------------------------------------------------
 def test_mean_shift_kernels(golden):
     from unseenobjectswithmeanshift_amd import synthetic as syn

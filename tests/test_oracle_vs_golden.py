@@ -116,6 +116,20 @@ def test_msda_realistic(golden):
     torch.testing.assert_close(o, T(g["r_out"]), rtol=1e-4, atol=1e-5)
 
 
+def test_msda_backward_against_reference_autograd(golden):
+    """Analytic col2im restatement vs fp64 autograd through the reference's PyTorch op, on the inputs of the
+    reference's gradcheck recipe (ops/test.py:66-89, channels 30/32/64) and a pixel-decoder-shaped case."""
+    g = golden("msda_backward")
+    for tag, tol in (("t30", 1e-12), ("t32", 1e-12), ("t64", 1e-12), ("r", 2e-5)):
+        G = lambda k: T(g[f"{tag}_{k}"]).double()
+        shapes = [tuple(int(v) for v in r) for r in g[f"{tag}_shapes"]]
+        gv, gl, gw = O.ms_deform_attn_core_backward(G("value"), shapes, G("loc"), G("aw"), G("gout"))
+        torch.testing.assert_close(O.ms_deform_attn_core(G("value"), shapes, G("loc"), G("aw")), G("out"), rtol=tol, atol=tol)
+        torch.testing.assert_close(gv, G("gvalue"), rtol=tol, atol=tol)
+        torch.testing.assert_close(gl, G("gloc"), rtol=tol, atol=tol)
+        torch.testing.assert_close(gw, G("gaw"), rtol=tol, atol=tol)
+
+
 def test_pixel_decoder_small(golden):
     g = golden("pixel_decoder_small")
     sd = syn.synth_state_dict(syn.pixel_decoder_param_shapes())

@@ -11,24 +11,34 @@ import torch
 from . import ops
 
 
-def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
-    """ops/src/ms_deform_attn.h:25-44.  The batch-chunking argument only has to satisfy the
-    reference's divisibility check (ms_deform_attn_cuda.cu:55-57); one launch covers the batch."""
+def _check_inputs(value, tensors, im2col_step):
     step = min(value.shape[0], int(im2col_step))
     if value.shape[0] % step != 0:
         raise RuntimeError("batch(%d) must divide im2col_step(%d)" % (value.shape[0], step))
-    for t, name in ((value, "value"), (spatial_shapes, "spatial_shapes"), (level_start_index, "level_start_index"),
-                    (sampling_loc, "sampling_loc"), (attn_weight, "attn_weight")):
+    for t, name in tensors:
         if not t.is_contiguous():
-            raise RuntimeError(f"{name} tensor has to be contiguous")      # cu:33-37
+            raise RuntimeError(f"{name} tensor has to be contiguous")      # cu:33-37 / cu:98-103
         if not t.is_cuda:
-            raise RuntimeError(f"{name} must be a CUDA tensor")             # cu:39-43
+            raise RuntimeError(f"{name} must be a CUDA tensor")             # cu:39-43 / cu:105-110
     if value.dtype == torch.float64:
-        raise NotImplementedError("the gfx950 kernel is fp32; cast inputs with .float()")
+        raise NotImplementedError("the gfx950 kernels are fp32; cast inputs with .float()")
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+    """ops/src/ms_deform_attn.h:25-44.  The batch-chunking argument only has to satisfy the
+    reference's divisibility check (ms_deform_attn_cuda.cu:55-57); one launch covers the batch."""
+    _check_inputs(value, ((value, "value"), (spatial_shapes, "spatial_shapes"), (level_start_index, "level_start_index"),
+                          (sampling_loc, "sampling_loc"), (attn_weight, "attn_weight")), im2col_step)
     return ops.ms_deform_attn(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
 
 
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
                             im2col_step):
-    raise NotImplementedError("training (col2im backward, ms_deform_im2col_cuda.cuh:306-925) is out of scope "
-                              "for the inference hot path; see SURVEY.md section 8(f)")
+    """ops/src/ms_deform_attn.h:46-66 -> [grad_value, grad_sampling_loc, grad_attn_weight]
+    (ms_deform_attn_cuda.cu:88-158), as MSDeformAttnFunction.backward expects (ms_deform_attn_func.py:41-49)."""
+    _check_inputs(value, ((value, "value"), (spatial_shapes, "spatial_shapes"), (level_start_index, "level_start_index"),
+                          (sampling_loc, "sampling_loc"), (attn_weight, "attn_weight"), (grad_output, "grad_output")),
+                  im2col_step)
+    gv, gl, gw = ops.ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                                             grad_output)
+    return [gv, gl, gw]

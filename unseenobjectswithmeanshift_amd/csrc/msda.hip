@@ -150,6 +150,99 @@ __global__ __launch_bounds__(256) void msda_kernel(const float* __restrict__ val
     }
 }
 
+// ---- backward (training): reference col2im kernels, cuh:306-925 (bilinear helper cuh:92-239) -------------------
+// Same lane mapping as the forward: a lane owns V channels of one (image, query, head), so the 4 corner reads
+// are 16-byte loads and the scatter into grad_value is V hardware fp32 atomics per corner
+// (global_atomic_add_f32; the reference also accumulates grad_value with atomicAdd, cuh:130-145, so the
+// summation order is not fixed there either).  grad_attn_weight / grad_sampling_loc belong to exactly one
+// (query, head, level, point): their channel sum is a shuffle butterfly over the head's D/V lanes followed by
+// one plain store (the reference's shared-memory reductions, cuh:368-386).  When D/V is not a power of two the
+// butterfly is replaced by atomics into zero-initialised outputs.
+template <int V, bool POW2>
+__global__ __launch_bounds__(256) void msda_bwd_kernel(const float* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                       const int64_t* __restrict__ lstart, const float* __restrict__ loc,
+                                                       const float* __restrict__ wgt, const float* __restrict__ gout,
+                                                       float* __restrict__ gvalue, float* __restrict__ gloc,
+                                                       float* __restrict__ gwgt, int B, int S, int M, int D, int L, int Lq,
+                                                       int P) {
+    const int D4 = D / V;
+    const int per_img = Lq * M * D4;
+    const int b = blockIdx.x % B;
+    const int idx = (blockIdx.x / B) * 256 + threadIdx.x;
+    // POW2: the D4 lanes of a head sit in one wave (D4 <= 16 divides 64) and per_img is a multiple of D4, so a
+    // head is never split by the bound below; inactive lanes still take part in the shuffles with zeros.
+    const bool live = idx < per_img;
+    const int cidx = live ? idx : 0;
+    const int d4 = cidx % D4;
+    const int t = cidx / D4;
+    const int m = t % M;
+    const int qi = t / M;
+    if (!POW2 && !live) return;
+
+    const int64_t pix_stride = (int64_t)M * D;
+    const int64_t voff = (int64_t)b * S * pix_stride + m * D + d4 * V;
+    const Vec<V> go = ldv<V>(gout + (((int64_t)b * Lq + qi) * M + m) * D + d4 * V);
+    const int64_t base = (((int64_t)b * Lq + qi) * M + m) * L * P;
+    for (int l = 0; l < L; ++l) {
+        const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+        const int64_t lvl = voff + (int64_t)lstart[l] * pix_stride;
+        for (int p = 0; p < P; ++p) {
+            const int i = l * P + p;
+            const float loc_x = loc[(base + i) * 2], loc_y = loc[(base + i) * 2 + 1], aw = wgt[base + i];
+            const float h_im = loc_y * (float)H - 0.5f;
+            const float w_im = loc_x * (float)W - 0.5f;
+            float g_w = 0.f, g_x = 0.f, g_y = 0.f;
+            if (live && h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {   // cuh:352
+                const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+                const int h_high = h_low + 1, w_high = w_low + 1;
+                const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+                const float hh = 1.f - lh, hw = 1.f - lw;
+                const bool ok1 = h_low >= 0 && w_low >= 0, ok2 = h_low >= 0 && w_high <= W - 1;
+                const bool ok3 = h_high <= H - 1 && w_low >= 0, ok4 = h_high <= H - 1 && w_high <= W - 1;
+                const int64_t o1 = lvl + ((int64_t)h_low * W + w_low) * pix_stride, o2 = o1 + pix_stride;
+                const int64_t o3 = o1 + (int64_t)W * pix_stride, o4 = o3 + pix_stride;
+                Vec<V> v1, v2, v3, v4;
+#pragma unroll
+                for (int c = 0; c < V; ++c) v1.e[c] = v2.e[c] = v3.e[c] = v4.e[c] = 0.f;
+                if (ok1) v1 = ldv<V>(value + o1);
+                if (ok2) v2 = ldv<V>(value + o2);
+                if (ok3) v3 = ldv<V>(value + o3);
+                if (ok4) v4 = ldv<V>(value + o4);
+                const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
+#pragma unroll
+                for (int c = 0; c < V; ++c) {
+                    const float tg = go.e[c] * aw;                                           // top_grad_value, cuh:117
+                    if (ok1) unsafeAtomicAdd(gvalue + o1 + c, w1 * tg);                       // cuh:128-160
+                    if (ok2) unsafeAtomicAdd(gvalue + o2 + c, w2 * tg);
+                    if (ok3) unsafeAtomicAdd(gvalue + o3 + c, w3 * tg);
+                    if (ok4) unsafeAtomicAdd(gvalue + o4 + c, w4 * tg);
+                    g_w += go.e[c] * (w1 * v1.e[c] + w2 * v2.e[c] + w3 * v3.e[c] + w4 * v4.e[c]);   // cuh:164
+                    g_x += tg * (-hh * v1.e[c] + hh * v2.e[c] - lh * v3.e[c] + lh * v4.e[c]);      // grad_w_weight
+                    g_y += tg * (-hw * v1.e[c] - lw * v2.e[c] + hw * v3.e[c] + lw * v4.e[c]);      // grad_h_weight
+                }
+                g_x *= (float)W;                                                               // cuh:165-166
+                g_y *= (float)H;
+            }
+            if constexpr (POW2) {
+                for (int o = D4 >> 1; o > 0; o >>= 1) {
+                    g_w += __shfl_xor(g_w, o, 64);
+                    g_x += __shfl_xor(g_x, o, 64);
+                    g_y += __shfl_xor(g_y, o, 64);
+                }
+                if (live && d4 == 0) {
+                    gwgt[base + i] = g_w;
+                    gloc[(base + i) * 2] = g_x;
+                    gloc[(base + i) * 2 + 1] = g_y;
+                }
+            } else {
+                unsafeAtomicAdd(gwgt + base + i, g_w);
+                unsafeAtomicAdd(gloc + (base + i) * 2, g_x);
+                unsafeAtomicAdd(gloc + (base + i) * 2 + 1, g_y);
+            }
+        }
+    }
+}
+
 static int msda_common_checks(const char* name, const void* value, const void* out, int B, int S, int M, int D, int L,
                               int Lq, int P) {
     MSM_REQUIRE(B > 0 && S > 0 && M > 0 && Lq > 0 && P > 0, "%s: bad sizes", name);
@@ -199,5 +292,39 @@ extern "C" int msm_msdeform_attn_enc_fwd(const float* value, const int64_t* spat
         hipLaunchKernelGGL((msda_kernel<true, 1>), grid, block, 0, (hipStream_t)stream, value, spatial_shapes,
                            level_start_index, (const float*)nullptr, (const float*)nullptr, proj, out, B, S, M, D, L, S, P);
     MSM_CHECK_LAUNCH("msm_msdeform_attn_enc_fwd");
+    return MSM_OK;
+}
+
+extern "C" int msm_msdeform_attn_bwd(const float* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                     const float* sampling_loc, const float* attn_weight, const float* grad_output,
+                                     float* grad_value, float* grad_sampling_loc, float* grad_attn_weight, int B, int S,
+                                     int M, int D, int L, int Lq, int P, void* stream) {
+    MSM_REQUIRE(value && spatial_shapes && level_start_index && sampling_loc && attn_weight && grad_output && grad_value &&
+                    grad_sampling_loc && grad_attn_weight,
+                "msm_msdeform_attn_bwd: null pointer");
+    int rc = msda_common_checks("msm_msdeform_attn_bwd", value, grad_output, B, S, M, D, L, Lq, P);
+    if (rc != MSM_OK) return rc;
+    MSM_REQUIRE((((uintptr_t)grad_value) & 15) == 0, "msm_msdeform_attn_bwd: grad_value must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int V = (D % 4 == 0) ? 4 : 1;
+    const int D4 = D / V;
+    const bool pow2 = (D4 & (D4 - 1)) == 0;
+    MSM_CHECK_HIP(hipMemsetAsync(grad_value, 0, sizeof(float) * (size_t)B * S * M * D, st));
+    if (!pow2) {
+        MSM_CHECK_HIP(hipMemsetAsync(grad_sampling_loc, 0, sizeof(float) * (size_t)B * Lq * M * L * P * 2, st));
+        MSM_CHECK_HIP(hipMemsetAsync(grad_attn_weight, 0, sizeof(float) * (size_t)B * Lq * M * L * P, st));
+    }
+    const int64_t per_img = (int64_t)Lq * M * D4;
+    dim3 grid((unsigned)(((per_img + 255) / 256) * B)), block(256);
+#define MSDA_BWD(VV, PP)                                                                                              \
+    hipLaunchKernelGGL((msda_bwd_kernel<VV, PP>), grid, block, 0, st, value, spatial_shapes, level_start_index,        \
+                       sampling_loc, attn_weight, grad_output, grad_value, grad_sampling_loc, grad_attn_weight, B, S, M, \
+                       D, L, Lq, P)
+    if (V == 4 && pow2) MSDA_BWD(4, true);
+    else if (V == 4) MSDA_BWD(4, false);
+    else if (pow2) MSDA_BWD(1, true);
+    else MSDA_BWD(1, false);
+#undef MSDA_BWD
+    MSM_CHECK_LAUNCH("msm_msdeform_attn_bwd");
     return MSM_OK;
 }

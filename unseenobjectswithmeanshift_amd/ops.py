@@ -256,6 +256,25 @@ def ms_deform_attn(value, spatial_shapes, level_start_index, sampling_locations,
     return out
 
 
+def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, grad_output):
+    """Reference-ABI backward: returns (grad_value, grad_sampling_loc, grad_attn_weight)."""
+    _c(value, "value"), _c(sampling_locations, "sampling_locations"), _c(attention_weights, "attention_weights")
+    _c(grad_output, "grad_output")
+    _c(spatial_shapes, "spatial_shapes", torch.int64), _c(level_start_index, "level_start_index", torch.int64)
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = sampling_locations.shape
+    if tuple(grad_output.shape) != (N, Lq, M * D):
+        raise RuntimeError(f"grad_output must be {(N, Lq, M * D)}, got {tuple(grad_output.shape)}")
+    gv = torch.empty_like(value)
+    gl = torch.empty_like(sampling_locations)
+    gw = torch.empty_like(attention_weights)
+    rc = lib().msm_msdeform_attn_bwd(_p(value), _p(spatial_shapes), _p(level_start_index), _p(sampling_locations),
+                                     _p(attention_weights), _p(grad_output), _p(gv), _p(gl), _p(gw),
+                                     N, S, M, D, L, Lq, P, _stream())
+    check(rc, "msm_msdeform_attn_bwd")
+    return gv, gl, gw
+
+
 def ms_deform_attn_encoder(value, spatial_shapes, level_start_index, proj, heads, n_points):
     """Encoder self-attention form: value (N,S,C), proj (N,S,heads*L*P*3) raw offsets+logits."""
     _c(value, "value"), _c(proj, "proj")
