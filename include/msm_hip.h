@@ -23,6 +23,9 @@
  *   msm_msdeform_attn_enc_fwd    <- MSDeformAttn.forward lines OPS/modules/ms_deform_attn.py:101-118 fused
  *   msm_mask_logits_fwd          <- forward_prediction_heads einsum + attention-mask, DEC:668-680
  *   msm_hypersphere_attn_fwd     <- hypersphere_attention, AU:64-82 (+ head split/merge AU:364-375,424)
+ *   msm_dec_post_cross / msm_dec_post_self / msm_dec_heads
+ *                                <- the row-local ops between the attention cores of a decoder layer,
+ *                                   DEC:245-260, DEC:171-181, DEC:296-300, DEC:637-638, DEC:661-665
  *   msm_gemm_f32 / msm_layernorm_f32 / msm_groupnorm_* / msm_pos_embed_sine
  *                                <- the torch ops around them (F.linear, Conv2d 1x1/3x3, LayerNorm,
  *                                   GroupNorm, F.interpolate, PositionEmbeddingSine)
@@ -172,6 +175,48 @@ int64_t msm_encoder_block_stream_floats(int d_ffn, int proj_width);
 int msm_encoder_block_fwd(const float* attn, const float* src, const float* wstream, const float* small,
                           const float* pos, float* src_out, float* value_out, float* proj_out,
                           int M, int S, int d_ffn, int proj_width, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused row-local tails of one decoder layer on the query matrix [rows = B*Q][E], E fixed to 256.  Row r uses
+ * query_pos[r % Q].  Every weight MATRIX argument (wo, w_in, w1, w2, m0w..m2w, wq) is the PACKED form of torch's
+ * (out_features N, in_features K) matrix produced by msm_dec_pack_weight -- MFMA B-fragment order, so that a
+ * wavefront's 16-byte loads are 1 KiB contiguous:
+ *     packed[((t*(K/64) + kc)*4 + u)*256 + (lq*16 + lj)*4 + c] = W[t*16 + lj][kc*64 + u*16 + lq*4 + c]
+ * (t < N/16, kc < K/64, u,lq,c < 4, lj < 16).  Row blocks of 16 stay contiguous, so "rows [a, b) of W" is still the
+ * pointer offset a*K.  Bias / LayerNorm vectors are plain.
+ *
+ * msm_dec_post_cross -- after the cross-attention core (forward_post DEC:245-260, then the self-attention
+ *   in-projection AU:134-140 with q = k = tgt + query_pos, v = tgt, DEC:171-175):
+ *     x_out = LN(res + attn_out wo^T + bo);  qk_out [rows][2E] = (x + query_pos) w_in[0:2E]^T + b_in[0:2E];
+ *     v_out = x w_in[2E:3E]^T + b_in[2E:3E]
+ * msm_dec_post_self -- after the self-attention core (DEC:171-181, then the FFN body DEC:296-299 split over the
+ *   hidden dimension): x_out = LN(res + attn_out wo^T + bo);
+ *     parts[p] [rows][E] = relu(x w1[S_p]^T + b1[S_p]) w2[:, S_p]^T,  p < n_parts, S_p = the p-th of n_parts equal
+ *     slices of the hidden dimension (n_parts divides F/256; their sum is linear2's output WITHOUT its bias)
+ * msm_dec_heads -- FFN residual/norm, block norm and prediction-head inputs (DEC:300, DEC:637-638, DEC:661-665)
+ *   plus the next layer's cross-attention query projection:
+ *     t = x + sum_c parts[c] + bias;  if ln_g: t = LN(t);  if l2norm: t = t / max(||t||, 1e-12);  out = t
+ *     d_out = LN_dec(t);  e_out = m2(relu(m1(relu(m0(d)))));  q_out = (t + query_pos) wq^T + bq
+ *   out, d_out and the wq/bq/query_pos/q_out group are optional (null).
+ * ------------------------------------------------------------------------------------------- */
+int msm_dec_pack_weight(const float* w, float* packed, int N, int K, void* stream);
+int msm_dec_post_cross(const float* attn_out, const float* res, const float* query_pos,
+                       const float* wo, const float* bo, const float* ln_g, const float* ln_b,
+                       const float* w_in, const float* b_in,
+                       float* x_out, float* qk_out, float* v_out,
+                       int rows, int Q, int E, float eps, void* stream);
+int msm_dec_post_self(const float* attn_out, const float* res,
+                      const float* wo, const float* bo, const float* ln_g, const float* ln_b,
+                      const float* w1, const float* b1, const float* w2, int F,
+                      float* x_out, float* parts, int n_parts, int rows, int E, float eps, void* stream);
+int msm_dec_heads(const float* x, const float* parts, int n_parts, const float* bias,
+                  const float* ln_g, const float* ln_b, int l2norm,
+                  const float* dec_g, const float* dec_b,
+                  const float* m0w, const float* m0b, const float* m1w, const float* m1b,
+                  const float* m2w, const float* m2b,
+                  const float* wq, const float* bq, const float* query_pos,
+                  float* out, float* d_out, float* e_out, float* q_out,
+                  int rows, int Q, int E, float eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Classic vMF mean shift over unit embeddings X [n][d] (d == 64), cosine metric.

@@ -149,6 +149,20 @@ def test_decoder_execution_variants_agree():
     b = dec(xd, mfd)
     torch.testing.assert_close(b["pred_logits"], ref["pred_logits"], rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(b["pred_masks"], ref["pred_masks"], rtol=1e-4, atol=3e-4)
+    # fused row-local tails (3 launches per layer) vs one launch per op
+    assert dec.fused_tails
+    dec.fold_kv, dec.fused_tails = True, False
+    c = dec(xd, mfd)
+    torch.testing.assert_close(c["pred_logits"], ref["pred_logits"], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(c["pred_masks"], ref["pred_masks"], rtol=1e-4, atol=3e-4)
+    dec.aux_outputs = True
+    full_unfused = dec(xd, mfd)
+    dec.fused_tails = True
+    full_fused = dec(xd, mfd)
+    assert len(full_fused["aux_outputs"]) == len(full_unfused["aux_outputs"]) == dec.num_layers
+    for u, f in zip(full_unfused["aux_outputs"], full_fused["aux_outputs"]):
+        torch.testing.assert_close(f["pred_logits"], u["pred_logits"], rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(f["pred_masks"], u["pred_masks"], rtol=1e-4, atol=3e-4)
 
 
 def test_ucn_path_vs_reference(golden):

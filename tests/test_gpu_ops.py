@@ -222,6 +222,91 @@ def test_msda_realistic_and_fused(golden):
     close(got, ref, rtol=1e-4, atol=1e-5)
 
 
+# ---------------------------------------------------------------------------------------------
+def closed(got, ref, rtol, atol):
+    torch.testing.assert_close(got.double().cpu(), ref, rtol=rtol, atol=atol)
+
+
+def _ln(x, g, b, eps=1e-5):
+    return F.layer_norm(x, (x.shape[-1],), g, b, eps)
+
+
+@pytest.mark.parametrize("B,Q", [(2, 100), (1, 7), (3, 16)])
+def test_decoder_fused_tails(B, Q):
+    """csrc/dec_chain.hip against the same chain in torch fp64 (DEC:245-260, 171-181, 296-300, 637-638, 661-665);
+    tolerance: fp32 rounding of 256/2048-term dot products on O(1) values."""
+    E, Fh = 256, 2048
+    r = lambda *s, seed, k=1.0: (rnd(*s, seed=seed) * k)
+    o, res, qpos = r(B, Q, E, seed=1), r(B, Q, E, seed=2), r(Q, E, seed=3)
+    wo, bo = r(E, E, seed=4, k=E ** -0.5), r(E, seed=5, k=0.1)
+    g, b = 1 + r(E, seed=6, k=0.1), r(E, seed=7, k=0.1)
+    w_in, b_in = r(3 * E, E, seed=8, k=E ** -0.5), r(3 * E, seed=9, k=0.1)
+    dev = lambda *ts: [t.to(DEV) for t in ts]
+    dbl = lambda *ts: [t.double() for t in ts]
+    pack = lambda w: ops().dec_pack_weight(w.to(DEV))
+    # the documented fragment order (include/msm_hip.h)
+    N_, K_ = w_in.shape
+    want = w_in.view(N_ // 16, 16, K_ // 64, 4, 4, 4).permute(0, 2, 3, 4, 1, 5).contiguous().view(N_, K_)
+    assert torch.equal(pack(w_in).cpu(), want)
+    # post_cross
+    x, qk, v = ops().dec_post_cross(*dev(o, res, qpos), pack(wo), *dev(bo, g, b), pack(w_in), b_in.to(DEV))
+    O_, R_, P_, WO, BO, G_, B_, WI, BI = dbl(o, res, qpos, wo, bo, g, b, w_in, b_in)
+    xr = _ln(R_ + O_ @ WO.t() + BO, G_, B_)
+    closed(x, xr, rtol=1e-4, atol=2e-5)
+    closed(qk, (xr + P_) @ WI[:2 * E].t() + BI[:2 * E], rtol=1e-4, atol=5e-5)
+    closed(v, xr @ WI[2 * E:].t() + BI[2 * E:], rtol=1e-4, atol=5e-5)
+    # post_self
+    w1, b1 = r(Fh, E, seed=10, k=E ** -0.5), r(Fh, seed=11, k=0.1)
+    w2, b2 = r(E, Fh, seed=12, k=Fh ** -0.5), r(E, seed=13, k=0.1)
+    x2, parts = ops().dec_post_self(*dev(o, res), pack(wo), *dev(bo, g, b), pack(w1), b1.to(DEV), pack(w2))
+    closed(x2, xr, rtol=1e-4, atol=2e-5)
+    W1, B1, W2, B2 = dbl(w1, b1, w2, b2)
+    ffn = torch.relu(xr @ W1.t() + B1) @ W2.t()
+    closed(parts.double().sum(0), ffn, rtol=1e-4, atol=5e-5)
+    for n_parts in (1, 2, 8):
+        x3, p3 = ops().dec_post_self(*dev(o, res), pack(wo), *dev(bo, g, b), pack(w1), b1.to(DEV), pack(w2), n_parts=n_parts)
+        assert p3.shape == (n_parts, B, Q, E) and torch.equal(x3, x2)
+        closed(p3.double().sum(0), ffn, rtol=1e-4, atol=5e-5)
+    with pytest.raises(RuntimeError, match="must divide"):
+        ops().dec_post_self(*dev(o, res), pack(wo), *dev(bo, g, b), pack(w1), b1.to(DEV), pack(w2), n_parts=3)
+    # heads (with and without the optional pieces)
+    g1, be1 = 1 + r(E, seed=14, k=0.1), r(E, seed=15, k=0.1)
+    g2, be2 = 1 + r(E, seed=16, k=0.1), r(E, seed=17, k=0.1)
+    mlp = [(r(E, E, seed=20 + i, k=E ** -0.5), r(E, seed=30 + i, k=0.1)) for i in range(3)]
+    wq, bq = r(E, E, seed=40, k=E ** -0.5), r(E, seed=41, k=0.1)
+    mlp_d = [(pack(w), bb.to(DEV)) for w, bb in mlp]
+    out, d, e, q = ops().dec_heads(x2, *dev(g2, be2), mlp_d, parts=parts, bias=b2.to(DEV), ln_g=g1.to(DEV), ln_b=be1.to(DEV),
+                                   l2norm=True, wq=pack(wq), bq=bq.to(DEV), query_pos=qpos.to(DEV), want_d=True)
+    t = _ln(xr + ffn + B2, g1.double(), be1.double())
+    t = t / t.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    dr = _ln(t, g2.double(), be2.double())
+    er = dr
+    for i, (w, bb) in enumerate(mlp):
+        er = er @ w.double().t() + bb.double()
+        if i < 2:
+            er = torch.relu(er)
+    closed(out, t, rtol=1e-4, atol=1e-6)
+    closed(d, dr, rtol=1e-4, atol=5e-5)
+    closed(e, er, rtol=1e-4, atol=1e-4)
+    closed(q, (t + P_) @ wq.double().t() + bq.double(), rtol=1e-4, atol=5e-5)
+    # initial form: no parts, no FFN norm, no block norm, nothing optional
+    out0, d0, e0, q0 = ops().dec_heads(res.to(DEV), *dev(g2, be2), mlp_d, want_out=False)
+    assert out0 is None and d0 is None and q0 is None
+    er = _ln(R_, g2.double(), be2.double())
+    for i, (w, bb) in enumerate(mlp):
+        er = er @ w.double().t() + bb.double()
+        if i < 2:
+            er = torch.relu(er)
+    closed(e0, er, rtol=1e-4, atol=1e-4)
+
+
+def test_decoder_fused_tails_reject_bad_sizes():
+    E = 128
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    with pytest.raises(RuntimeError, match="only 256"):
+        ops().dec_post_cross(z(1, 4, E), z(1, 4, E), z(4, E), z(E, E), z(E), z(E), z(E), z(3 * E, E), z(3 * E))
+
+
 def _start(shapes):
     return torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
 

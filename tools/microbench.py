@@ -8,7 +8,10 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from unseenobjectswithmeanshift_amd import ops  # noqa: E402
+from unseenobjectswithmeanshift_amd import _lib, ops  # noqa: E402
+
+if os.environ.get("MSM_LIB"):        # experiment builds of the library (tuning only)
+    _lib.LIB_PATH = os.environ["MSM_LIB"]
 
 DEV = "cuda"
 
@@ -24,6 +27,29 @@ def timeit(fn, iters=20, warm=3):
     ev[1].record()
     torch.cuda.synchronize()
     return ev[0].elapsed_time(ev[1]) / iters * 1e3   # us
+
+
+def timeit_graph(fn, reps=20, iters=10):
+    """GPU time of one call with the host out of the way: `reps` calls captured in a HIP graph, replayed."""
+    fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        fn()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(reps):
+                fn()
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(iters):
+        g.replay()
+    ev[1].record()
+    torch.cuda.synchronize()
+    return ev[0].elapsed_time(ev[1]) / (iters * reps) * 1e3   # us
 
 
 def gemm():
@@ -76,6 +102,27 @@ def attn():
         t = timeit(lambda: ops.hypersphere_attention(q, k[..., :E], k[..., E:], 8, masked=m, row_any=ra), iters=30)
         fl = 2.0 * 2 * B * 100 * S * E
         print(f"hs_attn S={S}: {t:7.1f} us  {fl / t / 1e6:6.1f} TFLOP/s", flush=True)
+
+
+def tails():
+    """Fused decoder-layer tails (csrc/dec_chain.hip) at B=8, Q=100."""
+    B, Q, E, Fh = 8, 100, 256, 2048
+    r = lambda *s: torch.randn(*s, device=DEV)
+    o, res, qpos = r(B, Q, E), r(B, Q, E), r(Q, E)
+    pk = lambda n, k: ops.dec_pack_weight(r(n, k) * k ** -0.5)
+    wo, w_in, w1, w2, wq = pk(E, E), pk(3 * E, E), pk(Fh, E), pk(E, Fh), pk(E, E)
+    mlp = [(pk(E, E), r(E)) for _ in range(3)]
+    v = lambda: r(E)
+    bo, g, b, b_in, b1, b2 = v(), v(), v(), r(3 * E), r(Fh), v()
+    t = timeit_graph(lambda: ops.dec_post_cross(o, res, qpos, wo, bo, g, b, w_in, b_in))
+    print(f"dec_post_cross: {t:6.1f} us  (2 stages/block)", flush=True)
+    for n_parts in (8, 4, 2):
+        t = timeit_graph(lambda: ops.dec_post_self(o, res, wo, bo, g, b, w1, b1, w2, n_parts=n_parts))
+        print(f"dec_post_self n_parts={n_parts}: {t:6.1f} us  ({1 + 2 * 8 // n_parts} stages/block)", flush=True)
+    x, parts = ops.dec_post_self(o, res, wo, bo, g, b, w1, b1, w2)
+    t = timeit_graph(lambda: ops.dec_heads(x, g, b, mlp, parts=parts, bias=b2, ln_g=g, ln_b=b, l2norm=True, wq=wq, bq=bo,
+                                     query_pos=qpos))
+    print(f"dec_heads: {t:6.1f} us  (3 stages/block)", flush=True)
 
 
 def ucn():
@@ -134,4 +181,5 @@ def meanshift():
 
 
 if __name__ == "__main__":
-    {"gemm": gemm, "mask": mask, "enc": enc, "attn": attn, "ucn": ucn, "meanshift": meanshift, "cfg5": cfg5}[sys.argv[1]]()
+    {"gemm": gemm, "mask": mask, "enc": enc, "attn": attn, "ucn": ucn, "meanshift": meanshift, "cfg5": cfg5,
+     "tails": tails}[sys.argv[1]]()

@@ -1,0 +1,453 @@
+// Fused row-local tails of a decoder layer (see include/msm_hip.h: msm_dec_post_cross / msm_dec_post_self /
+// msm_dec_heads).
+//
+// Reference: between two attention calls every op of a decoder layer is row-local on the (B*Q, 256) query
+// matrix -- out_proj, residual + LayerNorm (forward_post, DEC:245-260 / DEC:171-181), the in-projections of
+// the next attention (AU:134-140), the FFN (DEC:296-300), the block norm (DEC:637-638) and the prediction
+// heads (DEC:660-668).  As separate launches that is 13 kernels per layer of ~6 us each on 800 rows: pure
+// launch/latency cost (0.1 GFLOP per GEMM).  Here a workgroup owns a 16-row tile, keeps it in LDS across the
+// whole chain and streams the (L2-resident) weights past it with v_mfma_f32_16x16x4_f32:
+//
+//   post_cross : x = LN(res + o Wo^T + bo);  [q|k] = (x + query_pos) Wqk^T + bqk;  v = x Wv^T + bv
+//   post_self  : x = LN(res + o Wo^T + bo);  parts[c] = relu(x W1[c]^T + b1[c]) W2[:, c]^T   (hidden split in
+//                256-wide chunks over blockIdx.y, so the 4 MB of FFN weights are spread over 8x more CUs)
+//   heads      : out = normalize(LN(x + sum_c parts[c] + b2));  d = LN_dec(out);  e = MLP3(d);
+//                q_next = (out + query_pos) Wq^T + bq
+//
+// MFMA operand mapping (K-order freedom): in k-chunk kc, step u, component c lane (lj = l & 15, lq = l >> 4)
+// carries k = kc*64 + u*16 + lq*4 + c for BOTH operands, so
+//   A: one ds_read_b128 of tile[lj][kc*64 + u*16 + lq*4 ..+3]   (row stride 260 floats: conflict-free)
+//   B: one 16-byte global load per lane from the PACKED weight (msm_dec_pack_weight):
+//        packed[((t*(K/64) + kc)*4 + u)*256 + lane*4 + c] = W[t*16 + lj][kc*64 + u*16 + lq*4 + c]
+//      so a wave load is 1 KiB contiguous.  (Reading torch's (out, in) layout directly makes the 16 lanes of a
+//      quarter-wave hit 16 different rows = 64 cache-line lookups per load; measured 9 us per 256x256 stage,
+//      L1-address-rate bound, against 1.7 us of MFMA time.)
+// Weight fragments are pipelined across the stages of a chain (see gemm256).
+#include "common.h"
+
+#ifndef DC_EXP
+#define DC_EXP 0   // tuning experiments only: 1 = no MFMAs, 2 = no weight loads (tools/microbench.py tails)
+#endif
+
+namespace msm {
+
+constexpr int DC_E = 256;
+constexpr int DC_R = 16;            // rows per workgroup
+constexpr int DC_LD = DC_E + 4;     // LDS row stride (floats)
+constexpr int DC_NW = 8;            // waves per workgroup
+constexpr int DC_NT = 16 / DC_NW;   // 16-column tiles per wave in a 256-column GEMM
+constexpr int DC_THREADS = DC_NW * 64;
+
+// B fragments of two 64-wide k-chunks of a 256-column weight block, in MFMA operand order (see the header)
+struct BFrag {
+    float4 v[2][DC_NT][4];
+};
+// W: packed weight, advanced to the first of the 256 output rows wanted (row offset n0 -> + n0*K floats);
+// kct = K/64 of the packed matrix; kc0 = first of the two k-chunks to fetch
+// (Rotating the k-chunk order per workgroup to de-phase their L2 accesses was measured: -3 % kernel time, and it
+// makes a row's rounding depend on its batch position; not kept.)
+__device__ __forceinline__ void bload(BFrag& f, const float* __restrict__ W, int kct, int kc_base, int half) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < DC_NT; ++t) {
+        const float* wp = W + ((int64_t)(wave * DC_NT + t) * kct + kc_base) * 1024 + lane * 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kc = half * 2 + h;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#if DC_EXP == 2
+                f.v[h][t][u] = make_float4((float)lane, 1.f, 2.f, (float)kc);
+#else
+                f.v[h][t][u] = *reinterpret_cast<const float4*>(wp + (kc * 4 + u) * 256);
+#endif
+            }
+        }
+    }
+}
+__device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT], const float* __restrict__ ap, const BFrag& f, int half) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float4 a[4];
+        const int kc = half * 2 + h;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(ap + kc * 64 + u * 16);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#if DC_EXP == 1
+#pragma unroll
+            for (int t = 0; t < DC_NT; ++t) acc[t][0] += a[u].x * f.v[h][t][u].x + a[u].y * f.v[h][t][u].y + a[u].z * f.v[h][t][u].z + a[u].w * f.v[h][t][u].w;
+            continue;
+#endif
+#if DC_EXP == 3
+#pragma unroll
+            for (int t = 0; t < DC_NT; ++t) {
+                acc[t] = mfma16(a[u].x, 1.0f, acc[t]);
+                acc[t] = mfma16(a[u].y, 2.0f, acc[t]);
+                acc[t] = mfma16(a[u].z, 3.0f, acc[t]);
+                acc[t] = mfma16(a[u].w, 4.0f, acc[t]);
+            }
+            if (h == 1 && u == 3) {   // consume the fragments once, after the MFMAs of this half
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                    for (int t = 0; t < DC_NT; ++t)
+#pragma unroll
+                        for (int uu = 0; uu < 4; ++uu) acc[t][1] += f.v[hh][t][uu].x + f.v[hh][t][uu].w;
+            }
+            continue;
+#endif
+#pragma unroll
+            for (int t = 0; t < DC_NT; ++t) acc[t] = mfma16(a[u].x, f.v[h][t][u].x, acc[t]);
+#pragma unroll
+            for (int t = 0; t < DC_NT; ++t) acc[t] = mfma16(a[u].y, f.v[h][t][u].y, acc[t]);
+#pragma unroll
+            for (int t = 0; t < DC_NT; ++t) acc[t] = mfma16(a[u].z, f.v[h][t][u].z, acc[t]);
+#pragma unroll
+            for (int t = 0; t < DC_NT; ++t) acc[t] = mfma16(a[u].w, f.v[h][t][u].w, acc[t]);
+        }
+    }
+}
+
+// D[16][256] = act(A[16][256] . W[n][k]^T + bias).  A in LDS.  TO_GLOBAL: D is row-major global with row stride
+// ldd, rows >= rows_valid are not written; otherwise D is an LDS tile (stride DC_LD).
+// Weight pipeline across the stages of a chain: on entry `lo` already holds k-chunks 0,1 of W (loaded during the
+// previous stage or at kernel start); chunks 2,3 are fetched while 0,1 are consumed, and the next stage's chunks
+// 0,1 (Wn, may be null) while 2,3 are consumed, so L2 latency hides behind 64 MFMAs (~2000 cycles) each time.
+// acc += A[16][256] . W-block^T for this wave's DC_NT column tiles (fragment pipeline as described above)
+template <bool NEXT>
+__device__ __forceinline__ void gemm_core(f32x4 (&acc)[DC_NT], const float* __restrict__ A, const float* __restrict__ W, int kct,
+                                          int kc_base, BFrag& lo, const float* __restrict__ Wn, int kctn, int kcn) {
+    const int lane = threadIdx.x & 63;
+    const float* ap = A + (lane & 15) * DC_LD + (lane >> 4) * 4;
+    BFrag hi;
+    bload(hi, W, kct, kc_base, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(acc, ap, lo, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // NEXT is a compile-time flag: a run-time branch here makes the waitcnt pass assume the shorter queue and
+    // wait for the prefetch itself before the last MFMAs
+    if constexpr (NEXT) bload(lo, Wn, kctn, kcn, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(acc, ap, hi, 1);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// D = act(acc + bias).  TO_GLOBAL: D is row-major global with row stride ldd, rows >= rows_valid are not written;
+// otherwise D is an LDS tile (stride DC_LD).
+template <bool TO_GLOBAL>
+__device__ __forceinline__ void gemm_store(const f32x4 (&acc)[DC_NT], const float (&bv)[DC_NT], bool relu, float* __restrict__ D,
+                                           int64_t ldd, int rows_valid) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lj = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < DC_NT; ++t) {
+        const int n = (wave * DC_NT + t) * 16 + lj;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[t][r] + bv[t];
+            if (relu) v = fmaxf(v, 0.f);
+            const int row = lq * 4 + r;
+            if constexpr (TO_GLOBAL) {
+                if (row < rows_valid) D[(int64_t)row * ldd + n] = v;
+            } else {
+                D[row * DC_LD + n] = v;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void load_bias(float (&bv)[DC_NT], const float* __restrict__ bias) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < DC_NT; ++t) bv[t] = bias ? bias[(wave * DC_NT + t) * 16 + (lane & 15)] : 0.f;
+}
+
+// D[16][256] = act(A[16][256] . W-block^T + bias): one stage of a chain.  On entry `lo` holds k-chunks 0,1 of W
+// (fetched during the previous stage or at kernel start); chunks 2,3 are fetched while 0,1 are consumed and the next
+// stage's first two chunks (Wn) while 2,3 are consumed, so L2 latency hides behind 64 MFMAs per wave each time.
+template <bool TO_GLOBAL, bool NEXT>
+__device__ __forceinline__ void gemm256(const float* __restrict__ A, const float* __restrict__ W, int kct, int kc_base,
+                                        const float* __restrict__ bias, bool relu, float* __restrict__ D, int64_t ldd,
+                                        int rows_valid, BFrag& lo, const float* __restrict__ Wn, int kctn, int kcn) {
+    f32x4 acc[DC_NT];
+#pragma unroll
+    for (int t = 0; t < DC_NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bv[DC_NT];
+    load_bias(bv, bias);            // requested before the MFMAs, consumed after them
+    gemm_core<NEXT>(acc, A, W, kct, kc_base, lo, Wn, kctn, kcn);
+    gemm_store<TO_GLOBAL>(acc, bv, relu, D, ldd, rows_valid);
+}
+
+// tile[16][256] <- src rows row0.. (clamped to the last valid row), 16-byte coalesced
+__device__ __forceinline__ void load_tile(float* __restrict__ tile, const float* __restrict__ src, int64_t ld, int row0,
+                                          int rows) {
+    for (int i = threadIdx.x; i < DC_R * (DC_E / 4); i += DC_THREADS) {
+        const int r = i / (DC_E / 4), c4 = i - r * (DC_E / 4);
+        const int gr = min(row0 + r, rows - 1);
+        *reinterpret_cast<float4*>(tile + r * DC_LD + c4 * 4) = *reinterpret_cast<const float4*>(src + (int64_t)gr * ld + c4 * 4);
+    }
+}
+
+struct RowStats {
+    float mean, rstd;
+};
+__device__ __forceinline__ RowStats row_stats(float4 v, float eps) {
+    const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / DC_E);
+    const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+    const float var = wave_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.0f / DC_E);
+    return RowStats{mean, 1.0f / sqrtf(var + eps)};
+}
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 affine4(float4 v, RowStats s, float4 g, float4 b) {
+    return make_float4((v.x - s.mean) * s.rstd * g.x + b.x, (v.y - s.mean) * s.rstd * g.y + b.y,
+                       (v.z - s.mean) * s.rstd * g.z + b.z, (v.w - s.mean) * s.rstd * g.w + b.w);
+}
+constexpr int DC_RPW = DC_R / DC_NW;   // rows per wave in the row-wise phases; lane owns columns 4*lane .. 4*lane+3
+
+// ---- x = LN(res + o Wo^T + bo), shared head of post_cross / post_self -------------------------------------------
+// On return (after the trailing barrier) X holds x and, if XP, XP holds x + query_pos; x rows are written to
+// x_out by the workgroups with store_x.  Every global operand of the row phase is requested before the GEMM so
+// its latency hides behind the MFMAs.
+__device__ __forceinline__ void attn_out_ln(const float* __restrict__ o, const float* __restrict__ res,
+                                            const float* __restrict__ wo, const float* __restrict__ bo,
+                                            const float* __restrict__ g, const float* __restrict__ b,
+                                            const float* __restrict__ qpos, int Q, float* __restrict__ x_out, bool store_x,
+                                            float* __restrict__ T0, float* __restrict__ X, float* __restrict__ XP, int row0,
+                                            int rows, float eps, BFrag& f, const float* __restrict__ w_next, int kct_next,
+                                            int kc_next) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bload(f, wo, 4, 0, 0);
+    load_tile(T0, o, DC_E, row0, rows);
+    float4 rv[DC_RPW], pv[DC_RPW];
+#pragma unroll
+    for (int i = 0; i < DC_RPW; ++i) {
+        const int gr = min(row0 + wave * DC_RPW + i, rows - 1);
+        rv[i] = ld4(res + (int64_t)gr * DC_E + lane * 4);
+        pv[i] = XP ? ld4(qpos + (int64_t)(gr % Q) * DC_E + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float4 gv = ld4(g + lane * 4), bv = ld4(b + lane * 4);
+    __syncthreads();
+    gemm256<false, true>(T0, wo, 4, 0, bo, false, X, 0, 0, f, w_next, kct_next, kc_next);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < DC_RPW; ++i) {
+        const int r = wave * DC_RPW + i;
+        const float4 v = add4(ld4(X + r * DC_LD + lane * 4), rv[i]);
+        const float4 y = affine4(v, row_stats(v, eps), gv, bv);
+        st4(X + r * DC_LD + lane * 4, y);
+        if (XP) st4(XP + r * DC_LD + lane * 4, add4(y, pv[i]));
+        if (store_x && row0 + r < rows) st4(x_out + (int64_t)(row0 + r) * DC_E + lane * 4, y);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(DC_THREADS) void dec_post_cross_kernel(
+    const float* __restrict__ o, const float* __restrict__ res, const float* __restrict__ qpos, const float* __restrict__ wo,
+    const float* __restrict__ bo, const float* __restrict__ g, const float* __restrict__ b, const float* __restrict__ w_in,
+    const float* __restrict__ b_in, float* __restrict__ x_out, float* __restrict__ qk_out, float* __restrict__ v_out,
+    int rows, int Q, float eps) {
+    __shared__ __attribute__((aligned(16))) float lds[3 * DC_R * DC_LD];
+    float *T0 = lds, *X = lds + DC_R * DC_LD, *XP = lds + 2 * DC_R * DC_LD;
+    const int row0 = blockIdx.x * DC_R;
+    const int valid = min(DC_R, rows - row0);
+    // blockIdx.y picks the projection (0: q, 1: k, 2: v): the 16-row tile is MFMA-bound on ONE CU at 3.4 us per
+    // 256x256 stage, so the three independent projections go to three CUs; each repeats the Wo + LN stage.
+    const int part = blockIdx.y;
+    const float* wp = w_in + (int64_t)part * DC_E * DC_E;
+    BFrag f;
+    attn_out_ln(o, res, wo, bo, g, b, qpos, Q, x_out, part == 0, T0, X, XP, row0, rows, eps, f, wp, 4, 0);
+    // q and k share tgt + query_pos (DEC:171-175); v = tgt
+    if (part < 2)
+        gemm256<true, false>(XP, wp, 4, 0, b_in + part * DC_E, false, qk_out + (int64_t)row0 * 2 * DC_E + part * DC_E, 2 * DC_E,
+                             valid, f, nullptr, 0, 0);
+    else
+        gemm256<true, false>(X, wp, 4, 0, b_in + 2 * DC_E, false, v_out + (int64_t)row0 * DC_E, DC_E, valid, f, nullptr, 0, 0);
+}
+
+__global__ __launch_bounds__(DC_THREADS) void dec_post_self_kernel(
+    const float* __restrict__ o, const float* __restrict__ res, const float* __restrict__ wo, const float* __restrict__ bo,
+    const float* __restrict__ g, const float* __restrict__ b, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2, int F, float* __restrict__ x_out, float* __restrict__ parts, int rows, float eps) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * DC_R * DC_LD];
+    float *T0 = lds, *X = lds + DC_R * DC_LD;
+    const int row0 = blockIdx.x * DC_R, chunk = blockIdx.y;
+    const int valid = min(DC_R, rows - row0);
+    // blockIdx.y owns F/256/gridDim.y consecutive 256-wide hidden chunks; their W2 products accumulate in registers.
+    // linear1: rows [c*256, +256) of the packed (F, 256) matrix; linear2 (256, F): k-chunks 4c..4c+3 of every row tile.
+    const int per = (F / DC_E) / gridDim.y, c0 = chunk * per;
+    const int kct2 = F / 64;
+    BFrag f;
+    attn_out_ln(o, res, wo, bo, g, b, nullptr, 1, x_out, chunk == 0, T0, X, nullptr, row0, rows, eps, f,
+                w1 + (int64_t)c0 * DC_E * DC_E, 4, 0);
+    f32x4 acc2[DC_NT];
+#pragma unroll
+    for (int t = 0; t < DC_NT; ++t) acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float zero_bias[DC_NT] = {};
+    for (int c = c0; c < c0 + per; ++c) {
+        // h = relu(x W1[c]^T + b1[c]) (DEC:297) -> T0;  acc2 += h W2[:, c]^T
+        gemm256<false, true>(X, w1 + (int64_t)c * DC_E * DC_E, 4, 0, b1 + c * DC_E, true, T0, 0, 0, f, w2, kct2, 4 * c);
+        __syncthreads();
+        const int cn = min(c + 1, c0 + per - 1);    // the last prefetch re-reads the current chunk: no branch in the pipeline
+        gemm_core<true>(acc2, T0, w2, kct2, 4 * c, f, w1 + (int64_t)cn * DC_E * DC_E, 4, 0);
+        __syncthreads();
+    }
+    gemm_store<true>(acc2, zero_bias, false, parts + ((int64_t)chunk * rows + row0) * DC_E, DC_E, valid);
+}
+
+__global__ __launch_bounds__(DC_THREADS) void dec_heads_kernel(
+    const float* __restrict__ x, const float* __restrict__ parts, int n_parts, const float* __restrict__ bias,
+    const float* __restrict__ g1, const float* __restrict__ b1, int l2norm, const float* __restrict__ g2,
+    const float* __restrict__ b2, const float* __restrict__ m0w, const float* __restrict__ m0b, const float* __restrict__ m1w,
+    const float* __restrict__ m1b, const float* __restrict__ m2w, const float* __restrict__ m2b, const float* __restrict__ wq,
+    const float* __restrict__ bq, const float* __restrict__ qpos, float* __restrict__ out, float* __restrict__ d_out,
+    float* __restrict__ e_out, float* __restrict__ q_out, int rows, int Q, float eps) {
+    __shared__ __attribute__((aligned(16))) float lds[3 * DC_R * DC_LD];
+    float *XP = lds, *Dn = lds + DC_R * DC_LD, *T0 = lds + 2 * DC_R * DC_LD;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = blockIdx.x * DC_R;
+    const int valid = min(DC_R, rows - row0);
+    // blockIdx.y == 1 (only launched when wq is given): the next layer's query projection; y == 0: the MLP chain
+    const bool qpart = blockIdx.y == 1;
+    BFrag f;
+    bload(f, qpart ? wq : m0w, 4, 0, 0);
+    // row phase: lane owns 4 consecutive columns; all global operands of the wave's rows are requested up front
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v[DC_RPW], pv[DC_RPW];
+#pragma unroll
+    for (int i = 0; i < DC_RPW; ++i) {
+        const int gr = min(row0 + wave * DC_RPW + i, rows - 1);
+        v[i] = ld4(x + (int64_t)gr * DC_E + lane * 4);
+        pv[i] = qpart ? ld4(qpos + (int64_t)(gr % Q) * DC_E + lane * 4) : zero4;
+    }
+    const float4 biasv = bias ? ld4(bias + lane * 4) : zero4;
+    const float4 g1v = g1 ? ld4(g1 + lane * 4) : zero4, b1v = g1 ? ld4(b1 + lane * 4) : zero4;
+    const float4 g2v = ld4(g2 + lane * 4), b2v = ld4(b2 + lane * 4);
+    for (int s0 = 0; s0 < n_parts; s0 += 8) {
+        float4 p[DC_RPW][8];
+#pragma unroll
+        for (int i = 0; i < DC_RPW; ++i) {
+            const int gr = min(row0 + wave * DC_RPW + i, rows - 1);
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                p[i][s] = ld4(parts + ((int64_t)min(s0 + s, n_parts - 1) * rows + gr) * DC_E + lane * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < DC_RPW; ++i)
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                if (s0 + s < n_parts) v[i] = add4(v[i], p[i][s]);
+    }
+#pragma unroll
+    for (int i = 0; i < DC_RPW; ++i) {
+        const int r = wave * DC_RPW + i;
+        const bool live = row0 + r < rows;
+        float4 t = add4(v[i], biasv);
+        if (g1) t = affine4(t, row_stats(t, eps), g1v, b1v);                         // FFN norm (DEC:300)
+        if (l2norm) {                                                                // block norm (DEC:637-638)
+            const float nrm = fmaxf(sqrtf(wave_sum((t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w))), 1e-12f);
+            t = make_float4(t.x / nrm, t.y / nrm, t.z / nrm, t.w / nrm);
+        }
+        if (qpart) {
+            st4(XP + r * DC_LD + lane * 4, add4(t, pv[i]));
+            continue;
+        }
+        if (out && live) st4(out + (int64_t)(row0 + r) * DC_E + lane * 4, t);
+        const float4 y = affine4(t, row_stats(t, eps), g2v, b2v);                    // decoder_norm (DEC:661)
+        st4(Dn + r * DC_LD + lane * 4, y);
+        if (d_out && live) st4(d_out + (int64_t)(row0 + r) * DC_E + lane * 4, y);
+    }
+    __syncthreads();
+    if (qpart) {                                                                     // next layer's query (uniform branch)
+        gemm256<true, false>(XP, wq, 4, 0, bq, false, q_out + (int64_t)row0 * DC_E, DC_E, valid, f, nullptr, 0, 0);
+        return;
+    }
+    gemm256<false, true>(Dn, m0w, 4, 0, m0b, true, T0, 0, 0, f, m1w, 4, 0);                                          // mask_embed MLP (DEC:665)
+    __syncthreads();
+    gemm256<false, true>(T0, m1w, 4, 0, m1b, true, Dn, 0, 0, f, m2w, 4, 0);
+    __syncthreads();
+    gemm256<true, false>(Dn, m2w, 4, 0, m2b, false, e_out + (int64_t)row0 * DC_E, DC_E, valid, f, nullptr, 0, 0);
+}
+
+// packed[((t*(K/64) + kc)*4 + u)*256 + (lq*16 + lj)*4 + c] = W[t*16 + lj][kc*64 + u*16 + lq*4 + c]
+__global__ __launch_bounds__(256) void dec_pack_weight_kernel(const float* __restrict__ w, float* __restrict__ packed, int N,
+                                                              int K) {
+    const int64_t total4 = (int64_t)N * K / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(i & 63);
+        int64_t r = i >> 6;
+        const int u = (int)(r & 3);
+        r >>= 2;
+        const int kct = K / 64;
+        const int kc = (int)(r % kct), t = (int)(r / kct);
+        const int lj = lane & 15, lq = lane >> 4;
+        *reinterpret_cast<float4*>(packed + i * 4) =
+            *reinterpret_cast<const float4*>(w + (int64_t)(t * 16 + lj) * K + kc * 64 + u * 16 + lq * 4);
+    }
+}
+
+static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace msm
+
+using namespace msm;
+
+extern "C" int msm_dec_pack_weight(const float* w, float* packed, int N, int K, void* stream) {
+    MSM_REQUIRE(w && packed && w != packed, "msm_dec_pack_weight: null or aliased pointer");
+    MSM_REQUIRE(N > 0 && K > 0 && N % 16 == 0 && K % 64 == 0, "msm_dec_pack_weight: N=%d must be a multiple of 16, K=%d of 64", N, K);
+    MSM_REQUIRE(aligned16(w) && aligned16(packed), "msm_dec_pack_weight: pointers must be 16-byte aligned");
+    const int64_t total4 = (int64_t)N * K / 4;
+    hipLaunchKernelGGL(dec_pack_weight_kernel, dim3((unsigned)min((int64_t)2048, (total4 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, w, packed, N, K);
+    MSM_CHECK_LAUNCH("msm_dec_pack_weight");
+    return MSM_OK;
+}
+
+extern "C" int msm_dec_post_cross(const float* attn_out, const float* res, const float* query_pos, const float* wo,
+                                  const float* bo, const float* ln_g, const float* ln_b, const float* w_in, const float* b_in,
+                                  float* x_out, float* qk_out, float* v_out, int rows, int Q, int E, float eps, void* stream) {
+    MSM_REQUIRE(attn_out && res && query_pos && wo && bo && ln_g && ln_b && w_in && b_in && x_out && qk_out && v_out,
+                "msm_dec_post_cross: null pointer");
+    MSM_REQUIRE(E == DC_E, "msm_dec_post_cross: E=%d, only 256 is supported", E);
+    MSM_REQUIRE(rows > 0 && Q > 0, "msm_dec_post_cross: bad sizes");
+    MSM_REQUIRE(aligned16(attn_out) && aligned16(wo) && aligned16(w_in), "msm_dec_post_cross: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(dec_post_cross_kernel, dim3(cdiv(rows, DC_R), 3), dim3(DC_THREADS), 0, (hipStream_t)stream, attn_out, res,
+                       query_pos, wo, bo, ln_g, ln_b, w_in, b_in, x_out, qk_out, v_out, rows, Q, eps);
+    MSM_CHECK_LAUNCH("msm_dec_post_cross");
+    return MSM_OK;
+}
+
+extern "C" int msm_dec_post_self(const float* attn_out, const float* res, const float* wo, const float* bo, const float* ln_g,
+                                 const float* ln_b, const float* w1, const float* b1, const float* w2, int F, float* x_out,
+                                 float* parts, int n_parts, int rows, int E, float eps, void* stream) {
+    MSM_REQUIRE(attn_out && res && wo && bo && ln_g && ln_b && w1 && b1 && w2 && x_out && parts, "msm_dec_post_self: null pointer");
+    MSM_REQUIRE(E == DC_E, "msm_dec_post_self: E=%d, only 256 is supported", E);
+    MSM_REQUIRE(rows > 0 && F > 0 && F % DC_E == 0, "msm_dec_post_self: F=%d must be a positive multiple of 256", F);
+    MSM_REQUIRE(n_parts > 0 && (F / DC_E) % n_parts == 0, "msm_dec_post_self: n_parts=%d must divide F/256=%d", n_parts, F / DC_E);
+    MSM_REQUIRE(aligned16(attn_out) && aligned16(wo) && aligned16(w1) && aligned16(w2), "msm_dec_post_self: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(dec_post_self_kernel, dim3(cdiv(rows, DC_R), n_parts), dim3(DC_THREADS), 0, (hipStream_t)stream, attn_out,
+                       res, wo, bo, ln_g, ln_b, w1, b1, w2, F, x_out, parts, rows, eps);
+    MSM_CHECK_LAUNCH("msm_dec_post_self");
+    return MSM_OK;
+}
+
+extern "C" int msm_dec_heads(const float* x, const float* parts, int n_parts, const float* bias, const float* ln_g,
+                             const float* ln_b, int l2norm, const float* dec_g, const float* dec_b, const float* m0w,
+                             const float* m0b, const float* m1w, const float* m1b, const float* m2w, const float* m2b,
+                             const float* wq, const float* bq, const float* query_pos, float* out, float* d_out, float* e_out,
+                             float* q_out, int rows, int Q, int E, float eps, void* stream) {
+    MSM_REQUIRE(x && dec_g && dec_b && m0w && m0b && m1w && m1b && m2w && m2b && e_out, "msm_dec_heads: null pointer");
+    MSM_REQUIRE(E == DC_E, "msm_dec_heads: E=%d, only 256 is supported", E);
+    MSM_REQUIRE(rows > 0 && Q > 0 && n_parts >= 0, "msm_dec_heads: bad sizes");
+    MSM_REQUIRE(n_parts == 0 || parts, "msm_dec_heads: parts missing");
+    MSM_REQUIRE((ln_g == nullptr) == (ln_b == nullptr), "msm_dec_heads: ln_g/ln_b must both be given or both be null");
+    MSM_REQUIRE(!wq || (bq && query_pos && q_out), "msm_dec_heads: the next-query projection needs bq, query_pos and q_out");
+    MSM_REQUIRE(aligned16(m0w) && aligned16(m1w) && aligned16(m2w) && aligned16(wq), "msm_dec_heads: weights must be 16-byte aligned");
+    hipLaunchKernelGGL(dec_heads_kernel, dim3(cdiv(rows, DC_R), wq ? 2 : 1), dim3(DC_THREADS), 0, (hipStream_t)stream, x, parts, n_parts, bias,
+                       ln_g, ln_b, l2norm, dec_g, dec_b, m0w, m0b, m1w, m1b, m2w, m2b, wq, bq, query_pos, out, d_out, e_out, q_out,
+                       rows, Q, eps);
+    MSM_CHECK_LAUNCH("msm_dec_heads");
+    return MSM_OK;
+}

@@ -231,6 +231,10 @@ class MeanShiftTransformerDecoder(nn.Module):
         # the latency-bound per-layer query kernels that leave most CUs idle
         self.overlap_kv = False    # measured neutral at B=8 on MI355X (5.76 vs 5.69 ms/step): off by default
         self._side = None
+        # the row-local ops between the attention cores run as three fused kernels per layer (csrc/dec_chain.hip)
+        # instead of 13 launches; needs E = 256, mask_dim = 256 and dim_feedforward % 256 == 0 (every MSMFormer yaml)
+        self.fused_tails = (hidden_dim == 256 and mask_dim == 256 and dim_feedforward % 256 == 0)
+        self._tails_cache = None
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
                               error_msgs):
@@ -305,6 +309,77 @@ class MeanShiftTransformerDecoder(nn.Module):
                                               sparse=self.sparse_taps)
         return cls, mask, attn, row_any
 
+    def _packed_tails(self):
+        """Weights of the fused tails in the kernels' fragment order (ops.dec_pack_weight), re-packed when a
+        parameter is replaced or modified in place."""
+        E = self.query_feat.weight.shape[1]
+        groups = {
+            "cross_q": [l.meanshift_attn.in_proj_weight[:E] for l in self.transformer_cross_attention_layers],
+            "cross_o": [l.meanshift_attn.out_proj.weight for l in self.transformer_cross_attention_layers],
+            "self_in": [l.self_attn.in_proj_weight for l in self.transformer_self_attention_layers],
+            "self_o": [l.self_attn.out_proj.weight for l in self.transformer_self_attention_layers],
+            "ffn1": [l.linear1.weight for l in self.transformer_ffn_layers],
+            "ffn2": [l.linear2.weight for l in self.transformer_ffn_layers],
+            "mlp": [l.weight for l in self.mask_embed.layers],
+        }
+        key = tuple((p.data_ptr(), p._version) for ws in groups.values() for p in ws)
+        if self._tails_cache is None or self._tails_cache[0] != key:
+            self._tails_cache = (key, {k: [ops.dec_pack_weight(w.contiguous()) for w in ws] for k, ws in groups.items()})
+        return self._tails_cache[1]
+
+    def _forward_fused(self, xs, sizes, kv_w, kv_c, mask_features, out, qpos):
+        """Same arithmetic as the loop in forward(), with the row-local ops of a layer in three launches:
+        heads (+ next cross-attention query) -> mask step -> K/V GEMM -> cross attention -> post_cross (out_proj, LN,
+        self-attention in-projection) -> self attention -> post_self (out_proj, LN, FFN by hidden chunk)."""
+        E = self.query_feat.weight.shape[1]
+        L = self.num_layers
+        full = self.aux_outputs
+        H = self.num_heads
+        pk = self._packed_tails()
+        mlp = [(pk["mlp"][j], l.bias) for j, l in enumerate(self.mask_embed.layers)]
+        dn = self.decoder_norm
+        pred_cls, pred_mask = [], []
+
+        def predict(d, e, i_next):
+            last = i_next == L
+            want = full or last
+            cls = ops.gemm(d, self.class_embed.weight, self.class_embed.bias) if want else None
+            tgt = None if (last and not full) else sizes[i_next % self.num_feature_levels]
+            m, attn, row_any = ops.mask_logits(e, mask_features, want_mask=want, target_size=tgt, sparse=self.sparse_taps)
+            pred_cls.append(cls)
+            pred_mask.append(m)
+            return attn, row_any
+
+        def next_query(i):
+            if i >= L:
+                return dict(wq=None, bq=None, query_pos=None)
+            return dict(wq=pk["cross_q"][i], bq=self.transformer_cross_attention_layers[i].meanshift_attn.in_proj_bias[:E],
+                        query_pos=qpos)
+
+        _, d, e, q = ops.dec_heads(out, dn.weight, dn.bias, mlp, want_out=False, want_d=full or L == 0, **next_query(0))
+        attn, row_any = predict(d, e, 0)
+        for i in range(L):
+            lvl = i % self.num_feature_levels                                     # DEC:608
+            ca = self.transformer_cross_attention_layers[i]
+            sa = self.transformer_self_attention_layers[i]
+            ff = self.transformer_ffn_layers[i]
+            kv = ops.conv1x1_nchw_to_tokens(xs[lvl], kv_w[i], kv_c[i])            # (B, hw, 2E) = [K | V]
+            o = ops.hypersphere_attention(q, kv[..., :E], kv[..., E:], H, masked=attn, row_any=row_any, kappa=float(KAPPA))
+            x, qk, v = ops.dec_post_cross(o, out, qpos, pk["cross_o"][i], ca.meanshift_attn.out_proj.bias, ca.norm.weight,
+                                          ca.norm.bias, pk["self_in"][i], sa.self_attn.in_proj_bias)
+            o = ops.hypersphere_attention(qk[..., :E], qk[..., E:], v, H, kappa=float(KAPPA))
+            x, parts = ops.dec_post_self(o, x, pk["self_o"][i], sa.self_attn.out_proj.bias, sa.norm.weight, sa.norm.bias,
+                                         pk["ffn1"][i], ff.linear1.bias, pk["ffn2"][i])
+            last = i == L - 1
+            out, d, e, q = ops.dec_heads(x, dn.weight, dn.bias, mlp, parts=parts, bias=ff.linear2.bias,
+                                         ln_g=ff.norm.weight, ln_b=ff.norm.bias, l2norm=self.decoder_block_norm,
+                                         want_out=not last, want_d=full or last, **next_query(i + 1))
+            attn, row_any = predict(d, e, i + 1)
+        res = {"pred_logits": pred_cls[-1], "pred_masks": pred_mask[-1], "aux_outputs": []}
+        if full:
+            res["aux_outputs"] = [{"pred_logits": a, "pred_masks": b} for a, b in zip(pred_cls[:-1], pred_mask[:-1])]
+        return res
+
     @torch.no_grad()
     def forward(self, x, mask_features, mask=None):
         assert len(x) == self.num_feature_levels
@@ -347,6 +422,8 @@ class MeanShiftTransformerDecoder(nn.Module):
         full = self.aux_outputs
         L = self.num_layers
         pred_cls, pred_mask = [], []
+        if self.fused_tails and self.fold_kv and kv_all is None:
+            return self._forward_fused(xs, sizes, kv_w, kv_c, mask_features, out, qpos)
         d = ops.layernorm(out, self.decoder_norm.weight, self.decoder_norm.bias)
         cls, m, attn, row_any = self._heads(d, mask_features, sizes[0], full or L == 0, full or L == 0)
         pred_cls.append(cls)

@@ -242,6 +242,77 @@ def hypersphere_attention(q, k, v, heads, *, masked=None, row_any=None, kappa=KA
     return out
 
 
+# ----------------------------------------------------------------------------------------------
+# fused decoder-layer tails (csrc/dec_chain.hip)
+# ----------------------------------------------------------------------------------------------
+def dec_pack_weight(w):
+    """(N, K) torch Linear weight -> the MFMA-fragment order the dec_* kernels stream (include/msm_hip.h)."""
+    _c(w, "w")
+    N, K = w.shape
+    packed = torch.empty_like(w)
+    rc = lib().msm_dec_pack_weight(_p(w), _p(packed), N, K, _stream())
+    check(rc, "msm_dec_pack_weight")
+    return packed
+
+
+def dec_post_cross(attn_out, res, query_pos, wo, bo, ln_g, ln_b, w_in, b_in, eps=1e-5):
+    """Weight matrices of the three dec_* calls are dec_pack_weight() outputs.
+    x = LN(res + attn_out wo^T + bo); qk = (x + query_pos) w_in[:2E]^T + b_in[:2E]; v = x w_in[2E:]^T + b_in[2E:].
+    attn_out/res (B,Q,E); query_pos (Q,E).  Returns (x (B,Q,E), qk (B,Q,2E), v (B,Q,E))."""
+    for t, n in ((attn_out, "attn_out"), (res, "res"), (query_pos, "query_pos"), (wo, "wo"), (bo, "bo"), (ln_g, "ln_g"),
+                 (ln_b, "ln_b"), (w_in, "w_in"), (b_in, "b_in")):
+        _c(t, n)
+    B, Q, E = attn_out.shape
+    x = torch.empty_like(attn_out)
+    qk = torch.empty((B, Q, 2 * E), device=attn_out.device, dtype=torch.float32)
+    v = torch.empty_like(attn_out)
+    rc = lib().msm_dec_post_cross(_p(attn_out), _p(res), _p(query_pos), _p(wo), _p(bo), _p(ln_g), _p(ln_b), _p(w_in),
+                                  _p(b_in), _p(x), _p(qk), _p(v), B * Q, Q, E, eps, _stream())
+    check(rc, "msm_dec_post_cross")
+    return x, qk, v
+
+
+def dec_post_self(attn_out, res, wo, bo, ln_g, ln_b, w1, b1, w2, n_parts=None, eps=1e-5):
+    """x = LN(res + attn_out wo^T + bo); parts (n_parts, B, Q, E): partial sums over equal slices of the hidden
+    dimension of linear2(relu(linear1(x))), without linear2's bias.  Default n_parts: about 200 workgroups."""
+    for t, n in ((attn_out, "attn_out"), (res, "res"), (wo, "wo"), (bo, "bo"), (ln_g, "ln_g"), (ln_b, "ln_b"),
+                 (w1, "w1"), (b1, "b1"), (w2, "w2")):
+        _c(t, n)
+    B, Q, E = attn_out.shape
+    F = w1.shape[0]
+    x = torch.empty_like(attn_out)
+    chunks = F // E
+    if n_parts is None:
+        tiles = (B * Q + 15) // 16
+        n_parts = max(d for d in range(1, chunks + 1) if chunks % d == 0 and (d == 1 or tiles * d <= 256))
+    parts = torch.empty((n_parts, B, Q, E), device=attn_out.device, dtype=torch.float32)
+    rc = lib().msm_dec_post_self(_p(attn_out), _p(res), _p(wo), _p(bo), _p(ln_g), _p(ln_b), _p(w1), _p(b1), _p(w2), F,
+                                 _p(x), _p(parts), n_parts, B * Q, E, eps, _stream())
+    check(rc, "msm_dec_post_self")
+    return x, parts
+
+
+def dec_heads(x, dec_g, dec_b, mlp, *, parts=None, bias=None, ln_g=None, ln_b=None, l2norm=False, wq=None, bq=None,
+              query_pos=None, want_out=True, want_d=False, eps=1e-5):
+    """t = x + sum(parts) + bias [-> LN] [-> unit length]; d = LN_dec(t); e = MLP3(d); q = (t + query_pos) wq^T + bq.
+    mlp = [(w0,b0),(w1,b1),(w2,b2)].  Returns (out|None, d|None, e, q|None)."""
+    ts = [x, parts, bias, ln_g, ln_b, dec_g, dec_b, wq, bq, query_pos] + [t for wb in mlp for t in wb]
+    for i, t in enumerate(ts):
+        _c(t, f"dec_heads arg {i}")
+    B, Q, E = x.shape
+    out = torch.empty_like(x) if want_out else None
+    d = torch.empty_like(x) if want_d else None
+    e = torch.empty_like(x)
+    q = torch.empty_like(x) if wq is not None else None
+    n_parts = 0 if parts is None else parts.shape[0]
+    (m0w, m0b), (m1w, m1b), (m2w, m2b) = mlp
+    rc = lib().msm_dec_heads(_p(x), _p(parts), n_parts, _p(bias), _p(ln_g), _p(ln_b), 1 if l2norm else 0, _p(dec_g),
+                             _p(dec_b), _p(m0w), _p(m0b), _p(m1w), _p(m1b), _p(m2w), _p(m2b), _p(wq), _p(bq),
+                             _p(query_pos), _p(out), _p(d), _p(e), _p(q), B * Q, Q, E, eps, _stream())
+    check(rc, "msm_dec_heads")
+    return out, d, e, q
+
+
 def ms_deform_attn(value, spatial_shapes, level_start_index, sampling_locations, attention_weights):
     """Reference-ABI core op: value (N,S,M,D), shapes (L,2) int64, start (L,) int64,
     loc (N,Lq,M,L,P,2), w (N,Lq,M,L,P) -> (N,Lq,M*D)."""
