@@ -27,7 +27,16 @@ namespace msm {
 
 constexpr int QB = 7;           // 16-row MFMA blocks per query chunk
 constexpr int QCH = QB * 16;    // 112 queries per chunk
-constexpr int KU = 8;           // k-steps (of 4) per prefetch group
+#ifndef MSM_MASK_KU
+#define MSM_MASK_KU 4
+#endif
+#ifndef MSM_MASK_MW
+#define MSM_MASK_MW 8
+#endif
+constexpr int KU = MSM_MASK_KU;  // k-steps (of 4) per prefetch group
+constexpr int MW = MSM_MASK_MW;  // waves per workgroup: the 116 KB mask_embed chunk allows ONE workgroup per CU, so 8 waves
+                                // give every SIMD two instruction streams (one wave alone cannot hide its own ds_read /
+                                // buffer-load issue and waitcnt bubbles behind its MFMAs)
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
@@ -55,7 +64,7 @@ __device__ __forceinline__ Cols<NC> ld_cols(__amdgpu_buffer_rsrc_t rsrc, unsigne
 // meanshiftformer_transformer_decoder.py:1012-1035 with target size == mask size: interpolate is the
 // identity); 2/4/8 = 2x2-tap average of a bilinear downsample by that factor.
 template <int POOL, bool WRITE, int NC>
-__global__ __launch_bounds__(256) void mask_logits_kernel(const float* __restrict__ emb, const float* __restrict__ feat,
+__global__ __launch_bounds__(MW * 64) void mask_logits_kernel(const float* __restrict__ emb, const float* __restrict__ feat,
                                                           float* __restrict__ mask_out, uint8_t* __restrict__ attn_out,
                                                           int32_t* __restrict__ row_any, int Q, int C, int H, int W,
                                                           int th, int tw, int ypar, int n_rowpairs, int rp_step,
@@ -76,7 +85,7 @@ __global__ __launch_bounds__(256) void mask_logits_kernel(const float* __restric
 
     // stage this chunk of mask_embed: rows >= Q are zero
     const float* eb = emb + ((int64_t)b * Q + q0) * C;
-    for (int idx = tid; idx < QCH * (C / 4); idx += 256) {
+    for (int idx = tid; idx < QCH * (C / 4); idx += MW * 64) {
         const int r = idx / (C / 4), c4 = (idx - r * (C / 4)) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q0 + r < Q) v = *reinterpret_cast<const float4*>(eb + (int64_t)r * C + c4);
@@ -97,7 +106,16 @@ __global__ __launch_bounds__(256) void mask_logits_kernel(const float* __restric
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)fbs, 0, feat_bytes, 0x00020000);   // feat_bytes = C*H*W*4 from the host: stays scalar
 
-    for (int t = blockIdx.x * 4 + wave; t < ntiles; t += gridDim.x * 4) {
+    // Tile schedule: full rounds go to all MW waves of every workgroup; the leftover tiles go first to waves 0..3
+    // (one per SIMD) of every workgroup, then to waves 4..7, and so on, so no SIMD gets two leftover tiles
+    // while another gets none (waves w, w+4, w+8, ... share a SIMD).
+    const int slots = gridDim.x * MW;
+    const int full_rounds = ntiles / slots;
+    const int left = ntiles - full_rounds * slots;
+    const int left_slot = (wave >> 2) * ((int)gridDim.x * 4) + (int)blockIdx.x * 4 + (wave & 3);
+    const int my_tiles = full_rounds + (left_slot < left ? 1 : 0);
+    for (int it = 0; it < my_tiles; ++it) {
+        const int t = (it < full_rounds) ? it * slots + (int)blockIdx.x * MW + wave : full_rounds * slots + left_slot;
         const int rp = t / ctiles, ct = t - rp * ctiles;
         const int ytop = ypar + 2 * (rp_first + rp * rp_step);  // may be -1 (odd pairing): clamp loads
         const int ybot = ytop + 1;                               // may be H
@@ -160,14 +178,18 @@ __global__ __launch_bounds__(256) void mask_logits_kernel(const float* __restric
         if (g < G) compute_group(tA, bA, g * (4 * KU));   // odd number of groups
 
         // ---- epilogue: lane holds queries q0 + m*16 + lq*4 + r, columns c..c+NC-1 of rows ytop (acc[.][cc])
-        //      and ybot (acc[.][NC+cc])
+        //      and ybot (acc[.][NC+cc]).  The query offset is made opaque here: the 28 per-query output base addresses
+        //      depend only on the lane, so LICM would otherwise hoist them out of the tile loop and hold 56 VGPRs
+        //      across the K loop (209 vs 157 VGPRs; the difference decides between 2 and 3 waves per SIMD).
+        int qlane = lq * 4;
+        asm volatile("" : "+v"(qlane));
         if constexpr (WRITE) {
             if (col_ok) {
 #pragma unroll
                 for (int m = 0; m < QB; ++m) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int q = q0 + m * 16 + lq * 4 + r;
+                        const int q = q0 + m * 16 + qlane + r;
                         if (q < Q) {
                             float* o = mask_out + ((int64_t)b * Q + q) * HW + c;
                             if constexpr (NC == 2) {
@@ -189,7 +211,7 @@ __global__ __launch_bounds__(256) void mask_logits_kernel(const float* __restric
                 for (int m = 0; m < QB; ++m) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int q = q0 + m * 16 + lq * 4 + r;
+                        const int q = q0 + m * 16 + qlane + r;
                         if (q >= Q) continue;
                         uint8_t* o = attn_out + ((int64_t)b * Q + q) * HW + c;
                         bool any = false;
@@ -225,13 +247,15 @@ __global__ __launch_bounds__(256) void mask_logits_kernel(const float* __restric
                         const float n2 = __shfl_down(acc[m][NC][r], 1, 64);
                         s = (acc[m][NC - 1][r] + n0) + (acc[m][2 * NC - 1][r] + n2);
                     }
-                    const int q = q0 + m * 16 + lq * 4 + r;
+                    const int q = q0 + m * 16 + qlane + r;
                     if (row_tap && col_tap && q < Q && tx < tw && ty < th) {
                         const bool masked = s < 0.f;
                         attn_out[((int64_t)b * Q + q) * (th * tw) + ty * tw + tx] = masked ? 1 : 0;
                         if (!masked) row_any[(int64_t)b * Q + q] = 1;
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);   // one row block at a time: keeps the epilogue's live set (shuffled
+                                                     // neighbours, addresses) from setting the kernel's VGPR count
             }
         }
     }
@@ -288,10 +312,10 @@ extern "C" int msm_mask_logits_fwd(const float* mask_embed, const float* mask_fe
     const int ctiles = cdiv(W, 16 * nc);
     const int ntiles = n_rowpairs * ctiles;
     // persistent-ish grid: enough workgroups per (image, chunk) to cover the chip once
-    int wg_per = cdiv(ntiles, 4);
+    int wg_per = cdiv(ntiles, MW);
     const int target = cdiv(256, B * qchunks);
     if (wg_per > target) wg_per = max(target, 1);
-    dim3 grid(wg_per, qchunks, B), block(256);
+    dim3 grid(wg_per, qchunks, B), block(MW * 64);
     const size_t lds = sizeof(float) * (size_t)QCH * (C + 2);
     typedef void (*kern_t)(const float*, const float*, float*, uint8_t*, int32_t*, int, int, int, int, int, int, int, int, int, int, int);
     kern_t kern;
