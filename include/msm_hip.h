@@ -23,6 +23,7 @@
  *   msm_msdeform_attn_enc_fwd    <- MSDeformAttn.forward lines OPS/modules/ms_deform_attn.py:101-118 fused
  *   msm_mask_logits_fwd          <- forward_prediction_heads einsum + attention-mask, DEC:668-680
  *   msm_hypersphere_attn_fwd     <- hypersphere_attention, AU:64-82 (+ head split/merge AU:364-375,424)
+ *   msm_kv_project_f32           <- memory/key path of the cross-attention layers, DEC:575, DEC:251, AU:134-140
  *   msm_dec_post_cross / msm_dec_post_self / msm_dec_heads
  *                                <- the row-local ops between the attention cores of a decoder layer,
  *                                   DEC:245-260, DEC:171-181, DEC:296-300, DEC:637-638, DEC:661-665
@@ -175,6 +176,15 @@ int64_t msm_encoder_block_stream_floats(int d_ffn, int proj_width);
 int msm_encoder_block_fwd(const float* attn, const float* src, const float* wstream, const float* small,
                           const float* pos, float* src_out, float* value_out, float* proj_out,
                           int M, int S, int d_ffn, int proj_width, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Folded key/value projection of one feature level (DEC:575 input_proj + level_embed, DEC:251 "+ pos", AU:134-140
+ * k/v in-projection -- everything affine in the level feature folded on the host):
+ *   out [B][HW][N] = x^T w^T + cmat,  x [B][C = 64][HW] (NCHW), w [N][64], cmat [HW][N] shared by the batch,
+ *   N in {256, 512} (512 = [K | V] of one cross-attention layer).
+ * ------------------------------------------------------------------------------------------- */
+int msm_kv_project_f32(const float* x, const float* w, const float* cmat, float* out,
+                       int B, int C, int HW, int N, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused row-local tails of one decoder layer on the query matrix [rows = B*Q][E], E fixed to 256.  Row r uses

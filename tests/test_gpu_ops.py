@@ -307,6 +307,15 @@ def test_decoder_fused_tails_reject_bad_sizes():
         ops().dec_post_cross(z(1, 4, E), z(1, 4, E), z(4, E), z(E, E), z(E), z(E), z(E), z(3 * E, E), z(3 * E))
 
 
+@pytest.mark.parametrize("B,H,W,N", [(8, 30, 40, 512), (3, 60, 80, 512), (2, 61, 67, 256), (1, 15, 20, 512)])
+def test_kv_project(B, H, W, N):
+    """msm_kv_project_f32 (and its small-shape GEMM route) vs x^T w^T + cmat in fp64 (DEC:575/251, AU:134-140 folded)."""
+    x, w, c = rnd(B, 64, H, W, seed=1), rnd(N, 64, seed=2, scale=0.125), rnd(H * W, N, seed=3)
+    got = ops().kv_project(x.to(DEV), w.to(DEV), c.to(DEV))
+    ref = torch.einsum("bkp,nk->bpn", x.double().flatten(2), w.double()) + c.double()
+    closed(got, ref, rtol=1e-5, atol=2e-5)
+
+
 def _start(shapes):
     return torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
 

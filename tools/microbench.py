@@ -104,6 +104,22 @@ def attn():
         print(f"hs_attn S={S}: {t:7.1f} us  {fl / t / 1e6:6.1f} TFLOP/s", flush=True)
 
 
+def kv():
+    """Folded K/V projection of the three feature levels (conv1x1_nchw_to_tokens with a matrix bias), B=8."""
+    B, Cin, E = 8, 64, 256
+    for (h, w) in ((15, 20), (30, 40), (60, 80)):
+        x = torch.randn(B, Cin, h, w, device=DEV)
+        wt = torch.randn(2 * E, Cin, device=DEV) * 0.1
+        c = torch.randn(h * w, 2 * E, device=DEV)
+        t = timeit_graph(lambda: ops.conv1x1_nchw_to_tokens(x, wt, c))
+        by = (x.numel() + c.numel() + B * h * w * 2 * E) * 4
+        print(f"kv proj {h}x{w}: {t:6.1f} us  {2.0 * B * h * w * Cin * 2 * E / t / 1e6:6.1f} TFLOP/s  {by / t / 1e6:6.2f} TB/s",
+              flush=True)
+        t2 = timeit_graph(lambda: ops.kv_project(x, wt, c))
+        err = (ops.kv_project(x, wt, c) - ops.conv1x1_nchw_to_tokens(x, wt, c)).abs().max().item()
+        print(f"   kv_project kernel: {t2:6.1f} us  {by / t2 / 1e6:6.2f} TB/s  max|diff| {err:.2e}", flush=True)
+
+
 def tails():
     """Fused decoder-layer tails (csrc/dec_chain.hip) at B=8, Q=100."""
     B, Q, E, Fh = 8, 100, 256, 2048
@@ -182,4 +198,4 @@ def meanshift():
 
 if __name__ == "__main__":
     {"gemm": gemm, "mask": mask, "enc": enc, "attn": attn, "ucn": ucn, "meanshift": meanshift, "cfg5": cfg5,
-     "tails": tails}[sys.argv[1]]()
+     "tails": tails, "kv": kv}[sys.argv[1]]()

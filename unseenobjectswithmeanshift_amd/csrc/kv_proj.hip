@@ -1,0 +1,128 @@
+// Folded K/V projection of one feature level (see include/msm_hip.h: msm_kv_project_f32):
+//     out[b][p][n] = sum_k x[b][k][p] * w[n][k] + cmat[p][n],     k < 64, n < N (N = 2E = 512: [K | V])
+//
+// Reference: the memory/key path of the cross-attention layers -- input_proj (1x1 conv) + level_embed (DEC:575),
+// "+ pos" (DEC:251) and the k/v in-projections (AU:134-140); everything affine in the 64-channel level feature is
+// folded into w (N, 64) and the per-position constant cmat (HW, N) on the host (modeling._folded_kv).
+//
+// Why not the generic GEMM: K = 64 is one or two k-steps, so a tiled GEMM workgroup is a load -> wait -> 64 MFMAs
+// -> store sequence with nothing to overlap (measured 66 us for 60x80 x 8 images = 1.5 TB/s of the 79 MB it
+// writes).  Here the weight is the stationary operand: every workgroup copies the whole w (128 KiB) into LDS once
+// and its 16 waves (4 per SIMD) then stream (position tile, image, feature half) units:
+//   * MFMA orientation D^T: rows = output features (A = w from LDS, ds_read_b128 with a 68-float row stride),
+//     cols = 16 tokens (B = x read straight from NCHW: for a fixed channel 16 consecutive pixels = 64 B);
+//     K order k = lq*16 + s for both operands; a lane ends with 4 consecutive features of one token, so cmat is
+//     the accumulator's initial value (one 16-byte load) and the result leaves as one 16-byte store;
+//   * a wave holds the 16 x-values of its token tile in registers for all 16 feature blocks of the unit;
+//   * units are ordered image-fastest, so the 8 images of a position tile read the same cmat rows out of L2.
+// Measured (B = 8, 60x80): 36-39 us against 62-66 us for the tiled GEMM; with the MFMAs removed the kernel still
+// takes 29 us, i.e. it now sits on the 98 MB it has to move (79 MB of them written).
+#include "common.h"
+
+namespace msm {
+
+constexpr int KP_K = 64;
+constexpr int KP_LD = KP_K + 4;      // LDS row stride of w (floats): 16 rows x b128 conflict-free
+constexpr int KP_FB = 16;            // feature blocks (of 16) per unit: 256 features
+constexpr int KP_W = 16;             // waves per workgroup (one workgroup per CU: w takes 136 KiB of LDS)
+
+__global__ __launch_bounds__(KP_W * 64) void kv_project_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ cmat, float* __restrict__ out, int B,
+                                                         int HW, int N) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [N][KP_LD]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    for (int i = tid; i < N * (KP_K / 4); i += KP_W * 64) {
+        const int n = i >> 4, c4 = i & 15;
+        *reinterpret_cast<float4*>(wl + n * KP_LD + c4 * 4) = *reinterpret_cast<const float4*>(w + (int64_t)n * KP_K + c4 * 4);
+    }
+    __syncthreads();
+
+    const int tiles = (HW + 15) / 16;
+    const int halves = N / (KP_FB * 16);
+    const int units = tiles * B * halves;
+    // full rounds over all waves; the leftover units go one per SIMD across all workgroups first (waves w, w+4, ...
+    // share a SIMD), so no SIMD runs two leftovers while another runs none
+    const int slots = gridDim.x * KP_W;
+    const int full_rounds = units / slots;
+    const int left = units - full_rounds * slots;
+    const int left_slot = (wave >> 2) * ((int)gridDim.x * 4) + (int)blockIdx.x * 4 + (wave & 3);
+    const int mine = full_rounds + (left_slot < left ? 1 : 0);
+    auto unit_of = [&](int it) {
+        return (it < full_rounds) ? it * slots + (int)blockIdx.x * KP_W + wave : full_rounds * slots + left_slot;
+    };
+    auto load_x = [&](int u, float (&xv)[16]) {
+        const int img = (u / halves) % B, tile = u / (halves * B);
+        const int p = min(tile * 16 + lj, HW - 1);
+        // B operand: x[img][k = lq*16 + s][p], s = 0..15
+        const float* xp = x + ((int64_t)img * KP_K + lq * 16) * HW + p;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) xv[s] = xp[(int64_t)s * HW];
+    };
+    float xb[16], xn[16];
+    if (mine > 0) load_x(unit_of(0), xb);
+    for (int it = 0; it < mine; ++it) {
+        const int u = unit_of(it);
+        const int half = u % halves;
+        const int tile = u / (halves * B), img = (u / halves) % B;
+        const int p = min(tile * 16 + lj, HW - 1);             // this lane's token (clamped; stores are guarded)
+        const bool live = tile * 16 + lj < HW;
+        const int n_base = half * KP_FB * 16;
+        const float* cp = cmat + (int64_t)p * N + n_base + lq * 4;
+        float* op = out + ((int64_t)img * HW + p) * N + n_base + lq * 4;
+        const float* wp = wl + (n_base + lj) * KP_LD + lq * 16;
+        // everything this unit reads from memory is requested before its first MFMA; the next unit's x rides along
+        float4 cm[KP_FB];
+#pragma unroll
+        for (int fb = 0; fb < KP_FB; ++fb) cm[fb] = *reinterpret_cast<const float4*>(cp + fb * 16);
+        load_x(unit_of(min(it + 1, mine - 1)), xn);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int fb = 0; fb < KP_FB; fb += 2) {
+            // two feature blocks in flight: consecutive MFMAs alternate accumulators
+            f32x4 a0 = f32x4{cm[fb].x, cm[fb].y, cm[fb].z, cm[fb].w};
+            f32x4 a1 = f32x4{cm[fb + 1].x, cm[fb + 1].y, cm[fb + 1].z, cm[fb + 1].w};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const float4 w0 = *reinterpret_cast<const float4*>(wp + fb * 16 * KP_LD + s4 * 4);
+                const float4 w1 = *reinterpret_cast<const float4*>(wp + (fb + 1) * 16 * KP_LD + s4 * 4);
+                a0 = mfma16(w0.x, xb[s4 * 4 + 0], a0);
+                a1 = mfma16(w1.x, xb[s4 * 4 + 0], a1);
+                a0 = mfma16(w0.y, xb[s4 * 4 + 1], a0);
+                a1 = mfma16(w1.y, xb[s4 * 4 + 1], a1);
+                a0 = mfma16(w0.z, xb[s4 * 4 + 2], a0);
+                a1 = mfma16(w1.z, xb[s4 * 4 + 2], a1);
+                a0 = mfma16(w0.w, xb[s4 * 4 + 3], a0);
+                a1 = mfma16(w1.w, xb[s4 * 4 + 3], a1);
+            }
+            if (live) {
+                *reinterpret_cast<float4*>(op + fb * 16) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+                *reinterpret_cast<float4*>(op + (fb + 1) * 16) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) xb[s] = xn[s];
+    }
+}
+
+}  // namespace msm
+
+using namespace msm;
+
+extern "C" int msm_kv_project_f32(const float* x, const float* w, const float* cmat, float* out, int B, int C, int HW, int N,
+                                  void* stream) {
+    MSM_REQUIRE(x && w && cmat && out, "msm_kv_project_f32: null pointer");
+    MSM_REQUIRE(C == KP_K, "msm_kv_project_f32: C=%d, only 64 input channels are supported", C);
+    MSM_REQUIRE(B > 0 && HW > 0 && N > 0 && N % (KP_FB * 16) == 0 && N <= 512,
+                "msm_kv_project_f32: N=%d must be 256 or 512", N);
+    MSM_REQUIRE(((((uintptr_t)w) | ((uintptr_t)cmat) | ((uintptr_t)out)) & 15) == 0 && (((uintptr_t)x) & 3) == 0,
+                "msm_kv_project_f32: w/cmat/out must be 16-byte aligned");
+    const size_t lds = sizeof(float) * (size_t)N * KP_LD;
+    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)kv_project_kernel, lds));
+    const int units = cdiv(HW, 16) * B * (N / (KP_FB * 16));
+    const int grid = max(1, min(256, cdiv(units, 4)));
+    hipLaunchKernelGGL(kv_project_kernel, dim3(grid), dim3(KP_W * 64), lds, (hipStream_t)stream, x, w, cmat, out, B, HW, N);
+    MSM_CHECK_LAUNCH("msm_kv_project_f32");
+    return MSM_OK;
+}

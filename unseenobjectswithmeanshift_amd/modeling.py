@@ -363,7 +363,7 @@ class MeanShiftTransformerDecoder(nn.Module):
             ca = self.transformer_cross_attention_layers[i]
             sa = self.transformer_self_attention_layers[i]
             ff = self.transformer_ffn_layers[i]
-            kv = ops.conv1x1_nchw_to_tokens(xs[lvl], kv_w[i], kv_c[i])            # (B, hw, 2E) = [K | V]
+            kv = ops.kv_project(xs[lvl], kv_w[i], kv_c[i])            # (B, hw, 2E) = [K | V]
             o = ops.hypersphere_attention(q, kv[..., :E], kv[..., E:], H, masked=attn, row_any=row_any, kappa=float(KAPPA))
             x, qk, v = ops.dec_post_cross(o, out, qpos, pk["cross_o"][i], ca.meanshift_attn.out_proj.bias, ca.norm.weight,
                                           ca.norm.bias, pk["self_in"][i], sa.self_attn.in_proj_bias)
@@ -403,7 +403,7 @@ class MeanShiftTransformerDecoder(nn.Module):
                 kv_all, kv_ready = [], []
                 with torch.cuda.stream(self._side):
                     for i in range(self.num_layers):
-                        kv_all.append(ops.conv1x1_nchw_to_tokens(xs[i % self.num_feature_levels], kv_w[i], kv_c[i]))
+                        kv_all.append(ops.kv_project(xs[i % self.num_feature_levels], kv_w[i], kv_c[i]))
                         ev = torch.cuda.Event()
                         ev.record(self._side)
                         kv_ready.append(ev)
@@ -436,7 +436,7 @@ class MeanShiftTransformerDecoder(nn.Module):
                     torch.cuda.current_stream().wait_event(kv_ready[i])               # join for layer i only
                     kv = kv_all[i]
                 else:
-                    kv = ops.conv1x1_nchw_to_tokens(xs[lvl], kv_w[i], kv_c[i])        # (B, hw, 2E) = [K | V]
+                    kv = ops.kv_project(xs[lvl], kv_w[i], kv_c[i])        # (B, hw, 2E) = [K | V]
                 t2 = ca.meanshift_attn.attend(out, None, None, query_pos=qpos, masked=attn, row_any=row_any,
                                               kv=(kv[..., :E], kv[..., E:]))
             else:

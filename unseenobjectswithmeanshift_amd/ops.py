@@ -94,6 +94,23 @@ def conv1x1_nchw_to_tokens(x, w, bias=None):
     return out
 
 
+def kv_project(x, w, cmat):
+    """Folded K/V projection: x (B, 64, H, W) NCHW, w (N, 64), cmat (H*W, N) -> (B, H*W, N).
+    Large maps with N in {256, 512} take the weight-stationary kernel (csrc/kv_proj.hip); small ones, where copying
+    w into every CU's LDS costs more than it saves, and other shapes take the tiled GEMM."""
+    _c(x, "x"), _c(w, "w"), _c(cmat, "cmat")
+    B, C, H, W = x.shape
+    N = w.shape[0]
+    if C != 64 or N not in (256, 512) or B * H * W < 8192:
+        return conv1x1_nchw_to_tokens(x, w, cmat)
+    if tuple(w.shape) != (N, C) or tuple(cmat.shape) != (H * W, N):
+        raise RuntimeError(f"kv_project: w must be (N, {C}) and cmat ({H * W}, N)")
+    out = torch.empty((B, H * W, N), device=x.device, dtype=torch.float32)
+    rc = lib().msm_kv_project_f32(_p(x), _p(w), _p(cmat), _p(out), B, C, H * W, N, _stream())
+    check(rc, "msm_kv_project_f32")
+    return out
+
+
 def conv1x1_tokens_to_nchw(t, w, bias=None):
     """tokens (B, HW, Cin) -> (B, Cout, HW) with the weight as the MFMA A operand so that the
     NCHW output rows are written contiguously (bias is per output row)."""
