@@ -108,11 +108,14 @@ int msm_transpose_f32(const float* in, float* out, int B, int R, int C, void* st
  *             i.e. the 2x2-tap average is negative; requires H/th == W/tw in {2,4,8}.
  *   row_any   (nullable with attn_out) int32 [B][Q]: set to 1 iff some key of the row is
  *             attendable (the reference resets all-masked rows, DEC:618); zeroed by this call.
- *   sparse != 0: rows of the mask that feed neither mask_out nor a tap are skipped.
+ *   flags: MSM_MASK_SPARSE (1): rows of the mask that feed neither mask_out nor a tap are skipped;
+ *          MSM_MASK_ROW_ANY_CLEARED (2): the caller already zeroed row_any (msm_dec_heads does), no fill is issued.
  * ------------------------------------------------------------------------------------------- */
+#define MSM_MASK_SPARSE 1
+#define MSM_MASK_ROW_ANY_CLEARED 2
 int msm_mask_logits_fwd(const float* mask_embed, const float* mask_feat, float* mask_out,
                         uint8_t* attn_out, int32_t* row_any,
-                        int B, int Q, int C, int H, int W, int th, int tw, int sparse, void* stream);
+                        int B, int Q, int C, int H, int W, int th, int tw, int flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-head hypersphere (vMF) attention core (AU:64-82) on already projected q/k/v:
@@ -207,7 +210,8 @@ int msm_kv_project_f32(const float* x, const float* w, const float* cmat, float*
  *   plus the next layer's cross-attention query projection:
  *     t = x + sum_c parts[c] + bias;  if ln_g: t = LN(t);  if l2norm: t = t / max(||t||, 1e-12);  out = t
  *     d_out = LN_dec(t);  e_out = m2(relu(m1(relu(m0(d)))));  q_out = (t + query_pos) wq^T + bq
- *   out, d_out and the wq/bq/query_pos/q_out group are optional (null).
+ *   out, d_out and the wq/bq/query_pos/q_out group are optional (null).  row_any_zero (nullable) int32 [rows] is
+ *   cleared: the row_any buffer of the mask step that consumes e_out (pass MSM_MASK_ROW_ANY_CLEARED there).
  * ------------------------------------------------------------------------------------------- */
 int msm_dec_pack_weight(const float* w, float* packed, int N, int K, void* stream);
 int msm_dec_post_cross(const float* attn_out, const float* res, const float* query_pos,
@@ -225,7 +229,7 @@ int msm_dec_heads(const float* x, const float* parts, int n_parts, const float* 
                   const float* m0w, const float* m0b, const float* m1w, const float* m1b,
                   const float* m2w, const float* m2b,
                   const float* wq, const float* bq, const float* query_pos,
-                  float* out, float* d_out, float* e_out, float* q_out,
+                  float* out, float* d_out, float* e_out, float* q_out, int32_t* row_any_zero,
                   int rows, int Q, int E, float eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

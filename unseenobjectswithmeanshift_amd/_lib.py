@@ -44,7 +44,7 @@ _SIGNATURES = {
     "msm_dec_pack_weight": (c_i, [c_f, c_f, c_i, c_i, c_p]),
     "msm_dec_post_cross": (c_i, [c_f] * 12 + [c_i, c_i, c_i, c_fl, c_p]),
     "msm_dec_post_self": (c_i, [c_f] * 9 + [c_i, c_f, c_f, c_i, c_i, c_i, c_fl, c_p]),
-    "msm_dec_heads": (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, c_i] + [c_f] * 15 + [c_i, c_i, c_i, c_fl, c_p]),
+    "msm_dec_heads": (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, c_i] + [c_f] * 15 + [c_p, c_i, c_i, c_i, c_fl, c_p]),
     "msm_ms_seed_workspace": (c_l, [c_i]),
     "msm_ms_select_seeds": (c_i, [c_f, c_i, c_i, c_i, c_l, c_f, c_p, c_f, c_l, c_p]),
     "msm_ms_hill_climb_workspace": (c_l, [c_i, c_i]),

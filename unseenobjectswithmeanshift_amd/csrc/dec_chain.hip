@@ -303,7 +303,7 @@ __global__ __launch_bounds__(DC_THREADS) void dec_heads_kernel(
     const float* __restrict__ b2, const float* __restrict__ m0w, const float* __restrict__ m0b, const float* __restrict__ m1w,
     const float* __restrict__ m1b, const float* __restrict__ m2w, const float* __restrict__ m2b, const float* __restrict__ wq,
     const float* __restrict__ bq, const float* __restrict__ qpos, float* __restrict__ out, float* __restrict__ d_out,
-    float* __restrict__ e_out, float* __restrict__ q_out, int rows, int Q, float eps) {
+    float* __restrict__ e_out, float* __restrict__ q_out, int32_t* __restrict__ row_any_zero, int rows, int Q, float eps) {
     __shared__ __attribute__((aligned(16))) float lds[3 * DC_R * DC_LD];
     float *XP = lds, *Dn = lds + DC_R * DC_LD, *T0 = lds + 2 * DC_R * DC_LD;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -311,6 +311,8 @@ __global__ __launch_bounds__(DC_THREADS) void dec_heads_kernel(
     const int valid = min(DC_R, rows - row0);
     // blockIdx.y == 1 (only launched when wq is given): the next layer's query projection; y == 0: the MLP chain
     const bool qpart = blockIdx.y == 1;
+    // the mask step that consumes e_out needs its row_any flags cleared: done here instead of a separate fill launch
+    if (row_any_zero && !qpart && (int)threadIdx.x < valid) row_any_zero[row0 + threadIdx.x] = 0;
     BFrag f;
     bload(f, qpart ? wq : m0w, 4, 0, 0);
     // row phase: lane owns 4 consecutive columns; all global operands of the wave's rows are requested up front
@@ -437,7 +439,7 @@ extern "C" int msm_dec_heads(const float* x, const float* parts, int n_parts, co
                              const float* ln_b, int l2norm, const float* dec_g, const float* dec_b, const float* m0w,
                              const float* m0b, const float* m1w, const float* m1b, const float* m2w, const float* m2b,
                              const float* wq, const float* bq, const float* query_pos, float* out, float* d_out, float* e_out,
-                             float* q_out, int rows, int Q, int E, float eps, void* stream) {
+                             float* q_out, int32_t* row_any_zero, int rows, int Q, int E, float eps, void* stream) {
     MSM_REQUIRE(x && dec_g && dec_b && m0w && m0b && m1w && m1b && m2w && m2b && e_out, "msm_dec_heads: null pointer");
     MSM_REQUIRE(E == DC_E, "msm_dec_heads: E=%d, only 256 is supported", E);
     MSM_REQUIRE(rows > 0 && Q > 0 && n_parts >= 0, "msm_dec_heads: bad sizes");
@@ -447,7 +449,7 @@ extern "C" int msm_dec_heads(const float* x, const float* parts, int n_parts, co
     MSM_REQUIRE(aligned16(m0w) && aligned16(m1w) && aligned16(m2w) && aligned16(wq), "msm_dec_heads: weights must be 16-byte aligned");
     hipLaunchKernelGGL(dec_heads_kernel, dim3(cdiv(rows, DC_R), wq ? 2 : 1), dim3(DC_THREADS), 0, (hipStream_t)stream, x, parts, n_parts, bias,
                        ln_g, ln_b, l2norm, dec_g, dec_b, m0w, m0b, m1w, m1b, m2w, m2b, wq, bq, query_pos, out, d_out, e_out, q_out,
-                       rows, Q, eps);
+                       row_any_zero, rows, Q, eps);
     MSM_CHECK_LAUNCH("msm_dec_heads");
     return MSM_OK;
 }

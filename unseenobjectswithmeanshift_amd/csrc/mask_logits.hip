@@ -267,7 +267,8 @@ using namespace msm;
 
 extern "C" int msm_mask_logits_fwd(const float* mask_embed, const float* mask_feat, float* mask_out,
                                    uint8_t* attn_out, int32_t* row_any, int B, int Q, int C, int H, int W,
-                                   int th, int tw, int sparse, void* stream) {
+                                   int th, int tw, int flags, void* stream) {
+    const int sparse = flags & MSM_MASK_SPARSE;
     MSM_REQUIRE(mask_embed && mask_feat, "msm_mask_logits_fwd: null input");
     MSM_REQUIRE(mask_out || attn_out, "msm_mask_logits_fwd: nothing to produce");
     MSM_REQUIRE(B > 0 && Q > 0 && H > 1 && W > 1, "msm_mask_logits_fwd: bad sizes");
@@ -286,7 +287,7 @@ extern "C" int msm_mask_logits_fwd(const float* mask_embed, const float* mask_fe
         MSM_REQUIRE(pool == 1 || pool == 2 || pool == 4 || pool == 8, "msm_mask_logits_fwd: pool factor %d not in {1,2,4,8}", pool);
     }
     hipStream_t st = (hipStream_t)stream;
-    if (attn_out) MSM_CHECK_HIP(hipMemsetAsync(row_any, 0, sizeof(int32_t) * (size_t)B * Q, st));
+    if (attn_out && !(flags & MSM_MASK_ROW_ANY_CLEARED)) MSM_CHECK_HIP(hipMemsetAsync(row_any, 0, sizeof(int32_t) * (size_t)B * Q, st));
 
     // row pairing: even (rows 2i, 2i+1) unless the taps need odd pairs (POOL 4/8 -> rows 4i+1,4i+2 / 8i+3,8i+4)
     int ypar = 0, n_rowpairs = H / 2, rp_step = 1, rp_first = 0;

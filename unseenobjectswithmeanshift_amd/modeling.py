@@ -340,12 +340,13 @@ class MeanShiftTransformerDecoder(nn.Module):
         dn = self.decoder_norm
         pred_cls, pred_mask = [], []
 
-        def predict(d, e, i_next):
+        def predict(d, e, ra, i_next):
             last = i_next == L
             want = full or last
             cls = ops.gemm(d, self.class_embed.weight, self.class_embed.bias) if want else None
             tgt = None if (last and not full) else sizes[i_next % self.num_feature_levels]
-            m, attn, row_any = ops.mask_logits(e, mask_features, want_mask=want, target_size=tgt, sparse=self.sparse_taps)
+            m, attn, row_any = ops.mask_logits(e, mask_features, want_mask=want, target_size=tgt, sparse=self.sparse_taps,
+                                               row_any=ra)       # ra: cleared by the heads kernel, no fill launch
             pred_cls.append(cls)
             pred_mask.append(m)
             return attn, row_any
@@ -356,8 +357,9 @@ class MeanShiftTransformerDecoder(nn.Module):
             return dict(wq=pk["cross_q"][i], bq=self.transformer_cross_attention_layers[i].meanshift_attn.in_proj_bias[:E],
                         query_pos=qpos)
 
-        _, d, e, q = ops.dec_heads(out, dn.weight, dn.bias, mlp, want_out=False, want_d=full or L == 0, **next_query(0))
-        attn, row_any = predict(d, e, 0)
+        _, d, e, q, ra = ops.dec_heads(out, dn.weight, dn.bias, mlp, want_out=False, want_d=full or L == 0,
+                                       zero_row_any=True, **next_query(0))
+        attn, row_any = predict(d, e, ra, 0)
         for i in range(L):
             lvl = i % self.num_feature_levels                                     # DEC:608
             ca = self.transformer_cross_attention_layers[i]
@@ -371,10 +373,11 @@ class MeanShiftTransformerDecoder(nn.Module):
             x, parts = ops.dec_post_self(o, x, pk["self_o"][i], sa.self_attn.out_proj.bias, sa.norm.weight, sa.norm.bias,
                                          pk["ffn1"][i], ff.linear1.bias, pk["ffn2"][i])
             last = i == L - 1
-            out, d, e, q = ops.dec_heads(x, dn.weight, dn.bias, mlp, parts=parts, bias=ff.linear2.bias,
-                                         ln_g=ff.norm.weight, ln_b=ff.norm.bias, l2norm=self.decoder_block_norm,
-                                         want_out=not last, want_d=full or last, **next_query(i + 1))
-            attn, row_any = predict(d, e, i + 1)
+            out, d, e, q, ra = ops.dec_heads(x, dn.weight, dn.bias, mlp, parts=parts, bias=ff.linear2.bias,
+                                             ln_g=ff.norm.weight, ln_b=ff.norm.bias, l2norm=self.decoder_block_norm,
+                                             want_out=not last, want_d=full or last, zero_row_any=True,
+                                             **next_query(i + 1))
+            attn, row_any = predict(d, e, ra, i + 1)
         res = {"pred_logits": pred_cls[-1], "pred_masks": pred_mask[-1], "aux_outputs": []}
         if full:
             res["aux_outputs"] = [{"pred_logits": a, "pred_masks": b} for a, b in zip(pred_cls[:-1], pred_mask[:-1])]

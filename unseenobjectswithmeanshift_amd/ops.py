@@ -210,26 +210,34 @@ def transpose_last2(x):
     return out
 
 
-def mask_logits(mask_embed, mask_features, *, want_mask=True, target_size=None, sparse=False):
+def mask_logits(mask_embed, mask_features, *, want_mask=True, target_size=None, sparse=False, row_any=None):
     """einsum('bqc,bchw->bqhw') with the next layer's attention mask fused.
-    Returns (mask (B,Q,H,W) or None, attn (B,Q,th*tw) uint8 or None, row_any (B,Q) int32 or None)."""
+    Returns (mask (B,Q,H,W) or None, attn (B,Q,th*tw) uint8 or None, row_any (B,Q) int32 or None).
+    row_any: an already ZEROED (B,Q) int32 buffer (dec_heads(zero_row_any=True) provides one) -- saves the fill launch."""
     _c(mask_embed, "mask_embed"), _c(mask_features, "mask_features")
     B, Q, C = mask_embed.shape
     _, _, H, W = mask_features.shape
     dev = mask_embed.device
     mask = torch.empty((B, Q, H, W), device=dev, dtype=torch.float32) if want_mask else None
-    attn = row_any = None
+    attn = None
     th = tw = 0
+    flags = 1 if sparse else 0
     if target_size is not None:
         th, tw = int(target_size[0]), int(target_size[1])
         attn = torch.empty((B, Q, th * tw), device=dev, dtype=torch.uint8)
-        row_any = torch.empty((B, Q), device=dev, dtype=torch.int32)
+        if row_any is None:
+            row_any = torch.empty((B, Q), device=dev, dtype=torch.int32)
+        else:
+            _c(row_any, "row_any", torch.int32)
+            flags |= 2
+    else:
+        row_any = None
     ev = None
     if MASK_STEP_EVENTS is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
     rc = lib().msm_mask_logits_fwd(_p(mask_embed), _p(mask_features), _p(mask), _p(attn), _p(row_any),
-                                   B, Q, C, H, W, th, tw, 1 if sparse else 0, _stream())
+                                   B, Q, C, H, W, th, tw, flags, _stream())
     check(rc, "msm_mask_logits_fwd")
     if ev is not None:
         ev[1].record()
@@ -310,9 +318,10 @@ def dec_post_self(attn_out, res, wo, bo, ln_g, ln_b, w1, b1, w2, n_parts=None, e
 
 
 def dec_heads(x, dec_g, dec_b, mlp, *, parts=None, bias=None, ln_g=None, ln_b=None, l2norm=False, wq=None, bq=None,
-              query_pos=None, want_out=True, want_d=False, eps=1e-5):
+              query_pos=None, want_out=True, want_d=False, zero_row_any=False, eps=1e-5):
     """t = x + sum(parts) + bias [-> LN] [-> unit length]; d = LN_dec(t); e = MLP3(d); q = (t + query_pos) wq^T + bq.
-    mlp = [(w0,b0),(w1,b1),(w2,b2)].  Returns (out|None, d|None, e, q|None)."""
+    mlp = [(w0,b0),(w1,b1),(w2,b2)].  Returns (out|None, d|None, e, q|None), plus a zeroed (B,Q) int32 row_any buffer
+    for the following mask step when zero_row_any."""
     ts = [x, parts, bias, ln_g, ln_b, dec_g, dec_b, wq, bq, query_pos] + [t for wb in mlp for t in wb]
     for i, t in enumerate(ts):
         _c(t, f"dec_heads arg {i}")
@@ -321,13 +330,14 @@ def dec_heads(x, dec_g, dec_b, mlp, *, parts=None, bias=None, ln_g=None, ln_b=No
     d = torch.empty_like(x) if want_d else None
     e = torch.empty_like(x)
     q = torch.empty_like(x) if wq is not None else None
+    ra = torch.empty((B, Q), device=x.device, dtype=torch.int32) if zero_row_any else None
     n_parts = 0 if parts is None else parts.shape[0]
     (m0w, m0b), (m1w, m1b), (m2w, m2b) = mlp
     rc = lib().msm_dec_heads(_p(x), _p(parts), n_parts, _p(bias), _p(ln_g), _p(ln_b), 1 if l2norm else 0, _p(dec_g),
                              _p(dec_b), _p(m0w), _p(m0b), _p(m1w), _p(m1b), _p(m2w), _p(m2b), _p(wq), _p(bq),
-                             _p(query_pos), _p(out), _p(d), _p(e), _p(q), B * Q, Q, E, eps, _stream())
+                             _p(query_pos), _p(out), _p(d), _p(e), _p(q), _p(ra), B * Q, Q, E, eps, _stream())
     check(rc, "msm_dec_heads")
-    return out, d, e, q
+    return (out, d, e, q, ra) if zero_row_any else (out, d, e, q)
 
 
 def ms_deform_attn(value, spatial_shapes, level_start_index, sampling_locations, attention_weights):
