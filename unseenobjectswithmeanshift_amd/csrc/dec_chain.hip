@@ -79,24 +79,6 @@ __device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT], const float* __re
             for (int t = 0; t < DC_NT; ++t) acc[t][0] += a[u].x * f.v[h][t][u].x + a[u].y * f.v[h][t][u].y + a[u].z * f.v[h][t][u].z + a[u].w * f.v[h][t][u].w;
             continue;
 #endif
-#if DC_EXP == 3
-#pragma unroll
-            for (int t = 0; t < DC_NT; ++t) {
-                acc[t] = mfma16(a[u].x, 1.0f, acc[t]);
-                acc[t] = mfma16(a[u].y, 2.0f, acc[t]);
-                acc[t] = mfma16(a[u].z, 3.0f, acc[t]);
-                acc[t] = mfma16(a[u].w, 4.0f, acc[t]);
-            }
-            if (h == 1 && u == 3) {   // consume the fragments once, after the MFMAs of this half
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                    for (int t = 0; t < DC_NT; ++t)
-#pragma unroll
-                        for (int uu = 0; uu < 4; ++uu) acc[t][1] += f.v[hh][t][uu].x + f.v[hh][t][uu].w;
-            }
-            continue;
-#endif
 #pragma unroll
             for (int t = 0; t < DC_NT; ++t) acc[t] = mfma16(a[u].x, f.v[h][t][u].x, acc[t]);
 #pragma unroll
