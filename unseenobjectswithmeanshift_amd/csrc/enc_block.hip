@@ -16,15 +16,17 @@
 //     leave registers between the five GEMMs of the chain and the two LayerNorms reduce over the 4
 //     lanes of a token with two shuffles;
 //   * weights are the A operand.  They are pre-packed (host, once per checkpoint) into a stream of
-//     4 KiB blocks in consumption order and staged through LDS in 32 KiB chunks (double buffered,
-//     one barrier per chunk) with an XOR swizzle that makes every ds_read_b128 conflict-free;
-//   * 4 waves x 16 tokens per workgroup, 64 KiB LDS -> 2 workgroups per CU.
+//     4 KiB blocks in consumption order and staged through LDS in 16 KiB halves of its 32 KiB chunks
+//     (double buffered, one barrier per half) with an XOR swizzle that makes every ds_read_b128 conflict-free;
+//   * 4 waves x 16 tokens per workgroup, 38 KiB LDS -> 4 workgroups per CU.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace msm {
 
 constexpr int EC = 64;                 // d_model
-constexpr int CHUNK_F4 = 2048;         // float4 per 32 KiB chunk (8 blocks of 256 float4)
+constexpr int CHUNK_F4 = 1024;         // float4 per 16 KiB LDS stage = HALF a 32 KiB stream chunk (4 blocks of 256 float4)
 
 struct EncSmall {                      // offsets (floats) into the packed small-parameter vector
     int bo, g1, be1, b1, b2, g2, be2, bv, bp;
@@ -97,36 +99,52 @@ __device__ __forceinline__ void layer_norm_L(float (&v)[4][4], const float* __re
     }
 }
 
-__global__ __launch_bounds__(256) void enc_block_kernel(const float* __restrict__ attn, const float* __restrict__ src,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void enc_block_kernel(const float* __restrict__ attn, const float* __restrict__ src,
                                                         const float4* __restrict__ wstream, const float* __restrict__ small,
                                                         EncSmall so, const float* __restrict__ pos,
                                                         float* __restrict__ src_out, float* __restrict__ value_out,
                                                         float* __restrict__ proj_out, int M, int S, int nffn, int nproj_blocks,
-                                                        int proj_ld, float eps, int n_small) {
+                                                        int proj_ld, float eps, int n_small, int n_normal) {
     extern __shared__ __attribute__((aligned(16))) float4 wl[];   // [2][CHUNK_F4] weight chunks, then the small parameters
     float* sm = reinterpret_cast<float*>(wl + 2 * CHUNK_F4);
     for (int i = threadIdx.x; i < n_small; i += 256) sm[i] = small[i];   // biases / LayerNorm vectors: read from LDS in the loop
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lj = lane & 15, lq = lane >> 4;
-    const int tok = blockIdx.x * 64 + wave * 16 + lj;
+    // Workgroups [0, n_normal): one 16-token tile per wave.  Workgroups >= n_normal are COOPERATIVE: all four waves
+    // work on ONE tile and split the FFN (by LDS stage) and the tail row blocks between them, so such a workgroup
+    // costs every SIMD about a quarter of a tile.  The host turns the tiles that would otherwise start a nearly
+    // empty extra round (B = 8: 3150 tiles = 3 x 1024 SIMDs + 78) into cooperative ones: SIMD makespan 4 -> 3.3 tiles.
+    const bool coop = (int)blockIdx.x >= n_normal;
+    const int tile = coop ? n_normal * 4 + ((int)blockIdx.x - n_normal) : (int)blockIdx.x * 4 + wave;
+    const int tok = tile * 16 + lj;
     const bool tok_ok = tok < M;
     const int tk = tok_ok ? tok : M - 1;
     const bool next = value_out != nullptr;
-    const int nchunks = 1 + nffn + (next ? 1 + (nproj_blocks - 4 + 7) / 8 : 0);
+    // The host stream is organised in 32 KiB chunks of 8 blocks (ops.pack_encoder_block); the kernel walks it in
+    // 16 KiB halves so that a workgroup needs 2 x 16 KiB + parameters = 38 KiB of LDS and FOUR workgroups fit a
+    // CU (the 3150 16-token tiles of B = 8 then are all resident at once: 3 or 4 waves per SIMD instead of a
+    // second, half-empty round).  Step s reads stream half sh(s): 0 = output_proj, (half 1 is the chunk's zero
+    // padding: skipped), 2.. = FFN (2 hidden blocks each), then value_proj, then 4 proj row blocks per half.
+    const int nhf = 2 * nffn;
+    const int ntail = next ? 1 + (nproj_blocks + 3) / 4 : 0;
+    const int nsteps = 1 + nhf + ntail;
 
-    // ---- weight chunk staging: 8 float4 per thread per chunk (one per block), swizzled into LDS ----
+    // ---- weight staging: 4 float4 per thread per half (one per block), swizzled into LDS ----
     // destination float4 index inside a block for this thread (row blocks / linear2 blocks)
     const int dst_row = (tid >> 4) * 16 + ((tid & 15) ^ (tid >> 4));
     const int dst_w2 = (tid >> 2) * 4 + ((tid & 3) ^ ((tid >> 4) & 3));
-#define ENC_CHUNK_LOAD(c)                                                                     \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) stage[i] = wstream[(int64_t)(c) * CHUNK_F4 + tid + 256 * i];
-#define ENC_CHUNK_STORE(c, buf)                                                               \
+#define ENC_STAGE_LOAD(s_)                                                                     \
     {                                                                                         \
-        const bool ffn_ = (c) >= 1 && (c) <= nffn;                                            \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i)(buf)[i * 256 + ((ffn_ && (i & 1)) ? dst_w2 : dst_row)] = stage[i]; \
+        const int sh_ = (s_) == 0 ? 0 : (s_) + 1;                                             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) stage[i] = wstream[(int64_t)sh_ * CHUNK_F4 + tid + 256 * i]; \
     }
-    float4 stage[8];
+#define ENC_STAGE_STORE(s_, buf)                                                               \
+    {                                                                                         \
+        const bool ffn_ = (s_) >= 1 && (s_) <= nhf;                                           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)(buf)[i * 256 + ((ffn_ && (i & 1)) ? dst_w2 : dst_row)] = stage[i]; \
+    }
+    float4 stage[4];
 
     // ---- tile inputs in layout L ----
     float act[4][4], res[4][4];
@@ -138,100 +156,136 @@ __global__ __launch_bounds__(256) void enc_block_kernel(const float* __restrict_
         res[fb][0] = r.x; res[fb][1] = r.y; res[fb][2] = r.z; res[fb][3] = r.w;
     }
 
-    ENC_CHUNK_LOAD(0)
-    ENC_CHUNK_STORE(0, wl)
+    ENC_STAGE_LOAD(0)
+    ENC_STAGE_STORE(0, wl)
     __syncthreads();
 
     float x[4][4];      // current activations (layout L)
     f32x4 acc2[4];
-    for (int c = 0; c < nchunks; ++c) {
-        const float4* buf = wl + (c & 1) * CHUNK_F4;
-        // prefetch the next chunk into registers; it is written to the other LDS buffer after this chunk's MFMAs
+    // ---- step 0 (peeled: act/res die here): output_proj + residual + LayerNorm1 (msdeformattn.py:124-126) ----
+    {
+        ENC_STAGE_LOAD(1)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            const f32x4 d = rowblock_mm(wl + ob * 256, lj, lq, act);
+            const float4 bo = *reinterpret_cast<const float4*>(sm + so.bo + ob * 16 + lq * 4);
+            x[ob][0] = d[0] + bo.x + res[ob][0];
+            x[ob][1] = d[1] + bo.y + res[ob][1];
+            x[ob][2] = d[2] + bo.z + res[ob][2];
+            x[ob][3] = d[3] + bo.w + res[ob][3];
+        }
+        layer_norm_L(x, sm + so.g1, sm + so.be1, lq, eps);
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) acc2[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_sched_barrier(0);
+        ENC_STAGE_STORE(1, wl + CHUNK_F4)
+        __syncthreads();
+    }
+    // ---- steps 1..nhf: FFN, 2 hidden blocks of 16 per stage; the hidden activation lives in 4 registers.  The 16
+    // linear1 MFMAs of block 1 are issued before block 0's result is read back (bias + ReLU) and fed to its 16
+    // linear2 MFMAs; both blocks' LDS fragments are requested up front.
+    for (int s = 1; s <= nhf; ++s) {
+        const float4* buf = wl + (s & 1) * CHUNK_F4;
+        // prefetch the next stage into registers; it is written to the other LDS buffer after this stage's MFMAs
         {
-            const int cn = min(c + 1, nchunks - 1);
-            ENC_CHUNK_LOAD(cn)
+            const int sn = min(s + 1, nsteps - 1);
+            ENC_STAGE_LOAD(sn)
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (c == 0) {
-            // ---- output_proj + residual + LayerNorm1 (msdeformattn.py:124-126) ----
-#pragma unroll
-            for (int ob = 0; ob < 4; ++ob) {
-                const f32x4 d = rowblock_mm(buf + ob * 256, lj, lq, act);
-                const float4 bo = *reinterpret_cast<const float4*>(sm + so.bo + ob * 16 + lq * 4);
-                x[ob][0] = d[0] + bo.x + res[ob][0];
-                x[ob][1] = d[1] + bo.y + res[ob][1];
-                x[ob][2] = d[2] + bo.z + res[ob][2];
-                x[ob][3] = d[3] + bo.w + res[ob][3];
-            }
-            layer_norm_L(x, sm + so.g1, sm + so.be1, lq, eps);
-#pragma unroll
-            for (int ob = 0; ob < 4; ++ob) acc2[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
-        } else if (c <= nffn) {
-            // ---- FFN: 4 hidden blocks of 16 per chunk; the hidden activation lives in 4 registers.
-            // Software pipeline over the hidden blocks q: the 16 linear1 MFMAs of block q+1 are issued
-            // before block q's result is read back (bias + ReLU) and fed to its 16 linear2 MFMAs, and the
-            // LDS fragments are fetched one block ahead, so neither MFMA results nor ds_reads are waited on.
-            float4 w1[2][4], w2[4];
+        if (!coop || ((s - 1) & 3) == wave) {
+            float4 w1[2][4], w2[2][4];
             f32x4 dd[2][2];
             rowblock_read(buf + 0 * 256, lj, lq, w1[0]);
             rowblock_read(buf + 2 * 256, lj, lq, w1[1]);
-            dd[0][0] = dd[0][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            rowblock_mma(w1[0], x, dd[0][0], dd[0][1]);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int cur = q & 1, nxt = cur ^ 1;
-                const int hb = (c - 1) * 4 + q;
-                // fragments: linear2 block q (used below), linear1 block q+2 (used next iteration)
+            for (int q = 0; q < 2; ++q) {
                 const float4* w2p = buf + (2 * q + 1) * 256;
 #pragma unroll
                 for (int ob = 0; ob < 4; ++ob) {
                     const int row = ob * 16 + lj;
-                    w2[ob] = lds4(w2p, row * 4 + (lq ^ ((row >> 2) & 3)));
+                    w2[q][ob] = lds4(w2p, row * 4 + (lq ^ ((row >> 2) & 3)));
                 }
-                if (q + 1 < 4) {
-                    dd[nxt][0] = dd[nxt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    rowblock_mma(w1[nxt], x, dd[nxt][0], dd[nxt][1]);          // linear1 of block q+1
-                    if (q + 2 < 4) rowblock_read(buf + (2 * (q + 2)) * 256, lj, lq, w1[cur]);
-                }
+            }
+            dd[0][0] = dd[0][1] = dd[1][0] = dd[1][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            rowblock_mma(w1[0], x, dd[0][0], dd[0][1]);
+            rowblock_mma(w1[1], x, dd[1][0], dd[1][1]);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int hb = (s - 1) * 2 + q;
                 const float4 b1 = *reinterpret_cast<const float4*>(sm + so.b1 + hb * 16 + lq * 4);
-                f32x4 h = dd[cur][0] + dd[cur][1];
+                f32x4 h = dd[q][0] + dd[q][1];
                 h[0] = fmaxf(h[0] + b1.x, 0.f);
                 h[1] = fmaxf(h[1] + b1.y, 0.f);
                 h[2] = fmaxf(h[2] + b1.z, 0.f);
                 h[3] = fmaxf(h[3] + b1.w, 0.f);
                 // linear2 of block q, order (r, ob): consecutive MFMAs hit different accumulators
 #pragma unroll
-                for (int ob = 0; ob < 4; ++ob) acc2[ob] = mfma16(w2[ob].x, h[0], acc2[ob]);
+                for (int ob = 0; ob < 4; ++ob) acc2[ob] = mfma16(w2[q][ob].x, h[0], acc2[ob]);
 #pragma unroll
-                for (int ob = 0; ob < 4; ++ob) acc2[ob] = mfma16(w2[ob].y, h[1], acc2[ob]);
+                for (int ob = 0; ob < 4; ++ob) acc2[ob] = mfma16(w2[q][ob].y, h[1], acc2[ob]);
 #pragma unroll
-                for (int ob = 0; ob < 4; ++ob) acc2[ob] = mfma16(w2[ob].z, h[2], acc2[ob]);
+                for (int ob = 0; ob < 4; ++ob) acc2[ob] = mfma16(w2[q][ob].z, h[2], acc2[ob]);
 #pragma unroll
-                for (int ob = 0; ob < 4; ++ob) acc2[ob] = mfma16(w2[ob].w, h[3], acc2[ob]);
+                for (int ob = 0; ob < 4; ++ob) acc2[ob] = mfma16(w2[q][ob].w, h[3], acc2[ob]);
             }
-            if (c == nffn) {
-                // ---- residual + LayerNorm2 (msdeformattn.py:116-118), write the layer output ----
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < nsteps) ENC_STAGE_STORE(s + 1, wl + ((s + 1) & 1) * CHUNK_F4)
+        __syncthreads();
+    }
+
+    // ---- between the loops no staged registers are live ----
+    if (coop) {
+        // sum the four waves' partial linear2 outputs through the LDS stage that was consumed last (every wave is
+        // past the barrier above, the next stage sits in the other buffer)
+        float* red = reinterpret_cast<float*>(wl + (nhf & 1) * CHUNK_F4);
 #pragma unroll
-                for (int ob = 0; ob < 4; ++ob) {
-                    const float4 b2 = *reinterpret_cast<const float4*>(sm + so.b2 + ob * 16 + lq * 4);
-                    x[ob][0] += acc2[ob][0] + b2.x;
-                    x[ob][1] += acc2[ob][1] + b2.y;
-                    x[ob][2] += acc2[ob][2] + b2.z;
-                    x[ob][3] += acc2[ob][3] + b2.w;
-                }
-                layer_norm_L(x, sm + so.g2, sm + so.be2, lq, eps);
-                if (tok_ok) {
+        for (int ob = 0; ob < 4; ++ob)
+            *reinterpret_cast<float4*>(red + ((wave * 4 + ob) * 64 + lane) * 4) =
+                make_float4(acc2[ob][0], acc2[ob][1], acc2[ob][2], acc2[ob][3]);
+        __syncthreads();
 #pragma unroll
-                    for (int ob = 0; ob < 4; ++ob)
-                        *reinterpret_cast<float4*>(src_out + (int64_t)tok * EC + ob * 16 + lq * 4) =
-                            make_float4(x[ob][0], x[ob][1], x[ob][2], x[ob][3]);
-                }
+        for (int ob = 0; ob < 4; ++ob) {
+            f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float4 v = *reinterpret_cast<const float4*>(red + ((w * 4 + ob) * 64 + lane) * 4);
+                t += f32x4{v.x, v.y, v.z, v.w};
             }
-        } else {
-            // ---- next layer's value_proj and [sampling_offsets | attention_weights] ----
-            const int cc = c - nffn - 1;
-            int blk0 = 0;
-            if (cc == 0) {
+            acc2[ob] = t;
+        }
+        __syncthreads();      // the buffer is a staging target again in the tail loop
+    }
+    // ---- residual + LayerNorm2 (msdeformattn.py:116-118), write the layer output ----
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+        const float4 b2 = *reinterpret_cast<const float4*>(sm + so.b2 + ob * 16 + lq * 4);
+        x[ob][0] += acc2[ob][0] + b2.x;
+        x[ob][1] += acc2[ob][1] + b2.y;
+        x[ob][2] += acc2[ob][2] + b2.z;
+        x[ob][3] += acc2[ob][3] + b2.w;
+    }
+    layer_norm_L(x, sm + so.g2, sm + so.be2, lq, eps);
+    if (tok_ok && (!coop || wave == 0)) {
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+            *reinterpret_cast<float4*>(src_out + (int64_t)tok * EC + ob * 16 + lq * 4) =
+                make_float4(x[ob][0], x[ob][1], x[ob][2], x[ob][3]);
+    }
+
+    // ---- tail stages: next layer's value_proj, then [sampling_offsets | attention_weights] 4 row blocks per stage ----
+    for (int s = nhf + 1; s < nsteps; ++s) {
+        const float4* buf = wl + (s & 1) * CHUNK_F4;
+        {
+            const int sn = min(s + 1, nsteps - 1);
+            ENC_STAGE_LOAD(sn)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int hh = s - nhf - 1;
+        const bool mine = !coop || (hh & 3) == wave;
+        if (hh == 0) {
+            if (mine) {
 #pragma unroll
                 for (int ob = 0; ob < 4; ++ob) {
                     const f32x4 d = rowblock_mm(buf + ob * 256, lj, lq, x);
@@ -240,35 +294,36 @@ __global__ __launch_bounds__(256) void enc_block_kernel(const float* __restrict_
                         *reinterpret_cast<float4*>(value_out + (int64_t)tok * EC + ob * 16 + lq * 4) =
                             make_float4(d[0] + bv.x, d[1] + bv.y, d[2] + bv.z, d[3] + bv.w);
                 }
-                // query = src + pos (msdeformattn.py:124): add the level/position code once
-                const int sp = tk % S;
-#pragma unroll
-                for (int fb = 0; fb < 4; ++fb) {
-                    const float4 pp = *reinterpret_cast<const float4*>(pos + (int64_t)sp * EC + fb * 16 + lq * 4);
-                    x[fb][0] += pp.x; x[fb][1] += pp.y; x[fb][2] += pp.z; x[fb][3] += pp.w;
-                }
-                blk0 = 4;
             }
-            // proj output blocks held by this chunk: chunk cc=0 has blocks 4..7 -> ob 0..3; cc>=1 has 8 each
-            const int ob_base = (cc == 0) ? 0 : 4 + (cc - 1) * 8;
-            for (int j = blk0; j < 8; ++j) {
-                const int ob = ob_base + (j - blk0);
-                if (ob >= nproj_blocks) break;
-                const f32x4 d = rowblock_mm(buf + j * 256, lj, lq, x);
-                const float4 bp = *reinterpret_cast<const float4*>(sm + so.bp + ob * 16 + lq * 4);
-                if (tok_ok)
-                    *reinterpret_cast<float4*>(proj_out + (int64_t)tok * proj_ld + ob * 16 + lq * 4) =
-                        make_float4(d[0] + bp.x, d[1] + bp.y, d[2] + bp.z, d[3] + bp.w);
+            // query = src + pos (msdeformattn.py:124): add the level/position code once
+            const int sp = tk % S;
+#pragma unroll
+            for (int fb = 0; fb < 4; ++fb) {
+                const float4 pp = *reinterpret_cast<const float4*>(pos + (int64_t)sp * EC + fb * 16 + lq * 4);
+                x[fb][0] += pp.x; x[fb][1] += pp.y; x[fb][2] += pp.z; x[fb][3] += pp.w;
+            }
+        } else if (mine) {
+            // proj output row blocks (hh-1)*4 .. +3
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ob = (hh - 1) * 4 + j;
+                if (ob < nproj_blocks) {
+                    const f32x4 d = rowblock_mm(buf + j * 256, lj, lq, x);
+                    const float4 bp = *reinterpret_cast<const float4*>(sm + so.bp + ob * 16 + lq * 4);
+                    if (tok_ok)
+                        *reinterpret_cast<float4*>(proj_out + (int64_t)tok * proj_ld + ob * 16 + lq * 4) =
+                            make_float4(d[0] + bp.x, d[1] + bp.y, d[2] + bp.z, d[3] + bp.w);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < nchunks) ENC_CHUNK_STORE(c + 1, wl + ((c + 1) & 1) * CHUNK_F4)
+        if (s + 1 < nsteps) ENC_STAGE_STORE(s + 1, wl + ((s + 1) & 1) * CHUNK_F4)
         __syncthreads();
     }
 }
 
-#undef ENC_CHUNK_LOAD
-#undef ENC_CHUNK_STORE
+#undef ENC_STAGE_LOAD
+#undef ENC_STAGE_STORE
 
 }  // namespace msm
 
@@ -278,7 +333,7 @@ extern "C" int64_t msm_encoder_block_stream_floats(int d_ffn, int proj_width) {
     const int nffn = d_ffn / 64;
     const int npb = cdiv(proj_width, 16);
     const int nchunks = 1 + nffn + 1 + cdiv(max(npb - 4, 0), 8);
-    return (int64_t)nchunks * CHUNK_F4 * 4;
+    return (int64_t)nchunks * 2 * CHUNK_F4 * 4;
 }
 
 extern "C" int msm_encoder_block_fwd(const float* attn, const float* src, const float* wstream, const float* small,
@@ -307,10 +362,17 @@ extern "C" int msm_encoder_block_fwd(const float* attn, const float* src, const 
     const int n_small = so.bp + proj_width;
     const size_t lds = sizeof(float4) * 2 * CHUNK_F4 + sizeof(float) * (size_t)((n_small + 3) / 4 * 4);
     MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)enc_block_kernel, lds));
-    dim3 grid(cdiv(M, 64)), block(256);
+    // workgroup plan: 4 tiles per normal workgroup; the partial last workgroup and, when they would start a sparsely
+    // filled extra round over the 256 CUs, the workgroups of that round become one cooperative workgroup per tile
+    const int tiles = cdiv(M, 16);
+    int n_normal = tiles / 4;
+    const int extra = n_normal % 256;
+    if (n_normal >= 256 && extra <= 64 && getenv("MSM_ENC_NO_COOP") == nullptr) n_normal -= extra;
+    const int n_coop = tiles - n_normal * 4;
+    dim3 grid(n_normal + n_coop), block(256);
     hipLaunchKernelGGL(enc_block_kernel, grid, block, lds, (hipStream_t)stream, attn, src,
                        reinterpret_cast<const float4*>(wstream), small, so, pos, src_out, value_out, proj_out, M, S, d_ffn / 64,
-                       proj_width / 16, proj_width, eps, n_small);
+                       proj_width / 16, proj_width, eps, n_small, n_normal);
     MSM_CHECK_LAUNCH("msm_encoder_block_fwd");
     return MSM_OK;
 }
