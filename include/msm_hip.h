@@ -164,6 +164,13 @@ int msm_msdeform_attn_enc_fwd(const float* value, const int64_t* spatial_shapes,
                               const int64_t* level_start_index, const float* proj, float* out,
                               int B, int S, int M, int D, int L, int P, void* stream);
 
+/* The same with `value_hm` in HEAD-MAJOR order [B][M][S][D]: the two x-neighbours of a bilinear tap are adjacent in
+ * memory, so a tap row is one contiguous 2*D*4-byte segment (the gather is bound by distinct cache lines per wave
+ * instruction).  D % 4 == 0 and 2*D/4 dividing 256 (or D % 4 != 0 and 2*D dividing 256). */
+int msm_msdeform_attn_enc_hm_fwd(const float* value_hm, const int64_t* spatial_shapes,
+                                 const int64_t* level_start_index, const float* proj, float* out,
+                                 int B, int S, int M, int D, int L, int P, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused token-wise block of one MSDeformAttn encoder layer (msdeformattn.py:122-131):
  *   src_out = LN2(x + linear2(relu(linear1(x)))),  x = LN1(src + output_proj(attn))
@@ -174,11 +181,13 @@ int msm_msdeform_attn_enc_fwd(const float* value, const int64_t* spatial_shapes,
  *   order (unseenobjectswithmeanshift_amd/modeling.py::pack_encoder_block documents the layout);
  *   msm_encoder_block_stream_floats() gives its length.  small: bo,g1,be1 (64 each), b1 (d_ffn), b2,
  *   g2,be2,bv (64 each), bp (proj_width).  d_model is fixed to 64.
+ *   value_heads: 0 -> value_out is token-major [M][64]; h > 0 -> head-major [M/S][h][S][64/h], the layout
+ *   msm_msdeform_attn_enc_hm_fwd reads.
  * ------------------------------------------------------------------------------------------- */
 int64_t msm_encoder_block_stream_floats(int d_ffn, int proj_width);
 int msm_encoder_block_fwd(const float* attn, const float* src, const float* wstream, const float* small,
                           const float* pos, float* src_out, float* value_out, float* proj_out,
-                          int M, int S, int d_ffn, int proj_width, float eps, void* stream);
+                          int M, int S, int d_ffn, int proj_width, int value_heads, float eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Folded key/value projection of one feature level (DEC:575 input_proj + level_embed, DEC:251 "+ pos", AU:134-140

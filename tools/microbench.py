@@ -91,6 +91,10 @@ def enc():
     st = torch.tensor([0, 300, 1500], dtype=torch.int64, device=DEV)
     t = timeit(lambda: ops.ms_deform_attn_encoder(value, ss, st, proj, 8, 4), iters=30)
     print(f"msda enc: {t:7.1f} us", flush=True)
+    # same taps per lane and bytes, but 64-byte instead of 32-byte contiguous segments (4 heads x 16 dims)
+    proj4 = torch.randn(B, S, 144, device=DEV)
+    t = timeit(lambda: ops.ms_deform_attn_encoder(value, ss, st, proj4, 4, 4), iters=30)
+    print(f"msda enc, 4 heads x 16 dims (segment-size experiment): {t:7.1f} us", flush=True)
 
 
 def attn():

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                         EncSmall so, const float* __restrict__ pos,
                                                         float* __restrict__ src_out, float* __restrict__ value_out,
                                                         float* __restrict__ proj_out, int M, int S, int nffn, int nproj_blocks,
-                                                        int proj_ld, float eps, int n_small, int n_normal) {
+                                                        int proj_ld, float eps, int n_small, int n_normal, int value_heads) {
     extern __shared__ __attribute__((aligned(16))) float4 wl[];   // [2][CHUNK_F4] weight chunks, then the small parameters
     float* sm = reinterpret_cast<float*>(wl + 2 * CHUNK_F4);
     for (int i = threadIdx.x; i < n_small; i += 256) sm[i] = small[i];   // biases / LayerNorm vectors: read from LDS in the loop
@@ -290,9 +290,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 for (int ob = 0; ob < 4; ++ob) {
                     const f32x4 d = rowblock_mm(buf + ob * 256, lj, lq, x);
                     const float4 bv = *reinterpret_cast<const float4*>(sm + so.bv + ob * 16 + lq * 4);
-                    if (tok_ok)
-                        *reinterpret_cast<float4*>(value_out + (int64_t)tok * EC + ob * 16 + lq * 4) =
-                            make_float4(d[0] + bv.x, d[1] + bv.y, d[2] + bv.z, d[3] + bv.w);
+                    if (tok_ok) {
+                        // token-major [tok][64], or head-major [b][head][t][64/heads] for msm_msdeform_attn_enc_hm_fwd
+                        const int f = ob * 16 + lq * 4;
+                        int64_t o = (int64_t)tok * EC + f;
+                        if (value_heads) {
+                            const int dh = EC / value_heads, bi = tok / S, ti = tok - bi * S;
+                            o = (((int64_t)bi * value_heads + f / dh) * S + ti) * dh + f % dh;
+                        }
+                        *reinterpret_cast<float4*>(value_out + o) = make_float4(d[0] + bv.x, d[1] + bv.y, d[2] + bv.z, d[3] + bv.w);
+                    }
                 }
             }
             // query = src + pos (msdeformattn.py:124): add the level/position code once
@@ -338,11 +345,13 @@ extern "C" int64_t msm_encoder_block_stream_floats(int d_ffn, int proj_width) {
 
 extern "C" int msm_encoder_block_fwd(const float* attn, const float* src, const float* wstream, const float* small,
                                      const float* pos, float* src_out, float* value_out, float* proj_out, int M, int S,
-                                     int d_ffn, int proj_width, float eps, void* stream) {
+                                     int d_ffn, int proj_width, int value_heads, float eps, void* stream) {
     MSM_REQUIRE(attn && src && wstream && small && src_out, "msm_encoder_block_fwd: null pointer");
     MSM_REQUIRE((value_out == nullptr) == (proj_out == nullptr), "msm_encoder_block_fwd: value_out and proj_out go together");
     MSM_REQUIRE(!value_out || pos, "msm_encoder_block_fwd: pos required when the next layer's projections are produced");
     MSM_REQUIRE(M > 0 && S > 0 && d_ffn > 0 && d_ffn % 64 == 0, "msm_encoder_block_fwd: bad sizes (d_ffn %% 64 == 0)");
+    MSM_REQUIRE(value_heads == 0 || (value_heads > 0 && EC % value_heads == 0 && (EC / value_heads) % 4 == 0 && M % S == 0),
+                "msm_encoder_block_fwd: value_heads=%d needs 64/heads to be a multiple of 4 and M a multiple of S", value_heads);
     MSM_REQUIRE(proj_width % 16 == 0 && proj_width >= 64, "msm_encoder_block_fwd: proj_width=%d must be a multiple of 16, >= 64",
                 proj_width);
     MSM_REQUIRE(((((uintptr_t)attn) | ((uintptr_t)src) | ((uintptr_t)wstream) | ((uintptr_t)small) | ((uintptr_t)src_out) |
@@ -372,7 +381,7 @@ extern "C" int msm_encoder_block_fwd(const float* attn, const float* src, const 
     dim3 grid(n_normal + n_coop), block(256);
     hipLaunchKernelGGL(enc_block_kernel, grid, block, lds, (hipStream_t)stream, attn, src,
                        reinterpret_cast<const float4*>(wstream), small, so, pos, src_out, value_out, proj_out, M, S, d_ffn / 64,
-                       proj_width / 16, proj_width, eps, n_small, n_normal);
+                       proj_width / 16, proj_width, eps, n_small, n_normal, value_heads);
     MSM_CHECK_LAUNCH("msm_encoder_block_fwd");
     return MSM_OK;
 }

@@ -150,6 +150,110 @@ __global__ __launch_bounds__(256) void msda_kernel(const float* __restrict__ val
     }
 }
 
+// ---- encoder form over a HEAD-MAJOR value tensor [B][M][S][D] ------------------------------------------------------
+// Measured on MI355X: the gather is bound by the number of distinct cache lines a wave instruction touches, not by
+// bytes -- with the token-major layout a (query, head) tap is a 32-byte segment (D = 8) and an instruction touches
+// 32 of them; running the same taps as 64-byte segments took 55 us instead of 79 us.  In head-major order the two
+// x-neighbours of a bilinear tap are adjacent in memory, so a group of 2*D/4 lanes owns one (query, head): lane
+// (cx, d4) fetches column w_low + cx, channels 4*d4..+3 -- one contiguous 2*D*4-byte segment per tap row -- and
+// accumulates its own column's share; the two columns are added with one shuffle at the end.  Per lane that is 2
+// loads per sampling point instead of 4.  The producer (msm_encoder_block_fwd, value_head_major = 1) writes this
+// layout directly.
+template <int V>
+__global__ __launch_bounds__(256) void msda_enc_hm_kernel(const float* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                          const int64_t* __restrict__ lstart, const float* __restrict__ proj,
+                                                          float* __restrict__ out, int B, int S, int M, int D, int L, int P) {
+    const int D4 = D / V;
+    const int G = 2 * D4;                       // lanes per (query, head)
+    const int per_img = S * M * G;
+    const int b = blockIdx.x % B;               // XCD-aware: one image's value map stays in one XCD's L2
+    const int idx = (blockIdx.x / B) * 256 + threadIdx.x;
+    const bool live = idx < per_img;            // G divides 256: a group is never split by this bound
+    const int cidx = live ? idx : 0;
+    const int g = cidx % G;
+    const int cx = g / D4, d4 = g - cx * D4;
+    const int t = cidx / G;
+    const int m = t % M;
+    const int qi = t / M;
+
+    int Hs[MAXL], Ws[MAXL], st[MAXL];
+#pragma unroll
+    for (int l = 0; l < MAXL; ++l) {
+        if (l < L) {
+            Hs[l] = (int)shapes[2 * l];
+            Ws[l] = (int)shapes[2 * l + 1];
+            st[l] = (int)lstart[l];
+        } else {
+            Hs[l] = Ws[l] = 1;
+            st[l] = 0;
+        }
+    }
+    const float* vb = value + ((int64_t)b * M + m) * S * D + d4 * V;       // head plane of this image
+    Vec<V> acc;
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc.e[i] = 0.f;
+
+    const int LP = L * P;
+    const float* pr = proj + ((int64_t)b * S + qi) * (M * LP * 3);
+    const float* offp = pr + (int64_t)m * LP * 2;
+    const float* lgp = pr + (int64_t)M * LP * 2 + (int64_t)m * LP;
+    // reference point = centre of pixel qi in its own level, normalised (msdeformattn.py:141-153)
+    int ql = 0;
+#pragma unroll
+    for (int l = 1; l < MAXL; ++l)
+        if (l < L && qi >= st[l]) ql = l;
+    const int local = qi - st[ql];
+    const int ry = local / Ws[ql], rx = local - ry * Ws[ql];
+    const float ref_x = ((float)rx + 0.5f) / (float)Ws[ql];
+    const float ref_y = ((float)ry + 0.5f) / (float)Hs[ql];
+    float mx = -INFINITY;                                                    // softmax over the L*P logits
+    for (int i = 0; i < LP; ++i) mx = fmaxf(mx, lgp[i]);
+    float den = 0.f;
+    for (int i = 0; i < LP; ++i) den += expf(lgp[i] - mx);
+    const float rden = 1.0f / den;
+    // (Tried and measured slower, 91-99 us against 80 us: v_exp_f32 numerators, float2 offsets, a single predicate
+    // instead of the early exits, 32-bit indices -- the early `continue`s skip most of the per-point work of the
+    // lane whose column is out of range and keep the body short.)
+#pragma unroll
+    for (int l = 0; l < MAXL; ++l) {
+        if (l >= L) break;
+        const int H = Hs[l], W = Ws[l];
+        const float* vl = vb + (int64_t)st[l] * D;
+        for (int p = 0; p < P; ++p) {
+            const int i = l * P + p;
+            const float lx = ref_x + offp[2 * i] / (float)W;                 // ms_deform_attn.py:107-109
+            const float ly = ref_y + offp[2 * i + 1] / (float)H;
+            const float wgt = expf(lgp[i] - mx) * rden;
+            const float h_im = ly * (float)H - 0.5f, w_im = lx * (float)W - 0.5f;
+            if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) continue;   // cuh:293
+            const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+            const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+            const int xw = w_low + cx;                                       // this lane's column
+            const float wxw = (cx ? lw : 1.f - lw) * wgt;
+            if (xw < 0 || xw > W - 1) continue;
+            Vec<V> vt, vbm;
+#pragma unroll
+            for (int c = 0; c < V; ++c) vt.e[c] = vbm.e[c] = 0.f;
+            if (h_low >= 0) vt = ldv<V>(vl + ((int64_t)h_low * W + xw) * D);
+            if (h_low + 1 <= H - 1) vbm = ldv<V>(vl + ((int64_t)(h_low + 1) * W + xw) * D);
+            const float wt = (1.f - lh) * wxw, wb = lh * wxw;
+#pragma unroll
+            for (int c = 0; c < V; ++c) acc.e[c] += wt * vt.e[c] + wb * vbm.e[c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < V; ++c) acc.e[c] += __shfl_xor(acc.e[c], D4, 64);    // left + right column
+    if (live && cx == 0) {
+        float* op = out + (((int64_t)b * S + qi) * M + m) * D + d4 * V;
+        if constexpr (V == 4) {
+            *reinterpret_cast<float4*>(op) = make_float4(acc.e[0], acc.e[1], acc.e[2], acc.e[3]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < V; ++c) op[c] = acc.e[c];
+        }
+    }
+}
+
 // ---- backward (training): reference col2im kernels, cuh:306-925 (bilinear helper cuh:92-239) -------------------
 // Same lane mapping as the forward: a lane owns V channels of one (image, query, head), so the 4 corner reads
 // are 16-byte loads and the scatter into grad_value is V hardware fp32 atomics per corner
@@ -326,5 +430,27 @@ extern "C" int msm_msdeform_attn_bwd(const float* value, const int64_t* spatial_
     else MSDA_BWD(1, false);
 #undef MSDA_BWD
     MSM_CHECK_LAUNCH("msm_msdeform_attn_bwd");
+    return MSM_OK;
+}
+
+extern "C" int msm_msdeform_attn_enc_hm_fwd(const float* value_hm, const int64_t* spatial_shapes,
+                                            const int64_t* level_start_index, const float* proj, float* out, int B, int S,
+                                            int M, int D, int L, int P, void* stream) {
+    MSM_REQUIRE(value_hm && spatial_shapes && level_start_index && proj && out, "msm_msdeform_attn_enc_hm_fwd: null pointer");
+    int rc = msda_common_checks("msm_msdeform_attn_enc_hm_fwd", value_hm, out, B, S, M, D, L, S, P);
+    if (rc != MSM_OK) return rc;
+    const int V = (D % 4 == 0) ? 4 : 1;
+    const int G = 2 * (D / V);
+    MSM_REQUIRE(256 % G == 0, "msm_msdeform_attn_enc_hm_fwd: D=%d: 2*D/%d lanes per head must divide 256", D, V);
+    MSM_REQUIRE((int64_t)S * D < ((int64_t)1 << 31), "msm_msdeform_attn_enc_hm_fwd: S*D must fit 31 bits");
+    const int64_t per_img = (int64_t)S * M * G;
+    dim3 grid((unsigned)(((per_img + 255) / 256) * B)), block(256);
+    if (V == 4)
+        hipLaunchKernelGGL((msda_enc_hm_kernel<4>), grid, block, 0, (hipStream_t)stream, value_hm, spatial_shapes,
+                           level_start_index, proj, out, B, S, M, D, L, P);
+    else
+        hipLaunchKernelGGL((msda_enc_hm_kernel<1>), grid, block, 0, (hipStream_t)stream, value_hm, spatial_shapes,
+                           level_start_index, proj, out, B, S, M, D, L, P);
+    MSM_CHECK_LAUNCH("msm_msdeform_attn_enc_hm_fwd");
     return MSM_OK;
 }

@@ -749,8 +749,10 @@ class MSDeformAttnPixelDecoder(nn.Module):
             for l, layer in enumerate(layers):
                 attn = ops.ms_deform_attn_encoder(value, ss, starts, proj, layer.self_attn.n_heads, layer.self_attn.n_points)
                 stream, small, d_ffn, pw = packed[l]
+                # layers 1.. read a head-major value (written so by the previous block): 64-byte instead of 32-byte taps
                 src, value, proj = ops.encoder_block(attn, src, stream, small, d_ffn, pw, pos=lvl_pos, tokens_per_image=S_tok,
-                                                     want_next=l + 1 < len(layers), eps=layer.norm1.eps)
+                                                     want_next=l + 1 < len(layers), eps=layer.norm1.eps,
+                                                     value_heads=layers[l + 1].self_attn.n_heads if l + 1 < len(layers) else 0)
         else:
             for layer in layers:
                 src = layer.forward_tokens(src, lvl_pos, ss, starts)

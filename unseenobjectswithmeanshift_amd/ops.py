@@ -374,11 +374,21 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
 
 
 def ms_deform_attn_encoder(value, spatial_shapes, level_start_index, proj, heads, n_points):
-    """Encoder self-attention form: value (N,S,C), proj (N,S,heads*L*P*3) raw offsets+logits."""
+    """Encoder self-attention form: proj (N,S,heads*L*P*3) raw offsets+logits; value (N,S,C) token-major, or
+    (N,heads,S,C/heads) head-major as written by encoder_block(value_heads=heads).  Returns (N,S,C)."""
     _c(value, "value"), _c(proj, "proj")
     _c(spatial_shapes, "spatial_shapes", torch.int64), _c(level_start_index, "level_start_index", torch.int64)
-    N, S, C = value.shape
     L = spatial_shapes.shape[0]
+    if value.dim() == 4:
+        N, M, S, D = value.shape
+        if M != heads:
+            raise RuntimeError("head-major value must be (N, heads, S, C/heads)")
+        out = torch.empty((N, S, M * D), device=value.device, dtype=torch.float32)
+        rc = lib().msm_msdeform_attn_enc_hm_fwd(_p(value), _p(spatial_shapes), _p(level_start_index), _p(proj), _p(out),
+                                                N, S, M, D, L, n_points, _stream())
+        check(rc, "msm_msdeform_attn_enc_hm_fwd")
+        return out
+    N, S, C = value.shape
     out = torch.empty((N, S, C), device=value.device, dtype=torch.float32)
     rc = lib().msm_msdeform_attn_enc_fwd(_p(value), _p(spatial_shapes), _p(level_start_index), _p(proj), _p(out),
                                          N, S, heads, C // heads, L, n_points, _stream())
@@ -492,18 +502,20 @@ def pack_encoder_block(wo, w1, w2, wv=None, wp=None):
     return torch.cat(blocks, 0).reshape(-1).contiguous()
 
 
-def encoder_block(attn, src, wstream, small, d_ffn, proj_width, *, pos=None, tokens_per_image=None, want_next=True, eps=1e-5):
+def encoder_block(attn, src, wstream, small, d_ffn, proj_width, *, pos=None, tokens_per_image=None, want_next=True,
+                  value_heads=0, eps=1e-5):
     """One fused encoder-layer tail.  attn/src (B,S,64).  Returns (src_out, value_out, proj_out) with the
-    last two None when want_next is False."""
+    last two None when want_next is False.  value_heads = h > 0: value_out is head-major (B,h,S,64/h)."""
     _c(attn, "attn"), _c(src, "src"), _c(wstream, "wstream"), _c(small, "small"), _c(pos, "pos")
     B, S, C = src.shape
     M = B * S
     src_out = torch.empty_like(src)
     value_out = proj_out = None
     if want_next:
-        value_out = torch.empty_like(src)
+        value_out = torch.empty((B, value_heads, S, C // value_heads), device=src.device, dtype=torch.float32) \
+            if value_heads else torch.empty_like(src)
         proj_out = torch.empty((B, S, proj_width), device=src.device, dtype=torch.float32)
     rc = lib().msm_encoder_block_fwd(_p(attn), _p(src), _p(wstream), _p(small), _p(pos), _p(src_out), _p(value_out),
-                                     _p(proj_out), M, tokens_per_image or S, d_ffn, proj_width, eps, _stream())
+                                     _p(proj_out), M, tokens_per_image or S, d_ffn, proj_width, int(value_heads), eps, _stream())
     check(rc, "msm_encoder_block_fwd")
     return src_out, value_out, proj_out
