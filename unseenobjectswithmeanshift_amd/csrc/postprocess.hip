@@ -71,38 +71,51 @@ __global__ __launch_bounds__(256) void inst_upsample_kernel(const float* __restr
     unsigned int cnt = 0;
     int xmin = 0x7fffffff, ymin = 0x7fffffff, xmax = -1, ymax = -1;
     const bool vec = (W % 4) == 0;     // 4 pixels per thread, one 16-byte store
-    for (int y = y0; y < y1; ++y) {
-        int ya, yb;
-        float ly;
-        src_index(y, sy, h, ya, yb, ly);
-        const float hy = 1.f - ly;
-        const float* ra = src + ya * w;
-        const float* rb = src + yb * w;
-        const int step = vec ? 4 : 1;
-        for (int x0 = (blockIdx.x * 256 + threadIdx.x) * step; x0 < W; x0 += gridDim.x * 256 * step) {
+    const int step = vec ? 4 : 1;
+    for (int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * step; x0 < W; x0 += gridDim.x * blockDim.x * step) {
+        // the column taps of this thread's pixels are the same for every row of the strip
+        int xa[4], xb[4];
+        float lx[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) src_index(min(x0 + e, W - 1), sx, w, xa[e], xb[e], lx[e]);
+        float fsum = 0.f;              // <= 4 * rows_per_block sigmoids in fp32, then into the double total
+        int xhit_min = 0x7fffffff, xhit_max = -1;
+        for (int y = y0; y < y1; ++y) {
+            int ya, yb;
+            float ly;
+            src_index(y, sy, h, ya, yb, ly);
+            const float hy = 1.f - ly;
+            const float* ra = src + ya * w;
+            const float* rb = src + yb * w;
             float o[4];
+            bool any = false;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 o[e] = 0.f;
                 if (e < step) {
-                    const int x = x0 + e;
-                    int xa, xb;
-                    float lx;
-                    src_index(x, sx, w, xa, xb, lx);
-                    const float hx = 1.f - lx;
-                    const float m = hy * (hx * ra[xa] + lx * ra[xb]) + ly * (hx * rb[xa] + lx * rb[xb]);
+                    const float hx = 1.f - lx[e];
+                    const float m = hy * (hx * ra[xa[e]] + lx[e] * ra[xb[e]]) + ly * (hx * rb[xa[e]] + lx[e] * rb[xb[e]]);
                     if (m > 0.f) {
                         o[e] = 1.f;
-                        sum += (double)(1.0f / (1.0f + expf(-m)));
+                        // sigmoid through v_exp_f32 / v_rcp_f32 (relative error ~1e-6; the score is a mean over the mask)
+                        fsum += __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * m));
                         cnt += 1;
-                        xmin = min(xmin, x); xmax = max(xmax, x);
-                        ymin = min(ymin, y); ymax = max(ymax, y);
+                        xhit_min = min(xhit_min, x0 + e);
+                        xhit_max = max(xhit_max, x0 + e);
+                        any = true;
                     }
                 }
+            }
+            if (any) {
+                ymin = min(ymin, y);
+                ymax = max(ymax, y);
             }
             if (vec) *reinterpret_cast<float4*>(dst + (int64_t)y * W + x0) = make_float4(o[0], o[1], o[2], o[3]);
             else dst[(int64_t)y * W + x0] = o[0];
         }
+        sum += (double)fsum;
+        xmin = min(xmin, xhit_min);
+        xmax = max(xmax, xhit_max);
     }
     // wave reduce, then one set of atomics per wave
 #pragma unroll
@@ -172,8 +185,10 @@ extern "C" int msm_instance_postprocess(const float* mask_logits, const int32_t*
     const int n = B * T;
     hipLaunchKernelGGL(inst_init_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, acc, n);
     const int rows = 16;
-    dim3 grid(cdiv((W % 4 == 0) ? W / 4 : W, 256), cdiv(H, rows), n);
-    hipLaunchKernelGGL(inst_upsample_kernel, grid, dim3(256), 0, st, mask_logits, query_index, pred_masks, acc, Q, T, h, w, H,
+    const int cols = (W % 4 == 0) ? W / 4 : W;                 // threads needed across a row
+    const int threads = min(256, cdiv(cols, 64) * 64);          // whole waves, no idle wave (640 px -> 192 threads)
+    dim3 grid(cdiv(cols, threads), cdiv(H, rows), n);
+    hipLaunchKernelGGL(inst_upsample_kernel, grid, dim3(threads), 0, st, mask_logits, query_index, pred_masks, acc, Q, T, h, w, H,
                        W, rows);
     hipLaunchKernelGGL(inst_finish_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, acc, class_scores, mask_score, boxes, n);
     MSM_CHECK_LAUNCH("msm_instance_postprocess");
