@@ -166,7 +166,9 @@ int msm_msdeform_attn_enc_fwd(const float* value, const int64_t* spatial_shapes,
 
 /* The same with `value_hm` in HEAD-MAJOR order [B][M][S][D]: the two x-neighbours of a bilinear tap are adjacent in
  * memory, so a tap row is one contiguous 2*D*4-byte segment (the gather is bound by distinct cache lines per wave
- * instruction).  D % 4 == 0 and 2*D/4 dividing 256 (or D % 4 != 0 and 2*D dividing 256). */
+ * instruction).  D % 4 == 0 and 2*D/4 dividing 256 (or D % 4 != 0 and 2*D dividing 256).
+ * msm_value_to_head_major_f32 converts a token-major value [B][S][M][D]; msm_encoder_block_fwd can write the layout itself. */
+int msm_value_to_head_major_f32(const float* value, float* value_hm, int B, int S, int M, int D, void* stream);
 int msm_msdeform_attn_enc_hm_fwd(const float* value_hm, const int64_t* spatial_shapes,
                                  const int64_t* level_start_index, const float* proj, float* out,
                                  int B, int S, int M, int D, int L, int P, void* stream);

@@ -222,6 +222,7 @@ def test_msda_realistic_and_fused(golden):
     close(got, ref, rtol=1e-4, atol=1e-5)
     # head-major value layout (N, M, S, D): same function, two taps per 64-byte segment
     value_hm = T("r_value").permute(0, 2, 1, 3).contiguous()
+    assert torch.equal(ops().value_to_head_major(value.contiguous().to(DEV), M).cpu(), value_hm)
     got_hm = ops().ms_deform_attn_encoder(value_hm.to(DEV), shapes.to(DEV), start.to(DEV), proj.to(DEV), M, P)
     close(got_hm, ref, rtol=1e-4, atol=1e-5)
 

@@ -13,6 +13,8 @@
 // re-reads the int64 shapes inside the point loop).  In the encoder form the softmax over the L*P
 // logits and the sampling-location arithmetic are done in registers, so sampling_locations and
 // attention_weights (7.3 MB per layer-image at 640x480) never exist in memory.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace msm {
@@ -254,6 +256,155 @@ __global__ __launch_bounds__(256) void msda_enc_hm_kernel(const float* __restric
     }
 }
 
+// Specialisation of the head-major form for D = 8 (the pixel decoder: 64 channels / 8 heads), L*P <= 16.
+// The 4 lanes of a (query, head) group are an aligned quad.  The generic kernel above makes every lane repeat the
+// group's softmax and sampling-location arithmetic (two fp32 divisions and an exp per point) and is VALU-bound
+// (80 us).  Here lane g of the quad does that arithmetic only for points g, g+4, g+8, g+12, and the quad exchanges
+// (x, y, weight) with DPP quad broadcasts: a third of the divisions/exps per lane plus 3 one-cycle moves per point.
+__device__ __forceinline__ float quad_bcast(float v, int src) {   // src is a compile-time constant after unrolling
+    const int iv = __float_as_int(v);
+    int r;
+    switch (src) {
+        case 0: r = __builtin_amdgcn_mov_dpp(iv, 0x00, 0xf, 0xf, true); break;
+        case 1: r = __builtin_amdgcn_mov_dpp(iv, 0x55, 0xf, 0xf, true); break;
+        case 2: r = __builtin_amdgcn_mov_dpp(iv, 0xAA, 0xf, 0xf, true); break;
+        default: r = __builtin_amdgcn_mov_dpp(iv, 0xFF, 0xf, 0xf, true); break;
+    }
+    return __int_as_float(r);
+}
+__device__ __forceinline__ float quad_max(float v) {
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)));   // quad_perm [1,0,3,2]
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true)));   // [2,3,0,1]
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));
+    return v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));
+}
+
+__global__ __launch_bounds__(256) void msda_enc_hm8_kernel(const float* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                           const int64_t* __restrict__ lstart, const float* __restrict__ proj,
+                                                           float* __restrict__ out, int B, int S, int M, int L, int P) {
+    constexpr int D = 8;
+    const int per_img = S * M * 4;
+    const int b = blockIdx.x % B;
+    const int idx = (blockIdx.x / B) * 256 + threadIdx.x;
+    const bool live = idx < per_img;            // whole quads live or dead together
+    const int cidx = live ? idx : 0;
+    const int g = cidx & 3;
+    const int cx = g >> 1, d4 = g & 1;
+    const int t = cidx >> 2;
+    const int m = t % M;
+    const int qi = t / M;
+
+    int Hs[MAXL], Ws[MAXL], st[MAXL];           // level geometry: wave-uniform, stays in SGPRs
+#pragma unroll
+    for (int l = 0; l < MAXL; ++l) {
+        if (l < L) {
+            Hs[l] = (int)shapes[2 * l];
+            Ws[l] = (int)shapes[2 * l + 1];
+            st[l] = (int)lstart[l];
+        } else {
+            Hs[l] = Ws[l] = 1;
+            st[l] = 0x7fffffff;
+        }
+    }
+    const int LP = L * P;
+    const float* pr = proj + ((int64_t)b * S + qi) * (M * LP * 3);
+    const float* offp = pr + (int64_t)m * LP * 2;
+    const float* lgp = pr + (int64_t)M * LP * 2 + (int64_t)m * LP;
+    // reference point = centre of pixel qi in its own level, normalised (msdeformattn.py:141-153)
+    int qW = Ws[0], qH = Hs[0], qs = 0;
+#pragma unroll
+    for (int l = 1; l < MAXL; ++l)
+        if (qi >= st[l]) { qW = Ws[l]; qH = Hs[l]; qs = st[l]; }
+    const int local = qi - qs;
+    const int ry = local / qW, rx = local - ry * qW;
+    const float ref_x = ((float)rx + 0.5f) / (float)qW;
+    const float ref_y = ((float)ry + 0.5f) / (float)qH;
+
+    // ---- this lane's share of the points: i = slot*4 + g ----
+    float px[4], py[4], pw[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int slot = 0; slot < 4; ++slot) {
+        const int i = slot * 4 + g;
+        const bool has = i < LP;
+        const int ic = has ? i : 0;
+        int W = Ws[0], H = Hs[0];               // level of point i: l = i / P
+#pragma unroll
+        for (int l = 1; l < MAXL; ++l)
+            if (l < L && ic >= l * P) { W = Ws[l]; H = Hs[l]; }
+        const float lg = has ? lgp[ic] : -INFINITY;
+        const float lx = ref_x + offp[2 * ic] / (float)W;                    // ms_deform_attn.py:107-109
+        const float ly = ref_y + offp[2 * ic + 1] / (float)H;
+        px[slot] = lx * (float)W - 0.5f;                                     // w_im, cuh:290-291
+        py[slot] = ly * (float)H - 0.5f;                                     // h_im
+        pw[slot] = lg;
+        mx = fmaxf(mx, lg);
+    }
+    mx = quad_max(mx);                                                       // softmax over the L*P logits (:103)
+    float den = 0.f;
+#pragma unroll
+    for (int slot = 0; slot < 4; ++slot) {
+        pw[slot] = expf(pw[slot] - mx);                                      // exp(-inf) = 0 for the padding slots
+        den += pw[slot];
+    }
+    const float rden = 1.0f / quad_sum(den);
+
+    // ---- gather: every lane walks all points, taking (x, y, w) from the owner lane of each ----
+    const float* vb = value + ((int64_t)b * M + m) * S * D + d4 * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i < LP) {
+            int W = Ws[0], H = Hs[0], s0 = 0;   // uniform: scalar selects
+#pragma unroll
+            for (int l = 1; l < MAXL; ++l)
+                if (l < L && i >= l * P) { W = Ws[l]; H = Hs[l]; s0 = st[l]; }
+            const float w_im = quad_bcast(px[i >> 2], i & 3);
+            const float h_im = quad_bcast(py[i >> 2], i & 3);
+            const float wgt = quad_bcast(pw[i >> 2], i & 3) * rden;
+            if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {              // cuh:293
+                const float hf = floorf(h_im), wf = floorf(w_im);
+                const int h_low = (int)hf, xw = (int)wf + cx;                // this lane's column
+                if (xw >= 0 && xw <= W - 1) {
+                    const float lh = h_im - hf, lw = w_im - wf;
+                    const float wxw = (cx ? lw : 1.f - lw) * wgt;
+                    const float* vp = vb + (int64_t)(s0 + h_low * W + xw) * D;
+                    float4 vt = make_float4(0.f, 0.f, 0.f, 0.f), vbm = vt;
+                    if (h_low >= 0) vt = *reinterpret_cast<const float4*>(vp);
+                    if (h_low + 1 <= H - 1) vbm = *reinterpret_cast<const float4*>(vp + W * D);
+                    const float wt = (1.f - lh) * wxw, wb = lh * wxw;
+                    acc.x += wt * vt.x + wb * vbm.x;
+                    acc.y += wt * vt.y + wb * vbm.y;
+                    acc.z += wt * vt.z + wb * vbm.z;
+                    acc.w += wt * vt.w + wb * vbm.w;
+                }
+            }
+        }
+    }
+    // left + right column: lanes g and g^2
+    acc.x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc.x), 0x4E, 0xf, 0xf, true));
+    acc.y += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc.y), 0x4E, 0xf, 0xf, true));
+    acc.z += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc.z), 0x4E, 0xf, 0xf, true));
+    acc.w += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc.w), 0x4E, 0xf, 0xf, true));
+    if (live && cx == 0) *reinterpret_cast<float4*>(out + (((int64_t)b * S + qi) * M + m) * D + d4 * 4) = acc;
+}
+
+// value [B][S][M][D] (token-major, what a value_proj GEMM writes) -> [B][M][S][D] (head-major)
+__global__ __launch_bounds__(256) void value_to_hm_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t total4,
+                                                          int S, int M, int D4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int d4 = (int)(i % D4);
+        int64_t r = i / D4;
+        const int m = (int)(r % M);
+        r /= M;
+        const int t = (int)(r % S);
+        const int64_t b = r / S;
+        reinterpret_cast<float4*>(out)[((b * M + m) * S + t) * D4 + d4] = reinterpret_cast<const float4*>(in)[i];
+    }
+}
+
 // ---- backward (training): reference col2im kernels, cuh:306-925 (bilinear helper cuh:92-239) -------------------
 // Same lane mapping as the forward: a lane owns V channels of one (image, query, head), so the 4 corner reads
 // are 16-byte loads and the scatter into grad_value is V hardware fp32 atomics per corner
@@ -445,12 +596,26 @@ extern "C" int msm_msdeform_attn_enc_hm_fwd(const float* value_hm, const int64_t
     MSM_REQUIRE((int64_t)S * D < ((int64_t)1 << 31), "msm_msdeform_attn_enc_hm_fwd: S*D must fit 31 bits");
     const int64_t per_img = (int64_t)S * M * G;
     dim3 grid((unsigned)(((per_img + 255) / 256) * B)), block(256);
-    if (V == 4)
+    if (D == 8 && L * P <= 16 && (int64_t)S * D < ((int64_t)1 << 31) && getenv("MSM_MSDA_GENERIC") == nullptr)
+        hipLaunchKernelGGL(msda_enc_hm8_kernel, grid, block, 0, (hipStream_t)stream, value_hm, spatial_shapes,
+                           level_start_index, proj, out, B, S, M, L, P);
+    else if (V == 4)
         hipLaunchKernelGGL((msda_enc_hm_kernel<4>), grid, block, 0, (hipStream_t)stream, value_hm, spatial_shapes,
                            level_start_index, proj, out, B, S, M, D, L, P);
     else
         hipLaunchKernelGGL((msda_enc_hm_kernel<1>), grid, block, 0, (hipStream_t)stream, value_hm, spatial_shapes,
                            level_start_index, proj, out, B, S, M, D, L, P);
     MSM_CHECK_LAUNCH("msm_msdeform_attn_enc_hm_fwd");
+    return MSM_OK;
+}
+
+extern "C" int msm_value_to_head_major_f32(const float* value, float* value_hm, int B, int S, int M, int D, void* stream) {
+    MSM_REQUIRE(value && value_hm && value != value_hm, "msm_value_to_head_major_f32: null or aliased pointer");
+    MSM_REQUIRE(B > 0 && S > 0 && M > 0 && D > 0 && D % 4 == 0, "msm_value_to_head_major_f32: D=%d must be a multiple of 4", D);
+    MSM_REQUIRE(((((uintptr_t)value) | ((uintptr_t)value_hm)) & 15) == 0, "msm_value_to_head_major_f32: pointers must be 16-byte aligned");
+    const int64_t total4 = (int64_t)B * S * M * (D / 4);
+    hipLaunchKernelGGL(value_to_hm_kernel, dim3((unsigned)min((int64_t)2048, (total4 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, value, value_hm, total4, S, M, D / 4);
+    MSM_CHECK_LAUNCH("msm_value_to_head_major_f32");
     return MSM_OK;
 }

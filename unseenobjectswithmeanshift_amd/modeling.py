@@ -742,7 +742,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
             # value / sampling projections (the 1024-wide FFN activation never leaves registers)
             packed = self._packed_encoder(dev)
             a0 = layers[0].self_attn
-            value = ops.gemm(src, a0.value_proj.weight, a0.value_proj.bias)
+            value = ops.value_to_head_major(ops.gemm(src, a0.value_proj.weight, a0.value_proj.bias), a0.n_heads)
             w, b = a0._proj_weights()
             proj = ops.gemm(src, w, b, a2=lvl_pos)
             S_tok = src.shape[1]

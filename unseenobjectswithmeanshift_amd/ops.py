@@ -373,6 +373,16 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     return gv, gl, gw
 
 
+def value_to_head_major(value, heads):
+    """(N, S, C) token-major value -> (N, heads, S, C/heads), the layout ms_deform_attn_encoder gathers fastest from."""
+    _c(value, "value")
+    N, S, C = value.shape
+    out = torch.empty((N, heads, S, C // heads), device=value.device, dtype=torch.float32)
+    rc = lib().msm_value_to_head_major_f32(_p(value), _p(out), N, S, heads, C // heads, _stream())
+    check(rc, "msm_value_to_head_major_f32")
+    return out
+
+
 def ms_deform_attn_encoder(value, spatial_shapes, level_start_index, proj, heads, n_points):
     """Encoder self-attention form: proj (N,S,heads*L*P*3) raw offsets+logits; value (N,S,C) token-major, or
     (N,heads,S,C/heads) head-major as written by encoder_block(value_heads=heads).  Returns (N,S,C)."""
