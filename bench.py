@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sparse-taps", action="store_true", help="skip mask rows that feed no attention-mask tap")
+    ap.add_argument("--overlap-kv", type=int, default=-1, help="1/0: K/V projections on a side stream (default: the decoder's own default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -101,6 +102,8 @@ def main():
 
     model = build_model(dev)
     model.sem_seg_head.predictor.sparse_taps = args.sparse_taps
+    if args.overlap_kv >= 0:
+        model.sem_seg_head.predictor.overlap_kv = bool(args.overlap_kv)
     # weak scaling: the global batch is world*8 images, rank r owns images [r*8, (r+1)*8)
     lo, hi = shard_range(world * BATCH, world, rank)
     feats = {k: v.to(dev) for k, v in syn.synth_backbone_features(hi - lo, H, W, seed=10 + rank).items()}

@@ -142,8 +142,9 @@ def test_decoder_execution_variants_agree():
     x, mf = syn.synth_decoder_inputs(2, 64, 96, seed=7)
     xd, mfd = [t.to(DEV) for t in x], mf.to(DEV)
     ref = dec(xd, mfd)
-    dec.overlap_kv = False
+    dec.overlap_kv = not dec.overlap_kv
     a = dec(xd, mfd)
+    dec.overlap_kv = not dec.overlap_kv
     assert torch.equal(a["pred_masks"], ref["pred_masks"]) and torch.equal(a["pred_logits"], ref["pred_logits"])
     dec.fold_kv = False
     b = dec(xd, mfd)

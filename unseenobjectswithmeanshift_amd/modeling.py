@@ -327,7 +327,7 @@ class MeanShiftTransformerDecoder(nn.Module):
             self._tails_cache = (key, {k: [ops.dec_pack_weight(w.contiguous()) for w in ws] for k, ws in groups.items()})
         return self._tails_cache[1]
 
-    def _forward_fused(self, xs, sizes, kv_w, kv_c, mask_features, out, qpos):
+    def _forward_fused(self, xs, sizes, kv_w, kv_c, mask_features, out, qpos, kv_all=None, kv_ready=None):
         """Same arithmetic as the loop in forward(), with the row-local ops of a layer in three launches:
         heads (+ next cross-attention query) -> mask step -> K/V GEMM -> cross attention -> post_cross (out_proj, LN,
         self-attention in-projection) -> self attention -> post_self (out_proj, LN, FFN by hidden chunk)."""
@@ -365,7 +365,11 @@ class MeanShiftTransformerDecoder(nn.Module):
             ca = self.transformer_cross_attention_layers[i]
             sa = self.transformer_self_attention_layers[i]
             ff = self.transformer_ffn_layers[i]
-            kv = ops.kv_project(xs[lvl], kv_w[i], kv_c[i])            # (B, hw, 2E) = [K | V]
+            if kv_all is not None:
+                torch.cuda.current_stream().wait_event(kv_ready[i])            # join for layer i only
+                kv = kv_all[i]
+            else:
+                kv = ops.kv_project(xs[lvl], kv_w[i], kv_c[i])        # (B, hw, 2E) = [K | V]
             o = ops.hypersphere_attention(q, kv[..., :E], kv[..., E:], H, masked=attn, row_any=row_any, kappa=float(KAPPA))
             x, qk, v = ops.dec_post_cross(o, out, qpos, pk["cross_o"][i], ca.meanshift_attn.out_proj.bias, ca.norm.weight,
                                           ca.norm.bias, pk["self_in"][i], sa.self_attn.in_proj_bias)
@@ -425,8 +429,11 @@ class MeanShiftTransformerDecoder(nn.Module):
         full = self.aux_outputs
         L = self.num_layers
         pred_cls, pred_mask = [], []
-        if self.fused_tails and self.fold_kv and kv_all is None:
-            return self._forward_fused(xs, sizes, kv_w, kv_c, mask_features, out, qpos)
+        if self.fused_tails and self.fold_kv:
+            res = self._forward_fused(xs, sizes, kv_w, kv_c, mask_features, out, qpos, kv_all, kv_ready)
+            if kv_all is not None:
+                self._side.wait_stream(torch.cuda.current_stream())   # side-stream buffers are not recycled under us
+            return res
         d = ops.layernorm(out, self.decoder_norm.weight, self.decoder_norm.bias)
         cls, m, attn, row_any = self._heads(d, mask_features, sizes[0], full or L == 0, full or L == 0)
         pred_cls.append(cls)
