@@ -194,11 +194,13 @@ int msm_encoder_block_fwd(const float* attn, const float* src, const float* wstr
 /* ---------------------------------------------------------------------------------------------
  * Folded key/value projection of one feature level (DEC:575 input_proj + level_embed, DEC:251 "+ pos", AU:134-140
  * k/v in-projection -- everything affine in the level feature folded on the host):
- *   out [B][HW][N] = x^T w^T + cmat,  x [B][C = 64][HW] (NCHW), w [N][64], cmat [HW][N] shared by the batch,
- *   N in {256, 512} (512 = [K | V] of one cross-attention layer).
+ *   out [B][HW][N] = x^T w^T + cmat,  w [N][64], cmat [HW][N] shared by the batch,
+ *   N in {256, 512} (512 = [K | V] of one cross-attention layer).  x: image b starts at x + b*x_batch_stride and is
+ *   [C = 64][HW] (x_tokens = 0, NCHW) or [HW][64] (x_tokens = 1: token-major = torch channels_last, e.g. a slice of
+ *   the pixel decoder's token buffer, so no transpose pass is needed).
  * ------------------------------------------------------------------------------------------- */
 int msm_kv_project_f32(const float* x, const float* w, const float* cmat, float* out,
-                       int B, int C, int HW, int N, void* stream);
+                       int B, int C, int HW, int N, int x_tokens, int64_t x_batch_stride, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused row-local tails of one decoder layer on the query matrix [rows = B*Q][E], E fixed to 256.  Row r uses

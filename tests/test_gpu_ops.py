@@ -319,6 +319,12 @@ def test_kv_project(B, H, W, N):
     got = ops().kv_project(x.to(DEV), w.to(DEV), c.to(DEV))
     ref = torch.einsum("bkp,nk->bpn", x.double().flatten(2), w.double()) + c.double()
     closed(got, ref, rtol=1e-5, atol=2e-5)
+    # token-major (channels_last) input inside a wider token buffer, as the pixel decoder hands it over
+    buf = torch.zeros(B, H * W + 7, 64, device=DEV)
+    buf[:, 3:3 + H * W] = x.flatten(2).transpose(1, 2).to(DEV)
+    view = buf[:, 3:3 + H * W].view(B, H, W, 64).permute(0, 3, 1, 2)
+    assert ops().is_token_major(view) and not view.is_contiguous()
+    closed(ops().kv_project(view, w.to(DEV), c.to(DEV)), ref, rtol=1e-5, atol=2e-5)
 
 
 def _start(shapes):

@@ -28,7 +28,7 @@ constexpr int KP_W = 16;             // waves per workgroup (one workgroup per C
 
 __global__ __launch_bounds__(KP_W * 64) void kv_project_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ cmat, float* __restrict__ out, int B,
-                                                         int HW, int N) {
+                                                         int HW, int N, int tokens, int64_t x_sb) {
     extern __shared__ __attribute__((aligned(16))) float wl[];   // [N][KP_LD]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -55,10 +55,20 @@ __global__ __launch_bounds__(KP_W * 64) void kv_project_kernel(const float* __re
     auto load_x = [&](int u, float (&xv)[16]) {
         const int img = (u / halves) % B, tile = u / (halves * B);
         const int p = min(tile * 16 + lj, HW - 1);
-        // B operand: x[img][k = lq*16 + s][p], s = 0..15
-        const float* xp = x + ((int64_t)img * KP_K + lq * 16) * HW + p;
+        // B operand: x[img][k = lq*16 + s][p], s = 0..15 (NCHW), or x[img][p][k] (token-major / channels-last:
+        // the 16 values are four 16-byte loads)
+        if (tokens) {
+            const float* xp = x + (int64_t)img * x_sb + (int64_t)p * KP_K + lq * 16;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) xv[s] = xp[(int64_t)s * HW];
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const float4 t = *reinterpret_cast<const float4*>(xp + s4 * 4);
+                xv[s4 * 4 + 0] = t.x; xv[s4 * 4 + 1] = t.y; xv[s4 * 4 + 2] = t.z; xv[s4 * 4 + 3] = t.w;
+            }
+        } else {
+            const float* xp = x + (int64_t)img * x_sb + (int64_t)lq * 16 * HW + p;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) xv[s] = xp[(int64_t)s * HW];
+        }
     };
     float xb[16], xn[16];
     if (mine > 0) load_x(unit_of(0), xb);
@@ -111,18 +121,20 @@ __global__ __launch_bounds__(KP_W * 64) void kv_project_kernel(const float* __re
 using namespace msm;
 
 extern "C" int msm_kv_project_f32(const float* x, const float* w, const float* cmat, float* out, int B, int C, int HW, int N,
-                                  void* stream) {
+                                  int x_tokens, int64_t x_batch_stride, void* stream) {
     MSM_REQUIRE(x && w && cmat && out, "msm_kv_project_f32: null pointer");
     MSM_REQUIRE(C == KP_K, "msm_kv_project_f32: C=%d, only 64 input channels are supported", C);
     MSM_REQUIRE(B > 0 && HW > 0 && N > 0 && N % (KP_FB * 16) == 0 && N <= 512,
                 "msm_kv_project_f32: N=%d must be 256 or 512", N);
     MSM_REQUIRE(((((uintptr_t)w) | ((uintptr_t)cmat) | ((uintptr_t)out)) & 15) == 0 && (((uintptr_t)x) & 3) == 0,
                 "msm_kv_project_f32: w/cmat/out must be 16-byte aligned");
+    MSM_REQUIRE(x_batch_stride >= (int64_t)C * HW && (!x_tokens || ((((uintptr_t)x) & 15) == 0 && x_batch_stride % 4 == 0)),
+                "msm_kv_project_f32: bad x batch stride / alignment");
     const size_t lds = sizeof(float) * (size_t)N * KP_LD;
     MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)kv_project_kernel, lds));
     const int units = cdiv(HW, 16) * B * (N / (KP_FB * 16));
     const int grid = max(1, min(256, cdiv(units, 4)));
-    hipLaunchKernelGGL(kv_project_kernel, dim3(grid), dim3(KP_W * 64), lds, (hipStream_t)stream, x, w, cmat, out, B, HW, N);
+    hipLaunchKernelGGL(kv_project_kernel, dim3(grid), dim3(KP_W * 64), lds, (hipStream_t)stream, x, w, cmat, out, B, HW, N, x_tokens, x_batch_stride);
     MSM_CHECK_LAUNCH("msm_kv_project_f32");
     return MSM_OK;
 }

@@ -398,7 +398,8 @@ class MeanShiftTransformerDecoder(nn.Module):
         for i in range(self.num_feature_levels):
             h, w = x[i].shape[-2:]
             sizes.append((int(h), int(w)))
-            xs.append(x[i].contiguous())
+            # token-major (channels_last) level maps, as the pixel decoder returns them, are consumed as they are
+            xs.append(x[i] if ops.is_token_major(x[i]) else x[i].contiguous())
         kv_all, kv_ready = None, None
         if self.fold_kv:
             kv_w, kv_c = self._folded_kv(sizes, dev)
@@ -420,9 +421,9 @@ class MeanShiftTransformerDecoder(nn.Module):
                 if isinstance(self.input_proj[i], nn.Conv2d):
                     wt = self.input_proj[i].weight.view(E, -1)
                     bias = self.input_proj[i].bias + self.level_embed.weight[i]          # DEC:575
-                    src.append(ops.conv1x1_nchw_to_tokens(xs[i], wt, bias.contiguous()))
+                    src.append(ops.conv1x1_nchw_to_tokens(xs[i].contiguous(), wt, bias.contiguous()))
                 else:
-                    src.append(ops.transpose_last2(xs[i].flatten(2)) + self.level_embed.weight[i])
+                    src.append(ops.transpose_last2(xs[i].contiguous().flatten(2)) + self.level_embed.weight[i])
         mask_features = mask_features.contiguous()
         qpos = self.query_embed.weight
         out = self.query_feat.weight[None].expand(B, -1, -1).contiguous()
@@ -683,6 +684,14 @@ class MSDeformAttnPixelDecoder(nn.Module):
         self._packed = None
         self.fused_encoder = True      # False: one GEMM / LayerNorm launch per op (same results up to rounding)
 
+    def _w3(self):
+        """layer_1's 3x3 weight in the implicit-GEMM order (Cout, 3*3*Cin), cached per parameter version."""
+        p = self.layer_1.weight
+        key = (p.data_ptr(), p._version)
+        if getattr(self, "_w3_cache", None) is None or self._w3_cache[0] != key:
+            self._w3_cache = (key, p.permute(0, 2, 3, 1).reshape(p.shape[0], -1).contiguous())
+        return self._w3_cache[1]
+
     def _packed_encoder(self, device):
         """Weight streams of the fused encoder kernel, rebuilt only when a parameter changes."""
         layers = self.transformer.encoder.layers
@@ -704,7 +713,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 stream = ops.pack_encoder_block(a.output_proj.weight, layer.linear1.weight, layer.linear2.weight, wv, wp)
                 pw = a.sampling_offsets.out_features + a.attention_weights.out_features
                 out.append((stream, torch.cat([t.reshape(-1) for t in smalls]).contiguous(), layer.linear1.out_features, pw))
-            self._packed = (key, out)
+            self._packed = (key, out, layers[0].self_attn._proj_weights())
         return self._packed[1]
 
     @classmethod
@@ -750,7 +759,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
             packed = self._packed_encoder(dev)
             a0 = layers[0].self_attn
             value = ops.value_to_head_major(ops.gemm(src, a0.value_proj.weight, a0.value_proj.bias), a0.n_heads)
-            w, b = a0._proj_weights()
+            w, b = self._packed[2]
             proj = ops.gemm(src, w, b, a2=lvl_pos)
             S_tok = src.shape[1]
             for l, layer in enumerate(layers):
@@ -763,20 +772,20 @@ class MSDeformAttnPixelDecoder(nn.Module):
         else:
             for layer in layers:
                 src = layer.forward_tokens(src, lvl_pos, ss, starts)
-        out_tok, out, o = [], [], 0
+        # multi-scale outputs: NCHW-shaped VIEWS of the token buffer (torch channels_last strides) -- no slice copies,
+        # no transposes; the decoder's K/V projection reads this layout directly
+        out, o = [], 0
         for (h, w) in shapes:
-            t = src[:, o:o + h * w].contiguous()
+            out.append(src[:, o:o + h * w].view(B, h, w, C).permute(0, 3, 1, 2))
             o += h * w
-            out_tok.append(t)
-            out.append(ops.transpose_last2(t).view(B, C, h, w))
+        up_tok = src[:, o - shapes[-1][0] * shapes[-1][1]:].contiguous()          # finest level, source of the FPN upsample
         # one FPN level on the highest-resolution backbone feature (MSD:343-351)
         x = features[self.in_features[0]].float().contiguous()
         H, W = int(x.shape[2]), int(x.shape[3])
         lat = ops.conv1x1_nchw_to_tokens(x, self.adapter_1.weight.view(C, -1), None)
         y = ops.groupnorm_tokens(lat, self.adapter_1.norm.weight, self.adapter_1.norm.bias, H, W, groups=32,
-                                 up=out_tok[-1], up_hw=shapes[-1], eps=self.adapter_1.norm.eps)
-        w3 = self.layer_1.weight.permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous()
-        y = ops.conv3x3_tokens(y, w3, H, W)
+                                 up=up_tok, up_hw=shapes[-1], eps=self.adapter_1.norm.eps)
+        y = ops.conv3x3_tokens(y, self._w3(), H, W)
         y = ops.groupnorm_tokens(y, self.layer_1.norm.weight, self.layer_1.norm.bias, H, W, groups=32, relu=True,
                                  eps=self.layer_1.norm.eps)
         mask_features = ops.conv1x1_tokens_to_nchw(y, self.mask_features.weight.view(self.mask_dim, C),

@@ -94,19 +94,32 @@ def conv1x1_nchw_to_tokens(x, w, bias=None):
     return out
 
 
+def is_token_major(x):
+    """True for a (B, C, H, W) tensor stored [B][H*W][C] (torch channels_last, possibly with a larger batch stride),
+    e.g. the NCHW-shaped views the pixel decoder returns over its token buffer."""
+    if x.dim() != 4:
+        return False
+    B, C, H, W = x.shape
+    return x.stride(1) == 1 and x.stride(3) == C and x.stride(2) == W * C and x.stride(0) >= H * W * C and C > 1
+
+
 def kv_project(x, w, cmat):
-    """Folded K/V projection: x (B, 64, H, W) NCHW, w (N, 64), cmat (H*W, N) -> (B, H*W, N).
-    Large maps with N in {256, 512} take the weight-stationary kernel (csrc/kv_proj.hip); small ones, where copying
-    w into every CU's LDS costs more than it saves, and other shapes take the tiled GEMM."""
-    _c(x, "x"), _c(w, "w"), _c(cmat, "cmat")
+    """Folded K/V projection: x (B, 64, H, W), w (N, 64), cmat (H*W, N) -> (B, H*W, N).
+    x is contiguous NCHW or token-major (is_token_major).  Maps with N in {256, 512} take the weight-stationary
+    kernel (csrc/kv_proj.hip); small NCHW ones, where copying w into every CU's LDS costs more than it saves, and
+    other shapes take the tiled GEMM."""
+    _chk(x, "x"), _c(w, "w"), _c(cmat, "cmat")
     B, C, H, W = x.shape
     N = w.shape[0]
-    if C != 64 or N not in (256, 512) or B * H * W < 8192:
-        return conv1x1_nchw_to_tokens(x, w, cmat)
+    tokens = is_token_major(x) and not x.is_contiguous()
+    if not tokens:
+        _c(x, "x")
+    if C != 64 or N not in (256, 512) or (not tokens and B * H * W < 8192):
+        return conv1x1_nchw_to_tokens(x.contiguous(), w, cmat)
     if tuple(w.shape) != (N, C) or tuple(cmat.shape) != (H * W, N):
         raise RuntimeError(f"kv_project: w must be (N, {C}) and cmat ({H * W}, N)")
     out = torch.empty((B, H * W, N), device=x.device, dtype=torch.float32)
-    rc = lib().msm_kv_project_f32(_p(x), _p(w), _p(cmat), _p(out), B, C, H * W, N, _stream())
+    rc = lib().msm_kv_project_f32(_p(x), _p(w), _p(cmat), _p(out), B, C, H * W, N, 1 if tokens else 0, x.stride(0), _stream())
     check(rc, "msm_kv_project_f32")
     return out
 
