@@ -24,6 +24,7 @@
  *   msm_mask_logits_fwd          <- forward_prediction_heads einsum + attention-mask, DEC:668-680
  *   msm_hypersphere_attn_fwd     <- hypersphere_attention, AU:64-82 (+ head split/merge AU:364-375,424)
  *   msm_kv_project_f32           <- memory/key path of the cross-attention layers, DEC:575, DEC:251, AU:134-140
+ *   msm_tokens_proj_nchw_f32     <- layer_1 GroupNorm + ReLU and the mask_features 1x1 convolution, MSD:349-358
  *   msm_dec_post_cross / msm_dec_post_self / msm_dec_heads
  *                                <- the row-local ops between the attention cores of a decoder layer,
  *                                   DEC:245-260, DEC:171-181, DEC:296-300, DEC:637-638, DEC:661-665
@@ -201,6 +202,14 @@ int msm_encoder_block_fwd(const float* attn, const float* src, const float* wstr
  * ------------------------------------------------------------------------------------------- */
 int msm_kv_project_f32(const float* x, const float* w, const float* cmat, float* out,
                        int B, int C, int HW, int N, int x_tokens, int64_t x_batch_stride, void* stream);
+
+/* mask_features (MSD:349-358): the last GroupNorm + ReLU of the FPN level fused into the 1x1 convolution after it.
+ *   out [B][N][HW] (NCHW) = bias + w act(x),  x [B][HW][64] tokens, w [N][64], N in {256, 512}, HW % 4 == 0;
+ *   act(x) = relu?((x - mean_g) * rstd_g * gamma + beta) with (mean, rstd) from gn_stats -- the per-(image, channel)
+ *   double (sum, sum of squares) written by msm_groupnorm_stats_f32 -- or the identity when gn_stats is null. */
+int msm_tokens_proj_nchw_f32(const float* x, const float* w, const float* bias, const double* gn_stats,
+                             const float* gn_gamma, const float* gn_beta, int groups, float eps, int relu, float* out,
+                             int B, int C, int HW, int N, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused row-local tails of one decoder layer on the query matrix [rows = B*Q][E], E fixed to 256.  Row r uses

@@ -327,6 +327,24 @@ def test_kv_project(B, H, W, N):
     closed(ops().kv_project(view, w.to(DEV), c.to(DEV)), ref, rtol=1e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("B,H,W,N,gn", [(2, 24, 32, 256, True), (3, 10, 14, 256, False), (1, 30, 40, 512, True)])
+def test_tokens_proj_nchw(B, H, W, N, gn):
+    """msm_tokens_proj_nchw_f32 = 1x1 conv to NCHW of relu(GroupNorm(x)) (MSD:349-358) against torch in fp64."""
+    x = rnd(B, H * W, 64, seed=1) * 2 + 0.5
+    w, b = rnd(N, 64, seed=2, scale=0.125), rnd(N, seed=3)
+    gamma, beta = 1 + rnd(64, seed=4, scale=0.2), rnd(64, seed=5, scale=0.2)
+    xd = x.to(DEV)
+    if gn:
+        got = ops().tokens_proj_nchw(xd, w.to(DEV), b.to(DEV), gn=(ops().groupnorm_stats(xd), gamma.to(DEV), beta.to(DEV), 32, 1e-5),
+                                     relu=True)
+        y = torch.relu(F.group_norm(x.double().transpose(1, 2), 32, gamma.double(), beta.double(), 1e-5))     # (B, 64, HW)
+    else:
+        got = ops().tokens_proj_nchw(xd, w.to(DEV), b.to(DEV))
+        y = x.double().transpose(1, 2)
+    ref = torch.einsum("nk,bkp->bnp", w.double(), y) + b.double()[None, :, None]
+    closed(got, ref, rtol=1e-4, atol=5e-5)
+
+
 def _start(shapes):
     return torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
 

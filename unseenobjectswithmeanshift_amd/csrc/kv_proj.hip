@@ -116,6 +116,118 @@ __global__ __launch_bounds__(KP_W * 64) void kv_project_kernel(const float* __re
     }
 }
 
+// ---- mask_features: GroupNorm + ReLU of the FPN output fused into the 1x1 convolution that follows it --------------
+//     out[b][n][p] = bias[n] + sum_k w[n][k] * relu((x[b][p][k] - mean_g) * rstd_g * gamma[k] + beta[k])      (MSD:349-358)
+// Same weight-stationary scheme as above with the MFMA operands swapped (rows = tokens, cols = output channels), so a
+// lane ends with 4 consecutive TOKENS of one channel and the NCHW result leaves as 16-byte stores; the normalisation
+// is applied to the x fragment in registers, which removes the GroupNorm-apply pass (39 MB written and read back).
+// stats: per (image, channel) double (sum, sum of squares) over the map, as written by msm_groupnorm_stats_f32.
+constexpr int MF_W = 8;              // waves per workgroup (w for N = 256 is 68 KiB: two workgroups per CU)
+
+__global__ __launch_bounds__(MF_W * 64) void tokens_proj_nchw_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                    const float* __restrict__ bias,
+                                                                    const double* __restrict__ stats,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                    float* __restrict__ out, int B, int HW, int N, int groups,
+                                                                    float eps, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [N][KP_LD], then per-image (scale, shift) [B][64][2]
+    float* aff = wl + N * KP_LD;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    for (int i = tid; i < N * (KP_K / 4); i += MF_W * 64) {
+        const int n = i >> 4, c4 = i & 15;
+        *reinterpret_cast<float4*>(wl + n * KP_LD + c4 * 4) = *reinterpret_cast<const float4*>(w + (int64_t)n * KP_K + c4 * 4);
+    }
+    for (int i = tid; i < B * KP_K; i += MF_W * 64) {
+        float sc = 1.f, sh = 0.f;
+        if (stats) {
+            const int b = i / KP_K, c = i - b * KP_K;
+            const int cpg = KP_K / groups, g0 = (c / cpg) * cpg;
+            double sm = 0.0, q = 0.0;
+            for (int k = 0; k < cpg; ++k) {
+                sm += stats[((int64_t)b * KP_K + g0 + k) * 2];
+                q += stats[((int64_t)b * KP_K + g0 + k) * 2 + 1];
+            }
+            const double cnt = (double)cpg * (double)HW;
+            const double mean = sm / cnt;
+            double var = q / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            sc = (float)(1.0 / sqrt(var + (double)eps)) * gamma[c];
+            sh = beta[c] - (float)mean * sc;       // y = x*sc + sh  ( = (x - mean)*rstd*gamma + beta up to one rounding)
+        }
+        aff[i * 2] = sc;
+        aff[i * 2 + 1] = sh;
+    }
+    __syncthreads();
+
+    const int tiles = (HW + 15) / 16;
+    const int halves = N / (KP_FB * 16);
+    const int units = tiles * B * halves;
+    const int slots = gridDim.x * MF_W;
+    const int full_rounds = units / slots;
+    const int left = units - full_rounds * slots;
+    const int left_slot = (wave >> 2) * ((int)gridDim.x * 4) + (int)blockIdx.x * 4 + (wave & 3);
+    const int mine = full_rounds + (left_slot < left ? 1 : 0);
+    auto unit_of = [&](int it) {
+        return (it < full_rounds) ? it * slots + (int)blockIdx.x * MF_W + wave : full_rounds * slots + left_slot;
+    };
+    auto load_x = [&](int u, float (&xv)[16]) {
+        const int img = (u / halves) % B, tile = u / (halves * B);
+        const int p = min(tile * 16 + lj, HW - 1);
+        const float* xp = x + ((int64_t)img * HW + p) * KP_K + lq * 16;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const float4 t = *reinterpret_cast<const float4*>(xp + s4 * 4);
+            xv[s4 * 4 + 0] = t.x; xv[s4 * 4 + 1] = t.y; xv[s4 * 4 + 2] = t.z; xv[s4 * 4 + 3] = t.w;
+        }
+    };
+    float xb[16], xn[16];
+    if (mine > 0) load_x(unit_of(0), xb);
+    for (int it = 0; it < mine; ++it) {
+        const int u = unit_of(it);
+        const int half = u % halves;
+        const int tile = u / (halves * B), img = (u / halves) % B;
+        load_x(unit_of(min(it + 1, mine - 1)), xn);
+        // A operand: this lane's 16 channels lq*16 .. +15 of token lj, normalised in registers
+        const float* af = aff + (img * KP_K + lq * 16) * 2;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float y = fmaf(xb[s], af[2 * s], af[2 * s + 1]);
+            xb[s] = relu ? fmaxf(y, 0.f) : y;
+        }
+        const int n_base = half * KP_FB * 16;
+        const int p4 = tile * 16 + lq * 4;                        // first of this lane's 4 output tokens
+        const float* wp = wl + (n_base + lj) * KP_LD + lq * 16;
+        float* op = out + ((int64_t)img * N + n_base + lj) * HW + p4;
+        const bool live = p4 < HW;                                // HW % 4 == 0: whole float4s are in or out
+#pragma unroll
+        for (int fb = 0; fb < KP_FB; fb += 2) {
+            const float b0 = bias ? bias[n_base + fb * 16 + lj] : 0.f, b1 = bias ? bias[n_base + (fb + 1) * 16 + lj] : 0.f;
+            f32x4 a0 = f32x4{b0, b0, b0, b0}, a1 = f32x4{b1, b1, b1, b1};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const float4 w0 = *reinterpret_cast<const float4*>(wp + fb * 16 * KP_LD + s4 * 4);
+                const float4 w1 = *reinterpret_cast<const float4*>(wp + (fb + 1) * 16 * KP_LD + s4 * 4);
+                a0 = mfma16(xb[s4 * 4 + 0], w0.x, a0);
+                a1 = mfma16(xb[s4 * 4 + 0], w1.x, a1);
+                a0 = mfma16(xb[s4 * 4 + 1], w0.y, a0);
+                a1 = mfma16(xb[s4 * 4 + 1], w1.y, a1);
+                a0 = mfma16(xb[s4 * 4 + 2], w0.z, a0);
+                a1 = mfma16(xb[s4 * 4 + 2], w1.z, a1);
+                a0 = mfma16(xb[s4 * 4 + 3], w0.w, a0);
+                a1 = mfma16(xb[s4 * 4 + 3], w1.w, a1);
+            }
+            if (live) {
+                *reinterpret_cast<float4*>(op + (int64_t)fb * 16 * HW) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+                *reinterpret_cast<float4*>(op + (int64_t)(fb + 1) * 16 * HW) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) xb[s] = xn[s];
+    }
+}
+
 }  // namespace msm
 
 using namespace msm;
@@ -136,5 +248,25 @@ extern "C" int msm_kv_project_f32(const float* x, const float* w, const float* c
     const int grid = max(1, min(256, cdiv(units, 4)));
     hipLaunchKernelGGL(kv_project_kernel, dim3(grid), dim3(KP_W * 64), lds, (hipStream_t)stream, x, w, cmat, out, B, HW, N, x_tokens, x_batch_stride);
     MSM_CHECK_LAUNCH("msm_kv_project_f32");
+    return MSM_OK;
+}
+
+extern "C" int msm_tokens_proj_nchw_f32(const float* x, const float* w, const float* bias, const double* gn_stats,
+                                        const float* gn_gamma, const float* gn_beta, int groups, float eps, int relu, float* out,
+                                        int B, int C, int HW, int N, void* stream) {
+    MSM_REQUIRE(x && w && out, "msm_tokens_proj_nchw_f32: null pointer");
+    MSM_REQUIRE(C == KP_K, "msm_tokens_proj_nchw_f32: C=%d, only 64 input channels are supported", C);
+    MSM_REQUIRE(B > 0 && B <= 64 && HW > 0 && HW % 4 == 0 && N > 0 && N % (KP_FB * 16) == 0 && N <= 512,
+                "msm_tokens_proj_nchw_f32: need B <= 64, HW %% 4 == 0, N in {256, 512}");
+    MSM_REQUIRE(!gn_stats || (gn_gamma && gn_beta && groups > 0 && KP_K % groups == 0), "msm_tokens_proj_nchw_f32: bad GroupNorm arguments");
+    MSM_REQUIRE(((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)out)) & 15) == 0, "msm_tokens_proj_nchw_f32: pointers must be 16-byte aligned");
+    const size_t lds = sizeof(float) * ((size_t)N * KP_LD + (size_t)B * KP_K * 2);
+    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)tokens_proj_nchw_kernel, lds));
+    const int units = cdiv(HW, 16) * B * (N / (KP_FB * 16));
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    const int grid = max(1, min(256 * per_cu, cdiv(units, 4)));
+    hipLaunchKernelGGL(tokens_proj_nchw_kernel, dim3(grid), dim3(MF_W * 64), lds, (hipStream_t)stream, x, w, bias, gn_stats, gn_gamma,
+                       gn_beta, out, B, HW, N, groups, eps, relu);
+    MSM_CHECK_LAUNCH("msm_tokens_proj_nchw_f32");
     return MSM_OK;
 }

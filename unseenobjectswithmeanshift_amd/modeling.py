@@ -786,8 +786,13 @@ class MSDeformAttnPixelDecoder(nn.Module):
         y = ops.groupnorm_tokens(lat, self.adapter_1.norm.weight, self.adapter_1.norm.bias, H, W, groups=32,
                                  up=up_tok, up_hw=shapes[-1], eps=self.adapter_1.norm.eps)
         y = ops.conv3x3_tokens(y, self._w3(), H, W)
-        y = ops.groupnorm_tokens(y, self.layer_1.norm.weight, self.layer_1.norm.bias, H, W, groups=32, relu=True,
-                                 eps=self.layer_1.norm.eps)
-        mask_features = ops.conv1x1_tokens_to_nchw(y, self.mask_features.weight.view(self.mask_dim, C),
-                                                   self.mask_features.bias).view(B, self.mask_dim, H, W)
+        wm = self.mask_features.weight.view(self.mask_dim, C)
+        if C == 64 and self.mask_dim in (256, 512) and (H * W) % 4 == 0 and B <= 64:
+            # layer_1's GroupNorm + ReLU is applied to the operand fragments of the mask_features convolution
+            gn = (ops.groupnorm_stats(y), self.layer_1.norm.weight, self.layer_1.norm.bias, 32, self.layer_1.norm.eps)
+            mask_features = ops.tokens_proj_nchw(y, wm, self.mask_features.bias, gn=gn, relu=True).view(B, self.mask_dim, H, W)
+        else:
+            y = ops.groupnorm_tokens(y, self.layer_1.norm.weight, self.layer_1.norm.bias, H, W, groups=32, relu=True,
+                                     eps=self.layer_1.norm.eps)
+            mask_features = ops.conv1x1_tokens_to_nchw(y, wm, self.mask_features.bias).view(B, self.mask_dim, H, W)
         return mask_features, out[0], out[:self.maskformer_num_feature_levels]

@@ -197,6 +197,34 @@ def groupnorm_tokens(x, gamma, beta, H, W, groups=32, *, up=None, up_hw=None, re
     return y
 
 
+def groupnorm_stats(x):
+    """Per-(image, channel) double (sum, sum of squares) of a token map x (B, HW, C) -> (B, C, 2) float64."""
+    _c(x, "x")
+    B, HW, C = x.shape
+    stats = torch.empty((B, C, 2), device=x.device, dtype=torch.float64)
+    check(lib().msm_groupnorm_stats_f32(_p(x), _p(stats), B, HW, C, _stream()), "msm_groupnorm_stats_f32")
+    return stats
+
+
+def tokens_proj_nchw(x, w, bias=None, *, gn=None, relu=False):
+    """1x1 convolution from tokens x (B, HW, 64) to NCHW (B, N, HW) with an optional GroupNorm (+ReLU) applied to x on
+    the fly: gn = (stats from groupnorm_stats(x), gamma, beta, groups, eps).  N in {256, 512}; other shapes use
+    conv1x1_tokens_to_nchw on a materialised GroupNorm output."""
+    _c(x, "x"), _c(w, "w"), _c(bias, "bias")
+    B, HW, C = x.shape
+    N = w.shape[0]
+    stats = gamma = beta = None
+    groups, eps = 1, 0.0
+    if gn is not None:
+        stats, gamma, beta, groups, eps = gn
+        _c(stats, "stats", torch.float64), _c(gamma, "gamma"), _c(beta, "beta")
+    out = torch.empty((B, N, HW), device=x.device, dtype=torch.float32)
+    rc = lib().msm_tokens_proj_nchw_f32(_p(x), _p(w), _p(bias), _p(stats), _p(gamma), _p(beta), int(groups), float(eps),
+                                        1 if relu else 0, _p(out), B, C, HW, N, _stream())
+    check(rc, "msm_tokens_proj_nchw_f32")
+    return out
+
+
 def pos_embed_sine(H, W, num_pos_feats, device, *, layout="nchw", add_c=None, temperature=10000.0,
                    scale=6.283185307179586):
     """PositionEmbeddingSine(normalize=True) for one map: (2N, H, W) for layout 'nchw',
