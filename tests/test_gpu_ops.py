@@ -463,7 +463,10 @@ def test_topk_and_postprocess():
 
 
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,S,want_next", [(2, 394, True), (1, 50, False), (3, 130, True)])
+@pytest.mark.parametrize("B,S,want_next", [(2, 394, True), (1, 50, False), (3, 130, True),
+                                           # 1032 / 1031 16-token tiles = 256 four-tile workgroups + 8 / 7 COOPERATIVE
+                                           # workgroups (four waves split one tile); ragged last tile
+                                           (2, 8249, True), (1, 16496, False)])
 def test_encoder_block_fused(B, S, want_next):
     """Fused encoder-layer tail vs the same chain in plain torch fp32 (msdeformattn.py:116-126)."""
     C, DF, PW = 64, 1024, 288
@@ -484,6 +487,10 @@ def test_encoder_block_fused(B, S, want_next):
     if want_next:
         close(vo, F.linear(y, wv, bv), rtol=1e-4, atol=2e-5)
         close(po, F.linear(y + pos, wp, bp), rtol=1e-4, atol=5e-5)
+        # head-major value output (B, heads, S, C/heads) is the same data in the layout the gather kernel reads
+        so2, vh, po2 = ops().encoder_block(d(attn), d(src), stream, small, DF, PW, pos=d(pos), tokens_per_image=S, value_heads=8)
+        assert vh.shape == (B, 8, S, C // 8)
+        assert torch.equal(vh.permute(0, 2, 1, 3).reshape(B, S, C), vo) and torch.equal(so2, so) and torch.equal(po2, po)
     else:
         assert vo is None and po is None
 
