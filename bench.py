@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sparse-taps", action="store_true", help="skip mask rows that feed no attention-mask tap")
+    ap.add_argument("--mask-step", choices=("f32", "bf16"), default="f32",
+                    help="bf16 (configs 3/5) is NOT the headline configuration: the JSON line then says dtype bf16-mask-step")
     ap.add_argument("--overlap-kv", type=int, default=-1, help="1/0: K/V projections on a side stream (default: the decoder's own default)")
     args = ap.parse_args()
 
@@ -102,6 +104,7 @@ def main():
 
     model = build_model(dev)
     model.sem_seg_head.predictor.sparse_taps = args.sparse_taps
+    model.sem_seg_head.predictor.mask_step_dtype = args.mask_step
     if args.overlap_kv >= 0:
         model.sem_seg_head.predictor.overlap_kv = bool(args.overlap_kv)
     # weak scaling: the global batch is world*8 images, rank r owns images [r*8, (r+1)*8)
@@ -173,6 +176,8 @@ def main():
     mask_ms = sum(per_call) / len(per_call)
     flops_per_launch = 2.0 * Q * C_MASK * (H // 4) * (W // 4) * (hi - lo)
     achieved = flops_per_launch / (mask_ms * 1e-3) / 1e12
+    # algorithmic bytes of a bf16 launch: packed features + fp32 mask_embed + (one of ten launches) the fp32 mask
+    bf16_bytes = (hi - lo) * (C_MASK * (H // 4) * (W // 4) * 2 + Q * C_MASK * 4 + Q * (H // 4) * (W // 4) * 4 // 10)
     # HBM traffic of the same kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; the
     # gfx950 x2 correction on FETCH_SIZE applied), summarised in profiles/ -- it cannot be measured in-process
     traffic = None
@@ -192,7 +197,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if args.mask_step == "f32" else "f32 (bf16 mask step, fp32 accumulation: NOT the headline configuration)",
         "data": "synthetic",
         "config": {"workload": "configs[1]: batch=8 640x480 frames per GPU, synthetic ResNet-50 res2..res5 features "
                                "-> MSDeformAttn pixel decoder (6 layers) -> 9-layer hypersphere decoder (100 queries) "
@@ -203,7 +208,13 @@ def main():
                      "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                      "launches_per_step": calls_per_step, "avg_launch_ms": round(mask_ms, 4),
-                     "flops_per_launch": flops_per_launch},
+                     "flops_per_launch": flops_per_launch} if args.mask_step == "f32" else
+                    # bf16 operands: the step is a stream over the packed feature map, HBM-bound
+                    {"bound": "hbm", "kernel": "mask_logits_bf16_kernel (msm_mask_logits_bf16_fwd)",
+                     "achieved": round(bf16_bytes / (mask_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                     "frac": round(bf16_bytes / (mask_ms * 1e-3) / 8e12, 4), "traffic": None,
+                     "launches_per_step": calls_per_step, "avg_launch_ms": round(mask_ms, 4),
+                     "bytes_per_launch": bf16_bytes},
         "breakdown": breakdown,
     }
     if not args.no_cpu_baseline and world == 1:

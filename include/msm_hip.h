@@ -118,6 +118,15 @@ int msm_mask_logits_fwd(const float* mask_embed, const float* mask_feat, float* 
                         uint8_t* attn_out, int32_t* row_any,
                         int B, int Q, int C, int H, int W, int th, int tw, int flags, void* stream);
 
+/* bf16 variant of the mask step (BASELINE configs 3 and 5; SURVEY 8d: HBM-bound at AI 71.6 FLOP/B): bf16 operands,
+ * fp32 accumulation, same outputs and flags.  mask_feat_packed is the channel-quad packed bf16 form of the feature
+ * map, [B][C/4][H*W][4] (bf16 bit patterns in uint16), written by msm_pack_mask_features_bf16 from fp32 NCHW;
+ * mask_embed stays fp32 and is rounded to bf16 (nearest even) inside the kernel.  C % 16 == 0, C <= 256. */
+int msm_pack_mask_features_bf16(const float* mask_feat, uint16_t* packed, int B, int C, int HW, void* stream);
+int msm_mask_logits_bf16_fwd(const float* mask_embed, const uint16_t* mask_feat_packed, float* mask_out,
+                             uint8_t* attn_out, int32_t* row_any,
+                             int B, int Q, int C, int H, int W, int th, int tw, int flags, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Multi-head hypersphere (vMF) attention core (AU:64-82) on already projected q/k/v:
  *   q [B][Lq][E], k,v [B][S][E] with per-batch strides (elements) q_sb, k_sb, v_sb and row

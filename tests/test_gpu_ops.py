@@ -345,6 +345,46 @@ def test_tokens_proj_nchw(B, H, W, N, gn):
     closed(got, ref, rtol=1e-4, atol=5e-5)
 
 
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("B,Q,C,H,W,tgt", [(2, 100, 256, 24, 32, (12, 16)), (1, 37, 64, 16, 48, (4, 12)), (2, 100, 256, 24, 32, (3, 4)),
+                                           (1, 120, 128, 8, 16, (8, 16)), (1, 20, 256, 24, 32, None)])
+def test_mask_logits_bf16(B, Q, C, H, W, tgt):
+    """bf16 mask step (msm_mask_logits_bf16_fwd): logits equal the einsum of the bf16-ROUNDED operands accumulated in
+    fp32 (rtol 1e-4: only the summation order differs); attention bits are the sign of the 2x2 tap sums of those logits."""
+    e, f = rnd(B, Q, C, seed=1, scale=0.3), rnd(B, C, H, W, seed=2)
+    packed = ops().pack_mask_features_bf16(f.to(DEV))
+    # the packed layout is (B, C/4, HW, 4) bf16
+    want = f.view(B, C // 4, 4, H * W).permute(0, 1, 3, 2).to(torch.bfloat16).contiguous()
+    assert torch.equal(packed.cpu().view(torch.bfloat16), want)
+    mask, attn, row_any = ops().mask_logits(e.to(DEV), f.to(DEV), want_mask=True, target_size=tgt, packed_bf16=packed)
+    ref = torch.einsum("bqc,bchw->bqhw", _bf16_round(e).double(), _bf16_round(f).double())
+    closed(mask, ref, rtol=1e-4, atol=1e-4)
+    if tgt is None:
+        assert attn is None
+        return
+    s = H // tgt[0]
+    m = mask.cpu().double()
+    if s == 1:
+        bits = m < 0
+    else:
+        r0 = torch.arange(tgt[0]) * s + s // 2 - 1
+        c0 = torch.arange(tgt[1]) * s + s // 2 - 1
+        tap = (m[:, :, r0][:, :, :, c0] + m[:, :, r0][:, :, :, c0 + 1]) + (m[:, :, r0 + 1][:, :, :, c0] + m[:, :, r0 + 1][:, :, :, c0 + 1])
+        bits = tap < 0
+    got = attn.cpu().view(B, Q, tgt[0], tgt[1]).bool()
+    near = (tap.abs() if s > 1 else m.abs()) < 1e-4
+    assert ((got != bits) & ~near).sum() == 0
+    assert torch.equal(row_any.cpu().bool(), (~got).flatten(2).any(-1))
+    # and against the fp32 step: bf16 operand rounding moves logits by ~1e-2 relative, flips a percent of the bits
+    m32, a32, _ = ops().mask_logits(e.to(DEV), f.to(DEV), want_mask=True, target_size=tgt)
+    scale = float(m32.abs().max())
+    assert float((mask - m32).abs().max()) < 3e-2 * scale
+    assert (attn != a32).float().mean() < 0.03
+
+
 def _start(shapes):
     return torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
 

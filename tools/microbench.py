@@ -76,6 +76,22 @@ def mask():
             print(f"mask nc={nc} target={tgt} write={wm}: {t:7.1f} us  {flops / t / 1e6:6.1f} TFLOP/s", flush=True)
 
 
+def maskbf16():
+    """bf16 mask step (configs 3/5): HBM-bound stream over the packed feature map."""
+    e = torch.randn(8, 100, 256, device=DEV) * 0.3
+    f = torch.randn(8, 256, 120, 160, device=DEV)
+    t = timeit_graph(lambda: ops.pack_mask_features_bf16(f))
+    print(f"pack_mask_features_bf16: {t:7.1f} us  {(f.numel() * 6) / t / 1e6:5.2f} TB/s", flush=True)
+    fp = ops.pack_mask_features_bf16(f)
+    flops = 2.0 * 100 * 256 * 19200 * 8
+    for tgt, wm in (((15, 20), False), ((30, 40), False), ((60, 80), False), (None, True)):
+        t = timeit_graph(lambda: ops.mask_logits(e, f, want_mask=wm, target_size=tgt, packed_bf16=fp))
+        by = fp.numel() * 2 + e.numel() * 4 + (8 * 100 * 19200 * 4 if wm else 8 * 100 * tgt[0] * tgt[1])
+        t32 = timeit_graph(lambda: ops.mask_logits(e, f, want_mask=wm, target_size=tgt))
+        print(f"mask bf16 target={tgt} write={wm}: {t:7.1f} us  {by / t / 1e6:5.2f} TB/s  {flops / t / 1e6:6.1f} TFLOP/s   (fp32: {t32:6.1f} us)",
+              flush=True)
+
+
 def enc():
     B, S = 8, 6300
     attn, src, pos = torch.randn(B, S, 64, device=DEV), torch.randn(B, S, 64, device=DEV), torch.randn(S, 64, device=DEV)
@@ -202,4 +218,4 @@ def meanshift():
 
 if __name__ == "__main__":
     {"gemm": gemm, "mask": mask, "enc": enc, "attn": attn, "ucn": ucn, "meanshift": meanshift, "cfg5": cfg5,
-     "tails": tails, "kv": kv}[sys.argv[1]]()
+     "tails": tails, "kv": kv, "maskbf16": maskbf16}[sys.argv[1]]()

@@ -60,6 +60,98 @@ __device__ __forceinline__ Cols<NC> ld_cols(__amdgpu_buffer_rsrc_t rsrc, unsigne
     return c;
 }
 
+// Per-tile epilogue shared by the fp32 and bf16 kernels: lane holds queries q0 + m*16 + lq*4 + r, columns c..c+NC-1 of
+// rows ytop (acc[.][cc]) and ybot (acc[.][NC+cc]).
+template <int POOL, bool WRITE, int NC>
+__device__ __forceinline__ void mask_tile_epilogue(const f32x4 (&acc)[QB][2 * NC], float* __restrict__ mask_out,
+                                                   uint8_t* __restrict__ attn_out, int32_t* __restrict__ row_any, int b, int Q,
+                                                   int q0, int H, int W, int th, int tw, int ytop, int ybot, int c, bool col_ok,
+                                                   int lj, int lq) {
+    const int HW = H * W;
+    (void)lj;
+    // ---- epilogue: lane holds queries q0 + m*16 + lq*4 + r, columns c..c+NC-1 of rows ytop (acc[.][cc])
+    //      and ybot (acc[.][NC+cc]).  The query offset is made opaque here: the 28 per-query output base addresses
+    //      depend only on the lane, so LICM would otherwise hoist them out of the tile loop and hold 56 VGPRs
+    //      across the K loop (209 vs 157 VGPRs; the difference decides between 2 and 3 waves per SIMD).
+    int qlane = lq * 4;
+    asm volatile("" : "+v"(qlane));
+    if constexpr (WRITE) {
+        if (col_ok) {
+#pragma unroll
+            for (int m = 0; m < QB; ++m) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = q0 + m * 16 + qlane + r;
+                    if (q < Q) {
+                        float* o = mask_out + ((int64_t)b * Q + q) * HW + c;
+                        if constexpr (NC == 2) {
+                            if (ytop >= 0) *reinterpret_cast<float2*>(o + (int64_t)ytop * W) = make_float2(acc[m][0][r], acc[m][1][r]);
+                            if (ybot < H) *reinterpret_cast<float2*>(o + (int64_t)ybot * W) = make_float2(acc[m][2][r], acc[m][3][r]);
+                        } else {
+                            if (ytop >= 0) o[(int64_t)ytop * W] = acc[m][0][r];
+                            if (ybot < H) o[(int64_t)ybot * W] = acc[m][1][r];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (POOL == 1) {
+        // mask at full resolution: one bit per logit
+        if (col_ok) {
+#pragma unroll
+            for (int m = 0; m < QB; ++m) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = q0 + m * 16 + qlane + r;
+                    if (q >= Q) continue;
+                    uint8_t* o = attn_out + ((int64_t)b * Q + q) * HW + c;
+                    bool any = false;
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) {
+                        if (ytop >= 0) { const bool mk = acc[m][cc][r] < 0.f; o[(int64_t)ytop * W + cc] = mk; any |= !mk; }
+                        if (ybot < H) { const bool mk = acc[m][NC + cc][r] < 0.f; o[(int64_t)ybot * W + cc] = mk; any |= !mk; }
+                    }
+                    if (any) row_any[(int64_t)b * Q + q] = 1;
+                }
+            }
+        }
+    } else if constexpr (POOL != 0) {
+        // tap rows are (POOL*i + POOL/2 - 1, +1): the pair (ytop, ybot) is a tap pair iff
+        // ytop % POOL == POOL/2 - 1 (always true for POOL == 2 with even pairing)
+        const bool row_tap = (ytop >= 0) && (ybot < H) && ((ytop % POOL) == POOL / 2 - 1);   // wave-uniform
+        // tap columns are (POOL*i + POOL/2 - 1, +1).  NC == 2, POOL == 2: both in this lane.  Otherwise
+        // the left tap is this lane's LAST column and the right tap the next lane's first.
+        constexpr bool IN_LANE = (NC == 2 && POOL == 2);
+        const int cleft = IN_LANE ? c : c + NC - 1;
+        const bool col_tap = col_ok && ((cleft % POOL) == POOL / 2 - 1) && (cleft + 1 < W);
+        const int tx = cleft / POOL;
+        const int ty = (ytop >= 0 ? ytop : 0) / POOL;
+#pragma unroll
+        for (int m = 0; m < QB; ++m) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s;
+                if constexpr (IN_LANE) {
+                    s = (acc[m][0][r] + acc[m][1][r]) + (acc[m][2][r] + acc[m][3][r]);
+                } else {
+                    const float n0 = __shfl_down(acc[m][0][r], 1, 64);
+                    const float n2 = __shfl_down(acc[m][NC][r], 1, 64);
+                    s = (acc[m][NC - 1][r] + n0) + (acc[m][2 * NC - 1][r] + n2);
+                }
+                const int q = q0 + m * 16 + qlane + r;
+                if (row_tap && col_tap && q < Q && tx < tw && ty < th) {
+                    const bool masked = s < 0.f;
+                    attn_out[((int64_t)b * Q + q) * (th * tw) + ty * tw + tx] = masked ? 1 : 0;
+                    if (!masked) row_any[(int64_t)b * Q + q] = 1;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // one row block at a time: keeps the epilogue's live set (shuffled
+                                                 // neighbours, addresses) from setting the kernel's VGPR count
+        }
+    }
+}
+
 // POOL: 0 = no attention mask; 1 = mask at the resolution of the logits (single-level decoder,
 // meanshiftformer_transformer_decoder.py:1012-1035 with target size == mask size: interpolate is the
 // identity); 2/4/8 = 2x2-tap average of a bilinear downsample by that factor.
@@ -177,87 +269,135 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_kernel(const float* __res
         }
         if (g < G) compute_group(tA, bA, g * (4 * KU));   // odd number of groups
 
-        // ---- epilogue: lane holds queries q0 + m*16 + lq*4 + r, columns c..c+NC-1 of rows ytop (acc[.][cc])
-        //      and ybot (acc[.][NC+cc]).  The query offset is made opaque here: the 28 per-query output base addresses
-        //      depend only on the lane, so LICM would otherwise hoist them out of the tile loop and hold 56 VGPRs
-        //      across the K loop (209 vs 157 VGPRs; the difference decides between 2 and 3 waves per SIMD).
-        int qlane = lq * 4;
-        asm volatile("" : "+v"(qlane));
-        if constexpr (WRITE) {
-            if (col_ok) {
+        mask_tile_epilogue<POOL, WRITE, NC>(acc, mask_out, attn_out, row_any, b, Q, q0, H, W, th, tw, ytop, ybot, c, col_ok, lj, lq);
+    }
+}
+
+// ---- bf16 variant (BASELINE configs 3 and 5) ------------------------------------------------------------------------
+// Same product with bf16 operands and fp32 accumulation (v_mfma_f32_16x16x16_bf16): at 2.5 PFLOP/s the 7.9 GFLOP of a
+// launch are ~4 us of MFMA, so the step becomes a stream over the feature map -- HBM-bound (AI 71.6 FLOP/B
+// against a bf16 ridge of ~312).  The features are kept in a channel-quad packed layout [B][C/4][HW][4] bf16
+// (msm_pack_mask_features_bf16): the MFMA B operand of lane (pixel lj, k-group lq) is then ONE 8-byte load and the 16
+// pixels of a k-group are a 128-byte line.  A whole tile's operands (32 loads) are requested while the previous tile
+// is being multiplied.  Tile shape, schedule and the fused attention-mask epilogue are those of the fp32 kernel.
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int BKS = 16;            // 16-channel k-steps held per tile: C <= 256
+
+__device__ __forceinline__ unsigned short f2bf(float x) {   // round to nearest even
+    const unsigned int u = __float_as_uint(x);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+template <int POOL, bool WRITE>
+__global__ __launch_bounds__(MW * 64) void mask_logits_bf16_kernel(const float* __restrict__ emb, const unsigned short* __restrict__ featp,
+                                                               float* __restrict__ mask_out, uint8_t* __restrict__ attn_out,
+                                                               int32_t* __restrict__ row_any, int Q, int C, int H, int W, int th,
+                                                               int tw, int ypar, int n_rowpairs, int rp_step, int rp_first,
+                                                               int feat_bytes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short Eb[];   // [QCH][C + 8] bf16
+    const int SEb = C + 8;           // 132 dwords per row at C = 256: ds_read_b64 of (lj, lq) hits 64 distinct banks
+    const int b = blockIdx.z, qc = blockIdx.y;
+    const int q0 = qc * QCH;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    const int HW = H * W;
+    const int nks = C / 16;
+
+    const float* eb = emb + ((int64_t)b * Q + q0) * C;
+    for (int idx = tid; idx < QCH * (C / 4); idx += MW * 64) {
+        const int r = idx / (C / 4), c4 = (idx - r * (C / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q0 + r < Q) v = *reinterpret_cast<const float4*>(eb + (int64_t)r * C + c4);
+        u32x2 pk;
+        pk.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+        pk.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+        *reinterpret_cast<u32x2*>(&Eb[r * SEb + c4]) = pk;
+    }
+    __syncthreads();
+
+    const int ctiles = (W + 15) / 16;
+    const int ntiles = n_rowpairs * ctiles;
+    const uint64_t fbu = (uint64_t)(featp + (int64_t)b * C * HW);
+    const uint64_t fbs = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(fbu >> 32)) << 32) |
+                         (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)fbu);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)fbs, 0, feat_bytes, 0x00020000);
+
+    const int slots = gridDim.x * MW;
+    const int full_rounds = ntiles / slots;
+    const int left = ntiles - full_rounds * slots;
+    const int left_slot = (wave >> 2) * ((int)gridDim.x * 4) + (int)blockIdx.x * 4 + (wave & 3);
+    const int my_tiles = full_rounds + (left_slot < left ? 1 : 0);
+    auto tile_of = [&](int it) {
+        return (it < full_rounds) ? it * slots + (int)blockIdx.x * MW + wave : full_rounds * slots + left_slot;
+    };
+    struct TileRegs {
+        u32x2 t[BKS], bt[BKS];
+    };
+    auto load_tile = [&](int t, TileRegs& r) {
+        const int rp = t / ctiles, ct = t - rp * ctiles;
+        const int ytop = ypar + 2 * (rp_first + rp * rp_step), ybot = ytop + 1;
+        const int c = ct * 16 + lj;
+        const int cl = c < W ? c : 0;
+        // packed element (k-quad, pixel): 8 bytes at ((kq * HW) + pixel) * 8; the k-step part travels in soffset
+        const unsigned voff_top = (unsigned)(((int64_t)lq * HW + (int64_t)max(ytop, 0) * W + cl) * 8);
+        const unsigned voff_bot = (unsigned)(((int64_t)lq * HW + (int64_t)min(ybot, H - 1) * W + cl) * 8);
+#pragma unroll
+        for (int ks = 0; ks < BKS; ++ks) {
+            const unsigned soff = (unsigned)min(ks, nks - 1) * 4u * (unsigned)HW * 8u;   // clamped: C < 256 re-reads, never faults
+            r.t[ks] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff_top, soff, 0);
+            r.bt[ks] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff_bot, soff, 0);
+        }
+    };
+    TileRegs cur, nxt;
+    if (my_tiles > 0) load_tile(tile_of(0), cur);
+    for (int it = 0; it < my_tiles; ++it) {
+        const int t = tile_of(it);
+        const int rp = t / ctiles, ct = t - rp * ctiles;
+        const int ytop = ypar + 2 * (rp_first + rp * rp_step);
+        const int ybot = ytop + 1;
+        const int c = ct * 16 + lj;
+        const bool col_ok = c < W;
+        load_tile(tile_of(min(it + 1, my_tiles - 1)), nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[QB][2];
+#pragma unroll
+        for (int m = 0; m < QB; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < BKS; ++ks) {
+            if (ks < nks) {                                              // wave-uniform
+                const unsigned short* er = &Eb[lj * SEb + ks * 16 + lq * 4];
+                const bf16x4 bt_ = __builtin_bit_cast(bf16x4, cur.t[ks]);
+                const bf16x4 bb_ = __builtin_bit_cast(bf16x4, cur.bt[ks]);
 #pragma unroll
                 for (int m = 0; m < QB; ++m) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int q = q0 + m * 16 + qlane + r;
-                        if (q < Q) {
-                            float* o = mask_out + ((int64_t)b * Q + q) * HW + c;
-                            if constexpr (NC == 2) {
-                                if (ytop >= 0) *reinterpret_cast<float2*>(o + (int64_t)ytop * W) = make_float2(acc[m][0][r], acc[m][1][r]);
-                                if (ybot < H) *reinterpret_cast<float2*>(o + (int64_t)ybot * W) = make_float2(acc[m][2][r], acc[m][3][r]);
-                            } else {
-                                if (ytop >= 0) o[(int64_t)ytop * W] = acc[m][0][r];
-                                if (ybot < H) o[(int64_t)ybot * W] = acc[m][1][r];
-                            }
-                        }
-                    }
+                    const bf16x4 a = __builtin_bit_cast(bf16x4, *reinterpret_cast<const u32x2*>(er + m * 16 * SEb));
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, bt_, acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, bb_, acc[m][1], 0, 0, 0);
                 }
             }
         }
-        if constexpr (POOL == 1) {
-            // mask at full resolution: one bit per logit
-            if (col_ok) {
+        __builtin_amdgcn_sched_barrier(0);
+        mask_tile_epilogue<POOL, WRITE, 1>(acc, mask_out, attn_out, row_any, b, Q, q0, H, W, th, tw, ytop, ybot, c, col_ok, lj, lq);
 #pragma unroll
-                for (int m = 0; m < QB; ++m) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int q = q0 + m * 16 + qlane + r;
-                        if (q >= Q) continue;
-                        uint8_t* o = attn_out + ((int64_t)b * Q + q) * HW + c;
-                        bool any = false;
-#pragma unroll
-                        for (int cc = 0; cc < NC; ++cc) {
-                            if (ytop >= 0) { const bool mk = acc[m][cc][r] < 0.f; o[(int64_t)ytop * W + cc] = mk; any |= !mk; }
-                            if (ybot < H) { const bool mk = acc[m][NC + cc][r] < 0.f; o[(int64_t)ybot * W + cc] = mk; any |= !mk; }
-                        }
-                        if (any) row_any[(int64_t)b * Q + q] = 1;
-                    }
-                }
-            }
-        } else if constexpr (POOL != 0) {
-            // tap rows are (POOL*i + POOL/2 - 1, +1): the pair (ytop, ybot) is a tap pair iff
-            // ytop % POOL == POOL/2 - 1 (always true for POOL == 2 with even pairing)
-            const bool row_tap = (ytop >= 0) && (ybot < H) && ((ytop % POOL) == POOL / 2 - 1);   // wave-uniform
-            // tap columns are (POOL*i + POOL/2 - 1, +1).  NC == 2, POOL == 2: both in this lane.  Otherwise
-            // the left tap is this lane's LAST column and the right tap the next lane's first.
-            constexpr bool IN_LANE = (NC == 2 && POOL == 2);
-            const int cleft = IN_LANE ? c : c + NC - 1;
-            const bool col_tap = col_ok && ((cleft % POOL) == POOL / 2 - 1) && (cleft + 1 < W);
-            const int tx = cleft / POOL;
-            const int ty = (ytop >= 0 ? ytop : 0) / POOL;
-#pragma unroll
-            for (int m = 0; m < QB; ++m) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float s;
-                    if constexpr (IN_LANE) {
-                        s = (acc[m][0][r] + acc[m][1][r]) + (acc[m][2][r] + acc[m][3][r]);
-                    } else {
-                        const float n0 = __shfl_down(acc[m][0][r], 1, 64);
-                        const float n2 = __shfl_down(acc[m][NC][r], 1, 64);
-                        s = (acc[m][NC - 1][r] + n0) + (acc[m][2 * NC - 1][r] + n2);
-                    }
-                    const int q = q0 + m * 16 + qlane + r;
-                    if (row_tap && col_tap && q < Q && tx < tw && ty < th) {
-                        const bool masked = s < 0.f;
-                        attn_out[((int64_t)b * Q + q) * (th * tw) + ty * tw + tx] = masked ? 1 : 0;
-                        if (!masked) row_any[(int64_t)b * Q + q] = 1;
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);   // one row block at a time: keeps the epilogue's live set (shuffled
-                                                     // neighbours, addresses) from setting the kernel's VGPR count
-            }
+        for (int ks = 0; ks < BKS; ++ks) {
+            cur.t[ks] = nxt.t[ks];
+            cur.bt[ks] = nxt.bt[ks];
         }
+    }
+}
+
+// fp32 NCHW [B][C][HW] -> bf16 channel-quad packed [B][C/4][HW][4]
+__global__ __launch_bounds__(256) void pack_mask_features_bf16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out,
+                                                                      int64_t total, int C4, int HW) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int p = (int)(i % HW);
+        const int64_t r = i / HW;                 // b * C4 + c4
+        const float* src = in + (r * 4) * HW + p;
+        u32x2 pk;
+        pk.x = (unsigned)f2bf(src[0]) | ((unsigned)f2bf(src[HW]) << 16);
+        pk.y = (unsigned)f2bf(src[2 * (int64_t)HW]) | ((unsigned)f2bf(src[3 * (int64_t)HW]) << 16);
+        *reinterpret_cast<u32x2*>(out + i * 4) = pk;
     }
 }
 
@@ -336,5 +476,74 @@ extern "C" int msm_mask_logits_fwd(const float* mask_embed, const float* mask_fe
     hipLaunchKernelGGL(kern, grid, block, lds, st, mask_embed, mask_feat, mask_out, attn_out, row_any, Q, C, H, W, th, tw,
                        ypar, n_rowpairs, rp_step, rp_first, (int)((int64_t)C * H * W * 4));
     MSM_CHECK_LAUNCH("msm_mask_logits_fwd");
+    return MSM_OK;
+}
+
+extern "C" int msm_pack_mask_features_bf16(const float* mask_feat, uint16_t* packed, int B, int C, int HW, void* stream) {
+    MSM_REQUIRE(mask_feat && packed, "msm_pack_mask_features_bf16: null pointer");
+    MSM_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 4 == 0, "msm_pack_mask_features_bf16: C=%d must be a multiple of 4", C);
+    MSM_REQUIRE((((uintptr_t)packed) & 7) == 0, "msm_pack_mask_features_bf16: packed must be 8-byte aligned");
+    const int64_t total = (int64_t)B * (C / 4) * HW;
+    hipLaunchKernelGGL(pack_mask_features_bf16_kernel, dim3((unsigned)min((int64_t)4096, (total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, mask_feat, packed, total, C / 4, HW);
+    MSM_CHECK_LAUNCH("msm_pack_mask_features_bf16");
+    return MSM_OK;
+}
+
+extern "C" int msm_mask_logits_bf16_fwd(const float* mask_embed, const uint16_t* mask_feat_packed, float* mask_out,
+                                        uint8_t* attn_out, int32_t* row_any, int B, int Q, int C, int H, int W, int th, int tw,
+                                        int flags, void* stream) {
+    const int sparse = flags & MSM_MASK_SPARSE;
+    MSM_REQUIRE(mask_embed && mask_feat_packed, "msm_mask_logits_bf16_fwd: null input");
+    MSM_REQUIRE(mask_out || attn_out, "msm_mask_logits_bf16_fwd: nothing to produce");
+    MSM_REQUIRE(B > 0 && Q > 0 && H > 1 && W > 1, "msm_mask_logits_bf16_fwd: bad sizes");
+    MSM_REQUIRE(C % 16 == 0 && C >= 16 && C <= 16 * BKS, "msm_mask_logits_bf16_fwd: C=%d must be a multiple of 16 and <= %d", C, 16 * BKS);
+    MSM_REQUIRE(W % 2 == 0 && H % 2 == 0, "msm_mask_logits_bf16_fwd: H=%d W=%d must be even", H, W);
+    MSM_REQUIRE((int64_t)C * H * W * 2 < (int64_t)1 << 31, "msm_mask_logits_bf16_fwd: one image of mask_feat must be < 2 GiB");
+    MSM_REQUIRE((((uintptr_t)mask_embed) & 15) == 0 && (((uintptr_t)mask_feat_packed) & 7) == 0, "msm_mask_logits_bf16_fwd: misaligned pointer");
+    int pool = 0;
+    if (attn_out) {
+        MSM_REQUIRE(row_any, "msm_mask_logits_bf16_fwd: row_any required with attn_out");
+        MSM_REQUIRE(th > 0 && tw > 0 && H % th == 0 && W % tw == 0 && H / th == W / tw,
+                    "msm_mask_logits_bf16_fwd: target %dx%d incompatible with %dx%d", th, tw, H, W);
+        pool = H / th;
+        MSM_REQUIRE(pool == 1 || pool == 2 || pool == 4 || pool == 8, "msm_mask_logits_bf16_fwd: pool factor %d not in {1,2,4,8}", pool);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (attn_out && !(flags & MSM_MASK_ROW_ANY_CLEARED)) MSM_CHECK_HIP(hipMemsetAsync(row_any, 0, sizeof(int32_t) * (size_t)B * Q, st));
+    int ypar = 0, n_rowpairs = H / 2, rp_step = 1, rp_first = 0;      // row pairing exactly as msm_mask_logits_fwd
+    if (pool == 4 || pool == 8) {
+        ypar = -1;
+        n_rowpairs = H / 2 + 1;
+        if (sparse && !mask_out) {
+            rp_step = pool / 2;
+            rp_first = pool / 4;
+            n_rowpairs = H / pool;
+        }
+    }
+    const int qchunks = cdiv(Q, QCH);
+    const int ntiles = n_rowpairs * cdiv(W, 16);
+    // bandwidth-bound: two workgroups per CU (57 KB of LDS each) keep more loads in flight
+    int wg_per = cdiv(ntiles, MW);
+    const int target = cdiv(512, B * qchunks);
+    if (wg_per > target) wg_per = max(target, 1);
+    dim3 grid(wg_per, qchunks, B), block(MW * 64);
+    const size_t lds = sizeof(unsigned short) * (size_t)QCH * (C + 8);
+    typedef void (*kern_t)(const float*, const unsigned short*, float*, uint8_t*, int32_t*, int, int, int, int, int, int, int, int, int, int, int);
+    const bool wr = mask_out != nullptr;
+    kern_t kern;
+#define MASKB_PICK(P) (wr ? (kern_t)mask_logits_bf16_kernel<P, true> : (kern_t)mask_logits_bf16_kernel<P, false>)
+    switch (pool) {
+        case 0: kern = (kern_t)mask_logits_bf16_kernel<0, true>; break;
+        case 1: kern = MASKB_PICK(1); break;
+        case 2: kern = MASKB_PICK(2); break;
+        case 4: kern = MASKB_PICK(4); break;
+        default: kern = MASKB_PICK(8); break;
+    }
+#undef MASKB_PICK
+    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)kern, lds));
+    hipLaunchKernelGGL(kern, grid, block, lds, st, mask_embed, mask_feat_packed, mask_out, attn_out, row_any, Q, C, H, W, th, tw, ypar,
+                       n_rowpairs, rp_step, rp_first, (int)((int64_t)C * H * W * 2));
+    MSM_CHECK_LAUNCH("msm_mask_logits_bf16_fwd");
     return MSM_OK;
 }

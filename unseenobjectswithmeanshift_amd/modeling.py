@@ -235,6 +235,10 @@ class MeanShiftTransformerDecoder(nn.Module):
         # instead of 13 launches; needs E = 256, mask_dim = 256 and dim_feedforward % 256 == 0 (every MSMFormer yaml)
         self.fused_tails = (hidden_dim == 256 and mask_dim == 256 and dim_feedforward % 256 == 0)
         self._tails_cache = None
+        # "bf16": the Q x pixel-embedding mask step runs with bf16 operands / fp32 accumulation on a packed copy of
+        # mask_features made once per forward (BASELINE configs 3 and 5); everything else stays fp32
+        self.mask_step_dtype = "f32"
+        self._packed_mf = None
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
                               error_msgs):
@@ -306,7 +310,7 @@ class MeanShiftTransformerDecoder(nn.Module):
         cls = ops.gemm(d, self.class_embed.weight, self.class_embed.bias) if want_cls else None
         e = self.mask_embed(d)
         mask, attn, row_any = ops.mask_logits(e, mask_features, want_mask=want_mask, target_size=target_size,
-                                              sparse=self.sparse_taps)
+                                              sparse=self.sparse_taps, packed_bf16=self._packed_mf)
         return cls, mask, attn, row_any
 
     def _packed_tails(self):
@@ -346,7 +350,8 @@ class MeanShiftTransformerDecoder(nn.Module):
             cls = ops.gemm(d, self.class_embed.weight, self.class_embed.bias) if want else None
             tgt = None if (last and not full) else sizes[i_next % self.num_feature_levels]
             m, attn, row_any = ops.mask_logits(e, mask_features, want_mask=want, target_size=tgt, sparse=self.sparse_taps,
-                                               row_any=ra)       # ra: cleared by the heads kernel, no fill launch
+                                               row_any=ra,       # ra: cleared by the heads kernel, no fill launch
+                                               packed_bf16=self._packed_mf)
             pred_cls.append(cls)
             pred_mask.append(m)
             return attn, row_any
@@ -425,6 +430,9 @@ class MeanShiftTransformerDecoder(nn.Module):
                 else:
                     src.append(ops.transpose_last2(xs[i].contiguous().flatten(2)) + self.level_embed.weight[i])
         mask_features = mask_features.contiguous()
+        if self.mask_step_dtype not in ("f32", "bf16"):
+            raise ValueError("mask_step_dtype must be 'f32' or 'bf16'")
+        self._packed_mf = ops.pack_mask_features_bf16(mask_features) if self.mask_step_dtype == "bf16" else None
         qpos = self.query_embed.weight
         out = self.query_feat.weight[None].expand(B, -1, -1).contiguous()
         full = self.aux_outputs

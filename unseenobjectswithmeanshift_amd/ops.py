@@ -251,10 +251,22 @@ def transpose_last2(x):
     return out
 
 
-def mask_logits(mask_embed, mask_features, *, want_mask=True, target_size=None, sparse=False, row_any=None):
+def pack_mask_features_bf16(mask_features):
+    """fp32 NCHW (B, C, H, W) -> the channel-quad packed bf16 layout (B, C/4, H*W, 4) (int16 bit patterns) the bf16 mask
+    step streams; do it once per forward, the 10 mask steps of a decoder pass reuse it."""
+    _c(mask_features, "mask_features")
+    B, C, H, W = mask_features.shape
+    out = torch.empty((B, C // 4, H * W, 4), device=mask_features.device, dtype=torch.int16)
+    rc = lib().msm_pack_mask_features_bf16(_p(mask_features), _p(out), B, C, H * W, _stream())
+    check(rc, "msm_pack_mask_features_bf16")
+    return out
+
+
+def mask_logits(mask_embed, mask_features, *, want_mask=True, target_size=None, sparse=False, row_any=None, packed_bf16=None):
     """einsum('bqc,bchw->bqhw') with the next layer's attention mask fused.
     Returns (mask (B,Q,H,W) or None, attn (B,Q,th*tw) uint8 or None, row_any (B,Q) int32 or None).
-    row_any: an already ZEROED (B,Q) int32 buffer (dec_heads(zero_row_any=True) provides one) -- saves the fill launch."""
+    row_any: an already ZEROED (B,Q) int32 buffer (dec_heads(zero_row_any=True) provides one) -- saves the fill launch.
+    packed_bf16: pack_mask_features_bf16(mask_features) -> the step runs with bf16 operands / fp32 accumulation."""
     _c(mask_embed, "mask_embed"), _c(mask_features, "mask_features")
     B, Q, C = mask_embed.shape
     _, _, H, W = mask_features.shape
@@ -277,9 +289,15 @@ def mask_logits(mask_embed, mask_features, *, want_mask=True, target_size=None, 
     if MASK_STEP_EVENTS is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    rc = lib().msm_mask_logits_fwd(_p(mask_embed), _p(mask_features), _p(mask), _p(attn), _p(row_any),
-                                   B, Q, C, H, W, th, tw, flags, _stream())
-    check(rc, "msm_mask_logits_fwd")
+    if packed_bf16 is not None:
+        _c(packed_bf16, "packed_bf16", torch.int16)
+        rc = lib().msm_mask_logits_bf16_fwd(_p(mask_embed), _p(packed_bf16), _p(mask), _p(attn), _p(row_any),
+                                            B, Q, C, H, W, th, tw, flags, _stream())
+        check(rc, "msm_mask_logits_bf16_fwd")
+    else:
+        rc = lib().msm_mask_logits_fwd(_p(mask_embed), _p(mask_features), _p(mask), _p(attn), _p(row_any),
+                                       B, Q, C, H, W, th, tw, flags, _stream())
+        check(rc, "msm_mask_logits_fwd")
     if ev is not None:
         ev[1].record()
         MASK_STEP_EVENTS.append(ev)
