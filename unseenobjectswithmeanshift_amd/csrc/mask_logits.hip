@@ -523,9 +523,11 @@ extern "C" int msm_mask_logits_bf16_fwd(const float* mask_embed, const uint16_t*
     }
     const int qchunks = cdiv(Q, QCH);
     const int ntiles = n_rowpairs * cdiv(W, 16);
-    // bandwidth-bound: two workgroups per CU (57 KB of LDS each) keep more loads in flight
+    // one workgroup per CU: with more, re-staging mask_embed (100 KB per workgroup) costs more than the extra loads in
+    // flight gain (measured 30 us at 256 workgroups, 41 us at 512, 46 us at 1024)
     int wg_per = cdiv(ntiles, MW);
-    const int target = cdiv(512, B * qchunks);
+    static const int tgt_total = getenv("MSM_MASKB_TARGET") ? atoi(getenv("MSM_MASKB_TARGET")) : 256;
+    const int target = cdiv(tgt_total, B * qchunks);
     if (wg_per > target) wg_per = max(target, 1);
     dim3 grid(wg_per, qchunks, B), block(MW * 64);
     const size_t lds = sizeof(unsigned short) * (size_t)QCH * (C + 8);
