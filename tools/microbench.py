@@ -140,6 +140,54 @@ def kv():
         print(f"   kv_project kernel: {t2:6.1f} us  {by / t2 / 1e6:6.2f} TB/s  max|diff| {err:.2e}", flush=True)
 
 
+def twostage():
+    """BASELINE configs[3]: two-stage RGB + depth-crop refinement at 640x480 over 16 frames (first stage on the frame,
+    depth filter, ROI crops resized to 224x224, one BATCHED second stage over all crops, paste-back).  The backbone is out of
+    scope: a cheap stand-in (tests/test_gpu_modules._TinyBackbone) produces res2..res5."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import test_gpu_modules as tg
+    from unseenobjectswithmeanshift_amd import two_stage as ts
+    from unseenobjectswithmeanshift_amd.meta_arch import Instances, MeanShiftMaskFormer, Network_RGBD
+    head = tg.make_pixel_decoder()
+    bb = tg._TinyBackbone().to(DEV).eval()
+
+    class RGBD(MeanShiftMaskFormer):
+        def forward(self, batched_inputs):
+            imgs = torch.stack([x["image"] for x in batched_inputs])
+            deps = torch.stack([x["depth"] for x in batched_inputs])
+            H, W = imgs.shape[-2:]
+            scores, classes, masks, boxes, _ = self.inference(self.backbone(imgs, deps), (int(H), int(W)))
+            return [{"instances": Instances((int(H), int(W)), pred_masks=masks[b], pred_boxes=boxes[b], scores=scores[b],
+                                            pred_classes=classes[b])} for b in range(len(batched_inputs))]
+
+    model = RGBD(backbone=bb, sem_seg_head=head, num_queries=100)
+    crops = []
+
+    class Pred(Network_RGBD):
+        def batch_call(self, samples):
+            crops.append(len(samples))
+            with torch.no_grad():
+                return self.model(samples)
+
+    first, second = Network_RGBD(model), Pred(model)
+    g = torch.Generator().manual_seed(3)
+    frames = [(torch.rand(3, 480, 640, generator=g).to(DEV), torch.rand(3, 480, 640, generator=g).to(DEV)) for _ in range(16)]
+
+    def run():
+        for im, dp in frames:
+            ts.test_sample_crop_nolabel({"image_color": im, "depth": dp}, first, second, confident_score=0.0, topk=False)
+
+    run()
+    torch.cuda.synchronize()
+    crops.clear()
+    t0 = time.perf_counter()
+    run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"two-stage 640x480, 16 frames: {dt * 1e3 / 16:7.2f} ms per frame = {16 / dt:6.1f} frames/s, "
+          f"{sum(crops) / max(1, len(crops)):.1f} crops per frame in one batched second-stage call", flush=True)
+
+
 def tails():
     """Fused decoder-layer tails (csrc/dec_chain.hip) at B=8, Q=100."""
     B, Q, E, Fh = 8, 100, 256, 2048
@@ -218,4 +266,4 @@ def meanshift():
 
 if __name__ == "__main__":
     {"gemm": gemm, "mask": mask, "enc": enc, "attn": attn, "ucn": ucn, "meanshift": meanshift, "cfg5": cfg5,
-     "tails": tails, "kv": kv, "maskbf16": maskbf16}[sys.argv[1]]()
+     "tails": tails, "kv": kv, "maskbf16": maskbf16, "twostage": twostage}[sys.argv[1]]()

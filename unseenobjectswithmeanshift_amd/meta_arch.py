@@ -193,6 +193,17 @@ def combine_masks(instances):
     return out
 
 
+def combine_masks_tensor(instances):
+    """combine_masks without leaving the device: (H,W) float64 tensor, identical values.  "Later instances overwrite
+    earlier ones" with labels growing in instance order is the per-pixel maximum of mask_i * (i + 2)."""
+    masks = instances.get("pred_masks")
+    if masks.dim() != 3 or masks.shape[0] == 0:
+        h, w = instances.image_size
+        return torch.zeros((h, w), dtype=torch.float64, device=masks.device)
+    ids = torch.arange(2, 2 + masks.shape[0], device=masks.device, dtype=torch.float64)
+    return ((masks != 0).to(torch.float64) * ids[:, None, None]).amax(0)
+
+
 # ----------------------------------------------------------------------------------------------
 def build_ucn_head(num_queries=100, dec_layers=6, num_classes=2, hidden_dim=256, mask_dim=256, conv_dim=64, nheads=8,
                    dim_feedforward=2048):

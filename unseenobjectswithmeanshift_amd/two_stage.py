@@ -22,10 +22,13 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .meta_arch import combine_masks, get_confident_instances
+from .meta_arch import combine_masks_tensor, combine_masks, get_confident_instances
 
 CROP_SIZE = 224          # cfg.TRAIN.SYN_CROP_SIZE, lib/fcn/config.py:130
 PADDING_PERCENTAGE = 0.25
+
+
+LABEL_BINS = 4096      # label images hold 0 and 2..N+1 with N <= detections per image (20 by default)
 
 
 def mask_to_tight_box(mask):
@@ -36,17 +39,18 @@ def mask_to_tight_box(mask):
 
 def filter_labels_depth(labels, depth, threshold):
     """Zero every label whose pixels have valid depth (z > 0) on less than `threshold` of their area.
-    labels (B,H,W), depth (B,3,H,W) xyz."""
+    labels (B,H,W) with small non-negative integer values, depth (B,3,H,W) xyz.  (lib/fcn/test_dataset.py:183-198; the
+    per-label loop of the reference is two histograms here: same integer counts, same fp32 division, no host syncs.)"""
     out = labels.clone()
     for i in range(labels.shape[0]):
-        label = labels[i]
-        valid = depth[i, 2] > 0
-        for mask_id in torch.unique(label):
-            if mask_id == 0:
-                continue
-            m = label == mask_id
-            if (valid & m).sum().float() / m.sum().float() < threshold:
-                out[i][m] = 0
+        lab = labels[i].reshape(-1).to(torch.int64)
+        k = int(LABEL_BINS)
+        valid = (depth[i, 2] > 0).reshape(-1)
+        area = torch.bincount(lab.clamp(0, k - 1), minlength=k)[:k]
+        good = torch.bincount(lab.clamp(0, k - 1)[valid], minlength=k)[:k]
+        bad = (good.float() / area.float().clamp_min(1.0) < threshold) & (area > 0)
+        bad[0] = False
+        out[i][bad[lab.clamp(0, k - 1)].view_as(labels[i])] = 0
     return out
 
 
@@ -87,11 +91,14 @@ def match_label_crop(initial_masks, labels_crop, out_label_crop, rois, depth_cro
     segments back at ROI resolution; later crops overwrite earlier ones.
     Returns (refined (1,H,W) float, labels_crop with rejected segments set to -1)."""
     num = labels_crop.shape[0]
-    for i in range(num):
-        for mask_id in torch.unique(labels_crop[i]):
-            m = labels_crop[i] == mask_id
-            if (m.float() * out_label_crop[i]).sum() / m.float().sum() < 0.5:
-                labels_crop[i][m] = -1
+    # overlap of every (crop, segment) with the first-stage mask as two histograms (TD:125-131: same counts, same fp32
+    # division as the reference's per-segment loop)
+    k = int(LABEL_BINS)
+    lab = labels_crop.reshape(num, -1).to(torch.int64).clamp(0, k - 1) + torch.arange(num, device=labels_crop.device)[:, None] * k
+    area = torch.bincount(lab.reshape(-1), minlength=num * k)[:num * k]
+    hit = torch.bincount(lab.reshape(-1), weights=out_label_crop.reshape(-1).float(), minlength=num * k)[:num * k]
+    bad = (hit.float() / area.float().clamp_min(1.0) < 0.5) & (area > 0)
+    labels_crop[bad[lab].view_as(labels_crop)] = -1
     keys = []
     for i in range(num):
         if depth_crop is not None:
@@ -159,7 +166,7 @@ def _labels_from_outputs(outputs, topk, confident_score, low_threshold, num_clas
                                    low_threshold=low_threshold)
     if use_nms:
         return combine_masks_with_NMS(conf)
-    return combine_masks(conf), None, None
+    return combine_masks_tensor(conf), None, None     # same values as combine_masks, no host round trip
 
 
 def test_sample_crop_nolabel(sample, predictor, predictor_crop=None, *, use_depth=True, topk=False,
