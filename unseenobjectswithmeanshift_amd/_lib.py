@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmsm_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "msm_hip.h")
 
 _lib = None
+ABI_VERSION = 2      # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
 
 c_f = ctypes.c_void_p      # float* (device)
 c_p = ctypes.c_void_p
@@ -82,6 +83,8 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        if L.msm_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} has ABI {L.msm_abi_version()}, these bindings need {ABI_VERSION}: rebuild it")
         _lib = L
     return _lib
 

@@ -40,4 +40,4 @@ int ensure_dynamic_lds(const void* kernel, size_t bytes) {
 }  // namespace msm
 
 extern "C" const char* msm_last_error_string(void) { return msm::g_err; }
-extern "C" int msm_abi_version(void) { return 1; }
+extern "C" int msm_abi_version(void) { return MSM_ABI_VERSION; }
