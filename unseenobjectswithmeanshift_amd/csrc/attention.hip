@@ -378,6 +378,185 @@ __global__ __launch_bounds__(256) void hs_attn_small_kernel(const float* __restr
     }
 }
 
+// ---- long key sequences, same idea: a workgroup owns MQ query blocks, its NW waves split the key blocks round-robin, the
+// partial sums meet in LDS (lane-contiguous, 9 values per lane and query block) and wave 0 finishes in registers.  No
+// partial tensors in memory, no combine launch; K/V of an (image, head) are re-read by the ceil(7/MQ) workgroups of that
+// head out of L2.
+template <int MQ, int NW>
+__global__ __launch_bounds__(NW * 64) void hs_attn_qk_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ v, const uint8_t* __restrict__ masked,
+                                                            const int32_t* __restrict__ row_any, float* __restrict__ out, int Lq,
+                                                            int S, int heads, int64_t ldq, int64_t q_sb, int64_t ldk,
+                                                            int64_t k_sb, int64_t ldv, int64_t v_sb, float kappa) {
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [NW-1][MQ][9][64]: partial O (8) and l (1) per lane
+    const int qb0 = blockIdx.x * MQ;                            // first 16-query block of this workgroup (all waves)
+
+    float qf[MQ][8];
+    bool use_mask[MQ];
+    const float* qbp = q + (int64_t)b * q_sb + h * HD + lq * 8;
+#pragma unroll
+    for (int m = 0; m < MQ; ++m) {
+        const int qi = (qb0 + m) * 16 + lj;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+        if (qi < Lq) {
+            const float* p = qbp + (int64_t)qi * ldq;
+            a = *reinterpret_cast<const float4*>(p);
+            c = *reinterpret_cast<const float4*>(p + 4);
+        }
+        float ss = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        const float rn = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        qf[m][0] = a.x * rn; qf[m][1] = a.y * rn; qf[m][2] = a.z * rn; qf[m][3] = a.w * rn;
+        qf[m][4] = c.x * rn; qf[m][5] = c.y * rn; qf[m][6] = c.z * rn; qf[m][7] = c.w * rn;
+        use_mask[m] = masked != nullptr && qi < Lq && (row_any == nullptr || row_any[(int64_t)b * Lq + qi] != 0);   // DEC:618
+    }
+    f32x4 o[MQ][2];
+    float lsum[MQ];
+#pragma unroll
+    for (int m = 0; m < MQ; ++m) {
+        o[m][0] = o[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        lsum[m] = 0.f;
+    }
+    const int nkb = (S + 15) / 16;
+    const float* kbp = k + (int64_t)b * k_sb + h * HD + lq * 8;
+    const float* vbp = v + (int64_t)b * v_sb + h * HD + lj;
+    const bool mask_vec = (S % 4) == 0;
+    struct Frag {
+        float4 ka, kc;
+        float v[4][2];
+        uint32_t mw[MQ];
+    };
+    auto fetch = [&](int kb, Frag& f) {
+        const float* kp = kbp + (int64_t)min(kb * 16 + lj, S - 1) * ldk;
+        f.ka = *reinterpret_cast<const float4*>(kp);
+        f.kc = *reinterpret_cast<const float4*>(kp + 4);
+        const int key_c0 = kb * 16 + lq * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* vp = vbp + (int64_t)min(key_c0 + r, S - 1) * ldv;
+            f.v[r][0] = vp[0];
+            f.v[r][1] = vp[16];
+        }
+#pragma unroll
+        for (int m = 0; m < MQ; ++m) {
+            uint32_t w = 0;
+            if (masked != nullptr) {
+                const uint8_t* mp = masked + ((int64_t)b * Lq + min((qb0 + m) * 16 + lj, Lq - 1)) * S;
+                if (mask_vec) {
+                    w = *reinterpret_cast<const uint32_t*>(mp + min(key_c0, S - 4));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) w |= (uint32_t)mp[min(key_c0 + r, S - 1)] << (8 * r);
+                }
+            }
+            f.mw[m] = w;
+        }
+    };
+    const float k2 = kappa * 1.4426950408889634f;
+    auto consume = [&](int kb, const Frag& f) {
+        const float4 a = f.ka, c = f.kc;
+        float ss = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        const float rn = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        const float kf[8] = {a.x * rn, a.y * rn, a.z * rn, a.w * rn, c.x * rn, c.y * rn, c.z * rn, c.w * rn};
+        const int key_c0 = kb * 16 + lq * 4;
+        f32x4 sc[MQ];
+#pragma unroll
+        for (int m = 0; m < MQ; ++m) sc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int m = 0; m < MQ; ++m) sc[m] = mfma16(kf[t], qf[m][t], sc[m]);
+#pragma unroll
+        for (int m = 0; m < MQ; ++m) {
+            const uint32_t mw = use_mask[m] ? f.mw[m] : 0u;
+            float p[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool dead = (key_c0 + r >= S) || ((mw >> (8 * r)) & 0xffu);
+                p[r] = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(sc[m][r], k2, -k2));
+            }
+            lsum[m] += (p[0] + p[1]) + (p[2] + p[3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o[m][0] = mfma16(p[r], f.v[r][0], o[m][0]);
+                o[m][1] = mfma16(p[r], f.v[r][1], o[m][1]);
+            }
+        }
+    };
+    {
+        Frag fa, fb;
+        int kb = wave;                             // key blocks wave, wave + NW, ...
+        if (kb < nkb) fetch(kb, fa);
+        for (; kb + NW < nkb; kb += 2 * NW) {
+            fetch(kb + NW, fb);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(kb, fa);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(min(kb + 2 * NW, nkb - 1), fa);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(kb + NW, fb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kb < nkb) consume(kb, fa);
+    }
+    // ---- sum the waves' partials: waves 1.. park theirs lane-contiguously, wave 0 adds them to its registers ----
+    if (wave > 0) {
+        float* mine = red + (size_t)(wave - 1) * MQ * 9 * 64;
+#pragma unroll
+        for (int m = 0; m < MQ; ++m) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                mine[(m * 9 + r) * 64 + lane] = o[m][0][r];
+                mine[(m * 9 + 4 + r) * 64 + lane] = o[m][1][r];
+            }
+            mine[(m * 9 + 8) * 64 + lane] = lsum[m];
+        }
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    for (int w = 1; w < NW; ++w) {
+        const float* src = red + (size_t)(w - 1) * MQ * 9 * 64;
+#pragma unroll
+        for (int m = 0; m < MQ; ++m) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o[m][0][r] += src[(m * 9 + r) * 64 + lane];
+                o[m][1][r] += src[(m * 9 + 4 + r) * 64 + lane];
+            }
+            lsum[m] += src[(m * 9 + 8) * 64 + lane];
+        }
+    }
+    // ---- finish in registers: o[m][half][r] = query (qb0+m)*16 + lq*4 + r, dim half*16 + lj ----
+#pragma unroll
+    for (int m = 0; m < MQ; ++m) {
+        float l = lsum[m];                     // per query lj (any lq) after the two reductions
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float lr = __shfl(l, lq * 4 + r, 64);          // denominator of this lane's output row
+            const float a0 = o[m][0][r] / lr, a1 = o[m][1][r] / lr;
+            float ss = a0 * a0 + a1 * a1;
+#pragma unroll
+            for (int x = 1; x < 16; x <<= 1) ss += __shfl_xor(ss, x, 64);
+            const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+            const int qi = (qb0 + m) * 16 + lq * 4 + r;
+            if (qi < Lq) {
+                float* o_ = out + ((int64_t)b * Lq + qi) * (heads * HD) + h * HD + lj;
+                o_[0] = a0 / nrm;
+                o_[16] = a1 / nrm;
+            }
+        }
+    }
+}
+
 // out[b][q][h*32 + d] = normalize( (sum_splits O) / (sum_splits l) )
 __global__ __launch_bounds__(128) void hs_attn_combine_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                               int Lq, int heads, int qchunks, int nsplit) {
@@ -449,6 +628,20 @@ extern "C" int msm_hypersphere_attn_fwd(const float* q, const float* k, const fl
                                q_sb, ldk, k_sb, ldv, v_sb, kappa);
         }
         MSM_CHECK_LAUNCH("msm_hypersphere_attn_fwd(small)");
+        return MSM_OK;
+    }
+    if (S <= 2048 && getenv("MSM_ATTN_SPLITK") == nullptr) {
+        // medium sequences: query-split workgroups whose waves split the keys (measured at 1200 keys: 23 us against
+        // 25 + 8 us for the split-K kernel + combine; at 4800 keys the split-K kernel, which normalises each key block
+        // once for all 7 query blocks, is faster: 60 + 8 against 71 us)
+        constexpr int MQ = 2;
+        dim3 grid(cdiv(cdiv(Lq, 16), MQ), heads, B);
+        constexpr int NW = 8;
+        const size_t lds2 = sizeof(float) * (size_t)(NW - 1) * MQ * 9 * 64;
+        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)hs_attn_qk_kernel<MQ, NW>, lds2));
+        hipLaunchKernelGGL((hs_attn_qk_kernel<MQ, NW>), grid, dim3(NW * 64), lds2, st, q, k, v, masked, row_any, out, Lq, S, heads,
+                           ldq, q_sb, ldk, k_sb, ldv, v_sb, kappa);
+        MSM_CHECK_LAUNCH("msm_hypersphere_attn_fwd(qk)");
         return MSM_OK;
     }
     const size_t lds = sizeof(float) * 4 * AQCH * PSTRIDE;
