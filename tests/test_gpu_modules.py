@@ -355,6 +355,26 @@ def test_meta_arch_inference_vs_oracle():
     assert lab.shape == (64, 96)
 
 
+def test_graphed_inference_equals_eager():
+    """graphs.GraphedInference: capture once per geometry, replay with new inputs -- identical to the eager path."""
+    from unseenobjectswithmeanshift_amd.meta_arch import MeanShiftMaskFormer
+    model = MeanShiftMaskFormer(backbone=None, sem_seg_head=make_pixel_decoder(), num_queries=100)
+    g = model.graphed()
+    for seed in (3, 4, 3):
+        feats = {k: v.to(DEV) for k, v in syn.synth_backbone_features(2, 64, 96, seed=seed).items()}
+        want = model.inference(feats, (64, 96))
+        got = g(feats, (64, 96))
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+    assert len(g._graphs) == 1
+    feats1 = {k: v[:1].contiguous() for k, v in feats.items()}
+    for a, b in zip(g(feats1, (64, 96)), model.inference(feats1, (64, 96))):
+        assert torch.equal(a, b)
+    assert len(g._graphs) == 2
+    with pytest.raises(RuntimeError):
+        g({k: v.cpu() for k, v in feats.items()}, (64, 96))
+
+
 class _TinyBackbone(torch.nn.Module):
     """Test-only stand-in for the (out-of-scope) ResNet-50: average-pool pyramid + fixed random 1x1 mixing,
     plain torch ops.  Gives res2..res5 with the right channel counts for any H, W divisible by 32."""

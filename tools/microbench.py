@@ -188,6 +188,22 @@ def twostage():
           f"{sum(crops) / max(1, len(crops)):.1f} crops per frame in one batched second-stage call", flush=True)
 
 
+def latency():
+    """Single-frame latency of the hot path (B=1, 640x480): eager Python launches against HIP-graph replay."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import test_gpu_modules as tg
+    from unseenobjectswithmeanshift_amd import synthetic as syn
+    from unseenobjectswithmeanshift_amd.meta_arch import MeanShiftMaskFormer
+    model = MeanShiftMaskFormer(backbone=None, sem_seg_head=tg.make_pixel_decoder(), num_queries=100)
+    g = model.graphed()
+    for B in (1, 2, 4, 8):
+        feats = {k: v.to(DEV) for k, v in syn.synth_backbone_features(B, 480, 640, seed=3).items()}
+        te = timeit(lambda: model.inference(feats, (480, 640)), iters=20)
+        tg_ = timeit(lambda: g(feats, (480, 640)), iters=20)
+        print(f"B={B}: eager {te / 1e3:6.2f} ms ({B / te * 1e6:7.1f} images/s)   graph replay incl. input copy {tg_ / 1e3:6.2f} ms "
+              f"({B / tg_ * 1e6:7.1f} images/s)", flush=True)
+
+
 def tails():
     """Fused decoder-layer tails (csrc/dec_chain.hip) at B=8, Q=100."""
     B, Q, E, Fh = 8, 100, 256, 2048
@@ -266,4 +282,4 @@ def meanshift():
 
 if __name__ == "__main__":
     {"gemm": gemm, "mask": mask, "enc": enc, "attn": attn, "ucn": ucn, "meanshift": meanshift, "cfg5": cfg5,
-     "tails": tails, "kv": kv, "maskbf16": maskbf16, "twostage": twostage}[sys.argv[1]]()
+     "tails": tails, "kv": kv, "maskbf16": maskbf16, "twostage": twostage, "latency": latency}[sys.argv[1]]()

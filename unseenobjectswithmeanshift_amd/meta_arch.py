@@ -130,6 +130,11 @@ class MeanShiftMaskFormer(nn.Module):
         masks, scores, boxes = ops.instance_postprocess(outputs["pred_masks"], qidx, image_size, class_scores=cls_scores)
         return scores, classes, masks, boxes, qidx
 
+    def graphed(self, warmup=2):
+        """HIP-graph replayed ``inference`` (graphs.GraphedInference): same results, no per-launch host cost."""
+        from .graphs import GraphedInference
+        return GraphedInference(self, warmup=warmup)
+
     @torch.no_grad()
     def forward(self, batched_inputs):
         """batched_inputs: list of dicts with "image" (3,H,W) -- or one dict holding a 4-D batch, as
