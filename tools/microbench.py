@@ -251,9 +251,11 @@ def cfg5():
     model = MeanShiftMaskFormer(backbone=None, sem_seg_head=head.to(DEV).eval(), num_queries=300)
     for B in (1, 4):
         feats = {k: v.to(DEV) for k, v in syn.synth_backbone_features(B, 960, 1280, seed=9).items()}
-        t = timeit(lambda: model.inference(feats, (960, 1280)), iters=5, warm=2)
-        print(f"cfg5 1280x960 Q=300 L=19 B={B}: {t / 1e3:8.2f} ms per batch, {B / (t * 1e-6):7.1f} images/s, "
-              f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
+        for mode in ("f32", "bf16"):
+            head.predictor.mask_step_dtype = mode
+            t = timeit(lambda: model.inference(feats, (960, 1280)), iters=5, warm=2)
+            print(f"cfg5 1280x960 Q=300 L=19 B={B} mask step {mode}: {t / 1e3:8.2f} ms per batch, {B / (t * 1e-6):7.1f} images/s, "
+                  f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
 
 
 def meanshift():
