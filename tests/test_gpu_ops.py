@@ -462,6 +462,21 @@ def test_mean_shift_kernels(golden):
     assert torch.equal(lab2.cpu(), exp)
 
 
+@pytest.mark.parametrize("n", [4096, 70001, 150000, 393216])
+def test_mean_shift_persistent_seeding_equals_stepwise(n, monkeypatch):
+    """The single-launch persistent seeding kernel (map held in registers, grid barrier per step) selects exactly the
+    indices of the one-launch-per-step path: same butterfly dot products, same (value, ~index) keys."""
+    from unseenobjectswithmeanshift_amd import synthetic as syn
+    X, _ = syn.synth_unit_embeddings(n, 64, clusters=9, sigma=0.2, seed=n % 97)
+    Xd = X.to(DEV)
+    seeds_p, sel_p = ops().ms_select_seeds(Xd, 40, n // 3)
+    monkeypatch.setenv("MSM_MS_NO_PERSISTENT", "1")
+    seeds_s, sel_s = ops().ms_select_seeds(Xd, 40, n // 3)
+    assert int(sel_p.min()) >= 0                       # -1 would mean the persistent kernel gave up
+    assert torch.equal(sel_p, sel_s) and torch.equal(seeds_p, seeds_s)
+    assert int(sel_p[0]) == n // 3 and sel_p.unique().numel() == 40
+
+
 def test_mean_shift_many_seeds():
     from unseenobjectswithmeanshift_amd import synthetic as syn
     X, _ = syn.synth_unit_embeddings(5000, 64, clusters=24, sigma=0.15, seed=2)

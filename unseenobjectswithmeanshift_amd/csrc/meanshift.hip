@@ -138,16 +138,137 @@ __global__ __launch_bounds__(256) void ms_seed_step_kernel(const float* __restri
     }
 }
 
+// ---- persistent seeding for maps that fit the register file -----------------------------------------------------
+// All S-1 farthest-point steps in ONE launch: X (n x 64 fp32 = 79 MB at 640x480) is read once into VGPRs -- a workgroup
+// of 8 waves holds 512*NG rows, 200 workgroups hold the map -- and every step is a dot product against the previous
+// winner's row from registers, the same butterfly and (value, ~index) atomicMax key as ms_seed_step_kernel (so the
+// selected indices are bit-identical), and a grid barrier (one release add per workgroup on an agent-scope counter,
+// relaxed polling).  The per-step cost is the barrier (~4 us) instead of a 79 MB stream (~22 us).
+// Safety: the grid never exceeds the number of CUs (one workgroup per CU is guaranteed by the launch bounds), so all
+// workgroups are co-resident; every wait is bounded and raises `status[1]`, which makes every workgroup leave and the
+// finish kernel report -1 indices instead of hanging the queue.
+constexpr int PS_W = 8;                      // waves per persistent workgroup
+constexpr unsigned PS_SPIN_LIMIT = 1u << 20; // polls (with s_sleep) before giving up: well under a second
+
+template <int NG>
+__global__ __launch_bounds__(PS_W * 64) void ms_seed_persistent_kernel(const float* __restrict__ X, int n,
+                                                                     unsigned long long* __restrict__ keys, int num_seeds,
+                                                                     unsigned int* __restrict__ status /* [0] arrivals, [1] abort */) {
+    __shared__ unsigned long long red[PS_W];
+    __shared__ unsigned long long prev_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, grp = lane >> 4;
+    const int blk0 = blockIdx.x * (PS_W * 4 * 16 * NG);
+    float4 x[NG][16];
+    float near[NG];
+    int rowj[NG];
+#pragma unroll
+    for (int t = 0; t < NG; ++t) {
+        const int base = blk0 + ((wave * 4 + grp) * NG + t) * 16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            x[t][i] = *reinterpret_cast<const float4*>(X + (int64_t)min(base + i, n - 1) * MS_D + j * 4);
+        rowj[t] = base + j;
+        near[t] = INFINITY;
+    }
+    for (int step = 1; step < num_seeds; ++step) {
+        if (tid == 0) prev_s = __hip_atomic_load(&keys[step - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned int cur = 0xFFFFFFFFu - (unsigned int)(prev_s & 0xFFFFFFFFull);
+        if (cur >= (unsigned int)n) return;      // only after an abort elsewhere (keys left at 0): leave, uniformly
+        const float4 s = *reinterpret_cast<const float4*>(X + (int64_t)cur * MS_D + j * 4);
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int t = 0; t < NG; ++t) {
+            float p[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) p[i] = x[t][i].x * s.x + x[t][i].y * s.y + x[t][i].z * s.z + x[t][i].w * s.w;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool hi = j & 8;
+                const float send = hi ? p[i] : p[i + 8];
+                const float keep = hi ? p[i + 8] : p[i];
+                p[i] = keep + __shfl_xor(send, 8, 64);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool hi = j & 4;
+                const float send = hi ? p[i] : p[i + 4];
+                const float keep = hi ? p[i + 4] : p[i];
+                p[i] = keep + __shfl_xor(send, 4, 64);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bool hi = j & 2;
+                const float send = hi ? p[i] : p[i + 2];
+                const float keep = hi ? p[i + 2] : p[i];
+                p[i] = keep + __shfl_xor(send, 2, 64);
+            }
+            {
+                const bool hi = j & 1;
+                const float send = hi ? p[0] : p[1];
+                const float keep = hi ? p[1] : p[0];
+                p[0] = keep + __shfl_xor(send, 1, 64);
+            }
+            if (rowj[t] < n) {
+                const float d = fminf(near[t], 0.5f * (1.0f - p[0]));
+                near[t] = d;
+                const unsigned long long key =
+                    ((unsigned long long)ordered_bits(d) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)rowj[t]);
+                best = key > best ? key : best;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(best, o, 64);
+            best = other > best ? other : best;
+        }
+        if (lane == 0) red[wave] = best;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long b = red[0];
+#pragma unroll
+            for (int w = 1; w < PS_W; ++w) b = red[w] > b ? red[w] : b;
+            if (b) __hip_atomic_fetch_max(&keys[step], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // grid barrier: the release orders the key update before the arrival; polling is relaxed and bounded.
+            // (A two-level arrival -- one counter per XCD class, the last of a class forwards -- was measured at the
+            // same 10 us per step: the cost is the cross-XCD round trips, not the 200 same-address atomics.)
+            __hip_atomic_fetch_add(&status[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int target = (unsigned int)step * gridDim.x;
+            unsigned int polls = 0;
+            while (__hip_atomic_load(&status[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                if (__hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                if (++polls > PS_SPIN_LIMIT) {
+                    __hip_atomic_store(&status[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);     // agent scope by default: later key reads see the other XCDs' updates
+        }
+        __syncthreads();
+        if (__hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // uniform per block after the barrier
+    }
+}
+
+__global__ void ms_seed_status_init_kernel(unsigned int* __restrict__ status) {
+    if (threadIdx.x < 2) status[threadIdx.x] = 0u;
+}
+
 __global__ void ms_seed_init_kernel(unsigned long long* __restrict__ keys, int num_seeds, int64_t first) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < num_seeds) keys[i] = i == 0 ? (0xFFFFFFFF00000000ull | (unsigned long long)(0xFFFFFFFFu - (unsigned int)first)) : 0ull;
 }
 
 __global__ void ms_seed_finish_kernel(const float* __restrict__ X, const unsigned long long* __restrict__ keys,
-                                      int64_t* __restrict__ sel, float* __restrict__ seeds) {
+                                      int64_t* __restrict__ sel, float* __restrict__ seeds, const unsigned int* __restrict__ status,
+                                      int n) {
     const int i = blockIdx.x;
-    const unsigned int idx = 0xFFFFFFFFu - (unsigned int)(keys[i] & 0xFFFFFFFFull);
-    if (threadIdx.x == 0) sel[i] = (int64_t)idx;
+    unsigned int idx = 0xFFFFFFFFu - (unsigned int)(keys[i] & 0xFFFFFFFFull);
+    if ((status && status[1] != 0u) || idx >= (unsigned int)n) {      // persistent kernel gave up: report, do not fabricate
+        if (threadIdx.x == 0) sel[i] = -1;
+        idx = 0;
+    } else if (threadIdx.x == 0) sel[i] = (int64_t)idx;
     if (threadIdx.x < MS_D) seeds[(int64_t)i * MS_D + threadIdx.x] = X[(int64_t)idx * MS_D + threadIdx.x];
 }
 
@@ -401,6 +522,7 @@ static int hill_wgs(int n) { return max(1, min(512, ((n + 15) / 16 + 3) / 4)); }
 
 using namespace msm;
 
+// keys [S] u64 | 8 words (2 used: barrier arrivals, abort flag) | nearest [n] (stepwise path)
 extern "C" int64_t msm_ms_seed_workspace(int n) { return (int64_t)n + 2 * (MS_SB * 16) + 16; }
 
 extern "C" int msm_ms_select_seeds(const float* X, int n, int d, int num_seeds, int64_t first_index, float* seeds_out,
@@ -419,10 +541,31 @@ extern "C" int msm_ms_select_seeds(const float* X, int n, int d, int num_seeds, 
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(workspace);       // [num_seeds]
     float* nearest = workspace + 2 * (MS_SB * 16) + 8;
     hipLaunchKernelGGL(ms_seed_init_kernel, dim3(cdiv(num_seeds, 64)), dim3(64), 0, st, keys, num_seeds, first_index);
+    // persistent single-launch path when the map fits the register files of the CUs (see ms_seed_persistent_kernel)
+    static const int n_cus = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+        return v;
+    }();
+    const int ng = cdiv(n, 256 * PS_W * 64);                       // rows per workgroup = 512 * ng
+    const int pgrid = ng >= 1 && ng <= 3 ? cdiv(n, PS_W * 64 * ng) : 0;
+    unsigned int* status = reinterpret_cast<unsigned int*>(workspace + 2 * (MS_SB * 16) + 4);   // 2 words between keys and nearest
+    if (pgrid > 0 && pgrid <= n_cus && n >= 4096 && num_seeds > 2 && getenv("MSM_MS_NO_PERSISTENT") == nullptr) {
+        hipLaunchKernelGGL(ms_seed_status_init_kernel, dim3(1), dim3(64), 0, st, status);
+        switch (ng) {
+            case 1: hipLaunchKernelGGL(ms_seed_persistent_kernel<1>, dim3(pgrid), dim3(PS_W * 64), 0, st, X, n, keys, num_seeds, status); break;
+            case 2: hipLaunchKernelGGL(ms_seed_persistent_kernel<2>, dim3(pgrid), dim3(PS_W * 64), 0, st, X, n, keys, num_seeds, status); break;
+            default: hipLaunchKernelGGL(ms_seed_persistent_kernel<3>, dim3(pgrid), dim3(PS_W * 64), 0, st, X, n, keys, num_seeds, status); break;
+        }
+        hipLaunchKernelGGL(ms_seed_finish_kernel, dim3(num_seeds), dim3(64), 0, st, X, keys, indices_out, seeds_out, status, n);
+        MSM_CHECK_LAUNCH("msm_ms_select_seeds(persistent)");
+        return MSM_OK;
+    }
     for (int i = 1; i < num_seeds; ++i)
         if (n >= 16) hipLaunchKernelGGL(ms_seed_step_kernel<false>, dim3(nblk), dim3(256), 0, st, X, n, keys, i, nearest);
         else hipLaunchKernelGGL(ms_seed_step_kernel<true>, dim3(nblk), dim3(256), 0, st, X, n, keys, i, nearest);
-    hipLaunchKernelGGL(ms_seed_finish_kernel, dim3(num_seeds), dim3(64), 0, st, X, keys, indices_out, seeds_out);
+    hipLaunchKernelGGL(ms_seed_finish_kernel, dim3(num_seeds), dim3(64), 0, st, X, keys, indices_out, seeds_out,
+                       (const unsigned int*)nullptr, n);
     MSM_CHECK_LAUNCH("msm_ms_select_seeds");
     return MSM_OK;
 }
