@@ -84,6 +84,8 @@ def mean_shift_smart_init(X, kappa, num_seeds=100, max_iters=10, metric="cosine"
     seeds, selected = select_smart_seeds(X, num_seeds, return_selected_indices=True, metric=metric,
                                          first_index=first_index)
     seed_labels, Z = mean_shift_with_seeds(X, seeds, kappa, max_iters=max_iters, metric=metric)
+    if int(selected.min()) < 0:      # the persistent seeding kernel gave up at a bounded wait (never seen; fail loudly)
+        raise RuntimeError("msm_ms_select_seeds: the persistent seeding kernel aborted; set MSM_MS_NO_PERSISTENT=1")
     num = int(torch.unique(seed_labels).numel())
     labels, counts = ops.ms_assign(X, Z, seed_labels.to(X.device), num)
     ops.ms_relabel_largest_zero(labels, counts)
