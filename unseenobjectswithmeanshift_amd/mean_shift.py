@@ -40,19 +40,19 @@ def connected_components(Z, epsilon, metric="cosine"):
     Zc = Z.detach().to("cpu", torch.float32)
     n = Zc.shape[0]
     K = 0
-    labels = torch.full((n,), -1, dtype=torch.long)
+    labels = np.full((n,), -1, dtype=np.int64)          # bookkeeping in numpy: ~100 seeds, a dozen components
     for i in range(n):
-        if labels[i] == -1:
-            comp = (0.5 * (1 - Zc @ Zc[i])) <= epsilon
-            seen = labels[comp]
-            if torch.unique(seen).shape[0] > 1:
-                t = seen.numpy()
-                label = get_label_mode(t[t != -1])
-            else:
-                label = K
-                K += 1
-            labels[comp] = label
-    return labels
+        if labels[i] != -1:
+            continue
+        comp = ((0.5 * (1 - Zc @ Zc[i])) <= epsilon).numpy()     # same fp32 matrix-vector product as the reference
+        seen = labels[comp]
+        if np.unique(seen).shape[0] > 1:
+            label = get_label_mode(seen[seen != -1])
+        else:
+            label = K
+            K += 1
+        labels[comp] = label
+    return torch.from_numpy(labels)
 
 
 def seed_hill_climbing_ball(X, Z, kappa, max_iters=10, metric="cosine"):
