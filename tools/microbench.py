@@ -271,12 +271,15 @@ def meanshift():
         Z = ops.ms_hill_climb(Xd, seeds, 20.0, iters)
         lab = torch.zeros(S, dtype=torch.int64, device=DEV)
         t_asg = timeit(lambda: ops.ms_assign(Xd, Z, lab, 1), iters=3, warm=1)
+        for _ in range(2):                      # warm-up: host BLAS threads, allocator
+            ms.mean_shift_smart_init(Xd, 20.0, S, iters, first_index=7)
         torch.cuda.synchronize()
+        reps = 10 if n < 500000 else 3
         t0 = time.perf_counter()
-        for _ in range(3):
+        for _ in range(reps):
             labels, sel = ms.mean_shift_smart_init(Xd, 20.0, S, iters, first_index=7)
         torch.cuda.synchronize()
-        t_all = (time.perf_counter() - t0) / 3
+        t_all = (time.perf_counter() - t0) / reps
         print(f"mean-shift n={n} S={S} it={iters}: seeding {t_seed / 1e3:7.2f} ms ({S * n * 256 / t_seed / 1e6:6.2f} TB/s), "
               f"hill-climb {t_hill / 1e3:7.2f} ms ({4.0 * S * n * 64 * iters / t_hill / 1e6:6.1f} TFLOP/s), assign {t_asg / 1e3:6.2f} ms, "
               f"end-to-end {t_all * 1e3:7.2f} ms = {1 / t_all:6.1f} images/s, clusters={int(labels.max()) + 1}", flush=True)
