@@ -89,14 +89,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X: the hot path has no CPU implementation (oracle/ is test-only)")
+    torch.cuda.set_device(local_rank)           # before the process group: RCCL binds its communicator to the current device
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
-    if not torch.cuda.is_available():
-        raise RuntimeError("bench.py needs an MI355X: the hot path has no CPU implementation (oracle/ is test-only)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", device_id=dev)
 
     from unseenobjectswithmeanshift_amd import ops
     from unseenobjectswithmeanshift_amd import synthetic as syn
