@@ -33,6 +33,7 @@
  *                                   GroupNorm, F.interpolate, PositionEmbeddingSine)
  *   msm_ms_*                     <- select_smart_seeds MS:128-189, seed_hill_climbing_ball MS:79-109,
  *                                   the assignment/relabel tail of mean_shift_smart_init MS:206-229
+ *   msm_label_stats              <- per-label loops of the two-stage harness, lib/fcn/test_dataset.py:62-131,183-198
  *   msm_instance_postprocess     <- F.interpolate + instance_inference,
  *                                   MSMFormer/meanshiftformer/pretrained_meanshiftformer_model.py:337-343,461-497
  */
@@ -307,6 +308,20 @@ int msm_instance_postprocess(const float* mask_logits, const int32_t* query_inde
                              const float* class_scores, float* pred_masks, float* mask_score, float* boxes,
                              int B, int Q, int T, int h, int w, int H, int W,
                              float* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Label-image statistics of the two-stage harness: one pass instead of the reference's per-label
+ * unique()/masked-reduction/.item() loops (lib/fcn/test_dataset.py:62-112 crop_rois +
+ * lib/utils/mask.py:179-186 tight boxes, test_dataset.py:121-126 overlap test, :183-198 depth filter).
+ *   labels [B][H][W] float, integer valued in [0, k); weight [B][H][W] float or NULL.
+ *   stats  [B][k][5] int32 = area, x_min, y_min, x_max, y_max (W, H, -1, -1 for an absent label)
+ *   wsum   [B][k] float    = sum of weight over the label's pixels (0 when weight is NULL); fp32 sum in
+ *                            unspecified order: exact for 0/1 weights (counts < 2^24)
+ *   overflow [B] int32     = pixels whose value lies outside [0, k) (they are counted in the clamped bin;
+ *                            callers treat a non-zero count as an error)
+ * k <= 2048 (per-workgroup LDS table). */
+int msm_label_stats(const float* labels, const float* weight, int32_t* stats, float* wsum, int32_t* overflow,
+                    int B, int H, int W, int k, void* stream);
 
 #ifdef __cplusplus
 }

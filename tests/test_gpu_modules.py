@@ -3,6 +3,7 @@ golden vectors captured from the reference and against the CPU oracle.  pytest -
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import msm_oracle as O
 from unseenobjectswithmeanshift_amd import synthetic as syn
@@ -393,6 +394,36 @@ class _TinyBackbone(torch.nn.Module):
             p = torch.nn.functional.avg_pool2d(x, s)
             out[name] = torch.relu(torch.einsum("oc,bchw->bohw", w, p)).contiguous()
         return out
+
+
+def test_two_stage_harness_on_gpu_vs_reference(golden):
+    """The harness functions against the reference's outputs with every tensor on the GPU: depth filter, ROI boxes and
+    the overlap test go through msm_label_stats (tests/test_two_stage_cpu.py runs the same check on CPU tensors)."""
+    import test_two_stage_cpu as tc
+    tc.check_harness(golden, DEV)
+
+
+def test_label_stats_kernel_equals_definition():
+    """msm_label_stats against the torch definition (two_stage.label_stats on CPU tensors): ragged widths, several
+    images, weights, absent labels, out-of-range pixels; integers bit-exact, 0/1-weight sums exact."""
+    from unseenobjectswithmeanshift_amd import two_stage as ts
+    g = torch.Generator().manual_seed(11)
+    for B, H, W, nlab in ((1, 480, 640, 12), (3, 224, 224, 40), (2, 37, 53, 5), (1, 1, 7, 3), (4, 96, 128, 1000)):
+        coarse = torch.randint(0, nlab, (B, 1, max(1, H // 9), max(1, W // 11)), generator=g).float()
+        lab = F.interpolate(coarse, size=(H, W), mode="nearest")[:, 0].contiguous()          # blobs: mostly wave-uniform
+        lab[:, ::7, ::5] = torch.randint(0, nlab, lab[:, ::7, ::5].shape, generator=g).float()   # + per-pixel noise
+        wgt = (torch.rand(B, H, W, generator=g) < 0.6).float()
+        ref = ts.label_stats(lab, wgt)
+        got = ts.label_stats(lab.to(DEV), wgt.to(DEV))
+        for r, o in zip(ref, got):
+            assert o.is_cuda and torch.equal(r, o.cpu())
+        got = ts.label_stats(lab.to(DEV))
+        assert torch.equal(ref[0], got[0].cpu()) and float(got[1].abs().max()) == 0
+    lab = torch.zeros(1, 16, 64)
+    lab[0, 3, 5], lab[0, 4, 6] = 5000.0, -2.0
+    assert ts.label_stats(lab.to(DEV))[2].tolist() == [2] == ts.label_stats(lab)[2].tolist()
+    with pytest.raises(ValueError):
+        ts.crop_rois(torch.zeros(1, 3, 16, 64, device=DEV), lab.to(DEV), None)
 
 
 def test_two_stage_pipeline_on_gpu():

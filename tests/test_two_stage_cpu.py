@@ -37,37 +37,49 @@ def T(a):
 
 
 def test_harness_against_reference_functions(golden):
+    check_harness(golden, "cpu")
+
+
+def check_harness(golden, dev):
+    """The harness functions against the reference's outputs, with every tensor on `dev` (the GPU variant of this test
+    lives in test_gpu_modules.py: there the label statistics run in the HIP kernel)."""
     g = golden("harness")
     for case, seed in enumerate((1, 2, 3)):
-        masks, scores, classes, image, depth = harness_inputs(seed)
+        masks, scores, classes, image, depth = (t.to(dev) for t in harness_inputs(seed))
         inst = Instances((96, 128), pred_masks=masks, scores=scores, pred_classes=classes)
         conf = get_confident_instances({"instances": inst}, topk=False, score=0.6)
         label = combine_masks(conf)
         assert np.array_equal(label.astype(np.int16), g[f"c{case}_label"])
         conf_topk = get_confident_instances({"instances": inst}, topk=True, low_threshold=0.4)
         assert np.array_equal(combine_masks(conf_topk).astype(np.int16), g[f"c{case}_label_topk"])
+        # the sync-free label image used by the pipeline equals the two reference steps
+        li = ts.label_image({"instances": inst}, False, 0.6, 0.4, 2)
+        assert li.dtype == torch.float64 and np.array_equal(li.cpu().numpy().astype(np.int16), g[f"c{case}_label"])
+        li = ts.label_image({"instances": inst}, True, 0.7, 0.4, 2)
+        assert np.array_equal(li.cpu().numpy().astype(np.int16), g[f"c{case}_label_topk"])
         bin_mask, score_mask, bbox = ts.combine_masks_with_NMS(conf)
         assert np.array_equal(bin_mask.astype(np.int16), g[f"c{case}_nms_label"])
         assert np.array_equal(score_mask.astype(np.int16), g[f"c{case}_nms_score"])
         assert np.array_equal(bbox, g[f"c{case}_nms_bbox"])
-        out_label = torch.as_tensor(label).unsqueeze(0)
+        out_label = torch.as_tensor(label).unsqueeze(0).to(dev)
         filt = ts.filter_labels_depth(out_label, depth, 0.5)
-        assert torch.equal(filt.to(torch.int16), T(g[f"c{case}_filt"]))
+        assert torch.equal(filt.to(torch.int16).cpu(), T(g[f"c{case}_filt"]))
         rgb_crops, mask_crops, rois, depth_crops = ts.crop_rois(image, filt.clone(), depth)
-        assert torch.equal(rois, T(g[f"c{case}_rois"]))
-        torch.testing.assert_close(rgb_crops[:, :, ::3, ::3], T(g[f"c{case}_rgb_crops"]), rtol=1e-6, atol=1e-6)
-        torch.testing.assert_close(depth_crops[:, :, ::3, ::3], T(g[f"c{case}_depth_crops"]), rtol=1e-6, atol=1e-6)
+        assert torch.equal(rois.cpu(), T(g[f"c{case}_rois"]))
+        tol = 1e-6 if dev == "cpu" else 1e-5            # the GPU's bilinear interpolation orders the four products differently
+        torch.testing.assert_close(rgb_crops[:, :, ::3, ::3].cpu(), T(g[f"c{case}_rgb_crops"]), rtol=tol, atol=tol)
+        torch.testing.assert_close(depth_crops[:, :, ::3, ::3].cpu(), T(g[f"c{case}_depth_crops"]), rtol=tol, atol=tol)
         bits = np.unpackbits(g[f"c{case}_mask_crops"])[:mask_crops.numel()].reshape(mask_crops.shape)
-        assert np.array_equal((mask_crops > 0).numpy(), bits.astype(bool))
-        labels_crop = torch.zeros(rgb_crops.shape[0], 224, 224)
+        assert np.array_equal((mask_crops > 0).cpu().numpy(), bits.astype(bool))
+        labels_crop = torch.zeros(rgb_crops.shape[0], 224, 224, device=dev)
         for i in range(rgb_crops.shape[0]):
-            labels_crop[i] = mask_crops[i] * (2 + (torch.arange(224)[None, :] > 100).float())
+            labels_crop[i] = mask_crops[i] * (2 + (torch.arange(224, device=dev)[None, :] > 100).float())
             labels_crop[i][:20, :20] = 5
         refined, lc = ts.match_label_crop(filt, labels_crop.clone(), mask_crops, rois, depth_crops)
-        assert torch.equal(refined.to(torch.int16), T(g[f"c{case}_refined"]))
-        assert torch.equal(lc[:, ::2, ::2].to(torch.int8), T(g[f"c{case}_labels_crop_out"]))
+        assert torch.equal(refined.to(torch.int16).cpu(), T(g[f"c{case}_refined"]))
+        assert torch.equal(lc[:, ::2, ::2].to(torch.int8).cpu(), T(g[f"c{case}_labels_crop_out"]))
         refined_nd, _ = ts.match_label_crop(filt, labels_crop.clone(), mask_crops, rois, None)
-        assert torch.equal(refined_nd.to(torch.int16), T(g[f"c{case}_refined_nodepth"]))
+        assert torch.equal(refined_nd.to(torch.int16).cpu(), T(g[f"c{case}_refined_nodepth"]))
 
 
 class _FakePredictor:

@@ -184,6 +184,14 @@ def twostage():
     run()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if os.environ.get("MSM_CPROFILE"):                     # host-side breakdown of one more pass
+        import cProfile, pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        run()
+        torch.cuda.synchronize()
+        pr.disable()
+        pstats.Stats(pr).sort_stats(os.environ["MSM_CPROFILE"] if os.environ["MSM_CPROFILE"] in ("tottime", "cumulative") else "cumulative").print_stats(45)
     print(f"two-stage 640x480, 16 frames: {dt * 1e3 / 16:7.2f} ms per frame = {16 / dt:6.1f} frames/s, "
           f"{sum(crops) / max(1, len(crops)):.1f} crops per frame in one batched second-stage call", flush=True)
 

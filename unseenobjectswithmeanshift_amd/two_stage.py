@@ -28,7 +28,7 @@ CROP_SIZE = 224          # cfg.TRAIN.SYN_CROP_SIZE, lib/fcn/config.py:130
 PADDING_PERCENTAGE = 0.25
 
 
-LABEL_BINS = 4096      # label images hold 0 and 2..N+1 with N <= detections per image (20 by default)
+LABEL_BINS = 1024      # label images hold 0 and 2..N+1 with N <= detections per image (<= the number of queries)
 
 
 def mask_to_tight_box(mask):
@@ -37,21 +37,57 @@ def mask_to_tight_box(mask):
     return xs.min(), ys.min(), xs.max(), ys.max()
 
 
+def label_stats(labels, weight=None):
+    """Per-label statistics of integer-valued label images labels (B,H,W) with values in [0, LABEL_BINS):
+    (stats (B,k,5) = area, x_min, y_min, x_max, y_max [W, H, -1, -1 when absent]; wsum (B,k) = sum of `weight` over the
+    label's pixels; overflow (B,) = number of out-of-range pixels).  One pass replaces the reference's per-label
+    unique()/masked reductions (test_dataset.py:62-131, 183-198).  GPU tensors go through the HIP kernel
+    (msm_label_stats); CPU tensors -- the host-logic unit tests -- through the same definition in torch ops."""
+    k = int(LABEL_BINS)
+    B, H, W = labels.shape
+    if labels.is_cuda:
+        from . import ops
+        return ops.label_stats(labels.float().contiguous(), None if weight is None else weight.float().contiguous(), k)
+    lab = labels.reshape(B, -1).float()
+    idx = lab.to(torch.int64).clamp(0, k - 1)
+    overflow = (~(lab >= 0) | (lab.to(torch.int64) >= k)).sum(1).to(torch.int32)
+    ys = torch.arange(H).repeat_interleave(W).expand(B, -1)
+    xs = torch.arange(W).repeat(H).expand(B, -1)
+    area = torch.zeros((B, k), dtype=torch.int64).scatter_add(1, idx, torch.ones_like(idx))
+    stats = torch.stack([area,
+                         torch.full((B, k), W).scatter_reduce(1, idx, xs, "amin"),
+                         torch.full((B, k), H).scatter_reduce(1, idx, ys, "amin"),
+                         torch.full((B, k), -1).scatter_reduce(1, idx, xs, "amax"),
+                         torch.full((B, k), -1).scatter_reduce(1, idx, ys, "amax")], 2).to(torch.int32)
+    wsum = torch.zeros((B, k), dtype=torch.float32)
+    if weight is not None:
+        wsum.scatter_add_(1, idx, weight.reshape(B, -1).float())
+    return stats, wsum, overflow
+
+
 def filter_labels_depth(labels, depth, threshold):
     """Zero every label whose pixels have valid depth (z > 0) on less than `threshold` of their area.
     labels (B,H,W) with small non-negative integer values, depth (B,3,H,W) xyz.  (lib/fcn/test_dataset.py:183-198; the
-    per-label loop of the reference is two histograms here: same integer counts, same fp32 division, no host syncs.)"""
-    out = labels.clone()
-    for i in range(labels.shape[0]):
-        lab = labels[i].reshape(-1).to(torch.int64)
-        k = int(LABEL_BINS)
-        valid = (depth[i, 2] > 0).reshape(-1)
-        area = torch.bincount(lab.clamp(0, k - 1), minlength=k)[:k]
-        good = torch.bincount(lab.clamp(0, k - 1)[valid], minlength=k)[:k]
-        bad = (good.float() / area.float().clamp_min(1.0) < threshold) & (area > 0)
-        bad[0] = False
-        out[i][bad[lab.clamp(0, k - 1)].view_as(labels[i])] = 0
-    return out
+    per-label loop of the reference is one statistics pass here: same integer counts, same fp32 division, no host
+    syncs.)"""
+    stats, good, _ = label_stats(labels, (depth[:, 2] > 0).float())
+    area = stats[:, :, 0]
+    bad = (good / area.float().clamp_min(1.0) < threshold) & (area > 0)
+    bad[:, 0] = False
+    idx = labels.reshape(labels.shape[0], -1).to(torch.int64).clamp(0, int(LABEL_BINS) - 1)
+    return labels.masked_fill(torch.gather(bad, 1, idx).view_as(labels), 0)
+
+
+def _label_boxes(label_img):
+    """Labels present in an (H,W) label image (0 = background) and their tight boxes, in ascending label order:
+    [(label, x_min, y_min, x_max, y_max), ...] -- one statistics pass and ONE device -> host transfer instead of a
+    nonzero() + four .item() round trips per label (lib/utils/mask.py:179-186)."""
+    stats, _, overflow = label_stats(label_img[None])
+    t = torch.cat([stats[0].reshape(-1), overflow]).cpu().numpy()
+    if t[-1] != 0:
+        raise ValueError(f"label image values must be integers in [0, {LABEL_BINS}) ({t[-1]} pixels are not)")
+    t = t[:-1].reshape(-1, 5)
+    return [(int(v), int(t[v, 1]), int(t[v, 2]), int(t[v, 3]), int(t[v, 4])) for v in np.nonzero(t[:, 0])[0] if v != 0]
 
 
 def crop_rois(rgb, initial_masks, depth, crop_size=CROP_SIZE):
@@ -60,28 +96,26 @@ def crop_rois(rgb, initial_masks, depth, crop_size=CROP_SIZE):
     Returns (rgb_crops (N,3,S,S), mask_crops (N,S,S), rois (N,4) x0,y0,x1,y1 inclusive, depth_crops)."""
     _, H, W = initial_masks.shape
     dev = rgb.device
-    ids = torch.unique(initial_masks[0])
-    ids = ids[ids != 0] if ids.numel() and ids[0] == 0 else ids
-    n = ids.shape[0]
+    boxes = _label_boxes(initial_masks[0])
+    n = len(boxes)
     rgb_crops = torch.zeros((n, 3, crop_size, crop_size), device=dev)
     mask_crops = torch.zeros((n, crop_size, crop_size), device=dev)
     depth_crops = torch.zeros((n, 3, crop_size, crop_size), device=dev) if depth is not None else None
-    rois = torch.zeros((n, 4), device=dev)
     size = (crop_size, crop_size)
-    for k, mask_id in enumerate(ids):
-        mask = (initial_masks[0] == mask_id).float()
-        x0, y0, x1, y1 = (int(v) for v in mask_to_tight_box(mask))
-        # torch.round: half to even, as the reference (test_dataset.py:83-84)
-        xp = int(torch.round(torch.tensor(float(x1 - x0)) * PADDING_PERCENTAGE).item())
-        yp = int(torch.round(torch.tensor(float(y1 - y0)) * PADDING_PERCENTAGE).item())
+    rois_host = []
+    for k, (mask_id, x0, y0, x1, y1) in enumerate(boxes):
+        # round(): half to even, as the reference's torch.round on the exact product (test_dataset.py:83-84)
+        xp, yp = int(round((x1 - x0) * PADDING_PERCENTAGE)), int(round((y1 - y0) * PADDING_PERCENTAGE))
         x0, x1 = max(x0 - xp, 0), min(x1 + xp, W - 1)
         y0, y1 = max(y0 - yp, 0), min(y1 + yp, H - 1)
-        rois[k] = torch.tensor([x0, y0, x1, y1], dtype=torch.float32)
+        rois_host.append([x0, y0, x1, y1])
+        mask = (initial_masks[0, y0:y1 + 1, x0:x1 + 1] == mask_id).float()
         rgb_crops[k] = F.interpolate(rgb[0:1, :, y0:y1 + 1, x0:x1 + 1], size=size, mode="bilinear", align_corners=True)[0]
-        mask_crops[k] = F.interpolate(mask[None, None, y0:y1 + 1, x0:x1 + 1], size=size, mode="nearest")[0, 0]
+        mask_crops[k] = F.interpolate(mask[None, None], size=size, mode="nearest")[0, 0]
         if depth is not None:
             depth_crops[k] = F.interpolate(depth[0:1, :, y0:y1 + 1, x0:x1 + 1], size=size, mode="bilinear",
                                            align_corners=True)[0]
+    rois = torch.tensor(rois_host, dtype=torch.float32).reshape(n, 4).to(dev)
     return rgb_crops, mask_crops, rois, depth_crops
 
 
@@ -89,39 +123,43 @@ def match_label_crop(initial_masks, labels_crop, out_label_crop, rois, depth_cro
     """Reject second-stage segments that overlap the first-stage mask by < 50 %, order the crops
     (far-to-near by mean depth, or large-to-small ROI without depth) and paste the renumbered
     segments back at ROI resolution; later crops overwrite earlier ones.
-    Returns (refined (1,H,W) float, labels_crop with rejected segments set to -1)."""
+    Returns (refined (1,H,W) float, labels_crop with rejected segments set to -1).
+
+    The reference's per-crop / per-segment loops (test_dataset.py:116-179) are table lookups here: two histograms for
+    the overlap test, one (crop, label) -> new number table for the renumbering, and two host transfers in all (the
+    sort keys and the ROIs).  The mean depth of a crop is accumulated in fp64 (the reference's fp32 torch.mean can
+    order two crops whose mean depths agree to ~1e-7 either way)."""
     num = labels_crop.shape[0]
-    # overlap of every (crop, segment) with the first-stage mask as two histograms (TD:125-131: same counts, same fp32
-    # division as the reference's per-segment loop)
-    k = int(LABEL_BINS)
-    lab = labels_crop.reshape(num, -1).to(torch.int64).clamp(0, k - 1) + torch.arange(num, device=labels_crop.device)[:, None] * k
-    area = torch.bincount(lab.reshape(-1), minlength=num * k)[:num * k]
-    hit = torch.bincount(lab.reshape(-1), weights=out_label_crop.reshape(-1).float(), minlength=num * k)[:num * k]
-    bad = (hit.float() / area.float().clamp_min(1.0) < 0.5) & (area > 0)
-    labels_crop[bad[lab].view_as(labels_crop)] = -1
-    keys = []
-    for i in range(num):
-        if depth_crop is not None:
-            sel = labels_crop[i] > -1
-            z = depth_crop[i, 2][sel] if sel.sum() > 0 else depth_crop[i, 2]
-            keys.append((i, torch.mean(z[z > 0])))
-        else:
-            keys.append((i, (rois[i, 3] - rois[i, 1] + 1) * (rois[i, 2] - rois[i, 0] + 1)))
-    order = [i for i, _ in sorted(keys, key=lambda t: t[1], reverse=True)]
+    dev = labels_crop.device
     refined = torch.zeros_like(initial_masks).float()
-    count = 0
+    if num == 0:
+        return refined, labels_crop
+    k = int(LABEL_BINS)
+    stats, hit, _ = label_stats(labels_crop, out_label_crop)
+    area = stats[:, :, 0].reshape(-1)
+    lab = labels_crop.reshape(num, -1).to(torch.int64).clamp(0, k - 1) + torch.arange(num, device=dev)[:, None] * k
+    bad = (hit.reshape(-1) / area.float().clamp_min(1.0) < 0.5) & (area > 0)
+    labels_crop.masked_fill_(bad[lab].view_as(labels_crop), -1)
+    rois_host = [[int(v) for v in r] for r in rois.tolist()]
+    if depth_crop is not None:
+        sel = (labels_crop > -1).reshape(num, -1)
+        z = depth_crop[:, 2].reshape(num, -1)
+        use = (sel | ~sel.any(1, keepdim=True)) & (z > 0)
+        keys = ((z * use).sum(1, dtype=torch.float64) / use.sum(1)).tolist()            # 0/0 = nan like mean of nothing
+    else:
+        keys = [float((r[3] - r[1] + 1) * (r[2] - r[0] + 1)) for r in rois_host]
+    order = [i for i, _ in sorted(enumerate(keys), key=lambda t: t[1], reverse=True)]
+    # new numbers 1.. in (crop order, ascending surviving label) order
+    order_t = torch.tensor(order, device=dev)
+    alive = ((area > 0) & ~bad).view(num, k)[order_t]
+    number = torch.zeros((num, k), dtype=torch.float32, device=dev)
+    number[order_t] = (torch.cumsum(alive.reshape(-1), 0).view(num, k) * alive).float()
+    renum = number.view(-1)[lab].view(num, 1, *labels_crop.shape[1:])
     for i in order:
-        ids = torch.unique(labels_crop[i])
-        ids = ids[1:] if ids[0] == -1 else ids
-        renum = torch.zeros_like(labels_crop[i])
-        for mask_id in ids:
-            count += 1
-            renum[labels_crop[i] == mask_id] = count
-        x0, y0, x1, y1 = (int(v) for v in rois[i])
-        small = F.interpolate(renum[None, None].float(), size=(y1 - y0 + 1, x1 - x0 + 1), mode="nearest")[0, 0]
+        x0, y0, x1, y1 = rois_host[i]
+        small = F.interpolate(renum[i:i + 1], size=(y1 - y0 + 1, x1 - x0 + 1), mode="nearest")[0, 0]
         window = refined[0, y0:y1 + 1, x0:x1 + 1]
-        nz = small != 0
-        window[nz] = small[nz]
+        window.copy_(torch.where(small != 0, small, window))
     return refined, labels_crop
 
 
@@ -161,12 +199,30 @@ def combine_masks_with_NMS(instances):
     return bin_mask, score_mask, bbox
 
 
+def label_image(outputs, topk, confident_score, low_threshold, num_class):
+    """combine_masks(get_confident_instances(outputs, ...)) (test_utils.py:35-53, 93-112) without selecting the
+    instances first: instance i, if kept, carries label 2 + (number of kept instances before it), and "later
+    instances overwrite earlier ones" is the per-pixel maximum of those labels.  Same values as the two reference
+    steps, no data-dependent shapes, so no device -> host round trip.  Returns an (H,W) float64 tensor."""
+    inst = outputs["instances"]
+    masks, scores = inst.get("pred_masks"), inst.get("scores")
+    if masks.dim() != 3 or masks.shape[0] == 0:
+        h, w = inst.image_size
+        return torch.zeros((h, w), dtype=torch.float64, device=scores.device)
+    if topk:
+        keep = ((inst.get("pred_classes") == 1) & (scores > low_threshold)) if num_class >= 2 else torch.ones_like(scores, dtype=torch.bool)
+    else:
+        keep = scores > confident_score
+    lab = ((torch.cumsum(keep, 0) + 1) * keep).to(torch.int16)
+    return ((masks != 0).to(torch.int16) * lab[:, None, None]).amax(0).to(torch.float64)
+
+
 def _labels_from_outputs(outputs, topk, confident_score, low_threshold, num_class, use_nms):
-    conf = get_confident_instances(outputs, topk=topk, score=confident_score, num_class=num_class,
-                                   low_threshold=low_threshold)
     if use_nms:
+        conf = get_confident_instances(outputs, topk=topk, score=confident_score, num_class=num_class,
+                                       low_threshold=low_threshold)
         return combine_masks_with_NMS(conf)
-    return combine_masks_tensor(conf), None, None     # same values as combine_masks, no host round trip
+    return label_image(outputs, topk, confident_score, low_threshold, num_class), None, None
 
 
 def test_sample_crop_nolabel(sample, predictor, predictor_crop=None, *, use_depth=True, topk=False,
