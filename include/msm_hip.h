@@ -52,7 +52,7 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 2   /* 2: flags argument of the mask step, head-major value / packed-weight entry points */
+#define MSM_ABI_VERSION 3   /* 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats */
 int msm_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
