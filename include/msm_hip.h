@@ -306,7 +306,7 @@ int msm_topk_class_scores(const float* pred_logits, int B, int Q, int K1, int T,
 
 int msm_instance_postprocess(const float* mask_logits, const int32_t* query_index,
                              const float* class_scores, float* pred_masks, float* mask_score, float* boxes,
-                             int B, int Q, int T, int h, int w, int H, int W,
+                             int B, int Q, int T, int h, int w, int H, int W, int Hs, int Ws,
                              float* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -476,14 +476,16 @@ def canonical_topk(scores_flat, k):
     return torch.tensor(order, dtype=torch.long)
 
 
-def instance_inference(mask_cls, mask_pred_lowres, image_size, topk=20):
-    """One image.  mask_cls (Q,K+1); mask_pred_lowres (Q,h,w) logits; image_size (H,W).
-    Upsample (PM:337-343) -> top-k over Q*K class scores (PM:466-474) -> binary masks, boxes,
-    scores = class prob * mean sigmoid over the mask (PM:488-495)."""
+def instance_inference(mask_cls, mask_pred_lowres, image_size, topk=20, padded_size=None):
+    """One image.  mask_cls (Q,K+1); mask_pred_lowres (Q,h,w) logits; image_size (H,W); padded_size = the frame after
+    ImageList.from_tensors padding (PM:275), default image_size.
+    Upsample to the padded frame (PM:337-343), crop to the image (sem_seg_postprocess, PM:354-357; the second
+    interpolation there is the identity when the requested output size is the image size) -> top-k over Q*K class
+    scores (PM:466-474) -> binary masks, boxes, scores = class prob * mean sigmoid over the mask (PM:488-495)."""
     Q, K1 = mask_cls.shape
     K = K1 - 1
-    up = F.interpolate(mask_pred_lowres[None], size=tuple(image_size), mode="bilinear",
-                       align_corners=False)[0]
+    up = F.interpolate(mask_pred_lowres[None], size=tuple(padded_size or image_size), mode="bilinear",
+                       align_corners=False)[0][:, :image_size[0], :image_size[1]]
     scores = torch.softmax(mask_cls, -1)[:, :-1].flatten()
     idx = canonical_topk(scores, topk)
     s = scores[idx]

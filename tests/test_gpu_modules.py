@@ -356,6 +356,33 @@ def test_meta_arch_inference_vs_oracle():
     assert lab.shape == (64, 96)
 
 
+def test_meta_arch_pads_to_size_divisibility():
+    """A 60x90 frame is padded with zeros to 64x96 (ImageList.from_tensors, PM:275), the masks are upsampled to the
+    padded frame and cropped back (PM:337-343, 354-357): model(images) against the oracle on the same features."""
+    from unseenobjectswithmeanshift_amd.meta_arch import MeanShiftMaskFormer
+    head = make_pixel_decoder()
+    bb = _TinyBackbone().to(DEV).eval()
+    model = MeanShiftMaskFormer(backbone=bb, sem_seg_head=head, num_queries=100)
+    g = torch.Generator().manual_seed(21)
+    images = torch.rand(2, 3, 60, 90, generator=g).to(DEV)
+    res = model([{"image": images}])
+    with torch.no_grad():
+        feats = bb(F.pad(images, (0, 6, 0, 4)))
+    out, _ = head(feats)
+    for b in range(2):
+        ref = O.instance_inference(out["pred_logits"][b].cpu(), out["pred_masks"][b].cpu(), (60, 90), topk=20, padded_size=(64, 96))
+        inst = res[b]["instances"]
+        assert inst.image_size == (60, 90) and inst.pred_masks.shape == (20, 60, 90)
+        assert (inst.pred_masks.cpu() != ref["pred_masks"]).float().mean() < 1e-4
+        torch.testing.assert_close(inst.scores.cpu(), ref["scores"], rtol=1e-4, atol=1e-6)
+        assert torch.equal(inst.pred_classes.cpu(), ref["pred_classes"])
+    # features handed over directly: height / width name the image inside the padded frame
+    res2 = model.__class__(backbone=None, sem_seg_head=head, num_queries=100)([{"features": feats, "height": 60, "width": 90}])
+    assert torch.equal(res2[0]["instances"].pred_masks, res[0]["instances"].pred_masks)
+    with pytest.raises(ValueError):
+        model.__class__(backbone=None, sem_seg_head=head, num_queries=100)([{"features": feats, "height": 20, "width": 90}])
+
+
 def test_graphed_inference_equals_eager():
     """graphs.GraphedInference: capture once per geometry, replay with new inputs -- identical to the eager path."""
     from unseenobjectswithmeanshift_amd.meta_arch import MeanShiftMaskFormer

@@ -515,6 +515,23 @@ def test_topk_and_postprocess():
         if not mism.any():
             close(boxes[b], O.mask_boxes(up > 0), rtol=0, atol=0)
     assert float(ms[0, 0]) == 0.0 and torch.equal(boxes[0, 0].cpu(), torch.zeros(4))
+    # padded frame: upsample to (Hh, Ww), keep the top-left (Hc, Wc) image (PM:275, 354-357); odd widths take the
+    # scalar-store path
+    for Hc, Wc in ((Hh - 5, Ww - 7), (Hh - 31, Ww), (Hh, Ww - 4)):
+        pm, ms, boxes = ops().instance_postprocess(masks.to(DEV), force, (Hc, Wc), padded_size=(Hh, Ww))
+        assert pm.shape == (B, T, Hc, Wc)
+        for b in range(B):
+            up = F.interpolate(masks[b][None], size=(Hh, Ww), mode="bilinear", align_corners=False)[0][force[b].cpu().long()]
+            up = up[:, :Hc, :Wc]
+            binm = (up > 0).float()
+            mism = (pm[b].cpu() != binm)
+            assert mism.float().mean() < 1e-5
+            ref_score = (up.sigmoid().flatten(1) * binm.flatten(1)).sum(1) / (binm.flatten(1).sum(1) + 1e-6)
+            close(ms[b], ref_score, rtol=1e-4, atol=1e-5)
+            if not mism.any():
+                close(boxes[b], O.mask_boxes(up > 0), rtol=0, atol=0)
+    with pytest.raises(RuntimeError):
+        ops().instance_postprocess(masks.to(DEV), force, (Hh + 1, Ww), padded_size=(Hh, Ww))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -59,7 +59,7 @@ _SIGNATURES = {
     "msm_ms_relabel_largest_zero": (c_i, [c_p, c_i, c_p, c_i, c_p]),
     "msm_topk_class_scores": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),
     "msm_label_stats": (c_i, [c_f, c_f, c_p, c_f, c_p, c_i, c_i, c_i, c_i, c_p]),
-    "msm_instance_postprocess": (c_i, [c_f, c_p, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "msm_instance_postprocess": (c_i, [c_f, c_p, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
 }
 
 

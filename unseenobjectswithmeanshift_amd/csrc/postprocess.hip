@@ -59,13 +59,13 @@ __device__ __forceinline__ void src_index(int dst, float scale, int in, int& i0,
 // grid (tiles_x, rows/ROWS, B*T); each block upsamples a strip of the selected mask
 __global__ __launch_bounds__(256) void inst_upsample_kernel(const float* __restrict__ logits, const int32_t* __restrict__ qidx,
                                                             float* __restrict__ masks, InstAcc* __restrict__ acc, int Q, int T,
-                                                            int h, int w, int H, int W, int rows_per_block) {
+                                                            int h, int w, int H, int W, int Hs, int Ws, int rows_per_block) {
     const int bt = blockIdx.z;
     const int b = bt / T;
     const int q = qidx[bt];
     const float* src = logits + ((int64_t)b * Q + q) * h * w;
     float* dst = masks + (int64_t)bt * H * W;
-    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    const float sy = (float)h / (float)Hs, sx = (float)w / (float)Ws;     // scale of the (padded) frame; rows/cols >= H/W are cropped
     const int y0 = blockIdx.y * rows_per_block, y1 = min(H, y0 + rows_per_block);
     double sum = 0.0;
     unsigned int cnt = 0;
@@ -174,10 +174,11 @@ extern "C" int msm_topk_class_scores(const float* pred_logits, int B, int Q, int
 extern "C" int msm_instance_postprocess(const float* mask_logits, const int32_t* query_index,
                                         const float* class_scores, float* pred_masks,
                                         float* mask_score, float* boxes, int B, int Q, int T, int h, int w, int H, int W,
-                                        float* workspace, void* stream) {
+                                        int Hs, int Ws, float* workspace, void* stream) {
     MSM_REQUIRE(mask_logits && query_index && pred_masks && mask_score && boxes && workspace,
                 "msm_instance_postprocess: null pointer");
     MSM_REQUIRE(B > 0 && Q > 0 && T > 0 && h > 0 && w > 0 && H > 0 && W > 0, "msm_instance_postprocess: bad sizes");
+    MSM_REQUIRE(Hs >= H && Ws >= W, "msm_instance_postprocess: frame %dx%d smaller than the output %dx%d", Hs, Ws, H, W);
     MSM_REQUIRE((((uintptr_t)workspace) & 7) == 0 && (((uintptr_t)boxes) & 15) == 0 && (((uintptr_t)pred_masks) & 15) == 0,
                 "msm_instance_postprocess: misaligned pointer");
     hipStream_t st = (hipStream_t)stream;
@@ -189,7 +190,7 @@ extern "C" int msm_instance_postprocess(const float* mask_logits, const int32_t*
     const int threads = min(256, cdiv(cols, 64) * 64);          // whole waves, no idle wave (640 px -> 192 threads)
     dim3 grid(cdiv(cols, threads), cdiv(H, rows), n);
     hipLaunchKernelGGL(inst_upsample_kernel, grid, dim3(threads), 0, st, mask_logits, query_index, pred_masks, acc, Q, T, h, w, H,
-                       W, rows);
+                       W, Hs, Ws, rows);
     hipLaunchKernelGGL(inst_finish_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, acc, class_scores, mask_score, boxes, n);
     MSM_CHECK_LAUNCH("msm_instance_postprocess");
     return MSM_OK;

@@ -20,15 +20,16 @@ class GraphedInference:
         self._graphs = {}
         self._stream = None
 
-    def _key(self, features, image_size):
-        return (tuple((k, tuple(v.shape), v.dtype, v.device) for k, v in sorted(features.items())), tuple(image_size))
+    def _key(self, features, image_size, padded_size):
+        return (tuple((k, tuple(v.shape), v.dtype, v.device) for k, v in sorted(features.items())), tuple(image_size),
+                tuple(padded_size or image_size))
 
     @torch.no_grad()
-    def __call__(self, features, image_size):
+    def __call__(self, features, image_size, padded_size=None):
         for v in features.values():
             if not v.is_cuda:
                 raise RuntimeError("GraphedInference needs device tensors (there is no CPU path)")
-        key = self._key(features, image_size)
+        key = self._key(features, image_size, padded_size)
         entry = self._graphs.get(key)
         if entry is None:
             if self._stream is None:
@@ -38,11 +39,11 @@ class GraphedInference:
             self._stream.wait_stream(cur)
             with torch.cuda.stream(self._stream):
                 for _ in range(self.warmup):                       # builds every weight cache outside the capture
-                    self.model.inference(static_in, image_size)
+                    self.model.inference(static_in, image_size, padded_size)
                 self._stream.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=self._stream):
-                    static_out = self.model.inference(static_in, image_size)
+                    static_out = self.model.inference(static_in, image_size, padded_size)
             cur.wait_stream(self._stream)
             entry = (graph, static_in, static_out)
             self._graphs[key] = entry

@@ -12,6 +12,7 @@ meta-arch takes any ``backbone`` module mapping an image batch to {"res2".."res5
 the caller already passes backbone features.  Inference only.
 """
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from . import ops
@@ -121,13 +122,17 @@ class MeanShiftMaskFormer(nn.Module):
         self.instance_on = instance_on
 
     @torch.no_grad()
-    def inference(self, features, image_size):
+    def inference(self, features, image_size, padded_size=None):
         """features: dict res2..res5 (B,C,h,w) on the GPU.  Returns the per-batch tensors
-        (scores (B,T), classes (B,T), masks (B,T,H,W), boxes (B,T,4), query_index (B,T))."""
-        outputs, _ = self.sem_seg_head(features, image_size[0], image_size[1])
+        (scores (B,T), classes (B,T), masks (B,T,H,W), boxes (B,T,4), query_index (B,T)).  ``padded_size``: the frame
+        the features were computed on when the image was padded to the size divisibility (masks are cropped back to
+        image_size, PM:275,354-357)."""
+        padded_size = tuple(padded_size or image_size)
+        outputs, _ = self.sem_seg_head(features, padded_size[0], padded_size[1])
         cls_scores, classes, qidx = ops.topk_class_scores(outputs["pred_logits"], self.test_topk_per_image)
         # scores = class prob * mean mask prob (PM:495), fused into the post-process kernel
-        masks, scores, boxes = ops.instance_postprocess(outputs["pred_masks"], qidx, image_size, class_scores=cls_scores)
+        masks, scores, boxes = ops.instance_postprocess(outputs["pred_masks"], qidx, image_size, class_scores=cls_scores,
+                                                        padded_size=padded_size)
         return scores, classes, masks, boxes, qidx
 
     def graphed(self, warmup=2):
@@ -140,20 +145,26 @@ class MeanShiftMaskFormer(nn.Module):
         """batched_inputs: list of dicts with "image" (3,H,W) -- or one dict holding a 4-D batch, as
         the reference accepts (PM:270-273) -- plus, when ``backbone`` is None, "features"."""
         first = batched_inputs[0]
+        div = self.size_divisibility
         if self.backbone is None:
             feats = first["features"] if isinstance(first["features"], dict) and first["features"]["res2"].dim() == 4 \
                 else {k: torch.stack([x["features"][k] for x in batched_inputs]) for k in first["features"]}
+            padded = (4 * feats["res2"].shape[-2], 4 * feats["res2"].shape[-1])       # the frame the features cover
             H, W = first.get("height"), first.get("width")
             if H is None:
-                H, W = 4 * feats["res2"].shape[-2], 4 * feats["res2"].shape[-1]
+                H, W = padded
+            if not (padded[0] - div < H <= padded[0] and padded[1] - div < W <= padded[1]):
+                raise ValueError(f"height/width {H}x{W} do not fit features of a {padded[0]}x{padded[1]} frame")
         else:
             images = first["image"] if first["image"].dim() == 4 else torch.stack([x["image"] for x in batched_inputs])
             H, W = images.shape[-2:]
-            if H % self.size_divisibility or W % self.size_divisibility:
-                raise NotImplementedError("pad inputs to a multiple of %d (ImageList.from_tensors, PM:275)"
-                                          % self.size_divisibility)
+            if first.get("height", H) != H or first.get("width", W) != W:
+                raise NotImplementedError("output height/width other than the image size (sem_seg_postprocess resize, PM:354)")
+            padded = (-(-H // div) * div, -(-W // div) * div)
+            if padded != (H, W):            # ImageList.from_tensors(images, size_divisibility): zeros at the right / bottom
+                images = F.pad(images, (0, padded[1] - W, 0, padded[0] - H))
             feats = self.backbone(images)
-        scores, classes, masks, boxes, _ = self.inference(feats, (int(H), int(W)))
+        scores, classes, masks, boxes, _ = self.inference(feats, (int(H), int(W)), padded)
         results = []
         for b in range(scores.shape[0]):
             inst = Instances((int(H), int(W)), pred_masks=masks[b], pred_boxes=boxes[b], scores=scores[b],

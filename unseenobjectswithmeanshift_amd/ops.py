@@ -536,20 +536,23 @@ def topk_class_scores(pred_logits, topk):
     return scores, classes, qidx
 
 
-def instance_postprocess(mask_logits, query_index, image_size, class_scores=None):
+def instance_postprocess(mask_logits, query_index, image_size, class_scores=None, padded_size=None):
     """mask_logits (B,Q,h,w), query_index int32 (B,T) -> (pred_masks (B,T,H,W) float 0/1,
-    score (B,T) = mean mask probability [* class_scores], boxes (B,T,4))."""
+    score (B,T) = mean mask probability [* class_scores], boxes (B,T,4)).  The logits are upsampled to ``padded_size``
+    (the frame the network saw, default = image_size) and cropped to image_size = (H, W), as the reference does for
+    inputs padded to the size divisibility (PM:337-343 + sem_seg_postprocess, PM:354-357)."""
     _c(mask_logits, "mask_logits"), _c(query_index, "query_index", torch.int32), _c(class_scores, "class_scores")
     B, Q, h, w = mask_logits.shape
     T = query_index.shape[1]
     H, W = int(image_size[0]), int(image_size[1])
+    Hs, Ws = (H, W) if padded_size is None else (int(padded_size[0]), int(padded_size[1]))
     dev = mask_logits.device
     masks = torch.empty((B, T, H, W), device=dev, dtype=torch.float32)
     score = torch.empty((B, T), device=dev, dtype=torch.float32)
     boxes = torch.empty((B, T, 4), device=dev, dtype=torch.float32)
     ws = torch.empty((B * T * 8,), device=dev, dtype=torch.float32)
     rc = lib().msm_instance_postprocess(_p(mask_logits), _p(query_index), _p(class_scores), _p(masks), _p(score), _p(boxes),
-                                        B, Q, T, h, w, H, W, _p(ws), _stream())
+                                        B, Q, T, h, w, H, W, Hs, Ws, _p(ws), _stream())
     check(rc, "msm_instance_postprocess")
     return masks, score, boxes
 
