@@ -33,6 +33,7 @@
  *                                   GroupNorm, F.interpolate, PositionEmbeddingSine)
  *   msm_ms_*                     <- select_smart_seeds MS:128-189, seed_hill_climbing_ball MS:79-109,
  *                                   the assignment/relabel tail of mean_shift_smart_init MS:206-229
+ *   msm_conv1x1_in_f32           <- input_proj / lateral 1x1 convolutions of the pixel decoder + GroupNorm moments, MSD:212-238
  *   msm_label_stats              <- per-label loops of the two-stage harness, lib/fcn/test_dataset.py:62-131,183-198
  *   msm_instance_postprocess     <- F.interpolate + instance_inference,
  *                                   MSMFormer/meanshiftformer/pretrained_meanshiftformer_model.py:337-343,461-497
@@ -308,6 +309,37 @@ int msm_instance_postprocess(const float* mask_logits, const int32_t* query_inde
                              const float* class_scores, float* pred_masks, float* mask_score, float* boxes,
                              int B, int Q, int T, int h, int w, int H, int W, int Hs, int Ws,
                              float* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Input projections of the pixel decoder: 1x1 convolution of a backbone feature map to 64 channels, written
+ * token-major, with the GroupNorm moments of the result as a by-product (msdeformattn.py:212-220,326-329 input_proj
+ * on res3..res5; :225-238,343-347 lateral convolution on res2).
+ *   x [B][Cin][HW] (NCHW), bias [64] or NULL
+ *   w_packed: the (64, Cin) weight in MFMA fragment order, 64*Cin floats:
+ *       w_packed[(((k/8)*4 + o/16)*64 + ((k%8)/2)*16 + o%16)*2 + k%2] = w[o][k]
+ *   out: token (b, p) at out + b*out_batch_stride + p*64 (floats) -- a slice of a larger token buffer is allowed
+ *   stats [B][64][2] double or NULL: += (sum over p, sum of squares over p) per channel; zeroed here unless
+ *   stats_cleared != 0.  Cin a multiple of 128, HW a multiple of 4.  The K sum is split over 8 waves and reduced in a fixed order. */
+int msm_conv1x1_in_f32(const float* x, const float* w_packed, const float* bias, float* out, int64_t out_batch_stride,
+                       double* stats, int stats_cleared, int B, int Cin, int HW, void* stream);
+
+/* Encoder prologue: everything between the input projections and the first deformable-attention layer in one pass
+ * over the token buffer (msdeformattn.py:326-329 GroupNorm of input_proj, :60-75 level concatenation;
+ * ops/modules/ms_deform_attn.py:95-104 layer 0's value_proj / sampling_offsets / attention_weights):
+ *   src   = GroupNorm_l(raw)        raw [B][S][64]: msm_conv1x1_in_f32 outputs of the n_levels levels, concatenated;
+ *                                   level l of an image covers tokens [level_starts[l], level_starts[l+1]) (HOST array of
+ *                                   n_levels+1 ints, 0 .. S); stats [n_levels][B][64][2] double moments (same call);
+ *                                   gn_params [n_levels][2][64] = gamma, beta; src_out may alias raw
+ *   value = value_proj(src)         value_out [B][S][64] or, value_heads > 0, head-major [B][heads][S][64/heads]
+ *   proj  = [offsets|weights](src + pos)    proj_out [B][S][proj_width], pos [S][64]
+ *   wstream: value_proj weight (64,64) then the (proj_width,64) weight, as consecutive 16-row blocks of 1024 floats,
+ *   zero-padded to msm_encoder_prologue_stream_floats(proj_width); small = [value_proj bias (64) | proj bias].
+ * n_levels <= 4, S >= 64, proj_width a multiple of 16. */
+int64_t msm_encoder_prologue_stream_floats(int proj_width);
+int msm_encoder_prologue_fwd(const float* raw, const double* stats, const float* gn_params, const int32_t* level_starts,
+                             int n_levels, int groups, float gn_eps, const float* wstream, const float* small,
+                             const float* pos, float* src_out, float* value_out, float* proj_out, int B, int S,
+                             int proj_width, int value_heads, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Label-image statistics of the two-stage harness: one pass instead of the reference's per-label

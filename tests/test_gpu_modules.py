@@ -245,6 +245,23 @@ def test_pixel_decoder_small_vs_reference(golden):
     assert enc0 is ms[0]
 
 
+def test_pixel_decoder_front_variants_agree():
+    """Fused front end (input projections with GroupNorm moments + one prologue pass) against the separate GEMM /
+    GroupNorm / value / sampling launches, and a fused pass repeated (bitwise reproducible)."""
+    head = make_pixel_decoder()
+    pd = head.pixel_decoder
+    feats = {k: v.to(DEV) for k, v in syn.synth_backbone_features(3, 64, 96, seed=5).items()}
+    mf, _, ms = pd.forward_features(feats)
+    mf2, _, ms2 = pd.forward_features(feats)
+    assert torch.equal(mf, mf2) and all(torch.equal(a, b) for a, b in zip(ms, ms2))
+    pd.fused_front = False
+    mf0, _, ms0 = pd.forward_features(feats)
+    pd.fused_front = True
+    torch.testing.assert_close(mf, mf0, rtol=1e-4, atol=5e-5)
+    for a, b in zip(ms, ms0):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=5e-5)
+
+
 def test_pixel_decoder_480x640_vs_reference(golden):
     g = golden("pixel_decoder_480x640")
     head = make_pixel_decoder()

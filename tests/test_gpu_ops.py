@@ -1,5 +1,7 @@
 """Kernel-level parity: every C-ABI entry point against the CPU oracle / plain torch fp32 on the
 same seeded inputs.  Needs a real MI355X (pytest -m gpu)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -581,3 +583,74 @@ def test_pixel_decoder_fused_equals_unfused():
     torch.testing.assert_close(a[0], b[0], rtol=1e-4, atol=5e-5)
     for x, y in zip(a[2], b[2]):
         torch.testing.assert_close(x, y, rtol=1e-4, atol=5e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,Cin,H,W", [(2, 2048, 15, 20), (3, 1024, 30, 40), (8, 512, 60, 80), (1, 256, 10, 6), (2, 128, 7, 4)])
+def test_conv1x1_in_vs_fp64(B, Cin, H, W):
+    """msm_conv1x1_in_f32 (every tile width the host picks, ragged last tiles) against an fp64 1x1 convolution and the
+    fp64 moments of its own output; writing into a slice of a larger token buffer; moment accumulation."""
+    x, w, b = rnd(B, Cin, H, W, seed=1), rnd(64, Cin, seed=2, scale=Cin ** -0.5), rnd(64, seed=3)
+    ref = torch.einsum("bchw,oc->bhwo", x.double(), w.double()).reshape(B, H * W, 64) + b.double()
+    wp = ops().pack_conv_in_weight(w.to(DEV))
+    # the packed layout is the one include/msm_hip.h documents
+    k, o = torch.meshgrid(torch.arange(Cin), torch.arange(64), indexing="ij")
+    idx = (((k // 8) * 4 + o // 16) * 64 + ((k % 8) // 2) * 16 + o % 16) * 2 + k % 2
+    assert torch.equal(wp.cpu()[idx], w.t())
+    for nt in ("1", "2", "4", None):
+        if nt is None:
+            os.environ.pop("MSM_CONVIN_NT", None)
+        else:
+            os.environ["MSM_CONVIN_NT"] = nt
+        out, st = ops().conv1x1_in(x.to(DEV), wp, b.to(DEV))
+        closed(out, ref, rtol=2e-5, atol=2e-5)
+        mom = torch.stack([out.double().sum(1), (out.double() ** 2).sum(1)], -1).cpu()
+        torch.testing.assert_close(st.cpu(), mom, rtol=1e-5, atol=1e-4)     # fp32 partial sums per 16..64-pixel tile
+    # slice of a concatenated buffer, no bias, moments accumulated on top of what the caller put there
+    buf = torch.full((B, H * W + 24, 64), 7.0, device=DEV)
+    st0 = torch.ones(B, 64, 2, device=DEV, dtype=torch.float64)
+    out, st = ops().conv1x1_in(x.to(DEV), wp, None, out=buf[:, 8:8 + H * W], stats=st0, stats_cleared=True)
+    closed(out, ref - b.double(), rtol=2e-5, atol=2e-5)
+    assert float(buf[:, :8].min()) == 7.0 == float(buf[:, 8 + H * W:].max()) and st.data_ptr() == st0.data_ptr()
+    mom = torch.stack([out.double().sum(1), (out.double() ** 2).sum(1)], -1).cpu() + 1.0
+    torch.testing.assert_close(st.cpu(), mom, rtol=1e-5, atol=1e-4)
+    # run to run identical (fixed-order reduction over the K slices)
+    again, _ = ops().conv1x1_in(x.to(DEV), wp, None)
+    assert torch.equal(again, out)
+    with pytest.raises(RuntimeError):
+        ops().conv1x1_in(torch.zeros(1, 96, 4, 4, device=DEV), torch.zeros(64 * 96, device=DEV))
+
+
+def test_encoder_prologue_vs_fp64():
+    """msm_encoder_prologue_fwd: GroupNorm of three concatenated levels from the conv moments, value projection
+    (token- and head-major) and sampling projections of src + pos, against fp64 torch ops."""
+    B, shapes, pw = 3, ((3, 4), (6, 8), (12, 16)), 288
+    S = sum(h * w for h, w in shapes)
+    raw = rnd(B, S, 64, seed=4, scale=2.0) + 0.5
+    gam, bet = rnd(3, 64, seed=5) * 0.2 + 1.0, rnd(3, 64, seed=6) * 0.3
+    wv, bv, wp, bp = rnd(64, 64, seed=7, scale=0.2), rnd(64, seed=8), rnd(pw, 64, seed=9, scale=0.2), rnd(pw, seed=10)
+    pos = rnd(S, 64, seed=11)
+    bounds, parts, stats = [0], [], []
+    for l, (h, w) in enumerate(shapes):
+        seg = raw[:, bounds[-1]:bounds[-1] + h * w].double()
+        bounds.append(bounds[-1] + h * w)
+        stats.append(torch.stack([seg.sum(1), (seg ** 2).sum(1)], -1))
+        y = F.group_norm(seg.transpose(1, 2), 32, gam[l].double(), bet[l].double(), 1e-5).transpose(1, 2)
+        parts.append(y)
+    src_ref = torch.cat(parts, 1)
+    val_ref = src_ref @ wv.double().t() + bv.double()
+    proj_ref = (src_ref + pos.double()) @ wp.double().t() + bp.double()
+    o = ops()
+    stream = o.pack_encoder_prologue(wv.to(DEV), wp.to(DEV))
+    small = torch.cat([bv, bp]).to(DEV)
+    gnp = torch.stack([gam, bet], 1).contiguous().to(DEV)
+    st = torch.stack(stats).to(DEV)
+    for heads in (0, 8):
+        src, value, proj = o.encoder_prologue(raw.clone().to(DEV), st, gnp, bounds, stream, small, pos.to(DEV), pw, value_heads=heads)
+        closed(src, src_ref, rtol=2e-5, atol=2e-5)
+        closed(proj, proj_ref, rtol=5e-5, atol=5e-5)
+        if heads:
+            value = value.permute(0, 2, 1, 3).reshape(B, S, 64)
+        closed(value, val_ref, rtol=5e-5, atol=5e-5)
+    with pytest.raises(RuntimeError):
+        o.encoder_prologue(raw.to(DEV), st, gnp, [0, 12, 60, S + 1], stream, small, pos.to(DEV), pw)

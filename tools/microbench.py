@@ -140,6 +140,47 @@ def kv():
         print(f"   kv_project kernel: {t2:6.1f} us  {by / t2 / 1e6:6.2f} TB/s  max|diff| {err:.2e}", flush=True)
 
 
+def convs():
+    """Pixel-decoder front end at B=8, 640x480: the 1x1 input projections (NCHW -> tokens) + GroupNorm passes, the
+    layer-0 value / sampling projections and the 3x3 convolution."""
+    B = 8
+    for name, cin, h, w in (("res5", 2048, 15, 20), ("res4", 1024, 30, 40), ("res3", 512, 60, 80), ("res2", 256, 120, 160)):
+        x = torch.randn(B, cin, h, w, device=DEV)
+        wt = torch.randn(64, cin, device=DEV) * 0.05
+        b = torch.randn(64, device=DEV)
+        g, be = torch.rand(64, device=DEV) + 0.5, torch.randn(64, device=DEV)
+        t = timeit_graph(lambda: ops.conv1x1_nchw_to_tokens(x, wt, b))
+        tok = ops.conv1x1_nchw_to_tokens(x, wt, b)
+        t2 = timeit_graph(lambda: ops.groupnorm_tokens(tok, g, be, h, w, groups=32))
+        st0 = torch.zeros(B, 64, 2, device=DEV, dtype=torch.float64)
+        wpk = ops.pack_conv_in_weight(wt)
+        for ntv in ("1", "2", "4", ""):
+            os.environ.pop("MSM_CONVIN_NT", None)
+            if ntv:
+                os.environ["MSM_CONVIN_NT"] = ntv
+            t3 = timeit_graph(lambda: ops.conv1x1_in(x, wpk, b, stats=st0, stats_cleared=True))
+            o3, s3 = ops.conv1x1_in(x, wpk, b)
+            err = (o3 - tok).abs().max().item()
+            serr = ((s3 - ops.groupnorm_stats(tok)).abs() / (ops.groupnorm_stats(tok).abs() + 1)).max().item()
+            print(f"   conv1x1_in NT={ntv or 'auto'} (+GroupNorm moments, no fill): {t3:6.1f} us   max|diff| {err:.2e}  moments rel {serr:.2e}",
+                  flush=True)
+        by = (x.numel() + tok.numel()) * 4
+        print(f"{name} {cin}->64 @{h}x{w}: conv {t:6.1f} us ({by / t / 1e6:5.2f} TB/s, {2.0 * B * h * w * cin * 64 / t / 1e6:5.1f} TFLOP/s)"
+              f"   groupnorm {t2:6.1f} us", flush=True)
+    src = torch.randn(B, 6300, 64, device=DEV)
+    wv, bv = torch.randn(64, 64, device=DEV) * 0.1, torch.randn(64, device=DEV)
+    wp, bp = torch.randn(288, 64, device=DEV) * 0.1, torch.randn(288, device=DEV)
+    pos = torch.randn(6300, 64, device=DEV)
+    print(f"value_proj: {timeit_graph(lambda: ops.gemm(src, wv, bv)):6.1f} us   value_to_head_major: "
+          f"{timeit_graph(lambda: ops.value_to_head_major(src, 8)):6.1f} us   offsets/weights proj: "
+          f"{timeit_graph(lambda: ops.gemm(src, wp, bp, a2=pos)):6.1f} us", flush=True)
+    y = torch.randn(B, 19200, 64, device=DEV)
+    w3 = torch.randn(64, 576, device=DEV) * 0.05
+    t = timeit_graph(lambda: ops.conv3x3_tokens(y, w3, 120, 160))
+    print(f"conv3x3 64->64 @120x160: {t:6.1f} us ({2.0 * B * 19200 * 576 * 64 / t / 1e6:5.1f} TFLOP/s)   groupnorm_stats "
+          f"{timeit_graph(lambda: ops.groupnorm_stats(y)):6.1f} us", flush=True)
+
+
 def twostage():
     """BASELINE configs[3]: two-stage RGB + depth-crop refinement at 640x480 over 16 frames (first stage on the frame,
     depth filter, ROI crops resized to 224x224, one BATCHED second stage over all crops, paste-back).  The backbone is out of
@@ -295,4 +336,4 @@ def meanshift():
 
 if __name__ == "__main__":
     {"gemm": gemm, "mask": mask, "enc": enc, "attn": attn, "ucn": ucn, "meanshift": meanshift, "cfg5": cfg5,
-     "tails": tails, "kv": kv, "maskbf16": maskbf16, "twostage": twostage, "latency": latency}[sys.argv[1]]()
+     "tails": tails, "kv": kv, "maskbf16": maskbf16, "twostage": twostage, "convs": convs, "latency": latency}[sys.argv[1]]()

@@ -1,0 +1,228 @@
+// Input projections of the pixel decoder (see include/msm_hip.h: msm_conv1x1_in_f32):
+//     out[b][p][o] = sum_k w[o][k] * x[b][k][p] + bias[o],   o < 64,  k < Cin in {256 .. 2048},  x NCHW
+//     stats[b][o]  += (sum_p out, sum_p out^2)               (the GroupNorm statistics of the result)
+//
+// Reference: `input_proj[l] = Conv2d(Cin, 64, 1) + GroupNorm(32, 64)` on res3/res4/res5 (msdeformattn.py:212-220,
+// 326-329) and the FPN lateral `Conv2d(256, 64, 1, bias=False) + GroupNorm` on res2 (:225-238, 343-347).
+//
+// These are deep-K, 64-wide products: a stream over the backbone features (137 + 157 MB at B = 8) with 32 FLOP per
+// byte.  The tiled GEMM has too few 64x64 tiles to cover the chip on the coarse levels (res5: 40 tiles with a
+// 2048-deep K loop each -> 33 us for 20 MB) and needs a second pass over its output for the GroupNorm statistics.
+// Here a workgroup owns ONE 64-pixel tile of one image and its 8 waves split K:
+//   * MFMA orientation D^T: rows = output channels (A = w, pre-packed in fragment order so that a wave's operand load
+//     is 512 contiguous bytes), cols = 16 pixels (B = x: a lane loads NT consecutive pixels of one channel row with
+//     one 4*NT-byte load, pixel block nt of the tile being the strided set {px0 + NT*n + nt}).  K order inside an
+//     8-deep group is k = lq*2 + j for step j on both operands;
+//   * every wave accumulates the full 64 x 64 tile over its K slice (64 accumulator registers, no redundant loads
+//     of x), then the eight partial tiles are summed through LDS in two half rounds, in a fixed order
+//     (deterministic), wave w finishing blocks (channels 16*(w&3).., pixels 16*(w>>2).. and 32 + 16*(w>>2)..);
+//   * the finishing wave adds the bias, stores token-major float4s and reduces sum / sum-of-squares of its 16
+//     channels over its pixels; one double atomic per (workgroup, channel, moment) lands in stats.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace msm {
+
+constexpr int CI_W = 8;              // waves per workgroup = K slices
+constexpr int CI_O = 64;             // output channels
+
+// NT = 16-pixel blocks per workgroup (64 accumulator registers at NT = 4), D = K groups (of 8) in flight per wave.
+// Wide tiles (NT = 4, D = 2) read w once per 64 pixels and suit the fine levels; the coarse levels have too few
+// pixels to cover the chip with them, so they take NT = 1 with a deep ring of loads (D = 8) instead.
+template <int NT, int D>
+__global__ __launch_bounds__(CI_W * 64, 4) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            int64_t out_sb, double* __restrict__ stats, int Cin, int HW) {
+    constexpr int NB = 4 * NT;                        // 16 x 16 blocks of the tile
+    constexpr int HR = NT >= 2 ? 2 : 1;               // half rounds of the reduction (8 blocks each; NB = 4: one round of 4)
+    constexpr int RB = NB / HR;                       // blocks per round
+    extern __shared__ __attribute__((aligned(16))) float4 red[];   // [CI_W][RB blocks][64 lanes] + statistics
+    float* st = reinterpret_cast<float*>(red + CI_W * RB * 64);    // [2][64 ch][2]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    const int b = blockIdx.y;
+    const int px0 = (int)blockIdx.x * (16 * NT);
+    const int kw = Cin / CI_W;                        // K slice of this wave (a multiple of 8*D)
+    const int k0 = wave * kw;
+    // buffer descriptors (SGPRs) over this image of x and over w; per-lane byte offsets are loop invariant,
+    // the walk along K goes through the scalar offset of the load
+    auto uniform_ptr = [](const void* p) {
+        const uint64_t u = (uint64_t)p;
+        return (void*)(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                       (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u));
+    };
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(x + (int64_t)b * Cin * HW), 0, Cin * HW * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(w), 0, CI_O * Cin * 4, 0x00020000);
+    // x: a lane loads NT consecutive pixels of one channel row (one 4*NT-byte load; 16 lanes = 64*NT contiguous bytes);
+    // pixel block nt of the tile is therefore the strided set {px0 + NT*n + nt}.  w is pre-packed in fragment order
+    // (include/msm_hip.h): the four A operands of a group are 512-byte contiguous wave loads.
+    const unsigned xo = 4u * (unsigned)(lq * 2 * HW + min(px0 + NT * lj, HW - NT));
+    const unsigned wo = 8u * (unsigned)lane;
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // K is walked in groups of 8: step j in {0, 1} of a group covers k = lq*2 + j on both operands, so a lane's A
+    // operands of a group are one 8-byte load per channel block.  D register sets form a ring: the loads of group
+    // g + D are issued right after the MFMAs of group g (the loop is unrolled by D, so no register copies).
+    float2 wa[D][4];
+    float xa[D][NT][2];
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    auto load = [&](int kg, float2 (&wf)[4], float (&xf)[NT][2]) {
+        const unsigned ks = (unsigned)(k0 + kg * 8);            // wave-uniform
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(wr, wo, (ks / 8 * 4 + mt) * 512u, 0);
+            wf[mt] = make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned so = (ks + j) * (unsigned)HW * 4u;
+            if constexpr (NT == 4) {
+                const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(xr, xo, so, 0);
+                xf[0][j] = __uint_as_float(t.x); xf[1][j] = __uint_as_float(t.y);
+                xf[2][j] = __uint_as_float(t.z); xf[3][j] = __uint_as_float(t.w);
+            } else if constexpr (NT == 2) {
+                const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(xr, xo, so, 0);
+                xf[0][j] = __uint_as_float(t.x); xf[1][j] = __uint_as_float(t.y);
+            } else {
+                xf[0][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, xo, so, 0));
+            }
+        }
+    };
+    auto mma = [&](const float2 (&wf)[4], const float (&xf)[NT][2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const float a = j == 0 ? wf[mt].x : wf[mt].y;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(a, xf[nt][j], acc[mt][nt]);
+            }
+    };
+    const int groups = kw / 8;                        // a multiple of D
+#pragma unroll
+    for (int d = 0; d < D; ++d) load(d, wa[d], xa[d]);
+#pragma unroll 1
+    for (int kg = 0; kg < groups; kg += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            mma(wa[d], xa[d]);
+            if (kg + D + d < groups) load(kg + D + d, wa[d], xa[d]);
+        }
+    }
+
+    // ---- epilogue of one finished 16 x 16 block: bias, token-major store, GroupNorm moments into the LDS table ----
+    if (stats) {
+        for (int i = tid; i < 2 * CI_O * 2; i += CI_W * 64) st[i] = 0.f;
+        __syncthreads();
+    }
+    float sm[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};     // moments of this wave's finished blocks (one channel block)
+    auto finish = [&](const f32x4& v, int mt, int nt) {
+        const int ch = mt * 16 + lq * 4;
+        const int px = px0 + NT * lj + nt;                 // pixel block nt holds pixels px0 + NT*n + nt
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) bv = *reinterpret_cast<const float4*>(bias + ch);
+        const float v0 = v[0] + bv.x, v1 = v[1] + bv.y, v2 = v[2] + bv.z, v3 = v[3] + bv.w;
+        if (px < HW) {
+            *reinterpret_cast<float4*>(out + (int64_t)b * out_sb + (int64_t)px * CI_O + ch) = make_float4(v0, v1, v2, v3);
+            sm[0] += v0; sm[1] += v1; sm[2] += v2; sm[3] += v3;
+            sq[0] += v0 * v0; sq[1] += v1 * v1; sq[2] += v2 * v2; sq[3] += v3 * v3;
+        }
+    };
+    {
+        // sum the 8 partial tiles through LDS in HR rounds of RB blocks, fixed order (deterministic).  Block id inside
+        // a round = mt + 4*q with pixel block nt = h*(NT/HR) + q; wave w finishes block w of the round
+#pragma unroll
+        for (int h = 0; h < HR; ++h) {
+            if (h) __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NT / HR; ++q)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const f32x4 v = acc[mt][h * (NT / HR) + q];
+                    red[(wave * RB + mt + 4 * q) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            __syncthreads();
+            if (wave < RB) {
+                f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < CI_W; ++s) {
+                    const float4 v = red[(s * RB + wave) * 64 + lane];
+                    t += f32x4{v.x, v.y, v.z, v.w};
+                }
+                finish(t, wave & 3, h * (NT / HR) + (wave >> 2));
+            }
+        }
+    }
+    if (stats) {
+        // a wave's blocks all belong to channel block wave & 3: reduce over its 16 pixels per lane quarter, one LDS slot
+        // per (wave >> 2, channel) -- no atomics below the per-workgroup double adds, so the sums are reproducible
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                sm[r] += __shfl_xor(sm[r], o, 64);
+                sq[r] += __shfl_xor(sq[r], o, 64);
+            }
+        }
+        if (lj == 0 && wave < RB) {
+            const int ch = (wave & 3) * 16 + lq * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                st[((wave >> 2) * CI_O + ch + r) * 2 + 0] = sm[r];
+                st[((wave >> 2) * CI_O + ch + r) * 2 + 1] = sq[r];
+            }
+        }
+        __syncthreads();
+        if (tid < CI_O * 2) {
+            const double v = (double)st[tid] + (double)st[CI_O * 2 + tid];
+            atomicAdd(stats + (int64_t)b * CI_O * 2 + tid, v);
+        }
+    }
+}
+
+}  // namespace msm
+
+using namespace msm;
+
+extern "C" int msm_conv1x1_in_f32(const float* x, const float* w, const float* bias, float* out, int64_t out_batch_stride,
+                                  double* stats, int stats_cleared, int B, int Cin, int HW, void* stream) {
+    MSM_REQUIRE(x && w && out, "msm_conv1x1_in_f32: null pointer");
+    MSM_REQUIRE(HW % 4 == 0, "msm_conv1x1_in_f32: HW=%d must be a multiple of 4", HW);
+    MSM_REQUIRE(B > 0 && HW > 0 && Cin >= 128 && Cin % (CI_W * 16) == 0, "msm_conv1x1_in_f32: Cin=%d must be a multiple of %d", Cin,
+                CI_W * 16);
+    MSM_REQUIRE(out_batch_stride >= (int64_t)HW * CI_O && out_batch_stride % 4 == 0, "msm_conv1x1_in_f32: bad output batch stride");
+    MSM_REQUIRE((int64_t)Cin * HW < ((int64_t)1 << 30), "msm_conv1x1_in_f32: one image of x must be < 4 GiB (32-bit buffer offsets)");
+    MSM_REQUIRE(((((uintptr_t)w) | ((uintptr_t)out) | ((uintptr_t)bias) | ((uintptr_t)x)) & 15) == 0 && (((uintptr_t)stats) & 7) == 0,
+                "msm_conv1x1_in_f32: misaligned pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (stats && !stats_cleared) MSM_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * CI_O * (size_t)B, st));
+    // One pixel tile per workgroup, K split over its 8 waves: 64 pixels when such tiles cover the chip about twice,
+    // else 32 or 16 pixels with a deeper ring of loads (the coarse levels are latency bound: few pixels, K up to 2048)
+    const int64_t t64 = (int64_t)cdiv(HW, 64) * B;
+    int nt = t64 >= 512 ? 4 : (t64 >= 128 ? 2 : 1);
+    if (const char* e = getenv("MSM_CONVIN_NT")) nt = atoi(e) == 4 ? 4 : (atoi(e) == 2 ? 2 : 1);
+    const int kw = Cin / CI_W;
+    dim3 grid(cdiv(HW, 16 * nt), B), block(CI_W * 64);
+#define CI_LAUNCH(NT_, D_)                                                                                        \
+    {                                                                                                             \
+        const size_t lds = sizeof(float4) * CI_W * (4 * NT_ / (NT_ >= 2 ? 2 : 1)) * 64 + sizeof(float) * 2 * CI_O * 2; \
+        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv_in_kernel<NT_, D_>, lds));                 \
+        hipLaunchKernelGGL((conv_in_kernel<NT_, D_>), grid, block, lds, st, x, w, bias, out, out_batch_stride, stats, Cin, HW); \
+    }
+    if (nt == 4) CI_LAUNCH(4, 2)
+    else if (nt == 2 && kw % 32 == 0) CI_LAUNCH(2, 4)
+    else if (nt == 2) CI_LAUNCH(2, 2)
+    else if (kw % 64 == 0) CI_LAUNCH(1, 8)
+    else CI_LAUNCH(1, 2)
+#undef CI_LAUNCH
+    MSM_CHECK_LAUNCH("msm_conv1x1_in_f32");
+    return MSM_OK;
+}

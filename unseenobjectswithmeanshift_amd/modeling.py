@@ -698,6 +698,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         self._cache = {}
         self._packed = None
         self.fused_encoder = True      # False: one GEMM / LayerNorm launch per op (same results up to rounding)
+        self.fused_front = True        # False: input projections and layer 0's projections as separate GEMM / GroupNorm launches
 
     def _w3(self):
         """layer_1's 3x3 weight in the implicit-GEMM order (Cout, 3*3*Cin), cached per parameter version."""
@@ -753,30 +754,71 @@ class MSDeformAttnPixelDecoder(nn.Module):
             self._cache[key] = (ss, starts, torch.cat(pos, 0).contiguous())
         return self._cache[key]
 
+    def _packed_front(self, device):
+        """Fragment-order input_proj weights, GroupNorm parameters and the prologue weight stream (layer 0's value /
+        sampling projections), rebuilt only when one of those parameters changes."""
+        a0 = self.transformer.encoder.layers[0].self_attn
+        params = [p for m in self.input_proj for p in m.parameters()] + list(a0.value_proj.parameters()) + \
+            list(a0.sampling_offsets.parameters()) + list(a0.attention_weights.parameters())
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
+        if getattr(self, "_front", None) is None or self._front[0] != key:
+            C = self.conv_dim
+            wpk = [ops.pack_conv_in_weight(m[0].weight.view(C, -1)) for m in self.input_proj]
+            gnp = torch.stack([torch.stack([m[1].weight, m[1].bias]) for m in self.input_proj]).contiguous()
+            wp, bp = a0._proj_weights()
+            stream = ops.pack_encoder_prologue(a0.value_proj.weight, wp)
+            small = torch.cat([a0.value_proj.bias, bp]).contiguous()
+            self._front = (key, wpk, gnp, stream, small, wp.shape[0])
+        return self._front[1:]
+
     @torch.no_grad()
     def forward_features(self, features):
         C = self.conv_dim
-        toks, shapes = [], []
-        for idx, f in enumerate(self.transformer_in_features[::-1]):            # res5, res4, res3
-            x = features[f].float().contiguous()
-            B, _, H, W = x.shape
-            conv, gn = self.input_proj[idx][0], self.input_proj[idx][1]
-            t = ops.conv1x1_nchw_to_tokens(x, conv.weight.view(C, -1), conv.bias)
-            toks.append(ops.groupnorm_tokens(t, gn.weight, gn.bias, H, W, groups=32, eps=gn.eps))
-            shapes.append((int(H), int(W)))
-        dev = toks[0].device
+        levels = [features[f].float().contiguous() for f in self.transformer_in_features[::-1]]      # res5, res4, res3
+        B = levels[0].shape[0]
+        shapes = [(int(x.shape[2]), int(x.shape[3])) for x in levels]
+        dev = levels[0].device
         ss, starts, lvl_pos = self._geometry(shapes, dev)
-        src = torch.cat(toks, 1).contiguous()                                     # (B,S,C)
+        S_tok = sum(h * w for h, w in shapes)
         layers = self.transformer.encoder.layers
+        gns = [m[1] for m in self.input_proj]
+        front = (self.fused_encoder and self.fused_front and C == 64 and len(levels) <= 4 and S_tok >= 64
+                 and all(x.shape[1] % 128 == 0 and (x.shape[2] * x.shape[3]) % 4 == 0 for x in levels)
+                 and all(g.num_groups == gns[0].num_groups and g.eps == gns[0].eps for g in gns))
+        value = proj = None
+        if front:
+            # input projections straight into the concatenated token buffer with their GroupNorm moments as a
+            # by-product, then ONE prologue pass: GroupNorm, layer 0's value projection and sampling projections
+            wpk, gnp, pstream, psmall, pw = self._packed_front(dev)
+            src = torch.empty((B, S_tok, C), device=dev, dtype=torch.float32)
+            stats = torch.zeros((len(levels), B, C, 2), device=dev, dtype=torch.float64)
+            o = 0
+            for idx, x in enumerate(levels):
+                hw = shapes[idx][0] * shapes[idx][1]
+                ops.conv1x1_in(x, wpk[idx], self.input_proj[idx][0].bias, out=src[:, o:o + hw], stats=stats[idx], stats_cleared=True)
+                o += hw
+            a0 = layers[0].self_attn
+            bounds = [0]
+            for h, w in shapes:
+                bounds.append(bounds[-1] + h * w)
+            src, value, proj = ops.encoder_prologue(src, stats, gnp, bounds, pstream, psmall, lvl_pos, pw, groups=gns[0].num_groups,
+                                                    eps=gns[0].eps, value_heads=a0.n_heads)
+        else:
+            toks = []
+            for idx, x in enumerate(levels):
+                conv, gn = self.input_proj[idx][0], self.input_proj[idx][1]
+                t = ops.conv1x1_nchw_to_tokens(x, conv.weight.view(C, -1), conv.bias)
+                toks.append(ops.groupnorm_tokens(t, gn.weight, gn.bias, shapes[idx][0], shapes[idx][1], groups=gn.num_groups, eps=gn.eps))
+            src = torch.cat(toks, 1).contiguous()                                     # (B,S,C)
         if self.fused_encoder and C == 64:
             # layer l = MSDeformAttn gather + ONE fused token-wise kernel that also emits layer l+1's
             # value / sampling projections (the 1024-wide FFN activation never leaves registers)
             packed = self._packed_encoder(dev)
-            a0 = layers[0].self_attn
-            value = ops.value_to_head_major(ops.gemm(src, a0.value_proj.weight, a0.value_proj.bias), a0.n_heads)
-            w, b = self._packed[2]
-            proj = ops.gemm(src, w, b, a2=lvl_pos)
-            S_tok = src.shape[1]
+            if value is None:
+                a0 = layers[0].self_attn
+                value = ops.value_to_head_major(ops.gemm(src, a0.value_proj.weight, a0.value_proj.bias), a0.n_heads)
+                w, b = self._packed[2]
+                proj = ops.gemm(src, w, b, a2=lvl_pos)
             for l, layer in enumerate(layers):
                 attn = ops.ms_deform_attn_encoder(value, ss, starts, proj, layer.self_attn.n_heads, layer.self_attn.n_points)
                 stream, small, d_ffn, pw = packed[l]

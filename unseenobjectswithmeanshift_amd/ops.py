@@ -103,6 +103,44 @@ def conv1x1_nchw_to_tokens(x, w, bias=None):
     return out
 
 
+def pack_conv_in_weight(w):
+    """(64, Cin) 1x1-convolution weight -> the fragment order msm_conv1x1_in_f32 reads (include/msm_hip.h):
+    packed[(((k//8)*4 + o//16)*64 + ((k%8)//2)*16 + o%16)*2 + k%2] = w[o][k]."""
+    O, Cin = w.shape
+    if O != 64 or Cin % 8:
+        raise RuntimeError("pack_conv_in_weight needs a (64, Cin) weight with Cin a multiple of 8")
+    return w.reshape(4, 16, Cin // 8, 4, 2).permute(2, 0, 3, 1, 4).contiguous().reshape(-1)
+
+
+def conv1x1_in(x, w_packed, bias=None, *, out=None, stats=None, stats_cleared=False):
+    """Input projection of the pixel decoder: x (B, Cin, H, W) NCHW, w_packed = pack_conv_in_weight(w (64, Cin)) ->
+    tokens (B, H*W, 64) = x^T w^T + bias,
+    plus the GroupNorm moments of the result.  ``out``: a (B, H*W, 64) view with unit channel stride, row stride 64 and
+    any batch stride (e.g. ``buf[:, s:s + H*W]`` of the concatenated token buffer of the encoder); ``stats``: a
+    (B, 64, 2) float64 tensor that receives (sum, sum of squares) per (image, channel) -- accumulated into when
+    ``stats_cleared`` (the caller zeroed it), else zeroed first.  Returns (out, stats).  Cin must be a multiple of 128
+    (conv1x1_nchw_to_tokens + groupnorm_stats cover other shapes)."""
+    _c(x, "x"), _c(w_packed, "w_packed"), _c(bias, "bias"), _c(stats, "stats", torch.float64)
+    B, Cin, H, W = x.shape
+    HW = H * W
+    if w_packed.numel() != 64 * Cin or Cin % 128 or HW % 4:
+        raise RuntimeError("conv1x1_in needs a packed (64, Cin) weight, Cin a multiple of 128 and H*W a multiple of 4")
+    if out is None:
+        out = torch.empty((B, HW, 64), device=x.device, dtype=torch.float32)
+    _chk(out, "out")
+    if tuple(out.shape) != (B, HW, 64) or out.stride(2) != 1 or out.stride(1) != 64 or (B > 1 and out.stride(0) < HW * 64):
+        raise RuntimeError("out must be (B, H*W, 64) with strides (>= H*W*64, 64, 1)")
+    if stats is None:
+        stats = torch.empty((B, 64, 2), device=x.device, dtype=torch.float64)
+        stats_cleared = False
+    elif tuple(stats.shape) != (B, 64, 2):
+        raise RuntimeError("stats must be (B, 64, 2) float64")
+    rc = lib().msm_conv1x1_in_f32(_p(x), _p(w_packed), _p(bias), _p(out), out.stride(0) if B > 1 else HW * 64, _p(stats),
+                                  1 if stats_cleared else 0, B, Cin, HW, _stream())
+    check(rc, "msm_conv1x1_in_f32")
+    return out, stats
+
+
 def is_token_major(x):
     """True for a (B, C, H, W) tensor stored [B][H*W][C] (torch channels_last, possibly with a larger batch stride),
     e.g. the NCHW-shaped views the pixel decoder returns over its token buffer."""
@@ -555,6 +593,40 @@ def instance_postprocess(mask_logits, query_index, image_size, class_scores=None
                                         B, Q, T, h, w, H, W, Hs, Ws, _p(ws), _stream())
     check(rc, "msm_instance_postprocess")
     return masks, score, boxes
+
+
+def pack_encoder_prologue(wv, wp):
+    """Weight stream of msm_encoder_prologue_fwd: value_proj (64,64) then [sampling_offsets | attention_weights]
+    (proj_width,64) as consecutive 16-row blocks, zero-padded to the stream length."""
+    pw = wp.shape[0]
+    n = int(lib().msm_encoder_prologue_stream_floats(pw))
+    out = torch.zeros(n, device=wv.device, dtype=torch.float32)
+    out[:64 * 64] = wv.reshape(-1)
+    out[64 * 64:64 * 64 + pw * 64] = wp.reshape(-1)
+    return out
+
+
+def encoder_prologue(raw, stats, gn_params, level_starts, stream, small, pos, proj_width, *, groups=32, eps=1e-5, value_heads=0):
+    """raw (B,S,64) concatenated input projections (conv1x1_in), stats (L,B,64,2) float64 their GroupNorm moments,
+    gn_params (L,2,64) = gamma, beta, level_starts: L+1 token offsets (0..S).  Normalises raw IN PLACE (-> src) and
+    returns (src, value, proj) for the first encoder layer: value (B,S,64) or head-major (B,heads,S,64/heads),
+    proj (B,S,proj_width) = [sampling_offsets | attention_weights](src + pos)."""
+    _c(raw, "raw"), _c(stats, "stats", torch.float64), _c(gn_params, "gn_params"), _c(stream, "stream"), _c(small, "small"), _c(pos, "pos")
+    B, S, C = raw.shape
+    L = len(level_starts) - 1
+    if C != 64 or tuple(stats.shape) != (L, B, 64, 2) or tuple(gn_params.shape) != (L, 2, 64) or tuple(pos.shape) != (S, 64):
+        raise RuntimeError("encoder_prologue: inconsistent shapes")
+    if small.numel() != 64 + proj_width:
+        raise RuntimeError("encoder_prologue: small must hold the 64 value_proj biases and the proj_width projection biases")
+    dev = raw.device
+    value = torch.empty((B, value_heads, S, 64 // value_heads) if value_heads else (B, S, 64), device=dev, dtype=torch.float32)
+    proj = torch.empty((B, S, proj_width), device=dev, dtype=torch.float32)
+    ls = (ctypes.c_int32 * (L + 1))(*[int(v) for v in level_starts])
+    rc = lib().msm_encoder_prologue_fwd(_p(raw), _p(stats), _p(gn_params), ctypes.cast(ls, ctypes.c_void_p), L, int(groups), float(eps),
+                                        _p(stream), _p(small), _p(pos), _p(raw), _p(value), _p(proj), B, S, int(proj_width),
+                                        int(value_heads), _stream())
+    check(rc, "msm_encoder_prologue_fwd")
+    return raw, value, proj
 
 
 def label_stats(labels, weight=None, k=1024):
