@@ -87,12 +87,13 @@ int msm_layernorm_f32(const float* x, const float* parts, int n_parts, int64_t p
                       int rows, int E, float eps, void* stream);
 
 /* GroupNorm over token maps x [B][HW][C] (NHWC), `groups` groups of C/groups channels.
- * stats: double [B][C][2] (sum, sum of squares), zeroed by msm_groupnorm_stats_f32 itself. */
-int msm_groupnorm_stats_f32(const float* x, double* stats, int B, int HW, int C, void* stream);
-/* y = GN(x)*gamma+beta (+ bilinear_upsample(up [B][uh*uw][C]) when up != NULL, align_corners=False,
- * msdeformattn.py:348) (relu when relu != 0).  x/y are [B][H*W][C]. */
+ * stats: double [B][C][2] (sum, sum of squares), accumulated into; zeroed here first unless stats_cleared != 0. */
+int msm_groupnorm_stats_f32(const float* x, double* stats, int stats_cleared, int B, int HW, int C, void* stream);
+/* y = GN(x)*gamma+beta (+ bilinear_upsample(up) when up != NULL, align_corners=False, msdeformattn.py:348) (relu when
+ * relu != 0).  x/y are [B][H*W][C]; up: image b is [uh*uw][C] at up + b*up_batch_stride floats (0 = dense), e.g. the
+ * finest level inside the encoder's token buffer. */
 int msm_groupnorm_apply_f32(const float* x, const double* stats, const float* gamma, const float* beta,
-                            const float* up, int uh, int uw, float* y,
+                            const float* up, int uh, int uw, int64_t up_batch_stride, float* y,
                             int B, int H, int W, int C, int groups, float eps, int relu, void* stream);
 
 /* PositionEmbeddingSine(normalize=True) for one H x W map (position_encoding.py:29-52).

@@ -28,8 +28,8 @@ _SIGNATURES = {
                            c_l, c_l, c_l, c_l, c_l, c_l, c_l, c_l, c_l,
                            c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "msm_layernorm_f32": (c_i, [c_f, c_f, c_i, c_l, c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_p]),
-    "msm_groupnorm_stats_f32": (c_i, [c_f, c_p, c_i, c_i, c_i, c_p]),
-    "msm_groupnorm_apply_f32": (c_i, [c_f, c_p, c_f, c_f, c_f, c_i, c_i, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_i, c_p]),
+    "msm_groupnorm_stats_f32": (c_i, [c_f, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "msm_groupnorm_apply_f32": (c_i, [c_f, c_p, c_f, c_f, c_f, c_i, c_i, c_l, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_i, c_p]),
     "msm_pos_embed_sine": (c_i, [c_f, c_i, c_i, c_i, c_l, c_l, c_f, c_fl, c_fl, c_p]),
     "msm_transpose_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_p]),
     "msm_mask_logits_fwd": (c_i, [c_f, c_f, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),

@@ -128,7 +128,7 @@ __device__ __forceinline__ void bilin_src(int dst, int in, int out, int& i0, int
 // per block into LDS, the body is 16-byte loads/stores (thread = 4 channels of one pixel).
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const float* __restrict__ up, int uh, int uw,
+                                                       const float* __restrict__ up, int uh, int uw, int64_t up_sb,
                                                        float* __restrict__ y, int H, int W, int C, int groups,
                                                        float eps, int relu) {
     __shared__ float sc[256], sh[256], mn[256];
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
             float ly, lx;
             bilin_src(yy, uh, H, y0, y1, ly);
             bilin_src(xx, uw, W, x0, x1, lx);
-            const float* ub = up + (int64_t)b * uh * uw * C + c;
+            const float* ub = up + (int64_t)b * up_sb + c;
             const float4 v00 = *reinterpret_cast<const float4*>(ub + ((int64_t)y0 * uw + x0) * C);
             const float4 v01 = *reinterpret_cast<const float4*>(ub + ((int64_t)y0 * uw + x1) * C);
             const float4 v10 = *reinterpret_cast<const float4*>(ub + ((int64_t)y1 * uw + x0) * C);
@@ -259,12 +259,12 @@ extern "C" int msm_layernorm_f32(const float* x, const float* parts, int n_parts
     return MSM_OK;
 }
 
-extern "C" int msm_groupnorm_stats_f32(const float* x, double* stats, int B, int HW, int C, void* stream) {
+extern "C" int msm_groupnorm_stats_f32(const float* x, double* stats, int stats_cleared, int B, int HW, int C, void* stream) {
     MSM_REQUIRE(x && stats && B > 0 && HW > 0, "msm_groupnorm_stats_f32: bad arguments");
     MSM_REQUIRE(C >= 4 && C <= 256 && C % 4 == 0 && 1024 % C == 0, "msm_groupnorm_stats_f32: C=%d must be a multiple of 4 dividing 1024", C);
     MSM_REQUIRE((((uintptr_t)x) & 15) == 0, "msm_groupnorm_stats_f32: x must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    MSM_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * (size_t)B * C, st));
+    if (!stats_cleared) MSM_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * (size_t)B * C, st));
     const int ppb = 256;
     dim3 grid(cdiv(HW, ppb), B), block(256);
     hipLaunchKernelGGL(gn_stats_kernel, grid, block, 0, st, x, stats, HW, C, ppb);
@@ -273,16 +273,18 @@ extern "C" int msm_groupnorm_stats_f32(const float* x, double* stats, int B, int
 }
 
 extern "C" int msm_groupnorm_apply_f32(const float* x, const double* stats, const float* gamma, const float* beta,
-                                       const float* up, int uh, int uw, float* y, int B, int H, int W, int C,
-                                       int groups, float eps, int relu, void* stream) {
+                                       const float* up, int uh, int uw, int64_t up_batch_stride, float* y, int B, int H, int W,
+                                       int C, int groups, float eps, int relu, void* stream) {
     MSM_REQUIRE(x && stats && gamma && beta && y, "msm_groupnorm_apply_f32: null pointer");
     MSM_REQUIRE(groups > 0 && C % groups == 0 && C % 4 == 0 && C <= 256, "msm_groupnorm_apply_f32: C=%d groups=%d", C, groups);
     MSM_REQUIRE(((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)up)) & 15) == 0, "msm_groupnorm_apply_f32: pointers must be 16-byte aligned");
     MSM_REQUIRE(!up || (uh > 0 && uw > 0), "msm_groupnorm_apply_f32: bad upsample source size");
+    if (up_batch_stride == 0) up_batch_stride = (int64_t)uh * uw * C;
+    MSM_REQUIRE(!up || (up_batch_stride >= (int64_t)uh * uw * C && up_batch_stride % 4 == 0), "msm_groupnorm_apply_f32: bad upsample batch stride");
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = (int64_t)H * W * (C / 4);
     dim3 grid((unsigned)min((int64_t)1024, (total + 255) / 256), B), block(256);
-    hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, st, x, stats, gamma, beta, up, uh, uw, y, H, W, C, groups, eps,
+    hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, st, x, stats, gamma, beta, up, uh, uw, up_batch_stride, y, H, W, C, groups, eps,
                        relu);
     MSM_CHECK_LAUNCH("msm_groupnorm_apply_f32");
     return MSM_OK;

@@ -441,7 +441,11 @@ class MeanShiftTransformerDecoder(nn.Module):
             raise ValueError("mask_step_dtype must be 'f32' or 'bf16'")
         self._packed_mf = ops.pack_mask_features_bf16(mask_features) if self.mask_step_dtype == "bf16" else None
         qpos = self.query_embed.weight
-        out = self.query_feat.weight[None].expand(B, -1, -1).contiguous()
+        qf = self.query_feat.weight
+        qkey = (B, qf.data_ptr(), qf._version)
+        if getattr(self, "_q0", None) is None or self._q0[0] != qkey:          # the broadcast initial queries are read-only
+            self._q0 = (qkey, qf[None].expand(B, -1, -1).contiguous())
+        out = self._q0[1]
         full = self.aux_outputs
         L = self.num_layers
         pred_cls, pred_mask = [], []
@@ -786,12 +790,14 @@ class MSDeformAttnPixelDecoder(nn.Module):
                  and all(x.shape[1] % 128 == 0 and (x.shape[2] * x.shape[3]) % 4 == 0 for x in levels)
                  and all(g.num_groups == gns[0].num_groups and g.eps == gns[0].eps for g in gns))
         value = proj = None
+        fpn_stats = (None, None)
         if front:
             # input projections straight into the concatenated token buffer with their GroupNorm moments as a
             # by-product, then ONE prologue pass: GroupNorm, layer 0's value projection and sampling projections
             wpk, gnp, pstream, psmall, pw = self._packed_front(dev)
             src = torch.empty((B, S_tok, C), device=dev, dtype=torch.float32)
-            stats = torch.zeros((len(levels), B, C, 2), device=dev, dtype=torch.float64)
+            stats = torch.zeros((len(levels) + 2, B, C, 2), device=dev, dtype=torch.float64)      # + the two FPN GroupNorms
+            fpn_stats = (stats[len(levels)], stats[len(levels) + 1])
             o = 0
             for idx, x in enumerate(levels):
                 hw = shapes[idx][0] * shapes[idx][1]
@@ -801,7 +807,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
             bounds = [0]
             for h, w in shapes:
                 bounds.append(bounds[-1] + h * w)
-            src, value, proj = ops.encoder_prologue(src, stats, gnp, bounds, pstream, psmall, lvl_pos, pw, groups=gns[0].num_groups,
+            src, value, proj = ops.encoder_prologue(src, stats[:len(levels)], gnp, bounds, pstream, psmall, lvl_pos, pw, groups=gns[0].num_groups,
                                                     eps=gns[0].eps, value_heads=a0.n_heads)
         else:
             toks = []
@@ -835,18 +841,18 @@ class MSDeformAttnPixelDecoder(nn.Module):
         for (h, w) in shapes:
             out.append(src[:, o:o + h * w].view(B, h, w, C).permute(0, 3, 1, 2))
             o += h * w
-        up_tok = src[:, o - shapes[-1][0] * shapes[-1][1]:].contiguous()          # finest level, source of the FPN upsample
+        up_tok = src[:, o - shapes[-1][0] * shapes[-1][1]:]                       # finest level, source of the FPN upsample (a view)
         # one FPN level on the highest-resolution backbone feature (MSD:343-351)
         x = features[self.in_features[0]].float().contiguous()
         H, W = int(x.shape[2]), int(x.shape[3])
         lat = ops.conv1x1_nchw_to_tokens(x, self.adapter_1.weight.view(C, -1), None)
         y = ops.groupnorm_tokens(lat, self.adapter_1.norm.weight, self.adapter_1.norm.bias, H, W, groups=32,
-                                 up=up_tok, up_hw=shapes[-1], eps=self.adapter_1.norm.eps)
+                                 up=up_tok, up_hw=shapes[-1], eps=self.adapter_1.norm.eps, stats=fpn_stats[0])
         y = ops.conv3x3_tokens(y, self._w3(), H, W)
         wm = self.mask_features.weight.view(self.mask_dim, C)
         if C == 64 and self.mask_dim in (256, 512) and (H * W) % 4 == 0 and B <= 64:
             # layer_1's GroupNorm + ReLU is applied to the operand fragments of the mask_features convolution
-            gn = (ops.groupnorm_stats(y), self.layer_1.norm.weight, self.layer_1.norm.bias, 32, self.layer_1.norm.eps)
+            gn = (ops.groupnorm_stats(y, fpn_stats[1]), self.layer_1.norm.weight, self.layer_1.norm.bias, 32, self.layer_1.norm.eps)
             mask_features = ops.tokens_proj_nchw(y, wm, self.mask_features.bias, gn=gn, relu=True).view(B, self.mask_dim, H, W)
         else:
             y = ops.groupnorm_tokens(y, self.layer_1.norm.weight, self.layer_1.norm.bias, H, W, groups=32, relu=True,

@@ -229,27 +229,37 @@ def layernorm(x, g1, b1, *, parts=None, bias=None, l2norm=False, g2=None, b2=Non
     return (y, y2) if g2 is not None else y
 
 
-def groupnorm_tokens(x, gamma, beta, H, W, groups=32, *, up=None, up_hw=None, relu=False, eps=1e-5):
-    """GroupNorm over an NHWC token map x (B, H*W, C); optionally adds the bilinear upsample of
-    `up` (B, uh*uw, C) and applies ReLU."""
-    _c(x, "x"), _c(gamma, "gamma"), _c(beta, "beta"), _c(up, "up")
+def groupnorm_tokens(x, gamma, beta, H, W, groups=32, *, up=None, up_hw=None, relu=False, eps=1e-5, stats=None):
+    """GroupNorm over an NHWC token map x (B, H*W, C); optionally adds the bilinear upsample of `up` (B, uh*uw, C) -- dense
+    or a token-range slice of a larger buffer (row stride C, any batch stride) -- and applies ReLU.  ``stats``: a zeroed
+    (B, C, 2) float64 scratch to accumulate the moments in (saves the fill launch)."""
+    _c(x, "x"), _c(gamma, "gamma"), _c(beta, "beta"), _chk(up, "up")
     B, HW, C = x.shape
-    stats = torch.empty((B, C, 2), device=x.device, dtype=torch.float64)
-    check(lib().msm_groupnorm_stats_f32(_p(x), _p(stats), B, HW, C, _stream()), "msm_groupnorm_stats_f32")
+    stats = groupnorm_stats(x, stats)
     y = torch.empty_like(x)
     uh, uw = (0, 0) if up is None else up_hw
-    rc = lib().msm_groupnorm_apply_f32(_p(x), _p(stats), _p(gamma), _p(beta), _p(up), uh, uw, _p(y),
+    usb = 0
+    if up is not None:
+        if tuple(up.shape) != (B, uh * uw, C) or up.stride(2) != 1 or up.stride(1) != C or (B > 1 and up.stride(0) < uh * uw * C):
+            raise RuntimeError("up must be (B, uh*uw, C) with strides (>= uh*uw*C, C, 1)")
+        usb = up.stride(0) if B > 1 else 0
+    rc = lib().msm_groupnorm_apply_f32(_p(x), _p(stats), _p(gamma), _p(beta), _p(up), uh, uw, usb, _p(y),
                                        B, H, W, C, groups, eps, 1 if relu else 0, _stream())
     check(rc, "msm_groupnorm_apply_f32")
     return y
 
 
-def groupnorm_stats(x):
-    """Per-(image, channel) double (sum, sum of squares) of a token map x (B, HW, C) -> (B, C, 2) float64."""
-    _c(x, "x")
+def groupnorm_stats(x, stats=None):
+    """Per-(image, channel) double (sum, sum of squares) of a token map x (B, HW, C) -> (B, C, 2) float64.  ``stats``: a
+    ZEROED (B, C, 2) float64 tensor to accumulate into (then no fill launch is issued)."""
+    _c(x, "x"), _c(stats, "stats", torch.float64)
     B, HW, C = x.shape
-    stats = torch.empty((B, C, 2), device=x.device, dtype=torch.float64)
-    check(lib().msm_groupnorm_stats_f32(_p(x), _p(stats), B, HW, C, _stream()), "msm_groupnorm_stats_f32")
+    cleared = stats is not None
+    if stats is None:
+        stats = torch.empty((B, C, 2), device=x.device, dtype=torch.float64)
+    elif tuple(stats.shape) != (B, C, 2):
+        raise RuntimeError("stats must be (B, C, 2) float64")
+    check(lib().msm_groupnorm_stats_f32(_p(x), _p(stats), 1 if cleared else 0, B, HW, C, _stream()), "msm_groupnorm_stats_f32")
     return stats
 
 
