@@ -517,6 +517,13 @@ def test_topk_and_postprocess():
         if not mism.any():
             close(boxes[b], O.mask_boxes(up > 0), rtol=0, atol=0)
     assert float(ms[0, 0]) == 0.0 and torch.equal(boxes[0, 0].cpu(), torch.zeros(4))
+    # the 4x-specialised strip kernel (register-cached taps) equals the generic one bit for bit
+    if Hh == 4 * h and Ww == 4 * w:
+        os.environ["MSM_POST_GENERIC"] = "1"
+        pm_g, ms_g, boxes_g = ops().instance_postprocess(masks.to(DEV), force, (Hh, Ww))
+        os.environ.pop("MSM_POST_GENERIC")
+        assert torch.equal(pm, pm_g) and torch.equal(boxes, boxes_g)
+        close(ms, ms_g.cpu(), rtol=1e-6, atol=1e-7)          # fp32 partial sums are grouped per strip in both, atomics order differs
     # padded frame: upsample to (Hh, Ww), keep the top-left (Hc, Wc) image (PM:275, 354-357); odd widths take the
     # scalar-store path
     for Hc, Wc in ((Hh - 5, Ww - 7), (Hh - 31, Ww), (Hh, Ww - 4)):

@@ -7,6 +7,8 @@
 // class-score matrix and only the T selected masks are upsampled: one pass reads T low-res maps and
 // writes T binary maps (HBM-bound: 32 MB instead of >= 250 MB per image), with the score and box
 // reductions fused into it.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace msm {
@@ -138,6 +140,100 @@ __global__ __launch_bounds__(256) void inst_upsample_kernel(const float* __restr
     }
 }
 
+// The same strip for the 4x case every shipped configuration hits (mask logits at 1/4 of the padded frame, W % 4 == 0):
+// a thread's four output pixels 4k..4k+3 read source columns k-1, k, k+1 only and the 16 output rows of a strip read
+// six source rows, so a strip costs 18 loads per thread instead of 256 (the generic kernel is bound by its tap loads,
+// not by the 197 MB of masks it writes).  Same weights, same expression, same clamped taps: identical results.
+__global__ __launch_bounds__(256) void inst_upsample4_kernel(const float* __restrict__ logits, const int32_t* __restrict__ qidx,
+                                                             float* __restrict__ masks, InstAcc* __restrict__ acc, int Q, int T,
+                                                             int h, int w, int H, int W, int Hs, int Ws) {
+    const int bt = blockIdx.z;
+    const int b = bt / T;
+    const int q = qidx[bt];
+    const float* src = logits + ((int64_t)b * Q + q) * h * w;
+    float* dst = masks + (int64_t)bt * H * W;
+    const float sy = (float)h / (float)Hs, sx = (float)w / (float)Ws;
+    const int y0 = blockIdx.y * 16;
+    const int j0 = y0 >> 2;
+    double sum = 0.0;
+    unsigned int cnt = 0;
+    int xmin = 0x7fffffff, ymin = 0x7fffffff, xmax = -1, ymax = -1;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; 4 * k < W; k += gridDim.x * blockDim.x) {
+        const int x0 = 4 * k;
+        float lx[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int xa, xb;
+            src_index(x0 + e, sx, w, xa, xb, lx[e]);
+        }
+        const int c0 = max(k - 1, 0), c2 = min(k + 1, w - 1);
+        float v[6][3];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const float* row = src + min(max(j0 - 1 + i, 0), h - 1) * w;
+            v[i][0] = row[c0];
+            v[i][1] = row[k];
+            v[i][2] = row[c2];
+        }
+        float fsum = 0.f;
+        int xhit_min = 0x7fffffff, xhit_max = -1;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int y = y0 + t;
+            if (y < H) {
+                int ya, yb;
+                float ly;
+                src_index(y, sy, h, ya, yb, ly);
+                const float hy = 1.f - ly;
+                const int a = (t >> 2) + ((t & 3) < 2 ? 0 : 1);      // rows (j-1, j) for the upper half of a source row, (j, j+1) below
+                float o[4];
+                bool any = false;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ca = e < 2 ? 0 : 1;                      // columns (k-1, k) for pixels 4k, 4k+1; (k, k+1) for 4k+2, 4k+3
+                    const float hx = 1.f - lx[e];
+                    const float m = hy * (hx * v[a][ca] + lx[e] * v[a][ca + 1]) + ly * (hx * v[a + 1][ca] + lx[e] * v[a + 1][ca + 1]);
+                    o[e] = 0.f;
+                    if (m > 0.f) {
+                        o[e] = 1.f;
+                        fsum += __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * m));
+                        cnt += 1;
+                        xhit_min = min(xhit_min, x0 + e);
+                        xhit_max = max(xhit_max, x0 + e);
+                        any = true;
+                    }
+                }
+                if (any) {
+                    ymin = min(ymin, y);
+                    ymax = max(ymax, y);
+                }
+                *reinterpret_cast<float4*>(dst + (int64_t)y * W + x0) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        sum += (double)fsum;
+        xmin = min(xmin, xhit_min);
+        xmax = max(xmax, xhit_max);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sum += __shfl_xor(sum, o, 64);
+        cnt += __shfl_xor(cnt, o, 64);
+        xmin = min(xmin, __shfl_xor(xmin, o, 64));
+        ymin = min(ymin, __shfl_xor(ymin, o, 64));
+        xmax = max(xmax, __shfl_xor(xmax, o, 64));
+        ymax = max(ymax, __shfl_xor(ymax, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && cnt > 0) {
+        InstAcc* a = acc + bt;
+        atomicAdd(&a->sum_sig, sum);
+        atomicAdd(&a->cnt, cnt);
+        atomicMin(&a->xmin, xmin);
+        atomicMin(&a->ymin, ymin);
+        atomicMax(&a->xmax, xmax);
+        atomicMax(&a->ymax, ymax);
+    }
+}
+
 __global__ void inst_init_kernel(InstAcc* __restrict__ acc, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) acc[i] = InstAcc{0.0, 0u, 0x7fffffff, 0x7fffffff, -1, -1, 0};
@@ -189,8 +285,12 @@ extern "C" int msm_instance_postprocess(const float* mask_logits, const int32_t*
     const int cols = (W % 4 == 0) ? W / 4 : W;                 // threads needed across a row
     const int threads = min(256, cdiv(cols, 64) * 64);          // whole waves, no idle wave (640 px -> 192 threads)
     dim3 grid(cdiv(cols, threads), cdiv(H, rows), n);
-    hipLaunchKernelGGL(inst_upsample_kernel, grid, dim3(threads), 0, st, mask_logits, query_index, pred_masks, acc, Q, T, h, w, H,
-                       W, Hs, Ws, rows);
+    if (Hs == 4 * h && Ws == 4 * w && W % 4 == 0 && getenv("MSM_POST_GENERIC") == nullptr)
+        hipLaunchKernelGGL(inst_upsample4_kernel, grid, dim3(threads), 0, st, mask_logits, query_index, pred_masks, acc, Q, T, h, w,
+                           H, W, Hs, Ws);
+    else
+        hipLaunchKernelGGL(inst_upsample_kernel, grid, dim3(threads), 0, st, mask_logits, query_index, pred_masks, acc, Q, T, h, w,
+                           H, W, Hs, Ws, rows);
     hipLaunchKernelGGL(inst_finish_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, acc, class_scores, mask_score, boxes, n);
     MSM_CHECK_LAUNCH("msm_instance_postprocess");
     return MSM_OK;
