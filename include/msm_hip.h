@@ -324,6 +324,14 @@ int msm_instance_postprocess(const float* mask_logits, const int32_t* query_inde
 int msm_conv1x1_in_f32(const float* x, const float* w_packed, const float* bias, float* out, int64_t out_batch_stride,
                        double* stats, int stats_cleared, int B, int Cin, int HW, void* stream);
 
+/* The same for n_levels <= 4 levels in ONE launch (each coarse level alone fills a fraction of the chip): x / w_packed /
+ * bias / Cin / HW are HOST arrays of n_levels entries (bias entries may be NULL); level l writes tokens
+ * [sum_{i<l} HW[i], +HW[l]) of every image of out [B][out_batch_stride] and moments stats[l] of stats [n_levels][B][64][2].
+ * Workgroups are numbered level by level in the order given: pass the deepest-K level first. */
+int msm_conv1x1_in_multi_f32(int n_levels, const float* const* x, const float* const* w_packed, const float* const* bias,
+                             const int32_t* Cin, const int32_t* HW, float* out, int64_t out_batch_stride, double* stats,
+                             int stats_cleared, int B, void* stream);
+
 /* Encoder prologue: everything between the input projections and the first deformable-attention layer in one pass
  * over the token buffer (msdeformattn.py:326-329 GroupNorm of input_proj, :60-75 level concatenation;
  * ops/modules/ms_deform_attn.py:95-104 layer 0's value_proj / sampling_offsets / attention_weights):

@@ -661,3 +661,22 @@ def test_encoder_prologue_vs_fp64():
         closed(value, val_ref, rtol=5e-5, atol=5e-5)
     with pytest.raises(RuntimeError):
         o.encoder_prologue(raw.to(DEV), st, gnp, [0, 12, 60, S + 1], stream, small, pos.to(DEV), pw)
+
+
+def test_conv1x1_in_multi_equals_single_launches():
+    """msm_conv1x1_in_multi_f32 (all levels in one launch) is bit-identical to one msm_conv1x1_in_f32 per level."""
+    B = 3
+    xs = [rnd(B, c, h, w, seed=20 + i).to(DEV) for i, (c, h, w) in enumerate(((2048, 4, 6), (1024, 8, 12), (512, 16, 24)))]
+    ws = [ops().pack_conv_in_weight(rnd(64, x.shape[1], seed=30 + i, scale=x.shape[1] ** -0.5).to(DEV)) for i, x in enumerate(xs)]
+    bs = [rnd(64, seed=40).to(DEV), None, rnd(64, seed=42).to(DEV)]
+    S = sum(x.shape[2] * x.shape[3] for x in xs)
+    out = torch.empty(B, S, 64, device=DEV)
+    st = torch.zeros(3, B, 64, 2, device=DEV, dtype=torch.float64)
+    ops().conv1x1_in_multi(xs, ws, bs, out, st, stats_cleared=True)
+    o = 0
+    for l, x in enumerate(xs):
+        hw = x.shape[2] * x.shape[3]
+        ref, rst = ops().conv1x1_in(x, ws[l], bs[l])
+        assert torch.equal(out[:, o:o + hw], ref)
+        torch.testing.assert_close(st[l], rst, rtol=1e-12, atol=1e-9)
+        o += hw

@@ -167,6 +167,14 @@ def convs():
         by = (x.numel() + tok.numel()) * 4
         print(f"{name} {cin}->64 @{h}x{w}: conv {t:6.1f} us ({by / t / 1e6:5.2f} TB/s, {2.0 * B * h * w * cin * 64 / t / 1e6:5.1f} TFLOP/s)"
               f"   groupnorm {t2:6.1f} us", flush=True)
+    os.environ.pop("MSM_CONVIN_NT", None)
+    xs = [torch.randn(B, c, h, w, device=DEV) for c, h, w in ((2048, 15, 20), (1024, 30, 40), (512, 60, 80))]
+    wps = [ops.pack_conv_in_weight(torch.randn(64, x.shape[1], device=DEV) * 0.05) for x in xs]
+    bs = [torch.randn(64, device=DEV) for _ in xs]
+    buf = torch.empty(B, 6300, 64, device=DEV)
+    st3 = torch.zeros(3, B, 64, 2, device=DEV, dtype=torch.float64)
+    print(f"conv1x1_in_multi res5+res4+res3 (137 MB): {timeit_graph(lambda: ops.conv1x1_in_multi(xs, wps, bs, buf, st3, stats_cleared=True)):6.1f} us",
+          flush=True)
     src = torch.randn(B, 6300, 64, device=DEV)
     wv, bv = torch.randn(64, 64, device=DEV) * 0.1, torch.randn(64, device=DEV)
     wp, bp = torch.randn(288, 64, device=DEV) * 0.1, torch.randn(288, device=DEV)

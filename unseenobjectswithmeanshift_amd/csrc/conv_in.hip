@@ -30,20 +30,19 @@ constexpr int CI_O = 64;             // output channels
 // NT = 16-pixel blocks per workgroup (64 accumulator registers at NT = 4), D = K groups (of 8) in flight per wave.
 // Wide tiles (NT = 4, D = 2) read w once per 64 pixels and suit the fine levels; the coarse levels have too few
 // pixels to cover the chip with them, so they take NT = 1 with a deep ring of loads (D = 8) instead.
+// One tile: image b of x (Cin x HW), pixels [tile*16*NT, +16*NT).  out / stats point at this LEVEL (image b is indexed here).
 template <int NT, int D>
-__global__ __launch_bounds__(CI_W * 64, 4) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                            const float* __restrict__ bias, float* __restrict__ out,
-                                                            int64_t out_sb, double* __restrict__ stats, int Cin, int HW) {
+__device__ __forceinline__ void conv_in_tile(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                             float* __restrict__ out, int64_t out_sb, double* __restrict__ stats, int Cin, int HW,
+                                             int b, int tile, float4* red) {
     constexpr int NB = 4 * NT;                        // 16 x 16 blocks of the tile
     constexpr int HR = NT >= 2 ? 2 : 1;               // half rounds of the reduction (8 blocks each; NB = 4: one round of 4)
     constexpr int RB = NB / HR;                       // blocks per round
-    extern __shared__ __attribute__((aligned(16))) float4 red[];   // [CI_W][RB blocks][64 lanes] + statistics
-    float* st = reinterpret_cast<float*>(red + CI_W * RB * 64);    // [2][64 ch][2]
+    float* st = reinterpret_cast<float*>(red + CI_W * RB * 64);    // [2][64 ch][2], after the [CI_W][RB blocks][64 lanes] partial tiles
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lj = lane & 15, lq = lane >> 4;
-    const int b = blockIdx.y;
-    const int px0 = (int)blockIdx.x * (16 * NT);
+    const int px0 = tile * (16 * NT);
     const int kw = Cin / CI_W;                        // K slice of this wave (a multiple of 8*D)
     const int k0 = wave * kw;
     // buffer descriptors (SGPRs) over this image of x and over w; per-lane byte offsets are loop invariant,
@@ -188,12 +187,64 @@ __global__ __launch_bounds__(CI_W * 64, 4) void conv_in_kernel(const float* __re
     }
 }
 
+template <int NT, int D>
+__global__ __launch_bounds__(CI_W * 64, 4) void conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            int64_t out_sb, double* __restrict__ stats, int Cin, int HW) {
+    extern __shared__ __attribute__((aligned(16))) float4 red[];
+    conv_in_tile<NT, D>(x, w, bias, out, out_sb, stats, Cin, HW, blockIdx.y, blockIdx.x, red);
+}
+
+// All input projections of the pixel decoder in ONE launch: the levels are independent, and on its own each coarse level
+// fills a fraction of the chip (res5 at B = 8: 152 workgroups).  Workgroups are numbered level by level in the order given
+// (deepest K first, so the longest-running tiles start first); cfg selects the tile shape per level.
+constexpr int CI_MAXL = 4;
+struct ConvInLevels {
+    int n;
+    const float* x[CI_MAXL];
+    const float* w[CI_MAXL];
+    const float* bias[CI_MAXL];
+    float* out[CI_MAXL];
+    double* stats[CI_MAXL];
+    int Cin[CI_MAXL], HW[CI_MAXL], tiles[CI_MAXL], cfg[CI_MAXL];
+    int first[CI_MAXL + 1];       // first workgroup of each level
+};
+
+__global__ __launch_bounds__(CI_W * 64, 4) void conv_in_multi_kernel(ConvInLevels lv, int64_t out_sb) {
+    extern __shared__ __attribute__((aligned(16))) float4 red[];
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < CI_MAXL; ++i) l += (i < lv.n && (int)blockIdx.x >= lv.first[i]) ? 1 : 0;
+    const int local = (int)blockIdx.x - lv.first[l];
+    const int b = local / lv.tiles[l], tile = local - b * lv.tiles[l];
+    switch (lv.cfg[l]) {
+        case 0: conv_in_tile<4, 2>(lv.x[l], lv.w[l], lv.bias[l], lv.out[l], out_sb, lv.stats[l], lv.Cin[l], lv.HW[l], b, tile, red); break;
+        case 1: conv_in_tile<2, 4>(lv.x[l], lv.w[l], lv.bias[l], lv.out[l], out_sb, lv.stats[l], lv.Cin[l], lv.HW[l], b, tile, red); break;
+        case 2: conv_in_tile<2, 2>(lv.x[l], lv.w[l], lv.bias[l], lv.out[l], out_sb, lv.stats[l], lv.Cin[l], lv.HW[l], b, tile, red); break;
+        case 3: conv_in_tile<1, 8>(lv.x[l], lv.w[l], lv.bias[l], lv.out[l], out_sb, lv.stats[l], lv.Cin[l], lv.HW[l], b, tile, red); break;
+        default: conv_in_tile<1, 2>(lv.x[l], lv.w[l], lv.bias[l], lv.out[l], out_sb, lv.stats[l], lv.Cin[l], lv.HW[l], b, tile, red); break;
+    }
+}
+
 }  // namespace msm
 
 using namespace msm;
 
-extern "C" int msm_conv1x1_in_f32(const float* x, const float* w, const float* bias, float* out, int64_t out_batch_stride,
-                                  double* stats, int stats_cleared, int B, int Cin, int HW, void* stream) {
+// tile shape for one level: 64 pixels when such tiles cover the chip about twice, else 32 or 16 pixels with a deeper ring of
+// loads (the coarse levels are latency bound: few pixels, K up to 2048).  Returns cfg (see conv_in_multi_kernel), sets nt.
+static int conv_in_config(int B, int Cin, int HW, int& nt) {
+    const int64_t t64 = (int64_t)cdiv(HW, 64) * B;
+    nt = t64 >= 512 ? 4 : (t64 >= 128 ? 2 : 1);
+    if (const char* e = getenv("MSM_CONVIN_NT")) nt = atoi(e) == 4 ? 4 : (atoi(e) == 2 ? 2 : 1);
+    const int kw = Cin / CI_W;
+    if (nt == 4) return 0;
+    if (nt == 2) return kw % 32 == 0 ? 1 : 2;
+    return kw % 64 == 0 ? 3 : 4;
+}
+static size_t conv_in_lds(int nt) { return sizeof(float4) * CI_W * (4 * nt / (nt >= 2 ? 2 : 1)) * 64 + sizeof(float) * 2 * CI_O * 2; }
+
+static int conv_in_check(const float* x, const float* w, const float* bias, const float* out, const double* stats, int B, int Cin,
+                         int HW, int64_t out_batch_stride) {
     MSM_REQUIRE(x && w && out, "msm_conv1x1_in_f32: null pointer");
     MSM_REQUIRE(HW % 4 == 0, "msm_conv1x1_in_f32: HW=%d must be a multiple of 4", HW);
     MSM_REQUIRE(B > 0 && HW > 0 && Cin >= 128 && Cin % (CI_W * 16) == 0, "msm_conv1x1_in_f32: Cin=%d must be a multiple of %d", Cin,
@@ -202,27 +253,70 @@ extern "C" int msm_conv1x1_in_f32(const float* x, const float* w, const float* b
     MSM_REQUIRE((int64_t)Cin * HW < ((int64_t)1 << 30), "msm_conv1x1_in_f32: one image of x must be < 4 GiB (32-bit buffer offsets)");
     MSM_REQUIRE(((((uintptr_t)w) | ((uintptr_t)out) | ((uintptr_t)bias) | ((uintptr_t)x)) & 15) == 0 && (((uintptr_t)stats) & 7) == 0,
                 "msm_conv1x1_in_f32: misaligned pointer");
+    return MSM_OK;
+}
+
+extern "C" int msm_conv1x1_in_f32(const float* x, const float* w, const float* bias, float* out, int64_t out_batch_stride,
+                                  double* stats, int stats_cleared, int B, int Cin, int HW, void* stream) {
+    if (int rc = conv_in_check(x, w, bias, out, stats, B, Cin, HW, out_batch_stride)) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (stats && !stats_cleared) MSM_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * CI_O * (size_t)B, st));
-    // One pixel tile per workgroup, K split over its 8 waves: 64 pixels when such tiles cover the chip about twice,
-    // else 32 or 16 pixels with a deeper ring of loads (the coarse levels are latency bound: few pixels, K up to 2048)
-    const int64_t t64 = (int64_t)cdiv(HW, 64) * B;
-    int nt = t64 >= 512 ? 4 : (t64 >= 128 ? 2 : 1);
-    if (const char* e = getenv("MSM_CONVIN_NT")) nt = atoi(e) == 4 ? 4 : (atoi(e) == 2 ? 2 : 1);
-    const int kw = Cin / CI_W;
+    int nt;
+    const int cfg = conv_in_config(B, Cin, HW, nt);
     dim3 grid(cdiv(HW, 16 * nt), B), block(CI_W * 64);
+    const size_t lds = conv_in_lds(nt);
 #define CI_LAUNCH(NT_, D_)                                                                                        \
     {                                                                                                             \
-        const size_t lds = sizeof(float4) * CI_W * (4 * NT_ / (NT_ >= 2 ? 2 : 1)) * 64 + sizeof(float) * 2 * CI_O * 2; \
         MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv_in_kernel<NT_, D_>, lds));                 \
         hipLaunchKernelGGL((conv_in_kernel<NT_, D_>), grid, block, lds, st, x, w, bias, out, out_batch_stride, stats, Cin, HW); \
     }
-    if (nt == 4) CI_LAUNCH(4, 2)
-    else if (nt == 2 && kw % 32 == 0) CI_LAUNCH(2, 4)
-    else if (nt == 2) CI_LAUNCH(2, 2)
-    else if (kw % 64 == 0) CI_LAUNCH(1, 8)
-    else CI_LAUNCH(1, 2)
+    switch (cfg) {
+        case 0: CI_LAUNCH(4, 2) break;
+        case 1: CI_LAUNCH(2, 4) break;
+        case 2: CI_LAUNCH(2, 2) break;
+        case 3: CI_LAUNCH(1, 8) break;
+        default: CI_LAUNCH(1, 2) break;
+    }
 #undef CI_LAUNCH
     MSM_CHECK_LAUNCH("msm_conv1x1_in_f32");
+    return MSM_OK;
+}
+
+extern "C" int msm_conv1x1_in_multi_f32(int n_levels, const float* const* x, const float* const* w_packed, const float* const* bias,
+                                        const int32_t* Cin, const int32_t* HW, float* out, int64_t out_batch_stride, double* stats,
+                                        int stats_cleared, int B, void* stream) {
+    MSM_REQUIRE(n_levels >= 1 && n_levels <= CI_MAXL && x && w_packed && bias && Cin && HW && out,
+                "msm_conv1x1_in_multi_f32: bad arguments (1..%d levels)", CI_MAXL);
+    hipStream_t st = (hipStream_t)stream;
+    ConvInLevels lv;
+    lv.n = n_levels;
+    int64_t tok = 0;
+    int wg = 0, max_nt = 1;
+    for (int l = 0; l < n_levels; ++l) {
+        float* o = out + tok * CI_O;
+        double* s = stats ? stats + (size_t)l * B * CI_O * 2 : nullptr;
+        if (int rc = conv_in_check(x[l], w_packed[l], bias[l], o, s, B, Cin[l], HW[l], out_batch_stride)) return rc;
+        int nt;
+        lv.cfg[l] = conv_in_config(B, Cin[l], HW[l], nt);
+        max_nt = max(max_nt, nt);
+        lv.x[l] = x[l]; lv.w[l] = w_packed[l]; lv.bias[l] = bias[l]; lv.out[l] = o; lv.stats[l] = s;
+        lv.Cin[l] = Cin[l]; lv.HW[l] = HW[l];
+        lv.tiles[l] = cdiv(HW[l], 16 * nt);
+        lv.first[l] = wg;
+        wg += lv.tiles[l] * B;
+        tok += HW[l];
+    }
+    for (int l = n_levels; l <= CI_MAXL; ++l) lv.first[l] = wg;
+    for (int l = n_levels; l < CI_MAXL; ++l) {
+        lv.x[l] = nullptr; lv.w[l] = nullptr; lv.bias[l] = nullptr; lv.out[l] = nullptr; lv.stats[l] = nullptr;
+        lv.Cin[l] = lv.HW[l] = lv.tiles[l] = lv.cfg[l] = 0;
+    }
+    MSM_REQUIRE(out_batch_stride >= tok * CI_O, "msm_conv1x1_in_multi_f32: output batch stride smaller than the %lld tokens of an image",
+                (long long)tok);
+    if (stats && !stats_cleared) MSM_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * CI_O * (size_t)B * n_levels, st));
+    const size_t lds = conv_in_lds(max_nt);
+    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv_in_multi_kernel, lds));
+    hipLaunchKernelGGL(conv_in_multi_kernel, dim3(wg), dim3(CI_W * 64), lds, st, lv, out_batch_stride);
+    MSM_CHECK_LAUNCH("msm_conv1x1_in_multi_f32");
     return MSM_OK;
 }

@@ -798,11 +798,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
             src = torch.empty((B, S_tok, C), device=dev, dtype=torch.float32)
             stats = torch.zeros((len(levels) + 2, B, C, 2), device=dev, dtype=torch.float64)      # + the two FPN GroupNorms
             fpn_stats = (stats[len(levels)], stats[len(levels) + 1])
-            o = 0
-            for idx, x in enumerate(levels):
-                hw = shapes[idx][0] * shapes[idx][1]
-                ops.conv1x1_in(x, wpk[idx], self.input_proj[idx][0].bias, out=src[:, o:o + hw], stats=stats[idx], stats_cleared=True)
-                o += hw
+            ops.conv1x1_in_multi(levels, wpk, [m[0].bias for m in self.input_proj], src, stats[:len(levels)], stats_cleared=True)
             a0 = layers[0].self_attn
             bounds = [0]
             for h, w in shapes:

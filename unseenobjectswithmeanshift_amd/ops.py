@@ -141,6 +141,33 @@ def conv1x1_in(x, w_packed, bias=None, *, out=None, stats=None, stats_cleared=Fa
     return out, stats
 
 
+def conv1x1_in_multi(xs, ws_packed, biases, out, stats, stats_cleared=False):
+    """conv1x1_in for up to four levels in one launch.  xs: list of (B, Cin_l, H_l, W_l) NCHW maps (deepest Cin first),
+    ws_packed / biases: per level (a bias may be None), out: (B, sum H_l*W_l, 64) contiguous token buffer (level l fills its
+    token range), stats: (L, B, 64, 2) float64 moments (accumulated into when ``stats_cleared``)."""
+    L = len(xs)
+    B = xs[0].shape[0]
+    S = sum(x.shape[2] * x.shape[3] for x in xs)
+    _c(out, "out"), _c(stats, "stats", torch.float64)
+    if tuple(out.shape) != (B, S, 64) or tuple(stats.shape) != (L, B, 64, 2):
+        raise RuntimeError("conv1x1_in_multi: out must be (B, sum HW, 64) and stats (L, B, 64, 2)")
+    for x, w, b in zip(xs, ws_packed, biases):
+        _c(x, "x"), _c(w, "w_packed"), _c(b, "bias")
+        if x.shape[0] != B or w.numel() != 64 * x.shape[1]:
+            raise RuntimeError("conv1x1_in_multi: inconsistent level shapes")
+    vp = ctypes.c_void_p * L
+    ia = ctypes.c_int32 * L
+    xa, wa = vp(*[x.data_ptr() for x in xs]), vp(*[w.data_ptr() for w in ws_packed])
+    ba = vp(*[0 if b is None else b.data_ptr() for b in biases])
+    cin, hw = ia(*[x.shape[1] for x in xs]), ia(*[x.shape[2] * x.shape[3] for x in xs])
+    rc = lib().msm_conv1x1_in_multi_f32(L, ctypes.cast(xa, ctypes.c_void_p), ctypes.cast(wa, ctypes.c_void_p),
+                                        ctypes.cast(ba, ctypes.c_void_p), ctypes.cast(cin, ctypes.c_void_p),
+                                        ctypes.cast(hw, ctypes.c_void_p), _p(out), S * 64, _p(stats), 1 if stats_cleared else 0, B,
+                                        _stream())
+    check(rc, "msm_conv1x1_in_multi_f32")
+    return out, stats
+
+
 def is_token_major(x):
     """True for a (B, C, H, W) tensor stored [B][H*W][C] (torch channels_last, possibly with a larger batch stride),
     e.g. the NCHW-shaped views the pixel decoder returns over its token buffer."""
