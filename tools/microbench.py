@@ -107,6 +107,14 @@ def enc():
     st = torch.tensor([0, 300, 1500], dtype=torch.int64, device=DEV)
     t = timeit(lambda: ops.ms_deform_attn_encoder(value, ss, st, proj, 8, 4), iters=30)
     print(f"msda enc: {t:7.1f} us", flush=True)
+    vhm = ops.value_to_head_major(value, 8)
+    proj.mul_(0.3)                                   # sampling offsets of a few pixels, like a trained model's
+    t = timeit_graph(lambda: ops.ms_deform_attn_encoder(vhm, ss, st, proj, 8, 4))
+    print(f"msda enc, head-major value (quad-cooperative D=8 kernel): {t:7.1f} us", flush=True)
+    os.environ["MSM_MSDA_GENERIC"] = "1"
+    t = timeit_graph(lambda: ops.ms_deform_attn_encoder(vhm, ss, st, proj, 8, 4))
+    os.environ.pop("MSM_MSDA_GENERIC")
+    print(f"msda enc, head-major value (generic kernel): {t:7.1f} us", flush=True)
     # same taps per lane and bytes, but 64-byte instead of 32-byte contiguous segments (4 heads x 16 dims)
     proj4 = torch.randn(B, S, 144, device=DEV)
     t = timeit(lambda: ops.ms_deform_attn_encoder(value, ss, st, proj4, 4, 4), iters=30)

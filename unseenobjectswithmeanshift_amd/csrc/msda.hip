@@ -351,35 +351,53 @@ __global__ __launch_bounds__(256) void msda_enc_hm8_kernel(const float* __restri
     }
     const float rden = 1.0f / quad_sum(den);
 
-    // ---- gather: every lane walks all points, taking (x, y, w) from the owner lane of each ----
+    // ---- gather: every lane walks all points, taking (x, y, w) from the owner lane of each.  Branch-free, in groups of
+    // GP points: invalid taps keep a clamped (always readable) address and a zero weight, so the 2*GP loads of a group
+    // are issued back to back and the L2 round trip is paid once per group instead of once per point (with the
+    // reference's nested validity branches the compiler has to wait for every point's two loads before the next
+    // point: 12 serial round trips per wave, measured 57 us; this form: see DESIGN.md).  Same products, same order:
+    // a skipped tap adds 0 * v.
+    constexpr int GP = 4;
     const float* vb = value + ((int64_t)b * M + m) * S * D + d4 * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        if (i < LP) {
-            int W = Ws[0], H = Hs[0], s0 = 0;   // uniform: scalar selects
+    for (int i0 = 0; i0 < 16; i0 += GP) {
+        if (i0 < LP) {
+            float4 vt[GP], vbm[GP];
+            float wt[GP], wb[GP];
 #pragma unroll
-            for (int l = 1; l < MAXL; ++l)
-                if (l < L && i >= l * P) { W = Ws[l]; H = Hs[l]; s0 = st[l]; }
-            const float w_im = quad_bcast(px[i >> 2], i & 3);
-            const float h_im = quad_bcast(py[i >> 2], i & 3);
-            const float wgt = quad_bcast(pw[i >> 2], i & 3) * rden;
-            if (h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W) {              // cuh:293
-                const float hf = floorf(h_im), wf = floorf(w_im);
-                const int h_low = (int)hf, xw = (int)wf + cx;                // this lane's column
-                if (xw >= 0 && xw <= W - 1) {
+            for (int j = 0; j < GP; ++j) {
+                const int i = i0 + j;
+                wt[j] = wb[j] = 0.f;
+                vt[j] = vbm[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < LP) {                       // uniform
+                    int W = Ws[0], H = Hs[0], s0 = 0;   // uniform: scalar selects
+#pragma unroll
+                    for (int l = 1; l < MAXL; ++l)
+                        if (l < L && i >= l * P) { W = Ws[l]; H = Hs[l]; s0 = st[l]; }
+                    const float w_im = quad_bcast(px[i >> 2], i & 3);
+                    const float h_im = quad_bcast(py[i >> 2], i & 3);
+                    const float wgt = quad_bcast(pw[i >> 2], i & 3) * rden;
+                    const bool in = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;       // cuh:293
+                    const float hf = floorf(h_im), wf = floorf(w_im);
+                    const int h_low = (int)hf, xw = (int)wf + cx;                // this lane's column
+                    const bool okx = in && xw >= 0 && xw <= W - 1;
                     const float lh = h_im - hf, lw = w_im - wf;
                     const float wxw = (cx ? lw : 1.f - lw) * wgt;
-                    const float* vp = vb + (int64_t)(s0 + h_low * W + xw) * D;
-                    float4 vt = make_float4(0.f, 0.f, 0.f, 0.f), vbm = vt;
-                    if (h_low >= 0) vt = *reinterpret_cast<const float4*>(vp);
-                    if (h_low + 1 <= H - 1) vbm = *reinterpret_cast<const float4*>(vp + W * D);
-                    const float wt = (1.f - lh) * wxw, wb = lh * wxw;
-                    acc.x += wt * vt.x + wb * vbm.x;
-                    acc.y += wt * vt.y + wb * vbm.y;
-                    acc.z += wt * vt.z + wb * vbm.z;
-                    acc.w += wt * vt.w + wb * vbm.w;
+                    wt[j] = (okx && h_low >= 0) ? (1.f - lh) * wxw : 0.f;
+                    wb[j] = (okx && h_low + 1 <= H - 1) ? lh * wxw : 0.f;
+                    const int xc = min(max(xw, 0), W - 1);
+                    const int yt = min(max(h_low, 0), H - 1), yb = min(max(h_low + 1, 0), H - 1);
+                    vt[j] = *reinterpret_cast<const float4*>(vb + (int64_t)(s0 + yt * W + xc) * D);
+                    vbm[j] = *reinterpret_cast<const float4*>(vb + (int64_t)(s0 + yb * W + xc) * D);
                 }
+            }
+#pragma unroll
+            for (int j = 0; j < GP; ++j) {
+                acc.x += wt[j] * vt[j].x + wb[j] * vbm[j].x;
+                acc.y += wt[j] * vt[j].y + wb[j] * vbm[j].y;
+                acc.z += wt[j] * vt[j].z + wb[j] * vbm[j].z;
+                acc.w += wt[j] * vt[j].w + wb[j] * vbm[j].w;
             }
         }
     }
