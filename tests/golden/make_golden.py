@@ -382,9 +382,45 @@ def g_ucn():
     save("ucn_small", **arrs)
 
 
+def g_ucn_backbone():
+    """UCN RGB-D backbone: the reference's own Resnet34_8s towers (lib/networks/resnet_dilated.py, resnet.py) with the
+    SEGNET glue of lib/networks/SEG.py:104-117 (add fusion, L2 normalisation) on a 64x96 frame."""
+    import importlib.util
+    import types
+    import torch.nn.functional as F_
+    pkg = types.ModuleType("refnetworks")
+    pkg.__path__ = ["/root/reference/lib/networks"]
+    sys.modules["refnetworks"] = pkg
+    for name in ("resnet", "resnet_dilated"):
+        spec = importlib.util.spec_from_file_location(f"refnetworks.{name}", f"/root/reference/lib/networks/{name}.py")
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[f"refnetworks.{name}"] = mod
+        spec.loader.exec_module(mod)
+    RD = sys.modules["refnetworks.resnet_dilated"]
+    shapes = syn.ucn_backbone_param_shapes()
+    sd = syn.ucn_backbone_state_dict(shapes, salt=6)
+    towers = {}
+    for t in ("fcn", "fcn_depth"):
+        net = RD.Resnet34_8s(num_classes=64, input_channels=3, pretrained=False).eval()
+        ref_shapes = {f"{t}.{k}": tuple(v.shape) for k, v in net.state_dict().items()}
+        mine = {k: tuple(v) for k, v in shapes.items() if k.startswith(t + ".")}
+        assert ref_shapes == mine and list(ref_shapes) == list(mine), "backbone state-dict layout drifted"
+        net.load_state_dict({k[len(t) + 1:]: v for k, v in sd.items() if k.startswith(t + ".")}, strict=True)
+        towers[t] = net
+    g = torch.Generator().manual_seed(31)
+    img = torch.randn(2, 3, 64, 96, generator=g)
+    depth = torch.randn(2, 3, 64, 96, generator=g) * 0.5
+    with torch.no_grad():
+        rgb = towers["fcn"](img)
+        feats = F_.normalize(rgb + towers["fcn_depth"](depth), p=2, dim=1)           # SEG.py:104-117
+        rgb_only = F_.normalize(rgb, p=2, dim=1)                                      # INPUT 'COLOR' (SEG.py:99-100)
+    # inputs are regenerated from the seed by the tests (tests/test_backbone_cpu.py::backbone_inputs)
+    save("ucn_backbone", feats=feats[:, :, ::3, ::3].contiguous(), rgb_only=rgb_only[:, :, ::6, ::6].contiguous())
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pe", "attn", "decoder", "msda", "msda_bwd", "pixel", "ms", "harness", "ucn"]
+    which = sys.argv[1:] or ["pe", "attn", "decoder", "msda", "msda_bwd", "pixel", "ms", "harness", "ucn", "ucn_backbone"]
     fns = {"pe": g_position_encoding, "attn": g_hypersphere_attention, "decoder": g_decoder,
-           "msda": g_msda, "msda_bwd": g_msda_bwd, "pixel": g_pixel_decoder, "ms": g_mean_shift, "harness": g_harness, "ucn": g_ucn}
+           "msda": g_msda, "msda_bwd": g_msda_bwd, "pixel": g_pixel_decoder, "ms": g_mean_shift, "harness": g_harness, "ucn": g_ucn, "ucn_backbone": g_ucn_backbone}
     for w in which:
         fns[w]()

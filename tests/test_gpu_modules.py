@@ -400,6 +400,37 @@ def test_meta_arch_pads_to_size_divisibility():
         model.__class__(backbone=None, sem_seg_head=head, num_queries=100)([{"features": feats, "height": 20, "width": 90}])
 
 
+def test_ucn_backbone_on_gpu_vs_reference(golden):
+    """The UCN RGB-D backbone (stock convolutions through MIOpen, BatchNorm folded) on the GPU against the reference
+    towers' golden output (tests/test_backbone_cpu.py runs the same check on CPU)."""
+    import test_backbone_cpu as tb
+    tb.check_backbone(golden, DEV)
+
+
+def test_ucn_model_end_to_end():
+    """mixture_UCN.yaml end to end on the GPU: RGB-D frame -> UCN backbone -> SimpleBasePixelDecoder -> 6-layer decoder over
+    every pixel -> instances; the head + post-processing are checked against the oracle on the backbone's features."""
+    import test_backbone_cpu as tb
+    from unseenobjectswithmeanshift_amd.meta_arch import build_ucn_model
+    model = build_ucn_model().to(DEV).eval()
+    model.backbone.load_state_dict(syn.ucn_backbone_state_dict(salt=6), strict=True)
+    model.sem_seg_head.pixel_decoder.load_state_dict(syn.synth_state_dict({"mask_features.weight": (256, 64, 3, 3), "mask_features.bias": (256,)}, salt=3))
+    model.sem_seg_head.predictor.load_state_dict(syn.synth_state_dict(syn.decoder_param_shapes(dec_layers=6, num_feature_levels=1), salt=4))
+    img, depth = (t[:, :, :32, :64].contiguous().to(DEV) for t in tb.backbone_inputs())
+    res = model([{"image": img, "depth": depth}])
+    assert len(res) == 2 and res[0]["instances"].pred_masks.shape == (20, 32, 64)
+    feats = {"res5": F.normalize(model.backbone(img, None, depth), p=2, dim=1).contiguous()}
+    out, _ = model.sem_seg_head(feats)
+    for b in range(2):
+        ref = O.instance_inference(out["pred_logits"][b].cpu(), out["pred_masks"][b].cpu(), (32, 64), topk=20)
+        inst = res[b]["instances"]
+        assert (inst.pred_masks.cpu() != ref["pred_masks"]).float().mean() < 1e-4
+        torch.testing.assert_close(inst.scores.cpu(), ref["scores"], rtol=1e-4, atol=1e-6)
+    # a frame that is not a multiple of 32 is padded for the network and cropped back
+    res2 = model([{"image": img[:1, :, :30, :50].contiguous(), "depth": depth[:1, :, :30, :50].contiguous()}])
+    assert res2[0]["instances"].pred_masks.shape == (20, 30, 50)
+
+
 def test_graphed_inference_equals_eager():
     """graphs.GraphedInference: capture once per geometry, replay with new inputs -- identical to the eager path."""
     from unseenobjectswithmeanshift_amd.meta_arch import MeanShiftMaskFormer

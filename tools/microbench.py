@@ -304,6 +304,16 @@ def ucn():
     feat = {"res5": X.view(B, 480 * 640, 64).transpose(1, 2).reshape(B, 64, 480, 640).contiguous().to(DEV)}
     t = timeit(lambda: model.inference(feat, (480, 640)), iters=5, warm=2)
     print(f"ucn B={B} 480x640: {t / 1e3:8.2f} ms per batch, {B / (t * 1e-6):7.1f} images/s, peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
+    # with the RGB-D backbone in front (two ResNet34-8s towers through MIOpen, BatchNorm folded)
+    from unseenobjectswithmeanshift_amd.meta_arch import PretrainedMeanShiftMaskFormer
+    from unseenobjectswithmeanshift_amd.ucn_backbone import UCNBackbone
+    bb = UCNBackbone()
+    bb.load_state_dict(syn.ucn_backbone_state_dict(salt=6))
+    full = PretrainedMeanShiftMaskFormer(backbone=bb.to(DEV).eval(), sem_seg_head=head, num_queries=100)
+    img, dep = torch.randn(B, 3, 480, 640, device=DEV), torch.randn(B, 3, 480, 640, device=DEV)
+    tb = timeit(lambda: bb(img, None, dep), iters=5, warm=3)
+    t = timeit(lambda: full([{"image": img, "depth": dep}]), iters=5, warm=2)
+    print(f"ucn end to end (backbone {tb / 1e3:.2f} ms + head): {t / 1e3:8.2f} ms per batch, {B / (t * 1e-6):7.1f} images/s", flush=True)
 
 
 def cfg5():

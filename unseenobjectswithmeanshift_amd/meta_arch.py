@@ -173,6 +173,46 @@ class MeanShiftMaskFormer(nn.Module):
         return results
 
 
+class PretrainedMeanShiftMaskFormer(MeanShiftMaskFormer):
+    """The RGB-D (UCN backbone) meta-arch, eval branch (pretrained_meanshiftformer_model.py:280-301): the pretrained
+    embedding network sees the image and the xyz depth map, its L2-normalised 64-channel full-resolution output is the
+    single feature level 'res5' of the head.  ``backbone(img, label, depth)`` follows SEGNET.forward (ucn_backbone.py)."""
+
+    def __init__(self, *, backbone, sem_seg_head, num_queries, use_depth=True, **kw):
+        super().__init__(backbone=backbone, sem_seg_head=sem_seg_head, num_queries=num_queries, **kw)
+        self.use_depth = use_depth
+
+    @torch.no_grad()
+    def forward(self, batched_inputs):
+        first = batched_inputs[0]
+        images = first["image"] if first["image"].dim() == 4 else torch.stack([x["image"] for x in batched_inputs])
+        depth = None
+        if self.use_depth:
+            depth = first["depth"] if first["depth"].dim() == 4 else torch.stack([x["depth"] for x in batched_inputs])
+        H, W = int(images.shape[-2]), int(images.shape[-1])
+        if first.get("height", H) != H or first.get("width", W) != W:
+            raise NotImplementedError("output height/width other than the image size (sem_seg_postprocess resize, PM:354)")
+        div = max(int(self.size_divisibility), 1)
+        padded = (-(-H // div) * div, -(-W // div) * div)
+        if padded != (H, W):                      # ImageList.from_tensors: zeros at the right / bottom (PM:275, 286)
+            images = F.pad(images, (0, padded[1] - W, 0, padded[0] - H))
+            depth = None if depth is None else F.pad(depth, (0, padded[1] - W, 0, padded[0] - H))
+        feats = self.backbone(images, None, depth)
+        feats = {"res5": F.normalize(feats, p=2, dim=1).contiguous()}                     # PM:298-300
+        scores, classes, masks, boxes, _ = self.inference(feats, (H, W), padded)
+        return [{"instances": Instances((H, W), pred_masks=masks[b], pred_boxes=boxes[b], scores=scores[b], pred_classes=classes[b])}
+                for b in range(scores.shape[0])]
+
+
+def build_ucn_model(num_queries=100, dec_layers=6, use_depth=True, **head_kw):
+    """mixture_UCN.yaml end to end: UCN ResNet34-8s RGB-D backbone -> SimpleBasePixelDecoder -> 6-layer hypersphere
+    decoder over every pixel -> top-k instance post-processing (random-init; load checkpoints with load_state_dict)."""
+    from .ucn_backbone import UCNBackbone
+    head = build_ucn_head(num_queries=num_queries, dec_layers=dec_layers, **head_kw)
+    return PretrainedMeanShiftMaskFormer(backbone=UCNBackbone(num_units=64, in_channels=3, use_depth=use_depth), sem_seg_head=head,
+                                         num_queries=num_queries, use_depth=use_depth)
+
+
 class Network_RGBD:
     """lib/fcn/test_utils.py:150-166: ``predictor(sample) -> {"instances": ...}`` for one sample."""
 

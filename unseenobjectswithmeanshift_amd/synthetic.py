@@ -200,3 +200,60 @@ def synth_unit_embeddings(n, d=64, clusters=12, sigma=0.15, seed=0, background_f
         ids[idx] = -1
     X = torch.nn.functional.normalize(X, dim=1)
     return X.contiguous(), ids
+
+
+# ----------------------------------------------------------------------------------------------
+# UCN backbone (lib/networks/SEG.py SEGNET 'seg_resnet34_8s_embedding', RGB-D add fusion)
+# ----------------------------------------------------------------------------------------------
+def ucn_backbone_param_shapes(num_units=64, in_channels=3, use_depth=True):
+    """Keys/shapes of the two Resnet34_8s towers in the reference's state-dict order (resnet.py:139-177,
+    resnet_dilated.py:296-305)."""
+    def bn(p, c, s):
+        s[p + ".weight"] = (c,)
+        s[p + ".bias"] = (c,)
+        s[p + ".running_mean"] = (c,)
+        s[p + ".running_var"] = (c,)
+        s[p + ".num_batches_tracked"] = ()
+
+    s = {}
+    for tower in ("fcn", "fcn_depth")[:2 if use_depth else 1]:
+        r = tower + ".resnet34_8s."
+        s[r + "conv1.weight"] = (64, in_channels, 7, 7)
+        bn(r + "bn1", 64, s)
+        cin = 64
+        for i, (planes, blocks) in enumerate(((64, 3), (128, 4), (256, 6), (512, 3))):
+            for j in range(blocks):
+                b = f"{r}layer{i + 1}.{j}."
+                s[b + "conv1.weight"] = (planes, cin if j == 0 else planes, 3, 3)
+                bn(b + "bn1", planes, s)
+                s[b + "conv2.weight"] = (planes, planes, 3, 3)
+                bn(b + "bn2", planes, s)
+                if j == 0 and i > 0:
+                    s[b + "downsample.0.weight"] = (planes, cin, 1, 1)
+                    bn(b + "downsample.1", planes, s)
+            cin = planes
+        s[r + "fc.weight"] = (num_units, 512, 1, 1)
+        s[r + "fc.bias"] = (num_units,)
+    return s
+
+
+def ucn_backbone_state_dict(shapes=None, salt=0):
+    """Non-degenerate seeded weights for the backbone: He-scaled convolutions, BatchNorm gains around 1, running
+    variances in [0.8, 1.2]."""
+    shapes = ucn_backbone_param_shapes() if shapes is None else shapes
+    out = {}
+    for k, shp in shapes.items():
+        g = _gen(k, salt)
+        leaf = k.rsplit(".", 1)[-1]
+        if leaf == "num_batches_tracked":
+            out[k] = torch.zeros((), dtype=torch.long)
+        elif leaf == "running_var":
+            out[k] = 0.8 + 0.4 * torch.rand(shp, generator=g)
+        elif leaf == "running_mean":
+            out[k] = 0.1 * torch.randn(shp, generator=g)
+        elif len(shp) == 1:
+            is_gain = leaf == "weight"
+            out[k] = (1.0 if is_gain else 0.0) + (0.1 if is_gain else 0.05) * torch.randn(shp, generator=g)
+        else:
+            out[k] = math.sqrt(2.0 / int(np.prod(shp[1:]))) * torch.randn(shp, generator=g)
+    return out

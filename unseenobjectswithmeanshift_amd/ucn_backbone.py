@@ -1,0 +1,124 @@
+"""UCN RGB-D embedding backbone (inference): two dilated ResNet34-8s towers, add fusion, unit-norm 64-d embedding.
+
+SURVEY.md section 8 f rank 4 ("next" row): the network in front of the PretrainedMeanShiftTransformerDecoder / of the
+classic mean-shift clustering.  Reference: lib/networks/SEG.py:24-117 (SEGNET with network_name
+'seg_resnet34_8s_embedding': `fcn` on the image, `fcn_depth` on the xyz depth map, FUSION_TYPE 'add',
+EMBEDDING_NORMALIZATION), lib/networks/resnet_dilated.py:287-327 (Resnet34_8s: torchvision-style ResNet34 with the
+strides of layer3 / layer4 replaced by dilations 2 / 4, the classifier turned into a 1x1 convolution to the embedding
+width, bilinear upsampling with align_corners=True back to the input size), lib/networks/resnet.py:43-73,150-258.
+
+These are stock 3x3 convolutions: they run through torch's convolution (MIOpen) -- no hand-written kernel is
+warranted.  What is done for the MI355X: inference folds every BatchNorm into its convolution once per checkpoint
+(a conv + bias + ReLU chain with no separate normalisation pass over the 1/8-resolution maps), both towers run in
+channels_last, and the module keeps the reference's parameter names, so `SEGNET` checkpoints load unchanged
+(`fcn.resnet34_8s.layer1.0.conv1.weight`, ..., `fcn_depth.resnet34_8s.fc.bias`).
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+STAGES = ((64, 3, 1, 1), (128, 4, 2, 1), (256, 6, 1, 2), (512, 3, 1, 4))   # (planes, blocks, stride, dilation) at output stride 8
+
+
+class _Block(nn.Module):
+    """BasicBlock (resnet.py:43-73): conv3x3-BN-ReLU-conv3x3-BN, + shortcut, ReLU."""
+
+    def __init__(self, cin, planes, stride, dilation, project):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=dilation, dilation=dilation, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = nn.Sequential(nn.Conv2d(cin, planes, 1, stride=stride, bias=False), nn.BatchNorm2d(planes)) if project else None
+
+
+class _DilatedResNet34(nn.Module):
+    def __init__(self, num_units, in_channels):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_channels, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        cin = 64
+        for i, (planes, blocks, stride, dil) in enumerate(STAGES):
+            # resnet.py:203-246: once the output stride (8) is reached a stage's stride becomes a dilation; the first
+            # block of a stage has a projection shortcut when the width (or the nominal stride) changes
+            layer = [_Block(cin, planes, stride, dil, project=(i > 0))]
+            layer += [_Block(planes, planes, 1, dil, project=False) for _ in range(blocks - 1)]
+            setattr(self, f"layer{i + 1}", nn.Sequential(*layer))
+            cin = planes
+        self.fc = nn.Conv2d(512, num_units, 1)
+
+
+class _Tower(nn.Module):
+    """Resnet34_8s (resnet_dilated.py:287-327)."""
+
+    def __init__(self, num_units, in_channels):
+        super().__init__()
+        self.resnet34_8s = _DilatedResNet34(num_units, in_channels)
+
+
+def _fold(conv, bn):
+    """conv (no bias) followed by an eval-mode BatchNorm == conv with scaled weights and a bias."""
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    return (conv.weight * scale[:, None, None, None]).contiguous(memory_format=torch.channels_last), bn.bias - bn.running_mean * scale
+
+
+class UCNBackbone(nn.Module):
+    """``forward(img, label=None, depth=None) -> (B, num_units, H, W)`` unit-norm embedding, as SEGNET.forward for
+    INPUT 'RGBD' / FUSION_TYPE 'add' (SEG.py:88-117); with ``depth=None`` only the colour tower runs (INPUT 'COLOR')."""
+
+    def __init__(self, num_units=64, in_channels=3, use_depth=True, normalize=True):
+        super().__init__()
+        self.fcn = _Tower(num_units, in_channels)
+        self.fcn_depth = _Tower(num_units, in_channels) if use_depth else None
+        self.normalize = normalize
+        self._folded = None
+
+    def _plan(self):
+        """Per tower: the folded (weight, bias, stride, padding, dilation) of every convolution, rebuilt when a parameter
+        or a BatchNorm buffer changes."""
+        towers = [self.fcn] + ([self.fcn_depth] if self.fcn_depth is not None else [])
+        key = tuple((t.data_ptr(), t._version) for tw in towers for t in list(tw.parameters()) + list(tw.buffers()))
+        if self._folded is None or self._folded[0] != key:
+            plans = []
+            with torch.no_grad():
+                for tw in towers:
+                    net = tw.resnet34_8s
+                    stem = _fold(net.conv1, net.bn1)
+                    blocks = []
+                    for i in range(4):
+                        for blk in getattr(net, f"layer{i + 1}"):
+                            c1, c2 = _fold(blk.conv1, blk.bn1), _fold(blk.conv2, blk.bn2)
+                            sc = _fold(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None
+                            blocks.append((c1, c2, sc, blk.conv1.stride, blk.conv1.dilation))
+                    plans.append((stem, blocks, net.fc.weight, net.fc.bias))
+            self._folded = (key, plans)
+        return self._folded[1]
+
+    @staticmethod
+    def _run(plan, x):
+        (w, b), blocks, fcw, fcb = plan
+        size = x.shape[2:]
+        x = F.relu(F.conv2d(x.contiguous(memory_format=torch.channels_last), w, b, stride=2, padding=3))
+        x = F.max_pool2d(x, 3, stride=2, padding=1)
+        for (w1, b1), (w2, b2), sc, stride, dil in blocks:
+            y = F.relu(F.conv2d(x, w1, b1, stride=stride, padding=dil, dilation=dil))
+            y = F.conv2d(y, w2, b2, padding=dil, dilation=dil)
+            if sc is not None:
+                x = F.conv2d(x, sc[0], sc[1], stride=stride)
+            x = F.relu(y + x)
+        x = F.conv2d(x, fcw, fcb)
+        return F.interpolate(x, size=size, mode="bilinear", align_corners=True)      # nn.functional.upsample_bilinear
+
+    @torch.no_grad()
+    def forward(self, img, label=None, depth=None):
+        if self.training:
+            raise NotImplementedError("UCNBackbone is an inference module (BatchNorm folded into the convolutions): call .eval()")
+        plans = self._plan()
+        feats = self._run(plans[0], img.float())
+        if depth is not None:
+            if self.fcn_depth is None:
+                raise RuntimeError("this backbone was built without a depth tower")
+            feats = feats + self._run(plans[1], depth.float())
+        if self.normalize:
+            feats = F.normalize(feats, p=2, dim=1)
+        return feats.contiguous()
