@@ -557,33 +557,62 @@ __global__ __launch_bounds__(NW * 64) void hs_attn_qk_kernel(const float* __rest
     }
 }
 
-// out[b][q][h*32 + d] = normalize( (sum_splits O) / (sum_splits l) )
-__global__ __launch_bounds__(128) void hs_attn_combine_kernel(const float* __restrict__ part, float* __restrict__ out,
+// out[b][q][h*32 + d] = normalize( (sum_splits O) / (sum_splits l) ).  One workgroup per (head, image-chunk): the
+// partial tiles are summed element-wise with 4 splits x 15 elements of independent loads in flight per thread (a
+// per-query loop over the splits is a chain of nsplit * 33 dependent L2 round trips: 8.6 us), then two lanes per query
+// finish from LDS with 16-byte stores.
+// (Folding this into hs_attn_kernel -- last workgroup to arrive combines -- was measured: the device-scope release /
+// acquire it needs writes back and invalidates the per-XCD L2s on gfx950, 70 -> 130 us.  Two launches it is.)
+__global__ __launch_bounds__(256) void hs_attn_combine_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                               int Lq, int heads, int qchunks, int nsplit) {
+    __shared__ float tot[AQCH * PSTRIDE];
     const int h = blockIdx.x;
     const int b = blockIdx.y / qchunks, qc = blockIdx.y - b * qchunks;
-    const int ql = threadIdx.x;
-    const int qi = qc * AQCH + ql;
-    if (ql >= AQCH || qi >= Lq) return;
-    const float* src = part + (((int64_t)blockIdx.y * heads + h) * nsplit) * (AQCH * PSTRIDE) + ql * PSTRIDE;
-    float acc[HD + 1];
+    const int tid = threadIdx.x;
+    const float* base = part + (((int64_t)blockIdx.y * heads + h) * nsplit) * (AQCH * PSTRIDE);
+    constexpr int NE = (AQCH * PSTRIDE + 255) / 256;
+    float t[NE];
 #pragma unroll
-    for (int d = 0; d <= HD; ++d) acc[d] = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
+    for (int j = 0; j < NE; ++j) t[j] = 0.f;
+    for (int sp0 = 0; sp0 < nsplit; sp0 += 4) {
+        float u[4][NE];
 #pragma unroll
-        for (int d = 0; d <= HD; ++d) acc[d] += src[(int64_t)s * (AQCH * PSTRIDE) + d];
+        for (int r = 0; r < 4; ++r) {
+            const bool on = sp0 + r < nsplit;                      // uniform
+            const float* src = base + (int64_t)(on ? sp0 + r : sp0) * (AQCH * PSTRIDE);
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                const int i = tid + 256 * j;
+                u[r][j] = (on && i < AQCH * PSTRIDE) ? src[i] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < NE; ++j) t[j] += u[r][j];            // split order: s = 0, 1, 2, ...
     }
-    const float l = acc[HD];
+#pragma unroll
+    for (int j = 0; j < NE; ++j)
+        if (tid + 256 * j < AQCH * PSTRIDE) tot[tid + 256 * j] = t[j];
+    __syncthreads();
+    const int ql = tid >> 1, half = tid & 1;             // two lanes per query, 16 output dims each
+    const int qi = qc * AQCH + ql;
+    if (ql >= AQCH) return;
+    const float l = tot[ql * PSTRIDE + HD];
+    float a[16];
     float ss = 0.f;
 #pragma unroll
-    for (int d = 0; d < HD; ++d) {
-        acc[d] = acc[d] / l;
-        ss += acc[d] * acc[d];
+    for (int d = 0; d < 16; ++d) {
+        a[d] = tot[ql * PSTRIDE + half * 16 + d] / l;
+        ss += a[d] * a[d];
     }
+    ss += __shfl_xor(ss, 1, 64);
     const float nrm = fmaxf(sqrtf(ss), 1e-12f);
-    float* o = out + ((int64_t)b * Lq + qi) * (heads * HD) + h * HD;
+    if (qi < Lq) {
+        float* o = out + ((int64_t)b * Lq + qi) * (heads * HD) + h * HD + half * 16;
 #pragma unroll
-    for (int d = 0; d < HD; ++d) o[d] = acc[d] / nrm;
+        for (int d = 0; d < 16; ++d) o[d] = a[d] / nrm;
+    }
 }
 
 }  // namespace msm
@@ -651,7 +680,7 @@ extern "C" int msm_hypersphere_attn_fwd(const float* q, const float* k, const fl
                        ns, ldq, q_sb, ldk, k_sb, ldv, v_sb, kappa);
     MSM_CHECK_LAUNCH("msm_hypersphere_attn_fwd");
     if (ns == 1) return MSM_OK;
-    dim3 g2(heads, B * qchunks), b2(128);
+    dim3 g2(heads, B * qchunks), b2(256);
     hipLaunchKernelGGL(hs_attn_combine_kernel, g2, b2, 0, st, workspace, out, Lq, heads, qchunks, ns);
     MSM_CHECK_LAUNCH("msm_hypersphere_attn_fwd(combine)");
     return MSM_OK;
