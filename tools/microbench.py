@@ -127,7 +127,7 @@ def attn():
         q, k, v = torch.randn(B, 100, E, device=DEV), torch.randn(B, S, 2 * E, device=DEV), None
         m = (torch.rand(B, 100, S, device=DEV) < 0.5).to(torch.uint8)
         ra = torch.ones(B, 100, device=DEV, dtype=torch.int32)
-        t = timeit(lambda: ops.hypersphere_attention(q, k[..., :E], k[..., E:], 8, masked=m, row_any=ra), iters=30)
+        t = timeit_graph(lambda: ops.hypersphere_attention(q, k[..., :E], k[..., E:], 8, masked=m, row_any=ra))
         fl = 2.0 * 2 * B * 100 * S * E
         print(f"hs_attn S={S}: {t:7.1f} us  {fl / t / 1e6:6.1f} TFLOP/s", flush=True)
 

@@ -339,20 +339,27 @@ __global__ __launch_bounds__(256) void hs_attn_small_kernel(const float* __restr
         }
     };
     {
-        Frag fa, fb;
-        int kb = 0;
-        fetch(0, fa);
-        for (; kb + 1 < nkb; kb += 2) {
-            fetch(kb + 1, fb);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(kb, fa);
-            __builtin_amdgcn_sched_barrier(0);
-            fetch(min(kb + 2, nkb - 1), fa);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(kb + 1, fb);
-            __builtin_amdgcn_sched_barrier(0);
+        // A key block is 16 MFMAs (~0.2 us) per query block against ~1 us of load latency, and a wave is alone on its
+        // SIMD here (512 waves in all): a ring of RD blocks in flight instead of one (19 blocks at 300 keys: 18 -> see
+        // DESIGN.md us; the 7 blocks of a self-attention are all requested up front)
+#ifndef MSM_ATTN_RD
+#define MSM_ATTN_RD 4
+#endif
+        constexpr int RD = MQ == 1 ? MSM_ATTN_RD : 2;
+        Frag f[RD];
+#pragma unroll
+        for (int d = 0; d < RD; ++d) fetch(min(d, nkb - 1), f[d]);
+        for (int kb = 0; kb < nkb; kb += RD) {
+#pragma unroll
+            for (int d = 0; d < RD; ++d) {
+                if (kb + d < nkb) {                                  // wave-uniform
+                    __builtin_amdgcn_sched_barrier(0);
+                    consume(kb + d, f[d]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kb + d + RD < nkb) fetch(kb + d + RD, f[d]);
+                }
+            }
         }
-        if (kb < nkb) consume(kb, fa);
     }
     // ---- finish in registers: o[m][half][r] = query (qb0+m)*16 + lq*4 + r, dim half*16 + lj ----
 #pragma unroll
@@ -644,8 +651,11 @@ extern "C" int msm_hypersphere_attn_fwd(const float* q, const float* k, const fl
         return MSM_E_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (S <= 512 && getenv("MSM_ATTN_NO_SMALL") == nullptr) {
-        // short key sequences: query-split kernel, finished in registers
+    if (S <= 512 && getenv("MSM_ATTN_SMALL") != nullptr) {
+        // query-split kernel, one wave per query block walking all keys, finished in registers.  Not the default any
+        // more: a lone wave per SIMD exposes every dependency of a key block (~0.9 us per block whatever the load
+        // ring depth), and with the host out of the way (HIP-graph timing) the key-split kernel below is faster down to
+        // the shortest sequences: 300 keys 11.0 against 19.9 us, 100 keys (self-attention) 8.0 against 9.4 us.
         const int qblocks = cdiv(Lq, 16);
         if (getenv("MSM_ATTN_MQ2") != nullptr && S <= 128) {
             dim3 grid(cdiv(qblocks, 8), heads, B);
@@ -660,7 +670,7 @@ extern "C" int msm_hypersphere_attn_fwd(const float* q, const float* k, const fl
         return MSM_OK;
     }
     if (S <= 2048 && getenv("MSM_ATTN_SPLITK") == nullptr) {
-        // medium sequences: query-split workgroups whose waves split the keys (measured at 1200 keys: 23 us against
+        // short and medium sequences: query-split workgroups whose waves split the keys (measured at 1200 keys: 23 us against
         // 25 + 8 us for the split-K kernel + combine; at 4800 keys the split-K kernel, which normalises each key block
         // once for all 7 query blocks, is faster: 60 + 8 against 71 us)
         constexpr int MQ = 2;
