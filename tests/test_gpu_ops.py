@@ -174,10 +174,18 @@ def test_hypersphere_attention(B, Lq, S, masked):
     vh = v.view(B, S, H, 32).permute(0, 2, 1, 3).reshape(B * H, S, 32)
     o, _ = O.hypersphere_attention(qh, kh, vh, add)
     ref = o.view(B, H, Lq, 32).permute(0, 2, 1, 3).reshape(B, Lq, E)
-    got = ops().hypersphere_attention(q.to(DEV), k.to(DEV), v.to(DEV), H,
-                                      masked=None if m is None else m.to(torch.uint8).to(DEV),
-                                      row_any=None if row_any is None else row_any.to(DEV))
+    args = (q.to(DEV), k.to(DEV), v.to(DEV), H)
+    kw = dict(masked=None if m is None else m.to(torch.uint8).to(DEV), row_any=None if row_any is None else row_any.to(DEV))
+    got = ops().hypersphere_attention(*args, **kw)
     close(got, ref, rtol=1e-4, atol=2e-5)
+    # the alternative kernels the host can be told to take: one wave per query block (<= 512 keys), split-K + combine
+    for env in ("MSM_ATTN_SMALL", "MSM_ATTN_SPLITK"):
+        os.environ[env] = "1"
+        try:
+            alt = ops().hypersphere_attention(*args, **kw)
+        finally:
+            os.environ.pop(env)
+        close(alt, ref, rtol=1e-4, atol=2e-5)
 
 
 def test_hypersphere_attention_strided_views():
