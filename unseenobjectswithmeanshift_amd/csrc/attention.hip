@@ -669,17 +669,28 @@ extern "C" int msm_hypersphere_attn_fwd(const float* q, const float* k, const fl
         MSM_CHECK_LAUNCH("msm_hypersphere_attn_fwd(small)");
         return MSM_OK;
     }
-    if (S <= 2048 && getenv("MSM_ATTN_SPLITK") == nullptr) {
+    static const int qk_max = getenv("MSM_ATTN_QK_MAX") ? atoi(getenv("MSM_ATTN_QK_MAX")) : 2048;
+    if (S <= qk_max && getenv("MSM_ATTN_SPLITK") == nullptr) {
         // short and medium sequences: query-split workgroups whose waves split the keys (measured at 1200 keys: 23 us against
         // 25 + 8 us for the split-K kernel + combine; at 4800 keys the split-K kernel, which normalises each key block
         // once for all 7 query blocks, is faster: 60 + 8 against 71 us)
-        constexpr int MQ = 2;
-        dim3 grid(cdiv(cdiv(Lq, 16), MQ), heads, B);
-        constexpr int NW = 8;
-        const size_t lds2 = sizeof(float) * (size_t)(NW - 1) * MQ * 9 * 64;
-        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)hs_attn_qk_kernel<MQ, NW>, lds2));
-        hipLaunchKernelGGL((hs_attn_qk_kernel<MQ, NW>), grid, dim3(NW * 64), lds2, st, q, k, v, masked, row_any, out, Lq, S, heads,
-                           ldq, q_sb, ldk, k_sb, ldv, v_sb, kappa);
+        static const int cfg_env = getenv("MSM_ATTN_QKCFG") ? atoi(getenv("MSM_ATTN_QKCFG")) : -1;
+        // one query block per workgroup for the shortest sequences (self-attention, 100 keys: 6.9 against 8.0 us), two
+        // otherwise (K/V are read by half as many workgroups); other shapes measured slower at every length
+        const int cfg = cfg_env >= 0 ? cfg_env : (S <= 128 ? 1 : 0);
+#define QK_LAUNCH(MQ_, NW_)                                                                                            \
+    {                                                                                                                  \
+        dim3 grid(cdiv(cdiv(Lq, 16), MQ_), heads, B);                                                                  \
+        const size_t lds2 = sizeof(float) * (size_t)(NW_ - 1) * MQ_ * 9 * 64;                                          \
+        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)hs_attn_qk_kernel<MQ_, NW_>, lds2));                 \
+        hipLaunchKernelGGL((hs_attn_qk_kernel<MQ_, NW_>), grid, dim3(NW_ * 64), lds2, st, q, k, v, masked, row_any, out, Lq, S, \
+                           heads, ldq, q_sb, ldk, k_sb, ldv, v_sb, kappa);                                             \
+    }
+        switch (cfg) {
+            case 1: QK_LAUNCH(1, 8) break;
+            default: QK_LAUNCH(2, 8) break;
+        }
+#undef QK_LAUNCH
         MSM_CHECK_LAUNCH("msm_hypersphere_attn_fwd(qk)");
         return MSM_OK;
     }
