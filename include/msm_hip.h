@@ -343,7 +343,7 @@ int msm_conv1x1_in_multi_f32(int n_levels, const float* const* x, const float* c
  *   proj  = [offsets|weights](src + pos)    proj_out [B][S][proj_width], pos [S][64]
  *   wstream: value_proj weight (64,64) then the (proj_width,64) weight, as consecutive 16-row blocks of 1024 floats,
  *   zero-padded to msm_encoder_prologue_stream_floats(proj_width); small = [value_proj bias (64) | proj bias].
- * n_levels <= 4, S >= 64, proj_width a multiple of 16. */
+ * n_levels <= 4, S >= 86, proj_width a multiple of 16 and <= 512 (the weights are held in LDS). */
 int64_t msm_encoder_prologue_stream_floats(int proj_width);
 int msm_encoder_prologue_fwd(const float* raw, const double* stats, const float* gn_params, const int32_t* level_starts,
                              int n_levels, int groups, float gn_eps, const float* wstream, const float* small,

@@ -183,6 +183,13 @@ def convs():
     st3 = torch.zeros(3, B, 64, 2, device=DEV, dtype=torch.float64)
     print(f"conv1x1_in_multi res5+res4+res3 (137 MB): {timeit_graph(lambda: ops.conv1x1_in_multi(xs, wps, bs, buf, st3, stats_cleared=True)):6.1f} us",
           flush=True)
+    gnp = torch.stack([torch.stack([torch.rand(64, device=DEV) + 0.5, torch.randn(64, device=DEV)]) for _ in xs]).contiguous()
+    pstream = ops.pack_encoder_prologue(torch.randn(64, 64, device=DEV) * 0.1, torch.randn(288, 64, device=DEV) * 0.1)
+    psmall = torch.randn(64 + 288, device=DEV)
+    ppos = torch.randn(6300, 64, device=DEV)
+    ops.conv1x1_in_multi(xs, wps, bs, buf, st3, stats_cleared=True)
+    print(f"encoder_prologue (GroupNorm + value / sampling projections of layer 0, 97 MB): "
+          f"{timeit_graph(lambda: ops.encoder_prologue(buf, st3, gnp, [0, 300, 1500, 6300], pstream, psmall, ppos, 288, value_heads=8)):6.1f} us", flush=True)
     src = torch.randn(B, 6300, 64, device=DEV)
     wv, bv = torch.randn(64, 64, device=DEV) * 0.1, torch.randn(64, device=DEV)
     wp, bp = torch.randn(288, 64, device=DEV) * 0.1, torch.randn(288, device=DEV)

@@ -37,7 +37,10 @@ namespace msm {
 constexpr int DC_E = 256;
 constexpr int DC_R = 16;            // rows per workgroup
 constexpr int DC_LD = DC_E + 4;     // LDS row stride (floats)
-constexpr int DC_NW = 8;            // waves per workgroup
+#ifndef MSM_DC_NW
+#define MSM_DC_NW 8
+#endif
+constexpr int DC_NW = MSM_DC_NW;    // waves per workgroup
 constexpr int DC_NT = 16 / DC_NW;   // 16-column tiles per wave in a 256-column GEMM
 constexpr int DC_THREADS = DC_NW * 64;
 

@@ -339,9 +339,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 //     src   = GroupNorm_l(raw)                      raw = the 1x1 input projections of all levels, already concatenated
 //     value = value_proj(src)                       (token- or head-major, as enc_block_kernel writes it)
 //     proj  = [sampling_offsets | attention_weights](src + pos)
-// Same register layout L, weight-block format and LDS staging as enc_block_kernel's tail; the GroupNorm moments come
-// from msm_conv1x1_in_f32.  A workgroup's 64 tokens touch at most two images: their (mean, scale, beta) tables are
-// derived from the moments into LDS by the workgroup itself.
+// Same register layout L and weight-block format as enc_block_kernel's tail; the GroupNorm moments come from
+// msm_conv1x1_in_f32.  A workgroup's tokens touch at most two images: their (mean, scale, beta) tables are derived from the
+// moments into LDS by the workgroup itself.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int PRO_MAXL = 4;
 struct ProLevels {
@@ -349,23 +349,46 @@ struct ProLevels {
     int start[PRO_MAXL + 1];      // token offsets of the levels inside an image; start[n] = S
 };
 
-__global__ __launch_bounds__(256) void enc_prologue_kernel(const float* __restrict__ raw, const double* __restrict__ stats,
+// Weight-stationary: the 22 weight blocks (88 KiB) are copied into LDS once per workgroup and each of its PRO_W waves
+// then runs its 16-token tile through all 352 MFMAs without a barrier (the staged form of enc_block_kernel's tail paid
+// six barriers and 96 KiB of L2 reads per 64 tokens for 64 MFMAs per wave and stage: 52 us; this form: see DESIGN.md).
+constexpr int PRO_W = 16;
+constexpr int PRO_NIMG = 4;            // images a workgroup's 256 tokens may touch (S >= 86)
+__global__ __launch_bounds__(PRO_W * 64) void enc_prologue_kernel(const float* __restrict__ raw, const double* __restrict__ stats,
                                                            const float* __restrict__ gnp, ProLevels lv, int groups, float gn_eps,
                                                            const float4* __restrict__ wstream, const float* __restrict__ small,
                                                            const float* __restrict__ pos, float* __restrict__ src_out,
                                                            float* __restrict__ value_out, float* __restrict__ proj_out, int M,
                                                            int S, int B, int nproj_blocks, int proj_ld, int value_heads) {
-    extern __shared__ __attribute__((aligned(16))) float4 wl[];   // [2][CHUNK_F4] weight stages, GroupNorm tables, biases
-    float* gt = reinterpret_cast<float*>(wl + 2 * CHUNK_F4);     // [2 images][levels][3][64]: mean, rstd*gamma, beta
-    float* sm = gt + 2 * PRO_MAXL * 3 * EC;                       // bv [64], bp [proj width]
+    extern __shared__ __attribute__((aligned(16))) float4 wl[];   // [4 + nproj_blocks][256] weight blocks, GroupNorm tables, biases
+    const int nblocks = 4 + nproj_blocks;
+    float* gt = reinterpret_cast<float*>(wl + nblocks * 256);    // [PRO_NIMG images][levels][3][64]: mean, rstd*gamma, beta
+    float* sm = gt + PRO_NIMG * PRO_MAXL * 3 * EC;                // bv [64], bp [proj width]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lj = lane & 15, lq = lane >> 4;
+    // this tile's tokens first: their latency hides behind the weight copy and the table
+    const int tile = (int)blockIdx.x * PRO_W + wave;
+    const int tok = tile * 16 + lj;
+    const bool tok_ok = tok < M;
+    const int tk = tok_ok ? tok : M - 1;
+    float x[4][4];
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) {
+        const float4 r = *reinterpret_cast<const float4*>(raw + (int64_t)tk * EC + fb * 16 + lq * 4);
+        x[fb][0] = r.x; x[fb][1] = r.y; x[fb][2] = r.z; x[fb][3] = r.w;
+    }
+    // weight blocks -> LDS with the row-block swizzle (float4 i of a block: row i>>4, column group i&15)
+    for (int i = tid; i < nblocks * 256; i += PRO_W * 64) {
+        const int blk = i >> 8, e = i & 255;
+        wl[blk * 256 + (e >> 4) * 16 + ((e & 15) ^ (e >> 4))] = wstream[i];
+    }
     const int n_small = EC + nproj_blocks * 16;
-    for (int i = tid; i < n_small; i += 256) sm[i] = small[i];
-    const int b0 = (int)(((int64_t)blockIdx.x * 64) / S);
+    for (int i = tid; i < n_small; i += PRO_W * 64) sm[i] = small[i];
+    const int b0 = (int)(((int64_t)blockIdx.x * PRO_W * 16) / S);
     const int cpg = EC / groups;
-    for (int i = tid; i < 2 * lv.n * EC; i += 256) {
+    // a workgroup's PRO_W*16 = 256 tokens touch at most PRO_NIMG images (S >= 86, checked by the host)
+    for (int i = tid; i < PRO_NIMG * lv.n * EC; i += PRO_W * 64) {
         const int c = i % EC, l = (i / EC) % lv.n, bi = b0 + i / (EC * lv.n);
         float mean = 0.f, a = 0.f, be = 0.f;
         if (bi < B) {
@@ -389,29 +412,12 @@ __global__ __launch_bounds__(256) void enc_prologue_kernel(const float* __restri
         t[EC + c] = a;
         t[2 * EC + c] = be;
     }
-    const int tile = (int)blockIdx.x * 4 + wave;
-    const int tok = tile * 16 + lj;
-    const bool tok_ok = tok < M;
-    const int tk = tok_ok ? tok : M - 1;
     const int bi = tk / S, ti = tk - bi * S;
     int lvl = 0;
 #pragma unroll
     for (int l = 1; l < PRO_MAXL; ++l) lvl += (l < lv.n && ti >= lv.start[l]) ? 1 : 0;
-
-    const int nsteps = 1 + (nproj_blocks + 3) / 4;
-    const int dst_row = (tid >> 4) * 16 + ((tid & 15) ^ (tid >> 4));
-    float4 stage[4];
-#define PRO_LOAD(s_) _Pragma("unroll") for (int i = 0; i < 4; ++i) stage[i] = wstream[(int64_t)(s_) * CHUNK_F4 + tid + 256 * i];
-#define PRO_STORE(buf) _Pragma("unroll") for (int i = 0; i < 4; ++i)(buf)[i * 256 + dst_row] = stage[i];
-    PRO_LOAD(0)
-    float x[4][4];
-#pragma unroll
-    for (int fb = 0; fb < 4; ++fb) {
-        const float4 r = *reinterpret_cast<const float4*>(raw + (int64_t)tk * EC + fb * 16 + lq * 4);
-        x[fb][0] = r.x; x[fb][1] = r.y; x[fb][2] = r.z; x[fb][3] = r.w;
-    }
-    PRO_STORE(wl)
-    __syncthreads();               // stage 0, the tables and the biases are in LDS
+    __syncthreads();               // the only barrier: weights, tables and biases are in LDS
+    if (tile * 16 >= M) return;    // wave-uniform
     {
         const float* t = gt + ((bi - b0) * PRO_MAXL + lvl) * 3 * EC;
 #pragma unroll
@@ -428,50 +434,35 @@ __global__ __launch_bounds__(256) void enc_prologue_kernel(const float* __restri
                 *reinterpret_cast<float4*>(src_out + (int64_t)tok * EC + c) = make_float4(x[fb][0], x[fb][1], x[fb][2], x[fb][3]);
         }
     }
-    for (int s = 0; s < nsteps; ++s) {
-        const float4* buf = wl + (s & 1) * CHUNK_F4;
-        if (s + 1 < nsteps) PRO_LOAD(s + 1)
-        __builtin_amdgcn_sched_barrier(0);
-        if (s == 0) {
+    // query = src + pos (msdeformattn.py:124): requested now, added after the value projection
+    float4 pp[4];
 #pragma unroll
-            for (int ob = 0; ob < 4; ++ob) {
-                const f32x4 d = rowblock_mm(buf + ob * 256, lj, lq, x);
-                const float4 bv = *reinterpret_cast<const float4*>(sm + ob * 16 + lq * 4);
-                if (tok_ok) {
-                    const int f = ob * 16 + lq * 4;
-                    int64_t o = (int64_t)tok * EC + f;
-                    if (value_heads) {
-                        const int dh = EC / value_heads;
-                        o = (((int64_t)bi * value_heads + f / dh) * S + ti) * dh + f % dh;
-                    }
-                    *reinterpret_cast<float4*>(value_out + o) = make_float4(d[0] + bv.x, d[1] + bv.y, d[2] + bv.z, d[3] + bv.w);
-                }
-            }
-            // query = src + pos (msdeformattn.py:124)
+    for (int fb = 0; fb < 4; ++fb) pp[fb] = *reinterpret_cast<const float4*>(pos + (int64_t)ti * EC + fb * 16 + lq * 4);
 #pragma unroll
-            for (int fb = 0; fb < 4; ++fb) {
-                const float4 pp = *reinterpret_cast<const float4*>(pos + (int64_t)ti * EC + fb * 16 + lq * 4);
-                x[fb][0] += pp.x; x[fb][1] += pp.y; x[fb][2] += pp.z; x[fb][3] += pp.w;
+    for (int ob = 0; ob < 4; ++ob) {
+        const f32x4 d = rowblock_mm(wl + ob * 256, lj, lq, x);
+        const float4 bv = *reinterpret_cast<const float4*>(sm + ob * 16 + lq * 4);
+        if (tok_ok) {
+            const int f = ob * 16 + lq * 4;
+            int64_t o = (int64_t)tok * EC + f;
+            if (value_heads) {
+                const int dh = EC / value_heads;
+                o = (((int64_t)bi * value_heads + f / dh) * S + ti) * dh + f % dh;
             }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int ob = (s - 1) * 4 + j;
-                if (ob < nproj_blocks) {
-                    const f32x4 d = rowblock_mm(buf + j * 256, lj, lq, x);
-                    const float4 bp = *reinterpret_cast<const float4*>(sm + EC + ob * 16 + lq * 4);
-                    if (tok_ok)
-                        *reinterpret_cast<float4*>(proj_out + (int64_t)tok * proj_ld + ob * 16 + lq * 4) =
-                            make_float4(d[0] + bp.x, d[1] + bp.y, d[2] + bp.z, d[3] + bp.w);
-                }
-            }
+            *reinterpret_cast<float4*>(value_out + o) = make_float4(d[0] + bv.x, d[1] + bv.y, d[2] + bv.z, d[3] + bv.w);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < nsteps) PRO_STORE(wl + ((s + 1) & 1) * CHUNK_F4)
-        __syncthreads();
     }
-#undef PRO_LOAD
-#undef PRO_STORE
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) {
+        x[fb][0] += pp[fb].x; x[fb][1] += pp[fb].y; x[fb][2] += pp[fb].z; x[fb][3] += pp[fb].w;
+    }
+    for (int ob = 0; ob < nproj_blocks; ++ob) {
+        const f32x4 d = rowblock_mm(wl + (4 + ob) * 256, lj, lq, x);
+        const float4 bp = *reinterpret_cast<const float4*>(sm + EC + ob * 16 + lq * 4);
+        if (tok_ok)
+            *reinterpret_cast<float4*>(proj_out + (int64_t)tok * proj_ld + ob * 16 + lq * 4) =
+                make_float4(d[0] + bp.x, d[1] + bp.y, d[2] + bp.z, d[3] + bp.w);
+    }
 }
 
 }  // namespace msm
@@ -539,7 +530,7 @@ extern "C" int msm_encoder_prologue_fwd(const float* raw, const double* stats, c
     MSM_REQUIRE(raw && stats && gn_params && level_starts && wstream && small && pos && src_out && value_out && proj_out,
                 "msm_encoder_prologue_fwd: null pointer");
     MSM_REQUIRE(n_levels >= 1 && n_levels <= PRO_MAXL, "msm_encoder_prologue_fwd: n_levels=%d outside [1, %d]", n_levels, PRO_MAXL);
-    MSM_REQUIRE(B > 0 && S >= 64, "msm_encoder_prologue_fwd: need B > 0 and at least 64 tokens per image (S=%d)", S);
+    MSM_REQUIRE(B > 0 && S >= 86, "msm_encoder_prologue_fwd: need B > 0 and at least 86 tokens per image (S=%d)", S);
     MSM_REQUIRE(groups > 0 && EC % groups == 0, "msm_encoder_prologue_fwd: groups=%d must divide 64", groups);
     MSM_REQUIRE(proj_width % 16 == 0 && proj_width >= 16, "msm_encoder_prologue_fwd: proj_width=%d must be a multiple of 16", proj_width);
     MSM_REQUIRE(value_heads == 0 || (value_heads > 0 && EC % value_heads == 0 && (EC / value_heads) % 4 == 0),
@@ -555,9 +546,10 @@ extern "C" int msm_encoder_prologue_fwd(const float* raw, const double* stats, c
         MSM_REQUIRE(lv.start[l + 1] > lv.start[l], "msm_encoder_prologue_fwd: level_starts must increase");
     const int M = B * S;
     const int npb = proj_width / 16;
-    const size_t lds = sizeof(float4) * 2 * CHUNK_F4 + sizeof(float) * (size_t)(2 * PRO_MAXL * 3 * EC + (EC + proj_width + 3) / 4 * 4);
+    MSM_REQUIRE(proj_width <= 512, "msm_encoder_prologue_fwd: proj_width=%d > 512 (weights are held in LDS)", proj_width);
+    const size_t lds = sizeof(float4) * (size_t)(4 + npb) * 256 + sizeof(float) * (size_t)(PRO_NIMG * PRO_MAXL * 3 * EC + (EC + proj_width + 3) / 4 * 4);
     MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)enc_prologue_kernel, lds));
-    dim3 grid(cdiv(cdiv(M, 16), 4)), block(256);
+    dim3 grid(cdiv(cdiv(M, 16), PRO_W)), block(PRO_W * 64);
     hipLaunchKernelGGL(enc_prologue_kernel, grid, block, lds, (hipStream_t)stream, raw, stats, gn_params, lv, groups, gn_eps,
                        reinterpret_cast<const float4*>(wstream), small, pos, src_out, value_out, proj_out, M, S, B, npb, proj_width,
                        value_heads);

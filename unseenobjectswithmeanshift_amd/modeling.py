@@ -786,7 +786,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         S_tok = sum(h * w for h, w in shapes)
         layers = self.transformer.encoder.layers
         gns = [m[1] for m in self.input_proj]
-        front = (self.fused_encoder and self.fused_front and C == 64 and len(levels) <= 4 and S_tok >= 64
+        front = (self.fused_encoder and self.fused_front and C == 64 and len(levels) <= 4 and S_tok >= 86
                  and all(x.shape[1] % 128 == 0 and (x.shape[2] * x.shape[3]) % 4 == 0 for x in levels)
                  and all(g.num_groups == gns[0].num_groups and g.eps == gns[0].eps for g in gns))
         value = proj = None
