@@ -34,6 +34,7 @@
  *   msm_ms_*                     <- select_smart_seeds MS:128-189, seed_hill_climbing_ball MS:79-109,
  *                                   the assignment/relabel tail of mean_shift_smart_init MS:206-229
  *   msm_conv1x1_in_f32           <- input_proj / lateral 1x1 convolutions of the pixel decoder + GroupNorm moments, MSD:212-238
+ *   msm_conv3x3_c64_f32          <- FPN output convolution layer_1 + the moments of its GroupNorm, MSD:264-279,349-351
  *   msm_label_stats              <- per-label loops of the two-stage harness, lib/fcn/test_dataset.py:62-131,183-198
  *   msm_instance_postprocess     <- F.interpolate + instance_inference,
  *                                   MSMFormer/meanshiftformer/pretrained_meanshiftformer_model.py:337-343,461-497
@@ -331,6 +332,13 @@ int msm_conv1x1_in_f32(const float* x, const float* w_packed, const float* bias,
 int msm_conv1x1_in_multi_f32(int n_levels, const float* const* x, const float* const* w_packed, const float* const* bias,
                              const int32_t* Cin, const int32_t* HW, float* out, int64_t out_batch_stride, double* stats,
                              int stats_cleared, int B, void* stream);
+
+/* The FPN output convolution (msdeformattn.py:264-279, 349-351: Conv2d(64, 64, 3, padding=1) in front of a GroupNorm):
+ *   in / out [B][H*W][64] token maps, w_tap_major [64][9*64] with k = (dy*3 + dx)*64 + c_in (zero padding), no bias (a
+ *   norm follows); stats [B][64][2] double or NULL: += (sum, sum of squares) of out per (image, channel), zeroed here unless
+ *   stats_cleared != 0.  The whole weight is held in LDS (one workgroup per CU). */
+int msm_conv3x3_c64_f32(const float* in, const float* w_tap_major, float* out, double* stats,
+                        int stats_cleared, int B, int H, int W, void* stream);
 
 /* Encoder prologue: everything between the input projections and the first deformable-attention layer in one pass
  * over the token buffer (msdeformattn.py:326-329 GroupNorm of input_proj, :60-75 level concatenation;

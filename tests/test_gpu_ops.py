@@ -688,3 +688,21 @@ def test_conv1x1_in_multi_equals_single_launches():
         assert torch.equal(out[:, o:o + hw], ref)
         torch.testing.assert_close(st[l], rst, rtol=1e-12, atol=1e-9)
         o += hw
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 12, 16), (1, 5, 37), (3, 30, 40)])
+def test_conv3x3_c64_vs_fp64(B, H, W):
+    """msm_conv3x3_c64_f32 (weight held in LDS) against an fp64 conv2d with zero padding, ragged widths included, and the
+    fp64 moments of its own output; equal to the implicit-GEMM path up to summation order."""
+    x, w = rnd(B, H * W, 64, seed=1), rnd(64, 64, 3, 3, seed=2, scale=0.06)
+    ref = F.conv2d(x.double().view(B, H, W, 64).permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1).reshape(B, H * W, 64)
+    w3 = w.permute(0, 2, 3, 1).reshape(64, 576).contiguous().to(DEV)
+    out, st = ops().conv3x3_c64(x.to(DEV), w3, H, W)
+    closed(out, ref, rtol=2e-5, atol=2e-5)
+    mom = torch.stack([out.double().sum(1), (out.double() ** 2).sum(1)], -1).cpu()
+    torch.testing.assert_close(st.cpu(), mom, rtol=1e-5, atol=1e-4)
+    close(out, ops().conv3x3_tokens(x.to(DEV), w3, H, W).cpu(), rtol=2e-5, atol=2e-5)
+    st0 = torch.ones(B, 64, 2, device=DEV, dtype=torch.float64)
+    out2, st2 = ops().conv3x3_c64(x.to(DEV), w3, H, W, stats=st0, stats_cleared=True)
+    assert torch.equal(out2, out) and st2.data_ptr() == st0.data_ptr()
+    torch.testing.assert_close(st2.cpu(), mom + 1.0, rtol=1e-5, atol=1e-4)

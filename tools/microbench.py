@@ -200,6 +200,11 @@ def convs():
     y = torch.randn(B, 19200, 64, device=DEV)
     w3 = torch.randn(64, 576, device=DEV) * 0.05
     t = timeit_graph(lambda: ops.conv3x3_tokens(y, w3, 120, 160))
+    t3 = timeit_graph(lambda: ops.conv3x3_c64(y, w3, 120, 160))
+    o3, s3 = ops.conv3x3_c64(y, w3, 120, 160)
+    ref3 = ops.conv3x3_tokens(y, w3, 120, 160)
+    print(f"conv3x3_c64 (weight in LDS, + GroupNorm moments incl. fill): {t3:6.1f} us ({2.0 * B * 19200 * 576 * 64 / t3 / 1e6:5.1f} TFLOP/s)  "
+          f"max|diff| {(o3 - ref3).abs().max().item():.2e}  moments rel {((s3 - ops.groupnorm_stats(ref3)).abs() / (ops.groupnorm_stats(ref3).abs() + 1)).max().item():.2e}", flush=True)
     print(f"conv3x3 64->64 @120x160: {t:6.1f} us ({2.0 * B * 19200 * 576 * 64 / t / 1e6:5.1f} TFLOP/s)   groupnorm_stats "
           f"{timeit_graph(lambda: ops.groupnorm_stats(y)):6.1f} us", flush=True)
 

@@ -1,0 +1,175 @@
+// 3x3 / pad 1 convolution of a 64-channel token map to 64 channels (see include/msm_hip.h: msm_conv3x3_c64_f32):
+//     out[b][y][x][o] = sum_{dy,dx,c} w[o][(dy*3 + dx)*64 + c] * in[b][y+dy-1][x+dx-1][c]      (zero padding)
+//     stats[b][o]    += (sum, sum of squares) of out over the map        (the moments of the GroupNorm that follows)
+//
+// Reference: the FPN output convolution `layer_1 = Conv2d(64, 64, 3, padding=1, bias=False) + GroupNorm + ReLU`
+// (msdeformattn.py:264-279, 349-351).  11.3 GFLOP at B = 8, 120 x 160: MFMA work.
+//
+// As an implicit GEMM through the tiled kernel every 64 x 64 output tile re-reads the whole 147 KB weight out of L2 next
+// to its 147 KB of gathered input (133 us = 85 TFLOP/s, and a second pass for the GroupNorm moments).  Here the weight is
+// the stationary operand: a workgroup copies all of it into LDS once (row stride 580 floats: conflict-free 16-byte
+// reads) and its 16 waves stream 16-pixel tiles of ONE image:
+//   * MFMA orientation D^T: rows = output channels (A = w from LDS, one ds_read_b128 = four k-steps), cols = 16
+//     consecutive pixels of an image row (B = in: the lane of pixel lj and quarter lq reads channels ks*16 + lq*4 .. +3 of
+//     the tap's pixel as one 16-byte load; K order k = tap*64 + ks*16 + lq*4 + c on both operands);
+//   * a tile is 9 taps x 64 MFMAs; the 4 loads of the next tap are in flight during the 64 MFMAs of the current one;
+//     taps outside the image contribute zeros (clamped address, zeroed operand);
+//   * a lane ends with 4 consecutive channels of one pixel: 16-byte token-major stores; the per-channel moments are
+//     reduced over the 16 pixels with DPP-free shuffles, kept in registers across the wave's tiles and leave as one double
+//     atomic per (workgroup, channel, moment);
+//   * tiles are handed out per image (blockIdx.y) in full rounds over the image's workgroups, the leftover tiles one per
+//     SIMD first (waves w, w+4, ... share a SIMD).
+#include "common.h"
+
+namespace msm {
+
+constexpr int C3_C = 64;                 // channels in and out
+constexpr int C3_K = 9 * C3_C;           // 576
+constexpr int C3_LD = C3_K + 4;          // LDS row stride (floats): 145 float4, odd -> 16 rows hit 16 different 16-byte banks
+constexpr int C3_W = 16;                 // waves per workgroup (the weight takes 145 KiB: one workgroup per CU)
+
+__global__ __launch_bounds__(C3_W * 64) void conv3x3_c64_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                                float* __restrict__ out, double* __restrict__ stats,
+                                                                int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [64][C3_LD], then the moment scratch [C3_W][64][2]
+    float* msc = wl + C3_C * C3_LD;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    const int b = blockIdx.y;
+    for (int i = tid; i < C3_C * (C3_K / 4); i += C3_W * 64) {
+        const int n = i / (C3_K / 4), c4 = i - n * (C3_K / 4);
+        *reinterpret_cast<float4*>(wl + n * C3_LD + c4 * 4) = *reinterpret_cast<const float4*>(w + (int64_t)n * C3_K + c4 * 4);
+    }
+    __syncthreads();
+
+    const int xt = (W + 15) / 16;                    // 16-pixel tiles per image row
+    const int units = xt * H;                        // of this image
+    const int slots = gridDim.x * C3_W;
+    const int full_rounds = units / slots;
+    const int left = units - full_rounds * slots;
+    const int left_slot = (wave >> 2) * ((int)gridDim.x * 4) + (int)blockIdx.x * 4 + (wave & 3);
+    const int mine = full_rounds + (left_slot < left ? 1 : 0);
+    const float* ib = in + (int64_t)b * H * W * C3_C;
+    float* ob = out + (int64_t)b * H * W * C3_C;
+    float s[4][4], q[4][4];                          // moments of this lane's 4 x 4 channels over its pixels
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[mt][r] = q[mt][r] = 0.f;
+    const float* wp = wl + lj * C3_LD + lq * 4;
+
+    for (int it = 0; it < mine; ++it) {
+        const int u = (it < full_rounds) ? it * slots + (int)blockIdx.x * C3_W + wave : full_rounds * slots + left_slot;
+        const int y = u / xt, x0 = (u - y * xt) * 16;
+        const int px = x0 + lj;
+        // B operand of tap t: channels ks*16 + lq*4 .. +3 (ks = 0..3) of pixel (y + t/3 - 1, px + t%3 - 1), zeros outside
+        auto load_tap = [&](int t, float4 (&f)[4]) {
+            const int yy = y + t / 3 - 1, xx = px + t % 3 - 1;
+            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const float* p = ib + ((int64_t)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)) * C3_C + lq * 4;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const float4 v = *reinterpret_cast<const float4*>(p + ks * 16);
+                f[ks] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        f32x4 acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto mma_tap = [&](int t, const float4 (&cur)[4]) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                float4 a[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const float4*>(wp + mt * 16 * C3_LD + t * C3_C + ks * 16);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma16(a[mt].x, cur[ks].x, acc[mt]);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma16(a[mt].y, cur[ks].y, acc[mt]);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma16(a[mt].z, cur[ks].z, acc[mt]);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma16(a[mt].w, cur[ks].w, acc[mt]);
+            }
+        };
+        float4 fa[4], fb[4];
+        load_tap(0, fa);
+#pragma unroll 1
+        for (int t = 0; t < 8; t += 2) {          // taps in pairs: two register sets, the next tap's loads ride on the current MFMAs
+            load_tap(t + 1, fb);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_tap(t, fa);
+            __builtin_amdgcn_sched_barrier(0);
+            load_tap(t + 2, fa);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_tap(t + 1, fb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        mma_tap(8, fa);
+        if (px < W) {
+            float* op = ob + ((int64_t)y * W + px) * C3_C + lq * 4;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                *reinterpret_cast<float4*>(op + mt * 16) = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[mt][r] += acc[mt][r];
+                    q[mt][r] += acc[mt][r] * acc[mt][r];
+                }
+            }
+        }
+    }
+    if (stats) {
+        // over the 16 pixels of the lane quarter, then over the workgroup's waves (fixed order), then one double add each
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s[mt][r] += __shfl_xor(s[mt][r], o, 64);
+                    q[mt][r] += __shfl_xor(q[mt][r], o, 64);
+                }
+            }
+        if (lj == 0) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ch = mt * 16 + lq * 4 + r;
+                    msc[(wave * C3_C + ch) * 2 + 0] = s[mt][r];
+                    msc[(wave * C3_C + ch) * 2 + 1] = q[mt][r];
+                }
+        }
+        __syncthreads();
+        if (tid < C3_C * 2) {
+            double t = 0.0;
+            for (int wv = 0; wv < C3_W; ++wv) t += (double)msc[wv * C3_C * 2 + tid];
+            atomicAdd(stats + (int64_t)b * C3_C * 2 + tid, t);
+        }
+    }
+}
+
+}  // namespace msm
+
+using namespace msm;
+
+extern "C" int msm_conv3x3_c64_f32(const float* in, const float* w_tap_major, float* out, double* stats,
+                                   int stats_cleared, int B, int H, int W, void* stream) {
+    MSM_REQUIRE(in && w_tap_major && out && in != out, "msm_conv3x3_c64_f32: null or aliased pointer");
+    MSM_REQUIRE(B > 0 && H > 0 && W > 0 && (int64_t)H * W * C3_C < ((int64_t)1 << 31), "msm_conv3x3_c64_f32: bad sizes B=%d H=%d W=%d", B, H, W);
+    MSM_REQUIRE(((((uintptr_t)in) | ((uintptr_t)w_tap_major) | ((uintptr_t)out)) & 15) == 0 && (((uintptr_t)stats) & 7) == 0,
+                "msm_conv3x3_c64_f32: misaligned pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (stats && !stats_cleared) MSM_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * C3_C * (size_t)B, st));
+    const size_t lds = sizeof(float) * ((size_t)C3_C * C3_LD + (size_t)C3_W * C3_C * 2);
+    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_kernel, lds));
+    // workgroups per image: about one round of the chip over the batch, never more than the image has tiles for
+    const int units = cdiv(W, 16) * H;
+    int per_image = max(1, 256 / B);
+    per_image = min(per_image, cdiv(units, C3_W));
+    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(per_image, B), dim3(C3_W * 64), lds, st, in, w_tap_major, out, stats, H, W);
+    MSM_CHECK_LAUNCH("msm_conv3x3_c64_f32");
+    return MSM_OK;
+}

@@ -844,11 +844,16 @@ class MSDeformAttnPixelDecoder(nn.Module):
         lat = ops.conv1x1_nchw_to_tokens(x, self.adapter_1.weight.view(C, -1), None)
         y = ops.groupnorm_tokens(lat, self.adapter_1.norm.weight, self.adapter_1.norm.bias, H, W, groups=32,
                                  up=up_tok, up_hw=shapes[-1], eps=self.adapter_1.norm.eps, stats=fpn_stats[0])
-        y = ops.conv3x3_tokens(y, self._w3(), H, W)
+        y_stats = None
+        if C == 64:
+            # weight-stationary 3x3 kernel; the moments of layer_1's GroupNorm come out of its epilogue
+            y, y_stats = ops.conv3x3_c64(y, self._w3(), H, W, stats=fpn_stats[1], stats_cleared=fpn_stats[1] is not None)
+        else:
+            y = ops.conv3x3_tokens(y, self._w3(), H, W)
         wm = self.mask_features.weight.view(self.mask_dim, C)
         if C == 64 and self.mask_dim in (256, 512) and (H * W) % 4 == 0 and B <= 64:
             # layer_1's GroupNorm + ReLU is applied to the operand fragments of the mask_features convolution
-            gn = (ops.groupnorm_stats(y, fpn_stats[1]), self.layer_1.norm.weight, self.layer_1.norm.bias, 32, self.layer_1.norm.eps)
+            gn = (y_stats, self.layer_1.norm.weight, self.layer_1.norm.bias, 32, self.layer_1.norm.eps)
             mask_features = ops.tokens_proj_nchw(y, wm, self.mask_features.bias, gn=gn, relu=True).view(B, self.mask_dim, H, W)
         else:
             y = ops.groupnorm_tokens(y, self.layer_1.norm.weight, self.layer_1.norm.bias, H, W, groups=32, relu=True,

@@ -227,6 +227,25 @@ def conv3x3_tokens(t, w_tap_major, H, W):
     return out
 
 
+def conv3x3_c64(t, w_tap_major, H, W, *, stats=None, stats_cleared=False):
+    """3x3 / pad 1 convolution of a 64-channel token map t (B, H*W, 64) to 64 channels, weight (64, 9*64) tap-major, with
+    the GroupNorm moments of the result as a by-product: returns (out (B, H*W, 64), stats (B, 64, 2) float64).  ``stats``
+    given: accumulated into when ``stats_cleared`` (the caller zeroed it), else zeroed first."""
+    _c(t, "t"), _c(w_tap_major, "w"), _c(stats, "stats", torch.float64)
+    B, HW, C = t.shape
+    if C != 64 or tuple(w_tap_major.shape) != (64, 576) or HW != H * W:
+        raise RuntimeError("conv3x3_c64 needs a (B, H*W, 64) map and a (64, 576) tap-major weight")
+    out = torch.empty_like(t)
+    if stats is None:
+        stats = torch.empty((B, 64, 2), device=t.device, dtype=torch.float64)
+        stats_cleared = False
+    elif tuple(stats.shape) != (B, 64, 2):
+        raise RuntimeError("stats must be (B, 64, 2) float64")
+    rc = lib().msm_conv3x3_c64_f32(_p(t), _p(w_tap_major), _p(out), _p(stats), 1 if stats_cleared else 0, B, H, W, _stream())
+    check(rc, "msm_conv3x3_c64_f32")
+    return out, stats
+
+
 def conv3x3_tokens_to_nchw(t, w_tap_major, bias, H, W):
     """Same implicit GEMM, output written directly as NCHW (B, Cout, H*W) through the m-contiguous store
     path (SimpleBasePixelDecoder.mask_features, fpn.py:237-246: Conv2d 3x3 with bias)."""
