@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--sparse-taps", action="store_true", help="skip mask rows that feed no attention-mask tap")
     ap.add_argument("--mask-step", choices=("f32", "bf16"), default="f32",
                     help="bf16 (configs 3/5) is NOT the headline configuration: the JSON line then says dtype bf16-mask-step")
-    ap.add_argument("--overlap-kv", type=int, default=-1, help="1/0: K/V projections on a side stream (default: the decoder's own default)")
+    ap.add_argument("--batched-kv", type=int, default=-1, help="1/0: all K/V projections of the decoder in one launch (default: the decoder's own default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,8 +105,8 @@ def main():
     model = build_model(dev)
     model.sem_seg_head.predictor.sparse_taps = args.sparse_taps
     model.sem_seg_head.predictor.mask_step_dtype = args.mask_step
-    if args.overlap_kv >= 0:
-        model.sem_seg_head.predictor.overlap_kv = bool(args.overlap_kv)
+    if args.batched_kv >= 0:
+        model.sem_seg_head.predictor.batched_kv = bool(args.batched_kv)
     # weak scaling: the global batch is world*8 images, rank r owns images [r*8, (r+1)*8)
     lo, hi = shard_range(world * BATCH, world, rank)
     feats = {k: v.to(dev) for k, v in syn.synth_backbone_features(hi - lo, H, W, seed=10 + rank).items()}

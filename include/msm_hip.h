@@ -216,6 +216,12 @@ int msm_encoder_block_fwd(const float* attn, const float* src, const float* wstr
  * ------------------------------------------------------------------------------------------- */
 int msm_kv_project_f32(const float* x, const float* w, const float* cmat, float* out,
                        int B, int C, int HW, int N, int x_tokens, int64_t x_batch_stride, void* stream);
+/* n_jobs <= 16 such projections (one per cross-attention layer: its level's features, its folded weight and constant)
+ * in ONE launch; x / w / cmat / out / HW / x_tokens / x_batch_stride are HOST arrays of n_jobs entries, B, C = 64 and N
+ * are shared.  Each job gets a share of the chip's workgroups proportional to its HW. */
+int msm_kv_project_multi_f32(int n_jobs, const float* const* x, const float* const* w, const float* const* cmat,
+                             float* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride,
+                             int B, int C, int N, void* stream);
 
 /* mask_features (MSD:349-358): the last GroupNorm + ReLU of the FPN level fused into the 1x1 convolution after it.
  *   out [B][N][HW] (NCHW) = bias + w act(x),  x [B][HW][64] tokens, w [N][64], N in {256, 512}, HW % 4 == 0;

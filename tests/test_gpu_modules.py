@@ -138,15 +138,17 @@ def test_decoder_480x640_vs_reference(golden):
 
 
 def test_decoder_execution_variants_agree():
-    """Folded vs explicit K/V projection and side-stream overlap on/off are the same computation."""
+    """Folded vs explicit K/V projection and one batched K/V launch vs one per layer are the same computation."""
     dec = make_decoder()
     x, mf = syn.synth_decoder_inputs(2, 64, 96, seed=7)
     xd, mfd = [t.to(DEV) for t in x], mf.to(DEV)
     ref = dec(xd, mfd)
-    dec.overlap_kv = not dec.overlap_kv
+    dec.batched_kv = not dec.batched_kv
     a = dec(xd, mfd)
-    dec.overlap_kv = not dec.overlap_kv
-    assert torch.equal(a["pred_masks"], ref["pred_masks"]) and torch.equal(a["pred_logits"], ref["pred_logits"])
+    dec.batched_kv = not dec.batched_kv
+    # (small NCHW maps take the tiled GEMM when projected one by one: same values up to fp32 summation order)
+    torch.testing.assert_close(a["pred_masks"], ref["pred_masks"], rtol=1e-4, atol=2e-4)
+    torch.testing.assert_close(a["pred_logits"], ref["pred_logits"], rtol=1e-4, atol=1e-5)
     dec.fold_kv = False
     b = dec(xd, mfd)
     torch.testing.assert_close(b["pred_logits"], ref["pred_logits"], rtol=1e-4, atol=1e-4)

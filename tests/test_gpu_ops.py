@@ -706,3 +706,24 @@ def test_conv3x3_c64_vs_fp64(B, H, W):
     out2, st2 = ops().conv3x3_c64(x.to(DEV), w3, H, W, stats=st0, stats_cleared=True)
     assert torch.equal(out2, out) and st2.data_ptr() == st0.data_ptr()
     torch.testing.assert_close(st2.cpu(), mom + 1.0, rtol=1e-5, atol=1e-4)
+
+
+def test_kv_project_multi_equals_single_launches():
+    """msm_kv_project_multi_f32: nine jobs (three levels x three layers, NCHW and token-major inputs) in one launch are
+    bit-identical to nine msm_kv_project_f32 launches."""
+    B, N = 8, 512
+    buf = rnd(B, 30 * 40 + 60 * 80, 64, seed=50).to(DEV)                     # two levels as slices of one token buffer
+    levels = [rnd(B, 64, 15, 20, seed=51).to(DEV),
+              buf[:, :1200].view(B, 30, 40, 64).permute(0, 3, 1, 2), buf[:, 1200:].view(B, 60, 80, 64).permute(0, 3, 1, 2)]
+    xs, ws, cs = [], [], []
+    for i in range(9):
+        x = levels[i % 3]
+        xs.append(x)
+        ws.append(rnd(N, 64, seed=60 + i, scale=0.1).to(DEV))
+        cs.append(rnd(x.shape[2] * x.shape[3], N, seed=70 + i).to(DEV))
+    outs = ops().kv_project_multi(xs, ws, cs)
+    for x, w, c, o in zip(xs, ws, cs, outs):
+        ref = torch.einsum("bchw,nc->bhwn", x.double(), w.double()).reshape(B, -1, N) + c.double()
+        closed(o, ref.cpu(), rtol=2e-5, atol=2e-5)
+        if x.shape[2] * x.shape[3] * B >= 8192 or ops().is_token_major(x):        # the single launch takes the same kernel there
+            assert torch.equal(o, ops().kv_project(x, w, c))

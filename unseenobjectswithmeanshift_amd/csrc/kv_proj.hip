@@ -26,10 +26,10 @@ constexpr int KP_LD = KP_K + 4;      // LDS row stride of w (floats): 16 rows x 
 constexpr int KP_FB = 16;            // feature blocks (of 16) per unit: 256 features
 constexpr int KP_W = 16;             // waves per workgroup (one workgroup per CU: w takes 136 KiB of LDS)
 
-__global__ __launch_bounds__(KP_W * 64) void kv_project_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                         const float* __restrict__ cmat, float* __restrict__ out, int B,
-                                                         int HW, int N, int tokens, int64_t x_sb) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];   // [N][KP_LD]
+// the projection of ONE (level, layer) job by workgroup `wg` of the `nwg` workgroups assigned to it
+__device__ __forceinline__ void kv_project_body(const float* __restrict__ x, const float* __restrict__ w,
+                                                const float* __restrict__ cmat, float* __restrict__ out, int B, int HW, int N,
+                                                int tokens, int64_t x_sb, int wg, int nwg, float* wl) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lj = lane & 15, lq = lane >> 4;
@@ -44,13 +44,13 @@ __global__ __launch_bounds__(KP_W * 64) void kv_project_kernel(const float* __re
     const int units = tiles * B * halves;
     // full rounds over all waves; the leftover units go one per SIMD across all workgroups first (waves w, w+4, ...
     // share a SIMD), so no SIMD runs two leftovers while another runs none
-    const int slots = gridDim.x * KP_W;
+    const int slots = nwg * KP_W;
     const int full_rounds = units / slots;
     const int left = units - full_rounds * slots;
-    const int left_slot = (wave >> 2) * ((int)gridDim.x * 4) + (int)blockIdx.x * 4 + (wave & 3);
+    const int left_slot = (wave >> 2) * (nwg * 4) + wg * 4 + (wave & 3);
     const int mine = full_rounds + (left_slot < left ? 1 : 0);
     auto unit_of = [&](int it) {
-        return (it < full_rounds) ? it * slots + (int)blockIdx.x * KP_W + wave : full_rounds * slots + left_slot;
+        return (it < full_rounds) ? it * slots + wg * KP_W + wave : full_rounds * slots + left_slot;
     };
     auto load_x = [&](int u, float (&xv)[16]) {
         const int img = (u / halves) % B, tile = u / (halves * B);
@@ -114,6 +114,37 @@ __global__ __launch_bounds__(KP_W * 64) void kv_project_kernel(const float* __re
 #pragma unroll
         for (int s = 0; s < 16; ++s) xb[s] = xn[s];
     }
+}
+
+__global__ __launch_bounds__(KP_W * 64) void kv_project_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ cmat, float* __restrict__ out, int B,
+                                                         int HW, int N, int tokens, int64_t x_sb) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [N][KP_LD]
+    kv_project_body(x, w, cmat, out, B, HW, N, tokens, x_sb, blockIdx.x, gridDim.x, wl);
+}
+
+// All K/V projections of the decoder (one job per cross-attention layer: its level's features, its folded weight and
+// constant) in ONE launch.  They depend only on the pixel decoder's output, and one by one the coarse levels are
+// latency bound (15x20: 5 MB in 13 us, 30x40: 20 MB in 19.5 us; nine launches: 211 us per step).  Every job gets a share of
+// the chip's workgroups proportional to the bytes it writes; a workgroup copies its job's weight into LDS and streams
+// that job's units.
+constexpr int KP_MAXJ = 16;
+struct KvJobs {
+    int n;
+    const float* x[KP_MAXJ];
+    const float* w[KP_MAXJ];
+    const float* cmat[KP_MAXJ];
+    float* out[KP_MAXJ];
+    int HW[KP_MAXJ], tokens[KP_MAXJ], first[KP_MAXJ + 1];
+    int64_t x_sb[KP_MAXJ];
+};
+__global__ __launch_bounds__(KP_W * 64) void kv_project_multi_kernel(KvJobs jobs, int B, int N) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [N][KP_LD]
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < KP_MAXJ; ++i) j += (i < jobs.n && (int)blockIdx.x >= jobs.first[i]) ? 1 : 0;
+    kv_project_body(jobs.x[j], jobs.w[j], jobs.cmat[j], jobs.out[j], B, jobs.HW[j], N, jobs.tokens[j], jobs.x_sb[j],
+                    (int)blockIdx.x - jobs.first[j], jobs.first[j + 1] - jobs.first[j], wl);
 }
 
 // ---- mask_features: GroupNorm + ReLU of the FPN output fused into the 1x1 convolution that follows it --------------
@@ -248,6 +279,47 @@ extern "C" int msm_kv_project_f32(const float* x, const float* w, const float* c
     const int grid = max(1, min(256, cdiv(units, 4)));
     hipLaunchKernelGGL(kv_project_kernel, dim3(grid), dim3(KP_W * 64), lds, (hipStream_t)stream, x, w, cmat, out, B, HW, N, x_tokens, x_batch_stride);
     MSM_CHECK_LAUNCH("msm_kv_project_f32");
+    return MSM_OK;
+}
+
+extern "C" int msm_kv_project_multi_f32(int n_jobs, const float* const* x, const float* const* w, const float* const* cmat,
+                                        float* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride,
+                                        int B, int C, int N, void* stream) {
+    MSM_REQUIRE(n_jobs >= 1 && n_jobs <= KP_MAXJ && x && w && cmat && out && HW && x_tokens && x_batch_stride,
+                "msm_kv_project_multi_f32: bad arguments (1..%d jobs)", KP_MAXJ);
+    MSM_REQUIRE(C == KP_K, "msm_kv_project_multi_f32: C=%d, only 64 input channels are supported", C);
+    MSM_REQUIRE(B > 0 && N > 0 && N % (KP_FB * 16) == 0 && N <= 512, "msm_kv_project_multi_f32: N=%d must be 256 or 512", N);
+    KvJobs jobs;
+    jobs.n = n_jobs;
+    int64_t total = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        MSM_REQUIRE(x[j] && w[j] && cmat[j] && out[j] && HW[j] > 0, "msm_kv_project_multi_f32: job %d: null pointer or empty level", j);
+        MSM_REQUIRE(((((uintptr_t)w[j]) | ((uintptr_t)cmat[j]) | ((uintptr_t)out[j])) & 15) == 0 && (((uintptr_t)x[j]) & 3) == 0,
+                    "msm_kv_project_multi_f32: job %d: w/cmat/out must be 16-byte aligned", j);
+        MSM_REQUIRE(x_batch_stride[j] >= (int64_t)C * HW[j] && (!x_tokens[j] || ((((uintptr_t)x[j]) & 15) == 0 && x_batch_stride[j] % 4 == 0)),
+                    "msm_kv_project_multi_f32: job %d: bad x batch stride / alignment", j);
+        total += HW[j];
+    }
+    // workgroups: 256 shared out in proportion to the tokens of a job, at least one each, never more than a job has units / 4
+    int wg = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const int units = cdiv(HW[j], 16) * B * (N / (KP_FB * 16));
+        int n = (int)((256 * (int64_t)HW[j] + total / 2) / total);
+        n = max(1, min(n, cdiv(units, 4)));
+        jobs.x[j] = x[j]; jobs.w[j] = w[j]; jobs.cmat[j] = cmat[j]; jobs.out[j] = out[j];
+        jobs.HW[j] = HW[j]; jobs.tokens[j] = x_tokens[j]; jobs.x_sb[j] = x_batch_stride[j];
+        jobs.first[j] = wg;
+        wg += n;
+    }
+    for (int j = n_jobs; j <= KP_MAXJ; ++j) jobs.first[j] = wg;
+    for (int j = n_jobs; j < KP_MAXJ; ++j) {
+        jobs.x[j] = jobs.w[j] = jobs.cmat[j] = nullptr; jobs.out[j] = nullptr;
+        jobs.HW[j] = jobs.tokens[j] = 0; jobs.x_sb[j] = 0;
+    }
+    const size_t lds = sizeof(float) * (size_t)N * KP_LD;
+    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)kv_project_multi_kernel, lds));
+    hipLaunchKernelGGL(kv_project_multi_kernel, dim3(wg), dim3(KP_W * 64), lds, (hipStream_t)stream, jobs, B, N);
+    MSM_CHECK_LAUNCH("msm_kv_project_multi_f32");
     return MSM_OK;
 }
 

@@ -226,11 +226,10 @@ class MeanShiftTransformerDecoder(nn.Module):
         # level embedding, position code and the in-projection are folded into per-layer constants
         # (see _folded_kv).  False: materialise src = input_proj(x)+level_embed and project it (K=256).
         self.fold_kv = True
-        # the K/V projections depend only on the level features, not on the query chain: with overlap_kv they
-        # are issued on a side stream (fork/join events, also valid under HIP-graph capture) and run beside
-        # the latency-bound per-layer query kernels that leave most CUs idle
-        self.overlap_kv = False    # measured neutral at B=8 on MI355X (5.76 vs 5.69 ms/step): off by default
-        self._side = None
+        # the K/V projections depend only on the level features, not on the query chain: batched_kv computes those of all
+        # layers in ONE launch before the layer loop (nine launches, the coarse ones latency bound: 211 us per step at
+        # B=8; one launch: see DESIGN.md).  (Running them on a side stream next to the query chain was neutral.)
+        self.batched_kv = True
         # the row-local ops between the attention cores run as three fused kernels per layer (csrc/dec_chain.hip)
         # instead of 13 launches; needs E = 256, mask_dim = 256 and dim_feedforward % 256 == 0 (every MSMFormer yaml)
         self.fused_tails = (hidden_dim == 256 and mask_dim == 256 and dim_feedforward % 256 == 0)
@@ -338,7 +337,7 @@ class MeanShiftTransformerDecoder(nn.Module):
             self._tails_cache = (key, {k: [ops.dec_pack_weight(w.contiguous()) for w in ws] for k, ws in groups.items()})
         return self._tails_cache[1]
 
-    def _forward_fused(self, xs, sizes, kv_w, kv_c, mask_features, out, qpos, kv_all=None, kv_ready=None):
+    def _forward_fused(self, xs, sizes, kv_w, kv_c, mask_features, out, qpos, kv_all=None):
         """Same arithmetic as the loop in forward(), with the row-local ops of a layer in three launches:
         heads (+ next cross-attention query) -> mask step -> K/V GEMM -> cross attention -> post_cross (out_proj, LN,
         self-attention in-projection) -> self attention -> post_self (out_proj, LN, FFN by hidden chunk)."""
@@ -378,7 +377,6 @@ class MeanShiftTransformerDecoder(nn.Module):
             sa = self.transformer_self_attention_layers[i]
             ff = self.transformer_ffn_layers[i]
             if kv_all is not None:
-                torch.cuda.current_stream().wait_event(kv_ready[i])            # join for layer i only
                 kv = kv_all[i]
             else:
                 kv = ops.kv_project(xs[lvl], kv_w[i], kv_c[i])        # (B, hw, 2E) = [K | V]
@@ -412,21 +410,11 @@ class MeanShiftTransformerDecoder(nn.Module):
             sizes.append((int(h), int(w)))
             # token-major (channels_last) level maps, as the pixel decoder returns them, are consumed as they are
             xs.append(x[i] if ops.is_token_major(x[i]) else x[i].contiguous())
-        kv_all, kv_ready = None, None
+        kv_all = None
         if self.fold_kv:
             kv_w, kv_c = self._folded_kv(sizes, dev)
-            if self.overlap_kv:
-                if self._side is None:
-                    self._side = torch.cuda.Stream(device=dev)
-                cur = torch.cuda.current_stream()
-                self._side.wait_stream(cur)                                   # fork
-                kv_all, kv_ready = [], []
-                with torch.cuda.stream(self._side):
-                    for i in range(self.num_layers):
-                        kv_all.append(ops.kv_project(xs[i % self.num_feature_levels], kv_w[i], kv_c[i]))
-                        ev = torch.cuda.Event()
-                        ev.record(self._side)
-                        kv_ready.append(ev)
+            if self.batched_kv and self.num_layers <= 16 and all(xl.shape[1] == 64 for xl in xs) and kv_w[0].shape[0] in (256, 512):
+                kv_all = ops.kv_project_multi([xs[i % self.num_feature_levels] for i in range(self.num_layers)], kv_w, kv_c)
         else:
             for i in range(self.num_feature_levels):
                 pos.append(self._pos_tokens(*sizes[i], dev))
@@ -450,10 +438,7 @@ class MeanShiftTransformerDecoder(nn.Module):
         L = self.num_layers
         pred_cls, pred_mask = [], []
         if self.fused_tails and self.fold_kv:
-            res = self._forward_fused(xs, sizes, kv_w, kv_c, mask_features, out, qpos, kv_all, kv_ready)
-            if kv_all is not None:
-                self._side.wait_stream(torch.cuda.current_stream())   # side-stream buffers are not recycled under us
-            return res
+            return self._forward_fused(xs, sizes, kv_w, kv_c, mask_features, out, qpos, kv_all)
         d = ops.layernorm(out, self.decoder_norm.weight, self.decoder_norm.bias)
         cls, m, attn, row_any = self._heads(d, mask_features, sizes[0], full or L == 0, full or L == 0)
         pred_cls.append(cls)
@@ -463,7 +448,6 @@ class MeanShiftTransformerDecoder(nn.Module):
             ca = self.transformer_cross_attention_layers[i]
             if self.fold_kv:
                 if kv_all is not None:
-                    torch.cuda.current_stream().wait_event(kv_ready[i])               # join for layer i only
                     kv = kv_all[i]
                 else:
                     kv = ops.kv_project(xs[lvl], kv_w[i], kv_c[i])        # (B, hw, 2E) = [K | V]
@@ -493,8 +477,6 @@ class MeanShiftTransformerDecoder(nn.Module):
             cls, m, attn, row_any = self._heads(d, mask_features, tgt, full or last, full or last)
             pred_cls.append(cls)
             pred_mask.append(m)
-        if kv_all is not None:
-            self._side.wait_stream(torch.cuda.current_stream())   # side-stream buffers are not recycled under us
         res = {"pred_logits": pred_cls[-1], "pred_masks": pred_mask[-1], "aux_outputs": []}
         if full:
             res["aux_outputs"] = [{"pred_logits": a, "pred_masks": b} for a, b in zip(pred_cls[:-1], pred_mask[:-1])]

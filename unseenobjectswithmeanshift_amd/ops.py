@@ -535,6 +535,33 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     return gv, gl, gw
 
 
+def kv_project_multi(xs, ws, cmats):
+    """kv_project for a list of jobs in one launch: xs[j] (B, 64, H_j, W_j) contiguous NCHW or token-major
+    (is_token_major), ws[j] (N, 64), cmats[j] (H_j*W_j, N) -> list of (B, H_j*W_j, N).  N in {256, 512}, <= 16 jobs."""
+    n = len(xs)
+    B, N = xs[0].shape[0], ws[0].shape[0]
+    outs, tok, sb, hw = [], [], [], []
+    for x, w, c in zip(xs, ws, cmats):
+        _chk(x, "x"), _c(w, "w"), _c(c, "cmat")
+        Bx, C, H, W = x.shape
+        t = is_token_major(x) and not x.is_contiguous()
+        if not t:
+            _c(x, "x")
+        if Bx != B or C != 64 or w.shape[0] != N or tuple(w.shape) != (N, 64) or tuple(c.shape) != (H * W, N):
+            raise RuntimeError("kv_project_multi: inconsistent job shapes")
+        tok.append(1 if t else 0)
+        sb.append(x.stride(0) if t else C * H * W)
+        hw.append(H * W)
+        outs.append(torch.empty((B, H * W, N), device=x.device, dtype=torch.float32))
+    vp = ctypes.c_void_p * n
+    arr = lambda ts: ctypes.cast(vp(*[t.data_ptr() for t in ts]), ctypes.c_void_p)
+    ia, la = (ctypes.c_int32 * n), (ctypes.c_int64 * n)
+    rc = lib().msm_kv_project_multi_f32(n, arr(xs), arr(ws), arr(cmats), arr(outs), ctypes.cast(ia(*hw), ctypes.c_void_p),
+                                        ctypes.cast(ia(*tok), ctypes.c_void_p), ctypes.cast(la(*sb), ctypes.c_void_p), B, 64, N, _stream())
+    check(rc, "msm_kv_project_multi_f32")
+    return outs
+
+
 def value_to_head_major(value, heads):
     """(N, S, C) token-major value -> (N, heads, S, C/heads), the layout ms_deform_attn_encoder gathers fastest from."""
     _c(value, "value")
