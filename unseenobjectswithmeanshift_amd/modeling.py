@@ -413,7 +413,10 @@ class MeanShiftTransformerDecoder(nn.Module):
         kv_all = None
         if self.fold_kv:
             kv_w, kv_c = self._folded_kv(sizes, dev)
-            if self.batched_kv and self.num_layers <= 16 and all(xl.shape[1] == 64 for xl in xs) and kv_w[0].shape[0] in (256, 512):
+            kv_bytes = 4 * B * kv_w[0].shape[0] * sum(sizes[i % self.num_feature_levels][0] * sizes[i % self.num_feature_levels][1]
+                                                      for i in range(self.num_layers))
+            if (self.batched_kv and self.num_layers <= 16 and kv_bytes <= (2 << 30) and all(xl.shape[1] == 64 for xl in xs)
+                    and kv_w[0].shape[0] in (256, 512)):       # all layers' K/V live at once: only while that stays small
                 kv_all = ops.kv_project_multi([xs[i % self.num_feature_levels] for i in range(self.num_layers)], kv_w, kv_c)
         else:
             for i in range(self.num_feature_levels):
