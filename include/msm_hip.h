@@ -346,6 +346,12 @@ int msm_conv1x1_in_multi_f32(int n_levels, const float* const* x, const float* c
 int msm_conv3x3_c64_f32(const float* in, const float* w_tap_major, float* out, double* stats,
                         int stats_cleared, int B, int H, int W, void* stream);
 
+/* The same kernel with a planar result: out [B][Cout][H*W] (NCHW) = bias + conv3x3(in), Cout a multiple of 64 (every slice of
+ * 64 output channels has its own workgroups and its own 147 KB of the [Cout][9*64] weight in LDS), W % 4 == 0
+ * (SimpleBasePixelDecoder.mask_features: Conv2d(64, 256, 3, padding=1), fpn.py:237-246; 90.6 GFLOP per 640x480 frame). */
+int msm_conv3x3_c64_nchw_f32(const float* in, const float* w_tap_major, const float* bias, float* out, int B, int H, int W,
+                             int Cout, void* stream);
+
 /* Encoder prologue: everything between the input projections and the first deformable-attention layer in one pass
  * over the token buffer (msdeformattn.py:326-329 GroupNorm of input_proj, :60-75 level concatenation;
  * ops/modules/ms_deform_attn.py:95-104 layer 0's value_proj / sampling_offsets / attention_weights):

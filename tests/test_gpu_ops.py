@@ -727,3 +727,14 @@ def test_kv_project_multi_equals_single_launches():
         closed(o, ref.cpu(), rtol=2e-5, atol=2e-5)
         if x.shape[2] * x.shape[3] * B >= 8192 or ops().is_token_major(x):        # the single launch takes the same kernel there
             assert torch.equal(o, ops().kv_project(x, w, c))
+
+
+@pytest.mark.parametrize("B,H,W,Cout", [(2, 12, 16, 256), (1, 7, 36, 64), (1, 30, 40, 128)])
+def test_conv3x3_c64_nchw_vs_fp64(B, H, W, Cout):
+    """msm_conv3x3_c64_nchw_f32 (planar output, bias, several 64-channel slices) against an fp64 conv2d."""
+    x, w, b = rnd(B, H * W, 64, seed=1), rnd(Cout, 64, 3, 3, seed=2, scale=0.06), rnd(Cout, seed=3)
+    ref = F.conv2d(x.double().view(B, H, W, 64).permute(0, 3, 1, 2), w.double(), b.double(), padding=1).reshape(B, Cout, H * W)
+    w3 = w.permute(0, 2, 3, 1).reshape(Cout, 576).contiguous().to(DEV)
+    out = ops().conv3x3_tokens_to_nchw(x.to(DEV), w3, b.to(DEV), H, W)
+    closed(out, ref, rtol=2e-5, atol=2e-5)
+    closed(ops().conv3x3_tokens_to_nchw(x.to(DEV), w3, None, H, W), ref - b.double()[None, :, None], rtol=2e-5, atol=2e-5)

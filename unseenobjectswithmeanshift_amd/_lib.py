@@ -62,6 +62,7 @@ _SIGNATURES = {
     "msm_conv1x1_in_f32": (c_i, [c_f, c_f, c_f, c_f, c_l, c_p, c_i, c_i, c_i, c_i, c_p]),
     "msm_conv1x1_in_multi_f32": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_l, c_p, c_i, c_i, c_p]),
     "msm_conv3x3_c64_f32": (c_i, [c_f, c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "msm_conv3x3_c64_nchw_f32": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p]),
     "msm_encoder_prologue_stream_floats": (c_l, [c_i]),
     "msm_encoder_prologue_fwd": (c_i, [c_f, c_p, c_f, c_p, c_i, c_i, c_fl, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p]),
     "msm_label_stats": (c_i, [c_f, c_f, c_p, c_f, c_p, c_i, c_i, c_i, c_i, c_p]),

@@ -28,18 +28,24 @@ constexpr int C3_K = 9 * C3_C;           // 576
 constexpr int C3_LD = C3_K + 4;          // LDS row stride (floats): 145 float4, odd -> 16 rows hit 16 different 16-byte banks
 constexpr int C3_W = 16;                 // waves per workgroup (the weight takes 145 KiB: one workgroup per CU)
 
+// NCHW = false: token-major output [B][HW][64] (+ moments).  NCHW = true: output [B][Cout][HW] for Cout = 64 * gridDim.z, each
+// z slice of workgroups holding its own 64 rows of the weight; the MFMA operands are swapped (rows = pixels) so that a
+// lane ends with 4 consecutive PIXELS of one channel and the planes are written with 16-byte stores (W % 4 == 0); bias per
+// channel (SimpleBasePixelDecoder.mask_features: Conv2d(64, 256, 3, padding=1) with bias, fpn.py:237-246).
+template <bool NCHW>
 __global__ __launch_bounds__(C3_W * 64) void conv3x3_c64_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                                                                float* __restrict__ out, double* __restrict__ stats,
-                                                                int H, int W) {
+                                                                const float* __restrict__ bias, float* __restrict__ out,
+                                                                double* __restrict__ stats, int H, int W) {
     extern __shared__ __attribute__((aligned(16))) float wl[];   // [64][C3_LD], then the moment scratch [C3_W][64][2]
     float* msc = wl + C3_C * C3_LD;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lj = lane & 15, lq = lane >> 4;
     const int b = blockIdx.y;
+    const int o0 = NCHW ? (int)blockIdx.z * C3_C : 0;          // first output channel of this workgroup
     for (int i = tid; i < C3_C * (C3_K / 4); i += C3_W * 64) {
         const int n = i / (C3_K / 4), c4 = i - n * (C3_K / 4);
-        *reinterpret_cast<float4*>(wl + n * C3_LD + c4 * 4) = *reinterpret_cast<const float4*>(w + (int64_t)n * C3_K + c4 * 4);
+        *reinterpret_cast<float4*>(wl + n * C3_LD + c4 * 4) = *reinterpret_cast<const float4*>(w + (int64_t)(o0 + n) * C3_K + c4 * 4);
     }
     __syncthreads();
 
@@ -51,7 +57,12 @@ __global__ __launch_bounds__(C3_W * 64) void conv3x3_c64_kernel(const float* __r
     const int left_slot = (wave >> 2) * ((int)gridDim.x * 4) + (int)blockIdx.x * 4 + (wave & 3);
     const int mine = full_rounds + (left_slot < left ? 1 : 0);
     const float* ib = in + (int64_t)b * H * W * C3_C;
-    float* ob = out + (int64_t)b * H * W * C3_C;
+    float* ob = NCHW ? out + ((int64_t)b * gridDim.z * C3_C + o0) * H * W : out + (int64_t)b * H * W * C3_C;
+    float bch[4] = {0.f, 0.f, 0.f, 0.f};                         // NCHW: bias of this lane's channel in each 16-channel block
+    if (NCHW && bias) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) bch[mt] = bias[o0 + mt * 16 + lj];
+    }
     float s[4][4], q[4][4];                          // moments of this lane's 4 x 4 channels over its pixels
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -84,13 +95,13 @@ __global__ __launch_bounds__(C3_W * 64) void conv3x3_c64_kernel(const float* __r
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const float4*>(wp + mt * 16 * C3_LD + t * C3_C + ks * 16);
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma16(a[mt].x, cur[ks].x, acc[mt]);
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = NCHW ? mfma16(cur[ks].x, a[mt].x, acc[mt]) : mfma16(a[mt].x, cur[ks].x, acc[mt]);
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma16(a[mt].y, cur[ks].y, acc[mt]);
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = NCHW ? mfma16(cur[ks].y, a[mt].y, acc[mt]) : mfma16(a[mt].y, cur[ks].y, acc[mt]);
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma16(a[mt].z, cur[ks].z, acc[mt]);
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = NCHW ? mfma16(cur[ks].z, a[mt].z, acc[mt]) : mfma16(a[mt].z, cur[ks].z, acc[mt]);
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma16(a[mt].w, cur[ks].w, acc[mt]);
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = NCHW ? mfma16(cur[ks].w, a[mt].w, acc[mt]) : mfma16(a[mt].w, cur[ks].w, acc[mt]);
             }
         };
         float4 fa[4], fb[4];
@@ -107,7 +118,16 @@ __global__ __launch_bounds__(C3_W * 64) void conv3x3_c64_kernel(const float* __r
             __builtin_amdgcn_sched_barrier(0);
         }
         mma_tap(8, fa);
-        if (px < W) {
+        if constexpr (NCHW) {
+            // lane: channel mt*16 + lj, pixels x0 + lq*4 .. +3 of row y
+            const int xs = x0 + lq * 4;
+            if (xs < W) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    *reinterpret_cast<float4*>(ob + (int64_t)(mt * 16 + lj) * H * W + (int64_t)y * W + xs) =
+                        make_float4(acc[mt][0] + bch[mt], acc[mt][1] + bch[mt], acc[mt][2] + bch[mt], acc[mt][3] + bch[mt]);
+            }
+        } else if (px < W) {
             float* op = ob + ((int64_t)y * W + px) * C3_C + lq * 4;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
@@ -120,7 +140,7 @@ __global__ __launch_bounds__(C3_W * 64) void conv3x3_c64_kernel(const float* __r
             }
         }
     }
-    if (stats) {
+    if (!NCHW && stats) {
         // over the 16 pixels of the lane quarter, then over the workgroup's waves (fixed order), then one double add each
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -164,12 +184,31 @@ extern "C" int msm_conv3x3_c64_f32(const float* in, const float* w_tap_major, fl
     hipStream_t st = (hipStream_t)stream;
     if (stats && !stats_cleared) MSM_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * C3_C * (size_t)B, st));
     const size_t lds = sizeof(float) * ((size_t)C3_C * C3_LD + (size_t)C3_W * C3_C * 2);
-    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_kernel, lds));
+    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_kernel<false>, lds));
     // workgroups per image: about one round of the chip over the batch, never more than the image has tiles for
     const int units = cdiv(W, 16) * H;
     int per_image = max(1, 256 / B);
     per_image = min(per_image, cdiv(units, C3_W));
-    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(per_image, B), dim3(C3_W * 64), lds, st, in, w_tap_major, out, stats, H, W);
+    hipLaunchKernelGGL(conv3x3_c64_kernel<false>, dim3(per_image, B), dim3(C3_W * 64), lds, st, in, w_tap_major, nullptr, out, stats, H, W);
     MSM_CHECK_LAUNCH("msm_conv3x3_c64_f32");
+    return MSM_OK;
+}
+
+extern "C" int msm_conv3x3_c64_nchw_f32(const float* in, const float* w_tap_major, const float* bias, float* out, int B, int H, int W,
+                                        int Cout, void* stream) {
+    MSM_REQUIRE(in && w_tap_major && out && in != out, "msm_conv3x3_c64_nchw_f32: null or aliased pointer");
+    MSM_REQUIRE(B > 0 && H > 0 && W > 0 && W % 4 == 0 && Cout > 0 && Cout % C3_C == 0 && Cout <= 1024,
+                "msm_conv3x3_c64_nchw_f32: need W %% 4 == 0 and Cout a multiple of 64 (B=%d H=%d W=%d Cout=%d)", B, H, W, Cout);
+    MSM_REQUIRE((int64_t)H * W * C3_C < ((int64_t)1 << 31), "msm_conv3x3_c64_nchw_f32: image too large");
+    MSM_REQUIRE(((((uintptr_t)in) | ((uintptr_t)w_tap_major) | ((uintptr_t)out)) & 15) == 0, "msm_conv3x3_c64_nchw_f32: misaligned pointer");
+    const size_t lds = sizeof(float) * ((size_t)C3_C * C3_LD + (size_t)C3_W * C3_C * 2);
+    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_kernel<true>, lds));
+    const int units = cdiv(W, 16) * H;
+    const int slices = Cout / C3_C;
+    int per_image = max(1, 256 / (B * slices));
+    per_image = min(per_image, cdiv(units, C3_W));
+    hipLaunchKernelGGL(conv3x3_c64_kernel<true>, dim3(per_image, B, slices), dim3(C3_W * 64), lds, (hipStream_t)stream, in, w_tap_major,
+                       bias, out, nullptr, H, W);
+    MSM_CHECK_LAUNCH("msm_conv3x3_c64_nchw_f32");
     return MSM_OK;
 }
