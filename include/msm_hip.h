@@ -54,7 +54,7 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 3   /* 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats */
+#define MSM_ABI_VERSION 4   /* 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
 int msm_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
