@@ -225,7 +225,13 @@ def twostage():
             imgs = torch.stack([x["image"] for x in batched_inputs])
             deps = torch.stack([x["depth"] for x in batched_inputs])
             H, W = imgs.shape[-2:]
-            scores, classes, masks, boxes, _ = self.inference(self.backbone(imgs, deps), (int(H), int(W)))
+            feats = self.backbone(imgs, deps)
+            if os.environ.get("MSM_TS_GRAPH"):          # HIP-graph replay per geometry (frame / number of crops)
+                if getattr(self, "_g", None) is None:
+                    self._g = self.graphed()
+                scores, classes, masks, boxes, _ = self._g(feats, (int(H), int(W)))
+            else:
+                scores, classes, masks, boxes, _ = self.inference(feats, (int(H), int(W)))
             return [{"instances": Instances((int(H), int(W)), pred_masks=masks[b], pred_boxes=boxes[b], scores=scores[b],
                                             pred_classes=classes[b])} for b in range(len(batched_inputs))]
 
