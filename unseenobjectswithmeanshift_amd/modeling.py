@@ -760,8 +760,9 @@ class MSDeformAttnPixelDecoder(nn.Module):
             self._front = (key, wpk, gnp, stream, small, wp.shape[0])
         return self._front[1:]
 
-    @torch.no_grad()
-    def forward_features(self, features):
+    def _encode(self, features):
+        """Input projections + the six encoder layers.  Returns the token buffer (B, S, C) with the levels concatenated
+        coarse to fine, their (h, w) shapes and the pre-zeroed moment buffers of the two FPN GroupNorms (or Nones)."""
         C = self.conv_dim
         levels = [features[f].float().contiguous() for f in self.transformer_in_features[::-1]]      # res5, res4, res3
         B = levels[0].shape[0]
@@ -816,19 +817,19 @@ class MSDeformAttnPixelDecoder(nn.Module):
         else:
             for layer in layers:
                 src = layer.forward_tokens(src, lvl_pos, ss, starts)
-        # multi-scale outputs: NCHW-shaped VIEWS of the token buffer (torch channels_last strides) -- no slice copies,
-        # no transposes; the decoder's K/V projection reads this layout directly
-        out, o = [], 0
-        for (h, w) in shapes:
-            out.append(src[:, o:o + h * w].view(B, h, w, C).permute(0, 3, 1, 2))
-            o += h * w
-        up_tok = src[:, o - shapes[-1][0] * shapes[-1][1]:]                       # finest level, source of the FPN upsample (a view)
+        return src, shapes, fpn_stats
+
+    def _fpn_mask_features(self, features, up_tok, up_hw, fpn_stats):
+        """The one FPN level on res2 and the mask_features convolution (MSD:343-358); up_tok: the finest encoder level as a
+        token-range view of the encoder's buffer."""
+        C = self.conv_dim
+        B = up_tok.shape[0]
         # one FPN level on the highest-resolution backbone feature (MSD:343-351)
         x = features[self.in_features[0]].float().contiguous()
         H, W = int(x.shape[2]), int(x.shape[3])
         lat = ops.conv1x1_nchw_to_tokens(x, self.adapter_1.weight.view(C, -1), None)
         y = ops.groupnorm_tokens(lat, self.adapter_1.norm.weight, self.adapter_1.norm.bias, H, W, groups=32,
-                                 up=up_tok, up_hw=shapes[-1], eps=self.adapter_1.norm.eps, stats=fpn_stats[0])
+                                 up=up_tok, up_hw=up_hw, eps=self.adapter_1.norm.eps, stats=fpn_stats[0])
         y_stats = None
         if C == 64:
             # weight-stationary 3x3 kernel; the moments of layer_1's GroupNorm come out of its epilogue
@@ -844,4 +845,19 @@ class MSDeformAttnPixelDecoder(nn.Module):
             y = ops.groupnorm_tokens(y, self.layer_1.norm.weight, self.layer_1.norm.bias, H, W, groups=32, relu=True,
                                      eps=self.layer_1.norm.eps)
             mask_features = ops.conv1x1_tokens_to_nchw(y, wm, self.mask_features.bias).view(B, self.mask_dim, H, W)
+        return mask_features
+
+    @torch.no_grad()
+    def forward_features(self, features):
+        C = self.conv_dim
+        src, shapes, fpn_stats = self._encode(features)
+        B = src.shape[0]
+        # multi-scale outputs: NCHW-shaped VIEWS of the token buffer (torch channels_last strides) -- no slice copies,
+        # no transposes; the decoder's K/V projection reads this layout directly
+        out, o = [], 0
+        for (h, w) in shapes:
+            out.append(src[:, o:o + h * w].view(B, h, w, C).permute(0, 3, 1, 2))
+            o += h * w
+        up_tok = src[:, o - shapes[-1][0] * shapes[-1][1]:]                       # finest level, source of the FPN upsample (a view)
+        mask_features = self._fpn_mask_features(features, up_tok, shapes[-1], fpn_stats)
         return mask_features, out[0], out[:self.maskformer_num_feature_levels]
