@@ -54,7 +54,7 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 4   /* 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
+#define MSM_ABI_VERSION 5   /* 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
 int msm_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -97,6 +97,12 @@ int msm_groupnorm_apply_f32(const float* x, const double* stats, const float* ga
                             const float* up, int uh, int uw, int64_t up_batch_stride, float* y,
                             int B, int H, int W, int C, int groups, float eps, int relu, void* stream);
 
+/* y [B][C][HW] (NCHW planes) = GN(x [B][HW][C]) * gamma + beta (relu when relu != 0), stats from msm_groupnorm_stats_f32 /
+ * msm_conv3x3_c64_f32: the 64-channel activation the folded mask step contracts with (msm_mask_logits_fwd).
+ * C <= 128, HW % 4 == 0. */
+int msm_groupnorm_apply_nchw_f32(const float* x, const double* stats, const float* gamma, const float* beta, float* y,
+                                 int B, int HW, int C, int groups, float eps, int relu, void* stream);
+
 /* PositionEmbeddingSine(normalize=True) for one H x W map (position_encoding.py:29-52).
  * out element (c, y, x) at out + c*s_c + (y*W+x)*s_p; add_c (nullable, [2*npf]) is added per channel
  * (level embedding, msdeformattn.py:75). */
@@ -116,12 +122,20 @@ int msm_transpose_f32(const float* in, float* out, int B, int R, int C, void* st
  *             attendable (the reference resets all-masked rows, DEC:618); zeroed by this call.
  *   flags: MSM_MASK_SPARSE (1): rows of the mask that feed neither mask_out nor a tap are skipped;
  *          MSM_MASK_ROW_ANY_CLEARED (2): the caller already zeroed row_any (msm_dec_heads does), no fill is issued.
+ *   embed_ld: floats between consecutive rows of mask_embed (0 = C): the C columns may be the head of a wider buffer.
+ *   qbias (nullable): per-query constant added to every logit of the query, query (b, q) at qbias[(b*Q + q) * qbias_ld]
+ *             (0 = 1).  With these two the step also serves the FOLDED form of the contraction: the mask features are
+ *             a 1x1 convolution of the 64-channel FPN activation a (MSD:349-358), so
+ *                 einsum(e, Wm a + bm) = einsum(e Wm, a) + e.bm
+ *             is computed with C = 64 on `a` directly -- mask_embed = e Wm [B][Q][64], qbias = e.bm -- a quarter of
+ *             the FLOPs and of the bytes of the literal order (modeling.FoldedMaskFeatures).
  * ------------------------------------------------------------------------------------------- */
 #define MSM_MASK_SPARSE 1
 #define MSM_MASK_ROW_ANY_CLEARED 2
 int msm_mask_logits_fwd(const float* mask_embed, const float* mask_feat, float* mask_out,
                         uint8_t* attn_out, int32_t* row_any,
-                        int B, int Q, int C, int H, int W, int th, int tw, int flags, void* stream);
+                        int B, int Q, int C, int H, int W, int th, int tw, int flags,
+                        int64_t embed_ld, const float* qbias, int64_t qbias_ld, void* stream);
 
 /* bf16 variant of the mask step (BASELINE configs 3 and 5; SURVEY 8d: HBM-bound at AI 71.6 FLOP/B): bf16 operands,
  * fp32 accumulation, same outputs and flags.  mask_feat_packed is the channel-quad packed bf16 form of the feature
@@ -130,7 +144,8 @@ int msm_mask_logits_fwd(const float* mask_embed, const float* mask_feat, float* 
 int msm_pack_mask_features_bf16(const float* mask_feat, uint16_t* packed, int B, int C, int HW, void* stream);
 int msm_mask_logits_bf16_fwd(const float* mask_embed, const uint16_t* mask_feat_packed, float* mask_out,
                              uint8_t* attn_out, int32_t* row_any,
-                             int B, int Q, int C, int H, int W, int th, int tw, int flags, void* stream);
+                             int B, int Q, int C, int H, int W, int th, int tw, int flags,
+                             int64_t embed_ld, const float* qbias, int64_t qbias_ld, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-head hypersphere (vMF) attention core (AU:64-82) on already projected q/k/v:

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(L, s), s
     assert set(declared) == set(_lib._SIGNATURES), set(declared) ^ set(_lib._SIGNATURES)
-    assert _lib.lib().msm_abi_version() == _lib.ABI_VERSION == 4
+    assert _lib.lib().msm_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_argument_errors_are_reported_without_a_gpu():
@@ -27,7 +27,7 @@ def test_argument_errors_are_reported_without_a_gpu():
     rc = L.msm_gemm_f32(None, None, None, None, None, 1, 1, 1, 1, 1, 1, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, None)
     assert rc == -1 and b"null pointer" in L.msm_last_error_string()
     rc = L.msm_mask_logits_fwd(ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), None, None,
-                               1, 100, 250, 120, 160, 0, 0, 0, None)
+                               1, 100, 250, 120, 160, 0, 0, 0, 0, None, 0, None)
     assert rc == -1 and b"multiple of 32" in L.msm_last_error_string()
     assert L.msm_hypersphere_attn_workspace(8, 100, 4800, 8) > 0
 

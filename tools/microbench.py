@@ -66,14 +66,21 @@ def gemm():
 
 
 def mask():
-    e = torch.randn(8, 100, 256, device=DEV) * 0.3
-    f = torch.randn(8, 256, 120, 160, device=DEV)
-    flops = 2.0 * 100 * 256 * 19200 * 8
-    for nc in ("2", "1"):
-        os.environ["MSM_MASK_NC"] = nc
-        for tgt, wm in (((15, 20), False), ((30, 40), False), ((60, 80), False), (None, True)):
-            t = timeit(lambda: ops.mask_logits(e, f, want_mask=wm, target_size=tgt), iters=50)
-            print(f"mask nc={nc} target={tgt} write={wm}: {t:7.1f} us  {flops / t / 1e6:6.1f} TFLOP/s", flush=True)
+    """Mask step at B=8, 120x160 features: the literal contraction (C=256) and the folded one (C=64 activation, embedding =
+    leading 64 columns of a 256-wide buffer, per-query bias) -- HIP-graph timed."""
+    for C in (256, 64):
+        wide = torch.randn(8, 100, 256, device=DEV) * 0.3
+        e = wide[..., :C]
+        qb = wide[..., 64] if C == 64 else None
+        f = torch.randn(8, C, 120, 160, device=DEV)
+        flops = 2.0 * 100 * C * 19200 * 8
+        for nc in ("2", "1", ""):
+            os.environ.pop("MSM_MASK_NC", None)
+            if nc:
+                os.environ["MSM_MASK_NC"] = nc
+            for tgt, wm in (((15, 20), False), ((30, 40), False), ((60, 80), False), (None, True)):
+                t = timeit_graph(lambda: ops.mask_logits(e, f, want_mask=wm, target_size=tgt, qbias=qb))
+                print(f"mask C={C} nc={nc or 'auto'} target={tgt} write={wm}: {t:7.1f} us  {flops / t / 1e6:6.1f} TFLOP/s executed", flush=True)
 
 
 def maskbf16():

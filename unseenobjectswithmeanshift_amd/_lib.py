@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmsm_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "msm_hip.h")
 
 _lib = None
-ABI_VERSION = 4      # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
+ABI_VERSION = 5      # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
 
 c_f = ctypes.c_void_p      # float* (device)
 c_p = ctypes.c_void_p
@@ -30,11 +30,12 @@ _SIGNATURES = {
     "msm_layernorm_f32": (c_i, [c_f, c_f, c_i, c_l, c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_i, c_i, c_fl, c_p]),
     "msm_groupnorm_stats_f32": (c_i, [c_f, c_p, c_i, c_i, c_i, c_i, c_p]),
     "msm_groupnorm_apply_f32": (c_i, [c_f, c_p, c_f, c_f, c_f, c_i, c_i, c_l, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_i, c_p]),
+    "msm_groupnorm_apply_nchw_f32": (c_i, [c_f, c_p, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_i, c_p]),
     "msm_pos_embed_sine": (c_i, [c_f, c_i, c_i, c_i, c_l, c_l, c_f, c_fl, c_fl, c_p]),
     "msm_transpose_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_p]),
-    "msm_mask_logits_fwd": (c_i, [c_f, c_f, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "msm_mask_logits_fwd": (c_i, [c_f, c_f, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_f, c_l, c_p]),
     "msm_pack_mask_features_bf16": (c_i, [c_f, c_p, c_i, c_i, c_i, c_p]),
-    "msm_mask_logits_bf16_fwd": (c_i, [c_f, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "msm_mask_logits_bf16_fwd": (c_i, [c_f, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_f, c_l, c_p]),
     "msm_hypersphere_attn_workspace": (c_l, [c_i, c_i, c_i, c_i]),
     "msm_hypersphere_attn_fwd": (c_i, [c_f, c_f, c_f, c_p, c_p, c_f, c_i, c_i, c_i, c_i,
                                        c_l, c_l, c_l, c_l, c_l, c_l, c_fl, c_f, c_l, c_p]),

@@ -160,8 +160,9 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_kernel(const float* __res
                                                           float* __restrict__ mask_out, uint8_t* __restrict__ attn_out,
                                                           int32_t* __restrict__ row_any, int Q, int C, int H, int W,
                                                           int th, int tw, int ypar, int n_rowpairs, int rp_step,
-                                                          int rp_first, int feat_bytes) {
-    extern __shared__ __attribute__((aligned(16))) float Es[];
+                                                          int rp_first, int feat_bytes, int64_t emb_ld,
+                                                          const float* __restrict__ qbias, int64_t qbias_ld) {
+    extern __shared__ __attribute__((aligned(16))) float Es[];   // [QCH][C + 2] embeddings, then [QCH] per-query biases
     constexpr int TW = 16 * NC;      // tile width in columns
     constexpr int NA = 2 * NC;       // accumulator column blocks: [row (top,bottom)][cc]
     const int SE = C + 2;
@@ -175,16 +176,19 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_kernel(const float* __res
     const int lj = lane & 15, lq = lane >> 4;
     const int HW = H * W;
 
-    // stage this chunk of mask_embed: rows >= Q are zero
-    const float* eb = emb + ((int64_t)b * Q + q0) * C;
+    // stage this chunk of mask_embed: rows >= Q are zero; the per-query bias (the folded mask_features bias) starts every
+    // accumulator of its row
+    const float* eb = emb + ((int64_t)b * Q + q0) * emb_ld;
     for (int idx = tid; idx < QCH * (C / 4); idx += MW * 64) {
         const int r = idx / (C / 4), c4 = (idx - r * (C / 4)) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q0 + r < Q) v = *reinterpret_cast<const float4*>(eb + (int64_t)r * C + c4);
+        if (q0 + r < Q) v = *reinterpret_cast<const float4*>(eb + (int64_t)r * emb_ld + c4);
         float2* d = reinterpret_cast<float2*>(&Es[r * SE + c4]);
         d[0] = make_float2(v.x, v.y);
         d[1] = make_float2(v.z, v.w);
     }
+    float* qb = Es + QCH * SE;
+    for (int r = tid; r < QCH; r += MW * 64) qb[r] = (qbias && q0 + r < Q) ? qbias[((int64_t)b * Q + q0 + r) * qbias_ld] : 0.f;
     __syncthreads();
 
     const int ctiles = (W + TW - 1) / TW;
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_kernel(const float* __res
 #pragma unroll
         for (int m = 0; m < QB; ++m)
 #pragma unroll
-            for (int n = 0; n < NA; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int n = 0; n < NA; ++n) acc[m][n] = *reinterpret_cast<const f32x4*>(qb + m * 16 + lq * 4);
 
         // K loop: groups of KU k-steps, two register buffers (A/B) in ping-pong.  The loads of the
         // next group are issued BEFORE the MFMAs of the current one and pinned there with
@@ -293,8 +297,9 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_bf16_kernel(const float* 
                                                                float* __restrict__ mask_out, uint8_t* __restrict__ attn_out,
                                                                int32_t* __restrict__ row_any, int Q, int C, int H, int W, int th,
                                                                int tw, int ypar, int n_rowpairs, int rp_step, int rp_first,
-                                                               int feat_bytes) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short Eb[];   // [QCH][C + 8] bf16
+                                                               int feat_bytes, int64_t emb_ld, const float* __restrict__ qbias,
+                                                               int64_t qbias_ld) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short Eb[];   // [QCH][C + 8] bf16, then [QCH] fp32 per-query biases
     const int SEb = C + 8;           // 132 dwords per row at C = 256: ds_read_b64 of (lj, lq) hits 64 distinct banks
     const int b = blockIdx.z, qc = blockIdx.y;
     const int q0 = qc * QCH;
@@ -304,11 +309,13 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_bf16_kernel(const float* 
     const int HW = H * W;
     const int nks = C / 16;
 
-    const float* eb = emb + ((int64_t)b * Q + q0) * C;
+    const float* eb = emb + ((int64_t)b * Q + q0) * emb_ld;
+    float* qb = reinterpret_cast<float*>(Eb + QCH * SEb);
+    for (int r = tid; r < QCH; r += MW * 64) qb[r] = (qbias && q0 + r < Q) ? qbias[((int64_t)b * Q + q0 + r) * qbias_ld] : 0.f;
     for (int idx = tid; idx < QCH * (C / 4); idx += MW * 64) {
         const int r = idx / (C / 4), c4 = (idx - r * (C / 4)) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q0 + r < Q) v = *reinterpret_cast<const float4*>(eb + (int64_t)r * C + c4);
+        if (q0 + r < Q) v = *reinterpret_cast<const float4*>(eb + (int64_t)r * emb_ld + c4);
         u32x2 pk;
         pk.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
         pk.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_bf16_kernel(const float* 
         __builtin_amdgcn_sched_barrier(0);
         f32x4 acc[QB][2];
 #pragma unroll
-        for (int m = 0; m < QB; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < QB; ++m) acc[m][0] = acc[m][1] = *reinterpret_cast<const f32x4*>(qb + m * 16 + lq * 4);
 #pragma unroll
         for (int ks = 0; ks < BKS; ++ks) {
             if (ks < nks) {                                              // wave-uniform
@@ -405,14 +412,24 @@ __global__ __launch_bounds__(256) void pack_mask_features_bf16_kernel(const floa
 
 using namespace msm;
 
+static int mask_embed_check(const char* who, const float* mask_embed, int64_t& embed_ld, const float* qbias, int64_t& qbias_ld, int C) {
+    if (embed_ld == 0) embed_ld = C;
+    if (qbias && qbias_ld == 0) qbias_ld = 1;
+    MSM_REQUIRE(embed_ld >= C && embed_ld % 4 == 0 && (((uintptr_t)mask_embed) & 15) == 0, "%s: mask_embed row stride %lld must be >= C, a multiple of 4, base 16-byte aligned",
+                who, (long long)embed_ld);
+    MSM_REQUIRE(!qbias || qbias_ld >= 1, "%s: bad qbias stride", who);
+    return MSM_OK;
+}
+
 extern "C" int msm_mask_logits_fwd(const float* mask_embed, const float* mask_feat, float* mask_out,
                                    uint8_t* attn_out, int32_t* row_any, int B, int Q, int C, int H, int W,
-                                   int th, int tw, int flags, void* stream) {
+                                   int th, int tw, int flags, int64_t embed_ld, const float* qbias, int64_t qbias_ld, void* stream) {
     const int sparse = flags & MSM_MASK_SPARSE;
     MSM_REQUIRE(mask_embed && mask_feat, "msm_mask_logits_fwd: null input");
     MSM_REQUIRE(mask_out || attn_out, "msm_mask_logits_fwd: nothing to produce");
     MSM_REQUIRE(B > 0 && Q > 0 && H > 1 && W > 1, "msm_mask_logits_fwd: bad sizes");
     MSM_REQUIRE(C % 32 == 0 && C >= 32 && C <= 320, "msm_mask_logits_fwd: C=%d must be a multiple of 32 and <= 320", C);
+    if (int rc = mask_embed_check("msm_mask_logits_fwd", mask_embed, embed_ld, qbias, qbias_ld, C)) return rc;
     MSM_REQUIRE(W % 2 == 0 && H % 2 == 0, "msm_mask_logits_fwd: H=%d W=%d must be even", H, W);
     MSM_REQUIRE((int64_t)C * H * W * 4 < (int64_t)1 << 31, "msm_mask_logits_fwd: one image of mask_feat must be < 2 GiB");
     MSM_REQUIRE((((uintptr_t)mask_embed) & 15) == 0 && (((uintptr_t)mask_feat) & 7) == 0 &&
@@ -457,8 +474,9 @@ extern "C" int msm_mask_logits_fwd(const float* mask_embed, const float* mask_fe
     const int target = cdiv(256, B * qchunks);
     if (wg_per > target) wg_per = max(target, 1);
     dim3 grid(wg_per, qchunks, B), block(MW * 64);
-    const size_t lds = sizeof(float) * (size_t)QCH * (C + 2);
-    typedef void (*kern_t)(const float*, const float*, float*, uint8_t*, int32_t*, int, int, int, int, int, int, int, int, int, int, int);
+    const size_t lds = sizeof(float) * ((size_t)QCH * (C + 2) + QCH);
+    typedef void (*kern_t)(const float*, const float*, float*, uint8_t*, int32_t*, int, int, int, int, int, int, int, int, int, int, int, int64_t,
+                           const float*, int64_t);
     kern_t kern;
     const bool wr = mask_out != nullptr;
 #define MASK_PICK(P)                                                                                   \
@@ -474,7 +492,7 @@ extern "C" int msm_mask_logits_fwd(const float* mask_embed, const float* mask_fe
 #undef MASK_PICK
     MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)kern, lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, mask_embed, mask_feat, mask_out, attn_out, row_any, Q, C, H, W, th, tw,
-                       ypar, n_rowpairs, rp_step, rp_first, (int)((int64_t)C * H * W * 4));
+                       ypar, n_rowpairs, rp_step, rp_first, (int)((int64_t)C * H * W * 4), embed_ld, qbias, qbias_ld);
     MSM_CHECK_LAUNCH("msm_mask_logits_fwd");
     return MSM_OK;
 }
@@ -492,12 +510,13 @@ extern "C" int msm_pack_mask_features_bf16(const float* mask_feat, uint16_t* pac
 
 extern "C" int msm_mask_logits_bf16_fwd(const float* mask_embed, const uint16_t* mask_feat_packed, float* mask_out,
                                         uint8_t* attn_out, int32_t* row_any, int B, int Q, int C, int H, int W, int th, int tw,
-                                        int flags, void* stream) {
+                                        int flags, int64_t embed_ld, const float* qbias, int64_t qbias_ld, void* stream) {
     const int sparse = flags & MSM_MASK_SPARSE;
     MSM_REQUIRE(mask_embed && mask_feat_packed, "msm_mask_logits_bf16_fwd: null input");
     MSM_REQUIRE(mask_out || attn_out, "msm_mask_logits_bf16_fwd: nothing to produce");
     MSM_REQUIRE(B > 0 && Q > 0 && H > 1 && W > 1, "msm_mask_logits_bf16_fwd: bad sizes");
     MSM_REQUIRE(C % 16 == 0 && C >= 16 && C <= 16 * BKS, "msm_mask_logits_bf16_fwd: C=%d must be a multiple of 16 and <= %d", C, 16 * BKS);
+    if (int rc = mask_embed_check("msm_mask_logits_bf16_fwd", mask_embed, embed_ld, qbias, qbias_ld, C)) return rc;
     MSM_REQUIRE(W % 2 == 0 && H % 2 == 0, "msm_mask_logits_bf16_fwd: H=%d W=%d must be even", H, W);
     MSM_REQUIRE((int64_t)C * H * W * 2 < (int64_t)1 << 31, "msm_mask_logits_bf16_fwd: one image of mask_feat must be < 2 GiB");
     MSM_REQUIRE((((uintptr_t)mask_embed) & 15) == 0 && (((uintptr_t)mask_feat_packed) & 7) == 0, "msm_mask_logits_bf16_fwd: misaligned pointer");
@@ -530,8 +549,9 @@ extern "C" int msm_mask_logits_bf16_fwd(const float* mask_embed, const uint16_t*
     const int target = cdiv(tgt_total, B * qchunks);
     if (wg_per > target) wg_per = max(target, 1);
     dim3 grid(wg_per, qchunks, B), block(MW * 64);
-    const size_t lds = sizeof(unsigned short) * (size_t)QCH * (C + 8);
-    typedef void (*kern_t)(const float*, const unsigned short*, float*, uint8_t*, int32_t*, int, int, int, int, int, int, int, int, int, int, int);
+    const size_t lds = sizeof(unsigned short) * (size_t)QCH * (C + 8) + sizeof(float) * QCH;
+    typedef void (*kern_t)(const float*, const unsigned short*, float*, uint8_t*, int32_t*, int, int, int, int, int, int, int, int, int, int, int,
+                           int64_t, const float*, int64_t);
     const bool wr = mask_out != nullptr;
     kern_t kern;
 #define MASKB_PICK(P) (wr ? (kern_t)mask_logits_bf16_kernel<P, true> : (kern_t)mask_logits_bf16_kernel<P, false>)
@@ -545,7 +565,7 @@ extern "C" int msm_mask_logits_bf16_fwd(const float* mask_embed, const uint16_t*
 #undef MASKB_PICK
     MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)kern, lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, mask_embed, mask_feat_packed, mask_out, attn_out, row_any, Q, C, H, W, th, tw, ypar,
-                       n_rowpairs, rp_step, rp_first, (int)((int64_t)C * H * W * 2));
+                       n_rowpairs, rp_step, rp_first, (int)((int64_t)C * H * W * 2), embed_ld, qbias, qbias_ld);
     MSM_CHECK_LAUNCH("msm_mask_logits_bf16_fwd");
     return MSM_OK;
 }

@@ -189,6 +189,55 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     }
 }
 
+// y[b][c][p] = act(GN(x))[b][p][c]: GroupNorm (+ReLU) of a token map written as NCHW planes -- the 64-channel activation the
+// folded mask step contracts with directly (mask_features = Wm a + bm is never materialised, see msm_mask_logits_fwd).
+// A block normalises a 64-token x C tile and transposes it through LDS; 16-byte loads and stores on both sides.
+__global__ __launch_bounds__(256) void gn_apply_nchw_kernel(const float* __restrict__ x, const double* __restrict__ stats,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ y, int HW, int C, int groups, float eps, int relu) {
+    extern __shared__ float gl[];                // sc[C], sh[C], mn[C], tile[C][64 + 4]
+    float *sc = gl, *sh = gl + C, *mn = gl + 2 * C, *tile = gl + 3 * C;
+    const int b = blockIdx.y, p0 = blockIdx.x * 64;
+    const int cpg = C / groups;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int g0 = (c / cpg) * cpg;
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < cpg; ++k) {
+            s += stats[((int64_t)b * C + g0 + k) * 2];
+            q += stats[((int64_t)b * C + g0 + k) * 2 + 1];
+        }
+        const double cnt = (double)cpg * (double)HW;
+        const double mean = s / cnt;
+        double var = q / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        sc[c] = (float)(1.0 / sqrt(var + (double)eps)) * gamma[c];
+        sh[c] = beta[c];
+        mn[c] = (float)mean;
+    }
+    __syncthreads();
+    const int c4n = C >> 2;
+    for (int i = threadIdx.x; i < 64 * c4n; i += 256) {
+        const int t = i / c4n, c = (i - t * c4n) * 4;
+        const int p = min(p0 + t, HW - 1);
+        float4 v = *reinterpret_cast<const float4*>(x + ((int64_t)b * HW + p) * C + c);
+        v.x = (v.x - mn[c]) * sc[c] + sh[c];
+        v.y = (v.y - mn[c + 1]) * sc[c + 1] + sh[c + 1];
+        v.z = (v.z - mn[c + 2]) * sc[c + 2] + sh[c + 2];
+        v.w = (v.w - mn[c + 3]) * sc[c + 3] + sh[c + 3];
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        tile[(c + 0) * 68 + t] = v.x;
+        tile[(c + 1) * 68 + t] = v.y;
+        tile[(c + 2) * 68 + t] = v.z;
+        tile[(c + 3) * 68 + t] = v.w;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * 16; i += 256) {
+        const int c = i >> 4, t4 = (i & 15) * 4;
+        if (p0 + t4 < HW)          // HW % 4 == 0: a float4 is inside or outside as a whole
+            *reinterpret_cast<float4*>(y + ((int64_t)b * C + c) * HW + p0 + t4) = *reinterpret_cast<const float4*>(tile + c * 68 + t4);
+    }
+}
+
 // ---- position encoding -------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pos_embed_kernel(float* __restrict__ out, int H, int W, int npf, int64_t s_c,
                                                         int64_t s_p, const float* __restrict__ add_c,
@@ -287,6 +336,19 @@ extern "C" int msm_groupnorm_apply_f32(const float* x, const double* stats, cons
     hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, st, x, stats, gamma, beta, up, uh, uw, up_batch_stride, y, H, W, C, groups, eps,
                        relu);
     MSM_CHECK_LAUNCH("msm_groupnorm_apply_f32");
+    return MSM_OK;
+}
+
+extern "C" int msm_groupnorm_apply_nchw_f32(const float* x, const double* stats, const float* gamma, const float* beta, float* y,
+                                            int B, int HW, int C, int groups, float eps, int relu, void* stream) {
+    MSM_REQUIRE(x && stats && gamma && beta && y && x != y, "msm_groupnorm_apply_nchw_f32: null or aliased pointer");
+    MSM_REQUIRE(B > 0 && HW > 0 && HW % 4 == 0, "msm_groupnorm_apply_nchw_f32: HW=%d must be a positive multiple of 4", HW);
+    MSM_REQUIRE(groups > 0 && C % groups == 0 && C % 4 == 0 && C >= 4 && C <= 128, "msm_groupnorm_apply_nchw_f32: C=%d groups=%d", C, groups);
+    MSM_REQUIRE(((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0, "msm_groupnorm_apply_nchw_f32: pointers must be 16-byte aligned");
+    const size_t lds = sizeof(float) * ((size_t)3 * C + (size_t)C * 68);
+    dim3 grid(cdiv(HW, 64), B), block(256);
+    hipLaunchKernelGGL(gn_apply_nchw_kernel, grid, block, lds, (hipStream_t)stream, x, stats, gamma, beta, y, HW, C, groups, eps, relu);
+    MSM_CHECK_LAUNCH("msm_groupnorm_apply_nchw_f32");
     return MSM_OK;
 }
 

@@ -98,7 +98,13 @@ class MeanShiftMaskFormerHead(nn.Module):
         """Returns (predictions, last_feature_map).  The reference also upsamples mask_features to
         image size here (meanshift_former_head.py:121-126, 315 MB per 640x480 image) for the
         training-only embedding loss; inference returns None for it."""
-        mask_features, _, multi_scale_features = self.pixel_decoder.forward_features(features)
+        # a predictor that contracts mask_features in their factored form gets them that way (modeling.FoldedMaskFeatures):
+        # same predictions up to fp32 summation order, a quarter of the mask step's work
+        import inspect
+        kw = {}
+        if getattr(self.predictor, "folded_mask_features", False) and "folded" in inspect.signature(self.pixel_decoder.forward_features).parameters:
+            kw["folded"] = True
+        mask_features, _, multi_scale_features = self.pixel_decoder.forward_features(features, **kw)
         predictions = self.predictor(multi_scale_features, mask_features, mask)
         return predictions, None
 

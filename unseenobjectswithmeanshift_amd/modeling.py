@@ -72,6 +72,38 @@ def hypersphere_attention(q, k, v, attn_mask=None, dropout_p=0.0, kappa=KAPPA):
                                      row_any=row_any, kappa=float(kappa))
 
 
+class FoldedMaskFeatures:
+    """The mask features of MSDeformAttnPixelDecoder in factored form: mask_features = weight . act + bias with ``act`` the
+    64-channel FPN activation relu(GroupNorm(layer_1 conv)) as NCHW planes (B, 64, H, W) (msdeformattn.py:349-358).
+
+    Every consumer of mask_features on the inference path is the bilinear contraction einsum("bqc,bchw->bqhw", e,
+    mask_features) (DEC:668), and that is linear in mask_features:
+        einsum(e, W a + b) = einsum(e W, a) + e.b
+    so a decoder that understands this object contracts the 64-channel ``act`` with the folded embedding e W (64 columns)
+    plus a per-query constant e.b -- a quarter of the FLOPs and of the bytes of the mask step, and the 1x1 convolution that
+    would write the (B, 256, H, W) tensor is never run.  ``tensor()`` materialises the literal mask_features for any other
+    consumer (same kernels as the unfolded pixel decoder)."""
+
+    def __init__(self, act, weight, bias, materialize):
+        self.act, self.weight, self.bias = act, weight, bias
+        self._materialize = materialize
+        self._tensor = None
+
+    @property
+    def shape(self):
+        B, _, H, W = self.act.shape
+        return torch.Size((B, self.weight.shape[0], H, W))
+
+    @property
+    def device(self):
+        return self.act.device
+
+    def tensor(self):
+        if self._tensor is None:
+            self._tensor = self._materialize()
+        return self._tensor
+
+
 class MeanShiftAttention(nn.Module):
     """Parameters laid out as nn.MultiheadAttention(embed_dim, num_heads) (attention_util.py:469-472):
     in_proj_weight (3E,E), in_proj_bias (3E), out_proj.{weight,bias}."""
@@ -230,6 +262,9 @@ class MeanShiftTransformerDecoder(nn.Module):
         # layers in ONE launch before the layer loop (nine launches, the coarse ones latency bound: 211 us per step at
         # B=8; one launch: see DESIGN.md).  (Running them on a side stream next to the query chain was neutral.)
         self.batched_kv = True
+        # mask_features handed over as FoldedMaskFeatures are contracted in their 64-channel factored form (fused tails only)
+        self.folded_mask_features = True
+        self._fold_cache = None
         # the row-local ops between the attention cores run as three fused kernels per layer (csrc/dec_chain.hip)
         # instead of 13 launches; needs E = 256, mask_dim = 256 and dim_feedforward % 256 == 0 (every MSMFormer yaml)
         self.fused_tails = (hidden_dim == 256 and mask_dim == 256 and dim_feedforward % 256 == 0)
@@ -337,6 +372,28 @@ class MeanShiftTransformerDecoder(nn.Module):
             self._tails_cache = (key, {k: [ops.dec_pack_weight(w.contiguous()) for w in ws] for k, ws in groups.items()})
         return self._tails_cache[1]
 
+    def _folded_head(self, fm):
+        """Last mask_embed layer with the mask_features projection folded in (see FoldedMaskFeatures): for
+        e = d2 W3^T + b3 the step needs e Wm (64 columns) and e.bm (one), i.e. a Linear with weight [Wm^T W3 ; bm^T W3]
+        and bias [Wm^T b3 ; bm.b3] -- evaluated in fp64 once per parameter version, zero-padded to the 256 rows the
+        heads kernel writes, packed like the other tail weights.  Returns (packed weight, bias, n_columns)."""
+        l3 = self.mask_embed.layers[-1]
+        params = (l3.weight, l3.bias, fm.weight) + ((fm.bias,) if fm.bias is not None else ())
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._fold_cache is None or self._fold_cache[0] != key:
+            wm = fm.weight.detach().double().reshape(fm.weight.shape[0], -1)             # (mask_dim, 64)
+            bm = fm.bias.detach().double() if fm.bias is not None else torch.zeros(wm.shape[0], dtype=torch.float64, device=wm.device)
+            w3, b3 = l3.weight.detach().double(), l3.bias.detach().double()
+            n = wm.shape[1]
+            w = torch.zeros_like(w3)
+            b = torch.zeros_like(b3)
+            w[:n] = wm.t() @ w3
+            w[n] = bm @ w3
+            b[:n] = wm.t() @ b3
+            b[n] = bm @ b3
+            self._fold_cache = (key, ops.dec_pack_weight(w.float().contiguous()), b.float().contiguous(), n)
+        return self._fold_cache[1:]
+
     def _forward_fused(self, xs, sizes, kv_w, kv_c, mask_features, out, qpos, kv_all=None):
         """Same arithmetic as the loop in forward(), with the row-local ops of a layer in three launches:
         heads (+ next cross-attention query) -> mask step -> K/V GEMM -> cross attention -> post_cross (out_proj, LN,
@@ -347,6 +404,12 @@ class MeanShiftTransformerDecoder(nn.Module):
         H = self.num_heads
         pk = self._packed_tails()
         mlp = [(pk["mlp"][j], l.bias) for j, l in enumerate(self.mask_embed.layers)]
+        ncol = None
+        if isinstance(mask_features, FoldedMaskFeatures):
+            # the heads kernel emits [e Wm | e.bm | 0...] instead of e; the mask step runs on the 64-channel activation
+            wf, bf, ncol = self._folded_head(mask_features)
+            mlp[-1] = (wf, bf)
+            mask_features = mask_features.act
         dn = self.decoder_norm
         pred_cls, pred_mask = [], []
 
@@ -355,9 +418,10 @@ class MeanShiftTransformerDecoder(nn.Module):
             want = full or last
             cls = ops.gemm(d, self.class_embed.weight, self.class_embed.bias) if want else None
             tgt = None if (last and not full) else sizes[i_next % self.num_feature_levels]
-            m, attn, row_any = ops.mask_logits(e, mask_features, want_mask=want, target_size=tgt, sparse=self.sparse_taps,
+            emb, qb = (e, None) if ncol is None else (e[..., :ncol], e[..., ncol])
+            m, attn, row_any = ops.mask_logits(emb, mask_features, want_mask=want, target_size=tgt, sparse=self.sparse_taps,
                                                row_any=ra,       # ra: cleared by the heads kernel, no fill launch
-                                               packed_bf16=self._packed_mf)
+                                               packed_bf16=self._packed_mf, qbias=qb)
             pred_cls.append(cls)
             pred_mask.append(m)
             return attn, row_any
@@ -427,10 +491,16 @@ class MeanShiftTransformerDecoder(nn.Module):
                     src.append(ops.conv1x1_nchw_to_tokens(xs[i].contiguous(), wt, bias.contiguous()))
                 else:
                     src.append(ops.transpose_last2(xs[i].contiguous().flatten(2)) + self.level_embed.weight[i])
-        mask_features = mask_features.contiguous()
+        folded = isinstance(mask_features, FoldedMaskFeatures)
+        if folded and not (self.folded_mask_features and self.fused_tails and self.fold_kv and mask_features.act.shape[1] % 32 == 0
+                           and mask_features.act.shape[1] < self.query_feat.weight.shape[1]):
+            mask_features, folded = mask_features.tensor(), False           # literal order: materialise (B, mask_dim, H, W)
+        if not folded:
+            mask_features = mask_features.contiguous()
         if self.mask_step_dtype not in ("f32", "bf16"):
             raise ValueError("mask_step_dtype must be 'f32' or 'bf16'")
-        self._packed_mf = ops.pack_mask_features_bf16(mask_features) if self.mask_step_dtype == "bf16" else None
+        mf_planes = mask_features.act if folded else mask_features
+        self._packed_mf = ops.pack_mask_features_bf16(mf_planes) if self.mask_step_dtype == "bf16" else None
         qpos = self.query_embed.weight
         qf = self.query_feat.weight
         qkey = (B, qf.data_ptr(), qf._version)
@@ -819,7 +889,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 src = layer.forward_tokens(src, lvl_pos, ss, starts)
         return src, shapes, fpn_stats
 
-    def _fpn_mask_features(self, features, up_tok, up_hw, fpn_stats):
+    def _fpn_mask_features(self, features, up_tok, up_hw, fpn_stats, folded=False):
         """The one FPN level on res2 and the mask_features convolution (MSD:343-358); up_tok: the finest encoder level as a
         token-range view of the encoder's buffer."""
         C = self.conv_dim
@@ -840,7 +910,13 @@ class MSDeformAttnPixelDecoder(nn.Module):
         if C == 64 and self.mask_dim in (256, 512) and (H * W) % 4 == 0 and B <= 64:
             # layer_1's GroupNorm + ReLU is applied to the operand fragments of the mask_features convolution
             gn = (y_stats, self.layer_1.norm.weight, self.layer_1.norm.bias, 32, self.layer_1.norm.eps)
-            mask_features = ops.tokens_proj_nchw(y, wm, self.mask_features.bias, gn=gn, relu=True).view(B, self.mask_dim, H, W)
+            literal = lambda: ops.tokens_proj_nchw(y, wm, self.mask_features.bias, gn=gn, relu=True).view(B, self.mask_dim, H, W)
+            if folded:
+                # hand over the factored form: the 64-channel activation as NCHW planes + the 1x1 weight (FoldedMaskFeatures)
+                act = ops.groupnorm_nchw(y, y_stats, self.layer_1.norm.weight, self.layer_1.norm.bias, groups=32,
+                                         eps=self.layer_1.norm.eps, relu=True).view(B, C, H, W)
+                return FoldedMaskFeatures(act, wm, self.mask_features.bias, literal)
+            mask_features = literal()
         else:
             y = ops.groupnorm_tokens(y, self.layer_1.norm.weight, self.layer_1.norm.bias, H, W, groups=32, relu=True,
                                      eps=self.layer_1.norm.eps)
@@ -848,7 +924,10 @@ class MSDeformAttnPixelDecoder(nn.Module):
         return mask_features
 
     @torch.no_grad()
-    def forward_features(self, features):
+    def forward_features(self, features, folded=False):
+        """Returns (mask_features, encoder level 0, multi-scale features) like the reference.  ``folded=True`` (asked for by a
+        head whose predictor understands it) returns mask_features as FoldedMaskFeatures instead of a (B, mask_dim, H, W)
+        tensor."""
         C = self.conv_dim
         src, shapes, fpn_stats = self._encode(features)
         B = src.shape[0]
@@ -859,5 +938,5 @@ class MSDeformAttnPixelDecoder(nn.Module):
             out.append(src[:, o:o + h * w].view(B, h, w, C).permute(0, 3, 1, 2))
             o += h * w
         up_tok = src[:, o - shapes[-1][0] * shapes[-1][1]:]                       # finest level, source of the FPN upsample (a view)
-        mask_features = self._fpn_mask_features(features, up_tok, shapes[-1], fpn_stats)
+        mask_features = self._fpn_mask_features(features, up_tok, shapes[-1], fpn_stats, folded)
         return mask_features, out[0], out[:self.maskformer_num_feature_levels]

@@ -300,6 +300,18 @@ def groupnorm_tokens(x, gamma, beta, H, W, groups=32, *, up=None, up_hw=None, re
     return y
 
 
+def groupnorm_nchw(x, stats, gamma, beta, *, groups=32, eps=1e-5, relu=False):
+    """GroupNorm (+ReLU) of a token map x (B, HW, C) from its moments ``stats`` (B, C, 2) float64, written as NCHW planes
+    (B, C, HW): the activation the folded mask step contracts with.  C <= 128, HW % 4 == 0."""
+    _c(x, "x"), _c(stats, "stats", torch.float64), _c(gamma, "gamma"), _c(beta, "beta")
+    B, HW, C = x.shape
+    y = torch.empty((B, C, HW), device=x.device, dtype=torch.float32)
+    rc = lib().msm_groupnorm_apply_nchw_f32(_p(x), _p(stats), _p(gamma), _p(beta), _p(y), B, HW, C, int(groups), float(eps),
+                                            1 if relu else 0, _stream())
+    check(rc, "msm_groupnorm_apply_nchw_f32")
+    return y
+
+
 def groupnorm_stats(x, stats=None):
     """Per-(image, channel) double (sum, sum of squares) of a token map x (B, HW, C) -> (B, C, 2) float64.  ``stats``: a
     ZEROED (B, C, 2) float64 tensor to accumulate into (then no fill launch is issued)."""
@@ -370,14 +382,27 @@ def pack_mask_features_bf16(mask_features):
     return out
 
 
-def mask_logits(mask_embed, mask_features, *, want_mask=True, target_size=None, sparse=False, row_any=None, packed_bf16=None):
-    """einsum('bqc,bchw->bqhw') with the next layer's attention mask fused.
+def mask_logits(mask_embed, mask_features, *, want_mask=True, target_size=None, sparse=False, row_any=None, packed_bf16=None,
+                qbias=None):
+    """einsum('bqc,bchw->bqhw') (+ qbias[b, q]) with the next layer's attention mask fused.
     Returns (mask (B,Q,H,W) or None, attn (B,Q,th*tw) uint8 or None, row_any (B,Q) int32 or None).
+    mask_embed: (B,Q,C), contiguous or the leading C columns of a wider row-major buffer; qbias: (B,Q) per-query constant
+    (any uniform element stride) -- together they serve the folded form of the step (modeling.FoldedMaskFeatures).
     row_any: an already ZEROED (B,Q) int32 buffer (dec_heads(zero_row_any=True) provides one) -- saves the fill launch.
     packed_bf16: pack_mask_features_bf16(mask_features) -> the step runs with bf16 operands / fp32 accumulation."""
-    _c(mask_embed, "mask_embed"), _c(mask_features, "mask_features")
+    _chk(mask_embed, "mask_embed"), _c(mask_features, "mask_features"), _chk(qbias, "qbias")
     B, Q, C = mask_embed.shape
-    _, _, H, W = mask_features.shape
+    if mask_embed.stride(2) != 1 or (B > 1 and mask_embed.stride(0) != Q * mask_embed.stride(1)) or mask_embed.stride(1) < C:
+        raise RuntimeError("mask_embed must be (B,Q,C) with unit column stride and uniformly spaced rows")
+    embed_ld = mask_embed.stride(1)
+    qb_ld = 0
+    if qbias is not None:
+        if tuple(qbias.shape) != (B, Q) or (B > 1 and qbias.stride(0) != Q * qbias.stride(1)):
+            raise RuntimeError("qbias must be (B,Q) with uniformly spaced elements")
+        qb_ld = qbias.stride(1)
+    _, Cf, H, W = mask_features.shape
+    if Cf != C:
+        raise RuntimeError(f"mask_embed has {C} columns, mask_features {Cf} channels")
     dev = mask_embed.device
     mask = torch.empty((B, Q, H, W), device=dev, dtype=torch.float32) if want_mask else None
     attn = None
@@ -400,11 +425,11 @@ def mask_logits(mask_embed, mask_features, *, want_mask=True, target_size=None, 
     if packed_bf16 is not None:
         _c(packed_bf16, "packed_bf16", torch.int16)
         rc = lib().msm_mask_logits_bf16_fwd(_p(mask_embed), _p(packed_bf16), _p(mask), _p(attn), _p(row_any),
-                                            B, Q, C, H, W, th, tw, flags, _stream())
+                                            B, Q, C, H, W, th, tw, flags, embed_ld, _p(qbias), qb_ld, _stream())
         check(rc, "msm_mask_logits_bf16_fwd")
     else:
         rc = lib().msm_mask_logits_fwd(_p(mask_embed), _p(mask_features), _p(mask), _p(attn), _p(row_any),
-                                       B, Q, C, H, W, th, tw, flags, _stream())
+                                       B, Q, C, H, W, th, tw, flags, embed_ld, _p(qbias), qb_ld, _stream())
         check(rc, "msm_mask_logits_fwd")
     if ev is not None:
         ev[1].record()
