@@ -127,6 +127,7 @@ __device__ __forceinline__ void mask_tile_epilogue(const f32x4 (&acc)[QB][2 * NC
         const bool col_tap = col_ok && ((cleft % POOL) == POOL / 2 - 1) && (cleft + 1 < W);
         const int tx = cleft / POOL;
         const int ty = (ytop >= 0 ? ytop : 0) / POOL;
+        if (!row_tap) return;                     // wave-uniform: this row pair feeds no tap (every other pair at POOL 4, 3 of 4 at 8)
 #pragma unroll
         for (int m = 0; m < QB; ++m) {
 #pragma unroll
