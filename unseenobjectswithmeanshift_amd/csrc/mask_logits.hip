@@ -60,11 +60,15 @@ __device__ __forceinline__ Cols<NC> ld_cols(__amdgpu_buffer_rsrc_t rsrc, unsigne
     return c;
 }
 
+__device__ __forceinline__ float dpp_next_in_row(float v) {   // lane i <- lane i + 1 within its row of 16 lanes (row_shl:1)
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x101, 0xf, 0xf, true));
+}
+
 // Per-tile epilogue shared by the fp32 and bf16 kernels: lane holds queries q0 + m*16 + lq*4 + r, columns c..c+NC-1 of
 // rows ytop (acc[.][cc]) and ybot (acc[.][NC+cc]).
 template <int POOL, bool WRITE, int NC>
 __device__ __forceinline__ void mask_tile_epilogue(const f32x4 (&acc)[QB][2 * NC], float* __restrict__ mask_out,
-                                                   uint8_t* __restrict__ attn_out, int32_t* __restrict__ row_any, int b, int Q,
+                                                   uint8_t* __restrict__ attn_out, int* __restrict__ any_flags, int b, int Q,
                                                    int q0, int H, int W, int th, int tw, int ytop, int ybot, int c, bool col_ok,
                                                    int lj, int lq) {
     const int HW = H * W;
@@ -112,7 +116,7 @@ __device__ __forceinline__ void mask_tile_epilogue(const f32x4 (&acc)[QB][2 * NC
                         if (ytop >= 0) { const bool mk = acc[m][cc][r] < 0.f; o[(int64_t)ytop * W + cc] = mk; any |= !mk; }
                         if (ybot < H) { const bool mk = acc[m][NC + cc][r] < 0.f; o[(int64_t)ybot * W + cc] = mk; any |= !mk; }
                     }
-                    if (any) row_any[(int64_t)b * Q + q] = 1;
+                    if (any) any_flags[q - q0] = 1;
                 }
             }
         }
@@ -136,15 +140,17 @@ __device__ __forceinline__ void mask_tile_epilogue(const f32x4 (&acc)[QB][2 * NC
                 if constexpr (IN_LANE) {
                     s = (acc[m][0][r] + acc[m][1][r]) + (acc[m][2][r] + acc[m][3][r]);
                 } else {
-                    const float n0 = __shfl_down(acc[m][0][r], 1, 64);
-                    const float n2 = __shfl_down(acc[m][NC][r], 1, 64);
+                    // the right tap is the next lane of the same 16-lane row (a left tap is never lane 15: cleft % POOL ==
+                    // POOL/2 - 1 is odd): a DPP row shift instead of a ds_bpermute through the LDS crossbar
+                    const float n0 = dpp_next_in_row(acc[m][0][r]);
+                    const float n2 = dpp_next_in_row(acc[m][NC][r]);
                     s = (acc[m][NC - 1][r] + n0) + (acc[m][2 * NC - 1][r] + n2);
                 }
                 const int q = q0 + m * 16 + qlane + r;
                 if (row_tap && col_tap && q < Q && tx < tw && ty < th) {
                     const bool masked = s < 0.f;
                     attn_out[((int64_t)b * Q + q) * (th * tw) + ty * tw + tx] = masked ? 1 : 0;
-                    if (!masked) row_any[(int64_t)b * Q + q] = 1;
+                    if (!masked) any_flags[q - q0] = 1;      // LDS: flushed to row_any once per workgroup (not one hot global store per tile)
                 }
             }
             __builtin_amdgcn_sched_barrier(0);   // one row block at a time: keeps the epilogue's live set (shuffled
@@ -189,7 +195,11 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_kernel(const float* __res
         d[1] = make_float2(v.z, v.w);
     }
     float* qb = Es + QCH * SE;
-    for (int r = tid; r < QCH; r += MW * 64) qb[r] = (qbias && q0 + r < Q) ? qbias[((int64_t)b * Q + q0 + r) * qbias_ld] : 0.f;
+    int* any_flags = reinterpret_cast<int*>(qb + QCH);
+    for (int r = tid; r < QCH; r += MW * 64) {
+        qb[r] = (qbias && q0 + r < Q) ? qbias[((int64_t)b * Q + q0 + r) * qbias_ld] : 0.f;
+        any_flags[r] = 0;
+    }
     __syncthreads();
 
     const int ctiles = (W + TW - 1) / TW;
@@ -274,7 +284,12 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_kernel(const float* __res
         }
         if (g < G) compute_group(tA, bA, g * (4 * KU));   // odd number of groups
 
-        mask_tile_epilogue<POOL, WRITE, NC>(acc, mask_out, attn_out, row_any, b, Q, q0, H, W, th, tw, ytop, ybot, c, col_ok, lj, lq);
+        mask_tile_epilogue<POOL, WRITE, NC>(acc, mask_out, attn_out, any_flags, b, Q, q0, H, W, th, tw, ytop, ybot, c, col_ok, lj, lq);
+    }
+    if constexpr (POOL != 0) {
+        __syncthreads();
+        for (int r = tid; r < QCH; r += MW * 64)
+            if (any_flags[r] && q0 + r < Q) row_any[(int64_t)b * Q + q0 + r] = 1;
     }
 }
 
@@ -312,7 +327,11 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_bf16_kernel(const float* 
 
     const float* eb = emb + ((int64_t)b * Q + q0) * emb_ld;
     float* qb = reinterpret_cast<float*>(Eb + QCH * SEb);
-    for (int r = tid; r < QCH; r += MW * 64) qb[r] = (qbias && q0 + r < Q) ? qbias[((int64_t)b * Q + q0 + r) * qbias_ld] : 0.f;
+    int* any_flags = reinterpret_cast<int*>(qb + QCH);
+    for (int r = tid; r < QCH; r += MW * 64) {
+        qb[r] = (qbias && q0 + r < Q) ? qbias[((int64_t)b * Q + q0 + r) * qbias_ld] : 0.f;
+        any_flags[r] = 0;
+    }
     for (int idx = tid; idx < QCH * (C / 4); idx += MW * 64) {
         const int r = idx / (C / 4), c4 = (idx - r * (C / 4)) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -386,12 +405,17 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_bf16_kernel(const float* 
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        mask_tile_epilogue<POOL, WRITE, 1>(acc, mask_out, attn_out, row_any, b, Q, q0, H, W, th, tw, ytop, ybot, c, col_ok, lj, lq);
+        mask_tile_epilogue<POOL, WRITE, 1>(acc, mask_out, attn_out, any_flags, b, Q, q0, H, W, th, tw, ytop, ybot, c, col_ok, lj, lq);
 #pragma unroll
         for (int ks = 0; ks < BKS; ++ks) {
             cur.t[ks] = nxt.t[ks];
             cur.bt[ks] = nxt.bt[ks];
         }
+    }
+    if constexpr (POOL != 0) {
+        __syncthreads();
+        for (int r = tid; r < QCH; r += MW * 64)
+            if (any_flags[r] && q0 + r < Q) row_any[(int64_t)b * Q + q0 + r] = 1;
     }
 }
 
@@ -475,7 +499,7 @@ extern "C" int msm_mask_logits_fwd(const float* mask_embed, const float* mask_fe
     const int target = cdiv(256, B * qchunks);
     if (wg_per > target) wg_per = max(target, 1);
     dim3 grid(wg_per, qchunks, B), block(MW * 64);
-    const size_t lds = sizeof(float) * ((size_t)QCH * (C + 2) + QCH);
+    const size_t lds = sizeof(float) * ((size_t)QCH * (C + 2) + 2 * QCH);
     typedef void (*kern_t)(const float*, const float*, float*, uint8_t*, int32_t*, int, int, int, int, int, int, int, int, int, int, int, int64_t,
                            const float*, int64_t);
     kern_t kern;
@@ -550,7 +574,7 @@ extern "C" int msm_mask_logits_bf16_fwd(const float* mask_embed, const uint16_t*
     const int target = cdiv(tgt_total, B * qchunks);
     if (wg_per > target) wg_per = max(target, 1);
     dim3 grid(wg_per, qchunks, B), block(MW * 64);
-    const size_t lds = sizeof(unsigned short) * (size_t)QCH * (C + 8) + sizeof(float) * QCH;
+    const size_t lds = sizeof(unsigned short) * (size_t)QCH * (C + 8) + sizeof(float) * 2 * QCH;
     typedef void (*kern_t)(const float*, const unsigned short*, float*, uint8_t*, int32_t*, int, int, int, int, int, int, int, int, int, int, int,
                            int64_t, const float*, int64_t);
     const bool wr = mask_out != nullptr;
