@@ -54,9 +54,12 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     write = 1024.0 * sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"])
     json.dump({"kernel": "mask_logits_kernel", "bytes_per_launch": round(fetch + write),
                "fetch_bytes_corrected": round(fetch), "write_bytes": round(write),
-               "algorithmic_bytes_per_launch": 8 * (256 * 19200 + 100 * 256) * 4 + (8 * 100 * 19200 * 4) // 10,
+               # folded step (bench default): the 64-channel activation, the folded embedding and a tenth of the final mask;
+               # the literal 256-channel contraction would be 8 * (256 * 19200 + 100 * 256) * 4 + the same mask share
+               "algorithmic_bytes_per_launch": 8 * (64 * 19200 + 100 * 64) * 4 + (8 * 100 * 19200 * 4) // 10,
                "note": "mean over the 10 launches of a step (9 write only attention-mask bytes, 1 writes the full mask); "
-                       "FETCH_SIZE doubled per MI355X_MICROARCH.md (HBM section), WRITE_SIZE as reported",
+                       "FETCH_SIZE doubled per MI355X_MICROARCH.md (HBM section), WRITE_SIZE as reported; folded mask step "
+                       "(64-channel activation instead of the 256-channel mask_features tensor)",
                "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes ({tag})"},
               open("profiles/mask_step_traffic.json", "w"), indent=1)
 print("ok")
