@@ -247,6 +247,39 @@ def test_pixel_decoder_small_vs_reference(golden):
     assert enc0 is ms[0]
 
 
+def test_folded_mask_step_equals_literal():
+    """The head hands the decoder the mask features in factored form (FoldedMaskFeatures: 64-channel activation + 1x1 weight)
+    and the mask step contracts e.Wm with the activation plus e.bm; with folding off the literal (B,256,H,W) tensor is
+    contracted.  Same predictions up to fp32 summation order; the factored object materialises the literal tensor."""
+    from unseenobjectswithmeanshift_amd.modeling import FoldedMaskFeatures
+    head = make_pixel_decoder()
+    feats = {k: v.to(DEV) for k, v in syn.synth_backbone_features(2, 64, 96, seed=9).items()}
+    fm, _, ms = head.pixel_decoder.forward_features(feats, folded=True)
+    mf, _, _ = head.pixel_decoder.forward_features(feats)
+    assert isinstance(fm, FoldedMaskFeatures) and fm.shape == mf.shape and fm.act.shape == (2, 64, 16, 24)
+    torch.testing.assert_close(fm.tensor(), mf, rtol=0, atol=0)
+    lit = torch.einsum("ck,bkhw->bchw", head.pixel_decoder.mask_features.weight.view(256, 64).double(), fm.act.double()) \
+        + head.pixel_decoder.mask_features.bias.double()[None, :, None, None]
+    torch.testing.assert_close(mf.double(), lit, rtol=1e-5, atol=1e-5)
+    dec = head.predictor
+    dec.aux_outputs = True
+    a = dec(ms, fm)
+    dec.folded_mask_features = False
+    b = dec(ms, fm)                                    # folding off: the object is materialised and contracted literally
+    c = dec(ms, mf)
+    dec.folded_mask_features = True
+    dec.aux_outputs = False
+    assert torch.equal(b["pred_masks"], c["pred_masks"])
+    torch.testing.assert_close(a["pred_logits"], c["pred_logits"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(a["pred_masks"], c["pred_masks"], rtol=1e-4, atol=3e-4)
+    for x, y in zip(a["aux_outputs"], c["aux_outputs"]):
+        flips = ((x["pred_masks"] > 0) != (y["pred_masks"] > 0)).float().mean().item()
+        assert flips < 1e-4
+    # the head asks for the factored form by itself
+    out, _ = head(feats)
+    torch.testing.assert_close(out["pred_masks"], a["pred_masks"], rtol=0, atol=0)
+
+
 def test_pixel_decoder_front_variants_agree():
     """Fused front end (input projections with GroupNorm moments + one prologue pass) against the separate GEMM /
     GroupNorm / value / sampling launches, and a fused pass repeated (bitwise reproducible)."""
