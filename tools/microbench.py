@@ -136,7 +136,8 @@ def attn():
         ra = torch.ones(B, 100, device=DEV, dtype=torch.int32)
         t = timeit_graph(lambda: ops.hypersphere_attention(q, k[..., :E], k[..., E:], 8, masked=m, row_any=ra))
         fl = 2.0 * 2 * B * 100 * S * E
-        print(f"hs_attn S={S}: {t:7.1f} us  {fl / t / 1e6:6.1f} TFLOP/s", flush=True)
+        t0 = timeit_graph(lambda: ops.hypersphere_attention(q, k[..., :E], k[..., E:], 8))
+        print(f"hs_attn S={S}: {t:7.1f} us  {fl / t / 1e6:6.1f} TFLOP/s   (without a mask: {t0:6.1f} us)", flush=True)
 
 
 def kv():
