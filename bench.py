@@ -184,7 +184,8 @@ def main():
     folded = bool(model.sem_seg_head.predictor.folded_mask_features) and args.mask_step == "f32"
     executed = flops_per_launch * (64.0 / C_MASK if folded else 1.0)
     # algorithmic bytes of a bf16 launch: packed features + fp32 mask_embed + (one of ten launches) the fp32 mask
-    bf16_bytes = (hi - lo) * (C_MASK * (H // 4) * (W // 4) * 2 + Q * C_MASK * 4 + Q * (H // 4) * (W // 4) * 4 // 10)
+    c_read = 64 if bool(model.sem_seg_head.predictor.folded_mask_features) else C_MASK     # channels the step actually streams
+    bf16_bytes = (hi - lo) * (c_read * (H // 4) * (W // 4) * 2 + Q * c_read * 4 + Q * (H // 4) * (W // 4) * 4 // 10)
     # HBM traffic of the same kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; the
     # gfx950 x2 correction on FETCH_SIZE applied), summarised in profiles/ -- it cannot be measured in-process
     traffic = None
