@@ -54,7 +54,7 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 5   /* 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
+#define MSM_ABI_VERSION 6   /* 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
 int msm_abi_version(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -318,7 +318,8 @@ int msm_ms_relabel_largest_zero(int64_t* labels, int n, const int64_t* counts, i
  *   (align_corners=False), pred_masks [B][T][H*W] = (m > 0), mask_score [B][T] =
  *   sum(sigmoid(m)*[m>0]) / (sum([m>0]) + 1e-6), multiplied by class_scores [B][T] when that pointer
  *   is not NULL (result.scores, :495); boxes [B][T][4] = x0,y0,x1+1,y1+1 (zeros if empty).
- *   workspace floats >= B*T*8, zeroed here.
+ *   workspace floats >= msm_instance_postprocess_workspace(B, T, H, W) (one 32-byte partial per instance and workgroup; no
+ *   atomics: the partials are added in strip order by the finishing kernel).
  * ------------------------------------------------------------------------------------------- */
 /* Canonical top-k over the Q*K object-class scores of every image (pretrained_meanshiftformer_model.py:
  * 466-474): scores = softmax(pred_logits [B][Q][K+1])[:, :-1] flattened to Q*K entries (index =
@@ -328,6 +329,7 @@ int msm_ms_relabel_largest_zero(int64_t* labels, int n, const int64_t* counts, i
 int msm_topk_class_scores(const float* pred_logits, int B, int Q, int K1, int T,
                           float* scores_out, int64_t* classes_out, int32_t* query_index_out, void* stream);
 
+int64_t msm_instance_postprocess_workspace(int B, int T, int H, int W);
 int msm_instance_postprocess(const float* mask_logits, const int32_t* query_index,
                              const float* class_scores, float* pred_masks, float* mask_score, float* boxes,
                              int B, int Q, int T, int h, int w, int H, int W, int Hs, int Ws,

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmsm_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "msm_hip.h")
 
 _lib = None
-ABI_VERSION = 5      # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
+ABI_VERSION = 6      # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
 
 c_f = ctypes.c_void_p      # float* (device)
 c_p = ctypes.c_void_p
@@ -67,6 +67,7 @@ _SIGNATURES = {
     "msm_encoder_prologue_stream_floats": (c_l, [c_i]),
     "msm_encoder_prologue_fwd": (c_i, [c_f, c_p, c_f, c_p, c_i, c_i, c_fl, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p]),
     "msm_label_stats": (c_i, [c_f, c_f, c_p, c_f, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "msm_instance_postprocess_workspace": (c_l, [c_i, c_i, c_i, c_i]),
     "msm_instance_postprocess": (c_i, [c_f, c_p, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
 }
 

@@ -58,6 +58,30 @@ __device__ __forceinline__ void src_index(int dst, float scale, int in, int& i0,
     l1 = src - (float)i0;
 }
 
+// One partial per workgroup, no atomics: 90 workgroups of an instance used to queue six same-line atomics each behind one
+// another at L2 (that queue, not the 197 MB of stores, set the kernel's 81 us); the finish kernel adds the partials of an
+// instance in strip order (so the score no longer depends on the arrival order either).  The wave results meet in LDS.
+__device__ __forceinline__ void inst_store_partial(InstAcc* __restrict__ acc, int bt, double sum, unsigned int cnt, int xmin,
+                                                   int ymin, int xmax, int ymax) {
+    __shared__ InstAcc wacc[4];
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) wacc[wave] = InstAcc{sum, cnt, xmin, ymin, xmax, ymax, 0};
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        InstAcc a = wacc[0];
+        for (int w = 1; w < nw; ++w) {
+            a.sum_sig += wacc[w].sum_sig;
+            a.cnt += wacc[w].cnt;
+            a.xmin = min(a.xmin, wacc[w].xmin);
+            a.ymin = min(a.ymin, wacc[w].ymin);
+            a.xmax = max(a.xmax, wacc[w].xmax);
+            a.ymax = max(a.ymax, wacc[w].ymax);
+        }
+        const int parts = gridDim.x * gridDim.y;
+        acc[(int64_t)bt * parts + blockIdx.y * gridDim.x + blockIdx.x] = a;
+    }
+}
+
 // grid (tiles_x, rows/ROWS, B*T); each block upsamples a strip of the selected mask
 __global__ __launch_bounds__(256) void inst_upsample_kernel(const float* __restrict__ logits, const int32_t* __restrict__ qidx,
                                                             float* __restrict__ masks, InstAcc* __restrict__ acc, int Q, int T,
@@ -129,15 +153,7 @@ __global__ __launch_bounds__(256) void inst_upsample_kernel(const float* __restr
         xmax = max(xmax, __shfl_xor(xmax, o, 64));
         ymax = max(ymax, __shfl_xor(ymax, o, 64));
     }
-    if ((threadIdx.x & 63) == 0 && cnt > 0) {
-        InstAcc* a = acc + bt;
-        atomicAdd(&a->sum_sig, sum);
-        atomicAdd(&a->cnt, cnt);
-        atomicMin(&a->xmin, xmin);
-        atomicMin(&a->ymin, ymin);
-        atomicMax(&a->xmax, xmax);
-        atomicMax(&a->ymax, ymax);
-    }
+    inst_store_partial(acc, bt, sum, cnt, xmin, ymin, xmax, ymax);
 }
 
 // The same strip for the 4x case every shipped configuration hits (mask logits at 1/4 of the padded frame, W % 4 == 0):
@@ -236,27 +252,23 @@ __global__ __launch_bounds__(256) void inst_upsample4_kernel(const float* __rest
         xmax = max(xmax, __shfl_xor(xmax, o, 64));
         ymax = max(ymax, __shfl_xor(ymax, o, 64));
     }
-    if ((threadIdx.x & 63) == 0 && cnt > 0) {
-        InstAcc* a = acc + bt;
-        atomicAdd(&a->sum_sig, sum);
-        atomicAdd(&a->cnt, cnt);
-        atomicMin(&a->xmin, xmin);
-        atomicMin(&a->ymin, ymin);
-        atomicMax(&a->xmax, xmax);
-        atomicMax(&a->ymax, ymax);
-    }
+    inst_store_partial(acc, bt, sum, cnt, xmin, ymin, xmax, ymax);
 }
 
-__global__ void inst_init_kernel(InstAcc* __restrict__ acc, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) acc[i] = InstAcc{0.0, 0u, 0x7fffffff, 0x7fffffff, -1, -1, 0};
-}
-
-__global__ void inst_finish_kernel(const InstAcc* __restrict__ acc, const float* __restrict__ class_scores,
+__global__ void inst_finish_kernel(const InstAcc* __restrict__ acc, int parts, const float* __restrict__ class_scores,
                                    float* __restrict__ score, float* __restrict__ boxes, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const InstAcc a = acc[i];
+    InstAcc a = InstAcc{0.0, 0u, 0x7fffffff, 0x7fffffff, -1, -1, 0};
+    for (int p = 0; p < parts; ++p) {
+        const InstAcc t = acc[(int64_t)i * parts + p];
+        a.sum_sig += t.sum_sig;
+        a.cnt += t.cnt;
+        a.xmin = min(a.xmin, t.xmin);
+        a.ymin = min(a.ymin, t.ymin);
+        a.xmax = max(a.xmax, t.xmax);
+        a.ymax = max(a.ymax, t.ymax);
+    }
     const float ms = (float)a.sum_sig / ((float)a.cnt + 1e-6f);
     score[i] = class_scores ? class_scores[i] * ms : ms;
     float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -280,6 +292,12 @@ extern "C" int msm_topk_class_scores(const float* pred_logits, int B, int Q, int
     return MSM_OK;
 }
 
+extern "C" int64_t msm_instance_postprocess_workspace(int B, int T, int H, int W) {
+    const int cols = (W % 4 == 0) ? W / 4 : W;
+    const int threads = min(256, cdiv(cols, 64) * 64);
+    return (int64_t)B * T * cdiv(cols, threads) * cdiv(H, 16) * (int64_t)(sizeof(InstAcc) / sizeof(float));
+}
+
 extern "C" int msm_instance_postprocess(const float* mask_logits, const int32_t* query_index,
                                         const float* class_scores, float* pred_masks,
                                         float* mask_score, float* boxes, int B, int Q, int T, int h, int w, int H, int W,
@@ -293,7 +311,6 @@ extern "C" int msm_instance_postprocess(const float* mask_logits, const int32_t*
     hipStream_t st = (hipStream_t)stream;
     InstAcc* acc = reinterpret_cast<InstAcc*>(workspace);
     const int n = B * T;
-    hipLaunchKernelGGL(inst_init_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, acc, n);
     const int rows = 16;
     const int cols = (W % 4 == 0) ? W / 4 : W;                 // threads needed across a row
     const int threads = min(256, cdiv(cols, 64) * 64);          // whole waves, no idle wave (640 px -> 192 threads)
@@ -304,7 +321,8 @@ extern "C" int msm_instance_postprocess(const float* mask_logits, const int32_t*
     else
         hipLaunchKernelGGL(inst_upsample_kernel, grid, dim3(threads), 0, st, mask_logits, query_index, pred_masks, acc, Q, T, h, w,
                            H, W, Hs, Ws, rows);
-    hipLaunchKernelGGL(inst_finish_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, acc, class_scores, mask_score, boxes, n);
+    hipLaunchKernelGGL(inst_finish_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, acc, (int)(grid.x * grid.y), class_scores, mask_score, boxes,
+                       n);
     MSM_CHECK_LAUNCH("msm_instance_postprocess");
     return MSM_OK;
 }

@@ -701,7 +701,7 @@ def instance_postprocess(mask_logits, query_index, image_size, class_scores=None
     masks = torch.empty((B, T, H, W), device=dev, dtype=torch.float32)
     score = torch.empty((B, T), device=dev, dtype=torch.float32)
     boxes = torch.empty((B, T, 4), device=dev, dtype=torch.float32)
-    ws = torch.empty((B * T * 8,), device=dev, dtype=torch.float32)
+    ws = torch.empty((int(lib().msm_instance_postprocess_workspace(B, T, H, W)),), device=dev, dtype=torch.float32)
     rc = lib().msm_instance_postprocess(_p(mask_logits), _p(query_index), _p(class_scores), _p(masks), _p(score), _p(boxes),
                                         B, Q, T, h, w, H, W, Hs, Ws, _p(ws), _stream())
     check(rc, "msm_instance_postprocess")
