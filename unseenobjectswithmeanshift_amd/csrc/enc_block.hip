@@ -99,6 +99,16 @@ __device__ __forceinline__ void layer_norm_L(float (&v)[4][4], const float* __re
     }
 }
 
+// One LDS-DMA piece: lane l's 16 bytes at sbase + voff(l) land at LDS byte address lds_dst + 16 l.  M0 is written in
+// the statement that reads it (it is compiler-reserved); both scalar operands come from SALU code (no VALU-to-SGPR hazard).
+__device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void enc_block_kernel(const float* __restrict__ attn, const float* __restrict__ src,
                                                         const float4* __restrict__ wstream, const float* __restrict__ small,
                                                         EncSmall so, const float* __restrict__ pos,
@@ -130,21 +140,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int ntail = next ? 1 + (nproj_blocks + 3) / 4 : 0;
     const int nsteps = 1 + nhf + ntail;
 
-    // ---- weight staging: 4 float4 per thread per half (one per block), swizzled into LDS ----
-    // destination float4 index inside a block for this thread (row blocks / linear2 blocks)
-    const int dst_row = (tid >> 4) * 16 + ((tid & 15) ^ (tid >> 4));
-    const int dst_w2 = (tid >> 2) * 4 + ((tid & 3) ^ ((tid >> 4) & 3));
-#define ENC_STAGE_LOAD(s_)                                                                     \
+    // ---- weight staging: LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction, 4 per wave and stage), issued at
+    // the START of the stage before the one that consumes it and awaited (vmcnt(0)) just before that stage's closing
+    // barrier, so a stage's weights travel while the previous stage's 64 MFMAs per wave run.  The DMA writes LDS
+    // lane-linearly, so the XOR swizzle is applied to the SOURCE index (both swizzles are involutions that stay inside
+    // a wave's 64 float4).  Inline asm because hipcc would otherwise wait for an LDS-DMA in flight before ANY LDS read;
+    // with compiler-visible loads staged through registers the loads were sunk next to their ds_write (latency exposed
+    // on every stage: 164 us per launch).
+    const unsigned off_row = (unsigned)((tid >> 4) * 16 + ((tid & 15) ^ (tid >> 4))) * 16u;
+    const unsigned off_w2 = (unsigned)((tid >> 2) * 4 + ((tid & 3) ^ ((tid >> 4) & 3))) * 16u;
+    const unsigned lds_wave = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float4*)wl + (unsigned)wave * 1024u;
+#define ENC_STAGE_PIECE(s_, bufi_, i_)                                                         \
     {                                                                                         \
         const int sh_ = (s_) == 0 ? 0 : (s_) + 1;                                             \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) stage[i] = wstream[(int64_t)sh_ * CHUNK_F4 + tid + 256 * i]; \
-    }
-#define ENC_STAGE_STORE(s_, buf)                                                               \
-    {                                                                                         \
         const bool ffn_ = (s_) >= 1 && (s_) <= nhf;                                           \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)(buf)[i * 256 + ((ffn_ && (i & 1)) ? dst_w2 : dst_row)] = stage[i]; \
+        const char* sb_ = reinterpret_cast<const char*>(wstream + (int64_t)sh_ * CHUNK_F4);   \
+        const unsigned ld_ = lds_wave + (unsigned)(bufi_) * (CHUNK_F4 * 16u);                 \
+        glds16(sb_ + (i_) * 4096, (ffn_ && ((i_) & 1)) ? off_w2 : off_row, ld_ + (i_) * 4096u); \
     }
-    float4 stage[4];
+#define ENC_STAGE_ISSUE(s_, bufi_)                                                             \
+    { ENC_STAGE_PIECE(s_, bufi_, 0) ENC_STAGE_PIECE(s_, bufi_, 1) ENC_STAGE_PIECE(s_, bufi_, 2) ENC_STAGE_PIECE(s_, bufi_, 3) }
+#define ENC_STAGE_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- tile inputs in layout L ----
     float act[4][4], res[4][4];
@@ -156,15 +172,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         res[fb][0] = r.x; res[fb][1] = r.y; res[fb][2] = r.z; res[fb][3] = r.w;
     }
 
-    ENC_STAGE_LOAD(0)
-    ENC_STAGE_STORE(0, wl)
+    ENC_STAGE_ISSUE(0, 0)
+    ENC_STAGE_WAIT()
     __syncthreads();
 
     float x[4][4];      // current activations (layout L)
     f32x4 acc2[4];
     // ---- step 0 (peeled: act/res die here): output_proj + residual + LayerNorm1 (msdeformattn.py:124-126) ----
     {
-        ENC_STAGE_LOAD(1)
+        ENC_STAGE_ISSUE(1, 1)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob) {
@@ -179,7 +195,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob) acc2[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_sched_barrier(0);
-        ENC_STAGE_STORE(1, wl + CHUNK_F4)
+        ENC_STAGE_WAIT()
         __syncthreads();
     }
     // ---- steps 1..nhf: FFN, 2 hidden blocks of 16 per stage; the hidden activation lives in 4 registers.  The 16
@@ -187,13 +203,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // linear2 MFMAs; both blocks' LDS fragments are requested up front.
     for (int s = 1; s <= nhf; ++s) {
         const float4* buf = wl + (s & 1) * CHUNK_F4;
-        // prefetch the next stage into registers; it is written to the other LDS buffer after this stage's MFMAs
-        {
-            const int sn = min(s + 1, nsteps - 1);
-            ENC_STAGE_LOAD(sn)
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (!coop || ((s - 1) & 3) == wave) {
+        // The next stage's weights travel into the other LDS buffer (every wave is past the barrier that followed its
+        // last read) while this stage computes; the four DMA pieces are issued between the MFMA groups, where their
+        // issue slots are free.
+        // (the last stage of a launch without tail stages re-fetches itself into the idle buffer: no branch between the
+        // MFMA groups)
+        const int sn = min(s + 1, nsteps - 1), bn = (s + 1) & 1;
+        if (!coop) {
             float4 w1[2][4], w2[2][4];
             f32x4 dd[2][2];
             rowblock_read(buf + 0 * 256, lj, lq, w1[0]);
@@ -209,7 +225,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
             dd[0][0] = dd[0][1] = dd[1][0] = dd[1][1] = f32x4{0.f, 0.f, 0.f, 0.f};
             rowblock_mma(w1[0], x, dd[0][0], dd[0][1]);
+            ENC_STAGE_PIECE(sn, bn, 0)
             rowblock_mma(w1[1], x, dd[1][0], dd[1][1]);
+            ENC_STAGE_PIECE(sn, bn, 1)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int hb = (s - 1) * 2 + q;
@@ -228,10 +246,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 for (int ob = 0; ob < 4; ++ob) acc2[ob] = mfma16(w2[q][ob].z, h[2], acc2[ob]);
 #pragma unroll
                 for (int ob = 0; ob < 4; ++ob) acc2[ob] = mfma16(w2[q][ob].w, h[3], acc2[ob]);
+                if (q == 0) ENC_STAGE_PIECE(sn, bn, 2) else ENC_STAGE_PIECE(sn, bn, 3)
             }
+        } else {
+            // cooperative tile: wave (cq, ch) = (wave >> 1, wave & 1) runs linear1 of hidden block cq and linear2 of that
+            // block into output blocks 2 ch, 2 ch + 1 (accumulated in acc2[0], acc2[1]; sorted out after the loop): 24 MFMAs
+            // per wave and stage on EVERY SIMD instead of 64 on one -- a stage-by-stage rotation would slow one wave of
+            // each co-resident workgroup in every stage, and their barriers make that the pace of all of them.
+            ENC_STAGE_ISSUE(sn, bn)
+            const int cq = wave >> 1, ch = wave & 1;
+            float4 w1c[4], w2c[2];
+            rowblock_read(buf + (2 * cq) * 256, lj, lq, w1c);
+            const float4* w2p = buf + (2 * cq + 1) * 256;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = (2 * ch + j) * 16 + lj;
+                w2c[j] = lds4(w2p, row * 4 + (lq ^ ((row >> 2) & 3)));
+            }
+            f32x4 d0 = f32x4{0.f, 0.f, 0.f, 0.f}, d1 = d0;
+            rowblock_mma(w1c, x, d0, d1);
+            const float4 b1 = *reinterpret_cast<const float4*>(sm + so.b1 + ((s - 1) * 2 + cq) * 16 + lq * 4);
+            f32x4 h = d0 + d1;
+            h[0] = fmaxf(h[0] + b1.x, 0.f);
+            h[1] = fmaxf(h[1] + b1.y, 0.f);
+            h[2] = fmaxf(h[2] + b1.z, 0.f);
+            h[3] = fmaxf(h[3] + b1.w, 0.f);
+            acc2[0] = mfma16(w2c[0].x, h[0], acc2[0]);
+            acc2[1] = mfma16(w2c[1].x, h[0], acc2[1]);
+            acc2[0] = mfma16(w2c[0].y, h[1], acc2[0]);
+            acc2[1] = mfma16(w2c[1].y, h[1], acc2[1]);
+            acc2[0] = mfma16(w2c[0].z, h[2], acc2[0]);
+            acc2[1] = mfma16(w2c[1].z, h[2], acc2[1]);
+            acc2[0] = mfma16(w2c[0].w, h[3], acc2[0]);
+            acc2[1] = mfma16(w2c[1].w, h[3], acc2[1]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < nsteps) ENC_STAGE_STORE(s + 1, wl + ((s + 1) & 1) * CHUNK_F4)
+        ENC_STAGE_WAIT()
         __syncthreads();
     }
 
@@ -240,6 +290,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // sum the four waves' partial linear2 outputs through the LDS stage that was consumed last (every wave is
         // past the barrier above, the next stage sits in the other buffer)
         float* red = reinterpret_cast<float*>(wl + (nhf & 1) * CHUNK_F4);
+        if (wave & 1) {          // this wave's two accumulators are output blocks 2, 3
+            acc2[2] = acc2[0];
+            acc2[3] = acc2[1];
+            acc2[0] = acc2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob)
             *reinterpret_cast<float4*>(red + ((wave * 4 + ob) * 64 + lane) * 4) =
@@ -277,17 +332,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // ---- tail stages: next layer's value_proj, then [sampling_offsets | attention_weights] 4 row blocks per stage ----
     for (int s = nhf + 1; s < nsteps; ++s) {
         const float4* buf = wl + (s & 1) * CHUNK_F4;
-        {
-            const int sn = min(s + 1, nsteps - 1);
-            ENC_STAGE_LOAD(sn)
-        }
+        if (s + 1 < nsteps) ENC_STAGE_ISSUE(s + 1, (s + 1) & 1)
         __builtin_amdgcn_sched_barrier(0);
         const int hh = s - nhf - 1;
-        const bool mine = !coop || (hh & 3) == wave;
+        // a cooperative tile's four waves take one row block each
         if (hh == 0) {
-            if (mine) {
+            {
 #pragma unroll
                 for (int ob = 0; ob < 4; ++ob) {
+                    if (coop && ob != wave) continue;
                     const f32x4 d = rowblock_mm(buf + ob * 256, lj, lq, x);
                     const float4 bv = *reinterpret_cast<const float4*>(sm + so.bv + ob * 16 + lq * 4);
                     if (tok_ok) {
@@ -309,12 +362,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 const float4 pp = *reinterpret_cast<const float4*>(pos + (int64_t)sp * EC + fb * 16 + lq * 4);
                 x[fb][0] += pp.x; x[fb][1] += pp.y; x[fb][2] += pp.z; x[fb][3] += pp.w;
             }
-        } else if (mine) {
+        } else {
             // proj output row blocks (hh-1)*4 .. +3
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int ob = (hh - 1) * 4 + j;
-                if (ob < nproj_blocks) {
+                if (ob < nproj_blocks && (!coop || j == wave)) {
                     const f32x4 d = rowblock_mm(buf + j * 256, lj, lq, x);
                     const float4 bp = *reinterpret_cast<const float4*>(sm + so.bp + ob * 16 + lq * 4);
                     if (tok_ok)
@@ -324,13 +377,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < nsteps) ENC_STAGE_STORE(s + 1, wl + ((s + 1) & 1) * CHUNK_F4)
+        ENC_STAGE_WAIT()
         __syncthreads();
     }
 }
 
-#undef ENC_STAGE_LOAD
-#undef ENC_STAGE_STORE
+#undef ENC_STAGE_ISSUE
+#undef ENC_STAGE_WAIT
 
 // ---------------------------------------------------------------------------------------------------------------
 // Encoder prologue: what precedes the first deformable-attention layer (msdeformattn.py:326-329 GroupNorm of the
