@@ -25,6 +25,8 @@
 
 namespace msm {
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 constexpr int EC = 64;                 // d_model
 constexpr int CHUNK_F4 = 1024;         // float4 per 16 KiB LDS stage = HALF a 32 KiB stream chunk (4 blocks of 256 float4)
 
@@ -39,33 +41,32 @@ __device__ __forceinline__ void rowblock_read(const float4* __restrict__ blk, in
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb) w[fb] = lds4(blk, lj * 16 + ((fb * 4 + lq) ^ lj));
 }
-// 16 MFMAs: consecutive instructions alternate between two accumulators, so no MFMA waits for the 40-cycle
-// dependent-accumulator latency of its predecessor.  d0 + d1 is the block's output in layout L.
-__device__ __forceinline__ void rowblock_mma(const float4 (&w)[4], const float (&act)[4][4], f32x4& d0, f32x4& d1) {
-    d0 = mfma16(w[0].x, act[0][0], d0);
-    d1 = mfma16(w[1].x, act[1][0], d1);
-    d0 = mfma16(w[2].x, act[2][0], d0);
-    d1 = mfma16(w[3].x, act[3][0], d1);
-    d0 = mfma16(w[0].y, act[0][1], d0);
-    d1 = mfma16(w[1].y, act[1][1], d1);
-    d0 = mfma16(w[2].y, act[2][1], d0);
-    d1 = mfma16(w[3].y, act[3][1], d1);
-    d0 = mfma16(w[0].z, act[0][2], d0);
-    d1 = mfma16(w[1].z, act[1][2], d1);
-    d0 = mfma16(w[2].z, act[2][2], d0);
-    d1 = mfma16(w[3].z, act[3][2], d1);
-    d0 = mfma16(w[0].w, act[0][3], d0);
-    d1 = mfma16(w[1].w, act[1][3], d1);
-    d0 = mfma16(w[2].w, act[2][3], d0);
-    d1 = mfma16(w[3].w, act[3][3], d1);
+// 16 MFMAs on ONE accumulator chain that starts from `d` (the bias): dependent fp32 MFMAs issue back to back at the full
+// rate, while every VALU instruction costs its SIMD about six cycles of MFMA issue (tools/probes/mfma_probe.hip) -- so
+// no second accumulator to add up afterwards and no separate bias add.  The result is in layout L.
+__device__ __forceinline__ void rowblock_mma(const float4 (&w)[4], const float (&act)[4][4], f32x4& d) {
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) d = mfma16(w[fb].x, act[fb][0], d);
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) d = mfma16(w[fb].y, act[fb][1], d);
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) d = mfma16(w[fb].z, act[fb][2], d);
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) d = mfma16(w[fb].w, act[fb][3], d);
 }
-__device__ __forceinline__ f32x4 rowblock_mm(const float4* __restrict__ blk, int lj, int lq, const float (&act)[4][4]) {
+__device__ __forceinline__ f32x4 rowblock_mm(const float4* __restrict__ blk, int lj, int lq, const float (&act)[4][4],
+                                             const float* __restrict__ bias) {
     float4 w[4];
     rowblock_read(blk, lj, lq, w);
-    f32x4 d0 = f32x4{0.f, 0.f, 0.f, 0.f}, d1 = d0;
-    rowblock_mma(w, act, d0, d1);
-    return d0 + d1;
+    const float4 b = *reinterpret_cast<const float4*>(bias + lq * 4);
+    f32x4 d = f32x4{b.x, b.y, b.z, b.w};
+    rowblock_mma(w, act, d);
+    return d;
 }
+
+// ReLU in ONE VALU instruction (v_med3_f32 x, 0, 3e38 -- a finite bound, or the compiler folds it back into fmaxf, which
+// costs two: it canonicalises its operand first)
+__device__ __forceinline__ float relu1(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 3.0e38f); }
 
 __device__ __forceinline__ void layer_norm_L(float (&v)[4][4], const float* __restrict__ g, const float* __restrict__ b,
                                              int lq, float eps) {
@@ -184,12 +185,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob) {
-            const f32x4 d = rowblock_mm(wl + ob * 256, lj, lq, act);
-            const float4 bo = *reinterpret_cast<const float4*>(sm + so.bo + ob * 16 + lq * 4);
-            x[ob][0] = d[0] + bo.x + res[ob][0];
-            x[ob][1] = d[1] + bo.y + res[ob][1];
-            x[ob][2] = d[2] + bo.z + res[ob][2];
-            x[ob][3] = d[3] + bo.w + res[ob][3];
+            const f32x4 d = rowblock_mm(wl + ob * 256, lj, lq, act, sm + so.bo + ob * 16);
+            x[ob][0] = d[0] + res[ob][0];
+            x[ob][1] = d[1] + res[ob][1];
+            x[ob][2] = d[2] + res[ob][2];
+            x[ob][3] = d[3] + res[ob][3];
         }
         layer_norm_L(x, sm + so.g1, sm + so.be1, lq, eps);
 #pragma unroll
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int sn = min(s + 1, nsteps - 1), bn = (s + 1) & 1;
         if (!coop) {
             float4 w1[2][4], w2[2][4];
-            f32x4 dd[2][2];
+            f32x4 dd[2];
             rowblock_read(buf + 0 * 256, lj, lq, w1[0]);
             rowblock_read(buf + 2 * 256, lj, lq, w1[1]);
 #pragma unroll
@@ -223,20 +223,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     w2[q][ob] = lds4(w2p, row * 4 + (lq ^ ((row >> 2) & 3)));
                 }
             }
-            dd[0][0] = dd[0][1] = dd[1][0] = dd[1][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            rowblock_mma(w1[0], x, dd[0][0], dd[0][1]);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {        // linear1's bias is the initial accumulator
+                const float4 b1 = *reinterpret_cast<const float4*>(sm + so.b1 + ((s - 1) * 2 + q) * 16 + lq * 4);
+                dd[q] = f32x4{b1.x, b1.y, b1.z, b1.w};
+            }
+            rowblock_mma(w1[0], x, dd[0]);
             ENC_STAGE_PIECE(sn, bn, 0)
-            rowblock_mma(w1[1], x, dd[1][0], dd[1][1]);
+            rowblock_mma(w1[1], x, dd[1]);
             ENC_STAGE_PIECE(sn, bn, 1)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int hb = (s - 1) * 2 + q;
-                const float4 b1 = *reinterpret_cast<const float4*>(sm + so.b1 + hb * 16 + lq * 4);
-                f32x4 h = dd[q][0] + dd[q][1];
-                h[0] = fmaxf(h[0] + b1.x, 0.f);
-                h[1] = fmaxf(h[1] + b1.y, 0.f);
-                h[2] = fmaxf(h[2] + b1.z, 0.f);
-                h[3] = fmaxf(h[3] + b1.w, 0.f);
+                f32x4 h = dd[q];
+                h[0] = relu1(h[0]);
+                h[1] = relu1(h[1]);
+                h[2] = relu1(h[2]);
+                h[3] = relu1(h[3]);
                 // linear2 of block q, order (r, ob): consecutive MFMAs hit different accumulators
 #pragma unroll
                 for (int ob = 0; ob < 4; ++ob) acc2[ob] = mfma16(w2[q][ob].x, h[0], acc2[ob]);
@@ -263,14 +265,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 const int row = (2 * ch + j) * 16 + lj;
                 w2c[j] = lds4(w2p, row * 4 + (lq ^ ((row >> 2) & 3)));
             }
-            f32x4 d0 = f32x4{0.f, 0.f, 0.f, 0.f}, d1 = d0;
-            rowblock_mma(w1c, x, d0, d1);
             const float4 b1 = *reinterpret_cast<const float4*>(sm + so.b1 + ((s - 1) * 2 + cq) * 16 + lq * 4);
-            f32x4 h = d0 + d1;
-            h[0] = fmaxf(h[0] + b1.x, 0.f);
-            h[1] = fmaxf(h[1] + b1.y, 0.f);
-            h[2] = fmaxf(h[2] + b1.z, 0.f);
-            h[3] = fmaxf(h[3] + b1.w, 0.f);
+            f32x4 h = f32x4{b1.x, b1.y, b1.z, b1.w};
+            rowblock_mma(w1c, x, h);
+            h[0] = relu1(h[0]);
+            h[1] = relu1(h[1]);
+            h[2] = relu1(h[2]);
+            h[3] = relu1(h[3]);
             acc2[0] = mfma16(w2c[0].x, h[0], acc2[0]);
             acc2[1] = mfma16(w2c[1].x, h[0], acc2[1]);
             acc2[0] = mfma16(w2c[0].y, h[1], acc2[0]);
@@ -329,6 +330,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 make_float4(x[ob][0], x[ob][1], x[ob][2], x[ob][3]);
     }
 
+    // ---- store addressing of the tail stages, once per tile: byte offsets into buffer descriptors (a scalar offset per
+    // row block instead of 64-bit VALU arithmetic per store), image / position of the token by ONE division ----
+    const int t_img = tk / S, t_pos = tk - t_img * S;
+    const bool v_affine = value_heads == 0 || EC / value_heads <= 16;
+    unsigned vo0 = (unsigned)tk * (EC * 4u) + lq * 16u, vstep = 64u;           // token-major
+    if (value_heads && v_affine) {
+        const int dh = EC / value_heads, f0 = lq * 4;
+        vo0 = (unsigned)((((int64_t)t_img * value_heads + f0 / dh) * S + t_pos) * dh + f0 % dh) * 4u;
+        vstep = (unsigned)S * 64u;                                             // 16 / dh heads further: 16 S floats
+    }
+    const unsigned po0 = (unsigned)tk * ((unsigned)proj_ld * 4u) + lq * 16u;
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)value_out, 0, next ? M * EC * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)proj_out, 0, next ? M * proj_ld * 4 : 0, 0x00020000);
     // ---- tail stages: next layer's value_proj, then [sampling_offsets | attention_weights] 4 row blocks per stage ----
     for (int s = nhf + 1; s < nsteps; ++s) {
         const float4* buf = wl + (s & 1) * CHUNK_F4;
@@ -341,25 +355,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
                 for (int ob = 0; ob < 4; ++ob) {
                     if (coop && ob != wave) continue;
-                    const f32x4 d = rowblock_mm(buf + ob * 256, lj, lq, x);
-                    const float4 bv = *reinterpret_cast<const float4*>(sm + so.bv + ob * 16 + lq * 4);
+                    const f32x4 d = rowblock_mm(buf + ob * 256, lj, lq, x, sm + so.bv + ob * 16);
                     if (tok_ok) {
                         // token-major [tok][64], or head-major [b][head][t][64/heads] for msm_msdeform_attn_enc_hm_fwd
-                        const int f = ob * 16 + lq * 4;
-                        int64_t o = (int64_t)tok * EC + f;
-                        if (value_heads) {
-                            const int dh = EC / value_heads, bi = tok / S, ti = tok - bi * S;
-                            o = (((int64_t)bi * value_heads + f / dh) * S + ti) * dh + f % dh;
+                        unsigned o = vo0 + (unsigned)ob * vstep;
+                        if (!v_affine) {
+                            const int f = ob * 16 + lq * 4, dh = EC / value_heads;
+                            o = (unsigned)((((int64_t)t_img * value_heads + f / dh) * S + t_pos) * dh + f % dh) * 4u;
                         }
-                        *reinterpret_cast<float4*>(value_out + o) = make_float4(d[0] + bv.x, d[1] + bv.y, d[2] + bv.z, d[3] + bv.w);
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(d[0]), __float_as_uint(d[1]), __float_as_uint(d[2]), __float_as_uint(d[3])}, vrs, o, 0, 0);
                     }
                 }
             }
             // query = src + pos (msdeformattn.py:124): add the level/position code once
-            const int sp = tk % S;
 #pragma unroll
             for (int fb = 0; fb < 4; ++fb) {
-                const float4 pp = *reinterpret_cast<const float4*>(pos + (int64_t)sp * EC + fb * 16 + lq * 4);
+                const float4 pp = *reinterpret_cast<const float4*>(pos + (int64_t)t_pos * EC + fb * 16 + lq * 4);
                 x[fb][0] += pp.x; x[fb][1] += pp.y; x[fb][2] += pp.z; x[fb][3] += pp.w;
             }
         } else {
@@ -368,11 +379,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int j = 0; j < 4; ++j) {
                 const int ob = (hh - 1) * 4 + j;
                 if (ob < nproj_blocks && (!coop || j == wave)) {
-                    const f32x4 d = rowblock_mm(buf + j * 256, lj, lq, x);
-                    const float4 bp = *reinterpret_cast<const float4*>(sm + so.bp + ob * 16 + lq * 4);
+                    const f32x4 d = rowblock_mm(buf + j * 256, lj, lq, x, sm + so.bp + ob * 16);
                     if (tok_ok)
-                        *reinterpret_cast<float4*>(proj_out + (int64_t)tok * proj_ld + ob * 16 + lq * 4) =
-                            make_float4(d[0] + bp.x, d[1] + bp.y, d[2] + bp.z, d[3] + bp.w);
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(d[0]), __float_as_uint(d[1]), __float_as_uint(d[2]), __float_as_uint(d[3])}, prs, po0, (unsigned)ob * 64u, 0);
                 }
             }
         }
@@ -493,8 +502,7 @@ __global__ __launch_bounds__(PRO_W * 64) void enc_prologue_kernel(const float* _
     for (int fb = 0; fb < 4; ++fb) pp[fb] = *reinterpret_cast<const float4*>(pos + (int64_t)ti * EC + fb * 16 + lq * 4);
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) {
-        const f32x4 d = rowblock_mm(wl + ob * 256, lj, lq, x);
-        const float4 bv = *reinterpret_cast<const float4*>(sm + ob * 16 + lq * 4);
+        const f32x4 d = rowblock_mm(wl + ob * 256, lj, lq, x, sm + ob * 16);
         if (tok_ok) {
             const int f = ob * 16 + lq * 4;
             int64_t o = (int64_t)tok * EC + f;
@@ -502,7 +510,7 @@ __global__ __launch_bounds__(PRO_W * 64) void enc_prologue_kernel(const float* _
                 const int dh = EC / value_heads;
                 o = (((int64_t)bi * value_heads + f / dh) * S + ti) * dh + f % dh;
             }
-            *reinterpret_cast<float4*>(value_out + o) = make_float4(d[0] + bv.x, d[1] + bv.y, d[2] + bv.z, d[3] + bv.w);
+            *reinterpret_cast<float4*>(value_out + o) = make_float4(d[0], d[1], d[2], d[3]);
         }
     }
 #pragma unroll
@@ -510,11 +518,9 @@ __global__ __launch_bounds__(PRO_W * 64) void enc_prologue_kernel(const float* _
         x[fb][0] += pp[fb].x; x[fb][1] += pp[fb].y; x[fb][2] += pp[fb].z; x[fb][3] += pp[fb].w;
     }
     for (int ob = 0; ob < nproj_blocks; ++ob) {
-        const f32x4 d = rowblock_mm(wl + (4 + ob) * 256, lj, lq, x);
-        const float4 bp = *reinterpret_cast<const float4*>(sm + EC + ob * 16 + lq * 4);
+        const f32x4 d = rowblock_mm(wl + (4 + ob) * 256, lj, lq, x, sm + EC + ob * 16);
         if (tok_ok)
-            *reinterpret_cast<float4*>(proj_out + (int64_t)tok * proj_ld + ob * 16 + lq * 4) =
-                make_float4(d[0] + bp.x, d[1] + bp.y, d[2] + bp.z, d[3] + bp.w);
+            *reinterpret_cast<float4*>(proj_out + (int64_t)tok * proj_ld + ob * 16 + lq * 4) = make_float4(d[0], d[1], d[2], d[3]);
     }
 }
 
@@ -540,6 +546,7 @@ extern "C" int msm_encoder_block_fwd(const float* attn, const float* src, const 
                 "msm_encoder_block_fwd: value_heads=%d needs 64/heads to be a multiple of 4 and M a multiple of S", value_heads);
     MSM_REQUIRE(proj_width % 16 == 0 && proj_width >= 64, "msm_encoder_block_fwd: proj_width=%d must be a multiple of 16, >= 64",
                 proj_width);
+    MSM_REQUIRE((int64_t)M * max(proj_width, EC) * 4 < (int64_t)1 << 31, "msm_encoder_block_fwd: M=%d tokens exceed the 2 GiB the output descriptors address", M);
     MSM_REQUIRE(((((uintptr_t)attn) | ((uintptr_t)src) | ((uintptr_t)wstream) | ((uintptr_t)small) | ((uintptr_t)src_out) |
                   ((uintptr_t)value_out) | ((uintptr_t)proj_out) | ((uintptr_t)pos)) & 15) == 0,
                 "msm_encoder_block_fwd: pointers must be 16-byte aligned");
