@@ -506,6 +506,42 @@ def test_graphed_inference_equals_eager():
         g({k: v.cpu() for k, v in feats.items()}, (64, 96))
 
 
+def test_pipelined_inference_equals_eager():
+    """graphs.PipelinedInference: three batches in flight on three streams, each slot with its own graph and buffers;
+    every batch's outputs equal the eager path's, in any consumption order, also when a slot is re-used and when the
+    geometry of a slot changes."""
+    from unseenobjectswithmeanshift_amd.meta_arch import MeanShiftMaskFormer
+    model = MeanShiftMaskFormer(backbone=None, sem_seg_head=make_pixel_decoder(), num_queries=100)
+    pipe = model.pipelined(depth=3)
+    batches = [{k: v.to(DEV) for k, v in syn.synth_backbone_features(2, 64, 96, seed=20 + i).items()} for i in range(7)]
+    want = [[t.clone() for t in model.inference(f, (64, 96))] for f in batches]
+    handles = [pipe.submit(f, (64, 96)) for f in batches[:3]]
+    assert handles == [0, 1, 2]
+    for i in (2, 0, 1):                                    # consumed out of order
+        for a, b in zip(pipe.result(handles[i]), want[i]):
+            assert torch.equal(a, b)
+    for i in range(3, 7):                                  # steady state: submit, consume the oldest
+        h = pipe.submit(batches[i], (64, 96))
+        for a, b in zip(pipe.result(h, wait="host"), want[i]):
+            assert torch.equal(a, b)
+    # a producer writing into the slot's own input buffers (no copy at submit)
+    slot = pipe._next
+    for k, v in batches[1].items():
+        pipe.inputs(slot)[k].copy_(v)
+    h = pipe.submit(None, (64, 96), slot_inputs=True)
+    assert h == slot
+    for a, b in zip(pipe.result(h), want[1]):
+        assert torch.equal(a, b)
+    # another geometry rebuilds the slot it lands on
+    f1 = {k: v[:1].contiguous() for k, v in batches[0].items()}
+    h = pipe.submit(f1, (64, 96))
+    for a, b in zip(pipe.result(h), model.inference(f1, (64, 96))):
+        assert torch.equal(a, b)
+    pipe.drain()
+    with pytest.raises(RuntimeError):
+        pipe.submit({k: v.cpu() for k, v in f1.items()}, (64, 96))
+
+
 class _TinyBackbone(torch.nn.Module):
     """Test-only stand-in for the (out-of-scope) ResNet-50: average-pool pyramid + fixed random 1x1 mixing,
     plain torch ops.  Gives res2..res5 with the right channel counts for any H, W divisible by 32."""

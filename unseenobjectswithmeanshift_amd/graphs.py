@@ -6,6 +6,9 @@ so it is captured once per input geometry into a HIP graph and replayed: inputs 
 buffers, outputs are the graph's static tensors.  (The reference relies on eager PyTorch; a tracing compiler is
 deliberately not used -- explicit kernels + explicit graphs.)
 """
+import os
+import warnings
+
 import torch
 
 
@@ -52,3 +55,112 @@ class GraphedInference:
             static_in[k].copy_(v)
         graph.replay()
         return static_out
+
+
+class PipelinedInference:
+    """Throughput mode: ``depth`` batches in flight, each replayed from its own HIP graph on its own stream.
+
+    One pass of the hot path is a chain of ~140 dependent launches, and a fifth of its time goes to kernels that cannot fill
+    the chip on their own -- the decoder's row-local chains own 50 16-row tiles (50 of 256 CUs), the small-level attention
+    and the top-k a few dozen workgroups.  Nothing orders the passes of DIFFERENT batches, so a second and third batch on
+    their own streams fill those gaps (640x480, batch 8: 2.88 ms per batch alone, 2.45 with two in flight, 2.29 with four;
+    bench.py --inflight N).  Every slot owns its graph, its input buffers and its outputs; weights and the derived
+    weight caches are shared and read-only.
+
+        pipe = model.pipelined(depth=3)
+        h = pipe.submit(features, image_size)      # copies `features` into the slot's input buffers, replays its graph
+        ...                                        # submit more batches; up to `depth` overlap on the GPU
+        out = pipe.result(h)                       # waits for that batch; the tensors are the slot's own: consume (or
+                                                   # .clone()) them before the slot comes round again (depth submits later)
+
+    ``submit(None, image_size, slot_inputs=True)`` re-runs a slot on whatever its input buffers hold -- a producer (the
+    backbone) can write its outputs straight into ``pipe.inputs(slot)`` instead of paying the copy (after ``result(slot)``
+    of the slot's previous batch: its graph reads those buffers until then).
+    """
+
+    def __init__(self, model, depth=2, warmup=2):
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        self.model = model
+        self.depth = int(depth)
+        self.warmup = max(1, int(warmup))
+        # the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues; streams that share a
+        # queue serialise.  The variable is read when the runtime initialises, so it can only be checked here.
+        queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+        if self.depth + 1 > queues:
+            warnings.warn(f"PipelinedInference(depth={self.depth}): GPU_MAX_HW_QUEUES={queues} hardware queues; export "
+                          f"GPU_MAX_HW_QUEUES>={self.depth + 2} before the first HIP call or slots will share a queue and "
+                          "serialise", RuntimeWarning)
+        self._slots = [None] * self.depth      # (key, stream, graph, static_in, static_out, done_event)
+        self._next = 0
+
+    @staticmethod
+    def _key(features, image_size, padded_size):
+        return (tuple((k, tuple(v.shape), v.dtype, v.device) for k, v in sorted(features.items())), tuple(image_size),
+                tuple(padded_size or image_size))
+
+    def _build(self, i, features, image_size, padded_size):
+        old = self._slots[i]
+        stream = old[1] if old is not None else torch.cuda.Stream(device=next(iter(features.values())).device)
+        cur = torch.cuda.current_stream()
+        stream.wait_stream(cur)
+        with torch.cuda.stream(stream):
+            static_in = {k: v.clone() for k, v in features.items()}
+            for _ in range(self.warmup):                           # builds every weight cache outside the capture
+                self.model.inference(static_in, image_size, padded_size)
+            stream.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                static_out = self.model.inference(static_in, image_size, padded_size)
+        self._slots[i] = (self._key(features, image_size, padded_size), stream, graph, static_in, static_out,
+                          torch.cuda.Event())
+        return self._slots[i]
+
+    def inputs(self, slot):
+        """The input buffers of a slot (dict of device tensors) once it has been built by a first ``submit``."""
+        if self._slots[slot] is None:
+            raise RuntimeError("slot %d has not been used yet" % slot)
+        return self._slots[slot][3]
+
+    @torch.no_grad()
+    def submit(self, features, image_size, padded_size=None, slot_inputs=False):
+        """Queue one batch; returns the slot handle for ``result``.  Slots are taken round-robin."""
+        i = self._next
+        entry = self._slots[i]
+        if slot_inputs:
+            if entry is None:
+                raise RuntimeError("slot_inputs=True needs a slot that was built by an earlier submit")
+        else:
+            for v in features.values():
+                if not v.is_cuda:
+                    raise RuntimeError("PipelinedInference needs device tensors (there is no CPU path)")
+            if entry is None or entry[0] != self._key(features, image_size, padded_size):
+                entry = self._build(i, features, image_size, padded_size)
+        self._next = (i + 1) % self.depth
+        _, stream, graph, static_in, _, done = entry
+        stream.wait_stream(torch.cuda.current_stream())            # the producer of the inputs runs on the caller's stream
+        with torch.cuda.stream(stream):
+            if not slot_inputs:
+                for k, v in features.items():
+                    static_in[k].copy_(v, non_blocking=True)
+            graph.replay()
+            done.record(stream)
+        return i
+
+    def result(self, slot, wait="stream"):
+        """Outputs of the batch last submitted to ``slot``.  wait="stream": the caller's current stream waits for the batch
+        (no host block; what follows on that stream sees the results); wait="host": the host blocks until it is done."""
+        entry = self._slots[slot]
+        if entry is None:
+            raise RuntimeError("slot %d has not been used yet" % slot)
+        if wait == "host":
+            entry[5].synchronize()
+        else:
+            torch.cuda.current_stream().wait_event(entry[5])
+        return entry[4]
+
+    def drain(self):
+        """Host-block until every slot is idle."""
+        for e in self._slots:
+            if e is not None:
+                e[5].synchronize()

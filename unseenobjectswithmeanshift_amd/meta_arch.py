@@ -146,6 +146,11 @@ class MeanShiftMaskFormer(nn.Module):
         from .graphs import GraphedInference
         return GraphedInference(self, warmup=warmup)
 
+    def pipelined(self, depth=2, warmup=2):
+        """Throughput mode (graphs.PipelinedInference): ``depth`` batches in flight, one HIP graph and stream each."""
+        from .graphs import PipelinedInference
+        return PipelinedInference(self, depth=depth, warmup=warmup)
+
     @torch.no_grad()
     def forward(self, batched_inputs):
         """batched_inputs: list of dicts with "image" (3,H,W) -- or one dict holding a 4-D batch, as
