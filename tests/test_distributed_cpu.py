@@ -60,3 +60,26 @@ def test_gather_metrics_gloo_world2():
 
 def test_gather_metrics_single_process():
     assert gather_metrics({"images": 8, "elapsed_s": 1.0, "checksum": 2.0}) == [{"images": 8, "elapsed_s": 1.0, "checksum": 2.0}]
+
+
+def test_launch_modes_refuse_host_tensors_and_bad_depth():
+    """graphs.GraphedInference / PipelinedInference are device-only (no CPU fallback) and validate their arguments before
+    touching the model."""
+    import warnings
+    import pytest
+    import torch
+    from unseenobjectswithmeanshift_amd.graphs import GraphedInference, PipelinedInference
+    with pytest.raises(ValueError):
+        PipelinedInference(model=None, depth=0)
+    feats = {"res2": torch.zeros(1, 4, 2, 2)}
+    with pytest.raises(RuntimeError, match="device tensors"):
+        GraphedInference(model=None)(feats, (8, 8))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                       # the hardware-queue hint, irrelevant here
+        pipe = PipelinedInference(model=None, depth=2)
+    with pytest.raises(RuntimeError, match="device tensors"):
+        pipe.submit(feats, (8, 8))
+    with pytest.raises(RuntimeError, match="not been used"):
+        pipe.result(0)
+    with pytest.raises(RuntimeError, match="slot_inputs"):
+        pipe.submit(None, (8, 8), slot_inputs=True)
