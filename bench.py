@@ -2,21 +2,35 @@
 """Headline benchmark: MSMFormer inference hot path, images/sec at 640x480, 100 queries, 9 decoder
 layers (BASELINE.json).  One step = one pass of the hot path (MSDeformAttn pixel decoder ->
 hypersphere transformer decoder -> instance post-processing) over one batch of 8 synthetic frames'
-backbone features that are already resident in HBM.  Backbone excluded (SURVEY.md section 8).
-Throughput mode by default: `--inflight` (4) batches of 8 are in flight at a time, each replayed from its own HIP graph
-on its own stream (graphs.PipelinedInference) -- the passes of different batches are independent, and a single pass
-leaves a fifth of the chip-time to kernels that occupy 50 of the 256 CUs.  The JSON line also carries the figure with
-ONE batch in flight (`one_batch_in_flight`); `--inflight 1` times only that.
+backbone features that are already resident in HBM.  Backbone excluded (SURVEY.md section 8d).
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.  Weak scaling: every rank processes its own batch of 8 images
-(independent units, no data-path collective); ranks exchange only a small metrics record.
+* ``--gpus N`` (N > 1) launched WITHOUT torch.distributed.run starts the N ranks itself (one process per GPU,
+  LOCAL_RANK = device index, rendezvous on 127.0.0.1) -- the reference starts its N workers from one command the same way
+  (MSMFormer/tabletop_train_net_pretrained.py:326-336).  Under ``python -m torch.distributed.run --nproc-per-node N ...
+  bench.py --gpus N`` the ranks already exist (WORLD_SIZE is set) and nothing is spawned.
+* Weak scaling: every rank processes its own batches of 8 images (independent units, no data-path collective); ranks
+  exchange one small metrics record (images, elapsed, checksum) by all_gather after the timed region.
+* Throughput mode by default: ``--inflight`` (4) batches of 8 are in flight at a time, each replayed from its own HIP graph
+  on its own stream (graphs.PipelinedInference).  The JSON line also carries the figure with ONE batch in flight
+  (``one_batch_in_flight``); ``--inflight 1`` times only that.
+* The timed region is at least ``--min-seconds`` (1 s) long: when K steps would be shorter, more steps are timed and
+  ``steps`` reports the number actually timed (``steps_requested`` = K).
+* ``roofline``: the Q x pixel-embedding mask step (msm_mask_logits_fwd), FLOPs the kernel EXECUTES / its mean launch
+  duration (HIP events on the launch stream around every launch of three eager passes) / the fp32 MFMA peak.
+* N = 1 adds, on rank 0: ``kernels`` (event-timed per entry point of one eager pass), ``mean_shift`` (the classic UCN
+  clustering unit with its own roofline entries), ``configs`` (BASELINE configs[2] slice / [3] / [4] timed by this run)
+  and ``cpu_baseline`` (the oracle on the host cores).
+
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,19 +45,67 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 256 FLOP/clk/CU x 256 CUs x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2516.6   # same guide: dense bf16 MFMA (16x16x32), no sparsity
+PEAK_HBM_GBPS = 8000.0
 H, W, Q, C_MASK, BATCH = 480, 640, 100, 256, 8
+METRIC = "images/sec @640x480 RGB-D, 100 queries, 9 decoder layers; % MFMA roofline"
 
 
-def build_model(dev):
+def build_model(dev, num_queries=Q, dec_layers=9):
     from unseenobjectswithmeanshift_amd import synthetic as syn
     from unseenobjectswithmeanshift_amd.meta_arch import MeanShiftMaskFormer, build_resnet50_head
-    head = build_resnet50_head(num_queries=Q, dec_layers=9)
+    head = build_resnet50_head(num_queries=num_queries, dec_layers=dec_layers)
     head.pixel_decoder.load_state_dict(syn.synth_state_dict(syn.pixel_decoder_param_shapes()), strict=True)
-    head.predictor.load_state_dict(syn.synth_state_dict(syn.decoder_param_shapes()), strict=True)
-    return MeanShiftMaskFormer(backbone=None, sem_seg_head=head.to(dev).eval(), num_queries=Q)
+    head.predictor.load_state_dict(syn.synth_state_dict(syn.decoder_param_shapes(num_queries=num_queries, dec_layers=dec_layers)), strict=True)
+    return MeanShiftMaskFormer(backbone=None, sem_seg_head=head.to(dev).eval(), num_queries=num_queries)
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` starts N ranks
+# ----------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """Start `n` copies of this script as ranks 0..n-1 of one job (one process per GPU) and wait for them.  Rank 0 inherits
+    stdout (the JSON line); a failing rank takes the others down.  Returns the exit code."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in list(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                    for o in pending:
+                        procs[o].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle as the thing TIMED on the host cores -- never on the product path)
+# ----------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(images=6):
     """The oracle (CPU port of the reference algorithm, parity-pinned to reference goldens) on
     the host cores of this box: same synthetic inputs/weights, one warm-up image then `images`
@@ -64,11 +126,12 @@ def cpu_baseline(images=6):
 
     # pick the intra-op thread count that serves this workload best (all hardware threads is rarely it
     # for torch's CPU kernels at these sizes); the choice is reported in `cores`
-    best = None
+    best, sweep = None, {}
     for nt in sorted({min(ncpu, c) for c in (16, 32, 64, max(1, ncpu // 2))}):
         torch.set_num_threads(nt)
         one(100)                       # warm-up at this thread count
         t = one(100)
+        sweep[str(nt)] = round(1.0 / t, 3)
         if best is None or t < best[0]:
             best = (t, nt)
     warm, nt = best
@@ -76,9 +139,209 @@ def cpu_baseline(images=6):
     # bounded sample: aim for <= ~20 s of CPU work whatever the host is
     images = max(1, min(images, int(20.0 / max(warm, 1e-3))))
     dt = sum(one(101 + i) for i in range(images))
-    return {"value": round(images / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{images} frames at 640x480 after warm-up and a thread-count sweep (16/32/64/half the CPUs, best kept), batch 1, oracle pixel decoder + 9-layer decoder "
-                      f"+ instance post-processing in fp32 torch on {torch.get_num_threads()} threads"}
+    return {"value": round(images / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "host_cpus": ncpu,
+            "threads_sweep_images_per_sec": sweep, "kind": "port",
+            "sample": f"{images} frames at 640x480 after warm-up and a thread-count sweep (16/32/64/half the CPUs, best kept: "
+                      f"{torch.get_num_threads()} threads of {ncpu} host CPUs), batch 1, oracle pixel decoder + 9-layer decoder "
+                      f"+ instance post-processing in fp32 torch"}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# measurement helpers
+# ----------------------------------------------------------------------------------------------------------------------
+def timed(fn, reps, sync=True):
+    """Wall time per call of fn() over `reps` calls (after the caller's own warm-up), device-synchronised."""
+    if sync:
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    if sync:
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def event_ms(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    e[0].record()
+    for _ in range(reps):
+        fn()
+    e[1].record()
+    e[1].synchronize()
+    return e[0].elapsed_time(e[1]) / reps
+
+
+def mean_shift_unit(dev):
+    """the classic UCN clustering timed as its own unit -- clustering_features (lib/fcn/test_dataset.py:44-59)
+    on one 640x480 embedding map: n = 307 200 unit 64-vectors in 12 planted clusters, 100 seeds, 10 iterations, kappa 20."""
+    from unseenobjectswithmeanshift_amd import mean_shift as ms
+    from unseenobjectswithmeanshift_amd import ops
+    from unseenobjectswithmeanshift_amd import synthetic as syn
+    import numpy as np
+    n, S, iters, kappa = H * W, 100, 10, 20.0
+    X, _ = syn.synth_unit_embeddings(n, 64, clusters=12, sigma=0.15, seed=3)
+    feats = X.t().reshape(1, 64, H, W).contiguous().to(dev)
+    Xd = X.to(dev)
+    t_seed = event_ms(lambda: ops.ms_select_seeds(Xd, S, 7), reps=10)
+    seeds, _ = ops.ms_select_seeds(Xd, S, 7)
+    t_hill = event_ms(lambda: ops.ms_hill_climb(Xd, seeds, kappa, iters), reps=10)
+    Z = ops.ms_hill_climb(Xd, seeds, kappa, iters)
+    lab = torch.zeros(S, dtype=torch.int64, device=dev)
+    t_asg = event_ms(lambda: ops.ms_assign(Xd, Z, lab, 1), reps=10)
+    np.random.seed(3)
+    for _ in range(3):
+        ms.clustering_features(feats, num_seeds=S)
+    reps = 20
+    t_all = timed(lambda: ms.clustering_features(feats, num_seeds=S), reps)
+    ref_bytes = float(S) * n * 64 * 4                  # SURVEY 8d: the reference re-reads X for every seed
+    hill_flops = 4.0 * S * n * 64 * iters              # SURVEY 8d: Z X^T and W X per iteration
+    return {"workload": "clustering_features unit (lib/fcn/test_dataset.py:44-59): one 640x480 map, n=307200 unit 64-d embeddings in 12 "
+                        "planted clusters, 100 seeds, 10 iterations, kappa 20; includes the host-side connected_components",
+            "value": round(1.0 / t_all, 2), "unit": "images/sec", "ms_per_image": round(1e3 * t_all, 3),
+            "seeding": {"kernel": "ms_seed_persistent_kernel (one launch, map held in registers, grid barrier per step)",
+                        "ms": round(t_seed, 4), "bound": "hbm (reference form: S passes over X) -> barrier latency as executed",
+                        "achieved": round(ref_bytes / (t_seed * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                        "frac": round(n * 256.0 / (t_seed * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                        "executed_bytes": n * 256.0, "algorithmic_bytes": ref_bytes,
+                        "note": "achieved = the reference algorithm's S*n*256 bytes over the time (effective); the kernel reads X "
+                                "once (executed_bytes), frac is executed bytes / time / peak: the step is bound by S grid barriers"},
+            "hill_climb": {"kernel": "ms_hill_kernel + ms_hill_finish_kernel", "ms": round(t_hill, 4), "bound": "mfma",
+                           "achieved": round(hill_flops / (t_hill * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(hill_flops / (t_hill * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "flops": hill_flops},
+            "assign_ms": round(t_asg, 4)}
+
+
+def extra_configs(dev, args):
+    """BASELINE configs[2] (per-GPU slice), configs[3] and configs[4], timed by this run (rank 0, N = 1)."""
+    from unseenobjectswithmeanshift_amd import mean_shift as ms
+    from unseenobjectswithmeanshift_amd import ops
+    from unseenobjectswithmeanshift_amd import synthetic as syn
+    from unseenobjectswithmeanshift_amd import two_stage as ts
+    from unseenobjectswithmeanshift_amd.meta_arch import Instances, MeanShiftMaskFormer, Network_RGBD
+    out = {}
+    # configs[2], the slice one GPU of the 8 owns: batch 8 at 640x480, low-precision mode
+    model = build_model(dev)
+    feats = {k: v.to(dev) for k, v in syn.synth_backbone_features(BATCH, H, W, seed=10).items()}
+    if hasattr(model, "set_precision"):
+        model.set_precision("bf16")
+    else:
+        model.sem_seg_head.predictor.mask_step_dtype = "bf16"
+    g = model.graphed()
+    for _ in range(3):
+        g(feats, (H, W))
+    t = timed(lambda: g(feats, (H, W)), 50)
+    out["configs[2] per-GPU slice"] = {"workload": "batch 8 of the 64, 640x480, bf16 operands / fp32 accumulation, one HIP graph, one batch in flight",
+                                       "value": round(BATCH / t, 1), "unit": "images/sec", "ms_per_step": round(1e3 * t, 3),
+                                       "dtype": getattr(model, "precision", "f32 + bf16 mask step")}
+    del g, model
+    # configs[3]: two-stage refinement over 16 frames
+    model = build_model(dev)
+    bb = syn.StandInBackbone().to(dev).eval()
+
+    class RGBD(MeanShiftMaskFormer):
+        def forward(self, batched_inputs):
+            imgs = torch.stack([x["image"] for x in batched_inputs])
+            deps = torch.stack([x["depth"] for x in batched_inputs])
+            hh, ww = imgs.shape[-2:]
+            scores, classes, masks, boxes, _ = self.inference(self.backbone(imgs, deps), (int(hh), int(ww)))
+            return [{"instances": Instances((int(hh), int(ww)), pred_masks=masks[b], pred_boxes=boxes[b], scores=scores[b],
+                                            pred_classes=classes[b])} for b in range(len(batched_inputs))]
+
+    rgbd = RGBD(backbone=bb, sem_seg_head=model.sem_seg_head, num_queries=Q)
+    crops = []
+
+    class Pred(Network_RGBD):
+        def batch_call(self, samples):
+            crops.append(len(samples))
+            with torch.no_grad():
+                return self.model(samples)
+
+    first, second = Network_RGBD(rgbd), Pred(rgbd)
+    gen = torch.Generator().manual_seed(3)
+    frames = [(torch.rand(3, H, W, generator=gen).to(dev), torch.rand(3, H, W, generator=gen).to(dev)) for _ in range(16)]
+
+    def run():
+        for im, dp in frames:
+            ts.test_sample_crop_nolabel({"image_color": im, "depth": dp}, first, second, confident_score=0.0, topk=False)
+
+    run()
+    crops.clear()
+    t = timed(run, 2)
+    out["configs[3]"] = {"workload": "two-stage RGB + depth-crop refinement, 16 frames of 640x480: first stage, depth filter, ROI crops "
+                                     "resized to 224x224, ONE batched second stage over a frame's crops, paste-back; stand-in backbone",
+                         "value": round(16 / t, 1), "unit": "frames/sec", "ms_per_frame": round(1e3 * t / 16, 3),
+                         "crops_per_frame": round(sum(crops) / max(1, len(crops)), 1)}
+    del rgbd, model
+    # configs[4]: 1280x960, 300 queries, 20 decoder predictions (19 layers), B=1; mean shift with 300 seeds / 20 iterations
+    model = build_model(dev, num_queries=300, dec_layers=19)
+    feats = {k: v.to(dev) for k, v in syn.synth_backbone_features(1, 960, 1280, seed=9).items()}
+    res = {}
+    for mode in ("f32", "bf16"):
+        if hasattr(model, "set_precision"):
+            model.set_precision(mode)
+        else:
+            model.sem_seg_head.predictor.mask_step_dtype = mode
+        g = model.graphed()
+        for _ in range(2):
+            g(feats, (960, 1280))
+        t = timed(lambda: g(feats, (960, 1280)), 10)
+        res[mode] = {"value": round(1.0 / t, 1), "unit": "images/sec", "ms_per_image": round(1e3 * t, 3)}
+        del g
+    n, S, iters = 960 * 1280, 300, 20
+    X, _ = syn.synth_unit_embeddings(n, 64, clusters=24, sigma=0.15, seed=3)
+    Xd = X.to(dev)
+    for _ in range(2):
+        ms.mean_shift_smart_init(Xd, 20.0, S, iters, first_index=7)
+    t_ms = timed(lambda: ms.mean_shift_smart_init(Xd, 20.0, S, iters, first_index=7), 3)
+    t_seed = event_ms(lambda: ops.ms_select_seeds(Xd, S, 7), reps=3, warm=1)
+    seeds, _ = ops.ms_select_seeds(Xd, S, 7)
+    t_hill = event_ms(lambda: ops.ms_hill_climb(Xd, seeds, 20.0, iters), reps=3, warm=1)
+    out["configs[4]"] = {"workload": "1280x960, 300 queries, 19 decoder layers, batch 1 (pixel decoder + decoder + post-processing); classic "
+                                     "mean shift on n=1228800 embeddings, 300 seeds, 20 iterations",
+                         "hot_path": res,
+                         "mean_shift": {"ms": round(1e3 * t_ms, 2), "seeding_ms": round(t_seed, 3),
+                                        "seeding_GBps": round(float(S) * n * 256 / (t_seed * 1e-3) / 1e9, 1),
+                                        "seeding_frac_hbm": round(float(S) * n * 256 / (t_seed * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                                        "hill_climb_ms": round(t_hill, 3),
+                                        "hill_climb_TFLOPs": round(4.0 * S * n * 64 * iters / (t_hill * 1e-3) / 1e12, 1),
+                                        "hill_climb_frac_mfma": round(4.0 * S * n * 64 * iters / (t_hill * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}}
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def stub_main(args, world, rank):
+    """Test hook (tests/test_distributed_cpu.py): the launcher, the process group (gloo), the barrier / max-over-ranks timing
+    and the metrics all_gather with a trivial CPU step -- no GPU, no kernels, `data` says "stub"."""
+    import torch.distributed as dist
+    from unseenobjectswithmeanshift_amd.distributed import gather_metrics, shard_range
+    if world > 1:
+        dist.init_process_group("gloo")
+    lo, hi = shard_range(world * BATCH, world, rank)
+    x = torch.full((64, 64), float(rank + 1))
+    acc = 0.0
+    for _ in range(args.warmup):
+        acc += float((x @ x).sum())
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        acc = float((x @ x).sum())
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    rec = gather_metrics({"images": (hi - lo) * args.steps, "elapsed_s": elapsed, "checksum": acc}, dist if world > 1 else None)
+    if rank == 0:
+        t_max = max(r["elapsed_s"] for r in rec)
+        print(json.dumps({"metric": METRIC, "value": round(sum(r["images"] for r in rec) / t_max, 2), "unit": "images/sec",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * t_max / args.steps, 4),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "stub",
+                          "config": {"workload": "launcher self-test", "global_batch": world * BATCH, "parallelism": f"dp{world}"},
+                          "per_rank": [{"rank": i, "images": r["images"], "checksum": r["checksum"]} for i, r in enumerate(rec)]}),
+              flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -86,21 +349,35 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=120)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="lower bound of the timed region; more steps than --steps are timed if needed")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--inflight", type=int, default=4,
                     help="batches in flight, one HIP graph + stream each (graphs.PipelinedInference); 1 = one graph on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the mean-shift unit and the configs[2..4] sub-results")
     ap.add_argument("--folded-mask", type=int, default=-1, help="1/0: contract the mask features in factored form (64-channel activation; "
                     "default: the decoder's own default, on) or literally (256-channel mask_features tensor)")
     ap.add_argument("--sparse-taps", action="store_true", help="skip mask rows that feed no attention-mask tap")
-    ap.add_argument("--mask-step", choices=("f32", "bf16"), default="f32",
-                    help="bf16 (configs 3/5) is NOT the headline configuration: the JSON line then says dtype bf16-mask-step")
+    ap.add_argument("--precision", choices=("f32", "bf16"), default="f32",
+                    help="bf16 (configs 3/5) is NOT the headline configuration: the JSON line then says so in dtype")
     ap.add_argument("--batched-kv", type=int, default=-1, help="1/0: all K/V projections of the decoder in one launch (default: the decoder's own default)")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        if not args.stub:
+            have = torch.cuda.device_count()
+            if have < args.gpus:
+                raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible")
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.stub:
+        return stub_main(args, world, rank)
     dist = None
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: the hot path has no CPU implementation (oracle/ is test-only)")
@@ -111,17 +388,22 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from unseenobjectswithmeanshift_amd import ops
+    from unseenobjectswithmeanshift_amd import _lib, ops
     from unseenobjectswithmeanshift_amd import synthetic as syn
     from unseenobjectswithmeanshift_amd.distributed import gather_metrics, shard_range
 
     model = build_model(dev)
-    model.sem_seg_head.predictor.sparse_taps = args.sparse_taps
-    model.sem_seg_head.predictor.mask_step_dtype = args.mask_step
+    pred = model.sem_seg_head.predictor
+    pred.sparse_taps = args.sparse_taps
+    if args.precision == "bf16":
+        if hasattr(model, "set_precision"):
+            model.set_precision("bf16")
+        else:
+            pred.mask_step_dtype = "bf16"
     if args.folded_mask >= 0:
-        model.sem_seg_head.predictor.folded_mask_features = bool(args.folded_mask)
+        pred.folded_mask_features = bool(args.folded_mask)
     if args.batched_kv >= 0:
-        model.sem_seg_head.predictor.batched_kv = bool(args.batched_kv)
+        pred.batched_kv = bool(args.batched_kv)
     # weak scaling: the global batch is world*8 images, rank r owns images [r*8, (r+1)*8)
     lo, hi = shard_range(world * BATCH, world, rank)
     feats = {k: v.to(dev) for k, v in syn.synth_backbone_features(hi - lo, H, W, seed=10 + rank).items()}
@@ -140,13 +422,14 @@ def main():
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=stream):
                 out = step()
-            for _ in range(args.warmup):
-                graph.replay()
+        one = graph.replay if graph is not None else step
+        for _ in range(args.warmup):
+            one()
         stream.synchronize()
         # throughput mode: `inflight` batches in flight, each a HIP graph on its own stream (graphs.PipelinedInference);
         # every slot keeps its own copy of the inputs resident in HBM, a step = one replay of one slot's graph
         inflight = 1 if graph is None else max(1, args.inflight)
-        pipe, single = None, None
+        pipe = None
         if inflight > 1:
             from unseenobjectswithmeanshift_amd.graphs import PipelinedInference
             pipe = PipelinedInference(model, depth=inflight)
@@ -156,24 +439,26 @@ def main():
             for _ in range(args.warmup):
                 pipe.submit(None, (H, W), slot_inputs=True)
             pipe.drain()
-            # one batch in flight, for reference next to the headline (same K steps, untimed for `value`)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                graph.replay()
-            torch.cuda.synchronize()
-            single = time.perf_counter() - t1
+            one_piped = lambda: pipe.submit(None, (H, W), slot_inputs=True)
+        # step-time estimate -> number of timed steps (>= --steps, >= --min-seconds of work), agreed across the ranks
+        est = timed(one, 10)
+        single_steps = max(args.steps, int(math.ceil(args.min_seconds / max(est, 1e-6))))
+        single = None
+        if pipe is not None:
+            single = timed(one, single_steps) * single_steps          # one batch in flight, next to the headline (untimed for `value`)
+            est = timed(one_piped, 4 * inflight)
+        steps = max(args.steps, int(math.ceil(args.min_seconds / max(est, 1e-6))))
+        if dist is not None:
+            t = torch.tensor([steps], device=dev, dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            steps = int(t.item())
+        run_one = one_piped if pipe is not None else one
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            if pipe is not None:
-                pipe.submit(None, (H, W), slot_inputs=True)
-            elif graph is not None:
-                graph.replay()
-            else:
-                out = step()
+        for _ in range(steps):
+            run_one()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -182,46 +467,31 @@ def main():
             for a, b in zip(pipe.result(0, wait="host"), out):
                 assert torch.equal(a, b), "pipelined slot differs from the single-stream graph"
 
-        # dominant kernel (mask step, last-layer form writes the full mask): HIP events on this stream
-        ops.MASK_STEP_EVENTS = []
-        for _ in range(3):
-            step()
-        stream.synchronize()
-        per_call = [a.elapsed_time(b) for a, b in ops.MASK_STEP_EVENTS]
-        ops.MASK_STEP_EVENTS = None
-        # phase breakdown (eager, event-timed)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        ev[0].record()
-        mf, _, msf = model.sem_seg_head.pixel_decoder.forward_features(feats, folded=model.sem_seg_head.predictor.folded_mask_features)
-        ev[1].record()
-        pred = model.sem_seg_head.predictor(msf, mf)
-        ev[2].record()
-        sc, cl, qi = ops.topk_class_scores(pred["pred_logits"], 20)
-        ops.instance_postprocess(pred["pred_masks"], qi, (H, W), class_scores=sc)
-        ev[3].record()
-        stream.synchronize()
-        breakdown = {"pixel_decoder_ms": round(ev[0].elapsed_time(ev[1]), 3), "decoder_ms": round(ev[1].elapsed_time(ev[2]), 3),
-                     "postprocess_ms": round(ev[2].elapsed_time(ev[3]), 3), "launch": "eager"}
+        # per-entry-point launch durations of three eager passes: HIP events on this stream around every library launch
+        with _lib.CallTimer() as ct:
+            for _ in range(3):
+                step()
+            stream.synchronize()
+        dur = ct.durations()
 
     scores = out[0]
     checksum = float(scores.double().sum().item())
-    rec = gather_metrics({"images": (hi - lo) * args.steps, "elapsed_s": elapsed, "checksum": checksum}, dist)
+    rec = gather_metrics({"images": (hi - lo) * steps, "elapsed_s": elapsed, "checksum": checksum}, dist)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
     t_max = max(r["elapsed_s"] for r in rec)
     total_images = sum(r["images"] for r in rec)
+    bf16 = args.precision == "bf16"
+    mask_name = "msm_mask_logits_bf16_fwd" if (bf16 and "msm_mask_logits_bf16_fwd" in dur) else "msm_mask_logits_fwd"
+    per_call = dur[mask_name]
     calls_per_step = len(per_call) // 3
     mask_ms = sum(per_call) / len(per_call)
-    flops_per_launch = 2.0 * Q * C_MASK * (H // 4) * (W // 4) * (hi - lo)
-    achieved = flops_per_launch / (mask_ms * 1e-3) / 1e12
-    # the folded form of the step executes the contraction over the 64 FPN channels instead of the 256 mask channels
-    folded = bool(model.sem_seg_head.predictor.folded_mask_features) and args.mask_step == "f32"
-    executed = flops_per_launch * (64.0 / C_MASK if folded else 1.0)
-    # algorithmic bytes of a bf16 launch: packed features + fp32 mask_embed + (one of ten launches) the fp32 mask
-    c_read = 64 if bool(model.sem_seg_head.predictor.folded_mask_features) else C_MASK     # channels the step actually streams
-    bf16_bytes = (hi - lo) * (c_read * (H // 4) * (W // 4) * 2 + Q * c_read * 4 + Q * (H // 4) * (W // 4) * 4 // 10)
+    folded = bool(pred.folded_mask_features)
+    c_exec = 64 if folded else C_MASK                       # channels the launched kernel contracts over
+    flops_ref = 2.0 * Q * C_MASK * (H // 4) * (W // 4) * (hi - lo)         # the reference einsum
+    flops_exec = 2.0 * Q * c_exec * (H // 4) * (W // 4) * (hi - lo)        # what the kernel issues
     # HBM traffic of the same kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; the
     # gfx950 x2 correction on FETCH_SIZE applied), summarised in profiles/ -- it cannot be measured in-process
     traffic = None
@@ -230,18 +500,38 @@ def main():
             traffic = json.load(f)["bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
+    if not bf16:
+        achieved = flops_exec / (mask_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "mask_logits_kernel (msm_mask_logits_fwd)", "achieved": round(achieved, 2),
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "launches_per_step": calls_per_step, "avg_launch_ms": round(mask_ms, 4), "flops_per_launch": flops_exec,
+                    "effective_flops_per_launch": flops_ref, "effective_achieved": round(flops_ref / (mask_ms * 1e-3) / 1e12, 2),
+                    "note": ("achieved / frac count the FLOPs the kernel executes: the folded step contracts e.Wm with the 64-channel FPN "
+                             "activation (einsum(e, Wm a + bm) = einsum(e Wm, a) + e.bm, exact algebra), a quarter of the reference "
+                             "einsum's FLOPs; effective_* divide the reference contraction's FLOPs (SURVEY 8d) by the same time")
+                            if folded else "literal 256-channel contraction: executed = reference FLOPs"}
+    else:
+        # bf16 operands: the step is a stream over the packed feature map, HBM-bound
+        bf16_bytes = (hi - lo) * (c_exec * (H // 4) * (W // 4) * 2 + Q * c_exec * 4 + Q * (H // 4) * (W // 4) * 4 // 10)
+        roofline = {"bound": "hbm", "kernel": "mask_logits_bf16_kernel (msm_mask_logits_bf16_fwd)",
+                    "achieved": round(bf16_bytes / (mask_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                    "frac": round(bf16_bytes / (mask_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "traffic": None,
+                    "launches_per_step": calls_per_step, "avg_launch_ms": round(mask_ms, 4), "bytes_per_launch": bf16_bytes}
+    kernels = {k: {"launches_per_step": len(v) // 3, "ms_per_step": round(sum(v) / 3, 4), "avg_launch_us": round(1e3 * sum(v) / len(v), 2)}
+               for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1]))}
     result = {
-        "metric": "images/sec @640x480 RGB-D, 100 queries, 9 decoder layers; % MFMA roofline",
+        "metric": METRIC,
         "value": round(total_images / t_max, 2),
         "unit": "images/sec",
         "n_gpus": world,
-        "steps": args.steps,
+        "steps": steps,
+        "steps_requested": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": round(1e3 * t_max / args.steps, 4),
+        "ms_per_step": round(1e3 * t_max / steps, 4),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if args.mask_step == "f32" else "f32 (bf16 mask step, fp32 accumulation: NOT the headline configuration)",
+        "dtype": "f32" if not bf16 else "bf16 operands / fp32 accumulation (NOT the headline configuration)",
         "data": "synthetic",
         "config": {"workload": "configs[1]: batch=8 640x480 frames per GPU, synthetic ResNet-50 res2..res5 features "
                                "-> MSDeformAttn pixel decoder (6 layers) -> 9-layer hypersphere decoder (100 queries) "
@@ -249,31 +539,21 @@ def main():
                    "global_batch": world * BATCH, "per_gpu_batch": BATCH, "launch": "eager" if graph is None else ("hipgraph" if pipe is None else
                                                                       f"hipgraph x{inflight}: {inflight} batches of 8 in flight, one graph + stream each"),
                    "batches_in_flight": inflight,
-                   "sparse_taps": bool(args.sparse_taps), "folded_mask_step": bool(model.sem_seg_head.predictor.folded_mask_features),
+                   "sparse_taps": bool(args.sparse_taps), "folded_mask_step": folded,
                    "parallelism": f"dp{world}"},
-        "roofline": {"bound": "mfma", "kernel": "mask_logits_kernel (msm_mask_logits_fwd)",
-                     "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                     "launches_per_step": calls_per_step, "avg_launch_ms": round(mask_ms, 4),
-                     "flops_per_launch": flops_per_launch, "executed_flops_per_launch": executed,
-                     "executed_frac": round(executed / (mask_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                     "note": ("achieved = the reference contraction's FLOPs (SURVEY 8d: 2*Q*256*H/4*W/4 per image) over the launch "
-                              "time; the kernel executes a quarter of them -- einsum(e, Wm a + bm) = einsum(e Wm, a) + e.bm on the "
-                              "64-channel activation, exact algebra -- so frac can exceed 1; executed_frac is the share of the fp32 "
-                              "MFMA peak actually used (--folded-mask 0 runs the literal 256-channel contraction)") if folded else
-                             "literal 256-channel contraction"} if args.mask_step == "f32" else
-                    # bf16 operands: the step is a stream over the packed feature map, HBM-bound
-                    {"bound": "hbm", "kernel": "mask_logits_bf16_kernel (msm_mask_logits_bf16_fwd)",
-                     "achieved": round(bf16_bytes / (mask_ms * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                     "frac": round(bf16_bytes / (mask_ms * 1e-3) / 8e12, 4), "traffic": None,
-                     "launches_per_step": calls_per_step, "avg_launch_ms": round(mask_ms, 4),
-                     "bytes_per_launch": bf16_bytes},
-        "breakdown": breakdown,
+        "per_rank": [{"rank": i, "images_per_sec": round(r["images"] / r["elapsed_s"], 2), "checksum": r["checksum"]} for i, r in enumerate(rec)],
+        "roofline": roofline,
+        "kernels": {"launch": "eager, HIP events on the launch stream around every library entry point, mean of 3 passes", "by_entry_point": kernels,
+                    "sum_ms_per_step": round(sum(v["ms_per_step"] for v in kernels.values()), 4)},
     }
     if single is not None:
         # rank 0's own clock, one batch in flight (one graph, one stream): the latency-oriented figure
-        result["one_batch_in_flight"] = {"value": round((hi - lo) * args.steps / single, 2), "unit": "images/sec",
-                                         "ms_per_step": round(1e3 * single / args.steps, 4)}
+        result["one_batch_in_flight"] = {"value": round((hi - lo) * single_steps / single, 2), "unit": "images/sec",
+                                         "ms_per_step": round(1e3 * single / single_steps, 4), "steps": single_steps}
+    if world == 1 and not args.no_extras:
+        del pipe, graph
+        result["mean_shift"] = mean_shift_unit(dev)
+        result["configs"] = extra_configs(dev, args)
     if not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = cpu_baseline()
     print(json.dumps(result), flush=True)

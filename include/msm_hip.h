@@ -54,8 +54,33 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 6   /* 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
+#define MSM_ABI_VERSION 7   /* 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
 int msm_abi_version(void);
+
+/* Kernel-selection overrides for tools/ and tests/ (NOT read on the product path: every option defaults to
+ * MSM_OPT_AUTO and the library then picks by shape).  Process-wide, set between launches; msm_set_option
+ * returns MSM_OK or MSM_E_INVALID (unknown key), msm_get_option the current value.  The library reads no environment variable. */
+#define MSM_OPT_AUTO (-1)
+enum {
+    MSM_OPT_MASK_NC = 0,        /* mask step wave tile: 1 = 2x16, 2 = 2x32 */
+    MSM_OPT_MASKB_TARGET,       /* workgroups of the bf16 mask step */
+    MSM_OPT_GEMM_TILE,          /* 0..4 tile configuration of msm_gemm_f32 */
+    MSM_OPT_GEMM_SHALLOW,       /* 1: no deep-K tiles */
+    MSM_OPT_ATTN_TARGET,        /* workgroup target of the split-K attention kernel */
+    MSM_OPT_ATTN_KERNEL,        /* 1: one wave per query block (<= 512 keys), 2: its two-block form (<= 128 keys), 3: split-K for every length */
+    MSM_OPT_ATTN_QK_MAX,        /* longest sequence the key-split kernel takes */
+    MSM_OPT_ATTN_QKCFG,         /* 0 / 1: two / one query blocks per workgroup in the key-split kernel */
+    MSM_OPT_CONVIN_NT,          /* 1, 2, 4: pixel tiles per workgroup of the input projection */
+    MSM_OPT_POST_GENERIC,       /* 1: generic mask upsample instead of the 4x form */
+    MSM_OPT_ENC_NO_COOP,        /* 1: encoder block without cooperative workgroups */
+    MSM_OPT_MSDA_GENERIC,       /* 1: generic head-major MSDeformAttn gather */
+    MSM_OPT_MS_CHUNK,           /* 1..8 seed blocks per hill-climb launch */
+    MSM_OPT_MS_NO_PERSISTENT,   /* 1: one launch per seeding step */
+    MSM_OPT_ATTN_FUSED_KV,      /* 0: never project K/V inside the attention kernel */
+    MSM_OPT_COUNT
+};
+int msm_set_option(int key, int value);
+int msm_get_option(int key);
 
 /* ---------------------------------------------------------------------------------------------
  * Generic fp32 MFMA GEMM:  C[b](m,n) = act( sum_k (A[b](m,k) + A2[b](m,k)) * W[b](n,k) + bias )
@@ -294,11 +319,17 @@ int msm_dec_heads(const float* x, const float* parts, int n_parts, const float* 
  * ------------------------------------------------------------------------------------------- */
 /* Farthest-point seeding (MS:155-187): indices[0] = first_index, then S-1 x { nearest =
  * min(nearest, 0.5*(1 - X.s)); next = first argmax }.  seeds_out [S][d], indices_out int64 [S].
- * workspace floats >= msm_ms_seed_workspace(n). */
+ * workspace floats >= msm_ms_seed_workspace(n).
+ * Maps of up to 393 216 rows take ONE persistent launch whose workgroups meet at a grid barrier after every step; that
+ * needs all of them co-resident.  When other work holds CUs for too long the kernel gives up at a bounded wait and
+ * writes -1 to every index (the seeds are then undefined): the caller re-issues the call with flags bit 0 set, which
+ * takes the one-launch-per-step path (identical results).  flags bit 0: stepwise path. */
+#define MSM_MS_SEED_STEPWISE 1
+#define MSM_MS_SEED_TEST_GIVE_UP 2   /* tests: the persistent kernel starts with its give-up flag raised */
 int64_t msm_ms_seed_workspace(int n);
 int msm_ms_select_seeds(const float* X, int n, int d, int num_seeds, int64_t first_index,
                         float* seeds_out, int64_t* indices_out,
-                        float* workspace, int64_t workspace_elems, void* stream);
+                        float* workspace, int64_t workspace_elems, int flags, void* stream);
 /* iters x { Z = normalize( exp(kappa * Z X^T) X ) } (MS:90-107); Z [S][d] updated in place. */
 int64_t msm_ms_hill_climb_workspace(int n, int S);
 int msm_ms_hill_climb(const float* X, int n, int d, float* Z, int S, float kappa, int iters,

@@ -25,3 +25,19 @@ def golden():
         return cache[name]
 
     return load
+
+
+@pytest.fixture
+def lib_option():
+    """Scoped msm_set_option overrides (kernel-selection switches of libmsm_hip.so): ``lib_option("MASK_NC", 1)``;
+    every option the test touched is restored to MSM_OPT_AUTO afterwards."""
+    from unseenobjectswithmeanshift_amd import _lib
+    touched = []
+
+    def set_(name, value):
+        touched.append(name)
+        _lib.set_option(name, value)
+
+    yield set_
+    for name in touched:
+        _lib.set_option(name, _lib.OPT_AUTO)

@@ -154,3 +154,19 @@ def ref_functions(path, names, namespace):
     mod = ast.Module(body=keep, type_ignores=[])
     exec(compile(mod, REF_ROOT + "/" + path, "exec"), namespace)
     return namespace
+
+
+def ref_method(path, cls_name, names, namespace):
+    """Like ref_functions for METHODS: execute only the named ``def``s of class ``cls_name`` of a reference source file as
+    plain functions in `namespace` (their first argument stays ``self``: the caller passes a stand-in object)."""
+    import ast
+    with open(REF_ROOT + "/" + path) as f:
+        tree = ast.parse(f.read())
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls_name]
+    assert cls, cls_name
+    keep = [n for n in cls[0].body if isinstance(n, ast.FunctionDef) and n.name in names]
+    missing = set(names) - {n.name for n in keep}
+    assert not missing, missing
+    mod = ast.Module(body=keep, type_ignores=[])
+    exec(compile(mod, REF_ROOT + "/" + path, "exec"), namespace)
+    return namespace

@@ -418,9 +418,54 @@ def g_ucn_backbone():
     save("ucn_backbone", feats=feats[:, :, ::3, ::3].contiguous(), rgb_only=rgb_only[:, :, ::6, ::6].contiguous())
 
 
+def g_instance_inference():
+    """instance_inference (pretrained_meanshiftformer_model.py:461-497) executed from the reference source with stand-ins for
+    the three detectron2 containers it touches.  Pins the top-k over Q*K class scores, the class labels, the binary masks
+    and the score arithmetic.  NOT pinned: BitMasks.get_bounding_boxes (detectron2 v0.6 code, absent) -- the stand-in returns
+    nothing, boxes stay out of the fixture."""
+    import torch.nn.functional as F_
+
+    class Inst:
+        def __init__(self, image_size):
+            self.image_size = image_size
+
+    class Boxes:
+        def __init__(self, t):
+            self.tensor = t
+
+    class BitMasks:
+        def __init__(self, t):
+            self.tensor = t
+
+        def get_bounding_boxes(self):
+            return None
+
+    ns = R.ref_method("MSMFormer/meanshiftformer/pretrained_meanshiftformer_model.py", "PretrainedMeanShiftMaskFormer",
+                      ["instance_inference"], {"torch": torch, "F": F_, "Instances": Inst, "Boxes": Boxes, "BitMasks": BitMasks})
+    arrs = {}
+    for case, (Q, K, h, w, topk, seed, blobs) in enumerate([(100, 2, 30, 40, 20, 1, True), (100, 2, 120, 160, 20, 2, True),
+                                                            (30, 1, 16, 24, 10, 3, False), (100, 2, 15, 20, 100, 4, True)]):
+        me = type("M", (), {})()
+        me.sem_seg_head = type("H", (), {"num_classes": K})()
+        me.device, me.num_queries, me.test_topk_per_image, me.panoptic_on = "cpu", Q, topk, False
+        mask_cls, low = syn.synth_instance_inputs(Q, h, w, num_classes=K, seed=seed, blobs=blobs)
+        up = F_.interpolate(low[None], size=(4 * h, 4 * w), mode="bilinear", align_corners=False)[0]       # PM:337-343
+        res = ns["instance_inference"](me, mask_cls, up)
+        # which (query, class) pairs were kept: recover the query index of every kept mask by matching the thresholded maps
+        scores = torch.softmax(mask_cls, -1)[:, :-1].flatten()
+        kept_scores, kept = scores.topk(topk, sorted=False)
+        assert torch.equal(res.pred_classes, kept % K)
+        assert torch.equal(res.pred_masks, (up[kept // K] > 0).float())
+        arrs.update({f"c{case}_cfg": np.array([Q, K, h, w, topk, seed, int(blobs)]), f"c{case}_pair": kept,
+                     f"c{case}_classes": res.pred_classes, f"c{case}_scores": res.scores,
+                     f"c{case}_mask_bits": packbits(res.pred_masks > 0), f"c{case}_mask_area": res.pred_masks.flatten(1).sum(1)})
+    save("instance_inference", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pe", "attn", "decoder", "msda", "msda_bwd", "pixel", "ms", "harness", "ucn", "ucn_backbone"]
+    which = sys.argv[1:] or ["pe", "attn", "decoder", "msda", "msda_bwd", "pixel", "ms", "harness", "ucn", "ucn_backbone", "inst"]
     fns = {"pe": g_position_encoding, "attn": g_hypersphere_attention, "decoder": g_decoder,
-           "msda": g_msda, "msda_bwd": g_msda_bwd, "pixel": g_pixel_decoder, "ms": g_mean_shift, "harness": g_harness, "ucn": g_ucn, "ucn_backbone": g_ucn_backbone}
+           "msda": g_msda, "msda_bwd": g_msda_bwd, "pixel": g_pixel_decoder, "ms": g_mean_shift, "harness": g_harness, "ucn": g_ucn, "ucn_backbone": g_ucn_backbone,
+           "inst": g_instance_inference}
     for w in which:
         fns[w]()

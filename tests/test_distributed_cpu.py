@@ -58,6 +58,33 @@ def test_gather_metrics_gloo_world2():
         assert sum(r["checksum"] for r in rec) == float(sum(range(16)))  # every image processed exactly once
 
 
+def test_bench_launcher_spawns_ranks_gloo_stub():
+    """`python bench.py --gpus 2` (no torch.distributed.run around it) starts two ranks itself, which rendezvous on
+    127.0.0.1, time the same number of steps between barriers and all_gather their records; rank 0 prints ONE JSON line with
+    n_gpus = 2.  --stub swaps the GPU step for a trivial CPU one (backend gloo), everything else is the production plumbing."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub", "--steps", "7", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 7 and rec["scaling"] == "weak" and rec["data"] == "stub"
+    assert rec["config"]["global_batch"] == 16 and rec["config"]["parallelism"] == "dp2"
+    assert [p["rank"] for p in rec["per_rank"]] == [0, 1] and [p["images"] for p in rec["per_rank"]] == [56.0, 56.0]
+    # each rank's checksum comes from its own data (rank r multiplies matrices of r+1): 64*64*64*(r+1)^2
+    assert [p["checksum"] for p in rec["per_rank"]] == [64.0 ** 3, 4 * 64.0 ** 3]
+    assert rec["value"] > 0 and abs(rec["value"] - 112 / (rec["ms_per_step"] * 7e-3)) < 1e-2 * rec["value"]
+    # under torch.distributed.run the ranks exist already (WORLD_SIZE set): a --gpus that disagrees is refused
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub"], capture_output=True, text=True,
+                         timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0"), cwd=root)
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
+
+
 def test_gather_metrics_single_process():
     assert gather_metrics({"images": 8, "elapsed_s": 1.0, "checksum": 2.0}) == [{"images": 8, "elapsed_s": 1.0, "checksum": 2.0}]
 

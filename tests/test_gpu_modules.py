@@ -428,6 +428,25 @@ def test_meta_arch_inference_vs_oracle():
     assert lab.shape == (64, 96)
 
 
+def test_instance_postprocess_pinned_to_reference(golden):
+    """a21 on the HIP path: msm_topk_class_scores + msm_instance_postprocess against the reference's instance_inference
+    (tests/golden/instance_inference.npz, generated by executing pretrained_meanshiftformer_model.py:461-497): kept (query,
+    class) pairs, classes and scores; binary masks bit-exact except where the upsampled logit is within rounding of zero."""
+    import test_oracle_vs_golden as tov
+    from unseenobjectswithmeanshift_amd import ops
+    g = golden("instance_inference")
+    for c, Q, K, h, w, topk, (mask_cls, low) in tov.instance_cases(g):
+        cls_scores, classes, qidx = ops.topk_class_scores(mask_cls[None].to(DEV), topk)
+        masks, scores, boxes = ops.instance_postprocess(low[None].to(DEV), qidx, (4 * h, 4 * w), class_scores=cls_scores)
+        pair = qidx[0].long() * K + classes[0]
+        diff = tov.check_instances_against_reference(g, c, K, pair, classes[0], scores[0], masks[0], rtol=1e-4)
+        if diff.any():
+            up = F.interpolate(low[None], size=(4 * h, 4 * w), mode="bilinear", align_corners=False)[0][qidx[0].cpu().long()]
+            assert diff.float().mean() < 1e-5 and float(up[diff].abs().max()) < 1e-5
+        ref_boxes = O.mask_boxes(masks[0].cpu() > 0)                 # v0.6 convention (unpinned), on the HIP path's own masks
+        assert torch.equal(boxes[0].cpu(), ref_boxes)
+
+
 def test_meta_arch_pads_to_size_divisibility():
     """A 60x90 frame is padded with zeros to 64x96 (ImageList.from_tensors, PM:275), the masks are upsampled to the
     padded frame and cropped back (PM:337-343, 354-357): model(images) against the oracle on the same features."""
@@ -448,6 +467,16 @@ def test_meta_arch_pads_to_size_divisibility():
         assert (inst.pred_masks.cpu() != ref["pred_masks"]).float().mean() < 1e-4
         torch.testing.assert_close(inst.scores.cpu(), ref["scores"], rtol=1e-4, atol=1e-6)
         assert torch.equal(inst.pred_classes.cpu(), ref["pred_classes"])
+    # pixel_mean / pixel_std (meanshiftformer_model.py:241): normalise first, then pad -> zeros in normalised space
+    mean, std = [123.675, 116.28, 103.53], [58.395, 57.12, 57.375]
+    mnorm = MeanShiftMaskFormer(backbone=bb, sem_seg_head=head, num_queries=100, pixel_mean=mean, pixel_std=std).to(DEV)
+    raw = images * 255.0
+    pre = (raw - torch.tensor(mean, device=DEV).view(3, 1, 1)) / torch.tensor(std, device=DEV).view(3, 1, 1)
+    r_norm, r_pre = mnorm([{"image": raw}]), model([{"image": pre}])
+    assert "pixel_mean" not in mnorm.state_dict()                               # non-persistent, as in the reference
+    for a_, b_ in zip(r_norm, r_pre):
+        assert torch.equal(a_["instances"].pred_masks, b_["instances"].pred_masks)
+        assert torch.equal(a_["instances"].scores, b_["instances"].scores)
     # features handed over directly: height / width name the image inside the padded frame
     res2 = model.__class__(backbone=None, sem_seg_head=head, num_queries=100)([{"features": feats, "height": 60, "width": 90}])
     assert torch.equal(res2[0]["instances"].pred_masks, res[0]["instances"].pred_masks)
@@ -506,6 +535,49 @@ def test_graphed_inference_equals_eager():
         g({k: v.cpu() for k, v in feats.items()}, (64, 96))
 
 
+def test_graph_replay_survives_cache_turnover_and_parameter_updates():
+    """A captured graph reads the modules' derived tensors (broadcast initial queries, folded K/V constants, packed weights)
+    by address.  Capturing other batch sizes / more geometries than the caches keep must not free what an older graph reads
+    (graphs.cache_refs), and a parameter update re-captures instead of replaying stale weights."""
+    import gc
+    from unseenobjectswithmeanshift_amd.meta_arch import MeanShiftMaskFormer
+    model = MeanShiftMaskFormer(backbone=None, sem_seg_head=make_pixel_decoder(), num_queries=100)
+    g = model.graphed()
+    fa = {k: v.to(DEV) for k, v in syn.synth_backbone_features(2, 64, 96, seed=3).items()}
+    want_a = [t.clone() for t in model.inference(fa, (64, 96))]
+    for a, b in zip(g(fa, (64, 96)), want_a):
+        assert torch.equal(a, b)
+    # other batch sizes and ten more geometries: every single-entry / bounded cache of the modules turns over
+    for B, (h, w) in [(1, (64, 96)), (3, (64, 96))] + [(1, (64 * i, 128)) for i in range(1, 11)]:
+        f = {k: v.to(DEV) for k, v in syn.synth_backbone_features(B, h, w, seed=5).items()}
+        g(f, (h, w))
+    gc.collect()
+    torch.cuda.empty_cache()
+    junk = [torch.full((1 << 20,), float("nan"), device=DEV) for _ in range(64)]      # reuse whatever the allocator freed
+    for a, b in zip(g(fa, (64, 96)), want_a):
+        assert torch.equal(a, b)
+    del junk
+    # a parameter update: the graph is re-captured on the new weights
+    with torch.no_grad():
+        model.sem_seg_head.predictor.query_feat.weight.mul_(0.5)
+        model.sem_seg_head.predictor.class_embed.bias.add_(0.25)
+    want_new = model.inference(fa, (64, 96))
+    assert not torch.equal(want_new[0], want_a[0])
+    for a, b in zip(g(fa, (64, 96)), want_new):
+        assert torch.equal(a, b)
+    pipe = model.pipelined(depth=2)
+    h0 = pipe.submit(fa, (64, 96))
+    for a, b in zip(pipe.result(h0, wait="host"), want_new):
+        assert torch.equal(a, b)
+    with torch.no_grad():
+        model.sem_seg_head.predictor.class_embed.bias.sub_(0.25)
+    want_3 = model.inference(fa, (64, 96))
+    pipe.submit(fa, (64, 96))                                      # slot 1: first build
+    h0 = pipe.submit(fa, (64, 96))                                 # slot 0: stale signature -> rebuilt
+    for a, b in zip(pipe.result(h0, wait="host"), want_3):
+        assert torch.equal(a, b)
+
+
 def test_pipelined_inference_equals_eager():
     """graphs.PipelinedInference: three batches in flight on three streams, each slot with its own graph and buffers;
     every batch's outputs equal the eager path's, in any consumption order, also when a slot is re-used and when the
@@ -542,24 +614,7 @@ def test_pipelined_inference_equals_eager():
         pipe.submit({k: v.cpu() for k, v in f1.items()}, (64, 96))
 
 
-class _TinyBackbone(torch.nn.Module):
-    """Test-only stand-in for the (out-of-scope) ResNet-50: average-pool pyramid + fixed random 1x1 mixing,
-    plain torch ops.  Gives res2..res5 with the right channel counts for any H, W divisible by 32."""
-
-    def __init__(self):
-        super().__init__()
-        g = torch.Generator().manual_seed(5)
-        self.mix = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(c, 6, generator=g) * 0.5) for c in (256, 512, 1024, 2048)])
-
-    def forward(self, images, depth=None):
-        x = images if depth is None else torch.cat([images, depth], 1)
-        if x.shape[1] == 3:
-            x = torch.cat([x, x], 1)
-        out = {}
-        for name, s, w in zip(("res2", "res3", "res4", "res5"), (4, 8, 16, 32), self.mix):
-            p = torch.nn.functional.avg_pool2d(x, s)
-            out[name] = torch.relu(torch.einsum("oc,bchw->bohw", w, p)).contiguous()
-        return out
+_TinyBackbone = syn.StandInBackbone      # test-only stand-in for the (out-of-scope) ResNet-50: right shapes, plain torch ops
 
 
 def test_two_stage_harness_on_gpu_vs_reference(golden):

@@ -118,8 +118,8 @@ def ref_mask_step(e, f, tgt):
 @pytest.mark.parametrize("B,Q,H,W,pool", [(2, 100, 16, 24, 2), (2, 100, 16, 24, 4), (2, 100, 16, 24, 8),
                                           (1, 100, 120, 160, 8), (1, 100, 120, 160, 4), (1, 100, 120, 160, 2),
                                           (1, 300, 48, 64, 4), (2, 20, 8, 8, 2), (2, 100, 16, 24, 1), (1, 100, 60, 80, 1)])
-def test_mask_logits(B, Q, H, W, pool, nc, monkeypatch):
-    monkeypatch.setenv("MSM_MASK_NC", nc)          # wave tile 2x32 (8-byte loads) or 2x16 (4-byte loads)
+def test_mask_logits(B, Q, H, W, pool, nc, lib_option):
+    lib_option("MASK_NC", int(nc))          # wave tile 2x32 (8-byte loads) or 2x16 (4-byte loads)
     C = 256
     e, f = rnd(B, Q, C, seed=1, scale=0.3), rnd(B, C, H, W, seed=2)
     tgt = (H // pool, W // pool)
@@ -141,11 +141,11 @@ def test_mask_logits(B, Q, H, W, pool, nc, monkeypatch):
     assert attn is None and row_any is None
 
 
-def test_mask_logits_tile_choice_is_result_neutral(monkeypatch):
+def test_mask_logits_tile_choice_is_result_neutral(lib_option):
     e, f = rnd(8, 100, 256, seed=3, scale=0.3).to(DEV), rnd(8, 256, 120, 160, seed=4).to(DEV)
     outs = []
     for nc in ("2", "1"):
-        monkeypatch.setenv("MSM_MASK_NC", nc)
+        lib_option("MASK_NC", int(nc))
         outs.append(ops().mask_logits(e, f, want_mask=True, target_size=(30, 40)))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
 
@@ -179,12 +179,10 @@ def test_hypersphere_attention(B, Lq, S, masked):
     got = ops().hypersphere_attention(*args, **kw)
     close(got, ref, rtol=1e-4, atol=2e-5)
     # the alternative kernels the host can be told to take: one wave per query block (<= 512 keys), split-K + combine
-    for env in ("MSM_ATTN_SMALL", "MSM_ATTN_SPLITK"):
-        os.environ[env] = "1"
-        try:
+    from unseenobjectswithmeanshift_amd._lib import option
+    for kernel in (1, 3):
+        with option("ATTN_KERNEL", kernel):
             alt = ops().hypersphere_attention(*args, **kw)
-        finally:
-            os.environ.pop(env)
         close(alt, ref, rtol=1e-4, atol=2e-5)
 
 
@@ -473,18 +471,45 @@ def test_mean_shift_kernels(golden):
 
 
 @pytest.mark.parametrize("n", [4096, 70001, 150000, 393216])
-def test_mean_shift_persistent_seeding_equals_stepwise(n, monkeypatch):
+def test_mean_shift_persistent_seeding_equals_stepwise(n, lib_option):
     """The single-launch persistent seeding kernel (map held in registers, grid barrier per step) selects exactly the
     indices of the one-launch-per-step path: same butterfly dot products, same (value, ~index) keys."""
     from unseenobjectswithmeanshift_amd import synthetic as syn
     X, _ = syn.synth_unit_embeddings(n, 64, clusters=9, sigma=0.2, seed=n % 97)
     Xd = X.to(DEV)
     seeds_p, sel_p = ops().ms_select_seeds(Xd, 40, n // 3)
-    monkeypatch.setenv("MSM_MS_NO_PERSISTENT", "1")
+    lib_option("MS_NO_PERSISTENT", 1)
     seeds_s, sel_s = ops().ms_select_seeds(Xd, 40, n // 3)
     assert int(sel_p.min()) >= 0                       # -1 would mean the persistent kernel gave up
     assert torch.equal(sel_p, sel_s) and torch.equal(seeds_p, seeds_s)
     assert int(sel_p[0]) == n // 3 and sel_p.unique().numel() == 40
+
+
+def test_mean_shift_seeding_give_up_falls_back(monkeypatch):
+    """When the persistent seeding kernel loses co-residency it gives up (every index -1); mean_shift_smart_init and
+    select_smart_seeds then re-run seeding on the one-launch-per-step path instead of raising -- same labels as a clean run."""
+    from unseenobjectswithmeanshift_amd import mean_shift as ms
+    from unseenobjectswithmeanshift_amd import ops as opsmod
+    from unseenobjectswithmeanshift_amd import synthetic as syn
+    X, _ = syn.synth_unit_embeddings(20000, 64, clusters=7, sigma=0.15, seed=5)
+    Xd = X.to(DEV)
+    _, sel = ops().ms_select_seeds(Xd, 30, 11, _test_give_up=True)
+    assert int(sel.max()) == -1                                    # the simulated give-up is reported, not fabricated
+    clean_labels, clean_sel = ms.mean_shift_smart_init(Xd, kappa=20, num_seeds=30, max_iters=10, first_index=11)
+    real = opsmod.ms_select_seeds
+    calls = []
+
+    def flaky(X_, S_, first, stepwise=False, _test_give_up=False):
+        calls.append(stepwise)
+        return real(X_, S_, first, stepwise=stepwise, _test_give_up=not stepwise)
+
+    monkeypatch.setattr(opsmod, "ms_select_seeds", flaky)
+    labels, sel = ms.mean_shift_smart_init(Xd, kappa=20, num_seeds=30, max_iters=10, first_index=11)
+    assert calls == [False, True]
+    assert torch.equal(sel, clean_sel) and torch.equal(labels, clean_labels)
+    calls.clear()
+    (seeds,) = ms.select_smart_seeds(Xd, 30, first_index=11)
+    assert calls == [False, True] and torch.equal(seeds, Xd[clean_sel])
 
 
 def test_mean_shift_many_seeds():
@@ -527,9 +552,9 @@ def test_topk_and_postprocess():
     assert float(ms[0, 0]) == 0.0 and torch.equal(boxes[0, 0].cpu(), torch.zeros(4))
     # the 4x-specialised strip kernel (register-cached taps) equals the generic one bit for bit
     if Hh == 4 * h and Ww == 4 * w:
-        os.environ["MSM_POST_GENERIC"] = "1"
-        pm_g, ms_g, boxes_g = ops().instance_postprocess(masks.to(DEV), force, (Hh, Ww))
-        os.environ.pop("MSM_POST_GENERIC")
+        from unseenobjectswithmeanshift_amd._lib import option
+        with option("POST_GENERIC", 1):
+            pm_g, ms_g, boxes_g = ops().instance_postprocess(masks.to(DEV), force, (Hh, Ww))
         assert torch.equal(pm, pm_g) and torch.equal(boxes, boxes_g)
         close(ms, ms_g.cpu(), rtol=1e-6, atol=1e-7)          # fp32 partial sums are grouped per strip in both, atomics order differs
     # padded frame: upsample to (Hh, Ww), keep the top-left (Hc, Wc) image (PM:275, 354-357); odd widths take the
@@ -612,11 +637,9 @@ def test_conv1x1_in_vs_fp64(B, Cin, H, W):
     k, o = torch.meshgrid(torch.arange(Cin), torch.arange(64), indexing="ij")
     idx = (((k // 8) * 4 + o // 16) * 64 + ((k % 8) // 2) * 16 + o % 16) * 2 + k % 2
     assert torch.equal(wp.cpu()[idx], w.t())
-    for nt in ("1", "2", "4", None):
-        if nt is None:
-            os.environ.pop("MSM_CONVIN_NT", None)
-        else:
-            os.environ["MSM_CONVIN_NT"] = nt
+    from unseenobjectswithmeanshift_amd._lib import set_option
+    for nt in (1, 2, 4, -1):
+        set_option("CONVIN_NT", nt)
         out, st = ops().conv1x1_in(x.to(DEV), wp, b.to(DEV))
         closed(out, ref, rtol=2e-5, atol=2e-5)
         mom = torch.stack([out.double().sum(1), (out.double() ** 2).sum(1)], -1).cpu()

@@ -209,3 +209,40 @@ def test_msda_c_restatement(golden):
     torch.testing.assert_close(o, T(g["t_float_out"]), rtol=1e-5, atol=1e-8)
     o = run(L.msda_ref_f32, np.float32, g["r_value"], g["r_shapes"], g["r_loc"], g["r_aw"])
     torch.testing.assert_close(o, T(g["r_out"]), rtol=1e-4, atol=1e-5)
+
+
+def instance_cases(g):
+    """(case id, Q, K, h, w, topk, inputs) of tests/golden/instance_inference.npz (inputs regenerated from the seed)."""
+    for c in range(4):
+        Q, K, h, w, topk, seed, blobs = (int(v) for v in g[f"c{c}_cfg"])
+        yield c, Q, K, h, w, topk, syn.synth_instance_inputs(Q, h, w, num_classes=K, seed=seed, blobs=bool(blobs))
+
+
+def check_instances_against_reference(g, c, K, pair, classes, scores, masks, rtol=1e-5):
+    """Order-insensitive comparison (the reference's topk(sorted=False) order is implementation defined, PM:469): rows are
+    matched through their (query, class) pair."""
+    ref_pair = T(g[f"c{c}_pair"]).long()
+    got_pair = pair.long().cpu()
+    assert sorted(ref_pair.tolist()) == sorted(got_pair.tolist())
+    pos = {int(p): i for i, p in enumerate(ref_pair.tolist())}
+    perm = torch.tensor([pos[int(p)] for p in got_pair.tolist()])
+    assert torch.equal(classes.cpu().long(), T(g[f"c{c}_classes"]).long()[perm])
+    torch.testing.assert_close(scores.cpu(), T(g[f"c{c}_scores"])[perm], rtol=rtol, atol=1e-7)
+    ref_masks = torch.from_numpy(unpack(g[f"c{c}_mask_bits"], tuple(masks.shape)))[perm]
+    return (masks.cpu() > 0) != ref_masks
+
+
+def test_instance_inference_pinned_to_reference(golden):
+    """a21: the oracle's instance_inference against the reference's own (AST-executed, stand-in containers): kept (query,
+    class) pairs, classes, scores and binary masks.  Boxes follow the documented detectron2 v0.6 convention and stay unpinned."""
+    g = golden("instance_inference")
+    for c, Q, K, h, w, topk, (mask_cls, low) in instance_cases(g):
+        res = O.instance_inference(mask_cls, low, (4 * h, 4 * w), topk=topk)
+        pair = res["query_index"] * K + res["pred_classes"]
+        diff = check_instances_against_reference(g, c, K, pair, res["pred_classes"], res["scores"], res["pred_masks"])
+        assert not diff.any()
+        torch.testing.assert_close(res["pred_masks"].flatten(1).sum(1), T(g[f"c{c}_mask_area"])[
+            torch.tensor([T(g[f"c{c}_pair"]).tolist().index(int(p)) for p in pair.tolist()])])
+        # the canonical order of this build: score-descending (ties by index)
+        s = torch.softmax(mask_cls, -1)[:, :-1].flatten()[pair]
+        assert bool((s[:-1] >= s[1:]).all())

@@ -62,7 +62,7 @@ def gemm():
         out = torch.empty(M, N, device=DEV)
         t = timeit(lambda: ops.gemm(a, w, b, out=out))
         print(f"{name:6s} M={M:6d} N={N:5d} K={K:5d}  {t:8.1f} us  {2.0 * M * N * K / t / 1e6:7.1f} TFLOP/s  "
-              f"tile={os.environ.get('MSM_GEMM_TILE', 'auto')} nostore={'MSM_GEMM_NOSTORE' in os.environ}", flush=True)
+              f"tile={_lib.lib().msm_get_option(_lib.OPTIONS.index('GEMM_TILE'))}", flush=True)
 
 
 def mask():
@@ -75,9 +75,7 @@ def mask():
         f = torch.randn(8, C, 120, 160, device=DEV)
         flops = 2.0 * 100 * C * 19200 * 8
         for nc in ("2", "1", ""):
-            os.environ.pop("MSM_MASK_NC", None)
-            if nc:
-                os.environ["MSM_MASK_NC"] = nc
+            _lib.set_option("MASK_NC", int(nc) if nc else _lib.OPT_AUTO)
             for tgt, wm in (((15, 20), False), ((30, 40), False), ((60, 80), False), (None, True)):
                 t = timeit_graph(lambda: ops.mask_logits(e, f, want_mask=wm, target_size=tgt, qbias=qb))
                 print(f"mask C={C} nc={nc or 'auto'} target={tgt} write={wm}: {t:7.1f} us  {flops / t / 1e6:6.1f} TFLOP/s executed", flush=True)
@@ -118,9 +116,8 @@ def enc():
     proj.mul_(0.3)                                   # sampling offsets of a few pixels, like a trained model's
     t = timeit_graph(lambda: ops.ms_deform_attn_encoder(vhm, ss, st, proj, 8, 4))
     print(f"msda enc, head-major value (quad-cooperative D=8 kernel): {t:7.1f} us", flush=True)
-    os.environ["MSM_MSDA_GENERIC"] = "1"
-    t = timeit_graph(lambda: ops.ms_deform_attn_encoder(vhm, ss, st, proj, 8, 4))
-    os.environ.pop("MSM_MSDA_GENERIC")
+    with _lib.option("MSDA_GENERIC", 1):
+        t = timeit_graph(lambda: ops.ms_deform_attn_encoder(vhm, ss, st, proj, 8, 4))
     print(f"msda enc, head-major value (generic kernel): {t:7.1f} us", flush=True)
     # same taps per lane and bytes, but 64-byte instead of 32-byte contiguous segments (4 heads x 16 dims)
     proj4 = torch.randn(B, S, 144, device=DEV)
@@ -171,9 +168,7 @@ def convs():
         st0 = torch.zeros(B, 64, 2, device=DEV, dtype=torch.float64)
         wpk = ops.pack_conv_in_weight(wt)
         for ntv in ("1", "2", "4", ""):
-            os.environ.pop("MSM_CONVIN_NT", None)
-            if ntv:
-                os.environ["MSM_CONVIN_NT"] = ntv
+            _lib.set_option("CONVIN_NT", int(ntv) if ntv else _lib.OPT_AUTO)
             t3 = timeit_graph(lambda: ops.conv1x1_in(x, wpk, b, stats=st0, stats_cleared=True))
             o3, s3 = ops.conv1x1_in(x, wpk, b)
             err = (o3 - tok).abs().max().item()
@@ -183,7 +178,7 @@ def convs():
         by = (x.numel() + tok.numel()) * 4
         print(f"{name} {cin}->64 @{h}x{w}: conv {t:6.1f} us ({by / t / 1e6:5.2f} TB/s, {2.0 * B * h * w * cin * 64 / t / 1e6:5.1f} TFLOP/s)"
               f"   groupnorm {t2:6.1f} us", flush=True)
-    os.environ.pop("MSM_CONVIN_NT", None)
+    _lib.set_option("CONVIN_NT", _lib.OPT_AUTO)
     xs = [torch.randn(B, c, h, w, device=DEV) for c, h, w in ((2048, 15, 20), (1024, 30, 40), (512, 60, 80))]
     wps = [ops.pack_conv_in_weight(torch.randn(64, x.shape[1], device=DEV) * 0.05) for x in xs]
     bs = [torch.randn(64, device=DEV) for _ in xs]

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmsm_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "msm_hip.h")
 
 _lib = None
-ABI_VERSION = 6      # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
+ABI_VERSION = 7      # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
 
 c_f = ctypes.c_void_p      # float* (device)
 c_p = ctypes.c_void_p
@@ -24,6 +24,8 @@ c_fl = ctypes.c_float
 _SIGNATURES = {
     "msm_abi_version": (c_i, []),
     "msm_last_error_string": (ctypes.c_char_p, []),
+    "msm_set_option": (c_i, [c_i, c_i]),
+    "msm_get_option": (c_i, [c_i]),
     "msm_gemm_f32": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i,
                            c_l, c_l, c_l, c_l, c_l, c_l, c_l, c_l, c_l,
                            c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
@@ -54,7 +56,7 @@ _SIGNATURES = {
     "msm_dec_post_self": (c_i, [c_f] * 9 + [c_i, c_f, c_f, c_i, c_i, c_i, c_fl, c_p]),
     "msm_dec_heads": (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, c_i] + [c_f] * 15 + [c_p, c_i, c_i, c_i, c_fl, c_p]),
     "msm_ms_seed_workspace": (c_l, [c_i]),
-    "msm_ms_select_seeds": (c_i, [c_f, c_i, c_i, c_i, c_l, c_f, c_p, c_f, c_l, c_p]),
+    "msm_ms_select_seeds": (c_i, [c_f, c_i, c_i, c_i, c_l, c_f, c_p, c_f, c_l, c_i, c_p]),
     "msm_ms_hill_climb_workspace": (c_l, [c_i, c_i]),
     "msm_ms_hill_climb": (c_i, [c_f, c_i, c_i, c_f, c_i, c_fl, c_i, c_f, c_l, c_p]),
     "msm_ms_assign": (c_i, [c_f, c_i, c_i, c_f, c_i, c_p, c_p, c_p, c_i, c_p]),
@@ -97,6 +99,79 @@ def lib():
             raise RuntimeError(f"{LIB_PATH} has ABI {L.msm_abi_version()}, these bindings need {ABI_VERSION}: rebuild it")
         _lib = L
     return _lib
+
+
+# kernel-selection overrides of include/msm_hip.h (enum order), for tools/ and tests/ only
+OPTIONS = ("MASK_NC", "MASKB_TARGET", "GEMM_TILE", "GEMM_SHALLOW", "ATTN_TARGET", "ATTN_KERNEL", "ATTN_QK_MAX", "ATTN_QKCFG",
+           "CONVIN_NT", "POST_GENERIC", "ENC_NO_COOP", "MSDA_GENERIC", "MS_CHUNK", "MS_NO_PERSISTENT", "ATTN_FUSED_KV")
+OPT_AUTO = -1
+
+
+def set_option(name, value=OPT_AUTO):
+    """msm_set_option(MSM_OPT_<name>, value); value OPT_AUTO restores the library's own choice.  Returns the old value."""
+    key = OPTIONS.index(name)
+    old = lib().msm_get_option(key)
+    check(lib().msm_set_option(key, int(value)), "msm_set_option")
+    return old
+
+
+class option:
+    """``with option("MASK_NC", 1): ...`` -- scoped override, restored on exit."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
+        return False
+
+
+class CallTimer:
+    """Measurement aid for bench.py: while active, every launch entry point of the library (``msm_*`` functions taking a
+    stream) is bracketed by HIP events recorded on the stream it launches on (torch's current stream -- the one ops._stream()
+    hands to the library).  ``durations()`` -> {entry point: [ms per call]} after a synchronize.  Eager launches only:
+    events cannot time nodes inside a HIP-graph replay."""
+
+    def __init__(self):
+        self.records = []
+        self._saved = {}
+
+    def __enter__(self):
+        import torch
+        L = lib()
+        for name, (_, args) in _SIGNATURES.items():
+            if not args or args[-1] is not c_p or name.endswith("_workspace"):
+                continue
+            fn = getattr(L, name)
+            self._saved[name] = fn
+
+            def wrapped(*a, _fn=fn, _name=name):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = _fn(*a)
+                e1.record()
+                self.records.append((_name, e0, e1))
+                return rc
+
+            setattr(L, name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        L = lib()
+        for name, fn in self._saved.items():
+            setattr(L, name, fn)
+        self._saved = {}
+        return False
+
+    def durations(self):
+        out = {}
+        for name, e0, e1 in self.records:
+            out.setdefault(name, []).append(e0.elapsed_time(e1))
+        return out
 
 
 def check(rc, what):

@@ -29,7 +29,7 @@ constexpr int PSTRIDE = HD + 1;    // partial row: 32 outputs + softmax denomina
 
 static int attn_nsplit(int B, int qchunks, int heads, int S) {
     const int base = B * qchunks * heads;
-    static const int target = getenv("MSM_ATTN_TARGET") ? atoi(getenv("MSM_ATTN_TARGET")) : 512;
+    const int target = opt(MSM_OPT_ATTN_TARGET) > 0 ? opt(MSM_OPT_ATTN_TARGET) : 512;
     int ns = cdiv(target, base);
     const int maxs = max(1, S / 128);  // >= 2 key blocks per wave
     if (ns > maxs) ns = maxs;
@@ -651,13 +651,14 @@ extern "C" int msm_hypersphere_attn_fwd(const float* q, const float* k, const fl
         return MSM_E_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (S <= 512 && getenv("MSM_ATTN_SMALL") != nullptr) {
+    const int force = opt(MSM_OPT_ATTN_KERNEL);
+    if (S <= 512 && (force == 1 || force == 2)) {
         // query-split kernel, one wave per query block walking all keys, finished in registers.  Not the default any
         // more: a lone wave per SIMD exposes every dependency of a key block (~0.9 us per block whatever the load
         // ring depth), and with the host out of the way (HIP-graph timing) the key-split kernel below is faster down to
         // the shortest sequences: 300 keys 11.0 against 19.9 us, 100 keys (self-attention) 8.0 against 9.4 us.
         const int qblocks = cdiv(Lq, 16);
-        if (getenv("MSM_ATTN_MQ2") != nullptr && S <= 128) {
+        if (force == 2 && S <= 128) {
             dim3 grid(cdiv(qblocks, 8), heads, B);
             hipLaunchKernelGGL((hs_attn_small_kernel<2>), grid, dim3(256), 0, st, q, k, v, masked, row_any, out, Lq, S, heads, ldq,
                                q_sb, ldk, k_sb, ldv, v_sb, kappa);
@@ -669,12 +670,12 @@ extern "C" int msm_hypersphere_attn_fwd(const float* q, const float* k, const fl
         MSM_CHECK_LAUNCH("msm_hypersphere_attn_fwd(small)");
         return MSM_OK;
     }
-    static const int qk_max = getenv("MSM_ATTN_QK_MAX") ? atoi(getenv("MSM_ATTN_QK_MAX")) : 2048;
-    if (S <= qk_max && getenv("MSM_ATTN_SPLITK") == nullptr) {
+    const int qk_max = opt(MSM_OPT_ATTN_QK_MAX) > 0 ? opt(MSM_OPT_ATTN_QK_MAX) : 2048;
+    if (S <= qk_max && force != 3) {
         // short and medium sequences: query-split workgroups whose waves split the keys (measured at 1200 keys: 23 us against
         // 25 + 8 us for the split-K kernel + combine; at 4800 keys the split-K kernel, which normalises each key block
         // once for all 7 query blocks, is faster: 60 + 8 against 71 us)
-        static const int cfg_env = getenv("MSM_ATTN_QKCFG") ? atoi(getenv("MSM_ATTN_QKCFG")) : -1;
+        const int cfg_env = opt(MSM_OPT_ATTN_QKCFG);
         // one query block per workgroup for the shortest sequences (self-attention, 100 keys: 6.9 against 8.0 us), two
         // otherwise (K/V are read by half as many workgroups); other shapes measured slower at every length
         const int cfg = cfg_env >= 0 ? cfg_env : (S <= 128 ? 1 : 0);

@@ -10,6 +10,8 @@
 namespace msm {
 
 void set_error(const char* fmt, ...);
+// msm_set_option() value of MSM_OPT_* `key` (MSM_OPT_AUTO unless a tool or test set it)
+int opt(int key);
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, size): cheap on the hot path and
 // keeps the call out of HIP-graph capture after warm-up.  Returns a hipError_t value.
 int ensure_dynamic_lds(const void* kernel, size_t bytes);

@@ -235,7 +235,7 @@ using namespace msm;
 static int conv_in_config(int B, int Cin, int HW, int& nt) {
     const int64_t t64 = (int64_t)cdiv(HW, 64) * B;
     nt = t64 >= 512 ? 4 : (t64 >= 128 ? 2 : 1);
-    if (const char* e = getenv("MSM_CONVIN_NT")) nt = atoi(e) == 4 ? 4 : (atoi(e) == 2 ? 2 : 1);
+    if (const int o = opt(MSM_OPT_CONVIN_NT); o != MSM_OPT_AUTO) nt = o == 4 ? 4 : (o == 2 ? 2 : 1);
     const int kw = Cin / CI_W;
     if (nt == 4) return 0;
     if (nt == 2) return kw % 32 == 0 ? 1 : 2;

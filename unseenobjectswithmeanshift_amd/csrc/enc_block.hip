@@ -569,7 +569,7 @@ extern "C" int msm_encoder_block_fwd(const float* attn, const float* src, const 
     const int tiles = cdiv(M, 16);
     int n_normal = tiles / 4;
     const int extra = n_normal % 256;
-    if (n_normal >= 256 && extra <= 64 && getenv("MSM_ENC_NO_COOP") == nullptr) n_normal -= extra;
+    if (n_normal >= 256 && extra <= 64 && opt(MSM_OPT_ENC_NO_COOP) != 1) n_normal -= extra;
     const int n_coop = tiles - n_normal * 4;
     dim3 grid(n_normal + n_coop), block(256);
     hipLaunchKernelGGL(enc_block_kernel, grid, block, lds, (hipStream_t)stream, attn, src,

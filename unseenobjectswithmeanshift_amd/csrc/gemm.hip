@@ -28,7 +28,6 @@ struct GemmArgs {
     int conv_h, conv_w, conv_c;
     int bias_mode, act, split_k, k_per_split;
     int vec_a, vec_w, vec_c;
-    int dbg_nostore;   // tuning only (MSM_GEMM_NOSTORE=1): skip the epilogue stores
 };
 
 constexpr int BK = 32;
@@ -255,7 +254,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
                 }
                 v[r] = t;
             }
-            if (p.dbg_nostore && v[0] != 12345.678f) continue;
             float* dst = Cb + (int64_t)mb * p.c_sm + (int64_t)nb * p.c_sn;
             const bool full = SWAP ? (nb + 3 < p.N) : (mb + 3 < p.M);
             if (p.vec_c && full) {
@@ -296,11 +294,11 @@ static int launch_gemm_o(const GemmArgs& p, hipStream_t st) {
         if (blocks > best_blocks) { best_blocks = (int)blocks; fallback = c; }
     }
     if (pick < 0) pick = fallback;
-    if (const char* e = getenv("MSM_GEMM_TILE")) pick = atoi(e);
+    if (const int o = opt(MSM_OPT_GEMM_TILE); o >= 0 && o <= 4) pick = o;
     const int mi = cfgs[pick][0], ni = cfgs[pick][1];
     dim3 grid(cdiv(p.N, 32 * ni), cdiv(p.M, 32 * mi), p.batch * p.split_k);
     // deep LDS tiles for the small latency-bound shapes (row-major activations only)
-    const bool deep = AMODE == 0 && pick >= 3 && p.k_per_split >= 128 && getenv("MSM_GEMM_SHALLOW") == nullptr;
+    const bool deep = AMODE == 0 && pick >= 3 && p.k_per_split >= 128 && opt(MSM_OPT_GEMM_SHALLOW) != 1;
     switch (pick) {
         case 0: hipLaunchKernelGGL((gemm_kernel<4, 4, AMODE, SWAP, true, HAS_A2, 1>), grid, block, 0, st, p); break;
         case 1: hipLaunchKernelGGL((gemm_kernel<2, 4, AMODE, SWAP, true, HAS_A2, 1>), grid, block, 0, st, p); break;
@@ -354,7 +352,6 @@ extern "C" int msm_gemm_f32(const float* A, const float* A2, const float* W, con
     p.c_sm = c_sm; p.c_sn = c_sn; p.c_sb = c_sb; p.c_ss = c_ss;
     p.conv_h = conv_h; p.conv_w = conv_w; p.conv_c = conv_c;
     p.bias_mode = bias_mode; p.act = act; p.split_k = split_k;
-    p.dbg_nostore = getenv("MSM_GEMM_NOSTORE") != nullptr;
     int kps = cdiv(K, split_k);
     kps = cdiv(kps, BK) * BK;  // whole 32-deep sub-tiles per split (deep tiles zero-fill their tail)
     p.k_per_split = kps;

@@ -491,7 +491,7 @@ extern "C" int msm_mask_logits_fwd(const float* mask_embed, const float* mask_fe
     const int64_t t16 = (int64_t)n_rowpairs * cdiv(W, 16) * B * qchunks;
     const double cost32 = (double)cdiv(t32, 1024), cost16 = 0.5 * (double)cdiv(t16, 1024);
     int nc = (cost16 * 1.04 < cost32) ? 1 : 2;
-    if (const char* e = getenv("MSM_MASK_NC")) nc = atoi(e) == 1 ? 1 : 2;
+    if (const int o = opt(MSM_OPT_MASK_NC); o != MSM_OPT_AUTO) nc = o == 1 ? 1 : 2;
     const int ctiles = cdiv(W, 16 * nc);
     const int ntiles = n_rowpairs * ctiles;
     // persistent-ish grid: enough workgroups per (image, chunk) to cover the chip once
@@ -570,7 +570,7 @@ extern "C" int msm_mask_logits_bf16_fwd(const float* mask_embed, const uint16_t*
     // one workgroup per CU: with more, re-staging mask_embed (100 KB per workgroup) costs more than the extra loads in
     // flight gain (measured 30 us at 256 workgroups, 41 us at 512, 46 us at 1024)
     int wg_per = cdiv(ntiles, MW);
-    static const int tgt_total = getenv("MSM_MASKB_TARGET") ? atoi(getenv("MSM_MASKB_TARGET")) : 256;
+    const int tgt_total = opt(MSM_OPT_MASKB_TARGET) > 0 ? opt(MSM_OPT_MASKB_TARGET) : 256;
     const int target = cdiv(tgt_total, B * qchunks);
     if (wg_per > target) wg_per = max(target, 1);
     dim3 grid(wg_per, qchunks, B), block(MW * 64);

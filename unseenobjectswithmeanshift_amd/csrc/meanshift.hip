@@ -251,8 +251,8 @@ __global__ __launch_bounds__(PS_W * 64) void ms_seed_persistent_kernel(const flo
     }
 }
 
-__global__ void ms_seed_status_init_kernel(unsigned int* __restrict__ status) {
-    if (threadIdx.x < 2) status[threadIdx.x] = 0u;
+__global__ void ms_seed_status_init_kernel(unsigned int* __restrict__ status, unsigned int give_up) {
+    if (threadIdx.x < 2) status[threadIdx.x] = threadIdx.x == 1 ? give_up : 0u;
 }
 
 __global__ void ms_seed_init_kernel(unsigned long long* __restrict__ keys, int num_seeds, int64_t first) {
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256) void ms_assign_kernel(const float* __restrict_
             }
             const int p = p0 + lq * 4 + r;
             if (lj == 0 && p < n) {
-                const int64_t lab = seed_labels[bi[r]];
+                const int64_t lab = seed_labels[min(bi[r], S - 1)];        // all-NaN distances leave bi at its sentinel
                 labels_out[p] = lab;
                 if (lab >= 0 && lab < num_labels) atomicAdd(&hist[(int)lab], 1u);
             }
@@ -507,13 +507,10 @@ static int seed_blocks(int n) {
     const int passes = max(1, cdiv(n, 256 * 2048));
     return max(1, cdiv(n, 256 * passes));
 }
-// seed blocks per hill-climb launch: equal chunks of at most `cap` blocks (env MSM_MS_CHUNK overrides the cap)
+// seed blocks per hill-climb launch: equal chunks of at most `cap` blocks (MSM_OPT_MS_CHUNK overrides the cap)
 static int hill_chunk(int nsb) {
-    static const int cap = [] {
-        const char* e = getenv("MSM_MS_CHUNK");
-        const int v = e ? atoi(e) : 0;
-        return (v >= 1 && v <= MS_CH) ? v : MS_CH;
-    }();
+    const int v = opt(MSM_OPT_MS_CHUNK);
+    const int cap = (v >= 1 && v <= MS_CH) ? v : MS_CH;
     return cdiv(nsb, cdiv(nsb, cap));
 }
 static int hill_wgs(int n) { return max(1, min(512, ((n + 15) / 16 + 3) / 4)); }
@@ -526,7 +523,7 @@ using namespace msm;
 extern "C" int64_t msm_ms_seed_workspace(int n) { return (int64_t)n + 2 * (MS_SB * 16) + 16; }
 
 extern "C" int msm_ms_select_seeds(const float* X, int n, int d, int num_seeds, int64_t first_index, float* seeds_out,
-                                   int64_t* indices_out, float* workspace, int64_t workspace_elems, void* stream) {
+                                   int64_t* indices_out, float* workspace, int64_t workspace_elems, int flags, void* stream) {
     MSM_REQUIRE(X && seeds_out && indices_out && workspace, "msm_ms_select_seeds: null pointer");
     MSM_REQUIRE(d == MS_D, "msm_ms_select_seeds: d=%d, only d=64 is supported", d);
     MSM_REQUIRE(n > 0 && num_seeds > 0 && first_index >= 0 && first_index < n, "msm_ms_select_seeds: bad sizes");
@@ -550,8 +547,9 @@ extern "C" int msm_ms_select_seeds(const float* X, int n, int d, int num_seeds, 
     const int ng = cdiv(n, 256 * PS_W * 64);                       // rows per workgroup = 512 * ng
     const int pgrid = ng >= 1 && ng <= 3 ? cdiv(n, PS_W * 64 * ng) : 0;
     unsigned int* status = reinterpret_cast<unsigned int*>(workspace + 2 * (MS_SB * 16) + 4);   // 2 words between keys and nearest
-    if (pgrid > 0 && pgrid <= n_cus && n >= 4096 && num_seeds > 2 && getenv("MSM_MS_NO_PERSISTENT") == nullptr) {
-        hipLaunchKernelGGL(ms_seed_status_init_kernel, dim3(1), dim3(64), 0, st, status);
+    if (pgrid > 0 && pgrid <= n_cus && n >= 4096 && num_seeds > 2 && !(flags & MSM_MS_SEED_STEPWISE) &&
+        opt(MSM_OPT_MS_NO_PERSISTENT) != 1) {
+        hipLaunchKernelGGL(ms_seed_status_init_kernel, dim3(1), dim3(64), 0, st, status, (flags & MSM_MS_SEED_TEST_GIVE_UP) ? 1u : 0u);
         switch (ng) {
             case 1: hipLaunchKernelGGL(ms_seed_persistent_kernel<1>, dim3(pgrid), dim3(PS_W * 64), 0, st, X, n, keys, num_seeds, status); break;
             case 2: hipLaunchKernelGGL(ms_seed_persistent_kernel<2>, dim3(pgrid), dim3(PS_W * 64), 0, st, X, n, keys, num_seeds, status); break;

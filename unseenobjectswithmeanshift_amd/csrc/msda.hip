@@ -614,7 +614,7 @@ extern "C" int msm_msdeform_attn_enc_hm_fwd(const float* value_hm, const int64_t
     MSM_REQUIRE((int64_t)S * D < ((int64_t)1 << 31), "msm_msdeform_attn_enc_hm_fwd: S*D must fit 31 bits");
     const int64_t per_img = (int64_t)S * M * G;
     dim3 grid((unsigned)(((per_img + 255) / 256) * B)), block(256);
-    if (D == 8 && L * P <= 16 && (int64_t)S * D < ((int64_t)1 << 31) && getenv("MSM_MSDA_GENERIC") == nullptr)
+    if (D == 8 && L * P <= 16 && (int64_t)S * D < ((int64_t)1 << 31) && opt(MSM_OPT_MSDA_GENERIC) != 1)
         hipLaunchKernelGGL(msda_enc_hm8_kernel, grid, block, 0, (hipStream_t)stream, value_hm, spatial_shapes,
                            level_start_index, proj, out, B, S, M, L, P);
     else if (V == 4)

@@ -25,15 +25,19 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ log
         for (int c = 0; c < K1; ++c) mx = fmaxf(mx, lg[qi * K1 + c]);
         float den = 0.f;
         for (int c = 0; c < K1; ++c) den += expf(lg[qi * K1 + c] - mx);
+        // NaN logits rank as -inf (a total order: every slot of the outputs is written, the reference's topk would
+        // return NaN scores in an arbitrary order); the NaN itself is what is reported as the score
         for (int c = 0; c < K; ++c) sc[qi * K + c] = expf(lg[qi * K1 + c] - mx) / den;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += 256) {
         const float s = sc[i];
+        const float sk = s != s ? -INFINITY : s;
         int rank = 0;
         for (int j = 0; j < n; ++j) {
-            const float o = sc[j];
-            rank += (o > s || (o == s && j < i)) ? 1 : 0;
+            float o = sc[j];
+            o = o != o ? -INFINITY : o;
+            rank += (o > sk || (o == sk && j < i)) ? 1 : 0;
         }
         if (rank < T) {
             scores_out[(int64_t)b * T + rank] = s;
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(256) void inst_upsample_kernel(const float* __restr
                                                             int h, int w, int H, int W, int Hs, int Ws, int rows_per_block) {
     const int bt = blockIdx.z;
     const int b = bt / T;
-    const int q = qidx[bt];
+    const int q = min(max(qidx[bt], 0), Q - 1);          // caller-supplied indices never address outside the logits
     const float* src = logits + ((int64_t)b * Q + q) * h * w;
     float* dst = masks + (int64_t)bt * H * W;
     const float sy = (float)h / (float)Hs, sx = (float)w / (float)Ws;     // scale of the (padded) frame; rows/cols >= H/W are cropped
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(256) void inst_upsample4_kernel(const float* __rest
                                                              int h, int w, int H, int W, int Hs, int Ws) {
     const int bt = blockIdx.z;
     const int b = bt / T;
-    const int q = qidx[bt];
+    const int q = min(max(qidx[bt], 0), Q - 1);          // caller-supplied indices never address outside the logits
     const float* src = logits + ((int64_t)b * Q + q) * h * w;
     float* dst = masks + (int64_t)bt * H * W;
     const float sy = (float)h / (float)Hs, sx = (float)w / (float)Ws;
@@ -315,7 +319,7 @@ extern "C" int msm_instance_postprocess(const float* mask_logits, const int32_t*
     const int cols = (W % 4 == 0) ? W / 4 : W;                 // threads needed across a row
     const int threads = min(256, cdiv(cols, 64) * 64);          // whole waves, no idle wave (640 px -> 192 threads)
     dim3 grid(cdiv(cols, threads), cdiv(H, rows), n);
-    if (Hs == 4 * h && Ws == 4 * w && W % 4 == 0 && getenv("MSM_POST_GENERIC") == nullptr)
+    if (Hs == 4 * h && Ws == 4 * w && W % 4 == 0 && opt(MSM_OPT_POST_GENERIC) != 1)
         hipLaunchKernelGGL(inst_upsample4_kernel, grid, dim3(threads), 0, st, mask_logits, query_index, pred_masks, acc, Q, T, h, w,
                            H, W, Hs, Ws);
     else

@@ -11,6 +11,31 @@ import warnings
 
 import torch
 
+# attributes under which the modules keep derived tensors (packed weights, folded constants, position codes, broadcast
+# queries) that the kernels of a forward read by address
+_CACHE_ATTRS = ("_q0", "_kv_cache", "_fold_cache", "_tails_cache", "_pos_cache", "_cache", "_packed", "_front", "_w3_cache",
+                "_packed_mf", "_bf16_cache", "_folded_cache")
+
+
+def cache_refs(model):
+    """Strong references to every derived-tensor cache entry the model holds right now.  A captured HIP graph bakes the
+    device addresses of these tensors into its nodes; the modules may later replace or evict the entries (another batch
+    size, more input geometries than a cache keeps, a parameter update), so a graph keeps what it was captured with alive
+    for as long as it can be replayed."""
+    refs = []
+    for m in model.modules():
+        for a in _CACHE_ATTRS:
+            v = m.__dict__.get(a)
+            if v is not None:
+                refs.append(dict(v) if isinstance(v, dict) else v)      # a dict is copied: eviction edits it in place
+    return refs
+
+
+def param_signature(model):
+    """Changes whenever a parameter or buffer is replaced or modified in place (load_state_dict, an optimizer step): graphs
+    captured before are then stale -- their nodes read the derived caches of the OLD values -- and are re-captured."""
+    return tuple((t.data_ptr(), t._version) for t in list(model.parameters()) + list(model.buffers()))
+
 
 class GraphedInference:
     """``GraphedInference(model)(features, image_size)`` == ``model.inference(features, image_size)`` (meta_arch.py),
@@ -33,7 +58,10 @@ class GraphedInference:
             if not v.is_cuda:
                 raise RuntimeError("GraphedInference needs device tensors (there is no CPU path)")
         key = self._key(features, image_size, padded_size)
+        sig = param_signature(self.model)
         entry = self._graphs.get(key)
+        if entry is not None and entry[3] != sig:          # parameters changed since the capture
+            entry = None
         if entry is None:
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=next(iter(features.values())).device)
@@ -48,9 +76,9 @@ class GraphedInference:
                 with torch.cuda.graph(graph, stream=self._stream):
                     static_out = self.model.inference(static_in, image_size, padded_size)
             cur.wait_stream(self._stream)
-            entry = (graph, static_in, static_out)
+            entry = (graph, static_in, static_out, sig, cache_refs(self.model))
             self._graphs[key] = entry
-        graph, static_in, static_out = entry
+        graph, static_in, static_out = entry[:3]
         for k, v in features.items():
             static_in[k].copy_(v)
         graph.replay()
@@ -113,7 +141,7 @@ class PipelinedInference:
             with torch.cuda.graph(graph, stream=stream):
                 static_out = self.model.inference(static_in, image_size, padded_size)
         self._slots[i] = (self._key(features, image_size, padded_size), stream, graph, static_in, static_out,
-                          torch.cuda.Event())
+                          torch.cuda.Event(), param_signature(self.model), cache_refs(self.model))
         return self._slots[i]
 
     def inputs(self, slot):
@@ -134,15 +162,16 @@ class PipelinedInference:
             for v in features.values():
                 if not v.is_cuda:
                     raise RuntimeError("PipelinedInference needs device tensors (there is no CPU path)")
-            if entry is None or entry[0] != self._key(features, image_size, padded_size):
+            if entry is None or entry[0] != self._key(features, image_size, padded_size) or entry[6] != param_signature(self.model):
                 entry = self._build(i, features, image_size, padded_size)
         self._next = (i + 1) % self.depth
-        _, stream, graph, static_in, _, done = entry
+        stream, graph, static_in, done = entry[1], entry[2], entry[3], entry[5]
         stream.wait_stream(torch.cuda.current_stream())            # the producer of the inputs runs on the caller's stream
         with torch.cuda.stream(stream):
             if not slot_inputs:
                 for k, v in features.items():
-                    static_in[k].copy_(v, non_blocking=True)
+                    v.record_stream(stream)         # the caller may free `features` right after submit(): the allocator must
+                    static_in[k].copy_(v, non_blocking=True)        # not reuse that memory before this side-stream copy ran
             graph.replay()
             done.record(stream)
         return i

@@ -66,7 +66,7 @@ def mean_shift_with_seeds(X, Z, kappa, max_iters=10, metric="cosine"):
 
 
 def select_smart_seeds(X, num_seeds, return_selected_indices=False, init_seeds=None, num_init_seeds=None,
-                       metric="cosine", first_index=None):
+                       metric="cosine", first_index=None, stepwise=False):
     """mean_shift.py:128-189.  The first seed index comes from np.random.randint(0, n) like the
     reference (mean_shift.py:155) unless ``first_index`` is given."""
     _cosine_only(metric)
@@ -74,18 +74,30 @@ def select_smart_seeds(X, num_seeds, return_selected_indices=False, init_seeds=N
         raise NotImplementedError("init_seeds is unused by the inference path")
     if first_index is None:
         first_index = np.random.randint(0, X.shape[0])
-    seeds, idx = ops.ms_select_seeds(X.contiguous(), num_seeds, int(first_index))
-    return (seeds, idx) if return_selected_indices else (seeds,)
+    seeds, idx = ops.ms_select_seeds(X.contiguous(), num_seeds, int(first_index), stepwise=stepwise)
+    if not return_selected_indices:
+        # the caller cannot see the indices, so the give-up of the persistent kernel (ops.ms_select_seeds) is handled here
+        if not stepwise and int(idx.min()) < 0:
+            seeds, idx = ops.ms_select_seeds(X.contiguous(), num_seeds, int(first_index), stepwise=True)
+        return (seeds,)
+    return seeds, idx
 
 
 def mean_shift_smart_init(X, kappa, num_seeds=100, max_iters=10, metric="cosine", first_index=None):
     """mean_shift.py:192-229.  Returns (cluster_labels (n,) int64 on X.device, selected_indices (S,))."""
     X = X.contiguous()
+    if first_index is None:
+        first_index = np.random.randint(0, X.shape[0])                   # MS:155, drawn once: a retry reuses it
     seeds, selected = select_smart_seeds(X, num_seeds, return_selected_indices=True, metric=metric,
                                          first_index=first_index)
     seed_labels, Z = mean_shift_with_seeds(X, seeds, kappa, max_iters=max_iters, metric=metric)
-    if int(selected.min()) < 0:      # the persistent seeding kernel gave up at a bounded wait (never seen; fail loudly)
-        raise RuntimeError("msm_ms_select_seeds: the persistent seeding kernel aborted; set MSM_MS_NO_PERSISTENT=1")
+    # connected_components above is the first host sync of the call, so the give-up flag of the persistent seeding kernel
+    # (co-residency lost to other streams / processes) is read here, for free on the normal path; a give-up re-runs
+    # seeding on the one-launch-per-step path (identical results) and the hill climb on its seeds
+    if int(selected.min()) < 0:
+        seeds, selected = select_smart_seeds(X, num_seeds, return_selected_indices=True, metric=metric,
+                                             first_index=first_index, stepwise=True)
+        seed_labels, Z = mean_shift_with_seeds(X, seeds, kappa, max_iters=max_iters, metric=metric)
     num = int(torch.unique(seed_labels).numel())
     labels, counts = ops.ms_assign(X, Z, seed_labels.to(X.device), num)
     ops.ms_relabel_largest_zero(labels, counts)

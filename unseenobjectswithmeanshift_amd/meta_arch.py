@@ -115,11 +115,27 @@ class PretrainedMeanShiftMaskFormerHead(MeanShiftMaskFormerHead):
 
 
 class MeanShiftMaskFormer(nn.Module):
-    """Inference branch of the meta-arch (pretrained_meanshiftformer_model.py:244-303,334-378)."""
+    """Inference branch of the meta-arch (pretrained_meanshiftformer_model.py:244-303,334-378; meanshiftformer_model.py:
+    214-245,286-330).
+
+    Input normalisation: the reference has two meta-archs.  ``MeanShiftMaskFormer`` (meanshiftformer_model.py:115-116,241)
+    owns non-persistent ``pixel_mean`` / ``pixel_std`` buffers and computes (x - mean) / std BEFORE padding to the size
+    divisibility, so the padded border is zero in normalised space; pass ``pixel_mean`` / ``pixel_std`` (cfg.MODEL.PIXEL_MEAN /
+    PIXEL_STD, Base-COCO-InstanceSegmentation.yaml:6-7) to get that.  ``PretrainedMeanShiftMaskFormer`` -- the meta-arch
+    every shipped yaml selects, also for the ResNet-50 backbone (mixture_ResNet50.yaml:27, USE_OTHER_BACKBONE) -- does NOT
+    normalise (pretrained_meanshiftformer_model.py:270-275: the dataset / predictor hands over normalised images,
+    lib/datasets/ocid_dataset.py:105-106); that is the default here (``pixel_mean=None``)."""
 
     def __init__(self, *, backbone, sem_seg_head, num_queries, test_topk_per_image=20, size_divisibility=32,
-                 instance_on=True):
+                 instance_on=True, pixel_mean=None, pixel_std=None):
         super().__init__()
+        if (pixel_mean is None) != (pixel_std is None):
+            raise ValueError("pixel_mean and pixel_std go together")
+        if pixel_mean is not None:
+            self.register_buffer("pixel_mean", torch.tensor(pixel_mean, dtype=torch.float32).view(-1, 1, 1), False)
+            self.register_buffer("pixel_std", torch.tensor(pixel_std, dtype=torch.float32).view(-1, 1, 1), False)
+        else:
+            self.pixel_mean = self.pixel_std = None
         self.backbone = backbone
         self.sem_seg_head = sem_seg_head
         self.num_queries = num_queries
@@ -172,6 +188,8 @@ class MeanShiftMaskFormer(nn.Module):
             if first.get("height", H) != H or first.get("width", W) != W:
                 raise NotImplementedError("output height/width other than the image size (sem_seg_postprocess resize, PM:354)")
             padded = (-(-H // div) * div, -(-W // div) * div)
+            if self.pixel_mean is not None:                                   # meanshiftformer_model.py:241, before the padding
+                images = (images - self.pixel_mean) / self.pixel_std
             if padded != (H, W):            # ImageList.from_tensors(images, size_divisibility): zeros at the right / bottom
                 images = F.pad(images, (0, padded[1] - W, 0, padded[0] - H))
             feats = self.backbone(images)

@@ -503,10 +503,16 @@ class MeanShiftTransformerDecoder(nn.Module):
         self._packed_mf = ops.pack_mask_features_bf16(mf_planes) if self.mask_step_dtype == "bf16" else None
         qpos = self.query_embed.weight
         qf = self.query_feat.weight
-        qkey = (B, qf.data_ptr(), qf._version)
-        if getattr(self, "_q0", None) is None or self._q0[0] != qkey:          # the broadcast initial queries are read-only
-            self._q0 = (qkey, qf[None].expand(B, -1, -1).contiguous())
-        out = self._q0[1]
+        # the broadcast initial queries are read-only: one tensor per (batch size, parameter version).  A captured HIP
+        # graph reads it by address, so entries are only dropped wholesale and graphs hold the entries they were captured
+        # with (graphs.cache_refs)
+        qkey = (B, str(dev), qf.data_ptr(), qf._version)
+        q0 = getattr(self, "_q0", None)
+        if q0 is None or len(q0) > 32:
+            q0 = self._q0 = {}
+        if qkey not in q0:
+            q0[qkey] = qf[None].expand(B, -1, -1).contiguous()
+        out = q0[qkey]
         full = self.aux_outputs
         L = self.num_layers
         pred_cls, pred_mask = [], []

@@ -12,10 +12,6 @@ from ._lib import check, lib
 
 KAPPA = 30.0  # attention_util.py:26
 
-# bench.py sets this to a list to collect (start, end) HIP event pairs around the dominant kernel
-# (msm_mask_logits_fwd) on the stream it is launched on; None = no instrumentation.
-MASK_STEP_EVENTS = None
-
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _cur_device = getattr(torch._C, "_cuda_getDevice", None)
@@ -418,10 +414,6 @@ def mask_logits(mask_embed, mask_features, *, want_mask=True, target_size=None, 
             flags |= 2
     else:
         row_any = None
-    ev = None
-    if MASK_STEP_EVENTS is not None:
-        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        ev[0].record()
     if packed_bf16 is not None:
         _c(packed_bf16, "packed_bf16", torch.int16)
         rc = lib().msm_mask_logits_bf16_fwd(_p(mask_embed), _p(packed_bf16), _p(mask), _p(attn), _p(row_any),
@@ -431,9 +423,6 @@ def mask_logits(mask_embed, mask_features, *, want_mask=True, target_size=None, 
         rc = lib().msm_mask_logits_fwd(_p(mask_embed), _p(mask_features), _p(mask), _p(attn), _p(row_any),
                                        B, Q, C, H, W, th, tw, flags, embed_ld, _p(qbias), qb_ld, _stream())
         check(rc, "msm_mask_logits_fwd")
-    if ev is not None:
-        ev[1].record()
-        MASK_STEP_EVENTS.append(ev)
     return mask, attn, row_any
 
 
@@ -628,15 +617,18 @@ def ms_deform_attn_encoder(value, spatial_shapes, level_start_index, proj, heads
 # ----------------------------------------------------------------------------------------------
 # mean shift (lib/utils/mean_shift.py)
 # ----------------------------------------------------------------------------------------------
-def ms_select_seeds(X, num_seeds, first_index):
-    """Farthest-point seeding.  X (n,64) unit rows.  Returns (seeds (S,64), indices int64 (S,))."""
+def ms_select_seeds(X, num_seeds, first_index, stepwise=False, _test_give_up=False):
+    """Farthest-point seeding.  X (n,64) unit rows.  Returns (seeds (S,64), indices int64 (S,)).  The single-launch
+    persistent kernel (maps up to 393 216 rows) needs its workgroups co-resident; if other work holds the CUs it gives up
+    and every index is -1 -- callers re-issue with ``stepwise=True`` (mean_shift.mean_shift_smart_init does)."""
     _c(X, "X")
     n, d = X.shape
     seeds = torch.empty((num_seeds, d), device=X.device, dtype=torch.float32)
     idx = torch.empty((num_seeds,), device=X.device, dtype=torch.int64)
     need = lib().msm_ms_seed_workspace(n)
     ws = torch.empty((need,), device=X.device, dtype=torch.float32)
-    rc = lib().msm_ms_select_seeds(_p(X), n, d, num_seeds, int(first_index), _p(seeds), _p(idx), _p(ws), need, _stream())
+    rc = lib().msm_ms_select_seeds(_p(X), n, d, num_seeds, int(first_index), _p(seeds), _p(idx), _p(ws), need,
+                                   (1 if stepwise else 0) | (2 if _test_give_up else 0), _stream())
     check(rc, "msm_ms_select_seeds")
     return seeds, idx
 

@@ -257,3 +257,42 @@ def ucn_backbone_state_dict(shapes=None, salt=0):
         else:
             out[k] = math.sqrt(2.0 / int(np.prod(shp[1:]))) * torch.randn(shp, generator=g)
     return out
+
+
+def synth_instance_inputs(num_queries=100, h=30, w=40, num_classes=2, seed=0, blobs=True):
+    """Inputs of the instance post-processing (PM:337-343, 461-497) for one image: class logits (Q, K+1) and low-resolution
+    mask logits (Q, h, w).  ``blobs``: smooth object-like maps (a few gaussian bumps minus an offset) so that the masks have
+    interiors, borders and -- for some queries -- no positive pixel at all; else white noise."""
+    g = torch.Generator().manual_seed(seed)
+    mask_cls = torch.randn(num_queries, num_classes + 1, generator=g) * 2.0
+    if not blobs:
+        return mask_cls, torch.randn(num_queries, h, w, generator=g) * 3.0
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    m = torch.zeros(num_queries, h, w)
+    for q in range(num_queries):
+        for _ in range(1 + q % 3):
+            cy, cx = torch.rand(1, generator=g).item() * h, torch.rand(1, generator=g).item() * w
+            sy, sx = 1.5 + torch.rand(1, generator=g).item() * h / 4, 1.5 + torch.rand(1, generator=g).item() * w / 4
+            m[q] += 8.0 * torch.exp(-0.5 * (((yy - cy) / sy) ** 2 + ((xx - cx) / sx) ** 2))
+        m[q] -= 3.0 + 6.0 * (q % 7 == 0)                 # every seventh query: (almost) nothing above zero
+    return mask_cls, m + 0.1 * torch.randn(num_queries, h, w, generator=g)
+
+class StandInBackbone(torch.nn.Module):
+    """Stand-in for a ResNet-50 feature pyramid where only the SHAPES of res2..res5 matter (two-stage harness tests and the
+    configs[3] bench line, whose unit of work is the head, not the backbone): average-pool pyramid + fixed random 1x1
+    mixing, plain torch ops.  res2..res5 with 256/512/1024/2048 channels for any H, W divisible by 32."""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(5)
+        self.mix = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(c, 6, generator=g) * 0.5) for c in (256, 512, 1024, 2048)])
+
+    def forward(self, images, depth=None):
+        x = images if depth is None else torch.cat([images, depth], 1)
+        if x.shape[1] == 3:
+            x = torch.cat([x, x], 1)
+        out = {}
+        for name, s, w in zip(("res2", "res3", "res4", "res5"), (4, 8, 16, 32), self.mix):
+            p = torch.nn.functional.avg_pool2d(x, s)
+            out[name] = torch.relu(torch.einsum("oc,bchw->bohw", w, p)).contiguous()
+        return out
