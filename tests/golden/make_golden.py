@@ -418,6 +418,112 @@ def g_ucn_backbone():
     save("ucn_backbone", feats=feats[:, :, ::3, ::3].contiguous(), rgb_only=rgb_only[:, :, ::6, ::6].contiguous())
 
 
+def _head_outputs(pd, dec, feats):
+    with torch.no_grad():
+        mf, _, ms = pd.forward_features(feats)
+        return dec(ms, mf)
+
+
+def _head_outputs_fp64(pd, dec, feats):
+    """The same reference modules evaluated in float64 (parameters and inputs promoted; the pixel decoder's explicit
+    ``.float()`` of its inputs, msdeformattn.py:320, is redirected to ``.double()`` for the duration).  Ten discrete attention
+    masks make the head chaotic in its last digits: a mask logit within rounding of zero flips a key, and that can move a
+    query by 1e-3 .. 1e-1 a few layers later.  The fp64 run is the exact value both fp32 evaluations (the reference's and the
+    HIP path's) approximate; the fixtures carry it so that the tests can hold the HIP path to 'as close to exact as the
+    reference's own fp32 run'."""
+    import copy
+    pd64, dec64 = copy.deepcopy(pd).double(), copy.deepcopy(dec).double()
+    orig = torch.Tensor.float
+    torch.Tensor.float = lambda self, *a, **k: self.double()
+    try:
+        return _head_outputs(pd64, dec64, {k: v.double() for k, v in feats.items()})
+    finally:
+        torch.Tensor.float = orig
+
+
+def g_head_b8():
+    """BASELINE configs[1] as benchmarked: batch 8 at 640x480 through the reference pixel decoder -> 9-layer decoder (the
+    inputs are bench.py's own: synth_backbone_features(8, 480, 640, seed=10)).  Stored: class logits of all 8 images, and for
+    images 0 and 5 the packed sign bits + sampled values of the final masks and the sign bits of two intermediate predictions."""
+    pd, dec = build_ref_pixel_decoder(), build_ref_decoder()
+    feats = syn.synth_backbone_features(8, 480, 640, seed=10)
+    out = _head_outputs(pd, dec, feats)
+    out64 = _head_outputs_fp64(pd, dec, feats)
+    pm, pm64 = out["pred_masks"], out64["pred_masks"]
+    arrs = {"pred_logits": out["pred_logits"], "mask_absmax": pm.abs().amax((1, 2, 3)), "pred_logits64": out64["pred_logits"].float()}
+    idx = sample_idx(pm[0].numel())
+    for b in (0, 5):
+        arrs.update({f"b{b}_sign_bits": packbits(pm[b] > 0), f"b{b}_sample_val": pm[b].flatten()[idx],
+                     f"b{b}_near_zero": packbits(pm[b].abs() < 2e-4),
+                     f"b{b}_sign_bits64": packbits(pm64[b] > 0), f"b{b}_sample_val64": pm64[b].flatten()[idx].float()})
+        for i in (0, 4, 8):
+            a = out["aux_outputs"][i]
+            arrs[f"b{b}_aux{i}_sign_bits"] = packbits(a["pred_masks"][b] > 0)
+            arrs[f"b{b}_aux{i}_near_zero"] = packbits(a["pred_masks"][b].abs() < 2e-4)
+            arrs[f"b{b}_aux{i}_sign_bits64"] = packbits(out64["aux_outputs"][i]["pred_masks"][b] > 0)
+    arrs["mask_sample_idx"] = idx
+    for i, a in enumerate(out["aux_outputs"]):
+        arrs[f"aux{i}_logits"] = a["pred_logits"]
+        arrs[f"aux{i}_logits64"] = out64["aux_outputs"][i]["pred_logits"].float()
+    save("head_480x640_b8", **arrs)
+
+
+def g_head_cfg5():
+    """BASELINE configs[4] hot path: 1280x960, 300 queries, 19 decoder layers (20 predictions), batch 1, through the reference
+    pixel decoder -> decoder.  Stored: class logits, sampled final-mask values, packed sign bits of every 6th query."""
+    pd = build_ref_pixel_decoder()
+    dec = build_ref_decoder(dec_layers=19, num_queries=300)
+    feats = syn.synth_backbone_features(1, 960, 1280, seed=9)
+    out = _head_outputs(pd, dec, feats)
+    out64 = _head_outputs_fp64(pd, dec, feats)
+    pm, pm64 = out["pred_masks"][0], out64["pred_masks"][0]
+    idx = sample_idx(pm.numel(), k=16384)
+    qs = torch.arange(0, 300, 6)
+    arrs = {"pred_logits": out["pred_logits"], "mask_sample_idx": idx, "mask_sample_val": pm.flatten()[idx], "queries": qs,
+            "sign_bits": packbits(pm[qs] > 0), "near_zero": packbits(pm[qs].abs() < 2e-4), "mask_absmax": pm.abs().max(),
+            "positive_fraction": (pm > 0).float().mean(),
+            "pred_logits64": out64["pred_logits"].float(), "mask_sample_val64": pm64.flatten()[idx].float(),
+            "sign_bits64": packbits(pm64[qs] > 0), "positive_fraction64": (pm64 > 0).float().mean()}
+    for i in (0, 9, 18):
+        arrs[f"aux{i}_logits"] = out["aux_outputs"][i]["pred_logits"]
+        arrs[f"aux{i}_sign_bits"] = packbits(out["aux_outputs"][i]["pred_masks"][0][qs] > 0)
+        arrs[f"aux{i}_near_zero"] = packbits(out["aux_outputs"][i]["pred_masks"][0][qs].abs() < 2e-4)
+        arrs[f"aux{i}_logits64"] = out64["aux_outputs"][i]["pred_logits"].float()
+        arrs[f"aux{i}_sign_bits64"] = packbits(out64["aux_outputs"][i]["pred_masks"][0][qs] > 0)
+    save("head_cfg5_960x1280", **arrs)
+
+
+def g_ucn_full():
+    """UCN / RGB-D configuration at full size: SimpleBasePixelDecoder + PretrainedMeanShiftTransformerDecoder over the
+    480x640 embedding map -- 307 200 keys per image, attention mask at mask resolution, 6 layers, batch 1."""
+    DEC = R.ref("modeling.transformer_decoder.meanshiftformer_transformer_decoder")
+    FPN = R.ref("modeling.pixel_decoder.fpn")
+    SS = R._ShapeSpec
+    pd = FPN.SimpleBasePixelDecoder({"res5": SS(channels=64, stride=1)}, conv_dim=64, mask_dim=256, norm="GN").eval()
+    pd_shapes = {"mask_features.weight": (256, 64, 3, 3), "mask_features.bias": (256,)}
+    pd.load_state_dict(syn.synth_state_dict(pd_shapes, salt=3), strict=True)
+    dec = DEC.PretrainedMeanShiftTransformerDecoder(
+        in_channels=64, mask_classification=True, num_classes=2, hidden_dim=256, num_queries=100, nheads=8,
+        dim_feedforward=2048, dec_layers=6, pre_norm=False, mask_dim=256, enforce_input_project=False,
+        use_meanshift_cross_attention=True, disable_attention_mask=False, use_meanshift_self_attention=True,
+        decoder_block_norm=True).eval()
+    dec.load_state_dict(syn.synth_state_dict(syn.decoder_param_shapes(dec_layers=6, num_feature_levels=1), salt=4), strict=True)
+    X, _ = syn.synth_unit_embeddings(480 * 640, 64, clusters=12, sigma=0.3, seed=5)
+    feat = X.view(1, 480 * 640, 64).transpose(1, 2).reshape(1, 64, 480, 640).contiguous()
+    with torch.no_grad():
+        mf, _, ms = pd.forward_features({"res5": feat})
+        out = dec(ms, mf)
+    pm = out["pred_masks"][0]
+    idx = sample_idx(pm.numel(), k=16384)
+    qs = torch.arange(0, 100, 10)
+    arrs = {"pred_logits": out["pred_logits"], "mask_sample_idx": idx, "mask_sample_val": pm.flatten()[idx], "queries": qs,
+            "sign_bits": packbits(pm[qs] > 0), "near_zero": packbits(pm[qs].abs() < 2e-4), "mask_absmax": pm.abs().max(),
+            "mf_sample_val": mf.flatten()[idx % mf.numel()]}
+    for i, a in enumerate(out["aux_outputs"]):
+        arrs[f"aux{i}_logits"] = a["pred_logits"]
+    save("ucn_480x640", **arrs)
+
+
 def g_instance_inference():
     """instance_inference (pretrained_meanshiftformer_model.py:461-497) executed from the reference source with stand-ins for
     the three detectron2 containers it touches.  Pins the top-k over Q*K class scores, the class labels, the binary masks
@@ -463,9 +569,9 @@ def g_instance_inference():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pe", "attn", "decoder", "msda", "msda_bwd", "pixel", "ms", "harness", "ucn", "ucn_backbone", "inst"]
+    which = sys.argv[1:] or ["pe", "attn", "decoder", "msda", "msda_bwd", "pixel", "ms", "harness", "ucn", "ucn_backbone", "inst", "head_b8", "head_cfg5", "ucn_full"]
     fns = {"pe": g_position_encoding, "attn": g_hypersphere_attention, "decoder": g_decoder,
            "msda": g_msda, "msda_bwd": g_msda_bwd, "pixel": g_pixel_decoder, "ms": g_mean_shift, "harness": g_harness, "ucn": g_ucn, "ucn_backbone": g_ucn_backbone,
-           "inst": g_instance_inference}
+           "inst": g_instance_inference, "head_b8": g_head_b8, "head_cfg5": g_head_cfg5, "ucn_full": g_ucn_full}
     for w in which:
         fns[w]()

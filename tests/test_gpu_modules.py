@@ -280,26 +280,6 @@ def test_folded_mask_step_equals_literal():
     torch.testing.assert_close(out["pred_masks"], a["pred_masks"], rtol=0, atol=0)
 
 
-def test_folded_mask_step_full_size():
-    """BASELINE configs[1] geometry (640x480, B=2): the head with the folded mask step against the same head contracting the
-    literal mask_features tensor -- logits to fp32 tolerance, mask signs equal except where the logit is ~0."""
-    head = make_pixel_decoder()
-    feats = {k: v.to(DEV) for k, v in syn.synth_backbone_features(2, 480, 640, seed=12).items()}
-    a, _ = head(feats)
-    head.predictor.folded_mask_features = False
-    b, _ = head(feats)
-    head.predictor.folded_mask_features = True
-    # The two orders round differently (~1e-6 relative), so an attention-mask bit whose logit is ~0 may flip (51 M bits are
-    # derived per pass); a flipped bit moves that one query by ~1e-3.  Hence: almost every query agrees to fp32 tolerance,
-    # none moves far, and the final mask signs agree except on a vanishing fraction of pixels.
-    dl = (a["pred_logits"] - b["pred_logits"]).abs().amax(-1)                     # (B, Q)
-    dm = (a["pred_masks"] - b["pred_masks"]).abs().flatten(2).amax(-1)
-    assert (dl < 1e-4).float().mean().item() > 0.95 and float(dl.max()) < 0.05
-    assert (dm < 2e-3).float().mean().item() > 0.95 and float(dm.max()) < 0.5
-    flip = (a["pred_masks"] > 0) != (b["pred_masks"] > 0)
-    assert flip.float().mean().item() < 1e-4
-
-
 def test_pixel_decoder_front_variants_agree():
     """Fused front end (input projections with GroupNorm moments + one prologue pass) against the separate GEMM /
     GroupNorm / value / sampling launches, and a fused pass repeated (bitwise reproducible)."""
