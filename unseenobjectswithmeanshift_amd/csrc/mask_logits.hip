@@ -21,6 +21,8 @@
 //   * 7 x 4 accumulators (112 VGPRs), K-loop in register-prefetched groups of 8 k-steps.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace msm {
@@ -39,6 +41,15 @@ constexpr int MW = MSM_MASK_MW;  // waves per workgroup: the 116 KB mask_embed c
                                 // buffer-load issue and waitcnt bubbles behind its MFMAs)
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#ifdef MSM_MASK_TS   // probe build only (tools/probes/mask_ts.py): per-wave phase timestamps, 100 MHz wall clock
+__device__ unsigned long long g_mask_ts[256 * 8 * 16];
+#define MASK_TS(slot)                                                                                          \
+    if (lane == 0 && blockIdx.y == 0 && (int)(blockIdx.z * gridDim.x + blockIdx.x) < 256 && (slot) < 16)       \
+        g_mask_ts[((blockIdx.z * gridDim.x + blockIdx.x) * 8 + wave) * 16 + (slot)] = wall_clock64();
+#else
+#define MASK_TS(slot)
+#endif
 
 // NC consecutive columns per lane: NC == 2 -> one 8-byte load per (k-row, image row), wave tile 2 x 32;
 // NC == 1 -> 4-byte loads, wave tile 2 x 16 (finer tiles: less quantisation loss when the tile count per
@@ -60,109 +71,333 @@ __device__ __forceinline__ Cols<NC> ld_cols(__amdgpu_buffer_rsrc_t rsrc, unsigne
     return c;
 }
 
-__device__ __forceinline__ float dpp_next_in_row(float v) {   // lane i <- lane i + 1 within its row of 16 lanes (row_shl:1)
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x101, 0xf, 0xf, true));
+// ---- accumulator layout -----------------------------------------------------------------------------------------
+// The product is issued TRANSPOSED: the MFMA A operand is the feature fragment (16 pixels x 4 channels), the B operand
+// the mask_embed fragment (4 channels x 16 queries), so D[row = pixel][col = query] and lane (lq = l >> 4, lj = l & 15)
+// holds, for query 16 m + lj, the pixels of A rows 4 lq .. 4 lq + 3.  A row i is whatever pixel lane i loaded:
+//   NC == 2: lane i loads the float2 at columns c0 + 2 i, + 1 (even / odd column blocks)  -> lane lq owns the 8
+//            CONSECUTIVE pixels c0 + 8 lq .. + 7 of both image rows of the tile;
+//   NC == 1: lane i loads column c0 + i -> 4 consecutive pixels c0 + 4 lq .. + 3.
+// Every 2x2 tap of the bilinear downsample by 2, 4 (columns 4i+1, 4i+2) or 8 (8i+3, 8i+4) then lies inside ONE lane --
+// no cross-lane traffic -- and the attention-mask bytes of a lane are consecutive keys of one query: one dword (or
+// short / byte) store per 16-query block instead of one byte store per query.  (Queries-as-rows, the layout of round 1,
+// needed 28 byte-store instructions and 56 DPP moves per tile: 5-8 of the 30 us of a launch.)
+// The one case where a tap would straddle lanes (NC == 1, downsample by 8: columns 3|4 and 11|12) permutes the pixels
+// the lanes load: A rows 0..15 <- columns {3,4,2,5, 0,1,6,7, 11,12,10,13, 8,9,14,15}.
+template <int POOL, int NC>
+struct PixMap {
+    static constexpr bool PERM = (POOL == 8 && NC == 1);
+    // column (relative to the tile's first column) loaded by lane i of a 16-lane row
+    __device__ static __forceinline__ int load_col(int i) {
+        if constexpr (PERM) {
+            const int g = i >> 2, r = i & 3;
+            return (g >> 1) * 8 + (int)((((g & 1) ? 0x7610u : 0x5243u) >> (4 * r)) & 15u);
+        } else {
+            return NC * i;
+        }
+    }
+    // column of the lane's j-th value (j = 0 .. 4 NC - 1, in register order: NC == 2 -> reg r = j >> 1, block cc = j & 1)
+    __device__ static __forceinline__ int out_col(int lq, int j) {
+        if constexpr (PERM) return load_col(lq * 4 + j);
+        else return 4 * NC * lq + j;
+    }
+};
+
+template <int NC>
+__device__ __forceinline__ float acc_val(const f32x4 (&acc)[QB][2 * NC], int m, int row, int j) {
+    if constexpr (NC == 2) return acc[m][row * 2 + (j & 1)][j >> 1];
+    else return acc[m][row][j];
 }
 
-// Per-tile epilogue shared by the fp32 and bf16 kernels: lane holds queries q0 + m*16 + lq*4 + r, columns c..c+NC-1 of
-// rows ytop (acc[.][cc]) and ybot (acc[.][NC+cc]).
-template <int POOL, bool WRITE, int NC>
+// Generic per-tile epilogue shared by the fp32 and bf16 kernels (see the layout note above): any tile (partly outside the
+// map, unaligned rows, permuted pixels).  c0: first column of the tile; DO_WRITE / DO_ATTN select the two halves so that a
+// kernel can take the fast path (mask_tile_epilogue_fast below) for one and this one for the other.
+template <int POOL, bool WRITE, int NC, bool DO_WRITE = true, bool DO_ATTN = true>
 __device__ __forceinline__ void mask_tile_epilogue(const f32x4 (&acc)[QB][2 * NC], float* __restrict__ mask_out,
                                                    uint8_t* __restrict__ attn_out, int* __restrict__ any_flags, int b, int Q,
-                                                   int q0, int H, int W, int th, int tw, int ytop, int ybot, int c, bool col_ok,
-                                                   int lj, int lq) {
-    const int HW = H * W;
-    (void)lj;
-    // ---- epilogue: lane holds queries q0 + m*16 + lq*4 + r, columns c..c+NC-1 of rows ytop (acc[.][cc])
-    //      and ybot (acc[.][NC+cc]).  The query offset is made opaque here: the 28 per-query output base addresses
-    //      depend only on the lane, so LICM would otherwise hoist them out of the tile loop and hold 56 VGPRs
-    //      across the K loop (209 vs 157 VGPRs; the difference decides between 2 and 3 waves per SIMD).
-    int qlane = lq * 4;
-    asm volatile("" : "+v"(qlane));
-    if constexpr (WRITE) {
-        if (col_ok) {
+                                                   int q0, int H, int W, int th, int tw, int ytop, int ybot, int c0, int lj, int lq) {
+    using PM = PixMap<POOL, NC>;
+    constexpr int NP = 4 * NC;                       // values per lane and image row
+    // The query offset is made opaque: the per-query output base addresses depend only on the lane, so LICM would
+    // otherwise hoist them out of the tile loop and hold dozens of VGPRs across the K loop.
+    int ql = lj;
+    asm volatile("" : "+v"(ql));
+    const int xb = c0 + NP * lq;                     // first column of this lane (identity mapping)
+    if constexpr (WRITE && DO_WRITE) {
+        const bool vec = !PM::PERM && xb + NP <= W && (W & 3) == 0;       // 16-byte aligned rows, whole lane inside the map
 #pragma unroll
-            for (int m = 0; m < QB; ++m) {
+        for (int m = 0; m < QB; ++m) {
+            const int q = q0 + m * 16 + ql;
+            if (q >= Q) continue;
+            float* o = mask_out + ((int64_t)b * Q + q) * ((int64_t)H * W);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int q = q0 + m * 16 + qlane + r;
-                    if (q < Q) {
-                        float* o = mask_out + ((int64_t)b * Q + q) * HW + c;
-                        if constexpr (NC == 2) {
-                            if (ytop >= 0) *reinterpret_cast<float2*>(o + (int64_t)ytop * W) = make_float2(acc[m][0][r], acc[m][1][r]);
-                            if (ybot < H) *reinterpret_cast<float2*>(o + (int64_t)ybot * W) = make_float2(acc[m][2][r], acc[m][3][r]);
-                        } else {
-                            if (ytop >= 0) o[(int64_t)ytop * W] = acc[m][0][r];
-                            if (ybot < H) o[(int64_t)ybot * W] = acc[m][1][r];
-                        }
+            for (int row = 0; row < 2; ++row) {
+                const int y = row ? ybot : ytop;
+                if (y < 0 || y >= H) continue;
+                float* orow = o + (int64_t)y * W;
+                if (vec) {
+#pragma unroll
+                    for (int j = 0; j < NP; j += 4)
+                        *reinterpret_cast<float4*>(orow + xb + j) = make_float4(acc_val<NC>(acc, m, row, j), acc_val<NC>(acc, m, row, j + 1),
+                                                                               acc_val<NC>(acc, m, row, j + 2), acc_val<NC>(acc, m, row, j + 3));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) {
+                        const int x = c0 + PM::out_col(lq, j);
+                        if (x < W) orow[x] = acc_val<NC>(acc, m, row, j);
                     }
                 }
             }
         }
     }
-    if constexpr (POOL == 1) {
-        // mask at full resolution: one bit per logit
-        if (col_ok) {
-#pragma unroll
-            for (int m = 0; m < QB; ++m) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int q = q0 + m * 16 + qlane + r;
-                    if (q >= Q) continue;
-                    uint8_t* o = attn_out + ((int64_t)b * Q + q) * HW + c;
-                    bool any = false;
-#pragma unroll
-                    for (int cc = 0; cc < NC; ++cc) {
-                        if (ytop >= 0) { const bool mk = acc[m][cc][r] < 0.f; o[(int64_t)ytop * W + cc] = mk; any |= !mk; }
-                        if (ybot < H) { const bool mk = acc[m][NC + cc][r] < 0.f; o[(int64_t)ybot * W + cc] = mk; any |= !mk; }
-                    }
-                    if (any) any_flags[q - q0] = 1;
-                }
-            }
-        }
-    } else if constexpr (POOL != 0) {
-        // tap rows are (POOL*i + POOL/2 - 1, +1): the pair (ytop, ybot) is a tap pair iff
-        // ytop % POOL == POOL/2 - 1 (always true for POOL == 2 with even pairing)
-        const bool row_tap = (ytop >= 0) && (ybot < H) && ((ytop % POOL) == POOL / 2 - 1);   // wave-uniform
-        // tap columns are (POOL*i + POOL/2 - 1, +1).  NC == 2, POOL == 2: both in this lane.  Otherwise
-        // the left tap is this lane's LAST column and the right tap the next lane's first.
-        constexpr bool IN_LANE = (NC == 2 && POOL == 2);
-        const int cleft = IN_LANE ? c : c + NC - 1;
-        const bool col_tap = col_ok && ((cleft % POOL) == POOL / 2 - 1) && (cleft + 1 < W);
-        const int tx = cleft / POOL;
-        const int ty = (ytop >= 0 ? ytop : 0) / POOL;
-        if (!row_tap) return;                     // wave-uniform: this row pair feeds no tap (every other pair at POOL 4, 3 of 4 at 8)
+    if constexpr (!DO_ATTN) {
+        return;
+    } else if constexpr (POOL == 1) {
+        // mask at full resolution: one byte per logit, NP consecutive keys per lane and row
+        const int HW = H * W;
+        const bool vec = xb + NP <= W && (W & 3) == 0;
 #pragma unroll
         for (int m = 0; m < QB; ++m) {
+            const int q = q0 + m * 16 + ql;
+            if (q >= Q) continue;
+            uint8_t* o = attn_out + ((int64_t)b * Q + q) * HW;
+            bool any = false;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float s;
-                if constexpr (IN_LANE) {
-                    s = (acc[m][0][r] + acc[m][1][r]) + (acc[m][2][r] + acc[m][3][r]);
-                } else {
-                    // the right tap is the next lane of the same 16-lane row (a left tap is never lane 15: cleft % POOL ==
-                    // POOL/2 - 1 is odd): a DPP row shift instead of a ds_bpermute through the LDS crossbar
-                    const float n0 = dpp_next_in_row(acc[m][0][r]);
-                    const float n2 = dpp_next_in_row(acc[m][NC][r]);
-                    s = (acc[m][NC - 1][r] + n0) + (acc[m][2 * NC - 1][r] + n2);
-                }
-                const int q = q0 + m * 16 + qlane + r;
-                if (row_tap && col_tap && q < Q && tx < tw && ty < th) {
-                    const bool masked = s < 0.f;
-                    attn_out[((int64_t)b * Q + q) * (th * tw) + ty * tw + tx] = masked ? 1 : 0;
-                    if (!masked) any_flags[q - q0] = 1;      // LDS: flushed to row_any once per workgroup (not one hot global store per tile)
+            for (int row = 0; row < 2; ++row) {
+                const int y = row ? ybot : ytop;
+                if (y < 0 || y >= H) continue;
+#pragma unroll
+                for (int j0 = 0; j0 < NP; j0 += 4) {
+                    uint32_t w = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w |= (acc_val<NC>(acc, m, row, j0 + j) < 0.f ? 1u : 0u) << (8 * j);
+                    if (vec) {
+                        *reinterpret_cast<uint32_t*>(o + (int64_t)y * W + xb + j0) = w;
+                        any |= w != 0x01010101u;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int x = xb + j0 + j;
+                            if (x < W) { o[(int64_t)y * W + x] = (uint8_t)((w >> (8 * j)) & 1u); any |= ((w >> (8 * j)) & 1u) == 0u; }
+                        }
+                    }
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);   // one row block at a time: keeps the epilogue's live set (shuffled
-                                                 // neighbours, addresses) from setting the kernel's VGPR count
+            if (any) any_flags[q - q0] = 1;
         }
+    } else if constexpr (POOL != 0) {
+        // tap rows are (POOL*i + POOL/2 - 1, +1): the pair (ytop, ybot) is a tap pair iff ytop % POOL == POOL/2 - 1
+        // (always true for POOL == 2 with even pairing).  Wave-uniform: every other pair at POOL 4, 3 of 4 at 8 leave here.
+        if (!((ytop >= 0) && (ybot < H) && ((ytop % POOL) == POOL / 2 - 1))) return;
+        const int ty = ytop / POOL;
+        if (ty >= th) return;
+        // taps of this lane: value indices (jl, jl + 1) of both rows; their target columns are consecutive
+        constexpr int NT = PM::PERM ? 1 : (NP / POOL > 0 ? NP / POOL : 1);            // taps per lane
+        constexpr int J0 = PM::PERM ? 0 : POOL / 2 - 1;                                 // first left tap (value index)
+        constexpr int JS = PM::PERM ? 0 : POOL;                                         // value-index step between taps
+        // lanes that hold a tap: all (NP >= POOL), or -- one tap per two lanes -- the permuted NC == 1 / POOL == 8 case
+        const bool lane_tap = PM::PERM ? ((lq & 1) == 0) : true;
+        const int tx0 = PM::PERM ? (c0 / 8 + (lq >> 1)) : (xb / POOL);
+        static_assert(PM::PERM || NP >= POOL, "a lane must hold whole taps");
+        const bool vec = NT == 4 ? ((tw & 3) == 0 && tx0 + 4 <= tw) : (NT == 2 ? ((tw & 1) == 0 && tx0 + 2 <= tw) : (tx0 < tw));
+#pragma unroll
+        for (int m = 0; m < QB; ++m) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int jl = J0 + t * JS;
+                const float s = (acc_val<NC>(acc, m, 0, jl) + acc_val<NC>(acc, m, 0, jl + 1)) +
+                                (acc_val<NC>(acc, m, 1, jl) + acc_val<NC>(acc, m, 1, jl + 1));
+                w |= (s < 0.f ? 1u : 0u) << (8 * t);
+            }
+            const int q = q0 + m * 16 + ql;
+            if (q < Q && lane_tap) {
+                uint8_t* o = attn_out + ((int64_t)b * Q + q) * (th * tw) + ty * tw + tx0;
+                if (vec) {
+                    if constexpr (NT == 4) *reinterpret_cast<uint32_t*>(o) = w;
+                    else if constexpr (NT == 2) *reinterpret_cast<uint16_t*>(o) = (uint16_t)w;
+                    else *o = (uint8_t)w;
+                    constexpr uint32_t ALL = NT == 4 ? 0x01010101u : (NT == 2 ? 0x0101u : 0x01u);
+                    if (w != ALL) any_flags[q - q0] = 1;      // LDS: flushed to row_any once per workgroup
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        if (tx0 + t < tw) {
+                            o[t] = (uint8_t)((w >> (8 * t)) & 1u);
+                            if (((w >> (8 * t)) & 1u) == 0u) any_flags[q - q0] = 1;
+                        }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // one query block at a time: keeps the epilogue's live set small
+        }
+    }
+}
+
+// Per-lane constants of the fast epilogue, computed once per kernel: byte offsets of the lane's query rows (one per
+// 16-query block) in the attention-mask and mask outputs of image b, relative to buffer descriptors over that image's
+// outputs.  Rows q >= Q get offsets beyond the descriptor's size: the hardware drops those stores, so the tile loop has no
+// per-lane bounds logic at all; the per-tile part of the address (row, first column) is wave-uniform and travels in SGPRs.
+template <int POOL, bool WRITE, int NC>
+struct MaskEpiConst {
+    unsigned aoff[QB];     // attention mask: (q * TT + lane's first key) bytes, TT = keys per query
+    unsigned moff[QB];     // mask logits: (q * H*W + lane's first pixel) * 4 bytes
+    unsigned anyv[QB];     // != 0 once a key of the row was seen attendable
+    __amdgpu_buffer_rsrc_t arsrc, mrsrc;
+    bool attn_fast, write_fast;      // kernel-uniform: the alignment conditions of the vector stores hold
+};
+
+// a + b as ONE v_add_f32: left to itself hipcc pairs the tap sums into v_pk_add_f32 and pays two v_movs per pair to line
+// the operands up; every VALU instruction of the epilogue runs beside the sibling wave's MFMAs and costs ~40 cycles there
+__device__ __forceinline__ float add1(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// 1 iff x < 0 (the reference's sigmoid(x) < 0.5), as an integer: the sign bit.  x is a sum (a+b)+(c+d) of four logits:
+// -0.0 -- sign bit set, not < 0 -- would need all four logits to be exactly -0.0.
+__device__ __forceinline__ unsigned neg_bit(float x) { return __float_as_uint(x) >> 31; }
+
+__device__ __forceinline__ void* uniform_ptr64(const void* p) {
+    const uint64_t u = (uint64_t)p;
+    return (void*)(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                   (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u));
+}
+
+template <int POOL, bool WRITE, int NC>
+__device__ __forceinline__ void mask_epi_init(MaskEpiConst<POOL, WRITE, NC>& k, float* mask_out, uint8_t* attn_out, int b, int Q, int q0,
+                                              int H, int W, int th, int tw, int lj, int lq) {
+    using PM = PixMap<POOL, NC>;
+    constexpr int NP = 4 * NC;
+    const int HW = H * W;
+    const int TT = POOL == 1 ? HW : th * tw;
+    constexpr int NT = PM::PERM ? 1 : (POOL == 1 ? NP : (NP / (POOL > 0 ? POOL : 1) > 0 ? NP / (POOL > 0 ? POOL : 1) : 1));
+    // first key of the lane inside a tile row
+    const int lane_key = POOL == 1 ? NP * lq : (PM::PERM ? (lq >> 1) : (NP * lq) / (POOL > 0 ? POOL : 1));
+    const bool lane_on = PM::PERM ? ((lq & 1) == 0) : true;
+#pragma unroll
+    for (int m = 0; m < QB; ++m) {
+        const int q = q0 + m * 16 + lj;
+        k.aoff[m] = (lane_on && q < Q) ? (unsigned)(q * TT + lane_key) : 0xF0000000u;
+        k.moff[m] = q < Q ? (unsigned)((q * HW + NP * lq) * 4) : 0xF0000000u;
+        k.anyv[m] = 0u;
+    }
+    if constexpr (POOL != 0)
+        k.arsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr64(attn_out + (int64_t)b * Q * TT), 0, Q * TT, 0x00020000);
+    if constexpr (WRITE)
+        k.mrsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr64(mask_out + (int64_t)b * Q * HW), 0, Q * HW * 4, 0x00020000);
+    const int keys_row = POOL == 1 ? W : tw;
+    k.attn_fast = POOL != 0 && (NT == 4 || NT == 8 ? (keys_row & 3) == 0 : (NT == 2 ? (keys_row & 1) == 0 : true)) && (int64_t)Q * TT < 0xF0000000ll;
+    k.write_fast = WRITE && !PM::PERM && (W & 3) == 0 && (int64_t)Q * HW * 4 < 0xF0000000ll;
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Fast epilogue of a tile that lies completely inside the map (c0 + 16 NC <= W; the caller checks, wave-uniformly):
+// zero address arithmetic -- every store is one buffer instruction with a precomputed per-lane offset and an SGPR tile
+// offset --, the row_any flags are OR-ed into registers and reach LDS once per kernel.  VALU instructions next to a busy
+// MFMA pipe are expensive (the sibling wave of the SIMD is in its K loop): measured with in-kernel timestamps, the generic
+// epilogue cost 1.8 (15x20 / 30x40 targets) to 3.5 us (60x80) per 3 us tile, this one a few hundred ns.
+template <int POOL, bool WRITE, int NC, bool DO_WRITE, bool DO_ATTN>
+__device__ __forceinline__ void mask_tile_epilogue_fast(const f32x4 (&acc)[QB][2 * NC], MaskEpiConst<POOL, WRITE, NC>& k, int H, int W, int tw,
+                                                        int ytop, int ybot, int c0) {
+    using PM = PixMap<POOL, NC>;
+    constexpr int NP = 4 * NC;
+    if constexpr (WRITE && DO_WRITE) {
+        // NC == 1 only: the 16-byte store data must BE an accumulator tuple.  With 2 x 32 tiles the lane's consecutive pixels
+        // alternate between two tuples and hipcc assembles each float4 with v_movs into one scratch tuple, re-used for the
+        // next store -- and on gfx950 a buffer_store_dwordx4 WITH an SGPR soffset still reads its data registers when the
+        // following v_mov overwrites the first of them (the first dword of the stores of queries 12..15 of a block came out
+        // wrong; LLVM's hazard recogniser assumes the SGPR-offset form is exempt and inserts no wait state).  The host never
+        // pairs WRITE with NC == 2.
+        static_assert(NC == 1, "mask writes take 2 x 16 tiles");
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+            const int y = row ? ybot : ytop;
+            if (y < 0 || y >= H) continue;                                  // wave-uniform
+            const unsigned soff = (unsigned)(y * W + c0) * 4u;
+#pragma unroll
+            for (int m = 0; m < QB; ++m)
+#pragma unroll
+                for (int j = 0; j < NP; j += 4)
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(acc_val<NC>(acc, m, row, j)), __float_as_uint(acc_val<NC>(acc, m, row, j + 1)),
+                                                                 __float_as_uint(acc_val<NC>(acc, m, row, j + 2)), __float_as_uint(acc_val<NC>(acc, m, row, j + 3))},
+                                                           k.mrsrc, k.moff[m] + 4u * j, soff, 0);
+        }
+    }
+    if constexpr (!DO_ATTN || POOL == 0) {
+        return;
+    } else if constexpr (POOL == 1) {
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+            const int y = row ? ybot : ytop;
+            if (y < 0 || y >= H) continue;
+            const unsigned soff = (unsigned)(y * W + c0);
+#pragma unroll
+            for (int m = 0; m < QB; ++m)
+#pragma unroll
+                for (int j0 = 0; j0 < NP; j0 += 4) {
+                    unsigned w = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w |= acc_val<NC>(acc, m, row, j0 + j) < 0.f ? (1u << (8 * j)) : 0u;
+                    __builtin_amdgcn_raw_buffer_store_b32(w, k.arsrc, k.aoff[m] + j0, soff, 0);
+                    k.anyv[m] |= w ^ 0x01010101u;
+                }
+        }
+    } else {
+        if (!((ytop >= 0) && (ybot < H) && ((ytop % POOL) == POOL / 2 - 1))) return;       // no tap in this row pair (wave-uniform)
+        constexpr int NT = PM::PERM ? 1 : NP / POOL;
+        constexpr int J0 = PM::PERM ? 0 : POOL / 2 - 1;
+        constexpr int JS = PM::PERM ? 0 : POOL;
+        static_assert(PM::PERM || NP >= POOL, "a lane must hold whole taps");
+        const unsigned soff = (unsigned)((ytop / POOL) * tw + c0 / POOL);
+#pragma unroll
+        for (int m = 0; m < QB; ++m) {
+            unsigned w = 0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int jl = J0 + t * JS;
+                const float s = add1(add1(acc_val<NC>(acc, m, 0, jl), acc_val<NC>(acc, m, 0, jl + 1)),
+                                     add1(acc_val<NC>(acc, m, 1, jl), acc_val<NC>(acc, m, 1, jl + 1)));
+                w = t == 0 ? neg_bit(s) : (w | (neg_bit(s) << (8 * t)));
+            }
+#ifndef MSM_EPI_AUX
+#define MSM_EPI_AUX 0
+#endif
+            if constexpr (NT == 4) {
+#ifndef MSM_EPI_NOSTORE
+                __builtin_amdgcn_raw_buffer_store_b32(w, k.arsrc, k.aoff[m], soff, MSM_EPI_AUX);
+#endif
+                k.anyv[m] |= w ^ 0x01010101u;
+            } else if constexpr (NT == 2) {
+#ifndef MSM_EPI_NOSTORE
+                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)w, k.arsrc, k.aoff[m], soff, MSM_EPI_AUX);
+#endif
+                k.anyv[m] |= w ^ 0x0101u;
+            } else {
+#ifndef MSM_EPI_NOSTORE
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)w, k.arsrc, k.aoff[m], soff, MSM_EPI_AUX);
+#endif
+                k.anyv[m] |= w ^ 0x01u;
+            }
+        }
+    }
+}
+
+// flags collected by the fast path -> LDS (the generic path writes LDS directly); rows / lanes that never stored keep 0
+template <int POOL, bool WRITE, int NC>
+__device__ __forceinline__ void mask_epi_flush(const MaskEpiConst<POOL, WRITE, NC>& k, int* __restrict__ any_flags, int lj) {
+    if constexpr (POOL != 0) {
+#pragma unroll
+        for (int m = 0; m < QB; ++m)
+            if (k.anyv[m] != 0u && k.aoff[m] != 0xF0000000u) any_flags[m * 16 + lj] = 1;
     }
 }
 
 // POOL: 0 = no attention mask; 1 = mask at the resolution of the logits (single-level decoder,
 // meanshiftformer_transformer_decoder.py:1012-1035 with target size == mask size: interpolate is the
 // identity); 2/4/8 = 2x2-tap average of a bilinear downsample by that factor.
-template <int POOL, bool WRITE, int NC>
+// D: depth of the feature prefetch ring in groups of KU k-steps (G = C / (4 KU) must be a multiple of D).
+template <int POOL, bool WRITE, int NC, int D>
 __global__ __launch_bounds__(MW * 64) void mask_logits_kernel(const float* __restrict__ emb, const float* __restrict__ feat,
                                                           float* __restrict__ mask_out, uint8_t* __restrict__ attn_out,
                                                           int32_t* __restrict__ row_any, int Q, int C, int H, int W,
@@ -171,7 +406,7 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_kernel(const float* __res
                                                           const float* __restrict__ qbias, int64_t qbias_ld) {
     extern __shared__ __attribute__((aligned(16))) float Es[];   // [QCH][C + 2] embeddings, then [QCH] per-query biases
     constexpr int TW = 16 * NC;      // tile width in columns
-    constexpr int NA = 2 * NC;       // accumulator column blocks: [row (top,bottom)][cc]
+    constexpr int NA = 2 * NC;       // accumulator pixel blocks: [row (top,bottom)][cc]
     const int SE = C + 2;
     const int b = blockIdx.z, qc = blockIdx.y;
     const int q0 = qc * QCH;
@@ -182,36 +417,12 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_kernel(const float* __res
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lj = lane & 15, lq = lane >> 4;
     const int HW = H * W;
-
-    // stage this chunk of mask_embed: rows >= Q are zero; the per-query bias (the folded mask_features bias) starts every
-    // accumulator of its row
-    const float* eb = emb + ((int64_t)b * Q + q0) * emb_ld;
-    for (int idx = tid; idx < QCH * (C / 4); idx += MW * 64) {
-        const int r = idx / (C / 4), c4 = (idx - r * (C / 4)) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q0 + r < Q) v = *reinterpret_cast<const float4*>(eb + (int64_t)r * emb_ld + c4);
-        float2* d = reinterpret_cast<float2*>(&Es[r * SE + c4]);
-        d[0] = make_float2(v.x, v.y);
-        d[1] = make_float2(v.z, v.w);
-    }
-    float* qb = Es + QCH * SE;
-    int* any_flags = reinterpret_cast<int*>(qb + QCH);
-    for (int r = tid; r < QCH; r += MW * 64) {
-        qb[r] = (qbias && q0 + r < Q) ? qbias[((int64_t)b * Q + q0 + r) * qbias_ld] : 0.f;
-        any_flags[r] = 0;
-    }
-    __syncthreads();
+    MASK_TS(0)
 
     const int ctiles = (W + TW - 1) / TW;
     const int ntiles = n_rowpairs * ctiles;
-    const float* fb = feat + (int64_t)b * C * HW;
-    // buffer descriptor over this image's feature map, held in SGPRs
-    const uint64_t fbu = (uint64_t)fb;   // readfirstlane makes the uniformity provable (no waterfall loops)
-    // (readfirstlane returns int: go through unsigned, or a low half with bit 31 set sign-extends into the high half)
-    const uint64_t fbs = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(fbu >> 32)) << 32) |
-                         (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)fbu);
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)fbs, 0, feat_bytes, 0x00020000);   // feat_bytes = C*H*W*4 from the host: stays scalar
+    // buffer descriptor over this image's feature map, held in SGPRs (feat_bytes = C*H*W*4 from the host: stays scalar)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr64(feat + (int64_t)b * C * HW), 0, feat_bytes, 0x00020000);
 
     // Tile schedule: full rounds go to all MW waves of every workgroup; the leftover tiles go first to waves 0..3
     // (one per SIMD) of every workgroup, then to waves 4..7, and so on, so no SIMD gets two leftover tiles
@@ -221,40 +432,123 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_kernel(const float* __res
     const int left = ntiles - full_rounds * slots;
     const int left_slot = (wave >> 2) * ((int)gridDim.x * 4) + (int)blockIdx.x * 4 + (wave & 3);
     const int my_tiles = full_rounds + (left_slot < left ? 1 : 0);
-    for (int it = 0; it < my_tiles; ++it) {
-        const int t = (it < full_rounds) ? it * slots + (int)blockIdx.x * MW + wave : full_rounds * slots + left_slot;
+    auto tile_of = [&](int it) {
+        return (it < full_rounds) ? it * slots + (int)blockIdx.x * MW + wave : full_rounds * slots + left_slot;
+    };
+    // per-lane byte offsets of this lane's pixels in k-row `lq` for a tile; the k-group part of the address is
+    // wave-uniform and travels in the buffer instruction's SGPR soffset, so the loads need no per-lane 64-bit address
+    // arithmetic at all
+    auto tile_voffs = [&](int t, unsigned& vtop, unsigned& vbot) {
         const int rp = t / ctiles, ct = t - rp * ctiles;
         const int ytop = ypar + 2 * (rp_first + rp * rp_step);  // may be -1 (odd pairing): clamp loads
         const int ybot = ytop + 1;                               // may be H
-        const int c = ct * TW + NC * lj;
-        const bool col_ok = c < W;  // W is a multiple of NC
-        const int cl = col_ok ? c : 0;
-        // per-lane byte offsets of this lane's pixels in k-row `lq`; the k-group part of the
-        // address is wave-uniform and travels in the buffer instruction's SGPR soffset, so the
-        // loads need no per-lane 64-bit address arithmetic at all
-        const unsigned voff_top = (unsigned)(((int64_t)lq * HW + (int64_t)max(ytop, 0) * W + cl) * 4);
-        const unsigned voff_bot = (unsigned)(((int64_t)lq * HW + (int64_t)min(ybot, H - 1) * W + cl) * 4);
+        const int c = ct * TW + PixMap<POOL, NC>::load_col(lj);  // the column(s) this lane feeds into A row lj
+        const int cl = c < W ? c : 0;                            // W is a multiple of NC; lanes beyond the map re-read column 0
+        vtop = (unsigned)(((int64_t)lq * HW + (int64_t)max(ytop, 0) * W + cl) * 4);
+        vbot = (unsigned)(((int64_t)lq * HW + (int64_t)min(ybot, H - 1) * W + cl) * 4);
+    };
+    // K loop: groups of KU k-steps through a ring of D register buffers that runs ACROSS tiles: as soon as the MFMAs of a
+    // group are issued its buffer is refilled with the group D ahead -- of the next tile once this one runs out --, pinned
+    // there with sched_barrier (left alone, hipcc sinks the loads behind the MFMAs and waits at once); no buffer copies, so
+    // the only vmcnt waits are the counted ones at each buffer's first use.  D - 1 groups of MFMAs (D = 4: 2.2 us at the
+    // full MFMA rate) cover a load's latency: with D = 2 a wave that had the MFMA pipe to itself -- its sibling on the SIMD
+    // in its epilogue -- ran at half rate (in-kernel timestamps), so the two could not take turns.
+    Cols<NC> tR[D][KU], bR[D][KU];
+    auto load_group = [&](Cols<NC>(&t)[KU], Cols<NC>(&bt)[KU], int kbase, unsigned vtop, unsigned vbot) {
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const unsigned soff = (unsigned)(kbase + u * 4) * (unsigned)HW * 4u;
+            t[u] = ld_cols<NC>(rsrc, vtop, soff);
+            bt[u] = ld_cols<NC>(rsrc, vbot, soff);
+        }
+    };
+    // stage this chunk of mask_embed (rows >= Q are zero): its loads are issued FIRST, then the first tile's feature loads
+    // (memory returns in order: the LDS writes below wait for the embedding rows only, the feature loads stay in flight
+    // behind them while the chunk is staged)
+    const float* eb = emb + ((int64_t)b * Q + q0) * emb_ld;
+    const int c4n = C >> 2;
+    const bool colwise = (MW * 64) % c4n == 0 && 4 * ((MW * 64) / c4n) >= QCH;   // C = 64, 128, 256: a thread keeps its column, <= 4 rows
+    const int rpp = colwise ? (MW * 64) / c4n : 1, r0 = colwise ? tid / c4n : 0, c4 = colwise ? (tid - r0 * c4n) * 4 : 0;
+    float4 ev[4];
+    if (colwise) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + i * rpp;
+            ev[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < QCH && q0 + r < Q) ev[i] = *reinterpret_cast<const float4*>(eb + (int64_t)r * emb_ld + c4);
+        }
+    }
+    unsigned voff_top = 0, voff_bot = 0;
+    tile_voffs(tile_of(0), voff_top, voff_bot);       // my_tiles == 0: tile index beyond the schedule, clamped addresses
+    if (my_tiles > 0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) load_group(tR[d], bR[d], d * (4 * KU), voff_top, voff_bot);
+    }
+    if (colwise) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + i * rpp;
+            if (r < QCH) {
+                float2* d = reinterpret_cast<float2*>(&Es[r * SE + c4]);
+                d[0] = make_float2(ev[i].x, ev[i].y);
+                d[1] = make_float2(ev[i].z, ev[i].w);
+            }
+        }
+    } else {
+        for (int idx = tid; idx < QCH * c4n; idx += MW * 64) {
+            const int r = idx / c4n, cc4 = (idx - r * c4n) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q0 + r < Q) v = *reinterpret_cast<const float4*>(eb + (int64_t)r * emb_ld + cc4);
+            float2* d = reinterpret_cast<float2*>(&Es[r * SE + cc4]);
+            d[0] = make_float2(v.x, v.y);
+            d[1] = make_float2(v.z, v.w);
+        }
+    }
+    float* qb = Es + QCH * SE;
+    int* any_flags = reinterpret_cast<int*>(qb + QCH);
+    for (int r = tid; r < QCH; r += MW * 64) {
+        qb[r] = (qbias && q0 + r < Q) ? qbias[((int64_t)b * Q + q0 + r) * qbias_ld] : 0.f;
+        any_flags[r] = 0;
+    }
+    __syncthreads();
+    MASK_TS(1)
+
+    // per-lane constants: the bias of the lane's query of every block as a ready-made accumulator tuple (the first MFMA of a
+    // tile takes it as its C operand: no accumulator initialisation instructions), the store offsets of the fast epilogue
+    // (NC == 1 only: with 2 x 32 tiles the 28 registers do not fit next to 112 accumulators, the tuples are rebuilt per tile)
+    constexpr int NB4 = NC == 1 ? QB : 1;
+    f32x4 bias4[NB4];
+    if constexpr (NC == 1) {
+#pragma unroll
+        for (int m = 0; m < QB; ++m) {
+            const float q_b = qb[m * 16 + lj];
+            bias4[m] = f32x4{q_b, q_b, q_b, q_b};
+        }
+    }
+    MaskEpiConst<POOL, WRITE, NC> epi;
+    mask_epi_init<POOL, WRITE, NC>(epi, mask_out, attn_out, b, Q, q0, H, W, th, tw, lj, lq);
+
+    const int G = C / (4 * KU);          // even and >= 2: C is a multiple of 32
+    // (Reading the mask_embed fragments of a group one group ahead -- two register sets -- measured no gain: the sibling
+    // wave of the SIMD covers that latency.)
+    // Two waves share a SIMD (w and w + 4).  Left alone they run in lockstep -- both in their K loop (each at half the MFMA
+    // rate), then both in their epilogue with the MFMA pipe idle (in-kernel timestamps: 1.6 - 3.5 us of epilogue per 6 us
+    // K loop).  Priority to waves 0..3 breaks the symmetry: the favoured wave's K loop runs at the full rate, its sibling
+    // fills the pipe while it is in its epilogue, and from then on the two alternate.
+#ifndef MSM_MASK_NOPRIO
+    if (wave < 4) __builtin_amdgcn_s_setprio(3);
+#endif
+    for (int it = 0; it < my_tiles; ++it) {
+        const int t = tile_of(it);
+        const int rp = t / ctiles, ct = t - rp * ctiles;
+        const int ytop = ypar + 2 * (rp_first + rp * rp_step);
+        const int ybot = ytop + 1;
+        const int c0 = ct * TW;
+        unsigned nvoff_top, nvoff_bot;
+        tile_voffs(tile_of(min(it + 1, my_tiles - 1)), nvoff_top, nvoff_bot);   // the last tile re-reads its own first group
 
         f32x4 acc[QB][NA];
-#pragma unroll
-        for (int m = 0; m < QB; ++m)
-#pragma unroll
-            for (int n = 0; n < NA; ++n) acc[m][n] = *reinterpret_cast<const f32x4*>(qb + m * 16 + lq * 4);
-
-        // K loop: groups of KU k-steps, two register buffers (A/B) in ping-pong.  The loads of the
-        // next group are issued BEFORE the MFMAs of the current one and pinned there with
-        // sched_barrier (left alone, hipcc sinks them behind the MFMAs and waits at once); no
-        // buffer copies, so the only vmcnt waits are the counted ones at each buffer's first use.
-        Cols<NC> tA[KU], bA[KU], tB[KU], bB[KU];
-        auto load_group = [&](Cols<NC>(&t)[KU], Cols<NC>(&bt)[KU], int kbase) {
-#pragma unroll
-            for (int u = 0; u < KU; ++u) {
-                const unsigned soff = (unsigned)(kbase + u * 4) * (unsigned)HW * 4u;
-                t[u] = ld_cols<NC>(rsrc, voff_top, soff);
-                bt[u] = ld_cols<NC>(rsrc, voff_bot, soff);
-            }
-        };
-        auto compute_group = [&](const Cols<NC>(&t)[KU], const Cols<NC>(&bt)[KU], int kbase) {
+        auto compute_group = [&](auto first, const Cols<NC>(&t_)[KU], const Cols<NC>(&bt)[KU], int kbase) {
 #pragma unroll
             for (int u = 0; u < KU; ++u) {
                 const float* er = &Es[lj * SE + kbase + u * 4 + lq];
@@ -263,30 +557,61 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_kernel(const float* __res
                     const float a = er[m * 16 * SE];
 #pragma unroll
                     for (int cc = 0; cc < NC; ++cc) {
-                        acc[m][cc] = mfma16(a, t[u].v[cc], acc[m][cc]);
-                        acc[m][NC + cc] = mfma16(a, bt[u].v[cc], acc[m][NC + cc]);
+                        if (decltype(first)::value && u == 0) {                          // D[pixel][query], C operand = the query's bias
+                            f32x4 c4;
+                            if constexpr (NC == 1) {
+                                c4 = bias4[m];
+                            } else {
+                                const float q_b = qb[m * 16 + lj];
+                                c4 = f32x4{q_b, q_b, q_b, q_b};
+                            }
+                            acc[m][cc] = mfma16(t_[u].v[cc], a, c4);
+                            acc[m][NC + cc] = mfma16(bt[u].v[cc], a, c4);
+                        } else {
+                            acc[m][cc] = mfma16(t_[u].v[cc], a, acc[m][cc]);
+                            acc[m][NC + cc] = mfma16(bt[u].v[cc], a, acc[m][NC + cc]);
+                        }
                     }
                 }
             }
         };
-        const int G = C / (4 * KU);
-        load_group(tA, bA, 0);
-        int g = 0;
-        for (; g + 1 < G; g += 2) {   // straight-line body: nothing for LLVM to sink the loads into
-            load_group(tB, bB, (g + 1) * (4 * KU));
-            __builtin_amdgcn_sched_barrier(0);
-            compute_group(tA, bA, g * (4 * KU));
-            __builtin_amdgcn_sched_barrier(0);
-            load_group(tA, bA, min(g + 2, G - 1) * (4 * KU));
-            __builtin_amdgcn_sched_barrier(0);
-            compute_group(tB, bB, (g + 1) * (4 * KU));
-            __builtin_amdgcn_sched_barrier(0);
+        // straight-line bodies: nothing for LLVM to sink the loads into; the first D groups are peeled (bias as C operand)
+        auto ring_pass = [&](auto first, int gb) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int g = gb + d;
+                if (d == 0) compute_group(first, tR[d], bR[d], g * (4 * KU));
+                else compute_group(std::false_type{}, tR[d], bR[d], g * (4 * KU));
+                __builtin_amdgcn_sched_barrier(0);
+                const bool more = g + D < G;                                          // wave-uniform
+                load_group(tR[d], bR[d], (more ? g + D : g + D - G) * (4 * KU), more ? voff_top : nvoff_top, more ? voff_bot : nvoff_bot);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        ring_pass(std::true_type{}, 0);
+        for (int gb = D; gb < G; gb += D) ring_pass(std::false_type{}, gb);
+        voff_top = nvoff_top;
+        voff_bot = nvoff_bot;
+        MASK_TS(2 + 3 * it)
+#ifdef MSM_MASK_TS
+        {
+            float dep = acc[QB - 1][NA - 1][3];                   // result of the tile's last MFMA: the move issues once it is complete
+            asm volatile("v_mov_b32 %0, %0" : "+v"(dep));
+            MASK_TS(3 + 3 * it)
         }
-        if (g < G) compute_group(tA, bA, g * (4 * KU));   // odd number of groups
-
-        mask_tile_epilogue<POOL, WRITE, NC>(acc, mask_out, attn_out, any_flags, b, Q, q0, H, W, th, tw, ytop, ybot, c, col_ok, lj, lq);
+#endif
+        const bool inside = c0 + TW <= W;                                             // wave-uniform
+        if constexpr (WRITE) {
+            static_assert(NC == 1, "mask writes take 2 x 16 tiles (see mask_tile_epilogue_fast)");
+            if (inside && epi.write_fast) mask_tile_epilogue_fast<POOL, WRITE, NC, true, false>(acc, epi, H, W, tw, ytop, ybot, c0);
+            else mask_tile_epilogue<POOL, WRITE, NC, true, false>(acc, mask_out, attn_out, any_flags, b, Q, q0, H, W, th, tw, ytop, ybot, c0, lj, lq);
+        }
+        if (inside && epi.attn_fast) mask_tile_epilogue_fast<POOL, WRITE, NC, false, true>(acc, epi, H, W, tw, ytop, ybot, c0);
+        else mask_tile_epilogue<POOL, WRITE, NC, false, true>(acc, mask_out, attn_out, any_flags, b, Q, q0, H, W, th, tw, ytop, ybot, c0, lj, lq);
+        MASK_TS(4 + 3 * it)
     }
     if constexpr (POOL != 0) {
+        mask_epi_flush<POOL, WRITE, NC>(epi, any_flags, lj);
         __syncthreads();
         for (int r = tid; r < QCH; r += MW * 64)
             if (any_flags[r] && q0 + r < Q) row_any[(int64_t)b * Q + q0 + r] = 1;
@@ -364,7 +689,7 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_bf16_kernel(const float* 
     auto load_tile = [&](int t, TileRegs& r) {
         const int rp = t / ctiles, ct = t - rp * ctiles;
         const int ytop = ypar + 2 * (rp_first + rp * rp_step), ybot = ytop + 1;
-        const int c = ct * 16 + lj;
+        const int c = ct * 16 + PixMap<POOL, 1>::load_col(lj);
         const int cl = c < W ? c : 0;
         // packed element (k-quad, pixel): 8 bytes at ((kq * HW) + pixel) * 8; the k-step part travels in soffset
         const unsigned voff_top = (unsigned)(((int64_t)lq * HW + (int64_t)max(ytop, 0) * W + cl) * 8);
@@ -383,13 +708,12 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_bf16_kernel(const float* 
         const int rp = t / ctiles, ct = t - rp * ctiles;
         const int ytop = ypar + 2 * (rp_first + rp * rp_step);
         const int ybot = ytop + 1;
-        const int c = ct * 16 + lj;
-        const bool col_ok = c < W;
+        const int c0 = ct * 16;
         load_tile(tile_of(min(it + 1, my_tiles - 1)), nxt);
         __builtin_amdgcn_sched_barrier(0);
         f32x4 acc[QB][2];
 #pragma unroll
-        for (int m = 0; m < QB; ++m) acc[m][0] = acc[m][1] = *reinterpret_cast<const f32x4*>(qb + m * 16 + lq * 4);
+        for (int m = 0; m < QB; ++m) { const float q_b = qb[m * 16 + lj]; acc[m][0] = acc[m][1] = f32x4{q_b, q_b, q_b, q_b}; }
 #pragma unroll
         for (int ks = 0; ks < BKS; ++ks) {
             if (ks < nks) {                                              // wave-uniform
@@ -399,13 +723,13 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_bf16_kernel(const float* 
 #pragma unroll
                 for (int m = 0; m < QB; ++m) {
                     const bf16x4 a = __builtin_bit_cast(bf16x4, *reinterpret_cast<const u32x2*>(er + m * 16 * SEb));
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, bt_, acc[m][0], 0, 0, 0);
-                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, bb_, acc[m][1], 0, 0, 0);
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bt_, a, acc[m][0], 0, 0, 0);      // D[pixel][query]
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bb_, a, acc[m][1], 0, 0, 0);
                 }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        mask_tile_epilogue<POOL, WRITE, 1>(acc, mask_out, attn_out, any_flags, b, Q, q0, H, W, th, tw, ytop, ybot, c, col_ok, lj, lq);
+        mask_tile_epilogue<POOL, WRITE, 1>(acc, mask_out, attn_out, any_flags, b, Q, q0, H, W, th, tw, ytop, ybot, c0, lj, lq);
 #pragma unroll
         for (int ks = 0; ks < BKS; ++ks) {
             cur.t[ks] = nxt.t[ks];
@@ -492,23 +816,29 @@ extern "C" int msm_mask_logits_fwd(const float* mask_embed, const float* mask_fe
     const double cost32 = (double)cdiv(t32, 1024), cost16 = 0.5 * (double)cdiv(t16, 1024);
     int nc = (cost16 * 1.04 < cost32) ? 1 : 2;
     if (const int o = opt(MSM_OPT_MASK_NC); o != MSM_OPT_AUTO) nc = o == 1 ? 1 : 2;
+    if (mask_out) nc = 1;      // launches that write the logits take 2 x 16 tiles: their float4 stores are accumulator tuples
     const int ctiles = cdiv(W, 16 * nc);
     const int ntiles = n_rowpairs * ctiles;
     // persistent-ish grid: enough workgroups per (image, chunk) to cover the chip once
     int wg_per = cdiv(ntiles, MW);
-    const int target = cdiv(256, B * qchunks);
+    const size_t lds = sizeof(float) * ((size_t)QCH * (C + 2) + 2 * QCH);
+    const int occ = opt(MSM_OPT_MASK_WGS_PER_CU) > 0 ? opt(MSM_OPT_MASK_WGS_PER_CU) : 1;
+    const int target = cdiv(256 * occ, B * qchunks);
     if (wg_per > target) wg_per = max(target, 1);
     dim3 grid(wg_per, qchunks, B), block(MW * 64);
-    const size_t lds = sizeof(float) * ((size_t)QCH * (C + 2) + 2 * QCH);
     typedef void (*kern_t)(const float*, const float*, float*, uint8_t*, int32_t*, int, int, int, int, int, int, int, int, int, int, int, int64_t,
                            const float*, int64_t);
     kern_t kern;
     const bool wr = mask_out != nullptr;
-#define MASK_PICK(P)                                                                                   \
-    (nc == 2 ? (wr ? (kern_t)mask_logits_kernel<P, true, 2> : (kern_t)mask_logits_kernel<P, false, 2>)   \
-             : (wr ? (kern_t)mask_logits_kernel<P, true, 1> : (kern_t)mask_logits_kernel<P, false, 1>))
+    // prefetch ring of four groups (2 x 16 tiles, C a multiple of 64) instead of two: opt-in -- a lone wave then gets closer
+    // to the MFMA rate (K loop of a 3 us tile: 6.1 -> 4.8 us) but its 32 loads up front delay the first MFMA by 1.2 us
+    const bool deep = nc == 1 && (C / (4 * KU)) % 4 == 0 && opt(MSM_OPT_MASK_WGS_PER_CU) == 104;
+#define MASK_PICK(P)                                                                                                   \
+    (wr ? (deep ? (kern_t)mask_logits_kernel<P, true, 1, 4> : (kern_t)mask_logits_kernel<P, true, 1, 2>)                  \
+        : (nc == 2 ? (kern_t)mask_logits_kernel<P, false, 2, 2>                                                          \
+                   : (deep ? (kern_t)mask_logits_kernel<P, false, 1, 4> : (kern_t)mask_logits_kernel<P, false, 1, 2>)))
     switch (pool) {
-        case 0: kern = nc == 2 ? (kern_t)mask_logits_kernel<0, true, 2> : (kern_t)mask_logits_kernel<0, true, 1>; break;
+        case 0: kern = deep ? (kern_t)mask_logits_kernel<0, true, 1, 4> : (kern_t)mask_logits_kernel<0, true, 1, 2>; break;
         case 1: kern = MASK_PICK(1); break;
         case 2: kern = MASK_PICK(2); break;
         case 4: kern = MASK_PICK(4); break;
@@ -521,6 +851,12 @@ extern "C" int msm_mask_logits_fwd(const float* mask_embed, const float* mask_fe
     MSM_CHECK_LAUNCH("msm_mask_logits_fwd");
     return MSM_OK;
 }
+
+#ifdef MSM_MASK_TS
+extern "C" int msm_debug_mask_ts(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(msm::g_mask_ts), sizeof(unsigned long long) * 256 * 8 * 16);
+}
+#endif
 
 extern "C" int msm_pack_mask_features_bf16(const float* mask_feat, uint16_t* packed, int B, int C, int HW, void* stream) {
     MSM_REQUIRE(mask_feat && packed, "msm_pack_mask_features_bf16: null pointer");
