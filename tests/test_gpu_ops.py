@@ -141,6 +141,39 @@ def test_mask_logits(B, Q, H, W, pool, nc, lib_option):
     assert attn is None and row_any is None
 
 
+@pytest.mark.parametrize("kernel", ["r64", "lds"])
+@pytest.mark.parametrize("B,Q,H,W,pool", [(2, 100, 16, 24, 2), (2, 100, 16, 24, 4), (2, 100, 16, 24, 8), (8, 100, 120, 160, 8),
+                                          (1, 100, 120, 160, 4), (2, 100, 120, 160, 2), (1, 300, 48, 64, 4), (2, 20, 8, 8, 2),
+                                          (2, 100, 16, 24, 1), (1, 100, 60, 80, 1), (3, 100, 30, 40, 2), (1, 37, 18, 22, 2)])
+def test_mask_logits_folded_form(B, Q, H, W, pool, kernel, lib_option):
+    """The folded form of the step (modeling.FoldedMaskFeatures): 64 channels, the embedding is the leading 64 columns of a
+    256-wide buffer, a per-query bias starts every logit.  "lds": the default kernel; "r64": the one-wave-per-SIMD variant with
+    mask_embed in registers (MSM_OPT_MASK_KERNEL = 2)."""
+    if kernel == "r64":
+        lib_option("MASK_KERNEL", 2)
+    C = 64
+    wide = rnd(B, Q, 256, seed=1, scale=0.3)
+    e, qb = wide[..., :C], wide[..., 64]
+    f = rnd(B, C, H, W, seed=2)
+    tgt = (H // pool, W // pool)
+    full = torch.einsum("bqc,bchw->bqhw", e.double(), f.double()) + qb.double()[..., None, None]
+    pooled = F.interpolate(full.float(), size=tgt, mode="bilinear", align_corners=False)
+    attn_ref = pooled.sigmoid().flatten(2) < 0.5
+    wd, fd = wide.to(DEV), f.to(DEV)
+    for want_mask, sparse in ((True, False), (False, False), (False, True)):
+        mask, attn, row_any = ops().mask_logits(wd[..., :C], fd, want_mask=want_mask, target_size=tgt, sparse=sparse, qbias=wd[..., 64])
+        if want_mask:
+            close(mask, full.float(), rtol=1e-4, atol=1e-4)
+        got = attn.cpu().bool()
+        diff = got != attn_ref
+        if diff.any():                                # bits may differ only where the pooled logit is within rounding of zero
+            assert pooled.flatten(2)[diff].abs().max() < 1e-4
+        assert torch.equal(row_any.cpu().bool(), ~attn.cpu().bool().all(-1))
+    mask, attn, row_any = ops().mask_logits(wd[..., :C], fd, want_mask=True, target_size=None, qbias=wd[..., 64])
+    close(mask, full.float(), rtol=1e-4, atol=1e-4)
+    assert attn is None and row_any is None
+
+
 def test_mask_logits_tile_choice_is_result_neutral(lib_option):
     e, f = rnd(8, 100, 256, seed=3, scale=0.3).to(DEV), rnd(8, 256, 120, 160, seed=4).to(DEV)
     outs = []

@@ -74,12 +74,12 @@ def mask():
         qb = wide[..., 64] if C == 64 else None
         f = torch.randn(8, C, 120, 160, device=DEV)
         flops = 2.0 * 100 * C * 19200 * 8
-        for nc, occ in (("2", 1), ("1", 1), ("1", 2), ("1", 3), ("", 1)):
+        for nc, occ in (("2", -1), ("1", -1), ("", 2), ("", 3), ("", -1)):       # kernel 2: r64 (C = 64), 3: deep prefetch ring
             _lib.set_option("MASK_NC", int(nc) if nc else _lib.OPT_AUTO)
-            _lib.set_option("MASK_WGS_PER_CU", occ)
+            _lib.set_option("MASK_KERNEL", occ)
             for tgt, wm in (((15, 20), False), ((30, 40), False), ((60, 80), False), (None, True)):
                 t = timeit_graph(lambda: ops.mask_logits(e, f, want_mask=wm, target_size=tgt, qbias=qb))
-                print(f"mask C={C} nc={nc or 'auto'} wgs/CU={occ} target={tgt} write={wm}: {t:7.1f} us  {flops / t / 1e6:6.1f} TFLOP/s executed", flush=True)
+                print(f"mask C={C} nc={nc or 'auto'} kernel={occ} target={tgt} write={wm}: {t:7.1f} us  {flops / t / 1e6:6.1f} TFLOP/s executed", flush=True)
 
 
 def maskbf16():

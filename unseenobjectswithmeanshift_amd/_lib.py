@@ -103,7 +103,7 @@ def lib():
 
 # kernel-selection overrides of include/msm_hip.h (enum order), for tools/ and tests/ only
 OPTIONS = ("MASK_NC", "MASKB_TARGET", "GEMM_TILE", "GEMM_SHALLOW", "ATTN_TARGET", "ATTN_KERNEL", "ATTN_QK_MAX", "ATTN_QKCFG",
-           "CONVIN_NT", "POST_GENERIC", "ENC_NO_COOP", "MSDA_GENERIC", "MS_CHUNK", "MS_NO_PERSISTENT", "ATTN_FUSED_KV", "MASK_WGS_PER_CU")
+           "CONVIN_NT", "POST_GENERIC", "ENC_NO_COOP", "MSDA_GENERIC", "MS_CHUNK", "MS_NO_PERSISTENT", "ATTN_FUSED_KV", "MASK_KERNEL")
 OPT_AUTO = -1
 
 

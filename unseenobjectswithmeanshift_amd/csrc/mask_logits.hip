@@ -618,6 +618,171 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_kernel(const float* __res
     }
 }
 
+// ---- folded form, C = 64: mask_embed in registers, one wave per SIMD -----------------------------------------------------
+// The folded step (modeling.FoldedMaskFeatures) contracts over the 64 FPN channels: a tile is only 16 k-steps (224 MFMAs,
+// 3 us of the MFMA pipe) and everything around the MFMAs weighs four times what it does at C = 256.  In-kernel timestamps
+// of the kernel above (two waves per SIMD, LDS-resident mask_embed): a wave alone reaches ~70 % of the MFMA rate (its
+// ds_reads at every k-step and a prefetch distance of one group are exposed), and an epilogue that takes 0.55 us on an idle
+// SIMD takes 3 us beside a sibling wave that is issuing MFMAs (VALU instructions and stores queue behind them) -- the two
+// waves never settle into taking turns, wave priorities notwithstanding.  This kernel (an experiment, selected with
+// MSM_OPT_MASK_KERNEL = 2; see the measurements at its launch site) gives the SIMD to ONE wave with the whole register file
+// (512 VGPRs + AGPRs):
+//   * the wave's mask_embed fragments -- E[16 m + lj][4 u + lq], 7 blocks x 16 k-steps = 112 registers -- are read from
+//     LDS once and are the MFMA B operands of every tile: no LDS traffic in the K loop at all;
+//   * the feature fragments come through a ring of four groups (a whole tile): when a group's MFMAs are issued its slot is
+//     refilled with the same group of the NEXT tile, so every load has three groups (2.2 us) to arrive;
+//   * the epilogue (shared with the kernel above) runs on an otherwise idle SIMD at its nominal cost.
+constexpr int R64_C = 64, R64_W = 4;      // channels, waves per workgroup
+
+template <int POOL, bool WRITE>
+__global__ __launch_bounds__(R64_W * 64) void mask_logits_r64_kernel(const float* __restrict__ emb, const float* __restrict__ feat,
+                                                                  float* __restrict__ mask_out, uint8_t* __restrict__ attn_out,
+                                                                  int32_t* __restrict__ row_any, int Q, int C_unused, int H, int W,
+                                                                  int th, int tw, int ypar, int n_rowpairs, int rp_step,
+                                                                  int rp_first, int feat_bytes, int64_t emb_ld,
+                                                                  const float* __restrict__ qbias, int64_t qbias_ld) {
+    extern __shared__ __attribute__((aligned(16))) float Es[];   // [QCH][C + 2] embeddings, then [QCH] per-query biases, [QCH] flags
+    constexpr int NC = 1, TW = 16, NA = 2, C = R64_C, SE = C + 2, KS = C / 4, D = KS / KU;
+    static_assert(D == 4, "ring = one tile");
+    (void)C_unused;
+    const int b = blockIdx.z, qc = blockIdx.y;
+    const int q0 = qc * QCH;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    const int HW = H * W;
+    MASK_TS(0)
+
+    const int ctiles = (W + TW - 1) / TW;
+    const int ntiles = n_rowpairs * ctiles;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr64(feat + (int64_t)b * C * HW), 0, feat_bytes, 0x00020000);
+    // tile schedule: round-robin over all waves of the (image, query chunk)'s workgroups
+    const int slots = gridDim.x * R64_W;
+    const int slot = (int)blockIdx.x * R64_W + wave;
+    const int my_tiles = slot < ntiles ? (ntiles - slot + slots - 1) / slots : 0;
+    auto tile_of = [&](int it) { return it * slots + slot; };
+    auto tile_voffs = [&](int t, unsigned& vtop, unsigned& vbot) {
+        const int rp = t / ctiles, ct = t - rp * ctiles;
+        const int ytop = ypar + 2 * (rp_first + rp * rp_step);  // may be -1 (odd pairing): clamp loads
+        const int ybot = ytop + 1;                               // may be H
+        const int c = ct * TW + PixMap<POOL, NC>::load_col(lj);
+        const int cl = c < W ? c : 0;
+        vtop = (unsigned)(((int64_t)lq * HW + (int64_t)min(max(ytop, 0), H - 1) * W + cl) * 4);
+        vbot = (unsigned)(((int64_t)lq * HW + (int64_t)min(max(ybot, 0), H - 1) * W + cl) * 4);
+    };
+    Cols<NC> tR[D][KU], bR[D][KU];
+    auto load_group = [&](Cols<NC>(&t)[KU], Cols<NC>(&bt)[KU], int kbase, unsigned vtop, unsigned vbot) {
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const unsigned soff = (unsigned)(kbase + u * 4) * (unsigned)HW * 4u;
+            t[u] = ld_cols<NC>(rsrc, vtop, soff);
+            bt[u] = ld_cols<NC>(rsrc, vbot, soff);
+        }
+    };
+    // mask_embed chunk: global loads first, then the first tile's feature loads, then the LDS writes (memory returns in order)
+    const float* eb = emb + ((int64_t)b * Q + q0) * emb_ld;
+    constexpr int C4N = C / 4, RPP = (R64_W * 64) / C4N, NPASS = (QCH + RPP - 1) / RPP;      // 16 float4 per row, 16 rows per pass, 7 passes
+    const int r0 = tid / C4N, c4 = (tid - r0 * C4N) * 4;
+    float4 ev[NPASS];
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+        const int r = r0 + i * RPP;
+        ev[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < QCH && q0 + r < Q) ev[i] = *reinterpret_cast<const float4*>(eb + (int64_t)r * emb_ld + c4);
+    }
+    unsigned voff_top = 0, voff_bot = 0;
+    tile_voffs(min(tile_of(0), ntiles - 1), voff_top, voff_bot);
+    if (my_tiles > 0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) load_group(tR[d], bR[d], d * (4 * KU), voff_top, voff_bot);
+    }
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+        const int r = r0 + i * RPP;
+        if (r < QCH) {
+            float2* d = reinterpret_cast<float2*>(&Es[r * SE + c4]);
+            d[0] = make_float2(ev[i].x, ev[i].y);
+            d[1] = make_float2(ev[i].z, ev[i].w);
+        }
+    }
+    float* qb = Es + QCH * SE;
+    int* any_flags = reinterpret_cast<int*>(qb + QCH);
+    for (int r = tid; r < QCH; r += R64_W * 64) {
+        qb[r] = (qbias && q0 + r < Q) ? qbias[((int64_t)b * Q + q0 + r) * qbias_ld] : 0.f;
+        any_flags[r] = 0;
+    }
+    __syncthreads();
+    MASK_TS(1)
+    // this lane's mask_embed fragments and biases, for the whole kernel
+    float e[QB][KS];
+    f32x4 bias4[QB];
+#pragma unroll
+    for (int m = 0; m < QB; ++m) {
+        const float* er = &Es[(m * 16 + lj) * SE + lq];
+#pragma unroll
+        for (int u = 0; u < KS; ++u) e[m][u] = er[4 * u];
+        const float q_b = qb[m * 16 + lj];
+        bias4[m] = f32x4{q_b, q_b, q_b, q_b};
+    }
+    MaskEpiConst<POOL, WRITE, NC> epi;
+    mask_epi_init<POOL, WRITE, NC>(epi, mask_out, attn_out, b, Q, q0, H, W, th, tw, lj, lq);
+
+    for (int it = 0; it < my_tiles; ++it) {
+        const int t = tile_of(it);
+        const int rp = t / ctiles, ct = t - rp * ctiles;
+        const int ytop = ypar + 2 * (rp_first + rp * rp_step);
+        const int ybot = ytop + 1;
+        const int c0 = ct * TW;
+        unsigned nvoff_top, nvoff_bot;
+        tile_voffs(tile_of(min(it + 1, my_tiles - 1)), nvoff_top, nvoff_bot);   // the last tile re-reads its own groups
+        f32x4 acc[QB][NA];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+#pragma unroll
+                for (int m = 0; m < QB; ++m) {
+                    const float a = e[m][d * KU + u];
+                    if (d == 0 && u == 0) {                                  // D[pixel][query], C operand = the query's bias
+                        acc[m][0] = mfma16(tR[d][u].v[0], a, bias4[m]);
+                        acc[m][1] = mfma16(bR[d][u].v[0], a, bias4[m]);
+                    } else {
+                        acc[m][0] = mfma16(tR[d][u].v[0], a, acc[m][0]);
+                        acc[m][1] = mfma16(bR[d][u].v[0], a, acc[m][1]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef MSM_R64_NOLOAD
+            load_group(tR[d], bR[d], d * (4 * KU), nvoff_top, nvoff_bot);       // same group of the next tile
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        MASK_TS(2 + 3 * it)
+#ifdef MSM_MASK_TS
+        {
+            float dep = acc[QB - 1][NA - 1][3];
+            asm volatile("v_mov_b32 %0, %0" : "+v"(dep));
+            MASK_TS(3 + 3 * it)
+        }
+#endif
+        const bool inside = c0 + TW <= W;                                             // wave-uniform
+        if constexpr (WRITE) {
+            if (inside && epi.write_fast) mask_tile_epilogue_fast<POOL, WRITE, NC, true, false>(acc, epi, H, W, tw, ytop, ybot, c0);
+            else mask_tile_epilogue<POOL, WRITE, NC, true, false>(acc, mask_out, attn_out, any_flags, b, Q, q0, H, W, th, tw, ytop, ybot, c0, lj, lq);
+        }
+        if (inside && epi.attn_fast) mask_tile_epilogue_fast<POOL, WRITE, NC, false, true>(acc, epi, H, W, tw, ytop, ybot, c0);
+        else mask_tile_epilogue<POOL, WRITE, NC, false, true>(acc, mask_out, attn_out, any_flags, b, Q, q0, H, W, th, tw, ytop, ybot, c0, lj, lq);
+        MASK_TS(4 + 3 * it)
+    }
+    if constexpr (POOL != 0) {
+        mask_epi_flush<POOL, WRITE, NC>(epi, any_flags, lj);
+        __syncthreads();
+        for (int r = tid; r < QCH; r += R64_W * 64)
+            if (any_flags[r] && q0 + r < Q) row_any[(int64_t)b * Q + q0 + r] = 1;
+    }
+}
+
 // ---- bf16 variant (BASELINE configs 3 and 5) ------------------------------------------------------------------------
 // Same product with bf16 operands and fp32 accumulation (v_mfma_f32_16x16x16_bf16): at 2.5 PFLOP/s the 7.9 GFLOP of a
 // launch are ~4 us of MFMA, so the step becomes a stream over the feature map -- HBM-bound (AI 71.6 FLOP/B
@@ -822,8 +987,7 @@ extern "C" int msm_mask_logits_fwd(const float* mask_embed, const float* mask_fe
     // persistent-ish grid: enough workgroups per (image, chunk) to cover the chip once
     int wg_per = cdiv(ntiles, MW);
     const size_t lds = sizeof(float) * ((size_t)QCH * (C + 2) + 2 * QCH);
-    const int occ = opt(MSM_OPT_MASK_WGS_PER_CU) > 0 ? opt(MSM_OPT_MASK_WGS_PER_CU) : 1;
-    const int target = cdiv(256 * occ, B * qchunks);
+    const int target = cdiv(256, B * qchunks);
     if (wg_per > target) wg_per = max(target, 1);
     dim3 grid(wg_per, qchunks, B), block(MW * 64);
     typedef void (*kern_t)(const float*, const float*, float*, uint8_t*, int32_t*, int, int, int, int, int, int, int, int, int, int, int, int64_t,
@@ -832,7 +996,7 @@ extern "C" int msm_mask_logits_fwd(const float* mask_embed, const float* mask_fe
     const bool wr = mask_out != nullptr;
     // prefetch ring of four groups (2 x 16 tiles, C a multiple of 64) instead of two: opt-in -- a lone wave then gets closer
     // to the MFMA rate (K loop of a 3 us tile: 6.1 -> 4.8 us) but its 32 loads up front delay the first MFMA by 1.2 us
-    const bool deep = nc == 1 && (C / (4 * KU)) % 4 == 0 && opt(MSM_OPT_MASK_WGS_PER_CU) == 104;
+    const bool deep = nc == 1 && (C / (4 * KU)) % 4 == 0 && opt(MSM_OPT_MASK_KERNEL) == 3;
 #define MASK_PICK(P)                                                                                                   \
     (wr ? (deep ? (kern_t)mask_logits_kernel<P, true, 1, 4> : (kern_t)mask_logits_kernel<P, true, 1, 2>)                  \
         : (nc == 2 ? (kern_t)mask_logits_kernel<P, false, 2, 2>                                                          \
@@ -845,6 +1009,30 @@ extern "C" int msm_mask_logits_fwd(const float* mask_embed, const float* mask_fe
         default: kern = MASK_PICK(8); break;
     }
 #undef MASK_PICK
+    if (C == R64_C && opt(MSM_OPT_MASK_KERNEL) == 2) {
+        // folded form, opt-in: one wave per SIMD, mask_embed in registers (mask_logits_r64_kernel).  Measured at B = 8: 24.9 /
+        // 25.0 / 26.3 / 27.8 us (15x20 / 30x40 / 60x80 targets / final write) against 23.6 / 23.8 / 25.0 / 27.3 for the
+        // two-waves-per-SIMD kernel above: its K loop runs at 3.5 - 3.7 us per 3.0-us tile with or without the loads, i.e.
+        // a lone wave issues 16x16x4 MFMAs at ~85 % of the nominal rate, and nothing hides its epilogues.
+        const int nt16 = n_rowpairs * cdiv(W, 16);
+        int wgp = cdiv(nt16, R64_W);
+        const int tgt = cdiv(256, B * qchunks);
+        if (wgp > tgt) wgp = max(tgt, 1);
+#define MASK_PICK_R(P) (wr ? (kern_t)mask_logits_r64_kernel<P, true> : (kern_t)mask_logits_r64_kernel<P, false>)
+        switch (pool) {
+            case 0: kern = (kern_t)mask_logits_r64_kernel<0, true>; break;
+            case 1: kern = MASK_PICK_R(1); break;
+            case 2: kern = MASK_PICK_R(2); break;
+            case 4: kern = MASK_PICK_R(4); break;
+            default: kern = MASK_PICK_R(8); break;
+        }
+#undef MASK_PICK_R
+        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)kern, lds));
+        hipLaunchKernelGGL(kern, dim3(wgp, qchunks, B), dim3(R64_W * 64), lds, st, mask_embed, mask_feat, mask_out, attn_out, row_any, Q, C, H, W, th,
+                           tw, ypar, n_rowpairs, rp_step, rp_first, (int)((int64_t)C * H * W * 4), embed_ld, qbias, qbias_ld);
+        MSM_CHECK_LAUNCH("msm_mask_logits_fwd(r64)");
+        return MSM_OK;
+    }
     MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)kern, lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, mask_embed, mask_feat, mask_out, attn_out, row_any, Q, C, H, W, th, tw,
                        ypar, n_rowpairs, rp_step, rp_first, (int)((int64_t)C * H * W * 4), embed_ld, qbias, qbias_ld);
