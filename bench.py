@@ -236,6 +236,23 @@ def extra_configs(dev, args):
                                        "value": round(BATCH / t, 1), "unit": "images/sec", "ms_per_step": round(1e3 * t, 3),
                                        "dtype": getattr(model, "precision", "f32 + bf16 mask step")}
     del g, model
+    # configs[1] end to end: the same batch of 8 frames with the ResNet-50 backbone (stock MIOpen convolutions, frozen BN
+    # folded, channels_last) in front of the hot path -- reported separately, never mixed into the hot-path figure
+    from unseenobjectswithmeanshift_amd.meta_arch import build_resnet50_model
+    full = build_resnet50_model()
+    full.sem_seg_head.pixel_decoder.load_state_dict(syn.synth_state_dict(syn.pixel_decoder_param_shapes()), strict=True)
+    full.sem_seg_head.predictor.load_state_dict(syn.synth_state_dict(syn.decoder_param_shapes()), strict=True)
+    full = full.to(dev).eval()
+    images = torch.randn(BATCH, 3, H, W, device=dev)
+    for _ in range(3):
+        full([{"image": images}])
+    t_bb = timed(lambda: full.backbone(images), 10)
+    t_full = timed(lambda: full([{"image": images}]), 10)
+    out["configs[1] with backbone"] = {"workload": "batch 8, 640x480 RGB frames -> ResNet-50 (MIOpen, fp32, frozen BN folded) -> hot path -> instances; "
+                                                   "eager launches",
+                                       "value": round(BATCH / t_full, 1), "unit": "images/sec", "ms_per_step": round(1e3 * t_full, 3),
+                                       "backbone_ms": round(1e3 * t_bb, 3)}
+    del full
     # configs[3]: two-stage refinement over 16 frames
     model = build_model(dev)
     bb = syn.StandInBackbone().to(dev).eval()

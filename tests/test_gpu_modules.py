@@ -471,6 +471,39 @@ def test_ucn_backbone_on_gpu_vs_reference(golden):
     tb.check_backbone(golden, DEV)
 
 
+def test_resnet50_backbone_on_gpu_and_end_to_end():
+    """f4: the detectron2-layout ResNet-50 (frozen BN folded, channels_last through MIOpen) on the GPU against the float64
+    evaluation of its unfolded definition, then mixture_ResNet50.yaml end to end: images -> backbone -> HIP head -> instances,
+    with the head + post-processing checked against the oracle on the backbone's own features."""
+    import test_resnet_cpu as tr
+    from unseenobjectswithmeanshift_amd.meta_arch import build_resnet50_model
+    model = build_resnet50_model()
+    tr._randomise(model.backbone, seed=2)
+    model.sem_seg_head.pixel_decoder.load_state_dict(syn.synth_state_dict(syn.pixel_decoder_param_shapes()), strict=True)
+    model.sem_seg_head.predictor.load_state_dict(syn.synth_state_dict(syn.decoder_param_shapes()), strict=True)
+    ref_bb = tr._randomise(type(model.backbone)(), seed=2).double().eval()
+    model = model.to(DEV).eval()
+    g = torch.Generator().manual_seed(4)
+    images = torch.randn(2, 3, 64, 96, generator=g)
+    ref = ref_bb(images.double(), folded=False)
+    got = model.backbone(images.to(DEV))
+    for k in ("res2", "res3", "res4", "res5"):
+        assert got[k].is_contiguous() and got[k].dtype == torch.float32
+        scale = float(ref[k].abs().max())
+        assert float((got[k].cpu().double() - ref[k]).abs().max()) < 2e-4 * scale, k
+    res = model([{"image": images.to(DEV)}])
+    assert len(res) == 2 and res[0]["instances"].pred_masks.shape == (20, 64, 96)
+    out, _ = model.sem_seg_head(got)
+    for b in range(2):
+        r = O.instance_inference(out["pred_logits"][b].cpu(), out["pred_masks"][b].cpu(), (64, 96), topk=20)
+        inst = res[b]["instances"]
+        assert (inst.pred_masks.cpu() != r["pred_masks"]).float().mean() < 1e-4
+        torch.testing.assert_close(inst.scores.cpu(), r["scores"], rtol=1e-4, atol=1e-6)
+    # a frame that is not a multiple of 32 is padded for the network and cropped back
+    res2 = model([{"image": images[:1, :, :50, :70].contiguous().to(DEV)}])
+    assert res2[0]["instances"].pred_masks.shape == (20, 50, 70)
+
+
 def test_ucn_model_end_to_end():
     """mixture_UCN.yaml end to end on the GPU: RGB-D frame -> UCN backbone -> SimpleBasePixelDecoder -> 6-layer decoder over
     every pixel -> instances; the head + post-processing are checked against the oracle on the backbone's features."""

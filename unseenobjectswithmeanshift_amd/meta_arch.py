@@ -305,6 +305,16 @@ def build_ucn_head(num_queries=100, dec_layers=6, num_classes=2, hidden_dim=256,
                                              transformer_in_feature="multi_scale_pixel_decoder")
 
 
+def build_resnet50_model(num_queries=100, dec_layers=9, **head_kw):
+    """mixture_ResNet50.yaml end to end: detectron2-layout ResNet-50 (resnet_backbone.ResNet50Backbone) -> MSDeformAttn pixel
+    decoder -> 9-layer hypersphere decoder -> top-k instance post-processing, under the meta-arch every shipped yaml selects
+    (PretrainedMeanShiftMaskFormer with USE_OTHER_BACKBONE: no pixel normalisation inside the model).  Random-init; load the
+    published weights with checkpoint.load_reference_checkpoint(model, path)."""
+    from .resnet_backbone import ResNet50Backbone
+    head = build_resnet50_head(num_queries=num_queries, dec_layers=dec_layers, **head_kw)
+    return MeanShiftMaskFormer(backbone=ResNet50Backbone(), sem_seg_head=head, num_queries=num_queries)
+
+
 def build_resnet50_head(num_queries=100, dec_layers=9, num_classes=2, hidden_dim=256, mask_dim=256, conv_dim=64,
                         nheads=8, dim_feedforward=2048, enc_layers=6):
     """The configuration of MSMFormer/configs/mixture_ResNet50.yaml:31-77 (hot path only)."""

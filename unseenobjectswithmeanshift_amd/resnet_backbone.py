@@ -1,0 +1,147 @@
+"""detectron2-layout ResNet-50 backbone (inference) producing res2..res5 for the MSDeformAttn pixel decoder.
+
+SURVEY.md section 8 f rank 4 ("next" row).  The shipped ResNet-50 configuration (MSMFormer/configs/mixture_ResNet50.yaml:23
+USE_OTHER_BACKBONE, Base-COCO-InstanceSegmentation.yaml:2-15) builds detectron2's ``build_resnet_backbone`` with DEPTH 50,
+STEM_OUT_CHANNELS 64, STRIDE_IN_1X1 False, OUT_FEATURES res2..res5 and the default FrozenBN norm, and the meta-arch calls it
+as ``self.pretrained_backbone(images.tensor)`` (pretrained_meanshiftformer_model.py:277-279).
+
+detectron2 is not importable in this environment, so this module is written from the architecture those config keys
+select -- stem: 7x7/2 convolution (pad 3) + FrozenBN + ReLU + 3x3/2 max pool (pad 1); res2..res5: 3, 4, 6, 3 bottleneck blocks
+(1x1 -> 3x3 -> 1x1, widths 64/128/256/512 -> 256/512/1024/2048, ReLU after the residual add), the stride 2 of res3..res5 on
+the 3x3 convolution of the first block (STRIDE_IN_1X1 False), a 1x1 projection shortcut with the same stride on every first
+block -- and keeps detectron2's parameter names so that the published checkpoints load unchanged:
+``stem.conv1.weight``, ``stem.conv1.norm.{weight,bias,running_mean,running_var}``, ``res2.0.shortcut.weight``,
+``res2.0.conv1.weight``, ``res2.0.conv1.norm.weight`` ... ``res5.2.conv3.norm.running_var``.  PARITY UNPINNED: there is no
+reference implementation here to generate golden vectors from; tests check the structure (keys, shapes, strides), the
+BatchNorm folding against the unfolded definition in float64, and -- on the GPU -- the folded fp32 network against the same
+float64 evaluation.
+
+These are stock convolutions: they run through torch's convolution (MIOpen).  What is done for the MI355X: every frozen
+BatchNorm is folded into its convolution once per checkpoint (conv + bias + ReLU chains, no normalisation passes), the
+network runs in channels_last, and the four outputs are returned as contiguous NCHW fp32 maps -- the layout the pixel
+decoder's input projections stream.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+STAGE_BLOCKS = {"res2": 3, "res3": 4, "res4": 6, "res5": 3}          # DEPTH 50
+STAGE_WIDTHS = {"res2": (64, 256), "res3": (128, 512), "res4": (256, 1024), "res5": (512, 2048)}     # (bottleneck, out)
+STAGE_STRIDE = {"res2": 1, "res3": 2, "res4": 2, "res5": 2}
+OUT_STRIDES = {"res2": 4, "res3": 8, "res4": 16, "res5": 32}
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """BatchNorm2d with fixed statistics and affine parameters, all four as buffers (detectron2.layers.FrozenBatchNorm2d):
+    y = (x - running_mean) / sqrt(running_var + eps) * weight + bias."""
+
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.num_features, self.eps = num_features, eps
+        self.register_buffer("weight", torch.ones(num_features))
+        self.register_buffer("bias", torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features) - eps)
+
+    def forward(self, x):
+        scale = self.weight * (self.running_var + self.eps).rsqrt()
+        shift = self.bias - self.running_mean * scale
+        return x * scale.view(1, -1, 1, 1).to(x.dtype) + shift.view(1, -1, 1, 1).to(x.dtype)
+
+
+class _ConvBN(nn.Conv2d):
+    """detectron2.layers.Conv2d(..., bias=False, norm=FrozenBN): parameters .weight and .norm.*"""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0):
+        super().__init__(cin, cout, k, stride=stride, padding=padding, bias=False)
+        self.norm = FrozenBatchNorm2d(cout)
+
+    def forward(self, x):
+        return self.norm(super().forward(x))
+
+    def folded(self):
+        scale = self.norm.weight * (self.norm.running_var + self.norm.eps).rsqrt()
+        return ((self.weight * scale[:, None, None, None]).contiguous(memory_format=torch.channels_last),
+                (self.norm.bias - self.norm.running_mean * scale).contiguous())
+
+
+class BasicStem(nn.Module):
+    def __init__(self, in_channels=3, out_channels=64):
+        super().__init__()
+        self.conv1 = _ConvBN(in_channels, out_channels, 7, stride=2, padding=3)
+
+    def forward(self, x):
+        return F.max_pool2d(F.relu(self.conv1(x)), 3, stride=2, padding=1)
+
+
+class BottleneckBlock(nn.Module):
+    def __init__(self, cin, cout, bottleneck, stride):
+        super().__init__()
+        self.shortcut = _ConvBN(cin, cout, 1, stride=stride) if cin != cout else None
+        self.conv1 = _ConvBN(cin, bottleneck, 1)                                  # STRIDE_IN_1X1 False: the stride sits on conv2
+        self.conv2 = _ConvBN(bottleneck, bottleneck, 3, stride=stride, padding=1)
+        self.conv3 = _ConvBN(bottleneck, cout, 1)
+
+    def forward(self, x):
+        y = self.conv3(F.relu(self.conv2(F.relu(self.conv1(x)))))
+        return F.relu(y + (x if self.shortcut is None else self.shortcut(x)))
+
+
+class ResNet50Backbone(nn.Module):
+    """``forward(images (B,3,H,W)) -> {"res2": (B,256,H/4,W/4), "res3": (B,512,H/8,W/8), "res4": (B,1024,H/16,W/16),
+    "res5": (B,2048,H/32,W/32)}``; H, W multiples of 32 (the meta-arch pads).  ``folded=False`` evaluates the unfolded
+    definition (conv, frozen BN, ReLU as separate ops) -- the reference the folding is tested against."""
+
+    def __init__(self, in_channels=3, out_features=("res2", "res3", "res4", "res5")):
+        super().__init__()
+        self.stem = BasicStem(in_channels, 64)
+        cin = 64
+        for name in ("res2", "res3", "res4", "res5"):
+            bott, cout = STAGE_WIDTHS[name]
+            blocks = [BottleneckBlock(cin, cout, bott, STAGE_STRIDE[name])]
+            blocks += [BottleneckBlock(cout, cout, bott, 1) for _ in range(STAGE_BLOCKS[name] - 1)]
+            setattr(self, name, nn.Sequential(*blocks))
+            cin = cout
+        self.out_features = tuple(out_features)
+        self.size_divisibility = 32
+        self._plan_cache = None
+
+    def output_shape(self):
+        from .modeling import ShapeSpec
+        return {k: ShapeSpec(channels=STAGE_WIDTHS[k][1], stride=OUT_STRIDES[k]) for k in self.out_features}
+
+    def _plan(self):
+        key = tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        if self._plan_cache is None or self._plan_cache[0] != key:
+            with torch.no_grad():
+                stages = []
+                for name in ("res2", "res3", "res4", "res5"):
+                    stages.append([(blk.conv1.folded(), blk.conv2.folded(), blk.conv3.folded(),
+                                    None if blk.shortcut is None else blk.shortcut.folded(), blk.conv2.stride) for blk in getattr(self, name)])
+                self._plan_cache = (key, self.stem.conv1.folded(), stages)
+        return self._plan_cache[1:]
+
+    @torch.no_grad()
+    def forward(self, images, folded=True):
+        if self.training:
+            raise NotImplementedError("ResNet50Backbone is an inference module (frozen BatchNorm folded into the convolutions): call .eval()")
+        out = {}
+        if not folded:
+            x = self.stem(images)
+            for name in ("res2", "res3", "res4", "res5"):
+                x = getattr(self, name)(x)
+                if name in self.out_features:
+                    out[name] = x
+            return out
+        (ws, bs), stages = self._plan()
+        x = images.to(ws.dtype).contiguous(memory_format=torch.channels_last)
+        x = F.max_pool2d(F.relu(F.conv2d(x, ws, bs, stride=2, padding=3)), 3, stride=2, padding=1)
+        for name, blocks in zip(("res2", "res3", "res4", "res5"), stages):
+            for (w1, b1), (w2, b2), (w3, b3), sc, stride in blocks:
+                y = F.relu(F.conv2d(x, w1, b1))
+                y = F.relu(F.conv2d(y, w2, b2, stride=stride, padding=1))
+                y = F.conv2d(y, w3, b3)
+                x = F.relu(y + (x if sc is None else F.conv2d(x, sc[0], sc[1], stride=stride)))
+            if name in self.out_features:
+                out[name] = x.contiguous()                       # NCHW planes for the pixel decoder's input projections
+        return out
