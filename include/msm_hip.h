@@ -23,6 +23,7 @@
  *   msm_msdeform_attn_enc_fwd    <- MSDeformAttn.forward lines OPS/modules/ms_deform_attn.py:101-118 fused
  *   msm_mask_logits_fwd          <- forward_prediction_heads einsum + attention-mask, DEC:668-680
  *   msm_hypersphere_attn_fwd     <- hypersphere_attention, AU:64-82 (+ head split/merge AU:364-375,424)
+ *   msm_hypersphere_attn_bwd     <- its gradient under torch autograd (training step, tabletop_train_net_pretrained.py:209-246)
  *   msm_kv_project_f32           <- memory/key path of the cross-attention layers, DEC:575, DEC:251, AU:134-140
  *   msm_tokens_proj_nchw_f32     <- layer_1 GroupNorm + ReLU and the mask_features 1x1 convolution, MSD:349-358
  *   msm_dec_post_cross / msm_dec_post_self / msm_dec_heads
@@ -314,6 +315,17 @@ int msm_dec_heads(const float* x, const float* parts, int n_parts, const float* 
                   const float* wq, const float* bq, const float* query_pos,
                   float* out, float* d_out, float* e_out, float* q_out, int32_t* row_any_zero,
                   int rows, int Q, int E, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Backward of msm_hypersphere_attn_fwd (training step of the reference: hypersphere_attention under autograd, AU:64-82,
+ * MSMFormer/tabletop_train_net_pretrained.py:209-246).  q/k/v, masked, row_any, strides and kappa as in the forward call;
+ * grad_out [B][Lq][heads*32] -> grad_q [B][Lq][heads*32], grad_k / grad_v [B][S][heads*32] (all contiguous).  The
+ * probabilities are recomputed (nothing of size Lq x S is stored); workspace floats >= msm_hypersphere_attn_bwd_workspace. */
+int64_t msm_hypersphere_attn_bwd_workspace(int B, int Lq, int heads);
+int msm_hypersphere_attn_bwd(const float* q, const float* k, const float* v, const uint8_t* masked, const int32_t* row_any,
+                             const float* grad_out, float* grad_q, float* grad_k, float* grad_v, int B, int Lq, int S, int heads,
+                             int64_t ldq, int64_t q_sb, int64_t ldk, int64_t k_sb, int64_t ldv, int64_t v_sb, float kappa,
+                             float* workspace, int64_t workspace_elems, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Classic vMF mean shift over unit embeddings X [n][d] (d == 64), cosine metric.

@@ -524,6 +524,48 @@ def g_ucn_full():
     save("ucn_480x640", **arrs)
 
 
+def decoder_backward_loss(out, B, Q, h, w, seed=5):
+    """A fixed random linear functional of every prediction of the decoder (final + aux): the scalar whose gradient the
+    decoder-backward fixture holds.  Weights are regenerated from the seed by the tests."""
+    g = torch.Generator().manual_seed(seed)
+    preds = out["aux_outputs"] + [{"pred_logits": out["pred_logits"], "pred_masks": out["pred_masks"]}]
+    loss = 0.0
+    for p in preds:
+        wl = torch.randn(B, Q, p["pred_logits"].shape[-1], generator=g, dtype=torch.float64)
+        wm = torch.randn(B, Q, h, w, generator=g, dtype=torch.float64) / (h * w) ** 0.5
+        loss = loss + (p["pred_logits"].double() * wl.to(p["pred_logits"].device)).sum() + (p["pred_masks"].double() * wm.to(p["pred_masks"].device)).sum()
+    return loss
+
+
+def g_decoder_backward():
+    """f3: gradients of the reference decoder (fp64 autograd through the imported MeanShiftTransformerDecoder, 64x96 frame,
+    batch 2) of decoder_backward_loss with respect to its inputs and every parameter.  Stored: the loss, the input gradients
+    (mask_features subsampled), per-parameter gradient norms, and the full gradient of every parameter up to 70 000 elements."""
+    dec = build_ref_decoder().double()
+    dec.train(False)
+    x, mf = syn.synth_decoder_inputs(2, 64, 96, seed=1)
+    x = [t.double().requires_grad_(True) for t in x]
+    mf = mf.double().requires_grad_(True)
+    out = dec(x, mf)
+    loss = decoder_backward_loss(out, 2, 100, 16, 24)
+    loss.backward()
+    arrs = {"loss": loss.detach(), "g_x0": x[0].grad, "g_x1": x[1].grad, "g_x2": x[2].grad, "g_mf_sub": mf.grad[:, ::4].contiguous(),
+            "g_mf_norm": mf.grad.norm()}
+    names, norms = [], []
+    for n, p in dec.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        names.append(n)
+        norms.append(float(g.norm()))
+        if p.numel() <= 70000:
+            arrs["g__" + n] = g.float()
+    arrs["param_names"] = np.array(names)
+    arrs["param_grad_norms"] = np.array(norms)
+    for k in list(arrs):
+        if isinstance(arrs[k], torch.Tensor) and arrs[k].dtype == torch.float64 and k != "loss":
+            arrs[k] = arrs[k].float()
+    save("decoder_backward", **arrs)
+
+
 def g_instance_inference():
     """instance_inference (pretrained_meanshiftformer_model.py:461-497) executed from the reference source with stand-ins for
     the three detectron2 containers it touches.  Pins the top-k over Q*K class scores, the class labels, the binary masks
@@ -569,9 +611,9 @@ def g_instance_inference():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pe", "attn", "decoder", "msda", "msda_bwd", "pixel", "ms", "harness", "ucn", "ucn_backbone", "inst", "head_b8", "head_cfg5", "ucn_full"]
+    which = sys.argv[1:] or ["pe", "attn", "decoder", "msda", "msda_bwd", "pixel", "ms", "harness", "ucn", "ucn_backbone", "inst", "head_b8", "head_cfg5", "ucn_full", "dec_bwd"]
     fns = {"pe": g_position_encoding, "attn": g_hypersphere_attention, "decoder": g_decoder,
            "msda": g_msda, "msda_bwd": g_msda_bwd, "pixel": g_pixel_decoder, "ms": g_mean_shift, "harness": g_harness, "ucn": g_ucn, "ucn_backbone": g_ucn_backbone,
-           "inst": g_instance_inference, "head_b8": g_head_b8, "head_cfg5": g_head_cfg5, "ucn_full": g_ucn_full}
+           "inst": g_instance_inference, "dec_bwd": g_decoder_backward, "head_b8": g_head_b8, "head_cfg5": g_head_cfg5, "ucn_full": g_ucn_full}
     for w in which:
         fns[w]()

@@ -41,6 +41,9 @@ _SIGNATURES = {
     "msm_hypersphere_attn_workspace": (c_l, [c_i, c_i, c_i, c_i]),
     "msm_hypersphere_attn_fwd": (c_i, [c_f, c_f, c_f, c_p, c_p, c_f, c_i, c_i, c_i, c_i,
                                        c_l, c_l, c_l, c_l, c_l, c_l, c_fl, c_f, c_l, c_p]),
+    "msm_hypersphere_attn_bwd_workspace": (c_l, [c_i, c_i, c_i]),
+    "msm_hypersphere_attn_bwd": (c_i, [c_f, c_f, c_f, c_p, c_p, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i,
+                                       c_l, c_l, c_l, c_l, c_l, c_l, c_fl, c_f, c_l, c_p]),
     "msm_msdeform_attn_fwd": (c_i, [c_f, c_p, c_p, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "msm_msdeform_attn_bwd": (c_i, [c_f, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "msm_msdeform_attn_enc_fwd": (c_i, [c_f, c_p, c_p, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),

@@ -448,6 +448,28 @@ def hypersphere_attention(q, k, v, heads, *, masked=None, row_any=None, kappa=KA
     return out
 
 
+def hypersphere_attention_backward(q, k, v, heads, grad_out, *, masked=None, row_any=None, kappa=KAPPA):
+    """Gradient of hypersphere_attention: returns (grad_q (B,Lq,E), grad_k (B,S,E), grad_v (B,S,E)), contiguous."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _chk(t, n)
+        if t.stride(-1) != 1:
+            raise RuntimeError(f"{n}: last dim must be contiguous")
+    _c(grad_out, "grad_out"), _c(masked, "masked", torch.uint8), _c(row_any, "row_any", torch.int32)
+    B, Lq, E = q.shape
+    S = k.shape[1]
+    if E != heads * 32 or tuple(grad_out.shape) != (B, Lq, E):
+        raise RuntimeError("head_dim must be 32 and grad_out (B,Lq,E)")
+    gq = torch.empty((B, Lq, E), device=q.device, dtype=torch.float32)
+    gk = torch.empty((B, S, E), device=q.device, dtype=torch.float32)
+    gv = torch.empty((B, S, E), device=q.device, dtype=torch.float32)
+    need = lib().msm_hypersphere_attn_bwd_workspace(B, Lq, heads)
+    ws = torch.empty((need,), device=q.device, dtype=torch.float32)
+    rc = lib().msm_hypersphere_attn_bwd(_p(q), _p(k), _p(v), _p(masked), _p(row_any), _p(grad_out), _p(gq), _p(gk), _p(gv), B, Lq, S, heads,
+                                        q.stride(1), q.stride(0), k.stride(1), k.stride(0), v.stride(1), v.stride(0), kappa, _p(ws), need, _stream())
+    check(rc, "msm_hypersphere_attn_bwd")
+    return gq, gk, gv
+
+
 # ----------------------------------------------------------------------------------------------
 # fused decoder-layer tails (csrc/dec_chain.hip)
 # ----------------------------------------------------------------------------------------------
