@@ -432,6 +432,25 @@ int msm_encoder_prologue_fwd(const float* raw, const double* stats, const float*
                              int proj_width, int value_heads, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * bf16 form of msm_encoder_block_fwd (BASELINE configs 3 / 5; the reference's low-precision mode is autocast over the whole
+ * model, MSMFormer/tabletop_train_net_pretrained.py:232): bf16 MFMA operands, fp32 accumulation; the residual stream, the
+ * LayerNorms, the biases and every output stay fp32.  Same arguments as msm_encoder_block_fwd except the weight stream:
+ *   wstream: stages of 8 blocks of 2 KiB, a block = [4 k-groups][64 lanes][4 bf16] in MFMA fragment order
+ *     row block (16 rows r0.. of a (N,64) weight):  block[g][lq*16 + lj][c] = W[r0 + lj][g*16 + lq*4 + c]
+ *     linear2 block of hidden block hb:             block[ob][lq*16 + lj][c] = W2[ob*16 + lj][hb*16 + lq*4 + c]
+ *     stage 0: output_proj as 4 hi row blocks + 4 lo row blocks (w = hi + lo, both bf16: the three 64-wide projections
+ *     around the FFN are applied as w_lo x_hi + w_hi x_lo + w_hi x_hi); stages 1 .. d_ffn/64: [linear1 row block hb, linear2
+ *     block hb] for four consecutive hb (single bf16); then (with the next layer's projections) one stage value_proj (4 hi + 4 lo)
+ *     and the proj_width/16 row blocks of [sampling_offsets | attention_weights] as [hi, lo] pairs, four pairs per stage,
+ *     zero-padded to whole stages (msm_encoder_block_bf16_stream_bytes; ops.pack_encoder_block_bf16 builds it).
+ *   small: as msm_encoder_block_fwd (fp32).
+ * ------------------------------------------------------------------------------------------- */
+int64_t msm_encoder_block_bf16_stream_bytes(int d_ffn, int proj_width);
+int msm_encoder_block_bf16_fwd(const float* attn, const float* src, const void* wstream, const float* small, const float* pos,
+                               float* src_out, float* value_out, float* proj_out, int M, int tokens_per_image, int d_ffn,
+                               int proj_width, int value_heads, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Label-image statistics of the two-stage harness: one pass instead of the reference's per-label
  * unique()/masked-reduction/.item() loops (lib/fcn/test_dataset.py:62-112 crop_rois +
  * lib/utils/mask.py:179-186 tight boxes, test_dataset.py:121-126 overlap test, :183-198 depth filter).

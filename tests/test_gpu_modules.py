@@ -226,6 +226,35 @@ def test_decoder_bf16_mask_step():
     dec.mask_step_dtype = "f32"
 
 
+def test_head_bf16_precision_mode():
+    """set_precision("bf16") (configs 3 / 5): the encoder blocks and the mask step run with bf16 operands -- the outputs move
+    away from the fp32 path by bf16-sized amounts, stay close to it statistically (the tight check against the reference golden
+    at 640x480 is tests/test_gpu_configs.py::test_config2_slice_bf16_vs_reference), and a captured graph follows the switch."""
+    from unseenobjectswithmeanshift_amd.meta_arch import MeanShiftMaskFormer
+    head = make_pixel_decoder()
+    model = MeanShiftMaskFormer(backbone=None, sem_seg_head=head, num_queries=100)
+    feats = {k: v.to(DEV) for k, v in syn.synth_backbone_features(2, 64, 96, seed=3).items()}
+    g = model.graphed()
+    ref = [t.clone() for t in g(feats, (64, 96))]
+    mf32, _, ms32 = head.pixel_decoder.forward_features(feats)
+    model.set_precision("bf16")
+    assert model.precision == "bf16" and head.pixel_decoder.precision == "bf16" and head.predictor.mask_step_dtype == "bf16"
+    mfb, _, msb = head.pixel_decoder.forward_features(feats)
+    for a, b in zip(ms32, msb):
+        d = (a - b).abs()
+        assert 0 < float(d.max()) < 0.25 and float(d.mean()) < 2e-2
+    got = g(feats, (64, 96))                                   # re-captured: the plan signature changed
+    want = model.inference(feats, (64, 96))
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    assert not torch.equal(got[2], ref[2]) and float((got[2] != ref[2]).float().mean()) < 0.05
+    model.set_precision("f32")
+    for a, b in zip(g(feats, (64, 96)), ref):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        model.set_precision("fp8")
+
+
 def test_decoder_batch_consistency():
     """Images are independent units: a batch of 4 equals four batches of 1 (data-parallel sharding)."""
     dec = make_decoder()

@@ -642,6 +642,47 @@ def test_encoder_block_fused(B, S, want_next):
         assert vo is None and po is None
 
 
+@pytest.mark.parametrize("B,S,want_next", [(2, 394, True), (1, 6300, True), (3, 100, False), (8, 6300, True)])
+def test_encoder_block_bf16(B, S, want_next):
+    """bf16 form of the fused encoder-layer tail (configs 3 / 5): against the chain evaluated in float64 on the bf16-ROUNDED
+    operands (weights once; activations where they enter a GEMM) -- what the kernel computes up to fp32 accumulation order --
+    and, loosely, against the exact fp32 chain."""
+    C, DF, PW = 64, 1024, 288
+    attn, src, pos = rnd(B, S, C, seed=1), rnd(B, S, C, seed=2), rnd(S, C, seed=3)
+    wo, bo = rnd(C, C, seed=4, scale=C ** -0.5), rnd(C, seed=5, scale=0.1)
+    w1, b1 = rnd(DF, C, seed=6, scale=C ** -0.5), rnd(DF, seed=7, scale=0.1)
+    w2, b2 = rnd(C, DF, seed=8, scale=DF ** -0.5), rnd(C, seed=9, scale=0.1)
+    g1, be1, g2, be2 = 1 + 0.1 * rnd(C, seed=10), rnd(C, seed=11, scale=0.1), 1 + 0.1 * rnd(C, seed=12), rnd(C, seed=13, scale=0.1)
+    wv, bv = rnd(C, C, seed=14, scale=C ** -0.5), rnd(C, seed=15, scale=0.1)
+    wp, bp = rnd(PW, C, seed=16, scale=C ** -0.5), rnd(PW, seed=17)
+    r = lambda t: t.to(torch.bfloat16).double()                       # round to bf16, compute in float64
+    lin = lambda t, w, b_: F.linear(r(t.float()), r(w), b_.double())   # linear2: hidden activation and weight single bf16
+    lin1 = lambda t, w, b_: F.linear(t.double(), r(w), b_.double())    # linear1: weight bf16, activation hi + lo (exact to 2^-17)
+    linx = lambda t, w, b_: F.linear(t.double(), w.double(), b_.double())   # output / value / sampling projections: hi + lo both sides
+    x = F.layer_norm(src.double() + linx(attn, wo, bo), (C,), g1.double(), be1.double()).float()
+    y = F.layer_norm(x.double() + lin(F.relu(lin1(x, w1, b1)).float(), w2, b2), (C,), g2.double(), be2.double()).float()
+    y32 = F.layer_norm(src + F.linear(attn, wo, bo), (C,), g1, be1)
+    y32 = F.layer_norm(y32 + F.linear(F.relu(F.linear(y32, w1, b1)), w2, b2), (C,), g2, be2)
+    d = lambda t: t.to(DEV).contiguous()
+    stream = ops().pack_encoder_block_bf16(d(wo), d(w1), d(w2), d(wv) if want_next else None, d(wp) if want_next else None)
+    small = torch.cat([bo, g1, be1, b1, b2, g2, be2, bv, bp]).to(DEV)
+    so, vo, po = ops().encoder_block_bf16(d(attn), d(src), stream, small, DF, PW, pos=d(pos), tokens_per_image=S, want_next=want_next)
+    # an activation next to a bf16 rounding boundary may round the other way (fp32 here, float64 there): one such flip moves
+    # the outputs of its token by a few 1e-3; almost all elements agree to fp32 accumulation accuracy
+    err = (so.cpu() - y).abs()
+    assert float(err.max()) < 1e-2 and float((err > 2e-3).float().mean()) < 1e-4 and float(err.mean()) < 1e-4
+    assert float((so.cpu() - y32).abs().max()) < 0.1 and float((so.cpu() - y32).abs().mean()) < 5e-3
+    if want_next:
+        yk = so.cpu()                                  # the kernel's own layer output feeds its projections
+        close(vo, linx(yk, wv, bv).float(), rtol=2e-4, atol=2e-4)        # the three-term products are fp32-class
+        close(po, linx(yk + pos, wp, bp).float(), rtol=2e-4, atol=5e-4)
+        so2, vh, po2 = ops().encoder_block_bf16(d(attn), d(src), stream, small, DF, PW, pos=d(pos), tokens_per_image=S, value_heads=8)
+        assert vh.shape == (B, 8, S, C // 8)
+        assert torch.equal(vh.permute(0, 2, 1, 3).reshape(B, S, C), vo) and torch.equal(so2, so) and torch.equal(po2, po)
+    else:
+        assert vo is None and po is None
+
+
 def test_pixel_decoder_fused_equals_unfused():
     from unseenobjectswithmeanshift_amd import synthetic as syn
     from unseenobjectswithmeanshift_amd.meta_arch import build_resnet50_head

@@ -17,6 +17,10 @@ _CACHE_ATTRS = ("_q0", "_kv_cache", "_fold_cache", "_tails_cache", "_pos_cache",
                 "_packed_mf", "_bf16_cache", "_folded_cache")
 
 
+_PLAN_ATTRS = ("precision", "mask_step_dtype", "sparse_taps", "aux_outputs", "folded_mask_features", "batched_kv", "fold_kv",
+               "fused_tails", "fused_encoder", "fused_front", "fused_kv_attention")
+
+
 def cache_refs(model):
     """Strong references to every derived-tensor cache entry the model holds right now.  A captured HIP graph bakes the
     device addresses of these tensors into its nodes; the modules may later replace or evict the entries (another batch
@@ -34,7 +38,10 @@ def cache_refs(model):
 def param_signature(model):
     """Changes whenever a parameter or buffer is replaced or modified in place (load_state_dict, an optimizer step): graphs
     captured before are then stale -- their nodes read the derived caches of the OLD values -- and are re-captured."""
-    return tuple((t.data_ptr(), t._version) for t in list(model.parameters()) + list(model.buffers()))
+    sig = tuple((t.data_ptr(), t._version) for t in list(model.parameters()) + list(model.buffers()))
+    # ... or an execution-plan switch of a module is flipped (precision, folded / literal mask step, aux outputs, ...)
+    plan = tuple(m.__dict__.get(a) for m in model.modules() for a in _PLAN_ATTRS if a in m.__dict__)
+    return sig + plan
 
 
 class GraphedInference:

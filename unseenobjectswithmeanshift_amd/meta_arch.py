@@ -94,6 +94,18 @@ class MeanShiftMaskFormerHead(nn.Module):
     def forward(self, features, image_height=None, image_width=None, mask=None):
         return self.layers(features, image_height, image_width, mask)
 
+    def set_precision(self, mode):
+        """"f32" (the reference's arithmetic, default) or "bf16" (BASELINE configs 3 / 5): bf16 MFMA operands with fp32
+        accumulation in the encoder's token-wise GEMMs and in the Q x pixel-embedding mask step; everything that decides a
+        sign or normalises (LayerNorms, softmax, unit-norm, the residual streams) stays fp32."""
+        if mode not in ("f32", "bf16"):
+            raise ValueError("precision must be 'f32' or 'bf16'")
+        self.precision = mode
+        if hasattr(self.pixel_decoder, "precision"):
+            self.pixel_decoder.precision = mode
+        self.predictor.mask_step_dtype = mode
+        return self
+
     def layers(self, features, image_height=None, image_width=None, mask=None):
         """Returns (predictions, last_feature_map).  The reference also upsamples mask_features to
         image size here (meanshift_former_head.py:121-126, 315 MB per 640x480 image) for the
@@ -156,6 +168,15 @@ class MeanShiftMaskFormer(nn.Module):
         masks, scores, boxes = ops.instance_postprocess(outputs["pred_masks"], qidx, image_size, class_scores=cls_scores,
                                                         padded_size=padded_size)
         return scores, classes, masks, boxes, qidx
+
+    def set_precision(self, mode):
+        """See MeanShiftMaskFormerHead.set_precision."""
+        self.sem_seg_head.set_precision(mode)
+        return self
+
+    @property
+    def precision(self):
+        return getattr(self.sem_seg_head, "precision", "f32")
 
     def graphed(self, warmup=2):
         """HIP-graph replayed ``inference`` (graphs.GraphedInference): same results, no per-launch host cost."""

@@ -762,6 +762,10 @@ class MSDeformAttnPixelDecoder(nn.Module):
             self.add_module("layer_{}".format(idx + 1), _ConvNorm(conv_dim, conv_dim, 3, False, conv_dim))
         self._cache = {}
         self._packed = None
+        # "bf16" (BASELINE configs 3 / 5; the reference's low-precision mode is autocast over the whole model,
+        # tabletop_train_net_pretrained.py:232): the encoder's token-wise GEMMs run with bf16 MFMA operands and fp32
+        # accumulation (msm_encoder_block_bf16_fwd); residual stream, LayerNorms, sampling arithmetic and outputs stay fp32
+        self.precision = "f32"
         self.fused_encoder = True      # False: one GEMM / LayerNorm launch per op (same results up to rounding)
         self.fused_front = True        # False: input projections and layer 0's projections as separate GEMM / GroupNorm launches
 
@@ -776,7 +780,10 @@ class MSDeformAttnPixelDecoder(nn.Module):
     def _packed_encoder(self, device):
         """Weight streams of the fused encoder kernel, rebuilt only when a parameter changes."""
         layers = self.transformer.encoder.layers
-        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.transformer.encoder.parameters())
+        if self.precision not in ("f32", "bf16"):
+            raise ValueError("precision must be 'f32' or 'bf16'")
+        bf16 = self.precision == "bf16"
+        key = (str(device), bf16) + tuple((p.data_ptr(), p._version) for p in self.transformer.encoder.parameters())
         if self._packed is None or self._packed[0] != key:
             out = []
             for l, layer in enumerate(layers):
@@ -791,7 +798,8 @@ class MSDeformAttnPixelDecoder(nn.Module):
                     smalls += [nxt.value_proj.bias, bp]
                 else:
                     smalls += [torch.zeros(64, device=device), torch.zeros(a.sampling_offsets.out_features + a.attention_weights.out_features, device=device)]
-                stream = ops.pack_encoder_block(a.output_proj.weight, layer.linear1.weight, layer.linear2.weight, wv, wp)
+                pack = ops.pack_encoder_block_bf16 if bf16 else ops.pack_encoder_block
+                stream = pack(a.output_proj.weight, layer.linear1.weight, layer.linear2.weight, wv, wp)
                 pw = a.sampling_offsets.out_features + a.attention_weights.out_features
                 out.append((stream, torch.cat([t.reshape(-1) for t in smalls]).contiguous(), layer.linear1.out_features, pw))
             self._packed = (key, out, layers[0].self_attn._proj_weights())
@@ -887,7 +895,8 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 attn = ops.ms_deform_attn_encoder(value, ss, starts, proj, layer.self_attn.n_heads, layer.self_attn.n_points)
                 stream, small, d_ffn, pw = packed[l]
                 # layers 1.. read a head-major value (written so by the previous block): 64-byte instead of 32-byte taps
-                src, value, proj = ops.encoder_block(attn, src, stream, small, d_ffn, pw, pos=lvl_pos, tokens_per_image=S_tok,
+                block = ops.encoder_block_bf16 if self.precision == "bf16" else ops.encoder_block
+                src, value, proj = block(attn, src, stream, small, d_ffn, pw, pos=lvl_pos, tokens_per_image=S_tok,
                                                      want_next=l + 1 < len(layers), eps=layer.norm1.eps,
                                                      value_heads=layers[l + 1].self_attn.n_heads if l + 1 < len(layers) else 0)
         else:
