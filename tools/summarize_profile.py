@@ -16,13 +16,15 @@ rows = list(csv.DictReader(open(stats)))
 with open(f"profiles/{tag}_kernel_stats.md", "w") as f:
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     f.write(f"# rocprofv3 --kernel-trace --stats summary ({tag})\n\n")
-    f.write("command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 2 --no-graph --no-cpu-baseline` "
-            "(16 passes of the hot path per run: 2 warm-up + 10 timed + 3 event-timed + 1 phase-timed)\n\n")
+    f.write("command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 2 --no-graph --no-cpu-baseline "
+            "--no-extras --min-seconds 0` (tools/profile_round.sh; 25 passes of the hot path per run: 2 warm-up + 10 step-estimate + 10 timed "
+            "+ 3 event-timed)\n\n")
     f.write("| kernel | calls | avg us | total ms | % |\n|---|---:|---:|---:|---:|\n")
     for r in rows[:30]:
         f.write(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['TotalDurationNs']) / 1e6:.2f} | "
                 f"{100 * float(r['TotalDurationNs']) / tot:.1f} |\n")
-    f.write(f"\ntotal GPU kernel time {tot / 1e6:.1f} ms over 16 passes = {tot / 16e6:.2f} ms per pass of 8 images\n")
+    npass = next((int(r["Calls"]) for r in rows if "conv_in_multi_kernel" in r["Name"]), 1)
+    f.write(f"\ntotal GPU kernel time {tot / 1e6:.1f} ms over {npass} passes = {tot / npass / 1e6:.2f} ms per pass of 8 images\n")
 for pmc in sys.argv[3:]:
     fs = glob.glob(os.path.join(pmc, "*counter_collection.csv"))
     if not fs:
