@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(L, s), s
     assert set(declared) == set(_lib._SIGNATURES), set(declared) ^ set(_lib._SIGNATURES)
-    assert _lib.lib().msm_abi_version() == _lib.ABI_VERSION == 6
+    assert _lib.lib().msm_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_argument_errors_are_reported_without_a_gpu():
@@ -93,3 +93,20 @@ def test_instances_container():
     assert len(top) == 2 and bool((top.pred_classes == 1).all())
     lab = combine_masks(top)
     assert lab[1, 0] == 3 and lab[0, 0] == 2          # later instances overwrite earlier ones
+
+
+def test_library_options_are_explicit_and_default_to_auto():
+    """Kernel-selection overrides go through msm_set_option (no environment variable is read by the library); host-only calls."""
+    import subprocess
+    L = _lib.lib()
+    for i, name in enumerate(_lib.OPTIONS):
+        assert L.msm_get_option(i) == _lib.OPT_AUTO, name
+    assert _lib.set_option("MASK_NC", 2) == _lib.OPT_AUTO and L.msm_get_option(_lib.OPTIONS.index("MASK_NC")) == 2
+    with _lib.option("ATTN_KERNEL", 3):
+        assert L.msm_get_option(_lib.OPTIONS.index("ATTN_KERNEL")) == 3
+    assert L.msm_get_option(_lib.OPTIONS.index("ATTN_KERNEL")) == _lib.OPT_AUTO
+    _lib.set_option("MASK_NC")
+    assert L.msm_set_option(len(_lib.OPTIONS), 1) != 0 and b"unknown key" in L.msm_last_error_string()
+    assert L.msm_set_option(len(_lib.OPTIONS) - 1, 1) == 0 and L.msm_set_option(len(_lib.OPTIONS) - 1, -1) == 0     # enum and OPTIONS agree in length
+    out = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in out
