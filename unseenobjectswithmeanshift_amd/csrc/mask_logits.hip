@@ -979,7 +979,9 @@ extern "C" int msm_mask_logits_fwd(const float* mask_embed, const float* mask_fe
     const int64_t t32 = (int64_t)n_rowpairs * cdiv(W, 32) * B * qchunks;
     const int64_t t16 = (int64_t)n_rowpairs * cdiv(W, 16) * B * qchunks;
     const double cost32 = (double)cdiv(t32, 1024), cost16 = 0.5 * (double)cdiv(t16, 1024);
-    int nc = (cost16 * 1.04 < cost32) ? 1 : 2;
+    // (ties: with few rounds the narrow tile wins -- B = 2: 12.8 against 19.3 us, its tiles spread over twice the SIMDs --,
+    // with many the wide one does -- B = 16: 40.6 against 43.5 us, 1280x960 with 300 queries: 48.8 against 57.4)
+    int nc = (cost16 * 1.04 < cost32 || (cost16 <= cost32 && cost32 < 3.0)) ? 1 : 2;
     if (const int o = opt(MSM_OPT_MASK_NC); o != MSM_OPT_AUTO) nc = o == 1 ? 1 : 2;
     if (mask_out) nc = 1;      // launches that write the logits take 2 x 16 tiles: their float4 stores are accumulator tuples
     const int ctiles = cdiv(W, 16 * nc);
