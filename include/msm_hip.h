@@ -78,7 +78,7 @@ enum {
     MSM_OPT_MS_CHUNK,           /* 1..8 seed blocks per hill-climb launch */
     MSM_OPT_MS_NO_PERSISTENT,   /* 1: one launch per seeding step */
     MSM_OPT_ATTN_FUSED_KV,      /* 0: never project K/V inside the attention kernel */
-    MSM_OPT_MASK_KERNEL,        /* fp32 mask step: 2 = one wave per SIMD with mask_embed in registers (C = 64 only), 3 = prefetch ring of four groups */
+    MSM_OPT_MASK_KERNEL,        /* fp32 mask step: 2 = one wave per SIMD with mask_embed in registers (C = 64 only), 3 = prefetch ring of four groups, 4 = software-pipelined epilogue (C = 64 attention-mask launches) */
     MSM_OPT_COUNT
 };
 int msm_set_option(int key, int value);

@@ -141,7 +141,7 @@ def test_mask_logits(B, Q, H, W, pool, nc, lib_option):
     assert attn is None and row_any is None
 
 
-@pytest.mark.parametrize("kernel", ["r64", "lds"])
+@pytest.mark.parametrize("kernel", ["r64", "lds", "p64"])
 @pytest.mark.parametrize("B,Q,H,W,pool", [(2, 100, 16, 24, 2), (2, 100, 16, 24, 4), (2, 100, 16, 24, 8), (8, 100, 120, 160, 8),
                                           (1, 100, 120, 160, 4), (2, 100, 120, 160, 2), (1, 300, 48, 64, 4), (2, 20, 8, 8, 2),
                                           (2, 100, 16, 24, 1), (1, 100, 60, 80, 1), (3, 100, 30, 40, 2), (1, 37, 18, 22, 2)])
@@ -151,6 +151,8 @@ def test_mask_logits_folded_form(B, Q, H, W, pool, kernel, lib_option):
     mask_embed in registers (MSM_OPT_MASK_KERNEL = 2)."""
     if kernel == "r64":
         lib_option("MASK_KERNEL", 2)
+    if kernel == "p64":
+        lib_option("MASK_KERNEL", 4)       # software-pipelined epilogue (attention-mask launches with W % 16 == 0; others fall through)
     C = 64
     wide = rnd(B, Q, 256, seed=1, scale=0.3)
     e, qb = wide[..., :C], wide[..., 64]
