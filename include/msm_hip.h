@@ -55,7 +55,7 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 7   /* 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
+#define MSM_ABI_VERSION 8   /* 8: bf16 decoder tails; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
 int msm_abi_version(void);
 
 /* Kernel-selection overrides for tools/ and tests/ (NOT read on the product path: every option defaults to
@@ -315,6 +315,32 @@ int msm_dec_heads(const float* x, const float* parts, int n_parts, const float* 
                   const float* wq, const float* bq, const float* query_pos,
                   float* out, float* d_out, float* e_out, float* q_out, int32_t* row_any_zero,
                   int rows, int Q, int E, float eps, void* stream);
+
+/* The same three tails with bf16 MFMA operands and fp32 accumulation (low-precision mode, BASELINE configs 3 / 5; the
+ * reference's counterpart is torch.autocast over the whole model, MSMFormer/tabletop_train_net_pretrained.py:232).  Every
+ * weight MATRIX argument is the bf16 packed form produced by msm_dec_pack_weight_bf16 (same tile order, 2 bytes per
+ * weight):
+ *     packed[(((t*(K/64) + kc)*2 + up)*64 + lq*16 + lj)*8 + h*4 + c] = bf16(W[t*16 + lj][kc*64 + (2*up + h)*16 + lq*4 + c])
+ * so "rows [a, b) of W" is still the element offset a*K.  Activations enter the MFMAs as hi + lo bf16 pairs (exact to
+ * 2^-17); biases, LayerNorms, residual streams and every tensor that leaves the kernels stay fp32. */
+int msm_dec_pack_weight_bf16(const float* w, uint16_t* packed, int N, int K, void* stream);
+int msm_dec_post_cross_bf16(const float* attn_out, const float* res, const float* query_pos,
+                            const uint16_t* wo, const float* bo, const float* ln_g, const float* ln_b,
+                            const uint16_t* w_in, const float* b_in,
+                            float* x_out, float* qk_out, float* v_out,
+                            int rows, int Q, int E, float eps, void* stream);
+int msm_dec_post_self_bf16(const float* attn_out, const float* res,
+                           const uint16_t* wo, const float* bo, const float* ln_g, const float* ln_b,
+                           const uint16_t* w1, const float* b1, const uint16_t* w2, int F,
+                           float* x_out, float* parts, int n_parts, int rows, int E, float eps, void* stream);
+int msm_dec_heads_bf16(const float* x, const float* parts, int n_parts, const float* bias,
+                       const float* ln_g, const float* ln_b, int l2norm,
+                       const float* dec_g, const float* dec_b,
+                       const uint16_t* m0w, const float* m0b, const uint16_t* m1w, const float* m1b,
+                       const uint16_t* m2w, const float* m2b,
+                       const uint16_t* wq, const float* bq, const float* query_pos,
+                       float* out, float* d_out, float* e_out, float* q_out, int32_t* row_any_zero,
+                       int rows, int Q, int E, float eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward of msm_hypersphere_attn_fwd (training step of the reference: hypersphere_attention under autograd, AU:64-82,

@@ -280,9 +280,12 @@ def _ln(x, g, b, eps=1e-5):
 
 
 @pytest.mark.parametrize("B,Q", [(2, 100), (1, 7), (3, 16)])
-def test_decoder_fused_tails(B, Q):
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_decoder_fused_tails(B, Q, prec):
     """csrc/dec_chain.hip against the same chain in torch fp64 (DEC:245-260, 171-181, 296-300, 637-638, 661-665);
-    tolerance: fp32 rounding of 256/2048-term dot products on O(1) values."""
+    tolerance: fp32 rounding of 256/2048-term dot products on O(1) values.  prec = "bf16": the low-precision entry points
+    (bf16 weight fragments, activations as hi + lo bf16 pairs, fp32 accumulation) against the same fp64 chain on the
+    bf16-ROUNDED weights -- what is left is the 2^-17 residual of the activation split."""
     E, Fh = 256, 2048
     r = lambda *s, seed, k=1.0: (rnd(*s, seed=seed) * k)
     o, res, qpos = r(B, Q, E, seed=1), r(B, Q, E, seed=2), r(Q, E, seed=3)
@@ -291,11 +294,20 @@ def test_decoder_fused_tails(B, Q):
     w_in, b_in = r(3 * E, E, seed=8, k=E ** -0.5), r(3 * E, seed=9, k=0.1)
     dev = lambda *ts: [t.to(DEV) for t in ts]
     dbl = lambda *ts: [t.double() for t in ts]
-    pack = lambda w: ops().dec_pack_weight(w.to(DEV))
+    bf = prec == "bf16"
+    pack = (lambda w: ops().dec_pack_weight_bf16(w.to(DEV))) if bf else (lambda w: ops().dec_pack_weight(w.to(DEV)))
+    rw = _bf16_round if bf else (lambda w: w)                # the weights the kernels actually multiply by
+    tol = 4.0 if bf else 1.0
+    closed_ = globals()["closed"]
+    closed = lambda got, ref, rtol, atol: closed_(got, ref, rtol=rtol * tol, atol=atol * tol)  # noqa: E731
     # the documented fragment order (include/msm_hip.h)
     N_, K_ = w_in.shape
-    want = w_in.view(N_ // 16, 16, K_ // 64, 4, 4, 4).permute(0, 2, 3, 4, 1, 5).contiguous().view(N_, K_)
+    if bf:       # [t][kc][up][lq][lj][h][c] <- W[t*16 + lj][kc*64 + (2 up + h)*16 + lq*4 + c]
+        want = w_in.view(N_ // 16, 16, K_ // 64, 2, 2, 4, 4).permute(0, 2, 3, 5, 1, 4, 6).contiguous().view(N_, K_).to(torch.bfloat16)
+    else:
+        want = w_in.view(N_ // 16, 16, K_ // 64, 4, 4, 4).permute(0, 2, 3, 4, 1, 5).contiguous().view(N_, K_)
     assert torch.equal(pack(w_in).cpu(), want)
+    wo, w_in = rw(wo), rw(w_in)                              # references below use the rounded weights; pack() rounds again (idempotent)
     # post_cross
     x, qk, v = ops().dec_post_cross(*dev(o, res, qpos), pack(wo), *dev(bo, g, b), pack(w_in), b_in.to(DEV))
     O_, R_, P_, WO, BO, G_, B_, WI, BI = dbl(o, res, qpos, wo, bo, g, b, w_in, b_in)
@@ -304,8 +316,8 @@ def test_decoder_fused_tails(B, Q):
     closed(qk, (xr + P_) @ WI[:2 * E].t() + BI[:2 * E], rtol=1e-4, atol=5e-5)
     closed(v, xr @ WI[2 * E:].t() + BI[2 * E:], rtol=1e-4, atol=5e-5)
     # post_self
-    w1, b1 = r(Fh, E, seed=10, k=E ** -0.5), r(Fh, seed=11, k=0.1)
-    w2, b2 = r(E, Fh, seed=12, k=Fh ** -0.5), r(E, seed=13, k=0.1)
+    w1, b1 = rw(r(Fh, E, seed=10, k=E ** -0.5)), r(Fh, seed=11, k=0.1)
+    w2, b2 = rw(r(E, Fh, seed=12, k=Fh ** -0.5)), r(E, seed=13, k=0.1)
     x2, parts = ops().dec_post_self(*dev(o, res), pack(wo), *dev(bo, g, b), pack(w1), b1.to(DEV), pack(w2))
     closed(x2, xr, rtol=1e-4, atol=2e-5)
     W1, B1, W2, B2 = dbl(w1, b1, w2, b2)
@@ -320,8 +332,8 @@ def test_decoder_fused_tails(B, Q):
     # heads (with and without the optional pieces)
     g1, be1 = 1 + r(E, seed=14, k=0.1), r(E, seed=15, k=0.1)
     g2, be2 = 1 + r(E, seed=16, k=0.1), r(E, seed=17, k=0.1)
-    mlp = [(r(E, E, seed=20 + i, k=E ** -0.5), r(E, seed=30 + i, k=0.1)) for i in range(3)]
-    wq, bq = r(E, E, seed=40, k=E ** -0.5), r(E, seed=41, k=0.1)
+    mlp = [(rw(r(E, E, seed=20 + i, k=E ** -0.5)), r(E, seed=30 + i, k=0.1)) for i in range(3)]
+    wq, bq = rw(r(E, E, seed=40, k=E ** -0.5)), r(E, seed=41, k=0.1)
     mlp_d = [(pack(w), bb.to(DEV)) for w, bb in mlp]
     out, d, e, q = ops().dec_heads(x2, *dev(g2, be2), mlp_d, parts=parts, bias=b2.to(DEV), ln_g=g1.to(DEV), ln_b=be1.to(DEV),
                                    l2norm=True, wq=pack(wq), bq=bq.to(DEV), query_pos=qpos.to(DEV), want_d=True)

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(L, s), s
     assert set(declared) == set(_lib._SIGNATURES), set(declared) ^ set(_lib._SIGNATURES)
-    assert _lib.lib().msm_abi_version() == _lib.ABI_VERSION == 7
+    assert _lib.lib().msm_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_argument_errors_are_reported_without_a_gpu():

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmsm_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "msm_hip.h")
 
 _lib = None
-ABI_VERSION = 7      # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
+ABI_VERSION = 8      # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
 
 c_f = ctypes.c_void_p      # float* (device)
 c_p = ctypes.c_void_p
@@ -60,6 +60,11 @@ _SIGNATURES = {
     "msm_dec_post_cross": (c_i, [c_f] * 12 + [c_i, c_i, c_i, c_fl, c_p]),
     "msm_dec_post_self": (c_i, [c_f] * 9 + [c_i, c_f, c_f, c_i, c_i, c_i, c_fl, c_p]),
     "msm_dec_heads": (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, c_i] + [c_f] * 15 + [c_p, c_i, c_i, c_i, c_fl, c_p]),
+    "msm_dec_pack_weight_bf16": (c_i, [c_f, c_p, c_i, c_i, c_p]),
+    "msm_dec_post_cross_bf16": (c_i, [c_f, c_f, c_f, c_p, c_f, c_f, c_f, c_p, c_f, c_f, c_f, c_f] + [c_i, c_i, c_i, c_fl, c_p]),
+    "msm_dec_post_self_bf16": (c_i, [c_f, c_f, c_p, c_f, c_f, c_f, c_p, c_f, c_p] + [c_i, c_f, c_f, c_i, c_i, c_i, c_fl, c_p]),
+    "msm_dec_heads_bf16": (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_f, c_p, c_f, c_p, c_f, c_p, c_f, c_p, c_f, c_f] + [c_f] * 4 +
+                           [c_p, c_i, c_i, c_i, c_fl, c_p]),
     "msm_ms_seed_workspace": (c_l, [c_i]),
     "msm_ms_select_seeds": (c_i, [c_f, c_i, c_i, c_i, c_l, c_f, c_p, c_f, c_l, c_i, c_p]),
     "msm_ms_hill_climb_workspace": (c_l, [c_i, c_i]),

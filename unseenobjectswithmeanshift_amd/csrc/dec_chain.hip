@@ -23,6 +23,9 @@
 //      quarter-wave hit 16 different rows = 64 cache-line lookups per load; measured 9 us per 256x256 stage,
 //      L1-address-rate bound, against 1.7 us of MFMA time.)
 // Weight fragments are pipelined across the stages of a chain (see gemm256).
+#include <type_traits>
+
+#include "bf16.h"
 #include "common.h"
 
 #ifndef DC_IL
@@ -44,15 +47,27 @@ constexpr int DC_NW = MSM_DC_NW;    // waves per workgroup
 constexpr int DC_NT = 16 / DC_NW;   // 16-column tiles per wave in a 256-column GEMM
 constexpr int DC_THREADS = DC_NW * 64;
 
-// B fragments of two 64-wide k-chunks of a 256-column weight block, in MFMA operand order (see the header)
-struct BFrag {
+// B fragments of two 64-wide k-chunks of a 256-column weight block, in MFMA operand order (see the header).
+// WT = float: the fp32 chain.  WT = uint16_t: bf16 weights (msm_dec_pack_weight_bf16) for the low-precision mode -- a lane's
+// 16 weights of a (column tile, k-chunk) are two 16-byte loads {u = 2 h: c 0..3, u = 2 h + 1: c 0..3}, the activation
+// fragment read from LDS is split into hi + lo bf16 operands at the moment it is used (x = hi + lo up to 2^-17 |x|), and
+// v_mfma_f32_16x16x16_bf16 takes the 16 k of (k-chunk, u) at once: 32 MFMAs of 8 cycles per half stage instead of 64 of
+// 32, half the weight bytes -- a stage is bound by streaming 128 KiB of weights per workgroup, not by the matrix pipe.
+template <typename WT>
+struct BFrag;
+template <>
+struct BFrag<float> {
     float4 v[2][DC_NT][4];
 };
-// W: packed weight, advanced to the first of the 256 output rows wanted (row offset n0 -> + n0*K floats);
+template <>
+struct BFrag<uint16_t> {
+    u32x4b v[2][DC_NT][2];
+};
+// W: packed weight, advanced to the first of the 256 output rows wanted (row offset n0 -> + n0*K elements);
 // kct = K/64 of the packed matrix; kc0 = first of the two k-chunks to fetch
 // (Rotating the k-chunk order per workgroup to de-phase their L2 accesses was measured: -3 % kernel time, and it
 // makes a row's rounding depend on its batch position; not kept.)
-__device__ __forceinline__ void bload(BFrag& f, const float* __restrict__ W, int kct, int kc_base, int half) {
+__device__ __forceinline__ void bload(BFrag<float>& f, const float* __restrict__ W, int kct, int kc_base, int half) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int t = 0; t < DC_NT; ++t) {
@@ -71,7 +86,20 @@ __device__ __forceinline__ void bload(BFrag& f, const float* __restrict__ W, int
         }
     }
 }
-__device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT], const float* __restrict__ ap, const BFrag& f, int half) {
+__device__ __forceinline__ void bload(BFrag<uint16_t>& f, const uint16_t* __restrict__ W, int kct, int kc_base, int half) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < DC_NT; ++t) {
+        const uint16_t* wp = W + ((int64_t)(wave * DC_NT + t) * kct + kc_base) * 1024 + lane * 8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int kc = half * 2 + h;
+#pragma unroll
+            for (int up = 0; up < 2; ++up) f.v[h][t][up] = *reinterpret_cast<const u32x4b*>(wp + (kc * 2 + up) * 512);
+        }
+    }
+}
+__device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT], const float* __restrict__ ap, const BFrag<float>& f, int half) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         float4 a[4];
@@ -96,6 +124,32 @@ __device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT], const float* __re
         }
     }
 }
+__device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT], const float* __restrict__ ap, const BFrag<uint16_t>& f, int half) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float4 a[4];
+        const int kc = half * 2 + h;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(ap + kc * 64 + u * 16);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const Split4 x = split4(a[u].x, a[u].y, a[u].z, a[u].w);
+#pragma unroll
+            for (int t = 0; t < DC_NT; ++t) {
+                const u32x4b wv = f.v[h][t][u >> 1];
+                const bf16x4 w = __builtin_bit_cast(bf16x4, (u & 1) ? u32x2b{wv.z, wv.w} : u32x2b{wv.x, wv.y});
+                acc[t] = mfma_bf16(x.lo, w, acc[t]);
+                acc[t] = mfma_bf16(x.hi, w, acc[t]);
+            }
+        }
+    }
+}
+// prefetch loads per half stage (bload) and MFMAs between two of them
+template <typename WT>
+struct Pipe {
+    static constexpr int LOADS = std::is_same<WT, float>::value ? 8 * DC_NT : 4 * DC_NT;
+    static constexpr int IL = DC_IL;
+};
 
 // D[16][256] = act(A[16][256] . W[n][k]^T + bias).  A in LDS.  TO_GLOBAL: D is row-major global with row stride
 // ldd, rows >= rows_valid are not written; otherwise D is an LDS tile (stride DC_LD).
@@ -103,12 +157,12 @@ __device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT], const float* __re
 // previous stage or at kernel start); chunks 2,3 are fetched while 0,1 are consumed, and the next stage's chunks
 // 0,1 (Wn, may be null) while 2,3 are consumed, so L2 latency hides behind 64 MFMAs (~2000 cycles) each time.
 // acc += A[16][256] . W-block^T for this wave's DC_NT column tiles (fragment pipeline as described above)
-template <bool NEXT>
-__device__ __forceinline__ void gemm_core(f32x4 (&acc)[DC_NT], const float* __restrict__ A, const float* __restrict__ W, int kct,
-                                          int kc_base, BFrag& lo, const float* __restrict__ Wn, int kctn, int kcn) {
+template <bool NEXT, typename WT>
+__device__ __forceinline__ void gemm_core(f32x4 (&acc)[DC_NT], const float* __restrict__ A, const WT* __restrict__ W, int kct,
+                                          int kc_base, BFrag<WT>& lo, const WT* __restrict__ Wn, int kctn, int kcn) {
     const int lane = threadIdx.x & 63;
     const float* ap = A + (lane & 15) * DC_LD + (lane >> 4) * 4;
-    BFrag hi;
+    BFrag<WT> hi;
     // The prefetch loads are spread evenly between the MFMAs of the half they hide behind (1 load : DC_IL MFMAs,
     // sched_group_barrier), not issued as a burst in front of them: measured 16.2 -> 14.1 us (post_cross), 34.1 -> 29.1
     // (post_self), 23.1 -> 21.2 (heads).
@@ -116,9 +170,9 @@ __device__ __forceinline__ void gemm_core(f32x4 (&acc)[DC_NT], const float* __re
     bload(hi, W, kct, kc_base, 1);
     mfma_half(acc, ap, lo, 0);
 #pragma unroll
-    for (int i = 0; i < 8 * DC_NT; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // one VMEM read
-        __builtin_amdgcn_sched_group_barrier(0x008, DC_IL, 0);    // DC_IL MFMAs
+    for (int i = 0; i < Pipe<WT>::LOADS; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);               // one VMEM read
+        __builtin_amdgcn_sched_group_barrier(0x008, Pipe<WT>::IL, 0);    // DC_IL MFMAs
     }
     __builtin_amdgcn_sched_barrier(0);
     // NEXT is a compile-time flag: a run-time branch here makes the waitcnt pass assume the shorter queue and
@@ -126,9 +180,9 @@ __device__ __forceinline__ void gemm_core(f32x4 (&acc)[DC_NT], const float* __re
     if constexpr (NEXT) bload(lo, Wn, kctn, kcn, 0);
     mfma_half(acc, ap, hi, 1);
 #pragma unroll
-    for (int i = 0; i < 8 * DC_NT; ++i) {
+    for (int i = 0; i < Pipe<WT>::LOADS; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, DC_IL, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, Pipe<WT>::IL, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -166,16 +220,16 @@ __device__ __forceinline__ void load_bias(float (&bv)[DC_NT], const float* __res
 // D[16][256] = act(A[16][256] . W-block^T + bias): one stage of a chain.  On entry `lo` holds k-chunks 0,1 of W
 // (fetched during the previous stage or at kernel start); chunks 2,3 are fetched while 0,1 are consumed and the next
 // stage's first two chunks (Wn) while 2,3 are consumed, so L2 latency hides behind 64 MFMAs per wave each time.
-template <bool TO_GLOBAL, bool NEXT>
-__device__ __forceinline__ void gemm256(const float* __restrict__ A, const float* __restrict__ W, int kct, int kc_base,
+template <bool TO_GLOBAL, bool NEXT, typename WT>
+__device__ __forceinline__ void gemm256(const float* __restrict__ A, const WT* __restrict__ W, int kct, int kc_base,
                                         const float* __restrict__ bias, bool relu, float* __restrict__ D, int64_t ldd,
-                                        int rows_valid, BFrag& lo, const float* __restrict__ Wn, int kctn, int kcn) {
+                                        int rows_valid, BFrag<WT>& lo, const WT* __restrict__ Wn, int kctn, int kcn) {
     f32x4 acc[DC_NT];
 #pragma unroll
     for (int t = 0; t < DC_NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bv[DC_NT];
     load_bias(bv, bias);            // requested before the MFMAs, consumed after them
-    gemm_core<NEXT>(acc, A, W, kct, kc_base, lo, Wn, kctn, kcn);
+    gemm_core<NEXT, WT>(acc, A, W, kct, kc_base, lo, Wn, kctn, kcn);
     gemm_store<TO_GLOBAL>(acc, bv, relu, D, ldd, rows_valid);
 }
 
@@ -211,12 +265,13 @@ constexpr int DC_RPW = DC_R / DC_NW;   // rows per wave in the row-wise phases; 
 // On return (after the trailing barrier) X holds x and, if XP, XP holds x + query_pos; x rows are written to
 // x_out by the workgroups with store_x.  Every global operand of the row phase is requested before the GEMM so
 // its latency hides behind the MFMAs.
+template <typename WT>
 __device__ __forceinline__ void attn_out_ln(const float* __restrict__ o, const float* __restrict__ res,
-                                            const float* __restrict__ wo, const float* __restrict__ bo,
+                                            const WT* __restrict__ wo, const float* __restrict__ bo,
                                             const float* __restrict__ g, const float* __restrict__ b,
                                             const float* __restrict__ qpos, int Q, float* __restrict__ x_out, bool store_x,
                                             float* __restrict__ T0, float* __restrict__ X, float* __restrict__ XP, int row0,
-                                            int rows, float eps, BFrag& f, const float* __restrict__ w_next, int kct_next,
+                                            int rows, float eps, BFrag<WT>& f, const WT* __restrict__ w_next, int kct_next,
                                             int kc_next) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bload(f, wo, 4, 0, 0);
@@ -230,7 +285,7 @@ __device__ __forceinline__ void attn_out_ln(const float* __restrict__ o, const f
     }
     const float4 gv = ld4(g + lane * 4), bv = ld4(b + lane * 4);
     __syncthreads();
-    gemm256<false, true>(T0, wo, 4, 0, bo, false, X, 0, 0, f, w_next, kct_next, kc_next);
+    gemm256<false, true, WT>(T0, wo, 4, 0, bo, false, X, 0, 0, f, w_next, kct_next, kc_next);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < DC_RPW; ++i) {
@@ -244,9 +299,10 @@ __device__ __forceinline__ void attn_out_ln(const float* __restrict__ o, const f
     __syncthreads();
 }
 
+template <typename WT>
 __global__ __launch_bounds__(DC_THREADS) void dec_post_cross_kernel(
-    const float* __restrict__ o, const float* __restrict__ res, const float* __restrict__ qpos, const float* __restrict__ wo,
-    const float* __restrict__ bo, const float* __restrict__ g, const float* __restrict__ b, const float* __restrict__ w_in,
+    const float* __restrict__ o, const float* __restrict__ res, const float* __restrict__ qpos, const WT* __restrict__ wo,
+    const float* __restrict__ bo, const float* __restrict__ g, const float* __restrict__ b, const WT* __restrict__ w_in,
     const float* __restrict__ b_in, float* __restrict__ x_out, float* __restrict__ qk_out, float* __restrict__ v_out,
     int rows, int Q, float eps) {
     __shared__ __attribute__((aligned(16))) float lds[3 * DC_R * DC_LD];
@@ -256,21 +312,22 @@ __global__ __launch_bounds__(DC_THREADS) void dec_post_cross_kernel(
     // blockIdx.y picks the projection (0: q, 1: k, 2: v): the 16-row tile is MFMA-bound on ONE CU at 3.4 us per
     // 256x256 stage, so the three independent projections go to three CUs; each repeats the Wo + LN stage.
     const int part = blockIdx.y;
-    const float* wp = w_in + (int64_t)part * DC_E * DC_E;
-    BFrag f;
-    attn_out_ln(o, res, wo, bo, g, b, qpos, Q, x_out, part == 0, T0, X, XP, row0, rows, eps, f, wp, 4, 0);
+    const WT* wp = w_in + (int64_t)part * DC_E * DC_E;
+    BFrag<WT> f;
+    attn_out_ln<WT>(o, res, wo, bo, g, b, qpos, Q, x_out, part == 0, T0, X, XP, row0, rows, eps, f, wp, 4, 0);
     // q and k share tgt + query_pos (DEC:171-175); v = tgt
     if (part < 2)
-        gemm256<true, false>(XP, wp, 4, 0, b_in + part * DC_E, false, qk_out + (int64_t)row0 * 2 * DC_E + part * DC_E, 2 * DC_E,
-                             valid, f, nullptr, 0, 0);
+        gemm256<true, false, WT>(XP, wp, 4, 0, b_in + part * DC_E, false, qk_out + (int64_t)row0 * 2 * DC_E + part * DC_E, 2 * DC_E,
+                                 valid, f, nullptr, 0, 0);
     else
-        gemm256<true, false>(X, wp, 4, 0, b_in + 2 * DC_E, false, v_out + (int64_t)row0 * DC_E, DC_E, valid, f, nullptr, 0, 0);
+        gemm256<true, false, WT>(X, wp, 4, 0, b_in + 2 * DC_E, false, v_out + (int64_t)row0 * DC_E, DC_E, valid, f, nullptr, 0, 0);
 }
 
+template <typename WT>
 __global__ __launch_bounds__(DC_THREADS) void dec_post_self_kernel(
-    const float* __restrict__ o, const float* __restrict__ res, const float* __restrict__ wo, const float* __restrict__ bo,
-    const float* __restrict__ g, const float* __restrict__ b, const float* __restrict__ w1, const float* __restrict__ b1,
-    const float* __restrict__ w2, int F, float* __restrict__ x_out, float* __restrict__ parts, int rows, float eps) {
+    const float* __restrict__ o, const float* __restrict__ res, const WT* __restrict__ wo, const float* __restrict__ bo,
+    const float* __restrict__ g, const float* __restrict__ b, const WT* __restrict__ w1, const float* __restrict__ b1,
+    const WT* __restrict__ w2, int F, float* __restrict__ x_out, float* __restrict__ parts, int rows, float eps) {
     __shared__ __attribute__((aligned(16))) float lds[2 * DC_R * DC_LD];
     float *T0 = lds, *X = lds + DC_R * DC_LD;
     const int row0 = blockIdx.x * DC_R, chunk = blockIdx.y;
@@ -279,29 +336,30 @@ __global__ __launch_bounds__(DC_THREADS) void dec_post_self_kernel(
     // linear1: rows [c*256, +256) of the packed (F, 256) matrix; linear2 (256, F): k-chunks 4c..4c+3 of every row tile.
     const int per = (F / DC_E) / gridDim.y, c0 = chunk * per;
     const int kct2 = F / 64;
-    BFrag f;
-    attn_out_ln(o, res, wo, bo, g, b, nullptr, 1, x_out, chunk == 0, T0, X, nullptr, row0, rows, eps, f,
-                w1 + (int64_t)c0 * DC_E * DC_E, 4, 0);
+    BFrag<WT> f;
+    attn_out_ln<WT>(o, res, wo, bo, g, b, nullptr, 1, x_out, chunk == 0, T0, X, nullptr, row0, rows, eps, f,
+                    w1 + (int64_t)c0 * DC_E * DC_E, 4, 0);
     f32x4 acc2[DC_NT];
 #pragma unroll
     for (int t = 0; t < DC_NT; ++t) acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float zero_bias[DC_NT] = {};
     for (int c = c0; c < c0 + per; ++c) {
         // h = relu(x W1[c]^T + b1[c]) (DEC:297) -> T0;  acc2 += h W2[:, c]^T
-        gemm256<false, true>(X, w1 + (int64_t)c * DC_E * DC_E, 4, 0, b1 + c * DC_E, true, T0, 0, 0, f, w2, kct2, 4 * c);
+        gemm256<false, true, WT>(X, w1 + (int64_t)c * DC_E * DC_E, 4, 0, b1 + c * DC_E, true, T0, 0, 0, f, w2, kct2, 4 * c);
         __syncthreads();
         const int cn = min(c + 1, c0 + per - 1);    // the last prefetch re-reads the current chunk: no branch in the pipeline
-        gemm_core<true>(acc2, T0, w2, kct2, 4 * c, f, w1 + (int64_t)cn * DC_E * DC_E, 4, 0);
+        gemm_core<true, WT>(acc2, T0, w2, kct2, 4 * c, f, w1 + (int64_t)cn * DC_E * DC_E, 4, 0);
         __syncthreads();
     }
     gemm_store<true>(acc2, zero_bias, false, parts + ((int64_t)chunk * rows + row0) * DC_E, DC_E, valid);
 }
 
+template <typename WT>
 __global__ __launch_bounds__(DC_THREADS) void dec_heads_kernel(
     const float* __restrict__ x, const float* __restrict__ parts, int n_parts, const float* __restrict__ bias,
     const float* __restrict__ g1, const float* __restrict__ b1, int l2norm, const float* __restrict__ g2,
-    const float* __restrict__ b2, const float* __restrict__ m0w, const float* __restrict__ m0b, const float* __restrict__ m1w,
-    const float* __restrict__ m1b, const float* __restrict__ m2w, const float* __restrict__ m2b, const float* __restrict__ wq,
+    const float* __restrict__ b2, const WT* __restrict__ m0w, const float* __restrict__ m0b, const WT* __restrict__ m1w,
+    const float* __restrict__ m1b, const WT* __restrict__ m2w, const float* __restrict__ m2b, const WT* __restrict__ wq,
     const float* __restrict__ bq, const float* __restrict__ qpos, float* __restrict__ out, float* __restrict__ d_out,
     float* __restrict__ e_out, float* __restrict__ q_out, int32_t* __restrict__ row_any_zero, int rows, int Q, float eps) {
     __shared__ __attribute__((aligned(16))) float lds[3 * DC_R * DC_LD];
@@ -313,7 +371,7 @@ __global__ __launch_bounds__(DC_THREADS) void dec_heads_kernel(
     const bool qpart = blockIdx.y == 1;
     // the mask step that consumes e_out needs its row_any flags cleared: done here instead of a separate fill launch
     if (row_any_zero && !qpart && (int)threadIdx.x < valid) row_any_zero[row0 + threadIdx.x] = 0;
-    BFrag f;
+    BFrag<WT> f;
     bload(f, qpart ? wq : m0w, 4, 0, 0);
     // row phase: lane owns 4 consecutive columns; all global operands of the wave's rows are requested up front
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -363,14 +421,14 @@ __global__ __launch_bounds__(DC_THREADS) void dec_heads_kernel(
     }
     __syncthreads();
     if (qpart) {                                                                     // next layer's query (uniform branch)
-        gemm256<true, false>(XP, wq, 4, 0, bq, false, q_out + (int64_t)row0 * DC_E, DC_E, valid, f, nullptr, 0, 0);
+        gemm256<true, false, WT>(XP, wq, 4, 0, bq, false, q_out + (int64_t)row0 * DC_E, DC_E, valid, f, nullptr, 0, 0);
         return;
     }
-    gemm256<false, true>(Dn, m0w, 4, 0, m0b, true, T0, 0, 0, f, m1w, 4, 0);                                          // mask_embed MLP (DEC:665)
+    gemm256<false, true, WT>(Dn, m0w, 4, 0, m0b, true, T0, 0, 0, f, m1w, 4, 0);                                          // mask_embed MLP (DEC:665)
     __syncthreads();
-    gemm256<false, true>(T0, m1w, 4, 0, m1b, true, Dn, 0, 0, f, m2w, 4, 0);
+    gemm256<false, true, WT>(T0, m1w, 4, 0, m1b, true, Dn, 0, 0, f, m2w, 4, 0);
     __syncthreads();
-    gemm256<true, false>(Dn, m2w, 4, 0, m2b, false, e_out + (int64_t)row0 * DC_E, DC_E, valid, f, nullptr, 0, 0);
+    gemm256<true, false, WT>(Dn, m2w, 4, 0, m2b, false, e_out + (int64_t)row0 * DC_E, DC_E, valid, f, nullptr, 0, 0);
 }
 
 // packed[((t*(K/64) + kc)*4 + u)*256 + (lq*16 + lj)*4 + c] = W[t*16 + lj][kc*64 + u*16 + lq*4 + c]
@@ -387,6 +445,26 @@ __global__ __launch_bounds__(256) void dec_pack_weight_kernel(const float* __res
         const int lj = lane & 15, lq = lane >> 4;
         *reinterpret_cast<float4*>(packed + i * 4) =
             *reinterpret_cast<const float4*>(w + (int64_t)(t * 16 + lj) * K + kc * 64 + u * 16 + lq * 4);
+    }
+}
+
+// bf16: packed[(((t*(K/64) + kc)*2 + up)*64 + lane)*8 + h*4 + c] = bf16(W[t*16 + lj][kc*64 + (2 up + h)*16 + lq*4 + c])
+__global__ __launch_bounds__(256) void dec_pack_weight_bf16_kernel(const float* __restrict__ w, uint16_t* __restrict__ packed, int N,
+                                                                   int K) {
+    const int64_t total8 = (int64_t)N * K / 8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(i & 63);
+        int64_t r = i >> 6;
+        const int up = (int)(r & 1);
+        r >>= 1;
+        const int kct = K / 64;
+        const int kc = (int)(r % kct), t = (int)(r / kct);
+        const int lj = lane & 15, lq = lane >> 4;
+        const float* src = w + (int64_t)(t * 16 + lj) * K + kc * 64 + (2 * up) * 16 + lq * 4;
+        const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 16);
+        const bf16x4 pa = pack4(a.x, a.y, a.z, a.w), pb = pack4(b.x, b.y, b.z, b.w);
+        const u32x2b ua = __builtin_bit_cast(u32x2b, pa), ub = __builtin_bit_cast(u32x2b, pb);
+        *reinterpret_cast<u32x4b*>(packed + i * 8) = u32x4b{ua.x, ua.y, ub.x, ub.y};
     }
 }
 
@@ -407,31 +485,88 @@ extern "C" int msm_dec_pack_weight(const float* w, float* packed, int N, int K, 
     return MSM_OK;
 }
 
+extern "C" int msm_dec_pack_weight_bf16(const float* w, uint16_t* packed, int N, int K, void* stream) {
+    MSM_REQUIRE(w && packed, "msm_dec_pack_weight_bf16: null pointer");
+    MSM_REQUIRE(N > 0 && K > 0 && N % 16 == 0 && K % 64 == 0, "msm_dec_pack_weight_bf16: N=%d must be a multiple of 16, K=%d of 64", N, K);
+    MSM_REQUIRE(aligned16(w) && aligned16(packed), "msm_dec_pack_weight_bf16: pointers must be 16-byte aligned");
+    const int64_t total8 = (int64_t)N * K / 8;
+    hipLaunchKernelGGL(dec_pack_weight_bf16_kernel, dim3((unsigned)min((int64_t)2048, (total8 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, w, packed, N, K);
+    MSM_CHECK_LAUNCH("msm_dec_pack_weight_bf16");
+    return MSM_OK;
+}
+
+template <typename WT>
+static int dec_post_cross_impl(const char* who, const float* attn_out, const float* res, const float* query_pos, const WT* wo, const float* bo,
+                               const float* ln_g, const float* ln_b, const WT* w_in, const float* b_in, float* x_out, float* qk_out,
+                               float* v_out, int rows, int Q, int E, float eps, void* stream) {
+    MSM_REQUIRE(attn_out && res && query_pos && wo && bo && ln_g && ln_b && w_in && b_in && x_out && qk_out && v_out, "%s: null pointer", who);
+    MSM_REQUIRE(E == DC_E, "%s: E=%d, only 256 is supported", who, E);
+    MSM_REQUIRE(rows > 0 && Q > 0, "%s: bad sizes", who);
+    MSM_REQUIRE(aligned16(attn_out) && aligned16(wo) && aligned16(w_in), "%s: pointers must be 16-byte aligned", who);
+    hipLaunchKernelGGL(dec_post_cross_kernel<WT>, dim3(cdiv(rows, DC_R), 3), dim3(DC_THREADS), 0, (hipStream_t)stream, attn_out, res,
+                       query_pos, wo, bo, ln_g, ln_b, w_in, b_in, x_out, qk_out, v_out, rows, Q, eps);
+    MSM_CHECK_LAUNCH(who);
+    return MSM_OK;
+}
+
 extern "C" int msm_dec_post_cross(const float* attn_out, const float* res, const float* query_pos, const float* wo,
                                   const float* bo, const float* ln_g, const float* ln_b, const float* w_in, const float* b_in,
                                   float* x_out, float* qk_out, float* v_out, int rows, int Q, int E, float eps, void* stream) {
-    MSM_REQUIRE(attn_out && res && query_pos && wo && bo && ln_g && ln_b && w_in && b_in && x_out && qk_out && v_out,
-                "msm_dec_post_cross: null pointer");
-    MSM_REQUIRE(E == DC_E, "msm_dec_post_cross: E=%d, only 256 is supported", E);
-    MSM_REQUIRE(rows > 0 && Q > 0, "msm_dec_post_cross: bad sizes");
-    MSM_REQUIRE(aligned16(attn_out) && aligned16(wo) && aligned16(w_in), "msm_dec_post_cross: pointers must be 16-byte aligned");
-    hipLaunchKernelGGL(dec_post_cross_kernel, dim3(cdiv(rows, DC_R), 3), dim3(DC_THREADS), 0, (hipStream_t)stream, attn_out, res,
-                       query_pos, wo, bo, ln_g, ln_b, w_in, b_in, x_out, qk_out, v_out, rows, Q, eps);
-    MSM_CHECK_LAUNCH("msm_dec_post_cross");
+    return dec_post_cross_impl<float>("msm_dec_post_cross", attn_out, res, query_pos, wo, bo, ln_g, ln_b, w_in, b_in, x_out, qk_out, v_out, rows,
+                                      Q, E, eps, stream);
+}
+extern "C" int msm_dec_post_cross_bf16(const float* attn_out, const float* res, const float* query_pos, const uint16_t* wo,
+                                       const float* bo, const float* ln_g, const float* ln_b, const uint16_t* w_in, const float* b_in,
+                                       float* x_out, float* qk_out, float* v_out, int rows, int Q, int E, float eps, void* stream) {
+    return dec_post_cross_impl<uint16_t>("msm_dec_post_cross_bf16", attn_out, res, query_pos, wo, bo, ln_g, ln_b, w_in, b_in, x_out, qk_out,
+                                         v_out, rows, Q, E, eps, stream);
+}
+
+template <typename WT>
+static int dec_post_self_impl(const char* who, const float* attn_out, const float* res, const WT* wo, const float* bo, const float* ln_g,
+                              const float* ln_b, const WT* w1, const float* b1, const WT* w2, int F, float* x_out, float* parts, int n_parts,
+                              int rows, int E, float eps, void* stream) {
+    MSM_REQUIRE(attn_out && res && wo && bo && ln_g && ln_b && w1 && b1 && w2 && x_out && parts, "%s: null pointer", who);
+    MSM_REQUIRE(E == DC_E, "%s: E=%d, only 256 is supported", who, E);
+    MSM_REQUIRE(rows > 0 && F > 0 && F % DC_E == 0, "%s: F=%d must be a positive multiple of 256", who, F);
+    MSM_REQUIRE(n_parts > 0 && (F / DC_E) % n_parts == 0, "%s: n_parts=%d must divide F/256=%d", who, n_parts, F / DC_E);
+    MSM_REQUIRE(aligned16(attn_out) && aligned16(wo) && aligned16(w1) && aligned16(w2), "%s: pointers must be 16-byte aligned", who);
+    hipLaunchKernelGGL(dec_post_self_kernel<WT>, dim3(cdiv(rows, DC_R), n_parts), dim3(DC_THREADS), 0, (hipStream_t)stream, attn_out,
+                       res, wo, bo, ln_g, ln_b, w1, b1, w2, F, x_out, parts, rows, eps);
+    MSM_CHECK_LAUNCH(who);
     return MSM_OK;
 }
 
 extern "C" int msm_dec_post_self(const float* attn_out, const float* res, const float* wo, const float* bo, const float* ln_g,
                                  const float* ln_b, const float* w1, const float* b1, const float* w2, int F, float* x_out,
                                  float* parts, int n_parts, int rows, int E, float eps, void* stream) {
-    MSM_REQUIRE(attn_out && res && wo && bo && ln_g && ln_b && w1 && b1 && w2 && x_out && parts, "msm_dec_post_self: null pointer");
-    MSM_REQUIRE(E == DC_E, "msm_dec_post_self: E=%d, only 256 is supported", E);
-    MSM_REQUIRE(rows > 0 && F > 0 && F % DC_E == 0, "msm_dec_post_self: F=%d must be a positive multiple of 256", F);
-    MSM_REQUIRE(n_parts > 0 && (F / DC_E) % n_parts == 0, "msm_dec_post_self: n_parts=%d must divide F/256=%d", n_parts, F / DC_E);
-    MSM_REQUIRE(aligned16(attn_out) && aligned16(wo) && aligned16(w1) && aligned16(w2), "msm_dec_post_self: pointers must be 16-byte aligned");
-    hipLaunchKernelGGL(dec_post_self_kernel, dim3(cdiv(rows, DC_R), n_parts), dim3(DC_THREADS), 0, (hipStream_t)stream, attn_out,
-                       res, wo, bo, ln_g, ln_b, w1, b1, w2, F, x_out, parts, rows, eps);
-    MSM_CHECK_LAUNCH("msm_dec_post_self");
+    return dec_post_self_impl<float>("msm_dec_post_self", attn_out, res, wo, bo, ln_g, ln_b, w1, b1, w2, F, x_out, parts, n_parts, rows, E, eps,
+                                     stream);
+}
+extern "C" int msm_dec_post_self_bf16(const float* attn_out, const float* res, const uint16_t* wo, const float* bo, const float* ln_g,
+                                      const float* ln_b, const uint16_t* w1, const float* b1, const uint16_t* w2, int F, float* x_out,
+                                      float* parts, int n_parts, int rows, int E, float eps, void* stream) {
+    return dec_post_self_impl<uint16_t>("msm_dec_post_self_bf16", attn_out, res, wo, bo, ln_g, ln_b, w1, b1, w2, F, x_out, parts, n_parts, rows, E,
+                                        eps, stream);
+}
+
+template <typename WT>
+static int dec_heads_impl(const char* who, const float* x, const float* parts, int n_parts, const float* bias, const float* ln_g,
+                          const float* ln_b, int l2norm, const float* dec_g, const float* dec_b, const WT* m0w, const float* m0b, const WT* m1w,
+                          const float* m1b, const WT* m2w, const float* m2b, const WT* wq, const float* bq, const float* query_pos, float* out,
+                          float* d_out, float* e_out, float* q_out, int32_t* row_any_zero, int rows, int Q, int E, float eps, void* stream) {
+    MSM_REQUIRE(x && dec_g && dec_b && m0w && m0b && m1w && m1b && m2w && m2b && e_out, "%s: null pointer", who);
+    MSM_REQUIRE(E == DC_E, "%s: E=%d, only 256 is supported", who, E);
+    MSM_REQUIRE(rows > 0 && Q > 0 && n_parts >= 0, "%s: bad sizes", who);
+    MSM_REQUIRE(n_parts == 0 || parts, "%s: parts missing", who);
+    MSM_REQUIRE((ln_g == nullptr) == (ln_b == nullptr), "%s: ln_g/ln_b must both be given or both be null", who);
+    MSM_REQUIRE(!wq || (bq && query_pos && q_out), "%s: the next-query projection needs bq, query_pos and q_out", who);
+    MSM_REQUIRE(aligned16(m0w) && aligned16(m1w) && aligned16(m2w) && aligned16(wq), "%s: weights must be 16-byte aligned", who);
+    hipLaunchKernelGGL(dec_heads_kernel<WT>, dim3(cdiv(rows, DC_R), wq ? 2 : 1), dim3(DC_THREADS), 0, (hipStream_t)stream, x, parts, n_parts, bias,
+                       ln_g, ln_b, l2norm, dec_g, dec_b, m0w, m0b, m1w, m1b, m2w, m2b, wq, bq, query_pos, out, d_out, e_out, q_out,
+                       row_any_zero, rows, Q, eps);
+    MSM_CHECK_LAUNCH(who);
     return MSM_OK;
 }
 
@@ -440,16 +575,14 @@ extern "C" int msm_dec_heads(const float* x, const float* parts, int n_parts, co
                              const float* m0b, const float* m1w, const float* m1b, const float* m2w, const float* m2b,
                              const float* wq, const float* bq, const float* query_pos, float* out, float* d_out, float* e_out,
                              float* q_out, int32_t* row_any_zero, int rows, int Q, int E, float eps, void* stream) {
-    MSM_REQUIRE(x && dec_g && dec_b && m0w && m0b && m1w && m1b && m2w && m2b && e_out, "msm_dec_heads: null pointer");
-    MSM_REQUIRE(E == DC_E, "msm_dec_heads: E=%d, only 256 is supported", E);
-    MSM_REQUIRE(rows > 0 && Q > 0 && n_parts >= 0, "msm_dec_heads: bad sizes");
-    MSM_REQUIRE(n_parts == 0 || parts, "msm_dec_heads: parts missing");
-    MSM_REQUIRE((ln_g == nullptr) == (ln_b == nullptr), "msm_dec_heads: ln_g/ln_b must both be given or both be null");
-    MSM_REQUIRE(!wq || (bq && query_pos && q_out), "msm_dec_heads: the next-query projection needs bq, query_pos and q_out");
-    MSM_REQUIRE(aligned16(m0w) && aligned16(m1w) && aligned16(m2w) && aligned16(wq), "msm_dec_heads: weights must be 16-byte aligned");
-    hipLaunchKernelGGL(dec_heads_kernel, dim3(cdiv(rows, DC_R), wq ? 2 : 1), dim3(DC_THREADS), 0, (hipStream_t)stream, x, parts, n_parts, bias,
-                       ln_g, ln_b, l2norm, dec_g, dec_b, m0w, m0b, m1w, m1b, m2w, m2b, wq, bq, query_pos, out, d_out, e_out, q_out,
-                       row_any_zero, rows, Q, eps);
-    MSM_CHECK_LAUNCH("msm_dec_heads");
-    return MSM_OK;
+    return dec_heads_impl<float>("msm_dec_heads", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, m0w, m0b, m1w, m1b, m2w, m2b, wq, bq,
+                                 query_pos, out, d_out, e_out, q_out, row_any_zero, rows, Q, E, eps, stream);
+}
+extern "C" int msm_dec_heads_bf16(const float* x, const float* parts, int n_parts, const float* bias, const float* ln_g,
+                                  const float* ln_b, int l2norm, const float* dec_g, const float* dec_b, const uint16_t* m0w,
+                                  const float* m0b, const uint16_t* m1w, const float* m1b, const uint16_t* m2w, const float* m2b,
+                                  const uint16_t* wq, const float* bq, const float* query_pos, float* out, float* d_out, float* e_out,
+                                  float* q_out, int32_t* row_any_zero, int rows, int Q, int E, float eps, void* stream) {
+    return dec_heads_impl<uint16_t>("msm_dec_heads_bf16", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, m0w, m0b, m1w, m1b, m2w, m2b,
+                                    wq, bq, query_pos, out, d_out, e_out, q_out, row_any_zero, rows, Q, E, eps, stream);
 }

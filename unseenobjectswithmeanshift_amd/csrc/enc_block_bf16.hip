@@ -18,15 +18,10 @@
 //     [4 k-groups][64 lanes][4 bf16], lane l's operand of k-group g is the 8 bytes at (g*64 + l)*8 -- conflict-free
 //     ds_read_b64, and a stage of 8 blocks is a plain 16 KiB copy (LDS-DMA, no swizzle);
 //   * one 16-token tile per wave, 4 waves per workgroup, 2 x 16 KiB LDS stages + parameters: 4 workgroups per CU.
+#include "bf16.h"
 #include "common.h"
 
 namespace msm {
-
-typedef short bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2b __attribute__((ext_vector_type(2)));
 
 constexpr int EB_C = 64;                    // d_model
 constexpr int EB_BLOCK = 2048;              // bytes per weight block
@@ -36,29 +31,11 @@ struct EncSmallB {                          // offsets (floats) into the packed 
     int bo, g1, be1, b1, b2, g2, be2, bv, bp;
 };
 
-__device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
-    const bf16x2_t lo = __builtin_convertvector(f32x2{a, b}, bf16x2_t), hi = __builtin_convertvector(f32x2{c, d}, bf16x2_t);
-    const u32x2b u = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
-    return __builtin_bit_cast(bf16x4, u);
-}
-__device__ __forceinline__ f32x4 mfma_bf16(bf16x4 a, bf16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
 // An activation block as TWO bf16 operands, x = hi + lo up to 2^-17 |x|: the 64-wide contractions (output_proj, linear1, value
 // and sampling projections) have little averaging over k, and rounding their inputs to 8 mantissa bits moved the attention-mask
 // bits of the decoder behind them about five times as often as rounding the weights alone does (random-init worst case:
 // final-mask mismatch against the fp32 reference 1.7 % -> see DESIGN.md).  One more MFMA per k-group; the 1024-wide linear2
 // keeps a single bf16 operand.
-struct Split4 {
-    bf16x4 hi, lo;
-};
-__device__ __forceinline__ float bf16_hi_as_float(unsigned packed, int idx) { return __uint_as_float(idx ? (packed & 0xffff0000u) : (packed << 16)); }
-__device__ __forceinline__ Split4 split4(float a, float b, float c, float d) {
-    const bf16x2_t h0 = __builtin_convertvector(f32x2{a, b}, bf16x2_t), h1 = __builtin_convertvector(f32x2{c, d}, bf16x2_t);
-    const unsigned u0 = __builtin_bit_cast(unsigned, h0), u1 = __builtin_bit_cast(unsigned, h1);
-    Split4 r;
-    r.hi = __builtin_bit_cast(bf16x4, u32x2b{u0, u1});
-    r.lo = pack4(a - bf16_hi_as_float(u0, 0), b - bf16_hi_as_float(u0, 1), c - bf16_hi_as_float(u1, 0), d - bf16_hi_as_float(u1, 1));
-    return r;
-}
 __device__ __forceinline__ bf16x4 frag(const char* __restrict__ blk, int g, int lane) {
     return __builtin_bit_cast(bf16x4, *reinterpret_cast<const u32x2b*>(blk + (g * 64 + lane) * 8));
 }

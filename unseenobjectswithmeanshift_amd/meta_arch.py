@@ -104,6 +104,8 @@ class MeanShiftMaskFormerHead(nn.Module):
         if hasattr(self.pixel_decoder, "precision"):
             self.pixel_decoder.precision = mode
         self.predictor.mask_step_dtype = mode
+        if hasattr(self.predictor, "tails_dtype"):
+            self.predictor.tails_dtype = mode
         return self
 
     def layers(self, features, image_height=None, image_width=None, mask=None):

@@ -272,6 +272,9 @@ class MeanShiftTransformerDecoder(nn.Module):
         # "bf16": the Q x pixel-embedding mask step runs with bf16 operands / fp32 accumulation on a packed copy of
         # mask_features made once per forward (BASELINE configs 3 and 5); everything else stays fp32
         self.mask_step_dtype = "f32"
+        # "bf16": the fused row-local tails (dec_post_cross / dec_post_self / dec_heads) stream bf16 weights and multiply on
+        # bf16 MFMAs with fp32 accumulation (activations as hi + lo pairs); part of set_precision("bf16")
+        self.tails_dtype = "f32"
         self._packed_mf = None
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
@@ -367,9 +370,12 @@ class MeanShiftTransformerDecoder(nn.Module):
             "ffn2": [l.linear2.weight for l in self.transformer_ffn_layers],
             "mlp": [l.weight for l in self.mask_embed.layers],
         }
-        key = tuple((p.data_ptr(), p._version) for ws in groups.values() for p in ws)
+        if self.tails_dtype not in ("f32", "bf16"):
+            raise ValueError("tails_dtype must be 'f32' or 'bf16'")
+        pack = ops.dec_pack_weight if self.tails_dtype == "f32" else ops.dec_pack_weight_bf16
+        key = (self.tails_dtype,) + tuple((p.data_ptr(), p._version) for ws in groups.values() for p in ws)
         if self._tails_cache is None or self._tails_cache[0] != key:
-            self._tails_cache = (key, {k: [ops.dec_pack_weight(w.contiguous()) for w in ws] for k, ws in groups.items()})
+            self._tails_cache = (key, {k: [pack(w.contiguous()) for w in ws] for k, ws in groups.items()})
         return self._tails_cache[1]
 
     def _folded_head(self, fm):
@@ -379,7 +385,8 @@ class MeanShiftTransformerDecoder(nn.Module):
         heads kernel writes, packed like the other tail weights.  Returns (packed weight, bias, n_columns)."""
         l3 = self.mask_embed.layers[-1]
         params = (l3.weight, l3.bias, fm.weight) + ((fm.bias,) if fm.bias is not None else ())
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        pack = ops.dec_pack_weight if self.tails_dtype == "f32" else ops.dec_pack_weight_bf16
+        key = (self.tails_dtype,) + tuple((p.data_ptr(), p._version) for p in params)
         if self._fold_cache is None or self._fold_cache[0] != key:
             wm = fm.weight.detach().double().reshape(fm.weight.shape[0], -1)             # (mask_dim, 64)
             bm = fm.bias.detach().double() if fm.bias is not None else torch.zeros(wm.shape[0], dtype=torch.float64, device=wm.device)
@@ -391,7 +398,7 @@ class MeanShiftTransformerDecoder(nn.Module):
             w[n] = bm @ w3
             b[:n] = wm.t() @ b3
             b[n] = bm @ b3
-            self._fold_cache = (key, ops.dec_pack_weight(w.float().contiguous()), b.float().contiguous(), n)
+            self._fold_cache = (key, pack(w.float().contiguous()), b.float().contiguous(), n)
         return self._fold_cache[1:]
 
     def _forward_fused(self, xs, sizes, kv_w, kv_c, mask_features, out, qpos, kv_all=None):

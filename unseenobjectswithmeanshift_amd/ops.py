@@ -483,19 +483,41 @@ def dec_pack_weight(w):
     return packed
 
 
+def dec_pack_weight_bf16(w):
+    """(N, K) fp32 Linear weight -> bf16 in the fragment order of the low-precision dec_* kernels (msm_dec_pack_weight_bf16);
+    the result (dtype torch.bfloat16, shape (N, K), NOT row-major) is what dec_post_cross / dec_post_self / dec_heads take as
+    a weight in that mode: they pick the bf16 entry points by the weights' dtype."""
+    _c(w, "w")
+    N, K = w.shape
+    packed = torch.empty((N, K), device=w.device, dtype=torch.bfloat16)
+    rc = lib().msm_dec_pack_weight_bf16(_p(w), _p(packed), N, K, _stream())
+    check(rc, "msm_dec_pack_weight_bf16")
+    return packed
+
+
+def _wdtype(*ws):
+    """Common dtype of the packed weight matrices of a dec_* call (fp32 or bf16 fragments, never mixed)."""
+    dts = {w.dtype for w in ws if w is not None}
+    if len(dts) != 1 or next(iter(dts)) not in (torch.float32, torch.bfloat16):
+        raise RuntimeError(f"packed weights must be all float32 or all bfloat16, got {sorted(map(str, dts))}")
+    return next(iter(dts))
+
+
 def dec_post_cross(attn_out, res, query_pos, wo, bo, ln_g, ln_b, w_in, b_in, eps=1e-5):
     """Weight matrices of the three dec_* calls are dec_pack_weight() outputs.
     x = LN(res + attn_out wo^T + bo); qk = (x + query_pos) w_in[:2E]^T + b_in[:2E]; v = x w_in[2E:]^T + b_in[2E:].
     attn_out/res (B,Q,E); query_pos (Q,E).  Returns (x (B,Q,E), qk (B,Q,2E), v (B,Q,E))."""
-    for t, n in ((attn_out, "attn_out"), (res, "res"), (query_pos, "query_pos"), (wo, "wo"), (bo, "bo"), (ln_g, "ln_g"),
-                 (ln_b, "ln_b"), (w_in, "w_in"), (b_in, "b_in")):
+    wd = _wdtype(wo, w_in)
+    for t, n in ((attn_out, "attn_out"), (res, "res"), (query_pos, "query_pos"), (bo, "bo"), (ln_g, "ln_g"), (ln_b, "ln_b"), (b_in, "b_in")):
         _c(t, n)
+    _c(wo, "wo", wd), _c(w_in, "w_in", wd)
     B, Q, E = attn_out.shape
     x = torch.empty_like(attn_out)
     qk = torch.empty((B, Q, 2 * E), device=attn_out.device, dtype=torch.float32)
     v = torch.empty_like(attn_out)
-    rc = lib().msm_dec_post_cross(_p(attn_out), _p(res), _p(query_pos), _p(wo), _p(bo), _p(ln_g), _p(ln_b), _p(w_in),
-                                  _p(b_in), _p(x), _p(qk), _p(v), B * Q, Q, E, eps, _stream())
+    fn = lib().msm_dec_post_cross if wd == torch.float32 else lib().msm_dec_post_cross_bf16
+    rc = fn(_p(attn_out), _p(res), _p(query_pos), _p(wo), _p(bo), _p(ln_g), _p(ln_b), _p(w_in), _p(b_in), _p(x), _p(qk), _p(v), B * Q, Q, E,
+            eps, _stream())
     check(rc, "msm_dec_post_cross")
     return x, qk, v
 
@@ -503,9 +525,10 @@ def dec_post_cross(attn_out, res, query_pos, wo, bo, ln_g, ln_b, w_in, b_in, eps
 def dec_post_self(attn_out, res, wo, bo, ln_g, ln_b, w1, b1, w2, n_parts=None, eps=1e-5):
     """x = LN(res + attn_out wo^T + bo); parts (n_parts, B, Q, E): partial sums over equal slices of the hidden
     dimension of linear2(relu(linear1(x))), without linear2's bias.  Default n_parts: about 200 workgroups."""
-    for t, n in ((attn_out, "attn_out"), (res, "res"), (wo, "wo"), (bo, "bo"), (ln_g, "ln_g"), (ln_b, "ln_b"),
-                 (w1, "w1"), (b1, "b1"), (w2, "w2")):
+    wd = _wdtype(wo, w1, w2)
+    for t, n in ((attn_out, "attn_out"), (res, "res"), (bo, "bo"), (ln_g, "ln_g"), (ln_b, "ln_b"), (b1, "b1")):
         _c(t, n)
+    _c(wo, "wo", wd), _c(w1, "w1", wd), _c(w2, "w2", wd)
     B, Q, E = attn_out.shape
     F = w1.shape[0]
     x = torch.empty_like(attn_out)
@@ -514,8 +537,9 @@ def dec_post_self(attn_out, res, wo, bo, ln_g, ln_b, w1, b1, w2, n_parts=None, e
         tiles = (B * Q + 15) // 16
         n_parts = max(d for d in range(1, chunks + 1) if chunks % d == 0 and (d == 1 or tiles * d <= 256))
     parts = torch.empty((n_parts, B, Q, E), device=attn_out.device, dtype=torch.float32)
-    rc = lib().msm_dec_post_self(_p(attn_out), _p(res), _p(wo), _p(bo), _p(ln_g), _p(ln_b), _p(w1), _p(b1), _p(w2), F,
-                                 _p(x), _p(parts), n_parts, B * Q, E, eps, _stream())
+    fn = lib().msm_dec_post_self if wd == torch.float32 else lib().msm_dec_post_self_bf16
+    rc = fn(_p(attn_out), _p(res), _p(wo), _p(bo), _p(ln_g), _p(ln_b), _p(w1), _p(b1), _p(w2), F, _p(x), _p(parts), n_parts, B * Q, E, eps,
+            _stream())
     check(rc, "msm_dec_post_self")
     return x, parts
 
@@ -525,9 +549,11 @@ def dec_heads(x, dec_g, dec_b, mlp, *, parts=None, bias=None, ln_g=None, ln_b=No
     """t = x + sum(parts) + bias [-> LN] [-> unit length]; d = LN_dec(t); e = MLP3(d); q = (t + query_pos) wq^T + bq.
     mlp = [(w0,b0),(w1,b1),(w2,b2)].  Returns (out|None, d|None, e, q|None), plus a zeroed (B,Q) int32 row_any buffer
     for the following mask step when zero_row_any."""
-    ts = [x, parts, bias, ln_g, ln_b, dec_g, dec_b, wq, bq, query_pos] + [t for wb in mlp for t in wb]
-    for i, t in enumerate(ts):
+    wd = _wdtype(wq, *[w for w, _ in mlp])
+    for i, t in enumerate([x, parts, bias, ln_g, ln_b, dec_g, dec_b, bq, query_pos] + [b for _, b in mlp]):
         _c(t, f"dec_heads arg {i}")
+    for i, t in enumerate([wq] + [w for w, _ in mlp]):
+        _c(t, f"dec_heads weight {i}", wd)
     B, Q, E = x.shape
     out = torch.empty_like(x) if want_out else None
     d = torch.empty_like(x) if want_d else None
@@ -536,9 +562,9 @@ def dec_heads(x, dec_g, dec_b, mlp, *, parts=None, bias=None, ln_g=None, ln_b=No
     ra = torch.empty((B, Q), device=x.device, dtype=torch.int32) if zero_row_any else None
     n_parts = 0 if parts is None else parts.shape[0]
     (m0w, m0b), (m1w, m1b), (m2w, m2b) = mlp
-    rc = lib().msm_dec_heads(_p(x), _p(parts), n_parts, _p(bias), _p(ln_g), _p(ln_b), 1 if l2norm else 0, _p(dec_g),
-                             _p(dec_b), _p(m0w), _p(m0b), _p(m1w), _p(m1b), _p(m2w), _p(m2b), _p(wq), _p(bq),
-                             _p(query_pos), _p(out), _p(d), _p(e), _p(q), _p(ra), B * Q, Q, E, eps, _stream())
+    fn = lib().msm_dec_heads if wd == torch.float32 else lib().msm_dec_heads_bf16
+    rc = fn(_p(x), _p(parts), n_parts, _p(bias), _p(ln_g), _p(ln_b), 1 if l2norm else 0, _p(dec_g), _p(dec_b), _p(m0w), _p(m0b), _p(m1w),
+            _p(m1b), _p(m2w), _p(m2b), _p(wq), _p(bq), _p(query_pos), _p(out), _p(d), _p(e), _p(q), _p(ra), B * Q, Q, E, eps, _stream())
     check(rc, "msm_dec_heads")
     return (out, d, e, q, ra) if zero_row_any else (out, d, e, q)
 
