@@ -55,7 +55,7 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 8   /* 8: bf16 decoder tails; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
+#define MSM_ABI_VERSION 8   /* 8: bf16 decoder tails, low-precision attention and bf16 K/V projection; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
 int msm_abi_version(void);
 
 /* Kernel-selection overrides for tools/ and tests/ (NOT read on the product path: every option defaults to
@@ -190,6 +190,17 @@ int msm_hypersphere_attn_fwd(const float* q, const float* k, const float* v,
                              int64_t ldq, int64_t q_sb, int64_t ldk, int64_t k_sb,
                              int64_t ldv, int64_t v_sb, float kappa,
                              float* workspace, int64_t workspace_elems, void* stream);
+/* Low-precision form (BASELINE configs 3 / 5; the reference's counterpart is torch.autocast): q^, k^, the probabilities and V
+ * enter v_mfma_f32_16x16x16_bf16 as bf16 operands, accumulation / exp / row sums / normalisations stay fp32.  k and v are
+ * fp32 (kv_bf16 == 0: the self-attention operands written by msm_dec_post_cross) or bf16 (kv_bf16 != 0: as written by
+ * msm_kv_project_multi_bf16); ldk / k_sb / ldv / v_sb are in ELEMENTS of that type and must keep k rows 16-byte aligned.
+ * Everything else as msm_hypersphere_attn_fwd (same workspace size). */
+int msm_hypersphere_attn_lp_fwd(const float* q, const void* k, const void* v, int kv_bf16,
+                                const uint8_t* masked, const int32_t* row_any, float* out,
+                                int B, int Lq, int S, int heads,
+                                int64_t ldq, int64_t q_sb, int64_t ldk, int64_t k_sb,
+                                int64_t ldv, int64_t v_sb, float kappa,
+                                float* workspace, int64_t workspace_elems, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-scale deformable attention forward, reference ABI (OPS/src/ms_deform_attn.h:25-44):
@@ -264,6 +275,11 @@ int msm_kv_project_f32(const float* x, const float* w, const float* cmat, float*
 int msm_kv_project_multi_f32(int n_jobs, const float* const* x, const float* const* w, const float* const* cmat,
                              float* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride,
                              int B, int C, int N, void* stream);
+/* The same with the result stored as bf16 (low-precision mode): half the bytes of this write-bound launch and of the K/V
+ * reads of msm_hypersphere_attn_lp_fwd.  The products are exact fp32 MFMAs; only the stored value is rounded. */
+int msm_kv_project_multi_bf16(int n_jobs, const float* const* x, const float* const* w, const float* const* cmat,
+                              uint16_t* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride,
+                              int B, int C, int N, void* stream);
 
 /* mask_features (MSD:349-358): the last GroupNorm + ReLU of the FPN level fused into the 1x1 convolution after it.
  *   out [B][N][HW] (NCHW) = bias + w act(x),  x [B][HW][64] tokens, w [N][64], N in {256, 512}, HW % 4 == 0;

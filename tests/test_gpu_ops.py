@@ -221,6 +221,43 @@ def test_hypersphere_attention(B, Lq, S, masked):
         close(alt, ref, rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("kv_bf16", [False, True])
+@pytest.mark.parametrize("B,Lq,S,masked", [(2, 100, 300, True), (2, 100, 100, False), (1, 100, 4800, True), (2, 20, 37, True)])
+def test_hypersphere_attention_low_precision(B, Lq, S, masked, kv_bf16):
+    """msm_hypersphere_attn_lp_fwd (bf16 MFMA operands, fp32 accumulation; K / V stored as fp32 or bf16) against the oracle.
+    The unit vectors q^, k^ carry 8 mantissa bits, so a logit kappa q^.k^ moves by ~kappa 2^-9 / sqrt(32) ~ 1e-2 and the outputs
+    (components of unit vectors) by a few 1e-3; the oracle is fed the bf16-rounded K / V when those are what is stored."""
+    H, E = 8, 256
+    q, k, v = rnd(B, Lq, E, seed=1), rnd(B, S, E, seed=2), rnd(B, S, E, seed=3)
+    if kv_bf16:
+        k, v = _bf16_round(k), _bf16_round(v)
+    m = row_any = add = None
+    if masked:
+        g = torch.Generator().manual_seed(4)
+        m = torch.rand(B, Lq, S, generator=g) < 0.6
+        m[0, 1] = True
+        row_any = (~m.all(-1)).to(torch.int32)
+        eff = m.clone()
+        eff[m.all(-1)] = False
+        add = torch.zeros(B, 1, Lq, S)
+        add[eff[:, None]] = float("-inf")
+        add = add.expand(B, H, Lq, S).reshape(B * H, Lq, S)
+    hd = lambda t, n: t.view(B, n, H, 32).permute(0, 2, 1, 3).reshape(B * H, n, 32)
+    o, _ = O.hypersphere_attention(hd(q, Lq), hd(k, S), hd(v, S), add)
+    ref = o.view(B, H, Lq, 32).permute(0, 2, 1, 3).reshape(B, Lq, E)
+    kd, vd = (k.to(DEV).to(torch.bfloat16), v.to(DEV).to(torch.bfloat16)) if kv_bf16 else (k.to(DEV), v.to(DEV))
+    kw = dict(masked=None if m is None else m.to(torch.uint8).to(DEV), row_any=None if row_any is None else row_any.to(DEV))
+    got = ops().hypersphere_attention(q.to(DEV), kd, vd, H, low_precision=True, **kw)
+    err = (got.cpu() - ref).abs()
+    print(f"lp attention S={S} kv_bf16={kv_bf16}: max |d| {float(err.max()):.2e} mean {float(err.mean()):.2e}")
+    assert float(err.max()) < 3e-2 and float(err.mean()) < 2e-3
+    nrm = got.view(B, Lq, H, 32).norm(dim=-1)
+    close(nrm, torch.ones_like(nrm).cpu(), rtol=1e-5, atol=1e-5)                  # the output normalisation is fp32
+    with option_ctx("ATTN_KERNEL", 3):                                           # split-K kernel + combine at every length
+        alt = ops().hypersphere_attention(q.to(DEV), kd, vd, H, low_precision=True, **kw)
+    assert float((alt.cpu() - ref).abs().max()) < 3e-2
+
+
 def test_hypersphere_attention_strided_views():
     B, L, H, E = 2, 100, 8, 256
     qk, v = rnd(B, L, 2 * E, seed=1).to(DEV), rnd(B, L, E, seed=2).to(DEV)
@@ -398,6 +435,9 @@ def test_tokens_proj_nchw(B, H, W, N, gn):
         y = x.double().transpose(1, 2)
     ref = torch.einsum("nk,bkp->bnp", w.double(), y) + b.double()[None, :, None]
     closed(got, ref, rtol=1e-4, atol=5e-5)
+
+
+from unseenobjectswithmeanshift_amd._lib import option as option_ctx  # noqa: E402
 
 
 def _bf16_round(t):
@@ -838,6 +878,10 @@ def test_kv_project_multi_equals_single_launches():
         closed(o, ref.cpu(), rtol=2e-5, atol=2e-5)
         if x.shape[2] * x.shape[3] * B >= 8192 or ops().is_token_major(x):        # the single launch takes the same kernel there
             assert torch.equal(o, ops().kv_project(x, w, c))
+    # low-precision mode: the same fp32 products, stored as bf16 (round to nearest even)
+    outs16 = ops().kv_project_multi(xs, ws, cs, out_dtype=torch.bfloat16)
+    for o, o16 in zip(outs, outs16):
+        assert o16.dtype == torch.bfloat16 and torch.equal(o16, o.to(torch.bfloat16))
 
 
 @pytest.mark.parametrize("B,H,W,Cout", [(2, 12, 16, 256), (1, 7, 36, 64), (1, 30, 40, 128)])

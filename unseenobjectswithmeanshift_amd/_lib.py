@@ -41,6 +41,8 @@ _SIGNATURES = {
     "msm_hypersphere_attn_workspace": (c_l, [c_i, c_i, c_i, c_i]),
     "msm_hypersphere_attn_fwd": (c_i, [c_f, c_f, c_f, c_p, c_p, c_f, c_i, c_i, c_i, c_i,
                                        c_l, c_l, c_l, c_l, c_l, c_l, c_fl, c_f, c_l, c_p]),
+    "msm_hypersphere_attn_lp_fwd": (c_i, [c_f, c_p, c_p, c_i, c_p, c_p, c_f, c_i, c_i, c_i, c_i,
+                                          c_l, c_l, c_l, c_l, c_l, c_l, c_fl, c_f, c_l, c_p]),
     "msm_hypersphere_attn_bwd_workspace": (c_l, [c_i, c_i, c_i]),
     "msm_hypersphere_attn_bwd": (c_i, [c_f, c_f, c_f, c_p, c_p, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i,
                                        c_l, c_l, c_l, c_l, c_l, c_l, c_fl, c_f, c_l, c_p]),
@@ -55,6 +57,7 @@ _SIGNATURES = {
     "msm_encoder_block_bf16_fwd": (c_i, [c_f, c_f, c_p, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_p]),
     "msm_kv_project_f32": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_l, c_p]),
     "msm_kv_project_multi_f32": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "msm_kv_project_multi_bf16": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "msm_tokens_proj_nchw_f32": (c_i, [c_f, c_f, c_f, c_p, c_f, c_f, c_i, c_fl, c_i, c_f, c_i, c_i, c_i, c_i, c_p]),
     "msm_dec_pack_weight": (c_i, [c_f, c_f, c_i, c_i, c_p]),
     "msm_dec_post_cross": (c_i, [c_f] * 12 + [c_i, c_i, c_i, c_fl, c_p]),

@@ -18,6 +18,9 @@
 //     small combine kernel that also applies 1/l and the output L2 normalisation.
 #include <stdlib.h>
 
+#include <type_traits>
+
+#include "bf16.h"
 #include "common.h"
 
 namespace msm {
@@ -37,8 +40,73 @@ static int attn_nsplit(int B, int qchunks, int heads, int S) {
     return ns;
 }
 
-__global__ __launch_bounds__(256) void hs_attn_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                      const float* __restrict__ v, const uint8_t* __restrict__ masked,
+// ---- low-precision mode (BASELINE configs 3 / 5) --------------------------------------------------------------------------
+// Template parameters of the two default kernels below: KVT = storage type of K and V (float, or uint16_t = bf16 as written by
+// msm_kv_project_multi_bf16), BF = multiply on v_mfma_f32_16x16x16_bf16 (q^, k^, the probabilities and V rounded to bf16 at
+// the moment they become operands; fp32 accumulation, fp32 exp / row sums / normalisation).  A key block is then 2 + 2 MFMAs
+// of 8 cycles per query block instead of 8 + 8 of 32.  Same lane mapping: the k index a lane feeds is free as long as both
+// operands agree, so chunk c (0, 1) of the head dimension is dims lq*8 + 4c .. + 3, exactly the two halves of the 8 values
+// a lane already holds.
+template <typename KVT>
+struct KVRaw;
+template <>
+struct KVRaw<float> {
+    float4 ka, kc;
+    float v[4][2];
+};
+template <>
+struct KVRaw<uint16_t> {
+    u32x4b k;
+    unsigned short v[4][2];
+};
+// kp: this lane's 8 dims of its key row; vbp + key * ldv: dim lj of a key row
+__device__ __forceinline__ void kv_fetch(KVRaw<float>& f, const float* __restrict__ kp, const float* __restrict__ vbp, int64_t ldv, int key_c0, int S) {
+    f.ka = *reinterpret_cast<const float4*>(kp);
+    f.kc = *reinterpret_cast<const float4*>(kp + 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float* vp = vbp + (int64_t)min(key_c0 + r, S - 1) * ldv;
+        f.v[r][0] = vp[0];
+        f.v[r][1] = vp[16];
+    }
+}
+__device__ __forceinline__ void kv_fetch(KVRaw<uint16_t>& f, const uint16_t* __restrict__ kp, const uint16_t* __restrict__ vbp, int64_t ldv, int key_c0,
+                                         int S) {
+    f.k = *reinterpret_cast<const u32x4b*>(kp);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint16_t* vp = vbp + (int64_t)min(key_c0 + r, S - 1) * ldv;
+        f.v[r][0] = vp[0];
+        f.v[r][1] = vp[16];
+    }
+}
+__device__ __forceinline__ void k_floats(const KVRaw<float>& f, float (&kf)[8]) {
+    kf[0] = f.ka.x; kf[1] = f.ka.y; kf[2] = f.ka.z; kf[3] = f.ka.w;
+    kf[4] = f.kc.x; kf[5] = f.kc.y; kf[6] = f.kc.z; kf[7] = f.kc.w;
+}
+__device__ __forceinline__ void k_floats(const KVRaw<uint16_t>& f, float (&kf)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        kf[2 * i] = __uint_as_float(f.k[i] << 16);
+        kf[2 * i + 1] = __uint_as_float(f.k[i] & 0xffff0000u);
+    }
+}
+// the V fragments of a key block: fp32 MFMA operands (vf) or two bf16x4 B operands (dims lj and 16 + lj of keys 4 lq .. + 3)
+__device__ __forceinline__ void v_operands(const KVRaw<float>& f, bf16x4 (&vb)[2]) {
+    vb[0] = pack4(f.v[0][0], f.v[1][0], f.v[2][0], f.v[3][0]);
+    vb[1] = pack4(f.v[0][1], f.v[1][1], f.v[2][1], f.v[3][1]);
+}
+__device__ __forceinline__ void v_operands(const KVRaw<uint16_t>& f, bf16x4 (&vb)[2]) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+        vb[hh] = __builtin_bit_cast(bf16x4, u32x2b{(unsigned)f.v[0][hh] | ((unsigned)f.v[1][hh] << 16), (unsigned)f.v[2][hh] | ((unsigned)f.v[3][hh] << 16)});
+}
+__device__ __forceinline__ float v_float(const KVRaw<float>& f, int r, int hh) { return f.v[r][hh]; }
+__device__ __forceinline__ float v_float(const KVRaw<uint16_t>& f, int r, int hh) { return __uint_as_float((unsigned)f.v[r][hh] << 16); }
+
+template <typename KVT, bool BF>
+__global__ __launch_bounds__(256) void hs_attn_kernel(const float* __restrict__ q, const KVT* __restrict__ k,
+                                                      const KVT* __restrict__ v, const uint8_t* __restrict__ masked,
                                                       const int32_t* __restrict__ row_any, float* __restrict__ part,
                                                       float* __restrict__ out, int Lq, int S, int heads, int qchunks, int nsplit, int64_t ldq,
                                                       int64_t q_sb, int64_t ldk, int64_t k_sb, int64_t ldv,
@@ -53,6 +121,7 @@ __global__ __launch_bounds__(256) void hs_attn_kernel(const float* __restrict__ 
 
     // ---- Q^ fragments (B operand): lane (query lj of block m, dims lq*8 + t) ----
     float qf[AQB][8];
+    bf16x4 qh[BF ? AQB : 1][2];             // BF: the same fragments as bf16 B operands (dims lq*8 + 0..3 | + 4..7)
     const float* qb = q + (int64_t)b * q_sb + h * HD + lq * 8;
 #pragma unroll
     for (int m = 0; m < AQB; ++m) {
@@ -69,6 +138,10 @@ __global__ __launch_bounds__(256) void hs_attn_kernel(const float* __restrict__ 
         const float rn = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
         qf[m][0] = a.x * rn; qf[m][1] = a.y * rn; qf[m][2] = a.z * rn; qf[m][3] = a.w * rn;
         qf[m][4] = c.x * rn; qf[m][5] = c.y * rn; qf[m][6] = c.z * rn; qf[m][7] = c.w * rn;
+        if constexpr (BF) {
+            qh[m][0] = pack4(qf[m][0], qf[m][1], qf[m][2], qf[m][3]);
+            qh[m][1] = pack4(qf[m][4], qf[m][5], qf[m][6], qf[m][7]);
+        }
     }
     // per-row mask enable: rows whose keys are all masked attend everywhere (DEC:618)
     bool use_mask[AQB];
@@ -91,29 +164,20 @@ __global__ __launch_bounds__(256) void hs_attn_kernel(const float* __restrict__ 
     const int nkb = (S + 15) / 16;
     const int kb_per = (nkb + nsplit - 1) / nsplit;
     const int kb_beg = split * kb_per, kb_end = min(nkb, kb_beg + kb_per);
-    const float* kbp = k + (int64_t)b * k_sb + h * HD + lq * 8;
-    const float* vbp = v + (int64_t)b * v_sb + h * HD + lj;
+    const KVT* kbp = k + (int64_t)b * k_sb + h * HD + lq * 8;
+    const KVT* vbp = v + (int64_t)b * v_sb + h * HD + lj;
     const bool mask_vec = (S % 4) == 0;
 
     // Software prefetch: the K / V fragments and the 7 mask words of key block kb+4 are fetched (from
     // clamped, always-valid addresses) before the 112 MFMAs of block kb, pinned with sched_barrier.
     struct Frag {
-        float4 ka, kc;
-        float v[4][2];
+        KVRaw<KVT> kv;
         uint32_t mw[AQB];
     };
     auto fetch = [&](int kb, Frag& f) {
         const int key_a = min(kb * 16 + lj, S - 1);
-        const float* kp = kbp + (int64_t)key_a * ldk;
-        f.ka = *reinterpret_cast<const float4*>(kp);
-        f.kc = *reinterpret_cast<const float4*>(kp + 4);
         const int key_c0 = kb * 16 + lq * 4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float* vp = vbp + (int64_t)min(key_c0 + r, S - 1) * ldv;
-            f.v[r][0] = vp[0];
-            f.v[r][1] = vp[16];
-        }
+        kv_fetch(f.kv, kbp + (int64_t)key_a * ldk, vbp, ldv, key_c0, S);
 #pragma unroll
         for (int m = 0; m < AQB; ++m) {
             uint32_t w = 0;
@@ -132,18 +196,30 @@ __global__ __launch_bounds__(256) void hs_attn_kernel(const float* __restrict__ 
     };
     const float k2 = kappa * 1.4426950408889634f;   // kappa * log2(e)
     auto consume = [&](int kb, const Frag& f) {
-        const float4 a = f.ka, c = f.kc;
-        float ss = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
+        float kr[8];
+        k_floats(f.kv, kr);
+        float ss = (kr[0] * kr[0] + kr[1] * kr[1] + kr[2] * kr[2] + kr[3] * kr[3]) + (kr[4] * kr[4] + kr[5] * kr[5] + kr[6] * kr[6] + kr[7] * kr[7]);
         ss += __shfl_xor(ss, 16, 64);
         ss += __shfl_xor(ss, 32, 64);
         const float rn = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-        const float kf[8] = {a.x * rn, a.y * rn, a.z * rn, a.w * rn, c.x * rn, c.y * rn, c.z * rn, c.w * rn};
+        const float kf[8] = {kr[0] * rn, kr[1] * rn, kr[2] * rn, kr[3] * rn, kr[4] * rn, kr[5] * rn, kr[6] * rn, kr[7] * rn};
+        bf16x4 kh[2], vb[2];
+        if constexpr (BF) {
+            kh[0] = pack4(kf[0], kf[1], kf[2], kf[3]);
+            kh[1] = pack4(kf[4], kf[5], kf[6], kf[7]);
+            v_operands(f.kv, vb);
+        }
         const int key_c0 = kb * 16 + lq * 4;
 #pragma unroll
         for (int m = 0; m < AQB; ++m) {
             f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (BF) {
+                s = mfma_bf16(kh[0], qh[m][0], s);
+                s = mfma_bf16(kh[1], qh[m][1], s);
+            } else {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) s = mfma16(kf[t], qf[m][t], s);
+                for (int t = 0; t < 8; ++t) s = mfma16(kf[t], qf[m][t], s);
+            }
             // s[r]: key key_c0 + r, query q0 + m*16 + lj
             const uint32_t mw = use_mask[m] ? f.mw[m] : 0u;
             float p[4];
@@ -155,10 +231,16 @@ __global__ __launch_bounds__(256) void hs_attn_kernel(const float* __restrict__ 
                 p[r] = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], k2, -k2));
             }
             lsum[m] += (p[0] + p[1]) + (p[2] + p[3]);
+            if constexpr (BF) {
+                const bf16x4 pp = pack4(p[0], p[1], p[2], p[3]);
+                o[m][0] = mfma_bf16(pp, vb[0], o[m][0]);
+                o[m][1] = mfma_bf16(pp, vb[1], o[m][1]);
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                o[m][0] = mfma16(p[r], f.v[r][0], o[m][0]);
-                o[m][1] = mfma16(p[r], f.v[r][1], o[m][1]);
+                for (int r = 0; r < 4; ++r) {
+                    o[m][0] = mfma16(p[r], v_float(f.kv, r, 0), o[m][0]);
+                    o[m][1] = mfma16(p[r], v_float(f.kv, r, 1), o[m][1]);
+                }
             }
         }
     };
@@ -389,9 +471,9 @@ __global__ __launch_bounds__(256) void hs_attn_small_kernel(const float* __restr
 // partial sums meet in LDS (lane-contiguous, 9 values per lane and query block) and wave 0 finishes in registers.  No
 // partial tensors in memory, no combine launch; K/V of an (image, head) are re-read by the ceil(7/MQ) workgroups of that
 // head out of L2.
-template <int MQ, int NW>
-__global__ __launch_bounds__(NW * 64) void hs_attn_qk_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                            const float* __restrict__ v, const uint8_t* __restrict__ masked,
+template <int MQ, int NW, typename KVT, bool BF>
+__global__ __launch_bounds__(NW * 64) void hs_attn_qk_kernel(const float* __restrict__ q, const KVT* __restrict__ k,
+                                                            const KVT* __restrict__ v, const uint8_t* __restrict__ masked,
                                                             const int32_t* __restrict__ row_any, float* __restrict__ out, int Lq,
                                                             int S, int heads, int64_t ldq, int64_t q_sb, int64_t ldk,
                                                             int64_t k_sb, int64_t ldv, int64_t v_sb, float kappa) {
@@ -403,6 +485,7 @@ __global__ __launch_bounds__(NW * 64) void hs_attn_qk_kernel(const float* __rest
     const int qb0 = blockIdx.x * MQ;                            // first 16-query block of this workgroup (all waves)
 
     float qf[MQ][8];
+    bf16x4 qh[BF ? MQ : 1][2];
     bool use_mask[MQ];
     const float* qbp = q + (int64_t)b * q_sb + h * HD + lq * 8;
 #pragma unroll
@@ -420,6 +503,10 @@ __global__ __launch_bounds__(NW * 64) void hs_attn_qk_kernel(const float* __rest
         const float rn = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
         qf[m][0] = a.x * rn; qf[m][1] = a.y * rn; qf[m][2] = a.z * rn; qf[m][3] = a.w * rn;
         qf[m][4] = c.x * rn; qf[m][5] = c.y * rn; qf[m][6] = c.z * rn; qf[m][7] = c.w * rn;
+        if constexpr (BF) {
+            qh[m][0] = pack4(qf[m][0], qf[m][1], qf[m][2], qf[m][3]);
+            qh[m][1] = pack4(qf[m][4], qf[m][5], qf[m][6], qf[m][7]);
+        }
         use_mask[m] = masked != nullptr && qi < Lq && (row_any == nullptr || row_any[(int64_t)b * Lq + qi] != 0);   // DEC:618
     }
     f32x4 o[MQ][2];
@@ -430,25 +517,16 @@ __global__ __launch_bounds__(NW * 64) void hs_attn_qk_kernel(const float* __rest
         lsum[m] = 0.f;
     }
     const int nkb = (S + 15) / 16;
-    const float* kbp = k + (int64_t)b * k_sb + h * HD + lq * 8;
-    const float* vbp = v + (int64_t)b * v_sb + h * HD + lj;
+    const KVT* kbp = k + (int64_t)b * k_sb + h * HD + lq * 8;
+    const KVT* vbp = v + (int64_t)b * v_sb + h * HD + lj;
     const bool mask_vec = (S % 4) == 0;
     struct Frag {
-        float4 ka, kc;
-        float v[4][2];
+        KVRaw<KVT> kv;
         uint32_t mw[MQ];
     };
     auto fetch = [&](int kb, Frag& f) {
-        const float* kp = kbp + (int64_t)min(kb * 16 + lj, S - 1) * ldk;
-        f.ka = *reinterpret_cast<const float4*>(kp);
-        f.kc = *reinterpret_cast<const float4*>(kp + 4);
         const int key_c0 = kb * 16 + lq * 4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float* vp = vbp + (int64_t)min(key_c0 + r, S - 1) * ldv;
-            f.v[r][0] = vp[0];
-            f.v[r][1] = vp[16];
-        }
+        kv_fetch(f.kv, kbp + (int64_t)min(kb * 16 + lj, S - 1) * ldk, vbp, ldv, key_c0, S);
 #pragma unroll
         for (int m = 0; m < MQ; ++m) {
             uint32_t w = 0;
@@ -466,20 +544,34 @@ __global__ __launch_bounds__(NW * 64) void hs_attn_qk_kernel(const float* __rest
     };
     const float k2 = kappa * 1.4426950408889634f;
     auto consume = [&](int kb, const Frag& f) {
-        const float4 a = f.ka, c = f.kc;
-        float ss = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
+        float kr[8];
+        k_floats(f.kv, kr);
+        float ss = (kr[0] * kr[0] + kr[1] * kr[1] + kr[2] * kr[2] + kr[3] * kr[3]) + (kr[4] * kr[4] + kr[5] * kr[5] + kr[6] * kr[6] + kr[7] * kr[7]);
         ss += __shfl_xor(ss, 16, 64);
         ss += __shfl_xor(ss, 32, 64);
         const float rn = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-        const float kf[8] = {a.x * rn, a.y * rn, a.z * rn, a.w * rn, c.x * rn, c.y * rn, c.z * rn, c.w * rn};
+        const float kf[8] = {kr[0] * rn, kr[1] * rn, kr[2] * rn, kr[3] * rn, kr[4] * rn, kr[5] * rn, kr[6] * rn, kr[7] * rn};
+        bf16x4 kh[2], vb[2];
+        if constexpr (BF) {
+            kh[0] = pack4(kf[0], kf[1], kf[2], kf[3]);
+            kh[1] = pack4(kf[4], kf[5], kf[6], kf[7]);
+            v_operands(f.kv, vb);
+        }
         const int key_c0 = kb * 16 + lq * 4;
         f32x4 sc[MQ];
 #pragma unroll
         for (int m = 0; m < MQ; ++m) sc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (BF) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int m = 0; m < MQ; ++m) sc[m] = mfma16(kf[t], qf[m][t], sc[m]);
+                for (int m = 0; m < MQ; ++m) sc[m] = mfma_bf16(kh[c], qh[m][c], sc[m]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int m = 0; m < MQ; ++m) sc[m] = mfma16(kf[t], qf[m][t], sc[m]);
+        }
 #pragma unroll
         for (int m = 0; m < MQ; ++m) {
             const uint32_t mw = use_mask[m] ? f.mw[m] : 0u;
@@ -490,10 +582,16 @@ __global__ __launch_bounds__(NW * 64) void hs_attn_qk_kernel(const float* __rest
                 p[r] = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(sc[m][r], k2, -k2));
             }
             lsum[m] += (p[0] + p[1]) + (p[2] + p[3]);
+            if constexpr (BF) {
+                const bf16x4 pp = pack4(p[0], p[1], p[2], p[3]);
+                o[m][0] = mfma_bf16(pp, vb[0], o[m][0]);
+                o[m][1] = mfma_bf16(pp, vb[1], o[m][1]);
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                o[m][0] = mfma16(p[r], f.v[r][0], o[m][0]);
-                o[m][1] = mfma16(p[r], f.v[r][1], o[m][1]);
+                for (int r = 0; r < 4; ++r) {
+                    o[m][0] = mfma16(p[r], v_float(f.kv, r, 0), o[m][0]);
+                    o[m][1] = mfma16(p[r], v_float(f.kv, r, 1), o[m][1]);
+                }
             }
         }
     };
@@ -632,43 +730,46 @@ extern "C" int64_t msm_hypersphere_attn_workspace(int B, int Lq, int S, int head
     return (int64_t)B * qchunks * heads * ns * AQCH * PSTRIDE;
 }
 
-extern "C" int msm_hypersphere_attn_fwd(const float* q, const float* k, const float* v, const uint8_t* masked,
-                                        const int32_t* row_any, float* out, int B, int Lq, int S, int heads,
-                                        int64_t ldq, int64_t q_sb, int64_t ldk, int64_t k_sb, int64_t ldv,
-                                        int64_t v_sb, float kappa, float* workspace, int64_t workspace_elems,
-                                        void* stream) {
-    MSM_REQUIRE(q && k && v && out && workspace, "msm_hypersphere_attn_fwd: null pointer");
-    MSM_REQUIRE(B > 0 && Lq > 0 && S > 0 && heads > 0, "msm_hypersphere_attn_fwd: bad sizes");
-    MSM_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && q_sb % 4 == 0 && k_sb % 4 == 0 && (((uintptr_t)q) & 15) == 0 &&
-                    (((uintptr_t)k) & 15) == 0,
-                "msm_hypersphere_attn_fwd: q/k must be 16-byte aligned with strides multiple of 4");
-    MSM_REQUIRE(!masked || (((uintptr_t)masked) & 3) == 0, "msm_hypersphere_attn_fwd: mask must be 4-byte aligned");
+// KVT / BF: see the low-precision note above the kernels.  (The one-wave-per-query-block kernel, an opt-in experiment, exists
+// in fp32 only.)
+template <typename KVT, bool BF>
+static int attn_launch(const char* who, const float* q, const KVT* k, const KVT* v, const uint8_t* masked, const int32_t* row_any, float* out,
+                       int B, int Lq, int S, int heads, int64_t ldq, int64_t q_sb, int64_t ldk, int64_t k_sb, int64_t ldv, int64_t v_sb,
+                       float kappa, float* workspace, int64_t workspace_elems, void* stream) {
+    MSM_REQUIRE(q && k && v && out && workspace, "%s: null pointer", who);
+    MSM_REQUIRE(B > 0 && Lq > 0 && S > 0 && heads > 0, "%s: bad sizes", who);
+    constexpr int KA = 16 / (int)sizeof(KVT);      // elements per 16 bytes of K
+    MSM_REQUIRE(ldq % 4 == 0 && ldk % KA == 0 && q_sb % 4 == 0 && k_sb % KA == 0 && (((uintptr_t)q) & 15) == 0 && (((uintptr_t)k) & 15) == 0,
+                "%s: q/k must be 16-byte aligned with row / batch strides that keep them so", who);
+    MSM_REQUIRE(!masked || (((uintptr_t)masked) & 3) == 0, "%s: mask must be 4-byte aligned", who);
     const int qchunks = cdiv(Lq, AQCH);
     const int ns = attn_nsplit(B, qchunks, heads, S);
     const int64_t need = (int64_t)B * qchunks * heads * ns * AQCH * PSTRIDE;
     if (workspace_elems < need) {
-        set_error("msm_hypersphere_attn_fwd: workspace %lld < %lld floats", (long long)workspace_elems, (long long)need);
+        set_error("%s: workspace %lld < %lld floats", who, (long long)workspace_elems, (long long)need);
         return MSM_E_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
     const int force = opt(MSM_OPT_ATTN_KERNEL);
-    if (S <= 512 && (force == 1 || force == 2)) {
-        // query-split kernel, one wave per query block walking all keys, finished in registers.  Not the default any
-        // more: a lone wave per SIMD exposes every dependency of a key block (~0.9 us per block whatever the load
-        // ring depth), and with the host out of the way (HIP-graph timing) the key-split kernel below is faster down to
-        // the shortest sequences: 300 keys 11.0 against 19.9 us, 100 keys (self-attention) 8.0 against 9.4 us.
-        const int qblocks = cdiv(Lq, 16);
-        if (force == 2 && S <= 128) {
-            dim3 grid(cdiv(qblocks, 8), heads, B);
-            hipLaunchKernelGGL((hs_attn_small_kernel<2>), grid, dim3(256), 0, st, q, k, v, masked, row_any, out, Lq, S, heads, ldq,
-                               q_sb, ldk, k_sb, ldv, v_sb, kappa);
-        } else {
-            dim3 grid(cdiv(qblocks, 4), heads, B);
-            hipLaunchKernelGGL((hs_attn_small_kernel<1>), grid, dim3(256), 0, st, q, k, v, masked, row_any, out, Lq, S, heads, ldq,
-                               q_sb, ldk, k_sb, ldv, v_sb, kappa);
+    if constexpr (std::is_same<KVT, float>::value && !BF) {
+        if (S <= 512 && (force == 1 || force == 2)) {
+            // query-split kernel, one wave per query block walking all keys, finished in registers.  Not the default any
+            // more: a lone wave per SIMD exposes every dependency of a key block (~0.9 us per block whatever the load
+            // ring depth), and with the host out of the way (HIP-graph timing) the key-split kernel below is faster down to
+            // the shortest sequences: 300 keys 11.0 against 19.9 us, 100 keys (self-attention) 8.0 against 9.4 us.
+            const int qblocks = cdiv(Lq, 16);
+            if (force == 2 && S <= 128) {
+                dim3 grid(cdiv(qblocks, 8), heads, B);
+                hipLaunchKernelGGL((hs_attn_small_kernel<2>), grid, dim3(256), 0, st, q, k, v, masked, row_any, out, Lq, S, heads, ldq,
+                                   q_sb, ldk, k_sb, ldv, v_sb, kappa);
+            } else {
+                dim3 grid(cdiv(qblocks, 4), heads, B);
+                hipLaunchKernelGGL((hs_attn_small_kernel<1>), grid, dim3(256), 0, st, q, k, v, masked, row_any, out, Lq, S, heads, ldq,
+                                   q_sb, ldk, k_sb, ldv, v_sb, kappa);
+            }
+            MSM_CHECK_LAUNCH("msm_hypersphere_attn_fwd(small)");
+            return MSM_OK;
         }
-        MSM_CHECK_LAUNCH("msm_hypersphere_attn_fwd(small)");
-        return MSM_OK;
     }
     const int qk_max = opt(MSM_OPT_ATTN_QK_MAX) > 0 ? opt(MSM_OPT_ATTN_QK_MAX) : 2048;
     if (S <= qk_max && force != 3) {
@@ -679,31 +780,52 @@ extern "C" int msm_hypersphere_attn_fwd(const float* q, const float* k, const fl
         // one query block per workgroup for the shortest sequences (self-attention, 100 keys: 6.9 against 8.0 us), two
         // otherwise (K/V are read by half as many workgroups); other shapes measured slower at every length
         const int cfg = cfg_env >= 0 ? cfg_env : (S <= 128 ? 1 : 0);
-#define QK_LAUNCH(MQ_, NW_)                                                                                            \
-    {                                                                                                                  \
-        dim3 grid(cdiv(cdiv(Lq, 16), MQ_), heads, B);                                                                  \
-        const size_t lds2 = sizeof(float) * (size_t)(NW_ - 1) * MQ_ * 9 * 64;                                          \
-        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)hs_attn_qk_kernel<MQ_, NW_>, lds2));                 \
-        hipLaunchKernelGGL((hs_attn_qk_kernel<MQ_, NW_>), grid, dim3(NW_ * 64), lds2, st, q, k, v, masked, row_any, out, Lq, S, \
-                           heads, ldq, q_sb, ldk, k_sb, ldv, v_sb, kappa);                                             \
+#define QK_LAUNCH(MQ_, NW_)                                                                                                     \
+    {                                                                                                                           \
+        dim3 grid(cdiv(cdiv(Lq, 16), MQ_), heads, B);                                                                           \
+        const size_t lds2 = sizeof(float) * (size_t)(NW_ - 1) * MQ_ * 9 * 64;                                                   \
+        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)hs_attn_qk_kernel<MQ_, NW_, KVT, BF>, lds2));                 \
+        hipLaunchKernelGGL((hs_attn_qk_kernel<MQ_, NW_, KVT, BF>), grid, dim3(NW_ * 64), lds2, st, q, k, v, masked, row_any, out, Lq, S, \
+                           heads, ldq, q_sb, ldk, k_sb, ldv, v_sb, kappa);                                                      \
     }
         switch (cfg) {
             case 1: QK_LAUNCH(1, 8) break;
             default: QK_LAUNCH(2, 8) break;
         }
 #undef QK_LAUNCH
-        MSM_CHECK_LAUNCH("msm_hypersphere_attn_fwd(qk)");
+        MSM_CHECK_LAUNCH(who);
         return MSM_OK;
     }
     const size_t lds = sizeof(float) * 4 * AQCH * PSTRIDE;
-    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)hs_attn_kernel, lds));
+    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)hs_attn_kernel<KVT, BF>, lds));
     dim3 grid(ns, heads, B * qchunks), block(256);
-    hipLaunchKernelGGL(hs_attn_kernel, grid, block, lds, st, q, k, v, masked, row_any, workspace, out, Lq, S, heads, qchunks,
+    hipLaunchKernelGGL((hs_attn_kernel<KVT, BF>), grid, block, lds, st, q, k, v, masked, row_any, workspace, out, Lq, S, heads, qchunks,
                        ns, ldq, q_sb, ldk, k_sb, ldv, v_sb, kappa);
-    MSM_CHECK_LAUNCH("msm_hypersphere_attn_fwd");
+    MSM_CHECK_LAUNCH(who);
     if (ns == 1) return MSM_OK;
     dim3 g2(heads, B * qchunks), b2(256);
     hipLaunchKernelGGL(hs_attn_combine_kernel, g2, b2, 0, st, workspace, out, Lq, heads, qchunks, ns);
-    MSM_CHECK_LAUNCH("msm_hypersphere_attn_fwd(combine)");
+    MSM_CHECK_LAUNCH(who);
     return MSM_OK;
+}
+
+extern "C" int msm_hypersphere_attn_fwd(const float* q, const float* k, const float* v, const uint8_t* masked,
+                                        const int32_t* row_any, float* out, int B, int Lq, int S, int heads,
+                                        int64_t ldq, int64_t q_sb, int64_t ldk, int64_t k_sb, int64_t ldv,
+                                        int64_t v_sb, float kappa, float* workspace, int64_t workspace_elems,
+                                        void* stream) {
+    return attn_launch<float, false>("msm_hypersphere_attn_fwd", q, k, v, masked, row_any, out, B, Lq, S, heads, ldq, q_sb, ldk, k_sb, ldv, v_sb,
+                                     kappa, workspace, workspace_elems, stream);
+}
+
+extern "C" int msm_hypersphere_attn_lp_fwd(const float* q, const void* k, const void* v, int kv_bf16, const uint8_t* masked,
+                                           const int32_t* row_any, float* out, int B, int Lq, int S, int heads,
+                                           int64_t ldq, int64_t q_sb, int64_t ldk, int64_t k_sb, int64_t ldv,
+                                           int64_t v_sb, float kappa, float* workspace, int64_t workspace_elems,
+                                           void* stream) {
+    if (kv_bf16)
+        return attn_launch<uint16_t, true>("msm_hypersphere_attn_lp_fwd", q, (const uint16_t*)k, (const uint16_t*)v, masked, row_any, out, B, Lq, S,
+                                           heads, ldq, q_sb, ldk, k_sb, ldv, v_sb, kappa, workspace, workspace_elems, stream);
+    return attn_launch<float, true>("msm_hypersphere_attn_lp_fwd", q, (const float*)k, (const float*)v, masked, row_any, out, B, Lq, S, heads, ldq,
+                                    q_sb, ldk, k_sb, ldv, v_sb, kappa, workspace, workspace_elems, stream);
 }

@@ -17,6 +17,9 @@
 //   * units are ordered image-fastest, so the 8 images of a position tile read the same cmat rows out of L2.
 // Measured (B = 8, 60x80): 36-39 us against 62-66 us for the tiled GEMM; with the MFMAs removed the kernel still
 // takes 29 us, i.e. it now sits on the 98 MB it has to move (79 MB of them written).
+#include <type_traits>
+
+#include "bf16.h"
 #include "common.h"
 
 namespace msm {
@@ -26,9 +29,12 @@ constexpr int KP_LD = KP_K + 4;      // LDS row stride of w (floats): 16 rows x 
 constexpr int KP_FB = 16;            // feature blocks (of 16) per unit: 256 features
 constexpr int KP_W = 16;             // waves per workgroup (one workgroup per CU: w takes 136 KiB of LDS)
 
-// the projection of ONE (level, layer) job by workgroup `wg` of the `nwg` workgroups assigned to it
+// the projection of ONE (level, layer) job by workgroup `wg` of the `nwg` workgroups assigned to it.
+// OT = float, or uint16_t: the result is stored as bf16 (low-precision mode: half the bytes of this write-bound kernel and of
+// the attention kernels' K/V reads; the products are still exact fp32 MFMAs, only the stored value is rounded)
+template <typename OT>
 __device__ __forceinline__ void kv_project_body(const float* __restrict__ x, const float* __restrict__ w,
-                                                const float* __restrict__ cmat, float* __restrict__ out, int B, int HW, int N,
+                                                const float* __restrict__ cmat, OT* __restrict__ out, int B, int HW, int N,
                                                 int tokens, int64_t x_sb, int wg, int nwg, float* wl) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -80,7 +86,7 @@ __device__ __forceinline__ void kv_project_body(const float* __restrict__ x, con
         const bool live = tile * 16 + lj < HW;
         const int n_base = half * KP_FB * 16;
         const float* cp = cmat + (int64_t)p * N + n_base + lq * 4;
-        float* op = out + ((int64_t)img * HW + p) * N + n_base + lq * 4;
+        OT* op = out + ((int64_t)img * HW + p) * N + n_base + lq * 4;
         const float* wp = wl + (n_base + lj) * KP_LD + lq * 16;
         // everything this unit reads from memory is requested before its first MFMA; the next unit's x rides along
         float4 cm[KP_FB];
@@ -107,8 +113,13 @@ __device__ __forceinline__ void kv_project_body(const float* __restrict__ x, con
                 a1 = mfma16(w1.w, xb[s4 * 4 + 3], a1);
             }
             if (live) {
-                *reinterpret_cast<float4*>(op + fb * 16) = make_float4(a0[0], a0[1], a0[2], a0[3]);
-                *reinterpret_cast<float4*>(op + (fb + 1) * 16) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+                if constexpr (std::is_same<OT, float>::value) {
+                    *reinterpret_cast<float4*>(op + fb * 16) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+                    *reinterpret_cast<float4*>(op + (fb + 1) * 16) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+                } else {
+                    *reinterpret_cast<bf16x4*>(op + fb * 16) = pack4(a0[0], a0[1], a0[2], a0[3]);
+                    *reinterpret_cast<bf16x4*>(op + (fb + 1) * 16) = pack4(a1[0], a1[1], a1[2], a1[3]);
+                }
             }
         }
 #pragma unroll
@@ -120,7 +131,7 @@ __global__ __launch_bounds__(KP_W * 64) void kv_project_kernel(const float* __re
                                                          const float* __restrict__ cmat, float* __restrict__ out, int B,
                                                          int HW, int N, int tokens, int64_t x_sb) {
     extern __shared__ __attribute__((aligned(16))) float wl[];   // [N][KP_LD]
-    kv_project_body(x, w, cmat, out, B, HW, N, tokens, x_sb, blockIdx.x, gridDim.x, wl);
+    kv_project_body<float>(x, w, cmat, out, B, HW, N, tokens, x_sb, blockIdx.x, gridDim.x, wl);
 }
 
 // All K/V projections of the decoder (one job per cross-attention layer: its level's features, its folded weight and
@@ -134,16 +145,17 @@ struct KvJobs {
     const float* x[KP_MAXJ];
     const float* w[KP_MAXJ];
     const float* cmat[KP_MAXJ];
-    float* out[KP_MAXJ];
+    void* out[KP_MAXJ];
     int HW[KP_MAXJ], tokens[KP_MAXJ], first[KP_MAXJ + 1];
     int64_t x_sb[KP_MAXJ];
 };
+template <typename OT>
 __global__ __launch_bounds__(KP_W * 64) void kv_project_multi_kernel(KvJobs jobs, int B, int N) {
     extern __shared__ __attribute__((aligned(16))) float wl[];   // [N][KP_LD]
     int j = 0;
 #pragma unroll
     for (int i = 1; i < KP_MAXJ; ++i) j += (i < jobs.n && (int)blockIdx.x >= jobs.first[i]) ? 1 : 0;
-    kv_project_body(jobs.x[j], jobs.w[j], jobs.cmat[j], jobs.out[j], B, jobs.HW[j], N, jobs.tokens[j], jobs.x_sb[j],
+    kv_project_body<OT>(jobs.x[j], jobs.w[j], jobs.cmat[j], (OT*)jobs.out[j], B, jobs.HW[j], N, jobs.tokens[j], jobs.x_sb[j],
                     (int)blockIdx.x - jobs.first[j], jobs.first[j + 1] - jobs.first[j], wl);
 }
 
@@ -282,22 +294,23 @@ extern "C" int msm_kv_project_f32(const float* x, const float* w, const float* c
     return MSM_OK;
 }
 
-extern "C" int msm_kv_project_multi_f32(int n_jobs, const float* const* x, const float* const* w, const float* const* cmat,
-                                        float* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride,
-                                        int B, int C, int N, void* stream) {
+template <typename OT>
+static int kv_project_multi_impl(const char* who, int n_jobs, const float* const* x, const float* const* w, const float* const* cmat,
+                                 OT* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride, int B, int C,
+                                 int N, void* stream) {
     MSM_REQUIRE(n_jobs >= 1 && n_jobs <= KP_MAXJ && x && w && cmat && out && HW && x_tokens && x_batch_stride,
-                "msm_kv_project_multi_f32: bad arguments (1..%d jobs)", KP_MAXJ);
-    MSM_REQUIRE(C == KP_K, "msm_kv_project_multi_f32: C=%d, only 64 input channels are supported", C);
-    MSM_REQUIRE(B > 0 && N > 0 && N % (KP_FB * 16) == 0 && N <= 512, "msm_kv_project_multi_f32: N=%d must be 256 or 512", N);
+                "%s: bad arguments (1..%d jobs)", who, KP_MAXJ);
+    MSM_REQUIRE(C == KP_K, "%s: C=%d, only 64 input channels are supported", who, C);
+    MSM_REQUIRE(B > 0 && N > 0 && N % (KP_FB * 16) == 0 && N <= 512, "%s: N=%d must be 256 or 512", who, N);
     KvJobs jobs;
     jobs.n = n_jobs;
     int64_t total = 0;
     for (int j = 0; j < n_jobs; ++j) {
-        MSM_REQUIRE(x[j] && w[j] && cmat[j] && out[j] && HW[j] > 0, "msm_kv_project_multi_f32: job %d: null pointer or empty level", j);
+        MSM_REQUIRE(x[j] && w[j] && cmat[j] && out[j] && HW[j] > 0, "%s: job %d: null pointer or empty level", who, j);
         MSM_REQUIRE(((((uintptr_t)w[j]) | ((uintptr_t)cmat[j]) | ((uintptr_t)out[j])) & 15) == 0 && (((uintptr_t)x[j]) & 3) == 0,
-                    "msm_kv_project_multi_f32: job %d: w/cmat/out must be 16-byte aligned", j);
+                    "%s: job %d: w/cmat/out must be 16-byte aligned", who, j);
         MSM_REQUIRE(x_batch_stride[j] >= (int64_t)C * HW[j] && (!x_tokens[j] || ((((uintptr_t)x[j]) & 15) == 0 && x_batch_stride[j] % 4 == 0)),
-                    "msm_kv_project_multi_f32: job %d: bad x batch stride / alignment", j);
+                    "%s: job %d: bad x batch stride / alignment", who, j);
         total += HW[j];
     }
     // workgroups: 256 shared out in proportion to the tokens of a job, at least one each, never more than a job has units / 4
@@ -317,10 +330,21 @@ extern "C" int msm_kv_project_multi_f32(int n_jobs, const float* const* x, const
         jobs.HW[j] = jobs.tokens[j] = 0; jobs.x_sb[j] = 0;
     }
     const size_t lds = sizeof(float) * (size_t)N * KP_LD;
-    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)kv_project_multi_kernel, lds));
-    hipLaunchKernelGGL(kv_project_multi_kernel, dim3(wg), dim3(KP_W * 64), lds, (hipStream_t)stream, jobs, B, N);
-    MSM_CHECK_LAUNCH("msm_kv_project_multi_f32");
+    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)kv_project_multi_kernel<OT>, lds));
+    hipLaunchKernelGGL(kv_project_multi_kernel<OT>, dim3(wg), dim3(KP_W * 64), lds, (hipStream_t)stream, jobs, B, N);
+    MSM_CHECK_LAUNCH(who);
     return MSM_OK;
+}
+
+extern "C" int msm_kv_project_multi_f32(int n_jobs, const float* const* x, const float* const* w, const float* const* cmat,
+                                        float* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride,
+                                        int B, int C, int N, void* stream) {
+    return kv_project_multi_impl<float>("msm_kv_project_multi_f32", n_jobs, x, w, cmat, out, HW, x_tokens, x_batch_stride, B, C, N, stream);
+}
+extern "C" int msm_kv_project_multi_bf16(int n_jobs, const float* const* x, const float* const* w, const float* const* cmat,
+                                         uint16_t* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride,
+                                         int B, int C, int N, void* stream) {
+    return kv_project_multi_impl<uint16_t>("msm_kv_project_multi_bf16", n_jobs, x, w, cmat, out, HW, x_tokens, x_batch_stride, B, C, N, stream);
 }
 
 extern "C" int msm_tokens_proj_nchw_f32(const float* x, const float* w, const float* bias, const double* gn_stats,

@@ -104,8 +104,9 @@ class MeanShiftMaskFormerHead(nn.Module):
         if hasattr(self.pixel_decoder, "precision"):
             self.pixel_decoder.precision = mode
         self.predictor.mask_step_dtype = mode
-        if hasattr(self.predictor, "tails_dtype"):
-            self.predictor.tails_dtype = mode
+        for a in ("tails_dtype", "attention_dtype"):
+            if hasattr(self.predictor, a):
+                setattr(self.predictor, a, mode)
         return self
 
     def layers(self, features, image_height=None, image_width=None, mask=None):

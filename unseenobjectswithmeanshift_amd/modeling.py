@@ -275,6 +275,9 @@ class MeanShiftTransformerDecoder(nn.Module):
         # "bf16": the fused row-local tails (dec_post_cross / dec_post_self / dec_heads) stream bf16 weights and multiply on
         # bf16 MFMAs with fp32 accumulation (activations as hi + lo pairs); part of set_precision("bf16")
         self.tails_dtype = "f32"
+        # "bf16": the attention cores multiply on bf16 MFMAs (fp32 accumulation, exp, sums) and the batched K/V projection
+        # stores bf16; part of set_precision("bf16")
+        self.attention_dtype = "f32"
         self._packed_mf = None
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
@@ -451,10 +454,11 @@ class MeanShiftTransformerDecoder(nn.Module):
                 kv = kv_all[i]
             else:
                 kv = ops.kv_project(xs[lvl], kv_w[i], kv_c[i])        # (B, hw, 2E) = [K | V]
-            o = ops.hypersphere_attention(q, kv[..., :E], kv[..., E:], H, masked=attn, row_any=row_any, kappa=float(KAPPA))
+            lp = self.attention_dtype == "bf16"
+            o = ops.hypersphere_attention(q, kv[..., :E], kv[..., E:], H, masked=attn, row_any=row_any, kappa=float(KAPPA), low_precision=lp)
             x, qk, v = ops.dec_post_cross(o, out, qpos, pk["cross_o"][i], ca.meanshift_attn.out_proj.bias, ca.norm.weight,
                                           ca.norm.bias, pk["self_in"][i], sa.self_attn.in_proj_bias)
-            o = ops.hypersphere_attention(qk[..., :E], qk[..., E:], v, H, kappa=float(KAPPA))
+            o = ops.hypersphere_attention(qk[..., :E], qk[..., E:], v, H, kappa=float(KAPPA), low_precision=lp)
             x, parts = ops.dec_post_self(o, x, pk["self_o"][i], sa.self_attn.out_proj.bias, sa.norm.weight, sa.norm.bias,
                                          pk["ffn1"][i], ff.linear1.bias, pk["ffn2"][i])
             last = i == L - 1
@@ -488,7 +492,8 @@ class MeanShiftTransformerDecoder(nn.Module):
                                                       for i in range(self.num_layers))
             if (self.batched_kv and self.num_layers <= 16 and kv_bytes <= (2 << 30) and all(xl.shape[1] == 64 for xl in xs)
                     and kv_w[0].shape[0] in (256, 512)):       # all layers' K/V live at once: only while that stays small
-                kv_all = ops.kv_project_multi([xs[i % self.num_feature_levels] for i in range(self.num_layers)], kv_w, kv_c)
+                kv_all = ops.kv_project_multi([xs[i % self.num_feature_levels] for i in range(self.num_layers)], kv_w, kv_c,
+                                              out_dtype=torch.bfloat16 if self.attention_dtype == "bf16" else torch.float32)
         else:
             for i in range(self.num_feature_levels):
                 pos.append(self._pos_tokens(*sizes[i], dev))

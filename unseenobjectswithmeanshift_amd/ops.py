@@ -426,11 +426,18 @@ def mask_logits(mask_embed, mask_features, *, want_mask=True, target_size=None, 
     return mask, attn, row_any
 
 
-def hypersphere_attention(q, k, v, heads, *, masked=None, row_any=None, kappa=KAPPA):
+def hypersphere_attention(q, k, v, heads, *, masked=None, row_any=None, kappa=KAPPA, low_precision=False):
     """q (B,Lq,E), k/v (B,S,E) already projected (last dim contiguous, may be column slices of a
-    wider buffer); masked uint8 (B,Lq,S).  Returns (B,Lq,E)."""
+    wider buffer); masked uint8 (B,Lq,S).  Returns (B,Lq,E).
+    low_precision (or bf16 k / v): bf16 MFMA operands with fp32 accumulation (msm_hypersphere_attn_lp_fwd); k and v may then be
+    torch.bfloat16 (as written by kv_project_multi(..., out_dtype=torch.bfloat16)) or float32."""
+    kv_bf16 = k.dtype == torch.bfloat16
+    if kv_bf16 != (v.dtype == torch.bfloat16):
+        raise RuntimeError("k and v must have the same dtype")
+    _chk(q, "q")
+    for t, n in ((k, "k"), (v, "v")):
+        _chk(t, n, torch.bfloat16 if kv_bf16 else torch.float32)
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
-        _chk(t, n)
         if t.stride(-1) != 1:
             raise RuntimeError(f"{n}: last dim must be contiguous")
     _c(masked, "masked", torch.uint8), _c(row_any, "row_any", torch.int32)
@@ -441,6 +448,12 @@ def hypersphere_attention(q, k, v, heads, *, masked=None, row_any=None, kappa=KA
     out = torch.empty((B, Lq, E), device=q.device, dtype=torch.float32)
     need = lib().msm_hypersphere_attn_workspace(B, Lq, S, heads)
     ws = torch.empty((need,), device=q.device, dtype=torch.float32)
+    if kv_bf16 or low_precision:
+        rc = lib().msm_hypersphere_attn_lp_fwd(_p(q), _p(k), _p(v), 1 if kv_bf16 else 0, _p(masked), _p(row_any), _p(out), B, Lq, S, heads,
+                                               q.stride(1), q.stride(0), k.stride(1), k.stride(0), v.stride(1), v.stride(0),
+                                               kappa, _p(ws), need, _stream())
+        check(rc, "msm_hypersphere_attn_lp_fwd")
+        return out
     rc = lib().msm_hypersphere_attn_fwd(_p(q), _p(k), _p(v), _p(masked), _p(row_any), _p(out), B, Lq, S, heads,
                                         q.stride(1), q.stride(0), k.stride(1), k.stride(0), v.stride(1), v.stride(0),
                                         kappa, _p(ws), need, _stream())
@@ -602,9 +615,12 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     return gv, gl, gw
 
 
-def kv_project_multi(xs, ws, cmats):
+def kv_project_multi(xs, ws, cmats, out_dtype=torch.float32):
     """kv_project for a list of jobs in one launch: xs[j] (B, 64, H_j, W_j) contiguous NCHW or token-major
-    (is_token_major), ws[j] (N, 64), cmats[j] (H_j*W_j, N) -> list of (B, H_j*W_j, N).  N in {256, 512}, <= 16 jobs."""
+    (is_token_major), ws[j] (N, 64), cmats[j] (H_j*W_j, N) -> list of (B, H_j*W_j, N).  N in {256, 512}, <= 16 jobs.
+    out_dtype torch.bfloat16: the (fp32-computed) result is stored as bf16 (low-precision mode)."""
+    if out_dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("kv_project_multi: out_dtype must be float32 or bfloat16")
     n = len(xs)
     B, N = xs[0].shape[0], ws[0].shape[0]
     outs, tok, sb, hw = [], [], [], []
@@ -619,13 +635,14 @@ def kv_project_multi(xs, ws, cmats):
         tok.append(1 if t else 0)
         sb.append(x.stride(0) if t else C * H * W)
         hw.append(H * W)
-        outs.append(torch.empty((B, H * W, N), device=x.device, dtype=torch.float32))
+        outs.append(torch.empty((B, H * W, N), device=x.device, dtype=out_dtype))
     vp = ctypes.c_void_p * n
     arr = lambda ts: ctypes.cast(vp(*[t.data_ptr() for t in ts]), ctypes.c_void_p)
     ia, la = (ctypes.c_int32 * n), (ctypes.c_int64 * n)
-    rc = lib().msm_kv_project_multi_f32(n, arr(xs), arr(ws), arr(cmats), arr(outs), ctypes.cast(ia(*hw), ctypes.c_void_p),
-                                        ctypes.cast(ia(*tok), ctypes.c_void_p), ctypes.cast(la(*sb), ctypes.c_void_p), B, 64, N, _stream())
-    check(rc, "msm_kv_project_multi_f32")
+    fn = lib().msm_kv_project_multi_f32 if out_dtype == torch.float32 else lib().msm_kv_project_multi_bf16
+    rc = fn(n, arr(xs), arr(ws), arr(cmats), arr(outs), ctypes.cast(ia(*hw), ctypes.c_void_p), ctypes.cast(ia(*tok), ctypes.c_void_p),
+            ctypes.cast(la(*sb), ctypes.c_void_p), B, 64, N, _stream())
+    check(rc, "msm_kv_project_multi")
     return outs
 
 
