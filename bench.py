@@ -235,7 +235,21 @@ def extra_configs(dev, args):
     out["configs[2] per-GPU slice"] = {"workload": "batch 8 of the 64, 640x480, bf16 operands / fp32 accumulation, one HIP graph, one batch in flight",
                                        "value": round(BATCH / t, 1), "unit": "images/sec", "ms_per_step": round(1e3 * t, 3),
                                        "dtype": getattr(model, "precision", "f32 + bf16 mask step")}
-    del g, model
+    del g
+    # configs[1] again with the encoder's fp32 GEMMs on the bf16 matrix pipe (exact three-term splits, six MFMAs per product:
+    # fp32-accurate, csrc/enc_block_split.hip) -- NOT the headline: that keeps the fp32 MFMA everywhere
+    if hasattr(model, "set_precision"):
+        model.set_precision("f32_split")
+        g = model.graphed()
+        for _ in range(3):
+            g(feats, (H, W))
+        t = timed(lambda: g(feats, (H, W)), 50)
+        out["configs[1] fp32, split-bf16 encoder"] = {
+            "workload": "batch 8, 640x480, fp32; the six encoder blocks multiply exact three-term bf16 splits (6 MFMAs per product), "
+                        "one HIP graph, one batch in flight",
+            "value": round(BATCH / t, 1), "unit": "images/sec", "ms_per_step": round(1e3 * t, 3), "dtype": "f32 (split-bf16 products in the encoder)"}
+        del g
+    del model
     # configs[1] end to end: the same batch of 8 frames with the ResNet-50 backbone (stock MIOpen convolutions, frozen BN
     # folded, channels_last) in front of the hot path -- reported separately, never mixed into the hot-path figure
     from unseenobjectswithmeanshift_amd.meta_arch import build_resnet50_model
@@ -375,7 +389,7 @@ def main():
     ap.add_argument("--folded-mask", type=int, default=-1, help="1/0: contract the mask features in factored form (64-channel activation; "
                     "default: the decoder's own default, on) or literally (256-channel mask_features tensor)")
     ap.add_argument("--sparse-taps", action="store_true", help="skip mask rows that feed no attention-mask tap")
-    ap.add_argument("--precision", choices=("f32", "bf16"), default="f32",
+    ap.add_argument("--precision", choices=("f32", "f32_split", "bf16"), default="f32",
                     help="bf16 (configs 3/5) is NOT the headline configuration: the JSON line then says so in dtype")
     ap.add_argument("--batched-kv", type=int, default=-1, help="1/0: all K/V projections of the decoder in one launch (default: the decoder's own default)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
@@ -412,9 +426,9 @@ def main():
     model = build_model(dev)
     pred = model.sem_seg_head.predictor
     pred.sparse_taps = args.sparse_taps
-    if args.precision == "bf16":
+    if args.precision != "f32":
         if hasattr(model, "set_precision"):
-            model.set_precision("bf16")
+            model.set_precision(args.precision)
         else:
             pred.mask_step_dtype = "bf16"
     if args.folded_mask >= 0:

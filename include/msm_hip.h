@@ -55,7 +55,7 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 8   /* 8: bf16 decoder tails, low-precision attention and bf16 K/V projection; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
+#define MSM_ABI_VERSION 8   /* 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
 int msm_abi_version(void);
 
 /* Kernel-selection overrides for tools/ and tests/ (NOT read on the product path: every option defaults to
@@ -491,6 +491,17 @@ int64_t msm_encoder_block_bf16_stream_bytes(int d_ffn, int proj_width);
 int msm_encoder_block_bf16_fwd(const float* attn, const float* src, const void* wstream, const float* small, const float* pos,
                                float* src_out, float* value_out, float* proj_out, int M, int tokens_per_image, int d_ffn,
                                int proj_width, int value_heads, float eps, void* stream);
+
+/* The fp32 encoder-layer tail on the bf16 matrix pipe (csrc/enc_block_split.hip): every fp32 operand is split exactly into three
+ * bf16 terms and a product is the six bf16 MFMAs of weight >= 2^-18 with fp32 accumulation -- fp32-accurate results (the
+ * dropped terms are below 2^-26 of a product) at 6/16 of the fp32 MFMA's cost.  Same arguments as msm_encoder_block_bf16_fwd;
+ * wstream is the triple-split weight stream (blocks of [4 k-groups][64 lanes][4 bf16]; a logical block = its h, m, l blocks;
+ * 12 blocks per stage: output_proj | two hidden blocks [W1 h,m,l, W2 h,m,l] per stage | value_proj | four proj row blocks per
+ * stage, zero padded), msm_encoder_block_split_stream_bytes(d_ffn, proj_width) bytes. */
+int64_t msm_encoder_block_split_stream_bytes(int d_ffn, int proj_width);
+int msm_encoder_block_split_fwd(const float* attn, const float* src, const void* wstream, const float* small, const float* pos,
+                                float* src_out, float* value_out, float* proj_out, int M, int tokens_per_image, int d_ffn,
+                                int proj_width, int value_heads, float eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Label-image statistics of the two-stage harness: one pass instead of the reference's per-label

@@ -737,6 +737,52 @@ def test_encoder_block_bf16(B, S, want_next):
         assert vo is None and po is None
 
 
+@pytest.mark.parametrize("B,S,want_next", [(2, 394, True), (1, 6300, True), (3, 100, False), (8, 6300, True)])
+def test_encoder_block_split_is_fp32_accurate(B, S, want_next):
+    """msm_encoder_block_split_fwd: the fp32 encoder-layer tail computed as six bf16 MFMAs per product on exact three-term
+    splits of both operands.  It must be an fp32 kernel in everything but the instruction it multiplies with: the same
+    tolerances as test_encoder_block_fused against the plain torch fp32 chain, AND its deviation from the float64 chain must
+    not exceed the fp32-MFMA kernel's (msm_encoder_block_fwd) by more than 1.5x -- measured side by side, printed."""
+    C, DF, PW = 64, 1024, 288
+    attn, src, pos = rnd(B, S, C, seed=1), rnd(B, S, C, seed=2), rnd(S, C, seed=3)
+    wo, bo = rnd(C, C, seed=4, scale=C ** -0.5), rnd(C, seed=5, scale=0.1)
+    w1, b1 = rnd(DF, C, seed=6, scale=C ** -0.5), rnd(DF, seed=7, scale=0.1)
+    w2, b2 = rnd(C, DF, seed=8, scale=DF ** -0.5), rnd(C, seed=9, scale=0.1)
+    g1, be1, g2, be2 = 1 + 0.1 * rnd(C, seed=10), rnd(C, seed=11, scale=0.1), 1 + 0.1 * rnd(C, seed=12), rnd(C, seed=13, scale=0.1)
+    wv, bv = rnd(C, C, seed=14, scale=C ** -0.5), rnd(C, seed=15, scale=0.1)
+    wp, bp = rnd(PW, C, seed=16, scale=C ** -0.5), rnd(PW, seed=17)
+    D = lambda t: t.double()
+    x = F.layer_norm(D(src) + F.linear(D(attn), D(wo), D(bo)), (C,), D(g1), D(be1))
+    y = F.layer_norm(x + F.linear(F.relu(F.linear(x, D(w1), D(b1))), D(w2), D(b2)), (C,), D(g2), D(be2))           # float64 chain
+    d = lambda t: t.to(DEV).contiguous()
+    nxt = (d(wv), d(wp)) if want_next else (None, None)
+    small = torch.cat([bo, g1, be1, b1, b2, g2, be2, bv, bp]).to(DEV)
+    kw = dict(pos=d(pos), tokens_per_image=S, want_next=want_next)
+    so, vo, po = ops().encoder_block_split(d(attn), d(src), ops().pack_encoder_block_split(d(wo), d(w1), d(w2), *nxt), small, DF, PW, **kw)
+    s32, v32, p32 = ops().encoder_block(d(attn), d(src), ops().pack_encoder_block(d(wo), d(w1), d(w2), *nxt), small, DF, PW, **kw)
+    close(so, y.float(), rtol=1e-4, atol=2e-5)                                     # the fp32 kernel's own tolerances
+    e_split, e_mfma = (so.double().cpu() - y).abs(), (s32.double().cpu() - y).abs()
+    print(f"encoder block vs float64: split max {float(e_split.max()):.2e} mean {float(e_split.mean()):.2e} | "
+          f"fp32 MFMA max {float(e_mfma.max()):.2e} mean {float(e_mfma.mean()):.2e}")
+    assert float(e_split.mean()) <= 1.5 * float(e_mfma.mean()) and float(e_split.max()) <= 1.5 * float(e_mfma.max()) + 1e-7
+    if want_next:
+        yk = so.double().cpu()                              # the kernel's own layer output feeds its projections
+        vr, pr = F.linear(yk, D(wv), D(bv)), F.linear(yk + D(pos), D(wp), D(bp))
+        close(vo, vr.float(), rtol=1e-4, atol=2e-5)
+        close(po, pr.float(), rtol=1e-4, atol=5e-5)
+        y32 = s32.double().cpu()
+        ev, ev32 = (vo.double().cpu() - vr).abs().mean(), (v32.double().cpu() - F.linear(y32, D(wv), D(bv))).abs().mean()
+        ep, ep32 = (po.double().cpu() - pr).abs().mean(), (p32.double().cpu() - F.linear(y32 + D(pos), D(wp), D(bp))).abs().mean()
+        print(f"  value_proj mean error split {float(ev):.2e} / fp32 MFMA {float(ev32):.2e}; sampling projection {float(ep):.2e} / {float(ep32):.2e}")
+        assert float(ev) <= 1.5 * float(ev32) and float(ep) <= 1.5 * float(ep32)
+        so2, vh, po2 = ops().encoder_block_split(d(attn), d(src), ops().pack_encoder_block_split(d(wo), d(w1), d(w2), *nxt), small, DF, PW,
+                                                 pos=d(pos), tokens_per_image=S, value_heads=8)
+        assert vh.shape == (B, 8, S, C // 8)
+        assert torch.equal(vh.permute(0, 2, 1, 3).reshape(B, S, C), vo) and torch.equal(so2, so) and torch.equal(po2, po)
+    else:
+        assert vo is None and po is None
+
+
 def test_pixel_decoder_fused_equals_unfused():
     from unseenobjectswithmeanshift_amd import synthetic as syn
     from unseenobjectswithmeanshift_amd.meta_arch import build_resnet50_head

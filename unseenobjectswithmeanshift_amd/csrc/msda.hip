@@ -281,20 +281,33 @@ __device__ __forceinline__ float quad_sum(float v) {
     return v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));
 }
 
+// QM (query-major blocks): a workgroup is 64 CONSECUTIVE queries of ONE head instead of 8 queries x 8 heads.  Neighbouring
+// queries sample neighbouring locations, and with the head-major value layout a workgroup then works on one 200-KB map
+// instead of eight: the lines it gathers are re-used out of the CU's L1 instead of each being fetched from L2 once per
+// query that touches it.
+template <bool QM>
 __global__ __launch_bounds__(256) void msda_enc_hm8_kernel(const float* __restrict__ value, const int64_t* __restrict__ shapes,
                                                            const int64_t* __restrict__ lstart, const float* __restrict__ proj,
                                                            float* __restrict__ out, int B, int S, int M, int L, int P) {
     constexpr int D = 8;
-    const int per_img = S * M * 4;
     const int b = blockIdx.x % B;
-    const int idx = (blockIdx.x / B) * 256 + threadIdx.x;
-    const bool live = idx < per_img;            // whole quads live or dead together
-    const int cidx = live ? idx : 0;
-    const int g = cidx & 3;
+    const int blk = blockIdx.x / B;
+    const int g = threadIdx.x & 3;
     const int cx = g >> 1, d4 = g & 1;
-    const int t = cidx >> 2;
-    const int m = t % M;
-    const int qi = t / M;
+    int m, qi;
+    bool live;                                  // whole quads live or dead together
+    if constexpr (QM) {
+        m = blk % M;
+        const int q_raw = (blk / M) * 64 + ((int)threadIdx.x >> 2);
+        live = q_raw < S;
+        qi = live ? q_raw : 0;
+    } else {
+        const int idx = blk * 256 + threadIdx.x;
+        live = idx < S * M * 4;
+        const int t = (live ? idx : 0) >> 2;
+        m = t % M;
+        qi = t / M;
+    }
 
     int Hs[MAXL], Ws[MAXL], st[MAXL];           // level geometry: wave-uniform, stays in SGPRs
 #pragma unroll
@@ -614,9 +627,12 @@ extern "C" int msm_msdeform_attn_enc_hm_fwd(const float* value_hm, const int64_t
     MSM_REQUIRE((int64_t)S * D < ((int64_t)1 << 31), "msm_msdeform_attn_enc_hm_fwd: S*D must fit 31 bits");
     const int64_t per_img = (int64_t)S * M * G;
     dim3 grid((unsigned)(((per_img + 255) / 256) * B)), block(256);
-    if (D == 8 && L * P <= 16 && (int64_t)S * D < ((int64_t)1 << 31) && opt(MSM_OPT_MSDA_GENERIC) != 1)
-        hipLaunchKernelGGL(msda_enc_hm8_kernel, grid, block, 0, (hipStream_t)stream, value_hm, spatial_shapes,
+    if (D == 8 && L * P <= 16 && (int64_t)S * D < ((int64_t)1 << 31) && opt(MSM_OPT_MSDA_GENERIC) == 3)
+        hipLaunchKernelGGL(msda_enc_hm8_kernel<false>, grid, block, 0, (hipStream_t)stream, value_hm, spatial_shapes,
                            level_start_index, proj, out, B, S, M, L, P);
+    else if (D == 8 && L * P <= 16 && (int64_t)S * D < ((int64_t)1 << 31) && opt(MSM_OPT_MSDA_GENERIC) != 1)
+        hipLaunchKernelGGL(msda_enc_hm8_kernel<true>, dim3((unsigned)(cdiv(S, 64) * M * B)), block, 0, (hipStream_t)stream, value_hm,
+                           spatial_shapes, level_start_index, proj, out, B, S, M, L, P);
     else if (V == 4)
         hipLaunchKernelGGL((msda_enc_hm_kernel<4>), grid, block, 0, (hipStream_t)stream, value_hm, spatial_shapes,
                            level_start_index, proj, out, B, S, M, D, L, P);

@@ -886,6 +886,59 @@ def encoder_block_bf16(attn, src, wstream, small, d_ffn, proj_width, *, pos=None
     return src_out, value_out, proj_out
 
 
+def pack_encoder_block_split(wo, w1, w2, wv=None, wp=None):
+    """One encoder layer's matrices as the triple-split weight stream of msm_encoder_block_split_fwd (include/msm_hip.h):
+    every fp32 weight as w = h + m + l with h = bf16(w), m = bf16(w - h), l = bf16(w - h - m); 2-KiB blocks in the fragment
+    order of v_mfma_f32_16x16x32_bf16, a logical block = its (h, m, l) blocks, 12 blocks per stage.
+    Returns an int16 tensor (bf16 bit patterns)."""
+    dev = wo.device
+    d_ffn = w1.shape[0]
+
+    def rowblocks(w):       # (N, 64) -> (N/16, 1024): block[G][lq][lj][hh][c] = W[r0 + lj][(2G + hh)*16 + lq*4 + c]
+        return w.reshape(-1, 16, 2, 2, 4, 4).permute(0, 2, 4, 1, 3, 5).reshape(-1, 1024)
+
+    def w2pairs(w):         # (64, d_ffn) -> (d_ffn/32, 2048): [ob][lq][lj][hh][c] = W[ob*16 + lj][(2P + hh)*16 + lq*4 + c]
+        return w.reshape(4, 16, d_ffn // 32, 2, 4, 4).permute(2, 0, 4, 1, 3, 5).reshape(-1, 2048)
+
+    def split3(w):
+        h = w.to(torch.bfloat16).float()
+        m = (w - h).to(torch.bfloat16).float()
+        return h, m, (w - h - m).to(torch.bfloat16).float()
+
+    def triples(parts):                                   # three (n, k) lists -> (n, 3k) as [h | m | l] per logical block
+        return torch.cat(list(parts), 1)
+
+    w1t = triples(rowblocks(t) for t in split3(w1)).reshape(d_ffn // 32, 2 * 3 * 1024)        # per stage: W1(q0) h,m,l | W1(q1) h,m,l
+    w2t = triples(w2pairs(t) for t in split3(w2))                                            # per stage: W2 h | m | l (4 KiB each)
+    blocks = [triples(rowblocks(t) for t in split3(wo)).reshape(-1), torch.cat([w1t, w2t], 1).reshape(-1)]
+    if wv is not None:
+        blocks.append(triples(rowblocks(t) for t in split3(wv)).reshape(-1))
+        pt = triples(rowblocks(t) for t in split3(wp)).reshape(-1)
+        blocks += [pt, torch.zeros((-(pt.numel() // 1024)) % 12 * 1024, device=dev)]
+    out = torch.cat(blocks, 0).to(torch.bfloat16).contiguous().view(torch.int16).reshape(-1)
+    need = int(lib().msm_encoder_block_split_stream_bytes(d_ffn, 0 if wp is None else wp.shape[0]))
+    if out.numel() * 2 != need:
+        raise RuntimeError(f"pack_encoder_block_split: built {out.numel() * 2} bytes, the kernel expects {need}")
+    return out
+
+
+def encoder_block_split(attn, src, wstream, small, d_ffn, proj_width, *, pos=None, tokens_per_image=None, want_next=True,
+                        value_heads=0, eps=1e-5):
+    """encoder_block in fp32 accuracy on the bf16 matrix pipe (wstream from pack_encoder_block_split): fp32 in, fp32 out."""
+    _c(attn, "attn"), _c(src, "src"), _c(wstream, "wstream", torch.int16), _c(small, "small"), _c(pos, "pos")
+    B, S, C = src.shape
+    src_out = torch.empty_like(src)
+    value_out = proj_out = None
+    if want_next:
+        value_out = torch.empty((B, value_heads, S, C // value_heads), device=src.device, dtype=torch.float32) \
+            if value_heads else torch.empty_like(src)
+        proj_out = torch.empty((B, S, proj_width), device=src.device, dtype=torch.float32)
+    rc = lib().msm_encoder_block_split_fwd(_p(attn), _p(src), _p(wstream), _p(small), _p(pos), _p(src_out), _p(value_out), _p(proj_out),
+                                           B * S, tokens_per_image or S, d_ffn, proj_width, int(value_heads), eps, _stream())
+    check(rc, "msm_encoder_block_split_fwd")
+    return src_out, value_out, proj_out
+
+
 def encoder_block(attn, src, wstream, small, d_ffn, proj_width, *, pos=None, tokens_per_image=None, want_next=True,
                   value_heads=0, eps=1e-5):
     """One fused encoder-layer tail.  attn/src (B,S,64).  Returns (src_out, value_out, proj_out) with the
