@@ -74,10 +74,10 @@ enum {
     MSM_OPT_CONVIN_NT,          /* 1, 2, 4: pixel tiles per workgroup of the input projection */
     MSM_OPT_POST_GENERIC,       /* 1: generic mask upsample instead of the 4x form */
     MSM_OPT_ENC_NO_COOP,        /* 1: encoder block without cooperative workgroups */
-    MSM_OPT_MSDA_GENERIC,       /* 1: generic head-major MSDeformAttn gather */
+    MSM_OPT_MSDA_GENERIC,       /* 1: generic head-major MSDeformAttn gather; 3: the D = 8 kernel with 8-query x 8-head workgroups */
     MSM_OPT_MS_CHUNK,           /* 1..8 seed blocks per hill-climb launch */
     MSM_OPT_MS_NO_PERSISTENT,   /* 1: one launch per seeding step */
-    MSM_OPT_ATTN_FUSED_KV,      /* 0: never project K/V inside the attention kernel */
+    MSM_OPT_ATTN_FUSED_KV,      /* reserved (no effect) */
     MSM_OPT_MASK_KERNEL,        /* fp32 mask step: 2 = one wave per SIMD with mask_embed in registers (C = 64 only), 3 = prefetch ring of four groups, 4 = software-pipelined epilogue (C = 64 attention-mask launches) */
     MSM_OPT_COUNT
 };
