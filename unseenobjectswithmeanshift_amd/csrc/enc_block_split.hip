@@ -25,6 +25,10 @@
 #include "bf16.h"
 #include "common.h"
 
+#ifndef ES_EXP
+#define ES_EXP 0   // tuning builds only: 1 = weight fragments are register constants (no LDS reads), 2 = no MFMAs, 3 = no stage barriers / DMA waits
+#endif
+
 namespace msm {
 
 constexpr int ES_C = 64;                     // d_model
@@ -37,7 +41,15 @@ struct EncSmallS {                           // offsets (floats) into the packed
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ f32x4 mfma_bf16k32(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma_bf16k32(bf16x8 a, bf16x8 b, f32x4 c) {
+#if ES_EXP == 2
+    const u32x4b ua = __builtin_bit_cast(u32x4b, a), ub = __builtin_bit_cast(u32x4b, b);
+    c[0] += __uint_as_float(ua.x ^ ub.x);
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
 __device__ __forceinline__ bf16x8 cat8(bf16x4 a, bf16x4 b) {
     const u32x2b ua = __builtin_bit_cast(u32x2b, a), ub = __builtin_bit_cast(u32x2b, b);
     return __builtin_bit_cast(bf16x8, u32x4b{ua.x, ua.y, ub.x, ub.y});
@@ -62,7 +74,11 @@ __device__ __forceinline__ Split3 split3(float a, float b, float c, float d) {
 __device__ __forceinline__ Split3x8 join(const Split3& a, const Split3& b) { return Split3x8{cat8(a.h, b.h), cat8(a.m, b.m), cat8(a.l, b.l)}; }
 // the lane's operand of 32-wide k-group (or output row block) i of a physical block
 __device__ __forceinline__ bf16x8 sfrag(const char* __restrict__ blk, int i, int lane) {
+#if ES_EXP == 1
+    return __builtin_bit_cast(bf16x8, u32x4b{(unsigned)lane * 0x10001u, (unsigned)i, 0x3f803f80u, (unsigned)(uintptr_t)blk});
+#else
     return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4b*>(blk + (i * 64 + lane) * 16));
+#endif
 }
 // the six significant products of one k-group, smallest first, into two accumulators (low-order terms / leading term): the
 // chains of different row blocks interleave, and the small terms are summed among themselves before they meet the large one
@@ -197,8 +213,15 @@ __device__ __forceinline__ void enc_block_split_body(const float* __restrict__ a
     // per wave) do not cover an LDS-DMA round trip under load, two of them do (with two buffers a workgroup took ~1.8 us per
     // stage whatever it computed).  At the end of stage s the data of s + 1 must be there: everything but this stage's own
     // six DMA instructions (vmcnt is in order; later loads / stores only make the wait more conservative).
+#if ES_EXP == 3
+#define ES_WAIT_PREV() ;
+#define ES_WAIT_ALL() ;
+#define ES_SYNC()
+#else
 #define ES_WAIT_PREV() asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
 #define ES_WAIT_ALL() asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define ES_SYNC() __syncthreads();
+#endif
 
     float x[NT][4][4];
     Split3x8 xb[NT][2];
@@ -243,7 +266,7 @@ __device__ __forceinline__ void enc_block_split_body(const float* __restrict__ a
             split_tile(x[t], xb[t]);
         }
         if (more) ES_WAIT_PREV() else ES_WAIT_ALL()
-        __syncthreads();
+        ES_SYNC()
     }
     // ---- FFN: two hidden blocks of 16 per stage; the hidden activation never leaves registers ----
     f32x4 acc[NT][4];      // linear2's running sums: one chain per (tile, output block); low-order terms first within a k-group
@@ -303,7 +326,7 @@ __device__ __forceinline__ void enc_block_split_body(const float* __restrict__ a
                 for (int t = 0; t < NT; ++t) mac_term(term, acc[t][ob], acc[t][ob], w2f[ob], hb[t]);
         __builtin_amdgcn_sched_barrier(0);
         if (more) ES_WAIT_PREV() else ES_WAIT_ALL()
-        __syncthreads();
+        ES_SYNC()
     }
     // ---- residual + LayerNorm2 (msdeformattn.py:116-118), write the layer output ----
 #pragma unroll
@@ -385,11 +408,12 @@ __device__ __forceinline__ void enc_block_split_body(const float* __restrict__ a
             }
         }
         if (more) ES_WAIT_PREV() else ES_WAIT_ALL()
-        __syncthreads();
+        ES_SYNC()
     }
 }
 #undef ES_WAIT_PREV
 #undef ES_WAIT_ALL
+#undef ES_SYNC
 
 // Workgroups 0 .. n_heavy - 1 take two tiles per wave, the others one: 3150 tiles over the 2048 waves of two workgroups per
 // CU are one each and a second for 1102 of them, and the dispatcher's round-robin puts a heavy and a light workgroup on

@@ -285,11 +285,25 @@ __device__ __forceinline__ float quad_sum(float v) {
 // queries sample neighbouring locations, and with the head-major value layout a workgroup then works on one 200-KB map
 // instead of eight: the lines it gathers are re-used out of the CU's L1 instead of each being fetched from L2 once per
 // query that touches it.
-template <bool QM>
+typedef unsigned int msda_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldv4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+    const msda_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
+    return make_float4(__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w));
+}
+__device__ __forceinline__ int clamp0(int x, int hi) {        // min(max(x, 0), hi) as one v_med3_i32 (one SGPR operand: constant bus)
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi));
+    return r;
+}
+
+// LC / PC > 0: levels and points per level known at compile time (3 x 4: every shipped configuration) -- the per-point level
+// geometry is then a fixed SGPR instead of a chain of scalar selects, and the LP < 16 guards fold away.
+template <bool QM, int LC, int PC>
 __global__ __launch_bounds__(256) void msda_enc_hm8_kernel(const float* __restrict__ value, const int64_t* __restrict__ shapes,
                                                            const int64_t* __restrict__ lstart, const float* __restrict__ proj,
-                                                           float* __restrict__ out, int B, int S, int M, int L, int P) {
+                                                           float* __restrict__ out, int B, int S, int M, int L_rt, int P_rt) {
     constexpr int D = 8;
+    const int L = LC > 0 ? LC : L_rt, P = PC > 0 ? PC : P_rt;
     const int b = blockIdx.x % B;
     const int blk = blockIdx.x / B;
     const int g = threadIdx.x & 3;
@@ -371,7 +385,13 @@ __global__ __launch_bounds__(256) void msda_enc_hm8_kernel(const float* __restri
     // point: 12 serial round trips per wave, measured 57 us; this form: see DESIGN.md).  Same products, same order:
     // a skipped tap adds 0 * v.
     constexpr int GP = 4;
-    const float* vb = value + ((int64_t)b * M + m) * S * D + d4 * 4;
+    // buffer loads: the image's value planes behind one SGPR descriptor (M x S x 32 B = 1.6 MB), a 32-bit byte offset per tap
+    // instead of 64-bit pointer arithmetic (four VALU instructions per load of a VALU-bound kernel)
+    const uint64_t vbase = (uint64_t)(value + (int64_t)b * M * S * D);
+    const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(vbase >> 32)) << 32) | (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)vbase)),
+        0, M * S * D * 4, 0x00020000);
+    const unsigned vlane = (unsigned)((m * S) * D + d4 * 4) * 4u;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i0 = 0; i0 < 16; i0 += GP) {
@@ -391,18 +411,21 @@ __global__ __launch_bounds__(256) void msda_enc_hm8_kernel(const float* __restri
                     const float w_im = quad_bcast(px[i >> 2], i & 3);
                     const float h_im = quad_bcast(py[i >> 2], i & 3);
                     const float wgt = quad_bcast(pw[i >> 2], i & 3) * rden;
-                    const bool in = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;       // cuh:293
+                    // The reference's outer test (-1 < h_im < H, -1 < w_im < W, cuh:293) is implied by its per-tap bounds
+                    // (cuh:247-270): outside it no tap index lies in [0, H) x [0, W).  One unsigned compare per tap row /
+                    // column, one v_med3 per clamp: the kernel is VALU-bound (~1650 VALU instructions per wave).
                     const float hf = floorf(h_im), wf = floorf(w_im);
                     const int h_low = (int)hf, xw = (int)wf + cx;                // this lane's column
-                    const bool okx = in && xw >= 0 && xw <= W - 1;
                     const float lh = h_im - hf, lw = w_im - wf;
-                    const float wxw = (cx ? lw : 1.f - lw) * wgt;
-                    wt[j] = (okx && h_low >= 0) ? (1.f - lh) * wxw : 0.f;
-                    wb[j] = (okx && h_low + 1 <= H - 1) ? lh * wxw : 0.f;
-                    const int xc = min(max(xw, 0), W - 1);
-                    const int yt = min(max(h_low, 0), H - 1), yb = min(max(h_low + 1, 0), H - 1);
-                    vt[j] = *reinterpret_cast<const float4*>(vb + (int64_t)(s0 + yt * W + xc) * D);
-                    vbm[j] = *reinterpret_cast<const float4*>(vb + (int64_t)(s0 + yb * W + xc) * D);
+                    const float wxw = (unsigned)xw < (unsigned)W ? (cx ? lw : 1.f - lw) * wgt : 0.f;
+                    wt[j] = (unsigned)h_low < (unsigned)H ? (1.f - lh) * wxw : 0.f;
+                    wb[j] = (unsigned)(h_low + 1) < (unsigned)H ? lh * wxw : 0.f;
+                    const int xc = clamp0(xw, W - 1);
+                    const int yt = clamp0(h_low, H - 1), yb = clamp0(h_low + 1, H - 1);
+                    // (24-bit multiplies: full-rate v_mad_u32_u24; a 32-bit integer multiply is a quarter-rate instruction)
+                    const unsigned col = vlane + (unsigned)(s0 + xc) * (unsigned)(D * 4);
+                    vt[j] = ldv4(vrsrc, col + __umul24((unsigned)yt, (unsigned)(W * D * 4)));
+                    vbm[j] = ldv4(vrsrc, col + __umul24((unsigned)yb, (unsigned)(W * D * 4)));
                 }
             }
 #pragma unroll
@@ -627,11 +650,14 @@ extern "C" int msm_msdeform_attn_enc_hm_fwd(const float* value_hm, const int64_t
     MSM_REQUIRE((int64_t)S * D < ((int64_t)1 << 31), "msm_msdeform_attn_enc_hm_fwd: S*D must fit 31 bits");
     const int64_t per_img = (int64_t)S * M * G;
     dim3 grid((unsigned)(((per_img + 255) / 256) * B)), block(256);
-    if (D == 8 && L * P <= 16 && (int64_t)S * D < ((int64_t)1 << 31) && opt(MSM_OPT_MSDA_GENERIC) == 3)
-        hipLaunchKernelGGL(msda_enc_hm8_kernel<false>, grid, block, 0, (hipStream_t)stream, value_hm, spatial_shapes,
+    if (D == 8 && L * P <= 16 && (int64_t)M * S * D * 4 < ((int64_t)1 << 31) && opt(MSM_OPT_MSDA_GENERIC) == 3)
+        hipLaunchKernelGGL((msda_enc_hm8_kernel<false, 0, 0>), grid, block, 0, (hipStream_t)stream, value_hm, spatial_shapes,
                            level_start_index, proj, out, B, S, M, L, P);
-    else if (D == 8 && L * P <= 16 && (int64_t)S * D < ((int64_t)1 << 31) && opt(MSM_OPT_MSDA_GENERIC) != 1)
-        hipLaunchKernelGGL(msda_enc_hm8_kernel<true>, dim3((unsigned)(cdiv(S, 64) * M * B)), block, 0, (hipStream_t)stream, value_hm,
+    else if (D == 8 && L == 3 && P == 4 && (int64_t)M * S * D * 4 < ((int64_t)1 << 31) && opt(MSM_OPT_MSDA_GENERIC) != 1)
+        hipLaunchKernelGGL((msda_enc_hm8_kernel<true, 3, 4>), dim3((unsigned)(cdiv(S, 64) * M * B)), block, 0, (hipStream_t)stream, value_hm,
+                           spatial_shapes, level_start_index, proj, out, B, S, M, L, P);
+    else if (D == 8 && L * P <= 16 && (int64_t)M * S * D * 4 < ((int64_t)1 << 31) && opt(MSM_OPT_MSDA_GENERIC) != 1)
+        hipLaunchKernelGGL((msda_enc_hm8_kernel<true, 0, 0>), dim3((unsigned)(cdiv(S, 64) * M * B)), block, 0, (hipStream_t)stream, value_hm,
                            spatial_shapes, level_start_index, proj, out, B, S, M, L, P);
     else if (V == 4)
         hipLaunchKernelGGL((msda_enc_hm_kernel<4>), grid, block, 0, (hipStream_t)stream, value_hm, spatial_shapes,
