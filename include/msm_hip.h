@@ -502,6 +502,15 @@ int64_t msm_encoder_block_split_stream_bytes(int d_ffn, int proj_width);
 int msm_encoder_block_split_fwd(const float* attn, const float* src, const void* wstream, const float* small, const float* pos,
                                 float* src_out, float* value_out, float* proj_out, int M, int tokens_per_image, int d_ffn,
                                 int proj_width, int value_heads, float eps, void* stream);
+/* The low-precision encoder block on the same kernel structure (K = 32 bf16 MFMAs, two token tiles per wave): operands rounded
+ * exactly as msm_encoder_block_bf16_fwd rounds them -- projections w(h + m) x(h + m) without the m x m term, linear1 w(h) x(h + m),
+ * linear2 single bf16 operands -- and only the copies that are read in the stream: 12 blocks of [2 k-groups][64 lanes][8 bf16] per
+ * stage = output_proj [h, m] x 4 row blocks (+ 4 zero blocks) | three hidden pairs [W1(q0) h, W1(q1) h, W2 h (4 KiB)] per stage,
+ * the hidden dimension zero-padded to whole stages | value_proj like output_proj | six proj row blocks [h, m] per stage. */
+int64_t msm_encoder_block_lp_stream_bytes(int d_ffn, int proj_width);
+int msm_encoder_block_lp_fwd(const float* attn, const float* src, const void* wstream, const float* small, const float* pos,
+                             float* src_out, float* value_out, float* proj_out, int M, int tokens_per_image, int d_ffn,
+                             int proj_width, int value_heads, float eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Label-image statistics of the two-stage harness: one pass instead of the reference's per-label

@@ -696,8 +696,9 @@ def test_encoder_block_fused(B, S, want_next):
         assert vo is None and po is None
 
 
+@pytest.mark.parametrize("kernel", ["k16", "k32"])
 @pytest.mark.parametrize("B,S,want_next", [(2, 394, True), (1, 6300, True), (3, 100, False), (8, 6300, True)])
-def test_encoder_block_bf16(B, S, want_next):
+def test_encoder_block_bf16(B, S, want_next, kernel):
     """bf16 form of the fused encoder-layer tail (configs 3 / 5): against the chain evaluated in float64 on the bf16-ROUNDED
     operands (weights once; activations where they enter a GEMM) -- what the kernel computes up to fp32 accumulation order --
     and, loosely, against the exact fp32 chain."""
@@ -718,9 +719,11 @@ def test_encoder_block_bf16(B, S, want_next):
     y32 = F.layer_norm(src + F.linear(attn, wo, bo), (C,), g1, be1)
     y32 = F.layer_norm(y32 + F.linear(F.relu(F.linear(y32, w1, b1)), w2, b2), (C,), g2, be2)
     d = lambda t: t.to(DEV).contiguous()
-    stream = ops().pack_encoder_block_bf16(d(wo), d(w1), d(w2), d(wv) if want_next else None, d(wp) if want_next else None)
+    # "k16": enc_block_bf16.hip; "k32": the same roundings on the K = 32 / two-tiles-per-wave kernel (msm_encoder_block_lp_fwd)
+    pack, block = (ops().pack_encoder_block_bf16, ops().encoder_block_bf16) if kernel == "k16" else (ops().pack_encoder_block_lp, ops().encoder_block_lp)
+    stream = pack(d(wo), d(w1), d(w2), d(wv) if want_next else None, d(wp) if want_next else None)
     small = torch.cat([bo, g1, be1, b1, b2, g2, be2, bv, bp]).to(DEV)
-    so, vo, po = ops().encoder_block_bf16(d(attn), d(src), stream, small, DF, PW, pos=d(pos), tokens_per_image=S, want_next=want_next)
+    so, vo, po = block(d(attn), d(src), stream, small, DF, PW, pos=d(pos), tokens_per_image=S, want_next=want_next)
     # an activation next to a bf16 rounding boundary may round the other way (fp32 here, float64 there): one such flip moves
     # the outputs of its token by a few 1e-3; almost all elements agree to fp32 accumulation accuracy
     err = (so.cpu() - y).abs()
@@ -730,7 +733,7 @@ def test_encoder_block_bf16(B, S, want_next):
         yk = so.cpu()                                  # the kernel's own layer output feeds its projections
         close(vo, linx(yk, wv, bv).float(), rtol=2e-4, atol=2e-4)        # the three-term products are fp32-class
         close(po, linx(yk + pos, wp, bp).float(), rtol=2e-4, atol=5e-4)
-        so2, vh, po2 = ops().encoder_block_bf16(d(attn), d(src), stream, small, DF, PW, pos=d(pos), tokens_per_image=S, value_heads=8)
+        so2, vh, po2 = block(d(attn), d(src), stream, small, DF, PW, pos=d(pos), tokens_per_image=S, value_heads=8)
         assert vh.shape == (B, 8, S, C // 8)
         assert torch.equal(vh.permute(0, 2, 1, 3).reshape(B, S, C), vo) and torch.equal(so2, so) and torch.equal(po2, po)
     else:

@@ -57,6 +57,8 @@ _SIGNATURES = {
     "msm_encoder_block_bf16_fwd": (c_i, [c_f, c_f, c_p, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_p]),
     "msm_encoder_block_split_stream_bytes": (c_l, [c_i, c_i]),
     "msm_encoder_block_split_fwd": (c_i, [c_f, c_f, c_p, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_p]),
+    "msm_encoder_block_lp_stream_bytes": (c_l, [c_i, c_i]),
+    "msm_encoder_block_lp_fwd": (c_i, [c_f, c_f, c_p, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_p]),
     "msm_kv_project_f32": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_l, c_p]),
     "msm_kv_project_multi_f32": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "msm_kv_project_multi_bf16": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),

@@ -90,12 +90,35 @@ __device__ __forceinline__ void mac6(f32x4& lo, f32x4& hi, bf16x8 wh, bf16x8 wm,
     lo = mfma_bf16k32(wh, x.m, lo);
     hi = mfma_bf16k32(wh, x.h, hi);
 }
+// MODE 0: fp32 accuracy -- three weight copies everywhere, all six product terms.  MODE 1: the low-precision ("bf16") mode on
+// the same structure -- operands rounded as in enc_block_bf16.hip: the 64-wide projections w(h + m) x(h + m) without the
+// m x m term, linear1 w(h) x(h + m), linear2 single operands -- with only the copies it reads in the stream, so a stage holds
+// three hidden pairs or six projection row blocks and a layer is 16 stages instead of 38.
+template <int MODE>
+struct ESMode;
+template <>
+struct ESMode<0> {
+    static constexpr int WC = 3, W1C = 3, W2C = 3;      // weight copies per logical block: projections, linear1, linear2
+    static constexpr int HP = 1, PB = 4;                // hidden pairs (of 2 x 16) per FFN stage, projection row blocks per stage
+    static constexpr unsigned PROJ = 0x3f, L1 = 0x3f, L2 = 0x3f;      // product terms of mac_term used (bit = term)
+};
+template <>
+struct ESMode<1> {
+    static constexpr int WC = 2, W1C = 1, W2C = 1;
+    static constexpr int HP = 3, PB = 6;
+    static constexpr unsigned PROJ = 0x38, L1 = 0x30, L2 = 0x20;      // {wm xh, wh xm, wh xh}, {wh xm, wh xh}, {wh xh}
+};
 struct Frag3 {                                 // a weight fragment's three terms
     bf16x8 h, m, l;
 };
 // fragment i of a logical block whose h / m / l copies lie `step` bytes apart
+template <int COPIES>
 __device__ __forceinline__ Frag3 ld3(const char* __restrict__ blk, int step, int i, int lane) {
-    return Frag3{sfrag(blk, i, lane), sfrag(blk + step, i, lane), sfrag(blk + 2 * step, i, lane)};
+    Frag3 f;
+    f.h = sfrag(blk, i, lane);
+    f.m = COPIES > 1 ? sfrag(blk + step, i, lane) : f.h;          // copies a mode does not stream are never multiplied with
+    f.l = COPIES > 2 ? sfrag(blk + 2 * step, i, lane) : f.h;
+    return f;
 }
 // product term 0 .. 5 of mac6 on its own (callers interleave the terms of several accumulator chains)
 __device__ __forceinline__ void mac_term(int term, f32x4& lo, f32x4& hi, const Frag3& w, const Split3x8& x) {
@@ -112,7 +135,7 @@ __device__ __forceinline__ void mac_term(int term, f32x4& lo, f32x4& hi, const F
 // tiles: D (layout L) = bias + W x.  Every weight fragment is read from LDS ONCE for the NT tiles of the wave: with one tile
 // per wave the kernel sat on the LDS read port (a CU's waves read 288 KiB of fragments per stage round: 2304 cycles, as
 // many as the MFMAs of that round take).
-template <int NT>
+template <int NT, int COPIES, unsigned TERMS>
 __device__ __forceinline__ void rowblock6(const char* __restrict__ blk, int lane, const Split3x8 (&xb)[NT][2], const float* __restrict__ bias, int lq,
                                           f32x4 (&out)[NT]) {
     const float4 b = *reinterpret_cast<const float4*>(bias + lq * 4);
@@ -124,9 +147,13 @@ __device__ __forceinline__ void rowblock6(const char* __restrict__ blk, int lane
     }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-        const bf16x8 wh = sfrag(blk, g, lane), wm = sfrag(blk + ES_BLOCK, g, lane), wl = sfrag(blk + 2 * ES_BLOCK, g, lane);
+        const Frag3 w = ld3<COPIES>(blk, ES_BLOCK, g, lane);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) mac6(lo[t], hi[t], wh, wm, wl, xb[t][g]);
+        for (int term = 0; term < 6; ++term)
+            if ((TERMS >> term) & 1u) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) mac_term(term, lo[t], hi[t], w, xb[t][g]);
+            }
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) out[t] = hi[t] + lo[t];
@@ -176,7 +203,7 @@ __device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsign
 // small: the fp32 vector of enc_block.hip (biases, LayerNorm parameters); everything but linear1's bias (d_ffn floats, read
 // where it is) is copied to LDS.  NT = 16-token tiles per wave; tile0 = this workgroup's first tile (wave w: tiles
 // tile0 + w * NT ...).
-template <int NT>
+template <int NT, int MODE>
 __device__ __forceinline__ void enc_block_split_body(const float* __restrict__ attn, const float* __restrict__ src,
                                                      const char* __restrict__ wstream, const float* __restrict__ small, EncSmallS so,
                                                      const float* __restrict__ pos, float* __restrict__ src_out,
@@ -199,7 +226,8 @@ __device__ __forceinline__ void enc_block_split_body(const float* __restrict__ a
         tk[t] = tok_ok[t] ? tok[t] : M - 1;
     }
     const bool next = value_out != nullptr;
-    const int ntail = next ? 1 + (nproj_blocks + 3) / 4 : 0;
+    using MD = ESMode<MODE>;
+    const int ntail = next ? 1 + (nproj_blocks + MD::PB - 1) / MD::PB : 0;
     const int nsteps = 1 + nffn_stages + ntail;
 
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)wls;
@@ -254,7 +282,7 @@ __device__ __forceinline__ void enc_block_split_body(const float* __restrict__ a
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob) {
             f32x4 d[NT];
-            rowblock6<NT>(wls + (3 * ob) * ES_BLOCK, lane, xb, smo(so.bo) + ob * 16, lq, d);
+            rowblock6<NT, MD::WC, MD::PROJ>(wls + (MD::WC * ob) * ES_BLOCK, lane, xb, smo(so.bo) + ob * 16, lq, d);
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 x[t][ob][0] += d[t][0]; x[t][ob][1] += d[t][1]; x[t][ob][2] += d[t][2]; x[t][ob][3] += d[t][3];
@@ -281,50 +309,61 @@ __device__ __forceinline__ void enc_block_split_body(const float* __restrict__ a
         // Explicit order (sched_barrier pins it): all of linear1's fragments up front, linear2's requested while linear1's
         // MFMAs run, and consecutive MFMAs always on different accumulators -- term by term across the (hidden block, tile)
         // and (output block, tile) chains: as nested rowblock calls every block was load -> wait -> six dependent MFMAs.
-        Frag3 w1[2][2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int p = 0; p < MD::HP; ++p) {
+            const char* pb = buf + p * (2 * MD::W1C + 2 * MD::W2C) * ES_BLOCK;
+            const int hb0 = ((s - 1) * MD::HP + p) * 2;             // first of the pair's two 16-wide hidden blocks
+            Frag3 w1[2][2];
 #pragma unroll
-            for (int g = 0; g < 2; ++g) w1[q][g] = ld3(buf + (3 * q) * ES_BLOCK, ES_BLOCK, g, lane);
-        f32x4 hh[2][NT], hl[2][NT];
+            for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const float4 b = *reinterpret_cast<const float4*>(small + so.b1 + ((s - 1) * 2 + q) * 16 + lq * 4);
+                for (int g = 0; g < 2; ++g) w1[q][g] = ld3<MD::W1C>(pb + (MD::W1C * q) * ES_BLOCK, ES_BLOCK, g, lane);
+            f32x4 hh[2][NT], hl[2][NT];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                // (MODE 1 pads the hidden dimension to whole stages with zero weights: their bias is zero too)
+                const float4 b = (hb0 + q) * 16 < d_ffn ? *reinterpret_cast<const float4*>(small + so.b1 + (hb0 + q) * 16 + lq * 4)
+                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    hh[q][t] = f32x4{b.x, b.y, b.z, b.w};
+                    hl[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int term = 0; term < 6; ++term)
+                    if ((MD::L1 >> term) & 1u) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) mac_term(term, hl[q][t], hh[q][t], w1[q][g], xb[t][g]);
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+            const char* w2 = pb + 2 * MD::W1C * ES_BLOCK;           // copies of 4 KiB: [4 output row blocks][64 lanes][8 k]
+            Frag3 w2f[4];
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) w2f[ob] = ld3<MD::W2C>(w2, 2 * ES_BLOCK, ob, lane);
+            Split3x8 hb[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                hh[q][t] = f32x4{b.x, b.y, b.z, b.w};
-                hl[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 h0 = hh[0][t] + hl[0][t], h1 = hh[1][t] + hl[1][t];
+                hb[t] = join(split3(relu1s(h0[0]), relu1s(h0[1]), relu1s(h0[2]), relu1s(h0[3])),
+                             split3(relu1s(h1[0]), relu1s(h1[1]), relu1s(h1[2]), relu1s(h1[3])));
             }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int term = 0; term < 6; ++term)
+                if ((MD::L2 >> term) & 1u) {
 #pragma unroll
-                for (int q = 0; q < 2; ++q)
+                    for (int ob = 0; ob < 4; ++ob)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) mac_term(term, hl[q][t], hh[q][t], w1[q][g], xb[t][g]);
-        __builtin_amdgcn_sched_barrier(0);
-        const char* w2 = buf + 6 * ES_BLOCK;                        // h, m, l copies of 4 KiB: [4 output row blocks][64 lanes][8 k]
-        Frag3 w2f[4];
-#pragma unroll
-        for (int ob = 0; ob < 4; ++ob) w2f[ob] = ld3(w2, 2 * ES_BLOCK, ob, lane);
-        Split3x8 hb[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const f32x4 h0 = hh[0][t] + hl[0][t], h1 = hh[1][t] + hl[1][t];
-            hb[t] = join(split3(relu1s(h0[0]), relu1s(h0[1]), relu1s(h0[2]), relu1s(h0[3])),
-                         split3(relu1s(h1[0]), relu1s(h1[1]), relu1s(h1[2]), relu1s(h1[3])));
+                        for (int t = 0; t < NT; ++t) mac_term(term, acc[t][ob], acc[t][ob], w2f[ob], hb[t]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int term = 0; term < 6; ++term)
-#pragma unroll
-            for (int ob = 0; ob < 4; ++ob)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) mac_term(term, acc[t][ob], acc[t][ob], w2f[ob], hb[t]);
-        __builtin_amdgcn_sched_barrier(0);
         if (more) ES_WAIT_PREV() else ES_WAIT_ALL()
         ES_SYNC()
     }
@@ -374,7 +413,7 @@ __device__ __forceinline__ void enc_block_split_body(const float* __restrict__ a
 #pragma unroll
             for (int tb = 0; tb < 4; ++tb) {
                 f32x4 d[NT];
-                rowblock6<NT>(buf + (3 * tb) * ES_BLOCK, lane, xb, smo(so.bv) + tb * 16, lq, d);
+                rowblock6<NT, MD::WC, MD::PROJ>(buf + (MD::WC * tb) * ES_BLOCK, lane, xb, smo(so.bv) + tb * 16, lq, d);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     if (!tok_ok[t]) continue;
@@ -395,11 +434,11 @@ __device__ __forceinline__ void enc_block_split_body(const float* __restrict__ a
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int ob = (ts - 1) * 4 + j;
+            for (int j = 0; j < MD::PB; ++j) {
+                const int ob = (ts - 1) * MD::PB + j;
                 if (ob < nproj_blocks) {
                     f32x4 d[NT];
-                    rowblock6<NT>(buf + (3 * j) * ES_BLOCK, lane, xq, smo(so.bp) + ob * 16, lq, d);
+                    rowblock6<NT, MD::WC, MD::PROJ>(buf + (MD::WC * j) * ES_BLOCK, lane, xq, smo(so.bp) + ob * 16, lq, d);
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
                         if (tok_ok[t])
@@ -420,38 +459,43 @@ __device__ __forceinline__ void enc_block_split_body(const float* __restrict__ a
 // every CU (3 tiles per SIMD; 20 CUs get two heavy ones).  Two straight-line instantiations behind a workgroup-uniform
 // branch: per-wave tile counts decided by branches inside the stage loop cut it into 12-MFMA basic blocks whose LDS reads
 // nothing overlapped (116 us against 105).
+template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void enc_block_split_kernel(
     const float* __restrict__ attn, const float* __restrict__ src, const char* __restrict__ wstream, const float* __restrict__ small, EncSmallS so,
     const float* __restrict__ pos, float* __restrict__ src_out, float* __restrict__ value_out, float* __restrict__ proj_out, int M, int S,
     int nffn_stages, int nproj_blocks, int proj_ld, float eps, int n_small, int value_heads, int n_heavy) {
     const int b = blockIdx.x;
     if (b < n_heavy)
-        enc_block_split_body<2>(attn, src, wstream, small, so, pos, src_out, value_out, proj_out, M, S, nffn_stages, nproj_blocks, proj_ld, eps, n_small,
-                                value_heads, b * 8);
+        enc_block_split_body<2, MODE>(attn, src, wstream, small, so, pos, src_out, value_out, proj_out, M, S, nffn_stages, nproj_blocks, proj_ld, eps,
+                                      n_small, value_heads, b * 8);
     else
-        enc_block_split_body<1>(attn, src, wstream, small, so, pos, src_out, value_out, proj_out, M, S, nffn_stages, nproj_blocks, proj_ld, eps, n_small,
-                                value_heads, n_heavy * 8 + (b - n_heavy) * 4);
+        enc_block_split_body<1, MODE>(attn, src, wstream, small, so, pos, src_out, value_out, proj_out, M, S, nffn_stages, nproj_blocks, proj_ld, eps,
+                                      n_small, value_heads, n_heavy * 8 + (b - n_heavy) * 4);
 }
 
 }  // namespace msm
 
 using namespace msm;
 
-extern "C" int64_t msm_encoder_block_split_stream_bytes(int d_ffn, int proj_width) {
-    const int ntail = proj_width > 0 ? 1 + (proj_width / 16 + 3) / 4 : 0;
-    return (int64_t)(1 + d_ffn / 32 + ntail) * ES_STAGE;
+template <int MODE>
+static int64_t split_stream_bytes(int d_ffn, int proj_width) {
+    using MD = ESMode<MODE>;
+    const int ntail = proj_width > 0 ? 1 + cdiv(proj_width / 16, MD::PB) : 0;
+    return (int64_t)(1 + cdiv(d_ffn, 32 * MD::HP) + ntail) * ES_STAGE;
 }
 
-extern "C" int msm_encoder_block_split_fwd(const float* attn, const float* src, const void* wstream, const float* small, const float* pos,
-                                           float* src_out, float* value_out, float* proj_out, int M, int tokens_per_image, int d_ffn,
-                                           int proj_width, int value_heads, float eps, void* stream) {
-    MSM_REQUIRE(attn && src && wstream && small && src_out, "msm_encoder_block_split_fwd: null pointer");
-    MSM_REQUIRE(M > 0 && tokens_per_image > 0 && d_ffn > 0 && d_ffn % 32 == 0, "msm_encoder_block_split_fwd: d_ffn=%d must be a positive multiple of 32", d_ffn);
-    MSM_REQUIRE((value_out == nullptr) == (proj_out == nullptr), "msm_encoder_block_split_fwd: value_out and proj_out go together");
-    MSM_REQUIRE(!value_out || (pos && proj_width > 0 && proj_width % 16 == 0), "msm_encoder_block_split_fwd: the next layer's projections need pos and a proj width that is a multiple of 16");
-    MSM_REQUIRE(value_heads == 0 || (ES_C % value_heads == 0), "msm_encoder_block_split_fwd: value_heads=%d must divide 64", value_heads);
+template <int MODE>
+static int split_launch(const char* who, const float* attn, const float* src, const void* wstream, const float* small, const float* pos, float* src_out,
+                        float* value_out, float* proj_out, int M, int tokens_per_image, int d_ffn, int proj_width, int value_heads, float eps,
+                        void* stream) {
+    using MD = ESMode<MODE>;
+    MSM_REQUIRE(attn && src && wstream && small && src_out, "%s: null pointer", who);
+    MSM_REQUIRE(M > 0 && tokens_per_image > 0 && d_ffn > 0 && d_ffn % 32 == 0, "%s: d_ffn=%d must be a positive multiple of 32", who, d_ffn);
+    MSM_REQUIRE((value_out == nullptr) == (proj_out == nullptr), "%s: value_out and proj_out go together", who);
+    MSM_REQUIRE(!value_out || (pos && proj_width > 0 && proj_width % 16 == 0), "%s: the next layer's projections need pos and a proj width that is a multiple of 16", who);
+    MSM_REQUIRE(value_heads == 0 || (ES_C % value_heads == 0), "%s: value_heads=%d must divide 64", who, value_heads);
     MSM_REQUIRE(((((uintptr_t)attn) | ((uintptr_t)src) | ((uintptr_t)wstream) | ((uintptr_t)src_out) | ((uintptr_t)value_out) | ((uintptr_t)proj_out) | ((uintptr_t)pos) | ((uintptr_t)small)) & 15) == 0,
-                "msm_encoder_block_split_fwd: pointers must be 16-byte aligned");
+                "%s: pointers must be 16-byte aligned", who);
     const int pw = value_out ? proj_width : 0;
     EncSmallS so;
     so.bo = 0; so.g1 = 64; so.be1 = 128; so.b1 = 192; so.b2 = 192 + d_ffn; so.g2 = so.b2 + 64; so.be2 = so.g2 + 64; so.bv = so.be2 + 64; so.bp = so.bv + 64;
@@ -472,9 +516,25 @@ extern "C" int msm_encoder_block_split_fwd(const float* attn, const float* src, 
         n_heavy = cdiv(tiles, 8);
         n_light = 0;
     }
-    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)enc_block_split_kernel, lds));
-    hipLaunchKernelGGL(enc_block_split_kernel, dim3(n_heavy + n_light), dim3(256), lds, (hipStream_t)stream, attn, src, (const char*)wstream, small, so,
-                       pos, src_out, value_out, proj_out, M, tokens_per_image, d_ffn / 32, pw / 16, proj_width, eps, n_small, value_heads, n_heavy);
-    MSM_CHECK_LAUNCH("msm_encoder_block_split_fwd");
+    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)enc_block_split_kernel<MODE>, lds));
+    hipLaunchKernelGGL(enc_block_split_kernel<MODE>, dim3(n_heavy + n_light), dim3(256), lds, (hipStream_t)stream, attn, src, (const char*)wstream, small,
+                       so, pos, src_out, value_out, proj_out, M, tokens_per_image, cdiv(d_ffn, 32 * MD::HP), pw / 16, proj_width, eps, n_small,
+                       value_heads, n_heavy);
+    MSM_CHECK_LAUNCH(who);
     return MSM_OK;
+}
+
+extern "C" int64_t msm_encoder_block_split_stream_bytes(int d_ffn, int proj_width) { return split_stream_bytes<0>(d_ffn, proj_width); }
+extern "C" int msm_encoder_block_split_fwd(const float* attn, const float* src, const void* wstream, const float* small, const float* pos,
+                                           float* src_out, float* value_out, float* proj_out, int M, int tokens_per_image, int d_ffn,
+                                           int proj_width, int value_heads, float eps, void* stream) {
+    return split_launch<0>("msm_encoder_block_split_fwd", attn, src, wstream, small, pos, src_out, value_out, proj_out, M, tokens_per_image, d_ffn,
+                           proj_width, value_heads, eps, stream);
+}
+extern "C" int64_t msm_encoder_block_lp_stream_bytes(int d_ffn, int proj_width) { return split_stream_bytes<1>(d_ffn, proj_width); }
+extern "C" int msm_encoder_block_lp_fwd(const float* attn, const float* src, const void* wstream, const float* small, const float* pos,
+                                        float* src_out, float* value_out, float* proj_out, int M, int tokens_per_image, int d_ffn,
+                                        int proj_width, int value_heads, float eps, void* stream) {
+    return split_launch<1>("msm_encoder_block_lp_fwd", attn, src, wstream, small, pos, src_out, value_out, proj_out, M, tokens_per_image, d_ffn,
+                           proj_width, value_heads, eps, stream);
 }

@@ -776,7 +776,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         self._packed = None
         # "bf16" (BASELINE configs 3 / 5; the reference's low-precision mode is autocast over the whole model,
         # tabletop_train_net_pretrained.py:232): the encoder's token-wise GEMMs run with bf16 MFMA operands and fp32
-        # accumulation (msm_encoder_block_bf16_fwd); residual stream, LayerNorms, sampling arithmetic and outputs stay fp32.
+        # accumulation (msm_encoder_block_lp_fwd); residual stream, LayerNorms, sampling arithmetic and outputs stay fp32.
         # "f32_split": fp32 results on the bf16 matrix pipe -- every operand split exactly into three bf16 terms, six MFMAs
         # per product (msm_encoder_block_split_fwd); as accurate as "f32" (tests measure both against float64), ~30 % faster
         self.precision = "f32"
@@ -811,7 +811,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
                     smalls += [nxt.value_proj.bias, bp]
                 else:
                     smalls += [torch.zeros(64, device=device), torch.zeros(a.sampling_offsets.out_features + a.attention_weights.out_features, device=device)]
-                pack = {"f32": ops.pack_encoder_block, "f32_split": ops.pack_encoder_block_split, "bf16": ops.pack_encoder_block_bf16}[self.precision]
+                pack = {"f32": ops.pack_encoder_block, "f32_split": ops.pack_encoder_block_split, "bf16": ops.pack_encoder_block_lp}[self.precision]
                 stream = pack(a.output_proj.weight, layer.linear1.weight, layer.linear2.weight, wv, wp)
                 pw = a.sampling_offsets.out_features + a.attention_weights.out_features
                 out.append((stream, torch.cat([t.reshape(-1) for t in smalls]).contiguous(), layer.linear1.out_features, pw))
@@ -908,7 +908,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
                 attn = ops.ms_deform_attn_encoder(value, ss, starts, proj, layer.self_attn.n_heads, layer.self_attn.n_points)
                 stream, small, d_ffn, pw = packed[l]
                 # layers 1.. read a head-major value (written so by the previous block): 64-byte instead of 32-byte taps
-                block = {"f32": ops.encoder_block, "f32_split": ops.encoder_block_split, "bf16": ops.encoder_block_bf16}[self.precision]
+                block = {"f32": ops.encoder_block, "f32_split": ops.encoder_block_split, "bf16": ops.encoder_block_lp}[self.precision]
                 src, value, proj = block(attn, src, stream, small, d_ffn, pw, pos=lvl_pos, tokens_per_image=S_tok,
                                                      want_next=l + 1 < len(layers), eps=layer.norm1.eps,
                                                      value_heads=layers[l + 1].self_attn.n_heads if l + 1 < len(layers) else 0)

@@ -922,6 +922,61 @@ def pack_encoder_block_split(wo, w1, w2, wv=None, wp=None):
     return out
 
 
+def pack_encoder_block_lp(wo, w1, w2, wv=None, wp=None):
+    """One encoder layer's matrices as the weight stream of msm_encoder_block_lp_fwd (include/msm_hip.h): the low-precision
+    mode on the K = 32 kernel -- projections as [h, m] bf16 pairs, linear1 / linear2 as single bf16 copies, three hidden pairs
+    per 12-block stage.  Returns an int16 tensor (bf16 bit patterns)."""
+    dev = wo.device
+    d_ffn = w1.shape[0]
+
+    def rowblocks(w):       # (N, 64) -> (N/16, 1024): block[G][lq][lj][hh][c] = W[r0 + lj][(2G + hh)*16 + lq*4 + c]
+        return w.reshape(-1, 16, 2, 2, 4, 4).permute(0, 2, 4, 1, 3, 5).reshape(-1, 1024)
+
+    def w2pairs(w):         # (64, d_ffn) -> (d_ffn/32, 2048): [ob][lq][lj][hh][c] = W[ob*16 + lj][(2P + hh)*16 + lq*4 + c]
+        return w.reshape(4, 16, d_ffn // 32, 2, 4, 4).permute(2, 0, 4, 1, 3, 5).reshape(-1, 2048)
+
+    def hm(w):
+        h = w.to(torch.bfloat16).float()
+        return h, (w - h).to(torch.bfloat16).float()
+
+    def proj_stage_blocks(w, per_stage):                  # [h, m] per row block, zero padded to whole 12-block stages
+        h, m = (rowblocks(t) for t in hm(w))
+        t = torch.stack([h, m], 1).reshape(-1, 1024)
+        pad = (-t.shape[0]) % (2 * per_stage) if per_stage * 2 == 12 else (12 - t.shape[0] % 12) % 12
+        return torch.cat([t, torch.zeros(pad, 1024, device=dev)], 0)
+
+    npair = d_ffn // 32
+    w1h = rowblocks(w1.to(torch.bfloat16).float()).reshape(npair, 2048)            # W1(q0) | W1(q1) of a pair
+    w2h = w2pairs(w2.to(torch.bfloat16).float())                                    # (npair, 2048)
+    ffn = torch.cat([w1h, w2h], 1)                                                  # (npair, 4 blocks)
+    ffn = torch.cat([ffn, torch.zeros((-npair) % 3, 4096, device=dev)], 0).reshape(-1)
+    blocks = [proj_stage_blocks(wo, 4).reshape(-1), ffn]
+    if wv is not None:
+        blocks += [proj_stage_blocks(wv, 4).reshape(-1), proj_stage_blocks(wp, 6).reshape(-1)]
+    out = torch.cat(blocks, 0).to(torch.bfloat16).contiguous().view(torch.int16).reshape(-1)
+    need = int(lib().msm_encoder_block_lp_stream_bytes(d_ffn, 0 if wp is None else wp.shape[0]))
+    if out.numel() * 2 != need:
+        raise RuntimeError(f"pack_encoder_block_lp: built {out.numel() * 2} bytes, the kernel expects {need}")
+    return out
+
+
+def encoder_block_lp(attn, src, wstream, small, d_ffn, proj_width, *, pos=None, tokens_per_image=None, want_next=True,
+                     value_heads=0, eps=1e-5):
+    """encoder_block in the low-precision mode on the K = 32 kernel (wstream from pack_encoder_block_lp); fp32 in, fp32 out."""
+    _c(attn, "attn"), _c(src, "src"), _c(wstream, "wstream", torch.int16), _c(small, "small"), _c(pos, "pos")
+    B, S, C = src.shape
+    src_out = torch.empty_like(src)
+    value_out = proj_out = None
+    if want_next:
+        value_out = torch.empty((B, value_heads, S, C // value_heads), device=src.device, dtype=torch.float32) \
+            if value_heads else torch.empty_like(src)
+        proj_out = torch.empty((B, S, proj_width), device=src.device, dtype=torch.float32)
+    rc = lib().msm_encoder_block_lp_fwd(_p(attn), _p(src), _p(wstream), _p(small), _p(pos), _p(src_out), _p(value_out), _p(proj_out),
+                                        B * S, tokens_per_image or S, d_ffn, proj_width, int(value_heads), eps, _stream())
+    check(rc, "msm_encoder_block_lp_fwd")
+    return src_out, value_out, proj_out
+
+
 def encoder_block_split(attn, src, wstream, small, d_ffn, proj_width, *, pos=None, tokens_per_image=None, want_next=True,
                         value_heads=0, eps=1e-5):
     """encoder_block in fp32 accuracy on the bf16 matrix pipe (wstream from pack_encoder_block_split): fp32 in, fp32 out."""
