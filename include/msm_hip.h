@@ -78,6 +78,7 @@ enum {
     MSM_OPT_MS_CHUNK,           /* 1..8 seed blocks per hill-climb launch */
     MSM_OPT_MS_NO_PERSISTENT,   /* 1: one launch per seeding step */
     MSM_OPT_ATTN_FUSED_KV,      /* reserved (no effect) */
+    MSM_OPT_KV_PIPE,            /* msm_kv_project_multi_bf16: 0 = fp32 MFMAs with only the store rounded (default: bf16 MFMAs) */
     MSM_OPT_MASK_KERNEL,        /* fp32 mask step: 2 = one wave per SIMD with mask_embed in registers (C = 64 only), 3 = prefetch ring of four groups, 4 = software-pipelined epilogue (C = 64 attention-mask launches) */
     MSM_OPT_COUNT
 };
@@ -276,10 +277,16 @@ int msm_kv_project_multi_f32(int n_jobs, const float* const* x, const float* con
                              float* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride,
                              int B, int C, int N, void* stream);
 /* The same with the result stored as bf16 (low-precision mode): half the bytes of this write-bound launch and of the K/V
- * reads of msm_hypersphere_attn_lp_fwd.  The products are exact fp32 MFMAs; only the stored value is rounded. */
+ * reads of msm_hypersphere_attn_lp_fwd.  w is rounded to one bf16 and x enters as a hi + lo pair (bf16 MFMAs, fp32
+ * accumulation; MSM_OPT_KV_PIPE = 0: exact fp32 MFMAs, only the stored value rounded). */
 int msm_kv_project_multi_bf16(int n_jobs, const float* const* x, const float* const* w, const float* const* cmat,
                               uint16_t* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride,
                               int B, int C, int N, void* stream);
+/* fp32 results on the bf16 matrix pipe (exact three-term splits of x and w, six K = 32 MFMAs per product; see
+ * msm_encoder_block_split_fwd): same arguments and output as msm_kv_project_multi_f32. */
+int msm_kv_project_multi_split(int n_jobs, const float* const* x, const float* const* w, const float* const* cmat,
+                               float* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride,
+                               int B, int C, int N, void* stream);
 
 /* mask_features (MSD:349-358): the last GroupNorm + ReLU of the FPN level fused into the 1x1 convolution after it.
  *   out [B][N][HW] (NCHW) = bias + w act(x),  x [B][HW][64] tokens, w [N][64], N in {256, 512}, HW % 4 == 0;

@@ -927,10 +927,24 @@ def test_kv_project_multi_equals_single_launches():
         closed(o, ref.cpu(), rtol=2e-5, atol=2e-5)
         if x.shape[2] * x.shape[3] * B >= 8192 or ops().is_token_major(x):        # the single launch takes the same kernel there
             assert torch.equal(o, ops().kv_project(x, w, c))
-    # low-precision mode: the same fp32 products, stored as bf16 (round to nearest even)
-    outs16 = ops().kv_project_multi(xs, ws, cs, out_dtype=torch.bfloat16)
+    # low-precision mode: bf16 output.  KV_PIPE = 0: the same fp32 products, only the store rounded (round to nearest even);
+    # default: bf16 MFMAs -- w rounded to one bf16, x as a hi + lo pair -- against float64 on those operands
+    with option_ctx("KV_PIPE", 0):
+        outs16 = ops().kv_project_multi(xs, ws, cs, out_dtype=torch.bfloat16)
     for o, o16 in zip(outs, outs16):
         assert o16.dtype == torch.bfloat16 and torch.equal(o16, o.to(torch.bfloat16))
+    outs16 = ops().kv_project_multi(xs, ws, cs, out_dtype=torch.bfloat16)
+    for x, w, c, o16 in zip(xs, ws, cs, outs16):
+        ref = torch.einsum("bchw,nc->bhwn", x.double(), _bf16_round(w.cpu()).double().to(x.device)).reshape(B, -1, N) + c.double()
+        err = (o16.double() - ref).abs().cpu()
+        assert o16.dtype == torch.bfloat16 and float((err / (ref.abs().cpu() + 1.0)).max()) < 6e-3      # one bf16 rounding of the result (2^-8 relative)
+    # fp32 accuracy on the bf16 matrix pipe (exact three-term splits): the fp32 tolerances, and no further from float64 than the fp32 MFMAs
+    outs_s = ops().kv_project_multi(xs, ws, cs, split=True)
+    for x, w, c, o, os_ in zip(xs, ws, cs, outs, outs_s):
+        ref = (torch.einsum("bchw,nc->bhwn", x.double(), w.double()).reshape(B, -1, N) + c.double()).cpu()
+        closed(os_, ref, rtol=2e-5, atol=2e-5)
+        e_s, e_m = (os_.double().cpu() - ref).abs().mean(), (o.double().cpu() - ref).abs().mean()
+        assert float(e_s) <= 1.5 * float(e_m) + 1e-9
 
 
 @pytest.mark.parametrize("B,H,W,Cout", [(2, 12, 16, 256), (1, 7, 36, 64), (1, 30, 40, 128)])

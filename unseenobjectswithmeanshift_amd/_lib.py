@@ -62,6 +62,7 @@ _SIGNATURES = {
     "msm_kv_project_f32": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_l, c_p]),
     "msm_kv_project_multi_f32": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "msm_kv_project_multi_bf16": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "msm_kv_project_multi_split": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "msm_tokens_proj_nchw_f32": (c_i, [c_f, c_f, c_f, c_p, c_f, c_f, c_i, c_fl, c_i, c_f, c_i, c_i, c_i, c_i, c_p]),
     "msm_dec_pack_weight": (c_i, [c_f, c_f, c_i, c_i, c_p]),
     "msm_dec_post_cross": (c_i, [c_f] * 12 + [c_i, c_i, c_i, c_fl, c_p]),
@@ -120,7 +121,7 @@ def lib():
 
 # kernel-selection overrides of include/msm_hip.h (enum order), for tools/ and tests/ only
 OPTIONS = ("MASK_NC", "MASKB_TARGET", "GEMM_TILE", "GEMM_SHALLOW", "ATTN_TARGET", "ATTN_KERNEL", "ATTN_QK_MAX", "ATTN_QKCFG",
-           "CONVIN_NT", "POST_GENERIC", "ENC_NO_COOP", "MSDA_GENERIC", "MS_CHUNK", "MS_NO_PERSISTENT", "ATTN_FUSED_KV", "MASK_KERNEL")
+           "CONVIN_NT", "POST_GENERIC", "ENC_NO_COOP", "MSDA_GENERIC", "MS_CHUNK", "MS_NO_PERSISTENT", "ATTN_FUSED_KV", "KV_PIPE", "MASK_KERNEL")
 OPT_AUTO = -1
 
 

@@ -40,38 +40,6 @@ struct EncSmallS {                           // offsets (floats) into the packed
     int bo, g1, be1, b1, b2, g2, be2, bv, bp;
 };
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ f32x4 mfma_bf16k32(bf16x8 a, bf16x8 b, f32x4 c) {
-#if ES_EXP == 2
-    const u32x4b ua = __builtin_bit_cast(u32x4b, a), ub = __builtin_bit_cast(u32x4b, b);
-    c[0] += __uint_as_float(ua.x ^ ub.x);
-    return c;
-#else
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-#endif
-}
-__device__ __forceinline__ bf16x8 cat8(bf16x4 a, bf16x4 b) {
-    const u32x2b ua = __builtin_bit_cast(u32x2b, a), ub = __builtin_bit_cast(u32x2b, b);
-    return __builtin_bit_cast(bf16x8, u32x4b{ua.x, ua.y, ub.x, ub.y});
-}
-struct Split3 {                                // x = h + m + l, four values
-    bf16x4 h, m, l;
-};
-struct Split3x8 {                              // the same for the eight values a lane feeds into one K = 32 MFMA
-    bf16x8 h, m, l;
-};
-__device__ __forceinline__ Split3 split3(float a, float b, float c, float d) {
-    Split3 r;
-    r.h = pack4(a, b, c, d);
-    const u32x2b uh = __builtin_bit_cast(u32x2b, r.h);
-    const float ra = a - bf16_hi_as_float(uh.x, 0), rb = b - bf16_hi_as_float(uh.x, 1), rc = c - bf16_hi_as_float(uh.y, 0),
-                rd = d - bf16_hi_as_float(uh.y, 1);
-    r.m = pack4(ra, rb, rc, rd);
-    const u32x2b um = __builtin_bit_cast(u32x2b, r.m);
-    r.l = pack4(ra - bf16_hi_as_float(um.x, 0), rb - bf16_hi_as_float(um.x, 1), rc - bf16_hi_as_float(um.y, 0), rd - bf16_hi_as_float(um.y, 1));
-    return r;
-}
-__device__ __forceinline__ Split3x8 join(const Split3& a, const Split3& b) { return Split3x8{cat8(a.h, b.h), cat8(a.m, b.m), cat8(a.l, b.l)}; }
 // the lane's operand of 32-wide k-group (or output row block) i of a physical block
 __device__ __forceinline__ bf16x8 sfrag(const char* __restrict__ blk, int i, int lane) {
 #if ES_EXP == 1
@@ -108,9 +76,6 @@ struct ESMode<1> {
     static constexpr int HP = 3, PB = 6;
     static constexpr unsigned PROJ = 0x38, L1 = 0x30, L2 = 0x20;      // {wm xh, wh xm, wh xh}, {wh xm, wh xh}, {wh xh}
 };
-struct Frag3 {                                 // a weight fragment's three terms
-    bf16x8 h, m, l;
-};
 // fragment i of a logical block whose h / m / l copies lie `step` bytes apart
 template <int COPIES>
 __device__ __forceinline__ Frag3 ld3(const char* __restrict__ blk, int step, int i, int lane) {
@@ -119,17 +84,6 @@ __device__ __forceinline__ Frag3 ld3(const char* __restrict__ blk, int step, int
     f.m = COPIES > 1 ? sfrag(blk + step, i, lane) : f.h;          // copies a mode does not stream are never multiplied with
     f.l = COPIES > 2 ? sfrag(blk + 2 * step, i, lane) : f.h;
     return f;
-}
-// product term 0 .. 5 of mac6 on its own (callers interleave the terms of several accumulator chains)
-__device__ __forceinline__ void mac_term(int term, f32x4& lo, f32x4& hi, const Frag3& w, const Split3x8& x) {
-    switch (term) {
-        case 0: lo = mfma_bf16k32(w.l, x.h, lo); break;
-        case 1: lo = mfma_bf16k32(w.h, x.l, lo); break;
-        case 2: lo = mfma_bf16k32(w.m, x.m, lo); break;
-        case 3: lo = mfma_bf16k32(w.m, x.h, lo); break;
-        case 4: lo = mfma_bf16k32(w.h, x.m, lo); break;
-        default: hi = mfma_bf16k32(w.h, x.h, hi); break;
-    }
 }
 // one [16 rows][64 k] logical block (physical blocks blk, blk + 1, blk + 2 = h, m, l) applied to the two k-groups of NT token
 // tiles: D (layout L) = bias + W x.  Every weight fragment is read from LDS ONCE for the NT tiles of the wave: with one tile

@@ -159,6 +159,141 @@ __global__ __launch_bounds__(KP_W * 64) void kv_project_multi_kernel(KvJobs jobs
                     (int)blockIdx.x - jobs.first[j], jobs.first[j + 1] - jobs.first[j], wl);
 }
 
+// ---- the same projection on the bf16 matrix pipe ---------------------------------------------------------------------------
+// MODE 0 (precision "f32_split"): fp32 accuracy -- x and w as exact three-term bf16 splits, six K = 32 MFMAs per product
+// (bf16.h); 192 MFMAs of 16 cycles per (16 tokens x 256 features) unit instead of 256 of 32: the launch moves from the
+// fp32 MFMA's bound (63 us of matrix time at B = 8) to its 309-MB write.  MODE 1 (precision "bf16"): w rounded to one bf16,
+// x as hi + lo, two MFMAs per product, bf16 output.
+// The weight lives in LDS as bf16 copies, rows of 64 + 8 (144 B: 16 rows x ds_read_b128 conflict-free); a workgroup keeps ONE
+// 256-feature half of its job's weight (three copies: 108 KiB) and takes the units of that half -- workgroup parity picks
+// the half.  K order k = lq*16 + G*8 + e on both operands, so a lane's 16 x-values are its two B operands as they are loaded.
+constexpr int KS_LD = KP_K + 8;      // LDS row stride of a bf16 weight copy (elements)
+constexpr int KS_W = 8;              // waves per workgroup of the bf16-pipe kernel
+
+template <typename OT, int MODE>
+__device__ __forceinline__ void kv_project_split_body(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ cmat, OT* __restrict__ out, int B, int HW, int N,
+                                                      int tokens, int64_t x_sb, int wg, int nwg, unsigned short* wl) {
+    constexpr int COPIES = MODE == 0 ? 3 : 1;
+    constexpr unsigned TERMS = MODE == 0 ? 0x3fu : 0x30u;      // mac_term bits: all six | {wh xm, wh xh}
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    const int halves = N / (KP_FB * 16);
+    // this workgroup's half of the features (two halves: even / odd workgroups; a job given ONE workgroup walks both in turn)
+    const int nh = nwg >= halves ? 1 : halves;                  // halves this workgroup covers
+    const int h0 = nwg >= halves ? wg % halves : 0;
+    const int wg_h = nwg >= halves ? wg / halves : 0, nwg_h = nwg >= halves ? (nwg - h0 + halves - 1) / halves : 1;
+    const int tiles = (HW + 15) / 16;
+    for (int hh = 0; hh < nh; ++hh) {
+        const int half = h0 + hh;
+        const int n_base = half * KP_FB * 16;
+        if (hh > 0) __syncthreads();
+        for (int i = tid; i < KP_FB * 16 * (KP_K / 4); i += KS_W * 64) {
+            const int n = i >> 4, c4 = i & 15;
+            const float4 v = *reinterpret_cast<const float4*>(w + (int64_t)(n_base + n) * KP_K + c4 * 4);
+            const Split3 sp = split3(v.x, v.y, v.z, v.w);
+            unsigned short* dst = wl + n * KS_LD + c4 * 4;
+            *reinterpret_cast<bf16x4*>(dst) = sp.h;
+            if constexpr (COPIES > 1) {
+                *reinterpret_cast<bf16x4*>(dst + KP_FB * 16 * KS_LD) = sp.m;
+                *reinterpret_cast<bf16x4*>(dst + 2 * KP_FB * 16 * KS_LD) = sp.l;
+            }
+        }
+        __syncthreads();
+        const int units = tiles * B;
+        const int slots = nwg_h * KS_W;
+        const int full_rounds = units / slots;
+        const int left = units - full_rounds * slots;
+        const int left_slot = (wave >> 2) * (nwg_h * 4) + wg_h * 4 + (wave & 3);
+        const int mine = full_rounds + (left_slot < left ? 1 : 0);
+        auto unit_of = [&](int it) { return (it < full_rounds) ? it * slots + wg_h * KS_W + wave : full_rounds * slots + left_slot; };
+        auto load_x = [&](int u, float (&xv)[16]) {
+            const int img = u % B, tile = u / B;
+            const int p = min(tile * 16 + lj, HW - 1);
+            if (tokens) {
+                const float* xp = x + (int64_t)img * x_sb + (int64_t)p * KP_K + lq * 16;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const float4 t = *reinterpret_cast<const float4*>(xp + s4 * 4);
+                    xv[s4 * 4 + 0] = t.x; xv[s4 * 4 + 1] = t.y; xv[s4 * 4 + 2] = t.z; xv[s4 * 4 + 3] = t.w;
+                }
+            } else {
+                const float* xp = x + (int64_t)img * x_sb + (int64_t)lq * 16 * HW + p;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) xv[s] = xp[(int64_t)s * HW];
+            }
+        };
+        // (a wave gets a few units: nothing to prefetch across units; 8 waves per workgroup -- the 16 of the fp32 kernel leave
+        // 128 registers per lane, which the three-term operands do not fit: 80 - 350 spilled registers, 150 - 470 us)
+        for (int it = 0; it < mine; ++it) {
+            const int u = unit_of(it);
+            const int tile = u / B, img = u % B;
+            const int p = min(tile * 16 + lj, HW - 1);
+            const bool live = tile * 16 + lj < HW;
+            const float* cp = cmat + (int64_t)p * N + n_base + lq * 4;
+            OT* op = out + ((int64_t)img * HW + p) * N + n_base + lq * 4;
+            float xb[16];
+            load_x(u, xb);
+            float4 cm[KP_FB];
+#pragma unroll
+            for (int fb = 0; fb < KP_FB; ++fb) cm[fb] = *reinterpret_cast<const float4*>(cp + fb * 16);
+            Split3x8 xs[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                xs[g] = join(split3(xb[8 * g], xb[8 * g + 1], xb[8 * g + 2], xb[8 * g + 3]), split3(xb[8 * g + 4], xb[8 * g + 5], xb[8 * g + 6], xb[8 * g + 7]));
+            const unsigned short* wp = wl + lj * KS_LD + lq * 16;
+#pragma unroll
+            for (int fb = 0; fb < KP_FB; fb += 2) {
+                // two feature blocks in flight: consecutive MFMAs alternate accumulators; low-order terms apart from the leading one
+                f32x4 hi[2], lo[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    hi[j] = f32x4{cm[fb + j].x, cm[fb + j].y, cm[fb + j].z, cm[fb + j].w};
+                    lo[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    Frag3 wf[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const unsigned short* q = wp + (fb + j) * 16 * KS_LD + g * 8;
+                        wf[j].h = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4b*>(q));
+                        wf[j].m = COPIES > 1 ? __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4b*>(q + KP_FB * 16 * KS_LD)) : wf[j].h;
+                        wf[j].l = COPIES > 1 ? __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4b*>(q + 2 * KP_FB * 16 * KS_LD)) : wf[j].h;
+                    }
+#pragma unroll
+                    for (int term = 0; term < 6; ++term)
+                        if ((TERMS >> term) & 1u) {
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) mac_term(term, lo[j], hi[j], wf[j], xs[g]);
+                        }
+                }
+                if (live) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const f32x4 a = hi[j] + lo[j];
+                        if constexpr (std::is_same<OT, float>::value) *reinterpret_cast<float4*>(op + (fb + j) * 16) = make_float4(a[0], a[1], a[2], a[3]);
+                        else *reinterpret_cast<bf16x4*>(op + (fb + j) * 16) = pack4(a[0], a[1], a[2], a[3]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);      // one pair of feature blocks at a time: left alone hipcc hoists the fragment
+                                                        // reads of all sixteen to the top (96 x 4 registers: 250 spilled)
+            }
+        }
+    }
+}
+
+template <typename OT, int MODE>
+__global__ __launch_bounds__(KS_W * 64) void kv_project_multi_split_kernel(KvJobs jobs, int B, int N) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short wls[];   // [copies][256][KS_LD] bf16
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < KP_MAXJ; ++i) j += (i < jobs.n && (int)blockIdx.x >= jobs.first[i]) ? 1 : 0;
+    kv_project_split_body<OT, MODE>(jobs.x[j], jobs.w[j], jobs.cmat[j], (OT*)jobs.out[j], B, jobs.HW[j], N, jobs.tokens[j], jobs.x_sb[j],
+                                    (int)blockIdx.x - jobs.first[j], jobs.first[j + 1] - jobs.first[j], wls);
+}
+
 // ---- mask_features: GroupNorm + ReLU of the FPN output fused into the 1x1 convolution that follows it --------------
 //     out[b][n][p] = bias[n] + sum_k w[n][k] * relu((x[b][p][k] - mean_g) * rstd_g * gamma[k] + beta[k])      (MSD:349-358)
 // Same weight-stationary scheme as above with the MFMA operands swapped (rows = tokens, cols = output channels), so a
@@ -294,7 +429,8 @@ extern "C" int msm_kv_project_f32(const float* x, const float* w, const float* c
     return MSM_OK;
 }
 
-template <typename OT>
+// PIPE: -1 = fp32 MFMAs (kv_project_multi_kernel); 0 / 1 = MODE of kv_project_multi_split_kernel (bf16 matrix pipe)
+template <typename OT, int PIPE>
 static int kv_project_multi_impl(const char* who, int n_jobs, const float* const* x, const float* const* w, const float* const* cmat,
                                  OT* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride, int B, int C,
                                  int N, void* stream) {
@@ -329,9 +465,15 @@ static int kv_project_multi_impl(const char* who, int n_jobs, const float* const
         jobs.x[j] = jobs.w[j] = jobs.cmat[j] = nullptr; jobs.out[j] = nullptr;
         jobs.HW[j] = jobs.tokens[j] = 0; jobs.x_sb[j] = 0;
     }
-    const size_t lds = sizeof(float) * (size_t)N * KP_LD;
-    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)kv_project_multi_kernel<OT>, lds));
-    hipLaunchKernelGGL(kv_project_multi_kernel<OT>, dim3(wg), dim3(KP_W * 64), lds, (hipStream_t)stream, jobs, B, N);
+    if constexpr (PIPE >= 0) {
+        const size_t lds = sizeof(unsigned short) * (size_t)(PIPE == 0 ? 3 : 1) * KP_FB * 16 * KS_LD;
+        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)kv_project_multi_split_kernel<OT, PIPE>, lds));
+        hipLaunchKernelGGL((kv_project_multi_split_kernel<OT, PIPE>), dim3(wg), dim3(KS_W * 64), lds, (hipStream_t)stream, jobs, B, N);
+    } else {
+        const size_t lds = sizeof(float) * (size_t)N * KP_LD;
+        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)kv_project_multi_kernel<OT>, lds));
+        hipLaunchKernelGGL(kv_project_multi_kernel<OT>, dim3(wg), dim3(KP_W * 64), lds, (hipStream_t)stream, jobs, B, N);
+    }
     MSM_CHECK_LAUNCH(who);
     return MSM_OK;
 }
@@ -339,12 +481,20 @@ static int kv_project_multi_impl(const char* who, int n_jobs, const float* const
 extern "C" int msm_kv_project_multi_f32(int n_jobs, const float* const* x, const float* const* w, const float* const* cmat,
                                         float* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride,
                                         int B, int C, int N, void* stream) {
-    return kv_project_multi_impl<float>("msm_kv_project_multi_f32", n_jobs, x, w, cmat, out, HW, x_tokens, x_batch_stride, B, C, N, stream);
+    return kv_project_multi_impl<float, -1>("msm_kv_project_multi_f32", n_jobs, x, w, cmat, out, HW, x_tokens, x_batch_stride, B, C, N, stream);
 }
 extern "C" int msm_kv_project_multi_bf16(int n_jobs, const float* const* x, const float* const* w, const float* const* cmat,
                                          uint16_t* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride,
                                          int B, int C, int N, void* stream) {
-    return kv_project_multi_impl<uint16_t>("msm_kv_project_multi_bf16", n_jobs, x, w, cmat, out, HW, x_tokens, x_batch_stride, B, C, N, stream);
+    // bf16 MFMAs (w rounded to one bf16, x as hi + lo) unless option KV_PIPE says 0: fp32 MFMAs, only the store rounded
+    if (opt(MSM_OPT_KV_PIPE) == 0)
+        return kv_project_multi_impl<uint16_t, -1>("msm_kv_project_multi_bf16", n_jobs, x, w, cmat, out, HW, x_tokens, x_batch_stride, B, C, N, stream);
+    return kv_project_multi_impl<uint16_t, 1>("msm_kv_project_multi_bf16", n_jobs, x, w, cmat, out, HW, x_tokens, x_batch_stride, B, C, N, stream);
+}
+extern "C" int msm_kv_project_multi_split(int n_jobs, const float* const* x, const float* const* w, const float* const* cmat,
+                                          float* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride,
+                                          int B, int C, int N, void* stream) {
+    return kv_project_multi_impl<float, 0>("msm_kv_project_multi_split", n_jobs, x, w, cmat, out, HW, x_tokens, x_batch_stride, B, C, N, stream);
 }
 
 extern "C" int msm_tokens_proj_nchw_f32(const float* x, const float* w, const float* bias, const double* gn_stats,

@@ -17,7 +17,7 @@ _CACHE_ATTRS = ("_q0", "_kv_cache", "_fold_cache", "_tails_cache", "_pos_cache",
                 "_packed_mf", "_bf16_cache", "_folded_cache")
 
 
-_PLAN_ATTRS = ("precision", "mask_step_dtype", "tails_dtype", "attention_dtype", "sparse_taps", "aux_outputs", "folded_mask_features", "batched_kv", "fold_kv",
+_PLAN_ATTRS = ("precision", "mask_step_dtype", "tails_dtype", "attention_dtype", "kv_split", "sparse_taps", "aux_outputs", "folded_mask_features", "batched_kv", "fold_kv",
                "fused_tails", "fused_encoder", "fused_front", "fused_kv_attention")
 
 

@@ -98,8 +98,8 @@ class MeanShiftMaskFormerHead(nn.Module):
         """"f32" (the reference's arithmetic, default), "bf16" (BASELINE configs 3 / 5): bf16 MFMA operands with fp32
         accumulation in the encoder's token-wise GEMMs, the decoder's row-local tails, the attention cores and the
         Q x pixel-embedding mask step; everything that decides a sign or normalises (LayerNorms, softmax, unit-norm, the
-        residual streams) stays fp32 -- or "f32_split": fp32 everywhere, the encoder's GEMMs as exact three-term bf16 splits
-        on the bf16 matrix pipe (fp32-accurate, see csrc/enc_block_split.hip)."""
+        residual streams) stays fp32 -- or "f32_split": fp32 everywhere, the encoder's GEMMs and the K/V projection as exact
+        three-term bf16 splits on the bf16 matrix pipe (fp32-accurate, see csrc/enc_block_split.hip)."""
         if mode not in ("f32", "f32_split", "bf16"):
             raise ValueError("precision must be 'f32', 'f32_split' or 'bf16'")
         self.precision = mode
@@ -110,6 +110,8 @@ class MeanShiftMaskFormerHead(nn.Module):
         for a in ("tails_dtype", "attention_dtype"):
             if hasattr(self.predictor, a):
                 setattr(self.predictor, a, low)
+        if hasattr(self.predictor, "kv_split"):
+            self.predictor.kv_split = mode == "f32_split"
         return self
 
     def layers(self, features, image_height=None, image_width=None, mask=None):

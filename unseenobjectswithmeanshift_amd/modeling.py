@@ -278,6 +278,8 @@ class MeanShiftTransformerDecoder(nn.Module):
         # "bf16": the attention cores multiply on bf16 MFMAs (fp32 accumulation, exp, sums) and the batched K/V projection
         # stores bf16; part of set_precision("bf16")
         self.attention_dtype = "f32"
+        # True: the batched K/V projection computes its fp32 products as exact three-term bf16 splits (set_precision("f32_split"))
+        self.kv_split = False
         self._packed_mf = None
 
     def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
@@ -493,7 +495,8 @@ class MeanShiftTransformerDecoder(nn.Module):
             if (self.batched_kv and self.num_layers <= 16 and kv_bytes <= (2 << 30) and all(xl.shape[1] == 64 for xl in xs)
                     and kv_w[0].shape[0] in (256, 512)):       # all layers' K/V live at once: only while that stays small
                 kv_all = ops.kv_project_multi([xs[i % self.num_feature_levels] for i in range(self.num_layers)], kv_w, kv_c,
-                                              out_dtype=torch.bfloat16 if self.attention_dtype == "bf16" else torch.float32)
+                                              out_dtype=torch.bfloat16 if self.attention_dtype == "bf16" else torch.float32,
+                                              split=self.kv_split and self.attention_dtype != "bf16")
         else:
             for i in range(self.num_feature_levels):
                 pos.append(self._pos_tokens(*sizes[i], dev))

@@ -615,10 +615,13 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     return gv, gl, gw
 
 
-def kv_project_multi(xs, ws, cmats, out_dtype=torch.float32):
+def kv_project_multi(xs, ws, cmats, out_dtype=torch.float32, split=False):
     """kv_project for a list of jobs in one launch: xs[j] (B, 64, H_j, W_j) contiguous NCHW or token-major
     (is_token_major), ws[j] (N, 64), cmats[j] (H_j*W_j, N) -> list of (B, H_j*W_j, N).  N in {256, 512}, <= 16 jobs.
-    out_dtype torch.bfloat16: the (fp32-computed) result is stored as bf16 (low-precision mode)."""
+    out_dtype torch.bfloat16: low-precision mode (bf16 MFMAs: w rounded to bf16, x as a hi + lo pair; bf16 output).
+    split: fp32 results on the bf16 matrix pipe (exact three-term splits, msm_kv_project_multi_split)."""
+    if split and out_dtype != torch.float32:
+        raise RuntimeError("kv_project_multi: split is the fp32-accurate form (float32 output)")
     if out_dtype not in (torch.float32, torch.bfloat16):
         raise RuntimeError("kv_project_multi: out_dtype must be float32 or bfloat16")
     n = len(xs)
@@ -639,7 +642,7 @@ def kv_project_multi(xs, ws, cmats, out_dtype=torch.float32):
     vp = ctypes.c_void_p * n
     arr = lambda ts: ctypes.cast(vp(*[t.data_ptr() for t in ts]), ctypes.c_void_p)
     ia, la = (ctypes.c_int32 * n), (ctypes.c_int64 * n)
-    fn = lib().msm_kv_project_multi_f32 if out_dtype == torch.float32 else lib().msm_kv_project_multi_bf16
+    fn = (lib().msm_kv_project_multi_split if split else lib().msm_kv_project_multi_f32) if out_dtype == torch.float32 else lib().msm_kv_project_multi_bf16
     rc = fn(n, arr(xs), arr(ws), arr(cmats), arr(outs), ctypes.cast(ia(*hw), ctypes.c_void_p), ctypes.cast(ia(*tok), ctypes.c_void_p),
             ctypes.cast(la(*sb), ctypes.c_void_p), B, 64, N, _stream())
     check(rc, "msm_kv_project_multi")
