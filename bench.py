@@ -245,7 +245,7 @@ def extra_configs(dev, args):
             g(feats, (H, W))
         t = timed(lambda: g(feats, (H, W)), 50)
         out["configs[1] fp32, split-bf16 encoder"] = {
-            "workload": "batch 8, 640x480, fp32; the six encoder blocks multiply exact three-term bf16 splits (6 MFMAs per product), "
+            "workload": "batch 8, 640x480, fp32; the six encoder blocks and the K/V projection multiply exact three-term bf16 splits (6 MFMAs per product), "
                         "one HIP graph, one batch in flight",
             "value": round(BATCH / t, 1), "unit": "images/sec", "ms_per_step": round(1e3 * t, 3), "dtype": "f32 (split-bf16 products in the encoder)"}
         del g
