@@ -79,7 +79,7 @@ enum {
     MSM_OPT_MS_NO_PERSISTENT,   /* 1: one launch per seeding step */
     MSM_OPT_ATTN_FUSED_KV,      /* reserved (no effect) */
     MSM_OPT_KV_PIPE,            /* msm_kv_project_multi_bf16: 0 = fp32 MFMAs with only the store rounded (default: bf16 MFMAs) */
-    MSM_OPT_MASK_KERNEL,        /* fp32 mask step: 2 = one wave per SIMD with mask_embed in registers (C = 64 only), 3 = prefetch ring of four groups, 4 = software-pipelined epilogue (C = 64 attention-mask launches) */
+    MSM_OPT_MASK_KERNEL,        /* fp32 mask step: 2 = one wave per SIMD with mask_embed in registers (C = 64 only), 3 = prefetch ring of four groups, 4 = software-pipelined epilogue (C = 64 attention-mask launches), 5 = never the 4-query block on the 4x4x1 MFMA */
     MSM_OPT_COUNT
 };
 int msm_set_option(int key, int value);

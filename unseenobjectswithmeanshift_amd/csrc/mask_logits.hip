@@ -117,7 +117,7 @@ __device__ __forceinline__ float acc_val(const f32x4 (&acc)[QB][2 * NC], int m, 
 // Generic per-tile epilogue shared by the fp32 and bf16 kernels (see the layout note above): any tile (partly outside the
 // map, unaligned rows, permuted pixels).  c0: first column of the tile; DO_WRITE / DO_ATTN select the two halves so that a
 // kernel can take the fast path (mask_tile_epilogue_fast below) for one and this one for the other.
-template <int POOL, bool WRITE, int NC, bool DO_WRITE = true, bool DO_ATTN = true>
+template <int POOL, bool WRITE, int NC, bool DO_WRITE = true, bool DO_ATTN = true, bool R4 = false>
 __device__ __forceinline__ void mask_tile_epilogue(const f32x4 (&acc)[QB][2 * NC], float* __restrict__ mask_out,
                                                    uint8_t* __restrict__ attn_out, int* __restrict__ any_flags, int b, int Q,
                                                    int q0, int H, int W, int th, int tw, int ytop, int ybot, int c0, int lj, int lq) {
@@ -129,11 +129,15 @@ __device__ __forceinline__ void mask_tile_epilogue(const f32x4 (&acc)[QB][2 * NC
     asm volatile("" : "+v"(ql));
     const int xb = c0 + NP * lq;                     // first column of this lane (identity mapping)
     if constexpr (WRITE && DO_WRITE) {
-        const bool vec = !PM::PERM && xb + NP <= W && (W & 3) == 0;       // 16-byte aligned rows, whole lane inside the map
 #pragma unroll
         for (int m = 0; m < QB; ++m) {
-            const int q = q0 + m * 16 + ql;
-            if (q >= Q) continue;
+            // (R4: in the 4-query block lane lj of the lq == 0 quarter holds query 96 + (lj & 3) and pixel group lj >> 2)
+            const bool rem = R4 && m == QB - 1;
+            const int pg = rem ? (ql >> 2) : lq;
+            const int xb = c0 + NP * pg;
+            const bool vec = !PM::PERM && xb + NP <= W && (W & 3) == 0;   // 16-byte aligned rows, whole lane inside the map
+            const int q = rem ? q0 + m * 16 + (ql & 3) : q0 + m * 16 + ql;
+            if (q >= Q || (rem && lq != 0)) continue;
             float* o = mask_out + ((int64_t)b * Q + q) * ((int64_t)H * W);
 #pragma unroll
             for (int row = 0; row < 2; ++row) {
@@ -148,7 +152,7 @@ __device__ __forceinline__ void mask_tile_epilogue(const f32x4 (&acc)[QB][2 * NC
                 } else {
 #pragma unroll
                     for (int j = 0; j < NP; ++j) {
-                        const int x = c0 + PM::out_col(lq, j);
+                        const int x = c0 + PM::out_col(pg, j);
                         if (x < W) orow[x] = acc_val<NC>(acc, m, row, j);
                     }
                 }
@@ -268,22 +272,26 @@ __device__ __forceinline__ void* uniform_ptr64(const void* p) {
                    (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u));
 }
 
+// r4: the chunk is 6 full query blocks + 4 queries and block 6 is multiplied on v_mfma_f32_4x4x1_16b_f32 (see mask_logits_kernel):
+// there lane lj of the lq == 0 quarter holds query 96 + (lj & 3) and the pixels of group lj >> 2 (the role lq plays in a full block)
 template <int POOL, bool WRITE, int NC>
 __device__ __forceinline__ void mask_epi_init(MaskEpiConst<POOL, WRITE, NC>& k, float* mask_out, uint8_t* attn_out, int b, int Q, int q0,
-                                              int H, int W, int th, int tw, int lj, int lq) {
+                                              int H, int W, int th, int tw, int lj, int lq, bool r4 = false) {
     using PM = PixMap<POOL, NC>;
     constexpr int NP = 4 * NC;
     const int HW = H * W;
     const int TT = POOL == 1 ? HW : th * tw;
     constexpr int NT = PM::PERM ? 1 : (POOL == 1 ? NP : (NP / (POOL > 0 ? POOL : 1) > 0 ? NP / (POOL > 0 ? POOL : 1) : 1));
-    // first key of the lane inside a tile row
-    const int lane_key = POOL == 1 ? NP * lq : (PM::PERM ? (lq >> 1) : (NP * lq) / (POOL > 0 ? POOL : 1));
-    const bool lane_on = PM::PERM ? ((lq & 1) == 0) : true;
 #pragma unroll
     for (int m = 0; m < QB; ++m) {
-        const int q = q0 + m * 16 + lj;
+        const bool rem = r4 && m == QB - 1;
+        const int pgl = rem ? (lj >> 2) : lq;                  // pixel group of the lane: lq, or lj >> 2 in the 4-query block
+        const int q = rem ? q0 + m * 16 + (lj & 3) : q0 + m * 16 + lj;
+        // first key of the lane inside a tile row
+        const int lane_key = POOL == 1 ? NP * pgl : (PM::PERM ? (pgl >> 1) : (NP * pgl) / (POOL > 0 ? POOL : 1));
+        const bool lane_on = (PM::PERM ? ((pgl & 1) == 0) : true) && (!rem || lq == 0);
         k.aoff[m] = (lane_on && q < Q) ? (unsigned)(q * TT + lane_key) : 0xF0000000u;
-        k.moff[m] = q < Q ? (unsigned)((q * HW + NP * lq) * 4) : 0xF0000000u;
+        k.moff[m] = (q < Q && (!rem || lq == 0)) ? (unsigned)((q * HW + NP * pgl) * 4) : 0xF0000000u;
         k.anyv[m] = 0u;
     }
     if constexpr (POOL != 0)
@@ -302,7 +310,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // offset --, the row_any flags are OR-ed into registers and reach LDS once per kernel.  VALU instructions next to a busy
 // MFMA pipe are expensive (the sibling wave of the SIMD is in its K loop): measured with in-kernel timestamps, the generic
 // epilogue cost 1.8 (15x20 / 30x40 targets) to 3.5 us (60x80) per 3 us tile, this one a few hundred ns.
-template <int POOL, bool WRITE, int NC, bool DO_WRITE, bool DO_ATTN>
+// R4_PARTIAL: block QB - 1 holds per-channel-class PARTIAL sums (4-query block on the 4x4x1 MFMA, see mask_logits_kernel): the tap
+// sum is linear, so it is formed on the partials and the four classes (lanes l ^ 16, l ^ 32) are added afterwards -- two values per
+// tile and lane at POOL 2, one at 4 / 8, instead of all eight accumulators.
+template <int POOL, bool WRITE, int NC, bool DO_WRITE, bool DO_ATTN, bool R4_PARTIAL = false>
 __device__ __forceinline__ void mask_tile_epilogue_fast(const f32x4 (&acc)[QB][2 * NC], MaskEpiConst<POOL, WRITE, NC>& k, int H, int W, int tw,
                                                         int ytop, int ybot, int c0) {
     using PM = PixMap<POOL, NC>;
@@ -361,8 +372,14 @@ __device__ __forceinline__ void mask_tile_epilogue_fast(const f32x4 (&acc)[QB][2
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int jl = J0 + t * JS;
-                const float s = add1(add1(acc_val<NC>(acc, m, 0, jl), acc_val<NC>(acc, m, 0, jl + 1)),
-                                     add1(acc_val<NC>(acc, m, 1, jl), acc_val<NC>(acc, m, 1, jl + 1)));
+                float s = add1(add1(acc_val<NC>(acc, m, 0, jl), acc_val<NC>(acc, m, 0, jl + 1)),
+                               add1(acc_val<NC>(acc, m, 1, jl), acc_val<NC>(acc, m, 1, jl + 1)));
+                if constexpr (R4_PARTIAL) {
+                    if (m == QB - 1) {
+                        s += __shfl_xor(s, 16, 64);
+                        s += __shfl_xor(s, 32, 64);
+                    }
+                }
                 w = t == 0 ? neg_bit(s) : (w | (neg_bit(s) << (8 * t)));
             }
 #ifndef MSM_EPI_AUX
@@ -390,11 +407,11 @@ __device__ __forceinline__ void mask_tile_epilogue_fast(const f32x4 (&acc)[QB][2
 
 // flags collected by the fast path -> LDS (the generic path writes LDS directly); rows / lanes that never stored keep 0
 template <int POOL, bool WRITE, int NC>
-__device__ __forceinline__ void mask_epi_flush(const MaskEpiConst<POOL, WRITE, NC>& k, int* __restrict__ any_flags, int lj) {
+__device__ __forceinline__ void mask_epi_flush(const MaskEpiConst<POOL, WRITE, NC>& k, int* __restrict__ any_flags, int lj, bool r4 = false) {
     if constexpr (POOL != 0) {
 #pragma unroll
         for (int m = 0; m < QB; ++m)
-            if (k.anyv[m] != 0u && k.aoff[m] != 0xF0000000u) any_flags[m * 16 + lj] = 1;
+            if (k.anyv[m] != 0u && k.aoff[m] != 0xF0000000u) any_flags[m * 16 + ((r4 && m == QB - 1) ? (lj & 3) : lj)] = 1;
     }
 }
 
@@ -402,7 +419,7 @@ __device__ __forceinline__ void mask_epi_flush(const MaskEpiConst<POOL, WRITE, N
 // meanshiftformer_transformer_decoder.py:1012-1035 with target size == mask size: interpolate is the
 // identity); 2/4/8 = 2x2-tap average of a bilinear downsample by that factor.
 // D: depth of the feature prefetch ring in groups of KU k-steps (G = C / (4 KU) must be a multiple of D).
-template <int POOL, bool WRITE, int NC, int D>
+template <int POOL, bool WRITE, int NC, int D, bool R4 = false>
 __global__ __launch_bounds__(MW * 64) void mask_logits_kernel(const float* __restrict__ emb, const float* __restrict__ feat,
                                                           float* __restrict__ mask_out, uint8_t* __restrict__ attn_out,
                                                           int32_t* __restrict__ row_any, int Q, int C, int H, int W,
@@ -526,12 +543,15 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_kernel(const float* __res
     if constexpr (NC == 1) {
 #pragma unroll
         for (int m = 0; m < QB; ++m) {
-            const float q_b = qb[m * 16 + lj];
+            float q_b = qb[m * 16 + lj];
+            if (R4 && m == QB - 1) q_b = lq == 0 ? qb[m * 16 + (lj & 3)] : 0.f;   // 4-query block: the four channel classes lq are
+                                                                                  // summed at the end, the bias enters once
             bias4[m] = f32x4{q_b, q_b, q_b, q_b};
         }
     }
+    static_assert(!R4 || NC == 1, "the 4-query block exists for 2 x 16 tiles only");
     MaskEpiConst<POOL, WRITE, NC> epi;
-    mask_epi_init<POOL, WRITE, NC>(epi, mask_out, attn_out, b, Q, q0, H, W, th, tw, lj, lq);
+    mask_epi_init<POOL, WRITE, NC>(epi, mask_out, attn_out, b, Q, q0, H, W, th, tw, lj, lq, R4);
 
     const int G = C / (4 * KU);          // even and >= 2: C is a multiple of 32
     // (Reading the mask_embed fragments of a group one group ahead -- two register sets -- measured no gain: the sibling
@@ -559,6 +579,23 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_kernel(const float* __res
                 const float* er = &Es[lj * SE + kbase + u * 4 + lq];
 #pragma unroll
                 for (int m = 0; m < QB; ++m) {
+                    if constexpr (R4) {
+                        if (m == QB - 1) {
+                            // Q = 96 + 4: the last block holds four queries.  v_mfma_f32_4x4x1_16b_f32 = sixteen 4 x 4 x 1 products
+                            // (block = lane / 4; 8 cycles instead of 32): with this A operand block (lq, lj >> 2) is the four
+                            // pixels 4 (lj >> 2) .. + 3 at channel 4 u + lq, so B = mask_embed[96 + (lj & 3)][4 u + lq] gives
+                            // lane (lq, lj) the partial sum of channel class lq for query 96 + (lj & 3), pixels 4 (lj >> 2) + reg
+                            const float a4 = Es[(m * 16 + (lj & 3)) * SE + kbase + u * 4 + lq];
+                            if (decltype(first)::value && u == 0) {
+                                acc[m][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(t_[u].v[0], a4, bias4[m], 0, 0, 0);
+                                acc[m][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(bt[u].v[0], a4, bias4[m], 0, 0, 0);
+                            } else {
+                                acc[m][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(t_[u].v[0], a4, acc[m][0], 0, 0, 0);
+                                acc[m][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(bt[u].v[0], a4, acc[m][1], 0, 0, 0);
+                            }
+                            continue;
+                        }
+                    }
                     const float a = er[m * 16 * SE];
 #pragma unroll
                     for (int cc = 0; cc < NC; ++cc) {
@@ -606,17 +643,36 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_kernel(const float* __res
         }
 #endif
         const bool inside = c0 + TW <= W;                                             // wave-uniform
+        if constexpr (R4) {
+            // 4-query block: the attention-mask bits ALWAYS come from tap sums formed on the per-class partials and reduced
+            // afterwards -- the same arithmetic whether the launch also writes the logits (aux outputs) or not, so the two
+            // modes stay bit-identical; the written logits are the fully reduced accumulators.  (Host: every tile inside.)
+            mask_tile_epilogue_fast<POOL, WRITE, NC, false, true, true>(acc, epi, H, W, tw, ytop, ybot, c0);
+            if constexpr (WRITE) {
+#pragma unroll
+                for (int row = 0; row < 2; ++row)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[QB - 1][row][r];
+                        v += __shfl_xor(v, 16, 64);
+                        v += __shfl_xor(v, 32, 64);
+                        acc[QB - 1][row][r] = v;
+                    }
+            }
+        }
         if constexpr (WRITE) {
             static_assert(NC == 1, "mask writes take 2 x 16 tiles (see mask_tile_epilogue_fast)");
             if (inside && epi.write_fast) mask_tile_epilogue_fast<POOL, WRITE, NC, true, false>(acc, epi, H, W, tw, ytop, ybot, c0);
-            else mask_tile_epilogue<POOL, WRITE, NC, true, false>(acc, mask_out, attn_out, any_flags, b, Q, q0, H, W, th, tw, ytop, ybot, c0, lj, lq);
+            else mask_tile_epilogue<POOL, WRITE, NC, true, false, R4>(acc, mask_out, attn_out, any_flags, b, Q, q0, H, W, th, tw, ytop, ybot, c0, lj, lq);
         }
-        if (inside && epi.attn_fast) mask_tile_epilogue_fast<POOL, WRITE, NC, false, true>(acc, epi, H, W, tw, ytop, ybot, c0);
-        else mask_tile_epilogue<POOL, WRITE, NC, false, true>(acc, mask_out, attn_out, any_flags, b, Q, q0, H, W, th, tw, ytop, ybot, c0, lj, lq);
+        if constexpr (!R4) {
+            if (inside && epi.attn_fast) mask_tile_epilogue_fast<POOL, WRITE, NC, false, true>(acc, epi, H, W, tw, ytop, ybot, c0);
+            else mask_tile_epilogue<POOL, WRITE, NC, false, true>(acc, mask_out, attn_out, any_flags, b, Q, q0, H, W, th, tw, ytop, ybot, c0, lj, lq);
+        }
         MASK_TS(4 + 3 * it)
     }
     if constexpr (POOL != 0) {
-        mask_epi_flush<POOL, WRITE, NC>(epi, any_flags, lj);
+        mask_epi_flush<POOL, WRITE, NC>(epi, any_flags, lj, R4);
         __syncthreads();
         for (int r = tid; r < QCH; r += MW * 64)
             if (any_flags[r] && q0 + r < Q) row_any[(int64_t)b * Q + q0 + r] = 1;
@@ -1271,12 +1327,17 @@ extern "C" int msm_mask_logits_fwd(const float* mask_embed, const float* mask_fe
     // prefetch ring of four groups (2 x 16 tiles, C a multiple of 64) instead of two: opt-in -- a lone wave then gets closer
     // to the MFMA rate (K loop of a 3 us tile: 6.1 -> 4.8 us) but its 32 loads up front delay the first MFMA by 1.2 us
     const bool deep = nc == 1 && (C / (4 * KU)) % 4 == 0 && opt(MSM_OPT_MASK_KERNEL) == 3;
+    // Q = 96 + 4 (the 100 queries of every shipped configuration): the last query block on the 4x4x1 MFMA (8 cycles per k-step
+    // and image row instead of 32): 10.7 % less matrix time per tile.  Needs 2 x 16 tiles that all take the fast epilogue.
+    const bool r4 = nc == 1 && !deep && Q == 100 && W % 16 == 0 && (int64_t)Q * H * W * 4 < 0xF0000000ll && opt(MSM_OPT_MASK_KERNEL) != 5 &&
+                    (pool == 0 || pool == 2 || pool == 4 || pool == 8);
 #define MASK_PICK(P)                                                                                                   \
-    (wr ? (deep ? (kern_t)mask_logits_kernel<P, true, 1, 4> : (kern_t)mask_logits_kernel<P, true, 1, 2>)                  \
+    (wr ? (deep ? (kern_t)mask_logits_kernel<P, true, 1, 4> : (r4 ? (kern_t)mask_logits_kernel<P, true, 1, 2, true> : (kern_t)mask_logits_kernel<P, true, 1, 2>)) \
         : (nc == 2 ? (kern_t)mask_logits_kernel<P, false, 2, 2>                                                          \
-                   : (deep ? (kern_t)mask_logits_kernel<P, false, 1, 4> : (kern_t)mask_logits_kernel<P, false, 1, 2>)))
+                   : (deep ? (kern_t)mask_logits_kernel<P, false, 1, 4>                                                  \
+                           : (r4 ? (kern_t)mask_logits_kernel<P, false, 1, 2, true> : (kern_t)mask_logits_kernel<P, false, 1, 2>))))
     switch (pool) {
-        case 0: kern = deep ? (kern_t)mask_logits_kernel<0, true, 1, 4> : (kern_t)mask_logits_kernel<0, true, 1, 2>; break;
+        case 0: kern = deep ? (kern_t)mask_logits_kernel<0, true, 1, 4> : (r4 ? (kern_t)mask_logits_kernel<0, true, 1, 2, true> : (kern_t)mask_logits_kernel<0, true, 1, 2>); break;
         case 1: kern = MASK_PICK(1); break;
         case 2: kern = MASK_PICK(2); break;
         case 4: kern = MASK_PICK(4); break;
