@@ -32,6 +32,9 @@ constexpr int QCH = QB * 16;    // 112 queries per chunk
 #ifndef MSM_MASK_KU
 #define MSM_MASK_KU 4
 #endif
+#ifndef MSM_WRITE_AUX
+#define MSM_WRITE_AUX 0   // cache policy bits of the logit stores (tuning builds: 2 = nt)
+#endif
 #ifndef MSM_MASK_MW
 #define MSM_MASK_MW 8
 #endif
@@ -337,7 +340,7 @@ __device__ __forceinline__ void mask_tile_epilogue_fast(const f32x4 (&acc)[QB][2
                 for (int j = 0; j < NP; j += 4)
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(acc_val<NC>(acc, m, row, j)), __float_as_uint(acc_val<NC>(acc, m, row, j + 1)),
                                                                  __float_as_uint(acc_val<NC>(acc, m, row, j + 2)), __float_as_uint(acc_val<NC>(acc, m, row, j + 3))},
-                                                           k.mrsrc, k.moff[m] + 4u * j, soff, 0);
+                                                           k.mrsrc, k.moff[m] + 4u * j, soff, MSM_WRITE_AUX);
         }
     }
     if constexpr (!DO_ATTN || POOL == 0) {
