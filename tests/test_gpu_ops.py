@@ -222,7 +222,8 @@ def test_hypersphere_attention(B, Lq, S, masked):
 
 
 @pytest.mark.parametrize("kv_bf16", [False, True])
-@pytest.mark.parametrize("B,Lq,S,masked", [(2, 100, 300, True), (2, 100, 100, False), (1, 100, 4800, True), (2, 20, 37, True)])
+@pytest.mark.parametrize("B,Lq,S,masked", [(2, 100, 300, True), (2, 100, 100, False), (1, 100, 4800, True), (2, 20, 37, True), (1, 300, 1200, True),
+                                           (1, 300, 19200, True)])
 def test_hypersphere_attention_low_precision(B, Lq, S, masked, kv_bf16):
     """msm_hypersphere_attn_lp_fwd (bf16 MFMA operands, fp32 accumulation; K / V stored as fp32 or bf16) against the oracle.
     The unit vectors q^, k^ carry 8 mantissa bits, so a logit kappa q^.k^ moves by ~kappa 2^-9 / sqrt(32) ~ 1e-2 and the outputs
