@@ -1129,7 +1129,9 @@ __device__ __forceinline__ unsigned short f2bf(float x) {   // round to nearest 
     return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
-template <int POOL, bool WRITE>
+// NKS: 16-channel k-steps held per tile -- 4 for the folded step (C = 64: 8 loads and 56 MFMAs per tile; the generic 16 would
+// request every clamped slot again, 32 loads per tile of which 8 are needed), BKS otherwise (C <= 256, runtime count)
+template <int POOL, bool WRITE, int NKS>
 __global__ __launch_bounds__(MW * 64) void mask_logits_bf16_kernel(const float* __restrict__ emb, const unsigned short* __restrict__ featp,
                                                                float* __restrict__ mask_out, uint8_t* __restrict__ attn_out,
                                                                int32_t* __restrict__ row_any, int Q, int C, int H, int W, int th,
@@ -1180,7 +1182,7 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_bf16_kernel(const float* 
         return (it < full_rounds) ? it * slots + (int)blockIdx.x * MW + wave : full_rounds * slots + left_slot;
     };
     struct TileRegs {
-        u32x2 t[BKS], bt[BKS];
+        u32x2 t[NKS], bt[NKS];
     };
     auto load_tile = [&](int t, TileRegs& r) {
         const int rp = t / ctiles, ct = t - rp * ctiles;
@@ -1191,12 +1193,14 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_bf16_kernel(const float* 
         const unsigned voff_top = (unsigned)(((int64_t)lq * HW + (int64_t)max(ytop, 0) * W + cl) * 8);
         const unsigned voff_bot = (unsigned)(((int64_t)lq * HW + (int64_t)min(ybot, H - 1) * W + cl) * 8);
 #pragma unroll
-        for (int ks = 0; ks < BKS; ++ks) {
+        for (int ks = 0; ks < NKS; ++ks) {
             const unsigned soff = (unsigned)min(ks, nks - 1) * 4u * (unsigned)HW * 8u;   // clamped: C < 256 re-reads, never faults
             r.t[ks] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff_top, soff, 0);
             r.bt[ks] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff_bot, soff, 0);
         }
     };
+    MaskEpiConst<POOL, WRITE, 1> epi;
+    mask_epi_init<POOL, WRITE, 1>(epi, mask_out, attn_out, b, Q, q0, H, W, th, tw, lj, lq);
     TileRegs cur, nxt;
     if (my_tiles > 0) load_tile(tile_of(0), cur);
     for (int it = 0; it < my_tiles; ++it) {
@@ -1211,7 +1215,7 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_bf16_kernel(const float* 
 #pragma unroll
         for (int m = 0; m < QB; ++m) { const float q_b = qb[m * 16 + lj]; acc[m][0] = acc[m][1] = f32x4{q_b, q_b, q_b, q_b}; }
 #pragma unroll
-        for (int ks = 0; ks < BKS; ++ks) {
+        for (int ks = 0; ks < NKS; ++ks) {
             if (ks < nks) {                                              // wave-uniform
                 const unsigned short* er = &Eb[lj * SEb + ks * 16 + lq * 4];
                 const bf16x4 bt_ = __builtin_bit_cast(bf16x4, cur.t[ks]);
@@ -1225,14 +1229,22 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_bf16_kernel(const float* 
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        mask_tile_epilogue<POOL, WRITE, 1>(acc, mask_out, attn_out, any_flags, b, Q, q0, H, W, th, tw, ytop, ybot, c0, lj, lq);
+        // the fast epilogue of the fp32 kernel (precomputed per-lane offsets, one store per query block) for tiles inside the map
+        const bool inside = c0 + 16 <= W;                                             // wave-uniform
+        if constexpr (WRITE) {
+            if (inside && epi.write_fast) mask_tile_epilogue_fast<POOL, WRITE, 1, true, false>(acc, epi, H, W, tw, ytop, ybot, c0);
+            else mask_tile_epilogue<POOL, WRITE, 1, true, false>(acc, mask_out, attn_out, any_flags, b, Q, q0, H, W, th, tw, ytop, ybot, c0, lj, lq);
+        }
+        if (inside && epi.attn_fast) mask_tile_epilogue_fast<POOL, WRITE, 1, false, true>(acc, epi, H, W, tw, ytop, ybot, c0);
+        else mask_tile_epilogue<POOL, WRITE, 1, false, true>(acc, mask_out, attn_out, any_flags, b, Q, q0, H, W, th, tw, ytop, ybot, c0, lj, lq);
 #pragma unroll
-        for (int ks = 0; ks < BKS; ++ks) {
+        for (int ks = 0; ks < NKS; ++ks) {
             cur.t[ks] = nxt.t[ks];
             cur.bt[ks] = nxt.bt[ks];
         }
     }
     if constexpr (POOL != 0) {
+        mask_epi_flush<POOL, WRITE, 1>(epi, any_flags, lj);
         __syncthreads();
         for (int r = tid; r < QCH; r += MW * 64)
             if (any_flags[r] && q0 + r < Q) row_any[(int64_t)b * Q + q0 + r] = 1;
@@ -1457,9 +1469,11 @@ extern "C" int msm_mask_logits_bf16_fwd(const float* mask_embed, const uint16_t*
                            int64_t, const float*, int64_t);
     const bool wr = mask_out != nullptr;
     kern_t kern;
-#define MASKB_PICK(P) (wr ? (kern_t)mask_logits_bf16_kernel<P, true> : (kern_t)mask_logits_bf16_kernel<P, false>)
+#define MASKB_PICK(P)                                                                                                     \
+    (C <= 64 ? (wr ? (kern_t)mask_logits_bf16_kernel<P, true, 4> : (kern_t)mask_logits_bf16_kernel<P, false, 4>)            \
+             : (wr ? (kern_t)mask_logits_bf16_kernel<P, true, BKS> : (kern_t)mask_logits_bf16_kernel<P, false, BKS>))
     switch (pool) {
-        case 0: kern = (kern_t)mask_logits_bf16_kernel<0, true>; break;
+        case 0: kern = C <= 64 ? (kern_t)mask_logits_bf16_kernel<0, true, 4> : (kern_t)mask_logits_bf16_kernel<0, true, BKS>; break;
         case 1: kern = MASKB_PICK(1); break;
         case 2: kern = MASKB_PICK(2); break;
         case 4: kern = MASKB_PICK(4); break;
