@@ -275,6 +275,7 @@ class MeanShiftTransformerDecoder(nn.Module):
         # "bf16": the fused row-local tails (dec_post_cross / dec_post_self / dec_heads) stream bf16 weights and multiply on
         # bf16 MFMAs with fp32 accumulation (activations as hi + lo pairs); part of set_precision("bf16")
         self.tails_dtype = "f32"
+        self.ffn_parts = None          # hidden-dimension slices of the fused FFN tail (None: ops.dec_post_self's default)
         # "bf16": the attention cores multiply on bf16 MFMAs (fp32 accumulation, exp, sums) and the batched K/V projection
         # stores bf16; part of set_precision("bf16")
         self.attention_dtype = "f32"
@@ -462,7 +463,7 @@ class MeanShiftTransformerDecoder(nn.Module):
                                           ca.norm.bias, pk["self_in"][i], sa.self_attn.in_proj_bias)
             o = ops.hypersphere_attention(qk[..., :E], qk[..., E:], v, H, kappa=float(KAPPA), low_precision=lp)
             x, parts = ops.dec_post_self(o, x, pk["self_o"][i], sa.self_attn.out_proj.bias, sa.norm.weight, sa.norm.bias,
-                                         pk["ffn1"][i], ff.linear1.bias, pk["ffn2"][i])
+                                         pk["ffn1"][i], ff.linear1.bias, pk["ffn2"][i], n_parts=self.ffn_parts)
             last = i == L - 1
             out, d, e, q, ra = ops.dec_heads(x, dn.weight, dn.bias, mlp, parts=parts, bias=ff.linear2.bias,
                                              ln_g=ff.norm.weight, ln_b=ff.norm.bias, l2norm=self.decoder_block_norm,
