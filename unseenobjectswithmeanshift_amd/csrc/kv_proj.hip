@@ -112,14 +112,15 @@ __device__ __forceinline__ void kv_project_body(const float* __restrict__ x, con
                 a0 = mfma16(w0.w, xb[s4 * 4 + 3], a0);
                 a1 = mfma16(w1.w, xb[s4 * 4 + 3], a1);
             }
-            if (live) {
-                if constexpr (std::is_same<OT, float>::value) {
-                    *reinterpret_cast<float4*>(op + fb * 16) = make_float4(a0[0], a0[1], a0[2], a0[3]);
-                    *reinterpret_cast<float4*>(op + (fb + 1) * 16) = make_float4(a1[0], a1[1], a1[2], a1[3]);
-                } else {
-                    *reinterpret_cast<bf16x4*>(op + fb * 16) = pack4(a0[0], a0[1], a0[2], a0[3]);
-                    *reinterpret_cast<bf16x4*>(op + (fb + 1) * 16) = pack4(a1[0], a1[1], a1[2], a1[3]);
-                }
+            // no `live` test: lanes past the last token hold token HW - 1 again (clamped p, same x, same constant) and store the
+            // same values to the same address -- a branch here cuts the unit into eight basic blocks (LDS reads -> wait -> 32
+            // MFMAs -> stores, nothing overlapping across them)
+            if constexpr (std::is_same<OT, float>::value) {
+                *reinterpret_cast<float4*>(op + fb * 16) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+                *reinterpret_cast<float4*>(op + (fb + 1) * 16) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+            } else {
+                *reinterpret_cast<bf16x4*>(op + fb * 16) = pack4(a0[0], a0[1], a0[2], a0[3]);
+                *reinterpret_cast<bf16x4*>(op + (fb + 1) * 16) = pack4(a1[0], a1[1], a1[2], a1[3]);
             }
         }
 #pragma unroll
@@ -269,13 +270,11 @@ __device__ __forceinline__ void kv_project_split_body(const float* __restrict__ 
                             for (int j = 0; j < 2; ++j) mac_term(term, lo[j], hi[j], wf[j], xs[g]);
                         }
                 }
-                if (live) {
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const f32x4 a = hi[j] + lo[j];
-                        if constexpr (std::is_same<OT, float>::value) *reinterpret_cast<float4*>(op + (fb + j) * 16) = make_float4(a[0], a[1], a[2], a[3]);
-                        else *reinterpret_cast<bf16x4*>(op + (fb + j) * 16) = pack4(a[0], a[1], a[2], a[3]);
-                    }
+                for (int j = 0; j < 2; ++j) {          // (no `live` test: see kv_project_body)
+                    const f32x4 a = hi[j] + lo[j];
+                    if constexpr (std::is_same<OT, float>::value) *reinterpret_cast<float4*>(op + (fb + j) * 16) = make_float4(a[0], a[1], a[2], a[3]);
+                    else *reinterpret_cast<bf16x4*>(op + (fb + j) * 16) = pack4(a[0], a[1], a[2], a[3]);
                 }
                 __builtin_amdgcn_sched_barrier(0);      // one pair of feature blocks at a time: left alone hipcc hoists the fragment
                                                         // reads of all sixteen to the top (96 x 4 registers: 250 spilled)
