@@ -55,7 +55,7 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 8   /* 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
+#define MSM_ABI_VERSION 9   /* 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
 int msm_abi_version(void);
 
 /* Kernel-selection overrides for tools/ and tests/ (NOT read on the product path: every option defaults to
@@ -207,7 +207,10 @@ int msm_hypersphere_attn_lp_fwd(const float* q, const void* k, const void* v, in
  * Multi-scale deformable attention forward, reference ABI (OPS/src/ms_deform_attn.h:25-44):
  *   value [B][S][M][D], spatial_shapes int64 [L][2] = (H,W), level_start_index int64 [L],
  *   sampling_loc [B][Lq][M][L][P][2] (x,y in [0,1]), attn_weight [B][Lq][M][L][P],
- *   out [B][Lq][M*D].  D must be a multiple of 4 and <= 64.
+ *   out [B][Lq][M*D].  Any D (D <= 64 takes the tuned kernels: 16-byte taps when D % 4 == 0; larger D the
+ *   shape-generic kernel of csrc/msda_generic.hip).  The reference dispatches float and double
+ *   (OPS/src/cuda/ms_deform_attn_cuda.cu:69,139); the _f64 entry points are the double instantiation its own
+ *   test drives (OPS/test.py:33-43 exact forward check, :66-89 gradcheck).
  * ------------------------------------------------------------------------------------------- */
 int msm_msdeform_attn_fwd(const float* value, const int64_t* spatial_shapes,
                           const int64_t* level_start_index, const float* sampling_loc,
@@ -216,13 +219,26 @@ int msm_msdeform_attn_fwd(const float* value, const int64_t* spatial_shapes,
 
 /* Backward of the above, reference ABI ms_deform_attn_backward (OPS/src/ms_deform_attn.h:46-66,
  * OPS/src/cuda/ms_deform_attn_cuda.cu:88-158, kernels ms_deform_im2col_cuda.cuh:306-925):
- *   grad_output [B][Lq][M*D] -> grad_value [B][S][M][D] (zeroed here, accumulated with fp32 atomics as in
- *   the reference), grad_sampling_loc [B][Lq][M][L][P][2], grad_attn_weight [B][Lq][M][L][P]. */
+ *   grad_output [B][Lq][M*D] -> grad_value [B][S][M][D], grad_sampling_loc [B][Lq][M][L][P][2],
+ *   grad_attn_weight [B][Lq][M][L][P].
+ *   Exception to "the library only launches kernels": grad_value is accumulated with hardware atomics as in the
+ *   reference (cuh:128-160), so these entry points first zero-fill it (and, for the fp32 kernels when D/4 is not a
+ *   power of two, the other two outputs) with hipMemsetAsync on `stream` -- the counterpart of the reference's
+ *   at::zeros (cu:121-123).  Under stream capture that is a memset node of the graph. */
 int msm_msdeform_attn_bwd(const float* value, const int64_t* spatial_shapes,
                           const int64_t* level_start_index, const float* sampling_loc,
                           const float* attn_weight, const float* grad_output,
                           float* grad_value, float* grad_sampling_loc, float* grad_attn_weight,
                           int B, int S, int M, int D, int L, int Lq, int P, void* stream);
+int msm_msdeform_attn_fwd_f64(const double* value, const int64_t* spatial_shapes,
+                              const int64_t* level_start_index, const double* sampling_loc,
+                              const double* attn_weight, double* out,
+                              int B, int S, int M, int D, int L, int Lq, int P, void* stream);
+int msm_msdeform_attn_bwd_f64(const double* value, const int64_t* spatial_shapes,
+                              const int64_t* level_start_index, const double* sampling_loc,
+                              const double* attn_weight, const double* grad_output,
+                              double* grad_value, double* grad_sampling_loc, double* grad_attn_weight,
+                              int B, int S, int M, int D, int L, int Lq, int P, void* stream);
 
 /* Encoder self-attention form with the sampling arithmetic fused in
  * (OPS/modules/ms_deform_attn.py:101-109 + msdeformattn.py:141-153): query i is pixel i of the

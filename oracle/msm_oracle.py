@@ -235,6 +235,27 @@ def ms_deform_attn_core(value, spatial_shapes, sampling_locations, attention_wei
     return out.reshape(N, Lq, M * D)
 
 
+def ms_deform_attn_core_grid_sample(value, spatial_shapes, sampling_locations, attention_weights):
+    """The reference's pure-PyTorch form of the op (OPS/functions/ms_deform_attn_func.py:52-72), which its own test
+    treats as ground truth (OPS/test.py:40,55): per level, the value plane of every (image, head) is sampled with
+    F.grid_sample(bilinear, zeros padding, align_corners=False) at 2*loc - 1 and the samples are combined with the
+    attention weights.  Same function as ms_deform_attn_core above (which follows the CUDA kernel's arithmetic) up to
+    rounding; kept separately so that the reference's test can be reproduced with the comparison it makes."""
+    import torch.nn.functional as F
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = sampling_locations.shape
+    out = value.new_zeros(N, M, D, Lq)
+    begin = 0
+    for lvl, (H, W) in enumerate([(int(h), int(w)) for h, w in spatial_shapes]):
+        plane = value[:, begin:begin + H * W].permute(0, 2, 3, 1).reshape(N * M, D, H, W)     # (N*M, D, H, W)
+        begin += H * W
+        grid = (2.0 * sampling_locations[:, :, :, lvl] - 1.0).permute(0, 2, 1, 3, 4).reshape(N * M, Lq, P, 2)
+        taps = F.grid_sample(plane, grid, mode="bilinear", padding_mode="zeros", align_corners=False)   # (N*M, D, Lq, P)
+        w = attention_weights[:, :, :, lvl].permute(0, 2, 1, 3).reshape(N * M, 1, Lq, P)
+        out += (taps * w).sum(-1).view(N, M, D, Lq)
+    return out.permute(0, 3, 1, 2).reshape(N, Lq, M * D).contiguous()
+
+
 def ms_deform_attn_core_backward(value, spatial_shapes, sampling_locations, attention_weights, grad_output):
     """Analytic backward of ms_deform_attn_core, restating the col2im kernels: bilinear helper
     ms_deform_im2col_cuda.cuh:92-165 (grad_value scatter :128-160, grad_attn_weight = top_grad*val :164,

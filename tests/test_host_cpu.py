@@ -110,3 +110,41 @@ def test_library_options_are_explicit_and_default_to_auto():
     assert L.msm_set_option(len(_lib.OPTIONS) - 1, 1) == 0 and L.msm_set_option(len(_lib.OPTIONS) - 1, -1) == 0     # enum and OPTIONS agree in length
     out = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "getenv" not in out
+
+
+def test_graph_stale_check_is_cheap_and_sees_updates():
+    """graphs.StaleCheck (the per-replay staleness test of captured graphs): moves on in-place parameter updates, on
+    plan-attribute assignments with a NEW value and on invalidate(); does not move otherwise; costs tens of microseconds
+    where the exhaustive signature costs a millisecond."""
+    import time
+    from unseenobjectswithmeanshift_amd import graphs
+    from unseenobjectswithmeanshift_amd.meta_arch import build_resnet50_head
+    head = build_resnet50_head()
+    chk = graphs.StaleCheck(head)
+    s0 = chk()
+    assert chk() == s0
+    with torch.no_grad():
+        head.predictor.class_embed.bias.add_(1.0)
+    s1 = chk()
+    assert s1 != s0
+    head.predictor.aux_outputs = False                 # same value: no plan change
+    assert chk() == s1
+    head.predictor.aux_outputs = True
+    s2 = chk()
+    assert s2 != s1
+    head.predictor.ffn_parts = 4                       # every plan attribute is covered, also the tuning ones
+    s3 = chk()
+    assert s3 != s2
+    chk.invalidate()
+    assert chk() != s3
+    strict = graphs.StaleCheck(head, strict=True)
+    assert strict() == graphs.param_signature(head)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        chk()
+    fast = (time.perf_counter() - t0) / 200
+    t0 = time.perf_counter()
+    for _ in range(20):
+        strict()
+    slow = (time.perf_counter() - t0) / 20
+    assert fast < 0.2 * slow, (fast, slow)

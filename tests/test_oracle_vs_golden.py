@@ -211,6 +211,21 @@ def test_msda_c_restatement(golden):
     torch.testing.assert_close(o, T(g["r_out"]), rtol=1e-4, atol=1e-5)
 
 
+def test_msda_grid_sample_form_vs_reference(golden):
+    """oracle.ms_deform_attn_core_grid_sample (the comparison partner of tests/test_gpu_msda_reference_test.py) against
+    the outputs of the reference's ms_deform_attn_core_pytorch on the reference test's own inputs (OPS/test.py, seed 3)."""
+    g = golden("msda_core")
+    t = torch.tensor([(6, 4), (3, 2)])
+    o = O.ms_deform_attn_core_grid_sample(T(g["t_double_value"]).double(), t, T(g["t_double_loc"]).double(),
+                                          T(g["t_double_aw"]).double())
+    assert o.dtype == torch.float64 and g["t_double_out"].dtype == np.float64
+    assert torch.allclose(o, T(g["t_double_out"]), rtol=1e-12, atol=0)
+    o = O.ms_deform_attn_core_grid_sample(T(g["t_float_value"]), t, T(g["t_float_loc"]), T(g["t_float_aw"]))
+    torch.testing.assert_close(o, T(g["t_float_out"]), rtol=1e-6, atol=1e-9)
+    o = O.ms_deform_attn_core_grid_sample(T(g["r_value"]), torch.from_numpy(g["r_shapes"]), T(g["r_loc"]), T(g["r_aw"]))
+    torch.testing.assert_close(o, T(g["r_out"]), rtol=1e-5, atol=1e-6)
+
+
 def instance_cases(g):
     """(case id, Q, K, h, w, topk, inputs) of tests/golden/instance_inference.npz (inputs regenerated from the seed)."""
     for c in range(4):

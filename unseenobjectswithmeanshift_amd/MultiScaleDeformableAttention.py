@@ -5,6 +5,10 @@ module is importable under that name:
 
     import sys, unseenobjectswithmeanshift_amd.MultiScaleDeformableAttention as m
     sys.modules["MultiScaleDeformableAttention"] = m
+
+float32 and float64 like the reference's dispatch (ms_deform_attn_cuda.cu:69,139): the reference's own op test
+(ops/test.py: double forward check, float forward check, double gradcheck for D up to 3096) runs through this module as
+written (tests/test_gpu_msda_reference_test.py).
 """
 import torch
 
@@ -20,8 +24,8 @@ def _check_inputs(value, tensors, im2col_step):
             raise RuntimeError(f"{name} tensor has to be contiguous")      # cu:33-37 / cu:98-103
         if not t.is_cuda:
             raise RuntimeError(f"{name} must be a CUDA tensor")             # cu:39-43 / cu:105-110
-    if value.dtype == torch.float64:
-        raise NotImplementedError("the gfx950 kernels are fp32; cast inputs with .float()")
+    if value.dtype not in (torch.float32, torch.float64):                   # AT_DISPATCH_FLOATING_TYPES, cu:69 / cu:139
+        raise RuntimeError(f"ms_deform_attn is implemented for float and double, got {value.dtype}")
 
 
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmsm_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "msm_hip.h")
 
 _lib = None
-ABI_VERSION = 8      # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
+ABI_VERSION = 9      # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
 
 c_f = ctypes.c_void_p      # float* (device)
 c_p = ctypes.c_void_p
@@ -48,6 +48,8 @@ _SIGNATURES = {
                                        c_l, c_l, c_l, c_l, c_l, c_l, c_fl, c_f, c_l, c_p]),
     "msm_msdeform_attn_fwd": (c_i, [c_f, c_p, c_p, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "msm_msdeform_attn_bwd": (c_i, [c_f, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "msm_msdeform_attn_fwd_f64": (c_i, [c_f, c_p, c_p, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "msm_msdeform_attn_bwd_f64": (c_i, [c_f, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "msm_msdeform_attn_enc_fwd": (c_i, [c_f, c_p, c_p, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "msm_encoder_block_stream_floats": (c_l, [c_i, c_i]),
     "msm_value_to_head_major_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_p]),
@@ -130,6 +132,9 @@ def set_option(name, value=OPT_AUTO):
     key = OPTIONS.index(name)
     old = lib().msm_get_option(key)
     check(lib().msm_set_option(key, int(value)), "msm_set_option")
+    if old != int(value):
+        from ._plan import bump_plan_epoch
+        bump_plan_epoch()          # captured graphs hold the kernels the old option selected: they re-capture (graphs.py)
     return old
 
 

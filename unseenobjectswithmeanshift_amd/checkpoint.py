@@ -61,13 +61,32 @@ def convert_ucn_state_dict(state_dict):
     return out
 
 
-def load_reference_checkpoint(model, checkpoint, strict=True):
+def load_checkpoint_file(path, unsafe=False):
+    """torch.load of a checkpoint file, tensors-only by default: the published checkpoints are downloaded from third-party
+    links (README.md:86-95) and a full unpickle executes whatever the file says.  detectron2-style checkpoints hold
+    tensors, numpy arrays and plain containers, so the numpy reconstructors are allow-listed; ``unsafe=True`` is the
+    explicit opt-in to a full unpickle for legacy files that hold other objects."""
+    if unsafe:
+        return torch.load(path, map_location="cpu", weights_only=False)
+    import numpy as np
+    allow = [np.ndarray, np.dtype]
+    core = getattr(np, "_core", None) or getattr(np, "core")
+    for name in ("_reconstruct", "scalar"):
+        fn = getattr(core.multiarray, name, None)
+        if fn is not None:
+            allow.append(fn)
+    allow += [type(np.dtype(t)) for t in ("float32", "float64", "float16", "int64", "int32", "uint8", "bool")]
+    with torch.serialization.safe_globals(allow):
+        return torch.load(path, map_location="cpu", weights_only=True)
+
+
+def load_reference_checkpoint(model, checkpoint, strict=True, unsafe=False):
     """``checkpoint``: a path (``torch.load``-able) or an already loaded object.  ``model``: a meta-arch of this package.
     With ``strict`` every parameter / buffer of the model must be present and nothing may be left over; a model built
-    without a backbone (features handed over by the caller) ignores the checkpoint's backbone.*.  Returns the converted
-    state dict."""
+    without a backbone (features handed over by the caller) ignores the checkpoint's backbone.*.  Files are read
+    tensors-only (``load_checkpoint_file``) unless ``unsafe=True``.  Returns the converted state dict."""
     if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__"):
-        checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
+        checkpoint = load_checkpoint_file(checkpoint, unsafe=unsafe)
     sd = convert_reference_state_dict(checkpoint)
     if getattr(model, "backbone", None) is None:
         sd = {k: v for k, v in sd.items() if not k.startswith("backbone.")}

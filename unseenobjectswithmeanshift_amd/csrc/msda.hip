@@ -561,6 +561,13 @@ static int msda_common_checks(const char* name, const void* value, const void* o
     return MSM_OK;
 }
 
+// shape-generic kernels (msda_generic.hip): any D, any L
+int msda_any_fwd_f32(const float* value, const int64_t* shapes, const int64_t* lstart, const float* loc, const float* wgt,
+                     float* out, int B, int S, int M, int D, int L, int Lq, int P, void* stream);
+int msda_any_bwd_f32(const float* value, const int64_t* shapes, const int64_t* lstart, const float* loc, const float* wgt,
+                     const float* gout, float* gvalue, float* gloc, float* gwgt, int B, int S, int M, int D, int L, int Lq,
+                     int P, void* stream);
+
 }  // namespace msm
 
 using namespace msm;
@@ -570,6 +577,8 @@ extern "C" int msm_msdeform_attn_fwd(const float* value, const int64_t* spatial_
                                      int M, int D, int L, int Lq, int P, void* stream) {
     MSM_REQUIRE(value && spatial_shapes && level_start_index && sampling_loc && attn_weight && out,
                 "msm_msdeform_attn_fwd: null pointer");
+    if (D > 64 || L > MAXL)       // outside the tuned kernels' range (the reference's gradcheck sizes, ops/test.py:84)
+        return msda_any_fwd_f32(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, out, B, S, M, D, L, Lq, P, stream);
     int rc = msda_common_checks("msm_msdeform_attn_fwd", value, out, B, S, M, D, L, Lq, P);
     if (rc != MSM_OK) return rc;
     const int V = (D % 4 == 0) ? 4 : 1;
@@ -611,6 +620,9 @@ extern "C" int msm_msdeform_attn_bwd(const float* value, const int64_t* spatial_
     MSM_REQUIRE(value && spatial_shapes && level_start_index && sampling_loc && attn_weight && grad_output && grad_value &&
                     grad_sampling_loc && grad_attn_weight,
                 "msm_msdeform_attn_bwd: null pointer");
+    if (D > 64 || L > MAXL)
+        return msda_any_bwd_f32(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, grad_value,
+                                grad_sampling_loc, grad_attn_weight, B, S, M, D, L, Lq, P, stream);
     int rc = msda_common_checks("msm_msdeform_attn_bwd", value, grad_output, B, S, M, D, L, Lq, P);
     if (rc != MSM_OK) return rc;
     MSM_REQUIRE((((uintptr_t)grad_value) & 15) == 0, "msm_msdeform_attn_bwd: grad_value must be 16-byte aligned");

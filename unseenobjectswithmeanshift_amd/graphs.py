@@ -17,8 +17,7 @@ _CACHE_ATTRS = ("_q0", "_kv_cache", "_fold_cache", "_tails_cache", "_pos_cache",
                 "_packed_mf", "_bf16_cache", "_folded_cache")
 
 
-_PLAN_ATTRS = ("precision", "mask_step_dtype", "tails_dtype", "attention_dtype", "kv_split", "sparse_taps", "aux_outputs", "folded_mask_features", "batched_kv", "fold_kv",
-               "fused_tails", "fused_encoder", "fused_front", "fused_kv_attention")
+from ._plan import PLAN_ATTRS as _PLAN_ATTRS, plan_epoch
 
 
 def cache_refs(model):
@@ -36,12 +35,49 @@ def cache_refs(model):
 
 
 def param_signature(model):
-    """Changes whenever a parameter or buffer is replaced or modified in place (load_state_dict, an optimizer step): graphs
-    captured before are then stale -- their nodes read the derived caches of the OLD values -- and are re-captured."""
+    """The exhaustive signature (every tensor's address and version, every plan attribute of every module): ~1 ms of
+    Python for the head.  Used at capture time and by ``strict=True`` replays; the per-replay check is StaleCheck."""
     sig = tuple((t.data_ptr(), t._version) for t in list(model.parameters()) + list(model.buffers()))
-    # ... or an execution-plan switch of a module is flipped (precision, folded / literal mask step, aux outputs, ...)
-    plan = tuple(m.__dict__.get(a) for m in model.modules() for a in _PLAN_ATTRS if a in m.__dict__)
+    plan = tuple(m.__dict__.get(a) for m in model.modules() for a in sorted(_PLAN_ATTRS) if a in m.__dict__)
     return sig + plan
+
+
+class StaleCheck:
+    """Cheap per-replay staleness test of a captured graph (the exhaustive ``param_signature`` cost 0.75-1.3 ms per call,
+    a third of the 2.2 ms step it guards).  The signature is
+
+        (plan epoch, number of tensors, sum of the tensors' version counters, address of the first and last tensor)
+
+    * the plan epoch (``_plan.py``) moves when any plan attribute of a module is assigned a new value or a library option
+      is set: one integer compare instead of modules x attributes dictionary probes;
+    * in-place updates (``load_state_dict``, an optimizer step, ``.copy_``) bump ``_version`` of the tensor they touch;
+    * ``.to(device)`` / ``.half()`` move every tensor: the first and last addresses change.
+    Not seen: a Parameter OBJECT replaced by hand (``m.weight = nn.Parameter(...)``) with a tensor at version 0 -- call
+    ``invalidate()`` (or use ``strict=True``) in code that does that.  The tensor list is cached and rebuilt when the epoch
+    moves.  ~20 us for the head's 298 tensors."""
+
+    def __init__(self, model, strict=False):
+        self.model = model
+        self.strict = strict
+        self._tensors = None
+        self._epoch = None
+        self._manual = 0
+
+    def invalidate(self):
+        self._manual += 1
+        self._tensors = None
+
+    def __call__(self):
+        if self.strict:
+            return param_signature(self.model)
+        ep = plan_epoch()
+        if self._tensors is None or ep != self._epoch:
+            self._tensors = list(self.model.parameters()) + list(self.model.buffers())
+            self._epoch = ep
+        ts = self._tensors
+        if not ts:
+            return (ep, 0, 0, 0, 0, self._manual)
+        return (ep, len(ts), sum([t._version for t in ts]), ts[0].data_ptr(), ts[-1].data_ptr(), self._manual)
 
 
 class GraphedInference:
@@ -49,11 +85,16 @@ class GraphedInference:
     replayed from a HIP graph.  ``features``: dict of device tensors.  The returned tensors are owned by the graph and
     are overwritten by the next call with the same geometry: ``.clone()`` what must outlive it."""
 
-    def __init__(self, model, warmup=2):
+    def __init__(self, model, warmup=2, strict=False):
         self.model = model
         self.warmup = max(1, int(warmup))
         self._graphs = {}
         self._stream = None
+        self._sig = StaleCheck(model, strict)
+
+    def invalidate(self):
+        """Force a re-capture on the next call (after replacing Parameter objects by hand; see StaleCheck)."""
+        self._sig.invalidate()
 
     def _key(self, features, image_size, padded_size):
         return (tuple((k, tuple(v.shape), v.dtype, v.device) for k, v in sorted(features.items())), tuple(image_size),
@@ -65,7 +106,7 @@ class GraphedInference:
             if not v.is_cuda:
                 raise RuntimeError("GraphedInference needs device tensors (there is no CPU path)")
         key = self._key(features, image_size, padded_size)
-        sig = param_signature(self.model)
+        sig = self._sig()
         entry = self._graphs.get(key)
         if entry is not None and entry[3] != sig:          # parameters changed since the capture
             entry = None
@@ -113,12 +154,13 @@ class PipelinedInference:
     of the slot's previous batch: its graph reads those buffers until then).
     """
 
-    def __init__(self, model, depth=2, warmup=2):
+    def __init__(self, model, depth=2, warmup=2, strict=False):
         if depth < 1:
             raise ValueError("depth must be >= 1")
         self.model = model
         self.depth = int(depth)
         self.warmup = max(1, int(warmup))
+        self._sig = StaleCheck(model, strict)
         # the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues; streams that share a
         # queue serialise.  The variable is read when the runtime initialises, so it can only be checked here.
         queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
@@ -148,8 +190,12 @@ class PipelinedInference:
             with torch.cuda.graph(graph, stream=stream):
                 static_out = self.model.inference(static_in, image_size, padded_size)
         self._slots[i] = (self._key(features, image_size, padded_size), stream, graph, static_in, static_out,
-                          torch.cuda.Event(), param_signature(self.model), cache_refs(self.model))
+                          torch.cuda.Event(), self._sig(), cache_refs(self.model))
         return self._slots[i]
+
+    def invalidate(self):
+        """Force every slot to re-capture on its next submit (see StaleCheck)."""
+        self._sig.invalidate()
 
     def inputs(self, slot):
         """The input buffers of a slot (dict of device tensors) once it has been built by a first ``submit``."""
@@ -169,7 +215,7 @@ class PipelinedInference:
             for v in features.values():
                 if not v.is_cuda:
                     raise RuntimeError("PipelinedInference needs device tensors (there is no CPU path)")
-            if entry is None or entry[0] != self._key(features, image_size, padded_size) or entry[6] != param_signature(self.model):
+            if entry is None or entry[0] != self._key(features, image_size, padded_size) or entry[6] != self._sig():
                 entry = self._build(i, features, image_size, padded_size)
         self._next = (i + 1) % self.depth
         stream, graph, static_in, done = entry[1], entry[2], entry[3], entry[5]

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import ops
+from ._plan import PlanAttributes
 
 
 class Instances:
@@ -61,7 +62,7 @@ class Instances:
         return Instances(self.image_size, **{k: v.to(device) for k, v in self._fields.items()})
 
 
-class MeanShiftMaskFormerHead(nn.Module):
+class MeanShiftMaskFormerHead(PlanAttributes, nn.Module):
     _version = 2
 
     def __init__(self, input_shape, *, num_classes, pixel_decoder, loss_weight=1.0, ignore_value=-1,
@@ -134,7 +135,7 @@ class PretrainedMeanShiftMaskFormerHead(MeanShiftMaskFormerHead):
     calls exit() for any TRANSFORMER_IN_FEATURE other than "multi_scale_pixel_decoder" (:258-274)."""
 
 
-class MeanShiftMaskFormer(nn.Module):
+class MeanShiftMaskFormer(PlanAttributes, nn.Module):
     """Inference branch of the meta-arch (pretrained_meanshiftformer_model.py:244-303,334-378; meanshiftformer_model.py:
     214-245,286-330).
 

@@ -20,6 +20,7 @@ import torch
 from torch import nn
 
 from . import ops
+from ._plan import PlanAttributes, version_key
 
 KAPPA = 30  # attention_util.py:26
 
@@ -202,7 +203,7 @@ class MLP(nn.Module):
         return x
 
 
-class MeanShiftTransformerDecoder(nn.Module):
+class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
     """meanshiftformer_transformer_decoder.py:343-695.  Only the configuration every MSMFormer yaml
     selects is implemented (post-norm, mean-shift cross + self attention, attention masks on):
     anything else raises at construction.
@@ -586,7 +587,7 @@ class PretrainedMeanShiftTransformerDecoder(MeanShiftTransformerDecoder):
     NUM_FEATURE_LEVELS = 1
 
 
-class SimpleBasePixelDecoder(nn.Module):
+class SimpleBasePixelDecoder(PlanAttributes, nn.Module):
     """pixel_decoder/fpn.py:161-290: passes the backbone embedding through and, when mask_dim != 64,
     derives mask_features with one 3x3 convolution (with bias, no norm)."""
 
@@ -736,7 +737,7 @@ class _ConvNorm(nn.Conv2d):
         self.norm = nn.GroupNorm(32, norm_channels) if norm_channels else None
 
 
-class MSDeformAttnPixelDecoder(nn.Module):
+class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
     """pixel_decoder/msdeformattn.py:164-358 for norm == "GN"."""
 
     def __init__(self, input_shape, *, transformer_dropout, transformer_nheads, transformer_dim_feedforward,
@@ -800,7 +801,9 @@ class MSDeformAttnPixelDecoder(nn.Module):
         layers = self.transformer.encoder.layers
         if self.precision not in ("f32", "f32_split", "bf16"):
             raise ValueError("precision must be 'f32', 'f32_split' or 'bf16'")
-        key = (str(device), self.precision) + tuple((p.data_ptr(), p._version) for p in self.transformer.encoder.parameters())
+        if getattr(self, "_enc_params", None) is None:
+            self._enc_params = list(self.transformer.encoder.parameters())
+        key = (str(device), self.precision) + version_key(self._enc_params)
         if self._packed is None or self._packed[0] != key:
             out = []
             for l, layer in enumerate(layers):

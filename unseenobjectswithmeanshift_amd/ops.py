@@ -582,24 +582,37 @@ def dec_heads(x, dec_g, dec_b, mlp, *, parts=None, bias=None, ln_g=None, ln_b=No
     return (out, d, e, q, ra) if zero_row_any else (out, d, e, q)
 
 
+def _msda_dtype(value, others):
+    """float32 or float64 like the reference's dispatch (ms_deform_attn_cuda.cu:69); every floating tensor the same."""
+    dt = value.dtype
+    if dt not in (torch.float32, torch.float64):
+        raise RuntimeError(f"ms_deform_attn: value must be float32 or float64, got {dt}")
+    for t, name in others:
+        _c(t, name, dt)
+    return dt
+
+
 def ms_deform_attn(value, spatial_shapes, level_start_index, sampling_locations, attention_weights):
     """Reference-ABI core op: value (N,S,M,D), shapes (L,2) int64, start (L,) int64,
-    loc (N,Lq,M,L,P,2), w (N,Lq,M,L,P) -> (N,Lq,M*D)."""
-    _c(value, "value"), _c(sampling_locations, "sampling_locations"), _c(attention_weights, "attention_weights")
+    loc (N,Lq,M,L,P,2), w (N,Lq,M,L,P) -> (N,Lq,M*D).  float32 or float64."""
+    dt = _msda_dtype(value, ((value, "value"), (sampling_locations, "sampling_locations"),
+                             (attention_weights, "attention_weights")))
     _c(spatial_shapes, "spatial_shapes", torch.int64), _c(level_start_index, "level_start_index", torch.int64)
     N, S, M, D = value.shape
     _, Lq, _, L, P, _ = sampling_locations.shape
-    out = torch.empty((N, Lq, M * D), device=value.device, dtype=torch.float32)
-    rc = lib().msm_msdeform_attn_fwd(_p(value), _p(spatial_shapes), _p(level_start_index), _p(sampling_locations),
-                                     _p(attention_weights), _p(out), N, S, M, D, L, Lq, P, _stream())
-    check(rc, "msm_msdeform_attn_fwd")
+    out = torch.empty((N, Lq, M * D), device=value.device, dtype=dt)
+    fn, what = ((lib().msm_msdeform_attn_fwd, "msm_msdeform_attn_fwd") if dt == torch.float32 else
+                (lib().msm_msdeform_attn_fwd_f64, "msm_msdeform_attn_fwd_f64"))
+    rc = fn(_p(value), _p(spatial_shapes), _p(level_start_index), _p(sampling_locations),
+            _p(attention_weights), _p(out), N, S, M, D, L, Lq, P, _stream())
+    check(rc, what)
     return out
 
 
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, grad_output):
-    """Reference-ABI backward: returns (grad_value, grad_sampling_loc, grad_attn_weight)."""
-    _c(value, "value"), _c(sampling_locations, "sampling_locations"), _c(attention_weights, "attention_weights")
-    _c(grad_output, "grad_output")
+    """Reference-ABI backward: returns (grad_value, grad_sampling_loc, grad_attn_weight).  float32 or float64."""
+    dt = _msda_dtype(value, ((value, "value"), (sampling_locations, "sampling_locations"),
+                             (attention_weights, "attention_weights"), (grad_output, "grad_output")))
     _c(spatial_shapes, "spatial_shapes", torch.int64), _c(level_start_index, "level_start_index", torch.int64)
     N, S, M, D = value.shape
     _, Lq, _, L, P, _ = sampling_locations.shape
@@ -608,10 +621,12 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     gv = torch.empty_like(value)
     gl = torch.empty_like(sampling_locations)
     gw = torch.empty_like(attention_weights)
-    rc = lib().msm_msdeform_attn_bwd(_p(value), _p(spatial_shapes), _p(level_start_index), _p(sampling_locations),
-                                     _p(attention_weights), _p(grad_output), _p(gv), _p(gl), _p(gw),
-                                     N, S, M, D, L, Lq, P, _stream())
-    check(rc, "msm_msdeform_attn_bwd")
+    fn, what = ((lib().msm_msdeform_attn_bwd, "msm_msdeform_attn_bwd") if dt == torch.float32 else
+                (lib().msm_msdeform_attn_bwd_f64, "msm_msdeform_attn_bwd_f64"))
+    rc = fn(_p(value), _p(spatial_shapes), _p(level_start_index), _p(sampling_locations),
+            _p(attention_weights), _p(grad_output), _p(gv), _p(gl), _p(gw),
+            N, S, M, D, L, Lq, P, _stream())
+    check(rc, what)
     return gv, gl, gw
 
 

@@ -25,6 +25,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ._plan import version_key
+
 STAGE_BLOCKS = {"res2": 3, "res3": 4, "res4": 6, "res5": 3}          # DEPTH 50
 STAGE_WIDTHS = {"res2": (64, 256), "res3": (128, 512), "res4": (256, 1024), "res5": (512, 2048)}     # (bottleneck, out)
 STAGE_STRIDE = {"res2": 1, "res3": 2, "res4": 2, "res5": 2}
@@ -105,13 +107,16 @@ class ResNet50Backbone(nn.Module):
         self.out_features = tuple(out_features)
         self.size_divisibility = 32
         self._plan_cache = None
+        self._plan_tensors = None
 
     def output_shape(self):
         from .modeling import ShapeSpec
         return {k: ShapeSpec(channels=STAGE_WIDTHS[k][1], stride=OUT_STRIDES[k]) for k in self.out_features}
 
     def _plan(self):
-        key = tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        if self._plan_tensors is None:
+            self._plan_tensors = list(self.parameters()) + list(self.buffers())
+        key = version_key(self._plan_tensors)
         if self._plan_cache is None or self._plan_cache[0] != key:
             with torch.no_grad():
                 stages = []
