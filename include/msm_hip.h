@@ -68,7 +68,7 @@ enum {
     MSM_OPT_GEMM_TILE,          /* 0..4 tile configuration of msm_gemm_f32 */
     MSM_OPT_GEMM_SHALLOW,       /* 1: no deep-K tiles */
     MSM_OPT_ATTN_TARGET,        /* workgroup target of the split-K attention kernel */
-    MSM_OPT_ATTN_KERNEL,        /* 1: one wave per query block (<= 512 keys), 2: its two-block form (<= 128 keys), 3: split-K for every length */
+    MSM_OPT_ATTN_KERNEL,        /* 3: split-K kernel + combine for every length (fallback of the query-split kernel) */
     MSM_OPT_ATTN_QK_MAX,        /* longest sequence the key-split kernel takes */
     MSM_OPT_ATTN_QKCFG,         /* 0 / 1: two / one query blocks per workgroup in the key-split kernel */
     MSM_OPT_CONVIN_NT,          /* 1, 2, 4: pixel tiles per workgroup of the input projection */
@@ -79,7 +79,7 @@ enum {
     MSM_OPT_MS_NO_PERSISTENT,   /* 1: one launch per seeding step */
     MSM_OPT_ATTN_FUSED_KV,      /* reserved (no effect) */
     MSM_OPT_KV_PIPE,            /* msm_kv_project_multi_bf16: 0 = fp32 MFMAs with only the store rounded (default: bf16 MFMAs) */
-    MSM_OPT_MASK_KERNEL,        /* fp32 mask step: 2 = one wave per SIMD with mask_embed in registers (C = 64 only), 3 = prefetch ring of four groups, 4 = software-pipelined epilogue (C = 64 attention-mask launches), 5 = never the 4-query block on the 4x4x1 MFMA */
+    MSM_OPT_MASK_KERNEL,        /* fp32 mask step: 5 = never the 4-query block on the 4x4x1 MFMA (fallback kernel) */
     MSM_OPT_COUNT
 };
 int msm_set_option(int key, int value);
@@ -496,28 +496,9 @@ int msm_encoder_prologue_fwd(const float* raw, const double* stats, const float*
                              const float* pos, float* src_out, float* value_out, float* proj_out, int B, int S,
                              int proj_width, int value_heads, void* stream);
 
-/* ---------------------------------------------------------------------------------------------
- * bf16 form of msm_encoder_block_fwd (BASELINE configs 3 / 5; the reference's low-precision mode is autocast over the whole
- * model, MSMFormer/tabletop_train_net_pretrained.py:232): bf16 MFMA operands, fp32 accumulation; the residual stream, the
- * LayerNorms, the biases and every output stay fp32.  Same arguments as msm_encoder_block_fwd except the weight stream:
- *   wstream: stages of 8 blocks of 2 KiB, a block = [4 k-groups][64 lanes][4 bf16] in MFMA fragment order
- *     row block (16 rows r0.. of a (N,64) weight):  block[g][lq*16 + lj][c] = W[r0 + lj][g*16 + lq*4 + c]
- *     linear2 block of hidden block hb:             block[ob][lq*16 + lj][c] = W2[ob*16 + lj][hb*16 + lq*4 + c]
- *     stage 0: output_proj as 4 hi row blocks + 4 lo row blocks (w = hi + lo, both bf16: the three 64-wide projections
- *     around the FFN are applied as w_lo x_hi + w_hi x_lo + w_hi x_hi); stages 1 .. d_ffn/64: [linear1 row block hb, linear2
- *     block hb] for four consecutive hb (single bf16); then (with the next layer's projections) one stage value_proj (4 hi + 4 lo)
- *     and the proj_width/16 row blocks of [sampling_offsets | attention_weights] as [hi, lo] pairs, four pairs per stage,
- *     zero-padded to whole stages (msm_encoder_block_bf16_stream_bytes; ops.pack_encoder_block_bf16 builds it).
- *   small: as msm_encoder_block_fwd (fp32).
- * ------------------------------------------------------------------------------------------- */
-int64_t msm_encoder_block_bf16_stream_bytes(int d_ffn, int proj_width);
-int msm_encoder_block_bf16_fwd(const float* attn, const float* src, const void* wstream, const float* small, const float* pos,
-                               float* src_out, float* value_out, float* proj_out, int M, int tokens_per_image, int d_ffn,
-                               int proj_width, int value_heads, float eps, void* stream);
-
 /* The fp32 encoder-layer tail on the bf16 matrix pipe (csrc/enc_block_split.hip): every fp32 operand is split exactly into three
  * bf16 terms and a product is the six bf16 MFMAs of weight >= 2^-18 with fp32 accumulation -- fp32-accurate results (the
- * dropped terms are below 2^-26 of a product) at 6/16 of the fp32 MFMA's cost.  Same arguments as msm_encoder_block_bf16_fwd;
+ * dropped terms are below 2^-26 of a product) at 6/16 of the fp32 MFMA's cost.  Same arguments as msm_encoder_block_fwd except the weight stream;
  * wstream is the triple-split weight stream (blocks of [4 k-groups][64 lanes][4 bf16]; a logical block = its h, m, l blocks;
  * 12 blocks per stage: output_proj | two hidden blocks [W1 h,m,l, W2 h,m,l] per stage | value_proj | four proj row blocks per
  * stage, zero padded), msm_encoder_block_split_stream_bytes(d_ffn, proj_width) bytes. */
@@ -525,8 +506,10 @@ int64_t msm_encoder_block_split_stream_bytes(int d_ffn, int proj_width);
 int msm_encoder_block_split_fwd(const float* attn, const float* src, const void* wstream, const float* small, const float* pos,
                                 float* src_out, float* value_out, float* proj_out, int M, int tokens_per_image, int d_ffn,
                                 int proj_width, int value_heads, float eps, void* stream);
-/* The low-precision encoder block on the same kernel structure (K = 32 bf16 MFMAs, two token tiles per wave): operands rounded
- * exactly as msm_encoder_block_bf16_fwd rounds them -- projections w(h + m) x(h + m) without the m x m term, linear1 w(h) x(h + m),
+/* The low-precision encoder block (BASELINE configs 3 / 5; the reference's low-precision mode is autocast over the whole model,
+ * MSMFormer/tabletop_train_net_pretrained.py:232) on the same kernel structure (K = 32 bf16 MFMAs, two token tiles per wave):
+ * bf16 MFMA operands, fp32 accumulation; the residual stream, the LayerNorms, the biases and every output stay fp32.  Operand
+ * roundings: the three 64-wide projections w(h + m) x(h + m) without the m x m term (w = h + m, both bf16), linear1 w(h) x(h + m),
  * linear2 single bf16 operands -- and only the copies that are read in the stream: 12 blocks of [2 k-groups][64 lanes][8 bf16] per
  * stage = output_proj [h, m] x 4 row blocks (+ 4 zero blocks) | three hidden pairs [W1(q0) h, W1(q1) h, W2 h (4 KiB)] per stage,
  * the hidden dimension zero-padded to whole stages | value_proj like output_proj | six proj row blocks [h, m] per stage. */

@@ -74,7 +74,7 @@ def mask():
         qb = wide[..., 64] if C == 64 else None
         f = torch.randn(8, C, 120, 160, device=DEV)
         flops = 2.0 * 100 * C * 19200 * 8
-        for nc, occ in (("", 2), ("", 4), ("", -1)):       # kernel 2: r64 (C = 64), 3: deep prefetch ring
+        for nc, occ in (("", 5), ("", -1)):       # kernel 5: without the 4-query block on the 4x4x1 MFMA
             _lib.set_option("MASK_NC", int(nc) if nc else _lib.OPT_AUTO)
             _lib.set_option("MASK_KERNEL", occ)
             for tgt, wm in (((15, 20), False), ((30, 40), False), ((60, 80), False), (None, True)):

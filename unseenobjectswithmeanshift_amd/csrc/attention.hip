@@ -307,167 +307,11 @@ __global__ __launch_bounds__(256) void hs_attn_kernel(const float* __restrict__ 
     }
 }
 
-// ---- short key sequences (self-attention: 100 keys; the 15x20 level: 300 keys) ---------------------------------------
+// ---- short and medium key sequences (self-attention: 100 keys; the 15x20 / 30x40 levels) -----------------------------------
 // With few keys the kernel above is all fixed cost: every wave holds all 7 query blocks for 1-2 key blocks, the four
 // waves are reduced through 59 KB of LDS and 112 threads finish with strided 4-byte stores (14.6 us for 100 keys,
-// 4 % MFMA utilisation).  Here the QUERY blocks are split instead: a wave owns MQ query blocks, walks ALL key blocks
-// and finishes in registers (1/l, L2 normalisation, 64-byte row segments) -- no LDS, no second launch.
-template <int MQ>
-__global__ __launch_bounds__(256) void hs_attn_small_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                            const float* __restrict__ v, const uint8_t* __restrict__ masked,
-                                                            const int32_t* __restrict__ row_any, float* __restrict__ out, int Lq,
-                                                            int S, int heads, int64_t ldq, int64_t q_sb, int64_t ldk,
-                                                            int64_t k_sb, int64_t ldv, int64_t v_sb, float kappa) {
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lj = lane & 15, lq = lane >> 4;
-    const int qb0 = (blockIdx.x * 4 + wave) * MQ;              // first 16-query block of this wave
-    if (qb0 * 16 >= Lq) return;                                 // wave-uniform
-
-    float qf[MQ][8];
-    bool use_mask[MQ];
-    const float* qbp = q + (int64_t)b * q_sb + h * HD + lq * 8;
-#pragma unroll
-    for (int m = 0; m < MQ; ++m) {
-        const int qi = (qb0 + m) * 16 + lj;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
-        if (qi < Lq) {
-            const float* p = qbp + (int64_t)qi * ldq;
-            a = *reinterpret_cast<const float4*>(p);
-            c = *reinterpret_cast<const float4*>(p + 4);
-        }
-        float ss = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
-        const float rn = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-        qf[m][0] = a.x * rn; qf[m][1] = a.y * rn; qf[m][2] = a.z * rn; qf[m][3] = a.w * rn;
-        qf[m][4] = c.x * rn; qf[m][5] = c.y * rn; qf[m][6] = c.z * rn; qf[m][7] = c.w * rn;
-        use_mask[m] = masked != nullptr && qi < Lq && (row_any == nullptr || row_any[(int64_t)b * Lq + qi] != 0);   // DEC:618
-    }
-    f32x4 o[MQ][2];
-    float lsum[MQ];
-#pragma unroll
-    for (int m = 0; m < MQ; ++m) {
-        o[m][0] = o[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        lsum[m] = 0.f;
-    }
-    const int nkb = (S + 15) / 16;
-    const float* kbp = k + (int64_t)b * k_sb + h * HD + lq * 8;
-    const float* vbp = v + (int64_t)b * v_sb + h * HD + lj;
-    const bool mask_vec = (S % 4) == 0;
-    struct Frag {
-        float4 ka, kc;
-        float v[4][2];
-        uint32_t mw[MQ];
-    };
-    auto fetch = [&](int kb, Frag& f) {
-        const float* kp = kbp + (int64_t)min(kb * 16 + lj, S - 1) * ldk;
-        f.ka = *reinterpret_cast<const float4*>(kp);
-        f.kc = *reinterpret_cast<const float4*>(kp + 4);
-        const int key_c0 = kb * 16 + lq * 4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float* vp = vbp + (int64_t)min(key_c0 + r, S - 1) * ldv;
-            f.v[r][0] = vp[0];
-            f.v[r][1] = vp[16];
-        }
-#pragma unroll
-        for (int m = 0; m < MQ; ++m) {
-            uint32_t w = 0;
-            if (masked != nullptr) {
-                const uint8_t* mp = masked + ((int64_t)b * Lq + min((qb0 + m) * 16 + lj, Lq - 1)) * S;
-                if (mask_vec) {
-                    w = *reinterpret_cast<const uint32_t*>(mp + min(key_c0, S - 4));
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) w |= (uint32_t)mp[min(key_c0 + r, S - 1)] << (8 * r);
-                }
-            }
-            f.mw[m] = w;
-        }
-    };
-    const float k2 = kappa * 1.4426950408889634f;
-    auto consume = [&](int kb, const Frag& f) {
-        const float4 a = f.ka, c = f.kc;
-        float ss = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
-        const float rn = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-        const float kf[8] = {a.x * rn, a.y * rn, a.z * rn, a.w * rn, c.x * rn, c.y * rn, c.z * rn, c.w * rn};
-        const int key_c0 = kb * 16 + lq * 4;
-        f32x4 sc[MQ];
-#pragma unroll
-        for (int m = 0; m < MQ; ++m) sc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-            for (int m = 0; m < MQ; ++m) sc[m] = mfma16(kf[t], qf[m][t], sc[m]);
-#pragma unroll
-        for (int m = 0; m < MQ; ++m) {
-            const uint32_t mw = use_mask[m] ? f.mw[m] : 0u;
-            float p[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool dead = (key_c0 + r >= S) || ((mw >> (8 * r)) & 0xffu);
-                p[r] = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(sc[m][r], k2, -k2));
-            }
-            lsum[m] += (p[0] + p[1]) + (p[2] + p[3]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                o[m][0] = mfma16(p[r], f.v[r][0], o[m][0]);
-                o[m][1] = mfma16(p[r], f.v[r][1], o[m][1]);
-            }
-        }
-    };
-    {
-        // A key block is 16 MFMAs (~0.2 us) per query block against ~1 us of load latency, and a wave is alone on its
-        // SIMD here (512 waves in all): a ring of RD blocks in flight instead of one (19 blocks at 300 keys: 18 -> see
-        // DESIGN.md us; the 7 blocks of a self-attention are all requested up front)
-#ifndef MSM_ATTN_RD
-#define MSM_ATTN_RD 4
-#endif
-        constexpr int RD = MQ == 1 ? MSM_ATTN_RD : 2;
-        Frag f[RD];
-#pragma unroll
-        for (int d = 0; d < RD; ++d) fetch(min(d, nkb - 1), f[d]);
-        for (int kb = 0; kb < nkb; kb += RD) {
-#pragma unroll
-            for (int d = 0; d < RD; ++d) {
-                if (kb + d < nkb) {                                  // wave-uniform
-                    __builtin_amdgcn_sched_barrier(0);
-                    consume(kb + d, f[d]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (kb + d + RD < nkb) fetch(kb + d + RD, f[d]);
-                }
-            }
-        }
-    }
-    // ---- finish in registers: o[m][half][r] = query (qb0+m)*16 + lq*4 + r, dim half*16 + lj ----
-#pragma unroll
-    for (int m = 0; m < MQ; ++m) {
-        float l = lsum[m];                     // per query lj (any lq) after the two reductions
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float lr = __shfl(l, lq * 4 + r, 64);          // denominator of this lane's output row
-            const float a0 = o[m][0][r] / lr, a1 = o[m][1][r] / lr;
-            float ss = a0 * a0 + a1 * a1;
-#pragma unroll
-            for (int x = 1; x < 16; x <<= 1) ss += __shfl_xor(ss, x, 64);
-            const float nrm = fmaxf(sqrtf(ss), 1e-12f);
-            const int qi = (qb0 + m) * 16 + lq * 4 + r;
-            if (qi < Lq) {
-                float* o_ = out + ((int64_t)b * Lq + qi) * (heads * HD) + h * HD + lj;
-                o_[0] = a0 / nrm;
-                o_[16] = a1 / nrm;
-            }
-        }
-    }
-}
-
-// ---- long key sequences, same idea: a workgroup owns MQ query blocks, its NW waves split the key blocks round-robin, the
+// 4 % MFMA utilisation).  Here the QUERY blocks are split over workgroups: a workgroup owns MQ query blocks, its NW waves
+// split the key blocks round-robin, the
 // partial sums meet in LDS (lane-contiguous, 9 values per lane and query block) and wave 0 finishes in registers.  No
 // partial tensors in memory, no combine launch; K/V of an (image, head) are re-read by the ceil(7/MQ) workgroups of that
 // head out of L2.
@@ -730,8 +574,7 @@ extern "C" int64_t msm_hypersphere_attn_workspace(int B, int Lq, int S, int head
     return (int64_t)B * qchunks * heads * ns * AQCH * PSTRIDE;
 }
 
-// KVT / BF: see the low-precision note above the kernels.  (The one-wave-per-query-block kernel, an opt-in experiment, exists
-// in fp32 only.)
+// KVT / BF: see the low-precision note above the kernels.
 template <typename KVT, bool BF>
 static int attn_launch(const char* who, const float* q, const KVT* k, const KVT* v, const uint8_t* masked, const int32_t* row_any, float* out,
                        int B, int Lq, int S, int heads, int64_t ldq, int64_t q_sb, int64_t ldk, int64_t k_sb, int64_t ldv, int64_t v_sb,
@@ -750,27 +593,7 @@ static int attn_launch(const char* who, const float* q, const KVT* k, const KVT*
         return MSM_E_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    const int force = opt(MSM_OPT_ATTN_KERNEL);
-    if constexpr (std::is_same<KVT, float>::value && !BF) {
-        if (S <= 512 && (force == 1 || force == 2)) {
-            // query-split kernel, one wave per query block walking all keys, finished in registers.  Not the default any
-            // more: a lone wave per SIMD exposes every dependency of a key block (~0.9 us per block whatever the load
-            // ring depth), and with the host out of the way (HIP-graph timing) the key-split kernel below is faster down to
-            // the shortest sequences: 300 keys 11.0 against 19.9 us, 100 keys (self-attention) 8.0 against 9.4 us.
-            const int qblocks = cdiv(Lq, 16);
-            if (force == 2 && S <= 128) {
-                dim3 grid(cdiv(qblocks, 8), heads, B);
-                hipLaunchKernelGGL((hs_attn_small_kernel<2>), grid, dim3(256), 0, st, q, k, v, masked, row_any, out, Lq, S, heads, ldq,
-                                   q_sb, ldk, k_sb, ldv, v_sb, kappa);
-            } else {
-                dim3 grid(cdiv(qblocks, 4), heads, B);
-                hipLaunchKernelGGL((hs_attn_small_kernel<1>), grid, dim3(256), 0, st, q, k, v, masked, row_any, out, Lq, S, heads, ldq,
-                                   q_sb, ldk, k_sb, ldv, v_sb, kappa);
-            }
-            MSM_CHECK_LAUNCH("msm_hypersphere_attn_fwd(small)");
-            return MSM_OK;
-        }
-    }
+    const int force = opt(MSM_OPT_ATTN_KERNEL);      // 3: the split-K kernel + combine at every length (the tested fallback)
     const int qk_max = opt(MSM_OPT_ATTN_QK_MAX) > 0 ? opt(MSM_OPT_ATTN_QK_MAX) : 2048;
     if (S <= qk_max && force != 3) {
         // short and medium sequences: query-split workgroups whose waves split the keys (measured at 1200 keys: 23 us against

@@ -1,4 +1,4 @@
-// bf16 MFMA operand helpers shared by the low-precision kernels (enc_block_bf16.hip, dec_chain.hip).
+// bf16 MFMA operand helpers shared by the low-precision kernels (enc_block_split.hip, dec_chain.hip, attention.hip, kv_proj.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -11,9 +11,9 @@
 // Six MFMAs at 1/16 of the fp32 MFMA's cost: 0.375 of the matrix time for results that deviate from float64 exactly as much
 // as the fp32-MFMA kernel's do (tests/test_gpu_ops.py::test_encoder_block_split_is_fp32_accurate measures both).  Weights are
 // split once per checkpoint on the host (pack_encoder_block_split), activations with five VALU instructions per pair when
-// they become operands.  This is NOT the low-precision mode (enc_block_bf16.hip rounds operands to one or two bf16 terms).
+// they become operands.  This is NOT the low-precision mode (MODE 1 below rounds operands to one or two bf16 terms).
 //
-// Structure as enc_block_bf16_kernel: register layout L -- lane (token lj, quarter lq) holds features fb*16 + lq*4 + r --,
+// Register layout L -- lane (token lj, quarter lq) holds features fb*16 + lq*4 + r --,
 // weights as the MFMA A operand in fragment-ordered 2-KiB blocks streamed through two LDS stages by LDS-DMA, one 16-token
 // tile per wave, 4 waves per workgroup.  The MFMA is v_mfma_f32_16x16x32_bf16 (K = 32: the full-rate gfx950 instruction;
 // the K = 16 form of the low-precision kernels runs at half the rate): the k index a lane feeds is free as long as both
@@ -59,7 +59,7 @@ __device__ __forceinline__ void mac6(f32x4& lo, f32x4& hi, bf16x8 wh, bf16x8 wm,
     hi = mfma_bf16k32(wh, x.h, hi);
 }
 // MODE 0: fp32 accuracy -- three weight copies everywhere, all six product terms.  MODE 1: the low-precision ("bf16") mode on
-// the same structure -- operands rounded as in enc_block_bf16.hip: the 64-wide projections w(h + m) x(h + m) without the
+// the same structure -- operand roundings of the low-precision mode: the 64-wide projections w(h + m) x(h + m) without the
 // m x m term, linear1 w(h) x(h + m), linear2 single operands -- with only the copies it reads in the stream, so a stage holds
 // three hidden pairs or six projection row blocks and a layer is 16 stages instead of 38.
 template <int MODE>

@@ -682,439 +682,6 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_kernel(const float* __res
     }
 }
 
-// ---- folded form, C = 64: mask_embed in registers, one wave per SIMD -----------------------------------------------------
-// The folded step (modeling.FoldedMaskFeatures) contracts over the 64 FPN channels: a tile is only 16 k-steps (224 MFMAs,
-// 3 us of the MFMA pipe) and everything around the MFMAs weighs four times what it does at C = 256.  In-kernel timestamps
-// of the kernel above (two waves per SIMD, LDS-resident mask_embed): a wave alone reaches ~70 % of the MFMA rate (its
-// ds_reads at every k-step and a prefetch distance of one group are exposed), and an epilogue that takes 0.55 us on an idle
-// SIMD takes 3 us beside a sibling wave that is issuing MFMAs (VALU instructions and stores queue behind them) -- the two
-// waves never settle into taking turns, wave priorities notwithstanding.  This kernel (an experiment, selected with
-// MSM_OPT_MASK_KERNEL = 2; see the measurements at its launch site) gives the SIMD to ONE wave with the whole register file
-// (512 VGPRs + AGPRs):
-//   * the wave's mask_embed fragments -- E[16 m + lj][4 u + lq], 7 blocks x 16 k-steps = 112 registers -- are read from
-//     LDS once and are the MFMA B operands of every tile: no LDS traffic in the K loop at all;
-//   * the feature fragments come through a ring of four groups (a whole tile): when a group's MFMAs are issued its slot is
-//     refilled with the same group of the NEXT tile, so every load has three groups (2.2 us) to arrive;
-//   * the epilogue (shared with the kernel above) runs on an otherwise idle SIMD at its nominal cost.
-constexpr int R64_C = 64, R64_W = 4;      // channels, waves per workgroup
-
-template <int POOL, bool WRITE>
-__global__ __launch_bounds__(R64_W * 64) void mask_logits_r64_kernel(const float* __restrict__ emb, const float* __restrict__ feat,
-                                                                  float* __restrict__ mask_out, uint8_t* __restrict__ attn_out,
-                                                                  int32_t* __restrict__ row_any, int Q, int C_unused, int H, int W,
-                                                                  int th, int tw, int ypar, int n_rowpairs, int rp_step,
-                                                                  int rp_first, int feat_bytes, int64_t emb_ld,
-                                                                  const float* __restrict__ qbias, int64_t qbias_ld) {
-    extern __shared__ __attribute__((aligned(16))) float Es[];   // [QCH][C + 2] embeddings, then [QCH] per-query biases, [QCH] flags
-    constexpr int NC = 1, TW = 16, NA = 2, C = R64_C, SE = C + 2, KS = C / 4, D = KS / KU;
-    static_assert(D == 4, "ring = one tile");
-    (void)C_unused;
-    const int b = blockIdx.z, qc = blockIdx.y;
-    const int q0 = qc * QCH;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lj = lane & 15, lq = lane >> 4;
-    const int HW = H * W;
-    MASK_TS(0)
-
-    const int ctiles = (W + TW - 1) / TW;
-    const int ntiles = n_rowpairs * ctiles;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr64(feat + (int64_t)b * C * HW), 0, feat_bytes, 0x00020000);
-    // tile schedule: round-robin over all waves of the (image, query chunk)'s workgroups
-    const int slots = gridDim.x * R64_W;
-    const int slot = (int)blockIdx.x * R64_W + wave;
-    const int my_tiles = slot < ntiles ? (ntiles - slot + slots - 1) / slots : 0;
-    auto tile_of = [&](int it) { return it * slots + slot; };
-    auto tile_voffs = [&](int t, unsigned& vtop, unsigned& vbot) {
-        const int rp = t / ctiles, ct = t - rp * ctiles;
-        const int ytop = ypar + 2 * (rp_first + rp * rp_step);  // may be -1 (odd pairing): clamp loads
-        const int ybot = ytop + 1;                               // may be H
-        const int c = ct * TW + PixMap<POOL, NC>::load_col(lj);
-        const int cl = c < W ? c : 0;
-        vtop = (unsigned)(((int64_t)lq * HW + (int64_t)min(max(ytop, 0), H - 1) * W + cl) * 4);
-        vbot = (unsigned)(((int64_t)lq * HW + (int64_t)min(max(ybot, 0), H - 1) * W + cl) * 4);
-    };
-    Cols<NC> tR[D][KU], bR[D][KU];
-    auto load_group = [&](Cols<NC>(&t)[KU], Cols<NC>(&bt)[KU], int kbase, unsigned vtop, unsigned vbot) {
-#pragma unroll
-        for (int u = 0; u < KU; ++u) {
-            const unsigned soff = (unsigned)(kbase + u * 4) * (unsigned)HW * 4u;
-            t[u] = ld_cols<NC>(rsrc, vtop, soff);
-            bt[u] = ld_cols<NC>(rsrc, vbot, soff);
-        }
-    };
-    // mask_embed chunk: global loads first, then the first tile's feature loads, then the LDS writes (memory returns in order)
-    const float* eb = emb + ((int64_t)b * Q + q0) * emb_ld;
-    constexpr int C4N = C / 4, RPP = (R64_W * 64) / C4N, NPASS = (QCH + RPP - 1) / RPP;      // 16 float4 per row, 16 rows per pass, 7 passes
-    const int r0 = tid / C4N, c4 = (tid - r0 * C4N) * 4;
-    float4 ev[NPASS];
-#pragma unroll
-    for (int i = 0; i < NPASS; ++i) {
-        const int r = r0 + i * RPP;
-        ev[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < QCH && q0 + r < Q) ev[i] = *reinterpret_cast<const float4*>(eb + (int64_t)r * emb_ld + c4);
-    }
-    unsigned voff_top = 0, voff_bot = 0;
-    tile_voffs(min(tile_of(0), ntiles - 1), voff_top, voff_bot);
-    if (my_tiles > 0) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) load_group(tR[d], bR[d], d * (4 * KU), voff_top, voff_bot);
-    }
-#pragma unroll
-    for (int i = 0; i < NPASS; ++i) {
-        const int r = r0 + i * RPP;
-        if (r < QCH) {
-            float2* d = reinterpret_cast<float2*>(&Es[r * SE + c4]);
-            d[0] = make_float2(ev[i].x, ev[i].y);
-            d[1] = make_float2(ev[i].z, ev[i].w);
-        }
-    }
-    float* qb = Es + QCH * SE;
-    int* any_flags = reinterpret_cast<int*>(qb + QCH);
-    for (int r = tid; r < QCH; r += R64_W * 64) {
-        qb[r] = (qbias && q0 + r < Q) ? qbias[((int64_t)b * Q + q0 + r) * qbias_ld] : 0.f;
-        any_flags[r] = 0;
-    }
-    __syncthreads();
-    MASK_TS(1)
-    // this lane's mask_embed fragments and biases, for the whole kernel
-    float e[QB][KS];
-    f32x4 bias4[QB];
-#pragma unroll
-    for (int m = 0; m < QB; ++m) {
-        const float* er = &Es[(m * 16 + lj) * SE + lq];
-#pragma unroll
-        for (int u = 0; u < KS; ++u) e[m][u] = er[4 * u];
-        const float q_b = qb[m * 16 + lj];
-        bias4[m] = f32x4{q_b, q_b, q_b, q_b};
-    }
-    MaskEpiConst<POOL, WRITE, NC> epi;
-    mask_epi_init<POOL, WRITE, NC>(epi, mask_out, attn_out, b, Q, q0, H, W, th, tw, lj, lq);
-
-    for (int it = 0; it < my_tiles; ++it) {
-        const int t = tile_of(it);
-        const int rp = t / ctiles, ct = t - rp * ctiles;
-        const int ytop = ypar + 2 * (rp_first + rp * rp_step);
-        const int ybot = ytop + 1;
-        const int c0 = ct * TW;
-        unsigned nvoff_top, nvoff_bot;
-        tile_voffs(tile_of(min(it + 1, my_tiles - 1)), nvoff_top, nvoff_bot);   // the last tile re-reads its own groups
-        f32x4 acc[QB][NA];
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-#pragma unroll
-            for (int u = 0; u < KU; ++u) {
-#pragma unroll
-                for (int m = 0; m < QB; ++m) {
-                    const float a = e[m][d * KU + u];
-                    if (d == 0 && u == 0) {                                  // D[pixel][query], C operand = the query's bias
-                        acc[m][0] = mfma16(tR[d][u].v[0], a, bias4[m]);
-                        acc[m][1] = mfma16(bR[d][u].v[0], a, bias4[m]);
-                    } else {
-                        acc[m][0] = mfma16(tR[d][u].v[0], a, acc[m][0]);
-                        acc[m][1] = mfma16(bR[d][u].v[0], a, acc[m][1]);
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#ifndef MSM_R64_NOLOAD
-            load_group(tR[d], bR[d], d * (4 * KU), nvoff_top, nvoff_bot);       // same group of the next tile
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        MASK_TS(2 + 3 * it)
-#ifdef MSM_MASK_TS
-        {
-            float dep = acc[QB - 1][NA - 1][3];
-            asm volatile("v_mov_b32 %0, %0" : "+v"(dep));
-            MASK_TS(3 + 3 * it)
-        }
-#endif
-        const bool inside = c0 + TW <= W;                                             // wave-uniform
-        if constexpr (WRITE) {
-            if (inside && epi.write_fast) mask_tile_epilogue_fast<POOL, WRITE, NC, true, false>(acc, epi, H, W, tw, ytop, ybot, c0);
-            else mask_tile_epilogue<POOL, WRITE, NC, true, false>(acc, mask_out, attn_out, any_flags, b, Q, q0, H, W, th, tw, ytop, ybot, c0, lj, lq);
-        }
-        if (inside && epi.attn_fast) mask_tile_epilogue_fast<POOL, WRITE, NC, false, true>(acc, epi, H, W, tw, ytop, ybot, c0);
-        else mask_tile_epilogue<POOL, WRITE, NC, false, true>(acc, mask_out, attn_out, any_flags, b, Q, q0, H, W, th, tw, ytop, ybot, c0, lj, lq);
-        MASK_TS(4 + 3 * it)
-    }
-    if constexpr (POOL != 0) {
-        mask_epi_flush<POOL, WRITE, NC>(epi, any_flags, lj);
-        __syncthreads();
-        for (int r = tid; r < QCH; r += R64_W * 64)
-            if (any_flags[r] && q0 + r < Q) row_any[(int64_t)b * Q + q0 + r] = 1;
-    }
-}
-
-// Fillers of the software-pipelined epilogue (mask_logits_p64_kernel): VOLATILE asm, because instruction selection is free
-// to place a pure operation anywhere in its basic block -- sched_barrier only pins what the machine scheduler sees, and left
-// to itself hipcc issues the tap sums of several query blocks in one clump.  The operands are MFMA results that were
-// written at least four MFMA issues (128 cycles) earlier, so the XDL-write -> VALU-read wait states hipcc would insert for
-// its own instructions are met by construction.
-__device__ __forceinline__ float acc_pair_sum(float x, float y) {
-    float r;
-    asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
-    return r;
-}
-__device__ __forceinline__ unsigned sum_sign(float x, float y) {                 // sign bit of x + y
-    unsigned r;
-    asm volatile("v_add_f32 %0, %1, %2\n\tv_lshrrev_b32 %0, 31, %0" : "=v"(r) : "v"(x), "v"(y));
-    return r;
-}
-__device__ __forceinline__ unsigned sum_sign_or8(float x, float y, unsigned w) {   // w | sign bit of x + y << 8
-    unsigned r;
-    asm volatile("v_add_f32 %0, %2, %3\n\tv_lshrrev_b32 %0, 31, %0\n\tv_lshl_or_b32 %0, %0, 8, %1" : "=&v"(r) : "v"(w), "v"(x), "v"(y));
-    return r;
-}
-
-// ---- folded form, C = 64, attention-mask launches: software-pipelined epilogue ---------------------------------------------
-// What the two kernels above leave on the table is the epilogue: beside a sibling wave's MFMAs it takes 1.5 - 3.5 us per
-// 3.5-us tile, alone on the SIMD (r64) nothing overlaps it.  But a wave that issues back-to-back 16x16x4 MFMAs has ~5 free
-// issue slots in each 32-cycle gap (MI355X_MICROARCH.md, "single-issue instructions HIDDEN per MFMA gap"), and the
-// epilogue of a tile is only ~80 VALU instructions and 7 stores against 224 MFMAs.  So: one wave per SIMD, mask_embed
-// fragments in registers (no LDS in the K loop), and the tile is multiplied BLOCK-MAJOR -- the 32 MFMAs of query block m (16
-// k-steps x top / bottom image row: two accumulator tuples that alternate, 64 cycles between dependent MFMAs) -- so a
-// block's logits are final after 32 MFMAs and its epilogue (tap sums, sign bits, one store) is issued, one statement per
-// pair of MFMAs, between the MFMAs of block m + 1; the last block's runs under the first block of the next tile.  Only
-// two blocks' accumulators are live (16 registers instead of 112).  The feature operands of a whole tile sit in one of two
-// register rings; the other ring is refilled for the next tile, two loads per seven MFMA pairs.  The epilogue is
-// branch-free: a tile whose row pair carries no tap (every other pair at POOL 4, three of four at POOL 8) stores through a
-// zero-length buffer descriptor (the hardware drops the stores) and masks its row_any contribution.  Host-side
-// preconditions: C == 64, no mask output, POOL in {2, 4, 8}, W a multiple of 16 (every tile inside the map).
-template <int POOL, int NW>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))   // <= 256 registers: MFMA results in VGPRs
-    void mask_logits_p64_kernel(const float* __restrict__ emb, const float* __restrict__ feat,
-                                                                  float* __restrict__ mask_out_unused, uint8_t* __restrict__ attn_out,
-                                                                  int32_t* __restrict__ row_any, int Q, int C_unused, int H, int W,
-                                                                  int th, int tw, int ypar, int n_rowpairs, int rp_step,
-                                                                  int rp_first, int feat_bytes, int64_t emb_ld,
-                                                                  const float* __restrict__ qbias, int64_t qbias_ld) {
-    static_assert(POOL == 2 || POOL == 4 || POOL == 8, "attention-mask launches only");
-    constexpr int NC = 1, TW = 16, C = R64_C, KS = C / 4;
-    extern __shared__ __attribute__((aligned(16))) float Es[];   // [QCH][C + 4] embeddings, then [QCH] per-query biases
-    using PM = PixMap<POOL, NC>;
-    (void)C_unused;
-    (void)mask_out_unused;
-    const int b = blockIdx.z, qc = blockIdx.y;
-    const int q0 = qc * QCH;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lj = lane & 15, lq = lane >> 4;
-    const int HW = H * W;
-    MASK_TS(0)
-
-    const int ctiles = W / TW;
-    const int ntiles = n_rowpairs * ctiles;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr64(feat + (int64_t)b * C * HW), 0, feat_bytes, 0x00020000);
-    // Tile schedule: tile index = it * slots + slot.  Waves w and w + 4 share a SIMD: slots are numbered so that the waves
-    // 0..3 of every workgroup come first -- the leftover round then goes to distinct SIMDs before any SIMD gets a second tile.
-    const int slots = gridDim.x * NW;
-    const int slot = (wave >> 2) * ((int)gridDim.x * 4) + (int)blockIdx.x * 4 + (wave & 3);
-    const int my_tiles = slot < ntiles ? (ntiles - slot + slots - 1) / slots : 0;
-    // two operand rings (tile parity): [k-step] for the top and the bottom image row of the tile
-    float tA[KS], bA[KS], tB[KS], bB[KS];
-    auto load_step = [&](float(&t)[KS], float(&bt)[KS], int u, unsigned vtop, unsigned vbot) {
-        const unsigned soff = (unsigned)(16 * (u >> 2) + (u & 3)) * (unsigned)HW * 4u;   // channel 16 (u / 4) + 4 lq + u % 4: the lq part is in the lane offset
-        t[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vtop, soff, 0));
-        bt[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, vbot, soff, 0));
-    };
-    // tile bookkeeping without divisions in the loop: the tile index advances by `slots`, (row pair, column tile) by (drp, dct)
-    const int drp = slots / ctiles, dct = slots - drp * ctiles;
-    int rp = min(slot, ntiles - 1) / ctiles, ct = min(slot, ntiles - 1) - rp * ctiles;
-    auto voffs = [&](unsigned& vt, unsigned& vb) {                                // load offsets of tile (rp, ct)
-        const int y = ypar + 2 * (rp_first + rp * rp_step);                       // may be -1 (odd pairing); y + 1 may be H: clamped
-        const int c = ct * TW + PM::load_col(lj);
-        vt = (unsigned)(((int64_t)(4 * lq) * HW + (int64_t)min(max(y, 0), H - 1) * W + c) * 4);
-        vb = (unsigned)(((int64_t)(4 * lq) * HW + (int64_t)min(max(y + 1, 0), H - 1) * W + c) * 4);
-    };
-    // mask_embed chunk through LDS: global loads first, then the first tile's feature loads, then the LDS writes (memory returns
-    // in order).  The k index a lane feeds into an MFMA is free as long as both operands agree: lane (lj, lq) takes channel
-    // 16 (u / 4) + 4 lq + u % 4 at k-step u, so its 16 fragments of a query block are four 16-byte LDS reads (28 ds_read_b128
-    // per lane; channel 4 u + lq, the mapping of the kernels above, needs 112 ds_read_b32).  Row stride 68 floats: 16-byte
-    // aligned, and the 16 rows of a read land on 16 x 4 distinct banks.
-    constexpr int SE = C + 4;
-    const float* eb = emb + ((int64_t)b * Q + q0) * emb_ld;
-    constexpr int C4N = C / 4, RPP = (NW * 64) / C4N, NPASS = (QCH + RPP - 1) / RPP;
-    const int r0 = tid / C4N, c4 = (tid - r0 * C4N) * 4;
-    float4 ev[NPASS];
-#pragma unroll
-    for (int i = 0; i < NPASS; ++i) {
-        const int r = r0 + i * RPP;
-        ev[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < QCH && q0 + r < Q) ev[i] = *reinterpret_cast<const float4*>(eb + (int64_t)r * emb_ld + c4);
-    }
-    // The first tiles of all waves are one burst (8 waves x 32 loads x 256 B per CU, 17 MB over the chip at B = 8: ~3.5 us at
-    // HBM / Infinity Cache speed) and no MFMA can start before a wave's whole tile is there.  Waves 0..3 -- one per SIMD --
-    // ask first; their siblings ask once their mask_embed fragments are in registers, i.e. behind them in the queues, and
-    // find their operands while the first four are already multiplying.
-    const bool early = NW <= 4 || wave < 4;
-    if (early) {
-        unsigned vt, vb;
-        voffs(vt, vb);
-#pragma unroll
-        for (int u = 0; u < KS; ++u) load_step(tA, bA, u, vt, vb);
-    }
-#pragma unroll
-    for (int i = 0; i < NPASS; ++i) {
-        const int r = r0 + i * RPP;
-        if (r < QCH) *reinterpret_cast<float4*>(&Es[r * SE + c4]) = ev[i];
-    }
-    float* qb = Es + QCH * SE;
-    for (int r = tid; r < QCH; r += NW * 64) qb[r] = (qbias && q0 + r < Q) ? qbias[((int64_t)b * Q + q0 + r) * qbias_ld] : 0.f;
-    __syncthreads();
-    float e[QB][KS];
-    f32x4 bias4[QB];
-#pragma unroll
-    for (int m = 0; m < QB; ++m) {
-        const float* er = &Es[(m * 16 + lj) * SE + 4 * lq];
-#pragma unroll
-        for (int i = 0; i < KS / 4; ++i) {
-            const float4 v = *reinterpret_cast<const float4*>(er + 16 * i);
-            e[m][4 * i] = v.x;
-            e[m][4 * i + 1] = v.y;
-            e[m][4 * i + 2] = v.z;
-            e[m][4 * i + 3] = v.w;
-        }
-        const float q_b = qb[m * 16 + lj];
-        bias4[m] = f32x4{q_b, q_b, q_b, q_b};
-    }
-    if (!early) {
-        unsigned vt, vb;
-        voffs(vt, vb);
-#pragma unroll
-        for (int u = 0; u < KS; ++u) load_step(tA, bA, u, vt, vb);
-    }
-    MASK_TS(1)
-    MASK_TSC(13)
-    MaskEpiConst<POOL, false, NC> epi;
-    mask_epi_init<POOL, false, NC>(epi, nullptr, attn_out, b, Q, q0, H, W, th, tw, lj, lq);
-    const int TT = th * tw;
-    void* const abase = uniform_ptr64(attn_out + (int64_t)b * Q * TT);
-
-    constexpr int NT = PM::PERM ? 1 : 4 / POOL;
-    constexpr int J0 = PM::PERM ? 0 : POOL / 2 - 1;
-    constexpr int JS = PM::PERM ? 0 : POOL;
-    constexpr unsigned ALL = NT == 2 ? 0x0101u : 0x01u;
-
-    // store parameters of a tile (wave-uniform; readfirstlane: hipcc cannot prove the tile coordinates uniform and would wrap
-    // every store in a waterfall loop)
-    struct StoreParm {
-        unsigned soff, mask;
-        int n;
-    };
-    auto store_parm = [&]() {
-        const int y = ypar + 2 * (rp_first + rp * rp_step);
-        const bool tap = y >= 0 && y + 1 < H && (y % POOL) == POOL / 2 - 1;
-        StoreParm sp;
-        sp.soff = (unsigned)__builtin_amdgcn_readfirstlane(tap ? (y / POOL) * tw + (ct * TW) / POOL : 0);
-        sp.mask = (unsigned)__builtin_amdgcn_readfirstlane(tap ? -1 : 0);
-        sp.n = __builtin_amdgcn_readfirstlane(tap ? Q * TT : 0);
-        return sp;
-    };
-    // One tile from the ring (t, bt) while the other ring (nt, nbt) is refilled for the tile at (nvt, nvb).  (pt, pb): finished
-    // accumulators of the previous tile's last query block with its store parameters `pp`; on return they are this tile's.
-    // Source order IS the schedule (a sched_barrier after every pair of MFMAs; the fillers are volatile asm or memory
-    // operations, which instruction selection keeps in order).
-    auto tile = [&](const float(&t)[KS], const float(&bt)[KS], float(&nt)[KS], float(&nbt)[KS], unsigned nvt, unsigned nvb, f32x4& pt,
-                    f32x4& pb, StoreParm& pp, const StoreParm cur) {
-        const __amdgpu_buffer_rsrc_t ar_prev = __builtin_amdgcn_make_buffer_rsrc(abase, 0, __builtin_amdgcn_readfirstlane(pp.n), 0x00020000);
-        const __amdgpu_buffer_rsrc_t ar_cur = __builtin_amdgcn_make_buffer_rsrc(abase, 0, __builtin_amdgcn_readfirstlane(cur.n), 0x00020000);
-#pragma unroll
-        for (int m = 0; m < QB; ++m) {
-            const int pm = m == 0 ? QB - 1 : m - 1;                               // the block whose epilogue runs under this one
-            const __amdgpu_buffer_rsrc_t ar = m == 0 ? ar_prev : ar_cur;
-            const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)(m == 0 ? pp.soff : cur.soff));
-            const unsigned tapmask = (unsigned)__builtin_amdgcn_readfirstlane((int)(m == 0 ? pp.mask : cur.mask));
-            f32x4 top, bot;
-            float sa = 0.f, sb = 0.f;
-            unsigned w = 0;
-#pragma unroll
-            for (int u = 0; u < KS; ++u) {
-                if (u == 0) {                                                     // C operand = the query's bias
-                    top = mfma16(t[u], e[m][u], bias4[m]);
-                    bot = mfma16(bt[u], e[m][u], bias4[m]);
-                } else {
-                    top = mfma16(t[u], e[m][u], top);
-                    bot = mfma16(bt[u], e[m][u], bot);
-                }
-                if constexpr (NT == 2) {
-                    if (u == 1) sa = acc_pair_sum(pt[J0], pt[J0 + 1]);
-                    if (u == 3) sb = acc_pair_sum(pb[J0], pb[J0 + 1]);
-                    if (u == 5) w = sum_sign(sa, sb);
-                    if (u == 7) sa = acc_pair_sum(pt[J0 + JS], pt[J0 + JS + 1]);
-                    if (u == 9) sb = acc_pair_sum(pb[J0 + JS], pb[J0 + JS + 1]);
-                    if (u == 11) w = sum_sign_or8(sa, sb, w);
-                } else {
-                    if (u == 1) sa = acc_pair_sum(pt[J0], pt[J0 + 1]);
-                    if (u == 5) sb = acc_pair_sum(pb[J0], pb[J0 + 1]);
-                    if (u == 9) w = sum_sign(sa, sb);
-                }
-                if (u == 13) {
-                    if constexpr (NT == 2) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)w, ar, epi.aoff[pm], soff, 0);
-                    else __builtin_amdgcn_raw_buffer_store_b8((unsigned char)w, ar, epi.aoff[pm], soff, 0);
-                    epi.anyv[pm] |= (w ^ ALL) & tapmask;
-                }
-                const int sl = m * KS + u;                                        // 112 slots, 16 k-steps to reload: every 7th slot
-                if (sl % QB == 0) load_step(nt, nbt, sl / QB, nvt, nvb);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            pt = top;
-            pb = bot;
-        }
-        pp = cur;
-    };
-    // the last block of the last tile: nothing left to hide behind
-    auto last_block = [&](const f32x4& pt, const f32x4& pb, const StoreParm& pp) {
-        const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(abase, 0, pp.n, 0x00020000);
-        unsigned w = 0;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int jl = J0 + t * JS;
-            const float s = add1(add1(pt[jl], pt[jl + 1]), add1(pb[jl], pb[jl + 1]));
-            w = t == 0 ? neg_bit(s) : (w | (neg_bit(s) << (8 * t)));
-        }
-        if constexpr (NT == 2) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)w, ar, epi.aoff[QB - 1], pp.soff, 0);
-        else __builtin_amdgcn_raw_buffer_store_b8((unsigned char)w, ar, epi.aoff[QB - 1], pp.soff, 0);
-        epi.anyv[QB - 1] |= (w ^ ALL) & pp.mask;
-    };
-
-    if (my_tiles > 0) {
-        f32x4 pt = f32x4{0.f, 0.f, 0.f, 0.f}, pb = pt;
-        StoreParm pp{0u, 0u, 0};
-        int it = 0;
-        auto next_tile = [&](unsigned& nvt, unsigned& nvb) {                      // (rp, ct) -> successor (the last tile re-reads itself)
-            if (it + 1 < my_tiles) {
-                ct += dct;
-                rp += drp;
-                if (ct >= ctiles) { ct -= ctiles; ++rp; }
-            }
-            voffs(nvt, nvb);
-        };
-        while (true) {
-            unsigned nvt, nvb;
-            StoreParm cur = store_parm();
-            next_tile(nvt, nvb);
-            tile(tA, bA, tB, bB, nvt, nvb, pt, pb, pp, cur);
-            MASK_TS(2 + it)
-            if (++it == my_tiles) break;
-            cur = store_parm();
-            next_tile(nvt, nvb);
-            tile(tB, bB, tA, bA, nvt, nvb, pt, pb, pp, cur);
-            MASK_TS(2 + it)
-            if (++it == my_tiles) break;
-        }
-        last_block(pt, pb, pp);
-    }
-    MASK_TSC(14)
-    MASK_TS(15)
-    // row_any: a benign race (every writer stores 1); rows / lanes that never stored keep their zeros
-#pragma unroll
-    for (int m = 0; m < QB; ++m)
-        if (epi.anyv[m] != 0u && epi.aoff[m] != 0xF0000000u) row_any[(int64_t)b * Q + q0 + m * 16 + lj] = 1;
-}
-
-// ---- bf16 variant (BASELINE configs 3 and 5) ------------------------------------------------------------------------
 // Same product with bf16 operands and fp32 accumulation (v_mfma_f32_16x16x16_bf16): at 2.5 PFLOP/s the 7.9 GFLOP of a
 // launch are ~4 us of MFMA, so the step becomes a stream over the feature map -- HBM-bound (AI 71.6 FLOP/B
 // against a bf16 ridge of ~312).  The features are kept in a channel-quad packed layout [B][C/4][HW][4] bf16
@@ -1339,66 +906,25 @@ extern "C" int msm_mask_logits_fwd(const float* mask_embed, const float* mask_fe
                            const float*, int64_t);
     kern_t kern;
     const bool wr = mask_out != nullptr;
-    // prefetch ring of four groups (2 x 16 tiles, C a multiple of 64) instead of two: opt-in -- a lone wave then gets closer
-    // to the MFMA rate (K loop of a 3 us tile: 6.1 -> 4.8 us) but its 32 loads up front delay the first MFMA by 1.2 us
-    const bool deep = nc == 1 && (C / (4 * KU)) % 4 == 0 && opt(MSM_OPT_MASK_KERNEL) == 3;
     // Q = 96 + 4 (the 100 queries of every shipped configuration): the last query block on the 4x4x1 MFMA (8 cycles per k-step
     // and image row instead of 32): 10.7 % less matrix time per tile.  Needs 2 x 16 tiles that all take the fast epilogue.
-    const bool r4 = nc == 1 && !deep && Q == 100 && W % 16 == 0 && (int64_t)Q * H * W * 4 < 0xF0000000ll && opt(MSM_OPT_MASK_KERNEL) != 5 &&
+    // MSM_OPT_MASK_KERNEL = 5 selects the kernel without that block (the one tested fallback; round-2 experiments --
+    // mask_embed in registers with one wave per SIMD, a four-group prefetch ring, a software-pipelined block-major epilogue --
+    // were all measured slower, DESIGN.md section 5, and left the library in round 3).
+    const bool r4 = nc == 1 && Q == 100 && W % 16 == 0 && (int64_t)Q * H * W * 4 < 0xF0000000ll && opt(MSM_OPT_MASK_KERNEL) != 5 &&
                     (pool == 0 || pool == 2 || pool == 4 || pool == 8);
 #define MASK_PICK(P)                                                                                                   \
-    (wr ? (deep ? (kern_t)mask_logits_kernel<P, true, 1, 4> : (r4 ? (kern_t)mask_logits_kernel<P, true, 1, 2, true> : (kern_t)mask_logits_kernel<P, true, 1, 2>)) \
+    (wr ? (r4 ? (kern_t)mask_logits_kernel<P, true, 1, 2, true> : (kern_t)mask_logits_kernel<P, true, 1, 2>)             \
         : (nc == 2 ? (kern_t)mask_logits_kernel<P, false, 2, 2>                                                          \
-                   : (deep ? (kern_t)mask_logits_kernel<P, false, 1, 4>                                                  \
-                           : (r4 ? (kern_t)mask_logits_kernel<P, false, 1, 2, true> : (kern_t)mask_logits_kernel<P, false, 1, 2>))))
+                   : (r4 ? (kern_t)mask_logits_kernel<P, false, 1, 2, true> : (kern_t)mask_logits_kernel<P, false, 1, 2>)))
     switch (pool) {
-        case 0: kern = deep ? (kern_t)mask_logits_kernel<0, true, 1, 4> : (r4 ? (kern_t)mask_logits_kernel<0, true, 1, 2, true> : (kern_t)mask_logits_kernel<0, true, 1, 2>); break;
+        case 0: kern = r4 ? (kern_t)mask_logits_kernel<0, true, 1, 2, true> : (kern_t)mask_logits_kernel<0, true, 1, 2>; break;
         case 1: kern = MASK_PICK(1); break;
         case 2: kern = MASK_PICK(2); break;
         case 4: kern = MASK_PICK(4); break;
         default: kern = MASK_PICK(8); break;
     }
 #undef MASK_PICK
-    if (C == R64_C && !wr && (pool == 2 || pool == 4 || pool == 8) && W % 16 == 0 && (int64_t)Q * th * tw < 0xF0000000ll &&
-        opt(MSM_OPT_MASK_KERNEL) == 4) {
-        // folded attention-mask launches: software-pipelined epilogue (mask_logits_p64_kernel), two waves per SIMD
-        constexpr int PW = 8;
-        const int nt16 = n_rowpairs * (W / 16);
-        int wgp = cdiv(nt16, PW);
-        const int tgt = cdiv(256, B * qchunks);
-        if (wgp > tgt) wgp = max(tgt, 1);
-        kern = pool == 2 ? (kern_t)mask_logits_p64_kernel<2, PW> : (pool == 4 ? (kern_t)mask_logits_p64_kernel<4, PW> : (kern_t)mask_logits_p64_kernel<8, PW>);
-        const size_t plds = sizeof(float) * ((size_t)QCH * (C + 4) + QCH);
-        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)kern, plds));
-        hipLaunchKernelGGL(kern, dim3(wgp, qchunks, B), dim3(PW * 64), plds, st, mask_embed, mask_feat, mask_out, attn_out, row_any, Q, C, H, W, th,
-                           tw, ypar, n_rowpairs, rp_step, rp_first, (int)((int64_t)C * H * W * 4), embed_ld, qbias, qbias_ld);
-        MSM_CHECK_LAUNCH("msm_mask_logits_fwd(p64)");
-        return MSM_OK;
-    }
-    if (C == R64_C && opt(MSM_OPT_MASK_KERNEL) == 2) {
-        // folded form, opt-in: one wave per SIMD, mask_embed in registers (mask_logits_r64_kernel).  Measured at B = 8: 24.9 /
-        // 25.0 / 26.3 / 27.8 us (15x20 / 30x40 / 60x80 targets / final write) against 23.6 / 23.8 / 25.0 / 27.3 for the
-        // two-waves-per-SIMD kernel above: its K loop runs at 3.5 - 3.7 us per 3.0-us tile with or without the loads, i.e.
-        // a lone wave issues 16x16x4 MFMAs at ~85 % of the nominal rate, and nothing hides its epilogues.
-        const int nt16 = n_rowpairs * cdiv(W, 16);
-        int wgp = cdiv(nt16, R64_W);
-        const int tgt = cdiv(256, B * qchunks);
-        if (wgp > tgt) wgp = max(tgt, 1);
-#define MASK_PICK_R(P) (wr ? (kern_t)mask_logits_r64_kernel<P, true> : (kern_t)mask_logits_r64_kernel<P, false>)
-        switch (pool) {
-            case 0: kern = (kern_t)mask_logits_r64_kernel<0, true>; break;
-            case 1: kern = MASK_PICK_R(1); break;
-            case 2: kern = MASK_PICK_R(2); break;
-            case 4: kern = MASK_PICK_R(4); break;
-            default: kern = MASK_PICK_R(8); break;
-        }
-#undef MASK_PICK_R
-        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)kern, lds));
-        hipLaunchKernelGGL(kern, dim3(wgp, qchunks, B), dim3(R64_W * 64), lds, st, mask_embed, mask_feat, mask_out, attn_out, row_any, Q, C, H, W, th,
-                           tw, ypar, n_rowpairs, rp_step, rp_first, (int)((int64_t)C * H * W * 4), embed_ld, qbias, qbias_ld);
-        MSM_CHECK_LAUNCH("msm_mask_logits_fwd(r64)");
-        return MSM_OK;
-    }
     MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)kern, lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, mask_embed, mask_feat, mask_out, attn_out, row_any, Q, C, H, W, th, tw,
                        ypar, n_rowpairs, rp_step, rp_first, (int)((int64_t)C * H * W * 4), embed_ld, qbias, qbias_ld);

@@ -857,53 +857,6 @@ def pack_encoder_block(wo, w1, w2, wv=None, wp=None):
     return torch.cat(blocks, 0).reshape(-1).contiguous()
 
 
-def pack_encoder_block_bf16(wo, w1, w2, wv=None, wp=None):
-    """One encoder layer's matrices as the bf16 weight stream of msm_encoder_block_bf16_fwd (include/msm_hip.h): blocks of
-    [4 k-groups][64 lanes][4 bf16] in MFMA fragment order, 8 blocks per stage; output_proj, value_proj and the sampling
-    projection as hi + lo bf16 pairs.  Returns an int16 tensor (bf16 bit patterns)."""
-    dev = wo.device
-    d_ffn = w1.shape[0]
-
-    def rowblocks(w):                                     # (N, 64) -> (N/16, 1024): block[g][lq][lj][c] = W[r0 + lj][g*16 + lq*4 + c]
-        return w.reshape(-1, 16, 4, 4, 4).permute(0, 2, 3, 1, 4).reshape(-1, 1024)
-
-    def hi_lo(w):                                         # w = hi + lo up to 2^-17 |w|, both exactly representable in bf16
-        hi = w.to(torch.bfloat16).float()
-        return hi, (w - hi).to(torch.bfloat16).float()
-
-    zeros = lambda n: torch.zeros(n, 1024, device=dev)
-    w1b = rowblocks(w1)                                                                       # (d_ffn/16, 1024)
-    w2b = w2.reshape(4, 16, d_ffn // 16, 4, 4).permute(2, 0, 3, 1, 4).reshape(-1, 1024)      # [hb][ob][lq][lj][c]
-    blocks = [rowblocks(t) for t in hi_lo(wo)] + [torch.stack([w1b, w2b], 1).reshape(-1, 1024)]
-    if wv is not None:
-        blocks += [rowblocks(t) for t in hi_lo(wv)]
-        ph, pl = (rowblocks(t) for t in hi_lo(wp))
-        pairs = torch.stack([ph, pl], 1).reshape(-1, 1024)                                   # [hi, lo] per proj row block
-        blocks += [pairs, zeros((-pairs.shape[0]) % 8)]
-    out = torch.cat(blocks, 0).to(torch.bfloat16).contiguous().view(torch.int16).reshape(-1)
-    need = int(lib().msm_encoder_block_bf16_stream_bytes(d_ffn, 0 if wp is None else wp.shape[0]))
-    if out.numel() * 2 != need:
-        raise RuntimeError(f"pack_encoder_block_bf16: built {out.numel() * 2} bytes, the kernel expects {need}")
-    return out
-
-
-def encoder_block_bf16(attn, src, wstream, small, d_ffn, proj_width, *, pos=None, tokens_per_image=None, want_next=True,
-                       value_heads=0, eps=1e-5):
-    """encoder_block with bf16 MFMA operands / fp32 accumulation (wstream from pack_encoder_block_bf16); fp32 in, fp32 out."""
-    _c(attn, "attn"), _c(src, "src"), _c(wstream, "wstream", torch.int16), _c(small, "small"), _c(pos, "pos")
-    B, S, C = src.shape
-    src_out = torch.empty_like(src)
-    value_out = proj_out = None
-    if want_next:
-        value_out = torch.empty((B, value_heads, S, C // value_heads), device=src.device, dtype=torch.float32) \
-            if value_heads else torch.empty_like(src)
-        proj_out = torch.empty((B, S, proj_width), device=src.device, dtype=torch.float32)
-    rc = lib().msm_encoder_block_bf16_fwd(_p(attn), _p(src), _p(wstream), _p(small), _p(pos), _p(src_out), _p(value_out), _p(proj_out),
-                                          B * S, tokens_per_image or S, d_ffn, proj_width, int(value_heads), eps, _stream())
-    check(rc, "msm_encoder_block_bf16_fwd")
-    return src_out, value_out, proj_out
-
-
 def pack_encoder_block_split(wo, w1, w2, wv=None, wp=None):
     """One encoder layer's matrices as the triple-split weight stream of msm_encoder_block_split_fwd (include/msm_hip.h):
     every fp32 weight as w = h + m + l with h = bf16(w), m = bf16(w - h), l = bf16(w - h - m); 2-KiB blocks in the fragment
