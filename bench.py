@@ -106,44 +106,97 @@ def launch_ranks(n, argv):
 # ----------------------------------------------------------------------------------------------------------------------
 # CPU baseline (oracle as the thing TIMED on the host cores -- never on the product path)
 # ----------------------------------------------------------------------------------------------------------------------
-def cpu_baseline(images=6):
-    """The oracle (CPU port of the reference algorithm, parity-pinned to reference goldens) on
-    the host cores of this box: same synthetic inputs/weights, one warm-up image then `images`
-    timed ones, processed one at a time like the reference predictor (batch 1, test_utils.py:165)."""
+def cpu_baseline(iters=10, budget_s=28.0):
+    """The oracle (CPU port of the reference algorithm, parity-pinned to reference goldens) on the host cores of this box,
+    per piece as SURVEY 8d prescribes: pixel decoder / decoder / post-process at 640x480, batch 1 like the reference
+    predictor (test_utils.py:165), and the classic mean-shift clustering at n = 307 200 (lib/utils/mean_shift.py:192-229) --
+    3 warm-up + `iters` timed iterations each, MEDIAN reported.  Bounded: the whole leg stays within about `budget_s` seconds
+    of CPU work (the mean-shift leg takes fewer iterations when the host is slow, and says how many)."""
+    import statistics
     from oracle import msm_oracle as O
     from unseenobjectswithmeanshift_amd import synthetic as syn
     ncpu = os.cpu_count() or 1
     pd_sd = syn.synth_state_dict(syn.pixel_decoder_param_shapes())
     dec_sd = syn.synth_state_dict(syn.decoder_param_shapes())
+    t_start = time.perf_counter()
 
     def one(seed):
+        """-> seconds of (pixel decoder, decoder, post-process) for one frame"""
         feats = syn.synth_backbone_features(1, H, W, seed=seed)
         t0 = time.perf_counter()
         mf, _, ms = O.pixel_decoder_forward(pd_sd, feats)
+        t1 = time.perf_counter()
         out = O.decoder_forward(dec_sd, ms, mf)
+        t2 = time.perf_counter()
         O.instance_inference(out["pred_logits"][0], out["pred_masks"][0], (H, W), topk=20)
-        return time.perf_counter() - t0
+        return t1 - t0, t2 - t1, time.perf_counter() - t2
 
     # pick the intra-op thread count that serves this workload best (all hardware threads is rarely it
     # for torch's CPU kernels at these sizes); the choice is reported in `cores`
     best, sweep = None, {}
-    for nt in sorted({min(ncpu, c) for c in (16, 32, 64, max(1, ncpu // 2))}):
+    for nt in sorted({min(ncpu, c) for c in (16, 32, 64)}):
         torch.set_num_threads(nt)
         one(100)                       # warm-up at this thread count
-        t = one(100)
+        t = sum(one(100))
         sweep[str(nt)] = round(1.0 / t, 3)
         if best is None or t < best[0]:
             best = (t, nt)
     warm, nt = best
     torch.set_num_threads(nt)
-    # bounded sample: aim for <= ~20 s of CPU work whatever the host is
-    images = max(1, min(images, int(20.0 / max(warm, 1e-3))))
-    dt = sum(one(101 + i) for i in range(images))
-    return {"value": round(images / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "host_cpus": ncpu,
-            "threads_sweep_images_per_sec": sweep, "kind": "port",
-            "sample": f"{images} frames at 640x480 after warm-up and a thread-count sweep (16/32/64/half the CPUs, best kept: "
-                      f"{torch.get_num_threads()} threads of {ncpu} host CPUs), batch 1, oracle pixel decoder + 9-layer decoder "
-                      f"+ instance post-processing in fp32 torch"}
+    for i in range(2):
+        one(100)                       # 3 warm-up frames at the chosen thread count in all (one in the sweep)
+    n_it = max(3, min(iters, int(0.45 * budget_s / max(warm, 1e-3))))
+    samples = [one(101 + i) for i in range(n_it)]
+    med = lambda xs: statistics.median(xs)
+    t_pd, t_dec, t_post = (med([s_[i] for s_ in samples]) for i in range(3))
+    t_e2e = med([sum(s_) for s_ in samples])
+    # mean shift, its own unit (images/sec of the clustering of one 640x480 embedding map)
+    X, _ = syn.synth_unit_embeddings(H * W, 64, clusters=12, sigma=0.15, seed=3)
+    t0 = time.perf_counter()
+    O.mean_shift_smart_init(X, 20.0, 100, 10, 7)
+    t_first = time.perf_counter() - t0
+    left = budget_s - (time.perf_counter() - t_start)
+    n_ms = max(1, min(iters, int(left / max(t_first, 1e-3))))
+    ms_samples = []
+    for _ in range(n_ms):
+        t0 = time.perf_counter()
+        O.mean_shift_smart_init(X, 20.0, 100, 10, 7)
+        ms_samples.append(time.perf_counter() - t0)
+    t_ms = med(ms_samples)
+    return {"value": round(1.0 / t_e2e, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "host_cpus": ncpu,
+            "threads_sweep_images_per_sec": sweep, "kind": "port", "statistic": "median", "iterations": n_it,
+            "pieces": {"pixel_decoder_ms": round(1e3 * t_pd, 2), "decoder_ms": round(1e3 * t_dec, 2), "post_process_ms": round(1e3 * t_post, 2),
+                       "end_to_end_ms": round(1e3 * t_e2e, 2)},
+            "mean_shift": {"value": round(1.0 / t_ms, 4), "unit": "images/sec", "ms_per_image": round(1e3 * t_ms, 1), "iterations": n_ms,
+                           "workload": "mean_shift_smart_init on n=307200 unit 64-d embeddings (12 planted clusters), 100 seeds, 10 iterations, kappa 20"},
+            "sample": f"median of {n_it} frames at 640x480 (3 warm-up frames; thread-count sweep 16/32/64, best kept: "
+                      f"{torch.get_num_threads()} threads of {ncpu} host CPUs), batch 1, oracle pixel decoder + 9-layer decoder + instance "
+                      f"post-processing in fp32 torch, timed per piece; mean shift: median of {n_ms} clusterings of one 640x480 map after one warm-up"}
+
+
+def pin_to_gpu_numa_node(local_rank):
+    """One process per GPU: keep the rank's host threads on the CPUs of the NUMA node its GPU hangs off (launch and
+    event-polling latency; on an 8-GPU node the default is whatever core the launcher forked on).  Best effort -- returns a
+    short description for the JSON line, or None when the topology files are not there."""
+    try:
+        props = torch.cuda.get_device_properties(local_rank)
+        bdf = f"{getattr(props, 'pci_domain_id', 0):04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            cpus = set()
+            for part in f.read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return {"pci": bdf, "numa_node": node, "cpus": len(cpus)}
+    except (OSError, ValueError, AttributeError, RuntimeError):
+        return None
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -171,6 +224,85 @@ def event_ms(fn, reps=5, warm=2):
     e[1].record()
     e[1].synchronize()
     return e[0].elapsed_time(e[1]) / reps
+
+
+def mask_step_graph_ms(step, reps=100):
+    """The dominant kernel on its own: the mask-step launches of one pass (their real arguments, recorded from `step()`), replayed
+    back to back from a HIP graph between two HIP events on the current stream -- kernel time without the host's launch gaps and
+    without the event records that sit between eager launches (what rocprofv3 reports per dispatch).  -> (ms per launch, launches)"""
+    from unseenobjectswithmeanshift_amd import ops
+    calls, orig = [], ops.mask_logits
+
+    def recording(*a, **k):
+        calls.append((a, k))
+        return orig(*a, **k)
+
+    ops.mask_logits = recording
+    try:
+        step()
+    finally:
+        ops.mask_logits = orig
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):
+        stream.synchronize()
+        mg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(mg, stream=stream):
+            for a, k in calls:
+                orig(*a, **k)
+        for _ in range(5):
+            mg.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            mg.replay()
+        e1.record()
+        e1.synchronize()
+    torch.cuda.current_stream().wait_stream(stream)
+    return e0.elapsed_time(e1) / (reps * len(calls)), len(calls)
+
+
+def precision_leg(model, feats, dev, dist, args, precision, inflight):
+    """The per-GPU batch of 8 in another precision mode, timed on EVERY rank exactly like the headline region (barrier + sync on
+    both sides, max over ranks): under --gpus 8 this is BASELINE configs[2] (batch 64 over 8 GPUs, bf16).  Returns this rank's
+    (images, elapsed seconds, steps, one-batch-in-flight seconds per step)."""
+    from unseenobjectswithmeanshift_amd.graphs import PipelinedInference
+    model.set_precision(precision)
+    lone = PipelinedInference(model, depth=1)
+    lone.submit(feats, (H, W))
+    lone.drain()
+    run_lone = lambda: lone.submit(None, (H, W), slot_inputs=True)
+    for _ in range(3):
+        run_lone()
+    lone.drain()
+    single = timed(run_lone, 100)
+    del lone
+    pipe = PipelinedInference(model, depth=inflight)
+    for _ in range(inflight):
+        pipe.submit(feats, (H, W))
+    pipe.drain()
+    run = lambda: pipe.submit(None, (H, W), slot_inputs=True)
+    for _ in range(2 * inflight):
+        run()
+    pipe.drain()
+    est = timed(run, 4 * inflight)
+    steps = max(args.steps, int(math.ceil(args.min_seconds / max(est, 1e-6))))
+    if dist is not None:
+        t = torch.tensor([steps], device=dev, dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        steps = int(t.item())
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    del pipe
+    model.set_precision("f32")
+    return feats[next(iter(feats))].shape[0] * steps, elapsed, steps, single
 
 
 def mean_shift_unit(dev):
@@ -215,30 +347,18 @@ def mean_shift_unit(dev):
 
 def extra_configs(dev, args):
     """BASELINE configs[2] (per-GPU slice), configs[3] and configs[4], timed by this run (rank 0, N = 1)."""
+    from unseenobjectswithmeanshift_amd import _lib
     from unseenobjectswithmeanshift_amd import mean_shift as ms
     from unseenobjectswithmeanshift_amd import ops
     from unseenobjectswithmeanshift_amd import synthetic as syn
     from unseenobjectswithmeanshift_amd import two_stage as ts
     from unseenobjectswithmeanshift_amd.meta_arch import Instances, MeanShiftMaskFormer, Network_RGBD
     out = {}
-    # configs[2], the slice one GPU of the 8 owns: batch 8 at 640x480, low-precision mode
     model = build_model(dev)
     feats = {k: v.to(dev) for k, v in syn.synth_backbone_features(BATCH, H, W, seed=10).items()}
-    if hasattr(model, "set_precision"):
-        model.set_precision("bf16")
-    else:
-        model.sem_seg_head.predictor.mask_step_dtype = "bf16"
-    g = model.graphed()
-    for _ in range(3):
-        g(feats, (H, W))
-    t = timed(lambda: g(feats, (H, W)), 50)
-    out["configs[2] per-GPU slice"] = {"workload": "batch 8 of the 64, 640x480, bf16 operands / fp32 accumulation, one HIP graph, one batch in flight",
-                                       "value": round(BATCH / t, 1), "unit": "images/sec", "ms_per_step": round(1e3 * t, 3),
-                                       "dtype": getattr(model, "precision", "f32 + bf16 mask step")}
-    del g
     # configs[1] again with the encoder's fp32 GEMMs on the bf16 matrix pipe (exact three-term splits, six MFMAs per product:
     # fp32-accurate, csrc/enc_block_split.hip) -- NOT the headline: that keeps the fp32 MFMA everywhere
-    if hasattr(model, "set_precision"):
+    if True:
         model.set_precision("f32_split")
         g = model.graphed()
         for _ in range(3):
@@ -267,6 +387,65 @@ def extra_configs(dev, args):
                                        "value": round(BATCH / t_full, 1), "unit": "images/sec", "ms_per_step": round(1e3 * t_full, 3),
                                        "backbone_ms": round(1e3 * t_bb, 3)}
     del full
+    # the literal 256-channel mask step (what a decoder handed a plain mask_features tensor runs; DEC:668 as written) with its
+    # own roofline: executed FLOPs = the reference einsum's
+    model = build_model(dev)
+    model.sem_seg_head.predictor.folded_mask_features = False
+    feats = {k: v.to(dev) for k, v in syn.synth_backbone_features(BATCH, H, W, seed=10).items()}
+    g = model.graphed()
+    for _ in range(3):
+        g(feats, (H, W))
+    t = timed(lambda: g(feats, (H, W)), 30)
+    ms_lit, n_lit = mask_step_graph_ms(lambda: model.inference(feats, (H, W)))
+    fl = 2.0 * Q * C_MASK * (H // 4) * (W // 4) * BATCH
+    out["configs[1] literal mask step"] = {
+        "workload": "batch 8, 640x480, fp32, the mask step contracting the 256-channel mask_features tensor as the reference writes it "
+                    "(decoder.folded_mask_features = False); one HIP graph, one batch in flight, the graph copies its inputs",
+        "value": round(BATCH / t, 1), "unit": "images/sec", "ms_per_step": round(1e3 * t, 3),
+        "roofline": {"bound": "mfma", "kernel": "mask_logits_kernel, C = 256", "achieved": round(fl / (ms_lit * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(fl / (ms_lit * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "flops_per_launch": fl,
+                     "avg_launch_ms": round(ms_lit, 4), "launches_per_step": n_lit, "traffic": None}}
+    del g, model
+    # the UCN RGB-D path (configs/mixture_UCN.yaml): SimpleBasePixelDecoder + the single-level decoder whose keys
+    # are every pixel of the 480x640 embedding (307 200 keys, 6 layers); backbone excluded like the headline
+    from unseenobjectswithmeanshift_amd.meta_arch import PretrainedMeanShiftMaskFormer, build_ucn_head
+    uh = build_ucn_head()
+    uh.pixel_decoder.load_state_dict(syn.synth_state_dict({"mask_features.weight": (256, 64, 3, 3), "mask_features.bias": (256,)}, salt=3))
+    uh.predictor.load_state_dict(syn.synth_state_dict(syn.decoder_param_shapes(dec_layers=6, num_feature_levels=1), salt=4))
+    ucn = PretrainedMeanShiftMaskFormer(backbone=None, sem_seg_head=uh.to(dev).eval(), num_queries=Q)
+    UB = 2
+    X, _ = syn.synth_unit_embeddings(H * W, 64, clusters=12, sigma=0.3, seed=5)
+    emb = X.view(1, H * W, 64).transpose(1, 2).reshape(1, 64, H, W).repeat(UB, 1, 1, 1).contiguous().to(dev)
+    ufe = {"res5": emb}
+    for _ in range(2):
+        ucn.inference(ufe, (H, W))
+    t = timed(lambda: ucn.inference(ufe, (H, W)), 5)
+    with _lib.CallTimer() as ct:
+        ucn.inference(ufe, (H, W))
+        torch.cuda.synchronize()
+    ud = ct.durations()
+    attn_ms = sum(ud.get("msm_hypersphere_attn_fwd", [0.0]))
+    n_attn = len(ud.get("msm_hypersphere_attn_fwd", [])) or 1
+    S_keys = H * W
+    # cross-attention launches dominate (6 of the 12 attention launches carry 307 200 keys): FLOPs of Q^K^T and A V per launch
+    attn_flops = 2.0 * 2.0 * Q * S_keys * 256 * UB
+    cross = sorted(ud.get("msm_hypersphere_attn_fwd", [0.0]))[-6:]
+    cross_ms = sum(cross) / max(1, len(cross))
+    # bytes a cross-attention launch has to move: K and V (2 x S x 256 fp32) and the 1-byte mask (Q x S) per image
+    attn_bytes = UB * (2.0 * S_keys * 256 * 4 + Q * S_keys)
+    out["ucn_path"] = {
+        "workload": f"UCN RGB-D path: batch {UB} of 480x640 64-channel embeddings -> 3x3 mask_features convolution -> 6-layer hypersphere decoder "
+                    "over 307 200 keys per image -> post-processing; eager launches; backbone excluded",
+        "value": round(UB / t, 1), "unit": "images/sec", "ms_per_step": round(1e3 * t, 3),
+        "kernels_ms": {k: round(sum(v), 3) for k, v in sorted(ud.items(), key=lambda kv: -sum(kv[1]))[:6]},
+        "roofline": {"bound": "hbm", "kernel": "hs_attn_kernel + combine at 307 200 keys (msm_hypersphere_attn_fwd)",
+                     "achieved": round(attn_bytes / (cross_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                     "frac": round(attn_bytes / (cross_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "bytes_per_launch": attn_bytes,
+                     "avg_launch_ms": round(cross_ms, 4), "launches_per_step": 6, "traffic": None,
+                     "mfma_TFLOPs": round(attn_flops / (cross_ms * 1e-3) / 1e12, 2),
+                     "mfma_frac": round(attn_flops / (cross_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                     "note": "AI = 4*Q*256 / (2*256*4 + Q) = 47.7 FLOP/B against an fp32 ridge of ~20: MFMA-bound in fp32 by the numbers; both fractions are given"}}
+    del ucn, uh, emb
     # configs[3]: two-stage refinement over 16 frames
     model = build_model(dev)
     bb = syn.StandInBackbone().to(dev).eval()
@@ -386,6 +565,7 @@ def main():
                     help="batches in flight, one HIP graph + stream each (graphs.PipelinedInference); 1 = one graph on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the mean-shift unit and the configs[2..4] sub-results")
+    ap.add_argument("--no-bf16-leg", action="store_true", help="skip the bf16 timing of the per-GPU batch (BASELINE configs[2]) that follows the fp32 region")
     ap.add_argument("--folded-mask", type=int, default=-1, help="1/0: contract the mask features in factored form (64-channel activation; "
                     "default: the decoder's own default, on) or literally (256-channel mask_features tensor)")
     ap.add_argument("--sparse-taps", action="store_true", help="skip mask rows that feed no attention-mask tap")
@@ -414,6 +594,7 @@ def main():
         raise RuntimeError("bench.py needs an MI355X: the hot path has no CPU implementation (oracle/ is test-only)")
     torch.cuda.set_device(local_rank)           # before the process group: RCCL binds its communicator to the current device
     dev = torch.device("cuda", local_rank)
+    affinity = pin_to_gpu_numa_node(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -504,40 +685,20 @@ def main():
                 step()
             stream.synchronize()
         dur = ct.durations()
-        # the dominant kernel on its own: the ten mask-step launches of one pass (their real arguments, recorded from a pass),
-        # replayed back to back from a HIP graph between two HIP events on this stream -- kernel time without the host's
-        # launch gaps and without the event records that sit between eager launches (what rocprofv3 reports per dispatch)
-        calls, orig = [], ops.mask_logits
-
-        def recording(*a, **k):
-            calls.append((a, k))
-            return orig(*a, **k)
-
-        ops.mask_logits = recording
-        try:
-            step()
-        finally:
-            ops.mask_logits = orig
-        stream.synchronize()
-        mg = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(mg, stream=stream):
-            for a, k in calls:
-                orig(*a, **k)
-        for _ in range(5):
-            mg.replay()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 100
-        e0.record()
-        for _ in range(reps):
-            mg.replay()
-        e1.record()
-        e1.synchronize()
-        mask_graph_ms = e0.elapsed_time(e1) / (reps * len(calls))
-        mask_calls = len(calls)
+        mask_graph_ms, mask_calls = mask_step_graph_ms(step)
 
     scores = out[0]
     checksum = float(scores.double().sum().item())
     rec = gather_metrics({"images": (hi - lo) * steps, "elapsed_s": elapsed, "checksum": checksum}, dist)
+    # BASELINE configs[2] is a bf16 configuration (batch 64 over 8 GPUs): every rank also times its batch of 8 in the low-precision
+    # mode, same barriers, same max-over-ranks rule -- a `configs` entry of the line, never `value`
+    lp_rec = None
+    if args.precision == "f32" and not args.no_graph and not args.no_bf16_leg:
+        del pipe, graph
+        pipe = graph = None
+        with torch.cuda.stream(stream):
+            lp_images, lp_elapsed, lp_steps, lp_single = precision_leg(model, feats, dev, dist, args, "bf16", max(1, args.inflight))
+        lp_rec = gather_metrics({"images": lp_images, "elapsed_s": lp_elapsed, "checksum": lp_single}, dist)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -614,10 +775,20 @@ def main():
         # rank 0's own clock, one batch in flight (one graph, one stream): the latency-oriented figure
         result["one_batch_in_flight"] = {"value": round((hi - lo) * single_steps / single, 2), "unit": "images/sec",
                                          "ms_per_step": round(1e3 * single / single_steps, 4), "steps": single_steps}
+    result["config"]["rank0_cpu_affinity"] = affinity
+    if lp_rec is not None:
+        lp_t = max(r["elapsed_s"] for r in lp_rec)
+        result.setdefault("configs", {})["configs[2]"] = {
+            "workload": f"batch {world * BATCH} at 640x480 sharded over {world} GPU(s) (8 per GPU), bf16 MFMA operands / fp32 accumulation "
+                        f"(set_precision('bf16')), {max(1, args.inflight)} batches of 8 in flight per GPU; BASELINE configs[2] is this at 8 GPUs",
+            "value": round(sum(r["images"] for r in lp_rec) / lp_t, 1), "unit": "images/sec", "n_gpus": world, "steps": lp_steps,
+            "ms_per_step": round(1e3 * lp_t / lp_steps, 4), "dtype": "bf16 operands / fp32 accumulation",
+            "one_batch_in_flight": {"value": round(BATCH / lp_single, 1), "unit": "images/sec per GPU (rank 0)", "ms_per_step": round(1e3 * lp_single, 4)},
+            "per_rank_images_per_sec": [round(r["images"] / r["elapsed_s"], 1) for r in lp_rec]}
     if world == 1 and not args.no_extras:
-        del pipe, graph
+        pipe = graph = None
         result["mean_shift"] = mean_shift_unit(dev)
-        result["configs"] = extra_configs(dev, args)
+        result.setdefault("configs", {}).update(extra_configs(dev, args))
     if not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = cpu_baseline()
     print(json.dumps(result), flush=True)

@@ -443,8 +443,10 @@ def _head_outputs_fp64(pd, dec, feats):
 
 def g_head_b8():
     """BASELINE configs[1] as benchmarked: batch 8 at 640x480 through the reference pixel decoder -> 9-layer decoder (the
-    inputs are bench.py's own: synth_backbone_features(8, 480, 640, seed=10)).  Stored: class logits of all 8 images, and for
-    images 0 and 5 the packed sign bits + sampled values of the final masks and the sign bits of two intermediate predictions."""
+    inputs are bench.py's own: synth_backbone_features(8, 480, 640, seed=10)).  Stored, from the reference evaluated in
+    float32 AND in float64: class logits of all ten predictions of all 8 images; for EVERY image the packed sign bits of the
+    final masks (the float64 bits as the XOR against the float32 bits: a sparse map), the |logit| < 2e-4 map and 8192 sampled
+    values; for images 0 and 5 also the sign bits of three intermediate predictions."""
     pd, dec = build_ref_pixel_decoder(), build_ref_decoder()
     feats = syn.synth_backbone_features(8, 480, 640, seed=10)
     out = _head_outputs(pd, dec, feats)
@@ -452,15 +454,18 @@ def g_head_b8():
     pm, pm64 = out["pred_masks"], out64["pred_masks"]
     arrs = {"pred_logits": out["pred_logits"], "mask_absmax": pm.abs().amax((1, 2, 3)), "pred_logits64": out64["pred_logits"].float()}
     idx = sample_idx(pm[0].numel())
-    for b in (0, 5):
-        arrs.update({f"b{b}_sign_bits": packbits(pm[b] > 0), f"b{b}_sample_val": pm[b].flatten()[idx],
+    for b in range(8):
+        b32, b64 = packbits(pm[b] > 0), packbits(pm64[b] > 0)
+        arrs.update({f"b{b}_sign_bits": b32, f"b{b}_sample_val": pm[b].flatten()[idx],
                      f"b{b}_near_zero": packbits(pm[b].abs() < 2e-4),
-                     f"b{b}_sign_bits64": packbits(pm64[b] > 0), f"b{b}_sample_val64": pm64[b].flatten()[idx].float()})
+                     f"b{b}_sign_xor64": b32 ^ b64, f"b{b}_sample_val64": pm64[b].flatten()[idx].float()})
+    for b in (0, 5):
         for i in (0, 4, 8):
             a = out["aux_outputs"][i]
-            arrs[f"b{b}_aux{i}_sign_bits"] = packbits(a["pred_masks"][b] > 0)
+            a32, a64 = packbits(a["pred_masks"][b] > 0), packbits(out64["aux_outputs"][i]["pred_masks"][b] > 0)
+            arrs[f"b{b}_aux{i}_sign_bits"] = a32
             arrs[f"b{b}_aux{i}_near_zero"] = packbits(a["pred_masks"][b].abs() < 2e-4)
-            arrs[f"b{b}_aux{i}_sign_bits64"] = packbits(out64["aux_outputs"][i]["pred_masks"][b] > 0)
+            arrs[f"b{b}_aux{i}_sign_xor64"] = a32 ^ a64
     arrs["mask_sample_idx"] = idx
     for i, a in enumerate(out["aux_outputs"]):
         arrs[f"aux{i}_logits"] = a["pred_logits"]
