@@ -74,7 +74,7 @@ enum {
     MSM_OPT_CONVIN_NT,          /* 1, 2, 4: pixel tiles per workgroup of the input projection */
     MSM_OPT_POST_GENERIC,       /* 1: generic mask upsample instead of the 4x form */
     MSM_OPT_ENC_NO_COOP,        /* 1: encoder block without cooperative workgroups */
-    MSM_OPT_MSDA_GENERIC,       /* 1: generic head-major MSDeformAttn gather; 3: the D = 8 kernel with 8-query x 8-head workgroups */
+    MSM_OPT_MSDA_GENERIC,       /* 1: generic head-major MSDeformAttn gather; 2: the D = 8 kernel of round 2 (every lane repeats the tap geometry; fallback of the owner-record kernel); 3: that kernel with 8-query x 8-head workgroups */
     MSM_OPT_MS_CHUNK,           /* 1..8 seed blocks per hill-climb launch */
     MSM_OPT_MS_NO_PERSISTENT,   /* 1: one launch per seeding step */
     MSM_OPT_ATTN_FUSED_KV,      /* reserved (no effect) */
@@ -257,6 +257,19 @@ int msm_value_to_head_major_f32(const float* value, float* value_hm, int B, int 
 int msm_msdeform_attn_enc_hm_fwd(const float* value_hm, const int64_t* spatial_shapes,
                                  const int64_t* level_start_index, const float* proj, float* out,
                                  int B, int S, int M, int D, int L, int P, void* stream);
+
+/* The encoder form with the sampling projection computed in the kernel (round 3): instead of reading `proj`, a workgroup
+ * evaluates [sampling_offsets | attention_weights](src + pos) (OPS/modules/ms_deform_attn.py:99-101, query = src + pos
+ * msdeformattn.py:124) for its 64 queries and one head on the matrix pipe -- the 58 MB `proj` tensor per layer (B = 8)
+ * never exists.  value_hm as msm_msdeform_attn_enc_hm_fwd; src [B][S][64] the layer input, pos [S][64] its position /
+ * level code; wpack / bpack from msm_msda_pack_proj (per head: 24 offset rows, 12 logit rows, zero-padded to 48, in MFMA
+ * fragment order; (M*3*4*64*4) and (M*48) floats).  Only the pixel decoder's geometry: 8 heads x 8 channels, 3 levels x 4
+ * points.  Projected values are bitwise those msm_encoder_block_fwd writes. */
+int msm_msda_pack_proj(const float* w /* [M*L*P*3][64] = [offsets ; logits] */, const float* bias, float* wpack, float* bpack,
+                       int M, int L, int P, void* stream);
+int msm_msdeform_attn_enc_fused_fwd(const float* value_hm, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                    const float* src, const float* pos, const float* wpack, const float* bpack, float* out,
+                                    int B, int S, int M, int D, int L, int P, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused token-wise block of one MSDeformAttn encoder layer (msdeformattn.py:122-131):

@@ -729,3 +729,20 @@ def test_two_stage_pipeline_on_gpu():
         assert refined is not None and refined.shape == (1, 96, 128) and refined.is_cuda
         assert Pred.calls == 1                      # one batched second-stage call for all crops
         assert float(refined.max()) >= 1
+
+
+def test_pixel_decoder_fused_sampling_projection_is_bitwise_neutral():
+    """MSDeformAttnPixelDecoder.fused_msda (opt-in plan, fp32): every layer's gather computes its own sampling projection
+    and the token kernels stop writing the `proj` tensor -- outputs are bitwise those of the default plan."""
+    pd = make_pixel_decoder().pixel_decoder
+    feats = {k: v.to(DEV) for k, v in syn.synth_backbone_features(2, 96, 128, seed=4).items()}
+    pd.fused_msda = True
+    assert pd._use_fused_msda(torch.device(DEV))
+    a = pd.forward_features(feats)
+    pd.fused_msda = False
+    b = pd.forward_features(feats)
+    fa = a[0].tensor() if hasattr(a[0], "tensor") else a[0]
+    fb = b[0].tensor() if hasattr(b[0], "tensor") else b[0]
+    assert torch.equal(fa, fb)
+    for x, y in zip(a[2], b[2]):
+        assert torch.equal(x, y)

@@ -953,3 +953,42 @@ def test_conv3x3_c64_nchw_vs_fp64(B, H, W, Cout):
     out = ops().conv3x3_tokens_to_nchw(x.to(DEV), w3, b.to(DEV), H, W)
     closed(out, ref, rtol=2e-5, atol=2e-5)
     closed(ops().conv3x3_tokens_to_nchw(x.to(DEV), w3, None, H, W), ref - b.double()[None, :, None], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,shapes", [(2, [(15, 20), (30, 40), (60, 80)]), (1, [(4, 6), (8, 12), (16, 24)]), (3, [(7, 7), (14, 14), (28, 28)])])
+def test_msda_gather_with_fused_sampling_projection(B, shapes):
+    """msm_msdeform_attn_enc_fused_fwd computes [sampling_offsets | attention_weights](src + pos) for its own queries on the
+    matrix pipe instead of reading the tensor the token kernel wrote: same operands, same k order as msm_encoder_block_fwd, so
+    the gather output is BITWISE the unfused path's (encoder block -> proj -> owner-record gather) -- and that path's gather
+    kernels (owner records / round-2 / generic) agree with each other and with the oracle."""
+    C, DF, H8 = 64, 1024, 8
+    S = sum(h * w for h, w in shapes)
+    ss = torch.tensor(shapes, dtype=torch.int64, device=DEV)
+    starts = _start(ss.cpu()).to(DEV)
+    attn, src, pos = rnd(B, S, C, seed=1), rnd(B, S, C, seed=2), rnd(S, C, seed=3)
+    wo, w1, w2 = rnd(C, C, seed=4, scale=C ** -0.5), rnd(DF, C, seed=6, scale=C ** -0.5), rnd(C, DF, seed=8, scale=DF ** -0.5)
+    wv, wp, bp = rnd(C, C, seed=14, scale=C ** -0.5), rnd(288, C, seed=16, scale=0.5 * C ** -0.5), rnd(288, seed=17)
+    d = lambda t: t.to(DEV).contiguous()
+    stream = ops().pack_encoder_block(d(wo), d(w1), d(w2), d(wv), d(wp))
+    small = torch.cat([rnd(C, seed=5, scale=0.1), 1 + 0.1 * rnd(C, seed=10), rnd(C, seed=11, scale=0.1), rnd(DF, seed=7, scale=0.1), rnd(C, seed=9, scale=0.1),
+                       1 + 0.1 * rnd(C, seed=12), rnd(C, seed=13, scale=0.1), rnd(C, seed=15, scale=0.1), bp]).to(DEV)
+    so, vh, po = ops().encoder_block(d(attn), d(src), stream, small, DF, 288, pos=d(pos), tokens_per_image=S, value_heads=H8)
+    so2, vh2, po2 = ops().encoder_block(d(attn), d(src), stream, small, DF, 0, pos=d(pos), tokens_per_image=S, value_heads=H8)
+    assert po2 is None and torch.equal(so, so2) and torch.equal(vh, vh2)          # proj_width = 0: the same block without the projection
+    ref = ops().ms_deform_attn_encoder(vh, ss, starts, po, H8, 4)
+    wpack, bpack = ops().pack_msda_proj(d(wp), d(bp), H8, 3, 4)
+    got = ops().ms_deform_attn_encoder_fused(vh, ss, starts, so, d(pos), wpack, bpack, 4)
+    assert torch.equal(got, ref)
+    with option_ctx("MSDA_GENERIC", 2):        # round-2 gather kernel (IEEE divisions / expf in its prologue): same up to ~1e-6
+        close(ops().ms_deform_attn_encoder(vh, ss, starts, po, H8, 4), ref.cpu(), rtol=1e-5, atol=2e-6)
+    with option_ctx("MSDA_GENERIC", 1):
+        close(ops().ms_deform_attn_encoder(vh, ss, starts, po, H8, 4), ref.cpu(), rtol=1e-5, atol=1e-6)
+    # against the oracle's module arithmetic on the same projected values
+    off = po.cpu()[..., :192].view(B, S, H8, 3, 4, 2)
+    aw = torch.softmax(po.cpu()[..., 192:].view(B, S, H8, 12), -1).view(B, S, H8, 3, 4)
+    refp = O.encoder_reference_points(shapes, B)                                  # (B,S,L,2)
+    norm = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32)
+    loc = refp[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    value_tm = vh.cpu().permute(0, 2, 1, 3).contiguous()                          # (B,S,heads,8)
+    want = O.ms_deform_attn_core(value_tm, shapes, loc.contiguous(), aw)
+    close(got, want, rtol=1e-4, atol=1e-5)

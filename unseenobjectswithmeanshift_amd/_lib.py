@@ -54,6 +54,8 @@ _SIGNATURES = {
     "msm_encoder_block_stream_floats": (c_l, [c_i, c_i]),
     "msm_value_to_head_major_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_p]),
     "msm_msdeform_attn_enc_hm_fwd": (c_i, [c_f, c_p, c_p, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "msm_msda_pack_proj": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_p]),
+    "msm_msdeform_attn_enc_fused_fwd": (c_i, [c_f, c_p, c_p, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "msm_encoder_block_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_p]),
     "msm_encoder_block_split_stream_bytes": (c_l, [c_i, c_i]),
     "msm_encoder_block_split_fwd": (c_i, [c_f, c_f, c_p, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_p]),

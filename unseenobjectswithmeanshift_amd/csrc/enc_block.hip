@@ -539,12 +539,15 @@ extern "C" int msm_encoder_block_fwd(const float* attn, const float* src, const 
                                      const float* pos, float* src_out, float* value_out, float* proj_out, int M, int S,
                                      int d_ffn, int proj_width, int value_heads, float eps, void* stream) {
     MSM_REQUIRE(attn && src && wstream && small && src_out, "msm_encoder_block_fwd: null pointer");
-    MSM_REQUIRE((value_out == nullptr) == (proj_out == nullptr), "msm_encoder_block_fwd: value_out and proj_out go together");
+    // proj_width == 0 with a value_out: only the next layer's value projection (its sampling projection is computed by
+    // msm_msdeform_attn_enc_fused_fwd); otherwise value_out and proj_out go together
+    MSM_REQUIRE(proj_width == 0 ? (proj_out == nullptr) : ((value_out == nullptr) == (proj_out == nullptr)),
+                "msm_encoder_block_fwd: value_out and proj_out go together (proj_out must be null when proj_width == 0)");
     MSM_REQUIRE(!value_out || pos, "msm_encoder_block_fwd: pos required when the next layer's projections are produced");
     MSM_REQUIRE(M > 0 && S > 0 && d_ffn > 0 && d_ffn % 64 == 0, "msm_encoder_block_fwd: bad sizes (d_ffn %% 64 == 0)");
     MSM_REQUIRE(value_heads == 0 || (value_heads > 0 && EC % value_heads == 0 && (EC / value_heads) % 4 == 0 && M % S == 0),
                 "msm_encoder_block_fwd: value_heads=%d needs 64/heads to be a multiple of 4 and M a multiple of S", value_heads);
-    MSM_REQUIRE(proj_width % 16 == 0 && proj_width >= 64, "msm_encoder_block_fwd: proj_width=%d must be a multiple of 16, >= 64",
+    MSM_REQUIRE(proj_width == 0 || (proj_width % 16 == 0 && proj_width >= 64), "msm_encoder_block_fwd: proj_width=%d must be 0 or a multiple of 16, >= 64",
                 proj_width);
     MSM_REQUIRE((int64_t)M * max(proj_width, EC) * 4 < (int64_t)1 << 31, "msm_encoder_block_fwd: M=%d tokens exceed the 2 GiB the output descriptors address", M);
     MSM_REQUIRE(((((uintptr_t)attn) | ((uintptr_t)src) | ((uintptr_t)wstream) | ((uintptr_t)small) | ((uintptr_t)src_out) |
@@ -587,12 +590,12 @@ extern "C" int msm_encoder_prologue_fwd(const float* raw, const double* stats, c
                                         int n_levels, int groups, float gn_eps, const float* wstream, const float* small,
                                         const float* pos, float* src_out, float* value_out, float* proj_out, int B, int S,
                                         int proj_width, int value_heads, void* stream) {
-    MSM_REQUIRE(raw && stats && gn_params && level_starts && wstream && small && pos && src_out && value_out && proj_out,
+    MSM_REQUIRE(raw && stats && gn_params && level_starts && wstream && small && pos && src_out && value_out && (proj_out || proj_width == 0),
                 "msm_encoder_prologue_fwd: null pointer");
     MSM_REQUIRE(n_levels >= 1 && n_levels <= PRO_MAXL, "msm_encoder_prologue_fwd: n_levels=%d outside [1, %d]", n_levels, PRO_MAXL);
     MSM_REQUIRE(B > 0 && S >= 86, "msm_encoder_prologue_fwd: need B > 0 and at least 86 tokens per image (S=%d)", S);
     MSM_REQUIRE(groups > 0 && EC % groups == 0, "msm_encoder_prologue_fwd: groups=%d must divide 64", groups);
-    MSM_REQUIRE(proj_width % 16 == 0 && proj_width >= 16, "msm_encoder_prologue_fwd: proj_width=%d must be a multiple of 16", proj_width);
+    MSM_REQUIRE(proj_width % 16 == 0 && proj_width >= 0, "msm_encoder_prologue_fwd: proj_width=%d must be a multiple of 16 (0: value projection only)", proj_width);
     MSM_REQUIRE(value_heads == 0 || (value_heads > 0 && EC % value_heads == 0 && (EC / value_heads) % 4 == 0),
                 "msm_encoder_prologue_fwd: value_heads=%d needs 64/heads to be a multiple of 4", value_heads);
     MSM_REQUIRE(((((uintptr_t)raw) | ((uintptr_t)wstream) | ((uintptr_t)small) | ((uintptr_t)src_out) | ((uintptr_t)value_out) |

@@ -445,6 +445,386 @@ __global__ __launch_bounds__(256) void msda_enc_hm8_kernel(const float* __restri
     if (live && cx == 0) *reinterpret_cast<float4*>(out + (((int64_t)b * S + qi) * M + m) * D + d4 * 4) = acc;
 }
 
+// ---- cheap arithmetic for the gather prologues (round 3) ------------------------------------------------------------------
+// The rec / fused kernels are VALU-issue bound (72 % VALU-busy at 4.1 cycles per instruction, rocprofv3 SQ counters), and a
+// third of their instructions was the prologue's IEEE sequences: nine divisions (~11 instructions each), three expf (~12),
+// an integer division (~25).  Divisors here are level widths / heights -- small positive integers, exactly representable,
+// their reciprocals (v_rcp_f32 + one Newton step, once per wave and level) are within 1 ulp -- so
+//     x / W  ->  q = x * rW;  q += fma(-q, W, x) * rW        (one Newton step on the quotient: within 1 ulp of the IEEE result)
+//     exp(x) ->  v_exp_f32(x * log2 e)                      (x <= 0: relative error ~1e-6 from the argument's rounding)
+//     n / W  ->  (int)((n + 0.5f) * rW)                      (exact for n < 2^20: the product is >= 0.5 / W away from an integer)
+// The sampled locations move by ~1e-7 relative, far below the fp32 tolerances of SURVEY 8c; msda_enc_hm8_kernel (option
+// MSDA_GENERIC = 2) keeps the IEEE forms.
+struct LevelRcp {
+    float rw[4], rh[4];
+};
+__device__ __forceinline__ float div_by(float x, float W, float rW) {
+    const float q = x * rW;
+    return fmaf(fmaf(-q, W, x), rW, q);
+}
+__device__ __forceinline__ float exp_neg(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float rcp_nr(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.0f), r, r);
+}
+
+// ---- owner records (round 3) ------------------------------------------------------------------------------------------------
+// What bounds msda_enc_hm8_kernel is VALU issue (723 VALU instructions per wave against 24 loads): after the quad has
+// exchanged (x, y, weight) of a point, every one of its four lanes repeats the point's tap geometry -- floor, fractions,
+// validity tests, clamps, the four bilinear weights, the address arithmetic: ~40 instructions per point and lane, of which
+// only the column choice (cx) differs between the lanes.  Here the lane that OWNS a point (lane g of the quad: points g,
+// g + 4, g + 8, as before) does that arithmetic once, for both columns, and leaves two 16-byte records per point in LDS:
+//     rec[cx] = { byte offset of the top tap, byte offset of the bottom tap, weight of the top tap, weight of the bottom tap }
+// (offsets inside the head's value plane, clamped; invalid taps carry weight 0).  The gather loop of every lane is then, per
+// point: one ds_read_b128, two adds (its 16-byte channel half), two buffer loads, eight FMAs.  Products and summation order
+// are those of msda_enc_hm8_kernel -- the results are bitwise identical (asserted by the tests).  Compile-time geometry
+// (LC levels x PC points, LC * PC = 12 or 16 -> 3 or 4 slots per lane), query-major workgroups (64 consecutive queries of
+// one head).  LDS: 4 waves x 16 quads x (LP records x 2 + padding) x 16 B; a quad's block is 16 B longer than its records
+// so that neither the owners' ds_write_b128 nor the readers' ds_read_b128 meet a bank conflict.
+template <int LC, int PC>
+__global__ __launch_bounds__(256) void msda_enc_hm8_rec_kernel(const float* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                               const int64_t* __restrict__ lstart, const float* __restrict__ proj,
+                                                               float* __restrict__ out, int B, int S, int M) {
+    constexpr int D = 8, LP = LC * PC, SLOTS = LP / 4;
+    static_assert(PC == 4 && LP % 4 == 0 && LP <= 16, "a lane owns one point of every level: PC == 4");
+    constexpr int QSTRIDE = LP * 2 + 1;                      // float4 per quad: LP x 2 records + one of padding
+    __shared__ float4 recs[4 * 16 * QSTRIDE];
+    const int b = blockIdx.x % B;
+    const int blk = blockIdx.x / B;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = tid & 3, cx = g >> 1, d4 = g & 1;
+    const int m = blk % M;                                   // uniform: the head of this workgroup
+    const int q_raw = (blk / M) * 64 + (tid >> 2);
+    const bool live = q_raw < S;                             // whole quads live or dead together
+    const int qi = live ? q_raw : 0;
+
+    int Hs[LC], Ws[LC], st[LC];                              // level geometry: wave-uniform, stays in SGPRs
+#pragma unroll
+    for (int l = 0; l < LC; ++l) {
+        Hs[l] = (int)shapes[2 * l];
+        Ws[l] = (int)shapes[2 * l + 1];
+        st[l] = (int)lstart[l];
+    }
+    LevelRcp lr;
+#pragma unroll
+    for (int l = 0; l < LC; ++l) {
+        lr.rw[l] = rcp_nr((float)Ws[l]);
+        lr.rh[l] = rcp_nr((float)Hs[l]);
+    }
+    const float* pr = proj + ((int64_t)b * S + qi) * (M * LP * 3);
+    const float* offp = pr + (int64_t)m * LP * 2;
+    const float* lgp = pr + (int64_t)M * LP * 2 + (int64_t)m * LP;
+    // reference point = centre of pixel qi in its own level, normalised (msdeformattn.py:141-153)
+    int qW = Ws[0], qH = Hs[0], qs = 0;
+    float qrw = lr.rw[0], qrh = lr.rh[0];
+#pragma unroll
+    for (int l = 1; l < LC; ++l)
+        if (qi >= st[l]) { qW = Ws[l]; qH = Hs[l]; qs = st[l]; qrw = lr.rw[l]; qrh = lr.rh[l]; }
+    const int local = qi - qs;
+    const int ry = (int)(((float)local + 0.5f) * qrw), rx = local - ry * qW;
+    const float ref_x = div_by((float)rx + 0.5f, (float)qW, qrw);
+    const float ref_y = div_by((float)ry + 0.5f, (float)qH, qrh);
+
+    // ---- this lane's points: i = slot * 4 + g, level = slot ----
+    float px[SLOTS], py[SLOTS], pw[SLOTS];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int slot = 0; slot < SLOTS; ++slot) {
+        const int i = slot * 4 + g;
+        const float2 off = *reinterpret_cast<const float2*>(offp + 2 * i);
+        const float lg = lgp[i];
+        const float lx = ref_x + div_by(off.x, (float)Ws[slot], lr.rw[slot]);   // ms_deform_attn.py:107-109
+        const float ly = ref_y + div_by(off.y, (float)Hs[slot], lr.rh[slot]);
+        px[slot] = lx * (float)Ws[slot] - 0.5f;                              // w_im, cuh:290-291
+        py[slot] = ly * (float)Hs[slot] - 0.5f;                              // h_im
+        pw[slot] = lg;
+        mx = fmaxf(mx, lg);
+    }
+    mx = quad_max(mx);                                                       // softmax over the L*P logits (:103)
+    float den = 0.f;
+#pragma unroll
+    for (int slot = 0; slot < SLOTS; ++slot) {
+        pw[slot] = exp_neg(pw[slot] - mx);
+        den += pw[slot];
+    }
+    const float rden = rcp_nr(quad_sum(den));
+
+    // ---- the owner's tap geometry -> LDS records (same arithmetic as msda_enc_hm8_kernel, per column) ----
+    float4* qrec = recs + (wave * 16 + (lane >> 2)) * QSTRIDE;
+#pragma unroll
+    for (int slot = 0; slot < SLOTS; ++slot) {
+        const int W = Ws[slot], H = Hs[slot], s0 = st[slot];
+        const float w_im = px[slot], h_im = py[slot];
+        const float wgt = pw[slot] * rden;
+        const float hf = floorf(h_im), wf = floorf(w_im);
+        const int h_low = (int)hf, w_low = (int)wf;
+        const float lh = h_im - hf, lw = w_im - wf;
+        const float wx0 = (unsigned)w_low < (unsigned)W ? (1.f - lw) * wgt : 0.f;
+        const float wx1 = (unsigned)(w_low + 1) < (unsigned)W ? lw * wgt : 0.f;
+        const bool okt = (unsigned)h_low < (unsigned)H, okb = (unsigned)(h_low + 1) < (unsigned)H;
+        const unsigned rowt = __umul24((unsigned)clamp0(h_low, H - 1), (unsigned)(W * D * 4));
+        const unsigned rowb = __umul24((unsigned)clamp0(h_low + 1, H - 1), (unsigned)(W * D * 4));
+        const unsigned c0 = (unsigned)(s0 + clamp0(w_low, W - 1)) * (unsigned)(D * 4);
+        const unsigned c1 = (unsigned)(s0 + clamp0(w_low + 1, W - 1)) * (unsigned)(D * 4);
+        const int i = slot * 4 + g;
+        qrec[i * 2 + 0] = make_float4(__uint_as_float(c0 + rowt), __uint_as_float(c0 + rowb), okt ? (1.f - lh) * wx0 : 0.f, okb ? lh * wx0 : 0.f);
+        qrec[i * 2 + 1] = make_float4(__uint_as_float(c1 + rowt), __uint_as_float(c1 + rowb), okt ? (1.f - lh) * wx1 : 0.f, okb ? lh * wx1 : 0.f);
+    }
+    // a quad's records are written and read by the same wave: the LDS executes a wave's operations in order, so no barrier --
+    // only the compiler has to keep the order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- gather: the head's value plane behind one SGPR descriptor (S x 32 B), records from LDS ----
+    const uint64_t vbase = (uint64_t)(value + ((int64_t)b * M + m) * S * D);
+    const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(vbase >> 32)) << 32) | (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)vbase)),
+        0, S * D * 4, 0x00020000);
+    const unsigned lane_off = (unsigned)d4 * 16u;
+    const float4* myrec = qrec + cx;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int GP = 4;                                    // loads of GP points in flight together (as msda_enc_hm8_kernel)
+#pragma unroll
+    for (int i0 = 0; i0 < LP; i0 += GP) {
+        float4 vt[GP], vbm[GP], r[GP];
+#pragma unroll
+        for (int j = 0; j < GP; ++j) {
+            r[j] = myrec[(i0 + j) * 2];
+            vt[j] = ldv4(vrsrc, __float_as_uint(r[j].x) + lane_off);
+            vbm[j] = ldv4(vrsrc, __float_as_uint(r[j].y) + lane_off);
+        }
+#pragma unroll
+        for (int j = 0; j < GP; ++j) {
+            acc.x += r[j].z * vt[j].x + r[j].w * vbm[j].x;
+            acc.y += r[j].z * vt[j].y + r[j].w * vbm[j].y;
+            acc.z += r[j].z * vt[j].z + r[j].w * vbm[j].z;
+            acc.w += r[j].z * vt[j].w + r[j].w * vbm[j].w;
+        }
+    }
+    // left + right column: lanes g and g^2
+    acc.x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc.x), 0x4E, 0xf, 0xf, true));
+    acc.y += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc.y), 0x4E, 0xf, 0xf, true));
+    acc.z += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc.z), 0x4E, 0xf, 0xf, true));
+    acc.w += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc.w), 0x4E, 0xf, 0xf, true));
+    if (live && cx == 0) *reinterpret_cast<float4*>(out + (((int64_t)b * S + qi) * M + m) * D + d4 * 4) = acc;
+}
+
+// ---- sampling projection fused in (round 3) -------------------------------------------------------------------------------
+// The offsets / attention-logit projection of a layer, [sampling_offsets | attention_weights](src + pos)
+// (ops/modules/ms_deform_attn.py:99-101, query = src + pos msdeformattn.py:124), used to be written by the previous layer's
+// token kernel and read back here: 58 MB each way per layer at B = 8 (2.3x the kernel's other traffic), with an HBM round
+// trip at the head of every wave's dependency chain.  Here the workgroup computes it for its own 64 queries and ONE head:
+// a wave owns 16 tokens, x = src + pos in MFMA layout L (lane (token lj, quarter lq): features fb*16 + lq*4 + c, the layout
+// of enc_block_kernel), the head's 36 weight rows -- 24 offset rows, 12 logit rows, zero-padded to three 16-row blocks -- are
+// the A operand (pre-packed per head in fragment order: msm_msda_pack_proj), 48 v_mfma_f32_16x16x4_f32 per wave.  Same
+// operands and the same k order as enc_block_kernel's rowblock_mma, so every projected value is bitwise the one that kernel
+// wrote.  The result goes through the wave's LDS region ([token][52 floats]; the records of the owner scheme overwrite it
+// once the owners have read their three points) and the rest is msda_enc_hm8_rec_kernel.
+template <int LC, int PC>
+__global__ __launch_bounds__(256) void msda_enc_hm8_fused_kernel(const float* __restrict__ value, const int64_t* __restrict__ shapes,
+                                                                 const int64_t* __restrict__ lstart, const float* __restrict__ src,
+                                                                 const float* __restrict__ pos, const float4* __restrict__ wpack,
+                                                                 const float* __restrict__ bpack, float* __restrict__ out, int B,
+                                                                 int S, int M) {
+    constexpr int D = 8, LP = LC * PC, SLOTS = LP / 4, EC = 64;
+    static_assert(PC == 4 && LP == 12, "three 16-row blocks hold the 36 projection rows of a head");
+    constexpr int QSTRIDE = LP * 2 + 1;                      // float4 per quad: LP x 2 records + one of padding
+    constexpr int TSTRIDE = 52;                              // floats per token row of the projection tile (48 + 4: conflict-free b128 stores)
+    constexpr int WF4 = 3 * 4 * 64;                          // float4 of a head's weight fragments (12 KiB)
+    // One LDS region, two uses: phase A = [the head's weight fragments | four waves' projection tiles], afterwards = the four
+    // waves' owner records.  The sizes agree to the byte: 768 + 4 * 16 * 13 float4 = 4 * 16 * 25 float4 = 25 600 B.
+    static_assert(WF4 + 4 * 16 * TSTRIDE / 4 == 4 * 16 * QSTRIDE, "phase-A layout fills the record region exactly");
+    __shared__ float4 recs[4 * 16 * QSTRIDE];
+    const int b = blockIdx.x % B;
+    const int blk = blockIdx.x / B;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = blk % M;                                   // uniform: the head of this workgroup
+    const int q0 = (blk / M) * 64 + wave * 16;               // first query of this wave
+
+    // the wave's 16 tokens first (x = src + pos, layout L): their latency hides behind the weight copy
+    const int lj = lane & 15, lq = lane >> 4;
+    float x[4][4];
+    {
+        const int tk = min(q0 + lj, S - 1);
+        float4 a[4], p[4];
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) {
+            a[fb] = *reinterpret_cast<const float4*>(src + ((int64_t)b * S + tk) * EC + fb * 16 + lq * 4);
+            p[fb] = *reinterpret_cast<const float4*>(pos + (int64_t)tk * EC + fb * 16 + lq * 4);
+        }
+        // the head's weight fragments: ONE copy per workgroup (as four per-wave reads they were 12 KiB per wave through L1)
+#pragma unroll
+        for (int i = 0; i < WF4 / 256; ++i) recs[i * 256 + tid] = wpack[m * WF4 + i * 256 + tid];
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) {
+            x[fb][0] = a[fb].x + p[fb].x; x[fb][1] = a[fb].y + p[fb].y; x[fb][2] = a[fb].z + p[fb].z; x[fb][3] = a[fb].w + p[fb].w;
+        }
+    }
+    int Hs[LC], Ws[LC], st[LC];                              // level geometry: wave-uniform, stays in SGPRs
+#pragma unroll
+    for (int l = 0; l < LC; ++l) {
+        Hs[l] = (int)shapes[2 * l];
+        Ws[l] = (int)shapes[2 * l + 1];
+        st[l] = (int)lstart[l];
+    }
+    LevelRcp lr;
+#pragma unroll
+    for (int l = 0; l < LC; ++l) {
+        lr.rw[l] = rcp_nr((float)Ws[l]);
+        lr.rh[l] = rcp_nr((float)Hs[l]);
+    }
+    __syncthreads();
+    // ---- phase A: the head's projection of the wave's 16 tokens ----
+    float* tile = reinterpret_cast<float*>(recs + WF4) + wave * 16 * TSTRIDE;
+    {
+        float* trow = tile + lj * TSTRIDE + lq * 4;
+        f32x4 d[3];
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) {
+            const float4 bb = *reinterpret_cast<const float4*>(bpack + m * 48 + rb * 16 + lq * 4);
+            d[rb] = f32x4{bb.x, bb.y, bb.z, bb.w};
+        }
+        // per row block one accumulator chain from the bias, k order (c, fb): enc_block_kernel's rowblock_mma; the three
+        // chains are independent and interleave
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+                for (int rb = 0; rb < 3; ++rb) {
+                    const float4 w = recs[(rb * 4 + fb) * 64 + lane];
+                    d[rb] = mfma16(c == 0 ? w.x : (c == 1 ? w.y : (c == 2 ? w.z : w.w)), x[fb][c], d[rb]);
+                }
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb)
+            *reinterpret_cast<float4*>(trow + rb * 16) = make_float4(d[rb][0], d[rb][1], d[rb][2], d[rb][3]);   // features rb*16 + lq*4 .. + 3 of token lj
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- phase B: gather mapping -- quad = query, g = (column cx, channel half d4) ----
+    const int g = tid & 3, cx = g >> 1, d4 = g & 1;
+    const int quad = lane >> 2;
+    const int q_raw = q0 + quad;
+    const bool live = q_raw < S;                             // whole quads live or dead together
+    const int qi = live ? q_raw : S - 1;                     // (the projection tile clamps the same way)
+    // reference point = centre of pixel qi in its own level, normalised (msdeformattn.py:141-153)
+    int qW = Ws[0], qH = Hs[0], qs = 0;
+    float qrw = lr.rw[0], qrh = lr.rh[0];
+#pragma unroll
+    for (int l = 1; l < LC; ++l)
+        if (qi >= st[l]) { qW = Ws[l]; qH = Hs[l]; qs = st[l]; qrw = lr.rw[l]; qrh = lr.rh[l]; }
+    const int local = qi - qs;
+    const int ry = (int)(((float)local + 0.5f) * qrw), rx = local - ry * qW;
+    const float ref_x = div_by((float)rx + 0.5f, (float)qW, qrw);
+    const float ref_y = div_by((float)ry + 0.5f, (float)qH, qrh);
+
+    // ---- this lane's points: i = slot * 4 + g, level = slot; offsets at features 2 i, 2 i + 1, logit at 24 + i ----
+    const float* tq = tile + quad * TSTRIDE;
+    float px[SLOTS], py[SLOTS], pw[SLOTS];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int slot = 0; slot < SLOTS; ++slot) {
+        const int i = slot * 4 + g;
+        const float2 off = *reinterpret_cast<const float2*>(tq + 2 * i);
+        const float lg = tq[2 * LP + i];
+        const float lx = ref_x + div_by(off.x, (float)Ws[slot], lr.rw[slot]);   // ms_deform_attn.py:107-109
+        const float ly = ref_y + div_by(off.y, (float)Hs[slot], lr.rh[slot]);
+        px[slot] = lx * (float)Ws[slot] - 0.5f;                              // w_im, cuh:290-291
+        py[slot] = ly * (float)Hs[slot] - 0.5f;                              // h_im
+        pw[slot] = lg;
+        mx = fmaxf(mx, lg);
+    }
+    mx = quad_max(mx);                                                       // softmax over the L*P logits (:103)
+    float den = 0.f;
+#pragma unroll
+    for (int slot = 0; slot < SLOTS; ++slot) {
+        pw[slot] = exp_neg(pw[slot] - mx);
+        den += pw[slot];
+    }
+    const float rden = rcp_nr(quad_sum(den));
+    // every wave has read the weights and its projection tile: the records may overwrite the region
+    __syncthreads();
+
+    float4* qrec = recs + (wave * 16 + quad) * QSTRIDE;
+#pragma unroll
+    for (int slot = 0; slot < SLOTS; ++slot) {
+        const int W = Ws[slot], H = Hs[slot], s0 = st[slot];
+        const float w_im = px[slot], h_im = py[slot];
+        const float wgt = pw[slot] * rden;
+        const float hf = floorf(h_im), wf = floorf(w_im);
+        const int h_low = (int)hf, w_low = (int)wf;
+        const float lh = h_im - hf, lw = w_im - wf;
+        const float wx0 = (unsigned)w_low < (unsigned)W ? (1.f - lw) * wgt : 0.f;
+        const float wx1 = (unsigned)(w_low + 1) < (unsigned)W ? lw * wgt : 0.f;
+        const bool okt = (unsigned)h_low < (unsigned)H, okb = (unsigned)(h_low + 1) < (unsigned)H;
+        const unsigned rowt = __umul24((unsigned)clamp0(h_low, H - 1), (unsigned)(W * D * 4));
+        const unsigned rowb = __umul24((unsigned)clamp0(h_low + 1, H - 1), (unsigned)(W * D * 4));
+        const unsigned c0 = (unsigned)(s0 + clamp0(w_low, W - 1)) * (unsigned)(D * 4);
+        const unsigned c1 = (unsigned)(s0 + clamp0(w_low + 1, W - 1)) * (unsigned)(D * 4);
+        const int i = slot * 4 + g;
+        qrec[i * 2 + 0] = make_float4(__uint_as_float(c0 + rowt), __uint_as_float(c0 + rowb), okt ? (1.f - lh) * wx0 : 0.f, okb ? lh * wx0 : 0.f);
+        qrec[i * 2 + 1] = make_float4(__uint_as_float(c1 + rowt), __uint_as_float(c1 + rowb), okt ? (1.f - lh) * wx1 : 0.f, okb ? lh * wx1 : 0.f);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const uint64_t vbase = (uint64_t)(value + ((int64_t)b * M + m) * S * D);
+    const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(vbase >> 32)) << 32) | (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)vbase)),
+        0, S * D * 4, 0x00020000);
+    const unsigned lane_off = (unsigned)d4 * 16u;
+    const float4* myrec = qrec + cx;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int GP = 4;
+#pragma unroll
+    for (int i0 = 0; i0 < LP; i0 += GP) {
+        float4 vt[GP], vbm[GP], r[GP];
+#pragma unroll
+        for (int j = 0; j < GP; ++j) {
+            r[j] = myrec[(i0 + j) * 2];
+            vt[j] = ldv4(vrsrc, __float_as_uint(r[j].x) + lane_off);
+            vbm[j] = ldv4(vrsrc, __float_as_uint(r[j].y) + lane_off);
+        }
+#pragma unroll
+        for (int j = 0; j < GP; ++j) {
+            acc.x += r[j].z * vt[j].x + r[j].w * vbm[j].x;
+            acc.y += r[j].z * vt[j].y + r[j].w * vbm[j].y;
+            acc.z += r[j].z * vt[j].z + r[j].w * vbm[j].z;
+            acc.w += r[j].z * vt[j].w + r[j].w * vbm[j].w;
+        }
+    }
+    acc.x += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc.x), 0x4E, 0xf, 0xf, true));
+    acc.y += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc.y), 0x4E, 0xf, 0xf, true));
+    acc.z += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc.z), 0x4E, 0xf, 0xf, true));
+    acc.w += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc.w), 0x4E, 0xf, 0xf, true));
+    if (live && cx == 0) *reinterpret_cast<float4*>(out + (((int64_t)b * S + qi) * M + m) * D + d4 * 4) = acc;
+}
+
+// wpack[((m*3 + rb)*4 + fb)*64 + lq*16 + lj] = Wm[rb*16 + lj][fb*16 + lq*4 .. +3], bpack[m*48 + r] = bias of row r, where the 48
+// rows of head m are its 2*LP offset rows ((L, P, 2) order), its LP logit rows and zeros (ms_deform_attn.py:73-74 layouts)
+__global__ __launch_bounds__(256) void msda_pack_proj_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                             float4* __restrict__ wpack, float* __restrict__ bpack, int M, int LP) {
+    const int total = M * 3 * 4 * 64;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int lane = i & 63, fb = (i >> 6) & 3, rb = (i >> 8) % 3, m = i / 768;
+        const int lj = lane & 15, lq = lane >> 4;
+        const int r = rb * 16 + lj;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        int row = -1;
+        if (r < 2 * LP) row = m * 2 * LP + r;
+        else if (r < 3 * LP) row = M * 2 * LP + m * LP + (r - 2 * LP);
+        if (row >= 0) v = *reinterpret_cast<const float4*>(w + (int64_t)row * 64 + fb * 16 + lq * 4);
+        wpack[i] = v;
+        if (fb == 0 && lq == 0) bpack[m * 48 + r] = row >= 0 ? bias[row] : 0.f;
+    }
+}
+
 // value [B][S][M][D] (token-major, what a value_proj GEMM writes) -> [B][M][S][D] (head-major)
 __global__ __launch_bounds__(256) void value_to_hm_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t total4,
                                                           int S, int M, int D4) {
@@ -665,6 +1045,10 @@ extern "C" int msm_msdeform_attn_enc_hm_fwd(const float* value_hm, const int64_t
     if (D == 8 && L * P <= 16 && (int64_t)M * S * D * 4 < ((int64_t)1 << 31) && opt(MSM_OPT_MSDA_GENERIC) == 3)
         hipLaunchKernelGGL((msda_enc_hm8_kernel<false, 0, 0>), grid, block, 0, (hipStream_t)stream, value_hm, spatial_shapes,
                            level_start_index, proj, out, B, S, M, L, P);
+    else if (D == 8 && L == 3 && P == 4 && (int64_t)S * D * 4 < ((int64_t)1 << 31) && opt(MSM_OPT_MSDA_GENERIC) == MSM_OPT_AUTO)
+        // default (round 3): tap geometry once per point by its owner lane, records through LDS
+        hipLaunchKernelGGL((msda_enc_hm8_rec_kernel<3, 4>), dim3((unsigned)(cdiv(S, 64) * M * B)), block, 0, (hipStream_t)stream, value_hm,
+                           spatial_shapes, level_start_index, proj, out, B, S, M);
     else if (D == 8 && L == 3 && P == 4 && (int64_t)M * S * D * 4 < ((int64_t)1 << 31) && opt(MSM_OPT_MSDA_GENERIC) != 1)
         hipLaunchKernelGGL((msda_enc_hm8_kernel<true, 3, 4>), dim3((unsigned)(cdiv(S, 64) * M * B)), block, 0, (hipStream_t)stream, value_hm,
                            spatial_shapes, level_start_index, proj, out, B, S, M, L, P);
@@ -678,6 +1062,34 @@ extern "C" int msm_msdeform_attn_enc_hm_fwd(const float* value_hm, const int64_t
         hipLaunchKernelGGL((msda_enc_hm_kernel<1>), grid, block, 0, (hipStream_t)stream, value_hm, spatial_shapes,
                            level_start_index, proj, out, B, S, M, D, L, P);
     MSM_CHECK_LAUNCH("msm_msdeform_attn_enc_hm_fwd");
+    return MSM_OK;
+}
+
+extern "C" int msm_msda_pack_proj(const float* w, const float* bias, float* wpack, float* bpack, int M, int L, int P, void* stream) {
+    MSM_REQUIRE(w && bias && wpack && bpack, "msm_msda_pack_proj: null pointer");
+    MSM_REQUIRE(M > 0 && L * P == 12, "msm_msda_pack_proj: L*P=%d, the fused gather takes 12 sampling points per head", L * P);
+    MSM_REQUIRE(((((uintptr_t)w) | ((uintptr_t)wpack)) & 15) == 0, "msm_msda_pack_proj: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(msda_pack_proj_kernel, dim3((unsigned)cdiv(M * 768, 256)), dim3(256), 0, (hipStream_t)stream, w, bias,
+                       reinterpret_cast<float4*>(wpack), bpack, M, L * P);
+    MSM_CHECK_LAUNCH("msm_msda_pack_proj");
+    return MSM_OK;
+}
+
+extern "C" int msm_msdeform_attn_enc_fused_fwd(const float* value_hm, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                               const float* src, const float* pos, const float* wpack, const float* bpack, float* out,
+                                               int B, int S, int M, int D, int L, int P, void* stream) {
+    MSM_REQUIRE(value_hm && spatial_shapes && level_start_index && src && pos && wpack && bpack && out,
+                "msm_msdeform_attn_enc_fused_fwd: null pointer");
+    MSM_REQUIRE(B > 0 && S > 0 && M > 0, "msm_msdeform_attn_enc_fused_fwd: bad sizes");
+    MSM_REQUIRE(D == 8 && M * D == 64 && L == 3 && P == 4,
+                "msm_msdeform_attn_enc_fused_fwd: only the pixel decoder's geometry (64 channels = 8 heads x 8, 3 levels x 4 points); got M=%d D=%d L=%d P=%d",
+                M, D, L, P);
+    MSM_REQUIRE((int64_t)S * D * 4 < ((int64_t)1 << 31), "msm_msdeform_attn_enc_fused_fwd: S too large");
+    MSM_REQUIRE(((((uintptr_t)value_hm) | ((uintptr_t)src) | ((uintptr_t)pos) | ((uintptr_t)wpack) | ((uintptr_t)bpack) | ((uintptr_t)out)) & 15) == 0,
+                "msm_msdeform_attn_enc_fused_fwd: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL((msda_enc_hm8_fused_kernel<3, 4>), dim3((unsigned)(cdiv(S, 64) * M * B)), dim3(256), 0, (hipStream_t)stream, value_hm,
+                       spatial_shapes, level_start_index, src, pos, reinterpret_cast<const float4*>(wpack), bpack, out, B, S, M);
+    MSM_CHECK_LAUNCH("msm_msdeform_attn_enc_fused_fwd");
     return MSM_OK;
 }
 

@@ -787,6 +787,13 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
         self.precision = "f32"
         self.fused_encoder = True      # False: one GEMM / LayerNorm launch per op (same results up to rounding)
         self.fused_front = True        # False: input projections and layer 0's projections as separate GEMM / GroupNorm launches
+        # True: a layer's gather computes its own [sampling_offsets | attention_weights] projection on the matrix pipe
+        # (ops.ms_deform_attn_encoder_fused) instead of reading the `proj` tensor the previous token kernel wrote (58 MB per
+        # layer at B = 8); bitwise the same values.  fp32 plan only (the low-precision / split token kernels keep writing proj).
+        # Measured on MI355X at B = 8 (round 3): the token kernel drops from 152 to 123 us per layer, the gather rises from
+        # 32 to 59 us (48 MFMAs per wave in front of a latency-bound gather do not overlap with it): neutral in time, 116 MB
+        # less HBM traffic per layer -- off by default, DESIGN.md section 4
+        self.fused_msda = False
 
     def _w3(self):
         """layer_1's 3x3 weight in the implicit-GEMM order (Cout, 3*3*Cin), cached per parameter version."""
@@ -795,6 +802,14 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
         if getattr(self, "_w3_cache", None) is None or self._w3_cache[0] != key:
             self._w3_cache = (key, p.permute(0, 2, 3, 1).reshape(p.shape[0], -1).contiguous())
         return self._w3_cache[1]
+
+    def _use_fused_msda(self, device):
+        """The gather computes its own sampling projection: fp32 plan, the shipped geometry (64 channels, 8 heads, 3 levels x 4
+        points), 16-byte-aligned token buffers."""
+        if not (self.fused_msda and self.fused_encoder and self.precision == "f32" and self.conv_dim == 64):
+            return False
+        self._packed_encoder(device)
+        return self._packed[3] is not None and len(self.transformer_in_features) == 3
 
     def _packed_encoder(self, device):
         """Weight streams of the fused encoder kernel, rebuilt only when a parameter changes."""
@@ -822,7 +837,12 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
                 stream = pack(a.output_proj.weight, layer.linear1.weight, layer.linear2.weight, wv, wp)
                 pw = a.sampling_offsets.out_features + a.attention_weights.out_features
                 out.append((stream, torch.cat([t.reshape(-1) for t in smalls]).contiguous(), layer.linear1.out_features, pw))
-            self._packed = (key, out, layers[0].self_attn._proj_weights())
+            msda = None
+            if all(ly.self_attn.d_model == 64 and ly.self_attn.n_heads == 8 and ly.self_attn.n_levels * ly.self_attn.n_points == 12
+                   and ly.self_attn.n_points == 4 for ly in layers):
+                msda = [ops.pack_msda_proj(*ly.self_attn._proj_weights(), ly.self_attn.n_heads, ly.self_attn.n_levels, ly.self_attn.n_points)
+                        for ly in layers]
+            self._packed = (key, out, layers[0].self_attn._proj_weights(), msda)
         return self._packed[1]
 
     @classmethod
@@ -893,8 +913,9 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
             bounds = [0]
             for h, w in shapes:
                 bounds.append(bounds[-1] + h * w)
-            src, value, proj = ops.encoder_prologue(src, stats[:len(levels)], gnp, bounds, pstream, psmall, lvl_pos, pw, groups=gns[0].num_groups,
-                                                    eps=gns[0].eps, value_heads=a0.n_heads)
+            fuse0 = self._use_fused_msda(dev)
+            src, value, proj = ops.encoder_prologue(src, stats[:len(levels)], gnp, bounds, pstream, psmall[:64] if fuse0 else psmall, lvl_pos,
+                                                    0 if fuse0 else pw, groups=gns[0].num_groups, eps=gns[0].eps, value_heads=a0.n_heads)
         else:
             toks = []
             for idx, x in enumerate(levels):
@@ -906,14 +927,21 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
             # layer l = MSDeformAttn gather + ONE fused token-wise kernel that also emits layer l+1's
             # value / sampling projections (the 1024-wide FFN activation never leaves registers)
             packed = self._packed_encoder(dev)
+            fuse = self._use_fused_msda(dev)
             if value is None:
                 a0 = layers[0].self_attn
                 value = ops.value_to_head_major(ops.gemm(src, a0.value_proj.weight, a0.value_proj.bias), a0.n_heads)
-                w, b = self._packed[2]
-                proj = ops.gemm(src, w, b, a2=lvl_pos)
+                if not fuse:
+                    w, b = self._packed[2]
+                    proj = ops.gemm(src, w, b, a2=lvl_pos)
             for l, layer in enumerate(layers):
-                attn = ops.ms_deform_attn_encoder(value, ss, starts, proj, layer.self_attn.n_heads, layer.self_attn.n_points)
+                if fuse:
+                    attn = ops.ms_deform_attn_encoder_fused(value, ss, starts, src, lvl_pos, *self._packed[3][l], layer.self_attn.n_points)
+                else:
+                    attn = ops.ms_deform_attn_encoder(value, ss, starts, proj, layer.self_attn.n_heads, layer.self_attn.n_points)
                 stream, small, d_ffn, pw = packed[l]
+                if fuse:
+                    pw = 0                         # the block emits the next layer's value only
                 # layers 1.. read a head-major value (written so by the previous block): 64-byte instead of 32-byte taps
                 block = {"f32": ops.encoder_block, "f32_split": ops.encoder_block_split, "bf16": ops.encoder_block_lp}[self.precision]
                 src, value, proj = block(attn, src, stream, small, d_ffn, pw, pos=lvl_pos, tokens_per_image=S_tok,

@@ -697,6 +697,33 @@ def ms_deform_attn_encoder(value, spatial_shapes, level_start_index, proj, heads
     return out
 
 
+def pack_msda_proj(wp, bp, heads, n_levels, n_points):
+    """[sampling_offsets ; attention_weights] weight (heads*L*P*3, 64) and bias -> the per-head fragment-order stream and bias
+    table of ms_deform_attn_encoder_fused (msm_msda_pack_proj)."""
+    _c(wp, "wp"), _c(bp, "bp")
+    if tuple(wp.shape) != (heads * n_levels * n_points * 3, 64) or bp.numel() != wp.shape[0]:
+        raise RuntimeError(f"pack_msda_proj: weight must be ({heads * n_levels * n_points * 3}, 64) with a bias per row")
+    wpack = torch.empty(heads * 3 * 4 * 64 * 4, device=wp.device, dtype=torch.float32)
+    bpack = torch.empty(heads * 48, device=wp.device, dtype=torch.float32)
+    check(lib().msm_msda_pack_proj(_p(wp), _p(bp), _p(wpack), _p(bpack), heads, n_levels, n_points, _stream()), "msm_msda_pack_proj")
+    return wpack, bpack
+
+
+def ms_deform_attn_encoder_fused(value_hm, spatial_shapes, level_start_index, src, pos, wpack, bpack, n_points):
+    """Encoder self-attention with the sampling projection computed in the kernel: value_hm (N,heads,S,8) head-major,
+    src (N,S,64) the layer input, pos (S,64); wpack / bpack from pack_msda_proj.  Returns (N,S,64)."""
+    _c(value_hm, "value_hm"), _c(src, "src"), _c(pos, "pos"), _c(wpack, "wpack"), _c(bpack, "bpack")
+    _c(spatial_shapes, "spatial_shapes", torch.int64), _c(level_start_index, "level_start_index", torch.int64)
+    N, M, S, D = value_hm.shape
+    if tuple(src.shape) != (N, S, M * D) or tuple(pos.shape) != (S, M * D):
+        raise RuntimeError("ms_deform_attn_encoder_fused: src must be (N,S,C) and pos (S,C) for a (N,heads,S,C/heads) value")
+    out = torch.empty((N, S, M * D), device=src.device, dtype=torch.float32)
+    rc = lib().msm_msdeform_attn_enc_fused_fwd(_p(value_hm), _p(spatial_shapes), _p(level_start_index), _p(src), _p(pos), _p(wpack),
+                                               _p(bpack), _p(out), N, S, M, D, spatial_shapes.shape[0], n_points, _stream())
+    check(rc, "msm_msdeform_attn_enc_fused_fwd")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # mean shift (lib/utils/mean_shift.py)
 # ----------------------------------------------------------------------------------------------
@@ -808,7 +835,7 @@ def encoder_prologue(raw, stats, gn_params, level_starts, stream, small, pos, pr
         raise RuntimeError("encoder_prologue: small must hold the 64 value_proj biases and the proj_width projection biases")
     dev = raw.device
     value = torch.empty((B, value_heads, S, 64 // value_heads) if value_heads else (B, S, 64), device=dev, dtype=torch.float32)
-    proj = torch.empty((B, S, proj_width), device=dev, dtype=torch.float32)
+    proj = torch.empty((B, S, proj_width), device=dev, dtype=torch.float32) if proj_width else None     # 0: value projection only
     ls = (ctypes.c_int32 * (L + 1))(*[int(v) for v in level_starts])
     rc = lib().msm_encoder_prologue_fwd(_p(raw), _p(stats), _p(gn_params), ctypes.cast(ls, ctypes.c_void_p), L, int(groups), float(eps),
                                         _p(stream), _p(small), _p(pos), _p(raw), _p(value), _p(proj), B, S, int(proj_width),
@@ -977,7 +1004,8 @@ def encoder_block(attn, src, wstream, small, d_ffn, proj_width, *, pos=None, tok
     if want_next:
         value_out = torch.empty((B, value_heads, S, C // value_heads), device=src.device, dtype=torch.float32) \
             if value_heads else torch.empty_like(src)
-        proj_out = torch.empty((B, S, proj_width), device=src.device, dtype=torch.float32)
+        # proj_width == 0: the next layer's gather computes its own sampling projection (ms_deform_attn_encoder_fused)
+        proj_out = torch.empty((B, S, proj_width), device=src.device, dtype=torch.float32) if proj_width else None
     rc = lib().msm_encoder_block_fwd(_p(attn), _p(src), _p(wstream), _p(small), _p(pos), _p(src_out), _p(value_out),
                                      _p(proj_out), M, tokens_per_image or S, d_ffn, proj_width, int(value_heads), eps, _stream())
     check(rc, "msm_encoder_block_fwd")
