@@ -992,3 +992,25 @@ def test_msda_gather_with_fused_sampling_projection(B, shapes):
     value_tm = vh.cpu().permute(0, 2, 1, 3).contiguous()                          # (B,S,heads,8)
     want = O.ms_deform_attn_core(value_tm, shapes, loc.contiguous(), aw)
     close(got, want, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("S,centres,noise,seed", [(100, 12, 0.02, 0), (100, 5, 0.25, 1), (300, 24, 0.3, 2), (304, 3, 0.35, 23), (37, 37, 0.0, 4),
+                                                  (64, 1, 0.2, 5), (150, 8, 0.28, 6)])
+def test_connected_components_on_device(S, centres, noise, seed):
+    """msm_ms_connected_components (the order-dependent merge of mean_shift.py:41-76 on one wave) against the host loop and the
+    oracle: identical labels, also where neighbourhoods overlap (noise levels that put many pairs around epsilon, so that the
+    'take the mode of the labels already present' branch runs) and at the 304-seed limit."""
+    from unseenobjectswithmeanshift_amd import mean_shift as ms
+    g = torch.Generator().manual_seed(seed)
+    c = F.normalize(torch.randn(centres, 64, generator=g), dim=1)
+    Z = F.normalize(c[torch.randint(0, centres, (S,), generator=g)] + noise * torch.randn(S, 64, generator=g) / 8.0, dim=1)
+    host = ms.connected_components_host(Z, 0.04)
+    want = O.connected_components(Z, 0.04)
+    assert torch.equal(host, want)
+    # pairs within float rounding of the threshold could legitimately differ between summation orders: none here
+    d = 0.5 * (1 - Z.double() @ Z.double().t())
+    assert float((d - 0.04).abs().min()) > 1e-6
+    got, num = ops().ms_connected_components(Z.to(DEV), 0.04)
+    assert torch.equal(got.cpu(), want)
+    assert int(num) >= int(want.max()) + 1 and int(num) <= S
+    assert torch.equal(ms.connected_components(Z.to(DEV), 0.04).cpu(), want)

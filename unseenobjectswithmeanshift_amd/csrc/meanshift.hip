@@ -156,6 +156,7 @@ __global__ __launch_bounds__(PS_W * 64) void ms_seed_persistent_kernel(const flo
                                                                      unsigned int* __restrict__ status /* [0] arrivals, [1] abort */) {
     __shared__ unsigned long long red[PS_W];
     __shared__ unsigned long long prev_s;
+    __shared__ unsigned int abort_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 15, grp = lane >> 4;
     const int blk0 = blockIdx.x * (PS_W * 4 * 16 * NG);
@@ -171,9 +172,9 @@ __global__ __launch_bounds__(PS_W * 64) void ms_seed_persistent_kernel(const flo
         rowj[t] = base + j;
         near[t] = INFINITY;
     }
+    if (tid == 0) prev_s = __hip_atomic_load(&keys[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
     for (int step = 1; step < num_seeds; ++step) {
-        if (tid == 0) prev_s = __hip_atomic_load(&keys[step - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
         const unsigned int cur = 0xFFFFFFFFu - (unsigned int)(prev_s & 0xFFFFFFFFull);
         if (cur >= (unsigned int)n) return;      // only after an abort elsewhere (keys left at 0): leave, uniformly
         const float4 s = *reinterpret_cast<const float4*>(X + (int64_t)cur * MS_D + j * 4);
@@ -230,24 +231,36 @@ __global__ __launch_bounds__(PS_W * 64) void ms_seed_persistent_kernel(const flo
 #pragma unroll
             for (int w = 1; w < PS_W; ++w) b = red[w] > b ? red[w] : b;
             if (b) __hip_atomic_fetch_max(&keys[step], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // grid barrier: the release orders the key update before the arrival; polling is relaxed and bounded.
-            // (A two-level arrival -- one counter per XCD class, the last of a class forwards -- was measured at the
-            // same 10 us per step: the cost is the cross-XCD round trips, not the 200 same-address atomics.)
-            __hip_atomic_fetch_add(&status[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            // Grid barrier, fence-free (round 3; 10 -> see DESIGN.md us per step).  Everything the workgroups exchange is the
+            // step's 8-byte key, and both sides touch it with agent-scope atomics only (the fetch_max above, the atomic load
+            // at the top of the next step) -- the "8-byte agent atomics on both sides" form of the guide: no L2 write-back
+            // (release) and no L1 invalidate (acquire) is needed, and those two fences were 3 - 4 us of every step.  What IS
+            // needed is order: the arrival may only be counted once this workgroup's key update has been performed, so the
+            // returning atomic is waited for (vmcnt) before the arrival is issued.  The other global reads of the loop are
+            // rows of X, which nobody writes.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(&status[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned int target = (unsigned int)step * gridDim.x;
-            unsigned int polls = 0;
-            while (__hip_atomic_load(&status[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                if (__hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+            unsigned int polls = 0, gave_up = 0;
+            // one 8-byte poll: low word = arrivals, high word = the abort flag
+            const unsigned long long* both = reinterpret_cast<const unsigned long long*>(status);
+            for (;;) {
+                const unsigned long long v = __hip_atomic_load(both, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v >> 32) != 0ull) { gave_up = 1; break; }
+                if ((unsigned int)v >= target) break;
                 if (++polls > PS_SPIN_LIMIT) {
                     __hip_atomic_store(&status[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    gave_up = 1;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
             }
-            __atomic_thread_fence(__ATOMIC_ACQUIRE);     // agent scope by default: later key reads see the other XCDs' updates
+            abort_s = gave_up;
+            // the winner of this step, read here by the polling lane: the next step starts without another round trip
+            prev_s = __hip_atomic_load(&keys[step], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
-        if (__hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;   // uniform per block after the barrier
+        if (abort_s != 0u) return;               // uniform per block after the barrier
     }
 }
 
@@ -420,6 +433,73 @@ __global__ __launch_bounds__(1024) void ms_hill_finish_kernel(const float* __res
         const float nrm = fmaxf(sqrtf(wave_sum(acc * acc)), 1e-12f);
         Z[(int64_t)s * MS_D + d] = acc / nrm;
     }
+}
+
+// ---- connected components of the converged seeds ------------------------------------------------------------------
+// mean_shift.py:41-76 is sequential and order dependent -- the i-th still-unlabelled seed claims every seed within epsilon
+// (cosine distance 0.5 (1 - z_j . z_i)); if some of those already carry labels it takes their mode (smallest label on
+// equal counts: np.unique sorts, argmax takes the first), otherwise a fresh label -- but every step of it is a parallel
+// operation over <= 304 seeds.  One wave walks the sequence: the seeds sit in LDS, a step's S dot products are one per
+// lane and chunk, the mode is an LDS histogram + a wave reduction.  What this buys is not the arithmetic (a dozen steps of
+// a microsecond) but the HOST: the loop used to run there on a copy of the seeds, i.e. a device synchronisation and a
+// transfer in the middle of every clustering, with the GPU idle behind it.
+constexpr int CC_MAXS = MS_SB * 16;
+__global__ __launch_bounds__(64) void ms_components_kernel(const float* __restrict__ Z, int S, float eps, int64_t* __restrict__ labels_out,
+                                                           int32_t* __restrict__ num_out) {
+    extern __shared__ __attribute__((aligned(16))) float cz[];           // [S][MS_D + 1], then int lab[S], cnt[S]
+    constexpr int ZS = MS_D + 1;
+    int* lab = reinterpret_cast<int*>(cz + (size_t)S * ZS);
+    int* cnt = lab + S;
+    const int lane = threadIdx.x;
+    for (int i = lane; i < S * MS_D; i += 64) cz[(i / MS_D) * ZS + (i % MS_D)] = Z[i];
+    for (int j = lane; j < S; j += 64) lab[j] = -1;
+    __syncthreads();
+    int K = 0;
+    constexpr int NCH = (CC_MAXS + 63) / 64;
+    for (int i = 0; i < S; ++i) {
+        if (lab[i] != -1) continue;                                      // uniform
+        for (int l = lane; l < K; l += 64) cnt[l] = 0;
+        __syncthreads();
+        bool comp[NCH];
+        bool labelled = false;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int j = c * 64 + lane;
+            comp[c] = false;
+            if (j < S) {
+                float dot = 0.f;
+#pragma unroll 16
+                for (int k = 0; k < MS_D; ++k) dot = fmaf(cz[j * ZS + k], cz[i * ZS + k], dot);
+                comp[c] = 0.5f * (1.0f - dot) <= eps;
+                if (comp[c] && lab[j] >= 0) {
+                    atomicAdd(&cnt[lab[j]], 1);
+                    labelled = true;
+                }
+            }
+        }
+        __syncthreads();
+        int label;
+        if (__any(labelled)) {
+            // mode of the labels already present (MS:30-38, 66-68): largest count, smallest label on ties
+            int bc = -1, bl = 0x7fffffff;
+            for (int l = lane; l < K; l += 64)
+                if (cnt[l] > bc) { bc = cnt[l]; bl = l; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const int oc = __shfl_xor(bc, o, 64), ol = __shfl_xor(bl, o, 64);
+                if (oc > bc || (oc == bc && ol < bl)) { bc = oc; bl = ol; }
+            }
+            label = bl;
+        } else {
+            label = K++;
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            if (comp[c]) lab[c * 64 + lane] = label;
+        __syncthreads();
+    }
+    for (int j = lane; j < S; j += 64) labels_out[j] = (int64_t)lab[j];
+    if (lane == 0) num_out[0] = K;
 }
 
 // ---- assignment -----------------------------------------------------------------------------------
@@ -642,6 +722,18 @@ extern "C" int msm_ms_assign(const float* X, int n, int d, const float* Z, int S
     hipLaunchKernelGGL(ms_assign_kernel, dim3(G), dim3(256), lds, st, X, n, Z, S, nchunks, seed_labels, labels_out,
                        reinterpret_cast<unsigned long long*>(counts), num_labels);
     MSM_CHECK_LAUNCH("msm_ms_assign");
+    return MSM_OK;
+}
+
+extern "C" int msm_ms_connected_components(const float* Z, int S, int d, float epsilon, int64_t* seed_labels, int32_t* num_labels,
+                                           void* stream) {
+    MSM_REQUIRE(Z && seed_labels && num_labels, "msm_ms_connected_components: null pointer");
+    MSM_REQUIRE(d == MS_D, "msm_ms_connected_components: d=%d, only d=64 is supported", d);
+    MSM_REQUIRE(S > 0 && S <= CC_MAXS, "msm_ms_connected_components: S=%d must be in 1..%d", S, CC_MAXS);
+    const size_t lds = sizeof(float) * (size_t)S * (MS_D + 1) + sizeof(int) * 2 * (size_t)S;
+    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)ms_components_kernel, lds));
+    hipLaunchKernelGGL(ms_components_kernel, dim3(1), dim3(64), lds, (hipStream_t)stream, Z, S, epsilon, seed_labels, num_labels);
+    MSM_CHECK_LAUNCH("msm_ms_connected_components");
     return MSM_OK;
 }
 

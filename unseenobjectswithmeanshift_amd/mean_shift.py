@@ -35,8 +35,16 @@ def get_label_mode(array):
 
 
 def connected_components(Z, epsilon, metric="cosine"):
-    """mean_shift.py:41-76 on the host (sequential, order dependent)."""
+    """mean_shift.py:41-76: sequential, order-dependent merge of the converged seeds.  On the device (one wave,
+    ops.ms_connected_components) for up to 304 seeds -- no host synchronisation; larger seed sets take the host loop."""
     _cosine_only(metric)
+    if Z.is_cuda and Z.shape[0] <= 304 and Z.shape[1] == 64:
+        return ops.ms_connected_components(Z.contiguous(), epsilon)[0]
+    return connected_components_host(Z, epsilon)
+
+
+def connected_components_host(Z, epsilon):
+    """The same merge on the host, on a copy of the seeds (the reference's own form; fallback and test partner)."""
     Zc = Z.detach().to("cpu", torch.float32)
     n = Zc.shape[0]
     K = 0
@@ -90,17 +98,22 @@ def mean_shift_smart_init(X, kappa, num_seeds=100, max_iters=10, metric="cosine"
         first_index = np.random.randint(0, X.shape[0])                   # MS:155, drawn once: a retry reuses it
     seeds, selected = select_smart_seeds(X, num_seeds, return_selected_indices=True, metric=metric,
                                          first_index=first_index)
-    seed_labels, Z = mean_shift_with_seeds(X, seeds, kappa, max_iters=max_iters, metric=metric)
-    # connected_components above is the first host sync of the call, so the give-up flag of the persistent seeding kernel
-    # (co-residency lost to other streams / processes) is read here, for free on the normal path; a give-up re-runs
-    # seeding on the one-launch-per-step path (identical results) and the hill climb on its seeds
+    def rest(seeds):
+        seed_labels, Z = mean_shift_with_seeds(X, seeds, kappa, max_iters=max_iters, metric=metric)
+        # labels are created in order 0, 1, ...: at most one per seed, so num_seeds bounds the histogram of the assignment
+        labels, counts = ops.ms_assign(X, Z, seed_labels.to(X.device), seeds.shape[0])
+        ops.ms_relabel_largest_zero(labels, counts)
+        return labels
+
+    labels = rest(seeds)
+    # The whole clustering is queued without a host synchronisation (the merge of the seeds runs on the device); the one
+    # check that needs the host comes last, when everything is in flight: the give-up flag of the persistent seeding kernel
+    # (co-residency lost to other streams / processes).  A give-up re-runs seeding on the one-launch-per-step path
+    # (identical results) and everything after it.
     if int(selected.min()) < 0:
         seeds, selected = select_smart_seeds(X, num_seeds, return_selected_indices=True, metric=metric,
                                              first_index=first_index, stepwise=True)
-        seed_labels, Z = mean_shift_with_seeds(X, seeds, kappa, max_iters=max_iters, metric=metric)
-    num = int(torch.unique(seed_labels).numel())
-    labels, counts = ops.ms_assign(X, Z, seed_labels.to(X.device), num)
-    ops.ms_relabel_largest_zero(labels, counts)
+        labels = rest(seeds)
     return labels, selected
 
 
