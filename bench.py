@@ -330,15 +330,15 @@ def mean_shift_unit(dev):
     ref_bytes = float(S) * n * 64 * 4                  # the reference re-reads X for every seed
     hill_flops = 4.0 * S * n * 64 * iters              # Z X^T and W X per iteration
     return {"workload": "clustering_features unit (lib/fcn/test_dataset.py:44-59): one 640x480 map, n=307200 unit 64-d embeddings in 12 "
-                        "planted clusters, 100 seeds, 10 iterations, kappa 20; includes the host-side connected_components",
+                        "planted clusters, 100 seeds, 10 iterations, kappa 20; connected_components on the device, one host check per image",
             "value": round(1.0 / t_all, 2), "unit": "images/sec", "ms_per_image": round(1e3 * t_all, 3),
-            "seeding": {"kernel": "ms_seed_persistent_kernel (one launch, map held in registers, grid barrier per step)",
-                        "ms": round(t_seed, 4), "bound": "hbm (reference form: S passes over X) -> barrier latency as executed",
+            "seeding": {"kernel": "ms_seed_persistent_kernel (one launch, map held in registers, data-tagged all-to-all exchange of the candidates per step)",
+                        "ms": round(t_seed, 4), "bound": "hbm (reference form: S passes over X) -> exchange latency as executed",
                         "achieved": round(ref_bytes / (t_seed * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                         "frac": round(n * 256.0 / (t_seed * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
                         "executed_bytes": n * 256.0, "algorithmic_bytes": ref_bytes,
                         "note": "achieved = the reference algorithm's S*n*256 bytes over the time (effective); the kernel reads X "
-                                "once (executed_bytes), frac is executed bytes / time / peak: the step is bound by S grid barriers"},
+                                "once (executed_bytes), frac is executed bytes / time / peak: the step is bound by S all-to-all exchanges"},
             "hill_climb": {"kernel": "ms_hill_kernel + ms_hill_finish_kernel", "ms": round(t_hill, 4), "bound": "mfma",
                            "achieved": round(hill_flops / (t_hill * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(hill_flops / (t_hill * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "flops": hill_flops},

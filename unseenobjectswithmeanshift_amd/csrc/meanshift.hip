@@ -142,18 +142,20 @@ __global__ __launch_bounds__(256) void ms_seed_step_kernel(const float* __restri
 // All S-1 farthest-point steps in ONE launch: X (n x 64 fp32 = 79 MB at 640x480) is read once into VGPRs -- a workgroup
 // of 8 waves holds 512*NG rows, 200 workgroups hold the map -- and every step is a dot product against the previous
 // winner's row from registers, the same butterfly and (value, ~index) atomicMax key as ms_seed_step_kernel (so the
-// selected indices are bit-identical), and a grid barrier (one release add per workgroup on an agent-scope counter,
-// relaxed polling).  The per-step cost is the barrier (~4 us) instead of a 79 MB stream (~22 us).
+// selected indices are bit-identical), and an all-to-all exchange of the workgroups' candidates through data-tagged 8-byte
+// granules (see the loop).  The per-step cost is that exchange (5.6 us) instead of a 79 MB stream (~22 us).
 // Safety: the grid never exceeds the number of CUs (one workgroup per CU is guaranteed by the launch bounds), so all
 // workgroups are co-resident; every wait is bounded and raises `status[1]`, which makes every workgroup leave and the
 // finish kernel report -1 indices instead of hanging the queue.
 constexpr int PS_W = 8;                      // waves per persistent workgroup
+constexpr int PS_MAXWG = 256;                // workgroups of the persistent launch (one per CU at most)
 constexpr unsigned PS_SPIN_LIMIT = 1u << 20; // polls (with s_sleep) before giving up: well under a second
 
 template <int NG>
 __global__ __launch_bounds__(PS_W * 64) void ms_seed_persistent_kernel(const float* __restrict__ X, int n,
                                                                      unsigned long long* __restrict__ keys, int num_seeds,
-                                                                     unsigned int* __restrict__ status /* [0] arrivals, [1] abort */) {
+                                                                     unsigned int* __restrict__ status /* [1] abort */,
+                                                                     unsigned long long* __restrict__ gran /* [2][2][PS_MAXWG] */) {
     __shared__ unsigned long long red[PS_W];
     __shared__ unsigned long long prev_s;
     __shared__ unsigned int abort_s;
@@ -226,46 +228,68 @@ __global__ __launch_bounds__(PS_W * 64) void ms_seed_persistent_kernel(const flo
         }
         if (lane == 0) red[wave] = best;
         __syncthreads();
-        if (tid == 0) {
+        if (wave == 0) {
+            // ---- the step's exchange, data-tagged (round 3: 10 -> 8.4 (fence-free counter) -> see DESIGN.md us per step) ----
+            // A counter barrier costs four dependent round trips to the memory-side atomics per step (max, arrival, poll,
+            // key read).  Here a workgroup PUBLISHES its candidate in its own slot as two 8-byte {step, payload} granules
+            // (one relaxed agent-scope store each: the data is the flag, guide recipe R2) and one wave per workgroup SWEEPS
+            // all slots -- <= 256 x 2 granules, eight 8-byte loads per lane, all in flight together -- until every tag
+            // equals the step, then takes the maximum itself: one store and (typically) two sweeps per step.  Slots are
+            // double-buffered by step parity: a workgroup can run at most one step ahead of the slowest (its next sweep
+            // needs everybody's next store), so a slot is never overwritten before every sweep of its previous use is over.
             unsigned long long b = red[0];
 #pragma unroll
             for (int w = 1; w < PS_W; ++w) b = red[w] > b ? red[w] : b;
-            if (b) __hip_atomic_fetch_max(&keys[step], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // Grid barrier, fence-free (round 3; 10 -> see DESIGN.md us per step).  Everything the workgroups exchange is the
-            // step's 8-byte key, and both sides touch it with agent-scope atomics only (the fetch_max above, the atomic load
-            // at the top of the next step) -- the "8-byte agent atomics on both sides" form of the guide: no L2 write-back
-            // (release) and no L1 invalidate (acquire) is needed, and those two fences were 3 - 4 us of every step.  What IS
-            // needed is order: the arrival may only be counted once this workgroup's key update has been performed, so the
-            // returning atomic is waited for (vmcnt) before the arrival is issued.  The other global reads of the loop are
-            // rows of X, which nobody writes.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(&status[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned int target = (unsigned int)step * gridDim.x;
-            unsigned int polls = 0, gave_up = 0;
-            // one 8-byte poll: low word = arrivals, high word = the abort flag
-            const unsigned long long* both = reinterpret_cast<const unsigned long long*>(status);
-            for (;;) {
-                const unsigned long long v = __hip_atomic_load(both, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((v >> 32) != 0ull) { gave_up = 1; break; }
-                if ((unsigned int)v >= target) break;
-                if (++polls > PS_SPIN_LIMIT) {
-                    __hip_atomic_store(&status[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long* ga = gran + (size_t)(step & 1) * 2 * PS_MAXWG;           // [2][PS_MAXWG]: value granules, index granules
+            const unsigned long long tag = (unsigned long long)(unsigned int)step << 32;
+            if (lane == 0) {
+                __hip_atomic_store(ga + blockIdx.x, tag | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ga + PS_MAXWG + blockIdx.x, tag | (b & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            unsigned long long win = 0ull;
+            unsigned int gave_up = 0;
+            for (unsigned int polls = 0;; ++polls) {
+                bool ok = true;
+                win = 0ull;
+#pragma unroll
+                for (int k = 0; k < PS_MAXWG / 64; ++k) {
+                    const int slot = k * 64 + lane;
+                    if (slot < (int)gridDim.x) {
+                        const unsigned long long va = __hip_atomic_load(ga + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long vi = __hip_atomic_load(ga + PS_MAXWG + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = ok && (va >> 32) == (tag >> 32) && (vi >> 32) == (tag >> 32);
+                        const unsigned long long key = (va << 32) | (vi & 0xFFFFFFFFull);
+                        win = key > win ? key : win;
+                    }
+                }
+                if (__all(ok)) break;
+                if ((polls & 15u) == 15u && __hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { gave_up = 1; break; }
+                if (polls > PS_SPIN_LIMIT) {
+                    if (lane == 0) __hip_atomic_store(&status[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     gave_up = 1;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
-            abort_s = gave_up;
-            // the winner of this step, read here by the polling lane: the next step starts without another round trip
-            prev_s = __hip_atomic_load(&keys[step], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned long long other = __shfl_xor(win, o, 64);
+                win = other > win ? other : win;
+            }
+            if (lane == 0) {
+                abort_s = gave_up;
+                prev_s = win;                                        // the winner of this step: the next step's row
+                if (blockIdx.x == 0 && !gave_up) keys[step] = win;   // for the finish kernel (next launch)
+            }
         }
         __syncthreads();
         if (abort_s != 0u) return;               // uniform per block after the barrier
     }
 }
 
-__global__ void ms_seed_status_init_kernel(unsigned int* __restrict__ status, unsigned int give_up) {
+__global__ void ms_seed_status_init_kernel(unsigned int* __restrict__ status, unsigned int give_up, unsigned long long* __restrict__ gran) {
     if (threadIdx.x < 2) status[threadIdx.x] = threadIdx.x == 1 ? give_up : 0u;
+    for (int i = threadIdx.x; i < 4 * PS_MAXWG; i += blockDim.x) gran[i] = 0ull;     // tag 0 = no step: polled words are re-initialised every call
 }
 
 __global__ void ms_seed_init_kernel(unsigned long long* __restrict__ keys, int num_seeds, int64_t first) {
@@ -627,13 +651,15 @@ extern "C" int msm_ms_select_seeds(const float* X, int n, int d, int num_seeds, 
     const int ng = cdiv(n, 256 * PS_W * 64);                       // rows per workgroup = 512 * ng
     const int pgrid = ng >= 1 && ng <= 3 ? cdiv(n, PS_W * 64 * ng) : 0;
     unsigned int* status = reinterpret_cast<unsigned int*>(workspace + 2 * (MS_SB * 16) + 4);   // 2 words between keys and nearest
-    if (pgrid > 0 && pgrid <= n_cus && n >= 4096 && num_seeds > 2 && !(flags & MSM_MS_SEED_STEPWISE) &&
+    if (pgrid > 0 && pgrid <= n_cus && pgrid <= PS_MAXWG && n >= 4096 && num_seeds > 2 && !(flags & MSM_MS_SEED_STEPWISE) &&
         opt(MSM_OPT_MS_NO_PERSISTENT) != 1) {
-        hipLaunchKernelGGL(ms_seed_status_init_kernel, dim3(1), dim3(64), 0, st, status, (flags & MSM_MS_SEED_TEST_GIVE_UP) ? 1u : 0u);
+        // the exchange slots live where the stepwise path keeps nearest[] (unused here): 2 parities x 2 granule rows x 256 slots x 8 B = 8 KiB
+        unsigned long long* gran = reinterpret_cast<unsigned long long*>(nearest);
+        hipLaunchKernelGGL(ms_seed_status_init_kernel, dim3(1), dim3(256), 0, st, status, (flags & MSM_MS_SEED_TEST_GIVE_UP) ? 1u : 0u, gran);
         switch (ng) {
-            case 1: hipLaunchKernelGGL(ms_seed_persistent_kernel<1>, dim3(pgrid), dim3(PS_W * 64), 0, st, X, n, keys, num_seeds, status); break;
-            case 2: hipLaunchKernelGGL(ms_seed_persistent_kernel<2>, dim3(pgrid), dim3(PS_W * 64), 0, st, X, n, keys, num_seeds, status); break;
-            default: hipLaunchKernelGGL(ms_seed_persistent_kernel<3>, dim3(pgrid), dim3(PS_W * 64), 0, st, X, n, keys, num_seeds, status); break;
+            case 1: hipLaunchKernelGGL(ms_seed_persistent_kernel<1>, dim3(pgrid), dim3(PS_W * 64), 0, st, X, n, keys, num_seeds, status, gran); break;
+            case 2: hipLaunchKernelGGL(ms_seed_persistent_kernel<2>, dim3(pgrid), dim3(PS_W * 64), 0, st, X, n, keys, num_seeds, status, gran); break;
+            default: hipLaunchKernelGGL(ms_seed_persistent_kernel<3>, dim3(pgrid), dim3(PS_W * 64), 0, st, X, n, keys, num_seeds, status, gran); break;
         }
         hipLaunchKernelGGL(ms_seed_finish_kernel, dim3(num_seeds), dim3(64), 0, st, X, keys, indices_out, seeds_out, status, n);
         MSM_CHECK_LAUNCH("msm_ms_select_seeds(persistent)");
