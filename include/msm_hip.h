@@ -37,6 +37,8 @@
  *   msm_conv1x1_in_f32           <- input_proj / lateral 1x1 convolutions of the pixel decoder + GroupNorm moments, MSD:212-238
  *   msm_conv3x3_c64_f32          <- FPN output convolution layer_1 + the moments of its GroupNorm, MSD:264-279,349-351
  *   msm_label_stats              <- per-label loops of the two-stage harness, lib/fcn/test_dataset.py:62-131,183-198
+ *   msm_label_image / msm_crop_resize / msm_paste_labels
+ *                                <- combine_masks test_utils.py:93-112, crop_rois test_dataset.py:62-112, paste-back :160-177, batched
  *   msm_instance_postprocess     <- F.interpolate + instance_inference,
  *                                   MSMFormer/meanshiftformer/pretrained_meanshiftformer_model.py:337-343,461-497
  */
@@ -549,6 +551,23 @@ int msm_encoder_block_lp_fwd(const float* attn, const float* src, const void* ws
  * k <= 2048 (per-workgroup LDS table). */
 int msm_label_stats(const float* labels, const float* weight, int32_t* stats, float* wsum, int32_t* overflow,
                     int B, int H, int W, int k, void* stream);
+
+/* Batched two-stage harness (lib/fcn/test_utils.py:375-406 walks frames and crops one at a time):
+ *   msm_label_image   combine_masks(get_confident_instances(...)) (test_utils.py:35-52, 93-112) for B images: masks [B][K][H][W]
+ *                     (non-zero = inside), inst_labels [B][K] = the label an instance carries (2 + kept instances before it; 0 =
+ *                     dropped) -> out [B][H][W] = per-pixel maximum ("later instances overwrite earlier ones").
+ *   msm_crop_resize   crop_rois (lib/fcn/test_dataset.py:62-112) for N ROIs of any frames in one launch: table [N][8] int32 =
+ *                     frame, label, x0, y0, x1, y1 (inclusive), 2 unused; rgb / depth [F][3][H][W] bilinear with
+ *                     align_corners=True (F.upsample_bilinear, :104,109), mask = (labels[frame] == label) nearest (:106)
+ *                     -> rgb_out / depth_out [N][3][S][S], mask_out [N][S][S].  depth / depth_out may both be NULL.
+ *   msm_paste_labels  paste-back of match_label_crop (test_dataset.py:160-177): renum [N][S][S] renumbered crop labels, order
+ *                     [N] the crops grouped by frame in paste order, frame_start [F+1]; refined [F][H][W] takes, per pixel, the
+ *                     last crop in order that covers it with a non-zero (nearest-resized) value, else 0. */
+int msm_label_image(const float* masks, const float* inst_labels, float* out, int B, int K, int H, int W, void* stream);
+int msm_crop_resize(const float* rgb, const float* depth, const float* labels, const int32_t* table, float* rgb_out,
+                    float* depth_out, float* mask_out, int N, int H, int W, int S, void* stream);
+int msm_paste_labels(const float* renum, const int32_t* table, const int32_t* order, const int32_t* frame_start,
+                     float* refined, int F, int H, int W, int S, void* stream);
 
 #ifdef __cplusplus
 }

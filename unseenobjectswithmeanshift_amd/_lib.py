@@ -90,6 +90,9 @@ _SIGNATURES = {
     "msm_encoder_prologue_stream_floats": (c_l, [c_i]),
     "msm_encoder_prologue_fwd": (c_i, [c_f, c_p, c_f, c_p, c_i, c_i, c_fl, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p]),
     "msm_label_stats": (c_i, [c_f, c_f, c_p, c_f, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "msm_label_image": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p]),
+    "msm_crop_resize": (c_i, [c_f, c_f, c_f, c_p, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p]),
+    "msm_paste_labels": (c_i, [c_f, c_p, c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_p]),
     "msm_instance_postprocess_workspace": (c_l, [c_i, c_i, c_i, c_i]),
     "msm_instance_postprocess": (c_i, [c_f, c_p, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
 }

@@ -101,6 +101,99 @@ __global__ __launch_bounds__(LS_THREADS) void label_stats_kernel(const float* __
     if (threadIdx.x == 0 && over) atomicAdd(overflow + b, over);
 }
 
+// ---- batched two-stage harness (round 3): label images, ROI crops and paste-back for a whole batch of frames ------------
+// lib/fcn/test_utils.py:375-406 walks frames and crops one at a time; the three kernels below let the harness run the first
+// stage on all frames at once, cut every frame's ROIs in one launch and paste every frame's refined labels in one launch.
+
+// label image of test_utils.py:93-112 (combine_masks after get_confident_instances :35-52): instance i, if kept, carries
+// label lab[b][i] = 2 + (kept instances before it), 0 when dropped; "later instances overwrite earlier ones" with labels
+// growing in instance order = the per-pixel maximum.
+__global__ __launch_bounds__(256) void label_image_kernel(const float* __restrict__ masks, const float* __restrict__ lab,
+                                                          float* __restrict__ out, int K, int64_t hw4) {
+    const int b = blockIdx.y;
+    const float4* m = reinterpret_cast<const float4*>(masks) + (int64_t)b * K * hw4;
+    const float* lb = lab + (int64_t)b * K;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < hw4; p += (int64_t)gridDim.x * 256) {
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < K; ++k) {
+            const float l = lb[k];
+            if (l == 0.f) continue;                              // uniform
+            const float4 v = m[(int64_t)k * hw4 + p];
+            r.x = fmaxf(r.x, v.x != 0.f ? l : 0.f);
+            r.y = fmaxf(r.y, v.y != 0.f ? l : 0.f);
+            r.z = fmaxf(r.z, v.z != 0.f ? l : 0.f);
+            r.w = fmaxf(r.w, v.w != 0.f ? l : 0.f);
+        }
+        reinterpret_cast<float4*>(out)[(int64_t)b * hw4 + p] = r;
+    }
+}
+
+// ROI table row (8 x int32): frame, label, x0, y0, x1, y1 (inclusive), 2 unused
+// crop_rois (lib/fcn/test_dataset.py:62-112): rgb / xyz resized with F.upsample_bilinear (align_corners=True, :104,109), the
+// mask (label == mask_id) with nearest (:106).  Index arithmetic as ATen's upsample kernels: scale = (in - 1) / (out - 1) in
+// fp32, src = scale * dst, i0 = (int)src, lambda = src - i0, second tap i0 + (i0 < in - 1); nearest: min((int)floorf(dst *
+// (in / out)), in - 1).
+__global__ __launch_bounds__(256) void crop_resize_kernel(const float* __restrict__ rgb, const float* __restrict__ depth,
+                                                          const float* __restrict__ labels, const int32_t* __restrict__ table,
+                                                          float* __restrict__ rgb_out, float* __restrict__ depth_out,
+                                                          float* __restrict__ mask_out, int H, int W, int S) {
+    const int n = blockIdx.y;
+    const int32_t* t = table + (int64_t)n * 8;
+    const int f = t[0], label = t[1], x0 = t[2], y0 = t[3], x1 = t[4], y1 = t[5];
+    const int ih = y1 - y0 + 1, iw = x1 - x0 + 1;
+    const float rh = S > 1 ? (float)(ih - 1) / (float)(S - 1) : 0.f, rw = S > 1 ? (float)(iw - 1) / (float)(S - 1) : 0.f;
+    const float nh = (float)ih / (float)S, nw = (float)iw / (float)S;
+    const int64_t plane = (int64_t)H * W;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < S * S; p += gridDim.x * 256) {
+        const int oy = p / S, ox = p - oy * S;
+        const float h1r = rh * (float)oy, w1r = rw * (float)ox;
+        const int h1 = (int)h1r, w1 = (int)w1r;
+        const int h1p = h1 < ih - 1 ? 1 : 0, w1p = w1 < iw - 1 ? 1 : 0;
+        const float h1l = h1r - (float)h1, h0l = 1.f - h1l, w1l = w1r - (float)w1, w0l = 1.f - w1l;
+        const int64_t o00 = (int64_t)(y0 + h1) * W + (x0 + w1), o01 = o00 + w1p, o10 = o00 + (int64_t)h1p * W, o11 = o10 + w1p;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* src = rgb + ((int64_t)f * 3 + c) * plane;
+            rgb_out[((int64_t)n * 3 + c) * S * S + p] = h0l * (w0l * src[o00] + w1l * src[o01]) + h1l * (w0l * src[o10] + w1l * src[o11]);
+        }
+        if (depth) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* src = depth + ((int64_t)f * 3 + c) * plane;
+                depth_out[((int64_t)n * 3 + c) * S * S + p] = h0l * (w0l * src[o00] + w1l * src[o01]) + h1l * (w0l * src[o10] + w1l * src[o11]);
+            }
+        }
+        const int sy = min((int)floorf((float)oy * nh), ih - 1), sx = min((int)floorf((float)ox * nw), iw - 1);
+        mask_out[(int64_t)n * S * S + p] = labels[(int64_t)f * plane + (int64_t)(y0 + sy) * W + (x0 + sx)] == (float)label ? 1.f : 0.f;
+    }
+}
+
+// paste-back of match_label_crop (lib/fcn/test_dataset.py:160-177): per frame the crops are pasted in `order`, each resized
+// (nearest) to its ROI, non-zero pixels overwriting what is there -- i.e. a pixel takes the LAST crop in order that covers
+// it with a non-zero value.  order[frame_start[f] .. frame_start[f+1]) lists frame f's crops in paste order.
+__global__ __launch_bounds__(256) void paste_labels_kernel(const float* __restrict__ renum, const int32_t* __restrict__ table,
+                                                           const int32_t* __restrict__ order, const int32_t* __restrict__ frame_start,
+                                                           float* __restrict__ refined, int H, int W, int S) {
+    const int f = blockIdx.y;
+    const int i0 = frame_start[f], i1 = frame_start[f + 1];
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < H * W; p += gridDim.x * 256) {
+        const int y = p / W, x = p - y * W;
+        float r = 0.f;
+        for (int i = i1 - 1; i >= i0; --i) {
+            const int n = order[i];
+            const int32_t* t = table + (int64_t)n * 8;
+            const int x0 = t[2], y0 = t[3], x1 = t[4], y1 = t[5];
+            if (x < x0 || x > x1 || y < y0 || y > y1) continue;
+            const int oh = y1 - y0 + 1, ow = x1 - x0 + 1;
+            const int sy = min((int)floorf((float)(y - y0) * ((float)S / (float)oh)), S - 1);
+            const int sx = min((int)floorf((float)(x - x0) * ((float)S / (float)ow)), S - 1);
+            const float v = renum[((int64_t)n * S + sy) * S + sx];
+            if (v != 0.f) { r = v; break; }
+        }
+        refined[(int64_t)f * H * W + p] = r;
+    }
+}
+
 }  // namespace
 
 extern "C" int msm_label_stats(const float* labels, const float* weight, int32_t* stats, float* wsum, int32_t* overflow,
@@ -118,5 +211,40 @@ extern "C" int msm_label_stats(const float* labels, const float* weight, int32_t
     hipLaunchKernelGGL(label_stats_kernel, dim3(gx, B), dim3(LS_THREADS), (size_t)k * LS_COLS * sizeof(int), s, labels, weight, stats,
                        wsum, overflow, H, W, k);
     MSM_CHECK_LAUNCH("msm_label_stats");
+    return MSM_OK;
+}
+
+extern "C" int msm_label_image(const float* masks, const float* inst_labels, float* out, int B, int K, int H, int W, void* stream) {
+    MSM_REQUIRE(masks && inst_labels && out, "msm_label_image: null pointer");
+    MSM_REQUIRE(B >= 0 && K >= 0 && H > 0 && W > 0 && ((int64_t)H * W) % 4 == 0, "msm_label_image: bad shape (H*W must be a multiple of 4)");
+    MSM_REQUIRE(((((uintptr_t)masks) | ((uintptr_t)out)) & 15) == 0, "msm_label_image: pointers must be 16-byte aligned");
+    if (B == 0) return MSM_OK;
+    const int64_t hw4 = (int64_t)H * W / 4;
+    const int gx = (int)max((int64_t)1, min((hw4 + 255) / 256, (int64_t)max(1, 2048 / B)));
+    hipLaunchKernelGGL(label_image_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, masks, inst_labels, out, K, hw4);
+    MSM_CHECK_LAUNCH("msm_label_image");
+    return MSM_OK;
+}
+
+extern "C" int msm_crop_resize(const float* rgb, const float* depth, const float* labels, const int32_t* table, float* rgb_out,
+                               float* depth_out, float* mask_out, int N, int H, int W, int S, void* stream) {
+    MSM_REQUIRE(rgb && labels && table && rgb_out && mask_out, "msm_crop_resize: null pointer");
+    MSM_REQUIRE((depth == nullptr) == (depth_out == nullptr), "msm_crop_resize: depth and depth_out go together");
+    MSM_REQUIRE(N >= 0 && H > 0 && W > 0 && S > 0, "msm_crop_resize: bad sizes");
+    if (N == 0) return MSM_OK;
+    hipLaunchKernelGGL(crop_resize_kernel, dim3(min(msm::cdiv(S * S, 256), 64), N), dim3(256), 0, (hipStream_t)stream, rgb, depth, labels, table,
+                       rgb_out, depth_out, mask_out, H, W, S);
+    MSM_CHECK_LAUNCH("msm_crop_resize");
+    return MSM_OK;
+}
+
+extern "C" int msm_paste_labels(const float* renum, const int32_t* table, const int32_t* order, const int32_t* frame_start,
+                                float* refined, int F, int H, int W, int S, void* stream) {
+    MSM_REQUIRE(renum && table && order && frame_start && refined, "msm_paste_labels: null pointer");
+    MSM_REQUIRE(F >= 0 && H > 0 && W > 0 && S > 0, "msm_paste_labels: bad sizes");
+    if (F == 0) return MSM_OK;
+    hipLaunchKernelGGL(paste_labels_kernel, dim3(min(msm::cdiv(H * W, 256), 256), F), dim3(256), 0, (hipStream_t)stream, renum, table, order,
+                       frame_start, refined, H, W, S);
+    MSM_CHECK_LAUNCH("msm_paste_labels");
     return MSM_OK;
 }

@@ -869,6 +869,40 @@ def label_stats(labels, weight=None, k=1024):
     return stats, wsum, overflow
 
 
+def label_image(masks, inst_labels):
+    """masks (B,K,H,W) float (non-zero = inside), inst_labels (B,K) float -> (B,H,W) float label images (msm_label_image)."""
+    _c(masks, "masks"), _c(inst_labels, "inst_labels")
+    B, K, H, W = masks.shape
+    out = torch.empty((B, H, W), device=masks.device, dtype=torch.float32)
+    check(lib().msm_label_image(_p(masks), _p(inst_labels), _p(out), B, K, H, W, _stream()), "msm_label_image")
+    return out
+
+
+def crop_resize(rgb, depth, labels, table, size):
+    """ROI crops of a batch of frames in one launch (msm_crop_resize): rgb / depth (F,3,H,W), labels (F,H,W) float, table (N,8)
+    int32 rows (frame, label, x0, y0, x1, y1, 0, 0) -> (rgb_crops (N,3,S,S), mask_crops (N,S,S), depth_crops or None)."""
+    _c(rgb, "rgb"), _c(depth, "depth"), _c(labels, "labels"), _c(table, "table", torch.int32)
+    N = table.shape[0]
+    F_, _, H, W = rgb.shape
+    dev = rgb.device
+    rgb_out = torch.empty((N, 3, size, size), device=dev, dtype=torch.float32)
+    mask_out = torch.empty((N, size, size), device=dev, dtype=torch.float32)
+    depth_out = torch.empty((N, 3, size, size), device=dev, dtype=torch.float32) if depth is not None else None
+    check(lib().msm_crop_resize(_p(rgb), _p(depth), _p(labels), _p(table), _p(rgb_out), _p(depth_out), _p(mask_out), N, H, W, int(size),
+                                _stream()), "msm_crop_resize")
+    return rgb_out, mask_out, depth_out
+
+
+def paste_labels(renum, table, order, frame_start, frames, H, W):
+    """Paste-back of a batch (msm_paste_labels): renum (N,S,S) float, table (N,8) int32, order (N,) int32, frame_start (F+1,)
+    int32 -> refined (F,H,W) float."""
+    _c(renum, "renum"), _c(table, "table", torch.int32), _c(order, "order", torch.int32), _c(frame_start, "frame_start", torch.int32)
+    refined = torch.empty((frames, H, W), device=renum.device, dtype=torch.float32)
+    check(lib().msm_paste_labels(_p(renum), _p(table), _p(order), _p(frame_start), _p(refined), frames, H, W, renum.shape[-1], _stream()),
+          "msm_paste_labels")
+    return refined
+
+
 # ----------------------------------------------------------------------------------------------
 # fused encoder block (msdeformattn.py:122-131)
 # ----------------------------------------------------------------------------------------------

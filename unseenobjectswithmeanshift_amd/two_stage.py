@@ -267,3 +267,138 @@ def test_sample_crop_nolabel(sample, predictor, predictor_crop=None, *, use_dept
                 labels_crop[i] = torch.as_tensor(lab).to(dev)
             refined, _ = match_label_crop(out_label, labels_crop, out_label_crop, rois, depth_crop)
     return out_label, refined, out_score, bbox
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The same pipeline for a BATCH of frames (BASELINE configs[3]: batch = 16): lib/fcn/test_utils.py:375-406 is a serial
+# loop over frames and, inside it, over crops (batch 1 each).  Nothing couples two frames, so here the first stage runs
+# on all frames in one call, every frame's ROIs are cut in one launch (ops.crop_resize), all crops of all frames go
+# through the second stage in batches of `crop_batch`, and every frame's refined labels are pasted in one launch
+# (ops.paste_labels).  Two device -> host transfers per batch in all (the label statistics that define the ROIs, the
+# depth keys that order the paste).  Per frame the results are those of test_sample_crop_nolabel (non-NMS form).
+# ----------------------------------------------------------------------------------------------------------------------
+def _batch_tensors(predictor, samples):
+    """(scores (B,K), classes (B,K), masks (B,K,H,W)) of a list of samples: a predictor that exposes ``batch_tensors`` hands the
+    batched tensors of its model over as they are; otherwise the per-sample Instances are stacked (a copy)."""
+    if hasattr(predictor, "batch_tensors"):
+        return predictor.batch_tensors(samples)
+    outs = predictor.batch_call(samples) if hasattr(predictor, "batch_call") else [predictor(s) for s in samples]
+    inst = [o["instances"] for o in outs]
+    return (torch.stack([i.get("scores") for i in inst]), torch.stack([i.get("pred_classes") for i in inst]),
+            torch.stack([i.get("pred_masks") for i in inst]))
+
+
+def instance_labels(scores, classes, topk, confident_score, low_threshold, num_class):
+    """The label each instance carries in the label image (label_image above, batched): 2 + (kept instances before it), 0
+    when the instance is dropped (get_confident_instances, test_utils.py:35-52).  scores / classes (B,K) -> (B,K) float."""
+    if topk:
+        keep = ((classes == 1) & (scores > low_threshold)) if num_class >= 2 else torch.ones_like(scores, dtype=torch.bool)
+    else:
+        keep = scores > confident_score
+    return ((torch.cumsum(keep, 1) + 1) * keep).float()
+
+
+def roi_table(stats, overflow, H, W):
+    """Host side of crop_rois for a batch: stats (F,k,5) / overflow (F,) as numpy (ONE transfer) -> list of rows
+    [frame, label, x0, y0, x1, y1, 0, 0] in (frame, ascending label) order, boxes padded by 25 % and clipped
+    (test_dataset.py:76-92; round half to even like torch.round)."""
+    if overflow.any():
+        raise ValueError(f"label image values must be integers in [0, {LABEL_BINS})")
+    rows = []
+    for f in range(stats.shape[0]):
+        t = stats[f]
+        for v in np.nonzero(t[:, 0])[0]:
+            if v == 0:
+                continue
+            x0, y0, x1, y1 = (int(t[v, 1]), int(t[v, 2]), int(t[v, 3]), int(t[v, 4]))
+            xp, yp = int(round((x1 - x0) * PADDING_PERCENTAGE)), int(round((y1 - y0) * PADDING_PERCENTAGE))
+            rows.append([f, int(v), max(x0 - xp, 0), max(y0 - yp, 0), min(x1 + xp, W - 1), min(y1 + yp, H - 1), 0, 0])
+    return rows
+
+
+def match_label_crop_batched(initial_masks, labels_crop, out_label_crop, rows, depth_crop):
+    """match_label_crop for the crops of a whole batch of frames: initial_masks (F,H,W), labels_crop / out_label_crop
+    (N,S,S), rows = roi_table(...) (crop n belongs to frame rows[n][0]), depth_crop (N,3,S,S) or None.
+    Returns refined (F,H,W).  Same arithmetic per frame as match_label_crop; the renumbering restarts at 1 in every frame."""
+    from . import ops
+    Fr, H, W = initial_masks.shape
+    num = labels_crop.shape[0]
+    dev = labels_crop.device
+    if num == 0:
+        return torch.zeros_like(initial_masks).float()
+    k = int(LABEL_BINS)
+    stats, hit, _ = label_stats(labels_crop, out_label_crop)
+    area = stats[:, :, 0].reshape(-1)
+    lab = labels_crop.reshape(num, -1).to(torch.int64).clamp(0, k - 1) + torch.arange(num, device=dev)[:, None] * k
+    bad = (hit.reshape(-1) / area.float().clamp_min(1.0) < 0.5) & (area > 0)
+    labels_crop.masked_fill_(bad[lab].view_as(labels_crop), -1)
+    frame_of = [r[0] for r in rows]
+    if depth_crop is not None:
+        sel = (labels_crop > -1).reshape(num, -1)
+        z = depth_crop[:, 2].reshape(num, -1)
+        use = (sel | ~sel.any(1, keepdim=True)) & (z > 0)
+        keys = ((z * use).sum(1, dtype=torch.float64) / use.sum(1)).tolist()            # the batch's second (last) transfer
+    else:
+        keys = [float((r[5] - r[3] + 1) * (r[4] - r[2] + 1)) for r in rows]
+    # paste order inside a frame: descending key, ties and NaN exactly as sorted(reverse=True) leaves them in match_label_crop
+    order, frame_start = [], [0]
+    for f in range(Fr):
+        mine = [n for n in range(num) if frame_of[n] == f]
+        order += [mine[i] for i, _ in sorted(enumerate([keys[n] for n in mine]), key=lambda t: t[1], reverse=True)]
+        frame_start.append(len(order))
+    order_t = torch.tensor(order, device=dev)
+    alive = ((area > 0) & ~bad).view(num, k)[order_t]                                    # rows in (frame, paste) order
+    c = torch.cumsum(alive.reshape(-1), 0).view(num, k)
+    # numbers restart at 1 in every frame: subtract what was counted before the frame's first crop
+    before = torch.cat([c.new_zeros(1), c[:, -1]])[torch.tensor([frame_start[frame_of[n]] for n in order], device=dev)]
+    number = torch.zeros((num, k), dtype=torch.float32, device=dev)
+    number[order_t] = ((c - before[:, None]) * alive).float()
+    renum = number.view(-1)[lab].view(num, *labels_crop.shape[1:]).contiguous()
+    table = torch.tensor(rows, dtype=torch.int32, device=dev)
+    return ops.paste_labels(renum, table, order_t.to(torch.int32), torch.tensor(frame_start, dtype=torch.int32, device=dev), Fr, H, W)
+
+
+def test_batch_crop_nolabel(samples, predictor, predictor_crop=None, *, use_depth=True, topk=False, confident_score=0.7,
+                            low_threshold=0.4, num_class=2, depth_threshold=0.5, crop_batch=64, stages=None):
+    """test_sample_crop_nolabel (non-NMS form) for a list of frames of one size, batched end to end.
+    samples: [{"image_color" (3,H,W), "depth" (3,H,W), ...}, ...] on the GPU.  Returns (out_label (F,H,W), refined (F,H,W) or
+    None, rows) -- frame f's results equal test_sample_crop_nolabel(samples[f], ...)[0][0] / [1][0]; ``rows`` is the ROI table
+    (frame, label, x0, y0, x1, y1, 0, 0) of the second stage.  ``stages``: a dict that receives the intermediate tensors
+    (crops, second-stage label images) -- for tests."""
+    from . import ops
+    images = torch.stack([s["image_color"][0] if s["image_color"].dim() == 4 else s["image_color"] for s in samples]).float().contiguous()
+    if not images.is_cuda:
+        raise RuntimeError("test_batch_crop_nolabel runs on the GPU (HIP kernels for the label images, crops and paste-back)")
+    Fr, _, H, W = images.shape
+    depths = None
+    if use_depth:
+        depths = torch.stack([s["depth"][0] if s["depth"].dim() == 4 else s["depth"] for s in samples]).float().contiguous()
+    first = [{"image": images[f], "depth": depths[f] if depths is not None else None, "height": H, "width": W} for f in range(Fr)]
+    kw = dict(topk=topk, confident_score=confident_score, low_threshold=low_threshold, num_class=num_class)
+    scores, classes, masks = _batch_tensors(predictor, first)
+    out_label = ops.label_image(masks.float().contiguous(), instance_labels(scores, classes, **kw))
+    if depths is not None:
+        thr = torch.tensor([0.8 if "OSD" in str(s.get("file_name", "")) else depth_threshold for s in samples],
+                           device=images.device, dtype=torch.float32)[:, None]          # test_utils.py:384-387
+        out_label = filter_labels_depth(out_label, depths, thr)
+    if predictor_crop is None:
+        return out_label, None, []
+    stats, _, overflow = label_stats(out_label)
+    packed = torch.cat([stats.reshape(-1), overflow]).cpu().numpy()                      # the batch's first transfer
+    rows = roi_table(packed[:-Fr].reshape(Fr, -1, 5), packed[-Fr:], H, W)
+    n = len(rows)
+    if n == 0:
+        return out_label, torch.zeros_like(out_label), rows
+    table = torch.tensor(rows, dtype=torch.int32, device=images.device)
+    rgb_crop, mask_crop, depth_crop = ops.crop_resize(images, depths, out_label, table, CROP_SIZE)
+    labels_crop = torch.empty((n, CROP_SIZE, CROP_SIZE), device=images.device, dtype=torch.float32)
+    for c0 in range(0, n, crop_batch):
+        c1 = min(n, c0 + crop_batch)
+        crops = [{"image": rgb_crop[i], "height": CROP_SIZE, "width": CROP_SIZE,
+                  "depth": depth_crop[i] if depth_crop is not None else None} for i in range(c0, c1)]
+        s2, k2, m2 = _batch_tensors(predictor_crop, crops)
+        labels_crop[c0:c1] = ops.label_image(m2.float().contiguous(), instance_labels(s2, k2, **kw))
+    if stages is not None:
+        stages.update(rgb_crop=rgb_crop, mask_crop=mask_crop, depth_crop=depth_crop, labels_crop=labels_crop.clone())
+    refined = match_label_crop_batched(out_label, labels_crop, mask_crop, rows, depth_crop)
+    return out_label, refined, rows
