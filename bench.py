@@ -496,7 +496,7 @@ def extra_configs(dev, args):
     n_crops = len(run_batch()[2])
     out["configs[3]"] = {"workload": "two-stage RGB + depth-crop refinement, batch of 16 frames of 640x480: first stage on all 16 frames in one "
                                      "pass, depth filter, every ROI of every frame cut and resized to 224x224 in one launch, the crops of all "
-                                     "frames through the second stage in batches of 64, one paste-back launch; two device->host transfers per "
+                                     "frames through the second stage in one call, one paste-back launch; two device->host transfers per "
                                      "batch; stand-in backbone",
                          "value": round(16 / t, 1), "unit": "frames/sec", "ms_per_frame": round(1e3 * t / 16, 3), "ms_per_batch": round(1e3 * t, 2),
                          "crops_per_frame": round(n_crops / 16, 1),
