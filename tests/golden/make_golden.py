@@ -615,10 +615,85 @@ def g_instance_inference():
     save("instance_inference", **arrs)
 
 
+def detectron2_resnet50_keys():
+    """State-dict layout of detectron2's build_resnet_backbone at DEPTH 50, FrozenBN (its default NORM;
+    Base-COCO-InstanceSegmentation.yaml:2-15 leaves NORM commented out), STRIDE_IN_1X1 False: BasicStem ``stem.conv1`` and
+    BottleneckBlocks ``res{2..5}.{i}.{conv1,conv2,conv3[,shortcut]}``, every Conv2d followed by a FrozenBatchNorm2d stored under
+    ``<conv>.norm`` with buffers weight / bias / running_mean / running_var (no num_batches_tracked).  detectron2 is not
+    installed here: written from its documented module layout, independently of resnet_backbone.py."""
+    keys = {}
+
+    def conv(name, cout, cin, k):
+        keys[f"{name}.weight"] = (cout, cin, k, k)
+        for b in ("weight", "bias", "running_mean", "running_var"):
+            keys[f"{name}.norm.{b}"] = (cout,)
+
+    conv("stem.conv1", 64, 3, 7)
+    cin = 64
+    for stage, (blocks, bott, cout) in {"res2": (3, 64, 256), "res3": (4, 128, 512), "res4": (6, 256, 1024), "res5": (3, 512, 2048)}.items():
+        for i in range(blocks):
+            if i == 0:
+                conv(f"{stage}.{i}.shortcut", cout, cin, 1)
+            conv(f"{stage}.{i}.conv1", bott, cin, 1)
+            conv(f"{stage}.{i}.conv2", bott, bott, 3)
+            conv(f"{stage}.{i}.conv3", cout, bott, 1)
+            cin = cout
+    return keys
+
+
+def g_checkpoint_keys():
+    """Key list + shapes (NAMES ONLY, no values) of the checkpoints the reference publishes (README.md:86-95): what
+    detectron2's checkpointer saves for the meta-arch PretrainedMeanShiftMaskFormer under the two shipped configuration
+    families -- ``pretrained_backbone.*`` (the attribute the meta-arch keeps its backbone under, also for the ResNet-50,
+    pretrained_meanshiftformer_model.py:148-158), ``sem_seg_head.pixel_decoder.*`` / ``sem_seg_head.predictor.*`` from the
+    reference's own modules built as the yamls configure them, ``criterion.empty_weight`` (SetCriterion's buffer).  pixel_mean /
+    pixel_std are non-persistent buffers (:134-135) and are not saved."""
+    import importlib.util
+    import json
+    import types
+    out = {}
+    pd, dec = build_ref_pixel_decoder(), build_ref_decoder()
+    r50 = {f"pretrained_backbone.{k}": list(v) for k, v in detectron2_resnet50_keys().items()}
+    r50.update({f"sem_seg_head.pixel_decoder.{k}": list(v.shape) for k, v in pd.state_dict().items()})
+    r50.update({f"sem_seg_head.predictor.{k}": list(v.shape) for k, v in dec.state_dict().items()})
+    r50["criterion.empty_weight"] = [3]
+    out["mixture_ResNet50"] = r50
+    # UCN RGB-D family (mixture_UCN.yaml): SEGNET towers fcn / fcn_depth (lib/networks/SEG.py:69-71,97-110), torchvision-style BatchNorm
+    pkg = types.ModuleType("refnetworks")
+    pkg.__path__ = ["/root/reference/lib/networks"]
+    sys.modules["refnetworks"] = pkg
+    for name in ("resnet", "resnet_dilated"):
+        spec = importlib.util.spec_from_file_location(f"refnetworks.{name}", f"/root/reference/lib/networks/{name}.py")
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[f"refnetworks.{name}"] = mod
+        spec.loader.exec_module(mod)
+    RD = sys.modules["refnetworks.resnet_dilated"]
+    DEC = R.ref("modeling.transformer_decoder.meanshiftformer_transformer_decoder")
+    FPN = R.ref("modeling.pixel_decoder.fpn")
+    ucn = {}
+    for t in ("fcn", "fcn_depth"):
+        net = RD.Resnet34_8s(num_classes=64, input_channels=3, pretrained=False)
+        ucn.update({f"pretrained_backbone.{t}.{k}": list(v.shape) for k, v in net.state_dict().items()})
+    upd = FPN.SimpleBasePixelDecoder({"res5": R._ShapeSpec(channels=64, stride=1)}, conv_dim=64, mask_dim=256, norm="GN")
+    udec = DEC.PretrainedMeanShiftTransformerDecoder(
+        in_channels=64, mask_classification=True, num_classes=2, hidden_dim=256, num_queries=100, nheads=8,
+        dim_feedforward=2048, dec_layers=6, pre_norm=False, mask_dim=256, enforce_input_project=False,
+        use_meanshift_cross_attention=True, disable_attention_mask=False, use_meanshift_self_attention=True,
+        decoder_block_norm=True)
+    ucn.update({f"sem_seg_head.pixel_decoder.{k}": list(v.shape) for k, v in upd.state_dict().items()})
+    ucn.update({f"sem_seg_head.predictor.{k}": list(v.shape) for k, v in udec.state_dict().items()})
+    ucn["criterion.empty_weight"] = [3]
+    out["mixture_UCN"] = ucn
+    path = os.path.join(HERE, "checkpoint_keys.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print(f"checkpoint_keys: {os.path.getsize(path) / 1024:.1f} KiB, {len(r50)} + {len(ucn)} keys")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pe", "attn", "decoder", "msda", "msda_bwd", "pixel", "ms", "harness", "ucn", "ucn_backbone", "inst", "head_b8", "head_cfg5", "ucn_full", "dec_bwd"]
+    which = sys.argv[1:] or ["pe", "attn", "decoder", "msda", "msda_bwd", "pixel", "ms", "harness", "ucn", "ucn_backbone", "inst", "head_b8", "head_cfg5", "ucn_full", "dec_bwd", "ckpt_keys"]
     fns = {"pe": g_position_encoding, "attn": g_hypersphere_attention, "decoder": g_decoder,
            "msda": g_msda, "msda_bwd": g_msda_bwd, "pixel": g_pixel_decoder, "ms": g_mean_shift, "harness": g_harness, "ucn": g_ucn, "ucn_backbone": g_ucn_backbone,
-           "inst": g_instance_inference, "dec_bwd": g_decoder_backward, "head_b8": g_head_b8, "head_cfg5": g_head_cfg5, "ucn_full": g_ucn_full}
+           "inst": g_instance_inference, "dec_bwd": g_decoder_backward, "ckpt_keys": g_checkpoint_keys, "head_b8": g_head_b8, "head_cfg5": g_head_cfg5, "ucn_full": g_ucn_full}
     for w in which:
         fns[w]()

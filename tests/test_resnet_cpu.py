@@ -71,7 +71,7 @@ def test_reference_checkpoint_conversion_round_trip():
     ref_sd["module.criterion.empty_weight"] = torch.ones(3).numpy()
     ref_sd["module.pretrained_backbone.stem.conv1.norm.num_batches_tracked"] = torch.tensor(0).numpy()
     sd = ck.load_reference_checkpoint(model, {"model": ref_sd, "iteration": 17499})
-    assert all(not k.startswith(("criterion", "module", "pretrained_backbone")) for k in sd)
+    assert all(not k.startswith(("criterion", "module", "pretrained_backbone")) and not k.endswith("num_batches_tracked") for k in sd)
     for k, v in model.state_dict().items():
         assert torch.equal(v, sd[k]), k
     # v1 decoder checkpoints name the query features static_query (DEC:348-369)
@@ -91,3 +91,56 @@ def test_reference_checkpoint_conversion_round_trip():
     ucn = ck.convert_ucn_state_dict({"module.fcn.resnet34_8s.conv1.weight": torch.zeros(64, 3, 7, 7), "module.fcn.resnet34_8s.bn1.num_batches_tracked": torch.tensor(1),
                                      "foo": torch.zeros(1)})
     assert list(ucn) == ["fcn.resnet34_8s.conv1.weight"]
+
+
+def _fixture_checkpoint(layout, as_numpy):
+    """A checkpoint file's content in the published layout (tests/golden/checkpoint_keys.json: names and shapes taken from the
+    reference's own modules, make_golden.py::g_checkpoint_keys): seeded values, detectron2's {"model": ..., "iteration": ...}
+    wrapper, DistributedDataParallel's ``module.`` prefix on every key."""
+    g = torch.Generator().manual_seed(5)
+    sd = {}
+    for k, shape in layout.items():
+        if k.endswith("num_batches_tracked"):
+            t = torch.tensor(7, dtype=torch.int64)
+        elif k.endswith("running_var"):
+            t = torch.rand(shape, generator=g) + 0.5
+        else:
+            t = torch.randn(shape, generator=g) * 0.05
+        sd["module." + k] = t.numpy() if as_numpy else t
+    return {"model": sd, "iteration": 17499, "__author__": "fixture"}
+
+
+def test_published_checkpoint_layouts_load_strictly(tmp_path):
+    """f4: the key lists of the published checkpoints (README.md:86-95) -- the ResNet-50 / RGB family and the UCN / RGB-D
+    family -- as files: ``load_reference_checkpoint(model, path, strict=True)`` consumes every model key, drops exactly the
+    training-only entries, and reads the file tensors-only (no arbitrary unpickling), also when the values are numpy arrays as
+    in detectron2's converted pickles."""
+    import json
+    import os
+    from unseenobjectswithmeanshift_amd.meta_arch import build_resnet50_model, build_ucn_model
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "golden", "checkpoint_keys.json")) as f:
+        layouts = json.load(f)
+    for name, build, as_numpy in (("mixture_ResNet50", build_resnet50_model, False), ("mixture_UCN", build_ucn_model, True)):
+        layout = layouts[name]
+        model = build()
+        path = tmp_path / f"{name}.pth"
+        torch.save(_fixture_checkpoint(layout, as_numpy), path)
+        sd = ck.load_reference_checkpoint(model, str(path), strict=True)
+        mine = model.state_dict()
+        assert set(sd) == set(mine), (sorted(set(sd) ^ set(mine))[:6])
+        dropped = {k for k in layout if not (k.replace("pretrained_backbone.", "backbone.") in sd)}
+        assert all(k.startswith("criterion.") for k in dropped), sorted(dropped)[:6]
+        for k, v in mine.items():
+            src = "pretrained_backbone." + k[len("backbone."):] if k.startswith("backbone.") else k
+            assert tuple(v.shape) == tuple(layout[src]), k
+            assert torch.equal(v, sd[k]), k
+    # a file that needs a full unpickle is refused unless the caller opts in
+    class Evil:
+        def __reduce__(self):
+            return (print, ("arbitrary code ran",))
+    bad = tmp_path / "evil.pth"
+    torch.save({"model": {"x": Evil()}}, bad)
+    import pytest
+    with pytest.raises(Exception):
+        ck.load_checkpoint_file(str(bad))

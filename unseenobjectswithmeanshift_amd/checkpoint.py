@@ -12,7 +12,8 @@ parameter names, so conversion is a matter of prefixes:
     sem_seg_head.pixel_decoder.*     -> unchanged
     sem_seg_head.predictor.*         -> unchanged           (``static_query`` -> ``query_feat`` of v1 checkpoints is migrated by
                                                             the decoder's own _load_from_state_dict, as in the reference)
-    criterion.*, pixel_mean, pixel_std, *.num_batches_tracked -> dropped (training-only / non-persistent)
+    criterion.*, pixel_mean, pixel_std -> dropped (training-only / non-persistent); *.num_batches_tracked -> dropped unless
+                                          the model keeps such a buffer (the UCN towers do)
     module.* (DistributedDataParallel wrapper)                 -> stripped
 
 UCN ``SEGNET`` checkpoints (lib/networks/SEG.py) carry ``fcn.*`` / ``fcn_depth.*`` (optionally under ``module.``): they load
@@ -40,7 +41,7 @@ def convert_reference_state_dict(state_dict):
     for k, v in _unwrap(state_dict).items():
         if k.startswith("module."):
             k = k[len("module."):]
-        if k.startswith(_DROP_PREFIXES) or k in _DROP_KEYS or k.endswith("num_batches_tracked"):
+        if k.startswith(_DROP_PREFIXES) or k in _DROP_KEYS:
             continue
         if k.startswith("pretrained_backbone."):
             k = "backbone." + k[len("pretrained_backbone."):]
@@ -90,6 +91,10 @@ def load_reference_checkpoint(model, checkpoint, strict=True, unsafe=False):
     sd = convert_reference_state_dict(checkpoint)
     if getattr(model, "backbone", None) is None:
         sd = {k: v for k, v in sd.items() if not k.startswith("backbone.")}
+    # BatchNorm step counters: kept where the model has them (the UCN towers keep torchvision's BatchNorm layout), dropped where
+    # it does not (a backbone whose frozen BatchNorm is folded away)
+    have = set(model.state_dict())
+    sd = {k: v for k, v in sd.items() if not k.endswith("num_batches_tracked") or k in have}
     missing, unexpected = model.load_state_dict(sd, strict=False)
     if strict and (missing or unexpected):
         raise RuntimeError(f"load_reference_checkpoint: missing keys {sorted(missing)[:8]}{'...' if len(missing) > 8 else ''}, "
