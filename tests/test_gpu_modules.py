@@ -531,6 +531,27 @@ def test_resnet50_backbone_on_gpu_and_end_to_end():
     # a frame that is not a multiple of 32 is padded for the network and cropped back
     res2 = model([{"image": images[:1, :, :50, :70].contiguous().to(DEV)}])
     assert res2[0]["instances"].pred_masks.shape == (20, 50, 70)
+    # the whole model from ONE HIP graph (backbone included) gives the eager path's results (MIOpen may pick another
+    # convolution algorithm while capturing, so the features agree to fp32 rounding, not bitwise)
+    gr = model.graphed(entry="inference_images")
+    eager = model.inference_images({"image": images.to(DEV)}, (64, 96))
+    replay = gr({"image": images.to(DEV)}, (64, 96))
+    torch.testing.assert_close(replay[0], eager[0], rtol=1e-3, atol=1e-4)                       # scores
+    assert float((replay[2] != eager[2]).float().mean()) < 1e-3                                  # masks
+    again = [t.clone() for t in gr({"image": images.to(DEV)}, (64, 96))]          # (MIOpen's kernels are not run-to-run bitwise either)
+    torch.testing.assert_close(gr({"image": images.to(DEV)}, (64, 96))[0], again[0], rtol=1e-3, atol=1e-4)
+    # bf16 mode of the backbone (MIOpen bf16 convolutions, fp32 accumulation; fp32 maps out): 53 layers of bf16 rounding on
+    # random-init weights stay within a few percent of the fp32 maps
+    model.set_precision("bf16")
+    assert model.backbone.backbone_dtype == "bf16"
+    low = model.backbone(images.to(DEV))
+    model.set_precision("f32")
+    for k in ("res2", "res3", "res4", "res5"):
+        assert low[k].dtype == torch.float32 and low[k].is_contiguous()
+        rel = float((low[k] - got[k]).norm() / got[k].norm())
+        print(f"bf16 backbone {k}: relative error {rel:.3e}")
+        assert rel < 5e-2
+    torch.testing.assert_close(model.backbone(images.to(DEV))["res5"], got["res5"], rtol=1e-4, atol=1e-5)    # back on the fp32 plan
 
 
 def test_ucn_model_end_to_end():

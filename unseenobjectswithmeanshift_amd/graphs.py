@@ -85,8 +85,9 @@ class GraphedInference:
     replayed from a HIP graph.  ``features``: dict of device tensors.  The returned tensors are owned by the graph and
     are overwritten by the next call with the same geometry: ``.clone()`` what must outlive it."""
 
-    def __init__(self, model, warmup=2, strict=False):
+    def __init__(self, model, warmup=2, strict=False, entry="inference"):
         self.model = model
+        self.entry = entry             # the model method that is captured: "inference" (features in) or "inference_images" (backbone included)
         self.warmup = max(1, int(warmup))
         self._graphs = {}
         self._stream = None
@@ -117,12 +118,13 @@ class GraphedInference:
             cur = torch.cuda.current_stream()
             self._stream.wait_stream(cur)
             with torch.cuda.stream(self._stream):
+                run = getattr(self.model, self.entry)
                 for _ in range(self.warmup):                       # builds every weight cache outside the capture
-                    self.model.inference(static_in, image_size, padded_size)
+                    run(static_in, image_size, padded_size)
                 self._stream.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=self._stream):
-                    static_out = self.model.inference(static_in, image_size, padded_size)
+                    static_out = run(static_in, image_size, padded_size)
             cur.wait_stream(self._stream)
             entry = (graph, static_in, static_out, sig, cache_refs(self.model))
             self._graphs[key] = entry

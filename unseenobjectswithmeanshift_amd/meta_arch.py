@@ -178,19 +178,33 @@ class MeanShiftMaskFormer(PlanAttributes, nn.Module):
                                                         padded_size=padded_size)
         return scores, classes, masks, boxes, qidx
 
+    @torch.no_grad()
+    def inference_images(self, inputs, image_size, padded_size=None):
+        """``inference`` with the backbone in front: inputs {"image": (B,3,Hp,Wp)[, "depth": (B,3,Hp,Wp)]} already padded to the
+        size divisibility (and normalised, if this meta-arch normalises).  One call = the whole model; ``graphed(entry=
+        "inference_images")`` replays it from a HIP graph (MIOpen's convolutions capture like any other launch once their
+        algorithms have been chosen by the warm-up passes)."""
+        if self.backbone is None:
+            raise RuntimeError("inference_images needs a backbone")
+        feats = self.backbone(inputs["image"], inputs["depth"]) if "depth" in inputs else self.backbone(inputs["image"])
+        return self.inference(feats, image_size, padded_size)
+
     def set_precision(self, mode):
-        """See MeanShiftMaskFormerHead.set_precision."""
+        """See MeanShiftMaskFormerHead.set_precision; a backbone with a ``backbone_dtype`` switch (ResNet50Backbone) follows."""
         self.sem_seg_head.set_precision(mode)
+        if hasattr(self.backbone, "backbone_dtype"):
+            self.backbone.backbone_dtype = "bf16" if mode == "bf16" else "f32"
         return self
 
     @property
     def precision(self):
         return getattr(self.sem_seg_head, "precision", "f32")
 
-    def graphed(self, warmup=2):
-        """HIP-graph replayed ``inference`` (graphs.GraphedInference): same results, no per-launch host cost."""
+    def graphed(self, warmup=2, entry="inference"):
+        """HIP-graph replayed ``inference`` (graphs.GraphedInference): same results, no per-launch host cost.
+        entry="inference_images": the backbone is part of the graph (inputs {"image": ...})."""
         from .graphs import GraphedInference
-        return GraphedInference(self, warmup=warmup)
+        return GraphedInference(self, warmup=warmup, entry=entry)
 
     def pipelined(self, depth=2, warmup=2):
         """Throughput mode (graphs.PipelinedInference): ``depth`` batches in flight, one HIP graph and stream each."""

@@ -25,7 +25,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ._plan import version_key
+from ._plan import PlanAttributes, version_key
 
 STAGE_BLOCKS = {"res2": 3, "res3": 4, "res4": 6, "res5": 3}          # DEPTH 50
 STAGE_WIDTHS = {"res2": (64, 256), "res3": (128, 512), "res4": (256, 1024), "res5": (512, 2048)}     # (bottleneck, out)
@@ -89,7 +89,7 @@ class BottleneckBlock(nn.Module):
         return F.relu(y + (x if self.shortcut is None else self.shortcut(x)))
 
 
-class ResNet50Backbone(nn.Module):
+class ResNet50Backbone(PlanAttributes, nn.Module):
     """``forward(images (B,3,H,W)) -> {"res2": (B,256,H/4,W/4), "res3": (B,512,H/8,W/8), "res4": (B,1024,H/16,W/16),
     "res5": (B,2048,H/32,W/32)}``; H, W multiples of 32 (the meta-arch pads).  ``folded=False`` evaluates the unfolded
     definition (conv, frozen BN, ReLU as separate ops) -- the reference the folding is tested against."""
@@ -108,6 +108,10 @@ class ResNet50Backbone(nn.Module):
         self.size_divisibility = 32
         self._plan_cache = None
         self._plan_tensors = None
+        # "f32": MIOpen fp32 convolutions (default).  "bf16": the folded weights and the activations in bfloat16 (MIOpen's
+        # bf16 convolutions accumulate in fp32), the four output maps converted back to fp32 -- the low-precision mode of
+        # BASELINE configs[2] / [4] (the reference's counterpart is autocast over the whole model)
+        self.backbone_dtype = "f32"
 
     def output_shape(self):
         from .modeling import ShapeSpec
@@ -116,14 +120,22 @@ class ResNet50Backbone(nn.Module):
     def _plan(self):
         if self._plan_tensors is None:
             self._plan_tensors = list(self.parameters()) + list(self.buffers())
-        key = version_key(self._plan_tensors)
+        if self.backbone_dtype not in ("f32", "bf16"):
+            raise ValueError("backbone_dtype must be 'f32' or 'bf16'")
+        low = self.backbone_dtype == "bf16"
+        key = version_key(self._plan_tensors) + (low,)
         if self._plan_cache is None or self._plan_cache[0] != key:
             with torch.no_grad():
                 stages = []
                 for name in ("res2", "res3", "res4", "res5"):
                     stages.append([(blk.conv1.folded(), blk.conv2.folded(), blk.conv3.folded(),
                                     None if blk.shortcut is None else blk.shortcut.folded(), blk.conv2.stride) for blk in getattr(self, name)])
-                self._plan_cache = (key, self.stem.conv1.folded(), stages)
+                stem = self.stem.conv1.folded()
+                if low:
+                    cast = lambda wb: None if wb is None else (wb[0].to(torch.bfloat16).contiguous(memory_format=torch.channels_last), wb[1].to(torch.bfloat16))
+                    stem = cast(stem)
+                    stages = [[(cast(a), cast(b), cast(c), cast(sc), st) for a, b, c, sc, st in blocks] for blocks in stages]
+                self._plan_cache = (key, stem, stages)
         return self._plan_cache[1:]
 
     @torch.no_grad()
@@ -148,5 +160,5 @@ class ResNet50Backbone(nn.Module):
                 y = F.conv2d(y, w3, b3)
                 x = F.relu(y + (x if sc is None else F.conv2d(x, sc[0], sc[1], stride=stride)))
             if name in self.out_features:
-                out[name] = x.contiguous()                       # NCHW planes for the pixel decoder's input projections
+                out[name] = (x.float() if x.dtype == torch.bfloat16 else x).contiguous()      # NCHW planes for the pixel decoder's input projections (fp32 also in the bf16 mode)
         return out
