@@ -177,6 +177,15 @@ int msm_mask_logits_bf16_fwd(const float* mask_embed, const uint16_t* mask_feat_
                              int B, int Q, int C, int H, int W, int th, int tw, int flags,
                              int64_t embed_ld, const float* qbias, int64_t qbias_ld, void* stream);
 
+/* The folded (64-channel) mask step in fp32 accuracy on the bf16 matrix pipe (precision mode f32_split): both operands as exact
+ * three-term bf16 splits, six v_mfma_f32_16x16x32_bf16 per product with fp32 accumulation (the dropped terms are below 2^-26
+ * of a product).  msm_pack_mask_features_split: fp32 NCHW [B][64][HW] -> [B][3 terms][8][HW][8] bf16, once per forward;
+ * msm_mask_logits_split_fwd: arguments as msm_mask_logits_bf16_fwd, C must be 64. */
+int msm_pack_mask_features_split(const float* mask_feat, uint16_t* packed, int B, int C, int HW, void* stream);
+int msm_mask_logits_split_fwd(const float* mask_embed, const uint16_t* mask_feat_split, float* mask_out,
+                              uint8_t* attn_out, int32_t* row_any, int B, int Q, int C, int H, int W, int th, int tw,
+                              int flags, int64_t embed_ld, const float* qbias, int64_t qbias_ld, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Multi-head hypersphere (vMF) attention core (AU:64-82) on already projected q/k/v:
  *   q [B][Lq][E], k,v [B][S][E] with per-batch strides (elements) q_sb, k_sb, v_sb and row

@@ -1014,3 +1014,46 @@ def test_connected_components_on_device(S, centres, noise, seed):
     assert torch.equal(got.cpu(), want)
     assert int(num) >= int(want.max()) + 1 and int(num) <= S
     assert torch.equal(ms.connected_components(Z.to(DEV), 0.04).cpu(), want)
+
+
+@pytest.mark.parametrize("B,Q,H,W,pool", [(2, 100, 16, 24, 2), (2, 100, 16, 24, 4), (8, 100, 120, 160, 8), (1, 100, 120, 160, 4),
+                                          (2, 100, 120, 160, 2), (1, 300, 48, 64, 4), (2, 20, 8, 8, 2), (2, 100, 16, 24, 1), (1, 37, 18, 22, 2)])
+def test_mask_logits_split_is_fp32_accurate(B, Q, H, W, pool):
+    """msm_mask_logits_split_fwd (precision mode f32_split): the folded 64-channel mask step as six bf16 MFMAs per product on
+    exact three-term splits of both operands.  An fp32 kernel in everything but the instruction it multiplies with: logits
+    against the float64 einsum with an error no larger than 1.5x the fp32-MFMA kernel's (measured side by side, printed), the
+    same attention-bit rules as test_mask_logits_folded_form."""
+    C = 64
+    wide = rnd(B, Q, 256, seed=1, scale=0.3)
+    e, qb = wide[..., :C], wide[..., 64]
+    f = rnd(B, C, H, W, seed=2)
+    tgt = (H // pool, W // pool)
+    full = torch.einsum("bqc,bchw->bqhw", e.double(), f.double()) + qb.double()[..., None, None]
+    pooled = F.interpolate(full.float(), size=tgt, mode="bilinear", align_corners=False)
+    attn_ref = pooled.sigmoid().flatten(2) < 0.5
+    wd, fd = wide.to(DEV), f.to(DEV)
+    packed = ops().pack_mask_features_split(fd)
+    # the three terms reproduce the activation exactly: h + m + l == x in fp32
+    terms = packed.view(torch.bfloat16).float()                                    # (B, 3, 8, HW, 8)
+    back = (terms[:, 0] + terms[:, 1] + terms[:, 2]).permute(0, 1, 3, 2).reshape(B, C, H, W)
+    assert torch.equal(back, fd)
+    for want_mask, sparse in ((True, False), (False, False), (False, True)):
+        mask, attn, row_any = ops().mask_logits(wd[..., :C], fd, want_mask=want_mask, target_size=tgt, sparse=sparse, qbias=wd[..., 64],
+                                                packed_split=packed)
+        if want_mask:
+            m32, _, _ = ops().mask_logits(wd[..., :C], fd, want_mask=True, target_size=tgt, qbias=wd[..., 64])
+            err_s = (mask.cpu().double() - full).abs()
+            err_f = (m32.cpu().double() - full).abs()
+            print(f"split mask step B={B} {H}x{W}: mean |err| {float(err_s.mean()):.3e} (fp32 MFMA {float(err_f.mean()):.3e}), "
+                  f"max {float(err_s.max()):.3e} ({float(err_f.max()):.3e})")
+            assert float(err_s.mean()) <= 1.5 * float(err_f.mean()) + 1e-9 and float(err_s.max()) <= 1.5 * float(err_f.max()) + 1e-7
+            close(mask, full.float(), rtol=1e-4, atol=1e-4)
+        got = attn.cpu().bool()
+        diff = got != attn_ref
+        if diff.any():
+            assert pooled.flatten(2)[diff].abs().max() < 1e-4
+        assert diff.float().mean() <= 1e-4
+        assert torch.equal(row_any.cpu().bool(), ~attn.cpu().bool().all(-1))
+    mask, attn, row_any = ops().mask_logits(wd[..., :C], fd, want_mask=True, target_size=None, qbias=wd[..., 64], packed_split=packed)
+    close(mask, full.float(), rtol=1e-4, atol=1e-4)
+    assert attn is None and row_any is None

@@ -38,6 +38,8 @@ _SIGNATURES = {
     "msm_mask_logits_fwd": (c_i, [c_f, c_f, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_f, c_l, c_p]),
     "msm_pack_mask_features_bf16": (c_i, [c_f, c_p, c_i, c_i, c_i, c_p]),
     "msm_mask_logits_bf16_fwd": (c_i, [c_f, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_f, c_l, c_p]),
+    "msm_pack_mask_features_split": (c_i, [c_f, c_p, c_i, c_i, c_i, c_p]),
+    "msm_mask_logits_split_fwd": (c_i, [c_f, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_f, c_l, c_p]),
     "msm_hypersphere_attn_workspace": (c_l, [c_i, c_i, c_i, c_i]),
     "msm_hypersphere_attn_fwd": (c_i, [c_f, c_f, c_f, c_p, c_p, c_f, c_i, c_i, c_i, c_i,
                                        c_l, c_l, c_l, c_l, c_l, c_l, c_fl, c_f, c_l, c_p]),

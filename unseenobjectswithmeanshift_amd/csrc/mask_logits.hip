@@ -23,6 +23,7 @@
 
 #include <type_traits>
 
+#include "bf16.h"
 #include "common.h"
 
 namespace msm {
@@ -688,7 +689,6 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_kernel(const float* __res
 // (msm_pack_mask_features_bf16): the MFMA B operand of lane (pixel lj, k-group lq) is then ONE 8-byte load and the 16
 // pixels of a k-group are a 128-byte line.  A whole tile's operands (32 loads) are requested while the previous tile
 // is being multiplied.  Tile shape, schedule and the fused attention-mask epilogue are those of the fp32 kernel.
-typedef short bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int BKS = 16;            // 16-channel k-steps held per tile: C <= 256
 
 __device__ __forceinline__ unsigned short f2bf(float x) {   // round to nearest even
@@ -829,6 +829,168 @@ __global__ __launch_bounds__(256) void pack_mask_features_bf16_kernel(const floa
         pk.x = (unsigned)f2bf(src[0]) | ((unsigned)f2bf(src[HW]) << 16);
         pk.y = (unsigned)f2bf(src[2 * (int64_t)HW]) | ((unsigned)f2bf(src[3 * (int64_t)HW]) << 16);
         *reinterpret_cast<u32x2*>(out + i * 4) = pk;
+    }
+}
+
+// ---- fp32-accurate mask step on the bf16 matrix pipe (precision mode f32_split; folded form, C = 64) -------------------------
+// The construction of enc_block_split.hip applied to the mask step: both operands as exact three-term bf16
+// splits x = h + m + l, a product as the six cross terms of weight >= 2^-18 -- l.h, h.l, m.m, m.h, h.m, h.h, every
+// bf16 x bf16 product exact in the fp32 accumulator -- on v_mfma_f32_16x16x32_bf16: 12 MFMAs of 16 cycles per 16-pixel x
+// 16-query block and image row instead of 16 fp32 MFMAs of 32 cycles.  The 64-channel activation is split ONCE per forward
+// (msm_pack_mask_features_split: [B][3 terms][C/8][HW][8] bf16, a lane's A operand = one 16-byte load), mask_embed when a
+// workgroup stages its query chunk (three bf16 copies in LDS).  Tile shape, schedule, per-query bias as the accumulators'
+// initial value and the fused attention-mask epilogue are those of the kernels above.
+constexpr int SPK = 2;             // K = 32 k-steps: C = 64
+template <int POOL, bool WRITE>
+__global__ __launch_bounds__(MW * 64) void mask_logits_split_kernel(const float* __restrict__ emb, const unsigned short* __restrict__ featp,
+                                                                float* __restrict__ mask_out, uint8_t* __restrict__ attn_out,
+                                                                int32_t* __restrict__ row_any, int Q, int C, int H, int W, int th,
+                                                                int tw, int ypar, int n_rowpairs, int rp_step, int rp_first,
+                                                                int feat_bytes, int64_t emb_ld, const float* __restrict__ qbias,
+                                                                int64_t qbias_ld) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short Esp[];   // [3 terms][QCH][C + 8] bf16, then [QCH] fp32 biases, [QCH] flags
+    constexpr int SE = 64 + 8;         // 144-byte rows: 16-byte aligned b128 reads
+    const int b = blockIdx.z, qc = blockIdx.y;
+    const int q0 = qc * QCH;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    const int HW = H * W;
+
+    const float* eb = emb + ((int64_t)b * Q + q0) * emb_ld;
+    float* qb = reinterpret_cast<float*>(Esp + 3 * QCH * SE);
+    int* any_flags = reinterpret_cast<int*>(qb + QCH);
+    for (int r = tid; r < QCH; r += MW * 64) {
+        qb[r] = (qbias && q0 + r < Q) ? qbias[((int64_t)b * Q + q0 + r) * qbias_ld] : 0.f;
+        any_flags[r] = 0;
+    }
+    for (int idx = tid; idx < QCH * (64 / 4); idx += MW * 64) {
+        const int r = idx / 16, c4 = (idx - r * 16) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q0 + r < Q) v = *reinterpret_cast<const float4*>(eb + (int64_t)r * emb_ld + c4);
+        const Split3 sp = split3(v.x, v.y, v.z, v.w);
+        *reinterpret_cast<u32x2*>(&Esp[(0 * QCH + r) * SE + c4]) = __builtin_bit_cast(u32x2, sp.h);
+        *reinterpret_cast<u32x2*>(&Esp[(1 * QCH + r) * SE + c4]) = __builtin_bit_cast(u32x2, sp.m);
+        *reinterpret_cast<u32x2*>(&Esp[(2 * QCH + r) * SE + c4]) = __builtin_bit_cast(u32x2, sp.l);
+    }
+    __syncthreads();
+
+    const int ctiles = (W + 15) / 16;
+    const int ntiles = n_rowpairs * ctiles;
+    const uint64_t fbu = (uint64_t)(featp + (int64_t)b * 3 * C * HW);
+    const uint64_t fbs = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(fbu >> 32)) << 32) |
+                         (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)fbu);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)fbs, 0, feat_bytes, 0x00020000);
+
+    const int slots = gridDim.x * MW;
+    const int full_rounds = ntiles / slots;
+    const int left = ntiles - full_rounds * slots;
+    const int left_slot = (wave >> 2) * ((int)gridDim.x * 4) + (int)blockIdx.x * 4 + (wave & 3);
+    const int my_tiles = full_rounds + (left_slot < left ? 1 : 0);
+    auto tile_of = [&](int it) {
+        return (it < full_rounds) ? it * slots + (int)blockIdx.x * MW + wave : full_rounds * slots + left_slot;
+    };
+    struct TileRegs {
+        u32x4b t[SPK][3], bt[SPK][3];          // [k-step][term]: top / bottom image row
+    };
+    auto load_tile = [&](int t, TileRegs& r) {
+        const int rp = t / ctiles, ct = t - rp * ctiles;
+        const int ytop = ypar + 2 * (rp_first + rp * rp_step), ybot = ytop + 1;
+        const int c = ct * 16 + PixMap<POOL, 1>::load_col(lj);
+        const int cl = c < W ? c : 0;
+        // packed element (term, k-octet kg = ks*4 + lq, pixel): 16 bytes at ((term * C/8 + kg) * HW + pixel) * 16
+        const unsigned voff_top = (unsigned)(((int64_t)lq * HW + (int64_t)max(ytop, 0) * W + cl) * 16);
+        const unsigned voff_bot = (unsigned)(((int64_t)lq * HW + (int64_t)min(ybot, H - 1) * W + cl) * 16);
+#pragma unroll
+        for (int ks = 0; ks < SPK; ++ks)
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm) {
+                const unsigned soff = (unsigned)(tm * (64 / 8) + ks * 4) * (unsigned)HW * 16u;
+                r.t[ks][tm] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_top, soff, 0);
+                r.bt[ks][tm] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_bot, soff, 0);
+            }
+    };
+    MaskEpiConst<POOL, WRITE, 1> epi;
+    mask_epi_init<POOL, WRITE, 1>(epi, mask_out, attn_out, b, Q, q0, H, W, th, tw, lj, lq);
+    TileRegs cur, nxt;
+    if (my_tiles > 0) load_tile(tile_of(0), cur);
+    for (int it = 0; it < my_tiles; ++it) {
+        const int t = tile_of(it);
+        const int rp = t / ctiles, ct = t - rp * ctiles;
+        const int ytop = ypar + 2 * (rp_first + rp * rp_step);
+        const int ybot = ytop + 1;
+        const int c0 = ct * 16;
+        load_tile(tile_of(min(it + 1, my_tiles - 1)), nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[QB][2];
+#pragma unroll
+        for (int m = 0; m < QB; ++m) { const float q_b = qb[m * 16 + lj]; acc[m][0] = acc[m][1] = f32x4{q_b, q_b, q_b, q_b}; }
+#pragma unroll
+        for (int ks = 0; ks < SPK; ++ks) {
+            bf16x8 ft[3], fb[3];
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm) {
+                ft[tm] = __builtin_bit_cast(bf16x8, cur.t[ks][tm]);
+                fb[tm] = __builtin_bit_cast(bf16x8, cur.bt[ks][tm]);
+            }
+            // query blocks in pairs: the six terms of a pair's four accumulators interleave (no back-to-back dependent MFMAs)
+#pragma unroll
+            for (int m0 = 0; m0 < QB; m0 += 2) {
+                bf16x8 e[2][3];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int tm = 0; tm < 3; ++tm)
+                        if (m0 + j < QB)
+                            e[j][tm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4b*>(&Esp[(tm * QCH + (m0 + j) * 16 + lj) * SE + ks * 32 + lq * 8]));
+                // (feature term, embedding term) of the six products, small ones first: l.h, h.l, m.m, m.h, h.m, h.h
+                constexpr int FT[6] = {2, 0, 1, 1, 0, 0}, ET[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int p = 0; p < 6; ++p)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        if (m0 + j < QB) {
+                            acc[m0 + j][0] = mfma_bf16k32(ft[FT[p]], e[j][ET[p]], acc[m0 + j][0]);      // D[pixel][query]
+                            acc[m0 + j][1] = mfma_bf16k32(fb[FT[p]], e[j][ET[p]], acc[m0 + j][1]);
+                        }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const bool inside = c0 + 16 <= W;                                             // wave-uniform
+        if constexpr (WRITE) {
+            if (inside && epi.write_fast) mask_tile_epilogue_fast<POOL, WRITE, 1, true, false>(acc, epi, H, W, tw, ytop, ybot, c0);
+            else mask_tile_epilogue<POOL, WRITE, 1, true, false>(acc, mask_out, attn_out, any_flags, b, Q, q0, H, W, th, tw, ytop, ybot, c0, lj, lq);
+        }
+        if (inside && epi.attn_fast) mask_tile_epilogue_fast<POOL, WRITE, 1, false, true>(acc, epi, H, W, tw, ytop, ybot, c0);
+        else mask_tile_epilogue<POOL, WRITE, 1, false, true>(acc, mask_out, attn_out, any_flags, b, Q, q0, H, W, th, tw, ytop, ybot, c0, lj, lq);
+        cur = nxt;
+    }
+    if constexpr (POOL != 0) {
+        mask_epi_flush<POOL, WRITE, 1>(epi, any_flags, lj);
+        __syncthreads();
+        for (int r = tid; r < QCH; r += MW * 64)
+            if (any_flags[r] && q0 + r < Q) row_any[(int64_t)b * Q + q0 + r] = 1;
+    }
+}
+
+// fp32 NCHW [B][C][HW] -> the exact three-term bf16 split [B][3][C/8][HW][8]: x = h + m + l (bf16.h split3)
+__global__ __launch_bounds__(256) void pack_mask_features_split_kernel(const float* __restrict__ in, unsigned short* __restrict__ out,
+                                                                       int64_t total, int C8, int HW) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int p = (int)(i % HW);
+        const int64_t r = i / HW;                 // b * C8 + kg
+        const int64_t bimg = r / C8;
+        const int kg = (int)(r - bimg * C8);
+        const float* src = in + (r * 8) * HW + p;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[(int64_t)j * HW];
+        const Split3 a = split3(v[0], v[1], v[2], v[3]), c = split3(v[4], v[5], v[6], v[7]);
+        const Split3x8 s8 = join(a, c);
+        unsigned short* dst = out + ((bimg * 3 * C8 + kg) * (int64_t)HW + p) * 8;
+        *reinterpret_cast<u32x4b*>(dst) = __builtin_bit_cast(u32x4b, s8.h);
+        *reinterpret_cast<u32x4b*>(dst + (int64_t)C8 * HW * 8) = __builtin_bit_cast(u32x4b, s8.m);
+        *reinterpret_cast<u32x4b*>(dst + 2 * (int64_t)C8 * HW * 8) = __builtin_bit_cast(u32x4b, s8.l);
     }
 }
 
@@ -1010,5 +1172,75 @@ extern "C" int msm_mask_logits_bf16_fwd(const float* mask_embed, const uint16_t*
     hipLaunchKernelGGL(kern, grid, block, lds, st, mask_embed, mask_feat_packed, mask_out, attn_out, row_any, Q, C, H, W, th, tw, ypar,
                        n_rowpairs, rp_step, rp_first, (int)((int64_t)C * H * W * 2), embed_ld, qbias, qbias_ld);
     MSM_CHECK_LAUNCH("msm_mask_logits_bf16_fwd");
+    return MSM_OK;
+}
+
+extern "C" int msm_pack_mask_features_split(const float* mask_feat, uint16_t* packed, int B, int C, int HW, void* stream) {
+    MSM_REQUIRE(mask_feat && packed, "msm_pack_mask_features_split: null pointer");
+    MSM_REQUIRE(B > 0 && C == 64 && HW > 0, "msm_pack_mask_features_split: C=%d, the split mask step takes the 64-channel folded form", C);
+    MSM_REQUIRE((((uintptr_t)packed) & 15) == 0, "msm_pack_mask_features_split: output must be 16-byte aligned");
+    const int64_t total = (int64_t)B * (C / 8) * HW;
+    hipLaunchKernelGGL(pack_mask_features_split_kernel, dim3((unsigned)min((int64_t)4096, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       mask_feat, packed, total, C / 8, HW);
+    MSM_CHECK_LAUNCH("msm_pack_mask_features_split");
+    return MSM_OK;
+}
+
+extern "C" int msm_mask_logits_split_fwd(const float* mask_embed, const uint16_t* mask_feat_split, float* mask_out,
+                                         uint8_t* attn_out, int32_t* row_any, int B, int Q, int C, int H, int W, int th, int tw,
+                                         int flags, int64_t embed_ld, const float* qbias, int64_t qbias_ld, void* stream) {
+    const int sparse = flags & MSM_MASK_SPARSE;
+    MSM_REQUIRE(mask_embed && mask_feat_split, "msm_mask_logits_split_fwd: null input");
+    MSM_REQUIRE(mask_out || attn_out, "msm_mask_logits_split_fwd: nothing to produce");
+    MSM_REQUIRE(B > 0 && Q > 0 && H > 1 && W > 1, "msm_mask_logits_split_fwd: bad sizes");
+    MSM_REQUIRE(C == 64, "msm_mask_logits_split_fwd: C=%d, only the 64-channel folded form", C);
+    if (int rc = mask_embed_check("msm_mask_logits_split_fwd", mask_embed, embed_ld, qbias, qbias_ld, C)) return rc;
+    MSM_REQUIRE(W % 2 == 0 && H % 2 == 0, "msm_mask_logits_split_fwd: H=%d W=%d must be even", H, W);
+    MSM_REQUIRE((int64_t)3 * C * H * W * 2 < (int64_t)1 << 31, "msm_mask_logits_split_fwd: one image of the split features must be < 2 GiB");
+    MSM_REQUIRE((((uintptr_t)mask_embed) & 15) == 0 && (((uintptr_t)mask_feat_split) & 15) == 0, "msm_mask_logits_split_fwd: misaligned pointer");
+    int pool = 0;
+    if (attn_out) {
+        MSM_REQUIRE(row_any, "msm_mask_logits_split_fwd: row_any required with attn_out");
+        MSM_REQUIRE(th > 0 && tw > 0 && H % th == 0 && W % tw == 0 && H / th == W / tw,
+                    "msm_mask_logits_split_fwd: target %dx%d incompatible with %dx%d", th, tw, H, W);
+        pool = H / th;
+        MSM_REQUIRE(pool == 1 || pool == 2 || pool == 4 || pool == 8, "msm_mask_logits_split_fwd: pool factor %d not in {1,2,4,8}", pool);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (attn_out && !(flags & MSM_MASK_ROW_ANY_CLEARED)) MSM_CHECK_HIP(hipMemsetAsync(row_any, 0, sizeof(int32_t) * (size_t)B * Q, st));
+    int ypar = 0, n_rowpairs = H / 2, rp_step = 1, rp_first = 0;      // row pairing exactly as msm_mask_logits_fwd
+    if (pool == 4 || pool == 8) {
+        ypar = -1;
+        n_rowpairs = H / 2 + 1;
+        if (sparse && !mask_out) {
+            rp_step = pool / 2;
+            rp_first = pool / 4;
+            n_rowpairs = H / pool;
+        }
+    }
+    const int qchunks = cdiv(Q, QCH);
+    const int ntiles = n_rowpairs * cdiv(W, 16);
+    int wg_per = cdiv(ntiles, MW);
+    const int target = cdiv(256, B * qchunks);
+    if (wg_per > target) wg_per = max(target, 1);
+    dim3 grid(wg_per, qchunks, B), block(MW * 64);
+    const size_t lds = sizeof(unsigned short) * (size_t)3 * QCH * (64 + 8) + sizeof(float) * 2 * QCH;
+    typedef void (*kern_t)(const float*, const unsigned short*, float*, uint8_t*, int32_t*, int, int, int, int, int, int, int, int, int, int, int,
+                           int64_t, const float*, int64_t);
+    const bool wr = mask_out != nullptr;
+    kern_t kern;
+#define MASKS_PICK(P) (wr ? (kern_t)mask_logits_split_kernel<P, true> : (kern_t)mask_logits_split_kernel<P, false>)
+    switch (pool) {
+        case 0: kern = (kern_t)mask_logits_split_kernel<0, true>; break;
+        case 1: kern = MASKS_PICK(1); break;
+        case 2: kern = MASKS_PICK(2); break;
+        case 4: kern = MASKS_PICK(4); break;
+        default: kern = MASKS_PICK(8); break;
+    }
+#undef MASKS_PICK
+    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)kern, lds));
+    hipLaunchKernelGGL(kern, grid, block, lds, st, mask_embed, mask_feat_split, mask_out, attn_out, row_any, Q, C, H, W, th, tw, ypar,
+                       n_rowpairs, rp_step, rp_first, (int)((int64_t)3 * C * H * W * 2), embed_ld, qbias, qbias_ld);
+    MSM_CHECK_LAUNCH("msm_mask_logits_split_fwd");
     return MSM_OK;
 }

@@ -99,15 +99,15 @@ class MeanShiftMaskFormerHead(PlanAttributes, nn.Module):
         """"f32" (the reference's arithmetic, default), "bf16" (BASELINE configs 3 / 5): bf16 MFMA operands with fp32
         accumulation in the encoder's token-wise GEMMs, the decoder's row-local tails, the attention cores and the
         Q x pixel-embedding mask step; everything that decides a sign or normalises (LayerNorms, softmax, unit-norm, the
-        residual streams) stays fp32 -- or "f32_split": fp32 everywhere, the encoder's GEMMs and the K/V projection as exact
-        three-term bf16 splits on the bf16 matrix pipe (fp32-accurate, see csrc/enc_block_split.hip)."""
+        residual streams) stays fp32 -- or "f32_split": fp32 everywhere, the encoder's GEMMs, the K/V projection and the
+        (folded) mask step as exact three-term bf16 splits on the bf16 matrix pipe (fp32-accurate, see csrc/enc_block_split.hip)."""
         if mode not in ("f32", "f32_split", "bf16"):
             raise ValueError("precision must be 'f32', 'f32_split' or 'bf16'")
         self.precision = mode
         if hasattr(self.pixel_decoder, "precision"):
             self.pixel_decoder.precision = mode
         low = "bf16" if mode == "bf16" else "f32"
-        self.predictor.mask_step_dtype = low
+        self.predictor.mask_step_dtype = "f32_split" if mode == "f32_split" else low
         for a in ("tails_dtype", "attention_dtype"):
             if hasattr(self.predictor, a):
                 setattr(self.predictor, a, low)

@@ -272,7 +272,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         self._tails_cache = None
         # "bf16": the Q x pixel-embedding mask step runs with bf16 operands / fp32 accumulation on a packed copy of
         # mask_features made once per forward (BASELINE configs 3 and 5); everything else stays fp32
-        self.mask_step_dtype = "f32"
+        self.mask_step_dtype = "f32"        # "bf16": bf16 operands; "f32_split": fp32-accurate three-term bf16 splits (folded form)
         # "bf16": the fused row-local tails (dec_post_cross / dec_post_self / dec_heads) stream bf16 weights and multiply on
         # bf16 MFMAs with fp32 accumulation (activations as hi + lo pairs); part of set_precision("bf16")
         self.tails_dtype = "f32"
@@ -361,7 +361,8 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         cls = ops.gemm(d, self.class_embed.weight, self.class_embed.bias) if want_cls else None
         e = self.mask_embed(d)
         mask, attn, row_any = ops.mask_logits(e, mask_features, want_mask=want_mask, target_size=target_size,
-                                              sparse=self.sparse_taps, packed_bf16=self._packed_mf)
+                                              sparse=self.sparse_taps, packed_bf16=self._packed_mf,
+                                              packed_split=getattr(self, "_packed_mf_split", None))
         return cls, mask, attn, row_any
 
     def _packed_tails(self):
@@ -435,7 +436,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             emb, qb = (e, None) if ncol is None else (e[..., :ncol], e[..., ncol])
             m, attn, row_any = ops.mask_logits(emb, mask_features, want_mask=want, target_size=tgt, sparse=self.sparse_taps,
                                                row_any=ra,       # ra: cleared by the heads kernel, no fill launch
-                                               packed_bf16=self._packed_mf, qbias=qb)
+                                               packed_bf16=self._packed_mf, qbias=qb, packed_split=getattr(self, "_packed_mf_split", None))
             pred_cls.append(cls)
             pred_mask.append(m)
             return attn, row_any
@@ -514,10 +515,14 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             mask_features, folded = mask_features.tensor(), False           # literal order: materialise (B, mask_dim, H, W)
         if not folded:
             mask_features = mask_features.contiguous()
-        if self.mask_step_dtype not in ("f32", "bf16"):
-            raise ValueError("mask_step_dtype must be 'f32' or 'bf16'")
+        if self.mask_step_dtype not in ("f32", "bf16", "f32_split"):
+            raise ValueError("mask_step_dtype must be 'f32', 'bf16' or 'f32_split'")
         mf_planes = mask_features.act if folded else mask_features
         self._packed_mf = ops.pack_mask_features_bf16(mf_planes) if self.mask_step_dtype == "bf16" else None
+        # f32_split: the folded 64-channel step as exact three-term bf16 splits on the bf16 matrix pipe (fp32-accurate); the
+        # literal 256-channel form keeps the fp32 MFMA kernel
+        self._packed_mf_split = ops.pack_mask_features_split(mf_planes) \
+            if (self.mask_step_dtype == "f32_split" and folded and mf_planes.shape[1] == 64) else None
         qpos = self.query_embed.weight
         qf = self.query_feat.weight
         # the broadcast initial queries are read-only: one tensor per (batch size, parameter version).  A captured HIP

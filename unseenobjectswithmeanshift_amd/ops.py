@@ -378,14 +378,25 @@ def pack_mask_features_bf16(mask_features):
     return out
 
 
+def pack_mask_features_split(mask_features):
+    """fp32 NCHW (B, 64, H, W) -> the exact three-term bf16 split (B, 3, 8, H*W, 8) (int16 bit patterns) of the fp32-accurate
+    mask step on the bf16 matrix pipe (msm_mask_logits_split_fwd); once per forward."""
+    _c(mask_features, "mask_features")
+    B, C, H, W = mask_features.shape
+    out = torch.empty((B, 3, C // 8, H * W, 8), device=mask_features.device, dtype=torch.int16)
+    check(lib().msm_pack_mask_features_split(_p(mask_features), _p(out), B, C, H * W, _stream()), "msm_pack_mask_features_split")
+    return out
+
+
 def mask_logits(mask_embed, mask_features, *, want_mask=True, target_size=None, sparse=False, row_any=None, packed_bf16=None,
-                qbias=None):
+                qbias=None, packed_split=None):
     """einsum('bqc,bchw->bqhw') (+ qbias[b, q]) with the next layer's attention mask fused.
     Returns (mask (B,Q,H,W) or None, attn (B,Q,th*tw) uint8 or None, row_any (B,Q) int32 or None).
     mask_embed: (B,Q,C), contiguous or the leading C columns of a wider row-major buffer; qbias: (B,Q) per-query constant
     (any uniform element stride) -- together they serve the folded form of the step (modeling.FoldedMaskFeatures).
     row_any: an already ZEROED (B,Q) int32 buffer (dec_heads(zero_row_any=True) provides one) -- saves the fill launch.
-    packed_bf16: pack_mask_features_bf16(mask_features) -> the step runs with bf16 operands / fp32 accumulation."""
+    packed_bf16: pack_mask_features_bf16(mask_features) -> the step runs with bf16 operands / fp32 accumulation.
+    packed_split: pack_mask_features_split(mask_features) (C = 64) -> fp32-accurate on the bf16 matrix pipe (exact 3-term splits)."""
     _chk(mask_embed, "mask_embed"), _c(mask_features, "mask_features"), _chk(qbias, "qbias")
     B, Q, C = mask_embed.shape
     if mask_embed.stride(2) != 1 or (B > 1 and mask_embed.stride(0) != Q * mask_embed.stride(1)) or mask_embed.stride(1) < C:
@@ -414,6 +425,12 @@ def mask_logits(mask_embed, mask_features, *, want_mask=True, target_size=None, 
             flags |= 2
     else:
         row_any = None
+    if packed_split is not None:
+        _c(packed_split, "packed_split", torch.int16)
+        rc = lib().msm_mask_logits_split_fwd(_p(mask_embed), _p(packed_split), _p(mask), _p(attn), _p(row_any),
+                                             B, Q, C, H, W, th, tw, flags, embed_ld, _p(qbias), qb_ld, _stream())
+        check(rc, "msm_mask_logits_split_fwd")
+        return mask, attn, row_any
     if packed_bf16 is not None:
         _c(packed_bf16, "packed_bf16", torch.int16)
         rc = lib().msm_mask_logits_bf16_fwd(_p(mask_embed), _p(packed_bf16), _p(mask), _p(attn), _p(row_any),
