@@ -119,3 +119,79 @@ def test_two_stage_pipeline_shapes_and_labels():
     assert ids[0] == 0 and torch.equal(ids[1:], torch.arange(1, len(ids), dtype=refined.dtype))
     out_label2, refined2, out_score2, bbox2 = ts.test_sample_crop_nolabel(sample, first, None, confident_score=0.6, use_nms=True)
     assert refined2 is None and out_score2.shape == (1, 96, 128) and bbox2.shape[1] == 5
+
+
+class _BlobPredictor:
+    """A deterministic stand-in predictor for host-logic tests: blobs derived from the image content, scores / classes from a seed.
+    ``__call__`` is the per-sample interface of the reference's predictor, ``batch_tensors`` what the batched harness prefers."""
+
+    def __init__(self, n_inst=6):
+        self.n = n_inst
+        self.calls = 0
+
+    def _one(self, sample):
+        img = sample["image"]
+        H, W = img.shape[-2:]
+        seed = int(float(img.sum()) * 1000) % 100003
+        g = torch.Generator().manual_seed(seed)
+        yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+        masks = torch.zeros(self.n, H, W)
+        for i in range(self.n):
+            cy, cx = torch.rand(1, generator=g).item() * H, torch.rand(1, generator=g).item() * W
+            ry, rx = H / 12 + torch.rand(1, generator=g).item() * H / 5, W / 12 + torch.rand(1, generator=g).item() * W / 5
+            masks[i] = ((((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2) <= 1).float()
+        scores = torch.rand(self.n, generator=g) * 0.6 + 0.35
+        classes = (torch.rand(self.n, generator=g) < 0.8).long()
+        return scores, classes, masks
+
+    def __call__(self, sample):
+        self.calls += 1
+        s, c, m = self._one(sample)
+        return {"instances": Instances(tuple(m.shape[-2:]), pred_masks=m, scores=s, pred_classes=c)}
+
+    def batch_call(self, samples):
+        return [self(s) for s in samples]
+
+    def batch_tensors(self, samples):
+        self.calls += 1
+        parts = [self._one(s) for s in samples]
+        return tuple(torch.stack([p[i] for p in parts]) for i in range(3))
+
+
+def test_batched_two_stage_equals_the_frame_by_frame_pipeline():
+    """two_stage.test_batch_crop_nolabel (BASELINE configs[3]: a batch of frames end to end) against test_sample_crop_nolabel
+    frame by frame -- the reference's own loop structure (lib/fcn/test_utils.py:375-406), whose pieces are pinned above -- with
+    the same deterministic predictor in both stages: identical first-stage label images, ROI tables, refined labels.  Host
+    logic only (ROI table from one statistics transfer, paste order per frame, per-frame renumbering, crop chunking)."""
+    g = torch.Generator().manual_seed(9)
+    H, W, Fr = 96, 128, 5
+    samples = []
+    for f in range(Fr):
+        image = torch.rand(3, H, W, generator=g)
+        z = 0.4 + 1.2 * torch.rand(1, H, W, generator=g)
+        z[torch.rand(1, H, W, generator=g) < 0.3] = 0
+        if f == 2:
+            z[:] = 0                                     # a frame whose labels are all filtered away: no crops
+        depth = torch.cat([torch.rand(2, H, W, generator=g), z], 0)
+        samples.append({"image_color": image, "depth": depth, "file_name": "OSD-x" if f == 3 else "f%d" % f})
+    kw = dict(topk=False, confident_score=0.5, low_threshold=0.4, num_class=2)
+    pred = _BlobPredictor()
+    for crop_batch in (256, 4):
+        pred.calls = 0
+        labels, refined, rows = ts.test_batch_crop_nolabel(samples, pred, pred, use_depth=True, crop_batch=crop_batch, **kw)
+        assert labels.shape == (Fr, H, W) and refined.shape == (Fr, H, W)
+        assert pred.calls == 1 + -(-len(rows) // crop_batch)
+        assert not any(r[0] == 2 for r in rows) and float(refined[2].abs().max()) == 0.0
+        for f, smp in enumerate(samples):
+            o_label, o_refined, _, _ = ts.test_sample_crop_nolabel(smp, pred, pred, use_depth=True, **kw)
+            assert torch.equal(labels[f].double(), o_label[0].double()), f
+            if o_refined is None:
+                assert float(refined[f].abs().max()) == 0.0
+            else:
+                assert torch.equal(refined[f].double(), o_refined[0].double()), f
+    # without depth: paste order by ROI area; topk selection rule
+    labels, refined, rows = ts.test_batch_crop_nolabel(samples, pred, pred, use_depth=False, topk=True, low_threshold=0.5, num_class=2)
+    for f, smp in enumerate(samples):
+        o_label, o_refined, _, _ = ts.test_sample_crop_nolabel(smp, pred, pred, use_depth=False, topk=True, low_threshold=0.5, num_class=2)
+        assert torch.equal(labels[f].double(), o_label[0].double())
+        assert torch.equal(refined[f].double(), (o_refined[0] if o_refined is not None else torch.zeros(H, W)).double())

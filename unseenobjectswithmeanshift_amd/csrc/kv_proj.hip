@@ -82,8 +82,7 @@ __device__ __forceinline__ void kv_project_body(const float* __restrict__ x, con
         const int u = unit_of(it);
         const int half = u % halves;
         const int tile = u / (halves * B), img = (u / halves) % B;
-        const int p = min(tile * 16 + lj, HW - 1);             // this lane's token (clamped; stores are guarded)
-        const bool live = tile * 16 + lj < HW;
+        const int p = min(tile * 16 + lj, HW - 1);             // this lane's token, clamped: lanes past the last token repeat it (see the stores)
         const int n_base = half * KP_FB * 16;
         const float* cp = cmat + (int64_t)p * N + n_base + lq * 4;
         OT* op = out + ((int64_t)img * HW + p) * N + n_base + lq * 4;
@@ -231,7 +230,6 @@ __device__ __forceinline__ void kv_project_split_body(const float* __restrict__ 
             const int u = unit_of(it);
             const int tile = u / B, img = u % B;
             const int p = min(tile * 16 + lj, HW - 1);
-            const bool live = tile * 16 + lj < HW;
             const float* cp = cmat + (int64_t)p * N + n_base + lq * 4;
             OT* op = out + ((int64_t)img * HW + p) * N + n_base + lq * 4;
             float xb[16];

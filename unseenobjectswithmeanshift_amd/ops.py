@@ -485,6 +485,10 @@ def hypersphere_attention_backward(q, k, v, heads, grad_out, *, masked=None, row
         if t.stride(-1) != 1:
             raise RuntimeError(f"{n}: last dim must be contiguous")
     _c(grad_out, "grad_out"), _c(masked, "masked", torch.uint8), _c(row_any, "row_any", torch.int32)
+    if masked is not None and row_any is None:
+        # a fully masked row has a zero softmax denominator in the recomputation (NaN gradients); the forward resets such rows
+        # through row_any (DEC:618), so the backward needs the same flags
+        raise RuntimeError("hypersphere_attention_backward: row_any is required whenever masked is given")
     B, Lq, E = q.shape
     S = k.shape[1]
     if E != heads * 32 or tuple(grad_out.shape) != (B, Lq, E):

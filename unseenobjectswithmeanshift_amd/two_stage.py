@@ -316,11 +316,51 @@ def roi_table(stats, overflow, H, W):
     return rows
 
 
+# GPU tensors go through the HIP kernels; CPU tensors -- the host-logic unit tests -- through the same definitions in torch ops
+# (the reference's own per-ROI F.interpolate calls), like label_stats above.
+def _label_image_batched(masks, inst_labels):
+    if masks.is_cuda:
+        from . import ops
+        return ops.label_image(masks.float().contiguous(), inst_labels.float().contiguous())
+    return ((masks != 0).float() * inst_labels[:, :, None, None].float()).amax(1) if masks.shape[1] else masks.new_zeros((masks.shape[0],) + masks.shape[2:])
+
+
+def _crop_resize_batched(images, depths, labels, rows, size):
+    if images.is_cuda:
+        from . import ops
+        return ops.crop_resize(images, depths, labels, torch.tensor(rows, dtype=torch.int32, device=images.device), size)
+    n = len(rows)
+    rgb = torch.zeros((n, 3, size, size))
+    msk = torch.zeros((n, size, size))
+    dep = torch.zeros((n, 3, size, size)) if depths is not None else None
+    for k, (f, lab, x0, y0, x1, y1, _, _) in enumerate(rows):
+        rgb[k] = F.interpolate(images[f:f + 1, :, y0:y1 + 1, x0:x1 + 1], size=(size, size), mode="bilinear", align_corners=True)[0]
+        msk[k] = F.interpolate((labels[f, y0:y1 + 1, x0:x1 + 1] == lab).float()[None, None], size=(size, size), mode="nearest")[0, 0]
+        if depths is not None:
+            dep[k] = F.interpolate(depths[f:f + 1, :, y0:y1 + 1, x0:x1 + 1], size=(size, size), mode="bilinear", align_corners=True)[0]
+    return rgb, msk, dep
+
+
+def _paste_batched(renum, rows, order, frame_start, frames, H, W):
+    if renum.is_cuda:
+        from . import ops
+        dev = renum.device
+        return ops.paste_labels(renum, torch.tensor(rows, dtype=torch.int32, device=dev), torch.tensor(order, dtype=torch.int32, device=dev),
+                                torch.tensor(frame_start, dtype=torch.int32, device=dev), frames, H, W)
+    refined = torch.zeros((frames, H, W))
+    for f in range(frames):
+        for n in order[frame_start[f]:frame_start[f + 1]]:
+            _, _, x0, y0, x1, y1, _, _ = rows[n]
+            small = F.interpolate(renum[n][None, None], size=(y1 - y0 + 1, x1 - x0 + 1), mode="nearest")[0, 0]
+            window = refined[f, y0:y1 + 1, x0:x1 + 1]
+            window.copy_(torch.where(small != 0, small, window))
+    return refined
+
+
 def match_label_crop_batched(initial_masks, labels_crop, out_label_crop, rows, depth_crop):
     """match_label_crop for the crops of a whole batch of frames: initial_masks (F,H,W), labels_crop / out_label_crop
     (N,S,S), rows = roi_table(...) (crop n belongs to frame rows[n][0]), depth_crop (N,3,S,S) or None.
     Returns refined (F,H,W).  Same arithmetic per frame as match_label_crop; the renumbering restarts at 1 in every frame."""
-    from . import ops
     Fr, H, W = initial_masks.shape
     num = labels_crop.shape[0]
     dev = labels_crop.device
@@ -354,8 +394,7 @@ def match_label_crop_batched(initial_masks, labels_crop, out_label_crop, rows, d
     number = torch.zeros((num, k), dtype=torch.float32, device=dev)
     number[order_t] = ((c - before[:, None]) * alive).float()
     renum = number.view(-1)[lab].view(num, *labels_crop.shape[1:]).contiguous()
-    table = torch.tensor(rows, dtype=torch.int32, device=dev)
-    return ops.paste_labels(renum, table, order_t.to(torch.int32), torch.tensor(frame_start, dtype=torch.int32, device=dev), Fr, H, W)
+    return _paste_batched(renum, rows, order, frame_start, Fr, H, W)
 
 
 def test_batch_crop_nolabel(samples, predictor, predictor_crop=None, *, use_depth=True, topk=False, confident_score=0.7,
@@ -365,10 +404,7 @@ def test_batch_crop_nolabel(samples, predictor, predictor_crop=None, *, use_dept
     None, rows) -- frame f's results equal test_sample_crop_nolabel(samples[f], ...)[0][0] / [1][0]; ``rows`` is the ROI table
     (frame, label, x0, y0, x1, y1, 0, 0) of the second stage.  ``stages``: a dict that receives the intermediate tensors
     (crops, second-stage label images) -- for tests."""
-    from . import ops
     images = torch.stack([s["image_color"][0] if s["image_color"].dim() == 4 else s["image_color"] for s in samples]).float().contiguous()
-    if not images.is_cuda:
-        raise RuntimeError("test_batch_crop_nolabel runs on the GPU (HIP kernels for the label images, crops and paste-back)")
     Fr, _, H, W = images.shape
     depths = None
     if use_depth:
@@ -376,7 +412,7 @@ def test_batch_crop_nolabel(samples, predictor, predictor_crop=None, *, use_dept
     first = [{"image": images[f], "depth": depths[f] if depths is not None else None, "height": H, "width": W} for f in range(Fr)]
     kw = dict(topk=topk, confident_score=confident_score, low_threshold=low_threshold, num_class=num_class)
     scores, classes, masks = _batch_tensors(predictor, first)
-    out_label = ops.label_image(masks.float().contiguous(), instance_labels(scores, classes, **kw))
+    out_label = _label_image_batched(masks, instance_labels(scores, classes, **kw))
     if depths is not None:
         thr = torch.tensor([0.8 if "OSD" in str(s.get("file_name", "")) else depth_threshold for s in samples],
                            device=images.device, dtype=torch.float32)[:, None]          # test_utils.py:384-387
@@ -389,15 +425,14 @@ def test_batch_crop_nolabel(samples, predictor, predictor_crop=None, *, use_dept
     n = len(rows)
     if n == 0:
         return out_label, torch.zeros_like(out_label), rows
-    table = torch.tensor(rows, dtype=torch.int32, device=images.device)
-    rgb_crop, mask_crop, depth_crop = ops.crop_resize(images, depths, out_label, table, CROP_SIZE)
+    rgb_crop, mask_crop, depth_crop = _crop_resize_batched(images, depths, out_label, rows, CROP_SIZE)
     labels_crop = torch.empty((n, CROP_SIZE, CROP_SIZE), device=images.device, dtype=torch.float32)
     for c0 in range(0, n, crop_batch):
         c1 = min(n, c0 + crop_batch)
         crops = [{"image": rgb_crop[i], "height": CROP_SIZE, "width": CROP_SIZE,
                   "depth": depth_crop[i] if depth_crop is not None else None} for i in range(c0, c1)]
         s2, k2, m2 = _batch_tensors(predictor_crop, crops)
-        labels_crop[c0:c1] = ops.label_image(m2.float().contiguous(), instance_labels(s2, k2, **kw))
+        labels_crop[c0:c1] = _label_image_batched(m2, instance_labels(s2, k2, **kw))
     if stages is not None:
         stages.update(rgb_crop=rgb_crop, mask_crop=mask_crop, depth_crop=depth_crop, labels_crop=labels_crop.clone())
     refined = match_label_crop_batched(out_label, labels_crop, mask_crop, rows, depth_crop)
