@@ -262,12 +262,13 @@ def mask_step_graph_ms(step, reps=100):
     return e0.elapsed_time(e1) / (reps * len(calls)), len(calls)
 
 
-def precision_leg(model, feats, dev, dist, args, precision, inflight):
+def precision_leg(model, feats, dev, dist, args, precision, inflight, sparse_taps=False):
     """The per-GPU batch of 8 in another precision mode, timed on EVERY rank exactly like the headline region (barrier + sync on
     both sides, max over ranks): under --gpus 8 this is BASELINE configs[2] (batch 64 over 8 GPUs, bf16).  Returns this rank's
     (images, elapsed seconds, steps, one-batch-in-flight seconds per step)."""
     from unseenobjectswithmeanshift_amd.graphs import PipelinedInference
     model.set_precision(precision)
+    model.sem_seg_head.predictor.sparse_taps = bool(sparse_taps)
     lone = PipelinedInference(model, depth=1)
     lone.submit(feats, (H, W))
     lone.drain()
@@ -302,6 +303,7 @@ def precision_leg(model, feats, dev, dist, args, precision, inflight):
     elapsed = time.perf_counter() - t0
     del pipe
     model.set_precision("f32")
+    model.sem_seg_head.predictor.sparse_taps = False
     return feats[next(iter(feats))].shape[0] * steps, elapsed, steps, single
 
 
@@ -361,6 +363,17 @@ def extra_configs(dev, args):
     class _A:
         steps, min_seconds = 50, 0.5
     imgs, el, st_, single = precision_leg(model, feats, dev, None, _A, "f32_split", max(1, args.inflight))
+    # the intermediate mask steps restricted to the image rows their attention masks sample (decoder.sparse_taps): the nine
+    # intermediate full-resolution mask predictions are never formed -- inference never reads them (PM:335-345), the final prediction
+    # is bitwise the same (tests) -- so the step executes 5.25 instead of 9 intermediate launch-equivalents.  SURVEY 8d allows this
+    # inference-only shortcut with executed and reference FLOPs reported apart; it is NOT the headline configuration.
+    si, sel, sst, ssingle = precision_leg(model, feats, dev, None, _A, "f32", max(1, args.inflight), sparse_taps=True)
+    out["configs[1] sparse taps"] = {
+        "workload": "batch 8, 640x480, fp32, as the headline except that the nine intermediate mask steps compute only the row pairs their "
+                    f"attention masks sample (final prediction bitwise identical); {max(1, args.inflight)} batches of 8 in flight",
+        "value": round(si / sel, 1), "unit": "images/sec", "ms_per_step": round(1e3 * sel / sst, 4),
+        "one_batch_in_flight": {"value": round(BATCH / ssingle, 1), "unit": "images/sec", "ms_per_step": round(1e3 * ssingle, 4)},
+        "dtype": "f32", "executed_mask_launch_equivalents": 1 + 3 * (0.25 + 0.5 + 1.0), "reference_mask_launches": 10}
     model.set_precision("f32_split")
     ms_split, n_split = mask_step_graph_ms(lambda: model.inference(feats, (H, W)))
     model.set_precision("f32")
