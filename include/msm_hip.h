@@ -142,6 +142,16 @@ int msm_pos_embed_sine(float* out, int H, int W, int npf, int64_t s_c, int64_t s
 /* batched 2-D transpose: out[b][c][r] = in[b][r][c] */
 int msm_transpose_f32(const float* in, float* out, int B, int R, int C, void* stream);
 
+/* y = x / max(||x||_2 over the C channels, eps) for an NCHW map [B][C][HW] (F.normalize(x, p=2, dim=1)): the UCN meta-arch's
+ * normalisation of the backbone embedding, pretrained_meanshiftformer_model.py:298-300. */
+int msm_l2_normalize_nchw_f32(const float* x, float* y, int B, int C, int HW, float eps, void* stream);
+
+/* The location / softmax glue of the general MSDeformAttn.forward (OPS/modules/ms_deform_attn.py:101-109):
+ *   attn_weight = softmax over L*P of logits [rows][M][L*P];  sampling_loc = reference_points[:, :, None, :, None, :] +
+ *   offsets / (W_l, H_l) with offsets [rows][M][L][P][2], reference_points [rows][L][2] (rows = N*Lq), spatial_shapes int64 [L][2]. */
+int msm_msda_locations(const float* offsets, const float* logits, const float* reference_points, const int64_t* spatial_shapes,
+                       float* sampling_loc, float* attn_weight, int64_t rows, int M, int L, int P, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Query x pixel-embedding mask step with fused attention-mask derivation (DEC:668-680).
  *   mask_embed [B][Q][C], mask_feat [B][C][H*W] (NCHW, as produced by the pixel decoder).

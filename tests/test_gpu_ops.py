@@ -1057,3 +1057,23 @@ def test_mask_logits_split_is_fp32_accurate(B, Q, H, W, pool):
     mask, attn, row_any = ops().mask_logits(wd[..., :C], fd, want_mask=True, target_size=None, qbias=wd[..., 64], packed_split=packed)
     close(mask, full.float(), rtol=1e-4, atol=1e-4)
     assert attn is None and row_any is None
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 48, 64), (1, 64, 7, 9), (2, 33, 10, 12), (1, 100, 8, 8)])
+def test_l2_normalize_nchw(B, C, H, W):
+    """msm_l2_normalize_nchw_f32 = F.normalize(x, p=2, dim=1) (pretrained_meanshiftformer_model.py:298-300), zero vectors included."""
+    x = rnd(B, C, H, W, seed=1)
+    x[0, :, 0, 0] = 0
+    y = ops().l2_normalize_nchw(x.to(DEV))
+    close(y, F.normalize(x, p=2, dim=1), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("N,Lq,M,L,P", [(2, 50, 8, 3, 4), (1, 7, 2, 2, 2), (1, 300, 8, 4, 4)])
+def test_msda_locations_and_general_forward(N, Lq, M, L, P):
+    """msm_msda_locations: softmax over L*P and loc = ref + off / (W_l, H_l) (ms_deform_attn.py:101-109) against torch."""
+    shapes = torch.tensor([(6 + 3 * l, 4 + 5 * l) for l in range(L)], dtype=torch.int64)
+    off, lg, ref = rnd(N, Lq, M, L, P, 2, seed=1), rnd(N, Lq, M, L * P, seed=2), torch.rand(N, Lq, L, 2, generator=torch.Generator().manual_seed(3))
+    loc, aw = ops().msda_locations(off.to(DEV), lg.to(DEV), ref.to(DEV), shapes.to(DEV))
+    norm = torch.stack([shapes[:, 1], shapes[:, 0]], -1).float()
+    close(loc, ref[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :], rtol=1e-6, atol=1e-7)
+    close(aw, torch.softmax(lg, -1).view(N, Lq, M, L, P), rtol=1e-5, atol=1e-7)

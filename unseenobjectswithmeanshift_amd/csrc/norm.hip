@@ -279,6 +279,71 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
+// ---- x / max(||x||_2 over channels, eps) for an NCHW map (F.normalize(x, p=2, dim=1)) -------------------------------------------
+// The UCN meta-arch normalises the backbone's 64-channel full-resolution embedding before the head
+// (pretrained_meanshiftformer_model.py:298-300): one pass -- a lane owns one pixel (a wave reads 256 contiguous bytes of each
+// channel plane), the C values stay in registers between the norm and the division (C <= 64), otherwise the map is read twice.
+template <int CMAX>
+__global__ __launch_bounds__(256) void l2norm_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int64_t hw, float eps) {
+    const int b = blockIdx.y;
+    const float* xb = x + (int64_t)b * C * hw;
+    float* yb = y + (int64_t)b * C * hw;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < hw; p += (int64_t)gridDim.x * 256) {
+        float ss = 0.f;
+        float v[CMAX > 0 ? CMAX : 1];
+        if constexpr (CMAX > 0) {
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c)
+                if (c < C) {
+                    v[c] = xb[(int64_t)c * hw + p];
+                    ss += v[c] * v[c];
+                }
+        } else {
+            for (int c = 0; c < C; ++c) {
+                const float t = xb[(int64_t)c * hw + p];
+                ss += t * t;
+            }
+        }
+        const float d = fmaxf(sqrtf(ss), eps);
+        if constexpr (CMAX > 0) {
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c)
+                if (c < C) yb[(int64_t)c * hw + p] = v[c] / d;
+        } else {
+            for (int c = 0; c < C; ++c) yb[(int64_t)c * hw + p] = xb[(int64_t)c * hw + p] / d;
+        }
+    }
+}
+
+// ---- the location / softmax glue of the general MSDeformAttn.forward (ops/modules/ms_deform_attn.py:101-109) -------------------
+//   attn = softmax over the L*P logits of a (query, head);  loc = ref[:, :, None, :, None, :] + off / (W_l, H_l)
+// off [N*Lq][M][L][P][2], logits [N*Lq][M][L*P], ref [N*Lq][L][2] -> loc [N*Lq][M][L][P][2], attn [N*Lq][M][L][P];
+// one lane per (query, head), L*P <= 64.
+__global__ __launch_bounds__(256) void msda_locations_kernel(const float* __restrict__ off, const float* __restrict__ logits,
+                                                             const float* __restrict__ ref, const int64_t* __restrict__ shapes,
+                                                             float* __restrict__ loc, float* __restrict__ attn, int64_t rows, int M,
+                                                             int L, int P) {
+    const int LP = L * P;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * M; i += (int64_t)gridDim.x * 256) {
+        const int64_t q = i / M;
+        const float* lg = logits + i * LP;
+        float mx = -INFINITY;
+        for (int j = 0; j < LP; ++j) mx = fmaxf(mx, lg[j]);
+        float den = 0.f;
+        for (int j = 0; j < LP; ++j) den += expf(lg[j] - mx);
+        for (int l = 0; l < L; ++l) {
+            const float Hf = (float)shapes[2 * l], Wf = (float)shapes[2 * l + 1];
+            const float rx = ref[(q * L + l) * 2], ry = ref[(q * L + l) * 2 + 1];
+            for (int p = 0; p < P; ++p) {
+                const int j = l * P + p;
+                loc[(i * LP + j) * 2] = rx + off[(i * LP + j) * 2] / Wf;              // offset_normalizer = (W_l, H_l), :106-109
+                loc[(i * LP + j) * 2 + 1] = ry + off[(i * LP + j) * 2 + 1] / Hf;
+                attn[i * LP + j] = expf(lg[j] - mx) / den;
+            }
+        }
+    }
+}
+
 }  // namespace msm
 
 using namespace msm;
@@ -369,5 +434,26 @@ extern "C" int msm_transpose_f32(const float* in, float* out, int B, int R, int 
     dim3 grid(cdiv(C, 32), cdiv(R, 32), B), block(256);
     hipLaunchKernelGGL(transpose_kernel, grid, block, 0, st, in, out, R, C);
     MSM_CHECK_LAUNCH("msm_transpose_f32");
+    return MSM_OK;
+}
+
+extern "C" int msm_l2_normalize_nchw_f32(const float* x, float* y, int B, int C, int HW, float eps, void* stream) {
+    MSM_REQUIRE(x && y, "msm_l2_normalize_nchw_f32: null pointer");
+    MSM_REQUIRE(B > 0 && C > 0 && HW > 0, "msm_l2_normalize_nchw_f32: bad shape");
+    const int64_t hw = HW;
+    dim3 grid((unsigned)max((int64_t)1, min((hw + 255) / 256, (int64_t)max(1, 8192 / B))), B), block(256);
+    if (C <= 64) hipLaunchKernelGGL(l2norm_nchw_kernel<64>, grid, block, 0, (hipStream_t)stream, x, y, C, hw, eps);
+    else hipLaunchKernelGGL(l2norm_nchw_kernel<0>, grid, block, 0, (hipStream_t)stream, x, y, C, hw, eps);
+    MSM_CHECK_LAUNCH("msm_l2_normalize_nchw_f32");
+    return MSM_OK;
+}
+
+extern "C" int msm_msda_locations(const float* offsets, const float* logits, const float* reference_points, const int64_t* spatial_shapes,
+                                  float* sampling_loc, float* attn_weight, int64_t rows, int M, int L, int P, void* stream) {
+    MSM_REQUIRE(offsets && logits && reference_points && spatial_shapes && sampling_loc && attn_weight, "msm_msda_locations: null pointer");
+    MSM_REQUIRE(rows > 0 && M > 0 && L > 0 && P > 0, "msm_msda_locations: bad sizes");
+    hipLaunchKernelGGL(msda_locations_kernel, dim3((unsigned)min((int64_t)4096, (rows * M + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       offsets, logits, reference_points, spatial_shapes, sampling_loc, attn_weight, rows, M, L, P);
+    MSM_CHECK_LAUNCH("msm_msda_locations");
     return MSM_OK;
 }

@@ -271,7 +271,11 @@ class PretrainedMeanShiftMaskFormer(MeanShiftMaskFormer):
             images = F.pad(images, (0, padded[1] - W, 0, padded[0] - H))
             depth = None if depth is None else F.pad(depth, (0, padded[1] - W, 0, padded[0] - H))
         feats = self.backbone(images, None, depth)
-        feats = {"res5": F.normalize(feats, p=2, dim=1).contiguous()}                     # PM:298-300
+        feats = feats.float().contiguous()
+        if feats.is_cuda:
+            feats = {"res5": ops.l2_normalize_nchw(feats)}                                # PM:298-300 (F.normalize over channels)
+        else:
+            feats = {"res5": F.normalize(feats, p=2, dim=1).contiguous()}
         scores, classes, masks, boxes, _ = self.inference(feats, (H, W), padded)
         return [{"instances": Instances((H, W), pred_masks=masks[b], pred_boxes=boxes[b], scores=scores[b], pred_classes=classes[b])}
                 for b in range(scores.shape[0])]

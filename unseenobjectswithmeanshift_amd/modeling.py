@@ -689,10 +689,9 @@ class MSDeformAttn(nn.Module):
         q = query.contiguous()
         off = ops.gemm(q, self.sampling_offsets.weight, self.sampling_offsets.bias).view(N, Lq, M, L, P, 2)
         aw = ops.gemm(q, self.attention_weights.weight, self.attention_weights.bias).view(N, Lq, M, L * P)
-        # the small location / softmax glue of the general (non-encoder) form stays in torch
-        aw = torch.softmax(aw, -1).view(N, Lq, M, L, P).contiguous()
-        normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1).to(off.dtype)
-        loc = (reference_points[:, :, None, :, None, :] + off / normalizer[None, None, None, :, None, :]).contiguous()
+        # softmax over the L*P logits and loc = ref + off / (W_l, H_l) (ms_deform_attn.py:101-109) in one HIP launch
+        loc, aw = ops.msda_locations(off.contiguous(), aw.contiguous(), reference_points.float().contiguous(),
+                                     input_spatial_shapes.to(torch.int64).contiguous())
         out = ops.ms_deform_attn(value, input_spatial_shapes, input_level_start_index, loc, aw)
         return ops.gemm(out, self.output_proj.weight, self.output_proj.bias)
 

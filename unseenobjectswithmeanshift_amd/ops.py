@@ -367,6 +367,29 @@ def transpose_last2(x):
     return out
 
 
+def l2_normalize_nchw(x, eps=1e-12):
+    """F.normalize(x, p=2, dim=1) for an NCHW map (B, C, H, W) (msm_l2_normalize_nchw_f32)."""
+    _c(x, "x")
+    B, C, H, W = x.shape
+    y = torch.empty_like(x)
+    check(lib().msm_l2_normalize_nchw_f32(_p(x), _p(y), B, C, H * W, float(eps), _stream()), "msm_l2_normalize_nchw_f32")
+    return y
+
+
+def msda_locations(offsets, logits, reference_points, spatial_shapes):
+    """The glue of the general MSDeformAttn.forward (ms_deform_attn.py:101-109): offsets (N,Lq,M,L,P,2), logits (N,Lq,M,L*P),
+    reference_points (N,Lq,L,2), spatial_shapes (L,2) int64 -> (sampling_locations (N,Lq,M,L,P,2), attention_weights (N,Lq,M,L,P))."""
+    _c(offsets, "offsets"), _c(logits, "logits"), _c(reference_points, "reference_points"), _c(spatial_shapes, "spatial_shapes", torch.int64)
+    N, Lq, M, L, P, _ = offsets.shape
+    if tuple(logits.shape) != (N, Lq, M, L * P) or tuple(reference_points.shape) != (N, Lq, L, 2):
+        raise RuntimeError("msda_locations: logits must be (N,Lq,M,L*P) and reference_points (N,Lq,L,2)")
+    loc = torch.empty_like(offsets)
+    attn = torch.empty((N, Lq, M, L, P), device=offsets.device, dtype=torch.float32)
+    check(lib().msm_msda_locations(_p(offsets), _p(logits), _p(reference_points), _p(spatial_shapes), _p(loc), _p(attn), N * Lq, M, L, P,
+                                   _stream()), "msm_msda_locations")
+    return loc, attn
+
+
 def pack_mask_features_bf16(mask_features):
     """fp32 NCHW (B, C, H, W) -> the channel-quad packed bf16 layout (B, C/4, H*W, 4) (int16 bit patterns) the bf16 mask
     step streams; do it once per forward, the 10 mask steps of a decoder pass reuse it."""
