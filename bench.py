@@ -289,7 +289,7 @@ def precision_leg(model, feats, dev, dist, args, precision, inflight, sparse_tap
     est = timed(run, 4 * inflight)
     steps = max(args.steps, int(math.ceil(args.min_seconds / max(est, 1e-6))))
     if dist is not None:
-        t = torch.tensor([steps], device=dev, dtype=torch.int64)
+        t = torch.tensor([steps], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.int64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         steps = int(t.item())
         dist.barrier()
@@ -631,12 +631,15 @@ def main():
                     help="bf16 (configs 3/5) is NOT the headline configuration: the JSON line then says so in dtype")
     ap.add_argument("--batched-kv", type=int, default=-1, help="1/0: all K/V projections of the decoder in one launch (default: the decoder's own default)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
+    # test hooks for the N > 1 code path on a ONE-GPU box (tests/test_gpu_configs.py): every rank on cuda:0, collectives over gloo
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help=argparse.SUPPRESS)
+    ap.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         if not args.stub:
             have = torch.cuda.device_count()
-            if have < args.gpus:
+            if have < args.gpus and not args.share_gpu:
                 raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible")
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
@@ -650,13 +653,18 @@ def main():
     dist = None
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: the hot path has no CPU implementation (oracle/ is test-only)")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)           # before the process group: RCCL binds its communicator to the current device
     dev = torch.device("cuda", local_rank)
     affinity = pin_to_gpu_numa_node(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from unseenobjectswithmeanshift_amd import _lib, ops
     from unseenobjectswithmeanshift_amd import synthetic as syn
@@ -719,7 +727,7 @@ def main():
             est = timed(one_piped, 4 * inflight)
         steps = max(args.steps, int(math.ceil(args.min_seconds / max(est, 1e-6))))
         if dist is not None:
-            t = torch.tensor([steps], device=dev, dtype=torch.int64)
+            t = torch.tensor([steps], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.int64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             steps = int(t.item())
         run_one = one_piped if pipe is not None else one
