@@ -767,3 +767,20 @@ def test_pixel_decoder_fused_sampling_projection_is_bitwise_neutral():
     assert torch.equal(fa, fb)
     for x, y in zip(a[2], b[2]):
         assert torch.equal(x, y)
+
+
+def test_head_beyond_64_images_keeps_the_folded_mask_step():
+    """More than 64 images per call (the second stage of the batched two-stage harness sends ~170 crops): the pixel decoder still
+    hands the decoder the factored mask features (the fused GroupNorm + 1x1 kernel's 64-image table only matters for the literal
+    tensor), and the predictions equal those of the same images in a small batch up to batch-size dependent summation orders."""
+    from unseenobjectswithmeanshift_amd.modeling import FoldedMaskFeatures
+    head = make_pixel_decoder()
+    feats = {k: v.to(DEV) for k, v in syn.synth_backbone_features(70, 64, 96, seed=6).items()}
+    mf, _, _ = head.pixel_decoder.forward_features(feats, folded=True)
+    assert isinstance(mf, FoldedMaskFeatures)
+    torch.testing.assert_close(mf.tensor()[:2], head.pixel_decoder.forward_features({k: v[:2].contiguous() for k, v in feats.items()})[0],
+                               rtol=1e-4, atol=1e-4)
+    big, _ = head(feats)
+    small, _ = head({k: v[:3].contiguous() for k, v in feats.items()})
+    torch.testing.assert_close(big["pred_logits"][:3], small["pred_logits"], rtol=1e-3, atol=1e-3)
+    assert float(((big["pred_masks"][:3] > 0) != (small["pred_masks"] > 0)).float().mean()) < 1e-3

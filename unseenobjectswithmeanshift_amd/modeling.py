@@ -974,10 +974,15 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
         else:
             y = ops.conv3x3_tokens(y, self._w3(), H, W)
         wm = self.mask_features.weight.view(self.mask_dim, C)
-        if C == 64 and self.mask_dim in (256, 512) and (H * W) % 4 == 0 and B <= 64:
+        if C == 64 and self.mask_dim in (256, 512) and (H * W) % 4 == 0 and (B <= 64 or folded):
             # layer_1's GroupNorm + ReLU is applied to the operand fragments of the mask_features convolution
             gn = (y_stats, self.layer_1.norm.weight, self.layer_1.norm.bias, 32, self.layer_1.norm.eps)
-            literal = lambda: ops.tokens_proj_nchw(y, wm, self.mask_features.bias, gn=gn, relu=True).view(B, self.mask_dim, H, W)
+            if B <= 64:
+                literal = lambda: ops.tokens_proj_nchw(y, wm, self.mask_features.bias, gn=gn, relu=True).view(B, self.mask_dim, H, W)
+            else:       # beyond the fused kernel's per-image GroupNorm table (the second stage of the two-stage harness: ~170 crops)
+                literal = lambda: ops.conv1x1_tokens_to_nchw(
+                    ops.groupnorm_tokens(y, self.layer_1.norm.weight, self.layer_1.norm.bias, H, W, groups=32, relu=True,
+                                         eps=self.layer_1.norm.eps), wm, self.mask_features.bias).view(B, self.mask_dim, H, W)
             if folded:
                 # hand over the factored form: the 64-channel activation as NCHW planes + the 1x1 weight (FoldedMaskFeatures)
                 act = ops.groupnorm_nchw(y, y_stats, self.layer_1.norm.weight, self.layer_1.norm.bias, groups=32,
