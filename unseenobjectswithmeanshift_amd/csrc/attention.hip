@@ -59,25 +59,28 @@ struct KVRaw<uint16_t> {
     u32x4b k;
     unsigned short v[4][2];
 };
-// kp: this lane's 8 dims of its key row; vbp + key * ldv: dim lj of a key row
-__device__ __forceinline__ void kv_fetch(KVRaw<float>& f, const float* __restrict__ kp, const float* __restrict__ vbp, int64_t ldv, int key_c0, int S) {
-    f.ka = *reinterpret_cast<const float4*>(kp);
-    f.kc = *reinterpret_cast<const float4*>(kp + 4);
+typedef unsigned u32x2a __attribute__((ext_vector_type(2)));
+// K / V through buffer descriptors: kr / vr cover K and V of one (image, head) from its first element, ko = byte offset of this
+// lane's 8 dims of its key row, vo[r] = byte offset of dim lj of the row of key 4 lq + r, ks / vs = wave-uniform byte offsets
+// (the key block) that ride in the scalar offset of the load
+__device__ __forceinline__ void kv_fetch(KVRaw<float>& f, __amdgpu_buffer_rsrc_t kr, unsigned ko, unsigned ks, __amdgpu_buffer_rsrc_t vr,
+                                         const unsigned (&vo)[4], unsigned vs) {
+    const u32x4b a = __builtin_amdgcn_raw_buffer_load_b128(kr, ko, ks, 0), c = __builtin_amdgcn_raw_buffer_load_b128(kr, ko + 16u, ks, 0);
+    f.ka = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+    f.kc = make_float4(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z), __uint_as_float(c.w));
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const float* vp = vbp + (int64_t)min(key_c0 + r, S - 1) * ldv;
-        f.v[r][0] = vp[0];
-        f.v[r][1] = vp[16];
+        f.v[r][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vr, vo[r], vs, 0));
+        f.v[r][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vr, vo[r] + 64u, vs, 0));
     }
 }
-__device__ __forceinline__ void kv_fetch(KVRaw<uint16_t>& f, const uint16_t* __restrict__ kp, const uint16_t* __restrict__ vbp, int64_t ldv, int key_c0,
-                                         int S) {
-    f.k = *reinterpret_cast<const u32x4b*>(kp);
+__device__ __forceinline__ void kv_fetch(KVRaw<uint16_t>& f, __amdgpu_buffer_rsrc_t kr, unsigned ko, unsigned ks, __amdgpu_buffer_rsrc_t vr,
+                                         const unsigned (&vo)[4], unsigned vs) {
+    f.k = __builtin_amdgcn_raw_buffer_load_b128(kr, ko, ks, 0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const uint16_t* vp = vbp + (int64_t)min(key_c0 + r, S - 1) * ldv;
-        f.v[r][0] = vp[0];
-        f.v[r][1] = vp[16];
+        f.v[r][0] = __builtin_amdgcn_raw_buffer_load_b16(vr, vo[r], vs, 0);
+        f.v[r][1] = __builtin_amdgcn_raw_buffer_load_b16(vr, vo[r] + 32u, vs, 0);
     }
 }
 __device__ __forceinline__ void k_floats(const KVRaw<float>& f, float (&kf)[8]) {
@@ -104,8 +107,249 @@ __device__ __forceinline__ void v_operands(const KVRaw<uint16_t>& f, bf16x4 (&vb
 __device__ __forceinline__ float v_float(const KVRaw<float>& f, int r, int hh) { return f.v[r][hh]; }
 __device__ __forceinline__ float v_float(const KVRaw<uint16_t>& f, int r, int hh) { return __uint_as_float((unsigned)f.v[r][hh] << 16); }
 
-template <typename KVT, bool BF>
-__global__ __launch_bounds__(256) void hs_attn_kernel(const float* __restrict__ q, const KVT* __restrict__ k,
+// 1 / max(sqrt(ss), 1e-12) (F.normalize, AU:70-71): v_rsq_f32 and one Newton step instead of sqrt + IEEE division
+__device__ __forceinline__ float rnorm(float ss) {
+    const float x = fmaxf(ss, 1e-24f);
+    const float y = __builtin_amdgcn_rsqf(x);
+    return fmaf(y, fmaf(-0.5f * x * y, y, 0.5f), y);
+}
+
+// ---- the key stream shared by the two kernels ------------------------------------------------------------------------------
+// NQ: 16-query blocks a wave holds.  MM: 0 no mask; 1 mask read as one 4-byte word per (query, 4 keys) -- needs S % 4 == 0;
+// 2 mask read bytewise (any S).
+//
+// In a wave's loop over 16-key blocks every VALU instruction costs matrix-pipe issue slots (the two waves of a SIMD take
+// turns on it), so the per-block overhead is kept off the vector ALU:
+//   * addresses: K, V and the mask are read through buffer descriptors (SGPRs) with loop-invariant 32-bit lane offsets; the
+//     key block rides in the scalar offset of the load, so a FULL key block (all 16 keys < S) costs no vector arithmetic.
+//     Only the ragged last block of a sequence (and every block of the bytewise mask mode) takes the clamped per-lane
+//     offsets (keys_fetch_any);
+//   * masking: the mask byte enters as the INITIAL VALUE of the score accumulator, s0 = byte * -1e5 (v_cvt_f32_ubyteN +
+//     one multiply), so a masked pair leaves the MFMA chain at -1e5 + cos and exp2 returns exactly 0 -- no compare /
+//     select per score; keys beyond S are handled the same way (tail block only);
+//   * the key norm as v_rsq_f32 + one Newton step.
+template <typename KVT, int NQ, int MM>
+struct KeyFrag {
+    KVRaw<KVT> kv;
+    uint32_t mw[MM ? NQ : 1];
+};
+__device__ __forceinline__ void* uniform_ptr64(const void* p) {
+    const uint64_t u = (uint64_t)p;
+    return (void*)(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                   (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u));
+}
+template <typename KVT, int NQ, int MM>
+struct KeyCursor {
+    __amdgpu_buffer_rsrc_t kr, vr, mr;   // K, V of this (image, head); the mask of this image
+    unsigned ldk_b, ldv_b;               // row strides in bytes
+    int S, lj, lq;
+    unsigned ko;                         // lane: byte offset of dims lq*8.. of key lj
+    unsigned vo[4];                      // lane: byte offset of dim lj of key 4 lq + r
+    unsigned mo[MM ? NQ : 1];            // lane: byte offset of (this lane's clamped query row of block m, key 4 lq)
+
+    // qrow0: first query row of query block 0 of this wave (rows qrow0 + 16 m + lj).  The launcher checks that S * ld * sizeof(KVT)
+    // and Lq * S fit the 32-bit offsets.
+    __device__ __forceinline__ void init(const KVT* k, const KVT* v, const uint8_t* masked_b, int qrow0, int Lq, int S_, int64_t ldk, int64_t ldv,
+                                         int lj_, int lq_) {
+        S = S_; lj = lj_; lq = lq_;
+        ldk_b = (unsigned)ldk * (unsigned)sizeof(KVT);
+        ldv_b = (unsigned)ldv * (unsigned)sizeof(KVT);
+        kr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr64(k), 0, (unsigned)(S - 1) * ldk_b + HD * (unsigned)sizeof(KVT), 0x00020000);
+        vr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr64(v), 0, (unsigned)(S - 1) * ldv_b + HD * (unsigned)sizeof(KVT), 0x00020000);
+        ko = (unsigned)lj * ldk_b + (unsigned)lq * 8u * (unsigned)sizeof(KVT);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vo[r] = (unsigned)(lq * 4 + r) * ldv_b + (unsigned)lj * (unsigned)sizeof(KVT);
+        if constexpr (MM != 0) {
+            mr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr64(masked_b), 0, (unsigned)Lq * (unsigned)S, 0x00020000);
+#pragma unroll
+            for (int m_ = 0; m_ < NQ; ++m_) mo[m_] = (unsigned)min(qrow0 + m_ * 16 + lj, Lq - 1) * (unsigned)S + (unsigned)lq * 4u;
+        }
+    }
+};
+
+// a full key block (16 kb + 15 < S); kb is wave-uniform: no vector arithmetic
+template <typename KVT, int NQ, int MM>
+__device__ __forceinline__ void keys_fetch_full(const KeyCursor<KVT, NQ, MM>& c, int kb, KeyFrag<KVT, NQ, MM>& f) {
+    kv_fetch(f.kv, c.kr, c.ko, (unsigned)kb * 16u * c.ldk_b, c.vr, c.vo, (unsigned)kb * 16u * c.ldv_b);
+    if constexpr (MM != 0) {
+#pragma unroll
+        for (int m_ = 0; m_ < NQ; ++m_) f.mw[m_] = __builtin_amdgcn_raw_buffer_load_b32(c.mr, c.mo[m_], (unsigned)kb * 16u, 0);
+    }
+}
+// any key block: offsets clamped into the sequence (the out-of-range keys are switched off in keys_consume<true, ..>)
+template <typename KVT, int NQ, int MM>
+__device__ __forceinline__ void keys_fetch_any(const KeyCursor<KVT, NQ, MM>& c, int kb, KeyFrag<KVT, NQ, MM>& f) {
+    const int key_c0 = kb * 16 + c.lq * 4;
+    const unsigned ko = (unsigned)min(kb * 16 + c.lj, c.S - 1) * c.ldk_b + (unsigned)c.lq * 8u * (unsigned)sizeof(KVT);
+    unsigned vo[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) vo[r] = (unsigned)min(key_c0 + r, c.S - 1) * c.ldv_b + (unsigned)c.lj * (unsigned)sizeof(KVT);
+    kv_fetch(f.kv, c.kr, ko, 0u, c.vr, vo, 0u);
+    if constexpr (MM != 0) {
+#pragma unroll
+        for (int m_ = 0; m_ < NQ; ++m_) {
+            const unsigned row = c.mo[m_] - (unsigned)c.lq * 4u;
+            uint32_t w = 0;
+            if constexpr (MM == 1) {
+                w = __builtin_amdgcn_raw_buffer_load_b32(c.mr, row + (unsigned)min(key_c0, c.S - 4), 0u, 0);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w |= (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(c.mr, row + (unsigned)min(key_c0 + r, c.S - 1), 0u, 0) << (8 * r);
+            }
+            f.mw[m_] = w;
+        }
+    }
+}
+
+constexpr float MASK_BIAS = -1.0e5f;      // initial score of a masked pair: exp2(k2 * (-1e5 + cos) - k2) = 0
+
+typedef float f32x2l __attribute__((ext_vector_type(2)));
+
+// One key block against the NQ query blocks of a wave: S^T = K^ Q^^T, p = exp(kappa s - kappa), O += P V, l += row sums.
+// exp(kappa*s - kappa) is one fma + v_exp_f32 on the finished cosine: the argument is in [-2*kappa, 0], so the absolute error of
+// the fp32 argument (< 6e-6 at kappa = 30) bounds the relative error of p at ~4e-6.  (Carrying kappa log2(e) in the K fragment
+// and -kappa log2(e) in the accumulator's initial value saves that fma -- and loses two bits: the chain then rounds at the
+// magnitude of kappa log2(e) = 43 instead of 1; measured 3x the error against float64, not kept.)
+// TAIL: keys >= S of this block are switched off.
+template <bool TAIL, typename KVT, bool BF, int NQ, int MM>
+__device__ __forceinline__ void keys_consume(const KeyFrag<KVT, NQ, MM>& f, int kb, int S, int lq, float k2, const float (&qf)[NQ][8],
+                                             const bf16x4 (&qh)[BF ? NQ : 1][2], const bool (&use_mask)[NQ], f32x4 (&o)[NQ][2],
+                                             f32x2l (&lacc)[NQ]) {
+    float kr[8];
+    k_floats(f.kv, kr);
+    float ss = (kr[0] * kr[0] + kr[1] * kr[1] + kr[2] * kr[2] + kr[3] * kr[3]) + (kr[4] * kr[4] + kr[5] * kr[5] + kr[6] * kr[6] + kr[7] * kr[7]);
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    const float rn = rnorm(ss);
+    const float kf[8] = {kr[0] * rn, kr[1] * rn, kr[2] * rn, kr[3] * rn, kr[4] * rn, kr[5] * rn, kr[6] * rn, kr[7] * rn};
+    bf16x4 kh[2], vb[2];
+    if constexpr (BF) {
+        kh[0] = pack4(kf[0], kf[1], kf[2], kf[3]);
+        kh[1] = pack4(kf[4], kf[5], kf[6], kf[7]);
+        v_operands(f.kv, vb);
+    }
+    uint32_t oob = 0;
+    if constexpr (TAIL) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (kb * 16 + lq * 4 + r >= S) oob |= 0xffu << (8 * r);
+    }
+    auto scores = [&](int m) {
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (MM != 0 || TAIL) {
+            uint32_t mw = 0;
+            if constexpr (MM != 0) mw = use_mask[m] ? f.mw[m] : 0u;
+            if constexpr (TAIL) mw |= oob;
+            s = f32x4{(float)(mw & 0xffu) * MASK_BIAS, (float)((mw >> 8) & 0xffu) * MASK_BIAS, (float)((mw >> 16) & 0xffu) * MASK_BIAS,
+                      (float)(mw >> 24) * MASK_BIAS};
+        }
+        if constexpr (BF) {
+            s = mfma_bf16(kh[0], qh[m][0], s);
+            s = mfma_bf16(kh[1], qh[m][1], s);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) s = mfma16(kf[t], qf[m][t], s);
+        }
+        return s;                            // s[r]: key 16 kb + 4 lq + r, query lj of block m
+    };
+    // the score MFMAs of block m + 1 are issued before the exponentials of block m: their 8 x 32 cycles cover the result
+    // latency of the chain and the vector work in between
+    f32x4 s = scores(0);
+#pragma unroll
+    for (int m = 0; m < NQ; ++m) {
+        f32x4 sn = s;
+        if (m + 1 < NQ) sn = scores(m + 1);
+        float p[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(fmaf(s[r], k2, -k2));
+        lacc[m] += f32x2l{p[0], p[1]} + f32x2l{p[2], p[3]};
+        if constexpr (BF) {
+            const bf16x4 pp = pack4(p[0], p[1], p[2], p[3]);
+            o[m][0] = mfma_bf16(pp, vb[0], o[m][0]);
+            o[m][1] = mfma_bf16(pp, vb[1], o[m][1]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o[m][0] = mfma16(p[r], v_float(f.kv, r, 0), o[m][0]);
+                o[m][1] = mfma16(p[r], v_float(f.kv, r, 1), o[m][1]);
+            }
+        }
+        s = sn;
+    }
+}
+
+// The key blocks first, first + stride, ... < end of one wave: full blocks two per trip through a ping-pong pair of fragments
+// (block i + 2 strides is requested before the MFMAs of block i, pinned with sched_barrier), then the ragged last block of the
+// sequence, if it is this wave's, through the clamped path.
+template <typename KVT, bool BF, int NQ, int MM>
+__device__ __forceinline__ void keys_stream(const KeyCursor<KVT, NQ, MM>& cur, int first, int stride, int end, float k2, const float (&qf)[NQ][8],
+                                            const bf16x4 (&qh)[BF ? NQ : 1][2], const bool (&use_mask)[NQ], f32x4 (&o)[NQ][2],
+                                            float (&lsum)[NQ]) {
+    const int S = cur.S;
+    const int n_full = S / 16;
+    int kb = first;
+    f32x2l lacc[NQ];                          // row sums as two partial sums per query block (v_pk_add_f32)
+#pragma unroll
+    for (int m = 0; m < NQ; ++m) lacc[m] = f32x2l{0.f, 0.f};
+    if constexpr (MM != 2) {
+        const int full_end = min(end, n_full);
+        KeyFrag<KVT, NQ, MM> fa, fb;
+        if (kb < full_end) keys_fetch_full(cur, kb, fa);
+        for (; kb + stride < full_end; kb += 2 * stride) {
+            keys_fetch_full(cur, kb + stride, fb);
+            __builtin_amdgcn_sched_barrier(0);
+            keys_consume<false, KVT, BF, NQ, MM>(fa, kb, S, cur.lq, k2, qf, qh, use_mask, o, lacc);
+            __builtin_amdgcn_sched_barrier(0);
+            keys_fetch_full(cur, min(kb + 2 * stride, n_full - 1), fa);
+            __builtin_amdgcn_sched_barrier(0);
+            keys_consume<false, KVT, BF, NQ, MM>(fb, kb + stride, S, cur.lq, k2, qf, qh, use_mask, o, lacc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kb < full_end) {
+            keys_consume<false, KVT, BF, NQ, MM>(fa, kb, S, cur.lq, k2, qf, qh, use_mask, o, lacc);
+            kb += stride;
+        }
+    }
+    for (; kb < end; kb += stride) {
+        KeyFrag<KVT, NQ, MM> f;
+        keys_fetch_any(cur, kb, f);
+        keys_consume<true, KVT, BF, NQ, MM>(f, kb, S, cur.lq, k2, qf, qh, use_mask, o, lacc);
+    }
+#pragma unroll
+    for (int m = 0; m < NQ; ++m) lsum[m] += lacc[m][0] + lacc[m][1];
+}
+
+// Q^ fragments (B operand) of NQ query blocks starting at row qrow0: lane (query lj of block m, dims lq*8 + t); the per-row
+// mask enable: rows whose keys are all masked attend everywhere (DEC:618)
+template <bool BF, int NQ>
+__device__ __forceinline__ void load_queries(const float* __restrict__ qb, int64_t ldq, int qrow0, int Lq, int lj, bool masked,
+                                             const int32_t* __restrict__ row_any_b, float (&qf)[NQ][8], bf16x4 (&qh)[BF ? NQ : 1][2],
+                                             bool (&use_mask)[NQ]) {
+#pragma unroll
+    for (int m = 0; m < NQ; ++m) {
+        const int qi = qrow0 + m * 16 + lj;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+        if (qi < Lq) {
+            const float* p = qb + (int64_t)qi * ldq;
+            a = *reinterpret_cast<const float4*>(p);
+            c = *reinterpret_cast<const float4*>(p + 4);
+        }
+        float ss = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        const float rn = rnorm(ss);
+        qf[m][0] = a.x * rn; qf[m][1] = a.y * rn; qf[m][2] = a.z * rn; qf[m][3] = a.w * rn;
+        qf[m][4] = c.x * rn; qf[m][5] = c.y * rn; qf[m][6] = c.z * rn; qf[m][7] = c.w * rn;
+        if constexpr (BF) {
+            qh[m][0] = pack4(qf[m][0], qf[m][1], qf[m][2], qf[m][3]);
+            qh[m][1] = pack4(qf[m][4], qf[m][5], qf[m][6], qf[m][7]);
+        }
+        use_mask[m] = masked && qi < Lq && (row_any_b == nullptr || row_any_b[qi] != 0);
+    }
+}
+
+template <typename KVT, bool BF, int MM>
+__global__ __launch_bounds__(256, 2) void hs_attn_kernel(const float* __restrict__ q, const KVT* __restrict__ k,
                                                       const KVT* __restrict__ v, const uint8_t* __restrict__ masked,
                                                       const int32_t* __restrict__ row_any, float* __restrict__ part,
                                                       float* __restrict__ out, int Lq, int S, int heads, int qchunks, int nsplit, int64_t ldq,
@@ -119,37 +363,11 @@ __global__ __launch_bounds__(256) void hs_attn_kernel(const float* __restrict__ 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably uniform: scalar key-block loop
     const int lj = lane & 15, lq = lane >> 4;
 
-    // ---- Q^ fragments (B operand): lane (query lj of block m, dims lq*8 + t) ----
     float qf[AQB][8];
     bf16x4 qh[BF ? AQB : 1][2];             // BF: the same fragments as bf16 B operands (dims lq*8 + 0..3 | + 4..7)
-    const float* qb = q + (int64_t)b * q_sb + h * HD + lq * 8;
-#pragma unroll
-    for (int m = 0; m < AQB; ++m) {
-        const int qi = q0 + m * 16 + lj;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
-        if (qi < Lq) {
-            const float* p = qb + (int64_t)qi * ldq;
-            a = *reinterpret_cast<const float4*>(p);
-            c = *reinterpret_cast<const float4*>(p + 4);
-        }
-        float ss = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
-        const float rn = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-        qf[m][0] = a.x * rn; qf[m][1] = a.y * rn; qf[m][2] = a.z * rn; qf[m][3] = a.w * rn;
-        qf[m][4] = c.x * rn; qf[m][5] = c.y * rn; qf[m][6] = c.z * rn; qf[m][7] = c.w * rn;
-        if constexpr (BF) {
-            qh[m][0] = pack4(qf[m][0], qf[m][1], qf[m][2], qf[m][3]);
-            qh[m][1] = pack4(qf[m][4], qf[m][5], qf[m][6], qf[m][7]);
-        }
-    }
-    // per-row mask enable: rows whose keys are all masked attend everywhere (DEC:618)
     bool use_mask[AQB];
-#pragma unroll
-    for (int m = 0; m < AQB; ++m) {
-        const int qi = q0 + m * 16 + lj;
-        use_mask[m] = masked != nullptr && qi < Lq && (row_any == nullptr || row_any[(int64_t)b * Lq + qi] != 0);
-    }
+    load_queries<BF, AQB>(q + (int64_t)b * q_sb + h * HD + lq * 8, ldq, q0, Lq, lj, MM != 0, row_any ? row_any + (int64_t)b * Lq : nullptr, qf, qh,
+                          use_mask);
 
     f32x4 o[AQB][2];
     float lsum[AQB];
@@ -164,102 +382,10 @@ __global__ __launch_bounds__(256) void hs_attn_kernel(const float* __restrict__ 
     const int nkb = (S + 15) / 16;
     const int kb_per = (nkb + nsplit - 1) / nsplit;
     const int kb_beg = split * kb_per, kb_end = min(nkb, kb_beg + kb_per);
-    const KVT* kbp = k + (int64_t)b * k_sb + h * HD + lq * 8;
-    const KVT* vbp = v + (int64_t)b * v_sb + h * HD + lj;
-    const bool mask_vec = (S % 4) == 0;
-
-    // Software prefetch: the K / V fragments and the 7 mask words of key block kb+4 are fetched (from
-    // clamped, always-valid addresses) before the 112 MFMAs of block kb, pinned with sched_barrier.
-    struct Frag {
-        KVRaw<KVT> kv;
-        uint32_t mw[AQB];
-    };
-    auto fetch = [&](int kb, Frag& f) {
-        const int key_a = min(kb * 16 + lj, S - 1);
-        const int key_c0 = kb * 16 + lq * 4;
-        kv_fetch(f.kv, kbp + (int64_t)key_a * ldk, vbp, ldv, key_c0, S);
-#pragma unroll
-        for (int m = 0; m < AQB; ++m) {
-            uint32_t w = 0;
-            if (masked != nullptr) {
-                const int qi = min(q0 + m * 16 + lj, Lq - 1);
-                const uint8_t* mp = masked + ((int64_t)b * Lq + qi) * S;
-                if (mask_vec) {
-                    w = *reinterpret_cast<const uint32_t*>(mp + min(key_c0, S - 4));
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) w |= (uint32_t)mp[min(key_c0 + r, S - 1)] << (8 * r);
-                }
-            }
-            f.mw[m] = w;
-        }
-    };
-    const float k2 = kappa * 1.4426950408889634f;   // kappa * log2(e)
-    auto consume = [&](int kb, const Frag& f) {
-        float kr[8];
-        k_floats(f.kv, kr);
-        float ss = (kr[0] * kr[0] + kr[1] * kr[1] + kr[2] * kr[2] + kr[3] * kr[3]) + (kr[4] * kr[4] + kr[5] * kr[5] + kr[6] * kr[6] + kr[7] * kr[7]);
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
-        const float rn = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-        const float kf[8] = {kr[0] * rn, kr[1] * rn, kr[2] * rn, kr[3] * rn, kr[4] * rn, kr[5] * rn, kr[6] * rn, kr[7] * rn};
-        bf16x4 kh[2], vb[2];
-        if constexpr (BF) {
-            kh[0] = pack4(kf[0], kf[1], kf[2], kf[3]);
-            kh[1] = pack4(kf[4], kf[5], kf[6], kf[7]);
-            v_operands(f.kv, vb);
-        }
-        const int key_c0 = kb * 16 + lq * 4;
-#pragma unroll
-        for (int m = 0; m < AQB; ++m) {
-            f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (BF) {
-                s = mfma_bf16(kh[0], qh[m][0], s);
-                s = mfma_bf16(kh[1], qh[m][1], s);
-            } else {
-#pragma unroll
-                for (int t = 0; t < 8; ++t) s = mfma16(kf[t], qf[m][t], s);
-            }
-            // s[r]: key key_c0 + r, query q0 + m*16 + lj
-            const uint32_t mw = use_mask[m] ? f.mw[m] : 0u;
-            float p[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool dead = (key_c0 + r >= S) || ((mw >> (8 * r)) & 0xffu);
-                // exp(kappa*s - kappa) as one fma + v_exp_f32: the argument is in [-2*kappa, 0], so the absolute
-                // error of the fp32 argument (< 6e-6 at kappa = 30) bounds the relative error of p at ~4e-6
-                p[r] = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], k2, -k2));
-            }
-            lsum[m] += (p[0] + p[1]) + (p[2] + p[3]);
-            if constexpr (BF) {
-                const bf16x4 pp = pack4(p[0], p[1], p[2], p[3]);
-                o[m][0] = mfma_bf16(pp, vb[0], o[m][0]);
-                o[m][1] = mfma_bf16(pp, vb[1], o[m][1]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    o[m][0] = mfma16(p[r], v_float(f.kv, r, 0), o[m][0]);
-                    o[m][1] = mfma16(p[r], v_float(f.kv, r, 1), o[m][1]);
-                }
-            }
-        }
-    };
-    {
-        Frag fa, fb;
-        int kb = kb_beg + wave;
-        if (kb < kb_end) fetch(kb, fa);
-        for (; kb + 4 < kb_end; kb += 8) {        // two blocks per trip: ping-pong without register copies
-            fetch(kb + 4, fb);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(kb, fa);
-            __builtin_amdgcn_sched_barrier(0);
-            fetch(min(kb + 8, nkb - 1), fa);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(kb + 4, fb);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (kb < kb_end) consume(kb, fa);
-    }
+    KeyCursor<KVT, AQB, MM> cur;
+    cur.init(k + (int64_t)b * k_sb + h * HD, v + (int64_t)b * v_sb + h * HD, MM != 0 ? masked + (int64_t)b * Lq * S : nullptr, q0, Lq, S, ldk, ldv, lj,
+             lq);
+    keys_stream<KVT, BF, AQB, MM>(cur, kb_beg + wave, 4, kb_end, kappa * 1.4426950408889634f /* kappa * log2(e) */, qf, qh, use_mask, o, lsum);
 
     // ---- reduce the 4 waves through LDS, then one partial per workgroup ----
     float* mine = red + wave * (AQCH * PSTRIDE);
@@ -315,7 +441,7 @@ __global__ __launch_bounds__(256) void hs_attn_kernel(const float* __restrict__ 
 // partial sums meet in LDS (lane-contiguous, 9 values per lane and query block) and wave 0 finishes in registers.  No
 // partial tensors in memory, no combine launch; K/V of an (image, head) are re-read by the ceil(7/MQ) workgroups of that
 // head out of L2.
-template <int MQ, int NW, typename KVT, bool BF>
+template <int MQ, int NW, typename KVT, bool BF, int MM>
 __global__ __launch_bounds__(NW * 64) void hs_attn_qk_kernel(const float* __restrict__ q, const KVT* __restrict__ k,
                                                             const KVT* __restrict__ v, const uint8_t* __restrict__ masked,
                                                             const int32_t* __restrict__ row_any, float* __restrict__ out, int Lq,
@@ -331,28 +457,8 @@ __global__ __launch_bounds__(NW * 64) void hs_attn_qk_kernel(const float* __rest
     float qf[MQ][8];
     bf16x4 qh[BF ? MQ : 1][2];
     bool use_mask[MQ];
-    const float* qbp = q + (int64_t)b * q_sb + h * HD + lq * 8;
-#pragma unroll
-    for (int m = 0; m < MQ; ++m) {
-        const int qi = (qb0 + m) * 16 + lj;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
-        if (qi < Lq) {
-            const float* p = qbp + (int64_t)qi * ldq;
-            a = *reinterpret_cast<const float4*>(p);
-            c = *reinterpret_cast<const float4*>(p + 4);
-        }
-        float ss = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
-        const float rn = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-        qf[m][0] = a.x * rn; qf[m][1] = a.y * rn; qf[m][2] = a.z * rn; qf[m][3] = a.w * rn;
-        qf[m][4] = c.x * rn; qf[m][5] = c.y * rn; qf[m][6] = c.z * rn; qf[m][7] = c.w * rn;
-        if constexpr (BF) {
-            qh[m][0] = pack4(qf[m][0], qf[m][1], qf[m][2], qf[m][3]);
-            qh[m][1] = pack4(qf[m][4], qf[m][5], qf[m][6], qf[m][7]);
-        }
-        use_mask[m] = masked != nullptr && qi < Lq && (row_any == nullptr || row_any[(int64_t)b * Lq + qi] != 0);   // DEC:618
-    }
+    load_queries<BF, MQ>(q + (int64_t)b * q_sb + h * HD + lq * 8, ldq, qb0 * 16, Lq, lj, MM != 0, row_any ? row_any + (int64_t)b * Lq : nullptr, qf,
+                         qh, use_mask);
     f32x4 o[MQ][2];
     float lsum[MQ];
 #pragma unroll
@@ -360,101 +466,11 @@ __global__ __launch_bounds__(NW * 64) void hs_attn_qk_kernel(const float* __rest
         o[m][0] = o[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         lsum[m] = 0.f;
     }
-    const int nkb = (S + 15) / 16;
-    const KVT* kbp = k + (int64_t)b * k_sb + h * HD + lq * 8;
-    const KVT* vbp = v + (int64_t)b * v_sb + h * HD + lj;
-    const bool mask_vec = (S % 4) == 0;
-    struct Frag {
-        KVRaw<KVT> kv;
-        uint32_t mw[MQ];
-    };
-    auto fetch = [&](int kb, Frag& f) {
-        const int key_c0 = kb * 16 + lq * 4;
-        kv_fetch(f.kv, kbp + (int64_t)min(kb * 16 + lj, S - 1) * ldk, vbp, ldv, key_c0, S);
-#pragma unroll
-        for (int m = 0; m < MQ; ++m) {
-            uint32_t w = 0;
-            if (masked != nullptr) {
-                const uint8_t* mp = masked + ((int64_t)b * Lq + min((qb0 + m) * 16 + lj, Lq - 1)) * S;
-                if (mask_vec) {
-                    w = *reinterpret_cast<const uint32_t*>(mp + min(key_c0, S - 4));
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) w |= (uint32_t)mp[min(key_c0 + r, S - 1)] << (8 * r);
-                }
-            }
-            f.mw[m] = w;
-        }
-    };
-    const float k2 = kappa * 1.4426950408889634f;
-    auto consume = [&](int kb, const Frag& f) {
-        float kr[8];
-        k_floats(f.kv, kr);
-        float ss = (kr[0] * kr[0] + kr[1] * kr[1] + kr[2] * kr[2] + kr[3] * kr[3]) + (kr[4] * kr[4] + kr[5] * kr[5] + kr[6] * kr[6] + kr[7] * kr[7]);
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
-        const float rn = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
-        const float kf[8] = {kr[0] * rn, kr[1] * rn, kr[2] * rn, kr[3] * rn, kr[4] * rn, kr[5] * rn, kr[6] * rn, kr[7] * rn};
-        bf16x4 kh[2], vb[2];
-        if constexpr (BF) {
-            kh[0] = pack4(kf[0], kf[1], kf[2], kf[3]);
-            kh[1] = pack4(kf[4], kf[5], kf[6], kf[7]);
-            v_operands(f.kv, vb);
-        }
-        const int key_c0 = kb * 16 + lq * 4;
-        f32x4 sc[MQ];
-#pragma unroll
-        for (int m = 0; m < MQ; ++m) sc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (BF) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int m = 0; m < MQ; ++m) sc[m] = mfma_bf16(kh[c], qh[m][c], sc[m]);
-        } else {
-#pragma unroll
-            for (int t = 0; t < 8; ++t)
-#pragma unroll
-                for (int m = 0; m < MQ; ++m) sc[m] = mfma16(kf[t], qf[m][t], sc[m]);
-        }
-#pragma unroll
-        for (int m = 0; m < MQ; ++m) {
-            const uint32_t mw = use_mask[m] ? f.mw[m] : 0u;
-            float p[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool dead = (key_c0 + r >= S) || ((mw >> (8 * r)) & 0xffu);
-                p[r] = dead ? 0.f : __builtin_amdgcn_exp2f(fmaf(sc[m][r], k2, -k2));
-            }
-            lsum[m] += (p[0] + p[1]) + (p[2] + p[3]);
-            if constexpr (BF) {
-                const bf16x4 pp = pack4(p[0], p[1], p[2], p[3]);
-                o[m][0] = mfma_bf16(pp, vb[0], o[m][0]);
-                o[m][1] = mfma_bf16(pp, vb[1], o[m][1]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    o[m][0] = mfma16(p[r], v_float(f.kv, r, 0), o[m][0]);
-                    o[m][1] = mfma16(p[r], v_float(f.kv, r, 1), o[m][1]);
-                }
-            }
-        }
-    };
-    {
-        Frag fa, fb;
-        int kb = wave;                             // key blocks wave, wave + NW, ...
-        if (kb < nkb) fetch(kb, fa);
-        for (; kb + NW < nkb; kb += 2 * NW) {
-            fetch(kb + NW, fb);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(kb, fa);
-            __builtin_amdgcn_sched_barrier(0);
-            fetch(min(kb + 2 * NW, nkb - 1), fa);
-            __builtin_amdgcn_sched_barrier(0);
-            consume(kb + NW, fb);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (kb < nkb) consume(kb, fa);
-    }
+    KeyCursor<KVT, MQ, MM> cur;
+    cur.init(k + (int64_t)b * k_sb + h * HD, v + (int64_t)b * v_sb + h * HD, MM != 0 ? masked + (int64_t)b * Lq * S : nullptr, qb0 * 16, Lq, S, ldk,
+             ldv, lj, lq);
+    keys_stream<KVT, BF, MQ, MM>(cur, wave, NW, (S + 15) / 16, kappa * 1.4426950408889634f, qf, qh, use_mask, o, lsum);   // blocks wave, wave + NW, ...
+
     // ---- sum the waves' partials: waves 1.. park theirs lane-contiguously, wave 0 adds them to its registers ----
     if (wave > 0) {
         float* mine = red + (size_t)(wave - 1) * MQ * 9 * 64;
@@ -506,20 +522,23 @@ __global__ __launch_bounds__(NW * 64) void hs_attn_qk_kernel(const float* __rest
     }
 }
 
-// out[b][q][h*32 + d] = normalize( (sum_splits O) / (sum_splits l) ).  One workgroup per (head, image-chunk): the
-// partial tiles are summed element-wise with 4 splits x 15 elements of independent loads in flight per thread (a
+// out[b][q][h*32 + d] = normalize( (sum_splits O) / (sum_splits l) ).  One workgroup per (head, image-chunk, 16-query block)
+// -- 448 workgroups at B = 8 (one per (head, image-chunk) left 192 of the 256 CUs idle for a launch that is all latency): the
+// block's 16 x 33 partial values are summed element-wise with 4 splits x 3 elements of independent loads in flight per thread (a
 // per-query loop over the splits is a chain of nsplit * 33 dependent L2 round trips: 8.6 us), then two lanes per query
 // finish from LDS with 16-byte stores.
 // (Folding this into hs_attn_kernel -- last workgroup to arrive combines -- was measured: the device-scope release /
 // acquire it needs writes back and invalidates the per-XCD L2s on gfx950, 70 -> 130 us.  Two launches it is.)
 __global__ __launch_bounds__(256) void hs_attn_combine_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                               int Lq, int heads, int qchunks, int nsplit) {
-    __shared__ float tot[AQCH * PSTRIDE];
-    const int h = blockIdx.x;
+    constexpr int BLK = 16 * PSTRIDE;                    // one query block of a partial tile
+    __shared__ float tot[BLK];
+    const int h = blockIdx.x, qb = blockIdx.z;
     const int b = blockIdx.y / qchunks, qc = blockIdx.y - b * qchunks;
     const int tid = threadIdx.x;
-    const float* base = part + (((int64_t)blockIdx.y * heads + h) * nsplit) * (AQCH * PSTRIDE);
-    constexpr int NE = (AQCH * PSTRIDE + 255) / 256;
+    if (qc * AQCH + qb * 16 >= Lq) return;              // a block of padding rows only
+    const float* base = part + (((int64_t)blockIdx.y * heads + h) * nsplit) * (AQCH * PSTRIDE) + qb * BLK;
+    constexpr int NE = (BLK + 255) / 256;
     float t[NE];
 #pragma unroll
     for (int j = 0; j < NE; ++j) t[j] = 0.f;
@@ -532,7 +551,7 @@ __global__ __launch_bounds__(256) void hs_attn_combine_kernel(const float* __res
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
                 const int i = tid + 256 * j;
-                u[r][j] = (on && i < AQCH * PSTRIDE) ? src[i] : 0.f;
+                u[r][j] = (on && i < BLK) ? src[i] : 0.f;
             }
         }
 #pragma unroll
@@ -542,11 +561,11 @@ __global__ __launch_bounds__(256) void hs_attn_combine_kernel(const float* __res
     }
 #pragma unroll
     for (int j = 0; j < NE; ++j)
-        if (tid + 256 * j < AQCH * PSTRIDE) tot[tid + 256 * j] = t[j];
+        if (tid + 256 * j < BLK) tot[tid + 256 * j] = t[j];
     __syncthreads();
     const int ql = tid >> 1, half = tid & 1;             // two lanes per query, 16 output dims each
-    const int qi = qc * AQCH + ql;
-    if (ql >= AQCH) return;
+    const int qi = qc * AQCH + qb * 16 + ql;
+    if (ql >= 16) return;
     const float l = tot[ql * PSTRIDE + HD];
     float a[16];
     float ss = 0.f;
@@ -585,6 +604,11 @@ static int attn_launch(const char* who, const float* q, const KVT* k, const KVT*
     MSM_REQUIRE(ldq % 4 == 0 && ldk % KA == 0 && q_sb % 4 == 0 && k_sb % KA == 0 && (((uintptr_t)q) & 15) == 0 && (((uintptr_t)k) & 15) == 0,
                 "%s: q/k must be 16-byte aligned with row / batch strides that keep them so", who);
     MSM_REQUIRE(!masked || (((uintptr_t)masked) & 3) == 0, "%s: mask must be 4-byte aligned", who);
+    MSM_REQUIRE(ldk > 0 && ldv > 0 && (int64_t)S * ldk * (int64_t)sizeof(KVT) < ((int64_t)1 << 32) && (int64_t)S * ldv * (int64_t)sizeof(KVT) < ((int64_t)1 << 32) &&
+                    (int64_t)Lq * S < ((int64_t)1 << 32),
+                "%s: one image of K / V / mask must stay below 4 GiB (32-bit buffer offsets)", who);
+    // mask access of the kernels: 0 none, 1 one 4-byte word per (query, key quad), 2 bytewise (key counts that are not multiples of 4)
+    const int mm = !masked ? 0 : (S % 4 == 0 ? 1 : 2);
     const int qchunks = cdiv(Lq, AQCH);
     const int ns = attn_nsplit(B, qchunks, heads, S);
     const int64_t need = (int64_t)B * qchunks * heads * ns * AQCH * PSTRIDE;
@@ -603,30 +627,46 @@ static int attn_launch(const char* who, const float* q, const KVT* k, const KVT*
         // one query block per workgroup for the shortest sequences (self-attention, 100 keys: 6.9 against 8.0 us), two
         // otherwise (K/V are read by half as many workgroups); other shapes measured slower at every length
         const int cfg = cfg_env >= 0 ? cfg_env : (S <= 128 ? 1 : 0);
-#define QK_LAUNCH(MQ_, NW_)                                                                                                     \
+#define QK_LAUNCH_M(MQ_, NW_, MM_)                                                                                              \
     {                                                                                                                           \
         dim3 grid(cdiv(cdiv(Lq, 16), MQ_), heads, B);                                                                           \
         const size_t lds2 = sizeof(float) * (size_t)(NW_ - 1) * MQ_ * 9 * 64;                                                   \
-        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)hs_attn_qk_kernel<MQ_, NW_, KVT, BF>, lds2));                 \
-        hipLaunchKernelGGL((hs_attn_qk_kernel<MQ_, NW_, KVT, BF>), grid, dim3(NW_ * 64), lds2, st, q, k, v, masked, row_any, out, Lq, S, \
-                           heads, ldq, q_sb, ldk, k_sb, ldv, v_sb, kappa);                                                      \
+        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)hs_attn_qk_kernel<MQ_, NW_, KVT, BF, MM_>, lds2));            \
+        hipLaunchKernelGGL((hs_attn_qk_kernel<MQ_, NW_, KVT, BF, MM_>), grid, dim3(NW_ * 64), lds2, st, q, k, v, masked, row_any, out, Lq, \
+                           S, heads, ldq, q_sb, ldk, k_sb, ldv, v_sb, kappa);                                                   \
+    }
+#define QK_LAUNCH(MQ_, NW_)                                                                                                     \
+    switch (mm) {                                                                                                               \
+        case 0: QK_LAUNCH_M(MQ_, NW_, 0) break;                                                                                 \
+        case 1: QK_LAUNCH_M(MQ_, NW_, 1) break;                                                                                 \
+        default: QK_LAUNCH_M(MQ_, NW_, 2) break;                                                                                \
     }
         switch (cfg) {
             case 1: QK_LAUNCH(1, 8) break;
             default: QK_LAUNCH(2, 8) break;
         }
 #undef QK_LAUNCH
+#undef QK_LAUNCH_M
         MSM_CHECK_LAUNCH(who);
         return MSM_OK;
     }
     const size_t lds = sizeof(float) * 4 * AQCH * PSTRIDE;
-    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)hs_attn_kernel<KVT, BF>, lds));
     dim3 grid(ns, heads, B * qchunks), block(256);
-    hipLaunchKernelGGL((hs_attn_kernel<KVT, BF>), grid, block, lds, st, q, k, v, masked, row_any, workspace, out, Lq, S, heads, qchunks,
-                       ns, ldq, q_sb, ldk, k_sb, ldv, v_sb, kappa);
+#define BIG_LAUNCH(MM_)                                                                                                         \
+    {                                                                                                                           \
+        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)hs_attn_kernel<KVT, BF, MM_>, lds));                          \
+        hipLaunchKernelGGL((hs_attn_kernel<KVT, BF, MM_>), grid, block, lds, st, q, k, v, masked, row_any, workspace, out, Lq, S, heads, \
+                           qchunks, ns, ldq, q_sb, ldk, k_sb, ldv, v_sb, kappa);                                                \
+    }
+    switch (mm) {
+        case 0: BIG_LAUNCH(0) break;
+        case 1: BIG_LAUNCH(1) break;
+        default: BIG_LAUNCH(2) break;
+    }
+#undef BIG_LAUNCH
     MSM_CHECK_LAUNCH(who);
     if (ns == 1) return MSM_OK;
-    dim3 g2(heads, B * qchunks), b2(256);
+    dim3 g2(heads, B * qchunks, AQB), b2(256);
     hipLaunchKernelGGL(hs_attn_combine_kernel, g2, b2, 0, st, workspace, out, Lq, heads, qchunks, ns);
     MSM_CHECK_LAUNCH(who);
     return MSM_OK;
