@@ -195,6 +195,134 @@ __global__ __launch_bounds__(CI_W * 64, 4) void conv_in_kernel(const float* __re
     conv_in_tile<NT, D>(x, w, bias, out, out_sb, stats, Cin, HW, blockIdx.y, blockIdx.x, red);
 }
 
+// ---- shallow K (the FPN lateral on res2: Cin = 256, 19 200 pixels per image) -------------------------------------------------
+// With K = 256 the eight-way K split above is all reduction (70 us at B = 8), and the tiled GEMM needs a second pass over its
+// output for the GroupNorm moments (61 + 10 us).  Here every wave owns its own 16*NT-pixel tile over the full K -- no partial
+// tiles, no reduction --, x and the packed weight (64 KB, L2 resident) stream through a ring of D k-groups per wave, four-wave
+// workgroups are dispatched as slots free up (4800 tiles over 1024 SIMDs: no fixed assignment to round up), and the moments
+// leave as one double atomic per (workgroup, channel, moment) as above.
+constexpr int CS_W = 4;             // waves per workgroup of the shallow-K kernel
+template <int NT, int D>
+__global__ __launch_bounds__(CS_W * 64, 4) void conv_in_shallow_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                    const float* __restrict__ bias, float* __restrict__ out,
+                                                                    int64_t out_sb, double* __restrict__ stats, int Cin, int HW) {
+    __shared__ float st[CS_W * CI_O * 2];                                 // [wave][64 ch][2]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    const int b = blockIdx.y;
+    const int tile = blockIdx.x * CS_W + wave;
+    const int px0 = tile * (16 * NT);
+    const bool live = px0 < HW;                                           // wave-uniform
+    float sm[4][4], sq[4][4];                                             // moments of this wave's tile per (channel block, r)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sm[mt][r] = sq[mt][r] = 0.f;
+    if (live) {
+        auto uniform_ptr = [](const void* p) {
+            const uint64_t u = (uint64_t)p;
+            return (void*)(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                           (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u));
+        };
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(x + (int64_t)b * Cin * HW), 0, Cin * HW * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(w), 0, CI_O * Cin * 4, 0x00020000);
+        const unsigned xo = 4u * (unsigned)(lq * 2 * HW + min(px0 + NT * lj, HW - NT));
+        const unsigned wo = 8u * (unsigned)lane;
+        f32x4 acc[4][NT];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float2 wa[D][4];
+        float xa[D][NT][2];
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        auto load = [&](int kg, float2 (&wf)[4], float (&xf)[NT][2]) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(wr, wo, (unsigned)(kg * 4 + mt) * 512u, 0);
+                wf[mt] = make_float2(__uint_as_float(t.x), __uint_as_float(t.y));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned so = (unsigned)(kg * 8 + j) * (unsigned)HW * 4u;
+                if constexpr (NT == 4) {
+                    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(xr, xo, so, 0);
+                    xf[0][j] = __uint_as_float(t.x); xf[1][j] = __uint_as_float(t.y);
+                    xf[2][j] = __uint_as_float(t.z); xf[3][j] = __uint_as_float(t.w);
+                } else {
+                    const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(xr, xo, so, 0);
+                    xf[0][j] = __uint_as_float(t.x); xf[1][j] = __uint_as_float(t.y);
+                }
+            }
+        };
+        auto mma = [&](const float2 (&wf)[4], const float (&xf)[NT][2]) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const float a = j == 0 ? wf[mt].x : wf[mt].y;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(a, xf[nt][j], acc[mt][nt]);
+                }
+        };
+        const int groups = Cin / 8;                       // a multiple of D
+#pragma unroll
+        for (int d = 0; d < D; ++d) load(d, wa[d], xa[d]);
+#pragma unroll 1
+        for (int kg = 0; kg < groups; kg += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                mma(wa[d], xa[d]);
+                if (kg + D + d < groups) load(kg + D + d, wa[d], xa[d]);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int ch = mt * 16 + lq * 4;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bias) bv = *reinterpret_cast<const float4*>(bias + ch);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int px = px0 + NT * lj + nt;             // pixel block nt holds pixels px0 + NT*n + nt
+                const f32x4 v = acc[mt][nt];
+                const float v0 = v[0] + bv.x, v1 = v[1] + bv.y, v2 = v[2] + bv.z, v3 = v[3] + bv.w;
+                if (px < HW) {
+                    *reinterpret_cast<float4*>(out + (int64_t)b * out_sb + (int64_t)px * CI_O + ch) = make_float4(v0, v1, v2, v3);
+                    sm[mt][0] += v0; sm[mt][1] += v1; sm[mt][2] += v2; sm[mt][3] += v3;
+                    sq[mt][0] += v0 * v0; sq[mt][1] += v1 * v1; sq[mt][2] += v2 * v2; sq[mt][3] += v3 * v3;
+                }
+            }
+        }
+    }
+    if (stats) {
+        // reduce over the 16 pixels of a lane quarter, one LDS slot per (wave, channel); the workgroup's four slots are summed in
+        // a fixed order, so nothing below the per-workgroup double adds depends on timing
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    sm[mt][r] += __shfl_xor(sm[mt][r], o, 64);
+                    sq[mt][r] += __shfl_xor(sq[mt][r], o, 64);
+                }
+                if (lj == 0) {
+                    st[(wave * CI_O + mt * 16 + lq * 4 + r) * 2 + 0] = sm[mt][r];
+                    st[(wave * CI_O + mt * 16 + lq * 4 + r) * 2 + 1] = sq[mt][r];
+                }
+            }
+        __syncthreads();
+        if (tid < CI_O * 2) {
+            double v = 0.0;
+#pragma unroll
+            for (int s = 0; s < CS_W; ++s) v += (double)st[s * CI_O * 2 + tid];
+            atomicAdd(stats + (int64_t)b * CI_O * 2 + tid, v);
+        }
+    }
+}
+
 // All input projections of the pixel decoder in ONE launch: the levels are independent, and on its own each coarse level
 // fills a fraction of the chip (res5 at B = 8: 152 workgroups).  Workgroups are numbered level by level in the order given
 // (deepest K first, so the longest-running tiles start first); cfg selects the tile shape per level.
@@ -263,6 +391,18 @@ extern "C" int msm_conv1x1_in_f32(const float* x, const float* w, const float* b
     if (stats && !stats_cleared) MSM_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * CI_O * (size_t)B, st));
     int nt;
     const int cfg = conv_in_config(B, Cin, HW, nt);
+    if (Cin <= 384 && Cin % 64 == 0 && (int64_t)B * HW >= 32 * 1024) {
+        // shallow K over many pixels (the FPN lateral): one tile per wave, no K split
+        const int snt = opt(MSM_OPT_CONVIN_NT) == 4 ? 4 : 2;
+        dim3 sgrid(cdiv(cdiv(HW, 16 * snt), CS_W), B);
+        if (snt == 4) {
+            hipLaunchKernelGGL((conv_in_shallow_kernel<4, 2>), sgrid, dim3(CS_W * 64), 0, st, x, w, bias, out, out_batch_stride, stats, Cin, HW);
+        } else {
+            hipLaunchKernelGGL((conv_in_shallow_kernel<2, 4>), sgrid, dim3(CS_W * 64), 0, st, x, w, bias, out, out_batch_stride, stats, Cin, HW);
+        }
+        MSM_CHECK_LAUNCH("msm_conv1x1_in_f32");
+        return MSM_OK;
+    }
     dim3 grid(cdiv(HW, 16 * nt), B), block(CI_W * 64);
     const size_t lds = conv_in_lds(nt);
 #define CI_LAUNCH(NT_, D_)                                                                                        \

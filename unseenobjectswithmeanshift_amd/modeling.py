@@ -807,6 +807,14 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
             self._w3_cache = (key, p.permute(0, 2, 3, 1).reshape(p.shape[0], -1).contiguous())
         return self._w3_cache[1]
 
+    def _w_lateral(self):
+        """adapter_1's 1x1 weight in the fragment order of msm_conv1x1_in_f32, cached per parameter version."""
+        p = self.adapter_1.weight
+        key = (p.data_ptr(), p._version)
+        if getattr(self, "_wl_cache", None) is None or self._wl_cache[0] != key:
+            self._wl_cache = (key, ops.pack_conv_in_weight(p.view(p.shape[0], -1)))
+        return self._wl_cache[1]
+
     def _use_fused_msda(self, device):
         """The gather computes its own sampling projection: fp32 plan, the shipped geometry (64 channels, 8 heads, 3 levels x 4
         points), 16-byte-aligned token buffers."""
@@ -964,9 +972,15 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
         # one FPN level on the highest-resolution backbone feature (MSD:343-351)
         x = features[self.in_features[0]].float().contiguous()
         H, W = int(x.shape[2]), int(x.shape[3])
-        lat = ops.conv1x1_nchw_to_tokens(x, self.adapter_1.weight.view(C, -1), None)
-        y = ops.groupnorm_tokens(lat, self.adapter_1.norm.weight, self.adapter_1.norm.bias, H, W, groups=32,
-                                 up=up_tok, up_hw=up_hw, eps=self.adapter_1.norm.eps, stats=fpn_stats[0])
+        if C == 64 and x.shape[1] % 128 == 0 and x.shape[1] <= 384 and (H * W) % 4 == 0 and B * H * W >= 32 * 1024:
+            # shallow-K input-projection kernel: the GroupNorm moments come out of its epilogue (no moments pass over lat)
+            lat, lat_stats = ops.conv1x1_in(x, self._w_lateral(), None, stats=fpn_stats[0], stats_cleared=fpn_stats[0] is not None)
+            y = ops.groupnorm_tokens(lat, self.adapter_1.norm.weight, self.adapter_1.norm.bias, H, W, groups=32,
+                                     up=up_tok, up_hw=up_hw, eps=self.adapter_1.norm.eps, stats=lat_stats, stats_ready=True)
+        else:
+            lat = ops.conv1x1_nchw_to_tokens(x, self.adapter_1.weight.view(C, -1), None)
+            y = ops.groupnorm_tokens(lat, self.adapter_1.norm.weight, self.adapter_1.norm.bias, H, W, groups=32,
+                                     up=up_tok, up_hw=up_hw, eps=self.adapter_1.norm.eps, stats=fpn_stats[0])
         y_stats = None
         if C == 64:
             # weight-stationary 3x3 kernel; the moments of layer_1's GroupNorm come out of its epilogue

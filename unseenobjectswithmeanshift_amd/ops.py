@@ -276,13 +276,19 @@ def layernorm(x, g1, b1, *, parts=None, bias=None, l2norm=False, g2=None, b2=Non
     return (y, y2) if g2 is not None else y
 
 
-def groupnorm_tokens(x, gamma, beta, H, W, groups=32, *, up=None, up_hw=None, relu=False, eps=1e-5, stats=None):
+def groupnorm_tokens(x, gamma, beta, H, W, groups=32, *, up=None, up_hw=None, relu=False, eps=1e-5, stats=None, stats_ready=False):
     """GroupNorm over an NHWC token map x (B, H*W, C); optionally adds the bilinear upsample of `up` (B, uh*uw, C) -- dense
     or a token-range slice of a larger buffer (row stride C, any batch stride) -- and applies ReLU.  ``stats``: a zeroed
-    (B, C, 2) float64 scratch to accumulate the moments in (saves the fill launch)."""
+    (B, C, 2) float64 scratch to accumulate the moments in (saves the fill launch) -- or, with ``stats_ready``, the finished
+    moments of x (the producer of x accumulated them: no moments pass)."""
     _c(x, "x"), _c(gamma, "gamma"), _c(beta, "beta"), _chk(up, "up")
     B, HW, C = x.shape
-    stats = groupnorm_stats(x, stats)
+    if stats_ready:
+        _c(stats, "stats", torch.float64)
+        if stats is None or tuple(stats.shape) != (B, C, 2):
+            raise RuntimeError("stats_ready needs stats (B, C, 2) float64")
+    else:
+        stats = groupnorm_stats(x, stats)
     y = torch.empty_like(x)
     uh, uw = (0, 0) if up is None else up_hw
     usb = 0
