@@ -800,7 +800,8 @@ def test_pixel_decoder_fused_equals_unfused():
 
 
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,Cin,H,W", [(2, 2048, 15, 20), (3, 1024, 30, 40), (8, 512, 60, 80), (1, 256, 10, 6), (2, 128, 7, 4)])
+@pytest.mark.parametrize("B,Cin,H,W", [(2, 2048, 15, 20), (3, 1024, 30, 40), (8, 512, 60, 80), (1, 256, 10, 6), (2, 128, 7, 4),
+                                        (2, 256, 100, 164), (1, 384, 128, 260)])      # the last two: the shallow-K kernel, ragged last tile
 def test_conv1x1_in_vs_fp64(B, Cin, H, W):
     """msm_conv1x1_in_f32 (every tile width the host picks, ragged last tiles) against an fp64 1x1 convolution and the
     fp64 moments of its own output; writing into a slice of a larger token buffer; moment accumulation."""

@@ -20,7 +20,7 @@ def in_path():
     return ops.groupnorm_tokens(lat, gw, gb, H, W, groups=32, up=up, up_hw=(60, 80), eps=1e-5, stats=st, stats_ready=True)
 print(f"gemm only           {timeit_graph(lambda: ops.conv1x1_nchw_to_tokens(x, w, None)):.1f} us")
 print(f"gemm + GN (stats pass + apply) {timeit_graph(gemm_path):.1f} us")
-for nt in (0, 1, 2, 4):
+for nt in (0,):
     with _lib.option("CONVIN_NT", nt):
         print(f"CONVIN_NT={nt}: conv1x1_in only {timeit_graph(lambda: ops.conv1x1_in(x, wp, None)):.1f} us;  + GN apply {timeit_graph(in_path):.1f} us")
 a, b = gemm_path(), in_path()

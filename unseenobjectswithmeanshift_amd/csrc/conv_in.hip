@@ -201,24 +201,20 @@ __global__ __launch_bounds__(CI_W * 64, 4) void conv_in_kernel(const float* __re
 // tiles, no reduction --, x and the packed weight (64 KB, L2 resident) stream through a ring of D k-groups per wave, four-wave
 // workgroups are dispatched as slots free up (4800 tiles over 1024 SIMDs: no fixed assignment to round up), and the moments
 // leave as one double atomic per (workgroup, channel, moment) as above.
-constexpr int CS_W = 4;             // waves per workgroup of the shallow-K kernel
-template <int NT, int D>
-__global__ __launch_bounds__(CS_W * 64, 4) void conv_in_shallow_kernel(const float* __restrict__ x, const float* __restrict__ w,
+// WV: waves per workgroup (WV x 16 NT consecutive pixels of every channel row)
+template <int NT, int D, int WV>
+__global__ __launch_bounds__(WV * 64, 4) void conv_in_shallow_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                     const float* __restrict__ bias, float* __restrict__ out,
                                                                     int64_t out_sb, double* __restrict__ stats, int Cin, int HW) {
-    __shared__ float st[CS_W * CI_O * 2];                                 // [wave][64 ch][2]
+    __shared__ float st[WV * CI_O * 2];                                 // [wave][64 ch][2]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lj = lane & 15, lq = lane >> 4;
     const int b = blockIdx.y;
-    const int tile = blockIdx.x * CS_W + wave;
+    const int tile = blockIdx.x * WV + wave;
     const int px0 = tile * (16 * NT);
     const bool live = px0 < HW;                                           // wave-uniform
-    float sm[4][4], sq[4][4];                                             // moments of this wave's tile per (channel block, r)
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sm[mt][r] = sq[mt][r] = 0.f;
+    const bool has_stats = stats != nullptr;
     if (live) {
         auto uniform_ptr = [](const void* p) {
             const uint64_t u = (uint64_t)p;
@@ -278,11 +274,14 @@ __global__ __launch_bounds__(CS_W * 64, 4) void conv_in_shallow_kernel(const flo
                 if (kg + D + d < groups) load(kg + D + d, wa[d], xa[d]);
             }
         }
+        // bias, token-major store, and the tile's moments: reduced over the 16 pixels of a lane quarter, one LDS slot per
+        // (wave, channel)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int ch = mt * 16 + lq * 4;
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (bias) bv = *reinterpret_cast<const float4*>(bias + ch);
+            float sm[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int px = px0 + NT * lj + nt;             // pixel block nt holds pixels px0 + NT*n + nt
@@ -290,34 +289,35 @@ __global__ __launch_bounds__(CS_W * 64, 4) void conv_in_shallow_kernel(const flo
                 const float v0 = v[0] + bv.x, v1 = v[1] + bv.y, v2 = v[2] + bv.z, v3 = v[3] + bv.w;
                 if (px < HW) {
                     *reinterpret_cast<float4*>(out + (int64_t)b * out_sb + (int64_t)px * CI_O + ch) = make_float4(v0, v1, v2, v3);
-                    sm[mt][0] += v0; sm[mt][1] += v1; sm[mt][2] += v2; sm[mt][3] += v3;
-                    sq[mt][0] += v0 * v0; sq[mt][1] += v1 * v1; sq[mt][2] += v2 * v2; sq[mt][3] += v3 * v3;
+                    sm[0] += v0; sm[1] += v1; sm[2] += v2; sm[3] += v3;
+                    sq[0] += v0 * v0; sq[1] += v1 * v1; sq[2] += v2 * v2; sq[3] += v3 * v3;
+                }
+            }
+            if (has_stats) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) {
+                        sm[r] += __shfl_xor(sm[r], o, 64);
+                        sq[r] += __shfl_xor(sq[r], o, 64);
+                    }
+                    if (lj == 0) {
+                        st[(wave * CI_O + ch + r) * 2 + 0] = sm[r];
+                        st[(wave * CI_O + ch + r) * 2 + 1] = sq[r];
+                    }
                 }
             }
         }
+    } else if (has_stats) {
+        for (int i = lane; i < CI_O * 2; i += 64) st[wave * CI_O * 2 + i] = 0.f;
     }
-    if (stats) {
-        // reduce over the 16 pixels of a lane quarter, one LDS slot per (wave, channel); the workgroup's four slots are summed in
-        // a fixed order, so nothing below the per-workgroup double adds depends on timing
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    sm[mt][r] += __shfl_xor(sm[mt][r], o, 64);
-                    sq[mt][r] += __shfl_xor(sq[mt][r], o, 64);
-                }
-                if (lj == 0) {
-                    st[(wave * CI_O + mt * 16 + lq * 4 + r) * 2 + 0] = sm[mt][r];
-                    st[(wave * CI_O + mt * 16 + lq * 4 + r) * 2 + 1] = sq[mt][r];
-                }
-            }
+    if (has_stats) {
+        // the workgroup's slots are summed in a fixed order, so nothing below the per-workgroup double adds depends on timing
         __syncthreads();
         if (tid < CI_O * 2) {
             double v = 0.0;
 #pragma unroll
-            for (int s = 0; s < CS_W; ++s) v += (double)st[s * CI_O * 2 + tid];
+            for (int s_ = 0; s_ < WV; ++s_) v += (double)st[s_ * CI_O * 2 + tid];
             atomicAdd(stats + (int64_t)b * CI_O * 2 + tid, v);
         }
     }
@@ -393,13 +393,11 @@ extern "C" int msm_conv1x1_in_f32(const float* x, const float* w, const float* b
     const int cfg = conv_in_config(B, Cin, HW, nt);
     if (Cin <= 384 && Cin % 64 == 0 && (int64_t)B * HW >= 32 * 1024) {
         // shallow K over many pixels (the FPN lateral): one tile per wave, no K split
-        const int snt = opt(MSM_OPT_CONVIN_NT) == 4 ? 4 : 2;
-        dim3 sgrid(cdiv(cdiv(HW, 16 * snt), CS_W), B);
-        if (snt == 4) {
-            hipLaunchKernelGGL((conv_in_shallow_kernel<4, 2>), sgrid, dim3(CS_W * 64), 0, st, x, w, bias, out, out_batch_stride, stats, Cin, HW);
-        } else {
-            hipLaunchKernelGGL((conv_in_shallow_kernel<2, 4>), sgrid, dim3(CS_W * 64), 0, st, x, w, bias, out, out_batch_stride, stats, Cin, HW);
-        }
+        // (measured at B = 8, 120x160: 64-66 us whether a lane takes 2 or 4 pixels, a workgroup 4 or 8 waves, the weight comes from
+        // L2 or LDS -- the tiled GEMM's time, without its 10-us moments pass)
+        constexpr int SNT = 2, SW = 8;
+        dim3 sgrid(cdiv(cdiv(HW, 16 * SNT), SW), B);
+        hipLaunchKernelGGL((conv_in_shallow_kernel<SNT, 4, SW>), sgrid, dim3(SW * 64), 0, st, x, w, bias, out, out_batch_stride, stats, Cin, HW);
         MSM_CHECK_LAUNCH("msm_conv1x1_in_f32");
         return MSM_OK;
     }
