@@ -113,7 +113,10 @@ __device__ __forceinline__ void conv_in_tile(const float* __restrict__ x, const 
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             mma(wa[d], xa[d]);
-            if (kg + D + d < groups) load(kg + D + d, wa[d], xa[d]);
+            // unconditional (the last trips re-read the final group): with a conditional load the number of loads in flight at the
+            // loop head depends on the path and hipcc waits for ALL of them there (s_waitcnt vmcnt(0)) -- the ring then exposes
+            // one memory round trip per D groups
+            load(min(kg + D + d, groups - 1), wa[d], xa[d]);
         }
     }
 
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(CI_W * 64, 4) void conv_in_kernel(const float* __re
 // leave as one double atomic per (workgroup, channel, moment) as above.
 // WV: waves per workgroup (WV x 16 NT consecutive pixels of every channel row)
 template <int NT, int D, int WV>
-__global__ __launch_bounds__(WV * 64, 4) void conv_in_shallow_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(WV * 64, 5) void conv_in_shallow_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                     const float* __restrict__ bias, float* __restrict__ out,
                                                                     int64_t out_sb, double* __restrict__ stats, int Cin, int HW) {
     __shared__ float st[WV * CI_O * 2];                                 // [wave][64 ch][2]
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(WV * 64, 4) void conv_in_shallow_kernel(const float
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 mma(wa[d], xa[d]);
-                if (kg + D + d < groups) load(kg + D + d, wa[d], xa[d]);
+                load(min(kg + D + d, groups - 1), wa[d], xa[d]);      // unconditional: see conv_in_tile
             }
         }
         // bias, token-major store, and the tile's moments: reduced over the 16 pixels of a lane quarter, one LDS slot per
@@ -395,7 +398,7 @@ extern "C" int msm_conv1x1_in_f32(const float* x, const float* w, const float* b
         // shallow K over many pixels (the FPN lateral): one tile per wave, no K split
         // (measured at B = 8, 120x160: 64-66 us whether a lane takes 2 or 4 pixels, a workgroup 4 or 8 waves, the weight comes from
         // L2 or LDS -- the tiled GEMM's time, without its 10-us moments pass)
-        constexpr int SNT = 2, SW = 8;
+        constexpr int SNT = 2, SW = 4;
         dim3 sgrid(cdiv(cdiv(HW, 16 * SNT), SW), B);
         hipLaunchKernelGGL((conv_in_shallow_kernel<SNT, 4, SW>), sgrid, dim3(SW * 64), 0, st, x, w, bias, out, out_batch_stride, stats, Cin, HW);
         MSM_CHECK_LAUNCH("msm_conv1x1_in_f32");
