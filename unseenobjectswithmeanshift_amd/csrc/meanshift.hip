@@ -398,14 +398,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int db = 0; db < 4; ++db) xb[r][db] = xs[(lq * 4 + r) * SZ + db * 16 + lj];
+        // exp(kappa*s) through v_exp_f32: |kappa*s*log2e| <= 29 at kappa = 20, relative error ~2e-6 (MS:26).  Only the last slab of
+        // the point set can hold rows beyond n (clamped copies, weight 0): every other slab skips the per-row test.
+        if (p0 + 16 <= n) {
 #pragma unroll
-        for (int sb = 0; sb < NSB; ++sb) {
+            for (int sb = 0; sb < NSB; ++sb) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                // exp(kappa*s) through v_exp_f32: |kappa*s*log2e| <= 29 at kappa = 20, relative error ~2e-6
-                const float w = (p0 + lq * 4 + r < n) ? __builtin_amdgcn_exp2f(kl2 * st[sb][r]) : 0.f;   // MS:26
+                for (int r = 0; r < 4; ++r) {
+                    const float w = __builtin_amdgcn_exp2f(kl2 * st[sb][r]);
 #pragma unroll
-                for (int db = 0; db < 4; ++db) zn[sb][db] = mfma16(w, xb[r][db], zn[sb][db]);
+                    for (int db = 0; db < 4; ++db) zn[sb][db] = mfma16(w, xb[r][db], zn[sb][db]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int sb = 0; sb < NSB; ++sb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float w = (p0 + lq * 4 + r < n) ? __builtin_amdgcn_exp2f(kl2 * st[sb][r]) : 0.f;
+#pragma unroll
+                    for (int db = 0; db < 4; ++db) zn[sb][db] = mfma16(w, xb[r][db], zn[sb][db]);
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
