@@ -22,6 +22,10 @@
 #include "bf16.h"
 #include "common.h"
 
+#ifndef KP_EXP
+#define KP_EXP 0   // tuning experiments only (tools/probes/kv_parts.sh): 1 = no stores, 2 = no MFMAs
+#endif
+
 namespace msm {
 
 constexpr int KP_K = 64;
@@ -102,6 +106,11 @@ __device__ __forceinline__ void kv_project_body(const float* __restrict__ x, con
             for (int s4 = 0; s4 < 4; ++s4) {
                 const float4 w0 = *reinterpret_cast<const float4*>(wp + fb * 16 * KP_LD + s4 * 4);
                 const float4 w1 = *reinterpret_cast<const float4*>(wp + (fb + 1) * 16 * KP_LD + s4 * 4);
+#if KP_EXP == 2
+                a0[0] += w0.x * xb[s4 * 4 + 0] + w0.y * xb[s4 * 4 + 1];
+                a1[0] += w1.z * xb[s4 * 4 + 2] + w1.w * xb[s4 * 4 + 3];
+                continue;
+#endif
                 a0 = mfma16(w0.x, xb[s4 * 4 + 0], a0);
                 a1 = mfma16(w1.x, xb[s4 * 4 + 0], a1);
                 a0 = mfma16(w0.y, xb[s4 * 4 + 1], a0);
@@ -114,6 +123,9 @@ __device__ __forceinline__ void kv_project_body(const float* __restrict__ x, con
             // no `live` test: lanes past the last token hold token HW - 1 again (clamped p, same x, same constant) and store the
             // same values to the same address -- a branch here cuts the unit into eight basic blocks (LDS reads -> wait -> 32
             // MFMAs -> stores, nothing overlapping across them)
+#if KP_EXP == 1
+            if (a0[0] == 12345.f && a1[1] == 5.f)
+#endif
             if constexpr (std::is_same<OT, float>::value) {
                 *reinterpret_cast<float4*>(op + fb * 16) = make_float4(a0[0], a0[1], a0[2], a0[3]);
                 *reinterpret_cast<float4*>(op + (fb + 1) * 16) = make_float4(a1[0], a1[1], a1[2], a1[3]);
