@@ -57,7 +57,7 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 9   /* 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
+#define MSM_ABI_VERSION 10   /* 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
 int msm_abi_version(void);
 
 /* Kernel-selection overrides for tools/ and tests/ (NOT read on the product path: every option defaults to
@@ -510,6 +510,10 @@ int msm_conv1x1_in_multi_f32(int n_levels, const float* const* x, const float* c
  *   stats_cleared != 0.  The whole weight is held in LDS (one workgroup per CU). */
 int msm_conv3x3_c64_f32(const float* in, const float* w_tap_major, float* out, double* stats,
                         int stats_cleared, int B, int H, int W, void* stream);
+/* Low-precision mode of the same convolution (same arguments, fp32 in / out): the weight rounded to bf16 as it enters LDS, the
+ * activations as hi + lo bf16 operands, v_mfma_f32_16x16x32_bf16 with fp32 accumulation; moments from the fp32 results. */
+int msm_conv3x3_c64_bf16(const float* in, const float* w_tap_major, float* out, double* stats,
+                         int stats_cleared, int B, int H, int W, void* stream);
 
 /* The same kernel with a planar result: out [B][Cout][H*W] (NCHW) = bias + conv3x3(in), Cout a multiple of 64 (every slice of
  * 64 output channels has its own workgroups and its own 147 KB of the [Cout][9*64] weight in LDS), W % 4 == 0

@@ -906,6 +906,24 @@ def test_conv3x3_c64_vs_fp64(B, H, W):
     torch.testing.assert_close(st2.cpu(), mom + 1.0, rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 12, 16), (1, 5, 37), (3, 30, 40)])
+def test_conv3x3_c64_bf16_mode(B, H, W):
+    """msm_conv3x3_c64_bf16 (low-precision mode: weight rounded to bf16, activations as hi + lo operands, fp32 accumulation)
+    against the fp64 convolution WITH THE SAME ROUNDED WEIGHT to the fp32 kernel's tolerance -- the activations' hi + lo pair
+    carries 16 mantissa bits --, against the unrounded fp64 convolution to bf16's, and the moments of its own output."""
+    x, w = rnd(B, H * W, 64, seed=1), rnd(64, 64, 3, 3, seed=2, scale=0.06)
+    xi = x.double().view(B, H, W, 64).permute(0, 3, 1, 2)
+    ref = F.conv2d(xi, w.double(), padding=1).permute(0, 2, 3, 1).reshape(B, H * W, 64)
+    ref_r = F.conv2d(xi, w.bfloat16().double(), padding=1).permute(0, 2, 3, 1).reshape(B, H * W, 64)
+    w3 = w.permute(0, 2, 3, 1).reshape(64, 576).contiguous().to(DEV)
+    out, st = ops().conv3x3_c64(x.to(DEV), w3, H, W, bf16=True)
+    closed(out, ref_r, rtol=1e-4, atol=1e-4)
+    err = float((out.cpu().double() - ref).abs().max())
+    assert err < 2e-2 * float(ref.abs().max()), err
+    mom = torch.stack([out.double().sum(1), (out.double() ** 2).sum(1)], -1).cpu()
+    torch.testing.assert_close(st.cpu(), mom, rtol=1e-5, atol=1e-4)
+
+
 def test_kv_project_multi_equals_single_launches():
     """msm_kv_project_multi_f32: nine jobs (three levels x three layers, NCHW and token-major inputs) in one launch are
     bit-identical to nine msm_kv_project_f32 launches."""

@@ -205,6 +205,8 @@ def convs():
     w3 = torch.randn(64, 576, device=DEV) * 0.05
     t = timeit_graph(lambda: ops.conv3x3_tokens(y, w3, 120, 160))
     t3 = timeit_graph(lambda: ops.conv3x3_c64(y, w3, 120, 160))
+    t3b = timeit_graph(lambda: ops.conv3x3_c64(y, w3, 120, 160, bf16=True))
+    print(f"conv3x3_c64 bf16 mode: {t3b:6.1f} us", flush=True)
     o3, s3 = ops.conv3x3_c64(y, w3, 120, 160)
     ref3 = ops.conv3x3_tokens(y, w3, 120, 160)
     print(f"conv3x3_c64 (weight in LDS, + GroupNorm moments incl. fill): {t3:6.1f} us ({2.0 * B * 19200 * 576 * 64 / t3 / 1e6:5.1f} TFLOP/s)  "

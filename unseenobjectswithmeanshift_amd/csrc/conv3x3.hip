@@ -19,6 +19,7 @@
 //     atomic per (workgroup, channel, moment);
 //   * tiles are handed out per image (blockIdx.y) in full rounds over the image's workgroups, the leftover tiles one per
 //     SIMD first (waves w, w+4, ... share a SIMD).
+#include "bf16.h"
 #include "common.h"
 
 namespace msm {
@@ -27,17 +28,25 @@ constexpr int C3_C = 64;                 // channels in and out
 constexpr int C3_K = 9 * C3_C;           // 576
 constexpr int C3_LD = C3_K + 4;          // LDS row stride (floats): 145 float4, odd -> 16 rows hit 16 different 16-byte banks
 constexpr int C3_W = 16;                 // waves per workgroup (the weight takes 145 KiB: one workgroup per CU)
+constexpr int C3_LDB = C3_K + 8;         // LDS row stride of the bf16 weight copy (bf16 elements): 73 x 16 bytes, odd
 
 // NCHW = false: token-major output [B][HW][64] (+ moments).  NCHW = true: output [B][Cout][HW] for Cout = 64 * gridDim.z, each
 // z slice of workgroups holding its own 64 rows of the weight; the MFMA operands are swapped (rows = pixels) so that a
 // lane ends with 4 consecutive PIXELS of one channel and the planes are written with 16-byte stores (W % 4 == 0); bias per
 // channel (SimpleBasePixelDecoder.mask_features: Conv2d(64, 256, 3, padding=1) with bias, fpn.py:237-246).
-template <bool NCHW>
+//
+// BF (low-precision mode, token-major output only): the weight is rounded to bf16 when it is copied into LDS, a tap's
+// activations become hi + lo bf16 operands when they are used (x = hi + lo up to 2^-17 |x|) and v_mfma_f32_16x16x32_bf16 takes
+// half a tap's channels at once: 16 MFMAs of 16 cycles per tap instead of 64 of 32 -- the kernel is then a stream over the map.
+// K order of a tap: channel kh*32 + lq*8 + i on both operands.
+template <bool NCHW, bool BF = false>
 __global__ __launch_bounds__(C3_W * 64) void conv3x3_c64_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                                 const float* __restrict__ bias, float* __restrict__ out,
                                                                 double* __restrict__ stats, int H, int W) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];   // [64][C3_LD], then the moment scratch [C3_W][64][2]
-    float* msc = wl + C3_C * C3_LD;
+    static_assert(!(NCHW && BF), "the bf16 form writes token-major output");
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [64][C3_LD] (BF: [64][C3_LDB] bf16), then the moment scratch [C3_W][64][2]
+    unsigned short* wlb = reinterpret_cast<unsigned short*>(wl);
+    float* msc = BF ? wl + C3_C * C3_LDB / 2 : wl + C3_C * C3_LD;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lj = lane & 15, lq = lane >> 4;
@@ -45,7 +54,9 @@ __global__ __launch_bounds__(C3_W * 64) void conv3x3_c64_kernel(const float* __r
     const int o0 = NCHW ? (int)blockIdx.z * C3_C : 0;          // first output channel of this workgroup
     for (int i = tid; i < C3_C * (C3_K / 4); i += C3_W * 64) {
         const int n = i / (C3_K / 4), c4 = i - n * (C3_K / 4);
-        *reinterpret_cast<float4*>(wl + n * C3_LD + c4 * 4) = *reinterpret_cast<const float4*>(w + (int64_t)(o0 + n) * C3_K + c4 * 4);
+        const float4 wv = *reinterpret_cast<const float4*>(w + (int64_t)(o0 + n) * C3_K + c4 * 4);
+        if constexpr (BF) *reinterpret_cast<bf16x4*>(wlb + n * C3_LDB + c4 * 4) = pack4(wv.x, wv.y, wv.z, wv.w);
+        else *reinterpret_cast<float4*>(wl + n * C3_LD + c4 * 4) = wv;
     }
     __syncthreads();
 
@@ -78,10 +89,11 @@ __global__ __launch_bounds__(C3_W * 64) void conv3x3_c64_kernel(const float* __r
         auto load_tap = [&](int t, float4 (&f)[4]) {
             const int yy = y + t / 3 - 1, xx = px + t % 3 - 1;
             const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-            const float* p = ib + ((int64_t)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)) * C3_C + lq * 4;
+            // (BF: f[2 kh + h] = channels kh*32 + lq*8 + 4 h .. + 3)
+            const float* p = ib + ((int64_t)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)) * C3_C + (BF ? lq * 8 : lq * 4);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const float4 v = *reinterpret_cast<const float4*>(p + ks * 16);
+                const float4 v = *reinterpret_cast<const float4*>(p + (BF ? (ks >> 1) * 32 + (ks & 1) * 4 : ks * 16));
                 f[ks] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         };
@@ -89,6 +101,23 @@ __global__ __launch_bounds__(C3_W * 64) void conv3x3_c64_kernel(const float* __r
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
         auto mma_tap = [&](int t, const float4 (&cur)[4]) {
+            if constexpr (BF) {
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh) {
+                    const Split4 s0 = split4(cur[2 * kh].x, cur[2 * kh].y, cur[2 * kh].z, cur[2 * kh].w);
+                    const Split4 s1 = split4(cur[2 * kh + 1].x, cur[2 * kh + 1].y, cur[2 * kh + 1].z, cur[2 * kh + 1].w);
+                    const bf16x8 xh = cat8(s0.hi, s1.hi), xl = cat8(s0.lo, s1.lo);
+                    bf16x8 a[4];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        a[mt] = *reinterpret_cast<const bf16x8*>(wlb + (mt * 16 + lj) * C3_LDB + t * C3_C + kh * 32 + lq * 8);
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma_bf16k32(a[mt], xl, acc[mt]);
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma_bf16k32(a[mt], xh, acc[mt]);
+                }
+                return;
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 float4 a[4];
@@ -175,23 +204,40 @@ __global__ __launch_bounds__(C3_W * 64) void conv3x3_c64_kernel(const float* __r
 
 using namespace msm;
 
-extern "C" int msm_conv3x3_c64_f32(const float* in, const float* w_tap_major, float* out, double* stats,
-                                   int stats_cleared, int B, int H, int W, void* stream) {
+static int conv3x3_c64_launch(const float* in, const float* w_tap_major, float* out, double* stats, int stats_cleared, int B, int H, int W,
+                              int bf, void* stream) {
     MSM_REQUIRE(in && w_tap_major && out && in != out, "msm_conv3x3_c64_f32: null or aliased pointer");
     MSM_REQUIRE(B > 0 && H > 0 && W > 0 && (int64_t)H * W * C3_C < ((int64_t)1 << 31), "msm_conv3x3_c64_f32: bad sizes B=%d H=%d W=%d", B, H, W);
     MSM_REQUIRE(((((uintptr_t)in) | ((uintptr_t)w_tap_major) | ((uintptr_t)out)) & 15) == 0 && (((uintptr_t)stats) & 7) == 0,
                 "msm_conv3x3_c64_f32: misaligned pointer");
     hipStream_t st = (hipStream_t)stream;
     if (stats && !stats_cleared) MSM_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * C3_C * (size_t)B, st));
-    const size_t lds = sizeof(float) * ((size_t)C3_C * C3_LD + (size_t)C3_W * C3_C * 2);
-    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_kernel<false>, lds));
     // workgroups per image: about one round of the chip over the batch, never more than the image has tiles for
     const int units = cdiv(W, 16) * H;
     int per_image = max(1, 256 / B);
     per_image = min(per_image, cdiv(units, C3_W));
-    hipLaunchKernelGGL(conv3x3_c64_kernel<false>, dim3(per_image, B), dim3(C3_W * 64), lds, st, in, w_tap_major, nullptr, out, stats, H, W);
+    if (bf) {
+        const size_t lds = sizeof(unsigned short) * (size_t)C3_C * C3_LDB + sizeof(float) * (size_t)C3_W * C3_C * 2;
+        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_kernel<false, true>, lds));
+        hipLaunchKernelGGL((conv3x3_c64_kernel<false, true>), dim3(per_image, B), dim3(C3_W * 64), lds, st, in, w_tap_major, nullptr, out, stats, H,
+                           W);
+    } else {
+        const size_t lds = sizeof(float) * ((size_t)C3_C * C3_LD + (size_t)C3_W * C3_C * 2);
+        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_kernel<false>, lds));
+        hipLaunchKernelGGL(conv3x3_c64_kernel<false>, dim3(per_image, B), dim3(C3_W * 64), lds, st, in, w_tap_major, nullptr, out, stats, H, W);
+    }
     MSM_CHECK_LAUNCH("msm_conv3x3_c64_f32");
     return MSM_OK;
+}
+
+extern "C" int msm_conv3x3_c64_f32(const float* in, const float* w_tap_major, float* out, double* stats,
+                                   int stats_cleared, int B, int H, int W, void* stream) {
+    return conv3x3_c64_launch(in, w_tap_major, out, stats, stats_cleared, B, H, W, 0, stream);
+}
+
+extern "C" int msm_conv3x3_c64_bf16(const float* in, const float* w_tap_major, float* out, double* stats,
+                                    int stats_cleared, int B, int H, int W, void* stream) {
+    return conv3x3_c64_launch(in, w_tap_major, out, stats, stats_cleared, B, H, W, 1, stream);
 }
 
 extern "C" int msm_conv3x3_c64_nchw_f32(const float* in, const float* w_tap_major, const float* bias, float* out, int B, int H, int W,

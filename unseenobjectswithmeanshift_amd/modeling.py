@@ -984,7 +984,8 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
         y_stats = None
         if C == 64:
             # weight-stationary 3x3 kernel; the moments of layer_1's GroupNorm come out of its epilogue
-            y, y_stats = ops.conv3x3_c64(y, self._w3(), H, W, stats=fpn_stats[1], stats_cleared=fpn_stats[1] is not None)
+            y, y_stats = ops.conv3x3_c64(y, self._w3(), H, W, stats=fpn_stats[1], stats_cleared=fpn_stats[1] is not None,
+                                         bf16=self.precision == "bf16")
         else:
             y = ops.conv3x3_tokens(y, self._w3(), H, W)
         wm = self.mask_features.weight.view(self.mask_dim, C)

@@ -223,10 +223,11 @@ def conv3x3_tokens(t, w_tap_major, H, W):
     return out
 
 
-def conv3x3_c64(t, w_tap_major, H, W, *, stats=None, stats_cleared=False):
+def conv3x3_c64(t, w_tap_major, H, W, *, stats=None, stats_cleared=False, bf16=False):
     """3x3 / pad 1 convolution of a 64-channel token map t (B, H*W, 64) to 64 channels, weight (64, 9*64) tap-major, with
     the GroupNorm moments of the result as a by-product: returns (out (B, H*W, 64), stats (B, 64, 2) float64).  ``stats``
-    given: accumulated into when ``stats_cleared`` (the caller zeroed it), else zeroed first."""
+    given: accumulated into when ``stats_cleared`` (the caller zeroed it), else zeroed first.  ``bf16``: the low-precision
+    mode (bf16 MFMA operands -- weight single, activations hi + lo --, fp32 accumulation and output)."""
     _c(t, "t"), _c(w_tap_major, "w"), _c(stats, "stats", torch.float64)
     B, HW, C = t.shape
     if C != 64 or tuple(w_tap_major.shape) != (64, 576) or HW != H * W:
@@ -237,8 +238,9 @@ def conv3x3_c64(t, w_tap_major, H, W, *, stats=None, stats_cleared=False):
         stats_cleared = False
     elif tuple(stats.shape) != (B, 64, 2):
         raise RuntimeError("stats must be (B, 64, 2) float64")
-    rc = lib().msm_conv3x3_c64_f32(_p(t), _p(w_tap_major), _p(out), _p(stats), 1 if stats_cleared else 0, B, H, W, _stream())
-    check(rc, "msm_conv3x3_c64_f32")
+    fn = lib().msm_conv3x3_c64_bf16 if bf16 else lib().msm_conv3x3_c64_f32
+    rc = fn(_p(t), _p(w_tap_major), _p(out), _p(stats), 1 if stats_cleared else 0, B, H, W, _stream())
+    check(rc, "msm_conv3x3_c64_bf16" if bf16 else "msm_conv3x3_c64_f32")
     return out, stats
 
 
