@@ -17,8 +17,11 @@ backbone features that are already resident in HBM.  Backbone excluded (SURVEY.m
   (``one_batch_in_flight``); ``--inflight 1`` times only that.
 * The timed region is at least ``--min-seconds`` (1 s) long: when K steps would be shorter, more steps are timed and
   ``steps`` reports the number actually timed (``steps_requested`` = K).
-* ``roofline``: the Q x pixel-embedding mask step (msm_mask_logits_fwd), FLOPs the kernel EXECUTES / its mean launch
-  duration (HIP events on the launch stream around every launch of three eager passes) / the fp32 MFMA peak.
+* ``roofline``: the dominant kernel of the step by time, the fused encoder-layer tail (msm_encoder_block_fwd): FLOPs it executes /
+  its mean launch duration (HIP events around graph replays of the step's six launches) / the fp32 MFMA peak, PMC traffic from
+  profiles/step_traffic.json.  ``roofline.mask_step``: the Q x pixel-embedding mask step the metric names -- the full-resolution
+  kernel characterised per launch, and what the default plan runs for the ten predictions (one full-resolution launch + nine at
+  key resolution) with executed and reference FLOPs side by side.
 * N = 1 adds, on rank 0: ``kernels`` (event-timed per entry point of one eager pass), ``mean_shift`` (the classic UCN
   clustering unit with its own roofline entries), ``configs`` (BASELINE configs[2] slice / [3] / [4] timed by this run)
   and ``cpu_baseline`` (the oracle on the host cores).
@@ -226,30 +229,38 @@ def event_ms(fn, reps=5, warm=2):
     return e[0].elapsed_time(e[1]) / reps
 
 
-def mask_step_graph_ms(step, reps=100):
-    """The dominant kernel on its own: the mask-step launches of one pass (their real arguments, recorded from `step()`), replayed
-    back to back from a HIP graph between two HIP events on the current stream -- kernel time without the host's launch gaps and
-    without the event records that sit between eager launches (what rocprofv3 reports per dispatch).  -> (ms per launch, launches)"""
+def entry_graph_ms(step, names, reps=100):
+    """One entry point of ops (or a list of them) on its own: its launches of one pass (their real arguments, recorded from `step()`),
+    replayed back to back from a HIP graph between two HIP events on the current stream -- kernel time without the host's launch gaps
+    and without the event records that sit between eager launches (what rocprofv3 reports per dispatch).
+    -> (ms per replay of all recorded launches, number of launches)"""
     from unseenobjectswithmeanshift_amd import ops
-    calls, orig = [], ops.mask_logits
+    names = [names] if isinstance(names, str) else list(names)
+    calls, origs = [], {n: getattr(ops, n) for n in names}
 
-    def recording(*a, **k):
-        calls.append((a, k))
-        return orig(*a, **k)
+    def recorder(n):
+        def rec(*a, **k):
+            calls.append((n, a, k))
+            return origs[n](*a, **k)
+        return rec
 
-    ops.mask_logits = recording
+    for n in names:
+        setattr(ops, n, recorder(n))
     try:
         step()
     finally:
-        ops.mask_logits = orig
+        for n in names:
+            setattr(ops, n, origs[n])
+    if not calls:
+        return 0.0, 0
     stream = torch.cuda.Stream()
     stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(stream):
         stream.synchronize()
         mg = torch.cuda.CUDAGraph()
         with torch.cuda.graph(mg, stream=stream):
-            for a, k in calls:
-                orig(*a, **k)
+            for n, a, k in calls:
+                origs[n](*a, **k)
         for _ in range(5):
             mg.replay()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -259,16 +270,30 @@ def mask_step_graph_ms(step, reps=100):
         e1.record()
         e1.synchronize()
     torch.cuda.current_stream().wait_stream(stream)
-    return e0.elapsed_time(e1) / (reps * len(calls)), len(calls)
+    return e0.elapsed_time(e1) / reps, len(calls)
 
 
-def precision_leg(model, feats, dev, dist, args, precision, inflight, sparse_taps=False):
+def mask_step_graph_ms(step, model, reps=100):
+    """The full-resolution mask-step kernel on its own: the ten launches a pass makes when every prediction's mask step runs at
+    120 x 160 (predictor.pooled_attention_masks = False for the recording).  -> (ms per launch, launches)"""
+    pred = model.sem_seg_head.predictor
+    keep = pred.pooled_attention_masks
+    pred.pooled_attention_masks = False
+    try:
+        ms, n = entry_graph_ms(step, "mask_logits", reps)
+    finally:
+        pred.pooled_attention_masks = keep
+    return ms / max(n, 1), n
+
+
+def precision_leg(model, feats, dev, dist, args, precision, inflight, sparse_taps=False, pooled=True):
     """The per-GPU batch of 8 in another precision mode, timed on EVERY rank exactly like the headline region (barrier + sync on
     both sides, max over ranks): under --gpus 8 this is BASELINE configs[2] (batch 64 over 8 GPUs, bf16).  Returns this rank's
     (images, elapsed seconds, steps, one-batch-in-flight seconds per step)."""
     from unseenobjectswithmeanshift_amd.graphs import PipelinedInference
     model.set_precision(precision)
     model.sem_seg_head.predictor.sparse_taps = bool(sparse_taps)
+    model.sem_seg_head.predictor.pooled_attention_masks = bool(pooled)
     lone = PipelinedInference(model, depth=1)
     lone.submit(feats, (H, W))
     lone.drain()
@@ -363,19 +388,24 @@ def extra_configs(dev, args):
     class _A:
         steps, min_seconds = 50, 0.5
     imgs, el, st_, single = precision_leg(model, feats, dev, None, _A, "f32_split", max(1, args.inflight))
-    # the intermediate mask steps restricted to the image rows their attention masks sample (decoder.sparse_taps): the nine
-    # intermediate full-resolution mask predictions are never formed -- inference never reads them (PM:335-345), the final prediction
-    # is bitwise the same (tests) -- so the step executes 5.25 instead of 9 intermediate launch-equivalents.  SURVEY 8d allows this
-    # inference-only shortcut with executed and reference FLOPs reported apart; it is NOT the headline configuration.
-    si, sel, sst, ssingle = precision_leg(model, feats, dev, None, _A, "f32", max(1, args.inflight), sparse_taps=True)
-    out["configs[1] sparse taps"] = {
-        "workload": "batch 8, 640x480, fp32, as the headline except that the nine intermediate mask steps compute only the row pairs their "
-                    f"attention masks sample (final prediction bitwise identical); {max(1, args.inflight)} batches of 8 in flight",
-        "value": round(si / sel, 1), "unit": "images/sec", "ms_per_step": round(1e3 * sel / sst, 4),
-        "one_batch_in_flight": {"value": round(BATCH / ssingle, 1), "unit": "images/sec", "ms_per_step": round(1e3 * ssingle, 4)},
-        "dtype": "f32", "executed_mask_launch_equivalents": 1 + 3 * (0.25 + 0.5 + 1.0), "reference_mask_launches": 10}
+    # the plan of rounds 1-3: every one of the ten mask steps at 120 x 160, the attention-mask taps pooled afterwards
+    # (predictor.pooled_attention_masks = False) -- and the same with the nine intermediate steps restricted to the image rows their
+    # attention masks sample (decoder.sparse_taps).  Reported next to the headline, which computes the intermediate attention masks at
+    # key resolution (csrc/attn_mask.hip: interpolation and contraction commute; SURVEY 8d names the inference-only shortcut)
+    fi, fel, fst, fsingle = precision_leg(model, feats, dev, None, _A, "f32", max(1, args.inflight), pooled=False)
+    si, sel, sst, ssingle = precision_leg(model, feats, dev, None, _A, "f32", max(1, args.inflight), sparse_taps=True, pooled=False)
+    model.sem_seg_head.predictor.pooled_attention_masks = True
+    out["configs[1] full-resolution mask steps"] = {
+        "workload": "batch 8, 640x480, fp32, as the headline except that all ten mask steps run at 120 x 160 (the attention-mask taps pooled "
+                    f"from the full-resolution logits, as the reference orders it); {max(1, args.inflight)} batches of 8 in flight",
+        "value": round(fi / fel, 1), "unit": "images/sec", "ms_per_step": round(1e3 * fel / fst, 4),
+        "one_batch_in_flight": {"value": round(BATCH / fsingle, 1), "unit": "images/sec", "ms_per_step": round(1e3 * fsingle, 4)},
+        "dtype": "f32",
+        "sparse_taps": {"note": "the nine intermediate steps restricted to the row pairs their attention masks sample",
+                        "value": round(si / sel, 1), "unit": "images/sec", "ms_per_step": round(1e3 * sel / sst, 4),
+                        "one_batch_in_flight_ms": round(1e3 * ssingle, 4)}}
     model.set_precision("f32_split")
-    ms_split, n_split = mask_step_graph_ms(lambda: model.inference(feats, (H, W)))
+    ms_split, n_split = mask_step_graph_ms(lambda: model.inference(feats, (H, W)), model)
     model.set_precision("f32")
     fl_useful = 2.0 * Q * 64 * (H // 4) * (W // 4) * BATCH               # the folded contraction's FLOPs
     fl_bf16 = 6.0 * fl_useful                                            # six bf16 products per fp32 product
@@ -435,7 +465,7 @@ def extra_configs(dev, args):
     for _ in range(3):
         g(feats, (H, W))
     t = timed(lambda: g(feats, (H, W)), 30)
-    ms_lit, n_lit = mask_step_graph_ms(lambda: model.inference(feats, (H, W)))
+    ms_lit, n_lit = mask_step_graph_ms(lambda: model.inference(feats, (H, W)), model)
     fl = 2.0 * Q * C_MASK * (H // 4) * (W // 4) * BATCH
     out["configs[1] literal mask step"] = {
         "workload": "batch 8, 640x480, fp32, the mask step contracting the 256-channel mask_features tensor as the reference writes it "
@@ -751,7 +781,13 @@ def main():
                 step()
             stream.synchronize()
         dur = ct.durations()
-        mask_graph_ms, mask_calls = mask_step_graph_ms(step)
+        mask_graph_ms, mask_calls = mask_step_graph_ms(step, model)
+        # what the default plan runs for the ten predictions: one full-resolution launch, the pooling launch, nine key-resolution launches
+        plan_ms, plan_calls = entry_graph_ms(step, ["mask_logits", "pool_mask_taps", "attn_mask_pooled"])
+        enc_name = {"f32": "encoder_block", "f32_split": "encoder_block_split", "bf16": "encoder_block_lp"}[args.precision]
+        enc_ms_all, enc_calls = entry_graph_ms(step, enc_name)
+        launch_label = "eager" if graph is None else ("hipgraph" if pipe is None else
+                                                      f"hipgraph x{inflight}: {inflight} batches of 8 in flight, one graph + stream each")
 
     scores = out[0]
     checksum = float(scores.double().sum().item())
@@ -789,25 +825,59 @@ def main():
             traffic = json.load(f)["bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
-    if not bf16:
-        achieved = flops_exec / (mask_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "mask_logits_kernel (msm_mask_logits_fwd)", "achieved": round(achieved, 2),
-                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "launches_per_step": calls_per_step, "avg_launch_ms": round(mask_ms, 4),
-                    "timing": "HIP events on the launch stream around 100 graph replays of the step's ten mask-step launches (back to back, real arguments)",
-                    "avg_launch_ms_eager_events": round(mask_eager_ms, 4), "flops_per_launch": flops_exec,
-                    "effective_flops_per_launch": flops_ref, "effective_achieved": round(flops_ref / (mask_ms * 1e-3) / 1e12, 2),
-                    "note": ("achieved / frac count the FLOPs the kernel executes: the folded step contracts e.Wm with the 64-channel FPN "
-                             "activation (einsum(e, Wm a + bm) = einsum(e Wm, a) + e.bm, exact algebra), a quarter of the reference "
-                             "einsum's FLOPs; effective_* divide the reference contraction's FLOPs (SURVEY 8d) by the same time")
-                            if folded else "literal 256-channel contraction: executed = reference FLOPs"}
+    traffic_tab = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "step_traffic.json")) as f:
+            traffic_tab = json.load(f)
+    except (OSError, ValueError):
+        pass
+    pooled_plan = bool(pred.pooled_attention_masks) and folded
+    # the mask step (the kernel BASELINE's metric names).  `kernel_*`: the full-resolution kernel characterised over the ten launches
+    # of a pass that runs every prediction at 120 x 160 (comparable with rounds 1-3); `plan_*`: what the default plan launches for the
+    # ten predictions of a pass, with the FLOPs it executes and the reference's over the same time
+    t_lv = [(H // 32) * (W // 32), (H // 16) * (W // 16), (H // 8) * (W // 8)]
+    flops_plan = flops_exec + (sum(2.0 * Q * c_exec * t_lv[i % 3] * (hi - lo) for i in range(9)) if pooled_plan else 9 * flops_exec)
+    mask_step = {"kernel": mask_name.replace("msm_", "").replace("_fwd", "") + " (" + mask_name + ")",
+                 "kernel_avg_launch_ms": round(mask_ms, 4), "kernel_launches_timed": calls_per_step,
+                 "kernel_flops_per_launch": flops_exec, "kernel_achieved_tflops": round(flops_exec / (mask_ms * 1e-3) / 1e12, 2),
+                 "kernel_frac_of_fp32_mfma_peak": round(flops_exec / (mask_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                 "plan": ("1 full-resolution launch (final prediction) + 1 pooling launch + 9 launches at key resolution (300 / 1200 / 4800 keys): "
+                          "interpolate(einsum(e, F)) = einsum(e, interpolate(F))") if pooled_plan else "10 full-resolution launches",
+                 "plan_launches_per_step": plan_calls, "plan_ms_per_step": round(plan_ms, 4),
+                 "plan_executed_flops_per_step": flops_plan, "plan_reference_flops_per_step": 10 * flops_ref,
+                 "plan_executed_tflops": round(flops_plan / (plan_ms * 1e-3) / 1e12, 2) if plan_ms else None,
+                 "plan_effective_tflops": round(10 * flops_ref / (plan_ms * 1e-3) / 1e12, 2) if plan_ms else None,
+                 "traffic_final_launch": (traffic_tab.get("mask_logits_kernel_final") or {}).get("bytes_per_launch"),
+                 "traffic_kernel_avg_launch": traffic,
+                 "note": "kernel_*: FLOPs the full-resolution kernel executes (the folded step contracts e.Wm with the 64-channel FPN activation, "
+                         "einsum(e, Wm a + bm) = einsum(e Wm, a) + e.bm, a quarter of the reference einsum's FLOPs) over its graph-timed launch; "
+                         "plan_effective divides the reference's ten full contractions (SURVEY 8d) by the time the plan's launches take"}
+    # the dominant kernel of the step by time: the fused encoder-layer tail (6 launches, ~40 % of the step)
+    tokens = (hi - lo) * sum(t_lv)
+    enc_ms = enc_ms_all / max(enc_calls, 1)
+    # per token: out_proj 64x64, linear1 / linear2 64x1024 each, and (all but the last layer) the next layer's value projection 64x64 and
+    # sampling projection 64x288
+    enc_flops = [2.0 * tokens * (64 * 64 + 2 * 64 * 1024 + (64 * 64 + 64 * 288 if l < enc_calls - 1 else 0)) for l in range(enc_calls)]
+    enc_fl = sum(enc_flops) / max(enc_calls, 1)
+    enc_traffic = (traffic_tab.get("enc_block_kernel") or {}).get("bytes_per_launch") if args.precision == "f32" else None
+    if args.precision == "f32":
+        enc_peak, enc_fl_exec, enc_unit_note = PEAK_F32_MFMA_TFLOPS, enc_fl, "fp32 MFMA (v_mfma_f32_16x16x4_f32)"
+    elif args.precision == "f32_split":
+        enc_peak, enc_fl_exec, enc_unit_note = PEAK_BF16_MFMA_TFLOPS, 6.0 * enc_fl, "bf16 MFMA, six products per fp32 product"
     else:
-        # bf16 operands: the step is a stream over the packed feature map, HBM-bound
-        bf16_bytes = (hi - lo) * (c_exec * (H // 4) * (W // 4) * 2 + Q * c_exec * 4 + Q * (H // 4) * (W // 4) * 4 // 10)
-        roofline = {"bound": "hbm", "kernel": "mask_logits_bf16_kernel (msm_mask_logits_bf16_fwd)",
-                    "achieved": round(bf16_bytes / (mask_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                    "frac": round(bf16_bytes / (mask_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "traffic": None,
-                    "launches_per_step": calls_per_step, "avg_launch_ms": round(mask_ms, 4), "bytes_per_launch": bf16_bytes}
+        enc_peak, enc_fl_exec, enc_unit_note = PEAK_BF16_MFMA_TFLOPS, enc_fl, "bf16 MFMA"
+    enc_ach = enc_fl_exec / (enc_ms * 1e-3) / 1e12 if enc_ms else 0.0
+    roofline = {"bound": "mfma", "kernel": f"enc_block kernel (msm_{enc_name}_fwd): the fused encoder-layer tail, the dominant kernel of the step by time",
+                "achieved": round(enc_ach, 2), "peak": enc_peak, "unit": "TFLOP/s", "frac": round(enc_ach / enc_peak, 4), "traffic": enc_traffic,
+                "launches_per_step": enc_calls, "avg_launch_ms": round(enc_ms, 4), "flops_per_launch": enc_fl_exec,
+                "share_of_step": round(enc_ms_all / (1e3 * t_max / steps), 3) if inflight == 1 else None,
+                "timing": "HIP events on the launch stream around 100 graph replays of the step's encoder-block launches (back to back, real arguments)",
+                "matrix_pipe": enc_unit_note,
+                "algorithmic_bytes_per_launch": (traffic_tab.get("enc_block_kernel") or {}).get("algorithmic_bytes_per_launch"),
+                "mask_step": mask_step,
+                "note": "rounds 1-3 put the mask step here; with the intermediate attention masks computed at key resolution it is 1-2 % of the "
+                        "step, so the object describes the kernel that dominates (MFMA-bound: 315 kFLOP per token against 2.3 KB of traffic) and "
+                        "carries the mask step's figures in `mask_step`"}
     kernels = {k: {"launches_per_step": len(v) // 3, "ms_per_step": round(sum(v) / 3, 4), "avg_launch_us": round(1e3 * sum(v) / len(v), 2)}
                for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1]))}
     result = {
@@ -827,10 +897,9 @@ def main():
         "config": {"workload": "configs[1]: batch=8 640x480 frames per GPU, synthetic ResNet-50 res2..res5 features "
                                "-> MSDeformAttn pixel decoder (6 layers) -> 9-layer hypersphere decoder (100 queries) "
                                "-> top-20 instance post-processing; backbone excluded",
-                   "global_batch": world * BATCH, "per_gpu_batch": BATCH, "launch": "eager" if graph is None else ("hipgraph" if pipe is None else
-                                                                      f"hipgraph x{inflight}: {inflight} batches of 8 in flight, one graph + stream each"),
+                   "global_batch": world * BATCH, "per_gpu_batch": BATCH, "launch": launch_label,
                    "batches_in_flight": inflight,
-                   "sparse_taps": bool(args.sparse_taps), "folded_mask_step": folded,
+                   "sparse_taps": bool(args.sparse_taps), "folded_mask_step": folded, "attention_masks_at_key_resolution": pooled_plan,
                    "parallelism": f"dp{world}"},
         "per_rank": [{"rank": i, "images_per_sec": round(r["images"] / r["elapsed_s"], 2), "checksum": r["checksum"]} for i, r in enumerate(rec)],
         "roofline": roofline,

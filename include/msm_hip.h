@@ -57,7 +57,7 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 10   /* 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
+#define MSM_ABI_VERSION 10   /* 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
 int msm_abi_version(void);
 
 /* Kernel-selection overrides for tools/ and tests/ (NOT read on the product path: every option defaults to
@@ -503,6 +503,19 @@ int msm_conv1x1_in_f32(const float* x, const float* w_packed, const float* bias,
 int msm_conv1x1_in_multi_f32(int n_levels, const float* const* x, const float* const* w_packed, const float* const* bias,
                              const int32_t* Cin, const int32_t* HW, float* out, int64_t out_batch_stride, double* stats,
                              int stats_cleared, int B, void* stream);
+
+/* The decoder's attention masks at the resolution they are used at (meanshiftformer_transformer_decoder.py:668-680; csrc/attn_mask.hip).
+ * interpolate(einsum(e, F), size, bilinear, align_corners=False) = einsum(e, interpolate(F)): the two act on different axes.
+ * msm_pool_mask_taps: act [B][64][H][W] (the 64-channel factored mask features, NCHW planes) -> for each of n_levels target sizes
+ *   th[l] x tw[l] (HOST arrays; H / th = W / tw in {2, 4, 8}) out[l] [B][th*tw][64] token-major = the bilinear reduction of act
+ *   (mean of the four centre taps of every p x p cell).  One launch.
+ * msm_attn_mask_pooled: attn [B][Q][T] bytes = (sum_c embed[b][q][c] pooled[b][t][c] + qbias[b][q]) < 0 for the 64-column embedding
+ *   (row stride embed_ld floats, batch stride Q * embed_ld; qbias NULL or element stride qbias_ld) and row_any [B][Q] = 1 where a
+ *   row keeps an unmasked key (zeroed here unless row_any_cleared != 0).  Q <= 112. */
+int msm_pool_mask_taps(const float* act, int B, int H, int W, int n_levels, const int32_t* th, const int32_t* tw,
+                       float* const* out, void* stream);
+int msm_attn_mask_pooled(const float* embed, int64_t embed_ld, const float* qbias, int64_t qbias_ld, const float* pooled,
+                         uint8_t* attn, int32_t* row_any, int row_any_cleared, int B, int Q, int T, void* stream);
 
 /* The FPN output convolution (msdeformattn.py:264-279, 349-351: Conv2d(64, 64, 3, padding=1) in front of a GroupNorm):
  *   in / out [B][H*W][64] token maps, w_tap_major [64][9*64] with k = (dy*3 + dx)*64 + c_in (zero padding), no bias (a

@@ -175,6 +175,48 @@ def test_mask_logits_folded_form(B, Q, H, W, pool, kernel, lib_option):
     assert attn is None and row_any is None
 
 
+@pytest.mark.parametrize("B,Q,H,W", [(2, 100, 16, 24), (8, 100, 120, 160), (1, 37, 48, 64), (3, 100, 56, 56), (2, 112, 16, 40), (1, 300, 48, 64)])
+def test_attention_masks_at_key_resolution(B, Q, H, W):
+    """msm_pool_mask_taps + msm_attn_mask_pooled: bilinear reduction and channel contraction commute
+    (interpolate(einsum(e, F)) = einsum(e, interpolate(F))), so the attention masks of the intermediate predictions come from
+    the activation pooled to the key resolutions.  Against the reference order in float64 (einsum at full resolution, then
+    F.interpolate, DEC:668-680) and against the full-resolution kernel: bits may differ only where the logit is within
+    rounding of zero; the row flags agree with the bits; the pooled activation is F.interpolate of the activation."""
+    wide = rnd(B, Q, 256, seed=1, scale=0.3)
+    f = rnd(B, 64, H, W, seed=2)
+    wd, fd = wide.to(DEV), f.to(DEV)
+    sizes = [(H // p, W // p) for p in (8, 4, 2)]
+    pooled = ops().pool_mask_taps(fd, sizes)
+    full = torch.einsum("bqc,bchw->bqhw", wide[..., :64].double(), f.double()) + wide[..., 64].double()[..., None, None]
+    for (th, tw), ap in zip(sizes, pooled):
+        assert ap.shape == (B, th * tw, 64)
+        ref_p = F.interpolate(f, size=(th, tw), mode="bilinear", align_corners=False).flatten(2).transpose(1, 2)
+        close(ap, ref_p, rtol=1e-6, atol=1e-6)
+        ref_logit = F.interpolate(full.float(), size=(th, tw), mode="bilinear", align_corners=False).flatten(2)
+        attn_ref = ref_logit.sigmoid() < 0.5
+        ra0 = torch.zeros(B, Q, device=DEV, dtype=torch.int32)
+        for ra in (None, ra0):
+            attn, row_any = ops().attn_mask_pooled(wd[..., :64], ap, qbias=wd[..., 64], row_any=ra)
+            got = attn.cpu().bool()
+            diff = got != attn_ref
+            if diff.any():
+                assert ref_logit[diff].abs().max() < 1e-4
+            assert diff.float().mean() <= 1e-4
+            assert torch.equal(row_any.cpu().bool(), ~got.all(-1))
+        _, attn_full, ra_full = ops().mask_logits(wd[..., :64], fd, want_mask=False, target_size=(th, tw), qbias=wd[..., 64])
+        d2 = attn_full.cpu() != attn.cpu()
+        if d2.any():
+            assert ref_logit[d2].abs().max() < 1e-4
+        assert d2.float().mean() <= 1e-4
+    # a key count that is no multiple of four (7 x 7: the coarsest level of a 224 x 224 crop) takes the bytewise stores
+    if H == 56:
+        ap = ops().pool_mask_taps(fd, [(7, 7)])[0]
+        attn, row_any = ops().attn_mask_pooled(wd[..., :64], ap, qbias=wd[..., 64])
+        ref_logit = F.interpolate(full.float(), size=(7, 7), mode="bilinear", align_corners=False).flatten(2)
+        diff = attn.cpu().bool() != (ref_logit < 0)
+        assert diff.float().mean() <= 1e-4 and torch.equal(row_any.cpu().bool(), ~attn.cpu().bool().all(-1))
+
+
 def test_mask_logits_tile_choice_is_result_neutral(lib_option):
     e, f = rnd(8, 100, 256, seed=3, scale=0.3).to(DEV), rnd(8, 256, 120, 160, seed=4).to(DEV)
     outs = []

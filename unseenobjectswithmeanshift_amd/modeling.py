@@ -234,6 +234,10 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         self.num_feature_levels = self.NUM_FEATURE_LEVELS
         self.aux_outputs = False
         self.sparse_taps = False
+        # inference: the nine intermediate mask steps at the resolution of their attention masks (interpolation and contraction
+        # commute: csrc/attn_mask.hip); False: every step at full resolution with the taps pooled afterwards; "always": also
+        # when aux_outputs asks for every full-resolution mask (then the full-resolution kernel only writes the masks)
+        self.pooled_attention_masks = True
         self.pe_layer = PositionEmbeddingSine(hidden_dim // 2, normalize=True)
         self.transformer_self_attention_layers = nn.ModuleList(
             MeanShiftSelfAttentionLayer(hidden_dim, nheads) for _ in range(dec_layers))
@@ -420,11 +424,21 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         pk = self._packed_tails()
         mlp = [(pk["mlp"][j], l.bias) for j, l in enumerate(self.mask_embed.layers)]
         ncol = None
+        pooled = {}
         if isinstance(mask_features, FoldedMaskFeatures):
             # the heads kernel emits [e Wm | e.bm | 0...] instead of e; the mask step runs on the 64-channel activation
             wf, bf, ncol = self._folded_head(mask_features)
             mlp[-1] = (wf, bf)
             mask_features = mask_features.act
+            if self.pooled_attention_masks and (not full or self.pooled_attention_masks == "always") and ncol == 64 and mask_features.shape[1] == 64:
+                # attention masks at key resolution: pool the activation once to every level size that is an integer reduction
+                Hm, Wm = int(mask_features.shape[2]), int(mask_features.shape[3])
+                want_sizes = []
+                for (th, tw) in sizes:
+                    if (th, tw) not in want_sizes and Hm % th == 0 and Wm % tw == 0 and Hm // th == Wm // tw and Hm // th in (2, 4, 8):
+                        want_sizes.append((int(th), int(tw)))
+                if want_sizes and L > 0:
+                    pooled = dict(zip(want_sizes, ops.pool_mask_taps(mask_features, want_sizes)))
         dn = self.decoder_norm
         pred_cls, pred_mask = [], []
 
@@ -434,6 +448,15 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             cls = ops.gemm(d, self.class_embed.weight, self.class_embed.bias) if want else None
             tgt = None if (last and not full) else sizes[i_next % self.num_feature_levels]
             emb, qb = (e, None) if ncol is None else (e[..., :ncol], e[..., ncol])
+            if tgt is not None and tuple(tgt) in pooled:
+                attn, row_any = ops.attn_mask_pooled(emb, pooled[tuple(tgt)], qbias=qb, row_any=ra)
+                m = None
+                if want:        # "always" with aux outputs: the full-resolution kernel only writes the mask
+                    m = ops.mask_logits(emb, mask_features, want_mask=True, target_size=None, packed_bf16=self._packed_mf, qbias=qb,
+                                        packed_split=getattr(self, "_packed_mf_split", None))[0]
+                pred_cls.append(cls)
+                pred_mask.append(m)
+                return attn, row_any
             m, attn, row_any = ops.mask_logits(emb, mask_features, want_mask=want, target_size=tgt, sparse=self.sparse_taps,
                                                row_any=ra,       # ra: cleared by the heads kernel, no fill launch
                                                packed_bf16=self._packed_mf, qbias=qb, packed_split=getattr(self, "_packed_mf_split", None))

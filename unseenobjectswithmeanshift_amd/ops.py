@@ -419,6 +419,55 @@ def pack_mask_features_split(mask_features):
     return out
 
 
+def pool_mask_taps(act, sizes):
+    """The 64-channel factored mask features act (B, 64, H, W) reduced bilinearly (align_corners=False) to each (th, tw) of
+    ``sizes`` (H / th = W / tw in {2, 4, 8}: the mean of the four centre taps of every cell) -> list of token-major
+    (B, th*tw, 64) tensors.  One launch (csrc/attn_mask.hip)."""
+    _c(act, "act")
+    B, C, H, W = act.shape
+    if C != 64 or not 1 <= len(sizes) <= 4:
+        raise RuntimeError("pool_mask_taps needs a (B, 64, H, W) activation and 1..4 target sizes")
+    outs = [torch.empty((B, int(th) * int(tw), 64), device=act.device, dtype=torch.float32) for th, tw in sizes]
+    n = len(sizes)
+    ths = (ctypes.c_int32 * n)(*[int(s[0]) for s in sizes])
+    tws = (ctypes.c_int32 * n)(*[int(s[1]) for s in sizes])
+    ptrs = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    rc = lib().msm_pool_mask_taps(_p(act), B, H, W, n, ctypes.cast(ths, ctypes.c_void_p), ctypes.cast(tws, ctypes.c_void_p),
+                                  ctypes.cast(ptrs, ctypes.c_void_p), _stream())
+    check(rc, "msm_pool_mask_taps")
+    return outs
+
+
+def attn_mask_pooled(mask_embed, pooled, *, qbias=None, row_any=None):
+    """The next layer's attention mask from the pooled activation (pool_mask_taps): attn (B, Q, T) uint8 =
+    (einsum('bqc,btc->bqt', mask_embed, pooled) + qbias[b, q]) < 0 and row_any (B, Q) int32 (1 where a row keeps an unmasked
+    key).  mask_embed: (B, Q, 64), contiguous or the leading 64 columns of a wider row-major buffer; qbias (B, Q), any uniform
+    element stride; row_any: an already ZEROED buffer (saves the fill launch).  Equal to the attention-mask output of
+    mask_logits(..., target_size) on the unpooled activation up to fp32 summation order."""
+    _chk(mask_embed, "mask_embed"), _c(pooled, "pooled"), _chk(qbias, "qbias")
+    B, Q, C = mask_embed.shape
+    T = pooled.shape[1]
+    if C != 64 or tuple(pooled.shape) != (B, T, 64):
+        raise RuntimeError("attn_mask_pooled needs a (B, Q, 64) embedding and a (B, T, 64) pooled activation")
+    if mask_embed.stride(2) != 1 or (B > 1 and mask_embed.stride(0) != Q * mask_embed.stride(1)) or mask_embed.stride(1) < C:
+        raise RuntimeError("mask_embed must be (B,Q,C) with unit column stride and uniformly spaced rows")
+    qb_ld = 0
+    if qbias is not None:
+        if tuple(qbias.shape) != (B, Q) or (B > 1 and qbias.stride(0) != Q * qbias.stride(1)):
+            raise RuntimeError("qbias must be (B,Q) with uniformly spaced elements")
+        qb_ld = qbias.stride(1)
+    attn = torch.empty((B, Q, T), device=mask_embed.device, dtype=torch.uint8)
+    cleared = row_any is not None
+    if row_any is None:
+        row_any = torch.empty((B, Q), device=mask_embed.device, dtype=torch.int32)
+    else:
+        _c(row_any, "row_any", torch.int32)
+    rc = lib().msm_attn_mask_pooled(_p(mask_embed), mask_embed.stride(1), _p(qbias), qb_ld, _p(pooled), _p(attn), _p(row_any),
+                                    1 if cleared else 0, B, Q, T, _stream())
+    check(rc, "msm_attn_mask_pooled")
+    return attn, row_any
+
+
 def mask_logits(mask_embed, mask_features, *, want_mask=True, target_size=None, sparse=False, row_any=None, packed_bf16=None,
                 qbias=None, packed_split=None):
     """einsum('bqc,bchw->bqhw') (+ qbias[b, q]) with the next layer's attention mask fused.
