@@ -430,6 +430,14 @@ def test_meta_arch_inference_vs_oracle():
         assert (inst.pred_masks.cpu() != ref["pred_masks"]).float().mean() < 1e-4
         torch.testing.assert_close(inst.scores.cpu(), ref["scores"], rtol=1e-4, atol=1e-6)
         assert torch.equal(inst.pred_classes.cpu(), ref["pred_classes"])
+    # inference ran the final mask step on the 20 kept queries only (modeling: _final_topk); with all 100 queries computed and the
+    # selection afterwards -- the reference's order -- the instances are the same, bit for bit
+    fast = model.inference(dfe, (64, 96))
+    model.topk_before_masks = False
+    slow = model.inference(dfe, (64, 96))
+    model.topk_before_masks = True
+    for a, b in zip(fast, slow):
+        assert torch.equal(a, b)
     pred = Network_RGBD(model)
     one = pred({"features": {k: v[:1] for k, v in dfe.items()}, "height": 64, "width": 96})
     conf = get_confident_instances(one, score=0.0)

@@ -171,10 +171,26 @@ class MeanShiftMaskFormer(PlanAttributes, nn.Module):
         the features were computed on when the image was padded to the size divisibility (masks are cropped back to
         image_size, PM:275,354-357)."""
         padded_size = tuple(padded_size or image_size)
-        outputs, _ = self.sem_seg_head(features, padded_size[0], padded_size[1])
-        cls_scores, classes, qidx = ops.topk_class_scores(outputs["pred_logits"], self.test_topk_per_image)
+        pred = getattr(self.sem_seg_head, "predictor", None)
+        if pred is not None and hasattr(pred, "_final_topk") and getattr(self, "topk_before_masks", True):
+            pred._final_topk = int(self.test_topk_per_image)       # the final mask step only for the queries kept below
+        try:
+            outputs, _ = self.sem_seg_head(features, padded_size[0], padded_size[1])
+        finally:
+            if pred is not None and hasattr(pred, "_final_topk"):
+                pred._final_topk = 0
+        if "topk" in outputs:
+            cls_scores, classes, qidx = outputs["topk"]
+            B, K = qidx.shape
+            key = (B, K, str(qidx.device))
+            if getattr(self, "_iota", (None,))[0] != key:
+                self._iota = (key, torch.arange(K, device=qidx.device, dtype=torch.int32)[None].expand(B, -1).contiguous())
+            local = self._iota[1]                                  # pred_masks holds exactly the K selected queries, in order
+        else:
+            cls_scores, classes, qidx = ops.topk_class_scores(outputs["pred_logits"], self.test_topk_per_image)
+            local = qidx
         # scores = class prob * mean mask prob (PM:495), fused into the post-process kernel
-        masks, scores, boxes = ops.instance_postprocess(outputs["pred_masks"], qidx, image_size, class_scores=cls_scores,
+        masks, scores, boxes = ops.instance_postprocess(outputs["pred_masks"], local, image_size, class_scores=cls_scores,
                                                         padded_size=padded_size)
         return scores, classes, masks, boxes, qidx
 

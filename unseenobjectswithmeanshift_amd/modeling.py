@@ -238,6 +238,10 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         # commute: csrc/attn_mask.hip); False: every step at full resolution with the taps pooled afterwards; "always": also
         # when aux_outputs asks for every full-resolution mask (then the full-resolution kernel only writes the masks)
         self.pooled_attention_masks = True
+        # inference entry of the meta-architecture: K > 0 -> the final mask step runs only for the K queries instance_inference
+        # keeps (top-K class scores, PM:461-497); the output dict then holds pred_masks (B, K, H, W) and "topk" = (scores, classes,
+        # query index).  0: all queries (the reference's head output)
+        self._final_topk = 0               # transient: set by MeanShiftMaskFormer.inference around its head call
         self.pe_layer = PositionEmbeddingSine(hidden_dim // 2, normalize=True)
         self.transformer_self_attention_layers = nn.ModuleList(
             MeanShiftSelfAttentionLayer(hidden_dim, nheads) for _ in range(dec_layers))
@@ -448,6 +452,17 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             cls = ops.gemm(d, self.class_embed.weight, self.class_embed.bias) if want else None
             tgt = None if (last and not full) else sizes[i_next % self.num_feature_levels]
             emb, qb = (e, None) if ncol is None else (e[..., :ncol], e[..., ncol])
+            if last and not full and ncol is not None and 0 < self._final_topk < e.shape[1] and cls is not None:
+                # only the masks instance_inference keeps: top-K class scores first, then the mask step on those K embeddings
+                topk = ops.topk_class_scores(cls, int(self._final_topk))
+                idx = topk[2].long()[..., None].expand(-1, -1, ncol + 4)
+                sel = torch.gather(e[..., :ncol + 4], 1, idx)                      # (B, K, 68): [e Wm | e.bm | pad], rows 16-byte aligned
+                m = ops.mask_logits(sel[..., :ncol], mask_features, want_mask=True, target_size=None, packed_bf16=self._packed_mf,
+                                    qbias=sel[..., ncol], packed_split=getattr(self, "_packed_mf_split", None))[0]
+                pred_cls.append(cls)
+                pred_mask.append(m)
+                self._topk_out = topk
+                return None, None
             if tgt is not None and tuple(tgt) in pooled:
                 attn, row_any = ops.attn_mask_pooled(emb, pooled[tuple(tgt)], qbias=qb, row_any=ra)
                 m = None
@@ -496,6 +511,8 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                                              **next_query(i + 1))
             attn, row_any = predict(d, e, ra, i + 1)
         res = {"pred_logits": pred_cls[-1], "pred_masks": pred_mask[-1], "aux_outputs": []}
+        if getattr(self, "_topk_out", None) is not None:
+            res["topk"], self._topk_out = self._topk_out, None
         if full:
             res["aux_outputs"] = [{"pred_logits": a, "pred_masks": b} for a, b in zip(pred_cls[:-1], pred_mask[:-1])]
         return res
