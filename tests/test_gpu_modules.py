@@ -792,3 +792,22 @@ def test_head_beyond_64_images_keeps_the_folded_mask_step():
     small, _ = head({k: v[:3].contiguous() for k, v in feats.items()})
     torch.testing.assert_close(big["pred_logits"][:3], small["pred_logits"], rtol=1e-3, atol=1e-3)
     assert float(((big["pred_masks"][:3] > 0) != (small["pred_masks"] > 0)).float().mean()) < 1e-3
+
+
+def test_parameter_only_subgraphs_follow_parameter_updates():
+    """What the head computes once per parameter version -- the folded mask-embedding Linear, the packed tail weights, prediction 0's
+    decoder_norm / MLP / first query (they start from the learned queries, not from the input) -- follows an in-place update of a
+    parameter they depend on: after the update the head equals a freshly built head holding the updated parameters."""
+    head = make_pixel_decoder()
+    feats = {k: v.to(DEV) for k, v in syn.synth_backbone_features(2, 64, 96, seed=4).items()}
+    before, _ = head(feats)
+    with torch.no_grad():
+        head.predictor.query_feat.weight.mul_(1.25)
+        head.predictor.mask_embed.layers[0].bias.add_(0.05)
+        head.pixel_decoder.mask_features.weight.mul_(0.9)
+    after, _ = head(feats)
+    assert float((after["pred_masks"] - before["pred_masks"]).abs().max()) > 1e-3
+    fresh = make_pixel_decoder()
+    fresh.load_state_dict(head.state_dict(), strict=True)
+    want, _ = fresh(feats)
+    assert torch.equal(after["pred_masks"], want["pred_masks"]) and torch.equal(after["pred_logits"], want["pred_logits"])

@@ -13,7 +13,7 @@ import torch
 
 # attributes under which the modules keep derived tensors (packed weights, folded constants, position codes, broadcast
 # queries) that the kernels of a forward read by address
-_CACHE_ATTRS = ("_q0", "_kv_cache", "_fold_cache", "_tails_cache", "_pos_cache", "_cache", "_packed", "_front", "_w3_cache", "_wl_cache", "_iota",
+_CACHE_ATTRS = ("_q0", "_kv_cache", "_fold_cache", "_tails_cache", "_pos_cache", "_cache", "_packed", "_front", "_w3_cache", "_wl_cache", "_iota", "_heads0_cache",
                 "_packed_mf", "_bf16_cache", "_folded_cache")
 
 

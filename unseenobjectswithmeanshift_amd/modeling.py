@@ -429,7 +429,9 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         mlp = [(pk["mlp"][j], l.bias) for j, l in enumerate(self.mask_embed.layers)]
         ncol = None
         pooled = {}
+        fm_params = None
         if isinstance(mask_features, FoldedMaskFeatures):
+            fm_params = [t for t in (mask_features.weight, mask_features.bias) if t is not None]
             # the heads kernel emits [e Wm | e.bm | 0...] instead of e; the mask step runs on the 64-channel activation
             wf, bf, ncol = self._folded_head(mask_features)
             mlp[-1] = (wf, bf)
@@ -485,8 +487,20 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             return dict(wq=pk["cross_q"][i], bq=self.transformer_cross_attention_layers[i].meanshift_attn.in_proj_bias[:E],
                         query_pos=qpos)
 
-        _, d, e, q, ra = ops.dec_heads(out, dn.weight, dn.bias, mlp, want_out=False, want_d=full or L == 0,
-                                       zero_row_any=True, **next_query(0))
+        if not full and L > 0 and fm_params is not None:
+            # prediction 0 starts from the learned queries: decoder_norm, the mask-embedding MLP and the first cross-attention query
+            # do not depend on the input -- computed once per parameter version (the attention mask they feed does: it contracts
+            # e0 with this pass's pooled activation)
+            hkey = (tuple(out.shape), str(out.device), self.tails_dtype) + version_key(list(self.parameters()) + fm_params)
+            hc = getattr(self, "_heads0_cache", None)
+            if hc is None or hc[0] != hkey:
+                _, d, e, q, _ = ops.dec_heads(out, dn.weight, dn.bias, mlp, want_out=False, want_d=False, zero_row_any=True, **next_query(0))
+                self._heads0_cache = hc = (hkey, d, e, q)
+            _, d, e, q = hc
+            ra = None                                       # the mask step clears its own row flags
+        else:
+            _, d, e, q, ra = ops.dec_heads(out, dn.weight, dn.bias, mlp, want_out=False, want_d=full or L == 0,
+                                           zero_row_any=True, **next_query(0))
         attn, row_any = predict(d, e, ra, 0)
         for i in range(L):
             lvl = i % self.num_feature_levels                                     # DEC:608
