@@ -417,6 +417,17 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             self._fold_cache = (key, pack(w.float().contiguous()), b.float().contiguous(), n)
         return self._fold_cache[1:]
 
+    @staticmethod
+    def _poolable_sizes(act, sizes):
+        """Level sizes that are integer reductions (2, 4, 8) of the mask-feature map: their attention masks can be computed at key
+        resolution (csrc/attn_mask.hip)."""
+        Hm, Wm = int(act.shape[2]), int(act.shape[3])
+        out = []
+        for (th, tw) in sizes:
+            if (int(th), int(tw)) not in out and Hm % th == 0 and Wm % tw == 0 and Hm // th == Wm // tw and Hm // th in (2, 4, 8):
+                out.append((int(th), int(tw)))
+        return out
+
     def _forward_fused(self, xs, sizes, kv_w, kv_c, mask_features, out, qpos, kv_all=None):
         """Same arithmetic as the loop in forward(), with the row-local ops of a layer in three launches:
         heads (+ next cross-attention query) -> mask step -> K/V GEMM -> cross attention -> post_cross (out_proj, LN,
@@ -438,11 +449,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             mask_features = mask_features.act
             if self.pooled_attention_masks and (not full or self.pooled_attention_masks == "always") and ncol == 64 and mask_features.shape[1] == 64:
                 # attention masks at key resolution: pool the activation once to every level size that is an integer reduction
-                Hm, Wm = int(mask_features.shape[2]), int(mask_features.shape[3])
-                want_sizes = []
-                for (th, tw) in sizes:
-                    if (th, tw) not in want_sizes and Hm % th == 0 and Wm % tw == 0 and Hm // th == Wm // tw and Hm // th in (2, 4, 8):
-                        want_sizes.append((int(th), int(tw)))
+                want_sizes = self._poolable_sizes(mask_features, sizes)
                 if want_sizes and L > 0:
                     pooled = dict(zip(want_sizes, ops.pool_mask_taps(mask_features, want_sizes)))
         dn = self.decoder_norm
@@ -459,8 +466,8 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                 topk = ops.topk_class_scores(cls, int(self._final_topk))
                 idx = topk[2].long()[..., None].expand(-1, -1, ncol + 4)
                 sel = torch.gather(e[..., :ncol + 4], 1, idx)                      # (B, K, 68): [e Wm | e.bm | pad], rows 16-byte aligned
-                m = ops.mask_logits(sel[..., :ncol], mask_features, want_mask=True, target_size=None, packed_bf16=self._packed_mf,
-                                    qbias=sel[..., ncol], packed_split=getattr(self, "_packed_mf_split", None))[0]
+                # (fp32 kernel in every precision mode: one launch on K queries does not pay for a packed copy of the activation)
+                m = ops.mask_logits(sel[..., :ncol], mask_features, want_mask=True, target_size=None, qbias=sel[..., ncol])[0]
                 pred_cls.append(cls)
                 pred_mask.append(m)
                 self._topk_out = topk
@@ -572,11 +579,16 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         if self.mask_step_dtype not in ("f32", "bf16", "f32_split"):
             raise ValueError("mask_step_dtype must be 'f32', 'bf16' or 'f32_split'")
         mf_planes = mask_features.act if folded else mask_features
-        self._packed_mf = ops.pack_mask_features_bf16(mf_planes) if self.mask_step_dtype == "bf16" else None
+        # the default inference plan never runs the full-resolution mask kernel on all queries (attention masks at key resolution,
+        # the final step on the top-K embeddings with the fp32 kernel): no packed copy of the activation is needed then
+        lean = (folded and self.fused_tails and self.fold_kv and not self.aux_outputs and self.pooled_attention_masks and self.num_layers > 0
+                and mf_planes.shape[1] == 64 and 0 < self._final_topk < self.query_feat.weight.shape[0]
+                and len(self._poolable_sizes(mf_planes, sizes)) == len(set((int(a), int(b)) for a, b in sizes)))
+        self._packed_mf = ops.pack_mask_features_bf16(mf_planes) if (self.mask_step_dtype == "bf16" and not lean) else None
         # f32_split: the folded 64-channel step as exact three-term bf16 splits on the bf16 matrix pipe (fp32-accurate); the
         # literal 256-channel form keeps the fp32 MFMA kernel
         self._packed_mf_split = ops.pack_mask_features_split(mf_planes) \
-            if (self.mask_step_dtype == "f32_split" and folded and mf_planes.shape[1] == 64) else None
+            if (self.mask_step_dtype == "f32_split" and folded and mf_planes.shape[1] == 64 and not lean) else None
         qpos = self.query_embed.weight
         qf = self.query_feat.weight
         # the broadcast initial queries are read-only: one tensor per (batch size, parameter version).  A captured HIP
