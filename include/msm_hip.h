@@ -57,7 +57,7 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 10   /* 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
+#define MSM_ABI_VERSION 11   /* 11: mean-shift hill climb with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split); 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
 int msm_abi_version(void);
 
 /* Kernel-selection overrides for tools/ and tests/ (NOT read on the product path: every option defaults to
@@ -446,6 +446,12 @@ int msm_ms_select_seeds(const float* X, int n, int d, int num_seeds, int64_t fir
 int64_t msm_ms_hill_climb_workspace(int n, int S);
 int msm_ms_hill_climb(const float* X, int n, int d, float* Z, int S, float kappa, int iters,
                       float* workspace, int64_t workspace_elems, void* stream);
+/* The same iteration (same arguments, same workspace) with every fp32 product carried out as six bf16 MFMAs on exact
+ * three-term splits of both operands (X, Z and the exp() weights): fp32-accurate results -- the error against float64 is not
+ * larger than the fp32 MFMA kernel's -- at 0.375 of its matrix time.  Opt-in (the host passes precision="f32_split"); Z must be
+ * 16-byte aligned as well. */
+int msm_ms_hill_climb_split(const float* X, int n, int d, float* Z, int S, float kappa, int iters,
+                            float* workspace, int64_t workspace_elems, void* stream);
 /* closest = first argmin_s 0.5*(1 - X.Z_s); labels_out[i] = seed_labels[closest] (int64);
  * counts int64 [num_labels] histogram of labels_out (zeroed here) (MS:206-221). */
 int msm_ms_assign(const float* X, int n, int d, const float* Z, int S, const int64_t* seed_labels,

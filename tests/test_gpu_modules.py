@@ -401,6 +401,38 @@ def test_mean_shift_full_size_matches_oracle():
         assert torch.unique(lab[ids == c]).numel() == 1
 
 
+def test_mean_shift_full_size_split_form():
+    """The same clustering with the hill climb in its f32_split form: labels identical to the oracle's at 640x480 and on the
+    golden cases, converged seeds not further from float64 than the fp32 MFMA kernel's (1.5x bound)."""
+    from unseenobjectswithmeanshift_amd import mean_shift as ms
+    X, ids = syn.synth_unit_embeddings(307200, 64, clusters=12, sigma=0.15, seed=3)
+    Xd = X.to(DEV)
+    labels, sel = ms.mean_shift_smart_init(Xd, kappa=20, num_seeds=100, max_iters=10, first_index=11, precision="f32_split")
+    ref_labels, ref_sel, _, _ = O.mean_shift_smart_init(X, 20.0, 100, 10, 11)
+    assert torch.equal(sel.cpu(), ref_sel)
+    assert torch.equal(labels.cpu(), ref_labels)
+    seeds = X[ref_sel].contiguous()
+    Z64 = seeds.double()
+    X64 = X.double()
+    for _ in range(10):
+        Z64 = torch.nn.functional.normalize(torch.exp(20.0 * (Z64 @ X64.t())) @ X64, dim=1)
+    e32 = (ms.seed_hill_climbing_ball(Xd, seeds.to(DEV), 20.0, 10).cpu().double() - Z64).abs().max().item()
+    esp = (ms.seed_hill_climbing_ball(Xd, seeds.to(DEV), 20.0, 10, precision="f32_split").cpu().double() - Z64).abs().max().item()
+    print(f"hill climb n=307200 S=100 x10: max |err| vs float64  fp32 MFMA {e32:.2e}  split {esp:.2e}")
+    assert esp <= max(1.5 * e32, 2e-7)
+
+
+def test_mean_shift_split_golden(golden):
+    from unseenobjectswithmeanshift_amd import mean_shift as ms
+    g = golden("mean_shift")
+    for tag, n, k, S in (("a", 4800, 8, 50), ("b", 19200, 12, 100)):
+        X, ids = syn.synth_unit_embeddings(n, 64, clusters=k, sigma=0.15, seed=10 + k)
+        labels, sel = ms.mean_shift_smart_init(X.to(DEV), kappa=20, num_seeds=S, max_iters=10,
+                                               first_index=int(g[f"{tag}_first"]), precision="f32_split")
+        assert torch.equal(sel.cpu(), T(g[f"{tag}_sel"]))
+        assert torch.equal(labels.cpu(), T(g[f"{tag}_labels"]).long())
+
+
 def test_clustering_features_api():
     from unseenobjectswithmeanshift_amd import mean_shift as ms
     X, ids = syn.synth_unit_embeddings(2 * 40 * 60, 64, clusters=5, sigma=0.1, seed=4)

@@ -651,6 +651,32 @@ def test_mean_shift_many_seeds():
     close(Z, Zref, rtol=1e-4, atol=1e-5)
 
 
+def _hill_f64(X, Z, kappa, iters):
+    X, Z = X.double(), Z.double()
+    for _ in range(iters):                                   # MS:90-107 in float64
+        Z = torch.nn.functional.normalize(torch.exp(kappa * (Z @ X.t())) @ X, dim=1)
+    return Z
+
+
+@pytest.mark.parametrize("n,S,iters", [(2000, 20, 10), (37, 1, 3), (4111, 50, 4), (5000, 300, 3), (19200, 100, 10), (31, 17, 2)])
+def test_mean_shift_hill_climb_split(n, S, iters):
+    """fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split): against float64 the error is bounded by 1.5x the
+    fp32 MFMA kernel's on the same inputs (ragged n, one seed, seed counts around the block and chunk sizes)."""
+    from unseenobjectswithmeanshift_amd import synthetic as syn
+    X, _ = syn.synth_unit_embeddings(n, 64, clusters=6, sigma=0.15, seed=n)
+    seeds = X[torch.randperm(n, generator=torch.Generator().manual_seed(S))[:S]] if S <= n else X[:S]
+    seeds = seeds.contiguous()
+    ref = _hill_f64(X, seeds, 20.0, iters)
+    z32 = ops().ms_hill_climb(X.to(DEV), seeds.to(DEV), 20.0, iters).cpu().double()
+    zsp = ops().ms_hill_climb(X.to(DEV), seeds.to(DEV), 20.0, iters, precision="f32_split").cpu().double()
+    e32, esp = (z32 - ref).abs().max().item(), (zsp - ref).abs().max().item()
+    print(f"hill climb n={n} S={S}: max |err| vs float64  fp32 MFMA {e32:.2e}  split {esp:.2e}")
+    assert esp <= max(1.5 * e32, 2e-7)
+    close(zsp.float(), ref.float(), rtol=1e-4, atol=1e-5)
+    with pytest.raises(ValueError):
+        ops().ms_hill_climb(X.to(DEV), seeds.to(DEV), 20.0, 1, precision="bf16")
+
+
 # ---------------------------------------------------------------------------------------------
 def test_topk_and_postprocess():
     B, Q, h, w, Hh, Ww, T = 2, 100, 30, 40, 120, 160, 20

@@ -15,6 +15,7 @@
 //               turns a 16-point block into exp() weights in registers, already in A-operand
 //               layout for the W X product;
 //   assignment: one more X pass, S^T tiles + an in-register first-min argmin.
+#include "bf16.h"
 #include "common.h"
 #include <cstdlib>
 
@@ -444,6 +445,189 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 #undef MS_LOAD_SLAB
 
+// ---- the same step with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split) -----------------------------
+// Every fp32 operand is an exact sum of three bf16 terms (bf16.h: split3), a product keeps the six terms above 2^-24 of it
+// and runs on v_mfma_f32_16x16x32_bf16: 6 x 16 cycles for 16x16x32 against 8 x 32 cycles of the fp32 instruction (0.375 of its
+// matrix time).  The splitting is VALU work beside the MFMAs, and X is needed in two operand orders (k = channel for the
+// scores, k = point for W X), so the kernel is arranged around what a wave can keep in registers:
+//   * a wave owns a 32-point slab (wave-private fp32 tile in LDS, register-staged prefetch of the next one) and HALF of the
+//     launch's seed blocks: waves w and w + 4 of the 512-thread workgroup walk the same slabs with seed blocks [0, NSBW) and
+//     [NSBW, nsb) -- 16 NSBW accumulator registers instead of 16 nsb, at the price of splitting X twice;
+//   * scores: A = X terms (point lj, channels 8 lq ..+7 of a 32-channel half), B = Z terms read from LDS planes that were
+//     split once per launch; small terms and the h.h term in separate accumulators, added at the end;
+//   * the D layout of the scores (lane = seed lj, registers = points 4 lq + r) IS the A layout of W X when the k index of the
+//     K = 32 instruction is read as k = 8 kq + e <-> point (e < 4 ? 4 kq + e : 16 + 4 kq + e - 4): the eight exp() weights of
+//     a lane (two 16-point score tiles) are split in place, the B operand gathers the same eight points of column 16 db + lj.
+// One workgroup per CU (2 waves per SIMD: one wave's splitting runs beside the other's MFMAs).
+constexpr int ZP_LD = MS_D + 8;        // bf16 row stride of the Z planes: 144 B = 9 slots of 16 B -> b128 reads of 8 rows hit 8 slots
+constexpr int HS_ROWS = 32;            // points per slab
+
+__device__ __forceinline__ f32x4 mfma_k32(const bf16x8& a, const bf16x8& b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+template <int NSBW>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void ms_hill_split_kernel(const float* __restrict__ X, int n,
+                                                                                                          const float* __restrict__ Z, int S, int nsb,
+                                                                                                          float kappa, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int zrows = nsb * 16;
+    uint16_t* zp = reinterpret_cast<uint16_t*>(lds);                               // [3][zrows][ZP_LD] bf16 terms of Z
+    float* xsa = lds + (3 * zrows * ZP_LD) / 2;                                    // [8 waves][32][SZ]
+    float* accum = lds;                                                            // [zrows][64] after the loop
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar branches
+    const int lj = lane & 15, lq = lane >> 4;
+    for (int i = tid; i < zrows * (MS_D / 4); i += 512) {
+        const int s = i / (MS_D / 4), c4 = (i - s * (MS_D / 4)) * 4;
+        const float4 v = (s < S) ? *reinterpret_cast<const float4*>(Z + (int64_t)s * MS_D + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const Split3 t = split3(v.x, v.y, v.z, v.w);
+        *reinterpret_cast<u32x2b*>(zp + (0 * zrows + s) * ZP_LD + c4) = __builtin_bit_cast(u32x2b, t.h);
+        *reinterpret_cast<u32x2b*>(zp + (1 * zrows + s) * ZP_LD + c4) = __builtin_bit_cast(u32x2b, t.m);
+        *reinterpret_cast<u32x2b*>(zp + (2 * zrows + s) * ZP_LD + c4) = __builtin_bit_cast(u32x2b, t.l);
+    }
+    __syncthreads();
+    const int pg = wave & 3, sb0 = (wave >> 2) * NSBW;
+    const int nb = min(NSBW, nsb - sb0);                 // this wave's seed blocks (may be 0 when nsb == 1)
+    float* xs = xsa + wave * HS_ROWS * SZ;
+
+    f32x4 zn[NSBW][4];
+#pragma unroll
+    for (int sb = 0; sb < NSBW; ++sb)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) zn[sb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const float kl2 = kappa * 1.4426950408889634f;
+    const int nslabs = (n + HS_ROWS - 1) / HS_ROWS;
+    const int srow = lane >> 4, scol = (lane & 15) * 4;
+    // register-staged prefetch of the next slab (eight named registers: an indexed array ends up in scratch)
+#define HS_ROW(P0, I) (X + (int64_t)min((P0) + (I) * 4 + srow, n - 1) * MS_D + scol)
+#define HS_LOAD_SLAB(P0)                                                                                              \
+    nx0 = *reinterpret_cast<const float4*>(HS_ROW(P0, 0)); nx1 = *reinterpret_cast<const float4*>(HS_ROW(P0, 1));     \
+    nx2 = *reinterpret_cast<const float4*>(HS_ROW(P0, 2)); nx3 = *reinterpret_cast<const float4*>(HS_ROW(P0, 3));     \
+    nx4 = *reinterpret_cast<const float4*>(HS_ROW(P0, 4)); nx5 = *reinterpret_cast<const float4*>(HS_ROW(P0, 5));     \
+    nx6 = *reinterpret_cast<const float4*>(HS_ROW(P0, 6)); nx7 = *reinterpret_cast<const float4*>(HS_ROW(P0, 7));
+#define HS_STORE_ROW(I, V) *reinterpret_cast<float4*>(xs + ((I) * 4 + srow) * SZ + scol) = V;
+    float4 nx0, nx1, nx2, nx3, nx4, nx5, nx6, nx7;
+    HS_LOAD_SLAB((blockIdx.x * 4 + pg) * HS_ROWS)
+    for (int sl = blockIdx.x * 4 + pg; sl < nslabs; sl += gridDim.x * 4) {
+        const int p0 = sl * HS_ROWS;
+        HS_STORE_ROW(0, nx0) HS_STORE_ROW(1, nx1) HS_STORE_ROW(2, nx2) HS_STORE_ROW(3, nx3)
+        HS_STORE_ROW(4, nx4) HS_STORE_ROW(5, nx5) HS_STORE_ROW(6, nx6) HS_STORE_ROW(7, nx7)
+        HS_LOAD_SLAB((sl + (int)gridDim.x * 4) * HS_ROWS)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // A operands of the scores: [16-point tile q][channel half h]
+        Split3x8 xa[2][2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float* src = xs + (q * 16 + lj) * SZ + h * 32 + lq * 8;
+                const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+                xa[q][h] = join(split3(v0.x, v0.y, v0.z, v0.w), split3(v1.x, v1.y, v1.z, v1.w));
+            }
+        // B operands of W X: the lane's eight points of column 16 db + lj
+        Split3x8 xb[4];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            float e[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e[r] = xs[(lq * 4 + r) * SZ + db * 16 + lj];
+                e[4 + r] = xs[(16 + lq * 4 + r) * SZ + db * 16 + lj];
+            }
+            xb[db] = join(split3(e[0], e[1], e[2], e[3]), split3(e[4], e[5], e[6], e[7]));
+        }
+        const bool tail = p0 + HS_ROWS > n;     // only the last slab can hold rows beyond n (clamped copies, weight 0)
+        // Software pipeline over the seed blocks: the score MFMAs of block sb + 1 are issued before the exp() / split work of
+        // block sb, so that a wave's own vector work runs beside its own matrix work as well as beside the other wave's.
+        f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, sbv = sa;
+        auto score = [&](int sb, f32x4& oa, f32x4& ob) {
+            bf16x8 zf[2][3];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    zf[h][t] = *reinterpret_cast<const bf16x8*>(zp + (t * zrows + (sb0 + sb) * 16 + lj) * ZP_LD + h * 32 + lq * 8);
+            f32x4 alo = f32x4{0.f, 0.f, 0.f, 0.f}, ahi = alo, blo = alo, bhi = alo;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                alo = mfma_k32(xa[0][h].l, zf[h][0], alo);
+                blo = mfma_k32(xa[1][h].l, zf[h][0], blo);
+                ahi = mfma_k32(xa[0][h].h, zf[h][0], ahi);
+                bhi = mfma_k32(xa[1][h].h, zf[h][0], bhi);
+                alo = mfma_k32(xa[0][h].h, zf[h][2], alo);
+                blo = mfma_k32(xa[1][h].h, zf[h][2], blo);
+                alo = mfma_k32(xa[0][h].m, zf[h][1], alo);
+                blo = mfma_k32(xa[1][h].m, zf[h][1], blo);
+                alo = mfma_k32(xa[0][h].m, zf[h][0], alo);
+                blo = mfma_k32(xa[1][h].m, zf[h][0], blo);
+                alo = mfma_k32(xa[0][h].h, zf[h][1], alo);
+                blo = mfma_k32(xa[1][h].h, zf[h][1], blo);
+            }
+            oa = alo + ahi;
+            ob = blo + bhi;
+        };
+        if (nb > 0) score(0, sa, sbv);
+#pragma unroll
+        for (int sb = 0; sb < NSBW; ++sb) {
+            if (sb < nb) {
+                const f32x4 ca = sa, cb = sbv;
+                if (sb + 1 < NSBW && sb + 1 < nb) score(sb + 1, sa, sbv);
+                float w[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    w[r] = __builtin_amdgcn_exp2f(kl2 * ca[r]);
+                    w[4 + r] = __builtin_amdgcn_exp2f(kl2 * cb[r]);
+                }
+                if (tail) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (p0 + lq * 4 + r >= n) w[r] = 0.f;
+                        if (p0 + 16 + lq * 4 + r >= n) w[4 + r] = 0.f;
+                    }
+                }
+                const Split3x8 w3 = join(split3(w[0], w[1], w[2], w[3]), split3(w[4], w[5], w[6], w[7]));
+                // six terms, smallest first, four independent chains (one per column block)
+#pragma unroll
+                for (int db = 0; db < 4; ++db) zn[sb][db] = mfma_k32(w3.l, xb[db].h, zn[sb][db]);
+#pragma unroll
+                for (int db = 0; db < 4; ++db) zn[sb][db] = mfma_k32(w3.h, xb[db].l, zn[sb][db]);
+#pragma unroll
+                for (int db = 0; db < 4; ++db) zn[sb][db] = mfma_k32(w3.m, xb[db].m, zn[sb][db]);
+#pragma unroll
+                for (int db = 0; db < 4; ++db) zn[sb][db] = mfma_k32(w3.m, xb[db].h, zn[sb][db]);
+#pragma unroll
+                for (int db = 0; db < 4; ++db) zn[sb][db] = mfma_k32(w3.h, xb[db].m, zn[sb][db]);
+#pragma unroll
+                for (int db = 0; db < 4; ++db) zn[sb][db] = mfma_k32(w3.h, xb[db].h, zn[sb][db]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#undef HS_LOAD_SLAB
+#undef HS_STORE_ROW
+#undef HS_ROW
+    // deterministic reduction over the four point groups: waves pg = 0..3 add into `accum` in turn (the two waves of a turn
+    // own disjoint seed rows)
+    __syncthreads();   // every wave is done reading the Z planes
+    for (int i = tid; i < zrows * MS_D; i += 512) accum[i] = 0.f;
+    __syncthreads();
+    for (int g = 0; g < 4; ++g) {
+        if (pg == g) {
+#pragma unroll
+            for (int sb = 0; sb < NSBW; ++sb)
+                if (sb < nb) {
+#pragma unroll
+                    for (int db = 0; db < 4; ++db)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) accum[((sb0 + sb) * 16 + lq * 4 + r) * MS_D + db * 16 + lj] += zn[sb][db][r];
+                }
+        }
+        __syncthreads();
+    }
+    float* dst = part + (int64_t)blockIdx.x * (zrows * MS_D);
+    for (int i = tid; i < zrows * MS_D; i += 512) dst[i] = accum[i];
+}
+
 // Z[s] = normalize(sum_wg part[wg][s])  (MS:103 F.normalize).  16 waves per seed: wave w adds its fixed slice of
 // the workgroup partials (8 loads in flight), then the slices are added in wave order -- deterministic.
 __global__ __launch_bounds__(1024) void ms_hill_finish_kernel(const float* __restrict__ part, int nwg, int rows_padded,
@@ -744,6 +928,58 @@ extern "C" int msm_ms_hill_climb(const float* X, int n, int d, float* Z, int S, 
         }
     }
     MSM_CHECK_LAUNCH("msm_ms_hill_climb");
+    return MSM_OK;
+}
+
+template <int NSBW>
+static int hill_split_launch(const float* X, int n, const float* Zc, int Sc, int nb, float kappa, float* ws, int G, hipStream_t st) {
+    const size_t lds = (size_t)3 * nb * 16 * ZP_LD * sizeof(uint16_t) + sizeof(float) * (size_t)8 * HS_ROWS * SZ;
+    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)ms_hill_split_kernel<NSBW>, lds));
+    hipLaunchKernelGGL((ms_hill_split_kernel<NSBW>), dim3(G), dim3(512), lds, st, X, n, Zc, Sc, nb, kappa, ws);
+    return MSM_OK;
+}
+
+extern "C" int msm_ms_hill_climb_split(const float* X, int n, int d, float* Z, int S, float kappa, int iters, float* workspace,
+                                       int64_t workspace_elems, void* stream) {
+    MSM_REQUIRE(X && Z && workspace, "msm_ms_hill_climb_split: null pointer");
+    MSM_REQUIRE(d == MS_D, "msm_ms_hill_climb_split: d=%d, only d=64 is supported", d);
+    MSM_REQUIRE(n > 0 && S > 0 && S <= MS_SB * 16 && iters >= 0, "msm_ms_hill_climb_split: bad sizes (S <= %d)", MS_SB * 16);
+    MSM_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)Z) & 15) == 0, "msm_ms_hill_climb_split: X and Z must be 16-byte aligned");
+    if (workspace_elems < msm_ms_hill_climb_workspace(n, S)) {
+        set_error("msm_ms_hill_climb_split: workspace too small");
+        return MSM_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    // one 512-thread workgroup per CU, four 32-point slabs in flight per workgroup (never more workgroups than hill_wgs(n):
+    // the workspace is sized for those)
+    const int G = max(1, min(256, cdiv(cdiv(n, HS_ROWS), 4)));
+    const int nsb = cdiv(S, 16);
+    const int CH = hill_chunk(nsb);
+    for (int it = 0; it < iters; ++it) {
+        float* ws = workspace;
+        for (int b0 = 0; b0 < nsb; b0 += CH) {
+            const int nb = min(CH, nsb - b0);
+            const float* Zc = Z + (int64_t)b0 * 16 * MS_D;
+            const int Sc = min(S - b0 * 16, nb * 16);
+            int rc = MSM_OK;
+            switch ((nb + 1) / 2) {
+                case 1: rc = hill_split_launch<1>(X, n, Zc, Sc, nb, kappa, ws, G, st); break;
+                case 2: rc = hill_split_launch<2>(X, n, Zc, Sc, nb, kappa, ws, G, st); break;
+                case 3: rc = hill_split_launch<3>(X, n, Zc, Sc, nb, kappa, ws, G, st); break;
+                default: rc = hill_split_launch<4>(X, n, Zc, Sc, nb, kappa, ws, G, st); break;
+            }
+            if (rc != MSM_OK) return rc;
+            ws += (int64_t)G * nb * 16 * MS_D;
+        }
+        ws = workspace;
+        for (int b0 = 0; b0 < nsb; b0 += CH) {
+            const int nb = min(CH, nsb - b0);
+            const int Sc = min(S - b0 * 16, nb * 16);
+            hipLaunchKernelGGL(ms_hill_finish_kernel, dim3(Sc), dim3(1024), 0, st, ws, G, nb * 16, Z + (int64_t)b0 * 16 * MS_D);
+            ws += (int64_t)G * nb * 16 * MS_D;
+        }
+    }
+    MSM_CHECK_LAUNCH("msm_ms_hill_climb_split");
     return MSM_OK;
 }
 

@@ -63,13 +63,15 @@ def connected_components_host(Z, epsilon):
     return torch.from_numpy(labels)
 
 
-def seed_hill_climbing_ball(X, Z, kappa, max_iters=10, metric="cosine"):
+def seed_hill_climbing_ball(X, Z, kappa, max_iters=10, metric="cosine", precision="f32"):
+    """mean_shift.py:79-109.  ``precision`` (not in the reference): "f32" (fp32 MFMAs) or "f32_split" (fp32 results on
+    the bf16 matrix pipe, ops.ms_hill_climb)."""
     _cosine_only(metric)
-    return ops.ms_hill_climb(X.contiguous(), Z.contiguous(), kappa, max_iters)
+    return ops.ms_hill_climb(X.contiguous(), Z.contiguous(), kappa, max_iters, precision=precision)
 
 
-def mean_shift_with_seeds(X, Z, kappa, max_iters=10, metric="cosine"):
-    Z = seed_hill_climbing_ball(X, Z, kappa, max_iters=max_iters, metric=metric)
+def mean_shift_with_seeds(X, Z, kappa, max_iters=10, metric="cosine", precision="f32"):
+    Z = seed_hill_climbing_ball(X, Z, kappa, max_iters=max_iters, metric=metric, precision=precision)
     return connected_components(Z, 2 * EMBEDDING_ALPHA, metric=metric), Z
 
 
@@ -91,7 +93,7 @@ def select_smart_seeds(X, num_seeds, return_selected_indices=False, init_seeds=N
     return seeds, idx
 
 
-def mean_shift_smart_init(X, kappa, num_seeds=100, max_iters=10, metric="cosine", first_index=None):
+def mean_shift_smart_init(X, kappa, num_seeds=100, max_iters=10, metric="cosine", first_index=None, precision="f32"):
     """mean_shift.py:192-229.  Returns (cluster_labels (n,) int64 on X.device, selected_indices (S,))."""
     X = X.contiguous()
     if first_index is None:
@@ -99,7 +101,7 @@ def mean_shift_smart_init(X, kappa, num_seeds=100, max_iters=10, metric="cosine"
     seeds, selected = select_smart_seeds(X, num_seeds, return_selected_indices=True, metric=metric,
                                          first_index=first_index)
     def rest(seeds):
-        seed_labels, Z = mean_shift_with_seeds(X, seeds, kappa, max_iters=max_iters, metric=metric)
+        seed_labels, Z = mean_shift_with_seeds(X, seeds, kappa, max_iters=max_iters, metric=metric, precision=precision)
         # labels are created in order 0, 1, ...: at most one per seed, so num_seeds bounds the histogram of the assignment
         labels, counts = ops.ms_assign(X, Z, seed_labels.to(X.device), seeds.shape[0])
         ops.ms_relabel_largest_zero(labels, counts)
@@ -117,7 +119,7 @@ def mean_shift_smart_init(X, kappa, num_seeds=100, max_iters=10, metric="cosine"
     return labels, selected
 
 
-def clustering_features(features, num_seeds=100, metric="cosine"):
+def clustering_features(features, num_seeds=100, metric="cosine", precision="f32"):
     """lib/fcn/test_dataset.py:44-59: features (B,C,H,W) unit-norm along C -> (out_label (B,H,W) float,
     selected_pixels list of (S,) index tensors).  kappa=20, 10 iterations."""
     B, C, H, W = features.shape
@@ -125,7 +127,7 @@ def clustering_features(features, num_seeds=100, metric="cosine"):
     selected_pixels = []
     for j in range(B):
         X = ops.transpose_last2(features[j].reshape(1, C, H * W).contiguous())[0]
-        labels, sel = mean_shift_smart_init(X, kappa=20, num_seeds=num_seeds, max_iters=10, metric=metric)
+        labels, sel = mean_shift_smart_init(X, kappa=20, num_seeds=num_seeds, max_iters=10, metric=metric, precision=precision)
         out_label[j] = labels.view(H, W).float()
         selected_pixels.append(sel)
     return out_label, selected_pixels

@@ -844,16 +844,20 @@ def ms_select_seeds(X, num_seeds, first_index, stepwise=False, _test_give_up=Fal
     return seeds, idx
 
 
-def ms_hill_climb(X, Z, kappa, iters):
-    """iters x { Z = normalize(exp(kappa Z X^T) X) }; returns the updated copy of Z."""
+def ms_hill_climb(X, Z, kappa, iters, precision="f32"):
+    """iters x { Z = normalize(exp(kappa Z X^T) X) }; returns the updated copy of Z.  precision "f32": fp32 MFMAs;
+    "f32_split": fp32 results from six bf16 MFMAs per product on exact three-term splits (msm_ms_hill_climb_split)."""
+    if precision not in ("f32", "f32_split"):
+        raise ValueError(f"ms_hill_climb: precision must be 'f32' or 'f32_split', not {precision!r}")
     _c(X, "X"), _c(Z, "Z")
     n, d = X.shape
     S = Z.shape[0]
     Z = Z.clone()
     need = lib().msm_ms_hill_climb_workspace(n, S)
     ws = torch.empty((need,), device=X.device, dtype=torch.float32)
-    rc = lib().msm_ms_hill_climb(_p(X), n, d, _p(Z), S, float(kappa), int(iters), _p(ws), need, _stream())
-    check(rc, "msm_ms_hill_climb")
+    fn = lib().msm_ms_hill_climb_split if precision == "f32_split" else lib().msm_ms_hill_climb
+    rc = fn(_p(X), n, d, _p(Z), S, float(kappa), int(iters), _p(ws), need, _stream())
+    check(rc, "msm_ms_hill_climb_split" if precision == "f32_split" else "msm_ms_hill_climb")
     return Z
 
 
