@@ -57,7 +57,7 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 11   /* 11: mean-shift hill climb with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split); 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
+#define MSM_ABI_VERSION 11   /* 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split); 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
 int msm_abi_version(void);
 
 /* Kernel-selection overrides for tools/ and tests/ (NOT read on the product path: every option defaults to
@@ -126,6 +126,12 @@ int msm_groupnorm_stats_f32(const float* x, double* stats, int stats_cleared, in
 int msm_groupnorm_apply_f32(const float* x, const double* stats, const float* gamma, const float* beta,
                             const float* up, int uh, int uw, int64_t up_batch_stride, float* y,
                             int B, int H, int W, int C, int groups, float eps, int relu, void* stream);
+
+/* The same result written as THREE bf16 planes, v = h + m + l exactly (planes + t * B*H*W*C elements, t = 0, 1, 2, each
+ * [B][H*W][C]): the activation operand of msm_conv3x3_c64_split, split once by its producer. */
+int msm_groupnorm_apply_split(const float* x, const double* stats, const float* gamma, const float* beta,
+                              const float* up, int uh, int uw, int64_t up_batch_stride, uint16_t* planes,
+                              int B, int H, int W, int C, int groups, float eps, int relu, void* stream);
 
 /* y [B][C][HW] (NCHW planes) = GN(x [B][HW][C]) * gamma + beta (relu when relu != 0), stats from msm_groupnorm_stats_f32 /
  * msm_conv3x3_c64_f32: the 64-channel activation the folded mask step contracts with (msm_mask_logits_fwd).
@@ -533,6 +539,11 @@ int msm_conv3x3_c64_f32(const float* in, const float* w_tap_major, float* out, d
  * activations as hi + lo bf16 operands, v_mfma_f32_16x16x32_bf16 with fp32 accumulation; moments from the fp32 results. */
 int msm_conv3x3_c64_bf16(const float* in, const float* w_tap_major, float* out, double* stats,
                          int stats_cleared, int B, int H, int W, void* stream);
+/* The same convolution with fp32-accurate results on the bf16 matrix pipe (f32_split plan): the activation as the three bf16
+ * planes of msm_groupnorm_apply_split, the weight (fp32, tap-major) split when a workgroup copies its 32 output channels
+ * into LDS, six bf16 MFMAs per product.  out / stats as msm_conv3x3_c64_f32. */
+int msm_conv3x3_c64_split(const uint16_t* planes, const float* w_tap_major, float* out, double* stats,
+                          int stats_cleared, int B, int H, int W, void* stream);
 
 /* The same kernel with a planar result: out [B][Cout][H*W] (NCHW) = bias + conv3x3(in), Cout a multiple of 64 (every slice of
  * 64 output channels has its own workgroups and its own 147 KB of the [Cout][9*64] weight in LDS), W % 4 == 0

@@ -992,6 +992,34 @@ def test_conv3x3_c64_bf16_mode(B, H, W):
     torch.testing.assert_close(st.cpu(), mom, rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 12, 16), (1, 5, 37), (3, 30, 40), (8, 120, 160)])
+def test_conv3x3_c64_split_form(B, H, W):
+    """f32_split: GroupNorm written as three bf16 planes (exact: h + m + l == the fp32 result bit for bit) and the 3x3
+    convolution as six bf16 MFMAs per product (msm_groupnorm_apply_split + msm_conv3x3_c64_split): against the fp64
+    convolution the error is bounded by 1.5x the fp32 MFMA kernel's, at ragged widths and at the headline size."""
+    x, w = rnd(B, H * W, 64, seed=1), rnd(64, 64, 3, 3, seed=2, scale=0.06)
+    g, be = 1 + 0.1 * rnd(64, seed=3), rnd(64, seed=4)
+    up = rnd(B, (H // 2) * (W // 2), 64, seed=5) if H % 2 == 0 and W % 2 == 0 else None
+    kw = dict(up=up.to(DEV), up_hw=(H // 2, W // 2)) if up is not None else {}
+    y32 = ops().groupnorm_tokens(x.to(DEV), g.to(DEV), be.to(DEV), H, W, **kw)
+    planes = ops().groupnorm_tokens(x.to(DEV), g.to(DEV), be.to(DEV), H, W, split_planes=True, **kw)
+    assert planes.shape == (3, B, H * W, 64) and planes.dtype == torch.bfloat16
+    assert torch.equal((planes[0].float() + planes[1].float()) + planes[2].float(), y32)
+    ref = F.conv2d(y32.cpu().double().view(B, H, W, 64).permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1).reshape(B, H * W, 64)
+    w3 = w.permute(0, 2, 3, 1).reshape(64, 576).contiguous().to(DEV)
+    o32, st32 = ops().conv3x3_c64(y32, w3, H, W)
+    osp, stsp = ops().conv3x3_c64(planes, w3, H, W, split=True)
+    e32, esp = float((o32.cpu().double() - ref).abs().max()), float((osp.cpu().double() - ref).abs().max())
+    print(f"conv3x3 {B}x{H}x{W}: max |err| vs float64  fp32 MFMA {e32:.2e}  split {esp:.2e}")
+    assert esp <= 1.5 * e32 + 1e-7
+    mom = torch.stack([osp.double().sum(1), (osp.double() ** 2).sum(1)], -1).cpu()
+    torch.testing.assert_close(stsp.cpu(), mom, rtol=1e-5, atol=1e-4)
+    st0 = torch.ones(B, 64, 2, device=DEV, dtype=torch.float64)
+    o2, st2 = ops().conv3x3_c64(planes, w3, H, W, split=True, stats=st0, stats_cleared=True)
+    assert torch.equal(o2, osp)
+    torch.testing.assert_close(st2.cpu(), mom + 1.0, rtol=1e-5, atol=1e-4)
+
+
 def test_kv_project_multi_equals_single_launches():
     """msm_kv_project_multi_f32: nine jobs (three levels x three layers, NCHW and token-major inputs) in one launch are
     bit-identical to nine msm_kv_project_f32 launches."""

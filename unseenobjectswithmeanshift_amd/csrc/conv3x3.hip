@@ -200,9 +200,227 @@ __global__ __launch_bounds__(C3_W * 64) void conv3x3_c64_kernel(const float* __r
     }
 }
 
+// ---- fp32 results on the bf16 matrix pipe (msm_conv3x3_c64_split) ---------------------------------------------------
+// Both operands as exact three-term bf16 splits, six v_mfma_f32_16x16x32_bf16 per product (small terms in their own accumulator).
+//   * the activation arrives already split (three bf16 planes written by msm_groupnorm_apply_split): a tap's B operand is three
+//     16-byte loads per 32 channels and no vector work -- splitting inside this kernel would repeat it for each of the nine taps
+//     and would bound the kernel by the vector pipe instead of the matrix pipe;
+//   * the three weight planes of all 64 output channels (3 x 73 KiB) do not fit the LDS: a workgroup holds 32 output channels
+//     (blockIdx.z), split once while it copies them in;
+//   * per tap and 32-channel half: 2 row blocks x 6 terms = 12 MFMAs on 12 weight fragments (ds_read_b128) and 3 activation
+//     fragments; the next tap's six loads ride on the current tap's 24 MFMAs.
+constexpr int C3S_N = 32;                // output channels per workgroup
+constexpr int C3S_W = 8;                 // waves per workgroup (two per SIMD: a wave keeps two input rows + a shifted copy in registers)
+
+// src shifted by one lane inside each row of 16 lanes (towards higher lanes: SHR, lane lj takes lane lj - 1); the lane without a
+// source keeps `old` (bound_ctrl off): that is where the halo pixel goes
+template <bool SHR>
+__device__ __forceinline__ bf16x8 shift_pixels(const bf16x8& src, const bf16x8& old) {
+    const u32x4b s = __builtin_bit_cast(u32x4b, src), o = __builtin_bit_cast(u32x4b, old);
+    u32x4b r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (unsigned)__builtin_amdgcn_update_dpp((int)o[i], (int)s[i], SHR ? 0x111 : 0x101, 0xf, 0xf, false);
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+// The nine taps of a 16-pixel tile read three input rows; the three taps of a row differ by one pixel, i.e. by one lane of the
+// B operand.  A row is loaded ONCE (six 16-byte loads per lane + the two halo pixels x0 - 1 / x0 + 16 by the lanes of pixel 0 /
+// 15) and the dx = -1 / +1 operands are lane shifts of it (v_mov_b32 row_shr / row_shl, 24 per tap): a third of the L2 -> CU
+// traffic of one load per tap -- at 6 bytes per element that traffic, not the matrix pipe, bounded the per-tap form (119 us).
+__global__ __launch_bounds__(C3S_W * 64) void conv3x3_c64_split_kernel(const uint16_t* __restrict__ planes, int64_t plane_stride,
+                                                                       const float* __restrict__ w, float* __restrict__ out,
+                                                                       double* __restrict__ stats, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [3][32][C3_LDB] bf16, then the moment scratch [C3S_W][32][2]
+    unsigned short* wlb = reinterpret_cast<unsigned short*>(wl);
+    constexpr int PL = C3S_N * C3_LDB;                            // elements per weight plane
+    float* msc = wl + 3 * PL / 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    const int b = blockIdx.y;
+    const int o0 = (int)blockIdx.z * C3S_N;
+    for (int i = tid; i < C3S_N * (C3_K / 4); i += C3S_W * 64) {
+        const int n = i / (C3_K / 4), c4 = i - n * (C3_K / 4);
+        const float4 wv = *reinterpret_cast<const float4*>(w + (int64_t)(o0 + n) * C3_K + c4 * 4);
+        const Split3 t3 = split3(wv.x, wv.y, wv.z, wv.w);
+        *reinterpret_cast<bf16x4*>(wlb + n * C3_LDB + c4 * 4) = t3.h;
+        *reinterpret_cast<bf16x4*>(wlb + PL + n * C3_LDB + c4 * 4) = t3.m;
+        *reinterpret_cast<bf16x4*>(wlb + 2 * PL + n * C3_LDB + c4 * 4) = t3.l;
+    }
+    __syncthreads();
+
+    const int xt = (W + 15) / 16;
+    const int units = xt * H;
+    const int slots = gridDim.x * C3S_W;
+    const int full_rounds = units / slots;
+    const int left = units - full_rounds * slots;
+    const int left_slot = (wave >> 2) * ((int)gridDim.x * 4) + (int)blockIdx.x * 4 + (wave & 3);
+    const int mine = full_rounds + (left_slot < left ? 1 : 0);
+    const uint16_t* ib = planes + (int64_t)b * H * W * C3_C;
+    float* ob = out + (int64_t)b * H * W * C3_C + o0;
+    float s[2][4], q[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[mt][r] = q[mt][r] = 0.f;
+    const unsigned short* wp = wlb + lj * C3_LDB + lq * 8;
+
+    struct Row {
+        bf16x8 f[2][3];        // [32-channel half][term h, m, l]
+    };
+    for (int it = 0; it < mine; ++it) {
+        const int u = (it < full_rounds) ? it * slots + (int)blockIdx.x * C3S_W + wave : full_rounds * slots + left_slot;
+        const int y = u / xt, x0 = (u - y * xt) * 16;
+        const int px = x0 + lj;
+        // centre pixels of input row y + dy (zeros outside the map) and, in lanes lj == 0 / lj == 15, the halo pixels x0 - 1 / x0 + 16
+        auto load_row = [&](int dy, Row& c, Row& halo) {
+            const int yy = y + dy;
+            const bool rok = yy >= 0 && yy < H;
+            const int yc = min(max(yy, 0), H - 1);
+            const u32x4b zero = {0u, 0u, 0u, 0u};
+            const bool ok = rok && px < W;
+            const uint16_t* p = ib + ((int64_t)yc * W + min(px, W - 1)) * C3_C + lq * 8;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int tm = 0; tm < 3; ++tm) {
+                    const u32x4b v = *reinterpret_cast<const u32x4b*>(p + tm * plane_stride + kh * 32);
+                    c.f[kh][tm] = __builtin_bit_cast(bf16x8, ok ? v : zero);
+                }
+            const int hx = lj == 0 ? x0 - 1 : x0 + 16;
+            const bool hok = rok && (lj == 0 || lj == 15) && hx >= 0 && hx < W;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int tm = 0; tm < 3; ++tm) halo.f[kh][tm] = __builtin_bit_cast(bf16x8, zero);
+            if (hok) {
+                const uint16_t* ph = ib + ((int64_t)yc * W + hx) * C3_C + lq * 8;
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                    for (int tm = 0; tm < 3; ++tm)
+                        halo.f[kh][tm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4b*>(ph + tm * plane_stride + kh * 32));
+            }
+        };
+        f32x4 lo[2], hi[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) lo[mt] = hi[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto mma_tap = [&](int t, const Row& x) {
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                bf16x8 a[2][3];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int tm = 0; tm < 3; ++tm)
+                        a[mt][tm] = *reinterpret_cast<const bf16x8*>(wp + tm * PL + mt * 16 * C3_LDB + t * C3_C + kh * 32);
+                // (weight term, activation term): l.h, h.l, m.m, m.h, h.m into lo; h.h into hi -- four independent chains
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) lo[mt] = mfma_bf16k32(a[mt][2], x.f[kh][0], lo[mt]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) hi[mt] = mfma_bf16k32(a[mt][0], x.f[kh][0], hi[mt]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) lo[mt] = mfma_bf16k32(a[mt][0], x.f[kh][2], lo[mt]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) lo[mt] = mfma_bf16k32(a[mt][1], x.f[kh][1], lo[mt]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) lo[mt] = mfma_bf16k32(a[mt][1], x.f[kh][0], lo[mt]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) lo[mt] = mfma_bf16k32(a[mt][0], x.f[kh][1], lo[mt]);
+            }
+        };
+        // the three taps of input row r (tap index 3 r + dx + 1)
+        auto mma_row = [&](int r, const Row& c, const Row& halo) {
+            Row sh;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int tm = 0; tm < 3; ++tm) sh.f[kh][tm] = shift_pixels<true>(c.f[kh][tm], halo.f[kh][tm]);
+            mma_tap(3 * r, sh);
+            mma_tap(3 * r + 1, c);
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int tm = 0; tm < 3; ++tm) sh.f[kh][tm] = shift_pixels<false>(c.f[kh][tm], halo.f[kh][tm]);
+            mma_tap(3 * r + 2, sh);
+        };
+        Row ca, ha, cb, hb;
+        load_row(-1, ca, ha);
+        load_row(0, cb, hb);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_row(0, ca, ha);
+        __builtin_amdgcn_sched_barrier(0);
+        load_row(1, ca, ha);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_row(1, cb, hb);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_row(2, ca, ha);
+        if (px < W) {
+            float* op = ob + ((int64_t)y * W + px) * C3_C + lq * 4;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const f32x4 acc = lo[mt] + hi[mt];
+                *reinterpret_cast<float4*>(op + mt * 16) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s[mt][r] += acc[r];
+                    q[mt][r] += acc[r] * acc[r];
+                }
+            }
+        }
+    }
+    if (stats) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s[mt][r] += __shfl_xor(s[mt][r], o, 64);
+                    q[mt][r] += __shfl_xor(q[mt][r], o, 64);
+                }
+            }
+        if (lj == 0) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ch = mt * 16 + lq * 4 + r;
+                    msc[(wave * C3S_N + ch) * 2 + 0] = s[mt][r];
+                    msc[(wave * C3S_N + ch) * 2 + 1] = q[mt][r];
+                }
+        }
+        __syncthreads();
+        if (tid < C3S_N * 2) {
+            double t = 0.0;
+            for (int wv = 0; wv < C3S_W; ++wv) t += (double)msc[wv * C3S_N * 2 + tid];
+            atomicAdd(stats + ((int64_t)b * C3_C + o0) * 2 + tid, t);
+        }
+    }
+}
+
 }  // namespace msm
 
 using namespace msm;
+
+extern "C" int msm_conv3x3_c64_split(const uint16_t* planes, const float* w_tap_major, float* out, double* stats, int stats_cleared, int B,
+                                     int H, int W, void* stream) {
+    MSM_REQUIRE(planes && w_tap_major && out, "msm_conv3x3_c64_split: null pointer");
+    MSM_REQUIRE(B > 0 && H > 0 && W > 0 && (int64_t)H * W * C3_C < ((int64_t)1 << 31), "msm_conv3x3_c64_split: bad sizes B=%d H=%d W=%d", B, H, W);
+    MSM_REQUIRE(((((uintptr_t)planes) | ((uintptr_t)w_tap_major) | ((uintptr_t)out)) & 15) == 0 && (((uintptr_t)stats) & 7) == 0,
+                "msm_conv3x3_c64_split: misaligned pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (stats && !stats_cleared) MSM_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * C3_C * (size_t)B, st));
+    const int units = cdiv(W, 16) * H;
+    int per_image = max(1, 256 / (2 * B));                  // two channel halves per image tile set, one workgroup per CU
+    per_image = min(per_image, cdiv(units, C3S_W));
+    const size_t lds = sizeof(unsigned short) * (size_t)3 * C3S_N * C3_LDB + sizeof(float) * (size_t)C3S_W * C3S_N * 2;
+    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_split_kernel, lds));
+    hipLaunchKernelGGL(conv3x3_c64_split_kernel, dim3(per_image, B, C3_C / C3S_N), dim3(C3S_W * 64), lds, st, planes,
+                       (int64_t)B * H * W * C3_C, w_tap_major, out, stats, H, W);
+    MSM_CHECK_LAUNCH("msm_conv3x3_c64_split");
+    return MSM_OK;
+}
 
 static int conv3x3_c64_launch(const float* in, const float* w_tap_major, float* out, double* stats, int stats_cleared, int B, int H, int W,
                               int bf, void* stream) {

@@ -9,6 +9,7 @@
 //
 // All of these are HBM-bound streaming kernels: one wave per row (LayerNorm) or one lane per
 // channel (GroupNorm) so that every global access is a full coalesced 256 B segment.
+#include "bf16.h"
 #include "common.h"
 
 namespace msm {
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ up, int uh, int uw, int64_t up_sb,
                                                        float* __restrict__ y, int H, int W, int C, int groups,
-                                                       float eps, int relu) {
+                                                       float eps, int relu, uint16_t* __restrict__ planes, int64_t plane_stride) {
     __shared__ float sc[256], sh[256], mn[256];
     const int b = blockIdx.y;
     const int HW = H * W;
@@ -185,7 +186,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
         if (relu) {
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
-        *reinterpret_cast<float4*>(yb + (int64_t)p * C + c) = v;
+        if (planes) {
+            // the result as three bf16 planes (v = h + m + l exactly): the operand of msm_conv3x3_c64_split, split once here
+            // instead of nine times (once per tap) in the consumer
+            const Split3 t3 = split3(v.x, v.y, v.z, v.w);
+            uint16_t* pb = planes + ((int64_t)b * HW + p) * C + c;
+            *reinterpret_cast<u32x2b*>(pb) = __builtin_bit_cast(u32x2b, t3.h);
+            *reinterpret_cast<u32x2b*>(pb + plane_stride) = __builtin_bit_cast(u32x2b, t3.m);
+            *reinterpret_cast<u32x2b*>(pb + 2 * plane_stride) = __builtin_bit_cast(u32x2b, t3.l);
+        } else {
+            *reinterpret_cast<float4*>(yb + (int64_t)p * C + c) = v;
+        }
     }
 }
 
@@ -386,22 +397,38 @@ extern "C" int msm_groupnorm_stats_f32(const float* x, double* stats, int stats_
     return MSM_OK;
 }
 
-extern "C" int msm_groupnorm_apply_f32(const float* x, const double* stats, const float* gamma, const float* beta,
+static int groupnorm_apply_impl(const char* who, const float* x, const double* stats, const float* gamma, const float* beta,
                                        const float* up, int uh, int uw, int64_t up_batch_stride, float* y, int B, int H, int W,
-                                       int C, int groups, float eps, int relu, void* stream) {
-    MSM_REQUIRE(x && stats && gamma && beta && y, "msm_groupnorm_apply_f32: null pointer");
-    MSM_REQUIRE(groups > 0 && C % groups == 0 && C % 4 == 0 && C <= 256, "msm_groupnorm_apply_f32: C=%d groups=%d", C, groups);
-    MSM_REQUIRE(((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)up)) & 15) == 0, "msm_groupnorm_apply_f32: pointers must be 16-byte aligned");
-    MSM_REQUIRE(!up || (uh > 0 && uw > 0), "msm_groupnorm_apply_f32: bad upsample source size");
+                                       int C, int groups, float eps, int relu, uint16_t* planes, void* stream) {
+    MSM_REQUIRE(x && stats && gamma && beta && (y || planes), "%s: null pointer", who);
+    MSM_REQUIRE(groups > 0 && C % groups == 0 && C % 4 == 0 && C <= 256, "%s: C=%d groups=%d", who, C, groups);
+    MSM_REQUIRE(((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)up)) & 15) == 0, "%s: pointers must be 16-byte aligned", who);
+    MSM_REQUIRE(!up || (uh > 0 && uw > 0), "%s: bad upsample source size", who);
     if (up_batch_stride == 0) up_batch_stride = (int64_t)uh * uw * C;
-    MSM_REQUIRE(!up || (up_batch_stride >= (int64_t)uh * uw * C && up_batch_stride % 4 == 0), "msm_groupnorm_apply_f32: bad upsample batch stride");
+    MSM_REQUIRE(!up || (up_batch_stride >= (int64_t)uh * uw * C && up_batch_stride % 4 == 0), "%s: bad upsample batch stride", who);
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = (int64_t)H * W * (C / 4);
     dim3 grid((unsigned)min((int64_t)1024, (total + 255) / 256), B), block(256);
     hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, st, x, stats, gamma, beta, up, uh, uw, up_batch_stride, y, H, W, C, groups, eps,
-                       relu);
-    MSM_CHECK_LAUNCH("msm_groupnorm_apply_f32");
+                       relu, planes, (int64_t)B * H * W * C);
+    MSM_CHECK_LAUNCH(who);
     return MSM_OK;
+}
+
+extern "C" int msm_groupnorm_apply_f32(const float* x, const double* stats, const float* gamma, const float* beta,
+                                       const float* up, int uh, int uw, int64_t up_batch_stride, float* y, int B, int H, int W,
+                                       int C, int groups, float eps, int relu, void* stream) {
+    MSM_REQUIRE(y, "msm_groupnorm_apply_f32: null pointer");
+    return groupnorm_apply_impl("msm_groupnorm_apply_f32", x, stats, gamma, beta, up, uh, uw, up_batch_stride, y, B, H, W, C, groups, eps, relu,
+                                nullptr, stream);
+}
+
+extern "C" int msm_groupnorm_apply_split(const float* x, const double* stats, const float* gamma, const float* beta,
+                                         const float* up, int uh, int uw, int64_t up_batch_stride, uint16_t* planes, int B, int H, int W,
+                                         int C, int groups, float eps, int relu, void* stream) {
+    MSM_REQUIRE(planes && (((uintptr_t)planes) & 15) == 0, "msm_groupnorm_apply_split: planes must be a 16-byte aligned pointer");
+    return groupnorm_apply_impl("msm_groupnorm_apply_split", x, stats, gamma, beta, up, uh, uw, up_batch_stride, nullptr, B, H, W, C, groups, eps,
+                                relu, planes, stream);
 }
 
 extern "C" int msm_groupnorm_apply_nchw_f32(const float* x, const double* stats, const float* gamma, const float* beta, float* y,

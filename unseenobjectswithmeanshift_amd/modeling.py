@@ -1038,20 +1038,23 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
         # one FPN level on the highest-resolution backbone feature (MSD:343-351)
         x = features[self.in_features[0]].float().contiguous()
         H, W = int(x.shape[2]), int(x.shape[3])
+        split3 = C == 64 and self.precision == "f32_split"       # the 3x3 convolution on the bf16 matrix pipe
         if C == 64 and x.shape[1] % 128 == 0 and x.shape[1] <= 384 and (H * W) % 4 == 0 and B * H * W >= 32 * 1024:
             # shallow-K input-projection kernel: the GroupNorm moments come out of its epilogue (no moments pass over lat)
             lat, lat_stats = ops.conv1x1_in(x, self._w_lateral(), None, stats=fpn_stats[0], stats_cleared=fpn_stats[0] is not None)
             y = ops.groupnorm_tokens(lat, self.adapter_1.norm.weight, self.adapter_1.norm.bias, H, W, groups=32,
-                                     up=up_tok, up_hw=up_hw, eps=self.adapter_1.norm.eps, stats=lat_stats, stats_ready=True)
+                                     up=up_tok, up_hw=up_hw, eps=self.adapter_1.norm.eps, stats=lat_stats, stats_ready=True,
+                                     split_planes=split3)
         else:
             lat = ops.conv1x1_nchw_to_tokens(x, self.adapter_1.weight.view(C, -1), None)
             y = ops.groupnorm_tokens(lat, self.adapter_1.norm.weight, self.adapter_1.norm.bias, H, W, groups=32,
-                                     up=up_tok, up_hw=up_hw, eps=self.adapter_1.norm.eps, stats=fpn_stats[0])
+                                     up=up_tok, up_hw=up_hw, eps=self.adapter_1.norm.eps, stats=fpn_stats[0], split_planes=split3)
         y_stats = None
         if C == 64:
-            # weight-stationary 3x3 kernel; the moments of layer_1's GroupNorm come out of its epilogue
+            # weight-stationary 3x3 kernel; the moments of layer_1's GroupNorm come out of its epilogue.  f32_split: the
+            # GroupNorm above wrote its result as three bf16 planes, the convolution multiplies exact three-term splits
             y, y_stats = ops.conv3x3_c64(y, self._w3(), H, W, stats=fpn_stats[1], stats_cleared=fpn_stats[1] is not None,
-                                         bf16=self.precision == "bf16")
+                                         bf16=self.precision == "bf16", split=split3)
         else:
             y = ops.conv3x3_tokens(y, self._w3(), H, W)
         wm = self.mask_features.weight.view(self.mask_dim, C)

@@ -223,24 +223,32 @@ def conv3x3_tokens(t, w_tap_major, H, W):
     return out
 
 
-def conv3x3_c64(t, w_tap_major, H, W, *, stats=None, stats_cleared=False, bf16=False):
+def conv3x3_c64(t, w_tap_major, H, W, *, stats=None, stats_cleared=False, bf16=False, split=False):
     """3x3 / pad 1 convolution of a 64-channel token map t (B, H*W, 64) to 64 channels, weight (64, 9*64) tap-major, with
     the GroupNorm moments of the result as a by-product: returns (out (B, H*W, 64), stats (B, 64, 2) float64).  ``stats``
     given: accumulated into when ``stats_cleared`` (the caller zeroed it), else zeroed first.  ``bf16``: the low-precision
-    mode (bf16 MFMA operands -- weight single, activations hi + lo --, fp32 accumulation and output)."""
-    _c(t, "t"), _c(w_tap_major, "w"), _c(stats, "stats", torch.float64)
-    B, HW, C = t.shape
+    mode (bf16 MFMA operands -- weight single, activations hi + lo --, fp32 accumulation and output).  ``split``: t is the
+    (3, B, H*W, 64) bf16 planes of groupnorm_tokens(split_planes=True); fp32-accurate results from six bf16 MFMAs per product."""
+    if split:
+        _c(t, "t", torch.bfloat16)
+        if t.dim() != 4 or t.shape[0] != 3:
+            raise RuntimeError("conv3x3_c64(split=True) needs the (3, B, H*W, 64) bf16 planes")
+        _, B, HW, C = t.shape
+    else:
+        _c(t, "t")
+        B, HW, C = t.shape
+    _c(w_tap_major, "w"), _c(stats, "stats", torch.float64)
     if C != 64 or tuple(w_tap_major.shape) != (64, 576) or HW != H * W:
         raise RuntimeError("conv3x3_c64 needs a (B, H*W, 64) map and a (64, 576) tap-major weight")
-    out = torch.empty_like(t)
+    out = torch.empty((B, HW, C), device=t.device, dtype=torch.float32)
     if stats is None:
         stats = torch.empty((B, 64, 2), device=t.device, dtype=torch.float64)
         stats_cleared = False
     elif tuple(stats.shape) != (B, 64, 2):
         raise RuntimeError("stats must be (B, 64, 2) float64")
-    fn = lib().msm_conv3x3_c64_bf16 if bf16 else lib().msm_conv3x3_c64_f32
-    rc = fn(_p(t), _p(w_tap_major), _p(out), _p(stats), 1 if stats_cleared else 0, B, H, W, _stream())
-    check(rc, "msm_conv3x3_c64_bf16" if bf16 else "msm_conv3x3_c64_f32")
+    name = "msm_conv3x3_c64_split" if split else ("msm_conv3x3_c64_bf16" if bf16 else "msm_conv3x3_c64_f32")
+    rc = getattr(lib(), name)(_p(t), _p(w_tap_major), _p(out), _p(stats), 1 if stats_cleared else 0, B, H, W, _stream())
+    check(rc, name)
     return out, stats
 
 
@@ -278,11 +286,13 @@ def layernorm(x, g1, b1, *, parts=None, bias=None, l2norm=False, g2=None, b2=Non
     return (y, y2) if g2 is not None else y
 
 
-def groupnorm_tokens(x, gamma, beta, H, W, groups=32, *, up=None, up_hw=None, relu=False, eps=1e-5, stats=None, stats_ready=False):
+def groupnorm_tokens(x, gamma, beta, H, W, groups=32, *, up=None, up_hw=None, relu=False, eps=1e-5, stats=None, stats_ready=False,
+                     split_planes=False):
     """GroupNorm over an NHWC token map x (B, H*W, C); optionally adds the bilinear upsample of `up` (B, uh*uw, C) -- dense
     or a token-range slice of a larger buffer (row stride C, any batch stride) -- and applies ReLU.  ``stats``: a zeroed
     (B, C, 2) float64 scratch to accumulate the moments in (saves the fill launch) -- or, with ``stats_ready``, the finished
-    moments of x (the producer of x accumulated them: no moments pass)."""
+    moments of x (the producer of x accumulated them: no moments pass).  ``split_planes``: the result as three bf16 planes
+    (3, B, H*W, C) with y = h + m + l exactly (the activation operand of conv3x3_c64(split=...)) instead of fp32."""
     _c(x, "x"), _c(gamma, "gamma"), _c(beta, "beta"), _chk(up, "up")
     B, HW, C = x.shape
     if stats_ready:
@@ -291,16 +301,16 @@ def groupnorm_tokens(x, gamma, beta, H, W, groups=32, *, up=None, up_hw=None, re
             raise RuntimeError("stats_ready needs stats (B, C, 2) float64")
     else:
         stats = groupnorm_stats(x, stats)
-    y = torch.empty_like(x)
+    y = torch.empty((3,) + tuple(x.shape), device=x.device, dtype=torch.bfloat16) if split_planes else torch.empty_like(x)
     uh, uw = (0, 0) if up is None else up_hw
     usb = 0
     if up is not None:
         if tuple(up.shape) != (B, uh * uw, C) or up.stride(2) != 1 or up.stride(1) != C or (B > 1 and up.stride(0) < uh * uw * C):
             raise RuntimeError("up must be (B, uh*uw, C) with strides (>= uh*uw*C, C, 1)")
         usb = up.stride(0) if B > 1 else 0
-    rc = lib().msm_groupnorm_apply_f32(_p(x), _p(stats), _p(gamma), _p(beta), _p(up), uh, uw, usb, _p(y),
-                                       B, H, W, C, groups, eps, 1 if relu else 0, _stream())
-    check(rc, "msm_groupnorm_apply_f32")
+    fn = lib().msm_groupnorm_apply_split if split_planes else lib().msm_groupnorm_apply_f32
+    rc = fn(_p(x), _p(stats), _p(gamma), _p(beta), _p(up), uh, uw, usb, _p(y), B, H, W, C, groups, eps, 1 if relu else 0, _stream())
+    check(rc, "msm_groupnorm_apply_split" if split_planes else "msm_groupnorm_apply_f32")
     return y
 
 
