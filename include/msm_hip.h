@@ -488,6 +488,12 @@ int msm_ms_relabel_largest_zero(int64_t* labels, int n, const int64_t* counts, i
  * scores_out [B][T] float, classes_out [B][T] int64, query_index_out [B][T] int32.  Q*K <= 4096. */
 int msm_topk_class_scores(const float* pred_logits, int B, int Q, int K1, int T,
                           float* scores_out, int64_t* classes_out, int32_t* query_index_out, void* stream);
+/* The same selection, and in the same launch the selected rows of a per-query matrix: gather_out [B][T][gather_cols] =
+ * gather_src [B][Q][gather_ld] rows query_index_out[b][t], leading gather_cols columns (the embeddings the final mask step keeps:
+ * replaces an index conversion + torch.gather pair of launches). */
+int msm_topk_class_scores_gather(const float* pred_logits, int B, int Q, int K1, int T,
+                          float* scores_out, int64_t* classes_out, int32_t* query_index_out, const float* gather_src, int64_t gather_ld, int gather_cols,
+                                 float* gather_out, void* stream);
 
 int64_t msm_instance_postprocess_workspace(int B, int T, int H, int W);
 int msm_instance_postprocess(const float* mask_logits, const int32_t* query_index,
@@ -520,12 +526,13 @@ int msm_conv1x1_in_multi_f32(int n_levels, const float* const* x, const float* c
  * interpolate(einsum(e, F), size, bilinear, align_corners=False) = einsum(e, interpolate(F)): the two act on different axes.
  * msm_pool_mask_taps: act [B][64][H][W] (the 64-channel factored mask features, NCHW planes) -> for each of n_levels target sizes
  *   th[l] x tw[l] (HOST arrays; H / th = W / tw in {2, 4, 8}) out[l] [B][th*tw][64] token-major = the bilinear reduction of act
- *   (mean of the four centre taps of every p x p cell).  One launch.
+ *   (mean of the four centre taps of every p x p cell).  One launch.  zero_buf (nullable): zero_count int32 words cleared by
+ *   the same launch (the row_any flags of the first msm_attn_mask_pooled call: no fill launch).
  * msm_attn_mask_pooled: attn [B][Q][T] bytes = (sum_c embed[b][q][c] pooled[b][t][c] + qbias[b][q]) < 0 for the 64-column embedding
  *   (row stride embed_ld floats, batch stride Q * embed_ld; qbias NULL or element stride qbias_ld) and row_any [B][Q] = 1 where a
  *   row keeps an unmasked key (zeroed here unless row_any_cleared != 0).  Q <= 112. */
 int msm_pool_mask_taps(const float* act, int B, int H, int W, int n_levels, const int32_t* th, const int32_t* tw,
-                       float* const* out, void* stream);
+                       float* const* out, int32_t* zero_buf, int64_t zero_count, void* stream);
 int msm_attn_mask_pooled(const float* embed, int64_t embed_ld, const float* qbias, int64_t qbias_ld, const float* pooled,
                          uint8_t* attn, int32_t* row_any, int row_any_cleared, int B, int Q, int T, void* stream);
 

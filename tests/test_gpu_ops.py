@@ -187,6 +187,11 @@ def test_attention_masks_at_key_resolution(B, Q, H, W):
     wd, fd = wide.to(DEV), f.to(DEV)
     sizes = [(H // p, W // p) for p in (8, 4, 2)]
     pooled = ops().pool_mask_taps(fd, sizes)
+    # the same launch clears a (B, Q) flag buffer when asked to (pre-filled here through the caching allocator's reuse)
+    torch.full((B, Q), 7, device=DEV, dtype=torch.int32)
+    pooled2, flags = ops().pool_mask_taps(fd, sizes, zero_rows=Q)
+    assert flags.shape == (B, Q) and flags.dtype == torch.int32 and int(flags.abs().sum()) == 0
+    assert all(torch.equal(a, b) for a, b in zip(pooled, pooled2))
     full = torch.einsum("bqc,bchw->bqhw", wide[..., :64].double(), f.double()) + wide[..., 64].double()[..., None, None]
     for (th, tw), ap in zip(sizes, pooled):
         assert ap.shape == (B, th * tw, 64)
@@ -684,6 +689,13 @@ def test_topk_and_postprocess():
     masks = rnd(B, Q, h, w, seed=2, scale=2.0)
     masks[0, 5] = -1.0                                  # an empty mask
     scores, classes, qidx = ops().topk_class_scores(logits.to(DEV), T)
+    # the gathering form: same selection, plus the kept rows of a per-query matrix (a column slice of a wider buffer)
+    wide = rnd(B, Q, 256, seed=9).to(DEV)
+    s2, c2, q2, sel = ops().topk_class_scores(logits.to(DEV), T, gather=wide, gather_cols=68)
+    assert torch.equal(s2, scores) and torch.equal(c2, classes) and torch.equal(q2, qidx)
+    assert torch.equal(sel, torch.gather(wide[..., :68], 1, qidx.long()[..., None].expand(-1, -1, 68)))
+    with pytest.raises(RuntimeError):
+        ops().topk_class_scores(logits.to(DEV), T, gather=wide[:, :, ::2], gather_cols=68)
     for b in range(B):
         ref = O.instance_inference(logits[b], masks[b], (Hh, Ww), topk=T)
         sc = torch.softmax(logits[b], -1)[:, :-1].flatten()

@@ -39,7 +39,7 @@ _SIGNATURES = {
     "msm_l2_normalize_nchw_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_fl, c_p]),
     "msm_msda_locations": (c_i, [c_f, c_f, c_f, c_p, c_f, c_f, c_l, c_i, c_i, c_i, c_p]),
     "msm_mask_logits_fwd": (c_i, [c_f, c_f, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_f, c_l, c_p]),
-    "msm_pool_mask_taps": (c_i, [c_f, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "msm_pool_mask_taps": (c_i, [c_f, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_l, c_p]),
     "msm_attn_mask_pooled": (c_i, [c_f, c_l, c_f, c_l, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "msm_pack_mask_features_bf16": (c_i, [c_f, c_p, c_i, c_i, c_i, c_p]),
     "msm_mask_logits_bf16_fwd": (c_i, [c_f, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_f, c_l, c_p]),
@@ -91,6 +91,7 @@ _SIGNATURES = {
     "msm_ms_connected_components": (c_i, [c_f, c_i, c_i, c_fl, c_p, c_p, c_p]),
     "msm_ms_relabel_largest_zero": (c_i, [c_p, c_i, c_p, c_i, c_p]),
     "msm_topk_class_scores": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),
+    "msm_topk_class_scores_gather": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_l, c_i, c_f, c_p]),
     "msm_conv1x1_in_f32": (c_i, [c_f, c_f, c_f, c_f, c_l, c_p, c_i, c_i, c_i, c_i, c_p]),
     "msm_conv1x1_in_multi_f32": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_l, c_p, c_i, c_i, c_p]),
     "msm_conv3x3_c64_f32": (c_i, [c_f, c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p]),

@@ -34,9 +34,15 @@ struct PoolLevels {
 };
 
 // out_l[b][ty*tw + tx][c] = mean of act[b][c][p*ty + p/2 - 1 .. + 1][p*tx + p/2 - 1 .. + 1].  grid (blocks of 16 targets, B, level)
-__global__ __launch_bounds__(256) void pool_taps_kernel(const float* __restrict__ act, PoolLevels lv, int H, int W) {
+__global__ __launch_bounds__(256) void pool_taps_kernel(const float* __restrict__ act, PoolLevels lv, int H, int W,
+                                                        int32_t* __restrict__ zero_buf, int64_t zero_count) {
     __shared__ __attribute__((aligned(16))) float tile[16][AM_C + 4];
     const int l = blockIdx.z, b = blockIdx.y;
+    if (zero_buf) {     // the row flags of the first attention-mask step, cleared here instead of by a fill launch
+        const int64_t nthreads = (int64_t)gridDim.x * gridDim.y * gridDim.z * 256;
+        for (int64_t i = (((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < zero_count; i += nthreads)
+            zero_buf[i] = 0;
+    }
     const int p = lv.pool[l], th = lv.th[l], tw = lv.tw[l], T = th * tw;
     const int t0 = blockIdx.x * 16;
     if (t0 >= T) return;                                   // the coarser levels have fewer blocks (uniform exit)
@@ -153,7 +159,8 @@ __global__ __launch_bounds__(256) void attn_mask_pooled_kernel(const float* __re
 using namespace msm;
 
 extern "C" int msm_pool_mask_taps(const float* act, int B, int H, int W, int n_levels, const int32_t* th, const int32_t* tw,
-                                  float* const* out, void* stream) {
+                                  float* const* out, int32_t* zero_buf, int64_t zero_count, void* stream) {
+    MSM_REQUIRE(!zero_buf || zero_count > 0, "msm_pool_mask_taps: zero_buf needs a positive count");
     MSM_REQUIRE(act && th && tw && out && n_levels >= 1 && n_levels <= AM_MAXL, "msm_pool_mask_taps: bad arguments (1..%d levels)", AM_MAXL);
     MSM_REQUIRE(B > 0 && H > 1 && W > 1, "msm_pool_mask_taps: bad sizes");
     PoolLevels lv;
@@ -172,7 +179,7 @@ extern "C" int msm_pool_mask_taps(const float* act, int B, int H, int W, int n_l
             lv.pool[l] = 2; lv.th[l] = lv.tw[l] = 0; lv.out[l] = nullptr;
         }
     }
-    hipLaunchKernelGGL(pool_taps_kernel, dim3(cdiv(maxT, 16), B, n_levels), dim3(256), 0, (hipStream_t)stream, act, lv, H, W);
+    hipLaunchKernelGGL(pool_taps_kernel, dim3(cdiv(maxT, 16), B, n_levels), dim3(256), 0, (hipStream_t)stream, act, lv, H, W, zero_buf, zero_count);
     MSM_CHECK_LAUNCH("msm_pool_mask_taps");
     return MSM_OK;
 }

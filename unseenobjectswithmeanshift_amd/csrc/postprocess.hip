@@ -15,8 +15,9 @@ namespace msm {
 
 __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ logits, int Q, int K1, int T,
                                                    float* __restrict__ scores_out, int64_t* __restrict__ classes_out,
-                                                   int32_t* __restrict__ qidx_out) {
-    extern __shared__ float sc[];  // Q*K scores
+                                                   int32_t* __restrict__ qidx_out, const float* __restrict__ gsrc, int64_t gld, int gcols,
+                                                   float* __restrict__ gout) {
+    extern __shared__ float sc[];  // Q*K scores, then T selected query indices
     const int b = blockIdx.x;
     const int K = K1 - 1, n = Q * K;
     const float* lg = logits + (int64_t)b * Q * K1;
@@ -43,7 +44,16 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ log
             scores_out[(int64_t)b * T + rank] = s;
             classes_out[(int64_t)b * T + rank] = (int64_t)(i % K);
             qidx_out[(int64_t)b * T + rank] = i / K;
+            if (gsrc) reinterpret_cast<int*>(sc + n)[rank] = i / K;
         }
+    }
+    if (!gsrc) return;
+    // the selected rows of the per-query matrix (uniform branch; every rank 0..T-1 was written exactly once above)
+    __syncthreads();
+    const int* sel = reinterpret_cast<const int*>(sc + n);
+    for (int i = threadIdx.x; i < T * gcols; i += 256) {
+        const int t = i / gcols, c = i - t * gcols;
+        gout[((int64_t)b * T + t) * gcols + c] = gsrc[((int64_t)b * Q + sel[t]) * gld + c];
     }
 }
 
@@ -284,16 +294,30 @@ __global__ void inst_finish_kernel(const InstAcc* __restrict__ acc, int parts, c
 
 using namespace msm;
 
-extern "C" int msm_topk_class_scores(const float* pred_logits, int B, int Q, int K1, int T, float* scores_out,
-                                     int64_t* classes_out, int32_t* query_index_out, void* stream) {
-    MSM_REQUIRE(pred_logits && scores_out && classes_out && query_index_out, "msm_topk_class_scores: null pointer");
-    MSM_REQUIRE(B > 0 && Q > 0 && K1 >= 2, "msm_topk_class_scores: bad sizes");
+static int topk_impl(const char* who, const float* pred_logits, int B, int Q, int K1, int T, float* scores_out, int64_t* classes_out,
+                     int32_t* query_index_out, const float* gather_src, int64_t gather_ld, int gather_cols, float* gather_out, void* stream) {
+    MSM_REQUIRE(pred_logits && scores_out && classes_out && query_index_out, "%s: null pointer", who);
+    MSM_REQUIRE(B > 0 && Q > 0 && K1 >= 2, "%s: bad sizes", who);
     const int n = Q * (K1 - 1);
-    MSM_REQUIRE(n <= 4096 && T > 0 && T <= n, "msm_topk_class_scores: need T <= Q*K <= 4096 (T=%d, Q*K=%d)", T, n);
-    hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(256), sizeof(float) * n, (hipStream_t)stream, pred_logits, Q, K1, T,
-                       scores_out, classes_out, query_index_out);
-    MSM_CHECK_LAUNCH("msm_topk_class_scores");
+    MSM_REQUIRE(n <= 4096 && T > 0 && T <= n, "%s: need T <= Q*K <= 4096 (T=%d, Q*K=%d)", who, T, n);
+    MSM_REQUIRE(!gather_src || (gather_out && gather_cols > 0 && gather_ld >= gather_cols), "%s: bad gather arguments", who);
+    hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(256), sizeof(float) * n + sizeof(int) * (gather_src ? T : 0), (hipStream_t)stream, pred_logits,
+                       Q, K1, T, scores_out, classes_out, query_index_out, gather_src, gather_ld, gather_cols, gather_out);
+    MSM_CHECK_LAUNCH(who);
     return MSM_OK;
+}
+
+extern "C" int msm_topk_class_scores(const float* pred_logits, int B, int Q, int K1, int T, float* scores_out, int64_t* classes_out,
+                                     int32_t* query_index_out, void* stream) {
+    return topk_impl("msm_topk_class_scores", pred_logits, B, Q, K1, T, scores_out, classes_out, query_index_out, nullptr, 0, 0, nullptr, stream);
+}
+
+extern "C" int msm_topk_class_scores_gather(const float* pred_logits, int B, int Q, int K1, int T, float* scores_out, int64_t* classes_out,
+                                            int32_t* query_index_out, const float* gather_src, int64_t gather_ld, int gather_cols,
+                                            float* gather_out, void* stream) {
+    MSM_REQUIRE(gather_src && gather_out, "msm_topk_class_scores_gather: null gather pointer");
+    return topk_impl("msm_topk_class_scores_gather", pred_logits, B, Q, K1, T, scores_out, classes_out, query_index_out, gather_src, gather_ld,
+                     gather_cols, gather_out, stream);
 }
 
 extern "C" int64_t msm_instance_postprocess_workspace(int B, int T, int H, int W) {

@@ -440,6 +440,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         mlp = [(pk["mlp"][j], l.bias) for j, l in enumerate(self.mask_embed.layers)]
         ncol = None
         pooled = {}
+        ra0 = None
         fm_params = None
         if isinstance(mask_features, FoldedMaskFeatures):
             fm_params = [t for t in (mask_features.weight, mask_features.bias) if t is not None]
@@ -451,7 +452,9 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                 # attention masks at key resolution: pool the activation once to every level size that is an integer reduction
                 want_sizes = self._poolable_sizes(mask_features, sizes)
                 if want_sizes and L > 0:
-                    pooled = dict(zip(want_sizes, ops.pool_mask_taps(mask_features, want_sizes)))
+                    # (the pooling launch also clears the row flags of prediction 0's attention-mask step)
+                    outs, ra0 = ops.pool_mask_taps(mask_features, want_sizes, zero_rows=int(out.shape[1]))
+                    pooled = dict(zip(want_sizes, outs))
         dn = self.decoder_norm
         pred_cls, pred_mask = [], []
 
@@ -463,9 +466,9 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             emb, qb = (e, None) if ncol is None else (e[..., :ncol], e[..., ncol])
             if last and not full and ncol is not None and 0 < self._final_topk < e.shape[1] and cls is not None:
                 # only the masks instance_inference keeps: top-K class scores first, then the mask step on those K embeddings
-                topk = ops.topk_class_scores(cls, int(self._final_topk))
-                idx = topk[2].long()[..., None].expand(-1, -1, ncol + 4)
-                sel = torch.gather(e[..., :ncol + 4], 1, idx)                      # (B, K, 68): [e Wm | e.bm | pad], rows 16-byte aligned
+                # (the top-K launch also copies the kept rows: (B, K, 68) = [e Wm | e.bm | pad], rows 16-byte aligned)
+                *topk, sel = ops.topk_class_scores(cls, int(self._final_topk), gather=e, gather_cols=ncol + 4)
+                topk = tuple(topk)
                 # (fp32 kernel in every precision mode: one launch on K queries does not pay for a packed copy of the activation)
                 m = ops.mask_logits(sel[..., :ncol], mask_features, want_mask=True, target_size=None, qbias=sel[..., ncol])[0]
                 pred_cls.append(cls)
@@ -504,7 +507,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                 _, d, e, q, _ = ops.dec_heads(out, dn.weight, dn.bias, mlp, want_out=False, want_d=False, zero_row_any=True, **next_query(0))
                 self._heads0_cache = hc = (hkey, d, e, q)
             _, d, e, q = hc
-            ra = None                                       # the mask step clears its own row flags
+            ra = ra0                                        # cleared by the pooling launch (None: the mask step clears its own)
         else:
             _, d, e, q, ra = ops.dec_heads(out, dn.weight, dn.bias, mlp, want_out=False, want_d=full or L == 0,
                                            zero_row_any=True, **next_query(0))

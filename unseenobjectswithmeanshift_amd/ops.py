@@ -429,10 +429,11 @@ def pack_mask_features_split(mask_features):
     return out
 
 
-def pool_mask_taps(act, sizes):
+def pool_mask_taps(act, sizes, zero_rows=0):
     """The 64-channel factored mask features act (B, 64, H, W) reduced bilinearly (align_corners=False) to each (th, tw) of
     ``sizes`` (H / th = W / tw in {2, 4, 8}: the mean of the four centre taps of every cell) -> list of token-major
-    (B, th*tw, 64) tensors.  One launch (csrc/attn_mask.hip)."""
+    (B, th*tw, 64) tensors.  One launch (csrc/attn_mask.hip).  ``zero_rows`` = Q > 0: the same launch also clears a (B, Q) int32
+    buffer (the row flags of the first attn_mask_pooled call), returned as a second result."""
     _c(act, "act")
     B, C, H, W = act.shape
     if C != 64 or not 1 <= len(sizes) <= 4:
@@ -442,10 +443,11 @@ def pool_mask_taps(act, sizes):
     ths = (ctypes.c_int32 * n)(*[int(s[0]) for s in sizes])
     tws = (ctypes.c_int32 * n)(*[int(s[1]) for s in sizes])
     ptrs = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    flags = torch.empty((B, int(zero_rows)), device=act.device, dtype=torch.int32) if zero_rows else None
     rc = lib().msm_pool_mask_taps(_p(act), B, H, W, n, ctypes.cast(ths, ctypes.c_void_p), ctypes.cast(tws, ctypes.c_void_p),
-                                  ctypes.cast(ptrs, ctypes.c_void_p), _stream())
+                                  ctypes.cast(ptrs, ctypes.c_void_p), _p(flags), B * int(zero_rows), _stream())
     check(rc, "msm_pool_mask_taps")
-    return outs
+    return (outs, flags) if zero_rows else outs
 
 
 def attn_mask_pooled(mask_embed, pooled, *, qbias=None, row_any=None):
@@ -903,16 +905,30 @@ def ms_relabel_largest_zero(labels, counts):
 # ----------------------------------------------------------------------------------------------
 # instance post-processing (pretrained_meanshiftformer_model.py:337-343, 461-497)
 # ----------------------------------------------------------------------------------------------
-def topk_class_scores(pred_logits, topk):
+def topk_class_scores(pred_logits, topk, gather=None, gather_cols=None):
+    """Top-K (query, class) pairs of softmax(pred_logits)[..., :-1] per image (PM:461-470): (scores (B,T), classes (B,T) int64,
+    query index (B,T) int32).  ``gather``: a (B, Q, >= gather_cols) per-query matrix with unit column stride; the selected rows'
+    leading ``gather_cols`` columns come back as a fourth result (B, T, gather_cols), copied by the same launch."""
     _c(pred_logits, "pred_logits")
     B, Q, K1 = pred_logits.shape
     dev = pred_logits.device
     scores = torch.empty((B, topk), device=dev, dtype=torch.float32)
     classes = torch.empty((B, topk), device=dev, dtype=torch.int64)
     qidx = torch.empty((B, topk), device=dev, dtype=torch.int32)
-    rc = lib().msm_topk_class_scores(_p(pred_logits), B, Q, K1, topk, _p(scores), _p(classes), _p(qidx), _stream())
-    check(rc, "msm_topk_class_scores")
-    return scores, classes, qidx
+    if gather is None:
+        rc = lib().msm_topk_class_scores(_p(pred_logits), B, Q, K1, topk, _p(scores), _p(classes), _p(qidx), _stream())
+        check(rc, "msm_topk_class_scores")
+        return scores, classes, qidx
+    _chk(gather, "gather")
+    cols = int(gather_cols)
+    if gather.dim() != 3 or gather.shape[0] != B or gather.shape[1] != Q or gather.shape[2] < cols or gather.stride(2) != 1 \
+            or (B > 1 and gather.stride(0) != Q * gather.stride(1)):
+        raise RuntimeError("gather must be (B, Q, >= gather_cols) with unit column stride and uniformly spaced rows")
+    sel = torch.empty((B, topk, cols), device=dev, dtype=torch.float32)
+    rc = lib().msm_topk_class_scores_gather(_p(pred_logits), B, Q, K1, topk, _p(scores), _p(classes), _p(qidx), _p(gather),
+                                            gather.stride(1), cols, _p(sel), _stream())
+    check(rc, "msm_topk_class_scores_gather")
+    return scores, classes, qidx, sel
 
 
 def instance_postprocess(mask_logits, query_index, image_size, class_scores=None, padded_size=None):
