@@ -82,6 +82,7 @@ enum {
     MSM_OPT_ATTN_FUSED_KV,      /* reserved (no effect) */
     MSM_OPT_KV_PIPE,            /* msm_kv_project_multi_bf16: 0 = fp32 MFMAs with only the store rounded (default: bf16 MFMAs) */
     MSM_OPT_MASK_KERNEL,        /* fp32 mask step: 5 = never the 4-query block on the 4x4x1 MFMA (fallback kernel) */
+    MSM_OPT_MS_SPLIT_KERNEL,    /* msm_ms_hill_climb_split: 1 = X split inside the iteration kernel (fallback of the pre-split planes) */
     MSM_OPT_COUNT
 };
 int msm_set_option(int key, int value);
@@ -452,10 +453,12 @@ int msm_ms_select_seeds(const float* X, int n, int d, int num_seeds, int64_t fir
 int64_t msm_ms_hill_climb_workspace(int n, int S);
 int msm_ms_hill_climb(const float* X, int n, int d, float* Z, int S, float kappa, int iters,
                       float* workspace, int64_t workspace_elems, void* stream);
-/* The same iteration (same arguments, same workspace) with every fp32 product carried out as six bf16 MFMAs on exact
- * three-term splits of both operands (X, Z and the exp() weights): fp32-accurate results -- the error against float64 is not
- * larger than the fp32 MFMA kernel's -- at 0.375 of its matrix time.  Opt-in (the host passes precision="f32_split"); Z must be
- * 16-byte aligned as well. */
+/* The same iteration with every fp32 product carried out as six bf16 MFMAs on exact three-term splits of both operands (X,
+ * Z and the exp() weights): fp32-accurate results -- the error against float64 stays within 1.5x of the fp32 MFMA kernel's --
+ * at 0.375 of its matrix time.  X is split once per call into three bf16 planes kept in the workspace (6 bytes per element),
+ * which is therefore larger: msm_ms_hill_climb_split_workspace floats, 16-byte aligned like X and Z.  Opt-in (the host passes
+ * precision="f32_split"). */
+int64_t msm_ms_hill_climb_split_workspace(int n, int S);
 int msm_ms_hill_climb_split(const float* X, int n, int d, float* Z, int S, float kappa, int iters,
                             float* workspace, int64_t workspace_elems, void* stream);
 /* closest = first argmin_s 0.5*(1 - X.Z_s); labels_out[i] = seed_labels[closest] (int64);

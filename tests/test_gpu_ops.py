@@ -664,7 +664,7 @@ def _hill_f64(X, Z, kappa, iters):
 
 
 @pytest.mark.parametrize("n,S,iters", [(2000, 20, 10), (37, 1, 3), (4111, 50, 4), (5000, 300, 3), (19200, 100, 10), (31, 17, 2)])
-def test_mean_shift_hill_climb_split(n, S, iters):
+def test_mean_shift_hill_climb_split(n, S, iters, lib_option):
     """fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split): against float64 the error is bounded by 1.5x the
     fp32 MFMA kernel's on the same inputs (ragged n, one seed, seed counts around the block and chunk sizes)."""
     from unseenobjectswithmeanshift_amd import synthetic as syn
@@ -678,6 +678,11 @@ def test_mean_shift_hill_climb_split(n, S, iters):
     print(f"hill climb n={n} S={S}: max |err| vs float64  fp32 MFMA {e32:.2e}  split {esp:.2e}")
     assert esp <= max(1.5 * e32, 2e-7)
     close(zsp.float(), ref.float(), rtol=1e-4, atol=1e-5)
+    # the fallback kernel (X split inside the iteration kernel instead of the pre-split planes) multiplies the same terms in the
+    # same order: bitwise the same seeds
+    lib_option("MS_SPLIT_KERNEL", 1)
+    zfb = ops().ms_hill_climb(X.to(DEV), seeds.to(DEV), 20.0, iters, precision="f32_split").cpu().double()
+    assert torch.equal(zfb, zsp)
     with pytest.raises(ValueError):
         ops().ms_hill_climb(X.to(DEV), seeds.to(DEV), 20.0, 1, precision="bf16")
 

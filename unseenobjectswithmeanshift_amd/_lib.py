@@ -86,6 +86,7 @@ _SIGNATURES = {
     "msm_ms_select_seeds": (c_i, [c_f, c_i, c_i, c_i, c_l, c_f, c_p, c_f, c_l, c_i, c_p]),
     "msm_ms_hill_climb_workspace": (c_l, [c_i, c_i]),
     "msm_ms_hill_climb": (c_i, [c_f, c_i, c_i, c_f, c_i, c_fl, c_i, c_f, c_l, c_p]),
+    "msm_ms_hill_climb_split_workspace": (c_l, [c_i, c_i]),
     "msm_ms_hill_climb_split": (c_i, [c_f, c_i, c_i, c_f, c_i, c_fl, c_i, c_f, c_l, c_p]),
     "msm_ms_assign": (c_i, [c_f, c_i, c_i, c_f, c_i, c_p, c_p, c_p, c_i, c_p]),
     "msm_ms_connected_components": (c_i, [c_f, c_i, c_i, c_fl, c_p, c_p, c_p]),
@@ -138,7 +139,8 @@ def lib():
 
 # kernel-selection overrides of include/msm_hip.h (enum order), for tools/ and tests/ only
 OPTIONS = ("MASK_NC", "MASKB_TARGET", "GEMM_TILE", "GEMM_SHALLOW", "ATTN_TARGET", "ATTN_KERNEL", "ATTN_QK_MAX", "ATTN_QKCFG",
-           "CONVIN_NT", "POST_GENERIC", "ENC_NO_COOP", "MSDA_GENERIC", "MS_CHUNK", "MS_NO_PERSISTENT", "ATTN_FUSED_KV", "KV_PIPE", "MASK_KERNEL")
+           "CONVIN_NT", "POST_GENERIC", "ENC_NO_COOP", "MSDA_GENERIC", "MS_CHUNK", "MS_NO_PERSISTENT", "ATTN_FUSED_KV", "KV_PIPE", "MASK_KERNEL",
+           "MS_SPLIT_KERNEL")
 OPT_AUTO = -1
 
 

@@ -628,6 +628,212 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int i = tid; i < zrows * MS_D; i += 512) dst[i] = accum[i];
 }
 
+// ---- the split form with X split ONCE per call (default of msm_ms_hill_climb_split) -------------------------------------------
+// ms_hill_split_kernel above is bound by vector issue: 2/3 of its non-matrix instructions split X, and X does not change over
+// the iterations.  Here a pre-pass writes X as three bf16 planes (ms_split_planes_kernel, 6 bytes per element instead of 4
+// read per iteration) and the iteration kernel touches X with no vector instruction at all:
+//   * a slab's three 32 x 64 bf16 planes (12 KiB) travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4), double-buffered per
+//     wave pair, the 16-byte chunks XOR-swizzled through the SOURCE address (chunk c of row r sits at slot c ^ (r & 7): the
+//     b128 reads of 8 rows hit 8 different slots);
+//   * score A operands are ds_read_b128 of a row's 8 channels; the W X B operands (8 POINTS of one channel per lane) come from
+//     the same row-major tile through ds_read_b64_tr_b16, which hands lane c of a 16-lane group column c of the 4 x 16 block the
+//     group's lanes address (lane i: row i / 4, elements 4 (i % 4) .. + 3);
+//   * what is left on the vector pipe is exp() and the split of the weights: ~90 instructions per 48 MFMAs.
+// The two waves of a pair share the tile, so a slab costs one workgroup barrier (the waves of a workgroup run in lockstep).
+constexpr int HP_PLANE = HS_ROWS * MS_D * 2;       // bytes of one plane of a slab tile
+constexpr int HP_TILE = 3 * HP_PLANE;
+
+__global__ __launch_bounds__(256) void ms_split_planes_kernel(const float* __restrict__ X, int n, int n_pad, uint16_t* __restrict__ planes) {
+    const int64_t total4 = (int64_t)n_pad * (MS_D / 4), ps = (int64_t)n_pad * MS_D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = (i < (int64_t)n * (MS_D / 4)) ? *reinterpret_cast<const float4*>(X + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const Split3 t = split3(v.x, v.y, v.z, v.w);
+        *reinterpret_cast<u32x2b*>(planes + i * 4) = __builtin_bit_cast(u32x2b, t.h);
+        *reinterpret_cast<u32x2b*>(planes + ps + i * 4) = __builtin_bit_cast(u32x2b, t.m);
+        *reinterpret_cast<u32x2b*>(planes + 2 * ps + i * 4) = __builtin_bit_cast(u32x2b, t.l);
+    }
+}
+
+// lane l's 16 bytes at sbase + voff(l) land at LDS byte address lds_dst + 16 l (see enc_block.hip: glds16)
+__device__ __forceinline__ void ms_glds16(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+typedef short v4i16_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x4 lds_read_tr16(const char* p) {
+    const v4i16_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4i16_t __attribute__((address_space(3)))*)(uintptr_t)(unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p);
+    return __builtin_bit_cast(bf16x4, r);
+}
+
+template <int NSBW>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void ms_hill_planes_kernel(const uint16_t* __restrict__ Xp, int64_t plane_stride,
+                                                                                                           int n, const float* __restrict__ Z, int S,
+                                                                                                           int nsb, float kappa, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int zrows = nsb * 16;
+    uint16_t* zp = reinterpret_cast<uint16_t*>(lds);                               // [3][zrows][ZP_LD] bf16 terms of Z
+    char* tiles = reinterpret_cast<char*>(lds) + (size_t)3 * zrows * ZP_LD * 2;    // [4 pairs][2 buffers][HP_TILE]
+    float* accum = lds;                                                            // [zrows][64] after the loop
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    for (int i = tid; i < zrows * (MS_D / 4); i += 512) {
+        const int s = i / (MS_D / 4), c4 = (i - s * (MS_D / 4)) * 4;
+        const float4 v = (s < S) ? *reinterpret_cast<const float4*>(Z + (int64_t)s * MS_D + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const Split3 t = split3(v.x, v.y, v.z, v.w);
+        *reinterpret_cast<u32x2b*>(zp + (0 * zrows + s) * ZP_LD + c4) = __builtin_bit_cast(u32x2b, t.h);
+        *reinterpret_cast<u32x2b*>(zp + (1 * zrows + s) * ZP_LD + c4) = __builtin_bit_cast(u32x2b, t.m);
+        *reinterpret_cast<u32x2b*>(zp + (2 * zrows + s) * ZP_LD + c4) = __builtin_bit_cast(u32x2b, t.l);
+    }
+    const int pg = wave & 3, sh = wave >> 2, sb0 = sh * NSBW;
+    const int nb = min(NSBW, nsb - sb0);
+    char* tile0 = tiles + pg * 2 * HP_TILE;
+    const unsigned tile_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)tile0;
+
+    f32x4 zn[NSBW][4];
+#pragma unroll
+    for (int sb = 0; sb < NSBW; ++sb)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) zn[sb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const float kl2 = kappa * 1.4426950408889634f;
+    const int nslabs = (n + HS_ROWS - 1) / HS_ROWS;
+    const int stride = (int)gridDim.x * 4;
+    const int iters = (nslabs - (int)blockIdx.x * 4 + stride - 1) / stride;      // of the workgroup's first pair: the others run as many
+    // DMA piece I = 0..11 of a tile: plane I / 4, rows 8 (I % 4) .. + 7; lane L writes slot L of the piece = row L / 8, position L % 8,
+    // which holds chunk (L % 8) ^ (row & 7) of that row
+    const unsigned dma_off = (unsigned)((lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) * 16));
+    auto issue = [&](int sl, int buf) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int I = sh * 6 + k, plane = I >> 2, quarter = I & 3;
+            const char* sbase = reinterpret_cast<const char*>(Xp + (int64_t)plane * plane_stride + ((int64_t)sl * HS_ROWS + quarter * 8) * MS_D);
+            ms_glds16(sbase, dma_off, tile_lds + (unsigned)(buf * HP_TILE + plane * HP_PLANE + quarter * 1024));
+        }
+    };
+    // per-lane byte offsets into a plane of the tile
+    unsigned a_off[2], b_off[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) a_off[h] = (unsigned)((lj * 8 + ((h * 4 + lq) ^ (lj & 7))) * 16);            // row lj (+16 q), channels 32 h + 8 lq ..
+    {
+        const int row = 4 * lq + (lj >> 2);                                                                  // (+16 for the second half of k)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) b_off[db] = (unsigned)((row * 8 + ((db * 2 + ((lj & 3) >> 1)) ^ (row & 7))) * 16 + (lj & 1) * 8);
+    }
+    const int sl0 = (int)blockIdx.x * 4 + pg;
+    if (sl0 < nslabs) issue(sl0, 0);
+    for (int it = 0; it < iters; ++it) {
+        const int sl = sl0 + it * stride, buf = it & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();          // the tile has landed (both waves' pieces); every wave is done with the other buffer (and, it = 0, Z is staged)
+        if (sl + stride < nslabs) issue(sl + stride, buf ^ 1);
+        if (sl < nslabs) {
+            const int p0 = sl * HS_ROWS;
+            const char* T = tile0 + buf * HP_TILE;
+            Split3x8 xa[2][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const char* src = T + a_off[h] + q * 2048;
+                    xa[q][h].h = *reinterpret_cast<const bf16x8*>(src);
+                    xa[q][h].m = *reinterpret_cast<const bf16x8*>(src + HP_PLANE);
+                    xa[q][h].l = *reinterpret_cast<const bf16x8*>(src + 2 * HP_PLANE);
+                }
+            Split3x8 xb[4];
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const char* src = T + b_off[db];
+                xb[db].h = cat8(lds_read_tr16(src), lds_read_tr16(src + 2048));
+                xb[db].m = cat8(lds_read_tr16(src + HP_PLANE), lds_read_tr16(src + HP_PLANE + 2048));
+                xb[db].l = cat8(lds_read_tr16(src + 2 * HP_PLANE), lds_read_tr16(src + 2 * HP_PLANE + 2048));
+            }
+            const bool tail = p0 + HS_ROWS > n;
+            f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, sbv = sa;
+            auto score = [&](int sb, f32x4& oa, f32x4& ob) {
+                bf16x8 zf[2][3];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+                        zf[h][t] = *reinterpret_cast<const bf16x8*>(zp + (t * zrows + (sb0 + sb) * 16 + lj) * ZP_LD + h * 32 + lq * 8);
+                f32x4 alo = f32x4{0.f, 0.f, 0.f, 0.f}, ahi = alo, blo = alo, bhi = alo;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    alo = mfma_k32(xa[0][h].l, zf[h][0], alo);
+                    blo = mfma_k32(xa[1][h].l, zf[h][0], blo);
+                    ahi = mfma_k32(xa[0][h].h, zf[h][0], ahi);
+                    bhi = mfma_k32(xa[1][h].h, zf[h][0], bhi);
+                    alo = mfma_k32(xa[0][h].h, zf[h][2], alo);
+                    blo = mfma_k32(xa[1][h].h, zf[h][2], blo);
+                    alo = mfma_k32(xa[0][h].m, zf[h][1], alo);
+                    blo = mfma_k32(xa[1][h].m, zf[h][1], blo);
+                    alo = mfma_k32(xa[0][h].m, zf[h][0], alo);
+                    blo = mfma_k32(xa[1][h].m, zf[h][0], blo);
+                    alo = mfma_k32(xa[0][h].h, zf[h][1], alo);
+                    blo = mfma_k32(xa[1][h].h, zf[h][1], blo);
+                }
+                oa = alo + ahi;
+                ob = blo + bhi;
+            };
+            if (nb > 0) score(0, sa, sbv);
+#pragma unroll
+            for (int sb = 0; sb < NSBW; ++sb) {
+                if (sb < nb) {
+                    const f32x4 ca = sa, cb = sbv;
+                    if (sb + 1 < NSBW && sb + 1 < nb) score(sb + 1, sa, sbv);
+                    float w[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        w[r] = __builtin_amdgcn_exp2f(kl2 * ca[r]);
+                        w[4 + r] = __builtin_amdgcn_exp2f(kl2 * cb[r]);
+                    }
+                    if (tail) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (p0 + lq * 4 + r >= n) w[r] = 0.f;
+                            if (p0 + 16 + lq * 4 + r >= n) w[4 + r] = 0.f;
+                        }
+                    }
+                    const Split3x8 w3 = join(split3(w[0], w[1], w[2], w[3]), split3(w[4], w[5], w[6], w[7]));
+#pragma unroll
+                    for (int db = 0; db < 4; ++db) zn[sb][db] = mfma_k32(w3.l, xb[db].h, zn[sb][db]);
+#pragma unroll
+                    for (int db = 0; db < 4; ++db) zn[sb][db] = mfma_k32(w3.h, xb[db].l, zn[sb][db]);
+#pragma unroll
+                    for (int db = 0; db < 4; ++db) zn[sb][db] = mfma_k32(w3.m, xb[db].m, zn[sb][db]);
+#pragma unroll
+                    for (int db = 0; db < 4; ++db) zn[sb][db] = mfma_k32(w3.m, xb[db].h, zn[sb][db]);
+#pragma unroll
+                    for (int db = 0; db < 4; ++db) zn[sb][db] = mfma_k32(w3.h, xb[db].m, zn[sb][db]);
+#pragma unroll
+                    for (int db = 0; db < 4; ++db) zn[sb][db] = mfma_k32(w3.h, xb[db].h, zn[sb][db]);
+                }
+            }
+        }
+    }
+    __syncthreads();   // every wave is done reading the Z planes
+    for (int i = tid; i < zrows * MS_D; i += 512) accum[i] = 0.f;
+    __syncthreads();
+    for (int g = 0; g < 4; ++g) {
+        if (pg == g) {
+#pragma unroll
+            for (int sb = 0; sb < NSBW; ++sb)
+                if (sb < nb) {
+#pragma unroll
+                    for (int db = 0; db < 4; ++db)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) accum[((sb0 + sb) * 16 + lq * 4 + r) * MS_D + db * 16 + lj] += zn[sb][db][r];
+                }
+        }
+        __syncthreads();
+    }
+    float* dst = part + (int64_t)blockIdx.x * (zrows * MS_D);
+    for (int i = tid; i < zrows * MS_D; i += 512) dst[i] = accum[i];
+}
+
 // Z[s] = normalize(sum_wg part[wg][s])  (MS:103 F.normalize).  16 waves per seed: wave w adds its fixed slice of
 // the workgroup partials (8 loads in flight), then the slices are added in wave order -- deterministic.
 __global__ __launch_bounds__(1024) void ms_hill_finish_kernel(const float* __restrict__ part, int nwg, int rows_padded,
@@ -939,39 +1145,72 @@ static int hill_split_launch(const float* X, int n, const float* Zc, int Sc, int
     return MSM_OK;
 }
 
+template <int NSBW>
+static int hill_planes_launch(const uint16_t* Xp, int64_t plane_stride, int n, const float* Zc, int Sc, int nb, float kappa, float* ws, int G,
+                              hipStream_t st) {
+    const size_t lds = (size_t)3 * nb * 16 * ZP_LD * sizeof(uint16_t) + (size_t)4 * 2 * HP_TILE;
+    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)ms_hill_planes_kernel<NSBW>, lds));
+    hipLaunchKernelGGL((ms_hill_planes_kernel<NSBW>), dim3(G), dim3(512), lds, st, Xp, plane_stride, n, Zc, Sc, nb, kappa, ws);
+    return MSM_OK;
+}
+
+// partial sums of the workgroups (as msm_ms_hill_climb) + the three bf16 planes of X, rows padded to whole 32-point slabs
+extern "C" int64_t msm_ms_hill_climb_split_workspace(int n, int S) {
+    const int64_t n_pad = (int64_t)cdiv(n, HS_ROWS) * HS_ROWS;
+    return msm_ms_hill_climb_workspace(n, S) + 3 * n_pad * MS_D / 2 + 4;
+}
+
 extern "C" int msm_ms_hill_climb_split(const float* X, int n, int d, float* Z, int S, float kappa, int iters, float* workspace,
                                        int64_t workspace_elems, void* stream) {
     MSM_REQUIRE(X && Z && workspace, "msm_ms_hill_climb_split: null pointer");
     MSM_REQUIRE(d == MS_D, "msm_ms_hill_climb_split: d=%d, only d=64 is supported", d);
     MSM_REQUIRE(n > 0 && S > 0 && S <= MS_SB * 16 && iters >= 0, "msm_ms_hill_climb_split: bad sizes (S <= %d)", MS_SB * 16);
-    MSM_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)Z) & 15) == 0, "msm_ms_hill_climb_split: X and Z must be 16-byte aligned");
-    if (workspace_elems < msm_ms_hill_climb_workspace(n, S)) {
+    MSM_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)Z) & 15) == 0 && (((uintptr_t)workspace) & 15) == 0,
+                "msm_ms_hill_climb_split: X, Z and workspace must be 16-byte aligned");
+    if (workspace_elems < msm_ms_hill_climb_split_workspace(n, S)) {
         set_error("msm_ms_hill_climb_split: workspace too small");
         return MSM_E_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
     // one 512-thread workgroup per CU, four 32-point slabs in flight per workgroup (never more workgroups than hill_wgs(n):
-    // the workspace is sized for those)
-    const int G = max(1, min(256, cdiv(cdiv(n, HS_ROWS), 4)));
+    // the partial-sum region is sized for those)
+    const int nslabs = cdiv(n, HS_ROWS);
+    const int G = max(1, min(256, cdiv(nslabs, 4)));
     const int nsb = cdiv(S, 16);
     const int CH = hill_chunk(nsb);
+    const bool planes = opt(MSM_OPT_MS_SPLIT_KERNEL) != 1;         // 1: X split inside the iteration kernel (fallback, no pre-pass)
+    const int64_t n_pad = (int64_t)nslabs * HS_ROWS;
+    uint16_t* Xp = reinterpret_cast<uint16_t*>(workspace);
+    float* parts = workspace + (3 * n_pad * MS_D / 2 + 3) / 4 * 4;
+    if (planes && iters > 0)
+        hipLaunchKernelGGL(ms_split_planes_kernel, dim3((unsigned)min((int64_t)2048, (n_pad * (MS_D / 4) + 255) / 256)), dim3(256), 0, st, X, n,
+                           (int)n_pad, Xp);
     for (int it = 0; it < iters; ++it) {
-        float* ws = workspace;
+        float* ws = parts;
         for (int b0 = 0; b0 < nsb; b0 += CH) {
             const int nb = min(CH, nsb - b0);
             const float* Zc = Z + (int64_t)b0 * 16 * MS_D;
             const int Sc = min(S - b0 * 16, nb * 16);
             int rc = MSM_OK;
-            switch ((nb + 1) / 2) {
-                case 1: rc = hill_split_launch<1>(X, n, Zc, Sc, nb, kappa, ws, G, st); break;
-                case 2: rc = hill_split_launch<2>(X, n, Zc, Sc, nb, kappa, ws, G, st); break;
-                case 3: rc = hill_split_launch<3>(X, n, Zc, Sc, nb, kappa, ws, G, st); break;
-                default: rc = hill_split_launch<4>(X, n, Zc, Sc, nb, kappa, ws, G, st); break;
+            if (planes) {
+                switch ((nb + 1) / 2) {
+                    case 1: rc = hill_planes_launch<1>(Xp, n_pad * MS_D, n, Zc, Sc, nb, kappa, ws, G, st); break;
+                    case 2: rc = hill_planes_launch<2>(Xp, n_pad * MS_D, n, Zc, Sc, nb, kappa, ws, G, st); break;
+                    case 3: rc = hill_planes_launch<3>(Xp, n_pad * MS_D, n, Zc, Sc, nb, kappa, ws, G, st); break;
+                    default: rc = hill_planes_launch<4>(Xp, n_pad * MS_D, n, Zc, Sc, nb, kappa, ws, G, st); break;
+                }
+            } else {
+                switch ((nb + 1) / 2) {
+                    case 1: rc = hill_split_launch<1>(X, n, Zc, Sc, nb, kappa, ws, G, st); break;
+                    case 2: rc = hill_split_launch<2>(X, n, Zc, Sc, nb, kappa, ws, G, st); break;
+                    case 3: rc = hill_split_launch<3>(X, n, Zc, Sc, nb, kappa, ws, G, st); break;
+                    default: rc = hill_split_launch<4>(X, n, Zc, Sc, nb, kappa, ws, G, st); break;
+                }
             }
             if (rc != MSM_OK) return rc;
             ws += (int64_t)G * nb * 16 * MS_D;
         }
-        ws = workspace;
+        ws = parts;
         for (int b0 = 0; b0 < nsb; b0 += CH) {
             const int nb = min(CH, nsb - b0);
             const int Sc = min(S - b0 * 16, nb * 16);

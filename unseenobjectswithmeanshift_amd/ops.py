@@ -865,7 +865,7 @@ def ms_hill_climb(X, Z, kappa, iters, precision="f32"):
     n, d = X.shape
     S = Z.shape[0]
     Z = Z.clone()
-    need = lib().msm_ms_hill_climb_workspace(n, S)
+    need = (lib().msm_ms_hill_climb_split_workspace if precision == "f32_split" else lib().msm_ms_hill_climb_workspace)(n, S)
     ws = torch.empty((need,), device=X.device, dtype=torch.float32)
     fn = lib().msm_ms_hill_climb_split if precision == "f32_split" else lib().msm_ms_hill_climb
     rc = fn(_p(X), n, d, _p(Z), S, float(kappa), int(iters), _p(ws), need, _stream())
