@@ -33,6 +33,17 @@ def test_argument_errors_are_reported_without_a_gpu():
                                1, 100, 250, 120, 160, 0, 0, 0, 0, None, 0, None)
     assert rc == -1 and b"multiple of 32" in L.msm_last_error_string()
     assert L.msm_hypersphere_attn_workspace(8, 100, 4800, 8) > 0
+    # the f32_split hill climb keeps X as three bf16 planes in its workspace: 96 floats per (padded) row more than the fp32 form
+    n, S = 307200, 100
+    assert L.msm_ms_hill_climb_split_workspace(n, S) == L.msm_ms_hill_climb_workspace(n, S) + 96 * n + 4
+    assert L.msm_ms_hill_climb_split_workspace(33, 1) == L.msm_ms_hill_climb_workspace(33, 1) + 96 * 64 + 4
+    rc = L.msm_ms_hill_climb_split(ctypes.c_void_p(16), 100, 64, ctypes.c_void_p(16), 5, 20.0, 1, ctypes.c_void_p(16), 8, None)
+    assert rc == -3 and b"workspace too small" in L.msm_last_error_string()
+    rc = L.msm_conv3x3_c64_split(None, ctypes.c_void_p(16), ctypes.c_void_p(16), None, 0, 1, 4, 4, None)
+    assert rc == -1 and b"null pointer" in L.msm_last_error_string()
+    rc = L.msm_topk_class_scores_gather(ctypes.c_void_p(16), 1, 10, 3, 4, ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16),
+                                        ctypes.c_void_p(16), 2, 4, ctypes.c_void_p(16), None)
+    assert rc == -1 and b"bad gather arguments" in L.msm_last_error_string()
 
 
 def test_ops_refuse_cpu_tensors():
@@ -41,6 +52,10 @@ def test_ops_refuse_cpu_tensors():
         ops.gemm(torch.zeros(4, 32), torch.zeros(8, 32))
     with pytest.raises(RuntimeError, match="GPU"):
         ops.mask_logits(torch.zeros(1, 4, 32), torch.zeros(1, 32, 4, 4))
+    with pytest.raises(ValueError, match="precision"):
+        ops.ms_hill_climb(torch.zeros(8, 64), torch.zeros(2, 64), 20.0, 1, precision="bf16")
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.ms_hill_climb(torch.zeros(8, 64), torch.zeros(2, 64), 20.0, 1, precision="f32_split")
 
 
 def test_state_dict_layout_matches_reference():
