@@ -26,9 +26,10 @@ namespace msm {
 
 constexpr int C3_C = 64;                 // channels in and out
 constexpr int C3_K = 9 * C3_C;           // 576
-constexpr int C3_LD = C3_K + 4;          // LDS row stride (floats): 145 float4, odd -> 16 rows hit 16 different 16-byte banks
+constexpr int C3_LD = C3_K + 8;          // LDS row stride (floats): 146 slots of 16 B.  ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... over 16 slots:
+                                         // with lane = (row lj, slot offset lq) a stride = 2 (mod 4) slots is conflict-free (an odd stride, 145, is 2-way)
 constexpr int C3_W = 16;                 // waves per workgroup (the weight takes 145 KiB: one workgroup per CU)
-constexpr int C3_LDB = C3_K + 8;         // LDS row stride of the bf16 weight copy (bf16 elements): 73 x 16 bytes, odd
+constexpr int C3_LDB = C3_K + 16;        // LDS row stride of the bf16 weight copies (bf16 elements): 74 slots of 16 B (see C3_LD)
 
 // NCHW = false: token-major output [B][HW][64] (+ moments).  NCHW = true: output [B][Cout][HW] for Cout = 64 * gridDim.z, each
 // z slice of workgroups holding its own 64 rows of the weight; the MFMA operands are swapped (rows = pixels) so that a
