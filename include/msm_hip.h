@@ -57,7 +57,7 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 11   /* 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
+#define MSM_ABI_VERSION 12   /* 12: head-major bf16 activations between the encoder kernels of the bf16 plan (msm_encoder_block_hm_fwd, msm_msdeform_attn_enc_lp_fwd, msm_f32_to_f16); 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
 int msm_abi_version(void);
 
 /* Kernel-selection overrides for tools/ and tests/ (NOT read on the product path: every option defaults to
@@ -572,12 +572,14 @@ int msm_conv3x3_c64_nchw_f32(const float* in, const float* w_tap_major, const fl
  *   proj  = [offsets|weights](src + pos)    proj_out [B][S][proj_width], pos [S][64]
  *   wstream: value_proj weight (64,64) then the (proj_width,64) weight, as consecutive 16-row blocks of 1024 floats,
  *   zero-padded to msm_encoder_prologue_stream_floats(proj_width); small = [value_proj bias (64) | proj bias].
- * n_levels <= 4, S >= 86, proj_width a multiple of 16 and <= 512 (the weights are held in LDS). */
+ * n_levels <= 4, S >= 86, proj_width a multiple of 16 and <= 512 (the weights are held in LDS).
+ * out_bf16_hm != 0 (8 heads, proj_width 288): value_out / proj_out are the bf16 plan's head-major fp16 tensors [B][8][S][8] and
+ * [B][8][S][36] (see msm_encoder_block_hm_fwd) instead of fp32. */
 int64_t msm_encoder_prologue_stream_floats(int proj_width);
 int msm_encoder_prologue_fwd(const float* raw, const double* stats, const float* gn_params, const int32_t* level_starts,
                              int n_levels, int groups, float gn_eps, const float* wstream, const float* small,
-                             const float* pos, float* src_out, float* value_out, float* proj_out, int B, int S,
-                             int proj_width, int value_heads, void* stream);
+                             const float* pos, float* src_out, void* value_out, void* proj_out, int B, int S,
+                             int proj_width, int value_heads, int out_bf16_hm, void* stream);
 
 /* The fp32 encoder-layer tail on the bf16 matrix pipe (csrc/enc_block_split.hip): every fp32 operand is split exactly into three
  * bf16 terms and a product is the six bf16 MFMAs of weight >= 2^-18 with fp32 accumulation -- fp32-accurate results (the
@@ -600,6 +602,46 @@ int64_t msm_encoder_block_lp_stream_bytes(int d_ffn, int proj_width);
 int msm_encoder_block_lp_fwd(const float* attn, const float* src, const void* wstream, const float* small, const float* pos,
                              float* src_out, float* value_out, float* proj_out, int M, int tokens_per_image, int d_ffn,
                              int proj_width, int value_heads, float eps, void* stream);
+
+/* ---- the bf16 plan's encoder layers with head-major bf16 activations between the kernels (csrc/enc_lp.hip) ----------------
+ * Replaces, per layer, MSDeformAttn.forward (ops/modules/ms_deform_attn.py:95-125) + the rest of
+ * MSDeformAttnTransformerEncoderLayer.forward (pixel_decoder/msdeformattn.py:116-131) when the model runs in the low-precision
+ * mode (BASELINE configs[2] / configs[4]).  All three 16-bit tensors are IEEE half (fp16, not bf16: same bytes, three more mantissa bits; bf16 offsets cost 1 % of
+ * the final mask bits): value_hm / attn_hm [B][8 heads][S][8 dims]; proj_hm [B][8][S][36] = per (image, head, query) the head's 24
+ * sampling offsets ((level, point, xy) order) and 12 attention logits.  The matrix pipe multiplies bf16 operands (an fp16 value
+ * is a hi + lo bf16 pair exactly); the residual stream stays fp32.
+ *
+ * msm_encoder_block_hm_fwd: src_out = LN2(x + linear2(relu(linear1(x)))), x = LN1(src + output_proj(attn));
+ *   value_out / proj_out (both null for the last layer) = the NEXT layer's value_proj(src_out) and
+ *   [sampling_offsets | attention_weights](src_out + pos).
+ *   wstream (msm_encoder_block_hm_stream_bytes(d_ffn, with_next) bytes of bf16 bit patterns): 1-KiB blocks in the A-operand
+ *   order of v_mfma_f32_16x16x32_bf16 ([kq = 4][row = 16][8 bf16] = lane kq*16 + row): resident 32 KiB = output_proj
+ *   [rb 4][G 2][h, l] (k natural: attn feature 32 G + 8 kq + j) | value_proj [rb 4][G 2][h, l] (row 16 rb + 4 lq + r = head
+ *   4 (rb >> 1) + lq, dim 4 (rb & 1) + r; k order L: feature (2 G + (j >> 2)) 16 + 4 kq + (j & 3)); then per pair P of 16-wide
+ *   hidden blocks 8 KiB = W1 [q 2][G 2] (rows hidden 16 (2 P + q) + i, k order L) | W2 [ob 4] (rows feature 16 ob + i, k = hidden
+ *   (2 P + (j >> 2)) 16 + 4 kq + (j & 3)); four pairs per 32-KiB stage, the hidden dimension zero-padded to whole stages; then
+ *   (with_next) three stages of eight projection row blocks [rb][G 2][h, l] (rows in (head, 36) order, k order L), zero padded.
+ *   small (msm_encoder_block_hm_small_floats(d_ffn) floats) = output_proj bias | norm1 w | norm1 b | linear2 bias | norm2 w |
+ *   norm2 b | value_proj bias (row order above) | projection bias (288, (head, 36) order) | linear1 bias (zero padded).
+ *   M = B * tokens_per_image tokens; pos [tokens_per_image][64]. */
+int64_t msm_encoder_block_hm_stream_bytes(int d_ffn, int with_next);
+int msm_encoder_block_hm_small_floats(int d_ffn);
+int msm_encoder_block_hm_fwd(const void* attn_hm, const float* src, const void* wstream, const float* small, const float* pos,
+                             float* src_out, void* value_out, void* proj_out, int M, int tokens_per_image, int d_ffn, float eps,
+                             void* stream);
+/* msm_msdeform_attn_enc_lp_fwd: out_hm = MSDeformAttn core (ms_deform_im2col_cuda.cuh:242-304) over the fp16 value_hm with the
+ *   sampling offsets / attention logits of proj_hm (encoder self-attention: reference points = pixel centres,
+ *   msdeformattn.py:141-153; softmax over the 12 logits, ms_deform_attn.py:102-109).  Shipped geometry only: M = 8, D = 8, L = 3, P = 4.
+ * msm_msdeform_attn_enc_lp_fused_fwd: the same with the projection computed in the kernel from src + pos (measured slower than
+ *   the stored projection; kept as the tested alternative).  wpack: per head 12 KiB = [rb 3][G 2][h, l] blocks (k order L)
+ *   of the head's 24 offset rows, 12 logit rows and 12 zero rows; bpack [M][48] their biases (fp32). */
+int msm_msdeform_attn_enc_lp_fwd(const void* value_hm, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                 const void* proj_hm, void* out_hm, int B, int S, int M, int D, int L, int P, void* stream);
+int msm_msdeform_attn_enc_lp_fused_fwd(const void* value_hm, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                       const float* src, const float* pos, const void* wpack, const float* bpack, void* out_hm, int B,
+                                       int S, int M, int D, int L, int P, void* stream);
+/* fp32 -> fp16, round to nearest even, clamped to the half range; n a multiple of 8 */
+int msm_f32_to_f16(const float* in, void* out, int64_t n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Label-image statistics of the two-stage harness: one pass instead of the reference's per-label

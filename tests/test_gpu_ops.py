@@ -868,6 +868,91 @@ def test_encoder_block_split_is_fp32_accurate(B, S, want_next):
         assert vo is None and po is None
 
 
+@pytest.mark.parametrize("B,S,want_next", [(2, 394, True), (1, 6300, True), (3, 100, False), (8, 6300, True), (1, 70000, True)])
+def test_encoder_block_hm(B, S, want_next):
+    """msm_encoder_block_hm_fwd (bf16 plan, head-major fp16 attn in / value + sampling projection out, one 16-wave workgroup per
+    CU): against the chain in float64 on the operands as the kernel rounds them (attn is fp16 data; linear1 weight, linear2
+    weight and hidden activation single bf16; everything else hi + lo = exact to 2^-17), and loosely against the exact fp32
+    chain.  (1, 70000): more tiles than 256 workgroups x 16 waves -- the grid grows past one workgroup per CU."""
+    C, DF, PW = 64, 1024, 288
+    attn, src, pos = rnd(B, S, C, seed=1).to(torch.float16).float(), rnd(B, S, C, seed=2), rnd(S, C, seed=3)
+    wo, bo = rnd(C, C, seed=4, scale=C ** -0.5), rnd(C, seed=5, scale=0.1)
+    w1, b1 = rnd(DF, C, seed=6, scale=C ** -0.5), rnd(DF, seed=7, scale=0.1)
+    w2, b2 = rnd(C, DF, seed=8, scale=DF ** -0.5), rnd(C, seed=9, scale=0.1)
+    g1, be1, g2, be2 = 1 + 0.1 * rnd(C, seed=10), rnd(C, seed=11, scale=0.1), 1 + 0.1 * rnd(C, seed=12), rnd(C, seed=13, scale=0.1)
+    wv, bv = rnd(C, C, seed=14, scale=C ** -0.5), rnd(C, seed=15, scale=0.1)
+    wp, bp = rnd(PW, C, seed=16, scale=C ** -0.5), rnd(PW, seed=17)
+    r = lambda t: t.to(torch.bfloat16).double()
+    lin = lambda t, w, b_: F.linear(r(t.float()), r(w), b_.double())
+    lin1 = lambda t, w, b_: F.linear(t.double(), r(w), b_.double())
+    linx = lambda t, w, b_: F.linear(t.double(), w.double(), b_.double())
+    x = F.layer_norm(src.double() + linx(attn, wo, bo), (C,), g1.double(), be1.double()).float()
+    y = F.layer_norm(x.double() + lin(F.relu(lin1(x, w1, b1)).float(), w2, b2), (C,), g2.double(), be2.double()).float()
+    y32 = F.layer_norm(src + F.linear(attn, wo, bo), (C,), g1, be1)
+    y32 = F.layer_norm(y32 + F.linear(F.relu(F.linear(y32, w1, b1)), w2, b2), (C,), g2, be2)
+    d = lambda t: t.to(DEV).contiguous()
+    nxt = (d(wv), d(wp)) if want_next else (None, None)
+    stream = ops().pack_encoder_block_hm(d(wo), d(w1), d(w2), *nxt)
+    small = ops().pack_encoder_block_hm_small(*[d(t) for t in (bo, g1, be1, b1, b2, g2, be2)], *((d(bv), d(bp)) if want_next else (None, None)))
+    attn_hm = d(attn.view(B, S, 8, 8).permute(0, 2, 1, 3).to(torch.float16))
+    so, vh, ph = ops().encoder_block_hm(attn_hm, d(src), stream, small, DF, pos=d(pos), want_next=want_next)
+    err = (so.cpu() - y).abs()
+    assert float(err.max()) < 1e-2 and float((err > 2e-3).float().mean()) < 1e-4 and float(err.mean()) < 1e-4
+    assert float((so.cpu() - y32).abs().max()) < 0.1 and float((so.cpu() - y32).abs().mean()) < 5e-3
+    if want_next:
+        assert vh.shape == (B, 8, S, 8) and vh.dtype == torch.float16 and ph.shape == (B, 8, S, 36) and ph.dtype == torch.float16
+        yk = so.cpu()                                          # the kernel's own layer output feeds its projections
+        got = vh.float().cpu().permute(0, 2, 1, 3).reshape(B, S, C)
+        close(got, linx(yk, wv, bv).float(), rtol=2 ** -10, atol=2e-4)         # one fp16 rounding of an fp32-class result
+        pref = ops().proj_to_head_major_f16(d(linx(yk + pos, wp, bp).float())).float().cpu()
+        close(ph.float().cpu(), pref, rtol=2 ** -10, atol=2e-4)                # (a value on a rounding boundary may round the other way)
+        assert float((ph.float().cpu() - pref).abs().mean()) < 1e-4
+    else:
+        assert vh is None and ph is None
+    with pytest.raises(RuntimeError):
+        ops().encoder_block_hm(attn_hm.float(), d(src), stream, small, DF, pos=d(pos), want_next=want_next)
+    with pytest.raises(RuntimeError):
+        ops().encoder_block_hm(attn_hm, d(src), stream, small, DF, pos=d(pos), want_next=not want_next)      # stream / plan mismatch
+
+
+@pytest.mark.parametrize("B,shp", [(2, [(6, 8), (12, 16), (24, 32)]), (8, [(15, 20), (30, 40), (60, 80)]), (1, [(2, 3), (4, 6), (8, 12)])])
+def test_msda_encoder_lp(B, shp):
+    """The bf16 plan's gathers (fp16 value taps, fp16 result; sampling projection read as head-major fp16 records, or computed in
+    the kernel from src + pos) against the fp32 pair they replace -- F.linear for [sampling_offsets | attention_weights](src + pos),
+    msm_msdeform_attn_enc_hm_fwd on the same (bf16-valued) value."""
+    M, D, L, P = 8, 8, 3, 4
+    S = sum(h * w for h, w in shp)
+    shapes = torch.tensor(shp, dtype=torch.int64)
+    start = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+    value = rnd(B, M, S, D, seed=1).to(torch.float16)
+    src, pos = rnd(B, S, 64, seed=2), rnd(S, 64, seed=3)
+    wp, bp = rnd(288, 64, seed=4, scale=0.05), rnd(288, seed=5)
+    wp[:192] *= 4.0                                              # offsets of a few pixels
+    d = lambda t: t.to(DEV).contiguous()
+    proj = F.linear((src + pos).double(), wp.double(), bp.double()).float()
+    # stored projection: the reference sees the fp16-rounded offsets / logits the kernel reads -> only the result's rounding is left
+    proj_hm = ops().proj_to_head_major_f16(d(proj))
+    assert proj_hm.shape == (B, M, S, 36)
+    pr = proj_hm.float().cpu()                                   # back to the reference's column order
+    proj_r = torch.cat([pr[..., :24].permute(0, 2, 1, 3).reshape(B, S, 192), pr[..., 24:].permute(0, 2, 1, 3).reshape(B, S, 96)], -1)
+    ref = ops().ms_deform_attn_encoder(d(value.float()), d(shapes), d(start), d(proj_r), M, P)      # (B, S, 64)
+    ref_hm = ref.view(B, S, M, D).permute(0, 2, 1, 3).cpu()
+    got = ops().ms_deform_attn_encoder_lp(d(value), d(shapes), d(start), proj_hm, P)
+    assert got.shape == (B, M, S, D) and got.dtype == torch.float16
+    close(got.float().cpu(), ref_hm, rtol=2 ** -10, atol=2e-5)
+    # projection in the kernel: hi + lo split of the projection (2^-17) and the rounding of the result
+    wpack, bpack = ops().pack_msda_proj_lp(d(wp), d(bp))
+    got = ops().ms_deform_attn_encoder_lp_fused(d(value), d(shapes), d(start), d(src), d(pos), wpack, bpack, P)
+    ref = ops().ms_deform_attn_encoder(d(value.float()), d(shapes), d(start), d(proj), M, P)
+    ref_hm = ref.view(B, S, M, D).permute(0, 2, 1, 3).cpu()
+    err = (got.float().cpu() - ref_hm).abs()
+    assert float(err.max()) < 5e-3 and float(err.mean()) < 3e-4, (float(err.max()), float(err.mean()))
+    # fp32 -> fp16 conversion entry point (clamped to the half range)
+    t = rnd(3, 8, 50, 8, seed=9)
+    t[0, 0, 0, 0], t[0, 0, 0, 1] = 1e6, -1e6
+    assert torch.equal(ops().to_f16(d(t)).cpu(), t.clamp(-65504, 65504).to(torch.float16))
+
+
 def test_pixel_decoder_fused_equals_unfused():
     from unseenobjectswithmeanshift_amd import synthetic as syn
     from unseenobjectswithmeanshift_amd.meta_arch import build_resnet50_head
@@ -950,6 +1035,10 @@ def test_encoder_prologue_vs_fp64():
         if heads:
             value = value.permute(0, 2, 1, 3).reshape(B, S, 64)
         closed(value, val_ref, rtol=5e-5, atol=5e-5)
+    # the bf16 plan's outputs: the same fp32 results rounded once, in the head-major layouts of csrc/enc_lp.hip
+    src, value, proj = o.encoder_prologue(raw.clone().to(DEV), st, gnp, bounds, stream, small, pos.to(DEV), pw, value_heads=8)
+    s2, v2, p2 = o.encoder_prologue(raw.clone().to(DEV), st, gnp, bounds, stream, small, pos.to(DEV), pw, value_heads=8, bf16_hm=True)
+    assert torch.equal(s2, src) and torch.equal(v2, value.to(torch.float16)) and torch.equal(p2, o.proj_to_head_major_f16(proj))
     with pytest.raises(RuntimeError):
         o.encoder_prologue(raw.to(DEV), st, gnp, [0, 12, 60, S + 1], stream, small, pos.to(DEV), pw)
 

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmsm_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "msm_hip.h")
 
 _lib = None
-ABI_VERSION = 11     # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
+ABI_VERSION = 12     # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
 
 c_f = ctypes.c_void_p      # float* (device)
 c_p = ctypes.c_void_p
@@ -68,6 +68,12 @@ _SIGNATURES = {
     "msm_encoder_block_split_fwd": (c_i, [c_f, c_f, c_p, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_p]),
     "msm_encoder_block_lp_stream_bytes": (c_l, [c_i, c_i]),
     "msm_encoder_block_lp_fwd": (c_i, [c_f, c_f, c_p, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_p]),
+    "msm_encoder_block_hm_stream_bytes": (c_l, [c_i, c_i]),
+    "msm_encoder_block_hm_small_floats": (c_i, [c_i]),
+    "msm_encoder_block_hm_fwd": (c_i, [c_p, c_f, c_p, c_f, c_f, c_f, c_p, c_p, c_i, c_i, c_i, c_fl, c_p]),
+    "msm_msdeform_attn_enc_lp_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "msm_msdeform_attn_enc_lp_fused_fwd": (c_i, [c_p, c_p, c_p, c_f, c_f, c_p, c_f, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "msm_f32_to_f16": (c_i, [c_f, c_p, c_l, c_p]),
     "msm_kv_project_f32": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_l, c_p]),
     "msm_kv_project_multi_f32": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "msm_kv_project_multi_bf16": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
@@ -100,7 +106,7 @@ _SIGNATURES = {
     "msm_conv3x3_c64_split": (c_i, [c_f, c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p]),
     "msm_conv3x3_c64_nchw_f32": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p]),
     "msm_encoder_prologue_stream_floats": (c_l, [c_i]),
-    "msm_encoder_prologue_fwd": (c_i, [c_f, c_p, c_f, c_p, c_i, c_i, c_fl, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p]),
+    "msm_encoder_prologue_fwd": (c_i, [c_f, c_p, c_f, c_p, c_i, c_i, c_fl, c_f, c_f, c_f, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "msm_label_stats": (c_i, [c_f, c_f, c_p, c_f, c_p, c_i, c_i, c_i, c_i, c_p]),
     "msm_label_image": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p]),
     "msm_crop_resize": (c_i, [c_f, c_f, c_f, c_p, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p]),

@@ -17,6 +17,16 @@ __device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
     const u32x2b u = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
     return __builtin_bit_cast(bf16x4, u);
 }
+// four floats -> four IEEE halves (round to nearest even): the tensors between the bf16 plan's encoder kernels are stored as
+// fp16 -- same bytes as bf16, three more mantissa bits, and their values are O(1) (see csrc/enc_lp.hip)
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float clamp_h(float v) { return __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }      // (no infinities from an outlier)
+__device__ __forceinline__ u32x2b pack4h(float a, float b, float c, float d) {
+    const f16x2_t lo = {(_Float16)clamp_h(a), (_Float16)clamp_h(b)}, hi = {(_Float16)clamp_h(c), (_Float16)clamp_h(d)};
+    return u32x2b{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+}
+__device__ __forceinline__ float half_lo(unsigned packed) { return (float)__builtin_bit_cast(f16x2_t, packed)[0]; }
+__device__ __forceinline__ float half_hi(unsigned packed) { return (float)__builtin_bit_cast(f16x2_t, packed)[1]; }
 // v_mfma_f32_16x16x16_bf16: A lane (i = l & 15, kq = l >> 4) holds A[i][4 kq .. 4 kq + 3], B lane (j, kq) holds B[4 kq .. + 3][j],
 // D lane (j = l & 15, rq = l >> 4) holds D[4 rq + r][j]
 __device__ __forceinline__ f32x4b mfma_bf16(bf16x4 a, bf16x4 b, f32x4b c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }

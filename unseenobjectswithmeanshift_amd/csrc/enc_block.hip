@@ -21,6 +21,7 @@
 //   * 4 waves x 16 tokens per workgroup, 38 KiB LDS -> 4 workgroups per CU.
 #include <stdlib.h>
 
+#include "bf16.h"
 #include "common.h"
 
 namespace msm {
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(PRO_W * 64) void enc_prologue_kernel(const float* _
                                                            const float4* __restrict__ wstream, const float* __restrict__ small,
                                                            const float* __restrict__ pos, float* __restrict__ src_out,
                                                            float* __restrict__ value_out, float* __restrict__ proj_out, int M,
-                                                           int S, int B, int nproj_blocks, int proj_ld, int value_heads) {
+                                                           int S, int B, int nproj_blocks, int proj_ld, int value_heads, int out_bf16_hm) {
     extern __shared__ __attribute__((aligned(16))) float4 wl[];   // [4 + nproj_blocks][256] weight blocks, GroupNorm tables, biases
     const int nblocks = 4 + nproj_blocks;
     float* gt = reinterpret_cast<float*>(wl + nblocks * 256);    // [PRO_NIMG images][levels][3][64]: mean, rstd*gamma, beta
@@ -503,7 +504,12 @@ __global__ __launch_bounds__(PRO_W * 64) void enc_prologue_kernel(const float* _
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) {
         const f32x4 d = rowblock_mm(wl + ob * 256, lj, lq, x, sm + ob * 16);
-        if (tok_ok) {
+        if (tok_ok && out_bf16_hm) {
+            // the bf16 plan's layout (csrc/enc_lp.hip): value [B][8][S][8] fp16 -- this lane's four dims are half a head
+            const int f = ob * 16 + lq * 4;
+            unsigned short* o = reinterpret_cast<unsigned short*>(value_out) + (((int64_t)bi * 8 + (f >> 3)) * S + ti) * 8 + (f & 7);
+            *reinterpret_cast<u32x2b*>(o) = pack4h(d[0], d[1], d[2], d[3]);
+        } else if (tok_ok) {
             const int f = ob * 16 + lq * 4;
             int64_t o = (int64_t)tok * EC + f;
             if (value_heads) {
@@ -519,7 +525,14 @@ __global__ __launch_bounds__(PRO_W * 64) void enc_prologue_kernel(const float* _
     }
     for (int ob = 0; ob < nproj_blocks; ++ob) {
         const f32x4 d = rowblock_mm(wl + (4 + ob) * 256, lj, lq, x, sm + EC + ob * 16);
-        if (tok_ok)
+        if (tok_ok && out_bf16_hm) {
+            // proj [B][8][S][36] fp16 records: row n of [192 offsets | 96 logits] is entry (head, c) = (n / 24, n % 24) or
+            // (n' / 12, 24 + n' % 12), n' = n - 192; four consecutive rows never leave a record
+            const int n = ob * 16 + lq * 4;
+            const int head = n < 192 ? n / 24 : (n - 192) / 12, c = n < 192 ? n - head * 24 : 24 + (n - 192) - head * 12;
+            unsigned short* o = reinterpret_cast<unsigned short*>(proj_out) + (((int64_t)bi * 8 + head) * S + ti) * 36 + c;
+            *reinterpret_cast<u32x2b*>(o) = pack4h(d[0], d[1], d[2], d[3]);
+        } else if (tok_ok)
             *reinterpret_cast<float4*>(proj_out + (int64_t)tok * proj_ld + ob * 16 + lq * 4) = make_float4(d[0], d[1], d[2], d[3]);
     }
 }
@@ -588,8 +601,8 @@ extern "C" int64_t msm_encoder_prologue_stream_floats(int proj_width) {
 
 extern "C" int msm_encoder_prologue_fwd(const float* raw, const double* stats, const float* gn_params, const int32_t* level_starts,
                                         int n_levels, int groups, float gn_eps, const float* wstream, const float* small,
-                                        const float* pos, float* src_out, float* value_out, float* proj_out, int B, int S,
-                                        int proj_width, int value_heads, void* stream) {
+                                        const float* pos, float* src_out, void* value_out, void* proj_out, int B, int S,
+                                        int proj_width, int value_heads, int out_bf16_hm, void* stream) {
     MSM_REQUIRE(raw && stats && gn_params && level_starts && wstream && small && pos && src_out && value_out && (proj_out || proj_width == 0),
                 "msm_encoder_prologue_fwd: null pointer");
     MSM_REQUIRE(n_levels >= 1 && n_levels <= PRO_MAXL, "msm_encoder_prologue_fwd: n_levels=%d outside [1, %d]", n_levels, PRO_MAXL);
@@ -601,6 +614,7 @@ extern "C" int msm_encoder_prologue_fwd(const float* raw, const double* stats, c
     MSM_REQUIRE(((((uintptr_t)raw) | ((uintptr_t)wstream) | ((uintptr_t)small) | ((uintptr_t)src_out) | ((uintptr_t)value_out) |
                   ((uintptr_t)proj_out) | ((uintptr_t)pos) | ((uintptr_t)gn_params)) & 15) == 0 && (((uintptr_t)stats) & 7) == 0,
                 "msm_encoder_prologue_fwd: pointers must be 16-byte aligned");
+    MSM_REQUIRE(!out_bf16_hm || (value_heads == 8 && proj_width == 288), "msm_encoder_prologue_fwd: head-major bf16 outputs need 8 heads and a 288-wide projection");
     ProLevels lv;
     lv.n = n_levels;
     for (int l = 0; l <= PRO_MAXL; ++l) lv.start[l] = level_starts[l < n_levels ? l : n_levels];
@@ -614,8 +628,8 @@ extern "C" int msm_encoder_prologue_fwd(const float* raw, const double* stats, c
     MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)enc_prologue_kernel, lds));
     dim3 grid(cdiv(cdiv(M, 16), PRO_W)), block(PRO_W * 64);
     hipLaunchKernelGGL(enc_prologue_kernel, grid, block, lds, (hipStream_t)stream, raw, stats, gn_params, lv, groups, gn_eps,
-                       reinterpret_cast<const float4*>(wstream), small, pos, src_out, value_out, proj_out, M, S, B, npb, proj_width,
-                       value_heads);
+                       reinterpret_cast<const float4*>(wstream), small, pos, src_out, (float*)value_out, (float*)proj_out, M, S, B, npb, proj_width,
+                       value_heads, out_bf16_hm);
     MSM_CHECK_LAUNCH("msm_encoder_prologue_fwd");
     return MSM_OK;
 }

@@ -867,6 +867,10 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
         # 32 to 59 us (48 MFMAs per wave in front of a latency-bound gather do not overlap with it): neutral in time, 116 MB
         # less HBM traffic per layer -- off by default, DESIGN.md section 4
         self.fused_msda = False
+        # bf16 plan only: head-major fp16 value / attention / sampling-projection tensors between the encoder kernels
+        # (csrc/enc_lp.hip: msm_encoder_block_hm_fwd + msm_msdeform_attn_enc_lp_fwd; 66 us per layer at B = 8 against 85 with the fp32
+        # tensors of round 3).  False: the round-3 kernels (msm_encoder_block_lp_fwd + the fp32 gather)
+        self.hm_activations = True
 
     def _w3(self):
         """layer_1's 3x3 weight in the implicit-GEMM order (Cout, 3*3*Cin), cached per parameter version."""
@@ -892,6 +896,14 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
         self._packed_encoder(device)
         return self._packed[3] is not None and len(self.transformer_in_features) == 3
 
+    def _use_hm(self):
+        """The bf16 plan's head-major bf16 activations: the shipped geometry (64 channels, 8 heads, 3 levels x 4 points)."""
+        layers = self.transformer.encoder.layers
+        return (self.precision == "bf16" and self.hm_activations and self.fused_encoder and self.conv_dim == 64
+                and len(self.transformer_in_features) == 3
+                and all(ly.self_attn.d_model == 64 and ly.self_attn.n_heads == 8 and ly.self_attn.n_levels == 3 and ly.self_attn.n_points == 4
+                        and ly.linear1.out_features % 32 == 0 for ly in layers))
+
     def _packed_encoder(self, device):
         """Weight streams of the fused encoder kernel, rebuilt only when a parameter changes."""
         layers = self.transformer.encoder.layers
@@ -899,12 +911,23 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
             raise ValueError("precision must be 'f32', 'f32_split' or 'bf16'")
         if getattr(self, "_enc_params", None) is None:
             self._enc_params = list(self.transformer.encoder.parameters())
-        key = (str(device), self.precision) + version_key(self._enc_params)
+        hm = self._use_hm()
+        key = (str(device), self.precision, hm) + version_key(self._enc_params)
         if self._packed is None or self._packed[0] != key:
             out = []
             for l, layer in enumerate(layers):
                 nxt = layers[l + 1].self_attn if l + 1 < len(layers) else None
                 a = layer.self_attn
+                if hm:
+                    wv = wp = bv = bp = None
+                    if nxt is not None:
+                        wv, bv = nxt.value_proj.weight, nxt.value_proj.bias
+                        wp, bp = nxt._proj_weights()
+                    stream = ops.pack_encoder_block_hm(a.output_proj.weight, layer.linear1.weight, layer.linear2.weight, wv, wp)
+                    small = ops.pack_encoder_block_hm_small(a.output_proj.bias, layer.norm1.weight, layer.norm1.bias, layer.linear1.bias,
+                                                            layer.linear2.bias, layer.norm2.weight, layer.norm2.bias, bv, bp)
+                    out.append((stream, small, layer.linear1.out_features, 0))
+                    continue
                 wv = wp = None
                 smalls = [a.output_proj.bias, layer.norm1.weight, layer.norm1.bias, layer.linear1.bias, layer.linear2.bias,
                           layer.norm2.weight, layer.norm2.bias]
@@ -996,7 +1019,8 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
                 bounds.append(bounds[-1] + h * w)
             fuse0 = self._use_fused_msda(dev)
             src, value, proj = ops.encoder_prologue(src, stats[:len(levels)], gnp, bounds, pstream, psmall[:64] if fuse0 else psmall, lvl_pos,
-                                                    0 if fuse0 else pw, groups=gns[0].num_groups, eps=gns[0].eps, value_heads=a0.n_heads)
+                                                    0 if fuse0 else pw, groups=gns[0].num_groups, eps=gns[0].eps, value_heads=a0.n_heads,
+                                                    bf16_hm=self._use_hm())
         else:
             toks = []
             for idx, x in enumerate(levels):
@@ -1015,6 +1039,18 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
                 if not fuse:
                     w, b = self._packed[2]
                     proj = ops.gemm(src, w, b, a2=lvl_pos)
+            if self._use_hm():
+                # bf16 plan: value / attention / sampling projection travel between the kernels as head-major fp16
+                # (layer 0's come from the fp32 prologue: one conversion each)
+                if value.dtype != torch.float16:                     # (the unfused front end: fp32 GEMM results, converted once)
+                    value = ops.to_f16(value if value.dim() == 4 else ops.value_to_head_major(value, 8))
+                    proj = ops.proj_to_head_major_f16(proj)
+                for l, layer in enumerate(layers):
+                    attn = ops.ms_deform_attn_encoder_lp(value, ss, starts, proj, layer.self_attn.n_points)
+                    stream, small, d_ffn, _ = packed[l]
+                    src, value, proj = ops.encoder_block_hm(attn, src, stream, small, d_ffn, pos=lvl_pos, want_next=l + 1 < len(layers),
+                                                            eps=layer.norm1.eps)
+                return src, shapes, fpn_stats
             for l, layer in enumerate(layers):
                 if fuse:
                     attn = ops.ms_deform_attn_encoder_fused(value, ss, starts, src, lvl_pos, *self._packed[3][l], layer.self_attn.n_points)

@@ -963,11 +963,13 @@ def pack_encoder_prologue(wv, wp):
     return out
 
 
-def encoder_prologue(raw, stats, gn_params, level_starts, stream, small, pos, proj_width, *, groups=32, eps=1e-5, value_heads=0):
+def encoder_prologue(raw, stats, gn_params, level_starts, stream, small, pos, proj_width, *, groups=32, eps=1e-5, value_heads=0,
+                     bf16_hm=False):
     """raw (B,S,64) concatenated input projections (conv1x1_in), stats (L,B,64,2) float64 their GroupNorm moments,
     gn_params (L,2,64) = gamma, beta, level_starts: L+1 token offsets (0..S).  Normalises raw IN PLACE (-> src) and
     returns (src, value, proj) for the first encoder layer: value (B,S,64) or head-major (B,heads,S,64/heads),
-    proj (B,S,proj_width) = [sampling_offsets | attention_weights](src + pos)."""
+    proj (B,S,proj_width) = [sampling_offsets | attention_weights](src + pos).  bf16_hm (8 heads, proj_width 288): value and
+    proj are the bf16 plan's head-major fp16 tensors (B,8,S,8) and (B,8,S,36) (encoder_block_hm)."""
     _c(raw, "raw"), _c(stats, "stats", torch.float64), _c(gn_params, "gn_params"), _c(stream, "stream"), _c(small, "small"), _c(pos, "pos")
     B, S, C = raw.shape
     L = len(level_starts) - 1
@@ -976,12 +978,16 @@ def encoder_prologue(raw, stats, gn_params, level_starts, stream, small, pos, pr
     if small.numel() != 64 + proj_width:
         raise RuntimeError("encoder_prologue: small must hold the 64 value_proj biases and the proj_width projection biases")
     dev = raw.device
-    value = torch.empty((B, value_heads, S, 64 // value_heads) if value_heads else (B, S, 64), device=dev, dtype=torch.float32)
-    proj = torch.empty((B, S, proj_width), device=dev, dtype=torch.float32) if proj_width else None     # 0: value projection only
+    if bf16_hm:
+        value = torch.empty((B, 8, S, 8), device=dev, dtype=torch.float16)
+        proj = torch.empty((B, 8, S, 36), device=dev, dtype=torch.float16)
+    else:
+        value = torch.empty((B, value_heads, S, 64 // value_heads) if value_heads else (B, S, 64), device=dev, dtype=torch.float32)
+        proj = torch.empty((B, S, proj_width), device=dev, dtype=torch.float32) if proj_width else None     # 0: value projection only
     ls = (ctypes.c_int32 * (L + 1))(*[int(v) for v in level_starts])
     rc = lib().msm_encoder_prologue_fwd(_p(raw), _p(stats), _p(gn_params), ctypes.cast(ls, ctypes.c_void_p), L, int(groups), float(eps),
                                         _p(stream), _p(small), _p(pos), _p(raw), _p(value), _p(proj), B, S, int(proj_width),
-                                        int(value_heads), _stream())
+                                        int(value_heads), int(bool(bf16_hm)), _stream())
     check(rc, "msm_encoder_prologue_fwd")
     return raw, value, proj
 
@@ -1149,6 +1155,181 @@ def encoder_block_lp(attn, src, wstream, small, d_ffn, proj_width, *, pos=None, 
                                         B * S, tokens_per_image or S, d_ffn, proj_width, int(value_heads), eps, _stream())
     check(rc, "msm_encoder_block_lp_fwd")
     return src_out, value_out, proj_out
+
+
+# ---- the bf16 plan's encoder layers with head-major bf16 activations (csrc/enc_lp.hip) ------------------------------------
+def _korder_L(K, device):
+    """k order "L" of a K-wide contraction whose B operand comes from layout-L registers (lane (token, lq) holds features
+    fb*16 + lq*4 + r): 32-wide group G, lane quarter kq, element j  <->  column (2G + (j >> 2))*16 + 4 kq + (j & 3)."""
+    G = torch.arange(K // 32, device=device).view(-1, 1, 1)
+    kq = torch.arange(4, device=device).view(1, -1, 1)
+    j = torch.arange(8, device=device).view(1, 1, -1)
+    return (2 * G + (j >> 2)) * 16 + 4 * kq + (j & 3)
+
+
+def _korder_natural(K, device):
+    G = torch.arange(K // 32, device=device).view(-1, 1, 1)
+    kq = torch.arange(4, device=device).view(1, -1, 1)
+    j = torch.arange(8, device=device).view(1, 1, -1)
+    return 32 * G + 8 * kq + j
+
+
+def _frag_blocks(w, korder):
+    """w (R, K) -> (R/16, K/32, 512): 1-KiB A-operand blocks of v_mfma_f32_16x16x32_bf16, block[rb][G][kq*16 + i][j] =
+    w[rb*16 + i][korder[G][kq][j]]."""
+    R, K = w.shape
+    t = w.reshape(R // 16, 16, K)[:, :, korder]              # (rb, i, G, kq, j)
+    return t.permute(0, 2, 3, 1, 4).reshape(R // 16, K // 32, 512)
+
+
+def _hl(w):
+    h = w.to(torch.bfloat16).float()
+    return h, (w - h).to(torch.bfloat16).float()
+
+
+def _value_row_perm(device):
+    """Row (16 rb + 4 lq + r) of the packed value_proj = value feature head*8 + dim with head = 4 (rb >> 1) + lq,
+    dim = 4 (rb & 1) + r: a lane's row blocks 2j, 2j + 1 are the eight dims of one head (one 16-byte store)."""
+    rb = torch.arange(4, device=device).view(-1, 1, 1)
+    lq = torch.arange(4, device=device).view(1, -1, 1)
+    r = torch.arange(4, device=device).view(1, 1, -1)
+    return ((4 * (rb >> 1) + lq) * 8 + 4 * (rb & 1) + r).reshape(-1)
+
+
+def _proj_row_perm(heads, LP, device):
+    """Row m*36 + c of the head-major projection = reference row m*2LP + c (offsets, c < 2LP) or heads*2LP + m*LP + c - 2LP (logits)."""
+    m = torch.arange(heads, device=device).view(-1, 1)
+    c = torch.arange(3 * LP, device=device).view(1, -1)
+    return torch.where(c < 2 * LP, m * 2 * LP + c, heads * 2 * LP + m * LP + c - 2 * LP).reshape(-1)
+
+
+def pack_encoder_block_hm(wo, w1, w2, wv=None, wp=None):
+    """One encoder layer's matrices as the weight stream of msm_encoder_block_hm_fwd (include/msm_hip.h): resident block
+    [output_proj | next layer's value_proj] as [h, l] bf16 pairs, linear1 / linear2 as single bf16 copies, four pairs of
+    16-wide hidden blocks per 32-KiB stage, then (wv / wp given) the next layer's sampling projection in (head, 36) row order as
+    [h, l] pairs, eight row blocks per stage.  Returns an int16 tensor (bf16 bit patterns)."""
+    dev = wo.device
+    d_ffn = w1.shape[0]
+    if wo.shape != (64, 64) or w1.shape[1] != 64 or tuple(w2.shape) != (64, d_ffn) or d_ffn % 32:
+        raise RuntimeError("pack_encoder_block_hm: d_model 64, d_ffn a multiple of 32")
+    if (wv is None) != (wp is None) or (wp is not None and tuple(wp.shape) != (288, 64)):
+        raise RuntimeError("pack_encoder_block_hm: wv and wp (288, 64) go together")
+    pad = (-d_ffn) % 128
+
+    def pair_hl(w, korder):                                   # (R, 64) -> (R/16, 2, 2, 512): [rb][G][h, l]
+        h, l = _hl(w)
+        return torch.stack([_frag_blocks(h, korder), _frag_blocks(l, korder)], 2)
+
+    kL, kn = _korder_L(64, dev), _korder_natural(64, dev)
+    res = [pair_hl(wo, kn).reshape(-1)]
+    res.append(pair_hl(wv[_value_row_perm(dev)], kL).reshape(-1) if wv is not None else torch.zeros(16 * 512, device=dev))
+    w1p = torch.cat([w1, torch.zeros(pad, 64, device=dev)], 0).to(torch.bfloat16).float()
+    w2p = torch.cat([w2, torch.zeros(64, pad, device=dev)], 1).to(torch.bfloat16).float()
+    npair = (d_ffn + pad) // 32
+    b1 = _frag_blocks(w1p, kL).reshape(npair, 4 * 512)                        # [P][q][G][512]
+    b2 = _frag_blocks(w2p, _korder_L(d_ffn + pad, dev)).permute(1, 0, 2).reshape(npair, 4 * 512)     # [P][ob][512]
+    parts = res + [torch.cat([b1, b2], 1).reshape(-1)]
+    if wp is not None:
+        pj = pair_hl(wp[_proj_row_perm(8, 12, dev)], kL).reshape(-1)         # 18 row blocks x 4 KiB
+        parts += [pj, torch.zeros(3 * 16384 - pj.numel(), device=dev)]
+    out = torch.cat(parts).to(torch.bfloat16).contiguous().view(torch.int16)
+    assert out.numel() * 2 == lib().msm_encoder_block_hm_stream_bytes(d_ffn, int(wp is not None))
+    return out
+
+
+def pack_encoder_block_hm_small(bo, g1, be1, b1, b2, g2, be2, bv=None, bp=None):
+    """The fp32 parameter vector of msm_encoder_block_hm_fwd (value_proj / projection biases in the packed row orders, linear1
+    bias zero padded to whole stages)."""
+    dev = bo.device
+    d_ffn = b1.numel()
+    bvp = bv[_value_row_perm(dev)] if bv is not None else torch.zeros(64, device=dev)
+    bpp = bp[_proj_row_perm(8, 12, dev)] if bp is not None else torch.zeros(288, device=dev)
+    out = torch.cat([bo, g1, be1, b2, g2, be2, bvp, bpp, b1, torch.zeros((-d_ffn) % 128, device=dev)]).contiguous()
+    assert out.numel() == lib().msm_encoder_block_hm_small_floats(d_ffn)
+    return out
+
+
+def pack_msda_proj_lp(wp, bp, heads=8, n_levels=3, n_points=4):
+    """[sampling_offsets ; attention_weights] weight (heads*L*P*3, 64) and bias -> the per-head [h, l] bf16 fragment stream
+    (int16, 12 KiB per head) and bias table (heads, 48) of msm_msdeform_attn_enc_lp_fused_fwd."""
+    LP = n_levels * n_points
+    if tuple(wp.shape) != (heads * LP * 3, 64) or bp.numel() != wp.shape[0] or LP != 12:
+        raise RuntimeError("pack_msda_proj_lp: the shipped geometry only (3 levels x 4 points)")
+    dev = wp.device
+    perm = _proj_row_perm(heads, LP, dev)
+    rows = torch.zeros(heads, 48, 64, device=dev)
+    bias = torch.zeros(heads, 48, device=dev)
+    rows[:, :3 * LP] = wp[perm].reshape(heads, 3 * LP, 64)
+    bias[:, :3 * LP] = bp[perm].reshape(heads, 3 * LP)
+    kL = _korder_L(64, dev)
+    h, l = _hl(rows.reshape(heads * 48, 64))
+    blocks = torch.stack([_frag_blocks(h, kL), _frag_blocks(l, kL)], 2)       # (heads*3, 2, 2, 512)
+    return blocks.reshape(-1).to(torch.bfloat16).contiguous().view(torch.int16), bias.contiguous()
+
+
+def proj_to_head_major_f16(proj, heads=8, LP=12):
+    """(B, S, heads*LP*3) fp32 in the reference's [offsets | logits] column order -> (B, heads, S, 36) fp16 records (torch ops:
+    tests and the unfused front end only; the fused prologue writes the records itself)."""
+    B, S, W = proj.shape
+    perm = _proj_row_perm(heads, LP, proj.device)
+    return proj[..., perm].reshape(B, S, heads, 3 * LP).permute(0, 2, 1, 3).to(torch.float16).contiguous()
+
+
+def to_f16(t):
+    """fp32 -> fp16 (round to nearest even, clamped to the half range) on the HIP path (msm_f32_to_f16)."""
+    _c(t, "t")
+    out = torch.empty(t.shape, device=t.device, dtype=torch.float16)
+    check(lib().msm_f32_to_f16(_p(t), _p(out), t.numel(), _stream()), "msm_f32_to_f16")
+    return out
+
+
+def encoder_block_hm(attn_hm, src, wstream, small, d_ffn, *, pos=None, want_next=True, eps=1e-5):
+    """One encoder-layer tail of the bf16 plan: attn_hm (B, 8, S, 8) fp16, src (B, S, 64) fp32 -> (src_out fp32, and for the
+    NEXT layer value_hm (B, 8, S, 8) and proj_hm (B, 8, S, 36), both fp16, or None, None)."""
+    _c(attn_hm, "attn_hm", torch.float16), _c(src, "src"), _c(wstream, "wstream", torch.int16), _c(small, "small"), _c(pos, "pos")
+    B, S, C = src.shape
+    if C != 64 or tuple(attn_hm.shape) != (B, 8, S, 8):
+        raise RuntimeError("encoder_block_hm: src (B, S, 64) and attn_hm (B, 8, S, 8)")
+    if want_next and (pos is None or tuple(pos.shape) != (S, 64)):
+        raise RuntimeError("encoder_block_hm: the next layer's projection needs pos (S, 64)")
+    if wstream.numel() * 2 != lib().msm_encoder_block_hm_stream_bytes(int(d_ffn), int(want_next)):
+        raise RuntimeError("encoder_block_hm: wstream does not match d_ffn / want_next (pack_encoder_block_hm)")
+    src_out = torch.empty_like(src)
+    value_out = torch.empty_like(attn_hm) if want_next else None
+    proj_out = torch.empty((B, 8, S, 36), device=src.device, dtype=torch.float16) if want_next else None
+    rc = lib().msm_encoder_block_hm_fwd(_p(attn_hm), _p(src), _p(wstream), _p(small), _p(pos if want_next else None), _p(src_out), _p(value_out),
+                                        _p(proj_out), B * S, S, int(d_ffn), float(eps), _stream())
+    check(rc, "msm_encoder_block_hm_fwd")
+    return src_out, value_out, proj_out
+
+
+def ms_deform_attn_encoder_lp(value_hm, spatial_shapes, level_start_index, proj_hm, n_points=4):
+    """Encoder self-attention gather of the bf16 plan: value_hm (B, 8, S, 8) fp16, proj_hm (B, 8, S, 36) fp16 records (offsets,
+    logits).  Returns attn_hm (B, 8, S, 8) fp16."""
+    _c(value_hm, "value_hm", torch.float16), _c(proj_hm, "proj_hm", torch.float16)
+    _c(spatial_shapes, "spatial_shapes", torch.int64), _c(level_start_index, "level_start_index", torch.int64)
+    B, M, S, D = value_hm.shape
+    if tuple(proj_hm.shape) != (B, M, S, 36):
+        raise RuntimeError("ms_deform_attn_encoder_lp: proj_hm must be (B, heads, S, 36)")
+    out = torch.empty_like(value_hm)
+    rc = lib().msm_msdeform_attn_enc_lp_fwd(_p(value_hm), _p(spatial_shapes), _p(level_start_index), _p(proj_hm), _p(out), B, S, M, D,
+                                            spatial_shapes.shape[0], int(n_points), _stream())
+    check(rc, "msm_msdeform_attn_enc_lp_fwd")
+    return out
+
+
+def ms_deform_attn_encoder_lp_fused(value_hm, spatial_shapes, level_start_index, src, pos, wpack, bpack, n_points=4):
+    """The same gather with the sampling projection of src + pos computed in the kernel (wpack / bpack from pack_msda_proj_lp)."""
+    _c(value_hm, "value_hm", torch.float16), _c(src, "src"), _c(pos, "pos"), _c(wpack, "wpack", torch.int16), _c(bpack, "bpack")
+    _c(spatial_shapes, "spatial_shapes", torch.int64), _c(level_start_index, "level_start_index", torch.int64)
+    B, M, S, D = value_hm.shape
+    if tuple(src.shape) != (B, S, M * D) or tuple(pos.shape) != (S, M * D):
+        raise RuntimeError("ms_deform_attn_encoder_lp_fused: src (B, S, 64), pos (S, 64)")
+    out = torch.empty_like(value_hm)
+    rc = lib().msm_msdeform_attn_enc_lp_fused_fwd(_p(value_hm), _p(spatial_shapes), _p(level_start_index), _p(src), _p(pos), _p(wpack),
+                                                  _p(bpack), _p(out), B, S, M, D, spatial_shapes.shape[0], int(n_points), _stream())
+    check(rc, "msm_msdeform_attn_enc_lp_fused_fwd")
+    return out
 
 
 def encoder_block_split(attn, src, wstream, small, d_ffn, proj_width, *, pos=None, tokens_per_image=None, want_next=True,
