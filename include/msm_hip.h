@@ -465,13 +465,16 @@ int msm_ms_hill_climb_split(const float* X, int n, int d, float* Z, int S, float
  * counts int64 [num_labels] histogram of labels_out (zeroed here) (MS:206-221). */
 int msm_ms_assign(const float* X, int n, int d, const float* Z, int S, const int64_t* seed_labels,
                   int64_t* labels_out, int64_t* counts, int num_labels, void* stream);
-/* swap label 0 with the first-argmax label of counts (MS:222-227); labels int64 [n] in place. */
 /* connected_components of the converged seeds (lib/utils/mean_shift.py:41-76: sequential, order dependent) on the device:
- * Z [S][64] unit rows, S <= 304; seed_labels int64 [S] (labels 0 .. *num_labels - 1 in order of creation; some may have
- * been overwritten, as in the reference); one wave, no host involvement. */
+ * Z [S][64] unit rows, S <= 304; seed_labels int64 [S] (labels in order of creation; a later step may overwrite every seed
+ * of an earlier label, as in the reference); num_labels int32 [2] = {labels that survive = len(unique(seed_labels)), labels
+ * created}; one wave, no host involvement. */
 int msm_ms_connected_components(const float* Z, int S, int d, float epsilon, int64_t* seed_labels, int32_t* num_labels,
                                 void* stream);
-int msm_ms_relabel_largest_zero(int64_t* labels, int n, const int64_t* counts, int num_labels,
+/* swap label 0 with the first-argmax label of counts[0 .. num) (MS:211-227); labels int64 [n] in place.  num = min(num_labels,
+ * *num_alive) when num_alive (device, e.g. num_labels[0] of msm_ms_connected_components) is given: the reference counts the
+ * labels 0 .. len(unique(seed_labels)) - 1 only, which differs from "every label" once a label has vanished. */
+int msm_ms_relabel_largest_zero(int64_t* labels, int n, const int64_t* counts, int num_labels, const int32_t* num_alive,
                                 void* stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -462,7 +462,7 @@ def test_meta_arch_inference_vs_oracle():
         assert (inst.pred_masks.cpu() != ref["pred_masks"]).float().mean() < 1e-4
         torch.testing.assert_close(inst.scores.cpu(), ref["scores"], rtol=1e-4, atol=1e-6)
         assert torch.equal(inst.pred_classes.cpu(), ref["pred_classes"])
-    # inference ran the final mask step on the 20 kept queries only (modeling: _final_topk); with all 100 queries computed and the
+    # inference ran the final mask step on the 20 kept queries only (modeling: final_topk); with all 100 queries computed and the
     # selection afterwards -- the reference's order -- the instances are the same, bit for bit
     fast = model.inference(dfe, (64, 96))
     model.topk_before_masks = False

@@ -1233,8 +1233,33 @@ def test_connected_components_on_device(S, centres, noise, seed):
     assert float((d - 0.04).abs().min()) > 1e-6
     got, num = ops().ms_connected_components(Z.to(DEV), 0.04)
     assert torch.equal(got.cpu(), want)
-    assert int(num) >= int(want.max()) + 1 and int(num) <= S
+    assert int(num[1]) >= int(want.max()) + 1 and int(num[1]) <= S          # labels created
+    assert int(num[0]) == int(torch.unique(want).numel()) == int(num[1])     # labels that survive (MS:211) = labels created
     assert torch.equal(ms.connected_components(Z.to(DEV), 0.04).cpu(), want)
+
+
+def test_mean_shift_relabel_counts_only_the_first_num_labels():
+    """mean_shift.py:211-222 takes the largest cluster among labels 0 .. len(unique(seed_labels)) - 1.  With label values that
+    have a gap (here {0, 2}: num = 2, so label 2 is never counted) that differs from "the argmax over every label" -- the
+    round-3 advisor finding.  (connected_components itself cannot leave a gap: the seed that opens a label is never inside a
+    later seed's neighbourhood, the metric being symmetric -- asserted on the device pass in
+    test_connected_components_on_device as num[0] == num[1] == len(unique).  The bound is honoured literally all the same.)"""
+    e = torch.eye(64)
+    Z = torch.stack([e[0], e[1], e[5]]).float()
+    seed_labels = torch.tensor([0, 0, 2])                          # as if label 1 had vanished
+    g = torch.Generator().manual_seed(0)
+    X = F.normalize(torch.cat([e[0][None] + 0.01 * torch.randn(10, 64, generator=g), e[5][None] + 0.01 * torch.randn(50, 64, generator=g)]), dim=1)
+    labels, counts = ops().ms_assign(X.to(DEV), Z.to(DEV), seed_labels.to(DEV), 4)
+    ref = seed_labels[torch.argmin(0.5 * (1 - X @ Z.t()), dim=1)]
+    assert torch.equal(labels.cpu(), ref) and counts.tolist() == [10, 0, 50, 0]
+    num = torch.tensor([len(torch.unique(seed_labels))], dtype=torch.int32, device=DEV)
+    out = ops().ms_relabel_largest_zero(labels.clone(), counts, num)
+    assert torch.equal(out.cpu(), ref)                              # argmax over counts[:2] = label 0: nothing moves (the reference)
+    out_all = ops().ms_relabel_largest_zero(labels.clone(), counts)
+    assert out_all.cpu().tolist() == [2] * 10 + [0] * 50           # every label counted: the swap the reference does not make
+    # the oracle's restatement of MS:206-229 on the same labels
+    cnt = torch.tensor([(ref == i).sum() for i in range(int(num))])
+    assert int(torch.argmax(cnt)) == 0
 
 
 @pytest.mark.parametrize("B,Q,H,W,pool", [(2, 100, 16, 24, 2), (2, 100, 16, 24, 4), (8, 100, 120, 160, 8), (1, 100, 120, 160, 4),

@@ -166,3 +166,55 @@ def test_graph_stale_check_is_cheap_and_sees_updates():
         strict()
     slow = (time.perf_counter() - t0) / 20
     assert fast < 0.2 * slow, (fast, slow)
+
+
+def test_stale_check_sees_replaced_and_repointed_middle_parameters():
+    """Round-3 advisor finding: the cheap signatures compared the tensor count, the version sum and the FIRST / LAST address, so
+    ``p.data = new`` on a middle tensor, ``m.weight = nn.Parameter(...)`` or ``load_state_dict(assign=True)`` kept stale packed
+    weights and graphs.  Now: every address enters the key (a sum), and the cached tensor lists are rebuilt when a Parameter /
+    buffer object is (re)registered anywhere (``_plan.TensorList`` on torch's registration hooks)."""
+    from torch import nn
+    from unseenobjectswithmeanshift_amd import _plan, graphs
+    from unseenobjectswithmeanshift_amd.meta_arch import build_resnet50_head
+    head = build_resnet50_head()
+    chk = graphs.StaleCheck(head)
+    mid = head.pixel_decoder.transformer.encoder.layers[2].linear1          # neither first nor last
+    s0 = chk()
+    mid.weight.data = mid.weight.data.clone()                                # same version, new storage
+    s1 = chk()
+    assert s1 != s0
+    mid.weight = nn.Parameter(mid.weight.detach().clone())                   # a new Parameter object at version 0
+    s2 = chk()
+    assert s2 != s1
+    sd = {k: v.clone() for k, v in mid.state_dict().items()}
+    mid.load_state_dict(sd, assign=True)
+    assert chk() != s2
+    # the module-level lists behind the packed-weight caches follow the same rule
+    tl = _plan.TensorList(lambda: head.pixel_decoder.transformer.encoder.parameters())
+    k0 = _plan.version_key(tl())
+    mid.weight = nn.Parameter(mid.weight.detach().clone())
+    k1 = _plan.version_key(tl())
+    assert k1 != k0 and any(t is mid.weight for t in tl())
+    mid.bias.data = mid.bias.data.clone()
+    assert _plan.version_key(tl()) != k1
+    # the inference-plan attributes of the meta-arch are plan attributes too (advisor: K selects kernels inside a captured graph)
+    assert {"test_topk_per_image", "topk_before_masks", "hm_activations"} <= _plan.PLAN_ATTRS
+
+
+class _NotATensor:
+    pass
+
+
+def test_checkpoint_loader_is_tensors_only_and_says_how_to_opt_out(tmp_path):
+    """load_checkpoint_file: numpy payloads of either numpy major version's module path are allow-listed; anything else fails
+    with a message that names unsafe=True (round-3 advisor finding: a bare UnpicklingError with no hint)."""
+    import pickle
+    from unseenobjectswithmeanshift_amd import checkpoint as c
+    p = str(tmp_path / "a.pth")
+    torch.save({"model": {"w": np.arange(4, dtype=np.float32), "t": torch.ones(2)}, "iteration": np.float64(3.0)}, p)
+    got = c.load_checkpoint_file(p)
+    assert got["model"]["w"].tolist() == [0.0, 1.0, 2.0, 3.0] and float(got["iteration"]) == 3.0
+
+    torch.save({"model": {"w": _NotATensor()}}, p)
+    with pytest.raises(pickle.UnpicklingError, match="unsafe=True"):
+        c.load_checkpoint_file(p)

@@ -96,7 +96,7 @@ _SIGNATURES = {
     "msm_ms_hill_climb_split": (c_i, [c_f, c_i, c_i, c_f, c_i, c_fl, c_i, c_f, c_l, c_p]),
     "msm_ms_assign": (c_i, [c_f, c_i, c_i, c_f, c_i, c_p, c_p, c_p, c_i, c_p]),
     "msm_ms_connected_components": (c_i, [c_f, c_i, c_i, c_fl, c_p, c_p, c_p]),
-    "msm_ms_relabel_largest_zero": (c_i, [c_p, c_i, c_p, c_i, c_p]),
+    "msm_ms_relabel_largest_zero": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p]),
     "msm_topk_class_scores": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p]),
     "msm_topk_class_scores_gather": (c_i, [c_f, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_f, c_l, c_i, c_f, c_p]),
     "msm_conv1x1_in_f32": (c_i, [c_f, c_f, c_f, c_f, c_l, c_p, c_i, c_i, c_i, c_i, c_p]),

@@ -69,6 +69,8 @@ def load_checkpoint_file(path, unsafe=False):
     explicit opt-in to a full unpickle for legacy files that hold other objects."""
     if unsafe:
         return torch.load(path, map_location="cpu", weights_only=False)
+    import pickle
+
     import numpy as np
     allow = [np.ndarray, np.dtype]
     core = getattr(np, "_core", None) or getattr(np, "core")
@@ -76,9 +78,22 @@ def load_checkpoint_file(path, unsafe=False):
         fn = getattr(core.multiarray, name, None)
         if fn is not None:
             allow.append(fn)
+            # torch matches allow-listed globals by "module.name": a file pickled under numpy 1.x names numpy.core.multiarray.*,
+            # one pickled under numpy 2.x numpy._core.multiarray.* -- register the reconstructors under BOTH paths
+            for mod in ("numpy.core.multiarray", "numpy._core.multiarray"):
+                allow.append((fn, f"{mod}.{name}"))
     allow += [type(np.dtype(t)) for t in ("float32", "float64", "float16", "int64", "int32", "uint8", "bool")]
-    with torch.serialization.safe_globals(allow):
-        return torch.load(path, map_location="cpu", weights_only=True)
+    try:
+        with torch.serialization.safe_globals(allow):
+            return torch.load(path, map_location="cpu", weights_only=True)
+    except TypeError:                                  # a torch whose safe_globals does not take (callable, name) pairs
+        with torch.serialization.safe_globals([a for a in allow if not isinstance(a, tuple)]):
+            return torch.load(path, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError as e:
+        raise pickle.UnpicklingError(
+            f"{path}: not loadable tensors-only ({e}).  Legacy detectron2 checkpoints may hold other objects (trainer state, "
+            "numpy scalars pickled by another numpy major version): if you trust the file, load it with unsafe=True "
+            "(load_checkpoint_file / load_reference_checkpoint), or re-save its 'model' entry as plain tensors") from e
 
 
 def load_reference_checkpoint(model, checkpoint, strict=True, unsafe=False):

@@ -933,7 +933,20 @@ __global__ __launch_bounds__(64) void ms_components_kernel(const float* __restri
         __syncthreads();
     }
     for (int j = lane; j < S; j += 64) labels_out[j] = (int64_t)lab[j];
-    if (lane == 0) num_out[0] = K;
+    // num_out[0] = labels that SURVIVE (a later step may overwrite every seed of an earlier label: the reference's
+    // `num = len(unique(seed_labels))`, MS:211, then counts only labels 0 .. num - 1), num_out[1] = labels created
+    for (int l = lane; l < K; l += 64) cnt[l] = 0;
+    __syncthreads();
+    for (int j = lane; j < S; j += 64) cnt[lab[j]] = 1;
+    __syncthreads();
+    int alive = 0;
+    for (int l = lane; l < K; l += 64) alive += cnt[l];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) alive += __shfl_xor(alive, o, 64);
+    if (lane == 0) {
+        num_out[0] = alive;
+        num_out[1] = K;
+    }
 }
 
 // ---- assignment -----------------------------------------------------------------------------------
@@ -1000,8 +1013,11 @@ __global__ __launch_bounds__(256) void ms_assign_kernel(const float* __restrict_
 }
 
 __global__ __launch_bounds__(256) void ms_relabel_kernel(int64_t* __restrict__ labels, int n, const int64_t* __restrict__ counts,
-                                                         int num_labels) {
-    // first argmax of counts (torch.argmax, MS:222); every thread recomputes it (<= 304 entries)
+                                                         int num_labels, const int32_t* __restrict__ num_alive) {
+    // first argmax of counts (torch.argmax, MS:222) over labels 0 .. num - 1, num = number of distinct seed labels (MS:211-216:
+    // with a vanished label the label values have gaps and the reference never counts the ones >= num); every thread
+    // recomputes it (<= 304 entries)
+    if (num_alive != nullptr) num_labels = min(num_labels, max((int)num_alive[0], 1));
     int lmax = 0;
     int64_t best = counts[0];
     for (int i = 1; i < num_labels; ++i) {
@@ -1258,10 +1274,11 @@ extern "C" int msm_ms_connected_components(const float* Z, int S, int d, float e
     return MSM_OK;
 }
 
-extern "C" int msm_ms_relabel_largest_zero(int64_t* labels, int n, const int64_t* counts, int num_labels, void* stream) {
+extern "C" int msm_ms_relabel_largest_zero(int64_t* labels, int n, const int64_t* counts, int num_labels, const int32_t* num_alive,
+                                           void* stream) {
     MSM_REQUIRE(labels && counts && n > 0 && num_labels > 0, "msm_ms_relabel_largest_zero: bad arguments");
     hipLaunchKernelGGL(ms_relabel_kernel, dim3(min(2048, cdiv(n, 256))), dim3(256), 0, (hipStream_t)stream, labels, n,
-                       counts, num_labels);
+                       counts, num_labels, num_alive);
     MSM_CHECK_LAUNCH("msm_ms_relabel_largest_zero");
     return MSM_OK;
 }

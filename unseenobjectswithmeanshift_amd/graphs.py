@@ -17,7 +17,7 @@ _CACHE_ATTRS = ("_q0", "_kv_cache", "_fold_cache", "_tails_cache", "_pos_cache",
                 "_packed_mf", "_bf16_cache", "_folded_cache")
 
 
-from ._plan import PLAN_ATTRS as _PLAN_ATTRS, plan_epoch
+from ._plan import PLAN_ATTRS as _PLAN_ATTRS, TensorList, plan_epoch
 
 
 def cache_refs(model):
@@ -46,38 +46,31 @@ class StaleCheck:
     """Cheap per-replay staleness test of a captured graph (the exhaustive ``param_signature`` cost 0.75-1.3 ms per call,
     a third of the 2.2 ms step it guards).  The signature is
 
-        (plan epoch, number of tensors, sum of the tensors' version counters, address of the first and last tensor)
+        (plan epoch, number of tensors, sum of the tensors' version counters, sum of the tensors' addresses)
 
     * the plan epoch (``_plan.py``) moves when any plan attribute of a module is assigned a new value or a library option
       is set: one integer compare instead of modules x attributes dictionary probes;
     * in-place updates (``load_state_dict``, an optimizer step, ``.copy_``) bump ``_version`` of the tensor they touch;
-    * ``.to(device)`` / ``.half()`` move every tensor: the first and last addresses change.
-    Not seen: a Parameter OBJECT replaced by hand (``m.weight = nn.Parameter(...)``) with a tensor at version 0 -- call
-    ``invalidate()`` (or use ``strict=True``) in code that does that.  The tensor list is cached and rebuilt when the epoch
-    moves.  ~20 us for the head's 298 tensors."""
+    * ``.to(device)`` / ``.half()`` / ``p.data = new`` move tensors: the address sum changes;
+    * a Parameter OBJECT replaced by hand (``m.weight = nn.Parameter(...)``, ``load_state_dict(assign=True)``, parametrize)
+      goes through ``Module.register_parameter``: the parameter epoch moves and the tensor list is rebuilt (``_plan.TensorList``).
+    ~60 us for the head's 298 tensors."""
 
     def __init__(self, model, strict=False):
         self.model = model
         self.strict = strict
-        self._tensors = None
-        self._epoch = None
+        self._tensors = TensorList(lambda: list(model.parameters()) + list(model.buffers()))
         self._manual = 0
 
     def invalidate(self):
         self._manual += 1
-        self._tensors = None
+        self._tensors.clear()
 
     def __call__(self):
         if self.strict:
             return param_signature(self.model)
-        ep = plan_epoch()
-        if self._tensors is None or ep != self._epoch:
-            self._tensors = list(self.model.parameters()) + list(self.model.buffers())
-            self._epoch = ep
-        ts = self._tensors
-        if not ts:
-            return (ep, 0, 0, 0, 0, self._manual)
-        return (ep, len(ts), sum([t._version for t in ts]), ts[0].data_ptr(), ts[-1].data_ptr(), self._manual)
+        ts = self._tensors()
+        return (plan_epoch(), len(ts), sum([t._version for t in ts]), sum([t.data_ptr() for t in ts]), self._manual)
 
 
 class GraphedInference:

@@ -75,6 +75,16 @@ def mean_shift_with_seeds(X, Z, kappa, max_iters=10, metric="cosine", precision=
     return connected_components(Z, 2 * EMBEDDING_ALPHA, metric=metric), Z
 
 
+def _components_with_count(Z, epsilon):
+    """(seed_labels, num) with num = len(unique(seed_labels)) as a 1-element int32 device tensor (no host synchronisation on
+    the device path): what mean_shift.py:211-216 bounds its per-label counts by."""
+    if Z.is_cuda and Z.shape[0] <= 304 and Z.shape[1] == 64:
+        labels, num = ops.ms_connected_components(Z.contiguous(), epsilon)
+        return labels, num[:1]
+    labels = connected_components_host(Z, epsilon)
+    return labels, torch.tensor([int(torch.unique(labels).numel())], dtype=torch.int32, device=Z.device)
+
+
 def select_smart_seeds(X, num_seeds, return_selected_indices=False, init_seeds=None, num_init_seeds=None,
                        metric="cosine", first_index=None, stepwise=False):
     """mean_shift.py:128-189.  The first seed index comes from np.random.randint(0, n) like the
@@ -101,10 +111,13 @@ def mean_shift_smart_init(X, kappa, num_seeds=100, max_iters=10, metric="cosine"
     seeds, selected = select_smart_seeds(X, num_seeds, return_selected_indices=True, metric=metric,
                                          first_index=first_index)
     def rest(seeds):
-        seed_labels, Z = mean_shift_with_seeds(X, seeds, kappa, max_iters=max_iters, metric=metric, precision=precision)
-        # labels are created in order 0, 1, ...: at most one per seed, so num_seeds bounds the histogram of the assignment
+        _cosine_only(metric)
+        Z = seed_hill_climbing_ball(X, seeds, kappa, max_iters=max_iters, metric=metric, precision=precision)
+        seed_labels, num = _components_with_count(Z, 2 * EMBEDDING_ALPHA)
+        # labels are created in order 0, 1, ...: at most one per seed, so num_seeds bounds the histogram of the assignment; the
+        # largest-cluster swap looks at labels 0 .. len(unique(seed_labels)) - 1 only, like the reference (MS:211-222)
         labels, counts = ops.ms_assign(X, Z, seed_labels.to(X.device), seeds.shape[0])
-        ops.ms_relabel_largest_zero(labels, counts)
+        ops.ms_relabel_largest_zero(labels, counts, num)
         return labels
 
     labels = rest(seeds)

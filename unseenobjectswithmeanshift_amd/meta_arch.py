@@ -11,12 +11,25 @@ detectron2 is not a dependency.  The backbone is out of scope (SURVEY.md section
 meta-arch takes any ``backbone`` module mapping an image batch to {"res2".."res5"}; ``None`` means
 the caller already passes backbone features.  Inference only.
 """
+import inspect
+
 import torch
 import torch.nn.functional as F
 from torch import nn
 
 from . import ops
 from ._plan import PlanAttributes
+
+_ACCEPTS = {}
+
+
+def _accepts(method, name):
+    """Does ``method`` take a parameter called ``name``?  (cached per function: inspect.signature costs ~15 us a call)"""
+    f = getattr(method, "__func__", method)
+    key = (f, name)
+    if key not in _ACCEPTS:
+        _ACCEPTS[key] = name in inspect.signature(f).parameters
+    return _ACCEPTS[key]
 
 
 class Instances:
@@ -92,8 +105,8 @@ class MeanShiftMaskFormerHead(PlanAttributes, nn.Module):
         super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
                                       error_msgs)
 
-    def forward(self, features, image_height=None, image_width=None, mask=None):
-        return self.layers(features, image_height, image_width, mask)
+    def forward(self, features, image_height=None, image_width=None, mask=None, final_topk=0):
+        return self.layers(features, image_height, image_width, mask, final_topk)
 
     def set_precision(self, mode):
         """"f32" (the reference's arithmetic, default), "bf16" (BASELINE configs 3 / 5): bf16 MFMA operands with fp32
@@ -115,18 +128,20 @@ class MeanShiftMaskFormerHead(PlanAttributes, nn.Module):
             self.predictor.kv_split = mode == "f32_split"
         return self
 
-    def layers(self, features, image_height=None, image_width=None, mask=None):
+    def layers(self, features, image_height=None, image_width=None, mask=None, final_topk=0):
         """Returns (predictions, last_feature_map).  The reference also upsamples mask_features to
         image size here (meanshift_former_head.py:121-126, 315 MB per 640x480 image) for the
         training-only embedding loss; inference returns None for it."""
         # a predictor that contracts mask_features in their factored form gets them that way (modeling.FoldedMaskFeatures):
         # same predictions up to fp32 summation order, a quarter of the mask step's work
-        import inspect
         kw = {}
-        if getattr(self.predictor, "folded_mask_features", False) and "folded" in inspect.signature(self.pixel_decoder.forward_features).parameters:
+        if getattr(self.predictor, "folded_mask_features", False) and _accepts(self.pixel_decoder.forward_features, "folded"):
             kw["folded"] = True
         mask_features, _, multi_scale_features = self.pixel_decoder.forward_features(features, **kw)
-        predictions = self.predictor(multi_scale_features, mask_features, mask)
+        if final_topk and _accepts(self.predictor.forward, "final_topk"):
+            predictions = self.predictor(multi_scale_features, mask_features, mask, final_topk=final_topk)
+        else:
+            predictions = self.predictor(multi_scale_features, mask_features, mask)
         return predictions, None
 
 
@@ -171,14 +186,12 @@ class MeanShiftMaskFormer(PlanAttributes, nn.Module):
         the features were computed on when the image was padded to the size divisibility (masks are cropped back to
         image_size, PM:275,354-357)."""
         padded_size = tuple(padded_size or image_size)
-        pred = getattr(self.sem_seg_head, "predictor", None)
-        if pred is not None and hasattr(pred, "_final_topk") and getattr(self, "topk_before_masks", True):
-            pred._final_topk = int(self.test_topk_per_image)       # the final mask step only for the queries kept below
-        try:
+        # the final mask step only for the queries kept below (an argument, not module state: two pipelines may share one model)
+        k = int(self.test_topk_per_image) if getattr(self, "topk_before_masks", True) else 0
+        if k and _accepts(self.sem_seg_head.forward, "final_topk"):
+            outputs, _ = self.sem_seg_head(features, padded_size[0], padded_size[1], final_topk=k)
+        else:
             outputs, _ = self.sem_seg_head(features, padded_size[0], padded_size[1])
-        finally:
-            if pred is not None and hasattr(pred, "_final_topk"):
-                pred._final_topk = 0
         if "topk" in outputs:
             cls_scores, classes, qidx = outputs["topk"]
             B, K = qidx.shape

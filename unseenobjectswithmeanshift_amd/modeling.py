@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from . import ops
-from ._plan import PlanAttributes, version_key
+from ._plan import PlanAttributes, TensorList, version_key
 
 KAPPA = 30  # attention_util.py:26
 
@@ -241,7 +241,6 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         # inference entry of the meta-architecture: K > 0 -> the final mask step runs only for the K queries instance_inference
         # keeps (top-K class scores, PM:461-497); the output dict then holds pred_masks (B, K, H, W) and "topk" = (scores, classes,
         # query index).  0: all queries (the reference's head output)
-        self._final_topk = 0               # transient: set by MeanShiftMaskFormer.inference around its head call
         self.pe_layer = PositionEmbeddingSine(hidden_dim // 2, normalize=True)
         self.transformer_self_attention_layers = nn.ModuleList(
             MeanShiftSelfAttentionLayer(hidden_dim, nheads) for _ in range(dec_layers))
@@ -428,7 +427,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                 out.append((int(th), int(tw)))
         return out
 
-    def _forward_fused(self, xs, sizes, kv_w, kv_c, mask_features, out, qpos, kv_all=None):
+    def _forward_fused(self, xs, sizes, kv_w, kv_c, mask_features, out, qpos, kv_all=None, final_topk=0):
         """Same arithmetic as the loop in forward(), with the row-local ops of a layer in three launches:
         heads (+ next cross-attention query) -> mask step -> K/V GEMM -> cross attention -> post_cross (out_proj, LN,
         self-attention in-projection) -> self attention -> post_self (out_proj, LN, FFN by hidden chunk)."""
@@ -457,6 +456,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                     pooled = dict(zip(want_sizes, outs))
         dn = self.decoder_norm
         pred_cls, pred_mask = [], []
+        topk_out = []
 
         def predict(d, e, ra, i_next):
             last = i_next == L
@@ -464,16 +464,16 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             cls = ops.gemm(d, self.class_embed.weight, self.class_embed.bias) if want else None
             tgt = None if (last and not full) else sizes[i_next % self.num_feature_levels]
             emb, qb = (e, None) if ncol is None else (e[..., :ncol], e[..., ncol])
-            if last and not full and ncol is not None and 0 < self._final_topk < e.shape[1] and cls is not None:
+            if last and not full and ncol is not None and 0 < final_topk < e.shape[1] and cls is not None:
                 # only the masks instance_inference keeps: top-K class scores first, then the mask step on those K embeddings
                 # (the top-K launch also copies the kept rows: (B, K, 68) = [e Wm | e.bm | pad], rows 16-byte aligned)
-                *topk, sel = ops.topk_class_scores(cls, int(self._final_topk), gather=e, gather_cols=ncol + 4)
+                *topk, sel = ops.topk_class_scores(cls, int(final_topk), gather=e, gather_cols=ncol + 4)
                 topk = tuple(topk)
                 # (fp32 kernel in every precision mode: one launch on K queries does not pay for a packed copy of the activation)
                 m = ops.mask_logits(sel[..., :ncol], mask_features, want_mask=True, target_size=None, qbias=sel[..., ncol])[0]
                 pred_cls.append(cls)
                 pred_mask.append(m)
-                self._topk_out = topk
+                topk_out.append(topk)
                 return None, None
             if tgt is not None and tuple(tgt) in pooled:
                 attn, row_any = ops.attn_mask_pooled(emb, pooled[tuple(tgt)], qbias=qb, row_any=ra)
@@ -501,7 +501,9 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             # prediction 0 starts from the learned queries: decoder_norm, the mask-embedding MLP and the first cross-attention query
             # do not depend on the input -- computed once per parameter version (the attention mask they feed does: it contracts
             # e0 with this pass's pooled activation)
-            hkey = (tuple(out.shape), str(out.device), self.tails_dtype) + version_key(list(self.parameters()) + fm_params)
+            if getattr(self, "_heads0_params", None) is None:
+                self._heads0_params = TensorList(self.parameters)
+            hkey = (tuple(out.shape), str(out.device), self.tails_dtype) + version_key(self._heads0_params()) + version_key(fm_params)
             hc = getattr(self, "_heads0_cache", None)
             if hc is None or hc[0] != hkey:
                 _, d, e, q, _ = ops.dec_heads(out, dn.weight, dn.bias, mlp, want_out=False, want_d=False, zero_row_any=True, **next_query(0))
@@ -535,16 +537,19 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                                              **next_query(i + 1))
             attn, row_any = predict(d, e, ra, i + 1)
         res = {"pred_logits": pred_cls[-1], "pred_masks": pred_mask[-1], "aux_outputs": []}
-        if getattr(self, "_topk_out", None) is not None:
-            res["topk"], self._topk_out = self._topk_out, None
+        if topk_out:
+            res["topk"] = topk_out[0]
         if full:
             res["aux_outputs"] = [{"pred_logits": a, "pred_masks": b} for a, b in zip(pred_cls[:-1], pred_mask[:-1])]
         return res
 
     @torch.no_grad()
-    def forward(self, x, mask_features, mask=None):
+    def forward(self, x, mask_features, mask=None, *, final_topk=0):
+        """``final_topk`` = K > 0 (MeanShiftMaskFormer.inference): the final mask step runs on the K (query, class) pairs
+        instance_inference keeps (PM:461-497) and the result carries them as "topk"; 0: all queries, like the reference."""
         assert len(x) == self.num_feature_levels
         del mask
+        final_topk = int(final_topk)
         B = x[0].shape[0]
         dev = x[0].device
         E = self.query_feat.weight.shape[1]
@@ -585,7 +590,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         # the default inference plan never runs the full-resolution mask kernel on all queries (attention masks at key resolution,
         # the final step on the top-K embeddings with the fp32 kernel): no packed copy of the activation is needed then
         lean = (folded and self.fused_tails and self.fold_kv and not self.aux_outputs and self.pooled_attention_masks and self.num_layers > 0
-                and mf_planes.shape[1] == 64 and 0 < self._final_topk < self.query_feat.weight.shape[0]
+                and mf_planes.shape[1] == 64 and 0 < final_topk < self.query_feat.weight.shape[0]
                 and len(self._poolable_sizes(mf_planes, sizes)) == len(set((int(a), int(b)) for a, b in sizes)))
         self._packed_mf = ops.pack_mask_features_bf16(mf_planes) if (self.mask_step_dtype == "bf16" and not lean) else None
         # f32_split: the folded 64-channel step as exact three-term bf16 splits on the bf16 matrix pipe (fp32-accurate); the
@@ -608,7 +613,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         L = self.num_layers
         pred_cls, pred_mask = [], []
         if self.fused_tails and self.fold_kv:
-            return self._forward_fused(xs, sizes, kv_w, kv_c, mask_features, out, qpos, kv_all)
+            return self._forward_fused(xs, sizes, kv_w, kv_c, mask_features, out, qpos, kv_all, final_topk)
         d = ops.layernorm(out, self.decoder_norm.weight, self.decoder_norm.bias)
         cls, m, attn, row_any = self._heads(d, mask_features, sizes[0], full or L == 0, full or L == 0)
         pred_cls.append(cls)
@@ -910,9 +915,9 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
         if self.precision not in ("f32", "f32_split", "bf16"):
             raise ValueError("precision must be 'f32', 'f32_split' or 'bf16'")
         if getattr(self, "_enc_params", None) is None:
-            self._enc_params = list(self.transformer.encoder.parameters())
+            self._enc_params = TensorList(lambda: self.transformer.encoder.parameters())
         hm = self._use_hm()
-        key = (str(device), self.precision, hm) + version_key(self._enc_params)
+        key = (str(device), self.precision, hm) + version_key(self._enc_params())
         if self._packed is None or self._packed[0] != key:
             out = []
             for l, layer in enumerate(layers):

@@ -885,19 +885,22 @@ def ms_assign(X, Z, seed_labels, num_labels):
 
 
 def ms_connected_components(Z, epsilon):
-    """mean_shift.py:41-76 on the device: Z (S,64) -> (seed_labels (S,) int64, number of labels created (1,) int32)."""
+    """mean_shift.py:41-76 on the device: Z (S,64) -> (seed_labels (S,) int64, num (2,) int32 = [labels that survive =
+    len(unique(seed_labels)), labels created])."""
     _c(Z, "Z")
     S = Z.shape[0]
     seed_labels = torch.empty((S,), device=Z.device, dtype=torch.int64)
-    num = torch.empty((1,), device=Z.device, dtype=torch.int32)
+    num = torch.empty((2,), device=Z.device, dtype=torch.int32)
     check(lib().msm_ms_connected_components(_p(Z), S, Z.shape[1], float(epsilon), _p(seed_labels), _p(num), _stream()),
           "msm_ms_connected_components")
     return seed_labels, num
 
 
-def ms_relabel_largest_zero(labels, counts):
-    _c(labels, "labels", torch.int64), _c(counts, "counts", torch.int64)
-    rc = lib().msm_ms_relabel_largest_zero(_p(labels), labels.numel(), _p(counts), counts.numel(), _stream())
+def ms_relabel_largest_zero(labels, counts, num_alive=None):
+    """mean_shift.py:211-227 in place: label 0 <-> the first-argmax label of counts[:num], num = len(unique(seed_labels)) read from
+    the device tensor ``num_alive`` (ms_connected_components()[1]) when given, else every entry of counts."""
+    _c(labels, "labels", torch.int64), _c(counts, "counts", torch.int64), _c(num_alive, "num_alive", torch.int32)
+    rc = lib().msm_ms_relabel_largest_zero(_p(labels), labels.numel(), _p(counts), counts.numel(), _p(num_alive), _stream())
     check(rc, "msm_ms_relabel_largest_zero")
     return labels
 

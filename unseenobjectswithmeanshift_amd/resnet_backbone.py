@@ -25,7 +25,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ._plan import PlanAttributes, version_key
+from ._plan import PlanAttributes, TensorList, version_key
 
 STAGE_BLOCKS = {"res2": 3, "res3": 4, "res4": 6, "res5": 3}          # DEPTH 50
 STAGE_WIDTHS = {"res2": (64, 256), "res3": (128, 512), "res4": (256, 1024), "res5": (512, 2048)}     # (bottleneck, out)
@@ -119,11 +119,11 @@ class ResNet50Backbone(PlanAttributes, nn.Module):
 
     def _plan(self):
         if self._plan_tensors is None:
-            self._plan_tensors = list(self.parameters()) + list(self.buffers())
+            self._plan_tensors = TensorList(lambda: list(self.parameters()) + list(self.buffers()))
         if self.backbone_dtype not in ("f32", "bf16"):
             raise ValueError("backbone_dtype must be 'f32' or 'bf16'")
         low = self.backbone_dtype == "bf16"
-        key = version_key(self._plan_tensors) + (low,)
+        key = version_key(self._plan_tensors()) + (low,)
         if self._plan_cache is None or self._plan_cache[0] != key:
             with torch.no_grad():
                 stages = []
