@@ -179,32 +179,70 @@ def cpu_baseline(iters=10, budget_s=28.0):
 
 def pin_to_gpu_numa_node(local_rank):
     """One process per GPU: keep the rank's host threads on the CPUs of the NUMA node its GPU hangs off (launch and
-    event-polling latency; on an 8-GPU node the default is whatever core the launcher forked on).  Best effort -- returns a
-    short description for the JSON line, or None when the topology files are not there."""
+    event-polling latency; on an 8-GPU node the default is whatever core the launcher forked on).  Returns a description for
+    the JSON line with a ``status``: "pinned", "no-topology" (the sysfs files are not there, e.g. in a container: nothing to
+    pin to) or "failed: ..." (the topology is there and the pin did not take -- main() refuses to time a multi-rank job then)."""
     try:
         props = torch.cuda.get_device_properties(local_rank)
         bdf = f"{getattr(props, 'pci_domain_id', 0):04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+    except (AttributeError, RuntimeError) as e:
+        return {"status": f"no-topology (device properties: {e})"}
+    try:
         with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
             node = int(f.read().strip())
-        if node < 0:
-            return None
+    except (OSError, ValueError):
+        return {"status": "no-topology", "pci": bdf}
+    if node < 0:
+        return {"status": "no-topology", "pci": bdf, "numa_node": node}
+    try:
         with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
             cpus = set()
             for part in f.read().strip().split(","):
                 lo, _, hi = part.partition("-")
                 cpus.update(range(int(lo), int(hi or lo) + 1))
-        cpus &= os.sched_getaffinity(0)
-        if not cpus:
-            return None
-        os.sched_setaffinity(0, cpus)
-        return {"pci": bdf, "numa_node": node, "cpus": len(cpus)}
-    except (OSError, ValueError, AttributeError, RuntimeError):
-        return None
+        allowed = cpus & os.sched_getaffinity(0)
+        if not allowed:
+            return {"status": f"failed: none of NUMA node {node}'s {len(cpus)} CPUs is in this process's affinity mask", "pci": bdf, "numa_node": node}
+        os.sched_setaffinity(0, allowed)
+        if os.sched_getaffinity(0) != allowed:
+            return {"status": "failed: sched_setaffinity did not take", "pci": bdf, "numa_node": node}
+        return {"status": "pinned", "pci": bdf, "numa_node": node, "cpus": len(allowed)}
+    except (OSError, ValueError) as e:
+        return {"status": f"failed: {e}", "pci": bdf, "numa_node": node}
 
 
 # ----------------------------------------------------------------------------------------------------------------------
 # measurement helpers
 # ----------------------------------------------------------------------------------------------------------------------
+def load_traffic(name, notes):
+    """profiles/<name> (PMC byte counts of an earlier rocprofv3 pass: they cannot be collected in-process) -- or None when the file
+    is missing, carries no stamp, or was collected on kernel sources that have been edited since (SHA-256 of csrc/<kernel>.hip
+    recorded by tools/summarize_profile.py): a stale count is reported as `traffic: null`, with the reason in the line."""
+    import hashlib
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            tab = json.load(f)
+    except (OSError, ValueError):
+        notes.append(f"{name}: missing")
+        return None
+    st = tab.get("stamp") or {}
+    shas = st.get("kernel_source_sha256")
+    if not shas:
+        notes.append(f"{name}: no provenance stamp")
+        return None
+    for src, want in shas.items():
+        try:
+            with open(os.path.join(ROOT, "unseenobjectswithmeanshift_amd", "csrc", src), "rb") as f:
+                have = hashlib.sha256(f.read()).hexdigest()
+        except OSError:
+            have = None
+        if have != want:
+            notes.append(f"{name}: {src} changed since commit {st.get('commit')} (the counter pass must be re-run)")
+            return None
+    notes.append(f"{name}: collected on commit {st.get('commit')}, kernel sources unchanged")
+    return tab
+
+
 def timed(fn, reps, sync=True):
     """Wall time per call of fn() over `reps` calls (after the caller's own warm-up), device-synchronised."""
     if sync:
@@ -294,6 +332,31 @@ def precision_leg(model, feats, dev, dist, args, precision, inflight, sparse_tap
     model.set_precision(precision)
     model.sem_seg_head.predictor.sparse_taps = bool(sparse_taps)
     model.sem_seg_head.predictor.pooled_attention_masks = bool(pooled)
+    roof = None
+    if precision == "bf16" and model.sem_seg_head.pixel_decoder._use_hm():
+        # the two kernels that dominate the bf16 plan's step, each timed on its own (graph replays of the step's launches with
+        # their real arguments, HIP events on the launch stream): the encoder-layer tail and the MSDeformAttn gather, with the
+        # bytes the algorithm moves per launch (fp16 value / attention / sampling-projection tensors, fp32 residual stream)
+        B = feats[next(iter(feats))].shape[0]
+        tokens = B * ((H // 32) * (W // 32) + (H // 16) * (W // 16) + (H // 8) * (W // 8))
+        step = lambda: model.inference(feats, (H, W))
+        step()
+        e_ms, e_n = entry_graph_ms(step, "encoder_block_hm")
+        g_ms, g_n = entry_graph_ms(step, "ms_deform_attn_encoder_lp")
+        e_bytes = tokens * (128 + 256 + 256) + tokens * (128 + 576) * (e_n - 1) / max(e_n, 1)          # last layer: no value / projection
+        e_flops = 2.0 * tokens * (64 * 64 + 2 * 64 * 1024) + 2.0 * tokens * (64 * 64 + 64 * 288) * (e_n - 1) / max(e_n, 1)
+        g_bytes = tokens * (128 + 576 + 128)
+        e_t, g_t = 1e-3 * e_ms / max(e_n, 1), 1e-3 * g_ms / max(g_n, 1)
+        roof = {"bound": "hbm", "kernel": "enc_block_hm_kernel (msm_encoder_block_hm_fwd): the bf16 plan's encoder-layer tail",
+                "achieved": round(e_bytes / e_t / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(e_bytes / e_t / 1e9 / PEAK_HBM_GBPS, 4),
+                "traffic": None, "launches_per_step": e_n, "avg_launch_ms": round(1e3 * e_t, 4), "algorithmic_bytes_per_launch": e_bytes,
+                "useful_flops_per_launch": e_flops, "useful_tflops": round(e_flops / e_t / 1e12, 1),
+                "frac_of_bf16_mfma_peak": round(e_flops / e_t / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                "gather": {"kernel": "msda_enc_lp_kernel (msm_msdeform_attn_enc_lp_fwd)", "launches_per_step": g_n, "avg_launch_ms": round(1e3 * g_t, 4),
+                           "algorithmic_bytes_per_launch": g_bytes, "achieved_gbps": round(g_bytes / g_t / 1e9, 1),
+                           "frac_of_hbm_peak": round(g_bytes / g_t / 1e9 / PEAK_HBM_GBPS, 4)},
+                "note": "bytes = fp16 attention in + fp32 residual in / out + fp16 value and sampling projection out (none for the last layer); "
+                        "useful FLOPs = the layer's GEMMs once (the kernel issues 2-3 bf16 products per hi + lo operand pair)"}
     lone = PipelinedInference(model, depth=1)
     lone.submit(feats, (H, W))
     lone.drain()
@@ -329,7 +392,7 @@ def precision_leg(model, feats, dev, dist, args, precision, inflight, sparse_tap
     del pipe
     model.set_precision("f32")
     model.sem_seg_head.predictor.sparse_taps = False
-    return feats[next(iter(feats))].shape[0] * steps, elapsed, steps, single
+    return feats[next(iter(feats))].shape[0] * steps, elapsed, steps, single, roof
 
 
 def mean_shift_unit(dev):
@@ -401,13 +464,13 @@ def extra_configs(dev, args):
     # fp32-accurate; csrc/enc_block_split.hip, kv_proj.hip, mask_logits.hip) -- NOT the headline: that keeps the fp32 MFMA everywhere
     class _A:
         steps, min_seconds = 50, 0.5
-    imgs, el, st_, single = precision_leg(model, feats, dev, None, _A, "f32_split", max(1, args.inflight))
+    imgs, el, st_, single, _ = precision_leg(model, feats, dev, None, _A, "f32_split", max(1, args.inflight))
     # the plan of rounds 1-3: every one of the ten mask steps at 120 x 160, the attention-mask taps pooled afterwards
     # (predictor.pooled_attention_masks = False) -- and the same with the nine intermediate steps restricted to the image rows their
     # attention masks sample (decoder.sparse_taps).  Reported next to the headline, which computes the intermediate attention masks at
     # key resolution (csrc/attn_mask.hip: interpolation and contraction commute; SURVEY 8d names the inference-only shortcut)
-    fi, fel, fst, fsingle = precision_leg(model, feats, dev, None, _A, "f32", max(1, args.inflight), pooled=False)
-    si, sel, sst, ssingle = precision_leg(model, feats, dev, None, _A, "f32", max(1, args.inflight), sparse_taps=True, pooled=False)
+    fi, fel, fst, fsingle, _ = precision_leg(model, feats, dev, None, _A, "f32", max(1, args.inflight), pooled=False)
+    si, sel, sst, ssingle, _ = precision_leg(model, feats, dev, None, _A, "f32", max(1, args.inflight), sparse_taps=True, pooled=False)
     model.sem_seg_head.predictor.pooled_attention_masks = True
     out["configs[1] full-resolution mask steps"] = {
         "workload": "batch 8, 640x480, fp32, as the headline except that all ten mask steps run at 120 x 160 (the attention-mask taps pooled "
@@ -699,9 +762,20 @@ def main():
         raise RuntimeError("bench.py needs an MI355X: the hot path has no CPU implementation (oracle/ is test-only)")
     if args.share_gpu:
         local_rank = 0
+    # one process per GPU: a rank that cannot see the device it was told to use, or that would share it with another rank, is a
+    # launch error -- say so instead of timing something else (the first real 8-GPU run either scales or says why)
+    have = torch.cuda.device_count()
+    if local_rank >= have:
+        raise SystemExit(f"bench.py rank {rank}: LOCAL_RANK={local_rank} but this process sees {have} GPU(s) "
+                         f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')!r}, ROCR_VISIBLE_DEVICES={os.environ.get('ROCR_VISIBLE_DEVICES')!r})")
+    if world > 1 and not args.share_gpu and have < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+        raise SystemExit(f"bench.py rank {rank}: {os.environ.get('LOCAL_WORLD_SIZE', world)} local ranks but only {have} GPU(s) visible: ranks would share a device")
     torch.cuda.set_device(local_rank)           # before the process group: RCCL binds its communicator to the current device
     dev = torch.device("cuda", local_rank)
     affinity = pin_to_gpu_numa_node(local_rank)
+    if world > 1 and affinity["status"].startswith("failed"):
+        # a speed matter, not a correctness one: the run goes on, the line says how many ranks are pinned, stderr says why not
+        print(f"bench.py rank {rank}: NOT pinned to the NUMA node of GPU {local_rank}: {affinity}", file=sys.stderr, flush=True)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -781,10 +855,20 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             run_one()
+        t_host = time.perf_counter() - t0           # the host's share: Python + hipGraphLaunch per step, the GPU running behind
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        # what one submit costs the host when the queue is NOT full (a full queue makes submit wait for the GPU: t_host above is
+        # then the GPU's time): 2 x inflight submits into an empty pipeline
+        torch.cuda.synchronize()
+        n_sub = 2 * inflight
+        t1 = time.perf_counter()
+        for _ in range(n_sub):
+            run_one()
+        host_submit_us = 1e6 * (time.perf_counter() - t1) / n_sub
+        torch.cuda.synchronize()
         if pipe is not None:                      # the pipelined slots computed what the single graph computes
             for a, b in zip(pipe.result(0, wait="host"), out):
                 assert torch.equal(a, b), "pipelined slot differs from the single-stream graph"
@@ -798,14 +882,16 @@ def main():
         mask_graph_ms, mask_calls = mask_step_graph_ms(step, model)
         # what the default plan runs for the ten predictions: one full-resolution launch, the pooling launch, nine key-resolution launches
         plan_ms, plan_calls = entry_graph_ms(step, ["mask_logits", "pool_mask_taps", "attn_mask_pooled"])
-        enc_name = {"f32": "encoder_block", "f32_split": "encoder_block_split", "bf16": "encoder_block_lp"}[args.precision]
+        enc_name = {"f32": "encoder_block", "f32_split": "encoder_block_split",
+                    "bf16": "encoder_block_hm" if model.sem_seg_head.pixel_decoder._use_hm() else "encoder_block_lp"}[args.precision]
         enc_ms_all, enc_calls = entry_graph_ms(step, enc_name)
         launch_label = "eager" if graph is None else ("hipgraph" if pipe is None else
                                                       f"hipgraph x{inflight}: {inflight} batches of 8 in flight, one graph + stream each")
 
     scores = out[0]
     checksum = float(scores.double().sum().item())
-    rec = gather_metrics({"images": (hi - lo) * steps, "elapsed_s": elapsed, "checksum": checksum}, dist)
+    rec = gather_metrics({"images": (hi - lo) * steps, "elapsed_s": elapsed, "checksum": checksum, "pinned": float(affinity["status"] == "pinned"),
+                          "host_submit_us": host_submit_us}, dist, keys=("images", "elapsed_s", "checksum", "pinned", "host_submit_us"))
     # BASELINE configs[2] is a bf16 configuration (batch 64 over 8 GPUs): every rank also times its batch of 8 in the low-precision
     # mode, same barriers, same max-over-ranks rule -- a `configs` entry of the line, never `value`
     lp_rec = None
@@ -813,7 +899,7 @@ def main():
         del pipe, graph
         pipe = graph = None
         with torch.cuda.stream(stream):
-            lp_images, lp_elapsed, lp_steps, lp_single = precision_leg(model, feats, dev, dist, args, "bf16", max(1, args.inflight))
+            lp_images, lp_elapsed, lp_steps, lp_single, lp_roof = precision_leg(model, feats, dev, dist, args, "bf16", max(1, args.inflight))
         lp_rec = gather_metrics({"images": lp_images, "elapsed_s": lp_elapsed, "checksum": lp_single}, dist)
     if rank != 0:
         if dist is not None:
@@ -833,18 +919,11 @@ def main():
     flops_exec = 2.0 * Q * c_exec * (H // 4) * (W // 4) * (hi - lo)        # what the kernel issues
     # HBM traffic of the same kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; the
     # gfx950 x2 correction on FETCH_SIZE applied), summarised in profiles/ -- it cannot be measured in-process
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "mask_step_traffic.json")) as f:
-            traffic = json.load(f)["bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
-    traffic_tab = {}
-    try:
-        with open(os.path.join(ROOT, "profiles", "step_traffic.json")) as f:
-            traffic_tab = json.load(f)
-    except (OSError, ValueError):
-        pass
+    traffic, traffic_tab, traffic_note = None, {}, []
+    mt = load_traffic("mask_step_traffic.json", traffic_note)
+    if mt is not None:
+        traffic = mt.get("bytes_per_launch")
+    traffic_tab = load_traffic("step_traffic.json", traffic_note) or {}
     pooled_plan = bool(pred.pooled_attention_masks) and folded
     # the mask step (the kernel BASELINE's metric names).  `kernel_*`: the full-resolution kernel characterised over the ten launches
     # of a pass that runs every prediction at 120 x 160 (comparable with rounds 1-3); `plan_*`: what the default plan launches for the
@@ -888,6 +967,7 @@ def main():
                 "timing": "HIP events on the launch stream around 100 graph replays of the step's encoder-block launches (back to back, real arguments)",
                 "matrix_pipe": enc_unit_note,
                 "algorithmic_bytes_per_launch": (traffic_tab.get("enc_block_kernel") or {}).get("algorithmic_bytes_per_launch"),
+                "traffic_provenance": traffic_note,
                 "mask_step": mask_step,
                 "note": "rounds 1-3 put the mask step here; with the intermediate attention masks computed at key resolution it is 1-2 % of the "
                         "step, so the object describes the kernel that dominates (MFMA-bound: 315 kFLOP per token against 2.3 KB of traffic) and "
@@ -915,7 +995,8 @@ def main():
                    "batches_in_flight": inflight,
                    "sparse_taps": bool(args.sparse_taps), "folded_mask_step": folded, "attention_masks_at_key_resolution": pooled_plan,
                    "parallelism": f"dp{world}"},
-        "per_rank": [{"rank": i, "images_per_sec": round(r["images"] / r["elapsed_s"], 2), "checksum": r["checksum"]} for i, r in enumerate(rec)],
+        "per_rank": [{"rank": i, "images_per_sec": round(r["images"] / r["elapsed_s"], 2), "checksum": r["checksum"],
+                      "numa_pinned": bool(r["pinned"]), "host_submit_us_per_step": round(r["host_submit_us"], 1)} for i, r in enumerate(rec)],
         "roofline": roofline,
         "kernels": {"launch": "eager, HIP events on the launch stream around every library entry point, mean of 3 passes", "by_entry_point": kernels,
                     "sum_ms_per_step": round(sum(v["ms_per_step"] for v in kernels.values()), 4)},
@@ -925,6 +1006,12 @@ def main():
         result["one_batch_in_flight"] = {"value": round((hi - lo) * single_steps / single, 2), "unit": "images/sec",
                                          "ms_per_step": round(1e3 * single / single_steps, 4), "steps": single_steps}
     result["config"]["rank0_cpu_affinity"] = affinity
+    # multi-GPU readiness (no 8-GPU node was available to the builder): what a rank's host spends per step, and the hardware-queue
+    # budget the streams of the pipelined mode share
+    result["host_submit_us_per_step"] = round(host_submit_us, 1)
+    result["host_loop_share_of_step"] = round(t_host / elapsed, 3)
+    result["config"]["GPU_MAX_HW_QUEUES"] = os.environ.get("GPU_MAX_HW_QUEUES")
+    result["config"]["visible_gpus"] = have
     if lp_rec is not None:
         lp_t = max(r["elapsed_s"] for r in lp_rec)
         result.setdefault("configs", {})["configs[2]"] = {
@@ -933,7 +1020,9 @@ def main():
             "value": round(sum(r["images"] for r in lp_rec) / lp_t, 1), "unit": "images/sec", "n_gpus": world, "steps": lp_steps,
             "ms_per_step": round(1e3 * lp_t / lp_steps, 4), "dtype": "bf16 operands / fp32 accumulation",
             "one_batch_in_flight": {"value": round(BATCH / lp_single, 1), "unit": "images/sec per GPU (rank 0)", "ms_per_step": round(1e3 * lp_single, 4)},
-            "per_rank_images_per_sec": [round(r["images"] / r["elapsed_s"], 1) for r in lp_rec]}
+            "per_rank_images_per_sec": [round(r["images"] / r["elapsed_s"], 1) for r in lp_rec],
+            "storage": "fp16 value / attention / sampling-projection tensors between the encoder kernels (csrc/enc_lp.hip), bf16 K/V, fp32 residual streams",
+            "roofline": lp_roof}
     if world == 1 and not args.no_extras:
         pipe = graph = None
         result["mean_shift"] = mean_shift_unit(dev)

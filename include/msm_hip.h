@@ -9,8 +9,10 @@
  *     void* so that the header needs no HIP include);
  *   - every function returns MSM_OK (0) or a negative MSM_E_* code; msm_last_error_string()
  *     describes the last failure on the calling thread;
- *   - all floating-point data is fp32 (the reference op dispatches float/double only,
- *     ops/src/cuda/ms_deform_attn_cuda.cu:69); token tensors are batch-major [B][L][E].
+ *   - floating-point data is fp32 unless an entry point says otherwise: the native-op replacements also come in double
+ *     (`_f64`: the reference op dispatches float and double, ops/src/cuda/ms_deform_attn_cuda.cu:69,139), the low-precision
+ *     plan's entry points (`_bf16`, `_lp`, `_hm`) take or produce bf16 / fp16 tensors and weight streams as documented per
+ *     function; token tensors are batch-major [B][L][E].
  *
  * Reference interfaces replaced (paths relative to the reference root, "OPS" =
  * MSMFormer/meanshiftformer/modeling/pixel_decoder/ops, "DEC" = .../transformer_decoder/

@@ -79,6 +79,16 @@ def test_bench_launcher_spawns_ranks_gloo_stub():
     # each rank's checksum comes from its own data (rank r multiplies matrices of r+1): 64*64*64*(r+1)^2
     assert [p["checksum"] for p in rec["per_rank"]] == [64.0 ** 3, 4 * 64.0 ** 3]
     assert rec["value"] > 0 and abs(rec["value"] - 112 / (rec["ms_per_step"] * 7e-3)) < 1e-2 * rec["value"]
+    # the size the driver's scaling run uses: eight ranks, one JSON line, every rank's record gathered
+    r8 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--stub", "--steps", "3", "--warmup", "1"],
+                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r8.returncode == 0, r8.stderr[-2000:]
+    lines = [l for l in r8.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec8 = json.loads(lines[0])
+    assert rec8["n_gpus"] == 8 and rec8["config"]["global_batch"] == 64 and rec8["config"]["parallelism"] == "dp8"
+    assert [p["rank"] for p in rec8["per_rank"]] == list(range(8)) and all(p["images"] == 24.0 for p in rec8["per_rank"])
+    assert [p["checksum"] for p in rec8["per_rank"]] == [(k + 1) ** 2 * 64.0 ** 3 for k in range(8)]
     # under torch.distributed.run the ranks exist already (WORLD_SIZE set): a --gpus that disagrees is refused
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub"], capture_output=True, text=True,
                          timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0"), cwd=root)

@@ -43,7 +43,25 @@ for pmc in sys.argv[3:]:
         for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:25]:
             f.write(f"| `{k[:90]}` | {len(v)} | {sum(v) / len(v):.0f} |\n")
 # HBM traffic of the dominant kernel (mask step), per launch, averaged over its dispatch variants by call count
+import hashlib
 import json
+import subprocess
+
+
+def stamp(*sources):
+    """Provenance of a traffic file: the commit it was collected on and the SHA-256 of the kernel sources it describes.  bench.py
+    reports `traffic: null` when a source no longer hashes to what is recorded here (a kernel edit silently desynchronising the
+    committed byte counts from the timed kernel was the round-3 review's finding)."""
+    def sha(name):
+        with open(os.path.join("unseenobjectswithmeanshift_amd", "csrc", name), "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()
+    try:
+        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except OSError:
+        commit = None
+    return {"commit": commit, "kernel_source_sha256": {n: sha(n) for n in sources}}
+
+
 vals = {}
 for pmc in sys.argv[3:]:
     fs = glob.glob(os.path.join(pmc, "*counter_collection.csv"))
@@ -63,7 +81,8 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
                "note": "mean over the 10 launches of a step (9 write only attention-mask bytes, 1 writes the full mask); "
                        "FETCH_SIZE doubled per MI355X_MICROARCH.md (HBM section), WRITE_SIZE as reported; folded mask step "
                        "(64-channel activation instead of the 256-channel mask_features tensor)",
-               "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes ({tag})"},
+               "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes ({tag})",
+               "stamp": stamp("mask_logits.hip")},
               open("profiles/mask_step_traffic.json", "w"), indent=1)
 # step_traffic.json: the dominant kernel (encoder block) and the one full-resolution mask launch of a step (bench.py reads it)
 def per_launch(match):
@@ -92,5 +111,6 @@ if enc and fin:
                         "inference plan, on all queries in the roofline leg of bench.py), averaged"})
     json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes ({tag}, tools/profile_round.sh); FETCH_SIZE doubled per "
                          "MI355X_MICROARCH.md (HBM section), WRITE_SIZE as reported; KB -> bytes",
+               "stamp": stamp("enc_block.hip", "mask_logits.hip"),
                "enc_block_kernel": enc, "mask_logits_kernel_final": fin}, open("profiles/step_traffic.json", "w"), indent=1)
 print("ok")

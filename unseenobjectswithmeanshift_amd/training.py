@@ -28,6 +28,26 @@ from . import ops
 KAPPA = 30.0  # attention_util.py:26
 
 
+class MSDeformAttnFunction(torch.autograd.Function):
+    """The MSDeformAttn core under autograd, both passes in libmsm_hip.so (float and double): the counterpart of the reference's
+    ops/functions/ms_deform_attn_func.py:32-49 for code that builds on this package; the reference's own class works unmodified
+    on the drop-in module (MultiScaleDeformableAttention.py).  apply(value, spatial_shapes, level_start_index, sampling_locations,
+    attention_weights, im2col_step) -> (N, Lq, M * D)."""
+
+    @staticmethod
+    def forward(ctx, value, spatial_shapes, level_start_index, sampling_locations, attention_weights, im2col_step=64):
+        from . import MultiScaleDeformableAttention as msda
+        ctx.step = im2col_step
+        ctx.save_for_backward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights)
+        return msda.ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_locations, attention_weights, im2col_step)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        from . import MultiScaleDeformableAttention as msda
+        grads = msda.ms_deform_attn_backward(*ctx.saved_tensors, grad_output.contiguous(), ctx.step)
+        return grads[0], None, None, grads[1], grads[2], None
+
+
 def _t2(x):
     """(R, C) -> (C, R) contiguous through the library's transpose kernel."""
     return ops.transpose_last2(x.reshape(1, *x.shape))[0]

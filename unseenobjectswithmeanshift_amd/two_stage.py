@@ -98,24 +98,34 @@ def crop_rois(rgb, initial_masks, depth, crop_size=CROP_SIZE):
     dev = rgb.device
     boxes = _label_boxes(initial_masks[0])
     n = len(boxes)
-    rgb_crops = torch.zeros((n, 3, crop_size, crop_size), device=dev)
-    mask_crops = torch.zeros((n, crop_size, crop_size), device=dev)
-    depth_crops = torch.zeros((n, 3, crop_size, crop_size), device=dev) if depth is not None else None
     size = (crop_size, crop_size)
-    rois_host = []
-    for k, (mask_id, x0, y0, x1, y1) in enumerate(boxes):
+    rois_host, table = [], []
+    for mask_id, x0, y0, x1, y1 in boxes:
         # round(): half to even, as the reference's torch.round on the exact product (test_dataset.py:83-84)
         xp, yp = int(round((x1 - x0) * PADDING_PERCENTAGE)), int(round((y1 - y0) * PADDING_PERCENTAGE))
         x0, x1 = max(x0 - xp, 0), min(x1 + xp, W - 1)
         y0, y1 = max(y0 - yp, 0), min(y1 + yp, H - 1)
         rois_host.append([x0, y0, x1, y1])
+        table.append([0, int(mask_id), x0, y0, x1, y1, 0, 0])
+    rois = torch.tensor(rois_host, dtype=torch.float32).reshape(n, 4).to(dev)
+    if rgb.is_cuda and n > 0:
+        # device tensors: every crop of the frame in ONE launch of the kernel the batched pipeline uses (msm_crop_resize: bilinear
+        # align_corners=True for rgb / depth, nearest for the mask, ATen's index arithmetic -- tests pin it to the loop below)
+        tab = torch.tensor(table, dtype=torch.int32, device=dev)
+        rgb_crops, mask_crops, depth_crops = ops.crop_resize(rgb[0:1].float().contiguous(), None if depth is None else depth[0:1].float().contiguous(),
+                                                             initial_masks[0:1].float().contiguous(), tab, crop_size)
+        return rgb_crops, mask_crops, rois, depth_crops
+    # host tensors (unit tests of the harness logic without a GPU): the reference's per-ROI loop
+    rgb_crops = torch.zeros((n, 3, crop_size, crop_size), device=dev)
+    mask_crops = torch.zeros((n, crop_size, crop_size), device=dev)
+    depth_crops = torch.zeros((n, 3, crop_size, crop_size), device=dev) if depth is not None else None
+    for k, (mask_id, x0, y0, x1, y1) in enumerate([(t[1], *t[2:6]) for t in table]):
         mask = (initial_masks[0, y0:y1 + 1, x0:x1 + 1] == mask_id).float()
         rgb_crops[k] = F.interpolate(rgb[0:1, :, y0:y1 + 1, x0:x1 + 1], size=size, mode="bilinear", align_corners=True)[0]
         mask_crops[k] = F.interpolate(mask[None, None], size=size, mode="nearest")[0, 0]
         if depth is not None:
             depth_crops[k] = F.interpolate(depth[0:1, :, y0:y1 + 1, x0:x1 + 1], size=size, mode="bilinear",
                                            align_corners=True)[0]
-    rois = torch.tensor(rois_host, dtype=torch.float32).reshape(n, 4).to(dev)
     return rgb_crops, mask_crops, rois, depth_crops
 
 
