@@ -463,6 +463,20 @@ int msm_ms_hill_climb(const float* X, int n, int d, float* Z, int S, float kappa
 int64_t msm_ms_hill_climb_split_workspace(int n, int S);
 int msm_ms_hill_climb_split(const float* X, int n, int d, float* Z, int S, float kappa, int iters,
                             float* workspace, int64_t workspace_elems, void* stream);
+/* ---- precision "bf16" of the classic clustering (BASELINE configs[4]: n = 1 228 800, 300 seeds, 20 iterations, "HBM-bound stress") ----
+ * One bf16 copy of X (rows padded with zeros to msm_ms_bf16_rows(n), a multiple of 32) serves seeding and the hill climb: half the
+ * bytes of the S seeding passes (lib/utils/mean_shift.py:128-189: at this size nothing but an HBM stream), one plane instead of
+ * three in the hill climb (MS:79-109) with single bf16 products except the seeds (h + l terms).  Distances are those of the rounded
+ * points: seeds and labels equal the fp32 results up to which member of a cluster is picked / a permutation of the labels
+ * (SURVEY 8c); the fp32 and f32_split entry points stay exact.
+ * msm_ms_select_seeds_bf16: workspace as msm_ms_select_seeds (msm_ms_seed_workspace(n) floats); seeds_out are rows of the fp32 X
+ * (MS:186-189 returns X[selected]); n >= 16.  msm_ms_hill_climb_bf16: workspace msm_ms_hill_climb_workspace(n, S) floats. */
+int64_t msm_ms_bf16_rows(int n);
+int msm_ms_pack_bf16(const float* X, int n, int d, void* Xb, void* stream);
+int msm_ms_select_seeds_bf16(const void* Xb, const float* X, int n, int d, int num_seeds, int64_t first_index, float* seeds_out,
+                             int64_t* indices_out, float* workspace, int64_t workspace_elems, void* stream);
+int msm_ms_hill_climb_bf16(const void* Xb, int n, int d, float* Z, int S, float kappa, int iters, float* workspace,
+                           int64_t workspace_elems, void* stream);
 /* closest = first argmin_s 0.5*(1 - X.Z_s); labels_out[i] = seed_labels[closest] (int64);
  * counts int64 [num_labels] histogram of labels_out (zeroed here) (MS:206-221). */
 int msm_ms_assign(const float* X, int n, int d, const float* Z, int S, const int64_t* seed_labels,

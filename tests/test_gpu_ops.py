@@ -684,7 +684,55 @@ def test_mean_shift_hill_climb_split(n, S, iters, lib_option):
     zfb = ops().ms_hill_climb(X.to(DEV), seeds.to(DEV), 20.0, iters, precision="f32_split").cpu().double()
     assert torch.equal(zfb, zsp)
     with pytest.raises(ValueError):
-        ops().ms_hill_climb(X.to(DEV), seeds.to(DEV), 20.0, 1, precision="bf16")
+        ops().ms_hill_climb(X.to(DEV), seeds.to(DEV), 20.0, 1, precision="fp8")
+
+
+@pytest.mark.parametrize("n,S,iters", [(2000, 20, 10), (37, 1, 3), (4111, 50, 4), (5000, 300, 3), (19200, 100, 10), (31, 17, 2), (40000, 161, 5)])
+def test_mean_shift_hill_climb_bf16(n, S, iters):
+    """msm_ms_hill_climb_bf16 (precision "bf16": one bf16 plane of X, seeds as h + l terms, single bf16 weights): against the float64
+    iteration ON THE ROUNDED POINTS (what the kernel is given) the only error left is the rounding of the exp() weights to bf16
+    (2^-9 each, averaged over a cluster's points) and fp32 accumulation; against the exact iteration the points' own rounding
+    comes on top.  Seed counts around the block sizes (one wave carries up to ten seed blocks: S = 161 -> 11 blocks, 6 per wave)."""
+    from unseenobjectswithmeanshift_amd import synthetic as syn
+    X, _ = syn.synth_unit_embeddings(n, 64, clusters=6, sigma=0.15, seed=n)
+    seeds = X[torch.randperm(n, generator=torch.Generator().manual_seed(S))[:S]] if S <= n else X[:S]
+    seeds = seeds.contiguous()
+    xb = ops().ms_pack_bf16(X.to(DEV))
+    assert xb.dtype == torch.bfloat16 and xb.shape == ((n + 31) // 32 * 32, 64)
+    assert torch.equal(xb[:n].cpu(), X.to(torch.bfloat16)) and float(xb[n:].float().abs().sum()) == 0.0
+    ref_r = _hill_f64(X.to(torch.bfloat16).float(), seeds, 20.0, iters)
+    ref = _hill_f64(X, seeds, 20.0, iters)
+    z = ops().ms_hill_climb(X.to(DEV), seeds.to(DEV), 20.0, iters, precision="bf16", xb=xb).cpu().double()
+    z2 = ops().ms_hill_climb(X.to(DEV), seeds.to(DEV), 20.0, iters, precision="bf16").cpu().double()          # makes its own copy
+    assert torch.equal(z, z2)
+    er, ex = (z - ref_r).abs().max().item(), (z - ref).abs().max().item()
+    print(f"hill climb bf16 n={n} S={S}: max |err| vs float64 on the rounded points {er:.2e}, on the exact points {ex:.2e}")
+    assert er < 2e-3 and ex < 4e-3
+    assert float((z.norm(dim=1) - 1).abs().max()) < 1e-5
+
+
+def test_mean_shift_seeding_bf16_streams_the_copy():
+    """msm_ms_select_seeds_bf16 (maps beyond the persistent kernel's 393 216 rows, precision "bf16"): farthest-point seeding on the
+    bf16 copy equals the fp32 stepwise kernel run ON THE ROUNDED POINTS index for index (same key, same butterfly; the dot products
+    differ only in fp32 summation order: checked on planted clusters where no two candidates tie), and returns rows of the fp32 X."""
+    from unseenobjectswithmeanshift_amd import synthetic as syn
+    n, S = 400000, 40
+    X, _ = syn.synth_unit_embeddings(n, 64, clusters=10, sigma=0.2, seed=5)
+    Xd = X.to(DEV)
+    xb = ops().ms_pack_bf16(Xd)
+    seeds, sel = ops().ms_select_seeds(Xd, S, 123, xb=xb)
+    Xr = torch.nn.functional.normalize(X.to(torch.bfloat16).float(), dim=1) * X.to(torch.bfloat16).float().norm(dim=1, keepdim=True)   # = the rounded points
+    _, sel_r = ops().ms_select_seeds(Xr.to(DEV).contiguous(), S, 123, stepwise=True)
+    assert int(sel[0]) == 123 and sel.unique().numel() == S
+    agree = float((sel == sel_r).float().mean())
+    print(f"bf16 seeding vs fp32 kernel on the rounded points: {agree:.3f} of the indices equal")
+    assert agree >= 0.9                                   # (a near-tie may resolve the other way under another summation order)
+    assert torch.equal(seeds.cpu(), X[sel.cpu()])
+    # small maps keep the fp32 persistent kernel whatever the precision
+    Xs = Xd[:5000].contiguous()
+    s1, i1 = ops().ms_select_seeds(Xs, 10, 7, xb=ops().ms_pack_bf16(Xs))
+    s2, i2 = ops().ms_select_seeds(Xs, 10, 7)
+    assert torch.equal(i1, i2) and torch.equal(s1, s2)
 
 
 # ---------------------------------------------------------------------------------------------

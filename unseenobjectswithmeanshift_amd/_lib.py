@@ -94,6 +94,10 @@ _SIGNATURES = {
     "msm_ms_hill_climb": (c_i, [c_f, c_i, c_i, c_f, c_i, c_fl, c_i, c_f, c_l, c_p]),
     "msm_ms_hill_climb_split_workspace": (c_l, [c_i, c_i]),
     "msm_ms_hill_climb_split": (c_i, [c_f, c_i, c_i, c_f, c_i, c_fl, c_i, c_f, c_l, c_p]),
+    "msm_ms_bf16_rows": (c_l, [c_i]),
+    "msm_ms_pack_bf16": (c_i, [c_f, c_i, c_i, c_p, c_p]),
+    "msm_ms_select_seeds_bf16": (c_i, [c_p, c_f, c_i, c_i, c_i, c_l, c_f, c_p, c_f, c_l, c_p]),
+    "msm_ms_hill_climb_bf16": (c_i, [c_p, c_i, c_i, c_f, c_i, c_fl, c_i, c_f, c_l, c_p]),
     "msm_ms_assign": (c_i, [c_f, c_i, c_i, c_f, c_i, c_p, c_p, c_p, c_i, c_p]),
     "msm_ms_connected_components": (c_i, [c_f, c_i, c_i, c_fl, c_p, c_p, c_p]),
     "msm_ms_relabel_largest_zero": (c_i, [c_p, c_i, c_p, c_i, c_p, c_p]),

@@ -139,6 +139,116 @@ __global__ __launch_bounds__(256) void ms_seed_step_kernel(const float* __restri
     }
 }
 
+// ---- the same step on a bf16 copy of X (precision "bf16": BASELINE configs[4], n = 1 228 800, 300 seeds) ------------------------
+// At that size seeding is S passes over X and nothing else: 300 x 314 MB = 94 GB, 15.5 ms at 6.1 TB/s -- the fp32 kernel sits on
+// the HBM wall (0.76 of the 8 TB/s peak, 0.97 of what a copy reaches).  The only way through is fewer bytes: a bf16 copy of X
+// (made once per clustering, ms_pack_bf16_kernel) is 157 MB, half the stream and small enough for the 256 MB Infinity Cache to
+// hold between the steps.  Distances are then those of the ROUNDED points (|d - d_fp32| < 2^-9): the seeds are a farthest-point
+// set of the same clusters, not the same indices (labels identical up to permutation on planted clusters) -- tests
+// compare this mode by cluster structure, the fp32 / f32_split modes exactly.
+// Same mapping as ms_seed_step_kernel: 16 lanes own 16 rows; a lane loads its 8-byte chunk (4 bf16) of each row, the dot product
+// is two v_dot2_f32_bf16 per row against the winner's chunk, the butterfly and the (value, ~index) key are unchanged.
+typedef __bf16 ms_bf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot4_bf16(uint2 a, uint2 b) {
+    float acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(ms_bf2, a.x), __builtin_bit_cast(ms_bf2, b.x), 0.f, false);
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(ms_bf2, a.y), __builtin_bit_cast(ms_bf2, b.y), acc, false);
+}
+
+__global__ __launch_bounds__(256) void ms_pack_bf16_kernel(const float* __restrict__ X, int n, int n_pad, uint16_t* __restrict__ Xb) {
+    const int64_t total4 = (int64_t)n_pad * (MS_D / 4);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = (i < (int64_t)n * (MS_D / 4)) ? *reinterpret_cast<const float4*>(X + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<u32x2b*>(Xb + i * 4) = __builtin_bit_cast(u32x2b, pack4(v.x, v.y, v.z, v.w));
+    }
+}
+
+// n >= 16 (the caller takes the fp32 kernel below that)
+__global__ __launch_bounds__(256) void ms_seed_step_bf16_kernel(const uint16_t* __restrict__ Xb, int n, unsigned long long* __restrict__ keys,
+                                                                int step, float* __restrict__ nearest) {
+    __shared__ uint2 seed2[16];
+    __shared__ unsigned long long red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, grp = lane >> 4;
+    const int rows_per_block = (((n + gridDim.x - 1) / gridDim.x) + 15) & ~15;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
+    int base = r0 + (wave * 4 + grp) * 16;
+    const unsigned long long prev = keys[step - 1];
+    uint2 x[16];
+    int gb = min(base, n - 16);
+    {
+        const uint16_t* src = Xb + (int64_t)gb * MS_D + j * 4;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = *reinterpret_cast<const uint2*>(src + i * MS_D);
+    }
+    float near = (step > 1) ? nearest[min(gb + j, n - 1)] : INFINITY;
+    const unsigned int cur = 0xFFFFFFFFu - (unsigned int)(prev & 0xFFFFFFFFull);
+    if (tid < 16) seed2[tid] = *reinterpret_cast<const uint2*>(Xb + (int64_t)cur * MS_D + tid * 4);
+    __syncthreads();
+    const uint2 s = seed2[j];
+    unsigned long long best = 0ull;
+    for (int pass = 0; base < r1; base += 256, ++pass) {
+        if (pass > 0) {
+            gb = min(base, n - 16);
+            const uint16_t* src = Xb + (int64_t)gb * MS_D + j * 4;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[i] = *reinterpret_cast<const uint2*>(src + i * MS_D);
+            if (step > 1) near = nearest[min(gb + j, n - 1)];
+        }
+        float p[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) p[i] = dot4_bf16(x[i], s);
+        const float near_now = near;
+        const int row = gb + j;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool hi = j & 8;
+            const float send = hi ? p[i] : p[i + 8];
+            const float keep = hi ? p[i + 8] : p[i];
+            p[i] = keep + __shfl_xor(send, 8, 64);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool hi = j & 4;
+            const float send = hi ? p[i] : p[i + 4];
+            const float keep = hi ? p[i + 4] : p[i];
+            p[i] = keep + __shfl_xor(send, 4, 64);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool hi = j & 2;
+            const float send = hi ? p[i] : p[i + 2];
+            const float keep = hi ? p[i + 2] : p[i];
+            p[i] = keep + __shfl_xor(send, 2, 64);
+        }
+        {
+            const bool hi = j & 1;
+            const float send = hi ? p[0] : p[1];
+            const float keep = hi ? p[1] : p[0];
+            p[0] = keep + __shfl_xor(send, 1, 64);
+        }
+        if (row < n) {
+            const float d = fminf(near_now, 0.5f * (1.0f - p[0]));
+            nearest[row] = d;
+            const unsigned long long key = ((unsigned long long)ordered_bits(d) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)row);
+            best = key > best ? key : best;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(best, o, 64);
+        best = other > best ? other : best;
+    }
+    if (lane == 0) red[wave] = best;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long b = red[0];
+        b = red[1] > b ? red[1] : b;
+        b = red[2] > b ? red[2] : b;
+        b = red[3] > b ? red[3] : b;
+        if (b) atomicMax(&keys[step], b);
+    }
+}
+
 // ---- persistent seeding for maps that fit the register file -----------------------------------------------------
 // All S-1 farthest-point steps in ONE launch: X (n x 64 fp32 = 79 MB at 640x480) is read once into VGPRs -- a workgroup
 // of 8 waves holds 512*NG rows, 200 workgroups hold the map -- and every step is a dot product against the previous
@@ -841,6 +951,150 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int i = tid; i < zrows * MS_D; i += 512) dst[i] = accum[i];
 }
 
+// ---- the step in the low-precision mode (precision "bf16": BASELINE configs[4]) ---------------------------------------------------
+// ms_hill_planes_kernel with ONE bf16 plane of X and single-term products: scores = Z(h + l) . x (the seeds keep both terms: an
+// error in z moves every weight of its row the same way), W = bf16(exp(kappa s)), W X one MFMA per column block -- 12 MFMAs per
+// (32-point slab, 16-seed block) instead of 48, ~25 vector instructions instead of ~90, 4 KiB of tile instead of 12.  With the
+// operands a third of the size a wave carries up to ten seed blocks (160 accumulator registers), so all 19 blocks of 300 seeds
+// are ONE launch per iteration and X (157 MB at n = 1 228 800) is read once per iteration instead of three times.
+constexpr int HB_TILE = HS_ROWS * MS_D * 2;        // bytes of a slab tile (one bf16 plane)
+
+template <int NSBW>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void ms_hill_bf16_kernel(const uint16_t* __restrict__ Xb, int n,
+                                                                                                         const float* __restrict__ Z, int S, int nsb,
+                                                                                                         float kappa, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int zrows = nsb * 16;
+    uint16_t* zp = reinterpret_cast<uint16_t*>(lds);                               // [2][zrows][ZP_LD]: h, l terms of Z
+    const size_t zbytes = (size_t)2 * zrows * ZP_LD * 2, abytes = (size_t)zrows * MS_D * 4;
+    char* tiles = reinterpret_cast<char*>(lds) + (zbytes > abytes ? zbytes : abytes);      // [4 pairs][2 buffers][HB_TILE], clear of `accum`
+    float* accum = lds;                                                            // [zrows][64] after the loop
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    for (int i = tid; i < zrows * (MS_D / 4); i += 512) {
+        const int s = i / (MS_D / 4), c4 = (i - s * (MS_D / 4)) * 4;
+        const float4 v = (s < S) ? *reinterpret_cast<const float4*>(Z + (int64_t)s * MS_D + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const Split4 t = split4(v.x, v.y, v.z, v.w);
+        *reinterpret_cast<u32x2b*>(zp + (0 * zrows + s) * ZP_LD + c4) = __builtin_bit_cast(u32x2b, t.hi);
+        *reinterpret_cast<u32x2b*>(zp + (1 * zrows + s) * ZP_LD + c4) = __builtin_bit_cast(u32x2b, t.lo);
+    }
+    const int pg = wave & 3, sh = wave >> 2, sb0 = sh * NSBW;
+    const int nb = min(NSBW, nsb - sb0);
+    char* tile0 = tiles + pg * 2 * HB_TILE;
+    const unsigned tile_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)tile0;
+
+    f32x4 zn[NSBW][4];
+#pragma unroll
+    for (int sb = 0; sb < NSBW; ++sb)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) zn[sb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const float kl2 = kappa * 1.4426950408889634f;
+    const int nslabs = (n + HS_ROWS - 1) / HS_ROWS;
+    const int stride = (int)gridDim.x * 4;
+    const int iters = (nslabs - (int)blockIdx.x * 4 + stride - 1) / stride;
+    // DMA piece I = 0..3 of a tile: rows 8 I .. + 7; lane L writes slot L of the piece = row L / 8, position L % 8, which holds
+    // chunk (L % 8) ^ (row & 7) of that row (the swizzle of ms_hill_planes_kernel); the two waves of a pair take two pieces each
+    const unsigned dma_off = (unsigned)((lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) * 16));
+    auto issue = [&](int sl, int buf) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int quarter = sh * 2 + k;
+            const char* sbase = reinterpret_cast<const char*>(Xb + ((int64_t)sl * HS_ROWS + quarter * 8) * MS_D);
+            ms_glds16(sbase, dma_off, tile_lds + (unsigned)(buf * HB_TILE + quarter * 1024));
+        }
+    };
+    unsigned a_off[2], b_off[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) a_off[h] = (unsigned)((lj * 8 + ((h * 4 + lq) ^ (lj & 7))) * 16);
+    {
+        const int row = 4 * lq + (lj >> 2);
+#pragma unroll
+        for (int db = 0; db < 4; ++db) b_off[db] = (unsigned)((row * 8 + ((db * 2 + ((lj & 3) >> 1)) ^ (row & 7))) * 16 + (lj & 1) * 8);
+    }
+    const int sl0 = (int)blockIdx.x * 4 + pg;
+    if (sl0 < nslabs) issue(sl0, 0);
+    __shared__ int arrive_b[4];
+    if (tid < 4) arrive_b[tid] = 0;
+    __syncthreads();              // Z planes staged, counters cleared
+    for (int it = 0; it < iters; ++it) {
+        const int sl = sl0 + it * stride, buf = it & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(&arrive_b[pg], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(&arrive_b[pg], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 2 * (it + 1)) __builtin_amdgcn_s_sleep(1);
+        if (sl + stride < nslabs) issue(sl + stride, buf ^ 1);
+        if (sl < nslabs) {
+            const int p0 = sl * HS_ROWS;
+            const char* T = tile0 + buf * HB_TILE;
+            bf16x8 xa[2][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) xa[q][h] = *reinterpret_cast<const bf16x8*>(T + a_off[h] + q * 2048);
+            bf16x8 xb[4];
+#pragma unroll
+            for (int db = 0; db < 4; ++db) xb[db] = cat8(lds_read_tr16(T + b_off[db]), lds_read_tr16(T + b_off[db] + 2048));
+            const bool tail = p0 + HS_ROWS > n;
+            f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, sbv = sa;
+            auto score = [&](int sb, f32x4& oa, f32x4& ob) {
+                f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = a;
+#pragma unroll
+                for (int t = 1; t >= 0; --t)                    // low-order term first
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const bf16x8 zf = *reinterpret_cast<const bf16x8*>(zp + (t * zrows + (sb0 + sb) * 16 + lj) * ZP_LD + h * 32 + lq * 8);
+                        a = mfma_k32(xa[0][h], zf, a);
+                        b = mfma_k32(xa[1][h], zf, b);
+                    }
+                oa = a;
+                ob = b;
+            };
+            if (nb > 0) score(0, sa, sbv);
+#pragma unroll
+            for (int sb = 0; sb < NSBW; ++sb) {
+                if (sb < nb) {
+                    const f32x4 ca = sa, cb = sbv;
+                    if (sb + 1 < NSBW && sb + 1 < nb) score(sb + 1, sa, sbv);
+                    float w[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        w[r] = __builtin_amdgcn_exp2f(kl2 * ca[r]);
+                        w[4 + r] = __builtin_amdgcn_exp2f(kl2 * cb[r]);
+                    }
+                    if (tail) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (p0 + lq * 4 + r >= n) w[r] = 0.f;
+                            if (p0 + 16 + lq * 4 + r >= n) w[4 + r] = 0.f;
+                        }
+                    }
+                    const bf16x8 w8 = cat8(pack4(w[0], w[1], w[2], w[3]), pack4(w[4], w[5], w[6], w[7]));
+#pragma unroll
+                    for (int db = 0; db < 4; ++db) zn[sb][db] = mfma_k32(w8, xb[db], zn[sb][db]);
+                }
+            }
+        }
+    }
+    __syncthreads();   // every wave is done reading the Z planes
+    for (int i = tid; i < zrows * MS_D; i += 512) accum[i] = 0.f;
+    __syncthreads();
+    for (int g = 0; g < 4; ++g) {
+        if (pg == g) {
+#pragma unroll
+            for (int sb = 0; sb < NSBW; ++sb)
+                if (sb < nb) {
+#pragma unroll
+                    for (int db = 0; db < 4; ++db)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) accum[((sb0 + sb) * 16 + lq * 4 + r) * MS_D + db * 16 + lj] += zn[sb][db][r];
+                }
+        }
+        __syncthreads();
+    }
+    float* dst = part + (int64_t)blockIdx.x * (zrows * MS_D);
+    for (int i = tid; i < zrows * MS_D; i += 512) dst[i] = accum[i];
+}
+
 // Z[s] = normalize(sum_wg part[wg][s])  (MS:103 F.normalize).  16 waves per seed: wave w adds its fixed slice of
 // the workgroup partials (8 loads in flight), then the slices are added in wave order -- deterministic.
 __global__ __launch_bounds__(1024) void ms_hill_finish_kernel(const float* __restrict__ part, int nwg, int rows_padded,
@@ -1242,6 +1496,87 @@ extern "C" int msm_ms_hill_climb_split(const float* X, int n, int d, float* Z, i
         }
     }
     MSM_CHECK_LAUNCH("msm_ms_hill_climb_split");
+    return MSM_OK;
+}
+
+// ---- precision "bf16": one bf16 copy of X shared by seeding and the hill climb -------------------------------------------------------
+extern "C" int64_t msm_ms_bf16_rows(int n) { return (int64_t)cdiv(n, HS_ROWS) * HS_ROWS; }
+
+extern "C" int msm_ms_pack_bf16(const float* X, int n, int d, void* Xb, void* stream) {
+    MSM_REQUIRE(X && Xb, "msm_ms_pack_bf16: null pointer");
+    MSM_REQUIRE(d == MS_D && n > 0, "msm_ms_pack_bf16: d=%d (only 64), n=%d", d, n);
+    MSM_REQUIRE(((((uintptr_t)X) | ((uintptr_t)Xb)) & 15) == 0, "msm_ms_pack_bf16: pointers must be 16-byte aligned");
+    const int64_t n_pad = msm_ms_bf16_rows(n);
+    hipLaunchKernelGGL(ms_pack_bf16_kernel, dim3((unsigned)min((int64_t)4096, (n_pad * (MS_D / 4) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, n,
+                       (int)n_pad, (uint16_t*)Xb);
+    MSM_CHECK_LAUNCH("msm_ms_pack_bf16");
+    return MSM_OK;
+}
+
+extern "C" int msm_ms_select_seeds_bf16(const void* Xb, const float* X, int n, int d, int num_seeds, int64_t first_index, float* seeds_out,
+                                        int64_t* indices_out, float* workspace, int64_t workspace_elems, void* stream) {
+    MSM_REQUIRE(Xb && X && seeds_out && indices_out && workspace, "msm_ms_select_seeds_bf16: null pointer");
+    MSM_REQUIRE(d == MS_D, "msm_ms_select_seeds_bf16: d=%d, only d=64 is supported", d);
+    MSM_REQUIRE(n >= 16 && num_seeds > 0 && first_index >= 0 && first_index < n, "msm_ms_select_seeds_bf16: bad sizes (n >= 16)");
+    MSM_REQUIRE(num_seeds <= MS_SB * 16, "msm_ms_select_seeds_bf16: at most %d seeds", MS_SB * 16);
+    MSM_REQUIRE((((uintptr_t)Xb) & 15) == 0 && (((uintptr_t)workspace) & 7) == 0, "msm_ms_select_seeds_bf16: misaligned pointer");
+    if (workspace_elems < msm_ms_seed_workspace(n)) {
+        set_error("msm_ms_select_seeds_bf16: workspace too small");
+        return MSM_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(workspace);
+    float* nearest = workspace + 2 * (MS_SB * 16) + 8;
+    hipLaunchKernelGGL(ms_seed_init_kernel, dim3(cdiv(num_seeds, 64)), dim3(64), 0, st, keys, num_seeds, first_index);
+    const int nblk = seed_blocks(n);
+    for (int i = 1; i < num_seeds; ++i)
+        hipLaunchKernelGGL(ms_seed_step_bf16_kernel, dim3(nblk), dim3(256), 0, st, (const uint16_t*)Xb, n, keys, i, nearest);
+    // the seeds handed on are rows of the caller's fp32 X (the reference returns X[selected], MS:186-189)
+    hipLaunchKernelGGL(ms_seed_finish_kernel, dim3(num_seeds), dim3(64), 0, st, X, keys, indices_out, seeds_out, (const unsigned int*)nullptr, n);
+    MSM_CHECK_LAUNCH("msm_ms_select_seeds_bf16");
+    return MSM_OK;
+}
+
+template <int NSBW>
+static int hill_bf16_launch(const uint16_t* Xb, int n, const float* Zc, int Sc, int nb, float kappa, float* ws, int G, hipStream_t st) {
+    const size_t zbytes = (size_t)2 * nb * 16 * ZP_LD * sizeof(uint16_t), abytes = (size_t)nb * 16 * MS_D * sizeof(float);
+    const size_t lds = (zbytes > abytes ? zbytes : abytes) + (size_t)4 * 2 * HB_TILE;
+    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)ms_hill_bf16_kernel<NSBW>, lds));
+    hipLaunchKernelGGL((ms_hill_bf16_kernel<NSBW>), dim3(G), dim3(512), lds, st, Xb, n, Zc, Sc, nb, kappa, ws);
+    return MSM_OK;
+}
+
+extern "C" int msm_ms_hill_climb_bf16(const void* Xb, int n, int d, float* Z, int S, float kappa, int iters, float* workspace,
+                                      int64_t workspace_elems, void* stream) {
+    MSM_REQUIRE(Xb && Z && workspace, "msm_ms_hill_climb_bf16: null pointer");
+    MSM_REQUIRE(d == MS_D, "msm_ms_hill_climb_bf16: d=%d, only d=64 is supported", d);
+    MSM_REQUIRE(n > 0 && S > 0 && S <= MS_SB * 16 && iters >= 0, "msm_ms_hill_climb_bf16: bad sizes (S <= %d)", MS_SB * 16);
+    MSM_REQUIRE((((uintptr_t)Xb) & 15) == 0 && (((uintptr_t)Z) & 15) == 0 && (((uintptr_t)workspace) & 15) == 0,
+                "msm_ms_hill_climb_bf16: Xb, Z and workspace must be 16-byte aligned");
+    if (workspace_elems < msm_ms_hill_climb_workspace(n, S)) {
+        set_error("msm_ms_hill_climb_bf16: workspace too small");
+        return MSM_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int nslabs = cdiv(n, HS_ROWS);
+    const int G = max(1, min(256, cdiv(nslabs, 4)));
+    const int nsb = cdiv(S, 16);
+    const int nsbw = (nsb + 1) / 2;                                  // seed blocks per wave: all of them in one launch
+    for (int it = 0; it < iters; ++it) {
+        int rc = MSM_OK;
+        switch (nsbw) {
+            case 1: rc = hill_bf16_launch<1>((const uint16_t*)Xb, n, Z, S, nsb, kappa, workspace, G, st); break;
+            case 2: rc = hill_bf16_launch<2>((const uint16_t*)Xb, n, Z, S, nsb, kappa, workspace, G, st); break;
+            case 3: rc = hill_bf16_launch<3>((const uint16_t*)Xb, n, Z, S, nsb, kappa, workspace, G, st); break;
+            case 4: rc = hill_bf16_launch<4>((const uint16_t*)Xb, n, Z, S, nsb, kappa, workspace, G, st); break;
+            case 5: case 6: rc = hill_bf16_launch<6>((const uint16_t*)Xb, n, Z, S, nsb, kappa, workspace, G, st); break;
+            case 7: case 8: rc = hill_bf16_launch<8>((const uint16_t*)Xb, n, Z, S, nsb, kappa, workspace, G, st); break;
+            default: rc = hill_bf16_launch<10>((const uint16_t*)Xb, n, Z, S, nsb, kappa, workspace, G, st); break;
+        }
+        if (rc != MSM_OK) return rc;
+        hipLaunchKernelGGL(ms_hill_finish_kernel, dim3(S), dim3(1024), 0, st, workspace, G, nsb * 16, Z);
+    }
+    MSM_CHECK_LAUNCH("msm_ms_hill_climb_bf16");
     return MSM_OK;
 }
 

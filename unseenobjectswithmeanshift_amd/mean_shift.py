@@ -63,11 +63,11 @@ def connected_components_host(Z, epsilon):
     return torch.from_numpy(labels)
 
 
-def seed_hill_climbing_ball(X, Z, kappa, max_iters=10, metric="cosine", precision="f32"):
-    """mean_shift.py:79-109.  ``precision`` (not in the reference): "f32" (fp32 MFMAs) or "f32_split" (fp32 results on
-    the bf16 matrix pipe, ops.ms_hill_climb)."""
+def seed_hill_climbing_ball(X, Z, kappa, max_iters=10, metric="cosine", precision="f32", xb=None):
+    """mean_shift.py:79-109.  ``precision`` (not in the reference): "f32" (fp32 MFMAs), "f32_split" (fp32 results on
+    the bf16 matrix pipe) or "bf16" (single bf16 products over a bf16 copy of X, BASELINE configs[4]); ops.ms_hill_climb."""
     _cosine_only(metric)
-    return ops.ms_hill_climb(X.contiguous(), Z.contiguous(), kappa, max_iters, precision=precision)
+    return ops.ms_hill_climb(X.contiguous(), Z.contiguous(), kappa, max_iters, precision=precision, xb=xb)
 
 
 def mean_shift_with_seeds(X, Z, kappa, max_iters=10, metric="cosine", precision="f32"):
@@ -86,7 +86,7 @@ def _components_with_count(Z, epsilon):
 
 
 def select_smart_seeds(X, num_seeds, return_selected_indices=False, init_seeds=None, num_init_seeds=None,
-                       metric="cosine", first_index=None, stepwise=False):
+                       metric="cosine", first_index=None, stepwise=False, xb=None):
     """mean_shift.py:128-189.  The first seed index comes from np.random.randint(0, n) like the
     reference (mean_shift.py:155) unless ``first_index`` is given."""
     _cosine_only(metric)
@@ -94,7 +94,7 @@ def select_smart_seeds(X, num_seeds, return_selected_indices=False, init_seeds=N
         raise NotImplementedError("init_seeds is unused by the inference path")
     if first_index is None:
         first_index = np.random.randint(0, X.shape[0])
-    seeds, idx = ops.ms_select_seeds(X.contiguous(), num_seeds, int(first_index), stepwise=stepwise)
+    seeds, idx = ops.ms_select_seeds(X.contiguous(), num_seeds, int(first_index), stepwise=stepwise, xb=xb)
     if not return_selected_indices:
         # the caller cannot see the indices, so the give-up of the persistent kernel (ops.ms_select_seeds) is handled here
         if not stepwise and int(idx.min()) < 0:
@@ -104,15 +104,18 @@ def select_smart_seeds(X, num_seeds, return_selected_indices=False, init_seeds=N
 
 
 def mean_shift_smart_init(X, kappa, num_seeds=100, max_iters=10, metric="cosine", first_index=None, precision="f32"):
-    """mean_shift.py:192-229.  Returns (cluster_labels (n,) int64 on X.device, selected_indices (S,))."""
+    """mean_shift.py:192-229.  Returns (cluster_labels (n,) int64 on X.device, selected_indices (S,)).  ``precision`` "f32" /
+    "f32_split": the reference's arithmetic (exact labels); "bf16" (BASELINE configs[4]): seeding and hill climb stream one bf16 copy
+    of X -- the same clusters, possibly other member points as seeds and another numbering of the labels."""
     X = X.contiguous()
     if first_index is None:
         first_index = np.random.randint(0, X.shape[0])                   # MS:155, drawn once: a retry reuses it
+    xb = ops.ms_pack_bf16(X) if precision == "bf16" else None
     seeds, selected = select_smart_seeds(X, num_seeds, return_selected_indices=True, metric=metric,
-                                         first_index=first_index)
+                                         first_index=first_index, xb=xb)
     def rest(seeds):
         _cosine_only(metric)
-        Z = seed_hill_climbing_ball(X, seeds, kappa, max_iters=max_iters, metric=metric, precision=precision)
+        Z = seed_hill_climbing_ball(X, seeds, kappa, max_iters=max_iters, metric=metric, precision=precision, xb=xb)
         seed_labels, num = _components_with_count(Z, 2 * EMBEDDING_ALPHA)
         # labels are created in order 0, 1, ...: at most one per seed, so num_seeds bounds the histogram of the assignment; the
         # largest-cluster swap looks at labels 0 .. len(unique(seed_labels)) - 1 only, like the reference (MS:211-222)

@@ -840,31 +840,57 @@ def ms_deform_attn_encoder_fused(value_hm, spatial_shapes, level_start_index, sr
 # ----------------------------------------------------------------------------------------------
 # mean shift (lib/utils/mean_shift.py)
 # ----------------------------------------------------------------------------------------------
-def ms_select_seeds(X, num_seeds, first_index, stepwise=False, _test_give_up=False):
+def ms_pack_bf16(X):
+    """X (n,64) fp32 -> the bf16 copy (msm_ms_bf16_rows(n), 64) (rows zero-padded to whole 32-point slabs) that the "bf16" precision
+    of the clustering streams instead of X (ms_select_seeds / ms_hill_climb with xb=...)."""
+    _c(X, "X")
+    n, d = X.shape
+    xb = torch.empty((lib().msm_ms_bf16_rows(n), d), device=X.device, dtype=torch.bfloat16)
+    check(lib().msm_ms_pack_bf16(_p(X), n, d, _p(xb), _stream()), "msm_ms_pack_bf16")
+    return xb
+
+
+def ms_select_seeds(X, num_seeds, first_index, stepwise=False, _test_give_up=False, xb=None):
     """Farthest-point seeding.  X (n,64) unit rows.  Returns (seeds (S,64), indices int64 (S,)).  The single-launch
     persistent kernel (maps up to 393 216 rows) needs its workgroups co-resident; if other work holds the CUs it gives up
-    and every index is -1 -- callers re-issue with ``stepwise=True`` (mean_shift.mean_shift_smart_init does)."""
+    and every index is -1 -- callers re-issue with ``stepwise=True`` (mean_shift.mean_shift_smart_init does).
+    ``xb`` (ms_pack_bf16(X); precision "bf16"): maps beyond the persistent kernel's reach stream the bf16 copy -- half the
+    bytes of a pass; distances are those of the rounded points, so the indices may differ from the fp32 path's."""
     _c(X, "X")
     n, d = X.shape
     seeds = torch.empty((num_seeds, d), device=X.device, dtype=torch.float32)
     idx = torch.empty((num_seeds,), device=X.device, dtype=torch.int64)
     need = lib().msm_ms_seed_workspace(n)
     ws = torch.empty((need,), device=X.device, dtype=torch.float32)
+    if xb is not None and n > 393216:
+        _c(xb, "xb", torch.bfloat16)
+        if xb.shape[0] < n or xb.shape[1] != d:
+            raise RuntimeError("ms_select_seeds: xb must be ms_pack_bf16(X)")
+        rc = lib().msm_ms_select_seeds_bf16(_p(xb), _p(X), n, d, num_seeds, int(first_index), _p(seeds), _p(idx), _p(ws), need, _stream())
+        check(rc, "msm_ms_select_seeds_bf16")
+        return seeds, idx
     rc = lib().msm_ms_select_seeds(_p(X), n, d, num_seeds, int(first_index), _p(seeds), _p(idx), _p(ws), need,
                                    (1 if stepwise else 0) | (2 if _test_give_up else 0), _stream())
     check(rc, "msm_ms_select_seeds")
     return seeds, idx
 
 
-def ms_hill_climb(X, Z, kappa, iters, precision="f32"):
+def ms_hill_climb(X, Z, kappa, iters, precision="f32", xb=None):
     """iters x { Z = normalize(exp(kappa Z X^T) X) }; returns the updated copy of Z.  precision "f32": fp32 MFMAs;
-    "f32_split": fp32 results from six bf16 MFMAs per product on exact three-term splits (msm_ms_hill_climb_split)."""
-    if precision not in ("f32", "f32_split"):
-        raise ValueError(f"ms_hill_climb: precision must be 'f32' or 'f32_split', not {precision!r}")
+    "f32_split": fp32 results from six bf16 MFMAs per product on exact three-term splits (msm_ms_hill_climb_split);
+    "bf16": single bf16 products over the bf16 copy ``xb`` = ms_pack_bf16(X) (made here when not given), seeds as h + l terms."""
+    if precision not in ("f32", "f32_split", "bf16"):
+        raise ValueError(f"ms_hill_climb: precision must be 'f32', 'f32_split' or 'bf16', not {precision!r}")
     _c(X, "X"), _c(Z, "Z")
     n, d = X.shape
     S = Z.shape[0]
     Z = Z.clone()
+    if precision == "bf16":
+        xb = ms_pack_bf16(X) if xb is None else _c(xb, "xb", torch.bfloat16)
+        need = lib().msm_ms_hill_climb_workspace(n, S)
+        ws = torch.empty((need,), device=X.device, dtype=torch.float32)
+        check(lib().msm_ms_hill_climb_bf16(_p(xb), n, d, _p(Z), S, float(kappa), int(iters), _p(ws), need, _stream()), "msm_ms_hill_climb_bf16")
+        return Z
     need = (lib().msm_ms_hill_climb_split_workspace if precision == "f32_split" else lib().msm_ms_hill_climb_workspace)(n, S)
     ws = torch.empty((need,), device=X.device, dtype=torch.float32)
     fn = lib().msm_ms_hill_climb_split if precision == "f32_split" else lib().msm_ms_hill_climb

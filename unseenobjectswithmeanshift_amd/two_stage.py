@@ -111,6 +111,7 @@ def crop_rois(rgb, initial_masks, depth, crop_size=CROP_SIZE):
     if rgb.is_cuda and n > 0:
         # device tensors: every crop of the frame in ONE launch of the kernel the batched pipeline uses (msm_crop_resize: bilinear
         # align_corners=True for rgb / depth, nearest for the mask, ATen's index arithmetic -- tests pin it to the loop below)
+        from . import ops
         tab = torch.tensor(table, dtype=torch.int32, device=dev)
         rgb_crops, mask_crops, depth_crops = ops.crop_resize(rgb[0:1].float().contiguous(), None if depth is None else depth[0:1].float().contiguous(),
                                                              initial_masks[0:1].float().contiguous(), tab, crop_size)
