@@ -649,39 +649,55 @@ def extra_configs(dev, args):
                          "frame_by_frame": {"value": round(16 / t_serial, 1), "unit": "frames/sec", "ms_per_frame": round(1e3 * t_serial / 16, 3),
                                             "note": "the reference's loop structure (one frame at a time, one batched second-stage call per frame)"}}
     del rgbd, model
-    # configs[4]: 1280x960, 300 queries, 20 decoder predictions (19 layers), B=1; mean shift with 300 seeds / 20 iterations
-    model = build_model(dev, num_queries=300, dec_layers=19)
-    feats = {k: v.to(dev) for k, v in syn.synth_backbone_features(1, 960, 1280, seed=9).items()}
+    # configs[4]: 1280x960, 300 queries; SURVEY 8d says "20 layers" -- timed with 20 decoder layers (21 predictions), and with the 19
+    # layers the parity fixture head_cfg5_960x1280 holds (the reference builds DEC_LAYERS - 1 layers, DEC:529: DEC_LAYERS = 20 -> 19)
     res = {}
-    for mode in ("f32", "bf16"):
-        if hasattr(model, "set_precision"):
-            model.set_precision(mode)
-        else:
-            model.sem_seg_head.predictor.mask_step_dtype = mode
-        g = model.graphed()
-        for _ in range(2):
-            g(feats, (960, 1280))
-        t = timed(lambda: g(feats, (960, 1280)), 10)
-        res[mode] = {"value": round(1.0 / t, 1), "unit": "images/sec", "ms_per_image": round(1e3 * t, 3)}
-        del g
+    for layers, batches in ((20, (1, 4)), (19, (1,))):
+        model = build_model(dev, num_queries=300, dec_layers=layers)
+        for B_ in batches:
+            feats = {k: v.to(dev) for k, v in syn.synth_backbone_features(B_, 960, 1280, seed=9).items()}
+            for mode in ("f32", "bf16"):
+                model.set_precision(mode)
+                g = model.graphed()
+                for _ in range(2):
+                    g(feats, (960, 1280))
+                t = timed(lambda: g(feats, (960, 1280)), 10)
+                res[f"{layers} layers, batch {B_}, {mode}"] = {"value": round(B_ / t, 1), "unit": "images/sec", "ms_per_batch": round(1e3 * t, 3)}
+                del g
+            del feats
+        del model
     n, S, iters = 960 * 1280, 300, 20
     X, _ = syn.synth_unit_embeddings(n, 64, clusters=24, sigma=0.15, seed=3)
     Xd = X.to(dev)
-    for _ in range(2):
-        ms.mean_shift_smart_init(Xd, 20.0, S, iters, first_index=7)
-    t_ms = timed(lambda: ms.mean_shift_smart_init(Xd, 20.0, S, iters, first_index=7), 3)
-    t_seed = event_ms(lambda: ops.ms_select_seeds(Xd, S, 7), reps=3, warm=1)
+    xb = ops.ms_pack_bf16(Xd)
     seeds, _ = ops.ms_select_seeds(Xd, S, 7)
-    t_hill = event_ms(lambda: ops.ms_hill_climb(Xd, seeds, 20.0, iters), reps=3, warm=1)
-    out["configs[4]"] = {"workload": "1280x960, 300 queries, 19 decoder layers, batch 1 (pixel decoder + decoder + post-processing); classic "
-                                     "mean shift on n=1228800 embeddings, 300 seeds, 20 iterations",
+    seed_bytes = {"f32": float(S) * n * 256, "f32_split": float(S) * n * 256, "bf16": float(S) * n * 128}       # S passes over X as the mode stores it
+    hill_flops = 4.0 * S * n * 64 * iters
+    msr = {}
+    for mode in ("bf16", "f32_split", "f32"):
+        for _ in range(2):
+            ms.mean_shift_smart_init(Xd, 20.0, S, iters, first_index=7, precision=mode)
+        t_ms = timed(lambda: ms.mean_shift_smart_init(Xd, 20.0, S, iters, first_index=7, precision=mode), 3)
+        t_seed = event_ms(lambda: ops.ms_select_seeds(Xd, S, 7, xb=xb if mode == "bf16" else None), reps=3, warm=1)
+        t_hill = event_ms(lambda: ops.ms_hill_climb(Xd, seeds, 20.0, iters, precision=mode, xb=xb if mode == "bf16" else None), reps=3, warm=1)
+        mult, peak = {"f32": (1.0, PEAK_F32_MFMA_TFLOPS), "f32_split": (6.0, PEAK_BF16_MFMA_TFLOPS), "bf16": (1.5, PEAK_BF16_MFMA_TFLOPS)}[mode]
+        msr[mode] = {"ms": round(1e3 * t_ms, 2),
+                     "seeding": {"ms": round(t_seed, 3), "bound": "hbm", "algorithmic_bytes": seed_bytes[mode],
+                                 "achieved": round(seed_bytes[mode] / (t_seed * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                 "frac": round(seed_bytes[mode] / (t_seed * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                                 "kernel": "ms_seed_step_bf16_kernel x (S - 1), 157 MB per pass" if mode == "bf16" else "ms_seed_step_kernel x (S - 1), 314 MB per pass"},
+                     "hill_climb": {"ms": round(t_hill, 3), "bound": "mfma", "useful_flops": hill_flops,
+                                    "useful_tflops": round(hill_flops / (t_hill * 1e-3) / 1e12, 1),
+                                    "executed_tflops": round(mult * hill_flops / (t_hill * 1e-3) / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
+                                    "frac": round(mult * hill_flops / (t_hill * 1e-3) / 1e12 / peak, 4),
+                                    "products_per_useful_product": mult,
+                                    "kernel": {"f32": "ms_hill_kernel (fp32 MFMA), 3 launches per iteration", "f32_split": "ms_hill_planes_kernel (six bf16 MFMAs per product), "
+                                               "3 launches per iteration", "bf16": "ms_hill_bf16_kernel (Z as h + l: 2 score MFMAs + 1 W X MFMA per pair), 1 launch per iteration"}[mode]}}
+    out["configs[4]"] = {"workload": "1280x960, 300 queries, batch 1 and 4 (pixel decoder + decoder + post-processing; 20 decoder layers as SURVEY 8d "
+                                     "states the config, and the 19 of the parity fixture); classic mean shift on n=1228800 embeddings, 300 seeds, "
+                                     "20 iterations (bf16 = the config's dtype: one bf16 copy of X streamed by seeding and hill climb; f32 / f32_split exact)",
                          "hot_path": res,
-                         "mean_shift": {"ms": round(1e3 * t_ms, 2), "seeding_ms": round(t_seed, 3),
-                                        "seeding_GBps": round(float(S) * n * 256 / (t_seed * 1e-3) / 1e9, 1),
-                                        "seeding_frac_hbm": round(float(S) * n * 256 / (t_seed * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
-                                        "hill_climb_ms": round(t_hill, 3),
-                                        "hill_climb_TFLOPs": round(4.0 * S * n * 64 * iters / (t_hill * 1e-3) / 1e12, 1),
-                                        "hill_climb_frac_mfma": round(4.0 * S * n * 64 * iters / (t_hill * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}}
+                         "mean_shift": dict(msr["bf16"], dtype="bf16 copy of X, fp32 accumulation / distances / seeds", other_precisions={k: msr[k] for k in ("f32_split", "f32")})}
     return out
 
 
