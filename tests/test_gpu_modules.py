@@ -101,12 +101,16 @@ def test_decoder_small_vs_reference(golden):
     assert torch.equal(out3["pred_masks"], out["pred_masks"])
 
 
-def test_decoder_480x640_vs_reference(golden):
+@pytest.mark.parametrize("precision", ["f32", "f32_split"])
+def test_decoder_480x640_vs_reference(golden, precision):
     """Full-size decoder against the reference.  Ten mask predictions feed nine discrete attention
     masks, so rounding differences are amplified layer by layer: logits are held to 1e-3 here (1e-4
-    on the small case above), mask sign bits to a 1e-4 mismatch rate."""
+    on the small case above), mask sign bits to a 1e-4 mismatch rate.  f32_split: the decoder's split-form
+    kernels (batched K/V projection, mask step), identical bounds."""
     g = golden("decoder_480x640")
     dec = make_decoder()
+    if precision == "f32_split":
+        dec.kv_split, dec.mask_step_dtype = True, "f32_split"        # (what MeanShiftMaskFormerHead.set_precision sets on the predictor)
     dec.aux_outputs = True
     x, mf = syn.synth_decoder_inputs(1, 480, 640, seed=2)
     out = dec([t.to(DEV) for t in x], mf.to(DEV))
@@ -326,9 +330,13 @@ def test_pixel_decoder_front_variants_agree():
         torch.testing.assert_close(a, b, rtol=1e-4, atol=5e-5)
 
 
-def test_pixel_decoder_480x640_vs_reference(golden):
+@pytest.mark.parametrize("precision", ["f32", "f32_split"])
+def test_pixel_decoder_480x640_vs_reference(golden, precision):
+    """Full-size pixel decoder against the reference; f32_split (encoder blocks and the 3x3 FPN convolution in split form) under
+    identical bounds."""
     g = golden("pixel_decoder_480x640")
     head = make_pixel_decoder()
+    head.set_precision(precision)
     feats = syn.synth_backbone_features(1, 480, 640, seed=4)
     mf, _, ms = head.pixel_decoder.forward_features({k: v.to(DEV) for k, v in feats.items()})
     idx = T(g["mf_sample_idx"])

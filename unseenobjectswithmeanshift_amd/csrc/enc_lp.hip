@@ -28,6 +28,10 @@
 #include "bf16.h"
 #include "common.h"
 
+#ifndef EH_EXP
+#define EH_EXP 0   // tuning builds only (tools/probes/enc_hm_parts.sh): 1 = weight fragments are register constants (no LDS reads), 2 = no MFMAs, 3 = no value / projection / src stores
+#endif
+
 namespace msm {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -55,8 +59,20 @@ __device__ __forceinline__ void glds16h(const void* sbase, unsigned voff, unsign
                  : "memory");
 }
 __device__ __forceinline__ bf16x8 ldfrag(const char* blk, int lane) {
+#if EH_EXP == 1
+    return __builtin_bit_cast(bf16x8, u32x4{(unsigned)lane * 0x10001u, 0x3f803f80u, 0x3f803f80u, (unsigned)(uintptr_t)blk});
+#else
     return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(blk + lane * 16));
+#endif
 }
+#if EH_EXP == 2
+#define mfma_bf16k32 eh_fake_mfma
+__device__ __forceinline__ f32x4 eh_fake_mfma(bf16x8 a, bf16x8 b, f32x4 c) {
+    const u32x4 ua = __builtin_bit_cast(u32x4, a), ub = __builtin_bit_cast(u32x4, b);
+    c[0] += __uint_as_float(ua.x ^ ub.x);
+    return c;
+}
+#endif
 __device__ __forceinline__ float relu1h(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 3.0e38f); }
 // x (layout L: lane (token lj, quarter lq) holds features fb*16 + lq*4 + r) -> the B operands of its two 32-wide k-groups:
 // group G = the lane's values of feature blocks 2G and 2G + 1 side by side (the weights are packed in the same k order)
@@ -117,6 +133,9 @@ __device__ __forceinline__ void finish_ffn(float (&x)[4][4], const f32x4 (&acc)[
     layer_norm_h(x, sm + EH_G2, sm + EH_BE2, lq, eps);
 }
 __device__ __forceinline__ void store_src(float* __restrict__ src_out, const float (&x)[4][4], int tok, bool tok_ok, int lq) {
+#if EH_EXP == 3
+    tok_ok = tok_ok && x[0][0] == 12345.678f;
+#endif
     if (tok_ok) {
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob)
@@ -295,7 +314,7 @@ __global__ __launch_bounds__(EH_WAVES * 64) void enc_block_hm_kernel(const unsig
                 d[rb] = mfma_bf16k32(wh, xl[g], d[rb]);
                 d[rb] = mfma_bf16k32(wh, xh[g], d[rb]);
             }
-        if (tok_ok) {                                                                                        // 2 stores
+        if (tok_ok && (EH_EXP != 3 || d[0][0] == 12345.678f)) {                                              // 2 stores
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 *reinterpret_cast<u32x4*>(value_out + (((int64_t)img * 8 + 4 * j + lq) * S + tpos) * 8) = pack8h(d[2 * j], d[2 * j + 1]);
@@ -324,7 +343,7 @@ __global__ __launch_bounds__(EH_WAVES * 64) void enc_block_hm_kernel(const unsig
                     }
                     const int idx = rb * 16 + lq * 4, head = idx / 36, c = idx - head * 36;
                     const u32x2b o = pack4h(d[0], d[1], d[2], d[3]);
-                    if (tok_ok) *reinterpret_cast<u32x2b*>(proj_out + (((int64_t)img * 8 + head) * S + tpos) * 36 + c) = o;
+                    if (tok_ok && (EH_EXP != 3 || d[0] == 12345.678f)) *reinterpret_cast<u32x2b*>(proj_out + (((int64_t)img * 8 + head) * S + tpos) * 36 + c) = o;
                 }
             }
         }
