@@ -632,9 +632,9 @@ def test_mean_shift_seeding_give_up_falls_back(monkeypatch):
     real = opsmod.ms_select_seeds
     calls = []
 
-    def flaky(X_, S_, first, stepwise=False, _test_give_up=False):
+    def flaky(X_, S_, first, stepwise=False, _test_give_up=False, xb=None):
         calls.append(stepwise)
-        return real(X_, S_, first, stepwise=stepwise, _test_give_up=not stepwise)
+        return real(X_, S_, first, stepwise=stepwise, _test_give_up=not stepwise, xb=xb)
 
     monkeypatch.setattr(opsmod, "ms_select_seeds", flaky)
     labels, sel = ms.mean_shift_smart_init(Xd, kappa=20, num_seeds=30, max_iters=10, first_index=11)
