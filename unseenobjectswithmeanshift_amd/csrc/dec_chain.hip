@@ -23,6 +23,17 @@
 //      quarter-wave hit 16 different rows = 64 cache-line lookups per load; measured 9 us per 256x256 stage,
 //      L1-address-rate bound, against 1.7 us of MFMA time.)
 // Weight fragments are pipelined across the stages of a chain (see gemm256).
+//
+// Round 4, fp32 chain: 8-ROW tiles on v_mfma_f32_4x4x1_16b_f32.  A 16-row stage is bound by the matrix pipe of the ONE CU that owns
+// the tile (256 MFMAs of 32 cycles per SIMD = 3.9 us at the 2.1 GHz the part holds) and the stages of a chain are serial: the
+// decoder's 800 rows are 50 such tiles on a 256-CU chip.  The 4x4x1 instruction multiplies sixteen independent 4 x 4 x 1 blocks in 8
+// cycles -- the same FLOP rate -- and with the fragment layout ABOVE a lane's block is (k-slice lq, column group lj >> 2): the
+// B operand is the packed weight exactly as the 16x16x4 form reads it (same msm_dec_pack_weight format, same loads), the A operand
+// of block (lq, .) is x[row i = lj & 3][k of slice lq], and the instruction is issued twice, for rows 0-3 and 4-7.  The four
+// k-slices of a column leave partial sums in four lanes 16 apart: three cross-lane adds per accumulator tuple at the end of a stage
+// (a reduce-scatter: lane lq ends with row 4 rg + lq).  A stage is then 256 MFMAs of 8 cycles per wave, 2 us per SIMD -- balanced
+// against the 64 B/clk at which a CU can stream the 256 KiB of a stage's weights from L2 -- on twice as many tiles (100 x parts).
+// The bf16 chain keeps 16-row tiles (its stage is weight-streaming bound already).
 #include <type_traits>
 
 #include "bf16.h"
@@ -38,8 +49,26 @@
 namespace msm {
 
 constexpr int DC_E = 256;
-constexpr int DC_R = 16;            // rows per workgroup
-constexpr int DC_LD = DC_E + 4;     // LDS row stride (floats)
+// Tile kinds: weight type, rows per workgroup, LDS row stride (floats), row groups of 4 per column tile.
+//   TileF16  fp32 weights, 16 rows on v_mfma_f32_16x16x4_f32; stride 260 (conflict-free b128 reads of 16 rows)
+//   TileF8   fp32 weights,  8 rows on v_mfma_f32_4x4x1_16b_f32 (header); stride 272 floats = 68 slots of 16 bytes = 4 (mod 16): the
+//            sixteen distinct float4 a wave's A read touches (row i, k-slice lq) sit in sixteen different slots
+//   TileH16  bf16 weights, 16 rows on v_mfma_f32_16x16x16_bf16
+// Which fp32 kind a launch takes is decided by the host per kernel and row count: 8-row tiles halve a stage but double the number
+// of workgroups that stream the stage's 256 KiB of weights -- they pay while tiles x parts still fit the chip in one round
+// (measured at 800 rows: heads 21.7 -> 14.5 us with 200 workgroups; post_cross 14.6 -> 18.4 with 300, post_self 27.7 -> 51 with 800).
+struct TileF16 {
+    using WT = float;
+    static constexpr int R = 16, LD = DC_E + 4, RG = 1;
+};
+struct TileF8 {
+    using WT = float;
+    static constexpr int R = 8, LD = DC_E + 16, RG = 2;
+};
+struct TileH16 {
+    using WT = uint16_t;
+    static constexpr int R = 16, LD = DC_E + 4, RG = 1;
+};
 #ifndef MSM_DC_NW
 #define MSM_DC_NW 8
 #endif
@@ -99,7 +128,8 @@ __device__ __forceinline__ void bload(BFrag<uint16_t>& f, const uint16_t* __rest
         }
     }
 }
-__device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT], const float* __restrict__ ap, const BFrag<float>& f, int half) {
+// fp32, 16-row tiles: ap = A + (lane & 15) * LD + (lane >> 4) * 4
+__device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT][1], const float* __restrict__ ap, const BFrag<float>& f, int half) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         float4 a[4];
@@ -110,21 +140,53 @@ __device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT], const float* __re
         for (int u = 0; u < 4; ++u) {
 #if DC_EXP == 1
 #pragma unroll
-            for (int t = 0; t < DC_NT; ++t) acc[t][0] += a[u].x * f.v[h][t][u].x + a[u].y * f.v[h][t][u].y + a[u].z * f.v[h][t][u].z + a[u].w * f.v[h][t][u].w;
+            for (int t = 0; t < DC_NT; ++t) acc[t][0][0] += a[u].x * f.v[h][t][u].x + a[u].y * f.v[h][t][u].y + a[u].z * f.v[h][t][u].z + a[u].w * f.v[h][t][u].w;
             continue;
 #endif
 #pragma unroll
-            for (int t = 0; t < DC_NT; ++t) acc[t] = mfma16(a[u].x, f.v[h][t][u].x, acc[t]);
+            for (int t = 0; t < DC_NT; ++t) acc[t][0] = mfma16(a[u].x, f.v[h][t][u].x, acc[t][0]);
 #pragma unroll
-            for (int t = 0; t < DC_NT; ++t) acc[t] = mfma16(a[u].y, f.v[h][t][u].y, acc[t]);
+            for (int t = 0; t < DC_NT; ++t) acc[t][0] = mfma16(a[u].y, f.v[h][t][u].y, acc[t][0]);
 #pragma unroll
-            for (int t = 0; t < DC_NT; ++t) acc[t] = mfma16(a[u].z, f.v[h][t][u].z, acc[t]);
+            for (int t = 0; t < DC_NT; ++t) acc[t][0] = mfma16(a[u].z, f.v[h][t][u].z, acc[t][0]);
 #pragma unroll
-            for (int t = 0; t < DC_NT; ++t) acc[t] = mfma16(a[u].w, f.v[h][t][u].w, acc[t]);
+            for (int t = 0; t < DC_NT; ++t) acc[t][0] = mfma16(a[u].w, f.v[h][t][u].w, acc[t][0]);
         }
     }
 }
-__device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT], const float* __restrict__ ap, const BFrag<uint16_t>& f, int half) {
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+// fp32: ap = A + (lane & 3) * LD + (lane >> 4) * 4 (row i of the lane's block, k-slice lq); acc[t][rg] = the 4 x 4 block (rows 4 rg ..
+// + 3, column t*16 + lj) of the lane's k-slice
+__device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT][2], const float* __restrict__ ap, const BFrag<float>& f, int half) {
+    constexpr int LD = TileF8::LD;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float4 a0[4], a1[4];
+        const int kc = half * 2 + h;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a0[u] = *reinterpret_cast<const float4*>(ap + kc * 64 + u * 16);
+            a1[u] = *reinterpret_cast<const float4*>(ap + 4 * LD + kc * 64 + u * 16);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#if DC_EXP == 1
+#pragma unroll
+            for (int t = 0; t < DC_NT; ++t) acc[t][0][0] += a0[u].x * f.v[h][t][u].x + a1[u].y * f.v[h][t][u].y + a0[u].z * f.v[h][t][u].z + a1[u].w * f.v[h][t][u].w;
+            continue;
+#endif
+#pragma unroll
+            for (int t = 0; t < DC_NT; ++t) { acc[t][0] = mfma4(a0[u].x, f.v[h][t][u].x, acc[t][0]); acc[t][1] = mfma4(a1[u].x, f.v[h][t][u].x, acc[t][1]); }
+#pragma unroll
+            for (int t = 0; t < DC_NT; ++t) { acc[t][0] = mfma4(a0[u].y, f.v[h][t][u].y, acc[t][0]); acc[t][1] = mfma4(a1[u].y, f.v[h][t][u].y, acc[t][1]); }
+#pragma unroll
+            for (int t = 0; t < DC_NT; ++t) { acc[t][0] = mfma4(a0[u].z, f.v[h][t][u].z, acc[t][0]); acc[t][1] = mfma4(a1[u].z, f.v[h][t][u].z, acc[t][1]); }
+#pragma unroll
+            for (int t = 0; t < DC_NT; ++t) { acc[t][0] = mfma4(a0[u].w, f.v[h][t][u].w, acc[t][0]); acc[t][1] = mfma4(a1[u].w, f.v[h][t][u].w, acc[t][1]); }
+        }
+    }
+}
+__device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT][1], const float* __restrict__ ap, const BFrag<uint16_t>& f, int half) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         float4 a[4];
@@ -138,30 +200,31 @@ __device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT], const float* __re
             for (int t = 0; t < DC_NT; ++t) {
                 const u32x4b wv = f.v[h][t][u >> 1];
                 const bf16x4 w = __builtin_bit_cast(bf16x4, (u & 1) ? u32x2b{wv.z, wv.w} : u32x2b{wv.x, wv.y});
-                acc[t] = mfma_bf16(x.lo, w, acc[t]);
-                acc[t] = mfma_bf16(x.hi, w, acc[t]);
+                acc[t][0] = mfma_bf16(x.lo, w, acc[t][0]);
+                acc[t][0] = mfma_bf16(x.hi, w, acc[t][0]);
             }
         }
     }
 }
 // prefetch loads per half stage (bload) and MFMAs between two of them
-template <typename WT>
+template <typename TK>
 struct Pipe {
-    static constexpr int LOADS = std::is_same<WT, float>::value ? 8 * DC_NT : 4 * DC_NT;
-    static constexpr int IL = DC_IL;
+    static constexpr int LOADS = std::is_same<typename TK::WT, float>::value ? 8 * DC_NT : 4 * DC_NT;
+    static constexpr int IL = TK::RG == 2 ? 2 * DC_IL : DC_IL;      // (8-row fp32: two 8-cycle MFMAs where the 16-row form has one of 32)
 };
 
 // D[16][256] = act(A[16][256] . W[n][k]^T + bias).  A in LDS.  TO_GLOBAL: D is row-major global with row stride
-// ldd, rows >= rows_valid are not written; otherwise D is an LDS tile (stride DC_LD).
+// ldd, rows >= rows_valid are not written; otherwise D is an LDS tile (stride TK::LD).
 // Weight pipeline across the stages of a chain: on entry `lo` already holds k-chunks 0,1 of W (loaded during the
 // previous stage or at kernel start); chunks 2,3 are fetched while 0,1 are consumed, and the next stage's chunks
 // 0,1 (Wn, may be null) while 2,3 are consumed, so L2 latency hides behind 64 MFMAs (~2000 cycles) each time.
 // acc += A[16][256] . W-block^T for this wave's DC_NT column tiles (fragment pipeline as described above)
-template <bool NEXT, typename WT>
-__device__ __forceinline__ void gemm_core(f32x4 (&acc)[DC_NT], const float* __restrict__ A, const WT* __restrict__ W, int kct,
-                                          int kc_base, BFrag<WT>& lo, const WT* __restrict__ Wn, int kctn, int kcn) {
+template <bool NEXT, typename TK>
+__device__ __forceinline__ void gemm_core(f32x4 (&acc)[DC_NT][TK::RG], const float* __restrict__ A, const typename TK::WT* __restrict__ W, int kct,
+                                          int kc_base, BFrag<typename TK::WT>& lo, const typename TK::WT* __restrict__ Wn, int kctn, int kcn) {
+    using WT = typename TK::WT;
     const int lane = threadIdx.x & 63;
-    const float* ap = A + (lane & 15) * DC_LD + (lane >> 4) * 4;
+    const float* ap = A + (TK::RG == 2 ? (lane & 3) : (lane & 15)) * TK::LD + (lane >> 4) * 4;
     BFrag<WT> hi;
     // The prefetch loads are spread evenly between the MFMAs of the half they hide behind (1 load : DC_IL MFMAs,
     // sched_group_barrier), not issued as a burst in front of them: measured 16.2 -> 14.1 us (post_cross), 34.1 -> 29.1
@@ -170,9 +233,9 @@ __device__ __forceinline__ void gemm_core(f32x4 (&acc)[DC_NT], const float* __re
     bload(hi, W, kct, kc_base, 1);
     mfma_half(acc, ap, lo, 0);
 #pragma unroll
-    for (int i = 0; i < Pipe<WT>::LOADS; ++i) {
+    for (int i = 0; i < Pipe<TK>::LOADS; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);               // one VMEM read
-        __builtin_amdgcn_sched_group_barrier(0x008, Pipe<WT>::IL, 0);    // DC_IL MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x008, Pipe<TK>::IL, 0);    // DC_IL MFMAs
     }
     __builtin_amdgcn_sched_barrier(0);
     // NEXT is a compile-time flag: a run-time branch here makes the waitcnt pass assume the shorter queue and
@@ -180,17 +243,17 @@ __device__ __forceinline__ void gemm_core(f32x4 (&acc)[DC_NT], const float* __re
     if constexpr (NEXT) bload(lo, Wn, kctn, kcn, 0);
     mfma_half(acc, ap, hi, 1);
 #pragma unroll
-    for (int i = 0; i < Pipe<WT>::LOADS; ++i) {
+    for (int i = 0; i < Pipe<TK>::LOADS; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, Pipe<WT>::IL, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, Pipe<TK>::IL, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
 }
 
 // D = act(acc + bias).  TO_GLOBAL: D is row-major global with row stride ldd, rows >= rows_valid are not written;
-// otherwise D is an LDS tile (stride DC_LD).
-template <bool TO_GLOBAL>
-__device__ __forceinline__ void gemm_store(const f32x4 (&acc)[DC_NT], const float (&bv)[DC_NT], bool relu, float* __restrict__ D,
+// otherwise D is an LDS tile (stride TK::LD).
+template <bool TO_GLOBAL, int LD>
+__device__ __forceinline__ void gemm_store(const f32x4 (&acc)[DC_NT][1], const float (&bv)[DC_NT], bool relu, float* __restrict__ D,
                                            int64_t ldd, int rows_valid) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lj = lane & 15, lq = lane >> 4;
@@ -199,13 +262,41 @@ __device__ __forceinline__ void gemm_store(const f32x4 (&acc)[DC_NT], const floa
         const int n = (wave * DC_NT + t) * 16 + lj;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float v = acc[t][r] + bv[t];
+            float v = acc[t][0][r] + bv[t];
             if (relu) v = fmaxf(v, 0.f);
             const int row = lq * 4 + r;
             if constexpr (TO_GLOBAL) {
                 if (row < rows_valid) D[(int64_t)row * ldd + n] = v;
             } else {
-                D[row * DC_LD + n] = v;
+                D[row * LD + n] = v;
+            }
+        }
+    }
+}
+// fp32 (4x4x1 blocks): the four k-slices of a column sit in the lanes lq = 0..3 of that column; a reduce-scatter over them leaves lane
+// lq with the total of row 4 rg + lq (three cross-lane adds per tuple), which it stores
+template <bool TO_GLOBAL, int LD>
+__device__ __forceinline__ void gemm_store(const f32x4 (&acc)[DC_NT][2], const float (&bv)[DC_NT], bool relu, float* __restrict__ D,
+                                           int64_t ldd, int rows_valid) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lj = lane & 15, lq = lane >> 4;
+    const bool up2 = lq & 2, up1 = lq & 1;
+#pragma unroll
+    for (int t = 0; t < DC_NT; ++t) {
+        const int n = (wave * DC_NT + t) * 16 + lj;
+#pragma unroll
+        for (int rg = 0; rg < 2; ++rg) {
+            const f32x4 d = acc[t][rg];
+            float k0 = up2 ? d[2] : d[0], k1 = up2 ? d[3] : d[1];
+            k0 += __shfl_xor(up2 ? d[0] : d[2], 32, 64);
+            k1 += __shfl_xor(up2 ? d[1] : d[3], 32, 64);
+            float v = (up1 ? k1 : k0) + __shfl_xor(up1 ? k0 : k1, 16, 64) + bv[t];
+            if (relu) v = fmaxf(v, 0.f);
+            const int row = rg * 4 + lq;
+            if constexpr (TO_GLOBAL) {
+                if (row < rows_valid) D[(int64_t)row * ldd + n] = v;
+            } else {
+                D[row * LD + n] = v;
             }
         }
     }
@@ -220,26 +311,29 @@ __device__ __forceinline__ void load_bias(float (&bv)[DC_NT], const float* __res
 // D[16][256] = act(A[16][256] . W-block^T + bias): one stage of a chain.  On entry `lo` holds k-chunks 0,1 of W
 // (fetched during the previous stage or at kernel start); chunks 2,3 are fetched while 0,1 are consumed and the next
 // stage's first two chunks (Wn) while 2,3 are consumed, so L2 latency hides behind 64 MFMAs per wave each time.
-template <bool TO_GLOBAL, bool NEXT, typename WT>
-__device__ __forceinline__ void gemm256(const float* __restrict__ A, const WT* __restrict__ W, int kct, int kc_base,
+template <bool TO_GLOBAL, bool NEXT, typename TK>
+__device__ __forceinline__ void gemm256(const float* __restrict__ A, const typename TK::WT* __restrict__ W, int kct, int kc_base,
                                         const float* __restrict__ bias, bool relu, float* __restrict__ D, int64_t ldd,
-                                        int rows_valid, BFrag<WT>& lo, const WT* __restrict__ Wn, int kctn, int kcn) {
-    f32x4 acc[DC_NT];
+                                        int rows_valid, BFrag<typename TK::WT>& lo, const typename TK::WT* __restrict__ Wn, int kctn, int kcn) {
+    f32x4 acc[DC_NT][TK::RG];
 #pragma unroll
-    for (int t = 0; t < DC_NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < DC_NT; ++t)
+#pragma unroll
+        for (int rg = 0; rg < TK::RG; ++rg) acc[t][rg] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bv[DC_NT];
     load_bias(bv, bias);            // requested before the MFMAs, consumed after them
-    gemm_core<NEXT, WT>(acc, A, W, kct, kc_base, lo, Wn, kctn, kcn);
-    gemm_store<TO_GLOBAL>(acc, bv, relu, D, ldd, rows_valid);
+    gemm_core<NEXT, TK>(acc, A, W, kct, kc_base, lo, Wn, kctn, kcn);
+    gemm_store<TO_GLOBAL, TK::LD>(acc, bv, relu, D, ldd, rows_valid);
 }
 
 // tile[16][256] <- src rows row0.. (clamped to the last valid row), 16-byte coalesced
+template <typename TK>
 __device__ __forceinline__ void load_tile(float* __restrict__ tile, const float* __restrict__ src, int64_t ld, int row0,
                                           int rows) {
-    for (int i = threadIdx.x; i < DC_R * (DC_E / 4); i += DC_THREADS) {
+    for (int i = threadIdx.x; i < TK::R * (DC_E / 4); i += DC_THREADS) {
         const int r = i / (DC_E / 4), c4 = i - r * (DC_E / 4);
         const int gr = min(row0 + r, rows - 1);
-        *reinterpret_cast<float4*>(tile + r * DC_LD + c4 * 4) = *reinterpret_cast<const float4*>(src + (int64_t)gr * ld + c4 * 4);
+        *reinterpret_cast<float4*>(tile + r * TK::LD + c4 * 4) = *reinterpret_cast<const float4*>(src + (int64_t)gr * ld + c4 * 4);
     }
 }
 
@@ -259,13 +353,13 @@ __device__ __forceinline__ float4 affine4(float4 v, RowStats s, float4 g, float4
     return make_float4((v.x - s.mean) * s.rstd * g.x + b.x, (v.y - s.mean) * s.rstd * g.y + b.y,
                        (v.z - s.mean) * s.rstd * g.z + b.z, (v.w - s.mean) * s.rstd * g.w + b.w);
 }
-constexpr int DC_RPW = DC_R / DC_NW;   // rows per wave in the row-wise phases; lane owns columns 4*lane .. 4*lane+3
+// rows per wave in the row-wise phases: TK::R / DC_NW; a lane owns columns 4*lane .. 4*lane+3
 
 // ---- x = LN(res + o Wo^T + bo), shared head of post_cross / post_self -------------------------------------------
 // On return (after the trailing barrier) X holds x and, if XP, XP holds x + query_pos; x rows are written to
 // x_out by the workgroups with store_x.  Every global operand of the row phase is requested before the GEMM so
 // its latency hides behind the MFMAs.
-template <typename WT>
+template <typename TK, typename WT = typename TK::WT>
 __device__ __forceinline__ void attn_out_ln(const float* __restrict__ o, const float* __restrict__ res,
                                             const WT* __restrict__ wo, const float* __restrict__ bo,
                                             const float* __restrict__ g, const float* __restrict__ b,
@@ -275,86 +369,88 @@ __device__ __forceinline__ void attn_out_ln(const float* __restrict__ o, const f
                                             int kc_next) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     bload(f, wo, 4, 0, 0);
-    load_tile(T0, o, DC_E, row0, rows);
-    float4 rv[DC_RPW], pv[DC_RPW];
+    load_tile<TK>(T0, o, DC_E, row0, rows);
+    float4 rv[(TK::R / DC_NW)], pv[(TK::R / DC_NW)];
 #pragma unroll
-    for (int i = 0; i < DC_RPW; ++i) {
-        const int gr = min(row0 + wave * DC_RPW + i, rows - 1);
+    for (int i = 0; i < (TK::R / DC_NW); ++i) {
+        const int gr = min(row0 + wave * (TK::R / DC_NW) + i, rows - 1);
         rv[i] = ld4(res + (int64_t)gr * DC_E + lane * 4);
         pv[i] = XP ? ld4(qpos + (int64_t)(gr % Q) * DC_E + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float4 gv = ld4(g + lane * 4), bv = ld4(b + lane * 4);
     __syncthreads();
-    gemm256<false, true, WT>(T0, wo, 4, 0, bo, false, X, 0, 0, f, w_next, kct_next, kc_next);
+    gemm256<false, true, TK>(T0, wo, 4, 0, bo, false, X, 0, 0, f, w_next, kct_next, kc_next);
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < DC_RPW; ++i) {
-        const int r = wave * DC_RPW + i;
-        const float4 v = add4(ld4(X + r * DC_LD + lane * 4), rv[i]);
+    for (int i = 0; i < (TK::R / DC_NW); ++i) {
+        const int r = wave * (TK::R / DC_NW) + i;
+        const float4 v = add4(ld4(X + r * TK::LD + lane * 4), rv[i]);
         const float4 y = affine4(v, row_stats(v, eps), gv, bv);
-        st4(X + r * DC_LD + lane * 4, y);
-        if (XP) st4(XP + r * DC_LD + lane * 4, add4(y, pv[i]));
+        st4(X + r * TK::LD + lane * 4, y);
+        if (XP) st4(XP + r * TK::LD + lane * 4, add4(y, pv[i]));
         if (store_x && row0 + r < rows) st4(x_out + (int64_t)(row0 + r) * DC_E + lane * 4, y);
     }
     __syncthreads();
 }
 
-template <typename WT>
+template <typename TK, typename WT = typename TK::WT>
 __global__ __launch_bounds__(DC_THREADS) void dec_post_cross_kernel(
     const float* __restrict__ o, const float* __restrict__ res, const float* __restrict__ qpos, const WT* __restrict__ wo,
     const float* __restrict__ bo, const float* __restrict__ g, const float* __restrict__ b, const WT* __restrict__ w_in,
     const float* __restrict__ b_in, float* __restrict__ x_out, float* __restrict__ qk_out, float* __restrict__ v_out,
     int rows, int Q, float eps) {
-    __shared__ __attribute__((aligned(16))) float lds[3 * DC_R * DC_LD];
-    float *T0 = lds, *X = lds + DC_R * DC_LD, *XP = lds + 2 * DC_R * DC_LD;
-    const int row0 = blockIdx.x * DC_R;
-    const int valid = min(DC_R, rows - row0);
+    __shared__ __attribute__((aligned(16))) float lds[3 * TK::R * TK::LD];
+    float *T0 = lds, *X = lds + TK::R * TK::LD, *XP = lds + 2 * TK::R * TK::LD;
+    const int row0 = blockIdx.x * TK::R;
+    const int valid = min(TK::R, rows - row0);
     // blockIdx.y picks the projection (0: q, 1: k, 2: v): the 16-row tile is MFMA-bound on ONE CU at 3.4 us per
     // 256x256 stage, so the three independent projections go to three CUs; each repeats the Wo + LN stage.
     const int part = blockIdx.y;
     const WT* wp = w_in + (int64_t)part * DC_E * DC_E;
     BFrag<WT> f;
-    attn_out_ln<WT>(o, res, wo, bo, g, b, qpos, Q, x_out, part == 0, T0, X, XP, row0, rows, eps, f, wp, 4, 0);
+    attn_out_ln<TK>(o, res, wo, bo, g, b, qpos, Q, x_out, part == 0, T0, X, XP, row0, rows, eps, f, wp, 4, 0);
     // q and k share tgt + query_pos (DEC:171-175); v = tgt
     if (part < 2)
-        gemm256<true, false, WT>(XP, wp, 4, 0, b_in + part * DC_E, false, qk_out + (int64_t)row0 * 2 * DC_E + part * DC_E, 2 * DC_E,
+        gemm256<true, false, TK>(XP, wp, 4, 0, b_in + part * DC_E, false, qk_out + (int64_t)row0 * 2 * DC_E + part * DC_E, 2 * DC_E,
                                  valid, f, nullptr, 0, 0);
     else
-        gemm256<true, false, WT>(X, wp, 4, 0, b_in + 2 * DC_E, false, v_out + (int64_t)row0 * DC_E, DC_E, valid, f, nullptr, 0, 0);
+        gemm256<true, false, TK>(X, wp, 4, 0, b_in + 2 * DC_E, false, v_out + (int64_t)row0 * DC_E, DC_E, valid, f, nullptr, 0, 0);
 }
 
-template <typename WT>
+template <typename TK, typename WT = typename TK::WT>
 __global__ __launch_bounds__(DC_THREADS) void dec_post_self_kernel(
     const float* __restrict__ o, const float* __restrict__ res, const WT* __restrict__ wo, const float* __restrict__ bo,
     const float* __restrict__ g, const float* __restrict__ b, const WT* __restrict__ w1, const float* __restrict__ b1,
     const WT* __restrict__ w2, int F, float* __restrict__ x_out, float* __restrict__ parts, int rows, float eps) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * DC_R * DC_LD];
-    float *T0 = lds, *X = lds + DC_R * DC_LD;
-    const int row0 = blockIdx.x * DC_R, chunk = blockIdx.y;
-    const int valid = min(DC_R, rows - row0);
+    __shared__ __attribute__((aligned(16))) float lds[2 * TK::R * TK::LD];
+    float *T0 = lds, *X = lds + TK::R * TK::LD;
+    const int row0 = blockIdx.x * TK::R, chunk = blockIdx.y;
+    const int valid = min(TK::R, rows - row0);
     // blockIdx.y owns F/256/gridDim.y consecutive 256-wide hidden chunks; their W2 products accumulate in registers.
     // linear1: rows [c*256, +256) of the packed (F, 256) matrix; linear2 (256, F): k-chunks 4c..4c+3 of every row tile.
     const int per = (F / DC_E) / gridDim.y, c0 = chunk * per;
     const int kct2 = F / 64;
     BFrag<WT> f;
-    attn_out_ln<WT>(o, res, wo, bo, g, b, nullptr, 1, x_out, chunk == 0, T0, X, nullptr, row0, rows, eps, f,
+    attn_out_ln<TK>(o, res, wo, bo, g, b, nullptr, 1, x_out, chunk == 0, T0, X, nullptr, row0, rows, eps, f,
                     w1 + (int64_t)c0 * DC_E * DC_E, 4, 0);
-    f32x4 acc2[DC_NT];
+    f32x4 acc2[DC_NT][TK::RG];
 #pragma unroll
-    for (int t = 0; t < DC_NT; ++t) acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < DC_NT; ++t)
+#pragma unroll
+        for (int rg = 0; rg < TK::RG; ++rg) acc2[t][rg] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float zero_bias[DC_NT] = {};
     for (int c = c0; c < c0 + per; ++c) {
         // h = relu(x W1[c]^T + b1[c]) (DEC:297) -> T0;  acc2 += h W2[:, c]^T
-        gemm256<false, true, WT>(X, w1 + (int64_t)c * DC_E * DC_E, 4, 0, b1 + c * DC_E, true, T0, 0, 0, f, w2, kct2, 4 * c);
+        gemm256<false, true, TK>(X, w1 + (int64_t)c * DC_E * DC_E, 4, 0, b1 + c * DC_E, true, T0, 0, 0, f, w2, kct2, 4 * c);
         __syncthreads();
         const int cn = min(c + 1, c0 + per - 1);    // the last prefetch re-reads the current chunk: no branch in the pipeline
-        gemm_core<true, WT>(acc2, T0, w2, kct2, 4 * c, f, w1 + (int64_t)cn * DC_E * DC_E, 4, 0);
+        gemm_core<true, TK>(acc2, T0, w2, kct2, 4 * c, f, w1 + (int64_t)cn * DC_E * DC_E, 4, 0);
         __syncthreads();
     }
-    gemm_store<true>(acc2, zero_bias, false, parts + ((int64_t)chunk * rows + row0) * DC_E, DC_E, valid);
+    gemm_store<true, TK::LD>(acc2, zero_bias, false, parts + ((int64_t)chunk * rows + row0) * DC_E, DC_E, valid);
 }
 
-template <typename WT>
+template <typename TK, typename WT = typename TK::WT>
 __global__ __launch_bounds__(DC_THREADS) void dec_heads_kernel(
     const float* __restrict__ x, const float* __restrict__ parts, int n_parts, const float* __restrict__ bias,
     const float* __restrict__ g1, const float* __restrict__ b1, int l2norm, const float* __restrict__ g2,
@@ -362,11 +458,11 @@ __global__ __launch_bounds__(DC_THREADS) void dec_heads_kernel(
     const float* __restrict__ m1b, const WT* __restrict__ m2w, const float* __restrict__ m2b, const WT* __restrict__ wq,
     const float* __restrict__ bq, const float* __restrict__ qpos, float* __restrict__ out, float* __restrict__ d_out,
     float* __restrict__ e_out, float* __restrict__ q_out, int32_t* __restrict__ row_any_zero, int rows, int Q, float eps) {
-    __shared__ __attribute__((aligned(16))) float lds[3 * DC_R * DC_LD];
-    float *XP = lds, *Dn = lds + DC_R * DC_LD, *T0 = lds + 2 * DC_R * DC_LD;
+    __shared__ __attribute__((aligned(16))) float lds[3 * TK::R * TK::LD];
+    float *XP = lds, *Dn = lds + TK::R * TK::LD, *T0 = lds + 2 * TK::R * TK::LD;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row0 = blockIdx.x * DC_R;
-    const int valid = min(DC_R, rows - row0);
+    const int row0 = blockIdx.x * TK::R;
+    const int valid = min(TK::R, rows - row0);
     // blockIdx.y == 1 (only launched when wq is given): the next layer's query projection; y == 0: the MLP chain
     const bool qpart = blockIdx.y == 1;
     // the mask step that consumes e_out needs its row_any flags cleared: done here instead of a separate fill launch
@@ -375,10 +471,10 @@ __global__ __launch_bounds__(DC_THREADS) void dec_heads_kernel(
     bload(f, qpart ? wq : m0w, 4, 0, 0);
     // row phase: lane owns 4 consecutive columns; all global operands of the wave's rows are requested up front
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 v[DC_RPW], pv[DC_RPW];
+    float4 v[(TK::R / DC_NW)], pv[(TK::R / DC_NW)];
 #pragma unroll
-    for (int i = 0; i < DC_RPW; ++i) {
-        const int gr = min(row0 + wave * DC_RPW + i, rows - 1);
+    for (int i = 0; i < (TK::R / DC_NW); ++i) {
+        const int gr = min(row0 + wave * (TK::R / DC_NW) + i, rows - 1);
         v[i] = ld4(x + (int64_t)gr * DC_E + lane * 4);
         pv[i] = qpart ? ld4(qpos + (int64_t)(gr % Q) * DC_E + lane * 4) : zero4;
     }
@@ -386,23 +482,23 @@ __global__ __launch_bounds__(DC_THREADS) void dec_heads_kernel(
     const float4 g1v = g1 ? ld4(g1 + lane * 4) : zero4, b1v = g1 ? ld4(b1 + lane * 4) : zero4;
     const float4 g2v = ld4(g2 + lane * 4), b2v = ld4(b2 + lane * 4);
     for (int s0 = 0; s0 < n_parts; s0 += 8) {
-        float4 p[DC_RPW][8];
+        float4 p[(TK::R / DC_NW)][8];
 #pragma unroll
-        for (int i = 0; i < DC_RPW; ++i) {
-            const int gr = min(row0 + wave * DC_RPW + i, rows - 1);
+        for (int i = 0; i < (TK::R / DC_NW); ++i) {
+            const int gr = min(row0 + wave * (TK::R / DC_NW) + i, rows - 1);
 #pragma unroll
             for (int s = 0; s < 8; ++s)
                 p[i][s] = ld4(parts + ((int64_t)min(s0 + s, n_parts - 1) * rows + gr) * DC_E + lane * 4);
         }
 #pragma unroll
-        for (int i = 0; i < DC_RPW; ++i)
+        for (int i = 0; i < (TK::R / DC_NW); ++i)
 #pragma unroll
             for (int s = 0; s < 8; ++s)
                 if (s0 + s < n_parts) v[i] = add4(v[i], p[i][s]);
     }
 #pragma unroll
-    for (int i = 0; i < DC_RPW; ++i) {
-        const int r = wave * DC_RPW + i;
+    for (int i = 0; i < (TK::R / DC_NW); ++i) {
+        const int r = wave * (TK::R / DC_NW) + i;
         const bool live = row0 + r < rows;
         float4 t = add4(v[i], biasv);
         if (g1) t = affine4(t, row_stats(t, eps), g1v, b1v);                         // FFN norm (DEC:300)
@@ -411,24 +507,24 @@ __global__ __launch_bounds__(DC_THREADS) void dec_heads_kernel(
             t = make_float4(t.x / nrm, t.y / nrm, t.z / nrm, t.w / nrm);
         }
         if (qpart) {
-            st4(XP + r * DC_LD + lane * 4, add4(t, pv[i]));
+            st4(XP + r * TK::LD + lane * 4, add4(t, pv[i]));
             continue;
         }
         if (out && live) st4(out + (int64_t)(row0 + r) * DC_E + lane * 4, t);
         const float4 y = affine4(t, row_stats(t, eps), g2v, b2v);                    // decoder_norm (DEC:661)
-        st4(Dn + r * DC_LD + lane * 4, y);
+        st4(Dn + r * TK::LD + lane * 4, y);
         if (d_out && live) st4(d_out + (int64_t)(row0 + r) * DC_E + lane * 4, y);
     }
     __syncthreads();
     if (qpart) {                                                                     // next layer's query (uniform branch)
-        gemm256<true, false, WT>(XP, wq, 4, 0, bq, false, q_out + (int64_t)row0 * DC_E, DC_E, valid, f, nullptr, 0, 0);
+        gemm256<true, false, TK>(XP, wq, 4, 0, bq, false, q_out + (int64_t)row0 * DC_E, DC_E, valid, f, nullptr, 0, 0);
         return;
     }
-    gemm256<false, true, WT>(Dn, m0w, 4, 0, m0b, true, T0, 0, 0, f, m1w, 4, 0);                                          // mask_embed MLP (DEC:665)
+    gemm256<false, true, TK>(Dn, m0w, 4, 0, m0b, true, T0, 0, 0, f, m1w, 4, 0);                                          // mask_embed MLP (DEC:665)
     __syncthreads();
-    gemm256<false, true, WT>(T0, m1w, 4, 0, m1b, true, Dn, 0, 0, f, m2w, 4, 0);
+    gemm256<false, true, TK>(T0, m1w, 4, 0, m1b, true, Dn, 0, 0, f, m2w, 4, 0);
     __syncthreads();
-    gemm256<true, false, WT>(Dn, m2w, 4, 0, m2b, false, e_out + (int64_t)row0 * DC_E, DC_E, valid, f, nullptr, 0, 0);
+    gemm256<true, false, TK>(Dn, m2w, 4, 0, m2b, false, e_out + (int64_t)row0 * DC_E, DC_E, valid, f, nullptr, 0, 0);
 }
 
 // packed[((t*(K/64) + kc)*4 + u)*256 + (lq*16 + lj)*4 + c] = W[t*16 + lj][kc*64 + u*16 + lq*4 + c]
@@ -496,7 +592,10 @@ extern "C" int msm_dec_pack_weight_bf16(const float* w, uint16_t* packed, int N,
     return MSM_OK;
 }
 
-template <typename WT>
+// 8-row fp32 tiles while tiles x parts fit the chip in one round (see the tile kinds above)
+static bool use_tile8(int rows, int parts) { return cdiv(rows, 8) * parts <= 256; }
+
+template <typename TK, typename WT = typename TK::WT>
 static int dec_post_cross_impl(const char* who, const float* attn_out, const float* res, const float* query_pos, const WT* wo, const float* bo,
                                const float* ln_g, const float* ln_b, const WT* w_in, const float* b_in, float* x_out, float* qk_out,
                                float* v_out, int rows, int Q, int E, float eps, void* stream) {
@@ -504,7 +603,7 @@ static int dec_post_cross_impl(const char* who, const float* attn_out, const flo
     MSM_REQUIRE(E == DC_E, "%s: E=%d, only 256 is supported", who, E);
     MSM_REQUIRE(rows > 0 && Q > 0, "%s: bad sizes", who);
     MSM_REQUIRE(aligned16(attn_out) && aligned16(wo) && aligned16(w_in), "%s: pointers must be 16-byte aligned", who);
-    hipLaunchKernelGGL(dec_post_cross_kernel<WT>, dim3(cdiv(rows, DC_R), 3), dim3(DC_THREADS), 0, (hipStream_t)stream, attn_out, res,
+    hipLaunchKernelGGL(dec_post_cross_kernel<TK>, dim3(cdiv(rows, TK::R), 3), dim3(DC_THREADS), 0, (hipStream_t)stream, attn_out, res,
                        query_pos, wo, bo, ln_g, ln_b, w_in, b_in, x_out, qk_out, v_out, rows, Q, eps);
     MSM_CHECK_LAUNCH(who);
     return MSM_OK;
@@ -513,17 +612,20 @@ static int dec_post_cross_impl(const char* who, const float* attn_out, const flo
 extern "C" int msm_dec_post_cross(const float* attn_out, const float* res, const float* query_pos, const float* wo,
                                   const float* bo, const float* ln_g, const float* ln_b, const float* w_in, const float* b_in,
                                   float* x_out, float* qk_out, float* v_out, int rows, int Q, int E, float eps, void* stream) {
-    return dec_post_cross_impl<float>("msm_dec_post_cross", attn_out, res, query_pos, wo, bo, ln_g, ln_b, w_in, b_in, x_out, qk_out, v_out, rows,
-                                      Q, E, eps, stream);
+    if (use_tile8(rows, 3))
+        return dec_post_cross_impl<TileF8>("msm_dec_post_cross", attn_out, res, query_pos, wo, bo, ln_g, ln_b, w_in, b_in, x_out, qk_out, v_out, rows,
+                                           Q, E, eps, stream);
+    return dec_post_cross_impl<TileF16>("msm_dec_post_cross", attn_out, res, query_pos, wo, bo, ln_g, ln_b, w_in, b_in, x_out, qk_out, v_out, rows,
+                                        Q, E, eps, stream);
 }
 extern "C" int msm_dec_post_cross_bf16(const float* attn_out, const float* res, const float* query_pos, const uint16_t* wo,
                                        const float* bo, const float* ln_g, const float* ln_b, const uint16_t* w_in, const float* b_in,
                                        float* x_out, float* qk_out, float* v_out, int rows, int Q, int E, float eps, void* stream) {
-    return dec_post_cross_impl<uint16_t>("msm_dec_post_cross_bf16", attn_out, res, query_pos, wo, bo, ln_g, ln_b, w_in, b_in, x_out, qk_out,
+    return dec_post_cross_impl<TileH16>("msm_dec_post_cross_bf16", attn_out, res, query_pos, wo, bo, ln_g, ln_b, w_in, b_in, x_out, qk_out,
                                          v_out, rows, Q, E, eps, stream);
 }
 
-template <typename WT>
+template <typename TK, typename WT = typename TK::WT>
 static int dec_post_self_impl(const char* who, const float* attn_out, const float* res, const WT* wo, const float* bo, const float* ln_g,
                               const float* ln_b, const WT* w1, const float* b1, const WT* w2, int F, float* x_out, float* parts, int n_parts,
                               int rows, int E, float eps, void* stream) {
@@ -532,7 +634,7 @@ static int dec_post_self_impl(const char* who, const float* attn_out, const floa
     MSM_REQUIRE(rows > 0 && F > 0 && F % DC_E == 0, "%s: F=%d must be a positive multiple of 256", who, F);
     MSM_REQUIRE(n_parts > 0 && (F / DC_E) % n_parts == 0, "%s: n_parts=%d must divide F/256=%d", who, n_parts, F / DC_E);
     MSM_REQUIRE(aligned16(attn_out) && aligned16(wo) && aligned16(w1) && aligned16(w2), "%s: pointers must be 16-byte aligned", who);
-    hipLaunchKernelGGL(dec_post_self_kernel<WT>, dim3(cdiv(rows, DC_R), n_parts), dim3(DC_THREADS), 0, (hipStream_t)stream, attn_out,
+    hipLaunchKernelGGL(dec_post_self_kernel<TK>, dim3(cdiv(rows, TK::R), n_parts), dim3(DC_THREADS), 0, (hipStream_t)stream, attn_out,
                        res, wo, bo, ln_g, ln_b, w1, b1, w2, F, x_out, parts, rows, eps);
     MSM_CHECK_LAUNCH(who);
     return MSM_OK;
@@ -541,17 +643,20 @@ static int dec_post_self_impl(const char* who, const float* attn_out, const floa
 extern "C" int msm_dec_post_self(const float* attn_out, const float* res, const float* wo, const float* bo, const float* ln_g,
                                  const float* ln_b, const float* w1, const float* b1, const float* w2, int F, float* x_out,
                                  float* parts, int n_parts, int rows, int E, float eps, void* stream) {
-    return dec_post_self_impl<float>("msm_dec_post_self", attn_out, res, wo, bo, ln_g, ln_b, w1, b1, w2, F, x_out, parts, n_parts, rows, E, eps,
-                                     stream);
+    if (n_parts > 0 && use_tile8(rows, n_parts))
+        return dec_post_self_impl<TileF8>("msm_dec_post_self", attn_out, res, wo, bo, ln_g, ln_b, w1, b1, w2, F, x_out, parts, n_parts, rows, E, eps,
+                                          stream);
+    return dec_post_self_impl<TileF16>("msm_dec_post_self", attn_out, res, wo, bo, ln_g, ln_b, w1, b1, w2, F, x_out, parts, n_parts, rows, E, eps,
+                                       stream);
 }
 extern "C" int msm_dec_post_self_bf16(const float* attn_out, const float* res, const uint16_t* wo, const float* bo, const float* ln_g,
                                       const float* ln_b, const uint16_t* w1, const float* b1, const uint16_t* w2, int F, float* x_out,
                                       float* parts, int n_parts, int rows, int E, float eps, void* stream) {
-    return dec_post_self_impl<uint16_t>("msm_dec_post_self_bf16", attn_out, res, wo, bo, ln_g, ln_b, w1, b1, w2, F, x_out, parts, n_parts, rows, E,
+    return dec_post_self_impl<TileH16>("msm_dec_post_self_bf16", attn_out, res, wo, bo, ln_g, ln_b, w1, b1, w2, F, x_out, parts, n_parts, rows, E,
                                         eps, stream);
 }
 
-template <typename WT>
+template <typename TK, typename WT = typename TK::WT>
 static int dec_heads_impl(const char* who, const float* x, const float* parts, int n_parts, const float* bias, const float* ln_g,
                           const float* ln_b, int l2norm, const float* dec_g, const float* dec_b, const WT* m0w, const float* m0b, const WT* m1w,
                           const float* m1b, const WT* m2w, const float* m2b, const WT* wq, const float* bq, const float* query_pos, float* out,
@@ -563,7 +668,7 @@ static int dec_heads_impl(const char* who, const float* x, const float* parts, i
     MSM_REQUIRE((ln_g == nullptr) == (ln_b == nullptr), "%s: ln_g/ln_b must both be given or both be null", who);
     MSM_REQUIRE(!wq || (bq && query_pos && q_out), "%s: the next-query projection needs bq, query_pos and q_out", who);
     MSM_REQUIRE(aligned16(m0w) && aligned16(m1w) && aligned16(m2w) && aligned16(wq), "%s: weights must be 16-byte aligned", who);
-    hipLaunchKernelGGL(dec_heads_kernel<WT>, dim3(cdiv(rows, DC_R), wq ? 2 : 1), dim3(DC_THREADS), 0, (hipStream_t)stream, x, parts, n_parts, bias,
+    hipLaunchKernelGGL(dec_heads_kernel<TK>, dim3(cdiv(rows, TK::R), wq ? 2 : 1), dim3(DC_THREADS), 0, (hipStream_t)stream, x, parts, n_parts, bias,
                        ln_g, ln_b, l2norm, dec_g, dec_b, m0w, m0b, m1w, m1b, m2w, m2b, wq, bq, query_pos, out, d_out, e_out, q_out,
                        row_any_zero, rows, Q, eps);
     MSM_CHECK_LAUNCH(who);
@@ -575,14 +680,17 @@ extern "C" int msm_dec_heads(const float* x, const float* parts, int n_parts, co
                              const float* m0b, const float* m1w, const float* m1b, const float* m2w, const float* m2b,
                              const float* wq, const float* bq, const float* query_pos, float* out, float* d_out, float* e_out,
                              float* q_out, int32_t* row_any_zero, int rows, int Q, int E, float eps, void* stream) {
-    return dec_heads_impl<float>("msm_dec_heads", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, m0w, m0b, m1w, m1b, m2w, m2b, wq, bq,
-                                 query_pos, out, d_out, e_out, q_out, row_any_zero, rows, Q, E, eps, stream);
+    if (use_tile8(rows, wq ? 2 : 1))
+        return dec_heads_impl<TileF8>("msm_dec_heads", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, m0w, m0b, m1w, m1b, m2w, m2b, wq, bq,
+                                      query_pos, out, d_out, e_out, q_out, row_any_zero, rows, Q, E, eps, stream);
+    return dec_heads_impl<TileF16>("msm_dec_heads", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, m0w, m0b, m1w, m1b, m2w, m2b, wq, bq,
+                                   query_pos, out, d_out, e_out, q_out, row_any_zero, rows, Q, E, eps, stream);
 }
 extern "C" int msm_dec_heads_bf16(const float* x, const float* parts, int n_parts, const float* bias, const float* ln_g,
                                   const float* ln_b, int l2norm, const float* dec_g, const float* dec_b, const uint16_t* m0w,
                                   const float* m0b, const uint16_t* m1w, const float* m1b, const uint16_t* m2w, const float* m2b,
                                   const uint16_t* wq, const float* bq, const float* query_pos, float* out, float* d_out, float* e_out,
                                   float* q_out, int32_t* row_any_zero, int rows, int Q, int E, float eps, void* stream) {
-    return dec_heads_impl<uint16_t>("msm_dec_heads_bf16", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, m0w, m0b, m1w, m1b, m2w, m2b,
+    return dec_heads_impl<TileH16>("msm_dec_heads_bf16", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, m0w, m0b, m1w, m1b, m2w, m2b,
                                     wq, bq, query_pos, out, d_out, e_out, q_out, row_any_zero, rows, Q, E, eps, stream);
 }
