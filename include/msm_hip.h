@@ -59,7 +59,7 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 12   /* 12: head-major bf16 activations between the encoder kernels of the bf16 plan (msm_encoder_block_hm_fwd, msm_msdeform_attn_enc_lp_fwd, msm_f32_to_f16); 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
+#define MSM_ABI_VERSION 13   /* 13: flags argument of msm_ms_select_seeds_bf16 (persistent on-chip seeding over the bf16 copy); 12: head-major bf16 activations between the encoder kernels of the bf16 plan (msm_encoder_block_hm_fwd, msm_msdeform_attn_enc_lp_fwd, msm_f32_to_f16); 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
 int msm_abi_version(void);
 
 /* Kernel-selection overrides for tools/ and tests/ (NOT read on the product path: every option defaults to
@@ -470,11 +470,13 @@ int msm_ms_hill_climb_split(const float* X, int n, int d, float* Z, int S, float
  * points: seeds and labels equal the fp32 results up to which member of a cluster is picked / a permutation of the labels
  * (SURVEY 8c); the fp32 and f32_split entry points stay exact.
  * msm_ms_select_seeds_bf16: workspace as msm_ms_select_seeds (msm_ms_seed_workspace(n) floats); seeds_out are rows of the fp32 X
- * (MS:186-189 returns X[selected]); n >= 16.  msm_ms_hill_climb_bf16: workspace msm_ms_hill_climb_workspace(n, S) floats. */
+ * (MS:186-189 returns X[selected]); n >= 16.  flags as msm_ms_select_seeds: maps of >= 65536 rows take ONE persistent launch that
+ * keeps 917 504 rows of the copy on chip (VGPRs + LDS) and streams the rest per step; it gives up (indices -1) under the same
+ * co-residency condition, and MSM_MS_SEED_STEPWISE selects the one-launch-per-step kernel, whose indices are bit-identical.  msm_ms_hill_climb_bf16: workspace msm_ms_hill_climb_workspace(n, S) floats. */
 int64_t msm_ms_bf16_rows(int n);
 int msm_ms_pack_bf16(const float* X, int n, int d, void* Xb, void* stream);
 int msm_ms_select_seeds_bf16(const void* Xb, const float* X, int n, int d, int num_seeds, int64_t first_index, float* seeds_out,
-                             int64_t* indices_out, float* workspace, int64_t workspace_elems, void* stream);
+                             int64_t* indices_out, float* workspace, int64_t workspace_elems, int flags, void* stream);
 int msm_ms_hill_climb_bf16(const void* Xb, int n, int d, float* Z, int S, float kappa, int iters, float* workspace,
                            int64_t workspace_elems, void* stream);
 /* closest = first argmin_s 0.5*(1 - X.Z_s); labels_out[i] = seed_labels[closest] (int64);

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmsm_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "msm_hip.h")
 
 _lib = None
-ABI_VERSION = 12     # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
+ABI_VERSION = 13     # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
 
 c_f = ctypes.c_void_p      # float* (device)
 c_p = ctypes.c_void_p
@@ -96,7 +96,7 @@ _SIGNATURES = {
     "msm_ms_hill_climb_split": (c_i, [c_f, c_i, c_i, c_f, c_i, c_fl, c_i, c_f, c_l, c_p]),
     "msm_ms_bf16_rows": (c_l, [c_i]),
     "msm_ms_pack_bf16": (c_i, [c_f, c_i, c_i, c_p, c_p]),
-    "msm_ms_select_seeds_bf16": (c_i, [c_p, c_f, c_i, c_i, c_i, c_l, c_f, c_p, c_f, c_l, c_p]),
+    "msm_ms_select_seeds_bf16": (c_i, [c_p, c_f, c_i, c_i, c_i, c_l, c_f, c_p, c_f, c_l, c_i, c_p]),
     "msm_ms_hill_climb_bf16": (c_i, [c_p, c_i, c_i, c_f, c_i, c_fl, c_i, c_f, c_l, c_p]),
     "msm_ms_assign": (c_i, [c_f, c_i, c_i, c_f, c_i, c_p, c_p, c_p, c_i, c_p]),
     "msm_ms_connected_components": (c_i, [c_f, c_i, c_i, c_fl, c_p, c_p, c_p]),

@@ -262,6 +262,85 @@ constexpr int PS_W = 8;                      // waves per persistent workgroup
 constexpr int PS_MAXWG = 256;                // workgroups of the persistent launch (one per CU at most)
 constexpr unsigned PS_SPIN_LIMIT = 1u << 20; // polls (with s_sleep) before giving up: well under a second
 
+// lane j of a 16-lane group ends with the full dot product of row j: p[i] holds this lane's partial of row i on entry
+__device__ __forceinline__ float butterfly16(float (&p)[16], int j) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const bool hi = j & 8;
+        const float send = hi ? p[i] : p[i + 8];
+        const float keep = hi ? p[i + 8] : p[i];
+        p[i] = keep + __shfl_xor(send, 8, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool hi = j & 4;
+        const float send = hi ? p[i] : p[i + 4];
+        const float keep = hi ? p[i + 4] : p[i];
+        p[i] = keep + __shfl_xor(send, 4, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const bool hi = j & 2;
+        const float send = hi ? p[i] : p[i + 2];
+        const float keep = hi ? p[i + 2] : p[i];
+        p[i] = keep + __shfl_xor(send, 2, 64);
+    }
+    const bool hi = j & 1;
+    const float send = hi ? p[0] : p[1];
+    const float keep = hi ? p[1] : p[0];
+    return keep + __shfl_xor(send, 1, 64);
+}
+
+// ---- the persistent kernels' per-step exchange, data-tagged (round 3: 10 -> 8.4 (fence-free counter) -> 5.6 us per step) ----
+// A counter barrier costs four dependent round trips to the memory-side atomics per step (max, arrival, poll, key read).
+// Here a workgroup PUBLISHES its candidate `b` in its own slot as two 8-byte {step, payload} granules (one relaxed
+// agent-scope store each: the data is the flag, guide recipe R2) and one wave per workgroup SWEEPS all slots -- <= 256 x 2
+// granules, eight 8-byte loads per lane, all in flight together -- until every tag equals the step, then takes the maximum
+// itself: one store and (typically) two sweeps per step.  Slots are double-buffered by step parity: a workgroup can run at
+// most one step ahead of the slowest (its next sweep needs everybody's next store), so a slot is never overwritten before
+// every sweep of its previous use is over.  Called by one whole wave; returns the step's winner, `gave_up` set when the
+// bounded wait ran out (or another workgroup raised status[1]).
+__device__ __forceinline__ unsigned long long ps_exchange(unsigned long long b, int step, unsigned long long* __restrict__ gran,
+                                                          unsigned int* __restrict__ status, int lane, unsigned int& gave_up) {
+    unsigned long long* ga = gran + (size_t)(step & 1) * 2 * PS_MAXWG;           // [2][PS_MAXWG]: value granules, index granules
+    const unsigned long long tag = (unsigned long long)(unsigned int)step << 32;
+    if (lane == 0) {
+        __hip_atomic_store(ga + blockIdx.x, tag | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ga + PS_MAXWG + blockIdx.x, tag | (b & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned long long win = 0ull;
+    gave_up = 0;
+    for (unsigned int polls = 0;; ++polls) {
+        bool ok = true;
+        win = 0ull;
+#pragma unroll
+        for (int k = 0; k < PS_MAXWG / 64; ++k) {
+            const int slot = k * 64 + lane;
+            if (slot < (int)gridDim.x) {
+                const unsigned long long va = __hip_atomic_load(ga + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long vi = __hip_atomic_load(ga + PS_MAXWG + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = ok && (va >> 32) == (tag >> 32) && (vi >> 32) == (tag >> 32);
+                const unsigned long long key = (va << 32) | (vi & 0xFFFFFFFFull);
+                win = key > win ? key : win;
+            }
+        }
+        if (__all(ok)) break;
+        if ((polls & 15u) == 15u && __hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { gave_up = 1; break; }
+        if (polls > PS_SPIN_LIMIT) {
+            if (lane == 0) __hip_atomic_store(&status[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gave_up = 1;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(win, o, 64);
+        win = other > win ? other : win;
+    }
+    return win;
+}
+
 template <int NG>
 __global__ __launch_bounds__(PS_W * 64) void ms_seed_persistent_kernel(const float* __restrict__ X, int n,
                                                                      unsigned long long* __restrict__ keys, int num_seeds,
@@ -340,53 +419,11 @@ __global__ __launch_bounds__(PS_W * 64) void ms_seed_persistent_kernel(const flo
         if (lane == 0) red[wave] = best;
         __syncthreads();
         if (wave == 0) {
-            // ---- the step's exchange, data-tagged (round 3: 10 -> 8.4 (fence-free counter) -> see DESIGN.md us per step) ----
-            // A counter barrier costs four dependent round trips to the memory-side atomics per step (max, arrival, poll,
-            // key read).  Here a workgroup PUBLISHES its candidate in its own slot as two 8-byte {step, payload} granules
-            // (one relaxed agent-scope store each: the data is the flag, guide recipe R2) and one wave per workgroup SWEEPS
-            // all slots -- <= 256 x 2 granules, eight 8-byte loads per lane, all in flight together -- until every tag
-            // equals the step, then takes the maximum itself: one store and (typically) two sweeps per step.  Slots are
-            // double-buffered by step parity: a workgroup can run at most one step ahead of the slowest (its next sweep
-            // needs everybody's next store), so a slot is never overwritten before every sweep of its previous use is over.
             unsigned long long b = red[0];
 #pragma unroll
             for (int w = 1; w < PS_W; ++w) b = red[w] > b ? red[w] : b;
-            unsigned long long* ga = gran + (size_t)(step & 1) * 2 * PS_MAXWG;           // [2][PS_MAXWG]: value granules, index granules
-            const unsigned long long tag = (unsigned long long)(unsigned int)step << 32;
-            if (lane == 0) {
-                __hip_atomic_store(ga + blockIdx.x, tag | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(ga + PS_MAXWG + blockIdx.x, tag | (b & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            unsigned long long win = 0ull;
-            unsigned int gave_up = 0;
-            for (unsigned int polls = 0;; ++polls) {
-                bool ok = true;
-                win = 0ull;
-#pragma unroll
-                for (int k = 0; k < PS_MAXWG / 64; ++k) {
-                    const int slot = k * 64 + lane;
-                    if (slot < (int)gridDim.x) {
-                        const unsigned long long va = __hip_atomic_load(ga + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const unsigned long long vi = __hip_atomic_load(ga + PS_MAXWG + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok = ok && (va >> 32) == (tag >> 32) && (vi >> 32) == (tag >> 32);
-                        const unsigned long long key = (va << 32) | (vi & 0xFFFFFFFFull);
-                        win = key > win ? key : win;
-                    }
-                }
-                if (__all(ok)) break;
-                if ((polls & 15u) == 15u && __hip_atomic_load(&status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { gave_up = 1; break; }
-                if (polls > PS_SPIN_LIMIT) {
-                    if (lane == 0) __hip_atomic_store(&status[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    gave_up = 1;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const unsigned long long other = __shfl_xor(win, o, 64);
-                win = other > win ? other : win;
-            }
+            unsigned int gave_up;
+            const unsigned long long win = ps_exchange(b, step, gran, status, lane, gave_up);     // see ps_exchange
             if (lane == 0) {
                 abort_s = gave_up;
                 prev_s = win;                                        // the winner of this step: the next step's row
@@ -395,6 +432,141 @@ __global__ __launch_bounds__(PS_W * 64) void ms_seed_persistent_kernel(const flo
         }
         __syncthreads();
         if (abort_s != 0u) return;               // uniform per block after the barrier
+    }
+}
+
+// ---- persistent seeding over the bf16 copy for maps BEYOND the register file (round 4) ---------------------------------------
+// At 1280x960 the bf16 copy is 157 MB: no longer register-resident, but most of it still fits ON CHIP.  One launch, one
+// workgroup per CU, and three homes for a workgroup's rows: NG tiles of 16 rows per 16-lane group in VGPRs (256 x 32 x NG x 16
+// = 655 360 rows at NG = 5), NL tiles per group in LDS (262 144 rows at NL = 2, 132 KiB per CU; a group's tiles are offset by
+// 128 B so the two groups of a 32-lane ds_read_b64 phase use opposite bank halves), and the remaining rows (311 296 = 40 MB at
+// 1280x960) streamed from HBM every step with their nearest-distance in global memory, as the stepwise kernel does for
+// all of them.  Every row's arithmetic is that of ms_seed_step_bf16_kernel (two v_dot2 per row chunk, the same butterfly,
+// the same (value, ~index) key), so the selected indices are bit-identical to the stepwise bf16 path; the steps' exchange is
+// ps_exchange.  Tiles past the end of the map re-cover its last 16 rows (duplicates cannot change a maximum).
+constexpr int PB_GROUPS = PS_W * 4;                               // 16-lane groups per workgroup
+
+template <int NG, int NL>
+__global__ __launch_bounds__(PS_W * 64) void ms_seed_persistent_bf16_kernel(const uint16_t* __restrict__ Xb, int n,
+                                                                          unsigned long long* __restrict__ keys, int num_seeds,
+                                                                          unsigned int* __restrict__ status, unsigned long long* __restrict__ gran,
+                                                                          float* __restrict__ nearest_tail, int tail0, int tail_rows_per_wg) {
+    constexpr int LDS_GROUP = NL * 16 * 128 + 128;                // bytes of a group's LDS tiles (+128: alternate bank halves)
+    extern __shared__ __attribute__((aligned(16))) unsigned char pb_lds[];
+    __shared__ unsigned long long red[PS_W];
+    __shared__ unsigned long long prev_s;
+    __shared__ unsigned int abort_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 15, grp = lane >> 4, gi = wave * 4 + grp;
+    const int gslot = blockIdx.x * PB_GROUPS + gi;
+    const int reg_rows = gridDim.x * PB_GROUPS * NG * 16;
+    uint2 x[NG][16];
+    float near[NG], near_l[NL];
+#pragma unroll
+    for (int t = 0; t < NG; ++t) {
+        const uint16_t* src = Xb + (int64_t)min((gslot * NG + t) * 16, n - 16) * MS_D + j * 4;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[t][i] = *reinterpret_cast<const uint2*>(src + i * MS_D);
+        near[t] = INFINITY;
+    }
+    unsigned char* ltile = pb_lds + gi * LDS_GROUP + j * 8;
+#pragma unroll
+    for (int t = 0; t < NL; ++t) {
+        const uint16_t* src = Xb + (int64_t)min(reg_rows + (gslot * NL + t) * 16, n - 16) * MS_D + j * 4;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) *reinterpret_cast<uint2*>(ltile + (t * 16 + i) * 128) = *reinterpret_cast<const uint2*>(src + i * MS_D);
+        near_l[t] = INFINITY;
+    }
+    // the streamed tail of this workgroup: rows [t0, t1), 512 per pass
+    const int t0 = min(n, tail0 + blockIdx.x * tail_rows_per_wg), t1 = min(n, t0 + tail_rows_per_wg);
+    // The tail's first pass does not depend on the step's seed: its rows are requested before the previous step's exchange and
+    // arrive behind it.
+    uint2 xs[16];
+    const bool has_tail = t0 + gi * 16 < t1;
+    const uint16_t* tail_src = Xb + (int64_t)min(t0 + gi * 16, n - 16) * MS_D + j * 4;
+    if (has_tail) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xs[i] = *reinterpret_cast<const uint2*>(tail_src + i * MS_D);
+    }
+    if (tid == 0) prev_s = __hip_atomic_load(&keys[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    for (int step = 1; step < num_seeds; ++step) {
+        const unsigned int cur = 0xFFFFFFFFu - (unsigned int)(prev_s & 0xFFFFFFFFull);
+        if (cur >= (unsigned int)n) return;      // only after an abort elsewhere (keys left at 0): leave, uniformly
+        const uint2 s = *reinterpret_cast<const uint2*>(Xb + (int64_t)cur * MS_D + j * 4);
+        unsigned long long best = 0ull;
+        // LDS tiles first, then the tail's first pass goes out and is in flight behind the register tiles
+#pragma unroll
+        for (int t = 0; t < NL; ++t) {
+            float p[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) p[i] = dot4_bf16(*reinterpret_cast<const uint2*>(ltile + (t * 16 + i) * 128), s);
+            const float d = fminf(near_l[t], 0.5f * (1.0f - butterfly16(p, j)));
+            near_l[t] = d;
+            const int row = min(reg_rows + (gslot * NL + t) * 16, n - 16) + j;
+            const unsigned long long key = ((unsigned long long)ordered_bits(d) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)row);
+            best = key > best ? key : best;
+            __builtin_amdgcn_sched_barrier(0);       // one tile at a time: interleaved tiles cost 16 live partials each
+        }
+        int base = t0 + gi * 16, gbs = min(base, n - 16);
+        float near_s = (step > 1 && base < t1) ? nearest_tail[gbs + j - tail0] : INFINITY;
+#pragma unroll
+        for (int t = 0; t < NG; ++t) {
+            float p[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) p[i] = dot4_bf16(x[t][i], s);
+            const float d = fminf(near[t], 0.5f * (1.0f - butterfly16(p, j)));
+            near[t] = d;
+            const int row = min((gslot * NG + t) * 16, n - 16) + j;
+            const unsigned long long key = ((unsigned long long)ordered_bits(d) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)row);
+            best = key > best ? key : best;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (; base < t1; base += PB_GROUPS * 16) {
+            float p[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) p[i] = dot4_bf16(xs[i], s);
+            const int row = gbs + j;
+            const float near_now = near_s;
+            // the next pass's rows go out before this pass's butterfly (the dot products above were the last use of xs)
+            const int nbase = base + PB_GROUPS * 16;
+            if (nbase < t1) {
+                gbs = min(nbase, n - 16);
+                const uint16_t* src = Xb + (int64_t)gbs * MS_D + j * 4;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) xs[i] = *reinterpret_cast<const uint2*>(src + i * MS_D);
+                if (step > 1) near_s = nearest_tail[gbs + j - tail0];
+            }
+            const float d = fminf(near_now, 0.5f * (1.0f - butterfly16(p, j)));
+            nearest_tail[row - tail0] = d;
+            const unsigned long long key = ((unsigned long long)ordered_bits(d) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned int)row);
+            best = key > best ? key : best;
+        }
+        if (has_tail && step + 1 < num_seeds) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xs[i] = *reinterpret_cast<const uint2*>(tail_src + i * MS_D);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(best, o, 64);
+            best = other > best ? other : best;
+        }
+        if (lane == 0) red[wave] = best;
+        __syncthreads();
+        if (wave == 0) {
+            unsigned long long b = red[0];
+#pragma unroll
+            for (int w = 1; w < PS_W; ++w) b = red[w] > b ? red[w] : b;
+            unsigned int gave_up;
+            const unsigned long long win = ps_exchange(b, step, gran, status, lane, gave_up);
+            if (lane == 0) {
+                abort_s = gave_up;
+                prev_s = win;
+                if (blockIdx.x == 0 && !gave_up) keys[step] = win;
+            }
+        }
+        __syncthreads();
+        if (abort_s != 0u) return;
     }
 }
 
@@ -1514,7 +1686,7 @@ extern "C" int msm_ms_pack_bf16(const float* X, int n, int d, void* Xb, void* st
 }
 
 extern "C" int msm_ms_select_seeds_bf16(const void* Xb, const float* X, int n, int d, int num_seeds, int64_t first_index, float* seeds_out,
-                                        int64_t* indices_out, float* workspace, int64_t workspace_elems, void* stream) {
+                                        int64_t* indices_out, float* workspace, int64_t workspace_elems, int flags, void* stream) {
     MSM_REQUIRE(Xb && X && seeds_out && indices_out && workspace, "msm_ms_select_seeds_bf16: null pointer");
     MSM_REQUIRE(d == MS_D, "msm_ms_select_seeds_bf16: d=%d, only d=64 is supported", d);
     MSM_REQUIRE(n >= 16 && num_seeds > 0 && first_index >= 0 && first_index < n, "msm_ms_select_seeds_bf16: bad sizes (n >= 16)");
@@ -1528,6 +1700,30 @@ extern "C" int msm_ms_select_seeds_bf16(const void* Xb, const float* X, int n, i
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(workspace);
     float* nearest = workspace + 2 * (MS_SB * 16) + 8;
     hipLaunchKernelGGL(ms_seed_init_kernel, dim3(cdiv(num_seeds, 64)), dim3(64), 0, st, keys, num_seeds, first_index);
+    // one persistent launch with the rows held in VGPRs / LDS / streamed (ms_seed_persistent_bf16_kernel): one workgroup per CU
+    static const int n_cus = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+        return v;
+    }();
+    constexpr int NG = 5, NL = 2;
+    const int pgrid = min(n_cus, PS_MAXWG);
+    const int tail0 = pgrid * PB_GROUPS * (NG + NL) * 16;
+    if (pgrid >= 64 && n >= 65536 && (n <= tail0 || n - tail0 >= 16) && num_seeds > 2 && !(flags & MSM_MS_SEED_STEPWISE) &&
+        opt(MSM_OPT_MS_NO_PERSISTENT) != 1) {
+        unsigned int* status = reinterpret_cast<unsigned int*>(workspace + 2 * (MS_SB * 16) + 4);
+        unsigned long long* gran = reinterpret_cast<unsigned long long*>(nearest);          // 8 KiB of exchange slots, then the tail's nearest[]
+        float* nearest_tail = nearest + 4 * PS_MAXWG * 2;
+        const int tail_rows_per_wg = n > tail0 ? cdiv(cdiv(n - tail0, pgrid), 16) * 16 : 0;
+        const size_t lds = (size_t)PB_GROUPS * (NL * 16 * 128 + 128);
+        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)ms_seed_persistent_bf16_kernel<NG, NL>, lds));
+        hipLaunchKernelGGL(ms_seed_status_init_kernel, dim3(1), dim3(256), 0, st, status, (flags & MSM_MS_SEED_TEST_GIVE_UP) ? 1u : 0u, gran);
+        hipLaunchKernelGGL((ms_seed_persistent_bf16_kernel<NG, NL>), dim3(pgrid), dim3(PS_W * 64), lds, st, (const uint16_t*)Xb, n, keys, num_seeds,
+                           status, gran, nearest_tail, tail0, tail_rows_per_wg);
+        hipLaunchKernelGGL(ms_seed_finish_kernel, dim3(num_seeds), dim3(64), 0, st, X, keys, indices_out, seeds_out, status, n);
+        MSM_CHECK_LAUNCH("msm_ms_select_seeds_bf16(persistent)");
+        return MSM_OK;
+    }
     const int nblk = seed_blocks(n);
     for (int i = 1; i < num_seeds; ++i)
         hipLaunchKernelGGL(ms_seed_step_bf16_kernel, dim3(nblk), dim3(256), 0, st, (const uint16_t*)Xb, n, keys, i, nearest);

@@ -98,7 +98,7 @@ def select_smart_seeds(X, num_seeds, return_selected_indices=False, init_seeds=N
     if not return_selected_indices:
         # the caller cannot see the indices, so the give-up of the persistent kernel (ops.ms_select_seeds) is handled here
         if not stepwise and int(idx.min()) < 0:
-            seeds, idx = ops.ms_select_seeds(X.contiguous(), num_seeds, int(first_index), stepwise=True)
+            seeds, idx = ops.ms_select_seeds(X.contiguous(), num_seeds, int(first_index), stepwise=True, xb=xb)
         return (seeds,)
     return seeds, idx
 
@@ -130,7 +130,7 @@ def mean_shift_smart_init(X, kappa, num_seeds=100, max_iters=10, metric="cosine"
     # (identical results) and everything after it.
     if int(selected.min()) < 0:
         seeds, selected = select_smart_seeds(X, num_seeds, return_selected_indices=True, metric=metric,
-                                             first_index=first_index, stepwise=True)
+                                             first_index=first_index, stepwise=True, xb=xb)
         labels = rest(seeds)
     return labels, selected
 

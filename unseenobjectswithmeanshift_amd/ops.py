@@ -854,8 +854,9 @@ def ms_select_seeds(X, num_seeds, first_index, stepwise=False, _test_give_up=Fal
     """Farthest-point seeding.  X (n,64) unit rows.  Returns (seeds (S,64), indices int64 (S,)).  The single-launch
     persistent kernel (maps up to 393 216 rows) needs its workgroups co-resident; if other work holds the CUs it gives up
     and every index is -1 -- callers re-issue with ``stepwise=True`` (mean_shift.mean_shift_smart_init does).
-    ``xb`` (ms_pack_bf16(X); precision "bf16"): maps beyond the persistent kernel's reach stream the bf16 copy -- half the
-    bytes of a pass; distances are those of the rounded points, so the indices may differ from the fp32 path's."""
+    ``xb`` (ms_pack_bf16(X); precision "bf16"): maps beyond the fp32 persistent kernel's reach work on the bf16 copy -- one
+    persistent launch that keeps 917 504 rows on chip (VGPRs + LDS) and streams the rest per step, or (``stepwise``) one
+    launch per step over the copy; distances are those of the rounded points, so the indices may differ from the fp32 path's."""
     _c(X, "X")
     n, d = X.shape
     seeds = torch.empty((num_seeds, d), device=X.device, dtype=torch.float32)
@@ -866,7 +867,8 @@ def ms_select_seeds(X, num_seeds, first_index, stepwise=False, _test_give_up=Fal
         _c(xb, "xb", torch.bfloat16)
         if xb.shape[0] < n or xb.shape[1] != d:
             raise RuntimeError("ms_select_seeds: xb must be ms_pack_bf16(X)")
-        rc = lib().msm_ms_select_seeds_bf16(_p(xb), _p(X), n, d, num_seeds, int(first_index), _p(seeds), _p(idx), _p(ws), need, _stream())
+        rc = lib().msm_ms_select_seeds_bf16(_p(xb), _p(X), n, d, num_seeds, int(first_index), _p(seeds), _p(idx), _p(ws), need,
+                                            (1 if stepwise else 0) | (2 if _test_give_up else 0), _stream())
         check(rc, "msm_ms_select_seeds_bf16")
         return seeds, idx
     rc = lib().msm_ms_select_seeds(_p(X), n, d, num_seeds, int(first_index), _p(seeds), _p(idx), _p(ws), need,
