@@ -345,6 +345,9 @@ def precision_leg(model, feats, dev, dist, args, precision, inflight, sparse_tap
         g_ms, g_n = entry_graph_ms(step, "ms_deform_attn_encoder_lp")
         e_bytes = tokens * (128 + 256 + 256) + tokens * (128 + 576) * (e_n - 1) / max(e_n, 1)          # last layer: no value / projection
         e_flops = 2.0 * tokens * (64 * 64 + 2 * 64 * 1024) + 2.0 * tokens * (64 * 64 + 64 * 288) * (e_n - 1) / max(e_n, 1)
+        # issued products: out_proj / value / sampling projection as three terms (w_lo x_hi + w_hi x_lo + w_hi x_hi), linear1 as two (x = h + l),
+        # linear2 as one
+        e_exec = 2.0 * tokens * (3 * 64 * 64 + 2 * 64 * 1024 + 64 * 1024) + 2.0 * tokens * 3 * (64 * 64 + 64 * 288) * (e_n - 1) / max(e_n, 1)
         g_bytes = tokens * (128 + 576 + 128)
         e_t, g_t = 1e-3 * e_ms / max(e_n, 1), 1e-3 * g_ms / max(g_n, 1)
         roof = {"bound": "hbm", "kernel": "enc_block_hm_kernel (msm_encoder_block_hm_fwd): the bf16 plan's encoder-layer tail",
@@ -352,6 +355,7 @@ def precision_leg(model, feats, dev, dist, args, precision, inflight, sparse_tap
                 "traffic": None, "launches_per_step": e_n, "avg_launch_ms": round(1e3 * e_t, 4), "algorithmic_bytes_per_launch": e_bytes,
                 "useful_flops_per_launch": e_flops, "useful_tflops": round(e_flops / e_t / 1e12, 1),
                 "frac_of_bf16_mfma_peak": round(e_flops / e_t / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                "issued_tflops": round(e_exec / e_t / 1e12, 1), "issued_frac_of_bf16_mfma_peak": round(e_exec / e_t / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
                 "gather": {"kernel": "msda_enc_lp_kernel (msm_msdeform_attn_enc_lp_fwd)", "launches_per_step": g_n, "avg_launch_ms": round(1e3 * g_t, 4),
                            "algorithmic_bytes_per_launch": g_bytes, "achieved_gbps": round(g_bytes / g_t / 1e9, 1),
                            "frac_of_hbm_peak": round(g_bytes / g_t / 1e9 / PEAK_HBM_GBPS, 4)},

@@ -59,7 +59,7 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 13   /* 13: flags argument of msm_ms_select_seeds_bf16 (persistent on-chip seeding over the bf16 copy); 12: head-major bf16 activations between the encoder kernels of the bf16 plan (msm_encoder_block_hm_fwd, msm_msdeform_attn_enc_lp_fwd, msm_f32_to_f16); 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
+#define MSM_ABI_VERSION 13   /* 13: flags argument of msm_ms_select_seeds_bf16 (persistent on-chip seeding over the bf16 copy), input projections on the bf16 matrix pipe (msm_conv1x1_in_lp, msm_conv1x1_in_multi_lp); 12: head-major bf16 activations between the encoder kernels of the bf16 plan (msm_encoder_block_hm_fwd, msm_msdeform_attn_enc_lp_fwd, msm_f32_to_f16); 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
 int msm_abi_version(void);
 
 /* Kernel-selection overrides for tools/ and tests/ (NOT read on the product path: every option defaults to
@@ -545,6 +545,18 @@ int msm_conv1x1_in_f32(const float* x, const float* w_packed, const float* bias,
 int msm_conv1x1_in_multi_f32(int n_levels, const float* const* x, const float* const* w_packed, const float* const* bias,
                              const int32_t* Cin, const int32_t* HW, float* out, int64_t out_batch_stride, double* stats,
                              int stats_cleared, int B, void* stream);
+
+/* The same two entry points on the bf16 matrix pipe (the bf16 plan; csrc/conv_in.hip, conv_in_lp_tile): both operands as hi + lo
+ * bf16 pairs, three K = 32 MFMAs per product (w_l x_h + w_h x_l + w_h x_h), fp32 accumulation and fp32 results -- the error against
+ * float64 stays at the fp32 kernels' level (the dropped term is 2^-18 of a product); what changes is the bound: the stream of x
+ * instead of the fp32 matrix pipe.  x is split in registers; the weight arrives pre-split:
+ *   w_packed: 2 * 64 * Cin bf16,  w_packed[(((g*4 + o/16)*2 + plane)*64 + ((k%32)/8)*16 + o%16)*8 + k%8] = plane(w)[o][k],  g = k/32,
+ *   plane 0 = bf16(w), plane 1 = bf16(w - plane 0).  Cin a multiple of 256, HW of 4; everything else as the fp32 entry points. */
+int msm_conv1x1_in_lp(const float* x, const void* w_packed, const float* bias, float* out, int64_t out_batch_stride,
+                      double* stats, int stats_cleared, int B, int Cin, int HW, void* stream);
+int msm_conv1x1_in_multi_lp(int n_levels, const float* const* x, const void* const* w_packed, const float* const* bias,
+                            const int32_t* Cin, const int32_t* HW, float* out, int64_t out_batch_stride, double* stats,
+                            int stats_cleared, int B, void* stream);
 
 /* The decoder's attention masks at the resolution they are used at (meanshiftformer_transformer_decoder.py:668-680; csrc/attn_mask.hip).
  * interpolate(einsum(e, F), size, bilinear, align_corners=False) = einsum(e, interpolate(F)): the two act on different axes.

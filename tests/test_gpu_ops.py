@@ -1072,6 +1072,60 @@ def test_conv1x1_in_vs_fp64(B, Cin, H, W):
         ops().conv1x1_in(torch.zeros(1, 96, 4, 4, device=DEV), torch.zeros(64 * 96, device=DEV))
 
 
+@pytest.mark.parametrize("B,Cin,H,W", [(2, 2048, 15, 20), (3, 1024, 30, 40), (8, 512, 60, 80), (1, 256, 10, 6), (2, 256, 100, 164),
+                                        (1, 512, 128, 65)])          # the last two: one tile per wave over the full K, ragged last tile
+def test_conv1x1_in_lp_vs_fp64(B, Cin, H, W):
+    """msm_conv1x1_in_lp (the bf16 plan's input projections: hi + lo bf16 operands, three K = 32 MFMAs per product, fp32 results)
+    against the fp64 convolution to the FP32 kernel's tolerance, its moments against the fp64 moments of its own output, the packed
+    layout against the header's formula, a slice of a larger buffer, and the multi-level launch against single launches."""
+    x, w, b = rnd(B, Cin, H, W, seed=1), rnd(64, Cin, seed=2, scale=Cin ** -0.5), rnd(64, seed=3)
+    ref = torch.einsum("bchw,oc->bhwo", x.double(), w.double()).reshape(B, H * W, 64) + b.double()
+    wp = ops().pack_conv_in_weight_lp(w.to(DEV))
+    hi = w.to(torch.bfloat16)
+    planes = torch.stack([hi, (w - hi.float()).to(torch.bfloat16)])
+    k, o = torch.meshgrid(torch.arange(Cin), torch.arange(64), indexing="ij")
+    for pl in range(2):
+        idx = ((((k // 32) * 4 + o // 16) * 2 + pl) * 64 + ((k % 32) // 8) * 16 + o % 16) * 8 + k % 8
+        assert torch.equal(wp.cpu()[idx], planes[pl].t())
+    out, st = ops().conv1x1_in(x.to(DEV), wp, b.to(DEV), lp=True)
+    closed(out, ref, rtol=6e-5, atol=6e-5)                 # (operands carry 16 mantissa bits: 3x the fp32 kernel's bound)
+    e_lp = float((out.double().cpu() - ref).abs().mean())
+    out32, _ = ops().conv1x1_in(x.to(DEV), ops().pack_conv_in_weight(w.to(DEV)), b.to(DEV))
+    e_32 = float((out32.double().cpu() - ref).abs().mean())
+    print(f"mean |error| against float64: hi+lo bf16 {e_lp:.3e}, fp32 MFMA {e_32:.3e}")
+    assert e_lp <= 1e-5              # operands carry 16 mantissa bits whatever K: three orders of magnitude under one bf16 rounding (2e-3)
+    mom = torch.stack([out.double().sum(1), (out.double() ** 2).sum(1)], -1).cpu()
+    torch.testing.assert_close(st.cpu(), mom, rtol=1e-5, atol=1e-4)
+    buf = torch.full((B, H * W + 24, 64), 7.0, device=DEV)
+    st0 = torch.ones(B, 64, 2, device=DEV, dtype=torch.float64)
+    out, st = ops().conv1x1_in(x.to(DEV), wp, None, out=buf[:, 8:8 + H * W], stats=st0, stats_cleared=True, lp=True)
+    closed(out, ref - b.double(), rtol=6e-5, atol=6e-5)
+    assert float(buf[:, :8].min()) == 7.0 == float(buf[:, 8 + H * W:].max()) and st.data_ptr() == st0.data_ptr()
+    torch.testing.assert_close(st.cpu(), torch.stack([out.double().sum(1), (out.double() ** 2).sum(1)], -1).cpu() + 1.0, rtol=1e-5, atol=1e-4)
+    again, _ = ops().conv1x1_in(x.to(DEV), wp, None, lp=True)
+    assert torch.equal(again, out)                        # fixed-order reduction over the K slices
+    with pytest.raises(RuntimeError):
+        ops().conv1x1_in(torch.zeros(1, 128, 4, 4, device=DEV), torch.zeros(128 * 128, device=DEV, dtype=torch.bfloat16), lp=True)
+
+
+def test_conv1x1_in_multi_lp_equals_single_launches():
+    B = 3
+    xs = [rnd(B, c, h, w, seed=20 + i).to(DEV) for i, (c, h, w) in enumerate(((2048, 4, 6), (1024, 8, 12), (512, 16, 24)))]
+    ws = [ops().pack_conv_in_weight_lp(rnd(64, x.shape[1], seed=30 + i, scale=x.shape[1] ** -0.5).to(DEV)) for i, x in enumerate(xs)]
+    bs = [rnd(64, seed=40).to(DEV), None, rnd(64, seed=42).to(DEV)]
+    S = sum(x.shape[2] * x.shape[3] for x in xs)
+    out = torch.empty(B, S, 64, device=DEV)
+    st = torch.zeros(3, B, 64, 2, device=DEV, dtype=torch.float64)
+    ops().conv1x1_in_multi(xs, ws, bs, out, st, stats_cleared=True, lp=True)
+    o = 0
+    for l, x in enumerate(xs):
+        hw = x.shape[2] * x.shape[3]
+        ref, rst = ops().conv1x1_in(x, ws[l], bs[l], lp=True)
+        assert torch.equal(out[:, o:o + hw], ref)
+        torch.testing.assert_close(st[l], rst, rtol=1e-12, atol=1e-9)
+        o += hw
+
+
 def test_encoder_prologue_vs_fp64():
     """msm_encoder_prologue_fwd: GroupNorm of three concatenated levels from the conv moments, value projection
     (token- and head-major) and sampling projections of src + pos, against fp64 torch ops."""

@@ -53,7 +53,7 @@ def test_ops_refuse_cpu_tensors():
     with pytest.raises(RuntimeError, match="GPU"):
         ops.mask_logits(torch.zeros(1, 4, 32), torch.zeros(1, 32, 4, 4))
     with pytest.raises(ValueError, match="precision"):
-        ops.ms_hill_climb(torch.zeros(8, 64), torch.zeros(2, 64), 20.0, 1, precision="bf16")
+        ops.ms_hill_climb(torch.zeros(8, 64), torch.zeros(2, 64), 20.0, 1, precision="fp8")
     with pytest.raises(RuntimeError, match="GPU"):
         ops.ms_hill_climb(torch.zeros(8, 64), torch.zeros(2, 64), 20.0, 1, precision="f32_split")
 

@@ -24,8 +24,33 @@ with open(f"profiles/{tag}_kernel_stats.md", "w") as f:
     for r in rows[:30]:
         f.write(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['TotalDurationNs']) / 1e6:.2f} | "
                 f"{100 * float(r['TotalDurationNs']) / tot:.1f} |\n")
-    npass = next((int(r["Calls"]) for r in rows if "conv_in_multi_kernel" in r["Name"]), 1)
+    npass = next((int(r["Calls"]) for r in rows if "conv_in_multi_kernel" in r["Name"] or "conv_in_lp_multi_kernel" in r["Name"]), 1)
     f.write(f"\ntotal GPU kernel time {tot / 1e6:.1f} ms over {npass} passes = {tot / npass / 1e6:.2f} ms per pass of 8 images\n")
+# One steady-state pass of the hot path, cut out of the kernel trace: the run's --stats table above mixes warm-up, the roofline
+# legs and the timed passes; here the trace is segmented at the first kernel of a pass (conv_in_multi_kernel), the segments of the
+# most common length are the plain passes, and their per-kernel averages are what one pass of 8 images launches.
+trace = glob.glob(os.path.join(prof, "*kernel_trace.csv"))
+if trace:
+    tr = sorted(csv.DictReader(open(trace[0])), key=lambda r: int(r["Start_Timestamp"]))
+    cut = [i for i, r in enumerate(tr) if "conv_in_multi_kernel" in r["Kernel_Name"] or "conv_in_lp_multi_kernel" in r["Kernel_Name"]]
+    segs = [tr[a:b] for a, b in zip(cut, cut[1:])]
+    if segs:
+        modal = collections.Counter(len(x) for x in segs).most_common(1)[0][0]
+        segs = [x for x in segs if len(x) == modal]
+        per = collections.OrderedDict()
+        for seg in segs:
+            for r in seg:
+                per.setdefault(r["Kernel_Name"], []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        busy = sum(sum(v) for v in per.values()) / len(segs)
+        span = sum(int(x[-1]["End_Timestamp"]) - int(x[0]["Start_Timestamp"]) for x in segs) / len(segs)
+        with open(f"profiles/{tag}_kernel_stats.md", "a") as f:
+            f.write(f"\n## One pass of 8 images (mean of the {len(segs)} plain passes of the trace, {modal} launches each)\n\n")
+            f.write(f"kernel time {busy / 1e3:.0f} us per pass; first start to last end {span / 1e3:.0f} us (eager launches under the profiler: "
+                    "the gaps are host launch latency, absent from the graph replays bench.py times)\n\n")
+            f.write("| kernel | launches per pass | avg us | us per pass | % of kernel time |\n|---|---:|---:|---:|---:|\n")
+            for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+                f.write(f"| `{k[:100]}` | {len(v) / len(segs):.0f} | {sum(v) / len(v) / 1e3:.1f} | {sum(v) / len(segs) / 1e3:.1f} | "
+                        f"{100 * sum(v) / len(segs) / busy:.1f} |\n")
 for pmc in sys.argv[3:]:
     fs = glob.glob(os.path.join(pmc, "*counter_collection.csv"))
     if not fs:

@@ -876,6 +876,7 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
         # (csrc/enc_lp.hip: msm_encoder_block_hm_fwd + msm_msdeform_attn_enc_lp_fwd; 66 us per layer at B = 8 against 85 with the fp32
         # tensors of round 3).  False: the round-3 kernels (msm_encoder_block_lp_fwd + the fp32 gather)
         self.hm_activations = True
+        self.lp_input_proj = True           # bf16 plan: the FPN lateral on the bf16 matrix pipe (hi + lo operands, fp32 results; 66 -> 50 us)
 
     def _w3(self):
         """layer_1's 3x3 weight in the implicit-GEMM order (Cout, 3*3*Cin), cached per parameter version."""
@@ -885,13 +886,20 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
             self._w3_cache = (key, p.permute(0, 2, 3, 1).reshape(p.shape[0], -1).contiguous())
         return self._w3_cache[1]
 
-    def _w_lateral(self):
-        """adapter_1's 1x1 weight in the fragment order of msm_conv1x1_in_f32, cached per parameter version."""
+    def _w_lateral(self, lp=False):
+        """adapter_1's 1x1 weight in the fragment order of msm_conv1x1_in_f32 (``lp``: the hi + lo bf16 order of msm_conv1x1_in_lp),
+        cached per parameter version."""
         p = self.adapter_1.weight
-        key = (p.data_ptr(), p._version)
+        key = (p.data_ptr(), p._version, bool(lp))
         if getattr(self, "_wl_cache", None) is None or self._wl_cache[0] != key:
-            self._wl_cache = (key, ops.pack_conv_in_weight(p.view(p.shape[0], -1)))
+            pack = ops.pack_conv_in_weight_lp if lp else ops.pack_conv_in_weight
+            self._wl_cache = (key, pack(p.view(p.shape[0], -1)))
         return self._wl_cache[1]
+
+    def _lp_input_proj(self, channels):
+        """The bf16 plan runs the FPN lateral on the bf16 matrix pipe (hi + lo operands, fp32 results): 64 output channels,
+        input channels a multiple of 256."""
+        return self.precision == "bf16" and self.lp_input_proj and self.conv_dim == 64 and all(int(c) % 256 == 0 for c in channels)
 
     def _use_fused_msda(self, device):
         """The gather computes its own sampling projection: fp32 plan, the shipped geometry (64 channels, 8 heads, 3 levels x 4
@@ -1017,6 +1025,8 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
             src = torch.empty((B, S_tok, C), device=dev, dtype=torch.float32)
             stats = torch.zeros((len(levels) + 2, B, C, 2), device=dev, dtype=torch.float64)      # + the two FPN GroupNorms
             fpn_stats = (stats[len(levels)], stats[len(levels) + 1])
+            # (fp32 MFMA kernel in every plan: on the bf16 pipe these three deep-K levels are bound by their weight traffic at the same
+            # 66 us -- DESIGN.md section 4a, k31; the bf16 plan moves the shallow lateral, whose weight fits LDS)
             ops.conv1x1_in_multi(levels, wpk, [m[0].bias for m in self.input_proj], src, stats[:len(levels)], stats_cleared=True)
             a0 = layers[0].self_attn
             bounds = [0]
@@ -1085,7 +1095,8 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
         split3 = C == 64 and self.precision == "f32_split"       # the 3x3 convolution on the bf16 matrix pipe
         if C == 64 and x.shape[1] % 128 == 0 and x.shape[1] <= 384 and (H * W) % 4 == 0 and B * H * W >= 32 * 1024:
             # shallow-K input-projection kernel: the GroupNorm moments come out of its epilogue (no moments pass over lat)
-            lat, lat_stats = ops.conv1x1_in(x, self._w_lateral(), None, stats=fpn_stats[0], stats_cleared=fpn_stats[0] is not None)
+            lp = self._lp_input_proj([x.shape[1]])
+            lat, lat_stats = ops.conv1x1_in(x, self._w_lateral(lp), None, stats=fpn_stats[0], stats_cleared=fpn_stats[0] is not None, lp=lp)
             y = ops.groupnorm_tokens(lat, self.adapter_1.norm.weight, self.adapter_1.norm.bias, H, W, groups=32,
                                      up=up_tok, up_hw=up_hw, eps=self.adapter_1.norm.eps, stats=lat_stats, stats_ready=True,
                                      split_planes=split3)

@@ -108,19 +108,32 @@ def pack_conv_in_weight(w):
     return w.reshape(4, 16, Cin // 8, 4, 2).permute(2, 0, 3, 1, 4).contiguous().reshape(-1)
 
 
-def conv1x1_in(x, w_packed, bias=None, *, out=None, stats=None, stats_cleared=False):
+def pack_conv_in_weight_lp(w):
+    """(64, Cin) weight -> the hi + lo bf16 fragment order msm_conv1x1_in_lp reads (include/msm_hip.h):
+    packed[g][o//16][plane][(k%32)//8][o%16][k%8] = plane(w)[o][k], g = k//32, plane 0 = bf16(w), plane 1 = bf16(w - plane 0)."""
+    O, Cin = w.shape
+    if O != 64 or Cin % 256:
+        raise RuntimeError("pack_conv_in_weight_lp needs a (64, Cin) weight with Cin a multiple of 256")
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    planes = torch.stack([hi, lo])                                                   # (2, 64, Cin)
+    return planes.reshape(2, 4, 16, Cin // 32, 4, 8).permute(3, 1, 0, 4, 2, 5).contiguous().reshape(-1)
+
+
+def conv1x1_in(x, w_packed, bias=None, *, out=None, stats=None, stats_cleared=False, lp=False):
     """Input projection of the pixel decoder: x (B, Cin, H, W) NCHW, w_packed = pack_conv_in_weight(w (64, Cin)) ->
-    tokens (B, H*W, 64) = x^T w^T + bias,
+    tokens (B, H*W, 64) = x^T w^T + bias  (``lp``: w_packed = pack_conv_in_weight_lp(w), hi + lo bf16 operands on the bf16
+    matrix pipe, fp32 results; Cin a multiple of 256),
     plus the GroupNorm moments of the result.  ``out``: a (B, H*W, 64) view with unit channel stride, row stride 64 and
     any batch stride (e.g. ``buf[:, s:s + H*W]`` of the concatenated token buffer of the encoder); ``stats``: a
     (B, 64, 2) float64 tensor that receives (sum, sum of squares) per (image, channel) -- accumulated into when
     ``stats_cleared`` (the caller zeroed it), else zeroed first.  Returns (out, stats).  Cin must be a multiple of 128
     (conv1x1_nchw_to_tokens + groupnorm_stats cover other shapes)."""
-    _c(x, "x"), _c(w_packed, "w_packed"), _c(bias, "bias"), _c(stats, "stats", torch.float64)
+    _c(x, "x"), _c(w_packed, "w_packed", torch.bfloat16 if lp else torch.float32), _c(bias, "bias"), _c(stats, "stats", torch.float64)
     B, Cin, H, W = x.shape
     HW = H * W
-    if w_packed.numel() != 64 * Cin or Cin % 128 or HW % 4:
-        raise RuntimeError("conv1x1_in needs a packed (64, Cin) weight, Cin a multiple of 128 and H*W a multiple of 4")
+    if w_packed.numel() != (128 if lp else 64) * Cin or Cin % (256 if lp else 128) or HW % 4:
+        raise RuntimeError("conv1x1_in needs a packed (64, Cin) weight, Cin a multiple of 128 (lp: 256) and H*W a multiple of 4")
     if out is None:
         out = torch.empty((B, HW, 64), device=x.device, dtype=torch.float32)
     _chk(out, "out")
@@ -131,14 +144,15 @@ def conv1x1_in(x, w_packed, bias=None, *, out=None, stats=None, stats_cleared=Fa
         stats_cleared = False
     elif tuple(stats.shape) != (B, 64, 2):
         raise RuntimeError("stats must be (B, 64, 2) float64")
-    rc = lib().msm_conv1x1_in_f32(_p(x), _p(w_packed), _p(bias), _p(out), out.stride(0) if B > 1 else HW * 64, _p(stats),
-                                  1 if stats_cleared else 0, B, Cin, HW, _stream())
-    check(rc, "msm_conv1x1_in_f32")
+    fn = lib().msm_conv1x1_in_lp if lp else lib().msm_conv1x1_in_f32
+    rc = fn(_p(x), _p(w_packed), _p(bias), _p(out), out.stride(0) if B > 1 else HW * 64, _p(stats), 1 if stats_cleared else 0, B, Cin, HW,
+            _stream())
+    check(rc, "msm_conv1x1_in_lp" if lp else "msm_conv1x1_in_f32")
     return out, stats
 
 
-def conv1x1_in_multi(xs, ws_packed, biases, out, stats, stats_cleared=False):
-    """conv1x1_in for up to four levels in one launch.  xs: list of (B, Cin_l, H_l, W_l) NCHW maps (deepest Cin first),
+def conv1x1_in_multi(xs, ws_packed, biases, out, stats, stats_cleared=False, lp=False):
+    """conv1x1_in for up to four levels in one launch (``lp``: ws_packed from pack_conv_in_weight_lp, the bf16 matrix pipe).  xs: list of (B, Cin_l, H_l, W_l) NCHW maps (deepest Cin first),
     ws_packed / biases: per level (a bias may be None), out: (B, sum H_l*W_l, 64) contiguous token buffer (level l fills its
     token range), stats: (L, B, 64, 2) float64 moments (accumulated into when ``stats_cleared``)."""
     L = len(xs)
@@ -148,19 +162,19 @@ def conv1x1_in_multi(xs, ws_packed, biases, out, stats, stats_cleared=False):
     if tuple(out.shape) != (B, S, 64) or tuple(stats.shape) != (L, B, 64, 2):
         raise RuntimeError("conv1x1_in_multi: out must be (B, sum HW, 64) and stats (L, B, 64, 2)")
     for x, w, b in zip(xs, ws_packed, biases):
-        _c(x, "x"), _c(w, "w_packed"), _c(b, "bias")
-        if x.shape[0] != B or w.numel() != 64 * x.shape[1]:
+        _c(x, "x"), _c(w, "w_packed", torch.bfloat16 if lp else torch.float32), _c(b, "bias")
+        if x.shape[0] != B or w.numel() != (128 if lp else 64) * x.shape[1]:
             raise RuntimeError("conv1x1_in_multi: inconsistent level shapes")
     vp = ctypes.c_void_p * L
     ia = ctypes.c_int32 * L
     xa, wa = vp(*[x.data_ptr() for x in xs]), vp(*[w.data_ptr() for w in ws_packed])
     ba = vp(*[0 if b is None else b.data_ptr() for b in biases])
     cin, hw = ia(*[x.shape[1] for x in xs]), ia(*[x.shape[2] * x.shape[3] for x in xs])
-    rc = lib().msm_conv1x1_in_multi_f32(L, ctypes.cast(xa, ctypes.c_void_p), ctypes.cast(wa, ctypes.c_void_p),
-                                        ctypes.cast(ba, ctypes.c_void_p), ctypes.cast(cin, ctypes.c_void_p),
-                                        ctypes.cast(hw, ctypes.c_void_p), _p(out), S * 64, _p(stats), 1 if stats_cleared else 0, B,
-                                        _stream())
-    check(rc, "msm_conv1x1_in_multi_f32")
+    fn = lib().msm_conv1x1_in_multi_lp if lp else lib().msm_conv1x1_in_multi_f32
+    rc = fn(L, ctypes.cast(xa, ctypes.c_void_p), ctypes.cast(wa, ctypes.c_void_p), ctypes.cast(ba, ctypes.c_void_p),
+            ctypes.cast(cin, ctypes.c_void_p), ctypes.cast(hw, ctypes.c_void_p), _p(out), S * 64, _p(stats), 1 if stats_cleared else 0, B,
+            _stream())
+    check(rc, "msm_conv1x1_in_multi_lp" if lp else "msm_conv1x1_in_multi_f32")
     return out, stats
 
 
