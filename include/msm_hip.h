@@ -59,7 +59,7 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 13   /* 13: flags argument of msm_ms_select_seeds_bf16 (persistent on-chip seeding over the bf16 copy), input projections on the bf16 matrix pipe (msm_conv1x1_in_lp, msm_conv1x1_in_multi_lp); 12: head-major bf16 activations between the encoder kernels of the bf16 plan (msm_encoder_block_hm_fwd, msm_msdeform_attn_enc_lp_fwd, msm_f32_to_f16); 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
+#define MSM_ABI_VERSION 14   /* 14: cmat_width argument of the K/V projections (separable position constants); 13: flags argument of msm_ms_select_seeds_bf16 (persistent on-chip seeding over the bf16 copy), input projections on the bf16 matrix pipe (msm_conv1x1_in_lp, msm_conv1x1_in_multi_lp); 12: head-major bf16 activations between the encoder kernels of the bf16 plan (msm_encoder_block_hm_fwd, msm_msdeform_attn_enc_lp_fwd, msm_f32_to_f16); 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
 int msm_abi_version(void);
 
 /* Kernel-selection overrides for tools/ and tests/ (NOT read on the product path: every option defaults to
@@ -326,26 +326,31 @@ int msm_encoder_block_fwd(const float* attn, const float* src, const float* wstr
  *   N in {256, 512} (512 = [K | V] of one cross-attention layer).  x: image b starts at x + b*x_batch_stride and is
  *   [C = 64][HW] (x_tokens = 0, NCHW) or [HW][64] (x_tokens = 1: token-major = torch channels_last, e.g. a slice of
  *   the pixel decoder's token buffer, so no transpose pass is needed).
+ *   cmat_width = 0: cmat is the dense [HW][N] constant.  cmat_width = W > 0 (W divides HW): the constant is SEPARABLE and cmat
+ *   holds [HW / W row vectors | W column vectors] x N -- token p = (y, x) gets row[y] + col[x] (the sine position embedding's
+ *   first half depends on y only, its second on x only, position_encoding.py:44-51): a 307 200-key map then reads two tables
+ *   of 1120 rows instead of 629 MB of constants.  Result: fl(fl(x^T w^T + row) + col).
  * ------------------------------------------------------------------------------------------- */
 int msm_kv_project_f32(const float* x, const float* w, const float* cmat, float* out,
-                       int B, int C, int HW, int N, int x_tokens, int64_t x_batch_stride, void* stream);
+                       int B, int C, int HW, int N, int x_tokens, int64_t x_batch_stride, int cmat_width, void* stream);
 /* n_jobs <= 16 such projections (one per cross-attention layer: its level's features, its folded weight and constant)
- * in ONE launch; x / w / cmat / out / HW / x_tokens / x_batch_stride are HOST arrays of n_jobs entries, B, C = 64 and N
- * are shared.  Each job gets a share of the chip's workgroups proportional to its HW. */
+ * in ONE launch; x / w / cmat / out / HW / x_tokens / x_batch_stride / cmat_width are HOST arrays of n_jobs entries (cmat_width may
+ * be NULL = all dense; all jobs separable or none), B, C = 64 and N are shared.  Each job gets a share of the chip's workgroups
+ * proportional to its HW. */
 int msm_kv_project_multi_f32(int n_jobs, const float* const* x, const float* const* w, const float* const* cmat,
                              float* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride,
-                             int B, int C, int N, void* stream);
+                             const int32_t* cmat_width, int B, int C, int N, void* stream);
 /* The same with the result stored as bf16 (low-precision mode): half the bytes of this write-bound launch and of the K/V
  * reads of msm_hypersphere_attn_lp_fwd.  w is rounded to one bf16 and x enters as a hi + lo pair (bf16 MFMAs, fp32
  * accumulation; MSM_OPT_KV_PIPE = 0: exact fp32 MFMAs, only the stored value rounded). */
 int msm_kv_project_multi_bf16(int n_jobs, const float* const* x, const float* const* w, const float* const* cmat,
                               uint16_t* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride,
-                              int B, int C, int N, void* stream);
+                              const int32_t* cmat_width, int B, int C, int N, void* stream);
 /* fp32 results on the bf16 matrix pipe (exact three-term splits of x and w, six K = 32 MFMAs per product; see
  * msm_encoder_block_split_fwd): same arguments and output as msm_kv_project_multi_f32. */
 int msm_kv_project_multi_split(int n_jobs, const float* const* x, const float* const* w, const float* const* cmat,
                                float* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride,
-                               int B, int C, int N, void* stream);
+                               const int32_t* cmat_width, int B, int C, int N, void* stream);
 
 /* mask_features (MSD:349-358): the last GroupNorm + ReLU of the FPN level fused into the 1x1 convolution after it.
  *   out [B][N][HW] (NCHW) = bias + w act(x),  x [B][HW][64] tokens, w [N][64], N in {256, 512}, HW % 4 == 0;

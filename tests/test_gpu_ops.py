@@ -465,6 +465,30 @@ def test_kv_project(B, H, W, N):
     closed(ops().kv_project(view, w.to(DEV), c.to(DEV)), ref, rtol=1e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("B,H,W,N", [(8, 30, 40, 512), (2, 61, 67, 256), (1, 15, 20, 512), (2, 96, 128, 512)])
+def test_kv_project_separable_constant(B, H, W, N):
+    """cmat_width = W: the constant of token (y, x) is row[y] + col[x] (two tables of H + W vectors, what the sine position embedding
+    folds to) -- every kernel form (fp32 MFMA, exact three-term splits, bf16) against float64 and against its own dense-constant
+    launch; the small-shape GEMM route densifies."""
+    x, w = rnd(B, 64, H, W, seed=1), rnd(N, 64, seed=2, scale=0.125)
+    rc = rnd(H + W, N, seed=3)
+    dense = ops().dense_kv_constant(rc.to(DEV), W)
+    assert torch.equal(dense.cpu().view(H, W, N), rc[:H, None] + rc[None, H:])
+    ref = torch.einsum("bkp,nk->bpn", x.double().flatten(2), w.double()) + dense.double().cpu()
+    xd, wd, cd = x.to(DEV), w.to(DEV), rc.to(DEV)
+    got = ops().kv_project(xd, wd, cd, W)
+    closed(got, ref, rtol=1e-5, atol=2e-5)
+    close(got, ops().kv_project(xd, wd, dense).cpu(), rtol=0, atol=1e-5)            # fl(fl(s + row) + col) against fl(s + fl(row + col)): a few ulps at |v| ~ 8
+    for kw, tol in ((dict(), 2e-5), (dict(split=True), 2e-5), (dict(out_dtype=torch.bfloat16), 3e-2)):
+        a = ops().kv_project_multi([xd, xd], [wd, wd], [cd, cd], cmat_widths=[W, W], **kw)
+        b = ops().kv_project_multi([xd, xd], [wd, wd], [dense, dense], **kw)
+        for u, v in zip(a, b):
+            closed(u.float(), ref, rtol=tol, atol=tol)
+            close(u.float(), v.float().cpu(), rtol=0, atol=1e-5 if u.dtype == torch.float32 else 7e-2)   # (bf16: one rounding step at |v| ~ 8)
+    with pytest.raises(RuntimeError):                      # all jobs separable or none
+        ops().kv_project_multi([xd, xd], [wd, wd], [cd, dense], cmat_widths=[W, 0])
+
+
 @pytest.mark.parametrize("B,H,W,N,gn", [(2, 24, 32, 256, True), (3, 10, 14, 256, False), (1, 30, 40, 512, True)])
 def test_tokens_proj_nchw(B, H, W, N, gn):
     """msm_tokens_proj_nchw_f32 = 1x1 conv to NCHW of relu(GroupNorm(x)) (MSD:349-358) against torch in fp64."""

@@ -14,3 +14,10 @@ cs = [torch.randn(h * w, 512, device=DEV) for h, w in lv] * 3
 t = timeit_graph(lambda: ops.kv_project_multi(xs, ws, cs))
 mb = sum(B * h * w * 512 * 4 for h, w in lv) * 3 / 1e6
 print(f"kv_project_multi: {t:.1f} us ({mb:.0f} MB written, {mb / t:.2f} TB/s; {2.0 * mb / 4 * 64 / t / 1e6 * 1e6 / 1e6:.1f} TFLOP/s)")
+# separable constants (row + column tables instead of the per-position matrix)
+cs2 = [torch.randn(h + w, 512, device=DEV) for h, w in lv] * 3
+cw = [w for _, w in lv] * 3
+for kw, name in ((dict(), "f32"), (dict(split=True), "f32_split"), (dict(out_dtype=torch.bfloat16), "bf16")):
+    t1 = timeit_graph(lambda: ops.kv_project_multi(xs, ws, cs, **kw))
+    t2 = timeit_graph(lambda: ops.kv_project_multi(xs, ws, cs2, cmat_widths=cw, **kw))
+    print(f"kv_project_multi {name}: dense constants {t1:.1f} us, separable {t2:.1f} us")

@@ -36,9 +36,13 @@ constexpr int KP_W = 16;             // waves per workgroup (one workgroup per C
 // the projection of ONE (level, layer) job by workgroup `wg` of the `nwg` workgroups assigned to it.
 // OT = float, or uint16_t: the result is stored as bf16 (low-precision mode: half the bytes of this write-bound kernel and of
 // the attention kernels' K/V reads; the products are still exact fp32 MFMAs, only the stored value is rounded)
-template <typename OT>
+// SEP: the constant is SEPARABLE, cmat = [HW / cw row vectors | cw column vectors] x N and the constant of token p = (y, x) is
+// row[y] + col[x] -- what the sine position embedding gives (its first half depends on y only, its second on x only,
+// position_encoding.py:44-51), so a 307 200-key map reads two tables of 1120 rows instead of 629 MB of constants (as many
+// bytes as it writes).  The row vector is the accumulator's initial value, the column vector is added before the store.
+template <typename OT, bool SEP>
 __device__ __forceinline__ void kv_project_body(const float* __restrict__ x, const float* __restrict__ w,
-                                                const float* __restrict__ cmat, OT* __restrict__ out, int B, int HW, int N,
+                                                const float* __restrict__ cmat, int cw, OT* __restrict__ out, int B, int HW, int N,
                                                 int tokens, int64_t x_sb, int wg, int nwg, float* wl) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -88,7 +92,9 @@ __device__ __forceinline__ void kv_project_body(const float* __restrict__ x, con
         const int tile = u / (halves * B), img = (u / halves) % B;
         const int p = min(tile * 16 + lj, HW - 1);             // this lane's token, clamped: lanes past the last token repeat it (see the stores)
         const int n_base = half * KP_FB * 16;
-        const float* cp = cmat + (int64_t)p * N + n_base + lq * 4;
+        const int py = SEP ? p / cw : 0;
+        const float* cp = cmat + (int64_t)(SEP ? py : p) * N + n_base + lq * 4;
+        const float* cq = cmat + (int64_t)(SEP ? HW / cw + (p - py * cw) : 0) * N + n_base + lq * 4;      // (SEP only)
         OT* op = out + ((int64_t)img * HW + p) * N + n_base + lq * 4;
         const float* wp = wl + (n_base + lj) * KP_LD + lq * 16;
         // everything this unit reads from memory is requested before its first MFMA; the next unit's x rides along
@@ -102,6 +108,11 @@ __device__ __forceinline__ void kv_project_body(const float* __restrict__ x, con
             // two feature blocks in flight: consecutive MFMAs alternate accumulators
             f32x4 a0 = f32x4{cm[fb].x, cm[fb].y, cm[fb].z, cm[fb].w};
             f32x4 a1 = f32x4{cm[fb + 1].x, cm[fb + 1].y, cm[fb + 1].z, cm[fb + 1].w};
+            float4 q0, q1;                                   // the column vectors of this pair: requested here, added after the MFMAs
+            if constexpr (SEP) {
+                q0 = *reinterpret_cast<const float4*>(cq + fb * 16);
+                q1 = *reinterpret_cast<const float4*>(cq + (fb + 1) * 16);
+            }
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 const float4 w0 = *reinterpret_cast<const float4*>(wp + fb * 16 * KP_LD + s4 * 4);
@@ -123,8 +134,19 @@ __device__ __forceinline__ void kv_project_body(const float* __restrict__ x, con
             // no `live` test: lanes past the last token hold token HW - 1 again (clamped p, same x, same constant) and store the
             // same values to the same address -- a branch here cuts the unit into eight basic blocks (LDS reads -> wait -> 32
             // MFMAs -> stores, nothing overlapping across them)
+            if constexpr (SEP) {
+                a0 += f32x4{q0.x, q0.y, q0.z, q0.w};
+                a1 += f32x4{q1.x, q1.y, q1.z, q1.w};
+            }
 #if KP_EXP == 1
             if (a0[0] == 12345.f && a1[1] == 5.f)
+#endif
+#if KP_EXP == 3     // what would whole-line stores buy?  the same bytes, a wave instruction = 1 KiB contiguous (values land in the wrong places)
+            if constexpr (std::is_same<OT, float>::value) {
+                float* ob = out + ((int64_t)img * HW + min(tile * 16, HW - 16)) * N + n_base * 16;
+                *reinterpret_cast<float4*>(ob + (fb * 64 + lane) * 4) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+                *reinterpret_cast<float4*>(ob + ((fb + 1) * 64 + lane) * 4) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+            } else
 #endif
             if constexpr (std::is_same<OT, float>::value) {
                 *reinterpret_cast<float4*>(op + fb * 16) = make_float4(a0[0], a0[1], a0[2], a0[3]);
@@ -139,11 +161,12 @@ __device__ __forceinline__ void kv_project_body(const float* __restrict__ x, con
     }
 }
 
+template <bool SEP>
 __global__ __launch_bounds__(KP_W * 64) void kv_project_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                         const float* __restrict__ cmat, float* __restrict__ out, int B,
+                                                         const float* __restrict__ cmat, int cw, float* __restrict__ out, int B,
                                                          int HW, int N, int tokens, int64_t x_sb) {
     extern __shared__ __attribute__((aligned(16))) float wl[];   // [N][KP_LD]
-    kv_project_body<float>(x, w, cmat, out, B, HW, N, tokens, x_sb, blockIdx.x, gridDim.x, wl);
+    kv_project_body<float, SEP>(x, w, cmat, cw, out, B, HW, N, tokens, x_sb, blockIdx.x, gridDim.x, wl);
 }
 
 // All K/V projections of the decoder (one job per cross-attention layer: its level's features, its folded weight and
@@ -159,16 +182,17 @@ struct KvJobs {
     const float* cmat[KP_MAXJ];
     void* out[KP_MAXJ];
     int HW[KP_MAXJ], tokens[KP_MAXJ], first[KP_MAXJ + 1];
+    int cw[KP_MAXJ];             // width of the map when the constant is separable (see kv_project_body), else 0
     int64_t x_sb[KP_MAXJ];
 };
-template <typename OT>
+template <typename OT, bool SEP>
 __global__ __launch_bounds__(KP_W * 64) void kv_project_multi_kernel(KvJobs jobs, int B, int N) {
     extern __shared__ __attribute__((aligned(16))) float wl[];   // [N][KP_LD]
     int j = 0;
 #pragma unroll
     for (int i = 1; i < KP_MAXJ; ++i) j += (i < jobs.n && (int)blockIdx.x >= jobs.first[i]) ? 1 : 0;
-    kv_project_body<OT>(jobs.x[j], jobs.w[j], jobs.cmat[j], (OT*)jobs.out[j], B, jobs.HW[j], N, jobs.tokens[j], jobs.x_sb[j],
-                    (int)blockIdx.x - jobs.first[j], jobs.first[j + 1] - jobs.first[j], wl);
+    kv_project_body<OT, SEP>(jobs.x[j], jobs.w[j], jobs.cmat[j], jobs.cw[j], (OT*)jobs.out[j], B, jobs.HW[j], N, jobs.tokens[j], jobs.x_sb[j],
+                             (int)blockIdx.x - jobs.first[j], jobs.first[j + 1] - jobs.first[j], wl);
 }
 
 // ---- the same projection on the bf16 matrix pipe ---------------------------------------------------------------------------
@@ -182,9 +206,9 @@ __global__ __launch_bounds__(KP_W * 64) void kv_project_multi_kernel(KvJobs jobs
 constexpr int KS_LD = KP_K + 8;      // LDS row stride of a bf16 weight copy (elements)
 constexpr int KS_W = 8;              // waves per workgroup of the bf16-pipe kernel
 
-template <typename OT, int MODE>
+template <typename OT, int MODE, bool SEP>
 __device__ __forceinline__ void kv_project_split_body(const float* __restrict__ x, const float* __restrict__ w,
-                                                      const float* __restrict__ cmat, OT* __restrict__ out, int B, int HW, int N,
+                                                      const float* __restrict__ cmat, int cw, OT* __restrict__ out, int B, int HW, int N,
                                                       int tokens, int64_t x_sb, int wg, int nwg, unsigned short* wl) {
     constexpr int COPIES = MODE == 0 ? 3 : 1;
     constexpr unsigned TERMS = MODE == 0 ? 0x3fu : 0x30u;      // mac_term bits: all six | {wh xm, wh xh}
@@ -242,7 +266,9 @@ __device__ __forceinline__ void kv_project_split_body(const float* __restrict__ 
             const int u = unit_of(it);
             const int tile = u / B, img = u % B;
             const int p = min(tile * 16 + lj, HW - 1);
-            const float* cp = cmat + (int64_t)p * N + n_base + lq * 4;
+            const int py = SEP ? p / cw : 0;
+            const float* cp = cmat + (int64_t)(SEP ? py : p) * N + n_base + lq * 4;
+            const float* cq = cmat + (int64_t)(SEP ? HW / cw + (p - py * cw) : 0) * N + n_base + lq * 4;      // (SEP only: kv_project_body)
             OT* op = out + ((int64_t)img * HW + p) * N + n_base + lq * 4;
             float xb[16];
             load_x(u, xb);
@@ -262,6 +288,10 @@ __device__ __forceinline__ void kv_project_split_body(const float* __restrict__ 
                 for (int j = 0; j < 2; ++j) {
                     hi[j] = f32x4{cm[fb + j].x, cm[fb + j].y, cm[fb + j].z, cm[fb + j].w};
                     lo[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (SEP) {                  // the column vector rides in the low-order accumulator
+                        const float4 q = *reinterpret_cast<const float4*>(cq + (fb + j) * 16);
+                        lo[j] = f32x4{q.x, q.y, q.z, q.w};
+                    }
                 }
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
@@ -293,14 +323,14 @@ __device__ __forceinline__ void kv_project_split_body(const float* __restrict__ 
     }
 }
 
-template <typename OT, int MODE>
+template <typename OT, int MODE, bool SEP>
 __global__ __launch_bounds__(KS_W * 64) void kv_project_multi_split_kernel(KvJobs jobs, int B, int N) {
     extern __shared__ __attribute__((aligned(16))) unsigned short wls[];   // [copies][256][KS_LD] bf16
     int j = 0;
 #pragma unroll
     for (int i = 1; i < KP_MAXJ; ++i) j += (i < jobs.n && (int)blockIdx.x >= jobs.first[i]) ? 1 : 0;
-    kv_project_split_body<OT, MODE>(jobs.x[j], jobs.w[j], jobs.cmat[j], (OT*)jobs.out[j], B, jobs.HW[j], N, jobs.tokens[j], jobs.x_sb[j],
-                                    (int)blockIdx.x - jobs.first[j], jobs.first[j + 1] - jobs.first[j], wls);
+    kv_project_split_body<OT, MODE, SEP>(jobs.x[j], jobs.w[j], jobs.cmat[j], jobs.cw[j], (OT*)jobs.out[j], B, jobs.HW[j], N, jobs.tokens[j],
+                                         jobs.x_sb[j], (int)blockIdx.x - jobs.first[j], jobs.first[j + 1] - jobs.first[j], wls);
 }
 
 // ---- mask_features: GroupNorm + ReLU of the FPN output fused into the 1x1 convolution that follows it --------------
@@ -420,8 +450,9 @@ __global__ __launch_bounds__(MF_W * 64) void tokens_proj_nchw_kernel(const float
 using namespace msm;
 
 extern "C" int msm_kv_project_f32(const float* x, const float* w, const float* cmat, float* out, int B, int C, int HW, int N,
-                                  int x_tokens, int64_t x_batch_stride, void* stream) {
+                                  int x_tokens, int64_t x_batch_stride, int cmat_width, void* stream) {
     MSM_REQUIRE(x && w && cmat && out, "msm_kv_project_f32: null pointer");
+    MSM_REQUIRE(cmat_width >= 0 && (cmat_width == 0 || HW % cmat_width == 0), "msm_kv_project_f32: cmat_width=%d must divide HW=%d", cmat_width, HW);
     MSM_REQUIRE(C == KP_K, "msm_kv_project_f32: C=%d, only 64 input channels are supported", C);
     MSM_REQUIRE(B > 0 && HW > 0 && N > 0 && N % (KP_FB * 16) == 0 && N <= 512,
                 "msm_kv_project_f32: N=%d must be 256 or 512", N);
@@ -430,10 +461,17 @@ extern "C" int msm_kv_project_f32(const float* x, const float* w, const float* c
     MSM_REQUIRE(x_batch_stride >= (int64_t)C * HW && (!x_tokens || ((((uintptr_t)x) & 15) == 0 && x_batch_stride % 4 == 0)),
                 "msm_kv_project_f32: bad x batch stride / alignment");
     const size_t lds = sizeof(float) * (size_t)N * KP_LD;
-    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)kv_project_kernel, lds));
     const int units = cdiv(HW, 16) * B * (N / (KP_FB * 16));
     const int grid = max(1, min(256, cdiv(units, 4)));
-    hipLaunchKernelGGL(kv_project_kernel, dim3(grid), dim3(KP_W * 64), lds, (hipStream_t)stream, x, w, cmat, out, B, HW, N, x_tokens, x_batch_stride);
+    if (cmat_width > 0) {
+        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)kv_project_kernel<true>, lds));
+        hipLaunchKernelGGL(kv_project_kernel<true>, dim3(grid), dim3(KP_W * 64), lds, (hipStream_t)stream, x, w, cmat, cmat_width, out, B, HW, N, x_tokens,
+                           x_batch_stride);
+    } else {
+        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)kv_project_kernel<false>, lds));
+        hipLaunchKernelGGL(kv_project_kernel<false>, dim3(grid), dim3(KP_W * 64), lds, (hipStream_t)stream, x, w, cmat, 0, out, B, HW, N, x_tokens,
+                           x_batch_stride);
+    }
     MSM_CHECK_LAUNCH("msm_kv_project_f32");
     return MSM_OK;
 }
@@ -441,8 +479,8 @@ extern "C" int msm_kv_project_f32(const float* x, const float* w, const float* c
 // PIPE: -1 = fp32 MFMAs (kv_project_multi_kernel); 0 / 1 = MODE of kv_project_multi_split_kernel (bf16 matrix pipe)
 template <typename OT, int PIPE>
 static int kv_project_multi_impl(const char* who, int n_jobs, const float* const* x, const float* const* w, const float* const* cmat,
-                                 OT* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride, int B, int C,
-                                 int N, void* stream) {
+                                 OT* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride,
+                                 const int32_t* cmat_width, int B, int C, int N, void* stream) {
     MSM_REQUIRE(n_jobs >= 1 && n_jobs <= KP_MAXJ && x && w && cmat && out && HW && x_tokens && x_batch_stride,
                 "%s: bad arguments (1..%d jobs)", who, KP_MAXJ);
     MSM_REQUIRE(C == KP_K, "%s: C=%d, only 64 input channels are supported", who, C);
@@ -450,7 +488,12 @@ static int kv_project_multi_impl(const char* who, int n_jobs, const float* const
     KvJobs jobs;
     jobs.n = n_jobs;
     int64_t total = 0;
+    // separable constants (kv_project_body): all jobs of a launch or none
+    const bool sep = cmat_width && cmat_width[0] > 0;
     for (int j = 0; j < n_jobs; ++j) {
+        const int cwj = cmat_width ? cmat_width[j] : 0;
+        MSM_REQUIRE((cwj > 0) == sep && (cwj == 0 || (HW[j] > 0 && HW[j] % cwj == 0)), "%s: job %d: cmat_width=%d (all jobs separable or none; it must divide HW)", who, j, cwj);
+        jobs.cw[j] = cwj;
         MSM_REQUIRE(x[j] && w[j] && cmat[j] && out[j] && HW[j] > 0, "%s: job %d: null pointer or empty level", who, j);
         MSM_REQUIRE(((((uintptr_t)w[j]) | ((uintptr_t)cmat[j]) | ((uintptr_t)out[j])) & 15) == 0 && (((uintptr_t)x[j]) & 3) == 0,
                     "%s: job %d: w/cmat/out must be 16-byte aligned", who, j);
@@ -473,37 +516,44 @@ static int kv_project_multi_impl(const char* who, int n_jobs, const float* const
     for (int j = n_jobs; j < KP_MAXJ; ++j) {
         jobs.x[j] = jobs.w[j] = jobs.cmat[j] = nullptr; jobs.out[j] = nullptr;
         jobs.HW[j] = jobs.tokens[j] = 0; jobs.x_sb[j] = 0;
+        jobs.cw[j] = 0;
+    }
+#define KV_LAUNCH(KERNEL, WAVES)                                                                                      \
+    {                                                                                                                 \
+        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)KERNEL, lds));                                      \
+        hipLaunchKernelGGL(KERNEL, dim3(wg), dim3(WAVES * 64), lds, (hipStream_t)stream, jobs, B, N);                 \
     }
     if constexpr (PIPE >= 0) {
         const size_t lds = sizeof(unsigned short) * (size_t)(PIPE == 0 ? 3 : 1) * KP_FB * 16 * KS_LD;
-        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)kv_project_multi_split_kernel<OT, PIPE>, lds));
-        hipLaunchKernelGGL((kv_project_multi_split_kernel<OT, PIPE>), dim3(wg), dim3(KS_W * 64), lds, (hipStream_t)stream, jobs, B, N);
+        if (sep) KV_LAUNCH((kv_project_multi_split_kernel<OT, PIPE, true>), KS_W)
+        else KV_LAUNCH((kv_project_multi_split_kernel<OT, PIPE, false>), KS_W)
     } else {
         const size_t lds = sizeof(float) * (size_t)N * KP_LD;
-        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)kv_project_multi_kernel<OT>, lds));
-        hipLaunchKernelGGL(kv_project_multi_kernel<OT>, dim3(wg), dim3(KP_W * 64), lds, (hipStream_t)stream, jobs, B, N);
+        if (sep) KV_LAUNCH((kv_project_multi_kernel<OT, true>), KP_W)
+        else KV_LAUNCH((kv_project_multi_kernel<OT, false>), KP_W)
     }
+#undef KV_LAUNCH
     MSM_CHECK_LAUNCH(who);
     return MSM_OK;
 }
 
 extern "C" int msm_kv_project_multi_f32(int n_jobs, const float* const* x, const float* const* w, const float* const* cmat,
                                         float* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride,
-                                        int B, int C, int N, void* stream) {
-    return kv_project_multi_impl<float, -1>("msm_kv_project_multi_f32", n_jobs, x, w, cmat, out, HW, x_tokens, x_batch_stride, B, C, N, stream);
+                                        const int32_t* cmat_width, int B, int C, int N, void* stream) {
+    return kv_project_multi_impl<float, -1>("msm_kv_project_multi_f32", n_jobs, x, w, cmat, out, HW, x_tokens, x_batch_stride, cmat_width, B, C, N, stream);
 }
 extern "C" int msm_kv_project_multi_bf16(int n_jobs, const float* const* x, const float* const* w, const float* const* cmat,
                                          uint16_t* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride,
-                                         int B, int C, int N, void* stream) {
+                                         const int32_t* cmat_width, int B, int C, int N, void* stream) {
     // bf16 MFMAs (w rounded to one bf16, x as hi + lo) unless option KV_PIPE says 0: fp32 MFMAs, only the store rounded
     if (opt(MSM_OPT_KV_PIPE) == 0)
-        return kv_project_multi_impl<uint16_t, -1>("msm_kv_project_multi_bf16", n_jobs, x, w, cmat, out, HW, x_tokens, x_batch_stride, B, C, N, stream);
-    return kv_project_multi_impl<uint16_t, 1>("msm_kv_project_multi_bf16", n_jobs, x, w, cmat, out, HW, x_tokens, x_batch_stride, B, C, N, stream);
+        return kv_project_multi_impl<uint16_t, -1>("msm_kv_project_multi_bf16", n_jobs, x, w, cmat, out, HW, x_tokens, x_batch_stride, cmat_width, B, C, N, stream);
+    return kv_project_multi_impl<uint16_t, 1>("msm_kv_project_multi_bf16", n_jobs, x, w, cmat, out, HW, x_tokens, x_batch_stride, cmat_width, B, C, N, stream);
 }
 extern "C" int msm_kv_project_multi_split(int n_jobs, const float* const* x, const float* const* w, const float* const* cmat,
                                           float* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride,
-                                          int B, int C, int N, void* stream) {
-    return kv_project_multi_impl<float, 0>("msm_kv_project_multi_split", n_jobs, x, w, cmat, out, HW, x_tokens, x_batch_stride, B, C, N, stream);
+                                          const int32_t* cmat_width, int B, int C, int N, void* stream) {
+    return kv_project_multi_impl<float, 0>("msm_kv_project_multi_split", n_jobs, x, w, cmat, out, HW, x_tokens, x_batch_stride, cmat_width, B, C, N, stream);
 }
 
 extern "C" int msm_tokens_proj_nchw_f32(const float* x, const float* w, const float* bias, const double* gn_stats,

@@ -270,6 +270,8 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         # layers in ONE launch before the layer loop (nine launches, the coarse ones latency bound: 211 us per step at
         # B=8; one launch: see DESIGN.md).  (Running them on a side stream next to the query chain was neutral.)
         self.batched_kv = True
+        # row + column tables instead of a per-position matrix for the folded K/V constants (see _folded_kv)
+        self.separable_kv_constants = True
         # mask_features handed over as FoldedMaskFeatures are contracted in their 64-channel factored form (fused tails only)
         self.folded_mask_features = True
         self._fold_cache = None
@@ -328,7 +330,8 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         """Per layer i (level l = i % 3):  K_i = (input_proj_l(x) + level_embed_l + pos_l) Wk_i^T + bk_i
                                         V_i = (input_proj_l(x) + level_embed_l)         Wv_i^T + bv_i
         (DEC:575, AU:134-140) are affine in x, so they equal x [Wk_i Wp_l ; Wv_i Wp_l]^T + C_i with an
-        input-independent (H_l W_l, 2E) matrix C_i.  Folding cuts the projection FLOPs 4x (K = 64 instead
+        input-independent (H_l W_l, 2E) matrix C_i.  Returns (weights, constants): constants[i] = (tensor, width) --
+        width 0: the dense matrix; width W: the separable form ops.kv_project takes as ``cmat_width``.  Folding cuts the projection FLOPs 4x (K = 64 instead
         of 256) and removes the src tensors; the constants are evaluated in fp64 once per checkpoint/shape."""
         E = self.query_feat.weight.shape[1]
         params = [self.level_embed.weight] + [p for m in self.input_proj for p in m.parameters()] + \
@@ -357,10 +360,23 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                     wp = torch.eye(E, dtype=torch.float64, device=device)
                     off = lvl
                 pos = self._pos_tokens(h, w, device).double()
-                kc = (pos + off) @ wk.t() + bk                               # (hw, E)
-                vc = (off @ wv.t() + bv).expand(h * w, -1)                   # (hw, E)
                 ws.append(torch.cat([wk @ wp, wv @ wp], 0).float().contiguous())
-                cs.append(torch.cat([kc, vc], 1).float().contiguous())
+                # The sine embedding is cat(pos_y, pos_x) (position_encoding.py:44-51): its first half depends on the row only,
+                # its second on the column only, so the constant of token (y, x) is row[y] + col[x] -- two tables of h + w
+                # vectors instead of h w (629 MB at 480x640: as many bytes as the projection writes).  Checked on the values,
+                # not assumed: any other embedding keeps the dense matrix.
+                pg, E2 = pos.view(h, w, E), E // 2
+                if (self.separable_kv_constants and h > 1 and w > 1 and torch.equal(pg[:, :1, :E2].expand(h, w, E2), pg[..., :E2])
+                        and torch.equal(pg[:1, :, E2:].expand(h, w, E - E2), pg[..., E2:])):
+                    row = torch.cat([pg[:, 0, :E2] @ wk[:, :E2].t() + (off @ wk.t() + bk), (off @ wv.t() + bv).expand(h, -1)], 1)
+                    col = torch.cat([pg[0, :, E2:] @ wk[:, E2:].t(), torch.zeros(w, E, dtype=torch.float64, device=device)], 1)
+                    cs.append((torch.cat([row, col], 0).float().contiguous(), w))        # (h + w, 2E), width
+                else:
+                    kc = (pos + off) @ wk.t() + bk                               # (hw, E)
+                    vc = (off @ wv.t() + bv).expand(h * w, -1)                   # (hw, E)
+                    cs.append((torch.cat([kc, vc], 1).float().contiguous(), 0))
+            if len({cw > 0 for _, cw in cs}) > 1:                                # one launch takes all jobs separable or none
+                cs = [(ops.dense_kv_constant(c, cw), 0) for c, cw in cs]
             self._kv_cache[skey] = (ws, cs)
         return self._kv_cache[skey]
 
@@ -426,6 +442,18 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             if (int(th), int(tw)) not in out and Hm % th == 0 and Wm % tw == 0 and Hm // th == Wm // tw and Hm // th in (2, 4, 8):
                 out.append((int(th), int(tw)))
         return out
+
+    def _kv_one(self, x, w, cc):
+        """One layer's folded K/V projection when the layers' K/V are not all resident at once (the 307 200-key UCN path): the
+        plan's precision applies as in the batched form -- bf16 output from bf16 MFMAs in the bf16 mode, exact three-term splits
+        under f32_split (a one-job launch of the batched kernel), the fp32 MFMA kernel otherwise."""
+        c, cw = cc
+        if x.shape[1] == 64 and w.shape[0] in (256, 512):
+            if self.attention_dtype == "bf16":
+                return ops.kv_project_multi([x], [w], [c], out_dtype=torch.bfloat16, cmat_widths=[cw])[0]
+            if self.kv_split:
+                return ops.kv_project_multi([x], [w], [c], split=True, cmat_widths=[cw])[0]
+        return ops.kv_project(x, w, c, cw)
 
     def _forward_fused(self, xs, sizes, kv_w, kv_c, mask_features, out, qpos, kv_all=None, final_topk=0):
         """Same arithmetic as the loop in forward(), with the row-local ops of a layer in three launches:
@@ -519,11 +547,11 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             ca = self.transformer_cross_attention_layers[i]
             sa = self.transformer_self_attention_layers[i]
             ff = self.transformer_ffn_layers[i]
+            lp = self.attention_dtype == "bf16"
             if kv_all is not None:
                 kv = kv_all[i]
             else:
-                kv = ops.kv_project(xs[lvl], kv_w[i], kv_c[i])        # (B, hw, 2E) = [K | V]
-            lp = self.attention_dtype == "bf16"
+                kv = self._kv_one(xs[lvl], kv_w[i], kv_c[i])          # (B, hw, 2E) = [K | V]
             o = ops.hypersphere_attention(q, kv[..., :E], kv[..., E:], H, masked=attn, row_any=row_any, kappa=float(KAPPA), low_precision=lp)
             x, qk, v = ops.dec_post_cross(o, out, qpos, pk["cross_o"][i], ca.meanshift_attn.out_proj.bias, ca.norm.weight,
                                           ca.norm.bias, pk["self_in"][i], sa.self_attn.in_proj_bias)
@@ -566,9 +594,9 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                                                       for i in range(self.num_layers))
             if (self.batched_kv and self.num_layers <= 16 and kv_bytes <= (2 << 30) and all(xl.shape[1] == 64 for xl in xs)
                     and kv_w[0].shape[0] in (256, 512)):       # all layers' K/V live at once: only while that stays small
-                kv_all = ops.kv_project_multi([xs[i % self.num_feature_levels] for i in range(self.num_layers)], kv_w, kv_c,
+                kv_all = ops.kv_project_multi([xs[i % self.num_feature_levels] for i in range(self.num_layers)], kv_w, [c for c, _ in kv_c],
                                               out_dtype=torch.bfloat16 if self.attention_dtype == "bf16" else torch.float32,
-                                              split=self.kv_split and self.attention_dtype != "bf16")
+                                              split=self.kv_split and self.attention_dtype != "bf16", cmat_widths=[cw for _, cw in kv_c])
         else:
             for i in range(self.num_feature_levels):
                 pos.append(self._pos_tokens(*sizes[i], dev))
@@ -625,7 +653,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                 if kv_all is not None:
                     kv = kv_all[i]
                 else:
-                    kv = ops.kv_project(xs[lvl], kv_w[i], kv_c[i])        # (B, hw, 2E) = [K | V]
+                    kv = ops.kv_project(xs[lvl], kv_w[i], *kv_c[i])       # (B, hw, 2E) = [K | V]
                 t2 = ca.meanshift_attn.attend(out, None, None, query_pos=qpos, masked=attn, row_any=row_any,
                                               kv=(kv[..., :E], kv[..., E:]))
             else:

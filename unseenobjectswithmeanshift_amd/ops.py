@@ -187,23 +187,34 @@ def is_token_major(x):
     return x.stride(1) == 1 and x.stride(3) == C and x.stride(2) == W * C and x.stride(0) >= H * W * C and C > 1
 
 
-def kv_project(x, w, cmat):
+def dense_kv_constant(cmat, cmat_width):
+    """The (H*W, N) matrix of a separable constant [(H row vectors | W column vectors), N] (cmat_width = W; 0: cmat itself)."""
+    if not cmat_width:
+        return cmat
+    h = cmat.shape[0] - cmat_width
+    return (cmat[:h, None, :] + cmat[None, h:, :]).reshape(h * cmat_width, cmat.shape[1]).contiguous()
+
+
+def kv_project(x, w, cmat, cmat_width=0):
     """Folded K/V projection: x (B, 64, H, W), w (N, 64), cmat (H*W, N) -> (B, H*W, N).
     x is contiguous NCHW or token-major (is_token_major).  Maps with N in {256, 512} take the weight-stationary
     kernel (csrc/kv_proj.hip); small NCHW ones, where copying w into every CU's LDS costs more than it saves, and
-    other shapes take the tiled GEMM."""
+    other shapes take the tiled GEMM.  ``cmat_width`` = W: the constant is separable, cmat = (H + W, N) holds H row vectors then
+    W column vectors and token (y, x) gets row[y] + col[x] (include/msm_hip.h)."""
     _chk(x, "x"), _c(w, "w"), _c(cmat, "cmat")
     B, C, H, W = x.shape
     N = w.shape[0]
+    if cmat_width and (cmat_width != W or tuple(cmat.shape) != (H + W, N)):
+        raise RuntimeError(f"kv_project: a separable constant must be ({H + W}, N) with cmat_width = {W}")
     tokens = is_token_major(x) and not x.is_contiguous()
     if not tokens:
         _c(x, "x")
     if C != 64 or N not in (256, 512) or (not tokens and B * H * W < 8192):
-        return conv1x1_nchw_to_tokens(x.contiguous(), w, cmat)
-    if tuple(w.shape) != (N, C) or tuple(cmat.shape) != (H * W, N):
+        return conv1x1_nchw_to_tokens(x.contiguous(), w, dense_kv_constant(cmat, cmat_width))
+    if tuple(w.shape) != (N, C) or (not cmat_width and tuple(cmat.shape) != (H * W, N)):
         raise RuntimeError(f"kv_project: w must be (N, {C}) and cmat ({H * W}, N)")
     out = torch.empty((B, H * W, N), device=x.device, dtype=torch.float32)
-    rc = lib().msm_kv_project_f32(_p(x), _p(w), _p(cmat), _p(out), B, C, H * W, N, 1 if tokens else 0, x.stride(0), _stream())
+    rc = lib().msm_kv_project_f32(_p(x), _p(w), _p(cmat), _p(out), B, C, H * W, N, 1 if tokens else 0, x.stride(0), int(cmat_width), _stream())
     check(rc, "msm_kv_project_f32")
     return out
 
@@ -757,11 +768,12 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     return gv, gl, gw
 
 
-def kv_project_multi(xs, ws, cmats, out_dtype=torch.float32, split=False):
+def kv_project_multi(xs, ws, cmats, out_dtype=torch.float32, split=False, cmat_widths=None):
     """kv_project for a list of jobs in one launch: xs[j] (B, 64, H_j, W_j) contiguous NCHW or token-major
     (is_token_major), ws[j] (N, 64), cmats[j] (H_j*W_j, N) -> list of (B, H_j*W_j, N).  N in {256, 512}, <= 16 jobs.
     out_dtype torch.bfloat16: low-precision mode (bf16 MFMAs: w rounded to bf16, x as a hi + lo pair; bf16 output).
-    split: fp32 results on the bf16 matrix pipe (exact three-term splits, msm_kv_project_multi_split)."""
+    split: fp32 results on the bf16 matrix pipe (exact three-term splits, msm_kv_project_multi_split).
+    cmat_widths[j] = W_j: separable constants, cmats[j] (H_j + W_j, N) (see kv_project); all jobs or none."""
     if split and out_dtype != torch.float32:
         raise RuntimeError("kv_project_multi: split is the fp32-accurate form (float32 output)")
     if out_dtype not in (torch.float32, torch.bfloat16):
@@ -769,13 +781,15 @@ def kv_project_multi(xs, ws, cmats, out_dtype=torch.float32, split=False):
     n = len(xs)
     B, N = xs[0].shape[0], ws[0].shape[0]
     outs, tok, sb, hw = [], [], [], []
-    for x, w, c in zip(xs, ws, cmats):
+    cws = [int(v) for v in cmat_widths] if cmat_widths is not None else [0] * n
+    for x, w, c, cw in zip(xs, ws, cmats, cws):
         _chk(x, "x"), _c(w, "w"), _c(c, "cmat")
         Bx, C, H, W = x.shape
         t = is_token_major(x) and not x.is_contiguous()
         if not t:
             _c(x, "x")
-        if Bx != B or C != 64 or w.shape[0] != N or tuple(w.shape) != (N, 64) or tuple(c.shape) != (H * W, N):
+        if Bx != B or C != 64 or w.shape[0] != N or tuple(w.shape) != (N, 64) or cw not in (0, W) \
+                or tuple(c.shape) != ((H + W, N) if cw else (H * W, N)):
             raise RuntimeError("kv_project_multi: inconsistent job shapes")
         tok.append(1 if t else 0)
         sb.append(x.stride(0) if t else C * H * W)
@@ -786,7 +800,7 @@ def kv_project_multi(xs, ws, cmats, out_dtype=torch.float32, split=False):
     ia, la = (ctypes.c_int32 * n), (ctypes.c_int64 * n)
     fn = (lib().msm_kv_project_multi_split if split else lib().msm_kv_project_multi_f32) if out_dtype == torch.float32 else lib().msm_kv_project_multi_bf16
     rc = fn(n, arr(xs), arr(ws), arr(cmats), arr(outs), ctypes.cast(ia(*hw), ctypes.c_void_p), ctypes.cast(ia(*tok), ctypes.c_void_p),
-            ctypes.cast(la(*sb), ctypes.c_void_p), B, 64, N, _stream())
+            ctypes.cast(la(*sb), ctypes.c_void_p), ctypes.cast(ia(*cws), ctypes.c_void_p), B, 64, N, _stream())
     check(rc, "msm_kv_project_multi")
     return outs
 
