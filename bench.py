@@ -590,6 +590,28 @@ def extra_configs(dev, args):
         ucn.inference(ufe, (H, W))
         torch.cuda.synchronize()
     ud = ct.durations()
+    # the same path in the bf16 mode (bf16 K/V written by bf16 MFMAs, low-precision attention cores / tails / mask step): its own entry
+    ucn.set_precision("bf16")
+    for _ in range(2):
+        ucn.inference(ufe, (H, W))
+    t_lp = {}
+    for depth in (1, 3):
+        up = PipelinedInference(ucn, depth=depth)
+        for _ in range(depth):
+            up.submit(ufe, (H, W))
+        up.drain()
+        urun = lambda: up.submit(None, (H, W), slot_inputs=True)
+        for _ in range(2 * depth):
+            urun()
+        up.drain()
+        t_lp[depth] = timed(urun, 6 * depth)
+        up.drain()
+        del up
+    with _lib.CallTimer() as ct:
+        ucn.inference(ufe, (H, W))
+        torch.cuda.synchronize()
+    ud_lp = ct.durations()
+    ucn.set_precision("f32")
     attn_ms = sum(ud.get("msm_hypersphere_attn_fwd", [0.0]))
     n_attn = len(ud.get("msm_hypersphere_attn_fwd", [])) or 1
     S_keys = H * W
@@ -608,6 +630,11 @@ def extra_configs(dev, args):
         "three_batches_in_flight": {"value": round(UB / t_pipe[3], 1), "ms_per_step": round(1e3 * t_pipe[3], 3)},
         "eager": {"value": round(UB / t_eager, 1), "ms_per_step": round(1e3 * t_eager, 3)},
         "kernels_ms": {k: round(sum(v), 3) for k, v in sorted(ud.items(), key=lambda kv: -sum(kv[1]))[:6]},
+        "bf16": {"dtype": "bf16 operands / fp32 accumulation, bf16 K/V", "value": round(UB / min(t_lp.values()), 1), "unit": "images/sec",
+                 "one_batch_in_flight": {"value": round(UB / t_lp[1], 1), "ms_per_step": round(1e3 * t_lp[1], 3)},
+                 "three_batches_in_flight": {"value": round(UB / t_lp[3], 1), "ms_per_step": round(1e3 * t_lp[3], 3)},
+                 "kernels_ms": {k: round(sum(v), 3) for k, v in sorted(ud_lp.items(), key=lambda kv: -sum(kv[1]))[:6]},
+                 "parity": "tests/test_gpu_configs.py::test_ucn_path_480x640_bf16_vs_reference (final-mask mismatch 0.1 % against the fp32 reference golden)"},
         "roofline": {"bound": "hbm", "kernel": "hs_attn_kernel + combine at 307 200 keys (msm_hypersphere_attn_fwd)",
                      "achieved": round(attn_bytes / (cross_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                      "frac": round(attn_bytes / (cross_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "bytes_per_launch": attn_bytes,
