@@ -59,7 +59,7 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 14   /* 14: cmat_width argument of the K/V projections (separable position constants); 13: flags argument of msm_ms_select_seeds_bf16 (persistent on-chip seeding over the bf16 copy), input projections on the bf16 matrix pipe (msm_conv1x1_in_lp, msm_conv1x1_in_multi_lp); 12: head-major bf16 activations between the encoder kernels of the bf16 plan (msm_encoder_block_hm_fwd, msm_msdeform_attn_enc_lp_fwd, msm_f32_to_f16); 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
+#define MSM_ABI_VERSION 14   /* 14: cmat_width argument of the K/V projections (separable position constants), msm_conv3x3_c64_nchw_bf16; 13: flags argument of msm_ms_select_seeds_bf16 (persistent on-chip seeding over the bf16 copy), input projections on the bf16 matrix pipe (msm_conv1x1_in_lp, msm_conv1x1_in_multi_lp); 12: head-major bf16 activations between the encoder kernels of the bf16 plan (msm_encoder_block_hm_fwd, msm_msdeform_attn_enc_lp_fwd, msm_f32_to_f16); 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
 int msm_abi_version(void);
 
 /* Kernel-selection overrides for tools/ and tests/ (NOT read on the product path: every option defaults to
@@ -598,6 +598,10 @@ int msm_conv3x3_c64_split(const uint16_t* planes, const float* w_tap_major, floa
  * (SimpleBasePixelDecoder.mask_features: Conv2d(64, 256, 3, padding=1), fpn.py:237-246; 90.6 GFLOP per 640x480 frame). */
 int msm_conv3x3_c64_nchw_f32(const float* in, const float* w_tap_major, const float* bias, float* out, int B, int H, int W,
                              int Cout, void* stream);
+/* ... in the low-precision mode of msm_conv3x3_c64_bf16 (weight rounded to one bf16 as it is copied into LDS, activations as hi + lo
+ * operands, fp32 accumulation and fp32 planes out): the UCN path's mask_features convolution under set_precision("bf16"). */
+int msm_conv3x3_c64_nchw_bf16(const float* in, const float* w_tap_major, const float* bias, float* out, int B, int H, int W,
+                              int Cout, void* stream);
 
 /* Encoder prologue: everything between the input projections and the first deformable-attention layer in one pass
  * over the token buffer (msdeformattn.py:326-329 GroupNorm of input_proj, :60-75 level concatenation;

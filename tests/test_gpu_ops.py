@@ -1320,6 +1320,12 @@ def test_conv3x3_c64_nchw_vs_fp64(B, H, W, Cout):
     out = ops().conv3x3_tokens_to_nchw(x.to(DEV), w3, b.to(DEV), H, W)
     closed(out, ref, rtol=2e-5, atol=2e-5)
     closed(ops().conv3x3_tokens_to_nchw(x.to(DEV), w3, None, H, W), ref - b.double()[None, :, None], rtol=2e-5, atol=2e-5)
+    # low-precision mode (msm_conv3x3_c64_nchw_bf16): against the fp64 convolution WITH THE ROUNDED WEIGHT to 1e-4 (the activations'
+    # hi + lo pair carries 16 mantissa bits), against the unrounded one to bf16's tolerance
+    ref_r = F.conv2d(x.double().view(B, H, W, 64).permute(0, 3, 1, 2), w.bfloat16().double(), b.double(), padding=1).reshape(B, Cout, H * W)
+    lp = ops().conv3x3_tokens_to_nchw(x.to(DEV), w3, b.to(DEV), H, W, bf16=True)
+    closed(lp, ref_r, rtol=1e-4, atol=1e-4)
+    assert float((lp.cpu().double() - ref).abs().max()) < 2e-2 * float(ref.abs().max())
 
 
 @pytest.mark.parametrize("B,shapes", [(2, [(15, 20), (30, 40), (60, 80)]), (1, [(4, 6), (8, 12), (16, 24)]), (3, [(7, 7), (14, 14), (28, 28)])])

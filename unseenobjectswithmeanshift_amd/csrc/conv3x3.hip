@@ -36,7 +36,7 @@ constexpr int C3_LDB = C3_K + 16;        // LDS row stride of the bf16 weight co
 // lane ends with 4 consecutive PIXELS of one channel and the planes are written with 16-byte stores (W % 4 == 0); bias per
 // channel (SimpleBasePixelDecoder.mask_features: Conv2d(64, 256, 3, padding=1) with bias, fpn.py:237-246).
 //
-// BF (low-precision mode, token-major output only): the weight is rounded to bf16 when it is copied into LDS, a tap's
+// BF (low-precision mode): the weight is rounded to bf16 when it is copied into LDS, a tap's
 // activations become hi + lo bf16 operands when they are used (x = hi + lo up to 2^-17 |x|) and v_mfma_f32_16x16x32_bf16 takes
 // half a tap's channels at once: 16 MFMAs of 16 cycles per tap instead of 64 of 32 -- the kernel is then a stream over the map.
 // K order of a tap: channel kh*32 + lq*8 + i on both operands.
@@ -44,7 +44,6 @@ template <bool NCHW, bool BF = false>
 __global__ __launch_bounds__(C3_W * 64) void conv3x3_c64_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                                 const float* __restrict__ bias, float* __restrict__ out,
                                                                 double* __restrict__ stats, int H, int W) {
-    static_assert(!(NCHW && BF), "the bf16 form writes token-major output");
     extern __shared__ __attribute__((aligned(16))) float wl[];   // [64][C3_LD] (BF: [64][C3_LDB] bf16), then the moment scratch [C3_W][64][2]
     unsigned short* wlb = reinterpret_cast<unsigned short*>(wl);
     float* msc = BF ? wl + C3_C * C3_LDB / 2 : wl + C3_C * C3_LD;
@@ -113,9 +112,9 @@ __global__ __launch_bounds__(C3_W * 64) void conv3x3_c64_kernel(const float* __r
                     for (int mt = 0; mt < 4; ++mt)
                         a[mt] = *reinterpret_cast<const bf16x8*>(wlb + (mt * 16 + lj) * C3_LDB + t * C3_C + kh * 32 + lq * 8);
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma_bf16k32(a[mt], xl, acc[mt]);
+                    for (int mt = 0; mt < 4; ++mt) acc[mt] = NCHW ? mfma_bf16k32(xl, a[mt], acc[mt]) : mfma_bf16k32(a[mt], xl, acc[mt]);
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma_bf16k32(a[mt], xh, acc[mt]);
+                    for (int mt = 0; mt < 4; ++mt) acc[mt] = NCHW ? mfma_bf16k32(xh, a[mt], acc[mt]) : mfma_bf16k32(a[mt], xh, acc[mt]);
                 }
                 return;
             }
@@ -459,21 +458,38 @@ extern "C" int msm_conv3x3_c64_bf16(const float* in, const float* w_tap_major, f
     return conv3x3_c64_launch(in, w_tap_major, out, stats, stats_cleared, B, H, W, 1, stream);
 }
 
-extern "C" int msm_conv3x3_c64_nchw_f32(const float* in, const float* w_tap_major, const float* bias, float* out, int B, int H, int W,
-                                        int Cout, void* stream) {
+static int conv3x3_c64_nchw_launch(const float* in, const float* w_tap_major, const float* bias, float* out, int B, int H, int W, int Cout, int bf,
+                                   void* stream) {
     MSM_REQUIRE(in && w_tap_major && out && in != out, "msm_conv3x3_c64_nchw_f32: null or aliased pointer");
     MSM_REQUIRE(B > 0 && H > 0 && W > 0 && W % 4 == 0 && Cout > 0 && Cout % C3_C == 0 && Cout <= 1024,
                 "msm_conv3x3_c64_nchw_f32: need W %% 4 == 0 and Cout a multiple of 64 (B=%d H=%d W=%d Cout=%d)", B, H, W, Cout);
     MSM_REQUIRE((int64_t)H * W * C3_C < ((int64_t)1 << 31), "msm_conv3x3_c64_nchw_f32: image too large");
     MSM_REQUIRE(((((uintptr_t)in) | ((uintptr_t)w_tap_major) | ((uintptr_t)out)) & 15) == 0, "msm_conv3x3_c64_nchw_f32: misaligned pointer");
-    const size_t lds = sizeof(float) * ((size_t)C3_C * C3_LD + (size_t)C3_W * C3_C * 2);
-    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_kernel<true>, lds));
     const int units = cdiv(W, 16) * H;
     const int slices = Cout / C3_C;
     int per_image = max(1, 256 / (B * slices));
     per_image = min(per_image, cdiv(units, C3_W));
-    hipLaunchKernelGGL(conv3x3_c64_kernel<true>, dim3(per_image, B, slices), dim3(C3_W * 64), lds, (hipStream_t)stream, in, w_tap_major,
-                       bias, out, nullptr, H, W);
+    if (bf) {
+        const size_t lds = sizeof(unsigned short) * (size_t)C3_C * C3_LDB + sizeof(float) * (size_t)C3_W * C3_C * 2;
+        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_kernel<true, true>, lds));
+        hipLaunchKernelGGL((conv3x3_c64_kernel<true, true>), dim3(per_image, B, slices), dim3(C3_W * 64), lds, (hipStream_t)stream, in, w_tap_major,
+                           bias, out, nullptr, H, W);
+    } else {
+        const size_t lds = sizeof(float) * ((size_t)C3_C * C3_LD + (size_t)C3_W * C3_C * 2);
+        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_kernel<true>, lds));
+        hipLaunchKernelGGL(conv3x3_c64_kernel<true>, dim3(per_image, B, slices), dim3(C3_W * 64), lds, (hipStream_t)stream, in, w_tap_major,
+                           bias, out, nullptr, H, W);
+    }
     MSM_CHECK_LAUNCH("msm_conv3x3_c64_nchw_f32");
     return MSM_OK;
+}
+
+extern "C" int msm_conv3x3_c64_nchw_f32(const float* in, const float* w_tap_major, const float* bias, float* out, int B, int H, int W,
+                                        int Cout, void* stream) {
+    return conv3x3_c64_nchw_launch(in, w_tap_major, bias, out, B, H, W, Cout, 0, stream);
+}
+
+extern "C" int msm_conv3x3_c64_nchw_bf16(const float* in, const float* w_tap_major, const float* bias, float* out, int B, int H, int W,
+                                         int Cout, void* stream) {
+    return conv3x3_c64_nchw_launch(in, w_tap_major, bias, out, B, H, W, Cout, 1, stream);
 }

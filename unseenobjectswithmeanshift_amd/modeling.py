@@ -704,6 +704,7 @@ class SimpleBasePixelDecoder(PlanAttributes, nn.Module):
         self.in_features = [k for k, v in input_shape]
         self.mask_dim = mask_dim
         self.conv_dim = conv_dim
+        self.precision = "f32"             # "bf16" (head.set_precision): the mask_features convolution in the low-precision form
         if mask_dim != 64:
             self.mask_features = nn.Conv2d(conv_dim, mask_dim, kernel_size=3, stride=1, padding=1)
         self.maskformer_num_feature_levels = 1
@@ -727,7 +728,7 @@ class SimpleBasePixelDecoder(PlanAttributes, nn.Module):
         B, C, H, W = y.shape
         tok = ops.transpose_last2(y.contiguous().view(B, C, H * W))                       # NHWC tokens
         w = self.mask_features.weight.permute(0, 2, 3, 1).reshape(self.mask_dim, 9 * C).contiguous()
-        mf = ops.conv3x3_tokens_to_nchw(tok, w, self.mask_features.bias, int(H), int(W))
+        mf = ops.conv3x3_tokens_to_nchw(tok, w, self.mask_features.bias, int(H), int(W), bf16=getattr(self, "precision", "f32") == "bf16")
         return mf.view(B, self.mask_dim, H, W), None, multi_scale_features
 
 

@@ -277,17 +277,19 @@ def conv3x3_c64(t, w_tap_major, H, W, *, stats=None, stats_cleared=False, bf16=F
     return out, stats
 
 
-def conv3x3_tokens_to_nchw(t, w_tap_major, bias, H, W):
+def conv3x3_tokens_to_nchw(t, w_tap_major, bias, H, W, bf16=False):
     """3x3 / pad 1 convolution of an NHWC token map with the output written directly as NCHW (B, Cout, H*W)
     (SimpleBasePixelDecoder.mask_features, fpn.py:237-246: Conv2d 3x3 with bias).  64 input channels, Cout % 64 == 0 and
-    W % 4 == 0 take the weight-stationary kernel (csrc/conv3x3.hip), other shapes the implicit GEMM."""
+    W % 4 == 0 take the weight-stationary kernel (csrc/conv3x3.hip), other shapes the implicit GEMM.  ``bf16`` (low-precision
+    mode, weight-stationary shapes only): the weight rounded to one bf16, activations as hi + lo operands, fp32 result."""
     _c(t, "t"), _c(w_tap_major, "w"), _c(bias, "bias")
     B, HW, Cin = t.shape
     Cout = w_tap_major.shape[0]
     out = torch.empty((B, Cout, HW), device=t.device, dtype=torch.float32)
     if Cin == 64 and Cout % 64 == 0 and Cout <= 1024 and W % 4 == 0 and HW == H * W:
-        rc = lib().msm_conv3x3_c64_nchw_f32(_p(t), _p(w_tap_major), _p(bias), _p(out), B, H, W, Cout, _stream())
-        check(rc, "msm_conv3x3_c64_nchw_f32")
+        fn = lib().msm_conv3x3_c64_nchw_bf16 if bf16 else lib().msm_conv3x3_c64_nchw_f32
+        rc = fn(_p(t), _p(w_tap_major), _p(bias), _p(out), B, H, W, Cout, _stream())
+        check(rc, "msm_conv3x3_c64_nchw_bf16" if bf16 else "msm_conv3x3_c64_nchw_f32")
         return out
     rc = lib().msm_gemm_f32(_p(t), None, _p(w_tap_major), _p(bias), _p(out), HW, Cout, 9 * Cin, B,
                             Cin, 1, HW * Cin, 0, 0, 1, HW, Cout * HW, 0,
