@@ -8,6 +8,6 @@ for e in 0 1 2 3; do
   objs=$(ls unseenobjectswithmeanshift_amd/build/*.o | grep -v kv_proj)
   hipcc --offload-arch=gfx950 -shared -fPIC $objs /tmp/kv_$e.o -o $L
   echo "== KP_EXP=$e"
-  timeout 200 python -u tools/probes/kv_multi_time.py 2>&1 | grep -v amdgpu
+  timeout 200 python -u tools/probes/kv_multi_time.py 2>&1 | grep -v amdgpu | grep "dense"
 done
 cp /tmp/ship.so $L

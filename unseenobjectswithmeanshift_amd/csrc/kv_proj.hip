@@ -205,6 +205,7 @@ __global__ __launch_bounds__(KP_W * 64) void kv_project_multi_kernel(KvJobs jobs
 // the half.  K order k = lq*16 + G*8 + e on both operands, so a lane's 16 x-values are its two B operands as they are loaded.
 constexpr int KS_LD = KP_K + 8;      // LDS row stride of a bf16 weight copy (elements)
 constexpr int KS_W = 8;              // waves per workgroup of the bf16-pipe kernel
+constexpr int KS_TR = 64 + 4;        // row stride (bf16 elements) of a wave's output transposition tile: 136 B = 34 banks, the 16 token rows of a ds_write_b64 land on 16 bank pairs
 
 template <typename OT, int MODE, bool SEP>
 __device__ __forceinline__ void kv_project_split_body(const float* __restrict__ x, const float* __restrict__ w,
@@ -280,6 +281,12 @@ __device__ __forceinline__ void kv_project_split_body(const float* __restrict__ 
             for (int g = 0; g < 2; ++g)
                 xs[g] = join(split3(xb[8 * g], xb[8 * g + 1], xb[8 * g + 2], xb[8 * g + 3]), split3(xb[8 * g + 4], xb[8 * g + 5], xb[8 * g + 6], xb[8 * g + 7]));
             const unsigned short* wp = wl + lj * KS_LD + lq * 16;
+            unsigned short* tr = wl + COPIES * KP_FB * 16 * KS_LD + wave * (16 * KS_TR);       // this wave's [16 tokens][KS_TR] transposition tile
+            float4 qn[2];                                 // SEP: the column vectors of the NEXT pair of feature blocks (one pair ahead:
+            if constexpr (SEP) {                          // with few MFMAs per pair their latency would otherwise be exposed)
+                qn[0] = *reinterpret_cast<const float4*>(cq);
+                qn[1] = *reinterpret_cast<const float4*>(cq + 16);
+            }
 #pragma unroll
             for (int fb = 0; fb < KP_FB; fb += 2) {
                 // two feature blocks in flight: consecutive MFMAs alternate accumulators; low-order terms apart from the leading one
@@ -289,8 +296,8 @@ __device__ __forceinline__ void kv_project_split_body(const float* __restrict__ 
                     hi[j] = f32x4{cm[fb + j].x, cm[fb + j].y, cm[fb + j].z, cm[fb + j].w};
                     lo[j] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if constexpr (SEP) {                  // the column vector rides in the low-order accumulator
-                        const float4 q = *reinterpret_cast<const float4*>(cq + (fb + j) * 16);
-                        lo[j] = f32x4{q.x, q.y, q.z, q.w};
+                        lo[j] = f32x4{qn[j].x, qn[j].y, qn[j].z, qn[j].w};
+                        qn[j] = *reinterpret_cast<const float4*>(cq + min(fb + 2 + j, KP_FB - 1) * 16);
                     }
                 }
 #pragma unroll
@@ -313,8 +320,30 @@ __device__ __forceinline__ void kv_project_split_body(const float* __restrict__ 
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {          // (no `live` test: see kv_project_body)
                     const f32x4 a = hi[j] + lo[j];
+#if KP_EXP == 1
+                    if (a[0] == 12345.f)
+#endif
                     if constexpr (std::is_same<OT, float>::value) *reinterpret_cast<float4*>(op + (fb + j) * 16) = make_float4(a[0], a[1], a[2], a[3]);
-                    else *reinterpret_cast<bf16x4*>(op + (fb + j) * 16) = pack4(a[0], a[1], a[2], a[3]);
+                    else *reinterpret_cast<bf16x4*>(tr + lj * KS_TR + (((fb + j) & 3) * 16 + lq * 4)) = pack4(a[0], a[1], a[2], a[3]);
+                }
+                if constexpr (!std::is_same<OT, float>::value) {
+                    // bf16 result: a lane's four values are 8 bytes, a token's run per store instruction 32 bytes -- a quarter of a
+                    // line (measured: 76 us as direct stores, 61 with the same bytes as whole lines, 46 without stores).  Four
+                    // feature blocks (64 features = 128 B per token) pass through a wave-private LDS tile and leave as whole lines:
+                    // lane -> (token l >> 3 (+ 8), 16-byte chunk l & 7).  Rows past the last token hold token HW - 1 again and
+                    // store the same values to the same address, as above.
+                    if ((fb & 2) != 0) {
+#if KP_EXP == 1
+                        if (xb[0] == 12345.f)
+#endif
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int r = (lane >> 3) + 8 * h;
+                            const u32x4b v = *reinterpret_cast<const u32x4b*>(tr + r * KS_TR + (lane & 7) * 8);
+                            const int pr = min(tile * 16 + r, HW - 1);
+                            *reinterpret_cast<u32x4b*>(out + ((int64_t)img * HW + pr) * N + n_base + (fb - 2) * 16 + (lane & 7) * 8) = v;
+                        }
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);      // one pair of feature blocks at a time: left alone hipcc hoists the fragment
                                                         // reads of all sixteen to the top (96 x 4 registers: 250 spilled)
@@ -524,7 +553,7 @@ static int kv_project_multi_impl(const char* who, int n_jobs, const float* const
         hipLaunchKernelGGL(KERNEL, dim3(wg), dim3(WAVES * 64), lds, (hipStream_t)stream, jobs, B, N);                 \
     }
     if constexpr (PIPE >= 0) {
-        const size_t lds = sizeof(unsigned short) * (size_t)(PIPE == 0 ? 3 : 1) * KP_FB * 16 * KS_LD;
+        const size_t lds = sizeof(unsigned short) * ((size_t)(PIPE == 0 ? 3 : 1) * KP_FB * 16 * KS_LD + (size_t)KS_W * 16 * KS_TR);
         if (sep) KV_LAUNCH((kv_project_multi_split_kernel<OT, PIPE, true>), KS_W)
         else KV_LAUNCH((kv_project_multi_split_kernel<OT, PIPE, false>), KS_W)
     } else {

@@ -337,7 +337,11 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         params = [self.level_embed.weight] + [p for m in self.input_proj for p in m.parameters()] + \
                  [p for l in self.transformer_cross_attention_layers for p in (l.meanshift_attn.in_proj_weight, l.meanshift_attn.in_proj_bias)]
         pkey = tuple((p.data_ptr(), p._version) for p in params)
-        skey = (tuple(sizes), str(device))
+        # separable constants (below) everywhere but on the small maps of the bf16 mode: its K/V kernel is issue-bound and the second
+        # table costs it 16 more loads per 16-token unit (measured at B = 8, 640x480 levels: 59 us dense, 69 separable; fp32 MFMA
+        # kernel: 135 dense, 128 separable); from 128x128 keys on the dense matrix is the larger cost in every mode
+        sep_min = 16384 if self.attention_dtype == "bf16" else 0
+        skey = (tuple(sizes), str(device), sep_min)
         # one entry per input geometry (the two-stage harness alternates between the frame and the 224x224 crops); a
         # parameter change drops them all
         if self._kv_cache is None or self._kv_cache.get("params") != pkey:
@@ -366,7 +370,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                 # vectors instead of h w (629 MB at 480x640: as many bytes as the projection writes).  Checked on the values,
                 # not assumed: any other embedding keeps the dense matrix.
                 pg, E2 = pos.view(h, w, E), E // 2
-                if (self.separable_kv_constants and h > 1 and w > 1 and torch.equal(pg[:, :1, :E2].expand(h, w, E2), pg[..., :E2])
+                if (self.separable_kv_constants and h > 1 and w > 1 and h * w >= sep_min and torch.equal(pg[:, :1, :E2].expand(h, w, E2), pg[..., :E2])
                         and torch.equal(pg[:1, :, E2:].expand(h, w, E - E2), pg[..., E2:])):
                     row = torch.cat([pg[:, 0, :E2] @ wk[:, :E2].t() + (off @ wk.t() + bk), (off @ wv.t() + bv).expand(h, -1)], 1)
                     col = torch.cat([pg[0, :, E2:] @ wk[:, E2:].t(), torch.zeros(w, E, dtype=torch.float64, device=device)], 1)
