@@ -157,6 +157,15 @@ def test_decoder_execution_variants_agree():
     b = dec(xd, mfd)
     torch.testing.assert_close(b["pred_logits"], ref["pred_logits"], rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(b["pred_masks"], ref["pred_masks"], rtol=1e-4, atol=3e-4)
+    # the folded constants as row + column tables (default) vs the dense per-position matrix: one rounding step apart
+    dec.fold_kv = True
+    assert dec.separable_kv_constants and all(cw > 0 for _, cw in dec._folded_kv([(int(t.shape[2]), int(t.shape[3])) for t in xd], xd[0].device)[1])
+    dec.separable_kv_constants, dec._kv_cache = False, None
+    d = dec(xd, mfd)
+    assert all(cw == 0 for _, cw in dec._folded_kv([(int(t.shape[2]), int(t.shape[3])) for t in xd], xd[0].device)[1])
+    dec.separable_kv_constants, dec._kv_cache = True, None
+    torch.testing.assert_close(d["pred_logits"], ref["pred_logits"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(d["pred_masks"], ref["pred_masks"], rtol=1e-4, atol=2e-4)
     # fused row-local tails (3 launches per layer) vs one launch per op
     assert dec.fused_tails
     dec.fold_kv, dec.fused_tails = True, False
