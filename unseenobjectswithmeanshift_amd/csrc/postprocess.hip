@@ -13,14 +13,19 @@
 
 namespace msm {
 
+// gridDim.y workgroups per image share the ranking: every one recomputes the Q*K scores (a few hundred exponentials), ranks the
+// candidates i = blockIdx.y*256 + thread (+ gridDim.y*256 ...) against all of them and writes / gathers the winners among its own
+// (one workgroup per image ranked 600 candidates of configs[4] in 67 us: 1800 compare rounds on a single CU).
 __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ logits, int Q, int K1, int T,
                                                    float* __restrict__ scores_out, int64_t* __restrict__ classes_out,
                                                    int32_t* __restrict__ qidx_out, const float* __restrict__ gsrc, int64_t gld, int gcols,
                                                    float* __restrict__ gout) {
-    extern __shared__ float sc[];  // Q*K scores, then T selected query indices
+    extern __shared__ float sc[];  // Q*K scores, then (rank, query) of this workgroup's winners
+    __shared__ int n_win;
     const int b = blockIdx.x;
     const int K = K1 - 1, n = Q * K;
     const float* lg = logits + (int64_t)b * Q * K1;
+    if (threadIdx.x == 0) n_win = 0;
     for (int qi = threadIdx.x; qi < Q; qi += 256) {
         float mx = -INFINITY;
         for (int c = 0; c < K1; ++c) mx = fmaxf(mx, lg[qi * K1 + c]);
@@ -31,7 +36,8 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ log
         for (int c = 0; c < K; ++c) sc[qi * K + c] = expf(lg[qi * K1 + c] - mx) / den;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 256) {
+    int2* win = reinterpret_cast<int2*>(sc + n + (n & 1));
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) {
         const float s = sc[i];
         const float sk = s != s ? -INFINITY : s;
         int rank = 0;
@@ -44,16 +50,16 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ log
             scores_out[(int64_t)b * T + rank] = s;
             classes_out[(int64_t)b * T + rank] = (int64_t)(i % K);
             qidx_out[(int64_t)b * T + rank] = i / K;
-            if (gsrc) reinterpret_cast<int*>(sc + n)[rank] = i / K;
+            if (gsrc) win[atomicAdd(&n_win, 1)] = make_int2(rank, i / K);
         }
     }
     if (!gsrc) return;
-    // the selected rows of the per-query matrix (uniform branch; every rank 0..T-1 was written exactly once above)
+    // the selected rows of the per-query matrix (uniform branch; every rank 0..T-1 is written exactly once over the image's workgroups)
     __syncthreads();
-    const int* sel = reinterpret_cast<const int*>(sc + n);
-    for (int i = threadIdx.x; i < T * gcols; i += 256) {
+    const int nw = n_win;
+    for (int i = threadIdx.x; i < nw * gcols; i += 256) {
         const int t = i / gcols, c = i - t * gcols;
-        gout[((int64_t)b * T + t) * gcols + c] = gsrc[((int64_t)b * Q + sel[t]) * gld + c];
+        gout[((int64_t)b * T + win[t].x) * gcols + c] = gsrc[((int64_t)b * Q + win[t].y) * gld + c];
     }
 }
 
@@ -301,8 +307,11 @@ static int topk_impl(const char* who, const float* pred_logits, int B, int Q, in
     const int n = Q * (K1 - 1);
     MSM_REQUIRE(n <= 4096 && T > 0 && T <= n, "%s: need T <= Q*K <= 4096 (T=%d, Q*K=%d)", who, T, n);
     MSM_REQUIRE(!gather_src || (gather_out && gather_cols > 0 && gather_ld >= gather_cols), "%s: bad gather arguments", who);
-    hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(256), sizeof(float) * n + sizeof(int) * (gather_src ? T : 0), (hipStream_t)stream, pred_logits,
-                       Q, K1, T, scores_out, classes_out, query_index_out, gather_src, gather_ld, gather_cols, gather_out);
+    // (the winners' list is 8-byte aligned: n rounded up to an even count of floats in front of it)
+    const int parts = min(16, cdiv(n, 256));          // one candidate per thread: the 600 of configs[4] are three workgroups, one round of compares each
+    hipLaunchKernelGGL(topk_kernel, dim3(B, parts), dim3(256), sizeof(float) * (n + (n & 1)) + sizeof(int) * 2 * (gather_src ? min(T, 256) : 0),
+                       (hipStream_t)stream, pred_logits, Q, K1, T, scores_out, classes_out, query_index_out, gather_src, gather_ld, gather_cols,
+                       gather_out);
     MSM_CHECK_LAUNCH(who);
     return MSM_OK;
 }

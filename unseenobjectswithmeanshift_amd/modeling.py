@@ -596,11 +596,18 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             kv_w, kv_c = self._folded_kv(sizes, dev)
             kv_bytes = 4 * B * kv_w[0].shape[0] * sum(sizes[i % self.num_feature_levels][0] * sizes[i % self.num_feature_levels][1]
                                                       for i in range(self.num_layers))
-            if (self.batched_kv and self.num_layers <= 16 and kv_bytes <= (2 << 30) and all(xl.shape[1] == 64 for xl in xs)
-                    and kv_w[0].shape[0] in (256, 512)):       # all layers' K/V live at once: only while that stays small
-                kv_all = ops.kv_project_multi([xs[i % self.num_feature_levels] for i in range(self.num_layers)], kv_w, [c for c, _ in kv_c],
-                                              out_dtype=torch.bfloat16 if self.attention_dtype == "bf16" else torch.float32,
-                                              split=self.kv_split and self.attention_dtype != "bf16", cmat_widths=[cw for _, cw in kv_c])
+            if (self.batched_kv and kv_bytes <= (1 << 30) and all(xl.shape[1] == 64 for xl in xs)
+                    and kv_w[0].shape[0] in (256, 512)):       # all layers' K/V live at once: only while that stays small (beyond ~1 GiB a
+                # layer's K/V is long out of the caches when its attention reads it: configs[4] at batch 4 is 1 % faster layer by layer)
+                # (a launch takes up to 16 jobs: the 20 layers of configs[4] are two launches)
+                kv_all = []
+                for j0 in range(0, self.num_layers, 16):
+                    jobs = range(j0, min(j0 + 16, self.num_layers))
+                    kv_all += ops.kv_project_multi([xs[i % self.num_feature_levels] for i in jobs], [kv_w[i] for i in jobs],
+                                                   [kv_c[i][0] for i in jobs],
+                                                   out_dtype=torch.bfloat16 if self.attention_dtype == "bf16" else torch.float32,
+                                                   split=self.kv_split and self.attention_dtype != "bf16",
+                                                   cmat_widths=[kv_c[i][1] for i in jobs])
         else:
             for i in range(self.num_feature_levels):
                 pos.append(self._pos_tokens(*sizes[i], dev))
