@@ -244,8 +244,9 @@ __device__ __forceinline__ void keys_consume(const KeyFrag<KVT, NQ, MM>& f, int 
                       (float)(mw >> 24) * MASK_BIAS};
         }
         if constexpr (BF) {
-            s = mfma_bf16(kh[0], qh[m][0], s);
-            s = mfma_bf16(kh[1], qh[m][1], s);
+            // one K = 32 MFMA over the head's 32 dims (a lane's eight dims 8 lq .. + 7 on both operands) instead of two dependent
+            // K = 16 ones, which also issue at half the rate
+            s = mfma_bf16k32(cat8(kh[0], kh[1]), cat8(qh[m][0], qh[m][1]), s);
         } else {
 #pragma unroll
             for (int t = 0; t < 8; ++t) s = mfma16(kf[t], qf[m][t], s);

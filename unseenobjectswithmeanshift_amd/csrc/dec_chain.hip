@@ -124,7 +124,13 @@ __device__ __forceinline__ void bload(BFrag<uint16_t>& f, const uint16_t* __rest
         for (int h = 0; h < 2; ++h) {
             const int kc = half * 2 + h;
 #pragma unroll
-            for (int up = 0; up < 2; ++up) f.v[h][t][up] = *reinterpret_cast<const u32x4b*>(wp + (kc * 2 + up) * 512);
+            for (int up = 0; up < 2; ++up) {
+#if DC_EXP == 2
+                f.v[h][t][up] = u32x4b{(unsigned)lane, 1u, 2u, (unsigned)kc};
+#else
+                f.v[h][t][up] = *reinterpret_cast<const u32x4b*>(wp + (kc * 2 + up) * 512);
+#endif
+            }
         }
     }
 }
@@ -186,6 +192,10 @@ __device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT][2], const float* _
         }
     }
 }
+// bf16 weights: v_mfma_f32_16x16x32_bf16 on TWO k-steps at once (round 4; the K = 16 instruction issues at half the rate and this loop
+// had 64 of them per stage in dependent lo -> hi pairs).  A lane's eight k of a pair (u, u + 1) are its four of u and its four of
+// u + 1 on both operands -- the packed fragment f.v[h][t][u >> 1] already holds exactly those eight --, so the pair is one MFMA per
+// term: 32 per stage, consecutive ones on different accumulators.
 __device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT][1], const float* __restrict__ ap, const BFrag<uint16_t>& f, int half) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -194,15 +204,22 @@ __device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT][1], const float* _
 #pragma unroll
         for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(ap + kc * 64 + u * 16);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const Split4 x = split4(a[u].x, a[u].y, a[u].z, a[u].w);
+        for (int up = 0; up < 2; ++up) {
+            const Split4 x0 = split4(a[2 * up].x, a[2 * up].y, a[2 * up].z, a[2 * up].w);
+            const Split4 x1 = split4(a[2 * up + 1].x, a[2 * up + 1].y, a[2 * up + 1].z, a[2 * up + 1].w);
+            const bf16x8 xh = cat8(x0.hi, x1.hi), xl = cat8(x0.lo, x1.lo);
+#if DC_EXP == 1
 #pragma unroll
             for (int t = 0; t < DC_NT; ++t) {
-                const u32x4b wv = f.v[h][t][u >> 1];
-                const bf16x4 w = __builtin_bit_cast(bf16x4, (u & 1) ? u32x2b{wv.z, wv.w} : u32x2b{wv.x, wv.y});
-                acc[t][0] = mfma_bf16(x.lo, w, acc[t][0]);
-                acc[t][0] = mfma_bf16(x.hi, w, acc[t][0]);
+                const u32x4b xa = __builtin_bit_cast(u32x4b, xh), xb = __builtin_bit_cast(u32x4b, xl);
+                acc[t][0][0] += __uint_as_float(((xa.x ^ xb.y ^ f.v[h][t][up].x) & 0x3fffffffu) | (xa.z ^ xb.w ^ f.v[h][t][up].z) >> 8);
             }
+            continue;
+#endif
+#pragma unroll
+            for (int t = 0; t < DC_NT; ++t) acc[t][0] = mfma_bf16k32(xl, __builtin_bit_cast(bf16x8, f.v[h][t][up]), acc[t][0]);
+#pragma unroll
+            for (int t = 0; t < DC_NT; ++t) acc[t][0] = mfma_bf16k32(xh, __builtin_bit_cast(bf16x8, f.v[h][t][up]), acc[t][0]);
         }
     }
 }
@@ -210,7 +227,8 @@ __device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT][1], const float* _
 template <typename TK>
 struct Pipe {
     static constexpr int LOADS = std::is_same<typename TK::WT, float>::value ? 8 * DC_NT : 4 * DC_NT;
-    static constexpr int IL = TK::RG == 2 ? 2 * DC_IL : DC_IL;      // (8-row fp32: two 8-cycle MFMAs where the 16-row form has one of 32)
+    // MFMAs between two prefetch loads: 8-row fp32 has two 8-cycle MFMAs where the 16-row form has one of 32; bf16 has 8 * DC_NT per half stage
+    static constexpr int IL = !std::is_same<typename TK::WT, float>::value ? DC_IL / 2 : (TK::RG == 2 ? 2 * DC_IL : DC_IL);
 };
 
 // D[16][256] = act(A[16][256] . W[n][k]^T + bias).  A in LDS.  TO_GLOBAL: D is row-major global with row stride
