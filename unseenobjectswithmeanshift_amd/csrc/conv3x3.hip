@@ -52,11 +52,25 @@ __global__ __launch_bounds__(C3_W * 64) void conv3x3_c64_kernel(const float* __r
     const int lj = lane & 15, lq = lane >> 4;
     const int b = blockIdx.y;
     const int o0 = NCHW ? (int)blockIdx.z * C3_C : 0;          // first output channel of this workgroup
-    for (int i = tid; i < C3_C * (C3_K / 4); i += C3_W * 64) {
-        const int n = i / (C3_K / 4), c4 = i - n * (C3_K / 4);
-        const float4 wv = *reinterpret_cast<const float4*>(w + (int64_t)(o0 + n) * C3_K + c4 * 4);
-        if constexpr (BF) *reinterpret_cast<bf16x4*>(wlb + n * C3_LDB + c4 * 4) = pack4(wv.x, wv.y, wv.z, wv.w);
-        else *reinterpret_cast<float4*>(wl + n * C3_LD + c4 * 4) = wv;
+    {
+        // the weight copy: all of a thread's loads are requested before the first is stored (a rolled loop exposes one L2 round trip
+        // per iteration -- nine of them in front of a kernel whose tiles take a few microseconds each)
+        constexpr int PER = C3_C * (C3_K / 4) / (C3_W * 64);       // 9 float4 per thread
+        static_assert(PER * C3_W * 64 == C3_C * (C3_K / 4), "the weight copy assumes an exact split");
+        float4 wv[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = tid + k * (C3_W * 64);
+            const int n = i / (C3_K / 4), c4 = i - n * (C3_K / 4);
+            wv[k] = *reinterpret_cast<const float4*>(w + (int64_t)(o0 + n) * C3_K + c4 * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = tid + k * (C3_W * 64);
+            const int n = i / (C3_K / 4), c4 = i - n * (C3_K / 4);
+            if constexpr (BF) *reinterpret_cast<bf16x4*>(wlb + n * C3_LDB + c4 * 4) = pack4(wv[k].x, wv[k].y, wv[k].z, wv[k].w);
+            else *reinterpret_cast<float4*>(wl + n * C3_LD + c4 * 4) = wv[k];
+        }
     }
     __syncthreads();
 
@@ -435,6 +449,9 @@ static int conv3x3_c64_launch(const float* in, const float* w_tap_major, float* 
     int per_image = max(1, 256 / B);
     per_image = min(per_image, cdiv(units, C3_W));
     if (bf) {
+        // (one load per input ROW with lane shifts for dx = -1 / +1, as the split kernel does, was measured for this form too: bitwise the
+        // same result, 55 us either way at B = 8, 120 x 160 -- the per-tile chain load -> split -> MFMA does not overlap with itself at
+        // 2.3 tiles per wave, whichever way the operands arrive)
         const size_t lds = sizeof(unsigned short) * (size_t)C3_C * C3_LDB + sizeof(float) * (size_t)C3_W * C3_C * 2;
         MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_kernel<false, true>, lds));
         hipLaunchKernelGGL((conv3x3_c64_kernel<false, true>), dim3(per_image, B), dim3(C3_W * 64), lds, st, in, w_tap_major, nullptr, out, stats, H,
