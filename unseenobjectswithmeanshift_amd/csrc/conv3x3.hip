@@ -40,11 +40,14 @@ constexpr int C3_LDB = C3_K + 16;        // LDS row stride of the bf16 weight co
 // activations become hi + lo bf16 operands when they are used (x = hi + lo up to 2^-17 |x|) and v_mfma_f32_16x16x32_bf16 takes
 // half a tap's channels at once: 16 MFMAs of 16 cycles per tap instead of 64 of 32 -- the kernel is then a stream over the map.
 // K order of a tap: channel kh*32 + lq*8 + i on both operands.
-template <bool NCHW, bool BF = false>
-__global__ __launch_bounds__(C3_W * 64) void conv3x3_c64_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                                                                const float* __restrict__ bias, float* __restrict__ out,
-                                                                double* __restrict__ stats, int H, int W) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];   // [64][C3_LD] (BF: [64][C3_LDB] bf16), then the moment scratch [C3_W][64][2]
+// PB: 16-pixel blocks per wave (a tile is 16 PB consecutive pixels of an image row) -- with PB = 2 a weight fragment read from LDS
+// feeds two MFMAs and a tap's loads hide behind twice the matrix work; WV: waves per workgroup (PB = 2 needs the registers of two
+// waves per SIMD: WV = 8).
+template <bool NCHW, bool BF = false, int PB = 1, int WV = C3_W>
+__global__ __launch_bounds__(WV * 64) void conv3x3_c64_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ out,
+                                                              double* __restrict__ stats, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [64][C3_LD] (BF: [64][C3_LDB] bf16), then the moment scratch [WV][64][2]
     unsigned short* wlb = reinterpret_cast<unsigned short*>(wl);
     float* msc = BF ? wl + C3_C * C3_LDB / 2 : wl + C3_C * C3_LD;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -55,18 +58,18 @@ __global__ __launch_bounds__(C3_W * 64) void conv3x3_c64_kernel(const float* __r
     {
         // the weight copy: all of a thread's loads are requested before the first is stored (a rolled loop exposes one L2 round trip
         // per iteration -- nine of them in front of a kernel whose tiles take a few microseconds each)
-        constexpr int PER = C3_C * (C3_K / 4) / (C3_W * 64);       // 9 float4 per thread
-        static_assert(PER * C3_W * 64 == C3_C * (C3_K / 4), "the weight copy assumes an exact split");
+        constexpr int PER = C3_C * (C3_K / 4) / (WV * 64);         // 9 (18) float4 per thread
+        static_assert(PER * WV * 64 == C3_C * (C3_K / 4), "the weight copy assumes an exact split");
         float4 wv[PER];
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const int i = tid + k * (C3_W * 64);
+            const int i = tid + k * (WV * 64);
             const int n = i / (C3_K / 4), c4 = i - n * (C3_K / 4);
             wv[k] = *reinterpret_cast<const float4*>(w + (int64_t)(o0 + n) * C3_K + c4 * 4);
         }
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const int i = tid + k * (C3_W * 64);
+            const int i = tid + k * (WV * 64);
             const int n = i / (C3_K / 4), c4 = i - n * (C3_K / 4);
             if constexpr (BF) *reinterpret_cast<bf16x4*>(wlb + n * C3_LDB + c4 * 4) = pack4(wv[k].x, wv[k].y, wv[k].z, wv[k].w);
             else *reinterpret_cast<float4*>(wl + n * C3_LD + c4 * 4) = wv[k];
@@ -74,9 +77,9 @@ __global__ __launch_bounds__(C3_W * 64) void conv3x3_c64_kernel(const float* __r
     }
     __syncthreads();
 
-    const int xt = (W + 15) / 16;                    // 16-pixel tiles per image row
+    const int xt = (W + 16 * PB - 1) / (16 * PB);    // tiles per image row
     const int units = xt * H;                        // of this image
-    const int slots = gridDim.x * C3_W;
+    const int slots = gridDim.x * WV;
     const int full_rounds = units / slots;
     const int left = units - full_rounds * slots;
     const int left_slot = (wave >> 2) * ((int)gridDim.x * 4) + (int)blockIdx.x * 4 + (wave & 3);
@@ -96,39 +99,56 @@ __global__ __launch_bounds__(C3_W * 64) void conv3x3_c64_kernel(const float* __r
     const float* wp = wl + lj * C3_LD + lq * 4;
 
     for (int it = 0; it < mine; ++it) {
-        const int u = (it < full_rounds) ? it * slots + (int)blockIdx.x * C3_W + wave : full_rounds * slots + left_slot;
-        const int y = u / xt, x0 = (u - y * xt) * 16;
-        const int px = x0 + lj;
-        // B operand of tap t: channels ks*16 + lq*4 .. +3 (ks = 0..3) of pixel (y + t/3 - 1, px + t%3 - 1), zeros outside
-        auto load_tap = [&](int t, float4 (&f)[4]) {
-            const int yy = y + t / 3 - 1, xx = px + t % 3 - 1;
-            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-            // (BF: f[2 kh + h] = channels kh*32 + lq*8 + 4 h .. + 3)
-            const float* p = ib + ((int64_t)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)) * C3_C + (BF ? lq * 8 : lq * 4);
+        const int u = (it < full_rounds) ? it * slots + (int)blockIdx.x * WV + wave : full_rounds * slots + left_slot;
+        const int y = u / xt, x0 = (u - y * xt) * (16 * PB);
+        // B operand of tap t, pixel block pb: channels ks*16 + lq*4 .. +3 (ks = 0..3) of pixel (y + t/3 - 1, x0 + 16 pb + lj + t%3 - 1),
+        // zeros outside
+        auto load_tap = [&](int t, float4 (&f)[PB][4]) {
+            const int yy = y + t / 3 - 1;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const float4 v = *reinterpret_cast<const float4*>(p + (BF ? (ks >> 1) * 32 + (ks & 1) * 4 : ks * 16));
-                f[ks] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int pb = 0; pb < PB; ++pb) {
+                const int xx = x0 + pb * 16 + lj + t % 3 - 1;
+                const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+                // (BF: f[2 kh + h] = channels kh*32 + lq*8 + 4 h .. + 3)
+                const float* p = ib + ((int64_t)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)) * C3_C + (BF ? lq * 8 : lq * 4);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const float4 v = *reinterpret_cast<const float4*>(p + (BF ? (ks >> 1) * 32 + (ks & 1) * 4 : ks * 16));
+                    f[pb][ks] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
         };
-        f32x4 acc[4];
+        f32x4 acc[PB][4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        auto mma_tap = [&](int t, const float4 (&cur)[4]) {
+        for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[pb][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto mma_tap = [&](int t, const float4 (&cur)[PB][4]) {
             if constexpr (BF) {
 #pragma unroll
                 for (int kh = 0; kh < 2; ++kh) {
-                    const Split4 s0 = split4(cur[2 * kh].x, cur[2 * kh].y, cur[2 * kh].z, cur[2 * kh].w);
-                    const Split4 s1 = split4(cur[2 * kh + 1].x, cur[2 * kh + 1].y, cur[2 * kh + 1].z, cur[2 * kh + 1].w);
-                    const bf16x8 xh = cat8(s0.hi, s1.hi), xl = cat8(s0.lo, s1.lo);
+                    bf16x8 xh[PB], xl[PB];
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb) {
+                        const Split4 s0 = split4(cur[pb][2 * kh].x, cur[pb][2 * kh].y, cur[pb][2 * kh].z, cur[pb][2 * kh].w);
+                        const Split4 s1 = split4(cur[pb][2 * kh + 1].x, cur[pb][2 * kh + 1].y, cur[pb][2 * kh + 1].z, cur[pb][2 * kh + 1].w);
+                        xh[pb] = cat8(s0.hi, s1.hi);
+                        xl[pb] = cat8(s0.lo, s1.lo);
+                    }
                     bf16x8 a[4];
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt)
                         a[mt] = *reinterpret_cast<const bf16x8*>(wlb + (mt * 16 + lj) * C3_LDB + t * C3_C + kh * 32 + lq * 8);
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) acc[mt] = NCHW ? mfma_bf16k32(xl, a[mt], acc[mt]) : mfma_bf16k32(a[mt], xl, acc[mt]);
+                    for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) acc[mt] = NCHW ? mfma_bf16k32(xh, a[mt], acc[mt]) : mfma_bf16k32(a[mt], xh, acc[mt]);
+                        for (int mt = 0; mt < 4; ++mt)
+                            acc[pb][mt] = NCHW ? mfma_bf16k32(xl[pb], a[mt], acc[pb][mt]) : mfma_bf16k32(a[mt], xl[pb], acc[pb][mt]);
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+                            acc[pb][mt] = NCHW ? mfma_bf16k32(xh[pb], a[mt], acc[pb][mt]) : mfma_bf16k32(a[mt], xh[pb], acc[pb][mt]);
                 }
                 return;
             }
@@ -137,17 +157,14 @@ __global__ __launch_bounds__(C3_W * 64) void conv3x3_c64_kernel(const float* __r
                 float4 a[4];
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const float4*>(wp + mt * 16 * C3_LD + t * C3_C + ks * 16);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = NCHW ? mfma16(cur[ks].x, a[mt].x, acc[mt]) : mfma16(a[mt].x, cur[ks].x, acc[mt]);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = NCHW ? mfma16(cur[ks].y, a[mt].y, acc[mt]) : mfma16(a[mt].y, cur[ks].y, acc[mt]);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = NCHW ? mfma16(cur[ks].z, a[mt].z, acc[mt]) : mfma16(a[mt].z, cur[ks].z, acc[mt]);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = NCHW ? mfma16(cur[ks].w, a[mt].w, acc[mt]) : mfma16(a[mt].w, cur[ks].w, acc[mt]);
+#define C3_STEP(C)                                                                                                                 \
+    _Pragma("unroll") for (int pb = 0; pb < PB; ++pb) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                             \
+        acc[pb][mt] = NCHW ? mfma16(cur[pb][ks].C, a[mt].C, acc[pb][mt]) : mfma16(a[mt].C, cur[pb][ks].C, acc[pb][mt]);
+                C3_STEP(x) C3_STEP(y) C3_STEP(z) C3_STEP(w)
+#undef C3_STEP
             }
         };
-        float4 fa[4], fb[4];
+        float4 fa[PB][4], fb[PB][4];
         load_tap(0, fa);
 #pragma unroll 1
         for (int t = 0; t < 8; t += 2) {          // taps in pairs: two register sets, the next tap's loads ride on the current MFMAs
@@ -161,24 +178,27 @@ __global__ __launch_bounds__(C3_W * 64) void conv3x3_c64_kernel(const float* __r
             __builtin_amdgcn_sched_barrier(0);
         }
         mma_tap(8, fa);
-        if constexpr (NCHW) {
-            // lane: channel mt*16 + lj, pixels x0 + lq*4 .. +3 of row y
-            const int xs = x0 + lq * 4;
-            if (xs < W) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    *reinterpret_cast<float4*>(ob + (int64_t)(mt * 16 + lj) * H * W + (int64_t)y * W + xs) =
-                        make_float4(acc[mt][0] + bch[mt], acc[mt][1] + bch[mt], acc[mt][2] + bch[mt], acc[mt][3] + bch[mt]);
-            }
-        } else if (px < W) {
-            float* op = ob + ((int64_t)y * W + px) * C3_C + lq * 4;
+        for (int pb = 0; pb < PB; ++pb) {
+            if constexpr (NCHW) {
+                // lane: channel mt*16 + lj, pixels x0 + 16 pb + lq*4 .. +3 of row y
+                const int xs = x0 + pb * 16 + lq * 4;
+                if (xs < W) {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                *reinterpret_cast<float4*>(op + mt * 16) = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+                    for (int mt = 0; mt < 4; ++mt)
+                        *reinterpret_cast<float4*>(ob + (int64_t)(mt * 16 + lj) * H * W + (int64_t)y * W + xs) =
+                            make_float4(acc[pb][mt][0] + bch[mt], acc[pb][mt][1] + bch[mt], acc[pb][mt][2] + bch[mt], acc[pb][mt][3] + bch[mt]);
+                }
+            } else if (x0 + pb * 16 + lj < W) {
+                float* op = ob + ((int64_t)y * W + x0 + pb * 16 + lj) * C3_C + lq * 4;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    s[mt][r] += acc[mt][r];
-                    q[mt][r] += acc[mt][r] * acc[mt][r];
+                for (int mt = 0; mt < 4; ++mt) {
+                    *reinterpret_cast<float4*>(op + mt * 16) = make_float4(acc[pb][mt][0], acc[pb][mt][1], acc[pb][mt][2], acc[pb][mt][3]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        s[mt][r] += acc[pb][mt][r];
+                        q[mt][r] += acc[pb][mt][r] * acc[pb][mt][r];
+                    }
                 }
             }
         }
@@ -208,7 +228,7 @@ __global__ __launch_bounds__(C3_W * 64) void conv3x3_c64_kernel(const float* __r
         __syncthreads();
         if (tid < C3_C * 2) {
             double t = 0.0;
-            for (int wv = 0; wv < C3_W; ++wv) t += (double)msc[wv * C3_C * 2 + tid];
+            for (int wv = 0; wv < WV; ++wv) t += (double)msc[wv * C3_C * 2 + tid];
             atomicAdd(stats + (int64_t)b * C3_C * 2 + tid, t);
         }
     }
@@ -448,13 +468,31 @@ static int conv3x3_c64_launch(const float* in, const float* w_tap_major, float* 
     const int units = cdiv(W, 16) * H;
     int per_image = max(1, 256 / B);
     per_image = min(per_image, cdiv(units, C3_W));
+    // two 16-pixel blocks per wave (8 waves per workgroup) when the image rows split into 32-pixel tiles without much waste
+    // (measured at B = 8, 120 x 160: bf16 55.4 -> 49.9 us, fp32 108.8 -> 108.2: the fp32 form keeps its round-3 shape; same output bits)
+    const int wopt = opt(MSM_OPT_CONV3_WIDE);
+    const bool wide = (wopt == 1 || (wopt == MSM_OPT_AUTO && bf)) && W >= 32;
+    const int units2 = cdiv(W, 32) * H;
+    const int per_image2 = min(max(1, 256 / B), cdiv(units2, 8));
     if (bf) {
         // (one load per input ROW with lane shifts for dx = -1 / +1, as the split kernel does, was measured for this form too: bitwise the
         // same result, 55 us either way at B = 8, 120 x 160 -- the per-tile chain load -> split -> MFMA does not overlap with itself at
         // 2.3 tiles per wave, whichever way the operands arrive)
-        const size_t lds = sizeof(unsigned short) * (size_t)C3_C * C3_LDB + sizeof(float) * (size_t)C3_W * C3_C * 2;
-        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_kernel<false, true>, lds));
-        hipLaunchKernelGGL((conv3x3_c64_kernel<false, true>), dim3(per_image, B), dim3(C3_W * 64), lds, st, in, w_tap_major, nullptr, out, stats, H,
+        if (wide) {
+            const size_t lds = sizeof(unsigned short) * (size_t)C3_C * C3_LDB + sizeof(float) * (size_t)8 * C3_C * 2;
+            MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_kernel<false, true, 2, 8>, lds));
+            hipLaunchKernelGGL((conv3x3_c64_kernel<false, true, 2, 8>), dim3(per_image2, B), dim3(8 * 64), lds, st, in, w_tap_major, nullptr, out, stats,
+                               H, W);
+        } else {
+            const size_t lds = sizeof(unsigned short) * (size_t)C3_C * C3_LDB + sizeof(float) * (size_t)C3_W * C3_C * 2;
+            MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_kernel<false, true>, lds));
+            hipLaunchKernelGGL((conv3x3_c64_kernel<false, true>), dim3(per_image, B), dim3(C3_W * 64), lds, st, in, w_tap_major, nullptr, out, stats,
+                               H, W);
+        }
+    } else if (wide) {
+        const size_t lds = sizeof(float) * ((size_t)C3_C * C3_LD + (size_t)8 * C3_C * 2);
+        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_kernel<false, false, 2, 8>, lds));
+        hipLaunchKernelGGL((conv3x3_c64_kernel<false, false, 2, 8>), dim3(per_image2, B), dim3(8 * 64), lds, st, in, w_tap_major, nullptr, out, stats, H,
                            W);
     } else {
         const size_t lds = sizeof(float) * ((size_t)C3_C * C3_LD + (size_t)C3_W * C3_C * 2);
