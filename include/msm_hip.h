@@ -59,7 +59,7 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 14   /* 14: cmat_width argument of the K/V projections (separable position constants), msm_conv3x3_c64_nchw_bf16; 13: flags argument of msm_ms_select_seeds_bf16 (persistent on-chip seeding over the bf16 copy), input projections on the bf16 matrix pipe (msm_conv1x1_in_lp, msm_conv1x1_in_multi_lp); 12: head-major bf16 activations between the encoder kernels of the bf16 plan (msm_encoder_block_hm_fwd, msm_msdeform_attn_enc_lp_fwd, msm_f32_to_f16); 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
+#define MSM_ABI_VERSION 14   /* 14: cmat_width argument of the K/V projections (separable position constants), msm_conv3x3_c64_nchw_bf16, msm_encoder_prologue_hm_fwd; 13: flags argument of msm_ms_select_seeds_bf16 (persistent on-chip seeding over the bf16 copy), input projections on the bf16 matrix pipe (msm_conv1x1_in_lp, msm_conv1x1_in_multi_lp); 12: head-major bf16 activations between the encoder kernels of the bf16 plan (msm_encoder_block_hm_fwd, msm_msdeform_attn_enc_lp_fwd, msm_f32_to_f16); 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
 int msm_abi_version(void);
 
 /* Kernel-selection overrides for tools/ and tests/ (NOT read on the product path: every option defaults to
@@ -623,6 +623,15 @@ int msm_encoder_prologue_fwd(const float* raw, const double* stats, const float*
                              int n_levels, int groups, float gn_eps, const float* wstream, const float* small,
                              const float* pos, float* src_out, void* value_out, void* proj_out, int B, int S,
                              int proj_width, int value_heads, int out_bf16_hm, void* stream);
+/* The same prologue for the bf16 plan (csrc/enc_lp.hip, enc_prologue_hm_kernel): value [B][8][S][8] and the sampling record
+ * [B][8][S][36] in fp16, the two projections on the bf16 matrix pipe with hi + lo operands (132 MFMAs of 16 cycles per 16-token tile
+ * instead of 352 of 32).  wblocks: msm_encoder_prologue_hm_weight_bytes() bytes = the value_proj blocks (16 KiB) and the projection
+ * blocks (72 KiB) exactly as msm_encoder_block_hm_fwd's stream holds them ([row block][k-group][hi, lo] 1-KiB fragments, rows in the
+ * value / (head, 36) orders); small: bv [64] and bp [288] in those row orders. */
+int64_t msm_encoder_prologue_hm_weight_bytes(void);
+int msm_encoder_prologue_hm_fwd(const float* raw, const double* stats, const float* gn_params, const int32_t* level_starts, int n_levels,
+                                int groups, float gn_eps, const void* wblocks, const float* small, const float* pos, float* src_out,
+                                void* value_out, void* proj_out, int B, int S, void* stream);
 
 /* The fp32 encoder-layer tail on the bf16 matrix pipe (csrc/enc_block_split.hip): every fp32 operand is split exactly into three
  * bf16 terms and a product is the six bf16 MFMAs of weight >= 2^-18 with fp32 accumulation -- fp32-accurate results (the

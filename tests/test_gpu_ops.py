@@ -1185,6 +1185,17 @@ def test_encoder_prologue_vs_fp64():
     src, value, proj = o.encoder_prologue(raw.clone().to(DEV), st, gnp, bounds, stream, small, pos.to(DEV), pw, value_heads=8)
     s2, v2, p2 = o.encoder_prologue(raw.clone().to(DEV), st, gnp, bounds, stream, small, pos.to(DEV), pw, value_heads=8, bf16_hm=True)
     assert torch.equal(s2, src) and torch.equal(v2, value.to(torch.float16)) and torch.equal(p2, o.proj_to_head_major_f16(proj))
+    # ... and the bf16 plan's own prologue (msm_encoder_prologue_hm_fwd: the two projections on the bf16 matrix pipe with hi + lo
+    # operands): the same src bit for bit, value / record equal to the fp64 reference to fp16 storage precision
+    blocks, small_hm = o.pack_encoder_prologue_hm(wv.to(DEV), wp.to(DEV), bv.to(DEV), bp.to(DEV))
+    s3, v3, p3 = o.encoder_prologue_hm(raw.clone().to(DEV), st, gnp, bounds, blocks, small_hm, pos.to(DEV))
+    assert torch.equal(s3, src) and v3.dtype == p3.dtype == torch.float16
+    val_hm = val_ref.view(B, S, 8, 8).permute(0, 2, 1, 3)
+    proj_hm = torch.cat([proj_ref[..., :192].reshape(B, S, 8, 24), proj_ref[..., 192:].reshape(B, S, 8, 12)], -1).permute(0, 2, 1, 3)
+    closed(v3.float(), val_hm, rtol=1.5e-3, atol=1.5e-3)              # (an fp16 rounding of O(1) values: 2^-11 relative)
+    closed(p3.float(), proj_hm, rtol=1.5e-3, atol=1.5e-3)
+    # against the fp32-MFMA prologue's rounded outputs: at most one fp16 step apart
+    assert float((v3.float() - v2.float()).abs().max()) <= 4e-3 and float((p3.float() - p2.float()).abs().max()) <= 4e-3
     with pytest.raises(RuntimeError):
         o.encoder_prologue(raw.to(DEV), st, gnp, [0, 12, 60, S + 1], stream, small, pos.to(DEV), pw)
 

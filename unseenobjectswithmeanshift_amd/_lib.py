@@ -114,6 +114,8 @@ _SIGNATURES = {
     "msm_conv3x3_c64_nchw_bf16": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p]),
     "msm_encoder_prologue_stream_floats": (c_l, [c_i]),
     "msm_encoder_prologue_fwd": (c_i, [c_f, c_p, c_f, c_p, c_i, c_i, c_fl, c_f, c_f, c_f, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "msm_encoder_prologue_hm_weight_bytes": (c_l, []),
+    "msm_encoder_prologue_hm_fwd": (c_i, [c_f, c_p, c_f, c_p, c_i, c_i, c_fl, c_p, c_f, c_f, c_f, c_p, c_p, c_i, c_i, c_p]),
     "msm_label_stats": (c_i, [c_f, c_f, c_p, c_f, c_p, c_i, c_i, c_i, c_i, c_p]),
     "msm_label_image": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p]),
     "msm_crop_resize": (c_i, [c_f, c_f, c_f, c_p, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p]),

@@ -589,6 +589,156 @@ __global__ __launch_bounds__(256) void f32_to_f16_kernel(const float4* __restric
     }
 }
 
+// ---- the encoder prologue of this plan (round 4) ----------------------------------------------------------------------------------
+// What precedes the first deformable-attention layer (msdeformattn.py:326-329 GroupNorm of the input projections, :60-75 level
+// concatenation, layer 0's value_proj / sampling_offsets / attention_weights linears, ops/modules/ms_deform_attn.py:95-104) with the
+// two projections as in enc_block_hm_kernel's tail: hi + lo bf16 operands, three K = 32 MFMAs per product, value and sampling record
+// written head-major in fp16.  The fp32 prologue (enc_block.hip) spends 352 fp32 MFMAs of 32 cycles on a 16-token tile -- with 3150
+// tiles on 1024 SIMDs that is four tiles = 21 us of matrix time per SIMD before anything else; here a tile is 132 MFMAs of 16 cycles.
+// Weight-stationary like that kernel: value (16 KiB) and projection (72 KiB) blocks are copied into LDS once per workgroup (all of a
+// thread's loads requested before its first store), each of the 16 waves runs one tile, one barrier.
+constexpr int PH_W = 16;
+constexpr int PH_NIMG = 4;             // images a workgroup's 256 tokens may touch (S >= 86)
+constexpr int PH_MAXL = 4;
+constexpr int PH_WBYTES = 16384 + 18 * 4096;
+struct HmLevels {
+    int n;
+    int start[PH_MAXL + 1];
+};
+
+__global__ __launch_bounds__(PH_W * 64) void enc_prologue_hm_kernel(const float* __restrict__ raw, const double* __restrict__ stats,
+                                                                    const float* __restrict__ gnp, HmLevels lv, int groups, float gn_eps,
+                                                                    const u32x4* __restrict__ wblocks, const float* __restrict__ small,
+                                                                    const float* __restrict__ pos, float* __restrict__ src_out,
+                                                                    unsigned short* __restrict__ value_out, unsigned short* __restrict__ proj_out,
+                                                                    int M, int S, int B) {
+    extern __shared__ __attribute__((aligned(16))) char phl[];    // value + projection blocks | GroupNorm tables | bv, bp
+    float* gt = reinterpret_cast<float*>(phl + PH_WBYTES);        // [PH_NIMG images][levels][3][64]: mean, rstd*gamma, beta
+    float* sm = gt + PH_NIMG * PH_MAXL * 3 * EH_C;                // bv [64] (value row order), bp [288] ((head, 36) row order)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    // this tile's tokens first: their latency hides behind the weight copy and the tables
+    const int tile = (int)blockIdx.x * PH_W + wave;
+    const int tok = tile * 16 + lj;
+    const bool tok_ok = tok < M;
+    const int tk = tok_ok ? tok : M - 1;
+    float x[4][4];
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) {
+        const float4 r = *reinterpret_cast<const float4*>(raw + (int64_t)tk * EH_C + fb * 16 + lq * 4);
+        x[fb][0] = r.x; x[fb][1] = r.y; x[fb][2] = r.z; x[fb][3] = r.w;
+    }
+    {
+        constexpr int N16 = PH_WBYTES / 16, PER = (N16 + PH_W * 64 - 1) / (PH_W * 64);      // 5632 pieces, 6 per thread (the last partly)
+        u32x4 wv[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) wv[k] = wblocks[min(tid + k * (PH_W * 64), N16 - 1)];
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            if (tid + k * (PH_W * 64) < N16) reinterpret_cast<u32x4*>(phl)[tid + k * (PH_W * 64)] = wv[k];
+    }
+    for (int i = tid; i < EH_C + EH_PROJ; i += PH_W * 64) sm[i] = small[i];
+    const int b0 = (int)(((int64_t)blockIdx.x * PH_W * 16) / S);
+    const int cpg = EH_C / groups;
+    for (int i = tid; i < PH_NIMG * lv.n * EH_C; i += PH_W * 64) {
+        const int c = i % EH_C, l = (i / EH_C) % lv.n, bi = b0 + i / (EH_C * lv.n);
+        float mean = 0.f, a = 0.f, be = 0.f;
+        if (bi < B) {
+            const int g0 = (c / cpg) * cpg;
+            double sum = 0.0, sq = 0.0;
+            for (int k = 0; k < cpg; ++k) {
+                const double* d = stats + (((int64_t)l * B + bi) * EH_C + g0 + k) * 2;
+                sum += d[0];
+                sq += d[1];
+            }
+            const double cnt = (double)cpg * (double)(lv.start[l + 1] - lv.start[l]);
+            const double mu = sum / cnt;
+            double var = sq / cnt - mu * mu;
+            if (var < 0.0) var = 0.0;
+            mean = (float)mu;
+            a = (float)(1.0 / sqrt(var + (double)gn_eps)) * gnp[(l * 2 + 0) * EH_C + c];
+            be = gnp[(l * 2 + 1) * EH_C + c];
+        }
+        float* t = gt + ((i / (EH_C * lv.n)) * PH_MAXL + l) * 3 * EH_C;
+        t[c] = mean;
+        t[EH_C + c] = a;
+        t[2 * EH_C + c] = be;
+    }
+    const int img = tk / S, tpos = tk - img * S;
+    int lvl = 0;
+#pragma unroll
+    for (int l = 1; l < PH_MAXL; ++l) lvl += (l < lv.n && tpos >= lv.start[l]) ? 1 : 0;
+    __syncthreads();               // the only barrier: weights, tables and biases are in LDS
+    if (tile * 16 >= M) return;    // wave-uniform
+    {
+        const float* t = gt + ((img - b0) * PH_MAXL + lvl) * 3 * EH_C;
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) {
+            const int c = fb * 16 + lq * 4;
+            const float4 mn = *reinterpret_cast<const float4*>(t + c);
+            const float4 sc = *reinterpret_cast<const float4*>(t + EH_C + c);
+            const float4 sh = *reinterpret_cast<const float4*>(t + 2 * EH_C + c);
+            x[fb][0] = (x[fb][0] - mn.x) * sc.x + sh.x;
+            x[fb][1] = (x[fb][1] - mn.y) * sc.y + sh.y;
+            x[fb][2] = (x[fb][2] - mn.z) * sc.z + sh.z;
+            x[fb][3] = (x[fb][3] - mn.w) * sc.w + sh.w;
+        }
+    }
+    store_src(src_out, x, tok, tok_ok, lq);
+    // query = src + pos (msdeformattn.py:124): requested now, added after the value projection
+    float4 pp[4];
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) pp[fb] = *reinterpret_cast<const float4*>(pos + (int64_t)tpos * EH_C + fb * 16 + lq * 4);
+    bf16x8 xh[2], xl[2];
+    split_L(x, xh, xl);
+    {
+        // value_proj: row blocks 2j, 2j + 1 of lane (token, lq) are dims 0-3 / 4-7 of head 4j + lq (one 16-byte store per j)
+        f32x4 d[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const float4 b = *reinterpret_cast<const float4*>(sm + rb * 16 + lq * 4);
+            d[rb] = f32x4{b.x, b.y, b.z, b.w};
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const char* blk = phl + ((rb * 2 + g) * 2) * 1024;
+                const bf16x8 wh = ldfrag(blk, lane), wl = ldfrag(blk + 1024, lane);
+                d[rb] = mfma_bf16k32(wl, xh[g], d[rb]);
+                d[rb] = mfma_bf16k32(wh, xl[g], d[rb]);
+                d[rb] = mfma_bf16k32(wh, xh[g], d[rb]);
+            }
+        if (tok_ok) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                *reinterpret_cast<u32x4*>(value_out + (((int64_t)img * 8 + 4 * j + lq) * S + tpos) * 8) = pack8h(d[2 * j], d[2 * j + 1]);
+        }
+    }
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) {
+        x[fb][0] += pp[fb].x; x[fb][1] += pp[fb].y; x[fb][2] += pp[fb].z; x[fb][3] += pp[fb].w;
+    }
+    split_L(x, xh, xl);
+    // [sampling_offsets | attention_weights](src + pos): row 16 rb + 4 lq + r = entry (head, c) = divmod(row, 36) of the record
+#pragma unroll 2
+    for (int rb = 0; rb < EH_PROJ / 16; ++rb) {
+        const float4 b = *reinterpret_cast<const float4*>(sm + EH_C + rb * 16 + lq * 4);
+        f32x4 d = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const char* blk = phl + 16384 + ((rb * 2 + g) * 2) * 1024;
+            const bf16x8 wh = ldfrag(blk, lane), wl = ldfrag(blk + 1024, lane);
+            d = mfma_bf16k32(wl, xh[g], d);
+            d = mfma_bf16k32(wh, xl[g], d);
+            d = mfma_bf16k32(wh, xh[g], d);
+        }
+        const int idx = rb * 16 + lq * 4, head = idx / 36, c = idx - head * 36;
+        if (tok_ok) *reinterpret_cast<u32x2b*>(proj_out + (((int64_t)img * 8 + head) * S + tpos) * 36 + c) = pack4h(d[0], d[1], d[2], d[3]);
+    }
+}
+
 }  // namespace msm
 
 using namespace msm;
@@ -671,6 +821,34 @@ extern "C" int msm_f32_to_f16(const float* in, void* out, int64_t n, void* strea
     const int64_t n8 = n / 8;
     const int grid = (int)(n8 / 256 + 1 > 4096 ? 4096 : n8 / 256 + 1);
     hipLaunchKernelGGL(f32_to_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4*)in, (u32x4*)out, n8);
+    MSM_CHECK_LAUNCH(who);
+    return MSM_OK;
+}
+
+extern "C" int64_t msm_encoder_prologue_hm_weight_bytes(void) { return PH_WBYTES; }
+
+extern "C" int msm_encoder_prologue_hm_fwd(const float* raw, const double* stats, const float* gn_params, const int32_t* level_starts,
+                                           int n_levels, int groups, float gn_eps, const void* wblocks, const float* small, const float* pos,
+                                           float* src_out, void* value_out, void* proj_out, int B, int S, void* stream) {
+    const char* who = "msm_encoder_prologue_hm_fwd";
+    MSM_REQUIRE(raw && stats && gn_params && level_starts && wblocks && small && pos && src_out && value_out && proj_out, "%s: null pointer", who);
+    MSM_REQUIRE(n_levels >= 1 && n_levels <= PH_MAXL, "%s: n_levels=%d outside [1, %d]", who, n_levels, PH_MAXL);
+    MSM_REQUIRE(B > 0 && S >= 86 && (int64_t)B * S < ((int64_t)1 << 31), "%s: need B > 0 and at least 86 tokens per image (S=%d)", who, S);
+    MSM_REQUIRE(groups > 0 && EH_C % groups == 0, "%s: groups=%d must divide 64", who, groups);
+    MSM_REQUIRE(((((uintptr_t)raw) | ((uintptr_t)wblocks) | ((uintptr_t)small) | ((uintptr_t)src_out) | ((uintptr_t)value_out) |
+                  ((uintptr_t)proj_out) | ((uintptr_t)pos) | ((uintptr_t)gn_params)) & 15) == 0 && (((uintptr_t)stats) & 7) == 0,
+                "%s: pointers must be 16-byte aligned", who);
+    HmLevels lv;
+    lv.n = n_levels;
+    for (int l = 0; l <= PH_MAXL; ++l) lv.start[l] = level_starts[l < n_levels ? l : n_levels];
+    MSM_REQUIRE(lv.start[0] == 0 && lv.start[n_levels] == S, "%s: level_starts must run from 0 to S", who);
+    for (int l = 0; l < n_levels; ++l) MSM_REQUIRE(lv.start[l + 1] > lv.start[l], "%s: level_starts must increase", who);
+    const int M = B * S;
+    const size_t lds = (size_t)PH_WBYTES + sizeof(float) * (size_t)(PH_NIMG * PH_MAXL * 3 * EH_C + EH_C + EH_PROJ);
+    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)enc_prologue_hm_kernel, lds));
+    hipLaunchKernelGGL(enc_prologue_hm_kernel, dim3(cdiv(cdiv(M, 16), PH_W)), dim3(PH_W * 64), lds, (hipStream_t)stream, raw, stats, gn_params, lv,
+                       groups, gn_eps, reinterpret_cast<const u32x4*>(wblocks), small, pos, src_out, (unsigned short*)value_out,
+                       (unsigned short*)proj_out, M, S, B);
     MSM_CHECK_LAUNCH(who);
     return MSM_OK;
 }

@@ -917,6 +917,7 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
         # tensors of round 3).  False: the round-3 kernels (msm_encoder_block_lp_fwd + the fp32 gather)
         self.hm_activations = True
         self.lp_input_proj = True           # bf16 plan: the FPN lateral on the bf16 matrix pipe (hi + lo operands, fp32 results; 66 -> 50 us)
+        self.lp_prologue = True             # bf16 plan: the prologue's projections on the bf16 matrix pipe (enc_prologue_hm_kernel)
 
     def _w3(self):
         """layer_1's 3x3 weight in the implicit-GEMM order (Cout, 3*3*Cin), cached per parameter version."""
@@ -1038,7 +1039,10 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
             wp, bp = a0._proj_weights()
             stream = ops.pack_encoder_prologue(a0.value_proj.weight, wp)
             small = torch.cat([a0.value_proj.bias, bp]).contiguous()
-            self._front = (key, wpk, gnp, stream, small, wp.shape[0])
+            # the bf16 plan's prologue (hi + lo bf16 fragment blocks): packed when that plan's geometry holds
+            hm = ops.pack_encoder_prologue_hm(a0.value_proj.weight, wp, a0.value_proj.bias, bp) \
+                if (C == 64 and tuple(wp.shape) == (288, 64) and a0.n_heads == 8) else None
+            self._front = (key, wpk, gnp, stream, small, wp.shape[0], hm)
         return self._front[1:]
 
     def _encode(self, features):
@@ -1061,7 +1065,7 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
         if front:
             # input projections straight into the concatenated token buffer with their GroupNorm moments as a
             # by-product, then ONE prologue pass: GroupNorm, layer 0's value projection and sampling projections
-            wpk, gnp, pstream, psmall, pw = self._packed_front(dev)
+            wpk, gnp, pstream, psmall, pw, phm = self._packed_front(dev)
             src = torch.empty((B, S_tok, C), device=dev, dtype=torch.float32)
             stats = torch.zeros((len(levels) + 2, B, C, 2), device=dev, dtype=torch.float64)      # + the two FPN GroupNorms
             fpn_stats = (stats[len(levels)], stats[len(levels) + 1])
@@ -1073,9 +1077,14 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
             for h, w in shapes:
                 bounds.append(bounds[-1] + h * w)
             fuse0 = self._use_fused_msda(dev)
-            src, value, proj = ops.encoder_prologue(src, stats[:len(levels)], gnp, bounds, pstream, psmall[:64] if fuse0 else psmall, lvl_pos,
-                                                    0 if fuse0 else pw, groups=gns[0].num_groups, eps=gns[0].eps, value_heads=a0.n_heads,
-                                                    bf16_hm=self._use_hm())
+            if self._use_hm() and phm is not None and self.lp_prologue:
+                # the bf16 plan: the two projections on the bf16 matrix pipe (csrc/enc_lp.hip, enc_prologue_hm_kernel)
+                src, value, proj = ops.encoder_prologue_hm(src, stats[:len(levels)], gnp, bounds, phm[0], phm[1], lvl_pos,
+                                                           groups=gns[0].num_groups, eps=gns[0].eps)
+            else:
+                src, value, proj = ops.encoder_prologue(src, stats[:len(levels)], gnp, bounds, pstream, psmall[:64] if fuse0 else psmall, lvl_pos,
+                                                        0 if fuse0 else pw, groups=gns[0].num_groups, eps=gns[0].eps, value_heads=a0.n_heads,
+                                                        bf16_hm=self._use_hm())
         else:
             toks = []
             for idx, x in enumerate(levels):

@@ -1298,6 +1298,41 @@ def pack_encoder_block_hm(wo, w1, w2, wv=None, wp=None):
     return out
 
 
+def pack_encoder_prologue_hm(wv, wp, bv, bp):
+    """Layer 0's value_proj (64, 64) and [sampling_offsets | attention_weights] (288, 64) as the weight blocks and bias vector of
+    msm_encoder_prologue_hm_fwd: the blocks of pack_encoder_block_hm, value first.  Returns (int16 blocks, float32 small)."""
+    dev = wv.device
+    if tuple(wv.shape) != (64, 64) or tuple(wp.shape) != (288, 64):
+        raise RuntimeError("pack_encoder_prologue_hm: value_proj (64, 64) and a (288, 64) sampling projection")
+    kL = _korder_L(64, dev)
+
+    def pair_hl(w):                                           # (R, 64) -> [rb][G][h, l][512]
+        h, l = _hl(w)
+        return torch.stack([_frag_blocks(h, kL), _frag_blocks(l, kL)], 2).reshape(-1)
+
+    blocks = torch.cat([pair_hl(wv[_value_row_perm(dev)]), pair_hl(wp[_proj_row_perm(8, 12, dev)])]).to(torch.bfloat16).contiguous().view(torch.int16)
+    assert blocks.numel() * 2 == lib().msm_encoder_prologue_hm_weight_bytes()
+    small = torch.cat([bv[_value_row_perm(dev)], bp[_proj_row_perm(8, 12, dev)]]).contiguous()
+    return blocks, small
+
+
+def encoder_prologue_hm(raw, stats, gn_params, level_starts, blocks, small, pos, *, groups=32, eps=1e-5):
+    """encoder_prologue for the bf16 plan with its projections on the bf16 matrix pipe (msm_encoder_prologue_hm_fwd): normalises raw
+    IN PLACE (-> src), returns (src, value (B,8,S,8) fp16, proj (B,8,S,36) fp16).  blocks / small: pack_encoder_prologue_hm."""
+    _c(raw, "raw"), _c(stats, "stats", torch.float64), _c(gn_params, "gn_params"), _c(blocks, "blocks", torch.int16), _c(small, "small"), _c(pos, "pos")
+    B, S, C = raw.shape
+    L = len(level_starts) - 1
+    if C != 64 or tuple(stats.shape) != (L, B, 64, 2) or tuple(gn_params.shape) != (L, 2, 64) or tuple(pos.shape) != (S, 64) or small.numel() != 352:
+        raise RuntimeError("encoder_prologue_hm: inconsistent shapes")
+    value = torch.empty((B, 8, S, 8), device=raw.device, dtype=torch.float16)
+    proj = torch.empty((B, 8, S, 36), device=raw.device, dtype=torch.float16)
+    ls = (ctypes.c_int32 * (L + 1))(*[int(v) for v in level_starts])
+    rc = lib().msm_encoder_prologue_hm_fwd(_p(raw), _p(stats), _p(gn_params), ctypes.cast(ls, ctypes.c_void_p), L, int(groups), float(eps),
+                                           _p(blocks), _p(small), _p(pos), _p(raw), _p(value), _p(proj), B, S, _stream())
+    check(rc, "msm_encoder_prologue_hm_fwd")
+    return raw, value, proj
+
+
 def pack_encoder_block_hm_small(bo, g1, be1, b1, b2, g2, be2, bv=None, bp=None):
     """The fp32 parameter vector of msm_encoder_block_hm_fwd (value_proj / projection biases in the packed row orders, linear1
     bias zero padded to whole stages)."""
