@@ -255,6 +255,19 @@ def timed(fn, reps, sync=True):
     return (time.perf_counter() - t0) / reps
 
 
+def timed_median(fn, reps):
+    """Median wall time of `reps` individually synchronised calls (a call with its own host synchronisation inside, like the mean-shift
+    driver: one slow call -- an allocator refill, a retried launch -- should not carry the figure)."""
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2]
+
+
 def event_ms(fn, reps=5, warm=2):
     for _ in range(warm):
         fn()
@@ -730,7 +743,7 @@ def extra_configs(dev, args):
     for mode in ("bf16", "f32_split", "f32"):
         for _ in range(2):
             ms.mean_shift_smart_init(Xd, 20.0, S, iters, first_index=7, precision=mode)
-        t_ms = timed(lambda: ms.mean_shift_smart_init(Xd, 20.0, S, iters, first_index=7, precision=mode), 3)
+        t_ms = timed_median(lambda: ms.mean_shift_smart_init(Xd, 20.0, S, iters, first_index=7, precision=mode), 5)
         t_seed = event_ms(lambda: ops.ms_select_seeds(Xd, S, 7, xb=xb if mode == "bf16" else None), reps=3, warm=1)
         t_seed_stepwise = event_ms(lambda: ops.ms_select_seeds(Xd, S, 7, xb=xb, stepwise=True), reps=3, warm=1) if mode == "bf16" else None
         t_hill = event_ms(lambda: ops.ms_hill_climb(Xd, seeds, 20.0, iters, precision=mode, xb=xb if mode == "bf16" else None), reps=3, warm=1)
