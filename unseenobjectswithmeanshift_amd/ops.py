@@ -153,14 +153,15 @@ def conv1x1_in(x, w_packed, bias=None, *, out=None, stats=None, stats_cleared=Fa
 
 def conv1x1_in_multi(xs, ws_packed, biases, out, stats, stats_cleared=False, lp=False):
     """conv1x1_in for up to four levels in one launch (``lp``: ws_packed from pack_conv_in_weight_lp, the bf16 matrix pipe).  xs: list of (B, Cin_l, H_l, W_l) NCHW maps (deepest Cin first),
-    ws_packed / biases: per level (a bias may be None), out: (B, sum H_l*W_l, 64) contiguous token buffer (level l fills its
-    token range), stats: (L, B, 64, 2) float64 moments (accumulated into when ``stats_cleared``)."""
+    ws_packed / biases: per level (a bias may be None), out: (B, sum H_l*W_l, 64) token buffer or a token-range view of a larger
+    one (level l fills its token range), stats: (L, B, 64, 2) float64 moments (accumulated into when ``stats_cleared``)."""
     L = len(xs)
     B = xs[0].shape[0]
     S = sum(x.shape[2] * x.shape[3] for x in xs)
-    _c(out, "out"), _c(stats, "stats", torch.float64)
-    if tuple(out.shape) != (B, S, 64) or tuple(stats.shape) != (L, B, 64, 2):
-        raise RuntimeError("conv1x1_in_multi: out must be (B, sum HW, 64) and stats (L, B, 64, 2)")
+    _chk(out, "out"), _c(stats, "stats", torch.float64)
+    if tuple(out.shape) != (B, S, 64) or tuple(stats.shape) != (L, B, 64, 2) or out.stride(2) != 1 or out.stride(1) != 64 \
+            or (B > 1 and out.stride(0) < S * 64):
+        raise RuntimeError("conv1x1_in_multi: out must be (B, sum HW, 64) with strides (>= sum HW * 64, 64, 1) and stats (L, B, 64, 2)")
     for x, w, b in zip(xs, ws_packed, biases):
         _c(x, "x"), _c(w, "w_packed", torch.bfloat16 if lp else torch.float32), _c(b, "bias")
         if x.shape[0] != B or w.numel() != (128 if lp else 64) * x.shape[1]:
@@ -172,8 +173,8 @@ def conv1x1_in_multi(xs, ws_packed, biases, out, stats, stats_cleared=False, lp=
     cin, hw = ia(*[x.shape[1] for x in xs]), ia(*[x.shape[2] * x.shape[3] for x in xs])
     fn = lib().msm_conv1x1_in_multi_lp if lp else lib().msm_conv1x1_in_multi_f32
     rc = fn(L, ctypes.cast(xa, ctypes.c_void_p), ctypes.cast(wa, ctypes.c_void_p), ctypes.cast(ba, ctypes.c_void_p),
-            ctypes.cast(cin, ctypes.c_void_p), ctypes.cast(hw, ctypes.c_void_p), _p(out), S * 64, _p(stats), 1 if stats_cleared else 0, B,
-            _stream())
+            ctypes.cast(cin, ctypes.c_void_p), ctypes.cast(hw, ctypes.c_void_p), _p(out), out.stride(0) if B > 1 else S * 64, _p(stats),
+            1 if stats_cleared else 0, B, _stream())
     check(rc, "msm_conv1x1_in_multi_lp" if lp else "msm_conv1x1_in_multi_f32")
     return out, stats
 
