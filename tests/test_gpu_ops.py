@@ -759,11 +759,12 @@ def test_mean_shift_seeding_bf16_streams_the_copy():
     assert torch.equal(i1, i2) and torch.equal(s1, s2)
 
 
-@pytest.mark.parametrize("n", [400000, 1000000, 1000003])
+@pytest.mark.parametrize("n", [400000, 1000000, 1000003, 917510])
 def test_mean_shift_seeding_bf16_persistent_equals_stepwise(n):
     """The one-launch seeding over the bf16 copy (rows in VGPRs, in LDS, and -- beyond 917 504 rows -- a tail streamed per step)
     selects the SAME indices as one launch per step: every row's arithmetic is shared, only its home differs.  400 000 rows:
-    all on chip (tiles past the end re-cover the last rows); 1 000 000: an 82 496-row tail; 1 000 003: a ragged last tile."""
+    all on chip (tiles past the end re-cover the last rows); 1 000 000: an 82 496-row tail; 1 000 003: a ragged last tile; 917 510: six rows
+    beyond the on-chip capacity -- fewer than a tile: the host takes the one-launch-per-step kernel by itself."""
     from unseenobjectswithmeanshift_amd import synthetic as syn
     S = 60
     X, _ = syn.synth_unit_embeddings(n, 64, clusters=12, sigma=0.2, seed=9)
@@ -776,7 +777,10 @@ def test_mean_shift_seeding_bf16_persistent_equals_stepwise(n):
     assert sel_p.unique().numel() == S
     # the give-up protocol of the fp32 persistent kernel: indices -1, never a hang or fabricated rows
     _, sel_g = ops().ms_select_seeds(Xd, S, 77, xb=xb, _test_give_up=True)
-    assert bool((sel_g[1:] == -1).all())
+    if n <= 917504 or n - 917504 >= 16:
+        assert bool((sel_g[1:] == -1).all())
+    else:                                                   # no persistent launch at this size: nothing to give up
+        assert torch.equal(sel_g, sel_s)
 
 
 # ---------------------------------------------------------------------------------------------
