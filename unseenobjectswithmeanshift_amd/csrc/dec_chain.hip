@@ -423,16 +423,24 @@ __global__ __launch_bounds__(DC_THREADS) void dec_post_cross_kernel(
     const int valid = min(TK::R, rows - row0);
     // blockIdx.y picks the projection (0: q, 1: k, 2: v): the 16-row tile is MFMA-bound on ONE CU at 3.4 us per
     // 256x256 stage, so the three independent projections go to three CUs; each repeats the Wo + LN stage.
+    // gridDim.y == 2 (8-row tiles: 100 tiles x 3 parts would not fit the chip in one round): part 0 runs q THEN k, part 1 runs v.
     const int part = blockIdx.y;
-    const WT* wp = w_in + (int64_t)part * DC_E * DC_E;
+    const bool two = gridDim.y == 2;
+    const int first = two ? (part == 0 ? 0 : 2) : part;        // the projection this workgroup starts with
+    const WT* wp = w_in + (int64_t)first * DC_E * DC_E;
     BFrag<WT> f;
     attn_out_ln<TK>(o, res, wo, bo, g, b, qpos, Q, x_out, part == 0, T0, X, XP, row0, rows, eps, f, wp, 4, 0);
     // q and k share tgt + query_pos (DEC:171-175); v = tgt
-    if (part < 2)
-        gemm256<true, false, TK>(XP, wp, 4, 0, b_in + part * DC_E, false, qk_out + (int64_t)row0 * 2 * DC_E + part * DC_E, 2 * DC_E,
-                                 valid, f, nullptr, 0, 0);
-    else
+    if (first == 2) {
         gemm256<true, false, TK>(X, wp, 4, 0, b_in + 2 * DC_E, false, v_out + (int64_t)row0 * DC_E, DC_E, valid, f, nullptr, 0, 0);
+    } else if (two) {
+        gemm256<true, true, TK>(XP, wp, 4, 0, b_in, false, qk_out + (int64_t)row0 * 2 * DC_E, 2 * DC_E, valid, f, wp + DC_E * DC_E, 4, 0);
+        gemm256<true, false, TK>(XP, wp + DC_E * DC_E, 4, 0, b_in + DC_E, false, qk_out + (int64_t)row0 * 2 * DC_E + DC_E, 2 * DC_E, valid, f,
+                                 nullptr, 0, 0);
+    } else {
+        gemm256<true, false, TK>(XP, wp, 4, 0, b_in + first * DC_E, false, qk_out + (int64_t)row0 * 2 * DC_E + first * DC_E, 2 * DC_E,
+                                 valid, f, nullptr, 0, 0);
+    }
 }
 
 template <typename TK, typename WT = typename TK::WT>
@@ -621,8 +629,9 @@ static int dec_post_cross_impl(const char* who, const float* attn_out, const flo
     MSM_REQUIRE(E == DC_E, "%s: E=%d, only 256 is supported", who, E);
     MSM_REQUIRE(rows > 0 && Q > 0, "%s: bad sizes", who);
     MSM_REQUIRE(aligned16(attn_out) && aligned16(wo) && aligned16(w_in), "%s: pointers must be 16-byte aligned", who);
-    hipLaunchKernelGGL(dec_post_cross_kernel<TK>, dim3(cdiv(rows, TK::R), 3), dim3(DC_THREADS), 0, (hipStream_t)stream, attn_out, res,
-                       query_pos, wo, bo, ln_g, ln_b, w_in, b_in, x_out, qk_out, v_out, rows, Q, eps);
+    // 8-row tiles take two parts (q then k | v): three would oversubscribe the chip at 800 rows (see use_tile8)
+    hipLaunchKernelGGL(dec_post_cross_kernel<TK>, dim3(cdiv(rows, TK::R), TK::RG == 2 ? 2 : 3), dim3(DC_THREADS), 0, (hipStream_t)stream, attn_out,
+                       res, query_pos, wo, bo, ln_g, ln_b, w_in, b_in, x_out, qk_out, v_out, rows, Q, eps);
     MSM_CHECK_LAUNCH(who);
     return MSM_OK;
 }
@@ -630,7 +639,7 @@ static int dec_post_cross_impl(const char* who, const float* attn_out, const flo
 extern "C" int msm_dec_post_cross(const float* attn_out, const float* res, const float* query_pos, const float* wo,
                                   const float* bo, const float* ln_g, const float* ln_b, const float* w_in, const float* b_in,
                                   float* x_out, float* qk_out, float* v_out, int rows, int Q, int E, float eps, void* stream) {
-    if (use_tile8(rows, 3))
+    if (use_tile8(rows, 2))
         return dec_post_cross_impl<TileF8>("msm_dec_post_cross", attn_out, res, query_pos, wo, bo, ln_g, ln_b, w_in, b_in, x_out, qk_out, v_out, rows,
                                            Q, E, eps, stream);
     return dec_post_cross_impl<TileF16>("msm_dec_post_cross", attn_out, res, query_pos, wo, bo, ln_g, ln_b, w_in, b_in, x_out, qk_out, v_out, rows,
