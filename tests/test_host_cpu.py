@@ -218,3 +218,37 @@ def test_checkpoint_loader_is_tensors_only_and_says_how_to_opt_out(tmp_path):
     torch.save({"model": {"w": _NotATensor()}}, p)
     with pytest.raises(pickle.UnpicklingError, match="unsafe=True"):
         c.load_checkpoint_file(p)
+
+
+def test_round4_weight_layouts_match_the_header_formulas():
+    """Host-side packing of the round-4 kernels, checked against the index formulas include/msm_hip.h documents (pure tensor code:
+    runs without a GPU): the hi + lo fragment order of msm_conv1x1_in_lp, the separable K/V constant, and the sizes the library
+    reports for the bf16 plan's prologue blocks."""
+    from unseenobjectswithmeanshift_amd import ops
+    from unseenobjectswithmeanshift_amd._lib import lib
+    g = torch.Generator().manual_seed(3)
+    Cin = 512
+    w = torch.randn(64, Cin, generator=g) * Cin ** -0.5
+    wp = ops.pack_conv_in_weight_lp(w)
+    assert wp.dtype == torch.bfloat16 and wp.numel() == 2 * 64 * Cin
+    hi = w.to(torch.bfloat16)
+    planes = torch.stack([hi, (w - hi.float()).to(torch.bfloat16)])
+    k, o = torch.meshgrid(torch.arange(Cin), torch.arange(64), indexing="ij")
+    for pl in range(2):
+        idx = ((((k // 32) * 4 + o // 16) * 2 + pl) * 64 + ((k % 32) // 8) * 16 + o % 16) * 8 + k % 8
+        assert torch.equal(wp[idx], planes[pl].t())
+    # hi + lo carries the weight to 2^-16 relative
+    assert float(((planes[0].float() + planes[1].float()) - w).abs().max()) <= float(w.abs().max()) * 2.0 ** -15
+    with pytest.raises(RuntimeError):
+        ops.pack_conv_in_weight_lp(torch.zeros(64, 128))
+    # separable K/V constant: H row vectors then W column vectors; token (y, x) gets row[y] + col[x]
+    H, W, N = 5, 7, 256
+    rc = torch.randn(H + W, N, generator=g)
+    dense = ops.dense_kv_constant(rc, W)
+    assert tuple(dense.shape) == (H * W, N) and torch.equal(dense.view(H, W, N)[3, 4], rc[3] + rc[H + 4])
+    assert ops.dense_kv_constant(dense, 0) is dense
+    # the prologue blocks of the bf16 plan: value (16 KiB) + projection (72 KiB) as [row block][k-group][hi, lo] 1-KiB fragments
+    assert lib().msm_encoder_prologue_hm_weight_bytes() == 16384 + 18 * 4096
+    blocks, small = ops.pack_encoder_prologue_hm(torch.randn(64, 64, generator=g), torch.randn(288, 64, generator=g),
+                                                 torch.randn(64, generator=g), torch.randn(288, generator=g))
+    assert blocks.dtype == torch.int16 and blocks.numel() * 2 == 16384 + 18 * 4096 and small.numel() == 352
