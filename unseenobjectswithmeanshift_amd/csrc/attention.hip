@@ -260,9 +260,10 @@ __device__ __forceinline__ void keys_consume(const KeyFrag<KVT, NQ, MM>& f, int 
     for (int m = 0; m < NQ; ++m) {
         f32x4 sn = s;
         if (m + 1 < NQ) sn = scores(m + 1);
-        float p[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(fmaf(s[r], k2, -k2));
+        // the four exponents as two v_pk_fma_f32 (same values as fmaf per score; the loop is vector-issue bound)
+        const f32x2l k2v = f32x2l{k2, k2};
+        const f32x2l e01 = __builtin_elementwise_fma(f32x2l{s[0], s[1]}, k2v, -k2v), e23 = __builtin_elementwise_fma(f32x2l{s[2], s[3]}, k2v, -k2v);
+        const float p[4] = {__builtin_amdgcn_exp2f(e01[0]), __builtin_amdgcn_exp2f(e01[1]), __builtin_amdgcn_exp2f(e23[0]), __builtin_amdgcn_exp2f(e23[1])};
         lacc[m] += f32x2l{p[0], p[1]} + f32x2l{p[2], p[3]};
         if constexpr (BF) {
             const bf16x4 pp = pack4(p[0], p[1], p[2], p[3]);
