@@ -498,6 +498,49 @@ def g_head_cfg5():
     save("head_cfg5_960x1280", **arrs)
 
 
+def g_head_b8_seeds():
+    """Three more batches of 8 at 640x480 (input seeds 11, 12, 13; same weights) through the reference pixel decoder -> 9-layer
+    decoder, float32 only: what the pooled bf16 parity test needs -- class logits, for every image the packed sign bits of the
+    final masks and 8192 sampled values.  With head_480x640_b8 (seed 10) that is 4 x 8 images = 3200 masks: single chaotic
+    events average out, arithmetic differences remain."""
+    pd, dec = build_ref_pixel_decoder(), build_ref_decoder()
+    for seed in (11, 12, 13):
+        feats = syn.synth_backbone_features(8, 480, 640, seed=seed)
+        out = _head_outputs(pd, dec, feats)
+        pm = out["pred_masks"]
+        idx = sample_idx(pm[0].numel())
+        arrs = {"pred_logits": out["pred_logits"], "mask_absmax": pm.abs().amax((1, 2, 3)), "mask_sample_idx": idx, "seed": seed}
+        for b in range(8):
+            arrs.update({f"b{b}_sign_bits": packbits(pm[b] > 0), f"b{b}_sample_val": pm[b].flatten()[idx]})
+        save(f"head_480x640_b8_s{seed}", **arrs)
+
+
+def g_head_cfg5_l20():
+    """BASELINE configs[4] hot path as bench.py times it: 1280x960, 300 queries, **20** decoder layers (21 predictions), batch 1
+    (SURVEY 8d states the config with 20 layers; head_cfg5_960x1280 holds the 19 the reference builds from DEC_LAYERS = 20).
+    Same contents as g_head_cfg5."""
+    pd = build_ref_pixel_decoder()
+    dec = build_ref_decoder(dec_layers=20, num_queries=300)
+    feats = syn.synth_backbone_features(1, 960, 1280, seed=9)
+    out = _head_outputs(pd, dec, feats)
+    out64 = _head_outputs_fp64(pd, dec, feats)
+    pm, pm64 = out["pred_masks"][0], out64["pred_masks"][0]
+    idx = sample_idx(pm.numel(), k=16384)
+    qs = torch.arange(0, 300, 6)
+    arrs = {"pred_logits": out["pred_logits"], "mask_sample_idx": idx, "mask_sample_val": pm.flatten()[idx], "queries": qs,
+            "sign_bits": packbits(pm[qs] > 0), "near_zero": packbits(pm[qs].abs() < 2e-4), "mask_absmax": pm.abs().max(),
+            "positive_fraction": (pm > 0).float().mean(),
+            "pred_logits64": out64["pred_logits"].float(), "mask_sample_val64": pm64.flatten()[idx].float(),
+            "sign_bits64": packbits(pm64[qs] > 0), "positive_fraction64": (pm64 > 0).float().mean()}
+    for i in (0, 9, 19):
+        arrs[f"aux{i}_logits"] = out["aux_outputs"][i]["pred_logits"]
+        arrs[f"aux{i}_sign_bits"] = packbits(out["aux_outputs"][i]["pred_masks"][0][qs] > 0)
+        arrs[f"aux{i}_near_zero"] = packbits(out["aux_outputs"][i]["pred_masks"][0][qs].abs() < 2e-4)
+        arrs[f"aux{i}_logits64"] = out64["aux_outputs"][i]["pred_logits"].float()
+        arrs[f"aux{i}_sign_bits64"] = packbits(out64["aux_outputs"][i]["pred_masks"][0][qs] > 0)
+    save("head_cfg5_960x1280_l20", **arrs)
+
+
 def g_ucn_full():
     """UCN / RGB-D configuration at full size: SimpleBasePixelDecoder + PretrainedMeanShiftTransformerDecoder over the
     480x640 embedding map -- 307 200 keys per image, attention mask at mask resolution, 6 layers, batch 1."""
@@ -691,9 +734,10 @@ def g_checkpoint_keys():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pe", "attn", "decoder", "msda", "msda_bwd", "pixel", "ms", "harness", "ucn", "ucn_backbone", "inst", "head_b8", "head_cfg5", "ucn_full", "dec_bwd", "ckpt_keys"]
+    which = sys.argv[1:] or ["pe", "attn", "decoder", "msda", "msda_bwd", "pixel", "ms", "harness", "ucn", "ucn_backbone", "inst", "head_b8", "head_cfg5", "ucn_full", "dec_bwd", "ckpt_keys", "head_b8_seeds", "head_cfg5_l20"]
     fns = {"pe": g_position_encoding, "attn": g_hypersphere_attention, "decoder": g_decoder,
            "msda": g_msda, "msda_bwd": g_msda_bwd, "pixel": g_pixel_decoder, "ms": g_mean_shift, "harness": g_harness, "ucn": g_ucn, "ucn_backbone": g_ucn_backbone,
-           "inst": g_instance_inference, "dec_bwd": g_decoder_backward, "ckpt_keys": g_checkpoint_keys, "head_b8": g_head_b8, "head_cfg5": g_head_cfg5, "ucn_full": g_ucn_full}
+           "inst": g_instance_inference, "dec_bwd": g_decoder_backward, "ckpt_keys": g_checkpoint_keys, "head_b8": g_head_b8, "head_cfg5": g_head_cfg5, "ucn_full": g_ucn_full,
+           "head_b8_seeds": g_head_b8_seeds, "head_cfg5_l20": g_head_cfg5_l20}
     for w in which:
         fns[w]()

@@ -190,7 +190,7 @@ def test_stale_check_sees_replaced_and_repointed_middle_parameters():
     mid.load_state_dict(sd, assign=True)
     assert chk() != s2
     # the module-level lists behind the packed-weight caches follow the same rule
-    tl = _plan.TensorList(lambda: head.pixel_decoder.transformer.encoder.parameters())
+    tl = _plan.TensorList.of(head.pixel_decoder, "transformer.encoder")
     k0 = _plan.version_key(tl())
     mid.weight = nn.Parameter(mid.weight.detach().clone())
     k1 = _plan.version_key(tl())
@@ -199,6 +199,48 @@ def test_stale_check_sees_replaced_and_repointed_middle_parameters():
     assert _plan.version_key(tl()) != k1
     # the inference-plan attributes of the meta-arch are plan attributes too (advisor: K selects kernels inside a captured graph)
     assert {"test_topk_per_image", "topk_before_masks", "hm_activations"} <= _plan.PLAN_ATTRS
+
+
+def test_tensor_lists_follow_deepcopy_and_pickle():
+    """Round-4 advisor finding: the tensor lists behind the packed-weight caches / graph staleness keys were built from lambdas
+    closing over the module; deepcopy copies functions atomically, so a copied model kept computing its key from the ORIGINAL's
+    tensors (an in-place update of the copy went unseen once the parameter epoch had moved) and pickle refused the lambda.  Now
+    the builder is an owner reference (re-bound by deepcopy, pickled with the module) and plain functions are refused."""
+    import copy
+    import pickle
+    from torch import nn
+    from unseenobjectswithmeanshift_amd import _plan, graphs
+    from unseenobjectswithmeanshift_amd.meta_arch import build_resnet50_head
+    head = build_resnet50_head()
+    pd = head.pixel_decoder
+    pd._enc_params = _plan.TensorList.of(pd, "transformer.encoder")          # what _encoder_stream() installs on first use
+    k_orig = _plan.version_key(pd._enc_params())                             # list cached on the original
+    chk = graphs.StaleCheck(head)
+    chk()
+    twin = copy.deepcopy(head)
+    chk2 = copy.deepcopy(chk)
+    assert twin.pixel_decoder._enc_params._owner is twin.pixel_decoder       # re-bound to the copy, cache dropped
+    assert twin.pixel_decoder._enc_params._list is None
+    _ = nn.Linear(2, 2)                                                      # any module construction moves the parameter epoch
+    k_twin = _plan.version_key(twin.pixel_decoder._enc_params())
+    with torch.no_grad():
+        twin.pixel_decoder.transformer.encoder.layers[1].linear1.weight.add_(1.0)
+    assert _plan.version_key(twin.pixel_decoder._enc_params()) != k_twin     # the copy sees its own update ...
+    assert _plan.version_key(pd._enc_params()) == k_orig                     # ... and the original did not change
+    assert all(a is not b for a, b in zip(pd._enc_params(), twin.pixel_decoder._enc_params()))
+    # a deep-copied StaleCheck follows ITS model copy (graphs.py keeps model + check together in GraphedInference)
+    assert chk2._tensors._owner is not head
+    # bound methods are re-bound by deepcopy as well
+    tl = _plan.TensorList(head.predictor.parameters)
+    tl()
+    assert copy.deepcopy(tl)._build.__self__ is not head.predictor
+    with pytest.raises(TypeError):
+        _plan.TensorList(lambda: head.parameters())
+    # pickle: a module that has used its list round-trips (the cached list is not part of the state)
+    blob = pickle.dumps(pd)
+    back = pickle.loads(blob)
+    assert back._enc_params._owner is back and back._enc_params._list is None
+    assert len(back._enc_params()) == len(pd._enc_params())
 
 
 class _NotATensor:

@@ -68,23 +68,65 @@ _HOOKED = _install_registration_hooks()
 
 
 class TensorList:
-    """``TensorList(lambda: list(module.parameters()))()`` -> the list, rebuilt when a Parameter / buffer object was
-    (re)registered anywhere in the process since it was built (cheap: module construction is rare on the hot path)."""
+    """The parameters (and buffers) of a module as a list, rebuilt when a Parameter / buffer object was (re)registered anywhere in
+    the process since it was built (cheap: module construction is rare on the hot path).
 
-    def __init__(self, build):
+        TensorList.of(module)                              -> module.parameters()
+        TensorList.of(module, "transformer.encoder")       -> module.transformer.encoder.parameters()
+        TensorList.of(module, buffers=True)                -> parameters + buffers
+        TensorList(module.parameters)                      -> a bound method as the builder
+
+    The builder is never a closure over the module: ``copy.deepcopy`` copies functions atomically, so a deep-copied model would
+    keep computing its staleness key from the ORIGINAL's tensors (and keep it alive), and ``pickle`` refuses local lambdas.  An
+    owner reference / bound method is re-bound to the copy by deepcopy and pickles with the module; the cached list is dropped
+    on both."""
+
+    def __init__(self, build=None, owner=None, path="", buffers=False):
+        if build is not None and getattr(build, "__self__", None) is None:
+            raise TypeError("TensorList: pass a bound method or use TensorList.of(module, path); a plain function / lambda "
+                            "would stay bound to the original module under copy.deepcopy")
         self._build = build
+        self._owner, self._path, self._buffers = owner, path, bool(buffers)
         self._list = None
         self._epoch = -1
+
+    @classmethod
+    def of(cls, owner, path="", buffers=False):
+        return cls(None, owner, path, buffers)
+
+    def _tensors(self):
+        if self._build is not None:
+            return list(self._build())
+        m = self._owner
+        for name in filter(None, self._path.split(".")):
+            m = getattr(m, name)
+        out = list(m.parameters())
+        if self._buffers:
+            out += list(m.buffers())
+        return out
 
     def __call__(self):
         ep = _param_epoch[0]
         if self._list is None or ep != self._epoch or not _HOOKED:
-            self._list = list(self._build())
+            self._list = self._tensors()
             self._epoch = ep
         return self._list
 
     def clear(self):
         self._list = None
+
+    def __getstate__(self):
+        return {"_build": self._build, "_owner": self._owner, "_path": self._path, "_buffers": self._buffers}
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self._list, self._epoch = None, -1
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = TensorList.__new__(TensorList)
+        new.__setstate__({k: copy.deepcopy(v, memo) for k, v in self.__getstate__().items()})
+        return new
 
 
 def version_key(tensors):

@@ -83,12 +83,16 @@ def load_checkpoint_file(path, unsafe=False):
             for mod in ("numpy.core.multiarray", "numpy._core.multiarray"):
                 allow.append((fn, f"{mod}.{name}"))
     allow += [type(np.dtype(t)) for t in ("float32", "float64", "float16", "int64", "int32", "uint8", "bool")]
+    def _load(globals_):
+        with torch.serialization.safe_globals(globals_):
+            return torch.load(path, map_location="cpu", weights_only=True)
+
+    plain = [a for a in allow if not isinstance(a, tuple)]
     try:
-        with torch.serialization.safe_globals(allow):
-            return torch.load(path, map_location="cpu", weights_only=True)
-    except TypeError:                                  # a torch whose safe_globals does not take (callable, name) pairs
-        with torch.serialization.safe_globals([a for a in allow if not isinstance(a, tuple)]):
-            return torch.load(path, map_location="cpu", weights_only=True)
+        try:
+            return _load(allow)
+        except (TypeError, AttributeError):            # a torch whose allow-list does not take (callable, "module.name") pairs: it accepts the
+            return _load(plain)                        # tuple into the list and fails inside torch.load ('tuple' has no __module__)
     except pickle.UnpicklingError as e:
         raise pickle.UnpicklingError(
             f"{path}: not loadable tensors-only ({e}).  Legacy detectron2 checkpoints may hold other objects (trainer state, "

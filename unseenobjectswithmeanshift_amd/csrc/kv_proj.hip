@@ -205,7 +205,8 @@ __global__ __launch_bounds__(KP_W * 64) void kv_project_multi_kernel(KvJobs jobs
 // the half.  K order k = lq*16 + G*8 + e on both operands, so a lane's 16 x-values are its two B operands as they are loaded.
 constexpr int KS_LD = KP_K + 8;      // LDS row stride of a bf16 weight copy (elements)
 constexpr int KS_W = 8;              // waves per workgroup of the bf16-pipe kernel
-constexpr int KS_TR = 64 + 4;        // row stride (bf16 elements) of a wave's output transposition tile: 136 B = 34 banks, the 16 token rows of a ds_write_b64 land on 16 bank pairs
+constexpr int KS_TR = 64 + 8;        // row stride (bf16 elements) of a wave's output transposition tile: 144 B = 36 banks -- a multiple of 16 B, so the ds_read_b128 of the
+                                     // store phase is naturally aligned on every row; the 16 token rows x 2 quads of a ds_write_b64 half-wave land on 64 distinct banks
 
 template <typename OT, int MODE, bool SEP>
 __device__ __forceinline__ void kv_project_split_body(const float* __restrict__ x, const float* __restrict__ w,

@@ -1495,11 +1495,15 @@ extern "C" int msm_ms_select_seeds(const float* X, int n, int d, int num_seeds, 
     float* nearest = workspace + 2 * (MS_SB * 16) + 8;
     hipLaunchKernelGGL(ms_seed_init_kernel, dim3(cdiv(num_seeds, 64)), dim3(64), 0, st, keys, num_seeds, first_index);
     // persistent single-launch path when the map fits the register files of the CUs (see ms_seed_persistent_kernel)
-    static const int n_cus = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
-        return v;
-    }();
+    // CU count of the CURRENT device (a process may drive several): cached per device ordinal
+    static int cu_cache[64] = {0};
+    int dev = 0, n_cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        if (dev >= 0 && dev < 64 && cu_cache[dev] > 0) n_cus = cu_cache[dev];
+        else if (hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) {
+            if (dev >= 0 && dev < 64) cu_cache[dev] = n_cus;
+        } else n_cus = 0;
+    }
     const int ng = cdiv(n, 256 * PS_W * 64);                       // rows per workgroup = 512 * ng
     const int pgrid = ng >= 1 && ng <= 3 ? cdiv(n, PS_W * 64 * ng) : 0;
     unsigned int* status = reinterpret_cast<unsigned int*>(workspace + 2 * (MS_SB * 16) + 4);   // 2 words between keys and nearest
@@ -1701,11 +1705,15 @@ extern "C" int msm_ms_select_seeds_bf16(const void* Xb, const float* X, int n, i
     float* nearest = workspace + 2 * (MS_SB * 16) + 8;
     hipLaunchKernelGGL(ms_seed_init_kernel, dim3(cdiv(num_seeds, 64)), dim3(64), 0, st, keys, num_seeds, first_index);
     // one persistent launch with the rows held in VGPRs / LDS / streamed (ms_seed_persistent_bf16_kernel): one workgroup per CU
-    static const int n_cus = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
-        return v;
-    }();
+    // CU count of the CURRENT device (a process may drive several): cached per device ordinal
+    static int cu_cache[64] = {0};
+    int dev = 0, n_cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        if (dev >= 0 && dev < 64 && cu_cache[dev] > 0) n_cus = cu_cache[dev];
+        else if (hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) {
+            if (dev >= 0 && dev < 64) cu_cache[dev] = n_cus;
+        } else n_cus = 0;
+    }
     constexpr int NG = 5, NL = 2;
     const int pgrid = min(n_cus, PS_MAXWG);
     const int tail0 = pgrid * PB_GROUPS * (NG + NL) * 16;

@@ -59,7 +59,7 @@ class StaleCheck:
     def __init__(self, model, strict=False):
         self.model = model
         self.strict = strict
-        self._tensors = TensorList(lambda: list(model.parameters()) + list(model.buffers()))
+        self._tensors = TensorList.of(model, buffers=True)
         self._manual = 0
 
     def invalidate(self):

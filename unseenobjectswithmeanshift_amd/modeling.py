@@ -594,7 +594,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         kv_all = None
         if self.fold_kv:
             kv_w, kv_c = self._folded_kv(sizes, dev)
-            kv_bytes = 4 * B * kv_w[0].shape[0] * sum(sizes[i % self.num_feature_levels][0] * sizes[i % self.num_feature_levels][1]
+            kv_bytes = (2 if self.attention_dtype == "bf16" else 4) * B * kv_w[0].shape[0] * sum(sizes[i % self.num_feature_levels][0] * sizes[i % self.num_feature_levels][1]
                                                       for i in range(self.num_layers))
             if (self.batched_kv and kv_bytes <= (1 << 30) and all(xl.shape[1] == 64 for xl in xs)
                     and kv_w[0].shape[0] in (256, 512)):       # all layers' K/V live at once: only while that stays small (beyond ~1 GiB a
@@ -964,7 +964,7 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
         if self.precision not in ("f32", "f32_split", "bf16"):
             raise ValueError("precision must be 'f32', 'f32_split' or 'bf16'")
         if getattr(self, "_enc_params", None) is None:
-            self._enc_params = TensorList(lambda: self.transformer.encoder.parameters())
+            self._enc_params = TensorList.of(self, "transformer.encoder")
         hm = self._use_hm()
         key = (str(device), self.precision, hm) + version_key(self._enc_params())
         if self._packed is None or self._packed[0] != key:

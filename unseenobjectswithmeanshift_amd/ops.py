@@ -881,6 +881,16 @@ def ms_pack_bf16(X):
     return xb
 
 
+def _check_xb(xb, n, d, who):
+    """``xb`` must be the whole padded copy ms_pack_bf16 makes: the kernels read entire 32-row slabs, so a shorter buffer (even one
+    with n rows) would be read past its end."""
+    _c(xb, "xb", torch.bfloat16)
+    want = (int(lib().msm_ms_bf16_rows(n)), d)
+    if tuple(xb.shape) != want:
+        raise RuntimeError(f"{who}: xb has shape {tuple(xb.shape)}, expected ms_pack_bf16(X) of shape {want}")
+    return xb
+
+
 def ms_select_seeds(X, num_seeds, first_index, stepwise=False, _test_give_up=False, xb=None):
     """Farthest-point seeding.  X (n,64) unit rows.  Returns (seeds (S,64), indices int64 (S,)).  The single-launch
     persistent kernel (maps up to 393 216 rows) needs its workgroups co-resident; if other work holds the CUs it gives up
@@ -895,9 +905,7 @@ def ms_select_seeds(X, num_seeds, first_index, stepwise=False, _test_give_up=Fal
     need = lib().msm_ms_seed_workspace(n)
     ws = torch.empty((need,), device=X.device, dtype=torch.float32)
     if xb is not None and n > 393216:
-        _c(xb, "xb", torch.bfloat16)
-        if xb.shape[0] < n or xb.shape[1] != d:
-            raise RuntimeError("ms_select_seeds: xb must be ms_pack_bf16(X)")
+        _check_xb(xb, n, d, "ms_select_seeds")
         rc = lib().msm_ms_select_seeds_bf16(_p(xb), _p(X), n, d, num_seeds, int(first_index), _p(seeds), _p(idx), _p(ws), need,
                                             (1 if stepwise else 0) | (2 if _test_give_up else 0), _stream())
         check(rc, "msm_ms_select_seeds_bf16")
@@ -919,7 +927,7 @@ def ms_hill_climb(X, Z, kappa, iters, precision="f32", xb=None):
     S = Z.shape[0]
     Z = Z.clone()
     if precision == "bf16":
-        xb = ms_pack_bf16(X) if xb is None else _c(xb, "xb", torch.bfloat16)
+        xb = ms_pack_bf16(X) if xb is None else _check_xb(xb, n, d, "ms_hill_climb")
         need = lib().msm_ms_hill_climb_workspace(n, S)
         ws = torch.empty((need,), device=X.device, dtype=torch.float32)
         check(lib().msm_ms_hill_climb_bf16(_p(xb), n, d, _p(Z), S, float(kappa), int(iters), _p(ws), need, _stream()), "msm_ms_hill_climb_bf16")

@@ -119,7 +119,7 @@ class ResNet50Backbone(PlanAttributes, nn.Module):
 
     def _plan(self):
         if self._plan_tensors is None:
-            self._plan_tensors = TensorList(lambda: list(self.parameters()) + list(self.buffers()))
+            self._plan_tensors = TensorList.of(self, buffers=True)
         if self.backbone_dtype not in ("f32", "bf16"):
             raise ValueError("backbone_dtype must be 'f32' or 'bf16'")
         low = self.backbone_dtype == "bf16"
