@@ -439,6 +439,14 @@ def mean_shift_unit(dev):
     for _ in range(3):
         ms.clustering_features(feats, num_seeds=S, precision="f32_split")
     t_all_sp = timed(lambda: ms.clustering_features(feats, num_seeds=S, precision="f32_split"), reps)
+    # the stress variant SURVEY 8d names: the same map with 2 % uniform background points -- the farthest-point seeds are then
+    # background points that stay singletons: ~S clusters through the merge, the assignment and the relabel
+    Xn, _ = syn.synth_unit_embeddings(n, 64, clusters=12, sigma=0.15, seed=3, background_frac=0.02)
+    feats_n = Xn.t().reshape(1, 64, H, W).contiguous().to(dev)
+    for _ in range(3):
+        ms.clustering_features(feats_n, num_seeds=S)
+    t_noisy = timed(lambda: ms.clustering_features(feats_n, num_seeds=S), reps)
+    n_clusters_noisy = int(ms.clustering_features(feats_n, num_seeds=S)[0].unique().numel())
     ref_bytes = float(S) * n * 64 * 4                  # the reference re-reads X for every seed
     hill_flops = 4.0 * S * n * 64 * iters              # Z X^T and W X per iteration
     return {"workload": "clustering_features unit (lib/fcn/test_dataset.py:44-59): one 640x480 map, n=307200 unit 64-d embeddings in 12 "
@@ -455,6 +463,9 @@ def mean_shift_unit(dev):
                            "achieved": round(hill_flops / (t_hill * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(hill_flops / (t_hill * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "flops": hill_flops},
             "assign_ms": round(t_asg, 4),
+            "background_2pct": {"value": round(1.0 / t_noisy, 2), "unit": "images/sec", "ms_per_image": round(1e3 * t_noisy, 3), "clusters": n_clusters_noisy,
+                                "note": "same map with 2 % uniform background points (synth_unit_embeddings background_frac=0.02): nearly every seed a "
+                                        "singleton cluster; parity: tests/test_gpu_modules.py::test_mean_shift_background_points_vs_oracle"},
             "f32_split": {"dtype": "f32 results, bf16x3 split products", "value": round(1.0 / t_all_sp, 2), "unit": "images/sec",
                           "ms_per_image": round(1e3 * t_all_sp, 3),
                           "hill_climb": {"kernel": "ms_split_planes_kernel (once) + ms_hill_planes_kernel + ms_hill_finish_kernel", "ms": round(t_hill_sp, 4),
@@ -766,11 +777,100 @@ def extra_configs(dev, args):
                                     "products_per_useful_product": mult,
                                     "kernel": {"f32": "ms_hill_kernel (fp32 MFMA), 3 launches per iteration", "f32_split": "ms_hill_planes_kernel (six bf16 MFMAs per product), "
                                                "3 launches per iteration", "bf16": "ms_hill_bf16_kernel (Z as h + l: 2 score MFMAs + 1 W X MFMA per pair), 1 launch per iteration"}[mode]}}
+    Xn, _ = syn.synth_unit_embeddings(n, 64, clusters=24, sigma=0.15, seed=3, background_frac=0.02)
+    Xnd = Xn.to(dev)
+    noisy = {}
+    for mode in ("bf16", "f32"):
+        for _ in range(2):
+            ms.mean_shift_smart_init(Xnd, 20.0, S, iters, first_index=7, precision=mode)
+        noisy[mode] = round(1e3 * timed_median(lambda: ms.mean_shift_smart_init(Xnd, 20.0, S, iters, first_index=7, precision=mode), 5), 2)
+    msr["bf16"]["background_2pct"] = {"ms": noisy["bf16"], "ms_f32": noisy["f32"],
+                                      "note": "the same clustering on a map with 2 % uniform background points (~S singleton clusters)"}
+    del Xnd
     out["configs[4]"] = {"workload": "1280x960, 300 queries, batch 1 and 4 (pixel decoder + decoder + post-processing; 20 decoder layers as SURVEY 8d "
                                      "states the config, and the 19 of the parity fixture); classic mean shift on n=1228800 embeddings, 300 seeds, "
                                      "20 iterations (bf16 = the config's dtype: one bf16 copy of X shared by seeding and hill climb; f32 / f32_split exact)",
                          "hot_path": res,
                          "mean_shift": dict(msr["bf16"], dtype="bf16 copy of X, fp32 accumulation / distances / seeds", other_precisions={k: msr[k] for k in ("f32_split", "f32")})}
+    return out
+
+
+def build_summary(result):
+    """<= 2 KB digest of the line, emitted as its LAST key (the driver keeps a fixed key set + the tail of stdout; the full line is
+    ~20 KB): per config the throughput `v` (images/s unless noted), the one-batch-in-flight step `ms1`, the dtype `dt` and the
+    roofline fraction `rf` of that config's dominant kernel.  Every number README / DESIGN quote is here or in `roofline`."""
+    cfg = result.get("configs") or {}
+    r = result["roofline"]
+
+    def pick(d, *path, nd=1):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return round(d, nd) if isinstance(d, float) else d
+
+    s = {"c1": {"v": result["value"], "ms1": r.get("one_batch_in_flight_ms"), "v1": r.get("one_batch_in_flight_images_per_sec"), "dt": "f32",
+                "rf": r["frac"], "mask_rf": r.get("mask_step_frac"), "mask_lit_rf": r.get("mask_step_literal_frac")}}
+    c = cfg.get("configs[1] f32_split")
+    if c:
+        s["c1_split"] = {"v": c["value"], "ms1": pick(c, "one_batch_in_flight", "ms_per_step", nd=3), "dt": "f32 via bf16x3", "rf": pick(c, "roofline", "frac", nd=3)}
+    c = cfg.get("configs[1] full-resolution mask steps")
+    if c:
+        s["c1_fullres"] = {"v": c["value"], "ms1": pick(c, "one_batch_in_flight", "ms_per_step", nd=3)}
+    c = cfg.get("configs[1] literal mask step")
+    if c:
+        s["c1_literal"] = {"v": c["value"], "ms1": c["ms_per_step"], "rf": pick(c, "roofline", "frac", nd=3)}
+    c = cfg.get("configs[1] with backbone")
+    if c:
+        s["c1_backbone"] = {k.replace("hipgraph_", ""): {"v": v["value"], "ms": v["ms_per_step"]} for k, v in c["variants"].items() if k.startswith("hipgraph_")}
+    for key, tag in (("configs[2]", "c2"), ("configs[2] f16", "c2_f16")):
+        c = cfg.get(key)
+        if c:
+            s[tag] = {"v": c["value"], "ms1": pick(c, "one_batch_in_flight", "ms_per_step", nd=3), "dt": "bf16" if tag == "c2" else "f16",
+                      "rf_hbm": pick(c, "roofline", "frac", nd=3), "rf_mfma": pick(c, "roofline", "frac_of_bf16_mfma_peak", nd=3),
+                      "traffic": pick(c, "roofline", "traffic")}
+    c = cfg.get("configs[3]")
+    if c:
+        s["c3"] = {"v": c["value"], "unit": "frames/s", "ms_batch16": c["ms_per_batch"]}
+    c = cfg.get("configs[4]")
+    if c:
+        s["c4"] = {"hot": {k.replace(" layers, batch ", "L_b").replace(", ", "_"): v["value"] for k, v in c["hot_path"].items()},
+                   "ms": {"bf16": pick(c, "mean_shift", "ms"), "f32_split": pick(c, "mean_shift", "other_precisions", "f32_split", "ms"),
+                          "f32": pick(c, "mean_shift", "other_precisions", "f32", "ms"), "unit": "ms per clustering",
+                          "seed_rf_hbm": pick(c, "mean_shift", "seeding", "frac", nd=3), "hill_rf_mfma": pick(c, "mean_shift", "hill_climb", "frac", nd=3),
+                          "noisy_bf16": pick(c, "mean_shift", "background_2pct", "ms")}}
+    c = cfg.get("ucn_path")
+    if c:
+        s["ucn"] = {"f32": {"v": c["value"], "ms1": pick(c, "one_batch_in_flight", "ms_per_step", nd=3)},
+                    "bf16": {"v": pick(c, "bf16", "value"), "ms1": pick(c, "bf16", "one_batch_in_flight", "ms_per_step", nd=3)},
+                    "rf_hbm": pick(c, "roofline", "frac", nd=3)}
+    c = cfg.get("ucn_rgbd_end_to_end")
+    if c:
+        s["ucn_e2e"] = {k: {"v": v["value"], "ms": v["ms_per_step"]} for k, v in c["variants"].items()}
+    m = result.get("mean_shift")
+    if m:
+        s["ms640"] = {"v": m["value"], "split": pick(m, "f32_split", "value"), "noisy": pick(m, "background_2pct", "value"),
+                      "hill_rf": pick(m, "hill_climb", "frac", nd=3)}
+    c = result.get("cpu_baseline")
+    if c:
+        s["cpu"] = {"v": c["value"], "cores": c["cores"], "ms640": pick(c, "mean_shift", "value", nd=3)}
+    while len(json.dumps(s)) > 2048 and len(s) > 1:          # never outgrow the budget: drop from the end
+        s.popitem()
+    return s
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def collective_entry(dist, rec, all_gather_s, rccl_log=None):
+    """What an N > 1 line says about its only collective: library version, the transport RCCL chose (rank 0's NCCL_DEBUG=INFO
+    log, summarised), the all_gather's own wall time, and the spread of the ranks' timed regions -- so a SCALE record either
+    shows ">= 6x at 8 GPUs over xGMI" or explains why not (a slow rank, a PCIe / SHM transport, an unpinned host thread)."""
+    from unseenobjectswithmeanshift_amd.distributed import communicator_report
+    el = [r["elapsed_s"] for r in rec]
+    out = communicator_report(dist, rccl_log)
+    out.update({"collective": "one all_gather of a per-rank metrics record (5 float64) after the timed region; none on the data path",
+                "all_gather_us": round(1e6 * all_gather_s, 1),
+                "per_rank_elapsed_s": {"min": round(min(el), 6), "max": round(max(el), 6), "spread_pct": round(100.0 * (max(el) - min(el)) / max(el), 2),
+                                       "slowest_rank": int(max(range(len(el)), key=el.__getitem__))}})
     return out
 
 
@@ -796,13 +896,16 @@ def stub_main(args, world, rank):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     rec = gather_metrics({"images": (hi - lo) * args.steps, "elapsed_s": elapsed, "checksum": acc}, dist if world > 1 else None)
+    from unseenobjectswithmeanshift_amd.distributed import timed_all_gather
+    ag_s = timed_all_gather(dist if world > 1 else None, reps=5)
     if rank == 0:
         t_max = max(r["elapsed_s"] for r in rec)
         print(json.dumps({"metric": METRIC, "value": round(sum(r["images"] for r in rec) / t_max, 2), "unit": "images/sec",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * t_max / args.steps, 4),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "stub",
                           "config": {"workload": "launcher self-test", "global_batch": world * BATCH, "parallelism": f"dp{world}"},
-                          "per_rank": [{"rank": i, "images": r["images"], "checksum": r["checksum"]} for i, r in enumerate(rec)]}),
+                          "per_rank": [{"rank": i, "images": r["images"], "checksum": r["checksum"]} for i, r in enumerate(rec)],
+                          "collective": collective_entry(dist if world > 1 else None, rec, ag_s)}),
               flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -826,6 +929,7 @@ def main():
     ap.add_argument("--precision", choices=("f32", "f32_split", "bf16"), default="f32",
                     help="bf16 (configs 3/5) is NOT the headline configuration: the JSON line then says so in dtype")
     ap.add_argument("--batched-kv", type=int, default=-1, help="1/0: all K/V projections of the decoder in one launch (default: the decoder's own default)")
+    ap.add_argument("--no-rccl-report", action="store_true", help="N > 1: do not record rank 0's NCCL_DEBUG=INFO log for the `collective` entry")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     # test hooks for the N > 1 code path on a ONE-GPU box (tests/test_gpu_configs.py): every rank on cuda:0, collectives over gloo
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help=argparse.SUPPRESS)
@@ -865,9 +969,15 @@ def main():
     if world > 1 and affinity["status"].startswith("failed"):
         # a speed matter, not a correctness one: the run goes on, the line says how many ranks are pinned, stderr says why not
         print(f"bench.py rank {rank}: NOT pinned to the NUMA node of GPU {local_rank}: {affinity}", file=sys.stderr, flush=True)
+    rccl_log = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl" and rank == 0 and not args.no_rccl_report and "NCCL_DEBUG" not in os.environ:
+            # rank 0 records what its communicator runs over (transport per channel, detected topology) into a file of its own --
+            # stdout keeps the one JSON line -- and summarises it under `collective` (distributed.parse_rccl_debug)
+            rccl_log = f"/tmp/msm_rccl_rank0_{os.getpid()}.log"
+            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,P2P", NCCL_DEBUG_FILE=rccl_log)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -875,7 +985,7 @@ def main():
 
     from unseenobjectswithmeanshift_amd import _lib, ops
     from unseenobjectswithmeanshift_amd import synthetic as syn
-    from unseenobjectswithmeanshift_amd.distributed import gather_metrics, shard_range
+    from unseenobjectswithmeanshift_amd.distributed import communicator_report, gather_metrics, shard_range, timed_all_gather
 
     model = build_model(dev)
     pred = model.sem_seg_head.predictor
@@ -992,12 +1102,14 @@ def main():
         with torch.cuda.stream(stream):
             lp_images, lp_elapsed, lp_steps, lp_single, lp_roof = precision_leg(model, feats, dev, dist, args, "bf16", max(1, args.inflight))
         lp_rec = gather_metrics({"images": lp_images, "elapsed_s": lp_elapsed, "checksum": lp_single}, dist)
+    ag_s = timed_all_gather(dist)                   # every rank takes part: the path's only collective, timed on its own
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
     t_max = max(r["elapsed_s"] for r in rec)
     total_images = sum(r["images"] for r in rec)
+    collective = collective_entry(dist, rec, ag_s, rccl_log)
     bf16 = args.precision == "bf16"
     mask_name = "msm_mask_logits_bf16_fwd" if (bf16 and "msm_mask_logits_bf16_fwd" in dur) else "msm_mask_logits_fwd"
     per_call = dur[mask_name]
@@ -1054,7 +1166,7 @@ def main():
     roofline = {"bound": "mfma", "kernel": f"enc_block kernel (msm_{enc_name}_fwd): the fused encoder-layer tail, the dominant kernel of the step by time",
                 "achieved": round(enc_ach, 2), "peak": enc_peak, "unit": "TFLOP/s", "frac": round(enc_ach / enc_peak, 4), "traffic": enc_traffic,
                 "launches_per_step": enc_calls, "avg_launch_ms": round(enc_ms, 4), "flops_per_launch": enc_fl_exec,
-                "share_of_step": round(enc_ms_all / (1e3 * t_max / steps), 3) if inflight == 1 else None,
+                "share_of_step": None,
                 "timing": "HIP events on the launch stream around 100 graph replays of the step's encoder-block launches (back to back, real arguments)",
                 "matrix_pipe": enc_unit_note,
                 "algorithmic_bytes_per_launch": (traffic_tab.get("enc_block_kernel") or {}).get("algorithmic_bytes_per_launch"),
@@ -1063,6 +1175,16 @@ def main():
                 "note": "rounds 1-3 put the mask step here; with the intermediate attention masks computed at key resolution it is 1-2 % of the "
                         "step, so the object describes the kernel that dominates (MFMA-bound: 315 kFLOP per token against 2.3 KB of traffic) and "
                         "carries the mask step's figures in `mask_step`"}
+    # flat copies of what the driver's record must show (its parser keeps the scalar members of `roofline`): the strict one-batch
+    # figure, the dominant kernel's share of THAT step, and the mask step (the kernel the metric names) as a fraction of the peak
+    one_ms = 1e3 * single / single_steps if single is not None else 1e3 * t_max / steps
+    roofline["share_of_step"] = round(enc_ms_all / one_ms, 3)
+    roofline["share_of_step_basis"] = "encoder-block launches of one pass / one batch in flight"
+    roofline["one_batch_in_flight_images_per_sec"] = round((hi - lo) / (one_ms * 1e-3), 1)
+    roofline["one_batch_in_flight_ms"] = round(one_ms, 4)
+    roofline["mask_step_frac"] = mask_step["kernel_frac_of_fp32_mfma_peak"]
+    roofline["mask_step_avg_launch_ms"] = mask_step["kernel_avg_launch_ms"]
+    roofline["mask_step_literal_frac"] = None           # filled from configs["configs[1] literal mask step"] below (N = 1 with extras)
     kernels = {k: {"launches_per_step": len(v) // 3, "ms_per_step": round(sum(v) / 3, 4), "avg_launch_us": round(1e3 * sum(v) / len(v), 2)}
                for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1]))}
     result = {
@@ -1120,6 +1242,15 @@ def main():
         result.setdefault("configs", {}).update(extra_configs(dev, args))
     if not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = cpu_baseline()
+    lit = (result.get("configs") or {}).get("configs[1] literal mask step")
+    if lit:
+        result["roofline"]["mask_step_literal_frac"] = lit["roofline"]["frac"]
+    if world > 1:
+        result["collective"] = collective
+    else:
+        result["collective"] = {"world_size": 1, "note": "N = 1: no process group; an N > 1 line carries the RCCL version, the transport of every channel "
+                                                         "(rank 0's NCCL_DEBUG=INFO log summarised), the all_gather's wall time and the per-rank spread here"}
+    result["summary"] = build_summary(result)            # LAST key, <= 2 KB: what the driver's 8-KB tail is sure to hold
     print(json.dumps(result), flush=True)
     if dist is not None:
         dist.destroy_process_group()

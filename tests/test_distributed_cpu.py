@@ -78,6 +78,31 @@ def test_bench_launcher_spawns_ranks_gloo_stub():
     assert [p["rank"] for p in rec["per_rank"]] == [0, 1] and [p["images"] for p in rec["per_rank"]] == [56.0, 56.0]
     # each rank's checksum comes from its own data (rank r multiplies matrices of r+1): 64*64*64*(r+1)^2
     assert [p["checksum"] for p in rec["per_rank"]] == [64.0 ** 3, 4 * 64.0 ** 3]
+    # the line explains its only collective: backend, the all_gather's own wall time, the spread of the ranks' timed regions
+    col = rec["collective"]
+    assert col["backend"] == "gloo" and col["world_size"] == 2 and col["all_gather_us"] > 0
+    assert set(col["per_rank_elapsed_s"]) == {"min", "max", "spread_pct", "slowest_rank"} and col["per_rank_elapsed_s"]["min"] <= col["per_rank_elapsed_s"]["max"]
+
+
+def test_rccl_debug_log_summary():
+    """distributed.parse_rccl_debug: rank 0's NCCL_DEBUG=INFO log -> transport per channel connection, xGMI mentions, version line
+    (what an N > 1 bench line reports under `collective`; no 8-GPU node was available to the builder, so the parser is pinned on
+    the log formats RCCL / NCCL print)."""
+    from unseenobjectswithmeanshift_amd.distributed import communicator_report, parse_rccl_debug
+    xgmi = """node:101:215 [0] NCCL INFO RCCL version 2.22.3+hip6.4 HEAD:9a3c
+node:101:215 [0] NCCL INFO GPU/2D000 + XGMI[48.0] - GPU/43000
+node:101:215 [0] NCCL INFO Channel 00/0 : 0[0] -> 1[1] via P2P/IPC/read
+node:101:215 [0] NCCL INFO Channel 01/0 : 0[0] -> 1[1] via P2P/IPC/read
+node:101:215 [0] NCCL INFO Channel 00/0 : 7[7] -> 0[0] via P2P/IPC/read
+"""
+    r = parse_rccl_debug(xgmi)
+    assert r["transport"].startswith("P2P only") and "xGMI" in r["transport"] and r["xgmi_mentions"] == 1
+    assert r["channel_connections"] == {"P2P/IPC/read": 3} and r["library_version_line"].startswith("RCCL version 2.22.3")
+    r = parse_rccl_debug("a [0] NCCL INFO Channel 00 : 0[0] -> 1[1] via SHM/direct/direct\nb [0] NCCL INFO Channel 00/0 : 1[1] -> 0[0] [send] via NET/Socket/0\n")
+    assert r["transport"] == "mixed: NET, SHM" and r["xgmi_mentions"] == 0
+    assert parse_rccl_debug("nothing useful")["transport"].startswith("unknown")
+    assert parse_rccl_debug("x via P2P/IPC")["transport"].startswith("P2P only (no xGMI")
+    assert communicator_report(None) == {"backend": None, "world_size": 1}
     assert rec["value"] > 0 and abs(rec["value"] - 112 / (rec["ms_per_step"] * 7e-3)) < 1e-2 * rec["value"]
     # the size the driver's scaling run uses: eight ranks, one JSON line, every rank's record gathered
     r8 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--stub", "--steps", "3", "--warmup", "1"],

@@ -399,6 +399,107 @@ def test_mean_shift_end_to_end_vs_reference(golden):
     labels, sel = ms.mean_shift_smart_init(X.to(DEV), kappa=20, num_seeds=50, max_iters=10)
     assert int(sel[0]) == int(g["a_first"])
     assert torch.equal(labels.cpu(), T(g["a_labels"]).long())
+    # the reference's noisy case (make_golden.py:263-269): 2 % uniform background points -- nearly every farthest-point seed is a
+    # background point and stays a cluster of its own (order-dependent merge over ~S components, MS:41-76; relabel over ~S
+    # labels, MS:206-229).  Seeds and labels bit for bit, in both fp32 forms.
+    X, _ = syn.synth_unit_embeddings(4800, 64, clusters=8, sigma=0.15, seed=33, background_frac=0.02)
+    for precision in ("f32", "f32_split"):
+        labels, sel = ms.mean_shift_smart_init(X.to(DEV), kappa=20, num_seeds=50, max_iters=10, first_index=int(g["n_first"]),
+                                               precision=precision)
+        assert torch.equal(sel.cpu(), T(g["n_sel"]))
+        assert torch.equal(labels.cpu(), T(g["n_labels"]).long())
+        assert labels.unique().numel() == T(g["n_labels"]).unique().numel() > 40
+
+
+_NOISY_MS = {}
+
+
+def _noisy_mean_shift_case(size):
+    """Inputs and the CPU oracle's answer of the clustering with 2 % background points (computed once for the three precisions)."""
+    if size not in _NOISY_MS:
+        n, S, iters, k = {"640x480": (307200, 100, 10, 12), "1280x960": (1228800, 300, 20, 24)}[size]
+        X, ids = syn.synth_unit_embeddings(n, 64, clusters=k, sigma=0.15, seed=3, background_frac=0.02)
+        torch.set_num_threads(min(64, torch.get_num_threads()))
+        ref_labels, ref_sel, Z, seed_labels = O.mean_shift_smart_init(X, 20.0, S, iters, 11)
+        # per point: how far the best seed of ANOTHER cluster is behind the best seed (fp32 distances as the reference computes them):
+        # a point whose gap is at rounding level may legitimately land on either side
+        gap = torch.empty(n)
+        for lo in range(0, n, 65536):
+            d = 0.5 * (1 - X[lo:lo + 65536] @ Z.t())
+            best = d.argmin(1)
+            other = d.masked_fill(seed_labels[None, :] == seed_labels[best][:, None], 9.0)
+            gap[lo:lo + 65536] = other.min(1).values - d.min(1).values
+        _NOISY_MS[size] = dict(X=X, ids=ids, ref_labels=ref_labels, ref_sel=ref_sel, S=S, iters=iters, k=k, gap=gap,
+                               n_clusters=int(seed_labels.unique().numel()))
+    return _NOISY_MS[size]
+
+
+@pytest.mark.parametrize("precision", ["f32", "f32_split", "bf16"])
+@pytest.mark.parametrize("size", ["640x480", "1280x960"])
+def test_mean_shift_background_points_vs_oracle(size, precision):
+    """The stress variant SURVEY 8d names, at the sizes bench.py times: planted clusters + 2 % uniform background points.  The
+    farthest-point seeding (MS:128-189) then picks background points almost exclusively, every one of them stays a singleton
+    through the hill climb, and the order-dependent merge (MS:41-76), the assignment and the largest-cluster relabel (MS:206-229)
+    run over ~S clusters instead of a dozen.
+    f32 / f32_split: seed indices identical to the oracle's and labels identical EXCEPT at points whose two nearest clusters are
+    within rounding of each other in the oracle's own fp32 distances (gap < 2e-6; among 6 000 / 24 000 background points a handful
+    are equidistant to that level -- the reference's argmin there depends on the summation order of its BLAS); at most 1e-5 of
+    the points may be such.  bf16: distances are those of the rounded points, so other points may be picked -- the planted
+    clusters must still be recovered whole, and the number of clusters must be the oracle's to within 2 %."""
+    from unseenobjectswithmeanshift_amd import mean_shift as ms
+    c = _noisy_mean_shift_case(size)
+    X, ids, ref_labels, ref_sel, S = c["X"], c["ids"], c["ref_labels"], c["ref_sel"], c["S"]
+    n = X.shape[0]
+    labels, sel = ms.mean_shift_smart_init(X.to(DEV), kappa=20, num_seeds=S, max_iters=c["iters"], first_index=11, precision=precision)
+    lab, sel = labels.cpu(), sel.cpu()
+    n_lab = int(lab.unique().numel())
+    print(f"noisy mean shift {size} [{precision}]: {n_lab} clusters (oracle {c['n_clusters']}), seeds equal "
+          f"{float((sel == ref_sel).float().mean()):.3f}, background seeds {int((ids[sel] == -1).sum())} of {S}")
+    assert int(sel[0]) == 11 and sel.unique().numel() == S and int(sel.min()) >= 0 and int(sel.max()) < n
+    counts = torch.bincount(lab)
+    assert int(torch.argmax(counts)) == 0                                      # MS:217-227
+    planted = ids >= 0
+    if precision != "bf16":
+        assert torch.equal(sel, ref_sel)
+        diff = lab != ref_labels
+        print(f"  labels differ at {int(diff.sum())} of {n} points; largest oracle gap among them "
+              f"{float(c['gap'][diff].max()) if diff.any() else 0.0:.2e}; points with gap < 2e-6: {int((c['gap'] < 2e-6).sum())}")
+        assert int(diff.sum()) <= max(2, int(1e-5 * n))
+        assert not diff.any() or float(c["gap"][diff].max()) < 2e-6
+        assert n_lab == c["n_clusters"]
+    else:
+        # seeding on non-ideal data, sharply: the kernel's distances are those of the bf16-rounded points (exact products, fp32
+        # sums), so its picks must be the ORACLE's picks on the rounded copy -- up to near-ties resolved by summation order
+        ref_sel_r = _noisy_rounded_seeds(size)
+        same = float((sel == ref_sel_r).float().mean())
+        ari = _adjusted_rand(lab, ref_labels)
+        print(f"  bf16: seeds equal to the oracle's on the bf16-rounded copy {same:.3f}; adjusted Rand index against the fp32 oracle's "
+              f"labels {ari:.4f}")
+        assert same >= 0.95
+        assert abs(n_lab - c["n_clusters"]) <= max(2, int(0.03 * c["n_clusters"]))
+        assert int((ids[sel] == -1).sum()) >= int(0.9 * (ids[ref_sel] == -1).sum())
+        # the partition: on this input the reference itself leaves planted clusters split between half-converged background seeds
+        # (at 640x480 the oracle splits one cluster 52 / 48), so where a boundary falls depends on the last digits of the seeds --
+        # a bijection cannot be asked of ANY bf16 evaluation; the permutation-invariant score is stated and floored
+        assert ari >= 0.80
+
+
+def _noisy_rounded_seeds(size):
+    c = _noisy_mean_shift_case(size)
+    if "ref_sel_rounded" not in c:
+        Xr = c["X"].bfloat16().float()
+        c["ref_sel_rounded"] = O.select_smart_seeds(Xr, c["S"], 11)[1]
+    return c["ref_sel_rounded"]
+
+
+def _adjusted_rand(a, b):
+    """Adjusted Rand index of two labelings from their contingency table (float64)."""
+    ka, kb = int(a.max()) + 1, int(b.max()) + 1
+    tab = torch.bincount(a.long() * kb + b.long(), minlength=ka * kb).view(ka, kb).double()
+    comb = lambda x: x * (x - 1) / 2
+    s_ij, s_a, s_b, n = comb(tab).sum(), comb(tab.sum(1)).sum(), comb(tab.sum(0)).sum(), tab.sum()
+    exp = s_a * s_b / comb(n)
+    return float((s_ij - exp) / (0.5 * (s_a + s_b) - exp))
 
 
 def test_mean_shift_full_size_matches_oracle():
