@@ -84,6 +84,21 @@ def test_bench_launcher_spawns_ranks_gloo_stub():
     assert col["backend"] == "gloo" and col["world_size"] == 2 and col["all_gather_us"] > 0
     assert set(col["per_rank_elapsed_s"]) == {"min", "max", "spread_pct", "slowest_rank"} and col["per_rank_elapsed_s"]["min"] <= col["per_rank_elapsed_s"]["max"]
 
+    # the size the driver's scaling run uses: eight ranks, one JSON line, every rank's record gathered
+    r8 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--stub", "--steps", "3", "--warmup", "1"],
+                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r8.returncode == 0, r8.stderr[-2000:]
+    lines = [l for l in r8.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec8 = json.loads(lines[0])
+    assert rec8["n_gpus"] == 8 and rec8["config"]["global_batch"] == 64 and rec8["config"]["parallelism"] == "dp8"
+    assert [p["rank"] for p in rec8["per_rank"]] == list(range(8)) and all(p["images"] == 24.0 for p in rec8["per_rank"])
+    assert [p["checksum"] for p in rec8["per_rank"]] == [(k + 1) ** 2 * 64.0 ** 3 for k in range(8)]
+    # under torch.distributed.run the ranks exist already (WORLD_SIZE set): a --gpus that disagrees is refused
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub"], capture_output=True, text=True,
+                         timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0"), cwd=root)
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
+
 
 def test_rccl_debug_log_summary():
     """distributed.parse_rccl_debug: rank 0's NCCL_DEBUG=INFO log -> transport per channel connection, xGMI mentions, version line
@@ -104,20 +119,6 @@ node:101:215 [0] NCCL INFO Channel 00/0 : 7[7] -> 0[0] via P2P/IPC/read
     assert parse_rccl_debug("nothing useful")["transport"].startswith("unknown")
     assert parse_rccl_debug("x via P2P/IPC")["transport"].startswith("P2P only (no xGMI")
     assert communicator_report(None) == {"backend": None, "world_size": 1}
-    # the size the driver's scaling run uses: eight ranks, one JSON line, every rank's record gathered
-    r8 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--stub", "--steps", "3", "--warmup", "1"],
-                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
-    assert r8.returncode == 0, r8.stderr[-2000:]
-    lines = [l for l in r8.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    rec8 = json.loads(lines[0])
-    assert rec8["n_gpus"] == 8 and rec8["config"]["global_batch"] == 64 and rec8["config"]["parallelism"] == "dp8"
-    assert [p["rank"] for p in rec8["per_rank"]] == list(range(8)) and all(p["images"] == 24.0 for p in rec8["per_rank"])
-    assert [p["checksum"] for p in rec8["per_rank"]] == [(k + 1) ** 2 * 64.0 ** 3 for k in range(8)]
-    # under torch.distributed.run the ranks exist already (WORLD_SIZE set): a --gpus that disagrees is refused
-    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub"], capture_output=True, text=True,
-                         timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0"), cwd=root)
-    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
 
 
 def test_gather_metrics_single_process():
