@@ -86,6 +86,7 @@ enum {
     MSM_OPT_MASK_KERNEL,        /* fp32 mask step: 5 = never the 4-query block on the 4x4x1 MFMA (fallback kernel) */
     MSM_OPT_MS_SPLIT_KERNEL,    /* msm_ms_hill_climb_split: 1 = X split inside the iteration kernel (fallback of the pre-split planes) */
     MSM_OPT_CONV3_WIDE,         /* msm_conv3x3_c64_f32 / _bf16: 0 = one 16-pixel block per wave, 16 waves per workgroup; 1 = two blocks, 8 waves (default: bf16 only) */
+    MSM_OPT_LP_F16,             /* low-precision decoder tails (msm_dec_*_bf16, msm_dec_pack_weight_bf16): 1 = fp16 weights with hi + lo fp16 activations, 2 = fp16 weights with one fp16 activation term (default: bf16 weights, hi + lo bf16 activations); set BEFORE the weights are packed */
     MSM_OPT_COUNT
 };
 int msm_set_option(int key, int value);

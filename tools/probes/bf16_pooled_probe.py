@@ -102,7 +102,24 @@ def v_f32():
     head.set_precision("f32")
 
 
-VARIANTS = {"default": v_default, "round3": v_round3, "f32": v_f32, "parts": v_parts, "storage": v_storage}
+def v_tails_f16():
+    """The decoder tails with fp16 instead of bf16 weights (MSM_OPT_LP_F16; same bytes, same MFMA rate): alone and inside the plan.
+    A fresh head per setting: the packed weights are cached per parameter version, not per option."""
+    global head
+    from unseenobjectswithmeanshift_amd import _lib
+    keep = head
+    for opt, label in ((1, "fp16 weights, hi + lo fp16 activations"), (2, "fp16 weights, one fp16 activation term")):
+        with _lib.option("LP_F16", opt):
+            head = tc.make_head()
+            head.set_precision("f32")
+            head.predictor.tails_dtype = "bf16"
+            score(f"only tails 16-bit: {label}")
+            head.set_precision("bf16")
+            score(f"whole plan, tails: {label}")
+    head = keep
+
+
+VARIANTS = {"default": v_default, "round3": v_round3, "f32": v_f32, "parts": v_parts, "storage": v_storage, "tails_f16": v_tails_f16}
 
 if __name__ == "__main__":
     for name in (sys.argv[1:] or list(VARIANTS)):

@@ -25,6 +25,13 @@ __device__ __forceinline__ u32x2b pack4h(float a, float b, float c, float d) {
     const f16x2_t lo = {(_Float16)clamp_h(a), (_Float16)clamp_h(b)}, hi = {(_Float16)clamp_h(c), (_Float16)clamp_h(d)};
     return u32x2b{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
 }
+// v_mfma_f32_16x16x32_f16: operand layout of the bf16 K = 32 form (below), IEEE half operands, the same issue rate
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f16x8 cvt8h(float a, float b, float c, float d, float e, float f, float g, float h) {
+    return f16x8{(_Float16)clamp_h(a), (_Float16)clamp_h(b), (_Float16)clamp_h(c), (_Float16)clamp_h(d), (_Float16)clamp_h(e), (_Float16)clamp_h(f),
+                 (_Float16)clamp_h(g), (_Float16)clamp_h(h)};
+}
+__device__ __forceinline__ f32x4b mfma_f16k32(f16x8 a, f16x8 b, f32x4b c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ float half_lo(unsigned packed) { return (float)__builtin_bit_cast(f16x2_t, packed)[0]; }
 __device__ __forceinline__ float half_hi(unsigned packed) { return (float)__builtin_bit_cast(f16x2_t, packed)[1]; }
 // v_mfma_f32_16x16x16_bf16: A lane (i = l & 15, kq = l >> 4) holds A[i][4 kq .. 4 kq + 3], B lane (j, kq) holds B[4 kq .. + 3][j],

@@ -69,6 +69,24 @@ struct TileH16 {
     using WT = uint16_t;
     static constexpr int R = 16, LD = DC_E + 4, RG = 1;
 };
+// fp16 weights (same bytes as bf16, 11 instead of 8 significand bits: weights are O(0.01 .. 1), far inside the fp16 range) on
+// v_mfma_f32_16x16x32_f16 -- the same rate as the bf16 instruction.  f16w: the activation fragment as hi + lo fp16 terms (two
+// MFMAs per pair of k-steps, like the bf16 form); f16s: one fp16 term (one MFMA: the activation's own rounding, 2^-12, is then of
+// the order of the weight's).
+struct f16w {
+    uint16_t v;
+};
+struct f16s {
+    uint16_t v;
+};
+struct TileQ16 {
+    using WT = f16w;
+    static constexpr int R = 16, LD = DC_E + 4, RG = 1;
+};
+struct TileQ16S {
+    using WT = f16s;
+    static constexpr int R = 16, LD = DC_E + 4, RG = 1;
+};
 #ifndef MSM_DC_NW
 #define MSM_DC_NW 8
 #endif
@@ -92,6 +110,10 @@ template <>
 struct BFrag<uint16_t> {
     u32x4b v[2][DC_NT][2];
 };
+template <>
+struct BFrag<f16w> : BFrag<uint16_t> {};
+template <>
+struct BFrag<f16s> : BFrag<uint16_t> {};
 // W: packed weight, advanced to the first of the 256 output rows wanted (row offset n0 -> + n0*K elements);
 // kct = K/64 of the packed matrix; kc0 = first of the two k-chunks to fetch
 // (Rotating the k-chunk order per workgroup to de-phase their L2 accesses was measured: -3 % kernel time, and it
@@ -223,12 +245,50 @@ __device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT][1], const float* _
         }
     }
 }
+// fp16 weights: the same fragment layout and loads as bf16
+__device__ __forceinline__ void bload(BFrag<f16w>& f, const f16w* __restrict__ W, int kct, int kc_base, int half) {
+    bload(static_cast<BFrag<uint16_t>&>(f), reinterpret_cast<const uint16_t*>(W), kct, kc_base, half);
+}
+__device__ __forceinline__ void bload(BFrag<f16s>& f, const f16s* __restrict__ W, int kct, int kc_base, int half) {
+    bload(static_cast<BFrag<uint16_t>&>(f), reinterpret_cast<const uint16_t*>(W), kct, kc_base, half);
+}
+template <bool SINGLE>
+__device__ __forceinline__ void mfma_half_f16(f32x4 (&acc)[DC_NT][1], const float* __restrict__ ap, const BFrag<uint16_t>& f, int half) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float4 a[4];
+        const int kc = half * 2 + h;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(ap + kc * 64 + u * 16);
+#pragma unroll
+        for (int up = 0; up < 2; ++up) {
+            const float4 p = a[2 * up], q = a[2 * up + 1];
+            const f16x8 xh = cvt8h(p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w);
+            if constexpr (!SINGLE) {
+                const f16x8 xl = cvt8h(p.x - (float)xh[0], p.y - (float)xh[1], p.z - (float)xh[2], p.w - (float)xh[3], q.x - (float)xh[4],
+                                       q.y - (float)xh[5], q.z - (float)xh[6], q.w - (float)xh[7]);
+#pragma unroll
+                for (int t = 0; t < DC_NT; ++t) acc[t][0] = mfma_f16k32(xl, __builtin_bit_cast(f16x8, f.v[h][t][up]), acc[t][0]);
+            }
+#pragma unroll
+            for (int t = 0; t < DC_NT; ++t) acc[t][0] = mfma_f16k32(xh, __builtin_bit_cast(f16x8, f.v[h][t][up]), acc[t][0]);
+        }
+    }
+}
+__device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT][1], const float* __restrict__ ap, const BFrag<f16w>& f, int half) {
+    mfma_half_f16<false>(acc, ap, f, half);
+}
+__device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT][1], const float* __restrict__ ap, const BFrag<f16s>& f, int half) {
+    mfma_half_f16<true>(acc, ap, f, half);
+}
 // prefetch loads per half stage (bload) and MFMAs between two of them
 template <typename TK>
 struct Pipe {
     static constexpr int LOADS = std::is_same<typename TK::WT, float>::value ? 8 * DC_NT : 4 * DC_NT;
-    // MFMAs between two prefetch loads: 8-row fp32 has two 8-cycle MFMAs where the 16-row form has one of 32; bf16 has 8 * DC_NT per half stage
-    static constexpr int IL = !std::is_same<typename TK::WT, float>::value ? DC_IL / 2 : (TK::RG == 2 ? 2 * DC_IL : DC_IL);
+    // MFMAs between two prefetch loads: 8-row fp32 has two 8-cycle MFMAs where the 16-row form has one of 32; bf16 / fp16 hi + lo have 8 * DC_NT
+    // per half stage, the single-term fp16 form 4 * DC_NT
+    static constexpr int IL = std::is_same<typename TK::WT, f16s>::value ? 1
+                              : !std::is_same<typename TK::WT, float>::value ? DC_IL / 2 : (TK::RG == 2 ? 2 * DC_IL : DC_IL);
 };
 
 // D[16][256] = act(A[16][256] . W[n][k]^T + bias).  A in LDS.  TO_GLOBAL: D is row-major global with row stride
@@ -571,6 +631,7 @@ __global__ __launch_bounds__(256) void dec_pack_weight_kernel(const float* __res
 }
 
 // bf16: packed[(((t*(K/64) + kc)*2 + up)*64 + lane)*8 + h*4 + c] = bf16(W[t*16 + lj][kc*64 + (2 up + h)*16 + lq*4 + c])
+template <bool F16>
 __global__ __launch_bounds__(256) void dec_pack_weight_bf16_kernel(const float* __restrict__ w, uint16_t* __restrict__ packed, int N,
                                                                    int K) {
     const int64_t total8 = (int64_t)N * K / 8;
@@ -584,8 +645,12 @@ __global__ __launch_bounds__(256) void dec_pack_weight_bf16_kernel(const float* 
         const int lj = lane & 15, lq = lane >> 4;
         const float* src = w + (int64_t)(t * 16 + lj) * K + kc * 64 + (2 * up) * 16 + lq * 4;
         const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 16);
-        const bf16x4 pa = pack4(a.x, a.y, a.z, a.w), pb = pack4(b.x, b.y, b.z, b.w);
-        const u32x2b ua = __builtin_bit_cast(u32x2b, pa), ub = __builtin_bit_cast(u32x2b, pb);
+        u32x2b ua, ub;
+        if constexpr (F16) {
+            ua = pack4h(a.x, a.y, a.z, a.w), ub = pack4h(b.x, b.y, b.z, b.w);
+        } else {
+            ua = __builtin_bit_cast(u32x2b, pack4(a.x, a.y, a.z, a.w)), ub = __builtin_bit_cast(u32x2b, pack4(b.x, b.y, b.z, b.w));
+        }
         *reinterpret_cast<u32x4b*>(packed + i * 8) = u32x4b{ua.x, ua.y, ub.x, ub.y};
     }
 }
@@ -612,8 +677,12 @@ extern "C" int msm_dec_pack_weight_bf16(const float* w, uint16_t* packed, int N,
     MSM_REQUIRE(N > 0 && K > 0 && N % 16 == 0 && K % 64 == 0, "msm_dec_pack_weight_bf16: N=%d must be a multiple of 16, K=%d of 64", N, K);
     MSM_REQUIRE(aligned16(w) && aligned16(packed), "msm_dec_pack_weight_bf16: pointers must be 16-byte aligned");
     const int64_t total8 = (int64_t)N * K / 8;
-    hipLaunchKernelGGL(dec_pack_weight_bf16_kernel, dim3((unsigned)min((int64_t)2048, (total8 + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, w, packed, N, K);
+    if (opt(MSM_OPT_LP_F16) > 0)
+        hipLaunchKernelGGL(dec_pack_weight_bf16_kernel<true>, dim3((unsigned)min((int64_t)2048, (total8 + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, w, packed, N, K);
+    else
+        hipLaunchKernelGGL(dec_pack_weight_bf16_kernel<false>, dim3((unsigned)min((int64_t)2048, (total8 + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, w, packed, N, K);
     MSM_CHECK_LAUNCH("msm_dec_pack_weight_bf16");
     return MSM_OK;
 }
@@ -648,6 +717,12 @@ extern "C" int msm_dec_post_cross(const float* attn_out, const float* res, const
 extern "C" int msm_dec_post_cross_bf16(const float* attn_out, const float* res, const float* query_pos, const uint16_t* wo,
                                        const float* bo, const float* ln_g, const float* ln_b, const uint16_t* w_in, const float* b_in,
                                        float* x_out, float* qk_out, float* v_out, int rows, int Q, int E, float eps, void* stream) {
+    if (opt(MSM_OPT_LP_F16) == 1)
+        return dec_post_cross_impl<TileQ16>("msm_dec_post_cross_bf16", attn_out, res, query_pos, (const f16w*)wo, bo, ln_g, ln_b, (const f16w*)w_in, b_in,
+                                            x_out, qk_out, v_out, rows, Q, E, eps, stream);
+    if (opt(MSM_OPT_LP_F16) == 2)
+        return dec_post_cross_impl<TileQ16S>("msm_dec_post_cross_bf16", attn_out, res, query_pos, (const f16s*)wo, bo, ln_g, ln_b, (const f16s*)w_in, b_in,
+                                             x_out, qk_out, v_out, rows, Q, E, eps, stream);
     return dec_post_cross_impl<TileH16>("msm_dec_post_cross_bf16", attn_out, res, query_pos, wo, bo, ln_g, ln_b, w_in, b_in, x_out, qk_out,
                                          v_out, rows, Q, E, eps, stream);
 }
@@ -679,6 +754,12 @@ extern "C" int msm_dec_post_self(const float* attn_out, const float* res, const 
 extern "C" int msm_dec_post_self_bf16(const float* attn_out, const float* res, const uint16_t* wo, const float* bo, const float* ln_g,
                                       const float* ln_b, const uint16_t* w1, const float* b1, const uint16_t* w2, int F, float* x_out,
                                       float* parts, int n_parts, int rows, int E, float eps, void* stream) {
+    if (opt(MSM_OPT_LP_F16) == 1)
+        return dec_post_self_impl<TileQ16>("msm_dec_post_self_bf16", attn_out, res, (const f16w*)wo, bo, ln_g, ln_b, (const f16w*)w1, b1, (const f16w*)w2, F,
+                                           x_out, parts, n_parts, rows, E, eps, stream);
+    if (opt(MSM_OPT_LP_F16) == 2)
+        return dec_post_self_impl<TileQ16S>("msm_dec_post_self_bf16", attn_out, res, (const f16s*)wo, bo, ln_g, ln_b, (const f16s*)w1, b1, (const f16s*)w2, F,
+                                            x_out, parts, n_parts, rows, E, eps, stream);
     return dec_post_self_impl<TileH16>("msm_dec_post_self_bf16", attn_out, res, wo, bo, ln_g, ln_b, w1, b1, w2, F, x_out, parts, n_parts, rows, E,
                                         eps, stream);
 }
@@ -718,6 +799,12 @@ extern "C" int msm_dec_heads_bf16(const float* x, const float* parts, int n_part
                                   const float* m0b, const uint16_t* m1w, const float* m1b, const uint16_t* m2w, const float* m2b,
                                   const uint16_t* wq, const float* bq, const float* query_pos, float* out, float* d_out, float* e_out,
                                   float* q_out, int32_t* row_any_zero, int rows, int Q, int E, float eps, void* stream) {
+    if (opt(MSM_OPT_LP_F16) == 1)
+        return dec_heads_impl<TileQ16>("msm_dec_heads_bf16", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, (const f16w*)m0w, m0b, (const f16w*)m1w,
+                                       m1b, (const f16w*)m2w, m2b, (const f16w*)wq, bq, query_pos, out, d_out, e_out, q_out, row_any_zero, rows, Q, E, eps, stream);
+    if (opt(MSM_OPT_LP_F16) == 2)
+        return dec_heads_impl<TileQ16S>("msm_dec_heads_bf16", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, (const f16s*)m0w, m0b, (const f16s*)m1w,
+                                        m1b, (const f16s*)m2w, m2b, (const f16s*)wq, bq, query_pos, out, d_out, e_out, q_out, row_any_zero, rows, Q, E, eps, stream);
     return dec_heads_impl<TileH16>("msm_dec_heads_bf16", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, m0w, m0b, m1w, m1b, m2w, m2b,
                                     wq, bq, query_pos, out, d_out, e_out, q_out, row_any_zero, rows, Q, E, eps, stream);
 }
