@@ -59,7 +59,7 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 14   /* 14: cmat_width argument of the K/V projections (separable position constants), msm_conv3x3_c64_nchw_bf16, msm_encoder_prologue_hm_fwd; 13: flags argument of msm_ms_select_seeds_bf16 (persistent on-chip seeding over the bf16 copy), input projections on the bf16 matrix pipe (msm_conv1x1_in_lp, msm_conv1x1_in_multi_lp); 12: head-major bf16 activations between the encoder kernels of the bf16 plan (msm_encoder_block_hm_fwd, msm_msdeform_attn_enc_lp_fwd, msm_f32_to_f16); 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
+#define MSM_ABI_VERSION 15   /* 15: IEEE-half operand forms of the 16-bit plan (precision "f16": msm_dec_*_f16, msm_encoder_block_hm_fwd ffn_f16, fp16 keys in the low-precision attention); 14: cmat_width argument of the K/V projections (separable position constants), msm_conv3x3_c64_nchw_bf16, msm_encoder_prologue_hm_fwd; 13: flags argument of msm_ms_select_seeds_bf16 (persistent on-chip seeding over the bf16 copy), input projections on the bf16 matrix pipe (msm_conv1x1_in_lp, msm_conv1x1_in_multi_lp); 12: head-major bf16 activations between the encoder kernels of the bf16 plan (msm_encoder_block_hm_fwd, msm_msdeform_attn_enc_lp_fwd, msm_f32_to_f16); 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
 int msm_abi_version(void);
 
 /* Kernel-selection overrides for tools/ and tests/ (NOT read on the product path: every option defaults to
@@ -86,7 +86,6 @@ enum {
     MSM_OPT_MASK_KERNEL,        /* fp32 mask step: 5 = never the 4-query block on the 4x4x1 MFMA (fallback kernel) */
     MSM_OPT_MS_SPLIT_KERNEL,    /* msm_ms_hill_climb_split: 1 = X split inside the iteration kernel (fallback of the pre-split planes) */
     MSM_OPT_CONV3_WIDE,         /* msm_conv3x3_c64_f32 / _bf16: 0 = one 16-pixel block per wave, 16 waves per workgroup; 1 = two blocks, 8 waves (default: bf16 only) */
-    MSM_OPT_LP_F16,             /* low-precision decoder tails (msm_dec_*_bf16, msm_dec_pack_weight_bf16): 1 = fp16 weights with hi + lo fp16 activations, 2 = fp16 weights with one fp16 activation term (default: bf16 weights, hi + lo bf16 activations); set BEFORE the weights are packed */
     MSM_OPT_COUNT
 };
 int msm_set_option(int key, int value);
@@ -224,11 +223,14 @@ int msm_hypersphere_attn_fwd(const float* q, const float* k, const float* v,
                              int64_t ldv, int64_t v_sb, float kappa,
                              float* workspace, int64_t workspace_elems, void* stream);
 /* Low-precision form (BASELINE configs 3 / 5; the reference's counterpart is torch.autocast): q^, k^, the probabilities and V
- * enter v_mfma_f32_16x16x16_bf16 as bf16 operands, accumulation / exp / row sums / normalisations stay fp32.  k and v are
- * fp32 (kv_bf16 == 0: the self-attention operands written by msm_dec_post_cross) or bf16 (kv_bf16 != 0: as written by
- * msm_kv_project_multi_bf16); ldk / k_sb / ldv / v_sb are in ELEMENTS of that type and must keep k rows 16-byte aligned.
+ * enter the bf16 MFMAs as bf16 operands, accumulation / exp / row sums / normalisations stay fp32.  kv_format: 0 = k and v fp32
+ * (the self-attention operands written by msm_dec_post_cross); 1 = both bf16 (as written by msm_kv_project_multi_bf16);
+ * 2 (precision "f16") = k IEEE half and v bf16 (msm_kv_project_multi_bf16 with half_format = 1) with q^ / k^ on
+ * v_mfma_f32_16x16x32_f16 -- kappa = 30 multiplies the cosine's rounding: 2 % of a softmax weight with bf16 operands, 0.25 % with
+ * fp16; the probabilities (e^-60 .. 1) and V stay bf16 --; 3 = fp32 k / v with the fp16 score operands of 2.
+ * ldk / k_sb / ldv / v_sb are in ELEMENTS of the storage type and must keep k rows 16-byte aligned.
  * Everything else as msm_hypersphere_attn_fwd (same workspace size). */
-int msm_hypersphere_attn_lp_fwd(const float* q, const void* k, const void* v, int kv_bf16,
+int msm_hypersphere_attn_lp_fwd(const float* q, const void* k, const void* v, int kv_format,
                                 const uint8_t* masked, const int32_t* row_any, float* out,
                                 int B, int Lq, int S, int heads,
                                 int64_t ldq, int64_t q_sb, int64_t ldk, int64_t k_sb,
@@ -344,10 +346,13 @@ int msm_kv_project_multi_f32(int n_jobs, const float* const* x, const float* con
                              const int32_t* cmat_width, int B, int C, int N, void* stream);
 /* The same with the result stored as bf16 (low-precision mode): half the bytes of this write-bound launch and of the K/V
  * reads of msm_hypersphere_attn_lp_fwd.  w is rounded to one bf16 and x enters as a hi + lo pair (bf16 MFMAs, fp32
- * accumulation; MSM_OPT_KV_PIPE = 0: exact fp32 MFMAs, only the stored value rounded). */
+ * accumulation; MSM_OPT_KV_PIPE = 0: exact fp32 MFMAs, only the stored value rounded).
+ * half_format = 1 (precision "f16"; N = 512 = [K | V]): w and x enter v_mfma_f32_16x16x32_f16 as one IEEE-half term each (one MFMA
+ * per product instead of two; 2^-12 roundings instead of w's 2^-9), the K columns [0, N/2) are stored as IEEE half, the V columns
+ * as bf16: the layout msm_hypersphere_attn_lp_fwd reads with kv_format = 2. */
 int msm_kv_project_multi_bf16(int n_jobs, const float* const* x, const float* const* w, const float* const* cmat,
                               uint16_t* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride,
-                              const int32_t* cmat_width, int B, int C, int N, void* stream);
+                              const int32_t* cmat_width, int B, int C, int N, int half_format, void* stream);
 /* fp32 results on the bf16 matrix pipe (exact three-term splits of x and w, six K = 32 MFMAs per product; see
  * msm_encoder_block_split_fwd): same arguments and output as msm_kv_project_multi_f32. */
 int msm_kv_project_multi_split(int n_jobs, const float* const* x, const float* const* w, const float* const* cmat,
@@ -430,6 +435,31 @@ int msm_dec_heads_bf16(const float* x, const float* parts, int n_parts, const fl
                        const uint16_t* wq, const float* bq, const float* query_pos,
                        float* out, float* d_out, float* e_out, float* q_out, int32_t* row_any_zero,
                        int rows, int Q, int E, float eps, void* stream);
+
+/* The same three tails with IEEE-half MFMA operands (precision "f16": the 16-bit plan with the smaller rounding error).  Weight
+ * matrices are the packed form of msm_dec_pack_weight_f16 -- the bf16 layout above with fp16(W) elements (Linear weights are
+ * O(0.01 .. 1): three more significand bits, no range concern) -- and the activation fragment enters v_mfma_f32_16x16x32_f16 as
+ * ONE fp16 term, clamped to +-65504 (its rounding is of the weight's order, so the hi + lo pair of the bf16 form buys nothing):
+ * half the MFMAs of the bf16 tails and an eighth of their rounding error (0.2 % against 0.85 % of the final
+ * mask bits for the tails alone; 28 us per layer against 32 at 800 rows).  Everything else as the bf16 form. */
+int msm_dec_pack_weight_f16(const float* w, uint16_t* packed, int N, int K, void* stream);
+int msm_dec_post_cross_f16(const float* attn_out, const float* res, const float* query_pos,
+                           const uint16_t* wo, const float* bo, const float* ln_g, const float* ln_b,
+                           const uint16_t* w_in, const float* b_in,
+                           float* x_out, float* qk_out, float* v_out,
+                           int rows, int Q, int E, float eps, void* stream);
+int msm_dec_post_self_f16(const float* attn_out, const float* res,
+                          const uint16_t* wo, const float* bo, const float* ln_g, const float* ln_b,
+                          const uint16_t* w1, const float* b1, const uint16_t* w2, int F,
+                          float* x_out, float* parts, int n_parts, int rows, int E, float eps, void* stream);
+int msm_dec_heads_f16(const float* x, const float* parts, int n_parts, const float* bias,
+                      const float* ln_g, const float* ln_b, int l2norm,
+                      const float* dec_g, const float* dec_b,
+                      const uint16_t* m0w, const float* m0b, const uint16_t* m1w, const float* m1b,
+                      const uint16_t* m2w, const float* m2b,
+                      const uint16_t* wq, const float* bq, const float* query_pos,
+                      float* out, float* d_out, float* e_out, float* q_out, int32_t* row_any_zero,
+                      int rows, int Q, int E, float eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward of msm_hypersphere_attn_fwd (training step of the reference: hypersphere_attention under autograd, AU:64-82,
@@ -617,18 +647,18 @@ int msm_conv3x3_c64_nchw_bf16(const float* in, const float* w_tap_major, const f
  *   wstream: value_proj weight (64,64) then the (proj_width,64) weight, as consecutive 16-row blocks of 1024 floats,
  *   zero-padded to msm_encoder_prologue_stream_floats(proj_width); small = [value_proj bias (64) | proj bias].
  * n_levels <= 4, S >= 86, proj_width a multiple of 16 and <= 512 (the weights are held in LDS).
- * out_bf16_hm != 0 (8 heads, proj_width 288): value_out / proj_out are the bf16 plan's head-major fp16 tensors [B][8][S][8] and
- * [B][8][S][36] (see msm_encoder_block_hm_fwd) instead of fp32. */
+ * out_bf16_hm != 0 (8 heads, proj_width 288): value_out / proj_out are the bf16 plan's head-major tensors -- value [B][8][S][8] fp16,
+ * proj [B][8][120 S bytes] (fp32 offsets + fp16 logits, plane-major; see msm_encoder_block_hm_fwd) -- instead of fp32. */
 int64_t msm_encoder_prologue_stream_floats(int proj_width);
 int msm_encoder_prologue_fwd(const float* raw, const double* stats, const float* gn_params, const int32_t* level_starts,
                              int n_levels, int groups, float gn_eps, const float* wstream, const float* small,
                              const float* pos, float* src_out, void* value_out, void* proj_out, int B, int S,
                              int proj_width, int value_heads, int out_bf16_hm, void* stream);
-/* The same prologue for the bf16 plan (csrc/enc_lp.hip, enc_prologue_hm_kernel): value [B][8][S][8] and the sampling record
- * [B][8][S][36] in fp16, the two projections on the bf16 matrix pipe with hi + lo operands (132 MFMAs of 16 cycles per 16-token tile
+/* The same prologue for the bf16 plan (csrc/enc_lp.hip, enc_prologue_hm_kernel): value [B][8][S][8] in fp16 and the sampling
+ * projection [B][8][120 S bytes] (fp32 offsets + fp16 logits, plane-major), the two projections on the bf16 matrix pipe with hi + lo operands (132 MFMAs of 16 cycles per 16-token tile
  * instead of 352 of 32).  wblocks: msm_encoder_prologue_hm_weight_bytes() bytes = the value_proj blocks (16 KiB) and the projection
  * blocks (72 KiB) exactly as msm_encoder_block_hm_fwd's stream holds them ([row block][k-group][hi, lo] 1-KiB fragments, rows in the
- * value / (head, 36) orders); small: bv [64] and bp [288] in those row orders. */
+ * value order / the reference's [192 offsets | 96 logits] order); small: bv [64] and bp [288] in those row orders. */
 int64_t msm_encoder_prologue_hm_weight_bytes(void);
 int msm_encoder_prologue_hm_fwd(const float* raw, const double* stats, const float* gn_params, const int32_t* level_starts, int n_levels,
                                 int groups, float gn_eps, const void* wblocks, const float* small, const float* pos, float* src_out,
@@ -659,10 +689,13 @@ int msm_encoder_block_lp_fwd(const float* attn, const float* src, const void* ws
 /* ---- the bf16 plan's encoder layers with head-major bf16 activations between the kernels (csrc/enc_lp.hip) ----------------
  * Replaces, per layer, MSDeformAttn.forward (ops/modules/ms_deform_attn.py:95-125) + the rest of
  * MSDeformAttnTransformerEncoderLayer.forward (pixel_decoder/msdeformattn.py:116-131) when the model runs in the low-precision
- * mode (BASELINE configs[2] / configs[4]).  All three 16-bit tensors are IEEE half (fp16, not bf16: same bytes, three more mantissa bits; bf16 offsets cost 1 % of
- * the final mask bits): value_hm / attn_hm [B][8 heads][S][8 dims]; proj_hm [B][8][S][36] = per (image, head, query) the head's 24
- * sampling offsets ((level, point, xy) order) and 12 attention logits.  The matrix pipe multiplies bf16 operands (an fp16 value
- * is a hi + lo bf16 pair exactly); the residual stream stays fp32.
+ * mode (BASELINE configs[2] / configs[4]).  value_hm / attn_hm [B][8 heads][S][8 dims] are IEEE half (fp16, not bf16: same bytes,
+ * three more mantissa bits).  proj_hm [B][8][120 S bytes] holds, per (image, head), the head's 24 sampling offsets ((level, point,
+ * xy) order) of every query as FLOAT32 and its 12 attention logits as fp16, plane-major: six planes [S][4 floats] (offsets 4 p ..
+ * 4 p + 3), then three planes [S][4 halves] (logits 4 p .. 4 p + 3) -- offsets are pixel distances of several pixels, and an fp16
+ * offset (2^-11 |o| ~ 2e-3 pixel) alone put 6e-3 of relative error into the encoder output (round 5; bf16 offsets: 5e-2); planes make
+ * the producers' stores contiguous over the 16 consecutive tokens of a tile.
+ * The matrix pipe multiplies bf16 operands (an fp16 value is a hi + lo bf16 pair exactly); the residual stream stays fp32.
  *
  * msm_encoder_block_hm_fwd: src_out = LN2(x + linear2(relu(linear1(x)))), x = LN1(src + output_proj(attn));
  *   value_out / proj_out (both null for the last layer) = the NEXT layer's value_proj(src_out) and
@@ -673,15 +706,19 @@ int msm_encoder_block_lp_fwd(const float* attn, const float* src, const void* ws
  *   4 (rb >> 1) + lq, dim 4 (rb & 1) + r; k order L: feature (2 G + (j >> 2)) 16 + 4 kq + (j & 3)); then per pair P of 16-wide
  *   hidden blocks 8 KiB = W1 [q 2][G 2] (rows hidden 16 (2 P + q) + i, k order L) | W2 [ob 4] (rows feature 16 ob + i, k = hidden
  *   (2 P + (j >> 2)) 16 + 4 kq + (j & 3)); four pairs per 32-KiB stage, the hidden dimension zero-padded to whole stages; then
- *   (with_next) three stages of eight projection row blocks [rb][G 2][h, l] (rows in (head, 36) order, k order L), zero padded.
+ *   (with_next) three stages of eight projection row blocks [rb][G 2][h, l] (rows: the offsets of all heads, 24 head + c, then the
+ *   logits, 192 + 12 head + c; k order L), zero padded.
  *   small (msm_encoder_block_hm_small_floats(d_ffn) floats) = output_proj bias | norm1 w | norm1 b | linear2 bias | norm2 w |
- *   norm2 b | value_proj bias (row order above) | projection bias (288, (head, 36) order) | linear1 bias (zero padded).
- *   M = B * tokens_per_image tokens; pos [tokens_per_image][64]. */
+ *   norm2 b | value_proj bias (row order above) | projection bias (288, the row order above) | linear1 bias (zero padded).
+ *   M = B * tokens_per_image tokens; pos [tokens_per_image][64].
+ *   ffn_f16 != 0 (precision "f16"): the W1 / W2 blocks of the FFN stages hold IEEE-half bit patterns (same layout), linear1 takes x
+ *   and linear2 the hidden activation as one fp16 term each (v_mfma_f32_16x16x32_f16; 8 instead of 12 MFMAs per pair of hidden
+ *   blocks, roundings of 2^-12 where the bf16 form has 2^-9); the resident / projection blocks stay [h, l] bf16 pairs. */
 int64_t msm_encoder_block_hm_stream_bytes(int d_ffn, int with_next);
 int msm_encoder_block_hm_small_floats(int d_ffn);
 int msm_encoder_block_hm_fwd(const void* attn_hm, const float* src, const void* wstream, const float* small, const float* pos,
                              float* src_out, void* value_out, void* proj_out, int M, int tokens_per_image, int d_ffn, float eps,
-                             void* stream);
+                             int ffn_f16, void* stream);
 /* msm_msdeform_attn_enc_lp_fwd: out_hm = MSDeformAttn core (ms_deform_im2col_cuda.cuh:242-304) over the fp16 value_hm with the
  *   sampling offsets / attention logits of proj_hm (encoder self-attention: reference points = pixel centres,
  *   msdeformattn.py:141-153; softmax over the 12 logits, ms_deform_attn.py:102-109).  Shipped geometry only: M = 8, D = 8, L = 3, P = 4.

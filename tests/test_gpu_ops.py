@@ -996,13 +996,16 @@ def test_encoder_block_hm(B, S, want_next):
     assert float(err.max()) < 1e-2 and float((err > 2e-3).float().mean()) < 1e-4 and float(err.mean()) < 1e-4
     assert float((so.cpu() - y32).abs().max()) < 0.1 and float((so.cpu() - y32).abs().mean()) < 5e-3
     if want_next:
-        assert vh.shape == (B, 8, S, 8) and vh.dtype == torch.float16 and ph.shape == (B, 8, S, 36) and ph.dtype == torch.float16
+        assert vh.shape == (B, 8, S, 8) and vh.dtype == torch.float16 and ph.shape == (B, 8, S, 30) and ph.dtype == torch.float32
         yk = so.cpu()                                          # the kernel's own layer output feeds its projections
         got = vh.float().cpu().permute(0, 2, 1, 3).reshape(B, S, C)
         close(got, linx(yk, wv, bv).float(), rtol=2 ** -10, atol=2e-4)         # one fp16 rounding of an fp32-class result
-        pref = ops().proj_to_head_major_f16(d(linx(yk + pos, wp, bp).float())).float().cpu()
-        close(ph.float().cpu(), pref, rtol=2 ** -10, atol=2e-4)                # (a value on a rounding boundary may round the other way)
-        assert float((ph.float().cpu() - pref).abs().mean()) < 1e-4
+        # the sampling records (round 5): 24 offsets in fp32 -- an fp32-class result (hi + lo operands: 2^-17) --, 12 logits in fp16
+        pexact = linx(yk + pos, wp, bp).float()
+        pgot = ops().proj_records_to_columns(ph).cpu()
+        close(pgot[..., :192], pexact[..., :192], rtol=1e-4, atol=1e-4)        # (three-term bf16 products: 2^-17 per term on O(1 .. 10) sums)
+        close(pgot[..., 192:], pexact[..., 192:], rtol=2 ** -10, atol=2e-4)    # (a value on a rounding boundary may round the other way)
+        assert torch.equal(ops().proj_records_to_columns(ops().proj_to_head_major_records(d(pexact))).cpu()[..., :192], pexact[..., :192])
     else:
         assert vh is None and ph is None
     with pytest.raises(RuntimeError):
@@ -1013,7 +1016,7 @@ def test_encoder_block_hm(B, S, want_next):
 
 @pytest.mark.parametrize("B,shp", [(2, [(6, 8), (12, 16), (24, 32)]), (8, [(15, 20), (30, 40), (60, 80)]), (1, [(2, 3), (4, 6), (8, 12)])])
 def test_msda_encoder_lp(B, shp):
-    """The bf16 plan's gathers (fp16 value taps, fp16 result; sampling projection read as head-major fp16 records, or computed in
+    """The bf16 plan's gathers (fp16 value taps, fp16 result; sampling projection read as head-major 120-byte records, or computed in
     the kernel from src + pos) against the fp32 pair they replace -- F.linear for [sampling_offsets | attention_weights](src + pos),
     msm_msdeform_attn_enc_hm_fwd on the same (bf16-valued) value."""
     M, D, L, P = 8, 8, 3, 4
@@ -1026,12 +1029,12 @@ def test_msda_encoder_lp(B, shp):
     wp[:192] *= 4.0                                              # offsets of a few pixels
     d = lambda t: t.to(DEV).contiguous()
     proj = F.linear((src + pos).double(), wp.double(), bp.double()).float()
-    # stored projection: the reference sees the fp16-rounded offsets / logits the kernel reads -> only the result's rounding is left
-    proj_hm = ops().proj_to_head_major_f16(d(proj))
-    assert proj_hm.shape == (B, M, S, 36)
-    pr = proj_hm.float().cpu()                                   # back to the reference's column order
-    proj_r = torch.cat([pr[..., :24].permute(0, 2, 1, 3).reshape(B, S, 192), pr[..., 24:].permute(0, 2, 1, 3).reshape(B, S, 96)], -1)
-    ref = ops().ms_deform_attn_encoder(d(value.float()), d(shapes), d(start), d(proj_r), M, P)      # (B, S, 64)
+    # stored projection: the reference sees the fp32 offsets / fp16-rounded logits the kernel reads -> only the result's rounding is left
+    proj_hm = ops().proj_to_head_major_records(d(proj))
+    assert proj_hm.shape == (B, M, S, 30) and proj_hm.dtype == torch.float32
+    proj_r = ops().proj_records_to_columns(proj_hm)              # back to the reference's column order
+    assert torch.equal(proj_r[..., :192].cpu(), proj[..., :192])
+    ref = ops().ms_deform_attn_encoder(d(value.float()), d(shapes), d(start), proj_r, M, P)      # (B, S, 64)
     ref_hm = ref.view(B, S, M, D).permute(0, 2, 1, 3).cpu()
     got = ops().ms_deform_attn_encoder_lp(d(value), d(shapes), d(start), proj_hm, P)
     assert got.shape == (B, M, S, D) and got.dtype == torch.float16
@@ -1188,18 +1191,20 @@ def test_encoder_prologue_vs_fp64():
     # the bf16 plan's outputs: the same fp32 results rounded once, in the head-major layouts of csrc/enc_lp.hip
     src, value, proj = o.encoder_prologue(raw.clone().to(DEV), st, gnp, bounds, stream, small, pos.to(DEV), pw, value_heads=8)
     s2, v2, p2 = o.encoder_prologue(raw.clone().to(DEV), st, gnp, bounds, stream, small, pos.to(DEV), pw, value_heads=8, bf16_hm=True)
-    assert torch.equal(s2, src) and torch.equal(v2, value.to(torch.float16)) and torch.equal(p2, o.proj_to_head_major_f16(proj))
+    assert torch.equal(s2, src) and torch.equal(v2, value.to(torch.float16)) and torch.equal(p2, o.proj_to_head_major_records(proj))
     # ... and the bf16 plan's own prologue (msm_encoder_prologue_hm_fwd: the two projections on the bf16 matrix pipe with hi + lo
     # operands): the same src bit for bit, value / record equal to the fp64 reference to fp16 storage precision
     blocks, small_hm = o.pack_encoder_prologue_hm(wv.to(DEV), wp.to(DEV), bv.to(DEV), bp.to(DEV))
     s3, v3, p3 = o.encoder_prologue_hm(raw.clone().to(DEV), st, gnp, bounds, blocks, small_hm, pos.to(DEV))
-    assert torch.equal(s3, src) and v3.dtype == p3.dtype == torch.float16
+    assert torch.equal(s3, src) and v3.dtype == torch.float16 and p3.dtype == torch.float32 and p3.shape == (B, 8, S, 30)
     val_hm = val_ref.view(B, S, 8, 8).permute(0, 2, 1, 3)
-    proj_hm = torch.cat([proj_ref[..., :192].reshape(B, S, 8, 24), proj_ref[..., 192:].reshape(B, S, 8, 12)], -1).permute(0, 2, 1, 3)
     closed(v3.float(), val_hm, rtol=1.5e-3, atol=1.5e-3)              # (an fp16 rounding of O(1) values: 2^-11 relative)
-    closed(p3.float(), proj_hm, rtol=1.5e-3, atol=1.5e-3)
-    # against the fp32-MFMA prologue's rounded outputs: at most one fp16 step apart
-    assert float((v3.float() - v2.float()).abs().max()) <= 4e-3 and float((p3.float() - p2.float()).abs().max()) <= 4e-3
+    c3, c2 = o.proj_records_to_columns(p3), o.proj_records_to_columns(p2)
+    closed(c3[..., :192], proj_ref[..., :192], rtol=5e-5, atol=5e-5)  # fp32 offsets from hi + lo operands: an fp32-class result
+    closed(c3[..., 192:], proj_ref[..., 192:], rtol=1.5e-3, atol=1.5e-3)
+    # against the fp32-MFMA prologue's outputs: value / logits at most one fp16 step apart, offsets to fp32 rounding
+    assert float((v3.float() - v2.float()).abs().max()) <= 4e-3 and float((c3[..., 192:] - c2[..., 192:]).abs().max()) <= 4e-3
+    assert float((c3[..., :192] - c2[..., :192]).abs().max()) <= 1e-4
     with pytest.raises(RuntimeError):
         o.encoder_prologue(raw.to(DEV), st, gnp, [0, 12, 60, S + 1], stream, small, pos.to(DEV), pw)
 

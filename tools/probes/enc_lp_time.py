@@ -38,7 +38,7 @@ st = torch.tensor([0, 300, 1500], dtype=torch.int64, device=DEV)
 wpack, bpack = ops.pack_msda_proj_lp(wp2, bp)
 value_hm = torch.randn(B, 8, S, 8, device=DEV).to(torch.float16)
 proj = torch.nn.functional.linear(src + pos, wp2, bp).contiguous()
-proj_hm = ops.proj_to_head_major_f16(proj)
+proj_hm = ops.proj_to_head_major_records(proj)
 t = timeit_graph(lambda: ops.ms_deform_attn_encoder_lp(value_hm, ss, st, proj_hm, 4))
 print(f"msda enc lp (stored bf16 projection, bf16 taps): {t:7.1f} us", flush=True)
 t = timeit_graph(lambda: ops.ms_deform_attn_encoder_lp_fused(value_hm, ss, st, src, pos, wpack, bpack, 4))

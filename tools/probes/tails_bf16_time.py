@@ -10,6 +10,10 @@ from unseenobjectswithmeanshift_amd import ops  # noqa: E402
 from microbench import timeit_graph  # noqa: E402
 
 DEV = "cuda:0"
+if len(sys.argv) > 2 and sys.argv[1] == "--lp-f16":          # MSM_OPT_LP_F16: 1 = fp16 weights + hi / lo fp16 activations, 2 = one fp16 activation term
+    from unseenobjectswithmeanshift_amd import _lib
+    _lib.set_option("LP_F16", int(sys.argv[2]))
+    print(f"LP_F16 = {sys.argv[2]}")
 B, Q, E, Fh = 8, 100, 256, 2048
 r = lambda *s: torch.randn(*s, device=DEV)
 o, res, qpos = r(B, Q, E), r(B, Q, E), r(Q, E)

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmsm_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "msm_hip.h")
 
 _lib = None
-ABI_VERSION = 14     # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
+ABI_VERSION = 15     # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
 
 c_f = ctypes.c_void_p      # float* (device)
 c_p = ctypes.c_void_p
@@ -70,13 +70,13 @@ _SIGNATURES = {
     "msm_encoder_block_lp_fwd": (c_i, [c_f, c_f, c_p, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_p]),
     "msm_encoder_block_hm_stream_bytes": (c_l, [c_i, c_i]),
     "msm_encoder_block_hm_small_floats": (c_i, [c_i]),
-    "msm_encoder_block_hm_fwd": (c_i, [c_p, c_f, c_p, c_f, c_f, c_f, c_p, c_p, c_i, c_i, c_i, c_fl, c_p]),
+    "msm_encoder_block_hm_fwd": (c_i, [c_p, c_f, c_p, c_f, c_f, c_f, c_p, c_p, c_i, c_i, c_i, c_fl, c_i, c_p]),
     "msm_msdeform_attn_enc_lp_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "msm_msdeform_attn_enc_lp_fused_fwd": (c_i, [c_p, c_p, c_p, c_f, c_f, c_p, c_f, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "msm_f32_to_f16": (c_i, [c_f, c_p, c_l, c_p]),
     "msm_kv_project_f32": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_l, c_i, c_p]),
     "msm_kv_project_multi_f32": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
-    "msm_kv_project_multi_bf16": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "msm_kv_project_multi_bf16": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "msm_kv_project_multi_split": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "msm_tokens_proj_nchw_f32": (c_i, [c_f, c_f, c_f, c_p, c_f, c_f, c_i, c_fl, c_i, c_f, c_i, c_i, c_i, c_i, c_p]),
     "msm_dec_pack_weight": (c_i, [c_f, c_f, c_i, c_i, c_p]),
@@ -88,6 +88,11 @@ _SIGNATURES = {
     "msm_dec_post_self_bf16": (c_i, [c_f, c_f, c_p, c_f, c_f, c_f, c_p, c_f, c_p] + [c_i, c_f, c_f, c_i, c_i, c_i, c_fl, c_p]),
     "msm_dec_heads_bf16": (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_f, c_p, c_f, c_p, c_f, c_p, c_f, c_p, c_f, c_f] + [c_f] * 4 +
                            [c_p, c_i, c_i, c_i, c_fl, c_p]),
+    "msm_dec_pack_weight_f16": (c_i, [c_f, c_p, c_i, c_i, c_p]),
+    "msm_dec_post_cross_f16": (c_i, [c_f, c_f, c_f, c_p, c_f, c_f, c_f, c_p, c_f, c_f, c_f, c_f] + [c_i, c_i, c_i, c_fl, c_p]),
+    "msm_dec_post_self_f16": (c_i, [c_f, c_f, c_p, c_f, c_f, c_f, c_p, c_f, c_p] + [c_i, c_f, c_f, c_i, c_i, c_i, c_fl, c_p]),
+    "msm_dec_heads_f16": (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_f, c_p, c_f, c_p, c_f, c_p, c_f, c_p, c_f, c_f] + [c_f] * 4 +
+                          [c_p, c_i, c_i, c_i, c_fl, c_p]),
     "msm_ms_seed_workspace": (c_l, [c_i]),
     "msm_ms_select_seeds": (c_i, [c_f, c_i, c_i, c_i, c_l, c_f, c_p, c_f, c_l, c_i, c_p]),
     "msm_ms_hill_climb_workspace": (c_l, [c_i, c_i]),
@@ -155,7 +160,7 @@ def lib():
 # kernel-selection overrides of include/msm_hip.h (enum order), for tools/ and tests/ only
 OPTIONS = ("MASK_NC", "MASKB_TARGET", "GEMM_TILE", "GEMM_SHALLOW", "ATTN_TARGET", "ATTN_KERNEL", "ATTN_QK_MAX", "ATTN_QKCFG",
            "CONVIN_NT", "POST_GENERIC", "ENC_NO_COOP", "MSDA_GENERIC", "MS_CHUNK", "MS_NO_PERSISTENT", "ATTN_FUSED_KV", "KV_PIPE", "MASK_KERNEL",
-           "MS_SPLIT_KERNEL", "CONV3_WIDE", "LP_F16")
+           "MS_SPLIT_KERNEL", "CONV3_WIDE")
 OPT_AUTO = -1
 
 

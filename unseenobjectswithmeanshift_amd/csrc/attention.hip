@@ -59,6 +59,15 @@ struct KVRaw<uint16_t> {
     u32x4b k;
     unsigned short v[4][2];
 };
+// kvh16 (precision "f16"): K stored as IEEE half (raw projection, as written by msm_kv_project_multi_bf16 with half_format = 1), V as
+// bf16.  BF = 2: q^ and k^ enter the score MFMA as fp16 (v_mfma_f32_16x16x32_f16) -- with kappa = 30 in front of the cosine the bf16
+// form's 2^-9 roundings of q^, k^ and the stored K are 2 % of a softmax weight; fp16 makes that 0.25 %.  P V stays on bf16 MFMAs: a
+// softmax weight exp(kappa (cos - 1)) spans e^-60 .. 1, which bf16 carries and fp16 does not.
+struct kvh16 {
+    uint16_t v;
+};
+template <>
+struct KVRaw<kvh16> : KVRaw<uint16_t> {};
 typedef unsigned u32x2a __attribute__((ext_vector_type(2)));
 // K / V through buffer descriptors: kr / vr cover K and V of one (image, head) from its first element, ko = byte offset of this
 // lane's 8 dims of its key row, vo[r] = byte offset of dim lj of the row of key 4 lq + r, ks / vs = wave-uniform byte offsets
@@ -83,6 +92,19 @@ __device__ __forceinline__ void kv_fetch(KVRaw<uint16_t>& f, __amdgpu_buffer_rsr
         f.v[r][1] = __builtin_amdgcn_raw_buffer_load_b16(vr, vo[r] + 32u, vs, 0);
     }
 }
+__device__ __forceinline__ void kv_fetch(KVRaw<kvh16>& f, __amdgpu_buffer_rsrc_t kr, unsigned ko, unsigned ks, __amdgpu_buffer_rsrc_t vr,
+                                         const unsigned (&vo)[4], unsigned vs) {
+    kv_fetch(static_cast<KVRaw<uint16_t>&>(f), kr, ko, ks, vr, vo, vs);
+}
+__device__ __forceinline__ void k_floats(const KVRaw<kvh16>& f, float (&kf)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        kf[2 * i] = half_lo(f.k[i]);
+        kf[2 * i + 1] = half_hi(f.k[i]);
+    }
+}
+__device__ __forceinline__ void v_operands(const KVRaw<kvh16>& f, bf16x4 (&vb)[2]);
+__device__ __forceinline__ float v_float(const KVRaw<kvh16>& f, int r, int hh) { return __uint_as_float((unsigned)f.v[r][hh] << 16); }
 __device__ __forceinline__ void k_floats(const KVRaw<float>& f, float (&kf)[8]) {
     kf[0] = f.ka.x; kf[1] = f.ka.y; kf[2] = f.ka.z; kf[3] = f.ka.w;
     kf[4] = f.kc.x; kf[5] = f.kc.y; kf[6] = f.kc.z; kf[7] = f.kc.w;
@@ -104,6 +126,7 @@ __device__ __forceinline__ void v_operands(const KVRaw<uint16_t>& f, bf16x4 (&vb
     for (int hh = 0; hh < 2; ++hh)
         vb[hh] = __builtin_bit_cast(bf16x4, u32x2b{(unsigned)f.v[0][hh] | ((unsigned)f.v[1][hh] << 16), (unsigned)f.v[2][hh] | ((unsigned)f.v[3][hh] << 16)});
 }
+__device__ __forceinline__ void v_operands(const KVRaw<kvh16>& f, bf16x4 (&vb)[2]) { v_operands(static_cast<const KVRaw<uint16_t>&>(f), vb); }
 __device__ __forceinline__ float v_float(const KVRaw<float>& f, int r, int hh) { return f.v[r][hh]; }
 __device__ __forceinline__ float v_float(const KVRaw<uint16_t>& f, int r, int hh) { return __uint_as_float((unsigned)f.v[r][hh] << 16); }
 
@@ -211,7 +234,7 @@ typedef float f32x2l __attribute__((ext_vector_type(2)));
 // and -kappa log2(e) in the accumulator's initial value saves that fma -- and loses two bits: the chain then rounds at the
 // magnitude of kappa log2(e) = 43 instead of 1; measured 3x the error against float64, not kept.)
 // TAIL: keys >= S of this block are switched off.
-template <bool TAIL, typename KVT, bool BF, int NQ, int MM>
+template <bool TAIL, typename KVT, int BF, int NQ, int MM>
 __device__ __forceinline__ void keys_consume(const KeyFrag<KVT, NQ, MM>& f, int kb, int S, int lq, float k2, const float (&qf)[NQ][8],
                                              const bf16x4 (&qh)[BF ? NQ : 1][2], const bool (&use_mask)[NQ], f32x4 (&o)[NQ][2],
                                              f32x2l (&lacc)[NQ]) {
@@ -224,8 +247,13 @@ __device__ __forceinline__ void keys_consume(const KeyFrag<KVT, NQ, MM>& f, int 
     const float kf[8] = {kr[0] * rn, kr[1] * rn, kr[2] * rn, kr[3] * rn, kr[4] * rn, kr[5] * rn, kr[6] * rn, kr[7] * rn};
     bf16x4 kh[2], vb[2];
     if constexpr (BF) {
-        kh[0] = pack4(kf[0], kf[1], kf[2], kf[3]);
-        kh[1] = pack4(kf[4], kf[5], kf[6], kf[7]);
+        if constexpr (BF == 2) {                   // fp16 score operands (unit vectors: no clamp needed)
+            kh[0] = __builtin_bit_cast(bf16x4, pack4h_nc(kf[0], kf[1], kf[2], kf[3]));
+            kh[1] = __builtin_bit_cast(bf16x4, pack4h_nc(kf[4], kf[5], kf[6], kf[7]));
+        } else {
+            kh[0] = pack4(kf[0], kf[1], kf[2], kf[3]);
+            kh[1] = pack4(kf[4], kf[5], kf[6], kf[7]);
+        }
         v_operands(f.kv, vb);
     }
     uint32_t oob = 0;
@@ -246,7 +274,8 @@ __device__ __forceinline__ void keys_consume(const KeyFrag<KVT, NQ, MM>& f, int 
         if constexpr (BF) {
             // one K = 32 MFMA over the head's 32 dims (a lane's eight dims 8 lq .. + 7 on both operands) instead of two dependent
             // K = 16 ones, which also issue at half the rate
-            s = mfma_bf16k32(cat8(kh[0], kh[1]), cat8(qh[m][0], qh[m][1]), s);
+            if constexpr (BF == 2) s = mfma_f16k32(__builtin_bit_cast(f16x8, cat8(kh[0], kh[1])), __builtin_bit_cast(f16x8, cat8(qh[m][0], qh[m][1])), s);
+            else s = mfma_bf16k32(cat8(kh[0], kh[1]), cat8(qh[m][0], qh[m][1]), s);
         } else {
 #pragma unroll
             for (int t = 0; t < 8; ++t) s = mfma16(kf[t], qf[m][t], s);
@@ -283,7 +312,7 @@ __device__ __forceinline__ void keys_consume(const KeyFrag<KVT, NQ, MM>& f, int 
 // The key blocks first, first + stride, ... < end of one wave: full blocks two per trip through a ping-pong pair of fragments
 // (block i + 2 strides is requested before the MFMAs of block i, pinned with sched_barrier), then the ragged last block of the
 // sequence, if it is this wave's, through the clamped path.
-template <typename KVT, bool BF, int NQ, int MM>
+template <typename KVT, int BF, int NQ, int MM>
 __device__ __forceinline__ void keys_stream(const KeyCursor<KVT, NQ, MM>& cur, int first, int stride, int end, float k2, const float (&qf)[NQ][8],
                                             const bf16x4 (&qh)[BF ? NQ : 1][2], const bool (&use_mask)[NQ], f32x4 (&o)[NQ][2],
                                             float (&lsum)[NQ]) {
@@ -323,7 +352,7 @@ __device__ __forceinline__ void keys_stream(const KeyCursor<KVT, NQ, MM>& cur, i
 
 // Q^ fragments (B operand) of NQ query blocks starting at row qrow0: lane (query lj of block m, dims lq*8 + t); the per-row
 // mask enable: rows whose keys are all masked attend everywhere (DEC:618)
-template <bool BF, int NQ>
+template <int BF, int NQ>
 __device__ __forceinline__ void load_queries(const float* __restrict__ qb, int64_t ldq, int qrow0, int Lq, int lj, bool masked,
                                              const int32_t* __restrict__ row_any_b, float (&qf)[NQ][8], bf16x4 (&qh)[BF ? NQ : 1][2],
                                              bool (&use_mask)[NQ]) {
@@ -342,7 +371,10 @@ __device__ __forceinline__ void load_queries(const float* __restrict__ qb, int64
         const float rn = rnorm(ss);
         qf[m][0] = a.x * rn; qf[m][1] = a.y * rn; qf[m][2] = a.z * rn; qf[m][3] = a.w * rn;
         qf[m][4] = c.x * rn; qf[m][5] = c.y * rn; qf[m][6] = c.z * rn; qf[m][7] = c.w * rn;
-        if constexpr (BF) {
+        if constexpr (BF == 2) {
+            qh[m][0] = __builtin_bit_cast(bf16x4, pack4h_nc(qf[m][0], qf[m][1], qf[m][2], qf[m][3]));
+            qh[m][1] = __builtin_bit_cast(bf16x4, pack4h_nc(qf[m][4], qf[m][5], qf[m][6], qf[m][7]));
+        } else if constexpr (BF == 1) {
             qh[m][0] = pack4(qf[m][0], qf[m][1], qf[m][2], qf[m][3]);
             qh[m][1] = pack4(qf[m][4], qf[m][5], qf[m][6], qf[m][7]);
         }
@@ -350,7 +382,7 @@ __device__ __forceinline__ void load_queries(const float* __restrict__ qb, int64
     }
 }
 
-template <typename KVT, bool BF, int MM>
+template <typename KVT, int BF, int MM>
 __global__ __launch_bounds__(256, 2) void hs_attn_kernel(const float* __restrict__ q, const KVT* __restrict__ k,
                                                       const KVT* __restrict__ v, const uint8_t* __restrict__ masked,
                                                       const int32_t* __restrict__ row_any, float* __restrict__ part,
@@ -443,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void hs_attn_kernel(const float* __restrict
 // partial sums meet in LDS (lane-contiguous, 9 values per lane and query block) and wave 0 finishes in registers.  No
 // partial tensors in memory, no combine launch; K/V of an (image, head) are re-read by the ceil(7/MQ) workgroups of that
 // head out of L2.
-template <int MQ, int NW, typename KVT, bool BF, int MM>
+template <int MQ, int NW, typename KVT, int BF, int MM>
 __global__ __launch_bounds__(NW * 64) void hs_attn_qk_kernel(const float* __restrict__ q, const KVT* __restrict__ k,
                                                             const KVT* __restrict__ v, const uint8_t* __restrict__ masked,
                                                             const int32_t* __restrict__ row_any, float* __restrict__ out, int Lq,
@@ -596,7 +628,7 @@ extern "C" int64_t msm_hypersphere_attn_workspace(int B, int Lq, int S, int head
 }
 
 // KVT / BF: see the low-precision note above the kernels.
-template <typename KVT, bool BF>
+template <typename KVT, int BF>
 static int attn_launch(const char* who, const float* q, const KVT* k, const KVT* v, const uint8_t* masked, const int32_t* row_any, float* out,
                        int B, int Lq, int S, int heads, int64_t ldq, int64_t q_sb, int64_t ldk, int64_t k_sb, int64_t ldv, int64_t v_sb,
                        float kappa, float* workspace, int64_t workspace_elems, void* stream) {
@@ -679,23 +711,30 @@ extern "C" int msm_hypersphere_attn_fwd(const float* q, const float* k, const fl
                                         int64_t ldq, int64_t q_sb, int64_t ldk, int64_t k_sb, int64_t ldv,
                                         int64_t v_sb, float kappa, float* workspace, int64_t workspace_elems,
                                         void* stream) {
-    return attn_launch<float, false>("msm_hypersphere_attn_fwd", q, k, v, masked, row_any, out, B, Lq, S, heads, ldq, q_sb, ldk, k_sb, ldv, v_sb,
+    return attn_launch<float, 0>("msm_hypersphere_attn_fwd", q, k, v, masked, row_any, out, B, Lq, S, heads, ldq, q_sb, ldk, k_sb, ldv, v_sb,
                                      kappa, workspace, workspace_elems, stream);
 }
 
-extern "C" int msm_hypersphere_attn_lp_fwd(const float* q, const void* k, const void* v, int kv_bf16, const uint8_t* masked,
+extern "C" int msm_hypersphere_attn_lp_fwd(const float* q, const void* k, const void* v, int kv_format, const uint8_t* masked,
                                            const int32_t* row_any, float* out, int B, int Lq, int S, int heads,
                                            int64_t ldq, int64_t q_sb, int64_t ldk, int64_t k_sb, int64_t ldv,
                                            int64_t v_sb, float kappa, float* workspace, int64_t workspace_elems,
                                            void* stream) {
-    if (kv_bf16)
-        return attn_launch<uint16_t, true>("msm_hypersphere_attn_lp_fwd", q, (const uint16_t*)k, (const uint16_t*)v, masked, row_any, out, B, Lq, S,
+    MSM_REQUIRE(kv_format >= 0 && kv_format <= 3, "msm_hypersphere_attn_lp_fwd: kv_format=%d (0 fp32 K/V, 1 bf16 K/V, 2 fp16 K + bf16 V, 3 fp32 K/V with fp16 scores)", kv_format);
+    if (kv_format == 2)
+        return attn_launch<kvh16, 2>("msm_hypersphere_attn_lp_fwd", q, (const kvh16*)k, (const kvh16*)v, masked, row_any, out, B, Lq, S, heads, ldq,
+                                     q_sb, ldk, k_sb, ldv, v_sb, kappa, workspace, workspace_elems, stream);
+    if (kv_format == 1)
+        return attn_launch<uint16_t, 1>("msm_hypersphere_attn_lp_fwd", q, (const uint16_t*)k, (const uint16_t*)v, masked, row_any, out, B, Lq, S,
                                            heads, ldq, q_sb, ldk, k_sb, ldv, v_sb, kappa, workspace, workspace_elems, stream);
     // very short fp32 sequences (the decoder's self-attention: 100 keys) stay on the fp32 MFMAs: the launch is latency-bound, the
     // operand conversions only add to it (measured 8.5 against 6.6 us)
     if (S <= 128)
-        return attn_launch<float, false>("msm_hypersphere_attn_lp_fwd", q, (const float*)k, (const float*)v, masked, row_any, out, B, Lq, S, heads,
+        return attn_launch<float, 0>("msm_hypersphere_attn_lp_fwd", q, (const float*)k, (const float*)v, masked, row_any, out, B, Lq, S, heads,
                                          ldq, q_sb, ldk, k_sb, ldv, v_sb, kappa, workspace, workspace_elems, stream);
-    return attn_launch<float, true>("msm_hypersphere_attn_lp_fwd", q, (const float*)k, (const float*)v, masked, row_any, out, B, Lq, S, heads, ldq,
+    if (kv_format == 3)
+        return attn_launch<float, 2>("msm_hypersphere_attn_lp_fwd", q, (const float*)k, (const float*)v, masked, row_any, out, B, Lq, S, heads, ldq,
+                                     q_sb, ldk, k_sb, ldv, v_sb, kappa, workspace, workspace_elems, stream);
+    return attn_launch<float, 1>("msm_hypersphere_attn_lp_fwd", q, (const float*)k, (const float*)v, masked, row_any, out, B, Lq, S, heads, ldq,
                                     q_sb, ldk, k_sb, ldv, v_sb, kappa, workspace, workspace_elems, stream);
 }

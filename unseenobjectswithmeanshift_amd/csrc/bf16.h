@@ -32,6 +32,10 @@ __device__ __forceinline__ f16x8 cvt8h(float a, float b, float c, float d, float
                  (_Float16)clamp_h(g), (_Float16)clamp_h(h)};
 }
 __device__ __forceinline__ f32x4b mfma_f16k32(f16x8 a, f16x8 b, f32x4b c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ u32x2b pack4h_nc(float a, float b, float c, float d) {          // no clamp: callers with bounded values (unit vectors)
+    const f16x2_t lo = {(_Float16)a, (_Float16)b}, hi = {(_Float16)c, (_Float16)d};
+    return u32x2b{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+}
 __device__ __forceinline__ float half_lo(unsigned packed) { return (float)__builtin_bit_cast(f16x2_t, packed)[0]; }
 __device__ __forceinline__ float half_hi(unsigned packed) { return (float)__builtin_bit_cast(f16x2_t, packed)[1]; }
 // v_mfma_f32_16x16x16_bf16: A lane (i = l & 15, kq = l >> 4) holds A[i][4 kq .. 4 kq + 3], B lane (j, kq) holds B[4 kq .. + 3][j],

@@ -69,22 +69,17 @@ struct TileH16 {
     using WT = uint16_t;
     static constexpr int R = 16, LD = DC_E + 4, RG = 1;
 };
-// fp16 weights (same bytes as bf16, 11 instead of 8 significand bits: weights are O(0.01 .. 1), far inside the fp16 range) on
-// v_mfma_f32_16x16x32_f16 -- the same rate as the bf16 instruction.  f16w: the activation fragment as hi + lo fp16 terms (two
-// MFMAs per pair of k-steps, like the bf16 form); f16s: one fp16 term (one MFMA: the activation's own rounding, 2^-12, is then of
-// the order of the weight's).
+// fp16 weights (precision "f16"): the same bytes as bf16 with 11 instead of 8 significand bits -- Linear weights are O(0.01 .. 1),
+// far inside the half range -- on v_mfma_f32_16x16x32_f16, which issues at the bf16 instruction's rate.  The activation fragment
+// enters as ONE fp16 term (clamped to the half range): its rounding, 2^-12, is of the order of the weight's, so the hi + lo pair
+// the bf16 form needs (to keep the activation's 2^-9 out of the product) would buy nothing.  Half the MFMAs of the bf16 form, an
+// eighth of its rounding error: measured over 3200 masks (tools/probes/bf16_pooled_probe.py) the tails alone flip 0.85 % of the
+// final mask bits with bf16 weights and 0.2 % with fp16 weights; 28.4 us per layer against 32.2 (B = 8).
 struct f16w {
-    uint16_t v;
-};
-struct f16s {
     uint16_t v;
 };
 struct TileQ16 {
     using WT = f16w;
-    static constexpr int R = 16, LD = DC_E + 4, RG = 1;
-};
-struct TileQ16S {
-    using WT = f16s;
     static constexpr int R = 16, LD = DC_E + 4, RG = 1;
 };
 #ifndef MSM_DC_NW
@@ -112,8 +107,6 @@ struct BFrag<uint16_t> {
 };
 template <>
 struct BFrag<f16w> : BFrag<uint16_t> {};
-template <>
-struct BFrag<f16s> : BFrag<uint16_t> {};
 // W: packed weight, advanced to the first of the 256 output rows wanted (row offset n0 -> + n0*K elements);
 // kct = K/64 of the packed matrix; kc0 = first of the two k-chunks to fetch
 // (Rotating the k-chunk order per workgroup to de-phase their L2 accesses was measured: -3 % kernel time, and it
@@ -245,15 +238,11 @@ __device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT][1], const float* _
         }
     }
 }
-// fp16 weights: the same fragment layout and loads as bf16
+// fp16 weights: the same fragment layout and loads as bf16; one MFMA per pair of k-steps and column tile
 __device__ __forceinline__ void bload(BFrag<f16w>& f, const f16w* __restrict__ W, int kct, int kc_base, int half) {
     bload(static_cast<BFrag<uint16_t>&>(f), reinterpret_cast<const uint16_t*>(W), kct, kc_base, half);
 }
-__device__ __forceinline__ void bload(BFrag<f16s>& f, const f16s* __restrict__ W, int kct, int kc_base, int half) {
-    bload(static_cast<BFrag<uint16_t>&>(f), reinterpret_cast<const uint16_t*>(W), kct, kc_base, half);
-}
-template <bool SINGLE>
-__device__ __forceinline__ void mfma_half_f16(f32x4 (&acc)[DC_NT][1], const float* __restrict__ ap, const BFrag<uint16_t>& f, int half) {
+__device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT][1], const float* __restrict__ ap, const BFrag<f16w>& f, int half) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         float4 a[4];
@@ -263,31 +252,19 @@ __device__ __forceinline__ void mfma_half_f16(f32x4 (&acc)[DC_NT][1], const floa
 #pragma unroll
         for (int up = 0; up < 2; ++up) {
             const float4 p = a[2 * up], q = a[2 * up + 1];
-            const f16x8 xh = cvt8h(p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w);
-            if constexpr (!SINGLE) {
-                const f16x8 xl = cvt8h(p.x - (float)xh[0], p.y - (float)xh[1], p.z - (float)xh[2], p.w - (float)xh[3], q.x - (float)xh[4],
-                                       q.y - (float)xh[5], q.z - (float)xh[6], q.w - (float)xh[7]);
+            const f16x8 x = cvt8h(p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w);
 #pragma unroll
-                for (int t = 0; t < DC_NT; ++t) acc[t][0] = mfma_f16k32(xl, __builtin_bit_cast(f16x8, f.v[h][t][up]), acc[t][0]);
-            }
-#pragma unroll
-            for (int t = 0; t < DC_NT; ++t) acc[t][0] = mfma_f16k32(xh, __builtin_bit_cast(f16x8, f.v[h][t][up]), acc[t][0]);
+            for (int t = 0; t < DC_NT; ++t) acc[t][0] = mfma_f16k32(x, __builtin_bit_cast(f16x8, f.v[h][t][up]), acc[t][0]);
         }
     }
-}
-__device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT][1], const float* __restrict__ ap, const BFrag<f16w>& f, int half) {
-    mfma_half_f16<false>(acc, ap, f, half);
-}
-__device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT][1], const float* __restrict__ ap, const BFrag<f16s>& f, int half) {
-    mfma_half_f16<true>(acc, ap, f, half);
 }
 // prefetch loads per half stage (bload) and MFMAs between two of them
 template <typename TK>
 struct Pipe {
     static constexpr int LOADS = std::is_same<typename TK::WT, float>::value ? 8 * DC_NT : 4 * DC_NT;
-    // MFMAs between two prefetch loads: 8-row fp32 has two 8-cycle MFMAs where the 16-row form has one of 32; bf16 / fp16 hi + lo have 8 * DC_NT
-    // per half stage, the single-term fp16 form 4 * DC_NT
-    static constexpr int IL = std::is_same<typename TK::WT, f16s>::value ? 1
+    // MFMAs between two prefetch loads: 8-row fp32 has two 8-cycle MFMAs where the 16-row form has one of 32; bf16 (hi + lo activation) has
+    // 8 * DC_NT per half stage, fp16 (one term) 4 * DC_NT
+    static constexpr int IL = std::is_same<typename TK::WT, f16w>::value ? 1
                               : !std::is_same<typename TK::WT, float>::value ? DC_IL / 2 : (TK::RG == 2 ? 2 * DC_IL : DC_IL);
 };
 
@@ -677,13 +654,20 @@ extern "C" int msm_dec_pack_weight_bf16(const float* w, uint16_t* packed, int N,
     MSM_REQUIRE(N > 0 && K > 0 && N % 16 == 0 && K % 64 == 0, "msm_dec_pack_weight_bf16: N=%d must be a multiple of 16, K=%d of 64", N, K);
     MSM_REQUIRE(aligned16(w) && aligned16(packed), "msm_dec_pack_weight_bf16: pointers must be 16-byte aligned");
     const int64_t total8 = (int64_t)N * K / 8;
-    if (opt(MSM_OPT_LP_F16) > 0)
-        hipLaunchKernelGGL(dec_pack_weight_bf16_kernel<true>, dim3((unsigned)min((int64_t)2048, (total8 + 255) / 256)), dim3(256), 0,
-                           (hipStream_t)stream, w, packed, N, K);
-    else
-        hipLaunchKernelGGL(dec_pack_weight_bf16_kernel<false>, dim3((unsigned)min((int64_t)2048, (total8 + 255) / 256)), dim3(256), 0,
-                           (hipStream_t)stream, w, packed, N, K);
+    hipLaunchKernelGGL(dec_pack_weight_bf16_kernel<false>, dim3((unsigned)min((int64_t)2048, (total8 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, w, packed, N, K);
     MSM_CHECK_LAUNCH("msm_dec_pack_weight_bf16");
+    return MSM_OK;
+}
+
+extern "C" int msm_dec_pack_weight_f16(const float* w, uint16_t* packed, int N, int K, void* stream) {
+    MSM_REQUIRE(w && packed, "msm_dec_pack_weight_f16: null pointer");
+    MSM_REQUIRE(N > 0 && K > 0 && N % 16 == 0 && K % 64 == 0, "msm_dec_pack_weight_f16: N=%d must be a multiple of 16, K=%d of 64", N, K);
+    MSM_REQUIRE(aligned16(w) && aligned16(packed), "msm_dec_pack_weight_f16: pointers must be 16-byte aligned");
+    const int64_t total8 = (int64_t)N * K / 8;
+    hipLaunchKernelGGL(dec_pack_weight_bf16_kernel<true>, dim3((unsigned)min((int64_t)2048, (total8 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, w, packed, N, K);
+    MSM_CHECK_LAUNCH("msm_dec_pack_weight_f16");
     return MSM_OK;
 }
 
@@ -717,14 +701,15 @@ extern "C" int msm_dec_post_cross(const float* attn_out, const float* res, const
 extern "C" int msm_dec_post_cross_bf16(const float* attn_out, const float* res, const float* query_pos, const uint16_t* wo,
                                        const float* bo, const float* ln_g, const float* ln_b, const uint16_t* w_in, const float* b_in,
                                        float* x_out, float* qk_out, float* v_out, int rows, int Q, int E, float eps, void* stream) {
-    if (opt(MSM_OPT_LP_F16) == 1)
-        return dec_post_cross_impl<TileQ16>("msm_dec_post_cross_bf16", attn_out, res, query_pos, (const f16w*)wo, bo, ln_g, ln_b, (const f16w*)w_in, b_in,
-                                            x_out, qk_out, v_out, rows, Q, E, eps, stream);
-    if (opt(MSM_OPT_LP_F16) == 2)
-        return dec_post_cross_impl<TileQ16S>("msm_dec_post_cross_bf16", attn_out, res, query_pos, (const f16s*)wo, bo, ln_g, ln_b, (const f16s*)w_in, b_in,
-                                             x_out, qk_out, v_out, rows, Q, E, eps, stream);
     return dec_post_cross_impl<TileH16>("msm_dec_post_cross_bf16", attn_out, res, query_pos, wo, bo, ln_g, ln_b, w_in, b_in, x_out, qk_out,
                                          v_out, rows, Q, E, eps, stream);
+}
+
+extern "C" int msm_dec_post_cross_f16(const float* attn_out, const float* res, const float* query_pos, const uint16_t* wo,
+                                      const float* bo, const float* ln_g, const float* ln_b, const uint16_t* w_in, const float* b_in,
+                                      float* x_out, float* qk_out, float* v_out, int rows, int Q, int E, float eps, void* stream) {
+    return dec_post_cross_impl<TileQ16>("msm_dec_post_cross_f16", attn_out, res, query_pos, (const f16w*)wo, bo, ln_g, ln_b, (const f16w*)w_in, b_in,
+                                        x_out, qk_out, v_out, rows, Q, E, eps, stream);
 }
 
 template <typename TK, typename WT = typename TK::WT>
@@ -754,14 +739,15 @@ extern "C" int msm_dec_post_self(const float* attn_out, const float* res, const 
 extern "C" int msm_dec_post_self_bf16(const float* attn_out, const float* res, const uint16_t* wo, const float* bo, const float* ln_g,
                                       const float* ln_b, const uint16_t* w1, const float* b1, const uint16_t* w2, int F, float* x_out,
                                       float* parts, int n_parts, int rows, int E, float eps, void* stream) {
-    if (opt(MSM_OPT_LP_F16) == 1)
-        return dec_post_self_impl<TileQ16>("msm_dec_post_self_bf16", attn_out, res, (const f16w*)wo, bo, ln_g, ln_b, (const f16w*)w1, b1, (const f16w*)w2, F,
-                                           x_out, parts, n_parts, rows, E, eps, stream);
-    if (opt(MSM_OPT_LP_F16) == 2)
-        return dec_post_self_impl<TileQ16S>("msm_dec_post_self_bf16", attn_out, res, (const f16s*)wo, bo, ln_g, ln_b, (const f16s*)w1, b1, (const f16s*)w2, F,
-                                            x_out, parts, n_parts, rows, E, eps, stream);
     return dec_post_self_impl<TileH16>("msm_dec_post_self_bf16", attn_out, res, wo, bo, ln_g, ln_b, w1, b1, w2, F, x_out, parts, n_parts, rows, E,
                                         eps, stream);
+}
+
+extern "C" int msm_dec_post_self_f16(const float* attn_out, const float* res, const uint16_t* wo, const float* bo, const float* ln_g,
+                                     const float* ln_b, const uint16_t* w1, const float* b1, const uint16_t* w2, int F, float* x_out,
+                                     float* parts, int n_parts, int rows, int E, float eps, void* stream) {
+    return dec_post_self_impl<TileQ16>("msm_dec_post_self_f16", attn_out, res, (const f16w*)wo, bo, ln_g, ln_b, (const f16w*)w1, b1, (const f16w*)w2, F,
+                                       x_out, parts, n_parts, rows, E, eps, stream);
 }
 
 template <typename TK, typename WT = typename TK::WT>
@@ -799,12 +785,14 @@ extern "C" int msm_dec_heads_bf16(const float* x, const float* parts, int n_part
                                   const float* m0b, const uint16_t* m1w, const float* m1b, const uint16_t* m2w, const float* m2b,
                                   const uint16_t* wq, const float* bq, const float* query_pos, float* out, float* d_out, float* e_out,
                                   float* q_out, int32_t* row_any_zero, int rows, int Q, int E, float eps, void* stream) {
-    if (opt(MSM_OPT_LP_F16) == 1)
-        return dec_heads_impl<TileQ16>("msm_dec_heads_bf16", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, (const f16w*)m0w, m0b, (const f16w*)m1w,
-                                       m1b, (const f16w*)m2w, m2b, (const f16w*)wq, bq, query_pos, out, d_out, e_out, q_out, row_any_zero, rows, Q, E, eps, stream);
-    if (opt(MSM_OPT_LP_F16) == 2)
-        return dec_heads_impl<TileQ16S>("msm_dec_heads_bf16", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, (const f16s*)m0w, m0b, (const f16s*)m1w,
-                                        m1b, (const f16s*)m2w, m2b, (const f16s*)wq, bq, query_pos, out, d_out, e_out, q_out, row_any_zero, rows, Q, E, eps, stream);
     return dec_heads_impl<TileH16>("msm_dec_heads_bf16", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, m0w, m0b, m1w, m1b, m2w, m2b,
                                     wq, bq, query_pos, out, d_out, e_out, q_out, row_any_zero, rows, Q, E, eps, stream);
+}
+extern "C" int msm_dec_heads_f16(const float* x, const float* parts, int n_parts, const float* bias, const float* ln_g,
+                                 const float* ln_b, int l2norm, const float* dec_g, const float* dec_b, const uint16_t* m0w,
+                                 const float* m0b, const uint16_t* m1w, const float* m1b, const uint16_t* m2w, const float* m2b,
+                                 const uint16_t* wq, const float* bq, const float* query_pos, float* out, float* d_out, float* e_out,
+                                 float* q_out, int32_t* row_any_zero, int rows, int Q, int E, float eps, void* stream) {
+    return dec_heads_impl<TileQ16>("msm_dec_heads_f16", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, (const f16w*)m0w, m0b, (const f16w*)m1w,
+                                   m1b, (const f16w*)m2w, m2b, (const f16w*)wq, bq, query_pos, out, d_out, e_out, q_out, row_any_zero, rows, Q, E, eps, stream);
 }

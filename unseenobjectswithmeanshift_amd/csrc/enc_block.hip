@@ -526,12 +526,19 @@ __global__ __launch_bounds__(PRO_W * 64) void enc_prologue_kernel(const float* _
     for (int ob = 0; ob < nproj_blocks; ++ob) {
         const f32x4 d = rowblock_mm(wl + (4 + ob) * 256, lj, lq, x, sm + EC + ob * 16);
         if (tok_ok && out_bf16_hm) {
-            // proj [B][8][S][36] fp16 records: row n of [192 offsets | 96 logits] is entry (head, c) = (n / 24, n % 24) or
-            // (n' / 12, 24 + n' % 12), n' = n - 192; four consecutive rows never leave a record
+            // the bf16 plan's sampling projection (csrc/enc_lp.hip, EH_REC): per (image, head) 120 S bytes = six planes [S][4 floats] of
+            // offsets and three planes [S][4 halves] of logits; row n of [192 offsets | 96 logits] is offset (head, c) = (n / 24, n % 24)
+            // or logit (n' / 12, n' % 12), n' = n - 192; a 16-row block is all offsets (ob < 12) or all logits
             const int n = ob * 16 + lq * 4;
-            const int head = n < 192 ? n / 24 : (n - 192) / 12, c = n < 192 ? n - head * 24 : 24 + (n - 192) - head * 12;
-            unsigned short* o = reinterpret_cast<unsigned short*>(proj_out) + (((int64_t)bi * 8 + head) * S + ti) * 36 + c;
-            *reinterpret_cast<u32x2b*>(o) = pack4h(d[0], d[1], d[2], d[3]);
+            unsigned char* base = reinterpret_cast<unsigned char*>(proj_out);
+            if (n < 192) {
+                const int head = n / 24, plane = (n - head * 24) >> 2;
+                typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+                *reinterpret_cast<f32x4_a8*>(base + ((int64_t)bi * 8 + head) * S * 120 + ((int64_t)plane * S + ti) * 16) = f32x4_a8{d[0], d[1], d[2], d[3]};
+            } else {
+                const int head = (n - 192) / 12, plane = ((n - 192) - head * 12) >> 2;
+                *reinterpret_cast<u32x2b*>(base + ((int64_t)bi * 8 + head) * S * 120 + (int64_t)S * 96 + ((int64_t)plane * S + ti) * 8) = pack4h(d[0], d[1], d[2], d[3]);
+            }
         } else if (tok_ok)
             *reinterpret_cast<float4*>(proj_out + (int64_t)tok * proj_ld + ob * 16 + lq * 4) = make_float4(d[0], d[1], d[2], d[3]);
     }

@@ -2,8 +2,8 @@
 // activations that only this plan's own kernels consume stored as HEAD-MAJOR 16-bit tensors in HBM:
 //     value_hm [B][8][S][8]  fp16   (encoder block l -> gather l + 1; a sampling tap = one 16-byte segment)
 //     attn_hm  [B][8][S][8]  fp16   (gather l        -> encoder block l; a lane's MFMA operand = one 16-byte load)
-//     proj_hm  [B][8][S][36] fp16   (encoder block l -> gather l + 1; the record of a (query, head): 24 sampling offsets,
-//                                    12 attention logits, ops/modules/ms_deform_attn.py:99-104)
+//     proj_hm  [B][8][120 S bytes]  (encoder block l -> gather l + 1; per (query, head) 24 sampling offsets as fp32 and 12 attention
+//                                    logits as fp16, plane-major, ops/modules/ms_deform_attn.py:99-104; round 5 -- see EH_REC below)
 // IEEE half, not bf16: same bytes, three more mantissa bits, and these are O(1) projections of LayerNorm outputs (converted with a
 // clamp to the half range).  Measured on the round-3 kernels with the tensor rounded in between (tools/probes/lp_rounding_probe.py,
 // batch 8 at 640x480, final-mask mismatch against the fp32 reference; fp32 tensors: 0.93 %): proj as bf16 2.03 % -- the offsets
@@ -43,7 +43,7 @@ constexpr int EH_RES = 32 * 1024;             // resident block: output_proj [rb
 constexpr int EH_WAVES = 16;
 // fp32 parameter vector (all of it is copied to LDS): bo, g1, be1, b2, g2, be2, bv (row order of the value store), b1 (padded)
 constexpr int EH_BO = 0, EH_G1 = 64, EH_BE1 = 128, EH_B2 = 192, EH_G2 = 256, EH_BE2 = 320, EH_BV = 384, EH_BP = 448, EH_B1 = 736;
-constexpr int EH_PROJ = 288, EH_PROJ_STAGES = 3;       // [sampling_offsets | attention_weights] rows in (head, 36) order: 18 row blocks, 8 per stage
+constexpr int EH_PROJ = 288, EH_PROJ_STAGES = 3;       // [sampling_offsets | attention_weights] rows, offsets first (24 head + c), then logits (192 + 12 head + c): 18 row blocks, 8 per stage
 
 __device__ __forceinline__ const void* uniform_ptr_lp(const void* p) {
     const uint64_t v = (uint64_t)p;
@@ -66,6 +66,7 @@ __device__ __forceinline__ bf16x8 ldfrag(const char* blk, int lane) {
 #endif
 }
 #if EH_EXP == 2
+#define mfma_f16k32(a, b, c) eh_fake_mfma(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c)
 #define mfma_bf16k32 eh_fake_mfma
 __device__ __forceinline__ f32x4 eh_fake_mfma(bf16x8 a, bf16x8 b, f32x4 c) {
     const u32x4 ua = __builtin_bit_cast(u32x4, a), ub = __builtin_bit_cast(u32x4, b);
@@ -74,6 +75,7 @@ __device__ __forceinline__ f32x4 eh_fake_mfma(bf16x8 a, bf16x8 b, f32x4 c) {
 }
 #endif
 __device__ __forceinline__ float relu1h(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 3.0e38f); }
+__device__ __forceinline__ float relu_h(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 65504.f); }      // ReLU + clamp to the half range
 // x (layout L: lane (token lj, quarter lq) holds features fb*16 + lq*4 + r) -> the B operands of its two 32-wide k-groups:
 // group G = the lane's values of feature blocks 2G and 2G + 1 side by side (the weights are packed in the same k order)
 __device__ __forceinline__ void split_L(const float (&v)[4][4], bf16x8 (&h)[2], bf16x8 (&l)[2]) {
@@ -120,6 +122,31 @@ __device__ __forceinline__ u32x4 pack8h(const f32x4& a, const f32x4& b) {       
     return u32x4{ul.x, ul.y, uh.x, uh.y};
 }
 
+// The sampling projection of a (image, head): EH_REC = 120 bytes per token = the head's 24 sampling offsets as FLOAT32 ((level,
+// point, xy) order) and its 12 attention logits as fp16, stored PLANE-major: six planes [S][4 floats] (offsets 4 p .. 4 p + 3 = the
+// (x, y) of points 2 p, 2 p + 1) followed by three planes [S][4 halves] (logits 4 p .. 4 p + 3).
+//  * fp32 offsets: they are pixel distances of several pixels (measured on the seeded weights: mean 3.8, maximum 36); an fp16 offset is
+//    off by up to 2^-11 |o| ~ 2e-3 pixel, and through the bilinear weights that alone put 6e-3 of relative error into the encoder's
+//    output -- the three fp16 tensors of round 4 together, with the offsets in fp32, leave 1.5e-3 (tools/probes/bf16_pooled_probe.py).
+//  * planes: the 16 tokens of a wave's tile are consecutive, so a store instruction writes 256 contiguous bytes per lane quarter
+//    instead of sixteen 16-byte pieces 120 bytes apart (token-major records: 49.8 us per launch; planes: see DESIGN 5b).
+// The packed projection rows are ordered offsets first (row 24 head + c), then logits (row 192 + 12 head + c) -- the reference's own
+// order --, so a 16-row block of the MFMA output is all offsets (rb < 12) or all logits and a lane's four results are one plane entry.
+constexpr int EH_REC = 120;
+typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+typedef float f32x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+// byte offset of the region of (image, head) in a [B][8][S * EH_REC] projection
+__device__ __forceinline__ int64_t proj_region(int img, int head, int S) { return ((int64_t)img * 8 + head) * S * EH_REC; }
+__device__ __forceinline__ void store_proj_rb(unsigned char* __restrict__ proj_out, int img, int tpos, int S, int rb, int lq, const f32x4& d) {
+    if (rb < 12) {
+        const int idx = rb * 16 + lq * 4, head = idx / 24, plane = (idx - head * 24) >> 2;
+        *reinterpret_cast<f32x4_a8*>(proj_out + proj_region(img, head, S) + ((int64_t)plane * S + tpos) * 16) = f32x4_a8{d[0], d[1], d[2], d[3]};
+    } else {
+        const int idx = (rb - 12) * 16 + lq * 4, head = idx / 12, plane = (idx - head * 12) >> 2;
+        *reinterpret_cast<u32x2b*>(proj_out + proj_region(img, head, S) + (int64_t)S * 96 + ((int64_t)plane * S + tpos) * 8) = pack4h(d[0], d[1], d[2], d[3]);
+    }
+}
+
 // residual + linear2 bias + LayerNorm2 (msdeformattn.py:116-118)
 __device__ __forceinline__ void finish_ffn(float (&x)[4][4], const f32x4 (&acc)[4], const float* __restrict__ sm, int lq, float eps) {
 #pragma unroll
@@ -144,8 +171,12 @@ __device__ __forceinline__ void store_src(float* __restrict__ src_out, const flo
 }
 
 // wstream: [resident 32 KiB][nffn FFN stages x 32 KiB][3 projection stages x 32 KiB, not for the last layer]; small: EH_B1 + 128 * nffn
-// floats.  attn_hm / value_out: [B][8][S][8] fp16, proj_out: [B][8][S][36] fp16.
+// floats.  attn_hm / value_out: [B][8][S][8] fp16, proj_out: [B][8][S * EH_REC bytes] (plane-major fp32 offsets + fp16 logits, see EH_REC).
 // Grid: workgroup g owns tiles g * tpw ... g * tpw + tpw - 1 (tpw <= 16: wave w takes tile w; the other waves only stream).
+// F16 (precision "f16"): the FFN stages hold IEEE-half bit patterns, x enters linear1 as ONE fp16 term and the hidden activation as
+// one fp16 term (v_mfma_f32_16x16x32_f16: 8 instead of 12 MFMAs per pair of hidden blocks, and 2^-12 roundings where the bf16 form has
+// 2^-9 on W1, W2 and the hidden activation).  The 64-wide projections keep their three-term bf16 products (2^-17) in both forms.
+template <bool F16>
 __global__ __launch_bounds__(EH_WAVES * 64) void enc_block_hm_kernel(const unsigned short* __restrict__ attn_hm, const float* __restrict__ src,
                                                                      const char* __restrict__ wstream, const float* __restrict__ small,
                                                                      const float* __restrict__ pos, float* __restrict__ src_out,
@@ -181,6 +212,7 @@ __global__ __launch_bounds__(EH_WAVES * 64) void enc_block_hm_kernel(const unsig
     const int img = tk / S, tpos = tk - img * S;
     float x[4][4];
     bf16x8 xh[2], xl[2];
+    f16x8 xf[2];
     if (active) {
         // attn: lane (token, kq = lq) of k-group G reads head 4G + lq, eight dims = 16 bytes of fp16 = a hi + lo bf16 pair exactly
         u32x4 ah[2];
@@ -219,7 +251,13 @@ __global__ __launch_bounds__(EH_WAVES * 64) void enc_block_hm_kernel(const unsig
             x[ob][0] += d[0]; x[ob][1] += d[1]; x[ob][2] += d[2]; x[ob][3] += d[3];
         }
         layer_norm_h(x, sm + EH_G1, sm + EH_BE1, lq, eps);
-        split_L(x, xh, xl);
+        if constexpr (F16) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                xf[g] = cvt8h(x[2 * g][0], x[2 * g][1], x[2 * g][2], x[2 * g][3], x[2 * g + 1][0], x[2 * g + 1][1], x[2 * g + 1][2], x[2 * g + 1][3]);
+        } else {
+            split_L(x, xh, xl);
+        }
     }
     // ---- FFN: four pairs of 16-wide hidden blocks per stage; the hidden activation never leaves registers ----
     f32x4 acc[4];
@@ -256,19 +294,33 @@ __global__ __launch_bounds__(EH_WAVES * 64) void enc_block_hm_kernel(const unsig
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
                     for (int g = 0; g < 2; ++g) w1[q][g] = ldfrag(pb + (q * 2 + g) * 1024, lane);
-                // low-order term first; consecutive MFMAs on different accumulators
+                if constexpr (F16) {
+                    // consecutive MFMAs on different accumulators
 #pragma unroll
-                for (int g = 0; g < 2; ++g)
+                    for (int g = 0; g < 2; ++g)
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) hh[q] = mfma_bf16k32(w1[q][g], xl[g], hh[q]);
+                        for (int q = 0; q < 2; ++q) hh[q] = mfma_f16k32(__builtin_bit_cast(f16x8, w1[q][g]), xf[g], hh[q]);
+                    // ReLU and the clamp to the half range are one v_med3_f32
+                    const f16x8 hb = {(_Float16)relu_h(hh[0][0]), (_Float16)relu_h(hh[0][1]), (_Float16)relu_h(hh[0][2]), (_Float16)relu_h(hh[0][3]),
+                                      (_Float16)relu_h(hh[1][0]), (_Float16)relu_h(hh[1][1]), (_Float16)relu_h(hh[1][2]), (_Float16)relu_h(hh[1][3])};
 #pragma unroll
-                for (int g = 0; g < 2; ++g)
+                    for (int ob = 0; ob < 4; ++ob)
+                        acc[ob] = mfma_f16k32(__builtin_bit_cast(f16x8, ldfrag(pb + 4096 + ob * 1024, lane)), hb, acc[ob]);
+                } else {
+                    // low-order term first; consecutive MFMAs on different accumulators
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) hh[q] = mfma_bf16k32(w1[q][g], xh[g], hh[q]);
-                const bf16x8 hb = cat8(pack4(relu1h(hh[0][0]), relu1h(hh[0][1]), relu1h(hh[0][2]), relu1h(hh[0][3])),
-                                       pack4(relu1h(hh[1][0]), relu1h(hh[1][1]), relu1h(hh[1][2]), relu1h(hh[1][3])));
+                    for (int g = 0; g < 2; ++g)
 #pragma unroll
-                for (int ob = 0; ob < 4; ++ob) acc[ob] = mfma_bf16k32(ldfrag(pb + 4096 + ob * 1024, lane), hb, acc[ob]);
+                        for (int q = 0; q < 2; ++q) hh[q] = mfma_bf16k32(w1[q][g], xl[g], hh[q]);
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) hh[q] = mfma_bf16k32(w1[q][g], xh[g], hh[q]);
+                    const bf16x8 hb = cat8(pack4(relu1h(hh[0][0]), relu1h(hh[0][1]), relu1h(hh[0][2]), relu1h(hh[0][3])),
+                                           pack4(relu1h(hh[1][0]), relu1h(hh[1][1]), relu1h(hh[1][2]), relu1h(hh[1][3])));
+#pragma unroll
+                    for (int ob = 0; ob < 4; ++ob) acc[ob] = mfma_bf16k32(ldfrag(pb + 4096 + ob * 1024, lane), hb, acc[ob]);
+                }
             }
         }
         // stage s + 1 (requested at the start of stage s - 1) must have landed: everything but this stage's own two pieces
@@ -322,7 +374,7 @@ __global__ __launch_bounds__(EH_WAVES * 64) void enc_block_hm_kernel(const unsig
         split_L(pq, xh, xl);                                         // the query operand of the projection stages
     }
     // ---- [sampling_offsets | attention_weights](src_out + pos), ms_deform_attn.py:99-101: eight row blocks per stage; row
-    // 16 rb + 4 lq + r = entry (head, c) = divmod(row, 36) of the head-major record (24 offsets, 12 logits): 8-byte stores ----
+    // 16 rb + 4 lq + r: an offset (rb < 12) or a logit of the head-major record (store_proj_rb): one store per row block ----
 #pragma unroll 1
     for (int t = 0; t < EH_PROJ_STAGES; ++t) {
         const char* buf = ring + ((nffn + t) % EH_NBUF) * EH_STAGE;
@@ -341,9 +393,8 @@ __global__ __launch_bounds__(EH_WAVES * 64) void enc_block_hm_kernel(const unsig
                         d = mfma_bf16k32(wh, xl[g], d);
                         d = mfma_bf16k32(wh, xh[g], d);
                     }
-                    const int idx = rb * 16 + lq * 4, head = idx / 36, c = idx - head * 36;
-                    const u32x2b o = pack4h(d[0], d[1], d[2], d[3]);
-                    if (tok_ok && (EH_EXP != 3 || d[0] == 12345.678f)) *reinterpret_cast<u32x2b*>(proj_out + (((int64_t)img * 8 + head) * S + tpos) * 36 + c) = o;
+                    if (tok_ok && (EH_EXP != 3 || d[0] == 12345.678f))
+                        store_proj_rb(reinterpret_cast<unsigned char*>(proj_out), img, tpos, S, rb, lq, d);
                 }
             }
         }
@@ -396,7 +447,7 @@ __device__ __forceinline__ float div_by_lp(float x, float W, float rW) {
 //  C  lane g = (column cx, row ry) of a tap: per point one ds_read_b64, ONE 16-byte load (the head's eight fp16 dims of that
 //     tap), eight v_fma_mix_f32; the quad's four partial sums meet by DPP and lane 0 stores the head's 16 bytes.
 // The fp32 kernel needed two loads per lane and point (a lane = a column and a 16-byte HALF of the fp32 dims).
-// FUSED = false: the projection was written by enc_block_hm_kernel as head-major fp16 records proj[b][m][q][36] (24 offsets in
+// FUSED = false: the projection was written by enc_block_hm_kernel as head-major records proj[b][m][q] of EH_REC bytes (24 fp32 offsets in
 // (level, point, xy) order, 12 logits): phase A is six small loads per owner lane.
 template <int LC, bool FUSED>
 __global__ __launch_bounds__(256) void msda_enc_lp_kernel(const unsigned short* __restrict__ value, const int64_t* __restrict__ shapes,
@@ -491,7 +542,7 @@ __global__ __launch_bounds__(256) void msda_enc_lp_kernel(const unsigned short* 
     const float ref_x = div_by_lp((float)rcol + 0.5f, (float)qW, qrw);       // msdeformattn.py:141-153
     const float ref_y = div_by_lp((float)rrow + 0.5f, (float)qH, qrh);
     const float* tq = tile + quad * TSTRIDE;
-    const unsigned short* pr = proj + (((int64_t)b * M + m) * S + qi) * 36;
+    const unsigned char* pr = reinterpret_cast<const unsigned char*>(proj) + proj_region(b, m, S);       // (M = 8: the head count of the records)
     float px[SLOTS], py[SLOTS], pw[SLOTS];
     float mx = -INFINITY;
 #pragma unroll
@@ -503,9 +554,9 @@ __global__ __launch_bounds__(256) void msda_enc_lp_kernel(const unsigned short* 
             off = *reinterpret_cast<const float2*>(tq + 2 * i);
             lg = tq[2 * LP + i];
         } else {
-            const unsigned o2 = *reinterpret_cast<const unsigned*>(pr + 2 * i);
-            off = make_float2(half_lo(o2), half_hi(o2));
-            lg = half_lo((unsigned)pr[2 * LP + i]);
+            const f32x2_a8 o2 = *reinterpret_cast<const f32x2_a8*>(pr + ((int64_t)(i >> 1) * S + qi) * 16 + (i & 1) * 8);     // fp32 (x, y) of point i
+            off = make_float2(o2[0], o2[1]);
+            lg = half_lo((unsigned)*reinterpret_cast<const unsigned short*>(pr + (int64_t)S * 96 + ((int64_t)(i >> 2) * S + qi) * 8 + (i & 3) * 2));
         }
         const float lx = ref_x + div_by_lp(off.x, (float)Ws[slot], rws[slot]);      // ms_deform_attn.py:107-109
         const float ly = ref_y + div_by_lp(off.y, (float)Hs[slot], rhs[slot]);
@@ -614,7 +665,7 @@ __global__ __launch_bounds__(PH_W * 64) void enc_prologue_hm_kernel(const float*
                                                                     int M, int S, int B) {
     extern __shared__ __attribute__((aligned(16))) char phl[];    // value + projection blocks | GroupNorm tables | bv, bp
     float* gt = reinterpret_cast<float*>(phl + PH_WBYTES);        // [PH_NIMG images][levels][3][64]: mean, rstd*gamma, beta
-    float* sm = gt + PH_NIMG * PH_MAXL * 3 * EH_C;                // bv [64] (value row order), bp [288] ((head, 36) row order)
+    float* sm = gt + PH_NIMG * PH_MAXL * 3 * EH_C;                // bv [64] (value row order), bp [288] (offsets-then-logits row order)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lj = lane & 15, lq = lane >> 4;
@@ -721,7 +772,7 @@ __global__ __launch_bounds__(PH_W * 64) void enc_prologue_hm_kernel(const float*
         x[fb][0] += pp[fb].x; x[fb][1] += pp[fb].y; x[fb][2] += pp[fb].z; x[fb][3] += pp[fb].w;
     }
     split_L(x, xh, xl);
-    // [sampling_offsets | attention_weights](src + pos): row 16 rb + 4 lq + r = entry (head, c) = divmod(row, 36) of the record
+    // [sampling_offsets | attention_weights](src + pos): row block rb < 12 = offsets, else logits (store_proj_rb)
 #pragma unroll 2
     for (int rb = 0; rb < EH_PROJ / 16; ++rb) {
         const float4 b = *reinterpret_cast<const float4*>(sm + EH_C + rb * 16 + lq * 4);
@@ -734,8 +785,7 @@ __global__ __launch_bounds__(PH_W * 64) void enc_prologue_hm_kernel(const float*
             d = mfma_bf16k32(wh, xl[g], d);
             d = mfma_bf16k32(wh, xh[g], d);
         }
-        const int idx = rb * 16 + lq * 4, head = idx / 36, c = idx - head * 36;
-        if (tok_ok) *reinterpret_cast<u32x2b*>(proj_out + (((int64_t)img * 8 + head) * S + tpos) * 36 + c) = pack4h(d[0], d[1], d[2], d[3]);
+        if (tok_ok) store_proj_rb(reinterpret_cast<unsigned char*>(proj_out), img, tpos, S, rb, lq, d);
     }
 }
 
@@ -750,7 +800,7 @@ extern "C" int msm_encoder_block_hm_small_floats(int d_ffn) { return EH_B1 + 128
 
 extern "C" int msm_encoder_block_hm_fwd(const void* attn_hm, const float* src, const void* wstream, const float* small, const float* pos,
                                         float* src_out, void* value_out, void* proj_out, int M, int tokens_per_image, int d_ffn, float eps,
-                                        void* stream) {
+                                        int ffn_f16, void* stream) {
     const char* who = "msm_encoder_block_hm_fwd";
     MSM_REQUIRE(attn_hm && src && wstream && small && src_out, "%s: null pointer", who);
     MSM_REQUIRE((value_out == nullptr) == (proj_out == nullptr) && (value_out == nullptr || pos != nullptr),
@@ -767,10 +817,17 @@ extern "C" int msm_encoder_block_hm_fwd(const void* attn_hm, const float* src, c
     int tpw = cdiv(tiles, 256);
     if (tpw > EH_WAVES) tpw = EH_WAVES;
     const int grid = cdiv(tiles, tpw);
-    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)enc_block_hm_kernel, lds));
-    hipLaunchKernelGGL(enc_block_hm_kernel, dim3(grid), dim3(EH_WAVES * 64), lds, (hipStream_t)stream, (const unsigned short*)attn_hm, src,
-                       (const char*)wstream, small, pos, src_out, (unsigned short*)value_out, (unsigned short*)proj_out, M, tokens_per_image, nffn,
-                       eps, tpw);
+    if (ffn_f16) {
+        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)enc_block_hm_kernel<true>, lds));
+        hipLaunchKernelGGL(enc_block_hm_kernel<true>, dim3(grid), dim3(EH_WAVES * 64), lds, (hipStream_t)stream, (const unsigned short*)attn_hm, src,
+                           (const char*)wstream, small, pos, src_out, (unsigned short*)value_out, (unsigned short*)proj_out, M, tokens_per_image, nffn,
+                           eps, tpw);
+    } else {
+        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)enc_block_hm_kernel<false>, lds));
+        hipLaunchKernelGGL(enc_block_hm_kernel<false>, dim3(grid), dim3(EH_WAVES * 64), lds, (hipStream_t)stream, (const unsigned short*)attn_hm, src,
+                           (const char*)wstream, small, pos, src_out, (unsigned short*)value_out, (unsigned short*)proj_out, M, tokens_per_image, nffn,
+                           eps, tpw);
+    }
     MSM_CHECK_LAUNCH(who);
     return MSM_OK;
 }
@@ -791,7 +848,7 @@ extern "C" int msm_msdeform_attn_enc_lp_fwd(const void* value_hm, const int64_t*
     const char* who = "msm_msdeform_attn_enc_lp_fwd";
     if (int rc = msda_lp_checks(who, value_hm, spatial_shapes, level_start_index, out_hm, B, S, M, D, L, P)) return rc;
     MSM_REQUIRE(proj_hm != nullptr, "%s: null pointer", who);
-    MSM_REQUIRE(((((uintptr_t)value_hm) | ((uintptr_t)out_hm)) & 15) == 0 && (((uintptr_t)proj_hm) & 3) == 0, "%s: value / out must be 16-byte aligned, proj 4-byte", who);
+    MSM_REQUIRE(((((uintptr_t)value_hm) | ((uintptr_t)out_hm)) & 15) == 0 && (((uintptr_t)proj_hm) & 7) == 0, "%s: value / out must be 16-byte aligned, proj 8-byte", who);
     hipLaunchKernelGGL((msda_enc_lp_kernel<3, false>), dim3((unsigned)((int64_t)B * M * cdiv(S, 64))), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)value_hm, spatial_shapes, level_start_index, (const float*)nullptr, (const float*)nullptr,
                        (const u32x4*)nullptr, (const float*)nullptr, (const unsigned short*)proj_hm, (unsigned short*)out_hm, B, S, M);

@@ -212,6 +212,7 @@ template <typename OT, int MODE, bool SEP>
 __device__ __forceinline__ void kv_project_split_body(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ cmat, int cw, OT* __restrict__ out, int B, int HW, int N,
                                                       int tokens, int64_t x_sb, int wg, int nwg, unsigned short* wl) {
+    // MODE 2 (precision "f16"): w and x as ONE IEEE-half term each on v_mfma_f32_16x16x32_f16; the K half of [K | V] leaves as half
     constexpr int COPIES = MODE == 0 ? 3 : 1;
     constexpr unsigned TERMS = MODE == 0 ? 0x3fu : 0x30u;      // mac_term bits: all six | {wh xm, wh xh}
     const int tid = threadIdx.x, lane = tid & 63;
@@ -230,8 +231,12 @@ __device__ __forceinline__ void kv_project_split_body(const float* __restrict__ 
         for (int i = tid; i < KP_FB * 16 * (KP_K / 4); i += KS_W * 64) {
             const int n = i >> 4, c4 = i & 15;
             const float4 v = *reinterpret_cast<const float4*>(w + (int64_t)(n_base + n) * KP_K + c4 * 4);
-            const Split3 sp = split3(v.x, v.y, v.z, v.w);
             unsigned short* dst = wl + n * KS_LD + c4 * 4;
+            if constexpr (MODE == 2) {
+                *reinterpret_cast<u32x2b*>(dst) = pack4h(v.x, v.y, v.z, v.w);
+                continue;
+            }
+            const Split3 sp = split3(v.x, v.y, v.z, v.w);
             *reinterpret_cast<bf16x4*>(dst) = sp.h;
             if constexpr (COPIES > 1) {
                 *reinterpret_cast<bf16x4*>(dst + KP_FB * 16 * KS_LD) = sp.m;
@@ -278,9 +283,14 @@ __device__ __forceinline__ void kv_project_split_body(const float* __restrict__ 
 #pragma unroll
             for (int fb = 0; fb < KP_FB; ++fb) cm[fb] = *reinterpret_cast<const float4*>(cp + fb * 16);
             Split3x8 xs[2];
+            f16x8 xf[2];
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
-                xs[g] = join(split3(xb[8 * g], xb[8 * g + 1], xb[8 * g + 2], xb[8 * g + 3]), split3(xb[8 * g + 4], xb[8 * g + 5], xb[8 * g + 6], xb[8 * g + 7]));
+            for (int g = 0; g < 2; ++g) {
+                if constexpr (MODE == 2)
+                    xf[g] = cvt8h(xb[8 * g], xb[8 * g + 1], xb[8 * g + 2], xb[8 * g + 3], xb[8 * g + 4], xb[8 * g + 5], xb[8 * g + 6], xb[8 * g + 7]);
+                else
+                    xs[g] = join(split3(xb[8 * g], xb[8 * g + 1], xb[8 * g + 2], xb[8 * g + 3]), split3(xb[8 * g + 4], xb[8 * g + 5], xb[8 * g + 6], xb[8 * g + 7]));
+            }
             const unsigned short* wp = wl + lj * KS_LD + lq * 16;
             unsigned short* tr = wl + COPIES * KP_FB * 16 * KS_LD + wave * (16 * KS_TR);       // this wave's [16 tokens][KS_TR] transposition tile
             float4 qn[2];                                 // SEP: the column vectors of the NEXT pair of feature blocks (one pair ahead:
@@ -304,6 +314,14 @@ __device__ __forceinline__ void kv_project_split_body(const float* __restrict__ 
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     Frag3 wf[2];
+                    if constexpr (MODE == 2) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const u32x4b wq = *reinterpret_cast<const u32x4b*>(wp + (fb + j) * 16 * KS_LD + g * 8);
+                            hi[j] = mfma_f16k32(__builtin_bit_cast(f16x8, wq), xf[g], hi[j]);
+                        }
+                        continue;
+                    }
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const unsigned short* q = wp + (fb + j) * 16 * KS_LD + g * 8;
@@ -325,6 +343,7 @@ __device__ __forceinline__ void kv_project_split_body(const float* __restrict__ 
                     if (a[0] == 12345.f)
 #endif
                     if constexpr (std::is_same<OT, float>::value) *reinterpret_cast<float4*>(op + (fb + j) * 16) = make_float4(a[0], a[1], a[2], a[3]);
+                    else if (MODE == 2 && half == 0) *reinterpret_cast<u32x2b*>(tr + lj * KS_TR + (((fb + j) & 3) * 16 + lq * 4)) = pack4h(a[0], a[1], a[2], a[3]);
                     else *reinterpret_cast<bf16x4*>(tr + lj * KS_TR + (((fb + j) & 3) * 16 + lq * 4)) = pack4(a[0], a[1], a[2], a[3]);
                 }
                 if constexpr (!std::is_same<OT, float>::value) {
@@ -506,7 +525,7 @@ extern "C" int msm_kv_project_f32(const float* x, const float* w, const float* c
     return MSM_OK;
 }
 
-// PIPE: -1 = fp32 MFMAs (kv_project_multi_kernel); 0 / 1 = MODE of kv_project_multi_split_kernel (bf16 matrix pipe)
+// PIPE: -1 = fp32 MFMAs (kv_project_multi_kernel); 0 / 1 / 2 = MODE of kv_project_multi_split_kernel (bf16 / fp16 matrix pipe)
 template <typename OT, int PIPE>
 static int kv_project_multi_impl(const char* who, int n_jobs, const float* const* x, const float* const* w, const float* const* cmat,
                                  OT* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride,
@@ -574,7 +593,11 @@ extern "C" int msm_kv_project_multi_f32(int n_jobs, const float* const* x, const
 }
 extern "C" int msm_kv_project_multi_bf16(int n_jobs, const float* const* x, const float* const* w, const float* const* cmat,
                                          uint16_t* const* out, const int32_t* HW, const int32_t* x_tokens, const int64_t* x_batch_stride,
-                                         const int32_t* cmat_width, int B, int C, int N, void* stream) {
+                                         const int32_t* cmat_width, int B, int C, int N, int half_format, void* stream) {
+    if (half_format) {
+        MSM_REQUIRE(half_format == 1 && N == 512, "msm_kv_project_multi_bf16: half_format=%d needs N = 512 ([K | V]), got N=%d", half_format, N);
+        return kv_project_multi_impl<uint16_t, 2>("msm_kv_project_multi_bf16", n_jobs, x, w, cmat, out, HW, x_tokens, x_batch_stride, cmat_width, B, C, N, stream);
+    }
     // bf16 MFMAs (w rounded to one bf16, x as hi + lo) unless option KV_PIPE says 0: fp32 MFMAs, only the store rounded
     if (opt(MSM_OPT_KV_PIPE) == 0)
         return kv_project_multi_impl<uint16_t, -1>("msm_kv_project_multi_bf16", n_jobs, x, w, cmat, out, HW, x_tokens, x_batch_stride, cmat_width, B, C, N, stream);

@@ -112,18 +112,27 @@ class MeanShiftMaskFormerHead(PlanAttributes, nn.Module):
         """"f32" (the reference's arithmetic, default), "bf16" (BASELINE configs 3 / 5): bf16 MFMA operands with fp32
         accumulation in the encoder's token-wise GEMMs, the decoder's row-local tails, the attention cores and the
         Q x pixel-embedding mask step; everything that decides a sign or normalises (LayerNorms, softmax, unit-norm, the
-        residual streams) stays fp32 -- or "f32_split": fp32 everywhere, the encoder's GEMMs, the K/V projection and the
+        residual streams) stays fp32 -- "f16": the same 16-bit plan with IEEE-half operands (v_mfma_f32_16x16x32_f16, the bf16
+        instruction's rate) wherever the operand's range is bounded -- Linear weights and LayerNorm'd activations of the tails and of
+        the encoder's FFN, unit-norm keys -- and bf16 where it is not (softmax weights, value rows): 2^-12 instead of 2^-9 roundings
+        on the products that carry the plan's error -- or "f32_split": fp32 everywhere, the encoder's GEMMs, the K/V projection and the
         (folded) mask step as exact three-term bf16 splits on the bf16 matrix pipe (fp32-accurate, see csrc/enc_block_split.hip)."""
-        if mode not in ("f32", "f32_split", "bf16"):
-            raise ValueError("precision must be 'f32', 'f32_split' or 'bf16'")
+        if mode not in ("f32", "f32_split", "bf16", "f16"):
+            raise ValueError("precision must be 'f32', 'f32_split', 'bf16' or 'f16'")
         self.precision = mode
+        lowp = mode in ("bf16", "f16")
         if hasattr(self.pixel_decoder, "precision"):
-            self.pixel_decoder.precision = mode
-        low = "bf16" if mode == "bf16" else "f32"
+            self.pixel_decoder.precision = "bf16" if lowp else mode          # the low-precision PLAN; its operand format below
+        if hasattr(self.pixel_decoder, "lp_operands"):
+            self.pixel_decoder.lp_operands = "f16" if mode == "f16" else "bf16"
+        low = "bf16" if lowp else "f32"
         self.predictor.mask_step_dtype = "f32_split" if mode == "f32_split" else low
-        for a in ("tails_dtype", "attention_dtype"):
-            if hasattr(self.predictor, a):
-                setattr(self.predictor, a, low)
+        if hasattr(self.predictor, "tails_dtype"):
+            self.predictor.tails_dtype = mode if lowp else "f32"
+        if hasattr(self.predictor, "attention_dtype"):
+            self.predictor.attention_dtype = low
+        if hasattr(self.predictor, "attention_keys"):
+            self.predictor.attention_keys = "f16" if mode == "f16" else "bf16"
         if hasattr(self.predictor, "kv_split"):
             self.predictor.kv_split = mode == "f32_split"
         return self
@@ -222,7 +231,7 @@ class MeanShiftMaskFormer(PlanAttributes, nn.Module):
         """See MeanShiftMaskFormerHead.set_precision; a backbone with a ``backbone_dtype`` switch (ResNet50Backbone) follows."""
         self.sem_seg_head.set_precision(mode)
         if hasattr(self.backbone, "backbone_dtype"):
-            self.backbone.backbone_dtype = "bf16" if mode == "bf16" else "f32"
+            self.backbone.backbone_dtype = "bf16" if mode in ("bf16", "f16") else "f32"
         return self
 
     @property

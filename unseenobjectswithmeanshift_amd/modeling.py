@@ -289,6 +289,9 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         # "bf16": the attention cores multiply on bf16 MFMAs (fp32 accumulation, exp, sums) and the batched K/V projection
         # stores bf16; part of set_precision("bf16")
         self.attention_dtype = "f32"
+        # low-precision attention only (head.set_precision("f16")): "f16" = the K columns of the K/V projection stored as IEEE half
+        # and q^ / k^ on fp16 MFMAs (kappa = 30 multiplies the cosine's rounding error), "bf16" = bf16 everywhere
+        self.attention_keys = "bf16"
         # True: the batched K/V projection computes its fp32 products as exact three-term bf16 splits (set_precision("f32_split"))
         self.kv_split = False
         self._packed_mf = None
@@ -405,13 +408,19 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             "ffn2": [l.linear2.weight for l in self.transformer_ffn_layers],
             "mlp": [l.weight for l in self.mask_embed.layers],
         }
-        if self.tails_dtype not in ("f32", "bf16"):
-            raise ValueError("tails_dtype must be 'f32' or 'bf16'")
-        pack = ops.dec_pack_weight if self.tails_dtype == "f32" else ops.dec_pack_weight_bf16
+        pack = self._tails_pack()
         key = (self.tails_dtype,) + tuple((p.data_ptr(), p._version) for ws in groups.values() for p in ws)
         if self._tails_cache is None or self._tails_cache[0] != key:
             self._tails_cache = (key, {k: [pack(w.contiguous()) for w in ws] for k, ws in groups.items()})
         return self._tails_cache[1]
+
+    def _tails_pack(self):
+        """The packer of the tails' weight matrices for ``tails_dtype``: fp32 fragments, bf16 fragments (activations as hi + lo bf16
+        pairs) or IEEE-half fragments (precision "f16": one fp16 activation term, csrc/dec_chain.hip)."""
+        try:
+            return {"f32": ops.dec_pack_weight, "bf16": ops.dec_pack_weight_bf16, "f16": ops.dec_pack_weight_f16}[self.tails_dtype]
+        except KeyError:
+            raise ValueError("tails_dtype must be 'f32', 'bf16' or 'f16'") from None
 
     def _folded_head(self, fm):
         """Last mask_embed layer with the mask_features projection folded in (see FoldedMaskFeatures): for
@@ -420,7 +429,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         heads kernel writes, packed like the other tail weights.  Returns (packed weight, bias, n_columns)."""
         l3 = self.mask_embed.layers[-1]
         params = (l3.weight, l3.bias, fm.weight) + ((fm.bias,) if fm.bias is not None else ())
-        pack = ops.dec_pack_weight if self.tails_dtype == "f32" else ops.dec_pack_weight_bf16
+        pack = self._tails_pack()
         key = (self.tails_dtype,) + tuple((p.data_ptr(), p._version) for p in params)
         if self._fold_cache is None or self._fold_cache[0] != key:
             wm = fm.weight.detach().double().reshape(fm.weight.shape[0], -1)             # (mask_dim, 64)
@@ -454,7 +463,8 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         c, cw = cc
         if x.shape[1] == 64 and w.shape[0] in (256, 512):
             if self.attention_dtype == "bf16":
-                return ops.kv_project_multi([x], [w], [c], out_dtype=torch.bfloat16, cmat_widths=[cw])[0]
+                return ops.kv_project_multi([x], [w], [c], out_dtype=torch.bfloat16, cmat_widths=[cw],
+                                            keys_f16=self.attention_keys == "f16" and w.shape[0] == 512)[0]
             if self.kv_split:
                 return ops.kv_project_multi([x], [w], [c], split=True, cmat_widths=[cw])[0]
         return ops.kv_project(x, w, c, cw)
@@ -556,10 +566,11 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                 kv = kv_all[i]
             else:
                 kv = self._kv_one(xs[lvl], kv_w[i], kv_c[i])          # (B, hw, 2E) = [K | V]
-            o = ops.hypersphere_attention(q, kv[..., :E], kv[..., E:], H, masked=attn, row_any=row_any, kappa=float(KAPPA), low_precision=lp)
+            kf = lp and self.attention_keys == "f16"
+            o = ops.hypersphere_attention(q, kv[..., :E], kv[..., E:], H, masked=attn, row_any=row_any, kappa=float(KAPPA), low_precision=lp, keys_f16=kf)
             x, qk, v = ops.dec_post_cross(o, out, qpos, pk["cross_o"][i], ca.meanshift_attn.out_proj.bias, ca.norm.weight,
                                           ca.norm.bias, pk["self_in"][i], sa.self_attn.in_proj_bias)
-            o = ops.hypersphere_attention(qk[..., :E], qk[..., E:], v, H, kappa=float(KAPPA), low_precision=lp)
+            o = ops.hypersphere_attention(qk[..., :E], qk[..., E:], v, H, kappa=float(KAPPA), low_precision=lp, keys_f16=kf)
             x, parts = ops.dec_post_self(o, x, pk["self_o"][i], sa.self_attn.out_proj.bias, sa.norm.weight, sa.norm.bias,
                                          pk["ffn1"][i], ff.linear1.bias, pk["ffn2"][i], n_parts=self.ffn_parts)
             last = i == L - 1
@@ -607,7 +618,8 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                                                    [kv_c[i][0] for i in jobs],
                                                    out_dtype=torch.bfloat16 if self.attention_dtype == "bf16" else torch.float32,
                                                    split=self.kv_split and self.attention_dtype != "bf16",
-                                                   cmat_widths=[kv_c[i][1] for i in jobs])
+                                                   cmat_widths=[kv_c[i][1] for i in jobs],
+                                                   keys_f16=self.attention_dtype == "bf16" and self.attention_keys == "f16")
         else:
             for i in range(self.num_feature_levels):
                 pos.append(self._pos_tokens(*sizes[i], dev))
@@ -916,7 +928,11 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
         # (csrc/enc_lp.hip: msm_encoder_block_hm_fwd + msm_msdeform_attn_enc_lp_fwd; 66 us per layer at B = 8 against 85 with the fp32
         # tensors of round 3).  False: the round-3 kernels (msm_encoder_block_lp_fwd + the fp32 gather)
         self.hm_activations = True
+        # operand format of the low-precision plan's FFN stages (head.set_precision("bf16" / "f16")): "f16" = IEEE-half W1 / W2 /
+        # activations on v_mfma_f32_16x16x32_f16 (8x smaller roundings at the same rate; csrc/enc_lp.hip, template F16)
+        self.lp_operands = "bf16"
         self.lp_input_proj = True           # bf16 plan: the FPN lateral on the bf16 matrix pipe (hi + lo operands, fp32 results; 66 -> 50 us)
+        self.lp_conv3x3 = True              # bf16 plan: the FPN output convolution with bf16 operands (csrc/conv3x3.hip); False: the fp32 kernel
         self.lp_prologue = True             # bf16 plan: the prologue's projections on the bf16 matrix pipe (enc_prologue_hm_kernel)
 
     def _w3(self):
@@ -966,7 +982,7 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
         if getattr(self, "_enc_params", None) is None:
             self._enc_params = TensorList.of(self, "transformer.encoder")
         hm = self._use_hm()
-        key = (str(device), self.precision, hm) + version_key(self._enc_params())
+        key = (str(device), self.precision, hm, self.lp_operands) + version_key(self._enc_params())
         if self._packed is None or self._packed[0] != key:
             out = []
             for l, layer in enumerate(layers):
@@ -977,7 +993,8 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
                     if nxt is not None:
                         wv, bv = nxt.value_proj.weight, nxt.value_proj.bias
                         wp, bp = nxt._proj_weights()
-                    stream = ops.pack_encoder_block_hm(a.output_proj.weight, layer.linear1.weight, layer.linear2.weight, wv, wp)
+                    stream = ops.pack_encoder_block_hm(a.output_proj.weight, layer.linear1.weight, layer.linear2.weight, wv, wp,
+                                                       ffn_f16=self.lp_operands == "f16")
                     small = ops.pack_encoder_block_hm_small(a.output_proj.bias, layer.norm1.weight, layer.norm1.bias, layer.linear1.bias,
                                                             layer.linear2.bias, layer.norm2.weight, layer.norm2.bias, bv, bp)
                     out.append((stream, small, layer.linear1.out_features, 0))
@@ -1108,12 +1125,12 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
                 # (layer 0's come from the fp32 prologue: one conversion each)
                 if value.dtype != torch.float16:                     # (the unfused front end: fp32 GEMM results, converted once)
                     value = ops.to_f16(value if value.dim() == 4 else ops.value_to_head_major(value, 8))
-                    proj = ops.proj_to_head_major_f16(proj)
+                    proj = ops.proj_to_head_major_records(proj)
                 for l, layer in enumerate(layers):
                     attn = ops.ms_deform_attn_encoder_lp(value, ss, starts, proj, layer.self_attn.n_points)
                     stream, small, d_ffn, _ = packed[l]
                     src, value, proj = ops.encoder_block_hm(attn, src, stream, small, d_ffn, pos=lvl_pos, want_next=l + 1 < len(layers),
-                                                            eps=layer.norm1.eps)
+                                                            eps=layer.norm1.eps, ffn_f16=self.lp_operands == "f16")
                 return src, shapes, fpn_stats
             for l, layer in enumerate(layers):
                 if fuse:
@@ -1158,7 +1175,7 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
             # weight-stationary 3x3 kernel; the moments of layer_1's GroupNorm come out of its epilogue.  f32_split: the
             # GroupNorm above wrote its result as three bf16 planes, the convolution multiplies exact three-term splits
             y, y_stats = ops.conv3x3_c64(y, self._w3(), H, W, stats=fpn_stats[1], stats_cleared=fpn_stats[1] is not None,
-                                         bf16=self.precision == "bf16", split=split3)
+                                         bf16=self.precision == "bf16" and self.lp_conv3x3, split=split3)
         else:
             y = ops.conv3x3_tokens(y, self._w3(), H, W)
         wm = self.mask_features.weight.view(self.mask_dim, C)

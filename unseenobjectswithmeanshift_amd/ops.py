@@ -563,11 +563,13 @@ def mask_logits(mask_embed, mask_features, *, want_mask=True, target_size=None, 
     return mask, attn, row_any
 
 
-def hypersphere_attention(q, k, v, heads, *, masked=None, row_any=None, kappa=KAPPA, low_precision=False):
+def hypersphere_attention(q, k, v, heads, *, masked=None, row_any=None, kappa=KAPPA, low_precision=False, keys_f16=False):
     """q (B,Lq,E), k/v (B,S,E) already projected (last dim contiguous, may be column slices of a
     wider buffer); masked uint8 (B,Lq,S).  Returns (B,Lq,E).
     low_precision (or bf16 k / v): bf16 MFMA operands with fp32 accumulation (msm_hypersphere_attn_lp_fwd); k and v may then be
-    torch.bfloat16 (as written by kv_project_multi(..., out_dtype=torch.bfloat16)) or float32."""
+    torch.bfloat16 (as written by kv_project_multi(..., out_dtype=torch.bfloat16)) or float32.
+    keys_f16 (precision "f16"): q^ / k^ enter the score MFMAs as IEEE halves; a 16-bit k then holds HALF bit patterns (the K columns
+    of kv_project_multi(..., keys_f16=True): a torch.bfloat16-typed view whose bits are fp16), v stays bf16."""
     kv_bf16 = k.dtype == torch.bfloat16
     if kv_bf16 != (v.dtype == torch.bfloat16):
         raise RuntimeError("k and v must have the same dtype")
@@ -586,7 +588,8 @@ def hypersphere_attention(q, k, v, heads, *, masked=None, row_any=None, kappa=KA
     need = lib().msm_hypersphere_attn_workspace(B, Lq, S, heads)
     ws = torch.empty((need,), device=q.device, dtype=torch.float32)
     if kv_bf16 or low_precision:
-        rc = lib().msm_hypersphere_attn_lp_fwd(_p(q), _p(k), _p(v), 1 if kv_bf16 else 0, _p(masked), _p(row_any), _p(out), B, Lq, S, heads,
+        fmt = (2 if kv_bf16 else 3) if keys_f16 else (1 if kv_bf16 else 0)
+        rc = lib().msm_hypersphere_attn_lp_fwd(_p(q), _p(k), _p(v), fmt, _p(masked), _p(row_any), _p(out), B, Lq, S, heads,
                                                q.stride(1), q.stride(0), k.stride(1), k.stride(0), v.stride(1), v.stride(0),
                                                kappa, _p(ws), need, _stream())
         check(rc, "msm_hypersphere_attn_lp_fwd")
@@ -649,11 +652,25 @@ def dec_pack_weight_bf16(w):
     return packed
 
 
+def dec_pack_weight_f16(w):
+    """(N, K) fp32 Linear weight -> IEEE half in the fragment order of the 16-bit dec_* kernels (msm_dec_pack_weight_f16; dtype
+    torch.float16, shape (N, K), NOT row-major): precision "f16" -- the dec_* wrappers pick the _f16 entry points by this dtype."""
+    _c(w, "w")
+    N, K = w.shape
+    packed = torch.empty((N, K), device=w.device, dtype=torch.float16)
+    rc = lib().msm_dec_pack_weight_f16(_p(w), _p(packed), N, K, _stream())
+    check(rc, "msm_dec_pack_weight_f16")
+    return packed
+
+
+_DEC_SUFFIX = {torch.float32: "", torch.bfloat16: "_bf16", torch.float16: "_f16"}
+
+
 def _wdtype(*ws):
-    """Common dtype of the packed weight matrices of a dec_* call (fp32 or bf16 fragments, never mixed)."""
+    """Common dtype of the packed weight matrices of a dec_* call (fp32, bf16 or fp16 fragments, never mixed)."""
     dts = {w.dtype for w in ws if w is not None}
-    if len(dts) != 1 or next(iter(dts)) not in (torch.float32, torch.bfloat16):
-        raise RuntimeError(f"packed weights must be all float32 or all bfloat16, got {sorted(map(str, dts))}")
+    if len(dts) != 1 or next(iter(dts)) not in _DEC_SUFFIX:
+        raise RuntimeError(f"packed weights must be all float32, all bfloat16 or all float16, got {sorted(map(str, dts))}")
     return next(iter(dts))
 
 
@@ -669,7 +686,7 @@ def dec_post_cross(attn_out, res, query_pos, wo, bo, ln_g, ln_b, w_in, b_in, eps
     x = torch.empty_like(attn_out)
     qk = torch.empty((B, Q, 2 * E), device=attn_out.device, dtype=torch.float32)
     v = torch.empty_like(attn_out)
-    fn = lib().msm_dec_post_cross if wd == torch.float32 else lib().msm_dec_post_cross_bf16
+    fn = getattr(lib(), "msm_dec_post_cross" + _DEC_SUFFIX[wd])
     rc = fn(_p(attn_out), _p(res), _p(query_pos), _p(wo), _p(bo), _p(ln_g), _p(ln_b), _p(w_in), _p(b_in), _p(x), _p(qk), _p(v), B * Q, Q, E,
             eps, _stream())
     check(rc, "msm_dec_post_cross")
@@ -691,7 +708,7 @@ def dec_post_self(attn_out, res, wo, bo, ln_g, ln_b, w1, b1, w2, n_parts=None, e
         tiles = (B * Q + 15) // 16
         n_parts = max(d for d in range(1, chunks + 1) if chunks % d == 0 and (d == 1 or tiles * d <= 256))
     parts = torch.empty((n_parts, B, Q, E), device=attn_out.device, dtype=torch.float32)
-    fn = lib().msm_dec_post_self if wd == torch.float32 else lib().msm_dec_post_self_bf16
+    fn = getattr(lib(), "msm_dec_post_self" + _DEC_SUFFIX[wd])
     rc = fn(_p(attn_out), _p(res), _p(wo), _p(bo), _p(ln_g), _p(ln_b), _p(w1), _p(b1), _p(w2), F, _p(x), _p(parts), n_parts, B * Q, E, eps,
             _stream())
     check(rc, "msm_dec_post_self")
@@ -716,7 +733,7 @@ def dec_heads(x, dec_g, dec_b, mlp, *, parts=None, bias=None, ln_g=None, ln_b=No
     ra = torch.empty((B, Q), device=x.device, dtype=torch.int32) if zero_row_any else None
     n_parts = 0 if parts is None else parts.shape[0]
     (m0w, m0b), (m1w, m1b), (m2w, m2b) = mlp
-    fn = lib().msm_dec_heads if wd == torch.float32 else lib().msm_dec_heads_bf16
+    fn = getattr(lib(), "msm_dec_heads" + _DEC_SUFFIX[wd])
     rc = fn(_p(x), _p(parts), n_parts, _p(bias), _p(ln_g), _p(ln_b), 1 if l2norm else 0, _p(dec_g), _p(dec_b), _p(m0w), _p(m0b), _p(m1w),
             _p(m1b), _p(m2w), _p(m2b), _p(wq), _p(bq), _p(query_pos), _p(out), _p(d), _p(e), _p(q), _p(ra), B * Q, Q, E, eps, _stream())
     check(rc, "msm_dec_heads")
@@ -771,12 +788,16 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     return gv, gl, gw
 
 
-def kv_project_multi(xs, ws, cmats, out_dtype=torch.float32, split=False, cmat_widths=None):
+def kv_project_multi(xs, ws, cmats, out_dtype=torch.float32, split=False, cmat_widths=None, keys_f16=False):
     """kv_project for a list of jobs in one launch: xs[j] (B, 64, H_j, W_j) contiguous NCHW or token-major
     (is_token_major), ws[j] (N, 64), cmats[j] (H_j*W_j, N) -> list of (B, H_j*W_j, N).  N in {256, 512}, <= 16 jobs.
     out_dtype torch.bfloat16: low-precision mode (bf16 MFMAs: w rounded to bf16, x as a hi + lo pair; bf16 output).
     split: fp32 results on the bf16 matrix pipe (exact three-term splits, msm_kv_project_multi_split).
-    cmat_widths[j] = W_j: separable constants, cmats[j] (H_j + W_j, N) (see kv_project); all jobs or none."""
+    cmat_widths[j] = W_j: separable constants, cmats[j] (H_j + W_j, N) (see kv_project); all jobs or none.
+    keys_f16 (out_dtype bfloat16, N = 512; precision "f16"): IEEE-half operands, and the K columns [:, :, :256] of the result hold
+    HALF bit patterns (the tensor stays typed bfloat16: only hypersphere_attention(..., keys_f16=True) should read them), V bf16."""
+    if keys_f16 and (out_dtype != torch.bfloat16 or ws[0].shape[0] != 512):
+        raise RuntimeError("kv_project_multi: keys_f16 goes with out_dtype=torch.bfloat16 and N = 512 ([K | V])")
     if split and out_dtype != torch.float32:
         raise RuntimeError("kv_project_multi: split is the fp32-accurate form (float32 output)")
     if out_dtype not in (torch.float32, torch.bfloat16):
@@ -802,8 +823,9 @@ def kv_project_multi(xs, ws, cmats, out_dtype=torch.float32, split=False, cmat_w
     arr = lambda ts: ctypes.cast(vp(*[t.data_ptr() for t in ts]), ctypes.c_void_p)
     ia, la = (ctypes.c_int32 * n), (ctypes.c_int64 * n)
     fn = (lib().msm_kv_project_multi_split if split else lib().msm_kv_project_multi_f32) if out_dtype == torch.float32 else lib().msm_kv_project_multi_bf16
+    extra = (int(bool(keys_f16)),) if out_dtype == torch.bfloat16 else ()
     rc = fn(n, arr(xs), arr(ws), arr(cmats), arr(outs), ctypes.cast(ia(*hw), ctypes.c_void_p), ctypes.cast(ia(*tok), ctypes.c_void_p),
-            ctypes.cast(la(*sb), ctypes.c_void_p), ctypes.cast(ia(*cws), ctypes.c_void_p), B, 64, N, _stream())
+            ctypes.cast(la(*sb), ctypes.c_void_p), ctypes.cast(ia(*cws), ctypes.c_void_p), B, 64, N, *extra, _stream())
     check(rc, "msm_kv_project_multi")
     return outs
 
@@ -1050,7 +1072,7 @@ def encoder_prologue(raw, stats, gn_params, level_starts, stream, small, pos, pr
     dev = raw.device
     if bf16_hm:
         value = torch.empty((B, 8, S, 8), device=dev, dtype=torch.float16)
-        proj = torch.empty((B, 8, S, 36), device=dev, dtype=torch.float16)
+        proj = torch.empty((B, 8, S, PROJ_REC_FLOATS), device=dev, dtype=torch.float32)
     else:
         value = torch.empty((B, value_heads, S, 64 // value_heads) if value_heads else (B, S, 64), device=dev, dtype=torch.float32)
         proj = torch.empty((B, S, proj_width), device=dev, dtype=torch.float32) if proj_width else None     # 0: value projection only
@@ -1267,17 +1289,29 @@ def _value_row_perm(device):
 
 
 def _proj_row_perm(heads, LP, device):
-    """Row m*36 + c of the head-major projection = reference row m*2LP + c (offsets, c < 2LP) or heads*2LP + m*LP + c - 2LP (logits)."""
+    """Packed row order of the [sampling_offsets | attention_weights] projection of the bf16 plan: the offsets of all heads (row
+    24 head + c), then the logits (192 + 12 head + c) -- the reference's own row order (ms_deform_attn.py:47-48, 99-101), so a
+    16-row block of the MFMA output is all offsets or all logits (csrc/enc_lp.hip, store_proj_rb).  (Round 4 interleaved them per head.)"""
+    return torch.arange(heads * 3 * LP, device=device)
+
+
+def _proj_row_perm_per_head(heads, LP, device):
+    """Row m*36 + c of the per-head projection blocks of msm_msdeform_attn_enc_lp_fused_fwd = reference row m*2LP + c (offsets,
+    c < 2LP) or heads*2LP + m*LP + c - 2LP (logits)."""
     m = torch.arange(heads, device=device).view(-1, 1)
     c = torch.arange(3 * LP, device=device).view(1, -1)
     return torch.where(c < 2 * LP, m * 2 * LP + c, heads * 2 * LP + m * LP + c - 2 * LP).reshape(-1)
 
 
-def pack_encoder_block_hm(wo, w1, w2, wv=None, wp=None):
+PROJ_REC_FLOATS = 30     # the bf16 plan's sampling projection: 120 bytes per (image, head, token) = 24 fp32 offsets + 12 fp16 logits, plane-major
+                         # per (image, head) (csrc/enc_lp.hip, EH_REC); tensors are typed (B, 8, S, 30) float32 for their size only
+
+
+def pack_encoder_block_hm(wo, w1, w2, wv=None, wp=None, ffn_f16=False):
     """One encoder layer's matrices as the weight stream of msm_encoder_block_hm_fwd (include/msm_hip.h): resident block
-    [output_proj | next layer's value_proj] as [h, l] bf16 pairs, linear1 / linear2 as single bf16 copies, four pairs of
-    16-wide hidden blocks per 32-KiB stage, then (wv / wp given) the next layer's sampling projection in (head, 36) row order as
-    [h, l] pairs, eight row blocks per stage.  Returns an int16 tensor (bf16 bit patterns)."""
+    [output_proj | next layer's value_proj] as [h, l] bf16 pairs, linear1 / linear2 as single bf16 copies -- ``ffn_f16``: as IEEE
+    halves (precision "f16") --, four pairs of 16-wide hidden blocks per 32-KiB stage, then (wv / wp given) the next layer's
+    sampling projection in (head, 36) row order as [h, l] pairs, eight row blocks per stage.  Returns an int16 tensor (bit patterns)."""
     dev = wo.device
     d_ffn = w1.shape[0]
     if wo.shape != (64, 64) or w1.shape[1] != 64 or tuple(w2.shape) != (64, d_ffn) or d_ffn % 32:
@@ -1293,16 +1327,17 @@ def pack_encoder_block_hm(wo, w1, w2, wv=None, wp=None):
     kL, kn = _korder_L(64, dev), _korder_natural(64, dev)
     res = [pair_hl(wo, kn).reshape(-1)]
     res.append(pair_hl(wv[_value_row_perm(dev)], kL).reshape(-1) if wv is not None else torch.zeros(16 * 512, device=dev))
-    w1p = torch.cat([w1, torch.zeros(pad, 64, device=dev)], 0).to(torch.bfloat16).float()
-    w2p = torch.cat([w2, torch.zeros(64, pad, device=dev)], 1).to(torch.bfloat16).float()
+    w1p = torch.cat([w1, torch.zeros(pad, 64, device=dev)], 0)
+    w2p = torch.cat([w2, torch.zeros(64, pad, device=dev)], 1)
     npair = (d_ffn + pad) // 32
     b1 = _frag_blocks(w1p, kL).reshape(npair, 4 * 512)                        # [P][q][G][512]
     b2 = _frag_blocks(w2p, _korder_L(d_ffn + pad, dev)).permute(1, 0, 2).reshape(npair, 4 * 512)     # [P][ob][512]
-    parts = res + [torch.cat([b1, b2], 1).reshape(-1)]
+    bits = lambda t, dt: t.to(dt).contiguous().view(torch.int16)             # fp32 -> 16-bit patterns (round to nearest even)
+    parts = [bits(torch.cat(res), torch.bfloat16), bits(torch.cat([b1, b2], 1).reshape(-1), torch.float16 if ffn_f16 else torch.bfloat16)]
     if wp is not None:
         pj = pair_hl(wp[_proj_row_perm(8, 12, dev)], kL).reshape(-1)         # 18 row blocks x 4 KiB
-        parts += [pj, torch.zeros(3 * 16384 - pj.numel(), device=dev)]
-    out = torch.cat(parts).to(torch.bfloat16).contiguous().view(torch.int16)
+        parts.append(bits(torch.cat([pj, torch.zeros(3 * 16384 - pj.numel(), device=dev)]), torch.bfloat16))
+    out = torch.cat(parts).contiguous()
     assert out.numel() * 2 == lib().msm_encoder_block_hm_stream_bytes(d_ffn, int(wp is not None))
     return out
 
@@ -1334,7 +1369,7 @@ def encoder_prologue_hm(raw, stats, gn_params, level_starts, blocks, small, pos,
     if C != 64 or tuple(stats.shape) != (L, B, 64, 2) or tuple(gn_params.shape) != (L, 2, 64) or tuple(pos.shape) != (S, 64) or small.numel() != 352:
         raise RuntimeError("encoder_prologue_hm: inconsistent shapes")
     value = torch.empty((B, 8, S, 8), device=raw.device, dtype=torch.float16)
-    proj = torch.empty((B, 8, S, 36), device=raw.device, dtype=torch.float16)
+    proj = torch.empty((B, 8, S, PROJ_REC_FLOATS), device=raw.device, dtype=torch.float32)
     ls = (ctypes.c_int32 * (L + 1))(*[int(v) for v in level_starts])
     rc = lib().msm_encoder_prologue_hm_fwd(_p(raw), _p(stats), _p(gn_params), ctypes.cast(ls, ctypes.c_void_p), L, int(groups), float(eps),
                                            _p(blocks), _p(small), _p(pos), _p(raw), _p(value), _p(proj), B, S, _stream())
@@ -1361,7 +1396,7 @@ def pack_msda_proj_lp(wp, bp, heads=8, n_levels=3, n_points=4):
     if tuple(wp.shape) != (heads * LP * 3, 64) or bp.numel() != wp.shape[0] or LP != 12:
         raise RuntimeError("pack_msda_proj_lp: the shipped geometry only (3 levels x 4 points)")
     dev = wp.device
-    perm = _proj_row_perm(heads, LP, dev)
+    perm = _proj_row_perm_per_head(heads, LP, dev)
     rows = torch.zeros(heads, 48, 64, device=dev)
     bias = torch.zeros(heads, 48, device=dev)
     rows[:, :3 * LP] = wp[perm].reshape(heads, 3 * LP, 64)
@@ -1372,12 +1407,24 @@ def pack_msda_proj_lp(wp, bp, heads=8, n_levels=3, n_points=4):
     return blocks.reshape(-1).to(torch.bfloat16).contiguous().view(torch.int16), bias.contiguous()
 
 
-def proj_to_head_major_f16(proj, heads=8, LP=12):
-    """(B, S, heads*LP*3) fp32 in the reference's [offsets | logits] column order -> (B, heads, S, 36) fp16 records (torch ops:
-    tests and the unfused front end only; the fused prologue writes the records itself)."""
+def proj_to_head_major_records(proj, heads=8, LP=12):
+    """(B, S, heads*LP*3) fp32 in the reference's [offsets | logits] column order -> the bf16 plan's sampling projection
+    (B, heads, S, 30) float32-TYPED (120 bytes per token; NOT a (.., S, 30) array): per (image, head) six planes [S][4 floats] of fp32
+    offsets then three planes [S][4 halves] of fp16 logits (csrc/enc_lp.hip, EH_REC).  Torch ops: tests and the unfused front end
+    only; the fused prologue writes this layout itself."""
     B, S, W = proj.shape
-    perm = _proj_row_perm(heads, LP, proj.device)
-    return proj[..., perm].reshape(B, S, heads, 3 * LP).permute(0, 2, 1, 3).to(torch.float16).contiguous()
+    off = proj[..., :heads * 2 * LP].reshape(B, S, heads, 2 * LP // 4, 4).permute(0, 2, 3, 1, 4).reshape(B, heads, -1)          # (B, heads, 6 S 4)
+    lg = proj[..., heads * 2 * LP:].reshape(B, S, heads, LP // 4, 4).permute(0, 2, 3, 1, 4).to(torch.float16).reshape(B, heads, -1)
+    return torch.cat([off, lg.contiguous().view(torch.float32)], -1).view(B, heads, S, PROJ_REC_FLOATS).contiguous()
+
+
+def proj_records_to_columns(rec, heads=8, LP=12):
+    """Inverse of proj_to_head_major_records (the logits come back as the fp16 values the planes hold): (B, S, heads*LP*3) fp32."""
+    B, M, S, _ = rec.shape
+    flat = rec.reshape(B, M, S * PROJ_REC_FLOATS)
+    off = flat[..., :S * 2 * LP].reshape(B, M, 2 * LP // 4, S, 4).permute(0, 3, 1, 2, 4).reshape(B, S, M * 2 * LP)
+    lg = flat[..., S * 2 * LP:].contiguous().view(torch.float16).reshape(B, M, LP // 4, S, 4).permute(0, 3, 1, 2, 4).reshape(B, S, M * LP).float()
+    return torch.cat([off, lg], -1).contiguous()
 
 
 def to_f16(t):
@@ -1388,9 +1435,10 @@ def to_f16(t):
     return out
 
 
-def encoder_block_hm(attn_hm, src, wstream, small, d_ffn, *, pos=None, want_next=True, eps=1e-5):
+def encoder_block_hm(attn_hm, src, wstream, small, d_ffn, *, pos=None, want_next=True, eps=1e-5, ffn_f16=False):
     """One encoder-layer tail of the bf16 plan: attn_hm (B, 8, S, 8) fp16, src (B, S, 64) fp32 -> (src_out fp32, and for the
-    NEXT layer value_hm (B, 8, S, 8) and proj_hm (B, 8, S, 36), both fp16, or None, None)."""
+    NEXT layer value_hm (B, 8, S, 8) fp16 and the sampling records proj_hm (B, 8, S, 30) float32-typed (24 fp32 offsets + 12 fp16
+    logits), or None, None)."""
     _c(attn_hm, "attn_hm", torch.float16), _c(src, "src"), _c(wstream, "wstream", torch.int16), _c(small, "small"), _c(pos, "pos")
     B, S, C = src.shape
     if C != 64 or tuple(attn_hm.shape) != (B, 8, S, 8):
@@ -1401,21 +1449,21 @@ def encoder_block_hm(attn_hm, src, wstream, small, d_ffn, *, pos=None, want_next
         raise RuntimeError("encoder_block_hm: wstream does not match d_ffn / want_next (pack_encoder_block_hm)")
     src_out = torch.empty_like(src)
     value_out = torch.empty_like(attn_hm) if want_next else None
-    proj_out = torch.empty((B, 8, S, 36), device=src.device, dtype=torch.float16) if want_next else None
+    proj_out = torch.empty((B, 8, S, PROJ_REC_FLOATS), device=src.device, dtype=torch.float32) if want_next else None
     rc = lib().msm_encoder_block_hm_fwd(_p(attn_hm), _p(src), _p(wstream), _p(small), _p(pos if want_next else None), _p(src_out), _p(value_out),
-                                        _p(proj_out), B * S, S, int(d_ffn), float(eps), _stream())
+                                        _p(proj_out), B * S, S, int(d_ffn), float(eps), int(bool(ffn_f16)), _stream())
     check(rc, "msm_encoder_block_hm_fwd")
     return src_out, value_out, proj_out
 
 
 def ms_deform_attn_encoder_lp(value_hm, spatial_shapes, level_start_index, proj_hm, n_points=4):
-    """Encoder self-attention gather of the bf16 plan: value_hm (B, 8, S, 8) fp16, proj_hm (B, 8, S, 36) fp16 records (offsets,
+    """Encoder self-attention gather of the bf16 plan: value_hm (B, 8, S, 8) fp16, proj_hm (B, 8, S, 30) 120-byte records (fp32 offsets,
     logits).  Returns attn_hm (B, 8, S, 8) fp16."""
-    _c(value_hm, "value_hm", torch.float16), _c(proj_hm, "proj_hm", torch.float16)
+    _c(value_hm, "value_hm", torch.float16), _c(proj_hm, "proj_hm", torch.float32)
     _c(spatial_shapes, "spatial_shapes", torch.int64), _c(level_start_index, "level_start_index", torch.int64)
     B, M, S, D = value_hm.shape
-    if tuple(proj_hm.shape) != (B, M, S, 36):
-        raise RuntimeError("ms_deform_attn_encoder_lp: proj_hm must be (B, heads, S, 36)")
+    if tuple(proj_hm.shape) != (B, M, S, PROJ_REC_FLOATS):
+        raise RuntimeError("ms_deform_attn_encoder_lp: proj_hm must be (B, heads, S, 30) float32-typed 120-byte records")
     out = torch.empty_like(value_hm)
     rc = lib().msm_msdeform_attn_enc_lp_fwd(_p(value_hm), _p(spatial_shapes), _p(level_start_index), _p(proj_hm), _p(out), B, S, M, D,
                                             spatial_shapes.shape[0], int(n_points), _stream())
