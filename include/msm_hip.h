@@ -182,6 +182,7 @@ int msm_msda_locations(const float* offsets, const float* logits, const float* r
  * ------------------------------------------------------------------------------------------- */
 #define MSM_MASK_SPARSE 1
 #define MSM_MASK_ROW_ANY_CLEARED 2
+#define MSM_MASK_F16 4              /* msm_mask_logits_bf16_fwd only: the packed features are IEEE halves (msm_pack_mask_features_f16), the product runs on the fp16 MFMA */
 int msm_mask_logits_fwd(const float* mask_embed, const float* mask_feat, float* mask_out,
                         uint8_t* attn_out, int32_t* row_any,
                         int B, int Q, int C, int H, int W, int th, int tw, int flags,
@@ -190,8 +191,12 @@ int msm_mask_logits_fwd(const float* mask_embed, const float* mask_feat, float* 
 /* bf16 variant of the mask step (BASELINE configs 3 and 5; SURVEY 8d: HBM-bound at AI 71.6 FLOP/B): bf16 operands,
  * fp32 accumulation, same outputs and flags.  mask_feat_packed is the channel-quad packed bf16 form of the feature
  * map, [B][C/4][H*W][4] (bf16 bit patterns in uint16), written by msm_pack_mask_features_bf16 from fp32 NCHW;
- * mask_embed stays fp32 and is rounded to bf16 (nearest even) inside the kernel.  C % 16 == 0, C <= 256. */
+ * mask_embed stays fp32 and is rounded to bf16 (nearest even) inside the kernel.  C % 16 == 0, C <= 256.
+ * Precision "f16": msm_pack_mask_features_f16 writes the same layout with IEEE-half elements (clamped to the half range) and
+ * the step is called with flags | MSM_MASK_F16 -- mask_embed is then rounded to fp16 and the product runs on
+ * v_mfma_f32_16x16x16_f16 (same rate; 2^-12 instead of 2^-9 roundings on the one step whose sign is the output). */
 int msm_pack_mask_features_bf16(const float* mask_feat, uint16_t* packed, int B, int C, int HW, void* stream);
+int msm_pack_mask_features_f16(const float* mask_feat, uint16_t* packed, int B, int C, int HW, void* stream);
 int msm_mask_logits_bf16_fwd(const float* mask_embed, const uint16_t* mask_feat_packed, float* mask_out,
                              uint8_t* attn_out, int32_t* row_any,
                              int B, int Q, int C, int H, int W, int th, int tw, int flags,
@@ -619,6 +624,10 @@ int msm_conv3x3_c64_f32(const float* in, const float* w_tap_major, float* out, d
  * activations as hi + lo bf16 operands, v_mfma_f32_16x16x32_bf16 with fp32 accumulation; moments from the fp32 results. */
 int msm_conv3x3_c64_bf16(const float* in, const float* w_tap_major, float* out, double* stats,
                          int stats_cleared, int B, int H, int W, void* stream);
+/* ... with IEEE-half operands (precision "f16"): weight and activations one fp16 term each (activations clamped to the half range),
+ * v_mfma_f32_16x16x32_f16: half the MFMAs of the bf16 form, 2^-12 roundings instead of the weight's 2^-9. */
+int msm_conv3x3_c64_f16(const float* in, const float* w_tap_major, float* out, double* stats,
+                        int stats_cleared, int B, int H, int W, void* stream);
 /* The same convolution with fp32-accurate results on the bf16 matrix pipe (f32_split plan): the activation as the three bf16
  * planes of msm_groupnorm_apply_split, the weight (fp32, tap-major) split when a workgroup copies its 32 output channels
  * into LDS, six bf16 MFMAs per product.  out / stats as msm_conv3x3_c64_f32. */
@@ -634,6 +643,8 @@ int msm_conv3x3_c64_nchw_f32(const float* in, const float* w_tap_major, const fl
  * operands, fp32 accumulation and fp32 planes out): the UCN path's mask_features convolution under set_precision("bf16"). */
 int msm_conv3x3_c64_nchw_bf16(const float* in, const float* w_tap_major, const float* bias, float* out, int B, int H, int W,
                               int Cout, void* stream);
+int msm_conv3x3_c64_nchw_f16(const float* in, const float* w_tap_major, const float* bias, float* out, int B, int H, int W,
+                             int Cout, void* stream);      /* the IEEE-half operand form (msm_conv3x3_c64_f16) */
 
 /* Encoder prologue: everything between the input projections and the first deformable-attention layer in one pass
  * over the token buffer (msdeformattn.py:326-329 GroupNorm of input_proj, :60-75 level concatenation;

@@ -19,6 +19,8 @@
 //     atomic per (workgroup, channel, moment);
 //   * tiles are handed out per image (blockIdx.y) in full rounds over the image's workgroups, the leftover tiles one per
 //     SIMD first (waves w, w+4, ... share a SIMD).
+#include <type_traits>
+
 #include "bf16.h"
 #include "common.h"
 
@@ -43,7 +45,9 @@ constexpr int C3_LDB = C3_K + 16;        // LDS row stride of the bf16 weight co
 // PB: 16-pixel blocks per wave (a tile is 16 PB consecutive pixels of an image row) -- with PB = 2 a weight fragment read from LDS
 // feeds two MFMAs and a tap's loads hide behind twice the matrix work; WV: waves per workgroup (PB = 2 needs the registers of two
 // waves per SIMD: WV = 8).
-template <bool NCHW, bool BF = false, int PB = 1, int WV = C3_W>
+// BF = 2 (precision "f16"): the weight as IEEE halves, a tap's activations as ONE fp16 term (clamped) on v_mfma_f32_16x16x32_f16: half
+// the MFMAs and no splitting work, 2^-12 roundings on both operands instead of 2^-9 on the weight.
+template <bool NCHW, int BF = 0, int PB = 1, int WV = C3_W>
 __global__ __launch_bounds__(WV * 64) void conv3x3_c64_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                               const float* __restrict__ bias, float* __restrict__ out,
                                                               double* __restrict__ stats, int H, int W) {
@@ -71,7 +75,8 @@ __global__ __launch_bounds__(WV * 64) void conv3x3_c64_kernel(const float* __res
         for (int k = 0; k < PER; ++k) {
             const int i = tid + k * (WV * 64);
             const int n = i / (C3_K / 4), c4 = i - n * (C3_K / 4);
-            if constexpr (BF) *reinterpret_cast<bf16x4*>(wlb + n * C3_LDB + c4 * 4) = pack4(wv[k].x, wv[k].y, wv[k].z, wv[k].w);
+            if constexpr (BF == 2) *reinterpret_cast<u32x2b*>(wlb + n * C3_LDB + c4 * 4) = pack4h(wv[k].x, wv[k].y, wv[k].z, wv[k].w);
+            else if constexpr (BF == 1) *reinterpret_cast<bf16x4*>(wlb + n * C3_LDB + c4 * 4) = pack4(wv[k].x, wv[k].y, wv[k].z, wv[k].w);
             else *reinterpret_cast<float4*>(wl + n * C3_LD + c4 * 4) = wv[k];
         }
     }
@@ -124,7 +129,27 @@ __global__ __launch_bounds__(WV * 64) void conv3x3_c64_kernel(const float* __res
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) acc[pb][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
         auto mma_tap = [&](int t, const float4 (&cur)[PB][4]) {
-            if constexpr (BF) {
+            if constexpr (BF == 2) {
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh) {
+                    f16x8 xf[PB];
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb)
+                        xf[pb] = cvt8h(cur[pb][2 * kh].x, cur[pb][2 * kh].y, cur[pb][2 * kh].z, cur[pb][2 * kh].w, cur[pb][2 * kh + 1].x,
+                                       cur[pb][2 * kh + 1].y, cur[pb][2 * kh + 1].z, cur[pb][2 * kh + 1].w);
+                    f16x8 a[4];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        a[mt] = *reinterpret_cast<const f16x8*>(wlb + (mt * 16 + lj) * C3_LDB + t * C3_C + kh * 32 + lq * 8);
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+                            acc[pb][mt] = NCHW ? mfma_f16k32(xf[pb], a[mt], acc[pb][mt]) : mfma_f16k32(a[mt], xf[pb], acc[pb][mt]);
+                }
+                return;
+            }
+            if constexpr (BF == 1) {
 #pragma unroll
                 for (int kh = 0; kh < 2; ++kh) {
                     bf16x8 xh[PB], xl[PB];
@@ -475,24 +500,30 @@ static int conv3x3_c64_launch(const float* in, const float* w_tap_major, float* 
     const int units2 = cdiv(W, 32) * H;
     const int per_image2 = min(max(1, 256 / B), cdiv(units2, 8));
     if (bf) {
+      auto go = [&](auto tag) -> int {
+        constexpr int BFV = decltype(tag)::value;
         // (one load per input ROW with lane shifts for dx = -1 / +1, as the split kernel does, was measured for this form too: bitwise the
         // same result, 55 us either way at B = 8, 120 x 160 -- the per-tile chain load -> split -> MFMA does not overlap with itself at
         // 2.3 tiles per wave, whichever way the operands arrive)
         if (wide) {
             const size_t lds = sizeof(unsigned short) * (size_t)C3_C * C3_LDB + sizeof(float) * (size_t)8 * C3_C * 2;
-            MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_kernel<false, true, 2, 8>, lds));
-            hipLaunchKernelGGL((conv3x3_c64_kernel<false, true, 2, 8>), dim3(per_image2, B), dim3(8 * 64), lds, st, in, w_tap_major, nullptr, out, stats,
+            MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_kernel<false, BFV, 2, 8>, lds));
+            hipLaunchKernelGGL((conv3x3_c64_kernel<false, BFV, 2, 8>), dim3(per_image2, B), dim3(8 * 64), lds, st, in, w_tap_major, nullptr, out, stats,
                                H, W);
         } else {
             const size_t lds = sizeof(unsigned short) * (size_t)C3_C * C3_LDB + sizeof(float) * (size_t)C3_W * C3_C * 2;
-            MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_kernel<false, true>, lds));
-            hipLaunchKernelGGL((conv3x3_c64_kernel<false, true>), dim3(per_image, B), dim3(C3_W * 64), lds, st, in, w_tap_major, nullptr, out, stats,
+            MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_kernel<false, BFV>, lds));
+            hipLaunchKernelGGL((conv3x3_c64_kernel<false, BFV>), dim3(per_image, B), dim3(C3_W * 64), lds, st, in, w_tap_major, nullptr, out, stats,
                                H, W);
         }
+        return MSM_OK;
+      };
+      const int rc = bf == 2 ? go(std::integral_constant<int, 2>{}) : go(std::integral_constant<int, 1>{});
+      if (rc != MSM_OK) return rc;
     } else if (wide) {
         const size_t lds = sizeof(float) * ((size_t)C3_C * C3_LD + (size_t)8 * C3_C * 2);
-        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_kernel<false, false, 2, 8>, lds));
-        hipLaunchKernelGGL((conv3x3_c64_kernel<false, false, 2, 8>), dim3(per_image2, B), dim3(8 * 64), lds, st, in, w_tap_major, nullptr, out, stats, H,
+        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_kernel<false, 0, 2, 8>, lds));
+        hipLaunchKernelGGL((conv3x3_c64_kernel<false, 0, 2, 8>), dim3(per_image2, B), dim3(8 * 64), lds, st, in, w_tap_major, nullptr, out, stats, H,
                            W);
     } else {
         const size_t lds = sizeof(float) * ((size_t)C3_C * C3_LD + (size_t)C3_W * C3_C * 2);
@@ -525,10 +556,16 @@ static int conv3x3_c64_nchw_launch(const float* in, const float* w_tap_major, co
     int per_image = max(1, 256 / (B * slices));
     per_image = min(per_image, cdiv(units, C3_W));
     if (bf) {
-        const size_t lds = sizeof(unsigned short) * (size_t)C3_C * C3_LDB + sizeof(float) * (size_t)C3_W * C3_C * 2;
-        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_kernel<true, true>, lds));
-        hipLaunchKernelGGL((conv3x3_c64_kernel<true, true>), dim3(per_image, B, slices), dim3(C3_W * 64), lds, (hipStream_t)stream, in, w_tap_major,
-                           bias, out, nullptr, H, W);
+        auto go = [&](auto tag) -> int {
+            constexpr int BFV = decltype(tag)::value;
+            const size_t lds = sizeof(unsigned short) * (size_t)C3_C * C3_LDB + sizeof(float) * (size_t)C3_W * C3_C * 2;
+            MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_kernel<true, BFV>, lds));
+            hipLaunchKernelGGL((conv3x3_c64_kernel<true, BFV>), dim3(per_image, B, slices), dim3(C3_W * 64), lds, (hipStream_t)stream, in, w_tap_major,
+                               bias, out, nullptr, H, W);
+            return MSM_OK;
+        };
+        const int rc = bf == 2 ? go(std::integral_constant<int, 2>{}) : go(std::integral_constant<int, 1>{});
+        if (rc != MSM_OK) return rc;
     } else {
         const size_t lds = sizeof(float) * ((size_t)C3_C * C3_LD + (size_t)C3_W * C3_C * 2);
         MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_kernel<true>, lds));
@@ -547,4 +584,12 @@ extern "C" int msm_conv3x3_c64_nchw_f32(const float* in, const float* w_tap_majo
 extern "C" int msm_conv3x3_c64_nchw_bf16(const float* in, const float* w_tap_major, const float* bias, float* out, int B, int H, int W,
                                          int Cout, void* stream) {
     return conv3x3_c64_nchw_launch(in, w_tap_major, bias, out, B, H, W, Cout, 1, stream);
+}
+extern "C" int msm_conv3x3_c64_f16(const float* in, const float* w_tap_major, float* out, double* stats,
+                                   int stats_cleared, int B, int H, int W, void* stream) {
+    return conv3x3_c64_launch(in, w_tap_major, out, stats, stats_cleared, B, H, W, 2, stream);
+}
+extern "C" int msm_conv3x3_c64_nchw_f16(const float* in, const float* w_tap_major, const float* bias, float* out, int B, int H, int W,
+                                        int Cout, void* stream) {
+    return conv3x3_c64_nchw_launch(in, w_tap_major, bias, out, B, H, W, Cout, 2, stream);
 }

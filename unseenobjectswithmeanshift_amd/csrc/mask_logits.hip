@@ -698,7 +698,14 @@ __device__ __forceinline__ unsigned short f2bf(float x) {   // round to nearest 
 
 // NKS: 16-channel k-steps held per tile -- 4 for the folded step (C = 64: 8 loads and 56 MFMAs per tile; the generic 16 would
 // request every clamped slot again, 32 loads per tile of which 8 are needed), BKS otherwise (C <= 256, runtime count)
-template <int POOL, bool WRITE, int NKS>
+// F16 (flag MSM_MASK_F16, precision "f16"): both operands hold IEEE halves (msm_pack_mask_features_f16; mask_embed converted with a
+// clamp when it is staged) and the product runs on v_mfma_f32_16x16x16_f16 -- same layouts, same rate, 2^-12 instead of 2^-9 roundings
+// on the operands of the one step whose sign IS the output.
+__device__ __forceinline__ unsigned short f2h(float x) {     // round to nearest even, clamped to the half range
+    return __builtin_bit_cast(unsigned short, (_Float16)__builtin_amdgcn_fmed3f(x, -65504.f, 65504.f));
+}
+typedef _Float16 f16x4m __attribute__((ext_vector_type(4)));
+template <int POOL, bool WRITE, int NKS, bool F16 = false>
 __global__ __launch_bounds__(MW * 64) void mask_logits_bf16_kernel(const float* __restrict__ emb, const unsigned short* __restrict__ featp,
                                                                float* __restrict__ mask_out, uint8_t* __restrict__ attn_out,
                                                                int32_t* __restrict__ row_any, int Q, int C, int H, int W, int th,
@@ -727,8 +734,13 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_bf16_kernel(const float* 
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q0 + r < Q) v = *reinterpret_cast<const float4*>(eb + (int64_t)r * emb_ld + c4);
         u32x2 pk;
-        pk.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
-        pk.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+        if constexpr (F16) {
+            pk.x = (unsigned)f2h(v.x) | ((unsigned)f2h(v.y) << 16);
+            pk.y = (unsigned)f2h(v.z) | ((unsigned)f2h(v.w) << 16);
+        } else {
+            pk.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+            pk.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+        }
         *reinterpret_cast<u32x2*>(&Eb[r * SEb + c4]) = pk;
     }
     __syncthreads();
@@ -790,8 +802,13 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_bf16_kernel(const float* 
 #pragma unroll
                 for (int m = 0; m < QB; ++m) {
                     const bf16x4 a = __builtin_bit_cast(bf16x4, *reinterpret_cast<const u32x2*>(er + m * 16 * SEb));
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bt_, a, acc[m][0], 0, 0, 0);      // D[pixel][query]
-                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bb_, a, acc[m][1], 0, 0, 0);
+                    if constexpr (F16) {
+                        acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4m, bt_), __builtin_bit_cast(f16x4m, a), acc[m][0], 0, 0, 0);
+                        acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4m, bb_), __builtin_bit_cast(f16x4m, a), acc[m][1], 0, 0, 0);
+                    } else {
+                        acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bt_, a, acc[m][0], 0, 0, 0);      // D[pixel][query]
+                        acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(bb_, a, acc[m][1], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -819,6 +836,7 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_bf16_kernel(const float* 
 }
 
 // fp32 NCHW [B][C][HW] -> bf16 channel-quad packed [B][C/4][HW][4]
+template <bool F16>
 __global__ __launch_bounds__(256) void pack_mask_features_bf16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out,
                                                                       int64_t total, int C4, int HW) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -826,8 +844,13 @@ __global__ __launch_bounds__(256) void pack_mask_features_bf16_kernel(const floa
         const int64_t r = i / HW;                 // b * C4 + c4
         const float* src = in + (r * 4) * HW + p;
         u32x2 pk;
-        pk.x = (unsigned)f2bf(src[0]) | ((unsigned)f2bf(src[HW]) << 16);
-        pk.y = (unsigned)f2bf(src[2 * (int64_t)HW]) | ((unsigned)f2bf(src[3 * (int64_t)HW]) << 16);
+        if constexpr (F16) {
+            pk.x = (unsigned)f2h(src[0]) | ((unsigned)f2h(src[HW]) << 16);
+            pk.y = (unsigned)f2h(src[2 * (int64_t)HW]) | ((unsigned)f2h(src[3 * (int64_t)HW]) << 16);
+        } else {
+            pk.x = (unsigned)f2bf(src[0]) | ((unsigned)f2bf(src[HW]) << 16);
+            pk.y = (unsigned)f2bf(src[2 * (int64_t)HW]) | ((unsigned)f2bf(src[3 * (int64_t)HW]) << 16);
+        }
         *reinterpret_cast<u32x2*>(out + i * 4) = pk;
     }
 }
@@ -1100,15 +1123,22 @@ extern "C" int msm_debug_mask_ts(unsigned long long* host_out) {
 }
 #endif
 
-extern "C" int msm_pack_mask_features_bf16(const float* mask_feat, uint16_t* packed, int B, int C, int HW, void* stream) {
-    MSM_REQUIRE(mask_feat && packed, "msm_pack_mask_features_bf16: null pointer");
-    MSM_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 4 == 0, "msm_pack_mask_features_bf16: C=%d must be a multiple of 4", C);
-    MSM_REQUIRE((((uintptr_t)packed) & 7) == 0, "msm_pack_mask_features_bf16: packed must be 8-byte aligned");
+static int pack_mask_features_16(const char* who, const float* mask_feat, uint16_t* packed, int B, int C, int HW, bool f16, void* stream) {
+    MSM_REQUIRE(mask_feat && packed, "%s: null pointer", who);
+    MSM_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 4 == 0, "%s: C=%d must be a multiple of 4", who, C);
+    MSM_REQUIRE((((uintptr_t)packed) & 7) == 0, "%s: packed must be 8-byte aligned", who);
     const int64_t total = (int64_t)B * (C / 4) * HW;
-    hipLaunchKernelGGL(pack_mask_features_bf16_kernel, dim3((unsigned)min((int64_t)4096, (total + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, mask_feat, packed, total, C / 4, HW);
-    MSM_CHECK_LAUNCH("msm_pack_mask_features_bf16");
+    const dim3 grid((unsigned)min((int64_t)4096, (total + 255) / 256));
+    if (f16) hipLaunchKernelGGL(pack_mask_features_bf16_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, mask_feat, packed, total, C / 4, HW);
+    else hipLaunchKernelGGL(pack_mask_features_bf16_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, mask_feat, packed, total, C / 4, HW);
+    MSM_CHECK_LAUNCH(who);
     return MSM_OK;
+}
+extern "C" int msm_pack_mask_features_bf16(const float* mask_feat, uint16_t* packed, int B, int C, int HW, void* stream) {
+    return pack_mask_features_16("msm_pack_mask_features_bf16", mask_feat, packed, B, C, HW, false, stream);
+}
+extern "C" int msm_pack_mask_features_f16(const float* mask_feat, uint16_t* packed, int B, int C, int HW, void* stream) {
+    return pack_mask_features_16("msm_pack_mask_features_f16", mask_feat, packed, B, C, HW, true, stream);
 }
 
 extern "C" int msm_mask_logits_bf16_fwd(const float* mask_embed, const uint16_t* mask_feat_packed, float* mask_out,
@@ -1157,17 +1187,18 @@ extern "C" int msm_mask_logits_bf16_fwd(const float* mask_embed, const uint16_t*
                            int64_t, const float*, int64_t);
     const bool wr = mask_out != nullptr;
     kern_t kern;
-#define MASKB_PICK(P)                                                                                                     \
-    (C <= 64 ? (wr ? (kern_t)mask_logits_bf16_kernel<P, true, 4> : (kern_t)mask_logits_bf16_kernel<P, false, 4>)            \
-             : (wr ? (kern_t)mask_logits_bf16_kernel<P, true, BKS> : (kern_t)mask_logits_bf16_kernel<P, false, BKS>))
+    const bool f16 = (flags & MSM_MASK_F16) != 0;
+#define MASKB_PICK_T(P, WR, NK) (f16 ? (kern_t)mask_logits_bf16_kernel<P, WR, NK, true> : (kern_t)mask_logits_bf16_kernel<P, WR, NK, false>)
+#define MASKB_PICK(P) (C <= 64 ? (wr ? MASKB_PICK_T(P, true, 4) : MASKB_PICK_T(P, false, 4)) : (wr ? MASKB_PICK_T(P, true, BKS) : MASKB_PICK_T(P, false, BKS)))
     switch (pool) {
-        case 0: kern = C <= 64 ? (kern_t)mask_logits_bf16_kernel<0, true, 4> : (kern_t)mask_logits_bf16_kernel<0, true, BKS>; break;
+        case 0: kern = C <= 64 ? MASKB_PICK_T(0, true, 4) : MASKB_PICK_T(0, true, BKS); break;
         case 1: kern = MASKB_PICK(1); break;
         case 2: kern = MASKB_PICK(2); break;
         case 4: kern = MASKB_PICK(4); break;
         default: kern = MASKB_PICK(8); break;
     }
 #undef MASKB_PICK
+#undef MASKB_PICK_T
     MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)kern, lds));
     hipLaunchKernelGGL(kern, grid, block, lds, st, mask_embed, mask_feat_packed, mask_out, attn_out, row_any, Q, C, H, W, th, tw, ypar,
                        n_rowpairs, rp_step, rp_first, (int)((int64_t)C * H * W * 2), embed_ld, qbias, qbias_ld);

@@ -126,7 +126,7 @@ class MeanShiftMaskFormerHead(PlanAttributes, nn.Module):
         if hasattr(self.pixel_decoder, "lp_operands"):
             self.pixel_decoder.lp_operands = "f16" if mode == "f16" else "bf16"
         low = "bf16" if lowp else "f32"
-        self.predictor.mask_step_dtype = "f32_split" if mode == "f32_split" else low
+        self.predictor.mask_step_dtype = "f32_split" if mode == "f32_split" else (mode if lowp else "f32")
         if hasattr(self.predictor, "tails_dtype"):
             self.predictor.tails_dtype = mode if lowp else "f32"
         if hasattr(self.predictor, "attention_dtype"):

@@ -281,7 +281,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         self._tails_cache = None
         # "bf16": the Q x pixel-embedding mask step runs with bf16 operands / fp32 accumulation on a packed copy of
         # mask_features made once per forward (BASELINE configs 3 and 5); everything else stays fp32
-        self.mask_step_dtype = "f32"        # "bf16": bf16 operands; "f32_split": fp32-accurate three-term bf16 splits (folded form)
+        self.mask_step_dtype = "f32"        # "bf16": bf16 operands; "f16": IEEE-half operands (same kernel, fp16 MFMAs); "f32_split": fp32-accurate three-term bf16 splits (folded form)
         # "bf16": the fused row-local tails (dec_post_cross / dec_post_self / dec_heads) stream bf16 weights and multiply on
         # bf16 MFMAs with fp32 accumulation (activations as hi + lo pairs); part of set_precision("bf16")
         self.tails_dtype = "f32"
@@ -635,15 +635,16 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             mask_features, folded = mask_features.tensor(), False           # literal order: materialise (B, mask_dim, H, W)
         if not folded:
             mask_features = mask_features.contiguous()
-        if self.mask_step_dtype not in ("f32", "bf16", "f32_split"):
-            raise ValueError("mask_step_dtype must be 'f32', 'bf16' or 'f32_split'")
+        if self.mask_step_dtype not in ("f32", "bf16", "f16", "f32_split"):
+            raise ValueError("mask_step_dtype must be 'f32', 'bf16', 'f16' or 'f32_split'")
         mf_planes = mask_features.act if folded else mask_features
         # the default inference plan never runs the full-resolution mask kernel on all queries (attention masks at key resolution,
         # the final step on the top-K embeddings with the fp32 kernel): no packed copy of the activation is needed then
         lean = (folded and self.fused_tails and self.fold_kv and not self.aux_outputs and self.pooled_attention_masks and self.num_layers > 0
                 and mf_planes.shape[1] == 64 and 0 < final_topk < self.query_feat.weight.shape[0]
                 and len(self._poolable_sizes(mf_planes, sizes)) == len(set((int(a), int(b)) for a, b in sizes)))
-        self._packed_mf = ops.pack_mask_features_bf16(mf_planes) if (self.mask_step_dtype == "bf16" and not lean) else None
+        self._packed_mf = ops.pack_mask_features_bf16(mf_planes, f16=self.mask_step_dtype == "f16") \
+            if (self.mask_step_dtype in ("bf16", "f16") and not lean) else None
         # f32_split: the folded 64-channel step as exact three-term bf16 splits on the bf16 matrix pipe (fp32-accurate); the
         # literal 256-channel form keeps the fp32 MFMA kernel
         self._packed_mf_split = ops.pack_mask_features_split(mf_planes) \
@@ -728,6 +729,7 @@ class SimpleBasePixelDecoder(PlanAttributes, nn.Module):
         self.mask_dim = mask_dim
         self.conv_dim = conv_dim
         self.precision = "f32"             # "bf16" (head.set_precision): the mask_features convolution in the low-precision form
+        self.lp_operands = "bf16"          # ... with bf16 or IEEE-half ("f16") operands
         if mask_dim != 64:
             self.mask_features = nn.Conv2d(conv_dim, mask_dim, kernel_size=3, stride=1, padding=1)
         self.maskformer_num_feature_levels = 1
@@ -751,7 +753,9 @@ class SimpleBasePixelDecoder(PlanAttributes, nn.Module):
         B, C, H, W = y.shape
         tok = ops.transpose_last2(y.contiguous().view(B, C, H * W))                       # NHWC tokens
         w = self.mask_features.weight.permute(0, 2, 3, 1).reshape(self.mask_dim, 9 * C).contiguous()
-        mf = ops.conv3x3_tokens_to_nchw(tok, w, self.mask_features.bias, int(H), int(W), bf16=getattr(self, "precision", "f32") == "bf16")
+        lp = getattr(self, "precision", "f32") == "bf16"
+        mf = ops.conv3x3_tokens_to_nchw(tok, w, self.mask_features.bias, int(H), int(W),
+                                        bf16=("f16" if getattr(self, "lp_operands", "bf16") == "f16" else True) if lp else False)
         return mf.view(B, self.mask_dim, H, W), None, multi_scale_features
 
 
@@ -1175,7 +1179,8 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
             # weight-stationary 3x3 kernel; the moments of layer_1's GroupNorm come out of its epilogue.  f32_split: the
             # GroupNorm above wrote its result as three bf16 planes, the convolution multiplies exact three-term splits
             y, y_stats = ops.conv3x3_c64(y, self._w3(), H, W, stats=fpn_stats[1], stats_cleared=fpn_stats[1] is not None,
-                                         bf16=self.precision == "bf16" and self.lp_conv3x3, split=split3)
+                                         bf16=(self.lp_operands == "f16" and "f16" or True) if (self.precision == "bf16" and self.lp_conv3x3) else False,
+                                         split=split3)
         else:
             y = ops.conv3x3_tokens(y, self._w3(), H, W)
         wm = self.mask_features.weight.view(self.mask_dim, C)

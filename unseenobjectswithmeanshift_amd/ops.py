@@ -253,7 +253,8 @@ def conv3x3_c64(t, w_tap_major, H, W, *, stats=None, stats_cleared=False, bf16=F
     """3x3 / pad 1 convolution of a 64-channel token map t (B, H*W, 64) to 64 channels, weight (64, 9*64) tap-major, with
     the GroupNorm moments of the result as a by-product: returns (out (B, H*W, 64), stats (B, 64, 2) float64).  ``stats``
     given: accumulated into when ``stats_cleared`` (the caller zeroed it), else zeroed first.  ``bf16``: the low-precision
-    mode (bf16 MFMA operands -- weight single, activations hi + lo --, fp32 accumulation and output).  ``split``: t is the
+    mode (bf16 MFMA operands -- weight single, activations hi + lo --, fp32 accumulation and output); ``bf16="f16"``: IEEE-half
+    operands, one term each (precision "f16").  ``split``: t is the
     (3, B, H*W, 64) bf16 planes of groupnorm_tokens(split_planes=True); fp32-accurate results from six bf16 MFMAs per product."""
     if split:
         _c(t, "t", torch.bfloat16)
@@ -272,7 +273,7 @@ def conv3x3_c64(t, w_tap_major, H, W, *, stats=None, stats_cleared=False, bf16=F
         stats_cleared = False
     elif tuple(stats.shape) != (B, 64, 2):
         raise RuntimeError("stats must be (B, 64, 2) float64")
-    name = "msm_conv3x3_c64_split" if split else ("msm_conv3x3_c64_bf16" if bf16 else "msm_conv3x3_c64_f32")
+    name = "msm_conv3x3_c64_split" if split else ("msm_conv3x3_c64_f16" if bf16 == "f16" else "msm_conv3x3_c64_bf16" if bf16 else "msm_conv3x3_c64_f32")
     rc = getattr(lib(), name)(_p(t), _p(w_tap_major), _p(out), _p(stats), 1 if stats_cleared else 0, B, H, W, _stream())
     check(rc, name)
     return out, stats
@@ -282,15 +283,16 @@ def conv3x3_tokens_to_nchw(t, w_tap_major, bias, H, W, bf16=False):
     """3x3 / pad 1 convolution of an NHWC token map with the output written directly as NCHW (B, Cout, H*W)
     (SimpleBasePixelDecoder.mask_features, fpn.py:237-246: Conv2d 3x3 with bias).  64 input channels, Cout % 64 == 0 and
     W % 4 == 0 take the weight-stationary kernel (csrc/conv3x3.hip), other shapes the implicit GEMM.  ``bf16`` (low-precision
-    mode, weight-stationary shapes only): the weight rounded to one bf16, activations as hi + lo operands, fp32 result."""
+    mode, weight-stationary shapes only): the weight rounded to one bf16, activations as hi + lo operands, fp32 result;
+    ``bf16="f16"``: IEEE-half operands, one term each."""
     _c(t, "t"), _c(w_tap_major, "w"), _c(bias, "bias")
     B, HW, Cin = t.shape
     Cout = w_tap_major.shape[0]
     out = torch.empty((B, Cout, HW), device=t.device, dtype=torch.float32)
     if Cin == 64 and Cout % 64 == 0 and Cout <= 1024 and W % 4 == 0 and HW == H * W:
-        fn = lib().msm_conv3x3_c64_nchw_bf16 if bf16 else lib().msm_conv3x3_c64_nchw_f32
-        rc = fn(_p(t), _p(w_tap_major), _p(bias), _p(out), B, H, W, Cout, _stream())
-        check(rc, "msm_conv3x3_c64_nchw_bf16" if bf16 else "msm_conv3x3_c64_nchw_f32")
+        name = "msm_conv3x3_c64_nchw_f16" if bf16 == "f16" else "msm_conv3x3_c64_nchw_bf16" if bf16 else "msm_conv3x3_c64_nchw_f32"
+        rc = getattr(lib(), name)(_p(t), _p(w_tap_major), _p(bias), _p(out), B, H, W, Cout, _stream())
+        check(rc, name)
         return out
     rc = lib().msm_gemm_f32(_p(t), None, _p(w_tap_major), _p(bias), _p(out), HW, Cout, 9 * Cin, B,
                             Cin, 1, HW * Cin, 0, 0, 1, HW, Cout * HW, 0,
@@ -436,14 +438,16 @@ def msda_locations(offsets, logits, reference_points, spatial_shapes):
     return loc, attn
 
 
-def pack_mask_features_bf16(mask_features):
+def pack_mask_features_bf16(mask_features, f16=False):
     """fp32 NCHW (B, C, H, W) -> the channel-quad packed bf16 layout (B, C/4, H*W, 4) (int16 bit patterns) the bf16 mask
-    step streams; do it once per forward, the 10 mask steps of a decoder pass reuse it."""
+    step streams; do it once per forward, the 10 mask steps of a decoder pass reuse it.  ``f16`` (precision "f16"): IEEE-half
+    elements, returned as a torch.float16 tensor -- mask_logits(packed_bf16=...) picks the fp16 MFMAs by that dtype."""
     _c(mask_features, "mask_features")
     B, C, H, W = mask_features.shape
-    out = torch.empty((B, C // 4, H * W, 4), device=mask_features.device, dtype=torch.int16)
-    rc = lib().msm_pack_mask_features_bf16(_p(mask_features), _p(out), B, C, H * W, _stream())
-    check(rc, "msm_pack_mask_features_bf16")
+    out = torch.empty((B, C // 4, H * W, 4), device=mask_features.device, dtype=torch.float16 if f16 else torch.int16)
+    name = "msm_pack_mask_features_f16" if f16 else "msm_pack_mask_features_bf16"
+    rc = getattr(lib(), name)(_p(mask_features), _p(out), B, C, H * W, _stream())
+    check(rc, name)
     return out
 
 
@@ -552,9 +556,10 @@ def mask_logits(mask_embed, mask_features, *, want_mask=True, target_size=None, 
         check(rc, "msm_mask_logits_split_fwd")
         return mask, attn, row_any
     if packed_bf16 is not None:
-        _c(packed_bf16, "packed_bf16", torch.int16)
+        half = packed_bf16.dtype == torch.float16                 # pack_mask_features_bf16(..., f16=True): MSM_MASK_F16
+        _c(packed_bf16, "packed_bf16", torch.float16 if half else torch.int16)
         rc = lib().msm_mask_logits_bf16_fwd(_p(mask_embed), _p(packed_bf16), _p(mask), _p(attn), _p(row_any),
-                                            B, Q, C, H, W, th, tw, flags, embed_ld, _p(qbias), qb_ld, _stream())
+                                            B, Q, C, H, W, th, tw, flags | (4 if half else 0), embed_ld, _p(qbias), qb_ld, _stream())
         check(rc, "msm_mask_logits_bf16_fwd")
     else:
         rc = lib().msm_mask_logits_fwd(_p(mask_embed), _p(mask_features), _p(mask), _p(attn), _p(row_any),
