@@ -266,16 +266,22 @@ def test_hypersphere_attention(B, Lq, S, masked):
     close(alt, ref, rtol=1e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize("kv_bf16", [False, True])
+@pytest.mark.parametrize("kv_bf16", [False, True, "f16keys", "f16scores"])
 @pytest.mark.parametrize("B,Lq,S,masked", [(2, 100, 300, True), (2, 100, 100, False), (1, 100, 4800, True), (2, 20, 37, True), (1, 300, 1200, True),
                                            (1, 300, 19200, True)])
 def test_hypersphere_attention_low_precision(B, Lq, S, masked, kv_bf16):
     """msm_hypersphere_attn_lp_fwd (bf16 MFMA operands, fp32 accumulation; K / V stored as fp32 or bf16) against the oracle.
     The unit vectors q^, k^ carry 8 mantissa bits, so a logit kappa q^.k^ moves by ~kappa 2^-9 / sqrt(32) ~ 1e-2 and the outputs
-    (components of unit vectors) by a few 1e-3; the oracle is fed the bf16-rounded K / V when those are what is stored."""
+    (components of unit vectors) by a few 1e-3; the oracle is fed the bf16-rounded K / V when those are what is stored.
+    "f16keys" (precision "f16", kv_format 2): K stored as IEEE half, V as bf16, q^ / k^ on fp16 MFMAs; "f16scores" (kv_format 3): fp32
+    K / V with the fp16 score operands -- the scores' error drops eightfold, what is left is the bf16 rounding of the probabilities
+    and of V in P V (tighter bounds below)."""
     H, E = 8, 256
     q, k, v = rnd(B, Lq, E, seed=1), rnd(B, S, E, seed=2), rnd(B, S, E, seed=3)
-    if kv_bf16:
+    f16keys, f16scores = kv_bf16 == "f16keys", kv_bf16 == "f16scores"
+    if f16keys:
+        k, v = k.to(torch.float16).float(), _bf16_round(v)
+    elif kv_bf16 is True:
         k, v = _bf16_round(k), _bf16_round(v)
     m = row_any = add = None
     if masked:
@@ -291,11 +297,19 @@ def test_hypersphere_attention_low_precision(B, Lq, S, masked, kv_bf16):
     hd = lambda t, n: t.view(B, n, H, 32).permute(0, 2, 1, 3).reshape(B * H, n, 32)
     o, _ = O.hypersphere_attention(hd(q, Lq), hd(k, S), hd(v, S), add)
     ref = o.view(B, H, Lq, 32).permute(0, 2, 1, 3).reshape(B, Lq, E)
-    kd, vd = (k.to(DEV).to(torch.bfloat16), v.to(DEV).to(torch.bfloat16)) if kv_bf16 else (k.to(DEV), v.to(DEV))
-    kw = dict(masked=None if m is None else m.to(torch.uint8).to(DEV), row_any=None if row_any is None else row_any.to(DEV))
+    if f16keys:          # the K columns hold half bit patterns inside a bfloat16-typed tensor (kv_project_multi(keys_f16=True))
+        kd, vd = k.to(DEV).to(torch.float16).view(torch.bfloat16), v.to(DEV).to(torch.bfloat16)
+    elif kv_bf16 is True:
+        kd, vd = k.to(DEV).to(torch.bfloat16), v.to(DEV).to(torch.bfloat16)
+    else:
+        kd, vd = k.to(DEV), v.to(DEV)
+    kw = dict(masked=None if m is None else m.to(torch.uint8).to(DEV), row_any=None if row_any is None else row_any.to(DEV),
+              keys_f16=f16keys or f16scores)
     got = ops().hypersphere_attention(q.to(DEV), kd, vd, H, low_precision=True, **kw)
     err = (got.cpu() - ref).abs()
     print(f"lp attention S={S} kv_bf16={kv_bf16}: max |d| {float(err.max()):.2e} mean {float(err.mean()):.2e}")
+    if f16keys or f16scores:
+        assert float(err.max()) < 1.5e-2 and float(err.mean()) < 8e-4
     assert float(err.max()) < 3e-2 and float(err.mean()) < 2e-3
     nrm = got.view(B, Lq, H, 32).norm(dim=-1)
     close(nrm, torch.ones_like(nrm).cpu(), rtol=1e-5, atol=1e-5)                  # the output normalisation is fp32
@@ -363,12 +377,15 @@ def _ln(x, g, b, eps=1e-5):
 
 
 @pytest.mark.parametrize("B,Q", [(2, 100), (1, 7), (3, 16)])
-@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "bf16", "f16"])
 def test_decoder_fused_tails(B, Q, prec):
     """csrc/dec_chain.hip against the same chain in torch fp64 (DEC:245-260, 171-181, 296-300, 637-638, 661-665);
     tolerance: fp32 rounding of 256/2048-term dot products on O(1) values.  prec = "bf16": the low-precision entry points
     (bf16 weight fragments, activations as hi + lo bf16 pairs, fp32 accumulation) against the same fp64 chain on the
-    bf16-ROUNDED weights -- what is left is the 2^-17 residual of the activation split."""
+    bf16-ROUNDED weights -- what is left is the 2^-17 residual of the activation split.  prec = "f16" (round 5): IEEE-half weight
+    fragments and ONE fp16 activation term per product, against the fp64 chain with the weights AND each GEMM's input rounded to
+    fp16 -- what is left is fp32 accumulation; that this form is closer to the exact chain than the bf16 one is
+    test_decoder_tails_f16_is_closer_to_exact_than_bf16."""
     E, Fh = 256, 2048
     r = lambda *s, seed, k=1.0: (rnd(*s, seed=seed) * k)
     o, res, qpos = r(B, Q, E, seed=1), r(B, Q, E, seed=2), r(Q, E, seed=3)
@@ -378,15 +395,21 @@ def test_decoder_fused_tails(B, Q, prec):
     dev = lambda *ts: [t.to(DEV) for t in ts]
     dbl = lambda *ts: [t.double() for t in ts]
     bf = prec == "bf16"
-    pack = (lambda w: ops().dec_pack_weight_bf16(w.to(DEV))) if bf else (lambda w: ops().dec_pack_weight(w.to(DEV)))
-    rw = _bf16_round if bf else (lambda w: w)                # the weights the kernels actually multiply by
-    tol = 4.0 if bf else 1.0
+    f16 = prec == "f16"
+    pack = {"f32": lambda w: ops().dec_pack_weight(w.to(DEV)), "bf16": lambda w: ops().dec_pack_weight_bf16(w.to(DEV)),
+            "f16": lambda w: ops().dec_pack_weight_f16(w.to(DEV))}[prec]
+    rw = _bf16_round if bf else ((lambda w: w.to(torch.float16).float()) if f16 else (lambda w: w))      # the weights the kernels actually multiply by
+    # (f16: a stage's input differs from the reference's by ~1e-5, so a few per cent of its elements round to the neighbouring half --
+    # each such flip is 2^-11 |x| |w|: the price of rounding activations at all, and why this form's bound is twice the bf16 form's)
+    tol = 8.0 if f16 else (4.0 if bf else 1.0)
+    # f16: the activation enters every product as ONE fp16 term -- the references round it the same way in front of each GEMM
+    A = (lambda t: t.float().to(torch.float16).double()) if f16 else (lambda t: t)
     closed_ = globals()["closed"]
     closed = lambda got, ref, rtol, atol: closed_(got, ref, rtol=rtol * tol, atol=atol * tol)  # noqa: E731
     # the documented fragment order (include/msm_hip.h)
     N_, K_ = w_in.shape
-    if bf:       # [t][kc][up][lq][lj][h][c] <- W[t*16 + lj][kc*64 + (2 up + h)*16 + lq*4 + c]
-        want = w_in.view(N_ // 16, 16, K_ // 64, 2, 2, 4, 4).permute(0, 2, 3, 5, 1, 4, 6).contiguous().view(N_, K_).to(torch.bfloat16)
+    if bf or f16:       # [t][kc][up][lq][lj][h][c] <- W[t*16 + lj][kc*64 + (2 up + h)*16 + lq*4 + c]
+        want = w_in.view(N_ // 16, 16, K_ // 64, 2, 2, 4, 4).permute(0, 2, 3, 5, 1, 4, 6).contiguous().view(N_, K_).to(torch.float16 if f16 else torch.bfloat16)
     else:
         want = w_in.view(N_ // 16, 16, K_ // 64, 4, 4, 4).permute(0, 2, 3, 4, 1, 5).contiguous().view(N_, K_)
     assert torch.equal(pack(w_in).cpu(), want)
@@ -394,17 +417,17 @@ def test_decoder_fused_tails(B, Q, prec):
     # post_cross
     x, qk, v = ops().dec_post_cross(*dev(o, res, qpos), pack(wo), *dev(bo, g, b), pack(w_in), b_in.to(DEV))
     O_, R_, P_, WO, BO, G_, B_, WI, BI = dbl(o, res, qpos, wo, bo, g, b, w_in, b_in)
-    xr = _ln(R_ + O_ @ WO.t() + BO, G_, B_)
+    xr = _ln(R_ + A(O_) @ WO.t() + BO, G_, B_)
     closed(x, xr, rtol=1e-4, atol=2e-5)
-    closed(qk, (xr + P_) @ WI[:2 * E].t() + BI[:2 * E], rtol=1e-4, atol=5e-5)
-    closed(v, xr @ WI[2 * E:].t() + BI[2 * E:], rtol=1e-4, atol=5e-5)
+    closed(qk, A(xr + P_) @ WI[:2 * E].t() + BI[:2 * E], rtol=1e-4, atol=5e-5)
+    closed(v, A(xr) @ WI[2 * E:].t() + BI[2 * E:], rtol=1e-4, atol=5e-5)
     # post_self
     w1, b1 = rw(r(Fh, E, seed=10, k=E ** -0.5)), r(Fh, seed=11, k=0.1)
     w2, b2 = rw(r(E, Fh, seed=12, k=Fh ** -0.5)), r(E, seed=13, k=0.1)
     x2, parts = ops().dec_post_self(*dev(o, res), pack(wo), *dev(bo, g, b), pack(w1), b1.to(DEV), pack(w2))
     closed(x2, xr, rtol=1e-4, atol=2e-5)
     W1, B1, W2, B2 = dbl(w1, b1, w2, b2)
-    ffn = torch.relu(xr @ W1.t() + B1) @ W2.t()
+    ffn = A(torch.relu(A(xr) @ W1.t() + B1)) @ W2.t()
     closed(parts.double().sum(0), ffn, rtol=1e-4, atol=5e-5)
     for n_parts in (1, 2, 8):
         x3, p3 = ops().dec_post_self(*dev(o, res), pack(wo), *dev(bo, g, b), pack(w1), b1.to(DEV), pack(w2), n_parts=n_parts)
@@ -425,22 +448,43 @@ def test_decoder_fused_tails(B, Q, prec):
     dr = _ln(t, g2.double(), be2.double())
     er = dr
     for i, (w, bb) in enumerate(mlp):
-        er = er @ w.double().t() + bb.double()
+        er = A(er) @ w.double().t() + bb.double()
         if i < 2:
             er = torch.relu(er)
     closed(out, t, rtol=1e-4, atol=1e-6)
     closed(d, dr, rtol=1e-4, atol=5e-5)
     closed(e, er, rtol=1e-4, atol=1e-4)
-    closed(q, (t + P_) @ wq.double().t() + bq.double(), rtol=1e-4, atol=5e-5)
+    closed(q, A(t + P_) @ wq.double().t() + bq.double(), rtol=1e-4, atol=5e-5)
     # initial form: no parts, no FFN norm, no block norm, nothing optional
     out0, d0, e0, q0 = ops().dec_heads(res.to(DEV), *dev(g2, be2), mlp_d, want_out=False)
     assert out0 is None and d0 is None and q0 is None
     er = _ln(R_, g2.double(), be2.double())
     for i, (w, bb) in enumerate(mlp):
-        er = er @ w.double().t() + bb.double()
+        er = A(er) @ w.double().t() + bb.double()
         if i < 2:
             er = torch.relu(er)
     closed(e0, er, rtol=1e-4, atol=1e-4)
+    with pytest.raises(RuntimeError, match="all float32, all bfloat16 or all float16"):
+        ops().dec_post_cross(*dev(o, res, qpos), ops().dec_pack_weight_bf16(wo.to(DEV)), *dev(bo, g, b), ops().dec_pack_weight_f16(w_in.to(DEV)), b_in.to(DEV))
+
+
+def test_decoder_tails_f16_is_closer_to_exact_than_bf16():
+    """Why precision "f16" exists: the same FFN stage (msm_dec_post_self) against the fp64 chain on the EXACT weights -- the fp16 form
+    (2^-12 roundings of weights and activations) must be at least four times closer than the bf16 form (2^-9 on the weights)."""
+    B, Q, E, Fh = 2, 100, 256, 2048
+    r = lambda *s_, seed, k=1.0: (rnd(*s_, seed=seed) * k)
+    o, res = r(B, Q, E, seed=1), r(B, Q, E, seed=2)
+    wo, bo, g, b = r(E, E, seed=4, k=E ** -0.5), r(E, seed=5, k=0.1), 1 + r(E, seed=6, k=0.1), r(E, seed=7, k=0.1)
+    w1, b1, w2 = r(Fh, E, seed=10, k=E ** -0.5), r(Fh, seed=11, k=0.1), r(E, Fh, seed=12, k=Fh ** -0.5)
+    xr = _ln(res.double() + o.double() @ wo.double().t() + bo.double(), g.double(), b.double())
+    ffn = torch.relu(xr @ w1.double().t() + b1.double()) @ w2.double().t()
+    errs = {}
+    for prec, pk in (("bf16", ops().dec_pack_weight_bf16), ("f16", ops().dec_pack_weight_f16), ("f32", ops().dec_pack_weight)):
+        d = lambda t: t.to(DEV)
+        _, parts = ops().dec_post_self(d(o), d(res), pk(d(wo)), d(bo), d(g), d(b), pk(d(w1)), d(b1), pk(d(w2)))
+        errs[prec] = float((parts.double().sum(0).cpu() - ffn).abs().mean())
+    print(f"FFN stage, mean |error| against fp64 on the exact weights: {errs}")
+    assert errs["f16"] * 4 <= errs["bf16"] and errs["f32"] <= errs["f16"]
 
 
 def test_decoder_fused_tails_reject_bad_sizes():
@@ -548,6 +592,17 @@ def test_mask_logits_bf16(B, Q, C, H, W, tgt):
     scale = float(m32.abs().max())
     assert float((mask - m32).abs().max()) < 3e-2 * scale
     assert (attn != a32).float().mean() < 0.03
+    # precision "f16" (pack_mask_features_bf16(f16=True) -> MSM_MASK_F16): the einsum of the fp16-ROUNDED operands in fp32, and an
+    # eighth of the bf16 step's distance from the fp32 step
+    packed_h = ops().pack_mask_features_bf16(f.to(DEV), f16=True)
+    assert packed_h.dtype == torch.float16
+    assert torch.equal(packed_h.cpu(), f.view(B, C // 4, 4, H * W).permute(0, 1, 3, 2).to(torch.float16))
+    mh, ah, rah = ops().mask_logits(e.to(DEV), f.to(DEV), want_mask=True, target_size=tgt, packed_bf16=packed_h)
+    ref_h = torch.einsum("bqc,bchw->bqhw", e.to(torch.float16).double(), f.to(torch.float16).double())
+    close(mh.double(), ref_h, rtol=1e-4, atol=2e-4)
+    assert 4 * float((mh - m32).abs().mean()) <= float((mask - m32).abs().mean())
+    if tgt is not None:
+        assert (ah != a32).float().mean() < 0.005 and torch.equal(rah.cpu().bool(), (~ah.cpu().view(B, Q, -1).bool()).any(-1))
 
 
 def _start(shapes):
@@ -1008,6 +1063,19 @@ def test_encoder_block_hm(B, S, want_next):
         assert torch.equal(ops().proj_records_to_columns(ops().proj_to_head_major_records(d(pexact))).cpu()[..., :192], pexact[..., :192])
     else:
         assert vh is None and ph is None
+    # precision "f16" (ffn_f16): W1 / W2 / x / the hidden activation as IEEE halves, one term each -- against the float64 chain on
+    # the operands as THAT form rounds them, and at least three times closer to the exact fp32 chain than the bf16 form
+    h16 = lambda t: t.to(torch.float16).double()
+    hid = F.relu(F.linear(h16(x), h16(w1), b1.double())).float()
+    yh = F.layer_norm(x.double() + F.linear(h16(hid), h16(w2), b2.double()), (C,), g2.double(), be2.double()).float()
+    stream_h = ops().pack_encoder_block_hm(d(wo), d(w1), d(w2), *nxt, ffn_f16=True)
+    assert stream_h.shape == stream.shape and not torch.equal(stream_h, stream)
+    soh, _, _ = ops().encoder_block_hm(attn_hm, d(src), stream_h, small, DF, pos=d(pos), want_next=want_next, ffn_f16=True)
+    errh = (soh.cpu() - yh).abs()
+    assert float(errh.max()) < 2e-3 and float(errh.mean()) < 3e-5
+    e_h, e_b = float((soh.cpu() - y32).abs().mean()), float((so.cpu() - y32).abs().mean())
+    print(f"encoder block hm B={B} S={S}: mean |err| against the exact fp32 chain  bf16 FFN {e_b:.2e}  fp16 FFN {e_h:.2e}")
+    assert 3 * e_h <= e_b
     with pytest.raises(RuntimeError):
         ops().encoder_block_hm(attn_hm.float(), d(src), stream, small, DF, pos=d(pos), want_next=want_next)
     with pytest.raises(RuntimeError):
@@ -1262,6 +1330,17 @@ def test_conv3x3_c64_bf16_mode(B, H, W):
     assert err < 2e-2 * float(ref.abs().max()), err
     mom = torch.stack([out.double().sum(1), (out.double() ** 2).sum(1)], -1).cpu()
     torch.testing.assert_close(st.cpu(), mom, rtol=1e-5, atol=1e-4)
+    # precision "f16" (msm_conv3x3_c64_f16): weight and activations one IEEE-half term each -- against the fp64 convolution of the
+    # fp16-ROUNDED operands to the fp32 kernel's tolerance, and against the exact one at least four times closer than the bf16 form
+    h16 = lambda t: t.to(torch.float16).double()
+    ref_h = F.conv2d(h16(x).view(B, H, W, 64).permute(0, 3, 1, 2), h16(w), padding=1).permute(0, 2, 3, 1).reshape(B, H * W, 64)
+    outh, sth = ops().conv3x3_c64(x.to(DEV), w3, H, W, bf16="f16")
+    closed(outh, ref_h, rtol=1e-4, atol=1e-4)
+    e_h, e_b = float((outh.cpu().double() - ref).abs().mean()), float((out.cpu().double() - ref).abs().mean())
+    print(f"conv3x3 {B}x{H}x{W}: mean |err| vs exact fp64  bf16 form {e_b:.2e}  f16 form {e_h:.2e}")
+    assert 4 * e_h <= e_b
+    momh = torch.stack([outh.double().sum(1), (outh.double() ** 2).sum(1)], -1).cpu()
+    torch.testing.assert_close(sth.cpu(), momh, rtol=1e-5, atol=1e-4)
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 12, 16), (1, 5, 37), (3, 30, 40), (8, 120, 160)])
@@ -1322,6 +1401,21 @@ def test_kv_project_multi_equals_single_launches():
         ref = torch.einsum("bchw,nc->bhwn", x.double(), _bf16_round(w.cpu()).double().to(x.device)).reshape(B, -1, N) + c.double()
         err = (o16.double() - ref).abs().cpu()
         assert o16.dtype == torch.bfloat16 and float((err / (ref.abs().cpu() + 1.0)).max()) < 6e-3      # one bf16 rounding of the result (2^-8 relative)
+    # precision "f16" (N = 512 = [K | V]): IEEE-half operands (one term each), the K columns stored as HALF bit patterns, V as bf16 --
+    # against float64 on the fp16-rounded operands: K to one fp16 rounding of the result, V to one bf16 rounding
+    if N == 512:
+        outs_h = ops().kv_project_multi(xs, ws, cs, out_dtype=torch.bfloat16, keys_f16=True)
+        h16 = lambda t: t.to(torch.float16).double()
+        for x, w, c, oh, o in zip(xs, ws, cs, outs_h, outs):
+            ref = torch.einsum("bchw,nc->bhwn", h16(x), h16(w)).reshape(B, -1, N) + c.double()
+            kk = oh[..., :256].contiguous().view(torch.float16).double()
+            vv = oh[..., 256:].double()
+            assert float(((kk - ref[..., :256]).abs() / (ref[..., :256].abs() + 1.0)).max()) < 1.2e-3          # 2^-11 relative + the fp32 sum's rounding
+            assert float(((vv - ref[..., 256:]).abs() / (ref[..., 256:].abs() + 1.0)).max()) < 6e-3
+            # ... and against the EXACT fp32 result the K half is closer than a bf16 store could be
+            assert float((kk - o[..., :256].double()).abs().mean()) < 0.25 * float((o[..., :256].to(torch.bfloat16).double() - o[..., :256].double()).abs().mean())
+        with pytest.raises(RuntimeError, match="keys_f16"):
+            ops().kv_project_multi(xs, ws, cs, keys_f16=True)
     # fp32 accuracy on the bf16 matrix pipe (exact three-term splits): the fp32 tolerances, and no further from float64 than the fp32 MFMAs
     outs_s = ops().kv_project_multi(xs, ws, cs, split=True)
     for x, w, c, o, os_ in zip(xs, ws, cs, outs, outs_s):
@@ -1346,6 +1440,12 @@ def test_conv3x3_c64_nchw_vs_fp64(B, H, W, Cout):
     lp = ops().conv3x3_tokens_to_nchw(x.to(DEV), w3, b.to(DEV), H, W, bf16=True)
     closed(lp, ref_r, rtol=1e-4, atol=1e-4)
     assert float((lp.cpu().double() - ref).abs().max()) < 2e-2 * float(ref.abs().max())
+    # ... and with IEEE-half operands (msm_conv3x3_c64_nchw_f16): fp64 on the fp16-rounded operands
+    h16 = lambda t: t.to(torch.float16).double()
+    ref_h = F.conv2d(h16(x).view(B, H, W, 64).permute(0, 3, 1, 2), h16(w), b.double(), padding=1).reshape(B, Cout, H * W)
+    lh = ops().conv3x3_tokens_to_nchw(x.to(DEV), w3, b.to(DEV), H, W, bf16="f16")
+    closed(lh, ref_h, rtol=1e-4, atol=1e-4)
+    assert 4 * float((lh.cpu().double() - ref).abs().mean()) <= float((lp.cpu().double() - ref).abs().mean())
 
 
 @pytest.mark.parametrize("B,shapes", [(2, [(15, 20), (30, 40), (60, 80)]), (1, [(4, 6), (8, 12), (16, 24)]), (3, [(7, 7), (14, 14), (28, 28)])])
