@@ -346,7 +346,7 @@ def precision_leg(model, feats, dev, dist, args, precision, inflight, sparse_tap
     model.sem_seg_head.predictor.sparse_taps = bool(sparse_taps)
     model.sem_seg_head.predictor.pooled_attention_masks = bool(pooled)
     roof = None
-    if precision == "bf16" and model.sem_seg_head.pixel_decoder._use_hm():
+    if precision in ("bf16", "f16") and model.sem_seg_head.pixel_decoder._use_hm():
         # the two kernels that dominate the bf16 plan's step, each timed on its own (graph replays of the step's launches with
         # their real arguments, HIP events on the launch stream): the encoder-layer tail and the MSDeformAttn gather, with the
         # bytes the algorithm moves per launch (fp16 value / attention / sampling-projection tensors, fp32 residual stream)
@@ -356,12 +356,15 @@ def precision_leg(model, feats, dev, dist, args, precision, inflight, sparse_tap
         step()
         e_ms, e_n = entry_graph_ms(step, "encoder_block_hm")
         g_ms, g_n = entry_graph_ms(step, "ms_deform_attn_encoder_lp")
-        e_bytes = tokens * (128 + 256 + 256) + tokens * (128 + 576) * (e_n - 1) / max(e_n, 1)          # last layer: no value / projection
+        # per token: fp16 attention in (128 B), fp32 residual in / out (512 B); all but the last layer: fp16 value (128 B) and the sampling
+        # projection out (8 heads x 120 B: fp32 offsets + fp16 logits, round 5; 576 B before)
+        e_bytes = tokens * (128 + 256 + 256) + tokens * (128 + 960) * (e_n - 1) / max(e_n, 1)
         e_flops = 2.0 * tokens * (64 * 64 + 2 * 64 * 1024) + 2.0 * tokens * (64 * 64 + 64 * 288) * (e_n - 1) / max(e_n, 1)
         # issued products: out_proj / value / sampling projection as three terms (w_lo x_hi + w_hi x_lo + w_hi x_hi), linear1 as two (x = h + l),
         # linear2 as one
-        e_exec = 2.0 * tokens * (3 * 64 * 64 + 2 * 64 * 1024 + 64 * 1024) + 2.0 * tokens * 3 * (64 * 64 + 64 * 288) * (e_n - 1) / max(e_n, 1)
-        g_bytes = tokens * (128 + 576 + 128)
+        ffn_terms = 2 if precision == "f16" else 3              # f16: linear1 and linear2 one fp16 product each
+        e_exec = 2.0 * tokens * (3 * 64 * 64 + ffn_terms * 64 * 1024) + 2.0 * tokens * 3 * (64 * 64 + 64 * 288) * (e_n - 1) / max(e_n, 1)
+        g_bytes = tokens * (128 + 960 + 128)
         e_t, g_t = 1e-3 * e_ms / max(e_n, 1), 1e-3 * g_ms / max(g_n, 1)
         roof = {"bound": "hbm", "kernel": "enc_block_hm_kernel (msm_encoder_block_hm_fwd): the bf16 plan's encoder-layer tail",
                 "achieved": round(e_bytes / e_t / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(e_bytes / e_t / 1e9 / PEAK_HBM_GBPS, 4),
@@ -372,8 +375,11 @@ def precision_leg(model, feats, dev, dist, args, precision, inflight, sparse_tap
                 "gather": {"kernel": "msda_enc_lp_kernel (msm_msdeform_attn_enc_lp_fwd)", "launches_per_step": g_n, "avg_launch_ms": round(1e3 * g_t, 4),
                            "algorithmic_bytes_per_launch": g_bytes, "achieved_gbps": round(g_bytes / g_t / 1e9, 1),
                            "frac_of_hbm_peak": round(g_bytes / g_t / 1e9 / PEAK_HBM_GBPS, 4)},
-                "note": "bytes = fp16 attention in + fp32 residual in / out + fp16 value and sampling projection out (none for the last layer); "
-                        "useful FLOPs = the layer's GEMMs once (the kernel issues 2-3 bf16 products per hi + lo operand pair)"}
+                "note": "bytes = fp16 attention in + fp32 residual in / out + fp16 value and the sampling projection (fp32 offsets, fp16 logits) out "
+                        "(none for the last layer); useful FLOPs = the layer's GEMMs once (the kernel issues 1-3 products per operand pair)"}
+        tr = load_traffic("step_traffic_bf16.json", [])
+        if tr and precision == "bf16":
+            roof["traffic"] = (tr.get("enc_block_hm_kernel") or {}).get("bytes_per_launch")
     lone = PipelinedInference(model, depth=1)
     lone.submit(feats, (H, W))
     lone.drain()
@@ -614,27 +620,31 @@ def extra_configs(dev, args):
         ucn.inference(ufe, (H, W))
         torch.cuda.synchronize()
     ud = ct.durations()
-    # the same path in the bf16 mode (bf16 K/V written by bf16 MFMAs, low-precision attention cores / tails / mask step): its own entry
-    ucn.set_precision("bf16")
-    for _ in range(2):
-        ucn.inference(ufe, (H, W))
-    t_lp = {}
-    for depth in (1, 3):
-        up = PipelinedInference(ucn, depth=depth)
-        for _ in range(depth):
-            up.submit(ufe, (H, W))
-        up.drain()
-        urun = lambda: up.submit(None, (H, W), slot_inputs=True)
-        for _ in range(2 * depth):
-            urun()
-        up.drain()
-        t_lp[depth] = timed(urun, 6 * depth)
-        up.drain()
-        del up
-    with _lib.CallTimer() as ct:
-        ucn.inference(ufe, (H, W))
-        torch.cuda.synchronize()
-    ud_lp = ct.durations()
+    # the same path in the 16-bit modes (bf16 K/V written by bf16 MFMAs, low-precision attention cores / tails / mask step; "f16": IEEE-half
+    # operands where the range is bounded, fp16 keys): their own entries
+    lp_modes = {}
+    for mode in ("bf16", "f16"):
+        ucn.set_precision(mode)
+        for _ in range(2):
+            ucn.inference(ufe, (H, W))
+        t_lp = {}
+        for depth in (1, 3):
+            up = PipelinedInference(ucn, depth=depth)
+            for _ in range(depth):
+                up.submit(ufe, (H, W))
+            up.drain()
+            urun = lambda: up.submit(None, (H, W), slot_inputs=True)
+            for _ in range(2 * depth):
+                urun()
+            up.drain()
+            t_lp[depth] = timed(urun, 6 * depth)
+            up.drain()
+            del up
+        with _lib.CallTimer() as ct:
+            ucn.inference(ufe, (H, W))
+            torch.cuda.synchronize()
+        lp_modes[mode] = (t_lp, ct.durations())
+    t_lp, ud_lp = lp_modes["bf16"]
     ucn.set_precision("f32")
     attn_ms = sum(ud.get("msm_hypersphere_attn_fwd", [0.0]))
     n_attn = len(ud.get("msm_hypersphere_attn_fwd", [])) or 1
@@ -659,6 +669,10 @@ def extra_configs(dev, args):
                  "three_batches_in_flight": {"value": round(UB / t_lp[3], 1), "ms_per_step": round(1e3 * t_lp[3], 3)},
                  "kernels_ms": {k: round(sum(v), 3) for k, v in sorted(ud_lp.items(), key=lambda kv: -sum(kv[1]))[:6]},
                  "parity": "tests/test_gpu_configs.py::test_ucn_path_480x640_bf16_vs_reference (final-mask mismatch 0.1 % against the fp32 reference golden)"},
+        "f16": {"dtype": "fp16 / bf16 operands, fp32 accumulation, fp16 K + bf16 V", "value": round(UB / min(lp_modes["f16"][0].values()), 1), "unit": "images/sec",
+                "one_batch_in_flight": {"value": round(UB / lp_modes["f16"][0][1], 1), "ms_per_step": round(1e3 * lp_modes["f16"][0][1], 3)},
+                "three_batches_in_flight": {"value": round(UB / lp_modes["f16"][0][3], 1), "ms_per_step": round(1e3 * lp_modes["f16"][0][3], 3)},
+                "kernels_ms": {k: round(sum(v), 3) for k, v in sorted(lp_modes["f16"][1].items(), key=lambda kv: -sum(kv[1]))[:6]}},
         "roofline": {"bound": "hbm", "kernel": "hs_attn_kernel + combine at 307 200 keys (msm_hypersphere_attn_fwd)",
                      "achieved": round(attn_bytes / (cross_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                      "frac": round(attn_bytes / (cross_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "bytes_per_launch": attn_bytes,
@@ -731,7 +745,7 @@ def extra_configs(dev, args):
         model = build_model(dev, num_queries=300, dec_layers=layers)
         for B_ in batches:
             feats = {k: v.to(dev) for k, v in syn.synth_backbone_features(B_, 960, 1280, seed=9).items()}
-            for mode in ("f32", "bf16"):
+            for mode in (("f32", "bf16", "f16") if layers == 20 else ("f32", "bf16")):
                 model.set_precision(mode)
                 g = model.graphed()
                 for _ in range(2):
@@ -843,6 +857,7 @@ def build_summary(result):
     if c:
         s["ucn"] = {"f32": {"v": c["value"], "ms1": pick(c, "one_batch_in_flight", "ms_per_step", nd=3)},
                     "bf16": {"v": pick(c, "bf16", "value"), "ms1": pick(c, "bf16", "one_batch_in_flight", "ms_per_step", nd=3)},
+                    "f16": {"v": pick(c, "f16", "value"), "ms1": pick(c, "f16", "one_batch_in_flight", "ms_per_step", nd=3)},
                     "rf_hbm": pick(c, "roofline", "frac", nd=3)}
     c = cfg.get("ucn_rgbd_end_to_end")
     if c:
@@ -926,7 +941,7 @@ def main():
     ap.add_argument("--folded-mask", type=int, default=-1, help="1/0: contract the mask features in factored form (64-channel activation; "
                     "default: the decoder's own default, on) or literally (256-channel mask_features tensor)")
     ap.add_argument("--sparse-taps", action="store_true", help="skip mask rows that feed no attention-mask tap")
-    ap.add_argument("--precision", choices=("f32", "f32_split", "bf16"), default="f32",
+    ap.add_argument("--precision", choices=("f32", "f32_split", "bf16", "f16"), default="f32",
                     help="bf16 (configs 3/5) is NOT the headline configuration: the JSON line then says so in dtype")
     ap.add_argument("--batched-kv", type=int, default=-1, help="1/0: all K/V projections of the decoder in one launch (default: the decoder's own default)")
     ap.add_argument("--no-rccl-report", action="store_true", help="N > 1: do not record rank 0's NCCL_DEBUG=INFO log for the `collective` entry")
@@ -1084,7 +1099,8 @@ def main():
         # what the default plan runs for the ten predictions: one full-resolution launch, the pooling launch, nine key-resolution launches
         plan_ms, plan_calls = entry_graph_ms(step, ["mask_logits", "pool_mask_taps", "attn_mask_pooled"])
         enc_name = {"f32": "encoder_block", "f32_split": "encoder_block_split",
-                    "bf16": "encoder_block_hm" if model.sem_seg_head.pixel_decoder._use_hm() else "encoder_block_lp"}[args.precision]
+                    "bf16": "encoder_block_hm" if model.sem_seg_head.pixel_decoder._use_hm() else "encoder_block_lp",
+                    "f16": "encoder_block_hm" if model.sem_seg_head.pixel_decoder._use_hm() else "encoder_block_lp"}[args.precision]
         enc_ms_all, enc_calls = entry_graph_ms(step, enc_name)
         launch_label = "eager" if graph is None else ("hipgraph" if pipe is None else
                                                       f"hipgraph x{inflight}: {inflight} batches of 8 in flight, one graph + stream each")
@@ -1101,7 +1117,9 @@ def main():
         pipe = graph = None
         with torch.cuda.stream(stream):
             lp_images, lp_elapsed, lp_steps, lp_single, lp_roof = precision_leg(model, feats, dev, dist, args, "bf16", max(1, args.inflight))
+            h_images, h_elapsed, h_steps, h_single, h_roof = precision_leg(model, feats, dev, dist, args, "f16", max(1, args.inflight))
         lp_rec = gather_metrics({"images": lp_images, "elapsed_s": lp_elapsed, "checksum": lp_single}, dist)
+        h_rec = gather_metrics({"images": h_images, "elapsed_s": h_elapsed, "checksum": h_single}, dist)
     ag_s = timed_all_gather(dist)                   # every rank takes part: the path's only collective, timed on its own
     if rank != 0:
         if dist is not None:
@@ -1110,7 +1128,7 @@ def main():
     t_max = max(r["elapsed_s"] for r in rec)
     total_images = sum(r["images"] for r in rec)
     collective = collective_entry(dist, rec, ag_s, rccl_log)
-    bf16 = args.precision == "bf16"
+    bf16 = args.precision in ("bf16", "f16")
     mask_name = "msm_mask_logits_bf16_fwd" if (bf16 and "msm_mask_logits_bf16_fwd" in dur) else "msm_mask_logits_fwd"
     per_call = dur[mask_name]
     calls_per_step = mask_calls
@@ -1199,7 +1217,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32" if not bf16 else "bf16 operands / fp32 accumulation (NOT the headline configuration)",
+        "dtype": "f32" if not bf16 else f"{args.precision} operands / fp32 accumulation (NOT the headline configuration)",
         "data": "synthetic",
         "config": {"workload": "configs[1]: batch=8 640x480 frames per GPU, synthetic ResNet-50 res2..res5 features "
                                "-> MSDeformAttn pixel decoder (6 layers) -> 9-layer hypersphere decoder (100 queries) "
@@ -1234,8 +1252,20 @@ def main():
             "ms_per_step": round(1e3 * lp_t / lp_steps, 4), "dtype": "bf16 operands / fp32 accumulation",
             "one_batch_in_flight": {"value": round(BATCH / lp_single, 1), "unit": "images/sec per GPU (rank 0)", "ms_per_step": round(1e3 * lp_single, 4)},
             "per_rank_images_per_sec": [round(r["images"] / r["elapsed_s"], 1) for r in lp_rec],
-            "storage": "fp16 value / attention / sampling-projection tensors between the encoder kernels (csrc/enc_lp.hip), bf16 K/V, fp32 residual streams",
+            "storage": "fp16 value / attention tensors and fp32-offset sampling records between the encoder kernels (csrc/enc_lp.hip), bf16 K/V, fp32 residual streams",
+            "parity": "tests/test_gpu_configs.py::test_config2_slices_low_precision_vs_reference[bf16]: 1.07 % of the final mask bits, mean IoU 0.952 over 3200 masks",
             "roofline": lp_roof}
+        h_t = max(r["elapsed_s"] for r in h_rec)
+        result["configs"]["configs[2] f16"] = {
+            "workload": f"the same batch {world * BATCH} over {world} GPU(s) under set_precision('f16'): the 16-bit plan with IEEE-half operands "
+                        "(v_mfma_f32_16x16x32_f16, the bf16 instruction's rate) wherever the operand's range is bounded -- decoder tails, encoder FFN, "
+                        "K/V projection + attention scores, FPN 3x3 convolution, mask step -- and bf16 where it is not (softmax weights, value rows)",
+            "value": round(sum(r["images"] for r in h_rec) / h_t, 1), "unit": "images/sec", "n_gpus": world, "steps": h_steps,
+            "ms_per_step": round(1e3 * h_t / h_steps, 4), "dtype": "fp16 / bf16 operands, fp32 accumulation",
+            "one_batch_in_flight": {"value": round(BATCH / h_single, 1), "unit": "images/sec per GPU (rank 0)", "ms_per_step": round(1e3 * h_single, 4)},
+            "per_rank_images_per_sec": [round(r["images"] / r["elapsed_s"], 1) for r in h_rec],
+            "parity": "tests/test_gpu_configs.py::test_config2_slices_low_precision_vs_reference[f16]: 0.47 % of the final mask bits, mean IoU 0.979 over 3200 masks",
+            "roofline": h_roof}
     if world == 1 and not args.no_extras:
         pipe = graph = None
         result["mean_shift"] = mean_shift_unit(dev)

@@ -242,7 +242,7 @@ def test_decoder_bf16_mask_step():
 def test_head_bf16_precision_mode():
     """set_precision("bf16") (configs 3 / 5): the encoder blocks and the mask step run with bf16 operands -- the outputs move
     away from the fp32 path by bf16-sized amounts, stay close to it statistically (the tight check against the reference golden
-    at 640x480 is tests/test_gpu_configs.py::test_config2_slice_bf16_vs_reference), and a captured graph follows the switch."""
+    at 640x480 is tests/test_gpu_configs.py::test_config2_slices_low_precision_vs_reference), and a captured graph follows the switch."""
     from unseenobjectswithmeanshift_amd.meta_arch import MeanShiftMaskFormer
     head = make_pixel_decoder()
     model = MeanShiftMaskFormer(backbone=None, sem_seg_head=head, num_queries=100)
@@ -262,6 +262,22 @@ def test_head_bf16_precision_mode():
         assert torch.equal(a, b)
     assert not torch.equal(got[2], ref[2]) and float((got[2] != ref[2]).float().mean()) < 0.05
     model.set_precision("f32")
+    for a, b in zip(g(feats, (64, 96)), ref):
+        assert torch.equal(a, b)
+    # set_precision("f16") (round 5): the same plan (pixel_decoder.precision stays "bf16" = the low-precision plan) with IEEE-half
+    # operands -- every switch follows, the graph re-captures, the outputs differ from both other modes, and fp32 comes back bit for bit
+    model.set_precision("f16")
+    pd, pr = head.pixel_decoder, head.predictor
+    assert model.precision == "f16" and pd.precision == "bf16" and pd.lp_operands == "f16"
+    assert (pr.tails_dtype, pr.attention_dtype, pr.attention_keys, pr.mask_step_dtype) == ("f16", "bf16", "f16", "f16")
+    goth = g(feats, (64, 96))
+    for a, b in zip(goth, model.inference(feats, (64, 96))):
+        assert torch.equal(a, b)
+    assert not torch.equal(goth[2], ref[2]) and not torch.equal(goth[2], got[2]) and float((goth[2] != ref[2]).float().mean()) < 0.05
+    model.set_precision("bf16")
+    assert (pd.lp_operands, pr.tails_dtype, pr.attention_keys, pr.mask_step_dtype) == ("bf16", "bf16", "bf16", "bf16")
+    model.set_precision("f32")
+    assert (pd.precision, pd.lp_operands, pr.tails_dtype, pr.attention_dtype, pr.mask_step_dtype) == ("f32", "bf16", "f32", "f32", "f32")
     for a, b in zip(g(feats, (64, 96)), ref):
         assert torch.equal(a, b)
     with pytest.raises(ValueError):
