@@ -681,6 +681,36 @@ def extra_configs(dev, args):
                      "mfma_frac": round(attn_flops / (cross_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                      "note": "AI = 4*Q*256 / (2*256*4 + Q) = 47.7 FLOP/B against an fp32 ridge of ~20: MFMA-bound in fp32 by the numbers; both fractions are given"}}
     del ucn, uh, emb
+    # the TRUE RGB-D model end to end (lib/networks/SEG.py:26-126 -> pretrained_meanshiftformer_model.py:281-301): image +
+    # xyz depth -> the two dilated ResNet34-8s towers (pinned to the reference by tests/golden/ucn_backbone.npz; stock MIOpen convolutions,
+    # BatchNorm folded, channels_last) -> add fusion -> unit norm -> the UCN head above -> instances; one HIP graph per precision
+    from unseenobjectswithmeanshift_amd.meta_arch import build_ucn_model
+    um = build_ucn_model()
+    um.backbone.load_state_dict(syn.ucn_backbone_state_dict(syn.ucn_backbone_param_shapes(), salt=6), strict=True)
+    um.sem_seg_head.pixel_decoder.load_state_dict(syn.synth_state_dict({"mask_features.weight": (256, 64, 3, 3), "mask_features.bias": (256,)}, salt=3))
+    um.sem_seg_head.predictor.load_state_dict(syn.synth_state_dict(syn.decoder_param_shapes(dec_layers=6, num_feature_levels=1), salt=4))
+    um = um.to(dev).eval()
+    gen = torch.Generator().manual_seed(5)
+    uin = {"image": torch.randn(UB, 3, H, W, generator=gen).to(dev), "depth": torch.rand(UB, 3, H, W, generator=gen).to(dev)}
+    e2e = {}
+    for mode in ("f32", "bf16", "f16"):
+        um.set_precision(mode)
+        for _ in range(2):
+            um.inference_images(uin, (H, W))
+        t_bb = timed(lambda: um.backbone(uin["image"], None, uin["depth"]), 5)
+        gph = um.graphed(entry="inference_images")
+        for _ in range(3):
+            gph(uin, (H, W))
+        t_g = timed(lambda: gph(uin, (H, W)), 10)
+        e2e[mode] = {"value": round(UB / t_g, 1), "unit": "images/sec", "ms_per_step": round(1e3 * t_g, 3), "backbone_ms_eager": round(1e3 * t_bb, 3)}
+        del gph
+    um.set_precision("f32")
+    out["ucn_rgbd_end_to_end"] = {
+        "workload": f"the RGB-D model of mixture_UCN.yaml end to end: batch {UB} of 480x640 images + xyz depth maps -> two dilated ResNet34-8s towers "
+                    "(MIOpen convolutions, BatchNorm folded, channels_last; bf16 / f16 plans: bf16 convolutions) -> add fusion + unit norm -> "
+                    "SimpleBasePixelDecoder + 6-layer hypersphere decoder over 307 200 keys -> instances; one HIP graph, one batch in flight",
+        "value": e2e["f32"]["value"], "unit": "images/sec", "ms_per_step": e2e["f32"]["ms_per_step"], "variants": e2e}
+    del um, uin
     # configs[3]: two-stage refinement over 16 frames
     model = build_model(dev)
     bb = syn.StandInBackbone().to(dev).eval()

@@ -754,6 +754,24 @@ def test_ucn_model_end_to_end():
     # a frame that is not a multiple of 32 is padded for the network and cropped back
     res2 = model([{"image": img[:1, :, :30, :50].contiguous(), "depth": depth[:1, :, :30, :50].contiguous()}])
     assert res2[0]["instances"].pred_masks.shape == (20, 30, 50)
+    # round 5 (what bench.py's "ucn_rgbd_end_to_end" times): inference_images() is forward()'s body, the depth map reaches the depth
+    # tower (not SEGNET.forward's unused `label` argument), the whole model replays from ONE HIP graph, and the bf16 towers of the
+    # 16-bit plans stay within bf16 distance of the fp32 ones
+    sc, cl, mk, bx, _ = model.inference_images({"image": img, "depth": depth}, (32, 64))
+    for b in range(2):
+        assert torch.equal(res[b]["instances"].pred_masks, mk[b]) and torch.equal(res[b]["instances"].scores, sc[b])
+    assert not torch.equal(model.inference_images({"image": img, "depth": depth * 0.5}, (32, 64))[0], sc)
+    gr = model.graphed(entry="inference_images")
+    for _ in range(2):
+        got = gr({"image": img, "depth": depth}, (32, 64))
+    assert (got[2] != mk).float().mean() < 1e-3
+    e32 = model.backbone(img, None, depth)
+    model.set_precision("bf16")
+    assert model.backbone.backbone_dtype == "bf16"
+    e16 = model.backbone(img, None, depth)
+    assert e16.dtype == torch.float32 and 0 < float((e16 - e32).abs().max()) < 8e-2 and float((e16 - e32).abs().mean()) < 5e-3
+    model.set_precision("f32")
+    torch.testing.assert_close(model.backbone(img, None, depth), e32, rtol=1e-4, atol=1e-5)      # (MIOpen may pick another algorithm: not bitwise)
 
 
 def test_graphed_inference_equals_eager():
@@ -981,3 +999,4 @@ def test_parameter_only_subgraphs_follow_parameter_updates():
     fresh.load_state_dict(head.state_dict(), strict=True)
     want, _ = fresh(feats)
     assert torch.equal(after["pred_masks"], want["pred_masks"]) and torch.equal(after["pred_logits"], want["pred_logits"])
+

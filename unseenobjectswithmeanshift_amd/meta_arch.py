@@ -308,15 +308,23 @@ class PretrainedMeanShiftMaskFormer(MeanShiftMaskFormer):
         if padded != (H, W):                      # ImageList.from_tensors: zeros at the right / bottom (PM:275, 286)
             images = F.pad(images, (0, padded[1] - W, 0, padded[0] - H))
             depth = None if depth is None else F.pad(depth, (0, padded[1] - W, 0, padded[0] - H))
-        feats = self.backbone(images, None, depth)
+        scores, classes, masks, boxes, _ = self.inference_images({"image": images, **({} if depth is None else {"depth": depth})}, (H, W), padded)
+        return [{"instances": Instances((H, W), pred_masks=masks[b], pred_boxes=boxes[b], scores=scores[b], pred_classes=classes[b])}
+                for b in range(scores.shape[0])]
+
+    def inference_images(self, inputs, image_size, padded_size=None):
+        """The whole RGB-D model on padded inputs {"image": (B,3,Hp,Wp)[, "depth": xyz (B,3,Hp,Wp)]}: the two towers (SEG.py:88-117,
+        ``backbone(img, label=None, depth)``), the channel normalisation of pretrained_meanshiftformer_model.py:298-300, the head
+        and the post-processing; ``graphed(entry="inference_images")`` / ``pipelined`` replay exactly this."""
+        if self.backbone is None:
+            raise RuntimeError("inference_images needs a backbone")
+        feats = self.backbone(inputs["image"], None, inputs.get("depth") if self.use_depth else None)
         feats = feats.float().contiguous()
         if feats.is_cuda:
             feats = {"res5": ops.l2_normalize_nchw(feats)}                                # PM:298-300 (F.normalize over channels)
         else:
             feats = {"res5": F.normalize(feats, p=2, dim=1).contiguous()}
-        scores, classes, masks, boxes, _ = self.inference(feats, (H, W), padded)
-        return [{"instances": Instances((H, W), pred_masks=masks[b], pred_boxes=boxes[b], scores=scores[b], pred_classes=classes[b])}
-                for b in range(scores.shape[0])]
+        return self.inference(feats, image_size, padded_size)
 
 
 def build_ucn_model(num_queries=100, dec_layers=6, use_depth=True, **head_kw):

@@ -71,7 +71,11 @@ class UCNBackbone(nn.Module):
         self.fcn = _Tower(num_units, in_channels)
         self.fcn_depth = _Tower(num_units, in_channels) if use_depth else None
         self.normalize = normalize
+        # "bf16" (MeanShiftMaskFormer.set_precision("bf16" / "f16")): the towers' convolutions run in bfloat16 through MIOpen (fp32
+        # accumulation inside the library), the fusion add, the upsampling and the normalisation in fp32
+        self.backbone_dtype = "f32"
         self._folded = None
+        self._lp = None
 
     def _plan(self):
         """Per tower: the folded (weight, bias, stride, padding, dilation) of every convolution, rebuilt when a parameter
@@ -106,7 +110,7 @@ class UCNBackbone(nn.Module):
             if sc is not None:
                 x = F.conv2d(x, sc[0], sc[1], stride=stride)
             x = F.relu(y + x)
-        x = F.conv2d(x, fcw, fcb)
+        x = F.conv2d(x, fcw, fcb).float()
         return F.interpolate(x, size=size, mode="bilinear", align_corners=True)      # nn.functional.upsample_bilinear
 
     @torch.no_grad()
@@ -114,11 +118,20 @@ class UCNBackbone(nn.Module):
         if self.training:
             raise NotImplementedError("UCNBackbone is an inference module (BatchNorm folded into the convolutions): call .eval()")
         plans = self._plan()
-        feats = self._run(plans[0], img.float())
+        if self.backbone_dtype not in ("f32", "bf16"):
+            raise ValueError("backbone_dtype must be 'f32' or 'bf16'")
+        dt = torch.bfloat16 if self.backbone_dtype == "bf16" else torch.float32
+        if dt != torch.float32:                   # a 16-bit copy of the folded weights, made once per parameter version
+            if self._lp is None or self._lp[0] is not self._folded:
+                c = lambda t: None if t is None else t.to(dt)
+                self._lp = (self._folded, [((c(w), c(b)), [((c(w1), c(b1)), (c(w2), c(b2)), None if sc is None else (c(sc[0]), c(sc[1])), st, dl)
+                                                          for (w1, b1), (w2, b2), sc, st, dl in blocks], c(fcw), c(fcb)) for (w, b), blocks, fcw, fcb in plans])
+            plans = self._lp[1]
+        feats = self._run(plans[0], img.float().to(dt))
         if depth is not None:
             if self.fcn_depth is None:
                 raise RuntimeError("this backbone was built without a depth tower")
-            feats = feats + self._run(plans[1], depth.float())
+            feats = feats + self._run(plans[1], depth.float().to(dt))
         if self.normalize:
             feats = F.normalize(feats, p=2, dim=1)
         return feats.contiguous()
