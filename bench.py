@@ -377,9 +377,11 @@ def precision_leg(model, feats, dev, dist, args, precision, inflight, sparse_tap
                            "frac_of_hbm_peak": round(g_bytes / g_t / 1e9 / PEAK_HBM_GBPS, 4)},
                 "note": "bytes = fp16 attention in + fp32 residual in / out + fp16 value and the sampling projection (fp32 offsets, fp16 logits) out "
                         "(none for the last layer); useful FLOPs = the layer's GEMMs once (the kernel issues 1-3 products per operand pair)"}
-        tr = load_traffic("step_traffic_bf16.json", [])
-        if tr and precision == "bf16":
+        tnotes = []
+        tr = load_traffic(f"step_traffic_{precision}.json", tnotes)      # PMC bytes of a committed rocprofv3 pass of THIS plan (stamped; stale -> null)
+        if tr:
             roof["traffic"] = (tr.get("enc_block_hm_kernel") or {}).get("bytes_per_launch")
+        roof["traffic_provenance"] = tnotes
     lone = PipelinedInference(model, depth=1)
     lone.submit(feats, (H, W))
     lone.drain()

@@ -126,6 +126,15 @@ def per_launch(match):
     return {"fetch_bytes_corrected": round(fetch), "write_bytes": round(write), "bytes_per_launch": round(fetch + write)}
 
 
+# the 16-bit plans' dominant kernel (csrc/enc_lp.hip), when the profiled run was one of them: step_traffic_<precision>.json
+hm = per_launch(lambda k: "enc_block_hm_kernel" in k)
+if hm:
+    prec = "f16" if any("enc_block_hm_kernel<true>" in r["Name"] or "enc_block_hm_kernel<(bool)1>" in r["Name"] for r in rows) else "bf16"
+    hm["note"] = ("mean over the six launches of a pass (five with the next layer's value / sampling projection, the last without): fp16 attention "
+                  "in, fp32 residual in / out, fp16 value and fp32-offset sampling records out; weights stay in L2")
+    json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes ({tag}, tools/profile_round.sh <tag> {prec}); FETCH_SIZE "
+                         "doubled per MI355X_MICROARCH.md (HBM section), WRITE_SIZE as reported; KB -> bytes",
+               "stamp": stamp("enc_lp.hip"), "enc_block_hm_kernel": hm}, open(f"profiles/step_traffic_{prec}.json", "w"), indent=1)
 enc = per_launch(lambda k: "enc_block_kernel" in k)
 fin = per_launch(lambda k: "mask_logits_kernel<0, true" in k)
 if enc and fin:
