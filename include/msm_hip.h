@@ -242,6 +242,24 @@ int msm_hypersphere_attn_lp_fwd(const float* q, const void* k, const void* v, in
                                 int64_t ldv, int64_t v_sb, float kappa,
                                 float* workspace, int64_t workspace_elems, void* stream);
 
+/* Long key sequences in the 16-bit plans: the folded K/V projection INSIDE the attention kernel (csrc/attention.hip,
+ * hs_attn_fkv_kernel).  Replaces msm_kv_project_multi_bf16 + msm_hypersphere_attn_lp_fwd for the cross-attention of
+ * PretrainedMeanShiftTransformerDecoder (meanshiftformer_transformer_decoder.py:697-1048; 307 200 keys per image) and the finest level
+ * of the three-level decoder at 1280x960: [K | V](key) = x(key) W^T + row[y] + col[x] (attention_util.py:134-140 folded,
+ * msm_kv_project_f32's separable form) is computed per 16-key block from the 64-channel fp16 feature -- 128 bytes per key instead of
+ * 1024 bytes of bf16 K / V written and read back -- and never stored.
+ *   x_f16    [B][H*W][64] IEEE half, token-major (the level feature; msm_f32_to_f16 of its token-major form)
+ *   w_packed msm_attn_pack_kv_weights(w [2 * heads * 32][64] fp32 = [K rows | V rows]): fp16 MFMA fragments, heads * 8 KiB
+ *   rowcol   [H + W][2 * heads * 32] fp32: the separable constants exactly as msm_kv_project_f32 takes them (cmat_width = W)
+ *   col_v_t  [heads * 32][W] fp32: the V columns of the col table transposed (col[H + x][heads * 32 + d] -> col_v_t[d][x])
+ *   score_format 1: q^ / k^ as bf16 operands, 2: as IEEE halves (precision "f16"); probabilities and V always bf16
+ * W % 16 == 0.  q / masked / row_any / out / workspace (msm_hypersphere_attn_workspace(B, Lq, H*W, heads)) as msm_hypersphere_attn_fwd. */
+int msm_attn_pack_kv_weights(const float* w, void* packed, int heads, void* stream);
+int msm_hypersphere_attn_fused_kv_fwd(const float* q, const void* x_f16, const void* w_packed, const float* rowcol, const float* col_v_t,
+                                      int score_format, const uint8_t* masked, const int32_t* row_any, float* out,
+                                      int B, int Lq, int H, int W, int heads, int64_t ldq, int64_t q_sb, float kappa,
+                                      float* workspace, int64_t workspace_elems, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Multi-scale deformable attention forward, reference ABI (OPS/src/ms_deform_attn.h:25-44):
  *   value [B][S][M][D], spatial_shapes int64 [L][2] = (H,W), level_start_index int64 [L],

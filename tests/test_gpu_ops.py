@@ -318,6 +318,67 @@ def test_hypersphere_attention_low_precision(B, Lq, S, masked, kv_bf16):
     assert float((alt.cpu() - ref).abs().max()) < 3e-2
 
 
+@pytest.mark.parametrize("keys_f16", [False, True])
+@pytest.mark.parametrize("B,Lq,H,W,masked", [(2, 100, 16, 32, True), (1, 100, 40, 160, True), (1, 300, 120, 160, True), (2, 37, 8, 16, False)])
+def test_hypersphere_attention_fused_kv(B, Lq, H, W, masked, keys_f16):
+    """msm_hypersphere_attn_fused_kv_fwd (16-bit plans, long levels): the folded K/V projection [K | V] = x W^T + row[y] + col[x]
+    computed inside the attention kernel from the fp16 level feature.  Against (i) the oracle's hypersphere attention on K / V evaluated
+    in float64 from the operands as the kernel rounds them (x and W to fp16) -- the bounds of the unfused low-precision kernel --, and
+    (ii) the unfused pair it replaces (msm_kv_project_multi_bf16 + msm_hypersphere_attn_lp_fwd): statistically the same distance from
+    the exact result, the fused form a little closer (K is never stored, so it is rounded once less)."""
+    Hh, E = 8, 256
+    S = H * W
+    q = rnd(B, Lq, E, seed=1)
+    x = F.normalize(rnd(B, 64, H, W, seed=2), dim=1)                       # a unit-norm embedding map, NCHW like the UCN feature
+    w = rnd(2 * E, 64, seed=3, scale=0.35)
+    rowcol = rnd(H + W, 2 * E, seed=4, scale=0.3)
+    rowcol[H:, E:] *= 0.5
+    h16 = lambda t: t.to(torch.float16).double()
+    xt = x.flatten(2).transpose(1, 2)                                      # (B, S, 64)
+    const = (rowcol[:H, None] + rowcol[None, H:]).reshape(S, 2 * E).double()
+    kv = (h16(xt) @ h16(w).t() + const).float()
+    k, v = kv[..., :E], kv[..., E:]
+    m = row_any = add = None
+    if masked:
+        g = torch.Generator().manual_seed(4)
+        m = torch.rand(B, Lq, S, generator=g) < 0.6
+        m[0, 1] = True
+        row_any = (~m.all(-1)).to(torch.int32)
+        eff = m.clone()
+        eff[m.all(-1)] = False
+        add = torch.zeros(B, 1, Lq, S)
+        add[eff[:, None]] = float("-inf")
+        add = add.expand(B, Hh, Lq, S).reshape(B * Hh, Lq, S)
+    hd = lambda t, n: t.view(B, n, Hh, 32).permute(0, 2, 1, 3).reshape(B * Hh, n, 32)
+    o, _ = O.hypersphere_attention(hd(q, Lq), hd(k, S), hd(v, S), add)
+    ref = o.view(B, Hh, Lq, 32).permute(0, 2, 1, 3).reshape(B, Lq, E)
+    d = lambda t: t.to(DEV).contiguous()
+    xh = ops().tokens_f16(d(x))
+    assert xh.shape == (B, S, 64) and torch.equal(xh.cpu(), xt.to(torch.float16))
+    # a token-major view of a wider buffer (how the pixel decoder hands its levels over) packs to the same tokens
+    buf = torch.zeros(B, S + 5, 64, device=DEV)
+    buf[:, 2:2 + S] = d(xt)
+    assert torch.equal(ops().tokens_f16(buf[:, 2:2 + S].view(B, H, W, 64).permute(0, 3, 1, 2)), xh)
+    wp = ops().attn_pack_kv_weights(d(w), Hh)
+    kw = dict(masked=None if m is None else d(m.to(torch.uint8)), row_any=None if row_any is None else d(row_any))
+    got = ops().hypersphere_attention_fused_kv(d(q), xh, wp, d(rowcol), d(rowcol[H:, E:].t()), (H, W), Hh, keys_f16=keys_f16, **kw)
+    err = (got.cpu() - ref).abs()
+    print(f"fused K/V attention S={S} keys_f16={keys_f16}: max |d| {float(err.max()):.2e} mean {float(err.mean()):.2e}")
+    if keys_f16:
+        assert float(err.max()) < 1.5e-2 and float(err.mean()) < 8e-4
+    assert float(err.max()) < 3e-2 and float(err.mean()) < 2e-3
+    nrm = got.view(B, Lq, Hh, 32).norm(dim=-1)
+    close(nrm, torch.ones_like(nrm).cpu(), rtol=1e-5, atol=1e-5)
+    # the unfused pair on the same inputs
+    kvu = ops().kv_project_multi([d(x)], [d(w)], [d(rowcol)], out_dtype=torch.bfloat16, cmat_widths=[W], keys_f16=keys_f16)[0]
+    unf = ops().hypersphere_attention(d(q), kvu[..., :E], kvu[..., E:], Hh, low_precision=True, keys_f16=keys_f16, **kw)
+    e_unf = float((unf.cpu() - ref).abs().mean())
+    print(f"   unfused pair: mean |d| {e_unf:.2e}")
+    assert float(err.mean()) <= 1.25 * e_unf + 1e-5
+    with pytest.raises(RuntimeError, match="multiple of 16"):
+        ops().hypersphere_attention_fused_kv(d(q), xh[:, :S - H * 8].contiguous(), wp, d(rowcol[:H + W - 8]), d(rowcol[H:H + W - 8, E:].t()), (H, W - 8), Hh)
+
+
 def test_hypersphere_attention_strided_views():
     B, L, H, E = 2, 100, 8, 256
     qk, v = rnd(B, L, 2 * E, seed=1).to(DEV), rnd(B, L, E, seed=2).to(DEV)

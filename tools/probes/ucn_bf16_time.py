@@ -19,9 +19,11 @@ X, _ = syn.synth_unit_embeddings(H * W, 64, clusters=12, sigma=0.3, seed=5)
 emb = X.view(1, H * W, 64).transpose(1, 2).reshape(1, 64, H, W).repeat(UB, 1, 1, 1).contiguous().to(dev)
 ufe = {"res5": emb}
 ref = None
-for mode in ("f32", "f32_split", "bf16"):
+for mode, fused in (("f32", True), ("bf16", False), ("bf16", True), ("f16", False), ("f16", True)):
     try:
         ucn.set_precision(mode)
+        uh.predictor.fused_kv_attention = fused
+        mode = f"{mode} fused_kv={fused}"
         for _ in range(2):
             out = ucn.inference(ufe, (H, W))
         torch.cuda.synchronize()

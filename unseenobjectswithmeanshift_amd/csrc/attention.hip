@@ -467,6 +467,277 @@ __global__ __launch_bounds__(256, 2) void hs_attn_kernel(const float* __restrict
     }
 }
 
+// ---- long key sequences in the 16-bit plans: the K/V projection INSIDE the attention kernel -------------------------------------
+// Reference: the cross-attention of PretrainedMeanShiftTransformerDecoder / the finest level of MeanShiftTransformerDecoder
+// (meanshiftformer_transformer_decoder.py:697-1048, :245-260) with ms_in_projection_packed's key / value linears (attention_util.py:134-140)
+// and the head split (:364-375).  K and V are affine in the 64-channel level feature x (modeling._folded_kv):
+//     [K | V](key) = x(key) W^T + row[y(key)] + col[x(key)]            (separable position constants, msm_kv_project_f32)
+// Unfused, the 16-bit plans write them as 1024 bytes per key (2 x 256 bf16) and the attention kernel reads them back -- 3.8 GB per
+// decoder pass on the 307 200-key UCN path against the 128 bytes per key of the fp16 feature they are a linear image of, and the
+// projection launch (1.8 ms of a 5.9-ms step) does nothing else.  Here a workgroup = (key range, head, query chunk) as hs_attn_kernel;
+// per 16-key block a wave
+//   * loads its keys' 64 fp16 channels (two 16-byte loads per lane: channels 32 s + 8 lq .. + 7 of key lj -- the B operand of the K
+//     products AND the A operand of the V products as they are),
+//   * K_h^T [32 dims x 16 keys] = Wk_h x^T and V_h [16 keys x 32 dims] = x Wv_h^T: 4 + 4 v_mfma_f32_16x16x32_f16 with the head's
+//     weight fragments resident in 32 VGPRs and the position constants as the accumulators' initial values,
+//   * the K accumulators ARE the score MFMA's A operand up to a permutation of the head dimension (lane (key lj, lq) ends with dims
+//     4 lq + r and 16 + 4 lq + r: k index 8 lq + j <-> dim 16 (j >> 2) + 4 lq + (j & 3); the query fragments are loaded in the same order),
+//     the V accumulators (lane (dim lj, lq): keys 4 lq + r) ARE the B operand of P V: normalise, round, multiply -- no LDS, no transposition,
+//   * then the score / exp / P V chain of keys_consume.
+// The projection's operands are IEEE halves in both 16-bit plans (x is a unit-norm embedding or a LayerNorm output; one rounding of x,
+// one of W); K^ and the probabilities / V enter the score and P V MFMAs in the plan's own formats (BF = 1: bf16, BF = 2: fp16 scores).
+// Needs: separable constants, W % 16 == 0 (a key block lies in one image row and starts at a multiple of 16), S % 16 == 0.
+struct FkvConst {
+    float4 ck[2], rk[2];    // K: col[x0 + lj][16 t + 4 lq ..], row[y][16 t + 4 lq ..]
+    float4 cv[2];           // V: colT[16 t + lj][x0 + 4 lq ..]
+    float rv[2];            // V: row[y][256 + 16 t + lj]
+};
+template <int MM>
+struct FkvFrag {
+    u32x4b x[2];
+    FkvConst c;
+    uint32_t mw[MM ? AQB : 1];
+};
+
+template <int BF, int MM>
+__global__ __launch_bounds__(256, 2) void hs_attn_fkv_kernel(const float* __restrict__ q, const unsigned short* __restrict__ xh,
+                                                           const u32x4b* __restrict__ wfrag, const float* __restrict__ rc,
+                                                           const float* __restrict__ cvT, const uint8_t* __restrict__ masked,
+                                                           const int32_t* __restrict__ row_any, float* __restrict__ part,
+                                                           float* __restrict__ out, int Lq, int S, int Wimg, int heads, int qchunks, int nsplit,
+                                                           int64_t ldq, int64_t q_sb, float kappa) {
+    static_assert(BF == 1 || BF == 2, "the fused kernel exists for the 16-bit plans");
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [4][AQCH][PSTRIDE]
+    const int split = blockIdx.x, h = blockIdx.y;
+    const int b = blockIdx.z / qchunks, qc = blockIdx.z - b * qchunks;
+    const int q0 = qc * AQCH;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    const int Himg = S / Wimg;
+    const int N = 2 * heads * HD;                                // columns of the constants: [K | V]
+
+    // Q^ fragments in the head-dimension order of the K accumulators: k index 8 lq + j <-> dim 16 (j >> 2) + 4 lq + (j & 3)
+    bf16x4 qh[AQB][2];
+    bool use_mask[AQB];
+    {
+        const float* qb = q + (int64_t)b * q_sb + h * HD + lq * 4;
+        const int32_t* ra = row_any ? row_any + (int64_t)b * Lq : nullptr;
+#pragma unroll
+        for (int m = 0; m < AQB; ++m) {
+            const int qi = q0 + m * 16 + lj;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+            if (qi < Lq) {
+                const float* p = qb + (int64_t)qi * ldq;
+                a = *reinterpret_cast<const float4*>(p);
+                c = *reinterpret_cast<const float4*>(p + 16);
+            }
+            float ss = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            const float rn = rnorm(ss);
+            if constexpr (BF == 2) {
+                qh[m][0] = __builtin_bit_cast(bf16x4, pack4h_nc(a.x * rn, a.y * rn, a.z * rn, a.w * rn));
+                qh[m][1] = __builtin_bit_cast(bf16x4, pack4h_nc(c.x * rn, c.y * rn, c.z * rn, c.w * rn));
+            } else {
+                qh[m][0] = pack4(a.x * rn, a.y * rn, a.z * rn, a.w * rn);
+                qh[m][1] = pack4(c.x * rn, c.y * rn, c.z * rn, c.w * rn);
+            }
+            use_mask[m] = MM != 0 && qi < Lq && (ra == nullptr || ra[qi] != 0);
+        }
+    }
+    // the head's weight fragments: [kv][tile][k-step] x 16 bytes per lane (msm_attn_pack_kv_weights)
+    f16x8 wk[2][2], wv[2][2];
+    {
+        const u32x4b* wp = wfrag + (int64_t)h * 8 * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                wk[t][st] = __builtin_bit_cast(f16x8, wp[((0 * 2 + t) * 2 + st) * 64]);
+                wv[t][st] = __builtin_bit_cast(f16x8, wp[((1 * 2 + t) * 2 + st) * 64]);
+            }
+    }
+    f32x4 o[AQB][2];
+    f32x2l lacc[AQB];
+#pragma unroll
+    for (int m = 0; m < AQB; ++m) {
+        o[m][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        o[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        lacc[m] = f32x2l{0.f, 0.f};
+    }
+    const int nkb = S / 16;
+    const int kb_per = (nkb + nsplit - 1) / nsplit;
+    const int kb_beg = split * kb_per, kb_end = min(nkb, kb_beg + kb_per);
+    const float k2 = kappa * 1.4426950408889634f;
+
+    // buffer descriptors: x of this image, the constants, the mask of this image
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr64(xh + (int64_t)b * S * 64), 0, (unsigned)S * 128u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rcr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr64(rc), 0, (unsigned)(Himg + Wimg) * (unsigned)N * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t cvr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr64(cvT), 0, (unsigned)(heads * HD) * (unsigned)Wimg * 4u, 0x00020000);
+    __amdgpu_buffer_rsrc_t mr = xr;
+    unsigned mo[MM ? AQB : 1];
+    if constexpr (MM != 0) {
+        mr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr64(masked + (int64_t)b * Lq * S), 0, (unsigned)Lq * (unsigned)S, 0x00020000);
+#pragma unroll
+        for (int m = 0; m < AQB; ++m) mo[m] = (unsigned)min(q0 + m * 16 + lj, Lq - 1) * (unsigned)S + (unsigned)lq * 4u;
+    }
+    const unsigned xo = (unsigned)lj * 128u + (unsigned)lq * 16u;                                  // channels 8 lq .. + 7 of key lj (k-step 1: + 64 bytes)
+    const unsigned cko = ((unsigned)(Himg + lj) * (unsigned)N + (unsigned)(h * HD + lq * 4)) * 4u;   // col[lj][K dims 4 lq ..] (+ x0 rows, + 16 t)
+    const unsigned rko = (unsigned)(h * HD + lq * 4) * 4u;                                           // row[0][K dims 4 lq ..]
+    const unsigned cvo = ((unsigned)(h * HD + lj) * (unsigned)Wimg + (unsigned)lq * 4u) * 4u;        // colT[dim lj][4 lq ..]
+    const unsigned rvo = (unsigned)(heads * HD + h * HD + lj) * 4u;                                  // row[0][V dim lj]
+
+    auto fetch = [&](int kb, FkvFrag<MM>& f) {
+        const int y = (kb * 16) / Wimg, x0 = kb * 16 - y * Wimg;                                     // uniform
+        const unsigned ks = (unsigned)kb * 16u * 128u;
+        f.x[0] = __builtin_amdgcn_raw_buffer_load_b128(xr, xo, ks, 0);
+        f.x[1] = __builtin_amdgcn_raw_buffer_load_b128(xr, xo + 64u, ks, 0);
+        const unsigned cks = (unsigned)x0 * (unsigned)N * 4u, rks = (unsigned)y * (unsigned)N * 4u;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const u32x4b a = __builtin_amdgcn_raw_buffer_load_b128(rcr, cko + 64u * t, cks, 0);
+            const u32x4b r_ = __builtin_amdgcn_raw_buffer_load_b128(rcr, rko + 64u * t, rks, 0);
+            const u32x4b v_ = __builtin_amdgcn_raw_buffer_load_b128(cvr, cvo + (unsigned)(16 * t) * (unsigned)Wimg * 4u, (unsigned)x0 * 4u, 0);
+            f.c.ck[t] = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+            f.c.rk[t] = make_float4(__uint_as_float(r_.x), __uint_as_float(r_.y), __uint_as_float(r_.z), __uint_as_float(r_.w));
+            f.c.cv[t] = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w));
+            f.c.rv[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rcr, rvo + 64u * t, rks, 0));
+        }
+        if constexpr (MM != 0) {
+#pragma unroll
+            for (int m = 0; m < AQB; ++m) f.mw[m] = __builtin_amdgcn_raw_buffer_load_b32(mr, mo[m], (unsigned)kb * 16u, 0);
+        }
+    };
+    auto consume = [&](const FkvFrag<MM>& f) {
+        const f16x8 x0_ = __builtin_bit_cast(f16x8, f.x[0]), x1_ = __builtin_bit_cast(f16x8, f.x[1]);
+        // K_h^T (dims x keys) and V_h (keys x dims), constants as the initial values
+        f32x4 kt[2], vt[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            kt[t] = f32x4{f.c.ck[t].x + f.c.rk[t].x, f.c.ck[t].y + f.c.rk[t].y, f.c.ck[t].z + f.c.rk[t].z, f.c.ck[t].w + f.c.rk[t].w};
+            vt[t] = f32x4{f.c.cv[t].x + f.c.rv[t], f.c.cv[t].y + f.c.rv[t], f.c.cv[t].z + f.c.rv[t], f.c.cv[t].w + f.c.rv[t]};
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            kt[t] = mfma_f16k32(wk[t][0], x0_, kt[t]);
+            vt[t] = mfma_f16k32(x0_, wv[t][0], vt[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            kt[t] = mfma_f16k32(wk[t][1], x1_, kt[t]);
+            vt[t] = mfma_f16k32(x1_, wv[t][1], vt[t]);
+        }
+        // k^ = K / max(|K|, 1e-12) over the head's 32 dims: this lane's eight + the three other lane quarters of key lj
+        float ss = (kt[0][0] * kt[0][0] + kt[0][1] * kt[0][1] + kt[0][2] * kt[0][2] + kt[0][3] * kt[0][3]) +
+                   (kt[1][0] * kt[1][0] + kt[1][1] * kt[1][1] + kt[1][2] * kt[1][2] + kt[1][3] * kt[1][3]);
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        const float rn = rnorm(ss);
+        bf16x4 kh[2], vb[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if constexpr (BF == 2) kh[t] = __builtin_bit_cast(bf16x4, pack4h_nc(kt[t][0] * rn, kt[t][1] * rn, kt[t][2] * rn, kt[t][3] * rn));
+            else kh[t] = pack4(kt[t][0] * rn, kt[t][1] * rn, kt[t][2] * rn, kt[t][3] * rn);
+            vb[t] = pack4(vt[t][0], vt[t][1], vt[t][2], vt[t][3]);
+        }
+        auto scores = [&](int m) {
+            f32x4 s_ = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (MM != 0) {
+                const uint32_t mw = use_mask[m] ? f.mw[m] : 0u;
+                s_ = f32x4{(float)(mw & 0xffu) * MASK_BIAS, (float)((mw >> 8) & 0xffu) * MASK_BIAS, (float)((mw >> 16) & 0xffu) * MASK_BIAS,
+                           (float)(mw >> 24) * MASK_BIAS};
+            }
+            if constexpr (BF == 2) return mfma_f16k32(__builtin_bit_cast(f16x8, cat8(kh[0], kh[1])), __builtin_bit_cast(f16x8, cat8(qh[m][0], qh[m][1])), s_);
+            else return mfma_bf16k32(cat8(kh[0], kh[1]), cat8(qh[m][0], qh[m][1]), s_);
+        };
+        f32x4 s_ = scores(0);
+#pragma unroll
+        for (int m = 0; m < AQB; ++m) {
+            f32x4 sn = s_;
+            if (m + 1 < AQB) sn = scores(m + 1);
+            const f32x2l k2v = f32x2l{k2, k2};
+            const f32x2l e01 = __builtin_elementwise_fma(f32x2l{s_[0], s_[1]}, k2v, -k2v), e23 = __builtin_elementwise_fma(f32x2l{s_[2], s_[3]}, k2v, -k2v);
+            const float p[4] = {__builtin_amdgcn_exp2f(e01[0]), __builtin_amdgcn_exp2f(e01[1]), __builtin_amdgcn_exp2f(e23[0]), __builtin_amdgcn_exp2f(e23[1])};
+            lacc[m] += f32x2l{p[0], p[1]} + f32x2l{p[2], p[3]};
+            const bf16x4 pp = pack4(p[0], p[1], p[2], p[3]);
+            o[m][0] = mfma_bf16(pp, vb[0], o[m][0]);
+            o[m][1] = mfma_bf16(pp, vb[1], o[m][1]);
+            s_ = sn;
+        }
+    };
+    {
+        int kb = kb_beg + wave;
+        FkvFrag<MM> fa, fb;
+        if (kb < kb_end) fetch(kb, fa);
+        for (; kb + 4 < kb_end; kb += 8) {
+            fetch(kb + 4, fb);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(fa);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(min(kb + 8, nkb - 1), fa);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(fb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kb < kb_end) consume(fa);
+    }
+
+    // ---- reduce the 4 waves through LDS, then one partial per workgroup (as hs_attn_kernel) ----
+    float* mine = red + wave * (AQCH * PSTRIDE);
+#pragma unroll
+    for (int m = 0; m < AQB; ++m) {
+        float l = lacc[m][0] + lacc[m][1];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        if (lq == 0) mine[(m * 16 + lj) * PSTRIDE + HD] = l;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m * 16 + lq * 4 + r;
+            mine[row * PSTRIDE + lj] = o[m][0][r];
+            mine[row * PSTRIDE + 16 + lj] = o[m][1][r];
+        }
+    }
+    __syncthreads();
+    if (nsplit == 1) {
+        const int ql = tid;
+        const int qi = q0 + ql;
+        if (ql < AQCH && qi < Lq) {
+            float acc[HD + 1];
+#pragma unroll
+            for (int d = 0; d <= HD; ++d)
+                acc[d] = (red[ql * PSTRIDE + d] + red[AQCH * PSTRIDE + ql * PSTRIDE + d]) +
+                         (red[2 * AQCH * PSTRIDE + ql * PSTRIDE + d] + red[3 * AQCH * PSTRIDE + ql * PSTRIDE + d]);
+            const float l = acc[HD];
+            float ss = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                acc[d] = acc[d] / l;
+                ss += acc[d] * acc[d];
+            }
+            const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+            float* o_ = out + ((int64_t)b * Lq + qi) * (heads * HD) + h * HD;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) o_[d] = acc[d] / nrm;
+        }
+        return;
+    }
+    float* dst = part + ((((int64_t)blockIdx.z * heads + h) * nsplit) + split) * (AQCH * PSTRIDE);
+    for (int i = tid; i < AQCH * PSTRIDE; i += 256) dst[i] = (red[i] + red[AQCH * PSTRIDE + i]) + (red[2 * AQCH * PSTRIDE + i] + red[3 * AQCH * PSTRIDE + i]);
+}
+
+// W [K 256 | V 256][64] fp32 -> the fp16 fragments of hs_attn_fkv_kernel: [head][kv][tile t][k-step s][lane][8]:
+// lane (i = l & 15, kq = l >> 4) holds W[kv * heads * 32 + h * 32 + 16 t + i][32 s + 8 kq .. + 7]
+__global__ __launch_bounds__(256) void attn_pack_kv_weights_kernel(const float* __restrict__ w, u32x4b* __restrict__ out, int heads) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= heads * 8 * 64) return;
+    const int lane = idx & 63, fs = (idx >> 6) & 1, t = (idx >> 7) & 1, kv = (idx >> 8) & 1, h = idx >> 9;
+    const float* src = w + (int64_t)(kv * heads * HD + h * HD + 16 * t + (lane & 15)) * 64 + 32 * fs + 8 * (lane >> 4);
+    const float4 a = *reinterpret_cast<const float4*>(src), c = *reinterpret_cast<const float4*>(src + 4);
+    const u32x2b lo = pack4h(a.x, a.y, a.z, a.w), hi = pack4h(c.x, c.y, c.z, c.w);
+    out[idx] = u32x4b{lo.x, lo.y, hi.x, hi.y};
+}
+
 // ---- short and medium key sequences (self-attention: 100 keys; the 15x20 / 30x40 levels) -----------------------------------
 // With few keys the kernel above is all fixed cost: every wave holds all 7 query blocks for 1-2 key blocks, the four
 // waves are reduced through 59 KB of LDS and 112 threads finish with strided 4-byte stores (14.6 us for 100 keys,
@@ -737,4 +1008,58 @@ extern "C" int msm_hypersphere_attn_lp_fwd(const float* q, const void* k, const 
                                      q_sb, ldk, k_sb, ldv, v_sb, kappa, workspace, workspace_elems, stream);
     return attn_launch<float, 1>("msm_hypersphere_attn_lp_fwd", q, (const float*)k, (const float*)v, masked, row_any, out, B, Lq, S, heads, ldq,
                                     q_sb, ldk, k_sb, ldv, v_sb, kappa, workspace, workspace_elems, stream);
+}
+
+extern "C" int msm_attn_pack_kv_weights(const float* w, void* packed, int heads, void* stream) {
+    MSM_REQUIRE(w && packed && heads > 0 && heads <= 64, "msm_attn_pack_kv_weights: bad arguments");
+    MSM_REQUIRE(((((uintptr_t)w) | ((uintptr_t)packed)) & 15) == 0, "msm_attn_pack_kv_weights: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(attn_pack_kv_weights_kernel, dim3(cdiv(heads * 8 * 64, 256)), dim3(256), 0, (hipStream_t)stream, w, (u32x4b*)packed, heads);
+    MSM_CHECK_LAUNCH("msm_attn_pack_kv_weights");
+    return MSM_OK;
+}
+
+extern "C" int msm_hypersphere_attn_fused_kv_fwd(const float* q, const void* x_f16, const void* w_packed, const float* rowcol, const float* col_v_t,
+                                                 int score_format, const uint8_t* masked, const int32_t* row_any, float* out, int B, int Lq,
+                                                 int H, int W, int heads, int64_t ldq, int64_t q_sb, float kappa, float* workspace,
+                                                 int64_t workspace_elems, void* stream) {
+    const char* who = "msm_hypersphere_attn_fused_kv_fwd";
+    MSM_REQUIRE(q && x_f16 && w_packed && rowcol && col_v_t && out && workspace, "%s: null pointer", who);
+    MSM_REQUIRE(B > 0 && Lq > 0 && H > 0 && W > 0 && heads > 0, "%s: bad sizes", who);
+    MSM_REQUIRE(W % 16 == 0, "%s: W=%d must be a multiple of 16 (a 16-key block lies in one image row)", who, W);
+    MSM_REQUIRE(score_format == 1 || score_format == 2, "%s: score_format=%d (1 = bf16, 2 = fp16 q^ / k^ operands)", who, score_format);
+    const int64_t S64 = (int64_t)H * W;
+    MSM_REQUIRE(S64 * 128 < ((int64_t)1 << 32) && (int64_t)Lq * S64 < ((int64_t)1 << 32) && (int64_t)(H + W) * heads * HD * 8 < ((int64_t)1 << 32),
+                "%s: one image of x / the mask / the constants must stay below 4 GiB (32-bit buffer offsets)", who);
+    MSM_REQUIRE(ldq % 4 == 0 && q_sb % 4 == 0 && ((((uintptr_t)q) | ((uintptr_t)x_f16) | ((uintptr_t)w_packed) | ((uintptr_t)rowcol) | ((uintptr_t)col_v_t)) & 15) == 0,
+                "%s: pointers must be 16-byte aligned", who);
+    MSM_REQUIRE(!masked || (((uintptr_t)masked) & 3) == 0, "%s: mask must be 4-byte aligned", who);
+    const int S = (int)S64;
+    const int qchunks = cdiv(Lq, AQCH);
+    const int ns = attn_nsplit(B, qchunks, heads, S);
+    const int64_t need = (int64_t)B * qchunks * heads * ns * AQCH * PSTRIDE;
+    if (workspace_elems < need) {
+        set_error("%s: workspace %lld < %lld floats", who, (long long)workspace_elems, (long long)need);
+        return MSM_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = sizeof(float) * 4 * AQCH * PSTRIDE;
+    dim3 grid(ns, heads, B * qchunks), block(256);
+#define FKV_LAUNCH(BF_, MM_)                                                                                                       \
+    {                                                                                                                              \
+        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)hs_attn_fkv_kernel<BF_, MM_>, lds));                             \
+        hipLaunchKernelGGL((hs_attn_fkv_kernel<BF_, MM_>), grid, block, lds, st, q, (const unsigned short*)x_f16, (const u32x4b*)w_packed, rowcol, \
+                           col_v_t, masked, row_any, workspace, out, Lq, S, W, heads, qchunks, ns, ldq, q_sb, kappa);               \
+    }
+    if (score_format == 2) {
+        if (masked) FKV_LAUNCH(2, 1) else FKV_LAUNCH(2, 0)
+    } else {
+        if (masked) FKV_LAUNCH(1, 1) else FKV_LAUNCH(1, 0)
+    }
+#undef FKV_LAUNCH
+    MSM_CHECK_LAUNCH(who);
+    if (ns == 1) return MSM_OK;
+    dim3 g2(heads, B * qchunks, AQB), b2(256);
+    hipLaunchKernelGGL(hs_attn_combine_kernel, g2, b2, 0, st, workspace, out, Lq, heads, qchunks, ns);
+    MSM_CHECK_LAUNCH(who);
+    return MSM_OK;
 }

@@ -292,6 +292,10 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         # low-precision attention only (head.set_precision("f16")): "f16" = the K columns of the K/V projection stored as IEEE half
         # and q^ / k^ on fp16 MFMAs (kappa = 30 multiplies the cosine's rounding error), "bf16" = bf16 everywhere
         self.attention_keys = "bf16"
+        # 16-bit plans: the folded K/V projection of a LONG level (>= 16 384 keys, separable constants, W % 16 == 0: the 307 200-key UCN
+        # path, the 120 x 160 level of configs[4]) inside the attention kernel (csrc/attention.hip, hs_attn_fkv_kernel): K / V are never
+        # written.  False: msm_kv_project_multi_bf16 + msm_hypersphere_attn_lp_fwd (the tested alternative)
+        self.fused_kv_attention = True
         # True: the batched K/V projection computes its fp32 products as exact three-term bf16 splits (set_precision("f32_split"))
         self.kv_split = False
         self._packed_mf = None
@@ -349,7 +353,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         # parameter change drops them all
         if self._kv_cache is None or self._kv_cache.get("params") != pkey:
             self._kv_cache = {"params": pkey}
-        if len(self._kv_cache) > 9:                                           # bounded: params + 8 geometries
+        if len(self._kv_cache) > 17:                                          # bounded: params + 8 geometries (+ their fused-K/V packs)
             self._kv_cache = {"params": pkey}
         if skey not in self._kv_cache:
             ws, cs = [], []
@@ -469,7 +473,32 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                 return ops.kv_project_multi([x], [w], [c], split=True, cmat_widths=[cw])[0]
         return ops.kv_project(x, w, c, cw)
 
-    def _forward_fused(self, xs, sizes, kv_w, kv_c, mask_features, out, qpos, kv_all=None, final_topk=0):
+    def _fused_kv_plan(self, xs, sizes, kv_w, kv_c):
+        """Which cross-attention layers take the fused K/V + attention kernel (see ``fused_kv_attention``), with their packed weights /
+        transposed V constants (cached with the folded constants) and the fp16 token form of each such level (made once per forward).
+        -> None, or {"layers": [None | (w_packed, rowcol, col_v_t)], "x": {level: (B, S, 64) float16}}."""
+        if not (self.fused_kv_attention and self.fused_tails and self.attention_dtype == "bf16"):
+            return None
+        E = self.query_feat.weight.shape[1]
+        H = self.num_heads
+        cache = self._kv_cache.setdefault(("fkv", tuple(sizes), str(xs[0].device)), {})
+        layers, xh = [], {}
+        for i in range(self.num_layers):
+            l = i % self.num_feature_levels
+            h, w = sizes[l]
+            c, cw = kv_c[i]
+            if not (cw == w and w % 16 == 0 and h * w >= 16384 and xs[l].shape[1] == 64 and tuple(kv_w[i].shape) == (2 * E, 64) and E == H * 32
+                    and h * w * 128 < (1 << 32)):
+                layers.append(None)
+                continue
+            if i not in cache:
+                cache[i] = (ops.attn_pack_kv_weights(kv_w[i], H), c, c[h:, E:].t().contiguous())
+            layers.append(cache[i])
+            if l not in xh:
+                xh[l] = ops.tokens_f16(xs[l])
+        return {"layers": layers, "x": xh} if xh else None
+
+    def _forward_fused(self, xs, sizes, kv_w, kv_c, mask_features, out, qpos, kv_all=None, final_topk=0, fkv=None):
         """Same arithmetic as the loop in forward(), with the row-local ops of a layer in three launches:
         heads (+ next cross-attention query) -> mask step -> K/V GEMM -> cross attention -> post_cross (out_proj, LN,
         self-attention in-projection) -> self attention -> post_self (out_proj, LN, FFN by hidden chunk)."""
@@ -562,12 +591,15 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             sa = self.transformer_self_attention_layers[i]
             ff = self.transformer_ffn_layers[i]
             lp = self.attention_dtype == "bf16"
-            if kv_all is not None:
-                kv = kv_all[i]
-            else:
-                kv = self._kv_one(xs[lvl], kv_w[i], kv_c[i])          # (B, hw, 2E) = [K | V]
             kf = lp and self.attention_keys == "f16"
-            o = ops.hypersphere_attention(q, kv[..., :E], kv[..., E:], H, masked=attn, row_any=row_any, kappa=float(KAPPA), low_precision=lp, keys_f16=kf)
+            if fkv is not None and fkv["layers"][i] is not None:
+                # K / V of this level are projected inside the attention kernel and never stored
+                o = ops.hypersphere_attention_fused_kv(q, fkv["x"][lvl], *fkv["layers"][i], sizes[lvl], H, masked=attn, row_any=row_any,
+                                                       kappa=float(KAPPA), keys_f16=kf)
+            else:
+                kv = kv_all[i] if kv_all is not None else self._kv_one(xs[lvl], kv_w[i], kv_c[i])          # (B, hw, 2E) = [K | V]
+                o = ops.hypersphere_attention(q, kv[..., :E], kv[..., E:], H, masked=attn, row_any=row_any, kappa=float(KAPPA), low_precision=lp,
+                                              keys_f16=kf)
             x, qk, v = ops.dec_post_cross(o, out, qpos, pk["cross_o"][i], ca.meanshift_attn.out_proj.bias, ca.norm.weight,
                                           ca.norm.bias, pk["self_in"][i], sa.self_attn.in_proj_bias)
             o = ops.hypersphere_attention(qk[..., :E], qk[..., E:], v, H, kappa=float(KAPPA), low_precision=lp, keys_f16=kf)
@@ -603,23 +635,27 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             # token-major (channels_last) level maps, as the pixel decoder returns them, are consumed as they are
             xs.append(x[i] if ops.is_token_major(x[i]) else x[i].contiguous())
         kv_all = None
+        fkv = None
         if self.fold_kv:
             kv_w, kv_c = self._folded_kv(sizes, dev)
+            fkv = self._fused_kv_plan(xs, sizes, kv_w, kv_c)
             kv_bytes = (2 if self.attention_dtype == "bf16" else 4) * B * kv_w[0].shape[0] * sum(sizes[i % self.num_feature_levels][0] * sizes[i % self.num_feature_levels][1]
                                                       for i in range(self.num_layers))
             if (self.batched_kv and kv_bytes <= (1 << 30) and all(xl.shape[1] == 64 for xl in xs)
                     and kv_w[0].shape[0] in (256, 512)):       # all layers' K/V live at once: only while that stays small (beyond ~1 GiB a
                 # layer's K/V is long out of the caches when its attention reads it: configs[4] at batch 4 is 1 % faster layer by layer)
                 # (a launch takes up to 16 jobs: the 20 layers of configs[4] are two launches)
-                kv_all = []
-                for j0 in range(0, self.num_layers, 16):
-                    jobs = range(j0, min(j0 + 16, self.num_layers))
-                    kv_all += ops.kv_project_multi([xs[i % self.num_feature_levels] for i in jobs], [kv_w[i] for i in jobs],
+                kv_all = [None] * self.num_layers
+                todo = [i for i in range(self.num_layers) if fkv is None or fkv["layers"][i] is None]      # (fused layers project inside their attention)
+                for j0 in range(0, len(todo), 16):
+                    jobs = todo[j0:j0 + 16]
+                    for i, kv in zip(jobs, ops.kv_project_multi([xs[i % self.num_feature_levels] for i in jobs], [kv_w[i] for i in jobs],
                                                    [kv_c[i][0] for i in jobs],
                                                    out_dtype=torch.bfloat16 if self.attention_dtype == "bf16" else torch.float32,
                                                    split=self.kv_split and self.attention_dtype != "bf16",
                                                    cmat_widths=[kv_c[i][1] for i in jobs],
-                                                   keys_f16=self.attention_dtype == "bf16" and self.attention_keys == "f16")
+                                                   keys_f16=self.attention_dtype == "bf16" and self.attention_keys == "f16")):
+                        kv_all[i] = kv
         else:
             for i in range(self.num_feature_levels):
                 pos.append(self._pos_tokens(*sizes[i], dev))
@@ -665,7 +701,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         L = self.num_layers
         pred_cls, pred_mask = [], []
         if self.fused_tails and self.fold_kv:
-            return self._forward_fused(xs, sizes, kv_w, kv_c, mask_features, out, qpos, kv_all, final_topk)
+            return self._forward_fused(xs, sizes, kv_w, kv_c, mask_features, out, qpos, kv_all, final_topk, fkv)
         d = ops.layernorm(out, self.decoder_norm.weight, self.decoder_norm.bias)
         cls, m, attn, row_any = self._heads(d, mask_features, sizes[0], full or L == 0, full or L == 0)
         pred_cls.append(cls)

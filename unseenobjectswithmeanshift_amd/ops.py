@@ -606,6 +606,53 @@ def hypersphere_attention(q, k, v, heads, *, masked=None, row_any=None, kappa=KA
     return out
 
 
+def attn_pack_kv_weights(w, heads):
+    """[K rows | V rows] folded projection weight (2 * heads * 32, 64) fp32 -> the fp16 MFMA fragments of hypersphere_attention_fused_kv
+    (msm_attn_pack_kv_weights): (heads, 8, 64, 8) float16."""
+    _c(w, "w")
+    if tuple(w.shape) != (2 * heads * 32, 64):
+        raise RuntimeError("attn_pack_kv_weights: w must be (2 * heads * 32, 64)")
+    out = torch.empty((heads, 8, 64, 8), device=w.device, dtype=torch.float16)
+    check(lib().msm_attn_pack_kv_weights(_p(w), _p(out), int(heads), _stream()), "msm_attn_pack_kv_weights")
+    return out
+
+
+def tokens_f16(x):
+    """A level feature (B, 64, H, W) -- NCHW or a token-major (channels_last) view -- as the (B, H*W, 64) float16 token matrix
+    hypersphere_attention_fused_kv streams (one pass per forward: every layer of the decoder reads the same feature)."""
+    _chk(x, "x")
+    B, C, H, W = x.shape
+    if is_token_major(x):
+        t = x.permute(0, 2, 3, 1).reshape(B, H * W, C)
+    else:
+        t = transpose_last2(x.contiguous().view(B, C, H * W))
+    return to_f16(t.contiguous())
+
+
+def hypersphere_attention_fused_kv(q, x_f16, w_packed, rowcol, col_v_t, size, heads, *, masked=None, row_any=None, kappa=KAPPA, keys_f16=False):
+    """Cross attention over a long key sequence with the folded K/V projection inside the kernel (msm_hypersphere_attn_fused_kv_fwd;
+    16-bit plans): q (B, Lq, E) projected queries; x_f16 = tokens_f16(level feature) (B, H*W, 64); w_packed = attn_pack_kv_weights(w);
+    rowcol (H + W, 2E) the separable constants of kv_project(cmat_width=W); col_v_t (E, W) = rowcol[H:, E:].t(); size = (H, W), W % 16 == 0.
+    keys_f16: q^ / k^ as IEEE halves (precision "f16") instead of bf16.  Returns (B, Lq, E)."""
+    _chk(q, "q"), _c(x_f16, "x_f16", torch.float16), _c(w_packed, "w_packed", torch.float16), _c(rowcol, "rowcol"), _c(col_v_t, "col_v_t")
+    _c(masked, "masked", torch.uint8), _c(row_any, "row_any", torch.int32)
+    if q.stride(-1) != 1:
+        raise RuntimeError("q: last dim must be contiguous")
+    B, Lq, E = q.shape
+    H, W = int(size[0]), int(size[1])
+    S = H * W
+    if E != heads * 32 or tuple(x_f16.shape) != (B, S, 64) or tuple(rowcol.shape) != (H + W, 2 * E) or tuple(col_v_t.shape) != (E, W) \
+            or tuple(w_packed.shape) != (heads, 8, 64, 8) or (masked is not None and tuple(masked.shape) != (B, Lq, S)):
+        raise RuntimeError("hypersphere_attention_fused_kv: inconsistent shapes")
+    out = torch.empty((B, Lq, E), device=q.device, dtype=torch.float32)
+    need = lib().msm_hypersphere_attn_workspace(B, Lq, S, heads)
+    ws = torch.empty((need,), device=q.device, dtype=torch.float32)
+    rc = lib().msm_hypersphere_attn_fused_kv_fwd(_p(q), _p(x_f16), _p(w_packed), _p(rowcol), _p(col_v_t), 2 if keys_f16 else 1, _p(masked), _p(row_any),
+                                                 _p(out), B, Lq, H, W, heads, q.stride(1), q.stride(0), kappa, _p(ws), need, _stream())
+    check(rc, "msm_hypersphere_attn_fused_kv_fwd")
+    return out
+
+
 def hypersphere_attention_backward(q, k, v, heads, grad_out, *, masked=None, row_any=None, kappa=KAPPA):
     """Gradient of hypersphere_attention: returns (grad_q (B,Lq,E), grad_k (B,S,E), grad_v (B,S,E)), contiguous."""
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
