@@ -253,10 +253,15 @@ int msm_hypersphere_attn_lp_fwd(const float* q, const void* k, const void* v, in
  *   rowcol   [H + W][2 * heads * 32] fp32: the separable constants exactly as msm_kv_project_f32 takes them (cmat_width = W)
  *   col_v_t  [heads * 32][W] fp32: the V columns of the col table transposed (col[H + x][heads * 32 + d] -> col_v_t[d][x])
  *   score_format 1: q^ / k^ as bf16 operands, 2: as IEEE halves (precision "f16"); probabilities and V always bf16
- * W % 16 == 0.  q / masked / row_any / out / workspace (msm_hypersphere_attn_workspace(B, Lq, H*W, heads)) as msm_hypersphere_attn_fwd. */
+ *   mask_bits (or NULL) msm_attn_pack_mask_bits(masked [B][Lq][S] bytes): the mask bit-packed and blocked, msm_attn_mask_bits_bytes(B, Lq, S)
+ *            bytes = [B][ceil(Lq / 112)][S / 16][16 lj][8 m] uint16, bit k of word (lj, m) = masked[112 qc + 16 m + lj][16 kb + k] -- one
+ *            16-byte load per lane and key block instead of seven 4-byte loads that use 16 bytes of each of 16 cache lines
+ * W % 16 == 0.  q / row_any / out / workspace (msm_hypersphere_attn_workspace(B, Lq, H*W, heads)) as msm_hypersphere_attn_fwd. */
 int msm_attn_pack_kv_weights(const float* w, void* packed, int heads, void* stream);
+int64_t msm_attn_mask_bits_bytes(int B, int Lq, int S);
+int msm_attn_pack_mask_bits(const uint8_t* masked, void* bits, int B, int Lq, int S, void* stream);
 int msm_hypersphere_attn_fused_kv_fwd(const float* q, const void* x_f16, const void* w_packed, const float* rowcol, const float* col_v_t,
-                                      int score_format, const uint8_t* masked, const int32_t* row_any, float* out,
+                                      int score_format, const void* mask_bits, const int32_t* row_any, float* out,
                                       int B, int Lq, int H, int W, int heads, int64_t ldq, int64_t q_sb, float kappa,
                                       float* workspace, int64_t workspace_elems, void* stream);
 

@@ -360,6 +360,19 @@ def test_hypersphere_attention_fused_kv(B, Lq, H, W, masked, keys_f16):
     buf[:, 2:2 + S] = d(xt)
     assert torch.equal(ops().tokens_f16(buf[:, 2:2 + S].view(B, H, W, 64).permute(0, 3, 1, 2)), xh)
     wp = ops().attn_pack_kv_weights(d(w), Hh)
+    # the documented fragment order: [head][kv][tile t][k-step s][lane (i = l & 15, kq = l >> 4)][8] = W[kv E + 32 h + 16 t + i][32 s + 8 kq ..]
+    want = w.view(2, Hh, 2, 16, 2, 4, 8).permute(1, 0, 2, 4, 5, 3, 6).reshape(Hh, 8, 64, 8).to(torch.float16)
+    assert torch.equal(wp.cpu(), want)
+    if m is not None:
+        # the bit-packed, blocked mask: word [b, qc, kb, lj, mb] bit k = masked[b, 112 qc + 16 mb + lj, 16 kb + k]
+        bits = ops().attn_pack_mask_bits(d(m.to(torch.uint8))).cpu().to(torch.int32) & 0xffff
+        nqc = (Lq + 111) // 112
+        mp = torch.zeros(B, nqc * 128, S, dtype=torch.int32)
+        for qc in range(nqc):                                             # chunk qc holds queries 112 qc .. (7 blocks of 16), slot 7 empty
+            n = min(112, Lq - 112 * qc)
+            mp[:, 128 * qc:128 * qc + n] = m[:, 112 * qc:112 * qc + n].to(torch.int32)
+        wbits = (mp.view(B, nqc, 8, 16, S // 16, 16) << torch.arange(16, dtype=torch.int32)).sum(-1).permute(0, 1, 4, 3, 2)
+        assert torch.equal(bits, wbits)
     kw = dict(masked=None if m is None else d(m.to(torch.uint8)), row_any=None if row_any is None else d(row_any))
     got = ops().hypersphere_attention_fused_kv(d(q), xh, wp, d(rowcol), d(rowcol[H:, E:].t()), (H, W), Hh, keys_f16=keys_f16, **kw)
     err = (got.cpu() - ref).abs()

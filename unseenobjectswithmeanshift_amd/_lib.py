@@ -90,6 +90,8 @@ _SIGNATURES = {
     "msm_dec_heads_bf16": (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_f, c_p, c_f, c_p, c_f, c_p, c_f, c_p, c_f, c_f] + [c_f] * 4 +
                            [c_p, c_i, c_i, c_i, c_fl, c_p]),
     "msm_attn_pack_kv_weights": (c_i, [c_f, c_p, c_i, c_p]),
+    "msm_attn_mask_bits_bytes": (c_l, [c_i, c_i, c_i]),
+    "msm_attn_pack_mask_bits": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     "msm_hypersphere_attn_fused_kv_fwd": (c_i, [c_f, c_p, c_p, c_f, c_f, c_i, c_p, c_p, c_f, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_fl, c_f, c_l, c_p]),
     "msm_dec_pack_weight_f16": (c_i, [c_f, c_p, c_i, c_i, c_p]),
     "msm_dec_post_cross_f16": (c_i, [c_f, c_f, c_f, c_p, c_f, c_f, c_f, c_p, c_f, c_f, c_f, c_f] + [c_i, c_i, c_i, c_fl, c_p]),

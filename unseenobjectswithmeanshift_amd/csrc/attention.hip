@@ -487,22 +487,27 @@ __global__ __launch_bounds__(256, 2) void hs_attn_kernel(const float* __restrict
 // The projection's operands are IEEE halves in both 16-bit plans (x is a unit-norm embedding or a LayerNorm output; one rounding of x,
 // one of W); K^ and the probabilities / V enter the score and P V MFMAs in the plan's own formats (BF = 1: bf16, BF = 2: fp16 scores).
 // Needs: separable constants, W % 16 == 0 (a key block lies in one image row and starts at a multiple of 16), S % 16 == 0.
-struct FkvConst {
-    float4 ck[2], rk[2];    // K: col[x0 + lj][16 t + 4 lq ..], row[y][16 t + 4 lq ..]
-    float4 cv[2];           // V: colT[16 t + lj][x0 + 4 lq ..]
-    float rv[2];            // V: row[y][256 + 16 t + lj]
-};
-template <int MM>
+#ifndef FK_EXP
+#define FK_EXP 0   // tuning builds only (tools/probes/fkv_parts.sh): 1 no constant loads, 2 no mask loads, 3 no x loads, 4 no exponentials, 5 no P V MFMAs
+#endif
+// Round 5, what bounds it (tools/probes/fkv_parts.sh at 2 x 307 200 keys: 455 us as first written; without its mask loads 272, without its
+// constant loads 315, without x 389, without exponentials or P V MFMAs 453 / 451): the memory INSTRUCTIONS -- seven mask words per
+// block from a [query][key] byte mask (16 cache lines per instruction, 16 bytes used of each) and eight constant loads.  So:
+//   * the mask arrives bit-packed and blocked (msm_attn_pack_mask_bits): per 16-key block 256 bytes = [query lj][query block m]
+//     16-bit words (bit k = key 16 kb + k), ONE 16-byte load per lane and block, an eighth of the bytes;
+//   * a wave walks DOWN a 16-key column strip (units in column-major order u = strip * H + y): the column constants are loop
+//     invariant (16 VGPRs, reloaded when the strip changes), only the row constants (two 64-byte broadcast loads + two dwords) move.
 struct FkvFrag {
-    u32x4b x[2];
-    FkvConst c;
-    uint32_t mw[MM ? AQB : 1];
+    u32x4b x[2];            // this lane's 8 + 8 channels (k-steps 0, 1) of key lj
+    float4 rk[2];           // K: row[y][16 t + 4 lq ..]
+    float rv[2];            // V: row[y][heads * 32 + 16 t + lj]
+    u32x4b mw;              // mask words of query lj of the eight query blocks (16 bits per block)
 };
 
 template <int BF, int MM>
 __global__ __launch_bounds__(256, 2) void hs_attn_fkv_kernel(const float* __restrict__ q, const unsigned short* __restrict__ xh,
                                                            const u32x4b* __restrict__ wfrag, const float* __restrict__ rc,
-                                                           const float* __restrict__ cvT, const uint8_t* __restrict__ masked,
+                                                           const float* __restrict__ cvT, const u32x4b* __restrict__ mask_bits,
                                                            const int32_t* __restrict__ row_any, float* __restrict__ part,
                                                            float* __restrict__ out, int Lq, int S, int Wimg, int heads, int qchunks, int nsplit,
                                                            int64_t ldq, int64_t q_sb, float kappa) {
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void hs_attn_fkv_kernel(const float* __rest
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lj = lane & 15, lq = lane >> 4;
-    const int Himg = S / Wimg;
+    const int Himg = S / Wimg, strips = Wimg / 16;
     const int N = 2 * heads * HD;                                // columns of the constants: [K | V]
 
     // Q^ fragments in the head-dimension order of the K accumulators: k index 8 lq + j <-> dim 16 (j >> 2) + 4 lq + (j & 3)
@@ -566,57 +571,78 @@ __global__ __launch_bounds__(256, 2) void hs_attn_fkv_kernel(const float* __rest
         o[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         lacc[m] = f32x2l{0.f, 0.f};
     }
+    // units (16-key blocks) in column-major order, a contiguous range per workgroup, a contiguous quarter of it per wave
     const int nkb = S / 16;
-    const int kb_per = (nkb + nsplit - 1) / nsplit;
-    const int kb_beg = split * kb_per, kb_end = min(nkb, kb_beg + kb_per);
+    const int u_per = (nkb + nsplit - 1) / nsplit;
+    const int u_beg = split * u_per, u_end = min(nkb, u_beg + u_per);
+    const int w_per = (max(u_end - u_beg, 0) + 3) / 4;
+    const int u0 = u_beg + wave * w_per, u1 = min(u_end, u0 + w_per);
     const float k2 = kappa * 1.4426950408889634f;
 
-    // buffer descriptors: x of this image, the constants, the mask of this image
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr64(xh + (int64_t)b * S * 64), 0, (unsigned)S * 128u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rcr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr64(rc), 0, (unsigned)(Himg + Wimg) * (unsigned)N * 4u, 0x00020000);
     const __amdgpu_buffer_rsrc_t cvr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr64(cvT), 0, (unsigned)(heads * HD) * (unsigned)Wimg * 4u, 0x00020000);
     __amdgpu_buffer_rsrc_t mr = xr;
-    unsigned mo[MM ? AQB : 1];
-    if constexpr (MM != 0) {
-        mr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr64(masked + (int64_t)b * Lq * S), 0, (unsigned)Lq * (unsigned)S, 0x00020000);
-#pragma unroll
-        for (int m = 0; m < AQB; ++m) mo[m] = (unsigned)min(q0 + m * 16 + lj, Lq - 1) * (unsigned)S + (unsigned)lq * 4u;
-    }
+    if constexpr (MM != 0)
+        mr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr64(mask_bits + ((int64_t)b * qchunks + qc) * nkb * 16), 0, (unsigned)nkb * 256u, 0x00020000);
     const unsigned xo = (unsigned)lj * 128u + (unsigned)lq * 16u;                                  // channels 8 lq .. + 7 of key lj (k-step 1: + 64 bytes)
     const unsigned cko = ((unsigned)(Himg + lj) * (unsigned)N + (unsigned)(h * HD + lq * 4)) * 4u;   // col[lj][K dims 4 lq ..] (+ x0 rows, + 16 t)
     const unsigned rko = (unsigned)(h * HD + lq * 4) * 4u;                                           // row[0][K dims 4 lq ..]
     const unsigned cvo = ((unsigned)(h * HD + lj) * (unsigned)Wimg + (unsigned)lq * 4u) * 4u;        // colT[dim lj][4 lq ..]
     const unsigned rvo = (unsigned)(heads * HD + h * HD + lj) * 4u;                                  // row[0][V dim lj]
 
-    auto fetch = [&](int kb, FkvFrag<MM>& f) {
-        const int y = (kb * 16) / Wimg, x0 = kb * 16 - y * Wimg;                                     // uniform
-        const unsigned ks = (unsigned)kb * 16u * 128u;
-        f.x[0] = __builtin_amdgcn_raw_buffer_load_b128(xr, xo, ks, 0);
-        f.x[1] = __builtin_amdgcn_raw_buffer_load_b128(xr, xo + 64u, ks, 0);
-        const unsigned cks = (unsigned)x0 * (unsigned)N * 4u, rks = (unsigned)y * (unsigned)N * 4u;
+    float4 ck[2], cv[2];                                                                             // this strip's column constants
+    auto load_cols = [&](int strip) {
+        const unsigned x0 = (unsigned)strip * 16u;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const u32x4b a = __builtin_amdgcn_raw_buffer_load_b128(rcr, cko + 64u * t, cks, 0);
-            const u32x4b r_ = __builtin_amdgcn_raw_buffer_load_b128(rcr, rko + 64u * t, rks, 0);
-            const u32x4b v_ = __builtin_amdgcn_raw_buffer_load_b128(cvr, cvo + (unsigned)(16 * t) * (unsigned)Wimg * 4u, (unsigned)x0 * 4u, 0);
-            f.c.ck[t] = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
-            f.c.rk[t] = make_float4(__uint_as_float(r_.x), __uint_as_float(r_.y), __uint_as_float(r_.z), __uint_as_float(r_.w));
-            f.c.cv[t] = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w));
-            f.c.rv[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rcr, rvo + 64u * t, rks, 0));
-        }
-        if constexpr (MM != 0) {
-#pragma unroll
-            for (int m = 0; m < AQB; ++m) f.mw[m] = __builtin_amdgcn_raw_buffer_load_b32(mr, mo[m], (unsigned)kb * 16u, 0);
+#if FK_EXP == 1
+            ck[t] = cv[t] = make_float4((float)strip, 1.f, 2.f, (float)t);
+#else
+            const u32x4b a = __builtin_amdgcn_raw_buffer_load_b128(rcr, cko + 64u * t, x0 * (unsigned)N * 4u, 0);
+            const u32x4b v_ = __builtin_amdgcn_raw_buffer_load_b128(cvr, cvo + (unsigned)(16 * t) * (unsigned)Wimg * 4u, x0 * 4u, 0);
+            ck[t] = make_float4(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w));
+            cv[t] = make_float4(__uint_as_float(v_.x), __uint_as_float(v_.y), __uint_as_float(v_.z), __uint_as_float(v_.w));
+#endif
         }
     };
-    auto consume = [&](const FkvFrag<MM>& f) {
+    auto fetch = [&](int strip, int y, FkvFrag& f) {
+        const int kb = y * strips + strip;                                                           // uniform
+        const unsigned ks = (unsigned)kb * 16u * 128u;
+#if FK_EXP == 3
+        f.x[0] = f.x[1] = u32x4b{(unsigned)kb, 0x3c003c00u, 0x38003800u, (unsigned)lane};
+#else
+        f.x[0] = __builtin_amdgcn_raw_buffer_load_b128(xr, xo, ks, 0);
+        f.x[1] = __builtin_amdgcn_raw_buffer_load_b128(xr, xo + 64u, ks, 0);
+#endif
+        const unsigned rks = (unsigned)y * (unsigned)N * 4u;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#if FK_EXP == 1
+            f.rk[t] = make_float4((float)kb, 1.f, 2.f, (float)y);
+            f.rv[t] = (float)y;
+#else
+            const u32x4b r_ = __builtin_amdgcn_raw_buffer_load_b128(rcr, rko + 64u * t, rks, 0);
+            f.rk[t] = make_float4(__uint_as_float(r_.x), __uint_as_float(r_.y), __uint_as_float(r_.z), __uint_as_float(r_.w));
+            f.rv[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rcr, rvo + 64u * t, rks, 0));
+#endif
+        }
+        if constexpr (MM != 0) {
+#if FK_EXP == 2
+            f.mw = u32x4b{(unsigned)kb & 0x01010101u, 0u, (unsigned)y, 0u};
+#else
+            f.mw = __builtin_amdgcn_raw_buffer_load_b128(mr, (unsigned)lj * 16u, (unsigned)kb * 256u, 0);
+#endif
+        }
+    };
+    auto consume = [&](const FkvFrag& f) {
         const f16x8 x0_ = __builtin_bit_cast(f16x8, f.x[0]), x1_ = __builtin_bit_cast(f16x8, f.x[1]);
         // K_h^T (dims x keys) and V_h (keys x dims), constants as the initial values
         f32x4 kt[2], vt[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            kt[t] = f32x4{f.c.ck[t].x + f.c.rk[t].x, f.c.ck[t].y + f.c.rk[t].y, f.c.ck[t].z + f.c.rk[t].z, f.c.ck[t].w + f.c.rk[t].w};
-            vt[t] = f32x4{f.c.cv[t].x + f.c.rv[t], f.c.cv[t].y + f.c.rv[t], f.c.cv[t].z + f.c.rv[t], f.c.cv[t].w + f.c.rv[t]};
+            kt[t] = f32x4{ck[t].x + f.rk[t].x, ck[t].y + f.rk[t].y, ck[t].z + f.rk[t].z, ck[t].w + f.rk[t].w};
+            vt[t] = f32x4{cv[t].x + f.rv[t], cv[t].y + f.rv[t], cv[t].z + f.rv[t], cv[t].w + f.rv[t]};
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -644,9 +670,11 @@ __global__ __launch_bounds__(256, 2) void hs_attn_fkv_kernel(const float* __rest
         auto scores = [&](int m) {
             f32x4 s_ = f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (MM != 0) {
-                const uint32_t mw = use_mask[m] ? f.mw[m] : 0u;
-                s_ = f32x4{(float)(mw & 0xffu) * MASK_BIAS, (float)((mw >> 8) & 0xffu) * MASK_BIAS, (float)((mw >> 16) & 0xffu) * MASK_BIAS,
-                           (float)(mw >> 24) * MASK_BIAS};
+                // this lane's four mask bits of query block m: bit r of the nibble -> all ones -> the bits of MASK_BIAS
+                const unsigned nib = use_mask[m] ? (f.mw[m >> 1] >> (16 * (m & 1) + 4 * lq)) : 0u;
+                constexpr unsigned BB = 0xc7c35000u;              // -1.0e5f
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_[r] = __uint_as_float((unsigned)__builtin_amdgcn_sbfe((int)nib, r, 1) & BB);
             }
             if constexpr (BF == 2) return mfma_f16k32(__builtin_bit_cast(f16x8, cat8(kh[0], kh[1])), __builtin_bit_cast(f16x8, cat8(qh[m][0], qh[m][1])), s_);
             else return mfma_bf16k32(cat8(kh[0], kh[1]), cat8(qh[m][0], qh[m][1]), s_);
@@ -658,29 +686,44 @@ __global__ __launch_bounds__(256, 2) void hs_attn_fkv_kernel(const float* __rest
             if (m + 1 < AQB) sn = scores(m + 1);
             const f32x2l k2v = f32x2l{k2, k2};
             const f32x2l e01 = __builtin_elementwise_fma(f32x2l{s_[0], s_[1]}, k2v, -k2v), e23 = __builtin_elementwise_fma(f32x2l{s_[2], s_[3]}, k2v, -k2v);
+#if FK_EXP == 4
+            const float p[4] = {e01[0], e01[1], e23[0], e23[1]};
+#else
             const float p[4] = {__builtin_amdgcn_exp2f(e01[0]), __builtin_amdgcn_exp2f(e01[1]), __builtin_amdgcn_exp2f(e23[0]), __builtin_amdgcn_exp2f(e23[1])};
+#endif
             lacc[m] += f32x2l{p[0], p[1]} + f32x2l{p[2], p[3]};
             const bf16x4 pp = pack4(p[0], p[1], p[2], p[3]);
+#if FK_EXP == 5
+            o[m][0][0] += __uint_as_float(__builtin_bit_cast(u32x2b, pp).x ^ __builtin_bit_cast(u32x2b, vb[0]).x);
+            o[m][1][0] += __uint_as_float(__builtin_bit_cast(u32x2b, pp).y ^ __builtin_bit_cast(u32x2b, vb[1]).y);
+#else
             o[m][0] = mfma_bf16(pp, vb[0], o[m][0]);
             o[m][1] = mfma_bf16(pp, vb[1], o[m][1]);
+#endif
             s_ = sn;
         }
     };
-    {
-        int kb = kb_beg + wave;
-        FkvFrag<MM> fa, fb;
-        if (kb < kb_end) fetch(kb, fa);
-        for (; kb + 4 < kb_end; kb += 8) {
-            fetch(kb + 4, fb);
+    // a wave's range crosses a strip boundary once at most (a strip is H units): the column constants are loaded per strip segment, OUTSIDE
+    // the pipelined loop (reloading them under a uniform branch inside it costs 32 more registers than the kernel has)
+    for (int u = u0; u < u1;) {
+        const int strip = u / Himg, y0 = u - strip * Himg;         // uniform
+        const int y1 = min(Himg, y0 + (u1 - u));
+        load_cols(strip);
+        FkvFrag fa, fb;
+        fetch(strip, y0, fa);
+        int y = y0;
+        for (; y + 1 < y1; y += 2) {
+            fetch(strip, y + 1, fb);
             __builtin_amdgcn_sched_barrier(0);
             consume(fa);
             __builtin_amdgcn_sched_barrier(0);
-            fetch(min(kb + 8, nkb - 1), fa);
+            fetch(strip, min(y + 2, Himg - 1), fa);                 // (one row past the segment at its end: loaded, never used)
             __builtin_amdgcn_sched_barrier(0);
             consume(fb);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (kb < kb_end) consume(fa);
+        if (y < y1) consume(fa);
+        u += y1 - y0;
     }
 
     // ---- reduce the 4 waves through LDS, then one partial per workgroup (as hs_attn_kernel) ----
@@ -724,6 +767,38 @@ __global__ __launch_bounds__(256, 2) void hs_attn_fkv_kernel(const float* __rest
     }
     float* dst = part + ((((int64_t)blockIdx.z * heads + h) * nsplit) + split) * (AQCH * PSTRIDE);
     for (int i = tid; i < AQCH * PSTRIDE; i += 256) dst[i] = (red[i] + red[AQCH * PSTRIDE + i]) + (red[2 * AQCH * PSTRIDE + i] + red[3 * AQCH * PSTRIDE + i]);
+}
+
+// The attention mask of hs_attn_fkv_kernel: bytes [B][Lq][S] (nonzero = masked) -> bit-packed and blocked [B][qchunks][S / 16][16 lj][8 m] uint16:
+// word (lj, m) of key block kb holds bit k = masked[q = 112 qc + 16 m + lj][16 kb + k] (m = 7 and queries >= Lq: zero).  A thread packs
+// the eight words of one (key block, lj): 16-byte loads from seven query rows, one 16-byte store; a wave covers four consecutive key blocks.
+__global__ __launch_bounds__(256) void attn_pack_mask_bits_kernel(const uint8_t* __restrict__ masked, u32x4b* __restrict__ out, int Lq, int S,
+                                                                  int qchunks) {
+    const int nkb = S / 16;
+    const int64_t total = (int64_t)gridDim.y * nkb * 16;                // gridDim.y = B * qchunks
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int bq = blockIdx.y;
+    if (idx >= (int64_t)nkb * 16) return;
+    (void)total;
+    const int kb = (int)(idx >> 4), lj = (int)(idx & 15);
+    const int b = bq / qchunks, qc = bq - b * qchunks;
+    unsigned wds[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int qi = qc * AQCH + m * 16 + lj;
+        unsigned bits = 0;
+        if (m < AQB && qi < Lq) {
+            const u32x4b v = *reinterpret_cast<const u32x4b*>(masked + ((int64_t)b * Lq + qi) * S + (int64_t)kb * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned w = v[j];
+                w = ((((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) >> 7) & 0x01010101u;       // 1 per nonzero byte
+                bits |= ((w * 0x01020408u) >> 24) << (4 * j);                           // byte r -> bit r
+            }
+        }
+        wds[m] = bits;
+    }
+    out[((int64_t)bq * nkb + kb) * 16 + lj] = u32x4b{wds[0] | (wds[1] << 16), wds[2] | (wds[3] << 16), wds[4] | (wds[5] << 16), wds[6] | (wds[7] << 16)};
 }
 
 // W [K 256 | V 256][64] fp32 -> the fp16 fragments of hs_attn_fkv_kernel: [head][kv][tile t][k-step s][lane][8]:
@@ -1018,8 +1093,20 @@ extern "C" int msm_attn_pack_kv_weights(const float* w, void* packed, int heads,
     return MSM_OK;
 }
 
+extern "C" int64_t msm_attn_mask_bits_bytes(int B, int Lq, int S) { return (int64_t)B * cdiv(Lq, AQCH) * (S / 16) * 256; }
+
+extern "C" int msm_attn_pack_mask_bits(const uint8_t* masked, void* bits, int B, int Lq, int S, void* stream) {
+    MSM_REQUIRE(masked && bits && B > 0 && Lq > 0 && S > 0 && S % 16 == 0, "msm_attn_pack_mask_bits: bad arguments (S %% 16 == 0)");
+    MSM_REQUIRE(((((uintptr_t)masked) | ((uintptr_t)bits)) & 15) == 0, "msm_attn_pack_mask_bits: pointers must be 16-byte aligned");
+    const int qchunks = cdiv(Lq, AQCH);
+    hipLaunchKernelGGL(attn_pack_mask_bits_kernel, dim3(cdiv((int64_t)(S / 16) * 16, 256), B * qchunks), dim3(256), 0, (hipStream_t)stream, masked,
+                       (u32x4b*)bits, Lq, S, qchunks);
+    MSM_CHECK_LAUNCH("msm_attn_pack_mask_bits");
+    return MSM_OK;
+}
+
 extern "C" int msm_hypersphere_attn_fused_kv_fwd(const float* q, const void* x_f16, const void* w_packed, const float* rowcol, const float* col_v_t,
-                                                 int score_format, const uint8_t* masked, const int32_t* row_any, float* out, int B, int Lq,
+                                                 int score_format, const void* masked, const int32_t* row_any, float* out, int B, int Lq,
                                                  int H, int W, int heads, int64_t ldq, int64_t q_sb, float kappa, float* workspace,
                                                  int64_t workspace_elems, void* stream) {
     const char* who = "msm_hypersphere_attn_fused_kv_fwd";
@@ -1032,7 +1119,7 @@ extern "C" int msm_hypersphere_attn_fused_kv_fwd(const float* q, const void* x_f
                 "%s: one image of x / the mask / the constants must stay below 4 GiB (32-bit buffer offsets)", who);
     MSM_REQUIRE(ldq % 4 == 0 && q_sb % 4 == 0 && ((((uintptr_t)q) | ((uintptr_t)x_f16) | ((uintptr_t)w_packed) | ((uintptr_t)rowcol) | ((uintptr_t)col_v_t)) & 15) == 0,
                 "%s: pointers must be 16-byte aligned", who);
-    MSM_REQUIRE(!masked || (((uintptr_t)masked) & 3) == 0, "%s: mask must be 4-byte aligned", who);
+    MSM_REQUIRE(!masked || (((uintptr_t)masked) & 15) == 0, "%s: the packed mask must be 16-byte aligned", who);
     const int S = (int)S64;
     const int qchunks = cdiv(Lq, AQCH);
     const int ns = attn_nsplit(B, qchunks, heads, S);
@@ -1048,7 +1135,7 @@ extern "C" int msm_hypersphere_attn_fused_kv_fwd(const float* q, const void* x_f
     {                                                                                                                              \
         MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)hs_attn_fkv_kernel<BF_, MM_>, lds));                             \
         hipLaunchKernelGGL((hs_attn_fkv_kernel<BF_, MM_>), grid, block, lds, st, q, (const unsigned short*)x_f16, (const u32x4b*)w_packed, rowcol, \
-                           col_v_t, masked, row_any, workspace, out, Lq, S, W, heads, qchunks, ns, ldq, q_sb, kappa);               \
+                           col_v_t, (const u32x4b*)masked, row_any, workspace, out, Lq, S, W, heads, qchunks, ns, ldq, q_sb, kappa);               \
     }
     if (score_format == 2) {
         if (masked) FKV_LAUNCH(2, 1) else FKV_LAUNCH(2, 0)

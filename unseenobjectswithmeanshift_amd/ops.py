@@ -629,6 +629,19 @@ def tokens_f16(x):
     return to_f16(t.contiguous())
 
 
+def attn_pack_mask_bits(masked):
+    """uint8 mask (B, Lq, S) (nonzero = masked), S % 16 == 0 -> the bit-packed, blocked form hypersphere_attention_fused_kv reads
+    (msm_attn_pack_mask_bits): int16 (B, ceil(Lq / 112), S / 16, 16, 8), word [b, qc, kb, lj, m] bit k = masked[b, 112 qc + 16 m + lj, 16 kb + k]."""
+    _c(masked, "masked", torch.uint8)
+    B, Lq, S = masked.shape
+    if S % 16:
+        raise RuntimeError("attn_pack_mask_bits: S must be a multiple of 16")
+    out = torch.empty((B, (Lq + 111) // 112, S // 16, 16, 8), device=masked.device, dtype=torch.int16)
+    assert out.numel() * 2 == lib().msm_attn_mask_bits_bytes(B, Lq, S)
+    check(lib().msm_attn_pack_mask_bits(_p(masked), _p(out), B, Lq, S, _stream()), "msm_attn_pack_mask_bits")
+    return out
+
+
 def hypersphere_attention_fused_kv(q, x_f16, w_packed, rowcol, col_v_t, size, heads, *, masked=None, row_any=None, kappa=KAPPA, keys_f16=False):
     """Cross attention over a long key sequence with the folded K/V projection inside the kernel (msm_hypersphere_attn_fused_kv_fwd;
     16-bit plans): q (B, Lq, E) projected queries; x_f16 = tokens_f16(level feature) (B, H*W, 64); w_packed = attn_pack_kv_weights(w);
@@ -647,7 +660,8 @@ def hypersphere_attention_fused_kv(q, x_f16, w_packed, rowcol, col_v_t, size, he
     out = torch.empty((B, Lq, E), device=q.device, dtype=torch.float32)
     need = lib().msm_hypersphere_attn_workspace(B, Lq, S, heads)
     ws = torch.empty((need,), device=q.device, dtype=torch.float32)
-    rc = lib().msm_hypersphere_attn_fused_kv_fwd(_p(q), _p(x_f16), _p(w_packed), _p(rowcol), _p(col_v_t), 2 if keys_f16 else 1, _p(masked), _p(row_any),
+    bits = attn_pack_mask_bits(masked) if masked is not None else None      # one 16-byte load per lane and key block in the kernel
+    rc = lib().msm_hypersphere_attn_fused_kv_fwd(_p(q), _p(x_f16), _p(w_packed), _p(rowcol), _p(col_v_t), 2 if keys_f16 else 1, _p(bits), _p(row_any),
                                                  _p(out), B, Lq, H, W, heads, q.stride(1), q.stride(0), kappa, _p(ws), need, _stream())
     check(rc, "msm_hypersphere_attn_fused_kv_fwd")
     return out
