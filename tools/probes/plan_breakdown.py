@@ -16,6 +16,9 @@ from microbench import timeit_graph  # noqa: E402
 head = tc.make_head()
 feats = {k: v.cuda() for k, v in syn.synth_backbone_features(8, 480, 640, seed=10).items()}
 for mode in (sys.argv[1:] or ["bf16", "f16"]):
+    if ":" in mode:                                   # "f16:4096" = fused K/V attention from 4096 keys on
+        mode, mk = mode.split(":")
+        head.predictor.fused_kv_min_keys = int(mk)
     head.set_precision(mode)
     for _ in range(3):
         head(feats)

@@ -296,6 +296,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         # path, the 120 x 160 level of configs[4]) inside the attention kernel (csrc/attention.hip, hs_attn_fkv_kernel): K / V are never
         # written.  False: msm_kv_project_multi_bf16 + msm_hypersphere_attn_lp_fwd (the tested alternative)
         self.fused_kv_attention = True
+        self.fused_kv_min_keys = 4096       # levels with at least this many keys take the fused kernel (the 60 x 80 level of the headline shapes: 1337 -> 1264 us per pass)
         # True: the batched K/V projection computes its fp32 products as exact three-term bf16 splits (set_precision("f32_split"))
         self.kv_split = False
         self._packed_mf = None
@@ -347,13 +348,13 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         # separable constants (below) everywhere but on the small maps of the bf16 mode: its K/V kernel is issue-bound and the second
         # table costs it 16 more loads per 16-token unit (measured at B = 8, 640x480 levels: 59 us dense, 69 separable; fp32 MFMA
         # kernel: 135 dense, 128 separable); from 128x128 keys on the dense matrix is the larger cost in every mode
-        sep_min = 16384 if self.attention_dtype == "bf16" else 0
+        sep_min = (min(16384, int(self.fused_kv_min_keys)) if self.fused_kv_attention else 16384) if self.attention_dtype == "bf16" else 0
         skey = (tuple(sizes), str(device), sep_min)
         # one entry per input geometry (the two-stage harness alternates between the frame and the 224x224 crops); a
         # parameter change drops them all
         if self._kv_cache is None or self._kv_cache.get("params") != pkey:
             self._kv_cache = {"params": pkey}
-        if len(self._kv_cache) > 17:                                          # bounded: params + 8 geometries (+ their fused-K/V packs)
+        if len(self._kv_cache) > 48:                                          # bounded: params + geometries (+ their fused-K/V packs, dense copies)
             self._kv_cache = {"params": pkey}
         if skey not in self._kv_cache:
             ws, cs = [], []
@@ -386,8 +387,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                     kc = (pos + off) @ wk.t() + bk                               # (hw, E)
                     vc = (off @ wv.t() + bv).expand(h * w, -1)                   # (hw, E)
                     cs.append((torch.cat([kc, vc], 1).float().contiguous(), 0))
-            if len({cw > 0 for _, cw in cs}) > 1:                                # one launch takes all jobs separable or none
-                cs = [(ops.dense_kv_constant(c, cw), 0) for c, cw in cs]
+            # (a batched launch takes all its jobs separable or none: forward() densifies a mixed job list, see _uniform_constants)
             self._kv_cache[skey] = (ws, cs)
         return self._kv_cache[skey]
 
@@ -473,6 +473,22 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                 return ops.kv_project_multi([x], [w], [c], split=True, cmat_widths=[cw])[0]
         return ops.kv_project(x, w, c, cw)
 
+    def _uniform_constants(self, kv_c, jobs):
+        """The constants of the layers ``jobs`` for ONE batched projection launch, which takes all its jobs separable or none: a mixed
+        list (long levels separable, short ones dense) has its separable members expanded to the dense matrix (cached per layer)."""
+        cs = [kv_c[i] for i in jobs]
+        if len({cw > 0 for _, cw in cs}) <= 1:
+            return cs
+        out = []
+        for i, (c, cw) in zip(jobs, cs):
+            if cw > 0:
+                key = ("dense", i, c.data_ptr(), tuple(c.shape))
+                if key not in self._kv_cache:
+                    self._kv_cache[key] = ops.dense_kv_constant(c, cw)
+                c, cw = self._kv_cache[key], 0
+            out.append((c, cw))
+        return out
+
     def _fused_kv_plan(self, xs, sizes, kv_w, kv_c):
         """Which cross-attention layers take the fused K/V + attention kernel (see ``fused_kv_attention``), with their packed weights /
         transposed V constants (cached with the folded constants) and the fp16 token form of each such level (made once per forward).
@@ -487,7 +503,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             l = i % self.num_feature_levels
             h, w = sizes[l]
             c, cw = kv_c[i]
-            if not (cw == w and w % 16 == 0 and h * w >= 16384 and xs[l].shape[1] == 64 and tuple(kv_w[i].shape) == (2 * E, 64) and E == H * 32
+            if not (cw == w and w % 16 == 0 and h * w >= int(self.fused_kv_min_keys) and xs[l].shape[1] == 64 and tuple(kv_w[i].shape) == (2 * E, 64) and E == H * 32
                     and h * w * 128 < (1 << 32)):
                 layers.append(None)
                 continue
@@ -649,11 +665,12 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                 todo = [i for i in range(self.num_layers) if fkv is None or fkv["layers"][i] is None]      # (fused layers project inside their attention)
                 for j0 in range(0, len(todo), 16):
                     jobs = todo[j0:j0 + 16]
+                    jc = self._uniform_constants(kv_c, jobs)
                     for i, kv in zip(jobs, ops.kv_project_multi([xs[i % self.num_feature_levels] for i in jobs], [kv_w[i] for i in jobs],
-                                                   [kv_c[i][0] for i in jobs],
+                                                   [c for c, _ in jc],
                                                    out_dtype=torch.bfloat16 if self.attention_dtype == "bf16" else torch.float32,
                                                    split=self.kv_split and self.attention_dtype != "bf16",
-                                                   cmat_widths=[kv_c[i][1] for i in jobs],
+                                                   cmat_widths=[cw for _, cw in jc],
                                                    keys_f16=self.attention_dtype == "bf16" and self.attention_keys == "f16")):
                         kv_all[i] = kv
         else:
