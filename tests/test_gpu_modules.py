@@ -698,6 +698,14 @@ def test_resnet50_backbone_on_gpu_and_end_to_end():
         assert got[k].is_contiguous() and got[k].dtype == torch.float32
         scale = float(ref[k].abs().max())
         assert float((got[k].cpu().double() - ref[k]).abs().max()) < 2e-4 * scale, k
+    # round 5: the 1x1 convolutions run as hipBLASLt GEMMs on the NHWC view (gemm_1x1, default); MIOpen's convolution for them gives
+    # the same maps up to fp32 summation order
+    assert model.backbone.gemm_1x1
+    model.backbone.gemm_1x1 = False
+    alt = model.backbone(images.to(DEV))
+    model.backbone.gemm_1x1 = True
+    for k in ("res2", "res3", "res4", "res5"):
+        assert float((alt[k] - got[k]).abs().max()) < 1e-4 * float(ref[k].abs().max()), k
     res = model([{"image": images.to(DEV)}])
     assert len(res) == 2 and res[0]["instances"].pred_masks.shape == (20, 64, 96)
     out, _ = model.sem_seg_head(got)

@@ -112,6 +112,10 @@ class ResNet50Backbone(PlanAttributes, nn.Module):
         # bf16 convolutions accumulate in fp32), the four output maps converted back to fp32 -- the low-precision mode of
         # BASELINE configs[2] / [4] (the reference's counterpart is autocast over the whole model)
         self.backbone_dtype = "f32"
+        # the 1x1 convolutions (two thirds of the network's FLOPs) as plain GEMMs on the NHWC view of their channels_last input --
+        # hipBLASLt through torch.addmm, bias (+ ReLU) in its epilogue -- instead of MIOpen's convolution: batch 8 at 480x640 on one
+        # MI355X 7.9 -> 5.8 ms in fp32, 5.9 -> 2.95 ms in bf16 (tools/probes/resnet_gemm_time.py); same arithmetic, another summation order
+        self.gemm_1x1 = True
 
     def output_shape(self):
         from .modeling import ShapeSpec
@@ -153,12 +157,28 @@ class ResNet50Backbone(PlanAttributes, nn.Module):
         (ws, bs), stages = self._plan()
         x = images.to(ws.dtype).contiguous(memory_format=torch.channels_last)
         x = F.max_pool2d(F.relu(F.conv2d(x, ws, bs, stride=2, padding=3)), 3, stride=2, padding=1)
+        gemm = self.gemm_1x1 and x.is_cuda
+
+        def conv1x1(t, wb, relu, stride=1):
+            w, b = wb
+            if not gemm:
+                y = F.conv2d(t, w, b, stride=stride)
+                return F.relu(y) if relu else y
+            if stride != 1:
+                t = t[:, :, ::stride, ::stride].contiguous(memory_format=torch.channels_last)
+            B, C, H, W = t.shape
+            a = t.permute(0, 2, 3, 1).reshape(B * H * W, C)                 # the NHWC view of a channels_last map: no copy
+            w2d = w.flatten(1)                                              # (Cout, Cin, 1, 1) -> (Cout, Cin)
+            y = torch._addmm_activation(b, a, w2d.t(), use_gelu=False) if relu else torch.addmm(b, a, w2d.t())
+            return y.view(B, H, W, -1).permute(0, 3, 1, 2)                  # (B, Cout, H, W) in channels_last memory
+
         for name, blocks in zip(("res2", "res3", "res4", "res5"), stages):
-            for (w1, b1), (w2, b2), (w3, b3), sc, stride in blocks:
-                y = F.relu(F.conv2d(x, w1, b1))
+            for c1, (w2, b2), c3, sc, stride in blocks:
+                st = stride[0] if isinstance(stride, tuple) else stride
+                y = conv1x1(x, c1, True)
                 y = F.relu(F.conv2d(y, w2, b2, stride=stride, padding=1))
-                y = F.conv2d(y, w3, b3)
-                x = F.relu(y + (x if sc is None else F.conv2d(x, sc[0], sc[1], stride=stride)))
+                y = conv1x1(y, c3, False)
+                x = F.relu(y + (x if sc is None else conv1x1(x, sc, False, st)))
             if name in self.out_features:
                 out[name] = (x.float() if x.dtype == torch.bfloat16 else x).contiguous()      # NCHW planes for the pixel decoder's input projections (fp32 also in the bf16 mode)
         return out
