@@ -550,7 +550,7 @@ def extra_configs(dev, args):
     t_bb = timed(lambda: full.backbone(images), 10)
     t_full = timed(lambda: full([{"image": images}]), 10)
     bbres = {"eager_fp32": {"value": round(BATCH / t_full, 1), "ms_per_step": round(1e3 * t_full, 3), "backbone_ms": round(1e3 * t_bb, 3)}}
-    for mode in ("f32", "bf16"):
+    for mode in ("f32", "bf16", "f16"):
         # the whole model -- backbone included -- replayed from ONE HIP graph; bf16: MIOpen bf16 convolutions (fp32 accumulation) +
         # the hot path's low-precision mode
         full.set_precision(mode)

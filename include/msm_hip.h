@@ -257,6 +257,7 @@ int msm_hypersphere_attn_lp_fwd(const float* q, const void* k, const void* v, in
  *            bytes = [B][ceil(Lq / 112)][S / 16][16 lj][8 m] uint16, bit k of word (lj, m) = masked[112 qc + 16 m + lj][16 kb + k] -- one
  *            16-byte load per lane and key block instead of seven 4-byte loads that use 16 bytes of each of 16 cache lines
  * W % 16 == 0.  q / row_any / out / workspace (msm_hypersphere_attn_workspace(B, Lq, H*W, heads)) as msm_hypersphere_attn_fwd. */
+int msm_nchw_to_tokens_f16(const float* in, void* out, int B, int C, int HW, void* stream);   /* in [B][64][HW] fp32 -> out [B][HW][64] IEEE half (clamped): x_f16 of an NCHW level in one pass */
 int msm_attn_pack_kv_weights(const float* w, void* packed, int heads, void* stream);
 int64_t msm_attn_mask_bits_bytes(int B, int Lq, int S);
 int msm_attn_pack_mask_bits(const uint8_t* masked, void* bits, int B, int Lq, int S, void* stream);
@@ -631,11 +632,13 @@ int msm_conv1x1_in_multi_lp(int n_levels, const float* const* x, const void* con
  *   the same launch (the row_any flags of the first msm_attn_mask_pooled call: no fill launch).
  * msm_attn_mask_pooled: attn [B][Q][T] bytes = (sum_c embed[b][q][c] pooled[b][t][c] + qbias[b][q]) < 0 for the 64-column embedding
  *   (row stride embed_ld floats, batch stride Q * embed_ld; qbias NULL or element stride qbias_ld) and row_any [B][Q] = 1 where a
- *   row keeps an unmasked key (zeroed here unless row_any_cleared != 0).  Q <= 112. */
+ *   row keeps an unmasked key (zeroed here unless row_any_cleared != 0).  Q <= 112.
+ *   bits != 0 (T % 16 == 0): attn receives the mask bit-packed and blocked instead -- msm_attn_mask_bits_bytes(B, Q, T) bytes in the layout
+ *   of msm_attn_pack_mask_bits, what msm_hypersphere_attn_fused_kv_fwd reads (word 7 of a query's eight is never written nor read). */
 int msm_pool_mask_taps(const float* act, int B, int H, int W, int n_levels, const int32_t* th, const int32_t* tw,
                        float* const* out, int32_t* zero_buf, int64_t zero_count, void* stream);
 int msm_attn_mask_pooled(const float* embed, int64_t embed_ld, const float* qbias, int64_t qbias_ld, const float* pooled,
-                         uint8_t* attn, int32_t* row_any, int row_any_cleared, int B, int Q, int T, void* stream);
+                         uint8_t* attn, int32_t* row_any, int row_any_cleared, int bits, int B, int Q, int T, void* stream);
 
 /* The FPN output convolution (msdeformattn.py:264-279, 349-351: Conv2d(64, 64, 3, padding=1) in front of a GroupNorm):
  *   in / out [B][H*W][64] token maps, w_tap_major [64][9*64] with k = (dy*3 + dx)*64 + c_in (zero padding), no bias (a

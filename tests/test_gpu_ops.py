@@ -208,6 +208,20 @@ def test_attention_masks_at_key_resolution(B, Q, H, W):
                 assert ref_logit[diff].abs().max() < 1e-4
             assert diff.float().mean() <= 1e-4
             assert torch.equal(row_any.cpu().bool(), ~got.all(-1))
+        if (th * tw) % 16 == 0:
+            # the bit-packed, blocked form for the fused K/V attention (bits=True) = attn_pack_mask_bits of the byte mask, row flags alike
+            # (word 7 of a query's eight is never written: compared on the seven query blocks of a chunk)
+            ab, rab = ops().attn_mask_pooled(wd[..., :64], ap, qbias=wd[..., 64], bits=True)
+            assert ab.dtype == torch.int16 and ab.shape == (B, (Q + 111) // 112, th * tw // 16, 16, 8)
+            want_b = ops().attn_pack_mask_bits(attn)
+            nblk = [min(7, (Q - 112 * qc + 15) // 16) for qc in range(ab.shape[1])]
+            for qc, nb in enumerate(nblk):
+                got_b, exp_b = ab[:, qc, :, :, :nb].cpu(), want_b[:, qc, :, :, :nb].cpu()
+                if Q % 16 and qc == len(nblk) - 1:          # rows past Q in the last block: lanes without a query write nothing
+                    live = (torch.arange(16)[:, None] + 16 * torch.arange(nb)[None] + 112 * qc) < Q
+                    got_b, exp_b = got_b[..., live], exp_b[..., live]
+                assert torch.equal(got_b, exp_b)
+            assert torch.equal(rab, row_any)
         _, attn_full, ra_full = ops().mask_logits(wd[..., :64], fd, want_mask=False, target_size=(th, tw), qbias=wd[..., 64])
         d2 = attn_full.cpu() != attn.cpu()
         if d2.any():

@@ -40,7 +40,7 @@ _SIGNATURES = {
     "msm_msda_locations": (c_i, [c_f, c_f, c_f, c_p, c_f, c_f, c_l, c_i, c_i, c_i, c_p]),
     "msm_mask_logits_fwd": (c_i, [c_f, c_f, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_f, c_l, c_p]),
     "msm_pool_mask_taps": (c_i, [c_f, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_l, c_p]),
-    "msm_attn_mask_pooled": (c_i, [c_f, c_l, c_f, c_l, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "msm_attn_mask_pooled": (c_i, [c_f, c_l, c_f, c_l, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "msm_pack_mask_features_bf16": (c_i, [c_f, c_p, c_i, c_i, c_i, c_p]),
     "msm_pack_mask_features_f16": (c_i, [c_f, c_p, c_i, c_i, c_i, c_p]),
     "msm_mask_logits_bf16_fwd": (c_i, [c_f, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_f, c_l, c_p]),
@@ -89,6 +89,7 @@ _SIGNATURES = {
     "msm_dec_post_self_bf16": (c_i, [c_f, c_f, c_p, c_f, c_f, c_f, c_p, c_f, c_p] + [c_i, c_f, c_f, c_i, c_i, c_i, c_fl, c_p]),
     "msm_dec_heads_bf16": (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_f, c_p, c_f, c_p, c_f, c_p, c_f, c_p, c_f, c_f] + [c_f] * 4 +
                            [c_p, c_i, c_i, c_i, c_fl, c_p]),
+    "msm_nchw_to_tokens_f16": (c_i, [c_f, c_p, c_i, c_i, c_i, c_p]),
     "msm_attn_pack_kv_weights": (c_i, [c_f, c_p, c_i, c_p]),
     "msm_attn_mask_bits_bytes": (c_l, [c_i, c_i, c_i]),
     "msm_attn_pack_mask_bits": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),

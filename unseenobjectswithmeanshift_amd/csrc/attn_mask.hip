@@ -70,7 +70,10 @@ __global__ __launch_bounds__(256) void pool_taps_kernel(const float* __restrict_
 // consecutive keys of one query -- one 4-byte store.  K order: step s of the 16 carries channel lq*16 + s on both operands (a
 // lane reads 16 consecutive floats of its row).
 constexpr int AM_NQ = 2;             // query blocks per wave
-template <bool VEC>
+// BITS (round 5): the mask leaves bit-packed and blocked for msm_hypersphere_attn_fused_kv_fwd -- per 16-key block 256 bytes = [query lj][8 query
+// blocks of the 112-query chunk] 16-bit words, bit k = key 16 kb + k (msm_attn_pack_mask_bits' layout, T % 16 == 0) -- instead of bytes: the
+// four lane quarters of a query OR their nibbles together and one of them stores the word.
+template <bool VEC, bool BITS = false>
 __global__ __launch_bounds__(256) void attn_mask_pooled_kernel(const float* __restrict__ embed, int64_t embed_ld, const float* __restrict__ qbias,
                                                                int64_t qbias_ld, const float* __restrict__ pooled, uint8_t* __restrict__ attn,
                                                                int32_t* __restrict__ row_any, int Q, int T) {
@@ -123,7 +126,16 @@ __global__ __launch_bounds__(256) void attn_mask_pooled_kernel(const float* __re
             const int q = (qb0 + m) * 16 + lj;
             // sigmoid(x) < 0.5  <=>  x < 0 (DEC:677)
             const unsigned m0 = acc[0] < 0.f, m1 = acc[1] < 0.f, m2 = acc[2] < 0.f, m3 = acc[3] < 0.f;
-            if (q < Q) {
+            if constexpr (BITS) {
+                unsigned nib = (m0 | (m1 << 1) | (m2 << 2) | (m3 << 3)) << (4 * lq);
+                nib |= __shfl_xor(nib, 16, 64);
+                nib |= __shfl_xor(nib, 32, 64);
+                if ((m0 & m1 & m2 & m3) == 0) anyu |= 1u << m;
+                const int gq = qb0 + m, qc = gq / 7, mb = gq - qc * 7;            // 112-query chunk and block within it (attention.hip: AQB = 7)
+                const int qchunks = (Q + 111) / 112;
+                if (lq == 0 && q < Q)
+                    reinterpret_cast<unsigned short*>(attn)[((((int64_t)b * qchunks + qc) * nkb + kb) * 16 + lj) * 8 + mb] = (unsigned short)nib;
+            } else if (q < Q) {
                 if (VEC && key0 + 3 < T) {
 #if AM_EXP == 1
                     if (m0 + m1 + m2 + m3 == 77)
@@ -185,8 +197,9 @@ extern "C" int msm_pool_mask_taps(const float* act, int B, int H, int W, int n_l
 }
 
 extern "C" int msm_attn_mask_pooled(const float* embed, int64_t embed_ld, const float* qbias, int64_t qbias_ld, const float* pooled,
-                                    uint8_t* attn, int32_t* row_any, int row_any_cleared, int B, int Q, int T, void* stream) {
+                                    uint8_t* attn, int32_t* row_any, int row_any_cleared, int bits, int B, int Q, int T, void* stream) {
     MSM_REQUIRE(embed && pooled && attn && row_any, "msm_attn_mask_pooled: null pointer");
+    MSM_REQUIRE(!bits || (T % 16 == 0 && (((uintptr_t)attn) & 15) == 0), "msm_attn_mask_pooled: the bit-packed mask needs T %% 16 == 0 and a 16-byte aligned buffer");
     MSM_REQUIRE(B > 0 && Q > 0 && Q <= 65535 * 16 * AM_NQ && T > 0, "msm_attn_mask_pooled: bad sizes");
     MSM_REQUIRE(embed_ld >= AM_C && embed_ld % 4 == 0 && (((uintptr_t)embed) & 15) == 0 && (((uintptr_t)pooled) & 15) == 0,
                 "msm_attn_mask_pooled: embed / pooled must be 16-byte aligned rows of 64 floats");
@@ -198,7 +211,10 @@ extern "C" int msm_attn_mask_pooled(const float* embed, int64_t embed_ld, const 
     // about one wave per SIMD of the chip over (images, pairs): 1024 / (B * zq) waves walk an image's key blocks for a pair
     const int wgs = max(1, min(cdiv(nkb, 4), max(1, 256 / (B * zq))));     // (128 / 512 / 1024 measured slower at 4800 keys: 20.4 / 12.9 / 14.8 against 12.6 us)
     const bool vec = T % 4 == 0 && (((uintptr_t)attn) & 3) == 0;
-    if (vec)
+    if (bits)
+        hipLaunchKernelGGL((attn_mask_pooled_kernel<true, true>), dim3(wgs, B, zq), dim3(256), 0, st, embed, embed_ld, qbias, qbias_ld, pooled, attn, row_any,
+                           Q, T);
+    else if (vec)
         hipLaunchKernelGGL(attn_mask_pooled_kernel<true>, dim3(wgs, B, zq), dim3(256), 0, st, embed, embed_ld, qbias, qbias_ld, pooled, attn, row_any, Q,
                            T);
     else

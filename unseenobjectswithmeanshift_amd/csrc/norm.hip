@@ -290,6 +290,35 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
+// ---- a 64-channel NCHW fp32 map as fp16 tokens [B][HW][64] in one pass (the feature form msm_hypersphere_attn_fused_kv_fwd streams) ----
+// A block = 64 pixels: channel rows read as 256 contiguous bytes, transposed through LDS, a pixel's 64 halves written as 128 contiguous bytes.
+__global__ __launch_bounds__(256) void nchw_to_tokens_f16_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int HW) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.y, p0 = blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    const float* ib = in + (int64_t)b * 64 * HW;
+    {
+        const int p = tid & 63, cg = tid >> 6;
+        const int pp = min(p0 + p, HW - 1);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tile[cg * 16 + i][p] = ib[(int64_t)(cg * 16 + i) * HW + pp];
+    }
+    __syncthreads();
+    const int pix = tid >> 2, qd = tid & 3;
+    if (p0 + pix < HW) {
+        unsigned w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float a = __builtin_amdgcn_fmed3f(tile[qd * 16 + 2 * j][pix], -65504.f, 65504.f);
+            const float c = __builtin_amdgcn_fmed3f(tile[qd * 16 + 2 * j + 1][pix], -65504.f, 65504.f);
+            w[j] = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)a) | ((unsigned)__builtin_bit_cast(unsigned short, (_Float16)c) << 16);
+        }
+        uint4* dst = reinterpret_cast<uint4*>(out + ((int64_t)b * HW + p0 + pix) * 64 + qd * 16);
+        dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+}
+
 // ---- x / max(||x||_2 over channels, eps) for an NCHW map (F.normalize(x, p=2, dim=1)) -------------------------------------------
 // The UCN meta-arch normalises the backbone's 64-channel full-resolution embedding before the head
 // (pretrained_meanshiftformer_model.py:298-300): one pass -- a lane owns one pixel (a wave reads 256 contiguous bytes of each
@@ -461,6 +490,15 @@ extern "C" int msm_transpose_f32(const float* in, float* out, int B, int R, int 
     dim3 grid(cdiv(C, 32), cdiv(R, 32), B), block(256);
     hipLaunchKernelGGL(transpose_kernel, grid, block, 0, st, in, out, R, C);
     MSM_CHECK_LAUNCH("msm_transpose_f32");
+    return MSM_OK;
+}
+
+extern "C" int msm_nchw_to_tokens_f16(const float* in, void* out, int B, int C, int HW, void* stream) {
+    MSM_REQUIRE(in && out && B > 0 && HW > 0, "msm_nchw_to_tokens_f16: bad arguments");
+    MSM_REQUIRE(C == 64, "msm_nchw_to_tokens_f16: C=%d, only 64 channels", C);
+    MSM_REQUIRE((((uintptr_t)out) & 15) == 0, "msm_nchw_to_tokens_f16: out must be 16-byte aligned");
+    hipLaunchKernelGGL(nchw_to_tokens_f16_kernel, dim3(cdiv(HW, 64), B), dim3(256), 0, (hipStream_t)stream, in, (unsigned short*)out, HW);
+    MSM_CHECK_LAUNCH("msm_nchw_to_tokens_f16");
     return MSM_OK;
 }
 

@@ -563,7 +563,9 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                 topk_out.append(topk)
                 return None, None
             if tgt is not None and tuple(tgt) in pooled:
-                attn, row_any = ops.attn_mask_pooled(emb, pooled[tuple(tgt)], qbias=qb, row_any=ra)
+                # (a layer whose cross-attention projects K / V itself reads its mask bit-packed: written that way here)
+                as_bits = fkv is not None and i_next < L and fkv["layers"][i_next] is not None
+                attn, row_any = ops.attn_mask_pooled(emb, pooled[tuple(tgt)], qbias=qb, row_any=ra, bits=as_bits)
                 m = None
                 if want:        # "always" with aux outputs: the full-resolution kernel only writes the mask
                     m = ops.mask_logits(emb, mask_features, want_mask=True, target_size=None, packed_bf16=self._packed_mf, qbias=qb,

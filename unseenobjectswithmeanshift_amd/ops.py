@@ -482,12 +482,14 @@ def pool_mask_taps(act, sizes, zero_rows=0):
     return (outs, flags) if zero_rows else outs
 
 
-def attn_mask_pooled(mask_embed, pooled, *, qbias=None, row_any=None):
+def attn_mask_pooled(mask_embed, pooled, *, qbias=None, row_any=None, bits=False):
     """The next layer's attention mask from the pooled activation (pool_mask_taps): attn (B, Q, T) uint8 =
     (einsum('bqc,btc->bqt', mask_embed, pooled) + qbias[b, q]) < 0 and row_any (B, Q) int32 (1 where a row keeps an unmasked
     key).  mask_embed: (B, Q, 64), contiguous or the leading 64 columns of a wider row-major buffer; qbias (B, Q), any uniform
     element stride; row_any: an already ZEROED buffer (saves the fill launch).  Equal to the attention-mask output of
-    mask_logits(..., target_size) on the unpooled activation up to fp32 summation order."""
+    mask_logits(..., target_size) on the unpooled activation up to fp32 summation order.
+    ``bits`` (T % 16 == 0): attn comes back bit-packed and blocked instead -- int16 (B, ceil(Q / 112), T / 16, 16, 8), the layout of
+    attn_pack_mask_bits, what hypersphere_attention_fused_kv reads."""
     _chk(mask_embed, "mask_embed"), _c(pooled, "pooled"), _chk(qbias, "qbias")
     B, Q, C = mask_embed.shape
     T = pooled.shape[1]
@@ -500,14 +502,19 @@ def attn_mask_pooled(mask_embed, pooled, *, qbias=None, row_any=None):
         if tuple(qbias.shape) != (B, Q) or (B > 1 and qbias.stride(0) != Q * qbias.stride(1)):
             raise RuntimeError("qbias must be (B,Q) with uniformly spaced elements")
         qb_ld = qbias.stride(1)
-    attn = torch.empty((B, Q, T), device=mask_embed.device, dtype=torch.uint8)
+    if bits:
+        if T % 16:
+            raise RuntimeError("attn_mask_pooled(bits=True) needs T % 16 == 0")
+        attn = torch.empty((B, (Q + 111) // 112, T // 16, 16, 8), device=mask_embed.device, dtype=torch.int16)
+    else:
+        attn = torch.empty((B, Q, T), device=mask_embed.device, dtype=torch.uint8)
     cleared = row_any is not None
     if row_any is None:
         row_any = torch.empty((B, Q), device=mask_embed.device, dtype=torch.int32)
     else:
         _c(row_any, "row_any", torch.int32)
     rc = lib().msm_attn_mask_pooled(_p(mask_embed), mask_embed.stride(1), _p(qbias), qb_ld, _p(pooled), _p(attn), _p(row_any),
-                                    1 if cleared else 0, B, Q, T, _stream())
+                                    1 if cleared else 0, 1 if bits else 0, B, Q, T, _stream())
     check(rc, "msm_attn_mask_pooled")
     return attn, row_any
 
@@ -622,11 +629,14 @@ def tokens_f16(x):
     hypersphere_attention_fused_kv streams (one pass per forward: every layer of the decoder reads the same feature)."""
     _chk(x, "x")
     B, C, H, W = x.shape
-    if is_token_major(x):
-        t = x.permute(0, 2, 3, 1).reshape(B, H * W, C)
-    else:
-        t = transpose_last2(x.contiguous().view(B, C, H * W))
-    return to_f16(t.contiguous())
+    if is_token_major(x) and not x.is_contiguous():
+        return to_f16(x.permute(0, 2, 3, 1).reshape(B, H * W, C).contiguous())
+    x = x.contiguous()
+    if C != 64:
+        return to_f16(transpose_last2(x.view(B, C, H * W)))
+    out = torch.empty((B, H * W, C), device=x.device, dtype=torch.float16)
+    check(lib().msm_nchw_to_tokens_f16(_p(x), _p(out), B, C, H * W, _stream()), "msm_nchw_to_tokens_f16")
+    return out
 
 
 def attn_pack_mask_bits(masked):
@@ -646,21 +656,24 @@ def hypersphere_attention_fused_kv(q, x_f16, w_packed, rowcol, col_v_t, size, he
     """Cross attention over a long key sequence with the folded K/V projection inside the kernel (msm_hypersphere_attn_fused_kv_fwd;
     16-bit plans): q (B, Lq, E) projected queries; x_f16 = tokens_f16(level feature) (B, H*W, 64); w_packed = attn_pack_kv_weights(w);
     rowcol (H + W, 2E) the separable constants of kv_project(cmat_width=W); col_v_t (E, W) = rowcol[H:, E:].t(); size = (H, W), W % 16 == 0.
+    masked: uint8 (B, Lq, S), packed here, or the int16 bit-packed form (attn_pack_mask_bits / attn_mask_pooled(bits=True)).
     keys_f16: q^ / k^ as IEEE halves (precision "f16") instead of bf16.  Returns (B, Lq, E)."""
     _chk(q, "q"), _c(x_f16, "x_f16", torch.float16), _c(w_packed, "w_packed", torch.float16), _c(rowcol, "rowcol"), _c(col_v_t, "col_v_t")
-    _c(masked, "masked", torch.uint8), _c(row_any, "row_any", torch.int32)
+    prepacked = masked is not None and masked.dtype == torch.int16            # attn_mask_pooled(bits=True) / attn_pack_mask_bits output
+    _c(masked, "masked", torch.int16 if prepacked else torch.uint8), _c(row_any, "row_any", torch.int32)
     if q.stride(-1) != 1:
         raise RuntimeError("q: last dim must be contiguous")
     B, Lq, E = q.shape
     H, W = int(size[0]), int(size[1])
     S = H * W
+    mshape = (B, (Lq + 111) // 112, S // 16, 16, 8) if prepacked else (B, Lq, S)
     if E != heads * 32 or tuple(x_f16.shape) != (B, S, 64) or tuple(rowcol.shape) != (H + W, 2 * E) or tuple(col_v_t.shape) != (E, W) \
-            or tuple(w_packed.shape) != (heads, 8, 64, 8) or (masked is not None and tuple(masked.shape) != (B, Lq, S)):
+            or tuple(w_packed.shape) != (heads, 8, 64, 8) or (masked is not None and tuple(masked.shape) != mshape):
         raise RuntimeError("hypersphere_attention_fused_kv: inconsistent shapes")
     out = torch.empty((B, Lq, E), device=q.device, dtype=torch.float32)
     need = lib().msm_hypersphere_attn_workspace(B, Lq, S, heads)
     ws = torch.empty((need,), device=q.device, dtype=torch.float32)
-    bits = attn_pack_mask_bits(masked) if masked is not None else None      # one 16-byte load per lane and key block in the kernel
+    bits = None if masked is None else (masked if prepacked else attn_pack_mask_bits(masked))     # one 16-byte load per lane and key block in the kernel
     rc = lib().msm_hypersphere_attn_fused_kv_fwd(_p(q), _p(x_f16), _p(w_packed), _p(rowcol), _p(col_v_t), 2 if keys_f16 else 1, _p(bits), _p(row_any),
                                                  _p(out), B, Lq, H, W, heads, q.stride(1), q.stride(0), kappa, _p(ws), need, _stream())
     check(rc, "msm_hypersphere_attn_fused_kv_fwd")
