@@ -550,6 +550,21 @@ def extra_configs(dev, args):
     t_bb = timed(lambda: full.backbone(images), 10)
     t_full = timed(lambda: full([{"image": images}]), 10)
     bbres = {"eager_fp32": {"value": round(BATCH / t_full, 1), "ms_per_step": round(1e3 * t_full, 3), "backbone_ms": round(1e3 * t_bb, 3)}}
+    def two_in_flight(m, inputs, reps):
+        """The whole model (backbone in every slot's graph) with two batches in flight, as the headline runs four of the head alone."""
+        up = m.pipelined(depth=2, entry="inference_images")
+        for _ in range(2):
+            up.submit(inputs, (H, W))
+        up.drain()
+        run = lambda: up.submit(None, (H, W), slot_inputs=True)
+        for _ in range(4):
+            run()
+        up.drain()
+        t2 = timed(run, reps)
+        up.drain()
+        del up
+        return t2
+
     for mode in ("f32", "bf16", "f16"):
         # the whole model -- backbone included -- replayed from ONE HIP graph; bf16: MIOpen bf16 convolutions (fp32 accumulation) +
         # the hot path's low-precision mode
@@ -558,10 +573,12 @@ def extra_configs(dev, args):
         for _ in range(3):
             g({"image": images}, (H, W))
         t_g = timed(lambda: g({"image": images}, (H, W)), 20)
+        t_2 = two_in_flight(full, {"image": images}, 20)
         for _ in range(2):
             full.backbone(images)
         t_b = timed(lambda: full.backbone(images), 10)
-        bbres["hipgraph_" + mode] = {"value": round(BATCH / t_g, 1), "ms_per_step": round(1e3 * t_g, 3), "backbone_ms_eager": round(1e3 * t_b, 3)}
+        bbres["hipgraph_" + mode] = {"value": round(BATCH / t_g, 1), "ms_per_step": round(1e3 * t_g, 3), "backbone_ms_eager": round(1e3 * t_b, 3),
+                                     "two_batches_in_flight": {"value": round(BATCH / t_2, 1), "ms_per_step": round(1e3 * t_2, 3)}}
         del g
     full.set_precision("f32")
     out["configs[1] with backbone"] = {"workload": "batch 8, 640x480 RGB frames -> ResNet-50 (frozen BN folded, channels_last; 3x3 / 7x7 through MIOpen, 1x1 as hipBLASLt GEMMs) -> hot "
@@ -657,6 +674,25 @@ def extra_configs(dev, args):
     cross_ms = sum(cross) / max(1, len(cross))
     # bytes a cross-attention launch has to move: K and V (2 x S x 256 fp32) and the 1-byte mask (Q x S) per image
     attn_bytes = UB * (2.0 * S_keys * 256 * 4 + Q * S_keys)
+
+    def fused_roofline(durs):
+        """hs_attn_fkv_kernel (the 16-bit plans' cross attention at 307 200 keys: K/V projection inside the attention kernel).  Useful
+        FLOPs per launch and image: the folded projection once per head (2 S 64 512), scores and P V on the Q real queries (2 x 2 Q S 256);
+        bytes: the fp16 feature (128 B per key) + the bit-packed mask (16 B per key and 128-query chunk).  Its real limit is neither: the
+        dependent chain projection -> norm -> 7 x (score -> exp -> P V) per 16-key block and Q S 8 exponentials on the vector pipe."""
+        fk = durs.get("msm_hypersphere_attn_fused_kv_fwd", [])
+        if not fk:
+            return None
+        ms = sum(fk) / len(fk)
+        fl = UB * (2.0 * S_keys * 64 * 512 + 2.0 * 2.0 * Q * S_keys * 256)
+        by = UB * (S_keys * 128.0 + S_keys * 16.0 * ((Q + 127) // 128))
+        return {"bound": "mfma", "kernel": "hs_attn_fkv_kernel (msm_hypersphere_attn_fused_kv_fwd)", "achieved": round(fl / (ms * 1e-3) / 1e12, 1),
+                "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                "flops_per_launch": fl, "bytes_per_launch": by, "hbm_frac": round(by / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                "avg_launch_ms": round(ms, 4), "launches_per_step": len(fk), "share_of_kernel_time": round(sum(fk) / max(1e-9, sum(sum(v) for v in durs.values())), 3),
+                "traffic": None,
+                "note": "latency / vector-pipe bound: 2 Q S 8 exponentials with their mask and norm arithmetic are ~0.12 ms of VALU issue per launch; "
+                        "the unfused pair (K/V written and read back) took 0.68 ms"}
     out["ucn_path"] = {
         "workload": f"UCN RGB-D path: batch {UB} of 480x640 64-channel embeddings -> 3x3 mask_features convolution -> 6-layer hypersphere decoder "
                     "over 307 200 keys per image -> post-processing; HIP-graph replay, batches in flight as stated; backbone excluded",
@@ -670,11 +706,13 @@ def extra_configs(dev, args):
                  "one_batch_in_flight": {"value": round(UB / t_lp[1], 1), "ms_per_step": round(1e3 * t_lp[1], 3)},
                  "three_batches_in_flight": {"value": round(UB / t_lp[3], 1), "ms_per_step": round(1e3 * t_lp[3], 3)},
                  "kernels_ms": {k: round(sum(v), 3) for k, v in sorted(ud_lp.items(), key=lambda kv: -sum(kv[1]))[:6]},
+                 "roofline": fused_roofline(ud_lp),
                  "parity": "tests/test_gpu_configs.py::test_ucn_path_480x640_bf16_vs_reference (final-mask mismatch 0.1 % against the fp32 reference golden)"},
         "f16": {"dtype": "fp16 / bf16 operands, fp32 accumulation, fp16 K + bf16 V", "value": round(UB / min(lp_modes["f16"][0].values()), 1), "unit": "images/sec",
                 "one_batch_in_flight": {"value": round(UB / lp_modes["f16"][0][1], 1), "ms_per_step": round(1e3 * lp_modes["f16"][0][1], 3)},
                 "three_batches_in_flight": {"value": round(UB / lp_modes["f16"][0][3], 1), "ms_per_step": round(1e3 * lp_modes["f16"][0][3], 3)},
-                "kernels_ms": {k: round(sum(v), 3) for k, v in sorted(lp_modes["f16"][1].items(), key=lambda kv: -sum(kv[1]))[:6]}},
+                "kernels_ms": {k: round(sum(v), 3) for k, v in sorted(lp_modes["f16"][1].items(), key=lambda kv: -sum(kv[1]))[:6]},
+                "roofline": fused_roofline(lp_modes["f16"][1])},
         "roofline": {"bound": "hbm", "kernel": "hs_attn_kernel + combine at 307 200 keys (msm_hypersphere_attn_fwd)",
                      "achieved": round(attn_bytes / (cross_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                      "frac": round(attn_bytes / (cross_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "bytes_per_launch": attn_bytes,
@@ -704,7 +742,9 @@ def extra_configs(dev, args):
         for _ in range(3):
             gph(uin, (H, W))
         t_g = timed(lambda: gph(uin, (H, W)), 10)
-        e2e[mode] = {"value": round(UB / t_g, 1), "unit": "images/sec", "ms_per_step": round(1e3 * t_g, 3), "backbone_ms_eager": round(1e3 * t_bb, 3)}
+        t_2 = two_in_flight(um, uin, 10)
+        e2e[mode] = {"value": round(UB / t_g, 1), "unit": "images/sec", "ms_per_step": round(1e3 * t_g, 3), "backbone_ms_eager": round(1e3 * t_bb, 3),
+                     "two_batches_in_flight": {"value": round(UB / t_2, 1), "ms_per_step": round(1e3 * t_2, 3)}}
         del gph
     um.set_precision("f32")
     out["ucn_rgbd_end_to_end"] = {
@@ -868,7 +908,7 @@ def build_summary(result):
         s["c1_literal"] = {"v": c["value"], "ms1": c["ms_per_step"], "rf": pick(c, "roofline", "frac", nd=3)}
     c = cfg.get("configs[1] with backbone")
     if c:
-        s["c1_backbone"] = {k.replace("hipgraph_", ""): {"v": v["value"], "ms": v["ms_per_step"]} for k, v in c["variants"].items() if k.startswith("hipgraph_")}
+        s["c1_backbone"] = {k.replace("hipgraph_", ""): {"v": v["value"], "ms": v["ms_per_step"], "v2": pick(v, "two_batches_in_flight", "value")} for k, v in c["variants"].items() if k.startswith("hipgraph_")}
     for key, tag in (("configs[2]", "c2"), ("configs[2] f16", "c2_f16")):
         c = cfg.get(key)
         if c:
@@ -890,10 +930,11 @@ def build_summary(result):
         s["ucn"] = {"f32": {"v": c["value"], "ms1": pick(c, "one_batch_in_flight", "ms_per_step", nd=3)},
                     "bf16": {"v": pick(c, "bf16", "value"), "ms1": pick(c, "bf16", "one_batch_in_flight", "ms_per_step", nd=3)},
                     "f16": {"v": pick(c, "f16", "value"), "ms1": pick(c, "f16", "one_batch_in_flight", "ms_per_step", nd=3)},
-                    "rf_hbm": pick(c, "roofline", "frac", nd=3)}
+                    "rf_hbm": pick(c, "roofline", "frac", nd=3), "fkv_rf_mfma": pick(c, "bf16", "roofline", "frac", nd=3),
+                    "fkv_ms": pick(c, "bf16", "roofline", "avg_launch_ms", nd=4)}
     c = cfg.get("ucn_rgbd_end_to_end")
     if c:
-        s["ucn_e2e"] = {k: {"v": v["value"], "ms": v["ms_per_step"]} for k, v in c["variants"].items()}
+        s["ucn_e2e"] = {k: {"v": v["value"], "ms": v["ms_per_step"], "v2": pick(v, "two_batches_in_flight", "value")} for k, v in c["variants"].items()}
     m = result.get("mean_shift")
     if m:
         s["ms640"] = {"v": m["value"], "split": pick(m, "f32_split", "value"), "noisy": pick(m, "background_2pct", "value"),

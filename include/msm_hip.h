@@ -59,7 +59,7 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 15   /* 15: IEEE-half operand forms of the 16-bit plan (precision "f16": msm_dec_*_f16, msm_encoder_block_hm_fwd ffn_f16, fp16 keys in the low-precision attention); 14: cmat_width argument of the K/V projections (separable position constants), msm_conv3x3_c64_nchw_bf16, msm_encoder_prologue_hm_fwd; 13: flags argument of msm_ms_select_seeds_bf16 (persistent on-chip seeding over the bf16 copy), input projections on the bf16 matrix pipe (msm_conv1x1_in_lp, msm_conv1x1_in_multi_lp); 12: head-major bf16 activations between the encoder kernels of the bf16 plan (msm_encoder_block_hm_fwd, msm_msdeform_attn_enc_lp_fwd, msm_f32_to_f16); 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
+#define MSM_ABI_VERSION 16   /* 16: msm_mask_conv3x3_folded (the UCN mask step with the 3x3 mask_features convolution folded into the query embedding); 15: IEEE-half operand forms of the 16-bit plan (precision "f16": msm_dec_*_f16, msm_encoder_block_hm_fwd ffn_f16, fp16 keys in the low-precision attention); 14: cmat_width argument of the K/V projections (separable position constants), msm_conv3x3_c64_nchw_bf16, msm_encoder_prologue_hm_fwd; 13: flags argument of msm_ms_select_seeds_bf16 (persistent on-chip seeding over the bf16 copy), input projections on the bf16 matrix pipe (msm_conv1x1_in_lp, msm_conv1x1_in_multi_lp); 12: head-major bf16 activations between the encoder kernels of the bf16 plan (msm_encoder_block_hm_fwd, msm_msdeform_attn_enc_lp_fwd, msm_f32_to_f16); 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
 int msm_abi_version(void);
 
 /* Kernel-selection overrides for tools/ and tests/ (NOT read on the product path: every option defaults to
@@ -259,6 +259,21 @@ int msm_hypersphere_attn_lp_fwd(const float* q, const void* k, const void* v, in
  * W % 16 == 0.  q / row_any / out / workspace (msm_hypersphere_attn_workspace(B, Lq, H*W, heads)) as msm_hypersphere_attn_fwd. */
 int msm_nchw_to_tokens_f16(const float* in, void* out, int B, int C, int HW, void* stream);   /* in [B][64][HW] fp32 -> out [B][HW][64] IEEE half (clamped): x_f16 of an NCHW level in one pass */
 int msm_attn_pack_kv_weights(const float* w, void* packed, int heads, void* stream);
+/* The UCN path's mask step (16-bit plans) with the 3x3 mask_features convolution folded into the query embedding.
+ * Replaces, for a decoder that only needs the contraction: mask_features = Conv2d(64, 256, 3, padding 1)(x) (pixel_decoder/fpn.py:238-246,
+ * 283-290) followed by einsum("bqc,bchw->bqhw", e, mask_features) and, for the attention mask, sigmoid(.) < 0.5 at mask resolution
+ * (DEC:1012-1035).  Both are linear in x:  mask[b,q,(y,x)] = sum_{dy,dx,c} F[b,q,3 dy + dx,c] x[b,c,y+dy-1,x+dx-1] + F[b,q,576]  with
+ * F[b,q,t,c] = sum_o e[b,q,o] W[o,c,t] and F[b,q,576] = e[b,q,:] . bias -- one small GEMM per prediction.  The (B, 256, H, W) tensor is never made.
+ *   x_f16   [B][H*W][64] IEEE half, token-major (msm_nchw_to_tokens_f16: the tensor the fused K/V attention reads)
+ *   F       fp32, row q of image b at F + b * f_sb + q * ldf: 576 filter values (k = 64 * tap + channel, tap = 3 * ky + kx as in the
+ *           Conv2d weight) + the per-query constant at column 576; ldf % 4 == 0, ldf >= 577.  Rounded to IEEE half (clamped) in the kernel.
+ *   exactly one of
+ *   mask_bits  msm_attn_mask_bits_bytes(B, Q, H*W) bytes: bit = (mask < 0), bit-packed and blocked as msm_hypersphere_attn_fused_kv_fwd reads it,
+ *              with row_any int32 [B][Q] = 1 where a row keeps an unmasked key (zeroed here unless row_any_cleared != 0)
+ *   logits     fp32 [B][Q][H*W]
+ * Q <= 112, W % 16 == 0, one image of x below 4 GiB.  fp16 operands on v_mfma_f32_16x16x32_f16, fp32 accumulation. */
+int msm_mask_conv3x3_folded(const void* x_f16, const float* F, int64_t ldf, int64_t f_sb, void* mask_bits, int32_t* row_any, int row_any_cleared,
+                            float* logits, int B, int Q, int H, int W, void* stream);
 int64_t msm_attn_mask_bits_bytes(int B, int Lq, int S);
 int msm_attn_pack_mask_bits(const uint8_t* masked, void* bits, int B, int Lq, int S, void* stream);
 int msm_hypersphere_attn_fused_kv_fwd(const float* q, const void* x_f16, const void* w_packed, const float* rowcol, const float* col_v_t,

@@ -332,6 +332,76 @@ def test_hypersphere_attention_low_precision(B, Lq, S, masked, kv_bf16):
     assert float((alt.cpu() - ref).abs().max()) < 3e-2
 
 
+@pytest.mark.parametrize("B,Q,H,W", [(2, 100, 24, 48), (1, 20, 7, 16), (1, 112, 33, 80), (3, 37, 12, 160)])
+def test_mask_conv3x3_folded(B, Q, H, W):
+    """msm_mask_conv3x3_folded (UCN path, 16-bit plans): mask = einsum(e, Conv3x3(64 -> 256, padding 1)(x)) (fpn.py:238-246, DEC:1012-1035)
+    with the convolution folded into per-query 3x3 filters F = e W.  Against the literal order in float64 -- convolution first, then
+    the contraction -- on the operands as the kernel rounds them (x and F to IEEE half); the attention-mask bits (logit < 0), bit-packed
+    and blocked as the fused K/V attention reads them, must be those of the float64 logits wherever the logit is not within the
+    accumulation error of zero, and row_any must say which rows keep an unmasked key."""
+    Cm = 256
+    x = F.normalize(rnd(B, 64, H, W, seed=1), dim=1)
+    w = rnd(Cm, 64, 3, 3, seed=2, scale=1.0 / 24)
+    bias = rnd(Cm, seed=3, scale=0.1)
+    e = rnd(B, Q, Cm, seed=4)
+    e[0, 1] = 0.0                                      # a query whose logits are all exactly zero (undecided everywhere) ...
+    d = lambda t: t.to(DEV).contiguous()
+    wf = ops().mask_conv_fold_weight(d(w), d(bias))
+    assert wf.shape == (580, Cm)
+    # the documented row order: k = 64 * (3 ky + kx) + c, row 576 = bias
+    assert torch.equal(wf[:576].cpu(), w.permute(2, 3, 1, 0).reshape(576, Cm)) and torch.equal(wf[576].cpu(), bias) and not wf[577:].any()
+    Fq = ops().gemm(d(e), wf)                          # (B, Q, 580) fp32
+    Fq[0, 2, 576] = -1e4                               # ... and one that is masked everywhere (row_any = 0)
+    Fq[0, 2, :576] = 0.0
+    xh = ops().tokens_f16(d(x))
+    # float64 reference on the rounded operands: per-query filters (Q, 64, 3, 3) from F, convolution with zero padding
+    Fr = Fq.cpu()[..., :576].to(torch.float16).double().view(B, Q, 3, 3, 64).permute(0, 1, 4, 2, 3)
+    ref = torch.stack([F.conv2d(xh[b].cpu().double().t().reshape(1, 64, H, W), Fr[b], padding=1)[0] for b in range(B)])
+    ref = ref + Fq.cpu()[..., 576].double()[..., None, None]
+    # ... which is the literal order up to the fp16 rounding of F: convolution to 256 channels first, then the contraction
+    lit = torch.einsum("bqo,bohw->bqhw", e.double(), F.conv2d(x.double(), w.double(), bias.double(), padding=1))
+    sel = torch.ones(B, Q, dtype=torch.bool)
+    sel[0, 2] = False
+    sel[0, 1] = False
+    assert float((ref - lit)[sel].abs().max()) < 3e-3 * float(lit.abs().max())
+    got = ops().mask_conv3x3_folded(xh, Fq, (H, W), bits=False)
+    assert got.shape == (B, Q, H, W)
+    tol = 2e-5 * float(ref[sel].abs().max()) + 1e-6
+    err = (got.cpu().double() - ref).abs()
+    assert float(err[sel].max()) < tol, float(err[sel].max())
+    assert float(err[0, 2].max()) < 1e-2                                        # (fp32 spacing at 1e4)
+    bits, row_any = ops().mask_conv3x3_folded(xh, Fq, (H, W), bits=True)
+    S = H * W
+    assert bits.shape == (B, 1, S // 16, 16, 8) and row_any.shape == (B, Q)
+    words = bits.cpu().to(torch.int32) & 0xffff                                  # [b, 0, kb, lj, m]: bit k = masked[b, 16 m + lj, 16 kb + k]
+    k = torch.arange(16)
+    unpacked = ((words[:, 0, :, :, :, None] >> k) & 1).bool()                    # (B, kb, lj, m, k)
+    unpacked = unpacked.permute(0, 3, 2, 1, 4).reshape(B, 128, S)[:, :Q]         # query 16 m + lj, key 16 kb + k
+    assert not (words[:, 0, :, :, 7] != 0).any()                                 # queries >= 112 never exist
+    if Q % 16:
+        qpad = ((words[:, 0, :, :, :, None] >> k) & 1).bool().permute(0, 3, 2, 1, 4).reshape(B, 128, S)[:, Q:]
+        assert not qpad.any()
+    want = ref.view(B, Q, S) < 0
+    decided = ref.view(B, Q, S).abs() > tol
+    assert torch.equal(unpacked[decided], want[decided])
+    assert float(decided[sel].float().mean()) > 0.999 and not decided[0, 1].any()
+    ra = row_any.cpu().bool()
+    sure_any = ((~want) & decided).any(-1)                                       # some key certainly unmasked
+    sure_none = (want & decided).all(-1)                                         # every key certainly masked
+    assert ra[sure_any].all() and not ra[sure_none].any()
+    assert not ra[0, 2] and ra[0, 1]                                             # (a logit of exactly 0 is not masked: sigmoid(0) < 0.5 is false)
+    assert not unpacked[0, 1].any() and unpacked[0, 2].all()
+    # a row_any buffer the caller cleared is used as it is
+    pre = torch.zeros(B, Q, device=DEV, dtype=torch.int32)
+    bits2, ra2 = ops().mask_conv3x3_folded(xh, Fq, (H, W), bits=True, row_any=pre)
+    assert ra2.data_ptr() == pre.data_ptr() and torch.equal(bits2, bits) and torch.equal(ra2, row_any)
+    with pytest.raises(RuntimeError):
+        ops().mask_conv3x3_folded(xh[:, :S - 16].contiguous(), Fq, (H, W))
+    if W == 16:
+        with pytest.raises(RuntimeError):
+            ops().mask_conv3x3_folded(xh.view(B, H * 2, 8, 64).reshape(B, S, 64), Fq, (H * 2, 8))
+
+
 @pytest.mark.parametrize("keys_f16", [False, True])
 @pytest.mark.parametrize("B,Lq,H,W,masked", [(2, 100, 16, 32, True), (1, 100, 40, 160, True), (1, 300, 120, 160, True), (2, 37, 8, 16, False)])
 def test_hypersphere_attention_fused_kv(B, Lq, H, W, masked, keys_f16):

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmsm_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "msm_hip.h")
 
 _lib = None
-ABI_VERSION = 15     # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
+ABI_VERSION = 16     # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
 
 c_f = ctypes.c_void_p      # float* (device)
 c_p = ctypes.c_void_p
@@ -90,6 +90,7 @@ _SIGNATURES = {
     "msm_dec_heads_bf16": (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_f, c_p, c_f, c_p, c_f, c_p, c_f, c_p, c_f, c_f] + [c_f] * 4 +
                            [c_p, c_i, c_i, c_i, c_fl, c_p]),
     "msm_nchw_to_tokens_f16": (c_i, [c_f, c_p, c_i, c_i, c_i, c_p]),
+    "msm_mask_conv3x3_folded": (c_i, [c_p, c_f, c_l, c_l, c_p, c_p, c_i, c_f, c_i, c_i, c_i, c_i, c_p]),
     "msm_attn_pack_kv_weights": (c_i, [c_f, c_p, c_i, c_p]),
     "msm_attn_mask_bits_bytes": (c_l, [c_i, c_i, c_i]),
     "msm_attn_pack_mask_bits": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),

@@ -14,7 +14,7 @@ import torch
 # attributes under which the modules keep derived tensors (packed weights, folded constants, position codes, broadcast
 # queries) that the kernels of a forward read by address
 _CACHE_ATTRS = ("_q0", "_kv_cache", "_fold_cache", "_tails_cache", "_pos_cache", "_cache", "_packed", "_front", "_w3_cache", "_wl_cache", "_iota", "_heads0_cache",
-                "_packed_mf", "_bf16_cache", "_folded_cache")
+                "_packed_mf", "_bf16_cache", "_folded_cache", "_conv_fold_cache")
 
 
 from ._plan import PLAN_ATTRS as _PLAN_ATTRS, TensorList, plan_epoch
@@ -163,10 +163,11 @@ class PipelinedInference:
     of the slot's previous batch: its graph reads those buffers until then).
     """
 
-    def __init__(self, model, depth=2, warmup=2, strict=False):
+    def __init__(self, model, depth=2, warmup=2, strict=False, entry="inference"):
         if depth < 1:
             raise ValueError("depth must be >= 1")
         self.model = model
+        self.entry = entry             # "inference" (features in) or "inference_images" (backbone in the slot's graph, as GraphedInference)
         self.depth = int(depth)
         self.warmup = max(1, int(warmup))
         self._sig = StaleCheck(model, strict)
@@ -192,12 +193,13 @@ class PipelinedInference:
         stream.wait_stream(cur)
         with torch.cuda.stream(stream):
             static_in = {k: v.clone() for k, v in features.items()}
+            run = getattr(self.model, self.entry)
             for _ in range(self.warmup):                           # builds every weight cache outside the capture
-                self.model.inference(static_in, image_size, padded_size)
+                run(static_in, image_size, padded_size)
             stream.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=stream):
-                static_out = self.model.inference(static_in, image_size, padded_size)
+                static_out = run(static_in, image_size, padded_size)
         self._slots[i] = (self._key(features, image_size, padded_size), stream, graph, static_in, static_out,
                           torch.cuda.Event(), self._sig(), cache_refs(self.model))
         return self._slots[i]

@@ -244,10 +244,11 @@ class MeanShiftMaskFormer(PlanAttributes, nn.Module):
         from .graphs import GraphedInference
         return GraphedInference(self, warmup=warmup, entry=entry)
 
-    def pipelined(self, depth=2, warmup=2):
-        """Throughput mode (graphs.PipelinedInference): ``depth`` batches in flight, one HIP graph and stream each."""
+    def pipelined(self, depth=2, warmup=2, entry="inference"):
+        """Throughput mode (graphs.PipelinedInference): ``depth`` batches in flight, one HIP graph and stream each.
+        entry="inference_images": the backbone is part of every slot's graph (inputs {"image": ...[, "depth": ...]})."""
         from .graphs import PipelinedInference
-        return PipelinedInference(self, depth=depth, warmup=warmup)
+        return PipelinedInference(self, depth=depth, warmup=warmup, entry=entry)
 
     @torch.no_grad()
     def forward(self, batched_inputs):

@@ -105,6 +105,35 @@ class FoldedMaskFeatures:
         return self._tensor
 
 
+class ConvFoldedMaskFeatures:
+    """The mask features of SimpleBasePixelDecoder in factored form: mask_features = Conv3x3(x) + bias with ``x`` the 64-channel
+    level feature (B, 64, H, W) itself (fpn.py:238-246,283-290).  The decoder's only use of mask_features on the inference path is
+    einsum("bqc,bchw->bqhw", e, mask_features) (DEC:1012-1035), linear in x:
+        einsum(e, W * x + b) = (e W) * x + e.b        ((e W)[q] : a 3x3 filter over 64 channels per query)
+    so a decoder that understands this object convolves x with per-query filters (ops.mask_conv3x3_folded, K = 576 on the fp16
+    tokens the fused K/V attention reads) and the (B, 256, H, W) tensor -- 629 MB at batch 2 of 480x640 -- is never written.
+    ``tensor()`` materialises the literal mask_features for any other consumer."""
+
+    def __init__(self, x, weight, bias, materialize):
+        self.x, self.weight, self.bias = x, weight, bias
+        self._materialize = materialize
+        self._tensor = None
+
+    @property
+    def shape(self):
+        B, _, H, W = self.x.shape
+        return torch.Size((B, self.weight.shape[0], H, W))
+
+    @property
+    def device(self):
+        return self.x.device
+
+    def tensor(self):
+        if self._tensor is None:
+            self._tensor = self._materialize()
+        return self._tensor
+
+
 class MeanShiftAttention(nn.Module):
     """Parameters laid out as nn.MultiheadAttention(embed_dim, num_heads) (attention_util.py:469-472):
     in_proj_weight (3E,E), in_proj_bias (3E), out_proj.{weight,bias}."""
@@ -544,8 +573,36 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         dn = self.decoder_norm
         pred_cls, pred_mask = [], []
         topk_out = []
+        cf = None
+        if isinstance(mask_features, ConvFoldedMaskFeatures):
+            # per-query 3x3 filters F = e W (one small GEMM per prediction) convolved with the fp16 tokens of the level: bits for the next
+            # layer's fused K/V attention, fp32 logits for the final prediction (on the K kept queries when the caller selects first)
+            wkey = ("cfw", str(mask_features.device)) + version_key([mask_features.weight, mask_features.bias])
+            wc = getattr(self, "_conv_fold_cache", None)
+            if wc is None or wc[0] != wkey:
+                self._conv_fold_cache = wc = (wkey, ops.mask_conv_fold_weight(mask_features.weight, mask_features.bias))
+            cf = (fkv["x"][0], wc[1])
+
+        def predict_conv_folded(d, e, ra, i_next):
+            last = i_next == L
+            x16, wf = cf
+            if not last:
+                attn, row_any = ops.mask_conv3x3_folded(x16, ops.gemm(e, wf), sizes[0], bits=True, row_any=ra)
+                pred_cls.append(None)
+                pred_mask.append(None)
+                return attn, row_any
+            cls = ops.gemm(d, self.class_embed.weight, self.class_embed.bias)
+            if 0 < final_topk < e.shape[1]:
+                *topk, sel = ops.topk_class_scores(cls, int(final_topk), gather=e, gather_cols=e.shape[2])
+                topk_out.append(tuple(topk))
+                e = sel
+            pred_cls.append(cls)
+            pred_mask.append(ops.mask_conv3x3_folded(x16, ops.gemm(e, wf), sizes[0], bits=False))
+            return None, None
 
         def predict(d, e, ra, i_next):
+            if cf is not None:
+                return predict_conv_folded(d, e, ra, i_next)
             last = i_next == L
             want = full or last
             cls = ops.gemm(d, self.class_embed.weight, self.class_embed.bias) if want else None
@@ -636,6 +693,19 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             res["aux_outputs"] = [{"pred_logits": a, "pred_masks": b} for a, b in zip(pred_cls[:-1], pred_mask[:-1])]
         return res
 
+    def _initial_queries(self, B, dev):
+        """query_feat broadcast over the batch (read-only): one tensor per (batch size, parameter version).  A captured HIP graph
+        reads it by address, so entries are only dropped wholesale and graphs hold the entries they were captured with
+        (graphs.cache_refs)."""
+        qf = self.query_feat.weight
+        qkey = (B, str(dev), qf.data_ptr(), qf._version)
+        q0 = getattr(self, "_q0", None)
+        if q0 is None or len(q0) > 32:
+            q0 = self._q0 = {}
+        if qkey not in q0:
+            q0[qkey] = qf[None].expand(B, -1, -1).contiguous()
+        return q0[qkey]
+
     @torch.no_grad()
     def forward(self, x, mask_features, mask=None, *, final_topk=0):
         """``final_topk`` = K > 0 (MeanShiftMaskFormer.inference): the final mask step runs on the K (query, class) pairs
@@ -684,6 +754,17 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                     src.append(ops.conv1x1_nchw_to_tokens(xs[i].contiguous(), wt, bias.contiguous()))
                 else:
                     src.append(ops.transpose_last2(xs[i].contiguous().flatten(2)) + self.level_embed.weight[i])
+        if isinstance(mask_features, ConvFoldedMaskFeatures):
+            # the UCN path's factored mask features: taken when every cross attention reads bit-packed masks (fused K/V attention on
+            # every layer) and no intermediate logits are asked for; else the literal tensor
+            Qn = self.query_feat.weight.shape[0]
+            if (self.folded_mask_features and self.fused_tails and self.fold_kv and not self.aux_outputs and self.num_layers > 0
+                    and self.mask_step_dtype in ("bf16", "f16") and Qn <= 112 and fkv is not None and all(l is not None for l in fkv["layers"])
+                    and self.num_feature_levels == 1 and mask_features.x is x[0] and tuple(mask_features.weight.shape[1:]) == (64, 3, 3)
+                    and mask_features.weight.shape[0] == E):
+                return self._forward_fused(xs, sizes, kv_w, kv_c, mask_features, self._initial_queries(B, dev), self.query_embed.weight, kv_all,
+                                           final_topk, fkv)
+            mask_features = mask_features.tensor()
         folded = isinstance(mask_features, FoldedMaskFeatures)
         if folded and not (self.folded_mask_features and self.fused_tails and self.fold_kv and mask_features.act.shape[1] % 32 == 0
                            and mask_features.act.shape[1] < self.query_feat.weight.shape[1]):
@@ -705,17 +786,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         self._packed_mf_split = ops.pack_mask_features_split(mf_planes) \
             if (self.mask_step_dtype == "f32_split" and folded and mf_planes.shape[1] == 64 and not lean) else None
         qpos = self.query_embed.weight
-        qf = self.query_feat.weight
-        # the broadcast initial queries are read-only: one tensor per (batch size, parameter version).  A captured HIP
-        # graph reads it by address, so entries are only dropped wholesale and graphs hold the entries they were captured
-        # with (graphs.cache_refs)
-        qkey = (B, str(dev), qf.data_ptr(), qf._version)
-        q0 = getattr(self, "_q0", None)
-        if q0 is None or len(q0) > 32:
-            q0 = self._q0 = {}
-        if qkey not in q0:
-            q0[qkey] = qf[None].expand(B, -1, -1).contiguous()
-        out = q0[qkey]
+        out = self._initial_queries(B, dev)
         full = self.aux_outputs
         L = self.num_layers
         pred_cls, pred_mask = [], []
@@ -785,6 +856,7 @@ class SimpleBasePixelDecoder(PlanAttributes, nn.Module):
         self.conv_dim = conv_dim
         self.precision = "f32"             # "bf16" (head.set_precision): the mask_features convolution in the low-precision form
         self.lp_operands = "bf16"          # ... with bf16 or IEEE-half ("f16") operands
+        self.fold_mask_conv = True         # 16-bit plans: hand the decoder the factored form (ConvFoldedMaskFeatures) when it asks for it
         if mask_dim != 64:
             self.mask_features = nn.Conv2d(conv_dim, mask_dim, kernel_size=3, stride=1, padding=1)
         self.maskformer_num_feature_levels = 1
@@ -796,7 +868,9 @@ class SimpleBasePixelDecoder(PlanAttributes, nn.Module):
                     conv_dim=sh.CONVS_DIM, mask_dim=sh.MASK_DIM, norm=sh.NORM)
 
     @torch.no_grad()
-    def forward_features(self, features):
+    def forward_features(self, features, folded=False):
+        """``folded`` (16-bit plans, a 64-channel feature with W % 16 == 0): mask_features come back in factored form
+        (ConvFoldedMaskFeatures) -- the convolution is folded into the decoder's query embedding and never run."""
         multi_scale_features = []
         y = None
         for f in self.in_features[::-1]:
@@ -806,12 +880,18 @@ class SimpleBasePixelDecoder(PlanAttributes, nn.Module):
         if self.mask_dim == 64:
             return y, None, multi_scale_features
         B, C, H, W = y.shape
-        tok = ops.transpose_last2(y.contiguous().view(B, C, H * W))                       # NHWC tokens
-        w = self.mask_features.weight.permute(0, 2, 3, 1).reshape(self.mask_dim, 9 * C).contiguous()
         lp = getattr(self, "precision", "f32") == "bf16"
-        mf = ops.conv3x3_tokens_to_nchw(tok, w, self.mask_features.bias, int(H), int(W),
-                                        bf16=("f16" if getattr(self, "lp_operands", "bf16") == "f16" else True) if lp else False)
-        return mf.view(B, self.mask_dim, H, W), None, multi_scale_features
+
+        def literal():
+            tok = ops.transpose_last2(y.contiguous().view(B, C, H * W))                       # NHWC tokens
+            w = self.mask_features.weight.permute(0, 2, 3, 1).reshape(self.mask_dim, 9 * C).contiguous()
+            mf = ops.conv3x3_tokens_to_nchw(tok, w, self.mask_features.bias, int(H), int(W),
+                                            bf16=("f16" if getattr(self, "lp_operands", "bf16") == "f16" else True) if lp else False)
+            return mf.view(B, self.mask_dim, H, W)
+
+        if folded and lp and getattr(self, "fold_mask_conv", True) and y.is_cuda and C == 64 and W % 16 == 0 and H * W * 128 < (1 << 32) - 256:
+            return ConvFoldedMaskFeatures(y, self.mask_features.weight, self.mask_features.bias, literal), None, multi_scale_features
+        return literal(), None, multi_scale_features
 
 
 # ----------------------------------------------------------------------------------------------

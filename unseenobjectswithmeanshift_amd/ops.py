@@ -639,6 +639,54 @@ def tokens_f16(x):
     return out
 
 
+MASK_CONV_K = 576            # 9 taps x 64 channels; column 576 of a folded filter row is the per-query constant
+MASK_CONV_LD = 580           # row length of mask_conv_fold_weight's GEMM output (16-byte aligned rows)
+
+
+def mask_conv_fold_weight(weight, bias=None):
+    """Conv2d(64, Cm, 3, padding=1) weight (Cm, 64, 3, 3) [+ bias (Cm,)] -> the (580, Cm) matrix Wf with
+    gemm(e, Wf)[b, q] = [F[b, q, 64 * (3 ky + kx) + c] = sum_o e[b, q, o] W[o, c, ky, kx] | e[b, q, :] . bias | 0 0 0]:
+    the per-query 3x3 filters mask_conv3x3_folded convolves the 64-channel feature with (the convolution folded into the embedding)."""
+    Cm, C, kh, kw = weight.shape
+    if (C, kh, kw) != (64, 3, 3):
+        raise RuntimeError("mask_conv_fold_weight: a (Cm, 64, 3, 3) convolution weight")
+    wf = torch.zeros((MASK_CONV_LD, Cm), device=weight.device, dtype=torch.float32)
+    wf[:MASK_CONV_K] = weight.detach().float().permute(2, 3, 1, 0).reshape(MASK_CONV_K, Cm)
+    if bias is not None:
+        wf[MASK_CONV_K] = bias.detach().float()
+    return wf
+
+
+def mask_conv3x3_folded(x_f16, F, size, *, bits=True, row_any=None):
+    """The UCN path's mask step with the mask_features convolution folded into the embedding (msm_mask_conv3x3_folded; 16-bit plans):
+    x_f16 = tokens_f16(level feature) (B, H*W, 64) float16; F (B, Q, >= 577) fp32 = gemm(e, mask_conv_fold_weight(w, b)); size = (H, W),
+    W % 16 == 0, Q <= 112.  bits=True: returns (mask bits int16 (B, 1, S / 16, 16, 8) as hypersphere_attention_fused_kv reads them
+    [bit = logit < 0], row_any int32 (B, Q)); ``row_any`` given: a buffer the caller already cleared (dec_heads zero_row_any).
+    bits=False: returns the fp32 logits (B, Q, H, W)."""
+    _c(x_f16, "x_f16", torch.float16), _c(F, "F"), _c(row_any, "row_any", torch.int32)
+    B, Q, ldf = F.shape
+    H, W = int(size[0]), int(size[1])
+    S = H * W
+    if tuple(x_f16.shape) != (B, S, 64) or F.stride(2) != 1 or F.stride(1) % 4 or F.stride(0) % 4 or ldf < MASK_CONV_K + 1:
+        raise RuntimeError("mask_conv3x3_folded: x_f16 (B, H*W, 64) float16 and F (B, Q, >= 577) with 16-byte aligned rows")
+    if W % 16 or Q > 112:
+        raise RuntimeError("mask_conv3x3_folded: W % 16 == 0 and Q <= 112")
+    if bits:
+        out = torch.empty((B, 1, S // 16, 16, 8), device=F.device, dtype=torch.int16)
+        cleared = row_any is not None
+        if row_any is None:
+            row_any = torch.empty((B, Q), device=F.device, dtype=torch.int32)
+        elif tuple(row_any.shape) != (B, Q):
+            raise RuntimeError("mask_conv3x3_folded: row_any must be (B, Q)")
+        check(lib().msm_mask_conv3x3_folded(_p(x_f16), _p(F), F.stride(1), F.stride(0), _p(out), _p(row_any), 1 if cleared else 0, None,
+                                            B, Q, H, W, _stream()), "msm_mask_conv3x3_folded")
+        return out, row_any
+    out = torch.empty((B, Q, H, W), device=F.device, dtype=torch.float32)
+    check(lib().msm_mask_conv3x3_folded(_p(x_f16), _p(F), F.stride(1), F.stride(0), None, None, 0, _p(out), B, Q, H, W, _stream()),
+          "msm_mask_conv3x3_folded")
+    return out
+
+
 def attn_pack_mask_bits(masked):
     """uint8 mask (B, Lq, S) (nonzero = masked), S % 16 == 0 -> the bit-packed, blocked form hypersphere_attention_fused_kv reads
     (msm_attn_pack_mask_bits): int16 (B, ceil(Lq / 112), S / 16, 16, 8), word [b, qc, kb, lj, m] bit k = masked[b, 112 qc + 16 m + lj, 16 kb + k]."""
