@@ -693,6 +693,25 @@ def extra_configs(dev, args):
                 "traffic": None,
                 "note": "latency / vector-pipe bound: 2 Q S 8 exponentials with their mask and norm arithmetic are ~0.12 ms of VALU issue per launch; "
                         "the unfused pair (K/V written and read back) took 0.68 ms"}
+
+    def mask_conv_entry(durs):
+        """mask_conv_fold_kernel (16-bit plans): the mask step with the 3x3 mask_features convolution folded into per-query filters --
+        executed FLOPs per launch 2 B Qpad 576 H W (K = 9 taps x 64 channels on fp16 MFMAs; the literal order executes 2 B Q 256 H W on a
+        tensor this form never writes), bytes: the fp16 tokens once (128 B per key) + the bits written."""
+        mc = durs.get("msm_mask_conv3x3_folded", [])
+        if not mc:
+            return None
+        big = sorted(mc)[-max(1, len(mc) - 1):]                      # the Q = 100 launches (the last prediction runs on the K kept queries)
+        ms = sum(big) / len(big)
+        fl = 2.0 * UB * 112 * 576 * S_keys
+        by = UB * (S_keys * 128.0 + S_keys * 16.0)
+        return {"bound": "mfma", "kernel": "mask_conv_fold_kernel<0> (msm_mask_conv3x3_folded, Q = 100 -> attention-mask bits)",
+                "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                "flops_per_launch": fl, "bytes_per_launch": by, "avg_launch_ms": round(ms, 4), "launches_per_step": len(mc),
+                "all_launches_ms": round(sum(mc), 3), "traffic": None,
+                "note": "replaces the 3x3 convolution to 256 channels (0.68 ms), its packed copy (0.18 ms), seven 0.13-ms mask steps over it and the "
+                        "bit packing (6 x 0.016 ms) of the literal order: 1.9 -> 0.64 ms per pass; MFMA issue at the clock the part holds under this "
+                        "load (~1.7 GHz) is 50 us of the 78 (tools/probes/mask_conv_parts.sh)"}
     out["ucn_path"] = {
         "workload": f"UCN RGB-D path: batch {UB} of 480x640 64-channel embeddings -> 3x3 mask_features convolution -> 6-layer hypersphere decoder "
                     "over 307 200 keys per image -> post-processing; HIP-graph replay, batches in flight as stated; backbone excluded",
@@ -702,17 +721,17 @@ def extra_configs(dev, args):
         "three_batches_in_flight": {"value": round(UB / t_pipe[3], 1), "ms_per_step": round(1e3 * t_pipe[3], 3)},
         "eager": {"value": round(UB / t_eager, 1), "ms_per_step": round(1e3 * t_eager, 3)},
         "kernels_ms": {k: round(sum(v), 3) for k, v in sorted(ud.items(), key=lambda kv: -sum(kv[1]))[:6]},
-        "bf16": {"dtype": "bf16 operands / fp32 accumulation, bf16 K/V", "value": round(UB / min(t_lp.values()), 1), "unit": "images/sec",
+        "bf16": {"dtype": "bf16 operands / fp32 accumulation; K/V projected inside the attention kernel, mask_features folded into the query embedding (never written)", "value": round(UB / min(t_lp.values()), 1), "unit": "images/sec",
                  "one_batch_in_flight": {"value": round(UB / t_lp[1], 1), "ms_per_step": round(1e3 * t_lp[1], 3)},
                  "three_batches_in_flight": {"value": round(UB / t_lp[3], 1), "ms_per_step": round(1e3 * t_lp[3], 3)},
                  "kernels_ms": {k: round(sum(v), 3) for k, v in sorted(ud_lp.items(), key=lambda kv: -sum(kv[1]))[:6]},
-                 "roofline": fused_roofline(ud_lp),
-                 "parity": "tests/test_gpu_configs.py::test_ucn_path_480x640_bf16_vs_reference (final-mask mismatch 0.1 % against the fp32 reference golden)"},
-        "f16": {"dtype": "fp16 / bf16 operands, fp32 accumulation, fp16 K + bf16 V", "value": round(UB / min(lp_modes["f16"][0].values()), 1), "unit": "images/sec",
+                 "roofline": fused_roofline(ud_lp), "mask_step": mask_conv_entry(ud_lp),
+                 "parity": "tests/test_gpu_configs.py::test_ucn_path_480x640_bf16_vs_reference (final-mask mismatch 0.08 % (bf16) / 0.02 % (f16) against the fp32 reference golden)"},
+        "f16": {"dtype": "fp16 / bf16 operands, fp32 accumulation; as the bf16 entry with fp16 score operands", "value": round(UB / min(lp_modes["f16"][0].values()), 1), "unit": "images/sec",
                 "one_batch_in_flight": {"value": round(UB / lp_modes["f16"][0][1], 1), "ms_per_step": round(1e3 * lp_modes["f16"][0][1], 3)},
                 "three_batches_in_flight": {"value": round(UB / lp_modes["f16"][0][3], 1), "ms_per_step": round(1e3 * lp_modes["f16"][0][3], 3)},
                 "kernels_ms": {k: round(sum(v), 3) for k, v in sorted(lp_modes["f16"][1].items(), key=lambda kv: -sum(kv[1]))[:6]},
-                "roofline": fused_roofline(lp_modes["f16"][1])},
+                "roofline": fused_roofline(lp_modes["f16"][1]), "mask_step": mask_conv_entry(lp_modes["f16"][1])},
         "roofline": {"bound": "hbm", "kernel": "hs_attn_kernel + combine at 307 200 keys (msm_hypersphere_attn_fwd)",
                      "achieved": round(attn_bytes / (cross_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                      "frac": round(attn_bytes / (cross_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "bytes_per_launch": attn_bytes,

@@ -80,10 +80,12 @@ def stamp(*sources):
     def sha(name):
         with open(os.path.join("unseenobjectswithmeanshift_amd", "csrc", name), "rb") as f:
             return hashlib.sha256(f.read()).hexdigest()
-    try:
-        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
-    except OSError:
-        commit = None
+    commit = os.environ.get("MSM_COMMIT") or None         # (summarised on the GPU box, which has no .git: tools/profile_all.sh passes it)
+    if commit is None:
+        try:
+            commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+        except OSError:
+            commit = None
     return {"commit": commit, "kernel_source_sha256": {n: sha(n) for n in sources}}
 
 
