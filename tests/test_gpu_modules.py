@@ -210,6 +210,62 @@ def test_ucn_path_vs_reference(golden):
         torch.testing.assert_close(again["pred_masks"], out["pred_masks"], rtol=1e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+@pytest.mark.parametrize("B,H,W,layers", [(1, 224, 224, 8), (3, 72, 96, 6), (2, 66, 80, 6)])
+def test_ucn_folded_mask_features_route(B, H, W, layers, precision):
+    """16-bit plans of the UCN path at other shapes than the 480x640 golden (the 224x224 crop configuration with its 8 layers,
+    crop_mixture_UCN.yaml:62; an odd batch; a height that is not a multiple of the rows a wave takes): the route with mask_features folded into the query embedding
+    (ConvFoldedMaskFeatures -> msm_mask_conv3x3_folded, taken when every layer's cross attention is the fused K/V kernel) against the
+    literal route (3x3 convolution, packed copy, mask step, bit packing) of the same plan and against the fp32 path; and through
+    ``inference`` (the final mask step on the K kept queries only)."""
+    from unseenobjectswithmeanshift_amd.meta_arch import PretrainedMeanShiftMaskFormer, build_ucn_head
+    head = build_ucn_head(dec_layers=layers)
+    head.pixel_decoder.load_state_dict(syn.synth_state_dict({"mask_features.weight": (256, 64, 3, 3), "mask_features.bias": (256,)}, salt=3), strict=True)
+    head.predictor.load_state_dict(syn.synth_state_dict(syn.decoder_param_shapes(dec_layers=layers, num_feature_levels=1), salt=4), strict=True)
+    head = head.to(DEV).eval()
+    X, _ = syn.synth_unit_embeddings(B * H * W, 64, clusters=9, sigma=0.3, seed=31)
+    feat = X.view(B, H * W, 64).transpose(1, 2).reshape(B, 64, H, W).contiguous().to(DEV)
+    ref, _ = head({"res5": feat})                                          # fp32 kernels
+    head.set_precision(precision)
+    head.predictor._conv_fold_cache = None
+    got, _ = head({"res5": feat})
+    assert head.predictor._conv_fold_cache is not None                     # the folded route ran
+    head.pixel_decoder.fold_mask_conv = False
+    head.predictor._conv_fold_cache = None
+    lit, _ = head({"res5": feat})
+    assert head.predictor._conv_fold_cache is None
+    head.pixel_decoder.fold_mask_conv = True
+    rng = float(ref["pred_masks"].abs().max())
+    bits = lambda o: o["pred_masks"] > 0
+    mm = lambda a, b: float((bits(a) != bits(b)).float().mean())
+    print(f"ucn {B}x{H}x{W} L{layers} {precision}: folded vs fp32 {mm(got, ref):.3%}, literal vs fp32 {mm(lit, ref):.3%}, folded vs literal {mm(got, lit):.3%}; "
+          f"max|dmask| / range {float((got['pred_masks'] - ref['pred_masks']).abs().max()) / rng:.3f}")
+    # the plan's own distance from fp32 (literal route) bounds the folded route's: same arithmetic class, one rounding of F instead of two
+    assert mm(got, ref) <= max(0.004, 1.5 * mm(lit, ref)) and mm(got, lit) <= 0.006
+    assert float((got["pred_logits"] - ref["pred_logits"]).abs().max()) < 0.05
+    assert float((got["pred_masks"] - ref["pred_masks"]).abs().mean()) < 5e-3 * rng
+    # inference(): top-K selection first, the folded kernel in logits mode on the K kept queries
+    model = PretrainedMeanShiftMaskFormer(backbone=None, sem_seg_head=head, num_queries=100)
+    sc, cl, masks, boxes, qidx = model.inference({"res5": feat}, (H, W))
+    head.pixel_decoder.fold_mask_conv = False
+    sc2, cl2, masks2, boxes2, qidx2 = model.inference({"res5": feat}, (H, W))
+    head.pixel_decoder.fold_mask_conv = True
+    # (random weights: class scores are near-tied, so the ORDER of the kept pairs differs between two roundings; pairs are matched by
+    # (query, class))
+    hit = tot = 0
+    for b in range(B):
+        where2 = {(int(q), int(c)): j for j, (q, c) in enumerate(zip(qidx2[b].tolist(), cl2[b].tolist()))}
+        for j, (q, c) in enumerate(zip(qidx[b].tolist(), cl[b].tolist())):
+            tot += 1
+            k = where2.get((int(q), int(c)))
+            if k is None:
+                continue
+            hit += 1
+            assert float((masks[b, j] != masks2[b, k]).float().mean()) <= 0.01
+            assert abs(float(sc[b, j]) - float(sc2[b, k])) <= 0.02 + 0.05 * abs(float(sc2[b, k]))
+    assert hit >= 0.8 * tot
+
+
 def test_decoder_bf16_mask_step():
     """BASELINE configs 3/5: the mask step in bf16 (fp32 accumulation) against the fp32 path on the same inputs.
     Random-init weights are the worst case (logits centred on 0, attention-mask bits feed back discretely: SURVEY 8c
