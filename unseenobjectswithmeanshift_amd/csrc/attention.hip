@@ -151,6 +151,16 @@ __device__ __forceinline__ float rnorm(float ss) {
 //     one multiply), so a masked pair leaves the MFMA chain at -1e5 + cos and exp2 returns exactly 0 -- no compare /
 //     select per score; keys beyond S are handled the same way (tail block only);
 //   * the key norm as v_rsq_f32 + one Newton step.
+// v summed over the four lane rows (lanes l, l ^ 16, l ^ 32, l ^ 48) in the association of `v += shfl_xor(v, 16); v += shfl_xor(v, 32)`,
+// on gfx950's v_permlane16_swap / v_permlane32_swap (vector instructions) instead of two ds_bpermute round trips through the LDS
+// crossbar: the key norm sits on the dependent chain of every 16-key block.
+__device__ __forceinline__ float sum_lane_rows(float v) {
+    typedef unsigned u32x2r __attribute__((ext_vector_type(2)));
+    const u32x2r a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a.x) + __uint_as_float(a.y);
+    const u32x2r b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b.x) + __uint_as_float(b.y);
+}
 template <typename KVT, int NQ, int MM>
 struct KeyFrag {
     KVRaw<KVT> kv;
@@ -241,8 +251,7 @@ __device__ __forceinline__ void keys_consume(const KeyFrag<KVT, NQ, MM>& f, int 
     float kr[8];
     k_floats(f.kv, kr);
     float ss = (kr[0] * kr[0] + kr[1] * kr[1] + kr[2] * kr[2] + kr[3] * kr[3]) + (kr[4] * kr[4] + kr[5] * kr[5] + kr[6] * kr[6] + kr[7] * kr[7]);
-    ss += __shfl_xor(ss, 16, 64);
-    ss += __shfl_xor(ss, 32, 64);
+    ss = sum_lane_rows(ss);
     const float rn = rnorm(ss);
     const float kf[8] = {kr[0] * rn, kr[1] * rn, kr[2] * rn, kr[3] * rn, kr[4] * rn, kr[5] * rn, kr[6] * rn, kr[7] * rn};
     bf16x4 kh[2], vb[2];
@@ -657,8 +666,7 @@ __global__ __launch_bounds__(256, 2) void hs_attn_fkv_kernel(const float* __rest
         // k^ = K / max(|K|, 1e-12) over the head's 32 dims: this lane's eight + the three other lane quarters of key lj
         float ss = (kt[0][0] * kt[0][0] + kt[0][1] * kt[0][1] + kt[0][2] * kt[0][2] + kt[0][3] * kt[0][3]) +
                    (kt[1][0] * kt[1][0] + kt[1][1] * kt[1][1] + kt[1][2] * kt[1][2] + kt[1][3] * kt[1][3]);
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
+        ss = sum_lane_rows(ss);
         const float rn = rnorm(ss);
         bf16x4 kh[2], vb[2];
 #pragma unroll
