@@ -52,9 +52,35 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Sum over the 64 lanes, every lane gets the total: the butterfly v += v[lane ^ o], o = 32, 16, 8, 4, 2, 1 -- in that order, so the
+// association (and the rounding) is that of the __shfl_xor loop it replaces -- on vector instructions: v_permlane32/16_swap (gfx950)
+// for the two cross-row steps, DPP for the four steps inside a 16-lane row.  The __shfl_xor form compiles to six DEPENDENT
+// ds_bpermute_b32 round trips through the LDS crossbar (~100 cycles each): a LayerNorm's mean -> variance chain was ~1200 cycles of
+// latency on the critical path of every row-local decoder kernel.
+__device__ __forceinline__ float wave_xor_dpp8(float v) {        // v[lane ^ 8]: rotate the 16-lane row by 8
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_xor_dpp4(float v) {        // v[lane ^ 4]: banks (quads) 0, 2 take lane + 4, banks 1, 3 lane - 4
+    int t = __builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x104 /* row_shl:4 */, 0xf, 0x5, false);
+    t = __builtin_amdgcn_update_dpp(t, (int)__float_as_uint(v), 0x114 /* row_shr:4 */, 0xf, 0xa, false);
+    return __uint_as_float((unsigned)t);
+}
+__device__ __forceinline__ float wave_xor_dpp2(float v) {        // quad_perm [2, 3, 0, 1]
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x4e, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_xor_dpp1(float v) {        // quad_perm [1, 0, 3, 2]
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0xb1, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
+    const u32x2w a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a.x) + __uint_as_float(a.y);
+    const u32x2w b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(b.x) + __uint_as_float(b.y);
+    v += wave_xor_dpp8(v);
+    v += wave_xor_dpp4(v);
+    v += wave_xor_dpp2(v);
+    v += wave_xor_dpp1(v);
     return v;
 }
 
