@@ -151,16 +151,6 @@ __device__ __forceinline__ float rnorm(float ss) {
 //     one multiply), so a masked pair leaves the MFMA chain at -1e5 + cos and exp2 returns exactly 0 -- no compare /
 //     select per score; keys beyond S are handled the same way (tail block only);
 //   * the key norm as v_rsq_f32 + one Newton step.
-// v summed over the four lane rows (lanes l, l ^ 16, l ^ 32, l ^ 48) in the association of `v += shfl_xor(v, 16); v += shfl_xor(v, 32)`,
-// on gfx950's v_permlane16_swap / v_permlane32_swap (vector instructions) instead of two ds_bpermute round trips through the LDS
-// crossbar: the key norm sits on the dependent chain of every 16-key block.
-__device__ __forceinline__ float sum_lane_rows(float v) {
-    typedef unsigned u32x2r __attribute__((ext_vector_type(2)));
-    const u32x2r a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = __uint_as_float(a.x) + __uint_as_float(a.y);
-    const u32x2r b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(b.x) + __uint_as_float(b.y);
-}
 template <typename KVT, int NQ, int MM>
 struct KeyFrag {
     KVRaw<KVT> kv;
@@ -375,8 +365,7 @@ __device__ __forceinline__ void load_queries(const float* __restrict__ qb, int64
             c = *reinterpret_cast<const float4*>(p + 4);
         }
         float ss = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
+        ss = sum_lane_rows(ss);
         const float rn = rnorm(ss);
         qf[m][0] = a.x * rn; qf[m][1] = a.y * rn; qf[m][2] = a.z * rn; qf[m][3] = a.w * rn;
         qf[m][4] = c.x * rn; qf[m][5] = c.y * rn; qf[m][6] = c.z * rn; qf[m][7] = c.w * rn;
@@ -435,8 +424,7 @@ __global__ __launch_bounds__(256, 2) void hs_attn_kernel(const float* __restrict
 #pragma unroll
     for (int m = 0; m < AQB; ++m) {
         float l = lsum[m];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l = sum_lane_rows(l);
         if (lq == 0) mine[(m * 16 + lj) * PSTRIDE + HD] = l;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -547,8 +535,7 @@ __global__ __launch_bounds__(256, 2) void hs_attn_fkv_kernel(const float* __rest
                 c = *reinterpret_cast<const float4*>(p + 16);
             }
             float ss = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
-            ss += __shfl_xor(ss, 16, 64);
-            ss += __shfl_xor(ss, 32, 64);
+            ss = sum_lane_rows(ss);
             const float rn = rnorm(ss);
             if constexpr (BF == 2) {
                 qh[m][0] = __builtin_bit_cast(bf16x4, pack4h_nc(a.x * rn, a.y * rn, a.z * rn, a.w * rn));
@@ -739,8 +726,7 @@ __global__ __launch_bounds__(256, 2) void hs_attn_fkv_kernel(const float* __rest
 #pragma unroll
     for (int m = 0; m < AQB; ++m) {
         float l = lacc[m][0] + lacc[m][1];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l = sum_lane_rows(l);
         if (lq == 0) mine[(m * 16 + lj) * PSTRIDE + HD] = l;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -890,15 +876,13 @@ __global__ __launch_bounds__(NW * 64) void hs_attn_qk_kernel(const float* __rest
 #pragma unroll
     for (int m = 0; m < MQ; ++m) {
         float l = lsum[m];                     // per query lj (any lq) after the two reductions
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l = sum_lane_rows(l);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float lr = __shfl(l, lq * 4 + r, 64);          // denominator of this lane's output row
             const float a0 = o[m][0][r] / lr, a1 = o[m][1][r] / lr;
             float ss = a0 * a0 + a1 * a1;
-#pragma unroll
-            for (int x = 1; x < 16; x <<= 1) ss += __shfl_xor(ss, x, 64);
+            ss += wave_xor_dpp1(ss), ss += wave_xor_dpp2(ss), ss += wave_xor_dpp4(ss), ss += wave_xor_dpp8(ss);     // (over the 16-lane row, as the shfl_xor loop 1, 2, 4, 8)
             const float nrm = fmaxf(sqrtf(ss), 1e-12f);
             const int qi = (qb0 + m) * 16 + lq * 4 + r;
             if (qi < Lq) {
@@ -962,7 +946,7 @@ __global__ __launch_bounds__(256) void hs_attn_combine_kernel(const float* __res
         a[d] = tot[ql * PSTRIDE + half * 16 + d] / l;
         ss += a[d] * a[d];
     }
-    ss += __shfl_xor(ss, 1, 64);
+    ss += wave_xor_dpp1(ss);
     const float nrm = fmaxf(sqrtf(ss), 1e-12f);
     if (qi < Lq) {
         float* o = out + ((int64_t)b * Lq + qi) * (heads * HD) + h * HD + half * 16;

@@ -128,8 +128,7 @@ __global__ __launch_bounds__(256) void attn_mask_pooled_kernel(const float* __re
             const unsigned m0 = acc[0] < 0.f, m1 = acc[1] < 0.f, m2 = acc[2] < 0.f, m3 = acc[3] < 0.f;
             if constexpr (BITS) {
                 unsigned nib = (m0 | (m1 << 1) | (m2 << 2) | (m3 << 3)) << (4 * lq);
-                nib |= __shfl_xor(nib, 16, 64);
-                nib |= __shfl_xor(nib, 32, 64);
+                nib = or_lane_rows(nib);
                 if ((m0 & m1 & m2 & m3) == 0) anyu |= 1u << m;
                 const int gq = qb0 + m, qc = gq / 7, mb = gq - qc * 7;            // 112-query chunk and block within it (attention.hip: AQB = 7)
                 const int qchunks = (Q + 111) / 112;
@@ -157,8 +156,7 @@ __global__ __launch_bounds__(256) void attn_mask_pooled_kernel(const float* __re
         for (int u = 0; u < 4; ++u) a[u] = an[u];
     }
     // rows with at least one unmasked key keep their mask (DEC:618 resets the others): same flag value from every writer
-    anyu |= __shfl_xor(anyu, 16, 64);
-    anyu |= __shfl_xor(anyu, 32, 64);
+    anyu = or_lane_rows(anyu);
     if (lq == 0) {
 #pragma unroll
         for (int m = 0; m < AM_NQ; ++m)

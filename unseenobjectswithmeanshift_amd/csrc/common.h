@@ -84,6 +84,24 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// v summed (OR-ed) over the four lane rows (lanes l, l ^ 16, l ^ 32, l ^ 48) in the association of `v += shfl_xor(v, 16); v += shfl_xor(v, 32)`,
+// on v_permlane16_swap / v_permlane32_swap instead of two ds_bpermute round trips (the key norm of the attention kernels sits on the
+// dependent chain of every 16-key block).
+__device__ __forceinline__ float sum_lane_rows(float v) {
+    typedef unsigned u32x2r __attribute__((ext_vector_type(2)));
+    const u32x2r a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a.x) + __uint_as_float(a.y);
+    const u32x2r b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b.x) + __uint_as_float(b.y);
+}
+__device__ __forceinline__ unsigned or_lane_rows(unsigned v) {
+    typedef unsigned u32x2r __attribute__((ext_vector_type(2)));
+    const u32x2r a = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = a.x | a.y;
+    const u32x2r b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return b.x | b.y;
+}
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 }  // namespace msm

@@ -120,8 +120,7 @@ __device__ __forceinline__ void layer_norm_Ls(float (&v)[4][4], const float* __r
     for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) s += v[fb][r];
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
+    s = sum_lane_rows(s);
     const float mean = s * (1.0f / ES_C);
     float q = 0.f;
 #pragma unroll
@@ -131,8 +130,7 @@ __device__ __forceinline__ void layer_norm_Ls(float (&v)[4][4], const float* __r
             const float d = v[fb][r] - mean;
             q += d * d;
         }
-    q += __shfl_xor(q, 16, 64);
-    q += __shfl_xor(q, 32, 64);
+    q = sum_lane_rows(q);
     const float rstd = 1.0f / sqrtf(q * (1.0f / ES_C) + eps);
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb) {

@@ -93,8 +93,7 @@ __device__ __forceinline__ void layer_norm_h(float (&v)[4][4], const float* __re
     for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) s += v[fb][r];
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
+    s = sum_lane_rows(s);
     const float mean = s * (1.0f / EH_C);
     float q = 0.f;
 #pragma unroll
@@ -104,8 +103,7 @@ __device__ __forceinline__ void layer_norm_h(float (&v)[4][4], const float* __re
             const float d = v[fb][r] - mean;
             q += d * d;
         }
-    q += __shfl_xor(q, 16, 64);
-    q += __shfl_xor(q, 32, 64);
+    q = sum_lane_rows(q);
     const float rstd = 1.0f / sqrtf(q * (1.0f / EH_C) + eps);
 #pragma unroll
     for (int fb = 0; fb < 4; ++fb) {

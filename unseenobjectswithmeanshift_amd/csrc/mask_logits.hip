@@ -380,8 +380,7 @@ __device__ __forceinline__ void mask_tile_epilogue_fast(const f32x4 (&acc)[QB][2
                                add1(acc_val<NC>(acc, m, 1, jl), acc_val<NC>(acc, m, 1, jl + 1)));
                 if constexpr (R4_PARTIAL) {
                     if (m == QB - 1) {
-                        s += __shfl_xor(s, 16, 64);
-                        s += __shfl_xor(s, 32, 64);
+                        s = sum_lane_rows(s);
                     }
                 }
                 w = t == 0 ? neg_bit(s) : (w | (neg_bit(s) << (8 * t)));
@@ -658,8 +657,7 @@ __global__ __launch_bounds__(MW * 64) void mask_logits_kernel(const float* __res
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float v = acc[QB - 1][row][r];
-                        v += __shfl_xor(v, 16, 64);
-                        v += __shfl_xor(v, 32, 64);
+                        v = sum_lane_rows(v);
                         acc[QB - 1][row][r] = v;
                     }
             }
