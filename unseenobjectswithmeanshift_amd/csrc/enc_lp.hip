@@ -638,6 +638,18 @@ __global__ __launch_bounds__(256) void f32_to_f16_kernel(const float4* __restric
     }
 }
 
+// the same for [B][n] rows that are contiguous inside an image but spaced by in_bs floats between images (a level's token range of the
+// encoder's concatenated buffer): one launch instead of a copy to contiguous + the conversion
+__global__ __launch_bounds__(256) void f32_to_f16_rows_kernel(const float4* __restrict__ in, u32x4* __restrict__ out, int64_t n8, int64_t in_bs4) {
+    const float4* src = in + (int64_t)blockIdx.y * in_bs4;
+    u32x4* dst = out + (int64_t)blockIdx.y * n8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const float4 a = src[2 * i], b = src[2 * i + 1];
+        const u32x2b ul = pack4h(a.x, a.y, a.z, a.w), uh = pack4h(b.x, b.y, b.z, b.w);
+        dst[i] = u32x4{ul.x, ul.y, uh.x, uh.y};
+    }
+}
+
 // ---- the encoder prologue of this plan (round 4) ----------------------------------------------------------------------------------
 // What precedes the first deformable-attention layer (msdeformattn.py:326-329 GroupNorm of the input projections, :60-75 level
 // concatenation, layer 0's value_proj / sampling_offsets / attention_weights linears, ops/modules/ms_deform_attn.py:95-104) with the
@@ -876,6 +888,18 @@ extern "C" int msm_f32_to_f16(const float* in, void* out, int64_t n, void* strea
     const int64_t n8 = n / 8;
     const int grid = (int)(n8 / 256 + 1 > 4096 ? 4096 : n8 / 256 + 1);
     hipLaunchKernelGGL(f32_to_f16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4*)in, (u32x4*)out, n8);
+    MSM_CHECK_LAUNCH(who);
+    return MSM_OK;
+}
+
+extern "C" int msm_f32_to_f16_rows(const float* in, void* out, int B, int64_t n, int64_t in_batch_stride, void* stream) {
+    const char* who = "msm_f32_to_f16_rows";
+    MSM_REQUIRE(in && out && B > 0 && B <= 65535 && n > 0 && n % 8 == 0 && in_batch_stride >= n && in_batch_stride % 4 == 0,
+                "%s: n=%lld must be a positive multiple of 8, the batch stride %lld a multiple of 4 floats >= n", who, (long long)n, (long long)in_batch_stride);
+    MSM_REQUIRE(((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0, "%s: pointers must be 16-byte aligned", who);
+    const int64_t n8 = n / 8;
+    const int grid = (int)(n8 / 256 + 1 > 1024 ? 1024 : n8 / 256 + 1);
+    hipLaunchKernelGGL(f32_to_f16_rows_kernel, dim3(grid, B), dim3(256), 0, (hipStream_t)stream, (const float4*)in, (u32x4*)out, n8, in_batch_stride / 4);
     MSM_CHECK_LAUNCH(who);
     return MSM_OK;
 }

@@ -630,7 +630,14 @@ def tokens_f16(x):
     _chk(x, "x")
     B, C, H, W = x.shape
     if is_token_major(x) and not x.is_contiguous():
-        return to_f16(x.permute(0, 2, 3, 1).reshape(B, H * W, C).contiguous())
+        t = x.permute(0, 2, 3, 1)                                  # (B, H, W, C) view: rows contiguous inside an image
+        n = H * W * C
+        if t.stride(3) == 1 and t.stride(2) == C and t.stride(1) == W * C and n % 8 == 0 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 and B <= 65535:
+            # a level's token range of a wider buffer (the encoder's concatenated levels): converted in place, one launch
+            out = torch.empty((B, H * W, C), device=x.device, dtype=torch.float16)
+            check(lib().msm_f32_to_f16_rows(_p(t), _p(out), B, n, t.stride(0), _stream()), "msm_f32_to_f16_rows")
+            return out
+        return to_f16(t.reshape(B, H * W, C).contiguous())
     x = x.contiguous()
     if C != 64:
         return to_f16(transpose_last2(x.view(B, C, H * W)))
