@@ -234,10 +234,15 @@ __global__ __launch_bounds__(WV * 64) void conv3x3_c64_kernel(const float* __res
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s[mt][r] += __shfl_xor(s[mt][r], o, 64);
-                    q[mt][r] += __shfl_xor(q[mt][r], o, 64);
+                {          // (over the 16-lane row in the order 1, 2, 4, 8 of the shfl_xor loop it replaces, on DPP: bitwise the same sums)
+                    s[mt][r] += wave_xor_dpp1(s[mt][r]);
+                    q[mt][r] += wave_xor_dpp1(q[mt][r]);
+                    s[mt][r] += wave_xor_dpp2(s[mt][r]);
+                    q[mt][r] += wave_xor_dpp2(q[mt][r]);
+                    s[mt][r] += wave_xor_dpp4(s[mt][r]);
+                    q[mt][r] += wave_xor_dpp4(q[mt][r]);
+                    s[mt][r] += wave_xor_dpp8(s[mt][r]);
+                    q[mt][r] += wave_xor_dpp8(q[mt][r]);
                 }
             }
         if (lj == 0) {
@@ -433,10 +438,15 @@ __global__ __launch_bounds__(C3S_W * 64) void conv3x3_c64_split_kernel(const uin
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s[mt][r] += __shfl_xor(s[mt][r], o, 64);
-                    q[mt][r] += __shfl_xor(q[mt][r], o, 64);
+                {          // (over the 16-lane row in the order 1, 2, 4, 8 of the shfl_xor loop it replaces, on DPP: bitwise the same sums)
+                    s[mt][r] += wave_xor_dpp1(s[mt][r]);
+                    q[mt][r] += wave_xor_dpp1(q[mt][r]);
+                    s[mt][r] += wave_xor_dpp2(s[mt][r]);
+                    q[mt][r] += wave_xor_dpp2(q[mt][r]);
+                    s[mt][r] += wave_xor_dpp4(s[mt][r]);
+                    q[mt][r] += wave_xor_dpp4(q[mt][r]);
+                    s[mt][r] += wave_xor_dpp8(s[mt][r]);
+                    q[mt][r] += wave_xor_dpp8(q[mt][r]);
                 }
             }
         if (lj == 0) {

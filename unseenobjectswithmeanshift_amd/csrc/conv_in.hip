@@ -170,10 +170,15 @@ __device__ __forceinline__ void conv_in_tile(const float* __restrict__ x, const 
         // per (wave >> 2, channel) -- no atomics below the per-workgroup double adds, so the sums are reproducible
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                sm[r] += __shfl_xor(sm[r], o, 64);
-                sq[r] += __shfl_xor(sq[r], o, 64);
+            {          // (over the 16-lane row in the order 1, 2, 4, 8 of the shfl_xor loop it replaces, on DPP: bitwise the same sums)
+                sm[r] += wave_xor_dpp1(sm[r]);
+                sq[r] += wave_xor_dpp1(sq[r]);
+                sm[r] += wave_xor_dpp2(sm[r]);
+                sq[r] += wave_xor_dpp2(sq[r]);
+                sm[r] += wave_xor_dpp4(sm[r]);
+                sq[r] += wave_xor_dpp4(sq[r]);
+                sm[r] += wave_xor_dpp8(sm[r]);
+                sq[r] += wave_xor_dpp8(sq[r]);
             }
         }
         if (lj == 0 && wave < RB) {
@@ -301,10 +306,15 @@ __global__ __launch_bounds__(WV * 64, 5) void conv_in_shallow_kernel(const float
             if (has_stats) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) {
-                        sm[r] += __shfl_xor(sm[r], o, 64);
-                        sq[r] += __shfl_xor(sq[r], o, 64);
+                    {          // (over the 16-lane row in the order 1, 2, 4, 8 of the shfl_xor loop it replaces, on DPP: bitwise the same sums)
+                        sm[r] += wave_xor_dpp1(sm[r]);
+                        sq[r] += wave_xor_dpp1(sq[r]);
+                        sm[r] += wave_xor_dpp2(sm[r]);
+                        sq[r] += wave_xor_dpp2(sq[r]);
+                        sm[r] += wave_xor_dpp4(sm[r]);
+                        sq[r] += wave_xor_dpp4(sq[r]);
+                        sm[r] += wave_xor_dpp8(sm[r]);
+                        sq[r] += wave_xor_dpp8(sq[r]);
                     }
                     if (lj == 0) {
                         st[(wave * CI_O + ch + r) * 2 + 0] = sm[r];
@@ -566,10 +576,15 @@ __device__ __forceinline__ void conv_in_lp_stream(const float* __restrict__ x, c
     for (int i = 0; i < (KSPLIT ? 1 : 4); ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                sm[i][r] += __shfl_xor(sm[i][r], o, 64);
-                sq[i][r] += __shfl_xor(sq[i][r], o, 64);
+            {          // (over the 16-lane row in the order 1, 2, 4, 8 of the shfl_xor loop it replaces, on DPP: bitwise the same sums)
+                sm[i][r] += wave_xor_dpp1(sm[i][r]);
+                sq[i][r] += wave_xor_dpp1(sq[i][r]);
+                sm[i][r] += wave_xor_dpp2(sm[i][r]);
+                sq[i][r] += wave_xor_dpp2(sq[i][r]);
+                sm[i][r] += wave_xor_dpp4(sm[i][r]);
+                sq[i][r] += wave_xor_dpp4(sq[i][r]);
+                sm[i][r] += wave_xor_dpp8(sm[i][r]);
+                sq[i][r] += wave_xor_dpp8(sq[i][r]);
             }
     if constexpr (KSPLIT) {
         if (lj == 0 && count > 0) {
