@@ -59,7 +59,7 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 17   /* 17: msm_f32_to_f16_rows; 16: msm_mask_conv3x3_folded (the UCN mask step with the 3x3 mask_features convolution folded into the query embedding); 15: IEEE-half operand forms of the 16-bit plan (precision "f16": msm_dec_*_f16, msm_encoder_block_hm_fwd ffn_f16, fp16 keys in the low-precision attention); 14: cmat_width argument of the K/V projections (separable position constants), msm_conv3x3_c64_nchw_bf16, msm_encoder_prologue_hm_fwd; 13: flags argument of msm_ms_select_seeds_bf16 (persistent on-chip seeding over the bf16 copy), input projections on the bf16 matrix pipe (msm_conv1x1_in_lp, msm_conv1x1_in_multi_lp); 12: head-major bf16 activations between the encoder kernels of the bf16 plan (msm_encoder_block_hm_fwd, msm_msdeform_attn_enc_lp_fwd, msm_f32_to_f16); 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
+#define MSM_ABI_VERSION 18   /* 18: flags argument of msm_attn_mask_pooled (bit 1: IEEE-half operands); 17: msm_f32_to_f16_rows; 16: msm_mask_conv3x3_folded (the UCN mask step with the 3x3 mask_features convolution folded into the query embedding); 15: IEEE-half operand forms of the 16-bit plan (precision "f16": msm_dec_*_f16, msm_encoder_block_hm_fwd ffn_f16, fp16 keys in the low-precision attention); 14: cmat_width argument of the K/V projections (separable position constants), msm_conv3x3_c64_nchw_bf16, msm_encoder_prologue_hm_fwd; 13: flags argument of msm_ms_select_seeds_bf16 (persistent on-chip seeding over the bf16 copy), input projections on the bf16 matrix pipe (msm_conv1x1_in_lp, msm_conv1x1_in_multi_lp); 12: head-major bf16 activations between the encoder kernels of the bf16 plan (msm_encoder_block_hm_fwd, msm_msdeform_attn_enc_lp_fwd, msm_f32_to_f16); 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
 int msm_abi_version(void);
 
 /* Kernel-selection overrides for tools/ and tests/ (NOT read on the product path: every option defaults to
@@ -648,12 +648,14 @@ int msm_conv1x1_in_multi_lp(int n_levels, const float* const* x, const void* con
  * msm_attn_mask_pooled: attn [B][Q][T] bytes = (sum_c embed[b][q][c] pooled[b][t][c] + qbias[b][q]) < 0 for the 64-column embedding
  *   (row stride embed_ld floats, batch stride Q * embed_ld; qbias NULL or element stride qbias_ld) and row_any [B][Q] = 1 where a
  *   row keeps an unmasked key (zeroed here unless row_any_cleared != 0).  Q <= 112.
- *   bits != 0 (T % 16 == 0): attn receives the mask bit-packed and blocked instead -- msm_attn_mask_bits_bytes(B, Q, T) bytes in the layout
- *   of msm_attn_pack_mask_bits, what msm_hypersphere_attn_fused_kv_fwd reads (word 7 of a query's eight is never written nor read). */
+ *   flags & 1 (T % 16 == 0): attn receives the mask bit-packed and blocked instead -- msm_attn_mask_bits_bytes(B, Q, T) bytes in the layout
+ *   of msm_attn_pack_mask_bits, what msm_hypersphere_attn_fused_kv_fwd reads (word 7 of a query's eight is never written nor read).
+ *   flags & 2 (ABI 18; 16-bit plans): embedding and pooled activation enter two v_mfma_f32_16x16x32_f16 as IEEE halves (clamped), fp32
+ *   accumulation, instead of sixteen dependent fp32 MFMAs per (query block, key block). */
 int msm_pool_mask_taps(const float* act, int B, int H, int W, int n_levels, const int32_t* th, const int32_t* tw,
                        float* const* out, int32_t* zero_buf, int64_t zero_count, void* stream);
 int msm_attn_mask_pooled(const float* embed, int64_t embed_ld, const float* qbias, int64_t qbias_ld, const float* pooled,
-                         uint8_t* attn, int32_t* row_any, int row_any_cleared, int bits, int B, int Q, int T, void* stream);
+                         uint8_t* attn, int32_t* row_any, int row_any_cleared, int flags, int B, int Q, int T, void* stream);
 
 /* The FPN output convolution (msdeformattn.py:264-279, 349-351: Conv2d(64, 64, 3, padding=1) in front of a GroupNorm):
  *   in / out [B][H*W][64] token maps, w_tap_major [64][9*64] with k = (dy*3 + dx)*64 + c_in (zero padding), no bias (a

@@ -222,6 +222,26 @@ def test_attention_masks_at_key_resolution(B, Q, H, W):
                     got_b, exp_b = got_b[..., live], exp_b[..., live]
                 assert torch.equal(got_b, exp_b)
             assert torch.equal(rab, row_any)
+        # f16=True (16-bit plans): embedding and pooled activation as IEEE halves on the 16-bit matrix pipe -- against float64 on the operands
+        # as rounded (bits decided wherever the logit is beyond the fp32 accumulation error), close to the fp32 form, both output layouts
+        h16 = lambda t: t.to(torch.float16).double()
+        ref_h = torch.einsum("bqc,btc->bqt", h16(wide[..., :64]), h16(ap.cpu())) + wide[..., 64].double()[..., None]
+        ah, rah = ops().attn_mask_pooled(wd[..., :64], ap, qbias=wd[..., 64], f16=True)
+        dh = ah.cpu().bool() != (ref_h < 0)
+        if dh.any():
+            assert ref_h[dh].abs().max() < 2e-5 * float(ref_h.abs().max())
+        assert dh.float().mean() <= 1e-4 and torch.equal(rah.cpu().bool(), ~ah.cpu().bool().all(-1))
+        assert float((ah != attn).float().mean()) < 2e-3                          # (the half rounding moves logits by ~1e-3 of their scale)
+        if (th * tw) % 16 == 0:
+            abh, rabh = ops().attn_mask_pooled(wd[..., :64], ap, qbias=wd[..., 64], bits=True, f16=True)
+            want_h = ops().attn_pack_mask_bits(ah)
+            for qc, nb in enumerate(nblk):
+                got_b, exp_b = abh[:, qc, :, :, :nb].cpu(), want_h[:, qc, :, :, :nb].cpu()
+                if Q % 16 and qc == len(nblk) - 1:
+                    live = (torch.arange(16)[:, None] + 16 * torch.arange(nb)[None] + 112 * qc) < Q
+                    got_b, exp_b = got_b[..., live], exp_b[..., live]
+                assert torch.equal(got_b, exp_b)
+            assert torch.equal(rabh, rah)
         _, attn_full, ra_full = ops().mask_logits(wd[..., :64], fd, want_mask=False, target_size=(th, tw), qbias=wd[..., 64])
         d2 = attn_full.cpu() != attn.cpu()
         if d2.any():

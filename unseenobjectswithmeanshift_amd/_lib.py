@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmsm_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "msm_hip.h")
 
 _lib = None
-ABI_VERSION = 17     # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
+ABI_VERSION = 18     # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
 
 c_f = ctypes.c_void_p      # float* (device)
 c_p = ctypes.c_void_p

@@ -16,6 +16,7 @@
 // step's FLOPs (SURVEY 8d names the shortcut -- "compute only the taps needed for the next attention mask on 9 of 10 calls" --
 // and how to report it: executed and reference FLOPs side by side).  Same arithmetic up to fp32 summation order (the mean of the
 // taps is taken before the contraction instead of after it).
+#include "bf16.h"
 #include "common.h"
 
 #ifndef AM_EXP
@@ -73,7 +74,10 @@ constexpr int AM_NQ = 2;             // query blocks per wave
 // BITS (round 5): the mask leaves bit-packed and blocked for msm_hypersphere_attn_fused_kv_fwd -- per 16-key block 256 bytes = [query lj][8 query
 // blocks of the 112-query chunk] 16-bit words, bit k = key 16 kb + k (msm_attn_pack_mask_bits' layout, T % 16 == 0) -- instead of bytes: the
 // four lane quarters of a query OR their nibbles together and one of them stores the word.
-template <bool VEC, bool BITS = false>
+// F16 (16-bit plans, round 5): the 64-channel contraction as two v_mfma_f32_16x16x32_f16 per (query block, key block) instead of sixteen
+// dependent v_mfma_f32_16x16x4_f32 -- embedding and pooled activation rounded to IEEE half (clamped) as the plans' full-resolution mask
+// step rounds them; the fp32 chain is ~1000 cycles of matrix-pipe latency per key block and the launch is all latency.
+template <bool VEC, bool BITS = false, bool F16 = false>
 __global__ __launch_bounds__(256) void attn_mask_pooled_kernel(const float* __restrict__ embed, int64_t embed_ld, const float* __restrict__ qbias,
                                                                int64_t qbias_ld, const float* __restrict__ pooled, uint8_t* __restrict__ attn,
                                                                int32_t* __restrict__ row_any, int Q, int T) {
@@ -83,45 +87,60 @@ __global__ __launch_bounds__(256) void attn_mask_pooled_kernel(const float* __re
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lj = lane & 15, lq = lane >> 4;
+    // a lane's 16 of the 64 channels: fp32 form channels 16 lq .. + 15; F16 form 8 lq .. + 7 and 32 + 8 lq .. + 7 (the two K = 32 steps)
+    constexpr int LQW = F16 ? 8 : 16;
+    auto off = [](int u) { return F16 ? (u >> 1) * 32 + (u & 1) * 4 : u * 4; };
     float4 w[AM_NQ][4];
+    f16x8 wh[AM_NQ][2];
     float qb[AM_NQ];
 #pragma unroll
     for (int m = 0; m < AM_NQ; ++m) {
         const int q = (qb0 + m) * 16 + lj;
-        const float* ep = embed + ((int64_t)b * Q + min(q, Q - 1)) * embed_ld + lq * 16;
+        const float* ep = embed + ((int64_t)b * Q + min(q, Q - 1)) * embed_ld + lq * LQW;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) w[m][u] = q < Q ? *reinterpret_cast<const float4*>(ep + u * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < 4; ++u) w[m][u] = q < Q ? *reinterpret_cast<const float4*>(ep + off(u)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (F16) {
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_)
+                wh[m][s_] = cvt8h(w[m][2 * s_].x, w[m][2 * s_].y, w[m][2 * s_].z, w[m][2 * s_].w, w[m][2 * s_ + 1].x, w[m][2 * s_ + 1].y, w[m][2 * s_ + 1].z,
+                                  w[m][2 * s_ + 1].w);
+        }
         qb[m] = (qbias && q < Q) ? qbias[(int64_t)b * Q * qbias_ld + (int64_t)q * qbias_ld] : 0.f;
     }
     const int nq = min(AM_NQ, (Q - qb0 * 16 + 15) / 16);    // query blocks that hold a query (uniform)
     unsigned anyu = 0;                                      // bit m: some key of query (qb0 + m)*16 + lj was left unmasked by this lane
     const int nkb = (T + 15) / 16;
-    const float* pb = pooled + (int64_t)b * T * AM_C + lq * 16;
+    const float* pb = pooled + (int64_t)b * T * AM_C + lq * LQW;
     uint8_t* ab = attn + (int64_t)b * Q * T;
     int kb = blockIdx.x * 4 + wave;
     float4 a[4], an[4];
     if (kb < nkb) {
         const float* ap = pb + (int64_t)min(kb * 16 + lj, T - 1) * AM_C;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(ap + u * 4);
+        for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(ap + off(u));
     }
     for (; kb < nkb; kb += gridDim.x * 4) {
         // the next block's keys are requested before this block's MFMAs (clamped: the last trip re-reads its own block)
         const int kn = min(kb + (int)gridDim.x * 4, nkb - 1);
         const float* apn = pb + (int64_t)min(kn * 16 + lj, T - 1) * AM_C;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) an[u] = *reinterpret_cast<const float4*>(apn + u * 4);
+        for (int u = 0; u < 4; ++u) an[u] = *reinterpret_cast<const float4*>(apn + off(u));
         const int key0 = kb * 16 + lq * 4;
 #pragma unroll
         for (int m = 0; m < AM_NQ; ++m) {
             if (m >= nq) break;
             f32x4 acc = f32x4{qb[m], qb[m], qb[m], qb[m]};
+            if constexpr (F16) {
+                acc = mfma_f16k32(cvt8h(a[0].x, a[0].y, a[0].z, a[0].w, a[1].x, a[1].y, a[1].z, a[1].w), wh[m][0], acc);
+                acc = mfma_f16k32(cvt8h(a[2].x, a[2].y, a[2].z, a[2].w, a[3].x, a[3].y, a[3].z, a[3].w), wh[m][1], acc);
+            } else {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                acc = mfma16(a[u].x, w[m][u].x, acc);
-                acc = mfma16(a[u].y, w[m][u].y, acc);
-                acc = mfma16(a[u].z, w[m][u].z, acc);
-                acc = mfma16(a[u].w, w[m][u].w, acc);
+                for (int u = 0; u < 4; ++u) {
+                    acc = mfma16(a[u].x, w[m][u].x, acc);
+                    acc = mfma16(a[u].y, w[m][u].y, acc);
+                    acc = mfma16(a[u].z, w[m][u].z, acc);
+                    acc = mfma16(a[u].w, w[m][u].w, acc);
+                }
             }
             const int q = (qb0 + m) * 16 + lj;
             // sigmoid(x) < 0.5  <=>  x < 0 (DEC:677)
@@ -195,7 +214,9 @@ extern "C" int msm_pool_mask_taps(const float* act, int B, int H, int W, int n_l
 }
 
 extern "C" int msm_attn_mask_pooled(const float* embed, int64_t embed_ld, const float* qbias, int64_t qbias_ld, const float* pooled,
-                                    uint8_t* attn, int32_t* row_any, int row_any_cleared, int bits, int B, int Q, int T, void* stream) {
+                                    uint8_t* attn, int32_t* row_any, int row_any_cleared, int flags, int B, int Q, int T, void* stream) {
+    const int bits = flags & 1;
+    MSM_REQUIRE((flags & ~3) == 0, "msm_attn_mask_pooled: flags=%d (1 = bit-packed output, 2 = IEEE-half operands)", flags);
     MSM_REQUIRE(embed && pooled && attn && row_any, "msm_attn_mask_pooled: null pointer");
     MSM_REQUIRE(!bits || (T % 16 == 0 && (((uintptr_t)attn) & 15) == 0), "msm_attn_mask_pooled: the bit-packed mask needs T %% 16 == 0 and a 16-byte aligned buffer");
     MSM_REQUIRE(B > 0 && Q > 0 && Q <= 65535 * 16 * AM_NQ && T > 0, "msm_attn_mask_pooled: bad sizes");
@@ -209,15 +230,18 @@ extern "C" int msm_attn_mask_pooled(const float* embed, int64_t embed_ld, const 
     // about one wave per SIMD of the chip over (images, pairs): 1024 / (B * zq) waves walk an image's key blocks for a pair
     const int wgs = max(1, min(cdiv(nkb, 4), max(1, 256 / (B * zq))));     // (128 / 512 / 1024 measured slower at 4800 keys: 20.4 / 12.9 / 14.8 against 12.6 us)
     const bool vec = T % 4 == 0 && (((uintptr_t)attn) & 3) == 0;
-    if (bits)
-        hipLaunchKernelGGL((attn_mask_pooled_kernel<true, true>), dim3(wgs, B, zq), dim3(256), 0, st, embed, embed_ld, qbias, qbias_ld, pooled, attn, row_any,
-                           Q, T);
-    else if (vec)
-        hipLaunchKernelGGL(attn_mask_pooled_kernel<true>, dim3(wgs, B, zq), dim3(256), 0, st, embed, embed_ld, qbias, qbias_ld, pooled, attn, row_any, Q,
-                           T);
-    else
-        hipLaunchKernelGGL(attn_mask_pooled_kernel<false>, dim3(wgs, B, zq), dim3(256), 0, st, embed, embed_ld, qbias, qbias_ld, pooled, attn, row_any,
-                           Q, T);
+    const bool f16 = (flags & 2) != 0;
+#define AM_LAUNCH(V_, B_, F_)                                                                                                                          \
+    hipLaunchKernelGGL((attn_mask_pooled_kernel<V_, B_, F_>), dim3(wgs, B, zq), dim3(256), 0, st, embed, embed_ld, qbias, qbias_ld, pooled, attn, row_any, \
+                       Q, T)
+    if (bits) {
+        if (f16) AM_LAUNCH(true, true, true); else AM_LAUNCH(true, true, false);
+    } else if (vec) {
+        if (f16) AM_LAUNCH(true, false, true); else AM_LAUNCH(true, false, false);
+    } else {
+        if (f16) AM_LAUNCH(false, false, true); else AM_LAUNCH(false, false, false);
+    }
+#undef AM_LAUNCH
     MSM_CHECK_LAUNCH("msm_attn_mask_pooled");
     return MSM_OK;
 }

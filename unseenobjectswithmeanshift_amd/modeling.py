@@ -302,6 +302,8 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         # row + column tables instead of a per-position matrix for the folded K/V constants (see _folded_kv)
         self.separable_kv_constants = True
         # mask_features handed over as FoldedMaskFeatures are contracted in their 64-channel factored form (fused tails only)
+        self.lp_pooled_masks = False           # opt-in (16-bit plans): attention masks at key resolution on IEEE-half operands -- 1207 against 1211 us per pass, and
+                                               # the mask bits feed back: "mask step only in 16 bits" loses its 0.3 % bound on one image of eight (fp32 operands stay the default)
         self.folded_mask_features = True
         self._fold_cache = None
         # the row-local ops between the attention cores run as three fused kernels per layer (csrc/dec_chain.hip)
@@ -622,7 +624,8 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             if tgt is not None and tuple(tgt) in pooled:
                 # (a layer whose cross-attention projects K / V itself reads its mask bit-packed: written that way here)
                 as_bits = fkv is not None and i_next < L and fkv["layers"][i_next] is not None
-                attn, row_any = ops.attn_mask_pooled(emb, pooled[tuple(tgt)], qbias=qb, row_any=ra, bits=as_bits)
+                attn, row_any = ops.attn_mask_pooled(emb, pooled[tuple(tgt)], qbias=qb, row_any=ra, bits=as_bits,
+                                                          f16=self.mask_step_dtype in ("bf16", "f16") and self.lp_pooled_masks)
                 m = None
                 if want:        # "always" with aux outputs: the full-resolution kernel only writes the mask
                     m = ops.mask_logits(emb, mask_features, want_mask=True, target_size=None, packed_bf16=self._packed_mf, qbias=qb,

@@ -482,14 +482,15 @@ def pool_mask_taps(act, sizes, zero_rows=0):
     return (outs, flags) if zero_rows else outs
 
 
-def attn_mask_pooled(mask_embed, pooled, *, qbias=None, row_any=None, bits=False):
+def attn_mask_pooled(mask_embed, pooled, *, qbias=None, row_any=None, bits=False, f16=False):
     """The next layer's attention mask from the pooled activation (pool_mask_taps): attn (B, Q, T) uint8 =
     (einsum('bqc,btc->bqt', mask_embed, pooled) + qbias[b, q]) < 0 and row_any (B, Q) int32 (1 where a row keeps an unmasked
     key).  mask_embed: (B, Q, 64), contiguous or the leading 64 columns of a wider row-major buffer; qbias (B, Q), any uniform
     element stride; row_any: an already ZEROED buffer (saves the fill launch).  Equal to the attention-mask output of
     mask_logits(..., target_size) on the unpooled activation up to fp32 summation order.
     ``bits`` (T % 16 == 0): attn comes back bit-packed and blocked instead -- int16 (B, ceil(Q / 112), T / 16, 16, 8), the layout of
-    attn_pack_mask_bits, what hypersphere_attention_fused_kv reads."""
+    attn_pack_mask_bits, what hypersphere_attention_fused_kv reads.  ``f16`` (16-bit plans): IEEE-half operands on the 16-bit matrix
+    pipe (fp32 accumulation) instead of the fp32 MFMA chain."""
     _chk(mask_embed, "mask_embed"), _c(pooled, "pooled"), _chk(qbias, "qbias")
     B, Q, C = mask_embed.shape
     T = pooled.shape[1]
@@ -514,7 +515,7 @@ def attn_mask_pooled(mask_embed, pooled, *, qbias=None, row_any=None, bits=False
     else:
         _c(row_any, "row_any", torch.int32)
     rc = lib().msm_attn_mask_pooled(_p(mask_embed), mask_embed.stride(1), _p(qbias), qb_ld, _p(pooled), _p(attn), _p(row_any),
-                                    1 if cleared else 0, 1 if bits else 0, B, Q, T, _stream())
+                                    1 if cleared else 0, (1 if bits else 0) | (2 if f16 else 0), B, Q, T, _stream())
     check(rc, "msm_attn_mask_pooled")
     return attn, row_any
 
