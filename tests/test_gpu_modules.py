@@ -762,6 +762,25 @@ def test_resnet50_backbone_on_gpu_and_end_to_end():
     model.backbone.gemm_1x1 = True
     for k in ("res2", "res3", "res4", "res5"):
         assert float((alt[k] - got[k]).abs().max()) < 1e-4 * float(ref[k].abs().max()), k
+    # the elementwise glue around the library convolutions (bias + ReLU, bias + residual + ReLU, the NCHW hand-over) runs as one HIP launch
+    # each (fused_epilogues, default; csrc/backbone_ops.hip): in fp32 the same maps as the torch ops up to the order bias / residual are added in
+    assert model.backbone.fused_epilogues
+    model.backbone.fused_epilogues = False
+    alt = model.backbone(images.to(DEV))
+    for k in ("res2", "res3", "res4", "res5"):
+        assert alt[k].is_contiguous() and float((alt[k] - got[k]).abs().max()) < 1e-5 * float(ref[k].abs().max()), k
+    # ... and in the bf16 mode (fp32 arithmetic, ONE rounding where the torch sequence rounds after the bias, after the add and after the
+    # ReLU) no further from the float64 maps than the torch sequence
+    model.backbone.backbone_dtype = "bf16"
+    torch_lp = model.backbone(images.to(DEV))
+    model.backbone.fused_epilogues = True
+    fused_lp = model.backbone(images.to(DEV))
+    model.backbone.backbone_dtype = "f32"
+    for k in ("res2", "res3", "res4", "res5"):
+        assert fused_lp[k].is_contiguous() and fused_lp[k].dtype == torch.float32
+        e_f = float((fused_lp[k].cpu().double() - ref[k]).abs().mean())
+        e_t = float((torch_lp[k].cpu().double() - ref[k]).abs().mean())
+        assert e_f <= 1.05 * e_t, (k, e_f, e_t)
     res = model([{"image": images.to(DEV)}])
     assert len(res) == 2 and res[0]["instances"].pred_masks.shape == (20, 64, 96)
     out, _ = model.sem_seg_head(got)

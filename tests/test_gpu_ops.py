@@ -352,6 +352,37 @@ def test_hypersphere_attention_low_precision(B, Lq, S, masked, kv_bf16):
     assert float((alt.cpu() - ref).abs().max()) < 3e-2
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 9, 13), (1, 256, 30, 40), (3, 2048, 2, 3), (1, 8, 1, 1)])
+def test_backbone_glue_kernels(B, C, H, W, dtype):
+    """msm_bias_act_nhwc / msm_nhwc_to_nchw_f32 (csrc/backbone_ops.hip): x = act(x + bias (+ residual)) in place on a channels_last map,
+    in fp32 arithmetic with one rounding to the map's dtype -- against float64 rounded once; the NCHW fp32 hand-over exact."""
+    x = rnd(B, C, H, W, seed=1).to(dtype).contiguous(memory_format=torch.channels_last)
+    r = rnd(B, C, H, W, seed=2).to(dtype).contiguous(memory_format=torch.channels_last)
+    b = rnd(C, seed=3).to(dtype)
+    for res in (None, r):
+        for relu in (True, False):
+            ref = x.double() + b.double()[None, :, None, None] + (0 if res is None else res.double())
+            ref = ref.clamp_min(0) if relu else ref
+            xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+            got = ops().bias_act_nhwc_(xd, b.to(DEV), None if res is None else res.to(DEV).contiguous(memory_format=torch.channels_last), relu)
+            assert got.data_ptr() == xd.data_ptr() and got.is_contiguous(memory_format=torch.channels_last)
+            if dtype == torch.float32:
+                close(got, ref.float(), rtol=1e-6, atol=1e-6)
+            else:
+                # one rounding of the exact sum: at most one bf16 ulp from the double result rounded to bf16 (fp32 accumulation in between)
+                want = ref.to(torch.bfloat16)
+                d = (got.cpu().float() - want.float()).abs()
+                assert float((d > 0).float().mean()) < 0.01 and bool((d <= want.float().abs() * 2.0 ** -7 + 1e-30).all())
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    planes = ops().nhwc_to_nchw_f32(xd)
+    assert planes.is_contiguous() and planes.dtype == torch.float32 and torch.equal(planes.cpu(), x.float().contiguous())
+    with pytest.raises(RuntimeError):
+        ops().bias_act_nhwc_(x.to(DEV).contiguous(), b.to(DEV)) if (H * W > 1 and C > 1) else (_ for _ in ()).throw(RuntimeError("n/a"))
+    with pytest.raises(RuntimeError):
+        ops().bias_act_nhwc_(xd, b.to(DEV)[: C // 2].contiguous())
+
+
 @pytest.mark.parametrize("B,Q,H,W", [(2, 100, 24, 48), (1, 20, 7, 16), (1, 112, 33, 80), (3, 37, 12, 160)])
 def test_mask_conv3x3_folded(B, Q, H, W):
     """msm_mask_conv3x3_folded (UCN path, 16-bit plans): mask = einsum(e, Conv3x3(64 -> 256, padding 1)(x)) (fpn.py:238-246, DEC:1012-1035)

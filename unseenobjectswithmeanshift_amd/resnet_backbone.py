@@ -116,6 +116,9 @@ class ResNet50Backbone(PlanAttributes, nn.Module):
         # hipBLASLt through torch.addmm, bias (+ ReLU) in its epilogue -- instead of MIOpen's convolution: batch 8 at 480x640 on one
         # MI355X 7.9 -> 5.8 ms in fp32, 5.9 -> 2.95 ms in bf16 (tools/probes/resnet_gemm_time.py); same arithmetic, another summation order
         self.gemm_1x1 = True
+        # the elementwise glue around the convolutions (bias + ReLU, bias + residual + ReLU, the NCHW fp32 hand-over) as one HIP launch each
+        # instead of the bias kernel MIOpen appends, F.relu, the residual add and the conversions: see csrc/backbone_ops.hip
+        self.fused_epilogues = True
 
     def output_shape(self):
         from .modeling import ShapeSpec
@@ -156,8 +159,20 @@ class ResNet50Backbone(PlanAttributes, nn.Module):
             return out
         (ws, bs), stages = self._plan()
         x = images.to(ws.dtype).contiguous(memory_format=torch.channels_last)
-        x = F.max_pool2d(F.relu(F.conv2d(x, ws, bs, stride=2, padding=3)), 3, stride=2, padding=1)
         gemm = self.gemm_1x1 and x.is_cuda
+        # the elementwise glue around the library convolutions in one launch each (csrc/backbone_ops.hip): a convolution's bias + ReLU,
+        # a block's bias + residual add + ReLU, the NHWC -> NCHW fp32 hand-over to the pixel decoder
+        fuse = self.fused_epilogues and x.is_cuda and ws.dtype in (torch.float32, torch.bfloat16)
+        if fuse:
+            from . import ops
+        cl = lambda t: t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
+
+        def conv_bias_relu(t, w, b, **kw):
+            if not fuse:
+                return F.relu(F.conv2d(t, w, b, **kw))
+            return ops.bias_act_nhwc_(cl(F.conv2d(t, w, None, **kw)), b, None, True)
+
+        x = F.max_pool2d(conv_bias_relu(x, ws, bs, stride=2, padding=3), 3, stride=2, padding=1)
 
         def conv1x1(t, wb, relu, stride=1):
             w, b = wb
@@ -176,9 +191,15 @@ class ResNet50Backbone(PlanAttributes, nn.Module):
             for c1, (w2, b2), c3, sc, stride in blocks:
                 st = stride[0] if isinstance(stride, tuple) else stride
                 y = conv1x1(x, c1, True)
-                y = F.relu(F.conv2d(y, w2, b2, stride=stride, padding=1))
-                y = conv1x1(y, c3, False)
-                x = F.relu(y + (x if sc is None else conv1x1(x, sc, False, st)))
+                y = conv_bias_relu(y, w2, b2, stride=stride, padding=1)
+                res = x if sc is None else conv1x1(x, sc, False, st)
+                if fuse and gemm:
+                    B_, _, H_, W_ = y.shape
+                    y3 = torch.mm(y.permute(0, 2, 3, 1).reshape(B_ * H_ * W_, -1), c3[0].flatten(1).t()).view(B_, H_, W_, -1).permute(0, 3, 1, 2)
+                    x = ops.bias_act_nhwc_(y3, c3[1], cl(res), True)              # conv3's bias, the residual and the block's ReLU in one pass
+                else:
+                    x = F.relu(conv1x1(y, c3, False) + res)
             if name in self.out_features:
-                out[name] = (x.float() if x.dtype == torch.bfloat16 else x).contiguous()      # NCHW planes for the pixel decoder's input projections (fp32 also in the bf16 mode)
+                # NCHW planes for the pixel decoder's input projections (fp32 also in the bf16 mode)
+                out[name] = ops.nhwc_to_nchw_f32(cl(x)) if fuse else (x.float() if x.dtype == torch.bfloat16 else x).contiguous()
         return out

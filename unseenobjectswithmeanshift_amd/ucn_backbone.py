@@ -74,6 +74,7 @@ class UCNBackbone(nn.Module):
         # "bf16" (MeanShiftMaskFormer.set_precision("bf16" / "f16")): the towers' convolutions run in bfloat16 through MIOpen (fp32
         # accumulation inside the library), the fusion add, the upsampling and the normalisation in fp32
         self.backbone_dtype = "f32"
+        self.fused_epilogues = True        # bias + ReLU / bias + residual + ReLU around the library convolutions as one HIP launch each
         self._folded = None
         self._lp = None
 
@@ -98,18 +99,29 @@ class UCNBackbone(nn.Module):
             self._folded = (key, plans)
         return self._folded[1]
 
-    @staticmethod
-    def _run(plan, x):
+    def _run(self, plan, x):
         (w, b), blocks, fcw, fcb = plan
         size = x.shape[2:]
-        x = F.relu(F.conv2d(x.contiguous(memory_format=torch.channels_last), w, b, stride=2, padding=3))
+        # the elementwise glue of a BasicBlock (resnet_dilated.py / torchvision BasicBlock.forward: bias + ReLU, bias + residual + ReLU) as one
+        # HIP launch each instead of the bias kernel MIOpen appends + F.relu + add + F.relu (csrc/backbone_ops.hip)
+        fuse = getattr(self, "fused_epilogues", True) and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16)
+        if fuse:
+            from . import ops
+        cl = lambda t: t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
+
+        def conv_act(t, wt, bs, res=None, **kw):
+            if not fuse:
+                y = F.conv2d(t, wt, bs, **kw)
+                return F.relu(y if res is None else y + res)
+            return ops.bias_act_nhwc_(cl(F.conv2d(t, wt, None, **kw)), bs.contiguous(), None if res is None else cl(res), True)
+
+        x = conv_act(x.contiguous(memory_format=torch.channels_last), w, b, stride=2, padding=3)
         x = F.max_pool2d(x, 3, stride=2, padding=1)
         for (w1, b1), (w2, b2), sc, stride, dil in blocks:
-            y = F.relu(F.conv2d(x, w1, b1, stride=stride, padding=dil, dilation=dil))
-            y = F.conv2d(y, w2, b2, padding=dil, dilation=dil)
+            y = conv_act(x, w1, b1, stride=stride, padding=dil, dilation=dil)
             if sc is not None:
                 x = F.conv2d(x, sc[0], sc[1], stride=stride)
-            x = F.relu(y + x)
+            x = conv_act(y, w2, b2, res=x, padding=dil, dilation=dil)
         x = F.conv2d(x, fcw, fcb).float()
         return F.interpolate(x, size=size, mode="bilinear", align_corners=True)      # nn.functional.upsample_bilinear
 
