@@ -581,7 +581,7 @@ def extra_configs(dev, args):
                                      "two_batches_in_flight": {"value": round(BATCH / t_2, 1), "ms_per_step": round(1e3 * t_2, 3)}}
         del g
     full.set_precision("f32")
-    out["configs[1] with backbone"] = {"workload": "batch 8, 640x480 RGB frames -> ResNet-50 (frozen BN folded, channels_last; 3x3 / 7x7 through MIOpen, 1x1 as hipBLASLt GEMMs) -> hot "
+    out["configs[1] with backbone"] = {"workload": "batch 8, 640x480 RGB frames -> ResNet-50 (frozen BN folded, channels_last; 3x3 / 7x7 through MIOpen, 1x1 as hipBLASLt GEMMs, bias / ReLU / residual glue as one HIP launch each) -> hot "
                                                    "path -> instances; reported separately from the hot-path figure",
                                        "value": bbres["hipgraph_f32"]["value"], "unit": "images/sec", "ms_per_step": bbres["hipgraph_f32"]["ms_per_step"],
                                        "variants": bbres}
