@@ -352,6 +352,35 @@ def test_hypersphere_attention_low_precision(B, Lq, S, masked, kv_bf16):
     assert float((alt.cpu() - ref).abs().max()) < 3e-2
 
 
+@pytest.mark.parametrize("B,h,w,H,W", [(2, 6, 8, 48, 64), (1, 60, 80, 480, 640), (3, 5, 7, 37, 50), (1, 1, 1, 8, 8)])
+def test_ucn_embedding_tail(B, h, w, H, W):
+    """msm_ucn_embedding_tail: upsample_bilinear (align_corners=True) of both towers' low-resolution maps, add fusion and the channel
+    normalisation(s) of lib/networks/SEG.py:97-117 / pretrained_meanshiftformer_model.py:298-300 in one pass, against the torch ops in
+    float64 (one tower, two towers; 0, 1, 2 normalisations)."""
+    a = rnd(B, 64, h, w, seed=1).contiguous(memory_format=torch.channels_last)
+    b = rnd(B, 64, h, w, seed=2).contiguous(memory_format=torch.channels_last)
+    up = lambda t: F.interpolate(t.double(), size=(H, W), mode="bilinear", align_corners=True)
+    for two in (False, True):
+        for norms in (0, 1, 2):
+            ref = up(a) + (up(b) if two else 0)
+            for _ in range(norms):
+                ref = F.normalize(ref, p=2, dim=1)
+            got = ops().ucn_embedding_tail(a.to(DEV), b.to(DEV) if two else None, (H, W), norms=norms)
+            assert got.shape == (B, 64, H, W) and got.is_contiguous() and got.dtype == torch.float32
+            # (the source coordinate scale * x is an fp32 product, as in at::native's kernel: a tap weight is good to ~1e-5 at x = 639)
+            close(got, ref.float(), rtol=1e-4, atol=5e-5)
+            # ... and torch's own fp32 kernels on the device give the same map
+            dev_ref = F.interpolate(a.to(DEV), size=(H, W), mode="bilinear", align_corners=True)
+            if two:
+                dev_ref = dev_ref + F.interpolate(b.to(DEV), size=(H, W), mode="bilinear", align_corners=True)
+            for _ in range(norms):
+                dev_ref = F.normalize(dev_ref, p=2, dim=1)
+            close(got, dev_ref.cpu(), rtol=1e-4, atol=5e-5)
+    # a map that is not channels_last is taken as well (copied once)
+    got2 = ops().ucn_embedding_tail(a.contiguous().to(DEV), None, (H, W), norms=1)
+    close(got2, F.normalize(up(a), p=2, dim=1).float(), rtol=1e-4, atol=5e-5)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,C,H,W", [(2, 64, 9, 13), (1, 256, 30, 40), (3, 2048, 2, 3), (1, 8, 1, 1)])
 def test_backbone_glue_kernels(B, C, H, W, dtype):

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmsm_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "msm_hip.h")
 
 _lib = None
-ABI_VERSION = 19     # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
+ABI_VERSION = 20     # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
 
 c_f = ctypes.c_void_p      # float* (device)
 c_p = ctypes.c_void_p
@@ -77,6 +77,7 @@ _SIGNATURES = {
     "msm_f32_to_f16": (c_i, [c_f, c_p, c_l, c_p]),
     "msm_bias_act_nhwc": (c_i, [c_p, c_p, c_p, c_i, c_l, c_i, c_i, c_p]),
     "msm_nhwc_to_nchw_f32": (c_i, [c_p, c_f, c_i, c_i, c_i, c_i, c_p]),
+    "msm_ucn_embedding_tail": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_p]),
     "msm_f32_to_f16_rows": (c_i, [c_f, c_p, c_i, c_l, c_l, c_p]),
     "msm_kv_project_f32": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_l, c_i, c_p]),
     "msm_kv_project_multi_f32": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),

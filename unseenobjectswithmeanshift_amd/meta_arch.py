@@ -319,7 +319,12 @@ class PretrainedMeanShiftMaskFormer(MeanShiftMaskFormer):
         and the post-processing; ``graphed(entry="inference_images")`` / ``pipelined`` replay exactly this."""
         if self.backbone is None:
             raise RuntimeError("inference_images needs a backbone")
-        feats = self.backbone(inputs["image"], None, inputs.get("depth") if self.use_depth else None)
+        depth = inputs.get("depth") if self.use_depth else None
+        if _accepts(self.backbone.forward, "renormalize"):
+            # PM:298-300 (F.normalize over channels) inside the backbone's fused tail: no further pass over the embedding
+            feats = {"res5": self.backbone(inputs["image"], None, depth, renormalize=True).float().contiguous()}
+            return self.inference(feats, image_size, padded_size)
+        feats = self.backbone(inputs["image"], None, depth)
         feats = feats.float().contiguous()
         if feats.is_cuda:
             feats = {"res5": ops.l2_normalize_nchw(feats)}                                # PM:298-300 (F.normalize over channels)

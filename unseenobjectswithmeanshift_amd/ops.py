@@ -1591,6 +1591,24 @@ def nhwc_to_nchw_f32(x):
     return out
 
 
+def ucn_embedding_tail(a, b=None, size=None, norms=1, eps=1e-12):
+    """The tail of the UCN RGB-D backbone in one pass (msm_ucn_embedding_tail): a, b (B, 64, h, w) fp32 channels_last maps of the two towers
+    (b None: one tower) -> (B, 64, H, W) contiguous fp32 = N(..N(upsample_bilinear(a) + upsample_bilinear(b))), align_corners=True,
+    N = F.normalize over the channels applied ``norms`` (0..2) times."""
+    if a.dtype != torch.float32 or not a.is_cuda or a.dim() != 4 or a.shape[1] != 64:
+        raise RuntimeError("ucn_embedding_tail: (B, 64, h, w) float32 maps on the GPU")
+    a = a if a.is_contiguous(memory_format=torch.channels_last) else a.contiguous(memory_format=torch.channels_last)
+    if b is not None:
+        if b.shape != a.shape or b.dtype != a.dtype or b.device != a.device:
+            raise RuntimeError("ucn_embedding_tail: the two towers' maps must match")
+        b = b if b.is_contiguous(memory_format=torch.channels_last) else b.contiguous(memory_format=torch.channels_last)
+    B, _, h, w = a.shape
+    H, W = int(size[0]), int(size[1])
+    out = torch.empty((B, 64, H, W), device=a.device, dtype=torch.float32)
+    check(lib().msm_ucn_embedding_tail(_p(a), _p(b), _p(out), B, h, w, H, W, int(norms), float(eps), _stream()), "msm_ucn_embedding_tail")
+    return out
+
+
 def to_f16(t):
     """fp32 -> fp16 (round to nearest even, clamped to the half range) on the HIP path (msm_f32_to_f16)."""
     _c(t, "t")

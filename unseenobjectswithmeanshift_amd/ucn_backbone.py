@@ -99,7 +99,7 @@ class UCNBackbone(nn.Module):
             self._folded = (key, plans)
         return self._folded[1]
 
-    def _run(self, plan, x):
+    def _run(self, plan, x, upsample=True):
         (w, b), blocks, fcw, fcb = plan
         size = x.shape[2:]
         # the elementwise glue of a BasicBlock (resnet_dilated.py / torchvision BasicBlock.forward: bias + ReLU, bias + residual + ReLU) as one
@@ -123,10 +123,14 @@ class UCNBackbone(nn.Module):
                 x = F.conv2d(x, sc[0], sc[1], stride=stride)
             x = conv_act(y, w2, b2, res=x, padding=dil, dilation=dil)
         x = F.conv2d(x, fcw, fcb).float()
+        if not upsample:
+            return x                                                                 # (the fused tail upsamples both towers at once)
         return F.interpolate(x, size=size, mode="bilinear", align_corners=True)      # nn.functional.upsample_bilinear
 
     @torch.no_grad()
-    def forward(self, img, label=None, depth=None):
+    def forward(self, img, label=None, depth=None, *, renormalize=False):
+        """``renormalize`` (not a reference argument): apply the channel normalisation once more, as the meta-arch does to the
+        backbone's output (pretrained_meanshiftformer_model.py:298-300) -- inside the fused tail instead of in another pass."""
         if self.training:
             raise NotImplementedError("UCNBackbone is an inference module (BatchNorm folded into the convolutions): call .eval()")
         plans = self._plan()
@@ -139,11 +143,20 @@ class UCNBackbone(nn.Module):
                 self._lp = (self._folded, [((c(w), c(b)), [((c(w1), c(b1)), (c(w2), c(b2)), None if sc is None else (c(sc[0]), c(sc[1])), st, dl)
                                                           for (w1, b1), (w2, b2), sc, st, dl in blocks], c(fcw), c(fcb)) for (w, b), blocks, fcw, fcb in plans])
             plans = self._lp[1]
+        if depth is not None and self.fcn_depth is None:
+            raise RuntimeError("this backbone was built without a depth tower")
+        if self.fused_epilogues and img.is_cuda and plans[0][2].shape[0] == 64:
+            # upsampling of both towers, add fusion and the normalisation(s) in ONE pass over the output (csrc/backbone_ops.hip,
+            # ucn_tail_kernel) instead of eight passes of torch ops over the full-resolution embedding
+            from . import ops
+            lo_a = self._run(plans[0], img.float().to(dt), upsample=False)
+            lo_b = self._run(plans[1], depth.float().to(dt), upsample=False) if depth is not None else None
+            return ops.ucn_embedding_tail(lo_a, lo_b, img.shape[2:], norms=(1 if self.normalize else 0) + (1 if renormalize else 0))
         feats = self._run(plans[0], img.float().to(dt))
         if depth is not None:
-            if self.fcn_depth is None:
-                raise RuntimeError("this backbone was built without a depth tower")
             feats = feats + self._run(plans[1], depth.float().to(dt))
         if self.normalize:
+            feats = F.normalize(feats, p=2, dim=1)
+        if renormalize:
             feats = F.normalize(feats, p=2, dim=1)
         return feats.contiguous()
