@@ -787,7 +787,7 @@ int msm_msdeform_attn_enc_lp_fused_fwd(const void* value_hm, const int64_t* spat
 /* fp32 -> fp16, round to nearest even, clamped to the half range; n a multiple of 8 */
 /* Elementwise glue of the backbones (csrc/backbone_ops.hip; the convolutions stay MIOpen / hipBLASLt calls):
  * msm_bias_act_nhwc: x[p][c] = act(x[p][c] + bias[c] (+ residual[p][c])) in place on a channels_last map of `pixels` x C values; dtype 0: fp32
- *   (C % 4 == 0), 1: bf16 (C % 8 == 0; bias and residual in the same type; fp32 arithmetic, one rounding); relu != 0: max(., 0).  Replaces
+ *   (C % 4 == 0), 1: bf16, 2: IEEE half (C % 8 == 0; bias and residual in the same type; fp32 arithmetic, one rounding); relu != 0: max(., 0).  Replaces
  *   the bias kernel MIOpen appends to a convolution, F.relu, the residual add and its ReLU of detectron2's BottleneckBlock forward.
  * msm_nhwc_to_nchw_f32: in [B][HW][C] (dtype as above) -> out [B][C][HW] fp32. */
 int msm_bias_act_nhwc(void* x, const void* bias, const void* residual, int relu, int64_t pixels, int C, int dtype, void* stream);

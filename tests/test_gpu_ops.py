@@ -381,11 +381,11 @@ def test_ucn_embedding_tail(B, h, w, H, W):
     close(got2, F.normalize(up(a), p=2, dim=1).float(), rtol=1e-4, atol=5e-5)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,C,H,W", [(2, 64, 9, 13), (1, 256, 30, 40), (3, 2048, 2, 3), (1, 8, 1, 1)])
 def test_backbone_glue_kernels(B, C, H, W, dtype):
-    """msm_bias_act_nhwc / msm_nhwc_to_nchw_f32 (csrc/backbone_ops.hip): x = act(x + bias (+ residual)) in place on a channels_last map,
-    in fp32 arithmetic with one rounding to the map's dtype -- against float64 rounded once; the NCHW fp32 hand-over exact."""
+    """msm_bias_act_nhwc / msm_nhwc_to_nchw_f32 (csrc/backbone_ops.hip): x = act(x + bias (+ residual)) in place on a channels_last map
+    (fp32, bf16, fp16), in fp32 arithmetic with one rounding to the map's dtype -- against float64 rounded once; the NCHW fp32 hand-over exact."""
     x = rnd(B, C, H, W, seed=1).to(dtype).contiguous(memory_format=torch.channels_last)
     r = rnd(B, C, H, W, seed=2).to(dtype).contiguous(memory_format=torch.channels_last)
     b = rnd(C, seed=3).to(dtype)
@@ -400,9 +400,10 @@ def test_backbone_glue_kernels(B, C, H, W, dtype):
                 close(got, ref.float(), rtol=1e-6, atol=1e-6)
             else:
                 # one rounding of the exact sum: at most one bf16 ulp from the double result rounded to bf16 (fp32 accumulation in between)
-                want = ref.to(torch.bfloat16)
+                want = ref.to(dtype)
                 d = (got.cpu().float() - want.float()).abs()
-                assert float((d > 0).float().mean()) < 0.01 and bool((d <= want.float().abs() * 2.0 ** -7 + 1e-30).all())
+                ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+                assert float((d > 0).float().mean()) < 0.01 and bool((d <= want.float().abs() * ulp + 1e-7).all())
     xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
     planes = ops().nhwc_to_nchw_f32(xd)
     assert planes.is_contiguous() and planes.dtype == torch.float32 and torch.equal(planes.cpu(), x.float().contiguous())

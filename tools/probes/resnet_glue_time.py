@@ -24,7 +24,7 @@ def timed(fn, n=10):
     return 1e3 * (time.perf_counter() - t0) / n
 
 
-for dt in ("bf16", "f32"):
+for dt in ("bf16", "f16", "f32"):
     bb.backbone_dtype = dt
     for fused in (False, True):
         bb.fused_epilogues = fused

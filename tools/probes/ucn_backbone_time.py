@@ -27,7 +27,7 @@ def timed(fn, n=10):
 
 
 ref = None
-for dt in ("bf16", "f32"):
+for dt in ("bf16", "f16", "f32"):
     bb.backbone_dtype = dt
     for fused in (False, True):
         bb.fused_epilogues = fused

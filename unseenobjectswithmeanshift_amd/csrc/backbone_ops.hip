@@ -14,9 +14,19 @@ namespace msm {
 __device__ __forceinline__ float bf2f(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
 
 // sixteen bytes per thread: 8 bf16 or 4 fp32 values of one pixel's channel run (C % 8 == 0 / C % 4 == 0)
-template <bool BF>
+// T: 0 fp32, 1 bf16, 2 IEEE half
+template <int T>
+__device__ __forceinline__ void unpack2(unsigned w, float& lo, float& hi) {
+    if constexpr (T == 1) {
+        lo = __uint_as_float(w << 16), hi = __uint_as_float(w & 0xffff0000u);
+    } else {
+        lo = half_lo(w), hi = half_hi(w);
+    }
+}
+template <int T>
 __global__ __launch_bounds__(256) void bias_act_nhwc_kernel(void* __restrict__ xv, const void* __restrict__ biasv, const void* __restrict__ resv,
                                                             int relu, int64_t nvec, int C) {
+    constexpr bool BF = T != 0;
     constexpr int V = BF ? 8 : 4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
         const int c0 = (int)((i * V) % C);
@@ -28,10 +38,9 @@ __global__ __launch_bounds__(256) void bias_act_nhwc_kernel(void* __restrict__ x
             if (resv) rw = reinterpret_cast<const u32x4b*>(resv)[i];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                v[2 * j] = __uint_as_float(xw[j] << 16) + __uint_as_float(bw[j] << 16);
-                v[2 * j + 1] = __uint_as_float(xw[j] & 0xffff0000u) + __uint_as_float(bw[j] & 0xffff0000u);
-                r[2 * j] = __uint_as_float(rw[j] << 16);
-                r[2 * j + 1] = __uint_as_float(rw[j] & 0xffff0000u);
+                float x0, x1, b0, b1;
+                unpack2<T>(xw[j], x0, x1), unpack2<T>(bw[j], b0, b1), unpack2<T>(rw[j], r[2 * j], r[2 * j + 1]);
+                v[2 * j] = x0 + b0, v[2 * j + 1] = x1 + b1;
             }
         } else {
             const float4 xw = reinterpret_cast<const float4*>(xv)[i];
@@ -46,9 +55,12 @@ __global__ __launch_bounds__(256) void bias_act_nhwc_kernel(void* __restrict__ x
             v[j] += r[j];
             if (relu) v[j] = fmaxf(v[j], 0.f);
         }
-        if constexpr (BF) {
+        if constexpr (T == 1) {
             const bf16x4 lo = pack4(v[0], v[1], v[2], v[3]), hi = pack4(v[4], v[5], v[6], v[7]);
             const u32x2b a = __builtin_bit_cast(u32x2b, lo), b = __builtin_bit_cast(u32x2b, hi);
+            reinterpret_cast<u32x4b*>(xv)[i] = u32x4b{a.x, a.y, b.x, b.y};
+        } else if constexpr (T == 2) {
+            const u32x2b a = pack4h(v[0], v[1], v[2], v[3]), b = pack4h(v[4], v[5], v[6], v[7]);       // (clamped to the half range)
             reinterpret_cast<u32x4b*>(xv)[i] = u32x4b{a.x, a.y, b.x, b.y};
         } else {
             reinterpret_cast<float4*>(xv)[i] = make_float4(v[0], v[1], v[2], v[3]);
@@ -57,7 +69,7 @@ __global__ __launch_bounds__(256) void bias_act_nhwc_kernel(void* __restrict__ x
 }
 
 // in [B][HW][C] (bf16 or fp32) -> out [B][C][HW] fp32: 32 x 32 tiles through LDS
-template <bool BF>
+template <int T>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_f32_kernel(const void* __restrict__ inv, float* __restrict__ out, int HW, int C) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z;
@@ -68,7 +80,9 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_f32_kernel(const void* __res
         float v = 0.f;
         if (p < HW && c < C) {
             const int64_t idx = ((int64_t)b * HW + p) * C + c;
-            v = BF ? bf2f(reinterpret_cast<const unsigned short*>(inv)[idx]) : reinterpret_cast<const float*>(inv)[idx];
+            if constexpr (T == 0) v = reinterpret_cast<const float*>(inv)[idx];
+            else if constexpr (T == 1) v = bf2f(reinterpret_cast<const unsigned short*>(inv)[idx]);
+            else v = half_lo((unsigned)reinterpret_cast<const unsigned short*>(inv)[idx]);
         }
         tile[k][tx] = v;
     }
@@ -143,14 +157,15 @@ using namespace msm;
 extern "C" int msm_bias_act_nhwc(void* x, const void* bias, const void* residual, int relu, int64_t pixels, int C, int dtype, void* stream) {
     const char* who = "msm_bias_act_nhwc";
     MSM_REQUIRE(x && bias && pixels > 0 && C > 0, "%s: bad arguments", who);
-    MSM_REQUIRE(dtype == 0 || dtype == 1, "%s: dtype=%d (0 = fp32, 1 = bf16)", who, dtype);
+    MSM_REQUIRE(dtype >= 0 && dtype <= 2, "%s: dtype=%d (0 = fp32, 1 = bf16, 2 = fp16)", who, dtype);
     const int V = dtype ? 8 : 4;
     MSM_REQUIRE(C % V == 0, "%s: C=%d must be a multiple of %d", who, C, V);
     MSM_REQUIRE(((((uintptr_t)x) | ((uintptr_t)bias) | ((uintptr_t)residual)) & 15) == 0, "%s: pointers must be 16-byte aligned", who);
     const int64_t nvec = pixels * C / V;
     const int grid = (int)(nvec / 256 + 1 > 8192 ? 8192 : nvec / 256 + 1);
-    if (dtype) hipLaunchKernelGGL(bias_act_nhwc_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, bias, residual, relu, nvec, C);
-    else hipLaunchKernelGGL(bias_act_nhwc_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, bias, residual, relu, nvec, C);
+    if (dtype == 1) hipLaunchKernelGGL(bias_act_nhwc_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, bias, residual, relu, nvec, C);
+    else if (dtype == 2) hipLaunchKernelGGL(bias_act_nhwc_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, bias, residual, relu, nvec, C);
+    else hipLaunchKernelGGL(bias_act_nhwc_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, bias, residual, relu, nvec, C);
     MSM_CHECK_LAUNCH(who);
     return MSM_OK;
 }
@@ -158,11 +173,12 @@ extern "C" int msm_bias_act_nhwc(void* x, const void* bias, const void* residual
 extern "C" int msm_nhwc_to_nchw_f32(const void* in, float* out, int B, int C, int HW, int dtype, void* stream) {
     const char* who = "msm_nhwc_to_nchw_f32";
     MSM_REQUIRE(in && out && B > 0 && B <= 65535 && C > 0 && HW > 0, "%s: bad arguments", who);
-    MSM_REQUIRE(dtype == 0 || dtype == 1, "%s: dtype=%d (0 = fp32, 1 = bf16)", who, dtype);
+    MSM_REQUIRE(dtype >= 0 && dtype <= 2, "%s: dtype=%d (0 = fp32, 1 = bf16, 2 = fp16)", who, dtype);
     MSM_REQUIRE(cdiv(HW, 32) <= 65535, "%s: H*W=%d too large", who, HW);
     dim3 grid(cdiv(C, 32), cdiv(HW, 32), B), block(256);
-    if (dtype) hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel<true>, grid, block, 0, (hipStream_t)stream, in, out, HW, C);
-    else hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel<false>, grid, block, 0, (hipStream_t)stream, in, out, HW, C);
+    if (dtype == 1) hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel<1>, grid, block, 0, (hipStream_t)stream, in, out, HW, C);
+    else if (dtype == 2) hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel<2>, grid, block, 0, (hipStream_t)stream, in, out, HW, C);
+    else hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel<0>, grid, block, 0, (hipStream_t)stream, in, out, HW, C);
     MSM_CHECK_LAUNCH(who);
     return MSM_OK;
 }

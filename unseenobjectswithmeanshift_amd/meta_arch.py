@@ -231,7 +231,7 @@ class MeanShiftMaskFormer(PlanAttributes, nn.Module):
         """See MeanShiftMaskFormerHead.set_precision; a backbone with a ``backbone_dtype`` switch (ResNet50Backbone) follows."""
         self.sem_seg_head.set_precision(mode)
         if hasattr(self.backbone, "backbone_dtype"):
-            self.backbone.backbone_dtype = "bf16" if mode in ("bf16", "f16") else "f32"
+            self.backbone.backbone_dtype = mode if mode in ("bf16", "f16") else "f32"     # ("f16": IEEE-half convolutions, as the reference's autocast)
         return self
 
     @property

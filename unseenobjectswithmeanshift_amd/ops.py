@@ -1562,12 +1562,15 @@ def proj_records_to_columns(rec, heads=8, LP=12):
     return torch.cat([off, lg], -1).contiguous()
 
 
+_GLUE_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
 def bias_act_nhwc_(x, bias, residual=None, relu=True):
     """In place on a channels_last (B, C, H, W) map (fp32 or bfloat16): x = act(x + bias[c] (+ residual)) in one pass
     (msm_bias_act_nhwc) -- the bias kernel MIOpen appends to a convolution, F.relu, the residual add and its ReLU of a ResNet block
     as ONE launch.  bias (C,) and residual (same shape and memory format) in x's dtype.  Returns x."""
-    if x.dtype not in (torch.float32, torch.bfloat16) or not x.is_cuda:
-        raise RuntimeError("bias_act_nhwc_: a float32 or bfloat16 map on the GPU")
+    if x.dtype not in _GLUE_DTYPES or not x.is_cuda:
+        raise RuntimeError("bias_act_nhwc_: a float32, bfloat16 or float16 map on the GPU")
     if x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last):
         raise RuntimeError("bias_act_nhwc_: x must be (B, C, H, W) in channels_last memory")
     B, C, H, W = x.shape
@@ -1576,18 +1579,18 @@ def bias_act_nhwc_(x, bias, residual=None, relu=True):
     if residual is not None and (residual.dtype != x.dtype or residual.shape != x.shape or residual.device != x.device
                                  or not residual.is_contiguous(memory_format=torch.channels_last)):
         raise RuntimeError("bias_act_nhwc_: residual must match x (shape, dtype, channels_last)")
-    check(lib().msm_bias_act_nhwc(_p(x), _p(bias), _p(residual), 1 if relu else 0, B * H * W, C, 1 if x.dtype == torch.bfloat16 else 0, _stream()),
+    check(lib().msm_bias_act_nhwc(_p(x), _p(bias), _p(residual), 1 if relu else 0, B * H * W, C, _GLUE_DTYPES[x.dtype], _stream()),
           "msm_bias_act_nhwc")
     return x
 
 
 def nhwc_to_nchw_f32(x):
     """A channels_last (B, C, H, W) map (fp32 or bfloat16) as contiguous NCHW fp32 planes in one pass (msm_nhwc_to_nchw_f32)."""
-    if x.dtype not in (torch.float32, torch.bfloat16) or not x.is_cuda or x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last):
-        raise RuntimeError("nhwc_to_nchw_f32: a channels_last float32 / bfloat16 (B, C, H, W) map on the GPU")
+    if x.dtype not in _GLUE_DTYPES or not x.is_cuda or x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last):
+        raise RuntimeError("nhwc_to_nchw_f32: a channels_last float32 / bfloat16 / float16 (B, C, H, W) map on the GPU")
     B, C, H, W = x.shape
     out = torch.empty((B, C, H, W), device=x.device, dtype=torch.float32)
-    check(lib().msm_nhwc_to_nchw_f32(_p(x), _p(out), B, C, H * W, 1 if x.dtype == torch.bfloat16 else 0, _stream()), "msm_nhwc_to_nchw_f32")
+    check(lib().msm_nhwc_to_nchw_f32(_p(x), _p(out), B, C, H * W, _GLUE_DTYPES[x.dtype], _stream()), "msm_nhwc_to_nchw_f32")
     return out
 
 

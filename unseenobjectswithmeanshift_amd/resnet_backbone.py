@@ -127,9 +127,9 @@ class ResNet50Backbone(PlanAttributes, nn.Module):
     def _plan(self):
         if self._plan_tensors is None:
             self._plan_tensors = TensorList.of(self, buffers=True)
-        if self.backbone_dtype not in ("f32", "bf16"):
-            raise ValueError("backbone_dtype must be 'f32' or 'bf16'")
-        low = self.backbone_dtype == "bf16"
+        if self.backbone_dtype not in ("f32", "bf16", "f16"):
+            raise ValueError("backbone_dtype must be 'f32', 'bf16' or 'f16'")
+        low = {"f32": None, "bf16": torch.bfloat16, "f16": torch.float16}[self.backbone_dtype]
         key = version_key(self._plan_tensors()) + (low,)
         if self._plan_cache is None or self._plan_cache[0] != key:
             with torch.no_grad():
@@ -138,8 +138,8 @@ class ResNet50Backbone(PlanAttributes, nn.Module):
                     stages.append([(blk.conv1.folded(), blk.conv2.folded(), blk.conv3.folded(),
                                     None if blk.shortcut is None else blk.shortcut.folded(), blk.conv2.stride) for blk in getattr(self, name)])
                 stem = self.stem.conv1.folded()
-                if low:
-                    cast = lambda wb: None if wb is None else (wb[0].to(torch.bfloat16).contiguous(memory_format=torch.channels_last), wb[1].to(torch.bfloat16))
+                if low is not None:
+                    cast = lambda wb: None if wb is None else (wb[0].to(low).contiguous(memory_format=torch.channels_last), wb[1].to(low))
                     stem = cast(stem)
                     stages = [[(cast(a), cast(b), cast(c), cast(sc), st) for a, b, c, sc, st in blocks] for blocks in stages]
                 self._plan_cache = (key, stem, stages)
@@ -162,7 +162,7 @@ class ResNet50Backbone(PlanAttributes, nn.Module):
         gemm = self.gemm_1x1 and x.is_cuda
         # the elementwise glue around the library convolutions in one launch each (csrc/backbone_ops.hip): a convolution's bias + ReLU,
         # a block's bias + residual add + ReLU, the NHWC -> NCHW fp32 hand-over to the pixel decoder
-        fuse = self.fused_epilogues and x.is_cuda and ws.dtype in (torch.float32, torch.bfloat16)
+        fuse = self.fused_epilogues and x.is_cuda and ws.dtype in (torch.float32, torch.bfloat16, torch.float16)
         if fuse:
             from . import ops
         cl = lambda t: t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
@@ -201,5 +201,5 @@ class ResNet50Backbone(PlanAttributes, nn.Module):
                     x = F.relu(conv1x1(y, c3, False) + res)
             if name in self.out_features:
                 # NCHW planes for the pixel decoder's input projections (fp32 also in the bf16 mode)
-                out[name] = ops.nhwc_to_nchw_f32(cl(x)) if fuse else (x.float() if x.dtype == torch.bfloat16 else x).contiguous()
+                out[name] = ops.nhwc_to_nchw_f32(cl(x)) if fuse else (x.float() if x.dtype in (torch.bfloat16, torch.float16) else x).contiguous()
         return out

@@ -71,8 +71,11 @@ class UCNBackbone(nn.Module):
         self.fcn = _Tower(num_units, in_channels)
         self.fcn_depth = _Tower(num_units, in_channels) if use_depth else None
         self.normalize = normalize
-        # "bf16" (MeanShiftMaskFormer.set_precision("bf16" / "f16")): the towers' convolutions run in bfloat16 through MIOpen (fp32
-        # accumulation inside the library), the fusion add, the upsampling and the normalisation in fp32
+        # "bf16" / "f16" (MeanShiftMaskFormer.set_precision("bf16") / ("f16")): the towers' convolutions run in bfloat16 / IEEE half through
+        # MIOpen (fp32 accumulation inside the library), the fusion add, the upsampling and the normalisation in fp32.  Half is what the
+        # reference's own low-precision mode runs convolutions in (torch.autocast on CUDA defaults to float16) and is the faster of the two here:
+        # MIOpen's bf16 solvers accumulate into an fp32 workspace they zero and cast around every convolution (4.1 against 6.4 ms for both
+        # towers at batch 2); activations beyond the half range saturate at 65504 in the fused epilogues
         self.backbone_dtype = "f32"
         self.fused_epilogues = True        # bias + ReLU / bias + residual + ReLU around the library convolutions as one HIP launch each
         self._folded = None
@@ -104,7 +107,7 @@ class UCNBackbone(nn.Module):
         size = x.shape[2:]
         # the elementwise glue of a BasicBlock (resnet_dilated.py / torchvision BasicBlock.forward: bias + ReLU, bias + residual + ReLU) as one
         # HIP launch each instead of the bias kernel MIOpen appends + F.relu + add + F.relu (csrc/backbone_ops.hip)
-        fuse = getattr(self, "fused_epilogues", True) and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16)
+        fuse = getattr(self, "fused_epilogues", True) and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16, torch.float16)
         if fuse:
             from . import ops
         cl = lambda t: t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
@@ -134,14 +137,14 @@ class UCNBackbone(nn.Module):
         if self.training:
             raise NotImplementedError("UCNBackbone is an inference module (BatchNorm folded into the convolutions): call .eval()")
         plans = self._plan()
-        if self.backbone_dtype not in ("f32", "bf16"):
-            raise ValueError("backbone_dtype must be 'f32' or 'bf16'")
-        dt = torch.bfloat16 if self.backbone_dtype == "bf16" else torch.float32
+        if self.backbone_dtype not in ("f32", "bf16", "f16"):
+            raise ValueError("backbone_dtype must be 'f32', 'bf16' or 'f16'")
+        dt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[self.backbone_dtype]
         if dt != torch.float32:                   # a 16-bit copy of the folded weights, made once per parameter version
-            if self._lp is None or self._lp[0] is not self._folded:
+            if self._lp is None or self._lp[0] is not self._folded or self._lp[2] != dt:
                 c = lambda t: None if t is None else t.to(dt)
                 self._lp = (self._folded, [((c(w), c(b)), [((c(w1), c(b1)), (c(w2), c(b2)), None if sc is None else (c(sc[0]), c(sc[1])), st, dl)
-                                                          for (w1, b1), (w2, b2), sc, st, dl in blocks], c(fcw), c(fcb)) for (w, b), blocks, fcw, fcb in plans])
+                                                          for (w1, b1), (w2, b2), sc, st, dl in blocks], c(fcw), c(fcb)) for (w, b), blocks, fcw, fcb in plans], dt)
             plans = self._lp[1]
         if depth is not None and self.fcn_depth is None:
             raise RuntimeError("this backbone was built without a depth tower")
