@@ -102,6 +102,36 @@ __device__ __forceinline__ unsigned or_lane_rows(unsigned v) {
     return b.x | b.y;
 }
 
+// max over the 64 lanes of a 64-bit key, every lane gets it (the seeding kernels' candidate reduction): the six butterfly stages on
+// v_permlane*_swap / DPP word pairs instead of twelve dependent ds_bpermute round trips; a max is the same whatever the order.
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+    typedef unsigned u32x2m __attribute__((ext_vector_type(2)));
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    {
+        const u32x2m a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        const unsigned long long x = ((unsigned long long)b.x << 32) | a.x, y = ((unsigned long long)b.y << 32) | a.y;
+        v = x > y ? x : y;
+    }
+    lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    {
+        const u32x2m a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        const unsigned long long x = ((unsigned long long)b.x << 32) | a.x, y = ((unsigned long long)b.y << 32) | a.y;
+        v = x > y ? x : y;
+    }
+#define MSM_U64_STAGE(FN)                                                                                                     \
+    {                                                                                                                         \
+        const unsigned ol = __float_as_uint(FN(__uint_as_float((unsigned)v))), oh = __float_as_uint(FN(__uint_as_float((unsigned)(v >> 32)))); \
+        const unsigned long long o = ((unsigned long long)oh << 32) | ol;                                                     \
+        v = o > v ? o : v;                                                                                                    \
+    }
+    MSM_U64_STAGE(wave_xor_dpp8)
+    MSM_U64_STAGE(wave_xor_dpp4)
+    MSM_U64_STAGE(wave_xor_dpp2)
+    MSM_U64_STAGE(wave_xor_dpp1)
+#undef MSM_U64_STAGE
+    return v;
+}
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 }  // namespace msm

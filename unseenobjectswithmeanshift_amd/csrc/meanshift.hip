@@ -94,27 +94,27 @@ __global__ __launch_bounds__(256) void ms_seed_step_kernel(const float* __restri
             const bool hi = j & 8;
             const float send = hi ? p[i] : p[i + 8];
             const float keep = hi ? p[i + 8] : p[i];
-            p[i] = keep + __shfl_xor(send, 8, 64);
+            p[i] = keep + wave_xor_dpp8(send);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool hi = j & 4;
             const float send = hi ? p[i] : p[i + 4];
             const float keep = hi ? p[i + 4] : p[i];
-            p[i] = keep + __shfl_xor(send, 4, 64);
+            p[i] = keep + wave_xor_dpp4(send);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const bool hi = j & 2;
             const float send = hi ? p[i] : p[i + 2];
             const float keep = hi ? p[i + 2] : p[i];
-            p[i] = keep + __shfl_xor(send, 2, 64);
+            p[i] = keep + wave_xor_dpp2(send);
         }
         {
             const bool hi = j & 1;
             const float send = hi ? p[0] : p[1];
             const float keep = hi ? p[1] : p[0];
-            p[0] = keep + __shfl_xor(send, 1, 64);
+            p[0] = keep + wave_xor_dpp1(send);
         }
         if (row < n) {
             const float d = fminf(near_now, 0.5f * (1.0f - p[0]));
@@ -123,11 +123,7 @@ __global__ __launch_bounds__(256) void ms_seed_step_kernel(const float* __restri
             best = key > best ? key : best;
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long other = __shfl_xor(best, o, 64);
-        best = other > best ? other : best;
-    }
+    best = wave_max_u64(best);
     if (lane == 0) red[wave] = best;
     __syncthreads();
     if (tid == 0) {
@@ -204,27 +200,27 @@ __global__ __launch_bounds__(256) void ms_seed_step_bf16_kernel(const uint16_t* 
             const bool hi = j & 8;
             const float send = hi ? p[i] : p[i + 8];
             const float keep = hi ? p[i + 8] : p[i];
-            p[i] = keep + __shfl_xor(send, 8, 64);
+            p[i] = keep + wave_xor_dpp8(send);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool hi = j & 4;
             const float send = hi ? p[i] : p[i + 4];
             const float keep = hi ? p[i + 4] : p[i];
-            p[i] = keep + __shfl_xor(send, 4, 64);
+            p[i] = keep + wave_xor_dpp4(send);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const bool hi = j & 2;
             const float send = hi ? p[i] : p[i + 2];
             const float keep = hi ? p[i + 2] : p[i];
-            p[i] = keep + __shfl_xor(send, 2, 64);
+            p[i] = keep + wave_xor_dpp2(send);
         }
         {
             const bool hi = j & 1;
             const float send = hi ? p[0] : p[1];
             const float keep = hi ? p[1] : p[0];
-            p[0] = keep + __shfl_xor(send, 1, 64);
+            p[0] = keep + wave_xor_dpp1(send);
         }
         if (row < n) {
             const float d = fminf(near_now, 0.5f * (1.0f - p[0]));
@@ -233,11 +229,7 @@ __global__ __launch_bounds__(256) void ms_seed_step_bf16_kernel(const uint16_t* 
             best = key > best ? key : best;
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long other = __shfl_xor(best, o, 64);
-        best = other > best ? other : best;
-    }
+    best = wave_max_u64(best);
     if (lane == 0) red[wave] = best;
     __syncthreads();
     if (tid == 0) {
@@ -269,26 +261,26 @@ __device__ __forceinline__ float butterfly16(float (&p)[16], int j) {
         const bool hi = j & 8;
         const float send = hi ? p[i] : p[i + 8];
         const float keep = hi ? p[i + 8] : p[i];
-        p[i] = keep + __shfl_xor(send, 8, 64);
+        p[i] = keep + wave_xor_dpp8(send);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const bool hi = j & 4;
         const float send = hi ? p[i] : p[i + 4];
         const float keep = hi ? p[i + 4] : p[i];
-        p[i] = keep + __shfl_xor(send, 4, 64);
+        p[i] = keep + wave_xor_dpp4(send);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const bool hi = j & 2;
         const float send = hi ? p[i] : p[i + 2];
         const float keep = hi ? p[i + 2] : p[i];
-        p[i] = keep + __shfl_xor(send, 2, 64);
+        p[i] = keep + wave_xor_dpp2(send);
     }
     const bool hi = j & 1;
     const float send = hi ? p[0] : p[1];
     const float keep = hi ? p[1] : p[0];
-    return keep + __shfl_xor(send, 1, 64);
+    return keep + wave_xor_dpp1(send);
 }
 
 // ---- the persistent kernels' per-step exchange, data-tagged (round 3: 10 -> 8.4 (fence-free counter) -> 5.6 us per step) ----
@@ -333,11 +325,7 @@ __device__ __forceinline__ unsigned long long ps_exchange(unsigned long long b, 
         }
         __builtin_amdgcn_s_sleep(1);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long other = __shfl_xor(win, o, 64);
-        win = other > win ? other : win;
-    }
+    win = wave_max_u64(win);
     return win;
 }
 
@@ -381,27 +369,27 @@ __global__ __launch_bounds__(PS_W * 64) void ms_seed_persistent_kernel(const flo
                 const bool hi = j & 8;
                 const float send = hi ? p[i] : p[i + 8];
                 const float keep = hi ? p[i + 8] : p[i];
-                p[i] = keep + __shfl_xor(send, 8, 64);
+                p[i] = keep + wave_xor_dpp8(send);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bool hi = j & 4;
                 const float send = hi ? p[i] : p[i + 4];
                 const float keep = hi ? p[i + 4] : p[i];
-                p[i] = keep + __shfl_xor(send, 4, 64);
+                p[i] = keep + wave_xor_dpp4(send);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const bool hi = j & 2;
                 const float send = hi ? p[i] : p[i + 2];
                 const float keep = hi ? p[i + 2] : p[i];
-                p[i] = keep + __shfl_xor(send, 2, 64);
+                p[i] = keep + wave_xor_dpp2(send);
             }
             {
                 const bool hi = j & 1;
                 const float send = hi ? p[0] : p[1];
                 const float keep = hi ? p[1] : p[0];
-                p[0] = keep + __shfl_xor(send, 1, 64);
+                p[0] = keep + wave_xor_dpp1(send);
             }
             if (rowj[t] < n) {
                 const float d = fminf(near[t], 0.5f * (1.0f - p[0]));
@@ -411,11 +399,7 @@ __global__ __launch_bounds__(PS_W * 64) void ms_seed_persistent_kernel(const flo
                 best = key > best ? key : best;
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long other = __shfl_xor(best, o, 64);
-            best = other > best ? other : best;
-        }
+        best = wave_max_u64(best);
         if (lane == 0) red[wave] = best;
         __syncthreads();
         if (wave == 0) {
@@ -546,11 +530,7 @@ __global__ __launch_bounds__(PS_W * 64) void ms_seed_persistent_bf16_kernel(cons
 #pragma unroll
             for (int i = 0; i < 16; ++i) xs[i] = *reinterpret_cast<const uint2*>(tail_src + i * MS_D);
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long other = __shfl_xor(best, o, 64);
-            best = other > best ? other : best;
-        }
+        best = wave_max_u64(best);
         if (lane == 0) red[wave] = best;
         __syncthreads();
         if (wave == 0) {
