@@ -959,6 +959,48 @@ def test_pipelined_inference_equals_eager():
         pipe.submit({k: v.cpu() for k, v in f1.items()}, (64, 96))
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16"])
+def test_pipelined_whole_models_equal_eager(precision):
+    """model.pipelined(depth, entry="inference_images"): the backbone in every slot's graph (what bench.py's "two batches in flight"
+    figures of the with-backbone and RGB-D entries run) -- the ResNet-50 model and the RGB-D UCN model, results equal to the eager call."""
+    import test_resnet_cpu as tr
+    from unseenobjectswithmeanshift_amd.meta_arch import build_resnet50_model, build_ucn_model
+    g = torch.Generator().manual_seed(8)
+    rn = build_resnet50_model()
+    tr._randomise(rn.backbone, seed=2)
+    rn.sem_seg_head.pixel_decoder.load_state_dict(syn.synth_state_dict(syn.pixel_decoder_param_shapes()), strict=True)
+    rn.sem_seg_head.predictor.load_state_dict(syn.synth_state_dict(syn.decoder_param_shapes()), strict=True)
+    um = build_ucn_model()
+    um.backbone.load_state_dict(syn.ucn_backbone_state_dict(syn.ucn_backbone_param_shapes(), salt=6), strict=True)
+    um.sem_seg_head.pixel_decoder.load_state_dict(syn.synth_state_dict({"mask_features.weight": (256, 64, 3, 3), "mask_features.bias": (256,)}, salt=3))
+    um.sem_seg_head.predictor.load_state_dict(syn.synth_state_dict(syn.decoder_param_shapes(dec_layers=6, num_feature_levels=1), salt=4))
+    cases = [(rn, lambda i: {"image": torch.randn(2, 3, 64, 96, generator=g)}, (64, 96)),
+             (um, lambda i: {"image": torch.randn(1, 3, 64, 96, generator=g), "depth": torch.rand(1, 3, 64, 96, generator=g)}, (64, 96))]
+    for model, make, size in cases:
+        model = model.to(DEV).eval()
+        model.set_precision(precision)
+        batches = [{k: v.to(DEV) for k, v in make(i).items()} for i in range(4)]
+        want = [[t.clone() for t in model.inference_images(b, size)] for b in batches]
+        pipe = model.pipelined(depth=2, entry="inference_images")
+        for i in range(0, 4, 2):
+            h0, h1 = pipe.submit(batches[i], size), pipe.submit(batches[i + 1], size)
+            for h, w in ((h1, want[i + 1]), (h0, want[i])):
+                for a, b in zip(pipe.result(h, wait="host"), w):
+                    assert a.shape == b.shape and a.dtype == b.dtype
+                    if precision != "f32":
+                        continue
+                    # (MIOpen may pick another algorithm for a convolution inside a capture: compared closely, not bitwise -- a 0 / 1 mask
+                    # pixel whose logit sits at zero may flip)
+                    if a.dim() == 4:
+                        assert float((a != b).float().mean()) < 1e-3
+                    elif a.dtype.is_floating_point:
+                        torch.testing.assert_close(a, b, rtol=2e-3, atol=2e-3)
+        pipe.drain()
+        gph = model.graphed(entry="inference_images")
+        out = gph(batches[0], size)
+        assert all(a.shape == b.shape for a, b in zip(out, want[0]))
+
+
 _TinyBackbone = syn.StandInBackbone      # test-only stand-in for the (out-of-scope) ResNet-50: right shapes, plain torch ops
 
 
