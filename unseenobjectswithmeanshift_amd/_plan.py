@@ -8,7 +8,7 @@ epoch counter, so a replay compares one integer instead of probing every module 
 PLAN_ATTRS = frozenset((
     "precision", "mask_step_dtype", "tails_dtype", "attention_dtype", "kv_split", "sparse_taps", "aux_outputs",
     "folded_mask_features", "batched_kv", "fold_kv", "fused_tails", "fused_encoder", "fused_front", "ffn_parts",
-    "fused_kv_attention", "tails_plan", "graphed", "backbone_dtype", "fused_msda", "pooled_attention_masks", "hm_activations", "lp_input_proj", "lp_prologue", "separable_kv_constants", "lp_operands", "attention_keys", "lp_conv3x3", "fused_kv_min_keys", "gemm_1x1", "fold_mask_conv", "lp_pooled_masks", "fused_epilogues",
+    "fused_kv_attention", "tails_plan", "graphed", "backbone_dtype", "fused_msda", "pooled_attention_masks", "hm_activations", "lp_input_proj", "lp_prologue", "separable_kv_constants", "lp_operands", "attention_keys", "lp_conv3x3", "fused_kv_min_keys", "gemm_1x1", "fold_mask_conv", "lp_pooled_masks", "fused_epilogues", "miopen_find",
     "test_topk_per_image", "topk_before_masks"))
 
 _epoch = [0]
@@ -136,3 +136,25 @@ def version_key(tensors):
     if not tensors:
         return (0, 0, 0)
     return (len(tensors), sum([t._version for t in tensors]), sum([t.data_ptr() for t in tensors]))
+
+
+# ---- MIOpen solver search, scoped ----------------------------------------------------------------------------------------------
+import contextlib
+
+
+@contextlib.contextmanager
+def miopen_find(on):
+    """Inside: torch.backends.cudnn.benchmark = True, i.e. MIOpen measures its solvers for a convolution shape at the first call instead of
+    picking one by heuristic ("find" mode); restored on exit.  (torch.backends.cudnn.flags() would also set the benchmark limit, which
+    MIOpen does not support and warns about.)"""
+    import torch
+    if not on:
+        yield
+        return
+    old = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = True
+    try:
+        yield
+    finally:
+        torch.backends.cudnn.benchmark = old
+
