@@ -29,9 +29,18 @@ def timed(fn, n=10):
 ref = None
 for dt in ("bf16", "f16", "f32"):
     bb.backbone_dtype = dt
-    for fused in (False, True):
-        bb.fused_epilogues = fused
+    for fused, par in ((False, False), (True, False), (True, True)):
+        bb.fused_epilogues, bb.parallel_towers = fused, par
         out = bb(img, None, dep)
         if not fused:
             ref = out
-        print(f"{dt} fused_epilogues={fused}: {timed(lambda: bb(img, None, dep)):.3f} ms" + ("" if not fused else f"; max |d| against the torch ops {float((out - ref).abs().max()):.2e}"), flush=True)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            g = torch.cuda.CUDAGraph()
+            bb(img, None, dep)
+            s.synchronize()
+            with torch.cuda.graph(g, stream=s):
+                bb(img, None, dep)
+        torch.cuda.synchronize()
+        print(f"{dt} fused_epilogues={fused} parallel_towers={par}: eager {timed(lambda: bb(img, None, dep)):.3f} ms, graph {timed(g.replay, 20):.3f} ms"
+              + ("" if not fused else f"; max |d| against the torch ops {float((out - ref).abs().max()):.2e}"), flush=True)

@@ -64,6 +64,16 @@ def _fold(conv, bn):
     return (conv.weight * scale[:, None, None, None]).contiguous(memory_format=torch.channels_last), bn.bias - bn.running_mean * scale
 
 
+_TOWER_STREAMS = {}
+
+
+def _tower_stream(device):
+    key = str(device)
+    if key not in _TOWER_STREAMS:
+        _TOWER_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _TOWER_STREAMS[key]
+
+
 class UCNBackbone(nn.Module):
     """``forward(img, label=None, depth=None) -> (B, num_units, H, W)`` unit-norm embedding, as SEGNET.forward for
     INPUT 'RGBD' / FUSION_TYPE 'add' (SEG.py:88-117); with ``depth=None`` only the colour tower runs (INPUT 'COLOR')."""
@@ -81,6 +91,7 @@ class UCNBackbone(nn.Module):
         self.backbone_dtype = "f32"
         self.fused_epilogues = True        # bias + ReLU / bias + residual + ReLU around the library convolutions as one HIP launch each
         self.miopen_find = True            # MIOpen measures its solvers per convolution shape at the first call (see forward)
+        self.parallel_towers = True        # the depth tower on a second stream beside the colour tower (see _forward)
         self._folded = None
         self._lp = None
 
@@ -160,8 +171,23 @@ class UCNBackbone(nn.Module):
             # upsampling of both towers, add fusion and the normalisation(s) in ONE pass over the output (csrc/backbone_ops.hip,
             # ucn_tail_kernel) instead of eight passes of torch ops over the full-resolution embedding
             from . import ops
-            lo_a = self._run(plans[0], img.float().to(dt), upsample=False)
-            lo_b = self._run(plans[1], depth.float().to(dt), upsample=False) if depth is not None else None
+            if depth is not None and getattr(self, "parallel_towers", True):
+                # the colour and the depth tower are independent (SEG.py:97-110): the depth tower runs on a second stream -- its 1/8-resolution
+                # convolutions are a few hundred tiles each and leave most of the chip idle on their own (a HIP-graph capture records the
+                # fork and the join as a parallel branch)
+                cur = torch.cuda.current_stream()
+                side = _tower_stream(img.device)
+                xd = depth.float().to(dt)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    lo_b = self._run(plans[1], xd, upsample=False)
+                lo_a = self._run(plans[0], img.float().to(dt), upsample=False)
+                cur.wait_stream(side)
+                lo_b.record_stream(cur)
+                xd.record_stream(side)
+            else:
+                lo_a = self._run(plans[0], img.float().to(dt), upsample=False)
+                lo_b = self._run(plans[1], depth.float().to(dt), upsample=False) if depth is not None else None
             return ops.ucn_embedding_tail(lo_a, lo_b, img.shape[2:], norms=(1 if self.normalize else 0) + (1 if renormalize else 0))
         feats = self._run(plans[0], img.float().to(dt))
         if depth is not None:
