@@ -75,14 +75,15 @@ def test_bench_launcher_spawns_ranks_gloo_stub():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 7 and rec["scaling"] == "weak" and rec["data"] == "stub"
     assert rec["config"]["global_batch"] == 16 and rec["config"]["parallelism"] == "dp2"
-    assert [p["rank"] for p in rec["per_rank"]] == [0, 1] and [p["images"] for p in rec["per_rank"]] == [56.0, 56.0]
+    assert len(lines[0].encode()) <= 8000                                   # the compact line (bench.compact_line), as the real run prints it
+    assert rec["per_rank"]["images"] == [56.0, 56.0] and len(rec["per_rank"]["images_per_sec"]) == 2
     # each rank's checksum comes from its own data (rank r multiplies matrices of r+1): 64*64*64*(r+1)^2
-    assert [p["checksum"] for p in rec["per_rank"]] == [64.0 ** 3, 4 * 64.0 ** 3]
+    assert rec["per_rank"]["checksum"] == [64.0 ** 3, 4 * 64.0 ** 3]
     assert rec["value"] > 0 and abs(rec["value"] - 112 / (rec["ms_per_step"] * 7e-3)) < 1e-2 * rec["value"]
     # the line explains its only collective: backend, the all_gather's own wall time, the spread of the ranks' timed regions
     col = rec["collective"]
     assert col["backend"] == "gloo" and col["world_size"] == 2 and col["all_gather_us"] > 0
-    assert set(col["per_rank_elapsed_s"]) == {"min", "max", "spread_pct", "slowest_rank"} and col["per_rank_elapsed_s"]["min"] <= col["per_rank_elapsed_s"]["max"]
+    assert col["spread_pct"] >= 0 and col["slowest_rank"] in (0, 1)
 
     # the size the driver's scaling run uses: eight ranks, one JSON line, every rank's record gathered
     r8 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--stub", "--steps", "3", "--warmup", "1"],
@@ -92,8 +93,9 @@ def test_bench_launcher_spawns_ranks_gloo_stub():
     assert len(lines) == 1
     rec8 = json.loads(lines[0])
     assert rec8["n_gpus"] == 8 and rec8["config"]["global_batch"] == 64 and rec8["config"]["parallelism"] == "dp8"
-    assert [p["rank"] for p in rec8["per_rank"]] == list(range(8)) and all(p["images"] == 24.0 for p in rec8["per_rank"])
-    assert [p["checksum"] for p in rec8["per_rank"]] == [(k + 1) ** 2 * 64.0 ** 3 for k in range(8)]
+    assert len(lines[0].encode()) <= 8000
+    assert rec8["per_rank"]["images"] == [24.0] * 8 and len(rec8["per_rank"]["images_per_sec"]) == 8
+    assert rec8["per_rank"]["checksum"] == [(k + 1) ** 2 * 64.0 ** 3 for k in range(8)]
     # under torch.distributed.run the ranks exist already (WORLD_SIZE set): a --gpus that disagrees is refused
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub"], capture_output=True, text=True,
                          timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0"), cwd=root)

@@ -294,3 +294,62 @@ def test_round4_weight_layouts_match_the_header_formulas():
     blocks, small = ops.pack_encoder_prologue_hm(torch.randn(64, 64, generator=g), torch.randn(288, 64, generator=g),
                                                  torch.randn(64, generator=g), torch.randn(288, generator=g))
     assert blocks.dtype == torch.int16 and blocks.numel() * 2 == 16384 + 18 * 4096 and small.numel() == 352
+
+
+def test_bench_line_fits_the_drivers_record():
+    """bench.compact_line: the ONE stdout line of bench.py stays within the 8 KB tail of stdout the driver's record keeps (round 5's
+    27 KB line was not parsed).  Built from a full result document with every optional entry present (tests/golden/bench_full_sample.json:
+    a real N = 1 run's document with eight per-rank records and an RCCL `collective` entry grafted on), then from one whose strings and
+    lists are inflated: at most 8000 bytes either way, valid JSON, the contract's keys and the flat roofline / cpu_baseline scalars present."""
+    import copy
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    with open(os.path.join(root, "tests", "golden", "bench_full_sample.json")) as f:
+        full = json.load(f)
+    assert len(json.dumps(full).encode()) > 20000                       # the document itself is far over the budget
+    line = bench.compact_line(copy.deepcopy(full), "gpurun_out/bench_full.json")
+    raw = json.dumps(line)
+    assert len(raw.encode()) <= bench.LINE_BUDGET == 8000 and "\n" not in raw
+    back = json.loads(raw)
+    assert back == line
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "steps_requested", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "collective", "summary"):
+        assert k in back, k
+    assert back["metric"] == bench.METRIC and back["config"]["workload"].startswith("configs[1]")
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "one_batch_in_flight_ms",
+              "mask_step_frac", "mask_step_avg_launch_ms", "mask_step_literal_frac"):
+        assert k in back["roofline"], k
+    assert abs(back["roofline"]["frac"] - back["roofline"]["achieved"] / back["roofline"]["peak"]) < 1e-3
+    for k in ("value", "unit", "cores", "kind", "sample", "pixel_decoder_ms", "decoder_ms", "post_process_ms", "mean_shift_images_per_sec"):
+        assert k in back["cpu_baseline"], k
+    assert back["summary"]["c2"]["dt"] == "f16" and back["summary"]["c2_bf16"]["dt"] == "bf16"
+    assert len(back["per_rank"]["images_per_sec"]) == 8 and back["collective"]["world_size"] == 8
+    assert all(len(v) <= 120 for v in _strings(back))                   # the driver truncates strings at 120 characters
+    # inflated: long strings everywhere, 64 ranks, a summary over its own budget -> still within the budget, contract keys intact
+    fat = copy.deepcopy(full)
+    fat["per_rank"] = [dict(fat["per_rank"][0], rank=i) for i in range(64)]
+    fat["config"]["workload"] = "w" * 5000
+    fat["roofline"]["kernel"] = "k" * 5000
+    fat["cpu_baseline"]["sample"] = "s" * 5000
+    fat["cpu_baseline"].pop("sample_short", None)
+    fat["collective"]["transport"] = "t" * 5000
+    fat["summary"] = {f"k{i}": {"v": float(i), "note": "n" * 100} for i in range(200)}
+    raw = json.dumps(bench.compact_line(fat, "gpurun_out/" + "d" * 500))
+    assert len(raw.encode()) <= 8000
+    back = json.loads(raw)
+    assert back["value"] == full["value"] and back["roofline"]["frac"] == full["roofline"]["frac"] and back["cpu_baseline"]["value"] == full["cpu_baseline"]["value"]
+
+
+def _strings(obj):
+    if isinstance(obj, str):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _strings(v)
+    elif isinstance(obj, list):
+        for v in obj:
+            yield from _strings(v)

@@ -142,19 +142,31 @@ def version_key(tensors):
 import contextlib
 
 
+_find_lock = __import__("threading").RLock()
+_find_depth = [0, False]            # nesting depth of active scopes, the flag's value before the outermost one
+
+
 @contextlib.contextmanager
 def miopen_find(on):
     """Inside: torch.backends.cudnn.benchmark = True, i.e. MIOpen measures its solvers for a convolution shape at the first call instead of
-    picking one by heuristic ("find" mode); restored on exit.  (torch.backends.cudnn.flags() would also set the benchmark limit, which
-    MIOpen does not support and warns about.)"""
+    picking one by heuristic ("find" mode).  The flag is process-global: scopes are counted under a lock, the outermost one saves the
+    previous value and the last one to leave restores it (two threads running backbones never restore each other's value).  While a HIP
+    graph is being captured the flag is left alone -- a solver search must not run inside a capture; the warm-up passes before the
+    capture have measured every shape.  (torch.backends.cudnn.flags() would also set the benchmark limit, which MIOpen does not support
+    and warns about.)"""
     import torch
-    if not on:
+    if not on or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
         yield
         return
-    old = torch.backends.cudnn.benchmark
-    torch.backends.cudnn.benchmark = True
+    with _find_lock:
+        if _find_depth[0] == 0:
+            _find_depth[1] = torch.backends.cudnn.benchmark
+            torch.backends.cudnn.benchmark = True
+        _find_depth[0] += 1
     try:
         yield
     finally:
-        torch.backends.cudnn.benchmark = old
-
+        with _find_lock:
+            _find_depth[0] -= 1
+            if _find_depth[0] == 0:
+                torch.backends.cudnn.benchmark = _find_depth[1]

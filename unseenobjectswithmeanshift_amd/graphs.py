@@ -14,7 +14,8 @@ import torch
 # attributes under which the modules keep derived tensors (packed weights, folded constants, position codes, broadcast
 # queries) that the kernels of a forward read by address
 _CACHE_ATTRS = ("_q0", "_kv_cache", "_fold_cache", "_tails_cache", "_pos_cache", "_cache", "_packed", "_front", "_w3_cache", "_wl_cache", "_iota", "_heads0_cache",
-                "_packed_mf", "_bf16_cache", "_folded_cache", "_conv_fold_cache")
+                "_packed_mf", "_bf16_cache", "_folded_cache", "_conv_fold_cache",
+                "_folded", "_lp", "_plan_cache")        # the backbones' folded / 16-bit weight copies (ucn_backbone.py, resnet_backbone.py)
 
 
 from ._plan import PLAN_ATTRS as _PLAN_ATTRS, TensorList, plan_epoch

@@ -491,6 +491,11 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                 out.append((int(th), int(tw)))
         return out
 
+    def _keys_f16(self):
+        """Whether the 16-bit plan's K rows are IEEE-half bit patterns (kv_format 2): ONE decision for the projection that writes them and
+        the attention kernels that read them.  The half-key form exists for 2E = 512 only; any other width keeps bf16 keys."""
+        return self.attention_dtype == "bf16" and self.attention_keys == "f16" and 2 * self.query_feat.weight.shape[1] == 512
+
     def _kv_one(self, x, w, cc):
         """One layer's folded K/V projection when the layers' K/V are not all resident at once (the 307 200-key UCN path): the
         plan's precision applies as in the batched form -- bf16 output from bf16 MFMAs in the bf16 mode, exact three-term splits
@@ -499,7 +504,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         if x.shape[1] == 64 and w.shape[0] in (256, 512):
             if self.attention_dtype == "bf16":
                 return ops.kv_project_multi([x], [w], [c], out_dtype=torch.bfloat16, cmat_widths=[cw],
-                                            keys_f16=self.attention_keys == "f16" and w.shape[0] == 512)[0]
+                                            keys_f16=self._keys_f16())[0]
             if self.kv_split:
                 return ops.kv_project_multi([x], [w], [c], split=True, cmat_widths=[cw])[0]
         return ops.kv_project(x, w, c, cw)
@@ -669,7 +674,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             sa = self.transformer_self_attention_layers[i]
             ff = self.transformer_ffn_layers[i]
             lp = self.attention_dtype == "bf16"
-            kf = lp and self.attention_keys == "f16"
+            kf = self._keys_f16()
             if fkv is not None and fkv["layers"][i] is not None:
                 # K / V of this level are projected inside the attention kernel and never stored
                 o = ops.hypersphere_attention_fused_kv(q, fkv["x"][lvl], *fkv["layers"][i], sizes[lvl], H, masked=attn, row_any=row_any,
@@ -746,7 +751,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                                                    out_dtype=torch.bfloat16 if self.attention_dtype == "bf16" else torch.float32,
                                                    split=self.kv_split and self.attention_dtype != "bf16",
                                                    cmat_widths=[cw for _, cw in jc],
-                                                   keys_f16=self.attention_dtype == "bf16" and self.attention_keys == "f16")):
+                                                   keys_f16=self._keys_f16())):
                         kv_all[i] = kv
         else:
             for i in range(self.num_feature_levels):

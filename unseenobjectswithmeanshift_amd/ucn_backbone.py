@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ._plan import miopen_find
+from ._plan import PlanAttributes, miopen_find
 
 STAGES = ((64, 3, 1, 1), (128, 4, 2, 1), (256, 6, 1, 2), (512, 3, 1, 4))   # (planes, blocks, stride, dilation) at output stride 8
 
@@ -74,7 +74,7 @@ def _tower_stream(device):
     return _TOWER_STREAMS[key]
 
 
-class UCNBackbone(nn.Module):
+class UCNBackbone(PlanAttributes, nn.Module):
     """``forward(img, label=None, depth=None) -> (B, num_units, H, W)`` unit-norm embedding, as SEGNET.forward for
     INPUT 'RGBD' / FUSION_TYPE 'add' (SEG.py:88-117); with ``depth=None`` only the colour tower runs (INPUT 'COLOR')."""
 
