@@ -27,6 +27,7 @@ class Pred(Network_RGBD):
 
 
 p = Pred(rgbd)
+rgbd.set_precision(os.environ.get("MSM_PRECISION", "f32"))
 gen = torch.Generator().manual_seed(3)
 samples = [{"image_color": torch.rand(3, H, W, generator=gen).to(dev), "depth": torch.rand(3, H, W, generator=gen).to(dev)} for _ in range(16)]
 for _ in range(6):

@@ -292,7 +292,12 @@ class StandInBackbone(torch.nn.Module):
         if x.shape[1] == 3:
             x = torch.cat([x, x], 1)
         out = {}
+        p, prev = x, 1
         for name, s, w in zip(("res2", "res3", "res4", "res5"), (4, 8, 16, 32), self.mix):
-            p = torch.nn.functional.avg_pool2d(x, s)
-            out[name] = torch.relu(torch.einsum("oc,bchw->bohw", w, p)).contiguous()
+            # the pyramid level by pooling the previous level (the full-resolution input is read once, not four times) and the 1x1
+            # mixing as one batched matmul that writes NCHW directly (an einsum leaves a permuted result that .contiguous() copies)
+            p = torch.nn.functional.avg_pool2d(p, s // prev)
+            prev = s
+            b, c, h, ww = p.shape
+            out[name] = torch.matmul(w, p.reshape(b, c, h * ww)).relu_().view(b, -1, h, ww)
         return out

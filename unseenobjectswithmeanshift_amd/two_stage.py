@@ -368,33 +368,41 @@ def _paste_batched(renum, rows, order, frame_start, frames, H, W):
     return refined
 
 
-def match_label_crop_batched(initial_masks, labels_crop, out_label_crop, rows, depth_crop):
-    """match_label_crop for the crops of a whole batch of frames: initial_masks (F,H,W), labels_crop / out_label_crop
-    (N,S,S), rows = roi_table(...) (crop n belongs to frame rows[n][0]), depth_crop (N,3,S,S) or None.
-    Returns refined (F,H,W).  Same arithmetic per frame as match_label_crop; the renumbering restarts at 1 in every frame."""
-    Fr, H, W = initial_masks.shape
+def _match_pre(labels_crop, out_label_crop, depth_crop):
+    """Device half of match_label_crop_batched, before the paste order is known: the overlap test (second-stage segments that cover
+    the first-stage mask by < 50 % are set to -1 in ``labels_crop``, in place) and the crops' sort keys (mean valid depth of the
+    surviving segments, fp64; None without depth).  -> (area (N*k,), bad (N*k,), lab (N, S*S) indices into them, keys (N,) or None).
+    No host transfer, no data-dependent shape: this half is captured in the second-stage HIP graph of BatchedTwoStage."""
     num = labels_crop.shape[0]
-    dev = labels_crop.device
-    if num == 0:
-        return torch.zeros_like(initial_masks).float()
     k = int(LABEL_BINS)
     stats, hit, _ = label_stats(labels_crop, out_label_crop)
     area = stats[:, :, 0].reshape(-1)
-    lab = labels_crop.reshape(num, -1).to(torch.int64).clamp(0, k - 1) + torch.arange(num, device=dev)[:, None] * k
+    lab = labels_crop.reshape(num, -1).to(torch.int64).clamp(0, k - 1) + torch.arange(num, device=labels_crop.device)[:, None] * k
     bad = (hit.reshape(-1) / area.float().clamp_min(1.0) < 0.5) & (area > 0)
     labels_crop.masked_fill_(bad[lab].view_as(labels_crop), -1)
-    frame_of = [r[0] for r in rows]
+    keys = None
     if depth_crop is not None:
         sel = (labels_crop > -1).reshape(num, -1)
         z = depth_crop[:, 2].reshape(num, -1)
         use = (sel | ~sel.any(1, keepdim=True)) & (z > 0)
-        keys = ((z * use).sum(1, dtype=torch.float64) / use.sum(1)).tolist()            # the batch's second (last) transfer
-    else:
-        keys = [float((r[5] - r[3] + 1) * (r[4] - r[2] + 1)) for r in rows]
+        keys = (z * use).sum(1, dtype=torch.float64) / use.sum(1)                       # 0/0 = nan like mean of nothing
+    return area, bad, lab, keys
+
+
+def _match_post(area, bad, lab, keys, rows, frames, H, W, crop_shape):
+    """Host-ordered half: ``keys`` (list of floats, one per crop of ``rows``) -> paste order inside every frame, renumbering, paste.
+    area / bad / lab may describe MORE crops than len(rows) (a padded second-stage batch): only the first len(rows) are used."""
+    num = len(rows)
+    k = int(LABEL_BINS)
+    dev = lab.device
+    area, bad, lab = area.view(-1, k)[:num].reshape(-1), bad.view(-1, k)[:num].reshape(-1), lab[:num]
+    frame_of = [r[0] for r in rows]
     # paste order inside a frame: descending key, ties and NaN exactly as sorted(reverse=True) leaves them in match_label_crop
     order, frame_start = [], [0]
-    for f in range(Fr):
-        mine = [n for n in range(num) if frame_of[n] == f]
+    by_frame = [[] for _ in range(frames)]
+    for n, f in enumerate(frame_of):
+        by_frame[f].append(n)
+    for mine in by_frame:
         order += [mine[i] for i, _ in sorted(enumerate([keys[n] for n in mine]), key=lambda t: t[1], reverse=True)]
         frame_start.append(len(order))
     order_t = torch.tensor(order, device=dev)
@@ -404,8 +412,23 @@ def match_label_crop_batched(initial_masks, labels_crop, out_label_crop, rows, d
     before = torch.cat([c.new_zeros(1), c[:, -1]])[torch.tensor([frame_start[frame_of[n]] for n in order], device=dev)]
     number = torch.zeros((num, k), dtype=torch.float32, device=dev)
     number[order_t] = ((c - before[:, None]) * alive).float()
-    renum = number.view(-1)[lab].view(num, *labels_crop.shape[1:]).contiguous()
-    return _paste_batched(renum, rows, order, frame_start, Fr, H, W)
+    renum = number.view(-1)[lab].view(num, *crop_shape).contiguous()
+    return _paste_batched(renum, rows, order, frame_start, frames, H, W)
+
+
+def match_label_crop_batched(initial_masks, labels_crop, out_label_crop, rows, depth_crop):
+    """match_label_crop for the crops of a whole batch of frames: initial_masks (F,H,W), labels_crop / out_label_crop
+    (N,S,S), rows = roi_table(...) (crop n belongs to frame rows[n][0]), depth_crop (N,3,S,S) or None.
+    Returns refined (F,H,W).  Same arithmetic per frame as match_label_crop; the renumbering restarts at 1 in every frame."""
+    Fr, H, W = initial_masks.shape
+    if labels_crop.shape[0] == 0:
+        return torch.zeros_like(initial_masks).float()
+    area, bad, lab, keys = _match_pre(labels_crop, out_label_crop, depth_crop)
+    if keys is not None:
+        keys = keys.tolist()                                                             # the batch's second (last) transfer
+    else:
+        keys = [float((r[5] - r[3] + 1) * (r[4] - r[2] + 1)) for r in rows]
+    return _match_post(area, bad, lab, keys, rows, Fr, H, W, tuple(labels_crop.shape[1:]))
 
 
 def test_batch_crop_nolabel(samples, predictor, predictor_crop=None, *, use_depth=True, topk=False, confident_score=0.7,
@@ -448,3 +471,208 @@ def test_batch_crop_nolabel(samples, predictor, predictor_crop=None, *, use_dept
         stages.update(rgb_crop=rgb_crop, mask_crop=mask_crop, depth_crop=depth_crop, labels_crop=labels_crop.clone())
     refined = match_label_crop_batched(out_label, labels_crop, mask_crop, rows, depth_crop)
     return out_label, refined, rows
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# configs[3] as a replayable pipeline: both stages from captured HIP graphs, the two device -> host transfers of a batch
+# overlapped with the other batch in flight.
+# ----------------------------------------------------------------------------------------------------------------------
+class BatchedTwoStage:
+    """test_batch_crop_nolabel (non-NMS form, lib/fcn/test_utils.py:339-421 per frame) for batches of ``frames`` frames of one
+    size, with the model called directly (``model.inference_images``: backbone + head + post-processing) and both stages replayed
+    from HIP graphs:
+
+      graph 1   frames -> model -> label images -> depth filter -> label statistics -> pinned host buffer   (fixed shapes)
+      host      ROI table from the statistics (test_dataset.py:76-92), uploaded into the slot's table buffer
+      graph 2   (one per crop-count BUCKET: the N crops of a batch are padded to the next multiple of ``bucket`` (16) with copies of
+                crop 0, whose results are ignored) every ROI cut and resized -> model -> crop label images -> overlap test ->
+                the crops' depth keys -> pinned host buffer
+      host      paste order from the keys; renumbering + paste-back launches (eager: their shapes depend on N)
+
+    ``run(batches)`` keeps TWO batches in flight (two slots, one stream each): while the host waits for one slot's statistics
+    or keys, the GPU works on the other slot.  ``__call__(samples)`` runs one batch on slot 0.  Per frame the results are those
+    of test_batch_crop_nolabel up to the batch-size dependence of the head's reduction orders (a padded second-stage batch is a
+    different batch size: tests hold the pipeline to the same oracle bounds as the eager form).
+
+    The captured graphs follow the model's execution plan: a plan switch (set_precision, ...) or a parameter update re-captures
+    (graphs.StaleCheck)."""
+
+    def __init__(self, model, frames, size, *, use_depth=True, topk=False, confident_score=0.7, low_threshold=0.4, num_class=2,
+                 depth_threshold=0.5, bucket=16, crop_size=CROP_SIZE, slots=2, graphs=True):
+        from .graphs import StaleCheck, _slot_stream
+        self.model = model
+        self.frames, (self.H, self.W) = int(frames), (int(size[0]), int(size[1]))
+        self.use_depth = bool(use_depth)
+        self.kw = dict(topk=topk, confident_score=confident_score, low_threshold=low_threshold, num_class=num_class)
+        self.depth_threshold = float(depth_threshold)
+        self.bucket, self.crop_size, self.use_graphs = int(bucket), int(crop_size), bool(graphs)
+        self._sig = StaleCheck(model)
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("BatchedTwoStage needs the model on the GPU (there is no CPU path)")
+        self.dev = dev
+        self._slots = [self._new_slot(_slot_stream(dev, i)) for i in range(max(1, int(slots)))]
+
+    # ---- slot state ----
+    def _new_slot(self, stream):
+        Fr, H, W, dev = self.frames, self.H, self.W, self.dev
+        k = int(LABEL_BINS)
+        with torch.cuda.stream(stream):
+            st = dict(stream=stream, sig=None, g1=None, g2={}, label=None, s2={},
+                      images=torch.zeros((Fr, 3, H, W), device=dev), depths=torch.zeros((Fr, 3, H, W), device=dev) if self.use_depth else None,
+                      thr=torch.full((Fr, 1), self.depth_threshold, device=dev), thr_host=[self.depth_threshold] * Fr,
+                      host_stats=torch.zeros(Fr * k * 5 + Fr, dtype=torch.int32).pin_memory(),
+                      ev1=torch.cuda.Event(), ev2=torch.cuda.Event(), rows=None, n=0, nb=0)
+        return st
+
+    def _predict(self, images, depths):
+        inputs = {"image": images}
+        if depths is not None:
+            inputs["depth"] = depths
+        sc, cl, mk = self.model.inference_images(inputs, tuple(int(v) for v in images.shape[-2:]))[:3]
+        return sc, cl, mk
+
+    def _stage1(self, st):
+        sc, cl, mk = self._predict(st["images"], st["depths"])
+        lab = _label_image_batched(mk, instance_labels(sc, cl, **self.kw))
+        if st["depths"] is not None:
+            lab = filter_labels_depth(lab, st["depths"], st["thr"])
+        stats, _, overflow = label_stats(lab)
+        st["host_stats"].copy_(torch.cat([stats.reshape(-1), overflow]), non_blocking=True)          # the batch's first transfer
+        return lab
+
+    def _stage2(self, st, nb):
+        from . import ops
+        b = st["s2"][nb]
+        rgb, msk, dep = ops.crop_resize(st["images"], st["depths"], st["label"], b["table"], self.crop_size)
+        sc, cl, mk = self._predict(rgb, dep)
+        labels_crop = _label_image_batched(mk, instance_labels(sc, cl, **self.kw))
+        raw = labels_crop.clone()
+        area, bad, lab, keys = _match_pre(labels_crop, msk, dep)
+        if keys is not None:
+            b["host_keys"].copy_(keys, non_blocking=True)                                             # the batch's second transfer
+        return dict(rgb_crop=rgb, mask_crop=msk, depth_crop=dep, labels_crop=raw, area=area, bad=bad, lab=lab)
+
+    def _capture(self, st, fn, *args):
+        """Run fn twice (weight caches, MIOpen's solver choices), then capture it on the slot's stream."""
+        if not self.use_graphs:
+            return None, fn(st, *args)
+        for _ in range(2):
+            fn(st, *args)
+        st["stream"].synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st["stream"]):
+            out = fn(st, *args)
+        from .graphs import cache_refs
+        st["refs"].append(cache_refs(self.model))              # the derived tensors the graph reads by address stay alive with it
+        return g, out
+
+    # ---- the phases of one batch on one slot (all device work on the slot's stream) ----
+    @torch.no_grad()
+    def _phase1(self, st, samples):
+        if len(samples) != self.frames:
+            raise ValueError(f"BatchedTwoStage was built for {self.frames} frames, got {len(samples)}")
+        sig = self._sig()
+        if st["sig"] != sig:                                   # first use, plan switch or parameter update: re-capture everything
+            st["stream"].synchronize()
+            st.update(sig=sig, g1=None, g2={}, s2={}, label=None, refs=[])
+        with torch.cuda.stream(st["stream"]):
+            st["stream"].wait_stream(torch.cuda.current_stream())
+            torch.stack([s["image_color"][0] if s["image_color"].dim() == 4 else s["image_color"] for s in samples], out=st["images"])
+            if st["depths"] is not None:
+                torch.stack([s["depth"][0] if s["depth"].dim() == 4 else s["depth"] for s in samples], out=st["depths"])
+                thr = [0.8 if "OSD" in str(s.get("file_name", "")) else self.depth_threshold for s in samples]      # test_utils.py:384-387
+                if thr != st["thr_host"]:
+                    st["thr"].copy_(torch.tensor(thr, dtype=torch.float32)[:, None])
+                    st["thr_host"] = thr
+            if st["label"] is None:
+                st["g1"], st["label"] = self._capture(st, self._stage1)
+                if st["g1"] is not None:
+                    st["g1"].replay()
+            elif st["g1"] is not None:
+                st["g1"].replay()
+            else:
+                st["label"] = self._stage1(st)
+            st["ev1"].record(st["stream"])
+
+    @torch.no_grad()
+    def _phase2(self, st):
+        Fr, k = self.frames, int(LABEL_BINS)
+        st["ev1"].synchronize()
+        packed = st["host_stats"].numpy()
+        rows = roi_table(packed[:Fr * k * 5].reshape(Fr, k, 5), packed[Fr * k * 5:], self.H, self.W)
+        st["rows"], st["n"] = rows, len(rows)
+        if not rows:
+            return
+        nb = -(-len(rows) // self.bucket) * self.bucket
+        st["nb"] = nb
+        with torch.cuda.stream(st["stream"]):
+            if nb not in st["s2"]:
+                st["s2"][nb] = dict(table=torch.zeros((nb, 8), dtype=torch.int32, device=self.dev),
+                                    table_host=torch.zeros((nb, 8), dtype=torch.int32).pin_memory(),
+                                    host_keys=torch.zeros(nb, dtype=torch.float64).pin_memory(), out=None)
+            b = st["s2"][nb]
+            b["table_host"].copy_(torch.tensor(rows + [rows[0]] * (nb - len(rows)), dtype=torch.int32))
+            b["table"].copy_(b["table_host"], non_blocking=True)
+            if b["out"] is None:
+                st["g2"][nb], b["out"] = self._capture(st, self._stage2, nb)
+                if st["g2"][nb] is not None:
+                    st["g2"][nb].replay()
+            elif st["g2"][nb] is not None:
+                st["g2"][nb].replay()
+            else:
+                b["out"] = self._stage2(st, nb)
+            st["ev2"].record(st["stream"])
+
+    @torch.no_grad()
+    def _phase3(self, st, stages=None):
+        """-> (out_label (F,H,W), refined (F,H,W), rows): tensors owned by the slot (valid until its next batch)."""
+        label, rows, n = st["label"], st["rows"], st["n"]
+        if n == 0:
+            return label, torch.zeros_like(label), rows
+        st["ev2"].synchronize()
+        b = st["s2"][st["nb"]]
+        o = b["out"]
+        if self.use_depth:
+            keys = b["host_keys"].numpy()[:n].tolist()
+        else:
+            keys = [float((r[5] - r[3] + 1) * (r[4] - r[2] + 1)) for r in rows]
+        with torch.cuda.stream(st["stream"]):
+            refined = _match_post(o["area"], o["bad"], o["lab"], keys, rows, self.frames, self.H, self.W, (self.crop_size, self.crop_size))
+        torch.cuda.current_stream().wait_stream(st["stream"])
+        if stages is not None:
+            stages.update(rgb_crop=o["rgb_crop"][:n], mask_crop=o["mask_crop"][:n], depth_crop=None if o["depth_crop"] is None else o["depth_crop"][:n],
+                          labels_crop=o["labels_crop"][:n].clone())
+        return label, refined, rows
+
+    def __call__(self, samples, stages=None):
+        st = self._slots[0]
+        self._phase1(st, samples)
+        self._phase2(st)
+        return self._phase3(st, stages)
+
+    def run(self, batches, consume=None):
+        """Every batch of ``batches`` (lists of ``frames`` samples) through the pipeline with two batches in flight.  ``consume(i,
+        out_label, refined, rows)`` is called per batch while the slot still owns the tensors; without it the results are cloned
+        into the returned list."""
+        S = len(self._slots)
+        results = [None] * len(batches)
+
+        def finish(i):
+            out = self._phase3(self._slots[i % S])
+            if consume is not None:
+                consume(i, *out)
+            else:
+                results[i] = (out[0].clone(), out[1].clone(), out[2])
+
+        for i, samples in enumerate(batches):
+            if i >= 1:
+                self._phase2(self._slots[(i - 1) % S])          # batch i-1's statistics -> its second stage is queued ...
+            if i >= S:
+                finish(i - S)                                   # ... before the host waits for batch i-S's keys (whose slot batch i reuses)
+            self._phase1(self._slots[i % S], samples)
+        if batches:
+            self._phase2(self._slots[(len(batches) - 1) % S])
+        for i in range(max(0, len(batches) - S), len(batches)):
+            finish(i)
+        return None if consume is not None else results
