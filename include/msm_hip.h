@@ -86,6 +86,7 @@ enum {
     MSM_OPT_MASK_KERNEL,        /* fp32 mask step: 5 = never the 4-query block on the 4x4x1 MFMA (fallback kernel) */
     MSM_OPT_MS_SPLIT_KERNEL,    /* msm_ms_hill_climb_split: 1 = X split inside the iteration kernel (fallback of the pre-split planes) */
     MSM_OPT_CONV3_WIDE,         /* msm_conv3x3_c64_f32 / _bf16: 0 = one 16-pixel block per wave, 16 waves per workgroup; 1 = two blocks, 8 waves (default: bf16 only) */
+    MSM_OPT_DEC_TILE32,         /* msm_dec_*_f16: 1 = 32-row tiles (two 16-row MFMA tiles share every weight fragment), 0 = 16-row tiles (default: 32 from 4096 rows) */
     MSM_OPT_COUNT
 };
 int msm_set_option(int key, int value);

@@ -726,6 +726,40 @@ def test_decoder_tails_f16_is_closer_to_exact_than_bf16():
     assert errs["f16"] * 4 <= errs["bf16"] and errs["f32"] <= errs["f16"]
 
 
+def test_decoder_tails_f16_32_row_tiles_equal_16_row_tiles():
+    """Round 6, TileQ32 (csrc/dec_chain.hip): above 4096 rows -- the second stage of configs[3] -- the fp16 tails run 32 rows per
+    workgroup, two 16-row MFMA tiles sharing every weight fragment.  A row's arithmetic does not depend on the tile it sits in: all
+    three kernels must return bit for bit what the 16-row form returns, at row counts with a ragged last tile (rows % 32 in 1..31)."""
+    from unseenobjectswithmeanshift_amd import _lib
+    E, Fh = 256, 2048
+    r = lambda *s_, seed, k=1.0: (rnd(*s_, seed=seed) * k).to(DEV)
+    pk = ops().dec_pack_weight_f16
+    wo, bo, g, b = pk(r(E, E, seed=4, k=E ** -0.5)), r(E, seed=5, k=0.1), 1 + r(E, seed=6, k=0.1), r(E, seed=7, k=0.1)
+    w_in, b_in = pk(r(3 * E, E, seed=8, k=E ** -0.5)), r(3 * E, seed=9, k=0.1)
+    w1, b1, w2, b2 = pk(r(Fh, E, seed=10, k=E ** -0.5)), r(Fh, seed=11, k=0.1), pk(r(E, Fh, seed=12, k=Fh ** -0.5)), r(E, seed=13, k=0.1)
+    g1, be1, g2, be2 = 1 + r(E, seed=14, k=0.1), r(E, seed=15, k=0.1), 1 + r(E, seed=16, k=0.1), r(E, seed=17, k=0.1)
+    mlp = [(pk(r(E, E, seed=20 + i, k=E ** -0.5)), r(E, seed=30 + i, k=0.1)) for i in range(3)]
+    wq, bq = pk(r(E, E, seed=40, k=E ** -0.5)), r(E, seed=41, k=0.1)
+    for B, Q in ((3, 7), (2, 100), (45, 100)):                 # 21, 200 and 4500 rows (the last one takes TileQ32 by default)
+        o, res, qpos = r(B, Q, E, seed=1), r(B, Q, E, seed=2), r(Q, E, seed=3)
+        got = {}
+        for tile32 in (0, 1):
+            with _lib.option("DEC_TILE32", tile32):
+                x, qk, v = ops().dec_post_cross(o, res, qpos, wo, bo, g, b, w_in, b_in)
+                outs = [x, qk, v]
+                for n_parts in (1, 4):
+                    x2, parts = ops().dec_post_self(o, res, wo, bo, g, b, w1, b1, w2, n_parts=n_parts)
+                    out, d, e, q, ra = ops().dec_heads(x2, g2, be2, mlp, parts=parts, bias=b2, ln_g=g1, ln_b=be1, l2norm=True, wq=wq, bq=bq,
+                                                       query_pos=qpos, want_d=True, zero_row_any=True)
+                    outs += [x2, parts, out, d, e, q, ra]
+                got[tile32] = outs
+        for a, c in zip(got[0], got[1]):
+            assert torch.equal(a, c)
+        if B * Q >= 4096:                                       # the default choice at this size is the 32-row form
+            x2, parts = ops().dec_post_self(o, res, wo, bo, g, b, w1, b1, w2, n_parts=1)
+            assert torch.equal(parts, got[1][4])
+
+
 def test_decoder_fused_tails_reject_bad_sizes():
     E = 128
     z = lambda *s: torch.zeros(*s, device=DEV)

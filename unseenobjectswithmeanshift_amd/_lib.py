@@ -173,7 +173,7 @@ def lib():
 # kernel-selection overrides of include/msm_hip.h (enum order), for tools/ and tests/ only
 OPTIONS = ("MASK_NC", "MASKB_TARGET", "GEMM_TILE", "GEMM_SHALLOW", "ATTN_TARGET", "ATTN_KERNEL", "ATTN_QK_MAX", "ATTN_QKCFG",
            "CONVIN_NT", "POST_GENERIC", "ENC_NO_COOP", "MSDA_GENERIC", "MS_CHUNK", "MS_NO_PERSISTENT", "ATTN_FUSED_KV", "KV_PIPE", "MASK_KERNEL",
-           "MS_SPLIT_KERNEL", "CONV3_WIDE")
+           "MS_SPLIT_KERNEL", "CONV3_WIDE", "DEC_TILE32")
 OPT_AUTO = -1
 
 

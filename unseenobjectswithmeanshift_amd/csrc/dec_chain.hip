@@ -57,17 +57,24 @@ constexpr int DC_E = 256;
 // Which fp32 kind a launch takes is decided by the host per kernel and row count: 8-row tiles halve a stage but double the number
 // of workgroups that stream the stage's 256 KiB of weights -- they pay while tiles x parts still fit the chip in one round
 // (measured at 800 rows: heads 21.7 -> 14.5 us with 200 workgroups; post_cross 14.6 -> 18.4 with 300, post_self 27.7 -> 51 with 800).
+//   TileQ32  fp16 weights, 32 rows = TWO 16-row MFMA tiles per workgroup that share every weight fragment (round 6): above ~4000 rows
+//            (the second stage of configs[3]: 17 300 rows, configs[4] at batch 4) a launch is bound by the L2 -> CU weight stream --
+//            1082 16-row tiles x 2.2 MB = 2.4 GB per post_self launch at 33 TB/s -- and a fragment that feeds two MFMAs halves it
+// F8: the 4x4x1 fp32 form (its two "row groups" are the halves of ONE 8-row tile, reduced across lanes); RG otherwise counts 16-row tiles.
 struct TileF16 {
     using WT = float;
     static constexpr int R = 16, LD = DC_E + 4, RG = 1;
+    static constexpr bool F8 = false;
 };
 struct TileF8 {
     using WT = float;
     static constexpr int R = 8, LD = DC_E + 16, RG = 2;
+    static constexpr bool F8 = true;
 };
 struct TileH16 {
     using WT = uint16_t;
     static constexpr int R = 16, LD = DC_E + 4, RG = 1;
+    static constexpr bool F8 = false;
 };
 // fp16 weights (precision "f16"): the same bytes as bf16 with 11 instead of 8 significand bits -- Linear weights are O(0.01 .. 1),
 // far inside the half range -- on v_mfma_f32_16x16x32_f16, which issues at the bf16 instruction's rate.  The activation fragment
@@ -81,7 +88,15 @@ struct f16w {
 struct TileQ16 {
     using WT = f16w;
     static constexpr int R = 16, LD = DC_E + 4, RG = 1;
+    static constexpr bool F8 = false;
 };
+struct TileQ32 {
+    using WT = f16w;
+    static constexpr int R = 32, LD = DC_E + 4, RG = 2;
+    static constexpr bool F8 = false;
+};
+// (64-row tiles -- RG = 4, one 133-KB workgroup per CU -- were measured for post_self at 17 300 rows: 126 us against 90 for 32-row tiles and
+// 136 for 16-row tiles: one resident workgroup cannot keep the weight stream's latency covered.)
 #ifndef MSM_DC_NW
 #define MSM_DC_NW 8
 #endif
@@ -258,14 +273,37 @@ __device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT][1], const float* _
         }
     }
 }
+// fp16 weights, RT 16-row tiles per workgroup (TileQ32: RT = 2): every weight fragment feeds all tiles' MFMAs
+template <int RT>
+__device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT][RT], const float* __restrict__ ap, const BFrag<f16w>& f, int half) {
+    constexpr int LD = TileQ32::LD;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int kc = half * 2 + h;
+#pragma unroll
+        for (int up = 0; up < 2; ++up) {
+            f16x8 x[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const float4 p = *reinterpret_cast<const float4*>(ap + rt * 16 * LD + kc * 64 + (2 * up) * 16);
+                const float4 q = *reinterpret_cast<const float4*>(ap + rt * 16 * LD + kc * 64 + (2 * up + 1) * 16);
+                x[rt] = cvt8h(p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w);
+            }
+#pragma unroll
+            for (int t = 0; t < DC_NT; ++t)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[t][rt] = mfma_f16k32(x[rt], __builtin_bit_cast(f16x8, f.v[h][t][up]), acc[t][rt]);
+        }
+    }
+}
 // prefetch loads per half stage (bload) and MFMAs between two of them
 template <typename TK>
 struct Pipe {
     static constexpr int LOADS = std::is_same<typename TK::WT, float>::value ? 8 * DC_NT : 4 * DC_NT;
     // MFMAs between two prefetch loads: 8-row fp32 has two 8-cycle MFMAs where the 16-row form has one of 32; bf16 (hi + lo activation) has
     // 8 * DC_NT per half stage, fp16 (one term) 4 * DC_NT
-    static constexpr int IL = std::is_same<typename TK::WT, f16w>::value ? 1
-                              : !std::is_same<typename TK::WT, float>::value ? DC_IL / 2 : (TK::RG == 2 ? 2 * DC_IL : DC_IL);
+    static constexpr int IL = std::is_same<typename TK::WT, f16w>::value ? TK::RG
+                              : !std::is_same<typename TK::WT, float>::value ? DC_IL / 2 : (TK::F8 ? 2 * DC_IL : DC_IL);
 };
 
 // D[16][256] = act(A[16][256] . W[n][k]^T + bias).  A in LDS.  TO_GLOBAL: D is row-major global with row stride
@@ -279,7 +317,7 @@ __device__ __forceinline__ void gemm_core(f32x4 (&acc)[DC_NT][TK::RG], const flo
                                           int kc_base, BFrag<typename TK::WT>& lo, const typename TK::WT* __restrict__ Wn, int kctn, int kcn) {
     using WT = typename TK::WT;
     const int lane = threadIdx.x & 63;
-    const float* ap = A + (TK::RG == 2 ? (lane & 3) : (lane & 15)) * TK::LD + (lane >> 4) * 4;
+    const float* ap = A + (TK::F8 ? (lane & 3) : (lane & 15)) * TK::LD + (lane >> 4) * 4;
     BFrag<WT> hi;
     // The prefetch loads are spread evenly between the MFMAs of the half they hide behind (1 load : DC_IL MFMAs,
     // sched_group_barrier), not issued as a burst in front of them: measured 16.2 -> 14.1 us (post_cross), 34.1 -> 29.1
@@ -307,32 +345,34 @@ __device__ __forceinline__ void gemm_core(f32x4 (&acc)[DC_NT][TK::RG], const flo
 
 // D = act(acc + bias).  TO_GLOBAL: D is row-major global with row stride ldd, rows >= rows_valid are not written;
 // otherwise D is an LDS tile (stride TK::LD).
-template <bool TO_GLOBAL, int LD>
-__device__ __forceinline__ void gemm_store(const f32x4 (&acc)[DC_NT][1], const float (&bv)[DC_NT], bool relu, float* __restrict__ D,
-                                           int64_t ldd, int rows_valid) {
+template <bool TO_GLOBAL, int LD, int RG>
+__device__ __forceinline__ void gemm_store16(const f32x4 (&acc)[DC_NT][RG], const float (&bv)[DC_NT], bool relu, float* __restrict__ D,
+                                             int64_t ldd, int rows_valid) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lj = lane & 15, lq = lane >> 4;
 #pragma unroll
     for (int t = 0; t < DC_NT; ++t) {
         const int n = (wave * DC_NT + t) * 16 + lj;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = acc[t][0][r] + bv[t];
-            if (relu) v = fmaxf(v, 0.f);
-            const int row = lq * 4 + r;
-            if constexpr (TO_GLOBAL) {
-                if (row < rows_valid) D[(int64_t)row * ldd + n] = v;
-            } else {
-                D[row * LD + n] = v;
+        for (int rt = 0; rt < RG; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[t][rt][r] + bv[t];
+                if (relu) v = fmaxf(v, 0.f);
+                const int row = rt * 16 + lq * 4 + r;
+                if constexpr (TO_GLOBAL) {
+                    if (row < rows_valid) D[(int64_t)row * ldd + n] = v;
+                } else {
+                    D[row * LD + n] = v;
+                }
             }
-        }
     }
 }
 // fp32 (4x4x1 blocks): the four k-slices of a column sit in the lanes lq = 0..3 of that column; a reduce-scatter over them leaves lane
 // lq with the total of row 4 rg + lq (three cross-lane adds per tuple), which it stores
 template <bool TO_GLOBAL, int LD>
-__device__ __forceinline__ void gemm_store(const f32x4 (&acc)[DC_NT][2], const float (&bv)[DC_NT], bool relu, float* __restrict__ D,
-                                           int64_t ldd, int rows_valid) {
+__device__ __forceinline__ void gemm_store8(const f32x4 (&acc)[DC_NT][2], const float (&bv)[DC_NT], bool relu, float* __restrict__ D,
+                                            int64_t ldd, int rows_valid) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lj = lane & 15, lq = lane >> 4;
     const bool up2 = lq & 2, up1 = lq & 1;
@@ -357,6 +397,13 @@ __device__ __forceinline__ void gemm_store(const f32x4 (&acc)[DC_NT][2], const f
     }
 }
 
+template <bool TO_GLOBAL, typename TK>
+__device__ __forceinline__ void gemm_store(const f32x4 (&acc)[DC_NT][TK::RG], const float (&bv)[DC_NT], bool relu, float* __restrict__ D,
+                                           int64_t ldd, int rows_valid) {
+    if constexpr (TK::F8) gemm_store8<TO_GLOBAL, TK::LD>(acc, bv, relu, D, ldd, rows_valid);
+    else gemm_store16<TO_GLOBAL, TK::LD, TK::RG>(acc, bv, relu, D, ldd, rows_valid);
+}
+
 __device__ __forceinline__ void load_bias(float (&bv)[DC_NT], const float* __restrict__ bias) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -378,7 +425,7 @@ __device__ __forceinline__ void gemm256(const float* __restrict__ A, const typen
     float bv[DC_NT];
     load_bias(bv, bias);            // requested before the MFMAs, consumed after them
     gemm_core<NEXT, TK>(acc, A, W, kct, kc_base, lo, Wn, kctn, kcn);
-    gemm_store<TO_GLOBAL, TK::LD>(acc, bv, relu, D, ldd, rows_valid);
+    gemm_store<TO_GLOBAL, TK>(acc, bv, relu, D, ldd, rows_valid);
 }
 
 // tile[16][256] <- src rows row0.. (clamped to the last valid row), 16-byte coalesced
@@ -510,7 +557,7 @@ __global__ __launch_bounds__(DC_THREADS) void dec_post_self_kernel(
         gemm_core<true, TK>(acc2, T0, w2, kct2, 4 * c, f, w1 + (int64_t)cn * DC_E * DC_E, 4, 0);
         __syncthreads();
     }
-    gemm_store<true, TK::LD>(acc2, zero_bias, false, parts + ((int64_t)chunk * rows + row0) * DC_E, DC_E, valid);
+    gemm_store<true, TK>(acc2, zero_bias, false, parts + ((int64_t)chunk * rows + row0) * DC_E, DC_E, valid);
 }
 
 template <typename TK, typename WT = typename TK::WT>
@@ -544,19 +591,20 @@ __global__ __launch_bounds__(DC_THREADS) void dec_heads_kernel(
     const float4 biasv = bias ? ld4(bias + lane * 4) : zero4;
     const float4 g1v = g1 ? ld4(g1 + lane * 4) : zero4, b1v = g1 ? ld4(b1 + lane * 4) : zero4;
     const float4 g2v = ld4(g2 + lane * 4), b2v = ld4(b2 + lane * 4);
-    for (int s0 = 0; s0 < n_parts; s0 += 8) {
-        float4 p[(TK::R / DC_NW)][8];
+    constexpr int PS = (TK::R / DC_NW) > 2 ? 4 : 8;                 // partial sums in flight per row (register budget)
+    for (int s0 = 0; s0 < n_parts; s0 += PS) {
+        float4 p[(TK::R / DC_NW)][PS];
 #pragma unroll
         for (int i = 0; i < (TK::R / DC_NW); ++i) {
             const int gr = min(row0 + wave * (TK::R / DC_NW) + i, rows - 1);
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
+            for (int s = 0; s < PS; ++s)
                 p[i][s] = ld4(parts + ((int64_t)min(s0 + s, n_parts - 1) * rows + gr) * DC_E + lane * 4);
         }
 #pragma unroll
         for (int i = 0; i < (TK::R / DC_NW); ++i)
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
+            for (int s = 0; s < PS; ++s)
                 if (s0 + s < n_parts) v[i] = add4(v[i], p[i][s]);
     }
 #pragma unroll
@@ -673,6 +721,12 @@ extern "C" int msm_dec_pack_weight_f16(const float* w, uint16_t* packed, int N, 
 
 // 8-row fp32 tiles while tiles x parts fit the chip in one round (see the tile kinds above)
 static bool use_tile8(int rows, int parts) { return cdiv(rows, 8) * parts <= 256; }
+// fp16 weights: 32-row tiles (TileQ32) once the 16-row tiles alone oversubscribe the chip -- the launch is then bound by the aggregate
+// L2 -> CU weight stream, which a fragment shared by two tiles halves (MSM_OPT_DEC_TILE32: 1 always, 0 never)
+static bool use_tile32(int rows) {
+    const int o = opt(MSM_OPT_DEC_TILE32);
+    return o == 1 || (o != 0 && rows >= 4096);
+}
 
 template <typename TK, typename WT = typename TK::WT>
 static int dec_post_cross_impl(const char* who, const float* attn_out, const float* res, const float* query_pos, const WT* wo, const float* bo,
@@ -683,7 +737,7 @@ static int dec_post_cross_impl(const char* who, const float* attn_out, const flo
     MSM_REQUIRE(rows > 0 && Q > 0, "%s: bad sizes", who);
     MSM_REQUIRE(aligned16(attn_out) && aligned16(wo) && aligned16(w_in), "%s: pointers must be 16-byte aligned", who);
     // 8-row tiles take two parts (q then k | v): three would oversubscribe the chip at 800 rows (see use_tile8)
-    hipLaunchKernelGGL(dec_post_cross_kernel<TK>, dim3(cdiv(rows, TK::R), TK::RG == 2 ? 2 : 3), dim3(DC_THREADS), 0, (hipStream_t)stream, attn_out,
+    hipLaunchKernelGGL(dec_post_cross_kernel<TK>, dim3(cdiv(rows, TK::R), TK::F8 ? 2 : 3), dim3(DC_THREADS), 0, (hipStream_t)stream, attn_out,
                        res, query_pos, wo, bo, ln_g, ln_b, w_in, b_in, x_out, qk_out, v_out, rows, Q, eps);
     MSM_CHECK_LAUNCH(who);
     return MSM_OK;
@@ -708,6 +762,10 @@ extern "C" int msm_dec_post_cross_bf16(const float* attn_out, const float* res, 
 extern "C" int msm_dec_post_cross_f16(const float* attn_out, const float* res, const float* query_pos, const uint16_t* wo,
                                       const float* bo, const float* ln_g, const float* ln_b, const uint16_t* w_in, const float* b_in,
                                       float* x_out, float* qk_out, float* v_out, int rows, int Q, int E, float eps, void* stream) {
+    // (measured at 17 300 rows: 55 us with 16-row tiles, 66 with 32 -- three resident workgroups per CU hide more than one does)
+    if (opt(MSM_OPT_DEC_TILE32) == 1)
+        return dec_post_cross_impl<TileQ32>("msm_dec_post_cross_f16", attn_out, res, query_pos, (const f16w*)wo, bo, ln_g, ln_b, (const f16w*)w_in, b_in,
+                                            x_out, qk_out, v_out, rows, Q, E, eps, stream);
     return dec_post_cross_impl<TileQ16>("msm_dec_post_cross_f16", attn_out, res, query_pos, (const f16w*)wo, bo, ln_g, ln_b, (const f16w*)w_in, b_in,
                                         x_out, qk_out, v_out, rows, Q, E, eps, stream);
 }
@@ -746,6 +804,9 @@ extern "C" int msm_dec_post_self_bf16(const float* attn_out, const float* res, c
 extern "C" int msm_dec_post_self_f16(const float* attn_out, const float* res, const uint16_t* wo, const float* bo, const float* ln_g,
                                      const float* ln_b, const uint16_t* w1, const float* b1, const uint16_t* w2, int F, float* x_out,
                                      float* parts, int n_parts, int rows, int E, float eps, void* stream) {
+    if (use_tile32(rows))
+        return dec_post_self_impl<TileQ32>("msm_dec_post_self_f16", attn_out, res, (const f16w*)wo, bo, ln_g, ln_b, (const f16w*)w1, b1, (const f16w*)w2, F,
+                                           x_out, parts, n_parts, rows, E, eps, stream);
     return dec_post_self_impl<TileQ16>("msm_dec_post_self_f16", attn_out, res, (const f16w*)wo, bo, ln_g, ln_b, (const f16w*)w1, b1, (const f16w*)w2, F,
                                        x_out, parts, n_parts, rows, E, eps, stream);
 }
@@ -793,6 +854,9 @@ extern "C" int msm_dec_heads_f16(const float* x, const float* parts, int n_parts
                                  const float* m0b, const uint16_t* m1w, const float* m1b, const uint16_t* m2w, const float* m2b,
                                  const uint16_t* wq, const float* bq, const float* query_pos, float* out, float* d_out, float* e_out,
                                  float* q_out, int32_t* row_any_zero, int rows, int Q, int E, float eps, void* stream) {
+    if (use_tile32(rows))
+        return dec_heads_impl<TileQ32>("msm_dec_heads_f16", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, (const f16w*)m0w, m0b, (const f16w*)m1w,
+                                       m1b, (const f16w*)m2w, m2b, (const f16w*)wq, bq, query_pos, out, d_out, e_out, q_out, row_any_zero, rows, Q, E, eps, stream);
     return dec_heads_impl<TileQ16>("msm_dec_heads_f16", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, (const f16w*)m0w, m0b, (const f16w*)m1w,
                                    m1b, (const f16w*)m2w, m2b, (const f16w*)wq, bq, query_pos, out, d_out, e_out, q_out, row_any_zero, rows, Q, E, eps, stream);
 }
