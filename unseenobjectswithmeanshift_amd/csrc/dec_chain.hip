@@ -560,23 +560,47 @@ __global__ __launch_bounds__(DC_THREADS) void dec_post_self_kernel(
     gemm_store<true, TK>(acc2, zero_bias, false, parts + ((int64_t)chunk * rows + row0) * DC_E, DC_E, valid);
 }
 
-template <typename TK, typename WT = typename TK::WT>
+// The next layer's attention mask as the epilogue of the heads kernel (round 6, 16-bit plans with attention masks at key resolution,
+// csrc/attn_mask.hip): mask[b][q][t] = (sum_c e[b][q][c] pooled[b][t][c] + e[b][q][qcol]) < 0 over the T pooled keys of the level, and
+// row_any[b][q] = 1 where a row keeps an unmasked key (DEC:618, 677-680) -- the arithmetic of attn_mask_pooled_kernel bit for bit, in
+// either of its operand forms (sixteen fp32 MFMAs per key block, or two v_mfma_f32_16x16x32_f16; the query bias as the accumulator's
+// initial value), without the launch: e never leaves the workgroup's LDS tile before it is contracted.  Tiles are IMAGE-ALIGNED then (a tile's queries share
+// one pooled map): blockIdx.x = image * tiles_per_image + tile.  The key blocks of an image are shared out over `parts` workgroups per
+// tile (blockIdx.y: 0 and, behind the optional query-projection part, 2 ..): every part repeats the row phase and the three MLP
+// stages (weights from L2, 384 KiB) on its own CU -- the chain is latency, not throughput -- and only part 0 stores out / d / e.
+// row_any must arrive ZEROED (the decoder clears the flags of all its predictions in the pooling launch).
+struct HeadsMask {
+    const float* pooled;        // (B, T, 64) fp32 (msm_pool_mask_taps)
+    uint8_t* attn;              // (B, Q, T) bytes, or the bit-packed blocked form of msm_attn_pack_mask_bits when bits
+    int32_t* row_any;           // (B, Q), zeroed by the caller
+    int T, bits, parts, tiles_per_image, qcol, f16ops;
+};
+
+template <typename TK, bool MASK = false, typename WT = typename TK::WT>
 __global__ __launch_bounds__(DC_THREADS) void dec_heads_kernel(
     const float* __restrict__ x, const float* __restrict__ parts, int n_parts, const float* __restrict__ bias,
     const float* __restrict__ g1, const float* __restrict__ b1, int l2norm, const float* __restrict__ g2,
     const float* __restrict__ b2, const WT* __restrict__ m0w, const float* __restrict__ m0b, const WT* __restrict__ m1w,
     const float* __restrict__ m1b, const WT* __restrict__ m2w, const float* __restrict__ m2b, const WT* __restrict__ wq,
     const float* __restrict__ bq, const float* __restrict__ qpos, float* __restrict__ out, float* __restrict__ d_out,
-    float* __restrict__ e_out, float* __restrict__ q_out, int32_t* __restrict__ row_any_zero, int rows, int Q, float eps) {
+    float* __restrict__ e_out, float* __restrict__ q_out, int32_t* __restrict__ row_any_zero, int rows, int Q, float eps, HeadsMask hm) {
     __shared__ __attribute__((aligned(16))) float lds[3 * TK::R * TK::LD];
     float *XP = lds, *Dn = lds + TK::R * TK::LD, *T0 = lds + 2 * TK::R * TK::LD;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row0 = blockIdx.x * TK::R;
-    const int valid = min(TK::R, rows - row0);
-    // blockIdx.y == 1 (only launched when wq is given): the next layer's query projection; y == 0: the MLP chain
-    const bool qpart = blockIdx.y == 1;
+    int row0 = blockIdx.x * TK::R, valid = min(TK::R, rows - row0);
+    int img = 0, tile = 0;
+    if constexpr (MASK) {
+        img = blockIdx.x / hm.tiles_per_image, tile = blockIdx.x - img * hm.tiles_per_image;
+        row0 = img * Q + tile * TK::R;
+        valid = min(TK::R, Q - tile * TK::R);
+    }
+    // blockIdx.y == 1 (only launched when wq is given): the next layer's query projection; y == 0: the MLP chain; MASK: y = 0 and
+    // y >= (wq ? 2 : 1) are the mask parts
+    const bool qpart = wq != nullptr && blockIdx.y == 1;
+    const int mpart = MASK ? (blockIdx.y == 0 ? 0 : (int)blockIdx.y - (wq ? 1 : 0)) : 0;
+    const bool primary = mpart == 0;                                             // stores out / d / e (uniform)
     // the mask step that consumes e_out needs its row_any flags cleared: done here instead of a separate fill launch
-    if (row_any_zero && !qpart && (int)threadIdx.x < valid) row_any_zero[row0 + threadIdx.x] = 0;
+    if (row_any_zero && !qpart && primary && (int)threadIdx.x < valid) row_any_zero[row0 + threadIdx.x] = 0;
     BFrag<WT> f;
     bload(f, qpart ? wq : m0w, 4, 0, 0);
     // row phase: lane owns 4 consecutive columns; all global operands of the wave's rows are requested up front
@@ -610,7 +634,7 @@ __global__ __launch_bounds__(DC_THREADS) void dec_heads_kernel(
 #pragma unroll
     for (int i = 0; i < (TK::R / DC_NW); ++i) {
         const int r = wave * (TK::R / DC_NW) + i;
-        const bool live = row0 + r < rows;
+        const bool live = r < valid && primary;
         float4 t = add4(v[i], biasv);
         if (g1) t = affine4(t, row_stats(t, eps), g1v, b1v);                         // FFN norm (DEC:300)
         if (l2norm) {                                                                // block norm (DEC:637-638)
@@ -635,7 +659,87 @@ __global__ __launch_bounds__(DC_THREADS) void dec_heads_kernel(
     __syncthreads();
     gemm256<false, true, TK>(T0, m1w, 4, 0, m1b, true, Dn, 0, 0, f, m2w, 4, 0);
     __syncthreads();
-    gemm256<true, false, TK>(Dn, m2w, 4, 0, m2b, false, e_out + (int64_t)row0 * DC_E, DC_E, valid, f, nullptr, 0, 0);
+    if constexpr (!MASK) {
+        gemm256<true, false, TK>(Dn, m2w, 4, 0, m2b, false, e_out + (int64_t)row0 * DC_E, DC_E, valid, f, nullptr, 0, 0);
+    } else {
+        static_assert(TK::R == 16, "the mask epilogue walks one 16-query block per workgroup");
+        gemm256<false, false, TK>(Dn, m2w, 4, 0, m2b, false, T0, 0, 0, f, nullptr, 0, 0);                                // e -> LDS
+        __syncthreads();
+        if (primary)                                                                   // e_out: the final mask step / aux consumers read it
+            for (int i = threadIdx.x; i < valid * (DC_E / 4); i += DC_THREADS) {
+                const int r = i / (DC_E / 4), c4 = i - r * (DC_E / 4);
+                st4(e_out + (int64_t)(row0 + r) * DC_E + c4 * 4, ld4(T0 + r * TK::LD + c4 * 4));
+            }
+        // ---- the mask of this tile's 16 queries against key blocks mpart*DC_NW + wave, + parts*DC_NW, ... (attn_mask_pooled_kernel, F16 form) ----
+        const int lj = lane & 15, lq = lane >> 4;
+        const int T = hm.T, nkb = (T + 15) / 16, stride = hm.parts * DC_NW;
+        // operand forms of attn_mask_pooled_kernel: f16ops -- a lane's channels 8 lq .. + 7 and 32 + 8 lq .. + 7 (the two K = 32 steps of
+        // v_mfma_f32_16x16x32_f16); else fp32 -- channels 16 lq .. + 15, sixteen v_mfma_f32_16x16x4_f32 (the plans' default: the mask bits
+        // feed back into the attention, so their operands stay fp32 unless lp_pooled_masks asks otherwise)
+        const bool h16 = hm.f16ops != 0;                                               // (uniform)
+        const int lqw = h16 ? 8 : 16, o1 = 4, o2 = h16 ? 32 : 8, o3 = h16 ? 36 : 12;
+        const float* er = T0 + lj * TK::LD + lq * lqw;
+        const float4 w0 = ld4(er), w1 = ld4(er + o1), w2 = ld4(er + o2), w3 = ld4(er + o3);
+        const f16x8 wh0 = cvt8h(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w), wh1 = cvt8h(w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w);
+        const float qb = T0[lj * TK::LD + hm.qcol];
+        const bool qlive = lj < valid;
+        const int q = tile * 16 + lj;
+        const float* pb = hm.pooled + (int64_t)img * T * 64 + lq * lqw;
+        uint8_t* ab = hm.attn + (int64_t)img * Q * T;
+        unsigned anyu = 0;
+        int kb = mpart * DC_NW + wave;
+        float4 a[4], an[4];
+        if (kb < nkb) {
+            const float* ap = pb + (int64_t)min(kb * 16 + lj, T - 1) * 64;
+            a[0] = ld4(ap), a[1] = ld4(ap + o1), a[2] = ld4(ap + o2), a[3] = ld4(ap + o3);
+        }
+        for (; kb < nkb; kb += stride) {
+            const int kn = min(kb + stride, nkb - 1);                                  // the next block's keys are requested before this block's MFMAs
+            const float* apn = pb + (int64_t)min(kn * 16 + lj, T - 1) * 64;
+            an[0] = ld4(apn), an[1] = ld4(apn + o1), an[2] = ld4(apn + o2), an[3] = ld4(apn + o3);
+            f32x4 acc = f32x4{qb, qb, qb, qb};
+            if (h16) {
+                acc = mfma_f16k32(cvt8h(a[0].x, a[0].y, a[0].z, a[0].w, a[1].x, a[1].y, a[1].z, a[1].w), wh0, acc);
+                acc = mfma_f16k32(cvt8h(a[2].x, a[2].y, a[2].z, a[2].w, a[3].x, a[3].y, a[3].z, a[3].w), wh1, acc);
+            } else {
+                const float4 wv[4] = {w0, w1, w2, w3};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc = mfma16(a[u].x, wv[u].x, acc);
+                    acc = mfma16(a[u].y, wv[u].y, acc);
+                    acc = mfma16(a[u].z, wv[u].z, acc);
+                    acc = mfma16(a[u].w, wv[u].w, acc);
+                }
+            }
+            const int key0 = kb * 16 + lq * 4;
+            const unsigned m0 = acc[0] < 0.f, m1 = acc[1] < 0.f, m2 = acc[2] < 0.f, m3 = acc[3] < 0.f;   // sigmoid(x) < 0.5 <=> x < 0 (DEC:677)
+            if (hm.bits) {
+                unsigned nib = (m0 | (m1 << 1) | (m2 << 2) | (m3 << 3)) << (4 * lq);
+                nib = or_lane_rows(nib);
+                if ((m0 & m1 & m2 & m3) == 0) anyu = 1u;
+                const int qc = tile / 7, mb = tile - qc * 7, qchunks = (Q + 111) / 112;  // 112-query chunk and block within it (attention.hip: AQB = 7)
+                if (lq == 0 && qlive)
+                    reinterpret_cast<unsigned short*>(hm.attn)[((((int64_t)img * qchunks + qc) * nkb + kb) * 16 + lj) * 8 + mb] = (unsigned short)nib;
+            } else if (qlive) {
+                if ((T & 3) == 0 && key0 + 3 < T) {
+                    *reinterpret_cast<uint32_t*>(ab + (int64_t)q * T + key0) = m0 | (m1 << 8) | (m2 << 16) | (m3 << 24);
+                    if ((m0 & m1 & m2 & m3) == 0) anyu = 1u;
+                } else {
+                    const unsigned mm[4] = {m0, m1, m2, m3};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (key0 + r < T) {
+                            ab[(int64_t)q * T + key0 + r] = (uint8_t)mm[r];
+                            if (!mm[r]) anyu = 1u;
+                        }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = an[u];
+        }
+        anyu = or_lane_rows(anyu);                                                     // (same flag value from every writer)
+        if (lq == 0 && anyu && qlive) hm.row_any[(int64_t)img * Q + q] = 1;
+    }
 }
 
 // packed[((t*(K/64) + kc)*4 + u)*256 + (lq*16 + lj)*4 + c] = W[t*16 + lj][kc*64 + u*16 + lq*4 + c]
@@ -811,11 +915,12 @@ extern "C" int msm_dec_post_self_f16(const float* attn_out, const float* res, co
                                        x_out, parts, n_parts, rows, E, eps, stream);
 }
 
-template <typename TK, typename WT = typename TK::WT>
+template <typename TK, bool MASK = false, typename WT = typename TK::WT>
 static int dec_heads_impl(const char* who, const float* x, const float* parts, int n_parts, const float* bias, const float* ln_g,
                           const float* ln_b, int l2norm, const float* dec_g, const float* dec_b, const WT* m0w, const float* m0b, const WT* m1w,
                           const float* m1b, const WT* m2w, const float* m2b, const WT* wq, const float* bq, const float* query_pos, float* out,
-                          float* d_out, float* e_out, float* q_out, int32_t* row_any_zero, int rows, int Q, int E, float eps, void* stream) {
+                          float* d_out, float* e_out, float* q_out, int32_t* row_any_zero, int rows, int Q, int E, float eps, void* stream,
+                          HeadsMask hm = HeadsMask{}) {
     MSM_REQUIRE(x && dec_g && dec_b && m0w && m0b && m1w && m1b && m2w && m2b && e_out, "%s: null pointer", who);
     MSM_REQUIRE(E == DC_E, "%s: E=%d, only 256 is supported", who, E);
     MSM_REQUIRE(rows > 0 && Q > 0 && n_parts >= 0, "%s: bad sizes", who);
@@ -823,9 +928,20 @@ static int dec_heads_impl(const char* who, const float* x, const float* parts, i
     MSM_REQUIRE((ln_g == nullptr) == (ln_b == nullptr), "%s: ln_g/ln_b must both be given or both be null", who);
     MSM_REQUIRE(!wq || (bq && query_pos && q_out), "%s: the next-query projection needs bq, query_pos and q_out", who);
     MSM_REQUIRE(aligned16(m0w) && aligned16(m1w) && aligned16(m2w) && aligned16(wq), "%s: weights must be 16-byte aligned", who);
-    hipLaunchKernelGGL(dec_heads_kernel<TK>, dim3(cdiv(rows, TK::R), wq ? 2 : 1), dim3(DC_THREADS), 0, (hipStream_t)stream, x, parts, n_parts, bias,
+    dim3 grid(cdiv(rows, TK::R), wq ? 2 : 1);
+    if constexpr (MASK) {
+        MSM_REQUIRE(hm.pooled && hm.attn && hm.row_any && hm.T > 0 && rows % Q == 0, "%s: the mask epilogue needs pooled / attn / row_any, T > 0 and rows = B * Q", who);
+        MSM_REQUIRE(hm.qcol >= 64 && hm.qcol < DC_E && aligned16(hm.pooled), "%s: qcol=%d must name a column of e behind the 64 embedding columns", who, hm.qcol);
+        MSM_REQUIRE(!hm.bits || (hm.T % 16 == 0 && aligned16(hm.attn)), "%s: the bit-packed mask needs T %% 16 == 0 and a 16-byte aligned buffer", who);
+        hm.tiles_per_image = cdiv(Q, TK::R);
+        const int tiles = (rows / Q) * hm.tiles_per_image, nkb = cdiv(hm.T, 16);
+        // parts: about one chip of workgroups in all, at least ~3 key blocks per wave (every part repeats the MLP chain)
+        hm.parts = max(1, min(min(cdiv(nkb, 3 * DC_NW), 8), max(1, 256 / tiles - (wq ? 1 : 0))));
+        grid = dim3(tiles, hm.parts + (wq ? 1 : 0));
+    }
+    hipLaunchKernelGGL((dec_heads_kernel<TK, MASK>), grid, dim3(DC_THREADS), 0, (hipStream_t)stream, x, parts, n_parts, bias,
                        ln_g, ln_b, l2norm, dec_g, dec_b, m0w, m0b, m1w, m1b, m2w, m2b, wq, bq, query_pos, out, d_out, e_out, q_out,
-                       row_any_zero, rows, Q, eps);
+                       row_any_zero, rows, Q, eps, hm);
     MSM_CHECK_LAUNCH(who);
     return MSM_OK;
 }
@@ -859,4 +975,23 @@ extern "C" int msm_dec_heads_f16(const float* x, const float* parts, int n_parts
                                        m1b, (const f16w*)m2w, m2b, (const f16w*)wq, bq, query_pos, out, d_out, e_out, q_out, row_any_zero, rows, Q, E, eps, stream);
     return dec_heads_impl<TileQ16>("msm_dec_heads_f16", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, (const f16w*)m0w, m0b, (const f16w*)m1w,
                                    m1b, (const f16w*)m2w, m2b, (const f16w*)wq, bq, query_pos, out, d_out, e_out, q_out, row_any_zero, rows, Q, E, eps, stream);
+}
+
+// heads + the next layer's attention mask at key resolution in one launch (see HeadsMask above).  flags: 1 = bit-packed blocked mask
+// (msm_attn_pack_mask_bits' layout), 2 = fp16 weight fragments (msm_dec_pack_weight_f16; else bf16 fragments), 4 = the mask contraction on
+// IEEE-half operands (msm_attn_mask_pooled's flag 2; else its fp32 MFMA chain).
+extern "C" int msm_dec_heads_mask(const float* x, const float* parts, int n_parts, const float* bias, const float* ln_g, const float* ln_b, int l2norm,
+                                  const float* dec_g, const float* dec_b, const uint16_t* m0w, const float* m0b, const uint16_t* m1w,
+                                  const float* m1b, const uint16_t* m2w, const float* m2b, const uint16_t* wq, const float* bq,
+                                  const float* query_pos, float* out, float* d_out, float* e_out, float* q_out, const float* pooled, int T, int qcol,
+                                  uint8_t* attn, int32_t* row_any, int flags, int rows, int Q, int E, float eps, void* stream) {
+    MSM_REQUIRE((flags & ~7) == 0, "msm_dec_heads_mask: flags=%d (1 = bit-packed mask, 2 = fp16 weight fragments, 4 = IEEE-half mask operands)", flags);
+    HeadsMask hm{};
+    hm.pooled = pooled, hm.attn = attn, hm.row_any = row_any, hm.T = T, hm.bits = flags & 1, hm.qcol = qcol, hm.f16ops = (flags >> 2) & 1;
+    if (flags & 2)
+        return dec_heads_impl<TileQ16, true>("msm_dec_heads_mask", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, (const f16w*)m0w, m0b,
+                                             (const f16w*)m1w, m1b, (const f16w*)m2w, m2b, (const f16w*)wq, bq, query_pos, out, d_out, e_out, q_out, nullptr,
+                                             rows, Q, E, eps, stream, hm);
+    return dec_heads_impl<TileH16, true>("msm_dec_heads_mask", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, m0w, m0b, m1w, m1b, m2w, m2b,
+                                         wq, bq, query_pos, out, d_out, e_out, q_out, nullptr, rows, Q, E, eps, stream, hm);
 }

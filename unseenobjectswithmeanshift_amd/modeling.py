@@ -317,6 +317,13 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         # bf16 MFMAs with fp32 accumulation (activations as hi + lo pairs); part of set_precision("bf16")
         self.tails_dtype = "f32"
         self.ffn_parts = None          # hidden-dimension slices of the fused FFN tail (None: ops.dec_post_self's default)
+        # 16-bit plans with attention masks at key resolution: the next layer's mask as the epilogue of the heads kernel
+        # (ops.dec_heads_mask: one launch instead of dec_heads + attn_mask_pooled; the same values bit for bit).  Opt-in: measured on
+        # MI355X at B = 8, 640x480 it is NOT faster -- 14.6 / 17 / 27 us per fused launch at 300 / 1200 / 4800 keys against 11.2 + 5.2 / 6.5 /
+        # 12.0 us for the pair, 1.455 against 1.448 ms per graph-replayed pass (f16), and no better with IEEE-half mask operands: the
+        # contraction runs on the ONE CU that owns the 16-query tile (or on a few more that each repeat the MLP chain), where the
+        # separate launch spreads it over the chip, and a kernel boundary inside a HIP graph costs ~1.5 us
+        self.fused_head_masks = False
         # "bf16": the attention cores multiply on bf16 MFMAs (fp32 accumulation, exp, sums) and the batched K/V projection
         # stores bf16; part of set_precision("bf16")
         self.attention_dtype = "f32"
@@ -563,6 +570,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         ncol = None
         pooled = {}
         ra0 = None
+        ra_all, fuse_masks = None, False
         fm_params = None
         if isinstance(mask_features, FoldedMaskFeatures):
             fm_params = [t for t in (mask_features.weight, mask_features.bias) if t is not None]
@@ -575,7 +583,12 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                 want_sizes = self._poolable_sizes(mask_features, sizes)
                 if want_sizes and L > 0:
                     # (the pooling launch also clears the row flags of prediction 0's attention-mask step)
-                    outs, ra0 = ops.pool_mask_taps(mask_features, want_sizes, zero_rows=int(out.shape[1]))
+                    # (... and, for the fused heads + mask launches, of every later prediction's: one (L + 1, B, Q) buffer)
+                    fuse_masks = bool(self.fused_head_masks) and self.tails_dtype in ("bf16", "f16") and not full
+                    Bq, Qn = int(out.shape[0]), int(out.shape[1])
+                    outs, flags = ops.pool_mask_taps(mask_features, want_sizes, zero_rows=Qn * (L + 1 if fuse_masks else 1))
+                    ra_all = flags.view(-1)[:Bq * Qn * (L + 1 if fuse_masks else 1)].view(-1, Bq, Qn)
+                    ra0 = ra_all[0]
                     pooled = dict(zip(want_sizes, outs))
         dn = self.decoder_norm
         pred_cls, pred_mask = [], []
@@ -689,6 +702,17 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             x, parts = ops.dec_post_self(o, x, pk["self_o"][i], sa.self_attn.out_proj.bias, sa.norm.weight, sa.norm.bias,
                                          pk["ffn1"][i], ff.linear1.bias, pk["ffn2"][i], n_parts=self.ffn_parts)
             last = i == L - 1
+            tgt = None if last else tuple(sizes[(i + 1) % self.num_feature_levels])
+            if fuse_masks and cf is None and ncol is not None and tgt in pooled:
+                # prediction i + 1 of a plan that keeps only the final masks: its one product is the next layer's attention mask
+                as_bits = fkv is not None and fkv["layers"][i + 1] is not None
+                out, d, e, q, attn, row_any = ops.dec_heads_mask(x, dn.weight, dn.bias, mlp, pooled[tgt], ra_all[i + 1], qcol=ncol, bits=as_bits,
+                                                                 f16=self.mask_step_dtype in ("bf16", "f16") and self.lp_pooled_masks,
+                                                                 parts=parts, bias=ff.linear2.bias, ln_g=ff.norm.weight, ln_b=ff.norm.bias,
+                                                                 l2norm=self.decoder_block_norm, want_out=True, want_d=False, **next_query(i + 1))
+                pred_cls.append(None)
+                pred_mask.append(None)
+                continue
             out, d, e, q, ra = ops.dec_heads(x, dn.weight, dn.bias, mlp, parts=parts, bias=ff.linear2.bias,
                                              ln_g=ff.norm.weight, ln_b=ff.norm.bias, l2norm=self.decoder_block_norm,
                                              want_out=not last, want_d=full or last, zero_row_any=True,

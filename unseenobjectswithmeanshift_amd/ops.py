@@ -875,6 +875,43 @@ def dec_heads(x, dec_g, dec_b, mlp, *, parts=None, bias=None, ln_g=None, ln_b=No
     return (out, d, e, q, ra) if zero_row_any else (out, d, e, q)
 
 
+def dec_heads_mask(x, dec_g, dec_b, mlp, pooled, row_any, *, qcol=64, bits=False, f16=False, parts=None, bias=None, ln_g=None, ln_b=None, l2norm=False,
+                   wq=None, bq=None, query_pos=None, want_out=True, want_d=False, eps=1e-5):
+    """dec_heads (16-bit weight fragments) with the next layer's attention mask at key resolution as the kernel's epilogue
+    (msm_dec_heads_mask): the values of dec_heads(...) followed by attn_mask_pooled(e[..., :64], pooled, qbias=e[..., qcol],
+    row_any=row_any, bits=bits, f16=f16), bit for bit, in one launch.  ``mlp[-1]`` must be the folded final layer ([e Wm | e.bm | ..]);
+    ``row_any`` (B, Q) int32 must arrive ZEROED.  Returns (out|None, d|None, e, q|None, attn, row_any)."""
+    wd = _wdtype(wq, *[w for w, _ in mlp])
+    if wd not in (torch.bfloat16, torch.float16):
+        raise RuntimeError("dec_heads_mask needs bf16 or fp16 weight fragments (the fp32 plan keeps the two launches)")
+    for i, t in enumerate([x, parts, bias, ln_g, ln_b, dec_g, dec_b, bq, query_pos, pooled] + [b for _, b in mlp]):
+        _c(t, f"dec_heads_mask arg {i}")
+    for i, t in enumerate([wq] + [w for w, _ in mlp]):
+        _c(t, f"dec_heads_mask weight {i}", wd)
+    _c(row_any, "row_any", torch.int32)
+    B, Q, E = x.shape
+    T = pooled.shape[1]
+    if tuple(pooled.shape) != (B, T, 64) or tuple(row_any.shape) != (B, Q):
+        raise RuntimeError("dec_heads_mask needs a (B, T, 64) pooled activation and a (B, Q) row_any buffer")
+    out = torch.empty_like(x) if want_out else None
+    d = torch.empty_like(x) if want_d else None
+    e = torch.empty_like(x)
+    q = torch.empty_like(x) if wq is not None else None
+    if bits:
+        if T % 16:
+            raise RuntimeError("dec_heads_mask(bits=True) needs T % 16 == 0")
+        attn = torch.empty((B, (Q + 111) // 112, T // 16, 16, 8), device=x.device, dtype=torch.int16)
+    else:
+        attn = torch.empty((B, Q, T), device=x.device, dtype=torch.uint8)
+    n_parts = 0 if parts is None else parts.shape[0]
+    (m0w, m0b), (m1w, m1b), (m2w, m2b) = mlp
+    rc = lib().msm_dec_heads_mask(_p(x), _p(parts), n_parts, _p(bias), _p(ln_g), _p(ln_b), 1 if l2norm else 0, _p(dec_g), _p(dec_b), _p(m0w), _p(m0b),
+                                  _p(m1w), _p(m1b), _p(m2w), _p(m2b), _p(wq), _p(bq), _p(query_pos), _p(out), _p(d), _p(e), _p(q), _p(pooled), T,
+                                  int(qcol), _p(attn), _p(row_any), (1 if bits else 0) | (2 if wd == torch.float16 else 0) | (4 if f16 else 0), B * Q, Q, E, eps, _stream())
+    check(rc, "msm_dec_heads_mask")
+    return out, d, e, q, attn, row_any
+
+
 def _msda_dtype(value, others):
     """float32 or float64 like the reference's dispatch (ms_deform_attn_cuda.cu:69); every floating tensor the same."""
     dt = value.dtype
