@@ -106,6 +106,8 @@ _SIGNATURES = {
                           [c_p, c_i, c_i, c_i, c_fl, c_p]),
     "msm_dec_heads_mask": (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_f, c_p, c_f, c_p, c_f, c_p, c_f, c_p, c_f, c_f] + [c_f] * 4 +
                            [c_f, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_fl, c_p]),
+    "msm_l2_prefetch": (c_i, [c_p, c_p, c_i, c_p]),
+    "msm_dec_set_prefetch": (c_i, [c_p, c_p, c_i]),
     "msm_ms_seed_workspace": (c_l, [c_i]),
     "msm_ms_select_seeds": (c_i, [c_f, c_i, c_i, c_i, c_l, c_f, c_p, c_f, c_l, c_i, c_p]),
     "msm_ms_hill_climb_workspace": (c_l, [c_i, c_i]),

@@ -34,6 +34,8 @@
 // (a reduce-scatter: lane lq ends with row 4 rg + lq).  A stage is then 256 MFMAs of 8 cycles per wave, 2 us per SIMD -- balanced
 // against the 64 B/clk at which a CU can stream the 256 KiB of a stage's weights from L2 -- on twice as many tiles (100 x parts).
 // The bf16 chain keeps 16-row tiles (its stage is weight-streaming bound already).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "bf16.h"
@@ -439,6 +441,57 @@ __device__ __forceinline__ void load_tile(float* __restrict__ tile, const float*
     }
 }
 
+// ---- L2 prefetch rows (round 6) -------------------------------------------------------------------------------------------------
+// A layer's tail weights are 3.2 MB of fp16 fragments (6.4 MB fp32) that nothing keeps in the 4-MiB per-XCD L2s between two passes: every
+// tail starts on HBM latency (tools/probes/tails_cold_time.py, 800 rows: post_self 17.5 us cold, 13.4 with its weights resident; heads
+// 15.2 / 13.1; post_cross 10.7 / 9.6).  A tail launch can therefore carry ONE EXTRA ROW of workgroups (the last blockIdx.y) that do no
+// tail work (two rows when the ranges are long): they touch the byte ranges the NEXT launches of the chain will stream
+// (msm_dec_set_prefetch) -- one 4-byte load per 128-byte line -- and exit.  They are dispatched behind the launch's working workgroups onto CUs the 50-200 of them leave idle, and their loads
+// sit in their own waves' queues (a wave's loads return in order: the same loads issued by a working wave would stall its first wait).
+// Each XCD's L2 needs its own copy: the row's workgroups on XCD x (block id % 8 == x: an observed placement, relied on for speed only)
+// share every range between them.  A forked side stream for the same job costs ~10 us per fork / join inside a HIP graph (measured:
+// 1.41 -> 1.68 ms per pass).
+constexpr int DC_PF_MAX = 6;
+struct PfRanges {
+    const unsigned char* p[DC_PF_MAX];
+    int64_t bytes[DC_PF_MAX];
+    int n, rows;                                                       // rows: prefetch rows appended to the grid (0 = none)
+};
+// rows of gx workgroups so that a thread has about eight lines to touch (every XCD's share of the rows reads ALL the bytes), at most 2
+// (1, 2 and 4 rows measured alike at 800 rows: 1.375 - 1.381 ms per f16 pass against 1.405 without)
+static int prefetch_rows(const PfRanges& pf, int gx) {
+    if (pf.n <= 0) return 0;
+    int64_t lines = 0;
+    for (int j = 0; j < pf.n; ++j) lines += (pf.bytes[j] + 127) >> 7;
+    const int64_t want = (lines * 8 + (int64_t)gx * DC_THREADS * 8 - 1) / ((int64_t)gx * DC_THREADS * 8);
+    return (int)max((int64_t)1, min((int64_t)2, want));
+}
+__device__ __forceinline__ bool prefetch_part(const PfRanges& pf) {
+    if (pf.rows <= 0 || (int)blockIdx.y < (int)gridDim.y - pf.rows) return false;
+    const int first = gridDim.x * (gridDim.y - pf.rows);               // linear id of the first prefetch workgroup
+    const int total = gridDim.x * pf.rows;
+    const int j = ((int)blockIdx.y - ((int)gridDim.y - pf.rows)) * gridDim.x + blockIdx.x, xcd = (first + j) & 7;
+    const int j0 = (xcd - first) & 7;                                  // the first prefetch workgroup on this XCD
+    const int k = (j - j0) >> 3;                                       // this workgroup's index among the prefetch workgroups on its XCD
+    const int cnt = (total - j0 + 7) >> 3;                             // ... and their number
+    unsigned acc = 0;
+    for (int r = 0; r < pf.n; ++r) {
+        const int64_t lines = (pf.bytes[r] + 127) >> 7;
+        const int64_t per = (lines + cnt - 1) / cnt;
+        const int64_t l0 = (int64_t)k * per, l1 = min(lines, l0 + per);
+        const unsigned char* base = pf.p[r];
+        // four loads in flight per thread (a trip's loads are independent; lines past the end re-read the last one)
+        for (int64_t l = l0 + threadIdx.x; l < l1; l += 4 * DC_THREADS) {
+            unsigned v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const unsigned*>(base + (min(l + u * DC_THREADS, l1 - 1) << 7));
+            acc ^= (v[0] ^ v[1]) ^ (v[2] ^ v[3]);
+        }
+    }
+    if (acc == 0x9e3779b9u) asm volatile("s_nop 0" ::: "memory");     // (keeps the loads alive)
+    return true;
+}
+
 struct RowStats {
     float mean, rstd;
 };
@@ -500,16 +553,17 @@ __global__ __launch_bounds__(DC_THREADS) void dec_post_cross_kernel(
     const float* __restrict__ o, const float* __restrict__ res, const float* __restrict__ qpos, const WT* __restrict__ wo,
     const float* __restrict__ bo, const float* __restrict__ g, const float* __restrict__ b, const WT* __restrict__ w_in,
     const float* __restrict__ b_in, float* __restrict__ x_out, float* __restrict__ qk_out, float* __restrict__ v_out,
-    int rows, int Q, float eps) {
+    int rows, int Q, float eps, PfRanges pf) {
     __shared__ __attribute__((aligned(16))) float lds[3 * TK::R * TK::LD];
     float *T0 = lds, *X = lds + TK::R * TK::LD, *XP = lds + 2 * TK::R * TK::LD;
+    if (prefetch_part(pf)) return;                                     // the prefetch rows (see PfRanges)
     const int row0 = blockIdx.x * TK::R;
     const int valid = min(TK::R, rows - row0);
     // blockIdx.y picks the projection (0: q, 1: k, 2: v): the 16-row tile is MFMA-bound on ONE CU at 3.4 us per
     // 256x256 stage, so the three independent projections go to three CUs; each repeats the Wo + LN stage.
     // gridDim.y == 2 (8-row tiles: 100 tiles x 3 parts would not fit the chip in one round): part 0 runs q THEN k, part 1 runs v.
     const int part = blockIdx.y;
-    const bool two = gridDim.y == 2;
+    const bool two = (int)gridDim.y - pf.rows == 2;
     const int first = two ? (part == 0 ? 0 : 2) : part;        // the projection this workgroup starts with
     const WT* wp = w_in + (int64_t)first * DC_E * DC_E;
     BFrag<WT> f;
@@ -531,14 +585,16 @@ template <typename TK, typename WT = typename TK::WT>
 __global__ __launch_bounds__(DC_THREADS) void dec_post_self_kernel(
     const float* __restrict__ o, const float* __restrict__ res, const WT* __restrict__ wo, const float* __restrict__ bo,
     const float* __restrict__ g, const float* __restrict__ b, const WT* __restrict__ w1, const float* __restrict__ b1,
-    const WT* __restrict__ w2, int F, float* __restrict__ x_out, float* __restrict__ parts, int rows, float eps) {
+    const WT* __restrict__ w2, int F, float* __restrict__ x_out, float* __restrict__ parts, int rows, float eps, PfRanges pf) {
     __shared__ __attribute__((aligned(16))) float lds[2 * TK::R * TK::LD];
     float *T0 = lds, *X = lds + TK::R * TK::LD;
+    if (prefetch_part(pf)) return;                                     // the prefetch rows (see PfRanges)
+    const int n_chunks_y = (int)gridDim.y - pf.rows;
     const int row0 = blockIdx.x * TK::R, chunk = blockIdx.y;
     const int valid = min(TK::R, rows - row0);
     // blockIdx.y owns F/256/gridDim.y consecutive 256-wide hidden chunks; their W2 products accumulate in registers.
     // linear1: rows [c*256, +256) of the packed (F, 256) matrix; linear2 (256, F): k-chunks 4c..4c+3 of every row tile.
-    const int per = (F / DC_E) / gridDim.y, c0 = chunk * per;
+    const int per = (F / DC_E) / n_chunks_y, c0 = chunk * per;
     const int kct2 = F / 64;
     BFrag<WT> f;
     attn_out_ln<TK>(o, res, wo, bo, g, b, nullptr, 1, x_out, chunk == 0, T0, X, nullptr, row0, rows, eps, f,
@@ -583,9 +639,10 @@ __global__ __launch_bounds__(DC_THREADS) void dec_heads_kernel(
     const float* __restrict__ b2, const WT* __restrict__ m0w, const float* __restrict__ m0b, const WT* __restrict__ m1w,
     const float* __restrict__ m1b, const WT* __restrict__ m2w, const float* __restrict__ m2b, const WT* __restrict__ wq,
     const float* __restrict__ bq, const float* __restrict__ qpos, float* __restrict__ out, float* __restrict__ d_out,
-    float* __restrict__ e_out, float* __restrict__ q_out, int32_t* __restrict__ row_any_zero, int rows, int Q, float eps, HeadsMask hm) {
+    float* __restrict__ e_out, float* __restrict__ q_out, int32_t* __restrict__ row_any_zero, int rows, int Q, float eps, HeadsMask hm, PfRanges pf) {
     __shared__ __attribute__((aligned(16))) float lds[3 * TK::R * TK::LD];
     float *XP = lds, *Dn = lds + TK::R * TK::LD, *T0 = lds + 2 * TK::R * TK::LD;
+    if (prefetch_part(pf)) return;                                     // the prefetch rows (see PfRanges)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int row0 = blockIdx.x * TK::R, valid = min(TK::R, rows - row0);
     int img = 0, tile = 0;
@@ -786,6 +843,14 @@ __global__ __launch_bounds__(256) void dec_pack_weight_bf16_kernel(const float* 
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// the ranges the NEXT tail launch of this thread carries in its prefetch row (msm_dec_set_prefetch); taken (and cleared) by that launch
+static thread_local PfRanges g_next_prefetch = {};
+static PfRanges take_prefetch() {
+    const PfRanges pf = g_next_prefetch;
+    g_next_prefetch.n = 0;
+    return pf;
+}
+
 }  // namespace msm
 
 using namespace msm;
@@ -841,8 +906,10 @@ static int dec_post_cross_impl(const char* who, const float* attn_out, const flo
     MSM_REQUIRE(rows > 0 && Q > 0, "%s: bad sizes", who);
     MSM_REQUIRE(aligned16(attn_out) && aligned16(wo) && aligned16(w_in), "%s: pointers must be 16-byte aligned", who);
     // 8-row tiles take two parts (q then k | v): three would oversubscribe the chip at 800 rows (see use_tile8)
-    hipLaunchKernelGGL(dec_post_cross_kernel<TK>, dim3(cdiv(rows, TK::R), TK::F8 ? 2 : 3), dim3(DC_THREADS), 0, (hipStream_t)stream, attn_out,
-                       res, query_pos, wo, bo, ln_g, ln_b, w_in, b_in, x_out, qk_out, v_out, rows, Q, eps);
+    PfRanges pf = take_prefetch();
+    pf.rows = prefetch_rows(pf, cdiv(rows, TK::R));
+    hipLaunchKernelGGL(dec_post_cross_kernel<TK>, dim3(cdiv(rows, TK::R), (TK::F8 ? 2 : 3) + pf.rows), dim3(DC_THREADS), 0, (hipStream_t)stream,
+                       attn_out, res, query_pos, wo, bo, ln_g, ln_b, w_in, b_in, x_out, qk_out, v_out, rows, Q, eps, pf);
     MSM_CHECK_LAUNCH(who);
     return MSM_OK;
 }
@@ -883,8 +950,10 @@ static int dec_post_self_impl(const char* who, const float* attn_out, const floa
     MSM_REQUIRE(rows > 0 && F > 0 && F % DC_E == 0, "%s: F=%d must be a positive multiple of 256", who, F);
     MSM_REQUIRE(n_parts > 0 && (F / DC_E) % n_parts == 0, "%s: n_parts=%d must divide F/256=%d", who, n_parts, F / DC_E);
     MSM_REQUIRE(aligned16(attn_out) && aligned16(wo) && aligned16(w1) && aligned16(w2), "%s: pointers must be 16-byte aligned", who);
-    hipLaunchKernelGGL(dec_post_self_kernel<TK>, dim3(cdiv(rows, TK::R), n_parts), dim3(DC_THREADS), 0, (hipStream_t)stream, attn_out,
-                       res, wo, bo, ln_g, ln_b, w1, b1, w2, F, x_out, parts, rows, eps);
+    PfRanges pf = take_prefetch();
+    pf.rows = prefetch_rows(pf, cdiv(rows, TK::R));
+    hipLaunchKernelGGL(dec_post_self_kernel<TK>, dim3(cdiv(rows, TK::R), n_parts + pf.rows), dim3(DC_THREADS), 0, (hipStream_t)stream, attn_out,
+                       res, wo, bo, ln_g, ln_b, w1, b1, w2, F, x_out, parts, rows, eps, pf);
     MSM_CHECK_LAUNCH(who);
     return MSM_OK;
 }
@@ -939,9 +1008,12 @@ static int dec_heads_impl(const char* who, const float* x, const float* parts, i
         hm.parts = max(1, min(min(cdiv(nkb, 3 * DC_NW), 8), max(1, 256 / tiles - (wq ? 1 : 0))));
         grid = dim3(tiles, hm.parts + (wq ? 1 : 0));
     }
+    PfRanges pf = take_prefetch();
+    pf.rows = prefetch_rows(pf, (int)grid.x);
+    grid.y += pf.rows;
     hipLaunchKernelGGL((dec_heads_kernel<TK, MASK>), grid, dim3(DC_THREADS), 0, (hipStream_t)stream, x, parts, n_parts, bias,
                        ln_g, ln_b, l2norm, dec_g, dec_b, m0w, m0b, m1w, m1b, m2w, m2b, wq, bq, query_pos, out, d_out, e_out, q_out,
-                       row_any_zero, rows, Q, eps, hm);
+                       row_any_zero, rows, Q, eps, hm, pf);
     MSM_CHECK_LAUNCH(who);
     return MSM_OK;
 }
@@ -994,4 +1066,20 @@ extern "C" int msm_dec_heads_mask(const float* x, const float* parts, int n_part
                                              rows, Q, E, eps, stream, hm);
     return dec_heads_impl<TileH16, true>("msm_dec_heads_mask", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, m0w, m0b, m1w, m1b, m2w, m2b,
                                          wq, bq, query_pos, out, d_out, e_out, q_out, nullptr, rows, Q, E, eps, stream, hm);
+}
+
+// The byte ranges (16-byte aligned device pointers; HOST arrays of n <= 6 entries) that the NEXT msm_dec_post_cross* / msm_dec_post_self* /
+// msm_dec_heads* launch issued by this thread touches from an extra row of workgroups (see PfRanges above): the weights of the launches
+// that follow it in the chain.  n = 0 clears a pending request.  Affects speed only.
+extern "C" int msm_dec_set_prefetch(const void* const* ptrs, const int64_t* bytes, int n) {
+    MSM_REQUIRE(n >= 0 && n <= DC_PF_MAX && (n == 0 || (ptrs && bytes)), "msm_dec_set_prefetch: 0..%d ranges", DC_PF_MAX);
+    PfRanges pf{};
+    for (int j = 0; j < n; ++j) {
+        MSM_REQUIRE(ptrs[j] && bytes[j] > 0 && aligned16(ptrs[j]), "msm_dec_set_prefetch: range %d must be a 16-byte aligned device pointer with a positive size", j);
+        pf.p[j] = (const unsigned char*)ptrs[j];
+        pf.bytes[j] = bytes[j];
+    }
+    pf.n = n;
+    g_next_prefetch = pf;
+    return MSM_OK;
 }

@@ -324,6 +324,9 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         # contraction runs on the ONE CU that owns the 16-query tile (or on a few more that each repeat the MLP chain), where the
         # separate launch spreads it over the chip, and a kernel boundary inside a HIP graph costs ~1.5 us
         self.fused_head_masks = False
+        # L2 prefetch of the fused tails' packed weights by an extra row of workgroups in the tail launch in front (ops.dec_set_prefetch,
+        # csrc/dec_chain.hip PfRanges): True = in the 16-bit plans (a layer's tail weights are 3.2 MB there), "always" = in every plan, False = off
+        self.weight_prefetch = True
         # "bf16": the attention cores multiply on bf16 MFMAs (fp32 accumulation, exp, sums) and the batched K/V projection
         # stores bf16; part of set_precision("bf16")
         self.attention_dtype = "f32"
@@ -681,6 +684,14 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             _, d, e, q, ra = ops.dec_heads(out, dn.weight, dn.bias, mlp, want_out=False, want_d=full or L == 0,
                                            zero_row_any=True, **next_query(0))
         attn, row_any = predict(d, e, ra, 0)
+        # L2 prefetch of the tails' weights (weight_prefetch; ops.dec_set_prefetch): every tail launch carries a row of workgroups that
+        # touch the packed weights of the launches BEHIND it in the chain, so those start on L2 hits instead of HBM latency
+        pf_on = bool(self.weight_prefetch) and out.is_cuda and (self.weight_prefetch == "always" or self.tails_dtype in ("bf16", "f16"))
+
+        def prefetch(tensors):
+            if pf_on:
+                ops.dec_set_prefetch(tensors)
+
         for i in range(L):
             lvl = i % self.num_feature_levels                                     # DEC:608
             ca = self.transformer_cross_attention_layers[i]
@@ -696,12 +707,17 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                 kv = kv_all[i] if kv_all is not None else self._kv_one(xs[lvl], kv_w[i], kv_c[i])          # (B, hw, 2E) = [K | V]
                 o = ops.hypersphere_attention(q, kv[..., :E], kv[..., E:], H, masked=attn, row_any=row_any, kappa=float(KAPPA), low_precision=lp,
                                               keys_f16=kf)
+            prefetch([pk["self_o"][i], pk["ffn1"][i], pk["ffn2"][i]])              # post_self's weights, from post_cross's launch
             x, qk, v = ops.dec_post_cross(o, out, qpos, pk["cross_o"][i], ca.meanshift_attn.out_proj.bias, ca.norm.weight,
                                           ca.norm.bias, pk["self_in"][i], sa.self_attn.in_proj_bias)
             o = ops.hypersphere_attention(qk[..., :E], qk[..., E:], v, H, kappa=float(KAPPA), low_precision=lp, keys_f16=kf)
+            # (the heads' weights -- the shared mask-embedding MLP, the next query projection -- are L2 residents already: prefetching them from
+            # post_self's launch measured 1.386 against 1.380 ms per pass)
             x, parts = ops.dec_post_self(o, x, pk["self_o"][i], sa.self_attn.out_proj.bias, sa.norm.weight, sa.norm.bias,
                                          pk["ffn1"][i], ff.linear1.bias, pk["ffn2"][i], n_parts=self.ffn_parts)
             last = i == L - 1
+            if not last:
+                prefetch([pk["cross_o"][i + 1], pk["self_in"][i + 1]])           # the next layer's post_cross weights, from the heads' launch
             tgt = None if last else tuple(sizes[(i + 1) % self.num_feature_levels])
             if fuse_masks and cf is None and ncol is not None and tgt in pooled:
                 # prediction i + 1 of a plan that keeps only the final masks: its one product is the next layer's attention mask

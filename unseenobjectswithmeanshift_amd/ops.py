@@ -912,6 +912,34 @@ def dec_heads_mask(x, dec_g, dec_b, mlp, pooled, row_any, *, qcol=64, bits=False
     return out, d, e, q, attn, row_any
 
 
+def dec_set_prefetch(tensors):
+    """The NEXT dec_post_cross / dec_post_self / dec_heads(_mask) call of this thread touches the storage of ``tensors`` (<= 6 contiguous
+    device tensors: the packed weights of the launches behind it in the chain) from an extra row of workgroups, so that every XCD's L2
+    holds them when those launches start (msm_dec_set_prefetch).  Speed only; an empty list clears a pending request."""
+    ts = [t for t in tensors if t is not None and t.numel() > 0][:6]
+    for t in ts:
+        if not t.is_cuda or not t.is_contiguous():
+            raise RuntimeError("dec_set_prefetch needs contiguous device tensors")
+    n = len(ts)
+    ptrs = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in ts])
+    nbytes = (ctypes.c_int64 * max(n, 1))(*[t.numel() * t.element_size() for t in ts])
+    check(lib().msm_dec_set_prefetch(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(nbytes, ctypes.c_void_p), n), "msm_dec_set_prefetch")
+
+
+def l2_prefetch(tensors):
+    """Touch the storage of up to 8 device tensors per launch so that every XCD's L2 holds it (msm_l2_prefetch): issued on a side stream
+    beside a kernel that leaves the fabric idle, ahead of the kernel that streams these bytes.  Speed only."""
+    ts = [t for t in tensors if t is not None and t.numel() > 0]
+    for t in ts:
+        if not t.is_cuda or not t.is_contiguous():
+            raise RuntimeError("l2_prefetch needs contiguous device tensors")
+    for i in range(0, len(ts), 8):
+        grp = ts[i:i + 8]
+        ptrs = (ctypes.c_void_p * len(grp))(*[t.data_ptr() for t in grp])
+        nbytes = (ctypes.c_int64 * len(grp))(*[t.numel() * t.element_size() for t in grp])
+        check(lib().msm_l2_prefetch(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(nbytes, ctypes.c_void_p), len(grp), _stream()), "msm_l2_prefetch")
+
+
 def _msda_dtype(value, others):
     """float32 or float64 like the reference's dispatch (ms_deform_attn_cuda.cu:69); every floating tensor the same."""
     dt = value.dtype
