@@ -1,0 +1,152 @@
+#!/usr/bin/env python
+"""Turn rocprofv3 outputs under gpurun_out/ into the small tracked summaries under profiles/.
+   python tools/summarize_profile.py <prof_dir> <tag> [pmc_dir ...]"""
+import collections
+import csv
+import glob
+import os
+import shutil
+import sys
+
+prof, tag = sys.argv[1], sys.argv[2]
+os.makedirs("profiles", exist_ok=True)
+stats = glob.glob(os.path.join(prof, "*kernel_stats.csv"))[0]
+shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
+rows = list(csv.DictReader(open(stats)))
+with open(f"profiles/{tag}_kernel_stats.md", "w") as f:
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    f.write(f"# rocprofv3 --kernel-trace --stats summary ({tag})\n\n")
+    f.write("command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 10 --warmup 2 --no-graph --no-cpu-baseline "
+            "--no-extras --min-seconds 0` (tools/profile_round.sh; 25-30 passes of the hot path per run: warm-up, step estimate, timed, "
+            "event-timed -- plus the roofline legs of bench.py: 100 extra encoder-block replays and the full-resolution mask-step "
+            "launches, which is why those kernels have more calls than 6 / 1 per pass)\n\n")
+    f.write("| kernel | calls | avg us | total ms | % |\n|---|---:|---:|---:|---:|\n")
+    for r in rows[:30]:
+        f.write(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['TotalDurationNs']) / 1e6:.2f} | "
+                f"{100 * float(r['TotalDurationNs']) / tot:.1f} |\n")
+    npass = next((int(r["Calls"]) for r in rows if "conv_in_multi_kernel" in r["Name"] or "conv_in_lp_multi_kernel" in r["Name"]), 1)
+    f.write(f"\ntotal GPU kernel time {tot / 1e6:.1f} ms over {npass} passes = {tot / npass / 1e6:.2f} ms per pass of 8 images\n")
+# One steady-state pass of the hot path, cut out of the kernel trace: the run's --stats table above mixes warm-up, the roofline
+# legs and the timed passes; here the trace is segmented at the first kernel of a pass (conv_in_multi_kernel), the segments of the
+# most common length are the plain passes, and their per-kernel averages are what one pass of 8 images launches.
+trace = glob.glob(os.path.join(prof, "*kernel_trace.csv"))
+if trace:
+    tr = sorted(csv.DictReader(open(trace[0])), key=lambda r: int(r["Start_Timestamp"]))
+    cut = [i for i, r in enumerate(tr) if "conv_in_multi_kernel" in r["Kernel_Name"] or "conv_in_lp_multi_kernel" in r["Kernel_Name"]]
+    segs = [tr[a:b] for a, b in zip(cut, cut[1:])]
+    if segs:
+        modal = collections.Counter(len(x) for x in segs).most_common(1)[0][0]
+        segs = [x for x in segs if len(x) == modal]
+        per = collections.OrderedDict()
+        for seg in segs:
+            for r in seg:
+                per.setdefault(r["Kernel_Name"], []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        busy = sum(sum(v) for v in per.values()) / len(segs)
+        span = sum(int(x[-1]["End_Timestamp"]) - int(x[0]["Start_Timestamp"]) for x in segs) / len(segs)
+        with open(f"profiles/{tag}_kernel_stats.md", "a") as f:
+            f.write(f"\n## One pass of 8 images (mean of the {len(segs)} plain passes of the trace, {modal} launches each)\n\n")
+            f.write(f"kernel time {busy / 1e3:.0f} us per pass; first start to last end {span / 1e3:.0f} us (eager launches under the profiler: "
+                    "the gaps are host launch latency, absent from the graph replays bench.py times)\n\n")
+            f.write("| kernel | launches per pass | avg us | us per pass | % of kernel time |\n|---|---:|---:|---:|---:|\n")
+            for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+                f.write(f"| `{k[:100]}` | {len(v) / len(segs):.0f} | {sum(v) / len(v) / 1e3:.1f} | {sum(v) / len(segs) / 1e3:.1f} | "
+                        f"{100 * sum(v) / len(segs) / busy:.1f} |\n")
+for pmc in sys.argv[3:]:
+    fs = glob.glob(os.path.join(pmc, "*counter_collection.csv"))
+    if not fs:
+        continue
+    agg = collections.defaultdict(list)
+    name = None
+    for r in csv.DictReader(open(fs[0])):
+        name = r["Counter_Name"]
+        agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    with open(f"profiles/{tag}_pmc_{name}.md", "w") as f:
+        f.write(f"# rocprofv3 --pmc {name} ({tag}), per-dispatch average, KB as reported (uncorrected)\n\n")
+        f.write("FETCH_SIZE on gfx950 reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section): "
+                "double it before comparing with a byte count; WRITE_SIZE matched known byte counts 1:1 here "
+                "(inst_upsample: 205 MB reported vs 197 MB written).\n\n| kernel | dispatches | avg KB |\n|---|---:|---:|\n")
+        for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:25]:
+            f.write(f"| `{k[:90]}` | {len(v)} | {sum(v) / len(v):.0f} |\n")
+# HBM traffic of the dominant kernel (mask step), per launch, averaged over its dispatch variants by call count
+import hashlib
+import json
+import subprocess
+
+
+def stamp(*sources):
+    """Provenance of a traffic file: the commit it was collected on and the SHA-256 of the kernel sources it describes.  bench.py
+    reports `traffic: null` when a source no longer hashes to what is recorded here (a kernel edit silently desynchronising the
+    committed byte counts from the timed kernel was the round-3 review's finding)."""
+    def sha(name):
+        with open(os.path.join("unseenobjectswithmeanshift_amd", "csrc", name), "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()
+    commit = os.environ.get("MSM_COMMIT") or None         # (summarised on the GPU box, which has no .git: tools/profile_all.sh passes it)
+    if commit is None:
+        try:
+            commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+        except OSError:
+            commit = None
+    return {"commit": commit, "kernel_source_sha256": {n: sha(n) for n in sources}}
+
+
+vals = {}
+for pmc in sys.argv[3:]:
+    fs = glob.glob(os.path.join(pmc, "*counter_collection.csv"))
+    if not fs:
+        continue
+    for r in csv.DictReader(open(fs[0])):
+        if "mask_logits_kernel" in r["Kernel_Name"]:
+            vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+    fetch = 2.0 * 1024 * sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"])     # x2: gfx950 wide-read correction
+    write = 1024.0 * sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"])
+    json.dump({"kernel": "mask_logits_kernel", "bytes_per_launch": round(fetch + write),
+               "fetch_bytes_corrected": round(fetch), "write_bytes": round(write),
+               # folded step (bench default): the 64-channel activation, the folded embedding and a tenth of the final mask;
+               # the literal 256-channel contraction would be 8 * (256 * 19200 + 100 * 256) * 4 + the same mask share
+               "algorithmic_bytes_per_launch": 8 * (64 * 19200 + 100 * 64) * 4 + (8 * 100 * 19200 * 4) // 10,
+               "note": "mean over the 10 launches of a step (9 write only attention-mask bytes, 1 writes the full mask); "
+                       "FETCH_SIZE doubled per MI355X_MICROARCH.md (HBM section), WRITE_SIZE as reported; folded mask step "
+                       "(64-channel activation instead of the 256-channel mask_features tensor)",
+               "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes ({tag})",
+               "stamp": stamp("mask_logits.hip")},
+              open("profiles/mask_step_traffic.json", "w"), indent=1)
+# step_traffic.json: the dominant kernel (encoder block) and the one full-resolution mask launch of a step (bench.py reads it)
+def per_launch(match):
+    v = {}
+    for pmc in sys.argv[3:]:
+        fs = glob.glob(os.path.join(pmc, "*counter_collection.csv"))
+        if not fs:
+            continue
+        for r in csv.DictReader(open(fs[0])):
+            if match(r["Kernel_Name"]):
+                v.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+        return None
+    fetch = 2.0 * 1024 * sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"])
+    write = 1024.0 * sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])
+    return {"fetch_bytes_corrected": round(fetch), "write_bytes": round(write), "bytes_per_launch": round(fetch + write)}
+
+
+# the 16-bit plans' dominant kernel (csrc/enc_lp.hip), when the profiled run was one of them: step_traffic_<precision>.json
+hm = per_launch(lambda k: "enc_block_hm_kernel" in k)
+if hm:
+    prec = "f16" if any("enc_block_hm_kernel<true>" in r["Name"] or "enc_block_hm_kernel<(bool)1>" in r["Name"] for r in rows) else "bf16"
+    hm["note"] = ("mean over the six launches of a pass (five with the next layer's value / sampling projection, the last without): fp16 attention "
+                  "in, fp32 residual in / out, fp16 value and fp32-offset sampling records out; weights stay in L2")
+    json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes ({tag}, tools/profile_round.sh <tag> {prec}); FETCH_SIZE "
+                         "doubled per MI355X_MICROARCH.md (HBM section), WRITE_SIZE as reported; KB -> bytes",
+               "stamp": stamp("enc_lp.hip"), "enc_block_hm_kernel": hm}, open(f"profiles/step_traffic_{prec}.json", "w"), indent=1)
+enc = per_launch(lambda k: "enc_block_kernel" in k)
+fin = per_launch(lambda k: "mask_logits_kernel<0, true" in k)
+if enc and fin:
+    enc.update({"algorithmic_bytes_per_launch": 109670400,
+                "note": "reads the gathered attention output and the residual stream (2 x 64 floats per token), writes the new stream, the next "
+                        "layer's value projection and its sampling projection (64 + 64 + 288 floats per token); weights stay in L2"})
+    fin.update({"note": "the full-resolution mask launches of the profiled run (final prediction; on the top-K embeddings in the default "
+                        "inference plan, on all queries in the roofline leg of bench.py), averaged"})
+    json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes ({tag}, tools/profile_round.sh); FETCH_SIZE doubled per "
+                         "MI355X_MICROARCH.md (HBM section), WRITE_SIZE as reported; KB -> bytes",
+               "stamp": stamp("enc_block.hip", "mask_logits.hip"),
+               "enc_block_kernel": enc, "mask_logits_kernel_final": fin}, open("profiles/step_traffic.json", "w"), indent=1)
+print("ok")

@@ -59,7 +59,7 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 20   /* 20: msm_ucn_embedding_tail; 19: backbone glue (msm_bias_act_nhwc, msm_nhwc_to_nchw_f32); 18: flags argument of msm_attn_mask_pooled (bit 1: IEEE-half operands); 17: msm_f32_to_f16_rows; 16: msm_mask_conv3x3_folded (the UCN mask step with the 3x3 mask_features convolution folded into the query embedding); 15: IEEE-half operand forms of the 16-bit plan (precision "f16": msm_dec_*_f16, msm_encoder_block_hm_fwd ffn_f16, fp16 keys in the low-precision attention); 14: cmat_width argument of the K/V projections (separable position constants), msm_conv3x3_c64_nchw_bf16, msm_encoder_prologue_hm_fwd; 13: flags argument of msm_ms_select_seeds_bf16 (persistent on-chip seeding over the bf16 copy), input projections on the bf16 matrix pipe (msm_conv1x1_in_lp, msm_conv1x1_in_multi_lp); 12: head-major bf16 activations between the encoder kernels of the bf16 plan (msm_encoder_block_hm_fwd, msm_msdeform_attn_enc_lp_fwd, msm_f32_to_f16); 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
+#define MSM_ABI_VERSION 21   /* 21: msm_dec_heads_mask (the next layer's attention mask as the heads kernel's epilogue), msm_l2_prefetch / msm_dec_set_prefetch, MSM_OPT_DEC_TILE32; 20: msm_ucn_embedding_tail; 19: backbone glue (msm_bias_act_nhwc, msm_nhwc_to_nchw_f32); 18: flags argument of msm_attn_mask_pooled (bit 1: IEEE-half operands); 17: msm_f32_to_f16_rows; 16: msm_mask_conv3x3_folded (the UCN mask step with the 3x3 mask_features convolution folded into the query embedding); 15: IEEE-half operand forms of the 16-bit plan (precision "f16": msm_dec_*_f16, msm_encoder_block_hm_fwd ffn_f16, fp16 keys in the low-precision attention); 14: cmat_width argument of the K/V projections (separable position constants), msm_conv3x3_c64_nchw_bf16, msm_encoder_prologue_hm_fwd; 13: flags argument of msm_ms_select_seeds_bf16 (persistent on-chip seeding over the bf16 copy), input projections on the bf16 matrix pipe (msm_conv1x1_in_lp, msm_conv1x1_in_multi_lp); 12: head-major bf16 activations between the encoder kernels of the bf16 plan (msm_encoder_block_hm_fwd, msm_msdeform_attn_enc_lp_fwd, msm_f32_to_f16); 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
 int msm_abi_version(void);
 
 /* Kernel-selection overrides for tools/ and tests/ (NOT read on the product path: every option defaults to
@@ -86,6 +86,7 @@ enum {
     MSM_OPT_MASK_KERNEL,        /* fp32 mask step: 5 = never the 4-query block on the 4x4x1 MFMA (fallback kernel) */
     MSM_OPT_MS_SPLIT_KERNEL,    /* msm_ms_hill_climb_split: 1 = X split inside the iteration kernel (fallback of the pre-split planes) */
     MSM_OPT_CONV3_WIDE,         /* msm_conv3x3_c64_f32 / _bf16: 0 = one 16-pixel block per wave, 16 waves per workgroup; 1 = two blocks, 8 waves (default: bf16 only) */
+    MSM_OPT_DEC_TILE32,         /* msm_dec_*_f16: 1 = 32-row tiles (two 16-row MFMA tiles share every weight fragment), 0 = 16-row tiles (default: 32 from 4096 rows) */
     MSM_OPT_COUNT
 };
 int msm_set_option(int key, int value);
@@ -504,6 +505,34 @@ int msm_dec_heads_f16(const float* x, const float* parts, int n_parts, const flo
                       const uint16_t* wq, const float* bq, const float* query_pos,
                       float* out, float* d_out, float* e_out, float* q_out, int32_t* row_any_zero,
                       int rows, int Q, int E, float eps, void* stream);
+
+/* msm_dec_heads_bf16 / _f16 with the NEXT layer's attention mask at key resolution as the kernel's epilogue (round 6; replaces the
+ * pair msm_dec_heads_* + msm_attn_mask_pooled(flags & 2) of the 16-bit plans: DEC:660-682 with interpolate(einsum(e, F)) =
+ * einsum(e, interpolate(F))).  e_out must be the folded embedding [e Wm | e.bm | ...]: columns 0..63 contract with pooled
+ * [rows / Q][T][64] (msm_pool_mask_taps), column qcol (>= 64) is the per-query bias.  attn: (B, Q, T) bytes, or with flags & 1 the
+ * bit-packed blocked form of msm_attn_pack_mask_bits (T % 16 == 0); row_any (B, Q) must arrive ZEROED and receives 1 where a row
+ * keeps an unmasked key.  flags & 2: fp16 weight fragments (msm_dec_pack_weight_f16), else bf16 fragments; flags & 4: the mask
+ * contraction on IEEE-half operands (msm_attn_mask_pooled's flag 2), else its fp32 MFMA chain.  Same values as the two-launch form,
+ * bit for bit.  rows must be a multiple of Q: tiles
+ * are image-aligned (ceil(Q / 16) per image). */
+int msm_dec_heads_mask(const float* x, const float* parts, int n_parts, const float* bias,
+                       const float* ln_g, const float* ln_b, int l2norm,
+                       const float* dec_g, const float* dec_b,
+                       const uint16_t* m0w, const float* m0b, const uint16_t* m1w, const float* m1b,
+                       const uint16_t* m2w, const float* m2b,
+                       const uint16_t* wq, const float* bq, const float* query_pos,
+                       float* out, float* d_out, float* e_out, float* q_out,
+                       const float* pooled, int T, int qcol, uint8_t* attn, int32_t* row_any, int flags,
+                       int rows, int Q, int E, float eps, void* stream);
+
+/* msm_l2_prefetch -- touch up to 8 device byte ranges (16-byte aligned) so that every XCD's L2 holds them: launched on a side stream
+ * beside a kernel that leaves the fabric idle, ahead of the kernel that streams the ranges (the decoder tails' packed weights; round 6,
+ * csrc/prefetch.hip).  ptrs / bytes are HOST arrays of n entries.  Affects speed only. */
+int msm_l2_prefetch(const void* const* ptrs, const int64_t* bytes, int n, void* stream);
+/* msm_dec_set_prefetch -- the same job without a launch of its own: the NEXT msm_dec_post_cross* / msm_dec_post_self* / msm_dec_heads*
+ * call of this thread carries one extra row of workgroups that touch the n <= 6 ranges (the packed weights of the launches behind it in
+ * the decoder's chain) and exit; n = 0 clears a pending request.  (A forked side stream costs ~10 us per fork / join inside a HIP graph.) */
+int msm_dec_set_prefetch(const void* const* ptrs, const int64_t* bytes, int n);
 
 /* ---------------------------------------------------------------------------------------------
  * Backward of msm_hypersphere_attn_fwd (training step of the reference: hypersphere_attention under autograd, AU:64-82,

@@ -1128,3 +1128,67 @@ def test_parameter_only_subgraphs_follow_parameter_updates():
     want, _ = fresh(feats)
     assert torch.equal(after["pred_masks"], want["pred_masks"]) and torch.equal(after["pred_logits"], want["pred_logits"])
 
+
+
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
+def test_fused_head_masks_equal_two_launches(precision):
+    """decoder.fused_head_masks (round 6, 16-bit plans): the head at 640x480, batch 8, with the intermediate attention masks computed in
+    the heads kernels' epilogues returns bit for bit what it returns with dec_heads + attn_mask_pooled as two launches per layer."""
+    from unseenobjectswithmeanshift_amd import ops
+    from unseenobjectswithmeanshift_amd.meta_arch import build_resnet50_head
+    head = build_resnet50_head(num_queries=100, dec_layers=9)
+    head.pixel_decoder.load_state_dict(syn.synth_state_dict(syn.pixel_decoder_param_shapes()), strict=True)
+    head.predictor.load_state_dict(syn.synth_state_dict(syn.decoder_param_shapes()), strict=True)
+    head = head.to(DEV).eval()
+    head.set_precision(precision)
+    feats = {k: v.to(DEV) for k, v in syn.synth_backbone_features(8, 480, 640, seed=10).items()}
+    assert not head.predictor.fused_head_masks               # opt-in: not faster (modeling.py)
+    head.predictor.fused_head_masks = True
+    calls = []
+    orig = ops.dec_heads_mask
+    ops.dec_heads_mask = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        a, _ = head(feats)
+    finally:
+        ops.dec_heads_mask = orig
+    assert len(calls) == 8                                   # layers 0..7 feed a next layer; the last prediction keeps the two-step form
+    head.predictor.fused_head_masks = False
+    b, _ = head(feats)
+    assert torch.equal(a["pred_masks"], b["pred_masks"]) and torch.equal(a["pred_logits"], b["pred_logits"])
+
+
+@pytest.mark.parametrize("precision", ["f16", "bf16", "f32"])
+def test_weight_prefetch_rows_change_nothing(precision):
+    """decoder.weight_prefetch (round 6): the tails' launches carry an extra row of workgroups that only touch the next launches' packed
+    weights (msm_dec_set_prefetch) -- with it on (the 16-bit plans' default; "always" for fp32), off, and with odd requests in front of a
+    launch the head returns the same bits."""
+    from unseenobjectswithmeanshift_amd import ops
+    from unseenobjectswithmeanshift_amd.meta_arch import build_resnet50_head
+    head = build_resnet50_head(num_queries=100, dec_layers=9)
+    head.pixel_decoder.load_state_dict(syn.synth_state_dict(syn.pixel_decoder_param_shapes()), strict=True)
+    head.predictor.load_state_dict(syn.synth_state_dict(syn.decoder_param_shapes()), strict=True)
+    head = head.to(DEV).eval()
+    head.set_precision(precision)
+    feats = {k: v.to(DEV) for k, v in syn.synth_backbone_features(3, 480, 640, seed=10).items()}
+    calls = []
+    orig = ops.dec_set_prefetch
+    ops.dec_set_prefetch = lambda ts: (calls.append(len(ts)), orig(ts))[1]
+    try:
+        head.predictor.weight_prefetch = "always" if precision == "f32" else True
+        a, _ = head(feats)
+        n_on = len(calls)
+        head.predictor.weight_prefetch = False
+        b, _ = head(feats)
+    finally:
+        ops.dec_set_prefetch = orig
+    assert n_on == 9 + 8 and len(calls) == n_on               # the post_cross and (all but the last) heads launches carried prefetch rows
+    assert torch.equal(a["pred_masks"], b["pred_masks"]) and torch.equal(a["pred_logits"], b["pred_logits"])
+    # a request of odd sizes (1 byte past a line, six ranges, a range smaller than a line) in front of one launch; cleared by n = 0
+    w = [torch.randn(n, device=DEV) for n in (33, 4, 1 << 16, 12345, 64, 7)]
+    ops.dec_set_prefetch(w)
+    c, _ = head(feats)
+    ops.dec_set_prefetch(w)
+    ops.dec_set_prefetch([])
+    assert torch.equal(c["pred_masks"], b["pred_masks"])
+    with pytest.raises(RuntimeError, match="contiguous device"):
+        ops.dec_set_prefetch([torch.zeros(4)])

@@ -726,6 +726,83 @@ def test_decoder_tails_f16_is_closer_to_exact_than_bf16():
     assert errs["f16"] * 4 <= errs["bf16"] and errs["f32"] <= errs["f16"]
 
 
+def test_decoder_tails_f16_32_row_tiles_equal_16_row_tiles():
+    """Round 6, TileQ32 (csrc/dec_chain.hip): above 4096 rows -- the second stage of configs[3] -- the fp16 tails run 32 rows per
+    workgroup, two 16-row MFMA tiles sharing every weight fragment.  A row's arithmetic does not depend on the tile it sits in: all
+    three kernels must return bit for bit what the 16-row form returns, at row counts with a ragged last tile (rows % 32 in 1..31)."""
+    from unseenobjectswithmeanshift_amd import _lib
+    E, Fh = 256, 2048
+    r = lambda *s_, seed, k=1.0: (rnd(*s_, seed=seed) * k).to(DEV)
+    pk = ops().dec_pack_weight_f16
+    wo, bo, g, b = pk(r(E, E, seed=4, k=E ** -0.5)), r(E, seed=5, k=0.1), 1 + r(E, seed=6, k=0.1), r(E, seed=7, k=0.1)
+    w_in, b_in = pk(r(3 * E, E, seed=8, k=E ** -0.5)), r(3 * E, seed=9, k=0.1)
+    w1, b1, w2, b2 = pk(r(Fh, E, seed=10, k=E ** -0.5)), r(Fh, seed=11, k=0.1), pk(r(E, Fh, seed=12, k=Fh ** -0.5)), r(E, seed=13, k=0.1)
+    g1, be1, g2, be2 = 1 + r(E, seed=14, k=0.1), r(E, seed=15, k=0.1), 1 + r(E, seed=16, k=0.1), r(E, seed=17, k=0.1)
+    mlp = [(pk(r(E, E, seed=20 + i, k=E ** -0.5)), r(E, seed=30 + i, k=0.1)) for i in range(3)]
+    wq, bq = pk(r(E, E, seed=40, k=E ** -0.5)), r(E, seed=41, k=0.1)
+    for B, Q in ((3, 7), (2, 100), (45, 100)):                 # 21, 200 and 4500 rows (the last one takes TileQ32 by default)
+        o, res, qpos = r(B, Q, E, seed=1), r(B, Q, E, seed=2), r(Q, E, seed=3)
+        got = {}
+        for tile32 in (0, 1):
+            with _lib.option("DEC_TILE32", tile32):
+                x, qk, v = ops().dec_post_cross(o, res, qpos, wo, bo, g, b, w_in, b_in)
+                outs = [x, qk, v]
+                for n_parts in (1, 4):
+                    x2, parts = ops().dec_post_self(o, res, wo, bo, g, b, w1, b1, w2, n_parts=n_parts)
+                    out, d, e, q, ra = ops().dec_heads(x2, g2, be2, mlp, parts=parts, bias=b2, ln_g=g1, ln_b=be1, l2norm=True, wq=wq, bq=bq,
+                                                       query_pos=qpos, want_d=True, zero_row_any=True)
+                    outs += [x2, parts, out, d, e, q, ra]
+                got[tile32] = outs
+        for a, c in zip(got[0], got[1]):
+            assert torch.equal(a, c)
+        if B * Q >= 4096:                                       # the default choice at this size is the 32-row form
+            x2, parts = ops().dec_post_self(o, res, wo, bo, g, b, w1, b1, w2, n_parts=1)
+            assert torch.equal(parts, got[1][4])
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_decoder_heads_with_mask_epilogue(prec):
+    """Round 6, msm_dec_heads_mask: the heads kernel with the NEXT layer's attention mask at key resolution as its epilogue (image-aligned
+    tiles, the key blocks of an image shared out over several workgroups per tile) returns bit for bit what the two launches
+    dec_heads + attn_mask_pooled return -- out / e / next query, the mask (bytes, and the bit-packed blocked form the fused K/V attention
+    reads) and the row flags -- in both operand forms of the mask contraction, for ragged last tiles (Q = 100, 7) and key counts with a
+    ragged last block."""
+    E = 256
+    r = lambda *s_, seed, k=1.0: (rnd(*s_, seed=seed) * k).to(DEV)
+    pk = ops().dec_pack_weight_bf16 if prec == "bf16" else ops().dec_pack_weight_f16
+    g1, be1, g2, be2 = 1 + r(E, seed=14, k=0.1), r(E, seed=15, k=0.1), 1 + r(E, seed=16, k=0.1), r(E, seed=17, k=0.1)
+    mlp = [(pk(r(E, E, seed=20 + i, k=E ** -0.5)), r(E, seed=30 + i, k=0.1)) for i in range(3)]
+    wq, bq, b2 = pk(r(E, E, seed=40, k=E ** -0.5)), r(E, seed=41, k=0.1), r(E, seed=13, k=0.1)
+    for B, Q, T in ((3, 100, 300), (2, 100, 1200), (2, 100, 4800), (2, 7, 77), (1, 16, 48), (8, 100, 1200)):
+        x, qpos = r(B, Q, E, seed=1), r(Q, E, seed=3)
+        parts = r(4, B, Q, E, seed=2, k=0.3)
+        pooled = r(B, T, 64, seed=5)
+        for f16ops in (False, True):
+            for bits in ((False, True) if T % 16 == 0 else (False,)):
+                for with_q in (True, False):
+                    kw = dict(parts=parts, bias=b2, ln_g=g1, ln_b=be1, l2norm=True)
+                    if with_q:
+                        kw.update(wq=wq, bq=bq, query_pos=qpos)
+                    out, d, e, q, ra = ops().dec_heads(x, g2, be2, mlp, want_d=True, zero_row_any=True, **kw)
+                    attn, ra = ops().attn_mask_pooled(e[..., :64], pooled, qbias=e[..., 64], row_any=ra, bits=bits, f16=f16ops)
+                    flags = torch.zeros((B, Q), dtype=torch.int32, device=DEV)
+                    out2, d2, e2, q2, attn2, ra2 = ops().dec_heads_mask(x, g2, be2, mlp, pooled, flags, qcol=64, bits=bits, f16=f16ops, want_d=True, **kw)
+                    tag = f"B={B} Q={Q} T={T} f16ops={f16ops} bits={bits} q={with_q}"
+                    assert torch.equal(out, out2) and torch.equal(d, d2) and torch.equal(e, e2), tag
+                    assert (q is None and q2 is None) or torch.equal(q, q2), tag
+                    assert torch.equal(ra, ra2), tag
+                    if bits:
+                        # (B, chunks, T / 16, 16 queries of a block, 8 blocks of the chunk): words of queries >= Q are written by neither form
+                        lj, mb = torch.meshgrid(torch.arange(16), torch.arange(8), indexing="ij")
+                        ok = ((mb * 16 + lj < Q) & (mb < 7)).to(DEV)
+                        assert Q <= 112 and torch.equal(attn[:, 0][..., ok], attn2[:, 0][..., ok]), tag
+                    else:
+                        assert torch.equal(attn, attn2), tag
+    with pytest.raises(RuntimeError, match="bf16 or fp16"):
+        m32 = [(ops().dec_pack_weight(r(E, E, seed=50 + i)), r(E, seed=60 + i)) for i in range(3)]
+        ops().dec_heads_mask(r(1, 16, E, seed=1), g2, be2, m32, r(1, 48, 64, seed=5), torch.zeros((1, 16), dtype=torch.int32, device=DEV))
+
+
 def test_decoder_fused_tails_reject_bad_sizes():
     E = 128
     z = lambda *s: torch.zeros(*s, device=DEV)

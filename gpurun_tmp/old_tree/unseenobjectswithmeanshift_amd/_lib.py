@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmsm_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "msm_hip.h")
 
 _lib = None
-ABI_VERSION = 20     # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
+ABI_VERSION = 21     # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
 
 c_f = ctypes.c_void_p      # float* (device)
 c_p = ctypes.c_void_p
@@ -104,6 +104,10 @@ _SIGNATURES = {
     "msm_dec_post_self_f16": (c_i, [c_f, c_f, c_p, c_f, c_f, c_f, c_p, c_f, c_p] + [c_i, c_f, c_f, c_i, c_i, c_i, c_fl, c_p]),
     "msm_dec_heads_f16": (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_f, c_p, c_f, c_p, c_f, c_p, c_f, c_p, c_f, c_f] + [c_f] * 4 +
                           [c_p, c_i, c_i, c_i, c_fl, c_p]),
+    "msm_dec_heads_mask": (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_f, c_p, c_f, c_p, c_f, c_p, c_f, c_p, c_f, c_f] + [c_f] * 4 +
+                           [c_f, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_fl, c_p]),
+    "msm_l2_prefetch": (c_i, [c_p, c_p, c_i, c_p]),
+    "msm_dec_set_prefetch": (c_i, [c_p, c_p, c_i]),
     "msm_ms_seed_workspace": (c_l, [c_i]),
     "msm_ms_select_seeds": (c_i, [c_f, c_i, c_i, c_i, c_l, c_f, c_p, c_f, c_l, c_i, c_p]),
     "msm_ms_hill_climb_workspace": (c_l, [c_i, c_i]),
@@ -173,7 +177,7 @@ def lib():
 # kernel-selection overrides of include/msm_hip.h (enum order), for tools/ and tests/ only
 OPTIONS = ("MASK_NC", "MASKB_TARGET", "GEMM_TILE", "GEMM_SHALLOW", "ATTN_TARGET", "ATTN_KERNEL", "ATTN_QK_MAX", "ATTN_QKCFG",
            "CONVIN_NT", "POST_GENERIC", "ENC_NO_COOP", "MSDA_GENERIC", "MS_CHUNK", "MS_NO_PERSISTENT", "ATTN_FUSED_KV", "KV_PIPE", "MASK_KERNEL",
-           "MS_SPLIT_KERNEL", "CONV3_WIDE")
+           "MS_SPLIT_KERNEL", "CONV3_WIDE", "DEC_TILE32")
 OPT_AUTO = -1
 
 

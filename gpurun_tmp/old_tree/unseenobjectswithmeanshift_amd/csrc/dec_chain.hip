@@ -34,6 +34,8 @@
 // (a reduce-scatter: lane lq ends with row 4 rg + lq).  A stage is then 256 MFMAs of 8 cycles per wave, 2 us per SIMD -- balanced
 // against the 64 B/clk at which a CU can stream the 256 KiB of a stage's weights from L2 -- on twice as many tiles (100 x parts).
 // The bf16 chain keeps 16-row tiles (its stage is weight-streaming bound already).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "bf16.h"
@@ -57,17 +59,24 @@ constexpr int DC_E = 256;
 // Which fp32 kind a launch takes is decided by the host per kernel and row count: 8-row tiles halve a stage but double the number
 // of workgroups that stream the stage's 256 KiB of weights -- they pay while tiles x parts still fit the chip in one round
 // (measured at 800 rows: heads 21.7 -> 14.5 us with 200 workgroups; post_cross 14.6 -> 18.4 with 300, post_self 27.7 -> 51 with 800).
+//   TileQ32  fp16 weights, 32 rows = TWO 16-row MFMA tiles per workgroup that share every weight fragment (round 6): above ~4000 rows
+//            (the second stage of configs[3]: 17 300 rows, configs[4] at batch 4) a launch is bound by the L2 -> CU weight stream --
+//            1082 16-row tiles x 2.2 MB = 2.4 GB per post_self launch at 33 TB/s -- and a fragment that feeds two MFMAs halves it
+// F8: the 4x4x1 fp32 form (its two "row groups" are the halves of ONE 8-row tile, reduced across lanes); RG otherwise counts 16-row tiles.
 struct TileF16 {
     using WT = float;
     static constexpr int R = 16, LD = DC_E + 4, RG = 1;
+    static constexpr bool F8 = false;
 };
 struct TileF8 {
     using WT = float;
     static constexpr int R = 8, LD = DC_E + 16, RG = 2;
+    static constexpr bool F8 = true;
 };
 struct TileH16 {
     using WT = uint16_t;
     static constexpr int R = 16, LD = DC_E + 4, RG = 1;
+    static constexpr bool F8 = false;
 };
 // fp16 weights (precision "f16"): the same bytes as bf16 with 11 instead of 8 significand bits -- Linear weights are O(0.01 .. 1),
 // far inside the half range -- on v_mfma_f32_16x16x32_f16, which issues at the bf16 instruction's rate.  The activation fragment
@@ -81,7 +90,15 @@ struct f16w {
 struct TileQ16 {
     using WT = f16w;
     static constexpr int R = 16, LD = DC_E + 4, RG = 1;
+    static constexpr bool F8 = false;
 };
+struct TileQ32 {
+    using WT = f16w;
+    static constexpr int R = 32, LD = DC_E + 4, RG = 2;
+    static constexpr bool F8 = false;
+};
+// (64-row tiles -- RG = 4, one 133-KB workgroup per CU -- were measured for post_self at 17 300 rows: 126 us against 90 for 32-row tiles and
+// 136 for 16-row tiles: one resident workgroup cannot keep the weight stream's latency covered.)
 #ifndef MSM_DC_NW
 #define MSM_DC_NW 8
 #endif
@@ -258,14 +275,37 @@ __device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT][1], const float* _
         }
     }
 }
+// fp16 weights, RT 16-row tiles per workgroup (TileQ32: RT = 2): every weight fragment feeds all tiles' MFMAs
+template <int RT>
+__device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT][RT], const float* __restrict__ ap, const BFrag<f16w>& f, int half) {
+    constexpr int LD = TileQ32::LD;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int kc = half * 2 + h;
+#pragma unroll
+        for (int up = 0; up < 2; ++up) {
+            f16x8 x[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const float4 p = *reinterpret_cast<const float4*>(ap + rt * 16 * LD + kc * 64 + (2 * up) * 16);
+                const float4 q = *reinterpret_cast<const float4*>(ap + rt * 16 * LD + kc * 64 + (2 * up + 1) * 16);
+                x[rt] = cvt8h(p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w);
+            }
+#pragma unroll
+            for (int t = 0; t < DC_NT; ++t)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[t][rt] = mfma_f16k32(x[rt], __builtin_bit_cast(f16x8, f.v[h][t][up]), acc[t][rt]);
+        }
+    }
+}
 // prefetch loads per half stage (bload) and MFMAs between two of them
 template <typename TK>
 struct Pipe {
     static constexpr int LOADS = std::is_same<typename TK::WT, float>::value ? 8 * DC_NT : 4 * DC_NT;
     // MFMAs between two prefetch loads: 8-row fp32 has two 8-cycle MFMAs where the 16-row form has one of 32; bf16 (hi + lo activation) has
     // 8 * DC_NT per half stage, fp16 (one term) 4 * DC_NT
-    static constexpr int IL = std::is_same<typename TK::WT, f16w>::value ? 1
-                              : !std::is_same<typename TK::WT, float>::value ? DC_IL / 2 : (TK::RG == 2 ? 2 * DC_IL : DC_IL);
+    static constexpr int IL = std::is_same<typename TK::WT, f16w>::value ? TK::RG
+                              : !std::is_same<typename TK::WT, float>::value ? DC_IL / 2 : (TK::F8 ? 2 * DC_IL : DC_IL);
 };
 
 // D[16][256] = act(A[16][256] . W[n][k]^T + bias).  A in LDS.  TO_GLOBAL: D is row-major global with row stride
@@ -279,7 +319,7 @@ __device__ __forceinline__ void gemm_core(f32x4 (&acc)[DC_NT][TK::RG], const flo
                                           int kc_base, BFrag<typename TK::WT>& lo, const typename TK::WT* __restrict__ Wn, int kctn, int kcn) {
     using WT = typename TK::WT;
     const int lane = threadIdx.x & 63;
-    const float* ap = A + (TK::RG == 2 ? (lane & 3) : (lane & 15)) * TK::LD + (lane >> 4) * 4;
+    const float* ap = A + (TK::F8 ? (lane & 3) : (lane & 15)) * TK::LD + (lane >> 4) * 4;
     BFrag<WT> hi;
     // The prefetch loads are spread evenly between the MFMAs of the half they hide behind (1 load : DC_IL MFMAs,
     // sched_group_barrier), not issued as a burst in front of them: measured 16.2 -> 14.1 us (post_cross), 34.1 -> 29.1
@@ -307,32 +347,34 @@ __device__ __forceinline__ void gemm_core(f32x4 (&acc)[DC_NT][TK::RG], const flo
 
 // D = act(acc + bias).  TO_GLOBAL: D is row-major global with row stride ldd, rows >= rows_valid are not written;
 // otherwise D is an LDS tile (stride TK::LD).
-template <bool TO_GLOBAL, int LD>
-__device__ __forceinline__ void gemm_store(const f32x4 (&acc)[DC_NT][1], const float (&bv)[DC_NT], bool relu, float* __restrict__ D,
-                                           int64_t ldd, int rows_valid) {
+template <bool TO_GLOBAL, int LD, int RG>
+__device__ __forceinline__ void gemm_store16(const f32x4 (&acc)[DC_NT][RG], const float (&bv)[DC_NT], bool relu, float* __restrict__ D,
+                                             int64_t ldd, int rows_valid) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lj = lane & 15, lq = lane >> 4;
 #pragma unroll
     for (int t = 0; t < DC_NT; ++t) {
         const int n = (wave * DC_NT + t) * 16 + lj;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = acc[t][0][r] + bv[t];
-            if (relu) v = fmaxf(v, 0.f);
-            const int row = lq * 4 + r;
-            if constexpr (TO_GLOBAL) {
-                if (row < rows_valid) D[(int64_t)row * ldd + n] = v;
-            } else {
-                D[row * LD + n] = v;
+        for (int rt = 0; rt < RG; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[t][rt][r] + bv[t];
+                if (relu) v = fmaxf(v, 0.f);
+                const int row = rt * 16 + lq * 4 + r;
+                if constexpr (TO_GLOBAL) {
+                    if (row < rows_valid) D[(int64_t)row * ldd + n] = v;
+                } else {
+                    D[row * LD + n] = v;
+                }
             }
-        }
     }
 }
 // fp32 (4x4x1 blocks): the four k-slices of a column sit in the lanes lq = 0..3 of that column; a reduce-scatter over them leaves lane
 // lq with the total of row 4 rg + lq (three cross-lane adds per tuple), which it stores
 template <bool TO_GLOBAL, int LD>
-__device__ __forceinline__ void gemm_store(const f32x4 (&acc)[DC_NT][2], const float (&bv)[DC_NT], bool relu, float* __restrict__ D,
-                                           int64_t ldd, int rows_valid) {
+__device__ __forceinline__ void gemm_store8(const f32x4 (&acc)[DC_NT][2], const float (&bv)[DC_NT], bool relu, float* __restrict__ D,
+                                            int64_t ldd, int rows_valid) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lj = lane & 15, lq = lane >> 4;
     const bool up2 = lq & 2, up1 = lq & 1;
@@ -357,6 +399,13 @@ __device__ __forceinline__ void gemm_store(const f32x4 (&acc)[DC_NT][2], const f
     }
 }
 
+template <bool TO_GLOBAL, typename TK>
+__device__ __forceinline__ void gemm_store(const f32x4 (&acc)[DC_NT][TK::RG], const float (&bv)[DC_NT], bool relu, float* __restrict__ D,
+                                           int64_t ldd, int rows_valid) {
+    if constexpr (TK::F8) gemm_store8<TO_GLOBAL, TK::LD>(acc, bv, relu, D, ldd, rows_valid);
+    else gemm_store16<TO_GLOBAL, TK::LD, TK::RG>(acc, bv, relu, D, ldd, rows_valid);
+}
+
 __device__ __forceinline__ void load_bias(float (&bv)[DC_NT], const float* __restrict__ bias) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -378,7 +427,7 @@ __device__ __forceinline__ void gemm256(const float* __restrict__ A, const typen
     float bv[DC_NT];
     load_bias(bv, bias);            // requested before the MFMAs, consumed after them
     gemm_core<NEXT, TK>(acc, A, W, kct, kc_base, lo, Wn, kctn, kcn);
-    gemm_store<TO_GLOBAL, TK::LD>(acc, bv, relu, D, ldd, rows_valid);
+    gemm_store<TO_GLOBAL, TK>(acc, bv, relu, D, ldd, rows_valid);
 }
 
 // tile[16][256] <- src rows row0.. (clamped to the last valid row), 16-byte coalesced
@@ -390,6 +439,57 @@ __device__ __forceinline__ void load_tile(float* __restrict__ tile, const float*
         const int gr = min(row0 + r, rows - 1);
         *reinterpret_cast<float4*>(tile + r * TK::LD + c4 * 4) = *reinterpret_cast<const float4*>(src + (int64_t)gr * ld + c4 * 4);
     }
+}
+
+// ---- L2 prefetch rows (round 6) -------------------------------------------------------------------------------------------------
+// A layer's tail weights are 3.2 MB of fp16 fragments (6.4 MB fp32) that nothing keeps in the 4-MiB per-XCD L2s between two passes: every
+// tail starts on HBM latency (tools/probes/tails_cold_time.py, 800 rows: post_self 17.5 us cold, 13.4 with its weights resident; heads
+// 15.2 / 13.1; post_cross 10.7 / 9.6).  A tail launch can therefore carry ONE EXTRA ROW of workgroups (the last blockIdx.y) that do no
+// tail work (two rows when the ranges are long): they touch the byte ranges the NEXT launches of the chain will stream
+// (msm_dec_set_prefetch) -- one 4-byte load per 128-byte line -- and exit.  They are dispatched behind the launch's working workgroups onto CUs the 50-200 of them leave idle, and their loads
+// sit in their own waves' queues (a wave's loads return in order: the same loads issued by a working wave would stall its first wait).
+// Each XCD's L2 needs its own copy: the row's workgroups on XCD x (block id % 8 == x: an observed placement, relied on for speed only)
+// share every range between them.  A forked side stream for the same job costs ~10 us per fork / join inside a HIP graph (measured:
+// 1.41 -> 1.68 ms per pass).
+constexpr int DC_PF_MAX = 6;
+struct PfRanges {
+    const unsigned char* p[DC_PF_MAX];
+    int64_t bytes[DC_PF_MAX];
+    int n, rows;                                                       // rows: prefetch rows appended to the grid (0 = none)
+};
+// rows of gx workgroups so that a thread has about eight lines to touch (every XCD's share of the rows reads ALL the bytes), at most 2
+// (1, 2 and 4 rows measured alike at 800 rows: 1.375 - 1.381 ms per f16 pass against 1.405 without)
+static int prefetch_rows(const PfRanges& pf, int gx) {
+    if (pf.n <= 0) return 0;
+    int64_t lines = 0;
+    for (int j = 0; j < pf.n; ++j) lines += (pf.bytes[j] + 127) >> 7;
+    const int64_t want = (lines * 8 + (int64_t)gx * DC_THREADS * 8 - 1) / ((int64_t)gx * DC_THREADS * 8);
+    return (int)max((int64_t)1, min((int64_t)2, want));
+}
+__device__ __forceinline__ bool prefetch_part(const PfRanges& pf) {
+    if (pf.rows <= 0 || (int)blockIdx.y < (int)gridDim.y - pf.rows) return false;
+    const int first = gridDim.x * (gridDim.y - pf.rows);               // linear id of the first prefetch workgroup
+    const int total = gridDim.x * pf.rows;
+    const int j = ((int)blockIdx.y - ((int)gridDim.y - pf.rows)) * gridDim.x + blockIdx.x, xcd = (first + j) & 7;
+    const int j0 = (xcd - first) & 7;                                  // the first prefetch workgroup on this XCD
+    const int k = (j - j0) >> 3;                                       // this workgroup's index among the prefetch workgroups on its XCD
+    const int cnt = (total - j0 + 7) >> 3;                             // ... and their number
+    unsigned acc = 0;
+    for (int r = 0; r < pf.n; ++r) {
+        const int64_t lines = (pf.bytes[r] + 127) >> 7;
+        const int64_t per = (lines + cnt - 1) / cnt;
+        const int64_t l0 = (int64_t)k * per, l1 = min(lines, l0 + per);
+        const unsigned char* base = pf.p[r];
+        // four loads in flight per thread (a trip's loads are independent; lines past the end re-read the last one)
+        for (int64_t l = l0 + threadIdx.x; l < l1; l += 4 * DC_THREADS) {
+            unsigned v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const unsigned*>(base + (min(l + u * DC_THREADS, l1 - 1) << 7));
+            acc ^= (v[0] ^ v[1]) ^ (v[2] ^ v[3]);
+        }
+    }
+    if (acc == 0x9e3779b9u) asm volatile("s_nop 0" ::: "memory");     // (keeps the loads alive)
+    return true;
 }
 
 struct RowStats {
@@ -453,16 +553,17 @@ __global__ __launch_bounds__(DC_THREADS) void dec_post_cross_kernel(
     const float* __restrict__ o, const float* __restrict__ res, const float* __restrict__ qpos, const WT* __restrict__ wo,
     const float* __restrict__ bo, const float* __restrict__ g, const float* __restrict__ b, const WT* __restrict__ w_in,
     const float* __restrict__ b_in, float* __restrict__ x_out, float* __restrict__ qk_out, float* __restrict__ v_out,
-    int rows, int Q, float eps) {
+    int rows, int Q, float eps, PfRanges pf) {
     __shared__ __attribute__((aligned(16))) float lds[3 * TK::R * TK::LD];
     float *T0 = lds, *X = lds + TK::R * TK::LD, *XP = lds + 2 * TK::R * TK::LD;
+    if (prefetch_part(pf)) return;                                     // the prefetch rows (see PfRanges)
     const int row0 = blockIdx.x * TK::R;
     const int valid = min(TK::R, rows - row0);
     // blockIdx.y picks the projection (0: q, 1: k, 2: v): the 16-row tile is MFMA-bound on ONE CU at 3.4 us per
     // 256x256 stage, so the three independent projections go to three CUs; each repeats the Wo + LN stage.
     // gridDim.y == 2 (8-row tiles: 100 tiles x 3 parts would not fit the chip in one round): part 0 runs q THEN k, part 1 runs v.
     const int part = blockIdx.y;
-    const bool two = gridDim.y == 2;
+    const bool two = (int)gridDim.y - pf.rows == 2;
     const int first = two ? (part == 0 ? 0 : 2) : part;        // the projection this workgroup starts with
     const WT* wp = w_in + (int64_t)first * DC_E * DC_E;
     BFrag<WT> f;
@@ -484,14 +585,16 @@ template <typename TK, typename WT = typename TK::WT>
 __global__ __launch_bounds__(DC_THREADS) void dec_post_self_kernel(
     const float* __restrict__ o, const float* __restrict__ res, const WT* __restrict__ wo, const float* __restrict__ bo,
     const float* __restrict__ g, const float* __restrict__ b, const WT* __restrict__ w1, const float* __restrict__ b1,
-    const WT* __restrict__ w2, int F, float* __restrict__ x_out, float* __restrict__ parts, int rows, float eps) {
+    const WT* __restrict__ w2, int F, float* __restrict__ x_out, float* __restrict__ parts, int rows, float eps, PfRanges pf) {
     __shared__ __attribute__((aligned(16))) float lds[2 * TK::R * TK::LD];
     float *T0 = lds, *X = lds + TK::R * TK::LD;
+    if (prefetch_part(pf)) return;                                     // the prefetch rows (see PfRanges)
+    const int n_chunks_y = (int)gridDim.y - pf.rows;
     const int row0 = blockIdx.x * TK::R, chunk = blockIdx.y;
     const int valid = min(TK::R, rows - row0);
     // blockIdx.y owns F/256/gridDim.y consecutive 256-wide hidden chunks; their W2 products accumulate in registers.
     // linear1: rows [c*256, +256) of the packed (F, 256) matrix; linear2 (256, F): k-chunks 4c..4c+3 of every row tile.
-    const int per = (F / DC_E) / gridDim.y, c0 = chunk * per;
+    const int per = (F / DC_E) / n_chunks_y, c0 = chunk * per;
     const int kct2 = F / 64;
     BFrag<WT> f;
     attn_out_ln<TK>(o, res, wo, bo, g, b, nullptr, 1, x_out, chunk == 0, T0, X, nullptr, row0, rows, eps, f,
@@ -510,26 +613,51 @@ __global__ __launch_bounds__(DC_THREADS) void dec_post_self_kernel(
         gemm_core<true, TK>(acc2, T0, w2, kct2, 4 * c, f, w1 + (int64_t)cn * DC_E * DC_E, 4, 0);
         __syncthreads();
     }
-    gemm_store<true, TK::LD>(acc2, zero_bias, false, parts + ((int64_t)chunk * rows + row0) * DC_E, DC_E, valid);
+    gemm_store<true, TK>(acc2, zero_bias, false, parts + ((int64_t)chunk * rows + row0) * DC_E, DC_E, valid);
 }
 
-template <typename TK, typename WT = typename TK::WT>
+// The next layer's attention mask as the epilogue of the heads kernel (round 6, 16-bit plans with attention masks at key resolution,
+// csrc/attn_mask.hip): mask[b][q][t] = (sum_c e[b][q][c] pooled[b][t][c] + e[b][q][qcol]) < 0 over the T pooled keys of the level, and
+// row_any[b][q] = 1 where a row keeps an unmasked key (DEC:618, 677-680) -- the arithmetic of attn_mask_pooled_kernel bit for bit, in
+// either of its operand forms (sixteen fp32 MFMAs per key block, or two v_mfma_f32_16x16x32_f16; the query bias as the accumulator's
+// initial value), without the launch: e never leaves the workgroup's LDS tile before it is contracted.  Tiles are IMAGE-ALIGNED then (a tile's queries share
+// one pooled map): blockIdx.x = image * tiles_per_image + tile.  The key blocks of an image are shared out over `parts` workgroups per
+// tile (blockIdx.y: 0 and, behind the optional query-projection part, 2 ..): every part repeats the row phase and the three MLP
+// stages (weights from L2, 384 KiB) on its own CU -- the chain is latency, not throughput -- and only part 0 stores out / d / e.
+// row_any must arrive ZEROED (the decoder clears the flags of all its predictions in the pooling launch).
+struct HeadsMask {
+    const float* pooled;        // (B, T, 64) fp32 (msm_pool_mask_taps)
+    uint8_t* attn;              // (B, Q, T) bytes, or the bit-packed blocked form of msm_attn_pack_mask_bits when bits
+    int32_t* row_any;           // (B, Q), zeroed by the caller
+    int T, bits, parts, tiles_per_image, qcol, f16ops;
+};
+
+template <typename TK, bool MASK = false, typename WT = typename TK::WT>
 __global__ __launch_bounds__(DC_THREADS) void dec_heads_kernel(
     const float* __restrict__ x, const float* __restrict__ parts, int n_parts, const float* __restrict__ bias,
     const float* __restrict__ g1, const float* __restrict__ b1, int l2norm, const float* __restrict__ g2,
     const float* __restrict__ b2, const WT* __restrict__ m0w, const float* __restrict__ m0b, const WT* __restrict__ m1w,
     const float* __restrict__ m1b, const WT* __restrict__ m2w, const float* __restrict__ m2b, const WT* __restrict__ wq,
     const float* __restrict__ bq, const float* __restrict__ qpos, float* __restrict__ out, float* __restrict__ d_out,
-    float* __restrict__ e_out, float* __restrict__ q_out, int32_t* __restrict__ row_any_zero, int rows, int Q, float eps) {
+    float* __restrict__ e_out, float* __restrict__ q_out, int32_t* __restrict__ row_any_zero, int rows, int Q, float eps, HeadsMask hm, PfRanges pf) {
     __shared__ __attribute__((aligned(16))) float lds[3 * TK::R * TK::LD];
     float *XP = lds, *Dn = lds + TK::R * TK::LD, *T0 = lds + 2 * TK::R * TK::LD;
+    if (prefetch_part(pf)) return;                                     // the prefetch rows (see PfRanges)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row0 = blockIdx.x * TK::R;
-    const int valid = min(TK::R, rows - row0);
-    // blockIdx.y == 1 (only launched when wq is given): the next layer's query projection; y == 0: the MLP chain
-    const bool qpart = blockIdx.y == 1;
+    int row0 = blockIdx.x * TK::R, valid = min(TK::R, rows - row0);
+    int img = 0, tile = 0;
+    if constexpr (MASK) {
+        img = blockIdx.x / hm.tiles_per_image, tile = blockIdx.x - img * hm.tiles_per_image;
+        row0 = img * Q + tile * TK::R;
+        valid = min(TK::R, Q - tile * TK::R);
+    }
+    // blockIdx.y == 1 (only launched when wq is given): the next layer's query projection; y == 0: the MLP chain; MASK: y = 0 and
+    // y >= (wq ? 2 : 1) are the mask parts
+    const bool qpart = wq != nullptr && blockIdx.y == 1;
+    const int mpart = MASK ? (blockIdx.y == 0 ? 0 : (int)blockIdx.y - (wq ? 1 : 0)) : 0;
+    const bool primary = mpart == 0;                                             // stores out / d / e (uniform)
     // the mask step that consumes e_out needs its row_any flags cleared: done here instead of a separate fill launch
-    if (row_any_zero && !qpart && (int)threadIdx.x < valid) row_any_zero[row0 + threadIdx.x] = 0;
+    if (row_any_zero && !qpart && primary && (int)threadIdx.x < valid) row_any_zero[row0 + threadIdx.x] = 0;
     BFrag<WT> f;
     bload(f, qpart ? wq : m0w, 4, 0, 0);
     // row phase: lane owns 4 consecutive columns; all global operands of the wave's rows are requested up front
@@ -544,25 +672,26 @@ __global__ __launch_bounds__(DC_THREADS) void dec_heads_kernel(
     const float4 biasv = bias ? ld4(bias + lane * 4) : zero4;
     const float4 g1v = g1 ? ld4(g1 + lane * 4) : zero4, b1v = g1 ? ld4(b1 + lane * 4) : zero4;
     const float4 g2v = ld4(g2 + lane * 4), b2v = ld4(b2 + lane * 4);
-    for (int s0 = 0; s0 < n_parts; s0 += 8) {
-        float4 p[(TK::R / DC_NW)][8];
+    constexpr int PS = (TK::R / DC_NW) > 2 ? 4 : 8;                 // partial sums in flight per row (register budget)
+    for (int s0 = 0; s0 < n_parts; s0 += PS) {
+        float4 p[(TK::R / DC_NW)][PS];
 #pragma unroll
         for (int i = 0; i < (TK::R / DC_NW); ++i) {
             const int gr = min(row0 + wave * (TK::R / DC_NW) + i, rows - 1);
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
+            for (int s = 0; s < PS; ++s)
                 p[i][s] = ld4(parts + ((int64_t)min(s0 + s, n_parts - 1) * rows + gr) * DC_E + lane * 4);
         }
 #pragma unroll
         for (int i = 0; i < (TK::R / DC_NW); ++i)
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
+            for (int s = 0; s < PS; ++s)
                 if (s0 + s < n_parts) v[i] = add4(v[i], p[i][s]);
     }
 #pragma unroll
     for (int i = 0; i < (TK::R / DC_NW); ++i) {
         const int r = wave * (TK::R / DC_NW) + i;
-        const bool live = row0 + r < rows;
+        const bool live = r < valid && primary;
         float4 t = add4(v[i], biasv);
         if (g1) t = affine4(t, row_stats(t, eps), g1v, b1v);                         // FFN norm (DEC:300)
         if (l2norm) {                                                                // block norm (DEC:637-638)
@@ -587,7 +716,87 @@ __global__ __launch_bounds__(DC_THREADS) void dec_heads_kernel(
     __syncthreads();
     gemm256<false, true, TK>(T0, m1w, 4, 0, m1b, true, Dn, 0, 0, f, m2w, 4, 0);
     __syncthreads();
-    gemm256<true, false, TK>(Dn, m2w, 4, 0, m2b, false, e_out + (int64_t)row0 * DC_E, DC_E, valid, f, nullptr, 0, 0);
+    if constexpr (!MASK) {
+        gemm256<true, false, TK>(Dn, m2w, 4, 0, m2b, false, e_out + (int64_t)row0 * DC_E, DC_E, valid, f, nullptr, 0, 0);
+    } else {
+        static_assert(TK::R == 16, "the mask epilogue walks one 16-query block per workgroup");
+        gemm256<false, false, TK>(Dn, m2w, 4, 0, m2b, false, T0, 0, 0, f, nullptr, 0, 0);                                // e -> LDS
+        __syncthreads();
+        if (primary)                                                                   // e_out: the final mask step / aux consumers read it
+            for (int i = threadIdx.x; i < valid * (DC_E / 4); i += DC_THREADS) {
+                const int r = i / (DC_E / 4), c4 = i - r * (DC_E / 4);
+                st4(e_out + (int64_t)(row0 + r) * DC_E + c4 * 4, ld4(T0 + r * TK::LD + c4 * 4));
+            }
+        // ---- the mask of this tile's 16 queries against key blocks mpart*DC_NW + wave, + parts*DC_NW, ... (attn_mask_pooled_kernel, F16 form) ----
+        const int lj = lane & 15, lq = lane >> 4;
+        const int T = hm.T, nkb = (T + 15) / 16, stride = hm.parts * DC_NW;
+        // operand forms of attn_mask_pooled_kernel: f16ops -- a lane's channels 8 lq .. + 7 and 32 + 8 lq .. + 7 (the two K = 32 steps of
+        // v_mfma_f32_16x16x32_f16); else fp32 -- channels 16 lq .. + 15, sixteen v_mfma_f32_16x16x4_f32 (the plans' default: the mask bits
+        // feed back into the attention, so their operands stay fp32 unless lp_pooled_masks asks otherwise)
+        const bool h16 = hm.f16ops != 0;                                               // (uniform)
+        const int lqw = h16 ? 8 : 16, o1 = 4, o2 = h16 ? 32 : 8, o3 = h16 ? 36 : 12;
+        const float* er = T0 + lj * TK::LD + lq * lqw;
+        const float4 w0 = ld4(er), w1 = ld4(er + o1), w2 = ld4(er + o2), w3 = ld4(er + o3);
+        const f16x8 wh0 = cvt8h(w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w), wh1 = cvt8h(w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w);
+        const float qb = T0[lj * TK::LD + hm.qcol];
+        const bool qlive = lj < valid;
+        const int q = tile * 16 + lj;
+        const float* pb = hm.pooled + (int64_t)img * T * 64 + lq * lqw;
+        uint8_t* ab = hm.attn + (int64_t)img * Q * T;
+        unsigned anyu = 0;
+        int kb = mpart * DC_NW + wave;
+        float4 a[4], an[4];
+        if (kb < nkb) {
+            const float* ap = pb + (int64_t)min(kb * 16 + lj, T - 1) * 64;
+            a[0] = ld4(ap), a[1] = ld4(ap + o1), a[2] = ld4(ap + o2), a[3] = ld4(ap + o3);
+        }
+        for (; kb < nkb; kb += stride) {
+            const int kn = min(kb + stride, nkb - 1);                                  // the next block's keys are requested before this block's MFMAs
+            const float* apn = pb + (int64_t)min(kn * 16 + lj, T - 1) * 64;
+            an[0] = ld4(apn), an[1] = ld4(apn + o1), an[2] = ld4(apn + o2), an[3] = ld4(apn + o3);
+            f32x4 acc = f32x4{qb, qb, qb, qb};
+            if (h16) {
+                acc = mfma_f16k32(cvt8h(a[0].x, a[0].y, a[0].z, a[0].w, a[1].x, a[1].y, a[1].z, a[1].w), wh0, acc);
+                acc = mfma_f16k32(cvt8h(a[2].x, a[2].y, a[2].z, a[2].w, a[3].x, a[3].y, a[3].z, a[3].w), wh1, acc);
+            } else {
+                const float4 wv[4] = {w0, w1, w2, w3};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc = mfma16(a[u].x, wv[u].x, acc);
+                    acc = mfma16(a[u].y, wv[u].y, acc);
+                    acc = mfma16(a[u].z, wv[u].z, acc);
+                    acc = mfma16(a[u].w, wv[u].w, acc);
+                }
+            }
+            const int key0 = kb * 16 + lq * 4;
+            const unsigned m0 = acc[0] < 0.f, m1 = acc[1] < 0.f, m2 = acc[2] < 0.f, m3 = acc[3] < 0.f;   // sigmoid(x) < 0.5 <=> x < 0 (DEC:677)
+            if (hm.bits) {
+                unsigned nib = (m0 | (m1 << 1) | (m2 << 2) | (m3 << 3)) << (4 * lq);
+                nib = or_lane_rows(nib);
+                if ((m0 & m1 & m2 & m3) == 0) anyu = 1u;
+                const int qc = tile / 7, mb = tile - qc * 7, qchunks = (Q + 111) / 112;  // 112-query chunk and block within it (attention.hip: AQB = 7)
+                if (lq == 0 && qlive)
+                    reinterpret_cast<unsigned short*>(hm.attn)[((((int64_t)img * qchunks + qc) * nkb + kb) * 16 + lj) * 8 + mb] = (unsigned short)nib;
+            } else if (qlive) {
+                if ((T & 3) == 0 && key0 + 3 < T) {
+                    *reinterpret_cast<uint32_t*>(ab + (int64_t)q * T + key0) = m0 | (m1 << 8) | (m2 << 16) | (m3 << 24);
+                    if ((m0 & m1 & m2 & m3) == 0) anyu = 1u;
+                } else {
+                    const unsigned mm[4] = {m0, m1, m2, m3};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (key0 + r < T) {
+                            ab[(int64_t)q * T + key0 + r] = (uint8_t)mm[r];
+                            if (!mm[r]) anyu = 1u;
+                        }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = an[u];
+        }
+        anyu = or_lane_rows(anyu);                                                     // (same flag value from every writer)
+        if (lq == 0 && anyu && qlive) hm.row_any[(int64_t)img * Q + q] = 1;
+    }
 }
 
 // packed[((t*(K/64) + kc)*4 + u)*256 + (lq*16 + lj)*4 + c] = W[t*16 + lj][kc*64 + u*16 + lq*4 + c]
@@ -634,6 +843,14 @@ __global__ __launch_bounds__(256) void dec_pack_weight_bf16_kernel(const float* 
 
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// the ranges the NEXT tail launch of this thread carries in its prefetch row (msm_dec_set_prefetch); taken (and cleared) by that launch
+static thread_local PfRanges g_next_prefetch = {};
+static PfRanges take_prefetch() {
+    const PfRanges pf = g_next_prefetch;
+    g_next_prefetch.n = 0;
+    return pf;
+}
+
 }  // namespace msm
 
 using namespace msm;
@@ -673,6 +890,12 @@ extern "C" int msm_dec_pack_weight_f16(const float* w, uint16_t* packed, int N, 
 
 // 8-row fp32 tiles while tiles x parts fit the chip in one round (see the tile kinds above)
 static bool use_tile8(int rows, int parts) { return cdiv(rows, 8) * parts <= 256; }
+// fp16 weights: 32-row tiles (TileQ32) once the 16-row tiles alone oversubscribe the chip -- the launch is then bound by the aggregate
+// L2 -> CU weight stream, which a fragment shared by two tiles halves (MSM_OPT_DEC_TILE32: 1 always, 0 never)
+static bool use_tile32(int rows) {
+    const int o = opt(MSM_OPT_DEC_TILE32);
+    return o == 1 || (o != 0 && rows >= 4096);
+}
 
 template <typename TK, typename WT = typename TK::WT>
 static int dec_post_cross_impl(const char* who, const float* attn_out, const float* res, const float* query_pos, const WT* wo, const float* bo,
@@ -683,8 +906,10 @@ static int dec_post_cross_impl(const char* who, const float* attn_out, const flo
     MSM_REQUIRE(rows > 0 && Q > 0, "%s: bad sizes", who);
     MSM_REQUIRE(aligned16(attn_out) && aligned16(wo) && aligned16(w_in), "%s: pointers must be 16-byte aligned", who);
     // 8-row tiles take two parts (q then k | v): three would oversubscribe the chip at 800 rows (see use_tile8)
-    hipLaunchKernelGGL(dec_post_cross_kernel<TK>, dim3(cdiv(rows, TK::R), TK::RG == 2 ? 2 : 3), dim3(DC_THREADS), 0, (hipStream_t)stream, attn_out,
-                       res, query_pos, wo, bo, ln_g, ln_b, w_in, b_in, x_out, qk_out, v_out, rows, Q, eps);
+    PfRanges pf = take_prefetch();
+    pf.rows = prefetch_rows(pf, cdiv(rows, TK::R));
+    hipLaunchKernelGGL(dec_post_cross_kernel<TK>, dim3(cdiv(rows, TK::R), (TK::F8 ? 2 : 3) + pf.rows), dim3(DC_THREADS), 0, (hipStream_t)stream,
+                       attn_out, res, query_pos, wo, bo, ln_g, ln_b, w_in, b_in, x_out, qk_out, v_out, rows, Q, eps, pf);
     MSM_CHECK_LAUNCH(who);
     return MSM_OK;
 }
@@ -708,6 +933,10 @@ extern "C" int msm_dec_post_cross_bf16(const float* attn_out, const float* res, 
 extern "C" int msm_dec_post_cross_f16(const float* attn_out, const float* res, const float* query_pos, const uint16_t* wo,
                                       const float* bo, const float* ln_g, const float* ln_b, const uint16_t* w_in, const float* b_in,
                                       float* x_out, float* qk_out, float* v_out, int rows, int Q, int E, float eps, void* stream) {
+    // (measured at 17 300 rows: 55 us with 16-row tiles, 66 with 32 -- three resident workgroups per CU hide more than one does)
+    if (opt(MSM_OPT_DEC_TILE32) == 1)
+        return dec_post_cross_impl<TileQ32>("msm_dec_post_cross_f16", attn_out, res, query_pos, (const f16w*)wo, bo, ln_g, ln_b, (const f16w*)w_in, b_in,
+                                            x_out, qk_out, v_out, rows, Q, E, eps, stream);
     return dec_post_cross_impl<TileQ16>("msm_dec_post_cross_f16", attn_out, res, query_pos, (const f16w*)wo, bo, ln_g, ln_b, (const f16w*)w_in, b_in,
                                         x_out, qk_out, v_out, rows, Q, E, eps, stream);
 }
@@ -721,8 +950,10 @@ static int dec_post_self_impl(const char* who, const float* attn_out, const floa
     MSM_REQUIRE(rows > 0 && F > 0 && F % DC_E == 0, "%s: F=%d must be a positive multiple of 256", who, F);
     MSM_REQUIRE(n_parts > 0 && (F / DC_E) % n_parts == 0, "%s: n_parts=%d must divide F/256=%d", who, n_parts, F / DC_E);
     MSM_REQUIRE(aligned16(attn_out) && aligned16(wo) && aligned16(w1) && aligned16(w2), "%s: pointers must be 16-byte aligned", who);
-    hipLaunchKernelGGL(dec_post_self_kernel<TK>, dim3(cdiv(rows, TK::R), n_parts), dim3(DC_THREADS), 0, (hipStream_t)stream, attn_out,
-                       res, wo, bo, ln_g, ln_b, w1, b1, w2, F, x_out, parts, rows, eps);
+    PfRanges pf = take_prefetch();
+    pf.rows = prefetch_rows(pf, cdiv(rows, TK::R));
+    hipLaunchKernelGGL(dec_post_self_kernel<TK>, dim3(cdiv(rows, TK::R), n_parts + pf.rows), dim3(DC_THREADS), 0, (hipStream_t)stream, attn_out,
+                       res, wo, bo, ln_g, ln_b, w1, b1, w2, F, x_out, parts, rows, eps, pf);
     MSM_CHECK_LAUNCH(who);
     return MSM_OK;
 }
@@ -746,15 +977,19 @@ extern "C" int msm_dec_post_self_bf16(const float* attn_out, const float* res, c
 extern "C" int msm_dec_post_self_f16(const float* attn_out, const float* res, const uint16_t* wo, const float* bo, const float* ln_g,
                                      const float* ln_b, const uint16_t* w1, const float* b1, const uint16_t* w2, int F, float* x_out,
                                      float* parts, int n_parts, int rows, int E, float eps, void* stream) {
+    if (use_tile32(rows))
+        return dec_post_self_impl<TileQ32>("msm_dec_post_self_f16", attn_out, res, (const f16w*)wo, bo, ln_g, ln_b, (const f16w*)w1, b1, (const f16w*)w2, F,
+                                           x_out, parts, n_parts, rows, E, eps, stream);
     return dec_post_self_impl<TileQ16>("msm_dec_post_self_f16", attn_out, res, (const f16w*)wo, bo, ln_g, ln_b, (const f16w*)w1, b1, (const f16w*)w2, F,
                                        x_out, parts, n_parts, rows, E, eps, stream);
 }
 
-template <typename TK, typename WT = typename TK::WT>
+template <typename TK, bool MASK = false, typename WT = typename TK::WT>
 static int dec_heads_impl(const char* who, const float* x, const float* parts, int n_parts, const float* bias, const float* ln_g,
                           const float* ln_b, int l2norm, const float* dec_g, const float* dec_b, const WT* m0w, const float* m0b, const WT* m1w,
                           const float* m1b, const WT* m2w, const float* m2b, const WT* wq, const float* bq, const float* query_pos, float* out,
-                          float* d_out, float* e_out, float* q_out, int32_t* row_any_zero, int rows, int Q, int E, float eps, void* stream) {
+                          float* d_out, float* e_out, float* q_out, int32_t* row_any_zero, int rows, int Q, int E, float eps, void* stream,
+                          HeadsMask hm = HeadsMask{}) {
     MSM_REQUIRE(x && dec_g && dec_b && m0w && m0b && m1w && m1b && m2w && m2b && e_out, "%s: null pointer", who);
     MSM_REQUIRE(E == DC_E, "%s: E=%d, only 256 is supported", who, E);
     MSM_REQUIRE(rows > 0 && Q > 0 && n_parts >= 0, "%s: bad sizes", who);
@@ -762,9 +997,23 @@ static int dec_heads_impl(const char* who, const float* x, const float* parts, i
     MSM_REQUIRE((ln_g == nullptr) == (ln_b == nullptr), "%s: ln_g/ln_b must both be given or both be null", who);
     MSM_REQUIRE(!wq || (bq && query_pos && q_out), "%s: the next-query projection needs bq, query_pos and q_out", who);
     MSM_REQUIRE(aligned16(m0w) && aligned16(m1w) && aligned16(m2w) && aligned16(wq), "%s: weights must be 16-byte aligned", who);
-    hipLaunchKernelGGL(dec_heads_kernel<TK>, dim3(cdiv(rows, TK::R), wq ? 2 : 1), dim3(DC_THREADS), 0, (hipStream_t)stream, x, parts, n_parts, bias,
+    dim3 grid(cdiv(rows, TK::R), wq ? 2 : 1);
+    if constexpr (MASK) {
+        MSM_REQUIRE(hm.pooled && hm.attn && hm.row_any && hm.T > 0 && rows % Q == 0, "%s: the mask epilogue needs pooled / attn / row_any, T > 0 and rows = B * Q", who);
+        MSM_REQUIRE(hm.qcol >= 64 && hm.qcol < DC_E && aligned16(hm.pooled), "%s: qcol=%d must name a column of e behind the 64 embedding columns", who, hm.qcol);
+        MSM_REQUIRE(!hm.bits || (hm.T % 16 == 0 && aligned16(hm.attn)), "%s: the bit-packed mask needs T %% 16 == 0 and a 16-byte aligned buffer", who);
+        hm.tiles_per_image = cdiv(Q, TK::R);
+        const int tiles = (rows / Q) * hm.tiles_per_image, nkb = cdiv(hm.T, 16);
+        // parts: about one chip of workgroups in all, at least ~3 key blocks per wave (every part repeats the MLP chain)
+        hm.parts = max(1, min(min(cdiv(nkb, 3 * DC_NW), 8), max(1, 256 / tiles - (wq ? 1 : 0))));
+        grid = dim3(tiles, hm.parts + (wq ? 1 : 0));
+    }
+    PfRanges pf = take_prefetch();
+    pf.rows = prefetch_rows(pf, (int)grid.x);
+    grid.y += pf.rows;
+    hipLaunchKernelGGL((dec_heads_kernel<TK, MASK>), grid, dim3(DC_THREADS), 0, (hipStream_t)stream, x, parts, n_parts, bias,
                        ln_g, ln_b, l2norm, dec_g, dec_b, m0w, m0b, m1w, m1b, m2w, m2b, wq, bq, query_pos, out, d_out, e_out, q_out,
-                       row_any_zero, rows, Q, eps);
+                       row_any_zero, rows, Q, eps, hm, pf);
     MSM_CHECK_LAUNCH(who);
     return MSM_OK;
 }
@@ -793,6 +1042,44 @@ extern "C" int msm_dec_heads_f16(const float* x, const float* parts, int n_parts
                                  const float* m0b, const uint16_t* m1w, const float* m1b, const uint16_t* m2w, const float* m2b,
                                  const uint16_t* wq, const float* bq, const float* query_pos, float* out, float* d_out, float* e_out,
                                  float* q_out, int32_t* row_any_zero, int rows, int Q, int E, float eps, void* stream) {
+    if (use_tile32(rows))
+        return dec_heads_impl<TileQ32>("msm_dec_heads_f16", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, (const f16w*)m0w, m0b, (const f16w*)m1w,
+                                       m1b, (const f16w*)m2w, m2b, (const f16w*)wq, bq, query_pos, out, d_out, e_out, q_out, row_any_zero, rows, Q, E, eps, stream);
     return dec_heads_impl<TileQ16>("msm_dec_heads_f16", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, (const f16w*)m0w, m0b, (const f16w*)m1w,
                                    m1b, (const f16w*)m2w, m2b, (const f16w*)wq, bq, query_pos, out, d_out, e_out, q_out, row_any_zero, rows, Q, E, eps, stream);
+}
+
+// heads + the next layer's attention mask at key resolution in one launch (see HeadsMask above).  flags: 1 = bit-packed blocked mask
+// (msm_attn_pack_mask_bits' layout), 2 = fp16 weight fragments (msm_dec_pack_weight_f16; else bf16 fragments), 4 = the mask contraction on
+// IEEE-half operands (msm_attn_mask_pooled's flag 2; else its fp32 MFMA chain).
+extern "C" int msm_dec_heads_mask(const float* x, const float* parts, int n_parts, const float* bias, const float* ln_g, const float* ln_b, int l2norm,
+                                  const float* dec_g, const float* dec_b, const uint16_t* m0w, const float* m0b, const uint16_t* m1w,
+                                  const float* m1b, const uint16_t* m2w, const float* m2b, const uint16_t* wq, const float* bq,
+                                  const float* query_pos, float* out, float* d_out, float* e_out, float* q_out, const float* pooled, int T, int qcol,
+                                  uint8_t* attn, int32_t* row_any, int flags, int rows, int Q, int E, float eps, void* stream) {
+    MSM_REQUIRE((flags & ~7) == 0, "msm_dec_heads_mask: flags=%d (1 = bit-packed mask, 2 = fp16 weight fragments, 4 = IEEE-half mask operands)", flags);
+    HeadsMask hm{};
+    hm.pooled = pooled, hm.attn = attn, hm.row_any = row_any, hm.T = T, hm.bits = flags & 1, hm.qcol = qcol, hm.f16ops = (flags >> 2) & 1;
+    if (flags & 2)
+        return dec_heads_impl<TileQ16, true>("msm_dec_heads_mask", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, (const f16w*)m0w, m0b,
+                                             (const f16w*)m1w, m1b, (const f16w*)m2w, m2b, (const f16w*)wq, bq, query_pos, out, d_out, e_out, q_out, nullptr,
+                                             rows, Q, E, eps, stream, hm);
+    return dec_heads_impl<TileH16, true>("msm_dec_heads_mask", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, m0w, m0b, m1w, m1b, m2w, m2b,
+                                         wq, bq, query_pos, out, d_out, e_out, q_out, nullptr, rows, Q, E, eps, stream, hm);
+}
+
+// The byte ranges (16-byte aligned device pointers; HOST arrays of n <= 6 entries) that the NEXT msm_dec_post_cross* / msm_dec_post_self* /
+// msm_dec_heads* launch issued by this thread touches from an extra row of workgroups (see PfRanges above): the weights of the launches
+// that follow it in the chain.  n = 0 clears a pending request.  Affects speed only.
+extern "C" int msm_dec_set_prefetch(const void* const* ptrs, const int64_t* bytes, int n) {
+    MSM_REQUIRE(n >= 0 && n <= DC_PF_MAX && (n == 0 || (ptrs && bytes)), "msm_dec_set_prefetch: 0..%d ranges", DC_PF_MAX);
+    PfRanges pf{};
+    for (int j = 0; j < n; ++j) {
+        MSM_REQUIRE(ptrs[j] && bytes[j] > 0 && aligned16(ptrs[j]), "msm_dec_set_prefetch: range %d must be a 16-byte aligned device pointer with a positive size", j);
+        pf.p[j] = (const unsigned char*)ptrs[j];
+        pf.bytes[j] = bytes[j];
+    }
+    pf.n = n;
+    g_next_prefetch = pf;
+    return MSM_OK;
 }

@@ -317,6 +317,16 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         # bf16 MFMAs with fp32 accumulation (activations as hi + lo pairs); part of set_precision("bf16")
         self.tails_dtype = "f32"
         self.ffn_parts = None          # hidden-dimension slices of the fused FFN tail (None: ops.dec_post_self's default)
+        # 16-bit plans with attention masks at key resolution: the next layer's mask as the epilogue of the heads kernel
+        # (ops.dec_heads_mask: one launch instead of dec_heads + attn_mask_pooled; the same values bit for bit).  Opt-in: measured on
+        # MI355X at B = 8, 640x480 it is NOT faster -- 14.6 / 17 / 27 us per fused launch at 300 / 1200 / 4800 keys against 11.2 + 5.2 / 6.5 /
+        # 12.0 us for the pair, 1.455 against 1.448 ms per graph-replayed pass (f16), and no better with IEEE-half mask operands: the
+        # contraction runs on the ONE CU that owns the 16-query tile (or on a few more that each repeat the MLP chain), where the
+        # separate launch spreads it over the chip, and a kernel boundary inside a HIP graph costs ~1.5 us
+        self.fused_head_masks = False
+        # L2 prefetch of the fused tails' packed weights by an extra row of workgroups in the tail launch in front (ops.dec_set_prefetch,
+        # csrc/dec_chain.hip PfRanges): True = in the 16-bit plans (a layer's tail weights are 3.2 MB there), "always" = in every plan, False = off
+        self.weight_prefetch = True
         # "bf16": the attention cores multiply on bf16 MFMAs (fp32 accumulation, exp, sums) and the batched K/V projection
         # stores bf16; part of set_precision("bf16")
         self.attention_dtype = "f32"
@@ -563,6 +573,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         ncol = None
         pooled = {}
         ra0 = None
+        ra_all, fuse_masks = None, False
         fm_params = None
         if isinstance(mask_features, FoldedMaskFeatures):
             fm_params = [t for t in (mask_features.weight, mask_features.bias) if t is not None]
@@ -575,7 +586,12 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                 want_sizes = self._poolable_sizes(mask_features, sizes)
                 if want_sizes and L > 0:
                     # (the pooling launch also clears the row flags of prediction 0's attention-mask step)
-                    outs, ra0 = ops.pool_mask_taps(mask_features, want_sizes, zero_rows=int(out.shape[1]))
+                    # (... and, for the fused heads + mask launches, of every later prediction's: one (L + 1, B, Q) buffer)
+                    fuse_masks = bool(self.fused_head_masks) and self.tails_dtype in ("bf16", "f16") and not full
+                    Bq, Qn = int(out.shape[0]), int(out.shape[1])
+                    outs, flags = ops.pool_mask_taps(mask_features, want_sizes, zero_rows=Qn * (L + 1 if fuse_masks else 1))
+                    ra_all = flags.view(-1)[:Bq * Qn * (L + 1 if fuse_masks else 1)].view(-1, Bq, Qn)
+                    ra0 = ra_all[0]
                     pooled = dict(zip(want_sizes, outs))
         dn = self.decoder_norm
         pred_cls, pred_mask = [], []
@@ -668,6 +684,14 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             _, d, e, q, ra = ops.dec_heads(out, dn.weight, dn.bias, mlp, want_out=False, want_d=full or L == 0,
                                            zero_row_any=True, **next_query(0))
         attn, row_any = predict(d, e, ra, 0)
+        # L2 prefetch of the tails' weights (weight_prefetch; ops.dec_set_prefetch): every tail launch carries a row of workgroups that
+        # touch the packed weights of the launches BEHIND it in the chain, so those start on L2 hits instead of HBM latency
+        pf_on = bool(self.weight_prefetch) and out.is_cuda and (self.weight_prefetch == "always" or self.tails_dtype in ("bf16", "f16"))
+
+        def prefetch(tensors):
+            if pf_on:
+                ops.dec_set_prefetch(tensors)
+
         for i in range(L):
             lvl = i % self.num_feature_levels                                     # DEC:608
             ca = self.transformer_cross_attention_layers[i]
@@ -683,12 +707,28 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                 kv = kv_all[i] if kv_all is not None else self._kv_one(xs[lvl], kv_w[i], kv_c[i])          # (B, hw, 2E) = [K | V]
                 o = ops.hypersphere_attention(q, kv[..., :E], kv[..., E:], H, masked=attn, row_any=row_any, kappa=float(KAPPA), low_precision=lp,
                                               keys_f16=kf)
+            prefetch([pk["self_o"][i], pk["ffn1"][i], pk["ffn2"][i]])              # post_self's weights, from post_cross's launch
             x, qk, v = ops.dec_post_cross(o, out, qpos, pk["cross_o"][i], ca.meanshift_attn.out_proj.bias, ca.norm.weight,
                                           ca.norm.bias, pk["self_in"][i], sa.self_attn.in_proj_bias)
             o = ops.hypersphere_attention(qk[..., :E], qk[..., E:], v, H, kappa=float(KAPPA), low_precision=lp, keys_f16=kf)
+            # (the heads' weights -- the shared mask-embedding MLP, the next query projection -- are L2 residents already: prefetching them from
+            # post_self's launch measured 1.386 against 1.380 ms per pass)
             x, parts = ops.dec_post_self(o, x, pk["self_o"][i], sa.self_attn.out_proj.bias, sa.norm.weight, sa.norm.bias,
                                          pk["ffn1"][i], ff.linear1.bias, pk["ffn2"][i], n_parts=self.ffn_parts)
             last = i == L - 1
+            if not last:
+                prefetch([pk["cross_o"][i + 1], pk["self_in"][i + 1]])           # the next layer's post_cross weights, from the heads' launch
+            tgt = None if last else tuple(sizes[(i + 1) % self.num_feature_levels])
+            if fuse_masks and cf is None and ncol is not None and tgt in pooled:
+                # prediction i + 1 of a plan that keeps only the final masks: its one product is the next layer's attention mask
+                as_bits = fkv is not None and fkv["layers"][i + 1] is not None
+                out, d, e, q, attn, row_any = ops.dec_heads_mask(x, dn.weight, dn.bias, mlp, pooled[tgt], ra_all[i + 1], qcol=ncol, bits=as_bits,
+                                                                 f16=self.mask_step_dtype in ("bf16", "f16") and self.lp_pooled_masks,
+                                                                 parts=parts, bias=ff.linear2.bias, ln_g=ff.norm.weight, ln_b=ff.norm.bias,
+                                                                 l2norm=self.decoder_block_norm, want_out=True, want_d=False, **next_query(i + 1))
+                pred_cls.append(None)
+                pred_mask.append(None)
+                continue
             out, d, e, q, ra = ops.dec_heads(x, dn.weight, dn.bias, mlp, parts=parts, bias=ff.linear2.bias,
                                              ln_g=ff.norm.weight, ln_b=ff.norm.bias, l2norm=self.decoder_block_norm,
                                              want_out=not last, want_d=full or last, zero_row_any=True,

@@ -875,6 +875,71 @@ def dec_heads(x, dec_g, dec_b, mlp, *, parts=None, bias=None, ln_g=None, ln_b=No
     return (out, d, e, q, ra) if zero_row_any else (out, d, e, q)
 
 
+def dec_heads_mask(x, dec_g, dec_b, mlp, pooled, row_any, *, qcol=64, bits=False, f16=False, parts=None, bias=None, ln_g=None, ln_b=None, l2norm=False,
+                   wq=None, bq=None, query_pos=None, want_out=True, want_d=False, eps=1e-5):
+    """dec_heads (16-bit weight fragments) with the next layer's attention mask at key resolution as the kernel's epilogue
+    (msm_dec_heads_mask): the values of dec_heads(...) followed by attn_mask_pooled(e[..., :64], pooled, qbias=e[..., qcol],
+    row_any=row_any, bits=bits, f16=f16), bit for bit, in one launch.  ``mlp[-1]`` must be the folded final layer ([e Wm | e.bm | ..]);
+    ``row_any`` (B, Q) int32 must arrive ZEROED.  Returns (out|None, d|None, e, q|None, attn, row_any)."""
+    wd = _wdtype(wq, *[w for w, _ in mlp])
+    if wd not in (torch.bfloat16, torch.float16):
+        raise RuntimeError("dec_heads_mask needs bf16 or fp16 weight fragments (the fp32 plan keeps the two launches)")
+    for i, t in enumerate([x, parts, bias, ln_g, ln_b, dec_g, dec_b, bq, query_pos, pooled] + [b for _, b in mlp]):
+        _c(t, f"dec_heads_mask arg {i}")
+    for i, t in enumerate([wq] + [w for w, _ in mlp]):
+        _c(t, f"dec_heads_mask weight {i}", wd)
+    _c(row_any, "row_any", torch.int32)
+    B, Q, E = x.shape
+    T = pooled.shape[1]
+    if tuple(pooled.shape) != (B, T, 64) or tuple(row_any.shape) != (B, Q):
+        raise RuntimeError("dec_heads_mask needs a (B, T, 64) pooled activation and a (B, Q) row_any buffer")
+    out = torch.empty_like(x) if want_out else None
+    d = torch.empty_like(x) if want_d else None
+    e = torch.empty_like(x)
+    q = torch.empty_like(x) if wq is not None else None
+    if bits:
+        if T % 16:
+            raise RuntimeError("dec_heads_mask(bits=True) needs T % 16 == 0")
+        attn = torch.empty((B, (Q + 111) // 112, T // 16, 16, 8), device=x.device, dtype=torch.int16)
+    else:
+        attn = torch.empty((B, Q, T), device=x.device, dtype=torch.uint8)
+    n_parts = 0 if parts is None else parts.shape[0]
+    (m0w, m0b), (m1w, m1b), (m2w, m2b) = mlp
+    rc = lib().msm_dec_heads_mask(_p(x), _p(parts), n_parts, _p(bias), _p(ln_g), _p(ln_b), 1 if l2norm else 0, _p(dec_g), _p(dec_b), _p(m0w), _p(m0b),
+                                  _p(m1w), _p(m1b), _p(m2w), _p(m2b), _p(wq), _p(bq), _p(query_pos), _p(out), _p(d), _p(e), _p(q), _p(pooled), T,
+                                  int(qcol), _p(attn), _p(row_any), (1 if bits else 0) | (2 if wd == torch.float16 else 0) | (4 if f16 else 0), B * Q, Q, E, eps, _stream())
+    check(rc, "msm_dec_heads_mask")
+    return out, d, e, q, attn, row_any
+
+
+def dec_set_prefetch(tensors):
+    """The NEXT dec_post_cross / dec_post_self / dec_heads(_mask) call of this thread touches the storage of ``tensors`` (<= 6 contiguous
+    device tensors: the packed weights of the launches behind it in the chain) from an extra row of workgroups, so that every XCD's L2
+    holds them when those launches start (msm_dec_set_prefetch).  Speed only; an empty list clears a pending request."""
+    ts = [t for t in tensors if t is not None and t.numel() > 0][:6]
+    for t in ts:
+        if not t.is_cuda or not t.is_contiguous():
+            raise RuntimeError("dec_set_prefetch needs contiguous device tensors")
+    n = len(ts)
+    ptrs = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in ts])
+    nbytes = (ctypes.c_int64 * max(n, 1))(*[t.numel() * t.element_size() for t in ts])
+    check(lib().msm_dec_set_prefetch(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(nbytes, ctypes.c_void_p), n), "msm_dec_set_prefetch")
+
+
+def l2_prefetch(tensors):
+    """Touch the storage of up to 8 device tensors per launch so that every XCD's L2 holds it (msm_l2_prefetch): issued on a side stream
+    beside a kernel that leaves the fabric idle, ahead of the kernel that streams these bytes.  Speed only."""
+    ts = [t for t in tensors if t is not None and t.numel() > 0]
+    for t in ts:
+        if not t.is_cuda or not t.is_contiguous():
+            raise RuntimeError("l2_prefetch needs contiguous device tensors")
+    for i in range(0, len(ts), 8):
+        grp = ts[i:i + 8]
+        ptrs = (ctypes.c_void_p * len(grp))(*[t.data_ptr() for t in grp])
+        nbytes = (ctypes.c_int64 * len(grp))(*[t.numel() * t.element_size() for t in grp])
+        check(lib().msm_l2_prefetch(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(nbytes, ctypes.c_void_p), len(grp), _stream()), "msm_l2_prefetch")
+
+
 def _msda_dtype(value, others):
     """float32 or float64 like the reference's dispatch (ms_deform_attn_cuda.cu:69); every floating tensor the same."""
     dt = value.dtype

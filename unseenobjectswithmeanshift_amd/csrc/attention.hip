@@ -821,12 +821,16 @@ __global__ __launch_bounds__(NW * 64) void hs_attn_qk_kernel(const float* __rest
                                                             const int32_t* __restrict__ row_any, float* __restrict__ out, int Lq,
                                                             int S, int heads, int64_t ldq, int64_t q_sb, int64_t ldk,
                                                             int64_t k_sb, int64_t ldv, int64_t v_sb, float kappa) {
-    const int h = blockIdx.y, b = blockIdx.z;
+    // XCD-aware grid (round 6): (head, image, query-block group) -- workgroups are dealt to the 8 XCDs by linear id % 8, so with 8 heads
+    // every workgroup of head h runs on XCD h: the ceil(7 / MQ) workgroups that share an (image, head)'s K / V read them out of ONE L2
+    // (one HBM fetch instead of up to four) and an XCD's L2 holds an eighth of the level's K / V instead of half of it.  The old order
+    // (query-block group fastest) put the sharers on different XCDs.
+    const int h = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lj = lane & 15, lq = lane >> 4;
     extern __shared__ __attribute__((aligned(16))) float red[];   // [NW-1][MQ][9][64]: partial O (8) and l (1) per lane
-    const int qb0 = blockIdx.x * MQ;                            // first 16-query block of this workgroup (all waves)
+    const int qb0 = blockIdx.z * MQ;                            // first 16-query block of this workgroup (all waves)
 
     float qf[MQ][8];
     bf16x4 qh[BF ? MQ : 1][2];
@@ -1001,7 +1005,7 @@ static int attn_launch(const char* who, const float* q, const KVT* k, const KVT*
         const int cfg = cfg_env >= 0 ? cfg_env : (S <= 128 ? 1 : 0);
 #define QK_LAUNCH_M(MQ_, NW_, MM_)                                                                                              \
     {                                                                                                                           \
-        dim3 grid(cdiv(cdiv(Lq, 16), MQ_), heads, B);                                                                           \
+        dim3 grid(heads, B, cdiv(cdiv(Lq, 16), MQ_));                                                                           \
         const size_t lds2 = sizeof(float) * (size_t)(NW_ - 1) * MQ_ * 9 * 64;                                                   \
         MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)hs_attn_qk_kernel<MQ_, NW_, KVT, BF, MM_>, lds2));            \
         hipLaunchKernelGGL((hs_attn_qk_kernel<MQ_, NW_, KVT, BF, MM_>), grid, dim3(NW_ * 64), lds2, st, q, k, v, masked, row_any, out, Lq, \

@@ -81,7 +81,9 @@ template <bool VEC, bool BITS = false, bool F16 = false>
 __global__ __launch_bounds__(256) void attn_mask_pooled_kernel(const float* __restrict__ embed, int64_t embed_ld, const float* __restrict__ qbias,
                                                                int64_t qbias_ld, const float* __restrict__ pooled, uint8_t* __restrict__ attn,
                                                                int32_t* __restrict__ row_any, int Q, int T) {
-    const int b = blockIdx.y;
+    // XCD-aware grid (round 6): (image, key-block group, query-block pair) -- linear id % 8 = image % 8 when B is a multiple of 8, so the
+    // workgroups that walk one image's pooled tokens (up to 1.2 MB at 4800 keys) share ONE XCD's L2 instead of fetching them on several
+    const int b = blockIdx.x;
     const int qb0 = blockIdx.z * AM_NQ;                     // first query block of this wave
     if (qb0 * 16 >= Q) return;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -112,16 +114,16 @@ __global__ __launch_bounds__(256) void attn_mask_pooled_kernel(const float* __re
     const int nkb = (T + 15) / 16;
     const float* pb = pooled + (int64_t)b * T * AM_C + lq * LQW;
     uint8_t* ab = attn + (int64_t)b * Q * T;
-    int kb = blockIdx.x * 4 + wave;
+    int kb = blockIdx.y * 4 + wave;
     float4 a[4], an[4];
     if (kb < nkb) {
         const float* ap = pb + (int64_t)min(kb * 16 + lj, T - 1) * AM_C;
 #pragma unroll
         for (int u = 0; u < 4; ++u) a[u] = *reinterpret_cast<const float4*>(ap + off(u));
     }
-    for (; kb < nkb; kb += gridDim.x * 4) {
+    for (; kb < nkb; kb += gridDim.y * 4) {
         // the next block's keys are requested before this block's MFMAs (clamped: the last trip re-reads its own block)
-        const int kn = min(kb + (int)gridDim.x * 4, nkb - 1);
+        const int kn = min(kb + (int)gridDim.y * 4, nkb - 1);
         const float* apn = pb + (int64_t)min(kn * 16 + lj, T - 1) * AM_C;
 #pragma unroll
         for (int u = 0; u < 4; ++u) an[u] = *reinterpret_cast<const float4*>(apn + off(u));
@@ -232,7 +234,7 @@ extern "C" int msm_attn_mask_pooled(const float* embed, int64_t embed_ld, const 
     const bool vec = T % 4 == 0 && (((uintptr_t)attn) & 3) == 0;
     const bool f16 = (flags & 2) != 0;
 #define AM_LAUNCH(V_, B_, F_)                                                                                                                          \
-    hipLaunchKernelGGL((attn_mask_pooled_kernel<V_, B_, F_>), dim3(wgs, B, zq), dim3(256), 0, st, embed, embed_ld, qbias, qbias_ld, pooled, attn, row_any, \
+    hipLaunchKernelGGL((attn_mask_pooled_kernel<V_, B_, F_>), dim3(B, wgs, zq), dim3(256), 0, st, embed, embed_ld, qbias, qbias_ld, pooled, attn, row_any, \
                        Q, T)
     if (bits) {
         if (f16) AM_LAUNCH(true, true, true); else AM_LAUNCH(true, true, false);

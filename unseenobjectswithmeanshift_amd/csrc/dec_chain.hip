@@ -558,6 +558,7 @@ __global__ __launch_bounds__(DC_THREADS) void dec_post_cross_kernel(
     float *T0 = lds, *X = lds + TK::R * TK::LD, *XP = lds + 2 * TK::R * TK::LD;
     if (prefetch_part(pf)) return;                                     // the prefetch rows (see PfRanges)
     const int row0 = blockIdx.x * TK::R;
+    if (row0 >= rows) return;                                          // (grid.x is padded to a multiple of 8: see tile_grid_x)
     const int valid = min(TK::R, rows - row0);
     // blockIdx.y picks the projection (0: q, 1: k, 2: v): the 16-row tile is MFMA-bound on ONE CU at 3.4 us per
     // 256x256 stage, so the three independent projections go to three CUs; each repeats the Wo + LN stage.
@@ -591,6 +592,7 @@ __global__ __launch_bounds__(DC_THREADS) void dec_post_self_kernel(
     if (prefetch_part(pf)) return;                                     // the prefetch rows (see PfRanges)
     const int n_chunks_y = (int)gridDim.y - pf.rows;
     const int row0 = blockIdx.x * TK::R, chunk = blockIdx.y;
+    if (row0 >= rows) return;                                          // (padding tile)
     const int valid = min(TK::R, rows - row0);
     // blockIdx.y owns F/256/gridDim.y consecutive 256-wide hidden chunks; their W2 products accumulate in registers.
     // linear1: rows [c*256, +256) of the packed (F, 256) matrix; linear2 (256, F): k-chunks 4c..4c+3 of every row tile.
@@ -651,6 +653,7 @@ __global__ __launch_bounds__(DC_THREADS) void dec_heads_kernel(
         row0 = img * Q + tile * TK::R;
         valid = min(TK::R, Q - tile * TK::R);
     }
+    if (row0 >= rows) return;                                          // (padding tile)
     // blockIdx.y == 1 (only launched when wq is given): the next layer's query projection; y == 0: the MLP chain; MASK: y = 0 and
     // y >= (wq ? 2 : 1) are the mask parts
     const bool qpart = wq != nullptr && blockIdx.y == 1;
@@ -890,6 +893,11 @@ extern "C" int msm_dec_pack_weight_f16(const float* w, uint16_t* packed, int N, 
 
 // 8-row fp32 tiles while tiles x parts fit the chip in one round (see the tile kinds above)
 static bool use_tile8(int rows, int parts) { return cdiv(rows, 8) * parts <= 256; }
+// XCD-aware grids (round 6): workgroups are dealt to the 8 XCDs by linear id % 8 = (x + gridDim.x * y) % 8; with gridDim.x a multiple of 8 a
+// row tile x runs on XCD x % 8 in EVERY part (y) of EVERY tail launch, so what one tail wrote for tile x (x_out, q / k / v, the FFN partial sums:
+// plain stores stay in the writing XCD's L2) is read back by the next tail's workgroups of the same tile on the same XCD.  The padding tiles
+// (at most 7) exit at once.
+static int tile_grid_x(int tiles) { return (tiles + 7) & ~7; }
 // fp16 weights: 32-row tiles (TileQ32) once the 16-row tiles alone oversubscribe the chip -- the launch is then bound by the aggregate
 // L2 -> CU weight stream, which a fragment shared by two tiles halves (MSM_OPT_DEC_TILE32: 1 always, 0 never)
 static bool use_tile32(int rows) {
@@ -907,8 +915,9 @@ static int dec_post_cross_impl(const char* who, const float* attn_out, const flo
     MSM_REQUIRE(aligned16(attn_out) && aligned16(wo) && aligned16(w_in), "%s: pointers must be 16-byte aligned", who);
     // 8-row tiles take two parts (q then k | v): three would oversubscribe the chip at 800 rows (see use_tile8)
     PfRanges pf = take_prefetch();
-    pf.rows = prefetch_rows(pf, cdiv(rows, TK::R));
-    hipLaunchKernelGGL(dec_post_cross_kernel<TK>, dim3(cdiv(rows, TK::R), (TK::F8 ? 2 : 3) + pf.rows), dim3(DC_THREADS), 0, (hipStream_t)stream,
+    const int gx = tile_grid_x(cdiv(rows, TK::R));
+    pf.rows = prefetch_rows(pf, gx);
+    hipLaunchKernelGGL(dec_post_cross_kernel<TK>, dim3(gx, (TK::F8 ? 2 : 3) + pf.rows), dim3(DC_THREADS), 0, (hipStream_t)stream,
                        attn_out, res, query_pos, wo, bo, ln_g, ln_b, w_in, b_in, x_out, qk_out, v_out, rows, Q, eps, pf);
     MSM_CHECK_LAUNCH(who);
     return MSM_OK;
@@ -951,8 +960,9 @@ static int dec_post_self_impl(const char* who, const float* attn_out, const floa
     MSM_REQUIRE(n_parts > 0 && (F / DC_E) % n_parts == 0, "%s: n_parts=%d must divide F/256=%d", who, n_parts, F / DC_E);
     MSM_REQUIRE(aligned16(attn_out) && aligned16(wo) && aligned16(w1) && aligned16(w2), "%s: pointers must be 16-byte aligned", who);
     PfRanges pf = take_prefetch();
-    pf.rows = prefetch_rows(pf, cdiv(rows, TK::R));
-    hipLaunchKernelGGL(dec_post_self_kernel<TK>, dim3(cdiv(rows, TK::R), n_parts + pf.rows), dim3(DC_THREADS), 0, (hipStream_t)stream, attn_out,
+    const int gx = tile_grid_x(cdiv(rows, TK::R));
+    pf.rows = prefetch_rows(pf, gx);
+    hipLaunchKernelGGL(dec_post_self_kernel<TK>, dim3(gx, n_parts + pf.rows), dim3(DC_THREADS), 0, (hipStream_t)stream, attn_out,
                        res, wo, bo, ln_g, ln_b, w1, b1, w2, F, x_out, parts, rows, eps, pf);
     MSM_CHECK_LAUNCH(who);
     return MSM_OK;
@@ -997,7 +1007,7 @@ static int dec_heads_impl(const char* who, const float* x, const float* parts, i
     MSM_REQUIRE((ln_g == nullptr) == (ln_b == nullptr), "%s: ln_g/ln_b must both be given or both be null", who);
     MSM_REQUIRE(!wq || (bq && query_pos && q_out), "%s: the next-query projection needs bq, query_pos and q_out", who);
     MSM_REQUIRE(aligned16(m0w) && aligned16(m1w) && aligned16(m2w) && aligned16(wq), "%s: weights must be 16-byte aligned", who);
-    dim3 grid(cdiv(rows, TK::R), wq ? 2 : 1);
+    dim3 grid(tile_grid_x(cdiv(rows, TK::R)), wq ? 2 : 1);
     if constexpr (MASK) {
         MSM_REQUIRE(hm.pooled && hm.attn && hm.row_any && hm.T > 0 && rows % Q == 0, "%s: the mask epilogue needs pooled / attn / row_any, T > 0 and rows = B * Q", who);
         MSM_REQUIRE(hm.qcol >= 64 && hm.qcol < DC_E && aligned16(hm.pooled), "%s: qcol=%d must name a column of e behind the 64 embedding columns", who, hm.qcol);
