@@ -59,7 +59,7 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 21   /* 21: msm_dec_heads_mask (the next layer's attention mask as the heads kernel's epilogue), msm_l2_prefetch / msm_dec_set_prefetch, MSM_OPT_DEC_TILE32; 20: msm_ucn_embedding_tail; 19: backbone glue (msm_bias_act_nhwc, msm_nhwc_to_nchw_f32); 18: flags argument of msm_attn_mask_pooled (bit 1: IEEE-half operands); 17: msm_f32_to_f16_rows; 16: msm_mask_conv3x3_folded (the UCN mask step with the 3x3 mask_features convolution folded into the query embedding); 15: IEEE-half operand forms of the 16-bit plan (precision "f16": msm_dec_*_f16, msm_encoder_block_hm_fwd ffn_f16, fp16 keys in the low-precision attention); 14: cmat_width argument of the K/V projections (separable position constants), msm_conv3x3_c64_nchw_bf16, msm_encoder_prologue_hm_fwd; 13: flags argument of msm_ms_select_seeds_bf16 (persistent on-chip seeding over the bf16 copy), input projections on the bf16 matrix pipe (msm_conv1x1_in_lp, msm_conv1x1_in_multi_lp); 12: head-major bf16 activations between the encoder kernels of the bf16 plan (msm_encoder_block_hm_fwd, msm_msdeform_attn_enc_lp_fwd, msm_f32_to_f16); 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
+#define MSM_ABI_VERSION 21   /* 21: msm_dec_heads_mask (the next layer's attention mask as the heads kernel's epilogue), msm_l2_prefetch / msm_dec_set_prefetch, msm_dec_*_bf16x2 (hi + lo weight fragments), MSM_OPT_DEC_TILE32; 20: msm_ucn_embedding_tail; 19: backbone glue (msm_bias_act_nhwc, msm_nhwc_to_nchw_f32); 18: flags argument of msm_attn_mask_pooled (bit 1: IEEE-half operands); 17: msm_f32_to_f16_rows; 16: msm_mask_conv3x3_folded (the UCN mask step with the 3x3 mask_features convolution folded into the query embedding); 15: IEEE-half operand forms of the 16-bit plan (precision "f16": msm_dec_*_f16, msm_encoder_block_hm_fwd ffn_f16, fp16 keys in the low-precision attention); 14: cmat_width argument of the K/V projections (separable position constants), msm_conv3x3_c64_nchw_bf16, msm_encoder_prologue_hm_fwd; 13: flags argument of msm_ms_select_seeds_bf16 (persistent on-chip seeding over the bf16 copy), input projections on the bf16 matrix pipe (msm_conv1x1_in_lp, msm_conv1x1_in_multi_lp); 12: head-major bf16 activations between the encoder kernels of the bf16 plan (msm_encoder_block_hm_fwd, msm_msdeform_attn_enc_lp_fwd, msm_f32_to_f16); 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
 int msm_abi_version(void);
 
 /* Kernel-selection overrides for tools/ and tests/ (NOT read on the product path: every option defaults to
@@ -505,6 +505,29 @@ int msm_dec_heads_f16(const float* x, const float* parts, int n_parts, const flo
                       const uint16_t* wq, const float* bq, const float* query_pos,
                       float* out, float* d_out, float* e_out, float* q_out, int32_t* row_any_zero,
                       int rows, int Q, int E, float eps, void* stream);
+
+/* The bf16 tails with hi + lo WEIGHT fragments (round 6; what set_precision("bf16") runs): msm_dec_pack_weight_bf16x2 packs
+ * [bf16(W) | bf16(W - bf16(W))] along K (packed holds N x 2 K elements, the bf16 fragment order per half), and a stage accumulates the hi
+ * chunks and then the lo chunks -- with the activation's own hi + lo split every product keeps 2^-17 instead of the weight's 2^-9, which
+ * was 0.85 % of the bf16 plan's 1.08 % of flipped final-mask bits.  Twice the weight stream and MFMAs of the _bf16 forms; same arguments. */
+int msm_dec_pack_weight_bf16x2(const float* w, uint16_t* packed, int N, int K, void* stream);
+int msm_dec_post_cross_bf16x2(const float* attn_out, const float* res, const float* query_pos,
+                              const uint16_t* wo, const float* bo, const float* ln_g, const float* ln_b,
+                              const uint16_t* w_in, const float* b_in,
+                              float* x_out, float* qk_out, float* v_out,
+                              int rows, int Q, int E, float eps, void* stream);
+int msm_dec_post_self_bf16x2(const float* attn_out, const float* res,
+                             const uint16_t* wo, const float* bo, const float* ln_g, const float* ln_b,
+                             const uint16_t* w1, const float* b1, const uint16_t* w2, int F,
+                             float* x_out, float* parts, int n_parts, int rows, int E, float eps, void* stream);
+int msm_dec_heads_bf16x2(const float* x, const float* parts, int n_parts, const float* bias,
+                         const float* ln_g, const float* ln_b, int l2norm,
+                         const float* dec_g, const float* dec_b,
+                         const uint16_t* m0w, const float* m0b, const uint16_t* m1w, const float* m1b,
+                         const uint16_t* m2w, const float* m2b,
+                         const uint16_t* wq, const float* bq, const float* query_pos,
+                         float* out, float* d_out, float* e_out, float* q_out, int32_t* row_any_zero,
+                         int rows, int Q, int E, float eps, void* stream);
 
 /* msm_dec_heads_bf16 / _f16 with the NEXT layer's attention mask at key resolution as the kernel's epilogue (round 6; replaces the
  * pair msm_dec_heads_* + msm_attn_mask_pooled(flags & 2) of the 16-bit plans: DEC:660-682 with interpolate(einsum(e, F)) =

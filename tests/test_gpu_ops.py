@@ -616,7 +616,7 @@ def _ln(x, g, b, eps=1e-5):
 
 
 @pytest.mark.parametrize("B,Q", [(2, 100), (1, 7), (3, 16)])
-@pytest.mark.parametrize("prec", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("prec", ["f32", "bf16", "f16", "bf16x2"])
 def test_decoder_fused_tails(B, Q, prec):
     """csrc/dec_chain.hip against the same chain in torch fp64 (DEC:245-260, 171-181, 296-300, 637-638, 661-665);
     tolerance: fp32 rounding of 256/2048-term dot products on O(1) values.  prec = "bf16": the low-precision entry points
@@ -624,7 +624,9 @@ def test_decoder_fused_tails(B, Q, prec):
     bf16-ROUNDED weights -- what is left is the 2^-17 residual of the activation split.  prec = "f16" (round 5): IEEE-half weight
     fragments and ONE fp16 activation term per product, against the fp64 chain with the weights AND each GEMM's input rounded to
     fp16 -- what is left is fp32 accumulation; that this form is closer to the exact chain than the bf16 one is
-    test_decoder_tails_f16_is_closer_to_exact_than_bf16."""
+    test_decoder_tails_f16_is_closer_to_exact_than_bf16.  prec = "bf16x2" (round 6, what the "bf16" plan runs): hi + lo bf16 WEIGHT
+    fragments beside the hi + lo activation split -- against the fp64 chain on the EXACT weights under the bf16 form's bound (what is
+    left is 2^-17 per operand)."""
     E, Fh = 256, 2048
     r = lambda *s, seed, k=1.0: (rnd(*s, seed=seed) * k)
     o, res, qpos = r(B, Q, E, seed=1), r(B, Q, E, seed=2), r(Q, E, seed=3)
@@ -635,20 +637,25 @@ def test_decoder_fused_tails(B, Q, prec):
     dbl = lambda *ts: [t.double() for t in ts]
     bf = prec == "bf16"
     f16 = prec == "f16"
+    x2 = prec == "bf16x2"
     pack = {"f32": lambda w: ops().dec_pack_weight(w.to(DEV)), "bf16": lambda w: ops().dec_pack_weight_bf16(w.to(DEV)),
-            "f16": lambda w: ops().dec_pack_weight_f16(w.to(DEV))}[prec]
+            "f16": lambda w: ops().dec_pack_weight_f16(w.to(DEV)), "bf16x2": lambda w: ops().dec_pack_weight_bf16x2(w.to(DEV))}[prec]
     rw = _bf16_round if bf else ((lambda w: w.to(torch.float16).float()) if f16 else (lambda w: w))      # the weights the kernels actually multiply by
     # (f16: a stage's input differs from the reference's by ~1e-5, so a few per cent of its elements round to the neighbouring half --
     # each such flip is 2^-11 |x| |w|: the price of rounding activations at all, and why this form's bound is three times the bf16 form's)
-    tol = 12.0 if f16 else (4.0 if bf else 1.0)
+    tol = 12.0 if f16 else (4.0 if (bf or x2) else 1.0)
     # f16: the activation enters every product as ONE fp16 term -- the references round it the same way in front of each GEMM
     A = (lambda t: t.float().to(torch.float16).double()) if f16 else (lambda t: t)
     closed_ = globals()["closed"]
     closed = lambda got, ref, rtol, atol: closed_(got, ref, rtol=rtol * tol, atol=atol * tol + (4e-5 if f16 else 0.0))  # noqa: E731
     # the documented fragment order (include/msm_hip.h)
     N_, K_ = w_in.shape
-    if bf or f16:       # [t][kc][up][lq][lj][h][c] <- W[t*16 + lj][kc*64 + (2 up + h)*16 + lq*4 + c]
-        want = w_in.view(N_ // 16, 16, K_ // 64, 2, 2, 4, 4).permute(0, 2, 3, 5, 1, 4, 6).contiguous().view(N_, K_).to(torch.float16 if f16 else torch.bfloat16)
+    frag = lambda m, dt: m.view(N_ // 16, 16, K_ // 64, 2, 2, 4, 4).permute(0, 2, 3, 5, 1, 4, 6).contiguous().view(N_ // 16, K_ // 64, 1024).to(dt)
+    if x2:              # per row tile: the K / 64 chunks of bf16(W), then the K / 64 chunks of bf16(W - bf16(W))
+        hi = w_in.to(torch.bfloat16)
+        want = torch.cat([frag(hi.float(), torch.bfloat16), frag(w_in - hi.float(), torch.bfloat16)], 1).reshape(N_, 2 * K_)
+    elif bf or f16:     # [t][kc][up][lq][lj][h][c] <- W[t*16 + lj][kc*64 + (2 up + h)*16 + lq*4 + c]
+        want = frag(w_in, torch.float16 if f16 else torch.bfloat16).reshape(N_, K_)
     else:
         want = w_in.view(N_ // 16, 16, K_ // 64, 4, 4, 4).permute(0, 2, 3, 4, 1, 5).contiguous().view(N_, K_)
     assert torch.equal(pack(w_in).cpu(), want)
@@ -705,6 +712,8 @@ def test_decoder_fused_tails(B, Q, prec):
     closed(e0, er, rtol=1e-4, atol=1e-4)
     with pytest.raises(RuntimeError, match="all float32, all bfloat16 or all float16"):
         ops().dec_post_cross(*dev(o, res, qpos), ops().dec_pack_weight_bf16(wo.to(DEV)), *dev(bo, g, b), ops().dec_pack_weight_f16(w_in.to(DEV)), b_in.to(DEV))
+    with pytest.raises(RuntimeError, match="all hi \\+ lo bf16 fragments"):
+        ops().dec_post_cross(*dev(o, res, qpos), ops().dec_pack_weight_bf16(wo.to(DEV)), *dev(bo, g, b), ops().dec_pack_weight_bf16x2(w_in.to(DEV)), b_in.to(DEV))
 
 
 def test_decoder_tails_f16_is_closer_to_exact_than_bf16():
@@ -718,12 +727,14 @@ def test_decoder_tails_f16_is_closer_to_exact_than_bf16():
     xr = _ln(res.double() + o.double() @ wo.double().t() + bo.double(), g.double(), b.double())
     ffn = torch.relu(xr @ w1.double().t() + b1.double()) @ w2.double().t()
     errs = {}
-    for prec, pk in (("bf16", ops().dec_pack_weight_bf16), ("f16", ops().dec_pack_weight_f16), ("f32", ops().dec_pack_weight)):
+    for prec, pk in (("bf16", ops().dec_pack_weight_bf16), ("f16", ops().dec_pack_weight_f16), ("f32", ops().dec_pack_weight),
+                     ("bf16x2", ops().dec_pack_weight_bf16x2)):
         d = lambda t: t.to(DEV)
         _, parts = ops().dec_post_self(d(o), d(res), pk(d(wo)), d(bo), d(g), d(b), pk(d(w1)), d(b1), pk(d(w2)))
         errs[prec] = float((parts.double().sum(0).cpu() - ffn).abs().mean())
     print(f"FFN stage, mean |error| against fp64 on the exact weights: {errs}")
     assert errs["f16"] * 4 <= errs["bf16"] and errs["f32"] <= errs["f16"]
+    assert errs["bf16x2"] * 8 <= errs["bf16"] and errs["bf16x2"] <= errs["f16"]          # hi + lo weights: the 2^-9 of the weights is gone
 
 
 def test_decoder_tails_f16_32_row_tiles_equal_16_row_tiles():

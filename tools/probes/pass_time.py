@@ -23,6 +23,9 @@ feats = {k: v.to(dev) for k, v in syn.synth_backbone_features(8, 480, 640, seed=
 out = [os.path.dirname(unseenobjectswithmeanshift_amd.__file__).replace(ROOT, ".")]
 for mode in os.environ.get("MSM_MODES", "f16,bf16,f32").split(","):
     model.set_precision(mode)
+    if os.environ.get("MSM_TAILS_HL") and hasattr(model.sem_seg_head.predictor, "tails_hl"):
+        v = os.environ["MSM_TAILS_HL"]
+        model.sem_seg_head.predictor.tails_hl = {"0": False, "1": True}.get(v, tuple(v.split(",")))
     g = model.graphed()
     for _ in range(5):
         g(feats, (480, 640))

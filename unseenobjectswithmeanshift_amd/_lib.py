@@ -106,6 +106,11 @@ _SIGNATURES = {
                           [c_p, c_i, c_i, c_i, c_fl, c_p]),
     "msm_dec_heads_mask": (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_f, c_p, c_f, c_p, c_f, c_p, c_f, c_p, c_f, c_f] + [c_f] * 4 +
                            [c_f, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_fl, c_p]),
+    "msm_dec_pack_weight_bf16x2": (c_i, [c_f, c_p, c_i, c_i, c_p]),
+    "msm_dec_post_cross_bf16x2": (c_i, [c_f, c_f, c_f, c_p, c_f, c_f, c_f, c_p, c_f, c_f, c_f, c_f] + [c_i, c_i, c_i, c_fl, c_p]),
+    "msm_dec_post_self_bf16x2": (c_i, [c_f, c_f, c_p, c_f, c_f, c_f, c_p, c_f, c_p] + [c_i, c_f, c_f, c_i, c_i, c_i, c_fl, c_p]),
+    "msm_dec_heads_bf16x2": (c_i, [c_f, c_f, c_i, c_f, c_f, c_f, c_i, c_f, c_f, c_p, c_f, c_p, c_f, c_p, c_f, c_p, c_f, c_f] + [c_f] * 4 +
+                             [c_p, c_i, c_i, c_i, c_fl, c_p]),
     "msm_l2_prefetch": (c_i, [c_p, c_p, c_i, c_p]),
     "msm_dec_set_prefetch": (c_i, [c_p, c_p, c_i]),
     "msm_ms_seed_workspace": (c_l, [c_i]),

@@ -67,16 +67,19 @@ struct TileF16 {
     using WT = float;
     static constexpr int R = 16, LD = DC_E + 4, RG = 1;
     static constexpr bool F8 = false;
+    static constexpr int KP = 1;
 };
 struct TileF8 {
     using WT = float;
     static constexpr int R = 8, LD = DC_E + 16, RG = 2;
     static constexpr bool F8 = true;
+    static constexpr int KP = 1;
 };
 struct TileH16 {
     using WT = uint16_t;
     static constexpr int R = 16, LD = DC_E + 4, RG = 1;
     static constexpr bool F8 = false;
+    static constexpr int KP = 1;
 };
 // fp16 weights (precision "f16"): the same bytes as bf16 with 11 instead of 8 significand bits -- Linear weights are O(0.01 .. 1),
 // far inside the half range -- on v_mfma_f32_16x16x32_f16, which issues at the bf16 instruction's rate.  The activation fragment
@@ -91,11 +94,25 @@ struct TileQ16 {
     using WT = f16w;
     static constexpr int R = 16, LD = DC_E + 4, RG = 1;
     static constexpr bool F8 = false;
+    static constexpr int KP = 1;
+};
+// bf16 weights as hi + lo fragments (round 6, the "bf16" plan's tails): the packed matrix is [bf16(W) | bf16(W - bf16(W))] along K (msm_dec_pack_weight_bf16x2),
+// a stage walks the hi chunks, then the lo chunks, into the same accumulators -- with the activation's own hi + lo split every product keeps 2^-17:
+// the single-bf16 weights were 0.85 % of the plan's 1.08 % of flipped mask bits; twice the weight stream, twice the MFMAs.
+struct bf16hl {
+    uint16_t v;
+};
+struct TileH16x2 {
+    using WT = bf16hl;
+    static constexpr int R = 16, LD = DC_E + 4, RG = 1;
+    static constexpr bool F8 = false;
+    static constexpr int KP = 2;
 };
 struct TileQ32 {
     using WT = f16w;
     static constexpr int R = 32, LD = DC_E + 4, RG = 2;
     static constexpr bool F8 = false;
+    static constexpr int KP = 1;
 };
 // (64-row tiles -- RG = 4, one 133-KB workgroup per CU -- were measured for post_self at 17 300 rows: 126 us against 90 for 32-row tiles and
 // 136 for 16-row tiles: one resident workgroup cannot keep the weight stream's latency covered.)
@@ -124,6 +141,8 @@ struct BFrag<uint16_t> {
 };
 template <>
 struct BFrag<f16w> : BFrag<uint16_t> {};
+template <>
+struct BFrag<bf16hl> : BFrag<uint16_t> {};
 // W: packed weight, advanced to the first of the 256 output rows wanted (row offset n0 -> + n0*K elements);
 // kct = K/64 of the packed matrix; kc0 = first of the two k-chunks to fetch
 // (Rotating the k-chunk order per workgroup to de-phase their L2 accesses was measured: -3 % kernel time, and it
@@ -255,6 +274,13 @@ __device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT][1], const float* _
         }
     }
 }
+// bf16 hi + lo weights: the bf16 form's loads and MFMAs on either half of the packed K
+__device__ __forceinline__ void bload(BFrag<bf16hl>& f, const bf16hl* __restrict__ W, int kct, int kc_base, int half) {
+    bload(static_cast<BFrag<uint16_t>&>(f), reinterpret_cast<const uint16_t*>(W), kct, kc_base, half);
+}
+__device__ __forceinline__ void mfma_half(f32x4 (&acc)[DC_NT][1], const float* __restrict__ ap, const BFrag<bf16hl>& f, int half) {
+    mfma_half(acc, ap, static_cast<const BFrag<uint16_t>&>(f), half);
+}
 // fp16 weights: the same fragment layout and loads as bf16; one MFMA per pair of k-steps and column tile
 __device__ __forceinline__ void bload(BFrag<f16w>& f, const f16w* __restrict__ W, int kct, int kc_base, int half) {
     bload(static_cast<BFrag<uint16_t>&>(f), reinterpret_cast<const uint16_t*>(W), kct, kc_base, half);
@@ -305,7 +331,7 @@ struct Pipe {
     // MFMAs between two prefetch loads: 8-row fp32 has two 8-cycle MFMAs where the 16-row form has one of 32; bf16 (hi + lo activation) has
     // 8 * DC_NT per half stage, fp16 (one term) 4 * DC_NT
     static constexpr int IL = std::is_same<typename TK::WT, f16w>::value ? TK::RG
-                              : !std::is_same<typename TK::WT, float>::value ? DC_IL / 2 : (TK::F8 ? 2 * DC_IL : DC_IL);
+                              : !std::is_same<typename TK::WT, float>::value ? DC_IL / 2 : (TK::F8 ? 2 * DC_IL : DC_IL);      // (bf16hl: as bf16)
 };
 
 // D[16][256] = act(A[16][256] . W[n][k]^T + bias).  A in LDS.  TO_GLOBAL: D is row-major global with row stride
@@ -343,6 +369,19 @@ __device__ __forceinline__ void gemm_core(f32x4 (&acc)[DC_NT][TK::RG], const flo
         __builtin_amdgcn_sched_group_barrier(0x008, Pipe<TK>::IL, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
+}
+
+// gemm_core over all of a stage's k: one pass, or (TK::KP == 2: hi + lo weight fragments, packed K' = 2 K) the hi chunks [kc_base, + 4) and then
+// the lo chunks [kct + kc_base, + 4) of the same rows.  kct / kctn count the 64-wide chunks of the ORIGINAL K.
+template <bool NEXT, typename TK>
+__device__ __forceinline__ void gemm_core_k(f32x4 (&acc)[DC_NT][TK::RG], const float* __restrict__ A, const typename TK::WT* __restrict__ W, int kct,
+                                            int kc_base, BFrag<typename TK::WT>& lo, const typename TK::WT* __restrict__ Wn, int kctn, int kcn) {
+    if constexpr (TK::KP == 1) {
+        gemm_core<NEXT, TK>(acc, A, W, kct, kc_base, lo, Wn, kctn, kcn);
+    } else {
+        gemm_core<true, TK>(acc, A, W, 2 * kct, kc_base, lo, W, 2 * kct, kct + kc_base);
+        gemm_core<NEXT, TK>(acc, A, W, 2 * kct, kct + kc_base, lo, Wn, 2 * kctn, kcn);
+    }
 }
 
 // D = act(acc + bias).  TO_GLOBAL: D is row-major global with row stride ldd, rows >= rows_valid are not written;
@@ -426,7 +465,7 @@ __device__ __forceinline__ void gemm256(const float* __restrict__ A, const typen
         for (int rg = 0; rg < TK::RG; ++rg) acc[t][rg] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bv[DC_NT];
     load_bias(bv, bias);            // requested before the MFMAs, consumed after them
-    gemm_core<NEXT, TK>(acc, A, W, kct, kc_base, lo, Wn, kctn, kcn);
+    gemm_core_k<NEXT, TK>(acc, A, W, kct, kc_base, lo, Wn, kctn, kcn);
     gemm_store<TO_GLOBAL, TK>(acc, bv, relu, D, ldd, rows_valid);
 }
 
@@ -523,7 +562,7 @@ __device__ __forceinline__ void attn_out_ln(const float* __restrict__ o, const f
                                             int rows, float eps, BFrag<WT>& f, const WT* __restrict__ w_next, int kct_next,
                                             int kc_next) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    bload(f, wo, 4, 0, 0);
+    bload(f, wo, 4 * TK::KP, 0, 0);
     load_tile<TK>(T0, o, DC_E, row0, rows);
     float4 rv[(TK::R / DC_NW)], pv[(TK::R / DC_NW)];
 #pragma unroll
@@ -566,15 +605,15 @@ __global__ __launch_bounds__(DC_THREADS) void dec_post_cross_kernel(
     const int part = blockIdx.y;
     const bool two = (int)gridDim.y - pf.rows == 2;
     const int first = two ? (part == 0 ? 0 : 2) : part;        // the projection this workgroup starts with
-    const WT* wp = w_in + (int64_t)first * DC_E * DC_E;
+    const WT* wp = w_in + (int64_t)first * DC_E * DC_E * TK::KP;
     BFrag<WT> f;
     attn_out_ln<TK>(o, res, wo, bo, g, b, qpos, Q, x_out, part == 0, T0, X, XP, row0, rows, eps, f, wp, 4, 0);
     // q and k share tgt + query_pos (DEC:171-175); v = tgt
     if (first == 2) {
         gemm256<true, false, TK>(X, wp, 4, 0, b_in + 2 * DC_E, false, v_out + (int64_t)row0 * DC_E, DC_E, valid, f, nullptr, 0, 0);
     } else if (two) {
-        gemm256<true, true, TK>(XP, wp, 4, 0, b_in, false, qk_out + (int64_t)row0 * 2 * DC_E, 2 * DC_E, valid, f, wp + DC_E * DC_E, 4, 0);
-        gemm256<true, false, TK>(XP, wp + DC_E * DC_E, 4, 0, b_in + DC_E, false, qk_out + (int64_t)row0 * 2 * DC_E + DC_E, 2 * DC_E, valid, f,
+        gemm256<true, true, TK>(XP, wp, 4, 0, b_in, false, qk_out + (int64_t)row0 * 2 * DC_E, 2 * DC_E, valid, f, wp + DC_E * DC_E * TK::KP, 4, 0);
+        gemm256<true, false, TK>(XP, wp + DC_E * DC_E * TK::KP, 4, 0, b_in + DC_E, false, qk_out + (int64_t)row0 * 2 * DC_E + DC_E, 2 * DC_E, valid, f,
                                  nullptr, 0, 0);
     } else {
         gemm256<true, false, TK>(XP, wp, 4, 0, b_in + first * DC_E, false, qk_out + (int64_t)row0 * 2 * DC_E + first * DC_E, 2 * DC_E,
@@ -600,7 +639,7 @@ __global__ __launch_bounds__(DC_THREADS) void dec_post_self_kernel(
     const int kct2 = F / 64;
     BFrag<WT> f;
     attn_out_ln<TK>(o, res, wo, bo, g, b, nullptr, 1, x_out, chunk == 0, T0, X, nullptr, row0, rows, eps, f,
-                    w1 + (int64_t)c0 * DC_E * DC_E, 4, 0);
+                    w1 + (int64_t)c0 * DC_E * DC_E * TK::KP, 4, 0);
     f32x4 acc2[DC_NT][TK::RG];
 #pragma unroll
     for (int t = 0; t < DC_NT; ++t)
@@ -609,10 +648,10 @@ __global__ __launch_bounds__(DC_THREADS) void dec_post_self_kernel(
     const float zero_bias[DC_NT] = {};
     for (int c = c0; c < c0 + per; ++c) {
         // h = relu(x W1[c]^T + b1[c]) (DEC:297) -> T0;  acc2 += h W2[:, c]^T
-        gemm256<false, true, TK>(X, w1 + (int64_t)c * DC_E * DC_E, 4, 0, b1 + c * DC_E, true, T0, 0, 0, f, w2, kct2, 4 * c);
+        gemm256<false, true, TK>(X, w1 + (int64_t)c * DC_E * DC_E * TK::KP, 4, 0, b1 + c * DC_E, true, T0, 0, 0, f, w2, kct2, 4 * c);
         __syncthreads();
         const int cn = min(c + 1, c0 + per - 1);    // the last prefetch re-reads the current chunk: no branch in the pipeline
-        gemm_core<true, TK>(acc2, T0, w2, kct2, 4 * c, f, w1 + (int64_t)cn * DC_E * DC_E, 4, 0);
+        gemm_core_k<true, TK>(acc2, T0, w2, kct2, 4 * c, f, w1 + (int64_t)cn * DC_E * DC_E * TK::KP, 4, 0);
         __syncthreads();
     }
     gemm_store<true, TK>(acc2, zero_bias, false, parts + ((int64_t)chunk * rows + row0) * DC_E, DC_E, valid);
@@ -662,7 +701,7 @@ __global__ __launch_bounds__(DC_THREADS) void dec_heads_kernel(
     // the mask step that consumes e_out needs its row_any flags cleared: done here instead of a separate fill launch
     if (row_any_zero && !qpart && primary && (int)threadIdx.x < valid) row_any_zero[row0 + threadIdx.x] = 0;
     BFrag<WT> f;
-    bload(f, qpart ? wq : m0w, 4, 0, 0);
+    bload(f, qpart ? wq : m0w, 4 * TK::KP, 0, 0);
     // row phase: lane owns 4 consecutive columns; all global operands of the wave's rows are requested up front
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 v[(TK::R / DC_NW)], pv[(TK::R / DC_NW)];
@@ -820,25 +859,33 @@ __global__ __launch_bounds__(256) void dec_pack_weight_kernel(const float* __res
 }
 
 // bf16: packed[(((t*(K/64) + kc)*2 + up)*64 + lane)*8 + h*4 + c] = bf16(W[t*16 + lj][kc*64 + (2 up + h)*16 + lq*4 + c])
-template <bool F16>
+// HL: the packed matrix has K' = 2 K columns: chunks kc < K/64 hold bf16(W), chunks K/64 + kc hold bf16(W - bf16(W)) of the same columns
+template <bool F16, bool HL = false>
 __global__ __launch_bounds__(256) void dec_pack_weight_bf16_kernel(const float* __restrict__ w, uint16_t* __restrict__ packed, int N,
                                                                    int K) {
-    const int64_t total8 = (int64_t)N * K / 8;
+    const int kct = K / 64, kct_p = HL ? 2 * kct : kct;
+    const int64_t total8 = (int64_t)N * kct_p * 8;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (int64_t)gridDim.x * 256) {
         const int lane = (int)(i & 63);
         int64_t r = i >> 6;
         const int up = (int)(r & 1);
         r >>= 1;
-        const int kct = K / 64;
-        const int kc = (int)(r % kct), t = (int)(r / kct);
+        const int kcp = (int)(r % kct_p), t = (int)(r / kct_p);
+        const bool low = HL && kcp >= kct;
+        const int kc = low ? kcp - kct : kcp;
         const int lj = lane & 15, lq = lane >> 4;
         const float* src = w + (int64_t)(t * 16 + lj) * K + kc * 64 + (2 * up) * 16 + lq * 4;
-        const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 16);
+        float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 16);
         u32x2b ua, ub;
         if constexpr (F16) {
             ua = pack4h(a.x, a.y, a.z, a.w), ub = pack4h(b.x, b.y, b.z, b.w);
         } else {
-            ua = __builtin_bit_cast(u32x2b, pack4(a.x, a.y, a.z, a.w)), ub = __builtin_bit_cast(u32x2b, pack4(b.x, b.y, b.z, b.w));
+            if (low) {                                       // the residual of the hi term, itself rounded to bf16
+                const Split4 sa = split4(a.x, a.y, a.z, a.w), sb = split4(b.x, b.y, b.z, b.w);
+                ua = __builtin_bit_cast(u32x2b, sa.lo), ub = __builtin_bit_cast(u32x2b, sb.lo);
+            } else {
+                ua = __builtin_bit_cast(u32x2b, pack4(a.x, a.y, a.z, a.w)), ub = __builtin_bit_cast(u32x2b, pack4(b.x, b.y, b.z, b.w));
+            }
         }
         *reinterpret_cast<u32x4b*>(packed + i * 8) = u32x4b{ua.x, ua.y, ub.x, ub.y};
     }
@@ -877,6 +924,17 @@ extern "C" int msm_dec_pack_weight_bf16(const float* w, uint16_t* packed, int N,
     hipLaunchKernelGGL(dec_pack_weight_bf16_kernel<false>, dim3((unsigned)min((int64_t)2048, (total8 + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, w, packed, N, K);
     MSM_CHECK_LAUNCH("msm_dec_pack_weight_bf16");
+    return MSM_OK;
+}
+
+extern "C" int msm_dec_pack_weight_bf16x2(const float* w, uint16_t* packed, int N, int K, void* stream) {
+    MSM_REQUIRE(w && packed, "msm_dec_pack_weight_bf16x2: null pointer");
+    MSM_REQUIRE(N > 0 && K > 0 && N % 16 == 0 && K % 64 == 0, "msm_dec_pack_weight_bf16x2: N=%d must be a multiple of 16, K=%d of 64", N, K);
+    MSM_REQUIRE(aligned16(w) && aligned16(packed), "msm_dec_pack_weight_bf16x2: pointers must be 16-byte aligned");
+    const int64_t total8 = (int64_t)N * K / 4;               // packed holds N x 2 K elements
+    hipLaunchKernelGGL((dec_pack_weight_bf16_kernel<false, true>), dim3((unsigned)min((int64_t)2048, (total8 + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, w, packed, N, K);
+    MSM_CHECK_LAUNCH("msm_dec_pack_weight_bf16x2");
     return MSM_OK;
 }
 
@@ -939,6 +997,13 @@ extern "C" int msm_dec_post_cross_bf16(const float* attn_out, const float* res, 
                                          v_out, rows, Q, E, eps, stream);
 }
 
+extern "C" int msm_dec_post_cross_bf16x2(const float* attn_out, const float* res, const float* query_pos, const uint16_t* wo,
+                                         const float* bo, const float* ln_g, const float* ln_b, const uint16_t* w_in, const float* b_in,
+                                         float* x_out, float* qk_out, float* v_out, int rows, int Q, int E, float eps, void* stream) {
+    return dec_post_cross_impl<TileH16x2>("msm_dec_post_cross_bf16x2", attn_out, res, query_pos, (const bf16hl*)wo, bo, ln_g, ln_b, (const bf16hl*)w_in, b_in,
+                                          x_out, qk_out, v_out, rows, Q, E, eps, stream);
+}
+
 extern "C" int msm_dec_post_cross_f16(const float* attn_out, const float* res, const float* query_pos, const uint16_t* wo,
                                       const float* bo, const float* ln_g, const float* ln_b, const uint16_t* w_in, const float* b_in,
                                       float* x_out, float* qk_out, float* v_out, int rows, int Q, int E, float eps, void* stream) {
@@ -982,6 +1047,13 @@ extern "C" int msm_dec_post_self_bf16(const float* attn_out, const float* res, c
                                       float* parts, int n_parts, int rows, int E, float eps, void* stream) {
     return dec_post_self_impl<TileH16>("msm_dec_post_self_bf16", attn_out, res, wo, bo, ln_g, ln_b, w1, b1, w2, F, x_out, parts, n_parts, rows, E,
                                         eps, stream);
+}
+
+extern "C" int msm_dec_post_self_bf16x2(const float* attn_out, const float* res, const uint16_t* wo, const float* bo, const float* ln_g,
+                                        const float* ln_b, const uint16_t* w1, const float* b1, const uint16_t* w2, int F, float* x_out,
+                                        float* parts, int n_parts, int rows, int E, float eps, void* stream) {
+    return dec_post_self_impl<TileH16x2>("msm_dec_post_self_bf16x2", attn_out, res, (const bf16hl*)wo, bo, ln_g, ln_b, (const bf16hl*)w1, b1, (const bf16hl*)w2, F,
+                                         x_out, parts, n_parts, rows, E, eps, stream);
 }
 
 extern "C" int msm_dec_post_self_f16(const float* attn_out, const float* res, const uint16_t* wo, const float* bo, const float* ln_g,
@@ -1047,6 +1119,15 @@ extern "C" int msm_dec_heads_bf16(const float* x, const float* parts, int n_part
     return dec_heads_impl<TileH16>("msm_dec_heads_bf16", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, m0w, m0b, m1w, m1b, m2w, m2b,
                                     wq, bq, query_pos, out, d_out, e_out, q_out, row_any_zero, rows, Q, E, eps, stream);
 }
+extern "C" int msm_dec_heads_bf16x2(const float* x, const float* parts, int n_parts, const float* bias, const float* ln_g,
+                                    const float* ln_b, int l2norm, const float* dec_g, const float* dec_b, const uint16_t* m0w,
+                                    const float* m0b, const uint16_t* m1w, const float* m1b, const uint16_t* m2w, const float* m2b,
+                                    const uint16_t* wq, const float* bq, const float* query_pos, float* out, float* d_out, float* e_out,
+                                    float* q_out, int32_t* row_any_zero, int rows, int Q, int E, float eps, void* stream) {
+    return dec_heads_impl<TileH16x2>("msm_dec_heads_bf16x2", x, parts, n_parts, bias, ln_g, ln_b, l2norm, dec_g, dec_b, (const bf16hl*)m0w, m0b, (const bf16hl*)m1w,
+                                     m1b, (const bf16hl*)m2w, m2b, (const bf16hl*)wq, bq, query_pos, out, d_out, e_out, q_out, row_any_zero, rows, Q, E, eps, stream);
+}
+
 extern "C" int msm_dec_heads_f16(const float* x, const float* parts, int n_parts, const float* bias, const float* ln_g,
                                  const float* ln_b, int l2norm, const float* dec_g, const float* dec_b, const uint16_t* m0w,
                                  const float* m0b, const uint16_t* m1w, const float* m1b, const uint16_t* m2w, const float* m2b,

@@ -316,6 +316,13 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         # "bf16": the fused row-local tails (dec_post_cross / dec_post_self / dec_heads) stream bf16 weights and multiply on
         # bf16 MFMAs with fp32 accumulation (activations as hi + lo pairs); part of set_precision("bf16")
         self.tails_dtype = "f32"
+        # tails_dtype "bf16": which tail launches multiply by hi + lo bf16 WEIGHT fragments (ops.dec_pack_weight_bf16x2; round 6): True = all
+        # three, False = none, or a tuple of "post_cross" / "post_self" / "heads".  Measured over 3200 masks against the fp32 reference
+        # (test_config2_slices_low_precision_vs_reference; single fragments everywhere: 1.08 % of the final mask bits, mean IoU 0.9513 --
+        # SURVEY 8c asks 0.95): the heads' weights (the mask-embedding MLP and the next query projection) alone 0.96 % / 0.9568 for 1 % of the
+        # pass; post_cross alone 1.05 % / 0.9525; post_self (the FFN, two thirds of the bytes) alone 1.07 % / 0.9517 for 6 %; all three
+        # 0.92 % / 0.9583 for 8 %.  The embedding that is thresholded against every pixel is where a weight's 2^-9 shows.
+        self.tails_hl = ("heads",)
         self.ffn_parts = None          # hidden-dimension slices of the fused FFN tail (None: ops.dec_post_self's default)
         # 16-bit plans with attention masks at key resolution: the next layer's mask as the epilogue of the heads kernel
         # (ops.dec_heads_mask: one launch instead of dec_heads + attn_mask_pooled; the same values bit for bit).  Opt-in: measured on
@@ -453,17 +460,21 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             "ffn2": [l.linear2.weight for l in self.transformer_ffn_layers],
             "mlp": [l.weight for l in self.mask_embed.layers],
         }
-        pack = self._tails_pack()
-        key = (self.tails_dtype,) + tuple((p.data_ptr(), p._version) for ws in groups.values() for p in ws)
+        kernel_of = {"cross_q": "heads", "mlp": "heads", "cross_o": "post_cross", "self_in": "post_cross", "self_o": "post_self", "ffn1": "post_self",
+                     "ffn2": "post_self"}                     # the launch that multiplies by the group (a launch takes one fragment form)
+        key = (self.tails_dtype, str(self.tails_hl)) + tuple((p.data_ptr(), p._version) for ws in groups.values() for p in ws)
         if self._tails_cache is None or self._tails_cache[0] != key:
-            self._tails_cache = (key, {k: [pack(w.contiguous()) for w in ws] for k, ws in groups.items()})
+            self._tails_cache = (key, {k: [self._tails_pack(kernel_of[k])(w.contiguous()) for w in ws] for k, ws in groups.items()})
         return self._tails_cache[1]
 
-    def _tails_pack(self):
-        """The packer of the tails' weight matrices for ``tails_dtype``: fp32 fragments, bf16 fragments (activations as hi + lo bf16
-        pairs) or IEEE-half fragments (precision "f16": one fp16 activation term, csrc/dec_chain.hip)."""
+    def _tails_pack(self, kernel="heads"):
+        """The packer of the weight matrices of the tail launch ``kernel`` ("post_cross", "post_self", "heads") for ``tails_dtype``: fp32
+        fragments, bf16 fragments (activations as hi + lo bf16 pairs; the weights too where ``tails_hl`` names the launch) or IEEE-half
+        fragments (precision "f16": one fp16 activation term, csrc/dec_chain.hip)."""
+        hl = self.tails_hl is True or (isinstance(self.tails_hl, (tuple, list, set, frozenset)) and kernel in self.tails_hl)
         try:
-            return {"f32": ops.dec_pack_weight, "bf16": ops.dec_pack_weight_bf16, "f16": ops.dec_pack_weight_f16}[self.tails_dtype]
+            return {"f32": ops.dec_pack_weight, "bf16": ops.dec_pack_weight_bf16x2 if hl else ops.dec_pack_weight_bf16,
+                    "f16": ops.dec_pack_weight_f16}[self.tails_dtype]
         except KeyError:
             raise ValueError("tails_dtype must be 'f32', 'bf16' or 'f16'") from None
 
@@ -475,7 +486,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         l3 = self.mask_embed.layers[-1]
         params = (l3.weight, l3.bias, fm.weight) + ((fm.bias,) if fm.bias is not None else ())
         pack = self._tails_pack()
-        key = (self.tails_dtype,) + tuple((p.data_ptr(), p._version) for p in params)
+        key = (self.tails_dtype, str(self.tails_hl)) + tuple((p.data_ptr(), p._version) for p in params)
         if self._fold_cache is None or self._fold_cache[0] != key:
             wm = fm.weight.detach().double().reshape(fm.weight.shape[0], -1)             # (mask_dim, 64)
             bm = fm.bias.detach().double() if fm.bias is not None else torch.zeros(wm.shape[0], dtype=torch.float64, device=wm.device)
@@ -587,7 +598,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                 if want_sizes and L > 0:
                     # (the pooling launch also clears the row flags of prediction 0's attention-mask step)
                     # (... and, for the fused heads + mask launches, of every later prediction's: one (L + 1, B, Q) buffer)
-                    fuse_masks = bool(self.fused_head_masks) and self.tails_dtype in ("bf16", "f16") and not full
+                    fuse_masks = bool(self.fused_head_masks) and (self.tails_dtype == "f16" or (self.tails_dtype == "bf16" and not self.tails_hl)) and not full
                     Bq, Qn = int(out.shape[0]), int(out.shape[1])
                     outs, flags = ops.pool_mask_taps(mask_features, want_sizes, zero_rows=Qn * (L + 1 if fuse_masks else 1))
                     ra_all = flags.view(-1)[:Bq * Qn * (L + 1 if fuse_masks else 1)].view(-1, Bq, Qn)
@@ -673,7 +684,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             # e0 with this pass's pooled activation)
             if getattr(self, "_heads0_params", None) is None:
                 self._heads0_params = TensorList(self.parameters)
-            hkey = (tuple(out.shape), str(out.device), self.tails_dtype) + version_key(self._heads0_params()) + version_key(fm_params)
+            hkey = (tuple(out.shape), str(out.device), self.tails_dtype, str(self.tails_hl)) + version_key(self._heads0_params()) + version_key(fm_params)
             hc = getattr(self, "_heads0_cache", None)
             if hc is None or hc[0] != hkey:
                 _, d, e, q, _ = ops.dec_heads(out, dn.weight, dn.bias, mlp, want_out=False, want_d=False, zero_row_any=True, **next_query(0))

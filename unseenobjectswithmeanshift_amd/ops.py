@@ -787,6 +787,19 @@ def dec_pack_weight_bf16(w):
     return packed
 
 
+def dec_pack_weight_bf16x2(w):
+    """(N, K) fp32 Linear weight -> hi + lo bf16 fragments [bf16(W) | bf16(W - bf16(W))] (msm_dec_pack_weight_bf16x2; dtype
+    torch.bfloat16, shape (N, 2 K), NOT row-major): what the "bf16" plan's tails multiply by since round 6 -- the dec_* wrappers pick the
+    _bf16x2 entry points by the mark this function leaves on the tensor."""
+    _c(w, "w")
+    N, K = w.shape
+    packed = torch.empty((N, 2 * K), device=w.device, dtype=torch.bfloat16)
+    rc = lib().msm_dec_pack_weight_bf16x2(_p(w), _p(packed), N, K, _stream())
+    check(rc, "msm_dec_pack_weight_bf16x2")
+    packed._msm_x2 = True
+    return packed
+
+
 def dec_pack_weight_f16(w):
     """(N, K) fp32 Linear weight -> IEEE half in the fragment order of the 16-bit dec_* kernels (msm_dec_pack_weight_f16; dtype
     torch.float16, shape (N, K), NOT row-major): precision "f16" -- the dec_* wrappers pick the _f16 entry points by this dtype."""
@@ -809,6 +822,15 @@ def _wdtype(*ws):
     return next(iter(dts))
 
 
+def _dec_suffix(*ws):
+    """Entry-point suffix for the packed weights of a dec_* call: by dtype, and "_bf16x2" for hi + lo bf16 fragments (all or none)."""
+    wd = _wdtype(*ws)
+    x2 = {bool(getattr(w, "_msm_x2", False)) for w in ws if w is not None}
+    if len(x2) != 1:
+        raise RuntimeError("packed weights must be all hi + lo bf16 fragments (dec_pack_weight_bf16x2) or none")
+    return "_bf16x2" if x2.pop() else _DEC_SUFFIX[wd]
+
+
 def dec_post_cross(attn_out, res, query_pos, wo, bo, ln_g, ln_b, w_in, b_in, eps=1e-5):
     """Weight matrices of the three dec_* calls are dec_pack_weight() outputs.
     x = LN(res + attn_out wo^T + bo); qk = (x + query_pos) w_in[:2E]^T + b_in[:2E]; v = x w_in[2E:]^T + b_in[2E:].
@@ -821,7 +843,7 @@ def dec_post_cross(attn_out, res, query_pos, wo, bo, ln_g, ln_b, w_in, b_in, eps
     x = torch.empty_like(attn_out)
     qk = torch.empty((B, Q, 2 * E), device=attn_out.device, dtype=torch.float32)
     v = torch.empty_like(attn_out)
-    fn = getattr(lib(), "msm_dec_post_cross" + _DEC_SUFFIX[wd])
+    fn = getattr(lib(), "msm_dec_post_cross" + _dec_suffix(wo, w_in))
     rc = fn(_p(attn_out), _p(res), _p(query_pos), _p(wo), _p(bo), _p(ln_g), _p(ln_b), _p(w_in), _p(b_in), _p(x), _p(qk), _p(v), B * Q, Q, E,
             eps, _stream())
     check(rc, "msm_dec_post_cross")
@@ -843,7 +865,7 @@ def dec_post_self(attn_out, res, wo, bo, ln_g, ln_b, w1, b1, w2, n_parts=None, e
         tiles = (B * Q + 15) // 16
         n_parts = max(d for d in range(1, chunks + 1) if chunks % d == 0 and (d == 1 or tiles * d <= 256))
     parts = torch.empty((n_parts, B, Q, E), device=attn_out.device, dtype=torch.float32)
-    fn = getattr(lib(), "msm_dec_post_self" + _DEC_SUFFIX[wd])
+    fn = getattr(lib(), "msm_dec_post_self" + _dec_suffix(wo, w1, w2))
     rc = fn(_p(attn_out), _p(res), _p(wo), _p(bo), _p(ln_g), _p(ln_b), _p(w1), _p(b1), _p(w2), F, _p(x), _p(parts), n_parts, B * Q, E, eps,
             _stream())
     check(rc, "msm_dec_post_self")
@@ -868,7 +890,7 @@ def dec_heads(x, dec_g, dec_b, mlp, *, parts=None, bias=None, ln_g=None, ln_b=No
     ra = torch.empty((B, Q), device=x.device, dtype=torch.int32) if zero_row_any else None
     n_parts = 0 if parts is None else parts.shape[0]
     (m0w, m0b), (m1w, m1b), (m2w, m2b) = mlp
-    fn = getattr(lib(), "msm_dec_heads" + _DEC_SUFFIX[wd])
+    fn = getattr(lib(), "msm_dec_heads" + _dec_suffix(wq, *[w for w, _ in mlp]))
     rc = fn(_p(x), _p(parts), n_parts, _p(bias), _p(ln_g), _p(ln_b), 1 if l2norm else 0, _p(dec_g), _p(dec_b), _p(m0w), _p(m0b), _p(m1w),
             _p(m1b), _p(m2w), _p(m2b), _p(wq), _p(bq), _p(query_pos), _p(out), _p(d), _p(e), _p(q), _p(ra), B * Q, Q, E, eps, _stream())
     check(rc, "msm_dec_heads")
@@ -882,8 +904,8 @@ def dec_heads_mask(x, dec_g, dec_b, mlp, pooled, row_any, *, qcol=64, bits=False
     row_any=row_any, bits=bits, f16=f16), bit for bit, in one launch.  ``mlp[-1]`` must be the folded final layer ([e Wm | e.bm | ..]);
     ``row_any`` (B, Q) int32 must arrive ZEROED.  Returns (out|None, d|None, e, q|None, attn, row_any)."""
     wd = _wdtype(wq, *[w for w, _ in mlp])
-    if wd not in (torch.bfloat16, torch.float16):
-        raise RuntimeError("dec_heads_mask needs bf16 or fp16 weight fragments (the fp32 plan keeps the two launches)")
+    if wd not in (torch.bfloat16, torch.float16) or _dec_suffix(wq, *[w for w, _ in mlp]) == "_bf16x2":
+        raise RuntimeError("dec_heads_mask needs single bf16 or fp16 weight fragments (the fp32 plan and the hi + lo bf16 form keep the two launches)")
     for i, t in enumerate([x, parts, bias, ln_g, ln_b, dec_g, dec_b, bq, query_pos, pooled] + [b for _, b in mlp]):
         _c(t, f"dec_heads_mask arg {i}")
     for i, t in enumerate([wq] + [w for w, _ in mlp]):
