@@ -74,7 +74,7 @@ enum {
     MSM_OPT_ATTN_TARGET,        /* workgroup target of the split-K attention kernel */
     MSM_OPT_ATTN_KERNEL,        /* 3: split-K kernel + combine for every length (fallback of the query-split kernel) */
     MSM_OPT_ATTN_QK_MAX,        /* longest sequence the key-split kernel takes */
-    MSM_OPT_ATTN_QKCFG,         /* 0 / 1: two / one query blocks per workgroup in the key-split kernel */
+    MSM_OPT_ATTN_QKCFG,         /* 0 / 1 / 2: two / one / four (four waves) query blocks per workgroup in the key-split kernel */
     MSM_OPT_CONVIN_NT,          /* 1, 2, 4: pixel tiles per workgroup of the input projection */
     MSM_OPT_POST_GENERIC,       /* 1: generic mask upsample instead of the 4x form */
     MSM_OPT_ENC_NO_COOP,        /* 1: encoder block without cooperative workgroups */

@@ -298,6 +298,11 @@ def test_hypersphere_attention(B, Lq, S, masked):
     with option("ATTN_KERNEL", 3):
         alt = ops().hypersphere_attention(*args, **kw)
     close(alt, ref, rtol=1e-4, atol=2e-5)
+    # every workgroup shape of the key-split kernel (two / one / four query blocks per workgroup; four is what batches of >= 48 images take)
+    if S <= 2048:
+        for cfg in (0, 1, 2):
+            with option("ATTN_QKCFG", cfg):
+                close(ops().hypersphere_attention(*args, **kw), ref, rtol=1e-4, atol=2e-5)
 
 
 @pytest.mark.parametrize("kv_bf16", [False, True, "f16keys", "f16scores"])

@@ -1002,7 +1002,9 @@ static int attn_launch(const char* who, const float* q, const KVT* k, const KVT*
         const int cfg_env = opt(MSM_OPT_ATTN_QKCFG);
         // one query block per workgroup for the shortest sequences (self-attention, 100 keys: 6.9 against 8.0 us), two
         // otherwise (K/V are read by half as many workgroups); other shapes measured slower at every length
-        const int cfg = cfg_env >= 0 ? cfg_env : (S <= 128 ? 1 : 0);
+        // many images (the second stage of the two-stage harness: 170 crops of 224x224, 49 / 196 / 784 keys): thousands of workgroups of a few
+        // key blocks each are all launch and reduction -- four query blocks per workgroup of four waves there (cfg 2)
+        const int cfg = cfg_env >= 0 ? cfg_env : (B >= 48 && S <= 1024 ? 2 : (S <= 128 ? 1 : 0));
 #define QK_LAUNCH_M(MQ_, NW_, MM_)                                                                                              \
     {                                                                                                                           \
         dim3 grid(heads, B, cdiv(cdiv(Lq, 16), MQ_));                                                                           \
@@ -1019,6 +1021,7 @@ static int attn_launch(const char* who, const float* q, const KVT* k, const KVT*
     }
         switch (cfg) {
             case 1: QK_LAUNCH(1, 8) break;
+            case 2: QK_LAUNCH(4, 4) break;
             default: QK_LAUNCH(2, 8) break;
         }
 #undef QK_LAUNCH

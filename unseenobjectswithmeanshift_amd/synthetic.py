@@ -295,9 +295,10 @@ class StandInBackbone(torch.nn.Module):
         p, prev = x, 1
         for name, s, w in zip(("res2", "res3", "res4", "res5"), (4, 8, 16, 32), self.mix):
             # the pyramid level by pooling the previous level (the full-resolution input is read once, not four times) and the 1x1
-            # mixing as one batched matmul that writes NCHW directly (an einsum leaves a permuted result that .contiguous() copies)
+            # mixing as ONE bmm whose (B, C, HW) result IS the NCHW tensor (einsum / broadcasting matmul compute the transposed product
+            # and copy it: 27 copy launches of 83 us per two-stage batch under rocprofv3)
             p = torch.nn.functional.avg_pool2d(p, s // prev)
             prev = s
             b, c, h, ww = p.shape
-            out[name] = torch.matmul(w, p.reshape(b, c, h * ww)).relu_().view(b, -1, h, ww)
+            out[name] = torch.bmm(w.unsqueeze(0).expand(b, -1, -1), p.reshape(b, c, h * ww)).relu_().view(b, -1, h, ww)
         return out
