@@ -1144,6 +1144,7 @@ def test_fused_head_masks_equal_two_launches(precision):
     feats = {k: v.to(DEV) for k, v in syn.synth_backbone_features(8, 480, 640, seed=10).items()}
     assert not head.predictor.fused_head_masks               # opt-in: not faster (modeling.py)
     head.predictor.fused_head_masks = True
+    head.predictor.tails_hl = False                          # (the epilogue form exists for single weight fragments: the bf16 plan's hi + lo heads keep two launches)
     calls = []
     orig = ops.dec_heads_mask
     ops.dec_heads_mask = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
@@ -1192,3 +1193,54 @@ def test_weight_prefetch_rows_change_nothing(precision):
     assert torch.equal(c["pred_masks"], b["pred_masks"])
     with pytest.raises(RuntimeError, match="contiguous device"):
         ops.dec_set_prefetch([torch.zeros(4)])
+
+
+def test_batched_two_stage_edge_cases():
+    """two_stage.BatchedTwoStage beyond configs[3]'s shape: a small batch of small frames without depth (the paste order falls back to
+    the ROI areas, the second-stage graph takes no depth crops), a threshold that keeps no instance (no ROI: refined is all zero, no
+    second stage), a plan switch between two calls (the graphs re-capture), and without graphs (graphs=False: the same phases eager) --
+    always the eager batch's results."""
+    from unseenobjectswithmeanshift_amd import two_stage as ts
+    from unseenobjectswithmeanshift_amd.meta_arch import MeanShiftMaskFormer, build_resnet50_head
+    head = build_resnet50_head(num_queries=100, dec_layers=3)
+    head.pixel_decoder.load_state_dict(syn.synth_state_dict(syn.pixel_decoder_param_shapes()), strict=True)
+    head.predictor.load_state_dict(syn.synth_state_dict(syn.decoder_param_shapes(dec_layers=3)), strict=True)
+    model = MeanShiftMaskFormer(backbone=syn.StandInBackbone().to(DEV).eval(), sem_seg_head=head.to(DEV).eval(), num_queries=100)
+
+    class Pred:
+        def batch_tensors(self, samples):
+            imgs = torch.stack([x["image"] for x in samples])
+            inputs = {"image": imgs}
+            if samples[0]["depth"] is not None:
+                inputs["depth"] = torch.stack([x["depth"] for x in samples])
+            with torch.no_grad():
+                return model.inference_images(inputs, tuple(int(v) for v in imgs.shape[-2:]))[:3]
+
+    gen = torch.Generator().manual_seed(5)
+    H, W = 192, 256
+    samples = [{"image_color": torch.rand(3, H, W, generator=gen).to(DEV), "depth": torch.rand(3, H, W, generator=gen).to(DEV)} for _ in range(3)]
+    kw = dict(topk=False, confident_score=0.0)
+    for use_depth in (False, True):
+        for graphs in (True, False):
+            e_label, e_refined, e_rows = ts.test_batch_crop_nolabel(samples, Pred(), Pred(), use_depth=use_depth, **kw)
+            pipe = ts.BatchedTwoStage(model, 3, (H, W), use_depth=use_depth, graphs=graphs, **kw)
+            for rnd_ in range(2):
+                label, refined, rows = pipe(samples)
+                assert torch.equal(label, e_label) and rows == e_rows and len(rows) > 0
+                assert float((refined != e_refined).float().mean()) < 2e-3        # the padded crop batch is another batch size (summation orders)
+            res = pipe.run([samples, samples])
+            assert torch.equal(res[0][0], e_label) and torch.equal(res[1][1], res[0][1])
+    # nothing kept: no ROI, no second stage
+    pipe = ts.BatchedTwoStage(model, 3, (H, W), topk=False, confident_score=2.0)
+    label, refined, rows = pipe(samples)
+    assert rows == [] and float(label.abs().max()) == 0.0 and float(refined.abs().max()) == 0.0
+    # a plan switch between two calls re-captures
+    pipe = ts.BatchedTwoStage(model, 3, (H, W), **kw)
+    a = pipe(samples)[1].clone()
+    model.set_precision("f16")
+    b16 = pipe(samples)[1].clone()
+    model.set_precision("f32")
+    c = pipe(samples)[1]
+    assert torch.equal(a, c) and not torch.equal(a, b16)
+    with pytest.raises(ValueError, match="built for 3 frames"):
+        pipe(samples[:2])

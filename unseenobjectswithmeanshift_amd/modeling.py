@@ -467,11 +467,15 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             self._tails_cache = (key, {k: [self._tails_pack(kernel_of[k])(w.contiguous()) for w in ws] for k, ws in groups.items()})
         return self._tails_cache[1]
 
+    def _tails_hl_for(self, kernel):
+        """Whether the tail launch ``kernel`` multiplies by hi + lo bf16 weight fragments (``tails_hl``; the bf16 plan only)."""
+        return self.tails_dtype == "bf16" and (self.tails_hl is True or (isinstance(self.tails_hl, (tuple, list, set, frozenset)) and kernel in self.tails_hl))
+
     def _tails_pack(self, kernel="heads"):
         """The packer of the weight matrices of the tail launch ``kernel`` ("post_cross", "post_self", "heads") for ``tails_dtype``: fp32
         fragments, bf16 fragments (activations as hi + lo bf16 pairs; the weights too where ``tails_hl`` names the launch) or IEEE-half
         fragments (precision "f16": one fp16 activation term, csrc/dec_chain.hip)."""
-        hl = self.tails_hl is True or (isinstance(self.tails_hl, (tuple, list, set, frozenset)) and kernel in self.tails_hl)
+        hl = self._tails_hl_for(kernel)
         try:
             return {"f32": ops.dec_pack_weight, "bf16": ops.dec_pack_weight_bf16x2 if hl else ops.dec_pack_weight_bf16,
                     "f16": ops.dec_pack_weight_f16}[self.tails_dtype]
@@ -598,7 +602,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                 if want_sizes and L > 0:
                     # (the pooling launch also clears the row flags of prediction 0's attention-mask step)
                     # (... and, for the fused heads + mask launches, of every later prediction's: one (L + 1, B, Q) buffer)
-                    fuse_masks = bool(self.fused_head_masks) and (self.tails_dtype == "f16" or (self.tails_dtype == "bf16" and not self.tails_hl)) and not full
+                    fuse_masks = bool(self.fused_head_masks) and self.tails_dtype in ("bf16", "f16") and not self._tails_hl_for("heads") and not full
                     Bq, Qn = int(out.shape[0]), int(out.shape[1])
                     outs, flags = ops.pool_mask_taps(mask_features, want_sizes, zero_rows=Qn * (L + 1 if fuse_masks else 1))
                     ra_all = flags.view(-1)[:Bq * Qn * (L + 1 if fuse_masks else 1)].view(-1, Bq, Qn)
