@@ -541,6 +541,25 @@ def g_head_cfg5_l20():
     save("head_cfg5_960x1280_l20", **arrs)
 
 
+def g_head_cfg5_l20_frames():
+    """The other three frames of the batch of FOUR that bench.py times for configs[4] (input seeds 19, 29, 39; frame 0 = seed 9 is
+    head_cfg5_960x1280_l20): 1280x960, 300 queries, 20 decoder layers, through the reference pixel decoder -> decoder in float32, one frame
+    at a time.  Stored per frame: class logits, 16 384 sampled final-mask values, packed sign bits and near-zero bits of every 6th query."""
+    pd = build_ref_pixel_decoder()
+    dec = build_ref_decoder(dec_layers=20, num_queries=300)
+    qs = torch.arange(0, 300, 6)
+    arrs = {"queries": qs, "seeds": torch.tensor([19, 29, 39])}
+    for seed in (19, 29, 39):
+        feats = syn.synth_backbone_features(1, 960, 1280, seed=seed)
+        out = _head_outputs(pd, dec, feats)
+        pm = out["pred_masks"][0]
+        idx = sample_idx(pm.numel(), k=16384)
+        arrs.update({f"s{seed}_pred_logits": out["pred_logits"], f"s{seed}_mask_sample_idx": idx, f"s{seed}_mask_sample_val": pm.flatten()[idx],
+                     f"s{seed}_sign_bits": packbits(pm[qs] > 0), f"s{seed}_near_zero": packbits(pm[qs].abs() < 2e-4),
+                     f"s{seed}_mask_absmax": pm.abs().max(), f"s{seed}_positive_fraction": (pm > 0).float().mean()})
+    save("head_cfg5_960x1280_l20_frames", **arrs)
+
+
 def g_ucn_full():
     """UCN / RGB-D configuration at full size: SimpleBasePixelDecoder + PretrainedMeanShiftTransformerDecoder over the
     480x640 embedding map -- 307 200 keys per image, attention mask at mask resolution, 6 layers, batch 1."""
@@ -734,10 +753,10 @@ def g_checkpoint_keys():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pe", "attn", "decoder", "msda", "msda_bwd", "pixel", "ms", "harness", "ucn", "ucn_backbone", "inst", "head_b8", "head_cfg5", "ucn_full", "dec_bwd", "ckpt_keys", "head_b8_seeds", "head_cfg5_l20"]
+    which = sys.argv[1:] or ["pe", "attn", "decoder", "msda", "msda_bwd", "pixel", "ms", "harness", "ucn", "ucn_backbone", "inst", "head_b8", "head_cfg5", "ucn_full", "dec_bwd", "ckpt_keys", "head_b8_seeds", "head_cfg5_l20", "head_cfg5_l20_frames"]
     fns = {"pe": g_position_encoding, "attn": g_hypersphere_attention, "decoder": g_decoder,
            "msda": g_msda, "msda_bwd": g_msda_bwd, "pixel": g_pixel_decoder, "ms": g_mean_shift, "harness": g_harness, "ucn": g_ucn, "ucn_backbone": g_ucn_backbone,
            "inst": g_instance_inference, "dec_bwd": g_decoder_backward, "ckpt_keys": g_checkpoint_keys, "head_b8": g_head_b8, "head_cfg5": g_head_cfg5, "ucn_full": g_ucn_full,
-           "head_b8_seeds": g_head_b8_seeds, "head_cfg5_l20": g_head_cfg5_l20}
+           "head_b8_seeds": g_head_b8_seeds, "head_cfg5_l20": g_head_cfg5_l20, "head_cfg5_l20_frames": g_head_cfg5_l20_frames}
     for w in which:
         fns[w]()
