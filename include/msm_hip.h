@@ -77,7 +77,7 @@ enum {
     MSM_OPT_ATTN_QKCFG,         /* 0 / 1 / 2: two / one / four (four waves) query blocks per workgroup in the key-split kernel */
     MSM_OPT_CONVIN_NT,          /* 1, 2, 4: pixel tiles per workgroup of the input projection */
     MSM_OPT_POST_GENERIC,       /* 1: generic mask upsample instead of the 4x form */
-    MSM_OPT_ENC_NO_COOP,        /* 1: encoder block without cooperative workgroups */
+    MSM_OPT_ENC_NO_COOP,        /* 1: fp32 encoder block without cooperative workgroups; 2: msm_encoder_block_hm_fwd as ONE 16-wave workgroup per CU (rounds 4-5; default since round 6: eight waves, two workgroups per CU) */
     MSM_OPT_MSDA_GENERIC,       /* 1: generic head-major MSDeformAttn gather; 2: the D = 8 kernel of round 2 (every lane repeats the tap geometry; fallback of the owner-record kernel); 3: that kernel with 8-query x 8-head workgroups */
     MSM_OPT_MS_CHUNK,           /* 1..8 seed blocks per hill-climb launch */
     MSM_OPT_MS_NO_PERSISTENT,   /* 1: one launch per seeding step */

@@ -1408,6 +1408,15 @@ def test_encoder_block_hm(B, S, want_next):
     e_h, e_b = float((soh.cpu() - y32).abs().mean()), float((so.cpu() - y32).abs().mean())
     print(f"encoder block hm B={B} S={S}: mean |err| against the exact fp32 chain  bf16 FFN {e_b:.2e}  fp16 FFN {e_h:.2e}")
     assert 3 * e_h <= e_b
+    # round 6: the default is the half-size form (enc_block_hm2_kernel: eight waves, 16-KiB stages of the SAME stream, two workgroups per CU);
+    # the one-workgroup form (option ENC_NO_COOP = 2) returns the same bits -- a tile's arithmetic does not depend on the staging
+    from unseenobjectswithmeanshift_amd._lib import option
+    with option("ENC_NO_COOP", 2):
+        so1, vh1, ph1 = ops().encoder_block_hm(attn_hm, d(src), stream, small, DF, pos=d(pos), want_next=want_next)
+        soh1, _, _ = ops().encoder_block_hm(attn_hm, d(src), stream_h, small, DF, pos=d(pos), want_next=want_next, ffn_f16=True)
+    assert torch.equal(so1, so) and torch.equal(soh1, soh)
+    if want_next:
+        assert torch.equal(vh1, vh) and torch.equal(ph1.view(torch.int32), ph.view(torch.int32))
     with pytest.raises(RuntimeError):
         ops().encoder_block_hm(attn_hm.float(), d(src), stream, small, DF, pos=d(pos), want_next=want_next)
     with pytest.raises(RuntimeError):

@@ -15,9 +15,13 @@ import unseenobjectswithmeanshift_amd  # noqa: E402
 from unseenobjectswithmeanshift_amd import synthetic as syn  # noqa: E402
 
 dev = torch.device("cuda", 0)
+if os.environ.get("MSM_OPTION"):                      # e.g. MSM_OPTION=ENC_NO_COOP=2
+    from unseenobjectswithmeanshift_amd import _lib
+    name, val = os.environ["MSM_OPTION"].split("=")
+    _lib.set_option(name, int(val))
 model = bench.build_model(dev)
 feats = {k: v.to(dev) for k, v in syn.synth_backbone_features(8, 480, 640, seed=10).items()}
-model.set_precision("f16")
+model.set_precision(os.environ.get("MSM_PRECISION", "f16"))
 step = lambda: model.inference(feats, (480, 640))
 step()
 out = [os.path.dirname(unseenobjectswithmeanshift_amd.__file__).replace(ROOT, ".")]

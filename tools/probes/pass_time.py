@@ -18,9 +18,13 @@ from unseenobjectswithmeanshift_amd import synthetic as syn  # noqa: E402
 from unseenobjectswithmeanshift_amd.graphs import PipelinedInference  # noqa: E402
 
 dev = torch.device("cuda", 0)
+if os.environ.get("MSM_OPTION"):                      # e.g. MSM_OPTION=ENC_NO_COOP=2
+    from unseenobjectswithmeanshift_amd import _lib
+    name, val = os.environ["MSM_OPTION"].split("=")
+    _lib.set_option(name, int(val))
 model = bench.build_model(dev)
 feats = {k: v.to(dev) for k, v in syn.synth_backbone_features(8, 480, 640, seed=10).items()}
-out = [os.path.dirname(unseenobjectswithmeanshift_amd.__file__).replace(ROOT, ".")]
+out = [os.path.dirname(unseenobjectswithmeanshift_amd.__file__).replace(ROOT, ".") + " " + os.environ.get("MSM_OPTION", "")]
 for mode in os.environ.get("MSM_MODES", "f16,bf16,f32").split(","):
     model.set_precision(mode)
     if os.environ.get("MSM_TAILS_HL") and hasattr(model.sem_seg_head.predictor, "tails_hl"):

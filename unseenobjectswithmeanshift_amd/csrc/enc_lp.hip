@@ -17,7 +17,8 @@
 //   msda_enc_lp_kernel    softmax + sampling locations from the stored projection (or the projection itself, FUSED) + bilinear
 //                         gather of bf16 value taps
 //
-// enc_block_hm_kernel: ONE 16-wave workgroup per CU, a 16-token tile per wave, all waves share the weight stream: an FFN stage is
+// enc_block_hm_kernel (rounds 4-5; since round 6 the default is its half-size form enc_block_hm2_kernel below, same stream, same bits):
+// ONE 16-wave workgroup per CU, a 16-token tile per wave, all waves share the weight stream: an FFN stage is
 // 32 KiB (four pairs of 16-wide hidden blocks: W1 2 x 2 KiB, W2 4 KiB each) = two 1-KiB LDS-DMA pieces per wave, three stage
 // buffers, a stage is requested two stages ahead; output_proj and value_proj (hi + lo copies, 32 KiB) stay resident.  What
 // the round-3 kernel (enc_block_split.hip, MODE 1: 4-wave workgroups, 2 per CU, six pieces per wave and stage, 16 stages)
@@ -408,6 +409,265 @@ __global__ __launch_bounds__(EH_WAVES * 64) void enc_block_hm_kernel(const unsig
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (t + 1 < EH_PROJ_STAGES) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+}
+
+// ---- the same layer tail with HALF the workgroup (round 6): two workgroups per CU --------------------------------------------------
+// enc_block_hm_kernel is one 1024-thread workgroup per CU with 133 KB of LDS: its 256 workgroups march in lock step -- matrix pipe busy a
+// quarter of the time, then 67 MB of stores in one burst -- and no second launch (another batch in flight) can share a CU with it.  This
+// form reads the SAME weight stream in 16-KiB stages (two pairs of hidden blocks; four projection row blocks) with eight waves: resident
+// block = output_proj only (16 KiB; the value projection becomes a stage of its own between the FFN and the sampling projection), ring of
+// three stages, 71 KB of LDS per workgroup -- two workgroups per CU, each on its own schedule (and either may belong to another batch).
+// Per wave and stage two 1-KiB DMA pieces, as before.  Stage sequence: FFN 0 .. nf-1 (nf = d_ffn / 64), [value, projection 0 .. 4].
+constexpr int E2_WAVES = 8;
+constexpr int E2_STAGE = 16 * 1024;
+constexpr int E2_RES = 16 * 1024;
+constexpr int E2_PROJ_STAGES = 5;              // 18 row blocks, four per stage
+
+template <bool F16>
+__global__ __launch_bounds__(E2_WAVES * 64, 4) void enc_block_hm2_kernel(const unsigned short* __restrict__ attn_hm, const float* __restrict__ src,
+                                                                        const char* __restrict__ wstream, const float* __restrict__ small,
+                                                                        const float* __restrict__ pos, float* __restrict__ src_out,
+                                                                        unsigned short* __restrict__ value_out, unsigned short* __restrict__ proj_out, int M,
+                                                                        int S, int nf, float eps, int tpw) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];      // [output_proj 16 KiB][3 stages x 16 KiB][small]
+    char* const res = lds;
+    char* const ring = lds + E2_RES;
+    float* const sm = reinterpret_cast<float*>(lds + E2_RES + EH_NBUF * E2_STAGE);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    const int n_small = EH_B1 + 64 * nf;
+    const bool next = value_out != nullptr;                          // (uniform) not the last layer
+    const int nstages = nf + (next ? 1 + E2_PROJ_STAGES : 0);
+    for (int i = tid; i < n_small; i += E2_WAVES * 64) sm[i] = small[i];
+
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    const void* ws = uniform_ptr_lp(wstream);
+    // byte offset of stage j in the stream of pack_encoder_block_hm: [output_proj 16K | value_proj 16K | FFN nf x 16K | projection 96K]
+    auto stage_off = [&](int j) -> int64_t {
+        if (j < nf) return 2 * (int64_t)E2_STAGE + (int64_t)j * E2_STAGE;
+        if (j == nf) return E2_STAGE;                                // the value projection
+        return 2 * (int64_t)E2_STAGE + (int64_t)nf * E2_STAGE + (int64_t)(j - nf - 1) * E2_STAGE;
+    };
+    auto issue_at = [&](int64_t src_off, unsigned dst_off) {         // this wave's two pieces of a 16-KiB block
+        glds16h((const char*)ws + src_off + wave * 2048, (unsigned)lane * 16u, lds_base + dst_off + (unsigned)wave * 2048u);
+        glds16h((const char*)ws + src_off + wave * 2048 + 1024, (unsigned)lane * 16u, lds_base + dst_off + (unsigned)wave * 2048u + 1024u);
+    };
+    auto issue = [&](int j) { issue_at(stage_off(j), E2_RES + (unsigned)(j % EH_NBUF) * E2_STAGE); };
+    issue_at(0, 0);
+    if (nstages > 0) issue(0);
+    if (nstages > 1) issue(1);
+
+    const int tile = blockIdx.x * tpw + wave;
+    const bool active = wave < tpw && tile * 16 < M;                 // wave-uniform
+    const int tok = tile * 16 + lj;
+    const bool tok_ok = active && tok < M;
+    const int tk = tok_ok ? tok : M - 1;
+    const int img = tk / S, tpos = tk - img * S;
+    float x[4][4];
+    bf16x8 xh[2], xl[2];
+    f16x8 xf[2];
+    if (active) {
+        u32x4 ah[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) ah[g] = *reinterpret_cast<const u32x4*>(attn_hm + (((int64_t)img * 8 + 4 * g + lq) * S + tpos) * 8);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const Split4 a = split4(half_lo(ah[g][0]), half_hi(ah[g][0]), half_lo(ah[g][1]), half_hi(ah[g][1]));
+            const Split4 b = split4(half_lo(ah[g][2]), half_hi(ah[g][2]), half_lo(ah[g][3]), half_hi(ah[g][3]));
+            xh[g] = cat8(a.hi, b.hi);
+            xl[g] = cat8(a.lo, b.lo);
+        }
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb) {
+            const float4 r = *reinterpret_cast<const float4*>(src + (int64_t)tk * EH_C + fb * 16 + lq * 4);
+            x[fb][0] = r.x; x[fb][1] = r.y; x[fb][2] = r.z; x[fb][3] = r.w;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- output_proj + residual + LayerNorm1 (msdeformattn.py:124-126): w(h + l) x(h + l) without l x l ----
+    if (active) {
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            const float4 b = *reinterpret_cast<const float4*>(sm + EH_BO + ob * 16 + lq * 4);
+            f32x4 d = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const char* blk = res + ((ob * 2 + g) * 2) * 1024;
+                const bf16x8 wh = ldfrag(blk, lane), wl = ldfrag(blk + 1024, lane);
+                d = mfma_bf16k32(wl, xh[g], d);
+                d = mfma_bf16k32(wh, xl[g], d);
+                d = mfma_bf16k32(wh, xh[g], d);
+            }
+            x[ob][0] += d[0]; x[ob][1] += d[1]; x[ob][2] += d[2]; x[ob][3] += d[3];
+        }
+        layer_norm_h(x, sm + EH_G1, sm + EH_BE1, lq, eps);
+        if constexpr (F16) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                xf[g] = cvt8h(x[2 * g][0], x[2 * g][1], x[2 * g][2], x[2 * g][3], x[2 * g + 1][0], x[2 * g + 1][1], x[2 * g + 1][2], x[2 * g + 1][3]);
+        } else {
+            split_L(x, xh, xl);
+        }
+    }
+    // ---- FFN: two pairs of 16-wide hidden blocks per stage; the hidden activation never leaves registers ----
+    f32x4 acc[4];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) acc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float pq[4][4];
+    for (int s = 0; s < nf; ++s) {
+        const bool more = s + 2 < nstages;
+        // the next layer's query is src_out + pos: an ordinary load beside LDS-DMA in flight, issued ahead of the last FFN stage's pieces
+        // and used before the next pieces are requested (see enc_block_hm_kernel)
+        if (next && active && s == nf - 1) {
+#pragma unroll
+            for (int fb = 0; fb < 4; ++fb) {
+                const float4 r = *reinterpret_cast<const float4*>(pos + (int64_t)tpos * EH_C + fb * 16 + lq * 4);
+                pq[fb][0] = r.x; pq[fb][1] = r.y; pq[fb][2] = r.z; pq[fb][3] = r.w;
+            }
+        }
+        if (more) issue(s + 2);                                      // its buffer was read in stage s - 1: every wave is past that stage's barrier
+        if (active) {
+            const char* buf = ring + (s % EH_NBUF) * E2_STAGE;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const char* pb = buf + p * 8192;
+                f32x4 hh[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float4 b = *reinterpret_cast<const float4*>(sm + EH_B1 + ((s * 2 + p) * 2 + q) * 16 + lq * 4);
+                    hh[q] = f32x4{b.x, b.y, b.z, b.w};
+                }
+                bf16x8 w1[2][2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) w1[q][g] = ldfrag(pb + (q * 2 + g) * 1024, lane);
+                if constexpr (F16) {
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) hh[q] = mfma_f16k32(__builtin_bit_cast(f16x8, w1[q][g]), xf[g], hh[q]);
+                    const f16x8 hb = {(_Float16)relu_h(hh[0][0]), (_Float16)relu_h(hh[0][1]), (_Float16)relu_h(hh[0][2]), (_Float16)relu_h(hh[0][3]),
+                                      (_Float16)relu_h(hh[1][0]), (_Float16)relu_h(hh[1][1]), (_Float16)relu_h(hh[1][2]), (_Float16)relu_h(hh[1][3])};
+#pragma unroll
+                    for (int ob = 0; ob < 4; ++ob)
+                        acc[ob] = mfma_f16k32(__builtin_bit_cast(f16x8, ldfrag(pb + 4096 + ob * 1024, lane)), hb, acc[ob]);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) hh[q] = mfma_bf16k32(w1[q][g], xl[g], hh[q]);
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) hh[q] = mfma_bf16k32(w1[q][g], xh[g], hh[q]);
+                    const bf16x8 hb = cat8(pack4(relu1h(hh[0][0]), relu1h(hh[0][1]), relu1h(hh[0][2]), relu1h(hh[0][3])),
+                                           pack4(relu1h(hh[1][0]), relu1h(hh[1][1]), relu1h(hh[1][2]), relu1h(hh[1][3])));
+#pragma unroll
+                    for (int ob = 0; ob < 4; ++ob) acc[ob] = mfma_bf16k32(ldfrag(pb + 4096 + ob * 1024, lane), hb, acc[ob]);
+                }
+            }
+        }
+        // stage s + 1 (requested at the start of stage s - 1) must have landed: everything but this stage's own two pieces
+        if (more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (s + 1 < nstages) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    if (active) finish_ffn(x, acc, sm, lq, eps);                     // residual + LayerNorm2: the layer output
+    if (!next) {
+        if (active) store_src(src_out, x, tok, tok_ok, lq);
+        return;
+    }
+    if (active) {
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pq[fb][r] += x[fb][r];
+    }
+#pragma unroll
+    for (int fb = 0; fb < 4; ++fb) asm volatile("" : "+v"(pq[fb][0]));   // (the four pos loads are waited for here, ahead of the next request)
+    // ---- stage nf: the next layer's value_proj, w(h + l) x(h + l) without l x l; 4 + 2 stores ----
+    issue(nf + 2);
+    if (active) {
+        store_src(src_out, x, tok, tok_ok, lq);
+        split_L(x, xh, xl);
+        const char* vb = ring + (nf % EH_NBUF) * E2_STAGE;
+        f32x4 d[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            const float4 b = *reinterpret_cast<const float4*>(sm + EH_BV + rb * 16 + lq * 4);
+            d[rb] = f32x4{b.x, b.y, b.z, b.w};
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const char* blk = vb + ((rb * 2 + g) * 2) * 1024;
+                const bf16x8 wh = ldfrag(blk, lane), wl = ldfrag(blk + 1024, lane);
+                d[rb] = mfma_bf16k32(wl, xh[g], d[rb]);
+                d[rb] = mfma_bf16k32(wh, xl[g], d[rb]);
+                d[rb] = mfma_bf16k32(wh, xh[g], d[rb]);
+            }
+        if (tok_ok) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                *reinterpret_cast<u32x4*>(value_out + (((int64_t)img * 8 + 4 * j + lq) * S + tpos) * 8) = pack8h(d[2 * j], d[2 * j + 1]);
+        }
+        split_L(pq, xh, xl);                                         // the query operand of the projection stages
+    }
+    // stage nf + 1 (requested before the last FFN stage) must have landed: everything but this stage's two pieces and its 4 + 2 stores
+    if (active) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // ---- stages nf + 1 + t: [sampling_offsets | attention_weights](src_out + pos), four row blocks per stage, one store each ----
+#pragma unroll 1
+    for (int t = 0; t < E2_PROJ_STAGES; ++t) {
+        const int j = nf + 1 + t;
+        const bool more = j + 2 < nstages;
+        if (more) issue(j + 2);
+        const char* buf = ring + (j % EH_NBUF) * E2_STAGE;
+        if (active) {
+#pragma unroll 2
+            for (int i = 0; i < 4; ++i) {
+                const int rb = t * 4 + i;
+                if (rb < EH_PROJ / 16) {                              // (uniform)
+                    const float4 b = *reinterpret_cast<const float4*>(sm + EH_BP + rb * 16 + lq * 4);
+                    f32x4 d = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const char* blk = buf + ((i * 2 + g) * 2) * 1024;
+                        const bf16x8 wh = ldfrag(blk, lane), wl = ldfrag(blk + 1024, lane);
+                        d = mfma_bf16k32(wl, xh[g], d);
+                        d = mfma_bf16k32(wh, xl[g], d);
+                        d = mfma_bf16k32(wh, xh[g], d);
+                    }
+                    if (tok_ok) store_proj_rb(reinterpret_cast<unsigned char*>(proj_out), img, tpos, S, rb, lq, d);
+                }
+            }
+        }
+        // Stage j + 1 must have landed: everything but what this wave issued after requesting it (at the start of stage j - 1): the stores of
+        // stage j - 1 (6 after the value stage, else 4), this stage's two pieces (when requested) and this stage's 4 stores.  (vmcnt counts
+        // stores, in order; a partly valid tile issues every store instruction, exec-masked; waves without a tile issue no stores.)
+        if (t + 1 < E2_PROJ_STAGES) {
+            if (active) {
+                if (t == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else if (more) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                if (more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
@@ -827,6 +1087,27 @@ extern "C" int msm_encoder_block_hm_fwd(const void* attn_hm, const float* src, c
     int tpw = cdiv(tiles, 256);
     if (tpw > EH_WAVES) tpw = EH_WAVES;
     const int grid = cdiv(tiles, tpw);
+    // round 6: the half-size form (two workgroups per CU, see enc_block_hm2_kernel) -- MSM_OPT_ENC_NO_COOP = 2 selects the one-workgroup form
+    if (opt(MSM_OPT_ENC_NO_COOP) != 2 && d_ffn % 128 == 0) {
+        const int nf = d_ffn / 64;
+        const size_t lds2 = E2_RES + EH_NBUF * E2_STAGE + sizeof(float) * (size_t)(EH_B1 + 64 * nf);
+        int tpw2 = cdiv(tiles, 512);
+        if (tpw2 > E2_WAVES) tpw2 = E2_WAVES;
+        const int grid2 = cdiv(tiles, tpw2);
+        if (ffn_f16) {
+            MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)enc_block_hm2_kernel<true>, lds2));
+            hipLaunchKernelGGL(enc_block_hm2_kernel<true>, dim3(grid2), dim3(E2_WAVES * 64), lds2, (hipStream_t)stream, (const unsigned short*)attn_hm, src,
+                               (const char*)wstream, small, pos, src_out, (unsigned short*)value_out, (unsigned short*)proj_out, M, tokens_per_image, nf,
+                               eps, tpw2);
+        } else {
+            MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)enc_block_hm2_kernel<false>, lds2));
+            hipLaunchKernelGGL(enc_block_hm2_kernel<false>, dim3(grid2), dim3(E2_WAVES * 64), lds2, (hipStream_t)stream, (const unsigned short*)attn_hm, src,
+                               (const char*)wstream, small, pos, src_out, (unsigned short*)value_out, (unsigned short*)proj_out, M, tokens_per_image, nf,
+                               eps, tpw2);
+        }
+        MSM_CHECK_LAUNCH(who);
+        return MSM_OK;
+    }
     if (ffn_f16) {
         MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)enc_block_hm_kernel<true>, lds));
         hipLaunchKernelGGL(enc_block_hm_kernel<true>, dim3(grid), dim3(EH_WAVES * 64), lds, (hipStream_t)stream, (const unsigned short*)attn_hm, src,
