@@ -369,7 +369,7 @@ def precision_leg(model, feats, dev, dist, args, precision, inflight, sparse_tap
         e_exec = 2.0 * tokens * (3 * 64 * 64 + ffn_terms * 64 * 1024) + 2.0 * tokens * 3 * (64 * 64 + 64 * 288) * (e_n - 1) / max(e_n, 1)
         g_bytes = tokens * (128 + 960 + 128)
         e_t, g_t = 1e-3 * e_ms / max(e_n, 1), 1e-3 * g_ms / max(g_n, 1)
-        roof = {"bound": "hbm", "kernel": "enc_block_hm_kernel (msm_encoder_block_hm_fwd): the bf16 plan's encoder-layer tail",
+        roof = {"bound": "hbm", "kernel": "enc_block_hm2_kernel (msm_encoder_block_hm_fwd): the 16-bit plans' encoder-layer tail",
                 "achieved": round(e_bytes / e_t / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(e_bytes / e_t / 1e9 / PEAK_HBM_GBPS, 4),
                 "traffic": None, "launches_per_step": e_n, "avg_launch_ms": round(1e3 * e_t, 4), "algorithmic_bytes_per_launch": e_bytes,
                 "useful_flops_per_launch": e_flops, "useful_tflops": round(e_flops / e_t / 1e12, 1),

@@ -129,9 +129,9 @@ def per_launch(match):
 
 
 # the 16-bit plans' dominant kernel (csrc/enc_lp.hip), when the profiled run was one of them: step_traffic_<precision>.json
-hm = per_launch(lambda k: "enc_block_hm_kernel" in k)
+hm = per_launch(lambda k: "enc_block_hm_kernel" in k or "enc_block_hm2_kernel" in k)
 if hm:
-    prec = "f16" if any("enc_block_hm_kernel<true>" in r["Name"] or "enc_block_hm_kernel<(bool)1>" in r["Name"] for r in rows) else "bf16"
+    prec = "f16" if any(("enc_block_hm" in r["Name"] and "_kernel<true>" in r["Name"]) or ("enc_block_hm" in r["Name"] and "_kernel<(bool)1>" in r["Name"]) for r in rows) else "bf16"
     hm["note"] = ("mean over the six launches of a pass (five with the next layer's value / sampling projection, the last without): fp16 attention "
                   "in, fp32 residual in / out, fp16 value and fp32-offset sampling records out; weights stay in L2")
     json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes ({tag}, tools/profile_round.sh <tag> {prec}); FETCH_SIZE "
