@@ -1182,7 +1182,7 @@ def test_weight_prefetch_rows_change_nothing(precision):
         b, _ = head(feats)
     finally:
         ops.dec_set_prefetch = orig
-    assert n_on == 9 + 8 and len(calls) == n_on               # the post_cross and (all but the last) heads launches carried prefetch rows
+    assert n_on == 1 + 9 + 8 and len(calls) == n_on           # (a clearing call first;) the post_cross and (all but the last) heads launches carried prefetch rows
     assert torch.equal(a["pred_masks"], b["pred_masks"]) and torch.equal(a["pred_logits"], b["pred_logits"])
     # a request of odd sizes (1 byte past a line, six ranges, a range smaller than a line) in front of one launch; cleared by n = 0
     w = [torch.randn(n, device=DEV) for n in (33, 4, 1 << 16, 12345, 64, 7)]

@@ -707,6 +707,9 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
             if pf_on:
                 ops.dec_set_prefetch(tensors)
 
+        if pf_on:
+            ops.dec_set_prefetch([])          # a request is consumed by the NEXT tail launch of this thread: drop one an aborted forward left behind
+
         for i in range(L):
             lvl = i % self.num_feature_levels                                     # DEC:608
             ca = self.transformer_cross_attention_layers[i]
