@@ -703,7 +703,9 @@ int msm_conv1x1_in_multi_lp(int n_levels, const float* const* x, const void* con
  *   flags & 1 (T % 16 == 0): attn receives the mask bit-packed and blocked instead -- msm_attn_mask_bits_bytes(B, Q, T) bytes in the layout
  *   of msm_attn_pack_mask_bits, what msm_hypersphere_attn_fused_kv_fwd reads (word 7 of a query's eight is never written nor read).
  *   flags & 2 (ABI 18; 16-bit plans): embedding and pooled activation enter two v_mfma_f32_16x16x32_f16 as IEEE halves (clamped), fp32
- *   accumulation, instead of sixteen dependent fp32 MFMAs per (query block, key block). */
+ *   accumulation, instead of sixteen dependent fp32 MFMAs per (query block, key block).
+ *   flags & 4 (ABI 21; the 16-bit plans' default since round 6; not with flags & 2): both operands as hi + lo IEEE-half pairs (2^-22), three terms per
+ *   product -- six K = 32 MFMAs per key block with fp32-class logits (the mask bits feed back into the attention). */
 int msm_pool_mask_taps(const float* act, int B, int H, int W, int n_levels, const int32_t* th, const int32_t* tw,
                        float* const* out, int32_t* zero_buf, int64_t zero_count, void* stream);
 int msm_attn_mask_pooled(const float* embed, int64_t embed_ld, const float* qbias, int64_t qbias_ld, const float* pooled,

@@ -242,6 +242,24 @@ def test_attention_masks_at_key_resolution(B, Q, H, W):
                     got_b, exp_b = got_b[..., live], exp_b[..., live]
                 assert torch.equal(got_b, exp_b)
             assert torch.equal(rabh, rah)
+        # f16="x3" (round 6, the 16-bit plans' default): hi + lo IEEE-half operand pairs, three terms per product -- held to the FP32 form's bounds
+        # against the float64 reference order (bits may differ only where the logit is within rounding of zero), both output layouts
+        a3, ra3 = ops().attn_mask_pooled(wd[..., :64], ap, qbias=wd[..., 64], f16="x3")
+        d3 = a3.cpu().bool() != attn_ref
+        if d3.any():
+            assert ref_logit[d3].abs().max() < 1e-4
+        assert d3.float().mean() <= 1e-4 and torch.equal(ra3.cpu().bool(), ~a3.cpu().bool().all(-1))
+        assert float((a3 != attn).float().mean()) <= 2e-5                         # (against the fp32 MFMA chain: a few logits within 1e-6 of zero)
+        if (th * tw) % 16 == 0:
+            ab3, rab3 = ops().attn_mask_pooled(wd[..., :64], ap, qbias=wd[..., 64], bits=True, f16="x3")
+            want_3 = ops().attn_pack_mask_bits(a3)
+            for qc, nb in enumerate(nblk):
+                got_b, exp_b = ab3[:, qc, :, :, :nb].cpu(), want_3[:, qc, :, :, :nb].cpu()
+                if Q % 16 and qc == len(nblk) - 1:
+                    live = (torch.arange(16)[:, None] + 16 * torch.arange(nb)[None] + 112 * qc) < Q
+                    got_b, exp_b = got_b[..., live], exp_b[..., live]
+                assert torch.equal(got_b, exp_b)
+            assert torch.equal(rab3, ra3)
         _, attn_full, ra_full = ops().mask_logits(wd[..., :64], fd, want_mask=False, target_size=(th, tw), qbias=wd[..., 64])
         d2 = attn_full.cpu() != attn.cpu()
         if d2.any():

@@ -77,7 +77,15 @@ constexpr int AM_NQ = 2;             // query blocks per wave
 // F16 (16-bit plans, round 5): the 64-channel contraction as two v_mfma_f32_16x16x32_f16 per (query block, key block) instead of sixteen
 // dependent v_mfma_f32_16x16x4_f32 -- embedding and pooled activation rounded to IEEE half (clamped) as the plans' full-resolution mask
 // step rounds them; the fp32 chain is ~1000 cycles of matrix-pipe latency per key block and the launch is all latency.
-template <bool VEC, bool BITS = false, bool F16 = false>
+// F16 = 2 (round 6, the 16-bit plans' default): both operands as hi + lo IEEE-half pairs (x = h + l up to 2^-22 |x|), three terms per product
+// (l h, h l, h h: six K = 32 MFMAs per key block, 96 cycles of the matrix pipe against the fp32 chain's 512) -- fp32-class logits, so the mask
+// bits that feed back into the attention keep the accuracy the fp32 form was kept for; 12.0 -> ~7 us at 4800 keys.
+__device__ __forceinline__ void split8h(const float4& p, const float4& q, f16x8& h, f16x8& l) {
+    h = cvt8h(p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w);
+    l = f16x8{(_Float16)(p.x - (float)h[0]), (_Float16)(p.y - (float)h[1]), (_Float16)(p.z - (float)h[2]), (_Float16)(p.w - (float)h[3]),
+              (_Float16)(q.x - (float)h[4]), (_Float16)(q.y - (float)h[5]), (_Float16)(q.z - (float)h[6]), (_Float16)(q.w - (float)h[7])};
+}
+template <bool VEC, bool BITS = false, int F16 = 0>
 __global__ __launch_bounds__(256) void attn_mask_pooled_kernel(const float* __restrict__ embed, int64_t embed_ld, const float* __restrict__ qbias,
                                                                int64_t qbias_ld, const float* __restrict__ pooled, uint8_t* __restrict__ attn,
                                                                int32_t* __restrict__ row_any, int Q, int T) {
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(256) void attn_mask_pooled_kernel(const float* __re
     constexpr int LQW = F16 ? 8 : 16;
     auto off = [](int u) { return F16 ? (u >> 1) * 32 + (u & 1) * 4 : u * 4; };
     float4 w[AM_NQ][4];
-    f16x8 wh[AM_NQ][2];
+    f16x8 wh[AM_NQ][2], wl[AM_NQ][2];
     float qb[AM_NQ];
 #pragma unroll
     for (int m = 0; m < AM_NQ; ++m) {
@@ -101,7 +109,10 @@ __global__ __launch_bounds__(256) void attn_mask_pooled_kernel(const float* __re
         const float* ep = embed + ((int64_t)b * Q + min(q, Q - 1)) * embed_ld + lq * LQW;
 #pragma unroll
         for (int u = 0; u < 4; ++u) w[m][u] = q < Q ? *reinterpret_cast<const float4*>(ep + off(u)) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (F16) {
+        if constexpr (F16 == 2) {
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) split8h(w[m][2 * s_], w[m][2 * s_ + 1], wh[m][s_], wl[m][s_]);
+        } else if constexpr (F16 == 1) {
 #pragma unroll
             for (int s_ = 0; s_ < 2; ++s_)
                 wh[m][s_] = cvt8h(w[m][2 * s_].x, w[m][2 * s_].y, w[m][2 * s_].z, w[m][2 * s_].w, w[m][2 * s_ + 1].x, w[m][2 * s_ + 1].y, w[m][2 * s_ + 1].z,
@@ -132,7 +143,19 @@ __global__ __launch_bounds__(256) void attn_mask_pooled_kernel(const float* __re
         for (int m = 0; m < AM_NQ; ++m) {
             if (m >= nq) break;
             f32x4 acc = f32x4{qb[m], qb[m], qb[m], qb[m]};
-            if constexpr (F16) {
+            if constexpr (F16 == 2) {
+                f16x8 ah0, al0, ah1, al1;                        // (split once per key block would cost registers the two query blocks need)
+                split8h(a[0], a[1], ah0, al0);
+                split8h(a[2], a[3], ah1, al1);
+                f32x4 lo = f32x4{0.f, 0.f, 0.f, 0.f};            // the small terms in their own accumulator, added last
+                lo = mfma_f16k32(al0, wh[m][0], lo);
+                lo = mfma_f16k32(ah0, wl[m][0], lo);
+                lo = mfma_f16k32(al1, wh[m][1], lo);
+                lo = mfma_f16k32(ah1, wl[m][1], lo);
+                acc = mfma_f16k32(ah0, wh[m][0], acc);
+                acc = mfma_f16k32(ah1, wh[m][1], acc);
+                acc = acc + lo;
+            } else if constexpr (F16 == 1) {
                 acc = mfma_f16k32(cvt8h(a[0].x, a[0].y, a[0].z, a[0].w, a[1].x, a[1].y, a[1].z, a[1].w), wh[m][0], acc);
                 acc = mfma_f16k32(cvt8h(a[2].x, a[2].y, a[2].z, a[2].w, a[3].x, a[3].y, a[3].z, a[3].w), wh[m][1], acc);
             } else {
@@ -218,7 +241,7 @@ extern "C" int msm_pool_mask_taps(const float* act, int B, int H, int W, int n_l
 extern "C" int msm_attn_mask_pooled(const float* embed, int64_t embed_ld, const float* qbias, int64_t qbias_ld, const float* pooled,
                                     uint8_t* attn, int32_t* row_any, int row_any_cleared, int flags, int B, int Q, int T, void* stream) {
     const int bits = flags & 1;
-    MSM_REQUIRE((flags & ~3) == 0, "msm_attn_mask_pooled: flags=%d (1 = bit-packed output, 2 = IEEE-half operands)", flags);
+    MSM_REQUIRE((flags & ~7) == 0 && (flags & 6) != 6, "msm_attn_mask_pooled: flags=%d (1 = bit-packed output, 2 = IEEE-half operands, 4 = hi + lo IEEE-half operands)", flags);
     MSM_REQUIRE(embed && pooled && attn && row_any, "msm_attn_mask_pooled: null pointer");
     MSM_REQUIRE(!bits || (T % 16 == 0 && (((uintptr_t)attn) & 15) == 0), "msm_attn_mask_pooled: the bit-packed mask needs T %% 16 == 0 and a 16-byte aligned buffer");
     MSM_REQUIRE(B > 0 && Q > 0 && Q <= 65535 * 16 * AM_NQ && T > 0, "msm_attn_mask_pooled: bad sizes");
@@ -232,17 +255,22 @@ extern "C" int msm_attn_mask_pooled(const float* embed, int64_t embed_ld, const 
     // about one wave per SIMD of the chip over (images, pairs): 1024 / (B * zq) waves walk an image's key blocks for a pair
     const int wgs = max(1, min(cdiv(nkb, 4), max(1, 256 / (B * zq))));     // (128 / 512 / 1024 measured slower at 4800 keys: 20.4 / 12.9 / 14.8 against 12.6 us)
     const bool vec = T % 4 == 0 && (((uintptr_t)attn) & 3) == 0;
-    const bool f16 = (flags & 2) != 0;
+    const int f16 = (flags & 4) ? 2 : ((flags & 2) ? 1 : 0);
 #define AM_LAUNCH(V_, B_, F_)                                                                                                                          \
     hipLaunchKernelGGL((attn_mask_pooled_kernel<V_, B_, F_>), dim3(B, wgs, zq), dim3(256), 0, st, embed, embed_ld, qbias, qbias_ld, pooled, attn, row_any, \
                        Q, T)
+#define AM_FORMS(V_, B_)                      \
+    if (f16 == 2) AM_LAUNCH(V_, B_, 2);       \
+    else if (f16 == 1) AM_LAUNCH(V_, B_, 1);  \
+    else AM_LAUNCH(V_, B_, 0)
     if (bits) {
-        if (f16) AM_LAUNCH(true, true, true); else AM_LAUNCH(true, true, false);
+        AM_FORMS(true, true);
     } else if (vec) {
-        if (f16) AM_LAUNCH(true, false, true); else AM_LAUNCH(true, false, false);
+        AM_FORMS(true, false);
     } else {
-        if (f16) AM_LAUNCH(false, false, true); else AM_LAUNCH(false, false, false);
+        AM_FORMS(false, false);
     }
+#undef AM_FORMS
 #undef AM_LAUNCH
     MSM_CHECK_LAUNCH("msm_attn_mask_pooled");
     return MSM_OK;

@@ -302,8 +302,11 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
         # row + column tables instead of a per-position matrix for the folded K/V constants (see _folded_kv)
         self.separable_kv_constants = True
         # mask_features handed over as FoldedMaskFeatures are contracted in their 64-channel factored form (fused tails only)
-        self.lp_pooled_masks = False           # opt-in (16-bit plans): attention masks at key resolution on IEEE-half operands -- 1207 against 1211 us per pass, and
-                                               # the mask bits feed back: "mask step only in 16 bits" loses its 0.3 % bound on one image of eight (fp32 operands stay the default)
+        # 16-bit plans, attention masks at key resolution: "x3" (default, round 6) = both operands as hi + lo IEEE-half pairs, three terms per
+        # product (fp32-class logits -- the mask bits feed back into the attention -- at six K = 32 MFMAs per key block instead of the fp32
+        # chain's sixteen: 12 -> 7 us at 4800 keys); True = single IEEE-half operands (round 5: "mask step only in 16 bits" then loses its
+        # 0.3 % bound on one image of eight); False = the fp32 MFMA chain
+        self.lp_pooled_masks = "x3"
         self.folded_mask_features = True
         self._fold_cache = None
         # the row-local ops between the attention cores run as three fused kernels per layer (csrc/dec_chain.hip)
@@ -602,7 +605,8 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                 if want_sizes and L > 0:
                     # (the pooling launch also clears the row flags of prediction 0's attention-mask step)
                     # (... and, for the fused heads + mask launches, of every later prediction's: one (L + 1, B, Q) buffer)
-                    fuse_masks = bool(self.fused_head_masks) and self.tails_dtype in ("bf16", "f16") and not self._tails_hl_for("heads") and not full
+                    fuse_masks = bool(self.fused_head_masks) and self.tails_dtype in ("bf16", "f16") and not self._tails_hl_for("heads") and not full \
+                        and self.lp_pooled_masks != "x3"          # (the epilogue form has the fp32 and the single-half contraction)
                     Bq, Qn = int(out.shape[0]), int(out.shape[1])
                     outs, flags = ops.pool_mask_taps(mask_features, want_sizes, zero_rows=Qn * (L + 1 if fuse_masks else 1))
                     ra_all = flags.view(-1)[:Bq * Qn * (L + 1 if fuse_masks else 1)].view(-1, Bq, Qn)
@@ -661,7 +665,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                 # (a layer whose cross-attention projects K / V itself reads its mask bit-packed: written that way here)
                 as_bits = fkv is not None and i_next < L and fkv["layers"][i_next] is not None
                 attn, row_any = ops.attn_mask_pooled(emb, pooled[tuple(tgt)], qbias=qb, row_any=ra, bits=as_bits,
-                                                          f16=self.mask_step_dtype in ("bf16", "f16") and self.lp_pooled_masks)
+                                                          f16=self.lp_pooled_masks if self.mask_step_dtype in ("bf16", "f16") else False)
                 m = None
                 if want:        # "always" with aux outputs: the full-resolution kernel only writes the mask
                     m = ops.mask_logits(emb, mask_features, want_mask=True, target_size=None, packed_bf16=self._packed_mf, qbias=qb,
@@ -741,7 +745,7 @@ class MeanShiftTransformerDecoder(PlanAttributes, nn.Module):
                 # prediction i + 1 of a plan that keeps only the final masks: its one product is the next layer's attention mask
                 as_bits = fkv is not None and fkv["layers"][i + 1] is not None
                 out, d, e, q, attn, row_any = ops.dec_heads_mask(x, dn.weight, dn.bias, mlp, pooled[tgt], ra_all[i + 1], qcol=ncol, bits=as_bits,
-                                                                 f16=self.mask_step_dtype in ("bf16", "f16") and self.lp_pooled_masks,
+                                                                 f16=self.mask_step_dtype in ("bf16", "f16") and self.lp_pooled_masks is True,
                                                                  parts=parts, bias=ff.linear2.bias, ln_g=ff.norm.weight, ln_b=ff.norm.bias,
                                                                  l2norm=self.decoder_block_norm, want_out=True, want_d=False, **next_query(i + 1))
                 pred_cls.append(None)

@@ -483,6 +483,7 @@ def pool_mask_taps(act, sizes, zero_rows=0):
 
 
 def attn_mask_pooled(mask_embed, pooled, *, qbias=None, row_any=None, bits=False, f16=False):
+    # f16: False = the fp32 MFMA chain, True = single IEEE-half operands, "x3" = hi + lo IEEE-half pairs (three terms: fp32-class logits)
     """The next layer's attention mask from the pooled activation (pool_mask_taps): attn (B, Q, T) uint8 =
     (einsum('bqc,btc->bqt', mask_embed, pooled) + qbias[b, q]) < 0 and row_any (B, Q) int32 (1 where a row keeps an unmasked
     key).  mask_embed: (B, Q, 64), contiguous or the leading 64 columns of a wider row-major buffer; qbias (B, Q), any uniform
@@ -515,7 +516,7 @@ def attn_mask_pooled(mask_embed, pooled, *, qbias=None, row_any=None, bits=False
     else:
         _c(row_any, "row_any", torch.int32)
     rc = lib().msm_attn_mask_pooled(_p(mask_embed), mask_embed.stride(1), _p(qbias), qb_ld, _p(pooled), _p(attn), _p(row_any),
-                                    1 if cleared else 0, (1 if bits else 0) | (2 if f16 else 0), B, Q, T, _stream())
+                                    1 if cleared else 0, (1 if bits else 0) | (4 if f16 == "x3" else (2 if f16 else 0)), B, Q, T, _stream())
     check(rc, "msm_attn_mask_pooled")
     return attn, row_any
 
