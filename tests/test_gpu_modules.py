@@ -1145,6 +1145,7 @@ def test_fused_head_masks_equal_two_launches(precision):
     assert not head.predictor.fused_head_masks               # opt-in: not faster (modeling.py)
     head.predictor.fused_head_masks = True
     head.predictor.tails_hl = False                          # (the epilogue form exists for single weight fragments: the bf16 plan's hi + lo heads keep two launches)
+    head.predictor.lp_pooled_masks = True                    # (... and for the single-half mask contraction, not the plans' hi + lo "x3" default)
     calls = []
     orig = ops.dec_heads_mask
     ops.dec_heads_mask = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
