@@ -59,7 +59,7 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 21   /* 21: msm_dec_heads_mask (the next layer's attention mask as the heads kernel's epilogue), msm_l2_prefetch / msm_dec_set_prefetch, msm_dec_*_bf16x2 (hi + lo weight fragments), MSM_OPT_DEC_TILE32; 20: msm_ucn_embedding_tail; 19: backbone glue (msm_bias_act_nhwc, msm_nhwc_to_nchw_f32); 18: flags argument of msm_attn_mask_pooled (bit 1: IEEE-half operands); 17: msm_f32_to_f16_rows; 16: msm_mask_conv3x3_folded (the UCN mask step with the 3x3 mask_features convolution folded into the query embedding); 15: IEEE-half operand forms of the 16-bit plan (precision "f16": msm_dec_*_f16, msm_encoder_block_hm_fwd ffn_f16, fp16 keys in the low-precision attention); 14: cmat_width argument of the K/V projections (separable position constants), msm_conv3x3_c64_nchw_bf16, msm_encoder_prologue_hm_fwd; 13: flags argument of msm_ms_select_seeds_bf16 (persistent on-chip seeding over the bf16 copy), input projections on the bf16 matrix pipe (msm_conv1x1_in_lp, msm_conv1x1_in_multi_lp); 12: head-major bf16 activations between the encoder kernels of the bf16 plan (msm_encoder_block_hm_fwd, msm_msdeform_attn_enc_lp_fwd, msm_f32_to_f16); 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
+#define MSM_ABI_VERSION 22   /* 22: msm_groupnorm_apply_f16 + msm_conv3x3_c64_f16h (the f16 plan's FPN level on a half token map); 21: msm_dec_heads_mask (the next layer's attention mask as the heads kernel's epilogue), msm_l2_prefetch / msm_dec_set_prefetch, msm_dec_*_bf16x2 (hi + lo weight fragments), MSM_OPT_DEC_TILE32; 20: msm_ucn_embedding_tail; 19: backbone glue (msm_bias_act_nhwc, msm_nhwc_to_nchw_f32); 18: flags argument of msm_attn_mask_pooled (bit 1: IEEE-half operands); 17: msm_f32_to_f16_rows; 16: msm_mask_conv3x3_folded (the UCN mask step with the 3x3 mask_features convolution folded into the query embedding); 15: IEEE-half operand forms of the 16-bit plan (precision "f16": msm_dec_*_f16, msm_encoder_block_hm_fwd ffn_f16, fp16 keys in the low-precision attention); 14: cmat_width argument of the K/V projections (separable position constants), msm_conv3x3_c64_nchw_bf16, msm_encoder_prologue_hm_fwd; 13: flags argument of msm_ms_select_seeds_bf16 (persistent on-chip seeding over the bf16 copy), input projections on the bf16 matrix pipe (msm_conv1x1_in_lp, msm_conv1x1_in_multi_lp); 12: head-major bf16 activations between the encoder kernels of the bf16 plan (msm_encoder_block_hm_fwd, msm_msdeform_attn_enc_lp_fwd, msm_f32_to_f16); 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
 int msm_abi_version(void);
 
 /* Kernel-selection overrides for tools/ and tests/ (NOT read on the product path: every option defaults to
@@ -137,6 +137,12 @@ int msm_groupnorm_apply_f32(const float* x, const double* stats, const float* ga
 int msm_groupnorm_apply_split(const float* x, const double* stats, const float* gamma, const float* beta,
                               const float* up, int uh, int uw, int64_t up_batch_stride, uint16_t* planes,
                               int B, int H, int W, int C, int groups, float eps, int relu, void* stream);
+
+/* The same result written as ONE plane of IEEE halves [B][H*W][C], clamped to the half range: the operand bits msm_conv3x3_c64_f16
+ * rounds its input to, produced once (the "f16" plan's FPN level: half the bytes between the two kernels; consumer msm_conv3x3_c64_f16h). */
+int msm_groupnorm_apply_f16(const float* x, const double* stats, const float* gamma, const float* beta,
+                            const float* up, int uh, int uw, int64_t up_batch_stride, void* y_f16,
+                            int B, int H, int W, int C, int groups, float eps, int relu, void* stream);
 
 /* y [B][C][HW] (NCHW planes) = GN(x [B][HW][C]) * gamma + beta (relu when relu != 0), stats from msm_groupnorm_stats_f32 /
  * msm_conv3x3_c64_f32: the 64-channel activation the folded mask step contracts with (msm_mask_logits_fwd).
@@ -725,6 +731,12 @@ int msm_conv3x3_c64_bf16(const float* in, const float* w_tap_major, float* out, 
  * v_mfma_f32_16x16x32_f16: half the MFMAs of the bf16 form, 2^-12 roundings instead of the weight's 2^-9. */
 int msm_conv3x3_c64_f16(const float* in, const float* w_tap_major, float* out, double* stats,
                         int stats_cleared, int B, int H, int W, void* stream);
+/* msm_conv3x3_c64_f16 on an input that already is the clamped halves (in_f16 [B][H*W][64] IEEE halves, msm_groupnorm_apply_f16):
+ * the same output bits; a wave takes up to three output rows of a 32-pixel strip with all of its loads in flight at once and the
+ * dx = -1 / +1 operands as lane shifts of a row loaded once.  out / stats as msm_conv3x3_c64_f32 (the moments' fp32 partial sums are
+ * grouped by unit, so they agree with msm_conv3x3_c64_f16's to rounding). */
+int msm_conv3x3_c64_f16h(const void* in_f16, const float* w_tap_major, float* out, double* stats,
+                         int stats_cleared, int B, int H, int W, void* stream);
 /* The same convolution with fp32-accurate results on the bf16 matrix pipe (f32_split plan): the activation as the three bf16
  * planes of msm_groupnorm_apply_split, the weight (fp32, tap-major) split when a workgroup copies its 32 output channels
  * into LDS, six bf16 MFMAs per product.  out / stats as msm_conv3x3_c64_f32. */

@@ -1730,6 +1730,41 @@ def test_conv3x3_c64_split_form(B, H, W):
     torch.testing.assert_close(st2.cpu(), mom + 1.0, rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 12, 16), (1, 5, 37), (3, 30, 40), (8, 120, 160), (20, 56, 56), (2, 240, 320), (1, 1, 4), (40, 7, 33)])
+def test_conv3x3_c64_half_map_form(B, H, W):
+    """The "f16" plan's FPN level (round 6): msm_groupnorm_apply_f16 writes the clamped IEEE halves msm_conv3x3_c64_f16 rounds its input
+    to -- bit for bit --, and msm_conv3x3_c64_f16h (a wave = up to three output rows of a 32-pixel strip, every load of the unit in flight
+    at once, dx = -1 / +1 operands as lane shifts) returns msm_conv3x3_c64_f16's output bits on them: ragged widths, one-row maps, more
+    images than workgroup slots, the headline size; moments of its own output; accumulation into a caller's zeroed moments."""
+    x, w = rnd(B, H * W, 64, seed=1), rnd(64, 64, 3, 3, seed=2, scale=0.06)
+    g, be = 1 + 0.1 * rnd(64, seed=3), rnd(64, seed=4)
+    up = rnd(B, (H // 2) * (W // 2), 64, seed=5) if H % 2 == 0 and W % 2 == 0 else None
+    kw = dict(up=up.to(DEV), up_hw=(H // 2, W // 2)) if up is not None else {}
+    xd = x.to(DEV)
+    for big in (True, False):                                    # (a channel beyond the half range: the clamp, not infinities)
+        gg = g.clone()
+        if big:
+            gg[0] = 3e5
+        y32 = ops().groupnorm_tokens(xd, gg.to(DEV), be.to(DEV), H, W, **kw)
+        y16 = ops().groupnorm_tokens(xd, gg.to(DEV), be.to(DEV), H, W, out_f16=True, **kw)
+        assert y16.dtype == torch.float16 and y16.shape == y32.shape
+        assert torch.equal(y16, y32.clamp(-65504.0, 65504.0).to(torch.float16)) and bool(torch.isfinite(y16).all())
+        assert not big or H * W < 8 or float(y32.abs().max()) > 65504.0
+    w3 = w.permute(0, 2, 3, 1).reshape(64, 576).contiguous().to(DEV)
+    o_ref, st_ref = ops().conv3x3_c64(y32, w3, H, W, bf16="f16")
+    o, st = ops().conv3x3_c64(y16, w3, H, W, bf16="f16")
+    assert o.dtype == torch.float32 and torch.equal(o, o_ref)
+    mom = torch.stack([o.double().sum(1), (o.double() ** 2).sum(1)], -1).cpu()
+    torch.testing.assert_close(st.cpu(), mom, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(st.cpu(), st_ref.cpu(), rtol=1e-5, atol=1e-4)
+    st0 = torch.ones(B, 64, 2, device=DEV, dtype=torch.float64)
+    o2, st2 = ops().conv3x3_c64(y16, w3, H, W, bf16="f16", stats=st0, stats_cleared=True)
+    assert torch.equal(o2, o) and st2.data_ptr() == st0.data_ptr()
+    torch.testing.assert_close(st2.cpu(), mom + 1.0, rtol=1e-5, atol=1e-4)
+    with pytest.raises(RuntimeError):
+        ops().conv3x3_c64(y16, w3, H, W, bf16=True)
+
+
 def test_kv_project_multi_equals_single_launches():
     """msm_kv_project_multi_f32: nine jobs (three levels x three layers, NCHW and token-major inputs) in one launch are
     bit-identical to nine msm_kv_project_f32 launches."""

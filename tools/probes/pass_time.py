@@ -24,12 +24,21 @@ if os.environ.get("MSM_OPTION"):                      # e.g. MSM_OPTION=ENC_NO_C
     _lib.set_option(name, int(val))
 model = bench.build_model(dev)
 feats = {k: v.to(dev) for k, v in syn.synth_backbone_features(8, 480, 640, seed=10).items()}
-out = [os.path.dirname(unseenobjectswithmeanshift_amd.__file__).replace(ROOT, ".") + " " + os.environ.get("MSM_OPTION", "")]
+out = [os.path.dirname(unseenobjectswithmeanshift_amd.__file__).replace(ROOT, ".") + " " + os.environ.get("MSM_OPTION", "") + " " + os.environ.get("MSM_ATTR", "")]
 for mode in os.environ.get("MSM_MODES", "f16,bf16,f32").split(","):
     model.set_precision(mode)
     if os.environ.get("MSM_TAILS_HL") and hasattr(model.sem_seg_head.predictor, "tails_hl"):
         v = os.environ["MSM_TAILS_HL"]
         model.sem_seg_head.predictor.tails_hl = {"0": False, "1": True}.get(v, tuple(v.split(",")))
+    for item in filter(None, os.environ.get("MSM_ATTR", "").split(";")):       # e.g. MSM_ATTR="pixel_decoder.fpn_half_map=False"
+        import ast
+        path, val = item.split("=")
+        obj = model.sem_seg_head
+        *mods, attr = path.split(".")
+        for m in mods:
+            obj = getattr(obj, m)
+        assert hasattr(obj, attr), path
+        setattr(obj, attr, ast.literal_eval(val))
     g = model.graphed()
     for _ in range(5):
         g(feats, (480, 640))

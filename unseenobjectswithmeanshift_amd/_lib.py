@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmsm_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "msm_hip.h")
 
 _lib = None
-ABI_VERSION = 21     # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
+ABI_VERSION = 22     # must equal MSM_ABI_VERSION of include/msm_hip.h (checked when the library is loaded)
 
 c_f = ctypes.c_void_p      # float* (device)
 c_p = ctypes.c_void_p
@@ -33,6 +33,7 @@ _SIGNATURES = {
     "msm_groupnorm_stats_f32": (c_i, [c_f, c_p, c_i, c_i, c_i, c_i, c_p]),
     "msm_groupnorm_apply_f32": (c_i, [c_f, c_p, c_f, c_f, c_f, c_i, c_i, c_l, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_i, c_p]),
     "msm_groupnorm_apply_split": (c_i, [c_f, c_p, c_f, c_f, c_f, c_i, c_i, c_l, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_i, c_p]),
+    "msm_groupnorm_apply_f16": (c_i, [c_f, c_p, c_f, c_f, c_f, c_i, c_i, c_l, c_p, c_i, c_i, c_i, c_i, c_i, c_fl, c_i, c_p]),
     "msm_groupnorm_apply_nchw_f32": (c_i, [c_f, c_p, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_i, c_p]),
     "msm_pos_embed_sine": (c_i, [c_f, c_i, c_i, c_i, c_l, c_l, c_f, c_fl, c_fl, c_p]),
     "msm_transpose_f32": (c_i, [c_f, c_f, c_i, c_i, c_i, c_p]),
@@ -135,6 +136,7 @@ _SIGNATURES = {
     "msm_conv3x3_c64_f32": (c_i, [c_f, c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p]),
     "msm_conv3x3_c64_bf16": (c_i, [c_f, c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p]),
     "msm_conv3x3_c64_f16": (c_i, [c_f, c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "msm_conv3x3_c64_f16h": (c_i, [c_p, c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p]),
     "msm_conv3x3_c64_nchw_f16": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p]),
     "msm_conv3x3_c64_split": (c_i, [c_f, c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p]),
     "msm_conv3x3_c64_nchw_f32": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p]),

@@ -8,7 +8,7 @@ epoch counter, so a replay compares one integer instead of probing every module 
 PLAN_ATTRS = frozenset((
     "precision", "mask_step_dtype", "tails_dtype", "attention_dtype", "kv_split", "sparse_taps", "aux_outputs",
     "folded_mask_features", "batched_kv", "fold_kv", "fused_tails", "fused_encoder", "fused_front", "ffn_parts",
-    "fused_kv_attention", "tails_plan", "graphed", "backbone_dtype", "fused_msda", "pooled_attention_masks", "hm_activations", "lp_input_proj", "lp_prologue", "separable_kv_constants", "lp_operands", "attention_keys", "lp_conv3x3", "fused_kv_min_keys", "gemm_1x1", "fold_mask_conv", "lp_pooled_masks", "fused_epilogues", "miopen_find", "parallel_towers", "fused_head_masks", "weight_prefetch", "tails_hl",
+    "fused_kv_attention", "tails_plan", "graphed", "backbone_dtype", "fused_msda", "pooled_attention_masks", "hm_activations", "lp_input_proj", "lp_prologue", "separable_kv_constants", "lp_operands", "attention_keys", "lp_conv3x3", "fused_kv_min_keys", "gemm_1x1", "fold_mask_conv", "lp_pooled_masks", "fused_epilogues", "miopen_find", "parallel_towers", "fused_head_masks", "weight_prefetch", "tails_hl", "fpn_half_map",
     "test_topk_per_image", "topk_before_masks"))
 
 _epoch = [0]

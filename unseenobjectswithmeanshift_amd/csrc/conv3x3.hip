@@ -468,6 +468,221 @@ __global__ __launch_bounds__(C3S_W * 64) void conv3x3_c64_split_kernel(const uin
     }
 }
 
+
+// ---- the "f16" plan's form on an IEEE-half token map (msm_conv3x3_c64_f16h; round 6) ---------------------------------------------
+// conv3x3_c64_kernel<false, 2, 2, 8> spends its 49 us (B = 8, 120 x 160) waiting: a wave walks 2.3 tiles of 9 taps, one memory round
+// trip per tap with one tap in flight, on two waves per SIMD.  Here the producer (msm_groupnorm_apply_f16) already wrote the map as
+// the clamped halves this kernel would round to -- the same operand bits, half the bytes -- and a wave owns a UNIT of up to C3R_R
+// consecutive output rows of a 32-pixel strip:
+//   * all loads of the unit (its R + 2 input rows: four 16-byte loads per row and lane, + one halo pixel left and right) are issued
+//     before anything else -- in front of the workgroup's weight copy, so the copy hides under them: ONE round trip per unit;
+//   * an input row is loaded once; the dx = -1 / +1 operands of its three taps are lane shifts (v_mov_b32 row_shr / row_shl, the
+//     pixel at the junction of the two 16-pixel blocks through a row rotate, the strip's outer neighbours from the halo registers);
+//   * taps in the order 0..8, halves kh = 0, 1, one accumulator chain per (block, channel block): the output bits of
+//     conv3x3_c64_kernel<false, 2, 2, 8> on the same halves;
+//   * units are numbered strip-fastest; with a grid of a multiple of 8 workgroups per image each XCD (workgroup id mod 8) takes a
+//     contiguous range of units, so the rows two bands share are read from HBM by one L2.
+constexpr int C3R_R = 3;                 // output rows per unit (R + 2 input rows of 24 registers each stay in flight)
+constexpr int C3R_W = 8;                 // waves per workgroup
+
+// lane lj of each 16-lane row takes lane lj - 1 (SHR) / lj + 1 of src; the lane without a source (0 / 15) keeps `old`
+template <bool SHR>
+__device__ __forceinline__ u32x4b shift_px(const u32x4b& src, const u32x4b& old) {
+    u32x4b r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (unsigned)__builtin_amdgcn_update_dpp((int)old[i], (int)src[i], SHR ? 0x111 : 0x101, 0xf, 0xf, false);
+    return r;
+}
+// rotate right by N inside each row of 16 lanes (lane i takes lane (i - N) mod 16)
+template <int N>
+__device__ __forceinline__ u32x4b rotate_px(const u32x4b& src) {
+    u32x4b r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)src[i], 0x120 + N, 0xf, 0xf, false);
+    return r;
+}
+
+__global__ __launch_bounds__(C3R_W * 64) void conv3x3_c64_rows_kernel(const uint16_t* __restrict__ in, const float* __restrict__ w,
+                                                                      float* __restrict__ out, double* __restrict__ stats, int H, int W,
+                                                                      int R) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [64][C3_LDB] halves, then the moment scratch [C3R_W][64][2]
+    unsigned short* wlb = reinterpret_cast<unsigned short*>(wl);
+    float* msc = wl + C3_C * C3_LDB / 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    const int b = blockIdx.y;
+    const int xt = (W + 31) / 32;                    // strips per image row
+    const int units = xt * ((H + R - 1) / R);        // of this image
+    // this wave's units: first, first + step, ... below last
+    int u, step, last;
+    if ((gridDim.x & 7) == 0) {
+        const int chunk = (units + 7) / 8, xcd = (int)blockIdx.x & 7;
+        u = xcd * chunk + ((int)blockIdx.x >> 3) * C3R_W + wave;
+        step = ((int)gridDim.x >> 3) * C3R_W;
+        last = min(units, (xcd + 1) * chunk);
+    } else {
+        u = (int)blockIdx.x * C3R_W + wave;
+        step = (int)gridDim.x * C3R_W;
+        last = units;
+    }
+    const uint16_t* ib = in + (int64_t)b * H * W * C3_C;
+    float* ob = out + (int64_t)b * H * W * C3_C;
+    const u32x4b zero = {0u, 0u, 0u, 0u};
+
+    struct Rows {
+        u32x4b c[C3R_R + 2][2][2];        // [input row][16-pixel block][32-channel half]: channels kh*32 + lq*8 .. +7 of pixel x0 + 16 pb + lj
+        u32x4b h[C3R_R + 2][2];           // lane lj == 0: pixel x0 - 1, lane lj == 15: pixel x0 + 32 (zeros outside the map)
+    };
+    auto load_unit = [&](int uu, Rows& rw) {
+        const int band = uu / xt, x0 = (uu - band * xt) * 32, y0 = band * R;
+#pragma unroll
+        for (int i = 0; i < C3R_R + 2; ++i) {
+            const int yy = y0 - 1 + i;
+            const bool rok = yy >= 0 && yy < H && i < R + 2;
+            const uint16_t* rp = ib + (int64_t)min(max(yy, 0), H - 1) * W * C3_C + lq * 8;
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                const int px = x0 + pb * 16 + lj;
+                const bool ok = rok && px < W;
+                const uint16_t* p = rp + (int64_t)min(px, W - 1) * C3_C;
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh) {
+                    const u32x4b v = *reinterpret_cast<const u32x4b*>(p + kh * 32);
+                    rw.c[i][pb][kh] = ok ? v : zero;
+                }
+            }
+            const int hx = lj < 8 ? x0 - 1 : x0 + 32;
+            const bool hok = rok && hx >= 0 && hx < W;
+            const uint16_t* ph = rp + (int64_t)min(max(hx, 0), W - 1) * C3_C;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                const u32x4b v = *reinterpret_cast<const u32x4b*>(ph + kh * 32);
+                rw.h[i][kh] = hok ? v : zero;
+            }
+        }
+    };
+    Rows rw;
+    if (u < last) load_unit(u, rw);
+    {
+        // the weight copy (fp32 -> halves), behind the first unit's loads
+        constexpr int PER = C3_C * (C3_K / 4) / (C3R_W * 64);      // 18 float4 per thread
+        static_assert(PER * C3R_W * 64 == C3_C * (C3_K / 4), "the weight copy assumes an exact split");
+#pragma unroll
+        for (int k0 = 0; k0 < PER; k0 += 6) {
+            float4 wv[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) wv[k] = *reinterpret_cast<const float4*>(w + (int64_t)(tid + (k0 + k) * (C3R_W * 64)) * 4);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int i = tid + (k0 + k) * (C3R_W * 64);
+                const int n = i / (C3_K / 4), c4 = i - n * (C3_K / 4);
+                *reinterpret_cast<u32x2b*>(wlb + n * C3_LDB + c4 * 4) = pack4h(wv[k].x, wv[k].y, wv[k].z, wv[k].w);
+            }
+        }
+    }
+    __syncthreads();
+
+    float s[4][4], q[4][4];                          // moments of this lane's 4 x 4 channels over its pixels
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[mt][r] = q[mt][r] = 0.f;
+    const unsigned short* wp = wlb + lj * C3_LDB + lq * 8;
+
+    for (; u < last; u += step) {
+        const int band = u / xt, x0 = (u - band * xt) * 32, y0 = band * R;
+        const int nr = min(R, H - y0);
+#pragma unroll
+        for (int r = 0; r < C3R_R; ++r) {
+            if (r >= nr) break;
+            f32x4 acc[2][4];
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[pb][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int i = r + dy;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int t = dy * 3 + dx;
+#pragma unroll
+                    for (int kh = 0; kh < 2; ++kh) {
+                        u32x4b x[2];
+                        if (dx == 0) {
+                            x[0] = shift_px<true>(rw.c[i][0][kh], rw.h[i][kh]);
+                            x[1] = shift_px<true>(rw.c[i][1][kh], rotate_px<1>(rw.c[i][0][kh]));
+                        } else if (dx == 1) {
+                            x[0] = rw.c[i][0][kh];
+                            x[1] = rw.c[i][1][kh];
+                        } else {
+                            x[0] = shift_px<false>(rw.c[i][0][kh], rotate_px<15>(rw.c[i][1][kh]));
+                            x[1] = shift_px<false>(rw.c[i][1][kh], rw.h[i][kh]);
+                        }
+                        f16x8 a[4];
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const f16x8*>(wp + mt * 16 * C3_LDB + t * C3_C + kh * 32);
+#pragma unroll
+                        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                            for (int mt = 0; mt < 4; ++mt) acc[pb][mt] = mfma_f16k32(a[mt], __builtin_bit_cast(f16x8, x[pb]), acc[pb][mt]);
+                    }
+                }
+            }
+            const int y = y0 + r;
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                if (x0 + pb * 16 + lj < W) {
+                    float* op = ob + ((int64_t)y * W + x0 + pb * 16 + lj) * C3_C + lq * 4;
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        *reinterpret_cast<float4*>(op + mt * 16) = make_float4(acc[pb][mt][0], acc[pb][mt][1], acc[pb][mt][2], acc[pb][mt][3]);
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            s[mt][rr] += acc[pb][mt][rr];
+                            q[mt][rr] += acc[pb][mt][rr] * acc[pb][mt][rr];
+                        }
+                    }
+                }
+            }
+        }
+        if (u + step < last) load_unit(u + step, rw);
+    }
+    if (stats) {
+        // over the 16 pixels of the lane quarter, then over the workgroup's waves (fixed order), then one double add each
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[mt][r] += wave_xor_dpp1(s[mt][r]);
+                q[mt][r] += wave_xor_dpp1(q[mt][r]);
+                s[mt][r] += wave_xor_dpp2(s[mt][r]);
+                q[mt][r] += wave_xor_dpp2(q[mt][r]);
+                s[mt][r] += wave_xor_dpp4(s[mt][r]);
+                q[mt][r] += wave_xor_dpp4(q[mt][r]);
+                s[mt][r] += wave_xor_dpp8(s[mt][r]);
+                q[mt][r] += wave_xor_dpp8(q[mt][r]);
+            }
+        if (lj == 0) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ch = mt * 16 + lq * 4 + r;
+                    msc[(wave * C3_C + ch) * 2 + 0] = s[mt][r];
+                    msc[(wave * C3_C + ch) * 2 + 1] = q[mt][r];
+                }
+        }
+        __syncthreads();
+        if (tid < C3_C * 2) {
+            double t = 0.0;
+            for (int wv = 0; wv < C3R_W; ++wv) t += (double)msc[wv * C3_C * 2 + tid];
+            atomicAdd(stats + (int64_t)b * C3_C * 2 + tid, t);
+        }
+    }
+}
+
 }  // namespace msm
 
 using namespace msm;
@@ -602,4 +817,29 @@ extern "C" int msm_conv3x3_c64_f16(const float* in, const float* w_tap_major, fl
 extern "C" int msm_conv3x3_c64_nchw_f16(const float* in, const float* w_tap_major, const float* bias, float* out, int B, int H, int W,
                                         int Cout, void* stream) {
     return conv3x3_c64_nchw_launch(in, w_tap_major, bias, out, B, H, W, Cout, 2, stream);
+}
+
+extern "C" int msm_conv3x3_c64_f16h(const void* in_f16, const float* w_tap_major, float* out, double* stats, int stats_cleared, int B, int H,
+                                    int W, void* stream) {
+    MSM_REQUIRE(in_f16 && w_tap_major && out, "msm_conv3x3_c64_f16h: null pointer");
+    MSM_REQUIRE(B > 0 && H > 0 && W > 0 && (int64_t)H * W * C3_C < ((int64_t)1 << 31), "msm_conv3x3_c64_f16h: bad sizes B=%d H=%d W=%d", B, H, W);
+    MSM_REQUIRE(((((uintptr_t)in_f16) | ((uintptr_t)w_tap_major) | ((uintptr_t)out)) & 15) == 0 && (((uintptr_t)stats) & 7) == 0,
+                "msm_conv3x3_c64_f16h: misaligned pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (stats && !stats_cleared) MSM_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * C3_C * (size_t)B, st));
+    // workgroups per image: about one round of the chip over the batch (a multiple of 8 when there are that many: the XCD-contiguous unit
+    // ranges); rows per unit: as few as keep every unit on its own wave, at most C3R_R
+    int pmax = max(1, 256 / B);
+    if (pmax >= 8) pmax &= ~7;
+    const int xt = cdiv(W, 32);
+    int R = 1;
+    while (R < C3R_R && xt * cdiv(H, R) > pmax * C3R_W) ++R;
+    const int units = xt * cdiv(H, R);
+    const int per_image = pmax >= 8 ? min(pmax, 8 * cdiv(cdiv(units, 8), C3R_W)) : min(pmax, cdiv(units, C3R_W));
+    const size_t lds = sizeof(unsigned short) * (size_t)C3_C * C3_LDB + sizeof(float) * (size_t)C3R_W * C3_C * 2;
+    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_rows_kernel, lds));
+    hipLaunchKernelGGL(conv3x3_c64_rows_kernel, dim3(per_image, B), dim3(C3R_W * 64), lds, st, (const uint16_t*)in_f16, w_tap_major, out, stats, H,
+                       W, R);
+    MSM_CHECK_LAUNCH("msm_conv3x3_c64_f16h");
+    return MSM_OK;
 }

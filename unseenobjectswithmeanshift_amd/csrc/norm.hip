@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ up, int uh, int uw, int64_t up_sb,
                                                        float* __restrict__ y, int H, int W, int C, int groups,
-                                                       float eps, int relu, uint16_t* __restrict__ planes, int64_t plane_stride) {
+                                                       float eps, int relu, uint16_t* __restrict__ planes, int64_t plane_stride, int h16) {
     __shared__ float sc[256], sh[256], mn[256];
     const int b = blockIdx.y;
     const int HW = H * W;
@@ -186,7 +186,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
         if (relu) {
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
-        if (planes) {
+        if (planes && h16) {
+            // the result as ONE plane of clamped IEEE halves: the operand bits msm_conv3x3_c64_f16 rounds to, written once by the producer
+            *reinterpret_cast<u32x2b*>(planes + ((int64_t)b * HW + p) * C + c) = pack4h(v.x, v.y, v.z, v.w);
+        } else if (planes) {
             // the result as three bf16 planes (v = h + m + l exactly): the operand of msm_conv3x3_c64_split, split once here
             // instead of nine times (once per tap) in the consumer
             const Split3 t3 = split3(v.x, v.y, v.z, v.w);
@@ -428,7 +431,7 @@ extern "C" int msm_groupnorm_stats_f32(const float* x, double* stats, int stats_
 
 static int groupnorm_apply_impl(const char* who, const float* x, const double* stats, const float* gamma, const float* beta,
                                        const float* up, int uh, int uw, int64_t up_batch_stride, float* y, int B, int H, int W,
-                                       int C, int groups, float eps, int relu, uint16_t* planes, void* stream) {
+                                       int C, int groups, float eps, int relu, uint16_t* planes, void* stream, int h16 = 0) {
     MSM_REQUIRE(x && stats && gamma && beta && (y || planes), "%s: null pointer", who);
     MSM_REQUIRE(groups > 0 && C % groups == 0 && C % 4 == 0 && C <= 256, "%s: C=%d groups=%d", who, C, groups);
     MSM_REQUIRE(((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)up)) & 15) == 0, "%s: pointers must be 16-byte aligned", who);
@@ -439,7 +442,7 @@ static int groupnorm_apply_impl(const char* who, const float* x, const double* s
     const int64_t total = (int64_t)H * W * (C / 4);
     dim3 grid((unsigned)min((int64_t)1024, (total + 255) / 256), B), block(256);
     hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, st, x, stats, gamma, beta, up, uh, uw, up_batch_stride, y, H, W, C, groups, eps,
-                       relu, planes, (int64_t)B * H * W * C);
+                       relu, planes, (int64_t)B * H * W * C, h16);
     MSM_CHECK_LAUNCH(who);
     return MSM_OK;
 }
@@ -458,6 +461,14 @@ extern "C" int msm_groupnorm_apply_split(const float* x, const double* stats, co
     MSM_REQUIRE(planes && (((uintptr_t)planes) & 15) == 0, "msm_groupnorm_apply_split: planes must be a 16-byte aligned pointer");
     return groupnorm_apply_impl("msm_groupnorm_apply_split", x, stats, gamma, beta, up, uh, uw, up_batch_stride, nullptr, B, H, W, C, groups, eps,
                                 relu, planes, stream);
+}
+
+extern "C" int msm_groupnorm_apply_f16(const float* x, const double* stats, const float* gamma, const float* beta,
+                                       const float* up, int uh, int uw, int64_t up_batch_stride, void* y_f16, int B, int H, int W,
+                                       int C, int groups, float eps, int relu, void* stream) {
+    MSM_REQUIRE(y_f16 && (((uintptr_t)y_f16) & 15) == 0, "msm_groupnorm_apply_f16: y must be a 16-byte aligned pointer");
+    return groupnorm_apply_impl("msm_groupnorm_apply_f16", x, stats, gamma, beta, up, uh, uw, up_batch_stride, nullptr, B, H, W, C, groups, eps,
+                                relu, (uint16_t*)y_f16, stream, 1);
 }
 
 extern "C" int msm_groupnorm_apply_nchw_f32(const float* x, const double* stats, const float* gamma, const float* beta, float* y,

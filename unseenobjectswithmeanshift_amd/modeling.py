@@ -1142,6 +1142,7 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
         self.lp_operands = "bf16"
         self.lp_input_proj = True           # bf16 plan: the FPN lateral on the bf16 matrix pipe (hi + lo operands, fp32 results; 66 -> 50 us)
         self.lp_conv3x3 = True              # bf16 plan: the FPN output convolution with bf16 operands (csrc/conv3x3.hip); False: the fp32 kernel
+        self.fpn_half_map = True            # f16 operands: the FPN level's GroupNorm output travels to that convolution as IEEE halves (same result bits)
         self.lp_prologue = True             # bf16 plan: the prologue's projections on the bf16 matrix pipe (enc_prologue_hm_kernel)
 
     def _w3(self):
@@ -1368,17 +1369,20 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
         x = features[self.in_features[0]].float().contiguous()
         H, W = int(x.shape[2]), int(x.shape[3])
         split3 = C == 64 and self.precision == "f32_split"       # the 3x3 convolution on the bf16 matrix pipe
+        # "f16" plan: the GroupNorm writes the halves the convolution would round to, the convolution keeps a unit's loads in flight at once
+        half_map = C == 64 and self.precision == "bf16" and self.lp_conv3x3 and self.lp_operands == "f16" and self.fpn_half_map
         if C == 64 and x.shape[1] % 128 == 0 and x.shape[1] <= 384 and (H * W) % 4 == 0 and B * H * W >= 32 * 1024:
             # shallow-K input-projection kernel: the GroupNorm moments come out of its epilogue (no moments pass over lat)
             lp = self._lp_input_proj([x.shape[1]])
             lat, lat_stats = ops.conv1x1_in(x, self._w_lateral(lp), None, stats=fpn_stats[0], stats_cleared=fpn_stats[0] is not None, lp=lp)
             y = ops.groupnorm_tokens(lat, self.adapter_1.norm.weight, self.adapter_1.norm.bias, H, W, groups=32,
                                      up=up_tok, up_hw=up_hw, eps=self.adapter_1.norm.eps, stats=lat_stats, stats_ready=True,
-                                     split_planes=split3)
+                                     split_planes=split3, out_f16=half_map)
         else:
             lat = ops.conv1x1_nchw_to_tokens(x, self.adapter_1.weight.view(C, -1), None)
             y = ops.groupnorm_tokens(lat, self.adapter_1.norm.weight, self.adapter_1.norm.bias, H, W, groups=32,
-                                     up=up_tok, up_hw=up_hw, eps=self.adapter_1.norm.eps, stats=fpn_stats[0], split_planes=split3)
+                                     up=up_tok, up_hw=up_hw, eps=self.adapter_1.norm.eps, stats=fpn_stats[0], split_planes=split3,
+                                     out_f16=half_map)
         y_stats = None
         if C == 64:
             # weight-stationary 3x3 kernel; the moments of layer_1's GroupNorm come out of its epilogue.  f32_split: the

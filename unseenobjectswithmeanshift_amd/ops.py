@@ -255,14 +255,19 @@ def conv3x3_c64(t, w_tap_major, H, W, *, stats=None, stats_cleared=False, bf16=F
     given: accumulated into when ``stats_cleared`` (the caller zeroed it), else zeroed first.  ``bf16``: the low-precision
     mode (bf16 MFMA operands -- weight single, activations hi + lo --, fp32 accumulation and output); ``bf16="f16"``: IEEE-half
     operands, one term each (precision "f16").  ``split``: t is the
-    (3, B, H*W, 64) bf16 planes of groupnorm_tokens(split_planes=True); fp32-accurate results from six bf16 MFMAs per product."""
+    (3, B, H*W, 64) bf16 planes of groupnorm_tokens(split_planes=True); fp32-accurate results from six bf16 MFMAs per product.
+    A float16 ``t`` (groupnorm_tokens(out_f16=True)) is the "f16" form on operands already rounded: the same output bits, the kernel
+    that keeps a unit's loads in flight at once (msm_conv3x3_c64_f16h)."""
+    half_in = t.dtype == torch.float16
+    if half_in and (split or bf16 != "f16"):
+        raise RuntimeError("conv3x3_c64: a float16 map is the input of the bf16=\"f16\" form only")
     if split:
         _c(t, "t", torch.bfloat16)
         if t.dim() != 4 or t.shape[0] != 3:
             raise RuntimeError("conv3x3_c64(split=True) needs the (3, B, H*W, 64) bf16 planes")
         _, B, HW, C = t.shape
     else:
-        _c(t, "t")
+        _c(t, "t", torch.float16 if half_in else torch.float32)
         B, HW, C = t.shape
     _c(w_tap_major, "w"), _c(stats, "stats", torch.float64)
     if C != 64 or tuple(w_tap_major.shape) != (64, 576) or HW != H * W:
@@ -273,7 +278,7 @@ def conv3x3_c64(t, w_tap_major, H, W, *, stats=None, stats_cleared=False, bf16=F
         stats_cleared = False
     elif tuple(stats.shape) != (B, 64, 2):
         raise RuntimeError("stats must be (B, 64, 2) float64")
-    name = "msm_conv3x3_c64_split" if split else ("msm_conv3x3_c64_f16" if bf16 == "f16" else "msm_conv3x3_c64_bf16" if bf16 else "msm_conv3x3_c64_f32")
+    name = "msm_conv3x3_c64_split" if split else "msm_conv3x3_c64_f16h" if half_in else ("msm_conv3x3_c64_f16" if bf16 == "f16" else "msm_conv3x3_c64_bf16" if bf16 else "msm_conv3x3_c64_f32")
     rc = getattr(lib(), name)(_p(t), _p(w_tap_major), _p(out), _p(stats), 1 if stats_cleared else 0, B, H, W, _stream())
     check(rc, name)
     return out, stats
@@ -317,12 +322,15 @@ def layernorm(x, g1, b1, *, parts=None, bias=None, l2norm=False, g2=None, b2=Non
 
 
 def groupnorm_tokens(x, gamma, beta, H, W, groups=32, *, up=None, up_hw=None, relu=False, eps=1e-5, stats=None, stats_ready=False,
-                     split_planes=False):
+                     split_planes=False, out_f16=False):
     """GroupNorm over an NHWC token map x (B, H*W, C); optionally adds the bilinear upsample of `up` (B, uh*uw, C) -- dense
     or a token-range slice of a larger buffer (row stride C, any batch stride) -- and applies ReLU.  ``stats``: a zeroed
     (B, C, 2) float64 scratch to accumulate the moments in (saves the fill launch) -- or, with ``stats_ready``, the finished
     moments of x (the producer of x accumulated them: no moments pass).  ``split_planes``: the result as three bf16 planes
-    (3, B, H*W, C) with y = h + m + l exactly (the activation operand of conv3x3_c64(split=...)) instead of fp32."""
+    (3, B, H*W, C) with y = h + m + l exactly (the activation operand of conv3x3_c64(split=...)) instead of fp32.  ``out_f16``: the
+    result as (B, H*W, C) float16, clamped to the half range (the operand conv3x3_c64(bf16="f16") rounds to, written once)."""
+    if split_planes and out_f16:
+        raise RuntimeError("groupnorm_tokens: split_planes and out_f16 are different output forms")
     _c(x, "x"), _c(gamma, "gamma"), _c(beta, "beta"), _chk(up, "up")
     B, HW, C = x.shape
     if stats_ready:
@@ -331,16 +339,17 @@ def groupnorm_tokens(x, gamma, beta, H, W, groups=32, *, up=None, up_hw=None, re
             raise RuntimeError("stats_ready needs stats (B, C, 2) float64")
     else:
         stats = groupnorm_stats(x, stats)
-    y = torch.empty((3,) + tuple(x.shape), device=x.device, dtype=torch.bfloat16) if split_planes else torch.empty_like(x)
+    y = torch.empty((3,) + tuple(x.shape), device=x.device, dtype=torch.bfloat16) if split_planes else \
+        torch.empty(x.shape, device=x.device, dtype=torch.float16) if out_f16 else torch.empty_like(x)
     uh, uw = (0, 0) if up is None else up_hw
     usb = 0
     if up is not None:
         if tuple(up.shape) != (B, uh * uw, C) or up.stride(2) != 1 or up.stride(1) != C or (B > 1 and up.stride(0) < uh * uw * C):
             raise RuntimeError("up must be (B, uh*uw, C) with strides (>= uh*uw*C, C, 1)")
         usb = up.stride(0) if B > 1 else 0
-    fn = lib().msm_groupnorm_apply_split if split_planes else lib().msm_groupnorm_apply_f32
-    rc = fn(_p(x), _p(stats), _p(gamma), _p(beta), _p(up), uh, uw, usb, _p(y), B, H, W, C, groups, eps, 1 if relu else 0, _stream())
-    check(rc, "msm_groupnorm_apply_split" if split_planes else "msm_groupnorm_apply_f32")
+    name = "msm_groupnorm_apply_split" if split_planes else "msm_groupnorm_apply_f16" if out_f16 else "msm_groupnorm_apply_f32"
+    rc = getattr(lib(), name)(_p(x), _p(stats), _p(gamma), _p(beta), _p(up), uh, uw, usb, _p(y), B, H, W, C, groups, eps, 1 if relu else 0, _stream())
+    check(rc, name)
     return y
 
 
