@@ -59,7 +59,7 @@ extern "C" {
 #define MSM_E_WORKSPACE (-3) /* workspace too small */
 
 const char* msm_last_error_string(void);
-#define MSM_ABI_VERSION 22   /* 22: msm_groupnorm_apply_f16 + msm_conv3x3_c64_f16h (the f16 plan's FPN level on a half token map); 21: msm_dec_heads_mask (the next layer's attention mask as the heads kernel's epilogue), msm_l2_prefetch / msm_dec_set_prefetch, msm_dec_*_bf16x2 (hi + lo weight fragments), MSM_OPT_DEC_TILE32; 20: msm_ucn_embedding_tail; 19: backbone glue (msm_bias_act_nhwc, msm_nhwc_to_nchw_f32); 18: flags argument of msm_attn_mask_pooled (bit 1: IEEE-half operands); 17: msm_f32_to_f16_rows; 16: msm_mask_conv3x3_folded (the UCN mask step with the 3x3 mask_features convolution folded into the query embedding); 15: IEEE-half operand forms of the 16-bit plan (precision "f16": msm_dec_*_f16, msm_encoder_block_hm_fwd ffn_f16, fp16 keys in the low-precision attention); 14: cmat_width argument of the K/V projections (separable position constants), msm_conv3x3_c64_nchw_bf16, msm_encoder_prologue_hm_fwd; 13: flags argument of msm_ms_select_seeds_bf16 (persistent on-chip seeding over the bf16 copy), input projections on the bf16 matrix pipe (msm_conv1x1_in_lp, msm_conv1x1_in_multi_lp); 12: head-major bf16 activations between the encoder kernels of the bf16 plan (msm_encoder_block_hm_fwd, msm_msdeform_attn_enc_lp_fwd, msm_f32_to_f16); 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
+#define MSM_ABI_VERSION 22   /* 22: msm_groupnorm_apply_f16 + msm_conv3x3_c64_f16h (the f16 plan's FPN level on a half token map), msm_conv1x1_in_multi_wide; 21: msm_dec_heads_mask (the next layer's attention mask as the heads kernel's epilogue), msm_l2_prefetch / msm_dec_set_prefetch, msm_dec_*_bf16x2 (hi + lo weight fragments), MSM_OPT_DEC_TILE32; 20: msm_ucn_embedding_tail; 19: backbone glue (msm_bias_act_nhwc, msm_nhwc_to_nchw_f32); 18: flags argument of msm_attn_mask_pooled (bit 1: IEEE-half operands); 17: msm_f32_to_f16_rows; 16: msm_mask_conv3x3_folded (the UCN mask step with the 3x3 mask_features convolution folded into the query embedding); 15: IEEE-half operand forms of the 16-bit plan (precision "f16": msm_dec_*_f16, msm_encoder_block_hm_fwd ffn_f16, fp16 keys in the low-precision attention); 14: cmat_width argument of the K/V projections (separable position constants), msm_conv3x3_c64_nchw_bf16, msm_encoder_prologue_hm_fwd; 13: flags argument of msm_ms_select_seeds_bf16 (persistent on-chip seeding over the bf16 copy), input projections on the bf16 matrix pipe (msm_conv1x1_in_lp, msm_conv1x1_in_multi_lp); 12: head-major bf16 activations between the encoder kernels of the bf16 plan (msm_encoder_block_hm_fwd, msm_msdeform_attn_enc_lp_fwd, msm_f32_to_f16); 11: mean-shift hill climb and the 3x3 FPN convolution with fp32 results on the bf16 matrix pipe (msm_ms_hill_climb_split, msm_groupnorm_apply_split + msm_conv3x3_c64_split), msm_topk_class_scores_gather, zero_buf arguments of msm_pool_mask_taps; 10: bf16-operand 3x3 convolution (msm_conv3x3_c64_bf16), attention masks at key resolution (msm_pool_mask_taps, msm_attn_mask_pooled); 9: float64 MSDeformAttn entry points (_f64), any channel count; 8: bf16 decoder tails, low-precision attention, bf16 K/V projection, split-fp32 encoder block; 7: msm_set_option replaces the environment switches; fused K/V attention, bf16 and backward entry points; 6: post-process workspace size; 5: embed stride / per-query bias of the mask step; 2: flags argument of the mask step, head-major value / packed-weight entry points; 3: msm_label_stats; 4: padded-frame post-process, GroupNorm moment / stride arguments, input-projection, prologue, 3x3 and batched K/V entry points */
 int msm_abi_version(void);
 
 /* Kernel-selection overrides for tools/ and tests/ (NOT read on the product path: every option defaults to
@@ -696,6 +696,13 @@ int msm_conv1x1_in_lp(const float* x, const void* w_packed, const float* bias, f
 int msm_conv1x1_in_multi_lp(int n_levels, const float* const* x, const void* const* w_packed, const float* const* bias,
                             const int32_t* Cin, const int32_t* HW, float* out, int64_t out_batch_stride, double* stats,
                             int stats_cleared, int B, void* stream);
+/* msm_conv1x1_in_multi_lp's arithmetic with the packed weight broadcast through LDS (round 6): an eight-wave workgroup covers 8 / KW adjacent
+ * 64-pixel tiles x KW slices of K (KW = Cin / the shallowest level's Cin, <= 4) and the 8-KiB packed weight of each 32-deep K group arrives
+ * once per workgroup by LDS-DMA -- the deep levels of the 16-bit plans at batch sizes that give every CU a workgroup (the per-tile weight
+ * re-reads from L2 bound the _lp form).  Same arguments; K slices are summed in a fixed order. */
+int msm_conv1x1_in_multi_wide(int n_levels, const float* const* x, const void* const* w_packed, const float* const* bias,
+                              const int32_t* Cin, const int32_t* HW, float* out, int64_t out_batch_stride, double* stats,
+                              int stats_cleared, int B, void* stream);
 
 /* The decoder's attention masks at the resolution they are used at (meanshiftformer_transformer_decoder.py:668-680; csrc/attn_mask.hip).
  * interpolate(einsum(e, F), size, bilinear, align_corners=False) = einsum(e, interpolate(F)): the two act on different axes.

@@ -1566,6 +1566,40 @@ def test_conv1x1_in_lp_vs_fp64(B, Cin, H, W):
         ops().conv1x1_in(torch.zeros(1, 128, 4, 4, device=DEV), torch.zeros(128 * 128, device=DEV, dtype=torch.bfloat16), lp=True)
 
 
+@pytest.mark.parametrize("B,levels", [(8, ((2048, 15, 20), (1024, 30, 40), (512, 60, 80))), (3, ((2048, 4, 6), (1024, 8, 12), (512, 16, 24))),
+                                      (2, ((512, 17, 20),)), (5, ((1024, 7, 12), (256, 14, 24))), (1, ((256, 2, 2), (256, 9, 8)))])
+def test_conv1x1_in_multi_wide_vs_fp64(B, levels):
+    """msm_conv1x1_in_multi_wide (round 6: the deep input projections of the 16-bit plans with the packed weight broadcast through LDS --
+    eight-wave workgroups over adjacent 64-pixel tiles x K slices, LDS-DMA ring, counted waits): against the fp64 convolution to the lp
+    form's tolerance (the same hi + lo operands), moments of its own output, ragged tiles (300 pixels), one / two / four K slices, biases
+    present and absent, a token-range view of a larger buffer, and run twice (fixed-order sums: the same bits)."""
+    xs = [rnd(B, c, h, w, seed=20 + i) for i, (c, h, w) in enumerate(levels)]
+    w32 = [rnd(64, x.shape[1], seed=30 + i, scale=x.shape[1] ** -0.5) for i, x in enumerate(xs)]
+    bs = [rnd(64, seed=40 + i) if i != 1 else None for i in range(len(xs))]
+    ws = [ops().pack_conv_in_weight_lp(w.to(DEV)) for w in w32]
+    S = sum(x.shape[2] * x.shape[3] for x in xs)
+    buf = torch.full((B, S + 24, 64), 7.0, device=DEV)
+    out = buf[:, 8:8 + S]
+    st = torch.ones(len(xs), B, 64, 2, device=DEV, dtype=torch.float64)
+    xd, bd = [x.to(DEV) for x in xs], [None if b is None else b.to(DEV) for b in bs]
+    ops().conv1x1_in_multi(xd, ws, bd, out, st, stats_cleared=True, lp="wide")
+    assert float(buf[:, :8].min()) == 7.0 == float(buf[:, 8 + S:].max())
+    o = 0
+    for l, x in enumerate(xs):
+        hw = x.shape[2] * x.shape[3]
+        ref = torch.einsum("bchw,oc->bhwo", x.double(), w32[l].double()).reshape(B, hw, 64) + (0 if bs[l] is None else bs[l].double())
+        got = out[:, o:o + hw]
+        closed(got, ref, rtol=6e-5, atol=6e-5)
+        assert float((got.double().cpu() - ref).abs().mean()) <= 1e-5
+        mom = torch.stack([got.double().sum(1), (got.double() ** 2).sum(1)], -1).cpu()
+        torch.testing.assert_close(st[l].cpu(), mom + 1.0, rtol=1e-5, atol=1e-4)
+        o += hw
+    first = out.clone()
+    st2 = torch.zeros_like(st)
+    ops().conv1x1_in_multi(xd, ws, bd, out, st2, stats_cleared=True, lp="wide")
+    assert torch.equal(out, first)
+
+
 def test_conv1x1_in_multi_lp_equals_single_launches():
     B = 3
     xs = [rnd(B, c, h, w, seed=20 + i).to(DEV) for i, (c, h, w) in enumerate(((2048, 4, 6), (1024, 8, 12), (512, 16, 24)))]

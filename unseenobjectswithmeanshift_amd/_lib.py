@@ -132,6 +132,7 @@ _SIGNATURES = {
     "msm_conv1x1_in_f32": (c_i, [c_f, c_f, c_f, c_f, c_l, c_p, c_i, c_i, c_i, c_i, c_p]),
     "msm_conv1x1_in_multi_f32": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_l, c_p, c_i, c_i, c_p]),
     "msm_conv1x1_in_multi_lp": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_l, c_p, c_i, c_i, c_p]),
+    "msm_conv1x1_in_multi_wide": (c_i, [c_i, c_p, c_p, c_p, c_p, c_p, c_f, c_l, c_p, c_i, c_i, c_p]),
     "msm_conv1x1_in_lp": (c_i, [c_f, c_p, c_f, c_f, c_l, c_p, c_i, c_i, c_i, c_i, c_p]),
     "msm_conv3x3_c64_f32": (c_i, [c_f, c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p]),
     "msm_conv3x3_c64_bf16": (c_i, [c_f, c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p]),

@@ -649,6 +649,241 @@ __global__ __launch_bounds__(CL_W * 64, 2) void conv_in_lp_multi_kernel(ConvInLp
     }
 }
 
+
+// ---- the deep levels on the bf16 matrix pipe with the weight broadcast through LDS (round 6: msm_conv1x1_in_multi_wide) ------------
+// What bounds conv_in_lp_stream on the deep levels is its weight traffic (k31): every wave re-reads its weight fragments from L2 for
+// every 64-pixel tile -- as many bytes as x -- and thousands of waves ask for the same lines at the same moment.  Here an eight-wave
+// workgroup covers PW = 8 / KW adjacent 64-pixel tiles x KW slices of K (KW = Cin / the shallowest level's Cin, so that every wave of
+// every level walks the same K depth: 131 KB of x per wave at the shipped sizes, one round of workgroups), and the packed weight of a
+// 32-deep K group (8 KiB per K slice) arrives ONCE per workgroup by LDS-DMA, in a ring of four stages three groups ahead; the waves
+// step through K together (one barrier per group) and read their A fragments from LDS.  x: a ring of two K groups per wave (16
+// 16-byte loads in flight per lane).  Waits are counted: loads return in order, a wave issues KW DMA pieces + 8 x loads per group,
+// and the x group it is about to use is followed by 8 + KW younger loads (sticky re-reads past the end keep the count
+// constant).  K splits meet in LDS at the end (fixed order: slice 0, 1, ...), the moments leave as one double atomic per
+// (workgroup, channel, moment).  Arithmetic as conv_in_lp_stream: x = hi + lo in registers, three bf16 MFMAs per product.
+constexpr int CW_W = 8;                       // waves per workgroup
+constexpr int CW_NBUF = 4;                    // ring stages (a stage is requested three groups ahead)
+constexpr int CW_D = 2;                       // x groups in flight per wave (16 16-byte loads per lane; three measured slower, four spill)
+constexpr int CW_KWMAX = 4;
+constexpr int CW_STAGE = CW_KWMAX * 8192;     // bytes of a stage: one 8-KiB packed K group per K slice
+
+struct ConvInWideLevels {
+    int n;
+    const float* x[CI_MAXL];
+    const uint16_t* w[CI_MAXL];
+    const float* bias[CI_MAXL];
+    float* out[CI_MAXL];
+    double* stats[CI_MAXL];
+    int Cin[CI_MAXL], HW[CI_MAXL], kw[CI_MAXL] /* K slices: 1, 2, 4 */, chunks[CI_MAXL] /* workgroups per image */;
+    int first[CI_MAXL + 1];
+};
+
+__device__ __forceinline__ void cw_glds16(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+
+template <int KW>
+__device__ __forceinline__ void conv_in_wide_body(const float* __restrict__ x, const uint16_t* __restrict__ w, const float* __restrict__ bias,
+                                                  float* __restrict__ out, int64_t out_sb, double* __restrict__ stats, int Cin, int HW, int b,
+                                                  int chunk, char* lds) {
+    constexpr int PW = CW_W / KW;
+    constexpr int NT = 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    const int pt = wave % PW, ks = wave / PW;
+    const int px0 = (chunk * PW + pt) * (16 * NT);
+    const int groups = Cin / KW / 32;                               // K groups per slice (>= 2)
+    const int g0 = ks * groups;
+    auto uniform_ptr = [](const void* p) {
+        const uint64_t u = (uint64_t)p;
+        return (void*)(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                       (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u));
+    };
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(x + (int64_t)b * Cin * HW), 0, Cin * HW * 4, 0x00020000);
+    const void* wb = uniform_ptr(w);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned xo = 4u * (unsigned)(lq * 8 * HW + min(px0 + NT * lj, HW - NT));      // (a tile past the map re-reads the last pixels: nothing is stored)
+    u32x4 xf[CW_D][8];                                              // raw 16-byte results: component nt of row e = pixel block nt
+    int lg = 0;                                                     // group of the next x load / DMA request (sticky at the last one)
+    int dg = 0;
+    auto load_x = [&](u32x4 (&xv)[8]) {
+        const unsigned gg = (unsigned)(g0 + lg);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] = __builtin_amdgcn_raw_buffer_load_b128(xr, xo, (gg * 32 + e) * (unsigned)HW * 4u, 0);
+        lg = lg + 1 < groups ? lg + 1 : lg;
+    };
+    auto request = [&](int stage) {                                 // the packed K group dg of every slice -> ring stage `stage`
+#pragma unroll
+        for (int s = 0; s < KW; ++s)
+            cw_glds16(wb, (unsigned)(s * groups + dg) * 8192u + (unsigned)tid * 16u, (unsigned)(stage * CW_STAGE + s * 8192 + wave * 1024));
+        dg = dg + 1 < groups ? dg + 1 : dg;
+    };
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](const char* stage, const u32x4 (&xv)[8], bool live) {
+        u32x4 wv[4][2];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const u32x4 t = *reinterpret_cast<const u32x4*>(stage + ks * 8192 + (mt * 2 + pl) * 1024 + lane * 16);
+                wv[mt][pl] = live ? t : u32x4{0u, 0u, 0u, 0u};       // (a padding round past the last K group adds zeros)
+            }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            auto f = [&](int e) { return __uint_as_float(xv[e][nt]); };
+            const Split4 s0 = split4(f(0), f(1), f(2), f(3)), s1 = split4(f(4), f(5), f(6), f(7));
+            const bf16x8 xh = cat8(s0.hi, s1.hi), xl = cat8(s0.lo, s1.lo);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = mfma_bf16k32(__builtin_bit_cast(bf16x8, wv[mt][1]), xh, acc[mt][nt]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = mfma_bf16k32(__builtin_bit_cast(bf16x8, wv[mt][0]), xl, acc[mt][nt]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = mfma_bf16k32(__builtin_bit_cast(bf16x8, wv[mt][0]), xh, acc[mt][nt]);
+        }
+    };
+    // issue order: DMA(0), DMA(1), x(0), DMA(2), x(1); then per group g: [wait, barrier, fragments, MFMAs] DMA(g + 3), x(g + 2).  The x
+    // group about to be used is followed by DMA(g + 2), x(g + 1): KW + 8 younger loads (its stage is older still).  Cursors are sticky
+    // past the last group (redundant re-reads keep the count constant).  No branch around loads in the loop: with loads on a conditional
+    // path hipcc waits for ALL loads at the join.
+    request(0);
+    request(1);
+    load_x(xf[0]);
+    request(2);
+    load_x(xf[1]);
+    int st = 0;                                                     // ring stage of the group in use
+#pragma unroll 1
+    for (int r = 0; r < groups / CW_D; ++r) {                       // (groups is even: see the launcher)
+#pragma unroll
+        for (int d = 0; d < CW_D; ++d) {
+            if constexpr (KW == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else if constexpr (KW == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                           // every wave's pieces of this stage have landed; everyone is done with the stage before it
+            const int nst = st + 3 >= CW_NBUF ? st + 3 - CW_NBUF : st + 3;
+            mma(lds + st * CW_STAGE, xf[d], true);
+            __builtin_amdgcn_sched_barrier(0);                      // (the reloads stay behind the MFMAs that read the old values: no copies at the back edge)
+            request(nst);
+            load_x(xf[d]);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's fragment reads are done before it reaches the next barrier
+            st = st + 1 == CW_NBUF ? 0 : st + 1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                                // the ring is free: reduction scratch from here on
+
+    float sm[4][4], sq[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sm[i][r] = sq[i][r] = 0.f;
+    auto finish = [&](const f32x4& v, int mt, int nt) {
+        const int ch = mt * 16 + lq * 4;
+        const int px = px0 + NT * lj + nt;                 // pixel block nt holds pixels px0 + NT*n + nt
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) bv = *reinterpret_cast<const float4*>(bias + ch);
+        const float v0 = v[0] + bv.x, v1 = v[1] + bv.y, v2 = v[2] + bv.z, v3 = v[3] + bv.w;
+        if (px < HW) {
+            *reinterpret_cast<float4*>(out + (int64_t)b * out_sb + (int64_t)px * CI_O + ch) = make_float4(v0, v1, v2, v3);
+            sm[mt][0] += v0; sm[mt][1] += v1; sm[mt][2] += v2; sm[mt][3] += v3;
+            sq[mt][0] += v0 * v0; sq[mt][1] += v1 * v1; sq[mt][2] += v2 * v2; sq[mt][3] += v3 * v3;
+        }
+    };
+    float4* red = reinterpret_cast<float4*>(lds);                   // [wave][mt][2 pixel blocks][64 lanes] per half: 64 KiB
+    if constexpr (KW == 1) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) finish(acc[mt][nt], mt, nt);
+    } else {
+        // the KW partial tiles of a pixel tile meet in LDS, two pixel blocks at a time; wave (pt, ks) finishes channel blocks ks, ks + KW, ..
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h) __syncthreads();
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int n2 = 0; n2 < 2; ++n2) {
+                    const f32x4 v = acc[mt][h * 2 + n2];
+                    red[((wave * 4 + mt) * 2 + n2) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            __syncthreads();
+#pragma unroll
+            for (int mi = 0; mi < 4 / KW; ++mi) {
+                const int mt = ks + mi * KW;
+#pragma unroll
+                for (int n2 = 0; n2 < 2; ++n2) {
+                    f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < KW; ++s) {
+                        const float4 v = red[(((s * PW + pt) * 4 + mt) * 2 + n2) * 64 + lane];
+                        t += f32x4{v.x, v.y, v.z, v.w};
+                    }
+                    // (mt is not a compile-time constant here: the moments go through a switch-free table below)
+#pragma unroll
+                    for (int m2 = 0; m2 < 4; ++m2)
+                        if (m2 == mt) finish(t, m2, h * 2 + n2);
+                }
+            }
+        }
+    }
+    if (!stats) return;
+    __syncthreads();
+    float* stt = reinterpret_cast<float*>(lds);                     // [CW_W][64 ch][2]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sm[i][r] += wave_xor_dpp1(sm[i][r]);
+            sq[i][r] += wave_xor_dpp1(sq[i][r]);
+            sm[i][r] += wave_xor_dpp2(sm[i][r]);
+            sq[i][r] += wave_xor_dpp2(sq[i][r]);
+            sm[i][r] += wave_xor_dpp4(sm[i][r]);
+            sq[i][r] += wave_xor_dpp4(sq[i][r]);
+            sm[i][r] += wave_xor_dpp8(sm[i][r]);
+            sq[i][r] += wave_xor_dpp8(sq[i][r]);
+        }
+    if (lj == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                stt[(wave * CI_O + mt * 16 + lq * 4 + r) * 2 + 0] = sm[mt][r];
+                stt[(wave * CI_O + mt * 16 + lq * 4 + r) * 2 + 1] = sq[mt][r];
+            }
+    }
+    __syncthreads();
+    if (tid < CI_O * 2) {
+        double v = 0.0;
+#pragma unroll
+        for (int s_ = 0; s_ < CW_W; ++s_) v += (double)stt[s_ * CI_O * 2 + tid];
+        atomicAdd(stats + (int64_t)b * CI_O * 2 + tid, v);
+    }
+}
+
+__global__ __launch_bounds__(CW_W * 64, 1) void conv_in_wide_kernel(ConvInWideLevels lv, int64_t out_sb) {
+    extern __shared__ __attribute__((aligned(16))) char cw_lds[];
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < CI_MAXL; ++i) l += (i < lv.n && (int)blockIdx.x >= lv.first[i]) ? 1 : 0;
+    const int local = (int)blockIdx.x - lv.first[l];
+    const int b = local / lv.chunks[l], c = local - b * lv.chunks[l];
+    switch (lv.kw[l]) {
+        case 1: conv_in_wide_body<1>(lv.x[l], lv.w[l], lv.bias[l], lv.out[l], out_sb, lv.stats[l], lv.Cin[l], lv.HW[l], b, c, cw_lds); break;
+        case 2: conv_in_wide_body<2>(lv.x[l], lv.w[l], lv.bias[l], lv.out[l], out_sb, lv.stats[l], lv.Cin[l], lv.HW[l], b, c, cw_lds); break;
+        default: conv_in_wide_body<4>(lv.x[l], lv.w[l], lv.bias[l], lv.out[l], out_sb, lv.stats[l], lv.Cin[l], lv.HW[l], b, c, cw_lds); break;
+    }
+}
+
 }  // namespace msm
 
 using namespace msm;
@@ -866,5 +1101,73 @@ extern "C" int msm_conv1x1_in_multi_lp(int n_levels, const float* const* x, cons
     MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv_in_lp_multi_kernel, lds));
     hipLaunchKernelGGL(conv_in_lp_multi_kernel, dim3(wg), dim3(CL_W * 64), lds, st, lv, out_batch_stride);
     MSM_CHECK_LAUNCH("msm_conv1x1_in_multi_lp");
+    return MSM_OK;
+}
+
+extern "C" int msm_conv1x1_in_multi_wide(int n_levels, const float* const* x, const void* const* w_packed, const float* const* bias,
+                                         const int32_t* Cin, const int32_t* HW, float* out, int64_t out_batch_stride, double* stats,
+                                         int stats_cleared, int B, void* stream) {
+    MSM_REQUIRE(n_levels >= 1 && n_levels <= CI_MAXL && x && w_packed && bias && Cin && HW && out,
+                "msm_conv1x1_in_multi_wide: bad arguments (1..%d levels)", CI_MAXL);
+    hipStream_t st = (hipStream_t)stream;
+    ConvInWideLevels lv;
+    lv.n = n_levels;
+    int cmin = Cin[0];
+    for (int l = 1; l < n_levels; ++l) cmin = min(cmin, Cin[l]);
+    // K slices per level: every wave walks about the shallowest level's K (a power of two, at most CW_KWMAX, whole rounds of CW_D groups per
+    // slice) -- then, while the launch stays under 160 workgroups (one per CU: 204 registers), the level with the most pixels is split further
+    // (measured at B = 8, 640x480: slices 4 / 2 / 1 = 144 workgroups 45 us, 4 / 4 / 2 = 256 workgroups 49 us; res3 on its own 35 -> 26 us)
+    int kws[CI_MAXL];
+    auto can_double = [&](int l) { return kws[l] < CW_KWMAX && Cin[l] % (2 * kws[l] * 64) == 0; };      // (a slice: at least two 32-deep groups)
+    auto wgs_of = [&](int l, int kw) { return cdiv(HW[l], 64 * (CW_W / kw)) * B; };
+    int total = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        kws[l] = 1;
+        while (can_double(l) && Cin[l] / (2 * kws[l]) >= cmin) kws[l] *= 2;
+        if (const int o_ = opt(MSM_OPT_CONVIN_NT); (o_ == 1 || o_ == 2 || o_ == 4) && Cin[l] % (o_ * 64) == 0) kws[l] = o_;      // (tuning: the same K split everywhere)
+        if (const int o_ = opt(MSM_OPT_CONVIN_NT); o_ >= 100) {                   // (tuning: one decimal digit per level, e.g. 421)
+            const int dgt = l == 0 ? o_ / 100 : (l == 1 ? o_ / 10 % 10 : o_ % 10);
+            if ((dgt == 1 || dgt == 2 || dgt == 4) && Cin[l] % (dgt * 64) == 0) kws[l] = dgt;
+        }
+        total += wgs_of(l, kws[l]);
+    }
+    for (bool again = opt(MSM_OPT_CONVIN_NT) == MSM_OPT_AUTO; again;) {
+        again = false;
+        int best = -1;
+        for (int l = 0; l < n_levels; ++l)
+            if (can_double(l) && total - wgs_of(l, kws[l]) + wgs_of(l, 2 * kws[l]) <= 160 && (best < 0 || HW[l] > HW[best])) best = l;
+        if (best >= 0) {
+            total += wgs_of(best, 2 * kws[best]) - wgs_of(best, kws[best]);
+            kws[best] *= 2;
+            again = true;
+        }
+    }
+    int64_t tok = 0;
+    int wg = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        float* o = out + tok * CI_O;
+        double* s = stats ? stats + (size_t)l * B * CI_O * 2 : nullptr;
+        if (int rc = conv_in_lp_check("msm_conv1x1_in_multi_wide", x[l], w_packed[l], bias[l], o, s, B, Cin[l], HW[l], out_batch_stride)) return rc;
+        const int kw = kws[l];
+        lv.x[l] = x[l]; lv.w[l] = (const uint16_t*)w_packed[l]; lv.bias[l] = bias[l]; lv.out[l] = o; lv.stats[l] = s;
+        lv.Cin[l] = Cin[l]; lv.HW[l] = HW[l]; lv.kw[l] = kw;
+        lv.chunks[l] = cdiv(HW[l], 64 * (CW_W / kw));
+        lv.first[l] = wg;
+        wg += lv.chunks[l] * B;
+        tok += HW[l];
+    }
+    for (int l = n_levels; l <= CI_MAXL; ++l) lv.first[l] = wg;
+    for (int l = n_levels; l < CI_MAXL; ++l) {
+        lv.x[l] = nullptr; lv.w[l] = nullptr; lv.bias[l] = nullptr; lv.out[l] = nullptr; lv.stats[l] = nullptr;
+        lv.Cin[l] = lv.HW[l] = 0;
+        lv.kw[l] = lv.chunks[l] = 1;
+    }
+    MSM_REQUIRE(out_batch_stride >= tok * CI_O, "msm_conv1x1_in_multi_wide: output batch stride smaller than the %lld tokens of an image",
+                (long long)tok);
+    if (stats && !stats_cleared) MSM_CHECK_HIP(hipMemsetAsync(stats, 0, sizeof(double) * 2 * CI_O * (size_t)B * n_levels, st));
+    const size_t lds = (size_t)CW_NBUF * CW_STAGE;
+    MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv_in_wide_kernel, lds));
+    hipLaunchKernelGGL(conv_in_wide_kernel, dim3(wg), dim3(CW_W * 64), lds, st, lv, out_batch_stride);
+    MSM_CHECK_LAUNCH("msm_conv1x1_in_multi_wide");
     return MSM_OK;
 }

@@ -1140,7 +1140,7 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
         # operand format of the low-precision plan's FFN stages (head.set_precision("bf16" / "f16")): "f16" = IEEE-half W1 / W2 /
         # activations on v_mfma_f32_16x16x32_f16 (8x smaller roundings at the same rate; csrc/enc_lp.hip, template F16)
         self.lp_operands = "bf16"
-        self.lp_input_proj = True           # bf16 plan: the FPN lateral on the bf16 matrix pipe (hi + lo operands, fp32 results; 66 -> 50 us)
+        self.lp_input_proj = "deep"         # bf16 plan: the FPN lateral on the bf16 matrix pipe (hi + lo operands, fp32 results; 66 -> 50 us); "deep": the three deep levels too (weight through LDS)
         self.lp_conv3x3 = True              # bf16 plan: the FPN output convolution with bf16 operands (csrc/conv3x3.hip); False: the fp32 kernel
         self.fpn_half_map = True            # f16 operands: the FPN level's GroupNorm output travels to that convolution as IEEE halves (same result bits)
         self.lp_prologue = True             # bf16 plan: the prologue's projections on the bf16 matrix pipe (enc_prologue_hm_kernel)
@@ -1269,7 +1269,10 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
             # the bf16 plan's prologue (hi + lo bf16 fragment blocks): packed when that plan's geometry holds
             hm = ops.pack_encoder_prologue_hm(a0.value_proj.weight, wp, a0.value_proj.bias, bp) \
                 if (C == 64 and tuple(wp.shape) == (288, 64) and a0.n_heads == 8) else None
-            self._front = (key, wpk, gnp, stream, small, wp.shape[0], hm)
+            # the 16-bit plans' deep levels: hi + lo bf16 fragment order (ops.conv1x1_in_multi(lp="wide")), packed when the shapes allow
+            wlp = [ops.pack_conv_in_weight_lp(m[0].weight.view(C, -1)) for m in self.input_proj] \
+                if C == 64 and all(m[0].weight.shape[1] % 256 == 0 for m in self.input_proj) else None
+            self._front = (key, wpk, gnp, stream, small, wp.shape[0], hm, wlp)
         return self._front[1:]
 
     def _encode(self, features):
@@ -1292,13 +1295,18 @@ class MSDeformAttnPixelDecoder(PlanAttributes, nn.Module):
         if front:
             # input projections straight into the concatenated token buffer with their GroupNorm moments as a
             # by-product, then ONE prologue pass: GroupNorm, layer 0's value projection and sampling projections
-            wpk, gnp, pstream, psmall, pw, phm = self._packed_front(dev)
+            wpk, gnp, pstream, psmall, pw, phm, wlp = self._packed_front(dev)
             src = torch.empty((B, S_tok, C), device=dev, dtype=torch.float32)
             stats = torch.zeros((len(levels) + 2, B, C, 2), device=dev, dtype=torch.float64)      # + the two FPN GroupNorms
             fpn_stats = (stats[len(levels)], stats[len(levels) + 1])
             # (fp32 MFMA kernel in every plan: on the bf16 pipe these three deep-K levels are bound by their weight traffic at the same
             # 66 us -- DESIGN.md section 4a, k31; the bf16 plan moves the shallow lateral, whose weight fits LDS)
-            ops.conv1x1_in_multi(levels, wpk, [m[0].bias for m in self.input_proj], src, stats[:len(levels)], stats_cleared=True)
+            # round 6: with the packed weight broadcast through LDS (eight-wave workgroups over adjacent tiles x K slices) the bf16 pipe wins
+            # where that shape gives every CU a workgroup -- lp_input_proj = "deep"; smaller batches keep the fp32 kernel
+            if self.precision == "bf16" and self.lp_input_proj == "deep" and wlp is not None and B * S_tok >= 16384:
+                ops.conv1x1_in_multi(levels, wlp, [m[0].bias for m in self.input_proj], src, stats[:len(levels)], stats_cleared=True, lp="wide")
+            else:
+                ops.conv1x1_in_multi(levels, wpk, [m[0].bias for m in self.input_proj], src, stats[:len(levels)], stats_cleared=True)
             a0 = layers[0].self_attn
             bounds = [0]
             for h, w in shapes:

@@ -152,7 +152,9 @@ def conv1x1_in(x, w_packed, bias=None, *, out=None, stats=None, stats_cleared=Fa
 
 
 def conv1x1_in_multi(xs, ws_packed, biases, out, stats, stats_cleared=False, lp=False):
-    """conv1x1_in for up to four levels in one launch (``lp``: ws_packed from pack_conv_in_weight_lp, the bf16 matrix pipe).  xs: list of (B, Cin_l, H_l, W_l) NCHW maps (deepest Cin first),
+    """conv1x1_in for up to four levels in one launch (``lp``: ws_packed from pack_conv_in_weight_lp, the bf16 matrix pipe; ``lp="wide"``: the
+    same arithmetic with the weight broadcast through LDS -- eight-wave workgroups over adjacent 64-pixel tiles x K slices, for batches that
+    fill the chip that way (msm_conv1x1_in_multi_wide)).  xs: list of (B, Cin_l, H_l, W_l) NCHW maps (deepest Cin first),
     ws_packed / biases: per level (a bias may be None), out: (B, sum H_l*W_l, 64) token buffer or a token-range view of a larger
     one (level l fills its token range), stats: (L, B, 64, 2) float64 moments (accumulated into when ``stats_cleared``)."""
     L = len(xs)
@@ -171,11 +173,12 @@ def conv1x1_in_multi(xs, ws_packed, biases, out, stats, stats_cleared=False, lp=
     xa, wa = vp(*[x.data_ptr() for x in xs]), vp(*[w.data_ptr() for w in ws_packed])
     ba = vp(*[0 if b is None else b.data_ptr() for b in biases])
     cin, hw = ia(*[x.shape[1] for x in xs]), ia(*[x.shape[2] * x.shape[3] for x in xs])
-    fn = lib().msm_conv1x1_in_multi_lp if lp else lib().msm_conv1x1_in_multi_f32
+    name = "msm_conv1x1_in_multi_wide" if lp == "wide" else "msm_conv1x1_in_multi_lp" if lp else "msm_conv1x1_in_multi_f32"
+    fn = getattr(lib(), name)
     rc = fn(L, ctypes.cast(xa, ctypes.c_void_p), ctypes.cast(wa, ctypes.c_void_p), ctypes.cast(ba, ctypes.c_void_p),
             ctypes.cast(cin, ctypes.c_void_p), ctypes.cast(hw, ctypes.c_void_p), _p(out), out.stride(0) if B > 1 else S * 64, _p(stats),
             1 if stats_cleared else 0, B, _stream())
-    check(rc, "msm_conv1x1_in_multi_lp" if lp else "msm_conv1x1_in_multi_f32")
+    check(rc, name)
     return out, stats
 
 
