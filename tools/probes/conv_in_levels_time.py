@@ -71,3 +71,14 @@ if hasattr(ops.lib(), "msm_conv1x1_in_multi_wide"):
             _lib.set_option("CONVIN_NT", cfg)
             t = timed(lambda i: ops.conv1x1_in_multi(xs[i], wl, bs, out, st, stats_cleared=True, lp="wide"), n=100)
             print(f"wide multi, K slices {cfg}: {t:.1f} us")
+    # the FPN lateral (res2: 256 channels, 120x160) through the same kernel, against its own lp form
+    _lib.set_option("CONVIN_NT", _lib.OPT_AUTO)
+    xl = [torch.randn(B, 256, 120, 160, generator=g).to(dev) for _ in range(3)]
+    w2 = torch.randn(64, 256, generator=g).to(dev) / 16
+    w2l = ops.pack_conv_in_weight_lp(w2)
+    o2 = torch.empty(B, 19200, 64, device=dev)
+    s2 = torch.zeros(1, B, 64, 2, device=dev, dtype=torch.float64)
+    print(f"lateral, lp form: {timed(lambda i: ops.conv1x1_in(xl[i % 3], w2l, None, out=o2, stats=s2[0], stats_cleared=True, lp=True)):.1f} us")
+    for cfg in (_lib.OPT_AUTO, 1, 2, 4):
+        _lib.set_option("CONVIN_NT", cfg)
+        print(f"lateral, wide form, K slices {cfg}: {timed(lambda i: ops.conv1x1_in_multi([xl[i % 3]], [w2l], [None], o2, s2, stats_cleared=True, lp='wide')):.1f} us")

@@ -9,6 +9,7 @@ import shutil
 import sys
 
 prof, tag = sys.argv[1], sys.argv[2]
+FIRST = ("conv_in_multi_kernel", "conv_in_lp_multi_kernel", "conv_in_wide_kernel")      # the first kernel of a pass, whichever plan
 os.makedirs("profiles", exist_ok=True)
 stats = glob.glob(os.path.join(prof, "*kernel_stats.csv"))[0]
 shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
@@ -24,7 +25,7 @@ with open(f"profiles/{tag}_kernel_stats.md", "w") as f:
     for r in rows[:30]:
         f.write(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['TotalDurationNs']) / 1e6:.2f} | "
                 f"{100 * float(r['TotalDurationNs']) / tot:.1f} |\n")
-    npass = next((int(r["Calls"]) for r in rows if "conv_in_multi_kernel" in r["Name"] or "conv_in_lp_multi_kernel" in r["Name"]), 1)
+    npass = next((int(r["Calls"]) for r in rows if any(k in r["Name"] for k in FIRST)), 1)
     f.write(f"\ntotal GPU kernel time {tot / 1e6:.1f} ms over {npass} passes = {tot / npass / 1e6:.2f} ms per pass of 8 images\n")
 # One steady-state pass of the hot path, cut out of the kernel trace: the run's --stats table above mixes warm-up, the roofline
 # legs and the timed passes; here the trace is segmented at the first kernel of a pass (conv_in_multi_kernel), the segments of the
@@ -32,7 +33,7 @@ with open(f"profiles/{tag}_kernel_stats.md", "w") as f:
 trace = glob.glob(os.path.join(prof, "*kernel_trace.csv"))
 if trace:
     tr = sorted(csv.DictReader(open(trace[0])), key=lambda r: int(r["Start_Timestamp"]))
-    cut = [i for i, r in enumerate(tr) if "conv_in_multi_kernel" in r["Kernel_Name"] or "conv_in_lp_multi_kernel" in r["Kernel_Name"]]
+    cut = [i for i, r in enumerate(tr) if any(k in r["Kernel_Name"] for k in FIRST)]
     segs = [tr[a:b] for a, b in zip(cut, cut[1:])]
     if segs:
         modal = collections.Counter(len(x) for x in segs).most_common(1)[0][0]
