@@ -1707,7 +1707,7 @@ def test_conv3x3_c64_vs_fp64(B, H, W):
     torch.testing.assert_close(st2.cpu(), mom + 1.0, rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 12, 16), (1, 5, 37), (3, 30, 40)])
+@pytest.mark.parametrize("B,H,W", [(2, 12, 16), (1, 5, 37), (3, 30, 40), (8, 120, 160), (40, 7, 33)])
 def test_conv3x3_c64_bf16_mode(B, H, W):
     """msm_conv3x3_c64_bf16 (low-precision mode: weight rounded to bf16, activations as hi + lo operands, fp32 accumulation)
     against the fp64 convolution WITH THE SAME ROUNDED WEIGHT to the fp32 kernel's tolerance -- the activations' hi + lo pair
@@ -1723,6 +1723,13 @@ def test_conv3x3_c64_bf16_mode(B, H, W):
     assert err < 2e-2 * float(ref.abs().max()), err
     mom = torch.stack([out.double().sum(1), (out.double() ** 2).sum(1)], -1).cpu()
     torch.testing.assert_close(st.cpu(), mom, rtol=1e-5, atol=1e-4)
+    # (round 6: maps at least 32 pixels wide take the one-row-per-unit kernel -- rows requested together, split once, dx taps as lane
+    # shifts; the per-tap kernel it replaces, MSM_OPT_CONV3_WIDE = 1, returns the same bits)
+    from unseenobjectswithmeanshift_amd import _lib
+    with _lib.option("CONV3_WIDE", 1):
+        out_tap, st_tap = ops().conv3x3_c64(x.to(DEV), w3, H, W, bf16=True)
+    assert torch.equal(out_tap, out)
+    torch.testing.assert_close(st_tap.cpu(), st.cpu(), rtol=1e-5, atol=1e-4)            # (fp32 partial sums grouped by unit)
     # precision "f16" (msm_conv3x3_c64_f16): weight and activations one IEEE-half term each -- against the fp64 convolution of the
     # fp16-ROUNDED operands to the fp32 kernel's tolerance, and against the exact one at least four times closer than the bf16 form
     h16 = lambda t: t.to(torch.float16).double()

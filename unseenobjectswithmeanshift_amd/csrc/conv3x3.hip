@@ -683,6 +683,207 @@ __global__ __launch_bounds__(C3R_W * 64) void conv3x3_c64_rows_kernel(const uint
     }
 }
 
+
+// ---- the "bf16" plan's form with a unit's loads in flight at once (round 6) --------------------------------------------------------
+// conv3x3_c64_kernel<false, 1, 2, 8> has the same chain as the f16 form had: nine taps, one memory round trip each, 2.3 tiles per wave
+// (50 us at B = 8, 120 x 160).  Its activation operand is an fp32 value as hi + lo bf16 terms -- no narrower map for a producer to
+// write -- so here a unit is ONE output row of a 32-pixel strip: its three input rows (eight 16-byte loads per row and lane + the halo
+// pixel left and right) are requested together, split into hi + lo ONCE per row (the per-tap form splits every value nine times), and
+// the dx = -1 / +1 operands are lane shifts of the split terms.  Taps 0..8, halves kh = 0, 1, lo then hi into one accumulator chain:
+// the output bits of conv3x3_c64_kernel<false, 1, 2, 8>.  Units and XCD ranges as conv3x3_c64_rows_kernel.
+__global__ __launch_bounds__(C3R_W * 64) void conv3x3_c64_rows_bf16_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                                           float* __restrict__ out, double* __restrict__ stats, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];   // [64][C3_LDB] bf16, then the moment scratch [C3R_W][64][2]
+    unsigned short* wlb = reinterpret_cast<unsigned short*>(wl);
+    float* msc = wl + C3_C * C3_LDB / 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lq = lane >> 4;
+    const int b = blockIdx.y;
+    const int xt = (W + 31) / 32;
+    const int units = xt * H;
+    int u, step, last;
+    if ((gridDim.x & 7) == 0) {
+        const int chunk = (units + 7) / 8, xcd = (int)blockIdx.x & 7;
+        u = xcd * chunk + ((int)blockIdx.x >> 3) * C3R_W + wave;
+        step = ((int)gridDim.x >> 3) * C3R_W;
+        last = min(units, (xcd + 1) * chunk);
+    } else {
+        u = (int)blockIdx.x * C3R_W + wave;
+        step = (int)gridDim.x * C3R_W;
+        last = units;
+    }
+    const float* ib = in + (int64_t)b * H * W * C3_C;
+    float* ob = out + (int64_t)b * H * W * C3_C;
+
+    struct Raw {
+        float4 c[3][2][2][2];             // [input row][16-pixel block][32-channel half][channels lq*8 + 4 h .. + 3]
+        float4 h[3][2][2];                // lanes lj < 8: pixel x0 - 1, lj >= 8: pixel x0 + 32
+    };
+    struct Row {
+        u32x4b ch[2][2], cl[2][2];        // hi / lo bf16 terms of one input row [16-pixel block][32-channel half]
+        u32x4b hh[2], hl[2];              // of its halo pixels (lane 0: left, lane 15: right; zeros outside the map)
+    };
+    auto load_unit = [&](int uu, Raw& rw) {
+        const int y = uu / xt, x0 = (uu - y * xt) * 32;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int yy = y - 1 + i;
+            const float* rp = ib + (int64_t)min(max(yy, 0), H - 1) * W * C3_C + lq * 8;
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) {
+                const float* p = rp + (int64_t)min(x0 + pb * 16 + lj, W - 1) * C3_C;
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) rw.c[i][pb][kh][h] = *reinterpret_cast<const float4*>(p + kh * 32 + h * 4);
+            }
+            const int hx = lj < 8 ? x0 - 1 : x0 + 32;
+            const float* ph = rp + (int64_t)min(max(hx, 0), W - 1) * C3_C;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) rw.h[i][kh][h] = *reinterpret_cast<const float4*>(ph + kh * 32 + h * 4);
+        }
+    };
+    Raw raw;
+    if (u < last) load_unit(u, raw);
+    {
+        constexpr int PER = C3_C * (C3_K / 4) / (C3R_W * 64);      // 18 float4 per thread
+#pragma unroll
+        for (int k0 = 0; k0 < PER; k0 += 6) {
+            float4 wv[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) wv[k] = *reinterpret_cast<const float4*>(w + (int64_t)(tid + (k0 + k) * (C3R_W * 64)) * 4);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int i = tid + (k0 + k) * (C3R_W * 64);
+                const int n = i / (C3_K / 4), c4 = i - n * (C3_K / 4);
+                *reinterpret_cast<bf16x4*>(wlb + n * C3_LDB + c4 * 4) = pack4(wv[k].x, wv[k].y, wv[k].z, wv[k].w);
+            }
+        }
+    }
+    __syncthreads();
+
+    float s[4][4], q[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[mt][r] = q[mt][r] = 0.f;
+    const unsigned short* wp = wlb + lj * C3_LDB + lq * 8;
+    const u32x4b zero = {0u, 0u, 0u, 0u};
+    auto split8 = [&](const float4& a, const float4& c, bool ok, u32x4b& hi, u32x4b& lo) {
+        const Split4 s0 = split4(a.x, a.y, a.z, a.w), s1 = split4(c.x, c.y, c.z, c.w);
+        hi = ok ? __builtin_bit_cast(u32x4b, cat8(s0.hi, s1.hi)) : zero;
+        lo = ok ? __builtin_bit_cast(u32x4b, cat8(s0.lo, s1.lo)) : zero;
+    };
+
+    for (; u < last; u += step) {
+        const int y = u / xt, x0 = (u - y * xt) * 32;
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[pb][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            // one input row at a time: split (the row's fp32 registers die here), then its three taps
+            Row rw;
+            const int yy = y - 1 + i;
+            const bool rok = yy >= 0 && yy < H;
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh)
+                    split8(raw.c[i][pb][kh][0], raw.c[i][pb][kh][1], rok && x0 + pb * 16 + lj < W, rw.ch[pb][kh], rw.cl[pb][kh]);
+            const int hx = lj < 8 ? x0 - 1 : x0 + 32;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) split8(raw.h[i][kh][0], raw.h[i][kh][1], rok && hx >= 0 && hx < W, rw.hh[kh], rw.hl[kh]);
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int t = i * 3 + dx;
+#pragma unroll
+                for (int kh = 0; kh < 2; ++kh) {
+                    u32x4b xh[2], xl[2];
+                    if (dx == 0) {
+                        xh[0] = shift_px<true>(rw.ch[0][kh], rw.hh[kh]);
+                        xh[1] = shift_px<true>(rw.ch[1][kh], rotate_px<1>(rw.ch[0][kh]));
+                        xl[0] = shift_px<true>(rw.cl[0][kh], rw.hl[kh]);
+                        xl[1] = shift_px<true>(rw.cl[1][kh], rotate_px<1>(rw.cl[0][kh]));
+                    } else if (dx == 1) {
+                        xh[0] = rw.ch[0][kh]; xh[1] = rw.ch[1][kh];
+                        xl[0] = rw.cl[0][kh]; xl[1] = rw.cl[1][kh];
+                    } else {
+                        xh[0] = shift_px<false>(rw.ch[0][kh], rotate_px<15>(rw.ch[1][kh]));
+                        xh[1] = shift_px<false>(rw.ch[1][kh], rw.hh[kh]);
+                        xl[0] = shift_px<false>(rw.cl[0][kh], rotate_px<15>(rw.cl[1][kh]));
+                        xl[1] = shift_px<false>(rw.cl[1][kh], rw.hl[kh]);
+                    }
+                    bf16x8 a[4];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const bf16x8*>(wp + mt * 16 * C3_LDB + t * C3_C + kh * 32);
+#pragma unroll
+                    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) acc[pb][mt] = mfma_bf16k32(a[mt], __builtin_bit_cast(bf16x8, xl[pb]), acc[pb][mt]);
+#pragma unroll
+                    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) acc[pb][mt] = mfma_bf16k32(a[mt], __builtin_bit_cast(bf16x8, xh[pb]), acc[pb][mt]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            if (x0 + pb * 16 + lj < W) {
+                float* op = ob + ((int64_t)y * W + x0 + pb * 16 + lj) * C3_C + lq * 4;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    *reinterpret_cast<float4*>(op + mt * 16) = make_float4(acc[pb][mt][0], acc[pb][mt][1], acc[pb][mt][2], acc[pb][mt][3]);
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        s[mt][rr] += acc[pb][mt][rr];
+                        q[mt][rr] += acc[pb][mt][rr] * acc[pb][mt][rr];
+                    }
+                }
+            }
+        }
+        if (u + step < last) load_unit(u + step, raw);           // (the split terms of a unit and the next unit's fp32 rows do not fit the registers together)
+    }
+    if (stats) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[mt][r] += wave_xor_dpp1(s[mt][r]);
+                q[mt][r] += wave_xor_dpp1(q[mt][r]);
+                s[mt][r] += wave_xor_dpp2(s[mt][r]);
+                q[mt][r] += wave_xor_dpp2(q[mt][r]);
+                s[mt][r] += wave_xor_dpp4(s[mt][r]);
+                q[mt][r] += wave_xor_dpp4(q[mt][r]);
+                s[mt][r] += wave_xor_dpp8(s[mt][r]);
+                q[mt][r] += wave_xor_dpp8(q[mt][r]);
+            }
+        if (lj == 0) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ch = mt * 16 + lq * 4 + r;
+                    msc[(wave * C3_C + ch) * 2 + 0] = s[mt][r];
+                    msc[(wave * C3_C + ch) * 2 + 1] = q[mt][r];
+                }
+        }
+        __syncthreads();
+        if (tid < C3_C * 2) {
+            double t = 0.0;
+            for (int wv = 0; wv < C3R_W; ++wv) t += (double)msc[wv * C3_C * 2 + tid];
+            atomicAdd(stats + (int64_t)b * C3_C * 2 + tid, t);
+        }
+    }
+}
+
 }  // namespace msm
 
 using namespace msm;
@@ -724,7 +925,16 @@ static int conv3x3_c64_launch(const float* in, const float* w_tap_major, float* 
     const bool wide = (wopt == 1 || (wopt == MSM_OPT_AUTO && bf)) && W >= 32;
     const int units2 = cdiv(W, 32) * H;
     const int per_image2 = min(max(1, 256 / B), cdiv(units2, 8));
-    if (bf) {
+    if (bf == 1 && wopt == MSM_OPT_AUTO && W >= 32) {
+        // round 6: one output row of a 32-pixel strip per unit, its three input rows requested together (conv3x3_c64_rows_bf16_kernel)
+        int pmax = max(1, 256 / B);
+        if (pmax >= 8) pmax &= ~7;
+        const int runits = cdiv(W, 32) * H;
+        const int rper = pmax >= 8 ? min(pmax, 8 * cdiv(cdiv(runits, 8), C3R_W)) : min(pmax, cdiv(runits, C3R_W));
+        const size_t lds = sizeof(unsigned short) * (size_t)C3_C * C3_LDB + sizeof(float) * (size_t)C3R_W * C3_C * 2;
+        MSM_CHECK_HIP((hipError_t)ensure_dynamic_lds((const void*)conv3x3_c64_rows_bf16_kernel, lds));
+        hipLaunchKernelGGL(conv3x3_c64_rows_bf16_kernel, dim3(rper, B), dim3(C3R_W * 64), lds, st, in, w_tap_major, out, stats, H, W);
+    } else if (bf) {
       auto go = [&](auto tag) -> int {
         constexpr int BFV = decltype(tag)::value;
         // (one load per input ROW with lane shifts for dx = -1 / +1, as the split kernel does, was measured for this form too: bitwise the
