@@ -75,7 +75,7 @@ enum {
     MSM_OPT_ATTN_KERNEL,        /* 3: split-K kernel + combine for every length (fallback of the query-split kernel) */
     MSM_OPT_ATTN_QK_MAX,        /* longest sequence the key-split kernel takes */
     MSM_OPT_ATTN_QKCFG,         /* 0 / 1 / 2: two / one / four (four waves) query blocks per workgroup in the key-split kernel */
-    MSM_OPT_CONVIN_NT,          /* 1, 2, 4: pixel tiles per workgroup of the input projection */
+    MSM_OPT_CONVIN_NT,          /* 1, 2, 4: pixel tiles per workgroup of the input projection; msm_conv1x1_in_multi_wide: K slices of every level (tuning: three decimal digits = one per level, e.g. 421) */
     MSM_OPT_POST_GENERIC,       /* 1: generic mask upsample instead of the 4x form */
     MSM_OPT_ENC_NO_COOP,        /* 1: fp32 encoder block without cooperative workgroups; 2: msm_encoder_block_hm_fwd as ONE 16-wave workgroup per CU (rounds 4-5; default since round 6: eight waves, two workgroups per CU) */
     MSM_OPT_MSDA_GENERIC,       /* 1: generic head-major MSDeformAttn gather; 2: the D = 8 kernel of round 2 (every lane repeats the tap geometry; fallback of the owner-record kernel); 3: that kernel with 8-query x 8-head workgroups */

@@ -23,16 +23,21 @@ S = sum(h * w for _, h, w in levels)
 
 
 def timed(fn, n=60):
-    for i in range(6):
-        fn(i % POOL)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for i in range(n):
-        fn(i % POOL)
-    e1.record()
-    torch.cuda.synchronize()
-    return 1e3 * e0.elapsed_time(e1) / n
+    """Best of three event-timed runs of n back-to-back calls (a single run now and then carries a one-off stall of tens of
+    milliseconds -- 750 us per call where the kernel trace shows 46: rocprofv3's per-dispatch durations are the reference)."""
+    best = float("inf")
+    for _ in range(3):
+        for i in range(6):
+            fn(i % POOL)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(n):
+            fn(i % POOL)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, 1e3 * e0.elapsed_time(e1) / n)
+    return best
 
 
 print(os.path.dirname(ops.__file__))
