@@ -6,7 +6,9 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+if os.environ.get("MSM_TREE"):                         # A/B of two builds on one box
+    sys.path.insert(0, os.path.abspath(os.environ["MSM_TREE"]))
+sys.path.append(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench  # noqa: E402
 from unseenobjectswithmeanshift_amd import synthetic as syn, two_stage as ts  # noqa: E402
 from unseenobjectswithmeanshift_amd.meta_arch import MeanShiftMaskFormer  # noqa: E402
